@@ -1,0 +1,171 @@
+/* madnet_hip.h -- C-ABI of libmadnet_hip.so (MI355X / gfx950, hand-written HIP).
+ *
+ * Drop-in boundary for the MADNet/DispNet forward + online-adaptation backward hot path
+ * of CVLAB-Unibo/Real-time-self-adaptive-deep-stereo.  The reference's
+ * native boundary is a TensorFlow custom op pair with C++ launchers
+ *     void ShiftCorrKernelLauncher(const float*, const float*, int max_disp, int batch,
+ *                                  int in_h, int in_w_padded, int channels, float* out)
+ *                                              (Nets/Native/shift_corr.cc:22-23, .cu.cc:193)
+ *     void ShiftCorrGradKernelLauncher(...)    (Nets/Native/shift_corr.cc:58-60, .cu.cc:235)
+ * and everything else on the path is a TF-1.12 library kernel (tf.nn.conv2d, ...).  This
+ * header declares the extern "C" entry points that replace BOTH: mh_corr_* replace the
+ * ShiftCorr launchers (un-padded NHWC in, NHWC out, explicit stream, int status), the
+ * rest replace the TF kernels the reference graph calls (call sites cited per function).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer owned by the caller
+ *     (the library never allocates or frees tensor memory; borrowed until the stream op ends)
+ *   - all tensors float32 NHWC; `*_ld` = element stride between consecutive pixels
+ *     (lets a tensor be a channel-slice of a wider, concatenated buffer)
+ *   - `stream` is a hipStream_t passed as void*; kernels are stateless and re-entrant
+ *   - return 0 on success; negative = argument check failed; positive = hipError_t.
+ *     mh_last_error() returns a thread-local message.  No exceptions cross the ABI.
+ */
+#ifndef MADNET_HIP_H
+#define MADNET_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MH_ABI_VERSION 1
+
+const char* mh_last_error(void);
+int mh_abi_version(void);
+/* number of visible HIP devices (<=0: none) -- lets the host fail loudly without torch */
+int mh_device_count(void);
+
+/* ---- convolution family: tf.nn.conv2d / atrous_conv2d / conv2d_transpose + bias_add +
+ *      leaky (Nets/sharedLayers.py:54-92), and their registered gradients -------------- */
+typedef struct mh_conv_desc {
+    int32_t B, Hi, Wi, Ho, Wo;      /* Hi/Wi: spatial size of `in`; Ho/Wo: of `out`              */
+    int32_t K;                      /* channels contracted per tap (GEMM-K per tap)              */
+    int32_t N;                      /* channels produced (GEMM-N)                                */
+    int32_t kh, kw, stride, dil;    /* of the FORWARD convolution this call belongs to           */
+    int32_t pad_t, pad_l;           /* TF 'SAME' pad_before of the forward convolution            */
+    int32_t mode;                   /* 0: out[oy]<-in[oy*stride+ky*dil-pad]  (forward conv)
+                                       1: out[y] <-in[(y+pad-ky*dil)/stride] (dgrad / conv2d_transpose) */
+    int32_t w_trans;                /* 0: w is [tap][K][N]   1: w is [tap][N][K] (dgrad reads HWIO transposed) */
+    int32_t in_ld, out_ld, mask_ld;
+    int32_t accumulate;             /* out = result + out                                        */
+    float alpha;                    /* leaky slope applied to (acc+bias); 1 = linear             */
+    float mask_alpha;               /* if mask_ref: out *= (mask_ref>0 ? 1 : mask_alpha)  (fused leaky-grad) */
+} mh_conv_desc;
+
+int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w, const float* bias,
+              float* out, const float* mask_ref, void* stream);
+
+/* weight+bias gradient: dw[tap][K][N] += sum_pixels in(pixel,tap)[k] * dout[pixel][n] ;
+ * db[n] += sum_pixels dout[pixel][n].  `d` describes the FORWARD conv (mode 0 geometry:
+ * B,Hi,Wi = input, Ho,Wo = output, K = Cin, N = Cout).  dw/db are ACCUMULATED (fp32
+ * atomics over pixel splits) -- zero them first.  db may be NULL. */
+int mh_conv2d_wgrad(const mh_conv_desc* d, const float* in, const float* dout, int32_t dout_ld,
+                    float* dw, float* db, void* stream);
+
+/* ---- correlation / cost volume: sharedLayers.correlation (Nets/sharedLayers.py:23-51),
+ *      replaces ShiftCorrKernelLauncher / ShiftCorrGradKernelLauncher ------------------- */
+/* out[p][coff + j] = mean_c L[p][c]*R[p + (j*stride - max_disp)][c]   (R zero outside the row)
+ * if copy_left: out[p][0..C) = L[p][:]  (fused tf.concat([reference, corr]), MadNet.py:370-375)
+ * if u:         out[p][coff + D] = u[p] (fused tf.concat([costs, upsampled_disp]), MadNet.py:77-80)
+ * channels [coff + D (+1), out_ld) are zero-filled when zero_tail != 0. */
+int mh_corr_fwd(const float* L, int32_t l_ld, const float* R, int32_t r_ld, const float* u,
+                float* out, int32_t out_ld, int32_t coff,
+                int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t stride,
+                int32_t copy_left, int32_t zero_tail, void* stream);
+/* g: gradient w.r.t. the buffer written by mh_corr_fwd (same ld / coff).
+ * dL[p][c] (+)= [copy_left] g[p][c] + (1/C) sum_j g[p][coff+j] R[p+i_j][c]
+ * dR[p][c] (+)=                      (1/C) sum_j g[p-i_j][coff+j] L[p-i_j][c]
+ * du[p]    (+)= g[p][coff+D]     (du may be NULL).   acc_* select += vs =. */
+int mh_corr_bwd(const float* g, int32_t g_ld, int32_t coff, const float* L, int32_t l_ld,
+                const float* R, int32_t r_ld, float* dL, int32_t dl_ld, int32_t acc_l,
+                float* dR, int32_t dr_ld, int32_t acc_r, float* du, int32_t acc_u,
+                int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t stride,
+                int32_t copy_left, void* stream);
+
+/* ---- MadNet._build_indeces + _linear_warping (Nets/MadNet.py:378-436) ---------------- */
+int mh_warp_fwd(const float* img, int32_t img_ld, const float* u, float* out, int32_t out_ld,
+                int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+/* dimg += scatter (fp32 atomics; zero/initialise it first); du (+)= coordinate gradient
+ * (NULL when the coordinates are stop_gradient-ed, i.e. bulkhead / MAD). */
+int mh_warp_bwd(const float* g, int32_t g_ld, const float* img, int32_t img_ld, const float* u,
+                float* dimg, int32_t dimg_ld, float* du, int32_t acc_u,
+                int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+
+/* ---- tf.image.resize_images (TF1 legacy bilinear) fused with scale / relu / centre crop:
+ *      MadNet._make_disp (MadNet.py:68-71), final prediction (:362-364), inter-level
+ *      upsample (:274), preprocessing.rescale_image (preprocessing.py:269-277) ----------
+ * virtual resize of in[B,Hi,Wi] to [Hr,Wr], then crop at (cy,cx) to out[B,Ho,Wo].
+ * mode 0: out = mul*resize(in)   1: out = resize(relu(mul*in))   2: out = relu(mul*resize(in)) */
+int mh_resize_fwd(const float* in, float* out, int32_t B, int32_t Hi, int32_t Wi,
+                  int32_t Hr, int32_t Wr, int32_t cy, int32_t cx, int32_t Ho, int32_t Wo,
+                  float mul, int32_t mode, void* stream);
+/* din (+)= gradient (deterministic gather form).  `in` is the forward input (needed for
+ * the relu masks of modes 1/2). */
+int mh_resize_bwd(const float* g, const float* in, float* din, int32_t accumulate,
+                  int32_t B, int32_t Hi, int32_t Wi, int32_t Hr, int32_t Wr, int32_t cy, int32_t cx,
+                  int32_t Ho, int32_t Wo, float mul, int32_t mode, void* stream);
+
+/* ---- preprocessing.pad_image (REFLECT, preprocessing.py:7-29) fused with the float cast
+ *      and the channel padding 3 -> out_ld (extra channels zero) ------------------------ */
+int mh_pad_reflect(const float* in, float* out, int32_t B, int32_t H, int32_t W, int32_t C,
+                   int32_t Hp, int32_t Wp, int32_t pad_t, int32_t pad_l, int32_t out_ld, void* stream);
+
+/* ---- loss_factory.get_reprojection_loss('mean_SSIM_l1') forward + gradient w.r.t. the
+ *      disparity (Losses/loss_factory.py:128-164,353-395; preprocessing.py:121-230) ------
+ * left,right: [B,H,W,3] in 0..255;  disp: [B,H,W].  ws: workspace of mh_loss_ws_floats()
+ * floats.  result[0] = loss, result[1] = mean SSIM term, result[2] = mean L1 term.
+ * ddisp (may be NULL: forward only) = grad_scale * dLoss/ddisp. */
+int64_t mh_loss_ws_floats(int32_t B, int32_t H, int32_t W);
+int mh_reprojection_loss(const float* left, const float* right, const float* disp,
+                         float* ws, float* result, float* ddisp, float grad_scale,
+                         int32_t B, int32_t H, int32_t W, void* stream);
+
+/* ---- validation ops (Stereo_Online_Adaptation.py:74-82): result[0]=EPE, result[1]=bad3,
+ *      result[2]=#valid.  ws: >= mh_metrics_ws_floats() floats. ---------------------------- */
+int64_t mh_metrics_ws_floats(int32_t B, int32_t H, int32_t W);
+int mh_metrics(const float* disp, const float* gt, float* ws, float* result, float pixel_th,
+               int32_t B, int32_t H, int32_t W, void* stream);
+
+/* ---- tf.train.MomentumOptimizer apply (Stereo_Online_Adaptation.py:85):
+ *      accum = momentum*accum + grad_scale*g ;  var -= lr*accum   (n contiguous floats) --- */
+int mh_momentum(float* var, float* accum, const float* grad, int64_t n, float lr, float momentum,
+                float grad_scale, void* stream);
+
+/* ---- small glue ------------------------------------------------------------------------ */
+/* dst[p][c] (+)= scale * src[p][c], c < nch  (tf.concat pieces, final_disp add, concat-grad splits) */
+int mh_copy_channels(const float* src, int32_t src_ld, float* dst, int32_t dst_ld, int64_t npix,
+                     int32_t nch, float scale, int32_t accumulate, void* stream);
+/* dy[p][c] *= (y[p][c] > 0 ? 1 : alpha)   (gradient of tf.maximum(alpha*x,x)) */
+int mh_leaky_bwd(float* dy, int32_t dy_ld, const float* y, int32_t y_ld, int64_t npix, int32_t nch,
+                 float alpha, void* stream);
+int mh_fill(float* p, int64_t n, float v, void* stream);
+
+/* ---- native plan executor: the host (Python) compiles the network into an array of op
+ *      records once; one FFI call replays it (optionally captured into a hipGraph). ------ */
+enum { MH_OP_CONV = 1, MH_OP_WGRAD, MH_OP_CORR_FWD, MH_OP_CORR_BWD, MH_OP_WARP_FWD, MH_OP_WARP_BWD,
+       MH_OP_RESIZE_FWD, MH_OP_RESIZE_BWD, MH_OP_PAD_REFLECT, MH_OP_LOSS, MH_OP_METRICS,
+       MH_OP_MOMENTUM, MH_OP_COPY_CH, MH_OP_LEAKY_BWD, MH_OP_FILL };
+typedef struct mh_op {
+    int32_t kind;
+    int32_t i[27];
+    float f[4];
+    void* p[8];
+    int64_t n;
+} mh_op;
+int mh_plan_run(const mh_op* ops, int32_t nops, void* stream);
+/* hipGraph wrappers: capture everything launched on `stream` between begin/end. */
+int mh_graph_begin(void* stream);
+int mh_graph_end(void* stream, void** graph_exec_out);
+int mh_graph_launch(void* graph_exec, void* stream);
+int mh_graph_destroy(void* graph_exec);
+/* HIP-event timing helpers on the caller's stream (bench.py roofline leg) */
+int mh_event_create(void** ev);
+int mh_event_record(void* ev, void* stream);
+int mh_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);
+int mh_event_destroy(void* ev);
+int mh_stream_sync(void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

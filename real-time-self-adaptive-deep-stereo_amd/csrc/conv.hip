@@ -1,0 +1,354 @@
+// conv.hip -- implicit-GEMM convolution on the gfx950 matrix cores (exact fp32:
+// v_mfma_f32_16x16x4_f32, bitwise an fmaf chain) for the MADNet/DispNet conv stacks.
+//
+// Replaces tf.nn.conv2d / tf.nn.atrous_conv2d / tf.nn.conv2d_transpose + bias_add + leaky
+// (Nets/sharedLayers.py:54-92) and, with mode=1 / w_trans=1, their input gradients.
+//
+// GEMM view:  C[m][n] = sum_{tap,k} A[m][(tap,k)] * B[(tap,k)][n]
+//   m = output pixel (b,oy,ox) -- NHWC so C row m lives at out + m*out_ld
+//   A[m][(tap,k)] = in[b, iy(oy,ky), ix(ox,kx), k]  (0 outside / not on the stride lattice)
+//   B[(tap,k)][n] = w[tap][k][n] (forward, HWIO as stored) or w[tap][n][k] (dgrad)
+// K is walked in groups of 4 channels flattened across taps (group g -> tap=g/G, c4=g%G,
+// G=ceil(K/4)), so odd channel counts (3, 38, 33, 197 ...) cost no padded MFMA work beyond
+// the last group.  One workgroup = 4 waves computes a BM x BN tile; a K-tile = 4 groups =
+// 16 k-values; global->register prefetch of tile t+1 overlaps the MFMAs of tile t; LDS is
+// double buffered with ONE barrier per K-tile.
+#include "mh_common.h"
+
+namespace {
+
+struct ConvArgs {
+    const float* in; const float* w; const float* bias; float* out; const float* mask_ref;
+    int in_ld, out_ld, mask_ld;
+    int B, Hi, Wi, Ho, Wo;
+    int K, N, G, taps;
+    int kh, kw, stride, dil, pad_t, pad_l;
+    int mode, w_trans, accumulate;
+    int M;           // B*Ho*Wo
+    int vecA, vecB;  // 16-byte vector loads legal for A / B
+    int mtiles, ntiles;
+    float alpha, mask_alpha;
+};
+
+constexpr int KT = 16;        // k-values per K-tile
+constexpr int AS = KT + 4;    // LDS row stride of the A tile (floats)
+
+template <int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
+    constexpr int BM = WM * MT * 16;
+    constexpr int BN = WN * NT * 16;
+    constexpr int BS = BN + 4;
+    constexpr int AROWS = (BM + 63) / 64;              // A rows handled per thread
+    constexpr int BVEC = KT * BN / 4;                  // float4 items in a B tile
+    constexpr int BITEMS = (BVEC + 255) / 256;         // per thread
+
+    __shared__ __attribute__((aligned(16))) float As[2][BM * AS];
+    __shared__ __attribute__((aligned(16))) float Bs[2][KT * BS];
+    __shared__ int tap_dy[64], tap_dx[64];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int nwg = p.mtiles * p.ntiles;
+    const int lin = mh_xcd_remap(blockIdx.x, nwg);
+    const int tile_n = lin % p.ntiles;
+    const int tile_m = lin / p.ntiles;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    if (tid < p.taps) {
+        const int ky = tid / p.kw, kx = tid - ky * p.kw;
+        tap_dy[tid] = ky * p.dil;
+        tap_dx[tid] = kx * p.dil;
+    }
+
+    // ---- per-thread A-row geometry (constant over the K loop) --------------------------
+    const int ga = tid & 3;           // which of the 4 channel groups of a K-tile
+    const int ra = tid >> 2;          // row 0..63
+    int a_by[AROWS], a_bx[AROWS];
+    int64_t a_img[AROWS];
+    bool a_rowok[AROWS];
+#pragma unroll
+    for (int j = 0; j < AROWS; ++j) {
+        const int r = ra + 64 * j;
+        const int m = m0 + r;
+        const bool ok = (r < BM) && (m < p.M);
+        const int mm = ok ? m : 0;
+        const int ox = mm % p.Wo;
+        const int t2 = mm / p.Wo;
+        const int oy = t2 % p.Ho;
+        const int b = t2 / p.Ho;
+        a_rowok[j] = ok;
+        a_img[j] = (int64_t)b * p.Hi * p.Wi;
+        if (p.mode == 0) {
+            a_by[j] = oy * p.stride - p.pad_t;
+            a_bx[j] = ox * p.stride - p.pad_l;
+        } else {
+            a_by[j] = oy + p.pad_t;
+            a_bx[j] = ox + p.pad_l;
+        }
+    }
+    // group cursor of this thread's A loads: g = tile*4 + ga  ->  (tap, c4)
+    int a_tap = 0, a_c4 = ga;
+    while (a_c4 >= p.G) { a_c4 -= p.G; ++a_tap; }
+
+    // ---- per-thread B-item geometry ------------------------------------------------------
+    // w_trans == 0: item q -> row kk = q / (BN/4), n4 = q % (BN/4)      (float4 along n)
+    // w_trans == 1: item q -> n = q >> 2, gb = q & 3                    (float4 along k)
+    int b_tap[BITEMS], b_c4[BITEMS];
+#pragma unroll
+    for (int j = 0; j < BITEMS; ++j) {
+        const int q = tid + 256 * j;
+        const int gb = p.w_trans ? (q & 3) : ((q / (BN / 4)) >> 2);
+        int t = 0, c = gb;
+        while (c >= p.G) { c -= p.G; ++t; }
+        b_tap[j] = t; b_c4[j] = c;
+    }
+
+    float4 ra_v[AROWS];
+    float4 rb_v[BITEMS];
+
+    __syncthreads();   // tap tables visible
+
+    auto load_tile = [&]() {
+        // A
+        {
+            const bool gok = a_tap < p.taps;
+            const int dy = gok ? tap_dy[a_tap] : 0;
+            const int dx = gok ? tap_dx[a_tap] : 0;
+            const int kbase = a_c4 * 4;
+#pragma unroll
+            for (int j = 0; j < AROWS; ++j) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                bool ok = gok && a_rowok[j];
+                int iy, ix;
+                if (p.mode == 0) {
+                    iy = a_by[j] + dy; ix = a_bx[j] + dx;
+                    ok = ok && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+                } else {
+                    const int ny = a_by[j] - dy, nx = a_bx[j] - dx;
+                    ok = ok && ny >= 0 && nx >= 0;
+                    iy = ny / p.stride; ix = nx / p.stride;
+                    ok = ok && (iy * p.stride == ny) && (ix * p.stride == nx) && iy < p.Hi && ix < p.Wi;
+                }
+                if (ok) {
+                    const float* src = p.in + (a_img[j] + (int64_t)iy * p.Wi + ix) * p.in_ld + kbase;
+                    if (p.vecA) {
+                        v = *reinterpret_cast<const float4*>(src);
+                        if (kbase + 3 >= p.K) {     // last group: zero the channel padding
+                            if (kbase + 1 >= p.K) v.y = 0.f;
+                            if (kbase + 2 >= p.K) v.z = 0.f;
+                            v.w = 0.f;
+                        }
+                    } else {
+                        if (kbase + 0 < p.K) v.x = src[0];
+                        if (kbase + 1 < p.K) v.y = src[1];
+                        if (kbase + 2 < p.K) v.z = src[2];
+                        if (kbase + 3 < p.K) v.w = src[3];
+                    }
+                }
+                ra_v[j] = v;
+            }
+        }
+        // B
+#pragma unroll
+        for (int j = 0; j < BITEMS; ++j) {
+            const int q = tid + 256 * j;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < BVEC && b_tap[j] < p.taps) {
+                if (p.w_trans == 0) {
+                    const int kk = q / (BN / 4), n4 = q % (BN / 4);
+                    const int k = b_c4[j] * 4 + (kk & 3);
+                    const int n = n0 + n4 * 4;
+                    if (k < p.K && n < p.N) {
+                        const float* src = p.w + ((int64_t)b_tap[j] * p.K + k) * p.N + n;
+                        if (p.vecB) {
+                            v = *reinterpret_cast<const float4*>(src);
+                        } else {
+                            v.x = src[0];
+                            if (n + 1 < p.N) v.y = src[1];
+                            if (n + 2 < p.N) v.z = src[2];
+                            if (n + 3 < p.N) v.w = src[3];
+                        }
+                    }
+                } else {
+                    const int n = n0 + (q >> 2);
+                    const int k = b_c4[j] * 4;
+                    if (n < p.N && k < p.K) {
+                        const float* src = p.w + ((int64_t)b_tap[j] * p.N + n) * p.K + k;
+                        if (p.vecB) {
+                            v = *reinterpret_cast<const float4*>(src);
+                        } else {
+                            v.x = src[0];
+                            if (k + 1 < p.K) v.y = src[1];
+                            if (k + 2 < p.K) v.z = src[2];
+                            if (k + 3 < p.K) v.w = src[3];
+                        }
+                    }
+                }
+            }
+            rb_v[j] = v;
+        }
+        // advance the group cursors by one K-tile (4 groups)
+        a_c4 += 4;
+        while (a_c4 >= p.G) { a_c4 -= p.G; ++a_tap; }
+#pragma unroll
+        for (int j = 0; j < BITEMS; ++j) {
+            b_c4[j] += 4;
+            while (b_c4[j] >= p.G) { b_c4[j] -= p.G; ++b_tap[j]; }
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < AROWS; ++j) {
+            const int r = ra + 64 * j;
+            if (r < BM) *reinterpret_cast<float4*>(&As[buf][r * AS + ga * 4]) = ra_v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < BITEMS; ++j) {
+            const int q = tid + 256 * j;
+            if (q < BVEC) {
+                if (p.w_trans == 0) {
+                    const int kk = q / (BN / 4), n4 = q % (BN / 4);
+                    *reinterpret_cast<float4*>(&Bs[buf][kk * BS + n4 * 4]) = rb_v[j];
+                } else {
+                    const int n = q >> 2, gb = q & 3;
+                    Bs[buf][(gb * 4 + 0) * BS + n] = rb_v[j].x;
+                    Bs[buf][(gb * 4 + 1) * BS + n] = rb_v[j].y;
+                    Bs[buf][(gb * 4 + 2) * BS + n] = rb_v[j].z;
+                    Bs[buf][(gb * 4 + 3) * BS + n] = rb_v[j].w;
+                }
+            }
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int ntile = (p.taps * p.G + 3) >> 2;
+    const int li = lane & 15, lq = lane >> 4;
+
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+
+    for (int t = 0; t < ntile; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntile) load_tile();
+        const float* Ab = &As[buf][(wm * MT * 16 + li) * AS + lq];
+        const float* Bb = &Bs[buf][lq * BS + wn * NT * 16 + li];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            float a[MT], b[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = Ab[i * 16 * AS + ks * 4];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[j] = Bb[ks * 4 * BS + j * 16];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < ntile) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias + leaky (+ accumulate) (+ fused leaky-grad mask) ------------------
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * MT * 16 + i * 16 + lq * 4 + r;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = n0 + wn * NT * 16 + j * 16 + li;
+                if (n >= p.N) continue;
+                float v = acc[i][j][r];
+                if (p.bias) v += p.bias[n];
+                if (p.alpha != 1.0f) v = v > 0.f ? v : p.alpha * v;
+                float* dst = p.out + (int64_t)m * p.out_ld + n;
+                if (p.accumulate) v += *dst;
+                if (p.mask_ref) {
+                    const float y = p.mask_ref[(int64_t)m * p.mask_ld + n];
+                    v *= (y > 0.f) ? 1.0f : p.mask_alpha;
+                }
+                *dst = v;
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int MT, int NT>
+int launch_cfg(ConvArgs& a, hipStream_t s) {
+    constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
+    a.mtiles = mh_cdiv(a.M, BM);
+    a.ntiles = mh_cdiv(a.N, BN);
+    const int nwg = a.mtiles * a.ntiles;
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT>), dim3(nwg), dim3(256), 0, s, a);
+    return mh_check_launch("conv_igemm");
+}
+
+}  // namespace
+
+// tile-shape heuristic: N tile = smallest available >= min(N,128); M tile as large as
+// possible while still giving the 256 CUs >= ~1.5 workgroups each.
+static int conv_dispatch(ConvArgs& a, hipStream_t s) {
+    const int N = a.N;
+    const int64_t M = a.M;
+    auto wgs = [&](int bm, int bn) { return (int64_t)mh_cdiv(M, bm) * mh_cdiv(N, bn); };
+    const int64_t want = 384;
+    if (N > 96) {
+        if (wgs(128, 128) >= want) return launch_cfg<2, 2, 4, 4>(a, s);
+        if (wgs(64, 128) >= want / 2) return launch_cfg<1, 4, 4, 2>(a, s);
+        if (wgs(64, 64) >= want / 2) return launch_cfg<2, 2, 2, 2>(a, s);
+        return launch_cfg<2, 2, 1, 2>(a, s);                 // 32 x 64
+    }
+    if (N > 64) {
+        if (wgs(128, 96) >= want) return launch_cfg<2, 2, 4, 3>(a, s);
+        if (wgs(64, 96) >= want / 2) return launch_cfg<2, 2, 2, 3>(a, s);
+        return launch_cfg<2, 2, 1, 3>(a, s);                 // 32 x 96
+    }
+    if (N > 32) {
+        if (wgs(128, 64) >= want) return launch_cfg<2, 2, 4, 2>(a, s);
+        if (wgs(64, 64) >= want / 2) return launch_cfg<2, 2, 2, 2>(a, s);
+        return launch_cfg<2, 2, 1, 2>(a, s);                 // 32 x 64
+    }
+    if (N > 16) {
+        if (wgs(128, 32) >= want) return launch_cfg<4, 1, 2, 2>(a, s);
+        return launch_cfg<4, 1, 1, 2>(a, s);                 // 64 x 32
+    }
+    if (wgs(128, 16) >= want) return launch_cfg<4, 1, 2, 1>(a, s);
+    return launch_cfg<4, 1, 1, 1>(a, s);                     // 64 x 16
+}
+
+extern "C" int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w, const float* bias,
+                         float* out, const float* mask_ref, void* stream) {
+    MH_REQUIRE(d && in && w && out, MH_ERR_ARG, "mh_conv2d: null argument");
+    MH_REQUIRE(d->B > 0 && d->Hi > 0 && d->Wi > 0 && d->Ho > 0 && d->Wo > 0 && d->K > 0 && d->N > 0,
+               MH_ERR_ARG, "mh_conv2d: non-positive dimension");
+    MH_REQUIRE(d->kh > 0 && d->kw > 0 && d->kh * d->kw <= 64, MH_ERR_ARG, "mh_conv2d: kernel %dx%d unsupported", d->kh, d->kw);
+    MH_REQUIRE(d->stride >= 1 && d->dil >= 1, MH_ERR_ARG, "mh_conv2d: stride/dilation must be >= 1");
+    MH_REQUIRE(d->in_ld >= d->K && d->out_ld >= d->N, MH_ERR_ARG, "mh_conv2d: ld smaller than channel count");
+    MH_REQUIRE((int64_t)d->B * d->Ho * d->Wo < (1ll << 31), MH_ERR_ARG, "mh_conv2d: too many output pixels");
+    ConvArgs a;
+    a.in = in; a.w = w; a.bias = bias; a.out = out; a.mask_ref = mask_ref;
+    a.in_ld = d->in_ld; a.out_ld = d->out_ld; a.mask_ld = d->mask_ld;
+    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ho = d->Ho; a.Wo = d->Wo;
+    a.K = d->K; a.N = d->N; a.G = (d->K + 3) / 4; a.taps = d->kh * d->kw;
+    a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.dil = d->dil; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
+    a.mode = d->mode; a.w_trans = d->w_trans; a.accumulate = d->accumulate;
+    a.M = d->B * d->Ho * d->Wo;
+    a.alpha = d->alpha; a.mask_alpha = d->mask_alpha;
+    // 16-byte vector loads of A need every group start 16B aligned and the full group in-bounds
+    a.vecA = mh_aligned16(in) && (d->in_ld % 4 == 0) && (d->in_ld >= a.G * 4);
+    a.vecB = mh_aligned16(w) && (d->w_trans ? (d->K % 4 == 0) : (d->N % 4 == 0));
+    return conv_dispatch(a, (hipStream_t)stream);
+}

@@ -1,0 +1,279 @@
+// corr.hip -- 1-D correlation / cost volume for gfx950, forward and gradient.
+//
+// Replaces sharedLayers.correlation (Nets/sharedLayers.py:23-51; the 'TF' formulation is the
+// oracle) and the CUDA op behind it: CorrelateData / CorrelateDataBackward0/1 and their
+// launchers (Nets/Native/shift_corr.cu.cc:17-289).  Differences by design: inputs are
+// UN-padded NHWC (zero padding handled in-kernel), the output is NHWC written straight into
+// the estimator's concatenated input [reference | corr | upsampled_disp] (MadNet.py:77-80,
+// 370-375) so tf.concat costs nothing, and the backward follows the TF gradient (the CUDA
+// backward is defective).
+//
+// HBM-bound op: algorithmic bytes = B*H*W*(2C + D)*4.  One workgroup = one row segment of
+// TW pixels; the right-feature window [x0-md, x0+TW+md) x C is staged once in LDS with
+// coalesced 16-byte loads (each R element is then reused by the D shifts from LDS instead of
+// D global loads); each pixel is owned by a group of LPP lanes that split the channels and
+// combine the D partial dot products with wave shuffles (__shfl_xor butterflies).
+#include "mh_common.h"
+
+namespace {
+
+constexpr int MAXD_SMALL = 9;   // register-resident shift count of the small-D kernel
+
+struct CorrArgs {
+    const float* L; const float* R; const float* u; float* out;
+    int l_ld, r_ld, out_ld, coff;
+    int B, H, W, C, md, stride, D;
+    int copy_left, zero_tail, segs;
+};
+
+// LPP lanes per pixel (power of two <= 64), TW pixels per workgroup segment.
+template <int LPP, int TW>
+__global__ __launch_bounds__(256) void corr_fwd_small(CorrArgs p) {
+    HIP_DYNAMIC_SHARED(float, smem)   // [(TW + 2md)][C]; no static LDS in this kernel -> base is 16-byte aligned
+    const int tid = threadIdx.x;
+    const int seg = blockIdx.x % p.segs;
+    const int row = blockIdx.x / p.segs;          // b*H + y
+    const int x0 = seg * TW;
+    const int C4 = p.C >> 2;
+    const int win = TW + 2 * p.md;
+    const float* Rrow = p.R + (int64_t)row * p.W * p.r_ld;
+    // ---- stage the right window (zero outside the row: tf.pad in correlation_tf) ----------
+    for (int q = tid; q < win * C4; q += 256) {
+        const int px = q / C4, c4 = q - px * C4;
+        const int xs = x0 - p.md + px;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (xs >= 0 && xs < p.W) v = *reinterpret_cast<const float4*>(Rrow + (int64_t)xs * p.r_ld + c4 * 4);
+        *reinterpret_cast<float4*>(&smem[(px * C4 + c4) * 4]) = v;
+    }
+    __syncthreads();
+
+    constexpr int PPB = 256 / LPP;               // pixels per pass
+    const int sub = tid % LPP;
+    const float inv_c = 1.0f / (float)p.C;
+    for (int pp = tid / LPP; pp < TW; pp += PPB) {
+        const int x = x0 + pp;
+        const bool live = x < p.W;
+        float accd[MAXD_SMALL];
+#pragma unroll
+        for (int j = 0; j < MAXD_SMALL; ++j) accd[j] = 0.f;
+        const int64_t pix = (int64_t)row * p.W + (live ? x : 0);
+        const float* Lp = p.L + pix * p.l_ld;
+        float* Op = p.out + pix * p.out_ld;
+        for (int c4 = sub; c4 < C4; c4 += LPP) {
+            float4 l = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) {
+                l = *reinterpret_cast<const float4*>(Lp + c4 * 4);
+                if (p.copy_left) *reinterpret_cast<float4*>(Op + c4 * 4) = l;
+            }
+#pragma unroll
+            for (int j = 0; j < MAXD_SMALL; ++j) {
+                if (j < p.D) {
+                    const float4 r = *reinterpret_cast<const float4*>(&smem[((pp + j * p.stride) * C4 + c4) * 4]);
+                    accd[j] += l.x * r.x + l.y * r.y + l.z * r.z + l.w * r.w;
+                }
+            }
+        }
+        // butterfly over the LPP lanes that share this pixel
+#pragma unroll
+        for (int j = 0; j < MAXD_SMALL; ++j) {
+            if (j < p.D) {
+#pragma unroll
+                for (int o = LPP >> 1; o > 0; o >>= 1) accd[j] += __shfl_xor(accd[j], o);
+            }
+        }
+        if (live && sub == 0) {
+            float* dst = Op + p.coff;
+#pragma unroll
+            for (int j = 0; j < MAXD_SMALL; ++j)
+                if (j < p.D) dst[j] = accd[j] * inv_c;
+            int tail = p.coff + p.D;
+            if (p.u) { Op[tail] = p.u[pix]; ++tail; }
+            if (p.zero_tail)
+                for (; tail < p.out_ld; ++tail) Op[tail] = 0.f;
+        }
+    }
+}
+
+// Generic shift count (DispNet, D = 81): lane = one (pixel, shift) pair, channels looped from
+// LDS (left tile + right window staged once, rows padded by 4 floats against bank conflicts).
+template <int TW>
+__global__ __launch_bounds__(256) void corr_fwd_large(CorrArgs p) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    const int tid = threadIdx.x;
+    const int seg = blockIdx.x % p.segs;
+    const int row = blockIdx.x / p.segs;
+    const int x0 = seg * TW;
+    const int C4 = p.C >> 2;
+    const int rs = p.C + 4;                       // padded row stride (floats)
+    const int win = TW + 2 * p.md;
+    float* Ls = smem;                             // [TW][rs]
+    float* Rs = smem + TW * rs;                   // [win][rs]
+    const float* Rrow = p.R + (int64_t)row * p.W * p.r_ld;
+    const float* Lrow = p.L + (int64_t)row * p.W * p.l_ld;
+    for (int q = tid; q < win * C4; q += 256) {
+        const int px = q / C4, c4 = q - px * C4;
+        const int xs = x0 - p.md + px;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (xs >= 0 && xs < p.W) v = *reinterpret_cast<const float4*>(Rrow + (int64_t)xs * p.r_ld + c4 * 4);
+        *reinterpret_cast<float4*>(&Rs[px * rs + c4 * 4]) = v;
+    }
+    for (int q = tid; q < TW * C4; q += 256) {
+        const int px = q / C4, c4 = q - px * C4;
+        const int x = x0 + px;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (x < p.W) {
+            v = *reinterpret_cast<const float4*>(Lrow + (int64_t)x * p.l_ld + c4 * 4);
+            if (p.copy_left) *reinterpret_cast<float4*>(p.out + ((int64_t)row * p.W + x) * p.out_ld + c4 * 4) = v;
+        }
+        *reinterpret_cast<float4*>(&Ls[px * rs + c4 * 4]) = v;
+    }
+    __syncthreads();
+    const float inv_c = 1.0f / (float)p.C;
+    for (int q = tid; q < TW * p.D; q += 256) {
+        const int pp = q / p.D, j = q - pp * p.D;
+        const int x = x0 + pp;
+        if (x >= p.W) continue;
+        const float* l = &Ls[pp * rs];
+        const float* r = &Rs[(pp + j * p.stride) * rs];
+        float acc = 0.f;
+        for (int c4 = 0; c4 < C4; ++c4) {
+            const float4 a = *reinterpret_cast<const float4*>(l + c4 * 4);
+            const float4 b = *reinterpret_cast<const float4*>(r + c4 * 4);
+            acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+        }
+        p.out[((int64_t)row * p.W + x) * p.out_ld + p.coff + j] = acc * inv_c;
+    }
+    // tail (u / zero padding), one lane per pixel
+    for (int pp = tid; pp < TW; pp += 256) {
+        const int x = x0 + pp;
+        if (x >= p.W) continue;
+        const int64_t pix = (int64_t)row * p.W + x;
+        float* Op = p.out + pix * p.out_ld;
+        int tail = p.coff + p.D;
+        if (p.u) { Op[tail] = p.u[pix]; ++tail; }
+        if (p.zero_tail)
+            for (; tail < p.out_ld; ++tail) Op[tail] = 0.f;
+    }
+}
+
+struct CorrBwdArgs {
+    const float* g; const float* L; const float* R; float* dL; float* dR; float* du;
+    int g_ld, coff, l_ld, r_ld, dl_ld, dr_ld;
+    int acc_l, acc_r, acc_u;
+    int B, H, W, C, md, stride, D, copy_left;
+    int64_t total;   // B*H*W*C4
+};
+
+// gather form (no atomics, deterministic): one lane = one (pixel, 4-channel group).
+__global__ __launch_bounds__(256) void corr_bwd_kernel(CorrBwdArgs p) {
+    const int C4 = p.C >> 2;
+    const float inv_c = 1.0f / (float)p.C;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < p.total; q += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(q % C4);
+        const int64_t pix = q / C4;
+        const int x = (int)(pix % p.W);
+        const int64_t rowbase = pix - x;
+        const float* gp = p.g + pix * p.g_ld;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), r = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < p.D; ++j) {
+            const int i = j * p.stride - p.md;
+            const int xs = x + i;
+            if (xs >= 0 && xs < p.W) {
+                const float gv = gp[p.coff + j];
+                const float4 rv = *reinterpret_cast<const float4*>(p.R + (rowbase + xs) * p.r_ld + c4 * 4);
+                a.x += gv * rv.x; a.y += gv * rv.y; a.z += gv * rv.z; a.w += gv * rv.w;
+            }
+            const int xl = x - i;
+            if (xl >= 0 && xl < p.W) {
+                const float gv = p.g[(rowbase + xl) * p.g_ld + p.coff + j];
+                const float4 lv = *reinterpret_cast<const float4*>(p.L + (rowbase + xl) * p.l_ld + c4 * 4);
+                r.x += gv * lv.x; r.y += gv * lv.y; r.z += gv * lv.z; r.w += gv * lv.w;
+            }
+        }
+        a.x *= inv_c; a.y *= inv_c; a.z *= inv_c; a.w *= inv_c;
+        r.x *= inv_c; r.y *= inv_c; r.z *= inv_c; r.w *= inv_c;
+        if (p.copy_left) {
+            const float4 gl = *reinterpret_cast<const float4*>(gp + c4 * 4);
+            a.x += gl.x; a.y += gl.y; a.z += gl.z; a.w += gl.w;
+        }
+        float4* dl = reinterpret_cast<float4*>(p.dL + pix * p.dl_ld + c4 * 4);
+        if (p.acc_l) { const float4 o = *dl; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
+        *dl = a;
+        float4* dr = reinterpret_cast<float4*>(p.dR + pix * p.dr_ld + c4 * 4);
+        if (p.acc_r) { const float4 o = *dr; r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
+        *dr = r;
+        if (p.du && c4 == 0) {
+            const float gu = gp[p.coff + p.D];
+            p.du[pix] = p.acc_u ? p.du[pix] + gu : gu;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mh_corr_fwd(const float* L, int32_t l_ld, const float* R, int32_t r_ld, const float* u,
+                           float* out, int32_t out_ld, int32_t coff,
+                           int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t stride,
+                           int32_t copy_left, int32_t zero_tail, void* stream) {
+    MH_REQUIRE(L && R && out, MH_ERR_ARG, "mh_corr_fwd: null argument");
+    MH_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && max_disp >= 0 && stride >= 1, MH_ERR_ARG, "mh_corr_fwd: bad dimension");
+    MH_REQUIRE(C % 4 == 0 && l_ld % 4 == 0 && r_ld % 4 == 0 && mh_aligned16(L) && mh_aligned16(R), MH_ERR_ALIGN,
+               "mh_corr_fwd: C, l_ld, r_ld must be multiples of 4 and L/R 16-byte aligned");
+    const int D = 2 * max_disp / stride + 1;
+    MH_REQUIRE(coff + D + (u ? 1 : 0) <= out_ld, MH_ERR_ARG, "mh_corr_fwd: out_ld too small");
+    MH_REQUIRE(!copy_left || (out_ld % 4 == 0 && mh_aligned16(out) && coff >= C), MH_ERR_ALIGN,
+               "mh_corr_fwd: copy_left needs 16-byte aligned rows and coff >= C");
+    CorrArgs a;
+    a.L = L; a.R = R; a.u = u; a.out = out; a.l_ld = l_ld; a.r_ld = r_ld; a.out_ld = out_ld; a.coff = coff;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.md = max_disp; a.stride = stride; a.D = D;
+    a.copy_left = copy_left; a.zero_tail = zero_tail;
+    hipStream_t s = (hipStream_t)stream;
+    const int C4 = C / 4;
+    if (D <= MAXD_SMALL) {
+        // lanes per pixel: cover the channel groups with at most 16 lanes
+        const int TW = 64;
+        a.segs = mh_cdiv(W, TW);
+        const size_t lds = (size_t)(TW + 2 * max_disp) * C * sizeof(float);
+        MH_REQUIRE(lds <= 64 * 1024, MH_ERR_UNSUPPORTED, "mh_corr_fwd: window does not fit LDS (C=%d, md=%d)", C, max_disp);
+        const dim3 grid(a.segs * B * H);
+        if (C4 <= 4) hipLaunchKernelGGL((corr_fwd_small<4, 64>), grid, dim3(256), lds, s, a);
+        else if (C4 <= 8) hipLaunchKernelGGL((corr_fwd_small<8, 64>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((corr_fwd_small<16, 64>), grid, dim3(256), lds, s, a);
+    } else {
+        const int TW = 32;
+        a.segs = mh_cdiv(W, TW);
+        const size_t lds = (size_t)(2 * TW + 2 * max_disp) * (C + 4) * sizeof(float);
+        MH_REQUIRE(lds <= 150 * 1024, MH_ERR_UNSUPPORTED, "mh_corr_fwd: tiles do not fit LDS (C=%d, md=%d)", C, max_disp);
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_large<32>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            MH_REQUIRE(e == hipSuccess, (int)e, "mh_corr_fwd: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL((corr_fwd_large<32>), dim3(a.segs * B * H), dim3(256), lds, s, a);
+    }
+    return mh_check_launch("corr_fwd");
+}
+
+extern "C" int mh_corr_bwd(const float* g, int32_t g_ld, int32_t coff, const float* L, int32_t l_ld,
+                           const float* R, int32_t r_ld, float* dL, int32_t dl_ld, int32_t acc_l,
+                           float* dR, int32_t dr_ld, int32_t acc_r, float* du, int32_t acc_u,
+                           int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t stride,
+                           int32_t copy_left, void* stream) {
+    MH_REQUIRE(g && L && R && dL && dR, MH_ERR_ARG, "mh_corr_bwd: null argument");
+    MH_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && max_disp >= 0 && stride >= 1, MH_ERR_ARG, "mh_corr_bwd: bad dimension");
+    MH_REQUIRE(C % 4 == 0 && l_ld % 4 == 0 && r_ld % 4 == 0 && dl_ld % 4 == 0 && dr_ld % 4 == 0 &&
+               mh_aligned16(L) && mh_aligned16(R) && mh_aligned16(dL) && mh_aligned16(dR), MH_ERR_ALIGN,
+               "mh_corr_bwd: channel counts / lds must be multiples of 4 and pointers 16-byte aligned");
+    MH_REQUIRE(!copy_left || (g_ld % 4 == 0 && mh_aligned16(g)), MH_ERR_ALIGN, "mh_corr_bwd: copy_left needs aligned g rows");
+    CorrBwdArgs a;
+    a.g = g; a.L = L; a.R = R; a.dL = dL; a.dR = dR; a.du = du;
+    a.g_ld = g_ld; a.coff = coff; a.l_ld = l_ld; a.r_ld = r_ld; a.dl_ld = dl_ld; a.dr_ld = dr_ld;
+    a.acc_l = acc_l; a.acc_r = acc_r; a.acc_u = acc_u;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.md = max_disp; a.stride = stride; a.D = 2 * max_disp / stride + 1;
+    a.copy_left = copy_left;
+    a.total = (int64_t)B * H * W * (C / 4);
+    int blocks = (int)((a.total + 255) / 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(corr_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return mh_check_launch("corr_bwd");
+}

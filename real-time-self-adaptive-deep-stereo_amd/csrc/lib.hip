@@ -1,0 +1,168 @@
+// lib.hip -- host side of libmadnet_hip.so: error reporting, the native plan executor that
+// replays a compiled network (array of mh_op records) with one FFI call, hipGraph capture /
+// replay of such a plan, and HIP-event timing helpers.
+#include "mh_common.h"
+#include <stdarg.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void mh_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int mh_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        mh_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+extern "C" const char* mh_last_error(void) { return g_err; }
+extern "C" int mh_abi_version(void) { return MH_ABI_VERSION; }
+extern "C" int mh_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { mh_set_error("hipGetDeviceCount: %s", hipGetErrorString(e)); return -(int)e; }
+    return n;
+}
+
+// ---- plan executor ------------------------------------------------------------------------
+// Field packing of mh_op per kind (host side: madnet_hip/plan.py must match):
+//  CONV      i[0..20] = mh_conv_desc fields in declaration order (ints), f[0]=alpha f[1]=mask_alpha
+//            p[0]=in p[1]=w p[2]=bias p[3]=out p[4]=mask_ref
+//  WGRAD     same desc; i[21]=dout_ld ; p[0]=in p[1]=dout p[2]=dw p[3]=db
+//  CORR_FWD  i: l_ld r_ld out_ld coff B H W C md stride copy_left zero_tail ; p: L R u out
+//  CORR_BWD  i: g_ld coff l_ld r_ld dl_ld acc_l dr_ld acc_r acc_u B H W C md stride copy_left ; p: g L R dL dR du
+//  WARP_FWD  i: img_ld out_ld B H W C ; p: img u out
+//  WARP_BWD  i: g_ld img_ld dimg_ld acc_u B H W C ; p: g img u dimg du
+//  RESIZE_*  i: B Hi Wi Hr Wr cy cx Ho Wo mode accumulate ; f[0]=mul ; FWD p: in out ; BWD p: g in din
+//  PAD       i: B H W C Hp Wp pt pl out_ld ; p: in out
+//  LOSS      i: B H W ; f[0]=grad_scale ; p: left right disp ws result ddisp
+//  METRICS   i: B H W ; f[0]=pixel_th ; p: disp gt ws result
+//  MOMENTUM  n ; f: lr momentum grad_scale ; p: var accum grad
+//  COPY_CH   i: src_ld dst_ld nch accumulate ; n=npix ; f[0]=scale ; p: src dst
+//  LEAKY_BWD i: dy_ld y_ld nch ; n=npix ; f[0]=alpha ; p: dy y
+//  FILL      n ; f[0]=v ; p: ptr
+static void desc_from_op(const mh_op& o, mh_conv_desc& d) {
+    const int32_t* i = o.i;
+    d.B = i[0]; d.Hi = i[1]; d.Wi = i[2]; d.Ho = i[3]; d.Wo = i[4]; d.K = i[5]; d.N = i[6];
+    d.kh = i[7]; d.kw = i[8]; d.stride = i[9]; d.dil = i[10]; d.pad_t = i[11]; d.pad_l = i[12];
+    d.mode = i[13]; d.w_trans = i[14]; d.in_ld = i[15]; d.out_ld = i[16]; d.mask_ld = i[17]; d.accumulate = i[18];
+    d.alpha = o.f[0]; d.mask_alpha = o.f[1];
+}
+
+static int run_op(const mh_op& o, void* s) {
+    const int32_t* i = o.i;
+    void* const* p = o.p;
+    switch (o.kind) {
+        case MH_OP_CONV: {
+            mh_conv_desc d; desc_from_op(o, d);
+            return mh_conv2d(&d, (const float*)p[0], (const float*)p[1], (const float*)p[2], (float*)p[3], (const float*)p[4], s);
+        }
+        case MH_OP_WGRAD: {
+            mh_conv_desc d; desc_from_op(o, d);
+            return mh_conv2d_wgrad(&d, (const float*)p[0], (const float*)p[1], i[21], (float*)p[2], (float*)p[3], s);
+        }
+        case MH_OP_CORR_FWD:
+            return mh_corr_fwd((const float*)p[0], i[0], (const float*)p[1], i[1], (const float*)p[2], (float*)p[3], i[2], i[3],
+                               i[4], i[5], i[6], i[7], i[8], i[9], i[10], i[11], s);
+        case MH_OP_CORR_BWD:
+            return mh_corr_bwd((const float*)p[0], i[0], i[1], (const float*)p[1], i[2], (const float*)p[2], i[3],
+                               (float*)p[3], i[4], i[5], (float*)p[4], i[6], i[7], (float*)p[5], i[8],
+                               i[9], i[10], i[11], i[12], i[13], i[14], i[15], s);
+        case MH_OP_WARP_FWD:
+            return mh_warp_fwd((const float*)p[0], i[0], (const float*)p[1], (float*)p[2], i[1], i[2], i[3], i[4], i[5], s);
+        case MH_OP_WARP_BWD:
+            return mh_warp_bwd((const float*)p[0], i[0], (const float*)p[1], i[1], (const float*)p[2], (float*)p[3], i[2],
+                               (float*)p[4], i[3], i[4], i[5], i[6], i[7], s);
+        case MH_OP_RESIZE_FWD:
+            return mh_resize_fwd((const float*)p[0], (float*)p[1], i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7], i[8], o.f[0], i[9], s);
+        case MH_OP_RESIZE_BWD:
+            return mh_resize_bwd((const float*)p[0], (const float*)p[1], (float*)p[2], i[10], i[0], i[1], i[2], i[3], i[4], i[5], i[6],
+                                 i[7], i[8], o.f[0], i[9], s);
+        case MH_OP_PAD_REFLECT:
+            return mh_pad_reflect((const float*)p[0], (float*)p[1], i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7], i[8], s);
+        case MH_OP_LOSS:
+            return mh_reprojection_loss((const float*)p[0], (const float*)p[1], (const float*)p[2], (float*)p[3], (float*)p[4],
+                                        (float*)p[5], o.f[0], i[0], i[1], i[2], s);
+        case MH_OP_METRICS:
+            return mh_metrics((const float*)p[0], (const float*)p[1], (float*)p[2], (float*)p[3], o.f[0], i[0], i[1], i[2], s);
+        case MH_OP_MOMENTUM:
+            return mh_momentum((float*)p[0], (float*)p[1], (const float*)p[2], o.n, o.f[0], o.f[1], o.f[2], s);
+        case MH_OP_COPY_CH:
+            return mh_copy_channels((const float*)p[0], i[0], (float*)p[1], i[1], o.n, i[2], o.f[0], i[3], s);
+        case MH_OP_LEAKY_BWD:
+            return mh_leaky_bwd((float*)p[0], i[0], (const float*)p[1], i[1], o.n, i[2], o.f[0], s);
+        case MH_OP_FILL:
+            return mh_fill((float*)p[0], o.n, o.f[0], s);
+        default:
+            mh_set_error("mh_plan_run: unknown op kind %d", o.kind);
+            return MH_ERR_ARG;
+    }
+}
+
+extern "C" int mh_plan_run(const mh_op* ops, int32_t nops, void* stream) {
+    MH_REQUIRE(ops || nops == 0, MH_ERR_ARG, "mh_plan_run: null plan");
+    for (int32_t k = 0; k < nops; ++k) {
+        const int e = run_op(ops[k], stream);
+        if (e != 0) {
+            char tmp[400];
+            strncpy(tmp, g_err, sizeof(tmp) - 1); tmp[sizeof(tmp) - 1] = 0;
+            mh_set_error("plan op %d (kind %d): %s", k, ops[k].kind, tmp);
+            return e;
+        }
+    }
+    return 0;
+}
+
+#define MH_HIP(call)                                                        \
+    do {                                                                    \
+        hipError_t e_ = (call);                                             \
+        if (e_ != hipSuccess) {                                             \
+            mh_set_error("%s: %s", #call, hipGetErrorString(e_));           \
+            return (int)e_;                                                 \
+        }                                                                   \
+    } while (0)
+
+extern "C" int mh_graph_begin(void* stream) {
+    MH_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+    return 0;
+}
+extern "C" int mh_graph_end(void* stream, void** graph_exec_out) {
+    MH_REQUIRE(graph_exec_out, MH_ERR_ARG, "mh_graph_end: null output");
+    hipGraph_t g = nullptr;
+    MH_HIP(hipStreamEndCapture((hipStream_t)stream, &g));
+    hipGraphExec_t ge = nullptr;
+    hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (e != hipSuccess) { mh_set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return (int)e; }
+    *graph_exec_out = (void*)ge;
+    return 0;
+}
+extern "C" int mh_graph_launch(void* graph_exec, void* stream) {
+    MH_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int mh_graph_destroy(void* graph_exec) {
+    if (graph_exec) MH_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    return 0;
+}
+extern "C" int mh_event_create(void** ev) {
+    MH_REQUIRE(ev, MH_ERR_ARG, "mh_event_create: null output");
+    hipEvent_t e; MH_HIP(hipEventCreate(&e)); *ev = (void*)e; return 0;
+}
+extern "C" int mh_event_record(void* ev, void* stream) { MH_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream)); return 0; }
+extern "C" int mh_event_elapsed_ms(void* a, void* b, float* ms) {
+    MH_REQUIRE(ms, MH_ERR_ARG, "mh_event_elapsed_ms: null output");
+    MH_HIP(hipEventSynchronize((hipEvent_t)b));
+    MH_HIP(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+    return 0;
+}
+extern "C" int mh_event_destroy(void* ev) { if (ev) MH_HIP(hipEventDestroy((hipEvent_t)ev)); return 0; }
+extern "C" int mh_stream_sync(void* stream) { MH_HIP(hipStreamSynchronize((hipStream_t)stream)); return 0; }

@@ -1,0 +1,46 @@
+// mh_common.h -- shared helpers for the gfx950 kernels of libmadnet_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/madnet_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MH_ERR_ARG (-1)
+#define MH_ERR_ALIGN (-2)
+#define MH_ERR_UNSUPPORTED (-3)
+
+void mh_set_error(const char* fmt, ...);
+int mh_check_launch(const char* what);
+
+#define MH_REQUIRE(cond, code, ...)                \
+    do {                                           \
+        if (!(cond)) {                             \
+            mh_set_error(__VA_ARGS__);             \
+            return (code);                         \
+        }                                          \
+    } while (0)
+
+static inline int mh_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline bool mh_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// XCD-aware, bijective remap of a linear workgroup id (8 XCDs; block b runs on XCD b%8):
+// every XCD gets a contiguous chunk of the logical tile space so neighbouring tiles share
+// one L2 (cdna_hip_programming.md T1, bijective variant).
+__device__ __forceinline__ int mh_xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + idx;
+}
+
+__device__ __forceinline__ float mh_wave_sum(float v) {
+    v += __shfl_xor(v, 32);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    return v;
+}

@@ -1,0 +1,587 @@
+// ops.hip -- the bandwidth-bound glue of the MADNet hot path for gfx950: feature warping,
+// TF1-legacy bilinear resize (+scale/relu/crop fusions), reflect padding, the photometric
+// SSIM+L1 reprojection loss with its disparity gradient, validation metrics, momentum update.
+// Every kernel is a coalesced NHWC stream with 16-byte accesses where the layout allows;
+// reductions are two-stage (wave shuffles -> per-block partial -> one finishing block) so the
+// results are deterministic.
+#include "mh_common.h"
+
+namespace {
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+// ------------------------------------------------------------------------------------------
+// MadNet._linear_warping (Nets/MadNet.py:400-436) with coords from _build_indeces (:378-397)
+// ------------------------------------------------------------------------------------------
+struct WarpArgs {
+    const float* img; const float* u; const float* g; float* out; float* dimg; float* du;
+    int img_ld, out_ld, g_ld, dimg_ld, acc_u;
+    int B, H, W, C;
+    int64_t total;
+};
+
+__global__ __launch_bounds__(256) void warp_fwd_kernel(WarpArgs p) {
+    const int C4 = p.C >> 2;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < p.total; q += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(q % C4);
+        const int64_t pix = q / C4;
+        const int x = (int)(pix % p.W);
+        const int64_t rowbase = pix - x;
+        const float cx = (float)x + p.u[pix];
+        const float x0 = floorf(cx), x1 = x0 + 1.0f;
+        const float xmax = (float)(p.W - 1);
+        const float x0s = clampf(x0, 0.f, xmax), x1s = clampf(x1, 0.f, xmax);
+        const float w0 = (x1 - cx) * (x0 == x0s ? 1.f : 0.f);
+        const float w1 = (cx - x0) * (x1 == x1s ? 1.f : 0.f);
+        const float4 a = *reinterpret_cast<const float4*>(p.img + (rowbase + (int)x0s) * p.img_ld + c4 * 4);
+        const float4 b = *reinterpret_cast<const float4*>(p.img + (rowbase + (int)x1s) * p.img_ld + c4 * 4);
+        float4 o;
+        o.x = w0 * a.x + w1 * b.x; o.y = w0 * a.y + w1 * b.y;
+        o.z = w0 * a.z + w1 * b.z; o.w = w0 * a.w + w1 * b.w;
+        *reinterpret_cast<float4*>(p.out + pix * p.out_ld + c4 * 4) = o;
+    }
+}
+
+// one wave = 64 lanes = (64/LPP) pixels x LPP channel lanes; du reduced with shuffles.
+template <int LPP>
+__global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs p) {
+    const int C4 = p.C >> 2;
+    constexpr int PPB = 256 / LPP;
+    const int sub = threadIdx.x % LPP;
+    const int64_t npix = (int64_t)p.B * p.H * p.W;
+    const int64_t nit = (npix + PPB - 1) / PPB;
+    for (int64_t it = blockIdx.x; it < nit; it += gridDim.x) {
+        const int64_t pix = it * PPB + threadIdx.x / LPP;
+        const bool live = pix < npix;
+        const int64_t pp = live ? pix : 0;
+        const int x = (int)(pp % p.W);
+        const int64_t rowbase = pp - x;
+        const float cx = (float)x + p.u[pp];
+        const float x0 = floorf(cx), x1 = x0 + 1.0f;
+        const float xmax = (float)(p.W - 1);
+        const float x0s = clampf(x0, 0.f, xmax), x1s = clampf(x1, 0.f, xmax);
+        const float m0 = (x0 == x0s) ? 1.f : 0.f, m1 = (x1 == x1s) ? 1.f : 0.f;
+        const float w0 = (x1 - cx) * m0, w1 = (cx - x0) * m1;
+        const int i0 = (int)x0s, i1 = (int)x1s;
+        float dcx = 0.f;
+        for (int c4 = sub; c4 < C4; c4 += LPP) {
+            if (!live) continue;
+            const float4 gv = *reinterpret_cast<const float4*>(p.g + pp * p.g_ld + c4 * 4);
+            float* d0 = p.dimg + (rowbase + i0) * p.dimg_ld + c4 * 4;
+            float* d1 = p.dimg + (rowbase + i1) * p.dimg_ld + c4 * 4;
+            if (w0 != 0.f) { atomicAdd(d0 + 0, w0 * gv.x); atomicAdd(d0 + 1, w0 * gv.y); atomicAdd(d0 + 2, w0 * gv.z); atomicAdd(d0 + 3, w0 * gv.w); }
+            if (w1 != 0.f) { atomicAdd(d1 + 0, w1 * gv.x); atomicAdd(d1 + 1, w1 * gv.y); atomicAdd(d1 + 2, w1 * gv.z); atomicAdd(d1 + 3, w1 * gv.w); }
+            if (p.du) {
+                const float4 a = *reinterpret_cast<const float4*>(p.img + (rowbase + i0) * p.img_ld + c4 * 4);
+                const float4 b = *reinterpret_cast<const float4*>(p.img + (rowbase + i1) * p.img_ld + c4 * 4);
+                dcx += gv.x * (m1 * b.x - m0 * a.x) + gv.y * (m1 * b.y - m0 * a.y) +
+                       gv.z * (m1 * b.z - m0 * a.z) + gv.w * (m1 * b.w - m0 * a.w);
+            }
+        }
+        if (p.du) {
+#pragma unroll
+            for (int o = LPP >> 1; o > 0; o >>= 1) dcx += __shfl_xor(dcx, o);
+            if (live && sub == 0) p.du[pp] = p.acc_u ? p.du[pp] + dcx : dcx;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// TF1 legacy bilinear resize + scale / relu / crop fusions
+// ------------------------------------------------------------------------------------------
+struct ResizeArgs {
+    const float* in; const float* g; float* out; float* din;
+    int B, Hi, Wi, Hr, Wr, cy, cx, Ho, Wo, mode, accumulate;
+    float mul, sy, sx;   // sy = (float)Hi/(float)Hr
+};
+
+__device__ __forceinline__ void interp1(int i, float scale, int n, int& lo, int& hi, float& t) {
+    const float src = (float)i * scale;
+    lo = (int)src;
+    hi = min(lo + 1, n - 1);
+    t = src - (float)lo;
+}
+
+__device__ __forceinline__ float bilerp(const float* img, int Wi, int y0, int y1, float ty, int x0, int x1, float tx,
+                                        float mul, bool relu_in) {
+    float tl = img[(int64_t)y0 * Wi + x0], tr = img[(int64_t)y0 * Wi + x1];
+    float bl = img[(int64_t)y1 * Wi + x0], br = img[(int64_t)y1 * Wi + x1];
+    if (relu_in) {
+        tl = fmaxf(tl * mul, 0.f); tr = fmaxf(tr * mul, 0.f);
+        bl = fmaxf(bl * mul, 0.f); br = fmaxf(br * mul, 0.f);
+    }
+    const float top = tl + (tr - tl) * tx;
+    const float bot = bl + (br - bl) * tx;
+    return top + (bot - top) * ty;
+}
+
+__global__ __launch_bounds__(256) void resize_fwd_kernel(ResizeArgs p) {
+    const int64_t total = (int64_t)p.B * p.Ho * p.Wo;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int x = (int)(q % p.Wo);
+        const int64_t t2 = q / p.Wo;
+        const int y = (int)(t2 % p.Ho);
+        const int b = (int)(t2 / p.Ho);
+        int y0, y1, x0, x1; float ty, tx;
+        interp1(y + p.cy, p.sy, p.Hi, y0, y1, ty);
+        interp1(x + p.cx, p.sx, p.Wi, x0, x1, tx);
+        const float* img = p.in + (int64_t)b * p.Hi * p.Wi;
+        float v = bilerp(img, p.Wi, y0, y1, ty, x0, x1, tx, p.mul, p.mode == 1);
+        if (p.mode == 0) v *= p.mul;
+        else if (p.mode == 2) v = fmaxf(v * p.mul, 0.f);
+        p.out[q] = v;
+    }
+}
+
+// gather form of ResizeBilinearGrad: one lane per INPUT pixel, loops the output pixels whose
+// lower/upper source index hits it (exactly the forward's float index arithmetic).
+__global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeArgs p) {
+    const int64_t total = (int64_t)p.B * p.Hi * p.Wi;
+    const float isy = 1.0f / p.sy, isx = 1.0f / p.sx;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int sx = (int)(q % p.Wi);
+        const int64_t t2 = q / p.Wi;
+        const int sy = (int)(t2 % p.Hi);
+        const int b = (int)(t2 / p.Hi);
+        const float* img = p.in + (int64_t)b * p.Hi * p.Wi;
+        const float* gimg = p.g + (int64_t)b * p.Ho * p.Wo;
+        const int ya = max(p.cy, (int)floorf((float)(sy - 1) * isy) - 1);
+        const int yb = min(p.cy + p.Ho - 1, (int)ceilf((float)(sy + 1) * isy) + 1);
+        const int xa = max(p.cx, (int)floorf((float)(sx - 1) * isx) - 1);
+        const int xb = min(p.cx + p.Wo - 1, (int)ceilf((float)(sx + 1) * isx) + 1);
+        float acc = 0.f;
+        for (int Y = ya; Y <= yb; ++Y) {
+            int y0, y1; float ty;
+            interp1(Y, p.sy, p.Hi, y0, y1, ty);
+            const float wy = (y0 == sy ? 1.0f - ty : 0.f) + (y1 == sy ? ty : 0.f);
+            if (wy == 0.f) continue;
+            for (int X = xa; X <= xb; ++X) {
+                int x0, x1; float tx;
+                interp1(X, p.sx, p.Wi, x0, x1, tx);
+                const float wx = (x0 == sx ? 1.0f - tx : 0.f) + (x1 == sx ? tx : 0.f);
+                if (wx == 0.f) continue;
+                float gv = gimg[(int64_t)(Y - p.cy) * p.Wo + (X - p.cx)];
+                if (p.mode == 2) {
+                    const float z = bilerp(img, p.Wi, y0, y1, ty, x0, x1, tx, p.mul, false) * p.mul;
+                    if (!(z > 0.f)) gv = 0.f;
+                }
+                acc += gv * wy * wx;
+            }
+        }
+        acc *= p.mul;
+        if (p.mode == 1 && !(img[(int64_t)sy * p.Wi + sx] * p.mul > 0.f)) acc = 0.f;
+        p.din[q] = p.accumulate ? p.din[q] + acc : acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// preprocessing.pad_image (REFLECT) + channel padding
+// ------------------------------------------------------------------------------------------
+struct PadArgs { const float* in; float* out; int B, H, W, C, Hp, Wp, pt, pl, out_ld; };
+
+__global__ __launch_bounds__(256) void pad_reflect_kernel(PadArgs p) {
+    const int64_t total = (int64_t)p.B * p.Hp * p.Wp;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int x = (int)(q % p.Wp);
+        const int64_t t2 = q / p.Wp;
+        const int y = (int)(t2 % p.Hp);
+        const int b = (int)(t2 / p.Hp);
+        int sy = y - p.pt, sx = x - p.pl;
+        sy = sy < 0 ? -sy : (sy >= p.H ? 2 * (p.H - 1) - sy : sy);
+        sx = sx < 0 ? -sx : (sx >= p.W ? 2 * (p.W - 1) - sx : sx);
+        const float* src = p.in + (((int64_t)b * p.H + sy) * p.W + sx) * p.C;
+        float* dst = p.out + q * p.out_ld;
+        for (int c = 0; c < p.out_ld; ++c) dst[c] = c < p.C ? src[c] : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// reprojection loss (mean_SSIM_L1 of warp_image(right, disp) vs left)
+// ------------------------------------------------------------------------------------------
+struct LossArgs {
+    const float* left; const float* right; const float* disp;
+    float* rep; float* drep; float* coef; float* part1; float* part2; float* result; float* ddisp;
+    int B, H, W, nblk1, nblk2;
+    float grad_scale;
+};
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = mh_wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// stage 1: warp right by the disparity (bilinear_sampler: clamped indices, un-masked weights;
+// rows are integral so only the y0 taps carry weight), L1 partial sums.
+__global__ __launch_bounds__(256) void loss_warp_kernel(LossArgs p) {
+    __shared__ float red[4];
+    const int64_t total = (int64_t)p.B * p.H * p.W;
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float l1 = 0.f;
+    if (q < total) {
+        const int x = (int)(q % p.W);
+        const int64_t rowbase = q - x;
+        const float cx = (float)x - p.disp[q];
+        const float x0 = floorf(cx), x1 = x0 + 1.0f;
+        const float w0 = x1 - cx, w1 = cx - x0;
+        const float xmax = (float)(p.W - 1);
+        const int i0 = (int)clampf(x0, 0.f, xmax), i1 = (int)clampf(x1, 0.f, xmax);
+        const float* r0 = p.right + (rowbase + i0) * 3;
+        const float* r1 = p.right + (rowbase + i1) * 3;
+        const float* lp = p.left + q * 3;
+        float4 rep, dr;
+        const float s = 1.0f / 256.0f;
+        const float a0 = r0[0] * s, a1 = r0[1] * s, a2 = r0[2] * s;
+        const float b0 = r1[0] * s, b1 = r1[1] * s, b2 = r1[2] * s;
+        rep.x = w0 * a0 + w1 * b0; rep.y = w0 * a1 + w1 * b1; rep.z = w0 * a2 + w1 * b2; rep.w = 0.f;
+        dr.x = b0 - a0; dr.y = b1 - a1; dr.z = b2 - a2; dr.w = 0.f;
+        *reinterpret_cast<float4*>(p.rep + q * 4) = rep;
+        *reinterpret_cast<float4*>(p.drep + q * 4) = dr;
+        l1 = fabsf(rep.x - lp[0] * s) + fabsf(rep.y - lp[1] * s) + fabsf(rep.z - lp[2] * s);
+    }
+    const float tot = block_sum(l1, red);
+    if (threadIdx.x == 0) p.part1[blockIdx.x] = tot;
+}
+
+// stage 2: SSIM over 3x3 VALID windows; per-window derivative coefficients
+//   d map / d x_p = alpha + beta*y_p + gamma*x_p   for the 9 pixels p of the window.
+__global__ __launch_bounds__(256) void loss_ssim_kernel(LossArgs p) {
+    __shared__ float red[4];
+    const int Hw = p.H - 2, Ww = p.W - 2;
+    const int64_t total = (int64_t)p.B * Hw * Ww;
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float ssum = 0.f;
+    if (q < total) {
+        const int wx = (int)(q % Ww);
+        const int64_t t2 = q / Ww;
+        const int wy = (int)(t2 % Hw);
+        const int b = (int)(t2 / Hw);
+        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+        const float s = 1.0f / 256.0f;
+        float sx[3] = {0, 0, 0}, sy[3] = {0, 0, 0}, sxx[3] = {0, 0, 0}, syy[3] = {0, 0, 0}, sxy[3] = {0, 0, 0};
+        for (int dy = 0; dy < 3; ++dy)
+            for (int dx = 0; dx < 3; ++dx) {
+                const int64_t pix = ((int64_t)b * p.H + wy + dy) * p.W + wx + dx;
+                const float4 xr = *reinterpret_cast<const float4*>(p.rep + pix * 4);
+                const float* lp = p.left + pix * 3;
+                const float xv[3] = {xr.x, xr.y, xr.z};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float yv = lp[c] * s;
+                    sx[c] += xv[c]; sy[c] += yv; sxx[c] += xv[c] * xv[c]; syy[c] += yv * yv; sxy[c] += xv[c] * yv;
+                }
+            }
+        float co[12];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float inv9 = 1.0f / 9.0f;
+            const float mx = sx[c] * inv9, my = sy[c] * inv9;
+            const float vx = sxx[c] * inv9 - mx * mx, vy = syy[c] * inv9 - my * my, vxy = sxy[c] * inv9 - mx * my;
+            const float n1 = 2.f * mx * my + C1, n2 = 2.f * vxy + C2;
+            const float d1 = mx * mx + my * my + C1, d2 = vx + vy + C2;
+            const float S = (n1 * n2) / (d1 * d2);
+            const float mraw = (1.0f - S) * 0.5f;
+            ssum += clampf(mraw, 0.f, 1.f);
+            // tf.clip_by_value passes the gradient iff 0 <= x <= 1 ; d map = -0.5 dS
+            const float pass = (mraw >= 0.f && mraw <= 1.f) ? -0.5f * (2.0f / 9.0f) : 0.f;
+            const float idd = 1.0f / (d1 * d2);
+            const float beta = n1 * idd;
+            const float gamma = -S / d2;
+            const float alpha = (my * n2 - n1 * my) * idd - S * (mx * d2 - d1 * mx) * idd;
+            co[c * 4 + 0] = pass * alpha; co[c * 4 + 1] = pass * beta; co[c * 4 + 2] = pass * gamma; co[c * 4 + 3] = 0.f;
+        }
+        float4* dst = reinterpret_cast<float4*>(p.coef + q * 12);
+        dst[0] = make_float4(co[0], co[1], co[2], co[3]);
+        dst[1] = make_float4(co[4], co[5], co[6], co[7]);
+        dst[2] = make_float4(co[8], co[9], co[10], co[11]);
+    }
+    const float tot = block_sum(ssum, red);
+    if (threadIdx.x == 0) p.part2[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void loss_final_kernel(LossArgs p) {
+    __shared__ double red[256];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < p.nblk1; i += 256) a += (double)p.part1[i];
+    for (int i = threadIdx.x; i < p.nblk2; i += 256) b += (double)p.part2[i];
+    red[threadIdx.x] = a; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    const double l1 = red[0]; __syncthreads();
+    red[threadIdx.x] = b; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) {
+        const double n1 = (double)p.B * p.H * p.W * 3.0;
+        const double n2 = (double)p.B * (p.H - 2) * (p.W - 2) * 3.0;
+        const double ms = red[0] / n2, ml = l1 / n1;
+        p.result[0] = (float)(0.85 * ms + 0.15 * ml);
+        p.result[1] = (float)ms;
+        p.result[2] = (float)ml;
+    }
+}
+
+// stage 3: d loss / d disp[p] = - sum_ch (d loss / d rep[p,ch]) * drep[p,ch]
+__global__ __launch_bounds__(256) void loss_grad_kernel(LossArgs p) {
+    const int64_t total = (int64_t)p.B * p.H * p.W;
+    const int Hw = p.H - 2, Ww = p.W - 2;
+    const float k_ssim = 0.85f / ((float)p.B * (float)Hw * (float)Ww * 3.0f);
+    const float k_l1 = 0.15f / ((float)p.B * (float)p.H * (float)p.W * 3.0f);
+    const float s = 1.0f / 256.0f;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int x = (int)(q % p.W);
+        const int64_t t2 = q / p.W;
+        const int y = (int)(t2 % p.H);
+        const int b = (int)(t2 / p.H);
+        const float4 xr = *reinterpret_cast<const float4*>(p.rep + q * 4);
+        const float4 dr = *reinterpret_cast<const float4*>(p.drep + q * 4);
+        const float* lp = p.left + q * 3;
+        const float xv[3] = {xr.x, xr.y, xr.z};
+        const float dv[3] = {dr.x, dr.y, dr.z};
+        float A[3] = {0, 0, 0}, Bc[3] = {0, 0, 0}, Gc[3] = {0, 0, 0};
+        for (int wy = max(0, y - 2); wy <= min(Hw - 1, y); ++wy)
+            for (int wx = max(0, x - 2); wx <= min(Ww - 1, x); ++wx) {
+                const float4* cp = reinterpret_cast<const float4*>(p.coef + (((int64_t)b * Hw + wy) * Ww + wx) * 12);
+                const float4 c0 = cp[0], c1 = cp[1], c2 = cp[2];
+                A[0] += c0.x; Bc[0] += c0.y; Gc[0] += c0.z;
+                A[1] += c1.x; Bc[1] += c1.y; Gc[1] += c1.z;
+                A[2] += c2.x; Bc[2] += c2.y; Gc[2] += c2.z;
+            }
+        float gd = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float yv = lp[c] * s;
+            const float diff = xv[c] - yv;
+            const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+            const float grep = k_ssim * (A[c] + Bc[c] * yv + Gc[c] * xv[c]) + k_l1 * sgn;
+            gd -= grep * dv[c];
+        }
+        p.ddisp[q] = gd * p.grad_scale;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// validation metrics (Stereo_Online_Adaptation.py:74-82)
+// ------------------------------------------------------------------------------------------
+struct MetArgs { const float* disp; const float* gt; float* part; float* result; int64_t total; int nblk; float th; };
+
+__global__ __launch_bounds__(256) void metrics_kernel(MetArgs p) {
+    __shared__ float red[4];
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float e = 0.f, bad = 0.f, v = 0.f;
+    if (q < p.total) {
+        const float gt = p.gt[q];
+        v = (gt == 0.f) ? 0.f : 1.f;
+        e = fabsf(p.disp[q] - gt) * v;
+        bad = e > p.th ? 1.f : 0.f;
+    }
+    const float se = block_sum(e, red);
+    const float sb = block_sum(bad, red);
+    const float sv = block_sum(v, red);
+    if (threadIdx.x == 0) { p.part[blockIdx.x * 3 + 0] = se; p.part[blockIdx.x * 3 + 1] = sb; p.part[blockIdx.x * 3 + 2] = sv; }
+}
+
+__global__ __launch_bounds__(256) void metrics_final_kernel(MetArgs p) {
+    __shared__ double red[3][256];
+    double a = 0, b = 0, c = 0;
+    for (int i = threadIdx.x; i < p.nblk; i += 256) { a += p.part[i * 3]; b += p.part[i * 3 + 1]; c += p.part[i * 3 + 2]; }
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b; red[2][threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + o];
+            red[1][threadIdx.x] += red[1][threadIdx.x + o];
+            red[2][threadIdx.x] += red[2][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        p.result[0] = (float)(red[0][0] / red[2][0]);
+        p.result[1] = (float)(red[1][0] / red[2][0]);
+        p.result[2] = (float)red[2][0];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// momentum / glue
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void momentum_kernel(float* var, float* acc, const float* g, int64_t n, float lr, float mom, float gs) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float a = mom * acc[i] + gs * g[i];
+        acc[i] = a;
+        var[i] -= lr * a;
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_channels_kernel(const float* src, int src_ld, float* dst, int dst_ld, int64_t npix,
+                                                            int nch, float scale, int accumulate) {
+    const int64_t total = npix * nch;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int c = (int)(q % nch);
+        const int64_t pix = q / nch;
+        const float v = scale * src[pix * src_ld + c];
+        float* d = dst + pix * dst_ld + c;
+        *d = accumulate ? *d + v : v;
+    }
+}
+
+__global__ __launch_bounds__(256) void leaky_bwd_kernel(float* dy, int dy_ld, const float* y, int y_ld, int64_t npix, int nch, float alpha) {
+    const int64_t total = npix * nch;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int c = (int)(q % nch);
+        const int64_t pix = q / nch;
+        if (!(y[pix * y_ld + c] > 0.f)) dy[pix * dy_ld + c] *= alpha;
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* p, int64_t n, float v) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = v;
+}
+
+inline int grid_for(int64_t n, int cap = 256 * 16) {
+    int64_t b = (n + 255) / 256;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int mh_warp_fwd(const float* img, int32_t img_ld, const float* u, float* out, int32_t out_ld,
+                           int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+    MH_REQUIRE(img && u && out, MH_ERR_ARG, "mh_warp_fwd: null argument");
+    MH_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, MH_ERR_ARG, "mh_warp_fwd: bad dimension");
+    MH_REQUIRE(C % 4 == 0 && img_ld % 4 == 0 && out_ld % 4 == 0 && mh_aligned16(img) && mh_aligned16(out), MH_ERR_ALIGN,
+               "mh_warp_fwd: C and lds must be multiples of 4, pointers 16-byte aligned");
+    WarpArgs a{}; a.img = img; a.u = u; a.out = out; a.img_ld = img_ld; a.out_ld = out_ld;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.total = (int64_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(warp_fwd_kernel, dim3(grid_for(a.total)), dim3(256), 0, (hipStream_t)stream, a);
+    return mh_check_launch("warp_fwd");
+}
+
+extern "C" int mh_warp_bwd(const float* g, int32_t g_ld, const float* img, int32_t img_ld, const float* u,
+                           float* dimg, int32_t dimg_ld, float* du, int32_t acc_u,
+                           int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+    MH_REQUIRE(g && img && u && dimg, MH_ERR_ARG, "mh_warp_bwd: null argument");
+    MH_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, MH_ERR_ARG, "mh_warp_bwd: bad dimension");
+    MH_REQUIRE(C % 4 == 0 && img_ld % 4 == 0 && g_ld % 4 == 0 && mh_aligned16(img) && mh_aligned16(g), MH_ERR_ALIGN,
+               "mh_warp_bwd: C and lds must be multiples of 4, pointers 16-byte aligned");
+    WarpArgs a{}; a.g = g; a.img = img; a.u = u; a.dimg = dimg; a.du = du; a.acc_u = acc_u;
+    a.g_ld = g_ld; a.img_ld = img_ld; a.dimg_ld = dimg_ld; a.B = B; a.H = H; a.W = W; a.C = C;
+    const int C4 = C / 4;
+    const int64_t npix = (int64_t)B * H * W;
+    hipStream_t s = (hipStream_t)stream;
+    if (C4 <= 4) hipLaunchKernelGGL((warp_bwd_kernel<4>), dim3(grid_for(npix * 4)), dim3(256), 0, s, a);
+    else if (C4 <= 8) hipLaunchKernelGGL((warp_bwd_kernel<8>), dim3(grid_for(npix * 8)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((warp_bwd_kernel<16>), dim3(grid_for(npix * 16)), dim3(256), 0, s, a);
+    return mh_check_launch("warp_bwd");
+}
+
+static int resize_args(ResizeArgs& a, int B, int Hi, int Wi, int Hr, int Wr, int cy, int cx, int Ho, int Wo, float mul, int mode) {
+    MH_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Hr > 0 && Wr > 0 && Ho > 0 && Wo > 0, MH_ERR_ARG, "mh_resize: bad dimension");
+    MH_REQUIRE(cy >= 0 && cx >= 0 && cy + Ho <= Hr && cx + Wo <= Wr, MH_ERR_ARG, "mh_resize: crop outside the resized image");
+    MH_REQUIRE(mode >= 0 && mode <= 2, MH_ERR_ARG, "mh_resize: mode must be 0,1,2");
+    a.B = B; a.Hi = Hi; a.Wi = Wi; a.Hr = Hr; a.Wr = Wr; a.cy = cy; a.cx = cx; a.Ho = Ho; a.Wo = Wo; a.mode = mode;
+    a.mul = mul; a.sy = (float)Hi / (float)Hr; a.sx = (float)Wi / (float)Wr;
+    return 0;
+}
+
+extern "C" int mh_resize_fwd(const float* in, float* out, int32_t B, int32_t Hi, int32_t Wi, int32_t Hr, int32_t Wr,
+                             int32_t cy, int32_t cx, int32_t Ho, int32_t Wo, float mul, int32_t mode, void* stream) {
+    MH_REQUIRE(in && out, MH_ERR_ARG, "mh_resize_fwd: null argument");
+    ResizeArgs a{}; a.in = in; a.out = out;
+    if (int e = resize_args(a, B, Hi, Wi, Hr, Wr, cy, cx, Ho, Wo, mul, mode)) return e;
+    hipLaunchKernelGGL(resize_fwd_kernel, dim3(grid_for((int64_t)B * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, a);
+    return mh_check_launch("resize_fwd");
+}
+
+extern "C" int mh_resize_bwd(const float* g, const float* in, float* din, int32_t accumulate, int32_t B, int32_t Hi, int32_t Wi,
+                             int32_t Hr, int32_t Wr, int32_t cy, int32_t cx, int32_t Ho, int32_t Wo, float mul, int32_t mode,
+                             void* stream) {
+    MH_REQUIRE(g && in && din, MH_ERR_ARG, "mh_resize_bwd: null argument");
+    ResizeArgs a{}; a.in = in; a.g = g; a.din = din; a.accumulate = accumulate;
+    if (int e = resize_args(a, B, Hi, Wi, Hr, Wr, cy, cx, Ho, Wo, mul, mode)) return e;
+    hipLaunchKernelGGL(resize_bwd_kernel, dim3(grid_for((int64_t)B * Hi * Wi)), dim3(256), 0, (hipStream_t)stream, a);
+    return mh_check_launch("resize_bwd");
+}
+
+extern "C" int mh_pad_reflect(const float* in, float* out, int32_t B, int32_t H, int32_t W, int32_t C,
+                              int32_t Hp, int32_t Wp, int32_t pad_t, int32_t pad_l, int32_t out_ld, void* stream) {
+    MH_REQUIRE(in && out, MH_ERR_ARG, "mh_pad_reflect: null argument");
+    MH_REQUIRE(B > 0 && H > 1 && W > 1 && C > 0 && Hp >= H && Wp >= W && out_ld >= C, MH_ERR_ARG, "mh_pad_reflect: bad dimension");
+    MH_REQUIRE(pad_t >= 0 && pad_l >= 0 && pad_t < H && pad_l < W && Hp - H - pad_t < H && Wp - W - pad_l < W &&
+               Hp - H - pad_t >= 0 && Wp - W - pad_l >= 0, MH_ERR_ARG, "mh_pad_reflect: REFLECT pad must be smaller than the image");
+    PadArgs a{in, out, B, H, W, C, Hp, Wp, pad_t, pad_l, out_ld};
+    hipLaunchKernelGGL(pad_reflect_kernel, dim3(grid_for((int64_t)B * Hp * Wp)), dim3(256), 0, (hipStream_t)stream, a);
+    return mh_check_launch("pad_reflect");
+}
+
+static inline int64_t nblk(int64_t n) { return (n + 255) / 256; }
+
+extern "C" int64_t mh_loss_ws_floats(int32_t B, int32_t H, int32_t W) {
+    const int64_t n = (int64_t)B * H * W, nw = (int64_t)B * (H - 2) * (W - 2);
+    return 8 * n + 12 * nw + nblk(n) + nblk(nw) + 64;
+}
+
+extern "C" int mh_reprojection_loss(const float* left, const float* right, const float* disp, float* ws, float* result,
+                                    float* ddisp, float grad_scale, int32_t B, int32_t H, int32_t W, void* stream) {
+    MH_REQUIRE(left && right && disp && ws && result, MH_ERR_ARG, "mh_reprojection_loss: null argument");
+    MH_REQUIRE(B > 0 && H >= 3 && W >= 3, MH_ERR_ARG, "mh_reprojection_loss: image must be at least 3x3");
+    MH_REQUIRE(mh_aligned16(ws), MH_ERR_ALIGN, "mh_reprojection_loss: workspace must be 16-byte aligned");
+    const int64_t n = (int64_t)B * H * W, nw = (int64_t)B * (H - 2) * (W - 2);
+    MH_REQUIRE(n < (1ll << 31), MH_ERR_ARG, "mh_reprojection_loss: too many pixels");
+    LossArgs a{};
+    a.left = left; a.right = right; a.disp = disp; a.result = result; a.ddisp = ddisp; a.grad_scale = grad_scale;
+    a.B = B; a.H = H; a.W = W;
+    a.rep = ws; a.drep = ws + 4 * n; a.coef = ws + 8 * n;
+    a.part1 = ws + 8 * n + 12 * nw; a.nblk1 = (int)nblk(n);
+    a.part2 = a.part1 + a.nblk1; a.nblk2 = (int)nblk(nw);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(loss_warp_kernel, dim3(a.nblk1), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(loss_ssim_kernel, dim3(a.nblk2), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, a);
+    if (ddisp) hipLaunchKernelGGL(loss_grad_kernel, dim3(grid_for(n)), dim3(256), 0, s, a);
+    return mh_check_launch("reprojection_loss");
+}
+
+extern "C" int64_t mh_metrics_ws_floats(int32_t B, int32_t H, int32_t W) { return 3 * nblk((int64_t)B * H * W) + 16; }
+
+extern "C" int mh_metrics(const float* disp, const float* gt, float* ws, float* result, float pixel_th,
+                          int32_t B, int32_t H, int32_t W, void* stream) {
+    MH_REQUIRE(disp && gt && ws && result, MH_ERR_ARG, "mh_metrics: null argument");
+    MH_REQUIRE(B > 0 && H > 0 && W > 0, MH_ERR_ARG, "mh_metrics: bad dimension");
+    MetArgs a{disp, gt, ws, result, (int64_t)B * H * W, (int)nblk((int64_t)B * H * W), pixel_th};
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(metrics_kernel, dim3(a.nblk), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(metrics_final_kernel, dim3(1), dim3(256), 0, s, a);
+    return mh_check_launch("metrics");
+}
+
+extern "C" int mh_momentum(float* var, float* accum, const float* grad, int64_t n, float lr, float momentum,
+                           float grad_scale, void* stream) {
+    MH_REQUIRE(var && accum && grad && n > 0, MH_ERR_ARG, "mh_momentum: bad argument");
+    hipLaunchKernelGGL(momentum_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, var, accum, grad, n, lr, momentum, grad_scale);
+    return mh_check_launch("momentum");
+}
+
+extern "C" int mh_copy_channels(const float* src, int32_t src_ld, float* dst, int32_t dst_ld, int64_t npix,
+                                int32_t nch, float scale, int32_t accumulate, void* stream) {
+    MH_REQUIRE(src && dst && npix > 0 && nch > 0 && src_ld >= nch && dst_ld >= nch, MH_ERR_ARG, "mh_copy_channels: bad argument");
+    hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(npix * nch)), dim3(256), 0, (hipStream_t)stream,
+                       src, src_ld, dst, dst_ld, npix, nch, scale, accumulate);
+    return mh_check_launch("copy_channels");
+}
+
+extern "C" int mh_leaky_bwd(float* dy, int32_t dy_ld, const float* y, int32_t y_ld, int64_t npix, int32_t nch,
+                            float alpha, void* stream) {
+    MH_REQUIRE(dy && y && npix > 0 && nch > 0, MH_ERR_ARG, "mh_leaky_bwd: bad argument");
+    hipLaunchKernelGGL(leaky_bwd_kernel, dim3(grid_for(npix * nch)), dim3(256), 0, (hipStream_t)stream, dy, dy_ld, y, y_ld, npix, nch, alpha);
+    return mh_check_launch("leaky_bwd");
+}
+
+extern "C" int mh_fill(float* p, int64_t n, float v, void* stream) {
+    MH_REQUIRE(p && n > 0, MH_ERR_ARG, "mh_fill: bad argument");
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, n, v);
+    return mh_check_launch("fill");
+}

@@ -1,0 +1,122 @@
+"""ctypes binding of libmadnet_hip.so (C-ABI declared in include/madnet_hip.h).
+
+The reference binds its native op with tf.load_op_library (Nets/sharedLayers.py:11-17);
+cffi is not available here, stdlib ctypes is.  PyTorch tensors are storage only: every call
+passes raw device pointers + sizes + a hipStream_t.
+
+The product path FAILS LOUDLY if the HIP library is missing or no GPU is visible -- there is no
+CPU fallback.  (tests/emul builds a *separate* CPU functional emulator of the same kernel
+sources; it is only ever loaded explicitly by tests through `Lib(path)`.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmadnet_hip.so")
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("B", "Hi", "Wi", "Ho", "Wo", "K", "N", "kh", "kw", "stride", "dil", "pad_t", "pad_l",
+                 "mode", "w_trans", "in_ld", "out_ld", "mask_ld", "accumulate")] + \
+               [("alpha", C.c_float), ("mask_alpha", C.c_float)]
+
+
+class Op(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("i", C.c_int32 * 27), ("f", C.c_float * 4),
+                ("p", C.c_void_p * 8), ("n", C.c_int64)]
+
+
+(OP_CONV, OP_WGRAD, OP_CORR_FWD, OP_CORR_BWD, OP_WARP_FWD, OP_WARP_BWD, OP_RESIZE_FWD, OP_RESIZE_BWD,
+ OP_PAD_REFLECT, OP_LOSS, OP_METRICS, OP_MOMENTUM, OP_COPY_CH, OP_LEAKY_BWD, OP_FILL) = range(1, 16)
+
+_P = C.c_void_p
+_I = C.c_int32
+_F = C.c_float
+_L = C.c_int64
+
+# name -> (restype, argtypes); every symbol include/madnet_hip.h declares
+SIGNATURES = {
+    "mh_last_error": (C.c_char_p, []),
+    "mh_abi_version": (_I, []),
+    "mh_device_count": (_I, []),
+    "mh_conv2d": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
+    "mh_conv2d_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _I, _P, _P, _P]),
+    "mh_corr_fwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mh_corr_bwd": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mh_warp_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "mh_warp_bwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "mh_resize_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
+    "mh_resize_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
+    "mh_pad_reflect": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mh_loss_ws_floats": (_L, [_I, _I, _I]),
+    "mh_reprojection_loss": (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _P]),
+    "mh_metrics_ws_floats": (_L, [_I, _I, _I]),
+    "mh_metrics": (_I, [_P, _P, _P, _P, _F, _I, _I, _I, _P]),
+    "mh_momentum": (_I, [_P, _P, _P, _L, _F, _F, _F, _P]),
+    "mh_copy_channels": (_I, [_P, _I, _P, _I, _L, _I, _F, _I, _P]),
+    "mh_leaky_bwd": (_I, [_P, _I, _P, _I, _L, _I, _F, _P]),
+    "mh_fill": (_I, [_P, _L, _F, _P]),
+    "mh_plan_run": (_I, [C.POINTER(Op), _I, _P]),
+    "mh_graph_begin": (_I, [_P]),
+    "mh_graph_end": (_I, [_P, C.POINTER(_P)]),
+    "mh_graph_launch": (_I, [_P, _P]),
+    "mh_graph_destroy": (_I, [_P]),
+    "mh_event_create": (_I, [C.POINTER(_P)]),
+    "mh_event_record": (_I, [_P, _P]),
+    "mh_event_elapsed_ms": (_I, [_P, _P, C.POINTER(_F)]),
+    "mh_event_destroy": (_I, [_P]),
+    "mh_stream_sync": (_I, [_P]),
+}
+_NO_STATUS = {"mh_last_error", "mh_abi_version", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats"}
+
+
+class MadnetHipError(RuntimeError):
+    pass
+
+
+class Lib(object):
+    """Typed view of the shared library; status-returning calls raise MadnetHipError."""
+
+    def __init__(self, path=LIB_PATH):
+        if not os.path.exists(path):
+            raise MadnetHipError(
+                "HIP extension not built: %s is missing (run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C real-time-self-adaptive-deep-stereo_amd/csrc`). There is no CPU fallback." % path)
+        self.path = path
+        self._dll = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(self._dll, name)      # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, "_raw_" + name, fn)
+            if name in _NO_STATUS:
+                setattr(self, name[3:], fn)
+            else:
+                setattr(self, name[3:], self._checked(name, fn))
+
+    def _checked(self, name, fn):
+        def call(*a):
+            rc = fn(*a)
+            if rc != 0:
+                msg = self._dll.mh_last_error()
+                raise MadnetHipError("%s failed (%d): %s" % (name, rc, msg.decode() if msg else "?"))
+            return 0
+        call.__name__ = name
+        return call
+
+
+_lib = None
+
+
+def lib():
+    """The product library.  Raises if it is not built or no HIP device is visible."""
+    global _lib
+    if _lib is None:
+        l = Lib(LIB_PATH)
+        n = l.device_count()
+        if n <= 0:
+            raise MadnetHipError("libmadnet_hip.so loaded but no HIP device is visible (mh_device_count=%d); "
+                                 "the MI355X path has no CPU fallback" % n)
+        _lib = l
+    return _lib

@@ -1,0 +1,172 @@
+"""Host-side operator layer: torch tensors (storage only) -> C-ABI calls.
+
+Mirrors the operator set of Nets/sharedLayers.py:23-92 and Data_utils/preprocessing.py /
+Losses/loss_factory.py hot functions, with explicit forward and gradient entry points (the
+reference gets its gradients from TF's autodiff; here every gradient is a hand-written kernel).
+
+All tensors are float32 NHWC.  A `View` is (pointer, B, H, W, C, ld): a channel slice of a
+possibly wider buffer, which is how tf.concat is made free.
+"""
+import ctypes as C
+import torch
+from . import _ffi
+
+
+def same_pad(in_size, k, stride=1, dilation=1):
+    """TF 'SAME': out=ceil(in/s), pad_total=max((out-1)*s+keff-in,0), before=total//2."""
+    keff = (k - 1) * dilation + 1
+    out = -(-in_size // stride)
+    total = max((out - 1) * stride + keff - in_size, 0)
+    return out, total // 2, total - total // 2
+
+
+class View(object):
+    __slots__ = ("t", "ptr", "B", "H", "W", "C", "ld")
+
+    def __init__(self, t, B, H, W, C_, ld, coff=0):
+        self.t, self.B, self.H, self.W, self.C, self.ld = t, B, H, W, C_, ld
+        self.ptr = t.data_ptr() + 4 * coff
+
+    @property
+    def npix(self):
+        return self.B * self.H * self.W
+
+    def slice(self, c0, c1):
+        v = View(self.t, self.B, self.H, self.W, c1 - c0, self.ld)
+        v.ptr = self.ptr + 4 * c0
+        return v
+
+
+def view(t):
+    """View of a plain contiguous [B,H,W,C] (or [B,H,W]) float32 tensor."""
+    assert t.dtype == torch.float32 and t.is_contiguous(), "float32 contiguous tensors only"
+    if t.dim() == 3:
+        B, H, W = t.shape
+        return View(t, B, H, W, 1, 1)
+    B, H, W, Cc = t.shape
+    return View(t, B, H, W, Cc, Cc)
+
+
+def _p(x):
+    if x is None:
+        return None
+    if isinstance(x, View):
+        return C.c_void_p(x.ptr)
+    if isinstance(x, torch.Tensor):
+        return C.c_void_p(x.data_ptr())
+    return C.c_void_p(x)
+
+
+def conv_desc(B, Hi, Wi, Ho, Wo, K, N, kh, kw, stride, dil, pad_t, pad_l, mode, w_trans,
+              in_ld, out_ld, mask_ld=0, accumulate=0, alpha=1.0, mask_alpha=1.0):
+    return _ffi.ConvDesc(B, Hi, Wi, Ho, Wo, K, N, kh, kw, stride, dil, pad_t, pad_l, mode, w_trans,
+                         in_ld, out_ld, mask_ld, accumulate, alpha, mask_alpha)
+
+
+def conv_geometry(H, W, kh, kw, stride, dil):
+    Ho, pt, _ = same_pad(H, kh, stride, dil)
+    Wo, pl, _ = same_pad(W, kw, stride, dil)
+    return Ho, Wo, pt, pl
+
+
+def conv2d_fwd(lib, x, w, b, out, stride=1, dil=1, alpha=1.0, stream=None):
+    """out = leaky(conv2d_SAME(x, w) + b).  x,out: View; w: HWIO tensor [kh,kw,Cin,Cout]."""
+    kh, kw, cin, cout = w.shape
+    Ho, Wo, pt, pl = conv_geometry(x.H, x.W, kh, kw, stride, dil)
+    assert (out.H, out.W, out.C) == (Ho, Wo, cout) and x.C == cin
+    d = conv_desc(x.B, x.H, x.W, Ho, Wo, cin, cout, kh, kw, stride, dil, pt, pl, 0, 0, x.ld, out.ld, alpha=alpha)
+    lib.conv2d(C.byref(d), _p(x), _p(w), _p(b), _p(out), None, _p(stream))
+
+
+def conv2d_dgrad(lib, dz, w, dx, stride=1, dil=1, accumulate=False, mask_ref=None, mask_alpha=1.0, stream=None):
+    """dx (+)= conv2d_backprop_input(dz, w); optionally fused dx *= leaky'(mask_ref).
+    dz: View [B,Ho,Wo,Cout]; dx: View [B,H,W,Cin]; w: HWIO of the forward conv."""
+    kh, kw, cin, cout = w.shape
+    Ho, Wo, pt, pl = conv_geometry(dx.H, dx.W, kh, kw, stride, dil)
+    assert (dz.H, dz.W, dz.C) == (Ho, Wo, cout) and dx.C == cin
+    d = conv_desc(dx.B, Ho, Wo, dx.H, dx.W, cout, cin, kh, kw, stride, dil, pt, pl, 1, 1, dz.ld, dx.ld,
+                  mask_ld=(mask_ref.ld if mask_ref is not None else 0), accumulate=int(accumulate),
+                  alpha=1.0, mask_alpha=mask_alpha)
+    lib.conv2d(C.byref(d), _p(dz), _p(w), None, _p(dx), _p(mask_ref), _p(stream))
+
+
+def conv2d_wgrad(lib, x, dz, dw, db, stride=1, dil=1, stream=None):
+    """dw += conv2d_backprop_filter(x, dz) ; db += sum(dz).  dw: HWIO tensor (pre-zeroed)."""
+    kh, kw, cin, cout = dw.shape
+    Ho, Wo, pt, pl = conv_geometry(x.H, x.W, kh, kw, stride, dil)
+    assert (dz.H, dz.W, dz.C) == (Ho, Wo, cout) and x.C == cin
+    d = conv_desc(x.B, x.H, x.W, Ho, Wo, cin, cout, kh, kw, stride, dil, pt, pl, 0, 0, x.ld, dz.ld)
+    lib.conv2d_wgrad(C.byref(d), _p(x), _p(dz), dz.ld, _p(dw), _p(db), _p(stream))
+
+
+def conv2d_transpose_fwd(lib, x, w, b, out, stride=2, alpha=1.0, stream=None):
+    """tf.nn.conv2d_transpose(x, w[kh,kw,Cout,Cin], 'SAME') + b, leaky (sharedLayers.py:80-92):
+    the input-gradient of a SAME conv with HWIO = [kh,kw,I=Cout,O=Cin]."""
+    kh, kw, cout, cin = w.shape
+    Ho, Wo = x.H * stride, x.W * stride
+    _, _, pt, pl = conv_geometry(Ho, Wo, kh, kw, stride, 1)
+    assert (out.H, out.W, out.C) == (Ho, Wo, cout) and x.C == cin
+    d = conv_desc(x.B, x.H, x.W, Ho, Wo, cin, cout, kh, kw, stride, 1, pt, pl, 1, 1, x.ld, out.ld, alpha=alpha)
+    lib.conv2d(C.byref(d), _p(x), _p(w), _p(b), _p(out), None, _p(stream))
+
+
+def corr_fwd(lib, L, R, out, max_disp, stride=1, coff=0, u=None, copy_left=False, zero_tail=False, stream=None):
+    lib.corr_fwd(_p(L), L.ld, _p(R), R.ld, _p(u), _p(out), out.ld, coff, L.B, L.H, L.W, L.C, max_disp, stride,
+                 int(copy_left), int(zero_tail), _p(stream))
+
+
+def corr_bwd(lib, g, L, R, dL, dR, max_disp, stride=1, coff=0, du=None, acc_l=False, acc_r=False, acc_u=False,
+             copy_left=False, stream=None):
+    lib.corr_bwd(_p(g), g.ld, coff, _p(L), L.ld, _p(R), R.ld, _p(dL), dL.ld, int(acc_l), _p(dR), dR.ld, int(acc_r),
+                 _p(du), int(acc_u), L.B, L.H, L.W, L.C, max_disp, stride, int(copy_left), _p(stream))
+
+
+def warp_fwd(lib, img, u, out, stream=None):
+    lib.warp_fwd(_p(img), img.ld, _p(u), _p(out), out.ld, img.B, img.H, img.W, img.C, _p(stream))
+
+
+def warp_bwd(lib, g, img, u, dimg, du=None, acc_u=False, stream=None):
+    lib.warp_bwd(_p(g), g.ld, _p(img), img.ld, _p(u), _p(dimg), dimg.ld, _p(du), int(acc_u),
+                 img.B, img.H, img.W, img.C, _p(stream))
+
+
+def resize_fwd(lib, x, out, Hr, Wr, cy=0, cx=0, mul=1.0, mode=0, stream=None):
+    """x: [B,Hi,Wi] tensor; out: [B,Ho,Wo] tensor (crop of the virtual [Hr,Wr] resize at (cy,cx))."""
+    B, Hi, Wi = x.shape[0], x.shape[1], x.shape[2]
+    Ho, Wo = out.shape[1], out.shape[2]
+    lib.resize_fwd(_p(x), _p(out), B, Hi, Wi, Hr, Wr, cy, cx, Ho, Wo, mul, mode, _p(stream))
+
+
+def resize_bwd(lib, g, x, dx, Hr, Wr, cy=0, cx=0, mul=1.0, mode=0, accumulate=False, stream=None):
+    B, Hi, Wi = x.shape[0], x.shape[1], x.shape[2]
+    Ho, Wo = g.shape[1], g.shape[2]
+    lib.resize_bwd(_p(g), _p(x), _p(dx), int(accumulate), B, Hi, Wi, Hr, Wr, cy, cx, Ho, Wo, mul, mode, _p(stream))
+
+
+def pad_reflect(lib, x, out, pad_t, pad_l, stream=None):
+    """x: [B,H,W,C] tensor; out: [B,Hp,Wp,out_ld] tensor."""
+    B, H, W, Cc = x.shape
+    lib.pad_reflect(_p(x), _p(out), B, H, W, Cc, out.shape[1], out.shape[2], pad_t, pad_l, out.shape[3], _p(stream))
+
+
+def reprojection_loss(lib, left, right, disp, ws, result, ddisp=None, grad_scale=1.0, stream=None):
+    B, H, W = disp.shape[0], disp.shape[1], disp.shape[2]
+    lib.reprojection_loss(_p(left), _p(right), _p(disp), _p(ws), _p(result), _p(ddisp), grad_scale, B, H, W, _p(stream))
+
+
+def metrics(lib, disp, gt, ws, result, pixel_th=3.0, stream=None):
+    B, H, W = disp.shape[0], disp.shape[1], disp.shape[2]
+    lib.metrics(_p(disp), _p(gt), _p(ws), _p(result), pixel_th, B, H, W, _p(stream))
+
+
+def momentum(lib, var, accum, grad, lr, mom=0.9, grad_scale=1.0, n=None, stream=None):
+    lib.momentum(_p(var), _p(accum), _p(grad), n if n is not None else var.numel(), lr, mom, grad_scale, _p(stream))
+
+
+def copy_channels(lib, src, dst, nch=None, scale=1.0, accumulate=False, stream=None):
+    lib.copy_channels(_p(src), src.ld, _p(dst), dst.ld, src.npix, nch if nch is not None else src.C, scale,
+                      int(accumulate), _p(stream))
+
+
+def leaky_bwd(lib, dy, y, alpha, stream=None):
+    lib.leaky_bwd(_p(dy), dy.ld, _p(y), y.ld, dy.npix, dy.C, alpha, _p(stream))

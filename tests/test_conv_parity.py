@@ -1,0 +1,134 @@
+"""Conv family parity: HIP kernels (or their CPU-emulated build) vs the torch oracle."""
+import numpy as np
+import pytest
+import torch
+
+from madnet_hip import ops
+from oracle import tf_ops as T
+
+
+def _rand(shape, seed, dev, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev)
+
+
+def _padded(x, ld):
+    """copy [B,H,W,C] into a wider zero buffer [B,H,W,ld] and return (buffer, View)."""
+    B, H, W, C = x.shape
+    buf = torch.zeros(B, H, W, ld, device=x.device)
+    buf[..., :C] = x
+    return buf, ops.View(buf, B, H, W, C, ld)
+
+
+# (B,H,W,Cin,Cout,k,stride,dil,in_ld_extra,alpha)
+FWD_CASES = [
+    (1, 6, 20, 8, 16, 3, 1, 1, 0, 0.2),        # tiny level-6 like
+    (1, 9, 13, 3, 16, 3, 2, 1, 1, 0.2),        # conv1-like: Cin=3 padded to 4, stride 2, odd size
+    (2, 8, 12, 16, 32, 3, 2, 1, 0, 0.2),       # batch 2, even size stride 2 (pad only bottom/right)
+    (1, 7, 11, 38, 20, 3, 1, 1, 2, 0.2),       # odd Cin (38 in ld 40), Cout not multiple of 16
+    (1, 10, 12, 12, 1, 3, 1, 1, 0, 1.0),       # Cout = 1 (disp6/context7), linear
+    (1, 12, 16, 8, 24, 3, 1, 4, 0, 0.2),       # dilation 4
+    (1, 6, 9, 8, 8, 3, 1, 16, 0, 0.2),         # dilation 16 > feature size
+    (1, 8, 8, 5, 7, 5, 2, 1, 0, 0.1),          # 5x5 stride 2, unaligned channels (scalar path)
+    (1, 6, 6, 4, 4, 7, 2, 1, 0, 0.1),          # 7x7 stride 2
+    (1, 5, 7, 16, 8, 1, 1, 1, 0, 0.1),         # 1x1
+]
+
+
+@pytest.mark.parametrize("case", FWD_CASES)
+def test_conv2d_fwd(backend, case):
+    B, H, W, Ci, Co, k, s, d, extra, alpha = case
+    dev = backend.device
+    x = _rand((B, H, W, Ci), 1, dev)
+    w = _rand((k, k, Ci, Co), 2, dev, 0.3)
+    b = _rand((Co,), 3, dev)
+    ref = T.conv2d(x.cpu(), w.cpu(), b.cpu(), stride=s, dilation=d, alpha=alpha)
+    xb, xv = _padded(x, Ci + extra)
+    if extra:
+        xb[..., Ci:] = 7.0   # garbage in the channel padding must not leak
+    out = torch.full(ref.shape, float("nan"), device=dev)
+    ops.conv2d_fwd(backend.lib, xv, w, b, ops.view(out), stride=s, dil=d, alpha=alpha)
+    backend.sync()
+    err = (out.cpu() - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("shape", [(1, 40, 50, 32, 32), (1, 24, 80, 96, 96), (1, 16, 24, 128, 128), (2, 12, 40, 70, 128)])
+def test_conv2d_fwd_big_tiles(backend, shape):
+    """Shapes that select the larger tile configurations (more than one M tile, N tile = Cout)."""
+    if backend.name == "emul" and shape[3] * shape[4] > 96 * 96:
+        pytest.skip("too slow on the CPU emulator")
+    B, H, W, Ci, Co = shape
+    dev = backend.device
+    x = _rand((B, H, W, Ci), 4, dev)
+    w = _rand((3, 3, Ci, Co), 5, dev, 0.1)
+    b = _rand((Co,), 6, dev)
+    ref = T.conv2d(x.cpu(), w.cpu(), b.cpu(), alpha=0.2)
+    ld = (Ci + 3) // 4 * 4
+    xb, xv = _padded(x, ld)
+    out = torch.zeros_like(ref, device=dev)
+    ops.conv2d_fwd(backend.lib, xv, w, b, ops.view(out), alpha=0.2)
+    backend.sync()
+    err = (out.cpu() - ref).abs().max().item()
+    assert err <= 3e-5 * max(1.0, ref.abs().max().item()), err
+
+
+DG_CASES = [
+    (1, 6, 20, 8, 16, 3, 1, 1),
+    (2, 8, 12, 16, 32, 3, 2, 1),       # stride-2 dgrad (lattice masks)
+    (1, 9, 13, 3, 16, 3, 2, 1),        # odd size stride 2, Cin=3
+    (1, 7, 11, 38, 20, 3, 1, 1),
+    (1, 10, 12, 12, 1, 3, 1, 1),       # Cout=1: K=1 contraction (scalar weight path)
+    (1, 12, 16, 8, 24, 3, 1, 4),
+    (1, 8, 8, 5, 7, 5, 2, 1),
+]
+
+
+def _oracle_grads(x, w, b, s, d, alpha, gy):
+    x = x.clone().requires_grad_(True); w = w.clone().requires_grad_(True); b = b.clone().requires_grad_(True)
+    y = T.conv2d(x, w, b, stride=s, dilation=d, alpha=alpha)
+    gx, gw, gb = torch.autograd.grad(y, [x, w, b], gy)
+    return y.detach(), gx, gw, gb
+
+
+@pytest.mark.parametrize("case", DG_CASES)
+def test_conv2d_dgrad_wgrad(backend, case):
+    B, H, W, Ci, Co, k, s, d = case
+    dev = backend.device
+    x = _rand((B, H, W, Ci), 11, dev)
+    w = _rand((k, k, Ci, Co), 12, dev, 0.3)
+    b = _rand((Co,), 13, dev)
+    Ho, Wo, _, _ = ops.conv_geometry(H, W, k, k, s, d)
+    gz = _rand((B, Ho, Wo, Co), 14, dev)           # gradient w.r.t. the pre-activation (alpha=1 here)
+    _, gx_ref, gw_ref, gb_ref = _oracle_grads(x.cpu(), w.cpu(), b.cpu(), s, d, 1.0, gz.cpu())
+    ldx = (Ci + 3) // 4 * 4
+    ldz = (Co + 3) // 4 * 4
+    xb, xv = _padded(x, ldx)
+    zb, zv = _padded(gz, ldz)
+    # dgrad with accumulate + fused leaky mask:  dx = (old + dgrad) * (ref>0 ? 1 : 0.2)
+    old = _rand((B, H, W, Ci), 15, dev)
+    mref = _rand((B, H, W, Ci), 16, dev)
+    dxb, dxv = _padded(old, ldx)
+    mb, mv = _padded(mref, ldx)
+    ops.conv2d_dgrad(backend.lib, zv, w, dxv, stride=s, dil=d, accumulate=True, mask_ref=mv, mask_alpha=0.2)
+    dw = torch.zeros_like(w); db = torch.zeros_like(b)
+    ops.conv2d_wgrad(backend.lib, xv, zv, dw, db, stride=s, dil=d)
+    backend.sync()
+    exp_dx = (old.cpu() + gx_ref) * torch.where(mref.cpu() > 0, 1.0, 0.2)
+    sc = max(1.0, gx_ref.abs().max().item())
+    assert (dxb[..., :Ci].cpu() - exp_dx).abs().max().item() <= 3e-5 * sc
+    assert (dw.cpu() - gw_ref).abs().max().item() <= 1e-4 * max(1.0, gw_ref.abs().max().item())
+    assert (db.cpu() - gb_ref).abs().max().item() <= 1e-4 * max(1.0, gb_ref.abs().max().item())
+
+
+def test_conv2d_transpose(backend):
+    dev = backend.device
+    B, H, W, Ci, Co = 1, 5, 7, 8, 12
+    x = _rand((B, H, W, Ci), 21, dev)
+    w = _rand((4, 4, Co, Ci), 22, dev, 0.3)
+    b = _rand((Co,), 23, dev)
+    ref = T.conv2d_transpose(x.cpu(), w.cpu(), b.cpu(), stride=2, alpha=0.1)
+    out = torch.zeros_like(ref, device=dev)
+    ops.conv2d_transpose_fwd(backend.lib, ops.view(x), w, b, ops.view(out), stride=2, alpha=0.1)
+    backend.sync()
+    assert (out.cpu() - ref).abs().max().item() <= 3e-5 * max(1.0, ref.abs().max().item())
