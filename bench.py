@@ -1,0 +1,148 @@
+"""bench.py -- adapted stereo pairs/sec, MADNet full-backprop online adaptation, 1242x375.
+
+python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run, one rank
+per GPU).  A "step" = one pass of the hot path over one synthetic KITTI-shaped pair per GPU:
+forward + reprojection loss + EPE/bad3 + full backward + momentum update (the loop body of
+Stereo_Online_Adaptation.py:178-253), replayed as a captured hipGraph.  Streams are independent
+(private models): no data-path collective, weak scaling.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "real-time-self-adaptive-deep-stereo_amd")
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+
+def cpu_baseline(H, W, wn, l, r, gt, mode, steps=8):
+    """CPU stand-in for the reference TF1 CPU path (TensorFlow cannot run here): the torch-CPU
+    oracle executing the identical step on the same inputs and weights, on the host cores of this
+    box.  Bounded sample: 2 warm-up + `steps` timed steps (~10-30 s)."""
+    import torch
+    from oracle import madnet as OM
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    wt = {k: torch.from_numpy(v.copy()) for k, v in wn.items()}
+    acc = {k: torch.zeros_like(v) for k, v in wt.items()}
+    tl, tr, tg = (torch.from_numpy(a) for a in (l, r, gt))
+    for _ in range(2):
+        OM.step(wt, acc, tl, tr, tg, mode=mode, lr=1e-4)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        OM.step(wt, acc, tl, tr, tg, mode=mode, lr=1e-4)
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": "%d %s steps of the torch-CPU oracle (oracle/madnet.py) on the same %dx%d pair, "
+                      "torch.set_num_threads(%d)" % (steps, mode, W, H, cores)}
+
+
+def epe_vs_oracle(lib, H, W, wn, l, r, gt):
+    """mean |d_hip - d_oracle| of disparities[-1] on identical inputs and weights (single forward)."""
+    import torch
+    from madnet_hip import engine as E
+    from oracle import madnet as OM
+    eng = E.MadNetEngine(lib, H, W, B=1, device="cuda", weights=wn)
+    eng.set_inputs(l, r, gt[..., 0])
+    eng.build_plan("NONE").run(lib, 0)
+    torch.cuda.synchronize()
+    wt = {k: torch.from_numpy(v.copy()) for k, v in wn.items()}
+    with torch.no_grad():
+        d = OM.forward(wt, torch.from_numpy(l), torch.from_numpy(r))[-1][..., 0]
+    return float((eng.pred.cpu() - d).abs().mean().item())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", default="FULL", choices=["FULL", "NONE"])
+    ap.add_argument("--height", type=int, default=375)
+    ap.add_argument("--width", type=int, default=1242)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+
+    from madnet_hip import _ffi, engine as E, synthetic as S, benchtools as BT
+    lib = _ffi.lib()
+    H, W = args.height, args.width
+    shapes = dict((n, s) for n, s in E.madnet_manifest())
+    wn = S.calibrated_weights(shapes, 1)
+    l, r, gt = S.make_pair(H, W, stream_id=rank)
+    eng = E.MadNetEngine(lib, H, W, B=1, device=dev, weights=wn)
+    eng.set_inputs(l, r, gt[..., 0])
+    plan = eng.build_plan(args.mode, lr=1e-4)
+    stream = torch.cuda.Stream()
+    sh = stream.cuda_stream
+    with torch.cuda.stream(stream):
+        plan.run(lib, sh)                       # eager once (validates every launch)
+        stream.synchronize()
+        if not args.no_graph:
+            plan.capture(lib, sh)
+        for _ in range(args.warmup):
+            plan.launch(lib, sh)
+        stream.synchronize()
+
+        def barrier():
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            plan.launch(lib, sh)
+        stream.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(eng.res_loss[0].item())
+    epe_gt = float(eng.res_met[0].item())
+
+    out = {
+        "metric": "adapted stereo pairs/sec (whole node), MADNet full-backprop online adaptation 1242x375",
+        "value": world * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "MADNet %s adaptation step (fwd+SSIM/L1 loss+EPE+bwd+momentum), %dx%d, 1 pair/GPU/step, "
+                               "private model per stream" % (args.mode, W, H),
+                   "launch": "eager plan" if args.no_graph else "hipGraph replay",
+                   "ops_per_step": plan.n, "final_loss": loss, "epe_vs_synthetic_gt": epe_gt},
+    }
+    if rank == 0 and world == 1:
+        if not args.no_roofline:
+            out["roofline"], extra = BT.roofline(lib, eng, stream)
+            out.update(extra)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(H, W, wn, l, r, gt, args.mode)
+            out["epe_vs_oracle"] = epe_vs_oracle(lib, H, W, wn, l, r, gt)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

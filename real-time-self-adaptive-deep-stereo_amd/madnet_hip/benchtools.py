@@ -1,0 +1,70 @@
+"""Roofline micro-measurements used by bench.py (HIP events on the launch stream).
+
+Peaks (MI355X_MICROARCH.md): fp32 MFMA 157.3 TFLOP/s dense; HBM3E 8.0 TB/s spec."""
+import ctypes as C
+import torch
+
+from . import ops
+
+PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def _time_ms(lib, stream, fn, reps):
+    s = C.c_void_p(stream.cuda_stream)
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    lib.event_create(C.byref(e0)); lib.event_create(C.byref(e1))
+    for _ in range(3):
+        fn()
+    lib.stream_sync(s)
+    lib.event_record(e0, s)
+    for _ in range(reps):
+        fn()
+    lib.event_record(e1, s)
+    ms = C.c_float()
+    lib.event_elapsed_ms(e0, e1, C.byref(ms))
+    lib.event_destroy(e0); lib.event_destroy(e1)
+    return ms.value / reps
+
+
+def roofline(lib, eng, stream, reps=20):
+    """Dominant kernel of the step = the 128->128 3x3 implicit-GEMM conv at 1/4 resolution
+    (context-2/3, G2 disp-2: 27 of the 70 forward GFLOP; its dgrad is the same kernel).
+    achieved = algorithmic flops (2*Ho*Wo*9*Cin*Cout) / mean launch time over `reps` launches on
+    the bench stream, using the engine's own buffers and weights (context-2: dilation 2)."""
+    from . import engine as E
+    sh = stream.cuda_stream
+    x = ops.view(eng.Cx[0]); o = ops.view(eng.Cx[1])
+    w = eng.W_(E.ctx_name(2)); b = eng.b_(E.ctx_name(2))
+
+    def conv():
+        ops.conv2d_fwd(lib, x, w, b, o, dil=2, alpha=E.ALPHA, stream=sh)
+
+    ms = _time_ms(lib, stream, conv, reps)
+    flops = 2.0 * x.B * x.H * x.W * 9 * 128 * 128
+    ach = flops / (ms * 1e-3) / 1e12
+    rl = {"kernel": "conv_igemm_kernel<2,2,4,4> (3x3 128->128 @ %dx%d, dil 2)" % (x.H, x.W),
+          "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+          "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+          "launch_ms": ms, "algorithmic_flops_per_launch": flops}
+    # correlation protocol: level-2 shape with B=64 streams (working set > 256 MiB
+    # Infinity Cache) for the HBM claim, plus the in-situ B=1 time (cache resident).
+    extra = {}
+    try:
+        dev = eng.dev
+        Bc, H, W, Cc, md = 64, x.H, x.W, 32, eng.md
+        L = torch.randn(Bc, H, W, Cc, device=dev); R = torch.randn(Bc, H, W, Cc, device=dev)
+        D = 2 * md + 1
+        out = torch.empty(Bc, H, W, D, device=dev)
+        ms_c = _time_ms(lib, stream, lambda: ops.corr_fwd(lib, ops.view(L), ops.view(R), ops.view(out), md, stream=sh), 10)
+        byts = float(Bc) * H * W * (2 * Cc + D) * 4
+        g = byts / (ms_c * 1e-3) / 1e9
+        extra["roofline_corr"] = {"kernel": "corr_fwd_small<8,64> (B=64 x %dx%dx%d, D=%d)" % (H, W, Cc, D), "bound": "hbm",
+                                  "achieved": g, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": g / PEAK_HBM_GBS,
+                                  "traffic": None, "launch_ms": ms_c, "algorithmic_bytes_per_launch": byts}
+        L1, R1 = L[:1].contiguous(), R[:1].contiguous(); o1 = out[:1].contiguous()
+        ms_1 = _time_ms(lib, stream, lambda: ops.corr_fwd(lib, ops.view(L1), ops.view(R1), ops.view(o1), md, stream=sh), 20)
+        extra["roofline_corr"]["in_situ_B1_ms"] = ms_1
+    except Exception as ex:       # never let the auxiliary measurement kill the bench line
+        extra["roofline_corr"] = {"error": str(ex)}
+    return rl, extra

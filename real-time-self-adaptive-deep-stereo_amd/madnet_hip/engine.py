@@ -1,0 +1,485 @@
+"""MADNet executor for MI355X: static buffers + recorded forward / backward / update plans.
+
+Host-side mirror of Nets/MadNet.py:251-364 (graph), Losses/loss_factory.py:353-395 (loss),
+Stereo_Online_Adaptation.py:68-128 (loss / validation / train-op construction).  The reference
+builds a TF1 graph and lets Session.run prune it to the fetches; here every (mode, block)
+combination is compiled once into an op array (plan.py) and replayed natively / as a hipGraph.
+
+Memory layout (all float32, NHWC, resident in HBM for the life of the engine):
+  * one flat parameter buffer + one momentum buffer + one gradient buffer with identical
+    layout; MAD blocks are contiguous ranges so the update is one fused launch per range;
+  * both pyramid towers run as batch 2B (shared weights => their weight gradients sum for free);
+  * the estimator input [reference | corr | upsampled disparity] is ONE buffer written by the
+    correlation kernel (no tf.concat copies); channel counts are padded to multiples of 4 so all
+    row accesses are 16-byte vectors.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .plan import Recorder
+
+PYR = [(3, 16, 2), (16, 16, 1), (16, 32, 2), (32, 32, 1), (32, 64, 2), (64, 64, 1),
+       (64, 96, 2), (96, 96, 1), (96, 128, 2), (128, 128, 1), (128, 192, 2), (192, 192, 1)]
+EST = [128, 128, 96, 64, 32, 1]
+CTX = [(128, 1), (128, 2), (128, 4), (96, 8), (64, 16), (32, 1), (1, 1)]
+LEVELS = (6, 5, 4, 3, 2)
+FEAT = {6: 12, 5: 10, 4: 8, 3: 6, 2: 4}
+ALPHA = 0.2   # MadNet._leaky_relu (Nets/MadNet.py:366-367)
+
+
+def _r4(c):
+    return (c + 3) // 4 * 4
+
+
+def pyr_name(i):
+    return "model/gc-read-pyramid/conv%d" % i
+
+
+def est_name(k, j):
+    return "model/G%d/fgc-volume-filtering-%d/disp-%d" % (k, k, j)
+
+
+def ctx_name(j):
+    return "model/context-%d" % j
+
+
+def madnet_manifest(radius_d=2, stride=1):
+    """Ordered [(variable name, shape)] -- flat-buffer order.  Names are the TF variable names of
+    the reference graph; order groups the variables of each MAD block
+    (block_config/MadNet_full.json) contiguously."""
+    D = 2 * radius_d // stride + 1
+    out = []
+
+    def conv(base, k, ci, co):
+        out.append((base + "/weights", (k, k, ci, co)))
+        out.append((base + "/biases", (co,)))
+
+    pyr_of_level = {2: (1, 2, 3, 4), 3: (5, 6), 4: (7, 8), 5: (9, 10), 6: (11, 12)}
+    for k in (2, 3, 4, 5, 6):
+        for i in pyr_of_level[k]:
+            conv(pyr_name(i), 3, PYR[i - 1][0], PYR[i - 1][1])
+        cin = PYR[FEAT[k] - 1][1] + D + (0 if k == 6 else 1)
+        for j, co in enumerate(EST):
+            conv(est_name(k, j + 1), 3, cin, co)
+            cin = co
+        if k == 2:
+            cin = PYR[3][1] + 1
+            for j, (co, _) in enumerate(CTX):
+                conv(ctx_name(j + 1), 3, cin, co)
+                cin = co
+    return out
+
+
+class Params(object):
+    """Flat fp32 weight / momentum / gradient buffers + name -> (offset, shape) manifest."""
+
+    def __init__(self, manifest, device):
+        self.manifest = manifest
+        self.offset, self.shape = {}, {}
+        off = 0
+        for name, shp in manifest:
+            self.offset[name], self.shape[name] = off, tuple(shp)
+            off += (int(np.prod(shp)) + 3) // 4 * 4          # keep every tensor 16-byte aligned
+        self.total = off
+        self.w = torch.zeros(off, device=device)
+        self.m = torch.zeros(off, device=device)
+        self.g = torch.zeros(off, device=device)
+        self.w0 = None                                         # reset copy (restore target)
+
+    def numel(self, name):
+        return int(np.prod(self.shape[name]))
+
+    def tensor(self, name, which="w"):
+        buf = getattr(self, which)
+        o = self.offset[name]
+        return buf[o:o + self.numel(name)].view(self.shape[name])
+
+    def load(self, weights):
+        """weights: {name: ndarray / tensor} (HWIO); missing names keep their value."""
+        for name, v in weights.items():
+            if name in self.offset:
+                self.tensor(name).copy_(torch.as_tensor(v, dtype=torch.float32).reshape(self.shape[name]))
+
+    def export(self):
+        return {name: self.tensor(name).detach().cpu().numpy().copy() for name, _ in self.manifest}
+
+    def ranges(self, names):
+        """Coalesced (offset, count) ranges covering the given variables."""
+        spans = sorted((self.offset[n], (self.numel(n) + 3) // 4 * 4) for n in set(names))
+        out = []
+        for o, c in spans:
+            if out and out[-1][0] + out[-1][1] == o:
+                out[-1][1] += c
+            else:
+                out.append([o, c])
+        return [(o, c) for o, c in out]
+
+
+class MadNetEngine(object):
+    def __init__(self, lib, H, W, B=1, device="cuda", radius_d=2, stride=1, warping=True, weights=None):
+        if not warping:
+            raise NotImplementedError("warping=False is not supported by the MI355X engine yet")
+        self.lib, self.dev = lib, device
+        self.B, self.H0, self.W0 = B, H, W
+        self.md, self.cstride = radius_d, stride
+        self.D = 2 * radius_d // stride + 1
+        self.Hp = H if H % 64 == 0 else (H // 64 + 1) * 64          # preprocessing.pad_image(., 64)
+        self.Wp = W if W % 64 == 0 else (W // 64 + 1) * 64
+        self.pt, self.pl = (self.Hp - H) // 2, (self.Wp - W) // 2
+        self.params = Params(madnet_manifest(radius_d, stride), device)
+        if weights is not None:
+            self.params.load(weights)
+        self._alloc()
+        self._plans = {}
+        self._zeros_needed = []
+
+    # ---------------------------------------------------------------------------------------
+    def _buf(self, *shape):
+        return torch.zeros(*shape, device=self.dev)
+
+    def _alloc(self):
+        B, B2 = self.B, 2 * self.B
+        z = self._buf
+        self.left = z(B, self.H0, self.W0, 3); self.right = z(B, self.H0, self.W0, 3)
+        self.gt = z(B, self.H0, self.W0)
+        self.X0 = z(B2, self.Hp, self.Wp, 4)
+        self.F, self.dF = {}, {}
+        h, w = self.Hp, self.Wp
+        self.fshape = {}
+        for i, (ci, co, s) in enumerate(PYR, 1):
+            h, _, _ = ops.same_pad(h, 3, s); w, _, _ = ops.same_pad(w, 3, s)
+            self.fshape[i] = (h, w, co)
+            self.F[i] = z(B2, h, w, co); self.dF[i] = z(B2, h, w, co)
+        self.Rw, self.dRw, self.dsi, self.ddsi, self.E, self.dE, self.V, self.dV, self.u, self.du = ({} for _ in range(10))
+        self.dsi_ld = {}
+        for k in LEVELS:
+            h, w, c = self.fshape[FEAT[k]]
+            ld = _r4(c + self.D + (0 if k == 6 else 1))
+            self.dsi_ld[k] = ld
+            self.dsi[k] = z(B, h, w, ld); self.ddsi[k] = z(B, h, w, ld)
+            if k != 6:
+                self.Rw[k] = z(B, h, w, c); self.dRw[k] = z(B, h, w, c)
+                self.u[k] = z(B, h, w); self.du[k] = z(B, h, w)
+            self.E[k] = [z(B, h, w, co) for co in EST[:-1]]
+            self.dE[k] = [z(B, h, w, co) for co in EST[:-1]]
+            self.V[k] = z(B, h, w); self.dV[k] = z(B, h, w)
+        h, w, c = self.fshape[4]
+        self.ctx_ld = _r4(c + 1)
+        self.ctx_in = z(B, h, w, self.ctx_ld); self.dctx_in = z(B, h, w, self.ctx_ld)
+        self.Cx = [z(B, h, w, co) for co, _ in CTX[:-1]]
+        self.dCx = [z(B, h, w, co) for co, _ in CTX[:-1]]
+        self.final = z(B, h, w); self.dfinal = z(B, h, w)
+        self.pred = z(B, self.H0, self.W0); self.dpred = z(B, self.H0, self.W0)
+        self.disp_k = {k: z(B, self.H0, self.W0) for k in LEVELS}      # _make_disp outputs (k=2: context)
+        self.ddisp_k = z(B, self.H0, self.W0)
+        self.loss_ws = z(self.lib.loss_ws_floats(B, self.H0, self.W0))
+        self.loss_ws_k = z(self.lib.loss_ws_floats(B, self.H0, self.W0))
+        self.met_ws = z(self.lib.metrics_ws_floats(B, self.H0, self.W0))
+        self.res_loss = z(4); self.res_loss_k = z(4); self.res_met = z(4)
+
+    # views -----------------------------------------------------------------------------------
+    def _fv(self, t):
+        return ops.view(t)
+
+    def _half(self, t, right):
+        """left (first B) or right (last B) tower half of a batch-2B pyramid tensor."""
+        B = self.B
+        sub = t[B:] if right else t[:B]
+        return ops.view(sub)
+
+    def W_(self, base):
+        return self.params.tensor(base + "/weights")
+
+    def b_(self, base):
+        return self.params.tensor(base + "/biases")
+
+    # =========================================================================================
+    # forward  (MadNet._preprocess_inputs + _build_network, Nets/MadNet.py:56-66,251-364)
+    # =========================================================================================
+    def record_forward(self, r, make_disps=()):
+        B, lib = self.B, r
+        ops.pad_reflect(lib, self.left, self.X0[:B], self.pt, self.pl)
+        ops.pad_reflect(lib, self.right, self.X0[B:], self.pt, self.pl)
+        x = ops.View(self.X0, 2 * B, self.Hp, self.Wp, 3, 4)
+        for i, (ci, co, s) in enumerate(PYR, 1):
+            o = self._fv(self.F[i])
+            ops.conv2d_fwd(lib, x, self.W_(pyr_name(i)), self.b_(pyr_name(i)), o, stride=s, alpha=ALPHA)
+            x = o
+        for k in LEVELS:
+            f = FEAT[k]
+            h, w, c = self.fshape[f]
+            Lk = self._half(self.F[f], False)
+            Rk = self._half(self.F[f], True)
+            if k != 6:
+                ops.warp_fwd(lib, Rk, self.u[k], self._fv(self.Rw[k]))
+                Rk = self._fv(self.Rw[k])
+            ld = self.dsi_ld[k]
+            dsi = ops.View(self.dsi[k], B, h, w, ld, ld)
+            ops.corr_fwd(lib, Lk, Rk, dsi, self.md, self.cstride, coff=c, u=(None if k == 6 else self.u[k]),
+                         copy_left=True, zero_tail=True)
+            x = ops.View(self.dsi[k], B, h, w, c + self.D + (0 if k == 6 else 1), ld)
+            for j, co in enumerate(EST):
+                last = j == len(EST) - 1
+                o = self._fv(self.V[k]) if last else self._fv(self.E[k][j])
+                ops.conv2d_fwd(lib, x, self.W_(est_name(k, j + 1)), self.b_(est_name(k, j + 1)), o,
+                               alpha=(1.0 if last else ALPHA))
+                x = o
+            if k != 2:
+                sc = 2 ** (k - 1)
+                ops.resize_fwd(lib, self.V[k], self.u[k - 1], self.Hp // sc, self.Wp // sc, mul=20.0 / sc, mode=0)
+                if k in make_disps:
+                    self._make_disp(lib, self.V[k], self.disp_k[k])
+        # context network (MadNet._stereo_context_net, MadNet.py:122-171)
+        h, w, c = self.fshape[4]
+        cin = ops.View(self.ctx_in, B, h, w, c + 1, self.ctx_ld)
+        ops.copy_channels(lib, self._half(self.F[4], False), cin.slice(0, c))
+        ops.copy_channels(lib, self._fv(self.V[2]), cin.slice(c, c + 1))
+        x = cin
+        for j, (co, rate) in enumerate(CTX[:-1]):
+            o = self._fv(self.Cx[j])
+            ops.conv2d_fwd(lib, x, self.W_(ctx_name(j + 1)), self.b_(ctx_name(j + 1)), o, dil=rate, alpha=ALPHA)
+            x = o
+        # final_disp = V2_init + context7  (accumulating epilogue)
+        ops.copy_channels(lib, self._fv(self.V[2]), self._fv(self.final))
+        self._conv_acc(lib, x, ctx_name(7), self._fv(self.final), CTX[-1][1])
+        if 2 in make_disps:
+            self._make_disp(lib, self.final, self.disp_k[2])
+        # rescaled_prediction: relu AFTER resize (MadNet.py:362-364)
+        ops.resize_fwd(lib, self.final, self.pred, self.Hp, self.Wp, self.pt, self.pl, mul=-20.0, mode=2)
+
+    def _conv_acc(self, lib, x, base, out, rate):
+        import ctypes as C
+        w = self.W_(base)
+        kh, kw, cin, cout = w.shape
+        Ho, Wo, pt, pl = ops.conv_geometry(x.H, x.W, kh, kw, 1, rate)
+        d = ops.conv_desc(x.B, x.H, x.W, Ho, Wo, cin, cout, kh, kw, 1, rate, pt, pl, 0, 0, x.ld, out.ld,
+                          accumulate=1, alpha=1.0)
+        lib.conv2d(C.byref(d), ops._p(x), ops._p(w), ops._p(self.b_(base)), ops._p(out), None, None)
+
+    def _make_disp(self, lib, V, out):
+        """MadNet._make_disp (MadNet.py:68-71): crop(resize(relu(-20 V)))."""
+        ops.resize_fwd(lib, V, out, self.Hp, self.Wp, self.pt, self.pl, mul=-20.0, mode=1)
+
+    def record_loss_metrics(self, r, with_grad):
+        """full-resolution reprojection loss (Stereo_Online_Adaptation.py:70) + EPE/bad3 (:74-82)."""
+        ops.reprojection_loss(r, self.left, self.right, self.pred, self.loss_ws, self.res_loss,
+                              self.dpred if with_grad else None)
+        ops.metrics(r, self.pred, self.gt, self.met_ws, self.res_met, 3.0)
+
+    # =========================================================================================
+    # backward
+    # =========================================================================================
+    def _train_flags(self, train_vars, bulkhead):
+        tv = set(train_vars)
+        pyr_tr = {i: (pyr_name(i) + "/weights") in tv for i in range(1, 13)}
+        pyr_need = {}                       # gradient w.r.t. F_i needed?
+        acc = False
+        for i in range(1, 13):
+            acc = acc or pyr_tr[i]
+            pyr_need[i] = acc
+        est_tr = {k: [(est_name(k, j) + "/weights") in tv for j in range(1, 7)] for k in LEVELS}
+        ctx_tr = [(ctx_name(j) + "/weights") in tv for j in range(1, 8)]
+        # anything trainable upstream of V_k (deeper levels chain only through u when not bulkhead)
+        up_V = {}
+        prev = False
+        for k in LEVELS:
+            need_u = (not bulkhead) and prev and k != 6
+            up_V[k] = any(est_tr[k]) or pyr_need[FEAT[k]] or need_u
+            prev = up_V[k]
+        return pyr_tr, pyr_need, est_tr, ctx_tr, up_V
+
+    def record_backward(self, r, head, train_vars, bulkhead):
+        """head: 'final' (loss on rescaled_prediction, FULL mode) or a level k in LEVELS
+        (loss on the _make_disp of that level / of the context output for k=2, MAD mode).
+        Assumes the matching d(loss)/d(disparity map) is already in self.dpred / self.ddisp_k.
+        Emits: zero of the touched gradient ranges, all needed dgrad/wgrad kernels."""
+        lib, B = r, self.B
+        P = self.params
+        pyr_tr, pyr_need, est_tr, ctx_tr, up_V = self._train_flags(train_vars, bulkhead)
+        for o, c in P.ranges(train_vars):
+            ops_fill(lib, P.g, o, c)
+        written = set()                     # gradient buffers that already hold a contribution
+
+        def acc_flag(key):
+            a = key in written
+            written.add(key)
+            return a
+
+        def conv_bwd(xv, base, dzv, dxv, dx_key, x_act, stride=1, dil=1, need_dx=True, trainable=True):
+            if trainable:
+                ops.conv2d_wgrad(lib, xv, dzv, P.tensor(base + "/weights", "g"), P.tensor(base + "/biases", "g"),
+                                 stride=stride, dil=dil)
+            if need_dx:
+                ops.conv2d_dgrad(lib, dzv, self.W_(base), dxv, stride=stride, dil=dil, accumulate=acc_flag(dx_key),
+                                 mask_ref=x_act, mask_alpha=ALPHA)
+
+        start_level = 2 if head == "final" else head
+        h2, w2, c2 = self.fshape[4]
+        # ---- head -------------------------------------------------------------------------------
+        if head == "final":
+            ops.resize_bwd(lib, self.dpred, self.final, self.dfinal, self.Hp, self.Wp, self.pt, self.pl,
+                           mul=-20.0, mode=2, accumulate=False)
+        elif head == 2:
+            ops.resize_bwd(lib, self.ddisp_k, self.final, self.dfinal, self.Hp, self.Wp, self.pt, self.pl,
+                           mul=-20.0, mode=1, accumulate=False)
+        else:
+            ops.resize_bwd(lib, self.ddisp_k, self.V[head], self.dV[head], self.Hp, self.Wp, self.pt, self.pl,
+                           mul=-20.0, mode=1, accumulate=False)
+            written.add(("V", head))
+        # ---- context network ----------------------------------------------------------------------
+        if start_level == 2:
+            any_below = up_V[2]
+            if any(ctx_tr) or any_below:
+                # final = V2 + c7 : dc7 = dfinal ; dV2 (+)= dfinal
+                dz = self._fv(self.dfinal)
+                for j in range(7, 0, -1):
+                    xin = ops.View(self.ctx_in, B, h2, w2, c2 + 1, self.ctx_ld) if j == 1 else self._fv(self.Cx[j - 2])
+                    dx = ops.View(self.dctx_in, B, h2, w2, c2 + 1, self.ctx_ld) if j == 1 else self._fv(self.dCx[j - 2])
+                    need_dx = any(ctx_tr[:j - 1]) or any_below
+                    conv_bwd(xin, ctx_name(j), dz, dx, ("ctx", j - 1), (None if j == 1 else self._fv(self.Cx[j - 2])),
+                             dil=CTX[j - 1][1], need_dx=need_dx, trainable=ctx_tr[j - 1])
+                    dz = dx
+                    if not need_dx:
+                        break
+            if up_V[2]:
+                ops.copy_channels(lib, self._fv(self.dfinal), self._fv(self.dV[2]), accumulate=acc_flag(("V", 2)))
+                dci = ops.View(self.dctx_in, B, h2, w2, c2 + 1, self.ctx_ld)
+                ops.copy_channels(lib, dci.slice(c2, c2 + 1), self._fv(self.dV[2]), accumulate=acc_flag(("V", 2)))
+                if pyr_need[4]:
+                    ops.copy_channels(lib, dci.slice(0, c2), self._half(self.dF[4], False), accumulate=acc_flag(("F", 4, 0)))
+        # ---- levels start_level .. 6 ---------------------------------------------------------------
+        for k in LEVELS[::-1]:
+            if k < start_level:
+                continue
+            if not up_V[k] or ("V", k) not in written:
+                break
+            f = FEAT[k]
+            h, w, c = self.fshape[f]
+            ld = self.dsi_ld[k]
+            cin = c + self.D + (0 if k == 6 else 1)
+            need_u = (not bulkhead) and k != 6 and up_V[k + 1]
+            need_dsi = pyr_need[f] or need_u
+            dz = self._fv(self.dV[k])
+            for j in range(6, 0, -1):
+                xin = ops.View(self.dsi[k], B, h, w, cin, ld) if j == 1 else self._fv(self.E[k][j - 2])
+                dx = ops.View(self.ddsi[k], B, h, w, cin, ld) if j == 1 else self._fv(self.dE[k][j - 2])
+                need_dx = any(est_tr[k][:j - 1]) or need_dsi
+                conv_bwd(xin, est_name(k, j), dz, dx, ("est", k, j - 1), (None if j == 1 else self._fv(self.E[k][j - 2])),
+                         need_dx=need_dx, trainable=est_tr[k][j - 1])
+                dz = dx
+                if not need_dx:
+                    break
+            if not need_dsi:
+                break
+            # correlation (+ fused concat) gradient
+            Lk = self._half(self.F[f], False)
+            g = ops.View(self.ddsi[k], B, h, w, ld, ld)
+            dL = self._half(self.dF[f], False)
+            if k == 6:
+                Rk = self._half(self.F[f], True)
+                ops.corr_bwd(lib, g, Lk, Rk, dL, self._half(self.dF[f], True), self.md, self.cstride, coff=c, du=None,
+                             acc_l=acc_flag(("F", f, 0)), acc_r=acc_flag(("F", f, 1)), copy_left=True)
+            else:
+                Rk = self._fv(self.Rw[k])
+                du = self.du[k] if need_u else None
+                ops.corr_bwd(lib, g, Lk, Rk, dL, self._fv(self.dRw[k]), self.md, self.cstride, coff=c, du=du,
+                             acc_l=acc_flag(("F", f, 0)), acc_r=False, acc_u=False, copy_left=True)
+                # warp gradient: scatter into the right tower's feature gradient (atomics -> zero first)
+                dFr = self._half(self.dF[f], True)
+                if not acc_flag(("F", f, 1)):
+                    ops_fill(lib, self.dF[f][B:], 0, self.dF[f][B:].numel())
+                ops.warp_bwd(lib, self._fv(self.dRw[k]), self._half(self.F[f], True), self.u[k], dFr,
+                             du=du, acc_u=True)
+                if need_u:
+                    # u_k = resize(V_{k+1}) * 20/2^k   (MadNet.py:274: u_{k} built at level k+1 with scales[k])
+                    s_up = 2 ** k
+                    ops.resize_bwd(lib, self.du[k], self.V[k + 1], self.dV[k + 1], self.Hp // s_up, self.Wp // s_up,
+                                   mul=20.0 / s_up, mode=0, accumulate=acc_flag(("V", k + 1)))
+        # ---- pyramid towers (batch 2B, shared weights) ---------------------------------------------
+        top = None
+        for i in range(12, 0, -1):
+            if ("F", i, 0) in written or ("F", i, 1) in written or ("Fd", i) in written:
+                top = i
+                break
+        if top is not None and pyr_need[top]:
+            # features that feed only the cost volume still need their own leaky gradient
+            if ("Fd", top) not in written:
+                if ("F", top, 0) not in written:
+                    ops_fill(lib, self.dF[top][:B], 0, self.dF[top][:B].numel())
+                if ("F", top, 1) not in written:
+                    ops_fill(lib, self.dF[top][B:], 0, self.dF[top][B:].numel())
+                ops.leaky_bwd(lib, self._fv(self.dF[top]), self._fv(self.F[top]), ALPHA)
+            for i in range(top, 0, -1):
+                if not pyr_need[i]:
+                    break
+                xin = ops.View(self.X0, 2 * B, self.Hp, self.Wp, 3, 4) if i == 1 else self._fv(self.F[i - 1])
+                need_dx = i > 1 and pyr_need[i - 1]
+                accumulate = False
+                if need_dx:
+                    has_l, has_r = ("F", i - 1, 0) in written, ("F", i - 1, 1) in written
+                    accumulate = has_l or has_r
+                    if accumulate and not has_l:
+                        ops_fill(lib, self.dF[i - 1][:B], 0, self.dF[i - 1][:B].numel())
+                    if accumulate and not has_r:
+                        ops_fill(lib, self.dF[i - 1][B:], 0, self.dF[i - 1][B:].numel())
+                if pyr_tr[i]:
+                    ops.conv2d_wgrad(lib, xin, self._fv(self.dF[i]), P.tensor(pyr_name(i) + "/weights", "g"),
+                                     P.tensor(pyr_name(i) + "/biases", "g"), stride=PYR[i - 1][2])
+                if need_dx:
+                    ops.conv2d_dgrad(lib, self._fv(self.dF[i]), self.W_(pyr_name(i)), self._fv(self.dF[i - 1]),
+                                     stride=PYR[i - 1][2], accumulate=accumulate, mask_ref=self._fv(self.F[i - 1]),
+                                     mask_alpha=ALPHA)
+
+    def record_update(self, r, train_vars, lr, momentum=0.9, grad_scale=1.0):
+        """MomentumOptimizer apply on the (coalesced) ranges of train_vars."""
+        P = self.params
+        for o, c in P.ranges(train_vars):
+            ops.momentum(r, P.w[o:o + c], P.m[o:o + c], P.g[o:o + c], lr, momentum, grad_scale, n=c)
+
+    # =========================================================================================
+    # compiled step plans
+    # =========================================================================================
+    def all_vars(self):
+        return [n for n, _ in self.params.manifest]
+
+    def build_plan(self, mode, lr=1e-4, block_vars=None, block_level=None, grad_scale=1.0, update=True):
+        """mode: 'NONE' | 'FULL' | 'MAD'.  For MAD: block_level in LEVELS (2 = context output),
+        block_vars = variable names of the block.  Returns a compiled Plan."""
+        r = Recorder()
+        if mode == "NONE":
+            self.record_forward(r)
+            self.record_loss_metrics(r, with_grad=False)
+        elif mode == "FULL":
+            tv = self.all_vars()
+            self.record_forward(r)
+            self.record_loss_metrics(r, with_grad=True)
+            self.record_backward(r, "final", tv, bulkhead=False)
+            if update:
+                self.record_update(r, tv, lr, grad_scale=grad_scale)
+        elif mode == "MAD":
+            self.record_forward(r, make_disps=(block_level,))
+            self.record_loss_metrics(r, with_grad=False)
+            # reprojection loss of the block's prediction (Stereo_Online_Adaptation.py:98-107)
+            ops.reprojection_loss(r, self.left, self.right, self.disp_k[block_level], self.loss_ws_k, self.res_loss_k,
+                                  self.ddisp_k)
+            self.record_backward(r, block_level, block_vars, bulkhead=True)
+            if update:
+                self.record_update(r, block_vars, lr, grad_scale=grad_scale)
+        else:
+            raise ValueError("unknown mode %r" % (mode,))
+        return r.compile()
+
+    # convenience: eager single forward -------------------------------------------------------
+    def set_inputs(self, left, right, gt=None):
+        self.left.copy_(torch.as_tensor(left, dtype=torch.float32).reshape(self.left.shape))
+        self.right.copy_(torch.as_tensor(right, dtype=torch.float32).reshape(self.right.shape))
+        if gt is not None:
+            self.gt.copy_(torch.as_tensor(gt, dtype=torch.float32).reshape(self.gt.shape))
+
+
+def ops_fill(lib, t, off, count):
+    """record/launch a zero fill of t.flatten()[off:off+count]."""
+    import ctypes as C
+    flat = t.reshape(-1)
+    lib.fill(C.c_void_p(flat.data_ptr() + 4 * off), count, 0.0, None)

@@ -1,0 +1,127 @@
+"""Plan recording / replay: the host compiles a network ONCE into an array of mh_op records
+(include/madnet_hip.h); libmadnet_hip.so's native executor replays it with one FFI call, or
+captures it into a hipGraph.  This replaces TF1's graph + Session.run machinery for the path
+(Stereo_Online_Adaptation.py:208) -- there is no tracing compiler.
+
+`Recorder` exposes the same call surface as `_ffi.Lib`, so the wrappers in ops.py are reused
+verbatim to *record* instead of *launch*.  The packing below must match run_op() in
+csrc/lib.hip.
+"""
+import ctypes as C
+from . import _ffi
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, C.c_void_p):
+        return x.value
+    return int(x)
+
+
+class Recorder(object):
+    def __init__(self):
+        self.ops = []
+        self.keep = []          # python objects (tensors) that must outlive the plan
+
+    # -- helpers ---------------------------------------------------------------------------
+    def _op(self, kind, ints=(), floats=(), ptrs=(), n=0):
+        o = _ffi.Op()
+        o.kind = kind
+        for k, v in enumerate(ints):
+            o.i[k] = int(v)
+        for k, v in enumerate(floats):
+            o.f[k] = float(v)
+        for k, v in enumerate(ptrs):
+            o.p[k] = _ptr(v)
+        o.n = int(n)
+        self.ops.append(o)
+
+    @staticmethod
+    def _desc_ints(d):
+        return [d.B, d.Hi, d.Wi, d.Ho, d.Wo, d.K, d.N, d.kh, d.kw, d.stride, d.dil, d.pad_t, d.pad_l,
+                d.mode, d.w_trans, d.in_ld, d.out_ld, d.mask_ld, d.accumulate]
+
+    # -- same names / argument order as _ffi.Lib (minus the 'mh_' prefix) --------------------
+    def conv2d(self, dref, inp, w, bias, out, mask, stream):
+        d = dref._obj
+        self._op(_ffi.OP_CONV, self._desc_ints(d), [d.alpha, d.mask_alpha], [inp, w, bias, out, mask])
+
+    def conv2d_wgrad(self, dref, inp, dout, dout_ld, dw, db, stream):
+        d = dref._obj
+        ints = self._desc_ints(d) + [0, 0, dout_ld]
+        self._op(_ffi.OP_WGRAD, ints, [d.alpha, d.mask_alpha], [inp, dout, dw, db])
+
+    def corr_fwd(self, L, l_ld, R, r_ld, u, out, out_ld, coff, B, H, W, Cc, md, stride, copy_left, zero_tail, stream):
+        self._op(_ffi.OP_CORR_FWD, [l_ld, r_ld, out_ld, coff, B, H, W, Cc, md, stride, copy_left, zero_tail], [], [L, R, u, out])
+
+    def corr_bwd(self, g, g_ld, coff, L, l_ld, R, r_ld, dL, dl_ld, acc_l, dR, dr_ld, acc_r, du, acc_u,
+                 B, H, W, Cc, md, stride, copy_left, stream):
+        self._op(_ffi.OP_CORR_BWD, [g_ld, coff, l_ld, r_ld, dl_ld, acc_l, dr_ld, acc_r, acc_u, B, H, W, Cc, md, stride, copy_left],
+                 [], [g, L, R, dL, dR, du])
+
+    def warp_fwd(self, img, img_ld, u, out, out_ld, B, H, W, Cc, stream):
+        self._op(_ffi.OP_WARP_FWD, [img_ld, out_ld, B, H, W, Cc], [], [img, u, out])
+
+    def warp_bwd(self, g, g_ld, img, img_ld, u, dimg, dimg_ld, du, acc_u, B, H, W, Cc, stream):
+        self._op(_ffi.OP_WARP_BWD, [g_ld, img_ld, dimg_ld, acc_u, B, H, W, Cc], [], [g, img, u, dimg, du])
+
+    def resize_fwd(self, inp, out, B, Hi, Wi, Hr, Wr, cy, cx, Ho, Wo, mul, mode, stream):
+        self._op(_ffi.OP_RESIZE_FWD, [B, Hi, Wi, Hr, Wr, cy, cx, Ho, Wo, mode, 0], [mul], [inp, out])
+
+    def resize_bwd(self, g, inp, din, accumulate, B, Hi, Wi, Hr, Wr, cy, cx, Ho, Wo, mul, mode, stream):
+        self._op(_ffi.OP_RESIZE_BWD, [B, Hi, Wi, Hr, Wr, cy, cx, Ho, Wo, mode, accumulate], [mul], [g, inp, din])
+
+    def pad_reflect(self, inp, out, B, H, W, Cc, Hp, Wp, pt, pl, out_ld, stream):
+        self._op(_ffi.OP_PAD_REFLECT, [B, H, W, Cc, Hp, Wp, pt, pl, out_ld], [], [inp, out])
+
+    def reprojection_loss(self, left, right, disp, ws, result, ddisp, grad_scale, B, H, W, stream):
+        self._op(_ffi.OP_LOSS, [B, H, W], [grad_scale], [left, right, disp, ws, result, ddisp])
+
+    def metrics(self, disp, gt, ws, result, th, B, H, W, stream):
+        self._op(_ffi.OP_METRICS, [B, H, W], [th], [disp, gt, ws, result])
+
+    def momentum(self, var, accum, grad, n, lr, mom, gs, stream):
+        self._op(_ffi.OP_MOMENTUM, [], [lr, mom, gs], [var, accum, grad], n=n)
+
+    def copy_channels(self, src, src_ld, dst, dst_ld, npix, nch, scale, accumulate, stream):
+        self._op(_ffi.OP_COPY_CH, [src_ld, dst_ld, nch, accumulate], [scale], [src, dst], n=npix)
+
+    def leaky_bwd(self, dy, dy_ld, y, y_ld, npix, nch, alpha, stream):
+        self._op(_ffi.OP_LEAKY_BWD, [dy_ld, y_ld, nch], [alpha], [dy, y], n=npix)
+
+    def fill(self, p, n, v, stream):
+        self._op(_ffi.OP_FILL, [], [v], [p], n=n)
+
+    # -- finalise ---------------------------------------------------------------------------
+    def compile(self):
+        arr = (_ffi.Op * len(self.ops))(*self.ops)
+        return Plan(arr, len(self.ops), self.keep)
+
+
+class Plan(object):
+    """An immutable op array + (optionally) its captured hipGraph."""
+
+    def __init__(self, arr, n, keep):
+        self.arr, self.n, self.keep = arr, n, keep
+        self.graph = None
+
+    def run(self, lib, stream):
+        lib.plan_run(self.arr, self.n, C.c_void_p(stream))
+
+    def capture(self, lib, stream):
+        """Capture the plan into a hipGraph on `stream` (must not be the legacy default stream)."""
+        s = C.c_void_p(stream)
+        lib.graph_begin(s)
+        try:
+            lib.plan_run(self.arr, self.n, s)
+        finally:
+            g = C.c_void_p()
+            lib.graph_end(s, C.byref(g))
+        self.graph = g
+
+    def launch(self, lib, stream):
+        if self.graph is not None:
+            lib.graph_launch(self.graph, C.c_void_p(stream))
+        else:
+            self.run(lib, stream)

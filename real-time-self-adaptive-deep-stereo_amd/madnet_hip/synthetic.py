@@ -72,3 +72,14 @@ def xavier_weights(shapes, seed=0):
             lim = np.sqrt(6.0 / (kh * kw * a + kh * kw * b))
             out[name] = rng.uniform(-lim, lim, size=shp).astype(np.float32)
     return out
+
+
+def calibrated_weights(shapes, seed=1, conv1_gain=0.1):
+    """Xavier weights whose first layer is scaled so that the un-normalised 0..255 input
+    (MADNet feeds raw pixel values, Nets/MadNet.py:56-66) produces KITTI-like disparities
+    (mean ~15 px) instead of the hundreds of pixels a raw Xavier net gives."""
+    w = xavier_weights(shapes, seed)
+    for k in w:
+        if k.endswith("conv1/weights") and "pyramid" in k:
+            w[k] = (w[k] * conv1_gain).astype(np.float32)
+    return w

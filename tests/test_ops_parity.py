@@ -1,0 +1,220 @@
+"""Correlation / warp / resize / pad / loss / metrics / momentum parity vs the torch oracle
+(same tests run on the CPU-emulated build and, marked gpu, on the MI355X)."""
+import numpy as np
+import pytest
+import torch
+
+from madnet_hip import ops
+from oracle import tf_ops as T
+
+
+def _rand(shape, seed, dev, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev)
+
+
+def _close(a, b, rtol=2e-5, atol=2e-6):
+    a, b = a.detach().cpu(), b.detach().cpu()
+    err = (a - b).abs().max().item()
+    return err <= atol + rtol * max(1.0, b.abs().max().item()), err
+
+
+CORR_CASES = [(1, 6, 20, 192, 2, 1), (1, 5, 70, 32, 2, 1), (2, 4, 9, 64, 2, 1), (1, 3, 33, 96, 3, 2),
+              (1, 3, 17, 16, 4, 1), (1, 2, 40, 32, 10, 1), (1, 2, 70, 128, 40, 1)]
+
+
+@pytest.mark.parametrize("case", CORR_CASES)
+def test_corr_fwd_concat(backend, case):
+    """[L | corr | u | 0-pad] written by one kernel == tf.concat of the oracle pieces."""
+    B, H, W, C, md, st = case
+    if backend.name == "emul" and md == 40:
+        H = 1
+    dev = backend.device
+    L = _rand((B, H, W, C), 1, dev); R = _rand((B, H, W, C), 2, dev); u = _rand((B, H, W), 3, dev)
+    ref = T.correlation(L.cpu(), R.cpu(), md, st)
+    D = ref.shape[-1]
+    ld = (C + D + 1 + 3) // 4 * 4
+    out = torch.full((B, H, W, ld), float("nan"), device=dev)
+    ov = ops.View(out, B, H, W, ld, ld)
+    ops.corr_fwd(backend.lib, ops.view(L), ops.view(R), ov, md, st, coff=C, u=u, copy_left=True, zero_tail=True)
+    backend.sync()
+    o = out.cpu()
+    assert torch.equal(o[..., :C], L.cpu())
+    ok, err = _close(o[..., C:C + D], ref); assert ok, err
+    assert torch.equal(o[..., C + D], u.cpu())
+    assert torch.all(o[..., C + D + 1:] == 0)
+    # stand-alone form (sharedLayers.correlation): corr only, no concat
+    out2 = torch.full((B, H, W, D), float("nan"), device=dev)
+    ops.corr_fwd(backend.lib, ops.view(L), ops.view(R), ops.view(out2), md, st)
+    backend.sync()
+    ok, err = _close(out2, ref); assert ok, err
+
+
+@pytest.mark.parametrize("case", CORR_CASES[:6])
+def test_corr_bwd(backend, case):
+    B, H, W, C, md, st = case
+    dev = backend.device
+    L = _rand((B, H, W, C), 4, dev); R = _rand((B, H, W, C), 5, dev)
+    Lc = L.cpu().requires_grad_(True); Rc = R.cpu().requires_grad_(True)
+    ref = T.correlation(Lc, Rc, md, st)
+    D = ref.shape[-1]
+    ld = (C + D + 1 + 3) // 4 * 4
+    g = _rand((B, H, W, ld), 6, dev)
+    gl_ref, gr_ref = torch.autograd.grad(ref, [Lc, Rc], g.cpu()[..., C:C + D])
+    old_l = _rand((B, H, W, C), 7, dev)
+    dL = old_l.clone(); dR = torch.full((B, H, W, C), float("nan"), device=dev); du = torch.zeros(B, H, W, device=dev)
+    gv = ops.View(g, B, H, W, ld, ld)
+    ops.corr_bwd(backend.lib, gv, ops.view(L), ops.view(R), ops.view(dL), ops.view(dR), md, st, coff=C, du=du,
+                 acc_l=True, acc_r=False, acc_u=False, copy_left=True)
+    backend.sync()
+    ok, err = _close(dL, old_l.cpu() + g.cpu()[..., :C] + gl_ref); assert ok, err
+    ok, err = _close(dR, gr_ref); assert ok, err
+    assert torch.equal(du.cpu(), g.cpu()[..., C + D])
+
+
+@pytest.mark.parametrize("case", [(1, 6, 20, 128), (2, 5, 33, 32), (1, 4, 17, 16), (1, 3, 40, 96)])
+def test_warp_fwd_bwd(backend, case):
+    B, H, W, C = case
+    dev = backend.device
+    img = _rand((B, H, W, C), 8, dev)
+    u = _rand((B, H, W, 1), 9, dev, 4.0)
+    u[0, 0, 0, 0] = -3.0; u[0, 0, W - 1, 0] = 2.5; u[0, 1, 2, 0] = 1.0; u[0, 1, 3, 0] = -100.0   # out of range / integral
+    ic = img.cpu().requires_grad_(True); uc = u.cpu().requires_grad_(True)
+    ref = T.linear_warp(ic, uc)
+    g = _rand((B, H, W, C), 10, dev)
+    gi_ref, gu_ref = torch.autograd.grad(ref, [ic, uc], g.cpu())
+    out = torch.full((B, H, W, C), float("nan"), device=dev)
+    u3 = u[..., 0].contiguous()
+    ops.warp_fwd(backend.lib, ops.view(img), u3, ops.view(out))
+    dimg = torch.zeros(B, H, W, C, device=dev); du = torch.full((B, H, W), 0.5, device=dev)
+    ops.warp_bwd(backend.lib, ops.view(g), ops.view(img), u3, ops.view(dimg), du=du, acc_u=True)
+    backend.sync()
+    ok, err = _close(out, ref); assert ok, err
+    ok, err = _close(dimg, gi_ref, rtol=5e-5); assert ok, err
+    ok, err = _close(du, gu_ref[..., 0] + 0.5, rtol=5e-5, atol=2e-5); assert ok, err
+
+
+RESIZE_CASES = [  # Hi, Wi, Hr, Wr, cy, cx, Ho, Wo, mul, mode
+    (6, 20, 12, 40, 0, 0, 12, 40, 20.0 / 32, 0),       # inter-level upsample x2
+    (6, 20, 384, 1280, 4, 19, 375, 1242, -20.0, 1),    # _make_disp from level 6 (x64), relu first
+    (24, 80, 96, 320, 1, 5, 93, 311, -20.0, 2),        # final prediction style (x4), relu after
+    (7, 9, 7, 9, 0, 0, 7, 9, 1.0, 0),                  # identity size
+    (9, 11, 5, 7, 0, 1, 5, 5, 0.5, 0),                 # down-scaling, non-integer ratio
+    (5, 8, 13, 21, 2, 3, 9, 15, -1.5, 2),              # non-integer up ratio
+]
+
+
+@pytest.mark.parametrize("case", RESIZE_CASES)
+def test_resize_fwd_bwd(backend, case):
+    Hi, Wi, Hr, Wr, cy, cx, Ho, Wo, mul, mode = case
+    dev = backend.device
+    B = 2
+    x = _rand((B, Hi, Wi), 11, dev)
+    xc = x.cpu().requires_grad_(True)
+    xin = xc[..., None]
+    if mode == 0:
+        r = T.resize_bilinear(xin, Hr, Wr) * mul
+    elif mode == 1:
+        r = T.resize_bilinear(torch.relu(xin * mul), Hr, Wr)
+    else:
+        r = torch.relu(T.resize_bilinear(xin, Hr, Wr) * mul)
+    ref = r[:, cy:cy + Ho, cx:cx + Wo, 0]
+    g = _rand((B, Ho, Wo), 12, dev)
+    (gx_ref,) = torch.autograd.grad(ref, [xc], g.cpu())
+    out = torch.full((B, Ho, Wo), float("nan"), device=dev)
+    ops.resize_fwd(backend.lib, x, out, Hr, Wr, cy, cx, mul, mode)
+    old = _rand((B, Hi, Wi), 13, dev)
+    dx = old.clone()
+    ops.resize_bwd(backend.lib, g, x, dx, Hr, Wr, cy, cx, mul, mode, accumulate=True)
+    backend.sync()
+    ok, err = _close(out, ref); assert ok, err
+    ok, err = _close(dx, old.cpu() + gx_ref, rtol=5e-5, atol=1e-5); assert ok, err
+
+
+def test_pad_reflect(backend):
+    dev = backend.device
+    x = torch.arange(2 * 11 * 14 * 3, dtype=torch.float32).reshape(2, 11, 14, 3).to(dev)
+    ref = T.pad_image(x.cpu(), 8)
+    Hp, Wp = ref.shape[1], ref.shape[2]
+    out = torch.full((2, Hp, Wp, 4), float("nan"), device=dev)
+    ops.pad_reflect(backend.lib, x, out, (Hp - 11) // 2, (Wp - 14) // 2)
+    backend.sync()
+    assert torch.equal(out.cpu()[..., :3], ref)          # index path: bit exact
+    assert torch.all(out.cpu()[..., 3] == 0)
+
+
+@pytest.mark.parametrize("shape", [(1, 9, 14), (2, 12, 21)])
+def test_reprojection_loss_and_grad(backend, shape):
+    B, H, W = shape
+    dev = backend.device
+    g = torch.Generator().manual_seed(5)
+    left = torch.floor(torch.rand(B, H, W, 3, generator=g) * 256).to(dev)
+    right = torch.floor(torch.rand(B, H, W, 3, generator=g) * 256).to(dev)
+    disp = (torch.rand(B, H, W, generator=g) * 6 - 1).to(dev)       # includes negative / out of range warps
+    dc = disp.cpu().requires_grad_(True)
+    ref = T.reprojection_loss(dc[..., None], left.cpu(), right.cpu())
+    (gd_ref,) = torch.autograd.grad(ref, [dc])
+    ws = torch.zeros(backend.lib.loss_ws_floats(B, H, W), device=dev)
+    res = torch.zeros(4, device=dev); dd = torch.full((B, H, W), float("nan"), device=dev)
+    ops.reprojection_loss(backend.lib, left, right, disp, ws, res, dd, grad_scale=1.0)
+    backend.sync()
+    assert abs(res[0].item() - ref.item()) <= 2e-6 * max(1.0, abs(ref.item()))
+    ok, err = _close(dd, gd_ref, rtol=2e-4, atol=1e-7); assert ok, err
+
+
+def test_reprojection_loss_smooth_images(backend):
+    """Low-texture images: SSIM denominators near C1/C2 and clip boundaries are exercised."""
+    B, H, W = 1, 10, 16
+    dev = backend.device
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    left = torch.stack([xx * 3 + 10, yy * 5 + 20, xx + yy], -1)[None].to(dev)
+    right = torch.stack([xx * 3 + 16, yy * 5 + 20, xx + yy + 2], -1)[None].to(dev)
+    disp = torch.full((B, H, W), 2.25).to(dev)
+    dc = disp.cpu().requires_grad_(True)
+    ref = T.reprojection_loss(dc[..., None], left.cpu(), right.cpu())
+    (gd_ref,) = torch.autograd.grad(ref, [dc])
+    ws = torch.zeros(backend.lib.loss_ws_floats(B, H, W), device=dev)
+    res = torch.zeros(4, device=dev); dd = torch.zeros(B, H, W, device=dev)
+    ops.reprojection_loss(backend.lib, left, right, disp, ws, res, dd)
+    backend.sync()
+    assert abs(res[0].item() - ref.item()) <= 5e-6
+    ok, err = _close(dd, gd_ref, rtol=1e-3, atol=1e-6); assert ok, err
+
+
+def test_metrics(backend):
+    B, H, W = 1, 13, 29
+    dev = backend.device
+    g = torch.Generator().manual_seed(9)
+    disp = (torch.rand(B, H, W, generator=g) * 50).to(dev)
+    gt = (torch.rand(B, H, W, generator=g) * 50)
+    gt[torch.rand(B, H, W, generator=g) < 0.7] = 0.0
+    gt = gt.to(dev)
+    epe, bad = T.validation_metrics(disp.cpu()[..., None], gt.cpu()[..., None])
+    ws = torch.zeros(backend.lib.metrics_ws_floats(B, H, W), device=dev); res = torch.zeros(4, device=dev)
+    ops.metrics(backend.lib, disp, gt, ws, res, 3.0)
+    backend.sync()
+    assert abs(res[0].item() - epe.item()) <= 1e-5 * epe.item()
+    assert abs(res[1].item() - bad.item()) <= 1e-6
+    assert res[2].item() == float((gt != 0).sum())
+
+
+def test_momentum_and_glue(backend):
+    dev = backend.device
+    n = 1000
+    w = _rand((n,), 1, dev); m = _rand((n,), 2, dev); g = _rand((n,), 3, dev)
+    w0, m0 = w.cpu().clone(), m.cpu().clone()
+    ops.momentum(backend.lib, w, m, g, lr=1e-2, mom=0.9, grad_scale=0.5)
+    backend.sync()
+    m_ref = 0.9 * m0 + 0.5 * g.cpu()
+    assert torch.allclose(m.cpu(), m_ref, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(w.cpu(), w0 - 1e-2 * m_ref, rtol=1e-6, atol=1e-7)
+    # copy_channels into a slice of a wider buffer, accumulate + scale
+    src = _rand((1, 4, 5, 3), 4, dev); dst = _rand((1, 4, 5, 8), 5, dev); d0 = dst.cpu().clone()
+    dv = ops.View(dst, 1, 4, 5, 3, 8, coff=2)
+    ops.copy_channels(backend.lib, ops.view(src), dv, scale=2.0, accumulate=True)
+    y = _rand((1, 4, 5, 8), 6, dev); dy = _rand((1, 4, 5, 8), 7, dev); dy0 = dy.cpu().clone()
+    ops.leaky_bwd(backend.lib, ops.view(dy), ops.view(y), 0.2)
+    backend.sync()
+    exp = d0.clone(); exp[..., 2:5] += 2.0 * src.cpu()
+    assert torch.allclose(dst.cpu(), exp)
+    assert torch.allclose(dy.cpu(), dy0 * torch.where(y.cpu() > 0, 1.0, 0.2))
