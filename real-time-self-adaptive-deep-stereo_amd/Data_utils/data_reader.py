@@ -1,0 +1,102 @@
+"""Input list reader for the online-adaptation driver: same list format and centre crop/pad
+semantics as the reference's tf.data pipeline (Data_utils/data_reader.py:55-197), as a plain Python
+iterator (host IO is outside the hot path).
+
+List file: one sample per row `left,right,gt` (Data_utils/data_reader.py:55-78).  Images: PNG/JPG
+via Pillow; ground truth: 16-bit PNG (value/256, KITTI convention, :88-92), .pfm (:11-53) or .npy.
+Every frame is centre-cropped / zero-padded to crop_shape like tf.image.resize_image_with_crop_or_pad
+(:150) and yielded as float32 [1,H,W,C] holding the raw 0..255 values (:98)."""
+import os
+import re
+
+import numpy as np
+
+
+def read_list_file(path_file):
+    """Returns (left_files, right_files, gt_files); rows must have >= 3 comma separated fields."""
+    with open(path_file, 'r') as f_in:
+        rows = [x.strip().split(',') for x in f_in.readlines() if x.strip()]
+    if any(len(r) < 3 for r in rows):
+        raise Exception('Expected lines with at least 3 comma separated fields: left,right,gt')
+    return [r[0] for r in rows], [r[1] for r in rows], [r[2] for r in rows]
+
+
+def readPFM(file):
+    """Portable float map reader (header: PF|Pf, 'w h', scale; rows bottom-to-top)."""
+    with open(file, 'rb') as f:
+        header = f.readline().rstrip().decode('ascii')
+        if header not in ('PF', 'Pf'):
+            raise Exception('Not a PFM file.')
+        color = header == 'PF'
+        m = re.match(r'^(\d+)\s(\d+)\s$', f.readline().decode('ascii'))
+        if not m:
+            raise Exception('Malformed PFM header.')
+        width, height = int(m.group(1)), int(m.group(2))
+        scale = float(f.readline().rstrip().decode('ascii'))
+        data = np.fromfile(f, ('<' if scale < 0 else '>') + 'f')
+    shape = (height, width, 3) if color else (height, width, 1)
+    return np.flipud(np.reshape(data, shape)).astype(np.float32), abs(scale)
+
+
+def _read_image(path, is_gt=False):
+    ext = os.path.splitext(path)[1].lower()
+    if ext == '.npy':
+        a = np.load(path).astype(np.float32)
+        return a if a.ndim == 3 else a[..., None]
+    if ext == '.pfm':
+        return readPFM(path)[0]
+    from PIL import Image
+    im = Image.open(path)
+    a = np.asarray(im)
+    if is_gt:
+        a = a.astype(np.float32)
+        if a.ndim == 3:
+            a = a[..., 0]
+        if np.asarray(im).dtype != np.uint8:
+            a = a / 256.0                       # 16-bit KITTI disparity PNG
+        return a[..., None]
+    a = a.astype(np.float32)
+    if a.ndim == 2:
+        a = np.stack([a, a, a], -1)
+    return a[..., :3]
+
+
+def center_crop_or_pad(img, th, tw):
+    """tf.image.resize_image_with_crop_or_pad: centre crop (offset (in-target)//2) / zero pad."""
+    h, w = img.shape[:2]
+    if h > th:
+        o = (h - th) // 2
+        img = img[o:o + th]
+    if w > tw:
+        o = (w - tw) // 2
+        img = img[:, o:o + tw]
+    h, w = img.shape[:2]
+    if h < th or w < tw:
+        pt, pl = (th - h) // 2, (tw - w) // 2
+        out = np.zeros((th, tw) + img.shape[2:], img.dtype)
+        out[pt:pt + h, pl:pl + w] = img
+        img = out
+    return img
+
+
+class dataset(object):
+    """Iterator with the reference's constructor surface (the arguments the online script uses)."""
+
+    def __init__(self, path_file, batch_size=1, crop_shape=(320, 1216), num_epochs=1, augment=False,
+                 is_training=False, shuffle=False):
+        if batch_size != 1 or augment or is_training or shuffle:
+            raise NotImplementedError('online adaptation reads frames in order, batch 1, no augmentation')
+        self._left, self._right, self._gt = read_list_file(path_file)
+        self._crop = tuple(crop_shape)
+        self._epochs = num_epochs
+
+    def get_max_steps(self):
+        return len(self._left) * self._epochs
+
+    def __iter__(self):
+        for _ in range(self._epochs):
+            for l, r, g in zip(self._left, self._right, self._gt):
+                th, tw = self._crop
+                yield (center_crop_or_pad(_read_image(l), th, tw)[None],
+                       center_crop_or_pad(_read_image(r), th, tw)[None],
+                       center_crop_or_pad(_read_image(g, True), th, tw)[None])

@@ -1,0 +1,158 @@
+"""Online adaptation driver for MI355X -- same flags, loop semantics and output files (stats.csv,
+series.csv, params.sh, config.json, disparities/*.png) as the reference script
+(Stereo_Online_Adaptation.py:30-325); the per-frame loop body lives in madnet_hip.adapter.Adapter.step().
+
+--weights accepts an .npz of {TF variable name: HWIO array} (see `python -m madnet_hip.weights_io`),
+or the literal `xavier[:seed]` / `calibrated[:seed]` for synthetic weights.  TF checkpoints cannot be
+read here (no TensorFlow); the importer is a 'next' row."""
+import argparse
+import datetime
+import json
+import os
+import shutil
+import sys
+import time
+
+import numpy as np
+
+import Nets
+from Data_utils import data_reader
+from Sampler import sampler_factory
+
+MAX_DISP = 256
+PIXEL_TH = 3
+
+
+def load_weights(spec, radius_d=2, stride=1):
+    from madnet_hip import engine as E, synthetic
+    shapes = dict(E.madnet_manifest(radius_d, stride))
+    kind = spec.split(':')[0]
+    if kind in ('xavier', 'calibrated'):
+        seed = int(spec.split(':')[1]) if ':' in spec else (0 if kind == 'xavier' else 1)
+        return synthetic.xavier_weights(shapes, seed) if kind == 'xavier' else synthetic.calibrated_weights(shapes, seed)
+    if spec.endswith('.npz'):
+        z = np.load(spec)
+        w = {k: z[k] for k in z.files}
+        assert len(w) > 0                      # Stereo_Online_Adaptation.py:151
+        return w
+    raise Exception('Unsupported --weights %r: expected an .npz of TF-named variables, xavier[:seed] or '
+                    'calibrated[:seed] (TF checkpoints need TensorFlow, not available)' % spec)
+
+
+def main(args):
+    import torch
+    from madnet_hip.adapter import Adapter
+    with open(args.blockConfig) as json_data:
+        train_config = json.load(json_data)
+    data_set = data_reader.dataset(args.list, batch_size=1, crop_shape=args.imageShape, num_epochs=1,
+                                   augment=False, is_training=False, shuffle=False)
+    H, W = args.imageShape
+    dev = 'cuda'
+    left_img_batch = torch.zeros(1, H, W, 3, device=dev)
+    right_img_batch = torch.zeros(1, H, W, 3, device=dev)
+    net_args = {'left_img': left_img_batch, 'right_img': right_img_batch, 'split_layers': [None], 'sequence': True,
+                'train_portion': 'BEGIN', 'bulkhead': True if args.mode == 'MAD' else False,
+                'weights': load_weights(args.weights)}
+    stereo_net = Nets.get_stereo_net(args.modelName, net_args)
+    print('Stereo Prediction Model:\n', stereo_net)
+    predictions = stereo_net.get_disparities()
+    adapter = Adapter(stereo_net, mode=args.mode, block_config=train_config, lr=args.lr, sample_mode=args.sampleMode,
+                      num_blocks=args.numBlocks, fixed_id=args.fixedID, sample_frequency=args.sampleFrequency,
+                      ssim_th=args.SSIMTh, reprojection_scale=args.reprojectionScale)
+    print('Disparity Net Restored?: {}, number of restored variables: {}'.format(True, len(stereo_net.engine.params.manifest)))
+
+    epe_accumulator, bad3_accumulator = [], []
+    exec_time = 0
+    step = 0
+    max_steps = data_set.get_max_steps()
+    start_time = time.time()
+    t_begin = time.time()
+    try:
+        for left, right, gt in data_set:
+            out = adapter.step(left, right, gt[..., 0])
+            new_loss = out['loss']
+            epe_accumulator.append(out['epe'])
+            bad3_accumulator.append(out['bad3'])
+            if step % 100 == 0:
+                fbTime = (time.time() - start_time)
+                exec_time += fbTime
+                fbTime = fbTime / 100
+                missing_time = (max_steps - step) * fbTime
+                print('Step:{:4d}\tbad3:{:.2f}\tEPE:{:.2f}\tSSIM:{:.2f}\tf/b time:{:3f}\tMissing time:{}'.format(
+                    step, out['bad3'], out['epe'], new_loss, fbTime, datetime.timedelta(seconds=missing_time)))
+                start_time = time.time()
+            if args.logDispStep != -1 and step % args.logDispStep == 0:
+                from PIL import Image
+                dispy = out['disparity'][0].detach().cpu().numpy()
+                dispy_to_save = (np.clip(dispy, 0, MAX_DISP) * 256.0).astype(np.uint16)
+                Image.fromarray(dispy_to_save).save(os.path.join(args.output, 'disparities/disparity_{}.png'.format(step)))
+            step += 1
+    finally:
+        wall = time.time() - t_begin
+        epe_array, bad3_array = epe_accumulator, bad3_accumulator
+        epe_sum, bad3_sum = np.sum(epe_accumulator), np.sum(bad3_accumulator)
+        nstep = max(step, 1)
+        exec_time = max(exec_time, 1e-9)
+        with open(os.path.join(args.output, 'stats.csv'), 'w+') as f_out:
+            f_out.write('Metrics,cumulative,average\n')
+            f_out.write('EPE,{},{}\n'.format(epe_sum, epe_sum / nstep))
+            f_out.write('bad3,{},{}\n'.format(bad3_sum, bad3_sum / nstep))
+            f_out.write('time,{},{}\n'.format(exec_time, exec_time / nstep))
+            f_out.write('FPS,{}\n'.format(1 / (exec_time / nstep)))
+            f_out.write('wall_FPS,{}\n'.format(nstep / max(wall, 1e-9)))     # true wall clock
+            f_out.write('#resets,{}\n'.format(adapter.reset_counter))
+            f_out.write('Blocks')
+            for n in range(len(predictions) - 1):
+                f_out.write(',{}'.format(n))
+            f_out.write(',final\n')
+            f_out.write('fetch_counter')
+            for c in adapter.fetch_counter:
+                f_out.write(',{}'.format(c))
+            f_out.write('\n')
+            for c in adapter.sample_distribution:
+                f_out.write(',{}'.format(c))
+            f_out.write('\n')
+        step_time = exec_time / nstep
+        with open(os.path.join(args.output, 'series.csv'), 'w+') as f_out:
+            f_out.write('Iteration,Time,EPE,bad3\n')
+            for i, (e, b) in enumerate(zip(epe_array, bad3_array)):
+                f_out.write('{},{},{},{}\n'.format(i, str(i * step_time), e, b))
+        print('Result saved in {}'.format(args.output))
+        print('All Done, Bye Bye!')
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description='Script for online Adaptation of a Deep Stereo Network')
+    parser.add_argument("-l", "--list", help='path to the list file with frames to be processed', required=True)
+    parser.add_argument("-o", "--output", help="path to the output folder where the results will be saved", required=True)
+    parser.add_argument("--weights", help="path to the initial weights for the disparity estimation network", required=True)
+    parser.add_argument("--modelName", help="name of the stereo model to be used", default="Dispnet", choices=Nets.STEREO_FACTORY.keys())
+    parser.add_argument("--numBlocks", help="number of CNN portions to train at each iteration", type=int, default=1)
+    parser.add_argument("--lr", help="value for learning rate", default=0.0001, type=float)
+    parser.add_argument("--blockConfig", help="path to the block_config json file", required=True)
+    parser.add_argument("--sampleMode", help="choose the sampling heuristic to use", choices=sampler_factory.AVAILABLE_SAMPLER, default='SAMPLE')
+    parser.add_argument("--fixedID", help="index of the portions of network to train, used only if sampleMode=FIXED", type=int, nargs='+', default=[0])
+    parser.add_argument("--reprojectionScale", help="compute all loss function at 1/reprojectionScale", default=1, type=int)
+    parser.add_argument("--summary", help='flag to enable tensorboard summaries (ignored: no TensorBoard)', action='store_true')
+    parser.add_argument("--imageShape", help='two int for the size of the crop extracted from each image [height,width]', nargs='+', type=int, default=[320, 1216])
+    parser.add_argument("--SSIMTh", help="reset network to initial configuration if loss is above this value", type=float, default=0.5)
+    parser.add_argument("--sampleFrequency", help="sample new network portions to train every K frame", type=int, default=1)
+    parser.add_argument("--mode", help="online adaptation mode: NONE - perform only inference, FULL - full online backprop, MAD - backprop only on portions of the network", choices=['NONE', 'FULL', 'MAD'], default='MAD')
+    parser.add_argument("--logDispStep", help="save disparity every K step, -1 to disable", default=-1, type=int)
+    return parser
+
+
+if __name__ == '__main__':
+    args = build_parser().parse_args()
+    if not os.path.exists(args.output):
+        os.makedirs(args.output)
+    if args.logDispStep != -1 and not os.path.exists(os.path.join(args.output, 'disparities')):
+        os.makedirs(os.path.join(args.output, 'disparities'))
+    shutil.copy(args.blockConfig, os.path.join(args.output, 'config.json'))
+    with open(os.path.join(args.output, 'params.sh'), 'w+') as out:
+        sys.argv[0] = os.path.join(os.getcwd(), sys.argv[0])
+        out.write('#!/bin/bash\n')
+        out.write('python3 ')
+        out.write(' '.join(sys.argv))
+        out.write('\n')
+    main(args)

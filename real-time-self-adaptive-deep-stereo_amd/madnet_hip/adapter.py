@@ -1,0 +1,159 @@
+"""The step() surface: one iteration of the online-adaptation loop of the reference
+(Stereo_Online_Adaptation.py:178-253): sample -> ONE forward with pre-update weights -> full-res
+loss + EPE/bad3 -> selected backward(s) -> momentum update -> reward update -> reset check.
+
+Every (mode, sampled blocks) combination is compiled once into a plan and replayed as a hipGraph.
+Multi-GPU: streams are independent by default (private weights, no collective).  With
+shared_model=True the flat GRADIENT buffer is all-reduced (RCCL over xGMI via torch.distributed)
+between the backward plan and the fused momentum plan, which is exactly data-parallel SGD; the loss
+used for the reward / reset decisions is averaged too so every rank samples the same block.
+"""
+import numpy as np
+import torch
+
+from Sampler import sampler_factory
+from . import engine as E
+
+
+def softmax(x):
+    """Stereo_Online_Adaptation.py:25-27 (no max subtraction, replicated numerically)."""
+    return np.exp(x) / np.sum(np.exp(x), axis=0)
+
+
+class Adapter(object):
+    def __init__(self, net, mode="MAD", block_config=None, lr=1e-4, momentum=0.9, sample_mode="PROBABILITY",
+                 num_blocks=1, fixed_id=0, sample_frequency=1, ssim_th=0.5, reprojection_scale=1,
+                 use_graph=True, shared_model=False, process_group=None):
+        if mode not in ("NONE", "FULL", "MAD"):
+            raise ValueError("mode must be NONE, FULL or MAD")
+        if reprojection_scale != 1:
+            raise NotImplementedError("reprojectionScale != 1 is not supported by the MI355X engine")
+        self.net, self.eng, self.lib = net, net.engine, net._lib
+        self.mode, self.lr, self.momentum = mode, lr, momentum
+        self.sample_frequency, self.ssim_th = sample_frequency, ssim_th
+        self.shared, self.pg = shared_model, process_group
+        self.world = 1
+        if shared_model:
+            import torch.distributed as dist
+            self.dist = dist
+            self.world = dist.get_world_size(process_group)
+        dev = self.eng.left.device
+        self.cuda = dev.type == "cuda"
+        self.use_graph = use_graph and self.cuda
+        self.stream = torch.cuda.Stream(device=dev) if self.cuda else None
+        self.blocks = []
+        if mode == "MAD":
+            if getattr(net, "_bulkhead", True) is False:
+                print("WARNING: MAD adaptation expects the net built with bulkhead=True")
+            predictions = net.get_disparities()[:-1]
+            assert len(predictions) == len(block_config)           # Stereo_Online_Adaptation.py:97
+            for counter, layers in enumerate(block_config):
+                names = []
+                for layer in layers:
+                    names += [v.op_name for v in net.get_variables(layer)]
+                self.blocks.append((E.LEVELS[counter], names))
+            self.sampler = sampler_factory.get_sampler(sample_mode, num_blocks, fixed_id)
+        self.num_actions = len(self.blocks) if mode == "MAD" else (1 if mode == "FULL" else 0)
+        self.fetch_counter = [0] * self.num_actions
+        self.sample_distribution = np.zeros(shape=[self.num_actions])
+        self.loss_t_1 = self.loss_t_2 = 0.0
+        self.last_trained_blocks = []
+        self.blocks_to_train = []
+        self.reset_counter = 0
+        self.step_count = 0
+        self._plans = {}
+        self.eng.params.w0 = self.eng.params.w.clone()              # restore target (initial weights)
+        self._host = torch.zeros(8, pin_memory=self.cuda)
+
+    # -------------------------------------------------------------------------------------------
+    def _plan(self, key):
+        if key not in self._plans:
+            eng = self.eng
+            gs = 1.0 / self.world
+            parts = ("grad", "update") if self.shared else ("all",)
+            plans = []
+            for part in parts:
+                if key == "NONE":
+                    p = eng.build_plan("NONE", part=part)
+                elif key == "FULL":
+                    p = eng.build_plan("FULL", lr=self.lr, grad_scale=gs, part=part)
+                else:
+                    p = eng.build_plan("MAD", lr=self.lr, grad_scale=gs, part=part, blocks=[self.blocks[i] for i in key])
+                if self.use_graph and p.n > 0:
+                    with torch.cuda.stream(self.stream):
+                        p.capture(self.lib, self.stream.cuda_stream)
+                plans.append(p)
+            self._plans[key] = plans
+        return self._plans[key]
+
+    def _train_vars(self, key):
+        if key == "FULL":
+            return self.eng.all_vars()
+        if key == "NONE":
+            return []
+        return sum((self.blocks[i][1] for i in key), [])
+
+    def step(self, left, right, gt=None):
+        eng = self.eng
+        # ---- sample the portion(s) of the network to train (Stereo_Online_Adaptation.py:181-189)
+        if self.mode == "MAD" and self.step_count % self.sample_frequency == 0:
+            distribution = softmax(self.sample_distribution)
+            self.blocks_to_train = [int(b) for b in np.asarray(self.sampler.sample(distribution)).reshape(-1)]
+            for l in self.blocks_to_train:
+                self.fetch_counter[l] += 1
+        key = "FULL" if self.mode == "FULL" else ("NONE" if self.mode == "NONE" else tuple(self.blocks_to_train))
+        plans = self._plan(key)
+        sh = self.stream.cuda_stream if self.cuda else 0
+        ctx = torch.cuda.stream(self.stream) if self.cuda else _null()
+        with ctx:
+            eng.left.copy_(_as(left, eng.left), non_blocking=True)
+            eng.right.copy_(_as(right, eng.right), non_blocking=True)
+            if gt is not None:
+                eng.gt.copy_(_as(gt, eng.gt), non_blocking=True)
+            plans[0].launch(self.lib, sh)
+            if self.shared:
+                for o, c in eng.params.ranges(self._train_vars(key)):
+                    self.dist.all_reduce(eng.params.g[o:o + c], group=self.pg)
+                self.dist.all_reduce(eng.res_loss, group=self.pg)
+                eng.res_loss.div_(self.world)
+                plans[1].launch(self.lib, sh)
+            self._host[0:4].copy_(eng.res_loss, non_blocking=True)
+            self._host[4:8].copy_(eng.res_met, non_blocking=True)
+        if self.cuda:
+            self.stream.synchronize()
+        new_loss = float(self._host[0]); epe = float(self._host[4]); bad3 = float(self._host[5])
+        # ---- reward update of the sampling logits (Stereo_Online_Adaptation.py:211-224)
+        if self.mode == "MAD":
+            if self.step_count == 0:
+                self.loss_t_2 = new_loss
+                self.loss_t_1 = new_loss
+            expected_loss = 2 * self.loss_t_1 - self.loss_t_2
+            gain_loss = expected_loss - new_loss
+            self.sample_distribution = 0.99 * self.sample_distribution
+            for i in self.last_trained_blocks:
+                self.sample_distribution[i] += 0.01 * gain_loss
+            self.last_trained_blocks = self.blocks_to_train
+            self.loss_t_2 = self.loss_t_1
+            self.loss_t_1 = new_loss
+        # ---- reset to the initial weights if the loss explodes (:241-244); momentum is NOT reset
+        did_reset = False
+        if new_loss > self.ssim_th:
+            eng.params.w.copy_(eng.params.w0)
+            self.reset_counter += 1
+            did_reset = True
+        self.step_count += 1
+        return {"epe": epe, "bad3": bad3, "loss": new_loss, "disparity": eng.pred,
+                "blocks": list(self.blocks_to_train) if self.mode == "MAD" else [], "reset": did_reset}
+
+
+class _null(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def _as(x, like):
+    t = torch.as_tensor(x, dtype=torch.float32)
+    return t.reshape(like.shape)

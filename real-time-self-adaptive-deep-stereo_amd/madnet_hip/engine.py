@@ -443,29 +443,44 @@ class MadNetEngine(object):
     def all_vars(self):
         return [n for n, _ in self.params.manifest]
 
-    def build_plan(self, mode, lr=1e-4, block_vars=None, block_level=None, grad_scale=1.0, update=True):
-        """mode: 'NONE' | 'FULL' | 'MAD'.  For MAD: block_level in LEVELS (2 = context output),
-        block_vars = variable names of the block.  Returns a compiled Plan."""
+    def build_plan(self, mode, lr=1e-4, block_vars=None, block_level=None, grad_scale=1.0, update=True,
+                   blocks=None, part="all"):
+        """mode: 'NONE' | 'FULL' | 'MAD'.  For MAD: blocks = [(level, variable names), ...] (level in
+        LEVELS, 2 = context output); block_level/block_vars is the single-block shorthand.
+        part: 'all' | 'grad' (everything up to the gradients) | 'update' (momentum apply only) -- the
+        split lets a gradient all-reduce (shared-model multi-GPU mode) sit between two plans."""
         r = Recorder()
+        if blocks is None and block_level is not None:
+            blocks = [(block_level, block_vars)]
+        do_grad = part in ("all", "grad")
+        do_upd = update and part in ("all", "update")
         if mode == "NONE":
-            self.record_forward(r)
-            self.record_loss_metrics(r, with_grad=False)
+            if do_grad:
+                self.record_forward(r)
+                self.record_loss_metrics(r, with_grad=False)
         elif mode == "FULL":
             tv = self.all_vars()
-            self.record_forward(r)
-            self.record_loss_metrics(r, with_grad=True)
-            self.record_backward(r, "final", tv, bulkhead=False)
-            if update:
+            if do_grad:
+                self.record_forward(r)
+                self.record_loss_metrics(r, with_grad=True)
+                self.record_backward(r, "final", tv, bulkhead=False)
+            if do_upd:
                 self.record_update(r, tv, lr, grad_scale=grad_scale)
         elif mode == "MAD":
-            self.record_forward(r, make_disps=(block_level,))
-            self.record_loss_metrics(r, with_grad=False)
-            # reprojection loss of the block's prediction (Stereo_Online_Adaptation.py:98-107)
-            ops.reprojection_loss(r, self.left, self.right, self.disp_k[block_level], self.loss_ws_k, self.res_loss_k,
-                                  self.ddisp_k)
-            self.record_backward(r, block_level, block_vars, bulkhead=True)
-            if update:
-                self.record_update(r, block_vars, lr, grad_scale=grad_scale)
+            if do_grad:
+                self.record_forward(r, make_disps=tuple(lv for lv, _ in blocks))
+                self.record_loss_metrics(r, with_grad=False)
+            for lv, bv in blocks:
+                if do_grad:
+                    # reprojection loss of the block's prediction (Stereo_Online_Adaptation.py:98-107)
+                    ops.reprojection_loss(r, self.left, self.right, self.disp_k[lv], self.loss_ws_k, self.res_loss_k,
+                                          self.ddisp_k)
+                    self.record_backward(r, lv, bv, bulkhead=True)
+                if do_upd and part == "all":
+                    self.record_update(r, bv, lr, grad_scale=grad_scale)
+            if do_upd and part == "update":
+                for lv, bv in blocks:
+                    self.record_update(r, bv, lr, grad_scale=grad_scale)
         else:
             raise ValueError("unknown mode %r" % (mode,))
         return r.compile()
