@@ -19,13 +19,21 @@ for _p in (ROOT, PKG):
         sys.path.insert(0, _p)
 
 
+def _log(msg):
+    sys.stderr.write("[bench %.1fs] %s\n" % (time.perf_counter() - _T0, msg))
+    sys.stderr.flush()
+
+
+_T0 = time.perf_counter()
+
+
 def cpu_baseline(H, W, wn, l, r, gt, mode, steps=8):
     """CPU stand-in for the reference TF1 CPU path (TensorFlow cannot run here): the torch-CPU
     oracle executing the identical step on the same inputs and weights, on the host cores of this
     box.  Bounded sample: 2 warm-up + `steps` timed steps (~10-30 s)."""
     import torch
     from oracle import madnet as OM
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)     # oneDNN stops scaling (and oversubscribes) far below 256 threads
     torch.set_num_threads(cores)
     wt = {k: torch.from_numpy(v.copy()) for k, v in wn.items()}
     acc = {k: torch.zeros_like(v) for k, v in wt.items()}
@@ -92,11 +100,14 @@ def main():
     plan = eng.build_plan(args.mode, lr=1e-4)
     stream = torch.cuda.Stream()
     sh = stream.cuda_stream
+    _log("engine built, %d ops" % plan.n)
     with torch.cuda.stream(stream):
         plan.run(lib, sh)                       # eager once (validates every launch)
         stream.synchronize()
+        _log("eager step ok")
         if not args.no_graph:
             plan.capture(lib, sh)
+            _log("hipGraph captured")
         for _ in range(args.warmup):
             plan.launch(lib, sh)
         stream.synchronize()
@@ -131,13 +142,18 @@ def main():
                    "launch": "eager plan" if args.no_graph else "hipGraph replay",
                    "ops_per_step": plan.n, "final_loss": loss, "epe_vs_synthetic_gt": epe_gt},
     }
+    _log("timed region done: %.3f ms/step" % (1e3 * dt / args.steps))
     if rank == 0 and world == 1:
         if not args.no_roofline:
-            out["roofline"], extra = BT.roofline(lib, eng, stream)
+            with torch.cuda.stream(stream):
+                out["roofline"], extra = BT.roofline(lib, eng, stream)
             out.update(extra)
+            _log("roofline done")
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(H, W, wn, l, r, gt, args.mode)
             out["epe_vs_oracle"] = epe_vs_oracle(lib, H, W, wn, l, r, gt)
+            _log("epe_vs_oracle done")
+            out["cpu_baseline"] = cpu_baseline(H, W, wn, l, r, gt, args.mode)
+            _log("cpu baseline done")
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
