@@ -131,6 +131,8 @@ def main():
         dt = float(t.item())
     loss = float(eng.res_loss[0].item())
     epe_gt = float(eng.res_met[0].item())
+    nonzero = float((eng.pred > 0).float().mean().item())
+    assert nonzero >= 0.25, "degenerate synthetic network: only %.1f%% of the disparities are non-zero" % (100 * nonzero)
 
     out = {
         "metric": "adapted stereo pairs/sec (whole node), MADNet full-backprop online adaptation 1242x375",
@@ -140,7 +142,8 @@ def main():
         "config": {"workload": "MADNet %s adaptation step (fwd+SSIM/L1 loss+EPE+bwd+momentum), %dx%d, 1 pair/GPU/step, "
                                "private model per stream" % (args.mode, W, H),
                    "launch": "eager plan" if args.no_graph else "hipGraph replay",
-                   "ops_per_step": plan.n, "final_loss": loss, "epe_vs_synthetic_gt": epe_gt},
+                   "ops_per_step": plan.n, "final_loss": loss, "epe_vs_synthetic_gt": epe_gt,
+                   "pred_nonzero_frac": nonzero},
     }
     _log("timed region done: %.3f ms/step" % (1e3 * dt / args.steps))
     if rank == 0 and world == 1:

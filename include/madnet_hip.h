@@ -34,6 +34,9 @@ const char* mh_last_error(void);
 int mh_abi_version(void);
 /* number of visible HIP devices (<=0: none) -- lets the host fail loudly without torch */
 int mh_device_count(void);
+/* one-time set-up (opts every kernel instantiation into >64 KiB dynamic LDS); call once per
+ * process before the first launch and never inside a hipGraph capture */
+int mh_init(void);
 
 /* ---- convolution family: tf.nn.conv2d / atrous_conv2d / conv2d_transpose + bias_add +
  *      leaky (Nets/sharedLayers.py:54-92), and their registered gradients -------------- */

@@ -10,10 +10,11 @@
 //   B[(tap,k)][n] = w[tap][k][n] (forward, HWIO as stored) or w[tap][n][k] (dgrad)
 // K is walked in groups of 4 channels flattened across taps (group g -> tap=g/G, c4=g%G,
 // G=ceil(K/4)), so odd channel counts (3, 38, 33, 197 ...) cost no padded MFMA work beyond
-// the last group.  One workgroup = 4 waves computes a BM x BN tile; a K-tile = 4 groups =
-// 16 k-values; global->register prefetch of tile t+1 overlaps the MFMAs of tile t; LDS is
+// the last group.  One workgroup = 4 waves computes a BM x BN tile; a K-tile = 32 or 64
+// k-values; global->register prefetch of tile t+1 overlaps the MFMAs of tile t; LDS is
 // double buffered with ONE barrier per K-tile.
 #include "mh_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -30,21 +31,34 @@ struct ConvArgs {
     float alpha, mask_alpha;
 };
 
-constexpr int KT = 16;        // k-values per K-tile
-constexpr int AS = KT + 4;    // LDS row stride of the A tile (floats)
+// LDS tiles are k-contiguous for BOTH operands (As[row][k], Bs[col][k], row stride KT+4 floats) so
+// every lane fetches 4 consecutive k of its row/column with ONE ds_read_b128 and feeds 4 MFMAs:
+// MFMA step (s,t) contracts k = s*16 + (lane>>4)*4 + t -- any k permutation is legal as long as A
+// and B agree.  KT (k-values per K-tile) is 32 for the big tiles and 64 for the small, latency-bound
+// ones: fewer barriers, 2-4x more bytes in flight per barrier.
+// The B tile is written TRANSPOSED in the forward case (global float4 runs along n, LDS rows along k):
+// consecutive lanes then hit rows 4*LS floats apart = the same 2 banks.  XOR-ing the 4-float group
+// index with row bits (bijective per row, keeps each float4 intact) spreads those stores over 16
+// banks; the same involution is applied on the ds_read_b128 side.
+template <int GPT>
+__device__ __forceinline__ int swz_group(int row, int g) { return g ^ ((row >> 2) & (GPT - 1)); }
 
-template <int WM, int WN, int MT, int NT>
+template <int WM, int WN, int MT, int NT, int KT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     constexpr int BM = WM * MT * 16;
     constexpr int BN = WN * NT * 16;
-    constexpr int BS = BN + 4;
-    constexpr int AROWS = (BM + 63) / 64;              // A rows handled per thread
+    constexpr int LS = KT + 4;                         // LDS row stride (floats)
+    constexpr int GPT = KT / 4;                        // 4-channel groups per K-tile
+    constexpr int RPP = 256 / GPT;                     // rows loaded per pass
+    constexpr int AROWS = (BM + RPP - 1) / RPP;
     constexpr int BVEC = KT * BN / 4;                  // float4 items in a B tile
-    constexpr int BITEMS = (BVEC + 255) / 256;         // per thread
+    constexpr int BITEMS = (BVEC + 255) / 256;
 
-    __shared__ __attribute__((aligned(16))) float As[2][BM * AS];
-    __shared__ __attribute__((aligned(16))) float Bs[2][KT * BS];
-    __shared__ int tap_dy[64], tap_dx[64];
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* const As = smem;                            // [2][BM*LS]
+    float* const Bs = smem + 2 * BM * LS;              // [2][BN*LS]
+    int* const tap_dy = reinterpret_cast<int*>(smem + 2 * (BM + BN) * LS);
+    int* const tap_dx = tap_dy + 64;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -65,14 +79,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     }
 
     // ---- per-thread A-row geometry (constant over the K loop) --------------------------
-    const int ga = tid & 3;           // which of the 4 channel groups of a K-tile
-    const int ra = tid >> 2;          // row 0..63
+    const int ga = tid % GPT;          // which channel group of a K-tile
+    const int ra = tid / GPT;          // row within a pass
     int a_by[AROWS], a_bx[AROWS];
     int64_t a_img[AROWS];
     bool a_rowok[AROWS];
 #pragma unroll
     for (int j = 0; j < AROWS; ++j) {
-        const int r = ra + 64 * j;
+        const int r = ra + RPP * j;
         const int m = m0 + r;
         const bool ok = (r < BM) && (m < p.M);
         const int mm = ok ? m : 0;
@@ -90,18 +104,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             a_bx[j] = ox + p.pad_l;
         }
     }
-    // group cursor of this thread's A loads: g = tile*4 + ga  ->  (tap, c4)
-    int a_tap = 0, a_c4 = ga;
+    int a_tap = 0, a_c4 = ga;          // group cursor: g = tile*GPT + ga -> (tap, c4)
     while (a_c4 >= p.G) { a_c4 -= p.G; ++a_tap; }
 
     // ---- per-thread B-item geometry ------------------------------------------------------
-    // w_trans == 0: item q -> row kk = q / (BN/4), n4 = q % (BN/4)      (float4 along n)
-    // w_trans == 1: item q -> n = q >> 2, gb = q & 3                    (float4 along k)
+    // w_trans == 1 (k contiguous in memory): item q -> g = q % GPT, n = q / GPT     (float4 along k)
+    // w_trans == 0 (n contiguous in memory): item q -> n4 = q % (BN/4), kk = q / (BN/4) (float4 along n)
     int b_tap[BITEMS], b_c4[BITEMS];
 #pragma unroll
     for (int j = 0; j < BITEMS; ++j) {
         const int q = tid + 256 * j;
-        const int gb = p.w_trans ? (q & 3) : ((q / (BN / 4)) >> 2);
+        const int gb = p.w_trans ? (q % GPT) : ((q / (BN / 4)) >> 2);
         int t = 0, c = gb;
         while (c >= p.G) { c -= p.G; ++t; }
         b_tap[j] = t; b_c4[j] = c;
@@ -113,7 +126,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     __syncthreads();   // tap tables visible
 
     auto load_tile = [&]() {
-        // A
         {
             const bool gok = a_tap < p.taps;
             const int dy = gok ? tap_dy[a_tap] : 0;
@@ -152,7 +164,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
                 ra_v[j] = v;
             }
         }
-        // B
 #pragma unroll
         for (int j = 0; j < BITEMS; ++j) {
             const int q = tid + 256 * j;
@@ -174,7 +185,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
                         }
                     }
                 } else {
-                    const int n = n0 + (q >> 2);
+                    const int n = n0 + q / GPT;
                     const int k = b_c4[j] * 4;
                     if (n < p.N && k < p.K) {
                         const float* src = p.w + ((int64_t)b_tap[j] * p.N + n) * p.K + k;
@@ -191,21 +202,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             }
             rb_v[j] = v;
         }
-        // advance the group cursors by one K-tile (4 groups)
-        a_c4 += 4;
+        a_c4 += GPT;
         while (a_c4 >= p.G) { a_c4 -= p.G; ++a_tap; }
 #pragma unroll
         for (int j = 0; j < BITEMS; ++j) {
-            b_c4[j] += 4;
+            b_c4[j] += GPT;
             while (b_c4[j] >= p.G) { b_c4[j] -= p.G; ++b_tap[j]; }
         }
     };
 
     auto store_tile = [&](int buf) {
+        float* Ab = As + buf * (BM * LS);
+        float* Bb = Bs + buf * (BN * LS);
 #pragma unroll
         for (int j = 0; j < AROWS; ++j) {
-            const int r = ra + 64 * j;
-            if (r < BM) *reinterpret_cast<float4*>(&As[buf][r * AS + ga * 4]) = ra_v[j];
+            const int r = ra + RPP * j;
+            if (r < BM) *reinterpret_cast<float4*>(&Ab[r * LS + ga * 4]) = ra_v[j];
         }
 #pragma unroll
         for (int j = 0; j < BITEMS; ++j) {
@@ -213,13 +225,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             if (q < BVEC) {
                 if (p.w_trans == 0) {
                     const int kk = q / (BN / 4), n4 = q % (BN / 4);
-                    *reinterpret_cast<float4*>(&Bs[buf][kk * BS + n4 * 4]) = rb_v[j];
+                    // rows n4*4 .. n4*4+3 share (row>>2) = n4 -> one swizzled column for all four
+                    float* d = &Bb[(n4 * 4) * LS + swz_group<GPT>(n4 * 4, kk >> 2) * 4 + (kk & 3)];
+                    d[0] = rb_v[j].x; d[LS] = rb_v[j].y; d[2 * LS] = rb_v[j].z; d[3 * LS] = rb_v[j].w;
                 } else {
-                    const int n = q >> 2, gb = q & 3;
-                    Bs[buf][(gb * 4 + 0) * BS + n] = rb_v[j].x;
-                    Bs[buf][(gb * 4 + 1) * BS + n] = rb_v[j].y;
-                    Bs[buf][(gb * 4 + 2) * BS + n] = rb_v[j].z;
-                    Bs[buf][(gb * 4 + 3) * BS + n] = rb_v[j].w;
+                    const int g = q % GPT, n = q / GPT;
+                    *reinterpret_cast<float4*>(&Bb[n * LS + swz_group<GPT>(n, g) * 4]) = rb_v[j];
                 }
             }
         }
@@ -231,7 +242,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int ntile = (p.taps * p.G + 3) >> 2;
+    const int ntile = (p.taps * p.G + GPT - 1) / GPT;
     const int li = lane & 15, lq = lane >> 4;
 
     load_tile();
@@ -241,20 +252,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     for (int t = 0; t < ntile; ++t) {
         const int buf = t & 1;
         if (t + 1 < ntile) load_tile();
-        const float* Ab = &As[buf][(wm * MT * 16 + li) * AS + lq];
-        const float* Bb = &Bs[buf][lq * BS + wn * NT * 16 + li];
+        const float* Ab = As + buf * (BM * LS) + (wm * MT * 16 + li) * LS + lq * 4;
+        const float* Bb = Bs + buf * (BN * LS) + (wn * NT * 16 + li) * LS;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            float a[MT], b[NT];
+        for (int s = 0; s < KT / 16; ++s) {
+            float4 a[MT], b[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) a[i] = Ab[i * 16 * AS + ks * 4];
+            for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const float4*>(Ab + i * 16 * LS + s * 16);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) b[j] = Bb[ks * 4 * BS + j * 16];
+            for (int j = 0; j < NT; ++j)
+                b[j] = *reinterpret_cast<const float4*>(Bb + j * 16 * LS + swz_group<GPT>(wn * NT * 16 + j * 16 + li, s * 4 + lq) * 4);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                }
         }
         if (t + 1 < ntile) store_tile(buf ^ 1);
         __syncthreads();
@@ -286,47 +302,71 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     }
 }
 
-template <int WM, int WN, int MT, int NT>
+template <int WM, int WN, int MT, int NT, int KT>
 int launch_cfg(ConvArgs& a, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
+    constexpr size_t lds = (size_t)(2 * (BM + BN) * (KT + 4) + 128) * sizeof(float);
+    static bool attr_done = false;       // LDS > 64 KiB needs the opt-in once per instantiation
+    if (!attr_done) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, MT, NT, KT>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { mh_set_error("conv: hipFuncSetAttribute(%d B LDS): %s", (int)lds, hipGetErrorString(e)); return (int)e; }
+        }
+        attr_done = true;
+    }
+    if (s == nullptr && a.M < 0) return 0;   // mh_init(): attribute set-up only
     a.mtiles = mh_cdiv(a.M, BM);
     a.ntiles = mh_cdiv(a.N, BN);
     const int nwg = a.mtiles * a.ntiles;
-    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT>), dim3(nwg), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, KT>), dim3(nwg), dim3(256), lds, s, a);
     return mh_check_launch("conv_igemm");
 }
 
 }  // namespace
 
-// tile-shape heuristic: N tile = smallest available >= min(N,128); M tile as large as
-// possible while still giving the 256 CUs >= ~1.5 workgroups each.
+// tile-shape heuristic: N tile = smallest available >= min(N,128); the largest M tile that still
+// gives the 256 CUs >= ~0.75 workgroups each; big tiles use KT=32, small (latency-bound) ones KT=64.
+// MH_CONV_BM=128|64|32 (environment) forces the M tile for A/B experiments.
+static int forced_bm() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MH_CONV_BM"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
 static int conv_dispatch(ConvArgs& a, hipStream_t s) {
     const int N = a.N;
     const int64_t M = a.M;
     auto wgs = [&](int bm, int bn) { return (int64_t)mh_cdiv(M, bm) * mh_cdiv(N, bn); };
-    const int64_t want = 384;
-    if (N > 96) {
-        if (wgs(128, 128) >= want) return launch_cfg<2, 2, 4, 4>(a, s);
-        if (wgs(64, 128) >= want / 2) return launch_cfg<1, 4, 4, 2>(a, s);
-        if (wgs(64, 64) >= want / 2) return launch_cfg<2, 2, 2, 2>(a, s);
-        return launch_cfg<2, 2, 1, 2>(a, s);                 // 32 x 64
+    const int64_t want = 192;
+    const int bn = N > 96 ? 128 : (N > 64 ? 96 : (N > 32 ? 64 : (N > 16 ? 32 : 16)));
+    int bm = forced_bm();
+    if (bm == 0 || a.M < 0) bm = wgs(128, bn) >= want ? 128 : (wgs(64, bn) >= want / 2 ? 64 : 32);
+    if (bn == 16 && bm == 32) bm = 64;
+    const bool all = a.M < 0;               // mh_init(): touch every instantiation
+    int rc = 0;
+#define MH_CFG(BMv, BNv, ...)                                              \
+    if (all || (bm == BMv && bn == BNv)) {                                 \
+        rc = launch_cfg<__VA_ARGS__>(a, s);                                \
+        if (!all || rc) return rc;                                         \
     }
-    if (N > 64) {
-        if (wgs(128, 96) >= want) return launch_cfg<2, 2, 4, 3>(a, s);
-        if (wgs(64, 96) >= want / 2) return launch_cfg<2, 2, 2, 3>(a, s);
-        return launch_cfg<2, 2, 1, 3>(a, s);                 // 32 x 96
-    }
-    if (N > 32) {
-        if (wgs(128, 64) >= want) return launch_cfg<2, 2, 4, 2>(a, s);
-        if (wgs(64, 64) >= want / 2) return launch_cfg<2, 2, 2, 2>(a, s);
-        return launch_cfg<2, 2, 1, 2>(a, s);                 // 32 x 64
-    }
-    if (N > 16) {
-        if (wgs(128, 32) >= want) return launch_cfg<4, 1, 2, 2>(a, s);
-        return launch_cfg<4, 1, 1, 2>(a, s);                 // 64 x 32
-    }
-    if (wgs(128, 16) >= want) return launch_cfg<4, 1, 2, 1>(a, s);
-    return launch_cfg<4, 1, 1, 1>(a, s);                     // 64 x 16
+    MH_CFG(128, 128, 2, 2, 4, 4, 32) MH_CFG(64, 128, 1, 4, 4, 2, 64) MH_CFG(32, 128, 1, 4, 2, 2, 64)
+    MH_CFG(128, 96, 2, 2, 4, 3, 32)  MH_CFG(64, 96, 2, 2, 2, 3, 64)  MH_CFG(32, 96, 2, 2, 1, 3, 64)
+    MH_CFG(128, 64, 2, 2, 4, 2, 32)  MH_CFG(64, 64, 2, 2, 2, 2, 64)  MH_CFG(32, 64, 2, 2, 1, 2, 64)
+    MH_CFG(128, 32, 4, 1, 2, 2, 32)  MH_CFG(64, 32, 4, 1, 1, 2, 64)  MH_CFG(32, 32, 2, 2, 1, 1, 64)
+    MH_CFG(128, 16, 4, 1, 2, 1, 32)  MH_CFG(64, 16, 4, 1, 1, 1, 64)
+#undef MH_CFG
+    if (all) return 0;
+    mh_set_error("conv_dispatch: no tile configuration for bm=%d bn=%d", bm, bn);
+    return MH_ERR_UNSUPPORTED;
+}
+
+// one-time set-up of the >64 KiB dynamic-LDS opt-in for every instantiation (must not happen
+// inside a hipGraph capture)
+int mh_conv_init() {
+    ConvArgs a{};
+    a.M = -1; a.N = 1;
+    return conv_dispatch(a, nullptr);
 }
 
 extern "C" int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w, const float* bias,

@@ -23,7 +23,16 @@ int mh_check_launch(const char* what) {
     return 0;
 }
 
+int mh_conv_init();
+int mh_wgrad_init();
+
 extern "C" const char* mh_last_error(void) { return g_err; }
+// one-time, capture-unsafe set-up (dynamic-LDS opt-in of every kernel instantiation)
+extern "C" int mh_init(void) {
+    if (int e = mh_conv_init()) return e;
+    if (int e = mh_wgrad_init()) return e;
+    return 0;
+}
 extern "C" int mh_abi_version(void) { return MH_ABI_VERSION; }
 extern "C" int mh_device_count(void) {
     int n = 0;

@@ -6,8 +6,7 @@
 //   reduction index m = output pixel (b,oy,ox);  X[m][(tap,k)] = in[b, oy*s+ky*d-pt, ox*s+kx*d-pl, k]
 // The pixel axis is split over workgroups (grid = taps x k-tiles x n-tiles x splits) and
 // partial tiles are combined with fp32 atomics into the (pre-zeroed) flat gradient buffer.
-// LDS tiles are [16 pixels][channels] so both MFMA operands are read conflict-free with the
-// lane index running along channels.
+// Reduction tile = 32 pixels; LDS tiles are [channel][pixel] (see the kernel comment).
 #include "mh_common.h"
 
 namespace {
@@ -20,19 +19,26 @@ struct WgradArgs {
     int vecA, vecB;
 };
 
-constexpr int PT = 16;   // pixels per reduction tile
+template <int GPT>
+__device__ __forceinline__ int swz_group(int row, int g) { return g ^ ((row >> 2) & (GPT - 1)); }
 
-template <int WM, int WN, int MT, int NT>
+// LDS tiles are [channel][pixel] (pixel-contiguous, row stride PT+4) so that each lane reads 4
+// consecutive reduction indices of its channel with one ds_read_b128 (4 MFMAs per read).  Global
+// loads run along channels (NHWC), so the tiles are written transposed with scalar stores; the
+// 4-float group index is XOR-swizzled with row bits to spread those stores over the banks.
+template <int WM, int WN, int MT, int NT, int PT>
 __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
     constexpr int NTH = 64 * WM * WN;
     constexpr int BK = WM * MT * 16;     // k (input-channel) rows of the dW tile
     constexpr int BN = WN * NT * 16;
-    constexpr int ASs = BK + 4, BSs = BN + 4;
+    constexpr int LS = PT + 4;
+    constexpr int GPT = PT / 4;
     constexpr int AVEC = PT * BK / 4, BVEC = PT * BN / 4;
     constexpr int AITEMS = (AVEC + NTH - 1) / NTH, BITEMS = (BVEC + NTH - 1) / NTH;
 
-    __shared__ __attribute__((aligned(16))) float As[2][PT * ASs];
-    __shared__ __attribute__((aligned(16))) float Bs[2][PT * BSs];
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* const As = smem;                    // [2][BK*LS]
+    float* const Bs = smem + 2 * BK * LS;      // [2][BN*LS]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -91,7 +97,6 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
                 }
             }
             ra_v[j] = v;
-            // advance this item's pixel by PT
             a_m[j] += PT;
             a_ox[j] += PT;
             while (a_ox[j] >= p.Wo) {
@@ -123,12 +128,15 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
     };
 
     auto store_tile = [&](int buf) {
+        float* Ab = As + buf * (BK * LS);
+        float* Bb = Bs + buf * (BN * LS);
 #pragma unroll
         for (int j = 0; j < AITEMS; ++j) {
             const int q = tid + NTH * j;
             if (q < AVEC) {
                 const int kp = q / (BK / 4), c4 = q % (BK / 4);
-                *reinterpret_cast<float4*>(&As[buf][kp * ASs + c4 * 4]) = ra_v[j];
+                float* d = &Ab[(c4 * 4) * LS + swz_group<GPT>(c4 * 4, kp >> 2) * 4 + (kp & 3)];
+                d[0] = ra_v[j].x; d[LS] = ra_v[j].y; d[2 * LS] = ra_v[j].z; d[3 * LS] = ra_v[j].w;
             }
         }
 #pragma unroll
@@ -136,7 +144,8 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
             const int q = tid + NTH * j;
             if (q < BVEC) {
                 const int kp = q / (BN / 4), n4 = q % (BN / 4);
-                *reinterpret_cast<float4*>(&Bs[buf][kp * BSs + n4 * 4]) = rb_v[j];
+                float* d = &Bb[(n4 * 4) * LS + swz_group<GPT>(n4 * 4, kp >> 2) * 4 + (kp & 3)];
+                d[0] = rb_v[j].x; d[LS] = rb_v[j].y; d[2 * LS] = rb_v[j].z; d[3 * LS] = rb_v[j].w;
             }
         }
     };
@@ -157,24 +166,34 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
     for (int t = 0; t < ntile; ++t) {
         const int buf = t & 1;
         if (t + 1 < ntile) load_tile();
-        const float* Ab = &As[buf][lq * ASs + wm * MT * 16 + li];
-        const float* Bb = &Bs[buf][lq * BSs + wn * NT * 16 + li];
+        const float* Ab = As + buf * (BK * LS) + (wm * MT * 16 + li) * LS;
+        const float* Bb = Bs + buf * (BN * LS) + (wn * NT * 16 + li) * LS;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            float a[MT], b[NT];
+        for (int s = 0; s < PT / 16; ++s) {
+            float4 a[MT], b[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) a[i] = Ab[ks * 4 * ASs + i * 16];
+            for (int i = 0; i < MT; ++i)
+                a[i] = *reinterpret_cast<const float4*>(Ab + i * 16 * LS + swz_group<GPT>(wm * MT * 16 + i * 16 + li, s * 4 + lq) * 4);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) b[j] = Bb[ks * 4 * BSs + j * 16];
+            for (int j = 0; j < NT; ++j)
+                b[j] = *reinterpret_cast<const float4*>(Bb + j * 16 * LS + swz_group<GPT>(wn * NT * 16 + j * 16 + li, s * 4 + lq) * 4);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                }
         }
         if (do_bias) {
+            const float* row = Bs + buf * (BN * LS) + tid * LS;   // swizzle permutes within the row: the sum is unaffected
 #pragma unroll
-            for (int kp = 0; kp < PT; ++kp) bsum += Bs[buf][kp * BSs + tid];
+            for (int g = 0; g < GPT; ++g) {
+                const float4 v = *reinterpret_cast<const float4*>(row + g * 4);
+                bsum += (v.x + v.y) + (v.z + v.w);
+            }
         }
         if (t + 1 < ntile) store_tile(buf ^ 1);
         __syncthreads();
@@ -195,26 +214,69 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
     if (do_bias && n0 + tid < p.N) atomicAdd(p.db + n0 + tid, bsum);
 }
 
-template <int WM, int WN, int MT, int NT>
+template <int WM, int WN, int MT, int NT, int PT>
 int launch_wgrad(WgradArgs& a, hipStream_t s) {
     constexpr int BK = WM * MT * 16, BN = WN * NT * 16;
+    constexpr size_t lds = (size_t)(2 * (BK + BN) * (PT + 4)) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<WM, WN, MT, NT, PT>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { mh_set_error("wgrad: hipFuncSetAttribute(%d B LDS): %s", (int)lds, hipGetErrorString(e)); return (int)e; }
+        }
+        attr_done = true;
+    }
+    if (a.M < 0) return 0;               // mh_init(): attribute set-up only
     a.ktiles = mh_cdiv(a.K, BK);
     a.ntiles = mh_cdiv(a.N, BN);
     const int base = a.taps * a.ktiles * a.ntiles;
-    // enough pixel splits for ~3 workgroups per CU, but keep >= 8 reduction tiles per split
+    // enough pixel splits for ~3 workgroups per CU, but keep >= 4 reduction tiles per split
     int splits = mh_cdiv(768, base);
-    const int maxs = mh_cdiv(a.M, PT * 8);
+    const int maxs = mh_cdiv(a.M, PT * 4);
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;
     int chunk = mh_cdiv(a.M, splits);
     chunk = (chunk + PT - 1) / PT * PT;
     a.splits = mh_cdiv(a.M, chunk);
     a.chunk = chunk;
-    hipLaunchKernelGGL((wgrad_kernel<WM, WN, MT, NT>), dim3(base * a.splits), dim3(64 * WM * WN), 0, s, a);
+    hipLaunchKernelGGL((wgrad_kernel<WM, WN, MT, NT, PT>), dim3(base * a.splits), dim3(64 * WM * WN), lds, s, a);
     return mh_check_launch("wgrad");
 }
 
+static int wgrad_dispatch(WgradArgs& a, hipStream_t s) {
+    const int K = a.K, N = a.N;
+    const bool all = a.M < 0;
+    int rc = 0;
+#define MH_WG(cond, ...)                                       \
+    if (all || (cond)) {                                       \
+        rc = launch_wgrad<__VA_ARGS__>(a, s);                  \
+        if (!all || rc) return rc;                             \
+    }
+    // dW tile shape from the channel counts (rows = K = Cin, cols = N = Cout)
+    MH_WG(K > 64 && N > 64, 2, 2, 4, 4, 32)                 // 128 x 128
+    MH_WG(K > 64 && N > 32 && N <= 64, 2, 2, 4, 2, 32)      // 128 x 64
+    MH_WG(K > 64 && N <= 32, 4, 1, 2, 1, 32)                // 128 x 16
+    MH_WG(K > 32 && K <= 64 && N > 64, 2, 2, 2, 4, 32)      // 64 x 128
+    MH_WG(K > 32 && K <= 64 && N > 32 && N <= 64, 2, 2, 2, 2, 32)   // 64 x 64
+    MH_WG(K > 32 && K <= 64 && N <= 32, 4, 1, 1, 1, 32)     // 64 x 16
+    MH_WG(K > 16 && K <= 32 && N > 64, 1, 4, 2, 2, 32)      // 32 x 128
+    MH_WG(K > 16 && K <= 32 && N > 16 && N <= 64, 2, 2, 1, 1, 32)   // 32 x 32
+    MH_WG(K > 16 && K <= 32 && N <= 16, 2, 1, 1, 1, 32)     // 32 x 16
+    MH_WG(K <= 16 && N > 64, 1, 4, 1, 2, 32)                // 16 x 128
+    MH_WG(K <= 16 && N > 16 && N <= 64, 1, 2, 1, 1, 32)     // 16 x 32
+    MH_WG(K <= 16 && N <= 16, 1, 1, 1, 1, 32)               // 16 x 16
+#undef MH_WG
+    return 0;
+}
+
 }  // namespace
+
+int mh_wgrad_init() {
+    WgradArgs a{};
+    a.M = -1; a.K = 1; a.N = 1;
+    return wgrad_dispatch(a, nullptr);
+}
 
 extern "C" int mh_conv2d_wgrad(const mh_conv_desc* d, const float* in, const float* dout, int32_t dout_ld,
                                float* dw, float* db, void* stream) {
@@ -232,19 +294,5 @@ extern "C" int mh_conv2d_wgrad(const mh_conv_desc* d, const float* in, const flo
     a.M = d->B * d->Ho * d->Wo; a.taps = d->kh * d->kw;
     a.vecA = mh_aligned16(in) && (d->in_ld % 4 == 0) && (d->in_ld >= ((d->K + 3) & ~3));
     a.vecB = mh_aligned16(dout) && (dout_ld % 4 == 0) && (d->N % 4 == 0);
-    hipStream_t s = (hipStream_t)stream;
-    const int K = a.K, N = a.N;
-    // dW tile shape from the channel counts (rows = K, cols = N)
-    if (K > 64 && N > 64) return launch_wgrad<2, 2, 4, 4>(a, s);      // 128 x 128
-    if (K > 64 && N > 32) return launch_wgrad<2, 2, 4, 2>(a, s);      // 128 x 64
-    if (K > 64) return launch_wgrad<4, 1, 2, (1)>(a, s);              // 128 x 16  (N <= 32: 2 n-tiles at most)
-    if (K > 32 && N > 64) return launch_wgrad<2, 2, 2, 4>(a, s);      // 64 x 128
-    if (K > 32 && N > 32) return launch_wgrad<2, 2, 2, 2>(a, s);      // 64 x 64
-    if (K > 32) return launch_wgrad<4, 1, 1, 1>(a, s);                // 64 x 16
-    if (K > 16 && N > 64) return launch_wgrad<1, 4, 2, 2>(a, s);      // 32 x 128
-    if (K > 16 && N > 16) return launch_wgrad<2, 2, 1, 1>(a, s);      // 32 x 32
-    if (K > 16) return launch_wgrad<2, 1, 1, 1>(a, s);                // 32 x 16
-    if (N > 64) return launch_wgrad<1, 4, 1, 2>(a, s);                // 16 x 128
-    if (N > 16) return launch_wgrad<1, 2, 1, 1>(a, s);                // 16 x 32
-    return launch_wgrad<1, 1, 1, 1>(a, s);                            // 16 x 16
+    return wgrad_dispatch(a, (hipStream_t)stream);
 }

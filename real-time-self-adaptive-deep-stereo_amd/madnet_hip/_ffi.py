@@ -40,6 +40,7 @@ SIGNATURES = {
     "mh_last_error": (C.c_char_p, []),
     "mh_abi_version": (_I, []),
     "mh_device_count": (_I, []),
+    "mh_init": (_I, []),
     "mh_conv2d": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     "mh_conv2d_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _I, _P, _P, _P]),
     "mh_corr_fwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -94,6 +95,12 @@ class Lib(object):
                 setattr(self, name[3:], fn)
             else:
                 setattr(self, name[3:], self._checked(name, fn))
+        self._inited = False
+
+    def ensure_init(self):
+        if not self._inited:
+            self.init()
+            self._inited = True
 
     def _checked(self, name, fn):
         def call(*a):
@@ -118,5 +125,6 @@ def lib():
         if n <= 0:
             raise MadnetHipError("libmadnet_hip.so loaded but no HIP device is visible (mh_device_count=%d); "
                                  "the MI355X path has no CPU fallback" % n)
+        l.ensure_init()
         _lib = l
     return _lib

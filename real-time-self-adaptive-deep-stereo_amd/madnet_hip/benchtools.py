@@ -43,7 +43,7 @@ def roofline(lib, eng, stream, reps=20):
     ms = _time_ms(lib, stream, conv, reps)
     flops = 2.0 * x.B * x.H * x.W * 9 * 128 * 128
     ach = flops / (ms * 1e-3) / 1e12
-    rl = {"kernel": "conv_igemm_kernel<2,2,4,4> (3x3 128->128 @ %dx%d, dil 2)" % (x.H, x.W),
+    rl = {"kernel": "conv_igemm_kernel (3x3 128->128 @ %dx%d, dil 2; tile chosen by conv_dispatch)" % (x.H, x.W),
           "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
           "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
           "launch_ms": ms, "algorithmic_flops_per_launch": flops}

@@ -61,10 +61,12 @@ def make_pair(h=375, w=1242, stream_id=0, frame=0):
 
 
 def xavier_weights(shapes, seed=0):
-    """shapes: ordered {name: shape}.  Returns {name: float32 ndarray}."""
-    rng = np.random.default_rng(seed)
+    """shapes: {name: shape}.  Returns {name: float32 ndarray}.  Every tensor has its own stream
+    seeded by (seed, crc32(name)), so the values do not depend on the iteration order of `shapes`."""
+    import zlib
     out = {}
     for name, shp in shapes.items():
+        rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
         if len(shp) == 1:
             out[name] = np.zeros(shp, np.float32)
         else:

@@ -44,7 +44,9 @@ def _emul_backend():
         r = subprocess.run(["make", "-C", d, "-j8"], capture_output=True, text=True)
         if r.returncode != 0:
             pytest.skip("emulator build failed: " + r.stderr[-400:])
-        _cache["emul"] = Backend("emul", _ffi.Lib(os.path.join(d, "libmadnet_emul.so")), "cpu")
+        lib = _ffi.Lib(os.path.join(d, "libmadnet_emul.so"))
+        lib.ensure_init()
+        _cache["emul"] = Backend("emul", lib, "cpu")
     return _cache["emul"]
 
 
