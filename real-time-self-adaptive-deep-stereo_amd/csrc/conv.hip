@@ -24,7 +24,8 @@ struct ConvArgs {
     int B, Hi, Wi, Ho, Wo;
     int K, N, G, taps;
     int kh, kw, stride, dil, pad_t, pad_l;
-    int mode, w_trans, accumulate;
+    int mode, w_trans, accumulate, sshift;
+    unsigned in_bytes, w_bytes;
     int M;           // B*Ho*Wo
     int vecA, vecB;  // 16-byte vector loads legal for A / B
     int mtiles, ntiles;
@@ -43,7 +44,11 @@ struct ConvArgs {
 template <int GPT>
 __device__ __forceinline__ int swz_group(int row, int g) { return g ^ ((row >> 2) & (GPT - 1)); }
 
-template <int WM, int WN, int MT, int NT, int KT>
+// DGRAD selects the gather geometry + weight orientation at compile time (forward: mode 0 / HWIO
+// rows along n; dgrad & conv2d_transpose: mode 1 / rows along k); VEC = 16-byte global loads legal.
+// Every global load is UNCONDITIONAL (clamped address + select): a load inside a conditional block
+// makes hipcc drain vmcnt(0) before the MFMA block and kills the prefetch overlap.
+template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool VEC>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     constexpr int BM = WM * MT * 16;
     constexpr int BN = WN * NT * 16;
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     const int ga = tid % GPT;          // which channel group of a K-tile
     const int ra = tid / GPT;          // row within a pass
     int a_by[AROWS], a_bx[AROWS];
-    int64_t a_img[AROWS];
+    int a_img[AROWS];
     bool a_rowok[AROWS];
 #pragma unroll
     for (int j = 0; j < AROWS; ++j) {
@@ -95,8 +100,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         const int oy = t2 % p.Ho;
         const int b = t2 / p.Ho;
         a_rowok[j] = ok;
-        a_img[j] = (int64_t)b * p.Hi * p.Wi;
-        if (p.mode == 0) {
+        a_img[j] = b * p.Hi * p.Wi;
+        if (!DGRAD) {
             a_by[j] = oy * p.stride - p.pad_t;
             a_bx[j] = ox * p.stride - p.pad_l;
         } else {
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
     for (int j = 0; j < BITEMS; ++j) {
         const int q = tid + 256 * j;
-        const int gb = p.w_trans ? (q % GPT) : ((q / (BN / 4)) >> 2);
+        const int gb = DGRAD ? (q % GPT) : ((q / (BN / 4)) >> 2);
         int t = 0, c = gb;
         while (c >= p.G) { c -= p.G; ++t; }
         b_tap[j] = t; b_c4[j] = c;
@@ -125,41 +130,38 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 
     __syncthreads();   // tap tables visible
 
+    int a_kb_st = 0;    // kbase of the tile currently held in ra_v (used when it is stored)
+    const __amdgpu_buffer_rsrc_t rs_in = mh_make_rsrc(p.in, p.in_bytes);
+    const __amdgpu_buffer_rsrc_t rs_w = mh_make_rsrc(p.w, p.w_bytes);
+
     auto load_tile = [&]() {
         {
             const bool gok = a_tap < p.taps;
-            const int dy = gok ? tap_dy[a_tap] : 0;
-            const int dx = gok ? tap_dx[a_tap] : 0;
+            const int tapc = gok ? a_tap : 0;
+            const int dy = tap_dy[tapc], dx = tap_dx[tapc];
             const int kbase = a_c4 * 4;
+            a_kb_st = kbase;
 #pragma unroll
             for (int j = 0; j < AROWS; ++j) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 bool ok = gok && a_rowok[j];
                 int iy, ix;
-                if (p.mode == 0) {
+                if (!DGRAD) {
                     iy = a_by[j] + dy; ix = a_bx[j] + dx;
-                    ok = ok && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
                 } else {
                     const int ny = a_by[j] - dy, nx = a_bx[j] - dx;
-                    ok = ok && ny >= 0 && nx >= 0;
-                    iy = ny / p.stride; ix = nx / p.stride;
-                    ok = ok && (iy * p.stride == ny) && (ix * p.stride == nx) && iy < p.Hi && ix < p.Wi;
+                    iy = ny >> p.sshift; ix = nx >> p.sshift;            // stride is a power of two
+                    ok = ok && ((iy << p.sshift) == ny) && ((ix << p.sshift) == nx);
                 }
-                if (ok) {
-                    const float* src = p.in + (a_img[j] + (int64_t)iy * p.Wi + ix) * p.in_ld + kbase;
-                    if (p.vecA) {
-                        v = *reinterpret_cast<const float4*>(src);
-                        if (kbase + 3 >= p.K) {     // last group: zero the channel padding
-                            if (kbase + 1 >= p.K) v.y = 0.f;
-                            if (kbase + 2 >= p.K) v.z = 0.f;
-                            v.w = 0.f;
-                        }
-                    } else {
-                        if (kbase + 0 < p.K) v.x = src[0];
-                        if (kbase + 1 < p.K) v.y = src[1];
-                        if (kbase + 2 < p.K) v.z = src[2];
-                        if (kbase + 3 < p.K) v.w = src[3];
-                    }
+                ok = ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+                const int off = ((a_img[j] + iy * p.Wi + ix) * p.in_ld + kbase) * 4;      // bytes (< 2 GiB)
+                float4 v;
+                if (VEC) {
+                    v = mh_buf_load4(rs_in, ok ? off : MH_OOB);   // channel padding is zeroed at store time
+                } else {
+                    v.x = mh_buf_load1(rs_in, ok ? off : MH_OOB);
+                    v.y = mh_buf_load1(rs_in, (ok && kbase + 1 < p.K) ? off + 4 : MH_OOB);
+                    v.z = mh_buf_load1(rs_in, (ok && kbase + 2 < p.K) ? off + 8 : MH_OOB);
+                    v.w = mh_buf_load1(rs_in, (ok && kbase + 3 < p.K) ? off + 12 : MH_OOB);
                 }
                 ra_v[j] = v;
             }
@@ -167,38 +169,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < BITEMS; ++j) {
             const int q = tid + 256 * j;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q < BVEC && b_tap[j] < p.taps) {
-                if (p.w_trans == 0) {
-                    const int kk = q / (BN / 4), n4 = q % (BN / 4);
-                    const int k = b_c4[j] * 4 + (kk & 3);
-                    const int n = n0 + n4 * 4;
-                    if (k < p.K && n < p.N) {
-                        const float* src = p.w + ((int64_t)b_tap[j] * p.K + k) * p.N + n;
-                        if (p.vecB) {
-                            v = *reinterpret_cast<const float4*>(src);
-                        } else {
-                            v.x = src[0];
-                            if (n + 1 < p.N) v.y = src[1];
-                            if (n + 2 < p.N) v.z = src[2];
-                            if (n + 3 < p.N) v.w = src[3];
-                        }
-                    }
-                } else {
-                    const int n = n0 + q / GPT;
-                    const int k = b_c4[j] * 4;
-                    if (n < p.N && k < p.K) {
-                        const float* src = p.w + ((int64_t)b_tap[j] * p.N + n) * p.K + k;
-                        if (p.vecB) {
-                            v = *reinterpret_cast<const float4*>(src);
-                        } else {
-                            v.x = src[0];
-                            if (k + 1 < p.K) v.y = src[1];
-                            if (k + 2 < p.K) v.z = src[2];
-                            if (k + 3 < p.K) v.w = src[3];
-                        }
-                    }
-                }
+            const bool live = (q < BVEC) && (b_tap[j] < p.taps);
+            int k, n;
+            if (!DGRAD) {
+                const int kk = q / (BN / 4), n4 = q % (BN / 4);
+                k = b_c4[j] * 4 + (kk & 3);
+                n = n0 + n4 * 4;
+            } else {
+                n = n0 + q / GPT;
+                k = b_c4[j] * 4;
+            }
+            const bool ok = live && k < p.K && n < p.N;
+            // forward: w[tap][k][n] (float4 along n) ; dgrad: w[tap][n][k] (float4 along k)
+            const int off = (!DGRAD ? (b_tap[j] * p.K + k) * p.N + n : (b_tap[j] * p.N + n) * p.K + k) * 4;
+            const int lim = !DGRAD ? p.N - n : p.K - k;      // valid elements of the run starting at off
+            float4 v;
+            if (VEC) {
+                v = mh_buf_load4(rs_w, ok ? off : MH_OOB);
+            } else {
+                v.x = mh_buf_load1(rs_w, ok ? off : MH_OOB);
+                v.y = mh_buf_load1(rs_w, (ok && lim > 1) ? off + 4 : MH_OOB);
+                v.z = mh_buf_load1(rs_w, (ok && lim > 2) ? off + 8 : MH_OOB);
+                v.w = mh_buf_load1(rs_w, (ok && lim > 3) ? off + 12 : MH_OOB);
             }
             rb_v[j] = v;
         }
@@ -217,13 +209,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < AROWS; ++j) {
             const int r = ra + RPP * j;
-            if (r < BM) *reinterpret_cast<float4*>(&Ab[r * LS + ga * 4]) = ra_v[j];
+            float4 v = ra_v[j];
+            if (VEC) {   // zero the channel padding of the last group HERE (after the MFMAs), not at the
+                         // load: a select on the loaded value would force an early s_waitcnt vmcnt
+                v.y = (a_kb_st + 1 < p.K) ? v.y : 0.f;
+                v.z = (a_kb_st + 2 < p.K) ? v.z : 0.f;
+                v.w = (a_kb_st + 3 < p.K) ? v.w : 0.f;
+            }
+            if (r < BM) *reinterpret_cast<float4*>(&Ab[r * LS + ga * 4]) = v;
         }
 #pragma unroll
         for (int j = 0; j < BITEMS; ++j) {
             const int q = tid + 256 * j;
             if (q < BVEC) {
-                if (p.w_trans == 0) {
+                if (!DGRAD) {
                     const int kk = q / (BN / 4), n4 = q % (BN / 4);
                     // rows n4*4 .. n4*4+3 share (row>>2) = n4 -> one swizzled column for all four
                     float* d = &Bb[(n4 * 4) * LS + swz_group<GPT>(n4 * 4, kk >> 2) * 4 + (kk & 3)];
@@ -302,25 +301,37 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     }
 }
 
-template <int WM, int WN, int MT, int NT, int KT>
-int launch_cfg(ConvArgs& a, hipStream_t s) {
+template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool VEC>
+int launch_one(ConvArgs& a, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
     constexpr size_t lds = (size_t)(2 * (BM + BN) * (KT + 4) + 128) * sizeof(float);
     static bool attr_done = false;       // LDS > 64 KiB needs the opt-in once per instantiation
     if (!attr_done) {
         if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, MT, NT, KT>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) { mh_set_error("conv: hipFuncSetAttribute(%d B LDS): %s", (int)lds, hipGetErrorString(e)); return (int)e; }
         }
         attr_done = true;
     }
-    if (s == nullptr && a.M < 0) return 0;   // mh_init(): attribute set-up only
+    if (a.M < 0) return 0;               // mh_init(): attribute set-up only
     a.mtiles = mh_cdiv(a.M, BM);
     a.ntiles = mh_cdiv(a.N, BN);
     const int nwg = a.mtiles * a.ntiles;
-    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, KT>), dim3(nwg), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC>), dim3(nwg), dim3(256), lds, s, a);
     return mh_check_launch("conv_igemm");
+}
+
+template <int WM, int WN, int MT, int NT, int KT>
+int launch_cfg(ConvArgs& a, hipStream_t s) {
+    const bool all = a.M < 0;
+    const bool dg = a.mode == 1, vec = a.vecA && a.vecB;
+    int rc = 0;
+    if (all || (!dg && vec)) { rc = launch_one<WM, WN, MT, NT, KT, false, true>(a, s); if (!all || rc) return rc; }
+    if (all || (!dg && !vec)) { rc = launch_one<WM, WN, MT, NT, KT, false, false>(a, s); if (!all || rc) return rc; }
+    if (all || (dg && vec)) { rc = launch_one<WM, WN, MT, NT, KT, true, true>(a, s); if (!all || rc) return rc; }
+    if (all || (dg && !vec)) { rc = launch_one<WM, WN, MT, NT, KT, true, false>(a, s); if (!all || rc) return rc; }
+    return rc;
 }
 
 }  // namespace
@@ -350,9 +361,9 @@ static int conv_dispatch(ConvArgs& a, hipStream_t s) {
         rc = launch_cfg<__VA_ARGS__>(a, s);                                \
         if (!all || rc) return rc;                                         \
     }
-    MH_CFG(128, 128, 2, 2, 4, 4, 32) MH_CFG(64, 128, 1, 4, 4, 2, 64) MH_CFG(32, 128, 1, 4, 2, 2, 64)
-    MH_CFG(128, 96, 2, 2, 4, 3, 32)  MH_CFG(64, 96, 2, 2, 2, 3, 64)  MH_CFG(32, 96, 2, 2, 1, 3, 64)
-    MH_CFG(128, 64, 2, 2, 4, 2, 32)  MH_CFG(64, 64, 2, 2, 2, 2, 64)  MH_CFG(32, 64, 2, 2, 1, 2, 64)
+    MH_CFG(128, 128, 2, 2, 4, 4, 32) MH_CFG(64, 128, 1, 4, 4, 2, 32) MH_CFG(32, 128, 1, 4, 2, 2, 64)
+    MH_CFG(128, 96, 2, 2, 4, 3, 32)  MH_CFG(64, 96, 2, 2, 2, 3, 32)  MH_CFG(32, 96, 2, 2, 1, 3, 64)
+    MH_CFG(128, 64, 2, 2, 4, 2, 32)  MH_CFG(64, 64, 2, 2, 2, 2, 32)  MH_CFG(32, 64, 2, 2, 1, 2, 64)
     MH_CFG(128, 32, 4, 1, 2, 2, 32)  MH_CFG(64, 32, 4, 1, 1, 2, 64)  MH_CFG(32, 32, 2, 2, 1, 1, 64)
     MH_CFG(128, 16, 4, 1, 2, 1, 32)  MH_CFG(64, 16, 4, 1, 1, 1, 64)
 #undef MH_CFG
@@ -385,6 +396,17 @@ extern "C" int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w,
     a.K = d->K; a.N = d->N; a.G = (d->K + 3) / 4; a.taps = d->kh * d->kw;
     a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.dil = d->dil; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
     a.mode = d->mode; a.w_trans = d->w_trans; a.accumulate = d->accumulate;
+    MH_REQUIRE(d->mode == d->w_trans && (d->mode == 0 || d->mode == 1), MH_ERR_UNSUPPORTED,
+               "mh_conv2d: supported combinations are mode=0/w_trans=0 (forward) and mode=1/w_trans=1 (dgrad, conv2d_transpose)");
+    {
+        const int64_t inb = (((int64_t)d->B * d->Hi * d->Wi - 1) * d->in_ld + (int64_t)((d->K + 3) / 4) * 4) * 4;
+        const int64_t wb = (int64_t)d->kh * d->kw * d->K * d->N * 4;
+        MH_REQUIRE(inb < (1ll << 31) - 64 && wb < (1ll << 31) - 64, MH_ERR_UNSUPPORTED, "mh_conv2d: tensors must be < 2 GiB (32-bit buffer offsets)");
+        a.in_bytes = (unsigned)inb; a.w_bytes = (unsigned)wb;
+    }
+    a.sshift = 0;
+    while ((1 << a.sshift) < d->stride) ++a.sshift;
+    MH_REQUIRE(d->mode == 0 || (1 << a.sshift) == d->stride, MH_ERR_UNSUPPORTED, "mh_conv2d: mode 1 needs a power-of-two stride");
     a.M = d->B * d->Ho * d->Wo;
     a.alpha = d->alpha; a.mask_alpha = d->mask_alpha;
     // 16-byte vector loads of A need every group start 16B aligned and the full group in-bounds

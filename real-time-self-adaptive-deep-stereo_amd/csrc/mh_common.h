@@ -25,6 +25,26 @@ int mh_check_launch(const char* what);
 static inline int mh_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline bool mh_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// ---- buffer (SRD) loads with hardware bounds checking --------------------------------------
+// Every tile load of the GEMM kernels goes through a raw buffer descriptor built from kernel
+// arguments (wave-uniform => no waterfall loop): an element that must read as zero (outside the
+// image, padded tap, past the tensor) simply gets an out-of-range byte offset and the hardware
+// returns 0 -- the load itself stays UNCONDITIONAL, so hipcc keeps it in flight across the MFMA
+// block instead of draining vmcnt(0) at a branch join (cdna_hip_programming.md trap (c), T8).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define MH_OOB ((int)0x7fffffff)          /* > any num_records we accept (tensors < 2 GiB) */
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mh_make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 mh_buf_load4(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+    return __builtin_bit_cast(float4, v);
+}
+__device__ __forceinline__ float mh_buf_load1(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+
 // XCD-aware, bijective remap of a linear workgroup id (8 XCDs; block b runs on XCD b%8):
 // every XCD gets a contiguous chunk of the logical tile space so neighbouring tiles share
 // one L2 (cdna_hip_programming.md T1, bijective variant).

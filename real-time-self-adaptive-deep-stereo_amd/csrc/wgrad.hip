@@ -17,6 +17,7 @@ struct WgradArgs {
     int B, Hi, Wi, Ho, Wo, K, N, kh, kw, stride, dil, pad_t, pad_l;
     int M, taps, ktiles, ntiles, splits, chunk;
     int vecA, vecB;
+    unsigned in_bytes, dz_bytes;
 };
 
 template <int GPT>
@@ -26,7 +27,7 @@ __device__ __forceinline__ int swz_group(int row, int g) { return g ^ ((row >> 2
 // consecutive reduction indices of its channel with one ds_read_b128 (4 MFMAs per read).  Global
 // loads run along channels (NHWC), so the tiles are written transposed with scalar stores; the
 // 4-float group index is XOR-swizzled with row bits to spread those stores over the banks.
-template <int WM, int WN, int MT, int NT, int PT>
+template <int WM, int WN, int MT, int NT, int PT, bool VEC>
 __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
     constexpr int NTH = 64 * WM * WN;
     constexpr int BK = WM * MT * 16;     // k (input-channel) rows of the dW tile
@@ -75,26 +76,28 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
     float4 ra_v[AITEMS], rb_v[BITEMS];
     int tile_ld = 0;   // tiles loaded so far
 
+    const __amdgpu_buffer_rsrc_t rs_in = mh_make_rsrc(p.in, p.in_bytes);
+    const __amdgpu_buffer_rsrc_t rs_dz = mh_make_rsrc(p.dz, p.dz_bytes);
+
+    // all tile loads are unconditional buffer loads (out-of-range offset => 0), see mh_common.h
     auto load_tile = [&]() {
 #pragma unroll
         for (int j = 0; j < AITEMS; ++j) {
             const int q = tid + NTH * j;
             const int c4 = q % (BK / 4);
             const int k = k0 + c4 * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q < AVEC && a_m[j] < mend && k < Kr) {
-                const int iy = a_oy[j] * p.stride + dy, ix = a_ox[j] * p.stride + dx;
-                if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) {
-                    const float* src = p.in + (((int64_t)a_b[j] * p.Hi + iy) * p.Wi + ix) * p.in_ld + k;
-                    if (p.vecA) {
-                        v = *reinterpret_cast<const float4*>(src);
-                    } else {
-                        if (k + 0 < p.K) v.x = src[0];
-                        if (k + 1 < p.K) v.y = src[1];
-                        if (k + 2 < p.K) v.z = src[2];
-                        if (k + 3 < p.K) v.w = src[3];
-                    }
-                }
+            const int iy = a_oy[j] * p.stride + dy, ix = a_ox[j] * p.stride + dx;
+            const bool ok = (q < AVEC) && (a_m[j] < mend) && (k < Kr) &&
+                            (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const int off = (((a_b[j] * p.Hi + iy) * p.Wi + ix) * p.in_ld + k) * 4;
+            float4 v;
+            if (VEC) {
+                v = mh_buf_load4(rs_in, ok ? off : MH_OOB);
+            } else {
+                v.x = mh_buf_load1(rs_in, (ok && k + 0 < p.K) ? off : MH_OOB);
+                v.y = mh_buf_load1(rs_in, (ok && k + 1 < p.K) ? off + 4 : MH_OOB);
+                v.z = mh_buf_load1(rs_in, (ok && k + 2 < p.K) ? off + 8 : MH_OOB);
+                v.w = mh_buf_load1(rs_in, (ok && k + 3 < p.K) ? off + 12 : MH_OOB);
             }
             ra_v[j] = v;
             a_m[j] += PT;
@@ -110,17 +113,16 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
             const int kp = q / (BN / 4), n4 = q % (BN / 4);
             const int m = mbeg + tile_ld * PT + kp;
             const int n = n0 + n4 * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q < BVEC && m < mend && n < p.N) {
-                const float* src = p.dz + (int64_t)m * p.dz_ld + n;
-                if (p.vecB) {
-                    v = *reinterpret_cast<const float4*>(src);
-                } else {
-                    v.x = src[0];
-                    if (n + 1 < p.N) v.y = src[1];
-                    if (n + 2 < p.N) v.z = src[2];
-                    if (n + 3 < p.N) v.w = src[3];
-                }
+            const bool ok = (q < BVEC) && (m < mend) && (n < p.N);
+            const int off = (m * p.dz_ld + n) * 4;
+            float4 v;
+            if (VEC) {
+                v = mh_buf_load4(rs_dz, ok ? off : MH_OOB);
+            } else {
+                v.x = mh_buf_load1(rs_dz, ok ? off : MH_OOB);
+                v.y = mh_buf_load1(rs_dz, (ok && n + 1 < p.N) ? off + 4 : MH_OOB);
+                v.z = mh_buf_load1(rs_dz, (ok && n + 2 < p.N) ? off + 8 : MH_OOB);
+                v.w = mh_buf_load1(rs_dz, (ok && n + 3 < p.N) ? off + 12 : MH_OOB);
             }
             rb_v[j] = v;
         }
@@ -214,14 +216,14 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
     if (do_bias && n0 + tid < p.N) atomicAdd(p.db + n0 + tid, bsum);
 }
 
-template <int WM, int WN, int MT, int NT, int PT>
-int launch_wgrad(WgradArgs& a, hipStream_t s) {
+template <int WM, int WN, int MT, int NT, int PT, bool VEC>
+int launch_wgrad_one(WgradArgs& a, hipStream_t s) {
     constexpr int BK = WM * MT * 16, BN = WN * NT * 16;
     constexpr size_t lds = (size_t)(2 * (BK + BN) * (PT + 4)) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
         if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<WM, WN, MT, NT, PT>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<WM, WN, MT, NT, PT, VEC>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) { mh_set_error("wgrad: hipFuncSetAttribute(%d B LDS): %s", (int)lds, hipGetErrorString(e)); return (int)e; }
         }
@@ -240,8 +242,18 @@ int launch_wgrad(WgradArgs& a, hipStream_t s) {
     chunk = (chunk + PT - 1) / PT * PT;
     a.splits = mh_cdiv(a.M, chunk);
     a.chunk = chunk;
-    hipLaunchKernelGGL((wgrad_kernel<WM, WN, MT, NT, PT>), dim3(base * a.splits), dim3(64 * WM * WN), lds, s, a);
+    hipLaunchKernelGGL((wgrad_kernel<WM, WN, MT, NT, PT, VEC>), dim3(base * a.splits), dim3(64 * WM * WN), lds, s, a);
     return mh_check_launch("wgrad");
+}
+
+template <int WM, int WN, int MT, int NT, int PT>
+int launch_wgrad(WgradArgs& a, hipStream_t s) {
+    const bool all = a.M < 0;
+    const bool vec = a.vecA && a.vecB;
+    int rc = 0;
+    if (all || vec) { rc = launch_wgrad_one<WM, WN, MT, NT, PT, true>(a, s); if (!all || rc) return rc; }
+    if (all || !vec) { rc = launch_wgrad_one<WM, WN, MT, NT, PT, false>(a, s); if (!all || rc) return rc; }
+    return rc;
 }
 
 static int wgrad_dispatch(WgradArgs& a, hipStream_t s) {
@@ -294,5 +306,11 @@ extern "C" int mh_conv2d_wgrad(const mh_conv_desc* d, const float* in, const flo
     a.M = d->B * d->Ho * d->Wo; a.taps = d->kh * d->kw;
     a.vecA = mh_aligned16(in) && (d->in_ld % 4 == 0) && (d->in_ld >= ((d->K + 3) & ~3));
     a.vecB = mh_aligned16(dout) && (dout_ld % 4 == 0) && (d->N % 4 == 0);
+    {
+        const int64_t inb = (((int64_t)d->B * d->Hi * d->Wi - 1) * d->in_ld + (int64_t)((d->K + 3) / 4) * 4) * 4;
+        const int64_t dzb = (((int64_t)a.M - 1) * dout_ld + d->N) * 4;
+        MH_REQUIRE(inb < (1ll << 31) - 64 && dzb < (1ll << 31) - 64, MH_ERR_UNSUPPORTED, "mh_conv2d_wgrad: tensors must be < 2 GiB");
+        a.in_bytes = (unsigned)inb; a.dz_bytes = (unsigned)dzb;
+    }
     return wgrad_dispatch(a, (hipStream_t)stream);
 }

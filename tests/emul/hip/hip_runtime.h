@@ -225,6 +225,26 @@ static inline emul_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, 
     return d;
 }
 
+// raw buffer descriptor + bounds-checked loads (out of range -> 0, like the hardware)
+struct __amdgpu_buffer_rsrc_t { const char* base; unsigned bytes; };
+static inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int bytes, int) {
+    __amdgpu_buffer_rsrc_t r; r.base = (const char*)p; r.bytes = (unsigned)bytes; return r;
+}
+typedef unsigned int emul_u32x4 __attribute__((vector_size(16)));
+static inline emul_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
+    emul_u32x4 v = {0u, 0u, 0u, 0u};
+    const unsigned off = (unsigned)voff + (unsigned)soff;
+    for (int e = 0; e < 4; ++e)
+        if ((unsigned long long)off + 4ull * e + 4ull <= r.bytes) { unsigned x; memcpy(&x, r.base + off + 4 * e, 4); v[e] = x; }
+    return v;
+}
+static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
+    const unsigned off = (unsigned)voff + (unsigned)soff;
+    unsigned x = 0;
+    if ((unsigned long long)off + 4ull <= r.bytes) memcpy(&x, r.base + off, 4);
+    return x;
+}
+
 static inline float atomicAdd(float* addr, float v) {
     uint32_t* p = (uint32_t*)addr;
     uint32_t old = __atomic_load_n(p, __ATOMIC_RELAXED);
