@@ -143,6 +143,10 @@ int mh_leaky_bwd(float* dy, int32_t dy_ld, const float* y, int32_t y_ld, int64_t
                  float alpha, void* stream);
 int mh_fill(float* p, int64_t n, float v, void* stream);
 
+/* ---- tuning hooks used by scripts/microbench.py (0 = built-in heuristic) ------------------ */
+int mh_tune_conv_tile(int bm, int bn);
+int mh_tune_wgrad_wgs(int target_workgroups);
+
 /* ---- native plan executor: the host (Python) compiles the network into an array of op
  *      records once; one FFI call replays it (optionally captured into a hipGraph). ------ */
 enum { MH_OP_CONV = 1, MH_OP_WGRAD, MH_OP_CORR_FWD, MH_OP_CORR_BWD, MH_OP_WARP_FWD, MH_OP_WARP_BWD,

@@ -25,7 +25,8 @@ struct ConvArgs {
     int K, N, G, taps;
     int kh, kw, stride, dil, pad_t, pad_l;
     int mode, w_trans, accumulate, sshift;
-    unsigned in_bytes, w_bytes;
+    unsigned in_bytes, w_bytes, out_bytes, mask_bytes;
+    int vecC;        // 16-byte epilogue legal (N, out_ld, mask_ld multiples of 4, aligned pointers)
     int M;           // B*Ho*Wo
     int vecA, vecB;  // 16-byte vector loads legal for A / B
     int mtiles, ntiles;
@@ -276,6 +277,55 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     }
 
     // ---- epilogue: bias + leaky (+ accumulate) (+ fused leaky-grad mask) ------------------
+    // Fast path: the accumulator tile goes through LDS (free after the K loop) so that every lane
+    // owns 4 consecutive output channels: bias / old / mask are read and the result is written
+    // with 16-byte accesses along full NHWC rows (coalesced), all loads of a pass issued together.
+    if (p.vecC) {
+        constexpr int CS = BN + 4;                         // Cs[BM][CS] fits in the tile LDS
+        float* const Cs = smem;
+        __syncthreads();                                   // everyone is done reading the K-loop tiles
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Cs[(wm * MT * 16 + i * 16 + lq * 4 + r) * CS + wn * NT * 16 + j * 16 + li] = acc[i][j][r];
+        __syncthreads();
+        constexpr int C4 = BN / 4;                         // float4 per tile row
+        constexpr int RP = 256 / C4;                       // tile rows per pass (threads >= RP*C4 idle)
+        constexpr int PASSES = (BM + RP - 1) / RP;
+        const __amdgpu_buffer_rsrc_t rs_out = mh_make_rsrc(p.out, p.out_bytes);
+        const __amdgpu_buffer_rsrc_t rs_mask = mh_make_rsrc(p.mask_ref ? p.mask_ref : p.out, p.mask_ref ? p.mask_bytes : 0u);
+        const int c4 = tid % C4;
+        const int n = n0 + c4 * 4;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias && n < p.N) bv = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll 4
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int row = tid / C4 + ps * RP;
+            const int m = m0 + row;
+            const bool ok = (tid < RP * C4) && (row < BM) && (m < p.M) && (n < p.N);
+            float4 v = *reinterpret_cast<const float4*>(&Cs[(row < BM ? row : 0) * CS + c4 * 4]);
+            const int ooff = ok ? (m * p.out_ld + n) * 4 : MH_OOB;
+            float4 old = make_float4(0.f, 0.f, 0.f, 0.f), mk = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (p.accumulate) old = mh_buf_load4(rs_out, ooff);
+            if (p.mask_ref) mk = mh_buf_load4(rs_mask, ok ? (m * p.mask_ld + n) * 4 : MH_OOB);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            if (p.alpha != 1.0f) {
+                v.x = v.x > 0.f ? v.x : p.alpha * v.x; v.y = v.y > 0.f ? v.y : p.alpha * v.y;
+                v.z = v.z > 0.f ? v.z : p.alpha * v.z; v.w = v.w > 0.f ? v.w : p.alpha * v.w;
+            }
+            v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+            if (p.mask_ref) {
+                v.x *= (mk.x > 0.f) ? 1.0f : p.mask_alpha; v.y *= (mk.y > 0.f) ? 1.0f : p.mask_alpha;
+                v.z *= (mk.z > 0.f) ? 1.0f : p.mask_alpha; v.w *= (mk.w > 0.f) ? 1.0f : p.mask_alpha;
+            }
+            if (ok) *reinterpret_cast<float4*>(p.out + (int64_t)m * p.out_ld + n) = v;
+        }
+        return;
+    }
+    // generic path (odd channel counts / unaligned rows, e.g. the 1-channel disparity heads)
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -339,18 +389,21 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
 // tile-shape heuristic: N tile = smallest available >= min(N,128); the largest M tile that still
 // gives the 256 CUs >= ~0.75 workgroups each; big tiles use KT=32, small (latency-bound) ones KT=64.
 // MH_CONV_BM=128|64|32 (environment) forces the M tile for A/B experiments.
+static int g_force_bm = -1, g_force_bn = 0;
 static int forced_bm() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("MH_CONV_BM"); v = e ? atoi(e) : 0; }
-    return v;
+    if (g_force_bm < 0) { const char* e = getenv("MH_CONV_BM"); g_force_bm = e ? atoi(e) : 0; }
+    return g_force_bm;
 }
+// tuning hook (microbenchmarks): force the conv tile; 0 = heuristic
+extern "C" int mh_tune_conv_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; return 0; }
 
 static int conv_dispatch(ConvArgs& a, hipStream_t s) {
     const int N = a.N;
     const int64_t M = a.M;
     auto wgs = [&](int bm, int bn) { return (int64_t)mh_cdiv(M, bm) * mh_cdiv(N, bn); };
     const int64_t want = 192;
-    const int bn = N > 96 ? 128 : (N > 64 ? 96 : (N > 32 ? 64 : (N > 16 ? 32 : 16)));
+    int bn = N > 96 ? 128 : (N > 64 ? 96 : (N > 32 ? 64 : (N > 16 ? 32 : 16)));
+    if (g_force_bn > 0 && a.M >= 0) bn = g_force_bn;
     int bm = forced_bm();
     if (bm == 0 || a.M < 0) bm = wgs(128, bn) >= want ? 128 : (wgs(64, bn) >= want / 2 ? 64 : 32);
     if (bn == 16 && bm == 32) bm = 64;
@@ -403,6 +456,11 @@ extern "C" int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w,
         const int64_t wb = (int64_t)d->kh * d->kw * d->K * d->N * 4;
         MH_REQUIRE(inb < (1ll << 31) - 64 && wb < (1ll << 31) - 64, MH_ERR_UNSUPPORTED, "mh_conv2d: tensors must be < 2 GiB (32-bit buffer offsets)");
         a.in_bytes = (unsigned)inb; a.w_bytes = (unsigned)wb;
+        const int64_t ob = (((int64_t)d->B * d->Ho * d->Wo - 1) * d->out_ld + d->N) * 4;
+        const int64_t mb = mask_ref ? (((int64_t)d->B * d->Ho * d->Wo - 1) * d->mask_ld + d->N) * 4 : 0;
+        a.vecC = (d->N % 4 == 0) && (d->out_ld % 4 == 0) && mh_aligned16(out) && (!bias || mh_aligned16(bias)) &&
+                 (!mask_ref || (d->mask_ld % 4 == 0 && mh_aligned16(mask_ref))) && ob < (1ll << 31) - 64 && mb < (1ll << 31) - 64;
+        a.out_bytes = (unsigned)(a.vecC ? ob : 0); a.mask_bytes = (unsigned)(a.vecC ? mb : 0);
     }
     a.sshift = 0;
     while ((1 << a.sshift) < d->stride) ++a.sshift;

@@ -216,6 +216,10 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
     if (do_bias && n0 + tid < p.N) atomicAdd(p.db + n0 + tid, bsum);
 }
 
+static int g_wgrad_target_wgs = 768;
+// tuning hook (microbenchmarks): number of workgroups the pixel split aims for
+extern "C" int mh_tune_wgrad_wgs(int target) { g_wgrad_target_wgs = target > 0 ? target : 768; return 0; }
+
 template <int WM, int WN, int MT, int NT, int PT, bool VEC>
 int launch_wgrad_one(WgradArgs& a, hipStream_t s) {
     constexpr int BK = WM * MT * 16, BN = WN * NT * 16;
@@ -234,7 +238,7 @@ int launch_wgrad_one(WgradArgs& a, hipStream_t s) {
     a.ntiles = mh_cdiv(a.N, BN);
     const int base = a.taps * a.ktiles * a.ntiles;
     // enough pixel splits for ~3 workgroups per CU, but keep >= 4 reduction tiles per split
-    int splits = mh_cdiv(768, base);
+    int splits = mh_cdiv(g_wgrad_target_wgs, base);
     const int maxs = mh_cdiv(a.M, PT * 4);
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;

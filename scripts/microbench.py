@@ -1,0 +1,93 @@
+"""Per-layer kernel timing on the MI355X (HIP events), used to tune tile shapes / splits.
+usage: python scripts/microbench.py [conv|wgrad|corr|all]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "real-time-self-adaptive-deep-stereo_amd")):
+    sys.path.insert(0, p)
+import torch
+from madnet_hip import _ffi, ops
+from madnet_hip.benchtools import _time_ms
+
+lib = _ffi.lib()
+stream = torch.cuda.Stream()
+what = sys.argv[1] if len(sys.argv) > 1 else "all"
+dev = "cuda"
+
+# (name, B, H, W, Cin, Cout, stride, dil)
+LAYERS = [("L2 128->128 d2", 1, 96, 320, 128, 128, 1, 2), ("L2 128->96", 1, 96, 320, 128, 96, 1, 1),
+          ("L2 96->64", 1, 96, 320, 96, 64, 1, 1), ("L2 64->32", 1, 96, 320, 64, 32, 1, 1), ("L2 38->128", 1, 96, 320, 38, 128, 1, 1),
+          ("L3 128->128", 1, 48, 160, 128, 128, 1, 1), ("L4 128->128", 1, 24, 80, 128, 128, 1, 1), ("L5 128->128", 1, 12, 40, 128, 128, 1, 1),
+          ("P 16->16 @1/2 x2", 2, 192, 640, 16, 16, 1, 1), ("P 16->32 s2 x2", 2, 192, 640, 16, 32, 2, 1), ("P 32->32 @1/4 x2", 2, 96, 320, 32, 32, 1, 1),
+          ("P 64->64 @1/8 x2", 2, 48, 160, 64, 64, 1, 1)]
+TILES = [(0, 0), (128, 128), (64, 128), (32, 128), (128, 64), (64, 64), (32, 64), (128, 32), (64, 32)]
+
+
+def run_conv():
+    print("%-20s %-6s %s" % ("layer", "mode", " ".join("%9s" % ("auto" if t == (0, 0) else "%dx%d" % t) for t in TILES)) + "   GFLOP")
+    for name, B, H, W, Ci, Co, s, d in LAYERS:
+        ld = (Ci + 3) // 4 * 4
+        x = torch.randn(B, H, W, ld, device=dev); xv = ops.View(x, B, H, W, Ci, ld)
+        w = torch.randn(3, 3, Ci, Co, device=dev) * 0.05; b = torch.randn(Co, device=dev)
+        Ho, Wo, _, _ = ops.conv_geometry(H, W, 3, 3, s, d)
+        y = torch.empty(B, Ho, Wo, Co, device=dev); dx = torch.empty(B, H, W, ld, device=dev)
+        flops = 2.0 * B * Ho * Wo * 9 * Ci * Co
+        for mode in ("fwd", "dgrad"):
+            res = []
+            for bm, bn in TILES:
+                if bn and ((mode == "fwd" and bn > max(16, Co) * 2) or (mode == "dgrad" and bn > max(16, Ci) * 2)):
+                    res.append(None); continue
+                lib.tune_conv_tile(bm, bn)
+                try:
+                    with torch.cuda.stream(stream):
+                        if mode == "fwd":
+                            fn = lambda: ops.conv2d_fwd(lib, xv, w, b, ops.view(y), stride=s, dil=d, alpha=0.2, stream=stream.cuda_stream)
+                        else:
+                            fn = lambda: ops.conv2d_dgrad(lib, ops.view(y), w, ops.View(dx, B, H, W, Ci, ld), stride=s, dil=d, accumulate=True,
+                                                          mask_ref=xv, mask_alpha=0.2, stream=stream.cuda_stream)
+                        res.append(_time_ms(lib, stream, fn, 10) * 1e3)
+                except Exception as e:
+                    res.append(None)
+            lib.tune_conv_tile(0, 0)
+            print("%-20s %-6s %s   %.2f  (best %.0f TF/s)" % (name, mode, " ".join("%9s" % ("-" if r is None else "%.1f" % r) for r in res), flops / 1e9,
+                                                            flops / (min(r for r in res if r) * 1e-6) / 1e12))
+
+
+def run_wgrad():
+    targets = [192, 256, 384, 512, 768, 1536]
+    print("%-20s %s" % ("wgrad layer", " ".join("%9d" % t for t in targets)))
+    for name, B, H, W, Ci, Co, s, d in LAYERS:
+        ld = (Ci + 3) // 4 * 4
+        x = torch.randn(B, H, W, ld, device=dev); xv = ops.View(x, B, H, W, Ci, ld)
+        Ho, Wo, _, _ = ops.conv_geometry(H, W, 3, 3, s, d)
+        dz = torch.randn(B, Ho, Wo, Co, device=dev)
+        dw = torch.zeros(3, 3, Ci, Co, device=dev); db = torch.zeros(Co, device=dev)
+        flops = 2.0 * B * Ho * Wo * 9 * Ci * Co
+        res = []
+        for t in targets:
+            lib.tune_wgrad_wgs(t)
+            with torch.cuda.stream(stream):
+                res.append(_time_ms(lib, stream, lambda: ops.conv2d_wgrad(lib, xv, ops.view(dz), dw, db, stride=s, dil=d, stream=stream.cuda_stream), 10) * 1e3)
+        lib.tune_wgrad_wgs(0)
+        print("%-20s %s   (best %.0f TF/s)" % (name, " ".join("%9.1f" % r for r in res), flops / (min(res) * 1e-6) / 1e12))
+
+
+def run_corr():
+    for (B, H, W, Cc, md) in [(64, 96, 320, 32, 2), (16, 96, 320, 32, 2), (1, 96, 320, 32, 2), (64, 48, 160, 64, 2), (16, 96, 320, 128, 40)]:
+        L = torch.randn(B, H, W, Cc, device=dev); R = torch.randn(B, H, W, Cc, device=dev)
+        D = 2 * md + 1
+        out = torch.empty(B, H, W, D, device=dev)
+        with torch.cuda.stream(stream):
+            ms = _time_ms(lib, stream, lambda: ops.corr_fwd(lib, ops.view(L), ops.view(R), ops.view(out), md, stream=stream.cuda_stream), 10)
+        byts = float(B) * H * W * (2 * Cc + D) * 4
+        print("corr fwd B=%d %dx%dx%d D=%d: %.1f us  %.0f GB/s (%.1f%% of 8 TB/s)" % (B, H, W, Cc, D, ms * 1e3, byts / ms / 1e6, byts / ms / 1e6 / 80))
+
+
+if what in ("conv", "all"):
+    run_conv()
+if what in ("wgrad", "all"):
+    run_wgrad()
+if what in ("corr", "all"):
+    run_corr()
