@@ -386,42 +386,78 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
-// tile-shape heuristic: N tile = smallest available >= min(N,128); the largest M tile that still
-// gives the 256 CUs >= ~0.75 workgroups each; big tiles use KT=32, small (latency-bound) ones KT=64.
-// MH_CONV_BM=128|64|32 (environment) forces the M tile for A/B experiments.
-static int g_force_bm = -1, g_force_bn = 0;
+// ---- tile selection -------------------------------------------------------------------------
+// Measured on MI355X (scripts/microbench.py, profiles/r01_microbench.txt): at batch 1 the layers are
+// small relative to 256 CUs, so the best tile is the LARGEST one that still yields >= ~480
+// workgroups (about 2 per CU, i.e. 2 waves per SIMD to overlap one wave's load/LDS phase with
+// another's MFMAs); when no tile reaches that, take the one with the most workgroups.  Big tiles
+// use KT=32; the small, latency-bound ones KT=64/128 (fewer barriers, more bytes in flight).
+// mh_tune_conv_tile(bm, bn) / MH_CONV_BM force a tile for experiments.
+static int g_force_bm = -1, g_force_bn = 0, g_force_kt = 0;
 static int forced_bm() {
     if (g_force_bm < 0) { const char* e = getenv("MH_CONV_BM"); g_force_bm = e ? atoi(e) : 0; }
     return g_force_bm;
 }
-// tuning hook (microbenchmarks): force the conv tile; 0 = heuristic
-extern "C" int mh_tune_conv_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; return 0; }
+extern "C" int mh_tune_conv_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn & 0xffff; g_force_kt = bn >> 16; return 0; }
+
+struct TileCfg { int bm, bn, kt; };
+static const TileCfg kTiles[] = {
+    {128, 128, 32}, {128, 96, 32}, {128, 64, 32}, {64, 128, 32}, {64, 96, 32}, {64, 64, 32}, {128, 32, 32},
+    {32, 128, 64}, {32, 96, 64}, {32, 64, 64}, {64, 32, 64}, {32, 32, 64}, {128, 16, 32}, {64, 16, 64},
+    {32, 64, 128}, {64, 32, 128}, {32, 32, 128},
+};
 
 static int conv_dispatch(ConvArgs& a, hipStream_t s) {
-    const int N = a.N;
-    const int64_t M = a.M;
-    auto wgs = [&](int bm, int bn) { return (int64_t)mh_cdiv(M, bm) * mh_cdiv(N, bn); };
-    const int64_t want = 192;
-    int bn = N > 96 ? 128 : (N > 64 ? 96 : (N > 32 ? 64 : (N > 16 ? 32 : 16)));
-    if (g_force_bn > 0 && a.M >= 0) bn = g_force_bn;
-    int bm = forced_bm();
-    if (bm == 0 || a.M < 0) bm = wgs(128, bn) >= want ? 128 : (wgs(64, bn) >= want / 2 ? 64 : 32);
-    if (bn == 16 && bm == 32) bm = 64;
     const bool all = a.M < 0;               // mh_init(): touch every instantiation
-    int rc = 0;
-#define MH_CFG(BMv, BNv, ...)                                              \
-    if (all || (bm == BMv && bn == BNv)) {                                 \
-        rc = launch_cfg<__VA_ARGS__>(a, s);                                \
-        if (!all || rc) return rc;                                         \
+    int bm = 0, bn = 0, kt = 0;
+    if (!all) {
+        const int N = a.N;
+        const int64_t M = a.M;
+        const int ktot = a.taps * a.G * 4;
+        if (forced_bm() > 0 && g_force_bn > 0) {
+            bm = g_force_bm; bn = g_force_bn; kt = g_force_kt;
+        }
+        if (bm == 0) {
+            // admissible N tiles: the smallest tile >= N (no wasted columns beyond rounding), or 32/64
+            // column slices of a wider layer
+            const int bn_full = N > 96 ? 128 : (N > 64 ? 96 : (N > 32 ? 64 : (N > 16 ? 32 : 16)));
+            int64_t best_w = -1; int best_area = 0;
+            for (const TileCfg& t : kTiles) {
+                if (t.kt == 128) continue;                                   // only via the latency rule below
+                const bool n_ok = (t.bn == bn_full) || (t.bn < bn_full && t.bn >= 32 && bn_full % t.bn == 0 && bn_full != 96) ||
+                                  (bn_full == 96 && t.bn == 32);
+                if (!n_ok) continue;
+                if (forced_bm() > 0 && t.bm != g_force_bm) continue;
+                const int64_t w = (int64_t)mh_cdiv(M, t.bm) * mh_cdiv(N, t.bn);
+                const int area = t.bm * t.bn;
+                const bool enough = w >= 480, best_enough = best_w >= 480;
+                bool take;
+                if (best_w < 0) take = true;
+                else if (enough != best_enough) take = enough;
+                else if (enough) take = area > best_area;                    // both fill the chip: bigger tile
+                else take = (w > best_w) || (w == best_w && area > best_area);
+                if (take) { best_w = w; best_area = area; bm = t.bm; bn = t.bn; kt = t.kt; }
+            }
+            // latency-bound (few workgroups, long K): deepen the K-tile
+            if (best_w < 240 && ktot >= 512 && bm * bn <= 2048) kt = 128;
+        }
+        if (kt == 0) for (const TileCfg& t : kTiles) if (t.bm == bm && t.bn == bn) { kt = t.kt; break; }
     }
-    MH_CFG(128, 128, 2, 2, 4, 4, 32) MH_CFG(64, 128, 1, 4, 4, 2, 32) MH_CFG(32, 128, 1, 4, 2, 2, 64)
-    MH_CFG(128, 96, 2, 2, 4, 3, 32)  MH_CFG(64, 96, 2, 2, 2, 3, 32)  MH_CFG(32, 96, 2, 2, 1, 3, 64)
-    MH_CFG(128, 64, 2, 2, 4, 2, 32)  MH_CFG(64, 64, 2, 2, 2, 2, 32)  MH_CFG(32, 64, 2, 2, 1, 2, 64)
-    MH_CFG(128, 32, 4, 1, 2, 2, 32)  MH_CFG(64, 32, 4, 1, 1, 2, 64)  MH_CFG(32, 32, 2, 2, 1, 1, 64)
-    MH_CFG(128, 16, 4, 1, 2, 1, 32)  MH_CFG(64, 16, 4, 1, 1, 1, 64)
+    int rc = 0;
+#define MH_CFG(BMv, BNv, KTv, ...)                                                  \
+    if (all || (bm == BMv && bn == BNv && kt == KTv)) {                             \
+        rc = launch_cfg<__VA_ARGS__, KTv>(a, s);                                    \
+        if (!all || rc) return rc;                                                  \
+    }
+    MH_CFG(128, 128, 32, 2, 2, 4, 4) MH_CFG(128, 96, 32, 2, 2, 4, 3) MH_CFG(128, 64, 32, 2, 2, 4, 2)
+    MH_CFG(64, 128, 32, 1, 4, 4, 2)  MH_CFG(64, 96, 32, 2, 2, 2, 3)  MH_CFG(64, 64, 32, 2, 2, 2, 2)
+    MH_CFG(128, 32, 32, 4, 1, 2, 2)  MH_CFG(128, 16, 32, 4, 1, 2, 1)
+    MH_CFG(32, 128, 64, 1, 4, 2, 2)  MH_CFG(32, 96, 64, 2, 2, 1, 3)  MH_CFG(32, 64, 64, 2, 2, 1, 2)
+    MH_CFG(64, 32, 64, 4, 1, 1, 2)   MH_CFG(32, 32, 64, 2, 2, 1, 1)  MH_CFG(64, 16, 64, 4, 1, 1, 1)
+    MH_CFG(32, 64, 128, 2, 2, 1, 2)  MH_CFG(64, 32, 128, 4, 1, 1, 2) MH_CFG(32, 32, 128, 2, 2, 1, 1)
 #undef MH_CFG
     if (all) return 0;
-    mh_set_error("conv_dispatch: no tile configuration for bm=%d bn=%d", bm, bn);
+    mh_set_error("conv_dispatch: no tile configuration for bm=%d bn=%d kt=%d", bm, bn, kt);
     return MH_ERR_UNSUPPORTED;
 }
 

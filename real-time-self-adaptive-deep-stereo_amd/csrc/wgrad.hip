@@ -216,9 +216,9 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
     if (do_bias && n0 + tid < p.N) atomicAdd(p.db + n0 + tid, bsum);
 }
 
-static int g_wgrad_target_wgs = 768;
-// tuning hook (microbenchmarks): number of workgroups the pixel split aims for
-extern "C" int mh_tune_wgrad_wgs(int target) { g_wgrad_target_wgs = target > 0 ? target : 768; return 0; }
+static int g_wgrad_target_wgs = 0;
+// tuning hook (microbenchmarks): number of workgroups the pixel split aims for (0 = heuristic)
+extern "C" int mh_tune_wgrad_wgs(int target) { g_wgrad_target_wgs = target > 0 ? target : 0; return 0; }
 
 template <int WM, int WN, int MT, int NT, int PT, bool VEC>
 int launch_wgrad_one(WgradArgs& a, hipStream_t s) {
@@ -238,7 +238,11 @@ int launch_wgrad_one(WgradArgs& a, hipStream_t s) {
     a.ntiles = mh_cdiv(a.N, BN);
     const int base = a.taps * a.ktiles * a.ntiles;
     // enough pixel splits for ~3 workgroups per CU, but keep >= 4 reduction tiles per split
-    int splits = mh_cdiv(g_wgrad_target_wgs, base);
+    // measured (profiles/r01_microbench.txt): big dW tiles want ~1.5 workgroups per CU, tiny ones (a
+    // few MFMAs per reduction tile) need many more to hide their latency
+    constexpr int units = WM * WN * MT * NT;
+    const int target = g_wgrad_target_wgs > 0 ? g_wgrad_target_wgs : (units >= 32 ? 384 : (units >= 8 ? 768 : 1536));
+    int splits = mh_cdiv(target, base);
     const int maxs = mh_cdiv(a.M, PT * 4);
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;

@@ -22,11 +22,11 @@ LAYERS = [("L2 128->128 d2", 1, 96, 320, 128, 128, 1, 2), ("L2 128->96", 1, 96, 
           ("L3 128->128", 1, 48, 160, 128, 128, 1, 1), ("L4 128->128", 1, 24, 80, 128, 128, 1, 1), ("L5 128->128", 1, 12, 40, 128, 128, 1, 1),
           ("P 16->16 @1/2 x2", 2, 192, 640, 16, 16, 1, 1), ("P 16->32 s2 x2", 2, 192, 640, 16, 32, 2, 1), ("P 32->32 @1/4 x2", 2, 96, 320, 32, 32, 1, 1),
           ("P 64->64 @1/8 x2", 2, 48, 160, 64, 64, 1, 1)]
-TILES = [(0, 0), (128, 128), (64, 128), (32, 128), (128, 64), (64, 64), (32, 64), (128, 32), (64, 32)]
+TILES = [(0, 0, 0), (128, 64, 0), (64, 64, 0), (32, 64, 64), (32, 64, 128), (64, 32, 64), (64, 32, 128), (32, 32, 64), (32, 32, 128)]
 
 
 def run_conv():
-    print("%-20s %-6s %s" % ("layer", "mode", " ".join("%9s" % ("auto" if t == (0, 0) else "%dx%d" % t) for t in TILES)) + "   GFLOP")
+    print("%-20s %-6s %s" % ("layer", "mode", " ".join("%10s" % ("auto" if t[0] == 0 else "%dx%d/%d" % t) for t in TILES)) + "   GFLOP")
     for name, B, H, W, Ci, Co, s, d in LAYERS:
         ld = (Ci + 3) // 4 * 4
         x = torch.randn(B, H, W, ld, device=dev); xv = ops.View(x, B, H, W, Ci, ld)
@@ -36,10 +36,10 @@ def run_conv():
         flops = 2.0 * B * Ho * Wo * 9 * Ci * Co
         for mode in ("fwd", "dgrad"):
             res = []
-            for bm, bn in TILES:
+            for bm, bn, kt in TILES:
                 if bn and ((mode == "fwd" and bn > max(16, Co) * 2) or (mode == "dgrad" and bn > max(16, Ci) * 2)):
                     res.append(None); continue
-                lib.tune_conv_tile(bm, bn)
+                lib.tune_conv_tile(bm, bn | (kt << 16))
                 try:
                     with torch.cuda.stream(stream):
                         if mode == "fwd":
@@ -51,7 +51,7 @@ def run_conv():
                 except Exception as e:
                     res.append(None)
             lib.tune_conv_tile(0, 0)
-            print("%-20s %-6s %s   %.2f  (best %.0f TF/s)" % (name, mode, " ".join("%9s" % ("-" if r is None else "%.1f" % r) for r in res), flops / 1e9,
+            print("%-20s %-6s %s   %.2f  (best %.0f TF/s)" % (name, mode, " ".join("%10s" % ("-" if r is None else "%.1f" % r) for r in res), flops / 1e9,
                                                             flops / (min(r for r in res if r) * 1e-6) / 1e12))
 
 
