@@ -126,17 +126,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         b_tap[j] = t; b_c4[j] = c;
     }
 
-    // two register stages: K-tiles t+1 and t+2 are in flight while tile t is multiplied
-    float4 ra0[AROWS], ra1[AROWS];
-    float4 rb0[BITEMS], rb1[BITEMS];
-    int kb0 = 0, kb1 = 0;     // kbase of the A group held by each stage (for the padding select at store time)
+    float4 ra_v[AROWS];
+    float4 rb_v[BITEMS];
 
     __syncthreads();   // tap tables visible
 
+    int a_kb_st = 0;    // kbase of the tile currently held in ra_v (used when it is stored)
     const __amdgpu_buffer_rsrc_t rs_in = mh_make_rsrc(p.in, p.in_bytes);
     const __amdgpu_buffer_rsrc_t rs_w = mh_make_rsrc(p.w, p.w_bytes);
 
-    auto load_tile = [&](float4 (&ra_v)[AROWS], float4 (&rb_v)[BITEMS], int& a_kb_st) {
+    auto load_tile = [&]() {
         {
             const bool gok = a_tap < p.taps;
             const int tapc = gok ? a_tap : 0;
@@ -205,7 +204,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         }
     };
 
-    auto store_tile = [&](int buf, float4 (&ra_v)[AROWS], float4 (&rb_v)[BITEMS], int a_kb_st) {
+    auto store_tile = [&](int buf) {
         float* Ab = As + buf * (BM * LS);
         float* Bb = Bs + buf * (BN * LS);
 #pragma unroll
@@ -246,7 +245,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     const int ntile = (p.taps * p.G + GPT - 1) / GPT;
     const int li = lane & 15, lq = lane >> 4;
 
-    auto compute_tile = [&](int buf) {
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+
+    for (int t = 0; t < ntile; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntile) load_tile();
         const float* Ab = As + buf * (BM * LS) + (wm * MT * 16 + li) * LS + lq * 4;
         const float* Bb = Bs + buf * (BN * LS) + (wn * NT * 16 + li) * LS;
 #pragma unroll
@@ -267,25 +272,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-    };
-
-    // Software pipeline, prefetch distance 2: while tile t is multiplied out of LDS buffer t&1, tile t+1
-    // sits in one register stage (stored to the other LDS buffer after the MFMAs) and tile t+2 is being
-    // loaded into the other stage.  Loads past the last tile are issued anyway (their tap index is out of
-    // range => out-of-range buffer offsets => zeros, no memory traffic): keeping every load and store
-    // unconditional keeps hipcc's s_waitcnt vmcnt(N) COUNTED (a conditional load would force vmcnt(0)).
-    load_tile(ra0, rb0, kb0);            // tile 0
-    load_tile(ra1, rb1, kb1);            // tile 1
-    store_tile(0, ra0, rb0, kb0);
-    __syncthreads();
-    for (int t = 0; t < ntile; t += 2) {
-        load_tile(ra0, rb0, kb0);        // tile t+2
-        compute_tile(0);                 // tile t
-        store_tile(1, ra1, rb1, kb1);    // tile t+1
-        __syncthreads();
-        load_tile(ra1, rb1, kb1);        // tile t+3
-        if (t + 1 < ntile) compute_tile(1);   // tile t+1 (uniform branch, no global loads inside)
-        store_tile(0, ra0, rb0, kb0);    // tile t+2
+        if (t + 1 < ntile) store_tile(buf ^ 1);
         __syncthreads();
     }
 

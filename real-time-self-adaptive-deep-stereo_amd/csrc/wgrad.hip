@@ -73,14 +73,14 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
         a_b[j] = t2 / p.Ho;
     }
 
-    float4 ra0[AITEMS], ra1[AITEMS], rb0[BITEMS], rb1[BITEMS];   // two register stages (prefetch distance 2)
+    float4 ra_v[AITEMS], rb_v[BITEMS];
     int tile_ld = 0;   // tiles loaded so far
 
     const __amdgpu_buffer_rsrc_t rs_in = mh_make_rsrc(p.in, p.in_bytes);
     const __amdgpu_buffer_rsrc_t rs_dz = mh_make_rsrc(p.dz, p.dz_bytes);
 
     // all tile loads are unconditional buffer loads (out-of-range offset => 0), see mh_common.h
-    auto load_tile = [&](float4 (&ra_v)[AITEMS], float4 (&rb_v)[BITEMS]) {
+    auto load_tile = [&]() {
 #pragma unroll
         for (int j = 0; j < AITEMS; ++j) {
             const int q = tid + NTH * j;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
         ++tile_ld;
     };
 
-    auto store_tile = [&](int buf, float4 (&ra_v)[AITEMS], float4 (&rb_v)[BITEMS]) {
+    auto store_tile = [&](int buf) {
         float* Ab = As + buf * (BK * LS);
         float* Bb = Bs + buf * (BN * LS);
 #pragma unroll
@@ -161,7 +161,13 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
     const bool do_bias = (p.db != nullptr) && tap == 0 && tk == 0 && tid < BN;
     float bsum = 0.f;
 
-    auto compute_tile = [&](int buf) {
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+
+    for (int t = 0; t < ntile; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntile) load_tile();
         const float* Ab = As + buf * (BK * LS) + (wm * MT * 16 + li) * LS;
         const float* Bb = Bs + buf * (BN * LS) + (wn * NT * 16 + li) * LS;
 #pragma unroll
@@ -191,22 +197,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
                 bsum += (v.x + v.y) + (v.z + v.w);
             }
         }
-    };
-
-    // prefetch distance 2, every load/store unconditional (tiles past the range read as zeros) so the
-    // compiler's s_waitcnt vmcnt stay counted -- same scheme as conv_igemm_kernel
-    load_tile(ra0, rb0);
-    load_tile(ra1, rb1);
-    store_tile(0, ra0, rb0);
-    __syncthreads();
-    for (int t = 0; t < ntile; t += 2) {
-        load_tile(ra0, rb0);
-        compute_tile(0);
-        store_tile(1, ra1, rb1);
-        __syncthreads();
-        load_tile(ra1, rb1);
-        if (t + 1 < ntile) compute_tile(1);
-        store_tile(0, ra0, rb0);
+        if (t + 1 < ntile) store_tile(buf ^ 1);
         __syncthreads();
     }
 
