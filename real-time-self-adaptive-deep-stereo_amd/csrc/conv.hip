@@ -49,7 +49,10 @@ __device__ __forceinline__ int swz_group(int row, int g) { return g ^ ((row >> 2
 // rows along n; dgrad & conv2d_transpose: mode 1 / rows along k); VEC = 16-byte global loads legal.
 // Every global load is UNCONDITIONAL (clamped address + select): a load inside a conditional block
 // makes hipcc drain vmcnt(0) before the MFMA block and kills the prefetch overlap.
-template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool VEC>
+// UNI: every K-tile lies inside ONE tap (4*G % KT == 0, and stride 1 for DGRAD): the (tap, channel)
+// cursor is then wave-uniform (SALU) and a row's byte offset is base(row) + offset(tile) -- the loader
+// shrinks from ~20 to ~7 VALU per 16-byte load, which is what bounds the small, 1-wave-per-SIMD tiles.
+template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool VEC, bool UNI>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     constexpr int BM = WM * MT * 16;
     constexpr int BN = WN * NT * 16;
@@ -126,6 +129,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         b_tap[j] = t; b_c4[j] = c;
     }
 
+    // UNI fast path: thread-constant byte offsets + wave-uniform tile cursor
+    int a_off[AROWS];           // ((img + by*Wi + bx)*in_ld + ga*4)*4
+    int b_off[BITEMS];          // fwd: (kk*N + n)*4 ; dgrad: (n*K + g*4)*4   (MH_OOB when the item is dead)
+    if (UNI) {
+#pragma unroll
+        for (int j = 0; j < AROWS; ++j) a_off[j] = ((a_img[j] + a_by[j] * p.Wi + a_bx[j]) * p.in_ld + ga * 4) * 4;
+#pragma unroll
+        for (int j = 0; j < BITEMS; ++j) {
+            const int q = tid + 256 * j;
+            int n, o;
+            if (!DGRAD) { const int kk = q / (BN / 4), n4 = q % (BN / 4); n = n0 + n4 * 4; o = (kk * p.N + n) * 4; }
+            else { n = n0 + q / GPT; o = (n * p.K + (q % GPT) * 4) * 4; }
+            b_off[j] = (q < BVEC && n < p.N) ? o : MH_OOB;
+        }
+    }
+    int u_tap = 0, u_c0 = 0;    // wave-uniform cursor of the NEXT tile to load (UNI)
+
     float4 ra_v[AROWS];
     float4 rb_v[BITEMS];
 
@@ -136,6 +156,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     const __amdgpu_buffer_rsrc_t rs_w = mh_make_rsrc(p.w, p.w_bytes);
 
     auto load_tile = [&]() {
+        if (UNI) {
+            // tile = channels [u_c0, u_c0+KT) of tap u_tap -- all scalar
+            const bool tok = u_tap < p.taps;
+            const int tapc = tok ? u_tap : 0;
+            const int dy = __builtin_amdgcn_readfirstlane(tap_dy[tapc]);
+            const int dx = __builtin_amdgcn_readfirstlane(tap_dx[tapc]);
+            const int sdy = DGRAD ? -dy : dy, sdx = DGRAD ? -dx : dx;
+            const int toff = ((sdy * p.Wi + sdx) * p.in_ld + u_c0) * 4;
+            a_kb_st = 0;                                         // K % KT == 0: no channel padding inside a tile
+#pragma unroll
+            for (int j = 0; j < AROWS; ++j) {
+                const int iy = a_by[j] + sdy, ix = a_bx[j] + sdx;
+                const bool ok = tok && a_rowok[j] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+                ra_v[j] = mh_buf_load4(rs_in, ok ? a_off[j] + toff : MH_OOB);
+            }
+            const int woff = tok ? (!DGRAD ? (u_tap * p.K + u_c0) * p.N : u_tap * p.N * p.K + u_c0) * 4 : MH_OOB;
+#pragma unroll
+            for (int j = 0; j < BITEMS; ++j) {
+                // MH_OOB + anything stays out of range (offsets are < 2^31 and num_records < 2^31)
+                rb_v[j] = mh_buf_load4(rs_w, (b_off[j] == MH_OOB || !tok) ? MH_OOB : b_off[j] + woff);
+            }
+            u_c0 += KT;
+            if (u_c0 >= p.K) { u_c0 = 0; ++u_tap; }
+            return;
+        }
         {
             const bool gok = a_tap < p.taps;
             const int tapc = gok ? a_tap : 0;
@@ -351,14 +396,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     }
 }
 
-template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool VEC>
+static bool g_no_uni = false;    // tuning hook: disable the uniform-tap fast path (A/B experiments)
+
+template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool VEC, bool UNI>
 int launch_one(ConvArgs& a, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
     constexpr size_t lds = (size_t)(2 * (BM + BN) * (KT + 4) + 128) * sizeof(float);
     static bool attr_done = false;       // LDS > 64 KiB needs the opt-in once per instantiation
     if (!attr_done) {
         if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC, UNI>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) { mh_set_error("conv: hipFuncSetAttribute(%d B LDS): %s", (int)lds, hipGetErrorString(e)); return (int)e; }
         }
@@ -368,7 +415,7 @@ int launch_one(ConvArgs& a, hipStream_t s) {
     a.mtiles = mh_cdiv(a.M, BM);
     a.ntiles = mh_cdiv(a.N, BN);
     const int nwg = a.mtiles * a.ntiles;
-    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC>), dim3(nwg), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC, UNI>), dim3(nwg), dim3(256), lds, s, a);
     return mh_check_launch("conv_igemm");
 }
 
@@ -376,11 +423,15 @@ template <int WM, int WN, int MT, int NT, int KT>
 int launch_cfg(ConvArgs& a, hipStream_t s) {
     const bool all = a.M < 0;
     const bool dg = a.mode == 1, vec = a.vecA && a.vecB;
+    // uniform-tap fast path: whole K-tiles per tap, no channel padding, unit-stride gather
+    const bool uni = vec && (a.K % KT == 0) && (!dg || a.sshift == 0) && !g_no_uni;
     int rc = 0;
-    if (all || (!dg && vec)) { rc = launch_one<WM, WN, MT, NT, KT, false, true>(a, s); if (!all || rc) return rc; }
-    if (all || (!dg && !vec)) { rc = launch_one<WM, WN, MT, NT, KT, false, false>(a, s); if (!all || rc) return rc; }
-    if (all || (dg && vec)) { rc = launch_one<WM, WN, MT, NT, KT, true, true>(a, s); if (!all || rc) return rc; }
-    if (all || (dg && !vec)) { rc = launch_one<WM, WN, MT, NT, KT, true, false>(a, s); if (!all || rc) return rc; }
+    if (all || (!dg && vec && uni)) { rc = launch_one<WM, WN, MT, NT, KT, false, true, true>(a, s); if (!all || rc) return rc; }
+    if (all || (!dg && vec && !uni)) { rc = launch_one<WM, WN, MT, NT, KT, false, true, false>(a, s); if (!all || rc) return rc; }
+    if (all || (!dg && !vec)) { rc = launch_one<WM, WN, MT, NT, KT, false, false, false>(a, s); if (!all || rc) return rc; }
+    if (all || (dg && vec && uni)) { rc = launch_one<WM, WN, MT, NT, KT, true, true, true>(a, s); if (!all || rc) return rc; }
+    if (all || (dg && vec && !uni)) { rc = launch_one<WM, WN, MT, NT, KT, true, true, false>(a, s); if (!all || rc) return rc; }
+    if (all || (dg && !vec)) { rc = launch_one<WM, WN, MT, NT, KT, true, false, false>(a, s); if (!all || rc) return rc; }
     return rc;
 }
 
@@ -398,7 +449,11 @@ static int forced_bm() {
     if (g_force_bm < 0) { const char* e = getenv("MH_CONV_BM"); g_force_bm = e ? atoi(e) : 0; }
     return g_force_bm;
 }
-extern "C" int mh_tune_conv_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn & 0xffff; g_force_kt = bn >> 16; return 0; }
+extern "C" int mh_tune_conv_tile(int bm, int bn) {
+    g_force_bm = bm & 0xffff; g_force_bn = bn & 0xffff; g_force_kt = bn >> 16;
+    g_no_uni = (bm >> 16) != 0;      // bit 16 of bm: disable the uniform-tap fast path
+    return 0;
+}
 
 struct TileCfg { int bm, bn, kt; };
 static const TileCfg kTiles[] = {

@@ -245,6 +245,8 @@ static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc
     return x;
 }
 
+static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only used on wave-uniform values
+
 static inline float atomicAdd(float* addr, float v) {
     uint32_t* p = (uint32_t*)addr;
     uint32_t old = __atomic_load_n(p, __ATOMIC_RELAXED);

@@ -132,3 +132,42 @@ def test_conv2d_transpose(backend):
     ops.conv2d_transpose_fwd(backend.lib, ops.view(x), w, b, ops.view(out), stride=2, alpha=0.1)
     backend.sync()
     assert (out.cpu() - ref).abs().max().item() <= 3e-5 * max(1.0, ref.abs().max().item())
+
+
+# forced tiles: (bm, bn, kt) x shapes whose K is a multiple of kt -> uniform-tap (UNI) loader fast path
+UNI_CASES = [
+    ((32, 32, 64), (1, 9, 14, 64, 32, 1, 2)),     # dilation 2
+    ((64, 32, 64), (2, 8, 12, 128, 24, 1, 1)),
+    ((128, 32, 32), (1, 12, 20, 32, 32, 2, 1)),   # stride 2 forward (dgrad falls back to the generic loader)
+    ((64, 64, 32), (1, 10, 16, 96, 64, 1, 1)),
+    ((32, 64, 128), (1, 6, 10, 128, 40, 1, 4)),
+]
+
+
+@pytest.mark.parametrize("tile,shape", UNI_CASES)
+def test_conv_uniform_tap_fast_path(backend, tile, shape):
+    bm, bn, kt = tile
+    B, H, W, Ci, Co, s, d = shape
+    dev = backend.device
+    x = _rand((B, H, W, Ci), 31, dev)
+    w = _rand((3, 3, Ci, Co), 32, dev, 0.2)
+    b = _rand((Co,), 33, dev)
+    Ho, Wo, _, _ = ops.conv_geometry(H, W, 3, 3, s, d)
+    gz = _rand((B, Ho, Wo, Co), 34, dev)
+    y_ref, gx_ref, _, _ = _oracle_grads(x.cpu(), w.cpu(), b.cpu(), s, d, 1.0, gz.cpu())
+    outs = {}
+    for no_uni in (0, 1):
+        backend.lib.tune_conv_tile(bm | (no_uni << 16), bn | (kt << 16))
+        try:
+            y = torch.full(y_ref.shape, float("nan"), device=dev)
+            ops.conv2d_fwd(backend.lib, ops.view(x), w, b, ops.view(y), stride=s, dil=d, alpha=1.0)
+            dx = torch.full(x.shape, float("nan"), device=dev)
+            ops.conv2d_dgrad(backend.lib, ops.view(gz), w, ops.view(dx), stride=s, dil=d)
+            backend.sync()
+        finally:
+            backend.lib.tune_conv_tile(0, 0)
+        assert (y.cpu() - y_ref).abs().max().item() <= 3e-5 * max(1.0, y_ref.abs().max().item())
+        assert (dx.cpu() - gx_ref).abs().max().item() <= 3e-5 * max(1.0, gx_ref.abs().max().item())
+        outs[no_uni] = (y.cpu(), dx.cpu())
+    # same K order in both loaders -> bitwise identical results
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
