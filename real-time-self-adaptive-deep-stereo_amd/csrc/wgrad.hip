@@ -34,6 +34,8 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
     constexpr int BN = WN * NT * 16;
     constexpr int LS = PT + 4;
     constexpr int GPT = PT / 4;
+    constexpr int AVEC = PT * BK / 4, BVEC = PT * BN / 4;
+    constexpr int AITEMS = (AVEC + NTH - 1) / NTH, BITEMS = (BVEC + NTH - 1) / NTH;
 
     HIP_DYNAMIC_SHARED(float, smem)
     float* const As = smem;                    // [2][BK*LS]
@@ -57,18 +59,13 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
     const int ntile = (mend - mbeg + PT - 1) / PT;
     const int Kr = (p.K + 3) & ~3;
 
-    // ---- tile loaders ---------------------------------------------------------------------------
-    // A "unit" = 4 consecutive pixels x one 4-channel group: 4 coalesced 16-byte loads (NHWC rows), then
-    // an in-register 4x4 transpose gives, per channel, the 4 pixels as ONE float4 -> 4 ds_write_b128 into
-    // the [channel][pixel] LDS tile (instead of 16 scalar stores).  PT = 32 pixels = 8 units per group.
-    constexpr int AUN = (BK / 4) * (PT / 4), BUN = (BN / 4) * (PT / 4);
-    constexpr int AU = (AUN + NTH - 1) / NTH, BU = (BUN + NTH - 1) / NTH;
-    int a_ox[AU], a_oy[AU], a_b[AU], a_m[AU];       // cursor of the unit's first pixel
+    // per-item pixel cursors for the A loads (advance by PT pixels per tile)
+    int a_ox[AITEMS], a_oy[AITEMS], a_b[AITEMS], a_m[AITEMS];
 #pragma unroll
-    for (int j = 0; j < AU; ++j) {
-        const int u = tid + NTH * j;
-        const int pb = u / (BK / 4);
-        const int m = mbeg + pb * 4;
+    for (int j = 0; j < AITEMS; ++j) {
+        const int q = tid + NTH * j;
+        const int kp = q / (BK / 4);
+        const int m = mbeg + kp;
         a_m[j] = m;
         a_ox[j] = m % p.Wo;
         const int t2 = m / p.Wo;
@@ -76,7 +73,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
         a_b[j] = t2 / p.Ho;
     }
 
-    float4 ra_v[AU][4], rb_v[BU][4];
+    float4 ra_v[AITEMS], rb_v[BITEMS];
     int tile_ld = 0;   // tiles loaded so far
 
     const __amdgpu_buffer_rsrc_t rs_in = mh_make_rsrc(p.in, p.in_bytes);
@@ -85,38 +82,24 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
     // all tile loads are unconditional buffer loads (out-of-range offset => 0), see mh_common.h
     auto load_tile = [&]() {
 #pragma unroll
-        for (int j = 0; j < AU; ++j) {
-            const int u = tid + NTH * j;
-            const int c4 = u % (BK / 4);
+        for (int j = 0; j < AITEMS; ++j) {
+            const int q = tid + NTH * j;
+            const int c4 = q % (BK / 4);
             const int k = k0 + c4 * 4;
-            const bool uok = (u < AUN) && (k < Kr);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                // pixel e of the unit (row / image wrap handled branch-free)
-                int ox = a_ox[j] + e, oy = a_oy[j], b = a_b[j];
-                if (p.Wo >= 4) {            // uniform; at most one row wrap inside a 4-pixel unit
-                    const bool w1 = ox >= p.Wo;
-                    ox -= w1 ? p.Wo : 0; oy += w1 ? 1 : 0;
-                    const bool w2 = oy >= p.Ho;
-                    oy -= w2 ? p.Ho : 0; b += w2 ? 1 : 0;
-                } else {                    // degenerate widths (tiny test images)
-                    while (ox >= p.Wo) { ox -= p.Wo; if (++oy == p.Ho) { oy = 0; ++b; } }
-                }
-                const int iy = oy * p.stride + dy, ix = ox * p.stride + dx;
-                const bool ok = uok && (a_m[j] + e < mend) && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-                const int off = (((b * p.Hi + iy) * p.Wi + ix) * p.in_ld + k) * 4;
-                float4 v;
-                if (VEC) {
-                    v = mh_buf_load4(rs_in, ok ? off : MH_OOB);
-                } else {
-                    v.x = mh_buf_load1(rs_in, (ok && k + 0 < p.K) ? off : MH_OOB);
-                    v.y = mh_buf_load1(rs_in, (ok && k + 1 < p.K) ? off + 4 : MH_OOB);
-                    v.z = mh_buf_load1(rs_in, (ok && k + 2 < p.K) ? off + 8 : MH_OOB);
-                    v.w = mh_buf_load1(rs_in, (ok && k + 3 < p.K) ? off + 12 : MH_OOB);
-                }
-                ra_v[j][e] = v;
+            const int iy = a_oy[j] * p.stride + dy, ix = a_ox[j] * p.stride + dx;
+            const bool ok = (q < AVEC) && (a_m[j] < mend) && (k < Kr) &&
+                            (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const int off = (((a_b[j] * p.Hi + iy) * p.Wi + ix) * p.in_ld + k) * 4;
+            float4 v;
+            if (VEC) {
+                v = mh_buf_load4(rs_in, ok ? off : MH_OOB);
+            } else {
+                v.x = mh_buf_load1(rs_in, (ok && k + 0 < p.K) ? off : MH_OOB);
+                v.y = mh_buf_load1(rs_in, (ok && k + 1 < p.K) ? off + 4 : MH_OOB);
+                v.z = mh_buf_load1(rs_in, (ok && k + 2 < p.K) ? off + 8 : MH_OOB);
+                v.w = mh_buf_load1(rs_in, (ok && k + 3 < p.K) ? off + 12 : MH_OOB);
             }
-            // advance the unit by PT pixels
+            ra_v[j] = v;
             a_m[j] += PT;
             a_ox[j] += PT;
             while (a_ox[j] >= p.Wo) {
@@ -125,52 +108,47 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
             }
         }
 #pragma unroll
-        for (int j = 0; j < BU; ++j) {
-            const int u = tid + NTH * j;
-            const int pb = u / (BN / 4), n4 = u % (BN / 4);
-            const int m = mbeg + tile_ld * PT + pb * 4;
+        for (int j = 0; j < BITEMS; ++j) {
+            const int q = tid + NTH * j;
+            const int kp = q / (BN / 4), n4 = q % (BN / 4);
+            const int m = mbeg + tile_ld * PT + kp;
             const int n = n0 + n4 * 4;
-            const bool uok = (u < BUN) && (n < p.N);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const bool ok = uok && (m + e < mend);
-                const int off = ((m + e) * p.dz_ld + n) * 4;
-                float4 v;
-                if (VEC) {
-                    v = mh_buf_load4(rs_dz, ok ? off : MH_OOB);
-                } else {
-                    v.x = mh_buf_load1(rs_dz, ok ? off : MH_OOB);
-                    v.y = mh_buf_load1(rs_dz, (ok && n + 1 < p.N) ? off + 4 : MH_OOB);
-                    v.z = mh_buf_load1(rs_dz, (ok && n + 2 < p.N) ? off + 8 : MH_OOB);
-                    v.w = mh_buf_load1(rs_dz, (ok && n + 3 < p.N) ? off + 12 : MH_OOB);
-                }
-                rb_v[j][e] = v;
+            const bool ok = (q < BVEC) && (m < mend) && (n < p.N);
+            const int off = (m * p.dz_ld + n) * 4;
+            float4 v;
+            if (VEC) {
+                v = mh_buf_load4(rs_dz, ok ? off : MH_OOB);
+            } else {
+                v.x = mh_buf_load1(rs_dz, ok ? off : MH_OOB);
+                v.y = mh_buf_load1(rs_dz, (ok && n + 1 < p.N) ? off + 4 : MH_OOB);
+                v.z = mh_buf_load1(rs_dz, (ok && n + 2 < p.N) ? off + 8 : MH_OOB);
+                v.w = mh_buf_load1(rs_dz, (ok && n + 3 < p.N) ? off + 12 : MH_OOB);
             }
+            rb_v[j] = v;
         }
         ++tile_ld;
-    };
-
-    auto store_unit = [&](float* base, int row0, int pb, const float4 (&v)[4]) {
-        // rows row0..row0+3 (4 channels) share (row>>2): one swizzled 4-pixel group for all of them
-        float* d = base + row0 * LS + swz_group<GPT>(row0, pb) * 4;
-        *reinterpret_cast<float4*>(d) = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
-        *reinterpret_cast<float4*>(d + LS) = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
-        *reinterpret_cast<float4*>(d + 2 * LS) = make_float4(v[0].z, v[1].z, v[2].z, v[3].z);
-        *reinterpret_cast<float4*>(d + 3 * LS) = make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
     };
 
     auto store_tile = [&](int buf) {
         float* Ab = As + buf * (BK * LS);
         float* Bb = Bs + buf * (BN * LS);
 #pragma unroll
-        for (int j = 0; j < AU; ++j) {
-            const int u = tid + NTH * j;
-            if (u < AUN) store_unit(Ab, (u % (BK / 4)) * 4, u / (BK / 4), ra_v[j]);
+        for (int j = 0; j < AITEMS; ++j) {
+            const int q = tid + NTH * j;
+            if (q < AVEC) {
+                const int kp = q / (BK / 4), c4 = q % (BK / 4);
+                float* d = &Ab[(c4 * 4) * LS + swz_group<GPT>(c4 * 4, kp >> 2) * 4 + (kp & 3)];
+                d[0] = ra_v[j].x; d[LS] = ra_v[j].y; d[2 * LS] = ra_v[j].z; d[3 * LS] = ra_v[j].w;
+            }
         }
 #pragma unroll
-        for (int j = 0; j < BU; ++j) {
-            const int u = tid + NTH * j;
-            if (u < BUN) store_unit(Bb, (u % (BN / 4)) * 4, u / (BN / 4), rb_v[j]);
+        for (int j = 0; j < BITEMS; ++j) {
+            const int q = tid + NTH * j;
+            if (q < BVEC) {
+                const int kp = q / (BN / 4), n4 = q % (BN / 4);
+                float* d = &Bb[(n4 * 4) * LS + swz_group<GPT>(n4 * 4, kp >> 2) * 4 + (kp & 3)];
+                d[0] = rb_v[j].x; d[LS] = rb_v[j].y; d[2 * LS] = rb_v[j].z; d[3 * LS] = rb_v[j].w;
+            }
         }
     };
 
