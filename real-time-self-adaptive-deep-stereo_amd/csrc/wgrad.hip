@@ -18,6 +18,7 @@ struct WgradArgs {
     int M, taps, ktiles, ntiles, splits, chunk;
     int vecA, vecB;
     unsigned in_bytes, dz_bytes;
+    int dbg_plain_store;   // timing experiment only: plain stores instead of atomics (WRONG results)
 };
 
 template <int GPT>
@@ -210,7 +211,10 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int n = n0 + wn * NT * 16 + j * 16 + li;
-                if (n < p.N) atomicAdd(p.dw + ((int64_t)tap * p.K + k) * p.N + n, acc[i][j][r]);
+                if (n < p.N) {
+                    float* d = p.dw + ((int64_t)tap * p.K + k) * p.N + n;
+                    if (p.dbg_plain_store) *d = acc[i][j][r]; else atomicAdd(d, acc[i][j][r]);
+                }
             }
         }
     if (do_bias && n0 + tid < p.N) atomicAdd(p.db + n0 + tid, bsum);
@@ -218,7 +222,13 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
 
 static int g_wgrad_target_wgs = 0;
 // tuning hook (microbenchmarks): number of workgroups the pixel split aims for (0 = heuristic)
-extern "C" int mh_tune_wgrad_wgs(int target) { g_wgrad_target_wgs = target > 0 ? target : 0; return 0; }
+static int g_wgrad_plain = 0;
+extern "C" int mh_tune_wgrad_wgs(int target) {
+    g_wgrad_plain = target < 0;                    // negative: timing experiment with plain stores (wrong results)
+    if (target < 0) target = -target;
+    g_wgrad_target_wgs = target > 1 ? target : 0;
+    return 0;
+}
 
 template <int WM, int WN, int MT, int NT, int PT, bool VEC>
 int launch_wgrad_one(WgradArgs& a, hipStream_t s) {
@@ -314,6 +324,7 @@ extern "C" int mh_conv2d_wgrad(const mh_conv_desc* d, const float* in, const flo
     a.M = d->B * d->Ho * d->Wo; a.taps = d->kh * d->kw;
     a.vecA = mh_aligned16(in) && (d->in_ld % 4 == 0) && (d->in_ld >= ((d->K + 3) & ~3));
     a.vecB = mh_aligned16(dout) && (dout_ld % 4 == 0) && (d->N % 4 == 0);
+    a.dbg_plain_store = g_wgrad_plain;
     {
         const int64_t inb = (((int64_t)d->B * d->Hi * d->Wi - 1) * d->in_ld + (int64_t)((d->K + 3) / 4) * 4) * 4;
         const int64_t dzb = (((int64_t)a.M - 1) * dout_ld + d->N) * 4;

@@ -56,7 +56,7 @@ def run_conv():
 
 
 def run_wgrad():
-    targets = [192, 256, 384, 512, 768, 1536]
+    targets = [192, 384, 512, 768, 1536]
     print("%-20s %s" % ("wgrad layer", " ".join("%9d" % t for t in targets)))
     for name, B, H, W, Ci, Co, s, d in LAYERS:
         ld = (Ci + 3) // 4 * 4

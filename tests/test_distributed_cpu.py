@@ -1,0 +1,91 @@
+"""N>1 path on CPU: world_size-2 gloo processes.  (a) independent streams: rank-sharded synthetic
+streams, no collective; (b) shared model: all-reduce of the flat gradient buffer between the backward
+plan and the momentum plan == single-process step on the SUM of the two streams' gradients / 2.
+Runs the CPU-emulated build of the kernels (tests/emul) at a tiny resolution."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "real-time-self-adaptive-deep-stereo_amd")
+H, W = 48, 64
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["MH_EMUL_THREADS"] = "4"
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from madnet_hip import _ffi, engine as E, synthetic as S
+        from madnet_hip.adapter import Adapter
+        import Nets
+        lib = _ffi.Lib(os.path.join(ROOT, "tests", "emul", "libmadnet_emul.so"))
+        lib.ensure_init()
+        shapes = dict(E.madnet_manifest())
+        wn = S.calibrated_weights(shapes, 1)
+        l, r, gt = S.make_pair(H, W, stream_id=rank)              # stream i -> rank i
+        left = torch.from_numpy(l); right = torch.from_numpy(r)
+        net = Nets.get_stereo_net("MADNet", {"left_img": left, "right_img": right, "split_layers": [None], "sequence": True,
+                                              "train_portion": "BEGIN", "bulkhead": False, "weights": wn,
+                                              "_lib": lib, "_device": "cpu"})
+        ad = Adapter(net, mode="FULL", lr=1e-2, shared_model=True, use_graph=False)
+        out = ad.step(l, r, gt[..., 0])
+        w_after = net.engine.params.w.clone()
+        g_sum = net.engine.params.g.clone()                         # all-reduced (summed) gradient
+        # every rank must hold identical weights after the shared update
+        ws = [torch.zeros_like(w_after) for _ in range(world)]
+        dist.all_gather(ws, w_after)
+        q.put((rank, out["loss"], bool(torch.equal(ws[0], ws[1])), w_after.numpy(), g_sum.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_shared_model_allreduce_world2():
+    from conftest import _emul_backend
+    backend = _emul_backend()           # builds tests/emul/libmadnet_emul.so
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][2] and res[1][2], "ranks diverged after the shared update"
+    # reference: single process, gradients of both streams summed, scaled by 1/2
+    from madnet_hip import engine as E, synthetic as S
+    import numpy as np
+    shapes = dict(E.madnet_manifest())
+    wn = S.calibrated_weights(shapes, 1)
+    gsum = None
+    for sid in range(2):
+        l, r, gt = S.make_pair(H, W, stream_id=sid)
+        eng = E.MadNetEngine(backend.lib, H, W, B=1, device="cpu", weights=wn)
+        eng.set_inputs(l, r, gt[..., 0])
+        eng.build_plan("FULL", lr=1e-2, update=False).run(backend.lib, 0)
+        gsum = eng.params.g.clone() if gsum is None else gsum + eng.params.g
+    w0 = eng.params.w.clone()            # untouched (update=False)
+    w_ref = w0 - 1e-2 * (0.5 * gsum)     # first step: accum = g/2 ; w -= lr*accum
+    assert np.allclose(res[0][4], gsum.numpy(), rtol=1e-4, atol=1e-7 * float(gsum.abs().max()) + 1e-12)
+    assert np.allclose(res[0][3], w_ref.numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_stream_sharding_is_disjoint():
+    """stream i -> rank i mod G: bench.py / Adapter use make_pair(stream_id=rank)."""
+    from madnet_hip import synthetic as S
+    a = S.make_pair(32, 48, stream_id=0)[0]
+    b = S.make_pair(32, 48, stream_id=1)[0]
+    assert a.shape == b.shape and not (a == b).all()
