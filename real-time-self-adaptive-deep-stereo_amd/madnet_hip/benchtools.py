@@ -27,6 +27,18 @@ def _time_ms(lib, stream, fn, reps):
     return ms.value / reps
 
 
+def _pmc_traffic(key):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_roofline.json,
+    produced by scripts/gpu_pmc.sh); None if the file is absent."""
+    import json
+    import os
+    f = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles", "r01_pmc_roofline.json")
+    try:
+        return json.load(open(f))[key]["traffic_bytes"]
+    except Exception:
+        return None
+
+
 def roofline(lib, eng, stream, reps=20):
     """Dominant kernel of the step = the 128->128 3x3 implicit-GEMM conv at 1/4 resolution
     (context-2/3, G2 disp-2: 27 of the 70 forward GFLOP; its dgrad is the same kernel).
@@ -45,7 +57,7 @@ def roofline(lib, eng, stream, reps=20):
     ach = flops / (ms * 1e-3) / 1e12
     rl = {"kernel": "conv_igemm_kernel (3x3 128->128 @ %dx%d, dil 2; tile chosen by conv_dispatch)" % (x.H, x.W),
           "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-          "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+          "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": _pmc_traffic("conv_3x3_128_128_96x320"),
           "launch_ms": ms, "algorithmic_flops_per_launch": flops}
     # correlation protocol: level-2 shape with B=64 streams (working set > 256 MiB
     # Infinity Cache) for the HBM claim, plus the in-situ B=1 time (cache resident).
@@ -61,7 +73,7 @@ def roofline(lib, eng, stream, reps=20):
         g = byts / (ms_c * 1e-3) / 1e9
         extra["roofline_corr"] = {"kernel": "corr_fwd_small<8,64> (B=64 x %dx%dx%d, D=%d)" % (H, W, Cc, D), "bound": "hbm",
                                   "achieved": g, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": g / PEAK_HBM_GBS,
-                                  "traffic": None, "launch_ms": ms_c, "algorithmic_bytes_per_launch": byts}
+                                  "traffic": _pmc_traffic("corr_fwd_B64_96x320x32_D5"), "launch_ms": ms_c, "algorithmic_bytes_per_launch": byts}
         L1, R1 = L[:1].contiguous(), R[:1].contiguous(); o1 = out[:1].contiguous()
         ms_1 = _time_ms(lib, stream, lambda: ops.corr_fwd(lib, ops.view(L1), ops.view(R1), ops.view(o1), md, stream=sh), 20)
         extra["roofline_corr"]["in_situ_B1_ms"] = ms_1
