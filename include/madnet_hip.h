@@ -146,6 +146,7 @@ int mh_fill(float* p, int64_t n, float v, void* stream);
 /* ---- tuning hooks used by scripts/microbench.py (0 = built-in heuristic) ------------------ */
 int mh_tune_conv_tile(int bm, int bn);
 int mh_tune_wgrad_wgs(int target_workgroups);
+int mh_tune_corr(int direct);
 
 /* ---- native plan executor: the host (Python) compiles the network into an array of op
  *      records once; one FFI call replays it (optionally captured into a hipGraph). ------ */

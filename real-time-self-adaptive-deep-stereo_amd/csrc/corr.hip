@@ -24,6 +24,7 @@ struct CorrArgs {
     int l_ld, r_ld, out_ld, coff;
     int B, H, W, C, md, stride, D;
     int copy_left, zero_tail, segs;
+    unsigned l_bytes, r_bytes;
 };
 
 // LPP lanes per pixel (power of two <= 64), TW pixels per workgroup segment.
@@ -88,6 +89,62 @@ __global__ __launch_bounds__(256) void corr_fwd_small(CorrArgs p) {
                 if (j < p.D) dst[j] = accd[j] * inv_c;
             int tail = p.coff + p.D;
             if (p.u) { Op[tail] = p.u[pix]; ++tail; }
+            if (p.zero_tail)
+                for (; tail < p.out_ld; ++tail) Op[tail] = 0.f;
+        }
+    }
+}
+
+// Direct variant for small D: no LDS, no barrier.  Every lane issues its left float4 and the D shifted
+// right float4 as independent bounds-checked buffer loads (a shift that leaves the row gets an
+// out-of-range offset => the hardware returns the zero padding of correlation_tf), so D+1 16-byte loads
+// per lane are in flight at once; neighbouring pixels re-read the same right rows from L1 (5x request
+// amplification at the TA, still far below its bandwidth), HBM sees each byte once.
+template <int LPP>
+__global__ __launch_bounds__(256) void corr_fwd_direct(CorrArgs p) {
+    constexpr int PPB = 256 / LPP;
+    const int tid = threadIdx.x;
+    const int sub = tid % LPP;
+    const int C4 = p.C >> 2;
+    const float inv_c = 1.0f / (float)p.C;
+    const int64_t npix = (int64_t)p.B * p.H * p.W;
+    const int64_t nit = (npix + PPB - 1) / PPB;
+    const __amdgpu_buffer_rsrc_t rsL = mh_make_rsrc(p.L, p.l_bytes);
+    const __amdgpu_buffer_rsrc_t rsR = mh_make_rsrc(p.R, p.r_bytes);
+    for (int64_t it = blockIdx.x; it < nit; it += gridDim.x) {
+        const int64_t pix = it * PPB + tid / LPP;
+        const bool live = pix < npix;
+        const int pp = live ? (int)pix : 0;
+        const int x = pp % p.W;
+        float accd[MAXD_SMALL];
+#pragma unroll
+        for (int j = 0; j < MAXD_SMALL; ++j) accd[j] = 0.f;
+        float* Op = p.out + (int64_t)pp * p.out_ld;
+        for (int c4 = sub; c4 < C4; c4 += LPP) {
+            const float4 l = mh_buf_load4(rsL, live ? (pp * p.l_ld + c4 * 4) * 4 : MH_OOB);
+            float4 r[MAXD_SMALL];
+#pragma unroll
+            for (int j = 0; j < MAXD_SMALL; ++j) {
+                const int xs = x + j * p.stride - p.md;
+                const bool ok = live && (j < p.D) && (unsigned)xs < (unsigned)p.W;
+                r[j] = mh_buf_load4(rsR, ok ? ((pp + xs - x) * p.r_ld + c4 * 4) * 4 : MH_OOB);
+            }
+            if (live && p.copy_left) *reinterpret_cast<float4*>(Op + c4 * 4) = l;
+#pragma unroll
+            for (int j = 0; j < MAXD_SMALL; ++j) accd[j] += l.x * r[j].x + l.y * r[j].y + l.z * r[j].z + l.w * r[j].w;
+        }
+#pragma unroll
+        for (int j = 0; j < MAXD_SMALL; ++j) {
+#pragma unroll
+            for (int o = LPP >> 1; o > 0; o >>= 1) accd[j] += __shfl_xor(accd[j], o);
+        }
+        if (live && sub == 0) {
+            float* dst = Op + p.coff;
+#pragma unroll
+            for (int j = 0; j < MAXD_SMALL; ++j)
+                if (j < p.D) dst[j] = accd[j] * inv_c;
+            int tail = p.coff + p.D;
+            if (p.u) { Op[tail] = p.u[pp]; ++tail; }
             if (p.zero_tail)
                 for (; tail < p.out_ld; ++tail) Op[tail] = 0.f;
         }
@@ -211,6 +268,10 @@ __global__ __launch_bounds__(256) void corr_bwd_kernel(CorrBwdArgs p) {
 
 }  // namespace
 
+static int g_corr_direct = 1;
+// tuning hook: 0 = LDS-staged window kernel, 1 = direct (no LDS) kernel for D <= 9
+extern "C" int mh_tune_corr(int direct) { g_corr_direct = direct; return 0; }
+
 extern "C" int mh_corr_fwd(const float* L, int32_t l_ld, const float* R, int32_t r_ld, const float* u,
                            float* out, int32_t out_ld, int32_t coff,
                            int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t stride,
@@ -229,6 +290,16 @@ extern "C" int mh_corr_fwd(const float* L, int32_t l_ld, const float* R, int32_t
     a.copy_left = copy_left; a.zero_tail = zero_tail;
     hipStream_t s = (hipStream_t)stream;
     const int C4 = C / 4;
+    const int64_t lb = (((int64_t)B * H * W - 1) * l_ld + C) * 4, rb = (((int64_t)B * H * W - 1) * r_ld + C) * 4;
+    if (D <= MAXD_SMALL && g_corr_direct && lb < (1ll << 31) - 64 && rb < (1ll << 31) - 64) {
+        a.l_bytes = (unsigned)lb; a.r_bytes = (unsigned)rb;
+        const int64_t npix = (int64_t)B * H * W;
+        auto grid = [&](int lpp) { int64_t g = (npix * lpp + 255) / 256; return dim3((unsigned)(g > 256 * 32 ? 256 * 32 : g)); };
+        if (C4 <= 4) hipLaunchKernelGGL((corr_fwd_direct<4>), grid(4), dim3(256), 0, s, a);
+        else if (C4 <= 8) hipLaunchKernelGGL((corr_fwd_direct<8>), grid(8), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((corr_fwd_direct<16>), grid(16), dim3(256), 0, s, a);
+        return mh_check_launch("corr_fwd_direct");
+    }
     if (D <= MAXD_SMALL) {
         // lanes per pixel: cover the channel groups with at most 16 lanes
         const int TW = 64;

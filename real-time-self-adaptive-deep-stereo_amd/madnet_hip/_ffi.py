@@ -43,6 +43,7 @@ SIGNATURES = {
     "mh_init": (_I, []),
     "mh_tune_conv_tile": (_I, [_I, _I]),
     "mh_tune_wgrad_wgs": (_I, [_I]),
+    "mh_tune_corr": (_I, [_I]),
     "mh_conv2d": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     "mh_conv2d_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _I, _P, _P, _P]),
     "mh_corr_fwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -79,10 +79,13 @@ def run_corr():
         L = torch.randn(B, H, W, Cc, device=dev); R = torch.randn(B, H, W, Cc, device=dev)
         D = 2 * md + 1
         out = torch.empty(B, H, W, D, device=dev)
-        with torch.cuda.stream(stream):
-            ms = _time_ms(lib, stream, lambda: ops.corr_fwd(lib, ops.view(L), ops.view(R), ops.view(out), md, stream=stream.cuda_stream), 10)
         byts = float(B) * H * W * (2 * Cc + D) * 4
-        print("corr fwd B=%d %dx%dx%d D=%d: %.1f us  %.0f GB/s (%.1f%% of 8 TB/s)" % (B, H, W, Cc, D, ms * 1e3, byts / ms / 1e6, byts / ms / 1e6 / 80))
+        for direct in (0, 1):
+            lib.tune_corr(direct)
+            with torch.cuda.stream(stream):
+                ms = _time_ms(lib, stream, lambda: ops.corr_fwd(lib, ops.view(L), ops.view(R), ops.view(out), md, stream=stream.cuda_stream), 10)
+            print("corr fwd %s B=%d %dx%dx%d D=%d: %.1f us  %.0f GB/s (%.1f%% of 8 TB/s)" % ("direct" if direct else "lds   ", B, H, W, Cc, D, ms * 1e3, byts / ms / 1e6, byts / ms / 1e6 / 80))
+        lib.tune_corr(1)
 
 
 if what in ("conv", "all"):

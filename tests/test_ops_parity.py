@@ -218,3 +218,20 @@ def test_momentum_and_glue(backend):
     exp = d0.clone(); exp[..., 2:5] += 2.0 * src.cpu()
     assert torch.allclose(dst.cpu(), exp)
     assert torch.allclose(dy.cpu(), dy0 * torch.where(y.cpu() > 0, 1.0, 0.2))
+
+
+@pytest.mark.parametrize("direct", [0, 1])
+def test_corr_fwd_both_kernels(backend, direct):
+    """LDS-staged window kernel vs direct (bounds-checked buffer loads) kernel: same values."""
+    B, H, W, C, md = 2, 3, 37, 32, 2
+    dev = backend.device
+    L = _rand((B, H, W, C), 21, dev); R = _rand((B, H, W, C), 22, dev)
+    ref = T.correlation(L.cpu(), R.cpu(), md, 1)
+    out = torch.full((B, H, W, 5), float("nan"), device=dev)
+    backend.lib.tune_corr(direct)
+    try:
+        ops.corr_fwd(backend.lib, ops.view(L), ops.view(R), ops.view(out), md, 1)
+        backend.sync()
+    finally:
+        backend.lib.tune_corr(1)
+    ok, err = _close(out, ref); assert ok, err
