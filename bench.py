@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", default="FULL", choices=["FULL", "NONE"])
+    ap.add_argument("--model", default="madnet", choices=["madnet", "dispnet"])
     ap.add_argument("--height", type=int, default=375)
     ap.add_argument("--width", type=int, default=1242)
     ap.add_argument("--no-graph", action="store_true")
@@ -89,13 +90,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
 
-    from madnet_hip import _ffi, engine as E, synthetic as S, benchtools as BT
+    from madnet_hip import _ffi, engine as E, dispnet_engine as DE, synthetic as S, benchtools as BT
     lib = _ffi.lib()
     H, W = args.height, args.width
-    shapes = dict((n, s) for n, s in E.madnet_manifest())
+    dispnet = args.model == "dispnet"
+    shapes = dict(DE.dispnet_manifest() if dispnet else E.madnet_manifest())
     wn = S.calibrated_weights(shapes, 1)
     l, r, gt = S.make_pair(H, W, stream_id=rank)
-    eng = E.MadNetEngine(lib, H, W, B=1, device=dev, weights=wn)
+    eng = DE.DispNetEngine(lib, H, W, B=1, device=dev, weights=wn) if dispnet else E.MadNetEngine(lib, H, W, B=1, device=dev, weights=wn)
     eng.set_inputs(l, r, gt[..., 0])
     plan = eng.build_plan(args.mode, lr=1e-4)
     stream = torch.cuda.Stream()
@@ -131,22 +133,22 @@ def main():
         dt = float(t.item())
     loss = float(eng.res_loss[0].item())
     epe_gt = float(eng.res_met[0].item())
-    nonzero = float((eng.pred > 0).float().mean().item())
+    nonzero = float((eng.pred != 0).float().mean().item())
     assert nonzero >= 0.25, "degenerate synthetic network: only %.1f%% of the disparities are non-zero" % (100 * nonzero)
 
     out = {
-        "metric": "adapted stereo pairs/sec (whole node), MADNet full-backprop online adaptation 1242x375",
+        "metric": "adapted stereo pairs/sec (whole node), %s full-backprop online adaptation 1242x375" % ("DispNet" if dispnet else "MADNet"),
         "value": world * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "MADNet %s adaptation step (fwd+SSIM/L1 loss+EPE+bwd+momentum), %dx%d, 1 pair/GPU/step, "
+        "config": {"workload": ("DispNet" if dispnet else "MADNet") + " %s adaptation step (fwd+SSIM/L1 loss+EPE+bwd+momentum), %dx%d, 1 pair/GPU/step, "
                                "private model per stream" % (args.mode, W, H),
                    "launch": "eager plan" if args.no_graph else "hipGraph replay",
                    "ops_per_step": plan.n, "final_loss": loss, "epe_vs_synthetic_gt": epe_gt,
                    "pred_nonzero_frac": nonzero},
     }
     _log("timed region done: %.3f ms/step" % (1e3 * dt / args.steps))
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not dispnet:
         if not args.no_roofline:
             with torch.cuda.stream(stream):
                 out["roofline"], extra = BT.roofline(lib, eng, stream)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 1
+#define MH_ABI_VERSION 2
 
 const char* mh_last_error(void);
 int mh_abi_version(void);
@@ -53,6 +53,8 @@ typedef struct mh_conv_desc {
     int32_t accumulate;             /* out = result + out                                        */
     float alpha;                    /* leaky slope applied to (acc+bias); 1 = linear             */
     float mask_alpha;               /* if mask_ref: out *= (mask_ref>0 ? 1 : mask_alpha)  (fused leaky-grad) */
+    int32_t mask_c0, mask_c1;       /* the mask applies to output channels [mask_c0, mask_c1); 0,0 = all
+                                       (a concat gradient masks only the slice produced by an activation) */
 } mh_conv_desc;
 
 int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w, const float* bias,
@@ -110,8 +112,10 @@ int mh_resize_bwd(const float* g, const float* in, float* din, int32_t accumulat
 
 /* ---- preprocessing.pad_image (REFLECT, preprocessing.py:7-29) fused with the float cast
  *      and the channel padding 3 -> out_ld (extra channels zero) ------------------------ */
+/* out = in / div - sub  (MADNet: div=1, sub=0; DispNet._preprocess_inputs, DispNet.py:59-73: x/255 - 100/255) */
 int mh_pad_reflect(const float* in, float* out, int32_t B, int32_t H, int32_t W, int32_t C,
-                   int32_t Hp, int32_t Wp, int32_t pad_t, int32_t pad_l, int32_t out_ld, void* stream);
+                   int32_t Hp, int32_t Wp, int32_t pad_t, int32_t pad_l, int32_t out_ld,
+                   float div, float sub, void* stream);
 
 /* ---- loss_factory.get_reprojection_loss('mean_SSIM_l1') forward + gradient w.r.t. the
  *      disparity (Losses/loss_factory.py:128-164,353-395; preprocessing.py:121-230) ------
@@ -142,6 +146,8 @@ int mh_copy_channels(const float* src, int32_t src_ld, float* dst, int32_t dst_l
 int mh_leaky_bwd(float* dy, int32_t dy_ld, const float* y, int32_t y_ld, int64_t npix, int32_t nch,
                  float alpha, void* stream);
 int mh_fill(float* p, int64_t n, float v, void* stream);
+/* db[c] += sum_p dz[p][c]  (BiasAddGrad of conv2d_transpose, whose filter gradient runs with swapped operands) */
+int mh_bias_grad(const float* dz, int32_t dz_ld, int64_t npix, int32_t nch, float* db, void* stream);
 
 /* ---- tuning hooks used by scripts/microbench.py (0 = built-in heuristic) ------------------ */
 int mh_tune_conv_tile(int bm, int bn);
@@ -152,7 +158,7 @@ int mh_tune_corr(int direct);
  *      records once; one FFI call replays it (optionally captured into a hipGraph). ------ */
 enum { MH_OP_CONV = 1, MH_OP_WGRAD, MH_OP_CORR_FWD, MH_OP_CORR_BWD, MH_OP_WARP_FWD, MH_OP_WARP_BWD,
        MH_OP_RESIZE_FWD, MH_OP_RESIZE_BWD, MH_OP_PAD_REFLECT, MH_OP_LOSS, MH_OP_METRICS,
-       MH_OP_MOMENTUM, MH_OP_COPY_CH, MH_OP_LEAKY_BWD, MH_OP_FILL };
+       MH_OP_MOMENTUM, MH_OP_COPY_CH, MH_OP_LEAKY_BWD, MH_OP_FILL, MH_OP_BIAS_GRAD };
 typedef struct mh_op {
     int32_t kind;
     int32_t i[27];

@@ -31,6 +31,7 @@ struct ConvArgs {
     int vecA, vecB;  // 16-byte vector loads legal for A / B
     int mtiles, ntiles;
     float alpha, mask_alpha;
+    int mask_c0, mask_c1;   // channel range the leaky-grad mask applies to
 };
 
 // LDS tiles are k-contiguous for BOTH operands (As[row][k], Bs[col][k], row stride KT+4 floats) so
@@ -363,8 +364,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             }
             v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
             if (p.mask_ref) {
-                v.x *= (mk.x > 0.f) ? 1.0f : p.mask_alpha; v.y *= (mk.y > 0.f) ? 1.0f : p.mask_alpha;
-                v.z *= (mk.z > 0.f) ? 1.0f : p.mask_alpha; v.w *= (mk.w > 0.f) ? 1.0f : p.mask_alpha;
+                v.x *= (mk.x > 0.f || n + 0 < p.mask_c0 || n + 0 >= p.mask_c1) ? 1.0f : p.mask_alpha;
+                v.y *= (mk.y > 0.f || n + 1 < p.mask_c0 || n + 1 >= p.mask_c1) ? 1.0f : p.mask_alpha;
+                v.z *= (mk.z > 0.f || n + 2 < p.mask_c0 || n + 2 >= p.mask_c1) ? 1.0f : p.mask_alpha;
+                v.w *= (mk.w > 0.f || n + 3 < p.mask_c0 || n + 3 >= p.mask_c1) ? 1.0f : p.mask_alpha;
             }
             if (ok) *reinterpret_cast<float4*>(p.out + (int64_t)m * p.out_ld + n) = v;
         }
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
                 if (p.alpha != 1.0f) v = v > 0.f ? v : p.alpha * v;
                 float* dst = p.out + (int64_t)m * p.out_ld + n;
                 if (p.accumulate) v += *dst;
-                if (p.mask_ref) {
+                if (p.mask_ref && n >= p.mask_c0 && n < p.mask_c1) {
                     const float y = p.mask_ref[(int64_t)m * p.mask_ld + n];
                     v *= (y > 0.f) ? 1.0f : p.mask_alpha;
                 }
@@ -494,7 +497,8 @@ static int conv_dispatch(ConvArgs& a, hipStream_t s) {
                 if (take) { best_w = w; best_area = area; bm = t.bm; bn = t.bn; kt = t.kt; }
             }
             // latency-bound (few workgroups, long K): deepen the K-tile
-            if (best_w < 240 && ktot >= 512 && bm * bn <= 2048) kt = 128;
+            if (best_w < 240 && ktot >= 512)
+                for (const TileCfg& t : kTiles) if (t.bm == bm && t.bn == bn && t.kt == 128) kt = 128;
         }
         if (kt == 0) for (const TileCfg& t : kTiles) if (t.bm == bm && t.bn == bn) { kt = t.kt; break; }
     }
@@ -558,6 +562,7 @@ extern "C" int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w,
     MH_REQUIRE(d->mode == 0 || (1 << a.sshift) == d->stride, MH_ERR_UNSUPPORTED, "mh_conv2d: mode 1 needs a power-of-two stride");
     a.M = d->B * d->Ho * d->Wo;
     a.alpha = d->alpha; a.mask_alpha = d->mask_alpha;
+    a.mask_c0 = d->mask_c0; a.mask_c1 = (d->mask_c0 == 0 && d->mask_c1 == 0) ? d->N : d->mask_c1;
     // 16-byte vector loads of A need every group start 16B aligned and the full group in-bounds
     a.vecA = mh_aligned16(in) && (d->in_ld % 4 == 0) && (d->in_ld >= a.G * 4);
     a.vecB = mh_aligned16(w) && (d->w_trans ? (d->K % 4 == 0) : (d->N % 4 == 0));

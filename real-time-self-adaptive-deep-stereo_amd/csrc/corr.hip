@@ -268,6 +268,13 @@ __global__ __launch_bounds__(256) void corr_bwd_kernel(CorrBwdArgs p) {
 
 }  // namespace
 
+int mh_corr_init() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_large<32>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) { mh_set_error("corr: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
 static int g_corr_direct = 1;
 // tuning hook: 0 = LDS-staged window kernel, 1 = direct (no LDS) kernel for D <= 9
 extern "C" int mh_tune_corr(int direct) { g_corr_direct = direct; return 0; }
@@ -315,11 +322,7 @@ extern "C" int mh_corr_fwd(const float* L, int32_t l_ld, const float* R, int32_t
         a.segs = mh_cdiv(W, TW);
         const size_t lds = (size_t)(2 * TW + 2 * max_disp) * (C + 4) * sizeof(float);
         MH_REQUIRE(lds <= 150 * 1024, MH_ERR_UNSUPPORTED, "mh_corr_fwd: tiles do not fit LDS (C=%d, md=%d)", C, max_disp);
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_large<32>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            MH_REQUIRE(e == hipSuccess, (int)e, "mh_corr_fwd: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
-        }
+        // (the > 64 KiB dynamic-LDS opt-in of this kernel is done once in mh_init(), never during a capture)
         hipLaunchKernelGGL((corr_fwd_large<32>), dim3(a.segs * B * H), dim3(256), lds, s, a);
     }
     return mh_check_launch("corr_fwd");

@@ -25,12 +25,14 @@ int mh_check_launch(const char* what) {
 
 int mh_conv_init();
 int mh_wgrad_init();
+int mh_corr_init();
 
 extern "C" const char* mh_last_error(void) { return g_err; }
 // one-time, capture-unsafe set-up (dynamic-LDS opt-in of every kernel instantiation)
 extern "C" int mh_init(void) {
     if (int e = mh_conv_init()) return e;
     if (int e = mh_wgrad_init()) return e;
+    if (int e = mh_corr_init()) return e;
     return 0;
 }
 extern "C" int mh_abi_version(void) { return MH_ABI_VERSION; }
@@ -43,7 +45,7 @@ extern "C" int mh_device_count(void) {
 
 // ---- plan executor ------------------------------------------------------------------------
 // Field packing of mh_op per kind (host side: madnet_hip/plan.py must match):
-//  CONV      i[0..20] = mh_conv_desc fields in declaration order (ints), f[0]=alpha f[1]=mask_alpha
+//  CONV      i[0..18] = mh_conv_desc ints in declaration order, i[19]=mask_c0 i[20]=mask_c1, f[0]=alpha f[1]=mask_alpha
 //            p[0]=in p[1]=w p[2]=bias p[3]=out p[4]=mask_ref
 //  WGRAD     same desc; i[21]=dout_ld ; p[0]=in p[1]=dout p[2]=dw p[3]=db
 //  CORR_FWD  i: l_ld r_ld out_ld coff B H W C md stride copy_left zero_tail ; p: L R u out
@@ -51,19 +53,20 @@ extern "C" int mh_device_count(void) {
 //  WARP_FWD  i: img_ld out_ld B H W C ; p: img u out
 //  WARP_BWD  i: g_ld img_ld dimg_ld acc_u B H W C ; p: g img u dimg du
 //  RESIZE_*  i: B Hi Wi Hr Wr cy cx Ho Wo mode accumulate ; f[0]=mul ; FWD p: in out ; BWD p: g in din
-//  PAD       i: B H W C Hp Wp pt pl out_ld ; p: in out
+//  PAD       i: B H W C Hp Wp pt pl out_ld ; f: div sub ; p: in out
 //  LOSS      i: B H W ; f[0]=grad_scale ; p: left right disp ws result ddisp
 //  METRICS   i: B H W ; f[0]=pixel_th ; p: disp gt ws result
 //  MOMENTUM  n ; f: lr momentum grad_scale ; p: var accum grad
 //  COPY_CH   i: src_ld dst_ld nch accumulate ; n=npix ; f[0]=scale ; p: src dst
 //  LEAKY_BWD i: dy_ld y_ld nch ; n=npix ; f[0]=alpha ; p: dy y
 //  FILL      n ; f[0]=v ; p: ptr
+//  BIAS_GRAD i: dz_ld nch ; n=npix ; p: dz db
 static void desc_from_op(const mh_op& o, mh_conv_desc& d) {
     const int32_t* i = o.i;
     d.B = i[0]; d.Hi = i[1]; d.Wi = i[2]; d.Ho = i[3]; d.Wo = i[4]; d.K = i[5]; d.N = i[6];
     d.kh = i[7]; d.kw = i[8]; d.stride = i[9]; d.dil = i[10]; d.pad_t = i[11]; d.pad_l = i[12];
     d.mode = i[13]; d.w_trans = i[14]; d.in_ld = i[15]; d.out_ld = i[16]; d.mask_ld = i[17]; d.accumulate = i[18];
-    d.alpha = o.f[0]; d.mask_alpha = o.f[1];
+    d.alpha = o.f[0]; d.mask_alpha = o.f[1]; d.mask_c0 = i[19]; d.mask_c1 = i[20];
 }
 
 static int run_op(const mh_op& o, void* s) {
@@ -96,7 +99,7 @@ static int run_op(const mh_op& o, void* s) {
             return mh_resize_bwd((const float*)p[0], (const float*)p[1], (float*)p[2], i[10], i[0], i[1], i[2], i[3], i[4], i[5], i[6],
                                  i[7], i[8], o.f[0], i[9], s);
         case MH_OP_PAD_REFLECT:
-            return mh_pad_reflect((const float*)p[0], (float*)p[1], i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7], i[8], s);
+            return mh_pad_reflect((const float*)p[0], (float*)p[1], i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7], i[8], o.f[0], o.f[1], s);
         case MH_OP_LOSS:
             return mh_reprojection_loss((const float*)p[0], (const float*)p[1], (const float*)p[2], (float*)p[3], (float*)p[4],
                                         (float*)p[5], o.f[0], i[0], i[1], i[2], s);
@@ -110,6 +113,8 @@ static int run_op(const mh_op& o, void* s) {
             return mh_leaky_bwd((float*)p[0], i[0], (const float*)p[1], i[1], o.n, i[2], o.f[0], s);
         case MH_OP_FILL:
             return mh_fill((float*)p[0], o.n, o.f[0], s);
+        case MH_OP_BIAS_GRAD:
+            return mh_bias_grad((const float*)p[0], i[0], o.n, i[1], (float*)p[1], s);
         default:
             mh_set_error("mh_plan_run: unknown op kind %d", o.kind);
             return MH_ERR_ARG;

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeArgs p) {
 // ------------------------------------------------------------------------------------------
 // preprocessing.pad_image (REFLECT) + channel padding
 // ------------------------------------------------------------------------------------------
-struct PadArgs { const float* in; float* out; int B, H, W, C, Hp, Wp, pt, pl, out_ld; };
+struct PadArgs { const float* in; float* out; int B, H, W, C, Hp, Wp, pt, pl, out_ld; float div, sub; };
 
 __global__ __launch_bounds__(256) void pad_reflect_kernel(PadArgs p) {
     const int64_t total = (int64_t)p.B * p.Hp * p.Wp;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void pad_reflect_kernel(PadArgs p) {
         sx = sx < 0 ? -sx : (sx >= p.W ? 2 * (p.W - 1) - sx : sx);
         const float* src = p.in + (((int64_t)b * p.H + sy) * p.W + sx) * p.C;
         float* dst = p.out + q * p.out_ld;
-        for (int c = 0; c < p.out_ld; ++c) dst[c] = c < p.C ? src[c] : 0.f;
+        for (int c = 0; c < p.out_ld; ++c) dst[c] = c < p.C ? (p.div == 1.0f ? src[c] : src[c] / p.div) - p.sub : 0.f;
     }
 }
 
@@ -435,6 +435,17 @@ __global__ __launch_bounds__(256) void leaky_bwd_kernel(float* dy, int dy_ld, co
     }
 }
 
+// column sums: one workgroup = 256 pixels x all channels (looped), wave-level partial sums then one atomic per wave
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* dz, int dz_ld, int64_t npix, int nch, float* db) {
+    const int64_t p0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (int c = 0; c < nch; ++c) {
+        float v = 0.f;
+        for (int64_t q = p0; q < npix; q += (int64_t)gridDim.x * 256) v += dz[q * dz_ld + c];
+        v = mh_wave_sum(v);
+        if ((threadIdx.x & 63) == 0) atomicAdd(db + c, v);
+    }
+}
+
 __global__ __launch_bounds__(256) void fill_kernel(float* p, int64_t n, float v) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = v;
 }
@@ -507,12 +518,14 @@ extern "C" int mh_resize_bwd(const float* g, const float* in, float* din, int32_
 }
 
 extern "C" int mh_pad_reflect(const float* in, float* out, int32_t B, int32_t H, int32_t W, int32_t C,
-                              int32_t Hp, int32_t Wp, int32_t pad_t, int32_t pad_l, int32_t out_ld, void* stream) {
+                              int32_t Hp, int32_t Wp, int32_t pad_t, int32_t pad_l, int32_t out_ld,
+                              float div, float sub, void* stream) {
     MH_REQUIRE(in && out, MH_ERR_ARG, "mh_pad_reflect: null argument");
     MH_REQUIRE(B > 0 && H > 1 && W > 1 && C > 0 && Hp >= H && Wp >= W && out_ld >= C, MH_ERR_ARG, "mh_pad_reflect: bad dimension");
     MH_REQUIRE(pad_t >= 0 && pad_l >= 0 && pad_t < H && pad_l < W && Hp - H - pad_t < H && Wp - W - pad_l < W &&
                Hp - H - pad_t >= 0 && Wp - W - pad_l >= 0, MH_ERR_ARG, "mh_pad_reflect: REFLECT pad must be smaller than the image");
-    PadArgs a{in, out, B, H, W, C, Hp, Wp, pad_t, pad_l, out_ld};
+    MH_REQUIRE(div != 0.f, MH_ERR_ARG, "mh_pad_reflect: div must be non-zero");
+    PadArgs a{in, out, B, H, W, C, Hp, Wp, pad_t, pad_l, out_ld, div, sub};
     hipLaunchKernelGGL(pad_reflect_kernel, dim3(grid_for((int64_t)B * Hp * Wp)), dim3(256), 0, (hipStream_t)stream, a);
     return mh_check_launch("pad_reflect");
 }
@@ -578,6 +591,12 @@ extern "C" int mh_leaky_bwd(float* dy, int32_t dy_ld, const float* y, int32_t y_
     MH_REQUIRE(dy && y && npix > 0 && nch > 0, MH_ERR_ARG, "mh_leaky_bwd: bad argument");
     hipLaunchKernelGGL(leaky_bwd_kernel, dim3(grid_for(npix * nch)), dim3(256), 0, (hipStream_t)stream, dy, dy_ld, y, y_ld, npix, nch, alpha);
     return mh_check_launch("leaky_bwd");
+}
+
+extern "C" int mh_bias_grad(const float* dz, int32_t dz_ld, int64_t npix, int32_t nch, float* db, void* stream) {
+    MH_REQUIRE(dz && db && npix > 0 && nch > 0 && dz_ld >= nch, MH_ERR_ARG, "mh_bias_grad: bad argument");
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(grid_for(npix, 512)), dim3(256), 0, (hipStream_t)stream, dz, dz_ld, npix, nch, db);
+    return mh_check_launch("bias_grad");
 }
 
 extern "C" int mh_fill(float* p, int64_t n, float v, void* stream) {

@@ -19,7 +19,7 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("B", "Hi", "Wi", "Ho", "Wo", "K", "N", "kh", "kw", "stride", "dil", "pad_t", "pad_l",
                  "mode", "w_trans", "in_ld", "out_ld", "mask_ld", "accumulate")] + \
-               [("alpha", C.c_float), ("mask_alpha", C.c_float)]
+               [("alpha", C.c_float), ("mask_alpha", C.c_float), ("mask_c0", C.c_int32), ("mask_c1", C.c_int32)]
 
 
 class Op(C.Structure):
@@ -28,7 +28,7 @@ class Op(C.Structure):
 
 
 (OP_CONV, OP_WGRAD, OP_CORR_FWD, OP_CORR_BWD, OP_WARP_FWD, OP_WARP_BWD, OP_RESIZE_FWD, OP_RESIZE_BWD,
- OP_PAD_REFLECT, OP_LOSS, OP_METRICS, OP_MOMENTUM, OP_COPY_CH, OP_LEAKY_BWD, OP_FILL) = range(1, 16)
+ OP_PAD_REFLECT, OP_LOSS, OP_METRICS, OP_MOMENTUM, OP_COPY_CH, OP_LEAKY_BWD, OP_FILL, OP_BIAS_GRAD) = range(1, 17)
 
 _P = C.c_void_p
 _I = C.c_int32
@@ -52,7 +52,7 @@ SIGNATURES = {
     "mh_warp_bwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "mh_resize_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     "mh_resize_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
-    "mh_pad_reflect": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mh_pad_reflect": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
     "mh_loss_ws_floats": (_L, [_I, _I, _I]),
     "mh_reprojection_loss": (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _P]),
     "mh_metrics_ws_floats": (_L, [_I, _I, _I]),
@@ -61,6 +61,7 @@ SIGNATURES = {
     "mh_copy_channels": (_I, [_P, _I, _P, _I, _L, _I, _F, _I, _P]),
     "mh_leaky_bwd": (_I, [_P, _I, _P, _I, _L, _I, _F, _P]),
     "mh_fill": (_I, [_P, _L, _F, _P]),
+    "mh_bias_grad": (_I, [_P, _I, _L, _I, _P, _P]),
     "mh_plan_run": (_I, [C.POINTER(Op), _I, _P]),
     "mh_graph_begin": (_I, [_P]),
     "mh_graph_end": (_I, [_P, C.POINTER(_P)]),

@@ -42,6 +42,9 @@ class Adapter(object):
         self.use_graph = use_graph and self.cuda
         self.stream = torch.cuda.Stream(device=dev) if self.cuda else None
         self.blocks = []
+        if mode == "MAD" and not hasattr(self.eng, "record_backward") or (mode == "MAD" and net._netName != "MADNet"):
+            raise NotImplementedError("MAD adaptation is only defined for MADNet (the reference's own assert "
+                                      "Stereo_Online_Adaptation.py:97 fails for DispNet)")
         if mode == "MAD":
             if getattr(net, "_bulkhead", True) is False:
                 print("WARNING: MAD adaptation expects the net built with bulkhead=True")

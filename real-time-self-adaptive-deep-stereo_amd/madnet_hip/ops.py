@@ -58,9 +58,9 @@ def _p(x):
 
 
 def conv_desc(B, Hi, Wi, Ho, Wo, K, N, kh, kw, stride, dil, pad_t, pad_l, mode, w_trans,
-              in_ld, out_ld, mask_ld=0, accumulate=0, alpha=1.0, mask_alpha=1.0):
+              in_ld, out_ld, mask_ld=0, accumulate=0, alpha=1.0, mask_alpha=1.0, mask_c0=0, mask_c1=0):
     return _ffi.ConvDesc(B, Hi, Wi, Ho, Wo, K, N, kh, kw, stride, dil, pad_t, pad_l, mode, w_trans,
-                         in_ld, out_ld, mask_ld, accumulate, alpha, mask_alpha)
+                         in_ld, out_ld, mask_ld, accumulate, alpha, mask_alpha, mask_c0, mask_c1)
 
 
 def conv_geometry(H, W, kh, kw, stride, dil):
@@ -69,16 +69,20 @@ def conv_geometry(H, W, kh, kw, stride, dil):
     return Ho, Wo, pt, pl
 
 
-def conv2d_fwd(lib, x, w, b, out, stride=1, dil=1, alpha=1.0, stream=None):
-    """out = leaky(conv2d_SAME(x, w) + b).  x,out: View; w: HWIO tensor [kh,kw,Cin,Cout]."""
+def conv2d_fwd(lib, x, w, b, out, stride=1, dil=1, alpha=1.0, accumulate=False, mask_ref=None, mask_alpha=1.0,
+               mask_range=(0, 0), stream=None):
+    """out (+)= leaky(conv2d_SAME(x, w) + b) [* leaky'(mask_ref)].  x,out: View; w: HWIO [kh,kw,Cin,Cout]."""
     kh, kw, cin, cout = w.shape
     Ho, Wo, pt, pl = conv_geometry(x.H, x.W, kh, kw, stride, dil)
     assert (out.H, out.W, out.C) == (Ho, Wo, cout) and x.C == cin
-    d = conv_desc(x.B, x.H, x.W, Ho, Wo, cin, cout, kh, kw, stride, dil, pt, pl, 0, 0, x.ld, out.ld, alpha=alpha)
-    lib.conv2d(C.byref(d), _p(x), _p(w), _p(b), _p(out), None, _p(stream))
+    d = conv_desc(x.B, x.H, x.W, Ho, Wo, cin, cout, kh, kw, stride, dil, pt, pl, 0, 0, x.ld, out.ld, alpha=alpha,
+                  mask_ld=(mask_ref.ld if mask_ref is not None else 0), accumulate=int(accumulate), mask_alpha=mask_alpha,
+                  mask_c0=mask_range[0], mask_c1=mask_range[1])
+    lib.conv2d(C.byref(d), _p(x), _p(w), _p(b), _p(out), _p(mask_ref), _p(stream))
 
 
-def conv2d_dgrad(lib, dz, w, dx, stride=1, dil=1, accumulate=False, mask_ref=None, mask_alpha=1.0, stream=None):
+def conv2d_dgrad(lib, dz, w, dx, stride=1, dil=1, accumulate=False, mask_ref=None, mask_alpha=1.0, mask_range=(0, 0),
+                 stream=None):
     """dx (+)= conv2d_backprop_input(dz, w); optionally fused dx *= leaky'(mask_ref).
     dz: View [B,Ho,Wo,Cout]; dx: View [B,H,W,Cin]; w: HWIO of the forward conv."""
     kh, kw, cin, cout = w.shape
@@ -86,7 +90,7 @@ def conv2d_dgrad(lib, dz, w, dx, stride=1, dil=1, accumulate=False, mask_ref=Non
     assert (dz.H, dz.W, dz.C) == (Ho, Wo, cout) and dx.C == cin
     d = conv_desc(dx.B, Ho, Wo, dx.H, dx.W, cout, cin, kh, kw, stride, dil, pt, pl, 1, 1, dz.ld, dx.ld,
                   mask_ld=(mask_ref.ld if mask_ref is not None else 0), accumulate=int(accumulate),
-                  alpha=1.0, mask_alpha=mask_alpha)
+                  alpha=1.0, mask_alpha=mask_alpha, mask_c0=mask_range[0], mask_c1=mask_range[1])
     lib.conv2d(C.byref(d), _p(dz), _p(w), None, _p(dx), _p(mask_ref), _p(stream))
 
 
@@ -143,10 +147,15 @@ def resize_bwd(lib, g, x, dx, Hr, Wr, cy=0, cx=0, mul=1.0, mode=0, accumulate=Fa
     lib.resize_bwd(_p(g), _p(x), _p(dx), int(accumulate), B, Hi, Wi, Hr, Wr, cy, cx, Ho, Wo, mul, mode, _p(stream))
 
 
-def pad_reflect(lib, x, out, pad_t, pad_l, stream=None):
-    """x: [B,H,W,C] tensor; out: [B,Hp,Wp,out_ld] tensor."""
+def pad_reflect(lib, x, out, pad_t, pad_l, div=1.0, sub=0.0, stream=None):
+    """out = reflect_pad(x / div - sub).  x: [B,H,W,C] tensor; out: [B,Hp,Wp,out_ld] tensor."""
     B, H, W, Cc = x.shape
-    lib.pad_reflect(_p(x), _p(out), B, H, W, Cc, out.shape[1], out.shape[2], pad_t, pad_l, out.shape[3], _p(stream))
+    lib.pad_reflect(_p(x), _p(out), B, H, W, Cc, out.shape[1], out.shape[2], pad_t, pad_l, out.shape[3], div, sub, _p(stream))
+
+
+def bias_grad(lib, dz, db, stream=None):
+    """db += column sums of the View dz."""
+    lib.bias_grad(_p(dz), dz.ld, dz.npix, dz.C, _p(db), _p(stream))
 
 
 def reprojection_loss(lib, left, right, disp, ws, result, ddisp=None, grad_scale=1.0, stream=None):

@@ -40,7 +40,7 @@ class Recorder(object):
     @staticmethod
     def _desc_ints(d):
         return [d.B, d.Hi, d.Wi, d.Ho, d.Wo, d.K, d.N, d.kh, d.kw, d.stride, d.dil, d.pad_t, d.pad_l,
-                d.mode, d.w_trans, d.in_ld, d.out_ld, d.mask_ld, d.accumulate]
+                d.mode, d.w_trans, d.in_ld, d.out_ld, d.mask_ld, d.accumulate, d.mask_c0, d.mask_c1]
 
     # -- same names / argument order as _ffi.Lib (minus the 'mh_' prefix) --------------------
     def conv2d(self, dref, inp, w, bias, out, mask, stream):
@@ -49,7 +49,7 @@ class Recorder(object):
 
     def conv2d_wgrad(self, dref, inp, dout, dout_ld, dw, db, stream):
         d = dref._obj
-        ints = self._desc_ints(d) + [0, 0, dout_ld]
+        ints = self._desc_ints(d) + [dout_ld]
         self._op(_ffi.OP_WGRAD, ints, [d.alpha, d.mask_alpha], [inp, dout, dw, db])
 
     def corr_fwd(self, L, l_ld, R, r_ld, u, out, out_ld, coff, B, H, W, Cc, md, stride, copy_left, zero_tail, stream):
@@ -72,8 +72,8 @@ class Recorder(object):
     def resize_bwd(self, g, inp, din, accumulate, B, Hi, Wi, Hr, Wr, cy, cx, Ho, Wo, mul, mode, stream):
         self._op(_ffi.OP_RESIZE_BWD, [B, Hi, Wi, Hr, Wr, cy, cx, Ho, Wo, mode, accumulate], [mul], [g, inp, din])
 
-    def pad_reflect(self, inp, out, B, H, W, Cc, Hp, Wp, pt, pl, out_ld, stream):
-        self._op(_ffi.OP_PAD_REFLECT, [B, H, W, Cc, Hp, Wp, pt, pl, out_ld], [], [inp, out])
+    def pad_reflect(self, inp, out, B, H, W, Cc, Hp, Wp, pt, pl, out_ld, div, sub, stream):
+        self._op(_ffi.OP_PAD_REFLECT, [B, H, W, Cc, Hp, Wp, pt, pl, out_ld], [div, sub], [inp, out])
 
     def reprojection_loss(self, left, right, disp, ws, result, ddisp, grad_scale, B, H, W, stream):
         self._op(_ffi.OP_LOSS, [B, H, W], [grad_scale], [left, right, disp, ws, result, ddisp])
@@ -89,6 +89,9 @@ class Recorder(object):
 
     def leaky_bwd(self, dy, dy_ld, y, y_ld, npix, nch, alpha, stream):
         self._op(_ffi.OP_LEAKY_BWD, [dy_ld, y_ld, nch], [alpha], [dy, y], n=npix)
+
+    def bias_grad(self, dz, dz_ld, npix, nch, db, stream):
+        self._op(_ffi.OP_BIAS_GRAD, [dz_ld, nch], [], [dz, db], n=npix)
 
     def fill(self, p, n, v, stream):
         self._op(_ffi.OP_FILL, [], [v], [p], n=n)

@@ -76,7 +76,7 @@ def xavier_weights(shapes, seed=0):
     return out
 
 
-def calibrated_weights(shapes, seed=1, conv1_gain=0.1):
+def calibrated_weights(shapes, seed=1, conv1_gain=0.1, dispnet_pred_gain=60.0):
     """Xavier weights whose first layer is scaled so that the un-normalised 0..255 input
     (MADNet feeds raw pixel values, Nets/MadNet.py:56-66) produces KITTI-like disparities
     (mean ~15 px) instead of the hundreds of pixels a raw Xavier net gives."""
@@ -84,4 +84,6 @@ def calibrated_weights(shapes, seed=1, conv1_gain=0.1):
     for k in w:
         if k.endswith("conv1/weights") and "pyramid" in k:
             w[k] = (w[k] * conv1_gain).astype(np.float32)
+        if k == "model/prediction/weights":        # DispNet: random nets predict ~0.3 px; scale to tens of px
+            w[k] = (w[k] * dispnet_pred_gain).astype(np.float32)
     return w

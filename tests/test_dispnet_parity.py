@@ -1,0 +1,74 @@
+"""DispNet-C (BASELINE config 4): forward + FULL adaptation step of the MI355X engine vs the torch oracle."""
+import pytest
+import torch
+
+from madnet_hip import dispnet_engine as DE
+from madnet_hip import synthetic as S
+from oracle import dispnet as OD
+
+
+def test_manifest_matches_oracle_names():
+    assert list(OD.variable_shapes().items()) == [(n, tuple(s)) for n, s in DE.dispnet_manifest()]
+    assert sum(int(torch.tensor(s).prod()) for s in OD.variable_shapes().values()) == 42430107
+
+
+def _run(backend, H, W, mode):
+    wn = S.calibrated_weights(OD.variable_shapes(), 1)
+    l, r, gt = S.make_pair(H, W)
+    eng = DE.DispNetEngine(backend.lib, H, W, B=1, device=backend.device, weights=wn)
+    eng.set_inputs(l, r, gt[..., 0])
+    lr = 1e-3
+    eng.build_plan(mode, lr=lr).run(backend.lib, 0)
+    backend.sync()
+    wt = {k: torch.from_numpy(v.copy()) for k, v in wn.items()}
+    acc = {k: torch.zeros_like(v) for k, v in wt.items()}
+    o = OD.step(wt, acc, torch.from_numpy(l), torch.from_numpy(r), torch.from_numpy(gt), mode=mode, lr=lr)
+    d = o["disparity"][..., 0]
+    assert d.abs().mean().item() > 0.5                       # non-degenerate prediction
+    assert (eng.pred.cpu() - d).abs().mean().item() <= 1e-3  # north-star tolerance
+    assert abs(eng.res_loss[0].item() - o["loss"]) <= 2e-5 * max(1.0, abs(o["loss"]))
+    assert abs(eng.res_met[0].item() - o["epe"]) <= 1e-4 * max(1.0, o["epe"])
+    for n, g in o["grads"].items():
+        ge = eng.params.tensor(n, "g").cpu()
+        rel = (ge - g).norm().item() / max(g.norm().item(), 1e-30)
+        assert rel <= 2e-3, (n, rel)
+    for n in wt:
+        assert (eng.params.tensor(n).cpu() - wt[n]).abs().max().item() <= 1e-5 * max(1.0, wt[n].abs().max().item()), n
+
+
+@pytest.mark.slow
+def test_dispnet_full_step_emulated():
+    from conftest import _emul_backend
+    _run(_emul_backend(), 40, 64, "FULL")        # pads to 64x64
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(64, 128), (375, 1242)])
+@pytest.mark.parametrize("mode", ["NONE", "FULL"])
+def test_dispnet_step_gpu(hip, size, mode):
+    _run(hip, size[0], size[1], mode)
+
+
+@pytest.mark.gpu
+def test_dispnet_factory_and_disparities(hip):
+    import Nets
+    from madnet_hip.adapter import Adapter
+    H, W = 128, 256
+    wn = S.calibrated_weights(OD.variable_shapes(), 1)
+    l, r, gt = S.make_pair(H, W)
+    left = torch.from_numpy(l).cuda(); right = torch.from_numpy(r).cuda()
+    net = Nets.get_stereo_net("Dispnet", {"left_img": left, "right_img": right, "weights": wn})
+    disps = net.run()
+    torch.cuda.synchronize()
+    wt = {k: torch.from_numpy(v.copy()) for k, v in wn.items()}
+    with torch.no_grad():
+        ref = OD.forward(wt, torch.from_numpy(l), torch.from_numpy(r))
+    assert len(disps) == 7
+    for a, b in zip(disps, ref):
+        assert (a.cpu() - b).abs().mean().item() <= 1e-3
+    assert [v.op_name for v in net.get_variables("up5/deconv")] == ["model/up5/deconv/weights", "model/up5/deconv/bias"]
+    assert net.get_variables("conv1b") == []
+    with pytest.raises(NotImplementedError):
+        Adapter(net, mode="MAD", block_config=[[]] * 6)
+    out = Adapter(net, mode="FULL", lr=1e-4).step(l, r, gt[..., 0])
+    assert out["loss"] > 0
