@@ -23,9 +23,9 @@ MAX_DISP = 256
 PIXEL_TH = 3
 
 
-def load_weights(spec, radius_d=2, stride=1):
-    from madnet_hip import engine as E, synthetic
-    shapes = dict(E.madnet_manifest(radius_d, stride))
+def load_weights(spec, model_name="MADNet", radius_d=2, stride=1):
+    from madnet_hip import engine as E, dispnet_engine as DE, synthetic
+    shapes = dict(E.madnet_manifest(radius_d, stride) if model_name == "MADNet" else DE.dispnet_manifest())
     kind = spec.split(':')[0]
     if kind in ('xavier', 'calibrated'):
         seed = int(spec.split(':')[1]) if ':' in spec else (0 if kind == 'xavier' else 1)
@@ -52,7 +52,7 @@ def main(args):
     right_img_batch = torch.zeros(1, H, W, 3, device=dev)
     net_args = {'left_img': left_img_batch, 'right_img': right_img_batch, 'split_layers': [None], 'sequence': True,
                 'train_portion': 'BEGIN', 'bulkhead': True if args.mode == 'MAD' else False,
-                'weights': load_weights(args.weights)}
+                'weights': load_weights(args.weights, args.modelName)}
     stereo_net = Nets.get_stereo_net(args.modelName, net_args)
     print('Stereo Prediction Model:\n', stereo_net)
     predictions = stereo_net.get_disparities()
