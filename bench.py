@@ -49,12 +49,12 @@ def cpu_baseline(H, W, wn, l, r, gt, mode, steps=8):
                       "torch.set_num_threads(%d)" % (steps, mode, W, H, cores)}
 
 
-def epe_vs_oracle(lib, H, W, wn, l, r, gt):
+def epe_vs_oracle(lib, H, W, wn, l, r, gt, precision="fp32"):
     """mean |d_hip - d_oracle| of disparities[-1] on identical inputs and weights (single forward)."""
     import torch
     from madnet_hip import engine as E
     from oracle import madnet as OM
-    eng = E.MadNetEngine(lib, H, W, B=1, device="cuda", weights=wn)
+    eng = E.MadNetEngine(lib, H, W, B=1, device="cuda", weights=wn, precision=precision)
     eng.set_inputs(l, r, gt[..., 0])
     eng.build_plan("NONE").run(lib, 0)
     torch.cuda.synchronize()
@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", default="FULL", choices=["FULL", "NONE"])
     ap.add_argument("--model", default="madnet", choices=["madnet", "dispnet"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32 = exact fp32 MFMA (parity path); bf16 = bf16 MFMA inputs, fp32 accumulate/storage")
     ap.add_argument("--height", type=int, default=375)
     ap.add_argument("--width", type=int, default=1242)
     ap.add_argument("--no-graph", action="store_true")
@@ -97,7 +99,8 @@ def main():
     shapes = dict(DE.dispnet_manifest() if dispnet else E.madnet_manifest())
     wn = S.calibrated_weights(shapes, 1)
     l, r, gt = S.make_pair(H, W, stream_id=rank)
-    eng = DE.DispNetEngine(lib, H, W, B=1, device=dev, weights=wn) if dispnet else E.MadNetEngine(lib, H, W, B=1, device=dev, weights=wn)
+    eng = (DE.DispNetEngine(lib, H, W, B=1, device=dev, weights=wn, precision=args.precision) if dispnet
+           else E.MadNetEngine(lib, H, W, B=1, device=dev, weights=wn, precision=args.precision))
     eng.set_inputs(l, r, gt[..., 0])
     plan = eng.build_plan(args.mode, lr=1e-4)
     stream = torch.cuda.Stream()
@@ -140,7 +143,7 @@ def main():
         "metric": "adapted stereo pairs/sec (whole node), %s full-backprop online adaptation 1242x375" % ("DispNet" if dispnet else "MADNet"),
         "value": world * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
         "config": {"workload": ("DispNet" if dispnet else "MADNet") + " %s adaptation step (fwd+SSIM/L1 loss+EPE+bwd+momentum), %dx%d, 1 pair/GPU/step, "
                                "private model per stream" % (args.mode, W, H),
                    "launch": "eager plan" if args.no_graph else "hipGraph replay",
@@ -155,7 +158,7 @@ def main():
             out.update(extra)
             _log("roofline done")
         if not args.no_cpu_baseline:
-            out["epe_vs_oracle"] = epe_vs_oracle(lib, H, W, wn, l, r, gt)
+            out["epe_vs_oracle"] = epe_vs_oracle(lib, H, W, wn, l, r, gt, args.precision)
             _log("epe_vs_oracle done")
             out["cpu_baseline"] = cpu_baseline(H, W, wn, l, r, gt, args.mode)
             _log("cpu baseline done")

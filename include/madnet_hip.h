@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 2
+#define MH_ABI_VERSION 3
 
 const char* mh_last_error(void);
 int mh_abi_version(void);
@@ -55,6 +55,9 @@ typedef struct mh_conv_desc {
     float mask_alpha;               /* if mask_ref: out *= (mask_ref>0 ? 1 : mask_alpha)  (fused leaky-grad) */
     int32_t mask_c0, mask_c1;       /* the mask applies to output channels [mask_c0, mask_c1); 0,0 = all
                                        (a concat gradient masks only the slice produced by an activation) */
+    int32_t precision;              /* 0: exact fp32 (v_mfma_f32_16x16x4_f32) -- the parity path
+                                       1: bf16 MFMA inputs (RNE) with fp32 accumulation -- throughput mode;
+                                          tensors stay fp32 in memory either way */
 } mh_conv_desc;
 
 int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w, const float* bias,

@@ -26,6 +26,7 @@ struct ConvArgs {
     int kh, kw, stride, dil, pad_t, pad_l;
     int mode, w_trans, accumulate, sshift;
     unsigned in_bytes, w_bytes, out_bytes, mask_bytes;
+    int bf16;        // throughput mode: bf16 MFMA inputs, fp32 accumulate
     int vecC;        // 16-byte epilogue legal (N, out_ld, mask_ld multiples of 4, aligned pointers)
     int M;           // B*Ho*Wo
     int vecA, vecB;  // 16-byte vector loads legal for A / B
@@ -53,22 +54,44 @@ __device__ __forceinline__ int swz_group(int row, int g) { return g ^ ((row >> 2
 // UNI: every K-tile lies inside ONE tap (4*G % KT == 0, and stride 1 for DGRAD): the (tap, channel)
 // cursor is then wave-uniform (SALU) and a row's byte offset is base(row) + offset(tile) -- the loader
 // shrinks from ~20 to ~7 VALU per 16-byte load, which is what bounds the small, 1-wave-per-SIMD tiles.
-template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool VEC, bool UNI>
+// BF16 (throughput mode): activations / weights stay fp32 in HBM and are loaded exactly as in the fp32
+// kernel, but the LDS tiles hold bf16 (v_cvt_pk_bf16_f32, round-to-nearest-even, at the LDS store) and the
+// contraction runs on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (13x the fp32-MFMA rate): the kernel
+// becomes loader/L2-bound.  The forward B tile (HWIO rows run along n) is loaded as units of 4 consecutive
+// k rows and transposed in registers so that it is stored with 8-byte writes like the other tiles.
+template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool VEC, bool UNI, bool BF16>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     constexpr int BM = WM * MT * 16;
     constexpr int BN = WN * NT * 16;
-    constexpr int LS = KT + 4;                         // LDS row stride (floats)
+    constexpr int LS = KT + (BF16 ? 8 : 4);            // LDS row stride (elements: floats / bf16)
     constexpr int GPT = KT / 4;                        // 4-channel groups per K-tile
     constexpr int RPP = 256 / GPT;                     // rows loaded per pass
     constexpr int AROWS = (BM + RPP - 1) / RPP;
     constexpr int BVEC = KT * BN / 4;                  // float4 items in a B tile
-    constexpr int BITEMS = (BVEC + 255) / 256;
+    constexpr bool BT = BF16 && !DGRAD;                // B tile loaded as 4-row units, transposed in registers
+    constexpr int UN = GPT * (BN / 4);                 // such units per tile
+    constexpr int BITEMS = BT ? 4 * ((UN + 255) / 256) : (BVEC + 255) / 256;
+    constexpr int TILE_FLOATS = BF16 ? (BM + BN) * LS / 2 : (BM + BN) * LS;   // one buffer of both tiles, in floats
 
     HIP_DYNAMIC_SHARED(float, smem)
-    float* const As = smem;                            // [2][BM*LS]
-    float* const Bs = smem + 2 * BM * LS;              // [2][BN*LS]
-    int* const tap_dy = reinterpret_cast<int*>(smem + 2 * (BM + BN) * LS);
+    float* const As = smem;                            // fp32: [2][BM*LS] floats
+    float* const Bs = smem + 2 * BM * LS;              //       [2][BN*LS]
+    unsigned short* const Ah = reinterpret_cast<unsigned short*>(smem);          // bf16: [2][BM*LS] halfs
+    unsigned short* const Bh = Ah + 2 * BM * LS;                                //       [2][BN*LS]
+    int* const tap_dy = reinterpret_cast<int*>(smem + 2 * TILE_FLOATS);
     int* const tap_dx = tap_dy + 64;
+    // forward B item j of this thread -> (row kk of the K-tile, 4-column group n4, live)
+    auto b_item = [&](int j, int& kk, int& n4) -> bool {
+        if (BT) {
+            const int u = threadIdx.x + 256 * (j >> 2);
+            n4 = u % (BN / 4);
+            kk = (u / (BN / 4)) * 4 + (j & 3);
+            return u < UN;
+        }
+        const int q = threadIdx.x + 256 * j;
+        kk = q / (BN / 4); n4 = q % (BN / 4);
+        return q < BVEC;
+    };
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -124,7 +147,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
     for (int j = 0; j < BITEMS; ++j) {
         const int q = tid + 256 * j;
-        const int gb = DGRAD ? (q % GPT) : ((q / (BN / 4)) >> 2);
+        int kk0, n40;
+        b_item(j, kk0, n40);
+        const int gb = DGRAD ? (q % GPT) : (kk0 >> 2);
         int t = 0, c = gb;
         while (c >= p.G) { c -= p.G; ++t; }
         b_tap[j] = t; b_c4[j] = c;
@@ -140,9 +165,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         for (int j = 0; j < BITEMS; ++j) {
             const int q = tid + 256 * j;
             int n, o;
-            if (!DGRAD) { const int kk = q / (BN / 4), n4 = q % (BN / 4); n = n0 + n4 * 4; o = (kk * p.N + n) * 4; }
-            else { n = n0 + q / GPT; o = (n * p.K + (q % GPT) * 4) * 4; }
-            b_off[j] = (q < BVEC && n < p.N) ? o : MH_OOB;
+            bool live;
+            if (!DGRAD) { int kk, n4; live = b_item(j, kk, n4); n = n0 + n4 * 4; o = (kk * p.N + n) * 4; }
+            else { live = q < BVEC; n = n0 + q / GPT; o = (n * p.K + (q % GPT) * 4) * 4; }
+            b_off[j] = (live && n < p.N) ? o : MH_OOB;
         }
     }
     int u_tap = 0, u_c0 = 0;    // wave-uniform cursor of the NEXT tile to load (UNI)
@@ -216,13 +242,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < BITEMS; ++j) {
             const int q = tid + 256 * j;
-            const bool live = (q < BVEC) && (b_tap[j] < p.taps);
+            bool live;
             int k, n;
             if (!DGRAD) {
-                const int kk = q / (BN / 4), n4 = q % (BN / 4);
+                int kk, n4;
+                live = b_item(j, kk, n4) && (b_tap[j] < p.taps);
                 k = b_c4[j] * 4 + (kk & 3);
                 n = n0 + n4 * 4;
             } else {
+                live = (q < BVEC) && (b_tap[j] < p.taps);
                 n = n0 + q / GPT;
                 k = b_c4[j] * 4;
             }
@@ -251,8 +279,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     };
 
     auto store_tile = [&](int buf) {
-        float* Ab = As + buf * (BM * LS);
-        float* Bb = Bs + buf * (BN * LS);
 #pragma unroll
         for (int j = 0; j < AROWS; ++j) {
             const int r = ra + RPP * j;
@@ -263,8 +289,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
                 v.z = (a_kb_st + 2 < p.K) ? v.z : 0.f;
                 v.w = (a_kb_st + 3 < p.K) ? v.w : 0.f;
             }
-            if (r < BM) *reinterpret_cast<float4*>(&Ab[r * LS + ga * 4]) = v;
+            if (r < BM) {
+                if (BF16) *reinterpret_cast<uint2*>(&Ah[buf * (BM * LS) + r * LS + ga * 4]) = make_uint2(mh_pack_bf16(v.x, v.y), mh_pack_bf16(v.z, v.w));
+                else *reinterpret_cast<float4*>(&As[buf * (BM * LS) + r * LS + ga * 4]) = v;
+            }
         }
+        if (BT) {
+            // unit = rows kk..kk+3 (items 4u..4u+3) x columns n4*4..+3 : store column c as 4 consecutive k
+            unsigned short* Bb = Bh + buf * (BN * LS);
+#pragma unroll
+            for (int uj = 0; uj < BITEMS / 4; ++uj) {
+                int kk, n4;
+                if (b_item(4 * uj, kk, n4)) {
+                    const float4 v0 = rb_v[4 * uj], v1 = rb_v[4 * uj + 1], v2 = rb_v[4 * uj + 2], v3 = rb_v[4 * uj + 3];
+                    unsigned short* d = Bb + (n4 * 4) * LS + kk;
+                    *reinterpret_cast<uint2*>(d) = make_uint2(mh_pack_bf16(v0.x, v1.x), mh_pack_bf16(v2.x, v3.x));
+                    *reinterpret_cast<uint2*>(d + LS) = make_uint2(mh_pack_bf16(v0.y, v1.y), mh_pack_bf16(v2.y, v3.y));
+                    *reinterpret_cast<uint2*>(d + 2 * LS) = make_uint2(mh_pack_bf16(v0.z, v1.z), mh_pack_bf16(v2.z, v3.z));
+                    *reinterpret_cast<uint2*>(d + 3 * LS) = make_uint2(mh_pack_bf16(v0.w, v1.w), mh_pack_bf16(v2.w, v3.w));
+                }
+            }
+            return;
+        }
+        float* Bb = Bs + buf * (BN * LS);
 #pragma unroll
         for (int j = 0; j < BITEMS; ++j) {
             const int q = tid + 256 * j;
@@ -276,7 +323,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
                     d[0] = rb_v[j].x; d[LS] = rb_v[j].y; d[2 * LS] = rb_v[j].z; d[3 * LS] = rb_v[j].w;
                 } else {
                     const int g = q % GPT, n = q / GPT;
-                    *reinterpret_cast<float4*>(&Bb[n * LS + swz_group<GPT>(n, g) * 4]) = rb_v[j];
+                    if (BF16) *reinterpret_cast<uint2*>(&Bh[buf * (BN * LS) + n * LS + g * 4]) = make_uint2(mh_pack_bf16(rb_v[j].x, rb_v[j].y), mh_pack_bf16(rb_v[j].z, rb_v[j].w));
+                    else *reinterpret_cast<float4*>(&Bb[n * LS + swz_group<GPT>(n, g) * 4]) = rb_v[j];
                 }
             }
         }
@@ -298,6 +346,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     for (int t = 0; t < ntile; ++t) {
         const int buf = t & 1;
         if (t + 1 < ntile) load_tile();
+        if (BF16) {
+            const unsigned short* Ab = Ah + buf * (BM * LS) + (wm * MT * 16 + li) * LS + lq * 8;
+            const unsigned short* Bb = Bh + buf * (BN * LS) + (wn * NT * 16 + li) * LS + lq * 8;
+#pragma unroll
+            for (int s = 0; s < KT / 32; ++s) {
+                u32x4 a[MT], b[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const u32x4*>(Ab + i * 16 * LS + s * 32);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const u32x4*>(Bb + j * 16 * LS + s * 32);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = mh_mfma_bf16(a[i], b[j], acc[i][j]);
+            }
+        } else {
         const float* Ab = As + buf * (BM * LS) + (wm * MT * 16 + li) * LS + lq * 4;
         const float* Bb = Bs + buf * (BN * LS) + (wn * NT * 16 + li) * LS;
 #pragma unroll
@@ -317,6 +381,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
                 }
+        }
         }
         if (t + 1 < ntile) store_tile(buf ^ 1);
         __syncthreads();
@@ -401,14 +466,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 
 static bool g_no_uni = false;    // tuning hook: disable the uniform-tap fast path (A/B experiments)
 
-template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool VEC, bool UNI>
+template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool VEC, bool UNI, bool BF16>
 int launch_one(ConvArgs& a, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
-    constexpr size_t lds = (size_t)(2 * (BM + BN) * (KT + 4) + 128) * sizeof(float);
+    constexpr size_t lds = BF16 ? (size_t)(2 * (BM + BN) * (KT + 8)) * 2 + 512 : (size_t)(2 * (BM + BN) * (KT + 4) + 128) * sizeof(float);
     static bool attr_done = false;       // LDS > 64 KiB needs the opt-in once per instantiation
     if (!attr_done) {
         if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC, UNI>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC, UNI, BF16>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) { mh_set_error("conv: hipFuncSetAttribute(%d B LDS): %s", (int)lds, hipGetErrorString(e)); return (int)e; }
         }
@@ -418,23 +483,34 @@ int launch_one(ConvArgs& a, hipStream_t s) {
     a.mtiles = mh_cdiv(a.M, BM);
     a.ntiles = mh_cdiv(a.N, BN);
     const int nwg = a.mtiles * a.ntiles;
-    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC, UNI>), dim3(nwg), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC, UNI, BF16>), dim3(nwg), dim3(256), lds, s, a);
     return mh_check_launch("conv_igemm");
 }
 
-template <int WM, int WN, int MT, int NT, int KT>
+// F32 / B16: which arithmetic variants of this (tile, KT) are instantiated (bf16 runs KT = 64 only)
+template <int WM, int WN, int MT, int NT, int KT, bool F32, bool B16>
 int launch_cfg(ConvArgs& a, hipStream_t s) {
     const bool all = a.M < 0;
     const bool dg = a.mode == 1, vec = a.vecA && a.vecB;
     // uniform-tap fast path: whole K-tiles per tap, no channel padding, unit-stride gather
     const bool uni = vec && (a.K % KT == 0) && (!dg || a.sshift == 0) && !g_no_uni;
+    const bool bf = a.bf16 && vec;                 // the scalar (odd-shape) path stays fp32
     int rc = 0;
-    if (all || (!dg && vec && uni)) { rc = launch_one<WM, WN, MT, NT, KT, false, true, true>(a, s); if (!all || rc) return rc; }
-    if (all || (!dg && vec && !uni)) { rc = launch_one<WM, WN, MT, NT, KT, false, true, false>(a, s); if (!all || rc) return rc; }
-    if (all || (!dg && !vec)) { rc = launch_one<WM, WN, MT, NT, KT, false, false, false>(a, s); if (!all || rc) return rc; }
-    if (all || (dg && vec && uni)) { rc = launch_one<WM, WN, MT, NT, KT, true, true, true>(a, s); if (!all || rc) return rc; }
-    if (all || (dg && vec && !uni)) { rc = launch_one<WM, WN, MT, NT, KT, true, true, false>(a, s); if (!all || rc) return rc; }
-    if (all || (dg && !vec)) { rc = launch_one<WM, WN, MT, NT, KT, true, false, false>(a, s); if (!all || rc) return rc; }
+    if constexpr (F32) {
+        if (all || (!bf && !dg && vec && uni)) { rc = launch_one<WM, WN, MT, NT, KT, false, true, true, false>(a, s); if (!all || rc) return rc; }
+        if (all || (!bf && !dg && vec && !uni)) { rc = launch_one<WM, WN, MT, NT, KT, false, true, false, false>(a, s); if (!all || rc) return rc; }
+        if (all || (!dg && !vec)) { rc = launch_one<WM, WN, MT, NT, KT, false, false, false, false>(a, s); if (!all || rc) return rc; }
+        if (all || (!bf && dg && vec && uni)) { rc = launch_one<WM, WN, MT, NT, KT, true, true, true, false>(a, s); if (!all || rc) return rc; }
+        if (all || (!bf && dg && vec && !uni)) { rc = launch_one<WM, WN, MT, NT, KT, true, true, false, false>(a, s); if (!all || rc) return rc; }
+        if (all || (dg && !vec)) { rc = launch_one<WM, WN, MT, NT, KT, true, false, false, false>(a, s); if (!all || rc) return rc; }
+    }
+    if constexpr (B16) {
+        if (all || (bf && !dg && uni)) { rc = launch_one<WM, WN, MT, NT, KT, false, true, true, true>(a, s); if (!all || rc) return rc; }
+        if (all || (bf && !dg && !uni)) { rc = launch_one<WM, WN, MT, NT, KT, false, true, false, true>(a, s); if (!all || rc) return rc; }
+        if (all || (bf && dg && uni)) { rc = launch_one<WM, WN, MT, NT, KT, true, true, true, true>(a, s); if (!all || rc) return rc; }
+        if (all || (bf && dg && !uni)) { rc = launch_one<WM, WN, MT, NT, KT, true, true, false, true>(a, s); if (!all || rc) return rc; }
+    }
+    if (!all) { mh_set_error("conv: no kernel variant (bf16=%d vec=%d KT=%d)", (int)bf, (int)vec, KT); return MH_ERR_UNSUPPORTED; }
     return rc;
 }
 
@@ -501,19 +577,30 @@ static int conv_dispatch(ConvArgs& a, hipStream_t s) {
                 for (const TileCfg& t : kTiles) if (t.bm == bm && t.bn == bn && t.kt == 128) kt = 128;
         }
         if (kt == 0) for (const TileCfg& t : kTiles) if (t.bm == bm && t.bn == bn) { kt = t.kt; break; }
+        if (a.bf16 && a.vecA && a.vecB) kt = 64;        // bf16 tiles: 64 k-values (128 B) per LDS row
+        else if (kt == 64) {                            // fp32 has no KT=64 instance of the big (KT=32) tiles
+            bool has = false;
+            for (const TileCfg& t : kTiles) if (t.bm == bm && t.bn == bn && t.kt == 64) has = true;
+            if (!has) kt = 32;
+        }
     }
     int rc = 0;
-#define MH_CFG(BMv, BNv, KTv, ...)                                                  \
+#define MH_CFG(BMv, BNv, KTv, F32v, B16v, ...)                                      \
     if (all || (bm == BMv && bn == BNv && kt == KTv)) {                             \
-        rc = launch_cfg<__VA_ARGS__, KTv>(a, s);                                    \
+        rc = launch_cfg<__VA_ARGS__, KTv, F32v, B16v>(a, s);                        \
         if (!all || rc) return rc;                                                  \
     }
-    MH_CFG(128, 128, 32, 2, 2, 4, 4) MH_CFG(128, 96, 32, 2, 2, 4, 3) MH_CFG(128, 64, 32, 2, 2, 4, 2)
-    MH_CFG(64, 128, 32, 1, 4, 4, 2)  MH_CFG(64, 96, 32, 2, 2, 2, 3)  MH_CFG(64, 64, 32, 2, 2, 2, 2)
-    MH_CFG(128, 32, 32, 4, 1, 2, 2)  MH_CFG(128, 16, 32, 4, 1, 2, 1)
-    MH_CFG(32, 128, 64, 1, 4, 2, 2)  MH_CFG(32, 96, 64, 2, 2, 1, 3)  MH_CFG(32, 64, 64, 2, 2, 1, 2)
-    MH_CFG(64, 32, 64, 4, 1, 1, 2)   MH_CFG(32, 32, 64, 2, 2, 1, 1)  MH_CFG(64, 16, 64, 4, 1, 1, 1)
-    MH_CFG(32, 64, 128, 2, 2, 1, 2)  MH_CFG(64, 32, 128, 4, 1, 1, 2) MH_CFG(32, 32, 128, 2, 2, 1, 1)
+    // fp32 instances
+    MH_CFG(128, 128, 32, true, false, 2, 2, 4, 4) MH_CFG(128, 96, 32, true, false, 2, 2, 4, 3) MH_CFG(128, 64, 32, true, false, 2, 2, 4, 2)
+    MH_CFG(64, 128, 32, true, false, 1, 4, 4, 2)  MH_CFG(64, 96, 32, true, false, 2, 2, 2, 3)  MH_CFG(64, 64, 32, true, false, 2, 2, 2, 2)
+    MH_CFG(128, 32, 32, true, false, 4, 1, 2, 2)  MH_CFG(128, 16, 32, true, false, 4, 1, 2, 1)
+    MH_CFG(32, 64, 128, true, false, 2, 2, 1, 2)  MH_CFG(64, 32, 128, true, false, 4, 1, 1, 2) MH_CFG(32, 32, 128, true, false, 2, 2, 1, 1)
+    // KT = 64: fp32 for the small tiles, bf16 for every tile
+    MH_CFG(32, 128, 64, true, true, 1, 4, 2, 2)   MH_CFG(32, 96, 64, true, true, 2, 2, 1, 3)   MH_CFG(32, 64, 64, true, true, 2, 2, 1, 2)
+    MH_CFG(64, 32, 64, true, true, 4, 1, 1, 2)    MH_CFG(32, 32, 64, true, true, 2, 2, 1, 1)   MH_CFG(64, 16, 64, true, true, 4, 1, 1, 1)
+    MH_CFG(128, 128, 64, false, true, 2, 2, 4, 4) MH_CFG(128, 96, 64, false, true, 2, 2, 4, 3) MH_CFG(128, 64, 64, false, true, 2, 2, 4, 2)
+    MH_CFG(64, 128, 64, false, true, 1, 4, 4, 2)  MH_CFG(64, 96, 64, false, true, 2, 2, 2, 3)  MH_CFG(64, 64, 64, false, true, 2, 2, 2, 2)
+    MH_CFG(128, 32, 64, false, true, 4, 1, 2, 2)  MH_CFG(128, 16, 64, false, true, 4, 1, 2, 1)
 #undef MH_CFG
     if (all) return 0;
     mh_set_error("conv_dispatch: no tile configuration for bm=%d bn=%d kt=%d", bm, bn, kt);
@@ -543,7 +630,8 @@ extern "C" int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w,
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ho = d->Ho; a.Wo = d->Wo;
     a.K = d->K; a.N = d->N; a.G = (d->K + 3) / 4; a.taps = d->kh * d->kw;
     a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.dil = d->dil; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
-    a.mode = d->mode; a.w_trans = d->w_trans; a.accumulate = d->accumulate;
+    a.mode = d->mode; a.w_trans = d->w_trans; a.accumulate = d->accumulate; a.bf16 = (d->precision == 1);
+    MH_REQUIRE(d->precision == 0 || d->precision == 1, MH_ERR_ARG, "mh_conv2d: precision must be 0 (fp32) or 1 (bf16 MFMA)");
     MH_REQUIRE(d->mode == d->w_trans && (d->mode == 0 || d->mode == 1), MH_ERR_UNSUPPORTED,
                "mh_conv2d: supported combinations are mode=0/w_trans=0 (forward) and mode=1/w_trans=1 (dgrad, conv2d_transpose)");
     {

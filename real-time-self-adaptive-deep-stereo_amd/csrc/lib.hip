@@ -45,7 +45,7 @@ extern "C" int mh_device_count(void) {
 
 // ---- plan executor ------------------------------------------------------------------------
 // Field packing of mh_op per kind (host side: madnet_hip/plan.py must match):
-//  CONV      i[0..18] = mh_conv_desc ints in declaration order, i[19]=mask_c0 i[20]=mask_c1, f[0]=alpha f[1]=mask_alpha
+//  CONV      i[0..18] = mh_conv_desc ints in declaration order, i[19]=mask_c0 i[20]=mask_c1 i[22]=precision, f[0]=alpha f[1]=mask_alpha
 //            p[0]=in p[1]=w p[2]=bias p[3]=out p[4]=mask_ref
 //  WGRAD     same desc; i[21]=dout_ld ; p[0]=in p[1]=dout p[2]=dw p[3]=db
 //  CORR_FWD  i: l_ld r_ld out_ld coff B H W C md stride copy_left zero_tail ; p: L R u out
@@ -66,7 +66,7 @@ static void desc_from_op(const mh_op& o, mh_conv_desc& d) {
     d.B = i[0]; d.Hi = i[1]; d.Wi = i[2]; d.Ho = i[3]; d.Wo = i[4]; d.K = i[5]; d.N = i[6];
     d.kh = i[7]; d.kw = i[8]; d.stride = i[9]; d.dil = i[10]; d.pad_t = i[11]; d.pad_l = i[12];
     d.mode = i[13]; d.w_trans = i[14]; d.in_ld = i[15]; d.out_ld = i[16]; d.mask_ld = i[17]; d.accumulate = i[18];
-    d.alpha = o.f[0]; d.mask_alpha = o.f[1]; d.mask_c0 = i[19]; d.mask_c1 = i[20];
+    d.alpha = o.f[0]; d.mask_alpha = o.f[1]; d.mask_c0 = i[19]; d.mask_c1 = i[20]; d.precision = i[22];
 }
 
 static int run_op(const mh_op& o, void* s) {

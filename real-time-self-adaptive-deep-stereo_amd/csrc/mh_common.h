@@ -45,6 +45,8 @@ __device__ __forceinline__ float mh_buf_load1(__amdgpu_buffer_rsrc_t r, int byte
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
 }
 
+#include <mh_bf16_intrin.h>     // bf16 pack + bf16 MFMA (angle brackets: the CPU emulator shadows this header)
+
 // XCD-aware, bijective remap of a linear workgroup id (8 XCDs; block b runs on XCD b%8):
 // every XCD gets a contiguous chunk of the logical tile space so neighbouring tiles share
 // one L2 (cdna_hip_programming.md T1, bijective variant).

@@ -19,7 +19,7 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("B", "Hi", "Wi", "Ho", "Wo", "K", "N", "kh", "kw", "stride", "dil", "pad_t", "pad_l",
                  "mode", "w_trans", "in_ld", "out_ld", "mask_ld", "accumulate")] + \
-               [("alpha", C.c_float), ("mask_alpha", C.c_float), ("mask_c0", C.c_int32), ("mask_c1", C.c_int32)]
+               [("alpha", C.c_float), ("mask_alpha", C.c_float), ("mask_c0", C.c_int32), ("mask_c1", C.c_int32), ("precision", C.c_int32)]
 
 
 class Op(C.Structure):

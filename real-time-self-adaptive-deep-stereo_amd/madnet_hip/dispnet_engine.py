@@ -83,7 +83,10 @@ class Node(object):
 
 
 class DispNetEngine(object):
-    def __init__(self, lib, H, W, B=1, device="cuda", weights=None):
+    def __init__(self, lib, H, W, B=1, device="cuda", weights=None, precision="fp32"):
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self.precision = precision
         self.lib, self.dev = lib, device
         self.B, self.H0, self.W0 = B, H, W
         self.Hp = H if H % 64 == 0 else (H // 64 + 1) * 64
@@ -295,6 +298,13 @@ class DispNetEngine(object):
 
     def build_plan(self, mode, lr=1e-4, grad_scale=1.0, update=True, part="all", **_):
         r = Recorder()
+        ops.PRECISION = 1 if self.precision == "bf16" else 0
+        try:
+            return self._build_plan(r, mode, lr, grad_scale, update, part)
+        finally:
+            ops.PRECISION = 0
+
+    def _build_plan(self, r, mode, lr, grad_scale, update, part):
         do_grad = part in ("all", "grad")
         do_upd = update and part in ("all", "update")
         if mode not in ("NONE", "FULL"):

@@ -117,7 +117,12 @@ class Params(object):
 
 
 class MadNetEngine(object):
-    def __init__(self, lib, H, W, B=1, device="cuda", radius_d=2, stride=1, warping=True, weights=None):
+    def __init__(self, lib, H, W, B=1, device="cuda", radius_d=2, stride=1, warping=True, weights=None, precision="fp32"):
+        """precision: 'fp32' = exact fp32 MFMA (parity path, default) | 'bf16' = bf16 MFMA inputs with fp32
+        accumulation in the conv forward / input-gradient kernels (throughput mode; tensors stay fp32)."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self.precision = precision
         if not warping:
             raise NotImplementedError("warping=False is not supported by the MI355X engine yet")
         self.lib, self.dev = lib, device
@@ -450,6 +455,13 @@ class MadNetEngine(object):
         part: 'all' | 'grad' (everything up to the gradients) | 'update' (momentum apply only) -- the
         split lets a gradient all-reduce (shared-model multi-GPU mode) sit between two plans."""
         r = Recorder()
+        ops.PRECISION = 1 if self.precision == "bf16" else 0
+        try:
+            return self._build_plan(r, mode, lr, block_vars, block_level, grad_scale, update, blocks, part)
+        finally:
+            ops.PRECISION = 0
+
+    def _build_plan(self, r, mode, lr, block_vars, block_level, grad_scale, update, blocks, part):
         if blocks is None and block_level is not None:
             blocks = [(block_level, block_vars)]
         do_grad = part in ("all", "grad")

@@ -58,9 +58,15 @@ def _p(x):
 
 
 def conv_desc(B, Hi, Wi, Ho, Wo, K, N, kh, kw, stride, dil, pad_t, pad_l, mode, w_trans,
-              in_ld, out_ld, mask_ld=0, accumulate=0, alpha=1.0, mask_alpha=1.0, mask_c0=0, mask_c1=0):
+              in_ld, out_ld, mask_ld=0, accumulate=0, alpha=1.0, mask_alpha=1.0, mask_c0=0, mask_c1=0, precision=None):
     return _ffi.ConvDesc(B, Hi, Wi, Ho, Wo, K, N, kh, kw, stride, dil, pad_t, pad_l, mode, w_trans,
-                         in_ld, out_ld, mask_ld, accumulate, alpha, mask_alpha, mask_c0, mask_c1)
+                         in_ld, out_ld, mask_ld, accumulate, alpha, mask_alpha, mask_c0, mask_c1,
+                         PRECISION if precision is None else precision)
+
+
+# module-wide arithmetic mode of the conv family: 0 = exact fp32 (parity path), 1 = bf16 MFMA (throughput).
+# The engines set it while they record a plan (engine(..., precision="bf16")).
+PRECISION = 0
 
 
 def conv_geometry(H, W, kh, kw, stride, dil):

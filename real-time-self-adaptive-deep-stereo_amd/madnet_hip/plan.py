@@ -45,11 +45,11 @@ class Recorder(object):
     # -- same names / argument order as _ffi.Lib (minus the 'mh_' prefix) --------------------
     def conv2d(self, dref, inp, w, bias, out, mask, stream):
         d = dref._obj
-        self._op(_ffi.OP_CONV, self._desc_ints(d), [d.alpha, d.mask_alpha], [inp, w, bias, out, mask])
+        self._op(_ffi.OP_CONV, self._desc_ints(d) + [0, d.precision], [d.alpha, d.mask_alpha], [inp, w, bias, out, mask])
 
     def conv2d_wgrad(self, dref, inp, dout, dout_ld, dw, db, stream):
         d = dref._obj
-        ints = self._desc_ints(d) + [dout_ld]
+        ints = self._desc_ints(d) + [dout_ld, d.precision]
         self._op(_ffi.OP_WGRAD, ints, [d.alpha, d.mask_alpha], [inp, dout, dw, db])
 
     def corr_fwd(self, L, l_ld, R, r_ld, u, out, out_ld, coff, B, H, W, Cc, md, stride, copy_left, zero_tail, stream):

@@ -40,6 +40,8 @@ struct dim3 {
 struct __attribute__((aligned(16))) float4 { float x, y, z, w; };
 static inline float4 make_float4(float a, float b, float c, float d) { float4 v; v.x = a; v.y = b; v.z = c; v.w = d; return v; }
 struct __attribute__((aligned(8))) float2 { float x, y; };
+struct __attribute__((aligned(8))) uint2 { unsigned x, y; };
+static inline uint2 make_uint2(unsigned a, unsigned b) { uint2 v; v.x = a; v.y = b; return v; }
 
 typedef void* hipStream_t;
 typedef void* hipEvent_t;
@@ -77,6 +79,7 @@ struct Fiber {
 struct Wave {
     int gen = 0, count = 0, alive = 0;
     float fa[2][64], fb[2][64];
+    unsigned ua[2][64][4], ub[2][64][4];
 };
 
 struct Tls {

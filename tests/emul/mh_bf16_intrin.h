@@ -1,0 +1,33 @@
+// TEST INFRASTRUCTURE: CPU emulation of csrc/mh_bf16_intrin.h (shadows it through the include path).
+#pragma once
+static inline unsigned emul_bf16_bits(float f) {
+    unsigned u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;       // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                      // round to nearest even
+    return u >> 16;
+}
+static inline float emul_bf16_val(unsigned h) { unsigned u = h << 16; float f; memcpy(&f, &u, 4); return f; }
+static inline unsigned mh_pack_bf16(float lo, float hi) { return emul_bf16_bits(lo) | (emul_bf16_bits(hi) << 16); }
+
+static inline f32x4 mh_mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+    emul::Wave& w = emul::my_wave();
+    const int lane = emul::tls().cur_index & 63;
+    const int par = w.gen & 1;
+    for (int e = 0; e < 4; ++e) { w.ua[par][lane][e] = a[e]; w.ub[par][lane][e] = b[e]; }
+    emul::wave_rendezvous(w);
+    const int col = lane & 15;
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = (lane >> 4) * 4 + r;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) {
+            const int kq = k >> 3, e = k & 7;
+            const unsigned aw = w.ua[par][row + 16 * kq][e >> 1], bw = w.ub[par][col + 16 * kq][e >> 1];
+            const float av = emul_bf16_val((e & 1) ? (aw >> 16) : (aw & 0xffffu));
+            const float bv = emul_bf16_val((e & 1) ? (bw >> 16) : (bw & 0xffffu));
+            acc += av * bv;
+        }
+        d[r] = acc;
+    }
+    return d;
+}

@@ -171,3 +171,42 @@ def test_conv_uniform_tap_fast_path(backend, tile, shape):
         outs[no_uni] = (y.cpu(), dx.cpu())
     # same K order in both loaders -> bitwise identical results
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+BF16_CASES = [(1, 9, 14, 64, 32, 1, 2), (2, 8, 12, 128, 24, 1, 1), (1, 12, 20, 32, 32, 2, 1), (1, 7, 11, 38, 20, 1, 1),
+              (1, 10, 16, 96, 64, 1, 1), (1, 9, 13, 3, 16, 2, 1), (1, 6, 10, 128, 128, 1, 4)]
+
+
+@pytest.mark.parametrize("shape", BF16_CASES)
+def test_conv_bf16_throughput_mode(backend, shape):
+    """precision=1: operands rounded to bf16 (RNE) at the LDS store, fp32 accumulation.  Reference = the fp32
+    oracle applied to bf16-rounded operands (products of bf16 values are exact in fp32)."""
+    B, H, W, Ci, Co, s, d = shape
+    dev = backend.device
+    x = _rand((B, H, W, Ci), 41, dev)
+    w = _rand((3, 3, Ci, Co), 42, dev, 0.2)
+    b = _rand((Co,), 43, dev)
+    Ho, Wo, _, _ = ops.conv_geometry(H, W, 3, 3, s, d)
+    gz = _rand((B, Ho, Wo, Co), 44, dev)
+    y_ref = T.conv2d(_bf(x.cpu()), _bf(w.cpu()), b.cpu(), stride=s, dilation=d, alpha=0.2)
+    _, gx_ref, _, _ = _oracle_grads(x.cpu(), _bf(w.cpu()), b.cpu(), s, d, 1.0, _bf(gz.cpu()))
+    ld = (Ci + 3) // 4 * 4
+    xb, xv = _padded(x, ld)
+    ops.PRECISION = 1
+    try:
+        y = torch.full(y_ref.shape, float("nan"), device=dev)
+        ops.conv2d_fwd(backend.lib, xv, w, b, ops.view(y), stride=s, dil=d, alpha=0.2)
+        dxb, dxv = _padded(torch.full(x.shape, float("nan"), device=dev), ld)
+        ops.conv2d_dgrad(backend.lib, ops.view(gz), w, dxv, stride=s, dil=d)
+        backend.sync()
+    finally:
+        ops.PRECISION = 0
+    assert (y.cpu() - y_ref).abs().max().item() <= 1e-4 * max(1.0, y_ref.abs().max().item())
+    assert (dxb[..., :Ci].cpu() - gx_ref).abs().max().item() <= 1e-4 * max(1.0, gx_ref.abs().max().item())
+    # and it really is a reduced-precision path: it differs from the exact fp32 result
+    y32 = T.conv2d(x.cpu(), w.cpu(), b.cpu(), stride=s, dilation=d, alpha=0.2)
+    assert (y.cpu() - y32).abs().max().item() > 1e-4
