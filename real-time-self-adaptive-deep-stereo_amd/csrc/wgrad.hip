@@ -18,8 +18,19 @@ struct WgradArgs {
     int M, taps, ktiles, ntiles, splits, chunk;
     int vecA, vecB;
     unsigned in_bytes, dz_bytes;
+    int bf16;              // throughput mode (bf16 MFMA inputs, fp32 accumulate)
     int dbg_plain_store;   // timing experiment only: plain stores instead of atomics (WRONG results)
 };
+
+static int g_wgrad_target_wgs = 0;
+// tuning hook (microbenchmarks): number of workgroups the pixel split aims for (0 = heuristic)
+static int g_wgrad_plain = 0;
+extern "C" int mh_tune_wgrad_wgs(int target) {
+    g_wgrad_plain = target < 0;                    // negative: timing experiment with plain stores (wrong results)
+    if (target < 0) target = -target;
+    g_wgrad_target_wgs = target > 1 ? target : 0;
+    return 0;
+}
 
 template <int GPT>
 __device__ __forceinline__ int swz_group(int row, int g) { return g ^ ((row >> 2) & (GPT - 1)); }
@@ -220,14 +231,234 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
     if (do_bias && n0 + tid < p.N) atomicAdd(p.db + n0 + tid, bsum);
 }
 
-static int g_wgrad_target_wgs = 0;
-// tuning hook (microbenchmarks): number of workgroups the pixel split aims for (0 = heuristic)
-static int g_wgrad_plain = 0;
-extern "C" int mh_tune_wgrad_wgs(int target) {
-    g_wgrad_plain = target < 0;                    // negative: timing experiment with plain stores (wrong results)
-    if (target < 0) target = -target;
-    g_wgrad_target_wgs = target > 1 ? target : 0;
-    return 0;
+
+// ---- bf16 throughput-mode variant ----------------------------------------------------------------------
+// Same decomposition, but the reduction tile is 64 pixels, both LDS tiles are bf16 [channel][pixel]
+// (pixel-contiguous, row stride 64+8 halfs) and the contraction runs on v_mfma_f32_16x16x32_bf16 (lane
+// (i, q) reads the 8 consecutive pixels 8q..8q+7 of its channel with one ds_read_b128).  A "unit" = 4
+// consecutive pixels x one 4-channel group: 4 coalesced 16-byte loads along the NHWC rows, transposed in
+// registers and rounded to bf16 (v_cvt_pk_bf16_f32), stored as four 8-byte LDS writes.
+template <int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(WgradArgs p) {
+    constexpr int NTH = 64 * WM * WN;
+    constexpr int PT = 64;
+    constexpr int BK = WM * MT * 16, BN = WN * NT * 16;
+    constexpr int LS = PT + 8;                                   // halfs
+    constexpr int AUN = (BK / 4) * (PT / 4), BUN = (BN / 4) * (PT / 4);
+    constexpr int AU = (AUN + NTH - 1) / NTH, BU = (BUN + NTH - 1) / NTH;
+
+    HIP_DYNAMIC_SHARED(float, smem)
+    unsigned short* const Ah = reinterpret_cast<unsigned short*>(smem);   // [2][BK*LS]
+    unsigned short* const Bh = Ah + 2 * BK * LS;                         // [2][BN*LS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 15, lq = lane >> 4;
+
+    int bid = blockIdx.x;
+    const int split = bid % p.splits; bid /= p.splits;
+    const int tn = bid % p.ntiles; bid /= p.ntiles;
+    const int tk = bid % p.ktiles; bid /= p.ktiles;
+    const int tap = bid;
+    const int ky = tap / p.kw, kx = tap - ky * p.kw;
+    const int dy = ky * p.dil - p.pad_t, dx = kx * p.dil - p.pad_l;
+    const int k0 = tk * BK, n0 = tn * BN;
+    const int mbeg = split * p.chunk;
+    const int mend = min(p.M, mbeg + p.chunk);
+    if (mbeg >= mend) return;
+    const int ntile = (mend - mbeg + PT - 1) / PT;
+    const int Kr = (p.K + 3) & ~3;
+
+    // Pixel table: tab[buf][i] = byte offset of the input pixel that reduction-pixel i of a tile reads for this
+    // workgroup's tap, or -1 (padding / past the chunk).  64 threads keep one incremental (b, oy, ox) cursor
+    // each; the loaders fetch the 4 offsets of their unit with one ds_read_b128.
+    int* const tab = reinterpret_cast<int*>(Bh + 2 * BN * LS);            // [2][PT]
+    int c_m = mbeg + tid, c_ox = 0, c_oy = 0, c_b = 0;
+    if (tid < PT) {
+        c_ox = c_m % p.Wo;
+        const int t2 = c_m / p.Wo;
+        c_oy = t2 % p.Ho;
+        c_b = t2 / p.Ho;
+    }
+    auto table_step = [&](int buf) {
+        if (tid < PT) {
+            const int iy = c_oy * p.stride + dy, ix = c_ox * p.stride + dx;
+            const bool ok = c_m < mend && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            tab[buf * PT + tid] = ok ? ((c_b * p.Hi + iy) * p.Wi + ix) * p.in_ld * 4 : -1;
+            c_m += PT;
+            c_ox += PT;
+            while (c_ox >= p.Wo) {
+                c_ox -= p.Wo;
+                if (++c_oy == p.Ho) { c_oy = 0; ++c_b; }
+            }
+        }
+    };
+
+    float4 ra_v[AU][4], rb_v[BU][4];
+    int tile_ld = 0;
+    const __amdgpu_buffer_rsrc_t rs_in = mh_make_rsrc(p.in, p.in_bytes);
+    const __amdgpu_buffer_rsrc_t rs_dz = mh_make_rsrc(p.dz, p.dz_bytes);
+
+    auto load_tile = [&]() {
+        const int* tb = tab + (tile_ld & 1) * PT;
+#pragma unroll
+        for (int j = 0; j < AU; ++j) {
+            const int u = tid + NTH * j;
+            const int k = k0 + (u % (BK / 4)) * 4;
+            const bool uok = (u < AUN) && (k < Kr);
+            const int4 o = *reinterpret_cast<const int4*>(tb + ((u / (BK / 4)) & (PT / 4 - 1)) * 4);
+            ra_v[j][0] = mh_buf_load4(rs_in, (uok && o.x >= 0) ? o.x + k * 4 : MH_OOB);
+            ra_v[j][1] = mh_buf_load4(rs_in, (uok && o.y >= 0) ? o.y + k * 4 : MH_OOB);
+            ra_v[j][2] = mh_buf_load4(rs_in, (uok && o.z >= 0) ? o.z + k * 4 : MH_OOB);
+            ra_v[j][3] = mh_buf_load4(rs_in, (uok && o.w >= 0) ? o.w + k * 4 : MH_OOB);
+        }
+#pragma unroll
+        for (int j = 0; j < BU; ++j) {
+            const int u = tid + NTH * j;
+            const int m = mbeg + tile_ld * PT + (u / (BN / 4)) * 4;
+            const int n = n0 + (u % (BN / 4)) * 4;
+            const bool uok = (u < BUN) && (n < p.N);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                rb_v[j][e] = mh_buf_load4(rs_dz, (uok && m + e < mend) ? ((m + e) * p.dz_ld + n) * 4 : MH_OOB);
+        }
+        ++tile_ld;
+    };
+
+    // LDS position of (row, pixel-group pb): 8-pixel octets are XOR-swizzled by the row's 16-row block so that
+    // the 8-byte unit stores of a half wave fall into distinct banks; an MFMA operand read (16 consecutive
+    // rows of one block) sees one constant XOR and stays conflict free.
+    auto store_unit = [&](unsigned short* base, int row0, int pb, const float4 (&v)[4], bool zero_pad) {
+        unsigned short* d = base + row0 * LS + ((((pb >> 1) ^ (row0 >> 4)) & 7) * 2 + (pb & 1)) * 4;
+        *reinterpret_cast<uint2*>(d) = make_uint2(mh_pack_bf16(v[0].x, v[1].x), mh_pack_bf16(v[2].x, v[3].x));
+        *reinterpret_cast<uint2*>(d + LS) = make_uint2(mh_pack_bf16(v[0].y, v[1].y), mh_pack_bf16(v[2].y, v[3].y));
+        *reinterpret_cast<uint2*>(d + 2 * LS) = make_uint2(mh_pack_bf16(v[0].z, v[1].z), mh_pack_bf16(v[2].z, v[3].z));
+        *reinterpret_cast<uint2*>(d + 3 * LS) = make_uint2(mh_pack_bf16(v[0].w, v[1].w), mh_pack_bf16(v[2].w, v[3].w));
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < AU; ++j) {
+            const int u = tid + NTH * j;
+            if (u < AUN) store_unit(Ah + buf * (BK * LS), (u % (BK / 4)) * 4, u / (BK / 4), ra_v[j], false);
+        }
+#pragma unroll
+        for (int j = 0; j < BU; ++j) {
+            const int u = tid + NTH * j;
+            if (u < BUN) store_unit(Bh + buf * (BN * LS), (u % (BN / 4)) * 4, u / (BN / 4), rb_v[j], false);
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // bias gradient (exact fp32): the tap-0 / k-tile-0 workgroups sum their dz rows from the loaded registers
+    const bool do_bias = (p.db != nullptr) && tap == 0 && tk == 0;
+    float4 bsum[BU];
+#pragma unroll
+    for (int j = 0; j < BU; ++j) bsum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    table_step(0);
+    table_step(1);
+    __syncthreads();
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < ntile; ++t) {
+        const int buf = t & 1;
+        if (do_bias) {      // registers still hold tile t's dz rows until the next load overwrites them
+#pragma unroll
+            for (int j = 0; j < BU; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bsum[j].x += rb_v[j][e].x; bsum[j].y += rb_v[j][e].y; bsum[j].z += rb_v[j][e].z; bsum[j].w += rb_v[j][e].w;
+                }
+        }
+        if (t + 1 < ntile) load_tile();
+        table_step(buf);            // entries of tile t+2 (buffer last read at the top of iteration t-1)
+        const unsigned short* Ab = Ah + buf * (BK * LS) + (wm * MT * 16 + li) * LS;
+        const unsigned short* Bb = Bh + buf * (BN * LS) + (wn * NT * 16 + li) * LS;
+#pragma unroll
+        for (int s = 0; s < PT / 32; ++s) {
+            u32x4 a[MT], b[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                a[i] = *reinterpret_cast<const u32x4*>(Ab + i * 16 * LS + (((s * 4 + lq) ^ (wm * MT + i)) & 7) * 8);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                b[j] = *reinterpret_cast<const u32x4*>(Bb + j * 16 * LS + (((s * 4 + lq) ^ (wn * NT + j)) & 7) * 8);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mh_mfma_bf16(a[i], b[j], acc[i][j]);
+        }
+        if (t + 1 < ntile) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = k0 + wm * MT * 16 + i * 16 + lq * 4 + r;
+            if (k >= p.K) continue;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = n0 + wn * NT * 16 + j * 16 + li;
+                if (n < p.N) {
+                    float* d = p.dw + ((int64_t)tap * p.K + k) * p.N + n;
+                    if (p.dbg_plain_store) *d = acc[i][j][r]; else atomicAdd(d, acc[i][j][r]);
+                }
+            }
+        }
+    if (do_bias) {      // uniform per workgroup.  Reduce through LDS first: one global atomic per output channel
+        static_assert(NTH % (BN / 4) == 0, "unit -> channel-group mapping must not depend on j");
+        float4 bs = bsum[0];
+#pragma unroll
+        for (int j = 1; j < BU; ++j) { bs.x += bsum[j].x; bs.y += bsum[j].y; bs.z += bsum[j].z; bs.w += bsum[j].w; }
+        float* red = smem;                                      // [NTH / (BN/4)][BN]; the tiles are dead by now
+        *reinterpret_cast<float4*>(red + (tid / (BN / 4)) * BN + (tid % (BN / 4)) * 4) = bs;
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.N) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < NTH / (BN / 4); ++r) t += red[r * BN + tid];
+            atomicAdd(p.db + n0 + tid, t);
+        }
+    }
+}
+
+template <int WM, int WN, int MT, int NT>
+int launch_wgrad_bf16(WgradArgs& a, hipStream_t s) {
+    constexpr int BK = WM * MT * 16, BN = WN * NT * 16, PT = 64;
+    constexpr size_t lds = (size_t)(2 * (BK + BN) * (PT + 8)) * 2 + 2 * PT * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<WM, WN, MT, NT>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { mh_set_error("wgrad_bf16: hipFuncSetAttribute(%d B LDS): %s", (int)lds, hipGetErrorString(e)); return (int)e; }
+        }
+        attr_done = true;
+    }
+    if (a.M < 0) return 0;
+    a.ktiles = mh_cdiv(a.K, BK);
+    a.ntiles = mh_cdiv(a.N, BN);
+    const int base = a.taps * a.ktiles * a.ntiles;
+    constexpr int units = WM * WN * MT * NT;
+    const int target = g_wgrad_target_wgs > 0 ? g_wgrad_target_wgs : (units >= 32 ? 384 : (units >= 8 ? 768 : 1536));
+    int splits = mh_cdiv(target, base);
+    const int maxs = mh_cdiv(a.M, PT * 2);
+    if (splits > maxs) splits = maxs;
+    if (splits < 1) splits = 1;
+    int chunk = mh_cdiv(a.M, splits);
+    chunk = (chunk + PT - 1) / PT * PT;
+    a.splits = mh_cdiv(a.M, chunk);
+    a.chunk = chunk;
+    hipLaunchKernelGGL((wgrad_bf16_kernel<WM, WN, MT, NT>), dim3(base * a.splits), dim3(64 * WM * WN), lds, s, a);
+    return mh_check_launch("wgrad_bf16");
 }
 
 template <int WM, int WN, int MT, int NT, int PT, bool VEC>
@@ -269,6 +500,7 @@ int launch_wgrad(WgradArgs& a, hipStream_t s) {
     const bool all = a.M < 0;
     const bool vec = a.vecA && a.vecB;
     int rc = 0;
+    if (all || (vec && a.bf16)) { rc = launch_wgrad_bf16<WM, WN, MT, NT>(a, s); if (!all || rc) return rc; }
     if (all || vec) { rc = launch_wgrad_one<WM, WN, MT, NT, PT, true>(a, s); if (!all || rc) return rc; }
     if (all || !vec) { rc = launch_wgrad_one<WM, WN, MT, NT, PT, false>(a, s); if (!all || rc) return rc; }
     return rc;
@@ -325,6 +557,7 @@ extern "C" int mh_conv2d_wgrad(const mh_conv_desc* d, const float* in, const flo
     a.vecA = mh_aligned16(in) && (d->in_ld % 4 == 0) && (d->in_ld >= ((d->K + 3) & ~3));
     a.vecB = mh_aligned16(dout) && (dout_ld % 4 == 0) && (d->N % 4 == 0);
     a.dbg_plain_store = g_wgrad_plain;
+    a.bf16 = (d->precision == 1);
     {
         const int64_t inb = (((int64_t)d->B * d->Hi * d->Wi - 1) * d->in_ld + (int64_t)((d->K + 3) / 4) * 4) * 4;
         const int64_t dzb = (((int64_t)a.M - 1) * dout_ld + d->N) * 4;

@@ -42,6 +42,7 @@ static inline float4 make_float4(float a, float b, float c, float d) { float4 v;
 struct __attribute__((aligned(8))) float2 { float x, y; };
 struct __attribute__((aligned(8))) uint2 { unsigned x, y; };
 static inline uint2 make_uint2(unsigned a, unsigned b) { uint2 v; v.x = a; v.y = b; return v; }
+struct __attribute__((aligned(16))) int4 { int x, y, z, w; };
 
 typedef void* hipStream_t;
 typedef void* hipEvent_t;

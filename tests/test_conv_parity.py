@@ -202,9 +202,19 @@ def test_conv_bf16_throughput_mode(backend, shape):
         ops.conv2d_fwd(backend.lib, xv, w, b, ops.view(y), stride=s, dil=d, alpha=0.2)
         dxb, dxv = _padded(torch.full(x.shape, float("nan"), device=dev), ld)
         ops.conv2d_dgrad(backend.lib, ops.view(gz), w, dxv, stride=s, dil=d)
+        dw = torch.zeros_like(w)
+        db = torch.zeros_like(b)
+        ops.conv2d_wgrad(backend.lib, xv, ops.view(gz), dw, db, stride=s, dil=d)
         backend.sync()
     finally:
         ops.PRECISION = 0
+    # filter gradient: bf16-rounded activations x bf16-rounded dz, fp32 accumulate; bias gradient stays exact fp32
+    _, _, gw_ref, _ = _oracle_grads(_bf(x.cpu()), w.cpu(), b.cpu(), s, d, 1.0, _bf(gz.cpu()))
+    _, _, gw32, gb_ref = _oracle_grads(x.cpu(), w.cpu(), b.cpu(), s, d, 1.0, gz.cpu())
+    assert (dw.cpu() - gw_ref).abs().max().item() <= 1e-4 * max(1.0, gw_ref.abs().max().item())
+    assert (db.cpu() - gb_ref).abs().max().item() <= 1e-4 * max(1.0, gb_ref.abs().max().item())
+    if Ci % 4 == 0 and Co % 4 == 0:
+        assert (dw.cpu() - gw32).abs().max().item() > 1e-5      # the bf16 kernel really ran
     assert (y.cpu() - y_ref).abs().max().item() <= 1e-4 * max(1.0, y_ref.abs().max().item())
     assert (dxb[..., :Ci].cpu() - gx_ref).abs().max().item() <= 1e-4 * max(1.0, gx_ref.abs().max().item())
     # and it really is a reduced-precision path: it differs from the exact fp32 result
