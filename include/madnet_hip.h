@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 3
+#define MH_ABI_VERSION 4
 
 const char* mh_last_error(void);
 int mh_abi_version(void);
@@ -69,6 +69,24 @@ int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w, const floa
  * atomics over pixel splits) -- zero them first.  db may be NULL. */
 int mh_conv2d_wgrad(const mh_conv_desc* d, const float* in, const float* dout, int32_t dout_ld,
                     float* dw, float* db, void* stream);
+
+/* Atomic-free form for a whole training step (the per-layer conv2d_backprop_filter calls TF issues for
+ * Stereo_Online_Adaptation.py:114's minimize()): pixel split s writes its partial filter gradient to
+ * ws[s][kh*kw*K*N] with plain stores; mh_wgrad_reduce then sums the splits of EVERY layer in one launch.
+ *   query : ws == NULL -> *splits = number of pixel splits this geometry uses (nothing is launched);
+ *   launch: ws != NULL, *splits = the queried value; ws must hold *splits * kh*kw*K*N floats, 16-byte
+ *           aligned; it is fully overwritten (no zeroing needed).  db (may be NULL) is still accumulated. */
+int mh_conv2d_wgrad_partial(const mh_conv_desc* d, const float* in, const float* dout, int32_t dout_ld,
+                            float* ws, int32_t* splits, float* db, void* stream);
+typedef struct mh_wgrad_seg {
+    const float* ws;      /* [splits][size] partial sums of one layer */
+    float* dst;           /* [size] filter gradient */
+    int32_t size, splits;
+    int32_t blk0;         /* exclusive prefix sum of ceil(size/1024) over the table */
+    int32_t accumulate;   /* 0: dst = sum, 1: dst += sum (dst must then appear once per table) */
+} mh_wgrad_seg;
+/* segs_device: table in DEVICE memory; nblocks = sum of ceil(size/1024). */
+int mh_wgrad_reduce(const mh_wgrad_seg* segs_device, int32_t nseg, int32_t nblocks, void* stream);
 
 /* ---- correlation / cost volume: sharedLayers.correlation (Nets/sharedLayers.py:23-51),
  *      replaces ShiftCorrKernelLauncher / ShiftCorrGradKernelLauncher ------------------- */
@@ -161,7 +179,8 @@ int mh_tune_corr(int direct);
  *      records once; one FFI call replays it (optionally captured into a hipGraph). ------ */
 enum { MH_OP_CONV = 1, MH_OP_WGRAD, MH_OP_CORR_FWD, MH_OP_CORR_BWD, MH_OP_WARP_FWD, MH_OP_WARP_BWD,
        MH_OP_RESIZE_FWD, MH_OP_RESIZE_BWD, MH_OP_PAD_REFLECT, MH_OP_LOSS, MH_OP_METRICS,
-       MH_OP_MOMENTUM, MH_OP_COPY_CH, MH_OP_LEAKY_BWD, MH_OP_FILL, MH_OP_BIAS_GRAD };
+       MH_OP_MOMENTUM, MH_OP_COPY_CH, MH_OP_LEAKY_BWD, MH_OP_FILL, MH_OP_BIAS_GRAD,
+       MH_OP_WGRAD_PARTIAL, MH_OP_WGRAD_REDUCE };
 typedef struct mh_op {
     int32_t kind;
     int32_t i[27];

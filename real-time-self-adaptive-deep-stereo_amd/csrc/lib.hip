@@ -81,6 +81,13 @@ static int run_op(const mh_op& o, void* s) {
             mh_conv_desc d; desc_from_op(o, d);
             return mh_conv2d_wgrad(&d, (const float*)p[0], (const float*)p[1], i[21], (float*)p[2], (float*)p[3], s);
         }
+        case MH_OP_WGRAD_PARTIAL: {
+            mh_conv_desc d; desc_from_op(o, d);
+            int32_t splits = i[23];
+            return mh_conv2d_wgrad_partial(&d, (const float*)p[0], (const float*)p[1], i[21], (float*)p[2], &splits, (float*)p[3], s);
+        }
+        case MH_OP_WGRAD_REDUCE:
+            return mh_wgrad_reduce((const mh_wgrad_seg*)p[0], i[0], i[1], s);
         case MH_OP_CORR_FWD:
             return mh_corr_fwd((const float*)p[0], i[0], (const float*)p[1], i[1], (const float*)p[2], (float*)p[3], i[2], i[3],
                                i[4], i[5], i[6], i[7], i[8], i[9], i[10], i[11], s);

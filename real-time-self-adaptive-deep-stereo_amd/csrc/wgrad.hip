@@ -19,6 +19,9 @@ struct WgradArgs {
     int vecA, vecB;
     unsigned in_bytes, dz_bytes;
     int bf16;              // throughput mode (bf16 MFMA inputs, fp32 accumulate)
+    float* ws;             // != null: split s stores its partial dW to ws[s][taps*K*N] (no atomics)
+    int forced_splits;     // > 0: use exactly this split count (the workspace was sized for it)
+    int query;             // 1: compute `splits` only, launch nothing
     int dbg_plain_store;   // timing experiment only: plain stores instead of atomics (WRONG results)
 };
 
@@ -57,11 +60,15 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 15, lq = lane >> 4;
 
-    int bid = blockIdx.x;
-    const int split = bid % p.splits; bid /= p.splits;
+    // Workgroups that read the same pixel chunk (all taps / channel tiles of one split) get consecutive
+    // logical ids on ONE XCD, so the chunk comes from HBM once and the other taps*ktiles*ntiles-1 reads hit
+    // that XCD's L2 (the activations of a layer do not fit the 4 MiB L2: tap-major order re-streamed them
+    // from memory once per tap).
+    int bid = mh_xcd_remap(blockIdx.x, gridDim.x);
+    const int tap = bid % p.taps; bid /= p.taps;
     const int tn = bid % p.ntiles; bid /= p.ntiles;
     const int tk = bid % p.ktiles; bid /= p.ktiles;
-    const int tap = bid;
+    const int split = bid;
     const int ky = tap / p.kw, kx = tap - ky * p.kw;
     const int dy = ky * p.dil - p.pad_t, dx = kx * p.dil - p.pad_l;
     const int k0 = tk * BK, n0 = tn * BN;
@@ -213,6 +220,8 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
         __syncthreads();
     }
 
+    float* const dwb = p.ws ? p.ws + (int64_t)split * ((int64_t)p.taps * p.K * p.N) : p.dw;
+    const bool plain = (p.ws != nullptr) || p.dbg_plain_store;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -223,8 +232,8 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
             for (int j = 0; j < NT; ++j) {
                 const int n = n0 + wn * NT * 16 + j * 16 + li;
                 if (n < p.N) {
-                    float* d = p.dw + ((int64_t)tap * p.K + k) * p.N + n;
-                    if (p.dbg_plain_store) *d = acc[i][j][r]; else atomicAdd(d, acc[i][j][r]);
+                    float* d = dwb + ((int64_t)tap * p.K + k) * p.N + n;
+                    if (plain) *d = acc[i][j][r]; else atomicAdd(d, acc[i][j][r]);
                 }
             }
         }
@@ -255,11 +264,15 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(WgradArgs p) {
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 15, lq = lane >> 4;
 
-    int bid = blockIdx.x;
-    const int split = bid % p.splits; bid /= p.splits;
+    // Workgroups that read the same pixel chunk (all taps / channel tiles of one split) get consecutive
+    // logical ids on ONE XCD, so the chunk comes from HBM once and the other taps*ktiles*ntiles-1 reads hit
+    // that XCD's L2 (the activations of a layer do not fit the 4 MiB L2: tap-major order re-streamed them
+    // from memory once per tap).
+    int bid = mh_xcd_remap(blockIdx.x, gridDim.x);
+    const int tap = bid % p.taps; bid /= p.taps;
     const int tn = bid % p.ntiles; bid /= p.ntiles;
     const int tk = bid % p.ktiles; bid /= p.ktiles;
-    const int tap = bid;
+    const int split = bid;
     const int ky = tap / p.kw, kx = tap - ky * p.kw;
     const int dy = ky * p.dil - p.pad_t, dx = kx * p.dil - p.pad_l;
     const int k0 = tk * BK, n0 = tn * BN;
@@ -398,6 +411,8 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(WgradArgs p) {
         __syncthreads();
     }
 
+    float* const dwb = p.ws ? p.ws + (int64_t)split * ((int64_t)p.taps * p.K * p.N) : p.dw;
+    const bool plain = (p.ws != nullptr) || p.dbg_plain_store;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -408,8 +423,8 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(WgradArgs p) {
             for (int j = 0; j < NT; ++j) {
                 const int n = n0 + wn * NT * 16 + j * 16 + li;
                 if (n < p.N) {
-                    float* d = p.dw + ((int64_t)tap * p.K + k) * p.N + n;
-                    if (p.dbg_plain_store) *d = acc[i][j][r]; else atomicAdd(d, acc[i][j][r]);
+                    float* d = dwb + ((int64_t)tap * p.K + k) * p.N + n;
+                    if (plain) *d = acc[i][j][r]; else atomicAdd(d, acc[i][j][r]);
                 }
             }
         }
@@ -449,14 +464,15 @@ int launch_wgrad_bf16(WgradArgs& a, hipStream_t s) {
     const int base = a.taps * a.ktiles * a.ntiles;
     constexpr int units = WM * WN * MT * NT;
     const int target = g_wgrad_target_wgs > 0 ? g_wgrad_target_wgs : (units >= 32 ? 384 : (units >= 8 ? 768 : 1536));
-    int splits = mh_cdiv(target, base);
+    int splits = a.forced_splits > 0 ? a.forced_splits : mh_cdiv(target, base);
     const int maxs = mh_cdiv(a.M, PT * 2);
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;
     int chunk = mh_cdiv(a.M, splits);
     chunk = (chunk + PT - 1) / PT * PT;
-    a.splits = mh_cdiv(a.M, chunk);
+    a.splits = mh_cdiv(a.M, chunk);         // idempotent: forcing the returned count reproduces it
     a.chunk = chunk;
+    if (a.query) return 0;
     hipLaunchKernelGGL((wgrad_bf16_kernel<WM, WN, MT, NT>), dim3(base * a.splits), dim3(64 * WM * WN), lds, s, a);
     return mh_check_launch("wgrad_bf16");
 }
@@ -483,14 +499,15 @@ int launch_wgrad_one(WgradArgs& a, hipStream_t s) {
     // few MFMAs per reduction tile) need many more to hide their latency
     constexpr int units = WM * WN * MT * NT;
     const int target = g_wgrad_target_wgs > 0 ? g_wgrad_target_wgs : (units >= 32 ? 384 : (units >= 8 ? 768 : 1536));
-    int splits = mh_cdiv(target, base);
+    int splits = a.forced_splits > 0 ? a.forced_splits : mh_cdiv(target, base);
     const int maxs = mh_cdiv(a.M, PT * 4);
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;
     int chunk = mh_cdiv(a.M, splits);
     chunk = (chunk + PT - 1) / PT * PT;
-    a.splits = mh_cdiv(a.M, chunk);
+    a.splits = mh_cdiv(a.M, chunk);         // idempotent: forcing the returned count reproduces it
     a.chunk = chunk;
+    if (a.query) return 0;
     hipLaunchKernelGGL((wgrad_kernel<WM, WN, MT, NT, PT, VEC>), dim3(base * a.splits), dim3(64 * WM * WN), lds, s, a);
     return mh_check_launch("wgrad");
 }
@@ -540,9 +557,9 @@ int mh_wgrad_init() {
     return wgrad_dispatch(a, nullptr);
 }
 
-extern "C" int mh_conv2d_wgrad(const mh_conv_desc* d, const float* in, const float* dout, int32_t dout_ld,
-                               float* dw, float* db, void* stream) {
-    MH_REQUIRE(d && in && dout && dw, MH_ERR_ARG, "mh_conv2d_wgrad: null argument");
+static int wgrad_entry(const mh_conv_desc* d, const float* in, const float* dout, int32_t dout_ld, float* dw, float* db,
+                       float* ws, int forced_splits, int query, int* splits_out, void* stream) {
+    MH_REQUIRE(d && in && dout && (dw || ws || query), MH_ERR_ARG, "mh_conv2d_wgrad: null argument");
     MH_REQUIRE(d->mode == 0, MH_ERR_ARG, "mh_conv2d_wgrad: descriptor must be the forward (mode 0) geometry");
     MH_REQUIRE(d->B > 0 && d->Hi > 0 && d->Wi > 0 && d->Ho > 0 && d->Wo > 0 && d->K > 0 && d->N > 0,
                MH_ERR_ARG, "mh_conv2d_wgrad: non-positive dimension");
@@ -558,11 +575,70 @@ extern "C" int mh_conv2d_wgrad(const mh_conv_desc* d, const float* in, const flo
     a.vecB = mh_aligned16(dout) && (dout_ld % 4 == 0) && (d->N % 4 == 0);
     a.dbg_plain_store = g_wgrad_plain;
     a.bf16 = (d->precision == 1);
+    a.ws = ws; a.forced_splits = forced_splits; a.query = query;
     {
         const int64_t inb = (((int64_t)d->B * d->Hi * d->Wi - 1) * d->in_ld + (int64_t)((d->K + 3) / 4) * 4) * 4;
         const int64_t dzb = (((int64_t)a.M - 1) * dout_ld + d->N) * 4;
         MH_REQUIRE(inb < (1ll << 31) - 64 && dzb < (1ll << 31) - 64, MH_ERR_UNSUPPORTED, "mh_conv2d_wgrad: tensors must be < 2 GiB");
         a.in_bytes = (unsigned)inb; a.dz_bytes = (unsigned)dzb;
     }
-    return wgrad_dispatch(a, (hipStream_t)stream);
+    const int rc = wgrad_dispatch(a, (hipStream_t)stream);
+    if (splits_out) *splits_out = a.splits;
+    return rc;
+}
+
+extern "C" int mh_conv2d_wgrad(const mh_conv_desc* d, const float* in, const float* dout, int32_t dout_ld,
+                               float* dw, float* db, void* stream) {
+    return wgrad_entry(d, in, dout, dout_ld, dw, db, nullptr, 0, 0, nullptr, stream);
+}
+
+extern "C" int mh_conv2d_wgrad_partial(const mh_conv_desc* d, const float* in, const float* dout, int32_t dout_ld,
+                                       float* ws, int32_t* splits, float* db, void* stream) {
+    MH_REQUIRE(splits, MH_ERR_ARG, "mh_conv2d_wgrad_partial: splits must not be null");
+    if (!ws) return wgrad_entry(d, in, dout, dout_ld, nullptr, nullptr, nullptr, 0, 1, splits, stream);   // query
+    MH_REQUIRE(*splits > 0, MH_ERR_ARG, "mh_conv2d_wgrad_partial: *splits must come from a query call (ws = NULL)");
+    int used = 0;
+    const int want = *splits;
+    int rc = wgrad_entry(d, in, dout, dout_ld, nullptr, nullptr, nullptr, want, 1, &used, stream);
+    if (rc) return rc;
+    MH_REQUIRE(used == want, MH_ERR_ARG, "mh_conv2d_wgrad_partial: split count %d does not match this geometry (%d)", want, used);
+    return wgrad_entry(d, in, dout, dout_ld, nullptr, db, ws, want, 0, nullptr, stream);
+}
+
+// ---- reduction of the per-split partial filter gradients (one launch for every layer of a step) --------
+namespace {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const mh_wgrad_seg* __restrict__ segs, int nseg) {
+    // block -> segment: segs[].blk0 is the exclusive prefix of the segments' block counts
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (segs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const mh_wgrad_seg sg = segs[lo];
+    const int e0 = ((int)blockIdx.x - sg.blk0) * 1024 + threadIdx.x * 4;
+    if (e0 >= sg.size) return;
+    if ((sg.size & 3) == 0) {       // every split slice 16-byte aligned (ws is): vector path
+        const float* src = sg.ws + e0;
+        float4 t = *reinterpret_cast<const float4*>(src);
+        for (int s = 1; s < sg.splits; ++s) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)s * sg.size);
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        float* d = sg.dst + e0;
+        if (sg.accumulate) { d[0] += t.x; d[1] += t.y; d[2] += t.z; d[3] += t.w; }
+        else { d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w; }
+    } else {
+        for (int e = e0; e < min(e0 + 4, sg.size); ++e) {
+            float t = 0.f;
+            for (int s = 0; s < sg.splits; ++s) t += sg.ws[(int64_t)s * sg.size + e];
+            if (sg.accumulate) sg.dst[e] += t; else sg.dst[e] = t;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int mh_wgrad_reduce(const mh_wgrad_seg* segs_device, int32_t nseg, int32_t nblocks, void* stream) {
+    MH_REQUIRE(segs_device && nseg > 0 && nblocks > 0, MH_ERR_ARG, "mh_wgrad_reduce: empty segment table");
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, segs_device, nseg);
+    return mh_check_launch("wgrad_reduce");
 }

@@ -28,7 +28,13 @@ class Op(C.Structure):
 
 
 (OP_CONV, OP_WGRAD, OP_CORR_FWD, OP_CORR_BWD, OP_WARP_FWD, OP_WARP_BWD, OP_RESIZE_FWD, OP_RESIZE_BWD,
- OP_PAD_REFLECT, OP_LOSS, OP_METRICS, OP_MOMENTUM, OP_COPY_CH, OP_LEAKY_BWD, OP_FILL, OP_BIAS_GRAD) = range(1, 17)
+ OP_PAD_REFLECT, OP_LOSS, OP_METRICS, OP_MOMENTUM, OP_COPY_CH, OP_LEAKY_BWD, OP_FILL, OP_BIAS_GRAD,
+ OP_WGRAD_PARTIAL, OP_WGRAD_REDUCE) = range(1, 19)
+
+
+class WgradSeg(C.Structure):
+    _fields_ = [("ws", C.c_void_p), ("dst", C.c_void_p), ("size", C.c_int32), ("splits", C.c_int32),
+                ("blk0", C.c_int32), ("accumulate", C.c_int32)]
 
 _P = C.c_void_p
 _I = C.c_int32
@@ -46,6 +52,8 @@ SIGNATURES = {
     "mh_tune_corr": (_I, [_I]),
     "mh_conv2d": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     "mh_conv2d_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _I, _P, _P, _P]),
+    "mh_conv2d_wgrad_partial": (_I, [C.POINTER(ConvDesc), _P, _P, _I, _P, C.POINTER(C.c_int32), _P, _P]),
+    "mh_wgrad_reduce": (_I, [_P, _I, _I, _P]),
     "mh_corr_fwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mh_corr_bwd": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mh_warp_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),

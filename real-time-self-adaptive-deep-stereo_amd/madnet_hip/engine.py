@@ -138,6 +138,9 @@ class MadNetEngine(object):
         self._alloc()
         self._plans = {}
         self._zeros_needed = []
+        # filter gradients: atomic-free split reduction (ops.conv2d_wgrad_partial) unless switched off
+        self.partial_wgrad = True
+        self.wsa = ops.WgradWorkspace(device)
 
     # ---------------------------------------------------------------------------------------
     def _buf(self, *shape):
@@ -305,6 +308,14 @@ class MadNetEngine(object):
         for o, c in P.ranges(train_vars):
             ops_fill(lib, P.g, o, c)
         written = set()                     # gradient buffers that already hold a contribution
+        segs = []                           # partial filter-gradient segments of this backward pass
+
+        def wgrad(xv, dzv, base, stride=1, dil=1):
+            dw, db = P.tensor(base + "/weights", "g"), P.tensor(base + "/biases", "g")
+            if self.partial_wgrad:
+                ops.conv2d_wgrad_partial(lib, self.lib, self.wsa, segs, xv, dzv, dw, db, stride=stride, dil=dil)
+            else:
+                ops.conv2d_wgrad(lib, xv, dzv, dw, db, stride=stride, dil=dil)
 
         def acc_flag(key):
             a = key in written
@@ -313,8 +324,7 @@ class MadNetEngine(object):
 
         def conv_bwd(xv, base, dzv, dxv, dx_key, x_act, stride=1, dil=1, need_dx=True, trainable=True):
             if trainable:
-                ops.conv2d_wgrad(lib, xv, dzv, P.tensor(base + "/weights", "g"), P.tensor(base + "/biases", "g"),
-                                 stride=stride, dil=dil)
+                wgrad(xv, dzv, base, stride=stride, dil=dil)
             if need_dx:
                 ops.conv2d_dgrad(lib, dzv, self.W_(base), dxv, stride=stride, dil=dil, accumulate=acc_flag(dx_key),
                                  mask_ref=x_act, mask_alpha=ALPHA)
@@ -429,12 +439,12 @@ class MadNetEngine(object):
                     if accumulate and not has_r:
                         ops_fill(lib, self.dF[i - 1][B:], 0, self.dF[i - 1][B:].numel())
                 if pyr_tr[i]:
-                    ops.conv2d_wgrad(lib, xin, self._fv(self.dF[i]), P.tensor(pyr_name(i) + "/weights", "g"),
-                                     P.tensor(pyr_name(i) + "/biases", "g"), stride=PYR[i - 1][2])
+                    wgrad(xin, self._fv(self.dF[i]), pyr_name(i), stride=PYR[i - 1][2])
                 if need_dx:
                     ops.conv2d_dgrad(lib, self._fv(self.dF[i]), self.W_(pyr_name(i)), self._fv(self.dF[i - 1]),
                                      stride=PYR[i - 1][2], accumulate=accumulate, mask_ref=self._fv(self.F[i - 1]),
                                      mask_alpha=ALPHA)
+        ops.wgrad_reduce(lib, segs, self.dev, r.keep)
 
     def record_update(self, r, train_vars, lr, momentum=0.9, grad_scale=1.0):
         """MomentumOptimizer apply on the (coalesced) ranges of train_vars."""
@@ -455,6 +465,7 @@ class MadNetEngine(object):
         part: 'all' | 'grad' (everything up to the gradients) | 'update' (momentum apply only) -- the
         split lets a gradient all-reduce (shared-model multi-GPU mode) sit between two plans."""
         r = Recorder()
+        self.wsa.reset()
         ops.PRECISION = 1 if self.precision == "bf16" else 0
         try:
             return self._build_plan(r, mode, lr, block_vars, block_level, grad_scale, update, blocks, part)

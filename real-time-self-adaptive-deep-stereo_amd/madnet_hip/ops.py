@@ -109,6 +109,73 @@ def conv2d_wgrad(lib, x, dz, dw, db, stride=1, dil=1, stream=None):
     lib.conv2d_wgrad(C.byref(d), _p(x), _p(dz), dz.ld, _p(dw), _p(db), _p(stream))
 
 
+class WgradWorkspace(object):
+    """Arena for the per-split partial filter gradients of one training step + the segment table the single
+    reduction launch walks (mh_conv2d_wgrad_partial / mh_wgrad_reduce).  The arena is transient within one plan
+    execution, so every plan of an engine shares it (`reset()` at the start of each plan build); chunks are never
+    freed or moved because recorded plans hold raw pointers into them."""
+    CHUNK = 64 << 20            # floats per arena chunk (256 MiB)
+
+    def __init__(self, device):
+        self.device = device
+        self.chunks = []
+        self.reset()
+
+    def reset(self):
+        self.ci, self.off = 0, 0
+
+    def alloc(self, nfloats):
+        nfloats = (nfloats + 3) // 4 * 4
+        while True:
+            if self.ci == len(self.chunks):
+                self.chunks.append(torch.empty(max(self.CHUNK, nfloats), dtype=torch.float32, device=self.device))
+                self.off = 0
+            c = self.chunks[self.ci]
+            if self.off + nfloats <= c.numel():
+                p = c.data_ptr() + 4 * self.off
+                self.off += nfloats
+                return p
+            self.ci += 1
+            self.off = 0
+
+    @property
+    def nbytes(self):
+        return sum(c.numel() for c in self.chunks) * 4
+
+
+def conv2d_wgrad_partial(lib, qlib, wsa, segs, x, dz, dw, db, stride=1, dil=1, stream=None):
+    """Like conv2d_wgrad, but atomic-free: the pixel splits' partial sums go to the arena `wsa` and a segment
+    (ws, dst=dw, size, splits) is appended to `segs` for the step's single wgrad_reduce launch.
+    `qlib` is the real library (split-count query); `lib` may be a Recorder."""
+    kh, kw, cin, cout = dw.shape
+    Ho, Wo, pt, pl = conv_geometry(x.H, x.W, kh, kw, stride, dil)
+    assert (dz.H, dz.W, dz.C) == (Ho, Wo, cout) and x.C == cin
+    d = conv_desc(x.B, x.H, x.W, Ho, Wo, cin, cout, kh, kw, stride, dil, pt, pl, 0, 0, x.ld, dz.ld)
+    splits = C.c_int32(0)
+    qlib.conv2d_wgrad_partial(C.byref(d), _p(x), _p(dz), dz.ld, None, C.byref(splits), None, None)
+    size = dw.numel()
+    ws = wsa.alloc(size * splits.value)
+    lib.conv2d_wgrad_partial(C.byref(d), _p(x), _p(dz), dz.ld, C.c_void_p(ws), C.byref(splits), _p(db), _p(stream))
+    segs.append((ws, dw.data_ptr(), size, splits.value))
+
+
+def wgrad_reduce(lib, segs, device, keep, stream=None):
+    """One launch that sums the splits of every segment recorded by conv2d_wgrad_partial.  `keep`: list that
+    keeps the device table alive as long as the plan."""
+    if not segs:
+        return
+    assert len(set(s[1] for s in segs)) == len(segs), "a filter gradient may appear once per reduction"
+    arr = (_ffi.WgradSeg * len(segs))()
+    blk = 0
+    for k, (ws, dst, size, splits) in enumerate(segs):
+        arr[k].ws, arr[k].dst, arr[k].size, arr[k].splits, arr[k].blk0, arr[k].accumulate = ws, dst, size, splits, blk, 0
+        blk += (size + 1023) // 1024
+    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    table = host.to(device)
+    keep.append(table)
+    lib.wgrad_reduce(C.c_void_p(table.data_ptr()), len(segs), blk, _p(stream))
+
+
 def conv2d_transpose_fwd(lib, x, w, b, out, stride=2, alpha=1.0, stream=None):
     """tf.nn.conv2d_transpose(x, w[kh,kw,Cout,Cin], 'SAME') + b, leaky (sharedLayers.py:80-92):
     the input-gradient of a SAME conv with HWIO = [kh,kw,I=Cout,O=Cin]."""

@@ -52,6 +52,14 @@ class Recorder(object):
         ints = self._desc_ints(d) + [dout_ld, d.precision]
         self._op(_ffi.OP_WGRAD, ints, [d.alpha, d.mask_alpha], [inp, dout, dw, db])
 
+    def conv2d_wgrad_partial(self, dref, inp, dout, dout_ld, ws, splits_ref, db, stream):
+        d = dref._obj
+        ints = self._desc_ints(d) + [dout_ld, d.precision, splits_ref._obj.value]
+        self._op(_ffi.OP_WGRAD_PARTIAL, ints, [d.alpha, d.mask_alpha], [inp, dout, ws, db])
+
+    def wgrad_reduce(self, segs, nseg, nblocks, stream):
+        self._op(_ffi.OP_WGRAD_REDUCE, [nseg, nblocks], [], [segs])
+
     def corr_fwd(self, L, l_ld, R, r_ld, u, out, out_ld, coff, B, H, W, Cc, md, stride, copy_left, zero_tail, stream):
         self._op(_ffi.OP_CORR_FWD, [l_ld, r_ld, out_ld, coff, B, H, W, Cc, md, stride, copy_left, zero_tail], [], [L, R, u, out])
 

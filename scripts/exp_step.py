@@ -1,0 +1,35 @@
+"""Timing experiments on the full MADNet FULL step (hipGraph replay) under the library's tuning hooks.
+usage: python scripts/exp_step.py [--precision bf16] [--plain-wgrad] [--wgs N]   (GPU box only)"""
+import argparse, os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "real-time-self-adaptive-deep-stereo_amd"))
+from madnet_hip import _ffi, engine as E, synthetic as S
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--precision", default="bf16")
+ap.add_argument("--plain-wgrad", action="store_true", help="timing only: plain stores instead of atomics (wrong results)")
+ap.add_argument("--wgs", type=int, default=0)
+ap.add_argument("--mode", default="FULL")
+ap.add_argument("--steps", type=int, default=40)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+lib = _ffi.lib()
+wn = S.calibrated_weights(dict(E.madnet_manifest()), 1)
+l, r, gt = S.make_pair(375, 1242)
+eng = E.MadNetEngine(lib, 375, 1242, B=1, device=dev, weights=wn, precision=a.precision)
+eng.set_inputs(l, r, gt[..., 0])
+plan = eng.build_plan(a.mode, lr=1e-4)
+t = a.wgs if a.wgs else (1 if a.plain_wgrad else 0)
+lib.tune_wgrad_wgs(-t if a.plain_wgrad else t)
+st = torch.cuda.Stream(); sh = st.cuda_stream
+with torch.cuda.stream(st):
+    plan.run(lib, sh); st.synchronize()
+    plan.capture(lib, sh)
+    for _ in range(5): plan.launch(lib, sh)
+    st.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps): plan.launch(lib, sh)
+    st.synchronize()
+    dt = time.perf_counter() - t0
+print("precision %s mode %s plain_wgrad %s wgs %d: %.3f ms/step" % (a.precision, a.mode, a.plain_wgrad, a.wgs, 1e3 * dt / a.steps))

@@ -81,6 +81,7 @@ DG_CASES = [
     (1, 10, 12, 12, 1, 3, 1, 1),       # Cout=1: K=1 contraction (scalar weight path)
     (1, 12, 16, 8, 24, 3, 1, 4),
     (1, 8, 8, 5, 7, 5, 2, 1),
+    (1, 16, 40, 8, 16, 3, 1, 1),       # 640 pixels: several pixel splits (atomics / partial-sum workspace)
 ]
 
 
@@ -119,6 +120,22 @@ def test_conv2d_dgrad_wgrad(backend, case):
     assert (dxb[..., :Ci].cpu() - exp_dx).abs().max().item() <= 3e-5 * sc
     assert (dw.cpu() - gw_ref).abs().max().item() <= 1e-4 * max(1.0, gw_ref.abs().max().item())
     assert (db.cpu() - gb_ref).abs().max().item() <= 1e-4 * max(1.0, gb_ref.abs().max().item())
+    # atomic-free form: per-split partial sums in a workspace + one reduction launch (dw2 is overwritten, not
+    # accumulated: start from garbage)
+    for prec in (0, 1):
+        wsa = ops.WgradWorkspace(dev); wsa.CHUNK = 1 << 16
+        segs, keep = [], []
+        dw2 = torch.full_like(w, float("nan")); db2 = torch.zeros_like(b)
+        ops.PRECISION = prec
+        try:
+            ops.conv2d_wgrad_partial(backend.lib, backend.lib, wsa, segs, xv, zv, dw2, db2, stride=s, dil=d)
+        finally:
+            ops.PRECISION = 0
+        ops.wgrad_reduce(backend.lib, segs, dev, keep)
+        backend.sync()
+        tol = 1e-4 if prec == 0 else 2e-2
+        assert (dw2.cpu() - gw_ref).abs().max().item() <= tol * max(1.0, gw_ref.abs().max().item()), prec
+        assert (db2.cpu() - gb_ref).abs().max().item() <= 1e-4 * max(1.0, gb_ref.abs().max().item())
 
 
 def test_conv2d_transpose(backend):
