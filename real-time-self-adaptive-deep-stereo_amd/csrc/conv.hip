@@ -71,6 +71,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     constexpr bool BT = BF16 && !DGRAD;                // B tile loaded as 4-row units, transposed in registers
     constexpr int UN = GPT * (BN / 4);                 // such units per tile
     constexpr int BITEMS = BT ? 4 * ((UN + 255) / 256) : (BVEC + 255) / 256;
+    constexpr bool PF2 = (BM * BN <= 32 * 64) && (BM <= 64) && VEC;   // small tiles: prefetch distance 2 (see the K loop); the
+                                                                    // 128x16 tile (full-resolution layers) is throughput bound
     constexpr int TILE_FLOATS = BF16 ? (BM + BN) * LS / 2 : (BM + BN) * LS;   // one buffer of both tiles, in floats
 
     HIP_DYNAMIC_SHARED(float, smem)
@@ -173,16 +175,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     }
     int u_tap = 0, u_c0 = 0;    // wave-uniform cursor of the NEXT tile to load (UNI)
 
-    float4 ra_v[AROWS];
-    float4 rb_v[BITEMS];
+    // Register stages.  Small tiles (PF2) are latency bound -- one exposed load -> LDS -> MFMA round trip per
+    // K-tile -- and run with prefetch distance 2: K-tiles t+1 and t+2 are in flight while tile t is multiplied.
+    float4 ra0[AROWS], ra1[PF2 ? AROWS : 1];
+    float4 rb0[BITEMS], rb1[PF2 ? BITEMS : 1];
+    int kb0 = 0, kb1 = 0;     // kbase of the A group held by each stage (padding select at store time)
 
     __syncthreads();   // tap tables visible
 
-    int a_kb_st = 0;    // kbase of the tile currently held in ra_v (used when it is stored)
     const __amdgpu_buffer_rsrc_t rs_in = mh_make_rsrc(p.in, p.in_bytes);
     const __amdgpu_buffer_rsrc_t rs_w = mh_make_rsrc(p.w, p.w_bytes);
 
-    auto load_tile = [&]() {
+    auto load_tile = [&](auto& ra_v, auto& rb_v, int& a_kb_st) {
         if (UNI) {
             // tile = channels [u_c0, u_c0+KT) of tap u_tap -- all scalar
             const bool tok = u_tap < p.taps;
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         }
     };
 
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, auto& ra_v, auto& rb_v, int a_kb_st) {
 #pragma unroll
         for (int j = 0; j < AROWS; ++j) {
             const int r = ra + RPP * j;
@@ -339,13 +343,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     const int ntile = (p.taps * p.G + GPT - 1) / GPT;
     const int li = lane & 15, lq = lane >> 4;
 
-    load_tile();
-    store_tile(0);
-    __syncthreads();
-
-    for (int t = 0; t < ntile; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < ntile) load_tile();
+    auto compute_tile = [&](int buf) {
         if (BF16) {
             const unsigned short* Ab = Ah + buf * (BM * LS) + (wm * MT * 16 + li) * LS + lq * 8;
             const unsigned short* Bb = Bh + buf * (BN * LS) + (wn * NT * 16 + li) * LS + lq * 8;
@@ -383,8 +381,38 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
                 }
         }
         }
-        if (t + 1 < ntile) store_tile(buf ^ 1);
+    };
+
+    if constexpr (PF2) {
+        // While tile t is multiplied out of LDS buffer t&1, tile t+1 sits in one register stage (stored to the
+        // other LDS buffer after the MFMAs) and tile t+2 is being loaded into the other stage.  Loads past the
+        // last tile are issued anyway (tap index out of range => out-of-range buffer offsets => zeros, no
+        // memory traffic): unconditional loads keep hipcc's s_waitcnt vmcnt(N) counted.
+        load_tile(ra0, rb0, kb0);            // tile 0
+        load_tile(ra1, rb1, kb1);            // tile 1
+        store_tile(0, ra0, rb0, kb0);
         __syncthreads();
+        for (int t = 0; t < ntile; t += 2) {
+            load_tile(ra0, rb0, kb0);        // tile t+2
+            compute_tile(0);                 // tile t
+            store_tile(1, ra1, rb1, kb1);    // tile t+1
+            __syncthreads();
+            load_tile(ra1, rb1, kb1);        // tile t+3
+            if (t + 1 < ntile) compute_tile(1);   // tile t+1 (uniform branch, no global loads inside)
+            store_tile(0, ra0, rb0, kb0);    // tile t+2
+            __syncthreads();
+        }
+    } else {
+        load_tile(ra0, rb0, kb0);
+        store_tile(0, ra0, rb0, kb0);
+        __syncthreads();
+        for (int t = 0; t < ntile; ++t) {
+            const int buf = t & 1;
+            if (t + 1 < ntile) load_tile(ra0, rb0, kb0);
+            compute_tile(buf);
+            if (t + 1 < ntile) store_tile(buf ^ 1, ra0, rb0, kb0);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: bias + leaky (+ accumulate) (+ fused leaky-grad mask) ------------------
