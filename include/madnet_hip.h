@@ -181,6 +181,13 @@ enum { MH_OP_CONV = 1, MH_OP_WGRAD, MH_OP_CORR_FWD, MH_OP_CORR_BWD, MH_OP_WARP_F
        MH_OP_RESIZE_FWD, MH_OP_RESIZE_BWD, MH_OP_PAD_REFLECT, MH_OP_LOSS, MH_OP_METRICS,
        MH_OP_MOMENTUM, MH_OP_COPY_CH, MH_OP_LEAKY_BWD, MH_OP_FILL, MH_OP_BIAS_GRAD,
        MH_OP_WGRAD_PARTIAL, MH_OP_WGRAD_REDUCE };
+/* i[26] of every op is its scheduling word: low byte = lane (0 = the caller's stream; 1..MH_MAX_LANES-1 = side
+ * streams owned by the library: the op is forked from lane 0 right before it, i.e. ordered after everything recorded so
+ * far, and runs concurrently with the lane-0 ops that follow); MH_OP_JOIN = lane 0 first waits for all side lanes.
+ * mh_plan_run joins every side lane before it returns.  Under mh_graph_begin/end the lanes become parallel branches
+ * of the captured hipGraph. */
+#define MH_MAX_LANES 3
+#define MH_OP_JOIN 0x100
 typedef struct mh_op {
     int32_t kind;
     int32_t i[27];

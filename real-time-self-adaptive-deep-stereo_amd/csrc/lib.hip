@@ -26,6 +26,7 @@ int mh_check_launch(const char* what) {
 int mh_conv_init();
 int mh_wgrad_init();
 int mh_corr_init();
+static int mh_lanes_init();
 
 extern "C" const char* mh_last_error(void) { return g_err; }
 // one-time, capture-unsafe set-up (dynamic-LDS opt-in of every kernel instantiation)
@@ -33,7 +34,7 @@ extern "C" int mh_init(void) {
     if (int e = mh_conv_init()) return e;
     if (int e = mh_wgrad_init()) return e;
     if (int e = mh_corr_init()) return e;
-    return 0;
+    return mh_lanes_init();          // side streams / events of the plan executor (not creatable inside a capture)
 }
 extern "C" int mh_abi_version(void) { return MH_ABI_VERSION; }
 extern "C" int mh_device_count(void) {
@@ -128,20 +129,6 @@ static int run_op(const mh_op& o, void* s) {
     }
 }
 
-extern "C" int mh_plan_run(const mh_op* ops, int32_t nops, void* stream) {
-    MH_REQUIRE(ops || nops == 0, MH_ERR_ARG, "mh_plan_run: null plan");
-    for (int32_t k = 0; k < nops; ++k) {
-        const int e = run_op(ops[k], stream);
-        if (e != 0) {
-            char tmp[400];
-            strncpy(tmp, g_err, sizeof(tmp) - 1); tmp[sizeof(tmp) - 1] = 0;
-            mh_set_error("plan op %d (kind %d): %s", k, ops[k].kind, tmp);
-            return e;
-        }
-    }
-    return 0;
-}
-
 #define MH_HIP(call)                                                        \
     do {                                                                    \
         hipError_t e_ = (call);                                             \
@@ -150,6 +137,83 @@ extern "C" int mh_plan_run(const mh_op* ops, int32_t nops, void* stream) {
             return (int)e_;                                                 \
         }                                                                   \
     } while (0)
+
+// Side lanes: library-owned non-blocking streams (per device) + a small round-robin pool of timing-less events.
+// An op on lane L>0 is forked from the caller's stream right before it (event record on lane 0 -> lane L waits),
+// so it is ordered after everything lane 0 has been given so far and runs concurrently with what follows; an op
+// flagged MH_OP_JOIN makes lane 0 wait for every side lane first.  Under hipStreamBeginCapture on the caller's
+// stream the same calls become fork/join edges of the captured graph (parallel branches).
+namespace {
+struct Lanes {
+    hipStream_t aux[MH_MAX_LANES] = {};
+    hipEvent_t ev[32] = {};
+    int next = 0;
+    bool ready = false;
+};
+Lanes g_lanes[16];
+
+int lanes_get(Lanes** out) {
+    int dev = 0;
+    MH_HIP(hipGetDevice(&dev));
+    MH_REQUIRE(dev >= 0 && dev < 16, MH_ERR_UNSUPPORTED, "device index %d out of range", dev);
+    Lanes& L = g_lanes[dev];
+    if (!L.ready) {
+        for (int k = 1; k < MH_MAX_LANES; ++k) MH_HIP(hipStreamCreateWithFlags(&L.aux[k], hipStreamNonBlocking));
+        for (auto& e : L.ev) MH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        L.ready = true;
+    }
+    *out = &L;
+    return 0;
+}
+}  // namespace
+static int mh_lanes_init() { Lanes* L = nullptr; return lanes_get(&L); }
+namespace {
+int lane_edge(Lanes& L, hipStream_t from, hipStream_t to) {
+    hipEvent_t e = L.ev[L.next];
+    L.next = (L.next + 1) & 31;
+    MH_HIP(hipEventRecord(e, from));
+    MH_HIP(hipStreamWaitEvent(to, e, 0));
+    return 0;
+}
+}  // namespace
+
+extern "C" int mh_plan_run(const mh_op* ops, int32_t nops, void* stream) {
+    MH_REQUIRE(ops || nops == 0, MH_ERR_ARG, "mh_plan_run: null plan");
+    Lanes* L = nullptr;
+    bool dirty[MH_MAX_LANES] = {};
+    bool stale[MH_MAX_LANES];          // lane 0 has launched work since this lane's last fork edge
+    for (bool& b : stale) b = true;
+    hipStream_t main_s = (hipStream_t)stream;
+    auto join = [&]() -> int {
+        for (int l = 1; l < MH_MAX_LANES; ++l)
+            if (dirty[l]) { if (int e = lane_edge(*L, L->aux[l], main_s)) return e; dirty[l] = false; }
+        return 0;
+    };
+    for (int32_t k = 0; k < nops; ++k) {
+        const int sched = ops[k].i[26];
+        const int lane = sched & 0xff;
+        int e = 0;
+        if (lane >= MH_MAX_LANES) { mh_set_error("lane %d out of range", lane); e = MH_ERR_ARG; }
+        if (!e && (sched & MH_OP_JOIN)) e = join();
+        if (!e && lane > 0) {
+            if (!L) e = lanes_get(&L);
+            if (!e && stale[lane]) { e = lane_edge(*L, main_s, L->aux[lane]); stale[lane] = false; }
+            if (!e) { dirty[lane] = true; e = run_op(ops[k], (void*)L->aux[lane]); }
+        } else if (!e) {
+            e = run_op(ops[k], stream);
+            for (bool& b : stale) b = true;
+        }
+        if (e != 0) {
+            char tmp[400];
+            strncpy(tmp, g_err, sizeof(tmp) - 1); tmp[sizeof(tmp) - 1] = 0;
+            mh_set_error("plan op %d (kind %d): %s", k, ops[k].kind, tmp);
+            join();         // never leave a capture with an unjoined side stream
+            return e;
+        }
+    }
+    return join();
+}
+
 
 extern "C" int mh_graph_begin(void* stream) {
     MH_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));

@@ -32,6 +32,10 @@ class Op(C.Structure):
  OP_WGRAD_PARTIAL, OP_WGRAD_REDUCE) = range(1, 19)
 
 
+OP_JOIN = 0x100
+MAX_LANES = 3
+
+
 class WgradSeg(C.Structure):
     _fields_ = [("ws", C.c_void_p), ("dst", C.c_void_p), ("size", C.c_int32), ("splits", C.c_int32),
                 ("blk0", C.c_int32), ("accumulate", C.c_int32)]

@@ -140,6 +140,9 @@ class MadNetEngine(object):
         self._zeros_needed = []
         # filter gradients: atomic-free split reduction (ops.conv2d_wgrad_partial) unless switched off
         self.partial_wgrad = True
+        # ... recorded on a side lane: the filter gradients are off the critical path (only the optimizer needs
+        # them), so they overlap with the input-gradient chain as a parallel branch of the hipGraph
+        self.wgrad_lanes = 2
         self.wsa = ops.WgradWorkspace(device)
 
     # ---------------------------------------------------------------------------------------
@@ -310,12 +313,33 @@ class MadNetEngine(object):
         written = set()                     # gradient buffers that already hold a contribution
         segs = []                           # partial filter-gradient segments of this backward pass
 
+        pending = []                        # deferred filter-gradient launches (flushed as one side-lane batch)
+
         def wgrad(xv, dzv, base, stride=1, dil=1):
             dw, db = P.tensor(base + "/weights", "g"), P.tensor(base + "/biases", "g")
-            if self.partial_wgrad:
-                ops.conv2d_wgrad_partial(lib, self.lib, self.wsa, segs, xv, dzv, dw, db, stride=stride, dil=dil)
-            else:
+            if not self.partial_wgrad:
                 ops.conv2d_wgrad(lib, xv, dzv, dw, db, stride=stride, dil=dil)
+            elif self.wgrad_lanes > 0 and hasattr(lib, "lane"):
+                pending.append((xv, dzv, dw, db, stride, dil))
+            else:
+                ops.conv2d_wgrad_partial(lib, self.lib, self.wsa, segs, xv, dzv, dw, db, stride=stride, dil=dil)
+
+        nflush = [0]
+
+        def flush():
+            """Issue the deferred filter gradients as ONE batch on a side lane (one fork edge): they read only
+            buffers that nothing later in the step overwrites, so they may run concurrently with everything that
+            follows on lane 0 until the reduction joins them."""
+            if not pending:
+                return
+            lib.lane = 1 + nflush[0] % self.wgrad_lanes
+            nflush[0] += 1
+            try:
+                for xv, dzv, dw, db, stride, dil in pending:
+                    ops.conv2d_wgrad_partial(lib, self.lib, self.wsa, segs, xv, dzv, dw, db, stride=stride, dil=dil)
+            finally:
+                lib.lane = 0
+                del pending[:]
 
         def acc_flag(key):
             a = key in written
@@ -357,6 +381,7 @@ class MadNetEngine(object):
                     dz = dx
                     if not need_dx:
                         break
+            flush()
             if up_V[2]:
                 ops.copy_channels(lib, self._fv(self.dfinal), self._fv(self.dV[2]), accumulate=acc_flag(("V", 2)))
                 dci = ops.View(self.dctx_in, B, h2, w2, c2 + 1, self.ctx_ld)
@@ -385,6 +410,7 @@ class MadNetEngine(object):
                 dz = dx
                 if not need_dx:
                     break
+            flush()
             if not need_dsi:
                 break
             # correlation (+ fused concat) gradient
@@ -444,6 +470,10 @@ class MadNetEngine(object):
                     ops.conv2d_dgrad(lib, self._fv(self.dF[i]), self.W_(pyr_name(i)), self._fv(self.dF[i - 1]),
                                      stride=PYR[i - 1][2], accumulate=accumulate, mask_ref=self._fv(self.F[i - 1]),
                                      mask_alpha=ALPHA)
+                if i % 4 == 1:
+                    flush()
+        flush()
+        r.join_next = True
         ops.wgrad_reduce(lib, segs, self.dev, r.keep)
 
     def record_update(self, r, train_vars, lr, momentum=0.9, grad_scale=1.0):

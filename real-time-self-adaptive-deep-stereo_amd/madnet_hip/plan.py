@@ -23,6 +23,8 @@ class Recorder(object):
     def __init__(self):
         self.ops = []
         self.keep = []          # python objects (tensors) that must outlive the plan
+        self.lane = 0           # scheduling lane of the ops recorded next (mh_op.i[26], include/madnet_hip.h)
+        self.join_next = False  # next op: lane 0 first waits for the side lanes
 
     # -- helpers ---------------------------------------------------------------------------
     def _op(self, kind, ints=(), floats=(), ptrs=(), n=0):
@@ -35,6 +37,8 @@ class Recorder(object):
         for k, v in enumerate(ptrs):
             o.p[k] = _ptr(v)
         o.n = int(n)
+        o.i[26] = self.lane | (_ffi.OP_JOIN if self.join_next else 0)
+        self.join_next = False
         self.ops.append(o)
 
     @staticmethod

@@ -11,6 +11,7 @@ ap.add_argument("--precision", default="bf16")
 ap.add_argument("--plain-wgrad", action="store_true", help="timing only: plain stores instead of atomics (wrong results)")
 ap.add_argument("--wgs", type=int, default=0)
 ap.add_argument("--mode", default="FULL")
+ap.add_argument("--lanes", type=int, default=-1)
 ap.add_argument("--steps", type=int, default=40)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -19,6 +20,8 @@ wn = S.calibrated_weights(dict(E.madnet_manifest()), 1)
 l, r, gt = S.make_pair(375, 1242)
 eng = E.MadNetEngine(lib, 375, 1242, B=1, device=dev, weights=wn, precision=a.precision)
 eng.set_inputs(l, r, gt[..., 0])
+if a.lanes >= 0:
+    eng.wgrad_lanes = a.lanes
 plan = eng.build_plan(a.mode, lr=1e-4)
 t = a.wgs if a.wgs else (1 if a.plain_wgrad else 0)
 lib.tune_wgrad_wgs(-t if a.plain_wgrad else t)
@@ -32,4 +35,4 @@ with torch.cuda.stream(st):
     for _ in range(a.steps): plan.launch(lib, sh)
     st.synchronize()
     dt = time.perf_counter() - t0
-print("precision %s mode %s plain_wgrad %s wgs %d: %.3f ms/step" % (a.precision, a.mode, a.plain_wgrad, a.wgs, 1e3 * dt / a.steps))
+print("precision %s mode %s plain_wgrad %s wgs %d lanes %d: %.3f ms/step" % (a.precision, a.mode, a.plain_wgrad, a.wgs, a.lanes, 1e3 * dt / a.steps))
