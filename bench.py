@@ -71,8 +71,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", default="FULL", choices=["FULL", "NONE"])
     ap.add_argument("--model", default="madnet", choices=["madnet", "dispnet"])
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
-                    help="fp32 = exact fp32 MFMA (parity path); bf16 = bf16 MFMA inputs, fp32 accumulate/storage")
+    ap.add_argument("--precision", default="bf16", choices=["fp32", "bf16"],
+                    help="bf16 (default, BASELINE.json's config) = bf16 MFMA inputs, fp32 accumulate/storage; "
+                         "fp32 = exact fp32 MFMA (the parity path, also timed and reported as `parity_path`)")
+    ap.add_argument("--no-parity-path", action="store_true", help="skip the fp32 side measurement of a bf16 run")
     ap.add_argument("--height", type=int, default=375)
     ap.add_argument("--width", type=int, default=1242)
     ap.add_argument("--no-graph", action="store_true")
@@ -134,6 +136,22 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    def timed_replay(e, steps, warm=3):
+        """ms/step of a second engine's FULL plan (hipGraph replay) -- side measurement, rank 0 / N=1 only."""
+        p2 = e.build_plan(args.mode, lr=1e-4)
+        with torch.cuda.stream(stream):
+            p2.run(lib, sh); stream.synchronize()
+            if not args.no_graph:
+                p2.capture(lib, sh)
+            for _ in range(warm):
+                p2.launch(lib, sh)
+            stream.synchronize()
+            t = time.perf_counter()
+            for _ in range(steps):
+                p2.launch(lib, sh)
+            stream.synchronize()
+            return 1e3 * (time.perf_counter() - t) / steps
+
     loss = float(eng.res_loss[0].item())
     epe_gt = float(eng.res_met[0].item())
     nonzero = float((eng.pred != 0).float().mean().item())
@@ -157,8 +175,18 @@ def main():
                 out["roofline"], extra = BT.roofline(lib, eng, stream)
             out.update(extra)
             _log("roofline done")
+        if args.precision != "fp32" and not args.no_parity_path:
+            e32 = E.MadNetEngine(lib, H, W, B=1, device=dev, weights=wn, precision="fp32")
+            e32.set_inputs(l, r, gt[..., 0])
+            ms32 = timed_replay(e32, min(args.steps, 20))
+            out["parity_path"] = {"dtype": "f32", "ms_per_step": ms32, "value": 1e3 / ms32, "unit": "pairs/s",
+                                  "note": "same step with exact fp32 MFMA (the arithmetic the parity tests pin to the oracle)"}
+            del e32
+            _log("parity path done")
         if not args.no_cpu_baseline:
             out["epe_vs_oracle"] = epe_vs_oracle(lib, H, W, wn, l, r, gt, args.precision)
+            if "parity_path" in out:
+                out["parity_path"]["epe_vs_oracle"] = epe_vs_oracle(lib, H, W, wn, l, r, gt, "fp32")
             _log("epe_vs_oracle done")
             out["cpu_baseline"] = cpu_baseline(H, W, wn, l, r, gt, args.mode)
             _log("cpu baseline done")

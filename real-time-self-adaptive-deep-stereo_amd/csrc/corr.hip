@@ -100,53 +100,56 @@ __global__ __launch_bounds__(256) void corr_fwd_small(CorrArgs p) {
 // out-of-range offset => the hardware returns the zero padding of correlation_tf), so D+1 16-byte loads
 // per lane are in flight at once; neighbouring pixels re-read the same right rows from L1 (5x request
 // amplification at the TA, still far below its bandwidth), HBM sees each byte once.
-template <int LPP>
+template <int LPP, int DT>
 __global__ __launch_bounds__(256) void corr_fwd_direct(CorrArgs p) {
+    // One group of 256/LPP pixels per workgroup, no persistent loop (the launch covers every pixel: a
+    // grid of tens of thousands of small workgroups keeps more bytes in flight than a capped grid
+    // looping over 64-bit indices -- measured 74 % vs 45 % of the HBM peak, profiles/r01_corr_experiment.txt),
+    // 32-bit index math, DT = compile-time shift count (5 for radius_d 2) so that no dead load is issued.
     constexpr int PPB = 256 / LPP;
     const int tid = threadIdx.x;
     const int sub = tid % LPP;
     const int C4 = p.C >> 2;
     const float inv_c = 1.0f / (float)p.C;
-    const int64_t npix = (int64_t)p.B * p.H * p.W;
-    const int64_t nit = (npix + PPB - 1) / PPB;
+    const int npix = p.B * p.H * p.W;
     const __amdgpu_buffer_rsrc_t rsL = mh_make_rsrc(p.L, p.l_bytes);
     const __amdgpu_buffer_rsrc_t rsR = mh_make_rsrc(p.R, p.r_bytes);
-    for (int64_t it = blockIdx.x; it < nit; it += gridDim.x) {
-        const int64_t pix = it * PPB + tid / LPP;
-        const bool live = pix < npix;
-        const int pp = live ? (int)pix : 0;
-        const int x = pp % p.W;
-        float accd[MAXD_SMALL];
+    const int pix = blockIdx.x * PPB + tid / LPP;
+    const bool live = pix < npix;
+    const int pp = live ? pix : 0;
+    const int x = pp % p.W;
+    float accd[DT];
 #pragma unroll
-        for (int j = 0; j < MAXD_SMALL; ++j) accd[j] = 0.f;
-        float* Op = p.out + (int64_t)pp * p.out_ld;
-        for (int c4 = sub; c4 < C4; c4 += LPP) {
-            const float4 l = mh_buf_load4(rsL, live ? (pp * p.l_ld + c4 * 4) * 4 : MH_OOB);
-            float4 r[MAXD_SMALL];
+    for (int j = 0; j < DT; ++j) accd[j] = 0.f;
+    float* Op = p.out + (int64_t)pp * p.out_ld;
+    for (int c4 = sub; c4 < C4; c4 += LPP) {
+        const float4 l = mh_buf_load4(rsL, live ? (pp * p.l_ld + c4 * 4) * 4 : MH_OOB);
+        float4 r[DT];
 #pragma unroll
-            for (int j = 0; j < MAXD_SMALL; ++j) {
-                const int xs = x + j * p.stride - p.md;
-                const bool ok = live && (j < p.D) && (unsigned)xs < (unsigned)p.W;
-                r[j] = mh_buf_load4(rsR, ok ? ((pp + xs - x) * p.r_ld + c4 * 4) * 4 : MH_OOB);
-            }
-            if (live && p.copy_left) *reinterpret_cast<float4*>(Op + c4 * 4) = l;
-#pragma unroll
-            for (int j = 0; j < MAXD_SMALL; ++j) accd[j] += l.x * r[j].x + l.y * r[j].y + l.z * r[j].z + l.w * r[j].w;
+        for (int j = 0; j < DT; ++j) {
+            const int dx = j * p.stride - p.md;
+            const bool ok = live && (j < p.D) && (unsigned)(x + dx) < (unsigned)p.W;
+            r[j] = mh_buf_load4(rsR, ok ? ((pp + dx) * p.r_ld + c4 * 4) * 4 : MH_OOB);
         }
+        if (live && p.copy_left) *reinterpret_cast<float4*>(Op + c4 * 4) = l;
 #pragma unroll
-        for (int j = 0; j < MAXD_SMALL; ++j) {
+        for (int j = 0; j < DT; ++j) accd[j] += l.x * r[j].x + l.y * r[j].y + l.z * r[j].z + l.w * r[j].w;
+    }
 #pragma unroll
-            for (int o = LPP >> 1; o > 0; o >>= 1) accd[j] += __shfl_xor(accd[j], o);
-        }
-        if (live && sub == 0) {
-            float* dst = Op + p.coff;
+    for (int j = 0; j < DT; ++j) {
 #pragma unroll
-            for (int j = 0; j < MAXD_SMALL; ++j)
-                if (j < p.D) dst[j] = accd[j] * inv_c;
-            int tail = p.coff + p.D;
-            if (p.u) { Op[tail] = p.u[pp]; ++tail; }
-            if (p.zero_tail)
-                for (; tail < p.out_ld; ++tail) Op[tail] = 0.f;
+        for (int o = LPP >> 1; o > 0; o >>= 1) accd[j] += __shfl_xor(accd[j], o);
+    }
+    // outputs [coff, coff+D) = costs, then u, then the zero tail: entry e is written by lane e % LPP, so the
+    // D costs of a pixel leave as one store instruction of adjacent dwords instead of D one-lane stores
+    if (live) {
+        const int nout = p.zero_tail ? p.out_ld - p.coff : p.D + (p.u ? 1 : 0);
+        for (int e = sub; e < nout; e += LPP) {
+            float v = 0.f;
+#pragma unroll
+            for (int j = 0; j < DT; ++j) v = (e == j) ? accd[j] * inv_c : v;
+            if (p.u && e == p.D) v = p.u[pp];
+            Op[p.coff + e] = v;
         }
     }
 }
@@ -301,10 +304,13 @@ extern "C" int mh_corr_fwd(const float* L, int32_t l_ld, const float* R, int32_t
     if (D <= MAXD_SMALL && g_corr_direct && lb < (1ll << 31) - 64 && rb < (1ll << 31) - 64) {
         a.l_bytes = (unsigned)lb; a.r_bytes = (unsigned)rb;
         const int64_t npix = (int64_t)B * H * W;
-        auto grid = [&](int lpp) { int64_t g = (npix * lpp + 255) / 256; return dim3((unsigned)(g > 256 * 32 ? 256 * 32 : g)); };
-        if (C4 <= 4) hipLaunchKernelGGL((corr_fwd_direct<4>), grid(4), dim3(256), 0, s, a);
-        else if (C4 <= 8) hipLaunchKernelGGL((corr_fwd_direct<8>), grid(8), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((corr_fwd_direct<16>), grid(16), dim3(256), 0, s, a);
+        MH_REQUIRE(npix < (1ll << 31) - 256, MH_ERR_UNSUPPORTED, "mh_corr_fwd: too many pixels");
+        auto grid = [&](int lpp) { return dim3((unsigned)((npix * lpp + 255) / 256)); };
+#define MH_CORR(LPPv)                                                                                           \
+        { if (D <= 5) hipLaunchKernelGGL((corr_fwd_direct<LPPv, 5>), grid(LPPv), dim3(256), 0, s, a);            \
+          else hipLaunchKernelGGL((corr_fwd_direct<LPPv, MAXD_SMALL>), grid(LPPv), dim3(256), 0, s, a); }
+        if (C4 <= 4) MH_CORR(4) else if (C4 <= 8) MH_CORR(8) else MH_CORR(16)
+#undef MH_CORR
         return mh_check_launch("corr_fwd_direct");
     }
     if (D <= MAXD_SMALL) {

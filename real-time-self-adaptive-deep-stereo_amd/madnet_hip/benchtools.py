@@ -7,6 +7,7 @@ import torch
 from . import ops
 
 PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_BF16_MFMA_TFLOPS = 2500.0          # dense (the 5 PF headline includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -49,15 +50,23 @@ def roofline(lib, eng, stream, reps=20):
     x = ops.view(eng.Cx[0]); o = ops.view(eng.Cx[1])
     w = eng.W_(E.ctx_name(2)); b = eng.b_(E.ctx_name(2))
 
+    prec = ops.PRECISION_CODES[eng.precision] if hasattr(ops, "PRECISION_CODES") else (1 if eng.precision == "bf16" else 0)
+    peak = PEAK_BF16_MFMA_TFLOPS if prec == 1 else PEAK_F32_MFMA_TFLOPS
+
     def conv():
-        ops.conv2d_fwd(lib, x, w, b, o, dil=2, alpha=E.ALPHA, stream=sh)
+        ops.PRECISION = prec
+        try:
+            ops.conv2d_fwd(lib, x, w, b, o, dil=2, alpha=E.ALPHA, stream=sh)
+        finally:
+            ops.PRECISION = 0
 
     ms = _time_ms(lib, stream, conv, reps)
     flops = 2.0 * x.B * x.H * x.W * 9 * 128 * 128
     ach = flops / (ms * 1e-3) / 1e12
     rl = {"kernel": "conv_igemm_kernel (3x3 128->128 @ %dx%d, dil 2; tile chosen by conv_dispatch)" % (x.H, x.W),
-          "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-          "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": _pmc_traffic("conv_3x3_128_128_96x320"),
+          "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+          "frac": ach / peak, "arithmetic": "bf16 MFMA, f32 accumulate" if prec == 1 else "f32 MFMA",
+          "traffic": _pmc_traffic("conv_3x3_128_128_96x320"),
           "launch_ms": ms, "algorithmic_flops_per_launch": flops}
     # correlation protocol: level-2 shape with B=64 streams (working set > 256 MiB
     # Infinity Cache) for the HBM claim, plus the in-situ B=1 time (cache resident).
