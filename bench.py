@@ -64,12 +64,68 @@ def epe_vs_oracle(lib, H, W, wn, l, r, gt, precision="fp32"):
     return float((eng.pred.cpu() - d).abs().mean().item())
 
 
+def bench_mad(args, lib, dev, rank, world, dist):
+    """BASELINE config 3: MAD modular adaptation through the reference's own API surface (Nets.get_stereo_net +
+    Adapter.step): per step the host samples a block (Sampler/sampler_factory.py), replays that block's captured
+    graph (forward + full-res loss/metrics + block backward + block update), reads loss/EPE back and updates the
+    sampling logits -- i.e. a step includes the host round trip, exactly like the reference loop body."""
+    import torch
+    import Nets
+    from madnet_hip import engine as E, synthetic as S
+    from madnet_hip.adapter import Adapter
+    H, W = args.height, args.width
+    wn = S.calibrated_weights(dict(E.madnet_manifest()), 1)
+    l, r, gt = S.make_pair(H, W, stream_id=rank)
+    tl, tr, tg = (torch.from_numpy(a).to(dev) for a in (l, r, gt[..., 0]))
+    net = Nets.get_stereo_net("MADNet", {"left_img": tl, "right_img": tr, "split_layers": [None], "sequence": True,
+                                         "train_portion": "BEGIN", "bulkhead": True, "weights": wn,
+                                         "precision": args.precision, "warping": True, "context_net": True,
+                                         "radius_d": 2, "stride": 1})
+    cfg = json.load(open(os.path.join(PKG, "block_config", args.block_config)))
+    ad = Adapter(net, mode="MAD", block_config=cfg, lr=1e-4, sample_mode="PROBABILITY", num_blocks=1,
+                 use_graph=not args.no_graph)
+    for i in range(len(cfg)):
+        ad._plan((i,))                       # compile + capture every block's plan outside the timed region
+    for _ in range(args.warmup):
+        ad.step(tl, tr, tg)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out_step = ad.step(tl, tr, tg)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "adapted stereo pairs/sec (whole node), MADNet MAD modular online adaptation 1242x375",
+            "value": world * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
+            "config": {"workload": "MADNet MAD adaptation step via Nets.get_stereo_net + Adapter.step (host block sampling, "
+                                   "forward + loss + EPE + one block's backward + update, loss read-back), %dx%d, "
+                                   "1 pair/GPU/step, %s" % (W, H, args.block_config),
+                       "launch": "eager plan" if args.no_graph else "hipGraph replay per sampled block",
+                       "fetch_counter": ad.fetch_counter, "final_loss": out_step["loss"], "epe_vs_synthetic_gt": out_step["epe"]}}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mode", default="FULL", choices=["FULL", "NONE"])
+    ap.add_argument("--mode", default="FULL", choices=["FULL", "NONE", "MAD"])
+    ap.add_argument("--block-config", default="MadNet_piramid_only.json", help="MAD mode: file under block_config/")
     ap.add_argument("--model", default="madnet", choices=["madnet", "dispnet"])
     ap.add_argument("--precision", default="bf16", choices=["fp32", "bf16"],
                     help="bf16 (default, BASELINE.json's config) = bf16 MFMA inputs, fp32 accumulate/storage; "
@@ -97,6 +153,8 @@ def main():
     from madnet_hip import _ffi, engine as E, dispnet_engine as DE, synthetic as S, benchtools as BT
     lib = _ffi.lib()
     H, W = args.height, args.width
+    if args.mode == "MAD":
+        return bench_mad(args, lib, dev, rank, world, dist)
     dispnet = args.model == "dispnet"
     shapes = dict(DE.dispnet_manifest() if dispnet else E.madnet_manifest())
     wn = S.calibrated_weights(shapes, 1)

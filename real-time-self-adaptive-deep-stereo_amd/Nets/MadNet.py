@@ -67,7 +67,8 @@ class MadNet(Stereo_net.StereoNet):
             shapes = dict(E.madnet_manifest(args['radius_d'], args['stride']))
             weights = synthetic.xavier_weights(shapes, seed=0)
         self.engine = eng = E.MadNetEngine(lib, H, W, B=B, device=dev, radius_d=args['radius_d'],
-                                           stride=args['stride'], warping=args['warping'], weights=weights)
+                                           stride=args['stride'], warping=args['warping'], weights=weights,
+                                           precision=args.get('precision', 'fp32'))   # extra kwarg: 'bf16' = MFMA throughput mode
         self._lib = lib
         P = eng.params
 

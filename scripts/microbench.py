@@ -14,6 +14,8 @@ from madnet_hip.benchtools import _time_ms
 lib = _ffi.lib()
 stream = torch.cuda.Stream()
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
+if len(sys.argv) > 2 and sys.argv[2] == "bf16":
+    ops.PRECISION = 1
 dev = "cuda"
 
 # (name, B, H, W, Cin, Cout, stride, dil)
@@ -23,6 +25,8 @@ LAYERS = [("L2 128->128 d2", 1, 96, 320, 128, 128, 1, 2), ("L2 128->96", 1, 96, 
           ("P 16->16 @1/2 x2", 2, 192, 640, 16, 16, 1, 1), ("P 16->32 s2 x2", 2, 192, 640, 16, 32, 2, 1), ("P 32->32 @1/4 x2", 2, 96, 320, 32, 32, 1, 1),
           ("P 64->64 @1/8 x2", 2, 48, 160, 64, 64, 1, 1)]
 TILES = [(0, 0, 0), (128, 64, 0), (64, 64, 0), (32, 64, 64), (32, 64, 128), (64, 32, 64), (64, 32, 128), (32, 32, 64), (32, 32, 128)]
+if ops.PRECISION == 1:      # bf16 instances all have KT = 64
+    TILES = [(0, 0, 0), (128, 128, 64), (128, 64, 64), (64, 128, 64), (64, 64, 64), (128, 32, 64), (32, 128, 64), (32, 64, 64), (64, 32, 64), (32, 32, 64)]
 
 
 def run_conv():
