@@ -63,7 +63,10 @@ template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool VEC, bool UNI
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     constexpr int BM = WM * MT * 16;
     constexpr int BN = WN * NT * 16;
-    constexpr int LS = KT + (BF16 ? 8 : 4);            // LDS row stride (elements: floats / bf16)
+    // LDS row stride (elements: floats / bf16).  bf16: 80 halfs = 40 dwords: with the b128 lane groups of gfx950 a 36-dword
+    // stride costs a 2-way conflict on every operand read, 40 is conflict free (brute-forced over the lane groups of
+    // MI355X_MICROARCH.md; SQ_LDS_BANK_CONFLICT confirmed the model: profiles/r01_pmc_roofline.json)
+    constexpr int LS = KT + (BF16 ? 16 : 4);
     constexpr int GPT = KT / 4;                        // 4-channel groups per K-tile
     constexpr int RPP = 256 / GPT;                     // rows loaded per pass
     constexpr int AROWS = (BM + RPP - 1) / RPP;
@@ -306,7 +309,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
                 int kk, n4;
                 if (b_item(4 * uj, kk, n4)) {
                     const float4 v0 = rb_v[4 * uj], v1 = rb_v[4 * uj + 1], v2 = rb_v[4 * uj + 2], v3 = rb_v[4 * uj + 3];
-                    unsigned short* d = Bb + (n4 * 4) * LS + kk;
+                    // 16-byte chunks XOR-swizzled by the row block: the 16 lanes of a ds_write_b64 group hold 16 different
+                    // row blocks n4 at the same kk (rows 4*LS apart = 2 banks -> 8-way conflict unswizzled, 2-way with it)
+                    unsigned short* d = Bb + (n4 * 4) * LS + ((((kk >> 3) ^ n4) & (KT / 8 - 1)) << 3) + (kk & 7);
                     *reinterpret_cast<uint2*>(d) = make_uint2(mh_pack_bf16(v0.x, v1.x), mh_pack_bf16(v2.x, v3.x));
                     *reinterpret_cast<uint2*>(d + LS) = make_uint2(mh_pack_bf16(v0.y, v1.y), mh_pack_bf16(v2.y, v3.y));
                     *reinterpret_cast<uint2*>(d + 2 * LS) = make_uint2(mh_pack_bf16(v0.z, v1.z), mh_pack_bf16(v2.z, v3.z));
@@ -346,14 +351,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     auto compute_tile = [&](int buf) {
         if (BF16) {
             const unsigned short* Ab = Ah + buf * (BM * LS) + (wm * MT * 16 + li) * LS + lq * 8;
-            const unsigned short* Bb = Bh + buf * (BN * LS) + (wn * NT * 16 + li) * LS + lq * 8;
+            const unsigned short* Bb = Bh + buf * (BN * LS) + (wn * NT * 16 + li) * LS + (BT ? 0 : lq * 8);
 #pragma unroll
             for (int s = 0; s < KT / 32; ++s) {
                 u32x4 a[MT], b[NT];
 #pragma unroll
                 for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const u32x4*>(Ab + i * 16 * LS + s * 32);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const u32x4*>(Bb + j * 16 * LS + s * 32);
+                for (int j = 0; j < NT; ++j) {
+                    if (BT) b[j] = *reinterpret_cast<const u32x4*>(Bb + j * 16 * LS + ((((s * 4 + lq) ^ ((wn * NT * 16 + j * 16 + li) >> 2)) & (KT / 8 - 1)) << 3));
+                    else b[j] = *reinterpret_cast<const u32x4*>(Bb + j * 16 * LS + s * 32);
+                }
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -497,7 +505,7 @@ static bool g_no_uni = false;    // tuning hook: disable the uniform-tap fast pa
 template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool VEC, bool UNI, bool BF16>
 int launch_one(ConvArgs& a, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
-    constexpr size_t lds = BF16 ? (size_t)(2 * (BM + BN) * (KT + 8)) * 2 + 512 : (size_t)(2 * (BM + BN) * (KT + 4) + 128) * sizeof(float);
+    constexpr size_t lds = BF16 ? (size_t)(2 * (BM + BN) * (KT + 16)) * 2 + 512 : (size_t)(2 * (BM + BN) * (KT + 4) + 128) * sizeof(float);
     static bool attr_done = false;       // LDS > 64 KiB needs the opt-in once per instantiation
     if (!attr_done) {
         if (lds > 64 * 1024) {

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(WgradArgs p) {
     constexpr int NTH = 64 * WM * WN;
     constexpr int PT = 64;
     constexpr int BK = WM * MT * 16, BN = WN * NT * 16;
-    constexpr int LS = PT + 8;                                   // halfs
+    constexpr int LS = PT + 16;          // halfs: 40-dword rows = conflict-free ds_read_b128 operand reads (see conv.hip)
     constexpr int AUN = (BK / 4) * (PT / 4), BUN = (BN / 4) * (PT / 4);
     constexpr int AU = (AUN + NTH - 1) / NTH, BU = (BUN + NTH - 1) / NTH;
 
@@ -338,11 +338,11 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(WgradArgs p) {
         ++tile_ld;
     };
 
-    // LDS position of (row, pixel-group pb): 8-pixel octets are XOR-swizzled by the row's 16-row block so that
-    // the 8-byte unit stores of a half wave fall into distinct banks; an MFMA operand read (16 consecutive
-    // rows of one block) sees one constant XOR and stays conflict free.
+    // LDS position of (row, pixel-group pb): 8-pixel octets are XOR-swizzled by the row's 4-row block (= the unit's
+    // channel group): the 16 lanes of a ds_write_b64 group hold 16 different channel groups at the same pixels
+    // (rows 4*LS apart -> one bank unswizzled, 2-way with the XOR); operand reads stay conflict free (40-dword rows).
     auto store_unit = [&](unsigned short* base, int row0, int pb, const float4 (&v)[4], bool zero_pad) {
-        unsigned short* d = base + row0 * LS + ((((pb >> 1) ^ (row0 >> 4)) & 7) * 2 + (pb & 1)) * 4;
+        unsigned short* d = base + row0 * LS + ((((pb >> 1) ^ (row0 >> 2)) & 7) * 2 + (pb & 1)) * 4;
         *reinterpret_cast<uint2*>(d) = make_uint2(mh_pack_bf16(v[0].x, v[1].x), mh_pack_bf16(v[2].x, v[3].x));
         *reinterpret_cast<uint2*>(d + LS) = make_uint2(mh_pack_bf16(v[0].y, v[1].y), mh_pack_bf16(v[2].y, v[3].y));
         *reinterpret_cast<uint2*>(d + 2 * LS) = make_uint2(mh_pack_bf16(v[0].z, v[1].z), mh_pack_bf16(v[2].z, v[3].z));
@@ -398,10 +398,10 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(WgradArgs p) {
             u32x4 a[MT], b[NT];
 #pragma unroll
             for (int i = 0; i < MT; ++i)
-                a[i] = *reinterpret_cast<const u32x4*>(Ab + i * 16 * LS + (((s * 4 + lq) ^ (wm * MT + i)) & 7) * 8);
+                a[i] = *reinterpret_cast<const u32x4*>(Ab + i * 16 * LS + (((s * 4 + lq) ^ (((wm * MT + i) * 16 + li) >> 2)) & 7) * 8);
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                b[j] = *reinterpret_cast<const u32x4*>(Bb + j * 16 * LS + (((s * 4 + lq) ^ (wn * NT + j)) & 7) * 8);
+                b[j] = *reinterpret_cast<const u32x4*>(Bb + j * 16 * LS + (((s * 4 + lq) ^ (((wn * NT + j) * 16 + li) >> 2)) & 7) * 8);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(WgradArgs p) {
 template <int WM, int WN, int MT, int NT>
 int launch_wgrad_bf16(WgradArgs& a, hipStream_t s) {
     constexpr int BK = WM * MT * 16, BN = WN * NT * 16, PT = 64;
-    constexpr size_t lds = (size_t)(2 * (BK + BN) * (PT + 8)) * 2 + 2 * PT * 4;
+    constexpr size_t lds = (size_t)(2 * (BK + BN) * (PT + 16)) * 2 + 2 * PT * 4;
     static bool attr_done = false;
     if (!attr_done) {
         if (lds > 64 * 1024) {

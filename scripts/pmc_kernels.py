@@ -16,7 +16,11 @@ b = torch.randn(128, device=dev); y = torch.empty(1, 96, 320, 128, device=dev)
 L = torch.randn(64, 96, 320, 32, device=dev); R = torch.randn(64, 96, 320, 32, device=dev)
 out = torch.empty(64, 96, 320, 5, device=dev)
 for _ in range(5):
+    ops.PRECISION = 0
     ops.conv2d_fwd(lib, ops.view(x), w, b, ops.view(y), dil=2, alpha=0.2, stream=0)
+    ops.PRECISION = 1           # bf16 MFMA variant of the same layer
+    ops.conv2d_fwd(lib, ops.view(x), w, b, ops.view(y), dil=2, alpha=0.2, stream=0)
+    ops.PRECISION = 0
     ops.corr_fwd(lib, ops.view(L), ops.view(R), ops.view(out), 2, stream=0)
 torch.cuda.synchronize()
 print("done")

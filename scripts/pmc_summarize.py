@@ -1,0 +1,45 @@
+"""Summarise the rocprofv3 --pmc passes of scripts/gpu_pmc.sh into profiles/r01_pmc_roofline.json.
+usage: python scripts/pmc_summarize.py gpurun_out/<tag>      (copies the raw CSVs to profiles/r01_pmc/ too)"""
+import csv, glob, json, os, shutil, sys
+
+src = sys.argv[1]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dst = os.path.join(ROOT, "profiles", "r01_pmc")
+os.makedirs(dst, exist_ok=True)
+
+
+def load(counter_dir):
+    f = glob.glob(os.path.join(src, counter_dir, "**", "*counter_collection.csv"), recursive=True)[0]
+    shutil.copy(f, os.path.join(dst, counter_dir + "_counter_collection.csv"))
+    return list(csv.DictReader(open(f)))
+
+
+def mean_of(rows, pred, counter):
+    v = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == counter and pred(r["Kernel_Name"])]
+    d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if r["Counter_Name"] == counter and pred(r["Kernel_Name"])]
+    v, d = v[1:] or v, d[1:] or d             # drop the first (cold) launch
+    return sum(v) / len(v), sum(d) / len(d) / 1e3
+
+
+KERNELS = {
+    "conv_3x3_128_128_96x320": (lambda n: "conv_igemm" in n and n.split(">(")[0].endswith("false"), 2 * 15728640 + 589824 + 512),
+    "conv_3x3_128_128_96x320_bf16": (lambda n: "conv_igemm" in n and n.split(">(")[0].endswith("true"), 2 * 15728640 + 589824 + 512),
+    "corr_fwd_B64_96x320x32_D5": (lambda n: "corr_fwd" in n, 64 * 96 * 320 * (2 * 32 + 5) * 4),
+}
+fetch, write, sq = load("FETCH_SIZE"), load("WRITE_SIZE"), load("SQ")
+out = {"source": "scripts/gpu_pmc.sh (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ_* in separate passes, --kernel-trace only), raw CSVs in "
+                 "profiles/r01_pmc/; FETCH_SIZE and WRITE_SIZE are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies the 128-B "
+                 "requests of wide coalesced reads at 64 B); mean over launches 2..5 of scripts/pmc_kernels.py"}
+for key, (pred, alg) in KERNELS.items():
+    f, us = mean_of(fetch, pred, "FETCH_SIZE")
+    w, _ = mean_of(write, pred, "WRITE_SIZE")
+    out[key] = {"fetch_kib_raw": round(f, 1), "write_kib": round(w, 1), "traffic_bytes": int(2 * f * 1024 + w * 1024),
+                "algorithmic_bytes": alg, "launch_us_under_pmc": round(us, 1)}
+for key, pred in (("conv_sq", KERNELS["conv_3x3_128_128_96x320"][0]), ("conv_bf16_sq", KERNELS["conv_3x3_128_128_96x320_bf16"][0]),
+                  ("corr_sq", KERNELS["corr_fwd_B64_96x320x32_D5"][0])):
+    d = {}
+    for c in sorted(set(r["Counter_Name"] for r in sq)):
+        d[c] = int(mean_of(sq, pred, c)[0])
+    out[key] = d
+json.dump(out, open(os.path.join(ROOT, "profiles", "r01_pmc_roofline.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
