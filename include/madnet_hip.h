@@ -175,6 +175,10 @@ int mh_tune_conv_tile(int bm, int bn);
 int mh_tune_wgrad_wgs(int target_workgroups);
 int mh_tune_corr(int direct);
 
+/* host utility: CRC-32C (Castagnoli) of a host buffer, chained through `crc` (0 to start) -- used by the TensorFlow
+ * checkpoint importer that replaces tf.train.NewCheckpointReader (Data_utils/weights_utils.py:29). */
+uint32_t mh_crc32c(const void* data, int64_t n, uint32_t crc);
+
 /* ---- native plan executor: the host (Python) compiles the network into an array of op
  *      records once; one FFI call replays it (optionally captured into a hipGraph). ------ */
 enum { MH_OP_CONV = 1, MH_OP_WGRAD, MH_OP_CORR_FWD, MH_OP_CORR_BWD, MH_OP_WARP_FWD, MH_OP_WARP_BWD,

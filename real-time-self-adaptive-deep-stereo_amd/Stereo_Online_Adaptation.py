@@ -2,9 +2,9 @@
 series.csv, params.sh, config.json, disparities/*.png) as the reference script
 (Stereo_Online_Adaptation.py:30-325); the per-frame loop body lives in madnet_hip.adapter.Adapter.step().
 
---weights accepts an .npz of {TF variable name: HWIO array} (see `python -m madnet_hip.weights_io`),
-or the literal `xavier[:seed]` / `calibrated[:seed]` for synthetic weights.  TF checkpoints cannot be
-read here (no TensorFlow); the importer is a 'next' row."""
+--weights accepts a TensorFlow V2 checkpoint prefix (`<prefix>.index` + `.data-*`, read without TensorFlow by
+Data_utils/tf_checkpoint.py -- what the reference restores with weights_utils, :150-153), an .npz of
+{TF variable name: HWIO array}, or the literal `xavier[:seed]` / `calibrated[:seed]` for synthetic weights."""
 import argparse
 import datetime
 import json
@@ -35,8 +35,25 @@ def load_weights(spec, model_name="MADNet", radius_d=2, stride=1):
         w = {k: z[k] for k in z.files}
         assert len(w) > 0                      # Stereo_Online_Adaptation.py:151
         return w
-    raise Exception('Unsupported --weights %r: expected an .npz of TF-named variables, xavier[:seed] or '
-                    'calibrated[:seed] (TF checkpoints need TensorFlow, not available)' % spec)
+    from Data_utils import tf_checkpoint
+    if os.path.isdir(spec):
+        spec = tf_checkpoint.latest_checkpoint(spec) or spec
+    if tf_checkpoint.is_checkpoint(spec):
+        # Stereo_Online_Adaptation.py:150-153: restore every checkpoint variable whose name matches a graph variable
+        reader = tf_checkpoint.CheckpointReader(spec)
+        have = reader.get_variable_to_shape_map()
+        w = {k: reader.get_tensor(k).astype(np.float32) for k in shapes if k in have}
+        assert len(w) > 0, "no variable of %s found in checkpoint %s" % (model_name, spec)
+        missing = [k for k in shapes if k not in have]
+        if missing:
+            print('WARNING: %d variables not in the checkpoint keep their synthetic initial value (first: %s)' % (len(missing), missing[0]))
+            w0 = synthetic.xavier_weights(shapes, 0)
+            for k in missing:
+                w[k] = w0[k]
+        print('Disparity Net Restored?: {}, number of restored variables: {}'.format(True, len(w) - len(missing)))
+        return w
+    raise Exception('Unsupported --weights %r: expected a TF checkpoint prefix, an .npz of TF-named variables, '
+                    'xavier[:seed] or calibrated[:seed]' % spec)
 
 
 def main(args):

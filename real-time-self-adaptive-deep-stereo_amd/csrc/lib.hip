@@ -37,6 +37,23 @@ extern "C" int mh_init(void) {
     return mh_lanes_init();          // side streams / events of the plan executor (not creatable inside a capture)
 }
 extern "C" int mh_abi_version(void) { return MH_ABI_VERSION; }
+// host utility for the TensorFlow-checkpoint importer (Data_utils/tf_checkpoint.py): CRC-32C (Castagnoli), bytewise table
+extern "C" uint32_t mh_crc32c(const void* data, int64_t n, uint32_t crc) {
+    static uint32_t table[256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1) ? 0x82F63B78u : 0u);
+            table[i] = c;
+        }
+        ready = true;
+    }
+    const unsigned char* p = (const unsigned char*)data;
+    uint32_t c = crc ^ 0xFFFFFFFFu;
+    for (int64_t i = 0; i < n; ++i) c = table[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
 extern "C" int mh_device_count(void) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);

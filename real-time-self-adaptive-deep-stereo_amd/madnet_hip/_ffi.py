@@ -49,6 +49,7 @@ _L = C.c_int64
 SIGNATURES = {
     "mh_last_error": (C.c_char_p, []),
     "mh_abi_version": (_I, []),
+    "mh_crc32c": (C.c_uint32, [C.c_char_p, _L, C.c_uint32]),
     "mh_device_count": (_I, []),
     "mh_init": (_I, []),
     "mh_tune_conv_tile": (_I, [_I, _I]),
@@ -85,7 +86,7 @@ SIGNATURES = {
     "mh_event_destroy": (_I, [_P]),
     "mh_stream_sync": (_I, [_P]),
 }
-_NO_STATUS = {"mh_last_error", "mh_abi_version", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats"}
+_NO_STATUS = {"mh_last_error", "mh_abi_version", "mh_crc32c", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats"}
 
 
 class MadnetHipError(RuntimeError):
