@@ -100,3 +100,87 @@ class dataset(object):
                 yield (center_crop_or_pad(_read_image(l), th, tw)[None],
                        center_crop_or_pad(_read_image(r), th, tw)[None],
                        center_crop_or_pad(_read_image(g, True), th, tw)[None])
+
+
+class device_prefetcher(object):
+    """Decode-ahead + host-to-device overlap for the online loop (replaces tf.data's prefetch,
+    Data_utils/data_reader.py:171-175): a reader thread decodes frames `depth` ahead into a ring of PINNED host
+    buffers, the copies are issued on a private copy stream and each yielded triple carries a HIP event the
+    consumer stream waits on -- frame t+1 is decoded and uploaded while frame t adapts.
+
+        for left, right, gt in device_prefetcher(dataset(...), 'cuda', consumer_stream=adapter.stream):
+            adapter.step(left, right, gt)
+    """
+
+    def __init__(self, data_set, device='cuda', depth=3, consumer_stream=None):
+        import queue
+        import threading
+        import torch
+        self._torch = torch
+        self._ds, self._depth = data_set, max(2, depth)
+        self._dev = torch.device(device)
+        self._cuda = self._dev.type == 'cuda'
+        self._q = queue.Queue(maxsize=self._depth)
+        self._free = queue.Queue()
+        self._ring = None
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._reader, daemon=True)
+        self._copy_stream = torch.cuda.Stream(device=self._dev) if self._cuda else None
+        self._consumer = consumer_stream         # stream the frames are consumed on (default: the current stream)
+
+    def _slot(self, arrays):
+        t = self._torch
+        if self._ring is None:                   # allocate the ring on first use (shapes known now)
+            self._ring = []
+            for _ in range(self._depth + 1):
+                host = [t.empty(a.shape, dtype=t.float32, pin_memory=self._cuda) for a in arrays]
+                devb = [t.empty(a.shape, dtype=t.float32, device=self._dev) for a in arrays]
+                self._ring.append((host, devb, t.cuda.Event() if self._cuda else None))
+            for i in range(len(self._ring)):
+                self._free.put(i)
+        return self._free.get()
+
+    def _reader(self):
+        t = self._torch
+        try:
+            for arrays in self._ds:
+                if self._stop.is_set():
+                    return
+                i = self._slot(arrays)
+                host, devb, ev = self._ring[i]
+                for h, a in zip(host, arrays):
+                    h.copy_(t.from_numpy(np.ascontiguousarray(a, dtype=np.float32)))
+                if self._cuda:
+                    with t.cuda.stream(self._copy_stream):
+                        for h, d in zip(host, devb):
+                            d.copy_(h, non_blocking=True)
+                        ev.record(self._copy_stream)
+                else:
+                    for h, d in zip(host, devb):
+                        d.copy_(h)
+                self._q.put(i)
+            self._q.put(None)
+        except Exception as e:                   # surface reader errors in the consumer
+            self._q.put(e)
+
+    def __iter__(self):
+        self._thread.start()
+        prev = None
+        while True:
+            i = self._q.get()
+            if prev is not None:
+                if self._cuda:                   # the consumer's work on the previous slot must be done before reuse
+                    (self._consumer or self._torch.cuda.current_stream(self._dev)).synchronize()
+                self._free.put(prev)
+            if i is None:
+                return
+            if isinstance(i, Exception):
+                raise i
+            host, devb, ev = self._ring[i]
+            if self._cuda:
+                (self._consumer or self._torch.cuda.current_stream(self._dev)).wait_event(ev)
+            prev = i
+            yield tuple(devb)
+
+    def close(self):
+        self._stop.set()

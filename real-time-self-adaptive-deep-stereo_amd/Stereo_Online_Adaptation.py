@@ -85,7 +85,9 @@ def main(args):
     start_time = time.time()
     t_begin = time.time()
     try:
-        for left, right, gt in data_set:
+        # decode + upload frame t+1 while frame t adapts (pinned ring + copy stream, Data_utils/data_reader.py)
+        frames = data_reader.device_prefetcher(data_set, dev, depth=3, consumer_stream=adapter.stream)
+        for left, right, gt in frames:
             out = adapter.step(left, right, gt[..., 0])
             new_loss = out['loss']
             epe_accumulator.append(out['epe'])

@@ -55,3 +55,32 @@ def test_dataset_iterates_png16_and_pfm(tmp_path):
     assert np.array_equal(L[0, :, 1:31], l0[2:18].astype(np.float32))           # crop rows 2.., pad cols by 1
     assert np.allclose(G[0, :, 1:31, 0], np.floor(d0[2:18] * 256) / 256.0)
     assert np.allclose(out[1][2][0, :, 1:31, 0], d1[2:18])
+
+
+def test_device_prefetcher_preserves_order_and_content(tmp_path):
+    """CPU run of the decode-ahead ring (device='cpu': no pinning / streams): every frame arrives once, in order,
+    intact, also when the list is longer than the ring."""
+    rows = []
+    frames = []
+    for i in range(7):
+        a = np.full((6, 8, 3), float(i), np.float32); g = np.full((6, 8, 1), 10.0 + i, np.float32)
+        np.save(tmp_path / ("l%d.npy" % i), a); np.save(tmp_path / ("r%d.npy" % i), a + 0.5); np.save(tmp_path / ("g%d.npy" % i), g)
+        rows.append("%s,%s,%s" % (tmp_path / ("l%d.npy" % i), tmp_path / ("r%d.npy" % i), tmp_path / ("g%d.npy" % i)))
+        frames.append(i)
+    (tmp_path / "list.csv").write_text("\n".join(rows) + "\n")
+    ds = data_reader.dataset(str(tmp_path / "list.csv"), batch_size=1, crop_shape=[6, 8], num_epochs=1)
+    seen = []
+    for l, r, g in data_reader.device_prefetcher(ds, "cpu", depth=2):
+        assert l.shape == (1, 6, 8, 3) and g.shape == (1, 6, 8, 1)
+        i = int(l[0, 0, 0, 0].item())
+        assert float(r[0, 0, 0, 0]) == i + 0.5 and float(g[0, 0, 0, 0]) == 10.0 + i
+        seen.append(i)
+    assert seen == frames
+
+
+def test_device_prefetcher_surfaces_reader_errors(tmp_path):
+    (tmp_path / "list.csv").write_text("%s,%s,%s\n" % (tmp_path / "missing_l.npy", tmp_path / "missing_r.npy", tmp_path / "missing_g.npy"))
+    ds = data_reader.dataset(str(tmp_path / "list.csv"), batch_size=1, crop_shape=[6, 8], num_epochs=1)
+    with pytest.raises(Exception):
+        for _ in data_reader.device_prefetcher(ds, "cpu"):
+            pass
