@@ -102,6 +102,7 @@ class DispNetEngine(object):
         self.res_loss = z(4); self.res_met = z(4)
         self.ops = []
         self.nodes = {}
+        self.wsa = ops.WgradWorkspace(device)
         self._build()
 
     # ---- graph construction -----------------------------------------------------------------------
@@ -237,6 +238,28 @@ class DispNetEngine(object):
         ops_fill(lib, P.g, 0, P.total)
         for n in self.nodes.values():
             n.remaining, n.written = n.consumers, False
+        # filter gradients: atomic-free partial sums + one reduction launch, deferred in batches onto side lanes
+        # (see engine.MadNetEngine.record_backward); a weight shared by two convs (conv1/conv2 of the two towers)
+        # puts its second use into a second, accumulating reduction
+        segs, segs2, pending, nflush = [], [], [], [0]
+        seen_dst = set()
+
+        def wgrad(xv, dzv, dw, db, stride):
+            pending.append((xv, dzv, dw, db, stride))
+
+        def flush(force=False):
+            if not pending or (len(pending) < 3 and not force):
+                return
+            lib.lane = 1 + nflush[0] % 2
+            nflush[0] += 1
+            try:
+                for xv, dzv, dw, db, stride in pending:
+                    dst = segs2 if dw.data_ptr() in seen_dst else segs
+                    seen_dst.add(dw.data_ptr())
+                    ops.conv2d_wgrad_partial(lib, self.lib, self.wsa, dst, xv, dzv, dw, db, stride=stride)
+            finally:
+                lib.lane = 0
+                del pending[:]
 
         def conv_like_dgrad(emit, xnode):
             """emit(dx_view, accumulate, mask_ref, mask_alpha, mask_range); handles the leaky-mask fusion."""
@@ -263,7 +286,7 @@ class DispNetEngine(object):
                 _, x, wn, out, stride, alpha, x_grad = op
                 assert out.written and out.remaining == 0, "gradient of %s incomplete" % out.name
                 dz = out.gview()
-                ops.conv2d_wgrad(lib, x.view(), dz, self.W_(wn, "g"), self.b_(wn, "g"), stride=stride)
+                wgrad(x.view(), dz, self.W_(wn, "g"), self.b_(wn, "g"), stride)
                 if x_grad:
                     w = self.W_(wn)
                     conv_like_dgrad(lambda dx, acc, ref, ma, rng: ops.conv2d_dgrad(lib, dz, w, dx, stride=stride, accumulate=acc,
@@ -274,7 +297,7 @@ class DispNetEngine(object):
                 dz = out.gview()
                 # y = conv2d_transpose(x, w[kh,kw,Cout,Cin]) is the input-gradient of the SAME conv F with HWIO = w:
                 # dw = filter-gradient of F with (input = dz, output-gradient = x); db = sum(dz); dx = F(dz)
-                ops.conv2d_wgrad(lib, dz, x.view(), self.W_(wn, "g"), None, stride=2)
+                wgrad(dz, x.view(), self.W_(wn, "g"), None, 2)
                 ops.bias_grad(lib, dz, self.b_(wn, "g"))
                 w = self.W_(wn)
                 conv_like_dgrad(lambda dx, acc, ref, ma, rng: ops.conv2d_fwd(lib, dz, w, None, dx, stride=2, alpha=1.0, accumulate=acc,
@@ -288,6 +311,11 @@ class DispNetEngine(object):
                              acc_l=accL, acc_r=accR, copy_left=False)
                 for m in mL + mR:
                     ops.leaky_bwd(lib, m.gview(), m.view(), m.alpha)
+            flush()
+        flush(force=True)
+        r.join_next = True
+        ops.wgrad_reduce(lib, segs, self.dev, r.keep)
+        ops.wgrad_reduce(lib, segs2, self.dev, r.keep, accumulate=True)
 
     def record_update(self, r, lr, momentum=0.9, grad_scale=1.0):
         P = self.params
@@ -298,6 +326,7 @@ class DispNetEngine(object):
 
     def build_plan(self, mode, lr=1e-4, grad_scale=1.0, update=True, part="all", **_):
         r = Recorder()
+        self.wsa.reset()
         ops.PRECISION = 1 if self.precision == "bf16" else 0
         try:
             return self._build_plan(r, mode, lr, grad_scale, update, part)

@@ -159,16 +159,17 @@ def conv2d_wgrad_partial(lib, qlib, wsa, segs, x, dz, dw, db, stride=1, dil=1, s
     segs.append((ws, dw.data_ptr(), size, splits.value))
 
 
-def wgrad_reduce(lib, segs, device, keep, stream=None):
+def wgrad_reduce(lib, segs, device, keep, stream=None, accumulate=False):
     """One launch that sums the splits of every segment recorded by conv2d_wgrad_partial.  `keep`: list that
-    keeps the device table alive as long as the plan."""
+    keeps the device table alive as long as the plan.  accumulate: dst += sum (a weight used by a second conv --
+    its segments go into a second launch after the first)."""
     if not segs:
         return
     assert len(set(s[1] for s in segs)) == len(segs), "a filter gradient may appear once per reduction"
     arr = (_ffi.WgradSeg * len(segs))()
     blk = 0
     for k, (ws, dst, size, splits) in enumerate(segs):
-        arr[k].ws, arr[k].dst, arr[k].size, arr[k].splits, arr[k].blk0, arr[k].accumulate = ws, dst, size, splits, blk, 0
+        arr[k].ws, arr[k].dst, arr[k].size, arr[k].splits, arr[k].blk0, arr[k].accumulate = ws, dst, size, splits, blk, int(accumulate)
         blk += (size + 1023) // 1024
     host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
     table = host.to(device)
