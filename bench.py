@@ -107,7 +107,7 @@ def bench_mad(args, lib, dev, rank, world, dist):
     if rank == 0:
         print(json.dumps({
             "metric": "adapted stereo pairs/sec (whole node), MADNet MAD modular online adaptation 1242x375",
-            "value": world * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": world * SB * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": "MADNet MAD adaptation step via Nets.get_stereo_net + Adapter.step (host block sampling, "
@@ -133,6 +133,10 @@ def main():
     ap.add_argument("--no-parity-path", action="store_true", help="skip the fp32 side measurement of a bf16 run")
     ap.add_argument("--height", type=int, default=375)
     ap.add_argument("--width", type=int, default=1242)
+    ap.add_argument("--streams-per-gpu", type=int, default=1,
+                    help="B > 1: B stereo streams that SHARE one model are batched through the same kernels on each GPU "
+                         "(SURVEY 8(e); loss = mean over the B pairs = synchronous data-parallel SGD); default 1 = the reference's batch-1 loop")
+    ap.add_argument("--wgrad-lanes", type=int, default=-1, help="side lanes for the filter gradients (default: the engine's; 0 = serial, for clean per-kernel profiles)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -159,9 +163,17 @@ def main():
     shapes = dict(DE.dispnet_manifest() if dispnet else E.madnet_manifest())
     wn = S.calibrated_weights(shapes, 1)
     l, r, gt = S.make_pair(H, W, stream_id=rank)
-    eng = (DE.DispNetEngine(lib, H, W, B=1, device=dev, weights=wn, precision=args.precision) if dispnet
-           else E.MadNetEngine(lib, H, W, B=1, device=dev, weights=wn, precision=args.precision))
-    eng.set_inputs(l, r, gt[..., 0])
+    SB = args.streams_per_gpu
+    eng = (DE.DispNetEngine(lib, H, W, B=SB, device=dev, weights=wn, precision=args.precision) if dispnet
+           else E.MadNetEngine(lib, H, W, B=SB, device=dev, weights=wn, precision=args.precision))
+    if SB > 1:
+        import numpy as np
+        pairs = [S.make_pair(H, W, stream_id=rank * SB + i) for i in range(SB)]
+        eng.set_inputs(np.concatenate([q[0] for q in pairs]), np.concatenate([q[1] for q in pairs]), np.concatenate([q[2][..., 0] for q in pairs]))
+    else:
+        eng.set_inputs(l, r, gt[..., 0])
+    if args.wgrad_lanes >= 0 and hasattr(eng, "wgrad_lanes"):
+        eng.wgrad_lanes = args.wgrad_lanes
     plan = eng.build_plan(args.mode, lr=1e-4)
     stream = torch.cuda.Stream()
     sh = stream.cuda_stream
@@ -217,17 +229,18 @@ def main():
 
     out = {
         "metric": "adapted stereo pairs/sec (whole node), %s full-backprop online adaptation 1242x375" % ("DispNet" if dispnet else "MADNet"),
-        "value": world * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+        "value": world * SB * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
-        "config": {"workload": ("DispNet" if dispnet else "MADNet") + " %s adaptation step (fwd+SSIM/L1 loss+EPE+bwd+momentum), %dx%d, 1 pair/GPU/step, "
-                               "private model per stream" % (args.mode, W, H),
+        "config": {"workload": ("DispNet" if dispnet else "MADNet") + " %s adaptation step (fwd+SSIM/L1 loss+EPE+bwd+momentum), %dx%d, %d pair%s/GPU/step, %s"
+                               % (args.mode, W, H, SB, "" if SB == 1 else "s",
+                                  "private model per stream" if SB == 1 else "the %d streams of a GPU share one model (batched)" % SB),
                    "launch": "eager plan" if args.no_graph else "hipGraph replay",
                    "ops_per_step": plan.n, "final_loss": loss, "epe_vs_synthetic_gt": epe_gt,
                    "pred_nonzero_frac": nonzero},
     }
     _log("timed region done: %.3f ms/step" % (1e3 * dt / args.steps))
-    if rank == 0 and world == 1 and not dispnet:
+    if rank == 0 and world == 1 and not dispnet and SB == 1:
         if not args.no_roofline:
             with torch.cuda.stream(stream):
                 out["roofline"], extra = BT.roofline(lib, eng, stream)

@@ -59,8 +59,12 @@ __device__ __forceinline__ int swz_group(int row, int g) { return g ^ ((row >> 2
 // contraction runs on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (13x the fp32-MFMA rate): the kernel
 // becomes loader/L2-bound.  The forward B tile (HWIO rows run along n) is loaded as units of 4 consecutive
 // k rows and transposed in registers so that it is stored with 8-byte writes like the other tiles.
-template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool VEC, bool UNI, bool BF16>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
+// KG > 1 (intra-workgroup split-K, small tiles on a grid smaller than the chip): KG groups of 4 waves each own
+// their LDS tiles and walk every KG-th K-tile; the partial accumulator tiles meet in LDS in the epilogue.  A 32x32
+// tile at one wave per SIMD is bound by its ~200-instruction K-step (issue latency, not bytes): KG groups
+// interleave KG such instruction streams per SIMD.
+template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool VEC, bool UNI, bool BF16, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
     constexpr int BM = WM * MT * 16;
     constexpr int BN = WN * NT * 16;
     // LDS row stride (elements: floats / bf16).  bf16: 80 halfs = 40 dwords: with the b128 lane groups of gfx950 a 36-dword
@@ -78,27 +82,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
                                                                     // 128x16 tile (full-resolution layers) is throughput bound
     constexpr int TILE_FLOATS = BF16 ? (BM + BN) * LS / 2 : (BM + BN) * LS;   // one buffer of both tiles, in floats
 
-    HIP_DYNAMIC_SHARED(float, smem)
+    HIP_DYNAMIC_SHARED(float, smem_all)
+    const int kg = KG > 1 ? (int)(threadIdx.x >> 8) : 0;          // K group of this wave
+    float* const smem = smem_all + kg * (2 * TILE_FLOATS);         // this group's tiles (and, later, its C staging)
     float* const As = smem;                            // fp32: [2][BM*LS] floats
     float* const Bs = smem + 2 * BM * LS;              //       [2][BN*LS]
     unsigned short* const Ah = reinterpret_cast<unsigned short*>(smem);          // bf16: [2][BM*LS] halfs
     unsigned short* const Bh = Ah + 2 * BM * LS;                                //       [2][BN*LS]
-    int* const tap_dy = reinterpret_cast<int*>(smem + 2 * TILE_FLOATS);
+    int* const tap_dy = reinterpret_cast<int*>(smem_all + KG * 2 * TILE_FLOATS);
     int* const tap_dx = tap_dy + 64;
     // forward B item j of this thread -> (row kk of the K-tile, 4-column group n4, live)
     auto b_item = [&](int j, int& kk, int& n4) -> bool {
         if (BT) {
-            const int u = threadIdx.x + 256 * (j >> 2);
+            const int u = (threadIdx.x & 255) + 256 * (j >> 2);
             n4 = u % (BN / 4);
             kk = (u / (BN / 4)) * 4 + (j & 3);
             return u < UN;
         }
-        const int q = threadIdx.x + 256 * j;
+        const int q = (threadIdx.x & 255) + 256 * j;
         kk = q / (BN / 4); n4 = q % (BN / 4);
         return q < BVEC;
     };
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x & 255;                 // index within the K group
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             a_bx[j] = ox + p.pad_l;
         }
     }
-    int a_tap = 0, a_c4 = ga;          // group cursor: g = tile*GPT + ga -> (tap, c4)
+    int a_tap = 0, a_c4 = ga + kg * GPT;          // group cursor: g = tile*GPT + ga -> (tap, c4); first tile = kg
     while (a_c4 >= p.G) { a_c4 -= p.G; ++a_tap; }
 
     // ---- per-thread B-item geometry ------------------------------------------------------
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         int kk0, n40;
         b_item(j, kk0, n40);
         const int gb = DGRAD ? (q % GPT) : (kk0 >> 2);
-        int t = 0, c = gb;
+        int t = 0, c = gb + kg * GPT;
         while (c >= p.G) { c -= p.G; ++t; }
         b_tap[j] = t; b_c4[j] = c;
     }
@@ -176,7 +182,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             b_off[j] = (live && n < p.N) ? o : MH_OOB;
         }
     }
-    int u_tap = 0, u_c0 = 0;    // wave-uniform cursor of the NEXT tile to load (UNI)
+    int u_tap = 0, u_c0 = kg * KT;    // wave-uniform cursor of the NEXT tile to load (UNI); K % KT == 0
+    while (UNI && u_c0 >= p.K) { u_c0 -= p.K; ++u_tap; }
 
     // Register stages.  Small tiles (PF2) are latency bound -- one exposed load -> LDS -> MFMA round trip per
     // K-tile -- and run with prefetch distance 2: K-tiles t+1 and t+2 are in flight while tile t is multiplied.
@@ -211,8 +218,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
                 // MH_OOB + anything stays out of range (offsets are < 2^31 and num_records < 2^31)
                 rb_v[j] = mh_buf_load4(rs_w, (b_off[j] == MH_OOB || !tok) ? MH_OOB : b_off[j] + woff);
             }
-            u_c0 += KT;
-            if (u_c0 >= p.K) { u_c0 = 0; ++u_tap; }
+            u_c0 += KT * KG;
+            while (u_c0 >= p.K) { u_c0 -= p.K; ++u_tap; }
             return;
         }
         {
@@ -276,11 +283,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             }
             rb_v[j] = v;
         }
-        a_c4 += GPT;
+        a_c4 += GPT * KG;
         while (a_c4 >= p.G) { a_c4 -= p.G; ++a_tap; }
 #pragma unroll
         for (int j = 0; j < BITEMS; ++j) {
-            b_c4[j] += GPT;
+            b_c4[j] += GPT * KG;
             while (b_c4[j] >= p.G) { b_c4[j] -= p.G; ++b_tap[j]; }
         }
     };
@@ -345,7 +352,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int ntile = (p.taps * p.G + GPT - 1) / GPT;
+    const int ntile = ((p.taps * p.G + GPT - 1) / GPT + KG - 1) / KG;     // K-tiles per group (the same count for every group:
+                                                                          // tiles past the end load zeros)
     const int li = lane & 15, lq = lane >> 4;
 
     auto compute_tile = [&](int buf) {
@@ -429,7 +437,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     // with 16-byte accesses along full NHWC rows (coalesced), all loads of a pass issued together.
     if (p.vecC) {
         constexpr int CS = BN + 4;                         // Cs[BM][CS] fits in the tile LDS
-        float* const Cs = smem;
+        static_assert(BM * CS <= 2 * TILE_FLOATS, "C staging must fit the group's tile region");
+        float* const Cs = smem;                            // KG > 1: every group stages its PARTIAL tile in its own region
         __syncthreads();                                   // everyone is done reading the K-loop tiles
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -439,6 +448,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
                 for (int r = 0; r < 4; ++r)
                     Cs[(wm * MT * 16 + i * 16 + lq * 4 + r) * CS + wn * NT * 16 + j * 16 + li] = acc[i][j][r];
         __syncthreads();
+        if (kg != 0) return;                               // group 0 sums the partial tiles while it reads them (no barrier below)
         constexpr int C4 = BN / 4;                         // float4 per tile row
         constexpr int RP = 256 / C4;                       // tile rows per pass (threads >= RP*C4 idle)
         constexpr int PASSES = (BM + RP - 1) / RP;
@@ -454,6 +464,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             const int m = m0 + row;
             const bool ok = (tid < RP * C4) && (row < BM) && (m < p.M) && (n < p.N);
             float4 v = *reinterpret_cast<const float4*>(&Cs[(row < BM ? row : 0) * CS + c4 * 4]);
+#pragma unroll
+            for (int g = 1; g < KG; ++g) {
+                const float4 w = *reinterpret_cast<const float4*>(&Cs[g * (2 * TILE_FLOATS) + (row < BM ? row : 0) * CS + c4 * 4]);
+                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            }
             const int ooff = ok ? (m * p.out_ld + n) * 4 : MH_OOB;
             float4 old = make_float4(0.f, 0.f, 0.f, 0.f), mk = make_float4(1.f, 1.f, 1.f, 1.f);
             if (p.accumulate) old = mh_buf_load4(rs_out, ooff);
@@ -474,6 +489,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         }
         return;
     }
+    static_assert(KG == 1 || VEC, "the split-K variant needs the vector epilogue");
+    if (KG > 1) return;                                    // (never dispatched without vecC)
     // generic path (odd channel counts / unaligned rows, e.g. the 1-channel disparity heads)
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -501,15 +518,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 }
 
 static bool g_no_uni = false;    // tuning hook: disable the uniform-tap fast path (A/B experiments)
+static bool g_split_k = true;    // tuning hook: intra-workgroup split-K of the small tiles
 
-template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool VEC, bool UNI, bool BF16>
+template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool VEC, bool UNI, bool BF16, int KG = 1>
 int launch_one(ConvArgs& a, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
-    constexpr size_t lds = BF16 ? (size_t)(2 * (BM + BN) * (KT + 16)) * 2 + 512 : (size_t)(2 * (BM + BN) * (KT + 4) + 128) * sizeof(float);
+    constexpr size_t tiles = BF16 ? (size_t)(2 * (BM + BN) * (KT + 16)) * 2 : (size_t)(2 * (BM + BN) * (KT + 4)) * sizeof(float);
+    constexpr size_t lds = KG * tiles + 512;
+    static_assert(lds <= 160 * 1024, "tiles do not fit the 160 KiB LDS");
     static bool attr_done = false;       // LDS > 64 KiB needs the opt-in once per instantiation
     if (!attr_done) {
         if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC, UNI, BF16>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC, UNI, BF16, KG>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) { mh_set_error("conv: hipFuncSetAttribute(%d B LDS): %s", (int)lds, hipGetErrorString(e)); return (int)e; }
         }
@@ -519,8 +539,27 @@ int launch_one(ConvArgs& a, hipStream_t s) {
     a.mtiles = mh_cdiv(a.M, BM);
     a.ntiles = mh_cdiv(a.N, BN);
     const int nwg = a.mtiles * a.ntiles;
-    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC, UNI, BF16>), dim3(nwg), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC, UNI, BF16, KG>), dim3(nwg), dim3(256 * KG), lds, s, a);
     return mh_check_launch("conv_igemm");
+}
+
+// small latency-bound tile on a grid smaller than the chip with a long K walk: 4 K groups per workgroup
+template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool UNI, bool BF16>
+int launch_vec(ConvArgs& a, hipStream_t s) {
+    constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
+    constexpr bool SMALL = (BM * BN <= 32 * 64) && (BM <= 64) && KT == 64;
+    constexpr size_t tiles = BF16 ? (size_t)(2 * (BM + BN) * (KT + 16)) * 2 : (size_t)(2 * (BM + BN) * (KT + 4)) * sizeof(float);
+    constexpr int KGV = (4 * tiles + 512 <= 160 * 1024) ? 4 : 2;       // K groups that fit the LDS
+    if constexpr (SMALL) {
+        const bool all = a.M < 0;
+        const int64_t nwg = all ? 0 : (int64_t)mh_cdiv(a.M, BM) * mh_cdiv(a.N, BN);
+        const int ktiles = all ? 0 : mh_cdiv(a.taps * a.G * 4, KT);
+        if (all || (g_split_k && a.vecC && nwg <= 256 && ktiles >= 8)) {
+            const int rc = launch_one<WM, WN, MT, NT, KT, DGRAD, true, UNI, BF16, KGV>(a, s);
+            if (!all || rc) return rc;
+        }
+    }
+    return launch_one<WM, WN, MT, NT, KT, DGRAD, true, UNI, BF16>(a, s);
 }
 
 // F32 / B16: which arithmetic variants of this (tile, KT) are instantiated (bf16 runs KT = 64 only)
@@ -533,18 +572,18 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
     const bool bf = a.bf16 && vec;                 // the scalar (odd-shape) path stays fp32
     int rc = 0;
     if constexpr (F32) {
-        if (all || (!bf && !dg && vec && uni)) { rc = launch_one<WM, WN, MT, NT, KT, false, true, true, false>(a, s); if (!all || rc) return rc; }
-        if (all || (!bf && !dg && vec && !uni)) { rc = launch_one<WM, WN, MT, NT, KT, false, true, false, false>(a, s); if (!all || rc) return rc; }
+        if (all || (!bf && !dg && vec && uni)) { rc = launch_vec<WM, WN, MT, NT, KT, false, true, false>(a, s); if (!all || rc) return rc; }
+        if (all || (!bf && !dg && vec && !uni)) { rc = launch_vec<WM, WN, MT, NT, KT, false, false, false>(a, s); if (!all || rc) return rc; }
         if (all || (!dg && !vec)) { rc = launch_one<WM, WN, MT, NT, KT, false, false, false, false>(a, s); if (!all || rc) return rc; }
-        if (all || (!bf && dg && vec && uni)) { rc = launch_one<WM, WN, MT, NT, KT, true, true, true, false>(a, s); if (!all || rc) return rc; }
-        if (all || (!bf && dg && vec && !uni)) { rc = launch_one<WM, WN, MT, NT, KT, true, true, false, false>(a, s); if (!all || rc) return rc; }
+        if (all || (!bf && dg && vec && uni)) { rc = launch_vec<WM, WN, MT, NT, KT, true, true, false>(a, s); if (!all || rc) return rc; }
+        if (all || (!bf && dg && vec && !uni)) { rc = launch_vec<WM, WN, MT, NT, KT, true, false, false>(a, s); if (!all || rc) return rc; }
         if (all || (dg && !vec)) { rc = launch_one<WM, WN, MT, NT, KT, true, false, false, false>(a, s); if (!all || rc) return rc; }
     }
     if constexpr (B16) {
-        if (all || (bf && !dg && uni)) { rc = launch_one<WM, WN, MT, NT, KT, false, true, true, true>(a, s); if (!all || rc) return rc; }
-        if (all || (bf && !dg && !uni)) { rc = launch_one<WM, WN, MT, NT, KT, false, true, false, true>(a, s); if (!all || rc) return rc; }
-        if (all || (bf && dg && uni)) { rc = launch_one<WM, WN, MT, NT, KT, true, true, true, true>(a, s); if (!all || rc) return rc; }
-        if (all || (bf && dg && !uni)) { rc = launch_one<WM, WN, MT, NT, KT, true, true, false, true>(a, s); if (!all || rc) return rc; }
+        if (all || (bf && !dg && uni)) { rc = launch_vec<WM, WN, MT, NT, KT, false, true, true>(a, s); if (!all || rc) return rc; }
+        if (all || (bf && !dg && !uni)) { rc = launch_vec<WM, WN, MT, NT, KT, false, false, true>(a, s); if (!all || rc) return rc; }
+        if (all || (bf && dg && uni)) { rc = launch_vec<WM, WN, MT, NT, KT, true, true, true>(a, s); if (!all || rc) return rc; }
+        if (all || (bf && dg && !uni)) { rc = launch_vec<WM, WN, MT, NT, KT, true, false, true>(a, s); if (!all || rc) return rc; }
     }
     if (!all) { mh_set_error("conv: no kernel variant (bf16=%d vec=%d KT=%d)", (int)bf, (int)vec, KT); return MH_ERR_UNSUPPORTED; }
     return rc;
@@ -566,7 +605,8 @@ static int forced_bm() {
 }
 extern "C" int mh_tune_conv_tile(int bm, int bn) {
     g_force_bm = bm & 0xffff; g_force_bn = bn & 0xffff; g_force_kt = bn >> 16;
-    g_no_uni = (bm >> 16) != 0;      // bit 16 of bm: disable the uniform-tap fast path
+    g_no_uni = ((bm >> 16) & 1) != 0;      // bit 16 of bm: disable the uniform-tap fast path
+    g_split_k = ((bm >> 17) & 1) == 0;     // bit 17 of bm: disable the intra-workgroup split-K
     return 0;
 }
 
