@@ -435,15 +435,22 @@ __global__ __launch_bounds__(256) void leaky_bwd_kernel(float* dy, int dy_ld, co
     }
 }
 
-// column sums: one workgroup = 256 pixels x all channels (looped), wave-level partial sums then one atomic per wave
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float* dz, int dz_ld, int64_t npix, int nch, float* db) {
-    const int64_t p0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    for (int c = 0; c < nch; ++c) {
-        float v = 0.f;
-        for (int64_t q = p0; q < npix; q += (int64_t)gridDim.x * 256) v += dz[q * dz_ld + c];
-        v = mh_wave_sum(v);
-        if ((threadIdx.x & 63) == 0) atomicAdd(db + c, v);
-    }
+// column sums, coalesced along the channels: a wave row = 64/nchp pixels x nchp channels (nchp = power of two covering
+// min(nch, 64)), blockIdx.y = 64-channel chunk; pixels strided over waves and workgroups; shuffle reduction over the
+// pixels of a wave row, LDS over the 4 waves, one atomic per channel per workgroup.
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* dz, int dz_ld, int64_t npix, int nch, float* db, int nchp) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int ppw = 64 / nchp;
+    const int c = blockIdx.y * 64 + (lane & (nchp - 1));
+    const int pl = lane / nchp;
+    float v = 0.f;
+    if (c < nch)
+        for (int64_t q = ((int64_t)blockIdx.x * 4 + w) * ppw + pl; q < npix; q += (int64_t)gridDim.x * 4 * ppw) v += dz[q * dz_ld + c];
+    for (int o = nchp; o < 64; o <<= 1) v += __shfl_xor(v, o);
+    red[w][lane] = v;
+    __syncthreads();
+    if (w == 0 && pl == 0 && c < nch) atomicAdd(db + c, (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
 }
 
 __global__ __launch_bounds__(256) void fill_kernel(float* p, int64_t n, float v) {
@@ -595,7 +602,13 @@ extern "C" int mh_leaky_bwd(float* dy, int32_t dy_ld, const float* y, int32_t y_
 
 extern "C" int mh_bias_grad(const float* dz, int32_t dz_ld, int64_t npix, int32_t nch, float* db, void* stream) {
     MH_REQUIRE(dz && db && npix > 0 && nch > 0 && dz_ld >= nch, MH_ERR_ARG, "mh_bias_grad: bad argument");
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(grid_for(npix, 512)), dim3(256), 0, (hipStream_t)stream, dz, dz_ld, npix, nch, db);
+    int nchp = 1;
+    while (nchp < nch && nchp < 64) nchp <<= 1;
+    const int64_t rows = (npix + (64 / nchp) - 1) / (64 / nchp);          // wave rows of work
+    int gx = (int)((rows + 4 * 8 - 1) / (4 * 8));                          // ~8 rows per wave
+    if (gx > 1024) gx = 1024;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(gx, (nch + 63) / 64), dim3(256), 0, (hipStream_t)stream, dz, dz_ld, npix, nch, db, nchp);
     return mh_check_launch("bias_grad");
 }
 

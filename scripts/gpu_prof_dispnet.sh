@@ -1,0 +1,4 @@
+#!/bin/bash
+TAG=${1:-r02f}; PREC=${2:-bf16}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o dispnet -- python $GRAFT_REPO_ROOT/bench.py --model dispnet --precision $PREC --steps 10 --warmup 2 --no-graph --no-cpu-baseline --no-roofline --no-parity-path > $GRAFT_REPO_ROOT/$OUT/prof.log 2>&1)
+tail -1 $OUT/prof.log | cut -c1-200

@@ -150,7 +150,7 @@ inline void run_block(const std::function<void()>& body, unsigned bx, dim3 grid,
     t.waves.assign((n + 63) / 64, Wave());
     for (int i = 0; i < n; ++i) t.waves[i >> 6].alive++;
     t.nthreads = n; t.alive = n; t.bar_gen = 0; t.bar_count = 0;
-    t.bidx = uint3_{bx, 0, 0}; t.bdim = block; t.gdim = grid; t.body = &body;
+    t.bidx = uint3_{bx % grid.x, bx / grid.x, 0}; t.bdim = block; t.gdim = grid; t.body = &body;      // 2-D grids: bx linearised
     for (int i = 0; i < n; ++i) {
         Fiber& f = t.fibers[i];
         getcontext(&f.ctx);
@@ -176,7 +176,7 @@ inline void run_block(const std::function<void()>& body, unsigned bx, dim3 grid,
 template <typename F>
 inline void launch(F&& f, dim3 grid, dim3 block, size_t shmem) {
     const std::function<void()> body = f;
-    const unsigned nb = grid.x;
+    const unsigned nb = grid.x * grid.y;
     unsigned nthr = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), nb);
     const char* env = getenv("MH_EMUL_THREADS");
     if (env) nthr = std::max(1, std::min<int>(atoi(env), (int)nb));

@@ -235,3 +235,17 @@ def test_corr_fwd_both_kernels(backend, direct):
     finally:
         backend.lib.tune_corr(1)
     ok, err = _close(out, ref); assert ok, err
+
+
+@pytest.mark.parametrize("case", [(1000, 1, 1), (777, 3, 4), (513, 12, 16), (300, 64, 64), (129, 200, 200), (70, 1024, 1024), (5, 96, 100)])
+def test_bias_grad_column_sums(backend, case):
+    """db += column sums of a [npix, nch] view with row stride ld (BiasAddGrad of the transposed convs)."""
+    npix, nch, ld = case
+    dev = backend.device
+    t = _rand((1, 1, npix, ld), 31, dev)
+    v = ops.View(t, 1, 1, npix, nch, ld)
+    db = _rand((nch,), 32, dev)
+    ref = db.cpu().double() + t.cpu().double()[0, 0, :, :nch].sum(0)
+    ops.bias_grad(backend.lib, v, db)
+    backend.sync()
+    assert (db.cpu().double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
