@@ -517,6 +517,69 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
     }
 }
 
+// ---- single-output-channel forward conv (the disparity heads, Cin -> 1) ---------------------------------------------
+// out[p] = act(sum_{tap,k} x[p + tap][k] * w[tap][k] + b) (+ old): a per-pixel dot product of length taps*K, HBM/L2
+// bound.  N = 1 makes the HWIO weights k-contiguous, so both operands are read with 16-byte loads here (the tiled
+// kernel would fall back to its scalar path and waste 15/16 of a 16-column MFMA tile).  LPP lanes per pixel split the
+// channel groups, the weights are staged in LDS once per workgroup, partial sums meet in a shuffle butterfly.
+template <int LPP>
+__global__ __launch_bounds__(256) void conv_n1_fwd_kernel(ConvArgs p) {
+    HIP_DYNAMIC_SHARED(float, wsm)                 // [taps][K]
+    const int tid = threadIdx.x;
+    const int nw4 = p.taps * p.K / 4;
+    for (int i = tid; i < nw4; i += 256) reinterpret_cast<float4*>(wsm)[i] = reinterpret_cast<const float4*>(p.w)[i];
+    __syncthreads();
+    constexpr int PPB = 256 / LPP;
+    const int sub = tid % LPP;
+    const int G4 = p.K >> 2;
+    const __amdgpu_buffer_rsrc_t rs_in = mh_make_rsrc(p.in, p.in_bytes);
+    const float bias = p.bias ? p.bias[0] : 0.f;
+    for (int m = blockIdx.x * PPB + tid / LPP; m - tid / LPP < p.M; m += gridDim.x * PPB) {     // uniform trip count per wave
+        const bool live = m < p.M;
+        const int mm = live ? m : 0;
+        const int ox = mm % p.Wo;
+        const int t2 = mm / p.Wo;
+        const int oy = t2 % p.Ho, b = t2 / p.Ho;
+        float acc = 0.f;
+        for (int t = 0; t < p.taps; ++t) {
+            const int ky = t / p.kw, kx = t - ky * p.kw;
+            const int iy = oy * p.stride + ky * p.dil - p.pad_t, ix = ox * p.stride + kx * p.dil - p.pad_l;
+            const bool ok = live && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const int base = ((b * p.Hi + iy) * p.Wi + ix) * p.in_ld;
+            for (int g = sub; g < G4; g += LPP) {
+                const float4 x = mh_buf_load4(rs_in, ok ? (base + g * 4) * 4 : MH_OOB);
+                const float4 w = *reinterpret_cast<const float4*>(wsm + t * p.K + g * 4);
+                acc += (x.x * w.x + x.y * w.y) + (x.z * w.z + x.w * w.w);
+            }
+        }
+#pragma unroll
+        for (int o = LPP >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (live && sub == 0) {
+            float v = acc + bias;
+            if (p.alpha != 1.0f) v = v > 0.f ? v : p.alpha * v;
+            float* dst = p.out + (int64_t)m * p.out_ld;
+            if (p.accumulate) v += *dst;
+            *dst = v;
+        }
+    }
+}
+
+static bool conv_n1_ok(const ConvArgs& a) {
+    return a.mode == 0 && a.N == 1 && a.vecA && (a.K % 4 == 0) && mh_aligned16(a.w) && !a.mask_ref &&
+           (size_t)a.taps * a.K * 4 <= 64 * 1024 && a.M > 0;
+}
+
+static int launch_conv_n1(ConvArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)a.taps * a.K * sizeof(float);
+    const int g4 = a.K / 4;
+#define MH_N1(LPPv)                                                                                     \
+    {   int grid = mh_cdiv(a.M, 256 / LPPv); if (grid > 256 * 32) grid = 256 * 32;                       \
+        hipLaunchKernelGGL((conv_n1_fwd_kernel<LPPv>), dim3(grid), dim3(256), lds, s, a); }
+    if (g4 <= 4) MH_N1(4) else if (g4 <= 8) MH_N1(8) else MH_N1(16)
+#undef MH_N1
+    return mh_check_launch("conv_n1_fwd");
+}
+
 static bool g_no_uni = false;    // tuning hook: disable the uniform-tap fast path (A/B experiments)
 static bool g_split_k = true;    // tuning hook: intra-workgroup split-K of the small tiles
 
@@ -730,5 +793,6 @@ extern "C" int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w,
     // 16-byte vector loads of A need every group start 16B aligned and the full group in-bounds
     a.vecA = mh_aligned16(in) && (d->in_ld % 4 == 0) && (d->in_ld >= a.G * 4);
     a.vecB = mh_aligned16(w) && (d->w_trans ? (d->K % 4 == 0) : (d->N % 4 == 0));
+    if (conv_n1_ok(a)) return launch_conv_n1(a, (hipStream_t)stream);
     return conv_dispatch(a, (hipStream_t)stream);
 }

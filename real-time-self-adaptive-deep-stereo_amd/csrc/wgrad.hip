@@ -523,6 +523,84 @@ int launch_wgrad(WgradArgs& a, hipStream_t s) {
     return rc;
 }
 
+// ---- single-output-channel layers (the disparity heads: 3x3 Cin->1) ----------------------------------------------
+// dw[tap][k] = sum_p x[p + tap][k] * dz[p] is a memory-bound reduction, not a GEMM (a 16-column MFMA tile would be
+// 15/16 padding and N = 1 defeats the 16-byte dz/weight loads of the tiled kernels).  Thread = (4-channel group g,
+// pixel slot): TAPS float4 accumulators in registers, pixels of the split strided over the slots, slots reduced
+// through LDS, one store (workspace) or atomic (dw) per element per workgroup.
+template <int TAPS>
+__global__ __launch_bounds__(256) void wgrad_n1_kernel(WgradArgs p) {
+    HIP_DYNAMIC_SHARED(float, smem)               // [slots][TAPS][K] floats
+    const int tid = threadIdx.x;
+    const int G4 = p.K >> 2;                      // <= 256, power-of-two padded by the launcher: G4p
+    const int G4p = p.ktiles;                     // (reused field) padded group count, divides 256
+    const int slots = 256 / G4p;
+    const int g = tid % G4p, slot = tid / G4p;
+    const int split = blockIdx.x;
+    const int mbeg = split * p.chunk, mend = min(p.M, mbeg + p.chunk);
+    const bool gok = g < G4;
+    const __amdgpu_buffer_rsrc_t rs_in = mh_make_rsrc(p.in, p.in_bytes);
+    float4 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float bsum = 0.f;
+    for (int m = mbeg + slot; m < mend; m += slots) {
+        const float dzv = p.dz[(int64_t)m * p.dz_ld];
+        const int ox = m % p.Wo;
+        const int t2 = m / p.Wo;
+        const int oy = t2 % p.Ho, b = t2 / p.Ho;
+        bsum += dzv;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            const int ky = t / p.kw, kx = t - ky * p.kw;
+            const int iy = oy * p.stride + ky * p.dil - p.pad_t, ix = ox * p.stride + kx * p.dil - p.pad_l;
+            const bool ok = gok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const float4 x = mh_buf_load4(rs_in, ok ? (((b * p.Hi + iy) * p.Wi + ix) * p.in_ld + g * 4) * 4 : MH_OOB);
+            acc[t].x += x.x * dzv; acc[t].y += x.y * dzv; acc[t].z += x.z * dzv; acc[t].w += x.w * dzv;
+        }
+    }
+    if (gok) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) *reinterpret_cast<float4*>(smem + ((slot * TAPS + t) * G4 + g) * 4) = acc[t];
+    }
+    __shared__ float bred[256];
+    bred[tid] = (g == 0) ? bsum : 0.f;
+    __syncthreads();
+    float* const dst = p.ws ? p.ws + (int64_t)split * TAPS * p.K : p.dw;
+    for (int e = tid; e < TAPS * p.K; e += 256) {
+        float v = 0.f;
+        for (int sl = 0; sl < slots; ++sl) v += smem[sl * TAPS * p.K + e];
+        if (p.ws) dst[e] = v; else atomicAdd(dst + e, v);
+    }
+    if (p.db && tid == 0) {
+        float v = 0.f;
+        for (int i = 0; i < 256; ++i) v += bred[i];
+        atomicAdd(p.db, v);
+    }
+}
+
+static bool wgrad_n1_ok(const WgradArgs& a) {
+    return a.N == 1 && a.taps == 9 && a.vecA && (a.K % 4 == 0) && a.K <= 1024 && a.M > 0;
+}
+
+static int launch_wgrad_n1(WgradArgs& a, hipStream_t s) {
+    int g4p = 1;
+    while (g4p < a.K / 4) g4p <<= 1;
+    const int slots = 256 / g4p;
+    // ~8 pixels per slot per workgroup, at most 1024 workgroups
+    int splits = a.forced_splits > 0 ? a.forced_splits : mh_cdiv(a.M, slots * 8);
+    if (splits > 1024) splits = 1024;
+    if (splits < 1) splits = 1;
+    const int chunk = mh_cdiv(a.M, splits);
+    a.splits = mh_cdiv(a.M, chunk);
+    a.chunk = chunk;
+    a.ktiles = g4p;
+    if (a.query) return 0;
+    const size_t lds = (size_t)slots * 9 * a.K * sizeof(float);          // <= 36 KiB
+    hipLaunchKernelGGL(wgrad_n1_kernel<9>, dim3(a.splits), dim3(256), lds, s, a);
+    return mh_check_launch("wgrad_n1");
+}
+
 static int wgrad_dispatch(WgradArgs& a, hipStream_t s) {
     const int K = a.K, N = a.N;
     const bool all = a.M < 0;
@@ -582,7 +660,7 @@ static int wgrad_entry(const mh_conv_desc* d, const float* in, const float* dout
         MH_REQUIRE(inb < (1ll << 31) - 64 && dzb < (1ll << 31) - 64, MH_ERR_UNSUPPORTED, "mh_conv2d_wgrad: tensors must be < 2 GiB");
         a.in_bytes = (unsigned)inb; a.dz_bytes = (unsigned)dzb;
     }
-    const int rc = wgrad_dispatch(a, (hipStream_t)stream);
+    const int rc = wgrad_n1_ok(a) ? launch_wgrad_n1(a, (hipStream_t)stream) : wgrad_dispatch(a, (hipStream_t)stream);
     if (splits_out) *splits_out = a.splits;
     return rc;
 }
