@@ -252,7 +252,8 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(WgradArgs p) {
     constexpr int NTH = 64 * WM * WN;
     constexpr int PT = 64;
     constexpr int BK = WM * MT * 16, BN = WN * NT * 16;
-    constexpr int LS = PT + 16;          // halfs: 40-dword rows = conflict-free ds_read_b128 operand reads (see conv.hip)
+    constexpr int LS = PT + 8;           // halfs.  (PT + 16 = 40-dword rows would make the operand reads conflict free, but the
+                                         // 128x128 tile then needs 82 KB and only ONE workgroup fits a CU: measured 28 % slower)
     constexpr int AUN = (BK / 4) * (PT / 4), BUN = (BN / 4) * (PT / 4);
     constexpr int AU = (AUN + NTH - 1) / NTH, BU = (BUN + NTH - 1) / NTH;
 
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(WgradArgs p) {
 template <int WM, int WN, int MT, int NT>
 int launch_wgrad_bf16(WgradArgs& a, hipStream_t s) {
     constexpr int BK = WM * MT * 16, BN = WN * NT * 16, PT = 64;
-    constexpr size_t lds = (size_t)(2 * (BK + BN) * (PT + 16)) * 2 + 2 * PT * 4;
+    constexpr size_t lds = (size_t)(2 * (BK + BN) * (PT + 8)) * 2 + 2 * PT * 4;
     static bool attr_done = false;
     if (!attr_done) {
         if (lds > 64 * 1024) {
