@@ -237,3 +237,38 @@ def test_conv_bf16_throughput_mode(backend, shape):
     # and it really is a reduced-precision path: it differs from the exact fp32 result
     y32 = T.conv2d(x.cpu(), w.cpu(), b.cpu(), stride=s, dilation=d, alpha=0.2)
     assert (y.cpu() - y32).abs().max().item() > 1e-4
+
+
+# bf16 mode with forced BIG tiles (wave-specialised kernels: 4 MFMA waves + 4 loader waves per workgroup)
+WS_CASES = [((128, 64), (1, 10, 16, 64, 64, 1, 1)), ((128, 128), (1, 9, 15, 128, 128, 1, 2)), ((64, 64), (2, 8, 12, 96, 40, 1, 1)),
+            ((64, 128), (1, 12, 20, 32, 128, 2, 1)), ((128, 32), (1, 7, 11, 38, 20, 1, 1)), ((128, 96), (1, 6, 10, 64, 96, 1, 1))]
+
+
+@pytest.mark.parametrize("tile,shape", WS_CASES)
+def test_conv_bf16_big_tiles(backend, tile, shape):
+    bm, bn = tile
+    B, H, W, Ci, Co, s, d = shape
+    dev = backend.device
+    x = _rand((B, H, W, Ci), 61, dev)
+    w = _rand((3, 3, Ci, Co), 62, dev, 0.2)
+    b = _rand((Co,), 63, dev)
+    Ho, Wo, _, _ = ops.conv_geometry(H, W, 3, 3, s, d)
+    gz = _rand((B, Ho, Wo, Co), 64, dev)
+    y_ref = T.conv2d(_bf(x.cpu()), _bf(w.cpu()), b.cpu(), stride=s, dilation=d, alpha=0.2)
+    _, gx_ref, _, _ = _oracle_grads(x.cpu(), _bf(w.cpu()), b.cpu(), s, d, 1.0, _bf(gz.cpu()))
+    ld = (Ci + 3) // 4 * 4
+    xb, xv = _padded(x, ld)
+    ops.PRECISION = 1
+    try:
+        backend.lib.tune_conv_tile(bm, bn | (64 << 16))
+        y = torch.full(y_ref.shape, float("nan"), device=dev)
+        ops.conv2d_fwd(backend.lib, xv, w, b, ops.view(y), stride=s, dil=d, alpha=0.2)
+        backend.lib.tune_conv_tile(bm, (128 if (bn > Ci and Ci > 64) else bn) | (64 << 16))
+        dxb, dxv = _padded(torch.full(x.shape, float("nan"), device=dev), ld)
+        ops.conv2d_dgrad(backend.lib, ops.view(gz), w, dxv, stride=s, dil=d)
+        backend.sync()
+    finally:
+        ops.PRECISION = 0
+        backend.lib.tune_conv_tile(0, 0)
+    assert (y.cpu() - y_ref).abs().max().item() <= 1e-4 * max(1.0, y_ref.abs().max().item())
+    assert (dxb[..., :Ci].cpu() - gx_ref).abs().max().item() <= 1e-4 * max(1.0, gx_ref.abs().max().item())
