@@ -107,7 +107,7 @@ def bench_mad(args, lib, dev, rank, world, dist):
     if rank == 0:
         print(json.dumps({
             "metric": "adapted stereo pairs/sec (whole node), MADNet MAD modular online adaptation 1242x375",
-            "value": world * SB * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": world * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": "MADNet MAD adaptation step via Nets.get_stereo_net + Adapter.step (host block sampling, "

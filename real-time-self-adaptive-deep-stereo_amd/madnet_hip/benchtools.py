@@ -80,7 +80,7 @@ def roofline(lib, eng, stream, reps=20):
         ms_c = _time_ms(lib, stream, lambda: ops.corr_fwd(lib, ops.view(L), ops.view(R), ops.view(out), md, stream=sh), 10)
         byts = float(Bc) * H * W * (2 * Cc + D) * 4
         g = byts / (ms_c * 1e-3) / 1e9
-        extra["roofline_corr"] = {"kernel": "corr_fwd_small<8,64> (B=64 x %dx%dx%d, D=%d)" % (H, W, Cc, D), "bound": "hbm",
+        extra["roofline_corr"] = {"kernel": "corr_fwd_direct<8,5> (B=64 x %dx%dx%d, D=%d)" % (H, W, Cc, D), "bound": "hbm",
                                   "achieved": g, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": g / PEAK_HBM_GBS,
                                   "traffic": _pmc_traffic("corr_fwd_B64_96x320x32_D5"), "launch_ms": ms_c, "algorithmic_bytes_per_launch": byts}
         L1, R1 = L[:1].contiguous(), R[:1].contiguous(); o1 = out[:1].contiguous()
