@@ -33,6 +33,11 @@ struct ConvArgs {
     int mtiles, ntiles;
     float alpha, mask_alpha;
     int mask_c0, mask_c1;   // channel range the leaky-grad mask applies to
+    // Stride-2 input gradient / transposed conv as 4 stride-1 sub-problems, one per output parity class: class c covers
+    // the output pixels (2*qy + py, 2*qx + px) and ONLY the taps that land on the input lattice for that parity
+    // (iy = qy + dy[t]); walking every tap with a lattice mask instead wastes 3/4 of the loads and MFMAs.
+    int ncls;               // 0 = off
+    struct Cls { int py, px, Hq, Wq, M, tile0, ntaps, pad; signed char dy[16], dx[16]; unsigned char id[16]; } cls[4];
 };
 
 // LDS tiles are k-contiguous for BOTH operands (As[row][k], Bs[col][k], row stride KT+4 floats) so
@@ -113,13 +118,39 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
     const int lin = mh_xcd_remap(blockIdx.x, nwg);
     const int tile_n = lin % p.ntiles;
     const int tile_m = lin / p.ntiles;
-    const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
+    int* const tap_id = tap_dx + 64;                   // real tap index (weight slice) of the t-th tap this workgroup walks
+    int* const row_m = tap_id + 64;                    // [BM] output pixel of tile row r (-1: none), parity-class mode only
 
-    if (tid < p.taps) {
-        const int ky = tid / p.kw, kx = tid - ky * p.kw;
-        tap_dy[tid] = ky * p.dil;
-        tap_dx[tid] = kx * p.dil;
+    // parity-class mode (DGRAD, stride 2): this workgroup's class, its tap subset and its (qy, qx) pixel grid
+    const bool pcm = DGRAD && p.ncls > 0;
+    int cls = 0;
+    if (pcm) { while (cls + 1 < p.ncls && p.cls[cls + 1].tile0 <= tile_m) ++cls; }
+    const int ntaps = pcm ? p.cls[cls].ntaps : p.taps;
+    const int Hq = pcm ? p.cls[cls].Hq : p.Ho, Wq = pcm ? p.cls[cls].Wq : p.Wo, Mq = pcm ? p.cls[cls].M : p.M;
+    const int m0 = (tile_m - (pcm ? p.cls[cls].tile0 : 0)) * BM;
+    const int sshift = pcm ? 0 : p.sshift;             // class coordinates make it a stride-1 gather
+
+    if (tid < ntaps) {
+        if (pcm) {
+            tap_dy[tid] = -(int)p.cls[cls].dy[tid];    // DGRAD gathers at a_by - tap_dy
+            tap_dx[tid] = -(int)p.cls[cls].dx[tid];
+            tap_id[tid] = p.cls[cls].id[tid];
+        } else {
+            const int ky = tid / p.kw, kx = tid - ky * p.kw;
+            tap_dy[tid] = ky * p.dil;
+            tap_dx[tid] = kx * p.dil;
+            tap_id[tid] = tid;
+        }
+    }
+    if (pcm && tid < BM) {
+        const int m = m0 + tid;
+        int v = -1;
+        if (m < Mq) {
+            const int qx = m % Wq, t2 = m / Wq;
+            v = ((t2 / Hq) * p.Ho + 2 * (t2 % Hq) + p.cls[cls].py) * p.Wo + 2 * qx + p.cls[cls].px;
+        }
+        row_m[tid] = v;
     }
 
     // ---- per-thread A-row geometry (constant over the K loop) --------------------------
@@ -132,20 +163,20 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
     for (int j = 0; j < AROWS; ++j) {
         const int r = ra + RPP * j;
         const int m = m0 + r;
-        const bool ok = (r < BM) && (m < p.M);
+        const bool ok = (r < BM) && (m < Mq);
         const int mm = ok ? m : 0;
-        const int ox = mm % p.Wo;
-        const int t2 = mm / p.Wo;
-        const int oy = t2 % p.Ho;
-        const int b = t2 / p.Ho;
+        const int ox = mm % Wq;
+        const int t2 = mm / Wq;
+        const int oy = t2 % Hq;
+        const int b = t2 / Hq;
         a_rowok[j] = ok;
         a_img[j] = b * p.Hi * p.Wi;
         if (!DGRAD) {
             a_by[j] = oy * p.stride - p.pad_t;
             a_bx[j] = ox * p.stride - p.pad_l;
         } else {
-            a_by[j] = oy + p.pad_t;
-            a_bx[j] = ox + p.pad_l;
+            a_by[j] = pcm ? oy : oy + p.pad_t;            // class mode: (qy, qx), the padding is folded into the tap offsets
+            a_bx[j] = pcm ? ox : ox + p.pad_l;
         }
     }
     int a_tap = 0, a_c4 = ga + kg * GPT;          // group cursor: g = tile*GPT + ga -> (tap, c4); first tile = kg
@@ -199,7 +230,7 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
     auto load_tile = [&](auto& ra_v, auto& rb_v, int& a_kb_st) {
         if (UNI) {
             // tile = channels [u_c0, u_c0+KT) of tap u_tap -- all scalar
-            const bool tok = u_tap < p.taps;
+            const bool tok = u_tap < ntaps;
             const int tapc = tok ? u_tap : 0;
             const int dy = __builtin_amdgcn_readfirstlane(tap_dy[tapc]);
             const int dx = __builtin_amdgcn_readfirstlane(tap_dx[tapc]);
@@ -212,7 +243,8 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
                 const bool ok = tok && a_rowok[j] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
                 ra_v[j] = mh_buf_load4(rs_in, ok ? a_off[j] + toff : MH_OOB);
             }
-            const int woff = tok ? (!DGRAD ? (u_tap * p.K + u_c0) * p.N : u_tap * p.N * p.K + u_c0) * 4 : MH_OOB;
+            const int wt = pcm ? __builtin_amdgcn_readfirstlane(tap_id[tapc]) : u_tap;
+            const int woff = tok ? (!DGRAD ? (wt * p.K + u_c0) * p.N : wt * p.N * p.K + u_c0) * 4 : MH_OOB;
 #pragma unroll
             for (int j = 0; j < BITEMS; ++j) {
                 // MH_OOB + anything stays out of range (offsets are < 2^31 and num_records < 2^31)
@@ -223,7 +255,7 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
             return;
         }
         {
-            const bool gok = a_tap < p.taps;
+            const bool gok = a_tap < ntaps;
             const int tapc = gok ? a_tap : 0;
             const int dy = tap_dy[tapc], dx = tap_dx[tapc];
             const int kbase = a_c4 * 4;
@@ -236,8 +268,8 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
                     iy = a_by[j] + dy; ix = a_bx[j] + dx;
                 } else {
                     const int ny = a_by[j] - dy, nx = a_bx[j] - dx;
-                    iy = ny >> p.sshift; ix = nx >> p.sshift;            // stride is a power of two
-                    ok = ok && ((iy << p.sshift) == ny) && ((ix << p.sshift) == nx);
+                    iy = ny >> sshift; ix = nx >> sshift;                // stride is a power of two
+                    ok = ok && ((iy << sshift) == ny) && ((ix << sshift) == nx);
                 }
                 ok = ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
                 const int off = ((a_img[j] + iy * p.Wi + ix) * p.in_ld + kbase) * 4;      // bytes (< 2 GiB)
@@ -260,17 +292,18 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
             int k, n;
             if (!DGRAD) {
                 int kk, n4;
-                live = b_item(j, kk, n4) && (b_tap[j] < p.taps);
+                live = b_item(j, kk, n4) && (b_tap[j] < ntaps);
                 k = b_c4[j] * 4 + (kk & 3);
                 n = n0 + n4 * 4;
             } else {
-                live = (q < BVEC) && (b_tap[j] < p.taps);
+                live = (q < BVEC) && (b_tap[j] < ntaps);
                 n = n0 + q / GPT;
                 k = b_c4[j] * 4;
             }
             const bool ok = live && k < p.K && n < p.N;
             // forward: w[tap][k][n] (float4 along n) ; dgrad: w[tap][n][k] (float4 along k)
-            const int off = (!DGRAD ? (b_tap[j] * p.K + k) * p.N + n : (b_tap[j] * p.N + n) * p.K + k) * 4;
+            const int wt = pcm ? tap_id[live ? b_tap[j] : 0] : b_tap[j];
+            const int off = (!DGRAD ? (wt * p.K + k) * p.N + n : (wt * p.N + n) * p.K + k) * 4;
             const int lim = !DGRAD ? p.N - n : p.K - k;      // valid elements of the run starting at off
             float4 v;
             if (VEC) {
@@ -352,7 +385,7 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int ntile = ((p.taps * p.G + GPT - 1) / GPT + KG - 1) / KG;     // K-tiles per group (the same count for every group:
+    const int ntile = ((ntaps * p.G + GPT - 1) / GPT + KG - 1) / KG;     // K-tiles per group (the same count for every group:
                                                                           // tiles past the end load zeros)
     const int li = lane & 15, lq = lane >> 4;
 
@@ -461,8 +494,8 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll 4
         for (int ps = 0; ps < PASSES; ++ps) {
             const int row = tid / C4 + ps * RP;
-            const int m = m0 + row;
-            const bool ok = (tid < RP * C4) && (row < BM) && (m < p.M) && (n < p.N);
+            const int m = pcm ? row_m[row < BM ? row : 0] : m0 + row;
+            const bool ok = (tid < RP * C4) && (row < BM) && (pcm ? m >= 0 : m < p.M) && (n < p.N);
             float4 v = *reinterpret_cast<const float4*>(&Cs[(row < BM ? row : 0) * CS + c4 * 4]);
 #pragma unroll
             for (int g = 1; g < KG; ++g) {
@@ -496,8 +529,8 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wm * MT * 16 + i * 16 + lq * 4 + r;
-            if (m >= p.M) continue;
+            const int m = pcm ? row_m[wm * MT * 16 + i * 16 + lq * 4 + r] : m0 + wm * MT * 16 + i * 16 + lq * 4 + r;
+            if (pcm ? m < 0 : m >= p.M) continue;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int n = n0 + wn * NT * 16 + j * 16 + li;
@@ -582,12 +615,13 @@ static int launch_conv_n1(ConvArgs& a, hipStream_t s) {
 
 static bool g_no_uni = false;    // tuning hook: disable the uniform-tap fast path (A/B experiments)
 static bool g_split_k = true;    // tuning hook: intra-workgroup split-K of the small tiles
+static bool g_parity_classes = true;   // tuning hook: stride-2 dgrad as 4 parity-class sub-problems
 
 template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool VEC, bool UNI, bool BF16, int KG = 1>
 int launch_one(ConvArgs& a, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
     constexpr size_t tiles = BF16 ? (size_t)(2 * (BM + BN) * (KT + 16)) * 2 : (size_t)(2 * (BM + BN) * (KT + 4)) * sizeof(float);
-    constexpr size_t lds = KG * tiles + 512;
+    constexpr size_t lds = KG * tiles + 1536;          // + tap_dy / tap_dx / tap_id [64] and row_m [128]
     static_assert(lds <= 160 * 1024, "tiles do not fit the 160 KiB LDS");
     static bool attr_done = false;       // LDS > 64 KiB needs the opt-in once per instantiation
     if (!attr_done) {
@@ -601,6 +635,11 @@ int launch_one(ConvArgs& a, hipStream_t s) {
     if (a.M < 0) return 0;               // mh_init(): attribute set-up only
     a.mtiles = mh_cdiv(a.M, BM);
     a.ntiles = mh_cdiv(a.N, BN);
+    if (DGRAD && a.ncls > 0) {           // parity classes: tiles never straddle two classes
+        int t0 = 0;
+        for (int c = 0; c < a.ncls; ++c) { a.cls[c].tile0 = t0; t0 += mh_cdiv(a.cls[c].M, BM); }
+        a.mtiles = t0;
+    }
     const int nwg = a.mtiles * a.ntiles;
     hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC, UNI, BF16, KG>), dim3(nwg), dim3(256 * KG), lds, s, a);
     return mh_check_launch("conv_igemm");
@@ -612,7 +651,7 @@ int launch_vec(ConvArgs& a, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
     constexpr bool SMALL = (BM * BN <= 32 * 64) && (BM <= 64) && KT == 64;
     constexpr size_t tiles = BF16 ? (size_t)(2 * (BM + BN) * (KT + 16)) * 2 : (size_t)(2 * (BM + BN) * (KT + 4)) * sizeof(float);
-    constexpr int KGV = (4 * tiles + 512 <= 160 * 1024) ? 4 : 2;       // K groups that fit the LDS
+    constexpr int KGV = (4 * tiles + 1536 <= 160 * 1024) ? 4 : 2;       // K groups that fit the LDS
     if constexpr (SMALL) {
         const bool all = a.M < 0;
         const int64_t nwg = all ? 0 : (int64_t)mh_cdiv(a.M, BM) * mh_cdiv(a.N, BN);
@@ -631,7 +670,7 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
     const bool all = a.M < 0;
     const bool dg = a.mode == 1, vec = a.vecA && a.vecB;
     // uniform-tap fast path: whole K-tiles per tap, no channel padding, unit-stride gather
-    const bool uni = vec && (a.K % KT == 0) && (!dg || a.sshift == 0) && !g_no_uni;
+    const bool uni = vec && (a.K % KT == 0) && (!dg || a.sshift == 0 || a.ncls > 0) && !g_no_uni;
     const bool bf = a.bf16 && vec;                 // the scalar (odd-shape) path stays fp32
     int rc = 0;
     if constexpr (F32) {
@@ -670,6 +709,7 @@ extern "C" int mh_tune_conv_tile(int bm, int bn) {
     g_force_bm = bm & 0xffff; g_force_bn = bn & 0xffff; g_force_kt = bn >> 16;
     g_no_uni = ((bm >> 16) & 1) != 0;      // bit 16 of bm: disable the uniform-tap fast path
     g_split_k = ((bm >> 17) & 1) == 0;     // bit 17 of bm: disable the intra-workgroup split-K
+    g_parity_classes = ((bm >> 18) & 1) == 0;   // bit 18 of bm: disable the stride-2 parity classes
     return 0;
 }
 
@@ -786,6 +826,31 @@ extern "C" int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w,
     }
     a.sshift = 0;
     while ((1 << a.sshift) < d->stride) ++a.sshift;
+    a.ncls = 0;
+    if (d->mode == 1 && d->stride == 2 && g_parity_classes) {
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) {
+                ConvArgs::Cls c{};
+                c.py = py; c.px = px;
+                c.Hq = (d->Ho - py + 1) / 2; c.Wq = (d->Wo - px + 1) / 2;
+                c.M = d->B * c.Hq * c.Wq;
+                for (int ky = 0; ky < d->kh; ++ky)
+                    for (int kx = 0; kx < d->kw; ++kx) {
+                        const int ny = py + d->pad_t - ky * d->dil, nx = px + d->pad_l - kx * d->dil;
+                        if ((ny & 1) || (nx & 1)) continue;             // (two's complement: & 1 is the parity of negatives too)
+                        if (c.ntaps < 16 && ny / 2 >= -127 && ny / 2 <= 127 && nx / 2 >= -127 && nx / 2 <= 127) {
+                            c.dy[c.ntaps] = (signed char)(ny >> 1); c.dx[c.ntaps] = (signed char)(nx >> 1);
+                            c.id[c.ntaps] = (unsigned char)(ky * d->kw + kx);
+                        }
+                        ++c.ntaps;
+                    }
+                if (c.M > 0 && c.ntaps > 0) a.cls[a.ncls++] = c;
+                else if (c.M > 0) { a.ncls = -1; py = px = 2; }          // a class without taps would leave its pixels unwritten
+            }
+        bool fits = a.ncls > 0;
+        for (int c = 0; fits && c < a.ncls; ++c) fits = a.cls[c].ntaps <= 16;
+        if (!fits) a.ncls = 0;                                              // fall back to the lattice-mask walk
+    }
     MH_REQUIRE(d->mode == 0 || (1 << a.sshift) == d->stride, MH_ERR_UNSUPPORTED, "mh_conv2d: mode 1 needs a power-of-two stride");
     a.M = d->B * d->Ho * d->Wo;
     a.alpha = d->alpha; a.mask_alpha = d->mask_alpha;
