@@ -243,6 +243,11 @@ class DispNetEngine(object):
         # puts its second use into a second, accumulating reduction
         segs, segs2, pending, nflush = [], [], [], [0]
         seen_dst = set()
+        uses = {}
+        for op in self.ops:                   # weights used by two convs (the towers' conv1 / conv2) must not be written directly
+            if op[0] in ("conv", "deconv"):
+                uses[op[2]] = uses.get(op[2], 0) + 1
+        shared_dw = set(self.W_(wn, "g").data_ptr() for wn, c in uses.items() if c > 1)
 
         def wgrad(xv, dzv, dw, db, stride):
             pending.append((xv, dzv, dw, db, stride))
@@ -254,9 +259,10 @@ class DispNetEngine(object):
             nflush[0] += 1
             try:
                 for xv, dzv, dw, db, stride in pending:
-                    dst = segs2 if dw.data_ptr() in seen_dst else segs
+                    dup = dw.data_ptr() in seen_dst
                     seen_dst.add(dw.data_ptr())
-                    ops.conv2d_wgrad_partial(lib, self.lib, self.wsa, dst, xv, dzv, dw, db, stride=stride)
+                    ops.conv2d_wgrad_partial(lib, self.lib, self.wsa, segs2 if dup else segs, xv, dzv, dw, db, stride=stride,
+                                             direct_ok=not dup and dw.data_ptr() not in shared_dw)
             finally:
                 lib.lane = 0
                 del pending[:]

@@ -143,10 +143,11 @@ class WgradWorkspace(object):
         return sum(c.numel() for c in self.chunks) * 4
 
 
-def conv2d_wgrad_partial(lib, qlib, wsa, segs, x, dz, dw, db, stride=1, dil=1, stream=None):
+def conv2d_wgrad_partial(lib, qlib, wsa, segs, x, dz, dw, db, stride=1, dil=1, stream=None, direct_ok=True):
     """Like conv2d_wgrad, but atomic-free: the pixel splits' partial sums go to the arena `wsa` and a segment
     (ws, dst=dw, size, splits) is appended to `segs` for the step's single wgrad_reduce launch.
-    `qlib` is the real library (split-count query); `lib` may be a Recorder."""
+    `qlib` is the real library (split-count query); `lib` may be a Recorder.  direct_ok=False: dw already receives
+    another contribution in this step (shared weights) -- always go through a segment."""
     kh, kw, cin, cout = dw.shape
     Ho, Wo, pt, pl = conv_geometry(x.H, x.W, kh, kw, stride, dil)
     assert (dz.H, dz.W, dz.C) == (Ho, Wo, cout) and x.C == cin
@@ -154,6 +155,10 @@ def conv2d_wgrad_partial(lib, qlib, wsa, segs, x, dz, dw, db, stride=1, dil=1, s
     splits = C.c_int32(0)
     qlib.conv2d_wgrad_partial(C.byref(d), _p(x), _p(dz), dz.ld, None, C.byref(splits), None, None)
     size = dw.numel()
+    if splits.value == 1 and direct_ok and dw.data_ptr() % 16 == 0:
+        # a single split IS the gradient: let it store straight into dw (same [tap][K][N] layout), nothing to reduce
+        lib.conv2d_wgrad_partial(C.byref(d), _p(x), _p(dz), dz.ld, C.c_void_p(dw.data_ptr()), C.byref(splits), _p(db), _p(stream))
+        return
     ws = wsa.alloc(size * splits.value)
     lib.conv2d_wgrad_partial(C.byref(d), _p(x), _p(dz), dz.ld, C.c_void_p(ws), C.byref(splits), _p(db), _p(stream))
     segs.append((ws, dw.data_ptr(), size, splits.value))
