@@ -19,6 +19,18 @@ for _p in (ROOT, PKG):
         sys.path.insert(0, _p)
 
 
+def _emit(obj):
+    """The ONE JSON line, as the LAST thing on stdout: RCCL prints a version banner through C stdio when the first
+    communicator is created -- flush the C buffers first so it cannot trail the JSON line."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.write(json.dumps(obj) + "\n")
+    sys.stdout.flush()
+
+
 def _log(msg):
     sys.stderr.write("[bench %.1fs] %s\n" % (time.perf_counter() - _T0, msg))
     sys.stderr.flush()
@@ -104,8 +116,10 @@ def bench_mad(args, lib, dev, rank, world, dist):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if dist is not None:
+        dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({
+        _emit({
             "metric": "adapted stereo pairs/sec (whole node), MADNet MAD modular online adaptation 1242x375",
             "value": world * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -114,9 +128,7 @@ def bench_mad(args, lib, dev, rank, world, dist):
                                    "forward + loss + EPE + one block's backward + update, loss read-back), %dx%d, "
                                    "1 pair/GPU/step, %s" % (W, H, args.block_config),
                        "launch": "eager plan" if args.no_graph else "hipGraph replay per sampled block",
-                       "fetch_counter": ad.fetch_counter, "final_loss": out_step["loss"], "epe_vs_synthetic_gt": out_step["epe"]}}))
-    if dist is not None:
-        dist.destroy_process_group()
+                       "fetch_counter": ad.fetch_counter, "final_loss": out_step["loss"], "epe_vs_synthetic_gt": out_step["epe"]}})
 
 
 def main():
@@ -136,6 +148,9 @@ def main():
     ap.add_argument("--streams-per-gpu", type=int, default=1,
                     help="B > 1: B stereo streams that SHARE one model are batched through the same kernels on each GPU "
                          "(SURVEY 8(e); loss = mean over the B pairs = synchronous data-parallel SGD); default 1 = the reference's batch-1 loop")
+    ap.add_argument("--shared-model", action="store_true",
+                    help="the streams of ALL GPUs adapt ONE model: the flat gradient buffer is all-reduced (RCCL over xGMI) between "
+                         "the backward plan and the momentum plan, scaled by 1/world (BASELINE config 5); default: private models, no collective")
     ap.add_argument("--wgrad-lanes", type=int, default=-1, help="side lanes for the filter gradients (default: the engine's; 0 = serial, for clean per-kernel profiles)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -146,10 +161,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if rank != 0:
+        os.dup2(2, 1)                      # only rank 0 owns stdout (the ONE JSON line); library banners of the others -> stderr
     dist = None
-    if world > 1:
+    if world > 1 or args.shared_model:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
@@ -174,19 +192,38 @@ def main():
         eng.set_inputs(l, r, gt[..., 0])
     if args.wgrad_lanes >= 0 and hasattr(eng, "wgrad_lanes"):
         eng.wgrad_lanes = args.wgrad_lanes
-    plan = eng.build_plan(args.mode, lr=1e-4)
+    shared = args.shared_model and args.mode == "FULL"
+    if shared:
+        # data-parallel SGD over all streams: grads (sum over ranks) * 1/world -> identical momentum update everywhere
+        plan = eng.build_plan("FULL", lr=1e-4, grad_scale=1.0 / world, part="grad")
+        plan_upd = eng.build_plan("FULL", lr=1e-4, grad_scale=1.0 / world, part="update")
+    else:
+        plan = eng.build_plan(args.mode, lr=1e-4)
+        plan_upd = None
     stream = torch.cuda.Stream()
     sh = stream.cuda_stream
     _log("engine built, %d ops" % plan.n)
+
+    def one_step():
+        plan.launch(lib, sh)
+        if shared:
+            dist.all_reduce(eng.params.g)       # RCCL on the bench stream (torch orders it after the backward graph)
+            plan_upd.launch(lib, sh)
+
     with torch.cuda.stream(stream):
         plan.run(lib, sh)                       # eager once (validates every launch)
+        if shared:
+            dist.all_reduce(eng.params.g)
+            plan_upd.run(lib, sh)
         stream.synchronize()
         _log("eager step ok")
         if not args.no_graph:
             plan.capture(lib, sh)
+            if shared:
+                plan_upd.capture(lib, sh)
             _log("hipGraph captured")
         for _ in range(args.warmup):
-            plan.launch(lib, sh)
+            one_step()
         stream.synchronize()
 
         def barrier():
@@ -198,7 +235,7 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            plan.launch(lib, sh)
+            one_step()
         stream.synchronize()
         barrier()
         dt = time.perf_counter() - t0
@@ -234,13 +271,14 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
         "config": {"workload": ("DispNet" if dispnet else "MADNet") + " %s adaptation step (fwd+SSIM/L1 loss+EPE+bwd+momentum), %dx%d, %d pair%s/GPU/step, %s"
                                % (args.mode, W, H, SB, "" if SB == 1 else "s",
-                                  "private model per stream" if SB == 1 else "the %d streams of a GPU share one model (batched)" % SB),
+                                  ("ONE model shared by all streams: RCCL all-reduce of the %.1f MB gradient buffer per step" % (eng.params.g.numel() * 4e-6)) if shared
+                                  else ("private model per stream" if SB == 1 else "the %d streams of a GPU share one model (batched)" % SB)),
                    "launch": "eager plan" if args.no_graph else "hipGraph replay",
                    "ops_per_step": plan.n, "final_loss": loss, "epe_vs_synthetic_gt": epe_gt,
                    "pred_nonzero_frac": nonzero},
     }
     _log("timed region done: %.3f ms/step" % (1e3 * dt / args.steps))
-    if rank == 0 and world == 1 and not dispnet and SB == 1:
+    if rank == 0 and world == 1 and not dispnet and SB == 1 and not shared:
         if not args.no_roofline:
             with torch.cuda.stream(stream):
                 out["roofline"], extra = BT.roofline(lib, eng, stream)
@@ -261,10 +299,10 @@ def main():
             _log("epe_vs_oracle done")
             out["cpu_baseline"] = cpu_baseline(H, W, wn, l, r, gt, args.mode)
             _log("cpu baseline done")
-    if rank == 0:
-        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        _emit(out)
 
 
 if __name__ == "__main__":
