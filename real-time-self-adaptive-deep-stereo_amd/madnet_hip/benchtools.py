@@ -66,7 +66,7 @@ def roofline(lib, eng, stream, reps=20):
     rl = {"kernel": "conv_igemm_kernel (3x3 128->128 @ %dx%d, dil 2; tile chosen by conv_dispatch)" % (x.H, x.W),
           "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
           "frac": ach / peak, "arithmetic": "bf16 MFMA, f32 accumulate" if prec == 1 else "f32 MFMA",
-          "traffic": _pmc_traffic("conv_3x3_128_128_96x320"),
+          "traffic": _pmc_traffic("conv_3x3_128_128_96x320_bf16" if prec == 1 else "conv_3x3_128_128_96x320"),
           "launch_ms": ms, "algorithmic_flops_per_launch": flops}
     # correlation protocol: level-2 shape with B=64 streams (working set > 256 MiB
     # Infinity Cache) for the HBM claim, plus the in-situ B=1 time (cache resident).

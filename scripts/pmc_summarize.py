@@ -21,9 +21,14 @@ def mean_of(rows, pred, counter):
     return sum(v) / len(v), sum(d) / len(d) / 1e3
 
 
+def _targs(n):
+    return [a.strip() for a in n[n.index("<") + 1:n.index(">(")].split(",")]
+
+
 KERNELS = {
-    "conv_3x3_128_128_96x320": (lambda n: "conv_igemm" in n and n.split(">(")[0].endswith("false"), 2 * 15728640 + 589824 + 512),
-    "conv_3x3_128_128_96x320_bf16": (lambda n: "conv_igemm" in n and n.split(">(")[0].endswith("true"), 2 * 15728640 + 589824 + 512),
+    # conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC, UNI, BF16, KG>: template argument 9 is the arithmetic mode
+    "conv_3x3_128_128_96x320": (lambda n: "conv_igemm" in n and _targs(n)[8] == "false", 2 * 15728640 + 589824 + 512),
+    "conv_3x3_128_128_96x320_bf16": (lambda n: "conv_igemm" in n and _targs(n)[8] == "true", 2 * 15728640 + 589824 + 512),
     "corr_fwd_B64_96x320x32_D5": (lambda n: "corr_fwd" in n, 64 * 96 * 320 * (2 * 32 + 5) * 4),
 }
 fetch, write, sq = load("FETCH_SIZE"), load("WRITE_SIZE"), load("SQ")
