@@ -116,3 +116,72 @@ def test_two_steps_and_graph_replay(hip):
     assert (pred - o["disparity"][..., 0]).abs().mean().item() <= EPE_TOL
     for n in wt:
         assert (eng.params.tensor(n).cpu() - wt[n]).abs().max().item() <= 2e-5 * max(1.0, wt[n].abs().max().item()), n
+
+
+@pytest.mark.gpu
+def test_schedules_agree_and_batched_streams(hip):
+    """The same FULL step under every scheduling variant (filter gradients: atomics / workspace+reduction, serial / on
+    side lanes, eager / hipGraph replay) ends in the same weights up to fp32 summation order -- a race between a side
+    lane and the main lane would show up here; and B=2 streams through one engine (shared model) equal the oracle's
+    batch-2 step."""
+    H, W = 128, 256
+    shapes = OM.variable_shapes()
+    wn = S.calibrated_weights(shapes, 1)
+    l, r, gt = S.make_pair(H, W)
+    results = {}
+    for name, partial, lanes, graph in (("atomics", False, 0, False), ("partial", True, 0, False), ("lanes", True, 2, False),
+                                        ("lanes+graph", True, 2, True)):
+        eng = E.MadNetEngine(hip.lib, H, W, B=1, device=hip.device, weights=wn)
+        eng.partial_wgrad, eng.wgrad_lanes = partial, lanes
+        eng.set_inputs(l, r, gt[..., 0])
+        plan = eng.build_plan("FULL", lr=1e-4)
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            if graph:
+                plan.capture(hip.lib, st.cuda_stream)
+            for _ in range(3):                      # three steps: momentum + weights feed back
+                plan.launch(hip.lib, st.cuda_stream)
+            st.synchronize()
+        results[name] = (eng.params.w.clone(), eng.params.m.clone(), float(eng.res_loss[0].item()))
+    w0, m0, l0 = results["atomics"]
+    for name, (w, m, ls) in results.items():
+        assert abs(ls - l0) <= 1e-5 * max(1.0, abs(l0)), name
+        assert (w - w0).abs().max().item() <= 2e-6 * max(1.0, w0.abs().max().item()), name
+        assert (m - m0).norm().item() <= 2e-3 * max(m0.norm().item(), 1e-12), name
+    # batched streams: B = 2 with one model == oracle on the stacked batch
+    l2, r2, g2 = S.make_pair(H, W, stream_id=5)
+    L, R, G = np.concatenate([l, l2]), np.concatenate([r, r2]), np.concatenate([gt, g2])
+    eng = E.MadNetEngine(hip.lib, H, W, B=2, device=hip.device, weights=wn)
+    eng.set_inputs(L, R, G[..., 0])
+    eng.build_plan("FULL", lr=1e-4).run(hip.lib, 0)
+    torch.cuda.synchronize()
+    wt = {k: torch.from_numpy(v.copy()) for k, v in wn.items()}
+    acc = {k: torch.zeros_like(v) for k, v in wt.items()}
+    o = OM.step(wt, acc, torch.from_numpy(L), torch.from_numpy(R), torch.from_numpy(G), mode="FULL", lr=1e-4)
+    assert (eng.pred.cpu() - o["disparity"][..., 0]).abs().mean().item() <= EPE_TOL
+    assert abs(eng.res_loss[0].item() - o["loss"]) <= 2e-5 * max(1.0, abs(o["loss"]))
+    for n in wt:
+        assert (eng.params.tensor(n).cpu() - wt[n]).abs().max().item() <= 1e-5 * max(1.0, wt[n].abs().max().item()), n
+
+
+@pytest.mark.gpu
+def test_bf16_mode_end_to_end(hip):
+    """Throughput mode: same step with bf16 MFMA inputs.  Bounded deviation from the fp32 engine (documented in every
+    bench line as epe_vs_oracle), identical control outputs (loss / metrics finite, weights move the same way)."""
+    H, W = 128, 256
+    wn = S.calibrated_weights(OM.variable_shapes(), 1)
+    l, r, gt = S.make_pair(H, W)
+    out = {}
+    for prec in ("fp32", "bf16"):
+        eng = E.MadNetEngine(hip.lib, H, W, B=1, device=hip.device, weights=wn, precision=prec)
+        eng.set_inputs(l, r, gt[..., 0])
+        eng.build_plan("FULL", lr=1e-4).run(hip.lib, 0)
+        torch.cuda.synchronize()
+        out[prec] = (eng.pred.clone(), float(eng.res_loss[0].item()), eng.params.w.clone(), eng.params.g.clone())
+    p32, l32, w32, g32 = out["fp32"]; p16, l16, w16, g16 = out["bf16"]
+    scale = p32.abs().mean().item()
+    assert torch.isfinite(p16).all() and (p16 - p32).abs().mean().item() <= 0.03 * max(scale, 1.0)
+    assert abs(l16 - l32) <= 0.02 * max(abs(l32), 1e-3)
+    cos = torch.nn.functional.cosine_similarity(g16.flatten(), g32.flatten(), dim=0).item()
+    assert cos >= 0.98, cos                       # the bf16 gradient points the same way
+    assert not torch.equal(w16, w32)              # and it really is a different arithmetic
