@@ -163,14 +163,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if rank != 0:
         os.dup2(2, 1)                      # only rank 0 owns stdout (the ONE JSON line); library banners of the others -> stderr
+    torch.cuda.set_device(local_rank)          # before any collective: barrier()/all_reduce use the current device
+    dev = "cuda:%d" % local_rank
     dist = None
     if world > 1 or args.shared_model:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)
-    torch.cuda.set_device(local_rank)
-    dev = "cuda:%d" % local_rank
 
     from madnet_hip import _ffi, engine as E, dispnet_engine as DE, synthetic as S, benchtools as BT
     lib = _ffi.lib()
