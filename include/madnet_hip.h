@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 4
+#define MH_ABI_VERSION 5
 
 const char* mh_last_error(void);
 int mh_abi_version(void);
@@ -154,6 +154,14 @@ int64_t mh_metrics_ws_floats(int32_t B, int32_t H, int32_t W);
 int mh_metrics(const float* disp, const float* gt, float* ws, float* result, float pixel_th,
                int32_t B, int32_t H, int32_t W, void* stream);
 
+/* ---- proxy-label loss of the continual-adaptation variant: loss_factory.get_proxy_loss('mean_l1', weights=[w]*10)
+ *      (Losses/loss_factory.py:304-351, mean_l1 :28-38; Stereo_Continual_Adaptation.py:75,112)
+ * valid = !(proxy <= 0 || proxy >= 192);  result[0] = weight * sum(valid*|pred-proxy|) / sum(valid);  result[1] = sum(valid);
+ * dpred (may be NULL) = grad_scale * weight * valid * sign(pred - proxy) / sum(valid).  ws: mh_proxy_ws_floats() floats. */
+int64_t mh_proxy_ws_floats(int32_t B, int32_t H, int32_t W);
+int mh_proxy_loss(const float* pred, const float* proxy, float* ws, float* result, float* dpred, float weight,
+                  float grad_scale, int32_t B, int32_t H, int32_t W, void* stream);
+
 /* ---- tf.train.MomentumOptimizer apply (Stereo_Online_Adaptation.py:85):
  *      accum = momentum*accum + grad_scale*g ;  var -= lr*accum   (n contiguous floats) --- */
 int mh_momentum(float* var, float* accum, const float* grad, int64_t n, float lr, float momentum,
@@ -184,7 +192,7 @@ uint32_t mh_crc32c(const void* data, int64_t n, uint32_t crc);
 enum { MH_OP_CONV = 1, MH_OP_WGRAD, MH_OP_CORR_FWD, MH_OP_CORR_BWD, MH_OP_WARP_FWD, MH_OP_WARP_BWD,
        MH_OP_RESIZE_FWD, MH_OP_RESIZE_BWD, MH_OP_PAD_REFLECT, MH_OP_LOSS, MH_OP_METRICS,
        MH_OP_MOMENTUM, MH_OP_COPY_CH, MH_OP_LEAKY_BWD, MH_OP_FILL, MH_OP_BIAS_GRAD,
-       MH_OP_WGRAD_PARTIAL, MH_OP_WGRAD_REDUCE };
+       MH_OP_WGRAD_PARTIAL, MH_OP_WGRAD_REDUCE, MH_OP_PROXY_LOSS };
 /* i[26] of every op is its scheduling word: low byte = lane (0 = the caller's stream; 1..MH_MAX_LANES-1 = side
  * streams owned by the library: the op is forked from lane 0 right before it, i.e. ordered after everything recorded so
  * far, and runs concurrently with the lane-0 ops that follow); MH_OP_JOIN = lane 0 first waits for all side lanes.

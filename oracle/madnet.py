@@ -141,7 +141,7 @@ def momentum_update(wts, accum, grads, lr, momentum=0.9):
 
 
 def step(wts, accum, left, right, gt, mode="FULL", block_vars=None, block_index=None,
-         lr=1e-4, radius_d=2, stride=1):
+         lr=1e-4, radius_d=2, stride=1, loss="reprojection", proxy=None):
     """One iteration of the loop body Stereo_Online_Adaptation.py:178-253 (device part):
     ONE forward with pre-update weights, full-res loss + EPE/bad3, the selected
     backward and the momentum update.  mode in NONE/FULL/MAD.  For MAD, block_index is
@@ -151,7 +151,9 @@ def step(wts, accum, left, right, gt, mode="FULL", block_vars=None, block_index=
         wts[n].requires_grad_(mode != "NONE")
     bulk = (mode == "MAD")
     disps = forward(wts, left, right, bulkhead=bulk, radius_d=radius_d, stride=stride)
-    full_loss = T.reprojection_loss(disps[-1], left, right)
+    # loss="proxy": the continual-adaptation variant (Stereo_Continual_Adaptation.py:75,112): mean_l1 against proxy labels,
+    # weight 0.01 on the full-resolution loss, 0.1 on a MAD block's loss
+    full_loss = T.reprojection_loss(disps[-1], left, right) if loss == "reprojection" else T.proxy_loss(disps[-1], proxy, 0.01)
     epe, bad3 = T.validation_metrics(disps[-1].detach(), gt)
     grads = {}
     if mode == "FULL":
@@ -161,7 +163,7 @@ def step(wts, accum, left, right, gt, mode="FULL", block_vars=None, block_index=
         p = disps[block_index]
         mult = float(left.shape[1] // p.shape[1])                 # Stereo_Online_Adaptation.py:102-103
         p = T.resize_bilinear(p, left.shape[1], left.shape[2]) * mult
-        loss_k = T.reprojection_loss(p, left, right)
+        loss_k = T.reprojection_loss(p, left, right) if loss == "reprojection" else T.proxy_loss(p, proxy, 0.1)
         vs = [n for n in block_vars]
         gl = torch.autograd.grad(loss_k, [wts[n] for n in vs], allow_unused=True)
         grads = {n: g for n, g in zip(vs, gl) if g is not None}

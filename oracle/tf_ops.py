@@ -241,6 +241,14 @@ def reprojection_loss(disp, left, right):
     return mean_ssim_l1(rep, l)
 
 
+def proxy_loss(pred, proxy, weight=0.01):
+    """loss_factory.get_proxy_loss('mean_l1', weights=[weight]*10, reduced=True) on ONE full-resolution prediction
+    (Losses/loss_factory.py:304-351; mean_l1 :28-38): valid = !(proxy <= 0 | proxy >= 192) (the literal 192, not max_disp),
+    weight * sum(valid*|pred - proxy|) / sum(valid).  resize_to_prediction is the identity at equal sizes."""
+    valid = torch.where((proxy <= 0) | (proxy >= 192), torch.zeros_like(proxy), torch.ones_like(proxy))
+    return weight * (valid * (pred - proxy).abs()).sum() / valid.sum()
+
+
 def validation_metrics(disp, gt, pixel_th=3.0):
     """Stereo_Online_Adaptation.py:74-82: EPE and bad3 over gt != 0."""
     abs_err = (disp - gt).abs()

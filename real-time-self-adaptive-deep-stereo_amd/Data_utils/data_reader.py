@@ -133,8 +133,8 @@ class device_prefetcher(object):
         if self._ring is None:                   # allocate the ring on first use (shapes known now)
             self._ring = []
             for _ in range(self._depth + 1):
-                host = [t.empty(a.shape, dtype=t.float32, pin_memory=self._cuda) for a in arrays]
-                devb = [t.empty(a.shape, dtype=t.float32, device=self._dev) for a in arrays]
+                host = [t.empty(np.shape(a), dtype=t.float32, pin_memory=self._cuda) for a in arrays]
+                devb = [t.empty(np.shape(a), dtype=t.float32, device=self._dev) for a in arrays]
                 self._ring.append((host, devb, t.cuda.Event() if self._cuda else None))
             for i in range(len(self._ring)):
                 self._free.put(i)
@@ -149,7 +149,7 @@ class device_prefetcher(object):
                 i = self._slot(arrays)
                 host, devb, ev = self._ring[i]
                 for h, a in zip(host, arrays):
-                    h.copy_(t.from_numpy(np.ascontiguousarray(a, dtype=np.float32)))
+                    h.copy_(t.from_numpy(np.array(a, dtype=np.float32, order='C').reshape(tuple(h.shape))))
                 if self._cuda:
                     with t.cuda.stream(self._copy_stream):
                         for h, d in zip(host, devb):

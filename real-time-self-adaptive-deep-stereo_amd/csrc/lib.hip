@@ -104,6 +104,8 @@ static int run_op(const mh_op& o, void* s) {
             int32_t splits = i[23];
             return mh_conv2d_wgrad_partial(&d, (const float*)p[0], (const float*)p[1], i[21], (float*)p[2], &splits, (float*)p[3], s);
         }
+        case MH_OP_PROXY_LOSS:
+            return mh_proxy_loss((const float*)p[0], (const float*)p[1], (float*)p[2], (float*)p[3], (float*)p[4], o.f[0], o.f[1], i[0], i[1], i[2], s);
         case MH_OP_WGRAD_REDUCE:
             return mh_wgrad_reduce((const mh_wgrad_seg*)p[0], i[0], i[1], s);
         case MH_OP_CORR_FWD:

@@ -404,6 +404,53 @@ __global__ __launch_bounds__(256) void metrics_final_kernel(MetArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// proxy-label loss of the continual-adaptation variant: loss_factory.get_proxy_loss('mean_l1') (Losses/loss_factory.py:304-351)
+//   valid = !(proxy <= 0 || proxy >= 192) ; loss = weight * sum(valid * |pred - proxy|) / sum(valid)
+//   d loss / d pred = weight * valid * sign(pred - proxy) / sum(valid)       (tf.abs gradient: sign, 0 at 0)
+// ------------------------------------------------------------------------------------------
+struct ProxyArgs { const float* pred; const float* proxy; float* part; float* result; float* dpred; int64_t total; int nblk; float weight, gs; };
+
+__global__ __launch_bounds__(256) void proxy_partial_kernel(ProxyArgs p) {
+    __shared__ float red[4];
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float e = 0.f, v = 0.f;
+    if (q < p.total) {
+        const float px = p.proxy[q];
+        v = (px <= 0.f || px >= 192.f) ? 0.f : 1.f;
+        e = fabsf(p.pred[q] - px) * v;
+    }
+    const float se = block_sum(e, red);
+    const float sv = block_sum(v, red);
+    if (threadIdx.x == 0) { p.part[blockIdx.x * 2 + 0] = se; p.part[blockIdx.x * 2 + 1] = sv; }
+}
+
+__global__ __launch_bounds__(256) void proxy_final_kernel(ProxyArgs p) {
+    __shared__ double red[2][256];
+    double a = 0, c = 0;
+    for (int i = threadIdx.x; i < p.nblk; i += 256) { a += p.part[i * 2]; c += p.part[i * 2 + 1]; }
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        p.result[0] = (float)((double)p.weight * red[0][0] / red[1][0]);      // 0/0 = NaN like the TF graph
+        p.result[1] = (float)red[1][0];
+    }
+}
+
+__global__ __launch_bounds__(256) void proxy_grad_kernel(ProxyArgs p) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= p.total) return;
+    const float px = p.proxy[q];
+    const float v = (px <= 0.f || px >= 192.f) ? 0.f : 1.f;
+    const float d = p.pred[q] - px;
+    const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    p.dpred[q] = p.gs * p.weight * v * sgn / p.result[1];
+}
+
+// ------------------------------------------------------------------------------------------
 // momentum / glue
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void momentum_kernel(float* var, float* acc, const float* g, int64_t n, float lr, float mom, float gs) {
@@ -576,6 +623,20 @@ extern "C" int mh_metrics(const float* disp, const float* gt, float* ws, float* 
     hipLaunchKernelGGL(metrics_kernel, dim3(a.nblk), dim3(256), 0, s, a);
     hipLaunchKernelGGL(metrics_final_kernel, dim3(1), dim3(256), 0, s, a);
     return mh_check_launch("metrics");
+}
+
+extern "C" int64_t mh_proxy_ws_floats(int32_t B, int32_t H, int32_t W) { return 2 * nblk((int64_t)B * H * W); }
+
+extern "C" int mh_proxy_loss(const float* pred, const float* proxy, float* ws, float* result, float* dpred, float weight,
+                             float grad_scale, int32_t B, int32_t H, int32_t W, void* stream) {
+    MH_REQUIRE(pred && proxy && ws && result, MH_ERR_ARG, "mh_proxy_loss: null argument");
+    MH_REQUIRE(B > 0 && H > 0 && W > 0, MH_ERR_ARG, "mh_proxy_loss: bad dimension");
+    ProxyArgs a{pred, proxy, ws, result, dpred, (int64_t)B * H * W, (int)nblk((int64_t)B * H * W), weight, grad_scale};
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(proxy_partial_kernel, dim3(a.nblk), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(proxy_final_kernel, dim3(1), dim3(256), 0, s, a);
+    if (dpred) hipLaunchKernelGGL(proxy_grad_kernel, dim3(a.nblk), dim3(256), 0, s, a);
+    return mh_check_launch("proxy_loss");
 }
 
 extern "C" int mh_momentum(float* var, float* accum, const float* grad, int64_t n, float lr, float momentum,

@@ -29,7 +29,7 @@ class Op(C.Structure):
 
 (OP_CONV, OP_WGRAD, OP_CORR_FWD, OP_CORR_BWD, OP_WARP_FWD, OP_WARP_BWD, OP_RESIZE_FWD, OP_RESIZE_BWD,
  OP_PAD_REFLECT, OP_LOSS, OP_METRICS, OP_MOMENTUM, OP_COPY_CH, OP_LEAKY_BWD, OP_FILL, OP_BIAS_GRAD,
- OP_WGRAD_PARTIAL, OP_WGRAD_REDUCE) = range(1, 19)
+ OP_WGRAD_PARTIAL, OP_WGRAD_REDUCE, OP_PROXY_LOSS) = range(1, 20)
 
 
 OP_JOIN = 0x100
@@ -59,6 +59,8 @@ SIGNATURES = {
     "mh_conv2d_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _I, _P, _P, _P]),
     "mh_conv2d_wgrad_partial": (_I, [C.POINTER(ConvDesc), _P, _P, _I, _P, C.POINTER(C.c_int32), _P, _P]),
     "mh_wgrad_reduce": (_I, [_P, _I, _I, _P]),
+    "mh_proxy_ws_floats": (_L, [_I, _I, _I]),
+    "mh_proxy_loss": (_I, [_P, _P, _P, _P, _P, _F, _F, _I, _I, _I, _P]),
     "mh_corr_fwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mh_corr_bwd": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mh_warp_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -86,7 +88,7 @@ SIGNATURES = {
     "mh_event_destroy": (_I, [_P]),
     "mh_stream_sync": (_I, [_P]),
 }
-_NO_STATUS = {"mh_last_error", "mh_abi_version", "mh_crc32c", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats"}
+_NO_STATUS = {"mh_last_error", "mh_abi_version", "mh_crc32c", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats", "mh_proxy_ws_floats"}
 
 
 class MadnetHipError(RuntimeError):

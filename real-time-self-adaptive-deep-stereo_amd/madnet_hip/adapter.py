@@ -23,12 +23,22 @@ def softmax(x):
 class Adapter(object):
     def __init__(self, net, mode="MAD", block_config=None, lr=1e-4, momentum=0.9, sample_mode="PROBABILITY",
                  num_blocks=1, fixed_id=0, sample_frequency=1, ssim_th=0.5, reprojection_scale=1,
-                 use_graph=True, shared_model=False, process_group=None):
+                 use_graph=True, shared_model=False, process_group=None, loss="reprojection", dilation=1, decay=0.99, uf=0.01):
+        """loss='proxy', dilation, decay, uf: the continual-adaptation variant (Stereo_Continual_Adaptation.py:75-112,
+        205-249, 302-304): proxy-label mean_l1 loss, weight update only every `dilation`-th frame, reward update
+        sample_distribution = decay * sample_distribution (+ uf * gain on the last trained blocks)."""
         if mode not in ("NONE", "FULL", "MAD"):
             raise ValueError("mode must be NONE, FULL or MAD")
         if reprojection_scale != 1:
             raise NotImplementedError("reprojectionScale != 1 is not supported by the MI355X engine")
+        if loss not in ("reprojection", "proxy"):
+            raise ValueError("loss must be 'reprojection' or 'proxy'")
         self.net, self.eng, self.lib = net, net.engine, net._lib
+        self.loss, self.dilation, self.decay, self.uf = loss, max(1, int(dilation)), decay, uf
+        if loss == "proxy":
+            if not hasattr(self.eng, "proxy"):
+                raise NotImplementedError("the proxy-label loss is implemented for the MADNet engine")
+            self.eng.loss_kind = "proxy"
         self.mode, self.lr, self.momentum = mode, lr, momentum
         self.sample_frequency, self.ssim_th = sample_frequency, ssim_th
         self.shared, self.pg = shared_model, process_group
@@ -96,8 +106,10 @@ class Adapter(object):
             return []
         return sum((self.blocks[i][1] for i in key), [])
 
-    def step(self, left, right, gt=None):
+    def step(self, left, right, gt=None, proxy=None):
         eng = self.eng
+        if self.loss == "proxy" and proxy is None:
+            raise ValueError("loss='proxy' needs the proxy disparity map of every frame")
         # ---- sample the portion(s) of the network to train (Stereo_Online_Adaptation.py:181-189)
         if self.mode == "MAD" and self.step_count % self.sample_frequency == 0:
             distribution = softmax(self.sample_distribution)
@@ -105,6 +117,8 @@ class Adapter(object):
             for l in self.blocks_to_train:
                 self.fetch_counter[l] += 1
         key = "FULL" if self.mode == "FULL" else ("NONE" if self.mode == "NONE" else tuple(self.blocks_to_train))
+        if self.step_count % self.dilation != 0:        # Stereo_Continual_Adaptation.py:205: no update op on this frame
+            key = "NONE"
         plans = self._plan(key)
         sh = self.stream.cuda_stream if self.cuda else 0
         ctx = torch.cuda.stream(self.stream) if self.cuda else _null()
@@ -113,6 +127,8 @@ class Adapter(object):
             eng.right.copy_(_as(right, eng.right), non_blocking=True)
             if gt is not None:
                 eng.gt.copy_(_as(gt, eng.gt), non_blocking=True)
+            if proxy is not None:
+                eng.proxy.copy_(_as(proxy, eng.proxy), non_blocking=True)
             plans[0].launch(self.lib, sh)
             if self.shared:
                 for o, c in eng.params.ranges(self._train_vars(key)):
@@ -132,9 +148,9 @@ class Adapter(object):
                 self.loss_t_1 = new_loss
             expected_loss = 2 * self.loss_t_1 - self.loss_t_2
             gain_loss = expected_loss - new_loss
-            self.sample_distribution = 0.99 * self.sample_distribution
+            self.sample_distribution = self.decay * self.sample_distribution
             for i in self.last_trained_blocks:
-                self.sample_distribution[i] += 0.01 * gain_loss
+                self.sample_distribution[i] += self.uf * gain_loss
             self.last_trained_blocks = self.blocks_to_train
             self.loss_t_2 = self.loss_t_1
             self.loss_t_1 = new_loss

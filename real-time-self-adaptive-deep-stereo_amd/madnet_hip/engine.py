@@ -188,6 +188,10 @@ class MadNetEngine(object):
         self.loss_ws_k = z(self.lib.loss_ws_floats(B, self.H0, self.W0))
         self.met_ws = z(self.lib.metrics_ws_floats(B, self.H0, self.W0))
         self.res_loss = z(4); self.res_loss_k = z(4); self.res_met = z(4)
+        # continual-adaptation variant (loss_kind = 'proxy'): proxy labels + the mean_l1 loss workspace
+        self.proxy = z(B, self.H0, self.W0)
+        self.proxy_ws = z(self.lib.proxy_ws_floats(B, self.H0, self.W0))
+        self.loss_kind = "reprojection"
 
     # views -----------------------------------------------------------------------------------
     def _fv(self, t):
@@ -273,9 +277,13 @@ class MadNetEngine(object):
         ops.resize_fwd(lib, V, out, self.Hp, self.Wp, self.pt, self.pl, mul=-20.0, mode=1)
 
     def record_loss_metrics(self, r, with_grad):
-        """full-resolution reprojection loss (Stereo_Online_Adaptation.py:70) + EPE/bad3 (:74-82)."""
-        ops.reprojection_loss(r, self.left, self.right, self.pred, self.loss_ws, self.res_loss,
-                              self.dpred if with_grad else None)
+        """full-resolution reprojection loss (Stereo_Online_Adaptation.py:70) -- or, loss_kind 'proxy', the proxy-label
+        mean_l1 of the continual variant (Stereo_Continual_Adaptation.py:75, weight 0.01) -- + EPE/bad3 (:74-82)."""
+        if self.loss_kind == "proxy":
+            ops.proxy_loss(r, self.pred, self.proxy, self.proxy_ws, self.res_loss, self.dpred if with_grad else None, weight=0.01)
+        else:
+            ops.reprojection_loss(r, self.left, self.right, self.pred, self.loss_ws, self.res_loss,
+                                  self.dpred if with_grad else None)
         ops.metrics(r, self.pred, self.gt, self.met_ws, self.res_met, 3.0)
 
     # =========================================================================================
@@ -525,9 +533,13 @@ class MadNetEngine(object):
                 self.record_loss_metrics(r, with_grad=False)
             for lv, bv in blocks:
                 if do_grad:
-                    # reprojection loss of the block's prediction (Stereo_Online_Adaptation.py:98-107)
-                    ops.reprojection_loss(r, self.left, self.right, self.disp_k[lv], self.loss_ws_k, self.res_loss_k,
-                                          self.ddisp_k)
+                    # loss of the block's prediction: reprojection (Stereo_Online_Adaptation.py:98-107) or, continual
+                    # variant, proxy-label mean_l1 with weight 0.1 (Stereo_Continual_Adaptation.py:100-112)
+                    if self.loss_kind == "proxy":
+                        ops.proxy_loss(r, self.disp_k[lv], self.proxy, self.proxy_ws, self.res_loss_k, self.ddisp_k, weight=0.1)
+                    else:
+                        ops.reprojection_loss(r, self.left, self.right, self.disp_k[lv], self.loss_ws_k, self.res_loss_k,
+                                              self.ddisp_k)
                     self.record_backward(r, lv, bv, bulkhead=True)
                 if do_upd and part == "all":
                     self.record_update(r, bv, lr, grad_scale=grad_scale)
@@ -539,11 +551,13 @@ class MadNetEngine(object):
         return r.compile()
 
     # convenience: eager single forward -------------------------------------------------------
-    def set_inputs(self, left, right, gt=None):
+    def set_inputs(self, left, right, gt=None, proxy=None):
         self.left.copy_(torch.as_tensor(left, dtype=torch.float32).reshape(self.left.shape))
         self.right.copy_(torch.as_tensor(right, dtype=torch.float32).reshape(self.right.shape))
         if gt is not None:
             self.gt.copy_(torch.as_tensor(gt, dtype=torch.float32).reshape(self.gt.shape))
+        if proxy is not None:
+            self.proxy.copy_(torch.as_tensor(proxy, dtype=torch.float32).reshape(self.proxy.shape))
 
 
 def ops_fill(lib, t, off, count):

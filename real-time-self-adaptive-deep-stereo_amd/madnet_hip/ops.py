@@ -242,6 +242,12 @@ def reprojection_loss(lib, left, right, disp, ws, result, ddisp=None, grad_scale
     lib.reprojection_loss(_p(left), _p(right), _p(disp), _p(ws), _p(result), _p(ddisp), grad_scale, B, H, W, _p(stream))
 
 
+def proxy_loss(lib, pred, proxy, ws, result, dpred=None, weight=0.01, grad_scale=1.0, stream=None):
+    """result[0] = weight * mean_l1(pred, proxy, valid) (loss_factory.get_proxy_loss); dpred = its gradient (optional)."""
+    B, H, W = pred.shape[0], pred.shape[1], pred.shape[2]
+    lib.proxy_loss(_p(pred), _p(proxy), _p(ws), _p(result), _p(dpred), weight, grad_scale, B, H, W, _p(stream))
+
+
 def metrics(lib, disp, gt, ws, result, pixel_th=3.0, stream=None):
     B, H, W = disp.shape[0], disp.shape[1], disp.shape[2]
     lib.metrics(_p(disp), _p(gt), _p(ws), _p(result), pixel_th, B, H, W, _p(stream))

@@ -90,6 +90,9 @@ class Recorder(object):
     def reprojection_loss(self, left, right, disp, ws, result, ddisp, grad_scale, B, H, W, stream):
         self._op(_ffi.OP_LOSS, [B, H, W], [grad_scale], [left, right, disp, ws, result, ddisp])
 
+    def proxy_loss(self, pred, proxy, ws, result, dpred, weight, grad_scale, B, H, W, stream):
+        self._op(_ffi.OP_PROXY_LOSS, [B, H, W], [weight, grad_scale], [pred, proxy, ws, result, dpred])
+
     def metrics(self, disp, gt, ws, result, th, B, H, W, stream):
         self._op(_ffi.OP_METRICS, [B, H, W], [th], [disp, gt, ws, result])
 

@@ -46,3 +46,69 @@ def test_cli_end_to_end(hip, tmp_path, mode):
     assert d.dtype == np.uint16 and d.shape == (96, 160) and d.max() > 0
     if mode == "MAD":
         assert "fetch_counter,1,1,1,0,0" in stats          # SEQUENTIAL sampler over 3 frames
+
+
+def test_continual_cli_end_to_end(hip, tmp_path):
+    """Stereo_Continual_Adaptation.py plumbing: 4-column list with proxy labels, MAD + dilation 2,
+    overall.csv / series.csv / histogram.csv, --saveWeights writes a TF checkpoint that reads back."""
+    from PIL import Image
+    from madnet_hip import synthetic as S
+    import Stereo_Continual_Adaptation as SCA
+    from Data_utils import tf_checkpoint
+    rows = []
+    for t in range(4):
+        l, r, gt = S.make_pair(96, 160, frame=t)
+        names = [str(tmp_path / ("%s_%d.png" % (k, t))) for k in ("l", "r", "d", "p")]
+        Image.fromarray(l[0].astype(np.uint8)).save(names[0]); Image.fromarray(r[0].astype(np.uint8)).save(names[1])
+        Image.fromarray((gt[0, :, :, 0] * 256).astype(np.uint16)).save(names[2])
+        px = gt[0, :, :, 0].copy(); px[::3] = 0                       # proxy labels with holes
+        Image.fromarray((px * 256).astype(np.uint16)).save(names[3])
+        rows.append(";".join(names))
+    lst = tmp_path / "list.csv"
+    lst.write_text("# left;right;gt;proxy\n" + "\n".join(rows) + "\n")
+    out = tmp_path / "out"
+    os.makedirs(out / "disparities"); os.makedirs(out / "weights")
+    argv = ["-l", str(lst), "-o", str(out), "--weights", "calibrated:1", "--modelName", "MADNet",
+            "--blockConfig", os.path.join(PKG, "block_config", "MadNet_full.json"), "--mode", "MAD", "--sampleMode", "SEQUENTIAL",
+            "--imageShape", "96", "160", "--logDispStep", "2", "--SSIMTh", "1000", "--dilation", "2", "--saveWeights",
+            "--decay", "0.9", "--uf", "0.05"]
+    args = SCA.build_parser().parse_args(argv)
+    np.random.seed(0)
+    SCA.main(args)
+    overall = open(out / "overall.csv").read().split("\n")
+    assert overall[0] == "EPE\tD1" and len(overall[1].split("\t")) == 2
+    series = open(out / "series.csv").read().strip().split("\n")
+    assert series[0] == "step\tEPE\tD1" and len(series) == 5
+    assert open(out / "histogram.csv").read().startswith("Histogram\n[")
+    assert os.path.exists(out / "disparities" / "disparity_2.png")
+    ck = tf_checkpoint.latest_checkpoint(str(out / "weights"))
+    assert ck and ck.endswith("model-4")
+    r = tf_checkpoint.CheckpointReader(ck)
+    from madnet_hip import engine as E
+    names = [n for n, _ in E.madnet_manifest()]
+    assert all(r.has_tensor(n) and r.has_tensor(n + "/Momentum") for n in names)
+
+
+def test_adapter_dilation_updates_every_other_frame(hip):
+    """--dilation K: the weights move only on frames with step % K == 0 (Stereo_Continual_Adaptation.py:205)."""
+    import torch
+    import Nets
+    from madnet_hip import engine as E, synthetic as S
+    from madnet_hip.adapter import Adapter
+    H, W = 64, 128
+    wn = S.calibrated_weights(dict(E.madnet_manifest()), 1)
+    l, r, gt = S.make_pair(H, W)
+    tl, tr, tg = (torch.from_numpy(a).cuda() for a in (l, r, gt[..., 0]))
+    net = Nets.get_stereo_net("MADNet", {"left_img": tl, "right_img": tr, "split_layers": [None], "sequence": True,
+                                         "train_portion": "BEGIN", "bulkhead": False, "weights": wn})
+    ad = Adapter(net, mode="FULL", lr=1e-3, loss="proxy", dilation=2, ssim_th=1e9)
+    px = tg.clone(); px[:, ::4] = 0
+    moved = []
+    for _ in range(4):
+        w0 = net.engine.params.w.clone()
+        out = ad.step(tl, tr, tg, proxy=px)
+        assert np.isfinite(out["loss"])
+        moved.append(not torch.equal(w0, net.engine.params.w))
+    assert moved == [True, False, True, False]
+    with pytest.raises(ValueError):
+        ad.step(tl, tr, tg)                      # proxy labels are mandatory for loss='proxy'

@@ -185,3 +185,38 @@ def test_bf16_mode_end_to_end(hip):
     cos = torch.nn.functional.cosine_similarity(g16.flatten(), g32.flatten(), dim=0).item()
     assert cos >= 0.98, cos                       # the bf16 gradient points the same way
     assert not torch.equal(w16, w32)              # and it really is a different arithmetic
+
+
+def _proxy_from(gt, seed=3):
+    """Proxy labels = ground truth + noise, with holes (<= 0) and out-of-range values (>= 192) as the validity test expects."""
+    g = torch.Generator().manual_seed(seed)
+    px = gt[..., 0] + torch.randn(gt.shape[:-1], generator=g) * 1.5
+    px[torch.rand(px.shape, generator=g) < 0.3] = 0.0
+    px[0, :2, :5] = 200.0
+    return px
+
+
+@pytest.mark.parametrize("bname,size", [SIZES[0], pytest.param("hip", (128, 256), marks=pytest.mark.gpu, id="hip-128x256")])
+@pytest.mark.parametrize("mode,block", [("FULL", None), ("MAD", 4), ("MAD", 1)])
+def test_continual_proxy_step(bname, size, mode, block):
+    """The continual-adaptation variant (Stereo_Continual_Adaptation.py): proxy-label mean_l1 loss, weight 0.01 on the
+    full loss / 0.1 on a MAD block's loss, same backward + momentum machinery."""
+    backend = _backend(bname)
+    if bname == "emul" and block == 1:
+        pytest.skip("CPU emulator: one MAD block (time)")
+    eng, wn, wt, acc, (l, r, gt) = _setup(backend, *size)
+    px = _proxy_from(gt)
+    eng.loss_kind = "proxy"
+    eng.set_inputs(l, r, gt[..., 0], proxy=px)
+    lr = 1e-2
+    if mode == "FULL":
+        plan = eng.build_plan("FULL", lr=lr)
+        o = OM.step(wt, acc, l, r, gt, mode="FULL", lr=lr, loss="proxy", proxy=px[..., None])
+    else:
+        blocks = json.load(open(os.path.join(PKG, "block_config", "MadNet_full.json")))
+        lv = OM.layer_variables()
+        bv = sum([lv[n] for n in blocks[block]], [])
+        plan = eng.build_plan("MAD", lr=lr, block_vars=bv, block_level=E.LEVELS[block])
+        o = OM.step(wt, acc, l, r, gt, mode="MAD", block_vars=bv, block_index=block, lr=lr, loss="proxy", proxy=px[..., None])
+    plan.run(backend.lib, 0)
+    _check(eng, wn, wt, o, backend)

@@ -249,3 +249,27 @@ def test_bias_grad_column_sums(backend, case):
     ops.bias_grad(backend.lib, v, db)
     backend.sync()
     assert (db.cpu().double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("shape", [(1, 9, 14), (2, 12, 21), (1, 40, 70)])
+def test_proxy_loss_and_grad(backend, shape):
+    """Continual-adaptation loss: weight * masked mean L1 against proxy labels; proxies <= 0 or >= 192 are invalid."""
+    B, H, W = shape
+    dev = backend.device
+    g = torch.Generator().manual_seed(17)
+    pred = (torch.rand(B, H, W, generator=g) * 200 - 4).to(dev)
+    proxy = (torch.rand(B, H, W, generator=g) * 230 - 20)
+    proxy[0, 0, :3] = torch.tensor([0.0, 192.0, 191.99])          # boundary values of the validity test
+    pred[0, 1, 0] = proxy[0, 1, 0]                                  # |x| at 0: zero gradient
+    proxy = proxy.to(dev)
+    pc = pred.cpu().requires_grad_(True)
+    ref = T.proxy_loss(pc, proxy.cpu(), 0.1)
+    (gref,) = torch.autograd.grad(ref, [pc])
+    ws = torch.zeros(backend.lib.proxy_ws_floats(B, H, W), device=dev)
+    res = torch.zeros(4, device=dev); dp = torch.full((B, H, W), float("nan"), device=dev)
+    ops.proxy_loss(backend.lib, pred, proxy, ws, res, dp, weight=0.1, grad_scale=1.0)
+    backend.sync()
+    assert abs(res[0].item() - ref.item()) <= 2e-6 * max(1.0, abs(ref.item()))
+    valid = ((proxy.cpu() > 0) & (proxy.cpu() < 192)).sum().item()
+    assert res[1].item() == float(valid)
+    ok, err = _close(dp, gref, rtol=1e-5, atol=1e-9); assert ok, err
