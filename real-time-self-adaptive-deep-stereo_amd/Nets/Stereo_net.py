@@ -27,114 +27,87 @@ class Variable(object):
 
 
 class StereoNet(object):
+    """Registry of named layers (torch tensors backed by engine buffers), of the variables each layer owns, and of the
+    disparity outputs; subclasses fill it in `_build_network`.  Public surface = Nets/Stereo_net.py:141-222."""
+    _netName = "stereoNet"
     _valid_args = [
         ("split_layer", "name of the layer where the network will be splitted"),
         ("sequence", "flag to use network on a video sequence instead of on single images"),
         ("train_portion", "one among 'BEGIN' or 'END' specify which portion of the network will be trained"),
         ("is_training", "boolean to specify if the network is in train or inference mode"),
     ]
-    _netName = "stereoNet"
+    # kwarg -> default when the caller omits it (the reference prints a warning and carries on, Stereo_net.py:141-157)
+    _DEFAULTS = (("split_layers", [None]), ("sequence", False), ("is_training", False))
 
     @classmethod
-    def getPossibleArsg(cls):
+    def getPossibleArsg(cls):          # (sic: the reference's spelling)
         return cls._valid_args
 
     def __init__(self, **kwargs):
-        self._layers = OrderedDict()
-        self._disparities = []
-        self._placeholders = []
-        self._placeholderable = []
-        self._trainable_variables = OrderedDict()
-        self._layer_to_var = {}
-        self._after_split = False
-        print('=' * 50)
-        print('Starting Creation of {}'.format(self._netName))
-        print('=' * 50)
+        self._layers, self._layer_to_var = OrderedDict(), {}
+        self._disparities, self._placeholders = [], []
+        self._trainable = OrderedDict()
+        bar = "=" * 50
+        print("%s\nbuilding %s on the MI355X engine\n%s" % (bar, self._netName, bar))
         args = self._validate_args(kwargs)
-        print('Args Validated, setting up graph')
         self._preprocess_inputs(args)
-        print('Meta op to preprocess data created')
         self._build_network(args)
-        print('Network ready')
-        print('=' * 50)
+        print("%s ready: %d layers, %d disparity outputs\n%s" % (self._netName, len(self._layers), len(self._disparities), bar))
 
-    # ------------------------------------------------------------------ registry helpers
-    def _get_placeholder_name(self, name):
-        return name + '_placeholder'
+    # ---- argument handling ------------------------------------------------------------------------------------------
+    def _validate_args(self, args):
+        for key, default in self._DEFAULTS:
+            if key not in args:
+                print("WARNING: %s not given, using %r" % (key, default))
+                args[key] = default
+        if args["split_layers"] != [None]:
+            raise NotImplementedError("split_layers / placeholders are not supported by the MI355X engine "
+                                      "(no reference driver enables them)")
+        portion = args.setdefault("train_portion", "BEGIN")
+        if portion not in ("BEGIN", "END"):
+            raise Exception("Invalid portion options {}".format(portion))
+        # with no split point every layer lies "before the split": BEGIN = all trainable, END = none (Stereo_net.py:63-67)
+        self._trainable_portion = (portion == "BEGIN")
+        self._sequence = bool(args["sequence"])
+        return args
 
-    def _add_to_layers(self, name, op, variables=()):
-        """Register `op` (a tensor) under `name` with the variables created in its scope."""
-        self._layers[name] = op
-        variables = list(variables)
-        self._layer_to_var[name] = variables
-        if not self._after_split:
-            self._placeholderable.append(name)
-        if self._after_split != self._train_beginning:
-            for v in variables:
-                self._trainable_variables[v] = True
-        if name in self._split_layers_list:
-            self._after_split = True
-
-    def _get_layer_as_input(self, name):
-        if self._get_placeholder_name(name) in self._layers:
-            return self._layers[self._get_placeholder_name(name)]
-        if name in self._layers:
-            return self._layers[name]
-        raise Exception('Trying to fetch an unknown layer!')
-
-    def __str__(self):
-        ss = ""
-        for k, l in self._layers.items():
-            kind = "Prediction Layer" if any(l is d for d in self._disparities) else "Layer"
-            ss += "{} {}: {}\n".format(kind, k, str(tuple(l.shape)))
-        return ss
-
-    __repr__ = __str__
-
-    def __getitem__(self, key):
-        return self._layers[key]
-
-    # ------------------------------------------------------------------ to be provided by subclasses
     def _preprocess_inputs(self, args):
         raise NotImplementedError
 
     def _build_network(self, args):
         raise NotImplementedError
 
-    def _validate_args(self, args):
-        portion_options = ['BEGIN', 'END']
-        if 'split_layers' not in args:
-            print('WARNING: no split points selected, the network will flow without interruption')
-            args['split_layers'] = [None]
-        if 'train_portion' not in args:
-            print('WARNING: train_portion not specified, using default END')
-            args['train_portion'] = 'END' if args['split_layers'] != [None] else 'BEGIN'
-        elif args['train_portion'] not in portion_options:
-            raise Exception('Invalid portion options {}'.format(args['train_portion']))
-        if 'sequence' not in args:
-            print('WARNING: sequence flag not setted, configuring the network for single image adaptation')
-            args['sequence'] = False
-        if 'is_training' not in args:
-            print('WARNING: flag for trainign not setted, using default False')
-            args['is_training'] = False
-        if args['split_layers'] != [None]:
-            raise NotImplementedError('split_layers / placeholders are not supported by the MI355X engine '
-                                      '(no reference driver enables them)')
-        self._split_layers_list = args['split_layers']
-        self._train_beginning = (args['train_portion'] == 'BEGIN')
-        self._sequence = args['sequence']
-        self._isTraining = False
-        return args
+    # ---- registry ---------------------------------------------------------------------------------------------------------
+    def _add_to_layers(self, name, op, variables=()):
+        """`op`: tensor of the layer; `variables`: the trainable variables created in the layer's scope."""
+        owned = list(variables)
+        self._layers[name] = op
+        self._layer_to_var[name] = owned
+        if self._trainable_portion:
+            self._trainable.update((v, True) for v in owned)
 
-    # ------------------------------------------------------------------ public getters (Stereo_net.py:166-222)
+    def _get_layer_as_input(self, name):
+        try:
+            return self._layers[name]
+        except KeyError:
+            raise Exception("Trying to fetch an unknown layer!")
+
+    def __getitem__(self, key):
+        return self._layers[key]
+
+    def __str__(self):
+        is_pred = lambda t: any(t is d for d in self._disparities)
+        return "".join("%s %s: %s\n" % ("Prediction Layer" if is_pred(t) else "Layer", k, tuple(t.shape))
+                       for k, t in self._layers.items())
+
+    __repr__ = __str__
+
+    # ---- public getters ----------------------------------------------------------------------------------------------------
     def get_placeholders(self):
-        return self._placeholders
+        return self._placeholders                  # always empty: no split point, no placeholders
 
     def get_placeholder(self, name):
-        placeholder_name = self._get_placeholder_name(name)
-        if placeholder_name not in self._layers:
-            raise Exception('Unable to find placeholder for layer {}'.format(placeholder_name))
-        return self._layers[placeholder_name]
+        raise Exception("Unable to find placeholder for layer {}".format(name + "_placeholder"))
 
     def get_all_layers(self):
         return self._layers
@@ -146,7 +119,7 @@ class StereoNet(object):
         return self._disparities
 
     def get_trainable_variables(self):
-        return list(self._trainable_variables.keys())
+        return list(self._trainable)
 
     def get_variables(self, layer_name):
         if layer_name in self._layers and layer_name not in self._layer_to_var:

@@ -1,15 +1,15 @@
-"""Construction API of the reference kept verbatim (Nets/__init__.py:4-12):
-Nets.get_stereo_net(name, args), Nets.STEREO_FACTORY."""
-import Nets.DispNet
-import Nets.MadNet
+"""Model registry of the package -- the same two public names as the reference's Nets/__init__.py:4-12:
+`STEREO_FACTORY` (display name -> class) and `get_stereo_net(name, args)` (build a model from a kwargs dict)."""
+from Nets import DispNet as _dispnet, MadNet as _madnet
 
-STEREO_FACTORY = {
-    Nets.DispNet.DispNet._netName: Nets.DispNet.DispNet,
-    Nets.MadNet.MadNet._netName: Nets.MadNet.MadNet,
-}
+# keyed by each class's own `_netName` ("Dispnet", "MADNet"), i.e. the strings the --modelName flag accepts
+STEREO_FACTORY = {cls._netName: cls for cls in (_dispnet.DispNet, _madnet.MadNet)}
 
 
 def get_stereo_net(name, args):
-    if name not in STEREO_FACTORY:
+    """Instantiate the registered model `name` with the keyword arguments in the dict `args`."""
+    try:
+        model_cls = STEREO_FACTORY[name]
+    except KeyError:
         raise Exception('Unrecognized network name: {}'.format(name))
-    return STEREO_FACTORY[name](**args)
+    return model_cls(**args)

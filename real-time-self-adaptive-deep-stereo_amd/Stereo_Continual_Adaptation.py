@@ -94,28 +94,28 @@ def main(args):
 
 
 def build_parser():
-    parser = argparse.ArgumentParser(description='Script for online Adaptation of a Deep Stereo Network')
-    parser.add_argument("-l", "--list", help='path to the list file with frames to be processed', required=True)
-    parser.add_argument("-o", "--output", help="path to the output folder where the results will be saved", required=True)
-    parser.add_argument("--weights", help="path to the initial weights for the disparity estimation network", required=True)
-    parser.add_argument("--modelName", help="name of the stereo model to be used", default="Dispnet", choices=Nets.STEREO_FACTORY.keys())
-    parser.add_argument("--numBlocks", help="number of CNN portions to train at each iteration", type=int, default=1)
-    parser.add_argument("--lr", help="value for learning rate", default=0.0001, type=float)
-    parser.add_argument("--blockConfig", help="path to the block_config json file", required=True)
-    parser.add_argument("--sampleMode", help="choose the sampling heuristic to use", choices=sampler_factory.AVAILABLE_SAMPLER, default='SAMPLE')
-    parser.add_argument("--fixedID", help="index of the portions of network to train, used only if sampleMode=FIXED", type=int, nargs='+', default=[0])
-    parser.add_argument("--reprojectionScale", help="compute all loss function at 1/reprojectionScale", default=1, type=int)
-    parser.add_argument("--summary", help='flag to enable tensorboard summaries', action='store_true')
-    parser.add_argument("--imageShape", help='two int for image shape [height,width]', nargs='+', type=int, default=[320, 1216])
-    parser.add_argument("--SSIMTh", help="reset network to initial configuration if loss is above this value", type=float, default=0.5)
-    parser.add_argument("--sampleFrequency", help="sample new network portions to train every K frame", type=int, default=1)
-    parser.add_argument("--mode", help="online adaptation mode: NONE - perform only inference, FULL - full online backprop, MAD - backprop only on portions of the network", choices=['NONE', 'FULL', 'MAD'], default='MAD')
-    parser.add_argument("--logDispStep", help="save disparity every K step, -1 to disable", default=-1, type=int)
-    parser.add_argument("--eval", help="eval mode: DISP or DEPTH", choices=['DISP', 'DEPTH', 'SSIM'], default='DISP')
-    parser.add_argument("--saveWeights", help="save the adapted model", action='store_true')
-    parser.add_argument("--dilation", help="update the weights every K frames", type=int, default=1)
-    parser.add_argument("--decay", help="decay of the sampling logits", type=float, default=0.99)
-    parser.add_argument("--uf", help="update factor of the sampling logits", type=float, default=0.01)
+    parser = argparse.ArgumentParser(description='Online adaptation of a deep stereo network on the MI355X engine')
+    parser.add_argument("-l", "--list", help="CSV list of the frames to process (left,right,gt[,proxy] per row)", required=True)
+    parser.add_argument("-o", "--output", help="folder that receives the reports (created if missing)", required=True)
+    parser.add_argument("--weights", help="initial weights: TF checkpoint prefix, .npz of TF-named variables, xavier[:seed] or calibrated[:seed]", required=True)
+    parser.add_argument("--modelName", help="which registered stereo network to build", default="Dispnet", choices=Nets.STEREO_FACTORY.keys())
+    parser.add_argument("--numBlocks", help="how many network portions are trained per frame (MAD)", type=int, default=1)
+    parser.add_argument("--lr", help="SGD-with-momentum learning rate", default=0.0001, type=float)
+    parser.add_argument("--blockConfig", help="json file listing the layers of every trainable portion", required=True)
+    parser.add_argument("--sampleMode", help="strategy that picks the portions to train", choices=sampler_factory.AVAILABLE_SAMPLER, default='SAMPLE')
+    parser.add_argument("--fixedID", help="portion indices for --sampleMode FIXED", type=int, nargs='+', default=[0])
+    parser.add_argument("--reprojectionScale", help="losses at 1/scale resolution (only 1 is supported here)", default=1, type=int)
+    parser.add_argument("--summary", help="accepted for compatibility; no TensorBoard summaries are written", action='store_true')
+    parser.add_argument("--imageShape", help="height width every frame is centre-cropped / zero-padded to", nargs='+', type=int, default=[320, 1216])
+    parser.add_argument("--SSIMTh", help="restore the initial weights when the loss exceeds this value", type=float, default=0.5)
+    parser.add_argument("--sampleFrequency", help="draw new portions every K frames", type=int, default=1)
+    parser.add_argument("--mode", help="NONE = inference only, FULL = full back-propagation, MAD = modular adaptation", choices=['NONE', 'FULL', 'MAD'], default='MAD')
+    parser.add_argument("--logDispStep", help="dump the disparity every K frames (-1: never)", default=-1, type=int)
+    parser.add_argument("--eval", help="accepted for compatibility", choices=['DISP', 'DEPTH', 'SSIM'], default='DISP')
+    parser.add_argument("--saveWeights", help="write the adapted weights as a TF checkpoint under <output>/weights", action='store_true')
+    parser.add_argument("--dilation", help="update the weights only every K-th frame", type=int, default=1)
+    parser.add_argument("--decay", help="multiplicative decay of the sampling logits", type=float, default=0.99)
+    parser.add_argument("--uf", help="gain of the reward added to the logits of the last trained portions", type=float, default=0.01)
     return parser
 
 
