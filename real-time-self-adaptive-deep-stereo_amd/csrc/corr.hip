@@ -269,12 +269,77 @@ __global__ __launch_bounds__(256) void corr_bwd_kernel(CorrBwdArgs p) {
     }
 }
 
+// Large shift counts (DispNet, D = 81) on the matrix cores: out[x][d] = mean_c L[x][c] * R[x + d - md][c] is the band
+// |x' - x| <= md of the row-wise product L_row (W x C) * R_row^T (C x W).  One workgroup = one 64-pixel row segment,
+// one wave = 16 pixels; the right-feature window [x0 - md, x0 + 64 + md) is staged once in LDS (k-contiguous rows,
+// +4 floats of padding), the wave's left tile stays in registers as MFMA A operands, and the wave walks the
+// ceil((2 md + 16) / 16) 16-column blocks of its band with exact-fp32 v_mfma_f32_16x16x4_f32 (each lane feeds 4 MFMAs
+// from one ds_read_b128: the k permutation k = s*16 + (lane>>4)*4 + t is the same for both operands).  Band overhead
+// (2md+16)/(2md+1) = 1.19x of the useful MACs; the kernel is HBM-bound on L + R + the D-channel output.
+template <int CS16>     // C / 16 (compile time so the A tile stays in registers)
+__global__ __launch_bounds__(256) void corr_fwd_mfma(CorrArgs p) {
+    HIP_DYNAMIC_SHARED(float, smem)                   // [rows][C + 4]
+    constexpr int C = CS16 * 16, RS = C + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int seg = blockIdx.x % p.segs;
+    const int row = blockIdx.x / p.segs;              // b*H + y
+    const int x0 = seg * 64;
+    const int nb = (2 * p.md + 16 + 15) / 16;         // 16-column blocks per wave
+    const int rows = 48 + 16 * nb;                    // window rows any wave touches
+    const __amdgpu_buffer_rsrc_t rsL = mh_make_rsrc(p.L, p.l_bytes);
+    const __amdgpu_buffer_rsrc_t rsR = mh_make_rsrc(p.R, p.r_bytes);
+    // stage the right window (zeros outside the image row = correlation_tf's zero padding)
+    for (int q = tid; q < rows * (C / 4); q += 256) {
+        const int xw = q / (C / 4), c4 = q - xw * (C / 4);
+        const int xs = x0 - p.md + xw;
+        const bool ok = xs >= 0 && xs < p.W;
+        const float4 v = mh_buf_load4(rsR, ok ? ((row * p.W + xs) * p.r_ld + c4 * 4) * 4 : MH_OOB);
+        *reinterpret_cast<float4*>(smem + xw * RS + c4 * 4) = v;
+    }
+    // this wave's left tile: pixel xb + li, channels s*16 + lq*4 .. +3
+    const int xb = x0 + 16 * wave;
+    float4 a[CS16];
+    {
+        const bool ok = xb + li < p.W;
+#pragma unroll
+        for (int s = 0; s < CS16; ++s)
+            a[s] = mh_buf_load4(rsL, ok ? ((row * p.W + xb + li) * p.l_ld + s * 16 + lq * 4) * 4 : MH_OOB);
+    }
+    __syncthreads();
+    const float inv_c = 1.0f / (float)C;
+    for (int blk = 0; blk < nb; ++blk) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* Rb = smem + (16 * wave + 16 * blk + li) * RS + lq * 4;
+#pragma unroll
+        for (int s = 0; s < CS16; ++s) {
+            const float4 b = *reinterpret_cast<const float4*>(Rb + s * 16);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].w, b.w, acc, 0, 0, 0);
+        }
+        // acc[r]: row = pixel xb + 4*lq + r, column = window pixel 16*wave + 16*blk + li  ->  shift index d
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int x = xb + 4 * lq + r;
+            const int d = 16 * blk + li - (4 * lq + r);
+            if (x < p.W && d >= 0 && d < p.D) p.out[(int64_t)(row * p.W + x) * p.out_ld + p.coff + d] = acc[r] * inv_c;
+        }
+    }
+}
+
 }  // namespace
 
 int mh_corr_init() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_large<32>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e != hipSuccess) { mh_set_error("corr: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+#define MH_CORR_ATTR(CSv)                                                                                                     \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_mfma<CSv>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+    if (e != hipSuccess) { mh_set_error("corr: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    MH_CORR_ATTR(1) MH_CORR_ATTR(2) MH_CORR_ATTR(4) MH_CORR_ATTR(8) MH_CORR_ATTR(16)
+#undef MH_CORR_ATTR
     return 0;
 }
 
@@ -323,6 +388,21 @@ extern "C" int mh_corr_fwd(const float* L, int32_t l_ld, const float* R, int32_t
         if (C4 <= 4) hipLaunchKernelGGL((corr_fwd_small<4, 64>), grid, dim3(256), lds, s, a);
         else if (C4 <= 8) hipLaunchKernelGGL((corr_fwd_small<8, 64>), grid, dim3(256), lds, s, a);
         else hipLaunchKernelGGL((corr_fwd_small<16, 64>), grid, dim3(256), lds, s, a);
+    } else if (g_corr_direct && stride == 1 && !copy_left && !u && !zero_tail && (C == 16 || C == 32 || C == 64 || C == 128 || C == 256) &&
+               lb < (1ll << 31) - 64 && rb < (1ll << 31) - 64 &&
+               (size_t)(48 + 16 * ((2 * max_disp + 31) / 16)) * (C + 4) * sizeof(float) <= 150 * 1024) {
+        a.l_bytes = (unsigned)lb; a.r_bytes = (unsigned)rb;
+        a.segs = mh_cdiv(W, 64);
+        const size_t lds = (size_t)(48 + 16 * ((2 * max_disp + 31) / 16)) * (C + 4) * sizeof(float);
+        const dim3 grid(a.segs * B * H);
+        switch (C) {
+            case 16: hipLaunchKernelGGL((corr_fwd_mfma<1>), grid, dim3(256), lds, s, a); break;
+            case 32: hipLaunchKernelGGL((corr_fwd_mfma<2>), grid, dim3(256), lds, s, a); break;
+            case 64: hipLaunchKernelGGL((corr_fwd_mfma<4>), grid, dim3(256), lds, s, a); break;
+            case 128: hipLaunchKernelGGL((corr_fwd_mfma<8>), grid, dim3(256), lds, s, a); break;
+            default: hipLaunchKernelGGL((corr_fwd_mfma<16>), grid, dim3(256), lds, s, a); break;
+        }
+        return mh_check_launch("corr_fwd_mfma");
     } else {
         const int TW = 32;
         a.segs = mh_cdiv(W, TW);
