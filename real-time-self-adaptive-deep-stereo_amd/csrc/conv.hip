@@ -613,6 +613,125 @@ static int launch_conv_n1(ConvArgs& a, hipStream_t s) {
     return mh_check_launch("conv_n1_fwd");
 }
 
+// ---- thin full-resolution layers (3x3, Cin <= 32, Cout 16 / 32, many pixels): weights-stationary direct conv ----------
+// The tiled kernel spends its time on LDS staging and barriers for K-walks of 1-5 tiles (35 us for 1.1 GFLOP).  Here a
+// wave keeps the WHOLE filter bank as bf16 MFMA B operands in registers (taps*Cin <= 288 k-values = 9 steps x NT x 4
+// VGPRs), streams 16-pixel tiles, and gathers each A operand straight from global memory into the MFMA layout: lane
+// (pixel i, quarter q) needs 8 consecutive k = two 4-channel groups of the flattened (tap, channel) axis = two 16-byte
+// loads.  No LDS, no barrier; the 9x tap re-reads are L1/L2 hits.  bf16 mode only (the fp32 parity path keeps the
+// tiled exact-fp32 kernel).  DGRAD = stride-1 input gradient (flipped gather, transposed weights, fused mask).
+template <int NT, bool DGRAD>
+__global__ __launch_bounds__(256) void conv_thin_kernel(ConvArgs p) {
+    constexpr int MAXS = 9;
+    const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+    const int G = p.G;                                   // power of two (1, 2, 4, 8)
+    int gshift = 0;
+    while ((1 << gshift) < G) ++gshift;
+    const int ngroups = p.taps * G;
+    const int nsteps = (ngroups + 7) >> 3;
+    // filter bank -> registers (B operand: lane (n = li, q) holds k = 8q .. 8q+7 of every 32-k step)
+    u32x4 bw[MAXS][NT];
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float w8[8];
+            const int n = j * 16 + li;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int g = 8 * s + 2 * lq + (e >> 2);
+                const int tap = g >> gshift, k = (g & (G - 1)) * 4 + (e & 3);
+                const bool ok = s < nsteps && g < ngroups && k < p.K && n < p.N;
+                w8[e] = ok ? p.w[DGRAD ? (tap * p.N + n) * p.K + k : (tap * p.K + k) * p.N + n] : 0.f;
+            }
+            bw[s][j] = (u32x4){mh_pack_bf16(w8[0], w8[1]), mh_pack_bf16(w8[2], w8[3]), mh_pack_bf16(w8[4], w8[5]), mh_pack_bf16(w8[6], w8[7])};
+        }
+    float bias[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bias[j] = (p.bias && j * 16 + li < p.N) ? p.bias[j * 16 + li] : 0.f;
+    const __amdgpu_buffer_rsrc_t rs_in = mh_make_rsrc(p.in, p.in_bytes);
+    const bool kpad = (p.K & 3) != 0;                    // Cin = 3: the 4th lane of a group is padding
+    const int ntiles = (p.M + 15) >> 4;
+    const int nwaves = gridDim.x * 4;
+    for (int tile = blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += nwaves) {
+        const int m = tile * 16 + li;
+        const bool rowok = m < p.M;
+        const int mm = rowok ? m : 0;
+        const int ox = mm % p.Wo, t2 = mm / p.Wo;
+        const int oy = t2 % p.Ho, b = t2 / p.Ho;
+        const int by = DGRAD ? oy + p.pad_t : oy * p.stride - p.pad_t;
+        const int bx = DGRAD ? ox + p.pad_l : ox * p.stride - p.pad_l;
+        const int img = b * p.Hi * p.Wi;
+        f32x4 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+            if (s < nsteps) {                            // uniform
+                float4 v[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int g = 8 * s + 2 * lq + h;
+                    const int tap = g >> gshift, c4 = g & (G - 1);
+                    const int ky = (tap * 11) >> 5, kx = tap - ky * 3;          // tap / 3, tap % 3 for tap < 9 (+ past-the-end groups)
+                    const int iy = DGRAD ? by - ky : by + ky, ix = DGRAD ? bx - kx : bx + kx;
+                    const bool ok = rowok && g < ngroups && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+                    v[h] = mh_buf_load4(rs_in, ok ? ((img + iy * p.Wi + ix) * p.in_ld + c4 * 4) * 4 : MH_OOB);
+                }
+                if (kpad) { v[0].w = 0.f; v[1].w = 0.f; v[0].z = p.K > 2 ? v[0].z : 0.f; v[1].z = p.K > 2 ? v[1].z : 0.f;
+                            v[0].y = p.K > 1 ? v[0].y : 0.f; v[1].y = p.K > 1 ? v[1].y : 0.f; }
+                const u32x4 a = (u32x4){mh_pack_bf16(v[0].x, v[0].y), mh_pack_bf16(v[0].z, v[0].w), mh_pack_bf16(v[1].x, v[1].y), mh_pack_bf16(v[1].z, v[1].w)};
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = mh_mfma_bf16(a, bw[s][j], acc[j]);
+            }
+        }
+        // epilogue: lane holds column n = j*16 + li of the tile rows 4*lq + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int mo = tile * 16 + 4 * lq + r;
+            if (mo >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = j * 16 + li;
+                if (n >= p.N) continue;
+                float val = acc[j][r] + bias[j];
+                if (p.alpha != 1.0f) val = val > 0.f ? val : p.alpha * val;
+                float* dst = p.out + (int64_t)mo * p.out_ld + n;
+                if (p.accumulate) val += *dst;
+                if (p.mask_ref && n >= p.mask_c0 && n < p.mask_c1) val *= (p.mask_ref[(int64_t)mo * p.mask_ld + n] > 0.f) ? 1.0f : p.mask_alpha;
+                *dst = val;
+            }
+        }
+    }
+}
+
+static int g_thin_min_m = 16384;   // tuning hook (mh_tune_conv_thin): pixel count from which the weights-stationary kernel is used; < 0 = never
+
+static bool conv_thin_ok(const ConvArgs& a) {
+    const bool g_pow2 = a.G == 1 || a.G == 2 || a.G == 4 || a.G == 8;
+    // Measured (MADNet pyramid, us per launch, tiled kernel -> this one): 3->16 s2 @ 245760 px 44 -> 21, 16->16 33 -> 35,
+    // 16->32 s2 @ 61440 px 13.5 -> 40, 32->32 14.6 -> 58: every wave rebuilds the filter bank (8 scalar loads per lane per
+    // step), which only amortises for the 2-step image layer.  The default therefore takes Cin <= 4 forward layers only;
+    // mh_tune_conv_thin(n > 0) lifts the restriction for tests / experiments.
+    const bool wide_ok = g_thin_min_m != 16384;
+    return g_thin_min_m >= 0 && a.bf16 && a.vecA && a.kh == 3 && a.kw == 3 && a.dil == 1 && g_pow2 && (a.N == 16 || a.N == 32) &&
+           ((a.mode == 0 && a.stride <= 2) || (a.mode == 1 && a.stride == 1)) && a.M >= g_thin_min_m &&
+           (wide_ok || (a.G == 1 && a.mode == 0));
+}
+
+static int launch_conv_thin(ConvArgs& a, hipStream_t s) {
+    int grid = mh_cdiv(mh_cdiv(a.M, 16), 4);
+    if (grid > 256 * 8) grid = 256 * 8;
+    if (a.mode == 0) {
+        if (a.N <= 16) hipLaunchKernelGGL((conv_thin_kernel<1, false>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_thin_kernel<2, false>), dim3(grid), dim3(256), 0, s, a);
+    } else {
+        if (a.N <= 16) hipLaunchKernelGGL((conv_thin_kernel<1, true>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_thin_kernel<2, true>), dim3(grid), dim3(256), 0, s, a);
+    }
+    return mh_check_launch("conv_thin");
+}
+
 static bool g_no_uni = false;    // tuning hook: disable the uniform-tap fast path (A/B experiments)
 static bool g_split_k = true;    // tuning hook: intra-workgroup split-K of the small tiles
 static bool g_parity_classes = true;   // tuning hook: stride-2 dgrad as 4 parity-class sub-problems
@@ -705,6 +824,7 @@ static int forced_bm() {
     if (g_force_bm < 0) { const char* e = getenv("MH_CONV_BM"); g_force_bm = e ? atoi(e) : 0; }
     return g_force_bm;
 }
+extern "C" int mh_tune_conv_thin(int min_pixels) { g_thin_min_m = min_pixels == 0 ? 16384 : min_pixels; return 0; }
 extern "C" int mh_tune_conv_tile(int bm, int bn) {
     g_force_bm = bm & 0xffff; g_force_bn = bn & 0xffff; g_force_kt = bn >> 16;
     g_no_uni = ((bm >> 16) & 1) != 0;      // bit 16 of bm: disable the uniform-tap fast path
@@ -859,5 +979,6 @@ extern "C" int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w,
     a.vecA = mh_aligned16(in) && (d->in_ld % 4 == 0) && (d->in_ld >= a.G * 4);
     a.vecB = mh_aligned16(w) && (d->w_trans ? (d->K % 4 == 0) : (d->N % 4 == 0));
     if (conv_n1_ok(a)) return launch_conv_n1(a, (hipStream_t)stream);
+    if (conv_thin_ok(a)) return launch_conv_thin(a, (hipStream_t)stream);
     return conv_dispatch(a, (hipStream_t)stream);
 }

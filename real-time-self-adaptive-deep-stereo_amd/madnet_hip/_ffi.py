@@ -53,6 +53,7 @@ SIGNATURES = {
     "mh_device_count": (_I, []),
     "mh_init": (_I, []),
     "mh_tune_conv_tile": (_I, [_I, _I]),
+    "mh_tune_conv_thin": (_I, [_I]),
     "mh_tune_wgrad_wgs": (_I, [_I]),
     "mh_tune_corr": (_I, [_I]),
     "mh_conv2d": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),

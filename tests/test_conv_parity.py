@@ -272,3 +272,42 @@ def test_conv_bf16_big_tiles(backend, tile, shape):
         backend.lib.tune_conv_tile(0, 0)
     assert (y.cpu() - y_ref).abs().max().item() <= 1e-4 * max(1.0, y_ref.abs().max().item())
     assert (dxb[..., :Ci].cpu() - gx_ref).abs().max().item() <= 1e-4 * max(1.0, gx_ref.abs().max().item())
+
+
+THIN_CASES = [(2, 12, 20, 16, 16, 1), (1, 13, 17, 3, 16, 2), (1, 12, 16, 16, 32, 2), (1, 9, 14, 32, 32, 1), (1, 10, 12, 8, 16, 1)]
+
+
+@pytest.mark.parametrize("case", THIN_CASES)
+def test_conv_thin_layers(backend, case):
+    """bf16 weights-stationary kernel of the thin full-resolution layers (3x3, Cin <= 32, Cout 16/32): forward (stride 1 / 2)
+    with bias + leaky, and the stride-1 input gradient with accumulate + fused leaky-gradient mask."""
+    B, H, W, Ci, Co, s = case
+    dev = backend.device
+    x = _rand((B, H, W, Ci), 71, dev)
+    w = _rand((3, 3, Ci, Co), 72, dev, 0.2)
+    b = _rand((Co,), 73, dev)
+    Ho, Wo, _, _ = ops.conv_geometry(H, W, 3, 3, s, 1)
+    gz = _rand((B, Ho, Wo, Co), 74, dev)
+    y_ref = T.conv2d(_bf(x.cpu()), _bf(w.cpu()), b.cpu(), stride=s, dilation=1, alpha=0.2)
+    _, gx_ref, _, _ = _oracle_grads(x.cpu(), _bf(w.cpu()), b.cpu(), s, 1, 1.0, _bf(gz.cpu()))
+    ld = (Ci + 3) // 4 * 4
+    xb, xv = _padded(x, ld)
+    if ld != Ci:
+        xb[..., Ci:] = float("nan")                      # channel padding must never leak into the result
+    old = _rand((B, H, W, Ci), 75, dev); mref = _rand((B, H, W, Ci), 76, dev)
+    dxb, dxv = _padded(old, ld); mb, mv = _padded(mref, ld)
+    ops.PRECISION = 1
+    backend.lib.tune_conv_thin(1)
+    try:
+        y = torch.full(y_ref.shape, float("nan"), device=dev)
+        ops.conv2d_fwd(backend.lib, xv, w, b, ops.view(y), stride=s, alpha=0.2)
+        if s == 1:
+            ops.conv2d_dgrad(backend.lib, ops.view(gz), w, dxv, stride=1, accumulate=True, mask_ref=mv, mask_alpha=0.2)
+        backend.sync()
+    finally:
+        ops.PRECISION = 0
+        backend.lib.tune_conv_thin(0)
+    assert (y.cpu() - y_ref).abs().max().item() <= 1e-4 * max(1.0, y_ref.abs().max().item())
+    if s == 1:
+        exp = (old.cpu() + gx_ref) * torch.where(mref.cpu() > 0, 1.0, 0.2)
+        assert (dxb[..., :Ci].cpu() - exp).abs().max().item() <= 1e-4 * max(1.0, gx_ref.abs().max().item())
