@@ -30,6 +30,14 @@ extern "C" {
 
 #define MH_ABI_VERSION 5
 
+/* status codes of every int-returning entry point: 0 = launched; a NEGATIVE code means an argument check failed and
+ * nothing was launched or written; a POSITIVE value is the hipError_t of a failed launch / runtime call.
+ * (The reference launchers return void and never check cudaGetLastError, shift_corr.cu.cc:226-232.) */
+#define MH_OK 0
+#define MH_ERR_ARG (-1)          /* null pointer, non-positive size, ld smaller than the channel count, ... */
+#define MH_ERR_ALIGN (-2)        /* a 16-byte alignment / multiple-of-4 requirement of the entry point is violated */
+#define MH_ERR_UNSUPPORTED (-3)  /* valid arguments outside what the kernels implement (sizes >= 2 GiB, odd mode combinations) */
+
 const char* mh_last_error(void);
 int mh_abi_version(void);
 /* number of visible HIP devices (<=0: none) -- lets the host fail loudly without torch */

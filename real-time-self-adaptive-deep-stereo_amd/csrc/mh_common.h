@@ -7,10 +7,6 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define MH_ERR_ARG (-1)
-#define MH_ERR_ALIGN (-2)
-#define MH_ERR_UNSUPPORTED (-3)
-
 void mh_set_error(const char* fmt, ...);
 int mh_check_launch(const char* what);
 
