@@ -698,11 +698,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const mh_wgrad_seg* _
     if (e0 >= sg.size) return;
     if ((sg.size & 3) == 0) {       // every split slice 16-byte aligned (ws is): vector path
         const float* src = sg.ws + e0;
-        float4 t = *reinterpret_cast<const float4*>(src);
-        for (int s = 1; s < sg.splits; ++s) {
+        // 4 independent accumulators = 4 loads in flight per lane (a single dependent chain ran at 2.6 TB/s)
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t, t2 = t, t3 = t;
+        int s = 0;
+        for (; s + 4 <= sg.splits; s += 4) {
+            const float4 v0 = *reinterpret_cast<const float4*>(src + (int64_t)(s + 0) * sg.size);
+            const float4 v1 = *reinterpret_cast<const float4*>(src + (int64_t)(s + 1) * sg.size);
+            const float4 v2 = *reinterpret_cast<const float4*>(src + (int64_t)(s + 2) * sg.size);
+            const float4 v3 = *reinterpret_cast<const float4*>(src + (int64_t)(s + 3) * sg.size);
+            t.x += v0.x; t.y += v0.y; t.z += v0.z; t.w += v0.w;
+            t1.x += v1.x; t1.y += v1.y; t1.z += v1.z; t1.w += v1.w;
+            t2.x += v2.x; t2.y += v2.y; t2.z += v2.z; t2.w += v2.w;
+            t3.x += v3.x; t3.y += v3.y; t3.z += v3.z; t3.w += v3.w;
+        }
+        for (; s < sg.splits; ++s) {
             const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)s * sg.size);
             t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
         }
+        t.x += (t1.x + t2.x) + t3.x; t.y += (t1.y + t2.y) + t3.y; t.z += (t1.z + t2.z) + t3.z; t.w += (t1.w + t2.w) + t3.w;
         float* d = sg.dst + e0;
         if (sg.accumulate) { d[0] += t.x; d[1] += t.y; d[2] += t.z; d[3] += t.w; }
         else { d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w; }
