@@ -343,8 +343,11 @@ class MadNetEngine(object):
             lib.lane = 1 + nflush[0] % self.wgrad_lanes
             nflush[0] += 1
             try:
+                batch = []
                 for xv, dzv, dw, db, stride, dil in pending:
-                    ops.conv2d_wgrad_partial(lib, self.lib, self.wsa, segs, xv, dzv, dw, db, stride=stride, dil=dil)
+                    ops.conv2d_wgrad_partial(lib, self.lib, self.wsa, batch, xv, dzv, dw, db, stride=stride, dil=dil)
+                # the batch's split reduction follows on the SAME lane: it too is off the critical path
+                ops.wgrad_reduce(lib, batch, self.dev, r.keep)
             finally:
                 lib.lane = 0
                 del pending[:]
@@ -481,8 +484,8 @@ class MadNetEngine(object):
                 if i % 4 == 1:
                     flush()
         flush()
-        r.join_next = True
-        ops.wgrad_reduce(lib, segs, self.dev, r.keep)
+        ops.wgrad_reduce(lib, segs, self.dev, r.keep)          # (serial variant only: the side-lane batches reduce themselves)
+        r.join_next = True                                      # whatever comes next (the optimizer) waits for the side lanes
 
     def record_update(self, r, train_vars, lr, momentum=0.9, grad_scale=1.0):
         """MomentumOptimizer apply on the (coalesced) ranges of train_vars."""
