@@ -258,11 +258,15 @@ class DispNetEngine(object):
             lib.lane = 1 + nflush[0] % 2
             nflush[0] += 1
             try:
+                batch = []
                 for xv, dzv, dw, db, stride in pending:
                     dup = dw.data_ptr() in seen_dst
                     seen_dst.add(dw.data_ptr())
-                    ops.conv2d_wgrad_partial(lib, self.lib, self.wsa, segs2 if dup else segs, xv, dzv, dw, db, stride=stride,
-                                             direct_ok=not dup and dw.data_ptr() not in shared_dw)
+                    shared = dw.data_ptr() in shared_dw
+                    # un-shared weights: reduced right here on the lane; the two uses of a shared weight wait for the final pair
+                    ops.conv2d_wgrad_partial(lib, self.lib, self.wsa, (segs2 if dup else segs) if shared else batch, xv, dzv, dw, db,
+                                             stride=stride, direct_ok=not shared)
+                ops.wgrad_reduce(lib, batch, self.dev, r.keep)
             finally:
                 lib.lane = 0
                 del pending[:]
