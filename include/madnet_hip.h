@@ -207,7 +207,7 @@ enum { MH_OP_CONV = 1, MH_OP_WGRAD, MH_OP_CORR_FWD, MH_OP_CORR_BWD, MH_OP_WARP_F
  * far, and runs concurrently with the lane-0 ops that follow); MH_OP_JOIN = lane 0 first waits for all side lanes.
  * mh_plan_run joins every side lane before it returns.  Under mh_graph_begin/end the lanes become parallel branches
  * of the captured hipGraph. */
-#define MH_MAX_LANES 3
+#define MH_MAX_LANES 5
 #define MH_OP_JOIN 0x100
 typedef struct mh_op {
     int32_t kind;

@@ -33,7 +33,7 @@ class Op(C.Structure):
 
 
 OP_JOIN = 0x100
-MAX_LANES = 3
+MAX_LANES = 5
 
 
 class WgradSeg(C.Structure):
