@@ -872,7 +872,9 @@ static int conv_dispatch(ConvArgs& a, hipStream_t s) {
                 if (take) { best_w = w; best_area = area; bm = t.bm; bn = t.bn; kt = t.kt; }
             }
             // latency-bound (few workgroups, long K): deepen the K-tile
-            if (best_w < 240 && ktot >= 512)
+            // ... unless the intra-workgroup split-K variant (KT = 64 instances) takes the layer anyway
+            const bool split_k = g_split_k && a.vecC && a.vecA && a.vecB && bm * bn <= 32 * 64 && bm <= 64 && best_w <= 256;
+            if (best_w < 240 && ktot >= 512 && !split_k)
                 for (const TileCfg& t : kTiles) if (t.bm == bm && t.bn == bn && t.kt == 128) kt = 128;
         }
         if (kt == 0) for (const TileCfg& t : kTiles) if (t.bm == bm && t.bn == bn) { kt = t.kt; break; }
