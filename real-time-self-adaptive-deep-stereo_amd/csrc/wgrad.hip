@@ -19,6 +19,7 @@ struct WgradArgs {
     int vecA, vecB;
     unsigned in_bytes, dz_bytes;
     int bf16;              // throughput mode (bf16 MFMA inputs, fp32 accumulate)
+    int flat;              // bf16 kernel, Cin <= 4: the tile rows are (tap, channel) pairs -- BK/4 taps per workgroup share ONE dz tile
     float* ws;             // != null: split s stores its partial dW to ws[s][taps*K*N] (no atomics)
     int forced_splits;     // > 0: use exactly this split count (the workspace was sized for it)
     int query;             // 1: compute `splits` only, launch nothing
@@ -269,13 +270,15 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(WgradArgs p) {
     // logical ids on ONE XCD, so the chunk comes from HBM once and the other taps*ktiles*ntiles-1 reads hit
     // that XCD's L2 (the activations of a layer do not fit the 4 MiB L2: tap-major order re-streamed them
     // from memory once per tap).
+    // flat mode (Cin <= 4, e.g. the 7x7 / 3x3 image layers): tile row r = (tap0 + r/4, channel r%4), so TPW = BK/4 taps
+    // share one workgroup and ONE dz tile (per-tap workgroups re-read dz once per tap: 49x for the 7x7 layer).
+    const int TPW = p.flat ? BK / 4 : 1;
+    const int ntapg = (p.taps + TPW - 1) / TPW;
     int bid = mh_xcd_remap(blockIdx.x, gridDim.x);
-    const int tap = bid % p.taps; bid /= p.taps;
+    const int tap = (bid % ntapg) * TPW; bid /= ntapg;           // first tap of this workgroup
     const int tn = bid % p.ntiles; bid /= p.ntiles;
     const int tk = bid % p.ktiles; bid /= p.ktiles;
     const int split = bid;
-    const int ky = tap / p.kw, kx = tap - ky * p.kw;
-    const int dy = ky * p.dil - p.pad_t, dx = kx * p.dil - p.pad_l;
     const int k0 = tk * BK, n0 = tn * BN;
     const int mbeg = split * p.chunk;
     const int mend = min(p.M, mbeg + p.chunk);
@@ -283,10 +286,10 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(WgradArgs p) {
     const int ntile = (mend - mbeg + PT - 1) / PT;
     const int Kr = (p.K + 3) & ~3;
 
-    // Pixel table: tab[buf][i] = byte offset of the input pixel that reduction-pixel i of a tile reads for this
-    // workgroup's tap, or -1 (padding / past the chunk).  64 threads keep one incremental (b, oy, ox) cursor
-    // each; the loaders fetch the 4 offsets of their unit with one ds_read_b128.
-    int* const tab = reinterpret_cast<int*>(Bh + 2 * BN * LS);            // [2][PT]
+    // Pixel table: tab[buf][t][i] = byte offset of the input pixel that reduction-pixel i of a tile reads for tap
+    // tap + t of this workgroup, or -1 (padding / past the chunk / past the last tap).  64 threads keep one incremental
+    // (b, oy, ox) cursor each; the loaders fetch the 4 offsets of their unit with one ds_read_b128.
+    int* const tab = reinterpret_cast<int*>(Bh + 2 * BN * LS);            // [2][TPW][PT]
     int c_m = mbeg + tid, c_ox = 0, c_oy = 0, c_b = 0;
     if (tid < PT) {
         c_ox = c_m % p.Wo;
@@ -296,9 +299,13 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(WgradArgs p) {
     }
     auto table_step = [&](int buf) {
         if (tid < PT) {
-            const int iy = c_oy * p.stride + dy, ix = c_ox * p.stride + dx;
-            const bool ok = c_m < mend && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-            tab[buf * PT + tid] = ok ? ((c_b * p.Hi + iy) * p.Wi + ix) * p.in_ld * 4 : -1;
+            for (int t = 0; t < TPW; ++t) {
+                const int tp = tap + t;
+                const int ky = tp / p.kw, kx = tp - ky * p.kw;
+                const int iy = c_oy * p.stride + ky * p.dil - p.pad_t, ix = c_ox * p.stride + kx * p.dil - p.pad_l;
+                const bool ok = tp < p.taps && c_m < mend && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+                tab[(buf * TPW + t) * PT + tid] = ok ? ((c_b * p.Hi + iy) * p.Wi + ix) * p.in_ld * 4 : -1;
+            }
             c_m += PT;
             c_ox += PT;
             while (c_ox >= p.Wo) {
@@ -314,13 +321,14 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(WgradArgs p) {
     const __amdgpu_buffer_rsrc_t rs_dz = mh_make_rsrc(p.dz, p.dz_bytes);
 
     auto load_tile = [&]() {
-        const int* tb = tab + (tile_ld & 1) * PT;
+        const int* tb = tab + (tile_ld & 1) * TPW * PT;
 #pragma unroll
         for (int j = 0; j < AU; ++j) {
             const int u = tid + NTH * j;
-            const int k = k0 + (u % (BK / 4)) * 4;
+            const int r4 = u % (BK / 4);                          // row group: channel group, or (flat) tap of the workgroup
+            const int k = p.flat ? 0 : k0 + r4 * 4;
             const bool uok = (u < AUN) && (k < Kr);
-            const int4 o = *reinterpret_cast<const int4*>(tb + ((u / (BK / 4)) & (PT / 4 - 1)) * 4);
+            const int4 o = *reinterpret_cast<const int4*>(tb + (p.flat ? r4 * PT : 0) + ((u / (BK / 4)) & (PT / 4 - 1)) * 4);
             ra_v[j][0] = mh_buf_load4(rs_in, (uok && o.x >= 0) ? o.x + k * 4 : MH_OOB);
             ra_v[j][1] = mh_buf_load4(rs_in, (uok && o.y >= 0) ? o.y + k * 4 : MH_OOB);
             ra_v[j][2] = mh_buf_load4(rs_in, (uok && o.z >= 0) ? o.z + k * 4 : MH_OOB);
@@ -418,13 +426,15 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(WgradArgs p) {
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int k = k0 + wm * MT * 16 + i * 16 + lq * 4 + r;
-            if (k >= p.K) continue;
+            const int row = wm * MT * 16 + i * 16 + lq * 4 + r;
+            const int k = p.flat ? r : k0 + row;                   // flat: row = (tap offset, channel) -- lq*4 + r has channel r
+            const int tp = p.flat ? tap + (row >> 2) : tap;
+            if (k >= p.K || tp >= p.taps) continue;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int n = n0 + wn * NT * 16 + j * 16 + li;
                 if (n < p.N) {
-                    float* d = dwb + ((int64_t)tap * p.K + k) * p.N + n;
+                    float* d = dwb + ((int64_t)tp * p.K + k) * p.N + n;
                     if (plain) *d = acc[i][j][r]; else atomicAdd(d, acc[i][j][r]);
                 }
             }
@@ -449,24 +459,28 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(WgradArgs p) {
 template <int WM, int WN, int MT, int NT>
 int launch_wgrad_bf16(WgradArgs& a, hipStream_t s) {
     constexpr int BK = WM * MT * 16, BN = WN * NT * 16, PT = 64;
-    constexpr size_t lds = (size_t)(2 * (BK + BN) * (PT + 8)) * 2 + 2 * PT * 4;
+    constexpr size_t tiles_b = (size_t)(2 * (BK + BN) * (PT + 8)) * 2;
+    constexpr size_t lds_max = tiles_b + 2 * (BK / 4) * PT * 4;        // flat mode keeps BK/4 pixel tables per buffer
+    const size_t lds = tiles_b + 2 * (a.flat ? BK / 4 : 1) * PT * 4;
     static bool attr_done = false;
     if (!attr_done) {
-        if (lds > 64 * 1024) {
+        if (lds_max > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<WM, WN, MT, NT>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) { mh_set_error("wgrad_bf16: hipFuncSetAttribute(%d B LDS): %s", (int)lds, hipGetErrorString(e)); return (int)e; }
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+            if (e != hipSuccess) { mh_set_error("wgrad_bf16: hipFuncSetAttribute(%d B LDS): %s", (int)lds_max, hipGetErrorString(e)); return (int)e; }
         }
         attr_done = true;
     }
     if (a.M < 0) return 0;
-    a.ktiles = mh_cdiv(a.K, BK);
+    a.ktiles = a.flat ? 1 : mh_cdiv(a.K, BK);
     a.ntiles = mh_cdiv(a.N, BN);
-    const int base = a.taps * a.ktiles * a.ntiles;
+    const int base = (a.flat ? mh_cdiv(a.taps, BK / 4) : a.taps) * a.ktiles * a.ntiles;
     constexpr int units = WM * WN * MT * NT;
     const int target = g_wgrad_target_wgs > 0 ? g_wgrad_target_wgs : (units >= 32 ? 384 : (units >= 8 ? 768 : 1536));
     int splits = a.forced_splits > 0 ? a.forced_splits : mh_cdiv(target, base);
-    const int maxs = mh_cdiv(a.M, PT * 2);
+    int maxs = mh_cdiv(a.M, PT * 2);
+    if (maxs > 192) maxs = 192;          // the split reduction walks the splits of an element serially (1280 splits of the flat
+                                         // 3->16 layer cost a 190 us single-block tail in wgrad_reduce_kernel)
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;
     int chunk = mh_cdiv(a.M, splits);
@@ -603,7 +617,7 @@ static int launch_wgrad_n1(WgradArgs& a, hipStream_t s) {
 }
 
 static int wgrad_dispatch(WgradArgs& a, hipStream_t s) {
-    const int K = a.K, N = a.N;
+    const int K = a.flat ? a.taps * 4 : a.K, N = a.N;        // flat: the dW tile rows are (tap, channel) pairs
     const bool all = a.M < 0;
     int rc = 0;
 #define MH_WG(cond, ...)                                       \
@@ -654,6 +668,7 @@ static int wgrad_entry(const mh_conv_desc* d, const float* in, const float* dout
     a.vecB = mh_aligned16(dout) && (dout_ld % 4 == 0) && (d->N % 4 == 0);
     a.dbg_plain_store = g_wgrad_plain;
     a.bf16 = (d->precision == 1);
+    a.flat = (a.bf16 && a.vecA && a.vecB && d->K <= 4 && a.taps > 1) ? 1 : 0;
     a.ws = ws; a.forced_splits = forced_splits; a.query = query;
     {
         const int64_t inb = (((int64_t)d->B * d->Hi * d->Wi - 1) * d->in_ld + (int64_t)((d->K + 3) / 4) * 4) * 4;

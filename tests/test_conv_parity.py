@@ -311,3 +311,38 @@ def test_conv_thin_layers(backend, case):
     if s == 1:
         exp = (old.cpu() + gx_ref) * torch.where(mref.cpu() > 0, 1.0, 0.2)
         assert (dxb[..., :Ci].cpu() - exp).abs().max().item() <= 1e-4 * max(1.0, gx_ref.abs().max().item())
+
+
+@pytest.mark.parametrize("case", [(1, 20, 28, 3, 16, 7, 2), (2, 11, 13, 3, 32, 5, 1), (1, 10, 12, 4, 64, 3, 1), (1, 9, 9, 1, 16, 3, 1)])
+def test_wgrad_bf16_tap_flattened(backend, case):
+    """Cin <= 4 in bf16 mode: the filter-gradient tile rows are (tap, channel) pairs, BK/4 taps per workgroup share one dz
+    tile (DispNet's 7x7 image layer, MADNet's 3x3 one); compared with the oracle on bf16-rounded operands."""
+    B, H, W, Ci, Co, k, s = case
+    dev = backend.device
+    x = _rand((B, H, W, Ci), 81, dev)
+    w = _rand((k, k, Ci, Co), 82, dev, 0.2)
+    b = _rand((Co,), 83, dev)
+    Ho, Wo, _, _ = ops.conv_geometry(H, W, k, k, s, 1)
+    gz = _rand((B, Ho, Wo, Co), 84, dev)
+    _, _, gw_ref, _ = _oracle_grads(_bf(x.cpu()), w.cpu(), b.cpu(), s, 1, 1.0, _bf(gz.cpu()))
+    _, _, _, gb_ref = _oracle_grads(x.cpu(), w.cpu(), b.cpu(), s, 1, 1.0, gz.cpu())
+    ld = (Ci + 3) // 4 * 4
+    xb, xv = _padded(x, ld)
+    if ld != Ci:
+        xb[..., Ci:] = 7.0                               # junk in the channel padding must not reach dw
+    ops.PRECISION = 1
+    try:
+        dw = torch.zeros_like(w); db = torch.zeros_like(b)
+        ops.conv2d_wgrad(backend.lib, xv, ops.view(gz), dw, db, stride=s)
+        wsa = ops.WgradWorkspace(dev); wsa.CHUNK = 1 << 16
+        segs, keep = [], []
+        dw2 = torch.full_like(w, float("nan")); db2 = torch.zeros_like(b)
+        ops.conv2d_wgrad_partial(backend.lib, backend.lib, wsa, segs, xv, ops.view(gz), dw2, db2, stride=s)
+        ops.wgrad_reduce(backend.lib, segs, dev, keep)
+        backend.sync()
+    finally:
+        ops.PRECISION = 0
+    tol = 1e-4 * max(1.0, gw_ref.abs().max().item())
+    assert (dw.cpu() - gw_ref).abs().max().item() <= tol
+    assert (dw2.cpu() - gw_ref).abs().max().item() <= tol
+    assert (db.cpu() - gb_ref).abs().max().item() <= 1e-4 * max(1.0, gb_ref.abs().max().item())
