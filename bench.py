@@ -134,8 +134,8 @@ def bench_mad(args, lib, dev, rank, world, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--mode", default="FULL", choices=["FULL", "NONE", "MAD"])
     ap.add_argument("--block-config", default="MadNet_piramid_only.json", help="MAD mode: file under block_config/")
     ap.add_argument("--model", default="madnet", choices=["madnet", "dispnet"])

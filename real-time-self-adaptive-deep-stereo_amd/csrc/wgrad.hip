@@ -8,6 +8,7 @@
 // partial tiles are combined with fp32 atomics into the (pre-zeroed) flat gradient buffer.
 // Reduction tile = 32 pixels; LDS tiles are [channel][pixel] (see the kernel comment).
 #include "mh_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -479,7 +480,8 @@ int launch_wgrad_bf16(WgradArgs& a, hipStream_t s) {
     const int target = g_wgrad_target_wgs > 0 ? g_wgrad_target_wgs : (units >= 32 ? 384 : (units >= 8 ? 768 : 1536));
     int splits = a.forced_splits > 0 ? a.forced_splits : mh_cdiv(target, base);
     int maxs = mh_cdiv(a.M, PT * 2);
-    if (maxs > 192) maxs = 192;          // the split reduction walks the splits of an element serially (1280 splits of the flat
+    static const int cap = []() { const char* e = getenv("MH_WGRAD_MAXSPLITS"); return e ? atoi(e) : 192; }();   // A/B hook
+    if (maxs > cap) maxs = cap;          // the split reduction walks the splits of an element serially (1280 splits of the flat
                                          // 3->16 layer cost a 190 us single-block tail in wgrad_reduce_kernel)
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;
@@ -668,7 +670,10 @@ static int wgrad_entry(const mh_conv_desc* d, const float* in, const float* dout
     a.vecB = mh_aligned16(dout) && (dout_ld % 4 == 0) && (d->N % 4 == 0);
     a.dbg_plain_store = g_wgrad_plain;
     a.bf16 = (d->precision == 1);
-    a.flat = (a.bf16 && a.vecA && a.vecB && d->K <= 4 && a.taps > 1) ? 1 : 0;
+    static const int flat_on = []() { const char* e = getenv("MH_WGRAD_FLAT"); return e ? atoi(e) : 1; }();      // A/B hook
+    // measured: the 7x7 image layer of DispNet 210 -> ~60 us per tower, but MADNet's 3x3 one is 1 % slower flat (9 taps only
+    // re-read dz 9x from L2, and the flat tables cost more than they save) -> many-tap layers only; MH_WGRAD_FLAT=2 forces it
+    a.flat = (flat_on && a.bf16 && a.vecA && a.vecB && d->K <= 4 && (a.taps >= 16 || (flat_on == 2 && a.taps > 1))) ? 1 : 0;
     a.ws = ws; a.forced_splits = forced_splits; a.query = query;
     {
         const int64_t inb = (((int64_t)d->B * d->Hi * d->Wi - 1) * d->in_ld + (int64_t)((d->K + 3) / 4) * 4) * 4;
