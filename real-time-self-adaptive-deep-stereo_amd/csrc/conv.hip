@@ -1,18 +1,23 @@
-// conv.hip -- implicit-GEMM convolution on the gfx950 matrix cores (exact fp32:
-// v_mfma_f32_16x16x4_f32, bitwise an fmaf chain) for the MADNet/DispNet conv stacks.
+// conv.hip -- implicit-GEMM convolution on the gfx950 matrix cores for the MADNet/DispNet conv stacks, in two arithmetic
+// modes selected per launch (mh_conv_desc.precision): exact fp32 (v_mfma_f32_16x16x4_f32, bitwise an fmaf chain -- the
+// parity path) and bf16 inputs with fp32 accumulation (v_mfma_f32_16x16x32_bf16 -- the throughput path); tensors are
+// fp32 in HBM either way.
 //
 // Replaces tf.nn.conv2d / tf.nn.atrous_conv2d / tf.nn.conv2d_transpose + bias_add + leaky
 // (Nets/sharedLayers.py:54-92) and, with mode=1 / w_trans=1, their input gradients.
 //
 // GEMM view:  C[m][n] = sum_{tap,k} A[m][(tap,k)] * B[(tap,k)][n]
 //   m = output pixel (b,oy,ox) -- NHWC so C row m lives at out + m*out_ld
-//   A[m][(tap,k)] = in[b, iy(oy,ky), ix(ox,kx), k]  (0 outside / not on the stride lattice)
+//   A[m][(tap,k)] = in[b, iy(oy,ky), ix(ox,kx), k]  (0 outside the image)
 //   B[(tap,k)][n] = w[tap][k][n] (forward, HWIO as stored) or w[tap][n][k] (dgrad)
 // K is walked in groups of 4 channels flattened across taps (group g -> tap=g/G, c4=g%G,
 // G=ceil(K/4)), so odd channel counts (3, 38, 33, 197 ...) cost no padded MFMA work beyond
-// the last group.  One workgroup = 4 waves computes a BM x BN tile; a K-tile = 32 or 64
-// k-values; global->register prefetch of tile t+1 overlaps the MFMAs of tile t; LDS is
-// double buffered with ONE barrier per K-tile.
+// the last group.  One workgroup = 4 waves computes a BM x BN tile; a K-tile = 32 / 64 / 128
+// k-values; global->register prefetch of tile t+1 (t+2 for the small tiles) overlaps the MFMAs of
+// tile t; LDS is double buffered with ONE barrier per K-tile.
+// Variants in this file: conv_igemm_kernel (the tiled kernel, incl. intra-workgroup split-K groups for the small tiles and
+// the 4 parity classes of a stride-2 input gradient / transposed conv in one launch), conv_n1_fwd_kernel (single output
+// channel), conv_thin_kernel (weights-stationary direct conv of the image layer).
 #include "mh_common.h"
 #include <stdlib.h>
 

@@ -8,11 +8,13 @@
 // 370-375) so tf.concat costs nothing, and the backward follows the TF gradient (the CUDA
 // backward is defective).
 //
-// HBM-bound op: algorithmic bytes = B*H*W*(2C + D)*4.  One workgroup = one row segment of
-// TW pixels; the right-feature window [x0-md, x0+TW+md) x C is staged once in LDS with
-// coalesced 16-byte loads (each R element is then reused by the D shifts from LDS instead of
-// D global loads); each pixel is owned by a group of LPP lanes that split the channels and
-// combine the D partial dot products with wave shuffles (__shfl_xor butterflies).
+// HBM-bound op: algorithmic bytes = B*H*W*(2C + D)*4.  Forward kernels, by shift count D:
+//   corr_fwd_direct (D <= 9, the MADNet radius-2 volume; default): a group of LPP lanes owns a pixel and splits the
+//     channels, 1 + D independent 16-byte buffer loads per lane (the right-feature window is served from L1/L2), the D
+//     partial dot products meet in __shfl_xor butterflies -- 67-75 % of the HBM peak at the SURVEY 8(d) protocol shape;
+//   corr_fwd_small (D <= 9, LDS-staged right window; kept behind mh_tune_corr(0) -- measured slower than direct);
+//   corr_fwd_mfma (D > 9, DispNet's 81-shift volume): the band of the row-wise product L * R^T on the fp32 MFMA;
+//   corr_fwd_large (generic fallback for the fused-concat forms of large D).
 #include "mh_common.h"
 
 namespace {

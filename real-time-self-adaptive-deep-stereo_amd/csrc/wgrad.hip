@@ -1,12 +1,14 @@
-// wgrad.hip -- weight/bias gradient of the conv stacks on the gfx950 matrix cores (exact
-// fp32 v_mfma_f32_16x16x4_f32).  Gradient of tf.nn.conv2d / atrous_conv2d + bias_add
-// (Nets/sharedLayers.py:54-77) as TF's Conv2DBackpropFilter / BiasAddGrad compute it.
+// wgrad.hip -- weight/bias gradient of the conv stacks on the gfx950 matrix cores: exact fp32 (wgrad_kernel,
+// v_mfma_f32_16x16x4_f32) and bf16 inputs / fp32 accumulate (wgrad_bf16_kernel, v_mfma_f32_16x16x32_bf16).  Gradient of
+// tf.nn.conv2d / atrous_conv2d + bias_add (Nets/sharedLayers.py:54-77) as TF's Conv2DBackpropFilter / BiasAddGrad compute it.
 //
-// GEMM view per tap:  dW[tap][k][n] += sum_m  X[m][(tap,k)] * dZ[m][n]
+// GEMM view per tap:  dW[tap][k][n] = sum_m  X[m][(tap,k)] * dZ[m][n]
 //   reduction index m = output pixel (b,oy,ox);  X[m][(tap,k)] = in[b, oy*s+ky*d-pt, ox*s+kx*d-pl, k]
-// The pixel axis is split over workgroups (grid = taps x k-tiles x n-tiles x splits) and
-// partial tiles are combined with fp32 atomics into the (pre-zeroed) flat gradient buffer.
-// Reduction tile = 32 pixels; LDS tiles are [channel][pixel] (see the kernel comment).
+// The pixel axis is split over workgroups (grid = splits x k-tiles x n-tiles x taps, taps fastest and co-located on one
+// XCD so a pixel chunk streams from HBM once).  Two ways to combine the splits: mh_conv2d_wgrad accumulates with fp32
+// atomics into a pre-zeroed dW; mh_conv2d_wgrad_partial stores every split's tile to a workspace and mh_wgrad_reduce
+// sums them (what the engines use: no atomics, one reduction launch per batch of layers).  Also here: wgrad_n1_kernel
+// (single output channel = a pixel reduction) and the tap-flattened mode of the bf16 kernel for Cin <= 4.
 #include "mh_common.h"
 #include <stdlib.h>
 
