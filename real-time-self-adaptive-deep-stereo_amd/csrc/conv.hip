@@ -19,31 +19,10 @@
 // the 4 parity classes of a stride-2 input gradient / transposed conv in one launch), conv_n1_fwd_kernel (single output
 // channel), conv_thin_kernel (weights-stationary direct conv of the image layer).
 #include "mh_common.h"
+#include "conv_args.h"
 #include <stdlib.h>
 
 namespace {
-
-struct ConvArgs {
-    const float* in; const float* w; const float* bias; float* out; const float* mask_ref;
-    int in_ld, out_ld, mask_ld;
-    int B, Hi, Wi, Ho, Wo;
-    int K, N, G, taps;
-    int kh, kw, stride, dil, pad_t, pad_l;
-    int mode, w_trans, accumulate, sshift;
-    unsigned in_bytes, w_bytes, out_bytes, mask_bytes;
-    int bf16;        // throughput mode: bf16 MFMA inputs, fp32 accumulate
-    int vecC;        // 16-byte epilogue legal (N, out_ld, mask_ld multiples of 4, aligned pointers)
-    int M;           // B*Ho*Wo
-    int vecA, vecB;  // 16-byte vector loads legal for A / B
-    int mtiles, ntiles;
-    float alpha, mask_alpha;
-    int mask_c0, mask_c1;   // channel range the leaky-grad mask applies to
-    // Stride-2 input gradient / transposed conv as 4 stride-1 sub-problems, one per output parity class: class c covers
-    // the output pixels (2*qy + py, 2*qx + px) and ONLY the taps that land on the input lattice for that parity
-    // (iy = qy + dy[t]); walking every tap with a lattice mask instead wastes 3/4 of the loads and MFMAs.
-    int ncls;               // 0 = off
-    struct Cls { int py, px, Hq, Wq, M, tile0, ntaps, pad; signed char dy[16], dx[16]; unsigned char id[16]; } cls[4];
-};
 
 // LDS tiles are k-contiguous for BOTH operands (As[row][k], Bs[col][k], row stride KT+4 floats) so
 // every lane fetches 4 consecutive k of its row/column with ONE ds_read_b128 and feeds 4 MFMAs:
@@ -918,7 +897,8 @@ static int conv_dispatch(ConvArgs& a, hipStream_t s) {
 int mh_conv_init() {
     ConvArgs a{};
     a.M = -1; a.N = 1;
-    return conv_dispatch(a, nullptr);
+    const int rc = mh_conv_patch_launch(a, nullptr);
+    return rc ? rc : conv_dispatch(a, nullptr);
 }
 
 extern "C" int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w, const float* bias,
@@ -987,5 +967,6 @@ extern "C" int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w,
     a.vecB = mh_aligned16(w) && (d->w_trans ? (d->K % 4 == 0) : (d->N % 4 == 0));
     if (conv_n1_ok(a)) return launch_conv_n1(a, (hipStream_t)stream);
     if (conv_thin_ok(a)) return launch_conv_thin(a, (hipStream_t)stream);
+    if (mh_conv_patch_ok(a)) return mh_conv_patch_launch(a, (hipStream_t)stream);
     return conv_dispatch(a, (hipStream_t)stream);
 }

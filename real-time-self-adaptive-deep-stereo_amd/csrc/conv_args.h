@@ -1,0 +1,30 @@
+// conv_args.h -- kernel argument block shared by the convolution translation units (conv.hip, conv_patch.hip)
+#pragma once
+#include "mh_common.h"
+
+struct ConvArgs {
+    const float* in; const float* w; const float* bias; float* out; const float* mask_ref;
+    int in_ld, out_ld, mask_ld;
+    int B, Hi, Wi, Ho, Wo;
+    int K, N, G, taps;
+    int kh, kw, stride, dil, pad_t, pad_l;
+    int mode, w_trans, accumulate, sshift;
+    unsigned in_bytes, w_bytes, out_bytes, mask_bytes;
+    int bf16;        // throughput mode: bf16 MFMA inputs, fp32 accumulate
+    int vecC;        // 16-byte epilogue legal (N, out_ld, mask_ld multiples of 4, aligned pointers)
+    int M;           // B*Ho*Wo
+    int vecA, vecB;  // 16-byte vector loads legal for A / B
+    int mtiles, ntiles;
+    float alpha, mask_alpha;
+    int mask_c0, mask_c1;   // channel range the leaky-grad mask applies to
+    // Stride-2 input gradient / transposed conv as 4 stride-1 sub-problems, one per output parity class: class c covers
+    // the output pixels (2*qy + py, 2*qx + px) and ONLY the taps that land on the input lattice for that parity
+    // (iy = qy + dy[t]); walking every tap with a lattice mask instead wastes 3/4 of the loads and MFMAs.
+    int ncls;               // 0 = off
+    struct Cls { int py, px, Hq, Wq, M, tile0, ntaps, pad; signed char dy[16], dx[16]; unsigned char id[16]; } cls[4];
+};
+
+// conv_patch.hip: patch-staged bf16 kernel for the stride-1 3x3 (dilated) layers
+bool mh_conv_patch_ok(const ConvArgs& a);
+int mh_conv_patch_launch(ConvArgs& a, hipStream_t s);     // a.M < 0: attribute set-up only
+extern "C" int mh_tune_conv_patch(int mode);

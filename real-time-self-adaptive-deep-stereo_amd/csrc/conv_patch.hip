@@ -1,0 +1,429 @@
+// conv_patch.hip -- patch-staged bf16-MFMA kernel for the stride-1, "SAME"-padded 3x3 (dilated) layers of the
+// disparity estimators / context network (Nets/MadNet.py:70-118 via Nets/sharedLayers.py:54-92) and their input
+// gradients, in the throughput mode (mh_conv_desc.precision = 1).
+//
+// Why a second kernel: the implicit-GEMM kernel of conv.hip re-gathers the input once per tap (9 x 128 pixels x 64
+// channels of fp32 per K-tile pair) and converts it to bf16 on every pass: at 13x the fp32 MFMA rate it is bound by the
+// 64 B/clk L1 path and the ~200 VALU instructions of a K-step, not by the matrix cores (profiles/r01_pmc_roofline.json:
+// 7.5 M VALU for 0.9 M MFMA).  Here the workgroup stages the input ONCE:
+//   * output tile = TH x 16 pixels of ONE dilation sub-lattice (pixels y = cy + d*i, x = cx + d*j): on its own lattice a
+//     dilated 3x3 conv is a dense 3x3 conv, so the halo is one lattice pixel whatever the dilation;
+//   * the (TH+2) x 18 patch is converted to bf16 once and kept in LDS ([pixel][channel], row stride K+16 halfs: the
+//     b128 lane groups of gfx950 read 16 consecutive pixels conflict free for strides = 8 mod 16 dwords);
+//   * the K loop only streams the weights (64 k-values per barrier, double buffered, prefetched one tile ahead) and
+//     walks (tap, 32-channel chunk): the A fragments are ds_read_b128 at patch[(ty+oy)*18 + tx+ox][c..c+7].
+// Per 128x128 tile and 3x3x128 taps the L1 traffic drops from 864 KB to ~330 KB and the loader VALU work by ~5x.
+// Results are those of conv_igemm_kernel<BF16> up to the fp32 summation order (same bf16 rounding of both operands).
+#include "conv_args.h"
+#include <stdlib.h>
+
+namespace {
+
+struct PatchGeo {
+    int TH, tiles_y, tiles_x, ntiles_n, nwg;
+    int KP, CPT, PS;        // channels rounded to 32, 32-chunks per tap, patch row stride (halfs)
+    int nchunk;             // 9 * CPT
+    int patch_halfs;        // (TH+2)*18*PS
+    float inv_kp4;          // 1 / (KP/4)
+    int dbg;                // timing experiments (scripts/microbench.py patchdbg): 1 = skip the K walk, 2 = skip the patch staging
+};
+
+constexpr int LSB = 80;     // weight tile row stride (halfs): 64 k + 16 pad = 40 dwords (conflict-free b128 reads)
+constexpr int PW = 18;      // patch width (16 + halo)
+
+template <int WM, int WN, int MT, int NT, bool DGRAD>
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv_patch_kernel(ConvArgs p, PatchGeo g) {
+    constexpr int NTH = WM * WN * 64;
+    constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
+    constexpr int TH = BM / 16;
+    HIP_DYNAMIC_SHARED(float, smem_all)
+    unsigned short* const Ph = reinterpret_cast<unsigned short*>(smem_all);
+    unsigned short* const Bh = Ph + g.patch_halfs;               // [2][BN][LSB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 15, lq = lane >> 4;
+    const int d = p.dil;
+
+    int lin = mh_xcd_remap(blockIdx.x, g.nwg);
+    const int tile_n = lin % g.ntiles_n; lin /= g.ntiles_n;
+    const int ttx = lin % g.tiles_x; lin /= g.tiles_x;
+    const int tty = lin % g.tiles_y; lin /= g.tiles_y;
+    const int cx = lin % d; lin /= d;
+    const int cy = lin % d;
+    const int b = lin / d;
+    const int n0 = tile_n * BN;
+    const int y00 = cy + d * (tty * TH), x00 = cx + d * (ttx * 16);      // image position of tile pixel (0, 0)
+
+    const __amdgpu_buffer_rsrc_t rs_in = mh_make_rsrc(p.in, p.in_bytes);
+    const __amdgpu_buffer_rsrc_t rs_w = mh_make_rsrc(p.w, p.w_bytes);
+
+    // ---- weight tile loader: tile t = 32-chunks 2t, 2t+1 of the (tap, chunk) walk -------------------------------------
+    // forward (HWIO, n contiguous): unit = 4 k-rows x 4 columns, transposed in registers, 4 ds_write_b64 (XOR-swizzled
+    // 16-byte chunks, as conv_igemm_kernel's BT path);  dgrad (w[tap][n][k], k contiguous): float4 along k, 1 ds_write_b64.
+    // Addressing = thread-constant byte offset + wave-uniform (tap, chunk) offset kept in a scalar cursor; every load is
+    // unconditional (dead lanes / chunks past the walk get an out-of-range offset and read zeros).
+    constexpr int FU = 512 / NTH;                   // forward units per thread and tile (256 unit slots per chunk)
+    constexpr int DI = (16 * BN) / NTH;             // dgrad float4 items per thread and tile
+    constexpr int NB = DGRAD ? DI : 4 * FU;
+    constexpr int NV = DGRAD ? DI : FU;
+    float4 rb0[NB], rb1[NB];                        // two register stages: tiles t+1 and t+2 are in flight while tile t is multiplied
+    int voff[NV], vk[NV], vch[NV];                  // byte offset inside a (tap, chunk) slab, first k inside the chunk, chunk of the tile
+#pragma unroll
+    for (int jj = 0; jj < NV; ++jj) {
+        const int q = tid + NTH * jj;
+        if (!DGRAD) {
+            const int wi = q & 255;
+            const int n4 = wi % (BN / 4), kq = wi / (BN / 4);
+            const int n = n0 + n4 * 4;
+            vch[jj] = __builtin_amdgcn_readfirstlane(q >> 8);
+            vk[jj] = kq * 4;
+            voff[jj] = (kq < 8 && n < p.N) ? (kq * 4 * p.N + n) * 4 : MH_OOB;
+        } else {
+            const int ch = q / (8 * BN), rem = q - ch * (8 * BN);
+            const int nn = rem >> 3, kg = rem & 7;
+            vch[jj] = ch;                            // (8 * BN) % 64 == 0: wave uniform
+            vk[jj] = kg * 4;
+            voff[jj] = (n0 + nn < p.N) ? ((n0 + nn) * p.K + kg * 4) * 4 : MH_OOB;
+        }
+    }
+    int l_tap = 0, l_c32 = 0;                        // cursor of the next chunk pair to LOAD (scalar)
+    int l_base[2], l_krem[2];                        // (tap, chunk) slab offsets of the tile being loaded
+    auto load_begin = [&]() {
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const bool in = l_tap < 9;
+            // forward: slab (tap, c32) starts at row tap*K + c32*32 of the [9*K][N] matrix; dgrad: column c32*32 of w[tap][n][:]
+            l_base[ch] = !DGRAD ? ((l_tap * p.K + l_c32 * 32) * p.N) * 4 : (l_tap * p.N * p.K + l_c32 * 32) * 4;
+            l_krem[ch] = in ? p.K - l_c32 * 32 : 0;
+            if (++l_c32 == g.CPT) { l_c32 = 0; ++l_tap; }
+        }
+    };
+    // ONE 16-byte load (op o of NB) of the tile opened by load_begin()
+    auto load_op = [&](float4 (&rb)[NB], int o) {
+        const int jj = DGRAD ? o : o >> 2, r = DGRAD ? 0 : o & 3;
+        const int bs = vch[jj] ? l_base[1] : l_base[0], kr = vch[jj] ? l_krem[1] : l_krem[0];
+        rb[o] = mh_buf_load4(rs_w, (voff[jj] != MH_OOB && vk[jj] + r < kr) ? voff[jj] + bs + r * p.N * 4 : MH_OOB);   // dgrad: K % 4 == 0 (vecB)
+    };
+    // ONE 8-byte LDS store (piece o of NB): forward = column r of the transposed 4x4 unit, dgrad = one float4 along k
+    auto store_op = [&](int buf, const float4 (&rb)[NB], int o) {
+        unsigned short* Bb = Bh + buf * (BN * LSB);
+        if (!DGRAD) {
+            const int jj = o >> 2, r = o & 3;
+            const int wi = (tid + NTH * jj) & 255;
+            const int n4 = wi % (BN / 4), kq = wi / (BN / 4);
+            if (kq < 8) {
+                const int kk = vch[jj] * 32 + kq * 4;
+                const float4 v0 = rb[4 * jj], v1 = rb[4 * jj + 1], v2 = rb[4 * jj + 2], v3 = rb[4 * jj + 3];
+                unsigned short* dst = Bb + (n4 * 4 + r) * LSB + ((((kk >> 3) ^ n4) & 7) << 3) + (kk & 7);
+                const float e0 = r == 0 ? v0.x : r == 1 ? v0.y : r == 2 ? v0.z : v0.w, e1 = r == 0 ? v1.x : r == 1 ? v1.y : r == 2 ? v1.z : v1.w;
+                const float e2 = r == 0 ? v2.x : r == 1 ? v2.y : r == 2 ? v2.z : v2.w, e3 = r == 0 ? v3.x : r == 1 ? v3.y : r == 2 ? v3.z : v3.w;
+                *reinterpret_cast<uint2*>(dst) = make_uint2(mh_pack_bf16(e0, e1), mh_pack_bf16(e2, e3));
+            }
+        } else {
+            const int q = tid + NTH * o;
+            const int rem = q - vch[o] * (8 * BN);
+            const int nn = rem >> 3, kg = rem & 7;
+            *reinterpret_cast<uint2*>(Bb + nn * LSB + vch[o] * 32 + kg * 4) = make_uint2(mh_pack_bf16(rb[o].x, rb[o].y), mh_pack_bf16(rb[o].z, rb[o].w));
+        }
+    };
+    auto load_b = [&](float4 (&rb)[NB]) {
+        load_begin();
+#pragma unroll
+        for (int o = 0; o < NB; ++o) load_op(rb, o);
+    };
+    auto store_b = [&](int buf, const float4 (&rb)[NB]) {
+#pragma unroll
+        for (int o = 0; o < NB; ++o) store_op(buf, rb, o);
+    };
+
+    load_b(rb0);                                     // tile 0
+    load_b(rb1);                                     // tile 1
+
+    // ---- stage the input patch once (bf16): U independent 16-byte loads in flight per thread ----------------------------
+    {
+        constexpr int U = NTH == 512 ? 12 : 16;
+        const int kp4 = g.KP >> 2;
+        const int items = (g.dbg & 2) ? 0 : (TH + 2) * PW * kp4;
+        // item q = (patch pixel (pi, pj), 4-channel group c4); q advances by NTH per load: the cursor follows incrementally
+        // (no division in the loop); one cursor for the loads, a second one for the LDS stores
+        const int dpp = NTH / kp4, dc4 = NTH - dpp * kp4;
+        const int dpi = dpp / PW, dpj = dpp - dpi * PW;
+        const int ppx0 = (int)(((float)tid + 0.5f) * g.inv_kp4);
+        int c4 = tid - ppx0 * kp4, pi = ppx0 / PW, pj = ppx0 - pi * PW;
+        int iy = y00 + (pi - 1) * d, ix = x00 + (pj - 1) * d;
+        int off = (((b * p.Hi + iy) * p.Wi + ix) * p.in_ld + c4 * 4) * 4;                // global byte offset of the item
+        int lds = ppx0 * g.PS + c4 * 4;                                                   // its LDS position (halfs)
+        int c4s = c4, pis = pi, pjs = pj;
+        // uniform steps: adds only inside the loop (v_mul_lo_u32 is quarter rate)
+        const int s_col = d * p.in_ld * 4, s_row = d * p.Wi * p.in_ld * 4;
+        const int st_off = dpi * s_row + dpj * s_col + dc4 * 16, st_iy = dpi * d, st_ix = dpj * d;
+        const int w_off = s_col - kp4 * 16, r_off = s_row - PW * s_col, r_ix = PW * d;
+        const int st_lds = dpp * g.PS + dc4 * 4, w_lds = g.PS - kp4 * 4;
+        for (int q0 = tid; q0 < items; q0 += NTH * U) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool ok = (pi < TH + 2) && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi && (c4 < p.G);
+                v[u] = mh_buf_load4(rs_in, ok ? off : MH_OOB);
+                c4 += dc4; pj += dpj; pi += dpi; iy += st_iy; ix += st_ix; off += st_off;
+                if (c4 >= kp4) { c4 -= kp4; ++pj; ix += d; off += w_off; }
+                if (pj >= PW) { pj -= PW; ++pi; iy += d; ix -= r_ix; off += r_off; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (pis < TH + 2) {
+                    float4 w = v[u];
+                    w.y = (c4s * 4 + 1 < p.K) ? w.y : 0.f;       // the row padding between K and in_ld is not ours to trust
+                    w.z = (c4s * 4 + 2 < p.K) ? w.z : 0.f;
+                    w.w = (c4s * 4 + 3 < p.K) ? w.w : 0.f;
+                    *reinterpret_cast<uint2*>(Ph + lds) = make_uint2(mh_pack_bf16(w.x, w.y), mh_pack_bf16(w.z, w.w));
+                }
+                c4s += dc4; pjs += dpj; pis += dpi; lds += st_lds;
+                if (c4s >= kp4) { c4s -= kp4; ++pjs; lds += w_lds; }
+                if (pjs >= PW) { pjs -= PW; ++pis; }
+            }
+        }
+    }
+    store_b(0, rb0);
+    __syncthreads();
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // K walk, hand-interleaved.  Tile t = chunks 2t, 2t+1 out of LDS buffer t&1; tile t+1 waits in one register stage
+    // and tile t+2 is loaded into the other.  All waves of the workgroup meet at one barrier per tile, so they run the same
+    // phase at the same time: issued phase by phase (loads, LDS reads, MFMAs, LDS stores) the matrix cores idle through
+    // every other phase.  Instead ONE other operation is issued after each MFMA and sched_barrier pins that order:
+    //   MFMAs of chunk 2t   : + LDS reads of the fragments of chunk 2t+1, then the first half of the tile-(t+2) loads
+    //   MFMAs of chunk 2t+1 : + the other half of the loads, then convert + LDS-store tile t+1 into the other buffer
+    //   barrier, LDS reads of the fragments of chunk 2t+2 (the only exposed latency), next tile.
+    // Loads past the walk read zeros; a chunk past the walk (odd chunk counts) multiplies a zero weight tile.
+    const int ntile = (g.dbg & 1) ? 0 : (g.nchunk + 1) >> 1;
+    const unsigned short* const Pw = Ph + ((wm * MT) * PW + li) * g.PS + lq * 8;          // tile row wm*MT, column li
+    int c_tap = 0, c_c32 = 0;                        // cursor of the next chunk whose fragments are READ (scalar)
+    auto next_a = [&]() -> const unsigned short* {
+        const int tap = c_tap < 9 ? c_tap : 8;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int oy = DGRAD ? 2 - ky : ky, ox = DGRAD ? 2 - kx : kx;
+        const unsigned short* Ab = Pw + (oy * PW + ox) * g.PS + c_c32 * 32;
+        if (++c_c32 == g.CPT) { c_c32 = 0; ++c_tap; }
+        return Ab;
+    };
+    constexpr int NF = MT + NT, MM = MT * NT;
+    // fragment read f of chunk `ch` of buffer `buf`: f < MT -> A row block f, else B column block f - MT
+    auto frag_op = [&](int buf, int ch, const unsigned short* Ab, u32x4 (&fa)[MT], u32x4 (&fb)[NT], int f) {
+        if (f < MT) {
+            fa[f] = *reinterpret_cast<const u32x4*>(Ab + f * PW * g.PS);
+        } else {
+            const int j = f - MT;
+            const unsigned short* Bb = Bh + buf * (BN * LSB) + (wn * NT * 16 + li) * LSB;
+            if (!DGRAD) fb[j] = *reinterpret_cast<const u32x4*>(Bb + j * 16 * LSB + ((((ch * 4 + lq) ^ ((wn * NT * 16 + j * 16 + li) >> 2)) & 7) << 3));
+            else fb[j] = *reinterpret_cast<const u32x4*>(Bb + j * 16 * LSB + ch * 32 + lq * 8);
+        }
+    };
+    constexpr int NL0 = NB / 2;                      // loads issued with the first chunk
+    constexpr int OPS0 = NF + NL0, OPS1 = (NB - NL0) + NB;
+    u32x4 fa0[MT], fb0[NT], fa1[MT], fb1[NT];
+    // one tile: multiply out of `buf`, load into rbl, store rbs into buf^1
+    auto tile = [&](int buf, float4 (&rbl)[NB], const float4 (&rbs)[NB]) {
+        load_begin();
+        const unsigned short* Ab1 = next_a();
+#pragma unroll
+        for (int m = 0; m < MM; ++m) {
+            acc[m / NT][m % NT] = mh_mfma_bf16(fa0[m / NT], fb0[m % NT], acc[m / NT][m % NT]);
+#pragma unroll
+            for (int o = m * OPS0 / MM; o < (m + 1) * OPS0 / MM; ++o) {
+                if (o < NF) frag_op(buf, 1, Ab1, fa1, fb1, o);
+                else load_op(rbl, o - NF);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int m = 0; m < MM; ++m) {
+            acc[m / NT][m % NT] = mh_mfma_bf16(fa1[m / NT], fb1[m % NT], acc[m / NT][m % NT]);
+#pragma unroll
+            for (int o = m * OPS1 / MM; o < (m + 1) * OPS1 / MM; ++o) {
+                if (o < NB - NL0) load_op(rbl, NL0 + o);
+                else store_op(buf ^ 1, rbs, o - (NB - NL0));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        const unsigned short* Ab0 = next_a();
+#pragma unroll
+        for (int f = 0; f < NF; ++f) frag_op(buf ^ 1, 0, Ab0, fa0, fb0, f);
+    };
+    {
+        const unsigned short* Ab0 = next_a();
+#pragma unroll
+        for (int f = 0; f < NF; ++f) frag_op(0, 0, Ab0, fa0, fb0, f);
+    }
+    // (an odd last tile is peeled: a skip path inside the loop would reach the loop header with the OTHER register stage
+    //  in flight, and the waitcnt pass then drains the loads at every header -- seen as s_waitcnt vmcnt(1) in the ISA)
+    for (int t = 0; t + 1 < ntile; t += 2) {
+        tile(0, rb0, rb1);                           // multiply tile t, load t+2, store t+1
+        tile(1, rb1, rb0);                           // multiply tile t+1, load t+3, store t+2
+    }
+    if (ntile & 1) tile(0, rb0, rb1);
+
+    // ---- epilogue: accumulator tile through LDS, then bias + leaky (+ accumulate) (+ leaky-grad mask), 16-byte rows --------
+    constexpr int CS = BN + 4;
+    float* const Cs = smem_all;                       // [BM][CS], over the patch / weight tiles (all reads are behind the last barrier)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Cs[((wm * MT + i) * 16 + lq * 4 + r) * CS + wn * NT * 16 + j * 16 + li] = acc[i][j][r];
+    __syncthreads();
+    constexpr int C4 = BN / 4;
+    constexpr int RP = NTH / C4;
+    constexpr int PASSES = (BM + RP - 1) / RP;
+    const __amdgpu_buffer_rsrc_t rs_out = mh_make_rsrc(p.out, p.out_bytes);
+    const __amdgpu_buffer_rsrc_t rs_mask = mh_make_rsrc(p.mask_ref ? p.mask_ref : p.out, p.mask_ref ? p.mask_bytes : 0u);
+    const int c4 = tid % C4;
+    const int n = n0 + c4 * 4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && n < p.N) bv = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll 4
+    for (int ps = 0; ps < PASSES; ++ps) {
+        const int row = tid / C4 + ps * RP;
+        const int rr = row < BM ? row : 0;
+        const int y = y00 + (rr >> 4) * d, x = x00 + (rr & 15) * d;
+        const bool ok = (tid < RP * C4) && (row < BM) && (y < p.Ho) && (x < p.Wo) && (n < p.N);
+        const int m = (b * p.Ho + y) * p.Wo + x;
+        float4 v = *reinterpret_cast<const float4*>(&Cs[rr * CS + c4 * 4]);
+        const int ooff = ok ? (m * p.out_ld + n) * 4 : MH_OOB;
+        float4 old = make_float4(0.f, 0.f, 0.f, 0.f), mk = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (p.accumulate) old = mh_buf_load4(rs_out, ooff);
+        if (p.mask_ref) mk = mh_buf_load4(rs_mask, ok ? (m * p.mask_ld + n) * 4 : MH_OOB);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        if (p.alpha != 1.0f) {
+            v.x = v.x > 0.f ? v.x : p.alpha * v.x; v.y = v.y > 0.f ? v.y : p.alpha * v.y;
+            v.z = v.z > 0.f ? v.z : p.alpha * v.z; v.w = v.w > 0.f ? v.w : p.alpha * v.w;
+        }
+        v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+        if (p.mask_ref) {
+            v.x *= (mk.x > 0.f || n + 0 < p.mask_c0 || n + 0 >= p.mask_c1) ? 1.0f : p.mask_alpha;
+            v.y *= (mk.y > 0.f || n + 1 < p.mask_c0 || n + 1 >= p.mask_c1) ? 1.0f : p.mask_alpha;
+            v.z *= (mk.z > 0.f || n + 2 < p.mask_c0 || n + 2 >= p.mask_c1) ? 1.0f : p.mask_alpha;
+            v.w *= (mk.w > 0.f || n + 3 < p.mask_c0 || n + 3 >= p.mask_c1) ? 1.0f : p.mask_alpha;
+        }
+        if (ok) *reinterpret_cast<float4*>(p.out + (int64_t)m * p.out_ld + n) = v;
+    }
+}
+
+constexpr size_t PATCH_LDS_MAX = 150 * 1024;
+
+size_t patch_lds(int TH, int BM, int BN, int KP) {
+    const size_t tiles = (size_t)(TH + 2) * PW * (KP + 16) * 2 + (size_t)2 * BN * LSB * 2;
+    const size_t cs = (size_t)BM * (BN + 4) * 4;
+    return tiles > cs ? tiles : cs;
+}
+
+// mode: 0 = off, 1 = heuristic tile, 64 / 128 = forced pixel tile; bit 8: the 8-wave variant of the 128-pixel tile
+constexpr int PATCH_DEFAULT = 0;
+int g_patch_mode = -2;         // -2: not resolved yet (MH_CONV_PATCH in the environment overrides the default)
+int patch_mode() {
+    if (g_patch_mode == -2) { const char* e = getenv("MH_CONV_PATCH"); g_patch_mode = e ? atoi(e) : PATCH_DEFAULT; }
+    return g_patch_mode;
+}
+int g_patch_launches = 0;     // since the last mh_tune_conv_patch() call (tests check that the kernel under test really ran)
+
+template <int WM, int WN, int MT, int NT, bool DGRAD>
+int launch_patch(ConvArgs& a, hipStream_t s) {
+    constexpr int BM = WM * MT * 16, BN = WN * NT * 16, TH = BM / 16;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<WM, WN, MT, NT, DGRAD>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)PATCH_LDS_MAX);
+        if (e != hipSuccess) { mh_set_error("conv_patch: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_done = true;
+    }
+    if (a.M < 0) return 0;
+    PatchGeo g;
+    g.TH = TH;
+    const int d = a.dil;
+    g.tiles_y = mh_cdiv(mh_cdiv(a.Ho, d), TH);
+    g.tiles_x = mh_cdiv(mh_cdiv(a.Wo, d), 16);
+    g.ntiles_n = mh_cdiv(a.N, BN);
+    g.nwg = a.B * d * d * g.tiles_y * g.tiles_x * g.ntiles_n;
+    g.KP = (a.K + 31) & ~31;
+    g.CPT = g.KP / 32;
+    g.PS = g.KP + 16;
+    g.nchunk = 9 * g.CPT;
+    g.patch_halfs = (TH + 2) * PW * g.PS;
+    g.inv_kp4 = 1.0f / (float)(g.KP / 4);
+    g.dbg = (patch_mode() >> 9) & 3;
+    const size_t lds = patch_lds(TH, BM, BN, g.KP);
+    ++g_patch_launches;
+    hipLaunchKernelGGL((conv_patch_kernel<WM, WN, MT, NT, DGRAD>), dim3(g.nwg), dim3(WM * WN * 64), lds, s, a, g);
+    return mh_check_launch("conv_patch");
+}
+
+template <int WM, int WN, int MT, bool DGRAD>
+int launch_patch_n(ConvArgs& a, hipStream_t s, int bn) {
+    const bool all = a.M < 0;
+    int rc = 0;
+    if (all || bn == 128) { rc = launch_patch<WM, WN, MT, 4, DGRAD>(a, s); if (!all || rc) return rc; }
+    if (all || bn == 96) { rc = launch_patch<WM, WN, MT, 3, DGRAD>(a, s); if (!all || rc) return rc; }
+    if (all || bn == 64) { rc = launch_patch<WM, WN, MT, 2, DGRAD>(a, s); if (!all || rc) return rc; }
+    return rc;
+}
+
+int patch_bn(const ConvArgs& a) { return a.N > 96 ? 128 : (a.N > 64 ? 96 : 64); }
+
+// Tile choice of the heuristic mode (measured on MI355X, profiles/r01_microbench_conv_patch.txt): the forward layers run the
+// 128-pixel tile with 8 waves, the input gradients the 64-pixel tile (two workgroups per CU).
+int patch_bm(const ConvArgs& a) {
+    if ((patch_mode() & 0xff) == 64 || (patch_mode() & 0xff) == 128) return patch_mode() & 0xff;
+    return a.mode == 1 ? 64 : 128;
+}
+bool patch_w8(const ConvArgs& a) { return (patch_mode() & 0xff) == 1 ? a.mode == 0 : (patch_mode() & 0x100) != 0; }
+
+}  // namespace
+
+extern "C" int mh_tune_conv_patch(int mode) {
+    g_patch_mode = mode < 0 ? PATCH_DEFAULT : mode;
+    const int n = g_patch_launches;
+    g_patch_launches = 0;
+    return n;
+}
+
+bool mh_conv_patch_ok(const ConvArgs& a) {
+    if (patch_mode() == 0) return false;
+    if (!(a.bf16 && a.vecA && a.vecB && a.vecC)) return false;
+    if (!(a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad_t == a.dil && a.pad_l == a.dil && a.Hi == a.Ho && a.Wi == a.Wo)) return false;
+    if (a.ncls != 0 || a.N < 48 || a.K < 32 || a.dil > 64) return false;
+    const int bm = patch_bm(a), bn = patch_bn(a);
+    if (patch_lds(bm / 16, bm, bn, (a.K + 31) & ~31) > PATCH_LDS_MAX) return false;
+    // lattice fill: the share of tile pixels that are real output pixels (small images under a large dilation waste tiles)
+    const int d = a.dil, TH = bm / 16;
+    const int64_t cover = (int64_t)d * d * mh_cdiv(mh_cdiv(a.Ho, d), TH) * TH * mh_cdiv(mh_cdiv(a.Wo, d), 16) * 16;
+    if ((patch_mode() & 0xff) == 1) {
+        if (cover * 4 > (int64_t)a.Ho * a.Wo * 5) return false;               // < 80 % useful tile pixels: the gather kernel wins
+        if ((int64_t)a.B * a.Ho * a.Wo < 24576) return false;                  // fewer than ~200 128-pixel tiles: not enough workgroups per CU
+    }
+    return (int64_t)a.B * d * d * mh_cdiv(mh_cdiv(a.Ho, d), TH) * mh_cdiv(mh_cdiv(a.Wo, d), 16) < (1 << 30);
+}
+
+int mh_conv_patch_launch(ConvArgs& a, hipStream_t s) {
+    const bool all = a.M < 0;
+    const bool dg = a.mode == 1;
+    const int bm = all ? 0 : patch_bm(a), bn = all ? 0 : patch_bn(a);
+    const bool w8 = all ? false : patch_w8(a);
+    int rc = 0;
+    if (all || (!dg && bm == 128 && !w8)) { rc = launch_patch_n<2, 2, 4, false>(a, s, bn); if (!all || rc) return rc; }
+    if (all || (dg && bm == 128 && !w8)) { rc = launch_patch_n<2, 2, 4, true>(a, s, bn); if (!all || rc) return rc; }
+    if (all || (!dg && bm == 128 && w8)) { rc = launch_patch_n<4, 2, 2, false>(a, s, bn); if (!all || rc) return rc; }
+    if (all || (dg && bm == 128 && w8)) { rc = launch_patch_n<4, 2, 2, true>(a, s, bn); if (!all || rc) return rc; }
+    if (all || (!dg && bm == 64)) { rc = launch_patch_n<2, 2, 2, false>(a, s, bn); if (!all || rc) return rc; }
+    if (all || (dg && bm == 64)) { rc = launch_patch_n<2, 2, 2, true>(a, s, bn); if (!all || rc) return rc; }
+    if (all) return 0;
+    mh_set_error("conv_patch: no variant for bm=%d bn=%d", bm, bn);
+    return MH_ERR_UNSUPPORTED;
+}

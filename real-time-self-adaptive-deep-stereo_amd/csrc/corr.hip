@@ -331,6 +331,132 @@ __global__ __launch_bounds__(256) void corr_fwd_mfma(CorrArgs p) {
     }
 }
 
+// Gradient of the large-shift cost volume on the matrix cores (same banded-GEMM view as corr_fwd_mfma):
+//   RIGHT = false: dL[x][c]  = 1/C * sum_x' G[x][x'] * R[x'][c]      G[x][x'] = g[x][x' - x + md] inside the band, else 0
+//   RIGHT = true : dR[x'][c] = 1/C * sum_x  G[x][x'] * L[x][c]
+// One workgroup = 64 output pixels of a row, one wave = 16 of them; the other operand's window (64 + 2 md pixels, k-contiguous
+// rows + 4 floats of padding) and the needed rows of g are staged in LDS; the A operand (the band of g) is gathered from
+// the LDS copy of g with per-lane shift indices, the B operand is read column-wise from the window (conflict free:
+// row stride = 4 banks mod 64); exact-fp32 v_mfma_f32_16x16x4_f32, ceil((2md+16)/16) * 4 * C/16 MFMAs per wave.
+template <int CS16, bool RIGHT>
+__global__ __launch_bounds__(CS16 >= 2 ? 512 : 256) void corr_bwd_mfma(CorrBwdArgs p, int segs) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    constexpr int C = CS16 * 16, RS = C + 4;
+    constexpr int NT = CS16 >= 2 ? 512 : 256;              // 8 waves: two per 16-pixel strip, each owning half the channel blocks
+    constexpr int CBW = CS16 >= 2 ? CS16 / 2 : 1;          // channel blocks per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, half = tid >> 8;
+    const int li = lane & 15, lq = lane >> 4;
+    const int seg = blockIdx.x % segs;
+    const int row = blockIdx.x / segs;
+    const int x0 = seg * 64;
+    const int nb = (2 * p.md + 16 + 15) / 16;
+    const int rows = 48 + 16 * nb;                         // window pixels any wave touches
+    const int DP = (p.D + 3) & ~3;
+    float* const Ws = smem;                                // [rows][RS]   R (left gradient) or L (right gradient) window
+    float* const Gs = smem + rows * RS;                    // [grows][DP]  g rows: the 64 outputs (left) / the window (right)
+    const int grows = RIGHT ? rows : 64;
+    const float* Wsrc = RIGHT ? p.L : p.R;
+    const int w_ld = RIGHT ? p.l_ld : p.r_ld;
+    // staging in batches of U independent loads per thread (4-8 waves per CU: a load-store loop would serialise on the latency)
+    constexpr int U = 6;
+    const int wtot = rows * (C / 4);
+    for (int q0 = tid; q0 < wtot; q0 += NT * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = q0 + u * NT;
+            const int xw = q / (C / 4), c4 = q - xw * (C / 4);
+            const int xs = x0 - p.md + xw;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < wtot && xs >= 0 && xs < p.W) v[u] = *reinterpret_cast<const float4*>(Wsrc + ((int64_t)row * p.W + xs) * w_ld + c4 * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = q0 + u * NT;
+            if (q < wtot) *reinterpret_cast<float4*>(Ws + (q / (C / 4)) * RS + (q % (C / 4)) * 4) = v[u];
+        }
+    }
+    const int gx0 = RIGHT ? x0 - p.md : x0;
+    if (((p.g_ld | p.coff) & 3) == 0 && p.coff + DP <= p.g_ld) {
+        // 16-byte rows: the pad columns (d >= D) hold whatever follows the volume in the row; the band gather below never reads them
+        const int D4 = DP >> 2, gtot = grows * D4;
+        const float inv = 1.0f / (float)D4;
+        for (int q0 = tid; q0 < gtot; q0 += NT * U) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = q0 + u * NT;
+                const int gr = (int)(((float)q + 0.5f) * inv), d4 = q - gr * D4;
+                const int xs = gx0 + gr;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (q < gtot && xs >= 0 && xs < p.W) v[u] = *reinterpret_cast<const float4*>(p.g + ((int64_t)row * p.W + xs) * p.g_ld + p.coff + d4 * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = q0 + u * NT;
+                if (q < gtot) *reinterpret_cast<float4*>(Gs + q * 4) = v[u];
+            }
+        }
+    } else {
+        const int gtot = grows * DP;
+        const float inv = 1.0f / (float)DP;
+        for (int q0 = tid; q0 < gtot; q0 += NT * U) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = q0 + u * NT;
+                const int gr = (int)(((float)q + 0.5f) * inv), d = q - gr * DP;
+                const int xs = gx0 + gr;
+                v[u] = 0.f;
+                if (q < gtot && xs >= 0 && xs < p.W && d < p.D) v[u] = p.g[((int64_t)row * p.W + xs) * p.g_ld + p.coff + d];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = q0 + u * NT;
+                if (q < gtot) Gs[q] = v[u];
+            }
+        }
+    }
+    __syncthreads();
+    // A operand (band of g), 4 consecutive k per lane and k-step: k = ks*16 + lq*4 + t  <->  window pixel 16*wave + k
+    f32x4 acc[CBW];
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < nb; ++ks) {
+        float a[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int kw = ks * 16 + lq * 4 + t;
+            // left: row = output pixel 16*wave + li, shift d = kw - li ; right: row = window pixel 16*wave + kw, d = li - kw + 2 md
+            const int d = RIGHT ? li - kw + 2 * p.md : kw - li;
+            const int gr = RIGHT ? 16 * wave + kw : 16 * wave + li;
+            a[t] = (d >= 0 && d < p.D) ? Gs[gr * DP + d] : 0.f;
+        }
+        const float* Wb = Ws + (16 * wave + ks * 16 + lq * 4) * RS + half * (CBW * 16) + li;
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], Wb[t * RS + cb * 16], acc[cb], 0, 0, 0);
+        }
+    }
+    const float inv_c = 1.0f / (float)C;
+    float* const out = RIGHT ? p.dR : p.dL;
+    const int o_ld = RIGHT ? p.dr_ld : p.dl_ld;
+    const int accf = RIGHT ? p.acc_r : p.acc_l;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int x = x0 + 16 * wave + 4 * lq + r;
+        if (x >= p.W) continue;
+        float* o = out + ((int64_t)row * p.W + x) * o_ld + half * (CBW * 16) + li;
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb) {
+            const float v = acc[cb][r] * inv_c;
+            o[cb * 16] = accf ? o[cb * 16] + v : v;
+        }
+    }
+}
+
 }  // namespace
 
 int mh_corr_init() {
@@ -342,6 +468,12 @@ int mh_corr_init() {
     if (e != hipSuccess) { mh_set_error("corr: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     MH_CORR_ATTR(1) MH_CORR_ATTR(2) MH_CORR_ATTR(4) MH_CORR_ATTR(8) MH_CORR_ATTR(16)
 #undef MH_CORR_ATTR
+#define MH_CORRB_ATTR(CSv, Rv)                                                                                                 \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_bwd_mfma<CSv, Rv>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+    if (e != hipSuccess) { mh_set_error("corr: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    MH_CORRB_ATTR(1, false) MH_CORRB_ATTR(2, false) MH_CORRB_ATTR(4, false) MH_CORRB_ATTR(8, false) MH_CORRB_ATTR(16, false)
+    MH_CORRB_ATTR(1, true) MH_CORRB_ATTR(2, true) MH_CORRB_ATTR(4, true) MH_CORRB_ATTR(8, true) MH_CORRB_ATTR(16, true)
+#undef MH_CORRB_ATTR
     return 0;
 }
 
@@ -434,6 +566,28 @@ extern "C" int mh_corr_bwd(const float* g, int32_t g_ld, int32_t coff, const flo
     a.B = B; a.H = H; a.W = W; a.C = C; a.md = max_disp; a.stride = stride; a.D = 2 * max_disp / stride + 1;
     a.copy_left = copy_left;
     a.total = (int64_t)B * H * W * (C / 4);
+    {   // large shift counts: banded GEMM on the MFMA (two launches: left and right gradient)
+        const int nb = (2 * max_disp + 31) / 16, rows = 48 + 16 * nb, DP = (a.D + 3) & ~3;
+        const size_t lds_l = ((size_t)rows * (C + 4) + 64 * DP) * sizeof(float), lds_r = ((size_t)rows * (C + 4) + (size_t)rows * DP) * sizeof(float);
+        if (g_corr_direct && a.D > MAXD_SMALL && stride == 1 && !copy_left && !du && (C == 16 || C == 32 || C == 64 || C == 128 || C == 256) &&
+            lds_r <= 150 * 1024 && (int64_t)B * H * W < (1ll << 31) / 64) {
+            const int segs = mh_cdiv(W, 64);
+            const dim3 grid(segs * B * H);
+            hipStream_t s = (hipStream_t)stream;
+#define MH_CORRB(CSv)                                                                                        \
+            hipLaunchKernelGGL((corr_bwd_mfma<CSv, false>), grid, dim3(CSv >= 2 ? 512 : 256), lds_l, s, a, segs);  \
+            hipLaunchKernelGGL((corr_bwd_mfma<CSv, true>), grid, dim3(CSv >= 2 ? 512 : 256), lds_r, s, a, segs);
+            switch (C) {
+                case 16: MH_CORRB(1) break;
+                case 32: MH_CORRB(2) break;
+                case 64: MH_CORRB(4) break;
+                case 128: MH_CORRB(8) break;
+                default: MH_CORRB(16) break;
+            }
+#undef MH_CORRB
+            return mh_check_launch("corr_bwd_mfma");
+        }
+    }
     int blocks = (int)((a.total + 255) / 256);
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(corr_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);

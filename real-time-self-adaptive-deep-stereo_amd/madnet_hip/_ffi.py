@@ -12,7 +12,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmadnet_hip.so")
+# MADNET_HIP_LIB: another build of the same library (A/B runs of compiler options); default = the in-tree build
+LIB_PATH = os.environ.get("MADNET_HIP_LIB") or os.path.join(_HERE, "libmadnet_hip.so")
 
 
 class ConvDesc(C.Structure):
@@ -54,6 +55,7 @@ SIGNATURES = {
     "mh_init": (_I, []),
     "mh_tune_conv_tile": (_I, [_I, _I]),
     "mh_tune_conv_thin": (_I, [_I]),
+    "mh_tune_conv_patch": (_I, [_I]),
     "mh_tune_wgrad_wgs": (_I, [_I]),
     "mh_tune_corr": (_I, [_I]),
     "mh_conv2d": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
@@ -89,7 +91,7 @@ SIGNATURES = {
     "mh_event_destroy": (_I, [_P]),
     "mh_stream_sync": (_I, [_P]),
 }
-_NO_STATUS = {"mh_last_error", "mh_abi_version", "mh_crc32c", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats", "mh_proxy_ws_floats"}
+_NO_STATUS = {"mh_last_error", "mh_abi_version", "mh_tune_conv_patch", "mh_crc32c", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats", "mh_proxy_ws_floats"}
 
 
 class MadnetHipError(RuntimeError):

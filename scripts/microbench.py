@@ -90,8 +90,79 @@ def run_corr():
                 ms = _time_ms(lib, stream, lambda: ops.corr_fwd(lib, ops.view(L), ops.view(R), ops.view(out), md, stream=stream.cuda_stream), 10)
             print("corr fwd %s B=%d %dx%dx%d D=%d: %.1f us  %.0f GB/s (%.1f%% of 8 TB/s)" % ("direct" if direct else "lds   ", B, H, W, Cc, D, ms * 1e3, byts / ms / 1e6, byts / ms / 1e6 / 80))
         lib.tune_corr(1)
+    # gradient of the large-shift (DispNet) volume: gather kernel (tune_corr 0) vs the banded-GEMM MFMA pair (default)
+    for (B, H, W, Cc, md) in [(1, 96, 320, 128, 40), (16, 96, 320, 128, 40)]:
+        L = torch.randn(B, H, W, Cc, device=dev); R = torch.randn(B, H, W, Cc, device=dev)
+        D = 2 * md + 1; ld = (D + 3) // 4 * 4
+        g = torch.randn(B, H, W, ld, device=dev); dL = torch.empty_like(L); dR = torch.empty_like(R)
+        byts = float(B) * H * W * (4 * Cc + D) * 4
+        for direct in (0, 1):
+            lib.tune_corr(direct)
+            with torch.cuda.stream(stream):
+                ms = _time_ms(lib, stream, lambda: ops.corr_bwd(lib, ops.View(g, B, H, W, D, ld), ops.view(L), ops.view(R), ops.view(dL), ops.view(dR), md, 1,
+                                                                stream=stream.cuda_stream), 10)
+            print("corr bwd %s B=%d %dx%dx%d D=%d: %.1f us  %.0f GB/s (%.1f%% of 8 TB/s)" % ("mfma  " if direct else "gather", B, H, W, Cc, D, ms * 1e3, byts / ms / 1e6, byts / ms / 1e6 / 80))
+        lib.tune_corr(1)
 
 
+def run_patch():
+    """bf16 stride-1 3x3 layers: gather kernel (mode 0) vs the patch-staged kernel (128-px tile, its 8-wave variant, 64-px tile)."""
+    ops.PRECISION = 1
+    MODES = [0, 128, 128 + 256, 64]
+    PL = [("L2 128->128 d1", 1, 96, 320, 128, 128, 1), ("L2 128->128 d2", 1, 96, 320, 128, 128, 2), ("L2 128->128 d4", 1, 96, 320, 128, 128, 4),
+          ("L2 128->128 d8", 1, 96, 320, 128, 128, 8), ("L2 128->128 d16", 1, 96, 320, 128, 128, 16), ("L2 128->96", 1, 96, 320, 128, 96, 1),
+          ("L2 96->64", 1, 96, 320, 96, 64, 1), ("L2 40->128", 1, 96, 320, 40, 128, 1), ("L3 128->128", 1, 48, 160, 128, 128, 1),
+          ("L3 128->96", 1, 48, 160, 128, 96, 1), ("L4 128->128", 1, 24, 80, 128, 128, 1), ("L2 128->128 B4", 4, 96, 320, 128, 128, 1)]
+    print("%-18s %-6s %s" % ("layer (bf16)", "mode", " ".join("%10s" % ("gather" if m == 0 else "patch%d%s" % (m & 255, "w8" if m & 256 else "")) for m in MODES)))
+    for name, B, H, W, Ci, Co, d in PL:
+        x = torch.randn(B, H, W, Ci, device=dev); xv = ops.view(x)
+        w = torch.randn(3, 3, Ci, Co, device=dev) * 0.05; b = torch.randn(Co, device=dev)
+        y = torch.empty(B, H, W, Co, device=dev); dx = torch.empty(B, H, W, Ci, device=dev)
+        flops = 2.0 * B * H * W * 9 * Ci * Co
+        for mode in ("fwd", "dgrad"):
+            res = []
+            for m in MODES:
+                lib.tune_conv_patch(m)
+                with torch.cuda.stream(stream):
+                    if mode == "fwd":
+                        fn = lambda: ops.conv2d_fwd(lib, xv, w, b, ops.view(y), stride=1, dil=d, alpha=0.2, stream=stream.cuda_stream)
+                    else:
+                        fn = lambda: ops.conv2d_dgrad(lib, ops.view(y), w, ops.view(dx), stride=1, dil=d, accumulate=True, mask_ref=xv, mask_alpha=0.2,
+                                                      stream=stream.cuda_stream)
+                    res.append(_time_ms(lib, stream, fn, 10) * 1e3)
+            lib.tune_conv_patch(-1)
+            print("%-18s %-6s %s   (best %.0f TF/s)" % (name, mode, " ".join("%10.1f" % r for r in res), flops / (min(res) * 1e-6) / 1e12))
+    ops.PRECISION = 0
+
+
+def run_patchdbg():
+    """Where the time of the patch kernel goes: full kernel vs no K walk vs no patch staging vs neither (launch + epilogue)."""
+    ops.PRECISION = 1
+    for base in (128 + 256, 64):
+        MODES = [base, base + 512, base + 1024, base + 1536]
+        print("tile mode %d: %-14s %s" % (base, "layer", " ".join("%10s" % n for n in ("full", "noK", "nostage", "neither"))))
+        for name, B, H, W, Ci, Co, d in [("L2 128->128", 1, 96, 320, 128, 128, 1), ("L4 128->128", 1, 24, 80, 128, 128, 1), ("1 tile", 1, 8, 16, 128, 128, 1)]:
+            x = torch.randn(B, H, W, Ci, device=dev); xv = ops.view(x)
+            w = torch.randn(3, 3, Ci, Co, device=dev) * 0.05; b = torch.randn(Co, device=dev)
+            y = torch.empty(B, H, W, Co, device=dev)
+            res = []
+            for m in MODES:
+                lib.tune_conv_patch(m)
+                with torch.cuda.stream(stream):
+                    res.append(_time_ms(lib, stream, lambda: ops.conv2d_fwd(lib, xv, w, b, ops.view(y), stride=1, dil=d, alpha=0.2, stream=stream.cuda_stream), 20) * 1e3)
+            lib.tune_conv_patch(-1)
+            print("              %-14s %s" % (name, " ".join("%10.1f" % r for r in res)))
+    # launch floor: an (almost) empty kernel through the same path
+    t = torch.zeros(64, device=dev)
+    with torch.cuda.stream(stream):
+        print("launch floor (fill 64 floats): %.1f us" % (_time_ms(lib, stream, lambda: lib.fill(t.data_ptr(), 64, 0.0, stream.cuda_stream), 20) * 1e3))
+    ops.PRECISION = 0
+
+
+if what == "patchdbg":
+    run_patchdbg()
+if what == "patch":
+    run_patch()
 if what in ("conv", "all"):
     run_conv()
 if what in ("wgrad", "all"):

@@ -313,6 +313,45 @@ def test_conv_thin_layers(backend, case):
         assert (dxb[..., :Ci].cpu() - exp).abs().max().item() <= 1e-4 * max(1.0, gx_ref.abs().max().item())
 
 
+PATCH_CASES = [(1, 12, 20, 128, 128, 1, 128), (1, 9, 21, 96, 64, 2, 64), (2, 10, 18, 38, 128, 1, 64), (1, 14, 19, 64, 96, 4, 128),
+               (1, 8, 16, 128, 96, 1, 128 + 256), (1, 11, 17, 32, 64, 2, 1), (1, 7, 33, 160, 128, 1, 64)]
+
+
+@pytest.mark.parametrize("case", PATCH_CASES)
+def test_conv_bf16_patch_kernel(backend, case):
+    """Patch-staged bf16 kernel of the stride-1 3x3 (dilated) layers (csrc/conv_patch.hip): forward with bias + leaky and the
+    input gradient with accumulate + leaky-grad mask, against the oracle on bf16-rounded operands; every pixel tile
+    (64 / 128 pixels, 8-wave variant), dilation sub-lattices with ragged edges, Cin = 38 (row padding must not leak)."""
+    B, H, W, Ci, Co, dil, mode = case
+    dev = backend.device
+    x = _rand((B, H, W, Ci), 91, dev)
+    w = _rand((3, 3, Ci, Co), 92, dev, 0.2)
+    b = _rand((Co,), 93, dev)
+    gz = _rand((B, H, W, Co), 94, dev)
+    y_ref = T.conv2d(_bf(x.cpu()), _bf(w.cpu()), b.cpu(), stride=1, dilation=dil, alpha=0.2)
+    _, gx_ref, _, _ = _oracle_grads(x.cpu(), _bf(w.cpu()), b.cpu(), 1, dil, 1.0, _bf(gz.cpu()))
+    ld = (Ci + 3) // 4 * 4
+    xb, xv = _padded(x, ld)
+    if ld != Ci:
+        xb[..., Ci:] = float("nan")
+    old = _rand((B, H, W, Ci), 95, dev); mref = _rand((B, H, W, Ci), 96, dev)
+    dxb, dxv = _padded(old, ld); mb, mv = _padded(mref, ld)
+    ops.PRECISION = 1
+    backend.lib.tune_conv_patch(mode)
+    try:
+        y = torch.full(y_ref.shape, float("nan"), device=dev)
+        ops.conv2d_fwd(backend.lib, xv, w, b, ops.view(y), stride=1, dil=dil, alpha=0.2)
+        ops.conv2d_dgrad(backend.lib, ops.view(gz), w, dxv, stride=1, dil=dil, accumulate=True, mask_ref=mv, mask_alpha=0.2)
+        backend.sync()
+    finally:
+        ops.PRECISION = 0
+        launches = backend.lib.tune_conv_patch(-1)
+    assert launches == (0 if mode == 1 else (2 if Ci % 4 == 0 else 1))      # mode 1: too small for the tile heuristic -> gather kernel
+    assert (y.cpu() - y_ref).abs().max().item() <= 1e-4 * max(1.0, y_ref.abs().max().item())
+    exp = (old.cpu() + gx_ref) * torch.where(mref.cpu() > 0, 1.0, 0.2)
+    assert (dxb[..., :Ci].cpu() - exp).abs().max().item() <= 1e-4 * max(1.0, gx_ref.abs().max().item())
+
+
 @pytest.mark.parametrize("case", [(1, 20, 28, 3, 16, 7, 2), (2, 11, 13, 3, 32, 5, 1), (1, 10, 12, 4, 64, 3, 1), (1, 9, 9, 1, 16, 3, 1)])
 def test_wgrad_bf16_tap_flattened(backend, case):
     """Cin <= 4 in bf16 mode: the filter-gradient tile rows are (tap, channel) pairs, BK/4 taps per workgroup share one dz

@@ -72,6 +72,30 @@ def test_corr_bwd(backend, case):
     assert torch.equal(du.cpu(), g.cpu()[..., C + D])
 
 
+@pytest.mark.parametrize("case", [(1, 1, 70, 16, 40, 0, 0, 2), (2, 2, 37, 32, 40, 1, 0, 0), (1, 1, 130, 128, 40, 0, 1, 0), (1, 1, 64, 16, 20, 1, 1, 4),
+                                  (1, 2, 37, 48, 40, 0, 0, 0), (1, 1, 40, 64, 40, 0, 0, 1)])
+def test_corr_bwd_standalone_large_shift(backend, case):
+    """DispNet form (sharedLayers.correlation alone, D = 2*md+1 > 9): the banded-GEMM MFMA gradient kernels
+    (C a power of two; 16-byte and unaligned g rows) and the gather fallback (C = 48) against autograd of the oracle, with/without accumulation."""
+    B, H, W, C, md, al, ar, coff = case
+    dev = backend.device
+    L = _rand((B, H, W, C), 41, dev); R = _rand((B, H, W, C), 42, dev)
+    Lc = L.cpu().requires_grad_(True); Rc = R.cpu().requires_grad_(True)
+    ref = T.correlation(Lc, Rc, md, 1)
+    D = ref.shape[-1]
+    ld = (D + 3) // 4 * 4 + 4
+    g = _rand((B, H, W, ld), 43, dev)
+    gl_ref, gr_ref = torch.autograd.grad(ref, [Lc, Rc], g.cpu()[..., coff:coff + D])
+    old_l = _rand((B, H, W, C), 44, dev); old_r = _rand((B, H, W, C), 45, dev)
+    dL = old_l.clone() if al else torch.full((B, H, W, C), float("nan"), device=dev)
+    dR = old_r.clone() if ar else torch.full((B, H, W, C), float("nan"), device=dev)
+    ops.corr_bwd(backend.lib, ops.View(g, B, H, W, ld, ld), ops.view(L), ops.view(R), ops.view(dL), ops.view(dR), md, 1, coff=coff,
+                 acc_l=bool(al), acc_r=bool(ar), copy_left=False)
+    backend.sync()
+    ok, err = _close(dL, gl_ref + (old_l.cpu() if al else 0)); assert ok, err
+    ok, err = _close(dR, gr_ref + (old_r.cpu() if ar else 0)); assert ok, err
+
+
 @pytest.mark.parametrize("case", [(1, 6, 20, 128), (2, 5, 33, 32), (1, 4, 17, 16), (1, 3, 40, 96)])
 def test_warp_fwd_bwd(backend, case):
     B, H, W, C = case
