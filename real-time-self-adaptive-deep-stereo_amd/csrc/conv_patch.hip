@@ -31,7 +31,9 @@ struct PatchGeo {
 constexpr int LSB = 80;     // weight tile row stride (halfs): 64 k + 16 pad = 40 dwords (conflict-free b128 reads)
 constexpr int PW = 18;      // patch width (16 + halo)
 
-template <int WM, int WN, int MT, int NT, bool DGRAD>
+// CPTC > 0: the channel count is the compile-time constant 32 * CPTC (2 or 4 chunks per tap): tiles never straddle a tap,
+// no channel masking, and every LDS offset of the K walk is an instruction immediate (see the specialised walk below).
+template <int WM, int WN, int MT, int NT, bool DGRAD, int CPTC = 0>
 __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv_patch_kernel(ConvArgs p, PatchGeo g) {
     constexpr int NTH = WM * WN * 64;
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
@@ -185,6 +187,10 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1,
         }
     }
     store_b(0, rb0);
+    // vmcnt(0): nothing may be in flight at the loop headers below.  The tile-1 loads have landed long ago (they were issued
+    // before the patch loads), but if the scoreboard of hipcc's waitcnt pass still carries them into the loop, every
+    // register it recycles inside the loop gets a conservative s_waitcnt vmcnt at the header -- a full drain per iteration.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
 
     f32x4 acc[MT][NT];
@@ -256,6 +262,85 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1,
 #pragma unroll
         for (int f = 0; f < NF; ++f) frag_op(buf ^ 1, 0, Ab0, fa0, fb0, f);
     };
+    if constexpr (CPTC > 0) {
+        // ---- specialised walk: K == 32 * CPTC.  Patch row stride and chunk offsets are compile-time, so the fragment reads
+        // are `ds_read_b128 v, vbase offset:imm` off one VGPR per tap; a weight load is one v_add (thread-constant offset +
+        // scalar tile base; a base of 2^31 pushes every lane out of range = zeros past the walk) + the buffer load.
+        constexpr int PSC = 32 * CPTC + 16;
+        int vofs[NB];
+#pragma unroll
+        for (int o = 0; o < NB; ++o) {
+            const int jj = DGRAD ? o : o >> 2, r = DGRAD ? 0 : o & 3;
+            if (!DGRAD) vofs[o] = voff[jj] != MH_OOB ? voff[jj] + (vch[jj] * 32 + r) * p.N * 4 : MH_OOB;
+            else vofs[o] = voff[jj] != MH_OOB ? voff[jj] + vch[jj] * 128 : MH_OOB;
+        }
+        auto tap_ptr = [&](int tap) -> const unsigned short* {
+            const int tc = tap < 9 ? tap : 8;
+            const int ky = tc / 3, kx = tc - ky * 3;
+            const int oy = DGRAD ? 2 - ky : ky, ox = DGRAD ? 2 - kx : kx;
+            return Ph + ((wm * MT + oy) * PW + li + ox) * PSC + lq * 8;
+        };
+        // byte offset of the weight slab of chunk c (even) of tap `tap`; past the walk: 2^31
+        auto w_base = [&](int tap, int c) -> unsigned {
+            if (tap >= 9) return 0x80000000u;
+            return !DGRAD ? (unsigned)(((tap * CPTC + c) * 32 * p.N) * 4) : (unsigned)((tap * p.N * p.K + c * 32) * 4);
+        };
+        auto frag_c = [&](int buf, int ch, const unsigned short* Ab, u32x4 (&fa)[MT], u32x4 (&fb)[NT], int f) {
+            if (f < MT) fa[f] = *reinterpret_cast<const u32x4*>(Ab + f * PW * PSC);
+            else frag_op(buf, ch, Ab, fa, fb, f);
+        };
+        // multiply the tile in `buf` (fragments of its first chunk are in fa0/fb0), load the tile at `base` into rbl,
+        // store rbs into buf^1; A1 / An = patch pointers of this tile's second chunk / the next tile's first chunk
+        auto tile_c = [&](int buf, float4 (&rbl)[NB], const float4 (&rbs)[NB], const unsigned short* A1, const unsigned short* An, unsigned base) {
+#pragma unroll
+            for (int m = 0; m < MM; ++m) {
+                acc[m / NT][m % NT] = mh_mfma_bf16(fa0[m / NT], fb0[m % NT], acc[m / NT][m % NT]);
+#pragma unroll
+                for (int o = m * OPS0 / MM; o < (m + 1) * OPS0 / MM; ++o) {
+                    if (o < NF) frag_c(buf, 1, A1, fa1, fb1, o);
+                    else rbl[o - NF] = mh_buf_load4(rs_w, (int)((unsigned)vofs[o - NF] + base));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int m = 0; m < MM; ++m) {
+                acc[m / NT][m % NT] = mh_mfma_bf16(fa1[m / NT], fb1[m % NT], acc[m / NT][m % NT]);
+#pragma unroll
+                for (int o = m * OPS1 / MM; o < (m + 1) * OPS1 / MM; ++o) {
+                    if (o < NB - NL0) rbl[NL0 + o] = mh_buf_load4(rs_w, (int)((unsigned)vofs[NL0 + o] + base));
+                    else store_op(buf ^ 1, rbs, o - (NB - NL0));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int f = 0; f < NF; ++f) frag_c(buf ^ 1, 0, An, fa0, fb0, f);
+        };
+        const unsigned short* a_cur = tap_ptr(0);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) frag_c(0, 0, a_cur, fa0, fb0, f);
+        if (!(g.dbg & 1)) {
+            if constexpr (CPTC == 4) {
+                // two tiles per tap: chunks (0, 1) out of buffer 0, chunks (2, 3) out of buffer 1; loads run one tap ahead
+                for (int tap = 0; tap < 9; ++tap) {
+                    const unsigned short* a_nxt = tap_ptr(tap + 1);
+                    tile_c(0, rb0, rb1, a_cur + 32, a_cur + 64, w_base(tap + 1, 0));
+                    tile_c(1, rb1, rb0, a_cur + 96, a_nxt, w_base(tap + 1, 2));
+                    a_cur = a_nxt;
+                }
+            } else {
+                // one tile per tap: even taps out of buffer 0, odd taps out of buffer 1; loads run two taps ahead
+                for (int tap = 0; tap < 8; tap += 2) {
+                    const unsigned short* a_b = tap_ptr(tap + 1);
+                    const unsigned short* a_c = tap_ptr(tap + 2);
+                    tile_c(0, rb0, rb1, a_cur + 32, a_b, w_base(tap + 2, 0));
+                    tile_c(1, rb1, rb0, a_b + 32, a_c, w_base(tap + 3, 0));
+                    a_cur = a_c;
+                }
+                tile_c(0, rb0, rb1, a_cur + 32, a_cur, 0x80000000u);
+            }
+        }
+    } else {
     {
         const unsigned short* Ab0 = next_a();
 #pragma unroll
@@ -268,6 +353,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1,
         tile(1, rb1, rb0);                           // multiply tile t+1, load t+3, store t+2
     }
     if (ntile & 1) tile(0, rb0, rb1);
+    }
 
     // ---- epilogue: accumulator tile through LDS, then bias + leaky (+ accumulate) (+ leaky-grad mask), 16-byte rows --------
     constexpr int CS = BN + 4;
@@ -326,7 +412,7 @@ size_t patch_lds(int TH, int BM, int BN, int KP) {
 }
 
 // mode: 0 = off, 1 = heuristic tile, 64 / 128 = forced pixel tile; bit 8: the 8-wave variant of the 128-pixel tile
-constexpr int PATCH_DEFAULT = 0;
+constexpr int PATCH_DEFAULT = 1;
 int g_patch_mode = -2;         // -2: not resolved yet (MH_CONV_PATCH in the environment overrides the default)
 int patch_mode() {
     if (g_patch_mode == -2) { const char* e = getenv("MH_CONV_PATCH"); g_patch_mode = e ? atoi(e) : PATCH_DEFAULT; }
@@ -334,12 +420,12 @@ int patch_mode() {
 }
 int g_patch_launches = 0;     // since the last mh_tune_conv_patch() call (tests check that the kernel under test really ran)
 
-template <int WM, int WN, int MT, int NT, bool DGRAD>
+template <int WM, int WN, int MT, int NT, bool DGRAD, int CPTC = 0>
 int launch_patch(ConvArgs& a, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16, TH = BM / 16;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<WM, WN, MT, NT, DGRAD>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<WM, WN, MT, NT, DGRAD, CPTC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)PATCH_LDS_MAX);
         if (e != hipSuccess) { mh_set_error("conv_patch: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_done = true;
@@ -361,29 +447,42 @@ int launch_patch(ConvArgs& a, hipStream_t s) {
     g.dbg = (patch_mode() >> 9) & 3;
     const size_t lds = patch_lds(TH, BM, BN, g.KP);
     ++g_patch_launches;
-    hipLaunchKernelGGL((conv_patch_kernel<WM, WN, MT, NT, DGRAD>), dim3(g.nwg), dim3(WM * WN * 64), lds, s, a, g);
+    hipLaunchKernelGGL((conv_patch_kernel<WM, WN, MT, NT, DGRAD, CPTC>), dim3(g.nwg), dim3(WM * WN * 64), lds, s, a, g);
     return mh_check_launch("conv_patch");
+}
+
+// the channel-count-specialised instances exist for the 8-wave tile (the one the heuristic dispatches)
+template <int WM, int WN, int MT, int NT, bool DGRAD>
+int launch_patch_k(ConvArgs& a, hipStream_t s) {
+    const bool all = a.M < 0;
+    const bool generic = !all && ((patch_mode() >> 11) & 1) != 0;     // tuning hook (mode bit 11): never take the compile-time-K instances
+    int rc = 0;
+    if constexpr (WM == 4) {
+        if (all || (a.K == 128 && !generic)) { rc = launch_patch<WM, WN, MT, NT, DGRAD, 4>(a, s); if (!all || rc) return rc; }
+        if (all || (a.K == 64 && !generic)) { rc = launch_patch<WM, WN, MT, NT, DGRAD, 2>(a, s); if (!all || rc) return rc; }
+    }
+    return launch_patch<WM, WN, MT, NT, DGRAD>(a, s);
 }
 
 template <int WM, int WN, int MT, bool DGRAD>
 int launch_patch_n(ConvArgs& a, hipStream_t s, int bn) {
     const bool all = a.M < 0;
     int rc = 0;
-    if (all || bn == 128) { rc = launch_patch<WM, WN, MT, 4, DGRAD>(a, s); if (!all || rc) return rc; }
-    if (all || bn == 96) { rc = launch_patch<WM, WN, MT, 3, DGRAD>(a, s); if (!all || rc) return rc; }
-    if (all || bn == 64) { rc = launch_patch<WM, WN, MT, 2, DGRAD>(a, s); if (!all || rc) return rc; }
+    if (all || bn == 128) { rc = launch_patch_k<WM, WN, MT, 4, DGRAD>(a, s); if (!all || rc) return rc; }
+    if (all || bn == 96) { rc = launch_patch_k<WM, WN, MT, 3, DGRAD>(a, s); if (!all || rc) return rc; }
+    if (all || bn == 64) { rc = launch_patch_k<WM, WN, MT, 2, DGRAD>(a, s); if (!all || rc) return rc; }
     return rc;
 }
 
 int patch_bn(const ConvArgs& a) { return a.N > 96 ? 128 : (a.N > 64 ? 96 : 64); }
 
-// Tile choice of the heuristic mode (measured on MI355X, profiles/r01_microbench_conv_patch.txt): the forward layers run the
-// 128-pixel tile with 8 waves, the input gradients the 64-pixel tile (two workgroups per CU).
+// Tile choice of the heuristic mode (measured on MI355X, profiles/r01_microbench_conv_patch.txt): the 128-pixel tile with 8
+// waves for the forward pass and the input gradient alike (its compile-time-K instances take K = 64 / 128).
 int patch_bm(const ConvArgs& a) {
     if ((patch_mode() & 0xff) == 64 || (patch_mode() & 0xff) == 128) return patch_mode() & 0xff;
-    return a.mode == 1 ? 64 : 128;
+    return 128;
 }
-bool patch_w8(const ConvArgs& a) { return (patch_mode() & 0xff) == 1 ? a.mode == 0 : (patch_mode() & 0x100) != 0; }
+bool patch_w8(const ConvArgs& a) { return (patch_mode() & 0xff) == 1 ? true : (patch_mode() & 0x100) != 0; }
 
 }  // namespace
 

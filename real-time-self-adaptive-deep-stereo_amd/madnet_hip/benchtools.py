@@ -2,6 +2,7 @@
 
 Peaks (MI355X_MICROARCH.md): fp32 MFMA 157.3 TFLOP/s dense; HBM3E 8.0 TB/s spec."""
 import ctypes as C
+import os
 import torch
 
 from . import ops
@@ -63,7 +64,9 @@ def roofline(lib, eng, stream, reps=20):
     ms = _time_ms(lib, stream, conv, reps)
     flops = 2.0 * x.B * x.H * x.W * 9 * 128 * 128
     ach = flops / (ms * 1e-3) / 1e12
-    rl = {"kernel": "conv_igemm_kernel (3x3 128->128 @ %dx%d, dil 2; tile chosen by conv_dispatch)" % (x.H, x.W),
+    kname = ("conv_patch_kernel<4,2,2,4,fwd,K=128> (patch-staged bf16, 3x3 128->128 @ %dx%d, dil 2)" if prec == 1 and os.environ.get("MH_CONV_PATCH", "1") != "0"
+             else "conv_igemm_kernel (3x3 128->128 @ %dx%d, dil 2; tile chosen by conv_dispatch)") % (x.H, x.W)
+    rl = {"kernel": kname,
           "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
           "frac": ach / peak, "arithmetic": "bf16 MFMA, f32 accumulate" if prec == 1 else "f32 MFMA",
           "traffic": _pmc_traffic("conv_3x3_128_128_96x320_bf16" if prec == 1 else "conv_3x3_128_128_96x320"),

@@ -28,7 +28,8 @@ def _targs(n):
 KERNELS = {
     # conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC, UNI, BF16, KG>: template argument 9 is the arithmetic mode
     "conv_3x3_128_128_96x320": (lambda n: "conv_igemm" in n and _targs(n)[8] == "false", 2 * 15728640 + 589824 + 512),
-    "conv_3x3_128_128_96x320_bf16": (lambda n: "conv_igemm" in n and _targs(n)[8] == "true", 2 * 15728640 + 589824 + 512),
+    # the bf16 launch of that layer is taken by the patch-staged kernel (csrc/conv_patch.hip) unless MH_CONV_PATCH=0
+    "conv_3x3_128_128_96x320_bf16": (lambda n: "conv_patch_kernel" in n or ("conv_igemm" in n and _targs(n)[8] == "true"), 2 * 15728640 + 589824 + 512),
     "corr_fwd_B64_96x320x32_D5": (lambda n: "corr_fwd" in n, 64 * 96 * 320 * (2 * 32 + 5) * 4),
 }
 fetch, write, sq = load("FETCH_SIZE"), load("WRITE_SIZE"), load("SQ")

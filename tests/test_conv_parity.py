@@ -313,8 +313,12 @@ def test_conv_thin_layers(backend, case):
         assert (dxb[..., :Ci].cpu() - exp).abs().max().item() <= 1e-4 * max(1.0, gx_ref.abs().max().item())
 
 
+# (B, H, W, Cin, Cout, dilation, mh_tune_conv_patch mode): 128 / 64 = pixel tile, +256 = 8-wave variant (K = 64 / 128 take its
+# compile-time-K instances for the forward pass, Cout = 64 / 128 for the gradient), +2048 = generic instances only
 PATCH_CASES = [(1, 12, 20, 128, 128, 1, 128), (1, 9, 21, 96, 64, 2, 64), (2, 10, 18, 38, 128, 1, 64), (1, 14, 19, 64, 96, 4, 128),
-               (1, 8, 16, 128, 96, 1, 128 + 256), (1, 11, 17, 32, 64, 2, 1), (1, 7, 33, 160, 128, 1, 64)]
+               (1, 8, 16, 128, 96, 1, 128 + 256), (1, 11, 17, 32, 64, 2, 1), (1, 7, 33, 160, 128, 1, 64),
+               (1, 17, 35, 128, 128, 2, 128 + 256), (2, 9, 18, 64, 64, 1, 128 + 256), (1, 10, 20, 64, 128, 1, 128 + 256),
+               (1, 12, 19, 96, 128, 1, 128 + 256), (1, 9, 17, 128, 64, 1, 128 + 256 + 2048)]
 
 
 @pytest.mark.parametrize("case", PATCH_CASES)
