@@ -10,10 +10,15 @@
 //     dilated 3x3 conv is a dense 3x3 conv, so the halo is one lattice pixel whatever the dilation;
 //   * the (TH+2) x 18 patch is converted to bf16 once and kept in LDS ([pixel][channel], row stride K+16 halfs: the
 //     b128 lane groups of gfx950 read 16 consecutive pixels conflict free for strides = 8 mod 16 dwords);
-//   * the K loop only streams the weights (64 k-values per barrier, double buffered, prefetched one tile ahead) and
-//     walks (tap, 32-channel chunk): the A fragments are ds_read_b128 at patch[(ty+oy)*18 + tx+ox][c..c+7].
+//   * the K loop only streams the weights (64 k-values per barrier, LDS double buffered, two register stages = prefetch
+//     distance 2) and walks (tap, 32-channel chunk): the A fragments are ds_read_b128 at patch[(ty+oy)*18 + tx+ox][c..c+7];
+//   * the walk is interleaved by hand (one LDS read / global load / convert + LDS store after each MFMA, pinned with
+//     sched_barrier) and, for K = 64 / 128, specialised on the channel count so that every LDS offset is an immediate.
 // Per 128x128 tile and 3x3x128 taps the L1 traffic drops from 864 KB to ~330 KB and the loader VALU work by ~5x.
 // Results are those of conv_igemm_kernel<BF16> up to the fp32 summation order (same bf16 rounding of both operands).
+// Measured on MI355X (profiles/r01_microbench_conv_patch.txt): 3x3 128->128 @ 96x320 forward 33 -> 19.6 us, dgrad 35.5 -> 23 us.
+// Dispatch: mh_conv_patch_ok() below; build with -mllvm -amdgpu-mfma-vgpr-form=1 (csrc/Makefile) -- with AGPR accumulators
+// hipcc shuffles them through v_accvgpr_* moves at every loop back-edge.
 #include "conv_args.h"
 #include <stdlib.h>
 

@@ -318,7 +318,7 @@ def test_conv_thin_layers(backend, case):
 PATCH_CASES = [(1, 12, 20, 128, 128, 1, 128), (1, 9, 21, 96, 64, 2, 64), (2, 10, 18, 38, 128, 1, 64), (1, 14, 19, 64, 96, 4, 128),
                (1, 8, 16, 128, 96, 1, 128 + 256), (1, 11, 17, 32, 64, 2, 1), (1, 7, 33, 160, 128, 1, 64),
                (1, 17, 35, 128, 128, 2, 128 + 256), (2, 9, 18, 64, 64, 1, 128 + 256), (1, 10, 20, 64, 128, 1, 128 + 256),
-               (1, 12, 19, 96, 128, 1, 128 + 256), (1, 9, 17, 128, 64, 1, 128 + 256 + 2048)]
+               (1, 12, 19, 96, 128, 1, 128 + 256), (1, 9, 17, 128, 64, 1, 128 + 256 + 2048), (1, 9, 17, 64, 160, 1, 128 + 256)]
 
 
 @pytest.mark.parametrize("case", PATCH_CASES)
@@ -354,6 +354,34 @@ def test_conv_bf16_patch_kernel(backend, case):
     assert (y.cpu() - y_ref).abs().max().item() <= 1e-4 * max(1.0, y_ref.abs().max().item())
     exp = (old.cpu() + gx_ref) * torch.where(mref.cpu() > 0, 1.0, 0.2)
     assert (dxb[..., :Ci].cpu() - exp).abs().max().item() <= 1e-4 * max(1.0, gx_ref.abs().max().item())
+
+
+@pytest.mark.parametrize("case", [(1, 10, 18, 128, 128, 2, 128 + 256), (2, 7, 16, 96, 64, 1, 64)])
+def test_conv_bf16_patch_kernel_plain_epilogue(backend, case):
+    """Same kernel with the other epilogue combinations: forward without bias / activation, input gradient overwriting its
+    destination (no accumulate, no mask)."""
+    B, H, W, Ci, Co, dil, mode = case
+    dev = backend.device
+    x = _rand((B, H, W, Ci), 101, dev)
+    w = _rand((3, 3, Ci, Co), 102, dev, 0.2)
+    gz = _rand((B, H, W, Co), 103, dev)
+    zero_b = torch.zeros(Co)
+    y_ref = T.conv2d(_bf(x.cpu()), _bf(w.cpu()), zero_b, stride=1, dilation=dil, alpha=1.0)
+    _, gx_ref, _, _ = _oracle_grads(x.cpu(), _bf(w.cpu()), zero_b, 1, dil, 1.0, _bf(gz.cpu()))
+    ops.PRECISION = 1
+    backend.lib.tune_conv_patch(mode)
+    try:
+        y = torch.full(y_ref.shape, float("nan"), device=dev)
+        dx = torch.full((B, H, W, Ci), float("nan"), device=dev)
+        ops.conv2d_fwd(backend.lib, ops.view(x), w, None, ops.view(y), stride=1, dil=dil, alpha=1.0)
+        ops.conv2d_dgrad(backend.lib, ops.view(gz), w, ops.view(dx), stride=1, dil=dil)
+        backend.sync()
+    finally:
+        ops.PRECISION = 0
+        launches = backend.lib.tune_conv_patch(-1)
+    assert launches == 2
+    assert (y.cpu() - y_ref).abs().max().item() <= 1e-4 * max(1.0, y_ref.abs().max().item())
+    assert (dx.cpu() - gx_ref).abs().max().item() <= 1e-4 * max(1.0, gx_ref.abs().max().item())
 
 
 @pytest.mark.parametrize("case", [(1, 20, 28, 3, 16, 7, 2), (2, 11, 13, 3, 32, 5, 1), (1, 10, 12, 4, 64, 3, 1), (1, 9, 9, 1, 16, 3, 1)])
