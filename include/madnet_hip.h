@@ -189,7 +189,7 @@ int mh_bias_grad(const float* dz, int32_t dz_ld, int64_t npix, int32_t nch, floa
 /* ---- tuning hooks used by scripts/microbench.py (0 = built-in heuristic) ------------------ */
 int mh_tune_conv_tile(int bm, int bn);
 int mh_tune_conv_thin(int min_pixels);   /* weights-stationary thin-layer kernel from this many output pixels (0 = default, < 0 = never) */
-int mh_tune_conv_patch(int mode);        /* patch-staged bf16 kernel of the stride-1 3x3 layers: 0 = off, 1 = on (tile heuristic), 64 / 128 = forced pixel tile, +256 = 8-wave variant, < 0 = built-in default; returns the number of launches of that kernel since the previous call */
+int mh_tune_conv_patch(int mode);        /* patch-staged bf16 kernel of the stride-1 3x3 layers: 0 = off, 1 = on (tile heuristic), 64 / 128 = forced pixel tile, +256 = 8-wave variant, +2048 = generic-K instances only, +4096 = forward layers only, +8192 = no generic-K input gradients, < 0 = built-in default; returns the number of launches of that kernel since the previous call */
 int mh_tune_wgrad_wgs(int target_workgroups);
 int mh_tune_corr(int direct);
 

@@ -503,6 +503,8 @@ bool mh_conv_patch_ok(const ConvArgs& a) {
     if (!(a.bf16 && a.vecA && a.vecB && a.vecC)) return false;
     if (!(a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad_t == a.dil && a.pad_l == a.dil && a.Hi == a.Ho && a.Wi == a.Wo)) return false;
     if (a.ncls != 0 || a.N < 48 || a.K < 32 || a.dil > 64) return false;
+    if (a.mode == 1 && (patch_mode() & 0x1000)) return false;                                  // mode bit 12: forward layers only
+    if (a.mode == 1 && (patch_mode() & 0x2000) && a.K != 64 && a.K != 128) return false;       // mode bit 13: no generic-K input gradients
     const int bm = patch_bm(a), bn = patch_bn(a);
     if (patch_lds(bm / 16, bm, bn, (a.K + 31) & ~31) > PATCH_LDS_MAX) return false;
     // lattice fill: the share of tile pixels that are real output pixels (small images under a large dilation waste tiles)

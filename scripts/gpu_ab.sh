@@ -1,13 +1,9 @@
 #!/bin/bash
-# tests + bench A/B over the conv M-tile + rocprof kernel stats (csv)
-TAG=${1:-r01c}
-OUT=gpurun_out/$TAG
-mkdir -p $OUT
-export TMPDIR=/tmp
-timeout 600 python -m pytest tests -m gpu -q --timeout 300 -p no:cacheprovider > $OUT/pytest.log 2>&1; echo "pytest exit $?" >> $OUT/pytest.log
-timeout 150 python bench.py --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_default.log 2>&1
-MH_CONV_BM=64 timeout 150 python bench.py --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_bm64.log 2>&1
-MH_CONV_BM=128 timeout 150 python bench.py --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_bm128.log 2>&1
-(cd /tmp && timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o madnet -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-graph --no-cpu-baseline --no-roofline > $GRAFT_REPO_ROOT/$OUT/prof.log 2>&1)
-tail -3 $OUT/pytest.log
-for f in $OUT/bench_default.log $OUT/bench_bm64.log $OUT/bench_bm128.log; do echo "== $f"; grep -E "timed region|roofline" $f | cut -c1-200; tail -1 $f | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'], d.get('roofline',{}).get('achieved'), d.get('roofline_corr',{}).get('achieved'))"; done
+# In-situ A/B of the patch-kernel dispatch (whole-step bench, hipGraph replay): both directions / forward only / no generic-K dgrad.
+TAG=${1:-ab}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
+B="python bench.py --steps 150 --no-cpu-baseline --no-roofline --no-parity-path"
+for m in 1 4097 8193 0; do MH_CONV_PATCH=$m timeout 60 $B 2>/dev/null | tail -1 > $OUT/bench_m$m.json; done
+MH_CONV_PATCH=1 timeout 60 $B --wgrad-lanes 1 2>/dev/null | tail -1 > $OUT/bench_m1_lanes1.json
+MH_CONV_PATCH=8193 timeout 60 $B 2>/dev/null | tail -1 > $OUT/bench_m8193_b.json
+MH_CONV_PATCH=1 timeout 60 $B 2>/dev/null | tail -1 > $OUT/bench_m1_b.json
+for f in $OUT/bench_*.json; do echo "$f: $(python -c 'import sys,json; d=json.load(open(sys.argv[1])); print(round(d["value"],1), round(d["ms_per_step"],4))' $f)"; done
