@@ -511,8 +511,12 @@ bool mh_conv_patch_ok(const ConvArgs& a) {
     const int d = a.dil, TH = bm / 16;
     const int64_t cover = (int64_t)d * d * mh_cdiv(mh_cdiv(a.Ho, d), TH) * TH * mh_cdiv(mh_cdiv(a.Wo, d), 16) * 16;
     if ((patch_mode() & 0xff) == 1) {
-        if (cover * 4 > (int64_t)a.Ho * a.Wo * 5) return false;               // < 80 % useful tile pixels: the gather kernel wins
-        if ((int64_t)a.B * a.Ho * a.Wo < 24576) return false;                  // fewer than ~200 128-pixel tiles: not enough workgroups per CU
+        // thresholds of the heuristic (environment overrides for the in-situ A/B runs of scripts/gpu_ab.sh)
+        static int min_pix = -1, max_cover = -1;
+        if (min_pix < 0) { const char* e = getenv("MH_CONV_PATCH_MINPIX"); min_pix = e ? atoi(e) : 24576; }
+        if (max_cover < 0) { const char* e = getenv("MH_CONV_PATCH_COVER"); max_cover = e ? atoi(e) : 125; }
+        if (cover * 100 > (int64_t)a.Ho * a.Wo * max_cover) return false;      // default: < 80 % useful tile pixels -> the gather kernel wins
+        if ((int64_t)a.B * a.Ho * a.Wo < min_pix) return false;                // default: fewer than ~200 128-pixel tiles = not one workgroup per CU
     }
     return (int64_t)a.B * d * d * mh_cdiv(mh_cdiv(a.Ho, d), TH) * mh_cdiv(mh_cdiv(a.Wo, d), 16) < (1 << 30);
 }
