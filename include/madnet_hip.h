@@ -170,6 +170,19 @@ int64_t mh_proxy_ws_floats(int32_t B, int32_t H, int32_t W);
 int mh_proxy_loss(const float* pred, const float* proxy, float* ws, float* result, float* dpred, float weight,
                   float grad_scale, int32_t B, int32_t H, int32_t W, void* stream);
 
+/* ---- offline training (Train.py): supervised mean_l1 per predicted scale and the Adam update -------------------------------
+ * mh_supervised_loss: loss_factory.get_supervised_loss('mean_l1', multiScale=True, max_disp=MAX_DISP) term of ONE scale
+ *      (Losses/loss_factory.py:256-302, Train.py:100): valid = !(target == 0 || target >= max_disp); same outputs / workspace as
+ *      mh_proxy_loss.
+ * mh_adam: tf.train.AdamOptimizer(lr, beta1).apply (Train.py:95): state[0] / state[1] = beta1_power / beta2_power (initialised to
+ *      beta1 / beta2 by the caller); lr_t = lr * sqrt(1 - state[1]) / (1 - state[0]); m, v, var updated in place.
+ * mh_adam_advance: state[0] *= beta1, state[1] *= beta2 -- once per step, after the last mh_adam of the step. */
+int mh_supervised_loss(const float* pred, const float* target, float* ws, float* result, float* dpred, float weight,
+                       float grad_scale, float max_disp, int32_t B, int32_t H, int32_t W, void* stream);
+int mh_adam(float* var, float* m, float* v, const float* grad, int64_t n, const float* state, float lr, float beta1, float beta2,
+            float eps, float grad_scale, void* stream);
+int mh_adam_advance(float* state, float beta1, float beta2, void* stream);
+
 /* ---- tf.train.MomentumOptimizer apply (Stereo_Online_Adaptation.py:85):
  *      accum = momentum*accum + grad_scale*g ;  var -= lr*accum   (n contiguous floats) --- */
 int mh_momentum(float* var, float* accum, const float* grad, int64_t n, float lr, float momentum,
@@ -202,7 +215,7 @@ uint32_t mh_crc32c(const void* data, int64_t n, uint32_t crc);
 enum { MH_OP_CONV = 1, MH_OP_WGRAD, MH_OP_CORR_FWD, MH_OP_CORR_BWD, MH_OP_WARP_FWD, MH_OP_WARP_BWD,
        MH_OP_RESIZE_FWD, MH_OP_RESIZE_BWD, MH_OP_PAD_REFLECT, MH_OP_LOSS, MH_OP_METRICS,
        MH_OP_MOMENTUM, MH_OP_COPY_CH, MH_OP_LEAKY_BWD, MH_OP_FILL, MH_OP_BIAS_GRAD,
-       MH_OP_WGRAD_PARTIAL, MH_OP_WGRAD_REDUCE, MH_OP_PROXY_LOSS };
+       MH_OP_WGRAD_PARTIAL, MH_OP_WGRAD_REDUCE, MH_OP_PROXY_LOSS, MH_OP_SUPERVISED_LOSS, MH_OP_ADAM, MH_OP_ADAM_ADVANCE };
 /* i[26] of every op is its scheduling word: low byte = lane (0 = the caller's stream; 1..MH_MAX_LANES-1 = side
  * streams owned by the library: the op is forked from lane 0 right before it, i.e. ordered after everything recorded so
  * far, and runs concurrently with the lane-0 ops that follow); MH_OP_JOIN = lane 0 first waits for all side lanes.

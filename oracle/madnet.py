@@ -174,3 +174,29 @@ def step(wts, accum, left, right, gt, mode="FULL", block_vars=None, block_index=
     if grads:
         momentum_update(wts, accum, grads, lr)
     return out
+
+
+
+def train_step(wts, adam_m, adam_v, adam_state, left, right, gt, lr=1e-4, loss_weights=None, max_disp=192.0,
+               radius_d=2, stride=1):
+    """One iteration of the offline training loop Train.py:94-102,125-140 (device part): forward without bulkhead, the
+    multi-scale supervised mean_l1 (weights from full to lowest resolution = disparities[-1], [-2], ...), gradients of every
+    variable, Adam(lr, 0.9).  adam_state = [beta1_power, beta2_power] (python floats, updated in place)."""
+    names = list(wts.keys())
+    for n in names:
+        wts[n].requires_grad_(True)
+    disps = forward(wts, left, right, bulkhead=False, radius_d=radius_d, stride=stride)
+    lw = list(loss_weights) if loss_weights is not None else [1.0] * 10
+    parts = [T.supervised_loss(disps[-(i + 1)], gt, lw[i], max_disp) for i in range(len(disps))]
+    total = sum(parts)
+    gl = torch.autograd.grad(total, [wts[n] for n in names], allow_unused=True)
+    for n in names:
+        wts[n].requires_grad_(False)
+    grads = {n: g.detach() for n, g in zip(names, gl) if g is not None}
+    with torch.no_grad():
+        for n, g in grads.items():
+            T.adam_update(wts[n], adam_m[n], adam_v[n], g, adam_state, lr)
+        b1p = torch.tensor(adam_state[0], dtype=torch.float32) * torch.tensor(0.9, dtype=torch.float32)
+        b2p = torch.tensor(adam_state[1], dtype=torch.float32) * torch.tensor(0.999, dtype=torch.float32)
+        adam_state[0], adam_state[1] = float(b1p), float(b2p)
+    return {"loss": float(total.detach()), "losses": [float(x.detach()) for x in parts], "disparity": disps[-1].detach(), "grads": grads}

@@ -249,6 +249,30 @@ def proxy_loss(pred, proxy, weight=0.01):
     return weight * (valid * (pred - proxy).abs()).sum() / valid.sum()
 
 
+def supervised_loss(pred, target, weight=1.0, max_disp=192.0):
+    """ONE scale of loss_factory.get_supervised_loss('mean_l1', multiScale=True, max_disp=MAX_DISP) (Losses/loss_factory.py:256-302,
+    Train.py:19-20,100): valid = !(target == 0 | target >= max_disp); weight * sum(valid*|pred - target|) / sum(valid).  Every
+    MADNet / DispNet prediction is already full resolution (_make_disp), so resize_to_prediction is the identity and the scale
+    factor W_left / W_pred is 1."""
+    valid = torch.where((target == 0) | (target >= max_disp), torch.zeros_like(target), torch.ones_like(target))
+    return weight * (valid * (pred - target).abs()).sum() / valid.sum()
+
+
+def adam_update(var, m, v, g, state, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    """tf.train.AdamOptimizer(lr, beta1).apply_gradients for one variable (TF 1.12 python/training/adam.py + ApplyAdam kernel),
+    fp32 throughout: lr_t = lr*sqrt(1 - beta2_power)/(1 - beta1_power); m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2);
+    var -= (m * lr_t) / (sqrt(v) + eps).  state = [beta1_power, beta2_power] (advanced by the caller after all variables)."""
+    f32 = torch.float32
+    one = torch.tensor(1.0, dtype=f32)
+    b1p, b2p = torch.tensor(state[0], dtype=f32), torch.tensor(state[1], dtype=f32)
+    b1, b2 = torch.tensor(beta1, dtype=f32), torch.tensor(beta2, dtype=f32)
+    lr_t = torch.tensor(lr, dtype=f32) * torch.sqrt(one - b2p) / (one - b1p)
+    # the ApplyAdam functor (tensorflow/core/kernels/training_ops.cc): m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2)
+    m.add_((g - m) * (one - b1))
+    v.add_((g * g - v) * (one - b2))
+    var.sub_((m * lr_t) / (v.sqrt() + torch.tensor(eps, dtype=f32)))
+
+
 def validation_metrics(disp, gt, pixel_th=3.0):
     """Stereo_Online_Adaptation.py:74-82: EPE and bad3 over gt != 0."""
     abs_err = (disp - gt).abs()

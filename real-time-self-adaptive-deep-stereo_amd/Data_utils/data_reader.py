@@ -1,4 +1,4 @@
-"""Input list reader for the online-adaptation driver: same list format and centre crop/pad
+"""Input list reader for the online-adaptation driver and the offline trainer: same list format and centre crop/pad
 semantics as the reference's tf.data pipeline (Data_utils/data_reader.py:55-197), as a plain Python
 iterator (host IO is outside the hot path).
 
@@ -79,27 +79,113 @@ def center_crop_or_pad(img, th, tw):
     return img
 
 
+def random_crop(crop_shape, arrays, rng):
+    """Aligned random crop of [H,W,C] arrays (preprocessing.random_crop, Data_utils/preprocessing.py:31-58): the start row /
+    column are uniform in [0, H - crop_h - 1) / [0, W - crop_w - 1) -- the reference's own upper bounds, which never pick the
+    last admissible offset -- and [0, 1) = 0 when the image is not larger than the crop (short images are NOT padded there:
+    the slice is simply shorter and tf.set_shape fails; here that case raises)."""
+    h, w = arrays[0].shape[:2]
+    ch, cw = int(crop_shape[0]), int(crop_shape[1])
+    if h < ch or w < cw:
+        raise ValueError("random_crop: image %dx%d smaller than the crop %dx%d" % (h, w, ch, cw))
+    max_row, max_col = h - ch - 1, w - cw - 1
+    r0 = int(rng.integers(0, max_row if max_row > 0 else 1))
+    c0 = int(rng.integers(0, max_col if max_col > 0 else 1))
+    return [x[r0:r0 + ch, c0:c0 + cw] for x in arrays]
+
+
+def _rgb_to_hsv(x):
+    mx, mn = x.max(-1), x.min(-1)
+    d = mx - mn
+    s = np.where(mx > 0, d / np.where(mx > 0, mx, 1), 0)
+    dd = np.where(d > 0, d, 1)
+    r, g, b = x[..., 0], x[..., 1], x[..., 2]
+    h = np.where(mx == r, (g - b) / dd, np.where(mx == g, 2.0 + (b - r) / dd, 4.0 + (r - g) / dd))
+    h = np.where(d > 0, (h / 6.0) % 1.0, 0.0)
+    return h, s, mx
+
+
+def _hsv_to_rgb(h, s, v):
+    k = (np.stack([h * 6.0 + 5.0, h * 6.0 + 3.0, h * 6.0 + 1.0], -1)) % 6.0
+    return v[..., None] - (v * s)[..., None] * np.clip(np.minimum(k, 4.0 - k), 0.0, 1.0)
+
+
+def augment(left_img, right_img, rng):
+    """preprocessing.augment (Data_utils/preprocessing.py:63-89) on float32 [H,W,3] images holding 0..255: with probability 1/2
+    each (applied when the uniform draw is <= 0.5, like the tf.where there) the SAME brightness delta in +-0.05, contrast
+    factor in [0.8, 1.2] and hue rotation in [0.8, 1.2] turns (i.e. +-0.2 of the colour circle) go on both views; then
+    clip to [0, 255].  (The gamma branch is commented out in the reference.)"""
+    active = rng.uniform(0.0, 1.0, size=4)
+    delta = rng.uniform(-0.05, 0.05)
+    contrast = rng.uniform(0.8, 1.2)
+    hue = rng.uniform(0.8, 1.2)
+    out = []
+    for img in (left_img, right_img):
+        x = np.asarray(img, np.float32)
+        if active[1] <= 0.5:
+            x = x + np.float32(delta)                                   # tf.image.adjust_brightness on a float image
+        if active[2] <= 0.5:
+            m = x.mean(axis=(0, 1), keepdims=True)                       # tf.image.adjust_contrast: per-channel mean
+            x = (x - m) * np.float32(contrast) + m
+        if active[3] <= 0.5:
+            h, s, v = _rgb_to_hsv(x)
+            x = _hsv_to_rgb((h + hue) % 1.0, s, v).astype(np.float32)
+        out.append(np.clip(x, 0.0, 255.0).astype(np.float32))
+    return out[0], out[1]
+
+
 class dataset(object):
-    """Iterator with the reference's constructor surface (the arguments the online script uses)."""
+    """Iterator with the reference's constructor surface (Data_utils/data_reader.py:104-197).  Online adaptation reads the list
+    in order, batch 1, centre crop / pad.  is_training=True is Train.py's pipeline: repeat(num_epochs) -> shuffle buffer of
+    50 * batch_size samples -> aligned random crop -> optional augmentation -> batches of batch_size (remainder dropped)."""
 
     def __init__(self, path_file, batch_size=1, crop_shape=(320, 1216), num_epochs=1, augment=False,
-                 is_training=False, shuffle=False):
-        if batch_size != 1 or augment or is_training or shuffle:
-            raise NotImplementedError('online adaptation reads frames in order, batch 1, no augmentation')
+                 is_training=False, shuffle=False, seed=0):
         self._left, self._right, self._gt = read_list_file(path_file)
         self._crop = tuple(crop_shape)
         self._epochs = num_epochs
+        self._batch, self._augment, self._training, self._shuffle = int(batch_size), augment, is_training, shuffle
+        self._rng = np.random.default_rng(seed)
+
+    def __len__(self):
+        return len(self._left)
 
     def get_max_steps(self):
-        return len(self._left) * self._epochs
+        return (len(self._left) * self._epochs) // self._batch
+
+    def _samples(self):
+        order = [i for _ in range(self._epochs) for i in range(len(self._left))]
+        if not self._shuffle:
+            for i in order:
+                yield i
+            return
+        buf, cap = [], self._batch * 50                   # tf.data shuffle(buffer_size): draw uniformly from a sliding buffer
+        for i in order:
+            buf.append(i)
+            if len(buf) > cap:
+                yield buf.pop(int(self._rng.integers(0, len(buf))))
+        while buf:
+            yield buf.pop(int(self._rng.integers(0, len(buf))))
+
+    def _load(self, i):
+        th, tw = self._crop
+        l, r, g = _read_image(self._left[i]), _read_image(self._right[i]), _read_image(self._gt[i], True)
+        g = g[:, :l.shape[1]]                             # "crop gt to fit with image" (:146)
+        if self._training:
+            l, r, g = random_crop(self._crop, [l, r, g], self._rng)
+        else:
+            l, r, g = (center_crop_or_pad(x, th, tw) for x in (l, r, g))
+        if self._augment:
+            l, r = augment(l, r, self._rng)
+        return l, r, g
 
     def __iter__(self):
-        for _ in range(self._epochs):
-            for l, r, g in zip(self._left, self._right, self._gt):
-                th, tw = self._crop
-                yield (center_crop_or_pad(_read_image(l), th, tw)[None],
-                       center_crop_or_pad(_read_image(r), th, tw)[None],
-                       center_crop_or_pad(_read_image(g, True), th, tw)[None])
+        batch = []
+        for i in self._samples():
+            batch.append(self._load(i))
+            if len(batch) == self._batch:
+                yield tuple(np.stack([b[k] for b in batch]).astype(np.float32) for k in range(3))
+                batch = []
 
 
 class device_prefetcher(object):

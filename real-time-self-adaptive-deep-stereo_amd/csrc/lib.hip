@@ -104,6 +104,14 @@ static int run_op(const mh_op& o, void* s) {
             int32_t splits = i[23];
             return mh_conv2d_wgrad_partial(&d, (const float*)p[0], (const float*)p[1], i[21], (float*)p[2], &splits, (float*)p[3], s);
         }
+        case MH_OP_SUPERVISED_LOSS:
+            return mh_supervised_loss((const float*)p[0], (const float*)p[1], (float*)p[2], (float*)p[3], (float*)p[4], o.f[0], o.f[1], o.f[2], i[0], i[1], i[2], s);
+        case MH_OP_ADAM: {        // f = {lr, beta1, beta2, eps}; i[0] = bits of grad_scale
+            float gs; memcpy(&gs, &i[0], sizeof gs);
+            return mh_adam((float*)p[0], (float*)p[1], (float*)p[2], (const float*)p[3], o.n, (const float*)p[4], o.f[0], o.f[1], o.f[2], o.f[3], gs, s);
+        }
+        case MH_OP_ADAM_ADVANCE:
+            return mh_adam_advance((float*)p[0], o.f[0], o.f[1], s);
         case MH_OP_PROXY_LOSS:
             return mh_proxy_loss((const float*)p[0], (const float*)p[1], (float*)p[2], (float*)p[3], (float*)p[4], o.f[0], o.f[1], i[0], i[1], i[2], s);
         case MH_OP_WGRAD_REDUCE:

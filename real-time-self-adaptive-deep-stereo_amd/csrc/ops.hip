@@ -408,7 +408,13 @@ __global__ __launch_bounds__(256) void metrics_final_kernel(MetArgs p) {
 //   valid = !(proxy <= 0 || proxy >= 192) ; loss = weight * sum(valid * |pred - proxy|) / sum(valid)
 //   d loss / d pred = weight * valid * sign(pred - proxy) / sum(valid)       (tf.abs gradient: sign, 0 at 0)
 // ------------------------------------------------------------------------------------------
-struct ProxyArgs { const float* pred; const float* proxy; float* part; float* result; float* dpred; int64_t total; int nblk; float weight, gs; };
+// The supervised multi-scale loss of Train.py (loss_factory.get_supervised_loss('mean_l1'), Losses/loss_factory.py:256-302) is the
+// same reduction with valid = !(target == 0 || target >= max_disp): `hi` / `zero_only` select the rule.
+struct ProxyArgs { const float* pred; const float* proxy; float* part; float* result; float* dpred; int64_t total; int nblk; float weight, gs; float hi; int zero_only; };
+__device__ __forceinline__ float proxy_valid(const ProxyArgs& p, float px) {
+    const bool bad = (p.zero_only ? px == 0.f : px <= 0.f) || px >= p.hi;
+    return bad ? 0.f : 1.f;
+}
 
 __global__ __launch_bounds__(256) void proxy_partial_kernel(ProxyArgs p) {
     __shared__ float red[4];
@@ -416,7 +422,7 @@ __global__ __launch_bounds__(256) void proxy_partial_kernel(ProxyArgs p) {
     float e = 0.f, v = 0.f;
     if (q < p.total) {
         const float px = p.proxy[q];
-        v = (px <= 0.f || px >= 192.f) ? 0.f : 1.f;
+        v = proxy_valid(p, px);
         e = fabsf(p.pred[q] - px) * v;
     }
     const float se = block_sum(e, red);
@@ -444,7 +450,7 @@ __global__ __launch_bounds__(256) void proxy_grad_kernel(ProxyArgs p) {
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (q >= p.total) return;
     const float px = p.proxy[q];
-    const float v = (px <= 0.f || px >= 192.f) ? 0.f : 1.f;
+    const float v = proxy_valid(p, px);
     const float d = p.pred[q] - px;
     const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
     p.dpred[q] = p.gs * p.weight * v * sgn / p.result[1];
@@ -459,6 +465,24 @@ __global__ __launch_bounds__(256) void momentum_kernel(float* var, float* acc, c
         acc[i] = a;
         var[i] -= lr * a;
     }
+}
+
+// tf.train.AdamOptimizer(lr, beta1) of Train.py:95 (TF 1.12 training/adam.py, ApplyAdam):
+//   lr_t = lr * sqrt(1 - beta2_power) / (1 - beta1_power);  m += (g - m)(1 - b1);  v += (g^2 - v)(1 - b2);
+//   var -= (m * lr_t) / (sqrt(v) + eps)         state = {beta1_power, beta2_power}, multiplied by b1 / b2 AFTER the update
+__global__ __launch_bounds__(256) void adam_kernel(float* var, float* m, float* v, const float* g, int64_t n, const float* state,
+                                                   float lr, float b1, float b2, float eps, float gs) {
+    const float lr_t = lr * sqrtf(1.0f - state[1]) / (1.0f - state[0]);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = gs * g[i];
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);          // the ApplyAdam functor's own form (core/kernels/training_ops.cc)
+        const float vi = v[i] + (gi * gi - v[i]) * (1.0f - b2);
+        m[i] = mi; v[i] = vi;
+        var[i] -= (mi * lr_t) / (sqrtf(vi) + eps);
+    }
+}
+__global__ void adam_advance_kernel(float* state, float b1, float b2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { state[0] *= b1; state[1] *= b2; }
 }
 
 __global__ __launch_bounds__(256) void copy_channels_kernel(const float* src, int src_ld, float* dst, int dst_ld, int64_t npix,
@@ -627,16 +651,41 @@ extern "C" int mh_metrics(const float* disp, const float* gt, float* ws, float* 
 
 extern "C" int64_t mh_proxy_ws_floats(int32_t B, int32_t H, int32_t W) { return 2 * nblk((int64_t)B * H * W); }
 
-extern "C" int mh_proxy_loss(const float* pred, const float* proxy, float* ws, float* result, float* dpred, float weight,
-                             float grad_scale, int32_t B, int32_t H, int32_t W, void* stream) {
-    MH_REQUIRE(pred && proxy && ws && result, MH_ERR_ARG, "mh_proxy_loss: null argument");
-    MH_REQUIRE(B > 0 && H > 0 && W > 0, MH_ERR_ARG, "mh_proxy_loss: bad dimension");
-    ProxyArgs a{pred, proxy, ws, result, dpred, (int64_t)B * H * W, (int)nblk((int64_t)B * H * W), weight, grad_scale};
+static int masked_l1(const char* what, const float* pred, const float* target, float* ws, float* result, float* dpred, float weight,
+                     float grad_scale, float hi, int zero_only, int32_t B, int32_t H, int32_t W, void* stream) {
+    MH_REQUIRE(pred && target && ws && result, MH_ERR_ARG, "%s: null argument", what);
+    MH_REQUIRE(B > 0 && H > 0 && W > 0, MH_ERR_ARG, "%s: bad dimension", what);
+    ProxyArgs a{pred, target, ws, result, dpred, (int64_t)B * H * W, (int)nblk((int64_t)B * H * W), weight, grad_scale, hi, zero_only};
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(proxy_partial_kernel, dim3(a.nblk), dim3(256), 0, s, a);
     hipLaunchKernelGGL(proxy_final_kernel, dim3(1), dim3(256), 0, s, a);
     if (dpred) hipLaunchKernelGGL(proxy_grad_kernel, dim3(a.nblk), dim3(256), 0, s, a);
-    return mh_check_launch("proxy_loss");
+    return mh_check_launch(what);
+}
+
+extern "C" int mh_proxy_loss(const float* pred, const float* proxy, float* ws, float* result, float* dpred, float weight,
+                             float grad_scale, int32_t B, int32_t H, int32_t W, void* stream) {
+    return masked_l1("mh_proxy_loss", pred, proxy, ws, result, dpred, weight, grad_scale, 192.0f, 0, B, H, W, stream);
+}
+
+extern "C" int mh_supervised_loss(const float* pred, const float* target, float* ws, float* result, float* dpred, float weight,
+                                  float grad_scale, float max_disp, int32_t B, int32_t H, int32_t W, void* stream) {
+    MH_REQUIRE(max_disp > 0.f, MH_ERR_ARG, "mh_supervised_loss: max_disp must be positive");
+    return masked_l1("mh_supervised_loss", pred, target, ws, result, dpred, weight, grad_scale, max_disp, 1, B, H, W, stream);
+}
+
+extern "C" int mh_adam(float* var, float* m, float* v, const float* grad, int64_t n, const float* state, float lr, float beta1,
+                       float beta2, float eps, float grad_scale, void* stream) {
+    MH_REQUIRE(var && m && v && grad && state && n > 0, MH_ERR_ARG, "mh_adam: bad argument");
+    MH_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, MH_ERR_ARG, "mh_adam: beta out of [0, 1)");
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, var, m, v, grad, n, state, lr, beta1, beta2, eps, grad_scale);
+    return mh_check_launch("adam");
+}
+
+extern "C" int mh_adam_advance(float* state, float beta1, float beta2, void* stream) {
+    MH_REQUIRE(state, MH_ERR_ARG, "mh_adam_advance: null state");
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, beta1, beta2);
+    return mh_check_launch("adam_advance");
 }
 
 extern "C" int mh_momentum(float* var, float* accum, const float* grad, int64_t n, float lr, float momentum,

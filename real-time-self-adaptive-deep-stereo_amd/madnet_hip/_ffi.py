@@ -30,7 +30,7 @@ class Op(C.Structure):
 
 (OP_CONV, OP_WGRAD, OP_CORR_FWD, OP_CORR_BWD, OP_WARP_FWD, OP_WARP_BWD, OP_RESIZE_FWD, OP_RESIZE_BWD,
  OP_PAD_REFLECT, OP_LOSS, OP_METRICS, OP_MOMENTUM, OP_COPY_CH, OP_LEAKY_BWD, OP_FILL, OP_BIAS_GRAD,
- OP_WGRAD_PARTIAL, OP_WGRAD_REDUCE, OP_PROXY_LOSS) = range(1, 20)
+ OP_WGRAD_PARTIAL, OP_WGRAD_REDUCE, OP_PROXY_LOSS, OP_SUPERVISED_LOSS, OP_ADAM, OP_ADAM_ADVANCE) = range(1, 23)
 
 
 OP_JOIN = 0x100
@@ -64,6 +64,9 @@ SIGNATURES = {
     "mh_wgrad_reduce": (_I, [_P, _I, _I, _P]),
     "mh_proxy_ws_floats": (_L, [_I, _I, _I]),
     "mh_proxy_loss": (_I, [_P, _P, _P, _P, _P, _F, _F, _I, _I, _I, _P]),
+    "mh_supervised_loss": (_I, [_P, _P, _P, _P, _P, _F, _F, _F, _I, _I, _I, _P]),
+    "mh_adam": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _P]),
+    "mh_adam_advance": (_I, [_P, _F, _F, _P]),
     "mh_corr_fwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mh_corr_bwd": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mh_warp_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),

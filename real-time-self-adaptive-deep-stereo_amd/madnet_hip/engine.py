@@ -308,10 +308,12 @@ class MadNetEngine(object):
             prev = up_V[k]
         return pyr_tr, pyr_need, est_tr, ctx_tr, up_V
 
-    def record_backward(self, r, head, train_vars, bulkhead):
+    def record_backward(self, r, head, train_vars, bulkhead, heads=None):
         """head: 'final' (loss on rescaled_prediction, FULL mode) or a level k in LEVELS
         (loss on the _make_disp of that level / of the context output for k=2, MAD mode).
         Assumes the matching d(loss)/d(disparity map) is already in self.dpred / self.ddisp_k.
+        heads (offline training, Train.py:100): {'final' | level: gradient buffer} -- a loss on EVERY prediction at once;
+        the per-head gradients accumulate where the heads meet (dfinal, dV[k]).
         Emits: zero of the touched gradient ranges, all needed dgrad/wgrad kernels."""
         lib, B = r, self.B
         P = self.params
@@ -364,19 +366,22 @@ class MadNetEngine(object):
                 ops.conv2d_dgrad(lib, dzv, self.W_(base), dxv, stride=stride, dil=dil, accumulate=acc_flag(dx_key),
                                  mask_ref=x_act, mask_alpha=ALPHA)
 
-        start_level = 2 if head == "final" else head
+        if heads is None:
+            heads = {head: (self.dpred if head == "final" else self.ddisp_k)}
+        start_level = 2 if ("final" in heads or 2 in heads) else min(heads)
         h2, w2, c2 = self.fshape[4]
-        # ---- head -------------------------------------------------------------------------------
-        if head == "final":
-            ops.resize_bwd(lib, self.dpred, self.final, self.dfinal, self.Hp, self.Wp, self.pt, self.pl,
-                           mul=-20.0, mode=2, accumulate=False)
-        elif head == 2:
-            ops.resize_bwd(lib, self.ddisp_k, self.final, self.dfinal, self.Hp, self.Wp, self.pt, self.pl,
-                           mul=-20.0, mode=1, accumulate=False)
-        else:
-            ops.resize_bwd(lib, self.ddisp_k, self.V[head], self.dV[head], self.Hp, self.Wp, self.pt, self.pl,
-                           mul=-20.0, mode=1, accumulate=False)
-            written.add(("V", head))
+        # ---- heads ------------------------------------------------------------------------------
+        for hd in sorted(heads, key=lambda x: (0 if x == "final" else x)):
+            gbuf = heads[hd]
+            if hd == "final":
+                ops.resize_bwd(lib, gbuf, self.final, self.dfinal, self.Hp, self.Wp, self.pt, self.pl,
+                               mul=-20.0, mode=2, accumulate=acc_flag(("final",)))
+            elif hd == 2:
+                ops.resize_bwd(lib, gbuf, self.final, self.dfinal, self.Hp, self.Wp, self.pt, self.pl,
+                               mul=-20.0, mode=1, accumulate=acc_flag(("final",)))
+            else:
+                ops.resize_bwd(lib, gbuf, self.V[hd], self.dV[hd], self.Hp, self.Wp, self.pt, self.pl,
+                               mul=-20.0, mode=1, accumulate=acc_flag(("V", hd)))
         # ---- context network ----------------------------------------------------------------------
         if start_level == 2:
             any_below = up_V[2]
@@ -493,6 +498,27 @@ class MadNetEngine(object):
         for o, c in P.ranges(train_vars):
             ops.momentum(r, P.w[o:o + c], P.m[o:o + c], P.g[o:o + c], lr, momentum, grad_scale, n=c)
 
+    def record_update_adam(self, r, train_vars, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+        """tf.train.AdamOptimizer(lr, 0.9).apply_gradients (Train.py:95,102) on the coalesced ranges of train_vars; the
+        beta-power state advances once per step, after the last range."""
+        P = self.params
+        self._ensure_train_buffers()
+        for o, c in P.ranges(train_vars):
+            ops.adam(r, P.w[o:o + c], P.m[o:o + c], P.v[o:o + c], P.g[o:o + c], self.adam_state, lr, beta1, beta2, eps,
+                     grad_scale, n=c)
+        ops.adam_advance(r, self.adam_state, beta1, beta2)
+
+    def _ensure_train_buffers(self):
+        """Buffers only the offline-training plan needs: second Adam moment, beta powers, one gradient map and one result
+        slot per predicted scale."""
+        if getattr(self, "adam_state", None) is None:
+            z = lambda *shape: torch.zeros(*shape, device=self.dev)
+            self.params.v = z(self.params.total)
+            self.adam_state = torch.tensor([0.9, 0.999], device=self.dev)
+            self.ddisp_ms = {k: z(self.B, self.H0, self.W0) for k in LEVELS}
+            self.res_loss_ms = z(6, 4)                 # rows: final, level 2 (context), 3, 4, 5, 6 = disparities[-1], [-2], ...
+            self.sup_ws = z(self.lib.proxy_ws_floats(self.B, self.H0, self.W0))
+
     # =========================================================================================
     # compiled step plans
     # =========================================================================================
@@ -500,8 +526,10 @@ class MadNetEngine(object):
         return [n for n, _ in self.params.manifest]
 
     def build_plan(self, mode, lr=1e-4, block_vars=None, block_level=None, grad_scale=1.0, update=True,
-                   blocks=None, part="all"):
-        """mode: 'NONE' | 'FULL' | 'MAD'.  For MAD: blocks = [(level, variable names), ...] (level in
+                   blocks=None, part="all", loss_weights=None, max_disp=192.0):
+        """mode: 'NONE' | 'FULL' | 'MAD' | 'TRAIN' (offline training step of Train.py: multi-scale supervised mean_l1 against
+        self.gt with loss_weights from full to lowest resolution, every variable, Adam).
+        For MAD: blocks = [(level, variable names), ...] (level in
         LEVELS, 2 = context output); block_level/block_vars is the single-block shorthand.
         part: 'all' | 'grad' (everything up to the gradients) | 'update' (momentum apply only) -- the
         split lets a gradient all-reduce (shared-model multi-GPU mode) sit between two plans."""
@@ -509,9 +537,31 @@ class MadNetEngine(object):
         self.wsa.reset()
         ops.PRECISION = 1 if self.precision == "bf16" else 0
         try:
+            if mode == "TRAIN":
+                return self._build_train_plan(r, lr, grad_scale, update, part, loss_weights, max_disp)
             return self._build_plan(r, mode, lr, block_vars, block_level, grad_scale, update, blocks, part)
         finally:
             ops.PRECISION = 0
+
+    def _build_train_plan(self, r, lr, grad_scale, update, part, loss_weights, max_disp):
+        """Train.py:56-62,94-102: bulkhead off, loss = sum_i w_i * mean_l1(disparities[-(i+1)], gt, valid), Adam(lr, 0.9)."""
+        self._ensure_train_buffers()
+        lw = list(loss_weights) if loss_weights is not None else [1.0] * 10
+        tv = self.all_vars()
+        if part in ("all", "grad"):
+            self.record_forward(r, make_disps=tuple(LEVELS))
+            order = ["final"] + sorted(LEVELS)                      # disparities[-1], [-2] (context), [-3] (level 3) ... [-6] (level 6)
+            heads = {}
+            for i, hd in enumerate(order):
+                pred = self.pred if hd == "final" else self.disp_k[hd]
+                gbuf = self.dpred if hd == "final" else self.ddisp_ms[hd]
+                ops.supervised_loss(r, pred, self.gt, self.sup_ws, self.res_loss_ms[i], gbuf, weight=lw[i], max_disp=max_disp)
+                heads[hd] = gbuf
+            ops.metrics(r, self.pred, self.gt, self.met_ws, self.res_met, 3.0)
+            self.record_backward(r, None, tv, bulkhead=False, heads=heads)
+        if update and part in ("all", "update"):
+            self.record_update_adam(r, tv, lr, grad_scale=grad_scale)
+        return r.compile()
 
     def _build_plan(self, r, mode, lr, block_vars, block_level, grad_scale, update, blocks, part):
         if blocks is None and block_level is not None:

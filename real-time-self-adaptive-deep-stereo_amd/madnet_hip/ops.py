@@ -248,6 +248,22 @@ def proxy_loss(lib, pred, proxy, ws, result, dpred=None, weight=0.01, grad_scale
     lib.proxy_loss(_p(pred), _p(proxy), _p(ws), _p(result), _p(dpred), weight, grad_scale, B, H, W, _p(stream))
 
 
+def supervised_loss(lib, pred, target, ws, result, dpred=None, weight=1.0, grad_scale=1.0, max_disp=192.0, stream=None):
+    """result[0] = weight * mean_l1(pred, target, valid = !(target == 0 | target >= max_disp)) -- one scale of
+    loss_factory.get_supervised_loss (Train.py:100); dpred = its gradient (optional).  Workspace as proxy_loss."""
+    B, H, W = pred.shape[0], pred.shape[1], pred.shape[2]
+    lib.supervised_loss(_p(pred), _p(target), _p(ws), _p(result), _p(dpred), weight, grad_scale, max_disp, B, H, W, _p(stream))
+
+
+def adam(lib, var, m, v, grad, state, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, n=None, stream=None):
+    """tf.train.AdamOptimizer apply; state = device float[2] {beta1_power, beta2_power} (see adam_advance)."""
+    lib.adam(_p(var), _p(m), _p(v), _p(grad), n if n is not None else var.numel(), _p(state), lr, beta1, beta2, eps, grad_scale, _p(stream))
+
+
+def adam_advance(lib, state, beta1=0.9, beta2=0.999, stream=None):
+    lib.adam_advance(_p(state), beta1, beta2, _p(stream))
+
+
 def metrics(lib, disp, gt, ws, result, pixel_th=3.0, stream=None):
     B, H, W = disp.shape[0], disp.shape[1], disp.shape[2]
     lib.metrics(_p(disp), _p(gt), _p(ws), _p(result), pixel_th, B, H, W, _p(stream))

@@ -93,6 +93,16 @@ class Recorder(object):
     def proxy_loss(self, pred, proxy, ws, result, dpred, weight, grad_scale, B, H, W, stream):
         self._op(_ffi.OP_PROXY_LOSS, [B, H, W], [weight, grad_scale], [pred, proxy, ws, result, dpred])
 
+    def supervised_loss(self, pred, target, ws, result, dpred, weight, grad_scale, max_disp, B, H, W, stream):
+        self._op(_ffi.OP_SUPERVISED_LOSS, [B, H, W], [weight, grad_scale, max_disp], [pred, target, ws, result, dpred])
+
+    def adam(self, var, m, v, grad, n, state, lr, beta1, beta2, eps, gs, stream):
+        import struct
+        self._op(_ffi.OP_ADAM, [struct.unpack("<i", struct.pack("<f", gs))[0]], [lr, beta1, beta2, eps], [var, m, v, grad, state], n=n)
+
+    def adam_advance(self, state, beta1, beta2, stream):
+        self._op(_ffi.OP_ADAM_ADVANCE, [], [beta1, beta2], [state])
+
     def metrics(self, disp, gt, ws, result, th, B, H, W, stream):
         self._op(_ffi.OP_METRICS, [B, H, W], [th], [disp, gt, ws, result])
 

@@ -112,3 +112,30 @@ def test_adapter_dilation_updates_every_other_frame(hip):
     assert moved == [True, False, True, False]
     with pytest.raises(ValueError):
         ad.step(tl, tr, tg)                      # proxy labels are mandatory for loss='proxy'
+
+
+def test_train_cli_end_to_end(hip, tmp_path):
+    """Train.py plumbing: shuffled random-crop batches of 2, augmentation on, 3 steps of the multi-scale
+    supervised loss + Adam in bf16 mode; train_log.csv and a TF checkpoint with the Adam slots that loads back as --weights."""
+    import Train
+    from Data_utils import tf_checkpoint
+    lst = _make_list(tmp_path, 6, 140, 300)
+    out = tmp_path / "train_out"
+    os.makedirs(out)
+    argv = ["--trainingSet", lst, "--validationSet", lst, "-o", str(out), "--weights", "calibrated:1", "--modelName", "MADNet",
+            "--imageShape", "128", "256", "--batchSize", "2", "--numEpochs", "1", "--augment", "--lr", "1e-4",
+            "--lossWeights", "1", "0.8", "0.6", "0.4", "0.2", "0.1"]
+    Train.main(Train.build_parser().parse_args(argv))
+    log = open(out / "train_log.csv").read().strip().split("\n")
+    assert log[0] == "step,loss,EPE,bad3,val_EPE,val_bad3" and len(log) == 2 and log[1].startswith("0,")
+    loss0 = float(log[1].split(",")[1])
+    assert np.isfinite(loss0) and loss0 > 0 and log[1].split(",")[4] != ""
+    ck = tf_checkpoint.latest_checkpoint(str(out)) or str(out / "weights.ckpt-3")
+    rd = tf_checkpoint.CheckpointReader(ck)
+    names = rd.get_variable_to_shape_map()
+    assert int(rd.get_tensor("training_error/Variable")) == 3
+    assert any(n.endswith("/Adam_1") for n in names)
+    import Stereo_Online_Adaptation as SOA
+    w = SOA.load_weights(ck, "MADNet")
+    assert len(w) > 0 and all(np.isfinite(v).all() for v in w.values())
+

@@ -84,3 +84,72 @@ def test_device_prefetcher_surfaces_reader_errors(tmp_path):
     with pytest.raises(Exception):
         for _ in data_reader.device_prefetcher(ds, "cpu"):
             pass
+
+
+def test_training_pipeline_shuffle_crop_batch_augment(tmp_path):
+    """Train.py's input side (Data_utils/data_reader.py:104-197, preprocessing.py:31-89): repeat -> shuffle buffer -> aligned
+    random crop -> augmentation -> batches with the remainder dropped."""
+    rows = []
+    for t in range(5):
+        l = np.random.default_rng(t).integers(0, 256, size=(40, 60, 3)).astype(np.float32)
+        g = np.full((40, 70, 1), float(t + 1), np.float32)          # wider than the image: cropped to its width first
+        g[:, :60, 0] += np.arange(60, dtype=np.float32)[None, :] / 100.0
+        names = [str(tmp_path / ("%s%d.npy" % (k, t))) for k in ("l", "r", "g")]
+        np.save(names[0], l); np.save(names[1], l[:, ::-1].copy()); np.save(names[2], g)
+        rows.append(",".join(names))
+    lst = tmp_path / "train.csv"; lst.write_text("\n".join(rows) + "\n")
+    ds = data_reader.dataset(str(lst), batch_size=2, crop_shape=(32, 48), num_epochs=3, augment=False, is_training=True, shuffle=True, seed=7)
+    assert len(ds) == 5 and ds.get_max_steps() == 7
+    batches = list(ds)
+    assert len(batches) == 7                                          # 15 samples -> 7 batches, remainder dropped
+    ids = []
+    for l, r, g in batches:
+        assert l.shape == (2, 32, 48, 3) and r.shape == (2, 32, 48, 3) and g.shape == (2, 32, 48, 1) and l.dtype == np.float32
+        for b in range(2):
+            t = int(g[b, 0, 0, 0])                                    # sample id; the fractional part = start column / 100
+            c0 = int(round((g[b, 0, 0, 0] - t) * 100))
+            assert 0 <= c0 < 60 - 48 - 1                              # the reference's upper bound never reaches the last offset
+            ids.append(t - 1)
+    assert sorted(set(ids)) == [0, 1, 2, 3, 4] and ids != sorted(ids)  # shuffled, every sample seen
+    # the same crop window on all three arrays: right = mirrored left of the SAME rows / columns is not recoverable, so
+    # check alignment through gt's column ramp against left's known content
+    ds2 = data_reader.dataset(str(lst), batch_size=1, crop_shape=(32, 48), is_training=True, shuffle=False, seed=3)
+    l, r, g = next(iter(ds2))
+    c0 = int(round((g[0, 0, 0, 0] - 1.0) * 100)); full = np.load(str(tmp_path / "l0.npy"))
+    rows_match = [r0 for r0 in range(0, 40 - 32) if np.array_equal(full[r0:r0 + 32, c0:c0 + 48], l[0])]
+    assert len(rows_match) == 1
+    with pytest.raises(ValueError):
+        next(iter(data_reader.dataset(str(lst), batch_size=1, crop_shape=(64, 48), is_training=True)))
+
+
+def test_augment_semantics():
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(8, 9, 3)).astype(np.float32)
+    h, s, v = data_reader._rgb_to_hsv(img)
+    assert np.allclose(data_reader._hsv_to_rgb(h, s, v), img, atol=1e-3)                 # HSV round trip
+    assert np.allclose(data_reader._hsv_to_rgb((h + 1.0) % 1.0, s, v), img, atol=1e-3)   # one full turn = identity
+
+    class Fixed(object):                                     # scripted draws: active flags, delta, contrast, hue
+        def __init__(self, seq):
+            self.seq = list(seq)
+
+        def uniform(self, lo, hi, size=None):
+            return np.asarray(self.seq.pop(0)) if size is not None else self.seq.pop(0)
+
+    # every flag > 0.5: nothing applied (tf.where(active > 0.5, img, adjusted))
+    a, b = data_reader.augment(img, img[:, ::-1], Fixed([[0.9, 0.9, 0.9, 0.9], 0.05, 1.2, 1.2]))
+    assert np.array_equal(a, img) and np.array_equal(b, img[:, ::-1])
+    # contrast only: (x - channel mean) * f + mean, then clipped to [0, 255]; the same factor on both views
+    a, b = data_reader.augment(img, img, Fixed([[0.9, 0.9, 0.1, 0.9], 0.0, 1.2, 1.0]))
+    m = img.mean(axis=(0, 1), keepdims=True)
+    assert np.allclose(a, np.clip((img - m) * 1.2 + m, 0, 255), atol=1e-3) and np.array_equal(a, b)
+    # brightness only: +delta on the 0..255 scale
+    a, _ = data_reader.augment(img, img, Fixed([[0.9, 0.1, 0.9, 0.9], 0.05, 1.0, 1.0]))
+    assert np.allclose(a, np.clip(img + 0.05, 0, 255), atol=1e-4)
+    # hue: grey pixels are unchanged, value (max channel) preserved
+    grey = np.full((2, 2, 3), 77.0, np.float32)
+    a, _ = data_reader.augment(grey, grey, Fixed([[0.9, 0.9, 0.9, 0.1], 0.0, 1.0, 0.9]))
+    assert np.allclose(a, grey, atol=1e-3)
+    a, _ = data_reader.augment(img, img, Fixed([[0.9, 0.9, 0.9, 0.1], 0.0, 1.0, 0.9]))
+    assert np.allclose(a.max(-1), img.max(-1), atol=1e-2) and not np.allclose(a, img, atol=1.0)
+

@@ -220,3 +220,45 @@ def test_continual_proxy_step(bname, size, mode, block):
         o = OM.step(wt, acc, l, r, gt, mode="MAD", block_vars=bv, block_index=block, lr=lr, loss="proxy", proxy=px[..., None])
     plan.run(backend.lib, 0)
     _check(eng, wn, wt, o, backend)
+
+
+@pytest.mark.parametrize("bname,size", [SIZES[0], pytest.param("hip", (128, 256), marks=pytest.mark.gpu, id="hip-128x256")])
+def test_offline_training_step(bname, size):
+    """8(f)-4, Train.py:94-102: one offline training step = forward without bulkhead, multi-scale supervised mean_l1 on all
+    six predictions (distinct weights per scale), gradients of every variable, Adam -- two consecutive steps (the second one
+    exercises the advanced beta powers and non-zero moments) against the oracle's autograd + fp32 Adam restatement."""
+    backend = _backend(bname)
+    H, W = size
+    eng, wn, wt, _, (l, r, gt) = _setup(backend, H, W, seed=5)
+    lw = [1.0, 0.8, 0.6, 0.4, 0.2, 0.1]
+    plan = eng.build_plan("TRAIN", lr=1e-3, loss_weights=lw, max_disp=192.0)
+    am = {k: torch.zeros_like(v) for k, v in wt.items()}
+    av = {k: torch.zeros_like(v) for k, v in wt.items()}
+    st = [0.9, 0.999]
+    for step in range(2):
+        plan.run(backend.lib, 0)
+        backend.sync()
+        o = OM.train_step(wt, am, av, st, l, r, gt, lr=1e-3, loss_weights=lw, max_disp=192.0)
+        assert (eng.pred.cpu() - o["disparity"][..., 0]).abs().mean().item() <= EPE_TOL
+        got = eng.res_loss_ms[:, 0].cpu().tolist()
+        for i, (a, b) in enumerate(zip(got, o["losses"])):
+            assert abs(a - b) <= 5e-5 * max(1.0, abs(b)), (step, i, a, b)
+        if step == 0:                                   # gradients: same criteria as the adaptation steps
+            gmax = max(g.abs().max().item() for g in o["grads"].values())
+            for n, g in o["grads"].items():
+                ge = eng.params.tensor(n, "g").cpu()
+                rel = (ge - g).norm().item() / max(g.norm().item(), 1e-30)
+                # (|x| losses: a prediction within rounding of its target flips the sign of that pixel's gradient, so the
+                #  agreement of the filter gradients degrades with fewer pixels: 2e-3 holds from 60x100 up)
+                assert rel <= 2e-3 or g.abs().max().item() <= 1e-6 * gmax, (n, rel)
+        # Adam normalises every element's step to ~lr whatever the gradient's size (first step: lr * g / (|g| + 3e-7)), so an
+        # element whose gradient is at the rounding level moves by a different fraction of lr: bound the worst element by a
+        # fraction of lr and the mean deviation by a much smaller one
+        worst, mean = 0.0, 0.0
+        for n in wt:
+            d = (eng.params.tensor(n).cpu() - wt[n]).abs()
+            worst = max(worst, d.max().item()); mean = max(mean, d.mean().item())
+        print("offline step %d: worst |dw| %.3g lr, worst tensor-mean %.3g lr" % (step, worst / 1e-3, mean / 1e-3))
+        assert worst <= 0.25 * 1e-3 * (step + 1) and mean <= 1e-4 * 1e-3 * (step + 1), (step, worst, mean)
+        assert torch.allclose(eng.adam_state.cpu(), torch.tensor(st), rtol=1e-6)
+

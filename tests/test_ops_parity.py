@@ -297,3 +297,58 @@ def test_proxy_loss_and_grad(backend, shape):
     valid = ((proxy.cpu() > 0) & (proxy.cpu() < 192)).sum().item()
     assert res[1].item() == float(valid)
     ok, err = _close(dp, gref, rtol=1e-5, atol=1e-9); assert ok, err
+
+
+@pytest.mark.parametrize("shape", [(1, 9, 14), (2, 11, 23)])
+def test_supervised_loss_and_grad(backend, shape):
+    """Train.py's loss term of one scale: weight * masked mean L1 against the ground truth; gt == 0 or >= max_disp is invalid
+    (a NEGATIVE gt stays valid -- unlike the proxy rule)."""
+    B, H, W = shape
+    dev = backend.device
+    g = torch.Generator().manual_seed(23)
+    pred = (torch.rand(B, H, W, generator=g) * 200 - 4).to(dev)
+    gt = torch.rand(B, H, W, generator=g) * 230 - 20
+    gt[0, 0, :4] = torch.tensor([0.0, 192.0, 191.99, -0.0])
+    pred[0, 1, 0] = gt[0, 1, 0]
+    gt = gt.to(dev)
+    pc = pred.cpu().requires_grad_(True)
+    ref = T.supervised_loss(pc, gt.cpu(), 0.7, 192.0)
+    (gref,) = torch.autograd.grad(ref, [pc])
+    ws = torch.zeros(backend.lib.proxy_ws_floats(B, H, W), device=dev)
+    res = torch.zeros(4, device=dev); dp = torch.full((B, H, W), float("nan"), device=dev)
+    ops.supervised_loss(backend.lib, pred, gt, ws, res, dp, weight=0.7, grad_scale=1.0, max_disp=192.0)
+    backend.sync()
+    assert abs(res[0].item() - ref.item()) <= 2e-6 * max(1.0, abs(ref.item()))
+    assert res[1].item() == float(((gt.cpu() != 0) & (gt.cpu() < 192)).sum().item())
+    ok, err = _close(dp, gref, rtol=1e-5, atol=1e-9); assert ok, err
+
+
+def test_adam_update(backend):
+    """tf.train.AdamOptimizer(lr, 0.9): three steps over two variable ranges sharing one beta-power state, through the plan
+    recorder (the way the engine issues them) and eagerly -- against the oracle's fp32 restatement."""
+    from madnet_hip import plan as PL
+    dev = backend.device
+    n = 777
+    w = _rand((n,), 51, dev); m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev)
+    state = torch.tensor([0.9, 0.999], device=dev)
+    wr, mr, vr, sr = w.cpu().clone(), torch.zeros(n), torch.zeros(n), [0.9, 0.999]
+    for t in range(3):
+        g = _rand((n,), 60 + t, dev, 0.3)
+        if t == 1:                                   # recorded + replayed
+            r = PL.Recorder()
+            ops.adam(r, w[:300], m[:300], v[:300], g[:300], state, lr=1e-3, n=300)
+            ops.adam(r, w[300:], m[300:], v[300:], g[300:], state, lr=1e-3, n=n - 300)
+            ops.adam_advance(r, state)
+            r.keep.append(g)
+            r.compile().run(backend.lib, 0)
+        else:
+            ops.adam(backend.lib, w, m, v, g, state, lr=1e-3)
+            ops.adam_advance(backend.lib, state)
+        backend.sync()
+        T.adam_update(wr, mr, vr, g.cpu(), sr, 1e-3)
+        sr[0] = float(torch.tensor(sr[0], dtype=torch.float32) * torch.tensor(0.9, dtype=torch.float32))
+        sr[1] = float(torch.tensor(sr[1], dtype=torch.float32) * torch.tensor(0.999, dtype=torch.float32))
+        assert torch.allclose(w.cpu(), wr, rtol=2e-6, atol=1e-7), (t, (w.cpu() - wr).abs().max())
+        assert torch.allclose(v.cpu(), vr, rtol=1e-6, atol=1e-12) and torch.allclose(m.cpu(), mr, rtol=1e-6, atol=1e-9)
+        assert torch.allclose(state.cpu(), torch.tensor(sr), rtol=1e-7)
+

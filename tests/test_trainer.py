@@ -1,0 +1,121 @@
+"""the offline training step behind Train.py's surface (madnet_hip.trainer.Trainer) -- host logic, the
+data-parallel form over gloo (world size 2) and the checkpoint it writes.  Kernel-level parity of the supervised loss / Adam
+is in test_ops_parity.py, the full step against the oracle in test_engine_parity.py::test_offline_training_step."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "real-time-self-adaptive-deep-stereo_amd")
+H, W = 48, 64
+
+
+def _net(lib, wn, l, r, B=1):
+    import Nets
+    left = torch.from_numpy(np.repeat(l, B, 0)); right = torch.from_numpy(np.repeat(r, B, 0))
+    return Nets.get_stereo_net("MADNet", {"left_img": left, "right_img": right, "split_layers": [None], "sequence": True,
+                                          "train_portion": "BEGIN", "bulkhead": False, "weights": wn, "_lib": lib, "_device": "cpu"})
+
+
+def test_trainer_steps_match_oracle_and_checkpoint(tmp_path):
+    from conftest import _emul_backend
+    from madnet_hip import engine as E, synthetic as S
+    from madnet_hip.trainer import Trainer
+    from oracle import madnet as OM
+    from Data_utils import tf_checkpoint
+    import Train
+    backend = _emul_backend()
+    wn = S.calibrated_weights(dict(E.madnet_manifest()), 2)
+    l, r, gt = S.make_pair(H, W)
+    net = _net(backend.lib, wn, l, r)
+    with pytest.raises(ValueError):
+        Trainer(net, loss_weights=[1.0, 0.5])                       # one weight per predicted scale
+    with pytest.raises(NotImplementedError):
+        Trainer(net, loss_type="mean_huber")
+    lw = [1.0, 0.5, 0.5, 0.25, 0.25, 0.125]
+    tr = Trainer(net, lr=1e-3, loss_weights=lw, use_graph=False)
+    wt = {k: torch.from_numpy(v.copy()) for k, v in wn.items()}
+    am = {k: torch.zeros_like(v) for k, v in wt.items()}; av = {k: torch.zeros_like(v) for k, v in wt.items()}
+    st = [0.9, 0.999]
+    for step in range(1):
+        out = tr.step(l, r, gt[..., 0])
+        o = OM.train_step(wt, am, av, st, torch.from_numpy(l), torch.from_numpy(r), torch.from_numpy(gt), lr=1e-3, loss_weights=lw)
+        assert out["global_step"] == step + 1
+        assert abs(out["loss"] - o["loss"]) <= 1e-4 * max(1.0, abs(o["loss"]))
+        assert np.allclose(out["losses"], o["losses"], rtol=1e-4, atol=1e-6)
+    # checkpoint: variables, both Adam slots, the beta powers and the global step under the reference's names
+    path = Train.save_checkpoint(net, str(tmp_path), tr.global_step)
+    rd = tf_checkpoint.CheckpointReader(path)
+    names = rd.get_variable_to_shape_map()
+    some = next(iter(wn))
+    assert some in names and some + "/Adam" in names and some + "/Adam_1" in names
+    assert np.allclose(rd.get_tensor(some), net.engine.params.tensor(some).numpy())
+    assert np.isclose(rd.get_tensor("training_error/beta1_power"), 0.9 ** 2, rtol=1e-6)
+    assert int(rd.get_tensor("training_error/Variable")) == 1
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["MH_EMUL_THREADS"] = "4"
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from madnet_hip import _ffi, engine as E, synthetic as S
+        from madnet_hip.trainer import Trainer
+        lib = _ffi.Lib(os.path.join(ROOT, "tests", "emul", "libmadnet_emul.so"))
+        lib.ensure_init()
+        wn = S.calibrated_weights(dict(E.madnet_manifest()), 1)
+        l, r, gt = S.make_pair(H, W, stream_id=rank)              # every rank trains on its own sample
+        net = _net(lib, wn, l, r)
+        tr = Trainer(net, lr=1e-3, use_graph=False, data_parallel=True)
+        out = tr.step(l, r, gt[..., 0])
+        w_after = net.engine.params.w.clone()
+        ws = [torch.zeros_like(w_after) for _ in range(world)]
+        dist.all_gather(ws, w_after)
+        q.put((rank, out["loss"], bool(torch.equal(ws[0], ws[1])), w_after.numpy(), net.engine.params.g.clone().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_data_parallel_training_world2():
+    """Two gloo ranks, one sample each: after the step both hold identical weights = Adam applied to the MEAN of the two
+    per-sample gradients (computed here in one process)."""
+    from conftest import _emul_backend
+    from madnet_hip import engine as E, synthetic as S
+    from oracle import tf_ops as T
+    backend = _emul_backend()
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][2] and res[1][2], "ranks diverged after the data-parallel update"
+    wn = S.calibrated_weights(dict(E.madnet_manifest()), 1)
+    gsum = None
+    for sid in range(2):
+        l, r, gt = S.make_pair(H, W, stream_id=sid)
+        eng = E.MadNetEngine(backend.lib, H, W, B=1, device="cpu", weights=wn)
+        eng.set_inputs(l, r, gt[..., 0])
+        eng.build_plan("TRAIN", lr=1e-3, update=False).run(backend.lib, 0)
+        gsum = eng.params.g.clone() if gsum is None else gsum + eng.params.g
+    assert np.allclose(res[0][4], gsum.numpy(), rtol=1e-4, atol=1e-7 * float(gsum.abs().max()) + 1e-12)
+    w = eng.params.w.clone(); m = torch.zeros_like(w); v = torch.zeros_like(w)
+    T.adam_update(w, m, v, 0.5 * gsum, [0.9, 0.999], 1e-3)
+    d = (torch.from_numpy(res[0][3]) - w).abs()
+    assert d.max().item() <= 0.25e-3 and d.mean().item() <= 1e-7, (d.max().item(), d.mean().item())
