@@ -84,6 +84,11 @@ def test_corr_and_misc_argument_checks(backend):
     z = torch.zeros(64, device=dev)
     assert _raw(backend, "reprojection_loss")(P(z), P(z), P(z), P(z), P(z), None, 1.0, 1, 2, 2, None) == ERR_ARG
     assert _raw(backend, "momentum")(P(z), P(z), P(z), 0, 1e-4, 0.9, 1.0, None) == ERR_ARG
+    # offline-training entry points: Adam without its beta-power state / with beta = 1, supervised loss with max_disp <= 0
+    assert _raw(backend, "adam")(P(z), P(z), P(z), P(z), 64, None, 1e-4, 0.9, 0.999, 1e-8, 1.0, None) == ERR_ARG
+    assert _raw(backend, "adam")(P(z), P(z), P(z), P(z), 64, P(z), 1e-4, 1.0, 0.999, 1e-8, 1.0, None) == ERR_ARG and "beta" in _msg(backend)
+    assert _raw(backend, "adam_advance")(None, 0.9, 0.999, None) == ERR_ARG
+    assert _raw(backend, "supervised_loss")(P(z), P(z), P(z), P(z), None, 1.0, 1.0, 0.0, 1, 2, 2, None) == ERR_ARG and "max_disp" in _msg(backend)
     # plan executor: unknown op kind / lane out of range, reported with the op index
     op = (_ffi.Op * 1)(); op[0].kind = 99
     assert _raw(backend, "plan_run")(op, 1, None) == ERR_ARG and "plan op 0" in _msg(backend)
