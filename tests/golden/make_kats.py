@@ -101,6 +101,20 @@ def main():
     v = rnd((1000,), 961); a = rnd((1000,), 962); gr = rnd((1000,), 963)
     acc = 0.9 * a + gr
     out["momentum/accum"], out["momentum/var"] = acc, v - 1e-4 * acc
+    # offline training (Train.py): one scale of the supervised mean_l1 (gt == 0 / >= 192 invalid) with its gradient, three Adam
+    # steps (fp32, the ApplyAdam functor's arithmetic)
+    pr = (rnd((1, 10, 13, 1), 971, 60.0).abs()).float().requires_grad_(True)
+    tg = rnd((1, 10, 13, 1), 972, 90.0).abs().float(); tg[0, 0, :3, 0] = torch.tensor([0.0, 192.0, 250.0])
+    sl = T.supervised_loss(pr, tg, 0.7, 192.0)
+    out["supervised_loss/loss"] = sl.detach().reshape(1).double()
+    out["supervised_loss/gpred"] = torch.autograd.grad(sl, pr)[0]
+    av_, am_, avv = rnd((500,), 981).float(), torch.zeros(500), torch.zeros(500)
+    st = [0.9, 0.999]
+    for t in range(3):
+        T.adam_update(av_, am_, avv, rnd((500,), 982 + t, 0.3).float(), st, 1e-3)
+        st = [float(torch.tensor(st[0], dtype=torch.float32) * torch.tensor(0.9, dtype=torch.float32)),
+              float(torch.tensor(st[1], dtype=torch.float32) * torch.tensor(0.999, dtype=torch.float32))]
+    out["adam/var"], out["adam/m"], out["adam/v"] = av_.clone(), am_.clone(), avv.clone()
     # MADNet: full forward (6 disparities) and one FULL step (loss, EPE, updated weights digest) at 64x128
     wn, l, r, gt = madnet_inputs()
     wt = {k: torch.from_numpy(v.copy()) for k, v in wn.items()}
@@ -114,6 +128,13 @@ def main():
     names = sorted(wt)
     out["madnet_full_step/weight_sums"] = torch.tensor([float(wt[n].double().sum()) for n in names], dtype=torch.float64)
     out["madnet_full_step/weight_abs_sums"] = torch.tensor([float(wt[n].double().abs().sum()) for n in names], dtype=torch.float64)
+    # one offline training step (multi-scale supervised loss + Adam) from the same initial weights
+    wt2 = {k: torch.from_numpy(v.copy()) for k, v in wn.items()}
+    m2 = {k: torch.zeros_like(v) for k, v in wt2.items()}; v2 = {k: torch.zeros_like(v) for k, v in wt2.items()}
+    lw = [1.0, 0.8, 0.6, 0.4, 0.2, 0.1]
+    tres = OM.train_step(wt2, m2, v2, [0.9, 0.999], torch.from_numpy(l), torch.from_numpy(r), torch.from_numpy(gt), lr=1e-4, loss_weights=lw)
+    out["madnet_train_step/losses"] = torch.tensor(tres["losses"], dtype=torch.float64)
+    out["madnet_train_step/weight_sums"] = torch.tensor([float(wt2[n].double().sum()) for n in names], dtype=torch.float64)
     np.savez_compressed(os.path.join(HERE, "kats.npz"), **{k: v.detach().to(torch.float32 if v.dtype != torch.float64 or v.numel() > 64 else torch.float64).numpy() for k, v in out.items()})
     print("wrote %d arrays, %.1f KiB" % (len(out), os.path.getsize(os.path.join(HERE, "kats.npz")) / 1024))
 

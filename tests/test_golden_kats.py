@@ -199,3 +199,63 @@ def test_hip_madnet_forward_and_full_step_kats(backend):
     ref_s, ref_a = _gold("madnet_full_step/weight_sums"), _gold("madnet_full_step/weight_abs_sums")
     assert ((sums - ref_s).abs() <= 2e-5 * ref_a.clamp(min=1.0)).all()
     assert ((asums - ref_a).abs() <= 2e-5 * ref_a.clamp(min=1.0)).all()
+
+
+def _train_kat_inputs():
+    pr = MK.rnd((1, 10, 13, 1), 971, 60.0).abs().float()
+    tg = MK.rnd((1, 10, 13, 1), 972, 90.0).abs().float(); tg[0, 0, :3, 0] = torch.tensor([0.0, 192.0, 250.0])
+    return pr, tg
+
+
+def test_oracle_reproduces_training_kats():
+    pr, tg = _train_kat_inputs()
+    pr = pr.requires_grad_(True)
+    sl = T.supervised_loss(pr, tg, 0.7, 192.0)
+    _check(sl.reshape(1), "supervised_loss/loss", 1e-6)
+    _check(torch.autograd.grad(sl, pr)[0], "supervised_loss/gpred", 1e-6)
+    v, m, vv, st = MK.rnd((500,), 981).float(), torch.zeros(500), torch.zeros(500), [0.9, 0.999]
+    for t in range(3):
+        T.adam_update(v, m, vv, MK.rnd((500,), 982 + t, 0.3).float(), st, 1e-3)
+        st = [float(torch.tensor(st[0], dtype=torch.float32) * torch.tensor(0.9, dtype=torch.float32)),
+              float(torch.tensor(st[1], dtype=torch.float32) * torch.tensor(0.999, dtype=torch.float32))]
+    _check(v, "adam/var", 1e-7); _check(m, "adam/m", 1e-7); _check(vv, "adam/v", 1e-7)
+
+
+def test_hip_training_kats(backend):
+    """Train.py's kernels against the stored answers: supervised mean_l1 (+ gradient) and three Adam steps."""
+    dev = backend.device
+    pr, tg = _train_kat_inputs()
+    pred = pr[..., 0].contiguous().to(dev); gt = tg[..., 0].contiguous().to(dev)
+    ws = torch.zeros(backend.lib.proxy_ws_floats(1, 10, 13), device=dev); res = torch.zeros(4, device=dev)
+    dp = torch.full((1, 10, 13), float("nan"), device=dev)
+    ops.supervised_loss(backend.lib, pred, gt, ws, res, dp, weight=0.7, max_disp=192.0)
+    v = MK.rnd((500,), 981).float().to(dev); m = torch.zeros(500, device=dev); vv = torch.zeros(500, device=dev)
+    st = torch.tensor([0.9, 0.999], device=dev)
+    for t in range(3):
+        ops.adam(backend.lib, v, m, vv, MK.rnd((500,), 982 + t, 0.3).float().to(dev), st, lr=1e-3)
+        ops.adam_advance(backend.lib, st)
+    backend.sync()
+    _check(res[:1], "supervised_loss/loss", 2e-6)
+    _check(dp, "supervised_loss/gpred", 1e-5)
+    _check(v, "adam/var", 2e-6); _check(m, "adam/m", 2e-6); _check(vv, "adam/v", 2e-6)
+
+
+@pytest.mark.gpu
+def test_hip_madnet_train_step_kat(hip):
+    """The six loss terms and per-variable weight digests after one offline training step at 64x128 (lr 1e-4)."""
+    from madnet_hip import engine as E
+    wn, l, r, gt = MK.madnet_inputs()
+    eng = E.MadNetEngine(hip.lib, 64, 128, B=1, device=hip.device, weights=wn)
+    eng.set_inputs(l, r, gt[..., 0])
+    eng.build_plan("TRAIN", lr=1e-4, loss_weights=[1.0, 0.8, 0.6, 0.4, 0.2, 0.1]).run(hip.lib, 0)
+    hip.sync()
+    ref = _gold("madnet_train_step/losses")
+    got = eng.res_loss_ms[:, 0].cpu().double()
+    assert ((got - ref).abs() <= 5e-5 * ref.abs().clamp(min=1.0)).all(), (got, ref)
+    names = sorted(wn)
+    sums = torch.tensor([float(eng.params.tensor(n).double().sum()) for n in names], dtype=torch.float64)
+    ref_s, ref_a = _gold("madnet_train_step/weight_sums"), _gold("madnet_full_step/weight_abs_sums")
+    # every element moves by ~lr: the digest of a tensor may differ by a small fraction of (lr * numel)
+    numel = torch.tensor([float(eng.params.numel(n)) for n in names], dtype=torch.float64)
+    assert ((sums - ref_s).abs() <= 2e-5 * ref_a.clamp(min=1.0) + 2e-3 * 1e-4 * numel).all()
+
