@@ -60,12 +60,7 @@ def test_shared_model_allreduce_world2():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=600) for _ in procs], key=lambda x: x[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    assert res[0][2] and res[1][2], "ranks diverged after the shared update"
-    # reference: single process, gradients of both streams summed, scaled by 1/2
+    # reference (computed while the two ranks work): single process, gradients of both streams summed, scaled by 1/2
     from madnet_hip import engine as E, synthetic as S
     import numpy as np
     shapes = dict(E.madnet_manifest())
@@ -77,6 +72,11 @@ def test_shared_model_allreduce_world2():
         eng.set_inputs(l, r, gt[..., 0])
         eng.build_plan("FULL", lr=1e-2, update=False).run(backend.lib, 0)
         gsum = eng.params.g.clone() if gsum is None else gsum + eng.params.g
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][2] and res[1][2], "ranks diverged after the shared update"
     w0 = eng.params.w.clone()            # untouched (update=False)
     w_ref = w0 - 1e-2 * (0.5 * gsum)     # first step: accum = g/2 ; w -= lr*accum
     assert np.allclose(res[0][4], gsum.numpy(), rtol=1e-4, atol=1e-7 * float(gsum.abs().max()) + 1e-12)

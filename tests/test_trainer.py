@@ -101,11 +101,7 @@ def test_data_parallel_training_world2():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=600) for _ in procs], key=lambda x: x[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    assert res[0][2] and res[1][2], "ranks diverged after the data-parallel update"
+    # the single-process reference runs while the two ranks work
     wn = S.calibrated_weights(dict(E.madnet_manifest()), 1)
     gsum = None
     for sid in range(2):
@@ -114,6 +110,11 @@ def test_data_parallel_training_world2():
         eng.set_inputs(l, r, gt[..., 0])
         eng.build_plan("TRAIN", lr=1e-3, update=False).run(backend.lib, 0)
         gsum = eng.params.g.clone() if gsum is None else gsum + eng.params.g
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][2] and res[1][2], "ranks diverged after the data-parallel update"
     assert np.allclose(res[0][4], gsum.numpy(), rtol=1e-4, atol=1e-7 * float(gsum.abs().max()) + 1e-12)
     w = eng.params.w.clone(); m = torch.zeros_like(w); v = torch.zeros_like(w)
     T.adam_update(w, m, v, 0.5 * gsum, [0.9, 0.999], 1e-3)
