@@ -321,12 +321,19 @@ PATCH_CASES = [(1, 12, 20, 128, 128, 1, 128), (1, 9, 21, 96, 64, 2, 64), (2, 10,
                (1, 12, 19, 96, 128, 1, 128 + 256), (1, 9, 17, 128, 64, 1, 128 + 256 + 2048), (1, 9, 17, 64, 160, 1, 128 + 256)]
 
 
-@pytest.mark.parametrize("case", PATCH_CASES)
+# K = 32 (one chunk per tap, five weight tiles with a dead last half) in both directions.  Added after the round's GPU budget
+# was spent: run on the emulator only (the same instances run on the MI355X inside the engine / bench: the 64->32 layer's dgrad)
+PATCH_CASES_K32 = [(1, 9, 17, 64, 32, 1, 128 + 256), (1, 9, 17, 32, 64, 1, 128 + 256), (1, 9, 18, 32, 48, 2, 64)]
+
+
+@pytest.mark.parametrize("case", PATCH_CASES + PATCH_CASES_K32)
 def test_conv_bf16_patch_kernel(backend, case):
     """Patch-staged bf16 kernel of the stride-1 3x3 (dilated) layers (csrc/conv_patch.hip): forward with bias + leaky and the
     input gradient with accumulate + leaky-grad mask, against the oracle on bf16-rounded operands; every pixel tile
     (64 / 128 pixels, 8-wave variant), dilation sub-lattices with ragged edges, Cin = 38 (row padding must not leak)."""
     B, H, W, Ci, Co, dil, mode = case
+    if case in PATCH_CASES_K32 and backend.name != "emul":
+        pytest.skip("emulator-only case (see PATCH_CASES_K32)")
     dev = backend.device
     x = _rand((B, H, W, Ci), 91, dev)
     w = _rand((3, 3, Ci, Co), 92, dev, 0.2)
@@ -350,7 +357,11 @@ def test_conv_bf16_patch_kernel(backend, case):
     finally:
         ops.PRECISION = 0
         launches = backend.lib.tune_conv_patch(-1)
-    assert launches == (0 if mode == 1 else (2 if Ci % 4 == 0 else 1))      # mode 1: too small for the tile heuristic -> gather kernel
+    # dispatch rule (mh_conv_patch_ok): >= 48 output channels, >= 32 input channels, 16-byte rows; mode 1: these shapes are too
+    # small for the tile heuristic -> gather kernel
+    fwd_ok = Co >= 48 and Ci >= 32
+    dgrad_ok = Ci >= 48 and Co >= 32 and Ci % 4 == 0
+    assert launches == (0 if mode == 1 else int(fwd_ok) + int(dgrad_ok))
     assert (y.cpu() - y_ref).abs().max().item() <= 1e-4 * max(1.0, y_ref.abs().max().item())
     exp = (old.cpu() + gx_ref) * torch.where(mref.cpu() > 0, 1.0, 0.2)
     assert (dxb[..., :Ci].cpu() - exp).abs().max().item() <= 1e-4 * max(1.0, gx_ref.abs().max().item())
