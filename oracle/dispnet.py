@@ -117,3 +117,26 @@ def step(wts, accum, left, right, gt, mode="FULL", lr=1e-4):
     if grads:
         momentum_update(wts, accum, grads, lr)
     return out
+
+
+def train_step(wts, adam_m, adam_v, adam_state, left, right, gt, lr=1e-4, loss_weights=None, max_disp=192.0):
+    """One iteration of Train.py:94-102,125-140 for DispNet (its default model): multi-scale supervised mean_l1 over the 7
+    predictions (weights from disparities[-1] = rescaled_prediction down to up5/predict), every variable, Adam(lr, 0.9)."""
+    names = list(wts.keys())
+    for n in names:
+        wts[n].requires_grad_(True)
+    disps = forward(wts, left, right)
+    lw = list(loss_weights) if loss_weights is not None else [1.0] * 10
+    parts = [T.supervised_loss(disps[-(i + 1)], gt, lw[i], max_disp) for i in range(len(disps))]
+    total = sum(parts)
+    gl = torch.autograd.grad(total, [wts[n] for n in names], allow_unused=True)
+    for n in names:
+        wts[n].requires_grad_(False)
+    grads = {n: g.detach() for n, g in zip(names, gl) if g is not None}
+    with torch.no_grad():
+        for n, g in grads.items():
+            T.adam_update(wts[n], adam_m[n], adam_v[n], g, adam_state, lr)
+        adam_state[0] = float(torch.tensor(adam_state[0], dtype=torch.float32) * torch.tensor(0.9, dtype=torch.float32))
+        adam_state[1] = float(torch.tensor(adam_state[1], dtype=torch.float32) * torch.tensor(0.999, dtype=torch.float32))
+    return {"loss": float(total.detach()), "losses": [float(x.detach()) for x in parts], "disparity": disps[-1].detach(), "grads": grads}
+

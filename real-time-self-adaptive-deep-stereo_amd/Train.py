@@ -120,7 +120,7 @@ def build_parser():
     parser.add_argument("--validationSet", help="list file of the validation set", default=None, type=str)
     parser.add_argument("-o", "--output", help="folder for the checkpoints and the training log", required=True)
     parser.add_argument("--weights", help="initial weights: a TF checkpoint prefix / folder (optional)")
-    parser.add_argument("--modelName", help="stereo model", default="MADNet", choices=Nets.STEREO_FACTORY.keys())
+    parser.add_argument("--modelName", help="stereo model", default="Dispnet", choices=Nets.STEREO_FACTORY.keys())
     parser.add_argument("--lr", help="learning rate of Adam", default=0.0001, type=float)
     parser.add_argument("--imageShape", help='height and width of the random crop', nargs='+', type=int, default=[320, 1216])
     parser.add_argument("--batchSize", help='samples per step (per GPU)', type=int, default=4)

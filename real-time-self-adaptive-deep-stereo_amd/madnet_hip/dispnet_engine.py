@@ -233,11 +233,19 @@ class DispNetEngine(object):
                 last_masks.append(m)
         return acc, last_masks
 
-    def record_backward(self, r):
+    def record_backward(self, r, heads=()):
+        """heads (offline training): [(prediction node, d loss / d make_disp(node))] -- every _make_disp output carries its own
+        loss term (Train.py:100); each is one more consumer of its node and is injected before the op list is walked."""
         lib, B, P = r, self.B, self.params
         ops_fill(lib, P.g, 0, P.total)
         for n in self.nodes.values():
             n.remaining, n.written = n.consumers, False
+        for n, _ in heads:
+            n.remaining += 1
+        for n, gbuf in heads:
+            acc, _ = self._contribute(n)
+            ops.resize_bwd(lib, gbuf, n.st.t.view(B, n.st.H, n.st.W), n.st.g.view(B, n.st.H, n.st.W), self.Hp, self.Wp, self.pt, self.pl,
+                           mul=float(self.Wp) / float(n.st.W), mode=1, accumulate=acc)
         # filter gradients: atomic-free partial sums + one reduction launch, deferred in batches onto side lanes
         # (see engine.MadNetEngine.record_backward); a weight shared by two convs (conv1/conv2 of the two towers)
         # puts its second use into a second, accumulating reduction
@@ -289,9 +297,9 @@ class DispNetEngine(object):
             if kind == "final":
                 n = op[1]
                 g3 = n.st.g.view(B, n.st.H, n.st.W)
+                acc, _ = self._contribute(n)
                 ops.resize_bwd(lib, self.dpred, n.st.t.view(B, n.st.H, n.st.W), g3, self.Hp, self.Wp, self.pt, self.pl,
-                               mul=2.0, mode=0, accumulate=False)
-                self._contribute(n)
+                               mul=2.0, mode=0, accumulate=acc)
             elif kind == "conv":
                 _, x, wn, out, stride, alpha, x_grad = op
                 assert out.written and out.remaining == 0, "gradient of %s incomplete" % out.name
@@ -334,11 +342,47 @@ class DispNetEngine(object):
     def all_vars(self):
         return [n for n, _ in self.params.manifest]
 
-    def build_plan(self, mode, lr=1e-4, grad_scale=1.0, update=True, part="all", **_):
+    # ---- offline training (Train.py) -----------------------------------------------------
+    def _ensure_train_buffers(self):
+        if getattr(self, "adam_state", None) is None:
+            z = lambda *shape: torch.zeros(*shape, device=self.dev)
+            self.params.v = z(self.params.total)
+            self.adam_state = torch.tensor([0.9, 0.999], device=self.dev)
+            self.head_names = ["prediction"] + [u[0] for u in UP_BLOCKS[::-1]]     # disparities[-2], [-3] (up1) ... [-7] (up5)
+            self.disp_ms = {k: z(self.B, self.H0, self.W0) for k in self.head_names}
+            self.ddisp_ms = {k: z(self.B, self.H0, self.W0) for k in self.head_names}
+            self.res_loss_ms = z(1 + len(self.head_names), 4)                      # rows: rescaled_prediction, then head_names
+            self.sup_ws = z(self.lib.proxy_ws_floats(self.B, self.H0, self.W0))
+
+    def _build_train_plan(self, r, lr, grad_scale, update, part, loss_weights, max_disp):
+        """Train.py:94-102 for DispNet: loss = sum_i w_i * mean_l1(disparities[-(i+1)], gt, valid) over the 7 predictions
+        (rescaled_prediction, _make_disp(prediction), _make_disp(up1/predict) ... _make_disp(up5/predict)), Adam(lr, 0.9)."""
+        self._ensure_train_buffers()
+        lw = list(loss_weights) if loss_weights is not None else [1.0] * 10
+        if part in ("all", "grad"):
+            self.record_forward(r)
+            ops.supervised_loss(r, self.pred, self.gt, self.sup_ws, self.res_loss_ms[0], self.dpred, weight=lw[0], max_disp=max_disp)
+            heads = []
+            for i, name in enumerate(self.head_names):
+                self.record_make_disp(r, name, self.disp_ms[name])
+                ops.supervised_loss(r, self.disp_ms[name], self.gt, self.sup_ws, self.res_loss_ms[i + 1], self.ddisp_ms[name],
+                                    weight=lw[i + 1], max_disp=max_disp)
+                heads.append((self.prediction if name == "prediction" else self.predict[name], self.ddisp_ms[name]))
+            ops.metrics(r, self.pred, self.gt, self.met_ws, self.res_met, 3.0)
+            self.record_backward(r, heads=heads)
+        if update and part in ("all", "update"):
+            P = self.params
+            ops.adam(r, P.w, P.m, P.v, P.g, self.adam_state, lr, grad_scale=grad_scale, n=P.total)
+            ops.adam_advance(r, self.adam_state)
+        return r.compile()
+
+    def build_plan(self, mode, lr=1e-4, grad_scale=1.0, update=True, part="all", loss_weights=None, max_disp=192.0, **_):
         r = Recorder()
         self.wsa.reset()
         ops.PRECISION = 1 if self.precision == "bf16" else 0
         try:
+            if mode == "TRAIN":
+                return self._build_train_plan(r, lr, grad_scale, update, part, loss_weights, max_disp)
             return self._build_plan(r, mode, lr, grad_scale, update, part)
         finally:
             ops.PRECISION = 0

@@ -19,7 +19,7 @@ class Trainer(object):
             raise NotImplementedError("supervised loss '%s': the MI355X engine implements Train.py's default, mean_l1" % loss_type)
         eng = net.engine
         if not hasattr(eng, "_build_train_plan"):
-            raise NotImplementedError("offline training is implemented for the MADNet engine")
+            raise NotImplementedError("this engine has no offline-training plan")
         if getattr(net, "_bulkhead", False):
             print("WARNING: Train.py builds the network with bulkhead=False; this net has bulkhead=True")
         npred = len(net.get_disparities())
@@ -40,7 +40,8 @@ class Trainer(object):
         self.stream = torch.cuda.Stream(device=dev) if self.cuda else None
         self.global_step = 0
         self._plans = None
-        self._host = torch.zeros(6 * 4 + 4, pin_memory=self.cuda)
+        self.npred = npred
+        self._host = torch.zeros(npred * 4 + 4, pin_memory=self.cuda)
 
     def _build(self):
         eng = self.eng
@@ -72,14 +73,15 @@ class Trainer(object):
                 for o, c in eng.params.ranges(eng.all_vars()):
                     self.dist.all_reduce(eng.params.g[o:o + c], group=self.pg)
                 self._plans[1].launch(self.lib, sh)
-            self._host[0:24].copy_(eng.res_loss_ms.reshape(-1), non_blocking=True)
-            self._host[24:28].copy_(eng.res_met, non_blocking=True)
+            n4 = 4 * self.npred
+            self._host[0:n4].copy_(eng.res_loss_ms.reshape(-1), non_blocking=True)
+            self._host[n4:n4 + 4].copy_(eng.res_met, non_blocking=True)
         if self.cuda:
             self.stream.synchronize()
         h = self._host.numpy()
-        losses = [float(h[4 * i]) for i in range(6)]
+        losses = [float(h[4 * i]) for i in range(self.npred)]
         self.global_step += 1
-        return {"loss": float(np.sum(losses)), "losses": losses, "epe": float(h[24]), "bad3": float(h[25]),
+        return {"loss": float(np.sum(losses)), "losses": losses, "epe": float(h[4 * self.npred]), "bad3": float(h[4 * self.npred + 1]),
                 "global_step": self.global_step}
 
     def prediction(self):
