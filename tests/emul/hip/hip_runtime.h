@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <ucontext.h>
+#include <setjmp.h>
 #include <algorithm>
 #include <atomic>
 #include <functional>
@@ -76,7 +77,9 @@ static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 namespace emul {
 
 struct Fiber {
-    ucontext_t ctx;
+    ucontext_t ctx;            // first entry only (makecontext / setcontext put the fiber on its own stack)
+    jmp_buf env;               // every later switch: _setjmp / _longjmp (no signal-mask system call, ~20x cheaper than swapcontext)
+    bool started = false;
     char* stack = nullptr;
     bool done = true;
     uint3_ tidx{0, 0, 0};
@@ -92,6 +95,7 @@ struct Tls {
     std::vector<Fiber> fibers;
     std::vector<Wave> waves;
     ucontext_t main_ctx;
+    jmp_buf main_env;
     Fiber* cur = nullptr;
     int cur_index = 0;
     int nthreads = 0, alive = 0;
@@ -105,7 +109,7 @@ struct Tls {
 
 inline Tls& tls() { static thread_local Tls t; return t; }
 
-inline void yield() { Tls& t = tls(); swapcontext(&t.cur->ctx, &t.main_ctx); }
+inline void yield() { Tls& t = tls(); if (_setjmp(t.cur->env) == 0) _longjmp(t.main_env, 1); }
 
 inline void block_barrier() {
     Tls& t = tls();
@@ -134,7 +138,7 @@ inline void fiber_entry() {
     if (t.alive > 0 && t.bar_count >= t.alive) { t.bar_count = 0; ++t.bar_gen; }
     Wave& w = t.waves[t.cur_index >> 6];
     if (w.alive > 0 && w.count >= w.alive) { w.count = 0; ++w.gen; }
-    swapcontext(&t.cur->ctx, &t.main_ctx);
+    _longjmp(t.main_env, 1);                      // back to the scheduler for good (this stack is never resumed)
 }
 
 inline void run_block(const std::function<void()>& body, unsigned bx, dim3 grid, dim3 block, size_t shmem) {
@@ -155,7 +159,7 @@ inline void run_block(const std::function<void()>& body, unsigned bx, dim3 grid,
         Fiber& f = t.fibers[i];
         getcontext(&f.ctx);
         f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = STACK; f.ctx.uc_link = &t.main_ctx;
-        f.done = false; f.tidx = uint3_{(unsigned)i, 0, 0};
+        f.done = false; f.started = false; f.tidx = uint3_{(unsigned)i, 0, 0};
         makecontext(&f.ctx, (void (*)())fiber_entry, 0);
     }
     int remaining = n;
@@ -166,7 +170,10 @@ inline void run_block(const std::function<void()>& body, unsigned bx, dim3 grid,
             Fiber& f = t.fibers[i];
             if (f.done) continue;
             t.cur = &f; t.cur_index = i;
-            swapcontext(&t.main_ctx, &f.ctx);
+            if (_setjmp(t.main_env) == 0) {           // the fiber comes back here through _longjmp(main_env)
+                if (!f.started) { f.started = true; setcontext(&f.ctx); }
+                else _longjmp(f.env, 1);
+            }
             if (!f.done) ++remaining;
         }
         if (++spins > 50000000) { fprintf(stderr, "emul: deadlock suspected in block %u\n", bx); abort(); }
