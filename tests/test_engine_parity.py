@@ -187,6 +187,42 @@ def test_bf16_mode_end_to_end(hip):
     assert not torch.equal(w16, w32)              # and it really is a different arithmetic
 
 
+def test_bf16_step_patch_kernel_vs_gather_kernel_emulated():
+    """The patch-staged conv kernel inside the whole engine (channel-slice views, fused masks, accumulating gradients): one bf16
+    FULL step with the kernel forced onto every eligible layer (mh_tune_conv_patch(128 + 256) bypasses the size heuristic, so the
+    60x100 emulator case runs it at every level) against the same step on the gather kernel.  Both round their operands to
+    bf16 identically; only the fp32 summation order differs."""
+    from conftest import _emul_backend
+    backend = _emul_backend()
+    H, W = 60, 100
+    wn = S.calibrated_weights(OM.variable_shapes(), 1)
+    l, r, gt = S.make_pair(H, W)
+    out = {}
+    for mode in (0, 128 + 256, "fp32"):
+        backend.lib.tune_conv_patch(0 if mode == "fp32" else mode)
+        try:
+            eng = E.MadNetEngine(backend.lib, H, W, B=1, device="cpu", weights=wn, precision="fp32" if mode == "fp32" else "bf16")
+            eng.set_inputs(l, r, gt[..., 0])
+            eng.build_plan("FULL", lr=1e-4).run(backend.lib, 0)
+        finally:
+            launches = backend.lib.tune_conv_patch(-1)
+        out[mode] = (eng.pred.clone(), float(eng.res_loss[0].item()), eng.params.g.clone(), launches)
+    p0, l0, g0, n0 = out[0]; p1, l1, g1, n1 = out[128 + 256]; p32, l32, g32, _ = out["fp32"]
+    assert n0 == 0 and n1 >= 40, (n0, n1)                 # estimators 2-6 + context network, forward and input gradients
+    # A different fp32 summation order flips the bf16 rounding of an activation now and then (1 bf16 ulp = 0.4 %) and the next
+    # layers amplify it, so two bf16 runs agree only at the level of the bf16 noise itself.  The yardstick is therefore the fp32
+    # engine: the patch-kernel step must sit as close to it as the gather-kernel step does, and the two bf16 steps must be
+    # closer to each other than their two deviations combined.
+    dev0, dev1, mutual = (p0 - p32).abs().mean().item(), (p1 - p32).abs().mean().item(), (p1 - p0).abs().mean().item()
+    gd0 = (g0 - g32).norm().item() / g32.norm().item(); gd1 = (g1 - g32).norm().item() / g32.norm().item()
+    gm = (g1 - g0).norm().item() / g32.norm().item()
+    print("bf16 vs fp32 (emulated 60x100): disparity dev gather %.3g patch %.3g mutual %.3g; gradient dev gather %.3g patch %.3g mutual %.3g; "
+          "loss %.6f / %.6f / fp32 %.6f; patch launches %d" % (dev0, dev1, mutual, gd0, gd1, gm, l0, l1, l32, n1))
+    assert dev1 <= 1.5 * dev0 + 1e-3 and mutual <= dev0 + dev1
+    assert gd1 <= 1.5 * gd0 + 1e-3 and gm <= gd0 + gd1
+    assert abs(l1 - l32) <= 1.5 * abs(l0 - l32) + 1e-3 * abs(l32)
+
+
 def _proxy_from(gt, seed=3):
     """Proxy labels = ground truth + noise, with holes (<= 0) and out-of-range values (>= 192) as the validity test expects."""
     g = torch.Generator().manual_seed(seed)
