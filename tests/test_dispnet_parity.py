@@ -90,6 +90,36 @@ def test_dispnet_offline_training_step_emulated():
 
 
 @pytest.mark.slow
+def test_dispnet_bf16_patch_kernel_vs_gather_kernel_emulated():
+    """As test_engine_parity.test_bf16_step_patch_kernel_vs_gather_kernel_emulated, for DispNet: its stride-1 3x3 layers bring
+    channel counts the MADNet step never shows the patch-staged kernel (K = 193 from a concat storage, K = N = 256 = two column
+    tiles).  Yardstick = the fp32 engine."""
+    from conftest import _emul_backend
+    backend = _emul_backend()
+    H, W = 40, 64
+    wn = S.calibrated_weights(OD.variable_shapes(), 1)
+    l, r, gt = S.make_pair(H, W)
+    out = {}
+    for mode in (0, 128 + 256, "fp32"):
+        backend.lib.tune_conv_patch(0 if mode == "fp32" else mode)
+        try:
+            eng = DE.DispNetEngine(backend.lib, H, W, B=1, device="cpu", weights=wn, precision="fp32" if mode == "fp32" else "bf16")
+            eng.set_inputs(l, r, gt[..., 0])
+            eng.build_plan("FULL", lr=1e-4).run(backend.lib, 0)
+        finally:
+            launches = backend.lib.tune_conv_patch(-1)
+        out[mode] = (eng.pred.clone(), eng.params.g.clone(), launches)
+    (p0, g0, n0), (p1, g1, n1), (p32, g32, _) = out[0], out[128 + 256], out["fp32"]
+    assert n0 == 0 and n1 >= 3, (n0, n1)                  # conv3/1 forward + input gradient (K = N = 256), iconv2 forward (K = 193)
+    dev0, dev1, mutual = (p0 - p32).abs().mean().item(), (p1 - p32).abs().mean().item(), (p1 - p0).abs().mean().item()
+    gd0 = (g0 - g32).norm().item() / g32.norm().item(); gd1 = (g1 - g32).norm().item() / g32.norm().item()
+    print("DispNet bf16 vs fp32 (emulated): disparity dev gather %.3g patch %.3g mutual %.3g; gradient dev gather %.3g patch %.3g; patch launches %d"
+          % (dev0, dev1, mutual, gd0, gd1, n1))
+    assert dev1 <= 1.5 * dev0 + 1e-3 and mutual <= dev0 + dev1
+    assert gd1 <= 1.5 * gd0 + 1e-3
+
+
+@pytest.mark.slow
 def test_dispnet_full_step_emulated():
     from conftest import _emul_backend
     _run(_emul_backend(), 40, 64, "FULL")        # pads to 64x64
