@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 6
+#define MH_ABI_VERSION 7
 
 /* status codes of every int-returning entry point: 0 = launched; a NEGATIVE code means an argument check failed and
  * nothing was launched or written; a POSITIVE value is the hipError_t of a failed launch / runtime call.
@@ -115,6 +115,18 @@ int mh_corr_bwd(const float* g, int32_t g_ld, int32_t coff, const float* L, int3
                 float* dR, int32_t dr_ld, int32_t acc_r, float* du, int32_t acc_u,
                 int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t stride,
                 int32_t copy_left, void* stream);
+
+/* ---- the reference launchers under their LITERAL signature (+ an explicit stream, + a status) -- what a caller binds who
+ *      keeps sharedLayers.correlation_native (Nets/sharedLayers.py:31-39) as it is: in0 / in1 NHWC with W already zero-padded by
+ *      max_disp on both sides, out / grad NCHW [batch, 2*max_disp+1, in_h, in_w_padded - 2*max_disp].
+ *   mh_shift_corr      replaces ShiftCorrKernelLauncher     (Nets/Native/shift_corr.cc:22-23, shift_corr.cu.cc:193-233)
+ *   mh_shift_corr_grad replaces ShiftCorrGradKernelLauncher (Nets/Native/shift_corr.cc:58-60, shift_corr.cu.cc:235-288): out0 / out1
+ *      = gradient w.r.t. the padded in0 / in1, laid out like them (NHWC) -- the gradient of the forward formula, not the
+ *      reference kernels' defective arithmetic. */
+int mh_shift_corr(const float* in0, const float* in1, int32_t max_disp, int32_t batch, int32_t in_h, int32_t in_w_padded,
+                  int32_t channels, float* out, void* stream);
+int mh_shift_corr_grad(const float* in0, const float* in1, const float* grad, int32_t max_disp, int32_t batch, int32_t height,
+                       int32_t padded_width, int32_t channels, float* out0, float* out1, void* stream);
 
 /* ---- MadNet._build_indeces + _linear_warping (Nets/MadNet.py:378-436) ---------------- */
 int mh_warp_fwd(const float* img, int32_t img_ld, const float* u, float* out, int32_t out_ld,

@@ -69,6 +69,8 @@ SIGNATURES = {
     "mh_adam_advance": (_I, [_P, _F, _F, _P]),
     "mh_corr_fwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mh_corr_bwd": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mh_shift_corr": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "mh_shift_corr_grad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "mh_warp_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "mh_warp_bwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "mh_resize_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P]),

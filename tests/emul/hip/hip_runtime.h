@@ -68,6 +68,7 @@ static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
@@ -114,7 +115,11 @@ inline void yield() { Tls& t = tls(); if (_setjmp(t.cur->env) == 0) _longjmp(t.m
 inline void block_barrier() {
     Tls& t = tls();
     const int gen = t.bar_gen;
-    if (++t.bar_count >= t.alive) { t.bar_count = 0; ++t.bar_gen; }
+    // the releasing (last-arriving) fiber yields once too, so that after a barrier the fibers resume in thread order: code
+    // that relies on a warp running in lockstep behind a barrier (lane 0 reads what the other lanes wrote BEFORE they
+    // start the next iteration: /root/reference/Nets/Native/shift_corr.cu.cc:41-66, built by oracle/Makefile) then sees the
+    // same values as on the hardware
+    if (++t.bar_count >= t.alive) { t.bar_count = 0; ++t.bar_gen; yield(); }
     else while (t.bar_gen == gen) yield();
 }
 
@@ -154,7 +159,7 @@ inline void run_block(const std::function<void()>& body, unsigned bx, dim3 grid,
     t.waves.assign((n + 63) / 64, Wave());
     for (int i = 0; i < n; ++i) t.waves[i >> 6].alive++;
     t.nthreads = n; t.alive = n; t.bar_gen = 0; t.bar_count = 0;
-    t.bidx = uint3_{bx % grid.x, bx / grid.x, 0}; t.bdim = block; t.gdim = grid; t.body = &body;      // 2-D grids: bx linearised
+    t.bidx = uint3_{bx % grid.x, (bx / grid.x) % grid.y, bx / (grid.x * grid.y)}; t.bdim = block; t.gdim = grid; t.body = &body;      // 3-D grids: bx linearised
     for (int i = 0; i < n; ++i) {
         Fiber& f = t.fibers[i];
         getcontext(&f.ctx);
@@ -183,7 +188,7 @@ inline void run_block(const std::function<void()>& body, unsigned bx, dim3 grid,
 template <typename F>
 inline void launch(F&& f, dim3 grid, dim3 block, size_t shmem) {
     const std::function<void()> body = f;
-    const unsigned nb = grid.x * grid.y;
+    const unsigned nb = grid.x * grid.y * grid.z;
     unsigned nthr = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), nb);
     const char* env = getenv("MH_EMUL_THREADS");
     if (env) nthr = std::max(1, std::min<int>(atoi(env), (int)nb));
