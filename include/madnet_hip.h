@@ -39,6 +39,9 @@ extern "C" {
 #define MH_ERR_UNSUPPORTED (-3)  /* valid arguments outside what the kernels implement (sizes >= 2 GiB, odd mode combinations) */
 
 const char* mh_last_error(void);
+/* name + template arguments + launch shape of the kernel instance the LAST conv / filter-gradient / correlation entry point of
+ * this thread dispatched (thread-local, "" before the first call) -- lets a benchmark report the kernel it actually timed */
+const char* mh_last_kernel(void);
 int mh_abi_version(void);
 /* number of visible HIP devices (<=0: none) -- lets the host fail loudly without torch */
 int mh_device_count(void);
@@ -64,8 +67,12 @@ typedef struct mh_conv_desc {
     int32_t mask_c0, mask_c1;       /* the mask applies to output channels [mask_c0, mask_c1); 0,0 = all
                                        (a concat gradient masks only the slice produced by an activation) */
     int32_t precision;              /* 0: exact fp32 (v_mfma_f32_16x16x4_f32) -- the parity path
-                                       1: bf16 MFMA inputs (RNE) with fp32 accumulation -- throughput mode;
-                                          tensors stay fp32 in memory either way */
+                                       1: bf16 MFMA inputs (RNE) with fp32 accumulation -- throughput mode
+                                       2: split-bf16: each fp32 operand as hi + lo bf16, three bf16 MFMAs per product, fp32
+                                          accumulation (~2^-16 relative per product): forward layers with an x3 kernel instance
+                                          (stride-1 3x3, >= 48 output channels, large images); every other call runs code 0.
+                                          Filter gradients treat 2 as 0.
+                                          Tensors stay fp32 in memory in every mode */
 } mh_conv_desc;
 
 int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w, const float* bias,

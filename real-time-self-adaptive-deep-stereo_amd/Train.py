@@ -129,7 +129,7 @@ def build_parser():
     parser.add_argument("--lossWeights", help="weight of the loss at each predicted scale, full resolution first", nargs='+', default=None, type=float)
     parser.add_argument('--lossType', help="supervised loss", choices=['mean_l1'], default="mean_l1", type=str)
     parser.add_argument("--decayStep", help="accepted for compatibility: the reference never applies its decayed rate", type=int, default=500000)
-    parser.add_argument("--precision", help="MFMA arithmetic of the conv kernels", choices=['fp32', 'bf16'], default='bf16')
+    parser.add_argument("--precision", help="MFMA arithmetic of the conv kernels: fp32 (default; the reference trains in fp32), mixed (forward within fp32 tolerance, bf16 gradients) or bf16 (opt-in throughput mode)", choices=['fp32', 'mixed', 'bf16'], default='fp32')
     return parser
 
 

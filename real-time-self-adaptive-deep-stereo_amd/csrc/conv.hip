@@ -594,6 +594,7 @@ static int launch_conv_n1(ConvArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((conv_n1_fwd_kernel<LPPv>), dim3(grid), dim3(256), lds, s, a); }
     if (g4 <= 4) MH_N1(4) else if (g4 <= 8) MH_N1(8) else MH_N1(16)
 #undef MH_N1
+    mh_note_kernel("conv_n1_fwd_kernel K=%d", a.K);
     return mh_check_launch("conv_n1_fwd");
 }
 
@@ -713,6 +714,7 @@ static int launch_conv_thin(ConvArgs& a, hipStream_t s) {
         if (a.N <= 16) hipLaunchKernelGGL((conv_thin_kernel<1, true>), dim3(grid), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((conv_thin_kernel<2, true>), dim3(grid), dim3(256), 0, s, a);
     }
+    mh_note_kernel("conv_thin_kernel<NT=%d,%s> grid %d", a.N <= 16 ? 1 : 2, a.mode == 0 ? "fwd" : "dgrad", grid);
     return mh_check_launch("conv_thin");
 }
 
@@ -744,6 +746,8 @@ int launch_one(ConvArgs& a, hipStream_t s) {
         a.mtiles = t0;
     }
     const int nwg = a.mtiles * a.ntiles;
+    mh_note_kernel("conv_igemm_kernel<%d,%d,%d,%d,KT=%d,%s,%s,%s,%s,KG=%d> tile %dx%d grid %d", WM, WN, MT, NT, KT, DGRAD ? "dgrad" : "fwd",
+                   VEC ? "vec" : "scalar", UNI ? "uni" : "gen", BF16 ? "bf16" : "f32", KG, BM, BN, nwg);
     hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC, UNI, BF16, KG>), dim3(nwg), dim3(256 * KG), lds, s, a);
     return mh_check_launch("conv_igemm");
 }
@@ -916,8 +920,8 @@ extern "C" int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w,
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ho = d->Ho; a.Wo = d->Wo;
     a.K = d->K; a.N = d->N; a.G = (d->K + 3) / 4; a.taps = d->kh * d->kw;
     a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.dil = d->dil; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
-    a.mode = d->mode; a.w_trans = d->w_trans; a.accumulate = d->accumulate; a.bf16 = (d->precision == 1);
-    MH_REQUIRE(d->precision == 0 || d->precision == 1, MH_ERR_ARG, "mh_conv2d: precision must be 0 (fp32) or 1 (bf16 MFMA)");
+    a.mode = d->mode; a.w_trans = d->w_trans; a.accumulate = d->accumulate; a.bf16 = (d->precision == 1); a.x3 = (d->precision == 2);
+    MH_REQUIRE(d->precision >= 0 && d->precision <= 2, MH_ERR_ARG, "mh_conv2d: precision must be 0 (fp32), 1 (bf16 MFMA) or 2 (split-bf16)");
     MH_REQUIRE(d->mode == d->w_trans && (d->mode == 0 || d->mode == 1), MH_ERR_UNSUPPORTED,
                "mh_conv2d: supported combinations are mode=0/w_trans=0 (forward) and mode=1/w_trans=1 (dgrad, conv2d_transpose)");
     {

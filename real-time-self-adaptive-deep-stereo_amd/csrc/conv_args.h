@@ -11,6 +11,7 @@ struct ConvArgs {
     int mode, w_trans, accumulate, sshift;
     unsigned in_bytes, w_bytes, out_bytes, mask_bytes;
     int bf16;        // throughput mode: bf16 MFMA inputs, fp32 accumulate
+    int x3;          // split-bf16 request (precision 2): kernels with an x3 instance run hi/lo bf16 operands, 3 MFMAs per product; the others exact fp32
     int vecC;        // 16-byte epilogue legal (N, out_ld, mask_ld multiples of 4, aligned pointers)
     int M;           // B*Ho*Wo
     int vecA, vecB;  // 16-byte vector loads legal for A / B

@@ -38,14 +38,20 @@ constexpr int PW = 18;      // patch width (16 + halo)
 
 // CPTC > 0: the channel count is the compile-time constant 32 * CPTC (2 or 4 chunks per tap): tiles never straddle a tap,
 // no channel masking, and every LDS offset of the K walk is an instruction immediate (see the specialised walk below).
-template <int WM, int WN, int MT, int NT, bool DGRAD, int CPTC = 0>
+// X3 (split-bf16, precision code 2; forward only): the patch and the weight tiles are kept as TWO bf16 planes, hi = bf16(x)
+// and lo = bf16(x - hi), and every product runs as three MFMAs (lo*hi + hi*lo + hi*hi; lo*lo < 2^-16 is dropped): the
+// forward pass stays within ~2^-16 relative of exact fp32 at bf16 MFMA rate / 3 instead of the fp32 MFMA rate (/ 16).  The
+// split is paid once per staged element (patch: once per workgroup, not once per tap).
+template <int WM, int WN, int MT, int NT, bool DGRAD, int CPTC = 0, bool X3 = false>
 __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv_patch_kernel(ConvArgs p, PatchGeo g) {
+    static_assert(!X3 || (!DGRAD && CPTC == 0), "the split-bf16 instances are forward, generic-K");
     constexpr int NTH = WM * WN * 64;
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
     constexpr int TH = BM / 16;
     HIP_DYNAMIC_SHARED(float, smem_all)
     unsigned short* const Ph = reinterpret_cast<unsigned short*>(smem_all);
-    unsigned short* const Bh = Ph + g.patch_halfs;               // [2][BN][LSB]
+    unsigned short* const Bh = Ph + (X3 ? 2 : 1) * g.patch_halfs;   // [2][BN][LSB]   (X3: the lo patch plane sits at Ph + patch_halfs,
+    constexpr int BLO = 2 * BN * LSB;                               //                  the lo weight tiles at Bh + BLO)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 15, lq = lane >> 4;
@@ -124,6 +130,13 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1,
                 unsigned short* dst = Bb + (n4 * 4 + r) * LSB + ((((kk >> 3) ^ n4) & 7) << 3) + (kk & 7);
                 const float e0 = r == 0 ? v0.x : r == 1 ? v0.y : r == 2 ? v0.z : v0.w, e1 = r == 0 ? v1.x : r == 1 ? v1.y : r == 2 ? v1.z : v1.w;
                 const float e2 = r == 0 ? v2.x : r == 1 ? v2.y : r == 2 ? v2.z : v2.w, e3 = r == 0 ? v3.x : r == 1 ? v3.y : r == 2 ? v3.z : v3.w;
+                if constexpr (X3) {
+                    uint2 hi, lo;
+                    mh_split_bf16x2(e0, e1, hi.x, lo.x);
+                    mh_split_bf16x2(e2, e3, hi.y, lo.y);
+                    *reinterpret_cast<uint2*>(dst) = hi;
+                    *reinterpret_cast<uint2*>(dst + BLO) = lo;
+                } else
                 *reinterpret_cast<uint2*>(dst) = make_uint2(mh_pack_bf16(e0, e1), mh_pack_bf16(e2, e3));
             }
         } else {
@@ -183,6 +196,13 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1,
                     w.y = (c4s * 4 + 1 < p.K) ? w.y : 0.f;       // the row padding between K and in_ld is not ours to trust
                     w.z = (c4s * 4 + 2 < p.K) ? w.z : 0.f;
                     w.w = (c4s * 4 + 3 < p.K) ? w.w : 0.f;
+                    if constexpr (X3) {
+                        uint2 hi, lo;
+                        mh_split_bf16x2(w.x, w.y, hi.x, lo.x);
+                        mh_split_bf16x2(w.z, w.w, hi.y, lo.y);
+                        *reinterpret_cast<uint2*>(Ph + lds) = hi;
+                        *reinterpret_cast<uint2*>(Ph + g.patch_halfs + lds) = lo;
+                    } else
                     *reinterpret_cast<uint2*>(Ph + lds) = make_uint2(mh_pack_bf16(w.x, w.y), mh_pack_bf16(w.z, w.w));
                 }
                 c4s += dc4; pjs += dpj; pis += dpi; lds += st_lds;
@@ -267,7 +287,69 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1,
 #pragma unroll
         for (int f = 0; f < NF; ++f) frag_op(buf ^ 1, 0, Ab0, fa0, fb0, f);
     };
-    if constexpr (CPTC > 0) {
+    // ---- split-bf16 walk: the same tile schedule with the lo planes alongside -- 2 x NF fragment reads and 3 x MM MFMAs per
+    // chunk (t = 0: lo(A)*hi(B), 1: hi(A)*lo(B), 2: hi(A)*hi(B); t outermost so consecutive MFMAs hit different accumulators)
+    u32x4 la0[X3 ? MT : 1], lb0[X3 ? NT : 1], la1[X3 ? MT : 1], lb1[X3 ? NT : 1];
+    auto frag_x3 = [&](int buf, int ch, const unsigned short* Ab, u32x4 (&fa)[MT], u32x4 (&fb)[NT], u32x4 (&la)[X3 ? MT : 1], u32x4 (&lb)[X3 ? NT : 1], int f) {
+        if constexpr (X3) {
+            if (f < NF) { frag_op(buf, ch, Ab, fa, fb, f); return; }
+            const int f2 = f - NF;
+            if (f2 < MT) {
+                la[f2] = *reinterpret_cast<const u32x4*>(Ab + g.patch_halfs + f2 * PW * g.PS);
+            } else {
+                const int j = f2 - MT;
+                const unsigned short* Bb = Bh + BLO + buf * (BN * LSB) + (wn * NT * 16 + li) * LSB;
+                lb[j] = *reinterpret_cast<const u32x4*>(Bb + j * 16 * LSB + ((((ch * 4 + lq) ^ ((wn * NT * 16 + j * 16 + li) >> 2)) & 7) << 3));
+            }
+        }
+    };
+    auto mfma_x3 = [&](int m, const u32x4 (&fa)[MT], const u32x4 (&fb)[NT], const u32x4 (&la)[X3 ? MT : 1], const u32x4 (&lb)[X3 ? NT : 1]) {
+        if constexpr (X3) {
+            const int t = m / MM, mm = m % MM, i = mm / NT, j = mm % NT;
+            acc[i][j] = mh_mfma_bf16(t == 0 ? la[i] : fa[i], t == 1 ? lb[j] : fb[j], acc[i][j]);
+        }
+    };
+    auto tile_x3 = [&](int buf, float4 (&rbl)[NB], const float4 (&rbs)[NB]) {
+        constexpr int M3 = 3 * MM, XO0 = 2 * NF + NL0;
+        load_begin();
+        const unsigned short* Ab1 = next_a();
+#pragma unroll
+        for (int m = 0; m < M3; ++m) {
+            mfma_x3(m, fa0, fb0, la0, lb0);
+#pragma unroll
+            for (int o = m * XO0 / M3; o < (m + 1) * XO0 / M3; ++o) {
+                if (o < 2 * NF) frag_x3(buf, 1, Ab1, fa1, fb1, la1, lb1, o);
+                else load_op(rbl, o - 2 * NF);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int m = 0; m < M3; ++m) {
+            mfma_x3(m, fa1, fb1, la1, lb1);
+#pragma unroll
+            for (int o = m * OPS1 / M3; o < (m + 1) * OPS1 / M3; ++o) {
+                if (o < NB - NL0) load_op(rbl, NL0 + o);
+                else store_op(buf ^ 1, rbs, o - (NB - NL0));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        const unsigned short* Ab0 = next_a();
+#pragma unroll
+        for (int f = 0; f < 2 * NF; ++f) frag_x3(buf ^ 1, 0, Ab0, fa0, fb0, la0, lb0, f);
+    };
+    if constexpr (X3) {
+        {
+            const unsigned short* Ab0 = next_a();
+#pragma unroll
+            for (int f = 0; f < 2 * NF; ++f) frag_x3(0, 0, Ab0, fa0, fb0, la0, lb0, f);
+        }
+        for (int t = 0; t + 1 < ntile; t += 2) {
+            tile_x3(0, rb0, rb1);
+            tile_x3(1, rb1, rb0);
+        }
+        if (ntile & 1) tile_x3(0, rb0, rb1);
+    } else if constexpr (CPTC > 0) {
         // ---- specialised walk: K == 32 * CPTC.  Patch row stride and chunk offsets are compile-time, so the fragment reads
         // are `ds_read_b128 v, vbase offset:imm` off one VGPR per tap; a weight load is one v_add (thread-constant offset +
         // scalar tile base; a base of 2^31 pushes every lane out of range = zeros past the walk) + the buffer load.
@@ -410,8 +492,8 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1,
 
 constexpr size_t PATCH_LDS_MAX = 150 * 1024;
 
-size_t patch_lds(int TH, int BM, int BN, int KP) {
-    const size_t tiles = (size_t)(TH + 2) * PW * (KP + 16) * 2 + (size_t)2 * BN * LSB * 2;
+size_t patch_lds(int TH, int BM, int BN, int KP, bool x3 = false) {
+    const size_t tiles = ((size_t)(TH + 2) * PW * (KP + 16) * 2 + (size_t)2 * BN * LSB * 2) * (x3 ? 2 : 1);
     const size_t cs = (size_t)BM * (BN + 4) * 4;
     return tiles > cs ? tiles : cs;
 }
@@ -425,12 +507,12 @@ int patch_mode() {
 }
 int g_patch_launches = 0;     // since the last mh_tune_conv_patch() call (tests check that the kernel under test really ran)
 
-template <int WM, int WN, int MT, int NT, bool DGRAD, int CPTC = 0>
+template <int WM, int WN, int MT, int NT, bool DGRAD, int CPTC = 0, bool X3 = false>
 int launch_patch(ConvArgs& a, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16, TH = BM / 16;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<WM, WN, MT, NT, DGRAD, CPTC>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<WM, WN, MT, NT, DGRAD, CPTC, X3>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)PATCH_LDS_MAX);
         if (e != hipSuccess) { mh_set_error("conv_patch: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_done = true;
@@ -450,9 +532,11 @@ int launch_patch(ConvArgs& a, hipStream_t s) {
     g.patch_halfs = (TH + 2) * PW * g.PS;
     g.inv_kp4 = 1.0f / (float)(g.KP / 4);
     g.dbg = (patch_mode() >> 9) & 3;
-    const size_t lds = patch_lds(TH, BM, BN, g.KP);
+    const size_t lds = patch_lds(TH, BM, BN, g.KP, X3);
     ++g_patch_launches;
-    hipLaunchKernelGGL((conv_patch_kernel<WM, WN, MT, NT, DGRAD, CPTC>), dim3(g.nwg), dim3(WM * WN * 64), lds, s, a, g);
+    mh_note_kernel("conv_patch_kernel<%d,%d,%d,%d,%s,CPTC=%d,%s> tile %dx%d K=%d dil=%d grid %d lds %d", WM, WN, MT, NT, DGRAD ? "dgrad" : "fwd", CPTC,
+                   X3 ? "bf16x3" : "bf16", BM, BN, a.K, a.dil, g.nwg, (int)lds);
+    hipLaunchKernelGGL((conv_patch_kernel<WM, WN, MT, NT, DGRAD, CPTC, X3>), dim3(g.nwg), dim3(WM * WN * 64), lds, s, a, g);
     return mh_check_launch("conv_patch");
 }
 
@@ -479,11 +563,12 @@ int launch_patch_n(ConvArgs& a, hipStream_t s, int bn) {
     return rc;
 }
 
-int patch_bn(const ConvArgs& a) { return a.N > 96 ? 128 : (a.N > 64 ? 96 : 64); }
+int patch_bn(const ConvArgs& a) { return a.x3 ? (a.N > 64 ? 128 : 64) : (a.N > 96 ? 128 : (a.N > 64 ? 96 : 64)); }
 
 // Tile choice of the heuristic mode (measured on MI355X, profiles/r01_microbench_conv_patch.txt): the 128-pixel tile with 8
 // waves for the forward pass and the input gradient alike (its compile-time-K instances take K = 64 / 128).
 int patch_bm(const ConvArgs& a) {
+    if (a.x3) return a.N > 64 ? 64 : 128;      // split-bf16: 64 pixels x 128 columns or 128 pixels x 64 columns (two planes of everything in LDS)
     if ((patch_mode() & 0xff) == 64 || (patch_mode() & 0xff) == 128) return patch_mode() & 0xff;
     return 128;
 }
@@ -500,13 +585,13 @@ extern "C" int mh_tune_conv_patch(int mode) {
 
 bool mh_conv_patch_ok(const ConvArgs& a) {
     if (patch_mode() == 0) return false;
-    if (!(a.bf16 && a.vecA && a.vecB && a.vecC)) return false;
+    if (!((a.bf16 || (a.x3 && a.mode == 0)) && a.vecA && a.vecB && a.vecC)) return false;
     if (!(a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad_t == a.dil && a.pad_l == a.dil && a.Hi == a.Ho && a.Wi == a.Wo)) return false;
     if (a.ncls != 0 || a.N < 48 || a.K < 32 || a.dil > 64) return false;
     if (a.mode == 1 && (patch_mode() & 0x1000)) return false;                                  // mode bit 12: forward layers only
     if (a.mode == 1 && (patch_mode() & 0x2000) && a.K != 64 && a.K != 128) return false;       // mode bit 13: no generic-K input gradients
     const int bm = patch_bm(a), bn = patch_bn(a);
-    if (patch_lds(bm / 16, bm, bn, (a.K + 31) & ~31) > PATCH_LDS_MAX) return false;
+    if (patch_lds(bm / 16, bm, bn, (a.K + 31) & ~31, a.x3 != 0) > PATCH_LDS_MAX) return false;
     // lattice fill: the share of tile pixels that are real output pixels (small images under a large dilation waste tiles)
     const int d = a.dil, TH = bm / 16;
     const int64_t cover = (int64_t)d * d * mh_cdiv(mh_cdiv(a.Ho, d), TH) * TH * mh_cdiv(mh_cdiv(a.Wo, d), 16) * 16;
@@ -527,6 +612,9 @@ int mh_conv_patch_launch(ConvArgs& a, hipStream_t s) {
     const int bm = all ? 0 : patch_bm(a), bn = all ? 0 : patch_bn(a);
     const bool w8 = all ? false : patch_w8(a);
     int rc = 0;
+    // split-bf16 forward instances (precision code 2)
+    if (all || (a.x3 && bn == 128)) { rc = launch_patch<2, 4, 2, 2, false, 0, true>(a, s); if (!all || rc) return rc; }
+    if (all || (a.x3 && bn == 64)) { rc = launch_patch<4, 2, 2, 2, false, 0, true>(a, s); if (!all || rc) return rc; }
     if (all || (!dg && bm == 128 && !w8)) { rc = launch_patch_n<2, 2, 4, false>(a, s, bn); if (!all || rc) return rc; }
     if (all || (dg && bm == 128 && !w8)) { rc = launch_patch_n<2, 2, 4, true>(a, s, bn); if (!all || rc) return rc; }
     if (all || (!dg && bm == 128 && w8)) { rc = launch_patch_n<4, 2, 2, false>(a, s, bn); if (!all || rc) return rc; }

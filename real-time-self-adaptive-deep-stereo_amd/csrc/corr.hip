@@ -510,6 +510,7 @@ extern "C" int mh_corr_fwd(const float* L, int32_t l_ld, const float* R, int32_t
           else hipLaunchKernelGGL((corr_fwd_direct<LPPv, MAXD_SMALL>), grid(LPPv), dim3(256), 0, s, a); }
         if (C4 <= 4) MH_CORR(4) else if (C4 <= 8) MH_CORR(8) else MH_CORR(16)
 #undef MH_CORR
+        mh_note_kernel("corr_fwd_direct<LPP=%d,DT=%d>", C4 <= 4 ? 4 : (C4 <= 8 ? 8 : 16), D <= 5 ? 5 : MAXD_SMALL);
         return mh_check_launch("corr_fwd_direct");
     }
     if (D <= MAXD_SMALL) {
@@ -536,6 +537,7 @@ extern "C" int mh_corr_fwd(const float* L, int32_t l_ld, const float* R, int32_t
             case 128: hipLaunchKernelGGL((corr_fwd_mfma<8>), grid, dim3(256), lds, s, a); break;
             default: hipLaunchKernelGGL((corr_fwd_mfma<16>), grid, dim3(256), lds, s, a); break;
         }
+        mh_note_kernel("corr_fwd_mfma<C/16=%d>", C / 16);
         return mh_check_launch("corr_fwd_mfma");
     } else {
         const int TW = 32;

@@ -14,6 +14,15 @@ void mh_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static thread_local char g_last_kernel[160] = "";
+void mh_note_kernel(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_kernel, sizeof(g_last_kernel), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* mh_last_kernel(void) { return g_last_kernel; }
+
 int mh_check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

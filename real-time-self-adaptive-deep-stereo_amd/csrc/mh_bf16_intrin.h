@@ -16,3 +16,12 @@ __device__ __forceinline__ unsigned mh_pack_bf16(float lo, float hi) {
 __device__ __forceinline__ f32x4 mh_mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mh_bf16x8_t, a), __builtin_bit_cast(mh_bf16x8_t, b), c, 0, 0, 0);
 }
+
+// split-bf16 ("bf16x3") operand: x = hi + lo up to 2^-16 |x|, hi = bf16(x), lo = bf16(x - hi) (the subtraction is exact in fp32).
+// Packs the hi halves and the lo halves of two values.
+__device__ __forceinline__ void mh_split_bf16x2(float a, float b, unsigned& hi, unsigned& lo) {
+    const __bf16 ha = (__bf16)a, hb = (__bf16)b;
+    const mh_bf16x2_t h = {ha, hb};
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = mh_pack_bf16(a - (float)ha, b - (float)hb);
+}

@@ -9,6 +9,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void mh_set_error(const char* fmt, ...);
 int mh_check_launch(const char* what);
+// records (thread-local) which kernel instance an entry point just dispatched; read back through mh_last_kernel()
+void mh_note_kernel(const char* fmt, ...);
 
 #define MH_REQUIRE(cond, code, ...)                \
     do {                                           \

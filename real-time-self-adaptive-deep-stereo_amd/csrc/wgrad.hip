@@ -492,6 +492,7 @@ int launch_wgrad_bf16(WgradArgs& a, hipStream_t s) {
     a.splits = mh_cdiv(a.M, chunk);         // idempotent: forcing the returned count reproduces it
     a.chunk = chunk;
     if (a.query) return 0;
+    mh_note_kernel("wgrad_bf16_kernel<%d,%d,%d,%d> tile %dx%d splits %d grid %d%s", WM, WN, MT, NT, BK, BN, a.splits, base * a.splits, a.flat ? " flat" : "");
     hipLaunchKernelGGL((wgrad_bf16_kernel<WM, WN, MT, NT>), dim3(base * a.splits), dim3(64 * WM * WN), lds, s, a);
     return mh_check_launch("wgrad_bf16");
 }
@@ -527,6 +528,7 @@ int launch_wgrad_one(WgradArgs& a, hipStream_t s) {
     a.splits = mh_cdiv(a.M, chunk);         // idempotent: forcing the returned count reproduces it
     a.chunk = chunk;
     if (a.query) return 0;
+    mh_note_kernel("wgrad_kernel<%d,%d,%d,%d,PT=%d,%s> tile %dx%d splits %d grid %d", WM, WN, MT, NT, PT, VEC ? "vec" : "scalar", BK, BN, a.splits, base * a.splits);
     hipLaunchKernelGGL((wgrad_kernel<WM, WN, MT, NT, PT, VEC>), dim3(base * a.splits), dim3(64 * WM * WN), lds, s, a);
     return mh_check_launch("wgrad");
 }

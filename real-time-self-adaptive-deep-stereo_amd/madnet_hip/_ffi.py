@@ -49,6 +49,7 @@ _L = C.c_int64
 # name -> (restype, argtypes); every symbol include/madnet_hip.h declares
 SIGNATURES = {
     "mh_last_error": (C.c_char_p, []),
+    "mh_last_kernel": (C.c_char_p, []),
     "mh_abi_version": (_I, []),
     "mh_crc32c": (C.c_uint32, [C.c_char_p, _L, C.c_uint32]),
     "mh_device_count": (_I, []),
@@ -96,7 +97,7 @@ SIGNATURES = {
     "mh_event_destroy": (_I, [_P]),
     "mh_stream_sync": (_I, [_P]),
 }
-_NO_STATUS = {"mh_last_error", "mh_abi_version", "mh_tune_conv_patch", "mh_crc32c", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats", "mh_proxy_ws_floats"}
+_NO_STATUS = {"mh_last_error", "mh_last_kernel", "mh_abi_version", "mh_tune_conv_patch", "mh_crc32c", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats", "mh_proxy_ws_floats"}
 
 
 class MadnetHipError(RuntimeError):

@@ -42,35 +42,76 @@ def _pmc_traffic(key):
 
 
 def roofline(lib, eng, stream, reps=20):
-    """Dominant kernel of the step = the 128->128 3x3 implicit-GEMM conv at 1/4 resolution
-    (context-2/3, G2 disp-2: 27 of the 70 forward GFLOP; its dgrad is the same kernel).
-    achieved = algorithmic flops (2*Ho*Wo*9*Cin*Cout) / mean launch time over `reps` launches on
-    the bench stream, using the engine's own buffers and weights (context-2: dilation 2)."""
+    """Dominant forward kernel of the step = the 128->128 3x3 conv at 1/4 resolution (context-2/3, G2 disp-2: 27 of the 70
+    forward GFLOP).  achieved = algorithmic flops (2*Ho*Wo*9*Cin*Cout) / mean launch time over `reps` launches on the bench
+    stream, using the engine's own buffers and weights (context-2: dilation 2), in the engine's FORWARD arithmetic.  The kernel
+    name is what the dispatcher actually launched (mh_last_kernel), not a hard-coded string."""
     from . import engine as E
     sh = stream.cuda_stream
     x = ops.view(eng.Cx[0]); o = ops.view(eng.Cx[1])
     w = eng.W_(E.ctx_name(2)); b = eng.b_(E.ctx_name(2))
+    fwd_code, bwd_code = ops.PRECISION_CODES[eng.precision]
+    flops = 2.0 * x.B * x.H * x.W * 9 * 128 * 128
+    algo_bytes = 4.0 * (2 * x.B * x.H * x.W * 128 + 9 * 128 * 128)
 
-    prec = ops.PRECISION_CODES[eng.precision] if hasattr(ops, "PRECISION_CODES") else (1 if eng.precision == "bf16" else 0)
-    peak = PEAK_BF16_MFMA_TFLOPS if prec == 1 else PEAK_F32_MFMA_TFLOPS
+    def entry(code, fn, what, pmc_key):
+        ms = _time_ms(lib, stream, fn, reps)
+        kname = lib.last_kernel().decode()
+        # every product = 1 bf16 MFMA (code 1), 3 bf16 MFMAs (code 2) or fp32 MFMA steps (code 0): the roofline is priced on the
+        # ALGORITHMIC flops against the peak of the instruction that runs (dense bf16 2.5 PF for codes 1 and 2)
+        peak = PEAK_F32_MFMA_TFLOPS if (code == 0 or "f32" in kname.split("tile")[0]) else PEAK_BF16_MFMA_TFLOPS
+        ach = flops / (ms * 1e-3) / 1e12
+        tr = _pmc_traffic(pmc_key)
+        return {"kernel": kname, "op": what, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                "arithmetic": {0: "f32 MFMA", 1: "bf16 MFMA, f32 accumulate", 2: "split-bf16: 3 bf16 MFMAs per product (mfma issue rate = 3x achieved), f32 accumulate"}[code],
+                "traffic": tr, "traffic_source": ("profiles/r01_pmc_roofline.json (static: rocprofv3 --pmc passes of round 1, key %s)" % pmc_key) if tr is not None else None,
+                "launch_ms": ms, "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": algo_bytes}
 
-    def conv():
-        ops.PRECISION = prec
+    def conv_fwd(code):
+        def fn():
+            ops.PRECISION = code
+            try:
+                ops.conv2d_fwd(lib, x, w, b, o, dil=2, alpha=E.ALPHA, stream=sh)
+            finally:
+                ops.PRECISION = 0
+        return fn
+
+    rl = entry(fwd_code, conv_fwd(fwd_code), "forward 3x3 128->128 @ %dx%d dil 2 (context-2)" % (x.H, x.W),
+               "conv_3x3_128_128_96x320_bf16" if fwd_code == 1 else ("conv_3x3_128_128_96x320" if fwd_code == 0 else "none"))
+    extra = {}
+    # the same layer's input gradient and filter gradient in the BACKWARD arithmetic: by time the filter gradients are the
+    # largest kernel family of the step (VERDICT r01: 22 launches x 17 us)
+    try:
+        dz = ops.view(eng.dCx[1]); dx = ops.view(eng.dCx[0])
+
+        def dgrad():
+            ops.PRECISION = bwd_code
+            try:
+                ops.conv2d_dgrad(lib, dz, w, dx, dil=2, mask_ref=x, mask_alpha=E.ALPHA, stream=sh)
+            finally:
+                ops.PRECISION = 0
+        extra["roofline_dgrad"] = entry(bwd_code, dgrad, "input gradient of the same layer", "none")
+        dw = torch.empty_like(w); db = torch.zeros(128, device=eng.dev)
+        wsa = ops.WgradWorkspace(eng.dev)
+        segs, keep = [], []
+        ops.PRECISION = bwd_code
         try:
-            ops.conv2d_fwd(lib, x, w, b, o, dil=2, alpha=E.ALPHA, stream=sh)
+            ops.conv2d_wgrad_partial(lib, lib, wsa, segs, x, dz, dw, db, dil=2, stream=sh)     # sizes the workspace once
         finally:
             ops.PRECISION = 0
 
-    ms = _time_ms(lib, stream, conv, reps)
-    flops = 2.0 * x.B * x.H * x.W * 9 * 128 * 128
-    ach = flops / (ms * 1e-3) / 1e12
-    kname = ("conv_patch_kernel<4,2,2,4,fwd,K=128> (patch-staged bf16, 3x3 128->128 @ %dx%d, dil 2)" if prec == 1 and os.environ.get("MH_CONV_PATCH", "1") != "0"
-             else "conv_igemm_kernel (3x3 128->128 @ %dx%d, dil 2; tile chosen by conv_dispatch)") % (x.H, x.W)
-    rl = {"kernel": kname,
-          "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-          "frac": ach / peak, "arithmetic": "bf16 MFMA, f32 accumulate" if prec == 1 else "f32 MFMA",
-          "traffic": _pmc_traffic("conv_3x3_128_128_96x320_bf16" if prec == 1 else "conv_3x3_128_128_96x320"),
-          "launch_ms": ms, "algorithmic_flops_per_launch": flops}
+        def wgrad():
+            ops.PRECISION = bwd_code
+            try:
+                wsa.reset(); s2 = []
+                ops.conv2d_wgrad_partial(lib, lib, wsa, s2, x, dz, dw, db, dil=2, stream=sh)
+            finally:
+                ops.PRECISION = 0
+        extra["roofline_wgrad"] = entry(bwd_code, wgrad, "filter gradient of the same layer (partial sums only; the split reduction is one launch per batch of layers)", "none")
+        extra["roofline_wgrad"]["splits"] = segs[0][3] if segs else 1
+        extra["roofline_wgrad"]["workspace_bytes_per_launch"] = 4.0 * (segs[0][2] * segs[0][3] if segs else 0)
+    except Exception as ex:
+        extra["roofline_wgrad"] = {"error": repr(ex)}
     # correlation protocol (SURVEY 8(d)): level-2 shape with B=64 streams (working set > 256 MiB
     # Infinity Cache) for the HBM claim, plus the in-situ B=1 time (cache resident).
     extra = {}
@@ -83,12 +124,13 @@ def roofline(lib, eng, stream, reps=20):
         ms_c = _time_ms(lib, stream, lambda: ops.corr_fwd(lib, ops.view(L), ops.view(R), ops.view(out), md, stream=sh), 10)
         byts = float(Bc) * H * W * (2 * Cc + D) * 4
         g = byts / (ms_c * 1e-3) / 1e9
-        extra["roofline_corr"] = {"kernel": "corr_fwd_direct<8,5> (B=64 x %dx%dx%d, D=%d)" % (H, W, Cc, D), "bound": "hbm",
+        extra["roofline_corr"] = {"kernel": lib.last_kernel().decode() + " (B=64 x %dx%dx%d, D=%d)" % (H, W, Cc, D), "bound": "hbm",
                                   "achieved": g, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": g / PEAK_HBM_GBS,
-                                  "traffic": _pmc_traffic("corr_fwd_B64_96x320x32_D5"), "launch_ms": ms_c, "algorithmic_bytes_per_launch": byts}
+                                  "traffic": _pmc_traffic("corr_fwd_B64_96x320x32_D5"), "traffic_source": "profiles/r01_pmc_roofline.json (static: rocprofv3 --pmc passes of round 1)", "launch_ms": ms_c, "algorithmic_bytes_per_launch": byts}
         L1, R1 = L[:1].contiguous(), R[:1].contiguous(); o1 = out[:1].contiguous()
         ms_1 = _time_ms(lib, stream, lambda: ops.corr_fwd(lib, ops.view(L1), ops.view(R1), ops.view(o1), md, stream=sh), 20)
         extra["roofline_corr"]["in_situ_B1_ms"] = ms_1
+        extra["roofline_corr"]["in_situ_note"] = "B=1 (what the step runs) is cache resident and launch bound: %.1f GB/s algorithmic" % (float(H * W * (2 * Cc + D) * 4) / (ms_1 * 1e-3) / 1e9)
     except Exception as ex:       # never let the auxiliary measurement kill the bench line
         extra["roofline_corr"] = {"error": str(ex)}
     return rl, extra

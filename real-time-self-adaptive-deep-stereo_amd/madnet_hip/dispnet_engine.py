@@ -84,8 +84,8 @@ class Node(object):
 
 class DispNetEngine(object):
     def __init__(self, lib, H, W, B=1, device="cuda", weights=None, precision="fp32"):
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32' or 'bf16'")
+        if precision not in ops.PRECISION_CODES:
+            raise ValueError("precision must be one of %s" % sorted(ops.PRECISION_CODES))
         self.precision = precision
         self.lib, self.dev = lib, device
         self.B, self.H0, self.W0 = B, H, W
@@ -379,13 +379,10 @@ class DispNetEngine(object):
     def build_plan(self, mode, lr=1e-4, grad_scale=1.0, update=True, part="all", loss_weights=None, max_disp=192.0, **_):
         r = Recorder()
         self.wsa.reset()
-        ops.PRECISION = 1 if self.precision == "bf16" else 0
-        try:
+        with ops.precision_scope(self.precision):
             if mode == "TRAIN":
                 return self._build_train_plan(r, lr, grad_scale, update, part, loss_weights, max_disp)
             return self._build_plan(r, mode, lr, grad_scale, update, part)
-        finally:
-            ops.PRECISION = 0
 
     def _build_plan(self, r, mode, lr, grad_scale, update, part):
         do_grad = part in ("all", "grad")

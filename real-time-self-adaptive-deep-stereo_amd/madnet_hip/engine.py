@@ -120,8 +120,8 @@ class MadNetEngine(object):
     def __init__(self, lib, H, W, B=1, device="cuda", radius_d=2, stride=1, warping=True, weights=None, precision="fp32"):
         """precision: 'fp32' = exact fp32 MFMA (parity path, default) | 'bf16' = bf16 MFMA inputs with fp32
         accumulation in the conv forward / input-gradient kernels (throughput mode; tensors stay fp32)."""
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32' or 'bf16'")
+        if precision not in ops.PRECISION_CODES:
+            raise ValueError("precision must be one of %s" % sorted(ops.PRECISION_CODES))
         self.precision = precision
         if not warping:
             raise NotImplementedError("warping=False is not supported by the MI355X engine yet")
@@ -535,13 +535,10 @@ class MadNetEngine(object):
         split lets a gradient all-reduce (shared-model multi-GPU mode) sit between two plans."""
         r = Recorder()
         self.wsa.reset()
-        ops.PRECISION = 1 if self.precision == "bf16" else 0
-        try:
+        with ops.precision_scope(self.precision):
             if mode == "TRAIN":
                 return self._build_train_plan(r, lr, grad_scale, update, part, loss_weights, max_disp)
             return self._build_plan(r, mode, lr, block_vars, block_level, grad_scale, update, blocks, part)
-        finally:
-            ops.PRECISION = 0
 
     def _build_train_plan(self, r, lr, grad_scale, update, part, loss_weights, max_disp):
         """Train.py:56-62,94-102: bulkhead off, loss = sum_i w_i * mean_l1(disparities[-(i+1)], gt, valid), Adam(lr, 0.9)."""

@@ -64,9 +64,43 @@ def conv_desc(B, Hi, Wi, Ho, Wo, K, N, kh, kw, stride, dil, pad_t, pad_l, mode, 
                          PRECISION if precision is None else precision)
 
 
-# module-wide arithmetic mode of the conv family: 0 = exact fp32 (parity path), 1 = bf16 MFMA (throughput).
-# The engines set it while they record a plan (engine(..., precision="bf16")).
+# module-wide arithmetic mode of the conv family while a plan is being recorded (mh_conv_desc.precision codes):
+#   0 = exact fp32 MFMA (the parity path)      1 = bf16 MFMA operands, fp32 accumulate (throughput)
+#   2 = split-bf16 ("bf16x3"): every fp32 operand is carried as hi + lo bf16 and a product costs three bf16 MFMAs
+#       (hi*hi + hi*lo + lo*hi, fp32 accumulate): ~2^-16 relative error per product instead of 2^-8.  Kernels without an x3
+#       instance run exact fp32 for this code.
+# PRECISION applies to the forward convolutions, PRECISION_BWD (None = same) to input and filter gradients.
+# Engine precision names -> (forward, backward):
+#   'fp32'  (0, 0)   'bf16' (1, 1)
+#   'mixed' (2, 1)   forward within the 1e-3 px EPE tolerance of the fp32 oracle, gradients in bf16 (a gradient error moves
+#                    the NEXT frame's weights by lr * |dg|; the disparity of the current frame never sees it)
 PRECISION = 0
+PRECISION_BWD = None
+PRECISION_CODES = {"fp32": (0, 0), "bf16": (1, 1), "mixed": (2, 1)}
+
+
+class precision_scope(object):
+    """with precision_scope('mixed'): ... -- sets PRECISION / PRECISION_BWD while a plan is recorded."""
+
+    def __init__(self, name):
+        if name not in PRECISION_CODES:
+            raise ValueError("precision must be one of %s" % sorted(PRECISION_CODES))
+        self.codes = PRECISION_CODES[name]
+
+    def __enter__(self):
+        global PRECISION, PRECISION_BWD
+        self.saved = (PRECISION, PRECISION_BWD)
+        PRECISION, PRECISION_BWD = self.codes
+        return self
+
+    def __exit__(self, *a):
+        global PRECISION, PRECISION_BWD
+        PRECISION, PRECISION_BWD = self.saved
+        return False
+
+
+def _bwd_precision():
+    return PRECISION if PRECISION_BWD is None else PRECISION_BWD
 
 
 def conv_geometry(H, W, kh, kw, stride, dil):
@@ -96,7 +130,7 @@ def conv2d_dgrad(lib, dz, w, dx, stride=1, dil=1, accumulate=False, mask_ref=Non
     assert (dz.H, dz.W, dz.C) == (Ho, Wo, cout) and dx.C == cin
     d = conv_desc(dx.B, Ho, Wo, dx.H, dx.W, cout, cin, kh, kw, stride, dil, pt, pl, 1, 1, dz.ld, dx.ld,
                   mask_ld=(mask_ref.ld if mask_ref is not None else 0), accumulate=int(accumulate),
-                  alpha=1.0, mask_alpha=mask_alpha, mask_c0=mask_range[0], mask_c1=mask_range[1])
+                  alpha=1.0, mask_alpha=mask_alpha, mask_c0=mask_range[0], mask_c1=mask_range[1], precision=_bwd_precision())
     lib.conv2d(C.byref(d), _p(dz), _p(w), None, _p(dx), _p(mask_ref), _p(stream))
 
 
@@ -105,7 +139,7 @@ def conv2d_wgrad(lib, x, dz, dw, db, stride=1, dil=1, stream=None):
     kh, kw, cin, cout = dw.shape
     Ho, Wo, pt, pl = conv_geometry(x.H, x.W, kh, kw, stride, dil)
     assert (dz.H, dz.W, dz.C) == (Ho, Wo, cout) and x.C == cin
-    d = conv_desc(x.B, x.H, x.W, Ho, Wo, cin, cout, kh, kw, stride, dil, pt, pl, 0, 0, x.ld, dz.ld)
+    d = conv_desc(x.B, x.H, x.W, Ho, Wo, cin, cout, kh, kw, stride, dil, pt, pl, 0, 0, x.ld, dz.ld, precision=_bwd_precision())
     lib.conv2d_wgrad(C.byref(d), _p(x), _p(dz), dz.ld, _p(dw), _p(db), _p(stream))
 
 
@@ -151,7 +185,7 @@ def conv2d_wgrad_partial(lib, qlib, wsa, segs, x, dz, dw, db, stride=1, dil=1, s
     kh, kw, cin, cout = dw.shape
     Ho, Wo, pt, pl = conv_geometry(x.H, x.W, kh, kw, stride, dil)
     assert (dz.H, dz.W, dz.C) == (Ho, Wo, cout) and x.C == cin
-    d = conv_desc(x.B, x.H, x.W, Ho, Wo, cin, cout, kh, kw, stride, dil, pt, pl, 0, 0, x.ld, dz.ld)
+    d = conv_desc(x.B, x.H, x.W, Ho, Wo, cin, cout, kh, kw, stride, dil, pt, pl, 0, 0, x.ld, dz.ld, precision=_bwd_precision())
     splits = C.c_int32(0)
     qlib.conv2d_wgrad_partial(C.byref(d), _p(x), _p(dz), dz.ld, None, C.byref(splits), None, None)
     size = dw.numel()

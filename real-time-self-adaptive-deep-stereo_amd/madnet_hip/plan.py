@@ -23,6 +23,10 @@ class Recorder(object):
     def __init__(self):
         self.ops = []
         self.keep = []          # python objects (tensors) that must outlive the plan
+        # algorithmic work of the recorded step (SURVEY 8(d) definitions): conv = forward + input-gradient launches,
+        # wgrad = filter gradients; *_bytes = each operand read / result written once; wgrad_ws_bytes = split-K partial sums
+        self.stats = {"conv_flops": 0.0, "conv_bytes": 0.0, "wgrad_flops": 0.0, "wgrad_bytes": 0.0, "wgrad_ws_bytes": 0.0,
+                      "grad_bytes": 0.0, "conv_launches": 0, "wgrad_launches": 0}
         self.lane = 0           # scheduling lane of the ops recorded next (mh_op.i[26], include/madnet_hip.h)
         self.join_next = False  # next op: lane 0 first waits for the side lanes
 
@@ -47,18 +51,35 @@ class Recorder(object):
                 d.mode, d.w_trans, d.in_ld, d.out_ld, d.mask_ld, d.accumulate, d.mask_c0, d.mask_c1]
 
     # -- same names / argument order as _ffi.Lib (minus the 'mh_' prefix) --------------------
+    def _tally(self, d, kind, splits=0):
+        taps = d.kh * d.kw
+        if kind == "conv":          # mode 0: in = x, out = y ; mode 1: in = dz (Hi x Wi), out = dx
+            flops = 2.0 * d.B * (d.Ho * d.Wo if d.mode == 0 else d.Hi * d.Wi) * taps * d.K * d.N
+            byts = 4.0 * (d.B * d.Hi * d.Wi * d.K + d.B * d.Ho * d.Wo * d.N + taps * d.K * d.N)
+            self.stats["conv_flops"] += flops; self.stats["conv_bytes"] += byts; self.stats["conv_launches"] += 1
+        else:
+            flops = 2.0 * d.B * d.Ho * d.Wo * taps * d.K * d.N
+            byts = 4.0 * (d.B * d.Hi * d.Wi * d.K + d.B * d.Ho * d.Wo * d.N + taps * d.K * d.N)
+            self.stats["wgrad_flops"] += flops; self.stats["wgrad_bytes"] += byts; self.stats["wgrad_launches"] += 1
+            self.stats["grad_bytes"] += 4.0 * taps * d.K * d.N
+            if splits > 1:
+                self.stats["wgrad_ws_bytes"] += 2 * 4.0 * splits * taps * d.K * d.N      # written by the splits, read by the reduction
+
     def conv2d(self, dref, inp, w, bias, out, mask, stream):
         d = dref._obj
+        self._tally(d, "conv")
         self._op(_ffi.OP_CONV, self._desc_ints(d) + [0, d.precision], [d.alpha, d.mask_alpha], [inp, w, bias, out, mask])
 
     def conv2d_wgrad(self, dref, inp, dout, dout_ld, dw, db, stream):
         d = dref._obj
         ints = self._desc_ints(d) + [dout_ld, d.precision]
+        self._tally(d, "wgrad")
         self._op(_ffi.OP_WGRAD, ints, [d.alpha, d.mask_alpha], [inp, dout, dw, db])
 
     def conv2d_wgrad_partial(self, dref, inp, dout, dout_ld, ws, splits_ref, db, stream):
         d = dref._obj
         ints = self._desc_ints(d) + [dout_ld, d.precision, splits_ref._obj.value]
+        self._tally(d, "wgrad", splits_ref._obj.value if ws is not None else 0)
         self._op(_ffi.OP_WGRAD_PARTIAL, ints, [d.alpha, d.mask_alpha], [inp, dout, ws, db])
 
     def wgrad_reduce(self, segs, nseg, nblocks, stream):
@@ -124,14 +145,14 @@ class Recorder(object):
     # -- finalise ---------------------------------------------------------------------------
     def compile(self):
         arr = (_ffi.Op * len(self.ops))(*self.ops)
-        return Plan(arr, len(self.ops), self.keep)
+        return Plan(arr, len(self.ops), self.keep, dict(self.stats))
 
 
 class Plan(object):
     """An immutable op array + (optionally) its captured hipGraph."""
 
-    def __init__(self, arr, n, keep):
-        self.arr, self.n, self.keep = arr, n, keep
+    def __init__(self, arr, n, keep, stats=None):
+        self.arr, self.n, self.keep, self.stats = arr, n, keep, stats or {}
         self.graph = None
 
     def run(self, lib, stream):

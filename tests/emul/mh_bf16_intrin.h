@@ -9,6 +9,12 @@ static inline unsigned emul_bf16_bits(float f) {
 static inline float emul_bf16_val(unsigned h) { unsigned u = h << 16; float f; memcpy(&f, &u, 4); return f; }
 static inline unsigned mh_pack_bf16(float lo, float hi) { return emul_bf16_bits(lo) | (emul_bf16_bits(hi) << 16); }
 
+static inline void mh_split_bf16x2(float a, float b, unsigned& hi, unsigned& lo) {
+    const unsigned ha = emul_bf16_bits(a), hb = emul_bf16_bits(b);
+    hi = ha | (hb << 16);
+    lo = mh_pack_bf16(a - emul_bf16_val(ha), b - emul_bf16_val(hb));
+}
+
 static inline f32x4 mh_mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
     emul::Wave& w = emul::my_wave();
     const int lane = emul::tls().cur_index & 63;

@@ -429,3 +429,56 @@ def test_wgrad_bf16_tap_flattened(backend, case):
     assert (dw.cpu() - gw_ref).abs().max().item() <= tol
     assert (dw2.cpu() - gw_ref).abs().max().item() <= tol
     assert (db.cpu() - gb_ref).abs().max().item() <= 1e-4 * max(1.0, gb_ref.abs().max().item())
+
+
+# (B, H, W, Cin, Cout, dilation): Cout > 64 -> the 64-pixel x 128-column instance, Cout <= 64 -> 128 pixels x 64 columns; odd chunk
+# counts (Cin = 96: 27 chunks), Cin = 38 (row padding), ragged dilation lattices, two column tiles (Cout = 160)
+X3_CASES = [(1, 12, 20, 128, 128, 1), (1, 9, 21, 96, 64, 2), (2, 10, 18, 38, 128, 1), (1, 14, 19, 64, 96, 4), (1, 7, 33, 128, 96, 8),
+            (1, 9, 17, 32, 64, 1), (1, 9, 17, 64, 160, 1), (1, 11, 35, 36, 128, 1)]
+
+
+@pytest.mark.parametrize("case", X3_CASES)
+def test_conv_split_bf16_patch_kernel(backend, case):
+    """precision code 2 (split-bf16, three bf16 MFMAs per product) on the patch-staged forward kernel: judged against the
+    UNROUNDED fp32 oracle -- the error must be ~2^-16 relative (>= 50x below plain bf16), which is what lets the forward pass
+    of the 'mixed' engine mode stay inside the 1e-3 px tolerance while the matrix cores run bf16."""
+    B, H, W, Ci, Co, dil = case
+    dev = backend.device
+    x = _rand((B, H, W, Ci), 111, dev)
+    w = _rand((3, 3, Ci, Co), 112, dev, 0.2)
+    b = _rand((Co,), 113, dev)
+    y_ref = T.conv2d(x.cpu().double(), w.cpu().double(), b.cpu().double(), stride=1, dilation=dil, alpha=0.2).float()
+    y_bf = T.conv2d(_bf(x.cpu()), _bf(w.cpu()), b.cpu(), stride=1, dilation=dil, alpha=0.2)
+    ld = (Ci + 3) // 4 * 4
+    xb, xv = _padded(x, ld)
+    if ld != Ci:
+        xb[..., Ci:] = float("nan")
+    backend.lib.tune_conv_patch(128)                 # forced: these shapes are far below the pixel-count heuristic
+    try:
+        y = torch.full(y_ref.shape, float("nan"), device=dev)
+        with ops.precision_scope("mixed"):
+            ops.conv2d_fwd(backend.lib, xv, w, b, ops.view(y), stride=1, dil=dil, alpha=0.2)
+        backend.sync()
+    finally:
+        launches = backend.lib.tune_conv_patch(-1)
+    assert launches == 1
+    err = (y.cpu() - y_ref).abs().max().item()
+    err_bf = (y_bf - y_ref).abs().max().item()
+    scale = max(1.0, y_ref.abs().max().item())
+    assert err <= 4e-5 * scale, (err, err_bf)
+    assert err * 50 <= err_bf, (err, err_bf)
+
+
+def test_precision_code_2_falls_back_to_exact_fp32(backend):
+    """Layers without an x3 instance (stride 2, 5x5, few output channels) and every gradient run exact fp32 for code 2."""
+    dev = backend.device
+    x = _rand((1, 9, 14, 16), 121, dev); w = _rand((3, 3, 16, 32), 122, dev, 0.2); b = _rand((32,), 123, dev)
+    y0 = torch.empty(1, 5, 7, 32, device=dev); y2 = torch.empty_like(y0)
+    ops.conv2d_fwd(backend.lib, ops.view(x), w, b, ops.view(y0), stride=2, alpha=0.2)
+    ops.PRECISION = 2
+    try:
+        ops.conv2d_fwd(backend.lib, ops.view(x), w, b, ops.view(y2), stride=2, alpha=0.2)
+    finally:
+        ops.PRECISION = 0
+    backend.sync()
+    assert torch.equal(y0.cpu(), y2.cpu())

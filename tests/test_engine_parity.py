@@ -180,11 +180,87 @@ def test_bf16_mode_end_to_end(hip):
         out[prec] = (eng.pred.clone(), float(eng.res_loss[0].item()), eng.params.w.clone(), eng.params.g.clone())
     p32, l32, w32, g32 = out["fp32"]; p16, l16, w16, g16 = out["bf16"]
     scale = p32.abs().mean().item()
-    assert torch.isfinite(p16).all() and (p16 - p32).abs().mean().item() <= 0.03 * max(scale, 1.0)
+    assert torch.isfinite(p16).all() and (p16 - p32).abs().mean().item() <= 0.15           # measured 0.076 px at this shape (smoke)
     assert abs(l16 - l32) <= 0.02 * max(abs(l32), 1e-3)
     cos = torch.nn.functional.cosine_similarity(g16.flatten(), g32.flatten(), dim=0).item()
     assert cos >= 0.98, cos                       # the bf16 gradient points the same way
     assert not torch.equal(w16, w32)              # and it really is a different arithmetic
+
+
+def _mixed_vs_oracle(lib, device, H, W, force_patch):
+    """One FULL step in the 'mixed' mode (forward: split-bf16 on the layers with an x3 kernel, exact fp32 elsewhere;
+    gradients: bf16 MFMA) judged against the fp32 CPU oracle."""
+    wn = S.calibrated_weights(OM.variable_shapes(), 1)
+    l, r, gt = S.make_pair(H, W)
+    lib.tune_conv_patch(force_patch)
+    try:
+        eng = E.MadNetEngine(lib, H, W, B=1, device=device, weights=wn, precision="mixed")
+        eng.set_inputs(l, r, gt[..., 0])
+        lr = 1e-4
+        eng.build_plan("FULL", lr=lr).run(lib, 0)
+        if device != "cpu":
+            torch.cuda.synchronize()
+    finally:
+        launches = lib.tune_conv_patch(-1)
+    wt = {k: torch.from_numpy(v.copy()) for k, v in wn.items()}
+    acc = {k: torch.zeros_like(v) for k, v in wt.items()}
+    o = OM.step(wt, acc, torch.from_numpy(l), torch.from_numpy(r), torch.from_numpy(gt), mode="FULL", lr=lr)
+    epe = (eng.pred.cpu() - o["disparity"][..., 0]).abs().mean().item()
+    gh = torch.cat([eng.params.tensor(n, "g").cpu().flatten() for n in o["grads"]])
+    go = torch.cat([g.flatten() for g in o["grads"].values()])
+    cos = torch.nn.functional.cosine_similarity(gh, go, dim=0).item()
+    grel = (gh - go).norm().item() / go.norm().item()
+    dw = max((eng.params.tensor(n).cpu() - wt[n]).abs().max().item() for n in wt)
+    step = max((torch.from_numpy(wn[n]) - wt[n]).abs().max().item() for n in wt)          # size of the oracle's own update
+    loss_err = abs(eng.res_loss[0].item() - o["loss"])
+    return dict(epe=epe, cos=cos, grel=grel, dw=dw, step=step, loss_err=loss_err, loss=o["loss"], launches=launches,
+                mean_disp=o["disparity"].abs().mean().item())
+
+
+def test_mixed_mode_step_emulated():
+    """'mixed' on the emulator (60x100, the x3 patch kernel forced onto every eligible forward layer): the forward pass sits
+    inside the north-star tolerance with a wide margin, the bf16 gradients point the oracle's way."""
+    from conftest import _emul_backend
+    backend = _emul_backend()
+    m = _mixed_vs_oracle(backend.lib, "cpu", 60, 100, 128)
+    print("mixed (emulated 60x100): %s" % m)
+    assert m["launches"] >= 20, m                  # x3 forward instances + bf16 input-gradient instances really ran
+    assert m["epe"] <= 0.2 * EPE_TOL, m
+    assert m["loss_err"] <= 1e-4 * max(1.0, abs(m["loss"])), m
+    assert m["cos"] >= 0.98, m
+    assert m["dw"] <= 0.25 * m["step"], m          # the post-step weights deviate by a fraction of the step itself
+
+
+@pytest.mark.gpu
+def test_mixed_mode_headline_config_within_tolerance(hip):
+    """The bench default (BASELINE config 2, 1242x375): disparity of the 'mixed' step within 1e-3 px of the fp32 oracle --
+    the tolerance the north star states -- with the kernels the heuristic dispatches on its own (x3 patch kernel at 1/4
+    resolution, exact fp32 elsewhere in the forward pass, bf16 gradients)."""
+    m = _mixed_vs_oracle(hip.lib, hip.device, 375, 1242, -1)
+    print("mixed (MI355X 375x1242): %s" % m)
+    assert m["launches"] >= 10, m
+    assert m["epe"] <= EPE_TOL, m
+    assert m["loss_err"] <= 1e-4 * max(1.0, abs(m["loss"])), m
+    assert m["cos"] >= 0.98 and m["dw"] <= 0.25 * m["step"], m
+
+
+@pytest.mark.gpu
+def test_bf16_mode_headline_config_bounded(hip):
+    """Plain bf16 at the headline shape, where the patch-staged kernel is dispatched by the heuristic: NOT within the 1e-3
+    tolerance (that is what 'mixed' is for) -- bounded at 2x the measured 0.083 px (mean |d| 9.5 px)."""
+    wn = S.calibrated_weights(OM.variable_shapes(), 1)
+    l, r, gt = S.make_pair(375, 1242)
+    eng = E.MadNetEngine(hip.lib, 375, 1242, B=1, device=hip.device, weights=wn, precision="bf16")
+    eng.set_inputs(l, r, gt[..., 0])
+    hip.lib.tune_conv_patch(-1)
+    eng.build_plan("NONE").run(hip.lib, 0)
+    torch.cuda.synchronize()
+    assert hip.lib.tune_conv_patch(-1) >= 5
+    with torch.no_grad():
+        d = OM.forward({k: torch.from_numpy(v) for k, v in wn.items()}, torch.from_numpy(l), torch.from_numpy(r))[-1][..., 0]
+    epe = (eng.pred.cpu() - d).abs().mean().item()
+    print("bf16 (MI355X 375x1242) EPE vs oracle %.4f" % epe)
+    assert 1e-3 < epe <= 0.17
 
 
 def test_bf16_step_patch_kernel_vs_gather_kernel_emulated():
