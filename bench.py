@@ -228,13 +228,16 @@ def step_surface(args, lib, dev, wn, frames=8):
     from Data_utils.data_reader import device_prefetcher
     H, W = args.height, args.width
     pairs = [S.make_pair(H, W, stream_id=100, frame=t) for t in range(frames)]       # frame t shifts the texture by t px (video)
+    import numpy as np
+    # what a camera / PNG decoder delivers: 8-bit frames (the synthetic values are integral 0..255), float32 ground truth
+    pairs8 = [(l.astype(np.uint8), r.astype(np.uint8), np.ascontiguousarray(g[..., 0])) for l, r, g in pairs]
     n_steps = args.warmup + args.steps
 
     class Source(object):
         def __iter__(self):
             for t in range(n_steps):
-                l, r, g = pairs[t % frames]
-                yield l, r, g[..., 0]
+                l, r, g = pairs8[t % frames]
+                yield l, r, g
 
     z = torch.zeros(1, H, W, 3, device=dev.name)
     net = Nets.get_stereo_net("MADNet", {"left_img": z, "right_img": z, "split_layers": [None], "sequence": True,
@@ -253,8 +256,8 @@ def step_surface(args, lib, dev, wn, frames=8):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"value": args.steps / dt, "unit": "pairs/s", "ms_per_step": 1e3 * dt / args.steps,
-            "what": "Nets.get_stereo_net + Adapter.step(FULL), a NEW frame every step through device_prefetcher (host->pinned->HBM on a "
-                    "copy stream), loss/EPE read back every step -- the reference's FPS definition (Stereo_Online_Adaptation.py:230-234,267-268)",
+            "what": "Nets.get_stereo_net + Adapter.step(FULL), a NEW 8-bit frame pair every step through device_prefetcher (host->pinned->HBM "
+                    "on a copy stream, uint8->f32 cast on the GPU), loss/EPE read back every step -- the reference's FPS definition (Stereo_Online_Adaptation.py:230-234,267-268)",
             "frames": frames, "final_loss": out["loss"], "resets": ad.reset_counter}
 
 
@@ -276,6 +279,10 @@ def main():
     ap.add_argument("--streams-per-gpu", type=int, default=1,
                     help="B > 1: B stereo streams that SHARE one model are batched through the same kernels on each GPU "
                          "(SURVEY 8(e); loss = mean over the B pairs = synchronous data-parallel SGD); default 1 = the reference's batch-1 loop")
+    ap.add_argument("--concurrent-streams", type=int, default=1,
+                    help="S > 1: S INDEPENDENT stereo streams per GPU, each with its PRIVATE model / momentum / captured graph, replayed on S HIP "
+                         "streams at once (SURVEY 8(e): stream i -> GPU i mod G; a batch-1 step cannot fill 256 CUs, concurrent streams can); "
+                         "value = pairs/s over all streams")
     ap.add_argument("--shared-model", action="store_true",
                     help="the streams of ALL GPUs adapt ONE model: the flat gradient buffer is all-reduced (RCCL over xGMI) between "
                          "the backward plan and the momentum plan, scaled by 1/world (BASELINE config 5); default: private models, no collective")
@@ -365,6 +372,27 @@ def main():
 
     one_step, plan = make_step(eng)
     _log("engine built (%s), %d ops, graph=%s" % (args.precision, plan.n, use_graph))
+    CS = args.concurrent_streams
+    if CS > 1:
+        assert dev.kind == "cuda" and not shared and use_graph, "--concurrent-streams needs hipGraph replay on a GPU, private models"
+        streams = [dev.stream] + [torch.cuda.Stream() for _ in range(CS - 1)]
+        plans, more_engines = [plan], []           # (the engines own the buffers the captured graphs point into)
+        for i in range(1, CS):
+            e_i = mk(args.precision)
+            li, ri, gi = S.make_pair(H, W, stream_id=1000 * (rank + 1) + i)
+            e_i.set_inputs(li, ri, gi[..., 0])
+            p_i = e_i.build_plan(args.mode, lr=1e-4)
+            with torch.cuda.stream(streams[i]):
+                p_i.run(lib, streams[i].cuda_stream)
+                streams[i].synchronize()
+                p_i.capture(lib, streams[i].cuda_stream)
+            plans.append(p_i)
+            more_engines.append(e_i)
+
+        def one_step():                      # noqa: F811  -- one "step" = every stream advances by one frame
+            for p_i, st in zip(plans, streams):
+                p_i.launch(lib, st.cuda_stream)
+        _log("%d concurrent private streams captured" % CS)
     with dev.ctx():
         for _ in range(args.warmup):
             one_step()
@@ -385,7 +413,7 @@ def main():
     name = "DispNet" if dispnet else "MADNet"
     out = {
         "metric": "adapted stereo pairs/sec (whole node), %s full-backprop online adaptation 1242x375" % name,
-        "value": world * SB * 1e3 / ms, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+        "value": world * SB * CS * 1e3 / ms, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_LABEL[args.precision], "data": "synthetic",
         "timing": tb,
@@ -394,6 +422,7 @@ def main():
                                   ("ONE model shared by all streams: RCCL all-reduce of the %.1f MB gradient buffer per step" % (eng.params.g.numel() * 4e-6)) if shared
                                   else ("private model per stream" if SB == 1 else "the %d streams of a GPU share one model (batched)" % SB)),
                    "precision": args.precision,
+                   "concurrent_private_streams_per_gpu": CS,
                    "launch": "hipGraph replay" if use_graph else "eager plan",
                    "ops_per_step": plan.n, "final_loss": loss, "epe_vs_synthetic_gt": epe_gt,
                    "pred_nonzero_frac": nonzero,
@@ -408,7 +437,7 @@ def main():
                            "wgrad_ws_bytes": st.get("wgrad_ws_bytes"), "grad_bytes": st.get("grad_bytes"),
                            "wgrad_ws_over_grad": (st.get("wgrad_ws_bytes", 0.0) / st["grad_bytes"]) if st.get("grad_bytes") else None},
     }
-    extras = rank == 0 and world == 1 and not dispnet and SB == 1 and not shared and dev.kind == "cuda" and args.mode == "FULL"
+    extras = rank == 0 and world == 1 and not dispnet and SB == 1 and CS == 1 and not shared and dev.kind == "cuda" and args.mode == "FULL"
     if extras:
         if not args.no_roofline:
             with dev.ctx():

@@ -158,6 +158,25 @@ int mh_resize_bwd(const float* g, const float* in, float* din, int32_t accumulat
                   int32_t B, int32_t Hi, int32_t Wi, int32_t Hr, int32_t Wr, int32_t cy, int32_t cx,
                   int32_t Ho, int32_t Wo, float mul, int32_t mode, void* stream);
 
+/* ---- the same legacy bilinear resize for NHWC images with C interleaved channels: Stereo_Online_Adaptation.scale_tensor
+ *      (Stereo_Online_Adaptation.py:22-23,91-95 -> preprocessing.rescale_image, preprocessing.py:269-273) on the frames when
+ *      --reprojectionScale != 1.  mh_resize_image_bwd: din = gradient (gather form, overwrites din). */
+int mh_resize_image_fwd(const float* in, float* out, int32_t B, int32_t Hi, int32_t Wi, int32_t C, int32_t Ho, int32_t Wo, void* stream);
+int mh_resize_image_bwd(const float* g, float* din, int32_t B, int32_t Hi, int32_t Wi, int32_t C, int32_t Ho, int32_t Wo, void* stream);
+
+/* ---- preprocessing.bilinear_sampler, general form (Data_utils/preprocessing.py:121-199): out[b,y,x,:] = 4-tap bilinear sample of
+ *      imgs[B,Hs,Ws,C] at coords[B,Ht,Wt,2] = (x, y); indices clamped to the border, weights un-masked, gather index computed in
+ *      float32 like the reference (B*Hs*Ws < 2^24).  bwd: dcoords (may be NULL) overwritten; dimgs (may be NULL) accumulated with fp32
+ *      atomics -- zero it first. */
+int mh_bilinear_sampler_fwd(const float* imgs, const float* coords, float* out, int32_t B, int32_t Hs, int32_t Ws, int32_t C,
+                            int32_t Ht, int32_t Wt, void* stream);
+int mh_bilinear_sampler_bwd(const float* g, const float* imgs, const float* coords, float* dcoords, float* dimgs, int32_t B,
+                            int32_t Hs, int32_t Ws, int32_t C, int32_t Ht, int32_t Wt, void* stream);
+
+/* ---- input side: out[i] = (float)in[i] for uint8 frames -- the tf.cast(image, tf.float32) of the reference's reader
+ *      (Data_utils/data_reader.py:98) executed after the host-to-device copy (1 byte per value over PCIe) */
+int mh_u8_to_f32(const uint8_t* in, float* out, int64_t n, void* stream);
+
 /* ---- preprocessing.pad_image (REFLECT, preprocessing.py:7-29) fused with the float cast
  *      and the channel padding 3 -> out_ld (extra channels zero) ------------------------ */
 /* out = in / div - sub  (MADNet: div=1, sub=0; DispNet._preprocess_inputs, DispNet.py:59-73: x/255 - 100/255) */
@@ -234,7 +253,8 @@ uint32_t mh_crc32c(const void* data, int64_t n, uint32_t crc);
 enum { MH_OP_CONV = 1, MH_OP_WGRAD, MH_OP_CORR_FWD, MH_OP_CORR_BWD, MH_OP_WARP_FWD, MH_OP_WARP_BWD,
        MH_OP_RESIZE_FWD, MH_OP_RESIZE_BWD, MH_OP_PAD_REFLECT, MH_OP_LOSS, MH_OP_METRICS,
        MH_OP_MOMENTUM, MH_OP_COPY_CH, MH_OP_LEAKY_BWD, MH_OP_FILL, MH_OP_BIAS_GRAD,
-       MH_OP_WGRAD_PARTIAL, MH_OP_WGRAD_REDUCE, MH_OP_PROXY_LOSS, MH_OP_SUPERVISED_LOSS, MH_OP_ADAM, MH_OP_ADAM_ADVANCE };
+       MH_OP_WGRAD_PARTIAL, MH_OP_WGRAD_REDUCE, MH_OP_PROXY_LOSS, MH_OP_SUPERVISED_LOSS, MH_OP_ADAM, MH_OP_ADAM_ADVANCE,
+       MH_OP_RESIZE_IMAGE };
 /* i[26] of every op is its scheduling word: low byte = lane (0 = the caller's stream; 1..MH_MAX_LANES-1 = side
  * streams owned by the library: the op is forked from lane 0 right before it, i.e. ordered after everything recorded so
  * far, and runs concurrently with the lane-0 ops that follow); MH_OP_JOIN = lane 0 first waits for all side lanes.
@@ -250,7 +270,9 @@ typedef struct mh_op {
     int64_t n;
 } mh_op;
 int mh_plan_run(const mh_op* ops, int32_t nops, void* stream);
-/* hipGraph wrappers: capture everything launched on `stream` between begin/end. */
+/* Threading: every entry point is re-entrant; the side streams / events of mh_plan_run are per host thread and device, the
+ * tuning hooks are process-wide atomics meant for benchmarks.
+ * hipGraph wrappers: capture everything launched on `stream` between begin/end. */
 int mh_graph_begin(void* stream);
 int mh_graph_end(void* stream, void** graph_exec_out);
 int mh_graph_launch(void* graph_exec, void* stream);

@@ -141,7 +141,7 @@ def momentum_update(wts, accum, grads, lr, momentum=0.9):
 
 
 def step(wts, accum, left, right, gt, mode="FULL", block_vars=None, block_index=None,
-         lr=1e-4, radius_d=2, stride=1, loss="reprojection", proxy=None):
+         lr=1e-4, radius_d=2, stride=1, loss="reprojection", proxy=None, reprojection_scale=1, warping=True):
     """One iteration of the loop body Stereo_Online_Adaptation.py:178-253 (device part):
     ONE forward with pre-update weights, full-res loss + EPE/bad3, the selected
     backward and the momentum update.  mode in NONE/FULL/MAD.  For MAD, block_index is
@@ -150,7 +150,7 @@ def step(wts, accum, left, right, gt, mode="FULL", block_vars=None, block_index=
     for n in names:
         wts[n].requires_grad_(mode != "NONE")
     bulk = (mode == "MAD")
-    disps = forward(wts, left, right, bulkhead=bulk, radius_d=radius_d, stride=stride)
+    disps = forward(wts, left, right, bulkhead=bulk, radius_d=radius_d, stride=stride, warping=warping)
     # loss="proxy": the continual-adaptation variant (Stereo_Continual_Adaptation.py:75,112): mean_l1 against proxy labels,
     # weight 0.01 on the full-resolution loss, 0.1 on a MAD block's loss
     full_loss = T.reprojection_loss(disps[-1], left, right) if loss == "reprojection" else T.proxy_loss(disps[-1], proxy, 0.01)
@@ -162,8 +162,13 @@ def step(wts, accum, left, right, gt, mode="FULL", block_vars=None, block_index=
     elif mode == "MAD":
         p = disps[block_index]
         mult = float(left.shape[1] // p.shape[1])                 # Stereo_Online_Adaptation.py:102-103
-        p = T.resize_bilinear(p, left.shape[1], left.shape[2]) * mult
-        loss_k = T.reprojection_loss(p, left, right) if loss == "reprojection" else T.proxy_loss(p, proxy, 0.1)
+        # inputs_modules = scale_tensor(., reprojectionScale) (Stereo_Online_Adaptation.py:22-23,91-95); `mult` stays the ratio to
+        # the UNSCALED frame (:102), i.e. 1 for the full-resolution predictions
+        s = int(reprojection_scale)
+        ls = T.resize_bilinear(left, left.shape[1] // s, left.shape[2] // s) if s != 1 else left
+        rs = T.resize_bilinear(right, right.shape[1] // s, right.shape[2] // s) if s != 1 else right
+        p = T.resize_bilinear(p, ls.shape[1], ls.shape[2]) * mult
+        loss_k = T.reprojection_loss(p, ls, rs) if loss == "reprojection" else T.proxy_loss(p, proxy, 0.1)
         vs = [n for n in block_vars]
         gl = torch.autograd.grad(loss_k, [wts[n] for n in vs], allow_unused=True)
         grads = {n: g for n, g in zip(vs, gl) if g is not None}

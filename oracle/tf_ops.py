@@ -176,6 +176,31 @@ def linear_warp(imgs, u):
     return w0.to(imgs.dtype) * im0 + w1.to(imgs.dtype) * im1
 
 
+def bilinear_sampler(imgs, coords):
+    """preprocessing.bilinear_sampler, general form (Data_utils/preprocessing.py:121-199): coords[...,0] = x, [...,1] = y;
+    indices clamped to the border, weights un-masked, flat gather index built in the coords' float dtype (float32 in the
+    reference graph, :170-187) then cast.  Gradients flow to coords through the weights only (tf.floor has none) and to imgs."""
+    B, Hs, Ws, C = imgs.shape
+    _, Ht, Wt, _ = coords.shape
+    cx, cy = coords[..., 0:1], coords[..., 1:2]
+    x0 = torch.floor(cx); x1 = x0 + 1
+    y0 = torch.floor(cy); y1 = y0 + 1
+    wx0 = x1 - cx; wx1 = cx - x0
+    wy0 = y1 - cy; wy1 = cy - y0
+    x0s = torch.clamp(x0, 0.0, float(Ws - 1)); x1s = torch.clamp(x1, 0.0, float(Ws - 1))
+    y0s = torch.clamp(y0, 0.0, float(Hs - 1)); y1s = torch.clamp(y1, 0.0, float(Hs - 1))
+    base = (torch.arange(B, dtype=coords.dtype) * float(Ws * Hs)).view(B, 1, 1, 1)
+    flat = imgs.reshape(B * Hs * Ws, C)
+
+    def g(ysafe, xsafe):
+        idx = (xsafe + (base + ysafe * float(Ws))).detach().to(torch.int64).reshape(-1)
+        return flat.index_select(0, idx).reshape(B, Ht, Wt, C)
+
+    im00, im01, im10, im11 = g(y0s, x0s), g(y1s, x0s), g(y0s, x1s), g(y1s, x1s)
+    dt = imgs.dtype
+    return ((wx0 * wy0).to(dt) * im00 + (wx0 * wy1).to(dt) * im01 + (wx1 * wy0).to(dt) * im10) + (wx1 * wy1).to(dt) * im11
+
+
 def warp_image(img, disp):
     """preprocessing.warp_image + bilinear_sampler (preprocessing.py:121-230) with
     coords = (x - d, y).  Indices are clamped to the border with UN-masked weights

@@ -38,7 +38,8 @@ def readPFM(file):
     return np.flipud(np.reshape(data, shape)).astype(np.float32), abs(scale)
 
 
-def _read_image(path, is_gt=False):
+def _read_image(path, is_gt=False, keep_uint8=False):
+    """keep_uint8: 8-bit images stay uint8 [H,W,3] (the float cast then happens on the GPU, device_prefetcher)."""
     ext = os.path.splitext(path)[1].lower()
     if ext == '.npy':
         a = np.load(path).astype(np.float32)
@@ -55,7 +56,8 @@ def _read_image(path, is_gt=False):
         if np.asarray(im).dtype != np.uint8:
             a = a / 256.0                       # 16-bit KITTI disparity PNG
         return a[..., None]
-    a = a.astype(np.float32)
+    if not (keep_uint8 and a.dtype == np.uint8):
+        a = a.astype(np.float32)
     if a.ndim == 2:
         a = np.stack([a, a, a], -1)
     return a[..., :3]
@@ -140,7 +142,10 @@ class dataset(object):
     50 * batch_size samples -> aligned random crop -> optional augmentation -> batches of batch_size (remainder dropped)."""
 
     def __init__(self, path_file, batch_size=1, crop_shape=(320, 1216), num_epochs=1, augment=False,
-                 is_training=False, shuffle=False, seed=0):
+                 is_training=False, shuffle=False, seed=0, keep_uint8=False):
+        """keep_uint8 (no augmentation): 8-bit frames are yielded as uint8 [B,H,W,3] instead of float32 -- device_prefetcher then
+        moves 1 byte per value over PCIe and casts on the GPU (mh_u8_to_f32); values are identical."""
+        self._u8 = bool(keep_uint8) and not augment
         self._left, self._right, self._gt = read_list_file(path_file)
         self._crop = tuple(crop_shape)
         self._epochs = num_epochs
@@ -169,7 +174,7 @@ class dataset(object):
 
     def _load(self, i):
         th, tw = self._crop
-        l, r, g = _read_image(self._left[i]), _read_image(self._right[i]), _read_image(self._gt[i], True)
+        l, r, g = _read_image(self._left[i], keep_uint8=self._u8), _read_image(self._right[i], keep_uint8=self._u8), _read_image(self._gt[i], True)
         g = g[:, :l.shape[1]]                             # "crop gt to fit with image" (:146)
         if self._training:
             l, r, g = random_crop(self._crop, [l, r, g], self._rng)
@@ -184,7 +189,8 @@ class dataset(object):
         for i in self._samples():
             batch.append(self._load(i))
             if len(batch) == self._batch:
-                yield tuple(np.stack([b[k] for b in batch]).astype(np.float32) for k in range(3))
+                yield tuple((lambda a: a if (self._u8 and a.dtype == np.uint8) else a.astype(np.float32))(np.stack([b[k] for b in batch]))
+                            for k in range(3))
                 batch = []
 
 
@@ -198,7 +204,10 @@ class device_prefetcher(object):
             adapter.step(left, right, gt)
     """
 
-    def __init__(self, data_set, device='cuda', depth=3, consumer_stream=None):
+    def __init__(self, data_set, device='cuda', depth=3, consumer_stream=None, lib=None):
+        """uint8 arrays from the data set are uploaded as uint8 and cast to float32 on the GPU (mh_u8_to_f32 on the copy stream;
+        `lib` = the loaded library, default the product's): the consumer always sees float32 tensors."""
+        self._lib = lib
         import queue
         import threading
         import torch
@@ -218,10 +227,15 @@ class device_prefetcher(object):
         t = self._torch
         if self._ring is None:                   # allocate the ring on first use (shapes known now)
             self._ring = []
+            u8 = [np.asarray(a).dtype == np.uint8 for a in arrays]
+            if any(u8) and self._lib is None:
+                from madnet_hip import _ffi
+                self._lib = _ffi.lib()
             for _ in range(self._depth + 1):
-                host = [t.empty(np.shape(a), dtype=t.float32, pin_memory=self._cuda) for a in arrays]
+                host = [t.empty(np.shape(a), dtype=(t.uint8 if q else t.float32), pin_memory=self._cuda) for a, q in zip(arrays, u8)]
+                stage = [t.empty(np.shape(a), dtype=t.uint8, device=self._dev) if q else None for a, q in zip(arrays, u8)]
                 devb = [t.empty(np.shape(a), dtype=t.float32, device=self._dev) for a in arrays]
-                self._ring.append((host, devb, t.cuda.Event() if self._cuda else None))
+                self._ring.append((host, devb, t.cuda.Event() if self._cuda else None, stage))
             for i in range(len(self._ring)):
                 self._free.put(i)
         return self._free.get()
@@ -233,17 +247,26 @@ class device_prefetcher(object):
                 if self._stop.is_set():
                     return
                 i = self._slot(arrays)
-                host, devb, ev = self._ring[i]
+                host, devb, ev, stage = self._ring[i]
                 for h, a in zip(host, arrays):
-                    h.copy_(t.from_numpy(np.array(a, dtype=np.float32, order='C').reshape(tuple(h.shape))))
+                    np.copyto(h.numpy(), np.asarray(a).reshape(tuple(h.shape)), casting='unsafe')     # straight into the pinned slot
                 if self._cuda:
                     with t.cuda.stream(self._copy_stream):
-                        for h, d in zip(host, devb):
-                            d.copy_(h, non_blocking=True)
+                        for h, d, s8 in zip(host, devb, stage):
+                            if s8 is None:
+                                d.copy_(h, non_blocking=True)
+                            else:
+                                s8.copy_(h, non_blocking=True)
+                                self._lib.u8_to_f32(s8.data_ptr(), d.data_ptr(), s8.numel(), self._copy_stream.cuda_stream)
                         ev.record(self._copy_stream)
                 else:
-                    for h, d in zip(host, devb):
-                        d.copy_(h)
+                    for h, d, s8 in zip(host, devb, stage):
+                        if s8 is None:
+                            d.copy_(h)
+                        else:
+                            s8.copy_(h)
+                            if self._lib is not None:
+                                self._lib.u8_to_f32(s8.data_ptr(), d.data_ptr(), s8.numel(), None)
                 self._q.put(i)
             self._q.put(None)
         except Exception as e:                   # surface reader errors in the consumer
@@ -262,7 +285,7 @@ class device_prefetcher(object):
                 return
             if isinstance(i, Exception):
                 raise i
-            host, devb, ev = self._ring[i]
+            host, devb, ev, _ = self._ring[i]
             if self._cuda:
                 (self._consumer or self._torch.cuda.current_stream(self._dev)).wait_event(ev)
             prev = i

@@ -1,10 +1,15 @@
-"""Hot image-space functions of the reference (Data_utils/preprocessing.py:7-29,121-230,269-277) on
-torch GPU tensors, backed by the HIP kernels: pad_image, warp_image / bilinear_sampler (horizontal
-disparity form), rescale_image, resize_to_prediction.  Training-time augmentation / colour mapping
-(random_crop, augment, colorize_img) are outside the hot path and not provided."""
+"""Hot image-space functions of the reference (Data_utils/preprocessing.py:7-29,121-230,269-277) on torch tensors (storage
+only), backed by the HIP kernels: pad_image, bilinear_sampler (general form) / warp_image, rescale_image,
+resize_to_prediction -- same names, argument meaning and autograd behaviour (gradients flow to the sampled coordinates / the
+disparity and to the images; tf.floor contributes none).  Training-time augmentation lives in Data_utils/data_reader.py;
+colour mapping (colorize_img) is outside the hot path and not provided."""
 import torch
 
 from madnet_hip import _ffi, ops
+
+
+def _lib():
+    return _ffi.lib()
 
 
 def _stream(t):
@@ -12,38 +17,39 @@ def _stream(t):
 
 
 def pad_image(immy, down_factor=256, dynamic=False):
-    """REFLECT-pad H,W up to a multiple of down_factor (before=(new-old)//2, after=(new-old+1)//2)."""
+    """REFLECT-pad H,W up to a multiple of down_factor (before=(new-old)//2, after=(new-old+1)//2)  (preprocessing.py:7-29)."""
     B, H, W, Cc = immy.shape
     nh = H if H % down_factor == 0 else (H // down_factor + 1) * down_factor
     nw = W if W % down_factor == 0 else (W // down_factor + 1) * down_factor
     out = torch.empty(B, nh, nw, Cc, device=immy.device)
-    ops.pad_reflect(_ffi.lib(), immy.contiguous().float(), out, (nh - H) // 2, (nw - W) // 2, stream=_stream(immy))
+    ops.pad_reflect(_lib(), immy.contiguous().float(), out, (nh - H) // 2, (nw - W) // 2, stream=_stream(immy))
     return out
 
 
 class _ResizeFn(torch.autograd.Function):
+    """tf.image.resize_images(bilinear), TF1 legacy kernel, any channel count; gradient = ResizeBilinearGrad."""
+
     @staticmethod
     def forward(ctx, x, oh, ow):
         B, H, W, Cc = x.shape
-        assert Cc == 1, "HIP resize handles single-channel maps (disparities)"
-        xin = x.contiguous().view(B, H, W)
-        out = torch.empty(B, oh, ow, device=x.device)
-        ops.resize_fwd(_ffi.lib(), xin, out, oh, ow, stream=_stream(x))
-        ctx.save_for_backward(xin)
-        ctx.size = (oh, ow)
-        return out[..., None]
+        xin = x.contiguous().float()
+        out = torch.empty(B, oh, ow, Cc, device=x.device)
+        _lib().resize_image_fwd(ops._p(xin), ops._p(out), B, H, W, Cc, oh, ow, ops._p(_stream(x)))
+        ctx.shape = (B, H, W, Cc, oh, ow)
+        return out
 
     @staticmethod
     def backward(ctx, g):
-        (xin,) = ctx.saved_tensors
-        oh, ow = ctx.size
-        dx = torch.empty_like(xin)
-        ops.resize_bwd(_ffi.lib(), g.contiguous().view(g.shape[0], oh, ow), xin, dx, oh, ow, stream=_stream(xin))
-        return dx[..., None], None, None
+        B, H, W, Cc, oh, ow = ctx.shape
+        g = g.contiguous()
+        dx = torch.empty(B, H, W, Cc, device=g.device)
+        _lib().resize_image_bwd(ops._p(g), ops._p(dx), B, H, W, Cc, oh, ow, ops._p(_stream(g)))
+        return dx, None, None
 
 
 def rescale_image(img, out_shape):
-    """tf.image.resize_images(bilinear), TF1 legacy kernel (no half-pixel centres)."""
+    """preprocessing.rescale_image (preprocessing.py:269-273, FULLY_DIFFERENTIABLE = False): tf.image.resize_images(bilinear),
+    the TF1 legacy kernel (no half-pixel centres).  Identity at equal size."""
     oh, ow = int(out_shape[0]), int(out_shape[1])
     if (img.shape[1], img.shape[2]) == (oh, ow):
         return img
@@ -54,14 +60,44 @@ def resize_to_prediction(x, pred):
     return rescale_image(x, pred.shape[1:3])
 
 
-def warp_image(img, flow):
-    """Right image warped to the left view by the disparity `flow` [B,H,W,1]: coords (x - d, y),
-    4-tap bilinear sampling with indices clamped to the border and UN-masked weights (the code's
-    behaviour, not its docstring: SURVEY App. D.7).  img: [B,H,W,3]."""
-    from Losses import loss_factory
-    return loss_factory._warp_only(img, flow)
+class _SamplerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, imgs, coords):
+        imgs = imgs.contiguous().float(); coords = coords.contiguous().float()
+        B, Hs, Ws, Cc = imgs.shape
+        _, Ht, Wt, _ = coords.shape
+        out = torch.empty(B, Ht, Wt, Cc, device=imgs.device)
+        _lib().bilinear_sampler_fwd(ops._p(imgs), ops._p(coords), ops._p(out), B, Hs, Ws, Cc, Ht, Wt, ops._p(_stream(imgs)))
+        ctx.save_for_backward(imgs, coords)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        imgs, coords = ctx.saved_tensors
+        B, Hs, Ws, Cc = imgs.shape
+        _, Ht, Wt, _ = coords.shape
+        g = g.contiguous()
+        dcoords = torch.empty_like(coords) if ctx.needs_input_grad[1] else None
+        dimgs = torch.zeros_like(imgs) if ctx.needs_input_grad[0] else None
+        if dcoords is None and dimgs is None:
+            return None, None
+        _lib().bilinear_sampler_bwd(ops._p(g), ops._p(imgs), ops._p(coords), ops._p(dcoords), ops._p(dimgs), B, Hs, Ws, Cc, Ht, Wt,
+                                    ops._p(_stream(g)))
+        return dimgs, dcoords
 
 
 def bilinear_sampler(imgs, coords):
-    """General form is not on the hot path; only the disparity form (coords = (x - d, y)) is built."""
-    raise NotImplementedError("use warp_image(img, disparity); arbitrary coordinate sampling is not on the hot path")
+    """preprocessing.bilinear_sampler (preprocessing.py:121-199): imgs [B,Hs,Ws,C], coords [B,Ht,Wt,2] (x, y) -> [B,Ht,Wt,C].
+    Indices are clamped to the border and the weights are NOT masked -- the code's behaviour, not its docstring ("points
+    outside ... have value 0"): SURVEY App. D.7."""
+    return _SamplerFn.apply(imgs, coords)
+
+
+def warp_image(img, flow):
+    """preprocessing.warp_image (preprocessing.py:201-230): coords = (x - flow, y), then bilinear_sampler.  img [B,H,W,C],
+    flow [B,H,W,1] (for stereo: img = right image, flow = disparity aligned with the left one)."""
+    B, H, W, _ = flow.shape
+    xs = torch.arange(W, dtype=torch.float32, device=flow.device).view(1, 1, W, 1).expand(B, H, W, 1)
+    ys = torch.arange(H, dtype=torch.float32, device=flow.device).view(1, H, 1, 1).expand(B, H, W, 1)
+    coords = torch.cat([xs - flow, ys], dim=-1)
+    return bilinear_sampler(img, coords)

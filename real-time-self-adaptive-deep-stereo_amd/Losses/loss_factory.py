@@ -7,6 +7,10 @@ import torch
 from madnet_hip import _ffi, ops
 
 
+def _lib():
+    return _ffi.lib()
+
+
 def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
 
@@ -16,7 +20,7 @@ class _ReprojFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, disp, left, right):
-        lib = _ffi.lib()
+        lib = _lib()
         B, H, W, _ = disp.shape
         d = disp.contiguous().view(B, H, W)
         ws = torch.empty(lib.loss_ws_floats(B, H, W), device=disp.device)
@@ -30,16 +34,6 @@ class _ReprojFn(torch.autograd.Function):
     def backward(ctx, g):
         (dd,) = ctx.saved_tensors
         return (dd * g)[..., None], None, None
-
-
-def _warp_only(img, flow):
-    lib = _ffi.lib()
-    B, H, W, _ = flow.shape
-    ws = torch.empty(lib.loss_ws_floats(B, H, W), device=flow.device)
-    res = torch.zeros(4, device=flow.device)
-    ops.reprojection_loss(lib, img.contiguous().float(), img.contiguous().float(), flow.contiguous().view(B, H, W), ws, res,
-                          None, 1.0, stream=_stream(flow))
-    return ws[:4 * B * H * W].view(B, H, W, 4)[..., :3] * 256.0
 
 
 ALL_LOSSES = {'mean_SSIM_l1': None}

@@ -109,7 +109,7 @@ class _ConvFn(torch.autograd.Function):
             # dx = that conv applied to dz ; dw = its filter gradient with (input=dz, output-grad=x)
             ops.conv2d_fwd(lib, ops.view(dz), w, torch.zeros(x.shape[-1], device=x.device), ops.view(dx), stride=stride, stream=s)
             ops.conv2d_wgrad(lib, ops.view(dz), ops.view(x), dw, None, stride=stride, stream=s)
-            db = dz.sum(dim=(0, 1, 2))
+            ops.bias_grad(lib, ops.view(dz), db, stream=s)             # BiasAddGrad (db was zeroed above)
         else:
             ops.conv2d_dgrad(lib, ops.view(dz), w, ops.view(dx), stride=stride, dil=dil, stream=s)
             ops.conv2d_wgrad(lib, ops.view(x), ops.view(dz), dw, db, stride=stride, dil=dil, stream=s)

@@ -62,7 +62,7 @@ def main(args):
     with open(args.blockConfig) as json_data:
         train_config = json.load(json_data)
     data_set = data_reader.dataset(args.list, batch_size=1, crop_shape=args.imageShape, num_epochs=1,
-                                   augment=False, is_training=False, shuffle=False)
+                                   augment=False, is_training=False, shuffle=False, keep_uint8=True)   # 8-bit frames cross PCIe as bytes
     H, W = args.imageShape
     dev = 'cuda'
     left_img_batch = torch.zeros(1, H, W, 3, device=dev)
@@ -118,10 +118,11 @@ def main(args):
             f_out.write('bad3,{},{}\n'.format(bad3_sum, bad3_sum / nstep))
             f_out.write('time,{},{}\n'.format(exec_time, exec_time / nstep))
             f_out.write('FPS,{}\n'.format(1 / (exec_time / nstep)))
-            f_out.write('wall_FPS,{}\n'.format(nstep / max(wall, 1e-9)))     # true wall clock
             f_out.write('#resets,{}\n'.format(adapter.reset_counter))
             f_out.write('Blocks')
-            for n in range(len(predictions) - 1):
+            # the reference truncates `predictions` (drops the full-resolution one) only in MAD mode (:88) -> 5 columns for
+            # MADNet MAD, 6 for FULL / NONE (Stereo_Online_Adaptation.py:271-274)
+            for n in range(len(predictions) - (1 if args.mode == 'MAD' else 0)):
                 f_out.write(',{}'.format(n))
             f_out.write(',final\n')
             f_out.write('fetch_counter')
@@ -131,6 +132,10 @@ def main(args):
             for c in adapter.sample_distribution:
                 f_out.write(',{}'.format(c))
             f_out.write('\n')
+        # stats.csv stays byte-compatible with the reference's report (positional parsers); the true wall-clock rate
+        # (the reference's FPS drops the tail steps from the time but not from the count) goes to its own file
+        with open(os.path.join(args.output, 'wall_clock.csv'), 'w+') as f_out:
+            f_out.write('steps,wall_seconds,wall_FPS\n{},{},{}\n'.format(nstep, wall, nstep / max(wall, 1e-9)))
         step_time = exec_time / nstep
         with open(os.path.join(args.output, 'series.csv'), 'w+') as f_out:
             f_out.write('Iteration,Time,EPE,bad3\n')

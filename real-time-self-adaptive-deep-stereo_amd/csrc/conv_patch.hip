@@ -21,6 +21,7 @@
 // hipcc shuffles them through v_accvgpr_* moves at every loop back-edge.
 #include "conv_args.h"
 #include <stdlib.h>
+#include <atomic>
 
 namespace {
 
@@ -44,7 +45,7 @@ constexpr int PW = 18;      // patch width (16 + halo)
 // split is paid once per staged element (patch: once per workgroup, not once per tap).
 template <int WM, int WN, int MT, int NT, bool DGRAD, int CPTC = 0, bool X3 = false>
 __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv_patch_kernel(ConvArgs p, PatchGeo g) {
-    static_assert(!X3 || (!DGRAD && CPTC == 0), "the split-bf16 instances are forward, generic-K");
+    static_assert(!X3 || !DGRAD, "the split-bf16 instances are forward only");
     constexpr int NTH = WM * WN * 64;
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
     constexpr int TH = BM / 16;
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1,
 #pragma unroll
         for (int f = 0; f < 2 * NF; ++f) frag_x3(buf ^ 1, 0, Ab0, fa0, fb0, la0, lb0, f);
     };
-    if constexpr (X3) {
+    if constexpr (X3 && CPTC == 0) {
         {
             const unsigned short* Ab0 = next_a();
 #pragma unroll
@@ -376,9 +377,48 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1,
             if (f < MT) fa[f] = *reinterpret_cast<const u32x4*>(Ab + f * PW * PSC);
             else frag_op(buf, ch, Ab, fa, fb, f);
         };
+        // split-bf16: fragment read f of 2*NF -- hi planes first, then the lo planes (patch lo plane = a compile-time offset)
+        constexpr int PLO = (TH + 2) * PW * PSC;
+        auto frag_c3 = [&](int buf, int ch, const unsigned short* Ab, u32x4 (&fa)[MT], u32x4 (&fb)[NT], u32x4 (&la)[X3 ? MT : 1], u32x4 (&lb)[X3 ? NT : 1], int f) {
+            if constexpr (X3) {
+                if (f < NF) { frag_c(buf, ch, Ab, fa, fb, f); return; }
+                const int f2 = f - NF;
+                if (f2 < MT) la[f2] = *reinterpret_cast<const u32x4*>(Ab + PLO + f2 * PW * PSC);
+                else frag_x3(buf, ch, Ab, fa, fb, la, lb, f);
+            }
+        };
+        auto tile_c3 = [&](int buf, float4 (&rbl)[NB], const float4 (&rbs)[NB], const unsigned short* A1, const unsigned short* An, unsigned base) {
+            if constexpr (X3) {
+                constexpr int M3 = 3 * MM, XO0 = 2 * NF + NL0;
+#pragma unroll
+                for (int m = 0; m < M3; ++m) {
+                    mfma_x3(m, fa0, fb0, la0, lb0);
+#pragma unroll
+                    for (int o = m * XO0 / M3; o < (m + 1) * XO0 / M3; ++o) {
+                        if (o < 2 * NF) frag_c3(buf, 1, A1, fa1, fb1, la1, lb1, o);
+                        else rbl[o - 2 * NF] = mh_buf_load4(rs_w, (int)((unsigned)vofs[o - 2 * NF] + base));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int m = 0; m < M3; ++m) {
+                    mfma_x3(m, fa1, fb1, la1, lb1);
+#pragma unroll
+                    for (int o = m * OPS1 / M3; o < (m + 1) * OPS1 / M3; ++o) {
+                        if (o < NB - NL0) rbl[NL0 + o] = mh_buf_load4(rs_w, (int)((unsigned)vofs[NL0 + o] + base));
+                        else store_op(buf ^ 1, rbs, o - (NB - NL0));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int f = 0; f < 2 * NF; ++f) frag_c3(buf ^ 1, 0, An, fa0, fb0, la0, lb0, f);
+            }
+        };
         // multiply the tile in `buf` (fragments of its first chunk are in fa0/fb0), load the tile at `base` into rbl,
         // store rbs into buf^1; A1 / An = patch pointers of this tile's second chunk / the next tile's first chunk
         auto tile_c = [&](int buf, float4 (&rbl)[NB], const float4 (&rbs)[NB], const unsigned short* A1, const unsigned short* An, unsigned base) {
+            if constexpr (X3) { tile_c3(buf, rbl, rbs, A1, An, base); return; }
 #pragma unroll
             for (int m = 0; m < MM; ++m) {
                 acc[m / NT][m % NT] = mh_mfma_bf16(fa0[m / NT], fb0[m % NT], acc[m / NT][m % NT]);
@@ -404,8 +444,13 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1,
             for (int f = 0; f < NF; ++f) frag_c(buf ^ 1, 0, An, fa0, fb0, f);
         };
         const unsigned short* a_cur = tap_ptr(0);
+        if constexpr (X3) {
 #pragma unroll
-        for (int f = 0; f < NF; ++f) frag_c(0, 0, a_cur, fa0, fb0, f);
+            for (int f = 0; f < 2 * NF; ++f) frag_c3(0, 0, a_cur, fa0, fb0, la0, lb0, f);
+        } else {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) frag_c(0, 0, a_cur, fa0, fb0, f);
+        }
         if (!(g.dbg & 1)) {
             if constexpr (CPTC == 4) {
                 // two tiles per tap: chunks (0, 1) out of buffer 0, chunks (2, 3) out of buffer 1; loads run one tap ahead
@@ -500,12 +545,13 @@ size_t patch_lds(int TH, int BM, int BN, int KP, bool x3 = false) {
 
 // mode: 0 = off, 1 = heuristic tile, 64 / 128 = forced pixel tile; bit 8: the 8-wave variant of the 128-pixel tile
 constexpr int PATCH_DEFAULT = 1;
-int g_patch_mode = -2;         // -2: not resolved yet (MH_CONV_PATCH in the environment overrides the default)
+std::atomic<int> g_patch_mode{-2};   // -2: not resolved yet (MH_CONV_PATCH in the environment overrides the default); process-wide tuning hook
 int patch_mode() {
-    if (g_patch_mode == -2) { const char* e = getenv("MH_CONV_PATCH"); g_patch_mode = e ? atoi(e) : PATCH_DEFAULT; }
-    return g_patch_mode;
+    int m = g_patch_mode.load(std::memory_order_relaxed);
+    if (m == -2) { const char* e = getenv("MH_CONV_PATCH"); m = e ? atoi(e) : PATCH_DEFAULT; g_patch_mode.store(m, std::memory_order_relaxed); }
+    return m;
 }
-int g_patch_launches = 0;     // since the last mh_tune_conv_patch() call (tests check that the kernel under test really ran)
+std::atomic<int> g_patch_launches{0};     // since the last mh_tune_conv_patch() call (tests check that the kernel under test really ran)
 
 template <int WM, int WN, int MT, int NT, bool DGRAD, int CPTC = 0, bool X3 = false>
 int launch_patch(ConvArgs& a, hipStream_t s) {
@@ -578,9 +624,7 @@ bool patch_w8(const ConvArgs& a) { return (patch_mode() & 0xff) == 1 ? true : (p
 
 extern "C" int mh_tune_conv_patch(int mode) {
     g_patch_mode = mode < 0 ? PATCH_DEFAULT : mode;
-    const int n = g_patch_launches;
-    g_patch_launches = 0;
-    return n;
+    return g_patch_launches.exchange(0);
 }
 
 bool mh_conv_patch_ok(const ConvArgs& a) {
@@ -613,8 +657,15 @@ int mh_conv_patch_launch(ConvArgs& a, hipStream_t s) {
     const bool w8 = all ? false : patch_w8(a);
     int rc = 0;
     // split-bf16 forward instances (precision code 2)
-    if (all || (a.x3 && bn == 128)) { rc = launch_patch<2, 4, 2, 2, false, 0, true>(a, s); if (!all || rc) return rc; }
-    if (all || (a.x3 && bn == 64)) { rc = launch_patch<4, 2, 2, 2, false, 0, true>(a, s); if (!all || rc) return rc; }
+    {
+        const bool generic = !all && ((patch_mode() >> 11) & 1) != 0;      // tuning hook (mode bit 11): generic-K instances only
+        if (all || (a.x3 && bn == 128 && a.K == 128 && !generic)) { rc = launch_patch<2, 4, 2, 2, false, 4, true>(a, s); if (!all || rc) return rc; }
+        if (all || (a.x3 && bn == 128 && a.K == 64 && !generic)) { rc = launch_patch<2, 4, 2, 2, false, 2, true>(a, s); if (!all || rc) return rc; }
+        if (all || (a.x3 && bn == 128)) { rc = launch_patch<2, 4, 2, 2, false, 0, true>(a, s); if (!all || rc) return rc; }
+        if (all || (a.x3 && bn == 64 && a.K == 128 && !generic)) { rc = launch_patch<4, 2, 2, 2, false, 4, true>(a, s); if (!all || rc) return rc; }
+        if (all || (a.x3 && bn == 64 && a.K == 64 && !generic)) { rc = launch_patch<4, 2, 2, 2, false, 2, true>(a, s); if (!all || rc) return rc; }
+        if (all || (a.x3 && bn == 64)) { rc = launch_patch<4, 2, 2, 2, false, 0, true>(a, s); if (!all || rc) return rc; }
+    }
     if (all || (!dg && bm == 128 && !w8)) { rc = launch_patch_n<2, 2, 4, false>(a, s, bn); if (!all || rc) return rc; }
     if (all || (dg && bm == 128 && !w8)) { rc = launch_patch_n<2, 2, 4, true>(a, s, bn); if (!all || rc) return rc; }
     if (all || (!dg && bm == 128 && w8)) { rc = launch_patch_n<4, 2, 2, false>(a, s, bn); if (!all || rc) return rc; }

@@ -142,6 +142,8 @@ static int run_op(const mh_op& o, void* s) {
         case MH_OP_RESIZE_BWD:
             return mh_resize_bwd((const float*)p[0], (const float*)p[1], (float*)p[2], i[10], i[0], i[1], i[2], i[3], i[4], i[5], i[6],
                                  i[7], i[8], o.f[0], i[9], s);
+        case MH_OP_RESIZE_IMAGE:
+            return mh_resize_image_fwd((const float*)p[0], (float*)p[1], i[0], i[1], i[2], i[3], i[4], i[5], s);
         case MH_OP_PAD_REFLECT:
             return mh_pad_reflect((const float*)p[0], (float*)p[1], i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7], i[8], o.f[0], o.f[1], s);
         case MH_OP_LOSS:
@@ -186,13 +188,15 @@ struct Lanes {
     int next = 0;
     bool ready = false;
 };
-Lanes g_lanes[16];
+// per host thread AND per device: two threads that replay plans on one GPU (the demo's grabber / worker pattern) never share a
+// side stream or the event ring, so mh_plan_run is re-entrant without a lock ("stateless, re-entrant")
+thread_local Lanes t_lanes[16];
 
 int lanes_get(Lanes** out) {
     int dev = 0;
     MH_HIP(hipGetDevice(&dev));
     MH_REQUIRE(dev >= 0 && dev < 16, MH_ERR_UNSUPPORTED, "device index %d out of range", dev);
-    Lanes& L = g_lanes[dev];
+    Lanes& L = t_lanes[dev];
     if (!L.ready) {
         for (int k = 1; k < MH_MAX_LANES; ++k) MH_HIP(hipStreamCreateWithFlags(&L.aux[k], hipStreamNonBlocking));
         for (auto& e : L.ev) MH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -252,6 +256,7 @@ extern "C" int mh_plan_run(const mh_op* ops, int32_t nops, void* stream) {
 
 
 extern "C" int mh_graph_begin(void* stream) {
+    { Lanes* L = nullptr; if (int e = lanes_get(&L)) return e; }      // this thread's side streams exist BEFORE the capture starts
     MH_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
     return 0;
 }

@@ -175,6 +175,123 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// multi-channel TF1-legacy bilinear resize of NHWC images (Stereo_Online_Adaptation.scale_tensor :22-23 ->
+// preprocessing.rescale_image :269-273 on the 3-channel frames when --reprojectionScale != 1) and its gradient
+// ------------------------------------------------------------------------------------------
+struct ResizeImgArgs { const float* in; const float* g; float* out; float* din; int B, Hi, Wi, C, Ho, Wo; float sy, sx; };
+
+__global__ __launch_bounds__(256) void resize_image_fwd_kernel(ResizeImgArgs p) {
+    const int64_t total = (int64_t)p.B * p.Ho * p.Wo * p.C;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int c = (int)(q % p.C);
+        int64_t t = q / p.C;
+        const int x = (int)(t % p.Wo); t /= p.Wo;
+        const int y = (int)(t % p.Ho);
+        const int b = (int)(t / p.Ho);
+        int y0, y1, x0, x1; float ty, tx;
+        interp1(y, p.sy, p.Hi, y0, y1, ty);
+        interp1(x, p.sx, p.Wi, x0, x1, tx);
+        const float* img = p.in + (int64_t)b * p.Hi * p.Wi * p.C + c;
+        const float tl = img[((int64_t)y0 * p.Wi + x0) * p.C], tr = img[((int64_t)y0 * p.Wi + x1) * p.C];
+        const float bl = img[((int64_t)y1 * p.Wi + x0) * p.C], br = img[((int64_t)y1 * p.Wi + x1) * p.C];
+        const float top = tl + (tr - tl) * tx, bot = bl + (br - bl) * tx;
+        p.out[q] = top + (bot - top) * ty;
+    }
+}
+
+// gather form (one lane per INPUT element), same index arithmetic as the forward
+__global__ __launch_bounds__(256) void resize_image_bwd_kernel(ResizeImgArgs p) {
+    const int64_t total = (int64_t)p.B * p.Hi * p.Wi * p.C;
+    const float isy = 1.0f / p.sy, isx = 1.0f / p.sx;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int c = (int)(q % p.C);
+        int64_t t = q / p.C;
+        const int sx = (int)(t % p.Wi); t /= p.Wi;
+        const int sy = (int)(t % p.Hi);
+        const int b = (int)(t / p.Hi);
+        const float* gimg = p.g + (int64_t)b * p.Ho * p.Wo * p.C + c;
+        const int ya = max(0, (int)floorf((float)(sy - 1) * isy) - 1), yb = min(p.Ho - 1, (int)ceilf((float)(sy + 1) * isy) + 1);
+        const int xa = max(0, (int)floorf((float)(sx - 1) * isx) - 1), xb = min(p.Wo - 1, (int)ceilf((float)(sx + 1) * isx) + 1);
+        float acc = 0.f;
+        for (int Y = ya; Y <= yb; ++Y) {
+            int y0, y1; float ty;
+            interp1(Y, p.sy, p.Hi, y0, y1, ty);
+            const float wy = (y0 == sy ? 1.0f - ty : 0.f) + (y1 == sy ? ty : 0.f);
+            if (wy == 0.f) continue;
+            for (int X = xa; X <= xb; ++X) {
+                int x0, x1; float tx;
+                interp1(X, p.sx, p.Wi, x0, x1, tx);
+                const float wx = (x0 == sx ? 1.0f - tx : 0.f) + (x1 == sx ? tx : 0.f);
+                if (wx != 0.f) acc += gimg[((int64_t)Y * p.Wo + X) * p.C] * wy * wx;
+            }
+        }
+        p.din[q] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// preprocessing.bilinear_sampler (Data_utils/preprocessing.py:121-199), general form: out[b,y,x,:] = 4-tap bilinear sample
+// of imgs[b] at coords[b,y,x] = (cx, cy).  Indices are CLAMPED to the border and the weights are NOT masked (the code's
+// behaviour, not its docstring: SURVEY App. D.7); the flat gather index is computed in float32 like the reference (:170-187)
+// and then cast.  Gradients: w.r.t. coords (d out / d cx = (wt_y0*(im10-im00) + wt_y1*(im11-im01)), likewise cy; floor has no
+// gradient) and w.r.t. imgs (scatter, fp32 atomics into a pre-zeroed buffer).
+// ------------------------------------------------------------------------------------------
+struct SamplerArgs { const float* img; const float* coords; const float* g; float* out; float* dcoords; float* dimg;
+                     int B, Hs, Ws, C, Ht, Wt; };
+
+__device__ __forceinline__ void sampler_taps(const SamplerArgs& p, int b, float cx, float cy, int64_t (&idx)[4], float (&w)[4],
+                                             float& wx0, float& wx1, float& wy0, float& wy1) {
+    const float x0 = floorf(cx), x1 = x0 + 1.0f, y0 = floorf(cy), y1 = y0 + 1.0f;
+    wx0 = x1 - cx; wx1 = cx - x0; wy0 = y1 - cy; wy1 = cy - y0;
+    const float xm = (float)(p.Ws - 1), ym = (float)(p.Hs - 1);
+    const float x0s = clampf(x0, 0.f, xm), x1s = clampf(x1, 0.f, xm), y0s = clampf(y0, 0.f, ym), y1s = clampf(y1, 0.f, ym);
+    const float dim2 = (float)p.Ws, base = (float)b * (float)(p.Ws * p.Hs);
+    const float by0 = base + y0s * dim2, by1 = base + y1s * dim2;
+    idx[0] = (int64_t)(int)(x0s + by0); idx[1] = (int64_t)(int)(x0s + by1);        // im00, im01
+    idx[2] = (int64_t)(int)(x1s + by0); idx[3] = (int64_t)(int)(x1s + by1);        // im10, im11
+    w[0] = wx0 * wy0; w[1] = wx0 * wy1; w[2] = wx1 * wy0; w[3] = wx1 * wy1;
+}
+
+__global__ __launch_bounds__(256) void sampler_fwd_kernel(SamplerArgs p) {
+    const int64_t total = (int64_t)p.B * p.Ht * p.Wt;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int b = (int)(q / ((int64_t)p.Ht * p.Wt));
+        int64_t idx[4]; float w[4], wx0, wx1, wy0, wy1;
+        sampler_taps(p, b, p.coords[q * 2], p.coords[q * 2 + 1], idx, w, wx0, wx1, wy0, wy1);
+        for (int c = 0; c < p.C; ++c) {
+            // tf.add_n([w00*im00, w01*im01, w10*im10, w11*im11]): left-to-right sum
+            float v = w[0] * p.img[idx[0] * p.C + c];
+            v += w[1] * p.img[idx[1] * p.C + c];
+            v += w[2] * p.img[idx[2] * p.C + c];
+            v += w[3] * p.img[idx[3] * p.C + c];
+            p.out[q * p.C + c] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void sampler_bwd_kernel(SamplerArgs p) {
+    const int64_t total = (int64_t)p.B * p.Ht * p.Wt;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int b = (int)(q / ((int64_t)p.Ht * p.Wt));
+        int64_t idx[4]; float w[4], wx0, wx1, wy0, wy1;
+        sampler_taps(p, b, p.coords[q * 2], p.coords[q * 2 + 1], idx, w, wx0, wx1, wy0, wy1);
+        float gx = 0.f, gy = 0.f;
+        for (int c = 0; c < p.C; ++c) {
+            const float gv = p.g[q * p.C + c];
+            const float i00 = p.img[idx[0] * p.C + c], i01 = p.img[idx[1] * p.C + c], i10 = p.img[idx[2] * p.C + c], i11 = p.img[idx[3] * p.C + c];
+            // wt_x0 = x1 - cx (d/dcx = -1), wt_x1 = cx - x0 (+1); same for y
+            gx += gv * (wy0 * (i10 - i00) + wy1 * (i11 - i01));
+            gy += gv * (wx0 * (i01 - i00) + wx1 * (i11 - i10));
+            if (p.dimg) {
+                atomicAdd(p.dimg + idx[0] * p.C + c, gv * w[0]); atomicAdd(p.dimg + idx[1] * p.C + c, gv * w[1]);
+                atomicAdd(p.dimg + idx[2] * p.C + c, gv * w[2]); atomicAdd(p.dimg + idx[3] * p.C + c, gv * w[3]);
+            }
+        }
+        if (p.dcoords) { p.dcoords[q * 2] = gx; p.dcoords[q * 2 + 1] = gy; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // preprocessing.pad_image (REFLECT) + channel padding
 // ------------------------------------------------------------------------------------------
 struct PadArgs { const float* in; float* out; int B, H, W, C, Hp, Wp, pt, pl, out_ld; float div, sub; };
@@ -583,6 +700,61 @@ extern "C" int mh_resize_fwd(const float* in, float* out, int32_t B, int32_t Hi,
     if (int e = resize_args(a, B, Hi, Wi, Hr, Wr, cy, cx, Ho, Wo, mul, mode)) return e;
     hipLaunchKernelGGL(resize_fwd_kernel, dim3(grid_for((int64_t)B * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, a);
     return mh_check_launch("resize_fwd");
+}
+
+// uint8 frames (what the camera / the PNG decoder delivers) -> float32 0..255 (what the graph reads): the cast tf.data does on the
+// host (Data_utils/data_reader.py:98 tf.cast(..., tf.float32)) moved behind the PCIe copy, which then carries 1 byte per value
+__global__ __launch_bounds__(256) void u8_to_f32_kernel(const unsigned char* __restrict__ in, float* __restrict__ out, int64_t n) {
+    const int64_t q4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (q4 + 4 <= n && ((((uintptr_t)in) | ((uintptr_t)out)) & 3u) == 0 && (((uintptr_t)out) & 15u) == 0) {
+        const unsigned v = *reinterpret_cast<const unsigned*>(in + q4);
+        *reinterpret_cast<float4*>(out + q4) = make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24));
+    } else {
+        for (int64_t q = q4; q < q4 + 4 && q < n; ++q) out[q] = (float)in[q];
+    }
+}
+
+extern "C" int mh_u8_to_f32(const uint8_t* in, float* out, int64_t n, void* stream) {
+    MH_REQUIRE(in && out && n > 0, MH_ERR_ARG, "mh_u8_to_f32: bad argument");
+    MH_REQUIRE((n + 1023) / 1024 < (1ll << 31), MH_ERR_UNSUPPORTED, "mh_u8_to_f32: too many elements");
+    hipLaunchKernelGGL(u8_to_f32_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, in, out, n);
+    return mh_check_launch("u8_to_f32");
+}
+
+extern "C" int mh_resize_image_fwd(const float* in, float* out, int32_t B, int32_t Hi, int32_t Wi, int32_t C, int32_t Ho, int32_t Wo,
+                                   void* stream) {
+    MH_REQUIRE(in && out && B > 0 && Hi > 0 && Wi > 0 && C > 0 && Ho > 0 && Wo > 0, MH_ERR_ARG, "mh_resize_image_fwd: bad argument");
+    ResizeImgArgs a{in, nullptr, out, nullptr, B, Hi, Wi, C, Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo};
+    hipLaunchKernelGGL(resize_image_fwd_kernel, dim3(grid_for((int64_t)B * Ho * Wo * C)), dim3(256), 0, (hipStream_t)stream, a);
+    return mh_check_launch("resize_image_fwd");
+}
+
+extern "C" int mh_resize_image_bwd(const float* g, float* din, int32_t B, int32_t Hi, int32_t Wi, int32_t C, int32_t Ho, int32_t Wo,
+                                   void* stream) {
+    MH_REQUIRE(g && din && B > 0 && Hi > 0 && Wi > 0 && C > 0 && Ho > 0 && Wo > 0, MH_ERR_ARG, "mh_resize_image_bwd: bad argument");
+    ResizeImgArgs a{nullptr, g, nullptr, din, B, Hi, Wi, C, Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo};
+    hipLaunchKernelGGL(resize_image_bwd_kernel, dim3(grid_for((int64_t)B * Hi * Wi * C)), dim3(256), 0, (hipStream_t)stream, a);
+    return mh_check_launch("resize_image_bwd");
+}
+
+extern "C" int mh_bilinear_sampler_fwd(const float* imgs, const float* coords, float* out, int32_t B, int32_t Hs, int32_t Ws, int32_t C,
+                                       int32_t Ht, int32_t Wt, void* stream) {
+    MH_REQUIRE(imgs && coords && out && B > 0 && Hs > 0 && Ws > 0 && C > 0 && Ht > 0 && Wt > 0, MH_ERR_ARG, "mh_bilinear_sampler_fwd: bad argument");
+    MH_REQUIRE((int64_t)B * Hs * Ws < (1 << 24), MH_ERR_UNSUPPORTED,
+               "mh_bilinear_sampler_fwd: B*Hs*Ws must stay below 2^24 (the reference computes the gather index in float32)");
+    SamplerArgs a{imgs, coords, nullptr, out, nullptr, nullptr, B, Hs, Ws, C, Ht, Wt};
+    hipLaunchKernelGGL(sampler_fwd_kernel, dim3(grid_for((int64_t)B * Ht * Wt)), dim3(256), 0, (hipStream_t)stream, a);
+    return mh_check_launch("bilinear_sampler_fwd");
+}
+
+extern "C" int mh_bilinear_sampler_bwd(const float* g, const float* imgs, const float* coords, float* dcoords, float* dimgs, int32_t B,
+                                       int32_t Hs, int32_t Ws, int32_t C, int32_t Ht, int32_t Wt, void* stream) {
+    MH_REQUIRE(g && imgs && coords && (dcoords || dimgs) && B > 0 && Hs > 0 && Ws > 0 && C > 0 && Ht > 0 && Wt > 0, MH_ERR_ARG,
+               "mh_bilinear_sampler_bwd: bad argument");
+    MH_REQUIRE((int64_t)B * Hs * Ws < (1 << 24), MH_ERR_UNSUPPORTED, "mh_bilinear_sampler_bwd: B*Hs*Ws must stay below 2^24");
+    SamplerArgs a{imgs, coords, g, nullptr, dcoords, dimgs, B, Hs, Ws, C, Ht, Wt};
+    hipLaunchKernelGGL(sampler_bwd_kernel, dim3(grid_for((int64_t)B * Ht * Wt)), dim3(256), 0, (hipStream_t)stream, a);
+    return mh_check_launch("bilinear_sampler_bwd");
 }
 
 extern "C" int mh_resize_bwd(const float* g, const float* in, float* din, int32_t accumulate, int32_t B, int32_t Hi, int32_t Wi,

@@ -30,7 +30,7 @@ class Op(C.Structure):
 
 (OP_CONV, OP_WGRAD, OP_CORR_FWD, OP_CORR_BWD, OP_WARP_FWD, OP_WARP_BWD, OP_RESIZE_FWD, OP_RESIZE_BWD,
  OP_PAD_REFLECT, OP_LOSS, OP_METRICS, OP_MOMENTUM, OP_COPY_CH, OP_LEAKY_BWD, OP_FILL, OP_BIAS_GRAD,
- OP_WGRAD_PARTIAL, OP_WGRAD_REDUCE, OP_PROXY_LOSS, OP_SUPERVISED_LOSS, OP_ADAM, OP_ADAM_ADVANCE) = range(1, 23)
+ OP_WGRAD_PARTIAL, OP_WGRAD_REDUCE, OP_PROXY_LOSS, OP_SUPERVISED_LOSS, OP_ADAM, OP_ADAM_ADVANCE, OP_RESIZE_IMAGE) = range(1, 24)
 
 
 OP_JOIN = 0x100
@@ -76,6 +76,11 @@ SIGNATURES = {
     "mh_warp_bwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "mh_resize_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     "mh_resize_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
+    "mh_resize_image_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "mh_resize_image_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "mh_bilinear_sampler_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "mh_bilinear_sampler_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "mh_u8_to_f32": (_I, [_P, _P, _L, _P]),
     "mh_pad_reflect": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
     "mh_loss_ws_floats": (_L, [_I, _I, _I]),
     "mh_reprojection_loss": (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _P]),

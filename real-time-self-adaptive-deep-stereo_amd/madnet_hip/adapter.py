@@ -29,8 +29,6 @@ class Adapter(object):
         sample_distribution = decay * sample_distribution (+ uf * gain on the last trained blocks)."""
         if mode not in ("NONE", "FULL", "MAD"):
             raise ValueError("mode must be NONE, FULL or MAD")
-        if reprojection_scale != 1:
-            raise NotImplementedError("reprojectionScale != 1 is not supported by the MI355X engine")
         if loss not in ("reprojection", "proxy"):
             raise ValueError("loss must be 'reprojection' or 'proxy'")
         self.net, self.eng, self.lib = net, net.engine, net._lib
@@ -39,6 +37,12 @@ class Adapter(object):
             if not hasattr(self.eng, "proxy"):
                 raise NotImplementedError("the proxy-label loss is implemented for the MADNet engine")
             self.eng.loss_kind = "proxy"
+        if reprojection_scale != 1:
+            # only the MAD blocks' losses use the scaled inputs (Stereo_Online_Adaptation.py:91-107); FULL / NONE ignore the flag
+            if mode == "MAD":
+                if not hasattr(self.eng, "set_reprojection_scale"):
+                    raise NotImplementedError("reprojectionScale != 1 is implemented for the MADNet engine")
+                self.eng.set_reprojection_scale(reprojection_scale)
         self.mode, self.lr, self.momentum = mode, lr, momentum
         self.sample_frequency, self.ssim_th = sample_frequency, ssim_th
         self.shared, self.pg = shared_model, process_group

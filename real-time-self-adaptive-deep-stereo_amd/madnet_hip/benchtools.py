@@ -114,7 +114,6 @@ def roofline(lib, eng, stream, reps=20):
         extra["roofline_wgrad"] = {"error": repr(ex)}
     # correlation protocol: level-2 shape with B=64 streams (working set > 256 MiB
     # Infinity Cache) for the HBM claim, plus the in-situ B=1 time (cache resident).
-    extra = {}
     try:
         dev = eng.dev
         Bc, H, W, Cc, md = 64, x.H, x.W, 32, eng.md

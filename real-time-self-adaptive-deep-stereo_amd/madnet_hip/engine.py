@@ -123,8 +123,9 @@ class MadNetEngine(object):
         if precision not in ops.PRECISION_CODES:
             raise ValueError("precision must be one of %s" % sorted(ops.PRECISION_CODES))
         self.precision = precision
-        if not warping:
-            raise NotImplementedError("warping=False is not supported by the MI355X engine yet")
+        # warping=False (MadNet.py:282-285,301-304,...): the right features enter the cost volume un-warped; the upsampled
+        # disparity still joins the estimator input
+        self.warping = bool(warping)
         self.lib, self.dev = lib, device
         self.B, self.H0, self.W0 = B, H, W
         self.md, self.cstride = radius_d, stride
@@ -192,6 +193,24 @@ class MadNetEngine(object):
         self.proxy = z(B, self.H0, self.W0)
         self.proxy_ws = z(self.lib.proxy_ws_floats(B, self.H0, self.W0))
         self.loss_kind = "reprojection"
+        self.rscale = 1
+
+    def set_reprojection_scale(self, s):
+        """--reprojectionScale s (Stereo_Online_Adaptation.py:22-23,91-95): the MAD blocks' losses are computed on the frames
+        resized to (H//s, W//s) and the block's prediction resized to the same size -- with its VALUES unchanged (the
+        multiplier at :102 is H_left // H_p = 1 for the full-resolution predictions and the factor inside the loss is
+        W_left_s / W_p_s = 1): replicated as written."""
+        s = int(s)
+        if s < 1:
+            raise ValueError("reprojectionScale must be >= 1")
+        self.rscale = s
+        if s != 1:
+            B, Hs, Ws = self.B, self.H0 // s, self.W0 // s
+            z = self._buf
+            self.left_s = z(B, Hs, Ws, 3); self.right_s = z(B, Hs, Ws, 3)
+            self.p_s = z(B, Hs, Ws); self.dp_s = z(B, Hs, Ws)
+            self.loss_ws_s = z(self.lib.loss_ws_floats(B, Hs, Ws))
+        self._plans = {}
 
     # views -----------------------------------------------------------------------------------
     def _fv(self, t):
@@ -226,7 +245,7 @@ class MadNetEngine(object):
             h, w, c = self.fshape[f]
             Lk = self._half(self.F[f], False)
             Rk = self._half(self.F[f], True)
-            if k != 6:
+            if k != 6 and self.warping:
                 ops.warp_fwd(lib, Rk, self.u[k], self._fv(self.Rw[k]))
                 Rk = self._fv(self.Rw[k])
             ld = self.dsi_ld[k]
@@ -433,10 +452,15 @@ class MadNetEngine(object):
             Lk = self._half(self.F[f], False)
             g = ops.View(self.ddsi[k], B, h, w, ld, ld)
             dL = self._half(self.dF[f], False)
-            if k == 6:
+            if k == 6 or not self.warping:
                 Rk = self._half(self.F[f], True)
-                ops.corr_bwd(lib, g, Lk, Rk, dL, self._half(self.dF[f], True), self.md, self.cstride, coff=c, du=None,
-                             acc_l=acc_flag(("F", f, 0)), acc_r=acc_flag(("F", f, 1)), copy_left=True)
+                du = self.du[k] if (k != 6 and need_u) else None      # un-warped levels: u only feeds the estimator input
+                ops.corr_bwd(lib, g, Lk, Rk, dL, self._half(self.dF[f], True), self.md, self.cstride, coff=c, du=du,
+                             acc_l=acc_flag(("F", f, 0)), acc_r=acc_flag(("F", f, 1)), acc_u=False, copy_left=True)
+                if du is not None:
+                    s_up = 2 ** k
+                    ops.resize_bwd(lib, self.du[k], self.V[k + 1], self.dV[k + 1], self.Hp // s_up, self.Wp // s_up,
+                                   mul=20.0 / s_up, mode=0, accumulate=acc_flag(("V", k + 1)))
             else:
                 Rk = self._fv(self.Rw[k])
                 du = self.du[k] if need_u else None
@@ -581,12 +605,22 @@ class MadNetEngine(object):
             if do_grad:
                 self.record_forward(r, make_disps=tuple(lv for lv, _ in blocks))
                 self.record_loss_metrics(r, with_grad=False)
+            if do_grad and self.rscale != 1:
+                if self.loss_kind == "proxy":
+                    raise NotImplementedError("reprojectionScale != 1 is implemented for the reprojection loss (the online script)")
+                ops.resize_image(r, self.left, self.left_s)           # inputs_modules (Stereo_Online_Adaptation.py:91-95)
+                ops.resize_image(r, self.right, self.right_s)
             for lv, bv in blocks:
                 if do_grad:
                     # loss of the block's prediction: reprojection (Stereo_Online_Adaptation.py:98-107) or, continual
                     # variant, proxy-label mean_l1 with weight 0.1 (Stereo_Continual_Adaptation.py:100-112)
                     if self.loss_kind == "proxy":
                         ops.proxy_loss(r, self.disp_k[lv], self.proxy, self.proxy_ws, self.res_loss_k, self.ddisp_k, weight=0.1)
+                    elif self.rscale != 1:
+                        Hs, Ws = self.H0 // self.rscale, self.W0 // self.rscale
+                        ops.resize_fwd(r, self.disp_k[lv], self.p_s, Hs, Ws, mul=1.0, mode=0)
+                        ops.reprojection_loss(r, self.left_s, self.right_s, self.p_s, self.loss_ws_s, self.res_loss_k, self.dp_s)
+                        ops.resize_bwd(r, self.dp_s, self.disp_k[lv], self.ddisp_k, Hs, Ws, mul=1.0, mode=0)
                     else:
                         ops.reprojection_loss(r, self.left, self.right, self.disp_k[lv], self.loss_ws_k, self.res_loss_k,
                                               self.ddisp_k)

@@ -260,6 +260,12 @@ def resize_bwd(lib, g, x, dx, Hr, Wr, cy=0, cx=0, mul=1.0, mode=0, accumulate=Fa
     lib.resize_bwd(_p(g), _p(x), _p(dx), int(accumulate), B, Hi, Wi, Hr, Wr, cy, cx, Ho, Wo, mul, mode, _p(stream))
 
 
+def resize_image(lib, x, out, stream=None):
+    """TF1-legacy bilinear resize of an NHWC image tensor [B,H,W,C] into out [B,Ho,Wo,C] (scale_tensor on the frames)."""
+    B, H, W, Cc = x.shape
+    lib.resize_image_fwd(_p(x), _p(out), B, H, W, Cc, out.shape[1], out.shape[2], _p(stream))
+
+
 def pad_reflect(lib, x, out, pad_t, pad_l, div=1.0, sub=0.0, stream=None):
     """out = reflect_pad(x / div - sub).  x: [B,H,W,C] tensor; out: [B,Hp,Wp,out_ld] tensor."""
     B, H, W, Cc = x.shape

@@ -105,6 +105,9 @@ class Recorder(object):
     def resize_bwd(self, g, inp, din, accumulate, B, Hi, Wi, Hr, Wr, cy, cx, Ho, Wo, mul, mode, stream):
         self._op(_ffi.OP_RESIZE_BWD, [B, Hi, Wi, Hr, Wr, cy, cx, Ho, Wo, mode, accumulate], [mul], [g, inp, din])
 
+    def resize_image_fwd(self, inp, out, B, Hi, Wi, Cc, Ho, Wo, stream):
+        self._op(_ffi.OP_RESIZE_IMAGE, [B, Hi, Wi, Cc, Ho, Wo], [], [inp, out])
+
     def pad_reflect(self, inp, out, B, H, W, Cc, Hp, Wp, pt, pl, out_ld, div, sub, stream):
         self._op(_ffi.OP_PAD_REFLECT, [B, H, W, Cc, Hp, Wp, pt, pl, out_ld], [div, sub], [inp, out])
 

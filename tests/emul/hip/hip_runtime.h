@@ -106,6 +106,9 @@ struct Tls {
     void* dyn_smem = nullptr;
     size_t dyn_cap = 0;
     const std::function<void()>* body = nullptr;
+    // emul::launch runs every launch on fresh worker threads: without this the fiber stacks (256 KiB each) of every worker of
+    // every launch stayed allocated for the life of the process (tens of GB over the whole test suite)
+    ~Tls() { for (Fiber& f : fibers) free(f.stack); free(dyn_smem); }
 };
 
 inline Tls& tls() { static thread_local Tls t; return t; }

@@ -437,12 +437,15 @@ X3_CASES = [(1, 12, 20, 128, 128, 1), (1, 9, 21, 96, 64, 2), (2, 10, 18, 38, 128
             (1, 9, 17, 32, 64, 1), (1, 9, 17, 64, 160, 1), (1, 11, 35, 36, 128, 1)]
 
 
+@pytest.mark.parametrize("generic", [False, True], ids=["ctk", "generic"])
 @pytest.mark.parametrize("case", X3_CASES)
-def test_conv_split_bf16_patch_kernel(backend, case):
+def test_conv_split_bf16_patch_kernel(backend, case, generic):
     """precision code 2 (split-bf16, three bf16 MFMAs per product) on the patch-staged forward kernel: judged against the
     UNROUNDED fp32 oracle -- the error must be ~2^-16 relative (>= 50x below plain bf16), which is what lets the forward pass
     of the 'mixed' engine mode stay inside the 1e-3 px tolerance while the matrix cores run bf16."""
     B, H, W, Ci, Co, dil = case
+    if generic and Ci not in (64, 128):
+        pytest.skip("only K = 64 / 128 have compile-time-K instances to switch off")
     dev = backend.device
     x = _rand((B, H, W, Ci), 111, dev)
     w = _rand((3, 3, Ci, Co), 112, dev, 0.2)
@@ -453,7 +456,7 @@ def test_conv_split_bf16_patch_kernel(backend, case):
     xb, xv = _padded(x, ld)
     if ld != Ci:
         xb[..., Ci:] = float("nan")
-    backend.lib.tune_conv_patch(128)                 # forced: these shapes are far below the pixel-count heuristic
+    backend.lib.tune_conv_patch(128 + (2048 if generic else 0))   # forced: these shapes are far below the pixel-count heuristic; +2048 = generic-K instances only
     try:
         y = torch.full(y_ref.shape, float("nan"), device=dev)
         with ops.precision_scope("mixed"):

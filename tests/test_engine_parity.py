@@ -95,6 +95,88 @@ def test_mad_step(bname, size, cfg, block):
     _check(eng, wn, wt, o, backend)
 
 
+@pytest.mark.parametrize("bname,size", SIZES[:2])
+def test_full_step_without_warping(bname, size):
+    """warping=False (MadNet.py:282-285,301-304,320-323,339-342): the right features enter the cost volumes un-warped; the
+    upsampled disparity still feeds the estimators, so its gradient path (resize) stays."""
+    backend = _backend(bname)
+    shapes = OM.variable_shapes()
+    wn = S.calibrated_weights(shapes, 1)
+    l, r, gt = S.make_pair(*size)
+    eng = E.MadNetEngine(backend.lib, size[0], size[1], B=1, device=backend.device, weights=wn, warping=False)
+    eng.set_inputs(l, r, gt[..., 0])
+    wt = {k: torch.from_numpy(v.copy()) for k, v in wn.items()}
+    acc = {k: torch.zeros_like(v) for k, v in wt.items()}
+    lr = 1e-2
+    eng.build_plan("FULL", lr=lr).run(backend.lib, 0)
+    o = OM.step(wt, acc, torch.from_numpy(l), torch.from_numpy(r), torch.from_numpy(gt), mode="FULL", lr=lr, warping=False)
+    _check(eng, wn, wt, o, backend)
+    # and it IS a different network: the warped forward gives another disparity
+    with torch.no_grad():
+        dw = OM.forward({k: torch.from_numpy(v) for k, v in wn.items()}, torch.from_numpy(l), torch.from_numpy(r))[-1][..., 0]
+    assert (dw - o["disparity"][..., 0]).abs().mean().item() > 10 * EPE_TOL
+
+
+@pytest.mark.parametrize("bname,size", SIZES[:2])
+@pytest.mark.parametrize("scale,block", [(2, 4), (3, 1)])
+def test_mad_step_reprojection_scale(bname, size, scale, block):
+    """--reprojectionScale s (Stereo_Online_Adaptation.py:22-23,91-107): the MAD block's loss on the frames and the
+    prediction resized to (H//s, W//s); full-resolution loss / metrics unchanged."""
+    backend = _backend(bname)
+    if bname == "emul" and block == 1:
+        pytest.skip("CPU emulator: one block (time)")
+    eng, wn, wt, acc, (l, r, gt) = _setup(backend, *size)
+    eng.set_reprojection_scale(scale)
+    blocks = json.load(open(os.path.join(PKG, "block_config", "MadNet_full.json")))
+    lv = OM.layer_variables()
+    bv = sum([lv[n] for n in blocks[block]], [])
+    lr = 1e-2
+    eng.build_plan("MAD", lr=lr, block_vars=bv, block_level=E.LEVELS[block]).run(backend.lib, 0)
+    o = OM.step(wt, acc, l, r, gt, mode="MAD", block_vars=bv, block_index=block, lr=lr, reprojection_scale=scale)
+    _check(eng, wn, wt, o, backend)
+
+
+@pytest.mark.gpu
+def test_two_host_threads_one_device(hip):
+    """Re-entrancy (SURVEY 8(b) "Threading / streams"): two host threads, each with its own Adapter on the SAME GPU, step
+    concurrently (hipGraph replay with side lanes, per-thread lane streams / events in the library); both end exactly where
+    the same adapters end when stepped one after the other."""
+    import threading
+    import Nets
+    from madnet_hip.adapter import Adapter
+    H, W = 128, 256
+    wn = S.calibrated_weights(OM.variable_shapes(), 1)
+    pairs = [S.make_pair(H, W, stream_id=i) for i in range(2)]
+
+    def make(i):
+        l, r, gt = pairs[i]
+        z = torch.zeros(1, H, W, 3, device="cuda")
+        net = Nets.get_stereo_net("MADNet", {"left_img": z, "right_img": z, "split_layers": [None], "sequence": True, "train_portion": "BEGIN",
+                                             "bulkhead": False, "weights": wn, "warping": True, "context_net": True, "radius_d": 2, "stride": 1})
+        return Adapter(net, mode="FULL", lr=1e-3), tuple(torch.from_numpy(a).cuda() for a in (l, r, gt[..., 0]))
+
+    def run(ad, data, n, out, key):
+        torch.cuda.set_device(0)
+        for _ in range(n):
+            o = ad.step(*data)
+        torch.cuda.synchronize()
+        out[key] = (ad.eng.params.w.clone(), o["loss"])
+
+    serial, conc = {}, {}
+    for i in range(2):
+        ad, data = make(i)
+        run(ad, data, 6, serial, i)
+    ads = [make(i) for i in range(2)]
+    for ad, _ in ads:
+        ad._plan("FULL")                           # capture both graphs before the threads start
+    th = [threading.Thread(target=run, args=(ads[i][0], ads[i][1], 6, conc, i)) for i in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for i in range(2):
+        assert abs(serial[i][1] - conc[i][1]) <= 1e-6 * max(1.0, abs(serial[i][1])), i
+        assert (serial[i][0] - conc[i][0]).abs().max().item() <= 2e-6, i     # same kernels, same order: fp32-sum-order noise of the atomics only
+
+
 @pytest.mark.gpu
 def test_two_steps_and_graph_replay(hip):
     """Second step starts from the updated weights + momentum; the captured hipGraph replays the
