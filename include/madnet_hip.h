@@ -113,6 +113,15 @@ int mh_corr_fwd(const float* L, int32_t l_ld, const float* R, int32_t r_ld, cons
                 float* out, int32_t out_ld, int32_t coff,
                 int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t stride,
                 int32_t copy_left, int32_t zero_tail, void* stream);
+/* Fused front end of one MADNet pyramid level (Nets/MadNet.py:274-295 and the same lines of the other levels): in ONE launch
+ *   u[p]        = mul * resize_bilinear(Vc[B,Hc,Wc] -> [H,W])[p]                (tf.image.resize_images, TF1 legacy; MadNet.py:274)
+ *   Rw[p][c]    = linear warp of R at x + u[p] along the row, zero outside      (_build_indeces + _linear_warping, :378-436)
+ *   out[p]      = [ L[p][0..C) | mean_c L[p][c]*Rw[p + j - max_disp][c], j < D | u[p] | 0 ... ]   (the mh_corr_fwd concat layout)
+ * i.e. mh_resize_fwd(mode 0) + mh_warp_fwd + mh_corr_fwd(copy_left, u) with stride 1, D = 2*max_disp+1 <= 9.  Rw and u are
+ * outputs too (the backward pass reads them). */
+int mh_level_front_fwd(const float* Vc, int32_t Hc, int32_t Wc, float mul, const float* L, int32_t l_ld, const float* R, int32_t r_ld,
+                       float* out, int32_t out_ld, int32_t coff, float* Rw, int32_t rw_ld, float* u,
+                       int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t zero_tail, void* stream);
 /* g: gradient w.r.t. the buffer written by mh_corr_fwd (same ld / coff).
  * dL[p][c] (+)= [copy_left] g[p][c] + (1/C) sum_j g[p][coff+j] R[p+i_j][c]
  * dR[p][c] (+)=                      (1/C) sum_j g[p-i_j][coff+j] L[p-i_j][c]
@@ -254,7 +263,7 @@ enum { MH_OP_CONV = 1, MH_OP_WGRAD, MH_OP_CORR_FWD, MH_OP_CORR_BWD, MH_OP_WARP_F
        MH_OP_RESIZE_FWD, MH_OP_RESIZE_BWD, MH_OP_PAD_REFLECT, MH_OP_LOSS, MH_OP_METRICS,
        MH_OP_MOMENTUM, MH_OP_COPY_CH, MH_OP_LEAKY_BWD, MH_OP_FILL, MH_OP_BIAS_GRAD,
        MH_OP_WGRAD_PARTIAL, MH_OP_WGRAD_REDUCE, MH_OP_PROXY_LOSS, MH_OP_SUPERVISED_LOSS, MH_OP_ADAM, MH_OP_ADAM_ADVANCE,
-       MH_OP_RESIZE_IMAGE };
+       MH_OP_RESIZE_IMAGE, MH_OP_LEVEL_FRONT };
 /* i[26] of every op is its scheduling word: low byte = lane (0 = the caller's stream; 1..MH_MAX_LANES-1 = side
  * streams owned by the library: the op is forked from lane 0 right before it, i.e. ordered after everything recorded so
  * far, and runs concurrently with the lane-0 ops that follow); MH_OP_JOIN = lane 0 first waits for all side lanes.

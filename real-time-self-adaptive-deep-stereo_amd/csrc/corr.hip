@@ -156,6 +156,106 @@ __global__ __launch_bounds__(256) void corr_fwd_direct(CorrArgs p) {
     }
 }
 
+// ---- fused front end of one pyramid level (MadNet.py:274-295 per level): the inter-level upsample u = mul * resize(V_coarse)
+// (tf.image.resize_images, TF1 legacy bilinear), the horizontal linear warp of the right features by u (_build_indeces +
+// _linear_warping, MadNet.py:378-436: taps outside the row get weight ZERO) and the cost volume + concat, in ONE launch instead
+// of three (resize_fwd, warp_fwd, corr_fwd): at batch 1 these ops are launch-latency bound (5 us each for < 1 us of traffic).
+// The warped right pixel at every shift is rebuilt from two raw right pixels on the fly (1 + 2*D loads per lane instead of 1 + D,
+// all L1/L2 hits); the group of a pixel also stores its own warped feature row and u, which the backward pass reads.
+struct FrontArgs {
+    const float* Vc; const float* L; const float* R; float* out; float* Rw; float* u;
+    int Hc, Wc; float mul, sy, sx;
+    int l_ld, r_ld, out_ld, rw_ld, coff;
+    int B, H, W, C, md, D, zero_tail;
+    unsigned l_bytes, r_bytes;
+};
+
+template <int LPP, int DT>
+__global__ __launch_bounds__(256) void level_front_kernel(FrontArgs p) {
+    constexpr int PPB = 256 / LPP;
+    const int tid = threadIdx.x;
+    const int sub = tid % LPP;
+    const int C4 = p.C >> 2;
+    const float inv_c = 1.0f / (float)p.C;
+    const int npix = p.B * p.H * p.W;
+    const __amdgpu_buffer_rsrc_t rsL = mh_make_rsrc(p.L, p.l_bytes);
+    const __amdgpu_buffer_rsrc_t rsR = mh_make_rsrc(p.R, p.r_bytes);
+    const int pix = blockIdx.x * PPB + tid / LPP;
+    const bool live = pix < npix;
+    const int pp = live ? pix : 0;
+    const int x = pp % p.W;
+    const int t2 = pp / p.W;
+    const int y = t2 % p.H, b = t2 / p.H;
+    const int row = pp - x;
+    // vertical taps of the legacy resize are shared by the D shifts (same row)
+    const float srcy = (float)y * p.sy;
+    const int y0 = (int)srcy, y1 = min(y0 + 1, p.Hc - 1);
+    const float ty = srcy - (float)y0;
+    const float* V0 = p.Vc + ((int64_t)b * p.Hc + y0) * p.Wc;
+    const float* V1 = p.Vc + ((int64_t)b * p.Hc + y1) * p.Wc;
+    float w0[DT], w1[DT], uc = 0.f;
+    int o0[DT], o1[DT];
+#pragma unroll
+    for (int j = 0; j < DT; ++j) {
+        const int xs = x + j - p.md;
+        const bool in = live && j < p.D && (unsigned)xs < (unsigned)p.W;
+        const int xq = in ? xs : 0;
+        const float srcx = (float)xq * p.sx;
+        const int x0 = (int)srcx, x1 = min(x0 + 1, p.Wc - 1);
+        const float tx = srcx - (float)x0;
+        const float tl = V0[x0], tr = V0[x1], bl = V1[x0], br = V1[x1];
+        const float top = tl + (tr - tl) * tx, bot = bl + (br - bl) * tx;
+        const float uj = (top + (bot - top) * ty) * p.mul;                 // resize_fwd mode 0
+        if (j == p.md) uc = uj;
+        const float cx = (float)xq + uj;
+        const float f0 = floorf(cx), f1 = f0 + 1.0f;
+        const float xmax = (float)(p.W - 1);
+        const float f0s = fminf(fmaxf(f0, 0.f), xmax), f1s = fminf(fmaxf(f1, 0.f), xmax);
+        w0[j] = in ? (f1 - cx) * (f0 == f0s ? 1.f : 0.f) : 0.f;
+        w1[j] = in ? (cx - f0) * (f1 == f1s ? 1.f : 0.f) : 0.f;
+        o0[j] = in ? (row + (int)f0s) * p.r_ld * 4 : MH_OOB;
+        o1[j] = in ? (row + (int)f1s) * p.r_ld * 4 : MH_OOB;
+    }
+    float accd[DT];
+#pragma unroll
+    for (int j = 0; j < DT; ++j) accd[j] = 0.f;
+    float* Op = p.out + (int64_t)pp * p.out_ld;
+    for (int c4 = sub; c4 < C4; c4 += LPP) {
+        const float4 l = mh_buf_load4(rsL, live ? (pp * p.l_ld + c4 * 4) * 4 : MH_OOB);
+        float4 a[DT], bb[DT];
+#pragma unroll
+        for (int j = 0; j < DT; ++j) {
+            a[j] = mh_buf_load4(rsR, o0[j] == MH_OOB ? MH_OOB : o0[j] + c4 * 16);
+            bb[j] = mh_buf_load4(rsR, o1[j] == MH_OOB ? MH_OOB : o1[j] + c4 * 16);
+        }
+        if (live) *reinterpret_cast<float4*>(Op + c4 * 4) = l;
+#pragma unroll
+        for (int j = 0; j < DT; ++j) {
+            float4 r;
+            r.x = w0[j] * a[j].x + w1[j] * bb[j].x; r.y = w0[j] * a[j].y + w1[j] * bb[j].y;
+            r.z = w0[j] * a[j].z + w1[j] * bb[j].z; r.w = w0[j] * a[j].w + w1[j] * bb[j].w;
+            accd[j] += l.x * r.x + l.y * r.y + l.z * r.z + l.w * r.w;
+            if (j == p.md && live) *reinterpret_cast<float4*>(p.Rw + (int64_t)pp * p.rw_ld + c4 * 4) = r;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < DT; ++j) {
+#pragma unroll
+        for (int o = LPP >> 1; o > 0; o >>= 1) accd[j] += __shfl_xor(accd[j], o);
+    }
+    if (live) {
+        const int nout = p.zero_tail ? p.out_ld - p.coff : p.D + 1;
+        for (int e = sub; e < nout; e += LPP) {
+            float v = 0.f;
+#pragma unroll
+            for (int j = 0; j < DT; ++j) v = (e == j) ? accd[j] * inv_c : v;
+            if (e == p.D) v = uc;
+            Op[p.coff + e] = v;
+        }
+        if (sub == 0) p.u[pp] = uc;
+    }
+}
+
 // Generic shift count (DispNet, D = 81): lane = one (pixel, shift) pair, channels looped from
 // LDS (left tile + right window staged once, rows padded by 4 floats against bank conflicts).
 template <int TW>
@@ -548,6 +648,37 @@ extern "C" int mh_corr_fwd(const float* L, int32_t l_ld, const float* R, int32_t
         hipLaunchKernelGGL((corr_fwd_large<32>), dim3(a.segs * B * H), dim3(256), lds, s, a);
     }
     return mh_check_launch("corr_fwd");
+}
+
+extern "C" int mh_level_front_fwd(const float* Vc, int32_t Hc, int32_t Wc, float mul, const float* L, int32_t l_ld, const float* R,
+                                  int32_t r_ld, float* out, int32_t out_ld, int32_t coff, float* Rw, int32_t rw_ld, float* u,
+                                  int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t zero_tail, void* stream) {
+    MH_REQUIRE(Vc && L && R && out && Rw && u, MH_ERR_ARG, "mh_level_front_fwd: null argument");
+    MH_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && Hc > 0 && Wc > 0 && max_disp >= 0, MH_ERR_ARG, "mh_level_front_fwd: bad dimension");
+    const int D = 2 * max_disp + 1;
+    MH_REQUIRE(D <= MAXD_SMALL, MH_ERR_UNSUPPORTED, "mh_level_front_fwd: at most %d shifts (use mh_resize_fwd + mh_warp_fwd + mh_corr_fwd)", MAXD_SMALL);
+    MH_REQUIRE(C % 4 == 0 && l_ld % 4 == 0 && r_ld % 4 == 0 && rw_ld % 4 == 0 && out_ld % 4 == 0 && mh_aligned16(L) && mh_aligned16(R) &&
+               mh_aligned16(Rw) && mh_aligned16(out), MH_ERR_ALIGN, "mh_level_front_fwd: 16-byte rows required");
+    MH_REQUIRE(coff >= C && coff + D + 1 <= out_ld && rw_ld >= C, MH_ERR_ARG, "mh_level_front_fwd: out_ld / coff / rw_ld too small");
+    const int64_t npix = (int64_t)B * H * W;
+    const int64_t lb = ((npix - 1) * l_ld + C) * 4, rb = ((npix - 1) * r_ld + C) * 4;
+    MH_REQUIRE(npix < (1ll << 31) - 256 && lb < (1ll << 31) - 64 && rb < (1ll << 31) - 64, MH_ERR_UNSUPPORTED, "mh_level_front_fwd: tensors must be < 2 GiB");
+    FrontArgs a;
+    a.Vc = Vc; a.L = L; a.R = R; a.out = out; a.Rw = Rw; a.u = u; a.Hc = Hc; a.Wc = Wc; a.mul = mul;
+    a.sy = (float)Hc / (float)H; a.sx = (float)Wc / (float)W;
+    a.l_ld = l_ld; a.r_ld = r_ld; a.out_ld = out_ld; a.rw_ld = rw_ld; a.coff = coff;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.md = max_disp; a.D = D; a.zero_tail = zero_tail;
+    a.l_bytes = (unsigned)lb; a.r_bytes = (unsigned)rb;
+    hipStream_t s = (hipStream_t)stream;
+    const int C4 = C / 4;
+    auto grid = [&](int lpp) { return dim3((unsigned)((npix * lpp + 255) / 256)); };
+#define MH_FRONT(LPPv)                                                                                              \
+    { if (D <= 5) hipLaunchKernelGGL((level_front_kernel<LPPv, 5>), grid(LPPv), dim3(256), 0, s, a);                \
+      else hipLaunchKernelGGL((level_front_kernel<LPPv, MAXD_SMALL>), grid(LPPv), dim3(256), 0, s, a); }
+    if (C4 <= 4) MH_FRONT(4) else if (C4 <= 8) MH_FRONT(8) else MH_FRONT(16)
+#undef MH_FRONT
+    mh_note_kernel("level_front_kernel<LPP=%d,DT=%d>", C4 <= 4 ? 4 : (C4 <= 8 ? 8 : 16), D <= 5 ? 5 : MAXD_SMALL);
+    return mh_check_launch("level_front_fwd");
 }
 
 extern "C" int mh_corr_bwd(const float* g, int32_t g_ld, int32_t coff, const float* L, int32_t l_ld,

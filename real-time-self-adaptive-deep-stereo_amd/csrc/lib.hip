@@ -142,6 +142,9 @@ static int run_op(const mh_op& o, void* s) {
         case MH_OP_RESIZE_BWD:
             return mh_resize_bwd((const float*)p[0], (const float*)p[1], (float*)p[2], i[10], i[0], i[1], i[2], i[3], i[4], i[5], i[6],
                                  i[7], i[8], o.f[0], i[9], s);
+        case MH_OP_LEVEL_FRONT:
+            return mh_level_front_fwd((const float*)p[0], i[0], i[1], o.f[0], (const float*)p[1], i[2], (const float*)p[2], i[3], (float*)p[3],
+                                      i[4], i[5], (float*)p[4], i[6], (float*)p[5], i[7], i[8], i[9], i[10], i[11], i[12], s);
         case MH_OP_RESIZE_IMAGE:
             return mh_resize_image_fwd((const float*)p[0], (float*)p[1], i[0], i[1], i[2], i[3], i[4], i[5], s);
         case MH_OP_PAD_REFLECT:

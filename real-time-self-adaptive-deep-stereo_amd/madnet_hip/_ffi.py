@@ -30,7 +30,7 @@ class Op(C.Structure):
 
 (OP_CONV, OP_WGRAD, OP_CORR_FWD, OP_CORR_BWD, OP_WARP_FWD, OP_WARP_BWD, OP_RESIZE_FWD, OP_RESIZE_BWD,
  OP_PAD_REFLECT, OP_LOSS, OP_METRICS, OP_MOMENTUM, OP_COPY_CH, OP_LEAKY_BWD, OP_FILL, OP_BIAS_GRAD,
- OP_WGRAD_PARTIAL, OP_WGRAD_REDUCE, OP_PROXY_LOSS, OP_SUPERVISED_LOSS, OP_ADAM, OP_ADAM_ADVANCE, OP_RESIZE_IMAGE) = range(1, 24)
+ OP_WGRAD_PARTIAL, OP_WGRAD_REDUCE, OP_PROXY_LOSS, OP_SUPERVISED_LOSS, OP_ADAM, OP_ADAM_ADVANCE, OP_RESIZE_IMAGE, OP_LEVEL_FRONT) = range(1, 25)
 
 
 OP_JOIN = 0x100
@@ -69,6 +69,7 @@ SIGNATURES = {
     "mh_adam": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _P]),
     "mh_adam_advance": (_I, [_P, _F, _F, _P]),
     "mh_corr_fwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mh_level_front_fwd": (_I, [_P, _I, _I, _F, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "mh_corr_bwd": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mh_shift_corr": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "mh_shift_corr_grad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),

@@ -135,16 +135,26 @@ class Adapter(object):
                 eng.proxy.copy_(_as(proxy, eng.proxy), non_blocking=True)
             plans[0].launch(self.lib, sh)
             if self.shared:
-                for o, c in eng.params.ranges(self._train_vars(key)):
-                    self.dist.all_reduce(eng.params.g[o:o + c], group=self.pg)
-                self.dist.all_reduce(eng.res_loss, group=self.pg)
-                eng.res_loss.div_(self.world)
+                # ONE collective per contiguous gradient range; the loss result sits right behind the gradient buffer
+                # (engine.Params.g), so in FULL mode gradients + loss travel together.  Sums; the 1/world factors are applied
+                # by the momentum kernel (grad_scale) and on the host (loss).
+                P = eng.params
+                rng = P.ranges(self._train_vars(key))
+                tail = (P.total, 4)
+                if rng and rng[-1][0] + rng[-1][1] == P.total:
+                    rng[-1] = (rng[-1][0], rng[-1][1] + 4)
+                else:
+                    rng.append(tail)
+                for o, c in rng:
+                    self.dist.all_reduce(P.g[o:o + c], group=self.pg)
+                self.collectives_last_step = len(rng)
                 plans[1].launch(self.lib, sh)
             self._host[0:4].copy_(eng.res_loss, non_blocking=True)
             self._host[4:8].copy_(eng.res_met, non_blocking=True)
         if self.cuda:
             self.stream.synchronize()
-        new_loss = float(self._host[0]); epe = float(self._host[4]); bad3 = float(self._host[5])
+        new_loss = float(self._host[0]) / (self.world if self.shared else 1)
+        epe = float(self._host[4]); bad3 = float(self._host[5])
         # ---- reward update of the sampling logits (Stereo_Online_Adaptation.py:211-224)
         if self.mode == "MAD":
             if self.step_count == 0:

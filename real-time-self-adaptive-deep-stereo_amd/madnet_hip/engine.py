@@ -84,7 +84,9 @@ class Params(object):
         self.total = off
         self.w = torch.zeros(off, device=device)
         self.m = torch.zeros(off, device=device)
-        self.g = torch.zeros(off, device=device)
+        # + 4 floats behind the gradients: the step's loss result lives there, so the shared-model mode all-reduces the
+        # gradients AND the loss that drives the reward / reset logic with ONE collective (adapter.py)
+        self.g = torch.zeros(off + 4, device=device)
         self.w0 = None                                         # reset copy (restore target)
 
     def numel(self, name):
@@ -144,6 +146,8 @@ class MadNetEngine(object):
         # ... recorded on a side lane: the filter gradients are off the critical path (only the optimizer needs
         # them), so they overlap with the input-gradient chain as a parallel branch of the hipGraph
         self.wgrad_lanes = 2
+        # one launch per level for the inter-level upsample + warp + cost volume + concat (mh_level_front_fwd) instead of three
+        self.fuse_front = True
         self.wsa = ops.WgradWorkspace(device)
 
     # ---------------------------------------------------------------------------------------
@@ -188,7 +192,8 @@ class MadNetEngine(object):
         self.loss_ws = z(self.lib.loss_ws_floats(B, self.H0, self.W0))
         self.loss_ws_k = z(self.lib.loss_ws_floats(B, self.H0, self.W0))
         self.met_ws = z(self.lib.metrics_ws_floats(B, self.H0, self.W0))
-        self.res_loss = z(4); self.res_loss_k = z(4); self.res_met = z(4)
+        self.res_loss = self.params.g[self.params.total:self.params.total + 4]
+        self.res_loss_k = z(4); self.res_met = z(4)
         # continual-adaptation variant (loss_kind = 'proxy'): proxy labels + the mean_l1 loss workspace
         self.proxy = z(B, self.H0, self.W0)
         self.proxy_ws = z(self.lib.proxy_ws_floats(B, self.H0, self.W0))
@@ -245,13 +250,18 @@ class MadNetEngine(object):
             h, w, c = self.fshape[f]
             Lk = self._half(self.F[f], False)
             Rk = self._half(self.F[f], True)
-            if k != 6 and self.warping:
-                ops.warp_fwd(lib, Rk, self.u[k], self._fv(self.Rw[k]))
-                Rk = self._fv(self.Rw[k])
             ld = self.dsi_ld[k]
             dsi = ops.View(self.dsi[k], B, h, w, ld, ld)
-            ops.corr_fwd(lib, Lk, Rk, dsi, self.md, self.cstride, coff=c, u=(None if k == 6 else self.u[k]),
-                         copy_left=True, zero_tail=True)
+            fused = k != 6 and self._front_fused()
+            if fused:
+                # u_k = resize(V_{k+1}) * 20 / 2^k (MadNet.py:274), warp, cost volume + concat: one launch
+                ops.level_front_fwd(lib, self.V[k + 1], 20.0 / 2 ** k, Lk, Rk, dsi, self._fv(self.Rw[k]), self.u[k], self.md, coff=c)
+            else:
+                if k != 6 and self.warping:
+                    ops.warp_fwd(lib, Rk, self.u[k], self._fv(self.Rw[k]))
+                    Rk = self._fv(self.Rw[k])
+                ops.corr_fwd(lib, Lk, Rk, dsi, self.md, self.cstride, coff=c, u=(None if k == 6 else self.u[k]),
+                             copy_left=True, zero_tail=True)
             x = ops.View(self.dsi[k], B, h, w, c + self.D + (0 if k == 6 else 1), ld)
             for j, co in enumerate(EST):
                 last = j == len(EST) - 1
@@ -261,7 +271,8 @@ class MadNetEngine(object):
                 x = o
             if k != 2:
                 sc = 2 ** (k - 1)
-                ops.resize_fwd(lib, self.V[k], self.u[k - 1], self.Hp // sc, self.Wp // sc, mul=20.0 / sc, mode=0)
+                if not self._front_fused():          # (fused: level k-1's front kernel computes u itself)
+                    ops.resize_fwd(lib, self.V[k], self.u[k - 1], self.Hp // sc, self.Wp // sc, mul=20.0 / sc, mode=0)
                 if k in make_disps:
                     self._make_disp(lib, self.V[k], self.disp_k[k])
         # context network (MadNet._stereo_context_net, MadNet.py:122-171)
@@ -281,6 +292,9 @@ class MadNetEngine(object):
             self._make_disp(lib, self.final, self.disp_k[2])
         # rescaled_prediction: relu AFTER resize (MadNet.py:362-364)
         ops.resize_fwd(lib, self.final, self.pred, self.Hp, self.Wp, self.pt, self.pl, mul=-20.0, mode=2)
+
+    def _front_fused(self):
+        return self.fuse_front and self.warping and self.cstride == 1 and self.D <= 9
 
     def _conv_acc(self, lib, x, base, out, rate):
         import ctypes as C

@@ -232,6 +232,13 @@ def corr_fwd(lib, L, R, out, max_disp, stride=1, coff=0, u=None, copy_left=False
                  int(copy_left), int(zero_tail), _p(stream))
 
 
+def level_front_fwd(lib, Vc, mul, L, R, out, Rw, u, max_disp, coff, zero_tail=True, stream=None):
+    """u = mul * resize(Vc) ; Rw = warp(R, u) ; out = [L | corr(L, Rw) | u | 0]  -- one launch (mh_level_front_fwd).
+    Vc: [B,Hc,Wc] tensor; L, R, Rw: Views [B,H,W,C]; out: View of the estimator input; u: [B,H,W] tensor."""
+    lib.level_front_fwd(_p(Vc), Vc.shape[1], Vc.shape[2], mul, _p(L), L.ld, _p(R), R.ld, _p(out), out.ld, coff, _p(Rw), Rw.ld, _p(u),
+                        L.B, L.H, L.W, L.C, max_disp, int(zero_tail), _p(stream))
+
+
 def corr_bwd(lib, g, L, R, dL, dR, max_disp, stride=1, coff=0, du=None, acc_l=False, acc_r=False, acc_u=False,
              copy_left=False, stream=None):
     lib.corr_bwd(_p(g), g.ld, coff, _p(L), L.ld, _p(R), R.ld, _p(dL), dL.ld, int(acc_l), _p(dR), dR.ld, int(acc_r),

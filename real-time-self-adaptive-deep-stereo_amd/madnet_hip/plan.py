@@ -88,6 +88,9 @@ class Recorder(object):
     def corr_fwd(self, L, l_ld, R, r_ld, u, out, out_ld, coff, B, H, W, Cc, md, stride, copy_left, zero_tail, stream):
         self._op(_ffi.OP_CORR_FWD, [l_ld, r_ld, out_ld, coff, B, H, W, Cc, md, stride, copy_left, zero_tail], [], [L, R, u, out])
 
+    def level_front_fwd(self, Vc, Hc, Wc, mul, L, l_ld, R, r_ld, out, out_ld, coff, Rw, rw_ld, u, B, H, W, Cc, md, zero_tail, stream):
+        self._op(_ffi.OP_LEVEL_FRONT, [Hc, Wc, l_ld, r_ld, out_ld, coff, rw_ld, B, H, W, Cc, md, zero_tail], [mul], [Vc, L, R, out, Rw, u])
+
     def corr_bwd(self, g, g_ld, coff, L, l_ld, R, r_ld, dL, dl_ld, acc_l, dR, dr_ld, acc_r, du, acc_u,
                  B, H, W, Cc, md, stride, copy_left, stream):
         self._op(_ffi.OP_CORR_BWD, [g_ld, coff, l_ld, r_ld, dl_ld, acc_l, dr_ld, acc_r, acc_u, B, H, W, Cc, md, stride, copy_left],

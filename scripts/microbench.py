@@ -159,6 +159,31 @@ def run_patchdbg():
     ops.PRECISION = 0
 
 
+def run_x3dbg():
+    """split-bf16 (precision code 2) patch kernel: phase breakdown (full / no K walk / no staging / neither) and the generic-K
+    instance, next to plain bf16 and exact fp32 on the same layers."""
+    PL = [("L2 128->128 d1", 1, 96, 320, 128, 128, 1), ("L2 128->128 d2", 1, 96, 320, 128, 128, 2), ("L2 128->96", 1, 96, 320, 128, 96, 1),
+          ("L2 96->64", 1, 96, 320, 96, 64, 1), ("L2 40->128", 1, 96, 320, 40, 128, 1), ("L3 128->128", 1, 48, 160, 128, 128, 1),
+          ("L3 72->128", 1, 48, 160, 72, 128, 1), ("L4 128->128", 1, 24, 80, 128, 128, 1)]
+    print("%-16s %9s %9s %9s %9s %9s | %9s %9s" % ("layer (fwd)", "x3 full", "x3 noK", "x3 nostg", "x3 none", "x3 genK", "bf16", "fp32"))
+    for name, B, H, W, Ci, Co, d in PL:
+        x = torch.randn(B, H, W, Ci, device=dev); xv = ops.view(x)
+        w = torch.randn(3, 3, Ci, Co, device=dev) * 0.05; b = torch.randn(Co, device=dev)
+        y = torch.empty(B, H, W, Co, device=dev)
+        flops = 2.0 * B * H * W * 9 * Ci * Co
+        res = []
+        for code, m in ((2, 128), (2, 128 + 512), (2, 128 + 1024), (2, 128 + 1536), (2, 128 + 2048), (1, -1), (0, -1)):
+            lib.tune_conv_patch(m)
+            ops.PRECISION = code
+            with torch.cuda.stream(stream):
+                res.append(_time_ms(lib, stream, lambda: ops.conv2d_fwd(lib, xv, w, b, ops.view(y), stride=1, dil=d, alpha=0.2, stream=stream.cuda_stream), 20) * 1e3)
+            ops.PRECISION = 0
+        lib.tune_conv_patch(-1)
+        print("%-16s %s | %9.1f %9.1f   (x3 %.0f TF/s algorithmic)" % (name, " ".join("%9.1f" % r for r in res[:5]), res[5], res[6], flops / (res[0] * 1e-6) / 1e12))
+
+
+if what == "x3dbg":
+    run_x3dbg()
 if what == "patchdbg":
     run_patchdbg()
 if what == "patch":

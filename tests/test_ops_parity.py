@@ -352,3 +352,38 @@ def test_adam_update(backend):
         assert torch.allclose(v.cpu(), vr, rtol=1e-6, atol=1e-12) and torch.allclose(m.cpu(), mr, rtol=1e-6, atol=1e-9)
         assert torch.allclose(state.cpu(), torch.tensor(sr), rtol=1e-7)
 
+
+
+@pytest.mark.parametrize("case", [(1, 12, 40, 128, 2), (2, 6, 10, 32, 2), (1, 9, 17, 64, 3), (1, 24, 80, 96, 2), (1, 5, 7, 16, 1)])
+def test_level_front_fused_matches_resize_warp_corr(backend, case):
+    """mh_level_front_fwd (one launch) == mh_resize_fwd(mode 0) -> mh_warp_fwd -> mh_corr_fwd(copy_left, u, zero_tail), the
+    three launches it replaces, and == the oracle chain (tf.image.resize_images * 20/2^k, _linear_warping, correlation + concat;
+    MadNet.py:274-295,370-436).  Large upsampled disparities push taps outside the row (zero weight)."""
+    B, H, W, C, md = case
+    dev = backend.device
+    Hc, Wc = (H + 1) // 2, (W + 1) // 2
+    Vc = _rand((B, Hc, Wc), 61, dev, 1.5)
+    L = _rand((B, H, W, C), 62, dev); R = _rand((B, H, W, C), 63, dev)
+    mul = 20.0 / 8
+    D = 2 * md + 1
+    ld = (C + D + 1 + 3) // 4 * 4
+    # unfused chain
+    u0 = torch.empty(B, H, W, device=dev); Rw0 = torch.empty(B, H, W, C, device=dev)
+    out0 = torch.full((B, H, W, ld), float("nan"), device=dev)
+    ops.resize_fwd(backend.lib, Vc, u0, H, W, mul=mul, mode=0)
+    ops.warp_fwd(backend.lib, ops.view(R), u0, ops.view(Rw0))
+    ops.corr_fwd(backend.lib, ops.view(L), ops.view(Rw0), ops.View(out0, B, H, W, ld, ld), md, 1, coff=C, u=u0, copy_left=True, zero_tail=True)
+    # fused
+    u1 = torch.full((B, H, W), float("nan"), device=dev); Rw1 = torch.full((B, H, W, C), float("nan"), device=dev)
+    out1 = torch.full((B, H, W, ld), float("nan"), device=dev)
+    ops.level_front_fwd(backend.lib, Vc, mul, ops.view(L), ops.view(R), ops.View(out1, B, H, W, ld, ld), ops.view(Rw1), u1, md, coff=C)
+    backend.sync()
+    assert torch.equal(u1.cpu(), u0.cpu())
+    assert (Rw1.cpu() - Rw0.cpu()).abs().max().item() <= 1e-6
+    assert torch.equal(out1[..., :C].cpu(), L.cpu()) and torch.equal(out1[..., C + D].cpu(), u0.cpu())
+    assert torch.all(out1[..., C + D + 1:].cpu() == 0)
+    assert (out1[..., C:C + D].cpu() - out0[..., C:C + D].cpu()).abs().max().item() <= 2e-6
+    # oracle
+    uo = T.resize_bilinear(Vc.cpu()[..., None], H, W) * mul
+    ref = T.correlation(L.cpu(), T.linear_warp(R.cpu(), uo), md, 1)
+    ok, err = _close(out1[..., C:C + D], ref); assert ok, err
