@@ -113,6 +113,13 @@ int mh_corr_fwd(const float* L, int32_t l_ld, const float* R, int32_t r_ld, cons
                 float* out, int32_t out_ld, int32_t coff,
                 int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t stride,
                 int32_t copy_left, int32_t zero_tail, void* stream);
+/* mh_corr_fwd with an arithmetic mode for the LARGE search range (D > 9, DispNet's 81-shift volume, stand-alone form): 0 = exact
+ * fp32 MFMA (what mh_corr_fwd runs), 1 = bf16 operands / fp32 accumulate, 2 = split-bf16 (3 MFMAs per product, ~2^-16 relative).
+ * D <= 9 and the fused-concat forms ignore the mode (pure bandwidth kernels, exact fp32). */
+int mh_corr_fwd_prec(const float* L, int32_t l_ld, const float* R, int32_t r_ld, const float* u,
+                     float* out, int32_t out_ld, int32_t coff,
+                     int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t stride,
+                     int32_t copy_left, int32_t zero_tail, int32_t precision, void* stream);
 /* Fused front end of one MADNet pyramid level (Nets/MadNet.py:274-295 and the same lines of the other levels): in ONE launch
  *   u[p]        = mul * resize_bilinear(Vc[B,Hc,Wc] -> [H,W])[p]                (tf.image.resize_images, TF1 legacy; MadNet.py:274)
  *   Rw[p][c]    = linear warp of R at x + u[p] along the row, zero outside      (_build_indeces + _linear_warping, :378-436)

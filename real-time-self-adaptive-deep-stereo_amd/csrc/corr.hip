@@ -431,6 +431,101 @@ __global__ __launch_bounds__(256) void corr_fwd_mfma(CorrArgs p) {
     }
 }
 
+// The same band on the bf16 matrix cores (precision codes 1 / 2 of mh_corr_fwd_prec).  The exact-fp32 form above runs
+// 6 x C/4 = 192 v_mfma_f32_16x16x4_f32 per wave (6144 cycles: at 31 FLOP/B the fp32 MFMA rate -- 157 TFLOP/s -- is the ceiling
+// it hits at 32 % of the HBM peak); with bf16 operands (v_mfma_f32_16x16x32_bf16, fp32 accumulate) the same band costs
+// 6 x C/32 = 24 MFMAs (408 cycles) and the kernel becomes what the op is: a stream of L + R + the D-channel output.
+//   X3 = false: operands rounded to bf16 (RNE);  X3 = true: split-bf16, hi + lo planes, 3 MFMAs per product (~2^-16 relative).
+// Window rows are bf16 [pixel][C + 16 halfs] (the 8-dword-mod-16 row stride of conv_patch.hip: conflict-free b128 reads).
+template <int CS32, bool X3>    // C / 32
+__global__ __launch_bounds__(256) void corr_fwd_mfma_bf16(CorrArgs p) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    constexpr int C = CS32 * 32, RS = C + 16;            // halfs
+    unsigned short* const Wh = reinterpret_cast<unsigned short*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int seg = blockIdx.x % p.segs;
+    const int row = blockIdx.x / p.segs;              // b*H + y
+    const int x0 = seg * 64;
+    const int nb = (2 * p.md + 16 + 15) / 16;         // 16-column blocks per wave
+    const int rows = 48 + 16 * nb;                    // window rows any wave touches
+    const int PLO = rows * RS;                        // lo plane offset (X3)
+    const __amdgpu_buffer_rsrc_t rsL = mh_make_rsrc(p.L, p.l_bytes);
+    const __amdgpu_buffer_rsrc_t rsR = mh_make_rsrc(p.R, p.r_bytes);
+    // stage the right window: U independent 16-byte loads in flight per thread, converted at the LDS store
+    constexpr int U = 8;
+    const int items = rows * (C / 4);
+    for (int q0 = tid; q0 < items; q0 += 256 * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = q0 + 256 * u;
+            const int xw = q / (C / 4), c4 = q - xw * (C / 4);
+            const int xs = x0 - p.md + xw;
+            const bool ok = q < items && xs >= 0 && xs < p.W;
+            v[u] = mh_buf_load4(rsR, ok ? ((row * p.W + xs) * p.r_ld + c4 * 4) * 4 : MH_OOB);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = q0 + 256 * u;
+            if (q < items) {
+                const int xw = q / (C / 4), c4 = q - xw * (C / 4);
+                unsigned short* d = Wh + xw * RS + c4 * 4;
+                if constexpr (X3) {
+                    uint2 hi, lo;
+                    mh_split_bf16x2(v[u].x, v[u].y, hi.x, lo.x);
+                    mh_split_bf16x2(v[u].z, v[u].w, hi.y, lo.y);
+                    *reinterpret_cast<uint2*>(d) = hi;
+                    *reinterpret_cast<uint2*>(d + PLO) = lo;
+                } else {
+                    *reinterpret_cast<uint2*>(d) = make_uint2(mh_pack_bf16(v[u].x, v[u].y), mh_pack_bf16(v[u].z, v[u].w));
+                }
+            }
+        }
+    }
+    // this wave's left tile as MFMA A operands: pixel xb + li, channels s*32 + lq*8 .. +7
+    const int xb = x0 + 16 * wave;
+    u32x4 a[CS32], al[X3 ? CS32 : 1];
+    {
+        const bool ok = xb + li < p.W;
+#pragma unroll
+        for (int s = 0; s < CS32; ++s) {
+            const int off = ok ? ((row * p.W + xb + li) * p.l_ld + s * 32 + lq * 8) * 4 : MH_OOB;
+            const float4 v0 = mh_buf_load4(rsL, off), v1 = mh_buf_load4(rsL, off == MH_OOB ? MH_OOB : off + 16);
+            if constexpr (X3) {
+                unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+                mh_split_bf16x2(v0.x, v0.y, h0, l0); mh_split_bf16x2(v0.z, v0.w, h1, l1);
+                mh_split_bf16x2(v1.x, v1.y, h2, l2); mh_split_bf16x2(v1.z, v1.w, h3, l3);
+                a[s] = (u32x4){h0, h1, h2, h3}; al[s] = (u32x4){l0, l1, l2, l3};
+            } else {
+                a[s] = (u32x4){mh_pack_bf16(v0.x, v0.y), mh_pack_bf16(v0.z, v0.w), mh_pack_bf16(v1.x, v1.y), mh_pack_bf16(v1.z, v1.w)};
+            }
+        }
+    }
+    __syncthreads();
+    const float inv_c = 1.0f / (float)C;
+    for (int blk = 0; blk < nb; ++blk) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const unsigned short* Rb = Wh + (16 * wave + 16 * blk + li) * RS + lq * 8;
+#pragma unroll
+        for (int s = 0; s < CS32; ++s) {
+            const u32x4 b = *reinterpret_cast<const u32x4*>(Rb + s * 32);
+            if constexpr (X3) {
+                const u32x4 bl = *reinterpret_cast<const u32x4*>(Rb + PLO + s * 32);
+                acc = mh_mfma_bf16(al[s], b, acc);
+                acc = mh_mfma_bf16(a[s], bl, acc);
+            }
+            acc = mh_mfma_bf16(a[s], b, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int x = xb + 4 * lq + r;
+            const int d = 16 * blk + li - (4 * lq + r);
+            if (x < p.W && d >= 0 && d < p.D) p.out[(int64_t)(row * p.W + x) * p.out_ld + p.coff + d] = acc[r] * inv_c;
+        }
+    }
+}
+
 // Gradient of the large-shift cost volume on the matrix cores (same banded-GEMM view as corr_fwd_mfma):
 //   RIGHT = false: dL[x][c]  = 1/C * sum_x' G[x][x'] * R[x'][c]      G[x][x'] = g[x][x' - x + md] inside the band, else 0
 //   RIGHT = true : dR[x'][c] = 1/C * sum_x  G[x][x'] * L[x][c]
@@ -568,6 +663,12 @@ int mh_corr_init() {
     if (e != hipSuccess) { mh_set_error("corr: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     MH_CORR_ATTR(1) MH_CORR_ATTR(2) MH_CORR_ATTR(4) MH_CORR_ATTR(8) MH_CORR_ATTR(16)
 #undef MH_CORR_ATTR
+#define MH_CORRH_ATTR(CSv, Xv)                                                                                                 \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_mfma_bf16<CSv, Xv>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+    if (e != hipSuccess) { mh_set_error("corr: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    MH_CORRH_ATTR(1, false) MH_CORRH_ATTR(2, false) MH_CORRH_ATTR(4, false) MH_CORRH_ATTR(8, false)
+    MH_CORRH_ATTR(1, true) MH_CORRH_ATTR(2, true) MH_CORRH_ATTR(4, true) MH_CORRH_ATTR(8, true)
+#undef MH_CORRH_ATTR
 #define MH_CORRB_ATTR(CSv, Rv)                                                                                                 \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_bwd_mfma<CSv, Rv>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
     if (e != hipSuccess) { mh_set_error("corr: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
@@ -585,6 +686,14 @@ extern "C" int mh_corr_fwd(const float* L, int32_t l_ld, const float* R, int32_t
                            float* out, int32_t out_ld, int32_t coff,
                            int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t stride,
                            int32_t copy_left, int32_t zero_tail, void* stream) {
+    return mh_corr_fwd_prec(L, l_ld, R, r_ld, u, out, out_ld, coff, B, H, W, C, max_disp, stride, copy_left, zero_tail, 0, stream);
+}
+
+extern "C" int mh_corr_fwd_prec(const float* L, int32_t l_ld, const float* R, int32_t r_ld, const float* u,
+                                float* out, int32_t out_ld, int32_t coff,
+                                int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t stride,
+                                int32_t copy_left, int32_t zero_tail, int32_t precision, void* stream) {
+    MH_REQUIRE(precision >= 0 && precision <= 2, MH_ERR_ARG, "mh_corr_fwd_prec: precision must be 0 (fp32), 1 (bf16) or 2 (split-bf16)");
     MH_REQUIRE(L && R && out, MH_ERR_ARG, "mh_corr_fwd: null argument");
     MH_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && max_disp >= 0 && stride >= 1, MH_ERR_ARG, "mh_corr_fwd: bad dimension");
     MH_REQUIRE(C % 4 == 0 && l_ld % 4 == 0 && r_ld % 4 == 0 && mh_aligned16(L) && mh_aligned16(R), MH_ERR_ALIGN,
@@ -628,8 +737,20 @@ extern "C" int mh_corr_fwd(const float* L, int32_t l_ld, const float* R, int32_t
                (size_t)(48 + 16 * ((2 * max_disp + 31) / 16)) * (C + 4) * sizeof(float) <= 150 * 1024) {
         a.l_bytes = (unsigned)lb; a.r_bytes = (unsigned)rb;
         a.segs = mh_cdiv(W, 64);
-        const size_t lds = (size_t)(48 + 16 * ((2 * max_disp + 31) / 16)) * (C + 4) * sizeof(float);
         const dim3 grid(a.segs * B * H);
+        if (precision != 0 && C >= 32 && C <= 256) {
+            // bf16 / split-bf16 operands on v_mfma_f32_16x16x32_bf16 (the large-D volume only; D <= 9 is pure bandwidth and stays fp32)
+            const size_t ldsh = (size_t)(48 + 16 * ((2 * max_disp + 31) / 16)) * (C + 16) * 2 * (precision == 2 ? 2 : 1);
+            if (ldsh <= 150 * 1024) {
+#define MH_CH(CSv) { if (precision == 2) hipLaunchKernelGGL((corr_fwd_mfma_bf16<CSv, true>), grid, dim3(256), ldsh, s, a);         \
+                     else hipLaunchKernelGGL((corr_fwd_mfma_bf16<CSv, false>), grid, dim3(256), ldsh, s, a); }
+                switch (C) { case 32: MH_CH(1) break; case 64: MH_CH(2) break; case 128: MH_CH(4) break; default: MH_CH(8) break; }
+#undef MH_CH
+                mh_note_kernel("corr_fwd_mfma_bf16<C/32=%d,%s>", C / 32, precision == 2 ? "bf16x3" : "bf16");
+                return mh_check_launch("corr_fwd_mfma_bf16");
+            }
+        }
+        const size_t lds = (size_t)(48 + 16 * ((2 * max_disp + 31) / 16)) * (C + 4) * sizeof(float);
         switch (C) {
             case 16: hipLaunchKernelGGL((corr_fwd_mfma<1>), grid, dim3(256), lds, s, a); break;
             case 32: hipLaunchKernelGGL((corr_fwd_mfma<2>), grid, dim3(256), lds, s, a); break;

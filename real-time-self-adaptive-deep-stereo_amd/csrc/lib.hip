@@ -126,8 +126,8 @@ static int run_op(const mh_op& o, void* s) {
         case MH_OP_WGRAD_REDUCE:
             return mh_wgrad_reduce((const mh_wgrad_seg*)p[0], i[0], i[1], s);
         case MH_OP_CORR_FWD:
-            return mh_corr_fwd((const float*)p[0], i[0], (const float*)p[1], i[1], (const float*)p[2], (float*)p[3], i[2], i[3],
-                               i[4], i[5], i[6], i[7], i[8], i[9], i[10], i[11], s);
+            return mh_corr_fwd_prec((const float*)p[0], i[0], (const float*)p[1], i[1], (const float*)p[2], (float*)p[3], i[2], i[3],
+                                    i[4], i[5], i[6], i[7], i[8], i[9], i[10], i[11], i[12], s);
         case MH_OP_CORR_BWD:
             return mh_corr_bwd((const float*)p[0], i[0], i[1], (const float*)p[1], i[2], (const float*)p[2], i[3],
                                (float*)p[3], i[4], i[5], (float*)p[4], i[6], i[7], (float*)p[5], i[8],

@@ -69,6 +69,7 @@ SIGNATURES = {
     "mh_adam": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _P]),
     "mh_adam_advance": (_I, [_P, _F, _F, _P]),
     "mh_corr_fwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mh_corr_fwd_prec": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mh_level_front_fwd": (_I, [_P, _I, _I, _F, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "mh_corr_bwd": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mh_shift_corr": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),

@@ -146,7 +146,7 @@ class Adapter(object):
                 else:
                     rng.append(tail)
                 for o, c in rng:
-                    self.dist.all_reduce(P.g[o:o + c], group=self.pg)
+                    self.dist.all_reduce(P.g_loss[o:o + c], group=self.pg)
                 self.collectives_last_step = len(rng)
                 plans[1].launch(self.lib, sh)
             self._host[0:4].copy_(eng.res_loss, non_blocking=True)

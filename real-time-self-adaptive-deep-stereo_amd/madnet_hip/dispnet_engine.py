@@ -99,7 +99,7 @@ class DispNetEngine(object):
         self.left = z(B, H, W, 3); self.right = z(B, H, W, 3); self.gt = z(B, H, W)
         self.pred = z(B, H, W); self.dpred = z(B, H, W)
         self.loss_ws = z(lib.loss_ws_floats(B, H, W)); self.met_ws = z(lib.metrics_ws_floats(B, H, W))
-        self.res_loss = self.params.g[self.params.total:self.params.total + 4]; self.res_met = z(4)   # (loss result behind the gradients: one collective carries both)
+        self.res_loss = self.params.g_loss[self.params.total:self.params.total + 4]; self.res_met = z(4)   # (loss result behind the gradients: one collective carries both)
         self.ops = []
         self.nodes = {}
         self.wsa = ops.WgradWorkspace(device)

@@ -13,6 +13,8 @@ Memory layout (all float32, NHWC, resident in HBM for the life of the engine):
     correlation kernel (no tf.concat copies); channel counts are padded to multiples of 4 so all
     row accesses are 16-byte vectors.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -86,7 +88,8 @@ class Params(object):
         self.m = torch.zeros(off, device=device)
         # + 4 floats behind the gradients: the step's loss result lives there, so the shared-model mode all-reduces the
         # gradients AND the loss that drives the reward / reset logic with ONE collective (adapter.py)
-        self.g = torch.zeros(off + 4, device=device)
+        self.g_loss = torch.zeros(off + 4, device=device)     # [gradients | loss result (4 floats)]
+        self.g = self.g_loss[:off]
         self.w0 = None                                         # reset copy (restore target)
 
     def numel(self, name):
@@ -147,7 +150,7 @@ class MadNetEngine(object):
         # them), so they overlap with the input-gradient chain as a parallel branch of the hipGraph
         self.wgrad_lanes = 2
         # one launch per level for the inter-level upsample + warp + cost volume + concat (mh_level_front_fwd) instead of three
-        self.fuse_front = True
+        self.fuse_front = os.environ.get("MH_FUSE_FRONT", "1") != "0"        # (environment switch: in-situ A/B runs)
         self.wsa = ops.WgradWorkspace(device)
 
     # ---------------------------------------------------------------------------------------
@@ -192,7 +195,7 @@ class MadNetEngine(object):
         self.loss_ws = z(self.lib.loss_ws_floats(B, self.H0, self.W0))
         self.loss_ws_k = z(self.lib.loss_ws_floats(B, self.H0, self.W0))
         self.met_ws = z(self.lib.metrics_ws_floats(B, self.H0, self.W0))
-        self.res_loss = self.params.g[self.params.total:self.params.total + 4]
+        self.res_loss = self.params.g_loss[self.params.total:self.params.total + 4]
         self.res_loss_k = z(4); self.res_met = z(4)
         # continual-adaptation variant (loss_kind = 'proxy'): proxy labels + the mean_l1 loss workspace
         self.proxy = z(B, self.H0, self.W0)

@@ -227,9 +227,15 @@ def conv2d_transpose_fwd(lib, x, w, b, out, stride=2, alpha=1.0, stream=None):
     lib.conv2d(C.byref(d), _p(x), _p(w), _p(b), _p(out), None, _p(stream))
 
 
-def corr_fwd(lib, L, R, out, max_disp, stride=1, coff=0, u=None, copy_left=False, zero_tail=False, stream=None):
-    lib.corr_fwd(_p(L), L.ld, _p(R), R.ld, _p(u), _p(out), out.ld, coff, L.B, L.H, L.W, L.C, max_disp, stride,
-                 int(copy_left), int(zero_tail), _p(stream))
+def corr_fwd(lib, L, R, out, max_disp, stride=1, coff=0, u=None, copy_left=False, zero_tail=False, stream=None, precision=None):
+    """precision: None = the forward code of the plan being recorded (PRECISION); only the large-D MFMA kernel uses it."""
+    prec = PRECISION if precision is None else precision
+    if prec == 0:
+        lib.corr_fwd(_p(L), L.ld, _p(R), R.ld, _p(u), _p(out), out.ld, coff, L.B, L.H, L.W, L.C, max_disp, stride,
+                     int(copy_left), int(zero_tail), _p(stream))
+    else:
+        lib.corr_fwd_prec(_p(L), L.ld, _p(R), R.ld, _p(u), _p(out), out.ld, coff, L.B, L.H, L.W, L.C, max_disp, stride,
+                          int(copy_left), int(zero_tail), prec, _p(stream))
 
 
 def level_front_fwd(lib, Vc, mul, L, R, out, Rw, u, max_disp, coff, zero_tail=True, stream=None):

@@ -90,6 +90,16 @@ def run_corr():
                 ms = _time_ms(lib, stream, lambda: ops.corr_fwd(lib, ops.view(L), ops.view(R), ops.view(out), md, stream=stream.cuda_stream), 10)
             print("corr fwd %s B=%d %dx%dx%d D=%d: %.1f us  %.0f GB/s (%.1f%% of 8 TB/s)" % ("direct" if direct else "lds   ", B, H, W, Cc, D, ms * 1e3, byts / ms / 1e6, byts / ms / 1e6 / 80))
         lib.tune_corr(1)
+    # the large-shift (DispNet) volume by arithmetic mode: exact fp32 MFMA / bf16 MFMA / split-bf16 (mh_corr_fwd_prec)
+    for (B, H, W, Cc, md) in [(16, 96, 320, 128, 40), (1, 96, 320, 128, 40)]:
+        L = torch.randn(B, H, W, Cc, device=dev); R = torch.randn(B, H, W, Cc, device=dev)
+        D = 2 * md + 1
+        out = torch.empty(B, H, W, D, device=dev)
+        byts = float(B) * H * W * (2 * Cc + D) * 4
+        for prec, nm in ((0, "fp32 "), (1, "bf16 "), (2, "bf16x3")):
+            with torch.cuda.stream(stream):
+                ms = _time_ms(lib, stream, lambda: ops.corr_fwd(lib, ops.view(L), ops.view(R), ops.view(out), md, stream=stream.cuda_stream, precision=prec), 10)
+            print("corr fwd %s B=%d %dx%dx%d D=%d: %.1f us  %.0f GB/s (%.1f%% of 8 TB/s)  [%s]" % (nm, B, H, W, Cc, D, ms * 1e3, byts / ms / 1e6, byts / ms / 1e6 / 80, lib.last_kernel().decode()))
     # gradient of the large-shift (DispNet) volume: gather kernel (tune_corr 0) vs the banded-GEMM MFMA pair (default)
     for (B, H, W, Cc, md) in [(1, 96, 320, 128, 40), (16, 96, 320, 128, 40)]:
         L = torch.randn(B, H, W, Cc, device=dev); R = torch.randn(B, H, W, Cc, device=dev)

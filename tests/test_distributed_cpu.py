@@ -39,6 +39,7 @@ def _worker(rank, world, port, q):
                                               "_lib": lib, "_device": "cpu"})
         ad = Adapter(net, mode="FULL", lr=1e-2, shared_model=True, use_graph=False)
         out = ad.step(l, r, gt[..., 0])
+        assert ad.collectives_last_step == 1                         # gradients + loss travel in ONE all-reduce
         w_after = net.engine.params.w.clone()
         g_sum = net.engine.params.g.clone()                         # all-reduced (summed) gradient
         # every rank must hold identical weights after the shared update
@@ -72,6 +73,7 @@ def test_shared_model_allreduce_world2():
         eng.set_inputs(l, r, gt[..., 0])
         eng.build_plan("FULL", lr=1e-2, update=False).run(backend.lib, 0)
         gsum = eng.params.g.clone() if gsum is None else gsum + eng.params.g
+        lsum = lsum + float(eng.res_loss[0]) if sid else float(eng.res_loss[0])
     res = sorted([q.get(timeout=600) for _ in procs], key=lambda x: x[0])
     for p in procs:
         p.join(timeout=60)
@@ -80,6 +82,8 @@ def test_shared_model_allreduce_world2():
     w0 = eng.params.w.clone()            # untouched (update=False)
     w_ref = w0 - 1e-2 * (0.5 * gsum)     # first step: accum = g/2 ; w -= lr*accum
     assert np.allclose(res[0][4], gsum.numpy(), rtol=1e-4, atol=1e-7 * float(gsum.abs().max()) + 1e-12)
+    # the loss every rank acts on (reward / reset logic) is the mean over the streams
+    assert abs(res[0][1] - res[1][1]) < 1e-9 and abs(res[0][1] - 0.5 * lsum) <= 1e-6
     assert np.allclose(res[0][3], w_ref.numpy(), rtol=1e-5, atol=1e-7)
 
 
