@@ -142,10 +142,13 @@ class dataset(object):
     50 * batch_size samples -> aligned random crop -> optional augmentation -> batches of batch_size (remainder dropped)."""
 
     def __init__(self, path_file, batch_size=1, crop_shape=(320, 1216), num_epochs=1, augment=False,
-                 is_training=False, shuffle=False, seed=0, keep_uint8=False):
+                 is_training=False, shuffle=False, seed=0, keep_uint8=False, shard=(0, 1)):
         """keep_uint8 (no augmentation): 8-bit frames are yielded as uint8 [B,H,W,3] instead of float32 -- device_prefetcher then
         moves 1 byte per value over PCIe and casts on the GPU (mh_u8_to_f32); values are identical."""
         self._u8 = bool(keep_uint8) and not augment
+        # shard = (rank, world): data-parallel training reads every world-th sample of each epoch (one pass over the list per
+        # epoch in total, not one per rank)
+        self._rank, self._world = int(shard[0]), max(1, int(shard[1]))
         self._left, self._right, self._gt = read_list_file(path_file)
         self._crop = tuple(crop_shape)
         self._epochs = num_epochs
@@ -156,10 +159,11 @@ class dataset(object):
         return len(self._left)
 
     def get_max_steps(self):
-        return (len(self._left) * self._epochs) // self._batch
+        per_rank = len(range(self._rank, len(self._left), self._world))
+        return (per_rank * self._epochs) // self._batch
 
     def _samples(self):
-        order = [i for _ in range(self._epochs) for i in range(len(self._left))]
+        order = [i for _ in range(self._epochs) for i in range(self._rank, len(self._left), self._world)]
         if not self._shuffle:
             for i in order:
                 yield i

@@ -23,7 +23,10 @@ MAX_DISP = 256
 PIXEL_TH = 3
 
 
-def load_weights(spec, model_name="MADNet", radius_d=2, stride=1):
+def load_weights(spec, model_name="MADNet", radius_d=2, stride=1, allow_missing=False):
+    """allow_missing: a checkpoint that lacks some of the model's variables is an ERROR unless this is set (--allowMissingWeights);
+    then -- like the reference, whose Saver restores the matching names and leaves the others at their initializer
+    (Stereo_Online_Adaptation.py:150-153, weights_utils.py:4-37) -- the missing ones keep Xavier values."""
     from madnet_hip import engine as E, dispnet_engine as DE, synthetic
     shapes = dict(E.madnet_manifest(radius_d, stride) if model_name == "MADNet" else DE.dispnet_manifest())
     kind = spec.split(':')[0]
@@ -45,6 +48,9 @@ def load_weights(spec, model_name="MADNet", radius_d=2, stride=1):
         w = {k: reader.get_tensor(k).astype(np.float32) for k in shapes if k in have}
         assert len(w) > 0, "no variable of %s found in checkpoint %s" % (model_name, spec)
         missing = [k for k in shapes if k not in have]
+        if missing and not allow_missing:
+            raise Exception('checkpoint %s lacks %d of the %d variables of %s (first: %s); pass --allowMissingWeights to keep their '
+                            'Xavier initial values like the reference does' % (spec, len(missing), len(shapes), model_name, missing[0]))
         if missing:
             print('WARNING: %d variables not in the checkpoint keep their synthetic initial value (first: %s)' % (len(missing), missing[0]))
             w0 = synthetic.xavier_weights(shapes, 0)
@@ -69,7 +75,7 @@ def main(args):
     right_img_batch = torch.zeros(1, H, W, 3, device=dev)
     net_args = {'left_img': left_img_batch, 'right_img': right_img_batch, 'split_layers': [None], 'sequence': True,
                 'train_portion': 'BEGIN', 'bulkhead': True if args.mode == 'MAD' else False,
-                'weights': load_weights(args.weights, args.modelName)}
+                'weights': load_weights(args.weights, args.modelName, allow_missing=getattr(args, 'allowMissingWeights', False))}
     stereo_net = Nets.get_stereo_net(args.modelName, net_args)
     print('Stereo Prediction Model:\n', stereo_net)
     predictions = stereo_net.get_disparities()
@@ -162,6 +168,7 @@ def build_parser():
     parser.add_argument("--SSIMTh", help="restore the initial weights when the loss exceeds this value", type=float, default=0.5)
     parser.add_argument("--sampleFrequency", help="draw new portions every K frames", type=int, default=1)
     parser.add_argument("--mode", help="NONE = inference only, FULL = full back-propagation, MAD = modular adaptation", choices=['NONE', 'FULL', 'MAD'], default='MAD')
+    parser.add_argument("--allowMissingWeights", help="variables absent from the checkpoint keep Xavier values (the reference's silent behaviour) instead of raising", action='store_true')
     parser.add_argument("--logDispStep", help="dump the disparity every K frames (-1: never)", default=-1, type=int)
     return parser
 

@@ -52,8 +52,13 @@ def main(args):
         import torch.distributed as dist
         dist.init_process_group('nccl')
     H, W = args.imageShape
+    n_pred = 6 if args.modelName == 'MADNet' else 7               # predicted scales: MadNet.py:268-364 / DispNet.py:75-152
+    if args.lossWeights is not None and len(args.lossWeights) < n_pred:
+        raise SystemExit('--lossWeights needs %d values for %s (one per predicted scale, full resolution first); got %d'
+                         % (n_pred, args.modelName, len(args.lossWeights)))
     data_set = data_reader.dataset(args.trainingSet, batch_size=args.batchSize, crop_shape=args.imageShape,
-                                   num_epochs=args.numEpochs, augment=args.augment, is_training=True, shuffle=True, seed=rank)
+                                   num_epochs=args.numEpochs, augment=args.augment, is_training=True, shuffle=True, seed=rank,
+                                   shard=(rank, world))
     validation_set = None
     if args.validationSet is not None:
         validation_set = data_reader.dataset(args.validationSet, batch_size=args.batchSize, crop_shape=args.imageShape,

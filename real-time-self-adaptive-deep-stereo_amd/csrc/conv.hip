@@ -67,8 +67,15 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
     constexpr bool BT = BF16 && !DGRAD;                // B tile loaded as 4-row units, transposed in registers
     constexpr int UN = GPT * (BN / 4);                 // such units per tile
     constexpr int BITEMS = BT ? 4 * ((UN + 255) / 256) : (BVEC + 255) / 256;
-    constexpr bool PF2 = (BM * BN <= 32 * 64) && (BM <= 64) && VEC;   // small tiles: prefetch distance 2 (see the K loop); the
+    constexpr bool PF2 = (BM * BN <= 32 * 64) && (BM <= 64) && VEC;   // small tiles: deep register prefetch (see the K loop); the
                                                                     // 128x16 tile (full-resolution layers) is throughput bound
+    // prefetch distance of the small tiles: 4 K-tiles in flight for the 32x32 tile (16 staging VGPRs per stage: the 16-wave
+    // split-K variant stays under its 128-VGPR budget), 2 for the wider small tiles
+    // (the bf16 forward B tile keeps 4-row units = twice the staging registers: distance 4 would spill there)
+    // MEASURED (profiles/r02_experiments.txt): distance 4 made every 32x32-tile layer SLOWER (13.0 -> 16.3 us in situ, fp32 and
+    // bf16 alike) -- these launches are not waiting on the load round trip but issuing it (address VALU + zero-padding loads of
+    // 16 waves); the instances stay at distance 2.  The distance-4 schedule is kept for reference behind this constant.
+    constexpr int PFD = !PF2 ? 1 : 2;
     constexpr int TILE_FLOATS = BF16 ? (BM + BN) * LS / 2 : (BM + BN) * LS;   // one buffer of both tiles, in floats
 
     HIP_DYNAMIC_SHARED(float, smem_all)
@@ -202,9 +209,9 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
 
     // Register stages.  Small tiles (PF2) are latency bound -- one exposed load -> LDS -> MFMA round trip per
     // K-tile -- and run with prefetch distance 2: K-tiles t+1 and t+2 are in flight while tile t is multiplied.
-    float4 ra0[AROWS], ra1[PF2 ? AROWS : 1];
-    float4 rb0[BITEMS], rb1[PF2 ? BITEMS : 1];
-    int kb0 = 0, kb1 = 0;     // kbase of the A group held by each stage (padding select at store time)
+    float4 ra0[AROWS], ra1[PF2 ? AROWS : 1], ra2[PFD == 4 ? AROWS : 1], ra3[PFD == 4 ? AROWS : 1];
+    float4 rb0[BITEMS], rb1[PF2 ? BITEMS : 1], rb2[PFD == 4 ? BITEMS : 1], rb3[PFD == 4 ? BITEMS : 1];
+    int kb0 = 0, kb1 = 0, kb2 = 0, kb3 = 0;     // kbase of the A group held by each stage (padding select at store time)
 
     __syncthreads();   // tap tables visible
 
@@ -416,7 +423,35 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
         }
     };
 
-    if constexpr (PF2) {
+    if constexpr (PFD == 4) {
+        // Distance 4: tiles t+1 .. t+4 are in flight / parked in four register stages while tile t is multiplied.  The small
+        // tiles are bound by ONE exposed global-load round trip per K-tile (~1 us at these grid sizes: 10-13 us for a layer of
+        // 5-6 K-steps whatever its pixel count); with four tiles requested up front the round trip is paid once.
+        load_tile(ra0, rb0, kb0);            // tile 0
+        load_tile(ra1, rb1, kb1);            // tile 1
+        load_tile(ra2, rb2, kb2);            // tile 2
+        load_tile(ra3, rb3, kb3);            // tile 3
+        store_tile(0, ra0, rb0, kb0);
+        __syncthreads();
+        for (int t = 0; t < ntile; t += 4) {
+            load_tile(ra0, rb0, kb0);        // tile t+4
+            compute_tile(0);                 // tile t
+            store_tile(1, ra1, rb1, kb1);    // tile t+1
+            __syncthreads();
+            load_tile(ra1, rb1, kb1);        // tile t+5
+            if (t + 1 < ntile) compute_tile(1);
+            store_tile(0, ra2, rb2, kb2);    // tile t+2
+            __syncthreads();
+            load_tile(ra2, rb2, kb2);        // tile t+6
+            if (t + 2 < ntile) compute_tile(0);
+            store_tile(1, ra3, rb3, kb3);    // tile t+3
+            __syncthreads();
+            load_tile(ra3, rb3, kb3);        // tile t+7
+            if (t + 3 < ntile) compute_tile(1);
+            store_tile(0, ra0, rb0, kb0);    // tile t+4
+            __syncthreads();
+        }
+    } else if constexpr (PF2) {
         // While tile t is multiplied out of LDS buffer t&1, tile t+1 sits in one register stage (stored to the
         // other LDS buffer after the MFMAs) and tile t+2 is being loaded into the other stage.  Loads past the
         // last tile are issued anyway (tap index out of range => out-of-range buffer offsets => zeros, no

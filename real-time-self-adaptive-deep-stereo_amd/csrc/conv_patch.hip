@@ -645,7 +645,11 @@ bool mh_conv_patch_ok(const ConvArgs& a) {
         if (min_pix < 0) { const char* e = getenv("MH_CONV_PATCH_MINPIX"); min_pix = e ? atoi(e) : 24576; }
         if (max_cover < 0) { const char* e = getenv("MH_CONV_PATCH_COVER"); max_cover = e ? atoi(e) : 125; }
         if (cover * 100 > (int64_t)a.Ho * a.Wo * max_cover) return false;      // default: < 80 % useful tile pixels -> the gather kernel wins
-        if ((int64_t)a.B * a.Ho * a.Wo < min_pix) return false;                // default: fewer than ~200 128-pixel tiles = not one workgroup per CU
+        // default: fewer than ~200 128-pixel tiles = not one workgroup per CU.  Split-bf16 competes with the exact-fp32 gather
+        // kernel instead of the bf16 one, which moves the break-even down to the 1/8-resolution level (7680 pixels: 20 us vs
+        // 24-29 us; at 1920 pixels fp32 wins, 14 vs 19.5 us -- profiles/r02_microbench_x3dbg.txt)
+        // (measured in situ: 128-column layers 24-28 -> 19-20 us, the 64-column one 17.6 -> 20.8 us: wide layers only)
+        if ((int64_t)a.B * a.Ho * a.Wo < ((a.x3 && a.N > 64) ? min_pix * 5 / 16 : min_pix)) return false;
     }
     return (int64_t)a.B * d * d * mh_cdiv(mh_cdiv(a.Ho, d), TH) * mh_cdiv(mh_cdiv(a.Wo, d), 16) < (1 << 30);
 }

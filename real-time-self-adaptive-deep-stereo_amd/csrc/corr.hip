@@ -197,6 +197,9 @@ __global__ __launch_bounds__(256) void level_front_kernel(FrontArgs p) {
     int o0[DT], o1[DT];
 #pragma unroll
     for (int j = 0; j < DT; ++j) {
+#if defined(__clang__)
+#pragma clang fp contract(off)          // same un-contracted interpolation arithmetic as resize_fwd_kernel (ops.hip): bit-identical u
+#endif
         const int xs = x + j - p.md;
         const bool in = live && j < p.D && (unsigned)xs < (unsigned)p.W;
         const int xq = in ? xs : 0;

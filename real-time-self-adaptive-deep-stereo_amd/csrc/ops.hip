@@ -102,8 +102,13 @@ __device__ __forceinline__ void interp1(int i, float scale, int n, int& lo, int&
     t = src - (float)lo;
 }
 
+// (no mul+add contraction in the interpolation arithmetic: the resize kernels and the fused level front end of corr.hip then
+//  produce bit-identical values, and the CPU emulator build -- no fma on plain x86-64 -- matches the GPU)
 __device__ __forceinline__ float bilerp(const float* img, int Wi, int y0, int y1, float ty, int x0, int x1, float tx,
                                         float mul, bool relu_in) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
     float tl = img[(int64_t)y0 * Wi + x0], tr = img[(int64_t)y0 * Wi + x1];
     float bl = img[(int64_t)y1 * Wi + x0], br = img[(int64_t)y1 * Wi + x1];
     if (relu_in) {

@@ -266,11 +266,16 @@ class MadNetEngine(object):
                 ops.corr_fwd(lib, Lk, Rk, dsi, self.md, self.cstride, coff=c, u=(None if k == 6 else self.u[k]),
                              copy_left=True, zero_tail=True)
             x = ops.View(self.dsi[k], B, h, w, c + self.D + (0 if k == 6 else 1), ld)
+            # 'mixed': the estimators of the three coarsest levels run plain bf16 in the forward pass too -- measured
+            # contribution to the final disparity 8e-6 / 1e-5 / 1.3e-4 px (profiles/r02_precision_map.txt: rounding ONE group's
+            # operands to bf16, everything else fp32), against 2.7e-3 px for level 3 and 7e-2 px for level 2, which keep
+            # split-bf16 / exact fp32 like the pyramid and the context network
+            fprec = 1 if (self.precision == "mixed" and k >= 4) else None
             for j, co in enumerate(EST):
                 last = j == len(EST) - 1
                 o = self._fv(self.V[k]) if last else self._fv(self.E[k][j])
                 ops.conv2d_fwd(lib, x, self.W_(est_name(k, j + 1)), self.b_(est_name(k, j + 1)), o,
-                               alpha=(1.0 if last else ALPHA))
+                               alpha=(1.0 if last else ALPHA), precision=fprec)
                 x = o
             if k != 2:
                 sc = 2 ** (k - 1)

@@ -110,14 +110,14 @@ def conv_geometry(H, W, kh, kw, stride, dil):
 
 
 def conv2d_fwd(lib, x, w, b, out, stride=1, dil=1, alpha=1.0, accumulate=False, mask_ref=None, mask_alpha=1.0,
-               mask_range=(0, 0), stream=None):
+               mask_range=(0, 0), stream=None, precision=None):
     """out (+)= leaky(conv2d_SAME(x, w) + b) [* leaky'(mask_ref)].  x,out: View; w: HWIO [kh,kw,Cin,Cout]."""
     kh, kw, cin, cout = w.shape
     Ho, Wo, pt, pl = conv_geometry(x.H, x.W, kh, kw, stride, dil)
     assert (out.H, out.W, out.C) == (Ho, Wo, cout) and x.C == cin
     d = conv_desc(x.B, x.H, x.W, Ho, Wo, cin, cout, kh, kw, stride, dil, pt, pl, 0, 0, x.ld, out.ld, alpha=alpha,
                   mask_ld=(mask_ref.ld if mask_ref is not None else 0), accumulate=int(accumulate), mask_alpha=mask_alpha,
-                  mask_c0=mask_range[0], mask_c1=mask_range[1])
+                  mask_c0=mask_range[0], mask_c1=mask_range[1], precision=precision)
     lib.conv2d(C.byref(d), _p(x), _p(w), _p(b), _p(out), _p(mask_ref), _p(stream))
 
 

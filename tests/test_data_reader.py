@@ -153,3 +153,33 @@ def test_augment_semantics():
     a, _ = data_reader.augment(img, img, Fixed([[0.9, 0.9, 0.9, 0.1], 0.0, 1.0, 0.9]))
     assert np.allclose(a.max(-1), img.max(-1), atol=1e-2) and not np.allclose(a, img, atol=1.0)
 
+
+
+def test_dataset_rank_sharding_and_uint8(tmp_path):
+    """shard=(rank, world): every sample is read by exactly one rank per epoch (Train.py data-parallel mode); keep_uint8: 8-bit
+    frames stay uint8 with identical values (the float cast moves to the GPU, device_prefetcher)."""
+    from PIL import Image
+    from Data_utils import data_reader as DR
+    rows = []
+    for t in range(5):
+        names = [str(tmp_path / ("%s_%d.png" % (k, t))) for k in ("l", "r", "d")]
+        rng = np.random.default_rng(t)
+        Image.fromarray(rng.integers(0, 256, (20, 30, 3), dtype=np.uint8)).save(names[0])
+        Image.fromarray(rng.integers(0, 256, (20, 30, 3), dtype=np.uint8)).save(names[1])
+        Image.fromarray(rng.integers(0, 65535, (20, 30), dtype=np.uint16)).save(names[2])
+        rows.append(",".join(names))
+    lst = tmp_path / "list.csv"
+    lst.write_text("\n".join(rows) + "\n")
+    full = [b for b in DR.dataset(str(lst), batch_size=1, crop_shape=(16, 24), num_epochs=1)]
+    parts = [[b for b in DR.dataset(str(lst), batch_size=1, crop_shape=(16, 24), num_epochs=1, shard=(r, 2))] for r in range(2)]
+    assert len(full) == 5 and len(parts[0]) == 3 and len(parts[1]) == 2
+    assert DR.dataset(str(lst), batch_size=1, crop_shape=(16, 24), num_epochs=2, shard=(1, 2)).get_max_steps() == 4
+    for i, b in enumerate(full):
+        assert np.array_equal(b[0], parts[i % 2][i // 2][0])
+    u8 = [b for b in DR.dataset(str(lst), batch_size=1, crop_shape=(16, 24), num_epochs=1, keep_uint8=True)]
+    assert u8[0][0].dtype == np.uint8 and u8[0][1].dtype == np.uint8 and u8[0][2].dtype == np.float32
+    assert np.array_equal(u8[2][0].astype(np.float32), full[2][0]) and np.array_equal(u8[2][2], full[2][2])
+    # prefetcher on the CPU path keeps uint8 slots and (with a library) casts them; without one it only stages
+    got = list(DR.device_prefetcher(DR.dataset(str(lst), batch_size=1, crop_shape=(16, 24), num_epochs=1), device="cpu"))
+    import torch
+    assert len(got) == 5 and got[0][0].dtype == torch.float32

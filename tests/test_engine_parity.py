@@ -162,10 +162,12 @@ def test_two_host_threads_one_device(hip):
         torch.cuda.synchronize()
         out[key] = (ad.eng.params.w.clone(), o["loss"])
 
-    serial, conc = {}, {}
+    serial, serial2, conc = {}, {}, {}
     for i in range(2):
         ad, data = make(i)
         run(ad, data, 6, serial, i)
+        ad, data = make(i)
+        run(ad, data, 6, serial2, i)               # the run-to-run noise of the fp32 atomics (warp / bias gradients) after 6 steps
     ads = [make(i) for i in range(2)]
     for ad, _ in ads:
         ad._plan("FULL")                           # capture both graphs before the threads start
@@ -173,8 +175,14 @@ def test_two_host_threads_one_device(hip):
     for t in th: t.start()
     for t in th: t.join()
     for i in range(2):
-        assert abs(serial[i][1] - conc[i][1]) <= 1e-6 * max(1.0, abs(serial[i][1])), i
-        assert (serial[i][0] - conc[i][0]).abs().max().item() <= 2e-6, i     # same kernels, same order: fp32-sum-order noise of the atomics only
+        noise_w = (serial[i][0] - serial2[i][0]).abs().max().item()
+        noise_l = abs(serial[i][1] - serial2[i][1])
+        dw = (serial[i][0] - conc[i][0]).abs().max().item()
+        dl = abs(serial[i][1] - conc[i][1])
+        print("thread %d: |dw| concurrent-vs-serial %.3g (serial-vs-serial %.3g), |dloss| %.3g (%.3g)" % (i, dw, noise_w, dl, noise_l))
+        # same kernels, same order: only the summation order of the fp32 atomics differs, exactly as between two serial runs
+        assert dl <= 5 * noise_l + 1e-6 * max(1.0, abs(serial[i][1])), (i, dl, noise_l)
+        assert dw <= 5 * noise_w + 2e-6, (i, dw, noise_w)
 
 
 @pytest.mark.gpu

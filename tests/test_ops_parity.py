@@ -378,12 +378,14 @@ def test_level_front_fused_matches_resize_warp_corr(backend, case):
     out1 = torch.full((B, H, W, ld), float("nan"), device=dev)
     ops.level_front_fwd(backend.lib, Vc, mul, ops.view(L), ops.view(R), ops.View(out1, B, H, W, ld, ld), ops.view(Rw1), u1, md, coff=C)
     backend.sync()
-    # (the two code paths may contract mul+add into fma differently on the GPU: compare to a few ulps, not bitwise)
-    assert (u1.cpu() - u0.cpu()).abs().max().item() <= 1e-5
-    assert (Rw1.cpu() - Rw0.cpu()).abs().max().item() <= 1e-5
+    # u: both kernels run the interpolation un-contracted -> a few ulps at most; the warped features then differ by
+    # |du| * |dR/dx| (the warp is continuous in u, slope |R[x0+1] - R[x0]| ~ 3 here) plus fma-contraction noise
+    du = (u1.cpu() - u0.cpu()).abs().max().item()
+    assert du <= 1e-5
+    assert (Rw1.cpu() - Rw0.cpu()).abs().max().item() <= 1e-5 + 8.0 * du
     assert torch.equal(out1[..., :C].cpu(), L.cpu()) and torch.equal(out1[..., C + D].cpu(), u1.cpu())
     assert torch.all(out1[..., C + D + 1:].cpu() == 0)
-    assert (out1[..., C:C + D].cpu() - out0[..., C:C + D].cpu()).abs().max().item() <= 1e-5
+    assert (out1[..., C:C + D].cpu() - out0[..., C:C + D].cpu()).abs().max().item() <= 1e-5 + 8.0 * du
     # oracle
     uo = T.resize_bilinear(Vc.cpu()[..., None], H, W) * mul
     ref = T.correlation(L.cpu(), T.linear_warp(R.cpu(), uo), md, 1)
