@@ -30,11 +30,11 @@ def _time_ms(lib, stream, fn, reps):
 
 
 def _pmc_traffic(key):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_roofline.json,
-    produced by scripts/gpu_pmc.sh); None if the file is absent."""
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r02_pmc_roofline.json, produced by
+    scripts/gpu_pmc_r02.sh + scripts/pmc_summarize_r02.py); None if the file or the key is absent."""
     import json
     import os
-    f = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles", "r01_pmc_roofline.json")
+    f = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles", "r02_pmc_roofline.json")
     try:
         return json.load(open(f))[key]["traffic_bytes"]
     except Exception:
@@ -64,7 +64,7 @@ def roofline(lib, eng, stream, reps=20):
         tr = _pmc_traffic(pmc_key)
         return {"kernel": kname, "op": what, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                 "arithmetic": {0: "f32 MFMA", 1: "bf16 MFMA, f32 accumulate", 2: "split-bf16: 3 bf16 MFMAs per product (mfma issue rate = 3x achieved), f32 accumulate"}[code],
-                "traffic": tr, "traffic_source": ("profiles/r01_pmc_roofline.json (static: rocprofv3 --pmc passes of round 1, key %s)" % pmc_key) if tr is not None else None,
+                "traffic": tr, "traffic_source": ("profiles/r02_pmc_roofline.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_pmc_r02.sh, key %s; not re-measured in this run)" % pmc_key) if tr is not None else None,
                 "launch_ms": ms, "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": algo_bytes}
 
     def conv_fwd(code):
@@ -77,7 +77,7 @@ def roofline(lib, eng, stream, reps=20):
         return fn
 
     rl = entry(fwd_code, conv_fwd(fwd_code), "forward 3x3 128->128 @ %dx%d dil 2 (context-2)" % (x.H, x.W),
-               "conv_3x3_128_128_96x320_bf16" if fwd_code == 1 else ("conv_3x3_128_128_96x320" if fwd_code == 0 else "none"))
+               {0: "none", 1: "conv_fwd_bf16_patch_3x3_128_128_96x320", 2: "conv_fwd_x3_patch_3x3_128_128_96x320"}[fwd_code])
     extra = {}
     # the same layer's input gradient and filter gradient in the BACKWARD arithmetic: by time the filter gradients are the
     # largest kernel family of the step (22 launches x 17 us)
@@ -90,7 +90,7 @@ def roofline(lib, eng, stream, reps=20):
                 ops.conv2d_dgrad(lib, dz, w, dx, dil=2, mask_ref=x, mask_alpha=E.ALPHA, stream=sh)
             finally:
                 ops.PRECISION = 0
-        extra["roofline_dgrad"] = entry(bwd_code, dgrad, "input gradient of the same layer", "none")
+        extra["roofline_dgrad"] = entry(bwd_code, dgrad, "input gradient of the same layer", "conv_dgrad_bf16_patch_3x3_128_128_96x320" if bwd_code == 1 else "none")
         dw = torch.empty_like(w); db = torch.zeros(128, device=eng.dev)
         wsa = ops.WgradWorkspace(eng.dev)
         segs, keep = [], []
@@ -107,7 +107,8 @@ def roofline(lib, eng, stream, reps=20):
                 ops.conv2d_wgrad_partial(lib, lib, wsa, s2, x, dz, dw, db, dil=2, stream=sh)
             finally:
                 ops.PRECISION = 0
-        extra["roofline_wgrad"] = entry(bwd_code, wgrad, "filter gradient of the same layer (partial sums only; the split reduction is one launch per batch of layers)", "none")
+        extra["roofline_wgrad"] = entry(bwd_code, wgrad, "filter gradient of the same layer (partial sums only; the split reduction is one launch per batch of layers)",
+                                        "wgrad_bf16_partial_3x3_128_128_96x320" if bwd_code == 1 else "none")
         extra["roofline_wgrad"]["splits"] = segs[0][3] if segs else 1
         extra["roofline_wgrad"]["workspace_bytes_per_launch"] = 4.0 * (segs[0][2] * segs[0][3] if segs else 0)
     except Exception as ex:
@@ -125,7 +126,7 @@ def roofline(lib, eng, stream, reps=20):
         g = byts / (ms_c * 1e-3) / 1e9
         extra["roofline_corr"] = {"kernel": lib.last_kernel().decode() + " (B=64 x %dx%dx%d, D=%d)" % (H, W, Cc, D), "bound": "hbm",
                                   "achieved": g, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": g / PEAK_HBM_GBS,
-                                  "traffic": _pmc_traffic("corr_fwd_B64_96x320x32_D5"), "traffic_source": "profiles/r01_pmc_roofline.json (static: rocprofv3 --pmc passes of round 1)", "launch_ms": ms_c, "algorithmic_bytes_per_launch": byts}
+                                  "traffic": _pmc_traffic("corr_fwd_B64_96x320x32_D5"), "traffic_source": "profiles/r02_pmc_roofline.json (static: rocprofv3 --pmc passes of scripts/gpu_pmc_r02.sh; not re-measured in this run)", "launch_ms": ms_c, "algorithmic_bytes_per_launch": byts}
         L1, R1 = L[:1].contiguous(), R[:1].contiguous(); o1 = out[:1].contiguous()
         ms_1 = _time_ms(lib, stream, lambda: ops.corr_fwd(lib, ops.view(L1), ops.view(R1), ops.view(o1), md, stream=sh), 20)
         extra["roofline_corr"]["in_situ_B1_ms"] = ms_1
