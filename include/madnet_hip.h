@@ -154,8 +154,8 @@ int mh_shift_corr_grad(const float* in0, const float* in1, const float* grad, in
 /* ---- MadNet._build_indeces + _linear_warping (Nets/MadNet.py:378-436) ---------------- */
 int mh_warp_fwd(const float* img, int32_t img_ld, const float* u, float* out, int32_t out_ld,
                 int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
-/* dimg += scatter (fp32 atomics; zero/initialise it first); du (+)= coordinate gradient
- * (NULL when the coordinates are stop_gradient-ed, i.e. bulkhead / MAD). */
+/* dimg += scatter (fp32 atomics; zero/initialise it first; NULL = coordinate gradient only); du (+)= coordinate gradient
+ * (NULL when the coordinates are stop_gradient-ed, i.e. bulkhead / MAD, or when only the scatter is wanted). */
 int mh_warp_bwd(const float* g, int32_t g_ld, const float* img, int32_t img_ld, const float* u,
                 float* dimg, int32_t dimg_ld, float* du, int32_t acc_u,
                 int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
@@ -212,6 +212,10 @@ int mh_reprojection_loss(const float* left, const float* right, const float* dis
 
 /* ---- validation ops (Stereo_Online_Adaptation.py:74-82): result[0]=EPE, result[1]=bad3,
  *      result[2]=#valid.  ws: >= mh_metrics_ws_floats() floats. ---------------------------- */
+/* the same in two phases, so that the reduction of the loss VALUE (which no gradient needs) can leave the critical path of a step:
+ * phase 1 = warp + SSIM maps + gradient (partial sums stay in ws), phase 2 = the final reduction into result; 0 = both. */
+int mh_reprojection_loss_phase(const float* left, const float* right, const float* disp, float* ws, float* result, float* ddisp,
+                               float grad_scale, int32_t B, int32_t H, int32_t W, int32_t phase, void* stream);
 int64_t mh_metrics_ws_floats(int32_t B, int32_t H, int32_t W);
 int mh_metrics(const float* disp, const float* gt, float* ws, float* result, float pixel_th,
                int32_t B, int32_t H, int32_t W, void* stream);
@@ -278,6 +282,9 @@ enum { MH_OP_CONV = 1, MH_OP_WGRAD, MH_OP_CORR_FWD, MH_OP_CORR_BWD, MH_OP_WARP_F
  * of the captured hipGraph. */
 #define MH_MAX_LANES 5
 #define MH_OP_JOIN 0x100
+/* bits 16..23 of the scheduling word: lane 0 first waits for exactly the side lanes in this mask (bit l = lane l), leaving the others
+ * running -- e.g. the scatter half of a warp gradient joined right before the pyramid backward while the filter gradients go on */
+#define MH_OP_JOIN_LANES(mask) (((mask) & 0xff) << 16)
 typedef struct mh_op {
     int32_t kind;
     int32_t i[27];

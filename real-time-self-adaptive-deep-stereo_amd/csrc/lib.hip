@@ -150,8 +150,8 @@ static int run_op(const mh_op& o, void* s) {
         case MH_OP_PAD_REFLECT:
             return mh_pad_reflect((const float*)p[0], (float*)p[1], i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7], i[8], o.f[0], o.f[1], s);
         case MH_OP_LOSS:
-            return mh_reprojection_loss((const float*)p[0], (const float*)p[1], (const float*)p[2], (float*)p[3], (float*)p[4],
-                                        (float*)p[5], o.f[0], i[0], i[1], i[2], s);
+            return mh_reprojection_loss_phase((const float*)p[0], (const float*)p[1], (const float*)p[2], (float*)p[3], (float*)p[4],
+                                              (float*)p[5], o.f[0], i[0], i[1], i[2], i[3], s);
         case MH_OP_METRICS:
             return mh_metrics((const float*)p[0], (const float*)p[1], (float*)p[2], (float*)p[3], o.f[0], i[0], i[1], i[2], s);
         case MH_OP_MOMENTUM:
@@ -238,6 +238,10 @@ extern "C" int mh_plan_run(const mh_op* ops, int32_t nops, void* stream) {
         int e = 0;
         if (lane >= MH_MAX_LANES) { mh_set_error("lane %d out of range", lane); e = MH_ERR_ARG; }
         if (!e && (sched & MH_OP_JOIN)) e = join();
+        if (!e && ((sched >> 16) & 0xff)) {                   // join exactly these side lanes
+            for (int l = 1; l < MH_MAX_LANES && !e; ++l)
+                if (((sched >> 16) >> l) & 1) { if (dirty[l]) { e = lane_edge(*L, L->aux[l], main_s); dirty[l] = false; } }
+        }
         if (!e && lane > 0) {
             if (!L) e = lanes_get(&L);
             if (!e && stale[lane]) { e = lane_edge(*L, main_s, L->aux[lane]); stale[lane] = false; }

@@ -67,10 +67,12 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs p) {
         for (int c4 = sub; c4 < C4; c4 += LPP) {
             if (!live) continue;
             const float4 gv = *reinterpret_cast<const float4*>(p.g + pp * p.g_ld + c4 * 4);
-            float* d0 = p.dimg + (rowbase + i0) * p.dimg_ld + c4 * 4;
-            float* d1 = p.dimg + (rowbase + i1) * p.dimg_ld + c4 * 4;
-            if (w0 != 0.f) { atomicAdd(d0 + 0, w0 * gv.x); atomicAdd(d0 + 1, w0 * gv.y); atomicAdd(d0 + 2, w0 * gv.z); atomicAdd(d0 + 3, w0 * gv.w); }
-            if (w1 != 0.f) { atomicAdd(d1 + 0, w1 * gv.x); atomicAdd(d1 + 1, w1 * gv.y); atomicAdd(d1 + 2, w1 * gv.z); atomicAdd(d1 + 3, w1 * gv.w); }
+            if (p.dimg) {
+                float* d0 = p.dimg + (rowbase + i0) * p.dimg_ld + c4 * 4;
+                float* d1 = p.dimg + (rowbase + i1) * p.dimg_ld + c4 * 4;
+                if (w0 != 0.f) { atomicAdd(d0 + 0, w0 * gv.x); atomicAdd(d0 + 1, w0 * gv.y); atomicAdd(d0 + 2, w0 * gv.z); atomicAdd(d0 + 3, w0 * gv.w); }
+                if (w1 != 0.f) { atomicAdd(d1 + 0, w1 * gv.x); atomicAdd(d1 + 1, w1 * gv.y); atomicAdd(d1 + 2, w1 * gv.z); atomicAdd(d1 + 3, w1 * gv.w); }
+            }
             if (p.du) {
                 const float4 a = *reinterpret_cast<const float4*>(p.img + (rowbase + i0) * p.img_ld + c4 * 4);
                 const float4 b = *reinterpret_cast<const float4*>(p.img + (rowbase + i1) * p.img_ld + c4 * 4);
@@ -140,10 +142,19 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(ResizeArgs p) {
 
 // gather form of ResizeBilinearGrad: one lane per INPUT pixel, loops the output pixels whose
 // lower/upper source index hits it (exactly the forward's float index arithmetic).
+// LPP lanes share one input pixel and split the candidate output ROWS (an up-scaling by 4 gives an input pixel ~8 x 8 candidate
+// output pixels, each needing the forward's bilinear taps again for the relu mask of mode 2: serial per lane that was 21 us for the
+// 96x320 -> 375x1242 head at the start of the backward pass); partial sums meet in a shuffle butterfly.
+template <int LPP>
 __global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeArgs p) {
     const int64_t total = (int64_t)p.B * p.Hi * p.Wi;
     const float isy = 1.0f / p.sy, isx = 1.0f / p.sx;
-    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+    const int sub = LPP > 1 ? (int)(threadIdx.x % LPP) : 0;
+    const int64_t nit = (total * LPP + 255) / 256;              // every lane of a wave runs the same trip count (shuffles below)
+    for (int64_t it = blockIdx.x; it < nit; it += gridDim.x) {
+        const int64_t q0 = (it * 256 + threadIdx.x) / LPP;
+        const bool live = q0 < total;
+        const int64_t q = live ? q0 : 0;
         const int sx = (int)(q % p.Wi);
         const int64_t t2 = q / p.Wi;
         const int sy = (int)(t2 % p.Hi);
@@ -155,7 +166,7 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeArgs p) {
         const int xa = max(p.cx, (int)floorf((float)(sx - 1) * isx) - 1);
         const int xb = min(p.cx + p.Wo - 1, (int)ceilf((float)(sx + 1) * isx) + 1);
         float acc = 0.f;
-        for (int Y = ya; Y <= yb; ++Y) {
+        for (int Y = ya + sub; Y <= yb && live; Y += LPP) {
             int y0, y1; float ty;
             interp1(Y, p.sy, p.Hi, y0, y1, ty);
             const float wy = (y0 == sy ? 1.0f - ty : 0.f) + (y1 == sy ? ty : 0.f);
@@ -173,9 +184,13 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeArgs p) {
                 acc += gv * wy * wx;
             }
         }
-        acc *= p.mul;
-        if (p.mode == 1 && !(img[(int64_t)sy * p.Wi + sx] * p.mul > 0.f)) acc = 0.f;
-        p.din[q] = p.accumulate ? p.din[q] + acc : acc;
+#pragma unroll
+        for (int o = LPP >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (live && sub == 0) {
+            acc *= p.mul;
+            if (p.mode == 1 && !(img[(int64_t)sy * p.Wi + sx] * p.mul > 0.f)) acc = 0.f;
+            p.din[q] = p.accumulate ? p.din[q] + acc : acc;
+        }
     }
 }
 
@@ -674,7 +689,7 @@ extern "C" int mh_warp_fwd(const float* img, int32_t img_ld, const float* u, flo
 extern "C" int mh_warp_bwd(const float* g, int32_t g_ld, const float* img, int32_t img_ld, const float* u,
                            float* dimg, int32_t dimg_ld, float* du, int32_t acc_u,
                            int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
-    MH_REQUIRE(g && img && u && dimg, MH_ERR_ARG, "mh_warp_bwd: null argument");
+    MH_REQUIRE(g && img && u && (dimg || du), MH_ERR_ARG, "mh_warp_bwd: null argument");
     MH_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, MH_ERR_ARG, "mh_warp_bwd: bad dimension");
     MH_REQUIRE(C % 4 == 0 && img_ld % 4 == 0 && g_ld % 4 == 0 && mh_aligned16(img) && mh_aligned16(g), MH_ERR_ALIGN,
                "mh_warp_bwd: C and lds must be multiples of 4, pointers 16-byte aligned");
@@ -768,7 +783,9 @@ extern "C" int mh_resize_bwd(const float* g, const float* in, float* din, int32_
     MH_REQUIRE(g && in && din, MH_ERR_ARG, "mh_resize_bwd: null argument");
     ResizeArgs a{}; a.in = in; a.g = g; a.din = din; a.accumulate = accumulate;
     if (int e = resize_args(a, B, Hi, Wi, Hr, Wr, cy, cx, Ho, Wo, mul, mode)) return e;
-    hipLaunchKernelGGL(resize_bwd_kernel, dim3(grid_for((int64_t)B * Hi * Wi)), dim3(256), 0, (hipStream_t)stream, a);
+    // rows of candidates per input pixel ~ 2 / sy: split them over 4 lanes from an up-scaling of 3 on
+    if (a.sy <= 1.0f / 3.0f) hipLaunchKernelGGL((resize_bwd_kernel<4>), dim3(grid_for((int64_t)B * Hi * Wi * 4)), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((resize_bwd_kernel<1>), dim3(grid_for((int64_t)B * Hi * Wi)), dim3(256), 0, (hipStream_t)stream, a);
     return mh_check_launch("resize_bwd");
 }
 
@@ -794,6 +811,12 @@ extern "C" int64_t mh_loss_ws_floats(int32_t B, int32_t H, int32_t W) {
 
 extern "C" int mh_reprojection_loss(const float* left, const float* right, const float* disp, float* ws, float* result,
                                     float* ddisp, float grad_scale, int32_t B, int32_t H, int32_t W, void* stream) {
+    return mh_reprojection_loss_phase(left, right, disp, ws, result, ddisp, grad_scale, B, H, W, 0, stream);
+}
+
+extern "C" int mh_reprojection_loss_phase(const float* left, const float* right, const float* disp, float* ws, float* result,
+                                          float* ddisp, float grad_scale, int32_t B, int32_t H, int32_t W, int32_t phase, void* stream) {
+    MH_REQUIRE(phase >= 0 && phase <= 2, MH_ERR_ARG, "mh_reprojection_loss_phase: phase must be 0 (all), 1 (maps + gradient) or 2 (final reduction)");
     MH_REQUIRE(left && right && disp && ws && result, MH_ERR_ARG, "mh_reprojection_loss: null argument");
     MH_REQUIRE(B > 0 && H >= 3 && W >= 3, MH_ERR_ARG, "mh_reprojection_loss: image must be at least 3x3");
     MH_REQUIRE(mh_aligned16(ws), MH_ERR_ALIGN, "mh_reprojection_loss: workspace must be 16-byte aligned");
@@ -806,10 +829,12 @@ extern "C" int mh_reprojection_loss(const float* left, const float* right, const
     a.part1 = ws + 8 * n + 12 * nw; a.nblk1 = (int)nblk(n);
     a.part2 = a.part1 + a.nblk1; a.nblk2 = (int)nblk(nw);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(loss_warp_kernel, dim3(a.nblk1), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(loss_ssim_kernel, dim3(a.nblk2), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, a);
-    if (ddisp) hipLaunchKernelGGL(loss_grad_kernel, dim3(grid_for(n)), dim3(256), 0, s, a);
+    if (phase != 2) {
+        hipLaunchKernelGGL(loss_warp_kernel, dim3(a.nblk1), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(loss_ssim_kernel, dim3(a.nblk2), dim3(256), 0, s, a);
+        if (ddisp) hipLaunchKernelGGL(loss_grad_kernel, dim3(grid_for(n)), dim3(256), 0, s, a);     // (does not need the reduced loss value)
+    }
+    if (phase != 1) hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, a);
     return mh_check_launch("reprojection_loss");
 }
 

@@ -86,6 +86,7 @@ SIGNATURES = {
     "mh_pad_reflect": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
     "mh_loss_ws_floats": (_L, [_I, _I, _I]),
     "mh_reprojection_loss": (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _P]),
+    "mh_reprojection_loss_phase": (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P]),
     "mh_metrics_ws_floats": (_L, [_I, _I, _I]),
     "mh_metrics": (_I, [_P, _P, _P, _P, _F, _I, _I, _I, _P]),
     "mh_momentum": (_I, [_P, _P, _P, _L, _F, _F, _F, _P]),

@@ -28,6 +28,7 @@ CTX = [(128, 1), (128, 2), (128, 4), (96, 8), (64, 16), (32, 1), (1, 1)]
 LEVELS = (6, 5, 4, 3, 2)
 FEAT = {6: 12, 5: 10, 4: 8, 3: 6, 2: 4}
 ALPHA = 0.2   # MadNet._leaky_relu (Nets/MadNet.py:366-367)
+SCATTER_LANE = 3   # side lane of the warp-gradient scatters (lanes 1..2: filter gradients; include/madnet_hip.h MH_MAX_LANES)
 
 
 def _r4(c):
@@ -320,12 +321,27 @@ class MadNetEngine(object):
     def record_loss_metrics(self, r, with_grad):
         """full-resolution reprojection loss (Stereo_Online_Adaptation.py:70) -- or, loss_kind 'proxy', the proxy-label
         mean_l1 of the continual variant (Stereo_Continual_Adaptation.py:75, weight 0.01) -- + EPE/bad3 (:74-82)."""
+        side = self.wgrad_lanes > 0 and hasattr(r, "lane")
         if self.loss_kind == "proxy":
             ops.proxy_loss(r, self.pred, self.proxy, self.proxy_ws, self.res_loss, self.dpred if with_grad else None, weight=0.01)
+        elif side:
+            # only the maps + the gradient are on the critical path; the reduction of the loss VALUE and the validation metrics
+            # (read by the host after the step) run on a side lane next to the backward pass
+            ops.reprojection_loss(r, self.left, self.right, self.pred, self.loss_ws, self.res_loss,
+                                  self.dpred if with_grad else None, phase=1)
         else:
             ops.reprojection_loss(r, self.left, self.right, self.pred, self.loss_ws, self.res_loss,
                                   self.dpred if with_grad else None)
-        ops.metrics(r, self.pred, self.gt, self.met_ws, self.res_met, 3.0)
+        if side:
+            r.lane = 1
+            try:
+                if self.loss_kind != "proxy":
+                    ops.reprojection_loss(r, self.left, self.right, self.pred, self.loss_ws, self.res_loss, None, phase=2)
+                ops.metrics(r, self.pred, self.gt, self.met_ws, self.res_met, 3.0)
+            finally:
+                r.lane = 0
+        else:
+            ops.metrics(r, self.pred, self.gt, self.met_ws, self.res_met, 3.0)
 
     # =========================================================================================
     # backward
@@ -365,6 +381,7 @@ class MadNetEngine(object):
         segs = []                           # partial filter-gradient segments of this backward pass
 
         pending = []                        # deferred filter-gradient launches (flushed as one side-lane batch)
+        scatter_pending = [False]           # warp-gradient scatters issued on SCATTER_LANE and not joined yet
 
         def wgrad(xv, dzv, base, stride=1, dil=1):
             dw, db = P.tensor(base + "/weights", "g"), P.tensor(base + "/biases", "g")
@@ -490,16 +507,33 @@ class MadNetEngine(object):
                              acc_l=acc_flag(("F", f, 0)), acc_r=False, acc_u=False, copy_left=True)
                 # warp gradient: scatter into the right tower's feature gradient (atomics -> zero first)
                 dFr = self._half(self.dF[f], True)
-                if not acc_flag(("F", f, 1)):
-                    ops_fill(lib, self.dF[f][B:], 0, self.dF[f][B:].numel())
-                ops.warp_bwd(lib, self._fv(self.dRw[k]), self._half(self.F[f], True), self.u[k], dFr,
-                             du=du, acc_u=True)
+                fresh = not acc_flag(("F", f, 1))
+                if self.wgrad_lanes > 0 and hasattr(lib, "lane"):
+                    # the coordinate gradient feeds the next level (critical path); the scatter only feeds the pyramid backward at
+                    # the very end: it runs (with its zero fill) on side lane 3, joined right before the pyramid section
+                    if du is not None:
+                        ops.warp_bwd(lib, self._fv(self.dRw[k]), self._half(self.F[f], True), self.u[k], None, du=du, acc_u=True)
+                    lib.lane = SCATTER_LANE
+                    try:
+                        if fresh:
+                            ops_fill(lib, self.dF[f][B:], 0, self.dF[f][B:].numel())
+                        ops.warp_bwd(lib, self._fv(self.dRw[k]), self._half(self.F[f], True), self.u[k], dFr, du=None)
+                    finally:
+                        lib.lane = 0
+                    scatter_pending[0] = True
+                else:
+                    if fresh:
+                        ops_fill(lib, self.dF[f][B:], 0, self.dF[f][B:].numel())
+                    ops.warp_bwd(lib, self._fv(self.dRw[k]), self._half(self.F[f], True), self.u[k], dFr,
+                                 du=du, acc_u=True)
                 if need_u:
                     # u_k = resize(V_{k+1}) * 20/2^k   (MadNet.py:274: u_{k} built at level k+1 with scales[k])
                     s_up = 2 ** k
                     ops.resize_bwd(lib, self.du[k], self.V[k + 1], self.dV[k + 1], self.Hp // s_up, self.Wp // s_up,
                                    mul=20.0 / s_up, mode=0, accumulate=acc_flag(("V", k + 1)))
         # ---- pyramid towers (batch 2B, shared weights) ---------------------------------------------
+        if scatter_pending[0]:
+            r.join_lanes_next = 1 << SCATTER_LANE          # the right-tower scatters must have landed; the filter-gradient lanes keep going
         top = None
         for i in range(12, 0, -1):
             if ("F", i, 0) in written or ("F", i, 1) in written or ("Fd", i) in written:

@@ -256,7 +256,8 @@ def warp_fwd(lib, img, u, out, stream=None):
 
 
 def warp_bwd(lib, g, img, u, dimg, du=None, acc_u=False, stream=None):
-    lib.warp_bwd(_p(g), g.ld, _p(img), img.ld, _p(u), _p(dimg), dimg.ld, _p(du), int(acc_u),
+    """dimg None: coordinate gradient only; du None: scatter only."""
+    lib.warp_bwd(_p(g), g.ld, _p(img), img.ld, _p(u), _p(dimg), dimg.ld if dimg is not None else img.ld, _p(du), int(acc_u),
                  img.B, img.H, img.W, img.C, _p(stream))
 
 
@@ -290,9 +291,13 @@ def bias_grad(lib, dz, db, stream=None):
     lib.bias_grad(_p(dz), dz.ld, dz.npix, dz.C, _p(db), _p(stream))
 
 
-def reprojection_loss(lib, left, right, disp, ws, result, ddisp=None, grad_scale=1.0, stream=None):
+def reprojection_loss(lib, left, right, disp, ws, result, ddisp=None, grad_scale=1.0, stream=None, phase=0):
+    """phase 0 = everything; 1 = warp + SSIM maps + gradient (what the backward pass waits for); 2 = the reduction of the loss value."""
     B, H, W = disp.shape[0], disp.shape[1], disp.shape[2]
-    lib.reprojection_loss(_p(left), _p(right), _p(disp), _p(ws), _p(result), _p(ddisp), grad_scale, B, H, W, _p(stream))
+    if phase == 0:
+        lib.reprojection_loss(_p(left), _p(right), _p(disp), _p(ws), _p(result), _p(ddisp), grad_scale, B, H, W, _p(stream))
+    else:
+        lib.reprojection_loss_phase(_p(left), _p(right), _p(disp), _p(ws), _p(result), _p(ddisp), grad_scale, B, H, W, phase, _p(stream))
 
 
 def proxy_loss(lib, pred, proxy, ws, result, dpred=None, weight=0.01, grad_scale=1.0, stream=None):

@@ -29,6 +29,7 @@ class Recorder(object):
                       "grad_bytes": 0.0, "conv_launches": 0, "wgrad_launches": 0}
         self.lane = 0           # scheduling lane of the ops recorded next (mh_op.i[26], include/madnet_hip.h)
         self.join_next = False  # next op: lane 0 first waits for the side lanes
+        self.join_lanes_next = 0  # next op: lane 0 first waits for exactly the side lanes of this bit mask (bit l = lane l)
 
     # -- helpers ---------------------------------------------------------------------------
     def _op(self, kind, ints=(), floats=(), ptrs=(), n=0):
@@ -41,8 +42,9 @@ class Recorder(object):
         for k, v in enumerate(ptrs):
             o.p[k] = _ptr(v)
         o.n = int(n)
-        o.i[26] = self.lane | (_ffi.OP_JOIN if self.join_next else 0)
+        o.i[26] = self.lane | (_ffi.OP_JOIN if self.join_next else 0) | ((self.join_lanes_next & 0xff) << 16)
         self.join_next = False
+        self.join_lanes_next = 0
         self.ops.append(o)
 
     @staticmethod
@@ -118,7 +120,10 @@ class Recorder(object):
         self._op(_ffi.OP_PAD_REFLECT, [B, H, W, Cc, Hp, Wp, pt, pl, out_ld], [div, sub], [inp, out])
 
     def reprojection_loss(self, left, right, disp, ws, result, ddisp, grad_scale, B, H, W, stream):
-        self._op(_ffi.OP_LOSS, [B, H, W], [grad_scale], [left, right, disp, ws, result, ddisp])
+        self._op(_ffi.OP_LOSS, [B, H, W, 0], [grad_scale], [left, right, disp, ws, result, ddisp])
+
+    def reprojection_loss_phase(self, left, right, disp, ws, result, ddisp, grad_scale, B, H, W, phase, stream):
+        self._op(_ffi.OP_LOSS, [B, H, W, phase], [grad_scale], [left, right, disp, ws, result, ddisp])
 
     def proxy_loss(self, pred, proxy, ws, result, dpred, weight, grad_scale, B, H, W, stream):
         self._op(_ffi.OP_PROXY_LOSS, [B, H, W], [weight, grad_scale], [pred, proxy, ws, result, dpred])
