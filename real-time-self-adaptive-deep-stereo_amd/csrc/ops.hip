@@ -783,9 +783,14 @@ extern "C" int mh_resize_bwd(const float* g, const float* in, float* din, int32_
     MH_REQUIRE(g && in && din, MH_ERR_ARG, "mh_resize_bwd: null argument");
     ResizeArgs a{}; a.in = in; a.g = g; a.din = din; a.accumulate = accumulate;
     if (int e = resize_args(a, B, Hi, Wi, Hr, Wr, cy, cx, Ho, Wo, mul, mode)) return e;
-    // rows of candidates per input pixel ~ 2 / sy: split them over 4 lanes from an up-scaling of 3 on
-    if (a.sy <= 1.0f / 3.0f) hipLaunchKernelGGL((resize_bwd_kernel<4>), dim3(grid_for((int64_t)B * Hi * Wi * 4)), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((resize_bwd_kernel<1>), dim3(grid_for((int64_t)B * Hi * Wi)), dim3(256), 0, (hipStream_t)stream, a);
+    // rows of candidates per input pixel ~ 2 / sy (8 at an up-scaling of 4, 130 at 64: the full-resolution loss heads of the coarse
+    // MAD blocks): split them over 4 / 16 / 64 lanes
+    const int64_t npx = (int64_t)B * Hi * Wi;
+    hipStream_t s = (hipStream_t)stream;
+    if (a.sy <= 1.0f / 12.0f) hipLaunchKernelGGL((resize_bwd_kernel<64>), dim3(grid_for(npx * 64)), dim3(256), 0, s, a);
+    else if (a.sy <= 1.0f / 6.0f) hipLaunchKernelGGL((resize_bwd_kernel<16>), dim3(grid_for(npx * 16)), dim3(256), 0, s, a);
+    else if (a.sy <= 1.0f / 3.0f) hipLaunchKernelGGL((resize_bwd_kernel<4>), dim3(grid_for(npx * 4)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((resize_bwd_kernel<1>), dim3(grid_for(npx)), dim3(256), 0, s, a);
     return mh_check_launch("resize_bwd");
 }
 

@@ -28,7 +28,13 @@ CTX = [(128, 1), (128, 2), (128, 4), (96, 8), (64, 16), (32, 1), (1, 1)]
 LEVELS = (6, 5, 4, 3, 2)
 FEAT = {6: 12, 5: 10, 4: 8, 3: 6, 2: 4}
 ALPHA = 0.2   # MadNet._leaky_relu (Nets/MadNet.py:366-367)
-SCATTER_LANE = 3   # side lane of the warp-gradient scatters (lanes 1..2: filter gradients; include/madnet_hip.h MH_MAX_LANES)
+# Two ways of taking work off the critical path that were MEASURED AND REJECTED as defaults (profiles/r02_experiments.txt, same box,
+# MADNet FULL): the warp-gradient scatters on a side lane (SCATTER_LANE = 1..4; 0 = in line) and the reduction of the loss value +
+# the validation metrics on a side lane (SIDE_LOSS).  In line / in line: 2.454 ms; scatter lane 3 + side loss 2.52-2.54; side loss
+# only 2.62; scatter only 2.65 -- every fork / join edge between hardware queues costs more (~10 us of bubble) than the 5-28 us
+# kernels it hides.  The code paths stay behind these switches for A/B runs.
+SCATTER_LANE = int(os.environ.get("MH_SCATTER_LANE", "0"))
+SIDE_LOSS = os.environ.get("MH_SIDE_LOSS", "0") != "0"
 
 
 def _r4(c):
@@ -321,7 +327,7 @@ class MadNetEngine(object):
     def record_loss_metrics(self, r, with_grad):
         """full-resolution reprojection loss (Stereo_Online_Adaptation.py:70) -- or, loss_kind 'proxy', the proxy-label
         mean_l1 of the continual variant (Stereo_Continual_Adaptation.py:75, weight 0.01) -- + EPE/bad3 (:74-82)."""
-        side = self.wgrad_lanes > 0 and hasattr(r, "lane")
+        side = SIDE_LOSS and self.wgrad_lanes > 0 and hasattr(r, "lane")
         if self.loss_kind == "proxy":
             ops.proxy_loss(r, self.pred, self.proxy, self.proxy_ws, self.res_loss, self.dpred if with_grad else None, weight=0.01)
         elif side:
@@ -508,7 +514,7 @@ class MadNetEngine(object):
                 # warp gradient: scatter into the right tower's feature gradient (atomics -> zero first)
                 dFr = self._half(self.dF[f], True)
                 fresh = not acc_flag(("F", f, 1))
-                if self.wgrad_lanes > 0 and hasattr(lib, "lane"):
+                if SCATTER_LANE > 0 and self.wgrad_lanes > 0 and hasattr(lib, "lane"):
                     # the coordinate gradient feeds the next level (critical path); the scatter only feeds the pyramid backward at
                     # the very end: it runs (with its zero fill) on side lane 3, joined right before the pyramid section
                     if du is not None:
