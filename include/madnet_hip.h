@@ -78,6 +78,21 @@ typedef struct mh_conv_desc {
 int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w, const float* bias,
               float* out, const float* mask_ref, void* stream);
 
+/* mh_conv2d with an optional second view of the filter bank for the forward pass: wt[tap][Cout][Cin] = the transpose of the HWIO
+ * bank w (same byte count; written by mh_transpose_weights once per step).  With it the small stride-1/2 layers (<= 8192 output pixels)
+ * run the LDS-free kernel of conv_direct.hip in the bf16 / split-bf16 modes; wt = NULL behaves exactly like mh_conv2d.  Input
+ * gradients (mode 1) read the HWIO bank k-fastest as stored and never need wt. */
+int mh_conv2d_wt(const mh_conv_desc* d, const float* in, const float* w, const float* wt, const float* bias,
+                 float* out, const float* mask_ref, void* stream);
+typedef struct mh_transpose_seg {
+    const float* src;     /* HWIO bank [taps][K][N] */
+    float* dst;           /* [taps][N][K] */
+    int32_t taps, K, N;
+    int32_t blk0;         /* exclusive prefix sum of ceil(taps*K*N / 256) over the table */
+} mh_transpose_seg;
+/* segs_device: table in DEVICE memory; nblocks = sum of ceil(taps*K*N / 256): every filter bank of a network in one launch. */
+int mh_transpose_weights(const mh_transpose_seg* segs_device, int32_t nseg, int32_t nblocks, void* stream);
+
 /* weight+bias gradient: dw[tap][K][N] += sum_pixels in(pixel,tap)[k] * dout[pixel][n] ;
  * db[n] += sum_pixels dout[pixel][n].  `d` describes the FORWARD conv (mode 0 geometry:
  * B,Hi,Wi = input, Ho,Wo = output, K = Cin, N = Cout).  dw/db are ACCUMULATED (fp32
@@ -260,6 +275,7 @@ int mh_bias_grad(const float* dz, int32_t dz_ld, int64_t npix, int32_t nch, floa
 /* ---- tuning hooks used by scripts/microbench.py (0 = built-in heuristic) ------------------ */
 int mh_tune_conv_tile(int bm, int bn);
 int mh_tune_conv_thin(int min_pixels);   /* weights-stationary thin-layer kernel from this many output pixels (0 = default, < 0 = never) */
+int mh_tune_conv_direct(int mode);       /* LDS-free small-layer kernel: 0 = off, 1 = heuristic (default), 2 = forced whenever eligible; returns its launch count since the previous call */
 int mh_tune_conv_patch(int mode);        /* patch-staged bf16 kernel of the stride-1 3x3 layers: 0 = off, 1 = on (tile heuristic), 64 / 128 = forced pixel tile, +256 = 8-wave variant, +2048 = generic-K instances only, +4096 = forward layers only, +8192 = no generic-K input gradients, < 0 = built-in default; returns the number of launches of that kernel since the previous call */
 int mh_tune_wgrad_wgs(int target_workgroups);
 int mh_tune_corr(int direct);
@@ -274,7 +290,7 @@ enum { MH_OP_CONV = 1, MH_OP_WGRAD, MH_OP_CORR_FWD, MH_OP_CORR_BWD, MH_OP_WARP_F
        MH_OP_RESIZE_FWD, MH_OP_RESIZE_BWD, MH_OP_PAD_REFLECT, MH_OP_LOSS, MH_OP_METRICS,
        MH_OP_MOMENTUM, MH_OP_COPY_CH, MH_OP_LEAKY_BWD, MH_OP_FILL, MH_OP_BIAS_GRAD,
        MH_OP_WGRAD_PARTIAL, MH_OP_WGRAD_REDUCE, MH_OP_PROXY_LOSS, MH_OP_SUPERVISED_LOSS, MH_OP_ADAM, MH_OP_ADAM_ADVANCE,
-       MH_OP_RESIZE_IMAGE, MH_OP_LEVEL_FRONT };
+       MH_OP_RESIZE_IMAGE, MH_OP_LEVEL_FRONT, MH_OP_TRANSPOSE_W };
 /* i[26] of every op is its scheduling word: low byte = lane (0 = the caller's stream; 1..MH_MAX_LANES-1 = side
  * streams owned by the library: the op is forked from lane 0 right before it, i.e. ordered after everything recorded so
  * far, and runs concurrently with the lane-0 ops that follow); MH_OP_JOIN = lane 0 first waits for all side lanes.

@@ -942,6 +942,11 @@ int mh_conv_init() {
 
 extern "C" int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w, const float* bias,
                          float* out, const float* mask_ref, void* stream) {
+    return mh_conv2d_wt(d, in, w, nullptr, bias, out, mask_ref, stream);
+}
+
+extern "C" int mh_conv2d_wt(const mh_conv_desc* d, const float* in, const float* w, const float* wt, const float* bias,
+                            float* out, const float* mask_ref, void* stream) {
     MH_REQUIRE(d && in && w && out, MH_ERR_ARG, "mh_conv2d: null argument");
     MH_REQUIRE(d->B > 0 && d->Hi > 0 && d->Wi > 0 && d->Ho > 0 && d->Wo > 0 && d->K > 0 && d->N > 0,
                MH_ERR_ARG, "mh_conv2d: non-positive dimension");
@@ -1007,5 +1012,6 @@ extern "C" int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w,
     if (conv_n1_ok(a)) return launch_conv_n1(a, (hipStream_t)stream);
     if (conv_thin_ok(a)) return launch_conv_thin(a, (hipStream_t)stream);
     if (mh_conv_patch_ok(a)) return mh_conv_patch_launch(a, (hipStream_t)stream);
+    if (mh_conv_direct_ok(a, (wt && mh_aligned16(wt)) ? wt : nullptr)) return mh_conv_direct_launch(a, wt, (hipStream_t)stream);
     return conv_dispatch(a, (hipStream_t)stream);
 }

@@ -29,3 +29,6 @@ struct ConvArgs {
 bool mh_conv_patch_ok(const ConvArgs& a);
 int mh_conv_patch_launch(ConvArgs& a, hipStream_t s);     // a.M < 0: attribute set-up only
 extern "C" int mh_tune_conv_patch(int mode);
+// conv_direct.hip: LDS-free kernel of the small layers (wt = k-fastest transposed filter bank for the forward pass, may be null)
+bool mh_conv_direct_ok(const ConvArgs& a, const float* wt);
+int mh_conv_direct_launch(ConvArgs& a, const float* wt, hipStream_t s);

@@ -93,6 +93,9 @@ class Params(object):
         self.total = off
         self.w = torch.zeros(off, device=device)
         self.m = torch.zeros(off, device=device)
+        # transposed filter banks [tap][Cout][Cin] (same offsets as w): the k-fastest operand of the LDS-free small-layer kernel's
+        # forward pass, rewritten at the start of every step by ONE mh_transpose_weights launch (engine.record_forward)
+        self.wt = torch.zeros(off, device=device)
         # + 4 floats behind the gradients: the step's loss result lives there, so the shared-model mode all-reduces the
         # gradients AND the loss that drives the reward / reset logic with ONE collective (adapter.py)
         self.g_loss = torch.zeros(off + 4, device=device)     # [gradients | loss result (4 floats)]
@@ -158,6 +161,8 @@ class MadNetEngine(object):
         self.wgrad_lanes = 2
         # one launch per level for the inter-level upsample + warp + cost volume + concat (mh_level_front_fwd) instead of three
         self.fuse_front = os.environ.get("MH_FUSE_FRONT", "1") != "0"        # (environment switch: in-situ A/B runs)
+        # bf16 / mixed: hand every forward conv the transposed filter bank too, so that the small layers can take the LDS-free kernel
+        self.use_direct = precision != "fp32" and os.environ.get("MH_CONV_DIRECT", "1") != "0"
         self.wsa = ops.WgradWorkspace(device)
 
     # ---------------------------------------------------------------------------------------
@@ -243,17 +248,28 @@ class MadNetEngine(object):
     def b_(self, base):
         return self.params.tensor(base + "/biases")
 
+    def Wt_(self, base):
+        """transposed view of the layer's filter bank (None in the fp32 mode: the exact-fp32 path has no LDS-free kernel)"""
+        if not self.use_direct:
+            return None
+        P = self.params
+        o = P.offset[base + "/weights"]
+        return P.wt[o:o + P.numel(base + "/weights")]
+
     # =========================================================================================
     # forward  (MadNet._preprocess_inputs + _build_network, Nets/MadNet.py:56-66,251-364)
     # =========================================================================================
     def record_forward(self, r, make_disps=()):
         B, lib = self.B, r
+        if self.use_direct:
+            names = [n for n, shp in self.params.manifest if n.endswith("/weights") and shp[3] >= 16 and shp[2] % 8 == 0]
+            ops.transpose_weights(lib, [(self.params.tensor(n), self.Wt_(n[:-len("/weights")])) for n in names], self.dev, r.keep)
         ops.pad_reflect(lib, self.left, self.X0[:B], self.pt, self.pl)
         ops.pad_reflect(lib, self.right, self.X0[B:], self.pt, self.pl)
         x = ops.View(self.X0, 2 * B, self.Hp, self.Wp, 3, 4)
         for i, (ci, co, s) in enumerate(PYR, 1):
             o = self._fv(self.F[i])
-            ops.conv2d_fwd(lib, x, self.W_(pyr_name(i)), self.b_(pyr_name(i)), o, stride=s, alpha=ALPHA)
+            ops.conv2d_fwd(lib, x, self.W_(pyr_name(i)), self.b_(pyr_name(i)), o, stride=s, alpha=ALPHA, wt=self.Wt_(pyr_name(i)))
             x = o
         for k in LEVELS:
             f = FEAT[k]
@@ -282,7 +298,7 @@ class MadNetEngine(object):
                 last = j == len(EST) - 1
                 o = self._fv(self.V[k]) if last else self._fv(self.E[k][j])
                 ops.conv2d_fwd(lib, x, self.W_(est_name(k, j + 1)), self.b_(est_name(k, j + 1)), o,
-                               alpha=(1.0 if last else ALPHA), precision=fprec)
+                               alpha=(1.0 if last else ALPHA), precision=fprec, wt=self.Wt_(est_name(k, j + 1)))
                 x = o
             if k != 2:
                 sc = 2 ** (k - 1)
@@ -298,7 +314,7 @@ class MadNetEngine(object):
         x = cin
         for j, (co, rate) in enumerate(CTX[:-1]):
             o = self._fv(self.Cx[j])
-            ops.conv2d_fwd(lib, x, self.W_(ctx_name(j + 1)), self.b_(ctx_name(j + 1)), o, dil=rate, alpha=ALPHA)
+            ops.conv2d_fwd(lib, x, self.W_(ctx_name(j + 1)), self.b_(ctx_name(j + 1)), o, dil=rate, alpha=ALPHA, wt=self.Wt_(ctx_name(j + 1)))
             x = o
         # final_disp = V2_init + context7  (accumulating epilogue)
         ops.copy_channels(lib, self._fv(self.V[2]), self._fv(self.final))

@@ -110,7 +110,7 @@ def conv_geometry(H, W, kh, kw, stride, dil):
 
 
 def conv2d_fwd(lib, x, w, b, out, stride=1, dil=1, alpha=1.0, accumulate=False, mask_ref=None, mask_alpha=1.0,
-               mask_range=(0, 0), stream=None, precision=None):
+               mask_range=(0, 0), stream=None, precision=None, wt=None):
     """out (+)= leaky(conv2d_SAME(x, w) + b) [* leaky'(mask_ref)].  x,out: View; w: HWIO [kh,kw,Cin,Cout]."""
     kh, kw, cin, cout = w.shape
     Ho, Wo, pt, pl = conv_geometry(x.H, x.W, kh, kw, stride, dil)
@@ -118,7 +118,26 @@ def conv2d_fwd(lib, x, w, b, out, stride=1, dil=1, alpha=1.0, accumulate=False, 
     d = conv_desc(x.B, x.H, x.W, Ho, Wo, cin, cout, kh, kw, stride, dil, pt, pl, 0, 0, x.ld, out.ld, alpha=alpha,
                   mask_ld=(mask_ref.ld if mask_ref is not None else 0), accumulate=int(accumulate), mask_alpha=mask_alpha,
                   mask_c0=mask_range[0], mask_c1=mask_range[1], precision=precision)
-    lib.conv2d(C.byref(d), _p(x), _p(w), _p(b), _p(out), _p(mask_ref), _p(stream))
+    if wt is not None:       # wt: the transposed filter bank [tap][Cout][Cin] (transpose_weights): lets the small layers run LDS-free
+        lib.conv2d_wt(C.byref(d), _p(x), _p(w), _p(wt), _p(b), _p(out), _p(mask_ref), _p(stream))
+    else:
+        lib.conv2d(C.byref(d), _p(x), _p(w), _p(b), _p(out), _p(mask_ref), _p(stream))
+
+
+def transpose_weights(lib, pairs, device, keep, stream=None):
+    """pairs: [(src HWIO tensor, dst tensor of the same numel)] -> dst[tap][n][k] = src[tap][k][n] for every pair, ONE launch.
+    `keep`: list that keeps the device table alive as long as the plan."""
+    if not pairs:
+        return
+    arr = (_ffi.TransposeSeg * len(pairs))()
+    blk = 0
+    for i, (src, dst) in enumerate(pairs):
+        kh, kw, K, N = src.shape
+        arr[i].src, arr[i].dst, arr[i].taps, arr[i].K, arr[i].N, arr[i].blk0 = src.data_ptr(), dst.data_ptr(), kh * kw, K, N, blk
+        blk += (kh * kw * K * N + 255) // 256
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+    keep.append(table)
+    lib.transpose_weights(C.c_void_p(table.data_ptr()), len(pairs), blk, _p(stream))
 
 
 def conv2d_dgrad(lib, dz, w, dx, stride=1, dil=1, accumulate=False, mask_ref=None, mask_alpha=1.0, mask_range=(0, 0),
