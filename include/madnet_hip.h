@@ -79,9 +79,9 @@ int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w, const floa
               float* out, const float* mask_ref, void* stream);
 
 /* mh_conv2d with an optional second view of the filter bank for the forward pass: wt[tap][Cout][Cin] = the transpose of the HWIO
- * bank w (same byte count; written by mh_transpose_weights once per step).  With it the small stride-1/2 layers (<= 8192 output pixels)
- * run the LDS-free kernel of conv_direct.hip in the bf16 / split-bf16 modes; wt = NULL behaves exactly like mh_conv2d.  Input
- * gradients (mode 1) read the HWIO bank k-fastest as stored and never need wt. */
+ * bank w (same byte count; written by mh_transpose_weights).  Only the EXPERIMENTAL LDS-free kernel of conv_direct.hip uses it (bf16 /
+ * split-bf16 modes, off unless mh_tune_conv_direct / MH_CONV_DIRECT enable it: it measured slower than the tiled kernel);
+ * wt = NULL behaves exactly like mh_conv2d.  Input gradients (mode 1) read the HWIO bank k-fastest as stored and never need wt. */
 int mh_conv2d_wt(const mh_conv_desc* d, const float* in, const float* w, const float* wt, const float* bias,
                  float* out, const float* mask_ref, void* stream);
 typedef struct mh_transpose_seg {
@@ -275,7 +275,7 @@ int mh_bias_grad(const float* dz, int32_t dz_ld, int64_t npix, int32_t nch, floa
 /* ---- tuning hooks used by scripts/microbench.py (0 = built-in heuristic) ------------------ */
 int mh_tune_conv_tile(int bm, int bn);
 int mh_tune_conv_thin(int min_pixels);   /* weights-stationary thin-layer kernel from this many output pixels (0 = default, < 0 = never) */
-int mh_tune_conv_direct(int mode);       /* LDS-free small-layer kernel: 0 = off, 1 = heuristic (default), 2 = forced whenever eligible; returns its launch count since the previous call */
+int mh_tune_conv_direct(int mode);       /* experimental LDS-free small-layer kernel: 0 = off (default: measured slower than the tiled kernel), 1 = size heuristic, 2 = forced whenever eligible; returns its launch count since the previous call */
 int mh_tune_conv_patch(int mode);        /* patch-staged bf16 kernel of the stride-1 3x3 layers: 0 = off, 1 = on (tile heuristic), 64 / 128 = forced pixel tile, +256 = 8-wave variant, +2048 = generic-K instances only, +4096 = forward layers only, +8192 = no generic-K input gradients, < 0 = built-in default; returns the number of launches of that kernel since the previous call */
 int mh_tune_wgrad_wgs(int target_workgroups);
 int mh_tune_corr(int direct);

@@ -1,4 +1,5 @@
-// conv_direct.hip -- LDS-free, barrier-free bf16-MFMA kernel for the SMALL stride-1 layers (the estimator chains of the coarse
+// conv_direct.hip -- EXPERIMENT, OFF BY DEFAULT (measured slower, see the end of this header) -- LDS-free, barrier-free bf16-MFMA kernel
+// for the SMALL stride-1 layers (the estimator chains of the coarse
 // pyramid levels and the stride-1 pyramid layers: Nets/MadNet.py:73-120,173-249 via Nets/sharedLayers.py:54-63) and their input
 // gradients.
 //
@@ -16,6 +17,13 @@
 //     re-read each other's operands from L1 / L2: at most 2.6 MB of activations and 0.6 MB of weights per layer).
 // Precision: bf16 operands (code 1) or split-bf16 (code 2: hi/lo of both operands built in registers, 3 MFMAs per product).
 // The epilogue is the one of conv_igemm_kernel (bias + leaky, or accumulate + leaky-gradient mask with a channel range).
+//
+// MEASURED on the MI355X (profiles/r02_experiments.txt #12, in situ, serial rocprofv3 trace): 22-26 us per launch on average against
+// 10-13 us for the tiled kernel it was meant to replace; whole step 2.46 -> 3.05-3.14 ms (mixed), 2.24 -> 2.99 ms (bf16).  A four-stage
+// software pipeline of the operand loads changed nothing, so it is not the load round trip: every wave re-reads operands its
+// neighbours also read, 16 bytes per lane from 16 different cache lines per instruction -- ~96 line accesses per 32-k step and wave for
+// 2-6 MFMAs -- and the L1 (one line per clock) becomes the bound.  Sharing operands through LDS is what the tiled kernel is FOR.
+// The kernel stays as an opt-in (mh_tune_conv_direct(2) / MH_CONV_DIRECT=2: parity-tested) and as the record of the experiment.
 #include "conv_args.h"
 #include <stdlib.h>
 #include <atomic>
@@ -24,11 +32,10 @@ namespace {
 
 struct DirectGeo { int mtiles, ntiles, kchunks, nwaves; };
 
+// 8 consecutive fp32 (two 16-byte loads) -> one MFMA operand fragment (bf16, or hi + lo planes for split-bf16).  K is a multiple
+// of 8, so a lane's group of 8 channels is either entirely inside the channel range or entirely outside (out-of-range offset = zeros).
 template <bool X3>
-__device__ __forceinline__ void load_frag(__amdgpu_buffer_rsrc_t rs, int off, u32x4& hi, u32x4& lo) {
-    // 8 consecutive fp32 starting at byte offset `off` (MH_OOB: zeros).  K is a multiple of 8, so a lane's group of 8 is either
-    // entirely inside the channel range or entirely outside (then the caller passes MH_OOB)
-    const float4 v0 = mh_buf_load4(rs, off), v1 = mh_buf_load4(rs, off == MH_OOB ? MH_OOB : off + 16);
+__device__ __forceinline__ void to_frag(const float4& v0, const float4& v1, u32x4& hi, u32x4& lo) {
     if constexpr (X3) {
         unsigned h0, h1, h2, h3, l0, l1, l2, l3;
         mh_split_bf16x2(v0.x, v0.y, h0, l0); mh_split_bf16x2(v0.z, v0.w, h1, l1);
@@ -75,38 +82,73 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs p, DirectGeo 
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // The K walk = taps x 32-channel chunks, flattened, with the operand loads of step s + D issued while step s is multiplied
+    // (D = 4 register stages of raw fp32): without it every step waited for its own loads -- a dependent L2 round trip per 32 k,
+    // 22-26 us per layer (profiles/r02_experiments.txt #12).  Loads past the walk get out-of-range offsets (zeros, no traffic)
+    // and their MFMAs add nothing, so the loop needs no tail handling.
+    constexpr int D = 4;
     const int tap_stride = p.N * p.K * 4;                       // bytes per tap of the [tap][N][K] weight operand
-    for (int tap = 0; tap < p.taps; ++tap) {
-        const int ky = tap / p.kw, kx = tap - ky * p.kw;
-        int a_base[MT];
+    const int nsteps = p.taps * g.kchunks;
+    float4 ra[D][MT][2], rb[D][NT][2];
+    int i_tap = 0, i_c = 0;                                     // (tap, chunk) of the next step to ISSUE
+    int a_base[MT];
+    auto new_tap = [&]() {
+        const int ky = i_tap / p.kw, kx = i_tap - ky * p.kw;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int iy = DGRAD ? a_y[i] + p.pad_t - ky * p.dil : a_y[i] * p.stride - p.pad_t + ky * p.dil;
             const int ix = DGRAD ? a_x[i] + p.pad_l - kx * p.dil : a_x[i] * p.stride - p.pad_l + kx * p.dil;
-            const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const bool ok = i_tap < p.taps && a_ok[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
             a_base[i] = ok ? ((a_img[i] + iy * p.Wi + ix) * p.in_ld + lq * 8) * 4 : MH_OOB;
         }
-        const int wtap = tap * tap_stride + lq * 32;
-#pragma unroll 2
-        for (int c = 0; c < g.kchunks; ++c) {
-            const bool kin = c * 32 + lq * 8 < p.K;            // this lane's 8 channels exist (K % 8 == 0)
-            u32x4 ah[MT], al[MT], bh[NT], bl[NT];
+    };
+    new_tap();
+    auto issue = [&](float4 (&a)[MT][2], float4 (&b)[NT][2]) {
+        const bool kin = i_tap < p.taps && i_c * 32 + lq * 8 < p.K;          // this lane's 8 channels exist (K % 8 == 0)
+        const int wofs = i_tap * tap_stride + lq * 32 + i_c * 128;
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
-                load_frag<X3>(rs_in, (a_base[i] != MH_OOB && kin) ? a_base[i] + c * 128 : MH_OOB, ah[i], al[i]);
+        for (int i = 0; i < MT; ++i) {
+            const int off = (a_base[i] != MH_OOB && kin) ? a_base[i] + i_c * 128 : MH_OOB;
+            a[i][0] = mh_buf_load4(rs_in, off);
+            a[i][1] = mh_buf_load4(rs_in, off == MH_OOB ? MH_OOB : off + 16);
+        }
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
-                load_frag<X3>(rs_w, (b_off[j] != MH_OOB && kin) ? b_off[j] + wtap + c * 128 : MH_OOB, bh[j], bl[j]);
+        for (int j = 0; j < NT; ++j) {
+            const int off = (b_off[j] != MH_OOB && kin) ? b_off[j] + wofs : MH_OOB;
+            b[j][0] = mh_buf_load4(rs_w, off);
+            b[j][1] = mh_buf_load4(rs_w, off == MH_OOB ? MH_OOB : off + 16);
+        }
+        if (++i_c == g.kchunks) { i_c = 0; ++i_tap; new_tap(); }
+    };
+    auto consume = [&](const float4 (&a)[MT][2], const float4 (&b)[NT][2]) {
+        u32x4 ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i) to_frag<X3>(a[i][0], a[i][1], ah[i], al[i]);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    if constexpr (X3) {
-                        acc[i][j] = mh_mfma_bf16(al[i], bh[j], acc[i][j]);
-                        acc[i][j] = mh_mfma_bf16(ah[i], bl[j], acc[i][j]);
-                    }
-                    acc[i][j] = mh_mfma_bf16(ah[i], bh[j], acc[i][j]);
+        for (int j = 0; j < NT; ++j) to_frag<X3>(b[j][0], b[j][1], bh[j], bl[j]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if constexpr (X3) {
+                    acc[i][j] = mh_mfma_bf16(al[i], bh[j], acc[i][j]);
+                    acc[i][j] = mh_mfma_bf16(ah[i], bl[j], acc[i][j]);
                 }
+                acc[i][j] = mh_mfma_bf16(ah[i], bh[j], acc[i][j]);
+            }
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue(ra[d], rb[d]);
+    for (int s0 = 0; s0 < nsteps; s0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            float4 ca[MT][2], cb[NT][2];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) { ca[i][0] = ra[d][i][0]; ca[i][1] = ra[d][i][1]; }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) { cb[j][0] = rb[d][j][0]; cb[j][1] = rb[d][j][1]; }
+            issue(ra[d], rb[d]);                                  // step s0 + d + D into the stage just drained
+            consume(ca, cb);                                      // step s0 + d
         }
     }
     // epilogue: acc[i][j][r] = row (pixel) m0 + 16 i + 4 lq + r, column n0 + 16 j + li
@@ -131,12 +173,12 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs p, DirectGeo 
         }
 }
 
-// 0 = off, 1 = heuristic (default), 2 = forced (tests); process-wide tuning hook
+// 0 = off (default: measured slower), 1 = size heuristic, 2 = forced whenever eligible (tests); process-wide tuning hook
 std::atomic<int> g_direct_mode{-2};
 std::atomic<int> g_direct_launches{0};
 int direct_mode() {
     int m = g_direct_mode.load(std::memory_order_relaxed);
-    if (m == -2) { const char* e = getenv("MH_CONV_DIRECT"); m = e ? atoi(e) : 1; g_direct_mode.store(m, std::memory_order_relaxed); }
+    if (m == -2) { const char* e = getenv("MH_CONV_DIRECT"); m = e ? atoi(e) : 0; g_direct_mode.store(m, std::memory_order_relaxed); }
     return m;
 }
 
@@ -162,7 +204,7 @@ int launch_direct_tile(ConvArgs& a, hipStream_t s) {
 }  // namespace
 
 extern "C" int mh_tune_conv_direct(int mode) {
-    g_direct_mode = mode < 0 ? 1 : mode;
+    g_direct_mode = mode < 0 ? 0 : mode;
     return g_direct_launches.exchange(0);
 }
 

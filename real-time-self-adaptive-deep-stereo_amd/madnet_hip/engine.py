@@ -162,7 +162,8 @@ class MadNetEngine(object):
         # one launch per level for the inter-level upsample + warp + cost volume + concat (mh_level_front_fwd) instead of three
         self.fuse_front = os.environ.get("MH_FUSE_FRONT", "1") != "0"        # (environment switch: in-situ A/B runs)
         # bf16 / mixed: hand every forward conv the transposed filter bank too, so that the small layers can take the LDS-free kernel
-        self.use_direct = precision != "fp32" and os.environ.get("MH_CONV_DIRECT", "1") != "0"
+        # (EXPERIMENT, off by default: the LDS-free kernel measured slower, csrc/conv_direct.hip -- MH_CONV_DIRECT=1 / 2 enables it)
+        self.use_direct = precision != "fp32" and os.environ.get("MH_CONV_DIRECT", "0") != "0"
         self.wsa = ops.WgradWorkspace(device)
 
     # ---------------------------------------------------------------------------------------

@@ -6,12 +6,12 @@ timeout 900 python -m pytest tests/test_conv_parity.py tests/test_engine_parity.
 run() { name=$1; shift; env "$@" timeout 300 python bench.py $B 2>/dev/null | tail -1 > $OUT/bench_$name.json; }
 run mixed_direct1 MH_X=1
 run mixed_direct0 MH_CONV_DIRECT=0
-run bf16_direct1 MH_X=1 ; mv $OUT/bench_bf16_direct1.json $OUT/tmp.json
+
 timeout 300 python bench.py $B --precision bf16 2>/dev/null | tail -1 > $OUT/bench_bf16_direct1.json
 MH_CONV_DIRECT=0 timeout 300 python bench.py $B --precision bf16 2>/dev/null | tail -1 > $OUT/bench_bf16_direct0.json
 timeout 300 python bench.py $B --mode MAD 2>/dev/null | tail -1 > $OUT/bench_mad.json
 run mixed_direct1_again MH_X=1
-rm -f $OUT/tmp.json
+
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_serial -o madnet -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --repeats 1 --no-graph --no-cpu-baseline --no-roofline --no-paths --no-step-surface --wgrad-lanes 0 > $GRAFT_REPO_ROOT/$OUT/prof_serial.log 2>&1)
 cat $OUT/pytest_gpu.txt
 python - <<PY
