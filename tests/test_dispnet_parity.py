@@ -50,43 +50,50 @@ def _run(backend, H, W, mode):
         assert (eng.params.tensor(n).cpu() - wt[n]).abs().max().item() <= 1e-5 * max(1.0, wt[n].abs().max().item()), n
 
 
-@pytest.mark.slow
-def test_dispnet_offline_training_step_emulated():
+@pytest.mark.parametrize("bname,size", [pytest.param("emul", (40, 64), marks=pytest.mark.slow, id="emul-40x64"),
+                                        pytest.param("hip", (128, 256), marks=pytest.mark.gpu, id="hip-128x256")])
+def test_dispnet_offline_training_step(bname, size):
     """Train.py's default model: one offline training step of DispNet -- the 7 supervised loss terms, every
     gradient (one loss head per prediction, injected into the mechanically derived backward plan) and the Adam update --
-    against the oracle.  Emulator only: written after the round's GPU budget was spent; the kernels are the ones the MADNet
-    training step runs on the MI355X."""
-    from conftest import _emul_backend
-    backend = _emul_backend()
-    H, W = 40, 64
+    against the oracle; on the CPU emulator and on the MI355X."""
+    from conftest import _emul_backend, _hip_backend
+    backend = _emul_backend() if bname == "emul" else _hip_backend()
+    H, W = size
     wn = S.calibrated_weights(OD.variable_shapes(), 1)
     l, r, gt = S.make_pair(H, W)
-    eng = DE.DispNetEngine(backend.lib, H, W, B=1, device="cpu", weights=wn)
+    eng = DE.DispNetEngine(backend.lib, H, W, B=1, device=backend.device, weights=wn)
     eng.set_inputs(l, r, gt[..., 0])
     lw = [1.0, 0.9, 0.7, 0.5, 0.3, 0.2, 0.1]
     eng.build_plan("TRAIN", lr=1e-3, loss_weights=lw).run(backend.lib, 0)
+    backend.sync()
     wt = {k: torch.from_numpy(v.copy()) for k, v in wn.items()}
     am = {k: torch.zeros_like(v) for k, v in wt.items()}; av = {k: torch.zeros_like(v) for k, v in wt.items()}
     st = [0.9, 0.999]
     o = OD.train_step(wt, am, av, st, torch.from_numpy(l), torch.from_numpy(r), torch.from_numpy(gt), lr=1e-3, loss_weights=lw)
-    assert (eng.pred - o["disparity"][..., 0]).abs().mean().item() <= 1e-3
-    got = eng.res_loss_ms[:, 0].tolist()
+    assert (eng.pred.cpu() - o["disparity"][..., 0]).abs().mean().item() <= 1e-3
+    got = eng.res_loss_ms[:, 0].cpu().tolist()
     assert len(got) == 7
     for i, (a, b) in enumerate(zip(got, o["losses"])):
         assert abs(a - b) <= 5e-5 * max(1.0, abs(b)), (i, a, b)
     gmax = max(g.abs().max().item() for g in o["grads"].values())
     worst = 0.0
     for n, g in o["grads"].items():
-        ge = eng.params.tensor(n, "g")
+        ge = eng.params.tensor(n, "g").cpu()
         rel = (ge - g).norm().item() / max(g.norm().item(), 1e-30)
         worst = max(worst, rel)
         assert rel <= 5e-3 or g.abs().max().item() <= 1e-6 * gmax, (n, rel)       # |x| losses on 40x64 pixels: see test_engine_parity
+    # Adam's first step is +-lr whatever |g|: elements whose gradient sits at the rounding floor of their tensor follow the fp32
+    # summation order -> worst element over the solid gradients, mean over everything (tests/test_engine_parity.py)
     dmax, dmean = 0.0, 0.0
     for n in wt:
-        d = (eng.params.tensor(n) - wt[n]).abs()
-        dmax = max(dmax, d.max().item()); dmean = max(dmean, d.mean().item())
-    assert dmax <= 0.5e-3 and dmean <= 2e-4 * 1e-3, (dmax, dmean, worst)
-    assert torch.allclose(eng.adam_state, torch.tensor(st), rtol=1e-6)
+        d = (eng.params.tensor(n).cpu() - wt[n]).abs()
+        g = o["grads"].get(n)
+        solid = (g.abs() > 1e-4 * g.abs().max()) if g is not None else torch.ones_like(d, dtype=torch.bool)
+        if solid.any():
+            dmax = max(dmax, d[solid].max().item())
+        dmean = max(dmean, d.mean().item())
+    assert dmax <= 0.5e-3 and dmean <= 1e-3 * 1e-3, (dmax, dmean, worst)
+    assert torch.allclose(eng.adam_state.cpu(), torch.tensor(st), rtol=1e-6)
 
 
 @pytest.mark.slow

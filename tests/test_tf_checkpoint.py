@@ -124,3 +124,49 @@ def test_cli_weight_loader_reads_checkpoint(tmp_path):
     got2 = soa.load_weights(str(tmp_path), "MADNet")        # a directory: latest_checkpoint
     assert np.array_equal(got2["model/gc-read-pyramid/conv1/weights"] if "model/gc-read-pyramid/conv1/weights" in w else got2[sorted(w)[0]],
                           w.get("model/gc-read-pyramid/conv1/weights", w[sorted(w)[0]]))
+
+
+def test_reader_against_independent_c_writer(tmp_path):
+    """VERDICT r01 item 10 / ADVICE: the reader was only ever checked against its own writer.  tests/tools/tb_writer.c is a second,
+    independent implementation of the TensorBundle V2 / LevelDB-table format (C, written from the format description, shares no code with
+    Data_utils/tf_checkpoint.py): 1 KiB data blocks (several), prefix-compressed keys with restart interval 16, index block with restart
+    interval 1, proto3 zero-field omission.  The reader has to recover every tensor bit-exactly and detect a flipped data byte."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "tb_writer")
+    subprocess.run(["gcc", "-O2", "-o", exe, os.path.join(ROOT, "tests", "tools", "tb_writer.c"), "-lm"], check=True)
+    prefix = str(tmp_path / "model-77")
+    nt = 40
+    subprocess.run([exe, prefix, str(nt)], check=True)
+    assert CK.is_checkpoint(prefix)
+    r = CK.CheckpointReader(prefix)
+    sm = r.get_variable_to_shape_map()
+    assert len(sm) == 2 * nt
+    for t in range(nt):
+        for which, leaf in ((0, "biases"), (1, "weights")):
+            shp = (3, 3, t % 5 + 1, t % 7 + 2) if which else (t % 7 + 2,)
+            e = np.arange(int(np.prod(shp)), dtype=np.float64)
+            ref = np.sin(0.37 * t + 0.011 * e + (0.0 if which else 1.0)).astype(np.float32).reshape(shp)
+            name = "model/layer%03d/%s" % (t, leaf)
+            assert sm[name] == list(shp)
+            got = r.get_tensor(name)
+            assert got.dtype == np.float32 and np.array_equal(got, ref), name
+    # the index really has several data blocks (else the multi-block path was not exercised)
+    assert os.path.getsize(prefix + ".index") > 3 * 1024
+    # corruption of the data shard is caught by the per-tensor masked crc32c the C writer computed
+    data = prefix + ".data-00000-of-00001"
+    raw = bytearray(open(data, "rb").read())
+    raw[len(raw) // 2] ^= 0x40
+    open(data, "wb").write(bytes(raw))
+    r2 = CK.CheckpointReader(prefix)
+    with pytest.raises(Exception):
+        for name in sm:
+            r2.get_tensor(name)
+    # and of the index by the block trailer crc
+    idx = bytearray(open(prefix + ".index", "rb").read())
+    idx[100] ^= 0x01
+    open(prefix + ".index", "wb").write(bytes(idx))
+    with pytest.raises(Exception):
+        CK.CheckpointReader(prefix).get_variable_to_shape_map()
