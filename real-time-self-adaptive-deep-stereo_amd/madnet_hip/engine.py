@@ -155,7 +155,7 @@ class MadNetEngine(object):
         self._plans = {}
         self._zeros_needed = []
         # filter gradients: atomic-free split reduction (ops.conv2d_wgrad_partial) unless switched off
-        self.partial_wgrad = True
+        self.partial_wgrad = os.environ.get("MH_WGRAD_ATOMIC", "0") != "1"   # False: splits accumulate with fp32 atomics straight into g
         # ... recorded on a side lane: the filter gradients are off the critical path (only the optimizer needs
         # them), so they overlap with the input-gradient chain as a parallel branch of the hipGraph
         self.wgrad_lanes = 2
@@ -408,10 +408,10 @@ class MadNetEngine(object):
 
         def wgrad(xv, dzv, base, stride=1, dil=1):
             dw, db = P.tensor(base + "/weights", "g"), P.tensor(base + "/biases", "g")
-            if not self.partial_wgrad:
-                ops.conv2d_wgrad(lib, xv, dzv, dw, db, stride=stride, dil=dil)
-            elif self.wgrad_lanes > 0 and hasattr(lib, "lane"):
+            if self.wgrad_lanes > 0 and hasattr(lib, "lane"):
                 pending.append((xv, dzv, dw, db, stride, dil))
+            elif not self.partial_wgrad:
+                ops.conv2d_wgrad(lib, xv, dzv, dw, db, stride=stride, dil=dil)
             else:
                 ops.conv2d_wgrad_partial(lib, self.lib, self.wsa, segs, xv, dzv, dw, db, stride=stride, dil=dil)
 
@@ -428,9 +428,13 @@ class MadNetEngine(object):
             try:
                 batch = []
                 for xv, dzv, dw, db, stride, dil in pending:
-                    ops.conv2d_wgrad_partial(lib, self.lib, self.wsa, batch, xv, dzv, dw, db, stride=stride, dil=dil)
+                    if self.partial_wgrad:
+                        ops.conv2d_wgrad_partial(lib, self.lib, self.wsa, batch, xv, dzv, dw, db, stride=stride, dil=dil)
+                    else:
+                        ops.conv2d_wgrad(lib, xv, dzv, dw, db, stride=stride, dil=dil)
                 # the batch's split reduction follows on the SAME lane: it too is off the critical path
-                ops.wgrad_reduce(lib, batch, self.dev, r.keep)
+                if batch:
+                    ops.wgrad_reduce(lib, batch, self.dev, r.keep)
             finally:
                 lib.lane = 0
                 del pending[:]
