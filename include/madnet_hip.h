@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 7
+#define MH_ABI_VERSION 8
 
 /* status codes of every int-returning entry point: 0 = launched; a NEGATIVE code means an argument check failed and
  * nothing was launched or written; a POSITIVE value is the hipError_t of a failed launch / runtime call.
@@ -93,6 +93,26 @@ typedef struct mh_transpose_seg {
 /* segs_device: table in DEVICE memory; nblocks = sum of ceil(taps*K*N / 256): every filter bank of a network in one launch. */
 int mh_transpose_weights(const mh_transpose_seg* segs_device, int32_t nseg, int32_t nblocks, void* stream);
 
+/* mh_conv2d with the filter bank ALSO given as an "MFMA fragment bank" (forward, stride-1 3x3 layers in split-bf16 mode, precision 2):
+ * wb = the image mh_pack_weights writes -- bank[(tap * ceil(K/32) + chunk)][16-column tile][plane hi, lo][lane 0..63][8 bf16], lane l
+ * holding w[tap][32*chunk + 8*(l>>4) .. +7][16*tile + (l&15)], zero padded -- mh_pack_bytes(9, K, N, 2) bytes, 16-byte aligned.  The
+ * kernel then streams its weight operand straight from global memory into registers (no LDS staging, no barrier in the K walk).
+ * Layers the bank kernel does not cover, and wb = NULL, behave exactly like mh_conv2d.  The bank must be re-packed whenever w changes
+ * (the engines do it once per step, one launch for every layer).  Same arithmetic as the LDS-staged split-bf16 kernel. */
+int mh_conv2d_wb(const mh_conv_desc* d, const float* in, const float* w, const void* wb, const float* bias,
+                 float* out, const float* mask_ref, void* stream);
+typedef struct mh_pack_seg {
+    const float* src;     /* HWIO bank [taps][K][N] */
+    void* dst;            /* fragment bank, mh_pack_bytes(taps, K, N, planes) bytes */
+    int32_t taps, K, N;
+    int32_t planes;       /* 2: hi + lo (split-bf16); 1: hi only */
+    int32_t blk0;         /* exclusive prefix sum of ceil(taps*ceil(K/32)*ceil(N/16)*64 / 256) over the table */
+    int32_t pad;
+} mh_pack_seg;
+int64_t mh_pack_bytes(int32_t taps, int32_t K, int32_t N, int32_t planes);
+/* segs_device: table in DEVICE memory; nblocks = the sum the blk0 fields prefix. */
+int mh_pack_weights(const mh_pack_seg* segs_device, int32_t nseg, int32_t nblocks, void* stream);
+
 /* weight+bias gradient: dw[tap][K][N] += sum_pixels in(pixel,tap)[k] * dout[pixel][n] ;
  * db[n] += sum_pixels dout[pixel][n].  `d` describes the FORWARD conv (mode 0 geometry:
  * B,Hi,Wi = input, Ho,Wo = output, K = Cin, N = Cout).  dw/db are ACCUMULATED (fp32
@@ -108,6 +128,16 @@ int mh_conv2d_wgrad(const mh_conv_desc* d, const float* in, const float* dout, i
  *           aligned; it is fully overwritten (no zeroing needed).  db (may be NULL) is still accumulated. */
 int mh_conv2d_wgrad_partial(const mh_conv_desc* d, const float* in, const float* dout, int32_t dout_ld,
                             float* ws, int32_t* splits, float* db, void* stream);
+/* Several layers' partial filter gradients in one launch (same contract per item as mh_conv2d_wgrad_partial with ws != NULL: `splits` from a
+ * query call).  bf16-mode layers share one grid; exact-fp32 layers are launched one by one.  Replaces the per-layer Conv2DBackpropFilter nodes
+ * TF schedules for one tf.gradients() call (Stereo_Online_Adaptation.py:126-128). */
+typedef struct mh_wgrad_item {
+    mh_conv_desc d;
+    const float* in; const float* dout;
+    float* ws; float* db;
+    int32_t dout_ld, splits;
+} mh_wgrad_item;
+int mh_conv2d_wgrad_partial_group(const mh_wgrad_item* items, int32_t n, void* stream);
 typedef struct mh_wgrad_seg {
     const float* ws;      /* [splits][size] partial sums of one layer */
     float* dst;           /* [size] filter gradient */
@@ -277,6 +307,7 @@ int mh_tune_conv_tile(int bm, int bn);
 int mh_tune_conv_thin(int min_pixels);   /* weights-stationary thin-layer kernel from this many output pixels (0 = default, < 0 = never) */
 int mh_tune_conv_direct(int mode);       /* experimental LDS-free small-layer kernel: 0 = off (default: measured slower than the tiled kernel), 1 = size heuristic, 2 = forced whenever eligible; returns its launch count since the previous call */
 int mh_tune_conv_patch(int mode);        /* patch-staged bf16 kernel of the stride-1 3x3 layers: 0 = off, 1 = on (tile heuristic), 64 / 128 = forced pixel tile, +256 = 8-wave variant, +2048 = generic-K instances only, +4096 = forward layers only, +8192 = no generic-K input gradients, < 0 = built-in default; returns the number of launches of that kernel since the previous call */
+int mh_tune_conv_bank(int reset);        /* returns the number of fragment-bank kernel launches (mh_conv2d_wb) since the previous call */
 int mh_tune_wgrad_wgs(int target_workgroups);
 int mh_tune_corr(int direct);
 
@@ -290,7 +321,7 @@ enum { MH_OP_CONV = 1, MH_OP_WGRAD, MH_OP_CORR_FWD, MH_OP_CORR_BWD, MH_OP_WARP_F
        MH_OP_RESIZE_FWD, MH_OP_RESIZE_BWD, MH_OP_PAD_REFLECT, MH_OP_LOSS, MH_OP_METRICS,
        MH_OP_MOMENTUM, MH_OP_COPY_CH, MH_OP_LEAKY_BWD, MH_OP_FILL, MH_OP_BIAS_GRAD,
        MH_OP_WGRAD_PARTIAL, MH_OP_WGRAD_REDUCE, MH_OP_PROXY_LOSS, MH_OP_SUPERVISED_LOSS, MH_OP_ADAM, MH_OP_ADAM_ADVANCE,
-       MH_OP_RESIZE_IMAGE, MH_OP_LEVEL_FRONT, MH_OP_TRANSPOSE_W };
+       MH_OP_RESIZE_IMAGE, MH_OP_LEVEL_FRONT, MH_OP_TRANSPOSE_W, MH_OP_PACK_W };
 /* i[26] of every op is its scheduling word: low byte = lane (0 = the caller's stream; 1..MH_MAX_LANES-1 = side
  * streams owned by the library: the op is forked from lane 0 right before it, i.e. ordered after everything recorded so
  * far, and runs concurrently with the lane-0 ops that follow); MH_OP_JOIN = lane 0 first waits for all side lanes.

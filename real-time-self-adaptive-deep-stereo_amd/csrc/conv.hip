@@ -945,8 +945,18 @@ extern "C" int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w,
     return mh_conv2d_wt(d, in, w, nullptr, bias, out, mask_ref, stream);
 }
 
+static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, const float* wt, const void* wb, const float* bias,
+                      float* out, const float* mask_ref, void* stream);
 extern "C" int mh_conv2d_wt(const mh_conv_desc* d, const float* in, const float* w, const float* wt, const float* bias,
                             float* out, const float* mask_ref, void* stream) {
+    return conv_entry(d, in, w, wt, nullptr, bias, out, mask_ref, stream);
+}
+extern "C" int mh_conv2d_wb(const mh_conv_desc* d, const float* in, const float* w, const void* wb, const float* bias,
+                            float* out, const float* mask_ref, void* stream) {
+    return conv_entry(d, in, w, nullptr, wb, bias, out, mask_ref, stream);
+}
+static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, const float* wt, const void* wb, const float* bias,
+                      float* out, const float* mask_ref, void* stream) {
     MH_REQUIRE(d && in && w && out, MH_ERR_ARG, "mh_conv2d: null argument");
     MH_REQUIRE(d->B > 0 && d->Hi > 0 && d->Wi > 0 && d->Ho > 0 && d->Wo > 0 && d->K > 0 && d->N > 0,
                MH_ERR_ARG, "mh_conv2d: non-positive dimension");
@@ -956,6 +966,8 @@ extern "C" int mh_conv2d_wt(const mh_conv_desc* d, const float* in, const float*
     MH_REQUIRE((int64_t)d->B * d->Ho * d->Wo < (1ll << 31), MH_ERR_ARG, "mh_conv2d: too many output pixels");
     ConvArgs a;
     a.in = in; a.w = w; a.bias = bias; a.out = out; a.mask_ref = mask_ref;
+    a.wb = (wb && mh_aligned16(wb) && d->mode == 0 && d->precision == 2) ? wb : nullptr;
+    a.wb_bytes = a.wb ? (unsigned)mh_pack_bytes(d->kh * d->kw, d->K, d->N, 2) : 0u;
     a.in_ld = d->in_ld; a.out_ld = d->out_ld; a.mask_ld = d->mask_ld;
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ho = d->Ho; a.Wo = d->Wo;
     a.K = d->K; a.N = d->N; a.G = (d->K + 3) / 4; a.taps = d->kh * d->kw;

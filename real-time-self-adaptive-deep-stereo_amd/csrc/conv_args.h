@@ -4,6 +4,7 @@
 
 struct ConvArgs {
     const float* in; const float* w; const float* bias; float* out; const float* mask_ref;
+    const void* wb; unsigned wb_bytes;     // fragment bank of w (mh_pack_weights), or null
     int in_ld, out_ld, mask_ld;
     int B, Hi, Wi, Ho, Wo;
     int K, N, G, taps;

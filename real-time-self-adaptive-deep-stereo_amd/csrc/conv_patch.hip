@@ -535,12 +535,244 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1,
     }
 }
 
+
+// ---- "fragment bank" variant (forward, stride-1 3x3): the weights are NOT staged through LDS.  mh_pack_weights (below) rewrites a
+// filter bank once per step into the exact register image of the MFMA B operand -- bank[(tap * CPT + chunk)][16-column tile][plane]
+// [lane][8 bf16], plane = hi (and lo for split-bf16) -- so a wave fetches a fragment with ONE coalesced 1 KB buffer load per plane
+// (the waves of a workgroup that share a column tile hit L1, the workgroups of an XCD hit its L2).  What that removes from the K walk
+// of conv_patch_kernel: the fp32 weight loads + hi/lo conversion + LDS stores of every workgroup, half of the LDS fragment reads
+// (LDS bound: profiles/r02_experiments.txt #6) and the per-tile barrier -- the patch is read-only after staging, so the waves run
+// free.  Three register stages of B (prefetch distance 2-3 chunks) and of A (LDS, distance 1).
+template <int WM, int WN, int MT, int NT, bool X3>
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv_bank_kernel(ConvArgs p, PatchGeo g) {
+    constexpr int NTH = WM * WN * 64;
+    constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
+    constexpr int TH = BM / 16;
+    constexpr int PL = X3 ? 2 : 1;
+    HIP_DYNAMIC_SHARED(float, smem_all)
+    unsigned short* const Ph = reinterpret_cast<unsigned short*>(smem_all);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 15, lq = lane >> 4;
+    const int d = p.dil;
+
+    int lin = mh_xcd_remap(blockIdx.x, g.nwg);
+    const int tile_n = lin % g.ntiles_n; lin /= g.ntiles_n;
+    const int ttx = lin % g.tiles_x; lin /= g.tiles_x;
+    const int tty = lin % g.tiles_y; lin /= g.tiles_y;
+    const int cx = lin % d; lin /= d;
+    const int cy = lin % d;
+    const int b = lin / d;
+    const int n0 = tile_n * BN;
+    const int y00 = cy + d * (tty * TH), x00 = cx + d * (ttx * 16);
+
+    const __amdgpu_buffer_rsrc_t rs_in = mh_make_rsrc(p.in, p.in_bytes);
+    const __amdgpu_buffer_rsrc_t rs_b = mh_make_rsrc(p.wb, p.wb_bytes);
+
+    // ---- B fragments: thread-constant offset of column tile j (plane 0) + chunk * stride_b ------------------------------
+    const int np16 = (p.N + 15) >> 4;
+    const int stride_b = np16 * PL * 1024;
+    int voff_b[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int nt = tile_n * (BN / 16) + wn * NT + j;
+        voff_b[j] = nt < np16 ? nt * PL * 1024 + lane * 16 : MH_OOB;
+    }
+    u32x4 fb[3][NT][PL], fa[3][MT][PL];
+    const int nchunk = (g.dbg & 1) ? 0 : g.nchunk;                    // 9 * CPT: a multiple of 3
+    auto issue_b = [&](u32x4 (&f)[NT][PL], int q) {
+        const int base = q < nchunk ? q * stride_b : MH_OOB;         // past the walk: out of range = zeros
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl)
+                f[j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (int)((unsigned)voff_b[j] + (unsigned)base) + pl * 1024, 0, 0);
+    };
+    issue_b(fb[0], 0);
+    issue_b(fb[1], 1);
+    issue_b(fb[2], 2);
+
+    // ---- stage the input patch once (as conv_patch_kernel) ---------------------------------------------------------------
+    {
+        constexpr int U = NTH == 512 ? 12 : 16;
+        const int kp4 = g.KP >> 2;
+        const int items = (g.dbg & 2) ? 0 : (TH + 2) * PW * kp4;
+        const int dpp = NTH / kp4, dc4 = NTH - dpp * kp4;
+        const int dpi = dpp / PW, dpj = dpp - dpi * PW;
+        const int ppx0 = (int)(((float)tid + 0.5f) * g.inv_kp4);
+        int c4 = tid - ppx0 * kp4, pi = ppx0 / PW, pj = ppx0 - pi * PW;
+        int iy = y00 + (pi - 1) * d, ix = x00 + (pj - 1) * d;
+        int off = (((b * p.Hi + iy) * p.Wi + ix) * p.in_ld + c4 * 4) * 4;
+        int lds = ppx0 * g.PS + c4 * 4;
+        int c4s = c4, pis = pi, pjs = pj;
+        const int s_col = d * p.in_ld * 4, s_row = d * p.Wi * p.in_ld * 4;
+        const int st_off = dpi * s_row + dpj * s_col + dc4 * 16, st_iy = dpi * d, st_ix = dpj * d;
+        const int w_off = s_col - kp4 * 16, r_off = s_row - PW * s_col, r_ix = PW * d;
+        const int st_lds = dpp * g.PS + dc4 * 4, w_lds = g.PS - kp4 * 4;
+        for (int q0 = tid; q0 < items; q0 += NTH * U) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool ok = (pi < TH + 2) && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi && (c4 < p.G);
+                v[u] = mh_buf_load4(rs_in, ok ? off : MH_OOB);
+                c4 += dc4; pj += dpj; pi += dpi; iy += st_iy; ix += st_ix; off += st_off;
+                if (c4 >= kp4) { c4 -= kp4; ++pj; ix += d; off += w_off; }
+                if (pj >= PW) { pj -= PW; ++pi; iy += d; ix -= r_ix; off += r_off; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (pis < TH + 2) {
+                    float4 w = v[u];
+                    w.y = (c4s * 4 + 1 < p.K) ? w.y : 0.f;
+                    w.z = (c4s * 4 + 2 < p.K) ? w.z : 0.f;
+                    w.w = (c4s * 4 + 3 < p.K) ? w.w : 0.f;
+                    if constexpr (X3) {
+                        uint2 hi, lo;
+                        mh_split_bf16x2(w.x, w.y, hi.x, lo.x);
+                        mh_split_bf16x2(w.z, w.w, hi.y, lo.y);
+                        *reinterpret_cast<uint2*>(Ph + lds) = hi;
+                        *reinterpret_cast<uint2*>(Ph + g.patch_halfs + lds) = lo;
+                    } else
+                    *reinterpret_cast<uint2*>(Ph + lds) = make_uint2(mh_pack_bf16(w.x, w.y), mh_pack_bf16(w.z, w.w));
+                }
+                c4s += dc4; pjs += dpj; pis += dpi; lds += st_lds;
+                if (c4s >= kp4) { c4s -= kp4; ++pjs; lds += w_lds; }
+                if (pjs >= PW) { pjs -= PW; ++pis; }
+            }
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- K walk: chunk q = (tap q / CPT, 32 channels q % CPT); no barrier ----------------------------------------------
+    const unsigned short* const Pw = Ph + ((wm * MT) * PW + li) * g.PS + lq * 8;
+    int a_tap = 0, a_c = 0;                          // scalar cursor of the next chunk whose A fragments are read
+    auto issue_a = [&](u32x4 (&f)[MT][PL]) {
+        const int tap = a_tap < 9 ? a_tap : 8;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const unsigned short* Ab = Pw + (ky * PW + kx) * g.PS + a_c * 32;
+        if (++a_c == g.CPT) { a_c = 0; ++a_tap; }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            f[i][0] = *reinterpret_cast<const u32x4*>(Ab + i * PW * g.PS);
+            if constexpr (X3) f[i][1] = *reinterpret_cast<const u32x4*>(Ab + g.patch_halfs + i * PW * g.PS);
+        }
+    };
+    constexpr int MM = MT * NT, M3 = (X3 ? 3 : 1) * MM;
+    issue_a(fa[0]);
+    // nothing in flight at the loop header the first time (the B stages landed behind the patch loads): otherwise hipcc's waitcnt pass
+    // merges "unknown" into the header state and drains vmcnt(0) on every iteration
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (int q = 0; q < nchunk; q += 3) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            constexpr int dummy = 0; (void)dummy;
+            const int ns = (s + 1) % 3;
+#pragma unroll
+            for (int m = 0; m < M3; ++m) {
+                const int t = X3 ? m / MM : 2, mm = m % MM, i = mm / NT, j = mm % NT;
+                // split-bf16: lo(A)*hi(B), hi(A)*lo(B), hi(A)*hi(B) -- t outermost: consecutive MFMAs hit different accumulators
+                acc[i][j] = mh_mfma_bf16(fa[s][i][t == 0 ? PL - 1 : 0], fb[s][j][t == 1 ? PL - 1 : 0], acc[i][j]);
+                if (m == 0) issue_a(fa[ns]);                          // A fragments of the next chunk (LDS latency << one chunk of MFMAs)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            issue_b(fb[s], q + s + 3);                                // this stage's registers are free again: chunk q+s+3
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();                                 // every wave is done with the patch: the accumulator tile goes over it
+
+    constexpr int CS = BN + 4;
+    float* const Cs = smem_all;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Cs[((wm * MT + i) * 16 + lq * 4 + r) * CS + wn * NT * 16 + j * 16 + li] = acc[i][j][r];
+    __syncthreads();
+    constexpr int C4 = BN / 4;
+    constexpr int RP = NTH / C4;
+    constexpr int PASSES = (BM + RP - 1) / RP;
+    const __amdgpu_buffer_rsrc_t rs_out = mh_make_rsrc(p.out, p.out_bytes);
+    const __amdgpu_buffer_rsrc_t rs_mask = mh_make_rsrc(p.mask_ref ? p.mask_ref : p.out, p.mask_ref ? p.mask_bytes : 0u);
+    const int c4 = tid % C4;
+    const int n = n0 + c4 * 4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && n < p.N) bv = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll 4
+    for (int ps = 0; ps < PASSES; ++ps) {
+        const int row = tid / C4 + ps * RP;
+        const int rr = row < BM ? row : 0;
+        const int y = y00 + (rr >> 4) * d, x = x00 + (rr & 15) * d;
+        const bool ok = (tid < RP * C4) && (row < BM) && (y < p.Ho) && (x < p.Wo) && (n < p.N);
+        const int m = (b * p.Ho + y) * p.Wo + x;
+        float4 v = *reinterpret_cast<const float4*>(&Cs[rr * CS + c4 * 4]);
+        const int ooff = ok ? (m * p.out_ld + n) * 4 : MH_OOB;
+        float4 old = make_float4(0.f, 0.f, 0.f, 0.f), mk = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (p.accumulate) old = mh_buf_load4(rs_out, ooff);
+        if (p.mask_ref) mk = mh_buf_load4(rs_mask, ok ? (m * p.mask_ld + n) * 4 : MH_OOB);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        if (p.alpha != 1.0f) {
+            v.x = v.x > 0.f ? v.x : p.alpha * v.x; v.y = v.y > 0.f ? v.y : p.alpha * v.y;
+            v.z = v.z > 0.f ? v.z : p.alpha * v.z; v.w = v.w > 0.f ? v.w : p.alpha * v.w;
+        }
+        v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+        if (p.mask_ref) {
+            v.x *= (mk.x > 0.f || n + 0 < p.mask_c0 || n + 0 >= p.mask_c1) ? 1.0f : p.mask_alpha;
+            v.y *= (mk.y > 0.f || n + 1 < p.mask_c0 || n + 1 >= p.mask_c1) ? 1.0f : p.mask_alpha;
+            v.z *= (mk.z > 0.f || n + 2 < p.mask_c0 || n + 2 >= p.mask_c1) ? 1.0f : p.mask_alpha;
+            v.w *= (mk.w > 0.f || n + 3 < p.mask_c0 || n + 3 >= p.mask_c1) ? 1.0f : p.mask_alpha;
+        }
+        if (ok) *reinterpret_cast<float4*>(p.out + (int64_t)m * p.out_ld + n) = v;
+    }
+}
+
+// fragment bank writer: one thread per (chunk, 16-column tile, lane): 8 k-values of one output column -> 16 bytes per plane
+__global__ __launch_bounds__(256) void pack_weights_kernel(const mh_pack_seg* __restrict__ segs, int nseg) {
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (segs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const mh_pack_seg sg = segs[lo];
+    const int cpt = (sg.K + 31) >> 5, np16 = (sg.N + 15) >> 4;
+    const int e = ((int)blockIdx.x - sg.blk0) * 256 + (int)threadIdx.x;
+    const int lane = e & 63, qt = e >> 6;
+    if (qt >= sg.taps * cpt * np16) return;
+    const int nt = qt % np16, q = qt / np16;
+    const int c = q % cpt, tap = q / cpt;
+    const int k0 = c * 32 + (lane >> 4) * 8, n = nt * 16 + (lane & 15);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (k0 + j < sg.K && n < sg.N) ? sg.src[((int64_t)tap * sg.K + k0 + j) * sg.N + n] : 0.f;
+    unsigned hh[4], ll[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mh_split_bf16x2(v[2 * j], v[2 * j + 1], hh[j], ll[j]);
+    const u32x4 h = {hh[0], hh[1], hh[2], hh[3]}, l = {ll[0], ll[1], ll[2], ll[3]};
+    u32x4* dst = reinterpret_cast<u32x4*>(sg.dst) + ((int64_t)qt * sg.planes) * 64 + lane;
+    dst[0] = h;
+    if (sg.planes > 1) dst[64] = l;
+}
+
 constexpr size_t PATCH_LDS_MAX = 150 * 1024;
 
 size_t patch_lds(int TH, int BM, int BN, int KP, bool x3 = false) {
     const size_t tiles = ((size_t)(TH + 2) * PW * (KP + 16) * 2 + (size_t)2 * BN * LSB * 2) * (x3 ? 2 : 1);
     const size_t cs = (size_t)BM * (BN + 4) * 4;
     return tiles > cs ? tiles : cs;
+}
+
+size_t bank_lds(int TH, int BM, int BN, int KP, bool x3) {
+    const size_t patch = (size_t)(TH + 2) * PW * (KP + 16) * 2 * (x3 ? 2 : 1);
+    const size_t cs = (size_t)BM * (BN + 4) * 4;
+    return patch > cs ? patch : cs;
 }
 
 // mode: 0 = off, 1 = heuristic tile, 64 / 128 = forced pixel tile; bit 8: the 8-wave variant of the 128-pixel tile
@@ -586,6 +818,41 @@ int launch_patch(ConvArgs& a, hipStream_t s) {
     return mh_check_launch("conv_patch");
 }
 
+std::atomic<int> g_bank_launches{0};
+template <int WM, int WN, int MT, int NT, bool X3>
+int launch_bank(ConvArgs& a, hipStream_t s) {
+    constexpr int BM = WM * MT * 16, BN = WN * NT * 16, TH = BM / 16;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bank_kernel<WM, WN, MT, NT, X3>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)PATCH_LDS_MAX);
+        if (e != hipSuccess) { mh_set_error("conv_bank: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_done = true;
+    }
+    if (a.M < 0) return 0;
+    PatchGeo g;
+    g.TH = TH;
+    const int d = a.dil;
+    g.tiles_y = mh_cdiv(mh_cdiv(a.Ho, d), TH);
+    g.tiles_x = mh_cdiv(mh_cdiv(a.Wo, d), 16);
+    g.ntiles_n = mh_cdiv(a.N, BN);
+    g.nwg = a.B * d * d * g.tiles_y * g.tiles_x * g.ntiles_n;
+    g.KP = (a.K + 31) & ~31;
+    g.CPT = g.KP / 32;
+    g.PS = g.KP + 16;
+    g.nchunk = 9 * g.CPT;
+    g.patch_halfs = (TH + 2) * PW * g.PS;
+    g.inv_kp4 = 1.0f / (float)(g.KP / 4);
+    g.dbg = (patch_mode() >> 9) & 3;
+    const size_t lds = bank_lds(TH, BM, BN, g.KP, X3);
+    ++g_patch_launches;
+    ++g_bank_launches;
+    mh_note_kernel("conv_bank_kernel<%d,%d,%d,%d,%s> tile %dx%d K=%d dil=%d grid %d lds %d", WM, WN, MT, NT, X3 ? "bf16x3" : "bf16", BM, BN, a.K, a.dil,
+                   g.nwg, (int)lds);
+    hipLaunchKernelGGL((conv_bank_kernel<WM, WN, MT, NT, X3>), dim3(g.nwg), dim3(WM * WN * 64), lds, s, a, g);
+    return mh_check_launch("conv_bank");
+}
+
 // the channel-count-specialised instances exist for the 8-wave tile (the one the heuristic dispatches)
 template <int WM, int WN, int MT, int NT, bool DGRAD>
 int launch_patch_k(ConvArgs& a, hipStream_t s) {
@@ -627,6 +894,16 @@ extern "C" int mh_tune_conv_patch(int mode) {
     return g_patch_launches.exchange(0);
 }
 
+extern "C" int64_t mh_pack_bytes(int32_t taps, int32_t K, int32_t N, int32_t planes) {
+    return (int64_t)taps * ((K + 31) / 32) * ((N + 15) / 16) * planes * 1024;
+}
+extern "C" int mh_pack_weights(const mh_pack_seg* segs_device, int32_t nseg, int32_t nblocks, void* stream) {
+    MH_REQUIRE(segs_device && nseg > 0 && nblocks > 0, MH_ERR_ARG, "mh_pack_weights: empty segment table");
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, segs_device, nseg);
+    return mh_check_launch("pack_weights");
+}
+extern "C" int mh_tune_conv_bank(int reset) { (void)reset; return g_bank_launches.exchange(0); }
+
 bool mh_conv_patch_ok(const ConvArgs& a) {
     if (patch_mode() == 0) return false;
     if (!((a.bf16 || (a.x3 && a.mode == 0)) && a.vecA && a.vecB && a.vecC)) return false;
@@ -660,6 +937,14 @@ int mh_conv_patch_launch(ConvArgs& a, hipStream_t s) {
     const int bm = all ? 0 : patch_bm(a), bn = all ? 0 : patch_bn(a);
     const bool w8 = all ? false : patch_w8(a);
     int rc = 0;
+    // fragment-bank instances (mh_conv2d_wb: the layer's weights packed by mh_pack_weights; split-bf16 forward)
+    {
+        const bool wb = !all && a.wb && a.x3 && a.mode == 0 && !(patch_mode() & 0x4000);       // mode bit 14: ignore the bank
+        const bool big = !all && (patch_mode() & 0x8000) != 0;                                  // mode bit 15: 128-pixel tile (64x32 wave tiles)
+        if (all || (wb && bn == 128 && big)) { rc = launch_bank<2, 4, 4, 2, true>(a, s); if (!all || rc) return rc; }
+        if (all || (wb && bn == 128)) { rc = launch_bank<2, 4, 2, 2, true>(a, s); if (!all || rc) return rc; }
+        if (all || (wb && bn == 64)) { rc = launch_bank<4, 2, 2, 2, true>(a, s); if (!all || rc) return rc; }
+    }
     // split-bf16 forward instances (precision code 2)
     {
         const bool generic = !all && ((patch_mode() >> 11) & 1) != 0;      // tuning hook (mode bit 11): generic-K instances only

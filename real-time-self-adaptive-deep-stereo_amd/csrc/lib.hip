@@ -102,6 +102,7 @@ static int run_op(const mh_op& o, void* s) {
     switch (o.kind) {
         case MH_OP_CONV: {
             mh_conv_desc d; desc_from_op(o, d);
+            if (p[6]) return mh_conv2d_wb(&d, (const float*)p[0], (const float*)p[1], p[6], (const float*)p[2], (float*)p[3], (const float*)p[4], s);
             return mh_conv2d_wt(&d, (const float*)p[0], (const float*)p[1], (const float*)p[5], (const float*)p[2], (float*)p[3], (const float*)p[4], s);
         }
         case MH_OP_WGRAD: {
@@ -123,6 +124,8 @@ static int run_op(const mh_op& o, void* s) {
             return mh_adam_advance((float*)p[0], o.f[0], o.f[1], s);
         case MH_OP_PROXY_LOSS:
             return mh_proxy_loss((const float*)p[0], (const float*)p[1], (float*)p[2], (float*)p[3], (float*)p[4], o.f[0], o.f[1], i[0], i[1], i[2], s);
+        case MH_OP_PACK_W:
+            return mh_pack_weights((const mh_pack_seg*)p[0], i[0], i[1], s);
         case MH_OP_WGRAD_REDUCE:
             return mh_wgrad_reduce((const mh_wgrad_seg*)p[0], i[0], i[1], s);
         case MH_OP_CORR_FWD:
@@ -222,6 +225,19 @@ int lane_edge(Lanes& L, hipStream_t from, hipStream_t to) {
 }
 }  // namespace
 
+// consecutive partial-filter-gradient ops of one lane (a batch of independent layers) go out as ONE grouped launch
+static int run_wgrad_batch(const mh_op* ops, int m, void* s) {
+    mh_wgrad_item items[16];
+    for (int k = 0; k < m; ++k) {
+        const mh_op& o = ops[k];
+        desc_from_op(o, items[k].d);
+        items[k].in = (const float*)o.p[0]; items[k].dout = (const float*)o.p[1];
+        items[k].ws = (float*)o.p[2]; items[k].db = (float*)o.p[3];
+        items[k].dout_ld = o.i[21]; items[k].splits = o.i[23];
+    }
+    return mh_conv2d_wgrad_partial_group(items, m, s);
+}
+
 extern "C" int mh_plan_run(const mh_op* ops, int32_t nops, void* stream) {
     MH_REQUIRE(ops || nops == 0, MH_ERR_ARG, "mh_plan_run: null plan");
     Lanes* L = nullptr;
@@ -244,12 +260,17 @@ extern "C" int mh_plan_run(const mh_op* ops, int32_t nops, void* stream) {
             for (int l = 1; l < MH_MAX_LANES && !e; ++l)
                 if (((sched >> 16) >> l) & 1) { if (dirty[l]) { e = lane_edge(*L, L->aux[l], main_s); dirty[l] = false; } }
         }
+        // batch = this op + the following partial-filter-gradient ops of the same lane (no join / lane change in between)
+        int m = 1;
+        if (ops[k].kind == MH_OP_WGRAD_PARTIAL)
+            while (m < 16 && k + m < nops && ops[k + m].kind == MH_OP_WGRAD_PARTIAL && ops[k + m].i[26] == lane) ++m;
+        auto run = [&](void* s) -> int { return m > 1 ? run_wgrad_batch(ops + k, m, s) : run_op(ops[k], s); };
         if (!e && lane > 0) {
             if (!L) e = lanes_get(&L);
             if (!e && stale[lane]) { e = lane_edge(*L, main_s, L->aux[lane]); stale[lane] = false; }
-            if (!e) { dirty[lane] = true; e = run_op(ops[k], (void*)L->aux[lane]); }
+            if (!e) { dirty[lane] = true; e = run((void*)L->aux[lane]); }
         } else if (!e) {
-            e = run_op(ops[k], stream);
+            e = run(stream);
             for (bool& b : stale) b = true;
         }
         if (e != 0) {
@@ -259,6 +280,7 @@ extern "C" int mh_plan_run(const mh_op* ops, int32_t nops, void* stream) {
             join();         // never leave a capture with an unjoined side stream
             return e;
         }
+        k += m - 1;
     }
     return join();
 }

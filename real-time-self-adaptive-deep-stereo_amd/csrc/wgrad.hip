@@ -39,6 +39,21 @@ extern "C" int mh_tune_wgrad_wgs(int target) {
     return 0;
 }
 
+// ---- grouped launches (mh_conv2d_wgrad_partial_group): the bf16 tile shapes and the N = 1 reduction get an id; in capture mode the
+// launchers fill this record instead of launching, and wgrad_group_kernel runs up to MH_WG_GROUP_MAX layers in one grid ------------
+#define MH_WGRAD_CFGS(X) X(0, 2, 2, 4, 4) X(1, 2, 2, 4, 2) X(2, 4, 1, 2, 1) X(3, 2, 2, 2, 4) X(4, 2, 2, 2, 2) X(5, 4, 1, 1, 1) \
+    X(6, 1, 4, 2, 2) X(7, 2, 2, 1, 1) X(8, 2, 1, 1, 1) X(9, 1, 4, 1, 2) X(10, 1, 2, 1, 1) X(11, 1, 1, 1, 1)
+constexpr int MH_WG_CFG_N1 = 12;
+template <int WM, int WN, int MT, int NT>
+constexpr int wgrad_cfg_id() {
+#define X(id, a, b, c, d) if (WM == a && WN == b && MT == c && NT == d) return id;
+    MH_WGRAD_CFGS(X)
+#undef X
+    return -1;
+}
+struct WgradCapture { int cfg; int nblocks; size_t lds; };
+static thread_local WgradCapture* t_capture = nullptr;     // != null: record (cfg, grid, LDS) of the next dispatch, launch nothing
+
 template <int GPT>
 __device__ __forceinline__ int swz_group(int row, int g) { return g ^ ((row >> 2) & (GPT - 1)); }
 
@@ -252,8 +267,9 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
 // consecutive pixels x one 4-channel group: 4 coalesced 16-byte loads along the NHWC rows, transposed in
 // registers and rounded to bf16 (v_cvt_pk_bf16_f32), stored as four 8-byte LDS writes.
 template <int WM, int WN, int MT, int NT>
-__global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(WgradArgs p) {
+__device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& p, const int block_id, const int grid_dim, float* const smem) {
     constexpr int NTH = 64 * WM * WN;
+    if ((int)threadIdx.x >= NTH) return;      // grouped launches run every tile shape in 256-thread workgroups (whole waves retire)
     constexpr int PT = 64;
     constexpr int BK = WM * MT * 16, BN = WN * NT * 16;
     constexpr int LS = PT + 8;           // halfs.  (PT + 16 = 40-dword rows would make the operand reads conflict free, but the
@@ -261,7 +277,6 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(WgradArgs p) {
     constexpr int AUN = (BK / 4) * (PT / 4), BUN = (BN / 4) * (PT / 4);
     constexpr int AU = (AUN + NTH - 1) / NTH, BU = (BUN + NTH - 1) / NTH;
 
-    HIP_DYNAMIC_SHARED(float, smem)
     unsigned short* const Ah = reinterpret_cast<unsigned short*>(smem);   // [2][BK*LS]
     unsigned short* const Bh = Ah + 2 * BK * LS;                         // [2][BN*LS]
 
@@ -277,7 +292,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(WgradArgs p) {
     // share one workgroup and ONE dz tile (per-tap workgroups re-read dz once per tap: 49x for the 7x7 layer).
     const int TPW = p.flat ? BK / 4 : 1;
     const int ntapg = (p.taps + TPW - 1) / TPW;
-    int bid = mh_xcd_remap(blockIdx.x, gridDim.x);
+    int bid = mh_xcd_remap(block_id, grid_dim);
     const int tap = (bid % ntapg) * TPW; bid /= ntapg;           // first tap of this workgroup
     const int tn = bid % p.ntiles; bid /= p.ntiles;
     const int tk = bid % p.ktiles; bid /= p.ktiles;
@@ -460,6 +475,12 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(WgradArgs p) {
 }
 
 template <int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(64 * WM * WN) void wgrad_bf16_kernel(WgradArgs p) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    wgrad_bf16_body<WM, WN, MT, NT>(p, (int)blockIdx.x, (int)gridDim.x, smem);
+}
+
+template <int WM, int WN, int MT, int NT>
 int launch_wgrad_bf16(WgradArgs& a, hipStream_t s) {
     constexpr int BK = WM * MT * 16, BN = WN * NT * 16, PT = 64;
     constexpr size_t tiles_b = (size_t)(2 * (BK + BN) * (PT + 8)) * 2;
@@ -492,6 +513,7 @@ int launch_wgrad_bf16(WgradArgs& a, hipStream_t s) {
     a.splits = mh_cdiv(a.M, chunk);         // idempotent: forcing the returned count reproduces it
     a.chunk = chunk;
     if (a.query) return 0;
+    if (t_capture) { t_capture->cfg = wgrad_cfg_id<WM, WN, MT, NT>(); t_capture->nblocks = base * a.splits; t_capture->lds = lds; return 0; }
     mh_note_kernel("wgrad_bf16_kernel<%d,%d,%d,%d> tile %dx%d splits %d grid %d%s", WM, WN, MT, NT, BK, BN, a.splits, base * a.splits, a.flat ? " flat" : "");
     hipLaunchKernelGGL((wgrad_bf16_kernel<WM, WN, MT, NT>), dim3(base * a.splits), dim3(64 * WM * WN), lds, s, a);
     return mh_check_launch("wgrad_bf16");
@@ -528,6 +550,7 @@ int launch_wgrad_one(WgradArgs& a, hipStream_t s) {
     a.splits = mh_cdiv(a.M, chunk);         // idempotent: forcing the returned count reproduces it
     a.chunk = chunk;
     if (a.query) return 0;
+    if (t_capture) { t_capture->cfg = -1; return 0; }       // exact-fp32 tiles are not grouped
     mh_note_kernel("wgrad_kernel<%d,%d,%d,%d,PT=%d,%s> tile %dx%d splits %d grid %d", WM, WN, MT, NT, PT, VEC ? "vec" : "scalar", BK, BN, a.splits, base * a.splits);
     hipLaunchKernelGGL((wgrad_kernel<WM, WN, MT, NT, PT, VEC>), dim3(base * a.splits), dim3(64 * WM * WN), lds, s, a);
     return mh_check_launch("wgrad");
@@ -550,14 +573,14 @@ int launch_wgrad(WgradArgs& a, hipStream_t s) {
 // pixel slot): TAPS float4 accumulators in registers, pixels of the split strided over the slots, slots reduced
 // through LDS, one store (workspace) or atomic (dw) per element per workgroup.
 template <int TAPS>
-__global__ __launch_bounds__(256) void wgrad_n1_kernel(WgradArgs p) {
-    HIP_DYNAMIC_SHARED(float, smem)               // [slots][TAPS][K] floats
+__device__ __forceinline__ void wgrad_n1_body(const WgradArgs& p, const int block_id, float* const smem, float* const bred) {
+    // smem: [slots][TAPS][K] floats
     const int tid = threadIdx.x;
     const int G4 = p.K >> 2;                      // <= 256, power-of-two padded by the launcher: G4p
     const int G4p = p.ktiles;                     // (reused field) padded group count, divides 256
     const int slots = 256 / G4p;
     const int g = tid % G4p, slot = tid / G4p;
-    const int split = blockIdx.x;
+    const int split = block_id;
     const int mbeg = split * p.chunk, mend = min(p.M, mbeg + p.chunk);
     const bool gok = g < G4;
     const __amdgpu_buffer_rsrc_t rs_in = mh_make_rsrc(p.in, p.in_bytes);
@@ -584,7 +607,6 @@ __global__ __launch_bounds__(256) void wgrad_n1_kernel(WgradArgs p) {
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) *reinterpret_cast<float4*>(smem + ((slot * TAPS + t) * G4 + g) * 4) = acc[t];
     }
-    __shared__ float bred[256];
     bred[tid] = (g == 0) ? bsum : 0.f;
     __syncthreads();
     float* const dst = p.ws ? p.ws + (int64_t)split * TAPS * p.K : p.dw;
@@ -597,6 +619,47 @@ __global__ __launch_bounds__(256) void wgrad_n1_kernel(WgradArgs p) {
         float v = 0.f;
         for (int i = 0; i < 256; ++i) v += bred[i];
         atomicAdd(p.db, v);
+    }
+}
+template <int TAPS>
+__global__ __launch_bounds__(256) void wgrad_n1_kernel(WgradArgs p) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    __shared__ float bred[256];
+    wgrad_n1_body<TAPS>(p, (int)blockIdx.x, smem, bred);
+}
+
+// One grid for several layers' filter gradients (each segment = the grid the layer's own launch would use, padded to a multiple of 8
+// workgroups so that blockIdx & 7 is still the XCD inside every segment).  256-thread workgroups: narrower tile shapes retire their spare waves.
+constexpr int MH_WG_GROUP_MAX = 8;
+struct WgradGroup {
+    int n;
+    int blk0[MH_WG_GROUP_MAX + 1];
+    int cfg[MH_WG_GROUP_MAX];
+    int nblk[MH_WG_GROUP_MAX];
+    WgradArgs a[MH_WG_GROUP_MAX];
+};
+__global__ __launch_bounds__(256) void wgrad_group_kernel(WgradGroup g) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    __shared__ float bred[256];
+    int seg = 0;
+#pragma unroll
+    for (int q = 1; q < MH_WG_GROUP_MAX; ++q)
+        if (q < g.n && g.blk0[q] <= (int)blockIdx.x) seg = q;
+    seg = __builtin_amdgcn_readfirstlane(seg);
+    // the segment's record by a select chain over static indices: a dynamically indexed by-value argument is copied to scratch
+    int blk0 = g.blk0[0], nb = g.nblk[0], cfg = g.cfg[0];
+    WgradArgs p = g.a[0];
+#pragma unroll
+    for (int q = 1; q < MH_WG_GROUP_MAX; ++q)
+        if (seg == q) { blk0 = g.blk0[q]; nb = g.nblk[q]; cfg = g.cfg[q]; p = g.a[q]; }
+    const int bid = (int)blockIdx.x - blk0;
+    if (bid >= nb) return;                       // padding workgroup
+    switch (cfg) {
+#define X(id, a_, b_, c_, d_) case id: wgrad_bf16_body<a_, b_, c_, d_>(p, bid, nb, smem); break;
+        MH_WGRAD_CFGS(X)
+#undef X
+        case MH_WG_CFG_N1: wgrad_n1_body<9>(p, bid, smem, bred); break;
+        default: break;
     }
 }
 
@@ -618,6 +681,7 @@ static int launch_wgrad_n1(WgradArgs& a, hipStream_t s) {
     a.ktiles = g4p;
     if (a.query) return 0;
     const size_t lds = (size_t)slots * 9 * a.K * sizeof(float);          // <= 36 KiB
+    if (t_capture) { t_capture->cfg = MH_WG_CFG_N1; t_capture->nblocks = a.splits; t_capture->lds = lds; return 0; }
     hipLaunchKernelGGL(wgrad_n1_kernel<9>, dim3(a.splits), dim3(256), lds, s, a);
     return mh_check_launch("wgrad_n1");
 }
@@ -650,14 +714,19 @@ static int wgrad_dispatch(WgradArgs& a, hipStream_t s) {
 
 }  // namespace
 
+constexpr int MH_WG_GROUP_LDS = 96 * 1024;       // >= the largest tile shape's need (128x128 tiles, flat tables: 90 112 B)
 int mh_wgrad_init() {
     WgradArgs a{};
     a.M = -1; a.K = 1; a.N = 1;
-    return wgrad_dispatch(a, nullptr);
+    if (int rc = wgrad_dispatch(a, nullptr)) return rc;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MH_WG_GROUP_LDS);
+    if (e != hipSuccess) { mh_set_error("wgrad_group: hipFuncSetAttribute(%d B LDS): %s", MH_WG_GROUP_LDS, hipGetErrorString(e)); return (int)e; }
+    return 0;
 }
 
 static int wgrad_entry(const mh_conv_desc* d, const float* in, const float* dout, int32_t dout_ld, float* dw, float* db,
-                       float* ws, int forced_splits, int query, int* splits_out, void* stream) {
+                       float* ws, int forced_splits, int query, int* splits_out, void* stream,
+                       WgradArgs* out_args = nullptr, WgradCapture* cap = nullptr) {
     MH_REQUIRE(d && in && dout && (dw || ws || query), MH_ERR_ARG, "mh_conv2d_wgrad: null argument");
     MH_REQUIRE(d->mode == 0, MH_ERR_ARG, "mh_conv2d_wgrad: descriptor must be the forward (mode 0) geometry");
     MH_REQUIRE(d->B > 0 && d->Hi > 0 && d->Wi > 0 && d->Ho > 0 && d->Wo > 0 && d->K > 0 && d->N > 0,
@@ -685,8 +754,11 @@ static int wgrad_entry(const mh_conv_desc* d, const float* in, const float* dout
         MH_REQUIRE(inb < (1ll << 31) - 64 && dzb < (1ll << 31) - 64, MH_ERR_UNSUPPORTED, "mh_conv2d_wgrad: tensors must be < 2 GiB");
         a.in_bytes = (unsigned)inb; a.dz_bytes = (unsigned)dzb;
     }
+    t_capture = cap;
     const int rc = wgrad_n1_ok(a) ? launch_wgrad_n1(a, (hipStream_t)stream) : wgrad_dispatch(a, (hipStream_t)stream);
+    t_capture = nullptr;
     if (splits_out) *splits_out = a.splits;
+    if (out_args) *out_args = a;
     return rc;
 }
 
@@ -706,6 +778,57 @@ extern "C" int mh_conv2d_wgrad_partial(const mh_conv_desc* d, const float* in, c
     if (rc) return rc;
     MH_REQUIRE(used == want, MH_ERR_ARG, "mh_conv2d_wgrad_partial: split count %d does not match this geometry (%d)", want, used);
     return wgrad_entry(d, in, dout, dout_ld, nullptr, db, ws, want, 0, nullptr, stream);
+}
+
+// Several layers' partial filter gradients in ONE launch (they are independent: different workspaces, different biases).  A step of the
+// engines issues the filter gradients of a whole pyramid level / estimator as one batch; at 1/16-1/64 resolution each of those launches
+// is a handful of workgroups that costs its dispatch latency, not its work.  Exact-fp32 layers and leftovers go out one by one.
+extern "C" int mh_conv2d_wgrad_partial_group(const mh_wgrad_item* items, int32_t n, void* stream) {
+    MH_REQUIRE(items && n > 0, MH_ERR_ARG, "mh_conv2d_wgrad_partial_group: empty item list");
+    static const int group_on = []() { const char* e = getenv("MH_WGRAD_GROUP"); return e ? atoi(e) : 1; }();      // A/B hook
+    WgradGroup G;            // ~1.5 KB: built on the host, passed by value as the kernel argument
+    G.n = 0; G.blk0[0] = 0;
+    size_t lds = 0;
+    int first = -1;
+    auto single = [&](const mh_wgrad_item& it) -> int {
+        int32_t sp = it.splits;
+        return mh_conv2d_wgrad_partial(&it.d, it.in, it.dout, it.dout_ld, it.ws, &sp, it.db, stream);
+    };
+    auto flush = [&]() -> int {
+        int rc = 0;
+        if (G.n == 1) rc = single(items[first]);
+        else if (G.n > 1) {
+            mh_note_kernel("wgrad_group_kernel layers %d grid %d lds %d", G.n, G.blk0[G.n], (int)lds);
+            hipLaunchKernelGGL(wgrad_group_kernel, dim3(G.blk0[G.n]), dim3(256), lds, (hipStream_t)stream, G);
+            rc = mh_check_launch("wgrad_group");
+        }
+        G.n = 0; G.blk0[0] = 0; lds = 0; first = -1;
+        return rc;
+    };
+    for (int i = 0; i < n; ++i) {
+        const mh_wgrad_item& it = items[i];
+        MH_REQUIRE(it.ws && it.splits > 0, MH_ERR_ARG, "mh_conv2d_wgrad_partial_group: item %d: ws / splits must come from a query call", i);
+        int used = 0;
+        if (int rc = wgrad_entry(&it.d, it.in, it.dout, it.dout_ld, nullptr, nullptr, nullptr, it.splits, 1, &used, stream)) return rc;
+        MH_REQUIRE(used == it.splits, MH_ERR_ARG, "mh_conv2d_wgrad_partial_group: item %d: split count %d does not match this geometry (%d)", i, it.splits, used);
+        WgradArgs a; WgradCapture c{-1, 0, 0};
+        if (int rc = wgrad_entry(&it.d, it.in, it.dout, it.dout_ld, nullptr, it.db, it.ws, it.splits, 0, nullptr, stream, &a, &c)) return rc;
+        // grouped: layers whose own launch is dispatch-latency bound (<= max_m reduction pixels: 1/8 resolution and below).  The big layers
+        // fill the chip alone, and as one long grid they only coarsen the interleaving with the input-gradient chain (measured: +1.5 %
+        // step time with everything grouped); 1- and 2-wave tile shapes would idle most of a 256-thread workgroup.
+        static const int max_m = []() { const char* e = getenv("MH_WGRAD_GROUP_MAXM"); return e ? atoi(e) : 16384; }();
+        const bool narrow = (c.cfg == 8 || c.cfg == 10 || c.cfg == 11);
+        if (!group_on || c.cfg < 0 || narrow || a.M > max_m || c.lds > (size_t)MH_WG_GROUP_LDS || c.nblocks <= 0) {
+            if (int rc = single(it)) return rc;
+            continue;
+        }
+        if (G.n == 0) first = i;
+        G.cfg[G.n] = c.cfg; G.nblk[G.n] = c.nblocks; G.a[G.n] = a;
+        G.blk0[G.n + 1] = G.blk0[G.n] + ((c.nblocks + 7) & ~7);
+        if (c.lds > lds) lds = c.lds;
+        if (++G.n == MH_WG_GROUP_MAX) { if (int rc = flush()) return rc; }
+    }
+    return flush();
 }
 
 // ---- reduction of the per-split partial filter gradients (one launch for every layer of a step) --------

@@ -30,7 +30,7 @@ class Op(C.Structure):
 
 (OP_CONV, OP_WGRAD, OP_CORR_FWD, OP_CORR_BWD, OP_WARP_FWD, OP_WARP_BWD, OP_RESIZE_FWD, OP_RESIZE_BWD,
  OP_PAD_REFLECT, OP_LOSS, OP_METRICS, OP_MOMENTUM, OP_COPY_CH, OP_LEAKY_BWD, OP_FILL, OP_BIAS_GRAD,
- OP_WGRAD_PARTIAL, OP_WGRAD_REDUCE, OP_PROXY_LOSS, OP_SUPERVISED_LOSS, OP_ADAM, OP_ADAM_ADVANCE, OP_RESIZE_IMAGE, OP_LEVEL_FRONT, OP_TRANSPOSE_W) = range(1, 26)
+ OP_WGRAD_PARTIAL, OP_WGRAD_REDUCE, OP_PROXY_LOSS, OP_SUPERVISED_LOSS, OP_ADAM, OP_ADAM_ADVANCE, OP_RESIZE_IMAGE, OP_LEVEL_FRONT, OP_TRANSPOSE_W, OP_PACK_W) = range(1, 27)
 
 
 OP_JOIN = 0x100
@@ -44,6 +44,15 @@ class TransposeSeg(C.Structure):
 class WgradSeg(C.Structure):
     _fields_ = [("ws", C.c_void_p), ("dst", C.c_void_p), ("size", C.c_int32), ("splits", C.c_int32),
                 ("blk0", C.c_int32), ("accumulate", C.c_int32)]
+
+class PackSeg(C.Structure):          # mh_pack_seg
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("taps", C.c_int32), ("K", C.c_int32), ("N", C.c_int32),
+                ("planes", C.c_int32), ("blk0", C.c_int32), ("pad", C.c_int32)]
+
+
+class WgradItem(C.Structure):        # mh_wgrad_item
+    _fields_ = [("d", ConvDesc), ("inp", C.c_void_p), ("dout", C.c_void_p), ("ws", C.c_void_p), ("db", C.c_void_p),
+                ("dout_ld", C.c_int32), ("splits", C.c_int32)]
 
 _P = C.c_void_p
 _I = C.c_int32
@@ -69,6 +78,11 @@ SIGNATURES = {
     "mh_tune_conv_direct": (_I, [_I]),
     "mh_conv2d_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _I, _P, _P, _P]),
     "mh_conv2d_wgrad_partial": (_I, [C.POINTER(ConvDesc), _P, _P, _I, _P, C.POINTER(C.c_int32), _P, _P]),
+    "mh_conv2d_wb": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "mh_pack_weights": (_I, [_P, _I, _I, _P]),
+    "mh_pack_bytes": (_L, [_I, _I, _I, _I]),
+    "mh_tune_conv_bank": (_I, [_I]),
+    "mh_conv2d_wgrad_partial_group": (_I, [C.POINTER(WgradItem), _I, _P]),
     "mh_wgrad_reduce": (_I, [_P, _I, _I, _P]),
     "mh_proxy_ws_floats": (_L, [_I, _I, _I]),
     "mh_proxy_loss": (_I, [_P, _P, _P, _P, _P, _F, _F, _I, _I, _I, _P]),
@@ -112,7 +126,7 @@ SIGNATURES = {
     "mh_event_destroy": (_I, [_P]),
     "mh_stream_sync": (_I, [_P]),
 }
-_NO_STATUS = {"mh_last_error", "mh_last_kernel", "mh_tune_conv_direct", "mh_abi_version", "mh_tune_conv_patch", "mh_crc32c", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats", "mh_proxy_ws_floats"}
+_NO_STATUS = {"mh_last_error", "mh_last_kernel", "mh_tune_conv_direct", "mh_tune_conv_bank", "mh_pack_bytes", "mh_abi_version", "mh_tune_conv_patch", "mh_crc32c", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats", "mh_proxy_ws_floats"}
 
 
 class MadnetHipError(RuntimeError):

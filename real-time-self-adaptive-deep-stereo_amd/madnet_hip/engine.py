@@ -80,6 +80,11 @@ def madnet_manifest(radius_d=2, stride=1):
     return out
 
 
+# pyramid layers after whose input gradient the pending filter gradients are issued in addition to every 4th layer: the last batch
+# (conv4..conv1, half / full resolution) otherwise starts only after the LAST input gradient and runs alone as the step's tail
+PYR_TAIL_FLUSH = tuple(int(x) for x in os.environ.get("MH_PYR_TAIL_FLUSH", "3,2").split(",") if x)
+
+
 class Params(object):
     """Flat fp32 weight / momentum / gradient buffers + name -> (offset, shape) manifest."""
 
@@ -164,6 +169,10 @@ class MadNetEngine(object):
         # bf16 / mixed: hand every forward conv the transposed filter bank too, so that the small layers can take the LDS-free kernel
         # (EXPERIMENT, off by default: the LDS-free kernel measured slower, csrc/conv_direct.hip -- MH_CONV_DIRECT=1 / 2 enables it)
         self.use_direct = precision != "fp32" and os.environ.get("MH_CONV_DIRECT", "0") != "0"
+        # split-bf16 3x3 layers of the 1/4- and 1/8-resolution estimators and the context network stream their weights from MFMA
+        # fragment banks (mh_conv2d_wb), re-packed by ONE launch at the start of every step
+        self.use_bank = precision == "mixed" and os.environ.get("MH_CONV_BANK", "1") != "0"
+        self.banks = {}
         self.wsa = ops.WgradWorkspace(device)
 
     # ---------------------------------------------------------------------------------------
@@ -249,6 +258,15 @@ class MadNetEngine(object):
     def b_(self, base):
         return self.params.tensor(base + "/biases")
 
+    def Wb_(self, base):
+        """MFMA fragment bank of the layer (None: the layer does not run a bank kernel)"""
+        return self.banks.get(base)
+
+    def _bank_layers(self):
+        names = [est_name(k, j) for k in LEVELS if k < 4 for j in range(1, 7)] + [ctx_name(j) for j in range(1, 8)]
+        shapes = dict(self.params.manifest)
+        return [n for n in names if shapes[n + "/weights"][0] == 3 and shapes[n + "/weights"][2] >= 32 and shapes[n + "/weights"][3] >= 48]
+
     def Wt_(self, base):
         """transposed view of the layer's filter bank (None in the fp32 mode: the exact-fp32 path has no LDS-free kernel)"""
         if not self.use_direct:
@@ -265,6 +283,11 @@ class MadNetEngine(object):
         if self.use_direct:
             names = [n for n, shp in self.params.manifest if n.endswith("/weights") and shp[3] >= 16 and shp[2] % 8 == 0]
             ops.transpose_weights(lib, [(self.params.tensor(n), self.Wt_(n[:-len("/weights")])) for n in names], self.dev, r.keep)
+        if self.use_bank:
+            if not self.banks:
+                for n in self._bank_layers():
+                    self.banks[n] = torch.zeros(ops.pack_bytes(self.W_(n)) // 4, device=self.dev)
+            ops.pack_weights(lib, [(self.W_(n), self.banks[n]) for n in self._bank_layers()], self.dev, r.keep)
         ops.pad_reflect(lib, self.left, self.X0[:B], self.pt, self.pl)
         ops.pad_reflect(lib, self.right, self.X0[B:], self.pt, self.pl)
         x = ops.View(self.X0, 2 * B, self.Hp, self.Wp, 3, 4)
@@ -299,7 +322,8 @@ class MadNetEngine(object):
                 last = j == len(EST) - 1
                 o = self._fv(self.V[k]) if last else self._fv(self.E[k][j])
                 ops.conv2d_fwd(lib, x, self.W_(est_name(k, j + 1)), self.b_(est_name(k, j + 1)), o,
-                               alpha=(1.0 if last else ALPHA), precision=fprec, wt=self.Wt_(est_name(k, j + 1)))
+                               alpha=(1.0 if last else ALPHA), precision=fprec, wt=self.Wt_(est_name(k, j + 1)),
+                               wb=(self.Wb_(est_name(k, j + 1)) if fprec is None else None))
                 x = o
             if k != 2:
                 sc = 2 ** (k - 1)
@@ -315,7 +339,8 @@ class MadNetEngine(object):
         x = cin
         for j, (co, rate) in enumerate(CTX[:-1]):
             o = self._fv(self.Cx[j])
-            ops.conv2d_fwd(lib, x, self.W_(ctx_name(j + 1)), self.b_(ctx_name(j + 1)), o, dil=rate, alpha=ALPHA, wt=self.Wt_(ctx_name(j + 1)))
+            ops.conv2d_fwd(lib, x, self.W_(ctx_name(j + 1)), self.b_(ctx_name(j + 1)), o, dil=rate, alpha=ALPHA, wt=self.Wt_(ctx_name(j + 1)),
+                           wb=self.Wb_(ctx_name(j + 1)))
             x = o
         # final_disp = V2_init + context7  (accumulating epilogue)
         ops.copy_channels(lib, self._fv(self.V[2]), self._fv(self.final))
@@ -593,7 +618,7 @@ class MadNetEngine(object):
                     ops.conv2d_dgrad(lib, self._fv(self.dF[i]), self.W_(pyr_name(i)), self._fv(self.dF[i - 1]),
                                      stride=PYR[i - 1][2], accumulate=accumulate, mask_ref=self._fv(self.F[i - 1]),
                                      mask_alpha=ALPHA)
-                if i % 4 == 1:
+                if i % 4 == 1 or i in PYR_TAIL_FLUSH:
                     flush()
         flush()
         ops.wgrad_reduce(lib, segs, self.dev, r.keep)          # (serial variant only: the side-lane batches reduce themselves)

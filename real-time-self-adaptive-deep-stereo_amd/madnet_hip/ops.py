@@ -110,15 +110,18 @@ def conv_geometry(H, W, kh, kw, stride, dil):
 
 
 def conv2d_fwd(lib, x, w, b, out, stride=1, dil=1, alpha=1.0, accumulate=False, mask_ref=None, mask_alpha=1.0,
-               mask_range=(0, 0), stream=None, precision=None, wt=None):
-    """out (+)= leaky(conv2d_SAME(x, w) + b) [* leaky'(mask_ref)].  x,out: View; w: HWIO [kh,kw,Cin,Cout]."""
+               mask_range=(0, 0), stream=None, precision=None, wt=None, wb=None):
+    """out (+)= leaky(conv2d_SAME(x, w) + b) [* leaky'(mask_ref)].  x,out: View; w: HWIO [kh,kw,Cin,Cout].
+    wb: the layer's MFMA fragment bank (pack_weights) -- split-bf16 3x3 layers then stream their weights from it."""
     kh, kw, cin, cout = w.shape
     Ho, Wo, pt, pl = conv_geometry(x.H, x.W, kh, kw, stride, dil)
     assert (out.H, out.W, out.C) == (Ho, Wo, cout) and x.C == cin
     d = conv_desc(x.B, x.H, x.W, Ho, Wo, cin, cout, kh, kw, stride, dil, pt, pl, 0, 0, x.ld, out.ld, alpha=alpha,
                   mask_ld=(mask_ref.ld if mask_ref is not None else 0), accumulate=int(accumulate), mask_alpha=mask_alpha,
                   mask_c0=mask_range[0], mask_c1=mask_range[1], precision=precision)
-    if wt is not None:       # wt: the transposed filter bank [tap][Cout][Cin] (transpose_weights): lets the small layers run LDS-free
+    if wb is not None:
+        lib.conv2d_wb(C.byref(d), _p(x), _p(w), _p(wb), _p(b), _p(out), _p(mask_ref), _p(stream))
+    elif wt is not None:       # wt: the transposed filter bank [tap][Cout][Cin] (transpose_weights): lets the small layers run LDS-free
         lib.conv2d_wt(C.byref(d), _p(x), _p(w), _p(wt), _p(b), _p(out), _p(mask_ref), _p(stream))
     else:
         lib.conv2d(C.byref(d), _p(x), _p(w), _p(b), _p(out), _p(mask_ref), _p(stream))
@@ -138,6 +141,29 @@ def transpose_weights(lib, pairs, device, keep, stream=None):
     table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
     keep.append(table)
     lib.transpose_weights(C.c_void_p(table.data_ptr()), len(pairs), blk, _p(stream))
+
+
+def pack_bytes(w, planes=2):
+    kh, kw, K, N = w.shape
+    return kh * kw * ((K + 31) // 32) * ((N + 15) // 16) * planes * 1024
+
+
+def pack_weights(lib, pairs, device, keep, stream=None, planes=2):
+    """pairs: [(src HWIO tensor, dst uint8/any tensor of pack_bytes(src) bytes)] -> every dst = the MFMA fragment bank of src
+    (include/madnet_hip.h: mh_pack_weights), ONE launch.  `keep`: list that keeps the device table alive as long as the plan."""
+    if not pairs:
+        return
+    arr = (_ffi.PackSeg * len(pairs))()
+    blk = 0
+    for i, (src, dst) in enumerate(pairs):
+        kh, kw, K, N = src.shape
+        assert dst.numel() * dst.element_size() >= pack_bytes(src, planes) and dst.data_ptr() % 16 == 0
+        arr[i].src, arr[i].dst, arr[i].taps, arr[i].K, arr[i].N = src.data_ptr(), dst.data_ptr(), kh * kw, K, N
+        arr[i].planes, arr[i].blk0 = planes, blk
+        blk += (kh * kw * ((K + 31) // 32) * ((N + 15) // 16) * 64 + 255) // 256
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+    keep.append(table)
+    lib.pack_weights(C.c_void_p(table.data_ptr()), len(pairs), blk, _p(stream))
 
 
 def conv2d_dgrad(lib, dz, w, dx, stride=1, dil=1, accumulate=False, mask_ref=None, mask_alpha=1.0, mask_range=(0, 0),

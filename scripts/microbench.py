@@ -192,6 +192,46 @@ def run_x3dbg():
         print("%-16s %s | %9.1f %9.1f   (x3 %.0f TF/s algorithmic)" % (name, " ".join("%9.1f" % r for r in res[:5]), res[5], res[6], flops / (res[0] * 1e-6) / 1e12))
 
 
+def run_bank():
+    """split-bf16 forward: LDS-staged weights (conv_patch_kernel X3) vs the fragment-bank kernel (mh_conv2d_wb), with the bank kernel's
+    phase breakdown (no K walk / no staging) and the pack launch for the 13 bank layers of MADNet."""
+    PL = [("L2 128->128 d1", 1, 96, 320, 128, 128, 1), ("L2 128->128 d2", 1, 96, 320, 128, 128, 2), ("L2 128->128 d8", 1, 96, 320, 128, 128, 8),
+          ("L2 128->96", 1, 96, 320, 128, 96, 1), ("L2 96->64", 1, 96, 320, 96, 64, 1), ("L2 38->128", 1, 96, 320, 38, 128, 1),
+          ("L3 128->128", 1, 48, 160, 128, 128, 1), ("L3 70->128", 1, 48, 160, 70, 128, 1), ("L4 128->128", 1, 24, 80, 128, 128, 1)]
+    print("%-16s %9s | %9s %9s %9s %9s   %s" % ("layer (fwd)", "x3 LDS", "x3 bank", "bank noK", "bank nostg", "bank 128px", "max |diff|"))
+    for name, B, H, W, Ci, Co, d in PL:
+        ld = (Ci + 3) // 4 * 4
+        xb = torch.zeros(B, H, W, ld, device=dev); xb[..., :Ci] = torch.randn(B, H, W, Ci, device=dev); xv = ops.View(xb, B, H, W, Ci, ld)
+        w = torch.randn(3, 3, Ci, Co, device=dev) * 0.05; b = torch.randn(Co, device=dev)
+        y = torch.empty(B, H, W, Co, device=dev); y2 = torch.empty(B, H, W, Co, device=dev)
+        bank = torch.zeros(ops.pack_bytes(w) // 4, device=dev); keep = []
+        ops.pack_weights(lib, [(w, bank)], dev, keep)
+        flops = 2.0 * B * H * W * 9 * Ci * Co
+        res = []
+        ops.PRECISION = 2
+        for m, wb, out in ((128, None, y), (128, bank, y2), (128 + 512, bank, y2), (128 + 1024, bank, y2), (128 + 0x8000, bank, y2)):
+            lib.tune_conv_patch(m)
+            with torch.cuda.stream(stream):
+                res.append(_time_ms(lib, stream, lambda: ops.conv2d_fwd(lib, xv, w, b, ops.view(out), stride=1, dil=d, alpha=0.2, stream=stream.cuda_stream, wb=wb), 20) * 1e3)
+        lib.tune_conv_patch(128)
+        ops.conv2d_fwd(lib, xv, w, b, ops.view(y2), stride=1, dil=d, alpha=0.2, wb=bank)
+        ops.conv2d_fwd(lib, xv, w, b, ops.view(y), stride=1, dil=d, alpha=0.2)
+        torch.cuda.synchronize()
+        ops.PRECISION = 0
+        lib.tune_conv_patch(-1)
+        print("%-16s %9.1f | %9.1f %9.1f %9.1f %9.1f   %.3g   (bank %.0f TF/s algorithmic, %s)" % (name, res[0], res[1], res[2], res[3], res[4], (y - y2).abs().max().item(),
+              flops / (res[1] * 1e-6) / 1e12, lib.last_kernel().decode()[:60]))
+    shapes = [(38, 128), (128, 128), (128, 96), (96, 64), (70, 128), (128, 128), (128, 96), (96, 64), (33, 128), (128, 128), (128, 128), (128, 96), (96, 64)]
+    ws = [torch.randn(3, 3, k, n, device=dev) for k, n in shapes]
+    banks = [torch.zeros(ops.pack_bytes(w) // 4, device=dev) for w in ws]
+    keep = []
+    with torch.cuda.stream(stream):
+        t = _time_ms(lib, stream, lambda: ops.pack_weights(lib, list(zip(ws, banks)), dev, keep, stream=stream.cuda_stream), 20) * 1e3
+    print("mh_pack_weights, 13 layers (%.1f MB of banks): %.1f us" % (sum(b.numel() * 4 for b in banks) / 1e6, t))
+
+
+if what == "bank":
+    run_bank()
 if what == "x3dbg":
     run_x3dbg()
 if what == "patchdbg":

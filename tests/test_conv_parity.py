@@ -549,3 +549,87 @@ def test_conv_direct_kernel(backend, case, prec):
         assert "conv_direct" not in backend.lib.last_kernel().decode()
     finally:
         backend.lib.tune_conv_direct(-1)
+
+
+GROUP_LAYERS = [   # (H, W, Cin, Cout, stride, dil, precision): one batch = the filter gradients a pyramid level issues together
+    (12, 20, 128, 128, 1, 1, 1), (12, 20, 128, 96, 1, 1, 1), (12, 20, 96, 64, 1, 1, 1), (12, 20, 64, 32, 1, 1, 1), (12, 20, 32, 1, 1, 1, 1),
+    (12, 20, 38, 128, 1, 2, 1), (12, 20, 16, 16, 2, 1, 1), (12, 20, 3, 16, 2, 1, 1), (12, 20, 16, 32, 1, 1, 0), (12, 20, 32, 64, 1, 1, 1),
+]
+
+
+def test_wgrad_partial_group_matches_single_launches(backend):
+    """mh_conv2d_wgrad_partial_group (what mh_plan_run issues for consecutive partial-filter-gradient ops of one lane): the same layers in
+    ONE grid must give bit-identical partial sums to one launch per layer (the per-workgroup arithmetic is the same code); bias
+    gradients are atomics across workgroups -> compared with a tolerance.  10 layers = two grids of <= 8 + an exact-fp32 layer
+    and leftovers that go out alone."""
+    from madnet_hip import plan as PL
+    dev = backend.device
+    res = {}
+    for how in ("single", "plan"):
+        wsa = ops.WgradWorkspace(dev); wsa.CHUNK = 1 << 20
+        rec = PL.Recorder() if how == "plan" else None
+        tgt = rec if rec is not None else backend.lib
+        segs, keep, outs = [], [], []
+        for li, (H, W, Ci, Co, s, d, prec) in enumerate(GROUP_LAYERS):
+            x = _rand((1, H, W, Ci), 100 + li, dev)
+            Ho, Wo, _, _ = ops.conv_geometry(H, W, 3, 3, s, d)
+            gz = _rand((1, Ho, Wo, Co), 200 + li, dev)
+            xb, xv = _padded(x, (Ci + 3) // 4 * 4)
+            zb, zv = _padded(gz, (Co + 3) // 4 * 4)
+            dw = torch.full((3, 3, Ci, Co), float("nan"), device=dev); db = torch.zeros(Co, device=dev)
+            ops.PRECISION_BWD = prec
+            ops.PRECISION = prec
+            try:
+                ops.conv2d_wgrad_partial(tgt, backend.lib, wsa, segs, xv, zv, dw, db, stride=s, dil=d)
+            finally:
+                ops.PRECISION = 0
+                ops.PRECISION_BWD = None
+            outs.append((dw, db)); keep += [xb, zb]
+        ops.wgrad_reduce(tgt, segs, dev, keep)
+        if rec is not None:
+            pl = rec.compile()
+            assert pl.n == len(GROUP_LAYERS) + 1
+            pl.run(backend.lib, None)
+        backend.sync()
+        res[how] = [(a.cpu().clone(), b.cpu().clone()) for a, b in outs]
+    for li, ((dw1, db1), (dw2, db2)) in enumerate(zip(res["single"], res["plan"])):
+        assert torch.isfinite(dw1).all() and torch.isfinite(dw2).all(), li
+        assert torch.equal(dw1, dw2), (li, (dw1 - dw2).abs().max().item())
+        assert (db1 - db2).abs().max().item() <= 1e-4 * max(1.0, db1.abs().max().item()), li
+
+
+@pytest.mark.parametrize("case", X3_CASES)
+def test_conv_split_bf16_fragment_bank_kernel(backend, case):
+    """mh_conv2d_wb: the split-bf16 forward kernel that streams its weight operand from the MFMA fragment bank mh_pack_weights writes
+    (no LDS staging of the weights, no barrier in the K walk).  Same arithmetic, same summation order as the LDS-staged split-bf16
+    kernel -> compared bit for bit with it, and against the unrounded fp64 oracle at the 2^-16 level."""
+    B, H, W, Ci, Co, dil = case
+    dev = backend.device
+    x = _rand((B, H, W, Ci), 111, dev)
+    w = _rand((3, 3, Ci, Co), 112, dev, 0.2)
+    b = _rand((Co,), 113, dev)
+    y_ref = T.conv2d(x.cpu().double(), w.cpu().double(), b.cpu().double(), stride=1, dilation=dil, alpha=0.2).float()
+    ld = (Ci + 3) // 4 * 4
+    xb, xv = _padded(x, ld)
+    if ld != Ci:
+        xb[..., Ci:] = float("nan")
+    bank = torch.full((ops.pack_bytes(w) // 4,), float("nan"), device=dev)
+    assert ops.pack_bytes(w) == backend.lib.pack_bytes(9, Ci, Co, 2)
+    keep = []
+    ops.pack_weights(backend.lib, [(w, bank)], dev, keep)
+    backend.lib.tune_conv_patch(128)          # forced: these shapes are far below the pixel-count heuristic
+    backend.lib.tune_conv_bank(0)
+    try:
+        y = torch.full(y_ref.shape, float("nan"), device=dev)
+        y0 = torch.full(y_ref.shape, float("nan"), device=dev)
+        with ops.precision_scope("mixed"):
+            ops.conv2d_fwd(backend.lib, xv, w, b, ops.view(y), stride=1, dil=dil, alpha=0.2, wb=bank)
+            nb = backend.lib.tune_conv_bank(0)
+            ops.conv2d_fwd(backend.lib, xv, w, b, ops.view(y0), stride=1, dil=dil, alpha=0.2)
+        backend.sync()
+    finally:
+        launches = backend.lib.tune_conv_patch(-1)
+    assert nb == 1 and launches == 2 and backend.lib.tune_conv_bank(0) == 0
+    err = (y.cpu() - y_ref).abs().max().item()
+    assert err <= 4e-5 * max(1.0, y_ref.abs().max().item()), err
+    assert torch.equal(y.cpu(), y0.cpu()), (y.cpu() - y0.cpu()).abs().max().item()
