@@ -97,7 +97,9 @@ int mh_transpose_weights(const mh_transpose_seg* segs_device, int32_t nseg, int3
  * wb = the image mh_pack_weights writes -- bank[(tap * ceil(K/32) + chunk)][16-column tile][plane hi, lo][lane 0..63][8 bf16], lane l
  * holding w[tap][32*chunk + 8*(l>>4) .. +7][16*tile + (l&15)], zero padded -- mh_pack_bytes(9, K, N, 2) bytes, 16-byte aligned.  The
  * kernel then streams its weight operand straight from global memory into registers (no LDS staging, no barrier in the K walk).
- * Layers the bank kernel does not cover, and wb = NULL, behave exactly like mh_conv2d.  The bank must be re-packed whenever w changes
+ * Also taken by the small-layer bank kernel (<= 4096 output pixels, K <= 224: 16 waves split the reduction of one 32x32 tile), which
+ * additionally runs precision 1 (bank with planes = 1) and the input gradient (mode 1: bank packed with trans = 1, planes = 1).
+ * Layers the bank kernels do not cover, and wb = NULL, behave exactly like mh_conv2d.  The bank must be re-packed whenever w changes
  * (the engines do it once per step, one launch for every layer).  Same arithmetic as the LDS-staged split-bf16 kernel. */
 int mh_conv2d_wb(const mh_conv_desc* d, const float* in, const float* w, const void* wb, const float* bias,
                  float* out, const float* mask_ref, void* stream);
@@ -107,7 +109,8 @@ typedef struct mh_pack_seg {
     int32_t taps, K, N;
     int32_t planes;       /* 2: hi + lo (split-bf16); 1: hi only */
     int32_t blk0;         /* exclusive prefix sum of ceil(taps*ceil(K/32)*ceil(N/16)*64 / 256) over the table */
-    int32_t pad;
+    int32_t trans;        /* 0: src[tap][K][N] (forward: K = Cin, N = Cout); 1: src[tap][N][K] (the same HWIO bank seen by the input
+                             gradient: K = Cout is the reduction, N = Cin the output column) */
 } mh_pack_seg;
 int64_t mh_pack_bytes(int32_t taps, int32_t K, int32_t N, int32_t planes);
 /* segs_device: table in DEVICE memory; nblocks = the sum the blk0 fields prefix. */
@@ -307,7 +310,7 @@ int mh_tune_conv_tile(int bm, int bn);
 int mh_tune_conv_thin(int min_pixels);   /* weights-stationary thin-layer kernel from this many output pixels (0 = default, < 0 = never) */
 int mh_tune_conv_direct(int mode);       /* experimental LDS-free small-layer kernel: 0 = off (default: measured slower than the tiled kernel), 1 = size heuristic, 2 = forced whenever eligible; returns its launch count since the previous call */
 int mh_tune_conv_patch(int mode);        /* patch-staged bf16 kernel of the stride-1 3x3 layers: 0 = off, 1 = on (tile heuristic), 64 / 128 = forced pixel tile, +256 = 8-wave variant, +2048 = generic-K instances only, +4096 = forward layers only, +8192 = no generic-K input gradients, < 0 = built-in default; returns the number of launches of that kernel since the previous call */
-int mh_tune_conv_bank(int reset);        /* returns the number of fragment-bank kernel launches (mh_conv2d_wb) since the previous call */
+int mh_tune_conv_bank(int small_maxpix); /* fragment-bank kernels (mh_conv2d_wb): the small-layer kernel takes layers of up to this many output pixels (0 = never, < 0 = default 4096 / MH_CONV_BANK_SMALL_MAXPIX); returns the number of bank-kernel launches since the previous call */
 int mh_tune_wgrad_wgs(int target_workgroups);
 int mh_tune_corr(int direct);
 

@@ -54,6 +54,13 @@ __device__ __forceinline__ int swz_group(int row, int g) { return g ^ ((row >> 2
 // interleave KG such instruction streams per SIMD.
 template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool VEC, bool UNI, bool BF16, int KG = 1>
 __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
+#ifdef MH_PHASE_TIMING
+    const unsigned long long ts0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
+#define MH_STAMP(v) v = __builtin_amdgcn_s_memtime()
+#else
+#define MH_STAMP(v)
+#endif
     constexpr int BM = WM * MT * 16;
     constexpr int BN = WN * NT * 16;
     // LDS row stride (elements: floats / bf16).  bf16: 80 halfs = 40 dwords: with the b128 lane groups of gfx950 a 36-dword
@@ -214,6 +221,7 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
     int kb0 = 0, kb1 = 0, kb2 = 0, kb3 = 0;     // kbase of the A group held by each stage (padding select at store time)
 
     __syncthreads();   // tap tables visible
+    MH_STAMP(ts1);
 
     const __amdgpu_buffer_rsrc_t rs_in = mh_make_rsrc(p.in, p.in_bytes);
     const __amdgpu_buffer_rsrc_t rs_w = mh_make_rsrc(p.w, p.w_bytes);
@@ -460,6 +468,7 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
         load_tile(ra1, rb1, kb1);            // tile 1
         store_tile(0, ra0, rb0, kb0);
         __syncthreads();
+        MH_STAMP(ts2);
         for (int t = 0; t < ntile; t += 2) {
             load_tile(ra0, rb0, kb0);        // tile t+2
             compute_tile(0);                 // tile t
@@ -483,6 +492,7 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
         }
     }
 
+    MH_STAMP(ts3);
     // ---- epilogue: bias + leaky (+ accumulate) (+ fused leaky-grad mask) ------------------
     // Fast path: the accumulator tile goes through LDS (free after the K loop) so that every lane
     // owns 4 consecutive output channels: bias / old / mask are read and the result is written
@@ -500,6 +510,7 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
                 for (int r = 0; r < 4; ++r)
                     Cs[(wm * MT * 16 + i * 16 + lq * 4 + r) * CS + wn * NT * 16 + j * 16 + li] = acc[i][j][r];
         __syncthreads();
+        MH_STAMP(ts4);
         if (kg != 0) return;                               // group 0 sums the partial tiles while it reads them (no barrier below)
         constexpr int C4 = BN / 4;                         // float4 per tile row
         constexpr int RP = 256 / C4;                       // tile rows per pass (threads >= RP*C4 idle)
@@ -539,6 +550,14 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
             }
             if (ok) *reinterpret_cast<float4*>(p.out + (int64_t)m * p.out_ld + n) = v;
         }
+#ifdef MH_PHASE_TIMING
+        if (p.dbg && threadIdx.x == 0) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);            // the stores have been acknowledged
+            unsigned long long* d = p.dbg + (size_t)blockIdx.x * 8;
+            d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = ts3; d[4] = ts4; d[5] = __builtin_amdgcn_s_memtime();
+            d[6] = tr0; d[7] = __builtin_amdgcn_s_memrealtime();
+        }
+#endif
         return;
     }
     static_assert(KG == 1 || VEC, "the split-K variant needs the vector epilogue");
@@ -936,7 +955,8 @@ static int conv_dispatch(ConvArgs& a, hipStream_t s) {
 int mh_conv_init() {
     ConvArgs a{};
     a.M = -1; a.N = 1;
-    const int rc = mh_conv_patch_launch(a, nullptr);
+    int rc = mh_conv_patch_launch(a, nullptr);
+    if (!rc) rc = mh_conv_bank_small_launch(a, nullptr);
     return rc ? rc : conv_dispatch(a, nullptr);
 }
 
@@ -947,6 +967,10 @@ extern "C" int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w,
 
 static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, const float* wt, const void* wb, const float* bias,
                       float* out, const float* mask_ref, void* stream);
+#ifdef MH_PHASE_TIMING
+static unsigned long long* g_conv_dbg = nullptr;
+extern "C" int mh_tune_conv_dbg(void* buf) { g_conv_dbg = (unsigned long long*)buf; return 0; }
+#endif
 extern "C" int mh_conv2d_wt(const mh_conv_desc* d, const float* in, const float* w, const float* wt, const float* bias,
                             float* out, const float* mask_ref, void* stream) {
     return conv_entry(d, in, w, wt, nullptr, bias, out, mask_ref, stream);
@@ -966,8 +990,12 @@ static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, co
     MH_REQUIRE((int64_t)d->B * d->Ho * d->Wo < (1ll << 31), MH_ERR_ARG, "mh_conv2d: too many output pixels");
     ConvArgs a;
     a.in = in; a.w = w; a.bias = bias; a.out = out; a.mask_ref = mask_ref;
-    a.wb = (wb && mh_aligned16(wb) && d->mode == 0 && d->precision == 2) ? wb : nullptr;
-    a.wb_bytes = a.wb ? (unsigned)mh_pack_bytes(d->kh * d->kw, d->K, d->N, 2) : 0u;
+#ifdef MH_PHASE_TIMING
+    a.dbg = g_conv_dbg;
+#endif
+    // bank contract: forward = mh_pack_weights(trans 0, planes = 2 for precision 2, 1 for precision 1); mode 1 = (trans 1, 1 plane)
+    a.wb = (wb && mh_aligned16(wb) && (d->precision == 2 ? d->mode == 0 : d->precision == 1)) ? wb : nullptr;
+    a.wb_bytes = a.wb ? (unsigned)mh_pack_bytes(d->kh * d->kw, d->K, d->N, d->precision == 2 ? 2 : 1) : 0u;
     a.in_ld = d->in_ld; a.out_ld = d->out_ld; a.mask_ld = d->mask_ld;
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Ho = d->Ho; a.Wo = d->Wo;
     a.K = d->K; a.N = d->N; a.G = (d->K + 3) / 4; a.taps = d->kh * d->kw;
@@ -1023,6 +1051,7 @@ static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, co
     a.vecB = mh_aligned16(w) && (d->w_trans ? (d->K % 4 == 0) : (d->N % 4 == 0));
     if (conv_n1_ok(a)) return launch_conv_n1(a, (hipStream_t)stream);
     if (conv_thin_ok(a)) return launch_conv_thin(a, (hipStream_t)stream);
+    if (mh_conv_bank_small_ok(a)) return mh_conv_bank_small_launch(a, (hipStream_t)stream);
     if (mh_conv_patch_ok(a)) return mh_conv_patch_launch(a, (hipStream_t)stream);
     if (mh_conv_direct_ok(a, (wt && mh_aligned16(wt)) ? wt : nullptr)) return mh_conv_direct_launch(a, wt, (hipStream_t)stream);
     return conv_dispatch(a, (hipStream_t)stream);

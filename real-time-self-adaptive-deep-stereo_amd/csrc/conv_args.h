@@ -5,6 +5,9 @@
 struct ConvArgs {
     const float* in; const float* w; const float* bias; float* out; const float* mask_ref;
     const void* wb; unsigned wb_bytes;     // fragment bank of w (mh_pack_weights), or null
+#ifdef MH_PHASE_TIMING
+    unsigned long long* dbg;                // experiment build only (scripts/exp/phase_timing.sh): per-workgroup phase time stamps
+#endif
     int in_ld, out_ld, mask_ld;
     int B, Hi, Wi, Ho, Wo;
     int K, N, G, taps;
@@ -30,6 +33,9 @@ struct ConvArgs {
 bool mh_conv_patch_ok(const ConvArgs& a);
 int mh_conv_patch_launch(ConvArgs& a, hipStream_t s);     // a.M < 0: attribute set-up only
 extern "C" int mh_tune_conv_patch(int mode);
+// conv_patch.hip: fragment-bank kernel of the small layers (a.wb = the bank mh_pack_weights wrote for this mode / precision)
+bool mh_conv_bank_small_ok(const ConvArgs& a);
+int mh_conv_bank_small_launch(ConvArgs& a, hipStream_t s);     // a.M < 0: attribute set-up only
 // conv_direct.hip: LDS-free kernel of the small layers (wt = k-fastest transposed filter bank for the forward pass, may be null)
 bool mh_conv_direct_ok(const ConvArgs& a, const float* wt);
 int mh_conv_direct_launch(ConvArgs& a, const float* wt, hipStream_t s);

@@ -734,6 +734,139 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1,
     }
 }
 
+// ---- fragment-bank kernel of the SMALL layers (1/16 - 1/64 resolution: a few hundred output pixels, K = 9 x 32..224) ------------------
+// There a launch is one exposed memory round trip after the other (profiles/r02_experiments.txt #15: 1.5 us prologue, 1.7 us first
+// K-tile, ~1 us per further K-tile pair, 11 us in all for 17 MFLOP).  Here every byte the workgroup needs is requested in the first few
+// hundred cycles: 16 waves share one 32-pixel x 32-column output tile and SPLIT THE REDUCTION -- wave w takes chunks w, w+16, w+32, (w+48)
+// of the (tap, 32-channel) walk, fetches their weight fragments from the bank straight into registers (<= 4 chunks x 2 column tiles, all
+// issued before anything else), the 4 x 18 input patch is staged once by all 1024 threads, then <= 16 (48) MFMAs per wave, the 16 partial
+// tiles meet in LDS and thread e finishes output element e (bias, leaky, accumulate, leaky-gradient mask).
+// DGRAD: in = dz, bank = mh_pack_weights(trans = 1) of the HWIO bank, taps mirrored.  PL = 2: split-bf16 (three MFMAs per product).
+template <bool DGRAD, int PL>
+__global__ __launch_bounds__(1024) void conv_bank_small_kernel(ConvArgs p, PatchGeo g) {
+    constexpr int NTH = 1024, TH = 2, BM = 32, BN = 32, MT = 2, NT = 2, NCH = 4;
+    HIP_DYNAMIC_SHARED(float, smem_all)
+    unsigned short* const Ph = reinterpret_cast<unsigned short*>(smem_all);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int d = p.dil;
+
+    int lin = mh_xcd_remap(blockIdx.x, g.nwg);
+    const int tile_n = lin % g.ntiles_n; lin /= g.ntiles_n;
+    const int ttx = lin % g.tiles_x; lin /= g.tiles_x;
+    const int tty = lin % g.tiles_y; lin /= g.tiles_y;
+    const int cx = lin % d; lin /= d;
+    const int cy = lin % d;
+    const int b = lin / d;
+    const int n0 = tile_n * BN;
+    const int y00 = cy + d * (tty * TH), x00 = cx + d * (ttx * 16);
+
+    const __amdgpu_buffer_rsrc_t rs_in = mh_make_rsrc(p.in, p.in_bytes);
+    const __amdgpu_buffer_rsrc_t rs_b = mh_make_rsrc(p.wb, p.wb_bytes);
+
+    // ---- all weight fragments of this wave's chunks: requested first ------------------------------------------------------
+    const int np16 = (p.N + 15) >> 4;
+    const int stride_b = np16 * PL * 1024;
+    u32x4 fb[NCH][NT][PL];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int q = wave + 16 * c;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int nt = tile_n * (BN / 16) + j;
+            const int off = (q < g.nchunk && nt < np16) ? q * stride_b + nt * PL * 1024 + lane * 16 : MH_OOB;
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl) fb[c][j][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, off == MH_OOB ? MH_OOB : off + pl * 1024, 0, 0);
+        }
+    }
+
+    // ---- stage the 4 x 18 input patch (bf16; hi + lo planes for PL = 2) ---------------------------------------------------
+    {
+        const int kp4 = g.KP >> 2;
+        const int items = (TH + 2) * PW * kp4;
+        for (int q0 = tid; q0 < items; q0 += NTH) {
+            const int c4 = q0 % kp4, pp = q0 / kp4;
+            const int pi = pp / PW, pj = pp - pi * PW;
+            const int iy = y00 + (pi - 1) * d, ix = x00 + (pj - 1) * d;
+            const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi && (c4 < p.G);
+            float4 w = mh_buf_load4(rs_in, ok ? (((b * p.Hi + iy) * p.Wi + ix) * p.in_ld + c4 * 4) * 4 : MH_OOB);
+            w.y = (c4 * 4 + 1 < p.K) ? w.y : 0.f;           // the row padding between K and in_ld is not ours to trust
+            w.z = (c4 * 4 + 2 < p.K) ? w.z : 0.f;
+            w.w = (c4 * 4 + 3 < p.K) ? w.w : 0.f;
+            const int lds = pp * g.PS + c4 * 4;
+            if constexpr (PL == 2) {
+                uint2 hi, lo;
+                mh_split_bf16x2(w.x, w.y, hi.x, lo.x);
+                mh_split_bf16x2(w.z, w.w, hi.y, lo.y);
+                *reinterpret_cast<uint2*>(Ph + lds) = hi;
+                *reinterpret_cast<uint2*>(Ph + g.patch_halfs + lds) = lo;
+            } else
+            *reinterpret_cast<uint2*>(Ph + lds) = make_uint2(mh_pack_bf16(w.x, w.y), mh_pack_bf16(w.z, w.w));
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned short* const Pw = Ph + li * g.PS + lq * 8;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int q = wave + 16 * c;
+        if (q < g.nchunk) {                           // wave uniform
+            const int tap = q / g.CPT, c32 = q - tap * g.CPT;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int oy = DGRAD ? 2 - ky : ky, ox = DGRAD ? 2 - kx : kx;
+            const unsigned short* Ab = Pw + (oy * PW + ox) * g.PS + c32 * 32;
+            u32x4 fa[MT][PL];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int pl = 0; pl < PL; ++pl) fa[i][pl] = *reinterpret_cast<const u32x4*>(Ab + pl * g.patch_halfs + i * PW * g.PS);
+#pragma unroll
+            for (int t = (PL == 2 ? 0 : 2); t < 3; ++t)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = mh_mfma_bf16(fa[i][t == 0 ? PL - 1 : 0], fb[c][j][t == 1 ? PL - 1 : 0], acc[i][j]);
+        }
+    }
+    __syncthreads();                                 // the patch is dead: the partial tiles go over it
+    constexpr int CS = BN + 1;                       // [16 waves][32 rows][33]
+    float* const Cs = smem_all;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Cs[(wave * BM + i * 16 + lq * 4 + r) * CS + j * 16 + li] = acc[i][j][r];
+    __syncthreads();
+    {
+        const int row = tid >> 5, col = tid & 31;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) v += Cs[(w * BM + row) * CS + col];
+        const int n = n0 + col;
+        const int y = y00 + (row >> 4) * d, x = x00 + (row & 15) * d;
+        if (y < p.Ho && x < p.Wo && n < p.N) {
+            const int64_t m = ((int64_t)b * p.Ho + y) * p.Wo + x;
+            if (p.bias) v += p.bias[n];
+            if (p.alpha != 1.0f) v = v > 0.f ? v : p.alpha * v;
+            float* dst = p.out + m * p.out_ld + n;
+            if (p.accumulate) v += *dst;
+            if (p.mask_ref) {
+                const float mk = p.mask_ref[m * p.mask_ld + n];
+                v *= (mk > 0.f || n < p.mask_c0 || n >= p.mask_c1) ? 1.0f : p.mask_alpha;
+            }
+            *dst = v;
+        }
+    }
+}
+
 // fragment bank writer: one thread per (chunk, 16-column tile, lane): 8 k-values of one output column -> 16 bytes per plane
 __global__ __launch_bounds__(256) void pack_weights_kernel(const mh_pack_seg* __restrict__ segs, int nseg) {
     int lo = 0, hi = nseg - 1;
@@ -751,7 +884,8 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const mh_pack_seg* __
     const int k0 = c * 32 + (lane >> 4) * 8, n = nt * 16 + (lane & 15);
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (k0 + j < sg.K && n < sg.N) ? sg.src[((int64_t)tap * sg.K + k0 + j) * sg.N + n] : 0.f;
+    for (int j = 0; j < 8; ++j)
+        v[j] = (k0 + j < sg.K && n < sg.N) ? (sg.trans ? sg.src[((int64_t)tap * sg.N + n) * sg.K + k0 + j] : sg.src[((int64_t)tap * sg.K + k0 + j) * sg.N + n]) : 0.f;
     unsigned hh[4], ll[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) mh_split_bf16x2(v[2 * j], v[2 * j + 1], hh[j], ll[j]);
@@ -853,6 +987,39 @@ int launch_bank(ConvArgs& a, hipStream_t s) {
     return mh_check_launch("conv_bank");
 }
 
+template <bool DGRAD, int PL>
+int launch_bank_small(ConvArgs& a, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bank_small_kernel<DGRAD, PL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)PATCH_LDS_MAX);
+        if (e != hipSuccess) { mh_set_error("conv_bank_small: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_done = true;
+    }
+    if (a.M < 0) return 0;
+    PatchGeo g;
+    g.TH = 2;
+    const int d = a.dil;
+    g.tiles_y = mh_cdiv(mh_cdiv(a.Ho, d), 2);
+    g.tiles_x = mh_cdiv(mh_cdiv(a.Wo, d), 16);
+    g.ntiles_n = mh_cdiv(a.N, 32);
+    g.nwg = a.B * d * d * g.tiles_y * g.tiles_x * g.ntiles_n;
+    g.KP = (a.K + 31) & ~31;
+    g.CPT = g.KP / 32;
+    g.PS = g.KP + 16;
+    g.nchunk = 9 * g.CPT;
+    g.patch_halfs = 4 * PW * g.PS;
+    g.inv_kp4 = 1.0f / (float)(g.KP / 4);
+    g.dbg = 0;
+    const size_t patch = (size_t)g.patch_halfs * 2 * PL, cs = (size_t)16 * 32 * 33 * 4;
+    const size_t lds = patch > cs ? patch : cs;
+    ++g_bank_launches;
+    mh_note_kernel("conv_bank_small_kernel<%s,%s> tile 32x32 K=%d N=%d dil=%d grid %d lds %d", DGRAD ? "dgrad" : "fwd", PL == 2 ? "bf16x3" : "bf16", a.K, a.N, a.dil,
+                   g.nwg, (int)lds);
+    hipLaunchKernelGGL((conv_bank_small_kernel<DGRAD, PL>), dim3(g.nwg), dim3(1024), lds, s, a, g);
+    return mh_check_launch("conv_bank_small");
+}
+
 // the channel-count-specialised instances exist for the 8-wave tile (the one the heuristic dispatches)
 template <int WM, int WN, int MT, int NT, bool DGRAD>
 int launch_patch_k(ConvArgs& a, hipStream_t s) {
@@ -902,7 +1069,38 @@ extern "C" int mh_pack_weights(const mh_pack_seg* segs_device, int32_t nseg, int
     hipLaunchKernelGGL(pack_weights_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, segs_device, nseg);
     return mh_check_launch("pack_weights");
 }
-extern "C" int mh_tune_conv_bank(int reset) { (void)reset; return g_bank_launches.exchange(0); }
+std::atomic<int> g_bank_small_maxpix{-2};          // -2: not resolved yet (MH_CONV_BANK_SMALL_MAXPIX, default 4096)
+int bank_small_maxpix() {
+    int m = g_bank_small_maxpix.load(std::memory_order_relaxed);
+    if (m == -2) { const char* e = getenv("MH_CONV_BANK_SMALL_MAXPIX"); m = e ? atoi(e) : 4096; g_bank_small_maxpix.store(m, std::memory_order_relaxed); }
+    return m;
+}
+extern "C" int mh_tune_conv_bank(int small_maxpix) {
+    g_bank_small_maxpix = small_maxpix < 0 ? -2 : small_maxpix;
+    return g_bank_launches.exchange(0);
+}
+
+// small-layer bank kernel: stride-1 "SAME" 3x3, bank present, reduction <= 64 chunks (K <= 224), few enough pixels that the tiled kernels
+// are latency bound (default <= 4096 output pixels: the 1/16-1/64 levels; MH_CONV_BANK_SMALL_MAXPIX overrides, 0 = off)
+bool mh_conv_bank_small_ok(const ConvArgs& a) {
+    const int maxpix = bank_small_maxpix();
+    if (!a.wb || !(a.bf16 || a.x3) || (a.x3 && a.mode != 0)) return false;
+    if (!(a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad_t == a.dil && a.pad_l == a.dil && a.Hi == a.Ho && a.Wi == a.Wo)) return false;
+    if (a.ncls != 0 || a.N < 16 || a.K < 16 || a.dil > 64 || !a.vecA) return false;
+    if (9 * ((a.K + 31) / 32) > 64) return false;
+    if ((int64_t)a.B * a.Ho * a.Wo > maxpix) return false;
+    const int d = a.dil;
+    const int64_t cover = (int64_t)d * d * mh_cdiv(mh_cdiv(a.Ho, d), 2) * 2 * mh_cdiv(mh_cdiv(a.Wo, d), 16) * 16;
+    return cover * 100 <= (int64_t)a.Ho * a.Wo * 250 && (int64_t)a.B * cover / 32 * mh_cdiv(a.N, 32) < (1 << 20);
+}
+int mh_conv_bank_small_launch(ConvArgs& a, hipStream_t s) {
+    const bool all = a.M < 0;
+    int rc = 0;
+    if (all || (a.mode == 0 && a.x3)) { rc = launch_bank_small<false, 2>(a, s); if (!all || rc) return rc; }
+    if (all || (a.mode == 0 && !a.x3)) { rc = launch_bank_small<false, 1>(a, s); if (!all || rc) return rc; }
+    if (all || a.mode == 1) { rc = launch_bank_small<true, 1>(a, s); if (!all || rc) return rc; }
+    return rc;
+}
 
 bool mh_conv_patch_ok(const ConvArgs& a) {
     if (patch_mode() == 0) return false;

@@ -250,11 +250,29 @@ extern "C" int mh_plan_run(const mh_op* ops, int32_t nops, void* stream) {
             if (dirty[l]) { if (int e = lane_edge(*L, L->aux[l], main_s)) return e; dirty[l] = false; }
         return 0;
     };
+    // Side-lane launches are DEFERRED until the next lane-0 op has been launched (their fork edge is taken at the original point).  In a
+    // captured graph the first node created under a parent inherits the parent's hardware queue and later children move to another
+    // queue behind a cross-queue dependency (~15-20 us, seen as idle time on the critical path after every batch of filter gradients:
+    // profiles/r02_experiments.txt #16); this way the critical-path successor is the first child and the side batch pays the hop.
+    static const int defer_on = []() { const char* e = getenv("MH_DEFER_SIDE"); return e ? atoi(e) : 1; }();
+    struct Deferred { int32_t k; int m, lane; };
+    Deferred deferred[64];
+    int ndef = 0;
+    auto flush_deferred = [&]() -> int {
+        for (int q = 0; q < ndef; ++q) {
+            const Deferred& d = deferred[q];
+            const int e = d.m > 1 ? run_wgrad_batch(ops + d.k, d.m, (void*)L->aux[d.lane]) : run_op(ops[d.k], (void*)L->aux[d.lane]);
+            if (e) { ndef = 0; return e; }
+        }
+        ndef = 0;
+        return 0;
+    };
     for (int32_t k = 0; k < nops; ++k) {
         const int sched = ops[k].i[26];
         const int lane = sched & 0xff;
         int e = 0;
         if (lane >= MH_MAX_LANES) { mh_set_error("lane %d out of range", lane); e = MH_ERR_ARG; }
+        if (!e && ndef && ((sched & MH_OP_JOIN) || ((sched >> 16) & 0xff) || ndef >= 60)) e = flush_deferred();
         if (!e && (sched & MH_OP_JOIN)) e = join();
         if (!e && ((sched >> 16) & 0xff)) {                   // join exactly these side lanes
             for (int l = 1; l < MH_MAX_LANES && !e; ++l)
@@ -268,20 +286,27 @@ extern "C" int mh_plan_run(const mh_op* ops, int32_t nops, void* stream) {
         if (!e && lane > 0) {
             if (!L) e = lanes_get(&L);
             if (!e && stale[lane]) { e = lane_edge(*L, main_s, L->aux[lane]); stale[lane] = false; }
-            if (!e) { dirty[lane] = true; e = run((void*)L->aux[lane]); }
+            if (!e) {
+                dirty[lane] = true;
+                if (defer_on) { deferred[ndef].k = k; deferred[ndef].m = m; deferred[ndef].lane = lane; ++ndef; }
+                else e = run((void*)L->aux[lane]);
+            }
         } else if (!e) {
             e = run(stream);
             for (bool& b : stale) b = true;
+            if (!e && ndef) e = flush_deferred();
         }
         if (e != 0) {
             char tmp[400];
             strncpy(tmp, g_err, sizeof(tmp) - 1); tmp[sizeof(tmp) - 1] = 0;
             mh_set_error("plan op %d (kind %d): %s", k, ops[k].kind, tmp);
+            ndef = 0;
             join();         // never leave a capture with an unjoined side stream
             return e;
         }
         k += m - 1;
     }
+    if (ndef) { if (int e = flush_deferred()) { join(); return e; } }
     return join();
 }
 

@@ -32,9 +32,12 @@ struct WgradArgs {
 static int g_wgrad_target_wgs = 0;
 // tuning hook (microbenchmarks): number of workgroups the pixel split aims for (0 = heuristic)
 static int g_wgrad_plain = 0;
+static int g_wgrad_tile64 = 0;
 extern "C" int mh_tune_wgrad_wgs(int target) {
     g_wgrad_plain = target < 0;                    // negative: timing experiment with plain stores (wrong results)
     if (target < 0) target = -target;
+    g_wgrad_tile64 = target >= 100000;             // + 100000: timing experiment, 64x64 tiles for the 128-wide layers (4x fewer pixel splits)
+    target %= 100000;
     g_wgrad_target_wgs = target > 1 ? target : 0;
     return 0;
 }
@@ -696,6 +699,7 @@ static int wgrad_dispatch(WgradArgs& a, hipStream_t s) {
         if (!all || rc) return rc;                             \
     }
     // dW tile shape from the channel counts (rows = K = Cin, cols = N = Cout)
+    MH_WG(K > 64 && N > 64 && g_wgrad_tile64, 2, 2, 2, 2, 32)   // (experiment) 64 x 64 tiles
     MH_WG(K > 64 && N > 64, 2, 2, 4, 4, 32)                 // 128 x 128
     MH_WG(K > 64 && N > 32 && N <= 64, 2, 2, 4, 2, 32)      // 128 x 64
     MH_WG(K > 64 && N <= 32, 4, 1, 2, 1, 32)                // 128 x 16

@@ -47,7 +47,7 @@ class WgradSeg(C.Structure):
 
 class PackSeg(C.Structure):          # mh_pack_seg
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("taps", C.c_int32), ("K", C.c_int32), ("N", C.c_int32),
-                ("planes", C.c_int32), ("blk0", C.c_int32), ("pad", C.c_int32)]
+                ("planes", C.c_int32), ("blk0", C.c_int32), ("trans", C.c_int32)]
 
 
 class WgradItem(C.Structure):        # mh_wgrad_item

@@ -80,9 +80,10 @@ def madnet_manifest(radius_d=2, stride=1):
     return out
 
 
-# pyramid layers after whose input gradient the pending filter gradients are issued in addition to every 4th layer: the last batch
-# (conv4..conv1, half / full resolution) otherwise starts only after the LAST input gradient and runs alone as the step's tail
-PYR_TAIL_FLUSH = tuple(int(x) for x in os.environ.get("MH_PYR_TAIL_FLUSH", "3,2").split(",") if x)
+# pyramid layers after whose input gradient the pending filter gradients are issued in addition to every 4th layer (e.g. "3,2": the last
+# batch -- conv4..conv1 -- then does not wait for the LAST input gradient).  Measured: -0.4 % with two side lanes, +0.6 % with the one
+# lane that is the default since side launches are deferred (profiles/r02_experiments.txt #16) -> off by default
+PYR_TAIL_FLUSH = tuple(int(x) for x in os.environ.get("MH_PYR_TAIL_FLUSH", "").split(",") if x)
 
 
 class Params(object):
@@ -163,7 +164,9 @@ class MadNetEngine(object):
         self.partial_wgrad = os.environ.get("MH_WGRAD_ATOMIC", "0") != "1"   # False: splits accumulate with fp32 atomics straight into g
         # ... recorded on a side lane: the filter gradients are off the critical path (only the optimizer needs
         # them), so they overlap with the input-gradient chain as a parallel branch of the hipGraph
-        self.wgrad_lanes = 2
+        # ONE lane since mh_plan_run defers side launches past the next lane-0 op (2.08 ms against 2.28 ms with two lanes, 2.20 ms with
+        # two lanes undeferred: profiles/r02_experiments.txt #16)
+        self.wgrad_lanes = int(os.environ.get("MH_WGRAD_LANES", "1"))
         # one launch per level for the inter-level upsample + warp + cost volume + concat (mh_level_front_fwd) instead of three
         self.fuse_front = os.environ.get("MH_FUSE_FRONT", "1") != "0"        # (environment switch: in-situ A/B runs)
         # bf16 / mixed: hand every forward conv the transposed filter bank too, so that the small layers can take the LDS-free kernel
@@ -171,8 +174,11 @@ class MadNetEngine(object):
         self.use_direct = precision != "fp32" and os.environ.get("MH_CONV_DIRECT", "0") != "0"
         # split-bf16 3x3 layers of the 1/4- and 1/8-resolution estimators and the context network stream their weights from MFMA
         # fragment banks (mh_conv2d_wb), re-packed by ONE launch at the start of every step
-        self.use_bank = precision == "mixed" and os.environ.get("MH_CONV_BANK", "1") != "0"
+        # ... and (bf16 / mixed) the layers of the 1/16-1/64 levels -- forward and input gradient -- take the small-layer bank kernel
+        self.use_bank = precision in ("mixed", "bf16") and os.environ.get("MH_CONV_BANK", "1") != "0"
+        self.bank_small_maxpix = int(os.environ.get("MH_CONV_BANK_SMALL_MAXPIX", "4096"))
         self.banks = {}
+        self.banks_d = {}
         self.wsa = ops.WgradWorkspace(device)
 
     # ---------------------------------------------------------------------------------------
@@ -259,13 +265,46 @@ class MadNetEngine(object):
         return self.params.tensor(base + "/biases")
 
     def Wb_(self, base):
-        """MFMA fragment bank of the layer (None: the layer does not run a bank kernel)"""
+        """MFMA fragment bank of the layer for the forward pass (None: the layer does not run a bank kernel)"""
         return self.banks.get(base)
 
-    def _bank_layers(self):
-        names = [est_name(k, j) for k in LEVELS if k < 4 for j in range(1, 7)] + [ctx_name(j) for j in range(1, 8)]
+    def Wd_(self, base):
+        """... for the input gradient (small layers, bf16 backward)"""
+        return self.banks_d.get(base)
+
+    def _bank_plan(self):
+        """[(layer, planes, trans)]: which fragment banks this engine packs every step.  Forward: planes follow the precision code the
+        layer runs (2 = split-bf16 -> the 64x128 / 128x64 bank kernel or, <= bank_small_maxpix output pixels, the small-layer kernel;
+        1 = bf16 -> small-layer kernel only).  Input gradient (trans 1, bf16): small layers."""
+        if not self.use_bank:
+            return []
+        fcode, bcode = ops.PRECISION_CODES[self.precision]
         shapes = dict(self.params.manifest)
-        return [n for n in names if shapes[n + "/weights"][0] == 3 and shapes[n + "/weights"][2] >= 32 and shapes[n + "/weights"][3] >= 48]
+        B = self.B
+        layers = []          # (name, forward precision code, output pixels)
+        for i in range(2, 13, 2):                                   # the stride-1 pyramid layers
+            lv = [k for k, f in FEAT.items() if f == i]
+            h, w = (self.fshape[i][0], self.fshape[i][1])
+            layers.append((pyr_name(i), fcode, 2 * B * h * w))
+        for k in LEVELS:
+            h, w, _ = self.fshape[FEAT[k]]
+            code = 1 if (self.precision == "mixed" and k >= 4) else fcode
+            layers += [(est_name(k, j), code, B * h * w) for j in range(1, 7)]
+        h, w, _ = self.fshape[4]
+        layers += [(ctx_name(j), fcode, B * h * w) for j in range(1, 8)]
+        plan = []
+        for n, code, pix in layers:
+            kh, _, K, N = shapes[n + "/weights"]
+            if kh != 3:
+                continue
+            small = pix <= self.bank_small_maxpix and 9 * ((K + 31) // 32) <= 64
+            if code == 2 and N >= 16 and K >= 16 and (small or (N >= 48 and K >= 32)):
+                plan.append((n, 2, 0))
+            elif code == 1 and small and N >= 16 and K >= 16:
+                plan.append((n, 1, 0))
+            if bcode == 1 and pix <= self.bank_small_maxpix and K >= 16 and N >= 16 and 9 * ((N + 31) // 32) <= 64:
+                plan.append((n, 1, 1))
+        return plan
 
     def Wt_(self, base):
         """transposed view of the layer's filter bank (None in the fp32 mode: the exact-fp32 path has no LDS-free kernel)"""
@@ -284,16 +323,20 @@ class MadNetEngine(object):
             names = [n for n, shp in self.params.manifest if n.endswith("/weights") and shp[3] >= 16 and shp[2] % 8 == 0]
             ops.transpose_weights(lib, [(self.params.tensor(n), self.Wt_(n[:-len("/weights")])) for n in names], self.dev, r.keep)
         if self.use_bank:
-            if not self.banks:
-                for n in self._bank_layers():
-                    self.banks[n] = torch.zeros(ops.pack_bytes(self.W_(n)) // 4, device=self.dev)
-            ops.pack_weights(lib, [(self.W_(n), self.banks[n]) for n in self._bank_layers()], self.dev, r.keep)
+            plan = self._bank_plan()
+            for n, planes, trans in plan:
+                tgt = self.banks_d if trans else self.banks
+                if n not in tgt:
+                    tgt[n] = torch.zeros(ops.pack_bytes(self.W_(n), planes, trans) // 4, device=self.dev)
+            ops.pack_weights(lib, [(self.W_(n), (self.banks_d if trans else self.banks)[n], planes, trans) for n, planes, trans in plan],
+                             self.dev, r.keep)
         ops.pad_reflect(lib, self.left, self.X0[:B], self.pt, self.pl)
         ops.pad_reflect(lib, self.right, self.X0[B:], self.pt, self.pl)
         x = ops.View(self.X0, 2 * B, self.Hp, self.Wp, 3, 4)
         for i, (ci, co, s) in enumerate(PYR, 1):
             o = self._fv(self.F[i])
-            ops.conv2d_fwd(lib, x, self.W_(pyr_name(i)), self.b_(pyr_name(i)), o, stride=s, alpha=ALPHA, wt=self.Wt_(pyr_name(i)))
+            ops.conv2d_fwd(lib, x, self.W_(pyr_name(i)), self.b_(pyr_name(i)), o, stride=s, alpha=ALPHA, wt=self.Wt_(pyr_name(i)),
+                           wb=self.Wb_(pyr_name(i)))
             x = o
         for k in LEVELS:
             f = FEAT[k]
@@ -323,7 +366,7 @@ class MadNetEngine(object):
                 o = self._fv(self.V[k]) if last else self._fv(self.E[k][j])
                 ops.conv2d_fwd(lib, x, self.W_(est_name(k, j + 1)), self.b_(est_name(k, j + 1)), o,
                                alpha=(1.0 if last else ALPHA), precision=fprec, wt=self.Wt_(est_name(k, j + 1)),
-                               wb=(self.Wb_(est_name(k, j + 1)) if fprec is None else None))
+                               wb=self.Wb_(est_name(k, j + 1)))
                 x = o
             if k != 2:
                 sc = 2 ** (k - 1)
@@ -474,7 +517,7 @@ class MadNetEngine(object):
                 wgrad(xv, dzv, base, stride=stride, dil=dil)
             if need_dx:
                 ops.conv2d_dgrad(lib, dzv, self.W_(base), dxv, stride=stride, dil=dil, accumulate=acc_flag(dx_key),
-                                 mask_ref=x_act, mask_alpha=ALPHA)
+                                 mask_ref=x_act, mask_alpha=ALPHA, wb=self.Wd_(base))
 
         if heads is None:
             heads = {head: (self.dpred if head == "final" else self.ddisp_k)}
@@ -617,7 +660,7 @@ class MadNetEngine(object):
                 if need_dx:
                     ops.conv2d_dgrad(lib, self._fv(self.dF[i]), self.W_(pyr_name(i)), self._fv(self.dF[i - 1]),
                                      stride=PYR[i - 1][2], accumulate=accumulate, mask_ref=self._fv(self.F[i - 1]),
-                                     mask_alpha=ALPHA)
+                                     mask_alpha=ALPHA, wb=self.Wd_(pyr_name(i)))
                 if i % 4 == 1 or i in PYR_TAIL_FLUSH:
                     flush()
         flush()

@@ -143,23 +143,31 @@ def transpose_weights(lib, pairs, device, keep, stream=None):
     lib.transpose_weights(C.c_void_p(table.data_ptr()), len(pairs), blk, _p(stream))
 
 
-def pack_bytes(w, planes=2):
+def pack_bytes(w, planes=2, trans=0):
     kh, kw, K, N = w.shape
+    if trans:
+        K, N = N, K
     return kh * kw * ((K + 31) // 32) * ((N + 15) // 16) * planes * 1024
 
 
-def pack_weights(lib, pairs, device, keep, stream=None, planes=2):
-    """pairs: [(src HWIO tensor, dst uint8/any tensor of pack_bytes(src) bytes)] -> every dst = the MFMA fragment bank of src
-    (include/madnet_hip.h: mh_pack_weights), ONE launch.  `keep`: list that keeps the device table alive as long as the plan."""
+def pack_weights(lib, pairs, device, keep, stream=None):
+    """pairs: [(src HWIO tensor, dst tensor of pack_bytes(src, planes, trans) bytes[, planes = 2[, trans = 0]])] -> every dst = the MFMA
+    fragment bank of src (include/madnet_hip.h: mh_pack_weights), ONE launch.  planes 2 = hi + lo (split-bf16 forward), 1 = bf16;
+    trans 1 = the bank the input gradient reads (reduction over Cout).  `keep`: list that keeps the device table alive as long as the plan."""
     if not pairs:
         return
     arr = (_ffi.PackSeg * len(pairs))()
     blk = 0
-    for i, (src, dst) in enumerate(pairs):
+    for i, pr in enumerate(pairs):
+        src, dst = pr[0], pr[1]
+        planes = pr[2] if len(pr) > 2 else 2
+        trans = pr[3] if len(pr) > 3 else 0
         kh, kw, K, N = src.shape
-        assert dst.numel() * dst.element_size() >= pack_bytes(src, planes) and dst.data_ptr() % 16 == 0
+        if trans:
+            K, N = N, K
+        assert dst.numel() * dst.element_size() >= pack_bytes(src, planes, trans) and dst.data_ptr() % 16 == 0
         arr[i].src, arr[i].dst, arr[i].taps, arr[i].K, arr[i].N = src.data_ptr(), dst.data_ptr(), kh * kw, K, N
-        arr[i].planes, arr[i].blk0 = planes, blk
+        arr[i].planes, arr[i].blk0, arr[i].trans = planes, blk, trans
         blk += (kh * kw * ((K + 31) // 32) * ((N + 15) // 16) * 64 + 255) // 256
     table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
     keep.append(table)
@@ -167,7 +175,7 @@ def pack_weights(lib, pairs, device, keep, stream=None, planes=2):
 
 
 def conv2d_dgrad(lib, dz, w, dx, stride=1, dil=1, accumulate=False, mask_ref=None, mask_alpha=1.0, mask_range=(0, 0),
-                 stream=None):
+                 stream=None, wb=None):
     """dx (+)= conv2d_backprop_input(dz, w); optionally fused dx *= leaky'(mask_ref).
     dz: View [B,Ho,Wo,Cout]; dx: View [B,H,W,Cin]; w: HWIO of the forward conv."""
     kh, kw, cin, cout = w.shape
@@ -176,7 +184,10 @@ def conv2d_dgrad(lib, dz, w, dx, stride=1, dil=1, accumulate=False, mask_ref=Non
     d = conv_desc(dx.B, Ho, Wo, dx.H, dx.W, cout, cin, kh, kw, stride, dil, pt, pl, 1, 1, dz.ld, dx.ld,
                   mask_ld=(mask_ref.ld if mask_ref is not None else 0), accumulate=int(accumulate),
                   alpha=1.0, mask_alpha=mask_alpha, mask_c0=mask_range[0], mask_c1=mask_range[1], precision=_bwd_precision())
-    lib.conv2d(C.byref(d), _p(dz), _p(w), None, _p(dx), _p(mask_ref), _p(stream))
+    if wb is not None:       # wb: pack_weights(trans=1, planes=1) bank of w -- the small-layer bank kernel takes it in the bf16 mode
+        lib.conv2d_wb(C.byref(d), _p(dz), _p(w), _p(wb), None, _p(dx), _p(mask_ref), _p(stream))
+    else:
+        lib.conv2d(C.byref(d), _p(dz), _p(w), None, _p(dx), _p(mask_ref), _p(stream))
 
 
 def conv2d_wgrad(lib, x, dz, dw, db, stride=1, dil=1, stream=None):

@@ -1,0 +1,25 @@
+#!/bin/bash
+# round 2, call U: side-lane launches deferred past the next lane-0 op (critical-path successor = first child in the captured graph): A/B + parity + timeline
+TAG=${1:-r02u}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
+B="--no-cpu-baseline --no-paths --no-step-surface --no-roofline --steps 100 --repeats 3"
+run() { name=$1; shift; env "$@" timeout 300 python bench.py $B $EXTRA 2>/dev/null | tail -1 > $OUT/bench_$name.json; }
+timeout 900 python -m pytest tests/test_conv_parity.py tests/test_engine_parity.py tests/test_api_gpu.py -m gpu -x -q 2>&1 | tail -5 > $OUT/pytest_gpu.txt
+cat $OUT/pytest_gpu.txt
+run defer1 MH_DEFER_SIDE=1
+run defer0 MH_DEFER_SIDE=0
+EXTRA="--wgrad-lanes 1" run defer1_l1 MH_DEFER_SIDE=1
+EXTRA="--wgrad-lanes 3" run defer1_l3 MH_DEFER_SIDE=1
+EXTRA="--mode MAD" run mad_defer1 MH_DEFER_SIDE=1
+EXTRA="--mode MAD" run mad_defer0 MH_DEFER_SIDE=0
+run defer1_group0 MH_DEFER_SIDE=1 MH_WGRAD_GROUP=0
+run defer1_again MH_DEFER_SIDE=1
+C="--no-cpu-baseline --no-paths --no-step-surface --no-roofline --steps 12 --warmup 3 --repeats 1"
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_graph -o madnet -- python $GRAFT_REPO_ROOT/bench.py $C > $GRAFT_REPO_ROOT/$OUT/prof_graph.log 2>&1)
+f=$(ls $OUT/prof_graph/*kernel_trace.csv | head -1)
+python scripts/trace_timeline.py $f > $OUT/timeline.txt 2>&1
+rm -rf $OUT/prof_graph
+python - <<PY
+import json,glob
+for f in sorted(glob.glob("$OUT/bench_*.json")):
+    e=json.load(open(f)); print(f.split("/")[-1], ["%.3f"%x for x in e["timing"]["ms_per_step_all"]], e["config"].get("ops_per_step"))
+PY

@@ -78,6 +78,41 @@ def run_wgrad():
         print("%-20s %s   (best %.0f TF/s)" % (name, " ".join("%9.1f" % r for r in res), flops / (min(res) * 1e-6) / 1e12))
 
 
+def run_wgradp():
+    """atomic-free filter gradient as the engines run it (bf16 operands): partial launch into the split workspace + its share of the
+    reduction, for the default 128x128 tiles and the 64x64-tile experiment (4x fewer pixel splits for the same workgroup count)."""
+    PL = [("L2 128->128", 1, 96, 320, 128, 128, 1), ("L2 128->128 d4", 1, 96, 320, 128, 128, 4), ("L2 128->96", 1, 96, 320, 128, 96, 1),
+          ("L2 96->64", 1, 96, 320, 96, 64, 1), ("L2 38->128", 1, 96, 320, 38, 128, 1), ("L3 128->128", 1, 48, 160, 128, 128, 1)]
+    ops.PRECISION = 1
+    print("%-16s %s" % ("wgrad layer", "  [tile: partial us + reduce us = total, splits, workspace MB]"))
+    for name, B, H, W, Ci, Co, d in PL:
+        ld = (Ci + 3) // 4 * 4
+        x = torch.randn(B, H, W, ld, device=dev); xv = ops.View(x, B, H, W, Ci, ld)
+        dz = torch.randn(B, H, W, Co, device=dev)
+        out = []
+        for tile, tgt in (("128", 0), ("128/768wg", 768), ("64", 100000), ("64/768wg", 100768), ("64/1536wg", 101536)):
+            lib.tune_wgrad_wgs(tgt)
+            dw = torch.zeros(3, 3, Ci, Co, device=dev); db = torch.zeros(Co, device=dev)
+            wsa = ops.WgradWorkspace(dev); segs, keep = [], []
+            ops.conv2d_wgrad_partial(lib, lib, wsa, segs, xv, ops.view(dz), dw, db, dil=d)
+            if not segs:
+                out.append("%s: single split" % tile); continue
+            ws, dst, size, splits = segs[0]
+            desc = ops.conv_desc(B, H, W, H, W, Ci, Co, 3, 3, 1, d, d, d, 0, 0, ld, Co, precision=1)
+            sp = C.c_int32(splits)
+            with torch.cuda.stream(stream):
+                tp = _time_ms(lib, stream, lambda: lib.conv2d_wgrad_partial(C.byref(desc), C.c_void_p(x.data_ptr()), C.c_void_p(dz.data_ptr()), Co, C.c_void_p(ws),
+                                                                            C.byref(sp), C.c_void_p(db.data_ptr()), C.c_void_p(stream.cuda_stream)), 20) * 1e3
+            arr = (_ffi.WgradSeg * 1)(); arr[0].ws, arr[0].dst, arr[0].size, arr[0].splits, arr[0].blk0, arr[0].accumulate = ws, dst, size, splits, 0, 0
+            table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+            with torch.cuda.stream(stream):
+                tr = _time_ms(lib, stream, lambda: lib.wgrad_reduce(C.c_void_p(table.data_ptr()), 1, (size + 1023) // 1024, C.c_void_p(stream.cuda_stream)), 20) * 1e3
+            out.append("%s: %.1f + %.1f = %.1f, %d, %.1f" % (tile, tp, tr, tp + tr, splits, splits * size * 4 / 1e6))
+        lib.tune_wgrad_wgs(0)
+        print("%-16s %s" % (name, "  |  ".join(out)))
+    ops.PRECISION = 0
+
+
 def run_corr():
     for (B, H, W, Cc, md) in [(64, 96, 320, 32, 2), (16, 96, 320, 32, 2), (1, 96, 320, 32, 2), (64, 48, 160, 64, 2), (16, 96, 320, 128, 40)]:
         L = torch.randn(B, H, W, Cc, device=dev); R = torch.randn(B, H, W, Cc, device=dev)
@@ -206,6 +241,7 @@ def run_bank():
         y = torch.empty(B, H, W, Co, device=dev); y2 = torch.empty(B, H, W, Co, device=dev)
         bank = torch.zeros(ops.pack_bytes(w) // 4, device=dev); keep = []
         ops.pack_weights(lib, [(w, bank)], dev, keep)
+        lib.tune_conv_bank(0)         # the 64x128 / 128x64 bank kernel on every row (L4 would otherwise go to the small-layer kernel)
         flops = 2.0 * B * H * W * 9 * Ci * Co
         res = []
         ops.PRECISION = 2
@@ -219,6 +255,7 @@ def run_bank():
         torch.cuda.synchronize()
         ops.PRECISION = 0
         lib.tune_conv_patch(-1)
+        lib.tune_conv_bank(-1)
         print("%-16s %9.1f | %9.1f %9.1f %9.1f %9.1f   %.3g   (bank %.0f TF/s algorithmic, %s)" % (name, res[0], res[1], res[2], res[3], res[4], (y - y2).abs().max().item(),
               flops / (res[1] * 1e-6) / 1e12, lib.last_kernel().decode()[:60]))
     shapes = [(38, 128), (128, 128), (128, 96), (96, 64), (70, 128), (128, 128), (128, 96), (96, 64), (33, 128), (128, 128), (128, 128), (128, 96), (96, 64)]
@@ -230,6 +267,8 @@ def run_bank():
     print("mh_pack_weights, 13 layers (%.1f MB of banks): %.1f us" % (sum(b.numel() * 4 for b in banks) / 1e6, t))
 
 
+if what == "wgradp":
+    run_wgradp()
 if what == "bank":
     run_bank()
 if what == "x3dbg":

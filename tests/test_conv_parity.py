@@ -618,7 +618,7 @@ def test_conv_split_bf16_fragment_bank_kernel(backend, case):
     keep = []
     ops.pack_weights(backend.lib, [(w, bank)], dev, keep)
     backend.lib.tune_conv_patch(128)          # forced: these shapes are far below the pixel-count heuristic
-    backend.lib.tune_conv_bank(0)
+    backend.lib.tune_conv_bank(0)             # 0: the small-layer bank kernel stays out of the way (it has its own test)
     try:
         y = torch.full(y_ref.shape, float("nan"), device=dev)
         y0 = torch.full(y_ref.shape, float("nan"), device=dev)
@@ -629,7 +629,84 @@ def test_conv_split_bf16_fragment_bank_kernel(backend, case):
         backend.sync()
     finally:
         launches = backend.lib.tune_conv_patch(-1)
-    assert nb == 1 and launches == 2 and backend.lib.tune_conv_bank(0) == 0
+        nb2 = backend.lib.tune_conv_bank(-1)
+    assert nb == 1 and launches == 2 and nb2 == 0
     err = (y.cpu() - y_ref).abs().max().item()
     assert err <= 4e-5 * max(1.0, y_ref.abs().max().item()), err
     assert torch.equal(y.cpu(), y0.cpu()), (y.cpu() - y0.cpu()).abs().max().item()
+
+
+SMALL_BANK_CASES = [   # (B, H, W, Cin, Cout, dil): the 1/16-1/64 level shapes + ragged ones
+    (1, 6, 20, 128, 128, 1), (1, 6, 20, 197, 128, 1), (1, 12, 40, 128, 96, 1), (1, 7, 19, 96, 64, 1), (2, 6, 20, 64, 32, 1),
+    (1, 9, 33, 134, 128, 1), (1, 12, 20, 32, 48, 2), (1, 5, 17, 36, 20, 1),
+]
+
+
+@pytest.mark.parametrize("what", ["fwd-bf16", "fwd-x3", "dgrad-bf16"])
+@pytest.mark.parametrize("case", SMALL_BANK_CASES)
+def test_conv_small_layer_bank_kernel(backend, case, what):
+    """conv_bank_small_kernel (mh_conv2d_wb on layers of <= 4096 output pixels): 16 waves split the reduction of one 32x32 tile and fetch
+    their weight fragments from the bank.  Same operand rounding as the tiled kernels of the same precision code (bf16 / split-bf16), another
+    summation order: compared with the oracle run on identically rounded operands, and with the kernel the layer takes without a bank."""
+    B, H, W, Ci, Co, dil = case
+    dev = backend.device
+    w = _rand((3, 3, Ci, Co), 312, dev, 0.2)
+    b = _rand((Co,), 313, dev)
+    keep = []
+    backend.lib.tune_conv_bank(-1)
+    if what.startswith("fwd"):
+        x = _rand((B, H, W, Ci), 311, dev)
+        ld = (Ci + 3) // 4 * 4
+        xb, xv = _padded(x, ld)
+        if ld != Ci:
+            xb[..., Ci:] = float("nan")
+        x3 = what == "fwd-x3"
+        planes = 2 if x3 else 1
+        bank = torch.full((ops.pack_bytes(w, planes) // 4,), float("nan"), device=dev)
+        ops.pack_weights(backend.lib, [(w, bank, planes, 0)], dev, keep)
+        y = torch.full((B, H, W, Co), float("nan"), device=dev); y0 = torch.full((B, H, W, Co), float("nan"), device=dev)
+        with ops.precision_scope("mixed" if x3 else "bf16"):
+            ops.conv2d_fwd(backend.lib, xv, w, b, ops.view(y), dil=dil, alpha=0.2, wb=bank)
+            name = backend.lib.last_kernel().decode()
+            nb = backend.lib.tune_conv_bank(-1)
+            ops.conv2d_fwd(backend.lib, xv, w, b, ops.view(y0), dil=dil, alpha=0.2)
+        backend.sync()
+        assert nb == 1 and "conv_bank_small" in name, name
+        if x3:
+            ref = T.conv2d(x.cpu().double(), w.cpu().double(), b.cpu().double(), dilation=dil, alpha=0.2).float()
+            tol = 4e-5
+        else:
+            ref = T.conv2d(_bf(x.cpu()).double(), _bf(w.cpu()).double(), b.cpu().double(), dilation=dil, alpha=0.2).float()
+            tol = 2e-5
+        sc = max(1.0, ref.abs().max().item())
+        assert (y.cpu() - ref).abs().max().item() <= tol * sc
+        assert (y.cpu() - y0.cpu()).abs().max().item() <= 2 * tol * sc
+    else:
+        gz = _rand((B, H, W, Co), 314, dev)
+        old = _rand((B, H, W, Ci), 315, dev)
+        mref = _rand((B, H, W, Ci), 316, dev)
+        ldx = (Ci + 3) // 4 * 4
+        zb, zv = _padded(gz, (Co + 3) // 4 * 4)
+        mb, mv = _padded(mref, ldx)
+        bank = torch.full((ops.pack_bytes(w, 1, 1) // 4,), float("nan"), device=dev)
+        ops.pack_weights(backend.lib, [(w, bank, 1, 1)], dev, keep)
+        outs = []
+        for use_bank in (True, False):
+            dxb, dxv = _padded(old, ldx)
+            ops.PRECISION_BWD = 1
+            try:
+                ops.conv2d_dgrad(backend.lib, zv, w, dxv, dil=dil, accumulate=True, mask_ref=mv, mask_alpha=0.2, wb=(bank if use_bank else None))
+            finally:
+                ops.PRECISION_BWD = None
+            if use_bank:
+                name = backend.lib.last_kernel().decode()
+                assert backend.lib.tune_conv_bank(-1) == 1 and "conv_bank_small_kernel<dgrad" in name, name
+            backend.sync()
+            outs.append(dxb[..., :Ci].cpu().clone())
+        xr = torch.zeros(B, H, W, Ci, dtype=torch.float64, requires_grad=True)
+        yr = T.conv2d(xr, _bf(w.cpu()).double(), None, dilation=dil, alpha=1.0)
+        (gx,) = torch.autograd.grad(yr, [xr], _bf(gz.cpu()).double())
+        exp = ((old.cpu().double() + gx) * torch.where(mref.cpu() > 0, 1.0, 0.2)).float()
+        sc = max(1.0, gx.abs().max().item())
+        assert (outs[0] - exp).abs().max().item() <= 2e-5 * sc
+        assert (outs[0] - outs[1]).abs().max().item() <= 4e-5 * sc

@@ -368,6 +368,7 @@ def test_bf16_step_patch_kernel_vs_gather_kernel_emulated():
         backend.lib.tune_conv_patch(0 if mode == "fp32" else mode)
         try:
             eng = E.MadNetEngine(backend.lib, H, W, B=1, device="cpu", weights=wn, precision="fp32" if mode == "fp32" else "bf16")
+            eng.use_bank = False          # (the fragment-bank kernels would take the small layers: they have their own test below)
             eng.set_inputs(l, r, gt[..., 0])
             eng.build_plan("FULL", lr=1e-4).run(backend.lib, 0)
         finally:
@@ -386,6 +387,37 @@ def test_bf16_step_patch_kernel_vs_gather_kernel_emulated():
           "loss %.6f / %.6f / fp32 %.6f; patch launches %d" % (dev0, dev1, mutual, gd0, gd1, gm, l0, l1, l32, n1))
     assert dev1 <= 1.5 * dev0 + 1e-3 and mutual <= dev0 + dev1
     assert gd1 <= 1.5 * gd0 + 1e-3 and gm <= gd0 + gd1
+    assert abs(l1 - l32) <= 1.5 * abs(l0 - l32) + 1e-3 * abs(l32)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "mixed"])
+def test_step_fragment_bank_kernels_vs_tiled_kernels_emulated(precision):
+    """The fragment-bank kernels inside the whole engine (mh_pack_weights at the start of the plan, forward and input-gradient banks, channel-
+    slice views, fused masks, accumulating gradients): one FULL step with the banks on (at 60x100 every 3x3 stride-1 layer is a "small"
+    layer -> conv_bank_small_kernel; the split-bf16 ones of the 'mixed' mode too) against the same step on the tiled kernels.  Same
+    operand rounding, another summation order -> judged like the patch kernel above: against the fp32 engine."""
+    from conftest import _emul_backend
+    backend = _emul_backend()
+    H, W = 60, 100
+    wn = S.calibrated_weights(OM.variable_shapes(), 1)
+    l, r, gt = S.make_pair(H, W)
+    out = {}
+    for mode in ("tiled", "bank", "fp32"):
+        backend.lib.tune_conv_bank(-1)
+        eng = E.MadNetEngine(backend.lib, H, W, B=1, device="cpu", weights=wn, precision="fp32" if mode == "fp32" else precision)
+        eng.use_bank = mode == "bank"
+        eng.set_inputs(l, r, gt[..., 0])
+        eng.build_plan("FULL", lr=1e-4).run(backend.lib, 0)
+        out[mode] = (eng.pred.clone(), float(eng.res_loss[0].item()), eng.params.g.clone(), backend.lib.tune_conv_bank(-1))
+    p0, l0, g0, n0 = out["tiled"]; p1, l1, g1, n1 = out["bank"]; p32, l32, g32, _ = out["fp32"]
+    assert n0 == 0 and n1 >= 30, (n0, n1)          # estimators + context + stride-1 pyramid layers, forward and input gradients (the 1x2 .. 4x7 levels stay on the tiled kernel: tile cover)
+    dev0, dev1, mutual = (p0 - p32).abs().mean().item(), (p1 - p32).abs().mean().item(), (p1 - p0).abs().mean().item()
+    gd0 = (g0 - g32).norm().item() / g32.norm().item(); gd1 = (g1 - g32).norm().item() / g32.norm().item()
+    gm = (g1 - g0).norm().item() / g32.norm().item()
+    print("%s vs fp32 (emulated 60x100): disparity dev tiled %.3g bank %.3g mutual %.3g; gradient dev tiled %.3g bank %.3g mutual %.3g; "
+          "loss %.6f / %.6f / fp32 %.6f; bank launches %d" % (precision, dev0, dev1, mutual, gd0, gd1, gm, l0, l1, l32, n1))
+    assert dev1 <= 1.5 * dev0 + 1e-3 and mutual <= dev0 + dev1 + 1e-4
+    assert gd1 <= 1.5 * gd0 + 1e-3 and gm <= gd0 + gd1 + 1e-4
     assert abs(l1 - l32) <= 1.5 * abs(l0 - l32) + 1e-3 * abs(l32)
 
 
