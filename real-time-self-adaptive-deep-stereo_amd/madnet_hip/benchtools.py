@@ -51,6 +51,7 @@ def roofline(lib, eng, stream, reps=20):
     x = ops.view(eng.Cx[0]); o = ops.view(eng.Cx[1])
     w = eng.W_(E.ctx_name(2)); b = eng.b_(E.ctx_name(2))
     fwd_code, bwd_code = ops.PRECISION_CODES[eng.precision]
+    wb = eng.Wb_(E.ctx_name(2)) if hasattr(eng, "Wb_") else None       # the layer's fragment bank (packed by the step's own mh_pack_weights launch)
     flops = 2.0 * x.B * x.H * x.W * 9 * 128 * 128
     algo_bytes = 4.0 * (2 * x.B * x.H * x.W * 128 + 9 * 128 * 128)
 
@@ -62,7 +63,12 @@ def roofline(lib, eng, stream, reps=20):
         peak = PEAK_F32_MFMA_TFLOPS if (code == 0 or "f32" in kname.split("tile")[0]) else PEAK_BF16_MFMA_TFLOPS
         ach = flops / (ms * 1e-3) / 1e12
         tr = _pmc_traffic(pmc_key)
+        x3 = code == 2 and peak == PEAK_BF16_MFMA_TFLOPS
+        if x3:
+            # split-bf16 issues 3 bf16 MFMAs per algorithmic product: the ceiling of ALGORITHMIC flops is a third of the dense bf16 peak
+            peak = PEAK_BF16_MFMA_TFLOPS / 3.0
         return {"kernel": kname, "op": what, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                "peak_note": ("dense bf16 MFMA peak / 3 (three MFMAs per product); against the plain 2500 TFLOP/s the algorithmic rate is %.3f" % (ach / PEAK_BF16_MFMA_TFLOPS)) if x3 else None,
                 "arithmetic": {0: "f32 MFMA", 1: "bf16 MFMA, f32 accumulate", 2: "split-bf16: 3 bf16 MFMAs per product (mfma issue rate = 3x achieved), f32 accumulate"}[code],
                 "traffic": tr, "traffic_source": ("profiles/r02_pmc_roofline.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_pmc_r02.sh, key %s; not re-measured in this run)" % pmc_key) if tr is not None else None,
                 "launch_ms": ms, "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": algo_bytes}
@@ -71,13 +77,14 @@ def roofline(lib, eng, stream, reps=20):
         def fn():
             ops.PRECISION = code
             try:
-                ops.conv2d_fwd(lib, x, w, b, o, dil=2, alpha=E.ALPHA, stream=sh)
+                ops.conv2d_fwd(lib, x, w, b, o, dil=2, alpha=E.ALPHA, stream=sh, wb=(wb if code == 2 else None))
             finally:
                 ops.PRECISION = 0
         return fn
 
     rl = entry(fwd_code, conv_fwd(fwd_code), "forward 3x3 128->128 @ %dx%d dil 2 (context-2)" % (x.H, x.W),
-               {0: "none", 1: "conv_fwd_bf16_patch_3x3_128_128_96x320", 2: "conv_fwd_x3_patch_3x3_128_128_96x320"}[fwd_code])
+               {0: "none", 1: "conv_fwd_bf16_patch_3x3_128_128_96x320",
+                2: "conv_fwd_x3_bank_3x3_128_128_96x320" if wb is not None else "conv_fwd_x3_patch_3x3_128_128_96x320"}[fwd_code])
     extra = {}
     # the same layer's input gradient and filter gradient in the BACKWARD arithmetic: by time the filter gradients are the
     # largest kernel family of the step (22 launches x 17 us)

@@ -11,7 +11,7 @@ import torch
 from madnet_hip import _ffi, ops
 from madnet_hip.benchtools import _time_ms
 
-lib = _ffi.Lib(os.path.join(ROOT, "scripts", "exp", "libmadnet_hip_phase.so"))
+lib = _ffi.Lib(os.path.join(ROOT, "scripts", "exp", "libmadnet_hip_phase.so"))   # built by scripts/exp/build_phase_timing.sh
 lib.ensure_init()
 dll = lib.dll if hasattr(lib, "dll") else lib._dll
 dll.mh_tune_conv_dbg.argtypes = [C.c_void_p]; dll.mh_tune_conv_dbg.restype = C.c_int
@@ -38,8 +38,9 @@ for prec in (1, 0):
         with torch.cuda.stream(stream):
             t_ev = _time_ms(lib, stream, fn, 20) * 1e3
             res = []
-            for rep in range(5):
-                big.fill_(1.0)
+            for rep in range(10):
+                if rep >= 5:
+                    big.fill_(1.0)          # reps 5..9: L2 / Infinity Cache flushed (cold); reps 0..4: warm
                 buf.zero_()
                 stream.synchronize()
                 dll.mh_tune_conv_dbg(C.c_void_p(buf.data_ptr()))
@@ -48,14 +49,15 @@ for prec in (1, 0):
                 dll.mh_tune_conv_dbg(None)
                 res.append(buf.view(-1, 8).cpu().clone())
         ops.PRECISION = 0; ops.PRECISION_BWD = None
-        r = res[-1]; r = r[r[:, 0] != 0].double()
-        if r.numel() == 0:
-            print("%-20s %6.1f us (events)  -- no stamps (another kernel ran: %s)" % (name, t_ev, lib.last_kernel().decode()[:50])); continue
-        tick = (r[:, 7] - r[:, 6]).clamp(min=1) * 10.0 / (r[:, 5] - r[:, 0]).clamp(min=1)     # ns per s_memtime tick (s_memrealtime = 100 MHz)
-        ns = tick.median().item()
-        t0 = r[:, 0].min()
-        ph = [(r[:, i] - r[:, i - 1]).mean().item() * ns / 1e3 for i in range(1, 6)]
-        span = (r[:, 5].max() - t0).item() * ns / 1e3
-        late = (r[:, 0].max() - t0).item() * ns / 1e3
-        print("%-20s %6.1f us (events, warm)  %3d wgs | cold run: first->last entry %.2f, span %.2f us | per-wg phases us: prologue %.2f  first tile %.2f  K loop %.2f  stage %.2f  epilogue+ack %.2f  (tick %.2f ns)  %s"
-              % (name, t_ev, r.shape[0], late, span, ph[0], ph[1], ph[2], ph[3], ph[4], ns, lib.last_kernel().decode()[:44]))
+        line = "%-20s %6.1f us (events, warm) %s" % (name, t_ev, lib.last_kernel().decode()[:44])
+        for tag, r in (("warm", res[4]), ("cold", res[9])):
+            r = r[r[:, 0] != 0].double()
+            if r.numel() == 0:
+                line += " | %s: no stamps" % tag; continue
+            tick = (r[:, 7] - r[:, 6]).clamp(min=1) * 10.0 / (r[:, 5] - r[:, 0]).clamp(min=1)     # ns per s_memtime tick (s_memrealtime = 100 MHz)
+            ns = tick.median().item()
+            t0 = r[:, 0].min()
+            ph = [(r[:, i] - r[:, i - 1]).mean().item() * ns / 1e3 for i in range(1, 6)]
+            span = (r[:, 5].max() - t0).item() * ns / 1e3
+            line += " | %s %3d wgs span %.2f us: prologue %.2f first tile %.2f K loop %.2f stage %.2f epilogue+ack %.2f" % (tag, r.shape[0], span, ph[0], ph[1], ph[2], ph[3], ph[4])
+        print(line)

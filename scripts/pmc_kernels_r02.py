@@ -20,7 +20,14 @@ dw = torch.empty_like(w); db = torch.zeros(128, device=dev)
 wsa = ops.WgradWorkspace(dev)
 L = torch.randn(64, 96, 320, 32, device=dev); R = torch.randn(64, 96, 320, 32, device=dev); out = torch.empty(64, 96, 320, 5, device=dev)
 L2 = torch.randn(16, 96, 320, 128, device=dev); R2 = torch.randn(16, 96, 320, 128, device=dev); out2 = torch.empty(16, 96, 320, 81, device=dev)
+bank = torch.zeros(ops.pack_bytes(w) // 4, device=dev); keep = []
+ops.pack_weights(lib, [(w, bank)], dev, keep)
+xs = torch.randn(1, 24, 80, 128, device=dev); ys = torch.empty(1, 24, 80, 128, device=dev)          # 1/16 resolution: the small-layer bank kernel
+bank1 = torch.zeros(ops.pack_bytes(w, 1) // 4, device=dev)
+ops.pack_weights(lib, [(w, bank1, 1, 0)], dev, keep)
 for _ in range(5):
+    ops.conv2d_fwd(lib, ops.view(x), w, b, ops.view(y), dil=2, alpha=0.2, stream=0, precision=2, wb=bank)
+    ops.conv2d_fwd(lib, ops.view(xs), w, b, ops.view(ys), alpha=0.2, stream=0, precision=1, wb=bank1)
     ops.conv2d_fwd(lib, ops.view(x), w, b, ops.view(y), dil=2, alpha=0.2, stream=0, precision=2)
     ops.conv2d_fwd(lib, ops.view(x), w, b, ops.view(y), dil=2, alpha=0.2, stream=0, precision=1)
     ops.PRECISION = 1

@@ -26,6 +26,8 @@ def mean_of(rows, pred, counter):
 
 CONV_BYTES = 2 * 15728640 + 589824 + 512
 KERNELS = {
+    "conv_fwd_x3_bank_3x3_128_128_96x320": (lambda n: "conv_bank_kernel<2, 4, 2, 2, true>" in n, CONV_BYTES, 9059696640.0),
+    "conv_fwd_bf16_bank_small_3x3_128_128_24x80": (lambda n: "conv_bank_small_kernel<false, 1>" in n, 2 * 24 * 80 * 128 * 4 + 589824 // 2 + 512, 2.0 * 24 * 80 * 9 * 128 * 128),
     "conv_fwd_x3_patch_3x3_128_128_96x320": (lambda n: "conv_patch_kernel" in n and "false, 4, true" in n, CONV_BYTES, 9059696640.0),
     "conv_fwd_bf16_patch_3x3_128_128_96x320": (lambda n: "conv_patch_kernel" in n and "false, 4, false" in n, CONV_BYTES, 9059696640.0),
     "conv_dgrad_bf16_patch_3x3_128_128_96x320": (lambda n: "conv_patch_kernel" in n and "true, 4, false" in n, CONV_BYTES + 15728640, 9059696640.0),

@@ -88,7 +88,9 @@ def test_dispnet_offline_training_step(bname, size):
     for n in wt:
         d = (eng.params.tensor(n).cpu() - wt[n]).abs()
         g = o["grads"].get(n)
-        solid = (g.abs() > 1e-4 * g.abs().max()) if g is not None else torch.ones_like(d, dtype=torch.bool)
+        # solid = well above the gradient error the checks above allow (5e-3 of the tensor's norm): a smaller element can change sign under
+        # another fp32 summation order, and Adam's first step then differs by 2 lr (seen on the MI355X at 128x256: 1.7e-3)
+        solid = (g.abs() > 5e-2 * g.abs().max()) if g is not None else torch.ones_like(d, dtype=torch.bool)
         if solid.any():
             dmax = max(dmax, d[solid].max().item())
         dmean = max(dmean, d.mean().item())
