@@ -1083,7 +1083,8 @@ extern "C" int mh_tune_conv_bank(int small_maxpix) {
 // small-layer bank kernel: stride-1 "SAME" 3x3, bank present, reduction <= 64 chunks (K <= 224), few enough pixels that the tiled kernels
 // are latency bound (default <= 4096 output pixels: the 1/16-1/64 levels; MH_CONV_BANK_SMALL_MAXPIX overrides, 0 = off)
 bool mh_conv_bank_small_ok(const ConvArgs& a) {
-    const int maxpix = bank_small_maxpix();
+    static const int maxpix_dgrad = []() { const char* e = getenv("MH_CONV_BANK_SMALL_MAXPIX_DGRAD"); return e ? atoi(e) : 0; }();   // A/B hook: 0 = same as forward
+    const int maxpix = (a.mode == 1 && maxpix_dgrad > 0) ? maxpix_dgrad : bank_small_maxpix();
     if (!a.wb || !(a.bf16 || a.x3) || (a.x3 && a.mode != 0)) return false;
     if (!(a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad_t == a.dil && a.pad_l == a.dil && a.Hi == a.Ho && a.Wi == a.Wo)) return false;
     if (a.ncls != 0 || a.N < 16 || a.K < 16 || a.dil > 64 || !a.vecA) return false;
@@ -1106,7 +1107,10 @@ bool mh_conv_patch_ok(const ConvArgs& a) {
     if (patch_mode() == 0) return false;
     if (!((a.bf16 || (a.x3 && a.mode == 0)) && a.vecA && a.vecB && a.vecC)) return false;
     if (!(a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad_t == a.dil && a.pad_l == a.dil && a.Hi == a.Ho && a.Wi == a.Wo)) return false;
-    if (a.ncls != 0 || a.N < 48 || a.K < 32 || a.dil > 64) return false;
+    // with a fragment bank the split-bf16 forward kernel also takes 32..47 output channels (half of its 64-column tile idles, still 18 -> 11 us
+    // for the 64->32 layers at 1/4 resolution against the exact-fp32 gather kernel; step -0.9 %)
+    static const int bank_min_n = []() { const char* e = getenv("MH_CONV_BANK_MIN_N"); return e ? atoi(e) : 32; }();      // A/B hook
+    if (a.ncls != 0 || a.N < ((a.x3 && a.wb && a.mode == 0) ? bank_min_n : 48) || a.K < 32 || a.dil > 64) return false;
     if (a.mode == 1 && (patch_mode() & 0x1000)) return false;                                  // mode bit 12: forward layers only
     if (a.mode == 1 && (patch_mode() & 0x2000) && a.K != 64 && a.K != 128) return false;       // mode bit 13: no generic-K input gradients
     const int bm = patch_bm(a), bn = patch_bn(a);

@@ -28,13 +28,14 @@ CTX = [(128, 1), (128, 2), (128, 4), (96, 8), (64, 16), (32, 1), (1, 1)]
 LEVELS = (6, 5, 4, 3, 2)
 FEAT = {6: 12, 5: 10, 4: 8, 3: 6, 2: 4}
 ALPHA = 0.2   # MadNet._leaky_relu (Nets/MadNet.py:366-367)
-# Two ways of taking work off the critical path that were MEASURED AND REJECTED as defaults (profiles/r02_experiments.txt, same box,
-# MADNet FULL): the warp-gradient scatters on a side lane (SCATTER_LANE = 1..4; 0 = in line) and the reduction of the loss value +
-# the validation metrics on a side lane (SIDE_LOSS).  In line / in line: 2.454 ms; scatter lane 3 + side loss 2.52-2.54; side loss
-# only 2.62; scatter only 2.65 -- every fork / join edge between hardware queues costs more (~10 us of bubble) than the 5-28 us
-# kernels it hides.  The code paths stay behind these switches for A/B runs.
+# Two ways of taking small kernels off the critical path (profiles/r02_experiments.txt #10, #20; same box, MADNet FULL): the warp-gradient
+# scatters on a side lane (SCATTER_LANE = 1..4; 0 = in line) and the reduction of the loss value + the validation metrics on a side
+# lane (SIDE_LOSS).  While side launches went out BEFORE the next lane-0 op both lost (in line / in line 2.454 ms; scatter lane 3 +
+# side loss 2.52-2.54; side loss only 2.62; scatter only 2.65: the critical path hopped to another hardware queue at every fork).  With
+# deferred side launches (mh_plan_run) the side loss wins 0.9 % (2.048 -> 2.030 ms) and is on; the scatters still lose (2.056 on lane 1,
+# 2.27 on a lane of their own).
 SCATTER_LANE = int(os.environ.get("MH_SCATTER_LANE", "0"))
-SIDE_LOSS = os.environ.get("MH_SIDE_LOSS", "0") != "0"
+SIDE_LOSS = os.environ.get("MH_SIDE_LOSS", "1") != "0"     # on since side launches are deferred: 2.048 -> 2.030 ms (r02z)
 
 
 def _r4(c):
@@ -177,6 +178,8 @@ class MadNetEngine(object):
         # ... and (bf16 / mixed) the layers of the 1/16-1/64 levels -- forward and input gradient -- take the small-layer bank kernel
         self.use_bank = precision in ("mixed", "bf16") and os.environ.get("MH_CONV_BANK", "1") != "0"
         self.bank_small_maxpix = int(os.environ.get("MH_CONV_BANK_SMALL_MAXPIX", "4096"))
+        self.bank_small_maxpix_dgrad = int(os.environ.get("MH_CONV_BANK_SMALL_MAXPIX_DGRAD", "0"))
+        self.bank_min_n = int(os.environ.get("MH_CONV_BANK_MIN_N", "32"))
         self.banks = {}
         self.banks_d = {}
         self.wsa = ops.WgradWorkspace(device)
@@ -298,11 +301,11 @@ class MadNetEngine(object):
             if kh != 3:
                 continue
             small = pix <= self.bank_small_maxpix and 9 * ((K + 31) // 32) <= 64
-            if code == 2 and N >= 16 and K >= 16 and (small or (N >= 48 and K >= 32)):
+            if code == 2 and N >= 16 and K >= 16 and (small or (N >= self.bank_min_n and K >= 32)):
                 plan.append((n, 2, 0))
             elif code == 1 and small and N >= 16 and K >= 16:
                 plan.append((n, 1, 0))
-            if bcode == 1 and pix <= self.bank_small_maxpix and K >= 16 and N >= 16 and 9 * ((N + 31) // 32) <= 64:
+            if bcode == 1 and pix <= max(self.bank_small_maxpix, self.bank_small_maxpix_dgrad) and K >= 16 and N >= 16 and 9 * ((N + 31) // 32) <= 64:
                 plan.append((n, 1, 1))
         return plan
 

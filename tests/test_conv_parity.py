@@ -598,7 +598,7 @@ def test_wgrad_partial_group_matches_single_launches(backend):
         assert (db1 - db2).abs().max().item() <= 1e-4 * max(1.0, db1.abs().max().item()), li
 
 
-@pytest.mark.parametrize("case", X3_CASES)
+@pytest.mark.parametrize("case", X3_CASES + [(1, 12, 20, 64, 32, 1), (1, 9, 21, 40, 36, 2)])
 def test_conv_split_bf16_fragment_bank_kernel(backend, case):
     """mh_conv2d_wb: the split-bf16 forward kernel that streams its weight operand from the MFMA fragment bank mh_pack_weights writes
     (no LDS staging of the weights, no barrier in the K walk).  Same arithmetic, same summation order as the LDS-staged split-bf16
@@ -630,10 +630,14 @@ def test_conv_split_bf16_fragment_bank_kernel(backend, case):
     finally:
         launches = backend.lib.tune_conv_patch(-1)
         nb2 = backend.lib.tune_conv_bank(-1)
-    assert nb == 1 and launches == 2 and nb2 == 0
     err = (y.cpu() - y_ref).abs().max().item()
     assert err <= 4e-5 * max(1.0, y_ref.abs().max().item()), err
-    assert torch.equal(y.cpu(), y0.cpu()), (y.cpu() - y0.cpu()).abs().max().item()
+    if Co >= 48:
+        assert nb == 1 and launches == 2 and nb2 == 0
+        assert torch.equal(y.cpu(), y0.cpu()), (y.cpu() - y0.cpu()).abs().max().item()
+    else:       # 32..47 output channels: only the bank kernel has a split-bf16 instance (the LDS-staged one starts at 48; without a bank: exact fp32)
+        assert nb == 1 and launches == 1 and nb2 == 0
+        assert (y.cpu() - y0.cpu()).abs().max().item() <= 4e-5 * max(1.0, y_ref.abs().max().item())
 
 
 SMALL_BANK_CASES = [   # (B, H, W, Cin, Cout, dil): the 1/16-1/64 level shapes + ragged ones
