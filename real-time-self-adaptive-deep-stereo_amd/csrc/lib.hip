@@ -281,15 +281,18 @@ extern "C" int mh_plan_run(const mh_op* ops, int32_t nops, void* stream) {
         // batch = this op + the following partial-filter-gradient ops of the same lane (no join / lane change in between)
         int m = 1;
         if (ops[k].kind == MH_OP_WGRAD_PARTIAL)
-            while (m < 16 && k + m < nops && ops[k + m].kind == MH_OP_WGRAD_PARTIAL && ops[k + m].i[26] == lane) ++m;
+            while (m < 16 && k + m < nops && ops[k + m].kind == MH_OP_WGRAD_PARTIAL && (ops[k + m].i[26] & ~MH_OP_NODEFER) == lane) ++m;
         auto run = [&](void* s) -> int { return m > 1 ? run_wgrad_batch(ops + k, m, s) : run_op(ops[k], s); };
         if (!e && lane > 0) {
             if (!L) e = lanes_get(&L);
             if (!e && stale[lane]) { e = lane_edge(*L, main_s, L->aux[lane]); stale[lane] = false; }
             if (!e) {
                 dirty[lane] = true;
-                if (defer_on) { deferred[ndef].k = k; deferred[ndef].m = m; deferred[ndef].lane = lane; ++ndef; }
-                else e = run((void*)L->aux[lane]);
+                if (defer_on && !(sched & MH_OP_NODEFER)) { deferred[ndef].k = k; deferred[ndef].m = m; deferred[ndef].lane = lane; ++ndef; }
+                else {
+                    if (ndef) e = flush_deferred();          // keep the lane's order
+                    if (!e) e = run((void*)L->aux[lane]);
+                }
             }
         } else if (!e) {
             e = run(stream);

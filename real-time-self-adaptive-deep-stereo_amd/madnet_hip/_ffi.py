@@ -34,6 +34,7 @@ class Op(C.Structure):
 
 
 OP_JOIN = 0x100
+OP_NODEFER = 0x200
 MAX_LANES = 5
 
 

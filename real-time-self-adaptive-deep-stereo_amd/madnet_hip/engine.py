@@ -35,6 +35,8 @@ ALPHA = 0.2   # MadNet._leaky_relu (Nets/MadNet.py:366-367)
 # deferred side launches (mh_plan_run) the side loss wins 0.9 % (2.048 -> 2.030 ms) and is on; the scatters still lose (2.056 on lane 1,
 # 2.27 on a lane of their own).
 SCATTER_LANE = int(os.environ.get("MH_SCATTER_LANE", "0"))
+# the first N filter-gradient batches of a backward pass are launched at once instead of after the next lane-0 op (MH_OP_NODEFER)
+NODEFER_BATCHES = int(os.environ.get("MH_NODEFER_BATCHES", "0"))
 SIDE_LOSS = os.environ.get("MH_SIDE_LOSS", "1") != "0"     # on since side launches are deferred: 2.048 -> 2.030 ms (r02z)
 
 
@@ -495,6 +497,7 @@ class MadNetEngine(object):
             if not pending:
                 return
             lib.lane = 1 + nflush[0] % self.wgrad_lanes
+            lib.nodefer = nflush[0] < NODEFER_BATCHES        # the first batches (context network, 1/4-resolution estimator) carry most of the work
             nflush[0] += 1
             try:
                 batch = []
@@ -508,6 +511,7 @@ class MadNetEngine(object):
                     ops.wgrad_reduce(lib, batch, self.dev, r.keep)
             finally:
                 lib.lane = 0
+                lib.nodefer = False
                 del pending[:]
 
         def acc_flag(key):

@@ -30,6 +30,7 @@ class Recorder(object):
         self.lane = 0           # scheduling lane of the ops recorded next (mh_op.i[26], include/madnet_hip.h)
         self.join_next = False  # next op: lane 0 first waits for the side lanes
         self.join_lanes_next = 0  # next op: lane 0 first waits for exactly the side lanes of this bit mask (bit l = lane l)
+        self.nodefer = False      # side-lane ops recorded now are launched at once (MH_OP_NODEFER)
 
     # -- helpers ---------------------------------------------------------------------------
     def _op(self, kind, ints=(), floats=(), ptrs=(), n=0):
@@ -42,7 +43,8 @@ class Recorder(object):
         for k, v in enumerate(ptrs):
             o.p[k] = _ptr(v)
         o.n = int(n)
-        o.i[26] = self.lane | (_ffi.OP_JOIN if self.join_next else 0) | ((self.join_lanes_next & 0xff) << 16)
+        o.i[26] = (self.lane | (_ffi.OP_JOIN if self.join_next else 0) | ((self.join_lanes_next & 0xff) << 16)
+                   | (_ffi.OP_NODEFER if (self.nodefer and self.lane > 0) else 0))
         self.join_next = False
         self.join_lanes_next = 0
         self.ops.append(o)
