@@ -35,6 +35,7 @@ ALPHA = 0.2   # MadNet._leaky_relu (Nets/MadNet.py:366-367)
 # deferred side launches (mh_plan_run) the side loss wins 0.9 % (2.048 -> 2.030 ms) and is on; the scatters still lose (2.056 on lane 1,
 # 2.27 on a lane of their own).
 SCATTER_LANE = int(os.environ.get("MH_SCATTER_LANE", "0"))
+PACK_LANE = int(os.environ.get("MH_PACK_LANE", "0"))        # lane of the per-step mh_pack_weights launch (0 = in line)
 # the first N filter-gradient batches of a backward pass are launched at once instead of after the next lane-0 op (MH_OP_NODEFER)
 NODEFER_BATCHES = int(os.environ.get("MH_NODEFER_BATCHES", "0"))
 SIDE_LOSS = os.environ.get("MH_SIDE_LOSS", "1") != "0"     # on since side launches are deferred: 2.048 -> 2.030 ms (r02z)
@@ -333,16 +334,32 @@ class MadNetEngine(object):
                 tgt = self.banks_d if trans else self.banks
                 if n not in tgt:
                     tgt[n] = torch.zeros(ops.pack_bytes(self.W_(n), planes, trans) // 4, device=self.dev)
-            ops.pack_weights(lib, [(self.W_(n), (self.banks_d if trans else self.banks)[n], planes, trans) for n, planes, trans in plan],
-                             self.dev, r.keep)
+            # PACK_LANE = 1: the pack launch runs on the side lane next to the first pyramid layers (none of them reads a bank) and is
+            # joined in front of the first layer that does
+            side_pack = PACK_LANE > 0 and self.wgrad_lanes > 0 and hasattr(lib, "lane")
+            if side_pack:
+                lib.lane = PACK_LANE
+            try:
+                ops.pack_weights(lib, [(self.W_(n), (self.banks_d if trans else self.banks)[n], planes, trans) for n, planes, trans in plan],
+                                 self.dev, r.keep)
+            finally:
+                if side_pack:
+                    lib.lane = 0
+        else:
+            side_pack = False
         ops.pad_reflect(lib, self.left, self.X0[:B], self.pt, self.pl)
         ops.pad_reflect(lib, self.right, self.X0[B:], self.pt, self.pl)
         x = ops.View(self.X0, 2 * B, self.Hp, self.Wp, 3, 4)
         for i, (ci, co, s) in enumerate(PYR, 1):
             o = self._fv(self.F[i])
+            if side_pack and self.Wb_(pyr_name(i)) is not None:
+                r.join_lanes_next = 1 << PACK_LANE
+                side_pack = False
             ops.conv2d_fwd(lib, x, self.W_(pyr_name(i)), self.b_(pyr_name(i)), o, stride=s, alpha=ALPHA, wt=self.Wt_(pyr_name(i)),
                            wb=self.Wb_(pyr_name(i)))
             x = o
+        if side_pack:
+            r.join_lanes_next = 1 << PACK_LANE
         for k in LEVELS:
             f = FEAT[k]
             h, w, c = self.fshape[f]
