@@ -33,10 +33,12 @@ static int g_wgrad_target_wgs = 0;
 // tuning hook (microbenchmarks): number of workgroups the pixel split aims for (0 = heuristic)
 static int g_wgrad_plain = 0;
 static int g_wgrad_tile64 = 0;
+static int g_wgrad_w8 = 0;
 extern "C" int mh_tune_wgrad_wgs(int target) {
     g_wgrad_plain = target < 0;                    // negative: timing experiment with plain stores (wrong results)
     if (target < 0) target = -target;
-    g_wgrad_tile64 = target >= 100000;             // + 100000: timing experiment, 64x64 tiles for the 128-wide layers (4x fewer pixel splits)
+    g_wgrad_tile64 = (target / 100000) == 1;       // + 100000: timing experiment, 64x64 tiles for the 128-wide layers (4x fewer pixel splits)
+    g_wgrad_w8 = (target / 100000) == 2 ? 1 : (target / 100000) == 3 ? 2 : 0;      // + 200000 / + 300000: 8-wave workgroups for the 128x128 tile (2x4 / 4x2 waves)
     target %= 100000;
     g_wgrad_target_wgs = target > 1 ? target : 0;
     return 0;
@@ -700,6 +702,12 @@ static int wgrad_dispatch(WgradArgs& a, hipStream_t s) {
     }
     // dW tile shape from the channel counts (rows = K = Cin, cols = N = Cout)
     MH_WG(K > 64 && N > 64 && g_wgrad_tile64, 2, 2, 2, 2, 32)   // (experiment) 64 x 64 tiles
+    MH_WG(K > 64 && N > 64 && g_wgrad_w8 == 1, 2, 4, 4, 2, 32)   // (experiment) 128 x 128 tile, 8 waves of 64 x 32
+    // 128 x 128 tile with 8 waves of 32 x 64 for the layers that are launched on their own (> 16384 reduction pixels): 126 VGPRs instead of
+    // 208 -> 4 waves per SIMD instead of 2 for the same two workgroups per CU; 32.4 -> 28.6 us at 96x320 (profiles/r02_microbench_wgrad_tiles.txt;
+    // the 128x64 / 64x128 tiles gain nothing from 8 waves).  Smaller layers keep the 4-wave shape: it is the one the grouped launch runs.
+    static const int w8_on = []() { const char* e = getenv("MH_WGRAD_W8"); return e ? atoi(e) : 1; }();       // A/B hook
+    MH_WG(K > 64 && N > 64 && a.M > 16384 && a.bf16 && w8_on && g_wgrad_w8 != 3, 4, 2, 2, 4, 32)
     MH_WG(K > 64 && N > 64, 2, 2, 4, 4, 32)                 // 128 x 128
     MH_WG(K > 64 && N > 32 && N <= 64, 2, 2, 4, 2, 32)      // 128 x 64
     MH_WG(K > 64 && N <= 32, 4, 1, 2, 1, 32)                // 128 x 16

@@ -90,7 +90,7 @@ def run_wgradp():
         x = torch.randn(B, H, W, ld, device=dev); xv = ops.View(x, B, H, W, Ci, ld)
         dz = torch.randn(B, H, W, Co, device=dev)
         out = []
-        for tile, tgt in (("128", 0), ("128/768wg", 768), ("64", 100000), ("64/768wg", 100768), ("64/1536wg", 101536)):
+        for tile, tgt in (("128", 0), ("128/768wg", 768), ("64", 100000), ("128 8w 2x4", 200000), ("128 8w 4x2", 300000), ("128 8w 2x4/768", 200768)):
             lib.tune_wgrad_wgs(tgt)
             dw = torch.zeros(3, 3, Ci, Co, device=dev); db = torch.zeros(Co, device=dev)
             wsa = ops.WgradWorkspace(dev); segs, keep = [], []

@@ -714,3 +714,30 @@ def test_conv_small_layer_bank_kernel(backend, case, what):
         sc = max(1.0, gx.abs().max().item())
         assert (outs[0] - exp).abs().max().item() <= 2e-5 * sc
         assert (outs[0] - outs[1]).abs().max().item() <= 4e-5 * sc
+
+
+def test_wgrad_bf16_eight_wave_tile(backend):
+    """Filter gradient of a layer that is launched on its own (> 16384 reduction pixels) with > 64 input and output channels: the 128x128
+    tile with 8 waves of 32x64 (wgrad_bf16_kernel<4,2,2,4>), partial sums + reduction, against the oracle on bf16-rounded operands."""
+    B, H, W, Ci, Co = 1, 130, 130, 72, 80
+    dev = backend.device
+    x = _rand((B, H, W, Ci), 411, dev)
+    gz = _rand((B, H, W, Co), 412, dev)
+    xb, xv = _padded(x, Ci)
+    zb, zv = _padded(gz, Co)
+    dw = torch.full((3, 3, Ci, Co), float("nan"), device=dev); db = torch.zeros(Co, device=dev)
+    wsa = ops.WgradWorkspace(dev); segs, keep = [], []
+    ops.PRECISION = 1
+    try:
+        ops.conv2d_wgrad_partial(backend.lib, backend.lib, wsa, segs, xv, zv, dw, db)
+        name = backend.lib.last_kernel().decode()
+    finally:
+        ops.PRECISION = 0
+    ops.wgrad_reduce(backend.lib, segs, dev, keep)
+    backend.sync()
+    assert "wgrad_bf16_kernel<4,2,2,4>" in name, name
+    xr = _bf(x.cpu()).double(); w0 = torch.zeros(3, 3, Ci, Co, dtype=torch.float64, requires_grad=True)
+    y = T.conv2d(xr, w0, None, alpha=1.0)
+    (gw,) = torch.autograd.grad(y, [w0], _bf(gz.cpu()).double())
+    assert (dw.cpu().double() - gw).abs().max().item() <= 2e-5 * max(1.0, gw.abs().max().item())
+    assert (db.cpu().double() - gz.cpu().double().sum((0, 1, 2))).abs().max().item() <= 1e-4 * max(1.0, gz.cpu().abs().sum((0, 1, 2)).max().item())
