@@ -272,6 +272,9 @@ static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only used on wave-uniform values
 static inline void __builtin_amdgcn_sched_barrier(int) {}                 // scheduling hint only
 static inline void __builtin_amdgcn_s_waitcnt(int) {}                    // no asynchronous loads on the emulator
+static inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned sh) {     // v_alignbit_b32: ({hi, lo} >> sh[4:0]) & 0xffffffff
+    return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (sh & 31));
+}
 
 static inline float atomicAdd(float* addr, float v) {
     uint32_t* p = (uint32_t*)addr;
