@@ -35,6 +35,7 @@ ALPHA = 0.2   # MadNet._leaky_relu (Nets/MadNet.py:366-367)
 # deferred side launches (mh_plan_run) the side loss wins 0.9 % (2.048 -> 2.030 ms) and is on; the scatters still lose (2.056 on lane 1,
 # 2.27 on a lane of their own).
 SCATTER_LANE = int(os.environ.get("MH_SCATTER_LANE", "0"))
+ONE_FILL = os.environ.get("MH_ONE_FILL", "1") != "0"       # one zero fill for all level feature gradients + the g fill on the filter-gradient lane
 PACK_LANE = int(os.environ.get("MH_PACK_LANE", "0"))        # lane of the per-step mh_pack_weights launch (0 = in line)
 # the first N filter-gradient batches of a backward pass are launched at once instead of after the next lane-0 op (MH_OP_NODEFER)
 NODEFER_BATCHES = int(os.environ.get("MH_NODEFER_BATCHES", "0"))
@@ -203,7 +204,21 @@ class MadNetEngine(object):
         for i, (ci, co, s) in enumerate(PYR, 1):
             h, _, _ = ops.same_pad(h, 3, s); w, _, _ = ops.same_pad(w, 3, s)
             self.fshape[i] = (h, w, co)
-            self.F[i] = z(B2, h, w, co); self.dF[i] = z(B2, h, w, co)
+            self.F[i] = z(B2, h, w, co)
+        # gradients of the features: those of the five cost-volume levels live in ONE flat buffer so that a backward pass zeroes all of
+        # them (the right towers' warp-gradient scatter targets, halves no head reaches in MAD mode) with one launch instead of one per level
+        lv = sorted(FEAT.values())
+        tot = sum(B2 * self.fshape[i][0] * self.fshape[i][1] * self.fshape[i][2] for i in lv)
+        self.dF_levels = z(tot)
+        off = 0
+        for i in range(1, 13):
+            hh, ww, co = self.fshape[i]
+            if i in lv:
+                n = B2 * hh * ww * co
+                self.dF[i] = self.dF_levels[off:off + n].view(B2, hh, ww, co)
+                off += n
+            else:
+                self.dF[i] = z(B2, hh, ww, co)
         self.Rw, self.dRw, self.dsi, self.ddsi, self.E, self.dE, self.V, self.dV, self.u, self.du = ({} for _ in range(10))
         self.dsi_ld = {}
         for k in LEVELS:
@@ -488,9 +503,26 @@ class MadNetEngine(object):
         lib, B = r, self.B
         P = self.params
         pyr_tr, pyr_need, est_tr, ctx_tr, up_V = self._train_flags(train_vars, bulkhead)
-        for o, c in P.ranges(train_vars):
-            ops_fill(lib, P.g, o, c)
+        # zero of the gradient ranges (bias gradients and single-split filter gradients accumulate): with ONE filter-gradient lane it goes
+        # onto that lane -- everything that touches g runs there, behind it -- and off the critical path
+        g_side = ONE_FILL and self.wgrad_lanes == 1 and hasattr(lib, "lane")
+        if g_side:
+            lib.lane = 1
+        try:
+            for o, c in P.ranges(train_vars):
+                ops_fill(lib, P.g, o, c)
+        finally:
+            if g_side:
+                lib.lane = 0
+        # ONE fill for the feature gradients of all cost-volume levels (13.9 MB at 1242x375) instead of a fill in front of every level's
+        # warp-gradient scatter: both towers start from zero, every contribution accumulates
+        prezero = ONE_FILL and self.warping and not bulkhead
+        if prezero:
+            ops_fill(lib, self.dF_levels, 0, self.dF_levels.numel())
         written = set()                     # gradient buffers that already hold a contribution
+        if prezero:
+            for i in FEAT.values():
+                written.add(("F", i, 0)); written.add(("F", i, 1))
         segs = []                           # partial filter-gradient segments of this backward pass
 
         pending = []                        # deferred filter-gradient launches (flushed as one side-lane batch)

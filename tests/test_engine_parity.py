@@ -180,9 +180,11 @@ def test_two_host_threads_one_device(hip):
         dw = (serial[i][0] - conc[i][0]).abs().max().item()
         dl = abs(serial[i][1] - conc[i][1])
         print("thread %d: |dw| concurrent-vs-serial %.3g (serial-vs-serial %.3g), |dloss| %.3g (%.3g)" % (i, dw, noise_w, dl, noise_l))
-        # same kernels, same order: only the summation order of the fp32 atomics differs, exactly as between two serial runs
-        assert dl <= 5 * noise_l + 1e-6 * max(1.0, abs(serial[i][1])), (i, dl, noise_l)
-        assert dw <= 5 * noise_w + 2e-6, (i, dw, noise_w)
+        # same kernels, same order: only the summation order of the fp32 atomics differs, exactly as between two serial runs.  That
+        # difference is amplified chaotically over the 6 steps: measured serial-vs-serial samples on one box range from 1.5e-11 to 6e-5
+        # (weights) / 0 to 1e-5 (loss), so ONE sample is no yardstick for a 5x bound -- a broken lane / event ring shows up as 1e-2 and more
+        assert dl <= max(5 * noise_l, 2e-4 * max(1.0, abs(serial[i][1]))), (i, dl, noise_l)
+        assert dw <= max(5 * noise_w, 5e-4), (i, dw, noise_w)
 
 
 @pytest.mark.gpu
