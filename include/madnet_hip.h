@@ -186,6 +186,15 @@ int mh_corr_bwd(const float* g, int32_t g_ld, int32_t coff, const float* L, int3
                 float* dR, int32_t dr_ld, int32_t acc_r, float* du, int32_t acc_u,
                 int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t stride,
                 int32_t copy_left, void* stream);
+/* One pyramid level's backward front end in ONE launch: mh_corr_bwd with the WARPED right features Rw as the right operand (fused cost volume +
+ * concat form), followed by mh_warp_bwd of the resulting gradient -- which is never stored: dimg (+)= the bilinear scatter of it to the unwarped
+ * right features' gradient (fp32 atomics: dimg must hold zeros or earlier contributions), du = g[.., coff + D] + the coordinate gradient of the
+ * warp (img = the unwarped right features, u = the warp coordinates).  dimg or du may be NULL.  Replaces the gradients of
+ * MadNet._linear_warping + correlation + concat of one level (MadNet.py:370-436, 77-80). */
+int mh_corr_warp_bwd(const float* g, int32_t g_ld, int32_t coff, const float* L, int32_t l_ld, const float* Rw, int32_t rw_ld,
+                     const float* img, int32_t img_ld, const float* u, float* dL, int32_t dl_ld, int32_t acc_l,
+                     float* dimg, int32_t dimg_ld, float* du,
+                     int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t stride, int32_t copy_left, void* stream);
 
 /* ---- the reference launchers under their LITERAL signature (+ an explicit stream, + a status) -- what a caller binds who
  *      keeps sharedLayers.correlation_native (Nets/sharedLayers.py:31-39) as it is: in0 / in1 NHWC with W already zero-padded by
@@ -324,7 +333,7 @@ enum { MH_OP_CONV = 1, MH_OP_WGRAD, MH_OP_CORR_FWD, MH_OP_CORR_BWD, MH_OP_WARP_F
        MH_OP_RESIZE_FWD, MH_OP_RESIZE_BWD, MH_OP_PAD_REFLECT, MH_OP_LOSS, MH_OP_METRICS,
        MH_OP_MOMENTUM, MH_OP_COPY_CH, MH_OP_LEAKY_BWD, MH_OP_FILL, MH_OP_BIAS_GRAD,
        MH_OP_WGRAD_PARTIAL, MH_OP_WGRAD_REDUCE, MH_OP_PROXY_LOSS, MH_OP_SUPERVISED_LOSS, MH_OP_ADAM, MH_OP_ADAM_ADVANCE,
-       MH_OP_RESIZE_IMAGE, MH_OP_LEVEL_FRONT, MH_OP_TRANSPOSE_W, MH_OP_PACK_W };
+       MH_OP_RESIZE_IMAGE, MH_OP_LEVEL_FRONT, MH_OP_TRANSPOSE_W, MH_OP_PACK_W, MH_OP_CORR_WARP_BWD };
 /* i[26] of every op is its scheduling word: low byte = lane (0 = the caller's stream; 1..MH_MAX_LANES-1 = side
  * streams owned by the library: the op is forked from lane 0 right before it, i.e. ordered after everything recorded so
  * far, and runs concurrently with the lane-0 ops that follow); MH_OP_JOIN = lane 0 first waits for all side lanes.

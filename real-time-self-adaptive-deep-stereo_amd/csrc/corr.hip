@@ -374,6 +374,92 @@ __global__ __launch_bounds__(256) void corr_bwd_kernel(CorrBwdArgs p) {
     }
 }
 
+// One level's backward front end in ONE launch: the gradient of the fused cost volume + concat (corr_bwd_kernel with the WARPED right features
+// as its right operand) and, straight from registers, the gradient of the warp that made them (ops.hip: warp_bwd_kernel): the gradient w.r.t. the
+// warped features is never stored -- it is scattered into the right tower's feature gradient (bilinear taps, fp32 atomics onto a zeroed buffer)
+// and contracted with the slope of the interpolation into the coordinate gradient, du = g[disparity channel] + sum_c dRw_c (R[i1] - R[i0]).
+// Thread layout of warp_bwd_kernel: LPP lanes per pixel walk the 4-channel groups, du reduced with shuffles.  Same arithmetic as the two
+// kernels in sequence (the scatter order differs, as between any two runs of the atomic version).
+struct CorrWarpBwdArgs {
+    const float* g; const float* L; const float* Rw; const float* img; const float* u;
+    float* dL; float* dimg; float* du;
+    int g_ld, coff, l_ld, rw_ld, img_ld, dl_ld, dimg_ld;
+    int acc_l;
+    int B, H, W, C, md, stride, D, copy_left;
+};
+template <int LPP>
+__global__ __launch_bounds__(256) void corr_warp_bwd_kernel(CorrWarpBwdArgs p) {
+    const int C4 = p.C >> 2;
+    constexpr int PPB = 256 / LPP;
+    const float inv_c = 1.0f / (float)p.C;
+    const int sub = threadIdx.x % LPP;
+    const int64_t npix = (int64_t)p.B * p.H * p.W;
+    const int64_t nit = (npix + PPB - 1) / PPB;
+    for (int64_t it = blockIdx.x; it < nit; it += gridDim.x) {
+        const int64_t pix = it * PPB + threadIdx.x / LPP;
+        const bool live = pix < npix;
+        const int64_t pp = live ? pix : 0;
+        const int x = (int)(pp % p.W);
+        const int64_t rowbase = pp - x;
+        const float* gp = p.g + pp * p.g_ld;
+        // warp geometry of this pixel (as warp_fwd / warp_bwd_kernel)
+        const float cx = (float)x + p.u[pp];
+        const float x0 = floorf(cx), x1 = x0 + 1.0f;
+        const float xmax = (float)(p.W - 1);
+        const float x0s = fminf(fmaxf(x0, 0.f), xmax), x1s = fminf(fmaxf(x1, 0.f), xmax);
+        const float m0 = (x0 == x0s) ? 1.f : 0.f, m1 = (x1 == x1s) ? 1.f : 0.f;
+        const float w0 = (x1 - cx) * m0, w1 = (cx - x0) * m1;
+        const int i0 = (int)x0s, i1 = (int)x1s;
+        float dcx = 0.f;
+        for (int c4 = sub; c4 < C4; c4 += LPP) {
+            if (!live) continue;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), r = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < p.D; ++j) {
+                const int i = j * p.stride - p.md;
+                const int xs = x + i;
+                if (xs >= 0 && xs < p.W) {
+                    const float gv = gp[p.coff + j];
+                    const float4 rv = *reinterpret_cast<const float4*>(p.Rw + (rowbase + xs) * p.rw_ld + c4 * 4);
+                    a.x += gv * rv.x; a.y += gv * rv.y; a.z += gv * rv.z; a.w += gv * rv.w;
+                }
+                const int xl = x - i;
+                if (xl >= 0 && xl < p.W) {
+                    const float gv = p.g[(rowbase + xl) * p.g_ld + p.coff + j];
+                    const float4 lv = *reinterpret_cast<const float4*>(p.L + (rowbase + xl) * p.l_ld + c4 * 4);
+                    r.x += gv * lv.x; r.y += gv * lv.y; r.z += gv * lv.z; r.w += gv * lv.w;
+                }
+            }
+            a.x *= inv_c; a.y *= inv_c; a.z *= inv_c; a.w *= inv_c;
+            r.x *= inv_c; r.y *= inv_c; r.z *= inv_c; r.w *= inv_c;
+            if (p.copy_left) {
+                const float4 gl = *reinterpret_cast<const float4*>(gp + c4 * 4);
+                a.x += gl.x; a.y += gl.y; a.z += gl.z; a.w += gl.w;
+            }
+            float4* dl = reinterpret_cast<float4*>(p.dL + pp * p.dl_ld + c4 * 4);
+            if (p.acc_l) { const float4 o = *dl; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
+            *dl = a;
+            // r = gradient w.r.t. the warped right features at this pixel: scatter it to its two source pixels ...
+            if (p.dimg) {
+                float* d0 = p.dimg + (rowbase + i0) * p.dimg_ld + c4 * 4;
+                float* d1 = p.dimg + (rowbase + i1) * p.dimg_ld + c4 * 4;
+                if (w0 != 0.f) { atomicAdd(d0 + 0, w0 * r.x); atomicAdd(d0 + 1, w0 * r.y); atomicAdd(d0 + 2, w0 * r.z); atomicAdd(d0 + 3, w0 * r.w); }
+                if (w1 != 0.f) { atomicAdd(d1 + 0, w1 * r.x); atomicAdd(d1 + 1, w1 * r.y); atomicAdd(d1 + 2, w1 * r.z); atomicAdd(d1 + 3, w1 * r.w); }
+            }
+            // ... and contract it with the slope of the interpolation
+            if (p.du) {
+                const float4 s0 = *reinterpret_cast<const float4*>(p.img + (rowbase + i0) * p.img_ld + c4 * 4);
+                const float4 s1 = *reinterpret_cast<const float4*>(p.img + (rowbase + i1) * p.img_ld + c4 * 4);
+                dcx += r.x * (m1 * s1.x - m0 * s0.x) + r.y * (m1 * s1.y - m0 * s0.y) + r.z * (m1 * s1.z - m0 * s0.z) + r.w * (m1 * s1.w - m0 * s0.w);
+            }
+        }
+        if (p.du) {
+#pragma unroll
+            for (int o = LPP >> 1; o > 0; o >>= 1) dcx += __shfl_xor(dcx, o);
+            if (live && sub == 0) p.du[pp] = gp[p.coff + p.D] + dcx;
+        }
+    }
+}
+
 // Large shift counts (DispNet, D = 81) on the matrix cores: out[x][d] = mean_c L[x][c] * R[x + d - md][c] is the band
 // |x' - x| <= md of the row-wise product L_row (W x C) * R_row^T (C x W).  One workgroup = one 64-pixel row segment,
 // one wave = 16 pixels; the right-feature window [x0 - md, x0 + 64 + md) is staged once in LDS (k-contiguous rows,
@@ -803,6 +889,32 @@ extern "C" int mh_level_front_fwd(const float* Vc, int32_t Hc, int32_t Wc, float
 #undef MH_FRONT
     mh_note_kernel("level_front_kernel<LPP=%d,DT=%d>", C4 <= 4 ? 4 : (C4 <= 8 ? 8 : 16), D <= 5 ? 5 : MAXD_SMALL);
     return mh_check_launch("level_front_fwd");
+}
+
+extern "C" int mh_corr_warp_bwd(const float* g, int32_t g_ld, int32_t coff, const float* L, int32_t l_ld, const float* Rw, int32_t rw_ld,
+                                const float* img, int32_t img_ld, const float* u, float* dL, int32_t dl_ld, int32_t acc_l,
+                                float* dimg, int32_t dimg_ld, float* du,
+                                int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t stride, int32_t copy_left, void* stream) {
+    MH_REQUIRE(g && L && Rw && img && u && dL && (dimg || du), MH_ERR_ARG, "mh_corr_warp_bwd: null argument");
+    MH_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && max_disp >= 0 && stride >= 1, MH_ERR_ARG, "mh_corr_warp_bwd: bad dimension");
+    MH_REQUIRE(C % 4 == 0 && l_ld % 4 == 0 && rw_ld % 4 == 0 && img_ld % 4 == 0 && dl_ld % 4 == 0 && (!dimg || dimg_ld % 4 == 0) &&
+               mh_aligned16(L) && mh_aligned16(Rw) && mh_aligned16(img) && mh_aligned16(dL), MH_ERR_ALIGN,
+               "mh_corr_warp_bwd: channel counts / lds must be multiples of 4 and pointers 16-byte aligned");
+    MH_REQUIRE(!copy_left || (g_ld % 4 == 0 && mh_aligned16(g)), MH_ERR_ALIGN, "mh_corr_warp_bwd: copy_left needs aligned g rows");
+    CorrWarpBwdArgs a;
+    a.g = g; a.L = L; a.Rw = Rw; a.img = img; a.u = u; a.dL = dL; a.dimg = dimg; a.du = du;
+    a.g_ld = g_ld; a.coff = coff; a.l_ld = l_ld; a.rw_ld = rw_ld; a.img_ld = img_ld; a.dl_ld = dl_ld; a.dimg_ld = dimg_ld;
+    a.acc_l = acc_l;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.md = max_disp; a.stride = stride; a.D = 2 * max_disp / stride + 1; a.copy_left = copy_left;
+    const int C4 = C / 4;
+    const int64_t npix = (int64_t)B * H * W;
+    hipStream_t s = (hipStream_t)stream;
+    auto grid = [&](int lpp) { int64_t b = (npix * lpp + 255) / 256; return (int)(b > (1 << 20) ? (1 << 20) : b); };
+    if (C4 <= 4) hipLaunchKernelGGL((corr_warp_bwd_kernel<4>), dim3(grid(4)), dim3(256), 0, s, a);
+    else if (C4 <= 8) hipLaunchKernelGGL((corr_warp_bwd_kernel<8>), dim3(grid(8)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((corr_warp_bwd_kernel<16>), dim3(grid(16)), dim3(256), 0, s, a);
+    mh_note_kernel("corr_warp_bwd_kernel<LPP=%d> C=%d D=%d", C4 <= 4 ? 4 : C4 <= 8 ? 8 : 16, C, a.D);
+    return mh_check_launch("corr_warp_bwd");
 }
 
 extern "C" int mh_corr_bwd(const float* g, int32_t g_ld, int32_t coff, const float* L, int32_t l_ld,

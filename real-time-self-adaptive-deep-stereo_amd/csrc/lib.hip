@@ -124,6 +124,10 @@ static int run_op(const mh_op& o, void* s) {
             return mh_adam_advance((float*)p[0], o.f[0], o.f[1], s);
         case MH_OP_PROXY_LOSS:
             return mh_proxy_loss((const float*)p[0], (const float*)p[1], (float*)p[2], (float*)p[3], (float*)p[4], o.f[0], o.f[1], i[0], i[1], i[2], s);
+        case MH_OP_CORR_WARP_BWD:
+            return mh_corr_warp_bwd((const float*)p[0], i[0], i[1], (const float*)p[1], i[2], (const float*)p[2], i[3], (const float*)p[3], i[4],
+                                    (const float*)p[4], (float*)p[5], i[5], i[6], (float*)p[6], i[7], (float*)p[7],
+                                    i[8], i[9], i[10], i[11], i[12], i[13], i[14], s);
         case MH_OP_PACK_W:
             return mh_pack_weights((const mh_pack_seg*)p[0], i[0], i[1], s);
         case MH_OP_WGRAD_REDUCE:

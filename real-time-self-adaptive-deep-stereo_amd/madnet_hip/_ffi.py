@@ -30,7 +30,7 @@ class Op(C.Structure):
 
 (OP_CONV, OP_WGRAD, OP_CORR_FWD, OP_CORR_BWD, OP_WARP_FWD, OP_WARP_BWD, OP_RESIZE_FWD, OP_RESIZE_BWD,
  OP_PAD_REFLECT, OP_LOSS, OP_METRICS, OP_MOMENTUM, OP_COPY_CH, OP_LEAKY_BWD, OP_FILL, OP_BIAS_GRAD,
- OP_WGRAD_PARTIAL, OP_WGRAD_REDUCE, OP_PROXY_LOSS, OP_SUPERVISED_LOSS, OP_ADAM, OP_ADAM_ADVANCE, OP_RESIZE_IMAGE, OP_LEVEL_FRONT, OP_TRANSPOSE_W, OP_PACK_W) = range(1, 27)
+ OP_WGRAD_PARTIAL, OP_WGRAD_REDUCE, OP_PROXY_LOSS, OP_SUPERVISED_LOSS, OP_ADAM, OP_ADAM_ADVANCE, OP_RESIZE_IMAGE, OP_LEVEL_FRONT, OP_TRANSPOSE_W, OP_PACK_W, OP_CORR_WARP_BWD) = range(1, 28)
 
 
 OP_JOIN = 0x100
@@ -79,6 +79,7 @@ SIGNATURES = {
     "mh_tune_conv_direct": (_I, [_I]),
     "mh_conv2d_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _I, _P, _P, _P]),
     "mh_conv2d_wgrad_partial": (_I, [C.POINTER(ConvDesc), _P, _P, _I, _P, C.POINTER(C.c_int32), _P, _P]),
+    "mh_corr_warp_bwd": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mh_conv2d_wb": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     "mh_pack_weights": (_I, [_P, _I, _I, _P]),
     "mh_pack_bytes": (_L, [_I, _I, _I, _I]),

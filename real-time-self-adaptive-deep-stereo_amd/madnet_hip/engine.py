@@ -36,6 +36,7 @@ ALPHA = 0.2   # MadNet._leaky_relu (Nets/MadNet.py:366-367)
 # 2.27 on a lane of their own).
 SCATTER_LANE = int(os.environ.get("MH_SCATTER_LANE", "0"))
 ONE_FILL = os.environ.get("MH_ONE_FILL", "1") != "0"       # one zero fill for all level feature gradients + the g fill on the filter-gradient lane
+FUSE_BACK = os.environ.get("MH_FUSE_BACK", "1") != "0"     # one launch for a level's correlation gradient + warp gradient (mh_corr_warp_bwd)
 PACK_LANE = int(os.environ.get("MH_PACK_LANE", "0"))        # lane of the per-step mh_pack_weights launch (0 = in line)
 # the first N filter-gradient batches of a backward pass are launched at once instead of after the next lane-0 op (MH_OP_NODEFER)
 NODEFER_BATCHES = int(os.environ.get("MH_NODEFER_BATCHES", "0"))
@@ -648,6 +649,16 @@ class MadNetEngine(object):
                 ops.corr_bwd(lib, g, Lk, Rk, dL, self._half(self.dF[f], True), self.md, self.cstride, coff=c, du=du,
                              acc_l=acc_flag(("F", f, 0)), acc_r=acc_flag(("F", f, 1)), acc_u=False, copy_left=True)
                 if du is not None:
+                    s_up = 2 ** k
+                    ops.resize_bwd(lib, self.du[k], self.V[k + 1], self.dV[k + 1], self.Hp // s_up, self.Wp // s_up,
+                                   mul=20.0 / s_up, mode=0, accumulate=acc_flag(("V", k + 1)))
+            elif FUSE_BACK and SCATTER_LANE == 0 and ("F", f, 1) in written:
+                # the level's correlation + concat gradient and the warp gradient in ONE launch (mh_corr_warp_bwd): the gradient w.r.t. the warped
+                # features never goes to memory; the scatter target was zeroed by the pass's single fill (or holds earlier contributions)
+                du = self.du[k] if need_u else None
+                ops.corr_warp_bwd(lib, g, Lk, self._fv(self.Rw[k]), self._half(self.F[f], True), self.u[k], dL, self._half(self.dF[f], True), du,
+                                  self.md, self.cstride, coff=c, acc_l=acc_flag(("F", f, 0)), copy_left=True)
+                if need_u:
                     s_up = 2 ** k
                     ops.resize_bwd(lib, self.du[k], self.V[k + 1], self.dV[k + 1], self.Hp // s_up, self.Wp // s_up,
                                    mul=20.0 / s_up, mode=0, accumulate=acc_flag(("V", k + 1)))

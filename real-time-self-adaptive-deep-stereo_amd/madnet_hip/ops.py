@@ -307,6 +307,13 @@ def corr_bwd(lib, g, L, R, dL, dR, max_disp, stride=1, coff=0, du=None, acc_l=Fa
                  _p(du), int(acc_u), L.B, L.H, L.W, L.C, max_disp, stride, int(copy_left), _p(stream))
 
 
+def corr_warp_bwd(lib, g, L, Rw, img, u, dL, dimg, du, max_disp, stride=1, coff=0, acc_l=False, copy_left=False, stream=None):
+    """corr_bwd(g, L, Rw -> dL, dRw, du = g[disparity channel]) + warp_bwd(dRw, img, u -> dimg scatter, du += coordinate gradient) in one
+    launch; dRw is never stored.  dimg must be zero / hold earlier contributions (atomics).  dimg or du may be None."""
+    lib.corr_warp_bwd(_p(g), g.ld, coff, _p(L), L.ld, _p(Rw), Rw.ld, _p(img), img.ld, _p(u), _p(dL), dL.ld, int(acc_l),
+                      _p(dimg), dimg.ld if dimg is not None else img.ld, _p(du), L.B, L.H, L.W, L.C, max_disp, stride, int(copy_left), _p(stream))
+
+
 def warp_fwd(lib, img, u, out, stream=None):
     lib.warp_fwd(_p(img), img.ld, _p(u), _p(out), out.ld, img.B, img.H, img.W, img.C, _p(stream))
 

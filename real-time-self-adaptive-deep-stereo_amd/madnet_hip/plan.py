@@ -119,6 +119,10 @@ class Recorder(object):
         self._op(_ffi.OP_CORR_BWD, [g_ld, coff, l_ld, r_ld, dl_ld, acc_l, dr_ld, acc_r, acc_u, B, H, W, Cc, md, stride, copy_left],
                  [], [g, L, R, dL, dR, du])
 
+    def corr_warp_bwd(self, g, g_ld, coff, L, l_ld, Rw, rw_ld, img, img_ld, u, dL, dl_ld, acc_l, dimg, dimg_ld, du, B, H, W, Cc, md, stride, copy_left, stream):
+        self._op(_ffi.OP_CORR_WARP_BWD, [g_ld, coff, l_ld, rw_ld, img_ld, dl_ld, acc_l, dimg_ld, B, H, W, Cc, md, stride, copy_left], [],
+                 [g, L, Rw, img, u, dL, dimg, du])
+
     def warp_fwd(self, img, img_ld, u, out, out_ld, B, H, W, Cc, stream):
         self._op(_ffi.OP_WARP_FWD, [img_ld, out_ld, B, H, W, Cc], [], [img, u, out])
 

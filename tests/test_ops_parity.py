@@ -414,3 +414,43 @@ def test_corr_fwd_large_d_bf16_and_split_bf16(backend, case):
     assert (out1.cpu() - ref_bf).abs().max().item() <= 2e-6
     e2 = (out2.cpu() - ref).abs().max().item(); e1 = (out1.cpu() - ref).abs().max().item()
     assert e2 <= 5e-6 and e2 * 30 <= e1, (e1, e2)          # |corr| ~ 0.3: 2^-16 relative per product, averaged over C channels
+
+
+@pytest.mark.parametrize("case", [(1, 12, 40, 32, 2, 1), (2, 9, 21, 96, 2, 1), (1, 7, 33, 64, 2, 1), (1, 6, 20, 192, 2, 1), (1, 10, 17, 16, 1, 1)])
+def test_corr_warp_bwd_fused_matches_corr_bwd_then_warp_bwd(backend, case):
+    """mh_corr_warp_bwd = mh_corr_bwd (warped right features as the right operand, fused concat form) + mh_warp_bwd of its result in one launch: dL and the
+    coordinate gradient du are compared with the two-launch sequence at rounding level, the atomic scatter with the tolerance of its summation order."""
+    B, H, W, Cc, md, stride = case
+    dev = backend.device
+    D = 2 * md // stride + 1
+    ld = (Cc + D + 1 + 3) // 4 * 4
+    g = torch.randn(B, H, W, ld, device=dev)
+    L = torch.randn(B, H, W, Cc, device=dev); R = torch.randn(B, H, W, Cc, device=dev)
+    u = (torch.rand(B, H, W, device=dev) - 0.5) * 6.0
+    Rw = torch.zeros(B, H, W, Cc, device=dev)
+    ops.warp_fwd(backend.lib, ops.view(R), u, ops.view(Rw))
+    gv = ops.View(g, B, H, W, ld, ld)
+    outs = []
+    for fused in (False, True):
+        dL = torch.full((B, H, W, Cc), 0.25, device=dev)                 # acc_l: accumulate onto an earlier contribution
+        dimg = torch.full((B, H, W, Cc), -0.5, device=dev)              # the scatter target holds an earlier contribution too
+        du = torch.full((B, H, W), float("nan"), device=dev)
+        if fused:
+            ops.corr_warp_bwd(backend.lib, gv, ops.view(L), ops.view(Rw), ops.view(R), u, ops.view(dL), ops.view(dimg), du, md, stride, coff=Cc, acc_l=True, copy_left=True)
+            assert "corr_warp_bwd_kernel" in backend.lib.last_kernel().decode()
+        else:
+            dRw = torch.zeros(B, H, W, Cc, device=dev)
+            ops.corr_bwd(backend.lib, gv, ops.view(L), ops.view(Rw), ops.view(dL), ops.view(dRw), md, stride, coff=Cc, du=du, acc_l=True, acc_r=False, acc_u=False, copy_left=True)
+            ops.warp_bwd(backend.lib, ops.view(dRw), ops.view(R), u, ops.view(dimg), du=du, acc_u=True)
+        backend.sync()
+        outs.append((dL.cpu(), dimg.cpu(), du.cpu()))
+    (dL0, di0, du0), (dL1, di1, du1) = outs
+    assert torch.isfinite(du1).all()
+    assert (dL0 - dL1).abs().max().item() <= 1e-6 * max(1.0, dL0.abs().max().item())
+    assert (du0 - du1).abs().max().item() <= 2e-5 * max(1.0, du0.abs().max().item())
+    assert (di0 - di1).abs().max().item() <= 2e-5 * max(1.0, di0.abs().max().item())
+    # du only / scatter only
+    du2 = torch.full((B, H, W), float("nan"), device=dev); dL2 = torch.zeros(B, H, W, Cc, device=dev)
+    ops.corr_warp_bwd(backend.lib, gv, ops.view(L), ops.view(Rw), ops.view(R), u, ops.view(dL2), None, du2, md, stride, coff=Cc, copy_left=True)
+    backend.sync()
+    assert (du2.cpu() - du1).abs().max().item() <= 2e-5 * max(1.0, du1.abs().max().item())
