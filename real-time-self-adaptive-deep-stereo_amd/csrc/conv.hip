@@ -21,6 +21,7 @@
 #include "mh_common.h"
 #include "conv_args.h"
 #include <stdlib.h>
+#include <atomic>
 
 namespace {
 
@@ -52,8 +53,12 @@ __device__ __forceinline__ int swz_group(int row, int g) { return g ^ ((row >> 2
 // their LDS tiles and walk every KG-th K-tile; the partial accumulator tiles meet in LDS in the epilogue.  A 32x32
 // tile at one wave per SIMD is bound by its ~200-instruction K-step (issue latency, not bytes): KG groups
 // interleave KG such instruction streams per SIMD.
-template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool VEC, bool UNI, bool BF16, int KG = 1>
+// X3 (forward, BF16 layout): split-bf16 -- hi and lo planes of both tiles in LDS, three bf16 MFMAs per product (lo*hi + hi*lo + hi*hi): the
+// forward layers without a patch / bank instance (strided, thin, wide-K, 5x5 / 7x7: the MADNet pyramid, most of DispNet) stay inside the
+// 1e-3 px tolerance at a third of the bf16 MFMA rate instead of on the exact-fp32 MFMA (a sixteenth, and 8x the MFMA instruction count).
+template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool VEC, bool UNI, bool BF16, int KG = 1, bool X3 = false>
 __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
+    static_assert(!X3 || (BF16 && !DGRAD && VEC), "split-bf16 instances: forward, vector path, bf16 tile layout");
 #ifdef MH_PHASE_TIMING
     const unsigned long long ts0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
@@ -83,7 +88,8 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
     // bf16 alike) -- these launches are not waiting on the load round trip but issuing it (address VALU + zero-padding loads of
     // 16 waves); the instances stay at distance 2.  The distance-4 schedule is kept for reference behind this constant.
     constexpr int PFD = !PF2 ? 1 : 2;
-    constexpr int TILE_FLOATS = BF16 ? (BM + BN) * LS / 2 : (BM + BN) * LS;   // one buffer of both tiles, in floats
+    constexpr int TILE_FLOATS = (BF16 ? (BM + BN) * LS / 2 : (BM + BN) * LS) * (X3 ? 2 : 1);   // one buffer of both tiles (and planes), in floats
+    constexpr int LO = 2 * (BM + BN) * LS;             // X3: the lo planes of both buffers sit this many halfs behind the hi planes
 
     HIP_DYNAMIC_SHARED(float, smem_all)
     const int kg = KG > 1 ? (int)(threadIdx.x >> 8) : 0;          // K group of this wave
@@ -336,7 +342,13 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
                 v.w = (a_kb_st + 3 < p.K) ? v.w : 0.f;
             }
             if (r < BM) {
-                if (BF16) *reinterpret_cast<uint2*>(&Ah[buf * (BM * LS) + r * LS + ga * 4]) = make_uint2(mh_pack_bf16(v.x, v.y), mh_pack_bf16(v.z, v.w));
+                if constexpr (X3) {
+                    uint2 hi, lo;
+                    mh_split_bf16x2(v.x, v.y, hi.x, lo.x);
+                    mh_split_bf16x2(v.z, v.w, hi.y, lo.y);
+                    *reinterpret_cast<uint2*>(&Ah[buf * (BM * LS) + r * LS + ga * 4]) = hi;
+                    *reinterpret_cast<uint2*>(&Ah[LO + buf * (BM * LS) + r * LS + ga * 4]) = lo;
+                } else if (BF16) *reinterpret_cast<uint2*>(&Ah[buf * (BM * LS) + r * LS + ga * 4]) = make_uint2(mh_pack_bf16(v.x, v.y), mh_pack_bf16(v.z, v.w));
                 else *reinterpret_cast<float4*>(&As[buf * (BM * LS) + r * LS + ga * 4]) = v;
             }
         }
@@ -351,10 +363,22 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
                     // 16-byte chunks XOR-swizzled by the row block: the 16 lanes of a ds_write_b64 group hold 16 different
                     // row blocks n4 at the same kk (rows 4*LS apart = 2 banks -> 8-way conflict unswizzled, 2-way with it)
                     unsigned short* d = Bb + (n4 * 4) * LS + ((((kk >> 3) ^ n4) & (KT / 8 - 1)) << 3) + (kk & 7);
+                    if constexpr (X3) {
+                        const float e[4][4] = {{v0.x, v1.x, v2.x, v3.x}, {v0.y, v1.y, v2.y, v3.y}, {v0.z, v1.z, v2.z, v3.z}, {v0.w, v1.w, v2.w, v3.w}};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            uint2 hi, lo;
+                            mh_split_bf16x2(e[c][0], e[c][1], hi.x, lo.x);
+                            mh_split_bf16x2(e[c][2], e[c][3], hi.y, lo.y);
+                            *reinterpret_cast<uint2*>(d + c * LS) = hi;
+                            *reinterpret_cast<uint2*>(d + LO + c * LS) = lo;
+                        }
+                    } else {
                     *reinterpret_cast<uint2*>(d) = make_uint2(mh_pack_bf16(v0.x, v1.x), mh_pack_bf16(v2.x, v3.x));
                     *reinterpret_cast<uint2*>(d + LS) = make_uint2(mh_pack_bf16(v0.y, v1.y), mh_pack_bf16(v2.y, v3.y));
                     *reinterpret_cast<uint2*>(d + 2 * LS) = make_uint2(mh_pack_bf16(v0.z, v1.z), mh_pack_bf16(v2.z, v3.z));
                     *reinterpret_cast<uint2*>(d + 3 * LS) = make_uint2(mh_pack_bf16(v0.w, v1.w), mh_pack_bf16(v2.w, v3.w));
+                    }
                 }
             }
             return;
@@ -402,10 +426,25 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
                     if (BT) b[j] = *reinterpret_cast<const u32x4*>(Bb + j * 16 * LS + ((((s * 4 + lq) ^ ((wn * NT * 16 + j * 16 + li) >> 2)) & (KT / 8 - 1)) << 3));
                     else b[j] = *reinterpret_cast<const u32x4*>(Bb + j * 16 * LS + s * 32);
                 }
+                if constexpr (X3) {
+                    u32x4 al[MT], bl[NT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) al[i] = *reinterpret_cast<const u32x4*>(Ab + LO + i * 16 * LS + s * 32);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        bl[j] = *reinterpret_cast<const u32x4*>(Bb + LO + j * 16 * LS + ((((s * 4 + lq) ^ ((wn * NT * 16 + j * 16 + li) >> 2)) & (KT / 8 - 1)) << 3));
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)             // t outermost: consecutive MFMAs hit different accumulators
+#pragma unroll
+                        for (int i = 0; i < MT; ++i)
+#pragma unroll
+                            for (int j = 0; j < NT; ++j) acc[i][j] = mh_mfma_bf16(t == 0 ? al[i] : a[i], t == 1 ? bl[j] : b[j], acc[i][j]);
+                } else {
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j) acc[i][j] = mh_mfma_bf16(a[i], b[j], acc[i][j]);
+                }
             }
         } else {
         const float* Ab = As + buf * (BM * LS) + (wm * MT * 16 + li) * LS + lq * 4;
@@ -772,20 +811,30 @@ static int launch_conv_thin(ConvArgs& a, hipStream_t s) {
     return mh_check_launch("conv_thin");
 }
 
+// split-bf16 on the tiled kernel: OFF by default.  Measured (profiles/r02_experiments.txt #27): the forward layers that have no patch / bank instance
+// are latency bound on their small tiles, and the doubled LDS planes + split conversions cost more than the exact-fp32 MFMAs they replace
+// (MADNet FULL 2.02 -> 2.17 ms, DispNet 4.39 -> 4.35 ms).  MH_CONV_X3_IGEMM=1 / mh_tune_conv_x3_igemm(1) switch it on (parity-tested).
+static std::atomic<int> g_x3_igemm{-1};
+static bool conv_x3_igemm_on() {
+    int v = g_x3_igemm.load(std::memory_order_relaxed);
+    if (v < 0) { const char* e = getenv("MH_CONV_X3_IGEMM"); v = e ? (atoi(e) != 0) : 0; g_x3_igemm.store(v, std::memory_order_relaxed); }
+    return v != 0;
+}
+extern "C" int mh_tune_conv_x3_igemm(int on) { g_x3_igemm = on < 0 ? -1 : (on != 0); return 0; }
 static bool g_no_uni = false;    // tuning hook: disable the uniform-tap fast path (A/B experiments)
 static bool g_split_k = true;    // tuning hook: intra-workgroup split-K of the small tiles
 static bool g_parity_classes = true;   // tuning hook: stride-2 dgrad as 4 parity-class sub-problems
 
-template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool VEC, bool UNI, bool BF16, int KG = 1>
+template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool VEC, bool UNI, bool BF16, int KG = 1, bool X3 = false>
 int launch_one(ConvArgs& a, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
-    constexpr size_t tiles = BF16 ? (size_t)(2 * (BM + BN) * (KT + 16)) * 2 : (size_t)(2 * (BM + BN) * (KT + 4)) * sizeof(float);
+    constexpr size_t tiles = (BF16 ? (size_t)(2 * (BM + BN) * (KT + 16)) * 2 : (size_t)(2 * (BM + BN) * (KT + 4)) * sizeof(float)) * (X3 ? 2 : 1);
     constexpr size_t lds = KG * tiles + 1536;          // + tap_dy / tap_dx / tap_id [64] and row_m [128]
     static_assert(lds <= 160 * 1024, "tiles do not fit the 160 KiB LDS");
     static bool attr_done = false;       // LDS > 64 KiB needs the opt-in once per instantiation
     if (!attr_done) {
         if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC, UNI, BF16, KG>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC, UNI, BF16, KG, X3>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) { mh_set_error("conv: hipFuncSetAttribute(%d B LDS): %s", (int)lds, hipGetErrorString(e)); return (int)e; }
         }
@@ -801,28 +850,28 @@ int launch_one(ConvArgs& a, hipStream_t s) {
     }
     const int nwg = a.mtiles * a.ntiles;
     mh_note_kernel("conv_igemm_kernel<%d,%d,%d,%d,KT=%d,%s,%s,%s,%s,KG=%d> tile %dx%d grid %d", WM, WN, MT, NT, KT, DGRAD ? "dgrad" : "fwd",
-                   VEC ? "vec" : "scalar", UNI ? "uni" : "gen", BF16 ? "bf16" : "f32", KG, BM, BN, nwg);
-    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC, UNI, BF16, KG>), dim3(nwg), dim3(256 * KG), lds, s, a);
+                   VEC ? "vec" : "scalar", UNI ? "uni" : "gen", X3 ? "bf16x3" : BF16 ? "bf16" : "f32", KG, BM, BN, nwg);
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC, UNI, BF16, KG, X3>), dim3(nwg), dim3(256 * KG), lds, s, a);
     return mh_check_launch("conv_igemm");
 }
 
 // small latency-bound tile on a grid smaller than the chip with a long K walk: 4 K groups per workgroup
-template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool UNI, bool BF16>
+template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool UNI, bool BF16, bool X3 = false>
 int launch_vec(ConvArgs& a, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
     constexpr bool SMALL = (BM * BN <= 32 * 64) && (BM <= 64) && KT == 64;
-    constexpr size_t tiles = BF16 ? (size_t)(2 * (BM + BN) * (KT + 16)) * 2 : (size_t)(2 * (BM + BN) * (KT + 4)) * sizeof(float);
+    constexpr size_t tiles = (BF16 ? (size_t)(2 * (BM + BN) * (KT + 16)) * 2 : (size_t)(2 * (BM + BN) * (KT + 4)) * sizeof(float)) * (X3 ? 2 : 1);
     constexpr int KGV = (4 * tiles + 1536 <= 160 * 1024) ? 4 : 2;       // K groups that fit the LDS
     if constexpr (SMALL) {
         const bool all = a.M < 0;
         const int64_t nwg = all ? 0 : (int64_t)mh_cdiv(a.M, BM) * mh_cdiv(a.N, BN);
         const int ktiles = all ? 0 : mh_cdiv(a.taps * a.G * 4, KT);
         if (all || (g_split_k && a.vecC && nwg <= 256 && ktiles >= 8)) {
-            const int rc = launch_one<WM, WN, MT, NT, KT, DGRAD, true, UNI, BF16, KGV>(a, s);
+            const int rc = launch_one<WM, WN, MT, NT, KT, DGRAD, true, UNI, BF16, KGV, X3>(a, s);
             if (!all || rc) return rc;
         }
     }
-    return launch_one<WM, WN, MT, NT, KT, DGRAD, true, UNI, BF16>(a, s);
+    return launch_one<WM, WN, MT, NT, KT, DGRAD, true, UNI, BF16, 1, X3>(a, s);
 }
 
 // F32 / B16: which arithmetic variants of this (tile, KT) are instantiated (bf16 runs KT = 64 only)
@@ -833,7 +882,13 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
     // uniform-tap fast path: whole K-tiles per tap, no channel padding, unit-stride gather
     const bool uni = vec && (a.K % KT == 0) && (!dg || a.sshift == 0 || a.ncls > 0) && !g_no_uni;
     const bool bf = a.bf16 && vec;                 // the scalar (odd-shape) path stays fp32
+    constexpr bool X3FIT = B16 && ((size_t)(2 * (WM * MT * 16 + WN * NT * 16) * (KT + 16)) * 2 * 2 + 1536 <= 160 * 1024);
+    const bool x3 = X3FIT && a.x3 && vec && !dg && conv_x3_igemm_on();       // split-bf16 forward on the tiled kernel
     int rc = 0;
+    if constexpr (X3FIT) {
+        if (all || (x3 && uni)) { rc = launch_vec<WM, WN, MT, NT, KT, false, true, true, true>(a, s); if (!all || rc) return rc; }
+        if (all || (x3 && !uni)) { rc = launch_vec<WM, WN, MT, NT, KT, false, false, true, true>(a, s); if (!all || rc) return rc; }
+    }
     if constexpr (F32) {
         if (all || (!bf && !dg && vec && uni)) { rc = launch_vec<WM, WN, MT, NT, KT, false, true, false>(a, s); if (!all || rc) return rc; }
         if (all || (!bf && !dg && vec && !uni)) { rc = launch_vec<WM, WN, MT, NT, KT, false, false, false>(a, s); if (!all || rc) return rc; }
@@ -920,7 +975,9 @@ static int conv_dispatch(ConvArgs& a, hipStream_t s) {
                 for (const TileCfg& t : kTiles) if (t.bm == bm && t.bn == bn && t.kt == 128) kt = 128;
         }
         if (kt == 0) for (const TileCfg& t : kTiles) if (t.bm == bm && t.bn == bn) { kt = t.kt; break; }
-        if (a.bf16 && a.vecA && a.vecB) kt = 64;        // bf16 tiles: 64 k-values (128 B) per LDS row
+        const bool x3f = a.x3 && a.mode == 0 && a.vecA && a.vecB && conv_x3_igemm_on();
+        if (x3f && bm == 128 && bn == 128) bn = 64;     // split-bf16: both planes of a 128x128 tile pair do not fit the LDS
+        if ((a.bf16 || x3f) && a.vecA && a.vecB) kt = 64;        // bf16 tiles: 64 k-values (128 B) per LDS row
         else if (kt == 64) {                            // fp32 has no KT=64 instance of the big (KT=32) tiles
             bool has = false;
             for (const TileCfg& t : kTiles) if (t.bm == bm && t.bn == bn && t.kt == 64) has = true;

@@ -741,3 +741,43 @@ def test_wgrad_bf16_eight_wave_tile(backend):
     (gw,) = torch.autograd.grad(y, [w0], _bf(gz.cpu()).double())
     assert (dw.cpu().double() - gw).abs().max().item() <= 2e-5 * max(1.0, gw.abs().max().item())
     assert (db.cpu().double() - gz.cpu().double().sum((0, 1, 2))).abs().max().item() <= 1e-4 * max(1.0, gz.cpu().abs().sum((0, 1, 2)).max().item())
+
+
+X3_IGEMM_CASES = [   # (B, H, W, Cin, Cout, k, stride, dil): layers no patch / bank kernel takes -- strided, thin, wide-K, 5x5 / 7x7
+    (2, 24, 40, 3, 16, 3, 2, 1), (2, 24, 40, 16, 16, 3, 1, 1), (1, 20, 36, 32, 64, 3, 2, 1), (1, 13, 29, 64, 96, 3, 2, 1), (1, 8, 20, 128, 192, 3, 2, 1),
+    (1, 16, 24, 3, 64, 7, 2, 1), (1, 12, 20, 64, 128, 5, 2, 1), (1, 10, 16, 145, 256, 5, 2, 1), (1, 6, 10, 512, 512, 3, 1, 1), (1, 9, 17, 96, 64, 3, 1, 16),
+    (1, 6, 20, 40, 20, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", X3_IGEMM_CASES)
+def test_conv_split_bf16_tiled_kernel(backend, case):
+    """precision code 2 on the tiled implicit-GEMM kernel (conv_igemm_kernel<..., X3>): hi / lo planes of both tiles in LDS, three bf16 MFMAs per
+    product -- the forward layers that have no patch / bank instance (the MADNet pyramid, DispNet's strided 7x7 / 5x5 / wide layers) judged
+    against the UNROUNDED fp64 oracle at the 2^-16 level, bias + leaky + accumulate epilogue included."""
+    B, H, W, Ci, Co, k, s, d = case
+    dev = backend.device
+    x = _rand((B, H, W, Ci), 611, dev)
+    w = _rand((k, k, Ci, Co), 612, dev, 0.2)
+    b = _rand((Co,), 613, dev)
+    ref = T.conv2d(x.cpu().double(), w.cpu().double(), b.cpu().double(), stride=s, dilation=d, alpha=0.2).float()
+    ld = (Ci + 3) // 4 * 4
+    xb, xv = _padded(x, ld)
+    if ld != Ci:
+        xb[..., Ci:] = float("nan")
+    old = _rand(tuple(ref.shape), 614, dev)
+    y = old.clone()
+    backend.lib.tune_conv_patch(0)            # (keep the patch / bank kernels out of the way: this is about the tiled kernel)
+    backend.lib.tune_conv_x3_igemm(1)         # off by default (measured slower than exact fp32 on these latency-bound layers)
+    try:
+        with ops.precision_scope("mixed"):
+            ops.conv2d_fwd(backend.lib, xv, w, b, ops.view(y), stride=s, dil=d, alpha=0.2, accumulate=True)
+        name = backend.lib.last_kernel().decode()
+        backend.sync()
+    finally:
+        backend.lib.tune_conv_patch(-1)
+        backend.lib.tune_conv_x3_igemm(-1)
+    if Co % 4 == 0:
+        assert "conv_igemm_kernel" in name and "bf16x3" in name, name
+    err = (y.cpu() - old.cpu() - ref).abs().max().item()
+    assert err <= 4e-5 * max(1.0, ref.abs().max().item()), (err, name)
