@@ -437,6 +437,19 @@ def main():
                            "wgrad_ws_bytes": st.get("wgrad_ws_bytes"), "grad_bytes": st.get("grad_bytes"),
                            "wgrad_ws_over_grad": (st.get("wgrad_ws_bytes", 0.0) / st["grad_bytes"]) if st.get("grad_bytes") else None},
     }
+    if rank == 0 and world == 1 and dispnet and SB == 1 and dev.kind == "cuda" and not args.no_cpu_baseline:
+        # DispNet: disparity of the run's arithmetic mode against the fp32 CPU oracle on the bench pair (the same check MADNet's line carries)
+        from oracle import dispnet as OD
+        wt_ = {k: torch.from_numpy(v.copy()) for k, v in wn.items()}
+        with torch.no_grad():
+            d_or = OD.forward(wt_, torch.from_numpy(l), torch.from_numpy(r))[-1][..., 0]
+        e0 = mk(args.precision); feed(e0)
+        e0.build_plan("NONE").run(lib, 0)
+        torch.cuda.synchronize()
+        out["epe_vs_oracle"] = float((e0.pred.cpu() - d_or).abs().mean().item())
+        out["epe_tolerance"] = 1e-3
+        out["within_tolerance"] = out["epe_vs_oracle"] <= 1e-3
+        del e0
     extras = rank == 0 and world == 1 and not dispnet and SB == 1 and CS == 1 and not shared and dev.kind == "cuda" and args.mode == "FULL"
     if extras:
         if not args.no_roofline:

@@ -14,6 +14,7 @@ storages) and the backward plan is derived mechanically from it:
 MAD is not offered for DispNet: the shipped block_config/dispnet_full.json has 5 groups for 6
 predictions, so the reference's own assert fails (Stereo_Online_Adaptation.py:97).
 """
+import os
 import torch
 
 from . import ops
@@ -185,6 +186,17 @@ class DispNetEngine(object):
     def b_(self, n, which="w"):
         return self.params.tensor("model/%s/bias" % n, which)
 
+    # 'mixed': the layers whose bf16 rounding moves the final disparity by <= 1e-4 px each (3.3e-4 px together) run plain bf16 in the forward pass
+    # too -- conv_redir, conv3 .. conv6/1 and the three coarsest up-blocks (profiles/r02_precision_map_dispnet.txt: rounding ONE group's operands to
+    # bf16, everything else fp32); conv1 (6.9e-3), conv2 (9.7e-4), up2 (1.0e-3), up1 (5.7e-3) and prediction (9.1e-3) keep split-bf16 / exact fp32
+    MIXED_BF16_FWD = ("conv_redir", "conv3", "conv4", "conv5", "conv6", "up5", "up4", "up3")
+
+    def _fwd_code(self, wn):
+        if self.precision != "mixed" or os.environ.get("MH_DISPNET_MIXED_BF16", "1") == "0":
+            return None
+        head = wn.split("/")[0]
+        return 1 if head in self.MIXED_BF16_FWD else None
+
     # ---- forward --------------------------------------------------------------------------------------
     def record_forward(self, r):
         B = self.B
@@ -195,10 +207,10 @@ class DispNetEngine(object):
             kind = op[0]
             if kind == "conv":
                 _, x, wn, out, stride, alpha, _ = op
-                ops.conv2d_fwd(r, x.view(), self.W_(wn), self.b_(wn), out.view(), stride=stride, alpha=alpha)
+                ops.conv2d_fwd(r, x.view(), self.W_(wn), self.b_(wn), out.view(), stride=stride, alpha=alpha, precision=self._fwd_code(wn))
             elif kind == "deconv":
                 _, x, wn, out, alpha = op
-                ops.conv2d_transpose_fwd(r, x.view(), self.W_(wn), self.b_(wn), out.view(), stride=2, alpha=alpha)
+                ops.conv2d_transpose_fwd(r, x.view(), self.W_(wn), self.b_(wn), out.view(), stride=2, alpha=alpha, precision=self._fwd_code(wn))
             elif kind == "corr":
                 _, L, R, out, whole = op
                 ops.corr_fwd(r, L.view(), R.view(), whole.view(), MAX_DISP, 1, coff=0)

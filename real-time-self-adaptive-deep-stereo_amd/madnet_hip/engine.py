@@ -37,6 +37,7 @@ ALPHA = 0.2   # MadNet._leaky_relu (Nets/MadNet.py:366-367)
 SCATTER_LANE = int(os.environ.get("MH_SCATTER_LANE", "0"))
 ONE_FILL = os.environ.get("MH_ONE_FILL", "1") != "0"       # one zero fill for all level feature gradients + the g fill on the filter-gradient lane
 FUSE_BACK = os.environ.get("MH_FUSE_BACK", "1") != "0"     # one launch for a level's correlation gradient + warp gradient (mh_corr_warp_bwd)
+PYR_BF16_FROM = int(os.environ.get("MH_PYR_BF16_FROM", "7"))     # 'mixed': pyramid layers from this one on run plain bf16 in the forward pass (13 = none)
 PACK_LANE = int(os.environ.get("MH_PACK_LANE", "0"))        # lane of the per-step mh_pack_weights launch (0 = in line)
 # the first N filter-gradient batches of a backward pass are launched at once instead of after the next lane-0 op (MH_OP_NODEFER)
 NODEFER_BATCHES = int(os.environ.get("MH_NODEFER_BATCHES", "0"))
@@ -294,6 +295,14 @@ class MadNetEngine(object):
         """... for the input gradient (small layers, bf16 backward)"""
         return self.banks_d.get(base)
 
+    def _pyr_code(self, i, fcode=None):
+        """forward precision code of pyramid layer i: in 'mixed' conv7 .. conv12 (1/16 resolution and below) run plain bf16 -- rounding ONE of them
+        to bf16 moves the final disparity by 7e-5 (conv7), 6.8e-5 (conv8), 8e-6 (conv9 .. conv12) px, 1.7e-4 px together (per-layer map,
+        profiles/r02_precision_map.txt); conv1 .. conv6 (9e-3 .. 9e-4 each) keep split-bf16 / exact fp32.  None = the mode's code."""
+        if self.precision == "mixed" and i >= PYR_BF16_FROM:
+            return 1
+        return fcode
+
     def _bank_plan(self):
         """[(layer, planes, trans)]: which fragment banks this engine packs every step.  Forward: planes follow the precision code the
         layer runs (2 = split-bf16 -> the 64x128 / 128x64 bank kernel or, <= bank_small_maxpix output pixels, the small-layer kernel;
@@ -307,7 +316,7 @@ class MadNetEngine(object):
         for i in range(2, 13, 2):                                   # the stride-1 pyramid layers
             lv = [k for k, f in FEAT.items() if f == i]
             h, w = (self.fshape[i][0], self.fshape[i][1])
-            layers.append((pyr_name(i), fcode, 2 * B * h * w))
+            layers.append((pyr_name(i), self._pyr_code(i, fcode), 2 * B * h * w))
         for k in LEVELS:
             h, w, _ = self.fshape[FEAT[k]]
             code = 1 if (self.precision == "mixed" and k >= 4) else fcode
@@ -372,7 +381,7 @@ class MadNetEngine(object):
                 r.join_lanes_next = 1 << PACK_LANE
                 side_pack = False
             ops.conv2d_fwd(lib, x, self.W_(pyr_name(i)), self.b_(pyr_name(i)), o, stride=s, alpha=ALPHA, wt=self.Wt_(pyr_name(i)),
-                           wb=self.Wb_(pyr_name(i)))
+                           wb=self.Wb_(pyr_name(i)), precision=self._pyr_code(i))
             x = o
         if side_pack:
             r.join_lanes_next = 1 << PACK_LANE

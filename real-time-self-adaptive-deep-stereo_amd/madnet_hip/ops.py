@@ -272,14 +272,14 @@ def wgrad_reduce(lib, segs, device, keep, stream=None, accumulate=False):
     lib.wgrad_reduce(C.c_void_p(table.data_ptr()), len(segs), blk, _p(stream))
 
 
-def conv2d_transpose_fwd(lib, x, w, b, out, stride=2, alpha=1.0, stream=None):
+def conv2d_transpose_fwd(lib, x, w, b, out, stride=2, alpha=1.0, stream=None, precision=None):
     """tf.nn.conv2d_transpose(x, w[kh,kw,Cout,Cin], 'SAME') + b, leaky (sharedLayers.py:80-92):
     the input-gradient of a SAME conv with HWIO = [kh,kw,I=Cout,O=Cin]."""
     kh, kw, cout, cin = w.shape
     Ho, Wo = x.H * stride, x.W * stride
     _, _, pt, pl = conv_geometry(Ho, Wo, kh, kw, stride, 1)
     assert (out.H, out.W, out.C) == (Ho, Wo, cout) and x.C == cin
-    d = conv_desc(x.B, x.H, x.W, Ho, Wo, cin, cout, kh, kw, stride, 1, pt, pl, 1, 1, x.ld, out.ld, alpha=alpha)
+    d = conv_desc(x.B, x.H, x.W, Ho, Wo, cin, cout, kh, kw, stride, 1, pt, pl, 1, 1, x.ld, out.ld, alpha=alpha, precision=precision)
     lib.conv2d(C.byref(d), _p(x), _p(w), _p(b), _p(out), None, _p(stream))
 
 

@@ -166,3 +166,25 @@ def test_dispnet_factory_and_disparities(hip):
         Adapter(net, mode="MAD", block_config=[[]] * 6)
     out = Adapter(net, mode="FULL", lr=1e-4).step(l, r, gt[..., 0])
     assert out["loss"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,lo,hi", [("mixed", 0.0, 1e-3), ("fp32", 0.0, 1e-4), ("bf16", 1e-3, 0.05)])
+def test_dispnet_headline_modes_vs_oracle(precision, lo, hi):
+    """DispNet forward at the headline size (375x1242) in the three arithmetic modes against the fp32 CPU oracle: 'mixed' -- split-bf16 / exact fp32 on
+    conv1, conv2, up2, up1, prediction and plain bf16 on conv_redir, conv3 .. conv6/1, up5 .. up3 (profiles/r02_precision_map_dispnet.txt) --
+    must stay inside the 1e-3 px tolerance; 'bf16' everywhere does not (and is reported as such)."""
+    from conftest import _hip_backend
+    backend = _hip_backend()
+    H, W = 375, 1242
+    wn = S.calibrated_weights(OD.variable_shapes(), 1)
+    l, r, gt = S.make_pair(H, W)
+    eng = DE.DispNetEngine(backend.lib, H, W, B=1, device=backend.device, weights=wn, precision=precision)
+    eng.set_inputs(l, r, gt[..., 0])
+    eng.build_plan("NONE").run(backend.lib, 0)
+    backend.sync()
+    with torch.no_grad():
+        d = OD.forward({k: torch.from_numpy(v) for k, v in wn.items()}, torch.from_numpy(l), torch.from_numpy(r))[-1][..., 0]
+    epe = (eng.pred.cpu() - d).abs().mean().item()
+    print("DispNet %s (MI355X 375x1242) EPE vs oracle %.3g" % (precision, epe))
+    assert lo <= epe <= hi, epe
