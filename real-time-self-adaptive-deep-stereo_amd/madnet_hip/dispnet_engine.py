@@ -213,7 +213,9 @@ class DispNetEngine(object):
                 ops.conv2d_transpose_fwd(r, x.view(), self.W_(wn), self.b_(wn), out.view(), stride=2, alpha=alpha, precision=self._fwd_code(wn))
             elif kind == "corr":
                 _, L, R, out, whole = op
-                ops.corr_fwd(r, L.view(), R.view(), whole.view(), MAX_DISP, 1, coff=0)
+                # 'mixed': the 81-shift volume on plain bf16 MFMA -- rounding ITS operands to bf16 moves the final disparity by 1.3e-6 px
+                # (profiles/r02_precision_map_dispnet.txt), and conv3, which reads it, runs bf16 anyway
+                ops.corr_fwd(r, L.view(), R.view(), whole.view(), MAX_DISP, 1, coff=0, precision=self._fwd_code("conv3"))
             elif kind == "final":
                 # rescaled_prediction = crop(resize(prediction) * 2)  (DispNet.py:149-151; no relu)
                 ops.resize_fwd(r, op[1].st.t.view(B, op[1].st.H, op[1].st.W), self.pred, self.Hp, self.Wp, self.pt, self.pl,
