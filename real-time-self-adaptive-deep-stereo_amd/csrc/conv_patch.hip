@@ -1144,6 +1144,8 @@ int mh_conv_patch_launch(ConvArgs& a, hipStream_t s) {
         const bool wb = !all && a.wb && a.x3 && a.mode == 0 && !(patch_mode() & 0x4000);       // mode bit 14: ignore the bank
         const bool big = !all && (patch_mode() & 0x8000) != 0;                                  // mode bit 15: 128-pixel tile (64x32 wave tiles)
         if (all || (wb && bn == 128 && big)) { rc = launch_bank<2, 4, 4, 2, true>(a, s); if (!all || rc) return rc; }
+        const bool w4 = !all && (patch_mode() & 0x10000) != 0;                                 // mode bit 16: 64-pixel tile with 4 waves of 64x32 (half the fragment bytes per MFMA)
+        if (all || (wb && bn == 128 && w4)) { rc = launch_bank<1, 4, 4, 2, true>(a, s); if (!all || rc) return rc; }
         if (all || (wb && bn == 128)) { rc = launch_bank<2, 4, 2, 2, true>(a, s); if (!all || rc) return rc; }
         if (all || (wb && bn == 64)) { rc = launch_bank<4, 2, 2, 2, true>(a, s); if (!all || rc) return rc; }
     }

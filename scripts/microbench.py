@@ -233,7 +233,7 @@ def run_bank():
     PL = [("L2 128->128 d1", 1, 96, 320, 128, 128, 1), ("L2 128->128 d2", 1, 96, 320, 128, 128, 2), ("L2 128->128 d8", 1, 96, 320, 128, 128, 8),
           ("L2 128->96", 1, 96, 320, 128, 96, 1), ("L2 96->64", 1, 96, 320, 96, 64, 1), ("L2 38->128", 1, 96, 320, 38, 128, 1),
           ("L3 128->128", 1, 48, 160, 128, 128, 1), ("L3 70->128", 1, 48, 160, 70, 128, 1), ("L4 128->128", 1, 24, 80, 128, 128, 1)]
-    print("%-16s %9s | %9s %9s %9s %9s   %s" % ("layer (fwd)", "x3 LDS", "x3 bank", "bank noK", "bank nostg", "bank 128px", "max |diff|"))
+    print("%-16s %9s | %9s %9s %9s %9s %9s   %s" % ("layer (fwd)", "x3 LDS", "x3 bank", "bank noK", "bank nostg", "bank 128px", "bank 4w", "max |diff|"))
     for name, B, H, W, Ci, Co, d in PL:
         ld = (Ci + 3) // 4 * 4
         xb = torch.zeros(B, H, W, ld, device=dev); xb[..., :Ci] = torch.randn(B, H, W, Ci, device=dev); xv = ops.View(xb, B, H, W, Ci, ld)
@@ -245,7 +245,7 @@ def run_bank():
         flops = 2.0 * B * H * W * 9 * Ci * Co
         res = []
         ops.PRECISION = 2
-        for m, wb, out in ((128, None, y), (128, bank, y2), (128 + 512, bank, y2), (128 + 1024, bank, y2), (128 + 0x8000, bank, y2)):
+        for m, wb, out in ((128, None, y), (128, bank, y2), (128 + 512, bank, y2), (128 + 1024, bank, y2), (128 + 0x8000, bank, y2), (128 + 0x10000, bank, y2)):
             lib.tune_conv_patch(m)
             with torch.cuda.stream(stream):
                 res.append(_time_ms(lib, stream, lambda: ops.conv2d_fwd(lib, xv, w, b, ops.view(out), stride=1, dil=d, alpha=0.2, stream=stream.cuda_stream, wb=wb), 20) * 1e3)
@@ -256,7 +256,7 @@ def run_bank():
         ops.PRECISION = 0
         lib.tune_conv_patch(-1)
         lib.tune_conv_bank(-1)
-        print("%-16s %9.1f | %9.1f %9.1f %9.1f %9.1f   %.3g   (bank %.0f TF/s algorithmic, %s)" % (name, res[0], res[1], res[2], res[3], res[4], (y - y2).abs().max().item(),
+        print("%-16s %9.1f | %9.1f %9.1f %9.1f %9.1f %9.1f   %.3g   (bank %.0f TF/s algorithmic, %s)" % (name, res[0], res[1], res[2], res[3], res[4], res[5], (y - y2).abs().max().item(),
               flops / (res[1] * 1e-6) / 1e12, lib.last_kernel().decode()[:60]))
     shapes = [(38, 128), (128, 128), (128, 96), (96, 64), (70, 128), (128, 128), (128, 96), (96, 64), (33, 128), (128, 128), (128, 128), (128, 96), (96, 64)]
     ws = [torch.randn(3, 3, k, n, device=dev) for k, n in shapes]
