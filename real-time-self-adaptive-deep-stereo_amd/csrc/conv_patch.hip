@@ -1128,7 +1128,10 @@ bool mh_conv_patch_ok(const ConvArgs& a) {
         // kernel instead of the bf16 one, which moves the break-even down to the 1/8-resolution level (7680 pixels: 20 us vs
         // 24-29 us; at 1920 pixels fp32 wins, 14 vs 19.5 us -- profiles/r02_microbench_x3dbg.txt)
         // (measured in situ: 128-column layers 24-28 -> 19-20 us, the 64-column one 17.6 -> 20.8 us: wide layers only)
-        if ((int64_t)a.B * a.Ho * a.Wo < ((a.x3 && a.N > 64) ? min_pix * 5 / 16 : min_pix)) return false;
+        // with a fragment bank the split-bf16 kernel also beats the exact-fp32 gather kernel on the <= 64-column layers at 1/8 resolution
+        static const int bank_min_pix = []() { const char* e = getenv("MH_CONV_BANK_MINPIX"); return e ? atoi(e) : 7680; }();      // A/B hook
+        const int need = (a.x3 && a.wb && a.mode == 0) ? (bank_min_pix < min_pix ? bank_min_pix : min_pix) : ((a.x3 && a.N > 64) ? min_pix * 5 / 16 : min_pix);
+        if ((int64_t)a.B * a.Ho * a.Wo < need) return false;
     }
     return (int64_t)a.B * d * d * mh_cdiv(mh_cdiv(a.Ho, d), TH) * mh_cdiv(mh_cdiv(a.Wo, d), 16) < (1 << 30);
 }
