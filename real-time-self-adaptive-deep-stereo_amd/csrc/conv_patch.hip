@@ -750,6 +750,8 @@ __global__ __launch_bounds__(1024) void conv_bank_small_kernel(ConvArgs p, Patch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int d = p.dil;
+    const int st = DGRAD ? 1 : p.stride;             // forward: stride 1 (any dilation) or stride 2 (dilation 1): output pixel (i, j) reads patch (i*st + ky, j*st + kx)
+    const int PC = st * 16 + 3 - st;                 // patch columns: 18 / 33 ; rows: st * TH + 3 - st = 4 / 5
 
     int lin = mh_xcd_remap(blockIdx.x, g.nwg);
     const int tile_n = lin % g.ntiles_n; lin /= g.ntiles_n;
@@ -783,11 +785,11 @@ __global__ __launch_bounds__(1024) void conv_bank_small_kernel(ConvArgs p, Patch
     // ---- stage the 4 x 18 input patch (bf16; hi + lo planes for PL = 2) ---------------------------------------------------
     {
         const int kp4 = g.KP >> 2;
-        const int items = (TH + 2) * PW * kp4;
+        const int items = (st * TH + 3 - st) * PC * kp4;
         for (int q0 = tid; q0 < items; q0 += NTH) {
             const int c4 = q0 % kp4, pp = q0 / kp4;
-            const int pi = pp / PW, pj = pp - pi * PW;
-            const int iy = y00 + (pi - 1) * d, ix = x00 + (pj - 1) * d;
+            const int pi = pp / PC, pj = pp - pi * PC;
+            const int iy = y00 * st - p.pad_t + pi * d, ix = x00 * st - p.pad_l + pj * d;      // (stride 1: pad = dilation)
             const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi && (c4 < p.G);
             float4 w = mh_buf_load4(rs_in, ok ? (((b * p.Hi + iy) * p.Wi + ix) * p.in_ld + c4 * 4) * 4 : MH_OOB);
             w.y = (c4 * 4 + 1 < p.K) ? w.y : 0.f;           // the row padding between K and in_ld is not ours to trust
@@ -811,7 +813,7 @@ __global__ __launch_bounds__(1024) void conv_bank_small_kernel(ConvArgs p, Patch
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const unsigned short* const Pw = Ph + li * g.PS + lq * 8;
+    const unsigned short* const Pw = Ph + (li * st) * g.PS + lq * 8;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int q = wave + 16 * c;
@@ -819,12 +821,12 @@ __global__ __launch_bounds__(1024) void conv_bank_small_kernel(ConvArgs p, Patch
             const int tap = q / g.CPT, c32 = q - tap * g.CPT;
             const int ky = tap / 3, kx = tap - ky * 3;
             const int oy = DGRAD ? 2 - ky : ky, ox = DGRAD ? 2 - kx : kx;
-            const unsigned short* Ab = Pw + (oy * PW + ox) * g.PS + c32 * 32;
+            const unsigned short* Ab = Pw + (oy * PC + ox) * g.PS + c32 * 32;
             u32x4 fa[MT][PL];
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int pl = 0; pl < PL; ++pl) fa[i][pl] = *reinterpret_cast<const u32x4*>(Ab + pl * g.patch_halfs + i * PW * g.PS);
+                for (int pl = 0; pl < PL; ++pl) fa[i][pl] = *reinterpret_cast<const u32x4*>(Ab + pl * g.patch_halfs + (i * st) * PC * g.PS);
 #pragma unroll
             for (int t = (PL == 2 ? 0 : 2); t < 3; ++t)
 #pragma unroll
@@ -1008,7 +1010,8 @@ int launch_bank_small(ConvArgs& a, hipStream_t s) {
     g.CPT = g.KP / 32;
     g.PS = g.KP + 16;
     g.nchunk = 9 * g.CPT;
-    g.patch_halfs = 4 * PW * g.PS;
+    const int st = DGRAD ? 1 : a.stride;
+    g.patch_halfs = (st * 2 + 3 - st) * (st * 16 + 3 - st) * g.PS;
     g.inv_kp4 = 1.0f / (float)(g.KP / 4);
     g.dbg = 0;
     const size_t patch = (size_t)g.patch_halfs * 2 * PL, cs = (size_t)16 * 32 * 33 * 4;
@@ -1086,9 +1089,14 @@ bool mh_conv_bank_small_ok(const ConvArgs& a) {
     static const int maxpix_dgrad = []() { const char* e = getenv("MH_CONV_BANK_SMALL_MAXPIX_DGRAD"); return e ? atoi(e) : 0; }();   // A/B hook: 0 = same as forward
     const int maxpix = (a.mode == 1 && maxpix_dgrad > 0) ? maxpix_dgrad : bank_small_maxpix();
     if (!a.wb || !(a.bf16 || a.x3) || (a.x3 && a.mode != 0)) return false;
-    if (!(a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad_t == a.dil && a.pad_l == a.dil && a.Hi == a.Ho && a.Wi == a.Wo)) return false;
+    static const int s2_on = []() { const char* e = getenv("MH_CONV_BANK_SMALL_S2"); return e ? atoi(e) : 1; }();      // A/B hook: stride-2 forward layers
+    const bool s1 = a.stride == 1 && a.pad_t == a.dil && a.pad_l == a.dil && a.Hi == a.Ho && a.Wi == a.Wo;
+    const bool s2 = s2_on && a.stride == 2 && a.mode == 0 && a.dil == 1 && a.pad_t >= 0 && a.pad_t <= 1 && a.pad_l >= 0 && a.pad_l <= 1 &&
+                    a.Ho == (a.Hi + 1) / 2 && a.Wo == (a.Wi + 1) / 2;
+    if (!(a.kh == 3 && a.kw == 3 && (s1 || s2))) return false;
     if (a.ncls != 0 || a.N < 16 || a.K < 16 || a.dil > 64 || !a.vecA) return false;
     if (9 * ((a.K + 31) / 32) > 64) return false;
+    if (s2 && (size_t)5 * 33 * (((a.K + 31) & ~31) + 16) * 2 * (a.x3 ? 2 : 1) > PATCH_LDS_MAX) return false;
     if ((int64_t)a.B * a.Ho * a.Wo > maxpix) return false;
     const int d = a.dil;
     const int64_t cover = (int64_t)d * d * mh_cdiv(mh_cdiv(a.Ho, d), 2) * 2 * mh_cdiv(mh_cdiv(a.Wo, d), 16) * 16;

@@ -313,9 +313,13 @@ class MadNetEngine(object):
         shapes = dict(self.params.manifest)
         B = self.B
         layers = []          # (name, forward precision code, output pixels)
-        for i in range(2, 13, 2):                                   # the stride-1 pyramid layers
-            lv = [k for k, f in FEAT.items() if f == i]
+        stride2 = set()
+        for i in range(2, 13):                                      # the stride-1 pyramid layers and the small stride-2 ones (conv7 / 9 / 11)
             h, w = (self.fshape[i][0], self.fshape[i][1])
+            if PYR[i - 1][2] == 2:
+                if 2 * B * h * w > self.bank_small_maxpix:
+                    continue
+                stride2.add(pyr_name(i))
             layers.append((pyr_name(i), self._pyr_code(i, fcode), 2 * B * h * w))
         for k in LEVELS:
             h, w, _ = self.fshape[FEAT[k]]
@@ -333,6 +337,8 @@ class MadNetEngine(object):
                 plan.append((n, 2, 0))
             elif code == 1 and small and N >= 16 and K >= 16:
                 plan.append((n, 1, 0))
+            if n in stride2:
+                continue                                            # (forward only: the stride-2 input gradient runs parity classes on the tiled kernel)
             if bcode == 1 and pix <= max(self.bank_small_maxpix, self.bank_small_maxpix_dgrad) and K >= 16 and N >= 16 and 9 * ((N + 31) // 32) <= 64:
                 plan.append((n, 1, 1))
         return plan

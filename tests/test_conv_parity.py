@@ -646,6 +646,39 @@ SMALL_BANK_CASES = [   # (B, H, W, Cin, Cout, dil): the 1/16-1/64 level shapes +
 ]
 
 
+@pytest.mark.parametrize("x3", [False, True], ids=["bf16", "x3"])
+@pytest.mark.parametrize("case", [(2, 24, 80, 64, 96), (2, 12, 40, 96, 128), (1, 13, 41, 128, 192), (1, 9, 20, 70, 48), (1, 48, 64, 32, 64)])
+def test_conv_small_layer_bank_kernel_stride2(backend, case, x3):
+    """The stride-2 forward instances of the small-layer bank kernel (pyramid conv7 / conv9 / conv11: 5 x 33 input patch per 2 x 16 output tile), even
+    and odd input sizes (TF 'SAME': pad 0 / 1 in front), against the oracle on identically rounded operands."""
+    B, H, W, Ci, Co = case
+    dev = backend.device
+    x = _rand((B, H, W, Ci), 711, dev)
+    w = _rand((3, 3, Ci, Co), 712, dev, 0.2)
+    b = _rand((Co,), 713, dev)
+    ld = (Ci + 3) // 4 * 4
+    xb, xv = _padded(x, ld)
+    if ld != Ci:
+        xb[..., Ci:] = float("nan")
+    planes = 2 if x3 else 1
+    keep = []
+    bank = torch.full((ops.pack_bytes(w, planes) // 4,), float("nan"), device=dev)
+    ops.pack_weights(backend.lib, [(w, bank, planes, 0)], dev, keep)
+    Ho, Wo, _, _ = ops.conv_geometry(H, W, 3, 3, 2, 1)
+    y = torch.full((B, Ho, Wo, Co), float("nan"), device=dev)
+    backend.lib.tune_conv_bank(-1)
+    with ops.precision_scope("mixed" if x3 else "bf16"):
+        ops.conv2d_fwd(backend.lib, xv, w, b, ops.view(y), stride=2, alpha=0.2, wb=bank)
+    name = backend.lib.last_kernel().decode()
+    backend.sync()
+    assert backend.lib.tune_conv_bank(-1) == 1 and "conv_bank_small" in name, name
+    if x3:
+        ref = T.conv2d(x.cpu().double(), w.cpu().double(), b.cpu().double(), stride=2, alpha=0.2).float(); tol = 4e-5
+    else:
+        ref = T.conv2d(_bf(x.cpu()).double(), _bf(w.cpu()).double(), b.cpu().double(), stride=2, alpha=0.2).float(); tol = 2e-5
+    assert (y.cpu() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("what", ["fwd-bf16", "fwd-x3", "dgrad-bf16"])
 @pytest.mark.parametrize("case", SMALL_BANK_CASES)
 def test_conv_small_layer_bank_kernel(backend, case, what):
