@@ -1130,8 +1130,11 @@ bool mh_conv_patch_ok(const ConvArgs& a) {
         // thresholds of the heuristic (environment overrides for the in-situ A/B runs of scripts/gpu_ab.sh)
         static int min_pix = -1, max_cover = -1;
         if (min_pix < 0) { const char* e = getenv("MH_CONV_PATCH_MINPIX"); min_pix = e ? atoi(e) : 24576; }
-        if (max_cover < 0) { const char* e = getenv("MH_CONV_PATCH_COVER"); max_cover = e ? atoi(e) : 125; }
-        if (cover * 100 > (int64_t)a.Ho * a.Wo * max_cover) return false;      // default: < 80 % useful tile pixels -> the gather kernel wins
+        if (max_cover < 0) { const char* e = getenv("MH_CONV_PATCH_COVER"); max_cover = e ? atoi(e) : 220; }
+        // lattice tiles may cover up to 2.2x the image: round 1 set 125 % (bf16 kernel vs the bf16 gather kernel, stand-alone); in the round-2 step the
+        // context layers of dilation 8 / 16 (213 % at 96x320) are faster on the patch / bank kernels than on the tiled ones, forward (where the
+        // alternative is exact fp32: 40 us) and input gradient alike: 1.986 -> 1.956 ms, bf16 mode 1.887 -> 1.869, MAD 1.104 -> 1.087 (r03y3)
+        if (cover * 100 > (int64_t)a.Ho * a.Wo * max_cover) return false;
         // default: fewer than ~200 128-pixel tiles = not one workgroup per CU.  Split-bf16 competes with the exact-fp32 gather
         // kernel instead of the bf16 one, which moves the break-even down to the 1/8-resolution level (7680 pixels: 20 us vs
         // 24-29 us; at 1920 pixels fp32 wins, 14 vs 19.5 us -- profiles/r02_microbench_x3dbg.txt)
