@@ -505,7 +505,11 @@ int launch_wgrad_bf16(WgradArgs& a, hipStream_t s) {
     a.ntiles = mh_cdiv(a.N, BN);
     const int base = (a.flat ? mh_cdiv(a.taps, BK / 4) : a.taps) * a.ktiles * a.ntiles;
     constexpr int units = WM * WN * MT * NT;
-    const int target = g_wgrad_target_wgs > 0 ? g_wgrad_target_wgs : (units >= 32 ? 384 : (units >= 8 ? 768 : 1536));
+    // workgroup targets of the pixel split: 256 / 512 / 1024 by tile size (round 1: 384 / 768 / 1536, tuned while the filter gradients overlapped the
+    // input-gradient chain; in the deferred one-lane step they mostly run alone and fewer splits = less partial-sum traffic: 1.961 -> 1.912 ms at 2/3,
+    // 1.911 at 1/2, 1.964 at 0.4, 2.03 at 1/3; experiments #34).  MH_WGRAD_TARGET_PCT scales them (A/B hook).
+    static const int env_scale = []() { const char* e = getenv("MH_WGRAD_TARGET_PCT"); return e ? atoi(e) : 100; }();
+    const int target = g_wgrad_target_wgs > 0 ? g_wgrad_target_wgs : (units >= 32 ? 256 : (units >= 8 ? 512 : 1024)) * env_scale / 100;
     int splits = a.forced_splits > 0 ? a.forced_splits : mh_cdiv(target, base);
     int maxs = mh_cdiv(a.M, PT * 2);
     static const int cap = []() { const char* e = getenv("MH_WGRAD_MAXSPLITS"); return e ? atoi(e) : 192; }();   // A/B hook
