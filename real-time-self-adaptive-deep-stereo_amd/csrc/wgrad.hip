@@ -707,11 +707,11 @@ static int wgrad_dispatch(WgradArgs& a, hipStream_t s) {
     // dW tile shape from the channel counts (rows = K = Cin, cols = N = Cout)
     MH_WG(K > 64 && N > 64 && g_wgrad_tile64, 2, 2, 2, 2, 32)   // (experiment) 64 x 64 tiles
     MH_WG(K > 64 && N > 64 && g_wgrad_w8 == 1, 2, 4, 4, 2, 32)   // (experiment) 128 x 128 tile, 8 waves of 64 x 32
-    // 128 x 128 tile with 8 waves of 32 x 64 for the layers that are launched on their own (> 16384 reduction pixels): 126 VGPRs instead of
+    // 128 x 128 tile with 8 waves of 32 x 64 for the layers that are launched on their own (> 4096 reduction pixels): 126 VGPRs instead of
     // 208 -> 4 waves per SIMD instead of 2 for the same two workgroups per CU; 32.4 -> 28.6 us at 96x320 (profiles/r02_microbench_wgrad_tiles.txt;
     // the 128x64 / 64x128 tiles gain nothing from 8 waves).  Smaller layers keep the 4-wave shape: it is the one the grouped launch runs.
     static const int w8_on = []() { const char* e = getenv("MH_WGRAD_W8"); return e ? atoi(e) : 1; }();       // A/B hook
-    MH_WG(K > 64 && N > 64 && a.M > 16384 && a.bf16 && w8_on && g_wgrad_w8 != 3, 4, 2, 2, 4, 32)
+    MH_WG(K > 64 && N > 64 && a.M > 4096 && a.bf16 && w8_on && g_wgrad_w8 != 3, 4, 2, 2, 4, 32)
     MH_WG(K > 64 && N > 64, 2, 2, 4, 4, 32)                 // 128 x 128
     MH_WG(K > 64 && N > 32 && N <= 64, 2, 2, 4, 2, 32)      // 128 x 64
     MH_WG(K > 64 && N <= 32, 4, 1, 2, 1, 32)                // 128 x 16
@@ -829,10 +829,11 @@ extern "C" int mh_conv2d_wgrad_partial_group(const mh_wgrad_item* items, int32_t
         MH_REQUIRE(used == it.splits, MH_ERR_ARG, "mh_conv2d_wgrad_partial_group: item %d: split count %d does not match this geometry (%d)", i, it.splits, used);
         WgradArgs a; WgradCapture c{-1, 0, 0};
         if (int rc = wgrad_entry(&it.d, it.in, it.dout, it.dout_ld, nullptr, it.db, it.ws, it.splits, 0, nullptr, stream, &a, &c)) return rc;
-        // grouped: layers whose own launch is dispatch-latency bound (<= max_m reduction pixels: 1/8 resolution and below).  The big layers
+        // grouped: layers whose own launch is dispatch-latency bound (<= max_m reduction pixels: 1/16 resolution and below).  The big layers
         // fill the chip alone, and as one long grid they only coarsen the interleaving with the input-gradient chain (measured: +1.5 %
         // step time with everything grouped); 1- and 2-wave tile shapes would idle most of a 256-thread workgroup.
-        static const int max_m = []() { const char* e = getenv("MH_WGRAD_GROUP_MAXM"); return e ? atoi(e) : 16384; }();
+        // (cap re-swept at the end of round 2, experiments #35: 16384: 1.918 ms | 8192: 1.903 | 4096: 1.899 | 2048: 1.905)
+        static const int max_m = []() { const char* e = getenv("MH_WGRAD_GROUP_MAXM"); return e ? atoi(e) : 4096; }();
         const bool narrow = (c.cfg == 8 || c.cfg == 10 || c.cfg == 11);
         if (!group_on || c.cfg < 0 || narrow || a.M > max_m || c.lds > (size_t)MH_WG_GROUP_LDS || c.nblocks <= 0) {
             if (int rc = single(it)) return rc;

@@ -750,7 +750,7 @@ def test_conv_small_layer_bank_kernel(backend, case, what):
 
 
 def test_wgrad_bf16_eight_wave_tile(backend):
-    """Filter gradient of a layer that is launched on its own (> 16384 reduction pixels) with > 64 input and output channels: the 128x128
+    """Filter gradient of a layer that is launched on its own (> 4096 reduction pixels) with > 64 input and output channels: the 128x128
     tile with 8 waves of 32x64 (wgrad_bf16_kernel<4,2,2,4>), partial sums + reduction, against the oracle on bf16-rounded operands."""
     B, H, W, Ci, Co = 1, 130, 130, 72, 80
     dev = backend.device
