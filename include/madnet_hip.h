@@ -139,6 +139,9 @@ typedef struct mh_wgrad_item {
     const float* in; const float* dout;
     float* ws; float* db;
     int32_t dout_ld, splits;
+    int32_t group_max_m;  /* > 0: group this layer only if it has at most this many reduction pixels (0 = library default 4096 / MH_WGRAD_GROUP_MAXM);
+                             the largest value of a batch applies to the whole batch */
+    int32_t reserved;
 } mh_wgrad_item;
 int mh_conv2d_wgrad_partial_group(const mh_wgrad_item* items, int32_t n, void* stream);
 typedef struct mh_wgrad_seg {

@@ -238,6 +238,7 @@ static int run_wgrad_batch(const mh_op* ops, int m, void* s) {
         items[k].in = (const float*)o.p[0]; items[k].dout = (const float*)o.p[1];
         items[k].ws = (float*)o.p[2]; items[k].db = (float*)o.p[3];
         items[k].dout_ld = o.i[21]; items[k].splits = o.i[23];
+        items[k].group_max_m = o.i[24]; items[k].reserved = 0;
     }
     return mh_conv2d_wgrad_partial_group(items, m, s);
 }

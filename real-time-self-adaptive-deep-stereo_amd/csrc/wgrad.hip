@@ -509,7 +509,10 @@ int launch_wgrad_bf16(WgradArgs& a, hipStream_t s) {
     // input-gradient chain; in the deferred one-lane step they mostly run alone and fewer splits = less partial-sum traffic: 1.961 -> 1.912 ms at 2/3,
     // 1.911 at 1/2, 1.964 at 0.4, 2.03 at 1/3; experiments #34).  MH_WGRAD_TARGET_PCT scales them (A/B hook).
     static const int env_scale = []() { const char* e = getenv("MH_WGRAD_TARGET_PCT"); return e ? atoi(e) : 100; }();
-    const int target = g_wgrad_target_wgs > 0 ? g_wgrad_target_wgs : (units >= 32 ? 256 : (units >= 8 ? 512 : 1024)) * env_scale / 100;
+    // (layers with more than 65536 reduction pixels -- several streams batched through one model, DispNet's / the pyramid's full-size layers -- are
+    //  throughput bound and keep the round-1 targets: B = 4 batched 834 vs 796 pairs/s)
+    const int base_t = a.M > 65536 ? (units >= 32 ? 384 : (units >= 8 ? 768 : 1536)) : (units >= 32 ? 256 : (units >= 8 ? 512 : 1024));
+    const int target = g_wgrad_target_wgs > 0 ? g_wgrad_target_wgs : base_t * env_scale / 100;
     int splits = a.forced_splits > 0 ? a.forced_splits : mh_cdiv(target, base);
     int maxs = mh_cdiv(a.M, PT * 2);
     static const int cap = []() { const char* e = getenv("MH_WGRAD_MAXSPLITS"); return e ? atoi(e) : 192; }();   // A/B hook
@@ -821,6 +824,8 @@ extern "C" int mh_conv2d_wgrad_partial_group(const mh_wgrad_item* items, int32_t
         G.n = 0; G.blk0[0] = 0; lds = 0; first = -1;
         return rc;
     };
+    int batch_max_m = 0;
+    for (int i = 0; i < n; ++i) if (items[i].group_max_m > batch_max_m) batch_max_m = items[i].group_max_m;
     for (int i = 0; i < n; ++i) {
         const mh_wgrad_item& it = items[i];
         MH_REQUIRE(it.ws && it.splits > 0, MH_ERR_ARG, "mh_conv2d_wgrad_partial_group: item %d: ws / splits must come from a query call", i);
@@ -833,7 +838,8 @@ extern "C" int mh_conv2d_wgrad_partial_group(const mh_wgrad_item* items, int32_t
         // fill the chip alone, and as one long grid they only coarsen the interleaving with the input-gradient chain (measured: +1.5 %
         // step time with everything grouped); 1- and 2-wave tile shapes would idle most of a 256-thread workgroup.
         // (cap re-swept at the end of round 2, experiments #35: 16384: 1.918 ms | 8192: 1.903 | 4096: 1.899 | 2048: 1.905)
-        static const int max_m = []() { const char* e = getenv("MH_WGRAD_GROUP_MAXM"); return e ? atoi(e) : 4096; }();
+        static const int env_max_m = []() { const char* e = getenv("MH_WGRAD_GROUP_MAXM"); return e ? atoi(e) : 0; }();
+        const int max_m = env_max_m > 0 ? env_max_m : (batch_max_m > 0 ? batch_max_m : 4096);
         const bool narrow = (c.cfg == 8 || c.cfg == 10 || c.cfg == 11);
         if (!group_on || c.cfg < 0 || narrow || a.M > max_m || c.lds > (size_t)MH_WG_GROUP_LDS || c.nblocks <= 0) {
             if (int rc = single(it)) return rc;

@@ -53,7 +53,7 @@ class PackSeg(C.Structure):          # mh_pack_seg
 
 class WgradItem(C.Structure):        # mh_wgrad_item
     _fields_ = [("d", ConvDesc), ("inp", C.c_void_p), ("dout", C.c_void_p), ("ws", C.c_void_p), ("db", C.c_void_p),
-                ("dout_ld", C.c_int32), ("splits", C.c_int32)]
+                ("dout_ld", C.c_int32), ("splits", C.c_int32), ("group_max_m", C.c_int32), ("reserved", C.c_int32)]
 
 _P = C.c_void_p
 _I = C.c_int32

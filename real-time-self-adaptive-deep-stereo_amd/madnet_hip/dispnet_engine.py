@@ -392,6 +392,7 @@ class DispNetEngine(object):
 
     def build_plan(self, mode, lr=1e-4, grad_scale=1.0, update=True, part="all", loss_weights=None, max_disp=192.0, **_):
         r = Recorder()
+        r.wgrad_group_max_m = int(os.environ.get("MH_DISPNET_GROUP_MAXM", "0"))      # per-plan cap of the grouped filter gradients (0 = library default; 4096 and 16384 measure the same here)
         self.wsa.reset()
         with ops.precision_scope(self.precision):
             if mode == "TRAIN":

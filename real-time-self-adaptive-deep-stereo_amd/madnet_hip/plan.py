@@ -31,6 +31,7 @@ class Recorder(object):
         self.join_next = False  # next op: lane 0 first waits for the side lanes
         self.join_lanes_next = 0  # next op: lane 0 first waits for exactly the side lanes of this bit mask (bit l = lane l)
         self.nodefer = False      # side-lane ops recorded now are launched at once (MH_OP_NODEFER)
+        self.wgrad_group_max_m = 0  # grouped filter-gradient launches: pixel cap of this plan's layers (0 = library default)
 
     # -- helpers ---------------------------------------------------------------------------
     def _op(self, kind, ints=(), floats=(), ptrs=(), n=0):
@@ -98,7 +99,7 @@ class Recorder(object):
 
     def conv2d_wgrad_partial(self, dref, inp, dout, dout_ld, ws, splits_ref, db, stream):
         d = dref._obj
-        ints = self._desc_ints(d) + [dout_ld, d.precision, splits_ref._obj.value]
+        ints = self._desc_ints(d) + [dout_ld, d.precision, splits_ref._obj.value, self.wgrad_group_max_m]
         self._tally(d, "wgrad", splits_ref._obj.value if ws is not None else 0)
         self._op(_ffi.OP_WGRAD_PARTIAL, ints, [d.alpha, d.mask_alpha], [inp, dout, ws, db])
 
