@@ -10,6 +10,7 @@
 // sums them (what the engines use: no atomics, one reduction launch per batch of layers).  Also here: wgrad_n1_kernel
 // (single output channel = a pixel reduction) and the tap-flattened mode of the bf16 kernel for Cin <= 4.
 #include "mh_common.h"
+#include <atomic>
 #include <stdlib.h>
 
 namespace {
@@ -31,6 +32,8 @@ struct WgradArgs {
 
 static int g_wgrad_target_wgs = 0;
 // tuning hook (microbenchmarks): number of workgroups the pixel split aims for (0 = heuristic)
+static std::atomic<int> g_wgrad_target_pct{0};     // mh_tune_wgrad_target_pct: scale of the pixel-split workgroup targets while a plan is recorded (0 = default)
+extern "C" int mh_tune_wgrad_target_pct(int pct) { g_wgrad_target_pct = pct > 0 ? pct : 0; return 0; }
 static int g_wgrad_plain = 0;
 static int g_wgrad_tile64 = 0;
 static int g_wgrad_w8 = 0;
@@ -508,7 +511,9 @@ int launch_wgrad_bf16(WgradArgs& a, hipStream_t s) {
     // workgroup targets of the pixel split: 256 / 512 / 1024 by tile size (round 1: 384 / 768 / 1536, tuned while the filter gradients overlapped the
     // input-gradient chain; in the deferred one-lane step they mostly run alone and fewer splits = less partial-sum traffic: 1.961 -> 1.912 ms at 2/3,
     // 1.911 at 1/2, 1.964 at 0.4, 2.03 at 1/3; experiments #34).  MH_WGRAD_TARGET_PCT scales them (A/B hook).
-    static const int env_scale = []() { const char* e = getenv("MH_WGRAD_TARGET_PCT"); return e ? atoi(e) : 100; }();
+    static const int env_scale0 = []() { const char* e = getenv("MH_WGRAD_TARGET_PCT"); return e ? atoi(e) : 100; }();
+    const int tuned = g_wgrad_target_pct.load(std::memory_order_relaxed);
+    const int env_scale = tuned > 0 ? tuned : env_scale0;
     // (layers with more than 65536 reduction pixels -- several streams batched through one model, DispNet's / the pyramid's full-size layers -- are
     //  throughput bound and keep the round-1 targets: B = 4 batched 834 vs 796 pairs/s)
     const int base_t = a.M > 65536 ? (units >= 32 ? 384 : (units >= 8 ? 768 : 1536)) : (units >= 32 ? 256 : (units >= 8 ? 512 : 1024));

@@ -394,6 +394,15 @@ class DispNetEngine(object):
         r = Recorder()
         r.wgrad_group_max_m = int(os.environ.get("MH_DISPNET_GROUP_MAXM", "0"))      # per-plan cap of the grouped filter gradients (0 = library default; 4096 and 16384 measure the same here)
         self.wsa.reset()
+        # DispNet's filter gradients (few pixels, 256-1024 channels) keep the round-1 pixel-split targets: 3.99 vs 4.08 ms (the split counts are resolved
+        # while the plan is recorded and stored in it)
+        self.lib.tune_wgrad_target_pct(int(os.environ.get("MH_DISPNET_WGRAD_TARGET_PCT", "150")))
+        try:
+            return self._build_plan_scoped(r, mode, lr, grad_scale, update, part, loss_weights, max_disp)
+        finally:
+            self.lib.tune_wgrad_target_pct(0)
+
+    def _build_plan_scoped(self, r, mode, lr, grad_scale, update, part, loss_weights, max_disp):
         with ops.precision_scope(self.precision):
             if mode == "TRAIN":
                 return self._build_train_plan(r, lr, grad_scale, update, part, loss_weights, max_disp)
