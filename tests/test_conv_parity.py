@@ -814,3 +814,30 @@ def test_conv_split_bf16_tiled_kernel(backend, case):
         assert "conv_igemm_kernel" in name and "bf16x3" in name, name
     err = (y.cpu() - old.cpu() - ref).abs().max().item()
     assert err <= 4e-5 * max(1.0, ref.abs().max().item()), (err, name)
+
+
+def test_wgrad_split_targets_follow_the_tuning_hook(backend):
+    """mh_tune_wgrad_target_pct scales the pixel-split workgroup targets of the split counts resolved while it is set (DispNet's engine records its plans
+    with 150); a plan stores the counts it was recorded with, and a launch with a stored count is valid whatever the hook says at that time."""
+    import ctypes as C
+    dev = backend.device
+    H, W, Ci, Co = 40, 100, 96, 64                       # 4000 reduction pixels: the split count is target-limited, not pixel-limited
+    x = _rand((1, H, W, Ci), 811, dev); gz = _rand((1, H, W, Co), 812, dev)
+    xb, xv = _padded(x, Ci); zb, zv = _padded(gz, Co)
+    d = ops.conv_desc(1, H, W, H, W, Ci, Co, 3, 3, 1, 1, 1, 1, 0, 0, Ci, Co, precision=1)
+    counts = {}
+    for pct in (0, 150, 50):
+        backend.lib.tune_wgrad_target_pct(pct)
+        sp = C.c_int32(0)
+        backend.lib.conv2d_wgrad_partial(C.byref(d), ops._p(xv), ops._p(zv), zv.ld, None, C.byref(sp), None, None)
+        counts[pct] = sp.value
+    backend.lib.tune_wgrad_target_pct(0)
+    assert counts[150] > counts[0] > counts[50] >= 1, counts
+    # a count resolved under 150 % launches under the default setting
+    ws = torch.full((counts[150], 9 * Ci * Co), float("nan"), device=dev); db = torch.zeros(Co, device=dev)
+    sp = C.c_int32(counts[150])
+    backend.lib.conv2d_wgrad_partial(C.byref(d), ops._p(xv), ops._p(zv), zv.ld, C.c_void_p(ws.data_ptr()), C.byref(sp), C.c_void_p(db.data_ptr()), None)
+    backend.sync()
+    xr = _bf(x.cpu()).double(); w0 = torch.zeros(3, 3, Ci, Co, dtype=torch.float64, requires_grad=True)
+    (gw,) = torch.autograd.grad(T.conv2d(xr, w0, None, alpha=1.0), [w0], _bf(gz.cpu()).double())
+    assert (ws.cpu().double().sum(0).view(3, 3, Ci, Co) - gw).abs().max().item() <= 2e-5 * max(1.0, gw.abs().max().item())

@@ -509,3 +509,35 @@ def test_offline_training_step(bname, size):
             am[n] = eng.params.tensor(n, "m").cpu().clone(); av[n] = eng.params.tensor(n, "v").cpu().clone()
         assert torch.allclose(eng.adam_state.cpu(), torch.tensor(st), rtol=1e-6)
 
+
+
+def test_plan_scheduling_switches_do_not_change_results_emulated(monkeypatch):
+    """The scheduling knobs of a plan -- undeferred side batches (MH_OP_NODEFER), two filter-gradient lanes, no side loss, per-level fills instead of the
+    single one, unfused level backward -- only move launches between lanes / change their order: on the emulator (no atomics races: workgroups run one
+    after the other) every variant must reproduce the default plan's forward pass bit for bit and its updated weights to the order of the fp32 atomics."""
+    from conftest import _emul_backend
+    backend = _emul_backend()
+    H, W = 60, 100
+    wn = S.calibrated_weights(OM.variable_shapes(), 1)
+    l, r, gt = S.make_pair(H, W)
+
+    def run(**kw):
+        for k, v in kw.items():
+            if k != "lanes":
+                monkeypatch.setattr(E, k, v)
+        eng = E.MadNetEngine(backend.lib, H, W, B=1, device="cpu", weights=wn, precision="mixed")
+        if "lanes" in kw:
+            eng.wgrad_lanes = kw["lanes"]
+        eng.set_inputs(l, r, gt[..., 0])
+        eng.build_plan("FULL", lr=1e-4).run(backend.lib, 0)
+        monkeypatch.undo()
+        return eng.pred.clone(), float(eng.res_loss[0].item()), eng.params.w.clone()
+
+    p0, l0, w0 = run()
+    for kw, exact in (({"NODEFER_BATCHES": 3}, True), ({"lanes": 2}, True), ({"lanes": 0}, True), ({"SIDE_LOSS": False}, True),
+                      ({"ONE_FILL": False}, False), ({"FUSE_BACK": False}, False)):
+        p1, l1, w1 = run(**kw)
+        assert torch.equal(p0, p1) and l0 == l1, kw
+        # scheduling only: the same kernels on the same data (the fp32 atomics of the bias / warp gradients may land in another order: ~1e-13);
+        # ONE_FILL / FUSE_BACK swap kernels (accumulate onto zero, fused correlation + warp gradient) = another fp32 summation order
+        assert (w0 - w1).abs().max().item() <= (1e-10 if exact else 1e-7), (kw, (w0 - w1).abs().max().item())
