@@ -141,11 +141,14 @@ def momentum_update(wts, accum, grads, lr, momentum=0.9):
 
 
 def step(wts, accum, left, right, gt, mode="FULL", block_vars=None, block_index=None,
-         lr=1e-4, radius_d=2, stride=1, loss="reprojection", proxy=None, reprojection_scale=1, warping=True):
+         lr=1e-4, radius_d=2, stride=1, loss="reprojection", proxy=None, reprojection_scale=1, warping=True, adam=None):
     """One iteration of the loop body Stereo_Online_Adaptation.py:178-253 (device part):
     ONE forward with pre-update weights, full-res loss + EPE/bad3, the selected
     backward and the momentum update.  mode in NONE/FULL/MAD.  For MAD, block_index is
-    the sampled block (prediction index) and block_vars its variable-name list."""
+    the sampled block (prediction index) and block_vars its variable-name list.
+    adam = {"m": {...}, "v": {...}, "state": [beta1_power, beta2_power]}: the live demo's optimizer instead of momentum
+    (Demo/demo_model.py:164 tf.train.AdamOptimizer(lr); one optimizer object serves all of the demo's train ops (:121-142),
+    so the slots are per variable and the ONE pair of beta powers advances with every executed train op)."""
     names = list(wts.keys())
     for n in names:
         wts[n].requires_grad_(mode != "NONE")
@@ -176,7 +179,14 @@ def step(wts, accum, left, right, gt, mode="FULL", block_vars=None, block_index=
         wts[n].requires_grad_(False)
     out = {"loss": float(full_loss.detach()), "epe": float(epe), "bad3": float(bad3),
            "disparity": disps[-1].detach(), "grads": {k: v.detach() for k, v in grads.items()}}
-    if grads:
+    if grads and adam is not None:
+        with torch.no_grad():
+            for n, g in grads.items():
+                T.adam_update(wts[n], adam["m"][n], adam["v"][n], g, adam["state"], lr)
+            st = adam["state"]
+            st[0] = float(torch.tensor(st[0], dtype=torch.float32) * torch.tensor(0.9, dtype=torch.float32))
+            st[1] = float(torch.tensor(st[1], dtype=torch.float32) * torch.tensor(0.999, dtype=torch.float32))
+    elif grads:
         momentum_update(wts, accum, grads, lr)
     return out
 

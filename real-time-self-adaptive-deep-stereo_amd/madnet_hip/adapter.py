@@ -23,10 +23,17 @@ def softmax(x):
 class Adapter(object):
     def __init__(self, net, mode="MAD", block_config=None, lr=1e-4, momentum=0.9, sample_mode="PROBABILITY",
                  num_blocks=1, fixed_id=0, sample_frequency=1, ssim_th=0.5, reprojection_scale=1,
-                 use_graph=True, shared_model=False, process_group=None, loss="reprojection", dilation=1, decay=0.99, uf=0.01):
+                 use_graph=True, shared_model=False, process_group=None, loss="reprojection", dilation=1, decay=0.99, uf=0.01,
+                 optimizer="momentum", reset_optimizer=False, reward_every_step_first=False):
         """loss='proxy', dilation, decay, uf: the continual-adaptation variant (Stereo_Continual_Adaptation.py:75-112,
         205-249, 302-304): proxy-label mean_l1 loss, weight update only every `dilation`-th frame, reward update
-        sample_distribution = decay * sample_distribution (+ uf * gain on the last trained blocks)."""
+        sample_distribution = decay * sample_distribution (+ uf * gain on the last trained blocks).
+        optimizer='adam', reset_optimizer, reward_every_step_first: the live demo's variant of the loop (Demo/demo_model.py:164,
+        203-208, 253-262): tf.train.AdamOptimizer(lr) instead of momentum; a reset without a weight file re-runs the initialisers,
+        i.e. also clears the optimizer slots; its `first` flag is never cleared, so every step re-seeds both remembered losses."""
+        if optimizer not in ("momentum", "adam"):
+            raise ValueError("optimizer must be 'momentum' or 'adam'")
+        self.optimizer, self.reset_optimizer, self.reward_every_step_first = optimizer, reset_optimizer, reward_every_step_first
         if mode not in ("NONE", "FULL", "MAD"):
             raise ValueError("mode must be NONE, FULL or MAD")
         if loss not in ("reprojection", "proxy"):
@@ -93,9 +100,10 @@ class Adapter(object):
                 if key == "NONE":
                     p = eng.build_plan("NONE", part=part)
                 elif key == "FULL":
-                    p = eng.build_plan("FULL", lr=self.lr, grad_scale=gs, part=part)
+                    p = eng.build_plan("FULL", lr=self.lr, grad_scale=gs, part=part, optimizer=self.optimizer)
                 else:
-                    p = eng.build_plan("MAD", lr=self.lr, grad_scale=gs, part=part, blocks=[self.blocks[i] for i in key])
+                    p = eng.build_plan("MAD", lr=self.lr, grad_scale=gs, part=part, blocks=[self.blocks[i] for i in key],
+                                       optimizer=self.optimizer)
                 if self.use_graph and p.n > 0:
                     with torch.cuda.stream(self.stream):
                         p.capture(self.lib, self.stream.cuda_stream)
@@ -157,7 +165,7 @@ class Adapter(object):
         epe = float(self._host[4]); bad3 = float(self._host[5])
         # ---- reward update of the sampling logits (Stereo_Online_Adaptation.py:211-224)
         if self.mode == "MAD":
-            if self.step_count == 0:
+            if self.step_count == 0 or self.reward_every_step_first:
                 self.loss_t_2 = new_loss
                 self.loss_t_1 = new_loss
             expected_loss = 2 * self.loss_t_1 - self.loss_t_2
@@ -168,10 +176,18 @@ class Adapter(object):
             self.last_trained_blocks = self.blocks_to_train
             self.loss_t_2 = self.loss_t_1
             self.loss_t_1 = new_loss
-        # ---- reset to the initial weights if the loss explodes (:241-244); momentum is NOT reset
+        # ---- reset to the initial weights if the loss explodes (:241-244); momentum is NOT reset (the demo without a weight file
+        # re-initialises everything, optimizer slots included: reset_optimizer)
         did_reset = False
         if new_loss > self.ssim_th:
-            eng.params.w.copy_(eng.params.w0)
+            with (torch.cuda.stream(self.stream) if self.cuda else _null()):      # same stream as the next step's plan
+                eng.params.w.copy_(eng.params.w0)
+                if self.reset_optimizer:
+                    eng.params.m.zero_()
+                    if getattr(eng.params, "v", None) is not None:
+                        eng.params.v.zero_()
+                    if getattr(eng, "adam_state", None) is not None:
+                        eng.adam_state.copy_(torch.tensor([0.9, 0.999]))
             self.reset_counter += 1
             did_reset = True
         self.step_count += 1

@@ -390,7 +390,8 @@ class DispNetEngine(object):
             ops.adam_advance(r, self.adam_state)
         return r.compile()
 
-    def build_plan(self, mode, lr=1e-4, grad_scale=1.0, update=True, part="all", loss_weights=None, max_disp=192.0, **_):
+    def build_plan(self, mode, lr=1e-4, grad_scale=1.0, update=True, part="all", loss_weights=None, max_disp=192.0,
+                   optimizer="momentum", **_):
         r = Recorder()
         r.wgrad_group_max_m = int(os.environ.get("MH_DISPNET_GROUP_MAXM", "0"))      # per-plan cap of the grouped filter gradients (0 = library default; 4096 and 16384 measure the same here)
         self.wsa.reset()
@@ -398,17 +399,19 @@ class DispNetEngine(object):
         # while the plan is recorded and stored in it)
         self.lib.tune_wgrad_target_pct(int(os.environ.get("MH_DISPNET_WGRAD_TARGET_PCT", "150")))
         try:
-            return self._build_plan_scoped(r, mode, lr, grad_scale, update, part, loss_weights, max_disp)
+            return self._build_plan_scoped(r, mode, lr, grad_scale, update, part, loss_weights, max_disp, optimizer)
         finally:
             self.lib.tune_wgrad_target_pct(0)
 
-    def _build_plan_scoped(self, r, mode, lr, grad_scale, update, part, loss_weights, max_disp):
+    def _build_plan_scoped(self, r, mode, lr, grad_scale, update, part, loss_weights, max_disp, optimizer="momentum"):
         with ops.precision_scope(self.precision):
             if mode == "TRAIN":
                 return self._build_train_plan(r, lr, grad_scale, update, part, loss_weights, max_disp)
-            return self._build_plan(r, mode, lr, grad_scale, update, part)
+            return self._build_plan(r, mode, lr, grad_scale, update, part, optimizer)
 
-    def _build_plan(self, r, mode, lr, grad_scale, update, part):
+    def _build_plan(self, r, mode, lr, grad_scale, update, part, optimizer="momentum"):
+        if optimizer not in ("momentum", "adam"):
+            raise ValueError("optimizer must be 'momentum' or 'adam'")
         do_grad = part in ("all", "grad")
         do_upd = update and part in ("all", "update")
         if mode not in ("NONE", "FULL"):
@@ -419,7 +422,13 @@ class DispNetEngine(object):
             if mode == "FULL":
                 self.record_backward(r)
         if mode == "FULL" and do_upd:
-            self.record_update(r, lr, grad_scale=grad_scale)
+            if optimizer == "adam":                       # the live demo's FULL mode (Demo/demo_model.py:148-149,164)
+                self._ensure_train_buffers()
+                P = self.params
+                ops.adam(r, P.w, P.m, P.v, P.g, self.adam_state, lr, grad_scale=grad_scale, n=P.total)
+                ops.adam_advance(r, self.adam_state)
+            else:
+                self.record_update(r, lr, grad_scale=grad_scale)
         return r.compile()
 
     def set_inputs(self, left, right, gt=None):

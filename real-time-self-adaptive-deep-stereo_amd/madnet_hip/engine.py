@@ -783,11 +783,12 @@ class MadNetEngine(object):
         return [n for n, _ in self.params.manifest]
 
     def build_plan(self, mode, lr=1e-4, block_vars=None, block_level=None, grad_scale=1.0, update=True,
-                   blocks=None, part="all", loss_weights=None, max_disp=192.0):
+                   blocks=None, part="all", loss_weights=None, max_disp=192.0, optimizer="momentum"):
         """mode: 'NONE' | 'FULL' | 'MAD' | 'TRAIN' (offline training step of Train.py: multi-scale supervised mean_l1 against
         self.gt with loss_weights from full to lowest resolution, every variable, Adam).
         For MAD: blocks = [(level, variable names), ...] (level in
         LEVELS, 2 = context output); block_level/block_vars is the single-block shorthand.
+        optimizer: 'momentum' (Stereo_Online_Adaptation.py:122) | 'adam' (the live demo, Demo/demo_model.py:164) for FULL / MAD.
         part: 'all' | 'grad' (everything up to the gradients) | 'update' (momentum apply only) -- the
         split lets a gradient all-reduce (shared-model multi-GPU mode) sit between two plans."""
         r = Recorder()
@@ -795,7 +796,7 @@ class MadNetEngine(object):
         with ops.precision_scope(self.precision):
             if mode == "TRAIN":
                 return self._build_train_plan(r, lr, grad_scale, update, part, loss_weights, max_disp)
-            return self._build_plan(r, mode, lr, block_vars, block_level, grad_scale, update, blocks, part)
+            return self._build_plan(r, mode, lr, block_vars, block_level, grad_scale, update, blocks, part, optimizer)
 
     def _build_train_plan(self, r, lr, grad_scale, update, part, loss_weights, max_disp):
         """Train.py:56-62,94-102: bulkhead off, loss = sum_i w_i * mean_l1(disparities[-(i+1)], gt, valid), Adam(lr, 0.9)."""
@@ -817,7 +818,12 @@ class MadNetEngine(object):
             self.record_update_adam(r, tv, lr, grad_scale=grad_scale)
         return r.compile()
 
-    def _build_plan(self, r, mode, lr, block_vars, block_level, grad_scale, update, blocks, part):
+    def _build_plan(self, r, mode, lr, block_vars, block_level, grad_scale, update, blocks, part, optimizer="momentum"):
+        if optimizer not in ("momentum", "adam"):
+            raise ValueError("optimizer must be 'momentum' or 'adam'")
+        # one AdamOptimizer serves every train op of the demo graph (Demo/demo_model.py:164): per-variable slots, ONE pair of beta
+        # powers that advances with every executed train op -- which is what record_update_adam does per call
+        record_update = self.record_update if optimizer == "momentum" else self.record_update_adam
         if blocks is None and block_level is not None:
             blocks = [(block_level, block_vars)]
         do_grad = part in ("all", "grad")
@@ -833,7 +839,7 @@ class MadNetEngine(object):
                 self.record_loss_metrics(r, with_grad=True)
                 self.record_backward(r, "final", tv, bulkhead=False)
             if do_upd:
-                self.record_update(r, tv, lr, grad_scale=grad_scale)
+                record_update(r, tv, lr, grad_scale=grad_scale)
         elif mode == "MAD":
             if do_grad:
                 self.record_forward(r, make_disps=tuple(lv for lv, _ in blocks))
@@ -859,10 +865,10 @@ class MadNetEngine(object):
                                               self.ddisp_k)
                     self.record_backward(r, lv, bv, bulkhead=True)
                 if do_upd and part == "all":
-                    self.record_update(r, bv, lr, grad_scale=grad_scale)
+                    record_update(r, bv, lr, grad_scale=grad_scale)
             if do_upd and part == "update":
                 for lv, bv in blocks:
-                    self.record_update(r, bv, lr, grad_scale=grad_scale)
+                    record_update(r, bv, lr, grad_scale=grad_scale)
         else:
             raise ValueError("unknown mode %r" % (mode,))
         return r.compile()

@@ -541,3 +541,59 @@ def test_plan_scheduling_switches_do_not_change_results_emulated(monkeypatch):
         # scheduling only: the same kernels on the same data (the fp32 atomics of the bias / warp gradients may land in another order: ~1e-13);
         # ONE_FILL / FUSE_BACK swap kernels (accumulate onto zero, fused correlation + warp gradient) = another fp32 summation order
         assert (w0 - w1).abs().max().item() <= (1e-10 if exact else 1e-7), (kw, (w0 - w1).abs().max().item())
+
+
+@pytest.mark.parametrize("bname,size", [SIZES[0], pytest.param("hip", (128, 256), marks=pytest.mark.gpu, id="hip-128x256")])
+@pytest.mark.parametrize("mode,block", [("FULL", None), ("MAD", 4)])
+def test_live_demo_adaptation_step_adam(bname, size, mode, block):
+    """8(f)-4, Demo/demo_model.py:110-164,233-250: the live demo runs the SAME forward / reprojection loss / FULL or per-block backward as the online
+    script but applies tf.train.AdamOptimizer(lr) -- one optimizer object for every train op, so per-variable slots and one pair of beta powers that advances
+    with every executed train op.  Two consecutive steps against the oracle (autograd + the fp32 ApplyAdam restatement); criteria as in the offline step."""
+    backend = _backend(bname)
+    H, W = size
+    eng, wn, wt, acc, (l, r, gt) = _setup(backend, H, W, seed=3)
+    lr = 1e-3
+    bv = None
+    if mode == "MAD":
+        blocks = json.load(open(os.path.join(PKG, "block_config", "MadNet_full.json")))
+        lv = OM.layer_variables()
+        bv = sum([lv[n] for n in blocks[block]], [])
+        plan = eng.build_plan("MAD", lr=lr, block_vars=bv, block_level=E.LEVELS[block], optimizer="adam")
+    else:
+        plan = eng.build_plan("FULL", lr=lr, optimizer="adam")
+    with pytest.raises(ValueError):
+        eng.build_plan("FULL", lr=lr, optimizer="rmsprop")
+    adam = {"m": {k: torch.zeros_like(v) for k, v in wt.items()}, "v": {k: torch.zeros_like(v) for k, v in wt.items()}, "state": [0.9, 0.999]}
+    for step in range(2):
+        plan.run(backend.lib, 0)
+        backend.sync()
+        o = OM.step(wt, acc, l, r, gt, mode=mode, block_vars=bv, block_index=block, lr=lr, adam=adam)
+        assert (eng.pred.cpu() - o["disparity"][..., 0]).abs().mean().item() <= EPE_TOL
+        assert abs(eng.res_loss[0].item() - o["loss"]) <= 2e-5 * max(1.0, abs(o["loss"]))
+        worst, mean, nsolid, nall = 0.0, 0.0, 0, 0
+        for n in wt:
+            we = eng.params.tensor(n).cpu()
+            g = o["grads"].get(n)
+            if g is None:                                  # MAD: outside the sampled block nothing moves, slots stay zero
+                assert torch.equal(we, torch.from_numpy(wn[n])), n
+                assert not eng.params.tensor(n, "m").any() and not eng.params.tensor(n, "v").any(), n
+                continue
+            d = (we - wt[n]).abs()
+            # Adam normalises every element's step to ~lr (see test_offline_training_step); from the second step on the step is LINEAR in the gradient's
+            # relative error (lr_t (1-b1) dg / sqrt(v) ~ 0.5 lr dg/|g|), and the reprojection loss' gradients (SSIM + |x| kinks, warp) carry more
+            # summation-order noise than the supervised ones.  So the element bound is taken over the elements whose ENGINE gradient agrees with the oracle's
+            # to 5 % -- which must be nearly all of them -- and the tensor-mean bound over everything.
+            ge = eng.params.tensor(n, "g").cpu()
+            solid = (ge - g).abs() <= 0.05 * g.abs()
+            nsolid += int(solid.sum()); nall += solid.numel()
+            if solid.any():
+                worst = max(worst, d[solid].max().item())
+            mean = max(mean, d.mean().item())
+        print("demo adam step %d: worst |dw| %.3g lr, worst tensor-mean %.3g lr, %.4f of the elements within 5 %% gradient agreement"
+              % (step, worst / lr, mean / lr, nsolid / max(nall, 1)))
+        assert worst <= 0.1 * lr and mean <= 5e-3 * lr and nsolid >= 0.97 * nall, (step, worst, mean, nsolid, nall)
+        for n in o["grads"]:                               # continue from the engine's state (step 1 tests the step-1 arithmetic)
+            wt[n] = eng.params.tensor(n).cpu().clone()
+            adam["m"][n] = eng.params.tensor(n, "m").cpu().clone(); adam["v"][n] = eng.params.tensor(n, "v").cpu().clone()
+        assert torch.allclose(eng.adam_state.cpu(), torch.tensor(adam["state"]), rtol=1e-6)
+    assert torch.allclose(eng.adam_state.cpu(), torch.tensor([0.9 ** 3, 0.999 ** 3]), rtol=1e-5)
