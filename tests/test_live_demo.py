@@ -1,0 +1,226 @@
+"""SURVEY 8(f)-4, the live demo loop (Demo/Live_Adaptation_Demo.py, Demo/demo_model.py, Demo/grabber.py): the grabber factory and thread, the frame
+preparation (rescale + centre crop / pad), and the two-thread loop -- grabber -> one-slot queue -> RealTimeStereo -- whose every frame must be exactly
+one oracle step with Adam on the sampled block (the arithmetic of the step itself is pinned in test_engine_parity.py::test_live_demo_adaptation_step_adam).
+Runs on the CPU emulator build (test plumbing: `_lib` is injected; the product resolves it to the HIP library and fails without a GPU) and, marked gpu,
+on the MI355X through the CLI."""
+import json
+import os
+import queue
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "real-time-self-adaptive-deep-stereo_amd")
+DEMO = os.path.join(PKG, "Demo")
+if DEMO not in sys.path:
+    sys.path.insert(0, DEMO)
+
+
+def test_grabber_factory_and_sources(tmp_path):
+    import grabber
+    assert {"Synthetic", "ImageList"} <= set(grabber.get_available_camera())
+    with pytest.raises(Exception, match="Unrecognized camera type"):
+        grabber.get_camera("ZED_Maxi", queue.Queue(1))
+    # a user camera registers like the reference's example (Demo/grabber.py:24-29,155-174)
+
+    @grabber.register_camera_to_factory()
+    class Ramp(grabber.ImageGrabber):
+        _name = "Ramp"
+
+        def _connect_to_camera(self):
+            self.n, self.closed = 0, False
+
+        def _read_frame(self):
+            self.n += 1
+            if self.n > 3:
+                return None
+            return np.full((4, 6, 3), self.n, np.uint8), np.full((4, 6, 3), 10 * self.n, np.uint8)
+
+        def _disconnect_from_camera(self):
+            self.closed = True
+
+    q = queue.Queue(1)
+    g = grabber.get_camera("Ramp", q, framerate=0)
+    g.start()
+    got = []
+    while True:
+        f = q.get(timeout=5)
+        if f is None:
+            break
+        got.append(f)
+    g.join(5)
+    assert not g.is_alive() and g.closed and g.frames_delivered == 3
+    assert [f.shape for f in got] == [(2, 4, 6, 3)] * 3 and [int(f[0, 0, 0, 0]) for f in got] == [1, 2, 3] and int(got[2][1, 0, 0, 0]) == 30
+    # stop() ends a grabber nobody drains (full queue): the reference's blocking put would hang here
+    q2 = queue.Queue(1)
+    g2 = grabber.get_camera("Synthetic", q2, config={"height": 32, "width": 48}, framerate=0)
+    g2.start()
+    time.sleep(0.3)
+    g2.stop()
+    g2.join(5)
+    assert not g2.is_alive() and q2.full()
+    # ImageList: replays the rows of a CSV list, then the end mark
+    from PIL import Image
+    rows = []
+    for i in range(2):
+        for side in "lr":
+            Image.fromarray(np.full((5, 7, 3), 20 * i + (side == "r"), np.uint8)).save(str(tmp_path / ("%s%d.png" % (side, i))))
+        rows.append("%s,%s,unused" % (tmp_path / ("l%d.png" % i), tmp_path / ("r%d.png" % i)))
+    (tmp_path / "list.csv").write_text("\n".join(rows) + "\n")
+    cfg = tmp_path / "cam.json"
+    cfg.write_text(json.dumps({"list": str(tmp_path / "list.csv")}))
+    q3 = queue.Queue(1)
+    g3 = grabber.get_camera("ImageList", q3, config=str(cfg), framerate=0)
+    g3.start()
+    a, b, end = q3.get(timeout=5), q3.get(timeout=5), q3.get(timeout=5)
+    g3.join(5)
+    assert end is None and a.dtype == np.uint8 and a.shape == (2, 5, 7, 3) and int(a[1, 0, 0, 0]) == 1 and int(b[0, 0, 0, 0]) == 20
+    with pytest.raises(Exception, match="'list'"):
+        grabber.get_camera("ImageList", queue.Queue(1), config={})
+
+
+def test_crop_or_pad_matches_the_readers_centre_crop():
+    import demo_model
+    from Data_utils import data_reader
+    rng = np.random.default_rng(0)
+    for (h, w, th, tw) in [(9, 12, 5, 8), (5, 8, 9, 13), (9, 6, 4, 11), (7, 7, 7, 7)]:
+        x = rng.integers(0, 255, (2, h, w, 3)).astype(np.float32)
+        got = demo_model.crop_or_pad(torch.from_numpy(x), th, tw).numpy()
+        ref = np.stack([data_reader.center_crop_or_pad(x[i], th, tw) for i in range(2)])
+        assert got.shape == (2, th, tw, 3) and np.array_equal(got, ref)
+
+
+def _run_loop(lib, device, mode, n_frames, monkeypatch, H=60, W=100, **kw):
+    import demo_model
+    import grabber
+    from Data_utils import preprocessing as P
+    if lib is not None:
+        monkeypatch.setattr(P, "_lib", lambda: lib)
+    q = queue.Queue(1)
+    seen = []
+    dd = demo_model.RealTimeStereo(q, model_name="MADNet", weight_path="calibrated:1", learning_rate=1e-4,
+                                   block_config_path=os.path.join(PKG, "block_config", "MadNet_full.json"), image_shape=[H + 12, W + 20],
+                                   crop_shape=[H, W], SSIMTh=kw.pop("SSIMTh", 10.0), mode=mode, device=device, max_frames=n_frames,
+                                   on_frame=lambda it, rec, l, r, d: seen.append((it, rec, l.clone(), r.clone(), d.clone())), _lib=lib, **kw)
+    gg = grabber.get_camera("Synthetic", q, config={"height": 2 * H, "width": 2 * W, "distinct": 2}, framerate=0)
+    gg.start(); dd.start()
+    dd.join(600)
+    gg.stop(); gg.join(10)
+    assert not dd.is_alive() and not gg.is_alive()
+    if dd.error is not None:
+        raise dd.error
+    return dd, seen
+
+
+def test_live_loop_every_frame_is_one_oracle_adam_step_emulated(monkeypatch):
+    """Four frames through the two threads in MAD mode: the frames the network saw are the rescaled + cropped camera frames (oracle resize), and frame by
+    frame loss, trained block and the updated weights follow the oracle's step with Adam, continued from the engine's state."""
+    from conftest import _emul_backend
+    from oracle import madnet as OM, tf_ops as T
+    from madnet_hip import synthetic as S
+    backend = _emul_backend()
+    H, W = 60, 100
+    dd, seen = _run_loop(backend.lib, "cpu", "MAD", 4, monkeypatch, H, W)
+    assert len(seen) == 4 and len(dd.history) == 4
+    # frame preparation: camera frame 2H x 2W -> (H+12, W+20) bilinear -> centre crop H x W
+    l0, r0, _ = S.make_pair(2 * H, 2 * W, stream_id=0)
+    ref = T.resize_bilinear(torch.from_numpy(l0.astype(np.uint8).astype(np.float32)), H + 12, W + 20)[:, 6:6 + H, 10:10 + W]
+    assert (seen[0][2] - ref).abs().max().item() <= 1e-3
+    # the loop: oracle replay with the blocks the sampler drew
+    wn = S.calibrated_weights(OM.variable_shapes(), 1)
+    wt = {k: torch.from_numpy(v.copy()) for k, v in wn.items()}
+    acc = {k: torch.zeros_like(v) for k, v in wt.items()}
+    adam = {"m": {k: torch.zeros_like(v) for k, v in wt.items()}, "v": {k: torch.zeros_like(v) for k, v in wt.items()}, "state": [0.9, 0.999]}
+    blocks = json.load(open(os.path.join(PKG, "block_config", "MadNet_full.json")))
+    lv = OM.layer_variables()
+    gt = torch.zeros(1, H, W, 1)
+    for it, (loss, trained, reset), l, r, d in seen:
+        assert len(trained) == 1 and 0 <= trained[0] < 5 and not reset
+        bv = sum([lv[n] for n in blocks[trained[0]]], [])
+        o = OM.step(wt, acc, l, r, gt, mode="MAD", block_vars=bv, block_index=trained[0], lr=1e-4, adam=adam)
+        assert abs(loss - o["loss"]) <= 2e-5 * max(1.0, abs(o["loss"])), it
+        assert (d - o["disparity"][..., 0]).abs().mean().item() <= 1e-3, it
+    eng = dd._net.engine
+    touched = set()
+    for _, (_, trained, _), _, _, _ in seen:
+        touched |= set(sum([lv[n] for n in blocks[trained[0]]], []))
+    worst = 0.0
+    for n in wt:
+        we = eng.params.tensor(n)
+        if n not in touched:
+            assert torch.equal(we, torch.from_numpy(wn[n])), n
+        else:
+            worst = max(worst, (we - wt[n]).abs().mean().item())
+    assert worst <= 0.05 * 1e-4, worst                               # tensor-mean deviation after 4 Adam steps of size ~lr each
+    assert torch.allclose(eng.adam_state, torch.tensor([0.9 ** 5, 0.999 ** 5]), rtol=1e-5)
+    # the demo's reward rule (its `first` flag is never cleared): the logits never leave zero
+    assert not np.any(dd.sample_distribution)
+
+
+def test_live_loop_reset_full_none_and_online_reward_emulated(monkeypatch):
+    from conftest import _emul_backend
+    backend = _emul_backend()
+    # SSIMTh below any loss: every frame resets -> weights equal the initial ones, and (no weight file) the optimizer state is cleared as well
+    import demo_model
+    dd, seen = _run_loop(backend.lib, "cpu", "FULL", 2, monkeypatch, 48, 64, SSIMTh=-1.0)
+    assert [h[2] for h in dd.history] == [True, True]
+    eng = dd._net.engine
+    assert torch.equal(eng.params.w, eng.params.w0)
+    assert eng.params.m.any() and eng.params.v.any()                 # weight_path given ('calibrated:1'): slots survive the reset (Saver.restore)
+    assert torch.allclose(eng.adam_state, torch.tensor([0.9 ** 3, 0.999 ** 3]), rtol=1e-5)
+    dd._adapter.reset_optimizer = True                               # what weight_path=None selects (initialisers re-run, Demo/demo_model.py:206-208)
+    l, r = seen[-1][2], seen[-1][3]
+    dd._adapter.step(l, r)
+    assert not eng.params.m.any() and not eng.params.v.any() and torch.equal(eng.adam_state, torch.tensor([0.9, 0.999]))
+    # NONE: inference only, nothing moves
+    dn, _ = _run_loop(backend.lib, "cpu", "NONE", 2, monkeypatch, 48, 64)
+    assert torch.equal(dn._net.engine.params.w, dn._net.engine.params.w0) and len(dn.history) == 2
+    # the online script's reward rule moves the logits once a block has been trained
+    do, _ = _run_loop(backend.lib, "cpu", "MAD", 3, monkeypatch, 48, 64, reward_as_online=True)
+    assert np.any(do.sample_distribution)
+    with pytest.raises(ValueError):
+        demo_model.RealTimeStereo(queue.Queue(1), mode="HALF", _lib=backend.lib, device="cpu")
+
+
+@pytest.mark.gpu
+def test_live_demo_cli_gpu(tmp_path):
+    """The CLI on the MI355X: 12 synthetic frames in MAD mode, disparity PNGs written, a finite loss on every frame."""
+    out = tmp_path / "disp"
+    r = subprocess.run([sys.executable, os.path.join(DEMO, "Live_Adaptation_Demo.py"), "--weights", "calibrated:1", "--frames", "12", "--framerate", "0",
+                        "--output", str(out), "--logDispStep", "4", "--SSIMTh", "10"], capture_output=True, text=True, timeout=600, cwd=DEMO)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    steps = [l for l in r.stdout.splitlines() if l.startswith("Step ")]
+    assert len(steps) == 12 and all(np.isfinite(float(l.split(":")[1])) for l in steps)
+    assert sorted(os.listdir(str(out))) == ["disparity_0.png", "disparity_4.png", "disparity_8.png"]
+    assert "detector stopped" in r.stdout and "Camera grabber stopped" in r.stdout
+
+
+def test_live_loop_dispnet_full_adam_emulated(monkeypatch):
+    """--modelName Dispnet --mode FULL: the demo's Adam step on DispNet's single flat variable range; MAD is refused like the reference's assert does."""
+    from conftest import _emul_backend
+    import demo_model
+    backend = _emul_backend()
+    monkeypatch.setattr(demo_model.RealTimeStereo, "_initial_weights",
+                        lambda self: __import__("Stereo_Online_Adaptation").load_weights("calibrated:1", self._model_name))
+    import grabber
+    q = queue.Queue(1)
+    dd = demo_model.RealTimeStereo(q, model_name="Dispnet", weight_path=None, learning_rate=1e-4, image_shape=[-1], crop_shape=[64, 128], SSIMTh=10.0,
+                                   mode="FULL", device="cpu", max_frames=2, _lib=backend.lib)
+    gg = grabber.get_camera("Synthetic", q, config={"height": 64, "width": 128}, framerate=0)
+    gg.start(); dd.start(); dd.join(900); gg.stop(); gg.join(10)
+    if dd.error is not None:
+        raise dd.error
+    eng = dd._net.engine
+    assert len(dd.history) == 2 and all(np.isfinite(h[0]) for h in dd.history)
+    step = (eng.params.w - eng.params.w0).abs()
+    # two Adam steps: nothing moves by more than ~2 lr; the weights that have a gradient did move (at 64x128 the deep 3x3 filters mostly see padding)
+    assert step.max().item() <= 2.5e-4 and (step > 1e-5).float().mean().item() > 0.05
+    assert torch.allclose(eng.adam_state, torch.tensor([0.9 ** 3, 0.999 ** 3]), rtol=1e-5)
+    with pytest.raises(NotImplementedError):
+        demo_model.RealTimeStereo(queue.Queue(1), model_name="Dispnet", image_shape=[-1], crop_shape=[64, 128], mode="MAD", device="cpu", _lib=backend.lib,
+                                  block_config_path=os.path.join(PKG, "block_config", "MadNet_full.json"))
