@@ -25,3 +25,14 @@ __device__ __forceinline__ void mh_split_bf16x2(float a, float b, unsigned& hi, 
     hi = __builtin_bit_cast(unsigned, h);
     lo = mh_pack_bf16(a - (float)ha, b - (float)hb);
 }
+
+// ds_read_b64_tr_b16: the LDS transposing read of gfx950.  Every lane passes the address of 4 consecutive bf16 (8-byte aligned); within each
+// group of 16 lanes, lane i receives, as element j, element (i & 3) of what lane 4*j + (i >> 2) of the group addressed (measured on the MI355X:
+// scripts/exp/tr_probe.hip, profiles/r02_tr_probe.txt).  With lane s addressing row (s >> 2), elements 4*(s & 3)..+3 of a row-major
+// [4 rows][16 columns] bf16 block, lane i gets column i of the 4 rows: the MFMA operand order (8 consecutive k per lane = two such reads) out
+// of an image whose rows are the REDUCTION index -- NHWC pixels with channels contiguous, exactly as they sit in memory.
+typedef short mh_v4s_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 mh_lds_read_tr16(const unsigned short* p) {
+    const mh_v4s_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) mh_v4s_t*)p);
+    return __builtin_bit_cast(uint2, v);
+}

@@ -703,10 +703,215 @@ static int launch_wgrad_n1(WgradArgs& a, hipStream_t s) {
     return mh_check_launch("wgrad_n1");
 }
 
+// ---- "taps" kernel: all nine taps of a stride-1 3x3 layer in ONE workgroup, operands through the LDS transposing read --------------------------
+// The tiled kernel above gives every tap its own workgroup: each of them pulls the same dz pixels (and a shifted copy of the same input pixels)
+// out of L2 as fp32, converts them, transposes them in registers into [channel][pixel] LDS tiles -- 64 KB of loads and ~2000 VALU / LDS
+// instructions per 2 MFLOP tile, which is what bounds it (12 % of the bf16 MFMA peak).  Here a workgroup owns dW[9 taps][32 input channels][128
+// output channels] (144 accumulator registers per lane, 4 waves as 2 x 2: wave (wr, wc) = input channels 16 wr..+15, all taps, output channels
+// 64 wc..+63) and walks its share of the reduction in segments of 32 consecutive pixels of one image row (of one dilation sub-lattice):
+//   * per segment the dz pixels (32 x 128) and ONE new input row (34 x 32: the 3-row halo patch lives in a ring of 8 row slots, a vertical run
+//     of segments re-uses two of its three rows) are loaded once, rounded to bf16 and stored AS THEY ARE -- pixel-major, channels contiguous;
+//   * ds_read_b64_tr_b16 (mh_lds_read_tr16) turns 4 pixel rows x 16 channels into the MFMA operand order, so a tap is just a row offset into the
+//     patch: 9 A fragments + 4 B fragments feed 36 MFMAs per wave and segment; loads per flop drop ~6x against the tiled kernel;
+//   * the reduction index inside a segment is permuted (pixel 8 lq + 4 (r ^ (lq & 1)) + j for lane quad lq, read r, element j -- the same for both
+//     operands, so the sum is unchanged): with 96-byte patch rows and 288-byte dz rows the 32 lanes the LDS serves per cycle then hit 64 different
+//     banks (checked against the (address / 4) % 64 rule of the guide; unmeasured on hardware in round 2).
+// Partial sums go to the split workspace like the tiled kernel's (or, without one, fp32 atomics).  Opt-in: MH_WGRAD_TAPS=1 / mh_tune_wgrad_taps.
+constexpr int WT_PW = 34, WT_RSA = 48, WT_RSB = 144, WT_NSLOT = 8;       // row strides in halfs: 32 + 16 pad channels, 128 + 16
+constexpr int WT_PATCH_HALFS = WT_NSLOT * WT_PW * WT_RSA, WT_DZ_HALFS = 32 * WT_RSB;
+constexpr size_t WT_LDS = (size_t)(WT_PATCH_HALFS + 2 * WT_DZ_HALFS) * 2;      // 44 544 B
+
+__global__ __launch_bounds__(256) void wgrad_taps_kernel(WgradArgs p) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    unsigned short* const Pa = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* const Bz = Pa + WT_PATCH_HALFS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 15, lq = lane >> 4;
+    const int d = p.dil;
+    int bid = mh_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int tk = bid % p.ktiles; bid /= p.ktiles;              // the k-tiles of a split are neighbours on one XCD: dz comes out of its L2
+    const int tn = bid % p.ntiles; bid /= p.ntiles;
+    const int split = bid;
+    const int k0 = tk * 32, n0 = tn * 128;
+    const int Kr = (p.K + 3) & ~3;
+    const int Hl = (p.Ho + d - 1) / d, Wl = (p.Wo + d - 1) / d, nsx = (Wl + 31) >> 5;
+    const int S = p.B * d * d * nsx * Hl;                         // segments: (b, cy, cx, 32-column strip, lattice row), lattice row fastest
+    const int sbeg = split * p.chunk, send = min(S, sbeg + p.chunk);
+    const bool kvalid = k0 + wr * 16 < p.K;
+    int njw = (p.N - n0 - wc * 64 + 15) >> 4;
+    njw = njw < 0 ? 0 : (njw > 4 ? 4 : njw);
+    const bool active = kvalid && njw > 0;
+
+    const __amdgpu_buffer_rsrc_t rs_in = mh_make_rsrc(p.in, p.in_bytes);
+    const __amdgpu_buffer_rsrc_t rs_dz = mh_make_rsrc(p.dz, p.dz_bytes);
+
+    float4 rz[4], rp[4];
+    int ld_rows = 0;                                              // patch rows the registers hold (1 or 3)
+    auto issue_loads = [&](int s, bool fresh) {
+        const int ly = s % Hl; int t = s / Hl;
+        const int sx = t % nsx; t /= nsx;
+        const int cx = t % d; t /= d;
+        const int cy = t % d; const int b = t / d;
+        const int y = cy + d * ly;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = tid + 256 * u;
+            const int r = q >> 5, c4 = q & 31;
+            const int x = cx + d * (sx * 32 + r);
+            const bool ok = y < p.Ho && x < p.Wo && n0 + c4 * 4 < p.N;
+            rz[u] = mh_buf_load4(rs_dz, ok ? (((b * p.Ho + y) * p.Wo + x) * p.dz_ld + n0 + c4 * 4) * 4 : MH_OOB);
+        }
+        ld_rows = fresh ? 3 : 1;
+        const int lr0 = fresh ? ly - 1 : ly + 1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = tid + 256 * u;
+            const int rr = q / (WT_PW * 8), rem = q - rr * (WT_PW * 8);
+            const int pj = rem >> 3, c4 = rem & 7;
+            const int lr = lr0 + rr, lx = sx * 32 - 1 + pj;
+            const int yy = cy + d * lr, xx = cx + d * lx;
+            const bool ok = rr < ld_rows && lr >= 0 && yy < p.Hi && lx >= 0 && xx < p.Wi && k0 + c4 * 4 < Kr;
+            rp[u] = mh_buf_load4(rs_in, ok ? (((b * p.Hi + yy) * p.Wi + xx) * p.in_ld + k0 + c4 * 4) * 4 : MH_OOB);
+        }
+    };
+    const bool do_bias = (p.db != nullptr) && tk == 0;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto store_loads = [&](int buf, int slot0) {
+        unsigned short* const Bb = Bz + buf * WT_DZ_HALFS;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = tid + 256 * u;
+            const int r = q >> 5, c4 = q & 31;
+            *reinterpret_cast<uint2*>(Bb + r * WT_RSB + c4 * 4) = make_uint2(mh_pack_bf16(rz[u].x, rz[u].y), mh_pack_bf16(rz[u].z, rz[u].w));
+            if (do_bias) { bsum.x += rz[u].x; bsum.y += rz[u].y; bsum.z += rz[u].z; bsum.w += rz[u].w; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = tid + 256 * u;
+            const int rr = q / (WT_PW * 8), rem = q - rr * (WT_PW * 8);
+            const int pj = rem >> 3, c4 = rem & 7;
+            if (rr < ld_rows)
+                *reinterpret_cast<uint2*>(Pa + (((slot0 + rr) & (WT_NSLOT - 1)) * WT_PW + pj) * WT_RSA + c4 * 4) =
+                    make_uint2(mh_pack_bf16(rp[u].x, rp[u].y), mh_pack_bf16(rp[u].z, rp[u].w));
+        }
+    };
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // lane-constant parts of the transposing-read addresses: pixel rows of the two reads, 4-channel piece
+    const int row0 = 8 * lq + 4 * (lq & 1) + (li >> 2), row1 = 8 * lq + 4 * ((lq & 1) ^ 1) + (li >> 2);
+    const int pcA = wr * 16 + 4 * (li & 3), pcB = wc * 64 + 4 * (li & 3);
+
+    int base = 0;                                                 // ring slot of lattice row ly - 1 of the current segment
+    if (sbeg < send) {
+        issue_loads(sbeg, true);
+        store_loads(0, base);
+    }
+    __syncthreads();
+    for (int s = sbeg; s < send; ++s) {
+        const int buf = (s - sbeg) & 1;
+        const bool more = s + 1 < send;
+        const bool fresh = more && ((s + 1) / Hl != s / Hl);     // the next segment starts a new vertical run: three new rows
+        if (more) issue_loads(s + 1, fresh);
+        if (active) {
+            const unsigned short* const Bb = Bz + buf * WT_DZ_HALFS + pcB;
+            u32x4 bf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < njw) {
+                    const uint2 b0 = mh_lds_read_tr16(Bb + row0 * WT_RSB + j * 16), b1 = mh_lds_read_tr16(Bb + row1 * WT_RSB + j * 16);
+                    bf[j] = (u32x4){b0.x, b0.y, b1.x, b1.y};
+                }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ky = t / 3, kx = t - ky * 3;
+                const unsigned short* const Ab = Pa + (((base + ky) & (WT_NSLOT - 1)) * WT_PW + kx) * WT_RSA + pcA;
+                const uint2 a0 = mh_lds_read_tr16(Ab + row0 * WT_RSA), a1 = mh_lds_read_tr16(Ab + row1 * WT_RSA);
+                const u32x4 af = (u32x4){a0.x, a0.y, a1.x, a1.y};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < njw) acc[t][j] = mh_mfma_bf16(af, bf[j], acc[t][j]);
+            }
+        }
+        if (more) store_loads(buf ^ 1, base + 3);                 // slots base+3 .. base+5: never one of the three being read
+        base = (base + (fresh ? 3 : 1)) & (WT_NSLOT - 1);
+        __syncthreads();
+    }
+
+    float* const dwb = p.ws ? p.ws + (int64_t)split * ((int64_t)9 * p.K * p.N) : p.dw;
+    const bool plain = (p.ws != nullptr) || p.dbg_plain_store;
+    if (kvalid) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = k0 + wr * 16 + lq * 4 + r;
+                if (k >= p.K) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + wc * 64 + j * 16 + li;
+                    if (j < njw && n < p.N) {
+                        float* dst = dwb + ((int64_t)t * p.K + k) * p.N + n;
+                        if (plain) *dst = acc[t][j][r]; else atomicAdd(dst, acc[t][j][r]);
+                    }
+                }
+            }
+    }
+    if (do_bias) {                                                // 8 threads per 4-channel group -> LDS -> one atomic per output channel
+        float* red = smem;                                        // [8][128]; every wave is past the last barrier of the walk
+        *reinterpret_cast<float4*>(red + (tid >> 5) * 128 + (tid & 31) * 4) = bsum;
+        __syncthreads();
+        if (tid < 128 && n0 + tid < p.N) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t += red[r * 128 + tid];
+            atomicAdd(p.db + n0 + tid, t);
+        }
+    }
+}
+
+static std::atomic<int> g_wgrad_taps{-1};                          // -1: environment (MH_WGRAD_TAPS, default off), 0 / 1: mh_tune_wgrad_taps
+static bool wgrad_taps_ok(const WgradArgs& a) {
+    static const int env_on = []() { const char* e = getenv("MH_WGRAD_TAPS"); return e ? atoi(e) : 0; }();
+    static const int env_minm = []() { const char* e = getenv("MH_WGRAD_TAPS_MINM"); return e ? atoi(e) : 4096; }();
+    const int t = g_wgrad_taps.load(std::memory_order_relaxed);
+    if (!(t >= 0 ? t : env_on)) return false;
+    return a.bf16 && !a.flat && a.taps == 9 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad_t == a.dil && a.pad_l == a.dil &&
+           a.Hi == a.Ho && a.Wi == a.Wo && a.vecA && a.vecB && a.K >= 32 && a.N >= 32 && a.M > env_minm;
+}
+static int launch_wgrad_taps(WgradArgs& a, hipStream_t s) {
+    a.ktiles = mh_cdiv(a.K, 32);
+    a.ntiles = mh_cdiv(a.N, 128);
+    const int d = a.dil;
+    const int Hl = mh_cdiv(a.Ho, d), nsx = mh_cdiv(mh_cdiv(a.Wo, d), 32);
+    const int S = a.B * d * d * nsx * Hl;
+    const int base = a.ktiles * a.ntiles;
+    const int target = g_wgrad_target_wgs > 0 ? g_wgrad_target_wgs : 256;         // one workgroup per CU: the partial sums are 4 bytes x every accumulator in flight
+    int splits = a.forced_splits > 0 ? a.forced_splits : mh_cdiv(target, base);
+    int maxs = S / 4;                                                            // >= 4 segments per workgroup
+    if (maxs > 192) maxs = 192;
+    if (splits > maxs) splits = maxs;
+    if (splits < 1) splits = 1;
+    const int chunk = mh_cdiv(S, splits);
+    a.splits = mh_cdiv(S, chunk);
+    a.chunk = chunk;
+    if (a.query) return 0;
+    if (t_capture) { t_capture->cfg = -1; return 0; }            // never part of a grouped launch
+    mh_note_kernel("wgrad_taps_kernel K=%d N=%d dil=%d segments %d splits %d grid %d", a.K, a.N, d, S, a.splits, base * a.splits);
+    hipLaunchKernelGGL(wgrad_taps_kernel, dim3(base * a.splits), dim3(256), WT_LDS, s, a);
+    return mh_check_launch("wgrad_taps");
+}
+
 static int wgrad_dispatch(WgradArgs& a, hipStream_t s) {
     const int K = a.flat ? a.taps * 4 : a.K, N = a.N;        // flat: the dW tile rows are (tap, channel) pairs
     const bool all = a.M < 0;
     int rc = 0;
+    if (!all && wgrad_taps_ok(a)) return launch_wgrad_taps(a, s);
 #define MH_WG(cond, ...)                                       \
     if (all || (cond)) {                                       \
         rc = launch_wgrad<__VA_ARGS__>(a, s);                  \
@@ -737,6 +942,8 @@ static int wgrad_dispatch(WgradArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int mh_tune_wgrad_taps(int on) { g_wgrad_taps = on < 0 ? -1 : (on ? 1 : 0); return 0; }
 
 constexpr int MH_WG_GROUP_LDS = 96 * 1024;       // >= the largest tile shape's need (128x128 tiles, flat tables: 90 112 B)
 int mh_wgrad_init() {

@@ -85,6 +85,7 @@ SIGNATURES = {
     "mh_pack_bytes": (_L, [_I, _I, _I, _I]),
     "mh_tune_conv_bank": (_I, [_I]),
     "mh_tune_wgrad_target_pct": (_I, [_I]),
+    "mh_tune_wgrad_taps": (_I, [_I]),
     "mh_tune_conv_x3_igemm": (_I, [_I]),
     "mh_conv2d_wgrad_partial_group": (_I, [C.POINTER(WgradItem), _I, _P]),
     "mh_wgrad_reduce": (_I, [_P, _I, _I, _P]),

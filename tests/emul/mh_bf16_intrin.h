@@ -37,3 +37,25 @@ static inline f32x4 mh_mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
     }
     return d;
 }
+
+// ds_read_b64_tr_b16 (semantics measured on the MI355X, scripts/exp/tr_probe.hip): lane i of a 16-lane group receives, as element j, element
+// (i & 3) of the 4 halfs lane 4*j + (i >> 2) of the group addressed
+static inline uint2 mh_lds_read_tr16(const unsigned short* p) {
+    emul::Wave& w = emul::my_wave();
+    const int lane = emul::tls().cur_index & 63;
+    const int par = w.gen & 1;
+    const unsigned long long a = (unsigned long long)(uintptr_t)p;
+    w.ua[par][lane][0] = (unsigned)(a & 0xffffffffull); w.ua[par][lane][1] = (unsigned)(a >> 32);
+    emul::wave_rendezvous(w);
+    const int g0 = lane & ~15, i = lane & 15;
+    unsigned short h[4];
+    for (int j = 0; j < 4; ++j) {
+        const int s = g0 + 4 * j + (i >> 2);
+        const unsigned long long sa = (unsigned long long)w.ua[par][s][0] | ((unsigned long long)w.ua[par][s][1] << 32);
+        h[j] = ((const unsigned short*)(uintptr_t)sa)[i & 3];
+    }
+    uint2 r;
+    r.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
+    r.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
+    return r;
+}
