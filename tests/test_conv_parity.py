@@ -847,9 +847,9 @@ WGRAD_TAPS_CASES = [   # (B, H, W, Cin, Cout, dil, in_ld, dz_ld): stride-1 3x3 l
     (1, 70, 70, 128, 128, 1, 128, 128),        # the 1/4-resolution estimator shape class: 4 k-tiles, one 128-column tile
     (1, 67, 75, 72, 80, 1, 72, 80),            # ragged: 3 k-tiles (last one 8 channels), 80 columns (wave column tiles 4 + 1), ragged strips (75 = 2 x 32 + 11)
     (2, 48, 52, 40, 96, 1, 44, 96),            # batch 2, K % 32 = 8 with a padded input row (channels 40..43 hold NaN-free garbage of a neighbour)
-    (1, 66, 70, 96, 64, 2, 96, 64),            # dilation 2: four sub-lattices of 33 x 35
+    (1, 66, 70, 64, 96, 2, 64, 96),            # dilation 2: four sub-lattices of 33 x 35
     (1, 72, 80, 128, 96, 8, 128, 96),          # dilation 8: 64 sub-lattices of 9 x 10 (a 32-pixel segment holds 10 pixels)
-    (1, 65, 90, 64, 32, 16, 64, 32),           # dilation 16 (lattices of 5 x 6 and 4 x 5), the narrowest layer the kernel takes
+    (1, 65, 90, 64, 80, 16, 64, 80),           # dilation 16 (lattices of 5 x 6 and 4 x 5), 80 output channels
     (1, 64, 68, 160, 144, 1, 160, 144),        # two 128-column tiles (128 + 16), 5 k-tiles
 ]
 
@@ -921,13 +921,14 @@ def test_wgrad_taps_kernel_is_opt_in_and_keeps_small_layers(backend):
         backend.sync()
         return backend.lib.last_kernel().decode()
 
-    assert "wgrad_taps_kernel" not in kernel_of(70, 70, 64, 64)
+    assert "wgrad_taps_kernel" not in kernel_of(70, 70, 64, 128)
     backend.lib.tune_wgrad_taps(1)
     try:
-        assert "wgrad_taps_kernel" in kernel_of(70, 70, 64, 64)
-        assert "wgrad_taps_kernel" not in kernel_of(60, 60, 64, 64)            # 3600 pixels
-        assert "wgrad_taps_kernel" not in kernel_of(140, 140, 64, 64, stride=2)
-        assert "wgrad_taps_kernel" not in kernel_of(70, 70, 64, 64, precision=0)
-        assert "wgrad_taps_kernel" not in kernel_of(70, 70, 16, 64)
+        assert "wgrad_taps_kernel" in kernel_of(70, 70, 64, 128)
+        assert "wgrad_taps_kernel" not in kernel_of(60, 60, 64, 128)            # 3600 pixels
+        assert "wgrad_taps_kernel" not in kernel_of(140, 140, 64, 128, stride=2)
+        assert "wgrad_taps_kernel" not in kernel_of(70, 70, 64, 128, precision=0)
+        assert "wgrad_taps_kernel" not in kernel_of(70, 70, 16, 128)
+        assert "wgrad_taps_kernel" not in kernel_of(70, 70, 64, 64)             # <= 64 output channels would idle half the waves
     finally:
         backend.lib.tune_wgrad_taps(-1)
