@@ -197,7 +197,8 @@ class MadNetEngine(object):
     def _alloc(self):
         B, B2 = self.B, 2 * self.B
         z = self._buf
-        self.left = z(B, self.H0, self.W0, 3); self.right = z(B, self.H0, self.W0, 3)
+        self.lr = z(2 * B, self.H0, self.W0, 3)                    # both frames in one buffer: ONE padding launch for the pair
+        self.left, self.right = self.lr[:B], self.lr[B:]
         self.gt = z(B, self.H0, self.W0)
         self.X0 = z(B2, self.Hp, self.Wp, 4)
         self.F, self.dF = {}, {}
@@ -378,8 +379,7 @@ class MadNetEngine(object):
                     lib.lane = 0
         else:
             side_pack = False
-        ops.pad_reflect(lib, self.left, self.X0[:B], self.pt, self.pl)
-        ops.pad_reflect(lib, self.right, self.X0[B:], self.pt, self.pl)
+        ops.pad_reflect(lib, self.lr, self.X0, self.pt, self.pl)
         x = ops.View(self.X0, 2 * B, self.Hp, self.Wp, 3, 4)
         for i, (ci, co, s) in enumerate(PYR, 1):
             o = self._fv(self.F[i])

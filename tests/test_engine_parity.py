@@ -599,3 +599,31 @@ def test_live_demo_adaptation_step_adam(bname, size, mode, block):
             adam["m"][n] = eng.params.tensor(n, "m").cpu().clone(); adam["v"][n] = eng.params.tensor(n, "v").cpu().clone()
         assert torch.allclose(eng.adam_state.cpu(), torch.tensor(adam["state"]), rtol=1e-6)
     assert torch.allclose(eng.adam_state.cpu(), torch.tensor([0.9 ** 3, 0.999 ** 3]), rtol=1e-5)
+
+
+def test_step_with_all_taps_filter_gradients_emulated():
+    """The opt-in all-taps filter-gradient kernel inside a whole bf16 FULL step (forced for every size: mh_tune_wgrad_taps(1 + 16 * 0x100)): every stride-1 3x3
+    layer with >= 32 input and > 64 output channels -- estimators at all five levels incl. the 2 x 4-pixel one, the dilated context layers -- goes through it,
+    split counts resolved at record time, partial sums + the step's reductions; the updated weights must match the default step's to summation order."""
+    from conftest import _emul_backend
+    backend = _emul_backend()
+    H, W = 60, 100
+    wn = S.calibrated_weights(OM.variable_shapes(), 1)
+    l, r, gt = S.make_pair(H, W)
+    res = {}
+    for taps in (0, 1 + 16 * 0x100):
+        backend.lib.tune_wgrad_taps(taps)
+        try:
+            eng = E.MadNetEngine(backend.lib, H, W, B=1, device=backend.device, weights=wn, precision="bf16")
+            eng.set_inputs(l, r, gt[..., 0])
+            eng.build_plan("FULL", lr=1e-2).run(backend.lib, 0)
+            backend.sync()
+        finally:
+            launches = backend.lib.tune_wgrad_taps(-1)
+        res[taps] = (eng.params.w.clone(), eng.params.g.clone(), eng.pred.clone(), launches)
+    assert res[0][3] == 0 and res[1 + 16 * 0x100][3] >= 20, (res[0][3], res[1 + 16 * 0x100][3])
+    (w0, g0, p0, _), (w1, g1, p1, _) = res[0], res[1 + 16 * 0x100]
+    assert torch.equal(p0, p1)                                              # the forward pass is untouched
+    gs = g0.abs().max().item()
+    assert (g0 - g1).abs().max().item() <= 2e-5 * gs, (g0 - g1).abs().max().item() / gs
+    assert (w0 - w1).abs().max().item() <= 1e-2 * 2e-5 * gs + 1e-7
