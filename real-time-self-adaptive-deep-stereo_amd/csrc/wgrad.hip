@@ -981,7 +981,7 @@ __global__ __launch_bounds__(512) void wgrad_taps_kernel(WgradArgs p) {
     }
 }
 
-static std::atomic<int> g_wgrad_taps_dbg_fwd{0};
+static std::atomic<int> g_wgrad_taps_flags{0};
 static std::atomic<int> g_wgrad_taps_launches{0};
 static std::atomic<int> g_wgrad_taps{-1};                          // -1: environment (MH_WGRAD_TAPS, default off), 0 / 1: mh_tune_wgrad_taps
 static bool wgrad_taps_ok(const WgradArgs& a) {
@@ -989,7 +989,7 @@ static bool wgrad_taps_ok(const WgradArgs& a) {
     static const int env_minm = []() { const char* e = getenv("MH_WGRAD_TAPS_MINM"); return e ? atoi(e) : 4096; }();
     const int t = g_wgrad_taps.load(std::memory_order_relaxed);
     if (!(t >= 0 ? t : env_on)) return false;
-    const int min_m = (g_wgrad_taps_dbg_fwd.load(std::memory_order_relaxed) & 0x100) ? 0 : env_minm;       // mh_tune_wgrad_taps(1 + 16 * 0x100): every size (tests)
+    const int min_m = (g_wgrad_taps_flags.load(std::memory_order_relaxed) & 0x100) ? 0 : env_minm;       // mh_tune_wgrad_taps(1 + 16 * 0x100): every size (tests)
     return a.bf16 && !a.flat && a.taps == 9 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad_t == a.dil && a.pad_l == a.dil &&
            a.Hi == a.Ho && a.Wi == a.Wo && a.vecA && a.vecB && a.K >= 32 && a.N > 64 && a.M > min_m;     // (N <= 64 would idle the second wave column: tiled kernels)
 }
@@ -1011,7 +1011,7 @@ static int launch_wgrad_taps(WgradArgs& a, hipStream_t s) {
     a.chunk = chunk;
     if (a.query) return 0;
     if (t_capture) { t_capture->cfg = -1; return 0; }            // never part of a grouped launch
-    a.dbg_plain_store |= (g_wgrad_taps_dbg_fwd.load(std::memory_order_relaxed) & 0xff) << 4;
+    a.dbg_plain_store |= (g_wgrad_taps_flags.load(std::memory_order_relaxed) & 0xff) << 4;
     g_wgrad_taps_launches.fetch_add(1, std::memory_order_relaxed);
     mh_note_kernel("wgrad_taps_kernel K=%d N=%d dil=%d segments %d splits %d grid %d", a.K, a.N, d, S, a.splits, base * a.splits);
     if (a.N % 128 == 0) hipLaunchKernelGGL(wgrad_taps_kernel<true>, dim3(base * a.splits), dim3(512), WT_LDS, s, a);
@@ -1060,7 +1060,7 @@ static int wgrad_dispatch(WgradArgs& a, hipStream_t s) {
 // (+ 16 * 0x100: no lower bound on the reduction pixels -- tests).  Returns the number of all-taps launches since the previous call.
 extern "C" int mh_tune_wgrad_taps(int on) {
     g_wgrad_taps = on < 0 ? -1 : (on ? 1 : 0);
-    g_wgrad_taps_dbg_fwd = on >= 16 ? on >> 4 : 0;
+    g_wgrad_taps_flags = on >= 16 ? on >> 4 : 0;
     return g_wgrad_taps_launches.exchange(0, std::memory_order_relaxed);
 }
 
