@@ -326,7 +326,7 @@ int mh_tune_conv_x3_igemm(int on);       /* split-bf16 (precision 2) on the tile
 int mh_tune_conv_bank(int small_maxpix); /* fragment-bank kernels (mh_conv2d_wb): the small-layer kernel takes layers of up to this many output pixels (0 = never, < 0 = default 4096 / MH_CONV_BANK_SMALL_MAXPIX); returns the number of bank-kernel launches since the previous call */
 int mh_tune_wgrad_wgs(int target_workgroups);
 int mh_tune_wgrad_target_pct(int pct);   /* scale (percent) of the filter-gradient pixel-split workgroup targets for the split counts resolved from now on (a plan stores the counts it was recorded with); 0 = default.  DispNet's engine records with 150 */
-int mh_tune_wgrad_taps(int on);          /* filter gradients of the stride-1 3x3 bf16 layers with > 4096 reduction pixels on the all-taps kernel (operands through the LDS transposing read, csrc/wgrad.hip wgrad_taps_kernel): 1 = on, 0 = off, < 0 = default / MH_WGRAD_TAPS (off: faster stand-alone, slower inside the step, profiles/r02_microbench_wgrad_taps.txt); 1 + 16 * 0x100 = on for every size (tests).  Affects the split counts resolved from now on.  Returns the number of all-taps launches since the previous call (NOT a status code) */
+int mh_tune_wgrad_taps(int on);          /* filter gradients of the stride-1 3x3 bf16 layers with > 64 output channels and > 16384 reduction pixels (MH_WGRAD_TAPS_MINM) on the all-taps kernel (operands through the LDS transposing read, csrc/wgrad.hip wgrad_taps_kernel): 1 = on, 0 = off, < 0 = default / MH_WGRAD_TAPS (off: faster stand-alone, slower inside the step, profiles/r02_microbench_wgrad_taps.txt); 1 + 16 * 0x100 = on for every size (tests).  Affects the split counts resolved from now on.  Returns the number of all-taps launches since the previous call (NOT a status code) */
 int mh_tune_corr(int direct);
 
 /* host utility: CRC-32C (Castagnoli) of a host buffer, chained through `crc` (0 to start) -- used by the TensorFlow

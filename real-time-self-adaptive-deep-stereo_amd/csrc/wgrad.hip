@@ -986,7 +986,9 @@ static std::atomic<int> g_wgrad_taps_launches{0};
 static std::atomic<int> g_wgrad_taps{-1};                          // -1: environment (MH_WGRAD_TAPS, default off), 0 / 1: mh_tune_wgrad_taps
 static bool wgrad_taps_ok(const WgradArgs& a) {
     static const int env_on = []() { const char* e = getenv("MH_WGRAD_TAPS"); return e ? atoi(e) : 0; }();
-    static const int env_minm = []() { const char* e = getenv("MH_WGRAD_TAPS_MINM"); return e ? atoi(e) : 4096; }();
+    // (16384: the step A/B of round 2 ran with 4096, which also sent the 48x160 layers here -- 240 segments = 4 per workgroup against ~15 us of
+    //  per-workgroup prologue + 147 KB of partial sums; that alone may explain the slower step.  Not re-measured.)
+    static const int env_minm = []() { const char* e = getenv("MH_WGRAD_TAPS_MINM"); return e ? atoi(e) : 16384; }();
     const int t = g_wgrad_taps.load(std::memory_order_relaxed);
     if (!(t >= 0 ? t : env_on)) return false;
     const int min_m = (g_wgrad_taps_flags.load(std::memory_order_relaxed) & 0x100) ? 0 : env_minm;       // mh_tune_wgrad_taps(1 + 16 * 0x100): every size (tests)
@@ -1002,7 +1004,7 @@ static int launch_wgrad_taps(WgradArgs& a, hipStream_t s) {
     const int base = a.ktiles * a.ntiles;
     const int target = g_wgrad_target_wgs > 0 ? g_wgrad_target_wgs : 256;         // one workgroup per CU: the partial sums are 4 bytes x every accumulator in flight
     int splits = a.forced_splits > 0 ? a.forced_splits : mh_cdiv(target, base);
-    int maxs = S / 4;                                                            // >= 4 segments per workgroup
+    int maxs = S / 8;                                                            // >= 8 segments per workgroup
     if (maxs > 192) maxs = 192;
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;

@@ -843,7 +843,7 @@ def test_wgrad_split_targets_follow_the_tuning_hook(backend):
     assert (ws.cpu().double().sum(0).view(3, 3, Ci, Co) - gw).abs().max().item() <= 2e-5 * max(1.0, gw.abs().max().item())
 
 
-WGRAD_TAPS_CASES = [   # (B, H, W, Cin, Cout, dil, in_ld, dz_ld): stride-1 3x3 layers with > 4096 reduction pixels
+WGRAD_TAPS_CASES = [   # (B, H, W, Cin, Cout, dil, in_ld, dz_ld): stride-1 3x3 layers (the kernel's pixel floor is lifted for the test)
     (1, 70, 70, 128, 128, 1, 128, 128),        # the 1/4-resolution estimator shape class: 4 k-tiles, one 128-column tile
     (1, 67, 75, 72, 80, 1, 72, 80),            # ragged: 3 k-tiles (last one 8 channels), 80 columns (wave column tiles 4 + 1), ragged strips (75 = 2 x 32 + 11)
     (2, 48, 52, 40, 96, 1, 44, 96),            # batch 2, K % 32 = 8 with a padded input row (channels 40..43 hold NaN-free garbage of a neighbour)
@@ -870,7 +870,7 @@ def test_wgrad_taps_kernel(backend, case):
     zb, zv = _padded(gz, zld)
     res = {}
     for taps in (1, 0):
-        backend.lib.tune_wgrad_taps(taps)
+        backend.lib.tune_wgrad_taps(taps * (1 + 16 * 0x100))          # on for every size (default floor: 16384 reduction pixels)
         try:
             dw = torch.full((3, 3, Ci, Co), float("nan"), device=dev); db = torch.zeros(Co, device=dev)
             wsa = ops.WgradWorkspace(dev); segs, keep = [], []
@@ -904,8 +904,8 @@ def test_wgrad_taps_kernel(backend, case):
 
 
 def test_wgrad_taps_kernel_is_opt_in_and_keeps_small_layers(backend):
-    """Default off (unmeasured on hardware): the dispatcher picks the tiled kernels; switched on, layers with <= 4096 reduction pixels, strided layers and
-    exact-fp32 calls still go to the tiled / grouped kernels."""
+    """Default off (slower inside the step than the tiled kernels): the dispatcher picks the tiled kernels; switched on, layers with <= 16384 reduction pixels,
+    strided layers, exact-fp32 calls, thin inputs and <= 64 output channels still go to the tiled / grouped kernels."""
     import ctypes as C
     dev = backend.device
 
@@ -921,14 +921,14 @@ def test_wgrad_taps_kernel_is_opt_in_and_keeps_small_layers(backend):
         backend.sync()
         return backend.lib.last_kernel().decode()
 
-    assert "wgrad_taps_kernel" not in kernel_of(70, 70, 64, 128)
+    assert "wgrad_taps_kernel" not in kernel_of(130, 130, 64, 128)
     backend.lib.tune_wgrad_taps(1)
     try:
-        assert "wgrad_taps_kernel" in kernel_of(70, 70, 64, 128)
-        assert "wgrad_taps_kernel" not in kernel_of(60, 60, 64, 128)            # 3600 pixels
-        assert "wgrad_taps_kernel" not in kernel_of(140, 140, 64, 128, stride=2)
-        assert "wgrad_taps_kernel" not in kernel_of(70, 70, 64, 128, precision=0)
-        assert "wgrad_taps_kernel" not in kernel_of(70, 70, 16, 128)
-        assert "wgrad_taps_kernel" not in kernel_of(70, 70, 64, 64)             # <= 64 output channels would idle half the waves
+        assert "wgrad_taps_kernel" in kernel_of(130, 130, 64, 128)              # 16900 pixels
+        assert "wgrad_taps_kernel" not in kernel_of(120, 120, 64, 128)          # 14400 pixels
+        assert "wgrad_taps_kernel" not in kernel_of(260, 260, 64, 128, stride=2)
+        assert "wgrad_taps_kernel" not in kernel_of(130, 130, 64, 128, precision=0)
+        assert "wgrad_taps_kernel" not in kernel_of(130, 130, 16, 128)
+        assert "wgrad_taps_kernel" not in kernel_of(130, 130, 64, 64)           # <= 64 output channels would idle half the waves
     finally:
         backend.lib.tune_wgrad_taps(-1)
