@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 8
+#define MH_ABI_VERSION 9
 
 /* status codes of every int-returning entry point: 0 = launched; a NEGATIVE code means an argument check failed and
  * nothing was launched or written; a POSITIVE value is the hipError_t of a failed launch / runtime call.
@@ -153,6 +153,36 @@ typedef struct mh_wgrad_seg {
 } mh_wgrad_seg;
 /* segs_device: table in DEVICE memory; nblocks = sum of ceil(size/1024). */
 int mh_wgrad_reduce(const mh_wgrad_seg* segs_device, int32_t nseg, int32_t nblocks, void* stream);
+
+/* ---- filter gradients of the stride-1 3x3 (dilated) layers from bf16 "shadows", a whole backward batch per launch (csrc/wgrad_stream.hip) ----
+ * The same Conv2DBackpropFilter / BiasAddGrad nodes as mh_conv2d_wgrad_partial (Stereo_Online_Adaptation.py:126-128), bf16 operands / fp32
+ * accumulation, but the operands are read from bf16 NHWC copies ("shadows") of the layer input x and of d(loss)/d(output) dz whose channel
+ * stride is the channel count rounded up to a multiple of 32 with the padding channels ZERO.
+ *   mh_shadow_cast        : writes such shadows for a table of fp32 tensors (one launch; round to nearest even).
+ *   mh_wgrad_stream_plan  : HOST-side planner.  Fills ktiles / ntiles / splits / blk0 of every layer record so that about `target_wgs` workgroups
+ *                           of `nwaves` waves share the batch in proportion to the rows they stream; *nblocks_out = the grid.  The caller then
+ *                           points layer.ws at splits * 9*K*N floats (16-byte aligned; or at dw itself when splits == 1) and uploads the table.
+ *   mh_wgrad_stream       : the launch.  ws[split][9][K][N] is fully overwritten (sum the splits with mh_wgrad_reduce); db (may be NULL) is
+ *                           accumulated with atomics.  max_dil = the largest dilation in the table (1 .. 16). */
+typedef struct mh_shadow_seg {
+    const float* src;     /* fp32 [npix][src_ld], C valid channels */
+    void* dst;            /* bf16 [npix][dst_ld], dst_ld % 8 == 0, channels >= C zero-filled; 16-byte aligned */
+    int64_t npix;
+    int32_t C, src_ld, dst_ld;
+    int32_t blk0;         /* exclusive prefix sum of ceil(npix * dst_ld / 8 / 256) over the table */
+} mh_shadow_seg;
+int mh_shadow_cast(const mh_shadow_seg* segs_device, int32_t nseg, int32_t nblocks, void* stream);
+typedef struct mh_wgs_layer {
+    const void* x;        /* bf16 shadow of the layer input   [B][H][W][x_ld]  */
+    const void* dz;       /* bf16 shadow of d loss / d output [B][H][W][dz_ld] */
+    float* ws;            /* [splits][9][K][N] partial filter gradients */
+    float* db;            /* [N] bias gradient (accumulated) or NULL */
+    int32_t B, H, W, K, N, dil;
+    int32_t x_ld, dz_ld;  /* >= K, N rounded up to 32; multiples of 8 */
+    int32_t ktiles, ntiles, splits, blk0;      /* written by mh_wgrad_stream_plan */
+} mh_wgs_layer;
+int mh_wgrad_stream_plan(mh_wgs_layer* layers_host, int32_t n, int32_t target_wgs, int32_t nwaves, int32_t* nblocks_out);
+int mh_wgrad_stream(const mh_wgs_layer* layers_device, int32_t nlayers, int32_t nblocks, int32_t nwaves, int32_t max_dil, void* stream);
 
 /* ---- correlation / cost volume: sharedLayers.correlation (Nets/sharedLayers.py:23-51),
  *      replaces ShiftCorrKernelLauncher / ShiftCorrGradKernelLauncher ------------------- */
@@ -327,6 +357,7 @@ int mh_tune_conv_bank(int small_maxpix); /* fragment-bank kernels (mh_conv2d_wb)
 int mh_tune_wgrad_wgs(int target_workgroups);
 int mh_tune_wgrad_target_pct(int pct);   /* scale (percent) of the filter-gradient pixel-split workgroup targets for the split counts resolved from now on (a plan stores the counts it was recorded with); 0 = default.  DispNet's engine records with 150 */
 int mh_tune_wgrad_taps(int on);          /* filter gradients of the stride-1 3x3 bf16 layers with > 64 output channels and > 16384 reduction pixels (MH_WGRAD_TAPS_MINM) on the all-taps kernel (operands through the LDS transposing read, csrc/wgrad.hip wgrad_taps_kernel): 1 = on, 0 = off, < 0 = default / MH_WGRAD_TAPS (off: faster stand-alone, slower inside the step, profiles/r02_microbench_wgrad_taps.txt); 1 + 16 * 0x100 = on for every size (tests).  Affects the split counts resolved from now on.  Returns the number of all-taps launches since the previous call (NOT a status code) */
+int mh_tune_wgrad_stream(int dist);     /* prefetch distance (row groups in flight) of the streaming filter-gradient kernel: 1 or 2, 0 = default / MH_WGRAD_STREAM_DIST */
 int mh_tune_corr(int direct);
 
 /* host utility: CRC-32C (Castagnoli) of a host buffer, chained through `crc` (0 to start) -- used by the TensorFlow
@@ -339,7 +370,7 @@ enum { MH_OP_CONV = 1, MH_OP_WGRAD, MH_OP_CORR_FWD, MH_OP_CORR_BWD, MH_OP_WARP_F
        MH_OP_RESIZE_FWD, MH_OP_RESIZE_BWD, MH_OP_PAD_REFLECT, MH_OP_LOSS, MH_OP_METRICS,
        MH_OP_MOMENTUM, MH_OP_COPY_CH, MH_OP_LEAKY_BWD, MH_OP_FILL, MH_OP_BIAS_GRAD,
        MH_OP_WGRAD_PARTIAL, MH_OP_WGRAD_REDUCE, MH_OP_PROXY_LOSS, MH_OP_SUPERVISED_LOSS, MH_OP_ADAM, MH_OP_ADAM_ADVANCE,
-       MH_OP_RESIZE_IMAGE, MH_OP_LEVEL_FRONT, MH_OP_TRANSPOSE_W, MH_OP_PACK_W, MH_OP_CORR_WARP_BWD };
+       MH_OP_RESIZE_IMAGE, MH_OP_LEVEL_FRONT, MH_OP_TRANSPOSE_W, MH_OP_PACK_W, MH_OP_CORR_WARP_BWD, MH_OP_SHADOW_CAST, MH_OP_WGRAD_STREAM };
 /* i[26] of every op is its scheduling word: low byte = lane (0 = the caller's stream; 1..MH_MAX_LANES-1 = side
  * streams owned by the library: the op is forked from lane 0 right before it, i.e. ordered after everything recorded so
  * far, and runs concurrently with the lane-0 ops that follow); MH_OP_JOIN = lane 0 first waits for all side lanes.

@@ -34,6 +34,7 @@ int mh_check_launch(const char* what) {
 
 int mh_conv_init();
 int mh_wgrad_init();
+int mh_wgrad_stream_init();
 int mh_corr_init();
 static int mh_lanes_init();
 
@@ -42,6 +43,7 @@ extern "C" const char* mh_last_error(void) { return g_err; }
 extern "C" int mh_init(void) {
     if (int e = mh_conv_init()) return e;
     if (int e = mh_wgrad_init()) return e;
+    if (int e = mh_wgrad_stream_init()) return e;
     if (int e = mh_corr_init()) return e;
     return mh_lanes_init();          // side streams / events of the plan executor (not creatable inside a capture)
 }
@@ -128,6 +130,10 @@ static int run_op(const mh_op& o, void* s) {
             return mh_corr_warp_bwd((const float*)p[0], i[0], i[1], (const float*)p[1], i[2], (const float*)p[2], i[3], (const float*)p[3], i[4],
                                     (const float*)p[4], (float*)p[5], i[5], i[6], (float*)p[6], i[7], (float*)p[7],
                                     i[8], i[9], i[10], i[11], i[12], i[13], i[14], s);
+        case MH_OP_SHADOW_CAST:
+            return mh_shadow_cast((const mh_shadow_seg*)p[0], i[0], i[1], s);
+        case MH_OP_WGRAD_STREAM:
+            return mh_wgrad_stream((const mh_wgs_layer*)p[0], i[0], i[1], i[2], i[3], s);
         case MH_OP_PACK_W:
             return mh_pack_weights((const mh_pack_seg*)p[0], i[0], i[1], s);
         case MH_OP_WGRAD_REDUCE:

@@ -36,3 +36,32 @@ __device__ __forceinline__ uint2 mh_lds_read_tr16(const unsigned short* p) {
     const mh_v4s_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) mh_v4s_t*)p);
     return __builtin_bit_cast(uint2, v);
 }
+
+// ---- gfx950 primitives of the streaming filter-gradient kernel (csrc/wgrad_stream.hip) ------------------------------------------------
+// v_mfma_f32_32x32x16_bf16: lane l holds A[i = l&31][k = 8*(l>>5) .. +7] / B[k = 8*(l>>5) .. +7][j = l&31] as 8 bf16;
+// C/D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5) for register r of 16.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ f32x16 mh_mfma_bf16_32(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mh_bf16x8_t, a), __builtin_bit_cast(mh_bf16x8_t, b), c, 0, 0, 0);
+}
+// buffer_load_dwordx4 ... lds ("LDS DMA"): every lane copies the 16 bytes at byte offset `voff` of the buffer to LDS address
+// lds_wave_base + 16 * lane (the LDS base is wave-uniform: it travels in M0); an out-of-range offset stores zeros.  Asynchronous: counted by
+// vmcnt, ordered for the issuing wave's own ds_read only by MH_WAIT_VMCNT.
+// Inline asm on purpose: hipcc (ROCm 7.2) answers the builtin form (__builtin_amdgcn_raw_ptr_buffer_load_lds) with an s_waitcnt vmcnt(0) in front
+// of the next ds_read -- it cannot tell which LDS bytes a pending DMA writes -- which drains the prefetch every step.  Hidden in asm the DMA is
+// invisible to its bookkeeping and the kernel counts it itself (cdna_hip_programming.md 5.7: M0 saved and restored inside the statement).
+struct mh_dma_src { u32x4 w; };
+__device__ __forceinline__ mh_dma_src mh_make_dma_src(const void* p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    mh_dma_src r;
+    r.w = (u32x4){(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};      // raw buffer, stride 0 (as mh_make_rsrc)
+    return r;
+}
+__device__ __forceinline__ void mh_glds16(const mh_dma_src& r, void* lds_wave_base, int voff) {
+    const unsigned dst = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)lds_wave_base;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(dst), "s"(r.w) : "memory");
+}
+#define MH_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define MH_WAIT_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")

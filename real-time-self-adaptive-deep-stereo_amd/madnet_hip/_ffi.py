@@ -30,7 +30,8 @@ class Op(C.Structure):
 
 (OP_CONV, OP_WGRAD, OP_CORR_FWD, OP_CORR_BWD, OP_WARP_FWD, OP_WARP_BWD, OP_RESIZE_FWD, OP_RESIZE_BWD,
  OP_PAD_REFLECT, OP_LOSS, OP_METRICS, OP_MOMENTUM, OP_COPY_CH, OP_LEAKY_BWD, OP_FILL, OP_BIAS_GRAD,
- OP_WGRAD_PARTIAL, OP_WGRAD_REDUCE, OP_PROXY_LOSS, OP_SUPERVISED_LOSS, OP_ADAM, OP_ADAM_ADVANCE, OP_RESIZE_IMAGE, OP_LEVEL_FRONT, OP_TRANSPOSE_W, OP_PACK_W, OP_CORR_WARP_BWD) = range(1, 28)
+ OP_WGRAD_PARTIAL, OP_WGRAD_REDUCE, OP_PROXY_LOSS, OP_SUPERVISED_LOSS, OP_ADAM, OP_ADAM_ADVANCE, OP_RESIZE_IMAGE, OP_LEVEL_FRONT, OP_TRANSPOSE_W, OP_PACK_W, OP_CORR_WARP_BWD,
+ OP_SHADOW_CAST, OP_WGRAD_STREAM) = range(1, 30)
 
 
 OP_JOIN = 0x100
@@ -54,6 +55,16 @@ class PackSeg(C.Structure):          # mh_pack_seg
 class WgradItem(C.Structure):        # mh_wgrad_item
     _fields_ = [("d", ConvDesc), ("inp", C.c_void_p), ("dout", C.c_void_p), ("ws", C.c_void_p), ("db", C.c_void_p),
                 ("dout_ld", C.c_int32), ("splits", C.c_int32), ("group_max_m", C.c_int32), ("reserved", C.c_int32)]
+
+class ShadowSeg(C.Structure):        # mh_shadow_seg
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("npix", C.c_int64), ("C", C.c_int32), ("src_ld", C.c_int32),
+                ("dst_ld", C.c_int32), ("blk0", C.c_int32)]
+
+
+class WgsLayer(C.Structure):         # mh_wgs_layer
+    _fields_ = [("x", C.c_void_p), ("dz", C.c_void_p), ("ws", C.c_void_p), ("db", C.c_void_p)] + \
+               [(n, C.c_int32) for n in ("B", "H", "W", "K", "N", "dil", "x_ld", "dz_ld", "ktiles", "ntiles", "splits", "blk0")]
+
 
 _P = C.c_void_p
 _I = C.c_int32
@@ -89,6 +100,10 @@ SIGNATURES = {
     "mh_tune_conv_x3_igemm": (_I, [_I]),
     "mh_conv2d_wgrad_partial_group": (_I, [C.POINTER(WgradItem), _I, _P]),
     "mh_wgrad_reduce": (_I, [_P, _I, _I, _P]),
+    "mh_shadow_cast": (_I, [_P, _I, _I, _P]),
+    "mh_wgrad_stream_plan": (_I, [C.POINTER(WgsLayer), _I, _I, _I, C.POINTER(C.c_int32)]),
+    "mh_wgrad_stream": (_I, [_P, _I, _I, _I, _I, _P]),
+    "mh_tune_wgrad_stream": (_I, [_I]),
     "mh_proxy_ws_floats": (_L, [_I, _I, _I]),
     "mh_proxy_loss": (_I, [_P, _P, _P, _P, _P, _F, _F, _I, _I, _I, _P]),
     "mh_supervised_loss": (_I, [_P, _P, _P, _P, _P, _F, _F, _F, _I, _I, _I, _P]),

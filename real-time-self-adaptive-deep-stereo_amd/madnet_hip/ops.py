@@ -272,6 +272,87 @@ def wgrad_reduce(lib, segs, device, keep, stream=None, accumulate=False):
     lib.wgrad_reduce(C.c_void_p(table.data_ptr()), len(segs), blk, _p(stream))
 
 
+def shadow_ld(c):
+    """channel stride of the bf16 shadow of a C-channel tensor: C rounded up to 32 (the padding channels stay zero)"""
+    return (c + 31) // 32 * 32
+
+
+class Shadow(object):
+    """bf16 NHWC copy of an fp32 tensor for the streaming filter-gradient kernel (mh_wgrad_stream): [B,H,W,shadow_ld(C)], pad = 0."""
+    __slots__ = ("t", "B", "H", "W", "C", "ld")
+
+    def __init__(self, B, H, W, C_, device):
+        self.B, self.H, self.W, self.C, self.ld = B, H, W, C_, shadow_ld(C_)
+        self.t = torch.zeros(B, H, W, self.ld, dtype=torch.bfloat16, device=device)
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr()
+
+
+def shadow_cast(lib, pairs, device, keep, stream=None):
+    """pairs: [(View src, Shadow dst)] -> every dst = bf16(src), ONE launch (mh_shadow_cast).  `keep` keeps the device table alive."""
+    if not pairs:
+        return
+    arr = (_ffi.ShadowSeg * len(pairs))()
+    blk = 0
+    for i, (src, dst) in enumerate(pairs):
+        assert (src.B, src.H, src.W, src.C) == (dst.B, dst.H, dst.W, dst.C), "shadow / source geometry mismatch"
+        arr[i].src, arr[i].dst, arr[i].npix, arr[i].C = src.ptr, dst.ptr, src.npix, src.C
+        arr[i].src_ld, arr[i].dst_ld, arr[i].blk0 = src.ld, dst.ld, blk
+        blk += (src.npix * (dst.ld // 8) + 255) // 256
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+    keep.append(table)
+    lib.shadow_cast(C.c_void_p(table.data_ptr()), len(pairs), blk, _p(stream))
+
+
+WGRAD_STREAM_WAVES = 8          # waves per workgroup of the streaming filter-gradient kernel
+WGRAD_STREAM_WGS = 256          # workgroups a batch is divided into (one per CU)
+
+
+def wgrad_stream_ok(x, dz, dw, stride, dil):
+    """layers the streaming kernel covers: 3x3, stride 1, 'SAME' (dilation 1 .. 16)"""
+    kh, kw = dw.shape[0], dw.shape[1]
+    return kh == 3 and kw == 3 and stride == 1 and 1 <= dil <= 16 and (x.H, x.W) == (dz.H, dz.W)
+
+
+def wgrad_stream(lib, qlib, wsa, segs, items, device, keep, stream=None, target_wgs=None, nwaves=None):
+    """Filter + bias gradients of a batch of stride-1 3x3 layers in ONE launch from bf16 shadows (mh_wgrad_stream).
+    items: [(Shadow x, Shadow dz, dw tensor (HWIO, fp32), db tensor or None, dil)].  Per-split partial sums go to the arena `wsa` and a
+    segment per layer is appended to `segs` for the batch's wgrad_reduce; a layer with ONE split stores straight into dw.
+    `qlib` = the real library (host-side planner); `lib` may be a Recorder."""
+    if not items:
+        return
+    n = len(items)
+    arr = (_ffi.WgsLayer * n)()
+    max_dil = 1
+    for i, (xs, zs, dw, db, dil) in enumerate(items):
+        kh, kw, K, N = dw.shape
+        assert kh == 3 and kw == 3 and (xs.B, xs.H, xs.W) == (zs.B, zs.H, zs.W) and xs.C == K and zs.C == N
+        L = arr[i]
+        L.x, L.dz, L.db = xs.ptr, zs.ptr, (db.data_ptr() if db is not None else None)
+        L.B, L.H, L.W, L.K, L.N, L.dil, L.x_ld, L.dz_ld = xs.B, xs.H, xs.W, K, N, dil, xs.ld, zs.ld
+        max_dil = max(max_dil, dil)
+    nw = nwaves or WGRAD_STREAM_WAVES
+    if max_dil > 8:
+        nw = min(nw, 7)                   # 64-pixel row slots: 7 x 20 KB of rings fit the 160 KB LDS
+    nblk = C.c_int32(0)
+    qlib.wgrad_stream_plan(arr, n, target_wgs or WGRAD_STREAM_WGS, nw, C.byref(nblk))
+    for i, (xs, zs, dw, db, dil) in enumerate(items):
+        L = arr[i]
+        size = dw.numel()
+        if L.splits == 1 and dw.data_ptr() % 16 == 0:
+            L.ws = dw.data_ptr()
+        else:
+            L.ws = wsa.alloc(size * L.splits)
+            segs.append((L.ws, dw.data_ptr(), size, L.splits))
+        if hasattr(lib, "tally_wgrad"):
+            lib.tally_wgrad(xs.B, xs.H, xs.W, L.K, L.N, 9, L.splits)
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+    keep.append(table)
+    lib.wgrad_stream(C.c_void_p(table.data_ptr()), n, nblk.value, nw, max_dil, _p(stream))
+
+
 def conv2d_transpose_fwd(lib, x, w, b, out, stride=2, alpha=1.0, stream=None, precision=None):
     """tf.nn.conv2d_transpose(x, w[kh,kw,Cout,Cin], 'SAME') + b, leaky (sharedLayers.py:80-92):
     the input-gradient of a SAME conv with HWIO = [kh,kw,I=Cout,O=Cin]."""

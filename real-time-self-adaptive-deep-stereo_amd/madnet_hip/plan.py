@@ -103,6 +103,21 @@ class Recorder(object):
         self._tally(d, "wgrad", splits_ref._obj.value if ws is not None else 0)
         self._op(_ffi.OP_WGRAD_PARTIAL, ints, [d.alpha, d.mask_alpha], [inp, dout, ws, db])
 
+    def shadow_cast(self, segs, nseg, nblocks, stream):
+        self._op(_ffi.OP_SHADOW_CAST, [nseg, nblocks], [], [segs])
+
+    def wgrad_stream(self, layers, nlayers, nblocks, nwaves, max_dil, stream):
+        self._op(_ffi.OP_WGRAD_STREAM, [nlayers, nblocks, nwaves, max_dil], [], [layers])
+
+    def tally_wgrad(self, B, H, W, K, N, taps, splits):
+        """work of one layer of a streamed filter-gradient batch (the batch is ONE op)"""
+        self.stats["wgrad_flops"] += 2.0 * B * H * W * taps * K * N
+        self.stats["wgrad_bytes"] += 4.0 * (B * H * W * (K + N) + taps * K * N)
+        self.stats["wgrad_launches"] += 1
+        self.stats["grad_bytes"] += 4.0 * taps * K * N
+        if splits > 1:
+            self.stats["wgrad_ws_bytes"] += 2 * 4.0 * splits * taps * K * N
+
     def wgrad_reduce(self, segs, nseg, nblocks, stream):
         self._op(_ffi.OP_WGRAD_REDUCE, [nseg, nblocks], [], [segs])
 

@@ -59,3 +59,39 @@ static inline uint2 mh_lds_read_tr16(const unsigned short* p) {
     r.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
     return r;
 }
+
+// ---- primitives of csrc/wgrad_stream.hip (see csrc/mh_bf16_intrin.h) ---------------------------------------------------------------
+typedef float f32x16 __attribute__((vector_size(64)));
+static inline f32x16 mh_mfma_bf16_32(u32x4 a, u32x4 b, f32x16 c) {
+    emul::Wave& w = emul::my_wave();
+    const int lane = emul::tls().cur_index & 63;
+    const int par = w.gen & 1;
+    for (int e = 0; e < 4; ++e) { w.ua[par][lane][e] = a[e]; w.ub[par][lane][e] = b[e]; }
+    emul::wave_rendezvous(w);
+    const int col = lane & 31;
+    f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            const int kq = k >> 3, e = k & 7;                      // lane (row/col + 32 * kq) holds k = 8 kq .. 8 kq + 7
+            const unsigned aw = w.ua[par][row + 32 * kq][e >> 1], bw = w.ub[par][col + 32 * kq][e >> 1];
+            const float av = emul_bf16_val((e & 1) ? (aw >> 16) : (aw & 0xffffu));
+            const float bv = emul_bf16_val((e & 1) ? (bw >> 16) : (bw & 0xffffu));
+            acc += av * bv;
+        }
+        d[r] = acc;
+    }
+    return d;
+}
+// LDS DMA: synchronous on the emulator (a missing / wrong vmcnt wait cannot be detected here; the GPU tests cover that)
+struct mh_dma_src { const char* base; unsigned bytes; };
+static inline mh_dma_src mh_make_dma_src(const void* p, unsigned bytes) { mh_dma_src r; r.base = (const char*)p; r.bytes = bytes; return r; }
+static inline void mh_glds16(const mh_dma_src& r, void* lds_wave_base, int voff) {
+    const int lane = emul::tls().cur_index & 63;
+    const unsigned off = (unsigned)voff;
+    unsigned char* dst = (unsigned char*)lds_wave_base + 16 * lane;
+    if ((unsigned long long)off + 16ull <= r.bytes) memcpy(dst, r.base + off, 16); else memset(dst, 0, 16);
+}
+#define MH_WAIT_VMCNT(n) do { } while (0)
+#define MH_WAIT_LGKMCNT0() do { } while (0)
