@@ -189,6 +189,11 @@ class MadNetEngine(object):
         self.banks = {}
         self.banks_d = {}
         self.wsa = ops.WgradWorkspace(device)
+        # bf16 backward: the filter gradients of the stride-1 3x3 layers run on the streaming kernel (mh_wgrad_stream: one launch per batch,
+        # operands from bf16 shadows of the activations / gradient maps); MH_WGRAD_STREAM=0 keeps the tiled kernels
+        self.use_stream = precision in ("mixed", "bf16") and os.environ.get("MH_WGRAD_STREAM", "1") != "0"
+        self.stream_min_pix = int(os.environ.get("MH_WGRAD_STREAM_MINPIX", "0"))
+        self.shadows = {}                   # (data pointer, B, H, W, C) -> ops.Shadow, allocated once per engine
 
     # ---------------------------------------------------------------------------------------
     def _buf(self, *shape):
@@ -446,6 +451,16 @@ class MadNetEngine(object):
         # rescaled_prediction: relu AFTER resize (MadNet.py:362-364)
         ops.resize_fwd(lib, self.final, self.pred, self.Hp, self.Wp, self.pt, self.pl, mul=-20.0, mode=2)
 
+    def _shadow(self, v, casts):
+        """the bf16 shadow of View v (allocated on first use); queues its cast unless this plan section already did"""
+        key = (v.ptr, v.B, v.H, v.W, v.C)
+        sh = self.shadows.get(key)
+        if sh is None:
+            sh = self.shadows[key] = ops.Shadow(v.B, v.H, v.W, v.C, self.dev)
+        if not any(c[1] is sh for c in casts):
+            casts.append((v, sh))
+        return sh
+
     def _front_fused(self):
         return self.fuse_front and self.warping and self.cstride == 1 and self.D <= 9
 
@@ -561,12 +576,25 @@ class MadNetEngine(object):
             follows on lane 0 until the reduction joins them."""
             if not pending:
                 return
+            if os.environ.get("MH_DEBUG_SKIP_WGRAD", "0") == "1":       # timing experiment only (WRONG results): the step without any filter gradient
+                del pending[:]
+                return
             lib.lane = 1 + nflush[0] % self.wgrad_lanes
             lib.nodefer = nflush[0] < NODEFER_BATCHES        # the first batches (context network, 1/4-resolution estimator) carry most of the work
             nflush[0] += 1
             try:
                 batch = []
-                for xv, dzv, dw, db, stride, dil in pending:
+                todo = list(pending)
+                if self.use_stream and self.partial_wgrad and ops._bwd_precision() == 1:
+                    items, casts, todo = [], [], []
+                    for xv, dzv, dw, db, stride, dil in pending:
+                        if ops.wgrad_stream_ok(xv, dzv, dw, stride, dil) and xv.npix >= self.stream_min_pix:
+                            items.append((self._shadow(xv, casts), self._shadow(dzv, casts), dw, db, dil))
+                        else:
+                            todo.append((xv, dzv, dw, db, stride, dil))
+                    ops.shadow_cast(lib, casts, self.dev, r.keep)
+                    ops.wgrad_stream(lib, self.lib, self.wsa, batch, items, self.dev, r.keep)
+                for xv, dzv, dw, db, stride, dil in todo:
                     if self.partial_wgrad:
                         ops.conv2d_wgrad_partial(lib, self.lib, self.wsa, batch, xv, dzv, dw, db, stride=stride, dil=dil)
                     else:

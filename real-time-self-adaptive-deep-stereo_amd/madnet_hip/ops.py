@@ -306,8 +306,9 @@ def shadow_cast(lib, pairs, device, keep, stream=None):
     lib.shadow_cast(C.c_void_p(table.data_ptr()), len(pairs), blk, _p(stream))
 
 
-WGRAD_STREAM_WAVES = 8          # waves per workgroup of the streaming filter-gradient kernel
-WGRAD_STREAM_WGS = 256          # workgroups a batch is divided into (one per CU)
+import os as _os
+WGRAD_STREAM_WAVES = int(_os.environ.get("MH_WGRAD_STREAM_WAVES", "8"))       # waves per workgroup of the streaming filter-gradient kernel
+WGRAD_STREAM_WGS = int(_os.environ.get("MH_WGRAD_STREAM_WGS", "256"))        # workgroups a batch is divided into (one per CU)
 
 
 def wgrad_stream_ok(x, dz, dw, stride, dil):
