@@ -103,6 +103,11 @@ int mh_transpose_weights(const mh_transpose_seg* segs_device, int32_t nseg, int3
  * (the engines do it once per step, one launch for every layer).  Same arithmetic as the LDS-staged split-bf16 kernel. */
 int mh_conv2d_wb(const mh_conv_desc* d, const float* in, const float* w, const void* wb, const float* bias,
                  float* out, const float* mask_ref, void* stream);
+/* mh_conv2d_wb that ALSO writes out_shadow = bf16(out) as [pixel][N rounded up to 32] (round to nearest even; the padding channels are not
+ * touched: allocate the shadow zeroed) -- the operand layout of mh_wgrad_stream, produced where the value is computed instead of by a
+ * cast pass (+2 bytes per element written, nothing re-read).  wb and out_shadow may be NULL (then exactly mh_conv2d_wb / mh_conv2d). */
+int mh_conv2d_sh(const mh_conv_desc* d, const float* in, const float* w, const void* wb, const float* bias,
+                 float* out, const float* mask_ref, void* out_shadow, void* stream);
 typedef struct mh_pack_seg {
     const float* src;     /* HWIO bank [taps][K][N] */
     void* dst;            /* fragment bank, mh_pack_bytes(taps, K, N, planes) bytes */
@@ -356,7 +361,6 @@ int mh_tune_conv_x3_igemm(int on);       /* split-bf16 (precision 2) on the tile
 int mh_tune_conv_bank(int small_maxpix); /* fragment-bank kernels (mh_conv2d_wb): the small-layer kernel takes layers of up to this many output pixels (0 = never, < 0 = default 4096 / MH_CONV_BANK_SMALL_MAXPIX); returns the number of bank-kernel launches since the previous call */
 int mh_tune_wgrad_wgs(int target_workgroups);
 int mh_tune_wgrad_target_pct(int pct);   /* scale (percent) of the filter-gradient pixel-split workgroup targets for the split counts resolved from now on (a plan stores the counts it was recorded with); 0 = default.  DispNet's engine records with 150 */
-int mh_tune_wgrad_taps(int on);          /* filter gradients of the stride-1 3x3 bf16 layers with > 64 output channels and > 16384 reduction pixels (MH_WGRAD_TAPS_MINM) on the all-taps kernel (operands through the LDS transposing read, csrc/wgrad.hip wgrad_taps_kernel): 1 = on, 0 = off, < 0 = default / MH_WGRAD_TAPS (off: faster stand-alone, slower inside the step, profiles/r02_microbench_wgrad_taps.txt); 1 + 16 * 0x100 = on for every size (tests).  Affects the split counts resolved from now on.  Returns the number of all-taps launches since the previous call (NOT a status code) */
 int mh_tune_wgrad_stream(int dist);     /* prefetch distance (row groups in flight) of the streaming filter-gradient kernel: 1 or 2, 0 = default / MH_WGRAD_STREAM_DIST */
 int mh_tune_corr(int direct);
 

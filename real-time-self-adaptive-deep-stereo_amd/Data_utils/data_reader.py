@@ -158,12 +158,18 @@ class dataset(object):
     def __len__(self):
         return len(self._left)
 
+    def _per_rank(self):
+        """samples of one epoch EVERY rank reads: the list is cut to a multiple of the world size, so that all ranks yield the same number of
+        batches -- each training step issues collectives (madnet_hip/trainer.py), and a rank with one batch more would wait in an all-reduce
+        its peers never enter"""
+        return len(self._left) // self._world
+
     def get_max_steps(self):
-        per_rank = len(range(self._rank, len(self._left), self._world))
-        return (per_rank * self._epochs) // self._batch
+        return (self._per_rank() * self._epochs) // self._batch
 
     def _samples(self):
-        order = [i for _ in range(self._epochs) for i in range(self._rank, len(self._left), self._world)]
+        n = self._per_rank() * self._world
+        order = [i for _ in range(self._epochs) for i in range(self._rank, n, self._world)]
         if not self._shuffle:
             for i in order:
                 yield i

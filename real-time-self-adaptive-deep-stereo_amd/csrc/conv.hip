@@ -588,6 +588,7 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
                 v.w *= (mk.w > 0.f || n + 3 < p.mask_c0 || n + 3 >= p.mask_c1) ? 1.0f : p.mask_alpha;
             }
             if (ok) *reinterpret_cast<float4*>(p.out + (int64_t)m * p.out_ld + n) = v;
+            if (ok && p.shadow) *reinterpret_cast<uint2*>(p.shadow + (int64_t)m * p.shadow_ld + n) = make_uint2(mh_pack_bf16(v.x, v.y), mh_pack_bf16(v.z, v.w));
         }
 #ifdef MH_PHASE_TIMING
         if (p.dbg && threadIdx.x == 0) {
@@ -1023,7 +1024,8 @@ extern "C" int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w,
 }
 
 static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, const float* wt, const void* wb, const float* bias,
-                      float* out, const float* mask_ref, void* stream);
+                      float* out, const float* mask_ref, void* stream, void* out_shadow = nullptr);
+int mh_shadow_cast_one(const float* src, int src_ld, int C, void* dst, int dst_ld, int64_t npix, hipStream_t s);      // wgrad_stream.hip
 #ifdef MH_PHASE_TIMING
 static unsigned long long* g_conv_dbg = nullptr;
 extern "C" int mh_tune_conv_dbg(void* buf) { g_conv_dbg = (unsigned long long*)buf; return 0; }
@@ -1036,8 +1038,13 @@ extern "C" int mh_conv2d_wb(const mh_conv_desc* d, const float* in, const float*
                             float* out, const float* mask_ref, void* stream) {
     return conv_entry(d, in, w, nullptr, wb, bias, out, mask_ref, stream);
 }
+extern "C" int mh_conv2d_sh(const mh_conv_desc* d, const float* in, const float* w, const void* wb, const float* bias,
+                            float* out, const float* mask_ref, void* out_shadow, void* stream) {
+    MH_REQUIRE(!out_shadow || (((uintptr_t)out_shadow) & 15u) == 0, MH_ERR_ALIGN, "mh_conv2d_sh: out_shadow must be 16-byte aligned");
+    return conv_entry(d, in, w, nullptr, wb, bias, out, mask_ref, stream, out_shadow);
+}
 static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, const float* wt, const void* wb, const float* bias,
-                      float* out, const float* mask_ref, void* stream) {
+                      float* out, const float* mask_ref, void* stream, void* out_shadow) {
     MH_REQUIRE(d && in && w && out, MH_ERR_ARG, "mh_conv2d: null argument");
     MH_REQUIRE(d->B > 0 && d->Hi > 0 && d->Wi > 0 && d->Ho > 0 && d->Wo > 0 && d->K > 0 && d->N > 0,
                MH_ERR_ARG, "mh_conv2d: non-positive dimension");
@@ -1106,10 +1113,21 @@ static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, co
     // 16-byte vector loads of A need every group start 16B aligned and the full group in-bounds
     a.vecA = mh_aligned16(in) && (d->in_ld % 4 == 0) && (d->in_ld >= a.G * 4);
     a.vecB = mh_aligned16(w) && (d->w_trans ? (d->K % 4 == 0) : (d->N % 4 == 0));
-    if (conv_n1_ok(a)) return launch_conv_n1(a, (hipStream_t)stream);
-    if (conv_thin_ok(a)) return launch_conv_thin(a, (hipStream_t)stream);
-    if (mh_conv_bank_small_ok(a)) return mh_conv_bank_small_launch(a, (hipStream_t)stream);
-    if (mh_conv_patch_ok(a)) return mh_conv_patch_launch(a, (hipStream_t)stream);
-    if (mh_conv_direct_ok(a, (wt && mh_aligned16(wt)) ? wt : nullptr)) return mh_conv_direct_launch(a, wt, (hipStream_t)stream);
-    return conv_dispatch(a, (hipStream_t)stream);
+    // bf16 shadow of the output (operand of mh_wgrad_stream): written by the epilogue of the kernel families that have the store, by a cast
+    // launch behind the others
+    a.shadow = nullptr; a.shadow_ld = (d->N + 31) / 32 * 32; a.shadow_done = 0;
+    hipStream_t hs = (hipStream_t)stream;
+    int rc;
+    if (conv_n1_ok(a)) rc = launch_conv_n1(a, hs);
+    else if (conv_thin_ok(a)) rc = launch_conv_thin(a, hs);
+    else if (mh_conv_bank_small_ok(a)) { a.shadow = (unsigned short*)out_shadow; a.shadow_done = 1; rc = mh_conv_bank_small_launch(a, hs); }
+    else if (mh_conv_patch_ok(a)) { a.shadow = (unsigned short*)out_shadow; a.shadow_done = 1; rc = mh_conv_patch_launch(a, hs); }
+    else if (mh_conv_direct_ok(a, (wt && mh_aligned16(wt)) ? wt : nullptr)) rc = mh_conv_direct_launch(a, wt, hs);
+    else {
+        if (a.vecC) { a.shadow = (unsigned short*)out_shadow; a.shadow_done = 1; }      // the tiled kernel's vector epilogue has the store
+        rc = conv_dispatch(a, hs);
+    }
+    if (!rc && out_shadow && !a.shadow_done)
+        rc = mh_shadow_cast_one(out, d->out_ld, d->N, out_shadow, a.shadow_ld, (int64_t)d->B * d->Ho * d->Wo, hs);
+    return rc;
 }

@@ -532,6 +532,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1,
             v.w *= (mk.w > 0.f || n + 3 < p.mask_c0 || n + 3 >= p.mask_c1) ? 1.0f : p.mask_alpha;
         }
         if (ok) *reinterpret_cast<float4*>(p.out + (int64_t)m * p.out_ld + n) = v;
+        if (ok && p.shadow) *reinterpret_cast<uint2*>(p.shadow + (int64_t)m * p.shadow_ld + n) = make_uint2(mh_pack_bf16(v.x, v.y), mh_pack_bf16(v.z, v.w));
     }
 }
 
@@ -731,6 +732,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1,
             v.w *= (mk.w > 0.f || n + 3 < p.mask_c0 || n + 3 >= p.mask_c1) ? 1.0f : p.mask_alpha;
         }
         if (ok) *reinterpret_cast<float4*>(p.out + (int64_t)m * p.out_ld + n) = v;
+        if (ok && p.shadow) *reinterpret_cast<uint2*>(p.shadow + (int64_t)m * p.shadow_ld + n) = make_uint2(mh_pack_bf16(v.x, v.y), mh_pack_bf16(v.z, v.w));
     }
 }
 
@@ -865,6 +867,7 @@ __global__ __launch_bounds__(1024) void conv_bank_small_kernel(ConvArgs p, Patch
                 v *= (mk > 0.f || n < p.mask_c0 || n >= p.mask_c1) ? 1.0f : p.mask_alpha;
             }
             *dst = v;
+            if (p.shadow) p.shadow[m * p.shadow_ld + n] = (unsigned short)mh_pack_bf16(v, 0.f);
         }
     }
 }

@@ -59,6 +59,21 @@ __global__ __launch_bounds__(256) void shadow_cast_kernel(const mh_shadow_seg* _
     *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(sg.dst) + pix * sg.dst_ld + c0) = o;
 }
 
+__global__ __launch_bounds__(256) void shadow_cast_one_kernel(mh_shadow_seg sg) {
+    const int g8 = sg.dst_ld >> 3;
+    const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (item >= sg.npix * g8) return;
+    const int64_t pix = item / g8;
+    const int c0 = (int)(item - pix * g8) * 8;
+    const float* s = sg.src + pix * sg.src_ld + c0;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (c0 + e < sg.C) ? s[e] : 0.f;
+    u32x4 o;
+    o[0] = mh_pack_bf16(v[0], v[1]); o[1] = mh_pack_bf16(v[2], v[3]); o[2] = mh_pack_bf16(v[4], v[5]); o[3] = mh_pack_bf16(v[6], v[7]);
+    *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(sg.dst) + pix * sg.dst_ld + c0) = o;
+}
+
 // ---- the streaming kernel ---------------------------------------------------------------------------------------------------------------
 // NXG: LDS-DMA instructions per input row slot (slot = NXG x 16 pixels >= 32 + 2 d: 3 for d <= 8, 4 for d = 16); D: prefetch distance in steps.
 template <int NXG, int D>
@@ -260,6 +275,14 @@ static int stream_launch(const mh_wgs_layer* tab, int nlayers, int nblocks, int 
 static std::atomic<int> g_stream_dist{0};      // mh_tune_wgrad_stream: prefetch distance (0 = default)
 
 }  // namespace
+
+// one tensor, arguments by value (the fallback of mh_conv2d_sh for kernel families whose epilogue does not write the shadow)
+int mh_shadow_cast_one(const float* src, int src_ld, int C, void* dst, int dst_ld, int64_t npix, hipStream_t s) {
+    mh_shadow_seg sg;
+    sg.src = src; sg.dst = dst; sg.npix = npix; sg.C = C; sg.src_ld = src_ld; sg.dst_ld = dst_ld; sg.blk0 = 0;
+    hipLaunchKernelGGL(shadow_cast_one_kernel, dim3((unsigned)((npix * (dst_ld / 8) + 255) / 256)), dim3(256), 0, s, sg);
+    return mh_check_launch("shadow_cast_one");
+}
 
 int mh_wgrad_stream_init() {
     if (int rc = stream_launch<3, 1>(nullptr, 0, 0, 0, nullptr, true)) return rc;

@@ -194,6 +194,11 @@ class MadNetEngine(object):
         self.use_stream = precision in ("mixed", "bf16") and os.environ.get("MH_WGRAD_STREAM", "1") != "0"
         self.stream_min_pix = int(os.environ.get("MH_WGRAD_STREAM_MINPIX", "0"))
         self.shadows = {}                   # (data pointer, B, H, W, C) -> ops.Shadow, allocated once per engine
+        # ... written by the epilogue of the kernel that produces the tensor (mh_conv2d_sh) wherever a conv kernel is the producer; the rest
+        # (cost-volume buffers, heads, the top pyramid gradient) go through one mh_shadow_cast per batch.  MH_FUSE_SHADOWS=0: cast everything
+        self.fuse_shadows = os.environ.get("MH_FUSE_SHADOWS", "1") != "0"
+        self._fresh = set()                 # shadows a producer wrote in the plan being recorded
+        self._stream_train = set()          # trainable variables of that plan
 
     # ---------------------------------------------------------------------------------------
     def _buf(self, *shape):
@@ -391,8 +396,9 @@ class MadNetEngine(object):
             if side_pack and self.Wb_(pyr_name(i)) is not None:
                 r.join_lanes_next = 1 << PACK_LANE
                 side_pack = False
+            sh = self._out_shadow(o, pyr_name(i + 1)) if (i < 12 and PYR[i][2] == 1) else None       # F_i is the input of the stride-1 layer i + 1
             ops.conv2d_fwd(lib, x, self.W_(pyr_name(i)), self.b_(pyr_name(i)), o, stride=s, alpha=ALPHA, wt=self.Wt_(pyr_name(i)),
-                           wb=self.Wb_(pyr_name(i)), precision=self._pyr_code(i))
+                           wb=self.Wb_(pyr_name(i)), precision=self._pyr_code(i), shadow=sh)
             x = o
         if side_pack:
             r.join_lanes_next = 1 << PACK_LANE
@@ -424,7 +430,7 @@ class MadNetEngine(object):
                 o = self._fv(self.V[k]) if last else self._fv(self.E[k][j])
                 ops.conv2d_fwd(lib, x, self.W_(est_name(k, j + 1)), self.b_(est_name(k, j + 1)), o,
                                alpha=(1.0 if last else ALPHA), precision=fprec, wt=self.Wt_(est_name(k, j + 1)),
-                               wb=self.Wb_(est_name(k, j + 1)))
+                               wb=self.Wb_(est_name(k, j + 1)), shadow=(None if last else self._out_shadow(o, est_name(k, j + 2))))
                 x = o
             if k != 2:
                 sc = 2 ** (k - 1)
@@ -441,7 +447,7 @@ class MadNetEngine(object):
         for j, (co, rate) in enumerate(CTX[:-1]):
             o = self._fv(self.Cx[j])
             ops.conv2d_fwd(lib, x, self.W_(ctx_name(j + 1)), self.b_(ctx_name(j + 1)), o, dil=rate, alpha=ALPHA, wt=self.Wt_(ctx_name(j + 1)),
-                           wb=self.Wb_(ctx_name(j + 1)))
+                           wb=self.Wb_(ctx_name(j + 1)), shadow=self._out_shadow(o, ctx_name(j + 2)))
             x = o
         # final_disp = V2_init + context7  (accumulating epilogue)
         ops.copy_channels(lib, self._fv(self.V[2]), self._fv(self.final))
@@ -452,13 +458,28 @@ class MadNetEngine(object):
         ops.resize_fwd(lib, self.final, self.pred, self.Hp, self.Wp, self.pt, self.pl, mul=-20.0, mode=2)
 
     def _shadow(self, v, casts):
-        """the bf16 shadow of View v (allocated on first use); queues its cast unless this plan section already did"""
+        """the bf16 shadow of View v (allocated on first use); queues its cast unless the producing kernel wrote it (self._fresh) or this
+        batch already queued it"""
         key = (v.ptr, v.B, v.H, v.W, v.C)
         sh = self.shadows.get(key)
         if sh is None:
             sh = self.shadows[key] = ops.Shadow(v.B, v.H, v.W, v.C, self.dev)
-        if not any(c[1] is sh for c in casts):
+        if key not in self._fresh and not any(c[1] is sh for c in casts):
             casts.append((v, sh))
+        return sh
+
+    def _out_shadow(self, v, consumer):
+        """Shadow the PRODUCER of View v should write in its epilogue (mh_conv2d_sh), or None: only when the filter gradient of the layer
+        `consumer` (a variable base name) is streamed in the plan being recorded."""
+        if not (self.use_stream and self.fuse_shadows and self.partial_wgrad and ops._bwd_precision() == 1):
+            return None
+        if (consumer + "/weights") not in self._stream_train or v.npix < self.stream_min_pix:
+            return None
+        key = (v.ptr, v.B, v.H, v.W, v.C)
+        sh = self.shadows.get(key)
+        if sh is None:
+            sh = self.shadows[key] = ops.Shadow(v.B, v.H, v.W, v.C, self.dev)
+        self._fresh.add(key)
         return sh
 
     def _front_fused(self):
@@ -561,8 +582,8 @@ class MadNetEngine(object):
 
         def wgrad(xv, dzv, base, stride=1, dil=1):
             dw, db = P.tensor(base + "/weights", "g"), P.tensor(base + "/biases", "g")
-            if self.wgrad_lanes > 0 and hasattr(lib, "lane"):
-                pending.append((xv, dzv, dw, db, stride, dil))
+            if (self.wgrad_lanes > 0 and hasattr(lib, "lane")) or (self.use_stream and self.partial_wgrad):
+                pending.append((xv, dzv, dw, db, stride, dil))      # issued per batch (flush): on a side lane, and / or as one streamed launch
             elif not self.partial_wgrad:
                 ops.conv2d_wgrad(lib, xv, dzv, dw, db, stride=stride, dil=dil)
             else:
@@ -579,8 +600,10 @@ class MadNetEngine(object):
             if os.environ.get("MH_DEBUG_SKIP_WGRAD", "0") == "1":       # timing experiment only (WRONG results): the step without any filter gradient
                 del pending[:]
                 return
-            lib.lane = 1 + nflush[0] % self.wgrad_lanes
-            lib.nodefer = nflush[0] < NODEFER_BATCHES        # the first batches (context network, 1/4-resolution estimator) carry most of the work
+            side = self.wgrad_lanes > 0 and hasattr(lib, "lane")
+            if side:
+                lib.lane = 1 + nflush[0] % self.wgrad_lanes
+                lib.nodefer = nflush[0] < NODEFER_BATCHES        # the first batches (context network, 1/4-resolution estimator) carry most of the work
             nflush[0] += 1
             try:
                 batch = []
@@ -593,7 +616,7 @@ class MadNetEngine(object):
                         else:
                             todo.append((xv, dzv, dw, db, stride, dil))
                     ops.shadow_cast(lib, casts, self.dev, r.keep)
-                    ops.wgrad_stream(lib, self.lib, self.wsa, batch, items, self.dev, r.keep)
+                    ops.wgrad_stream(lib, self.lib, self.wsa, batch, items, self.dev, r.keep, nwaves=(4 if self.B == 1 else 8))
                 for xv, dzv, dw, db, stride, dil in todo:
                     if self.partial_wgrad:
                         ops.conv2d_wgrad_partial(lib, self.lib, self.wsa, batch, xv, dzv, dw, db, stride=stride, dil=dil)
@@ -603,8 +626,9 @@ class MadNetEngine(object):
                 if batch:
                     ops.wgrad_reduce(lib, batch, self.dev, r.keep)
             finally:
-                lib.lane = 0
-                lib.nodefer = False
+                if side:
+                    lib.lane = 0
+                    lib.nodefer = False
                 del pending[:]
 
         def acc_flag(key):
@@ -612,12 +636,15 @@ class MadNetEngine(object):
             written.add(key)
             return a
 
-        def conv_bwd(xv, base, dzv, dxv, dx_key, x_act, stride=1, dil=1, need_dx=True, trainable=True):
+        def conv_bwd(xv, base, dzv, dxv, dx_key, x_act, stride=1, dil=1, need_dx=True, trainable=True, below=None):
+            """below: the layer whose output gradient dxv is (its filter gradient reads it as dz): the input gradient's epilogue then also
+            writes the bf16 shadow"""
             if trainable:
                 wgrad(xv, dzv, base, stride=stride, dil=dil)
             if need_dx:
                 ops.conv2d_dgrad(lib, dzv, self.W_(base), dxv, stride=stride, dil=dil, accumulate=acc_flag(dx_key),
-                                 mask_ref=x_act, mask_alpha=ALPHA, wb=self.Wd_(base))
+                                 mask_ref=x_act, mask_alpha=ALPHA, wb=self.Wd_(base),
+                                 shadow=(self._out_shadow(dxv, below) if below else None))
 
         if heads is None:
             heads = {head: (self.dpred if head == "final" else self.ddisp_k)}
@@ -646,7 +673,7 @@ class MadNetEngine(object):
                     dx = ops.View(self.dctx_in, B, h2, w2, c2 + 1, self.ctx_ld) if j == 1 else self._fv(self.dCx[j - 2])
                     need_dx = any(ctx_tr[:j - 1]) or any_below
                     conv_bwd(xin, ctx_name(j), dz, dx, ("ctx", j - 1), (None if j == 1 else self._fv(self.Cx[j - 2])),
-                             dil=CTX[j - 1][1], need_dx=need_dx, trainable=ctx_tr[j - 1])
+                             dil=CTX[j - 1][1], need_dx=need_dx, trainable=ctx_tr[j - 1], below=(ctx_name(j - 1) if j > 1 else None))
                     dz = dx
                     if not need_dx:
                         break
@@ -675,7 +702,7 @@ class MadNetEngine(object):
                 dx = ops.View(self.ddsi[k], B, h, w, cin, ld) if j == 1 else self._fv(self.dE[k][j - 2])
                 need_dx = any(est_tr[k][:j - 1]) or need_dsi
                 conv_bwd(xin, est_name(k, j), dz, dx, ("est", k, j - 1), (None if j == 1 else self._fv(self.E[k][j - 2])),
-                         need_dx=need_dx, trainable=est_tr[k][j - 1])
+                         need_dx=need_dx, trainable=est_tr[k][j - 1], below=(est_name(k, j - 1) if j > 1 else None))
                 dz = dx
                 if not need_dx:
                     break
@@ -768,9 +795,11 @@ class MadNetEngine(object):
                 if pyr_tr[i]:
                     wgrad(xin, self._fv(self.dF[i]), pyr_name(i), stride=PYR[i - 1][2])
                 if need_dx:
+                    # dF[i-1] is complete after this launch (the cost-volume contributions were written earlier): it is the dz of layer i - 1
+                    sh = self._out_shadow(self._fv(self.dF[i - 1]), pyr_name(i - 1)) if PYR[i - 2][2] == 1 else None
                     ops.conv2d_dgrad(lib, self._fv(self.dF[i]), self.W_(pyr_name(i)), self._fv(self.dF[i - 1]),
                                      stride=PYR[i - 1][2], accumulate=accumulate, mask_ref=self._fv(self.F[i - 1]),
-                                     mask_alpha=ALPHA, wb=self.Wd_(pyr_name(i)))
+                                     mask_alpha=ALPHA, wb=self.Wd_(pyr_name(i)), shadow=sh)
                 if i % 4 == 1 or i in PYR_TAIL_FLUSH:
                     flush()
         flush()
@@ -821,6 +850,16 @@ class MadNetEngine(object):
         split lets a gradient all-reduce (shared-model multi-GPU mode) sit between two plans."""
         r = Recorder()
         self.wsa.reset()
+        self._fresh = set()
+        if mode in ("FULL", "TRAIN"):
+            self._stream_train = set(self.all_vars())
+        elif mode == "MAD":
+            bl = blocks if blocks is not None else ([(block_level, block_vars)] if block_level is not None else [])
+            self._stream_train = set(sum((list(bv) for _, bv in bl), [])) if len(bl) == 1 else set()      # several blocks re-run the backward: cast path
+        else:
+            self._stream_train = set()
+        if part == "update":
+            self._stream_train = set()
         with ops.precision_scope(self.precision):
             if mode == "TRAIN":
                 return self._build_train_plan(r, lr, grad_scale, update, part, loss_weights, max_disp)

@@ -110,7 +110,7 @@ def conv_geometry(H, W, kh, kw, stride, dil):
 
 
 def conv2d_fwd(lib, x, w, b, out, stride=1, dil=1, alpha=1.0, accumulate=False, mask_ref=None, mask_alpha=1.0,
-               mask_range=(0, 0), stream=None, precision=None, wt=None, wb=None):
+               mask_range=(0, 0), stream=None, precision=None, wt=None, wb=None, shadow=None):
     """out (+)= leaky(conv2d_SAME(x, w) + b) [* leaky'(mask_ref)].  x,out: View; w: HWIO [kh,kw,Cin,Cout].
     wb: the layer's MFMA fragment bank (pack_weights) -- split-bf16 3x3 layers then stream their weights from it."""
     kh, kw, cin, cout = w.shape
@@ -119,7 +119,10 @@ def conv2d_fwd(lib, x, w, b, out, stride=1, dil=1, alpha=1.0, accumulate=False, 
     d = conv_desc(x.B, x.H, x.W, Ho, Wo, cin, cout, kh, kw, stride, dil, pt, pl, 0, 0, x.ld, out.ld, alpha=alpha,
                   mask_ld=(mask_ref.ld if mask_ref is not None else 0), accumulate=int(accumulate), mask_alpha=mask_alpha,
                   mask_c0=mask_range[0], mask_c1=mask_range[1], precision=precision)
-    if wb is not None:
+    if shadow is not None:     # shadow: ops.Shadow of `out` -- the epilogue also writes bf16(out) there (operand of wgrad_stream)
+        assert (shadow.B, shadow.H, shadow.W, shadow.C) == (out.B, out.H, out.W, out.C)
+        lib.conv2d_sh(C.byref(d), _p(x), _p(w), _p(wb), _p(b), _p(out), _p(mask_ref), C.c_void_p(shadow.ptr), _p(stream))
+    elif wb is not None:
         lib.conv2d_wb(C.byref(d), _p(x), _p(w), _p(wb), _p(b), _p(out), _p(mask_ref), _p(stream))
     elif wt is not None:       # wt: the transposed filter bank [tap][Cout][Cin] (transpose_weights): lets the small layers run LDS-free
         lib.conv2d_wt(C.byref(d), _p(x), _p(w), _p(wt), _p(b), _p(out), _p(mask_ref), _p(stream))
@@ -175,7 +178,7 @@ def pack_weights(lib, pairs, device, keep, stream=None):
 
 
 def conv2d_dgrad(lib, dz, w, dx, stride=1, dil=1, accumulate=False, mask_ref=None, mask_alpha=1.0, mask_range=(0, 0),
-                 stream=None, wb=None):
+                 stream=None, wb=None, shadow=None):
     """dx (+)= conv2d_backprop_input(dz, w); optionally fused dx *= leaky'(mask_ref).
     dz: View [B,Ho,Wo,Cout]; dx: View [B,H,W,Cin]; w: HWIO of the forward conv."""
     kh, kw, cin, cout = w.shape
@@ -184,7 +187,10 @@ def conv2d_dgrad(lib, dz, w, dx, stride=1, dil=1, accumulate=False, mask_ref=Non
     d = conv_desc(dx.B, Ho, Wo, dx.H, dx.W, cout, cin, kh, kw, stride, dil, pt, pl, 1, 1, dz.ld, dx.ld,
                   mask_ld=(mask_ref.ld if mask_ref is not None else 0), accumulate=int(accumulate),
                   alpha=1.0, mask_alpha=mask_alpha, mask_c0=mask_range[0], mask_c1=mask_range[1], precision=_bwd_precision())
-    if wb is not None:       # wb: pack_weights(trans=1, planes=1) bank of w -- the small-layer bank kernel takes it in the bf16 mode
+    if shadow is not None:   # shadow: ops.Shadow of dx, written by the epilogue (dx is the next layer's dz operand of wgrad_stream)
+        assert (shadow.B, shadow.H, shadow.W, shadow.C) == (dx.B, dx.H, dx.W, dx.C)
+        lib.conv2d_sh(C.byref(d), _p(dz), _p(w), _p(wb), None, _p(dx), _p(mask_ref), C.c_void_p(shadow.ptr), _p(stream))
+    elif wb is not None:       # wb: pack_weights(trans=1, planes=1) bank of w -- the small-layer bank kernel takes it in the bf16 mode
         lib.conv2d_wb(C.byref(d), _p(dz), _p(w), _p(wb), None, _p(dx), _p(mask_ref), _p(stream))
     else:
         lib.conv2d(C.byref(d), _p(dz), _p(w), None, _p(dx), _p(mask_ref), _p(stream))
@@ -307,7 +313,9 @@ def shadow_cast(lib, pairs, device, keep, stream=None):
 
 
 import os as _os
-WGRAD_STREAM_WAVES = int(_os.environ.get("MH_WGRAD_STREAM_WAVES", "8"))       # waves per workgroup of the streaming filter-gradient kernel
+# waves per workgroup of the streaming filter-gradient kernel (0 = the caller's choice: the engines take 4 for a batch-1 step -- the
+# kernel then shares the chip with the input-gradient chain, 1.870 -> 1.818 ms per step -- and 8 for batched streams: 163 -> 138 us per batch)
+WGRAD_STREAM_WAVES = int(_os.environ.get("MH_WGRAD_STREAM_WAVES", "0"))
 WGRAD_STREAM_WGS = int(_os.environ.get("MH_WGRAD_STREAM_WGS", "256"))        # workgroups a batch is divided into (one per CU)
 
 
@@ -334,7 +342,7 @@ def wgrad_stream(lib, qlib, wsa, segs, items, device, keep, stream=None, target_
         L.x, L.dz, L.db = xs.ptr, zs.ptr, (db.data_ptr() if db is not None else None)
         L.B, L.H, L.W, L.K, L.N, L.dil, L.x_ld, L.dz_ld = xs.B, xs.H, xs.W, K, N, dil, xs.ld, zs.ld
         max_dil = max(max_dil, dil)
-    nw = nwaves or WGRAD_STREAM_WAVES
+    nw = WGRAD_STREAM_WAVES or nwaves or 8
     if max_dil > 8:
         nw = min(nw, 7)                   # 64-pixel row slots: 7 x 20 KB of rings fit the 160 KB LDS
     nblk = C.c_int32(0)

@@ -80,6 +80,11 @@ class Recorder(object):
         self._tally(d, "conv")
         self._op(_ffi.OP_CONV, self._desc_ints(d) + [0, d.precision], [d.alpha, d.mask_alpha], [inp, w, bias, out, mask, None, wb])
 
+    def conv2d_sh(self, dref, inp, w, wb, bias, out, mask, shadow, stream):
+        d = dref._obj
+        self._tally(d, "conv")
+        self._op(_ffi.OP_CONV, self._desc_ints(d) + [0, d.precision], [d.alpha, d.mask_alpha], [inp, w, bias, out, mask, None, wb, shadow])
+
     def pack_weights(self, segs, nseg, nblocks, stream):
         self._op(_ffi.OP_PACK_W, [nseg, nblocks], [], [segs])
 

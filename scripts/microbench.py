@@ -113,71 +113,6 @@ def run_wgradp():
     ops.PRECISION = 0
 
 
-def run_wgradt():
-    """all-taps filter-gradient kernel (mh_tune_wgrad_taps; LDS transposing reads) against the tiled kernel: partial launch + reduction, splits,
-    workspace, and the largest difference between the two results."""
-    PL = [("L2 128->128", 1, 96, 320, 128, 128, 1), ("ctx 128->128 d2", 1, 96, 320, 128, 128, 2), ("ctx 128->128 d4", 1, 96, 320, 128, 128, 4),
-          ("ctx 128->96 d8", 1, 96, 320, 128, 96, 8), ("L2 128->96", 1, 96, 320, 128, 96, 1), ("L2 38->128", 1, 96, 320, 38, 128, 1),
-          ("ctx 33->128", 1, 96, 320, 33, 128, 1), ("B4 128->128", 4, 96, 320, 128, 128, 1)]
-    ops.PRECISION = 1
-    print("%-16s %s" % ("wgrad layer", "  [kernel: partial us + reduce us = total, splits, workspace MB]"))
-    for name, B, H, W, Ci, Co, d in PL:
-        ld = (Ci + 3) // 4 * 4
-        x = torch.randn(B, H, W, ld, device=dev); xv = ops.View(x, B, H, W, Ci, ld)
-        dz = torch.randn(B, H, W, Co, device=dev)
-        out, results = [], []
-        for label, taps, tgt in (("tiled", 0, 0), ("taps", 1, 0), ("taps/512wg", 1, 512), ("taps/128wg", 1, 128)):
-            lib.tune_wgrad_taps(taps); lib.tune_wgrad_wgs(tgt)
-            dw = torch.zeros(3, 3, Ci, Co, device=dev); db = torch.zeros(Co, device=dev)
-            wsa = ops.WgradWorkspace(dev); segs, keep = [], []
-            ops.conv2d_wgrad_partial(lib, lib, wsa, segs, xv, ops.view(dz), dw, db, dil=d)
-            kname = lib.last_kernel().decode().split(" ")[0]
-            ops.wgrad_reduce(lib, segs, dev, keep)
-            torch.cuda.synchronize()
-            results.append(dw.clone())
-            ws, dst, size, splits = segs[0]
-            desc = ops.conv_desc(B, H, W, H, W, Ci, Co, 3, 3, 1, d, d, d, 0, 0, ld, Co, precision=1)
-            sp = C.c_int32(splits)
-            with torch.cuda.stream(stream):
-                tp = _time_ms(lib, stream, lambda: lib.conv2d_wgrad_partial(C.byref(desc), C.c_void_p(x.data_ptr()), C.c_void_p(dz.data_ptr()), Co, C.c_void_p(ws),
-                                                                            C.byref(sp), C.c_void_p(db.data_ptr()), C.c_void_p(stream.cuda_stream)), 20) * 1e3
-            arr = (_ffi.WgradSeg * 1)(); arr[0].ws, arr[0].dst, arr[0].size, arr[0].splits, arr[0].blk0, arr[0].accumulate = ws, dst, size, splits, 0, 0
-            table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
-            with torch.cuda.stream(stream):
-                tr = _time_ms(lib, stream, lambda: lib.wgrad_reduce(C.c_void_p(table.data_ptr()), 1, (size + 1023) // 1024, C.c_void_p(stream.cuda_stream)), 20) * 1e3
-            out.append("%s(%s): %.1f + %.1f = %.1f, %d, %.1f" % (label, kname.replace("wgrad_", "").replace("_kernel", ""), tp, tr, tp + tr, splits, splits * size * 4 / 1e6))
-        lib.tune_wgrad_taps(-1); lib.tune_wgrad_wgs(0)
-        diff = max((r - results[0]).abs().max().item() for r in results[1:]) / max(1.0, results[0].abs().max().item())
-        print("%-16s %s  | max rel diff %.2g" % (name, "  |  ".join(out), diff))
-    ops.PRECISION = 0
-
-
-def run_wgradtd():
-    """phase breakdown of the all-taps filter-gradient kernel: partial-launch time with parts switched off (mh_tune_wgrad_taps debug bits; wrong results)"""
-    ops.PRECISION = 1
-    names = {0: "full", 1: "no fragment reads / MFMAs", 4: "no global loads", 8: "no partial stores", 12: "no loads, no stores", 5: "no loads, no MFMA walk",
-             13: "barriers + LDS stores only"}
-    for name, B, H, W, Ci, Co, d in [("L2 128->128", 1, 96, 320, 128, 128, 1), ("B2 128->128", 2, 96, 320, 128, 128, 1), ("B4 128->128", 4, 96, 320, 128, 128, 1)]:
-        x = torch.randn(B, H, W, Ci, device=dev); xv = ops.View(x, B, H, W, Ci, Ci)
-        dz = torch.randn(B, H, W, Co, device=dev)
-        out = []
-        for bits in (0, 1, 4, 8, 12, 5, 13):
-            lib.tune_wgrad_taps(1 + 16 * bits)
-            dw = torch.zeros(3, 3, Ci, Co, device=dev); db = torch.zeros(Co, device=dev)
-            wsa = ops.WgradWorkspace(dev); segs, keep = [], []
-            ops.conv2d_wgrad_partial(lib, lib, wsa, segs, xv, ops.view(dz), dw, db, dil=d)
-            ws, dst, size, splits = segs[0]
-            desc = ops.conv_desc(B, H, W, H, W, Ci, Co, 3, 3, 1, d, d, d, 0, 0, Ci, Co, precision=1)
-            sp = C.c_int32(splits)
-            with torch.cuda.stream(stream):
-                tp = _time_ms(lib, stream, lambda: lib.conv2d_wgrad_partial(C.byref(desc), C.c_void_p(x.data_ptr()), C.c_void_p(dz.data_ptr()), Co, C.c_void_p(ws),
-                                                                            C.byref(sp), C.c_void_p(db.data_ptr()), C.c_void_p(stream.cuda_stream)), 20) * 1e3
-            out.append("%s %.1f" % (names[bits], tp))
-        lib.tune_wgrad_taps(-1)
-        print("%-14s %s" % (name, "  |  ".join(out)))
-    ops.PRECISION = 0
-
-
 def run_corr():
     for (B, H, W, Cc, md) in [(64, 96, 320, 32, 2), (16, 96, 320, 32, 2), (1, 96, 320, 32, 2), (64, 48, 160, 64, 2), (16, 96, 320, 128, 40)]:
         L = torch.randn(B, H, W, Cc, device=dev); R = torch.randn(B, H, W, Cc, device=dev)
@@ -334,10 +269,6 @@ def run_bank():
 
 if what == "wgradp":
     run_wgradp()
-if what == "wgradt":
-    run_wgradt()
-if what == "wgradtd":
-    run_wgradtd()
 if what == "bank":
     run_bank()
 if what == "x3dbg":

@@ -841,94 +841,3 @@ def test_wgrad_split_targets_follow_the_tuning_hook(backend):
     xr = _bf(x.cpu()).double(); w0 = torch.zeros(3, 3, Ci, Co, dtype=torch.float64, requires_grad=True)
     (gw,) = torch.autograd.grad(T.conv2d(xr, w0, None, alpha=1.0), [w0], _bf(gz.cpu()).double())
     assert (ws.cpu().double().sum(0).view(3, 3, Ci, Co) - gw).abs().max().item() <= 2e-5 * max(1.0, gw.abs().max().item())
-
-
-WGRAD_TAPS_CASES = [   # (B, H, W, Cin, Cout, dil, in_ld, dz_ld): stride-1 3x3 layers (the kernel's pixel floor is lifted for the test)
-    (1, 70, 70, 128, 128, 1, 128, 128),        # the 1/4-resolution estimator shape class: 4 k-tiles, one 128-column tile
-    (1, 67, 75, 72, 80, 1, 72, 80),            # ragged: 3 k-tiles (last one 8 channels), 80 columns (wave column tiles 4 + 1), ragged strips (75 = 2 x 32 + 11)
-    (2, 48, 52, 40, 96, 1, 44, 96),            # batch 2, K % 32 = 8 with a padded input row (channels 40..43 hold NaN-free garbage of a neighbour)
-    (1, 66, 70, 64, 96, 2, 64, 96),            # dilation 2: four sub-lattices of 33 x 35
-    (1, 72, 80, 128, 96, 8, 128, 96),          # dilation 8: 64 sub-lattices of 9 x 10 (a 32-pixel segment holds 10 pixels)
-    (1, 65, 90, 64, 80, 16, 64, 80),           # dilation 16 (lattices of 5 x 6 and 4 x 5), 80 output channels
-    (1, 64, 68, 160, 144, 1, 160, 144),        # two 128-column tiles (128 + 16), 5 k-tiles
-]
-
-
-@pytest.mark.parametrize("case", WGRAD_TAPS_CASES)
-def test_wgrad_taps_kernel(backend, case):
-    """All-taps filter-gradient kernel (wgrad_taps_kernel: nine taps per workgroup, both operands through the LDS transposing read, permuted reduction
-    order inside a 32-pixel segment, ring of patch rows along a vertical run, dilation as sub-lattices): partial sums + reduction AND the atomic form,
-    weights and bias, against the fp64 oracle on bf16-rounded operands -- and against the tiled kernel's result for the same call."""
-    import ctypes as C
-    B, H, W, Ci, Co, dil, ild, zld = case
-    dev = backend.device
-    x = _rand((B, H, W, Ci), 911, dev)
-    gz = _rand((B, H, W, Co), 912, dev)
-    xb, xv = _padded(x, ild)
-    if ild != Ci:
-        xb[..., Ci:] = 7.5                      # what a concat neighbour would hold: must only ever reach the (discarded) rows k >= K
-    zb, zv = _padded(gz, zld)
-    res = {}
-    for taps in (1, 0):
-        backend.lib.tune_wgrad_taps(taps * (1 + 16 * 0x100))          # on for every size (default floor: 16384 reduction pixels)
-        try:
-            dw = torch.full((3, 3, Ci, Co), float("nan"), device=dev); db = torch.zeros(Co, device=dev)
-            wsa = ops.WgradWorkspace(dev); segs, keep = [], []
-            ops.PRECISION = 1
-            try:
-                ops.conv2d_wgrad_partial(backend.lib, backend.lib, wsa, segs, xv, zv, dw, db, dil=dil)
-                name = backend.lib.last_kernel().decode()
-                dwa = torch.zeros(3, 3, Ci, Co, device=dev); dba = torch.zeros(Co, device=dev)
-                ops.conv2d_wgrad(backend.lib, xv, zv, dwa, dba, dil=dil)          # no workspace: fp32 atomics into dw
-                name_a = backend.lib.last_kernel().decode()
-            finally:
-                ops.PRECISION = 0
-            ops.wgrad_reduce(backend.lib, segs, dev, keep)
-            backend.sync()
-        finally:
-            backend.lib.tune_wgrad_taps(-1)
-        assert ("wgrad_taps_kernel" in name) == bool(taps) and ("wgrad_taps_kernel" in name_a) == bool(taps), (name, name_a)
-        res[taps] = (dw.cpu().double(), db.cpu().double(), dwa.cpu().double(), dba.cpu().double())
-    xr = _bf(x.cpu()).double(); w0 = torch.zeros(3, 3, Ci, Co, dtype=torch.float64, requires_grad=True)
-    y = T.conv2d(xr, w0, None, dilation=dil, alpha=1.0)
-    (gw,) = torch.autograd.grad(y, [w0], _bf(gz.cpu()).double())
-    gb = gz.cpu().double().sum((0, 1, 2))
-    sc = max(1.0, gw.abs().max().item())
-    for taps in (1, 0):
-        dw, db, dwa, dba = res[taps]
-        assert (dw - gw).abs().max().item() <= 2e-5 * sc, (taps, "partial")
-        assert (dwa - gw).abs().max().item() <= 2e-5 * sc, (taps, "atomic")
-        assert (db - gb).abs().max().item() <= 1e-4 * max(1.0, gz.cpu().abs().sum((0, 1, 2)).max().item())
-        assert (dba - gb).abs().max().item() <= 1e-4 * max(1.0, gz.cpu().abs().sum((0, 1, 2)).max().item())
-    assert (res[1][0] - res[0][0]).abs().max().item() <= 2e-5 * sc
-
-
-def test_wgrad_taps_kernel_is_opt_in_and_keeps_small_layers(backend):
-    """Default off (slower inside the step than the tiled kernels): the dispatcher picks the tiled kernels; switched on, layers with <= 16384 reduction pixels,
-    strided layers, exact-fp32 calls, thin inputs and <= 64 output channels still go to the tiled / grouped kernels."""
-    import ctypes as C
-    dev = backend.device
-
-    def kernel_of(H, W, Ci, Co, stride=1, precision=1):
-        Ho, Wo, pt, pl = ops.conv_geometry(H, W, 3, 3, stride, 1)
-        x = torch.zeros(1, H, W, Ci, device=dev); gz = torch.zeros(1, Ho, Wo, Co, device=dev)
-        dw = torch.zeros(3, 3, Ci, Co, device=dev); db = torch.zeros(Co, device=dev)
-        ops.PRECISION = precision
-        try:
-            ops.conv2d_wgrad(backend.lib, ops.view(x), ops.view(gz), dw, db, stride=stride)
-        finally:
-            ops.PRECISION = 0
-        backend.sync()
-        return backend.lib.last_kernel().decode()
-
-    assert "wgrad_taps_kernel" not in kernel_of(130, 130, 64, 128)
-    backend.lib.tune_wgrad_taps(1)
-    try:
-        assert "wgrad_taps_kernel" in kernel_of(130, 130, 64, 128)              # 16900 pixels
-        assert "wgrad_taps_kernel" not in kernel_of(120, 120, 64, 128)          # 14400 pixels
-        assert "wgrad_taps_kernel" not in kernel_of(260, 260, 64, 128, stride=2)
-        assert "wgrad_taps_kernel" not in kernel_of(130, 130, 64, 128, precision=0)
-        assert "wgrad_taps_kernel" not in kernel_of(130, 130, 16, 128)
-        assert "wgrad_taps_kernel" not in kernel_of(130, 130, 64, 64)           # <= 64 output channels would idle half the waves
-    finally:
-        backend.lib.tune_wgrad_taps(-1)

@@ -172,9 +172,14 @@ def test_dataset_rank_sharding_and_uint8(tmp_path):
     lst.write_text("\n".join(rows) + "\n")
     full = [b for b in DR.dataset(str(lst), batch_size=1, crop_shape=(16, 24), num_epochs=1)]
     parts = [[b for b in DR.dataset(str(lst), batch_size=1, crop_shape=(16, 24), num_epochs=1, shard=(r, 2))] for r in range(2)]
-    assert len(full) == 5 and len(parts[0]) == 3 and len(parts[1]) == 2
-    assert DR.dataset(str(lst), batch_size=1, crop_shape=(16, 24), num_epochs=2, shard=(1, 2)).get_max_steps() == 4
-    for i, b in enumerate(full):
+    # an odd list over two ranks: the epoch is cut to a multiple of the world size -- EVERY rank yields the same number of batches (each
+    # training step issues collectives: a rank with one batch more would wait in an all-reduce the others never enter)
+    assert len(full) == 5 and len(parts[0]) == 2 and len(parts[1]) == 2
+    for rk in range(2):
+        assert DR.dataset(str(lst), batch_size=1, crop_shape=(16, 24), num_epochs=2, shard=(rk, 2)).get_max_steps() == 4
+        assert DR.dataset(str(lst), batch_size=2, crop_shape=(16, 24), num_epochs=3, shard=(rk, 2)).get_max_steps() == 3
+        assert len(list(DR.dataset(str(lst), batch_size=2, crop_shape=(16, 24), num_epochs=3, shard=(rk, 2)))) == 3
+    for i, b in enumerate(full[:4]):
         assert np.array_equal(b[0], parts[i % 2][i // 2][0])
     u8 = [b for b in DR.dataset(str(lst), batch_size=1, crop_shape=(16, 24), num_epochs=1, keep_uint8=True)]
     assert u8[0][0].dtype == np.uint8 and u8[0][1].dtype == np.uint8 and u8[0][2].dtype == np.float32
