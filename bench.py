@@ -136,9 +136,10 @@ class _Null(object):
         return False
 
 
-def timed_regions(dev, dist, one_step, steps, repeats):
-    """[seconds] of `repeats` consecutive K-step regions, each bracketed by barrier + synchronize, MAX over ranks."""
+def timed_regions(dev, dist, one_step, steps, repeats, inner=1):
+    """[seconds] of `repeats` consecutive regions of inner x K steps, each bracketed by barrier + synchronize, MAX over ranks."""
     torch = dev.torch
+    steps = steps * inner
 
     def barrier():
         dev.sync()
@@ -162,10 +163,21 @@ def timed_regions(dev, dist, one_step, steps, repeats):
     return out
 
 
-def timing_block(regions, steps):
-    ms = sorted(1e3 * x / steps for x in regions)
+def timing_block(regions, steps, inner=1):
+    n = steps * inner
+    ms = sorted(1e3 * x / n for x in regions)
     return {"repeats": len(ms), "ms_per_step_median": statistics.median(ms), "ms_per_step_min": ms[0], "ms_per_step_max": ms[-1],
-            "ms_per_step_all": [1e3 * x / steps for x in regions], "timed_steps_per_repeat": steps}
+            "ms_per_step_all": [1e3 * x / n for x in regions], "timed_steps_per_repeat": n, "inner_repetitions": inner,
+            "seconds_per_repeat": [x for x in regions],
+            "note": "every timed region = inner_repetitions x --steps steps, so that a region lasts >= --min-region-seconds whatever --steps says"}
+
+
+def inner_reps(dev, dist, one_step, steps, min_seconds):
+    """how many times the K-step block is repeated inside one timed region so that the region lasts >= min_seconds (same on every rank)"""
+    if min_seconds <= 0:
+        return 1
+    t = timed_regions(dev, dist, one_step, steps, 1)[0]
+    return max(1, int(-(-min_seconds // max(t, 1e-6))))
 
 
 def bench_mad(args, lib, dev, rank, world, dist):
@@ -197,11 +209,12 @@ def bench_mad(args, lib, dev, rank, world, dist):
 
     for _ in range(args.warmup):
         one_step()
-    regions = timed_regions(dev, dist, one_step, args.steps, args.repeats)
+    inner = inner_reps(dev, dist, one_step, args.steps, args.min_region_seconds)
+    regions = timed_regions(dev, dist, one_step, args.steps, args.repeats, inner)
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:
-        tb = timing_block(regions, args.steps)
+        tb = timing_block(regions, args.steps, inner)
         ms = tb["ms_per_step_median"]
         _emit({
             "metric": "adapted stereo pairs/sec (whole node), MADNet MAD modular online adaptation 1242x375",
@@ -261,12 +274,46 @@ def step_surface(args, lib, dev, wn, frames=8):
             "frames": frames, "final_loss": out["loss"], "resets": ad.reset_counter}
 
 
+def drift_report(args, lib, dev, wn, mk, frames=8):
+    """SURVEY section 7 ("multi-step drift is reported, not bounded: online SGD is chaotic"): the run's arithmetic mode and the exact-fp32 engine adapt
+    side by side on the same frame-shifted synthetic video from the same weights; disparity EPE between the two after 10 and N steps, next to how
+    far the fp32 disparity itself moved since step 0."""
+    import torch
+    from madnet_hip import synthetic as S
+    H, W = args.height, args.width
+    pairs = [S.make_pair(H, W, stream_id=200, frame=t) for t in range(frames)]
+    ea, eb = mk(args.precision), mk("fp32")
+    pa, pb = ea.build_plan("FULL", lr=1e-4), eb.build_plan("FULL", lr=1e-4)
+    out = {"frames": frames, "lr": 1e-4, "what": "mean |d_%s - d_fp32| of the step's disparity after k adaptation steps (both engines start from the same weights, "
+                                              "frame t = texture shifted by t px); reported, not gated" % args.precision}
+    first = None
+    marks = sorted(set([1, 10, args.drift_steps]))
+    for k in range(1, args.drift_steps + 1):
+        l, r, g = pairs[(k - 1) % frames]
+        for e, p in ((ea, pa), (eb, pb)):
+            e.set_inputs(l, r, g[..., 0])
+            p.run(lib, 0)
+        if k in marks:
+            torch.cuda.synchronize()
+            if first is None:
+                first = eb.pred.clone()
+            out["step_%d" % k] = {"epe_vs_fp32_engine": float((ea.pred - eb.pred).abs().mean().item()),
+                                  "fp32_mean_abs_disparity": float(eb.pred.abs().mean().item()),
+                                  "loss": float(ea.res_loss[0].item()), "loss_fp32": float(eb.res_loss[0].item())}
+    wa, wb = ea.params.w, eb.params.w
+    out["weights_rel_l2_after_%d" % args.drift_steps] = float(((wa - wb).norm() / wb.norm()).item())
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--repeats", type=int, default=5, help="how many times the K-step region is timed (value = the median region)")
+    ap.add_argument("--min-region-seconds", type=float, default=1.0,
+                    help="every timed region is lengthened to at least this many seconds by repeating the K-step block inside it (0 = exactly K steps)")
+    ap.add_argument("--drift-steps", type=int, default=100, help="N-step drift report: 'mixed' vs the fp32 engine after 10 and N adaptation steps on a frame-shifted synthetic video (0 = skip)")
     ap.add_argument("--mode", default="FULL", choices=["FULL", "NONE", "MAD"])
     ap.add_argument("--block-config", default="MadNet_piramid_only.json", help="MAD mode: file under block_config/")
     ap.add_argument("--model", default="madnet", choices=["madnet", "dispnet"])
@@ -397,8 +444,9 @@ def main():
         for _ in range(args.warmup):
             one_step()
         dev.sync_stream()
-        regions = timed_regions(dev, dist, one_step, args.steps, args.repeats)
-    tb = timing_block(regions, args.steps)
+        inner = inner_reps(dev, dist, one_step, args.steps, args.min_region_seconds)
+        regions = timed_regions(dev, dist, one_step, args.steps, args.repeats, inner)
+    tb = timing_block(regions, args.steps, inner)
     ms = tb["ms_per_step_median"]
     _log("timed regions done: median %.3f ms/step (min %.3f, max %.3f)" % (ms, tb["ms_per_step_min"], tb["ms_per_step_max"]))
 
@@ -454,8 +502,36 @@ def main():
     if extras:
         if not args.no_roofline:
             with dev.ctx():
-                out["roofline"], extra = BT.roofline(lib, eng, dev.stream)
+                out["roofline_fwd"], extra = BT.roofline(lib, eng, dev.stream)
             out.update(extra)
+            # top-level `roofline` = the kernel family the recorded plan spends most of its time in (every op of the plan timed alone on a
+            # scratch engine), priced on its most expensive launch: algorithmic flops / time / the DENSE bf16 MFMA peak
+            try:
+                e_t = mk(args.precision); feed(e_t)
+                p_t = e_t.build_plan(args.mode, lr=1e-4)
+                with dev.ctx():
+                    rows, fam = BT.plan_table(lib, p_t, dev.stream)
+                tot = sum(r[3] for r in rows)
+                name, f = next(iter(fam.items()))
+                i_top = f["top_index"]
+                fl, by = p_t.work.get(i_top, BT.op_work(p_t.arr[i_top]))
+                kn = rows[i_top][2]
+                peak = BT.PEAK_F32_MFMA_TFLOPS if (",f32," in kn.replace(" ", "") or "wgrad_kernel<" in kn) else BT.PEAK_BF16_MFMA_TFLOPS
+                ach = fl / (f["top_us"] * 1e-6) / 1e12 if f["top_us"] > 0 else 0.0
+                tr = BT._pmc_traffic(kn)
+                out["roofline"] = {"kernel": kn, "family": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                                   "mfma_issue_frac": (3.0 if "bf16x3" in kn else 1.0) * ach / peak,
+                                   "traffic": tr, "traffic_source": ("profiles/r03_pmc_roofline.json, key = this kernel string (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                                     "passes over the same plan: scripts/gpu_pmc_r03.sh)") if tr is not None else None,
+                                   "launch_ms": f["top_us"] * 1e-3, "algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": by,
+                                   "plan_op_index": i_top, "family_launches_per_step": f["launches"], "family_us_per_step": f["us_per_step"],
+                                   "family_share_of_kernel_time": f["us_per_step"] / tot if tot else None,
+                                   "selection": "dominant kernel family of the recorded plan by summed stand-alone launch time (HIP events, 10 launches per op); priced on its longest launch"}
+                out["kernel_families"] = [{"kernel": k, "launches": v["launches"], "us_per_step": v["us_per_step"]} for k, v in list(fam.items())[:12]]
+                out["kernel_time_sum_us"] = tot
+                del e_t, p_t
+            except Exception as ex:      # never let the auxiliary measurement kill the bench line
+                out["roofline"] = {"error": repr(ex)}
             _log("roofline done")
         d_or = None
         if not args.no_cpu_baseline:
@@ -494,6 +570,12 @@ def main():
                     del e3
                 del e2
             _log("paths done")
+        if args.drift_steps > 0 and args.precision != "fp32" and not args.no_paths:
+            try:
+                out["drift"] = drift_report(args, lib, dev, wn, mk)
+            except Exception as ex:
+                out["drift"] = {"error": repr(ex)}
+            _log("drift done")
         if not args.no_step_surface:
             try:
                 out["step_surface"] = step_surface(args, lib, dev, wn)

@@ -30,13 +30,16 @@ def _time_ms(lib, stream, fn, reps):
 
 
 def _pmc_traffic(key):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r02_pmc_roofline.json, produced by
-    scripts/gpu_pmc_r02.sh + scripts/pmc_summarize_r02.py); None if the file or the key is absent."""
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r03_pmc_roofline.json, produced by
+    scripts/gpu_pmc_r03.sh + scripts/pmc_summarize_r03.py); None if the file or the key is absent."""
     import json
     import os
-    f = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles", "r02_pmc_roofline.json")
+    f = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles", "r03_pmc_roofline.json")
     try:
-        return json.load(open(f))[key]["traffic_bytes"]
+        j = json.load(open(f))
+        if key not in j and key in j.get("fixed_kernels", {}):
+            key = j["fixed_kernels"][key]              # roofline_* name -> the kernel string it ran
+        return j[key]["traffic_bytes"]
     except Exception:
         return None
 
@@ -62,15 +65,15 @@ def roofline(lib, eng, stream, reps=20):
         # ALGORITHMIC flops against the peak of the instruction that runs (dense bf16 2.5 PF for codes 1 and 2)
         peak = PEAK_F32_MFMA_TFLOPS if (code == 0 or "f32" in kname.split("tile")[0]) else PEAK_BF16_MFMA_TFLOPS
         ach = flops / (ms * 1e-3) / 1e12
-        tr = _pmc_traffic(pmc_key)
+        tr = _pmc_traffic(kname)
         x3 = code == 2 and peak == PEAK_BF16_MFMA_TFLOPS
-        if x3:
-            # split-bf16 issues 3 bf16 MFMAs per algorithmic product: the ceiling of ALGORITHMIC flops is a third of the dense bf16 peak
-            peak = PEAK_BF16_MFMA_TFLOPS / 3.0
+        # frac = ALGORITHMIC flops / time / the dense peak of the instruction family (2.5 PF for bf16 MFMA, whatever the number of
+        # MFMAs a product costs); the share of the MFMA ISSUE rate the kernel sustains (3 instructions per product in split-bf16) is reported beside it
         return {"kernel": kname, "op": what, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                "peak_note": ("dense bf16 MFMA peak / 3 (three MFMAs per product); against the plain 2500 TFLOP/s the algorithmic rate is %.3f" % (ach / PEAK_BF16_MFMA_TFLOPS)) if x3 else None,
-                "arithmetic": {0: "f32 MFMA", 1: "bf16 MFMA, f32 accumulate", 2: "split-bf16: 3 bf16 MFMAs per product (mfma issue rate = 3x achieved), f32 accumulate"}[code],
-                "traffic": tr, "traffic_source": ("profiles/r02_pmc_roofline.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_pmc_r02.sh, key %s; not re-measured in this run)" % pmc_key) if tr is not None else None,
+                "mfma_issue_frac": (3.0 if x3 else 1.0) * ach / peak,
+                "arithmetic": {0: "f32 MFMA", 1: "bf16 MFMA, f32 accumulate", 2: "split-bf16: 3 bf16 MFMAs per product (mfma_issue_frac = 3 x frac), f32 accumulate"}[code],
+                "traffic": tr, "traffic_source": ("profiles/r03_pmc_roofline.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_pmc_r03.sh on the same kernels and shapes, "
+                                                  "key %s; collected in the run that produced this round's committed bench line, not inside this process)" % pmc_key) if tr is not None else None,
                 "launch_ms": ms, "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": algo_bytes}
 
     def conv_fwd(code):
@@ -100,24 +103,63 @@ def roofline(lib, eng, stream, reps=20):
         extra["roofline_dgrad"] = entry(bwd_code, dgrad, "input gradient of the same layer", "conv_dgrad_bf16_patch_3x3_128_128_96x320" if bwd_code == 1 else "none")
         dw = torch.empty_like(w); db = torch.zeros(128, device=eng.dev)
         wsa = ops.WgradWorkspace(eng.dev)
-        segs, keep = [], []
-        ops.PRECISION = bwd_code
-        try:
-            ops.conv2d_wgrad_partial(lib, lib, wsa, segs, x, dz, dw, db, dil=2, stream=sh)     # sizes the workspace once
-        finally:
-            ops.PRECISION = 0
-
-        def wgrad():
+        keep = []
+        if bwd_code == 1 and getattr(eng, "use_stream", False):
+            # what the step runs: bf16 shadows (written by the producers' epilogues there; cast here, outside the timed launches) -> mh_wgrad_stream
+            def stream_entry(layers, what, pmc_key, nwaves):
+                items, pairs, fl = [], [], 0.0
+                for (xv, zv, dwt, dbt, dil) in layers:
+                    xs, zs = ops.Shadow(xv.B, xv.H, xv.W, xv.C, eng.dev), ops.Shadow(zv.B, zv.H, zv.W, zv.C, eng.dev)
+                    pairs += [(xv, xs), (zv, zs)]
+                    items.append((xs, zs, dwt, dbt, dil))
+                    fl += 2.0 * xv.B * xv.H * xv.W * 9 * xv.C * zv.C
+                ops.shadow_cast(lib, pairs, eng.dev, keep, stream=sh)
+                from .plan import Recorder
+                rec = Recorder(); segs = []
+                ops.wgrad_stream(rec, lib, wsa, segs, items, eng.dev, keep, nwaves=nwaves)
+                pl = rec.compile()
+                ms = _time_ms(lib, stream, lambda: pl.run(lib, sh), reps)
+                pl.run(lib, sh); kname = lib.last_kernel().decode()
+                ach = fl / (ms * 1e-3) / 1e12
+                tr = _pmc_traffic(kname)
+                byts = sum(2.0 * xv.B * xv.H * xv.W * (ops.shadow_ld(xv.C) + ops.shadow_ld(zv.C)) + 4.0 * 9 * xv.C * zv.C for xv, zv, _, _, _ in layers)
+                return {"kernel": kname, "op": what, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / PEAK_BF16_MFMA_TFLOPS, "mfma_issue_frac": ach / PEAK_BF16_MFMA_TFLOPS, "arithmetic": "bf16 MFMA (32x32x16), f32 accumulate; operands = bf16 shadows",
+                        "traffic": tr, "traffic_source": ("profiles/r03_pmc_roofline.json key %s (rocprofv3 --pmc passes of scripts/gpu_pmc_r03.sh)" % pmc_key) if tr is not None else None,
+                        "launch_ms": ms, "algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": byts,
+                        "splits": [sg[3] for sg in segs], "workspace_bytes_per_launch": 4.0 * sum(sg[2] * sg[3] for sg in segs)}
+            nw = 4 if x.B == 1 else 8
+            extra["roofline_wgrad"] = stream_entry([(x, dz, dw, db, 2)], "filter gradient of the same layer, alone in its launch (streaming kernel; partial sums only)",
+                                                   "wgrad_stream_3x3_128_128_96x320", nw)
+            k = 2
+            h, wd = eng.fshape[E.FEAT[k]][0], eng.fshape[E.FEAT[k]][1]
+            cin = eng.fshape[E.FEAT[k]][2] + eng.D + 1
+            lay = []
+            for j in range(1, 7):
+                xin = ops.View(eng.dsi[k], x.B, h, wd, cin, eng.dsi_ld[k]) if j == 1 else ops.view(eng.E[k][j - 2])
+                dzz = ops.view(eng.dV[k]) if j == 6 else ops.view(eng.dE[k][j - 1])
+                lay.append((xin, dzz, torch.empty_like(eng.W_(E.est_name(k, j))), torch.zeros(dzz.C, device=eng.dev), 1))
+            extra["roofline_wgrad_batch"] = stream_entry(lay, "filter gradients of the six estimator-2 layers in ONE launch (what the step runs per backward batch)",
+                                                         "wgrad_stream_est2_batch_96x320", nw)
+        else:
+            segs = []
             ops.PRECISION = bwd_code
             try:
-                wsa.reset(); s2 = []
-                ops.conv2d_wgrad_partial(lib, lib, wsa, s2, x, dz, dw, db, dil=2, stream=sh)
+                ops.conv2d_wgrad_partial(lib, lib, wsa, segs, x, dz, dw, db, dil=2, stream=sh)     # sizes the workspace once
             finally:
                 ops.PRECISION = 0
-        extra["roofline_wgrad"] = entry(bwd_code, wgrad, "filter gradient of the same layer (partial sums only; the split reduction is one launch per batch of layers)",
-                                        "wgrad_bf16_partial_3x3_128_128_96x320" if bwd_code == 1 else "none")
-        extra["roofline_wgrad"]["splits"] = segs[0][3] if segs else 1
-        extra["roofline_wgrad"]["workspace_bytes_per_launch"] = 4.0 * (segs[0][2] * segs[0][3] if segs else 0)
+
+            def wgrad():
+                ops.PRECISION = bwd_code
+                try:
+                    wsa.reset(); s2 = []
+                    ops.conv2d_wgrad_partial(lib, lib, wsa, s2, x, dz, dw, db, dil=2, stream=sh)
+                finally:
+                    ops.PRECISION = 0
+            extra["roofline_wgrad"] = entry(bwd_code, wgrad, "filter gradient of the same layer (partial sums only; the split reduction is one launch per batch of layers)",
+                                            "wgrad_bf16_partial_3x3_128_128_96x320" if bwd_code == 1 else "none")
+            extra["roofline_wgrad"]["splits"] = segs[0][3] if segs else 1
+            extra["roofline_wgrad"]["workspace_bytes_per_launch"] = 4.0 * (segs[0][2] * segs[0][3] if segs else 0)
     except Exception as ex:
         extra["roofline_wgrad"] = {"error": repr(ex)}
     # correlation protocol: level-2 shape with B=64 streams (working set > 256 MiB
@@ -133,7 +175,7 @@ def roofline(lib, eng, stream, reps=20):
         g = byts / (ms_c * 1e-3) / 1e9
         extra["roofline_corr"] = {"kernel": lib.last_kernel().decode() + " (B=64 x %dx%dx%d, D=%d)" % (H, W, Cc, D), "bound": "hbm",
                                   "achieved": g, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": g / PEAK_HBM_GBS,
-                                  "traffic": _pmc_traffic("corr_fwd_B64_96x320x32_D5"), "traffic_source": "profiles/r02_pmc_roofline.json (static: rocprofv3 --pmc passes of scripts/gpu_pmc_r02.sh; not re-measured in this run)", "launch_ms": ms_c, "algorithmic_bytes_per_launch": byts}
+                                  "traffic": _pmc_traffic("corr_fwd_B64_96x320x32_D5"), "traffic_source": "profiles/r03_pmc_roofline.json (rocprofv3 --pmc passes of scripts/gpu_pmc_r03.sh; collected beside this round's committed bench line, not inside this process)", "launch_ms": ms_c, "algorithmic_bytes_per_launch": byts}
         L1, R1 = L[:1].contiguous(), R[:1].contiguous(); o1 = out[:1].contiguous()
         ms_1 = _time_ms(lib, stream, lambda: ops.corr_fwd(lib, ops.view(L1), ops.view(R1), ops.view(o1), md, stream=sh), 20)
         extra["roofline_corr"]["in_situ_B1_ms"] = ms_1
@@ -141,3 +183,40 @@ def roofline(lib, eng, stream, reps=20):
     except Exception as ex:       # never let the auxiliary measurement kill the bench line
         extra["roofline_corr"] = {"error": str(ex)}
     return rl, extra
+
+
+def plan_table(lib, plan, stream, reps=10):
+    """Every op of a recorded plan timed ALONE (HIP events on the launch stream, `reps` launches each) with the kernel the dispatcher chose
+    (mh_last_kernel): which kernel family the step spends its time in, from the plan's own launch table.  The ops mutate the engine they were
+    recorded on (optimizer, accumulating gradients): run it on a scratch engine.  Returns (rows, families): rows = [(index, kind, kernel, us)],
+    families = {kernel template: {"launches", "us_per_step", "top_us", "top_index"}} sorted by time."""
+    import re
+    from . import _ffi
+    rows = []
+    sh = stream.cuda_stream
+    for i in range(plan.n):
+        one = (_ffi.Op * 1)(plan.arr[i])
+        one[0].i[26] = 0                                    # on the caller's stream, no join
+        us = 1e3 * _time_ms(lib, stream, lambda: lib.plan_run(one, 1, C.c_void_p(sh)), reps)
+        k = lib.last_kernel().decode() if plan.arr[i].kind in (_ffi.OP_CONV, _ffi.OP_WGRAD, _ffi.OP_WGRAD_PARTIAL, _ffi.OP_WGRAD_STREAM, _ffi.OP_CORR_FWD,
+                                                              _ffi.OP_CORR_BWD, _ffi.OP_LEVEL_FRONT, _ffi.OP_CORR_WARP_BWD) else ("op kind %d" % plan.arr[i].kind)
+        rows.append((i, int(plan.arr[i].kind), k, us))
+    fam = {}
+    for i, kind, k, us in rows:
+        key = re.split(r" tile | layers | grid | K=| \(", k)[0]
+        f = fam.setdefault(key, {"launches": 0, "us_per_step": 0.0, "top_us": 0.0, "top_index": -1})
+        f["launches"] += 1; f["us_per_step"] += us
+        if us > f["top_us"]:
+            f["top_us"], f["top_index"] = us, i
+    return rows, dict(sorted(fam.items(), key=lambda kv: -kv[1]["us_per_step"]))
+
+
+def op_work(op):
+    """(algorithmic flops, algorithmic bytes) of a conv / filter-gradient op record (SURVEY 8(d) definitions), else (0, 0)"""
+    from . import _ffi
+    if op.kind not in (_ffi.OP_CONV, _ffi.OP_WGRAD, _ffi.OP_WGRAD_PARTIAL):
+        return 0.0, 0.0
+    i = op.i
+    B, Hi, Wi, Ho, Wo, K, N, kh, kw, mode = i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7], i[8], i[13]
+    pix = Ho * Wo if (mode == 0 or op.kind != _ffi.OP_CONV) else Hi * Wi
+    return 2.0 * B * pix * kh * kw * K * N, 4.0 * (B * Hi * Wi * K + B * Ho * Wo * N + kh * kw * K * N)

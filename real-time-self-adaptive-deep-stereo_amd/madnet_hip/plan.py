@@ -32,6 +32,8 @@ class Recorder(object):
         self.join_lanes_next = 0  # next op: lane 0 first waits for exactly the side lanes of this bit mask (bit l = lane l)
         self.nodefer = False      # side-lane ops recorded now are launched at once (MH_OP_NODEFER)
         self.wgrad_group_max_m = 0  # grouped filter-gradient launches: pixel cap of this plan's layers (0 = library default)
+        self.work = {}              # op index -> (algorithmic flops, bytes) of the multi-layer ops (a streamed filter-gradient batch)
+        self._pending_work = [0.0, 0.0]
 
     # -- helpers ---------------------------------------------------------------------------
     def _op(self, kind, ints=(), floats=(), ptrs=(), n=0):
@@ -112,12 +114,16 @@ class Recorder(object):
         self._op(_ffi.OP_SHADOW_CAST, [nseg, nblocks], [], [segs])
 
     def wgrad_stream(self, layers, nlayers, nblocks, nwaves, max_dil, stream):
+        self.work[len(self.ops)] = tuple(self._pending_work)
+        self._pending_work = [0.0, 0.0]
         self._op(_ffi.OP_WGRAD_STREAM, [nlayers, nblocks, nwaves, max_dil], [], [layers])
 
     def tally_wgrad(self, B, H, W, K, N, taps, splits):
         """work of one layer of a streamed filter-gradient batch (the batch is ONE op)"""
         self.stats["wgrad_flops"] += 2.0 * B * H * W * taps * K * N
         self.stats["wgrad_bytes"] += 4.0 * (B * H * W * (K + N) + taps * K * N)
+        self._pending_work[0] += 2.0 * B * H * W * taps * K * N
+        self._pending_work[1] += 2.0 * B * H * W * ((K + 31) // 32 * 32 + (N + 31) // 32 * 32) + 4.0 * taps * K * N      # bf16 shadows in, fp32 gradient out
         self.stats["wgrad_launches"] += 1
         self.stats["grad_bytes"] += 4.0 * taps * K * N
         if splits > 1:
@@ -202,7 +208,9 @@ class Recorder(object):
     # -- finalise ---------------------------------------------------------------------------
     def compile(self):
         arr = (_ffi.Op * len(self.ops))(*self.ops)
-        return Plan(arr, len(self.ops), self.keep, dict(self.stats))
+        p = Plan(arr, len(self.ops), self.keep, dict(self.stats))
+        p.work = dict(self.work)
+        return p
 
 
 class Plan(object):
@@ -211,6 +219,7 @@ class Plan(object):
     def __init__(self, arr, n, keep, stats=None):
         self.arr, self.n, self.keep, self.stats = arr, n, keep, stats or {}
         self.graph = None
+        self.work = {}
 
     def run(self, lib, stream):
         lib.plan_run(self.arr, self.n, C.c_void_p(stream))
