@@ -514,19 +514,28 @@ def main():
                 tot = sum(r[3] for r in rows)
                 name, f = next(iter(fam.items()))
                 i_top = f["top_index"]
-                fl, by = p_t.work.get(i_top, BT.op_work(p_t.arr[i_top]))
                 kn = rows[i_top][2]
+                fam_rows = [rw for rw in rows if rw[2].startswith(name)]
+                fl = sum(p_t.work.get(rw[0], BT.op_work(p_t.arr[rw[0]]))[0] for rw in fam_rows)
+                by = sum(p_t.work.get(rw[0], BT.op_work(p_t.arr[rw[0]]))[1] for rw in fam_rows)
+                fl_top = p_t.work.get(i_top, BT.op_work(p_t.arr[i_top]))[0]
                 peak = BT.PEAK_F32_MFMA_TFLOPS if (",f32," in kn.replace(" ", "") or "wgrad_kernel<" in kn) else BT.PEAK_BF16_MFMA_TFLOPS
-                ach = fl / (f["top_us"] * 1e-6) / 1e12 if f["top_us"] > 0 else 0.0
-                tr = BT._pmc_traffic(kn)
-                out["roofline"] = {"kernel": kn, "family": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                ach = fl / (f["us_per_step"] * 1e-6) / 1e12 if f["us_per_step"] > 0 else 0.0
+                trs = [BT._pmc_traffic(rw[2]) for rw in fam_rows]
+                tr = sum(trs) if all(t is not None for t in trs) else None
+                out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                    "mfma_issue_frac": (3.0 if "bf16x3" in kn else 1.0) * ach / peak,
-                                   "traffic": tr, "traffic_source": ("profiles/r03_pmc_roofline.json, key = this kernel string (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                                                     "passes over the same plan: scripts/gpu_pmc_r03.sh)") if tr is not None else None,
-                                   "launch_ms": f["top_us"] * 1e-3, "algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": by,
-                                   "plan_op_index": i_top, "family_launches_per_step": f["launches"], "family_us_per_step": f["us_per_step"],
-                                   "family_share_of_kernel_time": f["us_per_step"] / tot if tot else None,
-                                   "selection": "dominant kernel family of the recorded plan by summed stand-alone launch time (HIP events, 10 launches per op); priced on its longest launch"}
+                                   "traffic": tr, "traffic_source": ("profiles/r03_pmc_roofline.json: sum over this family's launches, keyed by their kernel strings (rocprofv3 --pmc "
+                                                                     "FETCH_SIZE / WRITE_SIZE passes over the same plan: scripts/gpu_pmc_r03.sh)") if tr is not None else None,
+                                   "launch_ms": f["us_per_step"] * 1e-3 / f["launches"], "launches_per_step": f["launches"], "us_per_step": f["us_per_step"],
+                                   "algorithmic_flops_per_step": fl, "algorithmic_bytes_per_step": by,
+                                   "share_of_kernel_time": f["us_per_step"] / tot if tot else None,
+                                   "longest_launch": {"kernel": kn, "plan_op_index": i_top, "launch_ms": f["top_us"] * 1e-3,
+                                                      "achieved": fl_top / (f["top_us"] * 1e-6) / 1e12 if f["top_us"] > 0 else None,
+                                                      "frac": fl_top / (f["top_us"] * 1e-6) / 1e12 / peak if f["top_us"] > 0 else None,
+                                                      "traffic": BT._pmc_traffic(kn)},
+                                   "selection": "the kernel family the recorded plan spends most time in, from the plan's own launch table (every op timed alone with HIP events, "
+                                                "10 launches each); achieved = the family's algorithmic flops per step / its summed launch time; frac against the DENSE bf16 MFMA peak"}
                 out["kernel_families"] = [{"kernel": k, "launches": v["launches"], "us_per_step": v["us_per_step"]} for k, v in list(fam.items())[:12]]
                 out["kernel_time_sum_us"] = tot
                 del e_t, p_t

@@ -360,7 +360,7 @@ int mh_tune_conv_patch(int mode);        /* patch-staged bf16 kernel of the stri
 int mh_tune_conv_x3_igemm(int on);       /* split-bf16 (precision 2) on the tiled implicit-GEMM kernel for forward layers without a patch / bank instance: 0 = exact fp32 there (default: measured faster), 1 = on, < 0 = default / MH_CONV_X3_IGEMM */
 int mh_tune_conv_bank(int small_maxpix); /* fragment-bank kernels (mh_conv2d_wb): the small-layer kernel takes layers of up to this many output pixels (0 = never, < 0 = default 4096 / MH_CONV_BANK_SMALL_MAXPIX); returns the number of bank-kernel launches since the previous call */
 int mh_tune_wgrad_wgs(int target_workgroups);
-int mh_tune_wgrad_target_pct(int pct);   /* scale (percent) of the filter-gradient pixel-split workgroup targets for the split counts resolved from now on (a plan stores the counts it was recorded with); 0 = default.  DispNet's engine records with 150 */
+int mh_tune_wgrad_target_pct(int pct);   /* scale (percent) of the filter-gradient pixel-split workgroup targets for the split counts resolved from now on (a plan stores the counts it was recorded with); 0 = default.  Returns the PREVIOUS value (NOT a status code) so that a caller can scope the setting: DispNet's engine records with 150 under a process-wide lock and restores what it found */
 int mh_tune_wgrad_stream(int dist);     /* prefetch distance (row groups in flight) of the streaming filter-gradient kernel: 1 or 2, 0 = default / MH_WGRAD_STREAM_DIST */
 int mh_tune_corr(int direct);
 

@@ -24,7 +24,8 @@ def build_parser():
     parser = argparse.ArgumentParser(description='Real-time self-adaptive stereo, live loop on the MI355X engine')
     parser.add_argument("--modelName", help="which registered stereo network to run", default="MADNet", choices=Nets.STEREO_FACTORY.keys())
     parser.add_argument("--weights", help="initial weights (TF checkpoint prefix, .npz, xavier[:seed], calibrated[:seed]); none = random initialisation", default=None)
-    parser.add_argument("--mode", help="NONE = inference only, FULL = full back-propagation, MAD = one sampled portion per frame", default='MAD', choices=['NONE', 'FULL', 'MAD'])
+    parser.add_argument("--mode", help="NONE = inference only, FULL = full back-propagation, MAD = one sampled portion per frame", default='NONE', choices=['NONE', 'FULL', 'MAD'])   # (the reference's default, Demo/Live_Adaptation_Demo.py:19)
+    parser.add_argument("--strictWeights", help="fail if the weight file lacks a model variable (default: like the reference, restore what matches)", action='store_true')
     parser.add_argument("--lr", help="Adam learning rate", default=0.0001, type=float)
     parser.add_argument("--blockConfig", help="json file listing the layers of every trainable portion", default=os.path.join(currentdir, '..', 'block_config', 'MadNet_full.json'))
     parser.add_argument("--imageShape", help="height width the camera frames are rescaled to, -1 to disable", nargs='+', type=int, default=[480, 640])
@@ -58,7 +59,7 @@ def main(args):
     dd = demo_model.RealTimeStereo(camera_frames, model_name=args.modelName, weight_path=args.weights, learning_rate=args.lr,
                                    block_config_path=args.blockConfig, image_shape=args.imageShape, crop_shape=args.cropShape,
                                    SSIMTh=args.SSIMTh, mode=args.mode, device=args.device, on_frame=on_frame, max_frames=args.frames,
-                                   reward_as_online=args.rewardAsOnline)
+                                   reward_as_online=args.rewardAsOnline, allow_missing=not args.strictWeights)
     gg = grabber.get_camera(args.cameraName, camera_frames, config=args.cameraConfig, framerate=args.framerate)
     print('Threads ready to start')
     gg.start()

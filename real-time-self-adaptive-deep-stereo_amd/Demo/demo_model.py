@@ -60,7 +60,9 @@ class RealTimeStereo(threading.Thread):
     def __init__(self, camera_buffer, model_name='MADNet', weight_path=None, learning_rate=0.0001,
                  block_config_path='../block_config/MadNet_full.json', image_shape=[480, 640], crop_shape=[None, None],
                  SSIMTh=0.5, mode='MAD', device='cuda', on_frame=None, display=False, max_frames=None, reward_as_online=False,
-                 precision=None, _lib=None):
+                 precision=None, _lib=None, allow_missing=True):
+        """allow_missing (default True, like the reference demo whose Saver restores the matching names and leaves the rest at their
+        initializer, weights_utils.get_var_to_restore_list): a checkpoint that lacks some model variables still loads."""
         if mode not in ('NONE', 'FULL', 'MAD'):
             raise ValueError('mode must be NONE, FULL or MAD')
         self._camera_buffer = camera_buffer
@@ -79,6 +81,7 @@ class RealTimeStereo(threading.Thread):
         self._reward_as_online = reward_as_online
         self._precision = precision
         self._lib = _lib
+        self._allow_missing = bool(allow_missing)
         self._stop_flag = False
         self._adapter = None
         self.history = []                              # (loss, trained blocks, reset?) per processed frame
@@ -99,7 +102,7 @@ class RealTimeStereo(threading.Thread):
         # Stereo_Online_Adaptation.load_weights understands TF checkpoints, .npz and the synthetic initialisers; no file = the
         # reference's global_variables_initializer (Demo/demo_model.py:192-206), here a seeded Xavier draw
         import Stereo_Online_Adaptation as SOA
-        return SOA.load_weights(self._weight_path if self._weight_path is not None else 'xavier:0', self._model_name)
+        return SOA.load_weights(self._weight_path if self._weight_path is not None else 'xavier:0', self._model_name, allow_missing=self._allow_missing)
 
     def _setup_graph(self, net_shape):
         H, W = net_shape

@@ -4,6 +4,8 @@
 #include "mh_common.h"
 #include <stdarg.h>
 #include <string.h>
+#include <mutex>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -208,20 +210,47 @@ struct Lanes {
     bool ready = false;
 };
 // per host thread AND per device: two threads that replay plans on one GPU (the demo's grabber / worker pattern) never share a
-// side stream or the event ring, so mh_plan_run is re-entrant without a lock ("stateless, re-entrant")
-thread_local Lanes t_lanes[16];
+// side stream or the event ring, so mh_plan_run is re-entrant without a lock ("stateless, re-entrant").  The streams and
+// events of a thread go back to a per-device pool when the thread exits and the next new thread takes them over: a process that starts
+// many short-lived worker threads (one RealTimeStereo thread per demo run, bench workers, prefetch threads) holds as many lane sets as it
+// ever had threads ALIVE at once, not one per thread it ever started.  (Nothing is destroyed at thread exit: the HIP runtime may already be
+// shutting down then.)
+struct LanePool {
+    std::mutex m;
+    std::vector<Lanes*> free_[16];
+};
+LanePool& lane_pool() { static LanePool* p = new LanePool; return *p; }      // (never freed: thread-exit destructors may run after static destructors)
+struct ThreadLanes {
+    Lanes* l[16] = {};
+    ~ThreadLanes() {
+        LanePool& P = lane_pool();
+        std::lock_guard<std::mutex> g(P.m);
+        for (int d = 0; d < 16; ++d)
+            if (l[d]) { P.free_[d].push_back(l[d]); l[d] = nullptr; }
+    }
+};
+thread_local ThreadLanes t_lanes;
 
 int lanes_get(Lanes** out) {
     int dev = 0;
     MH_HIP(hipGetDevice(&dev));
     MH_REQUIRE(dev >= 0 && dev < 16, MH_ERR_UNSUPPORTED, "device index %d out of range", dev);
-    Lanes& L = t_lanes[dev];
-    if (!L.ready) {
-        for (int k = 1; k < MH_MAX_LANES; ++k) MH_HIP(hipStreamCreateWithFlags(&L.aux[k], hipStreamNonBlocking));
-        for (auto& e : L.ev) MH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        L.ready = true;
+    if (!t_lanes.l[dev]) {
+        LanePool& P = lane_pool();
+        Lanes* L = nullptr;
+        {
+            std::lock_guard<std::mutex> g(P.m);
+            if (!P.free_[dev].empty()) { L = P.free_[dev].back(); P.free_[dev].pop_back(); }
+        }
+        if (!L) {
+            L = new Lanes;
+            for (int k = 1; k < MH_MAX_LANES; ++k) MH_HIP(hipStreamCreateWithFlags(&L->aux[k], hipStreamNonBlocking));
+            for (auto& e : L->ev) MH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            L->ready = true;
+        }
+        t_lanes.l[dev] = L;
     }
-    *out = &L;
+    *out = t_lanes.l[dev];
     return 0;
 }
 }  // namespace

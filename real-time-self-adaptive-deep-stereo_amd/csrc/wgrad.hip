@@ -33,7 +33,7 @@ struct WgradArgs {
 static int g_wgrad_target_wgs = 0;
 // tuning hook (microbenchmarks): number of workgroups the pixel split aims for (0 = heuristic)
 static std::atomic<int> g_wgrad_target_pct{0};     // mh_tune_wgrad_target_pct: scale of the pixel-split workgroup targets while a plan is recorded (0 = default)
-extern "C" int mh_tune_wgrad_target_pct(int pct) { g_wgrad_target_pct = pct > 0 ? pct : 0; return 0; }
+extern "C" int mh_tune_wgrad_target_pct(int pct) { return g_wgrad_target_pct.exchange(pct > 0 ? pct : 0); }      // returns the PREVIOUS value (not a status): callers that scope the setting restore it
 static int g_wgrad_plain = 0;
 static int g_wgrad_tile64 = 0;
 static int g_wgrad_w8 = 0;

@@ -83,6 +83,10 @@ class Node(object):
         return self.members if self.members else [self]
 
 
+import threading
+_TUNE_LOCK = threading.Lock()      # serialises plan recording that scopes a process-wide tuning hook
+
+
 class DispNetEngine(object):
     def __init__(self, lib, H, W, B=1, device="cuda", weights=None, precision="fp32"):
         if precision not in ops.PRECISION_CODES:
@@ -397,11 +401,13 @@ class DispNetEngine(object):
         self.wsa.reset()
         # DispNet's filter gradients (few pixels, 256-1024 channels) keep the round-1 pixel-split targets: 3.99 vs 4.08 ms (the split counts are resolved
         # while the plan is recorded and stored in it)
-        self.lib.tune_wgrad_target_pct(int(os.environ.get("MH_DISPNET_WGRAD_TARGET_PCT", "150")))
-        try:
-            return self._build_plan_scoped(r, mode, lr, grad_scale, update, part, loss_weights, max_disp, optimizer)
-        finally:
-            self.lib.tune_wgrad_target_pct(0)
+        # (a process-wide hook: recorded under a lock, and what another caller had set is restored -- ADVICE r02)
+        with _TUNE_LOCK:
+            prev = self.lib.tune_wgrad_target_pct(int(os.environ.get("MH_DISPNET_WGRAD_TARGET_PCT", "150")))
+            try:
+                return self._build_plan_scoped(r, mode, lr, grad_scale, update, part, loss_weights, max_disp, optimizer)
+            finally:
+                self.lib.tune_wgrad_target_pct(prev)
 
     def _build_plan_scoped(self, r, mode, lr, grad_scale, update, part, loss_weights, max_disp, optimizer="momentum"):
         with ops.precision_scope(self.precision):

@@ -46,6 +46,31 @@ def test_cli_end_to_end(hip, tmp_path, mode):
     assert d.dtype == np.uint16 and d.shape == (96, 160) and d.max() > 0
     if mode == "MAD":
         assert "fetch_counter,1,1,1,0,0" in stats          # SEQUENTIAL sampler over 3 frames
+    else:
+        # a20 (Stereo_Online_Adaptation.py:246-251, an INT path): the dumped 16-bit PNG is exactly (clip(d, 0, 256) * 256).astype(uint16) of the
+        # step's disparity.  NONE mode never moves the weights, so the disparity of every frame can be recomputed: (1) by the engine itself on
+        # the same frame -> the file must match BIT FOR BIT; (2) by the fp32 CPU oracle -> the engine's disparity is within ~1e-5 px of it
+        # (2.6e-3 of a PNG step), so the two encodings may differ by one step where d * 256 sits on an integer, nowhere by more
+        import torch
+        from madnet_hip import engine as E, synthetic as S
+        from oracle import madnet as OM
+        wn = SOA.load_weights("calibrated:1", "MADNet")
+        wt = {k: torch.from_numpy(np.asarray(v).copy()) for k, v in wn.items()}
+        for t in range(3):
+            l, r, gt = S.make_pair(96, 160, frame=t)
+            png = np.asarray(Image.open(out / "disparities" / ("disparity_%d.png" % t)))
+            eng = E.MadNetEngine(hip.lib, 96, 160, B=1, device=hip.device, weights=wn)
+            eng.set_inputs(l, r, gt[..., 0])
+            eng.build_plan("NONE").run(hip.lib, 0)
+            hip.sync()
+            d_eng = eng.pred[0].cpu().numpy()
+            assert np.array_equal(png, (np.clip(d_eng, 0, 256) * 256.0).astype(np.uint16)), "frame %d: PNG != encoding of the engine's disparity" % t
+            with torch.no_grad():
+                d_or = OM.forward(wt, torch.from_numpy(l), torch.from_numpy(r))[-1][0, ..., 0].numpy()
+            exp = (np.clip(d_or, 0, 256) * 256.0).astype(np.uint16)
+            diff = np.abs(png.astype(np.int32) - exp.astype(np.int32))
+            assert diff.max() <= 1 and (diff == 0).mean() >= 0.98, (t, int(diff.max()), float((diff == 0).mean()))
+            assert exp.max() > 256                          # a non-trivial map (> 1 px somewhere)
 
 
 def test_continual_cli_end_to_end(hip, tmp_path):

@@ -144,6 +144,35 @@ def test_dispnet_step_gpu(hip, size, mode):
 
 
 @pytest.mark.gpu
+def test_dispnet_mixed_mode_full_step_headline_config(hip):
+    """BASELINE config 4 in the arithmetic its bench line runs ('mixed'), 1242x375, one FULL step against the fp32 oracle: disparity inside the
+    tolerance, gradients / post-step weights within 4 x the deviation measured on the MI355X (scripts/measure_mixed_parity.py, round 3: relative L2
+    of the whole gradient 2.2e-3, largest weight deviation 2.1e-3 of the step)."""
+    H, W = 375, 1242
+    wn = S.calibrated_weights(OD.variable_shapes(), 1)
+    l, r, gt = S.make_pair(H, W)
+    eng = DE.DispNetEngine(hip.lib, H, W, B=1, device=hip.device, weights=wn, precision="mixed")
+    eng.set_inputs(l, r, gt[..., 0])
+    lr = 1e-4
+    eng.build_plan("FULL", lr=lr).run(hip.lib, 0)
+    hip.sync()
+    wt = {k: torch.from_numpy(v.copy()) for k, v in wn.items()}
+    acc = {k: torch.zeros_like(v) for k, v in wt.items()}
+    o = OD.step(wt, acc, torch.from_numpy(l), torch.from_numpy(r), torch.from_numpy(gt), mode="FULL", lr=lr)
+    epe = (eng.pred.cpu() - o["disparity"][..., 0]).abs().mean().item()
+    gh = torch.cat([eng.params.tensor(n, "g").cpu().flatten() for n in o["grads"]])
+    go = torch.cat([g.flatten() for g in o["grads"].values()])
+    grel = (gh - go).norm().item() / go.norm().item()
+    cos = torch.nn.functional.cosine_similarity(gh, go, dim=0).item()
+    dw = max((eng.params.tensor(n).cpu() - wt[n]).abs().max().item() for n in o["grads"])
+    step = max((torch.from_numpy(wn[n]) - wt[n]).abs().max().item() for n in o["grads"])
+    print("DispNet mixed FULL (MI355X 375x1242): epe %.3g grel %.3g cos %.6f dw/step %.3g" % (epe, grel, cos, dw / step))
+    assert epe <= 1e-3
+    assert abs(eng.res_loss[0].item() - o["loss"]) <= 1e-4 * max(1.0, abs(o["loss"]))
+    assert cos >= 0.999 and grel <= 1e-2 and dw <= 1e-2 * step, (cos, grel, dw / step)
+
+
+@pytest.mark.gpu
 def test_dispnet_factory_and_disparities(hip):
     import Nets
     from madnet_hip.adapter import Adapter

@@ -279,9 +279,9 @@ def test_bf16_mode_end_to_end(hip):
     assert not torch.equal(w16, w32)              # and it really is a different arithmetic
 
 
-def _mixed_vs_oracle(lib, device, H, W, force_patch):
-    """One FULL step in the 'mixed' mode (forward: split-bf16 on the layers with an x3 kernel, exact fp32 elsewhere;
-    gradients: bf16 MFMA) judged against the fp32 CPU oracle."""
+def _mixed_vs_oracle(lib, device, H, W, force_patch, block=None):
+    """One FULL step (block = None) or one MAD step on block `block` of MadNet_full.json in the 'mixed' mode (forward: split-bf16 on the layers
+    with an x3 kernel, exact fp32 elsewhere; gradients: bf16 MFMA) judged against the fp32 CPU oracle."""
     wn = S.calibrated_weights(OM.variable_shapes(), 1)
     l, r, gt = S.make_pair(H, W)
     lib.tune_conv_patch(force_patch)
@@ -289,24 +289,35 @@ def _mixed_vs_oracle(lib, device, H, W, force_patch):
         eng = E.MadNetEngine(lib, H, W, B=1, device=device, weights=wn, precision="mixed")
         eng.set_inputs(l, r, gt[..., 0])
         lr = 1e-4
-        eng.build_plan("FULL", lr=lr).run(lib, 0)
+        bv = None
+        if block is None:
+            eng.build_plan("FULL", lr=lr).run(lib, 0)
+        else:
+            blocks = json.load(open(os.path.join(PKG, "block_config", "MadNet_full.json")))
+            lv = OM.layer_variables()
+            bv = sum([lv[n] for n in blocks[block]], [])
+            eng.build_plan("MAD", lr=lr, block_vars=bv, block_level=E.LEVELS[block]).run(lib, 0)
         if device != "cpu":
             torch.cuda.synchronize()
     finally:
         launches = lib.tune_conv_patch(-1)
     wt = {k: torch.from_numpy(v.copy()) for k, v in wn.items()}
     acc = {k: torch.zeros_like(v) for k, v in wt.items()}
-    o = OM.step(wt, acc, torch.from_numpy(l), torch.from_numpy(r), torch.from_numpy(gt), mode="FULL", lr=lr)
+    if block is None:
+        o = OM.step(wt, acc, torch.from_numpy(l), torch.from_numpy(r), torch.from_numpy(gt), mode="FULL", lr=lr)
+    else:
+        o = OM.step(wt, acc, torch.from_numpy(l), torch.from_numpy(r), torch.from_numpy(gt), mode="MAD", block_vars=bv, block_index=block, lr=lr)
     epe = (eng.pred.cpu() - o["disparity"][..., 0]).abs().mean().item()
     gh = torch.cat([eng.params.tensor(n, "g").cpu().flatten() for n in o["grads"]])
     go = torch.cat([g.flatten() for g in o["grads"].values()])
     cos = torch.nn.functional.cosine_similarity(gh, go, dim=0).item()
     grel = (gh - go).norm().item() / go.norm().item()
-    dw = max((eng.params.tensor(n).cpu() - wt[n]).abs().max().item() for n in wt)
-    step = max((torch.from_numpy(wn[n]) - wt[n]).abs().max().item() for n in wt)          # size of the oracle's own update
+    dw = max((eng.params.tensor(n).cpu() - wt[n]).abs().max().item() for n in o["grads"])
+    step = max((torch.from_numpy(wn[n]) - wt[n]).abs().max().item() for n in o["grads"])          # size of the oracle's own update
     loss_err = abs(eng.res_loss[0].item() - o["loss"])
+    untouched = all(torch.equal(eng.params.tensor(n).cpu(), torch.from_numpy(wn[n])) for n in wt if n not in o["grads"])
     return dict(epe=epe, cos=cos, grel=grel, dw=dw, step=step, loss_err=loss_err, loss=o["loss"], launches=launches,
-                mean_disp=o["disparity"].abs().mean().item())
+                mean_disp=o["disparity"].abs().mean().item(), untouched=untouched)
 
 
 def test_mixed_mode_step_emulated():
@@ -333,7 +344,22 @@ def test_mixed_mode_headline_config_within_tolerance(hip):
     assert m["launches"] >= 10, m
     assert m["epe"] <= EPE_TOL, m
     assert m["loss_err"] <= 1e-4 * max(1.0, abs(m["loss"])), m
-    assert m["cos"] >= 0.98 and m["dw"] <= 0.25 * m["step"], m
+    # the bf16 gradients: 4 x what scripts/measure_mixed_parity.py measured on the MI355X (round 3: relative L2 of the whole gradient 3.5e-3, largest
+    # post-step weight deviation 3.4e-3 of the step itself) -- a broken bf16 filter-gradient instance moves these by orders of magnitude
+    assert m["cos"] >= 0.999 and m["grel"] <= 1.5e-2 and m["dw"] <= 1.5e-2 * m["step"], m
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block,grel_max,dw_max", [(0, 9e-2, 7e-2), (4, 1.5e-2, 1.5e-2)])
+def test_mad_step_mixed_mode_headline_config(hip, block, grel_max, dw_max):
+    """The MAD bench line runs 'mixed': one MAD step on the coarsest (0: estimator 6 + conv11/12) and the finest block (4: estimator 2 + conv1-4 + the
+    context network) at 1242x375 against the fp32 oracle -- disparity inside the tolerance, the block's gradients within 4 x the measured deviation
+    (block 0: relative L2 2.2e-2, update 1.8e-2 of the step; block 4: 3.6e-3 / 3.6e-3), every variable outside the block BIT-identical."""
+    m = _mixed_vs_oracle(hip.lib, hip.device, 375, 1242, -1, block=block)
+    print("mixed MAD block %d (MI355X 375x1242): %s" % (block, m))
+    assert m["epe"] <= EPE_TOL and m["untouched"], m
+    assert m["loss_err"] <= 1e-4 * max(1.0, abs(m["loss"])), m
+    assert m["cos"] >= 0.999 and m["grel"] <= grel_max and m["dw"] <= dw_max * m["step"], m
 
 
 @pytest.mark.gpu
