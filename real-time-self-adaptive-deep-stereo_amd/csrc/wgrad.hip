@@ -869,6 +869,32 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const mh_wgrad_seg* _
         if (segs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const mh_wgrad_seg sg = segs[lo];
+    if (sg.size <= 1024 && sg.splits >= 32 && (sg.size & 3) == 0) {
+        // a small gradient with many splits (the 3-channel image layer: 432 values x 167 splits) is ONE block here: instead of ~100 threads walking
+        // every split (a chain of dependent loads: 22 us), the block's 256 threads share the splits of 64 elements at a time and meet in LDS
+        __shared__ float4 part[256];
+        for (int base = 0; base < sg.size; base += 64) {
+            const int e4 = threadIdx.x & 15, grp = threadIdx.x >> 4;      // 16 float4 columns x 16 split groups
+            const int e = base + e4 * 4;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < sg.size)
+                for (int sp = grp; sp < sg.splits; sp += 16) {
+                    const float4 v = *reinterpret_cast<const float4*>(sg.ws + (int64_t)sp * sg.size + e);
+                    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+                }
+            part[threadIdx.x] = t;
+            __syncthreads();
+            if (threadIdx.x < 16 && e < sg.size) {
+                float4 u = part[threadIdx.x];
+                for (int g2 = 1; g2 < 16; ++g2) { const float4 v = part[g2 * 16 + threadIdx.x]; u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w; }
+                float* d = sg.dst + e;
+                if (sg.accumulate) { d[0] += u.x; d[1] += u.y; d[2] += u.z; d[3] += u.w; }
+                else { d[0] = u.x; d[1] = u.y; d[2] = u.z; d[3] = u.w; }
+            }
+            __syncthreads();
+        }
+        return;
+    }
     const int e0 = ((int)blockIdx.x - sg.blk0) * 1024 + threadIdx.x * 4;
     if (e0 >= sg.size) return;
     if ((sg.size & 3) == 0) {       // every split slice 16-byte aligned (ws is): vector path

@@ -76,9 +76,11 @@ __global__ __launch_bounds__(256) void shadow_cast_one_kernel(mh_shadow_seg sg) 
 
 // ---- the streaming kernel ---------------------------------------------------------------------------------------------------------------
 // NXG: LDS-DMA instructions per input row slot (slot = NXG x 16 pixels >= 32 + 2 d: 3 for d <= 8, 4 for d = 16); D: prefetch distance in steps.
-template <int NXG, int D>
+// S: stride of the forward convolution (1, or 2 = the pyramid's down-sampling layers: 'SAME' on even sizes pads only behind, so output pixel
+// (y, x) reads input rows 2y .. 2y + 2 and columns 2x .. 2x + 2 -- two new input rows of 65 pixels per step, pixel stride 2 in the reads).
+template <int NXG, int D, int S>
 __global__ __launch_bounds__(512) void wgrad_stream_kernel(const mh_wgs_layer* __restrict__ tab, int nlayers) {
-    constexpr int XSLOT = NXG * 1024, RX = D + 3, RZ = D + 1, G = NXG + 2;
+    constexpr int XSLOT = NXG * 1024, RX = S * D + 3, RZ = D + 1, G = S * NXG + 2;
     constexpr int WAVE_BYTES = RX * XSLOT + RZ * WS_ZSLOT;
     HIP_DYNAMIC_SHARED(float, smem_f)
     unsigned char* const smem = reinterpret_cast<unsigned char*>(smem_f);
@@ -105,7 +107,8 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const mh_wgs_layer* _
     int s = wv * sq + (wv < sr ? wv : sr);
     const int s1 = s + sq + (wv < sr ? 1 : 0);
 
-    const mh_dma_src rs_x = mh_make_dma_src(L.x, (unsigned)((int64_t)L.B * L.H * L.W * L.x_ld * 2));
+    const int Hx = S * L.H, Wx = S * L.W;                                // input image size (the layer record carries the OUTPUT size)
+    const mh_dma_src rs_x = mh_make_dma_src(L.x, (unsigned)((int64_t)L.B * Hx * Wx * L.x_ld * 2));
     const mh_dma_src rs_z = mh_make_dma_src(L.dz, (unsigned)((int64_t)L.B * L.H * L.W * L.dz_ld * 2));
     unsigned char* const xw = smem + wave * WAVE_BYTES;                 // this wave's input-row ring, then its dz ring
     unsigned char* const zw = xw + RX * XSLOT;
@@ -120,7 +123,9 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const mh_wgs_layer* _
 
     // transposing-read lane constants (bytes inside a slot): pixel 8 (l >> 5) + ((l & 15) >> 2) of the 16-pixel half-step, 4-channel piece
     // 4 ((l >> 4) & 1) + (l & 3); the second read of a fragment is 4 pixels (256 bytes) further, the second half-step 16 pixels (1024 bytes)
-    const int lrd = (8 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + (4 * ((lane >> 4) & 1) + (lane & 3)) * 8;
+    const int lpx = 8 * (lane >> 5) + ((lane & 15) >> 2), lch = (4 * ((lane >> 4) & 1) + (lane & 3)) * 8;
+    const int lrd = lpx * 64 + lch;                                     // dz slots (and input slots at stride 1)
+    const int lrx = S * lpx * 64 + lch;                                 // input slots: pixel stride S
     const int kxb = d * 64;                                             // byte step of one tap column
 
     while (s < s1) {
@@ -136,8 +141,8 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const mh_wgs_layer* _
 #pragma unroll
         for (int g = 0; g < NXG; ++g) {
             const int cc = g * 64 + lane, p = cc >> 2, qq = cc & 3;
-            const int x = x0 - d + p;
-            const bool ok = (p < 32 + 2 * d) && x >= 0 && x < L.W;
+            const int x = (S == 1) ? x0 - d + p : 2 * x0 + p;            // stride 2: input columns 2 x0 .. 2 x0 + 64
+            const bool ok = (p < (S == 1 ? 32 + 2 * d : 65)) && x >= 0 && x < Wx;
             xl[g] = ok ? (x * L.x_ld + k0 + qq * 8) * 2 : WS_FLAG;
         }
 #pragma unroll
@@ -146,10 +151,10 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const mh_wgs_layer* _
             const int x = x0 + p;
             zl[g] = (x < L.W) ? (x * L.dz_ld + n0 + qq * 8) * 2 : WS_FLAG;
         }
-        const int xrow = L.W * L.x_ld * 2, zrow = L.W * L.dz_ld * 2;
-        auto issue_x = [&](int rr, bool live, int slot) {                // lattice row rr of this column (any integer: outside = zeros)
-            const int y = cy + d * rr;
-            const int base = (live && rr >= 0 && y < L.H) ? (b * L.H + y) * xrow : WS_FLAG;
+        const int xrow = Wx * L.x_ld * 2, zrow = L.W * L.dz_ld * 2;
+        auto issue_x = [&](int rr, bool live, int slot) {                // input row rr of this column (lattice row at stride 1, image row at stride 2; outside = zeros)
+            const int y = (S == 1) ? cy + d * rr : rr;
+            const int base = (live && rr >= 0 && y < Hx) ? (b * Hx + y) * xrow : WS_FLAG;
 #pragma unroll
             for (int g = 0; g < NXG; ++g) mh_glds16(rs_x, xw + slot * XSLOT + g * 1024, xl[g] + base);
         };
@@ -159,20 +164,32 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const mh_wgs_layer* _
 #pragma unroll
             for (int g = 0; g < 2; ++g) mh_glds16(rs_z, zw + slot * WS_ZSLOT + g * 1024, zl[g] + base);
         };
-        // prologue: rows r0 - 1, r0, then the load groups of steps 0 .. D - 1 (group j = input row r0 + j + 1 and dz row r0 + j)
-        issue_x(r0 - 1, true, 0);
-        issue_x(r0, true, 1);
+        // prologue: stride 1: rows r0 - 1, r0, then the load groups of steps 0 .. D - 1 (group j = input row r0 + j + 1 and dz row r0 + j);
+        // stride 2: row 2 r0, then groups j = input rows 2 (r0 + j) + 1, 2 (r0 + j) + 2 and dz row r0 + j
+        if (S == 1) {
+            issue_x(r0 - 1, true, 0);
+            issue_x(r0, true, 1);
+        } else issue_x(2 * r0, true, 0);
 #pragma unroll
         for (int j = 0; j < D; ++j) {
-            issue_x(r0 + j + 1, j < n, (j + 2) % RX);
+            if (S == 1) issue_x(r0 + j + 1, j < n, (j + 2) % RX);
+            else {
+                issue_x(2 * (r0 + j) + 1, j < n, (2 * j + 1) % RX);
+                issue_x(2 * (r0 + j) + 2, j < n, (2 * j + 2) % RX);
+            }
             issue_z(r0 + j, j < n, j % RZ);
         }
-        int xs = 0;                                                      // ring slot of input row (r0 + i - 1) at step i
+        int xs = 0;                                                      // ring slot of the first input row of step i
         int zs = 0;                                                      // ring slot of dz row (r0 + i)
-        int xl_next = (D + 2) % RX, zl_next = D % RZ;                    // slots of the next load group
+        int xl_next = (S == 1 ? D + 2 : 2 * D + 1) % RX, zl_next = D % RZ;        // slots of the next load group
         for (int i = 0; i < n; ++i) {
             // every ds_read of step i - 1 has returned (its MFMAs consumed them): the slots the next group overwrites are free
-            issue_x(r0 + i + D + 1, i + D < n, xl_next);
+            if (S == 1) issue_x(r0 + i + D + 1, i + D < n, xl_next);
+            else {
+                issue_x(2 * (r0 + i + D) + 1, i + D < n, xl_next);
+                if (++xl_next == RX) xl_next = 0;
+                issue_x(2 * (r0 + i + D) + 2, i + D < n, xl_next);
+            }
             issue_z(r0 + i + D, i + D < n, zl_next);
             if (++xl_next == RX) xl_next = 0;
             if (++zl_next == RZ) zl_next = 0;
@@ -195,19 +212,20 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const mh_wgs_layer* _
             for (int ky = 0; ky < 3; ++ky) {
                 int sl = xs + ky;
                 if (sl >= RX) sl -= RX;
-                const unsigned char* const xrow_b = xw + sl * XSLOT + lrd;
+                const unsigned char* const xrow_b = xw + sl * XSLOT + lrx;
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const unsigned short* const ab = reinterpret_cast<const unsigned short*>(xrow_b + kx * kxb);
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const uint2 a0 = mh_lds_read_tr16(ab + h * 512), a1 = mh_lds_read_tr16(ab + h * 512 + 128);
+                        const uint2 a0 = mh_lds_read_tr16(ab + h * (S * 512)), a1 = mh_lds_read_tr16(ab + h * (S * 512) + S * 128);
                         const u32x4 af = (u32x4){a0.x, a0.y, a1.x, a1.y};
                         acc[ky * 3 + kx] = mh_mfma_bf16_32(af, bf[h], acc[ky * 3 + kx]);
                     }
                 }
             }
-            if (++xs == RX) xs = 0;
+            xs += S;
+            if (xs >= RX) xs -= RX;
             if (++zs == RZ) zs = 0;
         }
         MH_WAIT_VMCNT(0);                                                // the trailing (out-of-range) groups must not land in the next run's rows
@@ -255,20 +273,20 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const mh_wgs_layer* _
 }
 
 struct StreamCfg { int nxg, dist; };
-template <int NXG, int D>
+template <int NXG, int D, int S = 1>
 static int stream_launch(const mh_wgs_layer* tab, int nlayers, int nblocks, int nw, hipStream_t s, bool attr_only) {
-    constexpr int WAVE_BYTES = (D + 3) * NXG * 1024 + (D + 1) * WS_ZSLOT;
+    constexpr int WAVE_BYTES = (S * D + 3) * NXG * 1024 + (D + 1) * WS_ZSLOT;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_stream_kernel<NXG, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_stream_kernel<NXG, D, S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { mh_set_error("wgrad_stream: hipFuncSetAttribute(160 KB LDS): %s", hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
     if (attr_only) return 0;
     const size_t lds = (size_t)nw * WAVE_BYTES;
     MH_REQUIRE(lds <= 160 * 1024, MH_ERR_UNSUPPORTED, "mh_wgrad_stream: %d waves x %d B of LDS rings exceed 160 KB", nw, WAVE_BYTES);
-    mh_note_kernel("wgrad_stream_kernel<%d,%d> layers %d grid %d x %d waves lds %d", NXG, D, nlayers, nblocks, nw, (int)lds);
-    hipLaunchKernelGGL((wgrad_stream_kernel<NXG, D>), dim3(nblocks), dim3(64 * nw), lds, s, tab, nlayers);
+    mh_note_kernel("wgrad_stream_kernel<%d,%d,s%d> layers %d grid %d x %d waves lds %d", NXG, D, S, nlayers, nblocks, nw, (int)lds);
+    hipLaunchKernelGGL((wgrad_stream_kernel<NXG, D, S>), dim3(nblocks), dim3(64 * nw), lds, s, tab, nlayers);
     return mh_check_launch("wgrad_stream");
 }
 
@@ -288,6 +306,7 @@ int mh_wgrad_stream_init() {
     if (int rc = stream_launch<3, 1>(nullptr, 0, 0, 0, nullptr, true)) return rc;
     if (int rc = stream_launch<3, 2>(nullptr, 0, 0, 0, nullptr, true)) return rc;
     if (int rc = stream_launch<4, 1>(nullptr, 0, 0, 0, nullptr, true)) return rc;
+    if (int rc = stream_launch<5, 1, 2>(nullptr, 0, 0, 0, nullptr, true)) return rc;
     return 0;
 }
 
@@ -308,10 +327,13 @@ extern "C" int mh_wgrad_stream_plan(mh_wgs_layer* layers, int32_t n, int32_t tar
     for (int i = 0; i < n; ++i) {
         mh_wgs_layer& L = layers[i];
         MH_REQUIRE(L.B > 0 && L.H > 0 && L.W > 0 && L.K > 0 && L.N > 0 && L.dil >= 1 && L.dil <= 16, MH_ERR_ARG, "mh_wgrad_stream_plan: layer %d: bad geometry", i);
+        if (L.stride == 0) L.stride = 1;
+        MH_REQUIRE(L.stride == 1 || (L.stride == 2 && L.dil == 1), MH_ERR_UNSUPPORTED, "mh_wgrad_stream_plan: layer %d: stride 1 (any dilation) or stride 2 (dilation 1)", i);
+        MH_REQUIRE(L.stride == layers[0].stride, MH_ERR_UNSUPPORTED, "mh_wgrad_stream_plan: the layers of one launch must share the stride");
         L.ktiles = mh_cdiv(L.K, 32); L.ntiles = mh_cdiv(L.N, 32);
         MH_REQUIRE(L.x_ld >= L.ktiles * 32 && L.dz_ld >= L.ntiles * 32 && L.x_ld % 8 == 0 && L.dz_ld % 8 == 0, MH_ERR_ARG,
                    "mh_wgrad_stream_plan: layer %d: shadow strides must cover the channel count rounded up to 32", i);
-        MH_REQUIRE((int64_t)L.B * L.H * L.W * L.x_ld * 2 < (int64_t)WS_FLAG && (int64_t)L.B * L.H * L.W * L.dz_ld * 2 < (int64_t)WS_FLAG, MH_ERR_UNSUPPORTED,
+        MH_REQUIRE((int64_t)L.B * L.H * L.W * L.stride * L.stride * L.x_ld * 2 < (int64_t)WS_FLAG && (int64_t)L.B * L.H * L.W * L.dz_ld * 2 < (int64_t)WS_FLAG, MH_ERR_UNSUPPORTED,
                    "mh_wgrad_stream_plan: layer %d: shadows must be < 1 GiB", i);
         const int64_t seg = (int64_t)L.B * L.dil * mh_cdiv(L.W, 32) * mh_cdiv(L.H, L.dil);
         if (seg > maxseg) maxseg = seg;
@@ -348,8 +370,9 @@ extern "C" int mh_wgrad_stream_plan(mh_wgs_layer* layers, int32_t n, int32_t tar
 extern "C" int mh_wgrad_stream(const mh_wgs_layer* layers_device, int32_t nlayers, int32_t nblocks, int32_t nwaves, int32_t max_dil, void* stream) {
     MH_REQUIRE(layers_device && nlayers > 0 && nblocks > 0, MH_ERR_ARG, "mh_wgrad_stream: empty layer table");
     MH_REQUIRE(nwaves >= 1 && nwaves <= 8, MH_ERR_ARG, "mh_wgrad_stream: 1 .. 8 waves per workgroup");
-    MH_REQUIRE(max_dil >= 1 && max_dil <= 16, MH_ERR_UNSUPPORTED, "mh_wgrad_stream: dilation 1 .. 16");
     hipStream_t s = (hipStream_t)stream;
+    if (max_dil == -2) return stream_launch<5, 1, 2>(layers_device, nlayers, nblocks, nwaves, s, false);      // a table of stride-2 layers
+    MH_REQUIRE(max_dil >= 1 && max_dil <= 16, MH_ERR_UNSUPPORTED, "mh_wgrad_stream: dilation 1 .. 16 (or -2: a table of stride-2 layers)");
     if (max_dil > 8) return stream_launch<4, 1>(layers_device, nlayers, nblocks, nwaves, s, false);
     static const int env_d = []() { const char* e = getenv("MH_WGRAD_STREAM_DIST"); return e ? atoi(e) : 0; }();
     int dist = g_stream_dist.load(std::memory_order_relaxed);

@@ -63,7 +63,7 @@ class ShadowSeg(C.Structure):        # mh_shadow_seg
 
 class WgsLayer(C.Structure):         # mh_wgs_layer
     _fields_ = [("x", C.c_void_p), ("dz", C.c_void_p), ("ws", C.c_void_p), ("db", C.c_void_p)] + \
-               [(n, C.c_int32) for n in ("B", "H", "W", "K", "N", "dil", "x_ld", "dz_ld", "ktiles", "ntiles", "splits", "blk0")]
+               [(n, C.c_int32) for n in ("B", "H", "W", "K", "N", "dil", "x_ld", "dz_ld", "ktiles", "ntiles", "splits", "blk0", "stride", "reserved")]
 
 
 _P = C.c_void_p

@@ -108,6 +108,10 @@ class DispNetEngine(object):
         self.ops = []
         self.nodes = {}
         self.wsa = ops.WgradWorkspace(device)
+        # bf16 backward: the filter gradients of the 3x3 layers (conv3/1 .. conv6/1, conv4 / 5 / 6 at stride 2, the up-sampling blocks' 3x3 convs and
+        # predictions) run on the streaming kernel (mh_wgrad_stream) from bf16 shadows cast per batch; MH_WGRAD_STREAM=0 keeps the tiled kernels
+        self.use_stream = precision in ("mixed", "bf16") and os.environ.get("MH_WGRAD_STREAM", "1") != "0"
+        self.shadows = {}
         self._build()
 
     # ---- graph construction -----------------------------------------------------------------------
@@ -285,7 +289,17 @@ class DispNetEngine(object):
             nflush[0] += 1
             try:
                 batch = []
-                for xv, dzv, dw, db, stride in pending:
+                todo = list(pending)
+                if self.use_stream and ops._bwd_precision() == 1:
+                    items, casts, todo = [], [], []
+                    for xv, dzv, dw, db, stride in pending:
+                        if ops.wgrad_stream_ok(xv, dzv, dw, stride, 1) and dw.data_ptr() not in shared_dw:
+                            items.append((self._shadow(xv, casts), self._shadow(dzv, casts), dw, db, 1))
+                        else:
+                            todo.append((xv, dzv, dw, db, stride))
+                    ops.shadow_cast(lib, casts, self.dev, r.keep)
+                    ops.wgrad_stream(lib, self.lib, self.wsa, batch, items, self.dev, r.keep, nwaves=(4 if self.B == 1 else 8))
+                for xv, dzv, dw, db, stride in todo:
                     dup = dw.data_ptr() in seen_dst
                     seen_dst.add(dw.data_ptr())
                     shared = dw.data_ptr() in shared_dw
@@ -352,6 +366,16 @@ class DispNetEngine(object):
         r.join_next = True
         ops.wgrad_reduce(lib, segs, self.dev, r.keep)
         ops.wgrad_reduce(lib, segs2, self.dev, r.keep, accumulate=True)
+
+    def _shadow(self, v, casts):
+        """the bf16 shadow of View v (allocated on first use) + its cast queued for this batch"""
+        key = (v.ptr, v.B, v.H, v.W, v.C)
+        sh = self.shadows.get(key)
+        if sh is None:
+            sh = self.shadows[key] = ops.Shadow(v.B, v.H, v.W, v.C, self.dev)
+        if not any(c[1] is sh for c in casts):
+            casts.append((v, sh))
+        return sh
 
     def record_update(self, r, lr, momentum=0.9, grad_scale=1.0):
         P = self.params

@@ -396,7 +396,7 @@ class MadNetEngine(object):
             if side_pack and self.Wb_(pyr_name(i)) is not None:
                 r.join_lanes_next = 1 << PACK_LANE
                 side_pack = False
-            sh = self._out_shadow(o, pyr_name(i + 1)) if (i < 12 and PYR[i][2] == 1) else None       # F_i is the input of the stride-1 layer i + 1
+            sh = self._out_shadow(o, pyr_name(i + 1)) if i < 12 else None       # F_i is the input of layer i + 1 (stride 1 or 2: both streamed)
             ops.conv2d_fwd(lib, x, self.W_(pyr_name(i)), self.b_(pyr_name(i)), o, stride=s, alpha=ALPHA, wt=self.Wt_(pyr_name(i)),
                            wb=self.Wb_(pyr_name(i)), precision=self._pyr_code(i), shadow=sh)
             x = o
@@ -796,7 +796,7 @@ class MadNetEngine(object):
                     wgrad(xin, self._fv(self.dF[i]), pyr_name(i), stride=PYR[i - 1][2])
                 if need_dx:
                     # dF[i-1] is complete after this launch (the cost-volume contributions were written earlier): it is the dz of layer i - 1
-                    sh = self._out_shadow(self._fv(self.dF[i - 1]), pyr_name(i - 1)) if PYR[i - 2][2] == 1 else None
+                    sh = self._out_shadow(self._fv(self.dF[i - 1]), pyr_name(i - 1)) if (i - 1 > 1) else None       # (conv1's 3-channel input keeps the tiled kernel)
                     ops.conv2d_dgrad(lib, self._fv(self.dF[i]), self.W_(pyr_name(i)), self._fv(self.dF[i - 1]),
                                      stride=PYR[i - 1][2], accumulate=accumulate, mask_ref=self._fv(self.F[i - 1]),
                                      mask_alpha=ALPHA, wb=self.Wd_(pyr_name(i)), shadow=sh)

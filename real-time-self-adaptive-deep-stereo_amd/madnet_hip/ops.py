@@ -320,9 +320,14 @@ WGRAD_STREAM_WGS = int(_os.environ.get("MH_WGRAD_STREAM_WGS", "256"))        # w
 
 
 def wgrad_stream_ok(x, dz, dw, stride, dil):
-    """layers the streaming kernel covers: 3x3, stride 1, 'SAME' (dilation 1 .. 16)"""
+    """layers the streaming kernel covers: 3x3 'SAME', stride 1 (dilation 1 .. 16) or stride 2 (dilation 1, even sizes: padding only behind); the
+    channel stride of the input's shadow is its channel count rounded up to 32, so very thin inputs (the 3-channel image) stay on the tiled kernels"""
     kh, kw = dw.shape[0], dw.shape[1]
-    return kh == 3 and kw == 3 and stride == 1 and 1 <= dil <= 16 and (x.H, x.W) == (dz.H, dz.W)
+    if not (kh == 3 and kw == 3 and x.C >= 8):
+        return False
+    if stride == 1:
+        return 1 <= dil <= 16 and (x.H, x.W) == (dz.H, dz.W)
+    return stride == 2 and dil == 1 and x.H % 2 == 0 and x.W % 2 == 0 and (x.H, x.W) == (2 * dz.H, 2 * dz.W)
 
 
 def wgrad_stream(lib, qlib, wsa, segs, items, device, keep, stream=None, target_wgs=None, nwaves=None):
@@ -332,19 +337,27 @@ def wgrad_stream(lib, qlib, wsa, segs, items, device, keep, stream=None, target_
     `qlib` = the real library (host-side planner); `lib` may be a Recorder."""
     if not items:
         return
+    # stride-2 layers go out as a launch of their own (another instance of the kernel)
+    s2 = [it for it in items if it[0].H == 2 * it[1].H]
+    if s2 and len(s2) != len(items):
+        wgrad_stream(lib, qlib, wsa, segs, [it for it in items if it[0].H != 2 * it[1].H], device, keep, stream, target_wgs, nwaves)
+        items = s2
+    stride = 2 if s2 else 1
     n = len(items)
     arr = (_ffi.WgsLayer * n)()
     max_dil = 1
     for i, (xs, zs, dw, db, dil) in enumerate(items):
         kh, kw, K, N = dw.shape
-        assert kh == 3 and kw == 3 and (xs.B, xs.H, xs.W) == (zs.B, zs.H, zs.W) and xs.C == K and zs.C == N
+        assert kh == 3 and kw == 3 and (xs.B, xs.H, xs.W) == (zs.B, stride * zs.H, stride * zs.W) and xs.C == K and zs.C == N
         L = arr[i]
         L.x, L.dz, L.db = xs.ptr, zs.ptr, (db.data_ptr() if db is not None else None)
-        L.B, L.H, L.W, L.K, L.N, L.dil, L.x_ld, L.dz_ld = xs.B, xs.H, xs.W, K, N, dil, xs.ld, zs.ld
+        L.B, L.H, L.W, L.K, L.N, L.dil, L.x_ld, L.dz_ld, L.stride = zs.B, zs.H, zs.W, K, N, dil, xs.ld, zs.ld, stride
         max_dil = max(max_dil, dil)
     nw = WGRAD_STREAM_WAVES or nwaves or 8
     if max_dil > 8:
         nw = min(nw, 7)                   # 64-pixel row slots: 7 x 20 KB of rings fit the 160 KB LDS
+    if stride == 2:
+        nw, max_dil = min(nw, 5), -2      # 80-pixel row slots, two new rows per step: 5 x 29 KB of rings
     nblk = C.c_int32(0)
     qlib.wgrad_stream_plan(arr, n, target_wgs or WGRAD_STREAM_WGS, nw, C.byref(nblk))
     for i, (xs, zs, dw, db, dil) in enumerate(items):
@@ -356,7 +369,7 @@ def wgrad_stream(lib, qlib, wsa, segs, items, device, keep, stream=None, target_
             L.ws = wsa.alloc(size * L.splits)
             segs.append((L.ws, dw.data_ptr(), size, L.splits))
         if hasattr(lib, "tally_wgrad"):
-            lib.tally_wgrad(xs.B, xs.H, xs.W, L.K, L.N, 9, L.splits)
+            lib.tally_wgrad(zs.B, zs.H, zs.W, L.K, L.N, 9, L.splits)
     table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
     keep.append(table)
     lib.wgrad_stream(C.c_void_p(table.data_ptr()), n, nblk.value, nw, max_dil, _p(stream))

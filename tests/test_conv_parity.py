@@ -841,3 +841,22 @@ def test_wgrad_split_targets_follow_the_tuning_hook(backend):
     xr = _bf(x.cpu()).double(); w0 = torch.zeros(3, 3, Ci, Co, dtype=torch.float64, requires_grad=True)
     (gw,) = torch.autograd.grad(T.conv2d(xr, w0, None, alpha=1.0), [w0], _bf(gz.cpu()).double())
     assert (ws.cpu().double().sum(0).view(3, 3, Ci, Co) - gw).abs().max().item() <= 2e-5 * max(1.0, gw.abs().max().item())
+
+
+def test_wgrad_reduce_small_gradient_many_splits(backend):
+    """mh_wgrad_reduce on a small gradient with many splits (the 3-channel image layer: 432 values x 167 splits) takes the one-block path that shares
+    the splits among the threads: same sums as the generic path (a 4096-value segment in the same launch), accumulate and overwrite forms."""
+    dev = backend.device
+    g = torch.Generator().manual_seed(5)
+    segs, keep, refs = [], [], []
+    for size, splits in ((432, 167), (4096, 3), (64, 40), (1024, 32)):
+        ws = torch.randn(splits, size, generator=g).to(dev)
+        dst = torch.full((size,), 2.0, device=dev)
+        segs.append((ws.data_ptr(), dst.data_ptr(), size, splits)); keep += [ws, dst]
+        refs.append((dst, ws.double().sum(0).cpu()))
+    for acc in (False, True):
+        ops.wgrad_reduce(backend.lib, segs, dev, keep, accumulate=acc)
+        backend.sync()
+        for dst, ref in refs:
+            want = ref + (ref if acc else 0)           # second pass: dst (= ref after the first) + ref
+            assert (dst.cpu().double() - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())

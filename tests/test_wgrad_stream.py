@@ -56,22 +56,30 @@ def test_shadow_cast(backend):
         assert (got[..., sh.C:] == 0).all(), "padding channels must be zero"
 
 
-def _run_batch(backend, layers, target_wgs, nwaves):
-    """layers: [(B, H, W, Cin, Cout, dil, in_ld)] -> [(dw, db)] through shadow_cast + wgrad_stream + wgrad_reduce."""
+def _oracle_s2(x, gz):
+    Ci, Co = x.shape[-1], gz.shape[-1]
+    w0 = torch.zeros(3, 3, Ci, Co, dtype=torch.float64, requires_grad=True)
+    y = T.conv2d(_bf(x.cpu()).double(), w0, None, stride=2, alpha=1.0)
+    (gw,) = torch.autograd.grad(y, [w0], _bf(gz.cpu()).double())
+    return gw, _bf(gz.cpu()).double().sum((0, 1, 2))
+
+
+def _run_batch(backend, layers, target_wgs, nwaves, stride=1):
+    """layers: [(B, H, W, Cin, Cout, dil, in_ld)] (H, W = the INPUT size) -> [(dw, db)] through shadow_cast + wgrad_stream + wgrad_reduce."""
     dev = backend.device
     items, pairs, outs, refs = [], [], [], []
     for k, (B, H, W, Ci, Co, dil, ild) in enumerate(layers):
         x = _rand((B, H, W, Ci), 700 + 2 * k, dev)
-        gz = _rand((B, H, W, Co), 701 + 2 * k, dev)
+        gz = _rand((B, H // stride, W // stride, Co), 701 + 2 * k, dev)
         xb, xv = _padded(x, ild)
         if ild != Ci:
             xb[..., Ci:] = 7.5
-        xs, zs = ops.Shadow(B, H, W, Ci, dev), ops.Shadow(B, H, W, Co, dev)
+        xs, zs = ops.Shadow(B, H, W, Ci, dev), ops.Shadow(B, H // stride, W // stride, Co, dev)
         pairs += [(xv, xs), (ops.view(gz) if Co > 1 else ops.view(gz[..., 0].contiguous()), zs)]
         dw = torch.full((3, 3, Ci, Co), float("nan"), device=dev)
         db = torch.zeros(Co, device=dev)
         items.append((xs, zs, dw, db, dil))
-        outs.append((dw, db)); refs.append(_oracle(x, gz, dil))
+        outs.append((dw, db)); refs.append(_oracle(x, gz, dil) if stride == 1 else _oracle_s2(x, gz))
     wsa = ops.WgradWorkspace(dev); segs, keep = [], []
     ops.shadow_cast(backend.lib, pairs, dev, keep)
     ops.wgrad_stream(backend.lib, backend.lib, wsa, segs, items, dev, keep, target_wgs=target_wgs, nwaves=nwaves)
@@ -103,6 +111,39 @@ def test_wgrad_stream(backend, batch):
         err = (dw.cpu().double() - gw).abs().max().item()
         assert err <= 2e-5 * sc, (lay, err, sc)
         assert (db.cpu().double() - gb).abs().max().item() <= 1e-4 * max(1.0, gb.abs().max().item()), lay
+
+
+STREAM_S2_BATCHES = [
+    ([(1, 12, 64, 16, 32, 1, 16)], 4, 4),                                   # the pyramid's 16 -> 32 down-sampling layer: one 32-column strip of the output
+    ([(2, 16, 80, 32, 64, 1, 32), (2, 8, 40, 64, 96, 1, 64)], 9, 4),         # two towers, ragged strips (40 = 32 + 8; 20 columns), two layers in one launch
+    ([(1, 20, 72, 40, 33, 1, 40)], 6, 5),                                   # ragged channel counts on both sides, 5 waves
+]
+
+
+@pytest.mark.parametrize("batch", STREAM_S2_BATCHES)
+def test_wgrad_stream_stride2(backend, batch):
+    """the stride-2 instance (the pyramid's down-sampling layers): output pixel (y, x) reads input rows 2y .. 2y + 2, columns 2x .. 2x + 2 ('SAME' on
+    even sizes pads behind only) -- two new 65-pixel input rows per step, pixel stride 2 in the transposing reads"""
+    layers, wgs, nw = batch
+    outs, refs, name, segs = _run_batch(backend, layers, wgs, nw, stride=2)
+    assert "wgrad_stream_kernel<5,1,s2>" in name, name
+    for (dw, db), (gw, gb), lay in zip(outs, refs, layers):
+        sc = max(1.0, gw.abs().max().item())
+        err = (dw.cpu().double() - gw).abs().max().item()
+        assert err <= 2e-5 * sc, (lay, err, sc)
+        assert (db.cpu().double() - gb).abs().max().item() <= 1e-4 * max(1.0, gb.abs().max().item()), lay
+
+
+@pytest.mark.gpu
+def test_wgrad_stream_stride2_pyramid_sizes(hip):
+    """conv3 / conv5 / conv7 of the pyramid at the headline size, both towers, one launch"""
+    layers = [(2, 192, 640, 16, 32, 1, 16), (2, 96, 320, 32, 64, 1, 32), (2, 48, 160, 64, 96, 1, 64)]
+    for rep in range(2):
+        outs, refs, name, segs = _run_batch(hip, layers, 256, 4, stride=2)
+        for (dw, db), (gw, gb), lay in zip(outs, refs, layers):
+            sc = max(1.0, gw.abs().max().item())
+            assert (dw.cpu().double() - gw).abs().max().item() <= 2e-5 * sc, (lay, name)
+            assert (db.cpu().double() - gb).abs().max().item() <= 1e-4 * max(1.0, gb.abs().max().item()), lay
 
 
 @pytest.mark.gpu
