@@ -168,7 +168,8 @@ int mh_wgrad_reduce(const mh_wgrad_seg* segs_device, int32_t nseg, int32_t nbloc
  *                           of `nwaves` waves share the batch in proportion to the rows they stream; *nblocks_out = the grid.  The caller then
  *                           points layer.ws at splits * 9*K*N floats (16-byte aligned; or at dw itself when splits == 1) and uploads the table.
  *   mh_wgrad_stream       : the launch.  ws[split][9][K][N] is fully overwritten (sum the splits with mh_wgrad_reduce); db (may be NULL) is
- *                           accumulated with atomics.  max_dil = the largest dilation in the table (1 .. 16), or -2 for a table of stride-2 layers. */
+ *                           accumulated with atomics.  max_dil = the largest dilation in the table (1 .. 16), -2 for a table of stride-2 layers, -3 for a table that mixes
+ *                           stride-1 (dilation <= 8) and stride-2 layers. */
 typedef struct mh_shadow_seg {
     const float* src;     /* fp32 [npix][src_ld], C valid channels */
     void* dst;            /* bf16 [npix][dst_ld], dst_ld % 8 == 0, channels >= C zero-filled; 16-byte aligned */
@@ -185,7 +186,7 @@ typedef struct mh_wgs_layer {
     int32_t B, H, W, K, N, dil;
     int32_t x_ld, dz_ld;  /* >= K, N rounded up to 32; multiples of 8 */
     int32_t ktiles, ntiles, splits, blk0;      /* written by mh_wgrad_stream_plan */
-    int32_t stride;       /* 1, or 2 (dilation 1, even sizes): then B, H, W are the OUTPUT (dz) size and x is [B][2H][2W][x_ld]; one stride per table */
+    int32_t stride;       /* 1, or 2 (dilation 1, even sizes): then B, H, W are the OUTPUT (dz) size and x is [B][2H][2W][x_ld] */
     int32_t reserved;
 } mh_wgs_layer;
 int mh_wgrad_stream_plan(mh_wgs_layer* layers_host, int32_t n, int32_t target_wgs, int32_t nwaves, int32_t* nblocks_out);

@@ -79,22 +79,13 @@ __global__ __launch_bounds__(256) void shadow_cast_one_kernel(mh_shadow_seg sg) 
 // S: stride of the forward convolution (1, or 2 = the pyramid's down-sampling layers: 'SAME' on even sizes pads only behind, so output pixel
 // (y, x) reads input rows 2y .. 2y + 2 and columns 2x .. 2x + 2 -- two new input rows of 65 pixels per step, pixel stride 2 in the reads).
 template <int NXG, int D, int S>
-__global__ __launch_bounds__(512) void wgrad_stream_kernel(const mh_wgs_layer* __restrict__ tab, int nlayers) {
+__device__ __forceinline__ void wgrad_stream_body(const mh_wgs_layer& L, const int id, float* const smem_f) {
     constexpr int XSLOT = NXG * 1024, RX = S * D + 3, RZ = D + 1, G = S * NXG + 2;
     constexpr int WAVE_BYTES = RX * XSLOT + RZ * WS_ZSLOT;
-    HIP_DYNAMIC_SHARED(float, smem_f)
     unsigned char* const smem = reinterpret_cast<unsigned char*>(smem_f);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NW = (int)blockDim.x >> 6;
-
-    const int bid = mh_xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    int li = 0;
-    for (int q = 1; q < nlayers; ++q)
-        if (tab[q].blk0 <= bid) li = q;
-    li = __builtin_amdgcn_readfirstlane(li);
-    const mh_wgs_layer L = tab[li];
-    const int id = bid - L.blk0;
     const int tiles = L.ktiles * L.ntiles;
     const int tile = id % tiles, split = id / tiles;
     const int kt = tile / L.ntiles, nt = tile - kt * L.ntiles;
@@ -272,6 +263,31 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(const mh_wgs_layer* _
     }
 }
 
+__device__ __forceinline__ int wgrad_stream_layer_of(const mh_wgs_layer* __restrict__ tab, int nlayers, int bid) {
+    int li = 0;
+    for (int q = 1; q < nlayers; ++q)
+        if (tab[q].blk0 <= bid) li = q;
+    return __builtin_amdgcn_readfirstlane(li);
+}
+
+template <int NXG, int D, int S>
+__global__ __launch_bounds__(512) void wgrad_stream_kernel(const mh_wgs_layer* __restrict__ tab, int nlayers) {
+    HIP_DYNAMIC_SHARED(float, smem_f)
+    const int bid = mh_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const mh_wgs_layer L = tab[wgrad_stream_layer_of(tab, nlayers, bid)];
+    wgrad_stream_body<NXG, D, S>(L, bid - L.blk0, smem_f);
+}
+
+// a table that mixes stride-1 (dilation <= 8) and stride-2 layers -- a pyramid batch: two down-sampling layers and the two layers behind them --
+// in ONE grid: the workgroup takes the instance of its layer's stride (wave-uniform), the LDS is sized for the larger ring
+__global__ __launch_bounds__(512) void wgrad_stream_mixed_kernel(const mh_wgs_layer* __restrict__ tab, int nlayers) {
+    HIP_DYNAMIC_SHARED(float, smem_f)
+    const int bid = mh_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const mh_wgs_layer L = tab[wgrad_stream_layer_of(tab, nlayers, bid)];
+    if (L.stride == 2) wgrad_stream_body<5, 1, 2>(L, bid - L.blk0, smem_f);
+    else wgrad_stream_body<3, 1, 1>(L, bid - L.blk0, smem_f);
+}
+
 struct StreamCfg { int nxg, dist; };
 template <int NXG, int D, int S = 1>
 static int stream_launch(const mh_wgs_layer* tab, int nlayers, int nblocks, int nw, hipStream_t s, bool attr_only) {
@@ -288,6 +304,22 @@ static int stream_launch(const mh_wgs_layer* tab, int nlayers, int nblocks, int 
     mh_note_kernel("wgrad_stream_kernel<%d,%d,s%d> layers %d grid %d x %d waves lds %d", NXG, D, S, nlayers, nblocks, nw, (int)lds);
     hipLaunchKernelGGL((wgrad_stream_kernel<NXG, D, S>), dim3(nblocks), dim3(64 * nw), lds, s, tab, nlayers);
     return mh_check_launch("wgrad_stream");
+}
+
+static int stream_launch_mixed(const mh_wgs_layer* tab, int nlayers, int nblocks, int nw, hipStream_t s, bool attr_only) {
+    constexpr int WAVE_BYTES = 5 * 5 * 1024 + 2 * WS_ZSLOT;            // the stride-2 instance's rings (the stride-1 ones need 16 KB)
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_stream_mixed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { mh_set_error("wgrad_stream: hipFuncSetAttribute(160 KB LDS): %s", hipGetErrorString(e)); return (int)e; }
+        attr_done = true;
+    }
+    if (attr_only) return 0;
+    const size_t lds = (size_t)nw * WAVE_BYTES;
+    MH_REQUIRE(lds <= 160 * 1024, MH_ERR_UNSUPPORTED, "mh_wgrad_stream: %d waves x %d B of LDS rings exceed 160 KB", nw, WAVE_BYTES);
+    mh_note_kernel("wgrad_stream_mixed_kernel layers %d grid %d x %d waves lds %d", nlayers, nblocks, nw, (int)lds);
+    hipLaunchKernelGGL(wgrad_stream_mixed_kernel, dim3(nblocks), dim3(64 * nw), lds, s, tab, nlayers);
+    return mh_check_launch("wgrad_stream_mixed");
 }
 
 static std::atomic<int> g_stream_dist{0};      // mh_tune_wgrad_stream: prefetch distance (0 = default)
@@ -307,6 +339,7 @@ int mh_wgrad_stream_init() {
     if (int rc = stream_launch<3, 2>(nullptr, 0, 0, 0, nullptr, true)) return rc;
     if (int rc = stream_launch<4, 1>(nullptr, 0, 0, 0, nullptr, true)) return rc;
     if (int rc = stream_launch<5, 1, 2>(nullptr, 0, 0, 0, nullptr, true)) return rc;
+    if (int rc = stream_launch_mixed(nullptr, 0, 0, 0, nullptr, true)) return rc;
     return 0;
 }
 
@@ -329,7 +362,7 @@ extern "C" int mh_wgrad_stream_plan(mh_wgs_layer* layers, int32_t n, int32_t tar
         MH_REQUIRE(L.B > 0 && L.H > 0 && L.W > 0 && L.K > 0 && L.N > 0 && L.dil >= 1 && L.dil <= 16, MH_ERR_ARG, "mh_wgrad_stream_plan: layer %d: bad geometry", i);
         if (L.stride == 0) L.stride = 1;
         MH_REQUIRE(L.stride == 1 || (L.stride == 2 && L.dil == 1), MH_ERR_UNSUPPORTED, "mh_wgrad_stream_plan: layer %d: stride 1 (any dilation) or stride 2 (dilation 1)", i);
-        MH_REQUIRE(L.stride == layers[0].stride, MH_ERR_UNSUPPORTED, "mh_wgrad_stream_plan: the layers of one launch must share the stride");
+        MH_REQUIRE(L.stride == layers[0].stride || L.dil <= 8, MH_ERR_UNSUPPORTED, "mh_wgrad_stream_plan: a table that mixes strides takes dilations <= 8");
         L.ktiles = mh_cdiv(L.K, 32); L.ntiles = mh_cdiv(L.N, 32);
         MH_REQUIRE(L.x_ld >= L.ktiles * 32 && L.dz_ld >= L.ntiles * 32 && L.x_ld % 8 == 0 && L.dz_ld % 8 == 0, MH_ERR_ARG,
                    "mh_wgrad_stream_plan: layer %d: shadow strides must cover the channel count rounded up to 32", i);
@@ -372,7 +405,8 @@ extern "C" int mh_wgrad_stream(const mh_wgs_layer* layers_device, int32_t nlayer
     MH_REQUIRE(nwaves >= 1 && nwaves <= 8, MH_ERR_ARG, "mh_wgrad_stream: 1 .. 8 waves per workgroup");
     hipStream_t s = (hipStream_t)stream;
     if (max_dil == -2) return stream_launch<5, 1, 2>(layers_device, nlayers, nblocks, nwaves, s, false);      // a table of stride-2 layers
-    MH_REQUIRE(max_dil >= 1 && max_dil <= 16, MH_ERR_UNSUPPORTED, "mh_wgrad_stream: dilation 1 .. 16 (or -2: a table of stride-2 layers)");
+    if (max_dil == -3) return stream_launch_mixed(layers_device, nlayers, nblocks, nwaves, s, false);          // stride-1 (dilation <= 8) and stride-2 layers
+    MH_REQUIRE(max_dil >= 1 && max_dil <= 16, MH_ERR_UNSUPPORTED, "mh_wgrad_stream: dilation 1 .. 16 (or -2: a table of stride-2 layers, -3: mixed strides)");
     if (max_dil > 8) return stream_launch<4, 1>(layers_device, nlayers, nblocks, nwaves, s, false);
     static const int env_d = []() { const char* e = getenv("MH_WGRAD_STREAM_DIST"); return e ? atoi(e) : 0; }();
     int dist = g_stream_dist.load(std::memory_order_relaxed);

@@ -337,27 +337,29 @@ def wgrad_stream(lib, qlib, wsa, segs, items, device, keep, stream=None, target_
     `qlib` = the real library (host-side planner); `lib` may be a Recorder."""
     if not items:
         return
-    # stride-2 layers go out as a launch of their own (another instance of the kernel)
+    # stride-2 layers: an instance of their own; together with stride-1 layers of dilation <= 8 (a pyramid batch) the mixed kernel, ONE launch
     s2 = [it for it in items if it[0].H == 2 * it[1].H]
-    if s2 and len(s2) != len(items):
+    mixed = bool(s2) and len(s2) != len(items)
+    if mixed and max(it[4] for it in items) > 8:
         wgrad_stream(lib, qlib, wsa, segs, [it for it in items if it[0].H != 2 * it[1].H], device, keep, stream, target_wgs, nwaves)
-        items = s2
-    stride = 2 if s2 else 1
+        items, mixed = s2, False
+    stride = 2 if (s2 and not mixed) else 1
     n = len(items)
     arr = (_ffi.WgsLayer * n)()
     max_dil = 1
     for i, (xs, zs, dw, db, dil) in enumerate(items):
         kh, kw, K, N = dw.shape
-        assert kh == 3 and kw == 3 and (xs.B, xs.H, xs.W) == (zs.B, stride * zs.H, stride * zs.W) and xs.C == K and zs.C == N
+        st_i = 2 if xs.H == 2 * zs.H else 1
+        assert kh == 3 and kw == 3 and (xs.B, xs.H, xs.W) == (zs.B, st_i * zs.H, st_i * zs.W) and xs.C == K and zs.C == N and (mixed or st_i == stride)
         L = arr[i]
         L.x, L.dz, L.db = xs.ptr, zs.ptr, (db.data_ptr() if db is not None else None)
-        L.B, L.H, L.W, L.K, L.N, L.dil, L.x_ld, L.dz_ld, L.stride = zs.B, zs.H, zs.W, K, N, dil, xs.ld, zs.ld, stride
+        L.B, L.H, L.W, L.K, L.N, L.dil, L.x_ld, L.dz_ld, L.stride = zs.B, zs.H, zs.W, K, N, dil, xs.ld, zs.ld, st_i
         max_dil = max(max_dil, dil)
     nw = WGRAD_STREAM_WAVES or nwaves or 8
     if max_dil > 8:
         nw = min(nw, 7)                   # 64-pixel row slots: 7 x 20 KB of rings fit the 160 KB LDS
-    if stride == 2:
-        nw, max_dil = min(nw, 5), -2      # 80-pixel row slots, two new rows per step: 5 x 29 KB of rings
+    if stride == 2 or mixed:
+        nw, max_dil = min(nw, 5), (-3 if mixed else -2)      # 80-pixel row slots, two new rows per step: 5 x 29 KB of rings
     nblk = C.c_int32(0)
     qlib.wgrad_stream_plan(arr, n, target_wgs or WGRAD_STREAM_WGS, nw, C.byref(nblk))
     for i, (xs, zs, dw, db, dil) in enumerate(items):

@@ -134,6 +134,31 @@ def test_wgrad_stream_stride2(backend, batch):
         assert (db.cpu().double() - gb).abs().max().item() <= 1e-4 * max(1.0, gb.abs().max().item()), lay
 
 
+def test_wgrad_stream_mixed_strides_one_launch(backend):
+    """a pyramid batch -- two down-sampling layers and the stride-1 layers behind them -- in ONE launch (wgrad_stream_mixed_kernel: the workgroup takes
+    the instance of its layer's stride)"""
+    dev = backend.device
+    specs = [(2, 16, 64, 16, 32, 2), (2, 8, 32, 32, 32, 1), (2, 8, 32, 32, 64, 2), (2, 4, 16, 64, 64, 1)]      # (B, H, W, Cin, Cout, stride), H x W = input size
+    items, pairs, outs, refs = [], [], [], []
+    for k, (B, H, W, Ci, Co, st) in enumerate(specs):
+        x = _rand((B, H, W, Ci), 900 + 2 * k, dev); gz = _rand((B, H // st, W // st, Co), 901 + 2 * k, dev)
+        xs, zs = ops.Shadow(B, H, W, Ci, dev), ops.Shadow(B, H // st, W // st, Co, dev)
+        pairs += [(ops.view(x), xs), (ops.view(gz), zs)]
+        dw = torch.full((3, 3, Ci, Co), float("nan"), device=dev); db = torch.zeros(Co, device=dev)
+        items.append((xs, zs, dw, db, 1)); outs.append((dw, db))
+        refs.append(_oracle(x, gz, 1) if st == 1 else _oracle_s2(x, gz))
+    wsa = ops.WgradWorkspace(dev); segs, keep = [], []
+    ops.shadow_cast(backend.lib, pairs, dev, keep)
+    ops.wgrad_stream(backend.lib, backend.lib, wsa, segs, items, dev, keep, target_wgs=16, nwaves=4)
+    assert "wgrad_stream_mixed_kernel layers 4" in backend.lib.last_kernel().decode()
+    ops.wgrad_reduce(backend.lib, segs, dev, keep)
+    backend.sync()
+    for (dw, db), (gw, gb), sp in zip(outs, refs, specs):
+        sc = max(1.0, gw.abs().max().item())
+        assert (dw.cpu().double() - gw).abs().max().item() <= 2e-5 * sc, sp
+        assert (db.cpu().double() - gb).abs().max().item() <= 1e-4 * max(1.0, gb.abs().max().item()), sp
+
+
 @pytest.mark.gpu
 def test_wgrad_stream_stride2_pyramid_sizes(hip):
     """conv3 / conv5 / conv7 of the pyramid at the headline size, both towers, one launch"""
