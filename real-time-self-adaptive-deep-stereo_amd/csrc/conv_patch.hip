@@ -1049,7 +1049,15 @@ int launch_patch_n(ConvArgs& a, hipStream_t s, int bn) {
     return rc;
 }
 
-int patch_bn(const ConvArgs& a) { return a.x3 ? (a.N > 64 ? 128 : 64) : (a.N > 96 ? 128 : (a.N > 64 ? 96 : 64)); }
+// (round 3: a 32-column tile for the layers with <= 32 output columns -- 32 -> 32, 64 -> 32 and their input gradients: with the 64-column tile half of
+//  every MFMA and of the epilogue was padding: 15.0 -> 13.6 us forward, 16.5 -> 14.9 us input gradient for the pyramid's 32 -> 32 layer at 96x320 x 2.
+//  A 16-column tile for the 16 -> 16 layer at 192x640 was measured too and is SLOWER than the tiled kernel (32.3 vs 28.7 us forward, 41.4 vs 28.4 us input
+//  gradient): per-workgroup latency, not padding, bounds that layer -- removed.  MH_CONV_PATCH_THIN=0 restores the 64-column floor)
+static int patch_thin() { static const int v = []() { const char* e = getenv("MH_CONV_PATCH_THIN"); return e ? atoi(e) : 1; }(); return v; }
+int patch_bn(const ConvArgs& a) {
+    if (patch_thin() && a.N <= 32) return 32;
+    return a.x3 ? (a.N > 64 ? 128 : 64) : (a.N > 96 ? 128 : (a.N > 64 ? 96 : 64));
+}
 
 // Tile choice of the heuristic mode (measured on MI355X, profiles/r01_microbench_conv_patch.txt): the 128-pixel tile with 8
 // waves for the forward pass and the input gradient alike (its compile-time-K instances take K = 64 / 128).
@@ -1121,7 +1129,10 @@ bool mh_conv_patch_ok(const ConvArgs& a) {
     // with a fragment bank the split-bf16 forward kernel also takes 32..47 output channels (half of its 64-column tile idles, still 18 -> 11 us
     // for the 64->32 layers at 1/4 resolution against the exact-fp32 gather kernel; step -0.9 %)
     static const int bank_min_n = []() { const char* e = getenv("MH_CONV_BANK_MIN_N"); return e ? atoi(e) : 32; }();      // A/B hook
-    if (a.ncls != 0 || a.N < ((a.x3 && a.wb && a.mode == 0) ? bank_min_n : 48) || a.K < 32 || a.dil > 64) return false;
+    const bool bank_fwd = a.x3 && a.wb && a.mode == 0;
+    const int min_n = patch_thin() ? 32 : (bank_fwd ? bank_min_n : 48);                           // the 32-column tile: from 32 output columns
+    if (a.ncls != 0 || a.N < min_n || a.K < 32 || a.dil > 64) return false;
+    if (a.x3 && a.mode == 0 && !a.wb && (a.N < 48 || a.K < 32)) return false;                      // the LDS-staged split-bf16 instances keep their floor
     if (a.mode == 1 && (patch_mode() & 0x1000)) return false;                                  // mode bit 12: forward layers only
     if (a.mode == 1 && (patch_mode() & 0x2000) && a.K != 64 && a.K != 128) return false;       // mode bit 13: no generic-K input gradients
     const int bm = patch_bm(a), bn = patch_bn(a);
@@ -1165,6 +1176,7 @@ int mh_conv_patch_launch(ConvArgs& a, hipStream_t s) {
         if (all || (wb && bn == 128 && w4)) { rc = launch_bank<1, 4, 4, 2, true>(a, s); if (!all || rc) return rc; }
         if (all || (wb && bn == 128)) { rc = launch_bank<2, 4, 2, 2, true>(a, s); if (!all || rc) return rc; }
         if (all || (wb && bn == 64)) { rc = launch_bank<4, 2, 2, 2, true>(a, s); if (!all || rc) return rc; }
+        if (all || (wb && bn == 32)) { rc = launch_bank<8, 1, 1, 2, true>(a, s); if (!all || rc) return rc; }
     }
     // split-bf16 forward instances (precision code 2)
     {
@@ -1176,6 +1188,8 @@ int mh_conv_patch_launch(ConvArgs& a, hipStream_t s) {
         if (all || (a.x3 && bn == 64 && a.K == 64 && !generic)) { rc = launch_patch<4, 2, 2, 2, false, 2, true>(a, s); if (!all || rc) return rc; }
         if (all || (a.x3 && bn == 64)) { rc = launch_patch<4, 2, 2, 2, false, 0, true>(a, s); if (!all || rc) return rc; }
     }
+    if (all || (!a.x3 && bn == 32 && !dg)) { rc = launch_patch<4, 2, 2, 1, false>(a, s); if (!all || rc) return rc; }
+    if (all || (!a.x3 && bn == 32 && dg)) { rc = launch_patch<4, 2, 2, 1, true>(a, s); if (!all || rc) return rc; }
     if (all || (!dg && bm == 128 && !w8)) { rc = launch_patch_n<2, 2, 4, false>(a, s, bn); if (!all || rc) return rc; }
     if (all || (dg && bm == 128 && !w8)) { rc = launch_patch_n<2, 2, 4, true>(a, s, bn); if (!all || rc) return rc; }
     if (all || (!dg && bm == 128 && w8)) { rc = launch_patch_n<4, 2, 2, false>(a, s, bn); if (!all || rc) return rc; }

@@ -344,7 +344,7 @@ class MadNetEngine(object):
             if kh != 3:
                 continue
             small = pix <= self.bank_small_maxpix and 9 * ((K + 31) // 32) <= 64
-            if code == 2 and N >= 16 and K >= 16 and (small or (N >= self.bank_min_n and K >= 32)):
+            if code == 2 and N >= 16 and K >= 16 and (small or (N >= self.bank_min_n and K >= self.bank_min_n)):
                 plan.append((n, 2, 0))
             elif code == 1 and small and N >= 16 and K >= 16:
                 plan.append((n, 1, 0))

@@ -325,9 +325,11 @@ PATCH_CASES = [(1, 12, 20, 128, 128, 1, 128), (1, 9, 21, 96, 64, 2, 64), (2, 10,
 # was spent: run on the emulator only (the same instances run on the MI355X inside the engine / bench: the 64->32 layer's dgrad)
 PATCH_CASES_K32 = [(1, 9, 17, 64, 32, 1, 128 + 256), (1, 9, 17, 32, 64, 1, 128 + 256), (1, 9, 18, 32, 48, 2, 64),
                    (1, 9, 17, 64, 160, 1, 128 + 256)]      # + Cout = 160: two column tiles, the second one partly dead (no such layer in either net)
+# 32-column tile (round 3): the layers with <= 32 output columns -- 32 -> 32, 64 -> 32 and their input gradients
+PATCH_CASES_THIN = [(2, 9, 21, 32, 32, 1, 128 + 256), (1, 10, 18, 64, 32, 2, 64), (1, 9, 33, 32, 64, 1, 128 + 256), (1, 11, 19, 40, 36, 1, 128)]
 
 
-@pytest.mark.parametrize("case", PATCH_CASES + PATCH_CASES_K32)
+@pytest.mark.parametrize("case", PATCH_CASES + PATCH_CASES_K32 + PATCH_CASES_THIN)
 def test_conv_bf16_patch_kernel(backend, case):
     """Patch-staged bf16 kernel of the stride-1 3x3 (dilated) layers (csrc/conv_patch.hip): forward with bias + leaky and the
     input gradient with accumulate + leaky-grad mask, against the oracle on bf16-rounded operands; every pixel tile
@@ -358,10 +360,10 @@ def test_conv_bf16_patch_kernel(backend, case):
     finally:
         ops.PRECISION = 0
         launches = backend.lib.tune_conv_patch(-1)
-    # dispatch rule (mh_conv_patch_ok): >= 48 output channels, >= 32 input channels, 16-byte rows; mode 1: these shapes are too
-    # small for the tile heuristic -> gather kernel
-    fwd_ok = Co >= 48 and Ci >= 32
-    dgrad_ok = Ci >= 48 and Co >= 32 and Ci % 4 == 0
+    # dispatch rule (mh_conv_patch_ok): >= 32 output columns (a 32-column tile since round 3), >= 32 reduction channels, 16-byte rows;
+    # mode 1: these shapes are too small for the tile heuristic -> gather kernel
+    fwd_ok = Co >= 32 and Ci >= 32 and Co % 4 == 0
+    dgrad_ok = Ci >= 32 and Co >= 32 and Ci % 4 == 0
     assert launches == (0 if mode == 1 else int(fwd_ok) + int(dgrad_ok))
     assert (y.cpu() - y_ref).abs().max().item() <= 1e-4 * max(1.0, y_ref.abs().max().item())
     exp = (old.cpu() + gx_ref) * torch.where(mref.cpu() > 0, 1.0, 0.2)
@@ -598,7 +600,8 @@ def test_wgrad_partial_group_matches_single_launches(backend):
         assert (db1 - db2).abs().max().item() <= 1e-4 * max(1.0, db1.abs().max().item()), li
 
 
-@pytest.mark.parametrize("case", X3_CASES + [(1, 12, 20, 64, 32, 1), (1, 9, 21, 40, 36, 2)])
+@pytest.mark.parametrize("case", X3_CASES + [(1, 12, 20, 64, 32, 1), (1, 9, 21, 40, 36, 2),
+                                            (2, 9, 21, 32, 32, 1), (1, 10, 18, 64, 32, 2)])      # the 32-column tile
 def test_conv_split_bf16_fragment_bank_kernel(backend, case):
     """mh_conv2d_wb: the split-bf16 forward kernel that streams its weight operand from the MFMA fragment bank mh_pack_weights writes
     (no LDS staging of the weights, no barrier in the K walk).  Same arithmetic, same summation order as the LDS-staged split-bf16
