@@ -330,6 +330,9 @@ def main():
                     help="S > 1: S INDEPENDENT stereo streams per GPU, each with its PRIVATE model / momentum / captured graph, replayed on S HIP "
                          "streams at once (SURVEY 8(e): stream i -> GPU i mod G; a batch-1 step cannot fill 256 CUs, concurrent streams can); "
                          "value = pairs/s over all streams")
+    ap.add_argument("--early-reduce", action="store_true", help="--shared-model: force the two-piece all-reduce on a 1-rank group too (default: only when world > 1)")
+    ap.add_argument("--late-reduce", action="store_true",
+                    help="--shared-model: ONE all-reduce behind the whole backward pass instead of [estimators + context + loss] early / [pyramid] late")
     ap.add_argument("--shared-model", action="store_true",
                     help="the streams of ALL GPUs adapt ONE model: the flat gradient buffer is all-reduced (RCCL over xGMI) between "
                          "the backward plan and the momentum plan, scaled by 1/world (BASELINE config 5); default: private models, no collective")
@@ -394,27 +397,55 @@ def main():
     def make_step(e):
         """compile + validate eagerly + capture; returns (one_step, plan)"""
         if shared:
-            # data-parallel SGD over all streams: grads (sum over ranks) * 1/world -> identical momentum update everywhere
-            plan = e.build_plan("FULL", lr=1e-4, grad_scale=1.0 / world, part="grad")
+            # data-parallel SGD over all streams: grads (sum over ranks) * 1/world -> identical momentum update everywhere.  Two pieces
+            # (madnet_hip/adapter.py): [estimators + context + loss] goes out asynchronously when the backward pass reaches the
+            # pyramid, [pyramid] behind the pyramid's backward graph.
+            early = hasattr(e, "pyramid_range") and (args.early_reduce or (world > 1 and not args.late_reduce))
+            if early:
+                plan, pyr = e.build_plan("FULL", lr=1e-4, grad_scale=1.0 / world, part="grad_split")
+                lo = e.pyramid_range()[1]
+            else:
+                plan, pyr, lo = e.build_plan("FULL", lr=1e-4, grad_scale=1.0 / world, part="grad"), None, 0
             upd = e.build_plan("FULL", lr=1e-4, grad_scale=1.0 / world, part="update")
+            G = e.params.g_loss if hasattr(e.params, "g_loss") else e.params.g
         else:
-            plan, upd = e.build_plan(args.mode, lr=1e-4), None
+            plan, upd, pyr = e.build_plan(args.mode, lr=1e-4), None, None
+
+        def reduce_and_update(launch):
+            if pyr is not None:
+                first = dist.all_reduce(G[lo:], async_op=True)
+                launch(pyr)
+                dist.all_reduce(G[:lo])
+                first.wait()
+            else:
+                dist.all_reduce(G)                    # RCCL: torch orders it after the backward graph on the bench stream
+            launch(upd)
+
         with dev.ctx():
             plan.run(lib, dev.sh)                   # eager once (validates every launch)
             if shared:
-                dist.all_reduce(e.params.g)
-                upd.run(lib, dev.sh)
+                reduce_and_update(lambda q: q.run(lib, dev.sh))
             dev.sync_stream()
             if use_graph:
-                plan.capture(lib, dev.sh)
-                if shared:
-                    upd.capture(lib, dev.sh)
+                for q in (plan, pyr, upd):
+                    if q is not None:
+                        q.capture(lib, dev.sh)
 
         def one_step():
             plan.launch(lib, dev.sh)
             if shared:
-                dist.all_reduce(e.params.g)         # RCCL on the bench stream (torch orders it after the backward graph)
-                upd.launch(lib, dev.sh)
+                reduce_and_update(lambda q: q.launch(lib, dev.sh))
+        one_step.n_ops = plan.n + (pyr.n if pyr is not None else 0) + (upd.n if upd is not None else 0)
+        if shared:
+            def collectives_only():
+                if pyr is not None:
+                    first = dist.all_reduce(G[lo:], async_op=True)
+                    dist.all_reduce(G[:lo])
+                    first.wait()
+                else:
+                    dist.all_reduce(G)
+            one_step.collectives_only = collectives_only
+            one_step.pieces = [int((G.numel() - lo) * 4), int(lo * 4)] if pyr is not None else [int(G.numel() * 4)]
         return one_step, plan
 
     one_step, plan = make_step(eng)
@@ -450,6 +481,31 @@ def main():
     ms = tb["ms_per_step_median"]
     _log("timed regions done: median %.3f ms/step (min %.3f, max %.3f)" % (ms, tb["ms_per_step_min"], tb["ms_per_step_max"]))
 
+    shared_info = None
+    if shared and hasattr(one_step, "collectives_only"):
+        # the collective(s) alone, back to back on the bench stream (nothing to overlap with): what the step would pay if none of it hid
+        # behind the pyramid's backward pass; NOTE the buffer is summed over and over here -- measured after the timed regions
+        import time as _t
+        with dev.ctx():
+            for _ in range(3):
+                one_step.collectives_only()
+            dev.sync_stream()
+            if dist is not None and world > 1:
+                dist.barrier()
+            t0 = _t.perf_counter()
+            for _ in range(20):
+                one_step.collectives_only()
+            dev.sync_stream()
+            coll_ms = (_t.perf_counter() - t0) * 1e3 / 20
+        shared_info = {"collective_ms_alone": coll_ms, "pieces_bytes": one_step.pieces,
+                       "order": ("[estimators + context + loss] async behind their backward pass, [pyramid] behind the pyramid's" if len(one_step.pieces) == 2
+                                 else "one all-reduce behind the backward pass"),
+                       "algbw_gbs": sum(one_step.pieces) / (coll_ms * 1e-3) / 1e9 if coll_ms > 0 else None}
+        with dev.ctx():
+            feed(eng)
+            one_step()                  # leave the engine with a real step's results for the fields below
+            dev.sync_stream()
+
     loss = float(eng.res_loss[0].item())
     epe_gt = float(eng.res_met[0].item())
     nonzero = float((eng.pred != 0).float().mean().item())
@@ -472,7 +528,7 @@ def main():
                    "precision": args.precision,
                    "concurrent_private_streams_per_gpu": CS,
                    "launch": "hipGraph replay" if use_graph else "eager plan",
-                   "ops_per_step": plan.n, "final_loss": loss, "epe_vs_synthetic_gt": epe_gt,
+                   "ops_per_step": getattr(one_step, "n_ops", plan.n), "final_loss": loss, "epe_vs_synthetic_gt": epe_gt,
                    "pred_nonzero_frac": nonzero,
                    "ranks_per_device": (world + dev.ndev - 1) // dev.ndev if dev.ndev else None},
         # whole-step aggregates: algorithmic conv work of the recorded plan (every operand read / result written once) over
@@ -485,6 +541,8 @@ def main():
                            "wgrad_ws_bytes": st.get("wgrad_ws_bytes"), "grad_bytes": st.get("grad_bytes"),
                            "wgrad_ws_over_grad": (st.get("wgrad_ws_bytes", 0.0) / st["grad_bytes"]) if st.get("grad_bytes") else None},
     }
+    if shared_info is not None:
+        out["shared_model"] = shared_info
     if rank == 0 and world == 1 and dispnet and SB == 1 and dev.kind == "cuda" and not args.no_cpu_baseline:
         # DispNet: disparity of the run's arithmetic mode against the fp32 CPU oracle on the bench pair (the same check MADNet's line carries)
         from oracle import dispnet as OD

@@ -692,6 +692,62 @@ static int launch_conv_n1(ConvArgs& a, hipStream_t s) {
     return mh_check_launch("conv_n1_fwd");
 }
 
+// ---- input gradient of a single-output-channel conv (the disparity heads, mode 1 with K = 1) ---------------------------------------
+// dx[p][n] = mask(sum_t dz[p + pad - tap_t] * w[t][n]) (+ old): one float of dz per tap, taps*N weights -- no reduction axis worth a
+// tile, the launch is bound by the dx store.  A thread owns 4 channels of a pixel (consecutive threads = consecutive channel groups:
+// full-line stores), the weights sit in LDS, exact fp32 whatever the mode.  The tiled kernel ran its scalar fp32 path here (9-11 us
+// against ~5 us for this one at every level).
+__global__ __launch_bounds__(256) void conv_k1_dgrad_kernel(ConvArgs p) {
+    HIP_DYNAMIC_SHARED(float, wsm)                 // [taps][N]
+    const int tid = threadIdx.x;
+    const int nw4 = p.taps * p.N / 4;
+    for (int i = tid; i < nw4; i += 256) reinterpret_cast<float4*>(wsm)[i] = reinterpret_cast<const float4*>(p.w)[i];
+    __syncthreads();
+    const int G4 = p.N >> 2;
+    const int total = p.M * G4;
+    for (int idx = blockIdx.x * 256 + tid; idx < total; idx += gridDim.x * 256) {
+        const int m = idx / G4, n = (idx - m * G4) * 4;
+        const int ox = m % p.Wo;
+        const int t2 = m / p.Wo;
+        const int oy = t2 % p.Ho, b = t2 / p.Ho;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < p.taps; ++t) {
+            const int ky = t / p.kw, kx = t - ky * p.kw;
+            const int iy = oy + p.pad_t - ky * p.dil, ix = ox + p.pad_l - kx * p.dil;
+            if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) {
+                const float z = p.in[(int64_t)((b * p.Hi + iy) * p.Wi + ix) * p.in_ld];
+                const float4 w = *reinterpret_cast<const float4*>(wsm + t * p.N + n);
+                v.x += z * w.x; v.y += z * w.y; v.z += z * w.z; v.w += z * w.w;
+            }
+        }
+        float* dst = p.out + (int64_t)m * p.out_ld + n;
+        if (p.accumulate) { const float4 o = *reinterpret_cast<const float4*>(dst); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        if (p.mask_ref) {
+            const float4 mk = *reinterpret_cast<const float4*>(p.mask_ref + (int64_t)m * p.mask_ld + n);
+            v.x *= (mk.x > 0.f || n + 0 < p.mask_c0 || n + 0 >= p.mask_c1) ? 1.0f : p.mask_alpha;
+            v.y *= (mk.y > 0.f || n + 1 < p.mask_c0 || n + 1 >= p.mask_c1) ? 1.0f : p.mask_alpha;
+            v.z *= (mk.z > 0.f || n + 2 < p.mask_c0 || n + 2 >= p.mask_c1) ? 1.0f : p.mask_alpha;
+            v.w *= (mk.w > 0.f || n + 3 < p.mask_c0 || n + 3 >= p.mask_c1) ? 1.0f : p.mask_alpha;
+        }
+        *reinterpret_cast<float4*>(dst) = v;
+        if (p.shadow) *reinterpret_cast<uint2*>(p.shadow + (int64_t)m * p.shadow_ld + n) = make_uint2(mh_pack_bf16(v.x, v.y), mh_pack_bf16(v.z, v.w));
+    }
+}
+
+static bool conv_k1_dgrad_ok(const ConvArgs& a) {
+    return a.mode == 1 && a.K == 1 && a.stride == 1 && a.vecC && mh_aligned16(a.w) && (a.N % 4 == 0) && !a.bias && a.alpha == 1.0f &&
+           (size_t)a.taps * a.N * 4 <= 64 * 1024 && a.M > 0 && (int64_t)a.M * (a.N / 4) < (1ll << 31);
+}
+
+static int launch_conv_k1_dgrad(ConvArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)a.taps * a.N * sizeof(float);
+    int grid = mh_cdiv(a.M * (a.N / 4), 256);
+    if (grid > 256 * 16) grid = 256 * 16;
+    hipLaunchKernelGGL(conv_k1_dgrad_kernel, dim3(grid), dim3(256), lds, s, a);
+    mh_note_kernel("conv_k1_dgrad_kernel N=%d", a.N);
+    return mh_check_launch("conv_k1_dgrad");
+}
+
 // ---- thin full-resolution layers (3x3, Cin <= 32, Cout 16 / 32, many pixels): weights-stationary direct conv ----------
 // The tiled kernel spends its time on LDS staging and barriers for K-walks of 1-5 tiles (35 us for 1.1 GFLOP).  Here a
 // wave keeps the WHOLE filter bank as bf16 MFMA B operands in registers (taps*Cin <= 288 k-values = 9 steps x NT x 4
@@ -1119,6 +1175,7 @@ static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, co
     hipStream_t hs = (hipStream_t)stream;
     int rc;
     if (conv_n1_ok(a)) rc = launch_conv_n1(a, hs);
+    else if (conv_k1_dgrad_ok(a)) { a.shadow = (unsigned short*)out_shadow; a.shadow_done = 1; rc = launch_conv_k1_dgrad(a, hs); }
     else if (conv_thin_ok(a)) rc = launch_conv_thin(a, hs);
     else if (mh_conv_bank_small_ok(a)) { a.shadow = (unsigned short*)out_shadow; a.shadow_done = 1; rc = mh_conv_bank_small_launch(a, hs); }
     else if (mh_conv_patch_ok(a)) { a.shadow = (unsigned short*)out_shadow; a.shadow_done = 1; rc = mh_conv_patch_launch(a, hs); }

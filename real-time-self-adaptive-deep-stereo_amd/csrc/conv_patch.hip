@@ -1097,8 +1097,10 @@ extern "C" int mh_tune_conv_bank(int small_maxpix) {
 // small-layer bank kernel: stride-1 "SAME" 3x3, bank present, reduction <= 64 chunks (K <= 224), few enough pixels that the tiled kernels
 // are latency bound (default <= 4096 output pixels: the 1/16-1/64 levels; MH_CONV_BANK_SMALL_MAXPIX overrides, 0 = off)
 bool mh_conv_bank_small_ok(const ConvArgs& a) {
-    static const int maxpix_dgrad = []() { const char* e = getenv("MH_CONV_BANK_SMALL_MAXPIX_DGRAD"); return e ? atoi(e) : 0; }();   // A/B hook: 0 = same as forward
-    const int maxpix = (a.mode == 1 && maxpix_dgrad > 0) ? maxpix_dgrad : bank_small_maxpix();
+    // input gradients: twice the forward limit (the 1/8-resolution level too: 1.804-1.809 -> 1.800-1.802 ms per step against the tiled kernel
+    // there, profiles/r03_experiments.txt #11; in the forward pass that level runs split-bf16 on the big bank kernel)
+    static const int maxpix_dgrad = []() { const char* e = getenv("MH_CONV_BANK_SMALL_MAXPIX_DGRAD"); return e ? atoi(e) : 0; }();   // A/B hook: 0 = 2 x forward
+    const int maxpix = a.mode == 1 ? (maxpix_dgrad > 0 ? maxpix_dgrad : 2 * bank_small_maxpix()) : bank_small_maxpix();
     if (!a.wb || !(a.bf16 || a.x3) || (a.x3 && a.mode != 0)) return false;
     static const int s2_on = []() { const char* e = getenv("MH_CONV_BANK_SMALL_S2"); return e ? atoi(e) : 1; }();      // A/B hook: stride-2 forward layers
     const bool s1 = a.stride == 1 && a.pad_t == a.dil && a.pad_l == a.dil && a.Hi == a.Ho && a.Wi == a.Wo;

@@ -351,92 +351,140 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
-// stage 1: warp right by the disparity (bilinear_sampler: clamped indices, un-masked weights;
-// rows are integral so only the y0 taps carry weight), L1 partial sums.
-__global__ __launch_bounds__(256) void loss_warp_kernel(LossArgs p) {
+// One launch for the maps and the gradient: a workgroup owns a 16 x 32 pixel tile and works through LDS on the tile + a 2-pixel halo
+// (a pixel's gradient needs the SSIM coefficients of the <= 9 windows that contain it, a window needs the warped image at its 9 pixels):
+//   A  warp right by the disparity at the 20 x 36 halo pixels (bilinear_sampler: clamped indices, un-masked weights; rows are integral
+//      so only the y0 taps carry weight) -> LDS; d rep / d x for the tile's own pixels -> LDS; L1 partial sum over the tile's pixels;
+//   B  SSIM over the 18 x 34 3x3 VALID windows that touch the tile -> per-window derivative coefficients in LDS
+//        d map / d x_p = alpha + beta*y_p + gamma*x_p   for the 9 pixels p of the window
+//      (windows outside the image: zeros); SSIM partial sum over the windows whose top-left corner is a pixel of the tile;
+//   C  d loss / d disp[p] = - sum_ch (d loss / d rep[p,ch]) * drep[p,ch].
+// (Three launches with the maps in HBM before: 39 us per step on the critical path at 375 x 1242; per-pixel arithmetic and summation order of
+// the gradient unchanged.)
+#define LT_H 16
+#define LT_W 32
+#define LT_HH (LT_H + 4)
+#define LT_HW (LT_W + 4)
+#define LT_WH (LT_H + 2)
+#define LT_WW (LT_W + 2)
+__global__ __launch_bounds__(256) void loss_tile_kernel(LossArgs p, int tiles_x, int tiles_y, int with_grad) {
     __shared__ float red[4];
-    const int64_t total = (int64_t)p.B * p.H * p.W;
-    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    __shared__ float s_rep[LT_HH * LT_HW * 3];
+    __shared__ float s_y[LT_HH * LT_HW * 3];
+    __shared__ float s_drep[LT_H * LT_W * 3];
+    __shared__ float s_coef[LT_WH * LT_WW * 9];
+    const int tid = threadIdx.x;
+    const int tx = blockIdx.x % tiles_x;
+    const int t2 = blockIdx.x / tiles_x;
+    const int ty = t2 % tiles_y, b = t2 / tiles_y;
+    const int y0t = ty * LT_H, x0t = tx * LT_W;
+    const float s = 1.0f / 256.0f;
+    const float xmax = (float)(p.W - 1);
+    // ---- A -------------------------------------------------------------------------------------
     float l1 = 0.f;
-    if (q < total) {
-        const int x = (int)(q % p.W);
-        const int64_t rowbase = q - x;
-        const float cx = (float)x - p.disp[q];
-        const float x0 = floorf(cx), x1 = x0 + 1.0f;
-        const float w0 = x1 - cx, w1 = cx - x0;
-        const float xmax = (float)(p.W - 1);
-        const int i0 = (int)clampf(x0, 0.f, xmax), i1 = (int)clampf(x1, 0.f, xmax);
-        const float* r0 = p.right + (rowbase + i0) * 3;
-        const float* r1 = p.right + (rowbase + i1) * 3;
-        const float* lp = p.left + q * 3;
-        float4 rep, dr;
-        const float s = 1.0f / 256.0f;
-        const float a0 = r0[0] * s, a1 = r0[1] * s, a2 = r0[2] * s;
-        const float b0 = r1[0] * s, b1 = r1[1] * s, b2 = r1[2] * s;
-        rep.x = w0 * a0 + w1 * b0; rep.y = w0 * a1 + w1 * b1; rep.z = w0 * a2 + w1 * b2; rep.w = 0.f;
-        dr.x = b0 - a0; dr.y = b1 - a1; dr.z = b2 - a2; dr.w = 0.f;
-        *reinterpret_cast<float4*>(p.rep + q * 4) = rep;
-        *reinterpret_cast<float4*>(p.drep + q * 4) = dr;
-        l1 = fabsf(rep.x - lp[0] * s) + fabsf(rep.y - lp[1] * s) + fabsf(rep.z - lp[2] * s);
+    for (int i = tid; i < LT_HH * LT_HW; i += 256) {
+        const int ly = i / LT_HW, lx = i - ly * LT_HW;
+        const int y = y0t - 2 + ly, x = x0t - 2 + lx;
+        float r0v = 0.f, r1v = 0.f, r2v = 0.f, y0v = 0.f, y1v = 0.f, y2v = 0.f;
+        if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
+            const int64_t rowbase = ((int64_t)b * p.H + y) * p.W;
+            const int64_t q = rowbase + x;
+            const float cx = (float)x - p.disp[q];
+            const float xf0 = floorf(cx), xf1 = xf0 + 1.0f;
+            const float w0 = xf1 - cx, w1 = cx - xf0;
+            const int i0 = (int)clampf(xf0, 0.f, xmax), i1 = (int)clampf(xf1, 0.f, xmax);
+            const float* r0 = p.right + (rowbase + i0) * 3;
+            const float* r1 = p.right + (rowbase + i1) * 3;
+            const float* lp = p.left + q * 3;
+            const float a0 = r0[0] * s, a1 = r0[1] * s, a2 = r0[2] * s;
+            const float b0 = r1[0] * s, b1 = r1[1] * s, b2 = r1[2] * s;
+            r0v = w0 * a0 + w1 * b0; r1v = w0 * a1 + w1 * b1; r2v = w0 * a2 + w1 * b2;
+            y0v = lp[0] * s; y1v = lp[1] * s; y2v = lp[2] * s;
+            const int iy = ly - 2, ix = lx - 2;
+            if ((unsigned)iy < (unsigned)LT_H && (unsigned)ix < (unsigned)LT_W) {
+                float* d = s_drep + (iy * LT_W + ix) * 3;
+                d[0] = b0 - a0; d[1] = b1 - a1; d[2] = b2 - a2;
+                l1 += fabsf(r0v - y0v) + fabsf(r1v - y1v) + fabsf(r2v - y2v);
+            }
+        }
+        s_rep[i * 3 + 0] = r0v; s_rep[i * 3 + 1] = r1v; s_rep[i * 3 + 2] = r2v;
+        s_y[i * 3 + 0] = y0v; s_y[i * 3 + 1] = y1v; s_y[i * 3 + 2] = y2v;
     }
-    const float tot = block_sum(l1, red);
-    if (threadIdx.x == 0) p.part1[blockIdx.x] = tot;
-}
-
-// stage 2: SSIM over 3x3 VALID windows; per-window derivative coefficients
-//   d map / d x_p = alpha + beta*y_p + gamma*x_p   for the 9 pixels p of the window.
-__global__ __launch_bounds__(256) void loss_ssim_kernel(LossArgs p) {
-    __shared__ float red[4];
+    __syncthreads();
+    // ---- B -------------------------------------------------------------------------------------
     const int Hw = p.H - 2, Ww = p.W - 2;
-    const int64_t total = (int64_t)p.B * Hw * Ww;
-    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float ssum = 0.f;
-    if (q < total) {
-        const int wx = (int)(q % Ww);
-        const int64_t t2 = q / Ww;
-        const int wy = (int)(t2 % Hw);
-        const int b = (int)(t2 / Hw);
-        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-        const float s = 1.0f / 256.0f;
-        float sx[3] = {0, 0, 0}, sy[3] = {0, 0, 0}, sxx[3] = {0, 0, 0}, syy[3] = {0, 0, 0}, sxy[3] = {0, 0, 0};
+    for (int i = tid; i < LT_WH * LT_WW; i += 256) {
+        const int ly = i / LT_WW, lx = i - ly * LT_WW;
+        const int wy = y0t - 2 + ly, wx = x0t - 2 + lx;              // window (wy, wx) = halo pixels (ly .. ly+2, lx .. lx+2)
+        float co[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if ((unsigned)wy < (unsigned)Hw && (unsigned)wx < (unsigned)Ww) {
+            const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+            float sx[3] = {0, 0, 0}, sy[3] = {0, 0, 0}, sxx[3] = {0, 0, 0}, syy[3] = {0, 0, 0}, sxy[3] = {0, 0, 0};
+            for (int dy = 0; dy < 3; ++dy)
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int h = ((ly + dy) * LT_HW + lx + dx) * 3;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float xv = s_rep[h + c], yv = s_y[h + c];
+                        sx[c] += xv; sy[c] += yv; sxx[c] += xv * xv; syy[c] += yv * yv; sxy[c] += xv * yv;
+                    }
+                }
+            const bool own = ly >= 2 && lx >= 2 && ly < 2 + LT_H && lx < 2 + LT_W;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float inv9 = 1.0f / 9.0f;
+                const float mx = sx[c] * inv9, my = sy[c] * inv9;
+                const float vx = sxx[c] * inv9 - mx * mx, vy = syy[c] * inv9 - my * my, vxy = sxy[c] * inv9 - mx * my;
+                const float n1 = 2.f * mx * my + C1, n2 = 2.f * vxy + C2;
+                const float d1 = mx * mx + my * my + C1, d2 = vx + vy + C2;
+                const float S = (n1 * n2) / (d1 * d2);
+                const float mraw = (1.0f - S) * 0.5f;
+                if (own) ssum += clampf(mraw, 0.f, 1.f);
+                // tf.clip_by_value passes the gradient iff 0 <= x <= 1 ; d map = -0.5 dS
+                const float pass = (mraw >= 0.f && mraw <= 1.f) ? -0.5f * (2.0f / 9.0f) : 0.f;
+                const float idd = 1.0f / (d1 * d2);
+                const float beta = n1 * idd;
+                const float gamma = -S / d2;
+                const float alpha = (my * n2 - n1 * my) * idd - S * (mx * d2 - d1 * mx) * idd;
+                co[c * 3 + 0] = pass * alpha; co[c * 3 + 1] = pass * beta; co[c * 3 + 2] = pass * gamma;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s_coef[i * 9 + k] = co[k];
+    }
+    const float tot1 = block_sum(l1, red);          // (its barriers also publish s_coef)
+    const float tot2 = block_sum(ssum, red);
+    if (tid == 0) { p.part1[blockIdx.x] = tot1; p.part2[blockIdx.x] = tot2; }
+    if (!with_grad) return;
+    // ---- C -------------------------------------------------------------------------------------
+    const float k_ssim = 0.85f / ((float)p.B * (float)Hw * (float)Ww * 3.0f);
+    const float k_l1 = 0.15f / ((float)p.B * (float)p.H * (float)p.W * 3.0f);
+    for (int i = tid; i < LT_H * LT_W; i += 256) {
+        const int iy = i / LT_W, ix = i - iy * LT_W;
+        const int y = y0t + iy, x = x0t + ix;
+        if (y >= p.H || x >= p.W) continue;
+        float A[3] = {0, 0, 0}, Bc[3] = {0, 0, 0}, Gc[3] = {0, 0, 0};
+        // windows (y-2 .. y, x-2 .. x) = local windows (iy .. iy+2, ix .. ix+2); the ones outside the image hold zeros
         for (int dy = 0; dy < 3; ++dy)
             for (int dx = 0; dx < 3; ++dx) {
-                const int64_t pix = ((int64_t)b * p.H + wy + dy) * p.W + wx + dx;
-                const float4 xr = *reinterpret_cast<const float4*>(p.rep + pix * 4);
-                const float* lp = p.left + pix * 3;
-                const float xv[3] = {xr.x, xr.y, xr.z};
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float yv = lp[c] * s;
-                    sx[c] += xv[c]; sy[c] += yv; sxx[c] += xv[c] * xv[c]; syy[c] += yv * yv; sxy[c] += xv[c] * yv;
-                }
+                const float* cp = s_coef + ((iy + dy) * LT_WW + ix + dx) * 9;
+                A[0] += cp[0]; Bc[0] += cp[1]; Gc[0] += cp[2];
+                A[1] += cp[3]; Bc[1] += cp[4]; Gc[1] += cp[5];
+                A[2] += cp[6]; Bc[2] += cp[7]; Gc[2] += cp[8];
             }
-        float co[12];
+        const int h = ((iy + 2) * LT_HW + ix + 2) * 3;
+        float gd = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float inv9 = 1.0f / 9.0f;
-            const float mx = sx[c] * inv9, my = sy[c] * inv9;
-            const float vx = sxx[c] * inv9 - mx * mx, vy = syy[c] * inv9 - my * my, vxy = sxy[c] * inv9 - mx * my;
-            const float n1 = 2.f * mx * my + C1, n2 = 2.f * vxy + C2;
-            const float d1 = mx * mx + my * my + C1, d2 = vx + vy + C2;
-            const float S = (n1 * n2) / (d1 * d2);
-            const float mraw = (1.0f - S) * 0.5f;
-            ssum += clampf(mraw, 0.f, 1.f);
-            // tf.clip_by_value passes the gradient iff 0 <= x <= 1 ; d map = -0.5 dS
-            const float pass = (mraw >= 0.f && mraw <= 1.f) ? -0.5f * (2.0f / 9.0f) : 0.f;
-            const float idd = 1.0f / (d1 * d2);
-            const float beta = n1 * idd;
-            const float gamma = -S / d2;
-            const float alpha = (my * n2 - n1 * my) * idd - S * (mx * d2 - d1 * mx) * idd;
-            co[c * 4 + 0] = pass * alpha; co[c * 4 + 1] = pass * beta; co[c * 4 + 2] = pass * gamma; co[c * 4 + 3] = 0.f;
+            const float xv = s_rep[h + c], yv = s_y[h + c];
+            const float diff = xv - yv;
+            const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+            const float grep = k_ssim * (A[c] + Bc[c] * yv + Gc[c] * xv) + k_l1 * sgn;
+            gd -= grep * s_drep[i * 3 + c];
         }
-        float4* dst = reinterpret_cast<float4*>(p.coef + q * 12);
-        dst[0] = make_float4(co[0], co[1], co[2], co[3]);
-        dst[1] = make_float4(co[4], co[5], co[6], co[7]);
-        dst[2] = make_float4(co[8], co[9], co[10], co[11]);
+        p.ddisp[((int64_t)b * p.H + y) * p.W + x] = gd * p.grad_scale;
     }
-    const float tot = block_sum(ssum, red);
-    if (threadIdx.x == 0) p.part2[blockIdx.x] = tot;
 }
 
 __global__ __launch_bounds__(256) void loss_final_kernel(LossArgs p) {
@@ -456,45 +504,6 @@ __global__ __launch_bounds__(256) void loss_final_kernel(LossArgs p) {
         p.result[0] = (float)(0.85 * ms + 0.15 * ml);
         p.result[1] = (float)ms;
         p.result[2] = (float)ml;
-    }
-}
-
-// stage 3: d loss / d disp[p] = - sum_ch (d loss / d rep[p,ch]) * drep[p,ch]
-__global__ __launch_bounds__(256) void loss_grad_kernel(LossArgs p) {
-    const int64_t total = (int64_t)p.B * p.H * p.W;
-    const int Hw = p.H - 2, Ww = p.W - 2;
-    const float k_ssim = 0.85f / ((float)p.B * (float)Hw * (float)Ww * 3.0f);
-    const float k_l1 = 0.15f / ((float)p.B * (float)p.H * (float)p.W * 3.0f);
-    const float s = 1.0f / 256.0f;
-    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
-        const int x = (int)(q % p.W);
-        const int64_t t2 = q / p.W;
-        const int y = (int)(t2 % p.H);
-        const int b = (int)(t2 / p.H);
-        const float4 xr = *reinterpret_cast<const float4*>(p.rep + q * 4);
-        const float4 dr = *reinterpret_cast<const float4*>(p.drep + q * 4);
-        const float* lp = p.left + q * 3;
-        const float xv[3] = {xr.x, xr.y, xr.z};
-        const float dv[3] = {dr.x, dr.y, dr.z};
-        float A[3] = {0, 0, 0}, Bc[3] = {0, 0, 0}, Gc[3] = {0, 0, 0};
-        for (int wy = max(0, y - 2); wy <= min(Hw - 1, y); ++wy)
-            for (int wx = max(0, x - 2); wx <= min(Ww - 1, x); ++wx) {
-                const float4* cp = reinterpret_cast<const float4*>(p.coef + (((int64_t)b * Hw + wy) * Ww + wx) * 12);
-                const float4 c0 = cp[0], c1 = cp[1], c2 = cp[2];
-                A[0] += c0.x; Bc[0] += c0.y; Gc[0] += c0.z;
-                A[1] += c1.x; Bc[1] += c1.y; Gc[1] += c1.z;
-                A[2] += c2.x; Bc[2] += c2.y; Gc[2] += c2.z;
-            }
-        float gd = 0.f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float yv = lp[c] * s;
-            const float diff = xv[c] - yv;
-            const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
-            const float grep = k_ssim * (A[c] + Bc[c] * yv + Gc[c] * xv[c]) + k_l1 * sgn;
-            gd -= grep * dv[c];
-        }
-        p.ddisp[q] = gd * p.grad_scale;
     }
 }
 
@@ -830,15 +839,14 @@ extern "C" int mh_reprojection_loss_phase(const float* left, const float* right,
     LossArgs a{};
     a.left = left; a.right = right; a.disp = disp; a.result = result; a.ddisp = ddisp; a.grad_scale = grad_scale;
     a.B = B; a.H = H; a.W = W;
-    a.rep = ws; a.drep = ws + 4 * n; a.coef = ws + 8 * n;
-    a.part1 = ws + 8 * n + 12 * nw; a.nblk1 = (int)nblk(n);
-    a.part2 = a.part1 + a.nblk1; a.nblk2 = (int)nblk(nw);
+    const int tiles_x = (W + LT_W - 1) / LT_W, tiles_y = (H + LT_H - 1) / LT_H;
+    const int64_t ntiles = (int64_t)B * tiles_x * tiles_y;               // <= nblk(n): the workspace keeps its layout
+    MH_REQUIRE(ntiles < (1ll << 31), MH_ERR_ARG, "mh_reprojection_loss: too many tiles");
+    a.rep = ws; a.drep = ws + 4 * n; a.coef = ws + 8 * n;                  // (maps: LDS only since the tile kernel; the offsets keep the layout)
+    a.part1 = ws + 8 * n + 12 * nw; a.nblk1 = (int)ntiles;
+    a.part2 = a.part1 + nblk(n); a.nblk2 = (int)ntiles;
     hipStream_t s = (hipStream_t)stream;
-    if (phase != 2) {
-        hipLaunchKernelGGL(loss_warp_kernel, dim3(a.nblk1), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(loss_ssim_kernel, dim3(a.nblk2), dim3(256), 0, s, a);
-        if (ddisp) hipLaunchKernelGGL(loss_grad_kernel, dim3(grid_for(n)), dim3(256), 0, s, a);     // (does not need the reduced loss value)
-    }
+    if (phase != 2) hipLaunchKernelGGL(loss_tile_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, a, tiles_x, tiles_y, ddisp ? 1 : 0);
     if (phase != 1) hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, a);
     return mh_check_launch("reprojection_loss");
 }

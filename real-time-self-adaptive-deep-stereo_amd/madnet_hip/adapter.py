@@ -7,6 +7,9 @@ Multi-GPU: streams are independent by default (private weights, no collective). 
 shared_model=True the flat GRADIENT buffer is all-reduced (RCCL over xGMI via torch.distributed)
 between the backward plan and the fused momentum plan, which is exactly data-parallel SGD; the loss
 used for the reward / reset decisions is averaged too so every rank samples the same block.
+FULL mode issues the collective in two pieces: [estimators + context network + loss] (73 % of the
+bytes, contiguous in the flat layout) as soon as the backward pass reaches the pyramid -- it runs on
+RCCL's stream while the pyramid's backward graph runs on ours -- and [pyramid] behind it.
 """
 import numpy as np
 import torch
@@ -24,7 +27,7 @@ class Adapter(object):
     def __init__(self, net, mode="MAD", block_config=None, lr=1e-4, momentum=0.9, sample_mode="PROBABILITY",
                  num_blocks=1, fixed_id=0, sample_frequency=1, ssim_th=0.5, reprojection_scale=1,
                  use_graph=True, shared_model=False, process_group=None, loss="reprojection", dilation=1, decay=0.99, uf=0.01,
-                 optimizer="momentum", reset_optimizer=False, reward_every_step_first=False):
+                 optimizer="momentum", reset_optimizer=False, reward_every_step_first=False, early_reduce=None):
         """loss='proxy', dilation, decay, uf: the continual-adaptation variant (Stereo_Continual_Adaptation.py:75-112,
         205-249, 302-304): proxy-label mean_l1 loss, weight update only every `dilation`-th frame, reward update
         sample_distribution = decay * sample_distribution (+ uf * gain on the last trained blocks).
@@ -58,6 +61,12 @@ class Adapter(object):
             import torch.distributed as dist
             self.dist = dist
             self.world = dist.get_world_size(process_group)
+        # shared FULL step: all-reduce the estimator / context gradients while the pyramid's backward pass still runs (False: ONE
+        # collective behind the whole backward pass).  None = when there is a wire to hide (world > 1): on a 1-rank group the second graph
+        # boundary + the extra stream hand-overs cost ~0.1 ms and hide nothing (profiles/r03_experiments.txt #11).
+        if early_reduce is None:
+            early_reduce = self.world > 1
+        self.early_reduce = bool(early_reduce) and shared_model and mode == "FULL" and hasattr(self.eng, "pyramid_range")
         dev = self.eng.left.device
         self.cuda = dev.type == "cuda"
         self.use_graph = use_graph and self.cuda
@@ -95,6 +104,8 @@ class Adapter(object):
             eng = self.eng
             gs = 1.0 / self.world
             parts = ("grad", "update") if self.shared else ("all",)
+            if self.shared and key == "FULL" and self.early_reduce:
+                parts = ("grad_split", "update")
             plans = []
             for part in parts:
                 if key == "NONE":
@@ -104,10 +115,11 @@ class Adapter(object):
                 else:
                     p = eng.build_plan("MAD", lr=self.lr, grad_scale=gs, part=part, blocks=[self.blocks[i] for i in key],
                                        optimizer=self.optimizer)
-                if self.use_graph and p.n > 0:
-                    with torch.cuda.stream(self.stream):
-                        p.capture(self.lib, self.stream.cuda_stream)
-                plans.append(p)
+                for q in (p if isinstance(p, list) else [p]):
+                    if self.use_graph and q.n > 0:
+                        with torch.cuda.stream(self.stream):
+                            q.capture(self.lib, self.stream.cuda_stream)
+                    plans.append(q)
             self._plans[key] = plans
         return self._plans[key]
 
@@ -142,10 +154,21 @@ class Adapter(object):
             if proxy is not None:
                 eng.proxy.copy_(_as(proxy, eng.proxy), non_blocking=True)
             plans[0].launch(self.lib, sh)
-            if self.shared:
+            if self.shared and len(plans) == 3:
+                # FULL, two pieces: plans = [forward + loss + estimator / context backward, pyramid backward, update].  The first
+                # collective is asynchronous: RCCL's stream waits for plans[0], ours goes on with the pyramid.
+                P = eng.params
+                lo = eng.pyramid_range()[1]
+                first = self.dist.all_reduce(P.g_loss[lo:P.total + 4], group=self.pg, async_op=True)
+                plans[1].launch(self.lib, sh)
+                self.dist.all_reduce(P.g_loss[0:lo], group=self.pg)
+                first.wait()
+                self.collectives_last_step = 2
+                plans[2].launch(self.lib, sh)
+            elif self.shared:
                 # ONE collective per contiguous gradient range; the loss result sits right behind the gradient buffer
-                # (engine.Params.g), so in FULL mode gradients + loss travel together.  Sums; the 1/world factors are applied
-                # by the momentum kernel (grad_scale) and on the host (loss).
+                # (engine.Params.g), so gradients + loss travel together when the last range ends there.  Sums; the 1/world factors
+                # are applied by the momentum kernel (grad_scale) and on the host (loss).
                 P = eng.params
                 rng = P.ranges(self._train_vars(key))
                 tail = (P.total, 4)

@@ -62,8 +62,7 @@ def ctx_name(j):
 
 def madnet_manifest(radius_d=2, stride=1):
     """Ordered [(variable name, shape)] -- flat-buffer order.  Names are the TF variable names of
-    the reference graph; order groups the variables of each MAD block
-    (block_config/MadNet_full.json) contiguously."""
+    the reference graph."""
     D = 2 * radius_d // stride + 1
     out = []
 
@@ -71,10 +70,13 @@ def madnet_manifest(radius_d=2, stride=1):
         out.append((base + "/weights", (k, k, ci, co)))
         out.append((base + "/biases", (co,)))
 
-    pyr_of_level = {2: (1, 2, 3, 4), 3: (5, 6), 4: (7, 8), 5: (9, 10), 6: (11, 12)}
+    # the twelve pyramid layers first, then estimator by estimator (the context network behind estimator 2): the backward pass
+    # finishes the estimator / context gradients BEFORE it starts on the pyramid, so [estimators | loss] is one contiguous range whose
+    # all-reduce overlaps the pyramid's backward pass in the shared-model mode, and the pyramid is the other (adapter.py).  A MAD
+    # block = its pyramid layers (contiguous) + its estimator (contiguous): two ranges.
+    for i in range(1, 13):
+        conv(pyr_name(i), 3, PYR[i - 1][0], PYR[i - 1][1])
     for k in (2, 3, 4, 5, 6):
-        for i in pyr_of_level[k]:
-            conv(pyr_name(i), 3, PYR[i - 1][0], PYR[i - 1][1])
         cin = PYR[FEAT[k] - 1][1] + D + (0 if k == 6 else 1)
         for j, co in enumerate(EST):
             conv(est_name(k, j + 1), 3, cin, co)
@@ -764,6 +766,11 @@ class MadNetEngine(object):
                     ops.resize_bwd(lib, self.du[k], self.V[k + 1], self.dV[k + 1], self.Hp // s_up, self.Wp // s_up,
                                    mul=20.0 / s_up, mode=0, accumulate=acc_flag(("V", k + 1)))
         # ---- pyramid towers (batch 2B, shared weights) ---------------------------------------------
+        # split point of build_plan(part='grad_split'): every gradient of the estimators / the context network is final here (their
+        # batches were flushed level by level), the pyramid's come after -- the shared-model step all-reduces the first range while
+        # the second is still being computed
+        if hasattr(r, "cut"):
+            r.cut()
         if scatter_pending[0]:
             r.join_lanes_next = 1 << SCATTER_LANE          # the right-tower scatters must have landed; the filter-gradient lanes keep going
         top = None
@@ -839,6 +846,13 @@ class MadNetEngine(object):
     def all_vars(self):
         return [n for n, _ in self.params.manifest]
 
+    def pyramid_range(self):
+        """(offset, count) of the pyramid's variables in the flat buffers: they lead the layout (madnet_manifest), the estimators and the
+        context network follow -- the two pieces of the shared-model all-reduce."""
+        rng = self.params.ranges([n for n, _ in self.params.manifest if "pyramid" in n])
+        assert len(rng) == 1 and rng[0][0] == 0
+        return rng[0]
+
     def build_plan(self, mode, lr=1e-4, block_vars=None, block_level=None, grad_scale=1.0, update=True,
                    blocks=None, part="all", loss_weights=None, max_disp=192.0, optimizer="momentum"):
         """mode: 'NONE' | 'FULL' | 'MAD' | 'TRAIN' (offline training step of Train.py: multi-scale supervised mean_l1 against
@@ -847,7 +861,8 @@ class MadNetEngine(object):
         LEVELS, 2 = context output); block_level/block_vars is the single-block shorthand.
         optimizer: 'momentum' (Stereo_Online_Adaptation.py:122) | 'adam' (the live demo, Demo/demo_model.py:164) for FULL / MAD.
         part: 'all' | 'grad' (everything up to the gradients) | 'update' (momentum apply only) -- the
-        split lets a gradient all-reduce (shared-model multi-GPU mode) sit between two plans."""
+        split lets a gradient all-reduce (shared-model multi-GPU mode) sit between two plans; 'grad_split' returns the 'grad' part as
+        a LIST of two plans cut where the pyramid's backward pass starts (see madnet_manifest)."""
         r = Recorder()
         self.wsa.reset()
         self._fresh = set()
@@ -893,7 +908,7 @@ class MadNetEngine(object):
         record_update = self.record_update if optimizer == "momentum" else self.record_update_adam
         if blocks is None and block_level is not None:
             blocks = [(block_level, block_vars)]
-        do_grad = part in ("all", "grad")
+        do_grad = part in ("all", "grad", "grad_split")
         do_upd = update and part in ("all", "update")
         if mode == "NONE":
             if do_grad:
@@ -938,7 +953,7 @@ class MadNetEngine(object):
                     record_update(r, bv, lr, grad_scale=grad_scale)
         else:
             raise ValueError("unknown mode %r" % (mode,))
-        return r.compile()
+        return r.compile_parts() if part == "grad_split" else r.compile()
 
     # convenience: eager single forward -------------------------------------------------------
     def set_inputs(self, left, right, gt=None, proxy=None):

@@ -34,6 +34,13 @@ class Recorder(object):
         self.wgrad_group_max_m = 0  # grouped filter-gradient launches: pixel cap of this plan's layers (0 = library default)
         self.work = {}              # op index -> (algorithmic flops, bytes) of the multi-layer ops (a streamed filter-gradient batch)
         self._pending_work = [0.0, 0.0]
+        self.cuts = []              # op indices where compile_parts() splits the recording (a collective goes between the parts)
+
+    def cut(self):
+        """Mark a split point: every op recorded so far forms one part (mh_plan_run joins the side lanes at the end of a plan, so
+        a part ends with all of its work ordered before whatever the caller enqueues next on the stream)."""
+        if len(self.ops) and (not self.cuts or self.cuts[-1] != len(self.ops)):
+            self.cuts.append(len(self.ops))
 
     # -- helpers ---------------------------------------------------------------------------
     def _op(self, kind, ints=(), floats=(), ptrs=(), n=0):
@@ -211,6 +218,17 @@ class Recorder(object):
         p = Plan(arr, len(self.ops), self.keep, dict(self.stats))
         p.work = dict(self.work)
         return p
+
+    def compile_parts(self):
+        """One Plan per section between cut() marks (the work statistics stay with the first)."""
+        bounds = [0] + [c for c in self.cuts if 0 < c < len(self.ops)] + [len(self.ops)]
+        parts = []
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            arr = (_ffi.Op * (b - a))(*self.ops[a:b])
+            p = Plan(arr, b - a, self.keep, dict(self.stats) if not parts else {})
+            p.work = {k - a: v for k, v in self.work.items() if a <= k < b}
+            parts.append(p)
+        return parts
 
 
 class Plan(object):

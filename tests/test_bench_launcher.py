@@ -38,3 +38,18 @@ def test_bench_rejects_world_size_mismatch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--device", "cpu", "--steps", "1"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_bench_shared_model_two_ranks_two_pieces():
+    """--shared-model over 2 gloo ranks: the step all-reduces [estimators + context + loss] asynchronously and [pyramid] behind it, and the
+    line carries the collective's own time and the byte counts of the two pieces."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--device", "cpu", "--height", "60", "--width", "100",
+                        "--steps", "1", "--warmup", "0", "--repeats", "1", "--shared-model", "--min-region-seconds", "0"], env=_env(),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    sm = d["shared_model"]
+    assert d["n_gpus"] == 2 and len(sm["pieces_bytes"]) == 2 and sm["collective_ms_alone"] > 0
+    assert sm["pieces_bytes"][0] > 2 * sm["pieces_bytes"][1] and sum(sm["pieces_bytes"]) == 4 * (3826088 + 4)

@@ -863,3 +863,40 @@ def test_wgrad_reduce_small_gradient_many_splits(backend):
         for dst, ref in refs:
             want = ref + (ref if acc else 0)           # second pass: dst (= ref after the first) + ref
             assert (dst.cpu().double() - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("case", [(1, 12, 20, 32, 1, False), (2, 9, 13, 32, 2, True), (1, 6, 20, 12, 1, True), (1, 24, 80, 64, 1, False)])
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_conv_k1_dgrad_kernel(backend, case, mode):
+    """conv_k1_dgrad_kernel: input gradient of a single-output-channel 3x3 conv (the disparity heads; mode 1 with K = 1), exact fp32 in every
+    arithmetic mode, with the accumulating / leaky-mask epilogue and the bf16 shadow of dx for the streamed filter gradient."""
+    B, H, W, Ci, dil, acc = case
+    dev = backend.device
+    w = _rand((3, 3, Ci, 1), 912, dev, 0.3)
+    gz = _rand((B, H, W, 1), 914, dev)
+    old = _rand((B, H, W, Ci), 915, dev)
+    mref = _rand((B, H, W, Ci), 916, dev)
+    ld = Ci + 4                                         # a concat neighbour behind the channels: must stay untouched
+    dxb, dxv = _padded(old, ld)
+    dxb[..., Ci:] = 7.0
+    mb, mv = _padded(mref, ld)
+    sh = ops.Shadow(B, H, W, Ci, dev)
+    sh.t.fill_(3.0)
+    ops.PRECISION_BWD = 1 if mode == "bf16" else None
+    try:
+        ops.conv2d_dgrad(backend.lib, ops.view(gz), w, dxv, dil=dil, accumulate=acc, mask_ref=mv, mask_alpha=0.2, shadow=sh)
+    finally:
+        ops.PRECISION_BWD = None
+    name = backend.lib.last_kernel().decode()
+    backend.sync()
+    assert "conv_k1_dgrad_kernel" in name, name
+    xr = torch.zeros(B, H, W, Ci, dtype=torch.float64, requires_grad=True)
+    yr = T.conv2d(xr, w.cpu().double(), None, dilation=dil, alpha=1.0)
+    (gx,) = torch.autograd.grad(yr, [xr], gz.cpu().double())
+    exp = (((old.cpu().double() if acc else 0.0) + gx) * torch.where(mref.cpu() > 0, 1.0, 0.2)).float()
+    sc = max(1.0, gx.abs().max().item())
+    got = dxb[..., :Ci].cpu()
+    assert (got - exp).abs().max().item() <= 3e-6 * sc
+    assert (dxb[..., Ci:] == 7.0).all()
+    assert torch.equal(sh.t[..., :Ci].cpu(), got.to(torch.bfloat16))             # RNE of exactly what went to dx
+    assert (sh.t[..., Ci:].cpu().float() == 3.0).all()                              # the shadow's channel padding is the caster's business

