@@ -1176,6 +1176,7 @@ static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, co
     int rc;
     if (conv_n1_ok(a)) rc = launch_conv_n1(a, hs);
     else if (conv_k1_dgrad_ok(a)) { a.shadow = (unsigned short*)out_shadow; a.shadow_done = 1; rc = launch_conv_k1_dgrad(a, hs); }
+    else if (mh_conv_rows_ok(a)) { a.shadow = (unsigned short*)out_shadow; a.shadow_done = 1; rc = mh_conv_rows_launch(a, hs); }
     else if (conv_thin_ok(a)) rc = launch_conv_thin(a, hs);
     else if (mh_conv_bank_small_ok(a)) { a.shadow = (unsigned short*)out_shadow; a.shadow_done = 1; rc = mh_conv_bank_small_launch(a, hs); }
     else if (mh_conv_patch_ok(a)) { a.shadow = (unsigned short*)out_shadow; a.shadow_done = 1; rc = mh_conv_patch_launch(a, hs); }

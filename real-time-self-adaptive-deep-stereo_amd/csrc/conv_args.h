@@ -38,6 +38,9 @@ extern "C" int mh_tune_conv_patch(int mode);
 // conv_patch.hip: fragment-bank kernel of the small layers (a.wb = the bank mh_pack_weights wrote for this mode / precision)
 bool mh_conv_bank_small_ok(const ConvArgs& a);
 int mh_conv_bank_small_launch(ConvArgs& a, hipStream_t s);     // a.M < 0: attribute set-up only
+// conv_rows.hip: row-streaming kernel of the thin 3x3 layers at 1/2 resolution (<= 16 input channels, stride 1)
+bool mh_conv_rows_ok(const ConvArgs& a);
+int mh_conv_rows_launch(ConvArgs& a, hipStream_t s);
 // conv_direct.hip: LDS-free kernel of the small layers (wt = k-fastest transposed filter bank for the forward pass, may be null)
 bool mh_conv_direct_ok(const ConvArgs& a, const float* wt);
 int mh_conv_direct_launch(ConvArgs& a, const float* wt, hipStream_t s);

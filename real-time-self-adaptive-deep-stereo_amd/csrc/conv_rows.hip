@@ -1,0 +1,303 @@
+// conv_rows.hip -- row-streaming 3x3 conv kernel for the thin layers at 1/2 resolution: MADNet pyramid conv1 (3 -> 16, stride 2, forward) and conv2
+// (16 -> 16 at 192x640 x 2 towers, forward and input gradient); Nets/MadNet.py:56-66, sharedLayers.py:54-92.
+//
+// Those layers are 0.3-1.1 GFLOP over 31-39 MB of activations: 6-8 us of HBM time, no MFMA time to speak of -- and 22-31 us on the tiled kernels, whose
+// workgroups re-gather every input pixel nine times through L2 and pay a stage / barrier / epilogue round trip per 128-pixel tile.
+// Here nothing is staged and nothing is shared:
+//   * a WAVE owns a 32-pixel column strip and walks down R output rows.  Roles are swapped against the other kernels: the FILTER BANK is the A
+//     operand (v_mfma_f32_32x32x16_bf16: 32 output channels x 16 input channels of one tap), converted once per wave and kept in registers for
+//     all 9 taps (36 VGPRs, 72 with the lo plane of the split-bf16 forward mode); the PIXELS are the B operand -- lane l holds 8 channels of pixel
+//     l & 31, i.e. 32 contiguous bytes of the NHWC row, loaded straight from global memory by two 16-byte buffer loads (out-of-range columns and
+//     rows read zeros: no border code);
+//   * stride 1: an input row is loaded ONCE per wave as three column-shifted fragments (the shifts hit L1) and feeds the three output rows it
+//     belongs to: three accumulators rotate through the walk (static register indices: the row loop is unrolled), the loads run two rows ahead of
+//     the 9 (27) MFMAs.  Stride 2: two new input rows per output row, the third stays in registers as the next row's first;
+//   * with the swap the accumulator layout is pixel-per-lane, 4 CONSECUTIVE CHANNELS per register quad: bias / leaky / accumulate / mask epilogue on
+//     float4s, 16-byte stores, bf16 shadow store for the streamed filter gradient -- no LDS transpose;
+//   * every load and store of the walk is UNCONDITIONAL (out-of-range offset into a buffer descriptor instead of a branch): a memory access behind a
+//     branch costs hipcc its count of what is in flight -- loaded registers become phi copies behind s_waitcnt vmcnt(0), a join takes the smaller
+//     store count -- and the walk then waits for its own stores at every row (22 -> 15-18 us, profiles/r03_experiments.txt #13).
+// LDS is used once, to hand the fp32 filter bank to the waves in fragment order.  Same arithmetic as the other kernels of the same precision code:
+// operands rounded to bf16 (precision 1) or split into hi + lo bf16 with 3 MFMAs per product (precision 2, forward), fp32 accumulation; another
+// summation order.
+#include "conv_args.h"
+#include <stdlib.h>
+#include <atomic>
+
+namespace {
+
+template <bool X3>
+__device__ __forceinline__ void rows_cvt(const float4& a, const float4& b, u32x4& hi, u32x4& lo) {
+    if (X3) {
+        unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+        mh_split_bf16x2(a.x, a.y, h0, l0); mh_split_bf16x2(a.z, a.w, h1, l1);
+        mh_split_bf16x2(b.x, b.y, h2, l2); mh_split_bf16x2(b.z, b.w, h3, l3);
+        hi = (u32x4){h0, h1, h2, h3}; lo = (u32x4){l0, l1, l2, l3};
+    } else {
+        hi = (u32x4){mh_pack_bf16(a.x, a.y), mh_pack_bf16(a.z, a.w), mh_pack_bf16(b.x, b.y), mh_pack_bf16(b.z, b.w)};
+    }
+}
+
+// p.mode 0: out = conv(in, w) ; p.mode 1: out = conv2d_backprop_input (stride 1: the same walk with the taps flipped and the bank transposed).
+// S = 2: the forward pass of the down-sampling layers (conv1 3 -> 16, conv3 16 -> 32): an output row takes input rows 2y - pad .. + 2, two new ones
+// per step (the third is the next step's first and stays in registers), lane pixels two apart.
+// EPI: the epilogue reads the old output (accumulate) and / or a leaky-gradient mask; those loads are issued BEFORE the next row's prefetch so that
+// waiting for them does not drain it.
+// NQ: channel quads per lane that exist (2: <= 16 output channels, 4: <= 32) -- compile time, so that no all-out-of-range store is issued.
+template <int S, bool X3, bool EPI, int NQ>
+__global__ __launch_bounds__(256) void conv_rows_kernel(ConvArgs p, int R, int strips, int rblocks, unsigned mulK, unsigned mulN) {
+    // filter bank -> LDS in A-fragment order, zero padded: sA[tap][output channel m < 32][input channel kk < 16].  forward: HWIO w[t][kk][m] ;
+    // input gradient: taps flipped and the bank transposed, w[8 - t][m][kk] (m = input channel of the forward conv)
+    __shared__ __attribute__((aligned(16))) float sA[9 * 32 * 16];
+    __shared__ __attribute__((aligned(16))) float sBias[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int unit = blockIdx.x * 4 + wave;                    // (image, row block, strip), strips fastest
+    const bool active = unit < p.B * rblocks * strips;          // (a spare wave of the last workgroup: its loads read zeros, it leaves after the barrier)
+    const int strip = unit % strips;
+    const int t2 = unit / strips;
+    const int rb = t2 % rblocks, b = t2 / rblocks;
+    const int x0 = strip * 32, r0 = rb * R;
+    const int r1 = min(r0 + R, p.Ho);
+    const int lp = lane & 31, lh = lane >> 5;
+
+    const __amdgpu_buffer_rsrc_t rs_in = mh_make_rsrc(p.in, p.in_bytes);
+    // byte offset of (row, pixel S * (x0 + lp) + dx - pad, channel 8 * lh) ; K <= 8: the upper half-wave has no channels
+    const bool kok = 8 * lh < p.K;
+    auto row_off = [&](int r, int dx) -> int {
+        const int x = S * (x0 + lp) + dx - p.pad_l;
+        const bool ok = active && kok && (unsigned)r < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
+        return ok ? (((b * p.Hi + r) * p.Wi + x) * p.in_ld + 8 * lh) * 4 : MH_OOB;
+    };
+    // K % 4 != 0 (the image layer: 3 channels in a 4-float pixel): whatever sits in the padding lanes of the last group must not meet the MFMA
+    const int ktail = p.K & 3;
+    auto load_row = [&](float4 (&dst)[3][2], int r) {
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int o = row_off(r, dx);
+            dst[dx][0] = mh_buf_load4(rs_in, o);
+            dst[dx][1] = mh_buf_load4(rs_in, (o == MH_OOB || 8 * lh + 4 >= p.K) ? MH_OOB : o + 16);
+        }
+    };
+    auto cvt_row = [&](float4 (&src)[3][2], u32x4* Bh, u32x4* Bl) {
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            if (ktail) {            // (wave-uniform; K < 8 here: only the first group carries channels)
+                float4& v = src[dx][0];
+                if (ktail < 2) v.y = 0.f;
+                if (ktail < 3) v.z = 0.f;
+                v.w = 0.f;
+            }
+            u32x4 lo = {0u, 0u, 0u, 0u};
+            rows_cvt<X3>(src[dx][0], src[dx][1], Bh[dx], lo);
+            Bl[dx] = lo;
+        }
+    };
+    float4 raw[3][2];
+    // the first rows are on their way while the filter bank is staged
+    float4 rawb[3][2];
+    if constexpr (S == 1) { load_row(raw, r0 - 1); load_row(rawb, r0); }
+    else load_row(raw, 2 * r0 - p.pad_t);
+
+    for (int i = tid; i < 9 * 32 * 16 / 4; i += 256) reinterpret_cast<float4*>(sA)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    // coalesced read of the bank as it lies in memory, scattered into fragment order (mode 0: source index (t*K + kk)*N + m ; mode 1: source tap
+    // 8 - t, index (t'*N + m)*K + kk): 9 independent loads per thread, one wait
+    const int nwt = 9 * p.K * p.N;                    // <= 4608
+    {
+        const __amdgpu_buffer_rsrc_t rs_w = mh_make_rsrc(p.w, p.w_bytes);
+        float wv[18];
+#pragma unroll
+        for (int u = 0; u < 18; ++u) { const int j = tid + 256 * u; wv[u] = mh_buf_load1(rs_w, j < nwt ? j * 4 : MH_OOB); }
+#pragma unroll
+        for (int u = 0; u < 18; ++u) {
+            const int j = tid + 256 * u;
+            // j / K, j / N by multiplication (mul = ceil(2^32 / d) from the host: exact for j < 2^16)
+            int t, m, kk;
+            if (p.mode == 0) { const int q = (int)__umulhi((unsigned)j, mulN); m = j - q * p.N; t = (int)__umulhi((unsigned)q, mulK); kk = q - t * p.K; }
+            else { const int q = (int)__umulhi((unsigned)j, mulK); kk = j - q * p.K; const int tt = (int)__umulhi((unsigned)q, mulN); m = q - tt * p.N; t = 8 - tt; }
+            if (j < nwt) sA[(t * 32 + m) * 16 + kk] = wv[u];
+        }
+    }
+    if (tid < 32) sBias[tid] = (p.bias && tid < p.N) ? p.bias[tid] : 0.f;
+    __syncthreads();
+    if (!active) return;
+
+    // ---- A fragments: row m = output channel (lane & 31), k = 8 * (lane >> 5) + j = input channel of the tap: 32 contiguous bytes of sA -------
+    u32x4 Ah[9], Al[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float4 v0 = *reinterpret_cast<const float4*>(sA + (t * 32 + lp) * 16 + 8 * lh);
+        const float4 v1 = *reinterpret_cast<const float4*>(sA + (t * 32 + lp) * 16 + 8 * lh + 4);
+        u32x4 lo = {0u, 0u, 0u, 0u};
+        rows_cvt<X3>(v0, v1, Ah[t], lo);
+        Al[t] = lo;
+    }
+
+    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto mac = [&](f32x16& acc, int dy, const u32x4* Bh, const u32x4* Bl) {
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int t = dy * 3 + dx;
+            acc = mh_mfma_bf16_32(Ah[t], Bh[dx], acc);
+            if (X3) {
+                acc = mh_mfma_bf16_32(Ah[t], Bl[dx], acc);
+                acc = mh_mfma_bf16_32(Al[t], Bh[dx], acc);
+            }
+        }
+    };
+    // epilogue of output row y: lane = pixel x0 + lp, register quad q = channels 8q + 4 lh .. +3
+    // Every access goes through a descriptor with an out-of-range offset for the lanes / channel groups that do not exist: straight-line code,
+    // so the compiler can count the outstanding stores and the next row's loads stay in flight across the epilogue.
+    const __amdgpu_buffer_rsrc_t rs_out = mh_make_rsrc(p.out, p.out_bytes);
+    const __amdgpu_buffer_rsrc_t rs_mask = mh_make_rsrc(p.mask_ref, p.mask_ref ? p.mask_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_sh = mh_make_rsrc(p.shadow, p.shadow ? (unsigned)p.M * (unsigned)p.shadow_ld * 2u : 0u);
+    float4 oldv[NQ], mkv[NQ];
+    auto epi_load = [&](int y) {
+        if (!EPI) return;
+        const int x = x0 + lp;
+        const int m = (b * p.Ho + y) * p.Wo + x;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int n = 8 * q + 4 * lh;
+            const bool ok = y >= 0 && x < p.Wo && n < p.N;
+            oldv[q] = mh_buf_load4(rs_out, (ok && p.accumulate) ? (m * p.out_ld + n) * 4 : MH_OOB);
+            mkv[q] = mh_buf_load4(rs_mask, ok ? (m * p.mask_ld + n) * 4 : MH_OOB);
+        }
+    };
+    auto store_row = [&](const f32x16& acc, int y) {
+        const int x = x0 + lp;
+        const int m = (b * p.Ho + y) * p.Wo + x;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int n = 8 * q + 4 * lh;
+            const bool ok = y >= 0 && x < p.Wo && n < p.N;
+            float4 v = make_float4(acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            const float4 bv = *reinterpret_cast<const float4*>(sBias + n);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            if (p.alpha != 1.0f) {
+                v.x = v.x > 0.f ? v.x : p.alpha * v.x; v.y = v.y > 0.f ? v.y : p.alpha * v.y;
+                v.z = v.z > 0.f ? v.z : p.alpha * v.z; v.w = v.w > 0.f ? v.w : p.alpha * v.w;
+            }
+            if (EPI) {
+                v.x += oldv[q].x; v.y += oldv[q].y; v.z += oldv[q].z; v.w += oldv[q].w;          // (zeros without accumulate)
+                if (p.mask_ref) {
+                    const float4 mk = mkv[q];
+                    v.x *= (mk.x > 0.f || n + 0 < p.mask_c0 || n + 0 >= p.mask_c1) ? 1.0f : p.mask_alpha;
+                    v.y *= (mk.y > 0.f || n + 1 < p.mask_c0 || n + 1 >= p.mask_c1) ? 1.0f : p.mask_alpha;
+                    v.z *= (mk.z > 0.f || n + 2 < p.mask_c0 || n + 2 >= p.mask_c1) ? 1.0f : p.mask_alpha;
+                    v.w *= (mk.w > 0.f || n + 3 < p.mask_c0 || n + 3 >= p.mask_c1) ? 1.0f : p.mask_alpha;
+                }
+            }
+            mh_buf_store4(rs_out, ok ? (m * p.out_ld + n) * 4 : MH_OOB, v);
+            mh_buf_store2(rs_sh, ok ? (m * p.shadow_ld + n) * 2 : MH_OOB, mh_pack_bf16(v.x, v.y), mh_pack_bf16(v.z, v.w));
+        }
+    };
+
+    if constexpr (S == 1) {
+        // ---- the walk: input rows r0 - 1 .. r1 (pad 1); input row r is tap row 0 of output row r + 1, 1 of r, 2 of r - 1 ---------------------
+        // one step: convert the loaded row, start the next row's loads, 3 x 3 (x 3) MFMAs, store the output row the step completed
+        // the loads run TWO rows ahead (two register buffers, alternating): one row of MFMAs is too short to cover the HBM latency
+        auto step = [&](f32x16& aNew, f32x16& aMid, f32x16& aOld, float4 (&buf)[3][2], int r) {
+            u32x4 Bh[3], Bl[3];
+            cvt_row(buf, Bh, Bl);
+            if (EPI) __builtin_amdgcn_sched_barrier(0);      // the row's loads are consumed BEFORE anything new is issued (else the wait covers the new loads too)
+            // (unconditional on purpose -- a row index of -1 reads zeros: loads under a branch turn their destination registers into phi copies
+            //  that hipcc resolves with moves behind an s_waitcnt vmcnt(0), i.e. no prefetch at all)
+            epi_load(r - 1 >= r0 ? r - 1 : -1);
+            load_row(buf, r + 2 <= r1 ? r + 2 : -1);
+            if (r + 1 < r1) { aNew = zero16; mac(aNew, 0, Bh, Bl); }
+            if (r >= r0 && r < r1) mac(aMid, 1, Bh, Bl);
+            if (r - 1 >= r0) mac(aOld, 2, Bh, Bl);
+            store_row(aOld, r - 1 >= r0 ? r - 1 : -1);          // (row -1: every offset out of range.  Unconditional for the same reason as the loads: behind
+                                                                //  a branch join hipcc falls back to the smaller of the two outstanding-store counts)
+        };
+        f32x16 a0 = zero16, a1 = zero16, a2 = zero16;
+        // output row y lives in a[(y - r0) % 3]: at input row r (i = r - r0 + 1): new = y = r + 1 -> (i) % 3, mid -> (i - 1) % 3, old -> (i - 2) % 3;
+        // row buffer i % 2
+        for (int r = r0 - 1; r <= r1; r += 6) {
+            step(a0, a2, a1, raw, r);                    // i = 0: new -> a0 ; mid = row r0 - 1 (outside) ; old = outside
+            if (r + 1 <= r1) step(a1, a0, a2, rawb, r + 1);
+            if (r + 2 <= r1) step(a2, a1, a0, raw, r + 2);
+            if (r + 3 <= r1) step(a0, a2, a1, rawb, r + 3);
+            if (r + 4 <= r1) step(a1, a0, a2, raw, r + 4);
+            if (r + 5 <= r1) step(a2, a1, a0, rawb, r + 5);
+        }
+    } else {
+        // ---- stride 2: output row y <- input rows 2y - pad_t + {0, 1, 2} ---------------------------------------------------------------------
+        u32x4 Ph[3], Pl[3], Qh[3], Ql[3], Th[3], Tl[3];
+        cvt_row(raw, Ph, Pl);
+        load_row(raw, 2 * r0 - p.pad_t + 1);
+        load_row(rawb, 2 * r0 - p.pad_t + 2);
+        for (int y = r0; y < r1; ++y) {
+            cvt_row(raw, Qh, Ql);
+            cvt_row(rawb, Th, Tl);
+            if (EPI) __builtin_amdgcn_sched_barrier(0);
+            epi_load(y);
+            load_row(raw, y + 1 < r1 ? 2 * y + 3 - p.pad_t : -1);
+            load_row(rawb, y + 1 < r1 ? 2 * y + 4 - p.pad_t : -1);
+            f32x16 acc = zero16;
+            mac(acc, 0, Ph, Pl); mac(acc, 1, Qh, Ql); mac(acc, 2, Th, Tl);
+            store_row(acc, y);
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) { Ph[dx] = Th[dx]; Pl[dx] = Tl[dx]; }
+        }
+    }
+}
+
+// minimum output pixels (B * H * W) of a layer for this kernel; 0 = off.  Default 65536: the 1/2-resolution layers (the thin tiles of the patch /
+// bank kernels keep the 32 -> 32 layers at 1/4 resolution)
+std::atomic<int> g_rows_minpix{-1};
+int rows_minpix() {
+    int v = g_rows_minpix.load(std::memory_order_relaxed);
+    if (v < 0) { const char* e = getenv("MH_CONV_ROWS_MINPIX"); v = e ? atoi(e) : 65536; g_rows_minpix.store(v, std::memory_order_relaxed); }
+    return v;
+}
+
+}  // namespace
+
+// 3x3 "SAME" layers with <= 16 input and <= 32 output channels (a multiple of 8), many pixels, bf16 or split-bf16 arithmetic: stride 1 (forward and
+// input gradient), stride 2 (forward)
+bool mh_conv_rows_ok(const ConvArgs& a) {
+    const int minpix = rows_minpix();
+    if (minpix <= 0) return false;
+    if (!(a.bf16 || (a.x3 && a.mode == 0))) return false;
+    if (!(a.kh == 3 && a.kw == 3 && a.dil == 1)) return false;
+    const bool s1 = a.stride == 1 && a.pad_t == 1 && a.pad_l == 1 && a.Hi == a.Ho && a.Wi == a.Wo && a.K % 4 == 0;
+    const bool s2 = a.stride == 2 && a.mode == 0 && a.pad_t >= 0 && a.pad_t <= 1 && a.pad_l >= 0 && a.pad_l <= 1 &&
+                    a.Ho == (a.Hi + 1) / 2 && a.Wo == (a.Wi + 1) / 2 && (a.K % 4 == 0 || a.K < 4);
+    if (!(s1 || s2)) return false;
+    if (a.ncls != 0 || a.K < 2 || a.K > 16 || a.N > 32 || a.N % 8 != 0 || !a.vecA || !a.vecC) return false;
+    if (a.x3 && (a.accumulate || a.mask_ref)) return false;        // (the split-bf16 instances have no registers left for the pre-loaded epilogue operands)
+    if ((int64_t)a.B * a.Ho * a.Wo * ((a.N + 31) / 32 * 32) * 2 >= (1ll << 31) - 64) return false;       // 32-bit offsets into the shadow
+    return (int64_t)a.B * a.Ho * a.Wo >= minpix;
+}
+
+int mh_conv_rows_launch(ConvArgs& a, hipStream_t s) {
+    // units = strips x row blocks x images; aim at ~2 waves per SIMD (2048 waves) with at least 4 rows per wave (stride 1: the 2 halo rows are
+    // re-loaded; stride 2: one of the 2R + 1).  Measured at 192x640x2 (profiles/r03_experiments.txt #13): R = 3 / 4 / 6 / 8 -> 22.5 / 18.0 / 20.8 / 20.6 us
+    const int strips = mh_cdiv(a.Wo, 32);
+    int R = 4;
+    while ((int64_t)a.B * strips * mh_cdiv(a.Ho, R) > 2048 && R < 16) ++R;
+    const int rblocks = mh_cdiv(a.Ho, R);
+    const int units = a.B * strips * rblocks;
+    const int grid = mh_cdiv(units, 4);
+    const bool epi = a.accumulate || a.mask_ref;
+    const unsigned mulK = (unsigned)(((1ull << 32) + a.K - 1) / a.K), mulN = (unsigned)(((1ull << 32) + a.N - 1) / a.N);
+#define MH_ROWS(Sv, X3v, EPIv)                                                                                                          \
+    { if (a.N <= 16) hipLaunchKernelGGL((conv_rows_kernel<Sv, X3v, EPIv, 2>), dim3(grid), dim3(256), 0, s, a, R, strips, rblocks, mulK, mulN);       \
+      else hipLaunchKernelGGL((conv_rows_kernel<Sv, X3v, EPIv, 4>), dim3(grid), dim3(256), 0, s, a, R, strips, rblocks, mulK, mulN); }
+    if (a.stride == 1) {
+        if (a.x3) MH_ROWS(1, true, false)
+        else if (epi) MH_ROWS(1, false, true)
+        else MH_ROWS(1, false, false)
+    } else {
+        if (a.x3) MH_ROWS(2, true, false)
+        else if (epi) MH_ROWS(2, false, true)
+        else MH_ROWS(2, false, false)
+    }
+#undef MH_ROWS
+    mh_note_kernel("conv_rows_kernel<%s,%s,s%d> R=%d grid %d", a.mode == 1 ? "dgrad" : "fwd", a.x3 ? "bf16x3" : "bf16", a.stride, R, grid);
+    return mh_check_launch("conv_rows");
+}
+
+extern "C" int mh_tune_conv_rows(int min_pixels) { return g_rows_minpix.exchange(min_pixels < 0 ? -1 : min_pixels); }

@@ -43,6 +43,16 @@ __device__ __forceinline__ float mh_buf_load1(__amdgpu_buffer_rsrc_t r, int byte
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
 }
 
+// stores through a descriptor: a lane whose offset is out of range (MH_OOB) stores nothing -- unconditional, straight-line epilogues whose
+// outstanding-store count the compiler can see (a store under a divergent branch makes every later s_waitcnt vmcnt conservative)
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void mh_buf_store4(__amdgpu_buffer_rsrc_t r, int byte_off, float4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, 0);
+}
+__device__ __forceinline__ void mh_buf_store2(__amdgpu_buffer_rsrc_t r, int byte_off, unsigned a, unsigned b) {
+    __builtin_amdgcn_raw_buffer_store_b64((u32x2){a, b}, r, byte_off, 0, 0);
+}
+
 #include <mh_bf16_intrin.h>     // bf16 pack + bf16 MFMA (angle brackets: the CPU emulator shadows this header)
 
 // XCD-aware, bijective remap of a linear workgroup id (8 XCDs; block b runs on XCD b%8):

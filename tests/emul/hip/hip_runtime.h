@@ -262,6 +262,18 @@ static inline emul_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_r
         if ((unsigned long long)off + 4ull * e + 4ull <= r.bytes) { unsigned x; memcpy(&x, r.base + off + 4 * e, 4); v[e] = x; }
     return v;
 }
+typedef unsigned int emul_u32x2 __attribute__((vector_size(8)));
+// stores: out-of-range elements are dropped (as the hardware does for a raw buffer)
+static inline void __builtin_amdgcn_raw_buffer_store_b128(emul_u32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
+    const unsigned off = (unsigned)voff + (unsigned)soff;
+    for (int e = 0; e < 4; ++e)
+        if ((unsigned long long)off + 4ull * e + 4ull <= r.bytes) { unsigned x = v[e]; memcpy((char*)r.base + off + 4 * e, &x, 4); }
+}
+static inline void __builtin_amdgcn_raw_buffer_store_b64(emul_u32x2 v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
+    const unsigned off = (unsigned)voff + (unsigned)soff;
+    for (int e = 0; e < 2; ++e)
+        if ((unsigned long long)off + 4ull * e + 4ull <= r.bytes) { unsigned x = v[e]; memcpy((char*)r.base + off + 4 * e, &x, 4); }
+}
 static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
     const unsigned off = (unsigned)voff + (unsigned)soff;
     unsigned x = 0;
@@ -269,6 +281,7 @@ static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc
     return x;
 }
 
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only used on wave-uniform values
 static inline void __builtin_amdgcn_sched_barrier(int) {}                 // scheduling hint only
 static inline void __builtin_amdgcn_s_waitcnt(int) {}                    // no asynchronous loads on the emulator

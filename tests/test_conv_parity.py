@@ -900,3 +900,142 @@ def test_conv_k1_dgrad_kernel(backend, case, mode):
     assert (dxb[..., Ci:] == 7.0).all()
     assert torch.equal(sh.t[..., :Ci].cpu(), got.to(torch.bfloat16))             # RNE of exactly what went to dx
     assert (sh.t[..., Ci:].cpu().float() == 3.0).all()                              # the shadow's channel padding is the caster's business
+
+
+ROWS_CASES = [   # (B, H, W, Cin, Cout): ragged strips (W % 32), ragged row blocks, one-row images, fewer channels than the MFMA tile
+    (1, 12, 64, 16, 16), (2, 9, 45, 16, 16), (1, 1, 33, 16, 16), (1, 2, 31, 8, 16), (1, 17, 70, 16, 32), (1, 5, 32, 12, 24), (1, 40, 100, 16, 16),
+]
+
+
+@pytest.mark.parametrize("what", ["fwd-bf16", "fwd-x3", "dgrad-bf16"])
+@pytest.mark.parametrize("case", ROWS_CASES)
+def test_conv_rows_kernel(backend, case, what):
+    """conv_rows_kernel (csrc/conv_rows.hip): the row-streaming kernel of the thin 3x3 stride-1 layers -- filter bank as the A operand in registers,
+    pixels as the B operand straight from global memory, three rotating accumulators.  Same operand rounding as the other kernels of the precision
+    code; compared with the fp64 oracle on identically rounded operands (bf16) / on the fp32 operands (split-bf16), and with the kernel the layer
+    takes otherwise.  Epilogues: bias + leaky + shadow (forward), accumulate + leaky mask + shadow (input gradient), a concat neighbour behind the
+    output channels."""
+    B, H, W, Ci, Co = case
+    dev = backend.device
+    w = _rand((3, 3, Ci, Co), 712, dev, 0.2)
+    b = _rand((Co,), 713, dev)
+    prev = backend.lib.tune_conv_rows(1)
+    try:
+        if what.startswith("fwd"):
+            x = _rand((B, H, W, Ci), 711, dev)
+            ld = Ci + 4
+            xb, xv = _padded(x, ld)
+            xb[..., Ci:] = float("nan")
+            x3 = what == "fwd-x3"
+            yb = torch.full((B, H, W, Co + 4), 5.0, device=dev)
+            yv = ops.View(yb, B, H, W, Co, Co + 4)
+            y0 = torch.full((B, H, W, Co), float("nan"), device=dev)
+            sh = ops.Shadow(B, H, W, Co, dev)
+            with ops.precision_scope("mixed" if x3 else "bf16"):
+                ops.conv2d_fwd(backend.lib, xv, w, b, yv, alpha=0.2, shadow=sh)
+                name = backend.lib.last_kernel().decode()
+                backend.lib.tune_conv_rows(0)
+                ops.conv2d_fwd(backend.lib, xv, w, b, ops.view(y0), alpha=0.2)
+                other = backend.lib.last_kernel().decode()
+            backend.sync()
+            assert "conv_rows_kernel<fwd,%s,s1>" % ("bf16x3" if x3 else "bf16") in name and "conv_rows" not in other, (name, other)
+            if x3:
+                ref = T.conv2d(x.cpu().double(), w.cpu().double(), b.cpu().double(), alpha=0.2).float()
+                tol = 4e-5
+            else:
+                ref = T.conv2d(_bf(x.cpu()).double(), _bf(w.cpu()).double(), b.cpu().double(), alpha=0.2).float()
+                tol = 2e-5
+            sc = max(1.0, ref.abs().max().item())
+            got = yb[..., :Co].cpu()
+            assert (got - ref).abs().max().item() <= tol * sc
+            if not x3:            # (without a rows kernel the split-bf16 request falls back to exact fp32 on these shapes)
+                assert (got - y0.cpu()).abs().max().item() <= 2 * tol * sc
+            assert (yb[..., Co:] == 5.0).all()
+            assert torch.equal(sh.t[..., :Co].cpu(), got.to(torch.bfloat16))
+        else:
+            if Co > 16 or Ci % 8:
+                pytest.skip("input gradient: the contraction runs over the OUTPUT channels of the forward layer (<= 16 for this kernel)")
+            gz = _rand((B, H, W, Co), 714, dev)
+            old = _rand((B, H, W, Ci), 715, dev)
+            mref = _rand((B, H, W, Ci), 716, dev)
+            ldx = Ci + 4
+            zb, zv = _padded(gz, Co)
+            mb, mv = _padded(mref, ldx)
+            outs = []
+            sh = ops.Shadow(B, H, W, Ci, dev)
+            for rows in (True, False):
+                backend.lib.tune_conv_rows(1 if rows else 0)
+                dxb, dxv = _padded(old, ldx)
+                dxb[..., Ci:] = 5.0
+                ops.PRECISION_BWD = 1
+                try:
+                    ops.conv2d_dgrad(backend.lib, zv, w, dxv, accumulate=True, mask_ref=mv, mask_alpha=0.2, shadow=(sh if rows else None))
+                finally:
+                    ops.PRECISION_BWD = None
+                name = backend.lib.last_kernel().decode()
+                assert ("conv_rows_kernel<dgrad,bf16,s1>" in name) == rows, name
+                backend.sync()
+                assert (dxb[..., Ci:] == 5.0).all()
+                outs.append(dxb[..., :Ci].cpu().clone())
+            xr = torch.zeros(B, H, W, Ci, dtype=torch.float64, requires_grad=True)
+            yr = T.conv2d(xr, _bf(w.cpu()).double(), None, alpha=1.0)
+            (gx,) = torch.autograd.grad(yr, [xr], _bf(gz.cpu()).double())
+            exp = ((old.cpu().double() + gx) * torch.where(mref.cpu() > 0, 1.0, 0.2)).float()
+            sc = max(1.0, gx.abs().max().item())
+            assert (outs[0] - exp).abs().max().item() <= 2e-5 * sc
+            assert (outs[0] - outs[1]).abs().max().item() <= 4e-5 * sc
+            assert torch.equal(sh.t[..., :Ci].cpu(), outs[0].to(torch.bfloat16))
+    finally:
+        backend.lib.tune_conv_rows(prev)
+
+
+ROWS_S2_CASES = [   # (B, H, W, Cin, Cout): even sizes (pad 0 / 1), odd sizes (pad 1 / 1), the image layer (3 channels in a 4-float pixel)
+    (1, 24, 64, 16, 32), (2, 18, 90, 16, 16), (1, 13, 35, 16, 32), (1, 20, 66, 3, 16), (2, 9, 33, 3, 16), (1, 2, 4, 8, 8),
+]
+
+
+@pytest.mark.parametrize("x3", [False, True], ids=["bf16", "x3"])
+@pytest.mark.parametrize("case", ROWS_S2_CASES)
+def test_conv_rows_kernel_stride2(backend, case, x3):
+    """conv_rows_kernel<.., s2>: forward pass of the down-sampling layers (conv1 3 -> 16 on the padded image, conv3 16 -> 32): two new input rows per
+    output row, the third stays in registers as the next row's first; TF 'SAME' padding for even and odd sizes; NaN in the padding channel of a
+    3-channel pixel must not reach the MFMA."""
+    B, H, W, Ci, Co = case
+    dev = backend.device
+    w = _rand((3, 3, Ci, Co), 722, dev, 0.2)
+    b = _rand((Co,), 723, dev)
+    x = _rand((B, H, W, Ci), 721, dev)
+    ld = (Ci + 3) // 4 * 4 if Ci < 4 else Ci + 4
+    xb, xv = _padded(x, ld)
+    xb[..., Ci:] = float("nan")
+    Ho, Wo, _, _ = ops.conv_geometry(H, W, 3, 3, 2, 1)
+    y = torch.full((B, Ho, Wo, Co), float("nan"), device=dev); y0 = torch.full((B, Ho, Wo, Co), float("nan"), device=dev)
+    sh = ops.Shadow(B, Ho, Wo, Co, dev)
+    prev = backend.lib.tune_conv_rows(1)
+    try:
+        if Ci < 4:
+            xb[..., Ci:] = 0.0                      # (the other kernels multiply the padding channel by a zero weight: keep it finite for them)
+        with ops.precision_scope("mixed" if x3 else "bf16"):
+            backend.lib.tune_conv_rows(0)
+            ops.conv2d_fwd(backend.lib, xv, w, b, ops.view(y0), stride=2, alpha=0.2)
+            other = backend.lib.last_kernel().decode()
+            backend.lib.tune_conv_rows(1)
+            if Ci < 4:
+                xb[..., Ci:] = float("nan")
+            ops.conv2d_fwd(backend.lib, xv, w, b, ops.view(y), stride=2, alpha=0.2, shadow=sh)
+            name = backend.lib.last_kernel().decode()
+        backend.sync()
+    finally:
+        backend.lib.tune_conv_rows(prev)
+    assert "conv_rows_kernel<fwd,%s,s2>" % ("bf16x3" if x3 else "bf16") in name and "conv_rows" not in other, (name, other)
+    if x3:
+        ref = T.conv2d(x.cpu().double(), w.cpu().double(), b.cpu().double(), stride=2, alpha=0.2).float()
+        tol = 4e-5
+    else:
+        ref = T.conv2d(_bf(x.cpu()).double(), _bf(w.cpu()).double(), b.cpu().double(), stride=2, alpha=0.2).float()
+        tol = 2e-5
+    sc = max(1.0, ref.abs().max().item())
+    assert (y.cpu() - ref).abs().max().item() <= tol * sc
+    if not x3:
+        assert (y.cpu() - y0.cpu()).abs().max().item() <= 2 * tol * sc
+    assert torch.equal(sh.t[..., :Co].cpu(), y.cpu().to(torch.bfloat16))
