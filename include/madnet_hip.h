@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 9
+#define MH_ABI_VERSION 10
 
 /* status codes of every int-returning entry point: 0 = launched; a NEGATIVE code means an argument check failed and
  * nothing was launched or written; a POSITIVE value is the hipError_t of a failed launch / runtime call.
@@ -294,6 +294,29 @@ int mh_u8_to_f32(const uint8_t* in, float* out, int64_t n, void* stream);
 /* ---- preprocessing.pad_image (REFLECT, preprocessing.py:7-29) fused with the float cast
  *      and the channel padding 3 -> out_ld (extra channels zero) ------------------------ */
 /* out = in / div - sub  (MADNet: div=1, sub=0; DispNet._preprocess_inputs, DispNet.py:59-73: x/255 - 100/255) */
+/* Forward pass of a disparity head (mh_conv2d with N = 1, mode 0) that also stores its result at up to two more places, each with its own
+ * pixel stride (floats): a channel slot of a concatenated buffer (the context network's input, Nets/MadNet.py:155-157) and / or the buffer the
+ * next stage accumulates into (final = V2 + context, MadNet.py:171).  out2 / out3 may be NULL.  Saves the copy launches behind the head. */
+int mh_conv2d_head(const mh_conv_desc* d, const float* in, const float* w, const float* bias, float* out,
+                   float* out2, int32_t out2_ld, float* out3, int32_t out3_ld, void* stream);
+/* Backward front end of a disparity head (3x3 conv Cin -> 1, the last layer of a MADNet estimator: Nets/MadNet.py:95-117) in ONE launch:
+ *   dV = [kind 0] gradient of u = resize_x2(V) * mul w.r.t. V, from the finer level's coordinate gradient src0 (= mh_resize_bwd mode 0, not accumulating)
+ *        [kind 1] src0[pixel * src0_ld] + src1[pixel * src1_ld]   (either may be NULL)
+ *   -> dV (fp32, [B,H,W]) and, if dV_shadow != NULL, its bf16 shadow (pixel stride 32 halfs, channel 0);
+ *   dx (+)= conv2d_backprop_input(dV, w) * leaky'(mask_ref)  ([B,H,W,N], pixel stride dx_ld) and, if dx_shadow != NULL, its bf16 shadow
+ *   (pixel stride round_up(N, 32)).  Replaces mh_resize_bwd / mh_copy_channels + mh_conv2d(mode 1, K = 1) of the reference's per-level
+ *   gradient chain. */
+typedef struct mh_head_bwd_desc {
+    int32_t kind;                       /* 0 | 1 */
+    int32_t B, H, W, N;                 /* head size, input channels of the head conv */
+    int32_t Hr, Wr, cy, cx, Ho, Wo;     /* kind 0: the resize (as mh_resize_bwd: resized size, crop origin, size of the fine map src0) */
+    float mul;                          /* kind 0 */
+    int32_t src0_ld, src1_ld;           /* kind 1: pixel strides of the addends (floats) */
+    int32_t dx_ld, mask_ld, accumulate_dx;
+    float mask_alpha;
+} mh_head_bwd_desc;
+int mh_head_bwd(const mh_head_bwd_desc* d, const float* src0, const float* src1, float* dV, void* dV_shadow, const float* w,
+                float* dx, const float* mask_ref, void* dx_shadow, void* stream);
 int mh_pad_reflect(const float* in, float* out, int32_t B, int32_t H, int32_t W, int32_t C,
                    int32_t Hp, int32_t Wp, int32_t pad_t, int32_t pad_l, int32_t out_ld,
                    float div, float sub, void* stream);
@@ -378,7 +401,7 @@ enum { MH_OP_CONV = 1, MH_OP_WGRAD, MH_OP_CORR_FWD, MH_OP_CORR_BWD, MH_OP_WARP_F
        MH_OP_RESIZE_FWD, MH_OP_RESIZE_BWD, MH_OP_PAD_REFLECT, MH_OP_LOSS, MH_OP_METRICS,
        MH_OP_MOMENTUM, MH_OP_COPY_CH, MH_OP_LEAKY_BWD, MH_OP_FILL, MH_OP_BIAS_GRAD,
        MH_OP_WGRAD_PARTIAL, MH_OP_WGRAD_REDUCE, MH_OP_PROXY_LOSS, MH_OP_SUPERVISED_LOSS, MH_OP_ADAM, MH_OP_ADAM_ADVANCE,
-       MH_OP_RESIZE_IMAGE, MH_OP_LEVEL_FRONT, MH_OP_TRANSPOSE_W, MH_OP_PACK_W, MH_OP_CORR_WARP_BWD, MH_OP_SHADOW_CAST, MH_OP_WGRAD_STREAM };
+       MH_OP_RESIZE_IMAGE, MH_OP_LEVEL_FRONT, MH_OP_TRANSPOSE_W, MH_OP_PACK_W, MH_OP_CORR_WARP_BWD, MH_OP_SHADOW_CAST, MH_OP_WGRAD_STREAM, MH_OP_HEAD_BWD, MH_OP_HEAD_FWD };
 /* i[26] of every op is its scheduling word: low byte = lane (0 = the caller's stream; 1..MH_MAX_LANES-1 = side
  * streams owned by the library: the op is forked from lane 0 right before it, i.e. ordered after everything recorded so
  * far, and runs concurrently with the lane-0 ops that follow); MH_OP_JOIN = lane 0 first waits for all side lanes.

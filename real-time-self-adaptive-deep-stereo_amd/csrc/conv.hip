@@ -671,6 +671,8 @@ __global__ __launch_bounds__(256) void conv_n1_fwd_kernel(ConvArgs p) {
             float* dst = p.out + (int64_t)m * p.out_ld;
             if (p.accumulate) v += *dst;
             *dst = v;
+            if (p.out2) p.out2[(int64_t)m * p.out2_ld] = v;
+            if (p.out3) p.out3[(int64_t)m * p.out3_ld] = v;
         }
     }
 }
@@ -1079,8 +1081,9 @@ extern "C" int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w,
     return mh_conv2d_wt(d, in, w, nullptr, bias, out, mask_ref, stream);
 }
 
+struct HeadOuts { float* out2; int out2_ld; float* out3; int out3_ld; };
 static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, const float* wt, const void* wb, const float* bias,
-                      float* out, const float* mask_ref, void* stream, void* out_shadow = nullptr);
+                      float* out, const float* mask_ref, void* stream, void* out_shadow = nullptr, const HeadOuts* head = nullptr);
 int mh_shadow_cast_one(const float* src, int src_ld, int C, void* dst, int dst_ld, int64_t npix, hipStream_t s);      // wgrad_stream.hip
 #ifdef MH_PHASE_TIMING
 static unsigned long long* g_conv_dbg = nullptr;
@@ -1099,8 +1102,15 @@ extern "C" int mh_conv2d_sh(const mh_conv_desc* d, const float* in, const float*
     MH_REQUIRE(!out_shadow || (((uintptr_t)out_shadow) & 15u) == 0, MH_ERR_ALIGN, "mh_conv2d_sh: out_shadow must be 16-byte aligned");
     return conv_entry(d, in, w, nullptr, wb, bias, out, mask_ref, stream, out_shadow);
 }
+extern "C" int mh_conv2d_head(const mh_conv_desc* d, const float* in, const float* w, const float* bias, float* out,
+                              float* out2, int32_t out2_ld, float* out3, int32_t out3_ld, void* stream) {
+    MH_REQUIRE(d && d->N == 1 && d->mode == 0, MH_ERR_ARG, "mh_conv2d_head: a forward conv with ONE output channel");
+    MH_REQUIRE((!out2 || out2_ld >= 1) && (!out3 || out3_ld >= 1), MH_ERR_ARG, "mh_conv2d_head: pixel strides of the extra outputs must be >= 1");
+    const HeadOuts h{out2, out2_ld, out3, out3_ld};
+    return conv_entry(d, in, w, nullptr, nullptr, bias, out, nullptr, stream, nullptr, &h);
+}
 static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, const float* wt, const void* wb, const float* bias,
-                      float* out, const float* mask_ref, void* stream, void* out_shadow) {
+                      float* out, const float* mask_ref, void* stream, void* out_shadow, const HeadOuts* head) {
     MH_REQUIRE(d && in && w && out, MH_ERR_ARG, "mh_conv2d: null argument");
     MH_REQUIRE(d->B > 0 && d->Hi > 0 && d->Wi > 0 && d->Ho > 0 && d->Wo > 0 && d->K > 0 && d->N > 0,
                MH_ERR_ARG, "mh_conv2d: non-positive dimension");
@@ -1110,6 +1120,7 @@ static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, co
     MH_REQUIRE((int64_t)d->B * d->Ho * d->Wo < (1ll << 31), MH_ERR_ARG, "mh_conv2d: too many output pixels");
     ConvArgs a;
     a.in = in; a.w = w; a.bias = bias; a.out = out; a.mask_ref = mask_ref;
+    a.out2 = a.out3 = nullptr; a.out2_ld = a.out3_ld = 0;
 #ifdef MH_PHASE_TIMING
     a.dbg = g_conv_dbg;
 #endif
@@ -1174,6 +1185,10 @@ static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, co
     a.shadow = nullptr; a.shadow_ld = (d->N + 31) / 32 * 32; a.shadow_done = 0;
     hipStream_t hs = (hipStream_t)stream;
     int rc;
+    if (head && (head->out2 || head->out3)) {
+        MH_REQUIRE(conv_n1_ok(a), MH_ERR_UNSUPPORTED, "mh_conv2d_head: the layer does not fit the single-output-channel kernel (Cin %% 4, aligned operands, <= 64 KB of weights)");
+        a.out2 = head->out2; a.out2_ld = head->out2_ld; a.out3 = head->out3; a.out3_ld = head->out3_ld;
+    }
     if (conv_n1_ok(a)) rc = launch_conv_n1(a, hs);
     else if (conv_k1_dgrad_ok(a)) { a.shadow = (unsigned short*)out_shadow; a.shadow_done = 1; rc = launch_conv_k1_dgrad(a, hs); }
     else if (mh_conv_rows_ok(a)) { a.shadow = (unsigned short*)out_shadow; a.shadow_done = 1; rc = mh_conv_rows_launch(a, hs); }

@@ -6,6 +6,7 @@ struct ConvArgs {
     const float* in; const float* w; const float* bias; float* out; const float* mask_ref;
     const void* wb; unsigned wb_bytes;     // fragment bank of w (mh_pack_weights), or null
     unsigned short* shadow; int shadow_ld; // != null: the epilogue also writes bf16(out) to shadow[pixel][shadow_ld] (operand of mh_wgrad_stream)
+    float* out2; float* out3; int out2_ld, out3_ld;   // single-output-channel forward conv (mh_conv2d_head): copies of the result (a concat slot, the next stage's accumulator)
     int shadow_done;                       // set by the launcher of a kernel family whose epilogue wrote the shadow (else conv_entry casts afterwards)
 #ifdef MH_PHASE_TIMING
     unsigned long long* dbg;                // experiment build only (scripts/exp/phase_timing.sh): per-workgroup phase time stamps

@@ -137,6 +137,17 @@ static int run_op(const mh_op& o, void* s) {
             return mh_shadow_cast((const mh_shadow_seg*)p[0], i[0], i[1], s);
         case MH_OP_WGRAD_STREAM:
             return mh_wgrad_stream((const mh_wgs_layer*)p[0], i[0], i[1], i[2], i[3], s);
+        case MH_OP_HEAD_FWD: {
+            mh_conv_desc d; desc_from_op(o, d);
+            return mh_conv2d_head(&d, (const float*)p[0], (const float*)p[1], (const float*)p[2], (float*)p[3], (float*)p[4], i[23], (float*)p[5], i[24], s);
+        }
+        case MH_OP_HEAD_BWD: {
+            mh_head_bwd_desc d;
+            d.kind = i[0]; d.B = i[1]; d.H = i[2]; d.W = i[3]; d.N = i[4]; d.Hr = i[5]; d.Wr = i[6]; d.cy = i[7]; d.cx = i[8]; d.Ho = i[9]; d.Wo = i[10];
+            d.src0_ld = i[11]; d.src1_ld = i[12]; d.dx_ld = i[13]; d.mask_ld = i[14]; d.accumulate_dx = i[15];
+            d.mul = o.f[0]; d.mask_alpha = o.f[1];
+            return mh_head_bwd(&d, (const float*)p[0], (const float*)p[1], (float*)p[2], p[3], (const float*)p[4], (float*)p[5], (const float*)p[6], p[7], s);
+        }
         case MH_OP_PACK_W:
             return mh_pack_weights((const mh_pack_seg*)p[0], i[0], i[1], s);
         case MH_OP_WGRAD_REDUCE:

@@ -195,6 +195,104 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// backward front end of a disparity head in ONE launch (mh_head_bwd): the head's output gradient dV is assembled from what feeds it --
+//   kind 0: the coordinate gradient du of the next finer level through the gradient of the x2 legacy resize (u = resize(V) * 20 / 2^k,
+//           Nets/MadNet.py:274): exactly resize_bwd_kernel<1>'s gather, same summation order;
+//   kind 1: two per-pixel addends with their own pixel strides (level 2: dfinal and the disparity channel of the context input's gradient)
+// -- written out (fp32 + the bf16 shadow the streamed filter gradient of the head reads), and pushed through the head's 3x3 Cin -> 1 conv
+// backwards (conv_k1_dgrad_kernel's arithmetic) with the leaky mask of the layer below, again with the shadow.  Two launches (three at
+// level 2) of ~7 us each on the critical chain before.  A workgroup owns 4 x 32 head pixels; dV of the tile + a one-pixel halo goes through LDS.
+// ------------------------------------------------------------------------------------------
+struct HeadBwdArgs {
+    ResizeArgs rz;                   // kind 0: rz.g = du (fine), Hi x Wi = the head's size
+    const float* a1; const float* a2; int a1_ld, a2_ld;      // kind 1
+    float* dV; unsigned short* dV_sh; int dV_sh_ld;
+    const float* w; float* dx; const float* mask_ref; unsigned short* dx_sh;
+    int N, dx_ld, mask_ld, dx_sh_ld, acc_dx, kind;
+    float mask_alpha;
+    int tiles_x, tiles_y;
+};
+#define HB_TH 4
+#define HB_TW 32
+__device__ __forceinline__ float head_dv_from_du(const ResizeArgs& p, int b, int sy, int sx) {
+    const float isy = 1.0f / p.sy, isx = 1.0f / p.sx;
+    const float* gimg = p.g + (int64_t)b * p.Ho * p.Wo;
+    const int ya = max(p.cy, (int)floorf((float)(sy - 1) * isy) - 1);
+    const int yb = min(p.cy + p.Ho - 1, (int)ceilf((float)(sy + 1) * isy) + 1);
+    const int xa = max(p.cx, (int)floorf((float)(sx - 1) * isx) - 1);
+    const int xb = min(p.cx + p.Wo - 1, (int)ceilf((float)(sx + 1) * isx) + 1);
+    float acc = 0.f;
+    for (int Y = ya; Y <= yb; ++Y) {
+        int y0, y1; float ty;
+        interp1(Y, p.sy, p.Hi, y0, y1, ty);
+        const float wy = (y0 == sy ? 1.0f - ty : 0.f) + (y1 == sy ? ty : 0.f);
+        if (wy == 0.f) continue;
+        for (int X = xa; X <= xb; ++X) {
+            int x0, x1; float tx;
+            interp1(X, p.sx, p.Wi, x0, x1, tx);
+            const float wx = (x0 == sx ? 1.0f - tx : 0.f) + (x1 == sx ? tx : 0.f);
+            if (wx == 0.f) continue;
+            acc += gimg[(int64_t)(Y - p.cy) * p.Wo + (X - p.cx)] * wy * wx;
+        }
+    }
+    return acc * p.mul;
+}
+__global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs p) {
+    __shared__ float sV[(HB_TH + 2) * (HB_TW + 2)];
+    __shared__ __attribute__((aligned(16))) float sW[9 * 64];
+    const int tid = threadIdx.x;
+    const int H = p.rz.Hi, W = p.rz.Wi;
+    const int tx = blockIdx.x % p.tiles_x;
+    const int t2 = blockIdx.x / p.tiles_x;
+    const int ty = t2 % p.tiles_y, b = t2 / p.tiles_y;
+    const int y0 = ty * HB_TH, x0 = tx * HB_TW;
+    for (int i = tid; i < 9 * p.N; i += 256) sW[i] = p.w[i];
+    if (tid < (HB_TH + 2) * (HB_TW + 2)) {
+        const int ly = tid / (HB_TW + 2), lx = tid - ly * (HB_TW + 2);
+        const int y = y0 - 1 + ly, x = x0 - 1 + lx;
+        float v = 0.f;
+        if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+            const int64_t pix = ((int64_t)b * H + y) * W + x;
+            if (p.kind == 0) v = head_dv_from_du(p.rz, b, y, x);
+            else v = (p.a1 ? p.a1[pix * p.a1_ld] : 0.f) + (p.a2 ? p.a2[pix * p.a2_ld] : 0.f);
+            if (ly >= 1 && ly <= HB_TH && lx >= 1 && lx <= HB_TW) {
+                p.dV[pix] = v;
+                if (p.dV_sh) p.dV_sh[pix * p.dV_sh_ld] = (unsigned short)mh_pack_bf16(v, 0.f);
+            }
+        }
+        sV[tid] = v;
+    }
+    __syncthreads();
+    // dx[y][x][n] = mask(sum_taps dV[y + 1 - ky][x + 1 - kx] * w[ky][kx][n]) (+ old)
+    const int G4 = p.N >> 2;
+    for (int i = tid; i < HB_TH * HB_TW * G4; i += 256) {
+        const int g = i % G4, px = i / G4;
+        const int iy = px / HB_TW, ix = px - iy * HB_TW;
+        const int y = y0 + iy, x = x0 + ix;
+        if (y >= H || x >= W) continue;
+        const int n = g * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t - ky * 3;
+            const float z = sV[(iy + 2 - ky) * (HB_TW + 2) + ix + 2 - kx];
+            const float4 w = *reinterpret_cast<const float4*>(sW + t * p.N + n);
+            v.x += z * w.x; v.y += z * w.y; v.z += z * w.z; v.w += z * w.w;
+        }
+        const int64_t m = ((int64_t)b * H + y) * W + x;
+        float* dst = p.dx + m * p.dx_ld + n;
+        if (p.acc_dx) { const float4 o = *reinterpret_cast<const float4*>(dst); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        if (p.mask_ref) {
+            const float4 mk = *reinterpret_cast<const float4*>(p.mask_ref + m * p.mask_ld + n);
+            v.x *= mk.x > 0.f ? 1.0f : p.mask_alpha; v.y *= mk.y > 0.f ? 1.0f : p.mask_alpha;
+            v.z *= mk.z > 0.f ? 1.0f : p.mask_alpha; v.w *= mk.w > 0.f ? 1.0f : p.mask_alpha;
+        }
+        *reinterpret_cast<float4*>(dst) = v;
+        if (p.dx_sh) *reinterpret_cast<uint2*>(p.dx_sh + m * p.dx_sh_ld + n) = make_uint2(mh_pack_bf16(v.x, v.y), mh_pack_bf16(v.z, v.w));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // multi-channel TF1-legacy bilinear resize of NHWC images (Stereo_Online_Adaptation.scale_tensor :22-23 ->
 // preprocessing.rescale_image :269-273 on the 3-channel frames when --reprojectionScale != 1) and its gradient
 // ------------------------------------------------------------------------------------------
@@ -801,6 +899,35 @@ extern "C" int mh_resize_bwd(const float* g, const float* in, float* din, int32_
     else if (a.sy <= 1.0f / 3.0f) hipLaunchKernelGGL((resize_bwd_kernel<4>), dim3(grid_for(npx * 4)), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((resize_bwd_kernel<1>), dim3(grid_for(npx)), dim3(256), 0, s, a);
     return mh_check_launch("resize_bwd");
+}
+
+extern "C" int mh_head_bwd(const mh_head_bwd_desc* d, const float* src0, const float* src1, float* dV, void* dV_shadow, const float* w,
+                           float* dx, const float* mask_ref, void* dx_shadow, void* stream) {
+    MH_REQUIRE(d && dV && w && dx && (src0 || src1), MH_ERR_ARG, "mh_head_bwd: null argument");
+    MH_REQUIRE(d->kind == 0 || d->kind == 1, MH_ERR_ARG, "mh_head_bwd: kind must be 0 (resize gradient of a finer level's du) or 1 (addends)");
+    MH_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->N >= 4 && d->N <= 64 && d->N % 4 == 0, MH_ERR_ARG, "mh_head_bwd: bad dimension (N = 4 .. 64, multiple of 4)");
+    MH_REQUIRE(d->dx_ld % 4 == 0 && d->dx_ld >= d->N && mh_aligned16(dx) && mh_aligned16(w) && (!mask_ref || (d->mask_ld % 4 == 0 && mh_aligned16(mask_ref))) &&
+               (!dx_shadow || mh_aligned16(dx_shadow)), MH_ERR_ALIGN, "mh_head_bwd: dx / mask / w must be 16-byte aligned with lds that are multiples of 4");
+    HeadBwdArgs a{};
+    if (d->kind == 0) {
+        MH_REQUIRE(src0, MH_ERR_ARG, "mh_head_bwd: kind 0 needs the finer level's coordinate gradient");
+        a.rz.g = src0;
+        if (int e = resize_args(a.rz, d->B, d->H, d->W, d->Hr, d->Wr, d->cy, d->cx, d->Ho, d->Wo, d->mul, 0)) return e;
+    } else {
+        a.rz.B = d->B; a.rz.Hi = d->H; a.rz.Wi = d->W;
+        a.a1 = src0; a.a2 = src1; a.a1_ld = d->src0_ld; a.a2_ld = d->src1_ld;
+        MH_REQUIRE((!src0 || d->src0_ld >= 1) && (!src1 || d->src1_ld >= 1), MH_ERR_ARG, "mh_head_bwd: addend pixel strides must be >= 1");
+    }
+    a.dV = dV; a.dV_sh = (unsigned short*)dV_shadow; a.dV_sh_ld = 32;
+    a.w = w; a.dx = dx; a.mask_ref = mask_ref; a.dx_sh = (unsigned short*)dx_shadow;
+    a.N = d->N; a.dx_ld = d->dx_ld; a.mask_ld = d->mask_ld; a.dx_sh_ld = (d->N + 31) / 32 * 32; a.acc_dx = d->accumulate_dx; a.kind = d->kind;
+    a.mask_alpha = d->mask_alpha;
+    a.tiles_x = (d->W + HB_TW - 1) / HB_TW; a.tiles_y = (d->H + HB_TH - 1) / HB_TH;
+    const int64_t grid = (int64_t)d->B * a.tiles_x * a.tiles_y;
+    MH_REQUIRE(grid < (1ll << 31), MH_ERR_ARG, "mh_head_bwd: too many tiles");
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+    mh_note_kernel("head_bwd_kernel kind %d N=%d", d->kind, d->N);
+    return mh_check_launch("head_bwd");
 }
 
 extern "C" int mh_pad_reflect(const float* in, float* out, int32_t B, int32_t H, int32_t W, int32_t C,

@@ -31,7 +31,7 @@ class Op(C.Structure):
 (OP_CONV, OP_WGRAD, OP_CORR_FWD, OP_CORR_BWD, OP_WARP_FWD, OP_WARP_BWD, OP_RESIZE_FWD, OP_RESIZE_BWD,
  OP_PAD_REFLECT, OP_LOSS, OP_METRICS, OP_MOMENTUM, OP_COPY_CH, OP_LEAKY_BWD, OP_FILL, OP_BIAS_GRAD,
  OP_WGRAD_PARTIAL, OP_WGRAD_REDUCE, OP_PROXY_LOSS, OP_SUPERVISED_LOSS, OP_ADAM, OP_ADAM_ADVANCE, OP_RESIZE_IMAGE, OP_LEVEL_FRONT, OP_TRANSPOSE_W, OP_PACK_W, OP_CORR_WARP_BWD,
- OP_SHADOW_CAST, OP_WGRAD_STREAM) = range(1, 30)
+ OP_SHADOW_CAST, OP_WGRAD_STREAM, OP_HEAD_BWD, OP_HEAD_FWD) = range(1, 32)
 
 
 OP_JOIN = 0x100
@@ -59,6 +59,11 @@ class WgradItem(C.Structure):        # mh_wgrad_item
 class ShadowSeg(C.Structure):        # mh_shadow_seg
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("npix", C.c_int64), ("C", C.c_int32), ("src_ld", C.c_int32),
                 ("dst_ld", C.c_int32), ("blk0", C.c_int32)]
+
+
+class HeadBwdDesc(C.Structure):      # mh_head_bwd_desc
+    _fields_ = [(n, C.c_int32) for n in ("kind", "B", "H", "W", "N", "Hr", "Wr", "cy", "cx", "Ho", "Wo")] + [("mul", C.c_float)] + \
+               [(n, C.c_int32) for n in ("src0_ld", "src1_ld", "dx_ld", "mask_ld", "accumulate_dx")] + [("mask_alpha", C.c_float)]
 
 
 class WgsLayer(C.Structure):         # mh_wgs_layer
@@ -102,6 +107,8 @@ SIGNATURES = {
     "mh_conv2d_wgrad_partial_group": (_I, [C.POINTER(WgradItem), _I, _P]),
     "mh_wgrad_reduce": (_I, [_P, _I, _I, _P]),
     "mh_shadow_cast": (_I, [_P, _I, _I, _P]),
+    "mh_conv2d_head": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I, _P, _I, _P]),
+    "mh_head_bwd": (_I, [C.POINTER(HeadBwdDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mh_wgrad_stream_plan": (_I, [C.POINTER(WgsLayer), _I, _I, _I, C.POINTER(C.c_int32)]),
     "mh_wgrad_stream": (_I, [_P, _I, _I, _I, _I, _P]),
     "mh_tune_wgrad_stream": (_I, [_I]),

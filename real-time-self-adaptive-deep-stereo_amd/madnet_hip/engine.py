@@ -92,6 +92,8 @@ def madnet_manifest(radius_d=2, stride=1):
 # pyramid layers after whose input gradient the pending filter gradients are issued in addition to every 4th layer (e.g. "3,2": the last
 # batch -- conv4..conv1 -- then does not wait for the LAST input gradient).  Measured: -0.4 % with two side lanes, +0.6 % with the one
 # lane that is the default since side launches are deferred (profiles/r02_experiments.txt #16) -> off by default
+# one launch for a head's output gradient + input gradient (mh_head_bwd) instead of resize gradient / copies + the K = 1 input-gradient kernel
+FUSE_HEAD = os.environ.get("MH_FUSE_HEAD", "1") != "0"
 PYR_TAIL_FLUSH = tuple(int(x) for x in os.environ.get("MH_PYR_TAIL_FLUSH", "").split(",") if x)
 
 
@@ -369,6 +371,7 @@ class MadNetEngine(object):
     # =========================================================================================
     def record_forward(self, r, make_disps=()):
         B, lib = self.B, r
+        head2_fused = False
         if self.use_direct:
             names = [n for n, shp in self.params.manifest if n.endswith("/weights") and shp[3] >= 16 and shp[2] % 8 == 0]
             ops.transpose_weights(lib, [(self.params.tensor(n), self.Wt_(n[:-len("/weights")])) for n in names], self.dev, r.keep)
@@ -430,6 +433,15 @@ class MadNetEngine(object):
             for j, co in enumerate(EST):
                 last = j == len(EST) - 1
                 o = self._fv(self.V[k]) if last else self._fv(self.E[k][j])
+                if last and k == 2 and FUSE_HEAD and hasattr(lib, "conv2d_head"):
+                    # the level-2 head also fills the disparity slot of the context network's input and seeds final = V2 + context7 (two copy
+                    # launches on the critical chain before)
+                    h4, w4, c4_ = self.fshape[4]
+                    ops.conv2d_head(lib, x, self.W_(est_name(k, j + 1)), self.b_(est_name(k, j + 1)), o,
+                                    copies=(ops.View(self.ctx_in, B, h4, w4, c4_ + 1, self.ctx_ld).slice(c4_, c4_ + 1), self._fv(self.final)))
+                    head2_fused = True
+                    x = o
+                    continue
                 ops.conv2d_fwd(lib, x, self.W_(est_name(k, j + 1)), self.b_(est_name(k, j + 1)), o,
                                alpha=(1.0 if last else ALPHA), precision=fprec, wt=self.Wt_(est_name(k, j + 1)),
                                wb=self.Wb_(est_name(k, j + 1)), shadow=(None if last else self._out_shadow(o, est_name(k, j + 2))))
@@ -444,7 +456,8 @@ class MadNetEngine(object):
         h, w, c = self.fshape[4]
         cin = ops.View(self.ctx_in, B, h, w, c + 1, self.ctx_ld)
         ops.copy_channels(lib, self._half(self.F[4], False), cin.slice(0, c))
-        ops.copy_channels(lib, self._fv(self.V[2]), cin.slice(c, c + 1))
+        if not head2_fused:
+            ops.copy_channels(lib, self._fv(self.V[2]), cin.slice(c, c + 1))
         x = cin
         for j, (co, rate) in enumerate(CTX[:-1]):
             o = self._fv(self.Cx[j])
@@ -452,7 +465,8 @@ class MadNetEngine(object):
                            wb=self.Wb_(ctx_name(j + 1)), shadow=self._out_shadow(o, ctx_name(j + 2)))
             x = o
         # final_disp = V2_init + context7  (accumulating epilogue)
-        ops.copy_channels(lib, self._fv(self.V[2]), self._fv(self.final))
+        if not head2_fused:
+            ops.copy_channels(lib, self._fv(self.V[2]), self._fv(self.final))
         self._conv_acc(lib, x, ctx_name(7), self._fv(self.final), CTX[-1][1])
         if 2 in make_disps:
             self._make_disp(lib, self.final, self.disp_k[2])
@@ -638,6 +652,25 @@ class MadNetEngine(object):
             written.add(key)
             return a
 
+        head_done = set()                   # levels whose head's input gradient went out with mh_head_bwd
+
+        def fuse_head(k, **src):
+            """dV[k] from its only source (the finer level's coordinate gradient through the x2 resize, or -- level 2 -- dfinal + the disparity
+            channel of the context input's gradient) AND the input gradient of estimator k's head, in one launch; False = not applicable
+            (another contribution already sits in dV[k], nothing below the head needs a gradient, switched off)."""
+            if not (FUSE_HEAD and hasattr(lib, "head_bwd") and up_V[k] and ("V", k) not in written):
+                return False
+            need_u_k = (not bulkhead) and k != 6 and up_V[k + 1]
+            if not (any(est_tr[k][:5]) or pyr_need[FEAT[k]] or need_u_k):
+                return False
+            dxv, dVv = self._fv(self.dE[k][4]), self._fv(self.dV[k])
+            ops.head_bwd(lib, self.W_(est_name(k, 6)), self.dV[k], dxv, mask_ref=self._fv(self.E[k][4]), mask_alpha=ALPHA,
+                         accumulate_dx=acc_flag(("est", k, 5)), dV_shadow=self._out_shadow(dVv, est_name(k, 6)),
+                         dx_shadow=self._out_shadow(dxv, est_name(k, 5)), **src)
+            written.add(("V", k))
+            head_done.add(k)
+            return True
+
         def conv_bwd(xv, base, dzv, dxv, dx_key, x_act, stride=1, dil=1, need_dx=True, trainable=True, below=None):
             """below: the layer whose output gradient dxv is (its filter gradient reads it as dz): the input gradient's epilogue then also
             writes the bf16 shadow"""
@@ -681,9 +714,10 @@ class MadNetEngine(object):
                         break
             flush()
             if up_V[2]:
-                ops.copy_channels(lib, self._fv(self.dfinal), self._fv(self.dV[2]), accumulate=acc_flag(("V", 2)))
                 dci = ops.View(self.dctx_in, B, h2, w2, c2 + 1, self.ctx_ld)
-                ops.copy_channels(lib, dci.slice(c2, c2 + 1), self._fv(self.dV[2]), accumulate=acc_flag(("V", 2)))
+                if not fuse_head(2, addends=(self._fv(self.dfinal), dci.slice(c2, c2 + 1))):
+                    ops.copy_channels(lib, self._fv(self.dfinal), self._fv(self.dV[2]), accumulate=acc_flag(("V", 2)))
+                    ops.copy_channels(lib, dci.slice(c2, c2 + 1), self._fv(self.dV[2]), accumulate=acc_flag(("V", 2)))
                 if pyr_need[4]:
                     ops.copy_channels(lib, dci.slice(0, c2), self._half(self.dF[4], False), accumulate=acc_flag(("F", 4, 0)))
         # ---- levels start_level .. 6 ---------------------------------------------------------------
@@ -703,6 +737,11 @@ class MadNetEngine(object):
                 xin = ops.View(self.dsi[k], B, h, w, cin, ld) if j == 1 else self._fv(self.E[k][j - 2])
                 dx = ops.View(self.ddsi[k], B, h, w, cin, ld) if j == 1 else self._fv(self.dE[k][j - 2])
                 need_dx = any(est_tr[k][:j - 1]) or need_dsi
+                if j == 6 and k in head_done:           # its input gradient is already there: only the filter gradient is left
+                    if est_tr[k][5]:
+                        wgrad(xin, dz, est_name(k, 6))
+                    dz = dx
+                    continue
                 conv_bwd(xin, est_name(k, j), dz, dx, ("est", k, j - 1), (None if j == 1 else self._fv(self.E[k][j - 2])),
                          need_dx=need_dx, trainable=est_tr[k][j - 1], below=(est_name(k, j - 1) if j > 1 else None))
                 dz = dx
@@ -722,8 +761,9 @@ class MadNetEngine(object):
                              acc_l=acc_flag(("F", f, 0)), acc_r=acc_flag(("F", f, 1)), acc_u=False, copy_left=True)
                 if du is not None:
                     s_up = 2 ** k
-                    ops.resize_bwd(lib, self.du[k], self.V[k + 1], self.dV[k + 1], self.Hp // s_up, self.Wp // s_up,
-                                   mul=20.0 / s_up, mode=0, accumulate=acc_flag(("V", k + 1)))
+                    if not fuse_head(k + 1, du=self.du[k], Hr=self.Hp // s_up, Wr=self.Wp // s_up, mul=20.0 / s_up):
+                        ops.resize_bwd(lib, self.du[k], self.V[k + 1], self.dV[k + 1], self.Hp // s_up, self.Wp // s_up,
+                                       mul=20.0 / s_up, mode=0, accumulate=acc_flag(("V", k + 1)))
             elif FUSE_BACK and SCATTER_LANE == 0 and ("F", f, 1) in written:
                 # the level's correlation + concat gradient and the warp gradient in ONE launch (mh_corr_warp_bwd): the gradient w.r.t. the warped
                 # features never goes to memory; the scatter target was zeroed by the pass's single fill (or holds earlier contributions)
@@ -732,8 +772,9 @@ class MadNetEngine(object):
                                   self.md, self.cstride, coff=c, acc_l=acc_flag(("F", f, 0)), copy_left=True)
                 if need_u:
                     s_up = 2 ** k
-                    ops.resize_bwd(lib, self.du[k], self.V[k + 1], self.dV[k + 1], self.Hp // s_up, self.Wp // s_up,
-                                   mul=20.0 / s_up, mode=0, accumulate=acc_flag(("V", k + 1)))
+                    if not fuse_head(k + 1, du=self.du[k], Hr=self.Hp // s_up, Wr=self.Wp // s_up, mul=20.0 / s_up):
+                        ops.resize_bwd(lib, self.du[k], self.V[k + 1], self.dV[k + 1], self.Hp // s_up, self.Wp // s_up,
+                                       mul=20.0 / s_up, mode=0, accumulate=acc_flag(("V", k + 1)))
             else:
                 Rk = self._fv(self.Rw[k])
                 du = self.du[k] if need_u else None
@@ -763,8 +804,9 @@ class MadNetEngine(object):
                 if need_u:
                     # u_k = resize(V_{k+1}) * 20/2^k   (MadNet.py:274: u_{k} built at level k+1 with scales[k])
                     s_up = 2 ** k
-                    ops.resize_bwd(lib, self.du[k], self.V[k + 1], self.dV[k + 1], self.Hp // s_up, self.Wp // s_up,
-                                   mul=20.0 / s_up, mode=0, accumulate=acc_flag(("V", k + 1)))
+                    if not fuse_head(k + 1, du=self.du[k], Hr=self.Hp // s_up, Wr=self.Wp // s_up, mul=20.0 / s_up):
+                        ops.resize_bwd(lib, self.du[k], self.V[k + 1], self.dV[k + 1], self.Hp // s_up, self.Wp // s_up,
+                                       mul=20.0 / s_up, mode=0, accumulate=acc_flag(("V", k + 1)))
         # ---- pyramid towers (batch 2B, shared weights) ---------------------------------------------
         # split point of build_plan(part='grad_split'): every gradient of the estimators / the context network is final here (their
         # batches were flushed level by level), the pyramid's come after -- the shared-model step all-reduces the first range while

@@ -442,6 +442,44 @@ def resize_bwd(lib, g, x, dx, Hr, Wr, cy=0, cx=0, mul=1.0, mode=0, accumulate=Fa
     lib.resize_bwd(_p(g), _p(x), _p(dx), int(accumulate), B, Hi, Wi, Hr, Wr, cy, cx, Ho, Wo, mul, mode, _p(stream))
 
 
+def conv2d_head(lib, x, w, b, out, copies=(), alpha=1.0, stream=None):
+    """Forward pass of a disparity head (3x3 Cin -> 1, mh_conv2d_head): out = conv(x, w) + b, ALSO stored at up to two more Views with C = 1
+    (`copies`: a channel slot of a concatenated buffer, the buffer the next stage accumulates into)."""
+    kh, kw, cin, cout = w.shape
+    assert cout == 1 and x.C == cin and len(copies) <= 2 and all((c.B, c.H, c.W, c.C) == (out.B, out.H, out.W, 1) for c in copies)
+    Ho, Wo, pt, pl = conv_geometry(x.H, x.W, kh, kw, 1, 1)
+    d = conv_desc(x.B, x.H, x.W, Ho, Wo, cin, 1, kh, kw, 1, 1, pt, pl, 0, 0, x.ld, out.ld, alpha=alpha)
+    c = list(copies) + [None, None]
+    lib.conv2d_head(C.byref(d), _p(x), _p(w), _p(b), _p(out), _p(c[0]), (c[0].ld if c[0] is not None else 0),
+                    _p(c[1]), (c[1].ld if c[1] is not None else 0), _p(stream))
+
+
+def head_bwd(lib, w, dV, dx, mask_ref=None, mask_alpha=1.0, accumulate_dx=False, du=None, Hr=0, Wr=0, mul=1.0, addends=(), dV_shadow=None,
+             dx_shadow=None, stream=None):
+    """Backward front end of a disparity head (mh_head_bwd): dV [B,H,W] tensor <- either the resize gradient of the finer level's coordinate
+    gradient `du` ([B,Ho,Wo] tensor; Hr, Wr, mul as resize_bwd mode 0) or the sum of up to two `addends` (Views with C = 1: channel slices are
+    fine); dx (View [B,H,W,N]) (+)= conv2d_backprop_input(dV, w) * leaky'(mask_ref).  w: HWIO [3,3,N,1] of the head conv.  Shadows: ops.Shadow of
+    dV (C = 1) / dx, written on the way."""
+    B, H, W = dV.shape
+    assert tuple(w.shape) == (3, 3, dx.C, 1) and (dx.B, dx.H, dx.W) == (B, H, W)
+    d = _ffi.HeadBwdDesc()
+    d.B, d.H, d.W, d.N = B, H, W, dx.C
+    d.dx_ld, d.mask_ld, d.accumulate_dx, d.mask_alpha = dx.ld, (mask_ref.ld if mask_ref is not None else 0), int(accumulate_dx), mask_alpha
+    if du is not None:
+        d.kind, d.Hr, d.Wr, d.cy, d.cx, d.Ho, d.Wo, d.mul = 0, Hr, Wr, 0, 0, du.shape[1], du.shape[2], mul
+        src0, src1 = _p(du), None
+    else:
+        assert 1 <= len(addends) <= 2 and all((a.B, a.H, a.W, a.C) == (B, H, W, 1) for a in addends)
+        d.kind = 1
+        d.src0_ld = addends[0].ld
+        d.src1_ld = addends[1].ld if len(addends) > 1 else 0
+        src0, src1 = _p(addends[0]), (_p(addends[1]) if len(addends) > 1 else None)
+    for sh, c in ((dV_shadow, 1), (dx_shadow, dx.C)):
+        assert sh is None or (sh.B, sh.H, sh.W, sh.C) == (B, H, W, c)
+    lib.head_bwd(C.byref(d), src0, src1, _p(dV), (C.c_void_p(dV_shadow.ptr) if dV_shadow is not None else None), _p(w), _p(dx), _p(mask_ref),
+                 (C.c_void_p(dx_shadow.ptr) if dx_shadow is not None else None), _p(stream))
+
+
 def resize_image(lib, x, out, stream=None):
     """TF1-legacy bilinear resize of an NHWC image tensor [B,H,W,C] into out [B,Ho,Wo,C] (scale_tensor on the frames)."""
     B, H, W, Cc = x.shape

@@ -136,6 +136,16 @@ class Recorder(object):
         if splits > 1:
             self.stats["wgrad_ws_bytes"] += 2 * 4.0 * splits * taps * K * N
 
+    def conv2d_head(self, dref, inp, w, bias, out, out2, out2_ld, out3, out3_ld, stream):
+        d = dref._obj
+        self._tally(d, "conv")
+        self._op(_ffi.OP_HEAD_FWD, self._desc_ints(d) + [0, d.precision, out2_ld, out3_ld], [d.alpha, d.mask_alpha], [inp, w, bias, out, out2, out3])
+
+    def head_bwd(self, dref, src0, src1, dV, dV_shadow, w, dx, mask, dx_shadow, stream):
+        d = dref._obj
+        self._op(_ffi.OP_HEAD_BWD, [d.kind, d.B, d.H, d.W, d.N, d.Hr, d.Wr, d.cy, d.cx, d.Ho, d.Wo, d.src0_ld, d.src1_ld, d.dx_ld, d.mask_ld,
+                                    d.accumulate_dx], [d.mul, d.mask_alpha], [src0, src1, dV, dV_shadow, w, dx, mask, dx_shadow])
+
     def wgrad_reduce(self, segs, nseg, nblocks, stream):
         self._op(_ffi.OP_WGRAD_REDUCE, [nseg, nblocks], [], [segs])
 

@@ -687,3 +687,37 @@ def test_step_with_streamed_filter_gradients_emulated(mode):
         a, b = engc.params.tensor(name, "g"), e1.params.tensor(name, "g")
         assert torch.equal(a, b) if name.endswith("/weights") else (a - b).abs().max().item() <= 1e-6 * max(a.abs().max().item(), 1e-6), name
     assert sum(o.i[0] for o in planc.arr if o.kind == _ffi.OP_SHADOW_CAST) > sum(o.i[0] for o in res[True][4].last_plan_arr if o.kind == _ffi.OP_SHADOW_CAST)
+
+
+def test_step_with_fused_head_backward_emulated():
+    """mh_head_bwd / mh_conv2d_head inside the engine: the FULL step with the heads' output gradient + input gradient in one launch (5 launches: level 2 from dfinal and
+    the context input's gradient, levels 3 .. 6 through the resize gradient) against the step on the separate launches (fp32 engine: same arithmetic,
+    one summation differs in its order)."""
+    from conftest import _emul_backend
+    backend = _emul_backend()
+    H, W = 60, 100
+    wn = S.calibrated_weights(OM.variable_shapes(), 1)
+    l, r, gt = S.make_pair(H, W)
+    out = {}
+    saved = E.FUSE_HEAD
+    try:
+        for fused in (True, False):
+            E.FUSE_HEAD = fused
+            eng = E.MadNetEngine(backend.lib, H, W, B=1, device="cpu", weights=wn, precision="fp32")
+            eng.set_inputs(l, r, gt[..., 0])
+            plan = eng.build_plan("FULL", lr=1e-4, update=False)
+            n_head = sum(1 for k in range(plan.n) if plan.arr[k].kind == _ffi_mod().OP_HEAD_BWD)
+            plan.run(backend.lib, 0)
+            out[fused] = (eng.params.g.clone(), n_head, plan.n)
+    finally:
+        E.FUSE_HEAD = saved
+    (g1, n1, ops1), (g0, n0, ops0) = out[True], out[False]
+    # backward: 2 copies + 4 resize gradients + 5 head input gradients -> 5 launches; forward: the level-2 head stores its result in the context
+    # input and in `final` itself (mh_conv2d_head): 2 copies less
+    assert n1 == 5 and n0 == 0 and ops1 == ops0 - 8
+    assert ((g1 - g0).norm() / g0.norm()).item() <= 1e-5
+
+
+def _ffi_mod():
+    from madnet_hip import _ffi
+    return _ffi

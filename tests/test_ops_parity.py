@@ -454,3 +454,53 @@ def test_corr_warp_bwd_fused_matches_corr_bwd_then_warp_bwd(backend, case):
     ops.corr_warp_bwd(backend.lib, gv, ops.view(L), ops.view(Rw), ops.view(R), u, ops.view(dL2), None, du2, md, stride, coff=Cc, copy_left=True)
     backend.sync()
     assert (du2.cpu() - du1).abs().max().item() <= 2e-5 * max(1.0, du1.abs().max().item())
+
+
+@pytest.mark.parametrize("case", [(1, 12, 40, 32), (2, 9, 21, 32), (1, 3, 5, 32), (1, 24, 80, 16), (1, 1, 2, 32)])
+@pytest.mark.parametrize("kind", ["du", "addends"])
+def test_head_bwd_matches_the_separate_launches(backend, case, kind):
+    """mh_head_bwd = mh_resize_bwd (mode 0, the x2 legacy resize of the disparity) or the per-pixel sum of two strided addends, followed by the
+    input gradient of the 3x3 Cin -> 1 head conv with the leaky mask of the layer below -- one launch, dV and dx bit-identical to the sequence
+    (same arithmetic, same order), bf16 shadows of both written on the way."""
+    B, H, W, N = case
+    dev = backend.device
+    w = torch.randn(3, 3, N, 1, device=dev) * 0.3
+    mref = torch.randn(B, H, W, N + 4, device=dev)
+    mv = ops.View(mref, B, H, W, N, N + 4)
+    old = torch.randn(B, H, W, N, device=dev)
+    V = torch.randn(B, H, W, device=dev)
+    outs = []
+    for fused in (False, True):
+        dV = torch.full((B, H, W), float("nan"), device=dev)
+        dxb = torch.full((B, H, W, N + 4), 7.0, device=dev)
+        dxb[..., :N] = old
+        dxv = ops.View(dxb, B, H, W, N, N + 4)
+        shV, shx = ops.Shadow(B, H, W, 1, dev), ops.Shadow(B, H, W, N, dev)
+        if kind == "du":
+            du = torch.randn(B, 2 * H, 2 * W, device=dev)
+            torch.manual_seed(5); du = torch.randn(B, 2 * H, 2 * W, device=dev)
+            if fused:
+                ops.head_bwd(backend.lib, w, dV, dxv, mask_ref=mv, mask_alpha=0.2, accumulate_dx=True, du=du, Hr=2 * H, Wr=2 * W, mul=2.5, dV_shadow=shV, dx_shadow=shx)
+            else:
+                ops.resize_bwd(backend.lib, du, V, dV, 2 * H, 2 * W, mul=2.5, mode=0, accumulate=False)
+        else:
+            torch.manual_seed(6)
+            a1 = torch.randn(B, H, W, device=dev); a2b = torch.randn(B, H, W, 8, device=dev)
+            a2 = ops.View(a2b, B, H, W, 8, 8).slice(5, 6)
+            if fused:
+                ops.head_bwd(backend.lib, w, dV, dxv, mask_ref=mv, mask_alpha=0.2, accumulate_dx=True, addends=(ops.view(a1), a2), dV_shadow=shV, dx_shadow=shx)
+            else:
+                ops.copy_channels(backend.lib, ops.view(a1), ops.view(dV))
+                ops.copy_channels(backend.lib, a2, ops.view(dV), accumulate=True)
+        if not fused:
+            ops.conv2d_dgrad(backend.lib, ops.view(dV), w, dxv, accumulate=True, mask_ref=mv, mask_alpha=0.2, shadow=shx)
+        else:
+            assert "head_bwd_kernel" in backend.lib.last_kernel().decode()
+        backend.sync()
+        assert (dxb[..., N:] == 7.0).all()
+        outs.append((dV.cpu().clone(), dxb[..., :N].cpu().clone(), shV.t.cpu().clone(), shx.t.cpu().clone()))
+    (dV0, dx0, _, shx0), (dV1, dx1, shV1, shx1) = outs
+    assert torch.equal(dV0, dV1)
+    assert (dx0 - dx1).abs().max().item() <= 1e-6 * max(1.0, dx0.abs().max().item())
+    assert torch.equal(shV1[..., 0], dV1.to(torch.bfloat16)) and (shV1[..., 1:] == 0).all()
+    assert torch.equal(shx1[..., :N], dx1.to(torch.bfloat16))
