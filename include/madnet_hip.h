@@ -294,6 +294,11 @@ int mh_u8_to_f32(const uint8_t* in, float* out, int64_t n, void* stream);
 /* ---- preprocessing.pad_image (REFLECT, preprocessing.py:7-29) fused with the float cast
  *      and the channel padding 3 -> out_ld (extra channels zero) ------------------------ */
 /* out = in / div - sub  (MADNet: div=1, sub=0; DispNet._preprocess_inputs, DispNet.py:59-73: x/255 - 100/255) */
+/* mh_conv2d_sh with the bf16 shadow of the INPUT tensor as well (pixel stride = K rounded up to 32 halfs, zero padded, as an earlier
+ * mh_conv2d_sh / mh_shadow_cast wrote it): the patch-staged input-gradient kernel (mode 1, bf16) then stages the shadow as it is -- half the
+ * bytes, no conversion, bit-identical result; every other kernel ignores it and reads `in`.  in_shadow may be NULL. */
+int mh_conv2d_sh2(const mh_conv_desc* d, const float* in, const void* in_shadow, const float* w, const void* wb, const float* bias,
+                  float* out, const float* mask_ref, void* out_shadow, void* stream);
 /* Forward pass of a disparity head (mh_conv2d with N = 1, mode 0) that also stores its result at up to two more places, each with its own
  * pixel stride (floats): a channel slot of a concatenated buffer (the context network's input, Nets/MadNet.py:155-157) and / or the buffer the
  * next stage accumulates into (final = V2 + context, MadNet.py:171).  out2 / out3 may be NULL.  Saves the copy launches behind the head. */

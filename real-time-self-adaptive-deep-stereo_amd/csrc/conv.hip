@@ -1081,7 +1081,7 @@ extern "C" int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w,
     return mh_conv2d_wt(d, in, w, nullptr, bias, out, mask_ref, stream);
 }
 
-struct HeadOuts { float* out2; int out2_ld; float* out3; int out3_ld; };
+struct HeadOuts { float* out2; int out2_ld; float* out3; int out3_ld; const void* in_shadow; };
 static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, const float* wt, const void* wb, const float* bias,
                       float* out, const float* mask_ref, void* stream, void* out_shadow = nullptr, const HeadOuts* head = nullptr);
 int mh_shadow_cast_one(const float* src, int src_ld, int C, void* dst, int dst_ld, int64_t npix, hipStream_t s);      // wgrad_stream.hip
@@ -1102,11 +1102,18 @@ extern "C" int mh_conv2d_sh(const mh_conv_desc* d, const float* in, const float*
     MH_REQUIRE(!out_shadow || (((uintptr_t)out_shadow) & 15u) == 0, MH_ERR_ALIGN, "mh_conv2d_sh: out_shadow must be 16-byte aligned");
     return conv_entry(d, in, w, nullptr, wb, bias, out, mask_ref, stream, out_shadow);
 }
+extern "C" int mh_conv2d_sh2(const mh_conv_desc* d, const float* in, const void* in_shadow, const float* w, const void* wb, const float* bias,
+                             float* out, const float* mask_ref, void* out_shadow, void* stream) {
+    MH_REQUIRE(!out_shadow || (((uintptr_t)out_shadow) & 15u) == 0, MH_ERR_ALIGN, "mh_conv2d_sh2: out_shadow must be 16-byte aligned");
+    MH_REQUIRE(!in_shadow || (((uintptr_t)in_shadow) & 15u) == 0, MH_ERR_ALIGN, "mh_conv2d_sh2: in_shadow must be 16-byte aligned");
+    const HeadOuts h{nullptr, 0, nullptr, 0, in_shadow};
+    return conv_entry(d, in, w, nullptr, wb, bias, out, mask_ref, stream, out_shadow, &h);
+}
 extern "C" int mh_conv2d_head(const mh_conv_desc* d, const float* in, const float* w, const float* bias, float* out,
                               float* out2, int32_t out2_ld, float* out3, int32_t out3_ld, void* stream) {
     MH_REQUIRE(d && d->N == 1 && d->mode == 0, MH_ERR_ARG, "mh_conv2d_head: a forward conv with ONE output channel");
     MH_REQUIRE((!out2 || out2_ld >= 1) && (!out3 || out3_ld >= 1), MH_ERR_ARG, "mh_conv2d_head: pixel strides of the extra outputs must be >= 1");
-    const HeadOuts h{out2, out2_ld, out3, out3_ld};
+    const HeadOuts h{out2, out2_ld, out3, out3_ld, nullptr};
     return conv_entry(d, in, w, nullptr, nullptr, bias, out, nullptr, stream, nullptr, &h);
 }
 static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, const float* wt, const void* wb, const float* bias,
@@ -1121,6 +1128,7 @@ static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, co
     ConvArgs a;
     a.in = in; a.w = w; a.bias = bias; a.out = out; a.mask_ref = mask_ref;
     a.out2 = a.out3 = nullptr; a.out2_ld = a.out3_ld = 0;
+    a.in_shadow = nullptr; a.in_shadow_bytes = 0;
 #ifdef MH_PHASE_TIMING
     a.dbg = g_conv_dbg;
 #endif
@@ -1194,7 +1202,14 @@ static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, co
     else if (mh_conv_rows_ok(a)) { a.shadow = (unsigned short*)out_shadow; a.shadow_done = 1; rc = mh_conv_rows_launch(a, hs); }
     else if (conv_thin_ok(a)) rc = launch_conv_thin(a, hs);
     else if (mh_conv_bank_small_ok(a)) { a.shadow = (unsigned short*)out_shadow; a.shadow_done = 1; rc = mh_conv_bank_small_launch(a, hs); }
-    else if (mh_conv_patch_ok(a)) { a.shadow = (unsigned short*)out_shadow; a.shadow_done = 1; rc = mh_conv_patch_launch(a, hs); }
+    else if (mh_conv_patch_ok(a)) {
+        a.shadow = (unsigned short*)out_shadow; a.shadow_done = 1;
+        if (head && head->in_shadow && a.mode == 1 && a.bf16) {          // (only this family stages a shadow; the others read the fp32 tensor)
+            const int64_t sb = (int64_t)d->B * d->Hi * d->Wi * ((d->K + 31) / 32 * 32) * 2;
+            if (sb < (1ll << 31) - 64) { a.in_shadow = (const unsigned short*)head->in_shadow; a.in_shadow_bytes = (unsigned)sb; }
+        }
+        rc = mh_conv_patch_launch(a, hs);
+    }
     else if (mh_conv_direct_ok(a, (wt && mh_aligned16(wt)) ? wt : nullptr)) rc = mh_conv_direct_launch(a, wt, hs);
     else {
         if (a.vecC) { a.shadow = (unsigned short*)out_shadow; a.shadow_done = 1; }      // the tiled kernel's vector epilogue has the store

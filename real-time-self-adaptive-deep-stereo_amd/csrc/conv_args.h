@@ -6,6 +6,8 @@ struct ConvArgs {
     const float* in; const float* w; const float* bias; float* out; const float* mask_ref;
     const void* wb; unsigned wb_bytes;     // fragment bank of w (mh_pack_weights), or null
     unsigned short* shadow; int shadow_ld; // != null: the epilogue also writes bf16(out) to shadow[pixel][shadow_ld] (operand of mh_wgrad_stream)
+    const unsigned short* in_shadow; unsigned in_shadow_bytes;   // != null: bf16 shadow of `in` (pixel stride = K rounded up to 32, zero padded): the patch-staged
+                                                                 // input-gradient kernel stages it as it is instead of converting the fp32 tensor
     float* out2; float* out3; int out2_ld, out3_ld;   // single-output-channel forward conv (mh_conv2d_head): copies of the result (a concat slot, the next stage's accumulator)
     int shadow_done;                       // set by the launcher of a kernel family whose epilogue wrote the shadow (else conv_entry casts afterwards)
 #ifdef MH_PHASE_TIMING

@@ -31,6 +31,7 @@ struct PatchGeo {
     int nchunk;             // 9 * CPT
     int patch_halfs;        // (TH+2)*18*PS
     float inv_kp4;          // 1 / (KP/4)
+    unsigned mul_kp8;       // ceil(2^32 / (KP/8)): q / (KP/8) by multiplication (shadow staging)
     int dbg;                // timing experiments (scripts/microbench.py patchdbg): 1 = skip the K walk, 2 = skip the patch staging
 };
 
@@ -161,7 +162,31 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1,
     load_b(rb1);                                     // tile 1
 
     // ---- stage the input patch once (bf16): U independent 16-byte loads in flight per thread ----------------------------
-    {
+    if (DGRAD && !X3 && p.in_shadow) {
+        // the producer left a bf16 copy of this tensor (the operand of the streamed filter gradient: pixel stride KP, zero padded): 8 channels
+        // per 16-byte load, no conversion, half the bytes.  Bit-identical to the fp32 path (the same round-to-nearest-even, done earlier).
+        constexpr int U = 6;
+        const int kp8 = g.KP >> 3;
+        const int items = (g.dbg & 2) ? 0 : (TH + 2) * PW * kp8;
+        const __amdgpu_buffer_rsrc_t rs_sh = mh_make_rsrc(p.in_shadow, p.in_shadow_bytes);
+        for (int q0 = tid; q0 < items; q0 += NTH * U) {
+            u32x4 v[U];
+            int lo[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = q0 + u * NTH;
+                const int ppx = (int)__umulhi((unsigned)q, g.mul_kp8), c8 = q - ppx * kp8;        // q / kp8 (mul = ceil(2^32 / kp8), q < 2^16)
+                const int pi = ppx / PW, pj = ppx - pi * PW;
+                const int iy = y00 + (pi - 1) * d, ix = x00 + (pj - 1) * d;
+                const bool ok = q < items && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+                v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_sh, ok ? (((b * p.Hi + iy) * p.Wi + ix) * g.KP + c8 * 8) * 2 : MH_OOB, 0, 0);
+                lo[u] = q < items ? ppx * g.PS + c8 * 8 : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (lo[u] >= 0) *reinterpret_cast<u32x4*>(Ph + lo[u]) = v[u];
+        }
+    } else {
         constexpr int U = NTH == 512 ? 12 : 16;
         const int kp4 = g.KP >> 2;
         const int items = (g.dbg & 2) ? 0 : (TH + 2) * PW * kp4;
@@ -948,6 +973,7 @@ int launch_patch(ConvArgs& a, hipStream_t s) {
     g.nchunk = 9 * g.CPT;
     g.patch_halfs = (TH + 2) * PW * g.PS;
     g.inv_kp4 = 1.0f / (float)(g.KP / 4);
+    g.mul_kp8 = (unsigned)(((1ull << 32) + (g.KP / 8) - 1) / (g.KP / 8));
     g.dbg = (patch_mode() >> 9) & 3;
     const size_t lds = patch_lds(TH, BM, BN, g.KP, X3);
     ++g_patch_launches;
@@ -982,6 +1008,7 @@ int launch_bank(ConvArgs& a, hipStream_t s) {
     g.nchunk = 9 * g.CPT;
     g.patch_halfs = (TH + 2) * PW * g.PS;
     g.inv_kp4 = 1.0f / (float)(g.KP / 4);
+    g.mul_kp8 = (unsigned)(((1ull << 32) + (g.KP / 8) - 1) / (g.KP / 8));
     g.dbg = (patch_mode() >> 9) & 3;
     const size_t lds = bank_lds(TH, BM, BN, g.KP, X3);
     ++g_patch_launches;
@@ -1016,6 +1043,7 @@ int launch_bank_small(ConvArgs& a, hipStream_t s) {
     const int st = DGRAD ? 1 : a.stride;
     g.patch_halfs = (st * 2 + 3 - st) * (st * 16 + 3 - st) * g.PS;
     g.inv_kp4 = 1.0f / (float)(g.KP / 4);
+    g.mul_kp8 = (unsigned)(((1ull << 32) + (g.KP / 8) - 1) / (g.KP / 8));
     g.dbg = 0;
     const size_t patch = (size_t)g.patch_halfs * 2 * PL, cs = (size_t)16 * 32 * 33 * 4;
     const size_t lds = patch > cs ? patch : cs;

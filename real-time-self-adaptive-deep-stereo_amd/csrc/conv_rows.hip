@@ -278,6 +278,7 @@ int mh_conv_rows_launch(ConvArgs& a, hipStream_t s) {
     const int strips = mh_cdiv(a.Wo, 32);
     int R = 4;
     while ((int64_t)a.B * strips * mh_cdiv(a.Ho, R) > 2048 && R < 16) ++R;
+    if (a.stride == 2) while (R > 1 && (int64_t)a.B * strips * mh_cdiv(a.Ho, R) < 1024) --R;       // (one shared row per block: short blocks are cheap there)
     const int rblocks = mh_cdiv(a.Ho, R);
     const int units = a.B * strips * rblocks;
     const int grid = mh_cdiv(units, 4);

@@ -214,9 +214,28 @@ struct HeadBwdArgs {
 };
 #define HB_TH 4
 #define HB_TW 32
-__device__ __forceinline__ float head_dv_from_du(const ResizeArgs& p, int b, int sy, int sx) {
-    const float isy = 1.0f / p.sy, isx = 1.0f / p.sx;
+__device__ __forceinline__ float head_dv_from_du(const ResizeArgs& p, int b, int sy, int sx, bool exact2) {
     const float* gimg = p.g + (int64_t)b * p.Ho * p.Wo;
+    if (exact2) {
+        // Hr = 2 Hi, no crop: fine row Y = 2 sy sits on the coarse row (weight 1), its neighbours half way (0.5; the last fine row clamps
+        // onto the last coarse row: 1).  Same candidates, weights and order as the general walk below -- bit-identical, without its index search.
+        float acc = 0.f;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int Y = 2 * sy + dy;
+            if ((unsigned)Y >= (unsigned)p.Ho) continue;
+            const float wy = dy == 0 ? 1.0f : ((dy == 1 && sy == p.Hi - 1) ? 1.0f : 0.5f);
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int X = 2 * sx + dx;
+                if ((unsigned)X >= (unsigned)p.Wo) continue;
+                const float wx = dx == 0 ? 1.0f : ((dx == 1 && sx == p.Wi - 1) ? 1.0f : 0.5f);
+                acc += gimg[(int64_t)Y * p.Wo + X] * wy * wx;
+            }
+        }
+        return acc * p.mul;
+    }
+    const float isy = 1.0f / p.sy, isx = 1.0f / p.sx;
     const int ya = max(p.cy, (int)floorf((float)(sy - 1) * isy) - 1);
     const int yb = min(p.cy + p.Ho - 1, (int)ceilf((float)(sy + 1) * isy) + 1);
     const int xa = max(p.cx, (int)floorf((float)(sx - 1) * isx) - 1);
@@ -246,6 +265,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs p) {
     const int t2 = blockIdx.x / p.tiles_x;
     const int ty = t2 % p.tiles_y, b = t2 / p.tiles_y;
     const int y0 = ty * HB_TH, x0 = tx * HB_TW;
+    const bool exact2 = p.kind == 0 && p.rz.Hr == 2 * H && p.rz.Wr == 2 * W && p.rz.cy == 0 && p.rz.cx == 0 && p.rz.Ho == p.rz.Hr && p.rz.Wo == p.rz.Wr;
     for (int i = tid; i < 9 * p.N; i += 256) sW[i] = p.w[i];
     if (tid < (HB_TH + 2) * (HB_TW + 2)) {
         const int ly = tid / (HB_TW + 2), lx = tid - ly * (HB_TW + 2);
@@ -253,7 +273,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs p) {
         float v = 0.f;
         if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
             const int64_t pix = ((int64_t)b * H + y) * W + x;
-            if (p.kind == 0) v = head_dv_from_du(p.rz, b, y, x);
+            if (p.kind == 0) v = head_dv_from_du(p.rz, b, y, x, exact2);
             else v = (p.a1 ? p.a1[pix * p.a1_ld] : 0.f) + (p.a2 ? p.a2[pix * p.a2_ld] : 0.f);
             if (ly >= 1 && ly <= HB_TH && lx >= 1 && lx <= HB_TW) {
                 p.dV[pix] = v;

@@ -107,6 +107,7 @@ SIGNATURES = {
     "mh_conv2d_wgrad_partial_group": (_I, [C.POINTER(WgradItem), _I, _P]),
     "mh_wgrad_reduce": (_I, [_P, _I, _I, _P]),
     "mh_shadow_cast": (_I, [_P, _I, _I, _P]),
+    "mh_conv2d_sh2": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mh_conv2d_head": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     "mh_head_bwd": (_I, [C.POINTER(HeadBwdDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mh_wgrad_stream_plan": (_I, [C.POINTER(WgsLayer), _I, _I, _I, C.POINTER(C.c_int32)]),

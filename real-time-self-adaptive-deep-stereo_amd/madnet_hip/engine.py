@@ -94,6 +94,8 @@ def madnet_manifest(radius_d=2, stride=1):
 # lane that is the default since side launches are deferred (profiles/r02_experiments.txt #16) -> off by default
 # one launch for a head's output gradient + input gradient (mh_head_bwd) instead of resize gradient / copies + the K = 1 input-gradient kernel
 FUSE_HEAD = os.environ.get("MH_FUSE_HEAD", "1") != "0"
+# input gradients stage the bf16 shadow of dz when the previous input gradient's epilogue wrote one (mh_conv2d_sh2)
+SHADOW_DGRAD = os.environ.get("MH_SHADOW_DGRAD", "1") != "0"
 PYR_TAIL_FLUSH = tuple(int(x) for x in os.environ.get("MH_PYR_TAIL_FLUSH", "").split(",") if x)
 
 
@@ -498,6 +500,14 @@ class MadNetEngine(object):
         self._fresh.add(key)
         return sh
 
+    def _fresh_shadow(self, v):
+        """the bf16 shadow of View v if a producer recorded earlier in this plan wrote it (the patch-staged input-gradient kernel then stages
+        it instead of converting v), else None"""
+        if not (SHADOW_DGRAD and ops._bwd_precision() == 1):
+            return None
+        key = (v.ptr, v.B, v.H, v.W, v.C)
+        return self.shadows.get(key) if key in self._fresh else None
+
     def _front_fused(self):
         return self.fuse_front and self.warping and self.cstride == 1 and self.D <= 9
 
@@ -679,7 +689,7 @@ class MadNetEngine(object):
             if need_dx:
                 ops.conv2d_dgrad(lib, dzv, self.W_(base), dxv, stride=stride, dil=dil, accumulate=acc_flag(dx_key),
                                  mask_ref=x_act, mask_alpha=ALPHA, wb=self.Wd_(base),
-                                 shadow=(self._out_shadow(dxv, below) if below else None))
+                                 shadow=(self._out_shadow(dxv, below) if below else None), dz_shadow=self._fresh_shadow(dzv))
 
         if heads is None:
             heads = {head: (self.dpred if head == "final" else self.ddisp_k)}

@@ -178,7 +178,7 @@ def pack_weights(lib, pairs, device, keep, stream=None):
 
 
 def conv2d_dgrad(lib, dz, w, dx, stride=1, dil=1, accumulate=False, mask_ref=None, mask_alpha=1.0, mask_range=(0, 0),
-                 stream=None, wb=None, shadow=None):
+                 stream=None, wb=None, shadow=None, dz_shadow=None):
     """dx (+)= conv2d_backprop_input(dz, w); optionally fused dx *= leaky'(mask_ref).
     dz: View [B,Ho,Wo,Cout]; dx: View [B,H,W,Cin]; w: HWIO of the forward conv."""
     kh, kw, cin, cout = w.shape
@@ -187,7 +187,12 @@ def conv2d_dgrad(lib, dz, w, dx, stride=1, dil=1, accumulate=False, mask_ref=Non
     d = conv_desc(dx.B, Ho, Wo, dx.H, dx.W, cout, cin, kh, kw, stride, dil, pt, pl, 1, 1, dz.ld, dx.ld,
                   mask_ld=(mask_ref.ld if mask_ref is not None else 0), accumulate=int(accumulate),
                   alpha=1.0, mask_alpha=mask_alpha, mask_c0=mask_range[0], mask_c1=mask_range[1], precision=_bwd_precision())
-    if shadow is not None:   # shadow: ops.Shadow of dx, written by the epilogue (dx is the next layer's dz operand of wgrad_stream)
+    if dz_shadow is not None:   # dz_shadow: ops.Shadow of dz a producer already wrote: the patch-staged kernel stages it instead of converting dz
+        assert (dz_shadow.B, dz_shadow.H, dz_shadow.W, dz_shadow.C) == (dz.B, dz.H, dz.W, dz.C)
+        assert shadow is None or (shadow.B, shadow.H, shadow.W, shadow.C) == (dx.B, dx.H, dx.W, dx.C)
+        lib.conv2d_sh2(C.byref(d), _p(dz), C.c_void_p(dz_shadow.ptr), _p(w), _p(wb), None, _p(dx), _p(mask_ref),
+                       (C.c_void_p(shadow.ptr) if shadow is not None else None), _p(stream))
+    elif shadow is not None:   # shadow: ops.Shadow of dx, written by the epilogue (dx is the next layer's dz operand of wgrad_stream)
         assert (shadow.B, shadow.H, shadow.W, shadow.C) == (dx.B, dx.H, dx.W, dx.C)
         lib.conv2d_sh(C.byref(d), _p(dz), _p(w), _p(wb), None, _p(dx), _p(mask_ref), C.c_void_p(shadow.ptr), _p(stream))
     elif wb is not None:       # wb: pack_weights(trans=1, planes=1) bank of w -- the small-layer bank kernel takes it in the bf16 mode

@@ -94,6 +94,11 @@ class Recorder(object):
         self._tally(d, "conv")
         self._op(_ffi.OP_CONV, self._desc_ints(d) + [0, d.precision], [d.alpha, d.mask_alpha], [inp, w, bias, out, mask, None, wb, shadow])
 
+    def conv2d_sh2(self, dref, inp, in_shadow, w, wb, bias, out, mask, shadow, stream):
+        d = dref._obj
+        self._tally(d, "conv")
+        self._op(_ffi.OP_CONV, self._desc_ints(d) + [0, d.precision, 1], [d.alpha, d.mask_alpha], [inp, w, bias, out, mask, in_shadow, wb, shadow])
+
     def pack_weights(self, segs, nseg, nblocks, stream):
         self._op(_ffi.OP_PACK_W, [nseg, nblocks], [], [segs])
 

@@ -1039,3 +1039,40 @@ def test_conv_rows_kernel_stride2(backend, case, x3):
     if not x3:
         assert (y.cpu() - y0.cpu()).abs().max().item() <= 2 * tol * sc
     assert torch.equal(sh.t[..., :Co].cpu(), y.cpu().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("case", [(1, 12, 20, 128, 128, 1), (1, 9, 21, 64, 96, 2), (2, 10, 18, 128, 40, 1), (1, 14, 19, 96, 64, 4), (1, 9, 33, 64, 32, 1)])
+def test_conv_patch_input_gradient_from_the_shadow(backend, case):
+    """mh_conv2d_sh2: the patch-staged input-gradient kernel stages the bf16 shadow of dz (written by an earlier epilogue / mh_shadow_cast) instead of
+    converting the fp32 tensor -- the same round-to-nearest-even done earlier, so dx is BIT-identical; the fp32 dz is not read at all (poisoned here)."""
+    B, H, W, Ci, Co, dil = case
+    dev = backend.device
+    w = _rand((3, 3, Ci, Co), 812, dev, 0.2)
+    gz = _rand((B, H, W, Co), 814, dev)
+    old = _rand((B, H, W, Ci), 815, dev)
+    mref = _rand((B, H, W, Ci), 816, dev)
+    zb, zv = _padded(gz, Co)
+    mb, mv = _padded(mref, Ci)
+    keep = []
+    shz = ops.Shadow(B, H, W, Co, dev)
+    ops.shadow_cast(backend.lib, [(zv, shz)], dev, keep)
+    backend.sync()
+    prev = backend.lib.tune_conv_patch(128)            # force the patch kernel at these small sizes
+    outs = []
+    try:
+        for use_shadow in (False, True):
+            dxb, dxv = _padded(old, Ci)
+            if use_shadow:
+                zb.fill_(float("nan"))
+            ops.PRECISION_BWD = 1
+            try:
+                ops.conv2d_dgrad(backend.lib, zv, w, dxv, dil=dil, accumulate=True, mask_ref=mv, mask_alpha=0.2, dz_shadow=(shz if use_shadow else None))
+            finally:
+                ops.PRECISION_BWD = None
+            name = backend.lib.last_kernel().decode()
+            assert "conv_patch_kernel" in name and "dgrad" in name, name
+            backend.sync()
+            outs.append(dxb[..., :Ci].cpu().clone())
+    finally:
+        backend.lib.tune_conv_patch(-1)
+    assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
