@@ -78,21 +78,6 @@ typedef struct mh_conv_desc {
 int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w, const float* bias,
               float* out, const float* mask_ref, void* stream);
 
-/* mh_conv2d with an optional second view of the filter bank for the forward pass: wt[tap][Cout][Cin] = the transpose of the HWIO
- * bank w (same byte count; written by mh_transpose_weights).  Only the EXPERIMENTAL LDS-free kernel of conv_direct.hip uses it (bf16 /
- * split-bf16 modes, off unless mh_tune_conv_direct / MH_CONV_DIRECT enable it: it measured slower than the tiled kernel);
- * wt = NULL behaves exactly like mh_conv2d.  Input gradients (mode 1) read the HWIO bank k-fastest as stored and never need wt. */
-int mh_conv2d_wt(const mh_conv_desc* d, const float* in, const float* w, const float* wt, const float* bias,
-                 float* out, const float* mask_ref, void* stream);
-typedef struct mh_transpose_seg {
-    const float* src;     /* HWIO bank [taps][K][N] */
-    float* dst;           /* [taps][N][K] */
-    int32_t taps, K, N;
-    int32_t blk0;         /* exclusive prefix sum of ceil(taps*K*N / 256) over the table */
-} mh_transpose_seg;
-/* segs_device: table in DEVICE memory; nblocks = sum of ceil(taps*K*N / 256): every filter bank of a network in one launch. */
-int mh_transpose_weights(const mh_transpose_seg* segs_device, int32_t nseg, int32_t nblocks, void* stream);
-
 /* mh_conv2d with the filter bank ALSO given as an "MFMA fragment bank" (forward, stride-1 3x3 layers in split-bf16 mode, precision 2):
  * wb = the image mh_pack_weights writes -- bank[(tap * ceil(K/32) + chunk)][16-column tile][plane hi, lo][lane 0..63][8 bf16], lane l
  * holding w[tap][32*chunk + 8*(l>>4) .. +7][16*tile + (l&15)], zero padded -- mh_pack_bytes(9, K, N, 2) bytes, 16-byte aligned.  The
@@ -386,7 +371,6 @@ int mh_bias_grad(const float* dz, int32_t dz_ld, int64_t npix, int32_t nch, floa
 /* ---- tuning hooks used by scripts/microbench.py (0 = built-in heuristic) ------------------ */
 int mh_tune_conv_tile(int bm, int bn);
 int mh_tune_conv_thin(int min_pixels);   /* weights-stationary thin-layer kernel from this many output pixels (0 = default, < 0 = never) */
-int mh_tune_conv_direct(int mode);       /* experimental LDS-free small-layer kernel: 0 = off (default: measured slower than the tiled kernel), 1 = size heuristic, 2 = forced whenever eligible; returns its launch count since the previous call */
 int mh_tune_conv_patch(int mode);        /* patch-staged bf16 kernel of the stride-1 3x3 layers: 0 = off, 1 = on (tile heuristic), 64 / 128 = forced pixel tile, +256 = 8-wave variant, +2048 = generic-K instances only, +4096 = forward layers only, +8192 = no generic-K input gradients, < 0 = built-in default; returns the number of launches of that kernel since the previous call */
 int mh_tune_conv_x3_igemm(int on);       /* split-bf16 (precision 2) on the tiled implicit-GEMM kernel for forward layers without a patch / bank instance: 0 = exact fp32 there (default: measured faster), 1 = on, < 0 = default / MH_CONV_X3_IGEMM */
 int mh_tune_conv_rows(int min_pixels);   /* row-streaming kernel of the thin 3x3 stride-1 layers (conv_rows.hip: <= 16 input, <= 32 output channels): takes layers of at least this many output pixels (0 = never, < 0 = default 65536 / MH_CONV_ROWS_MINPIX); returns the previous setting (-1 = default not resolved yet) */
@@ -406,7 +390,7 @@ enum { MH_OP_CONV = 1, MH_OP_WGRAD, MH_OP_CORR_FWD, MH_OP_CORR_BWD, MH_OP_WARP_F
        MH_OP_RESIZE_FWD, MH_OP_RESIZE_BWD, MH_OP_PAD_REFLECT, MH_OP_LOSS, MH_OP_METRICS,
        MH_OP_MOMENTUM, MH_OP_COPY_CH, MH_OP_LEAKY_BWD, MH_OP_FILL, MH_OP_BIAS_GRAD,
        MH_OP_WGRAD_PARTIAL, MH_OP_WGRAD_REDUCE, MH_OP_PROXY_LOSS, MH_OP_SUPERVISED_LOSS, MH_OP_ADAM, MH_OP_ADAM_ADVANCE,
-       MH_OP_RESIZE_IMAGE, MH_OP_LEVEL_FRONT, MH_OP_TRANSPOSE_W, MH_OP_PACK_W, MH_OP_CORR_WARP_BWD, MH_OP_SHADOW_CAST, MH_OP_WGRAD_STREAM, MH_OP_HEAD_BWD, MH_OP_HEAD_FWD };
+       MH_OP_RESIZE_IMAGE, MH_OP_LEVEL_FRONT, MH_OP_RESERVED_25 /* (was: transposed filter banks of the retired LDS-free kernel) */, MH_OP_PACK_W, MH_OP_CORR_WARP_BWD, MH_OP_SHADOW_CAST, MH_OP_WGRAD_STREAM, MH_OP_HEAD_BWD, MH_OP_HEAD_FWD };
 /* i[26] of every op is its scheduling word: low byte = lane (0 = the caller's stream; 1..MH_MAX_LANES-1 = side
  * streams owned by the library: the op is forked from lane 0 right before it, i.e. ordered after everything recorded so
  * far, and runs concurrently with the lane-0 ops that follow); MH_OP_JOIN = lane 0 first waits for all side lanes.

@@ -1076,11 +1076,6 @@ int mh_conv_init() {
     return rc ? rc : conv_dispatch(a, nullptr);
 }
 
-extern "C" int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w, const float* bias,
-                         float* out, const float* mask_ref, void* stream) {
-    return mh_conv2d_wt(d, in, w, nullptr, bias, out, mask_ref, stream);
-}
-
 struct HeadOuts { float* out2; int out2_ld; float* out3; int out3_ld; const void* in_shadow; };
 static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, const float* wt, const void* wb, const float* bias,
                       float* out, const float* mask_ref, void* stream, void* out_shadow = nullptr, const HeadOuts* head = nullptr);
@@ -1089,9 +1084,9 @@ int mh_shadow_cast_one(const float* src, int src_ld, int C, void* dst, int dst_l
 static unsigned long long* g_conv_dbg = nullptr;
 extern "C" int mh_tune_conv_dbg(void* buf) { g_conv_dbg = (unsigned long long*)buf; return 0; }
 #endif
-extern "C" int mh_conv2d_wt(const mh_conv_desc* d, const float* in, const float* w, const float* wt, const float* bias,
-                            float* out, const float* mask_ref, void* stream) {
-    return conv_entry(d, in, w, wt, nullptr, bias, out, mask_ref, stream);
+extern "C" int mh_conv2d(const mh_conv_desc* d, const float* in, const float* w, const float* bias,
+                         float* out, const float* mask_ref, void* stream) {
+    return conv_entry(d, in, w, nullptr, nullptr, bias, out, mask_ref, stream);
 }
 extern "C" int mh_conv2d_wb(const mh_conv_desc* d, const float* in, const float* w, const void* wb, const float* bias,
                             float* out, const float* mask_ref, void* stream) {
@@ -1210,7 +1205,6 @@ static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, co
         }
         rc = mh_conv_patch_launch(a, hs);
     }
-    else if (mh_conv_direct_ok(a, (wt && mh_aligned16(wt)) ? wt : nullptr)) rc = mh_conv_direct_launch(a, wt, hs);
     else {
         if (a.vecC) { a.shadow = (unsigned short*)out_shadow; a.shadow_done = 1; }      // the tiled kernel's vector epilogue has the store
         rc = conv_dispatch(a, hs);

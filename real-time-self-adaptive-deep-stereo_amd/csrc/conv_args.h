@@ -44,6 +44,3 @@ int mh_conv_bank_small_launch(ConvArgs& a, hipStream_t s);     // a.M < 0: attri
 // conv_rows.hip: row-streaming kernel of the thin 3x3 layers at 1/2 resolution (<= 16 input channels, stride 1)
 bool mh_conv_rows_ok(const ConvArgs& a);
 int mh_conv_rows_launch(ConvArgs& a, hipStream_t s);
-// conv_direct.hip: LDS-free kernel of the small layers (wt = k-fastest transposed filter bank for the forward pass, may be null)
-bool mh_conv_direct_ok(const ConvArgs& a, const float* wt);
-int mh_conv_direct_launch(ConvArgs& a, const float* wt, hipStream_t s);

@@ -1081,7 +1081,7 @@ int launch_patch_n(ConvArgs& a, hipStream_t s, int bn) {
 //  every MFMA and of the epilogue was padding: 15.0 -> 13.6 us forward, 16.5 -> 14.9 us input gradient for the pyramid's 32 -> 32 layer at 96x320 x 2.
 //  A 16-column tile for the 16 -> 16 layer at 192x640 was measured too and is SLOWER than the tiled kernel (32.3 vs 28.7 us forward, 41.4 vs 28.4 us input
 //  gradient): per-workgroup latency, not padding, bounds that layer -- removed.  MH_CONV_PATCH_THIN=0 restores the 64-column floor)
-static int patch_thin() { static const int v = []() { const char* e = getenv("MH_CONV_PATCH_THIN"); return e ? atoi(e) : 1; }(); return v; }
+static int patch_thin() { return 1; }
 int patch_bn(const ConvArgs& a) {
     if (patch_thin() && a.N <= 32) return 32;
     return a.x3 ? (a.N > 64 ? 128 : 64) : (a.N > 96 ? 128 : (a.N > 64 ? 96 : 64));
@@ -1127,12 +1127,10 @@ extern "C" int mh_tune_conv_bank(int small_maxpix) {
 bool mh_conv_bank_small_ok(const ConvArgs& a) {
     // input gradients: twice the forward limit (the 1/8-resolution level too: 1.804-1.809 -> 1.800-1.802 ms per step against the tiled kernel
     // there, profiles/r03_experiments.txt #11; in the forward pass that level runs split-bf16 on the big bank kernel)
-    static const int maxpix_dgrad = []() { const char* e = getenv("MH_CONV_BANK_SMALL_MAXPIX_DGRAD"); return e ? atoi(e) : 0; }();   // A/B hook: 0 = 2 x forward
-    const int maxpix = a.mode == 1 ? (maxpix_dgrad > 0 ? maxpix_dgrad : 2 * bank_small_maxpix()) : bank_small_maxpix();
+    const int maxpix = a.mode == 1 ? 2 * bank_small_maxpix() : bank_small_maxpix();
     if (!a.wb || !(a.bf16 || a.x3) || (a.x3 && a.mode != 0)) return false;
-    static const int s2_on = []() { const char* e = getenv("MH_CONV_BANK_SMALL_S2"); return e ? atoi(e) : 1; }();      // A/B hook: stride-2 forward layers
     const bool s1 = a.stride == 1 && a.pad_t == a.dil && a.pad_l == a.dil && a.Hi == a.Ho && a.Wi == a.Wo;
-    const bool s2 = s2_on && a.stride == 2 && a.mode == 0 && a.dil == 1 && a.pad_t >= 0 && a.pad_t <= 1 && a.pad_l >= 0 && a.pad_l <= 1 &&
+    const bool s2 = a.stride == 2 && a.mode == 0 && a.dil == 1 && a.pad_t >= 0 && a.pad_t <= 1 && a.pad_l >= 0 && a.pad_l <= 1 &&
                     a.Ho == (a.Hi + 1) / 2 && a.Wo == (a.Wi + 1) / 2;
     if (!(a.kh == 3 && a.kw == 3 && (s1 || s2))) return false;
     if (a.ncls != 0 || a.N < 16 || a.K < 16 || a.dil > 64 || !a.vecA) return false;
@@ -1158,7 +1156,7 @@ bool mh_conv_patch_ok(const ConvArgs& a) {
     if (!(a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad_t == a.dil && a.pad_l == a.dil && a.Hi == a.Ho && a.Wi == a.Wo)) return false;
     // with a fragment bank the split-bf16 forward kernel also takes 32..47 output channels (half of its 64-column tile idles, still 18 -> 11 us
     // for the 64->32 layers at 1/4 resolution against the exact-fp32 gather kernel; step -0.9 %)
-    static const int bank_min_n = []() { const char* e = getenv("MH_CONV_BANK_MIN_N"); return e ? atoi(e) : 32; }();      // A/B hook
+    constexpr int bank_min_n = 32;
     const bool bank_fwd = a.x3 && a.wb && a.mode == 0;
     const int min_n = patch_thin() ? 32 : (bank_fwd ? bank_min_n : 48);                           // the 32-column tile: from 32 output columns
     if (a.ncls != 0 || a.N < min_n || a.K < 32 || a.dil > 64) return false;

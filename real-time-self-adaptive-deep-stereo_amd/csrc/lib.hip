@@ -109,7 +109,7 @@ static int run_op(const mh_op& o, void* s) {
             if (i[23]) return mh_conv2d_sh2(&d, (const float*)p[0], p[5], (const float*)p[1], p[6], (const float*)p[2], (float*)p[3], (const float*)p[4], p[7], s);
             if (p[7]) return mh_conv2d_sh(&d, (const float*)p[0], (const float*)p[1], p[6], (const float*)p[2], (float*)p[3], (const float*)p[4], p[7], s);
             if (p[6]) return mh_conv2d_wb(&d, (const float*)p[0], (const float*)p[1], p[6], (const float*)p[2], (float*)p[3], (const float*)p[4], s);
-            return mh_conv2d_wt(&d, (const float*)p[0], (const float*)p[1], (const float*)p[5], (const float*)p[2], (float*)p[3], (const float*)p[4], s);
+            return mh_conv2d(&d, (const float*)p[0], (const float*)p[1], (const float*)p[2], (float*)p[3], (const float*)p[4], s);
         }
         case MH_OP_WGRAD: {
             mh_conv_desc d; desc_from_op(o, d);
@@ -173,8 +173,6 @@ static int run_op(const mh_op& o, void* s) {
         case MH_OP_LEVEL_FRONT:
             return mh_level_front_fwd((const float*)p[0], i[0], i[1], o.f[0], (const float*)p[1], i[2], (const float*)p[2], i[3], (float*)p[3],
                                       i[4], i[5], (float*)p[4], i[6], (float*)p[5], i[7], i[8], i[9], i[10], i[11], i[12], s);
-        case MH_OP_TRANSPOSE_W:
-            return mh_transpose_weights((const mh_transpose_seg*)p[0], i[0], i[1], s);
         case MH_OP_RESIZE_IMAGE:
             return mh_resize_image_fwd((const float*)p[0], (float*)p[1], i[0], i[1], i[2], i[3], i[4], i[5], s);
         case MH_OP_PAD_REFLECT:

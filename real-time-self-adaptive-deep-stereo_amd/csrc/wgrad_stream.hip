@@ -408,9 +408,7 @@ extern "C" int mh_wgrad_stream(const mh_wgs_layer* layers_device, int32_t nlayer
     if (max_dil == -3) return stream_launch_mixed(layers_device, nlayers, nblocks, nwaves, s, false);          // stride-1 (dilation <= 8) and stride-2 layers
     MH_REQUIRE(max_dil >= 1 && max_dil <= 16, MH_ERR_UNSUPPORTED, "mh_wgrad_stream: dilation 1 .. 16 (or -2: a table of stride-2 layers, -3: mixed strides)");
     if (max_dil > 8) return stream_launch<4, 1>(layers_device, nlayers, nblocks, nwaves, s, false);
-    static const int env_d = []() { const char* e = getenv("MH_WGRAD_STREAM_DIST"); return e ? atoi(e) : 0; }();
     int dist = g_stream_dist.load(std::memory_order_relaxed);
-    if (dist <= 0) dist = env_d;
     if (dist <= 0) dist = nwaves <= 6 ? 2 : 1;                          // the deepest ring that fits 160 KB
     if (dist >= 2 && nwaves <= 6) return stream_launch<3, 2>(layers_device, nlayers, nblocks, nwaves, s, false);
     return stream_launch<3, 1>(layers_device, nlayers, nblocks, nwaves, s, false);

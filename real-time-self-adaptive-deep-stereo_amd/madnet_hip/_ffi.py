@@ -30,17 +30,13 @@ class Op(C.Structure):
 
 (OP_CONV, OP_WGRAD, OP_CORR_FWD, OP_CORR_BWD, OP_WARP_FWD, OP_WARP_BWD, OP_RESIZE_FWD, OP_RESIZE_BWD,
  OP_PAD_REFLECT, OP_LOSS, OP_METRICS, OP_MOMENTUM, OP_COPY_CH, OP_LEAKY_BWD, OP_FILL, OP_BIAS_GRAD,
- OP_WGRAD_PARTIAL, OP_WGRAD_REDUCE, OP_PROXY_LOSS, OP_SUPERVISED_LOSS, OP_ADAM, OP_ADAM_ADVANCE, OP_RESIZE_IMAGE, OP_LEVEL_FRONT, OP_TRANSPOSE_W, OP_PACK_W, OP_CORR_WARP_BWD,
+ OP_WGRAD_PARTIAL, OP_WGRAD_REDUCE, OP_PROXY_LOSS, OP_SUPERVISED_LOSS, OP_ADAM, OP_ADAM_ADVANCE, OP_RESIZE_IMAGE, OP_LEVEL_FRONT, OP_RESERVED_25, OP_PACK_W, OP_CORR_WARP_BWD,
  OP_SHADOW_CAST, OP_WGRAD_STREAM, OP_HEAD_BWD, OP_HEAD_FWD) = range(1, 32)
 
 
 OP_JOIN = 0x100
 OP_NODEFER = 0x200
 MAX_LANES = 5
-
-
-class TransposeSeg(C.Structure):
-    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("taps", C.c_int32), ("K", C.c_int32), ("N", C.c_int32), ("blk0", C.c_int32)]
 
 
 class WgradSeg(C.Structure):
@@ -90,9 +86,6 @@ SIGNATURES = {
     "mh_tune_wgrad_wgs": (_I, [_I]),
     "mh_tune_corr": (_I, [_I]),
     "mh_conv2d": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
-    "mh_conv2d_wt": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
-    "mh_transpose_weights": (_I, [_P, _I, _I, _P]),
-    "mh_tune_conv_direct": (_I, [_I]),
     "mh_conv2d_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _I, _P, _P, _P]),
     "mh_conv2d_wgrad_partial": (_I, [C.POINTER(ConvDesc), _P, _P, _I, _P, C.POINTER(C.c_int32), _P, _P]),
     "mh_corr_warp_bwd": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -155,7 +148,7 @@ SIGNATURES = {
     "mh_event_destroy": (_I, [_P]),
     "mh_stream_sync": (_I, [_P]),
 }
-_NO_STATUS = {"mh_tune_wgrad_target_pct", "mh_tune_conv_rows", "mh_last_error", "mh_last_kernel", "mh_tune_conv_direct", "mh_tune_conv_bank", "mh_pack_bytes", "mh_abi_version", "mh_tune_conv_patch", "mh_crc32c", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats", "mh_proxy_ws_floats"}
+_NO_STATUS = {"mh_tune_wgrad_target_pct", "mh_tune_conv_rows", "mh_last_error", "mh_last_kernel", "mh_tune_conv_bank", "mh_pack_bytes", "mh_abi_version", "mh_tune_conv_patch", "mh_crc32c", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats", "mh_proxy_ws_floats"}
 
 
 class MadnetHipError(RuntimeError):

@@ -28,17 +28,12 @@ CTX = [(128, 1), (128, 2), (128, 4), (96, 8), (64, 16), (32, 1), (1, 1)]
 LEVELS = (6, 5, 4, 3, 2)
 FEAT = {6: 12, 5: 10, 4: 8, 3: 6, 2: 4}
 ALPHA = 0.2   # MadNet._leaky_relu (Nets/MadNet.py:366-367)
-# Two ways of taking small kernels off the critical path (profiles/r02_experiments.txt #10, #20; same box, MADNet FULL): the warp-gradient
-# scatters on a side lane (SCATTER_LANE = 1..4; 0 = in line) and the reduction of the loss value + the validation metrics on a side
-# lane (SIDE_LOSS).  While side launches went out BEFORE the next lane-0 op both lost (in line / in line 2.454 ms; scatter lane 3 +
-# side loss 2.52-2.54; side loss only 2.62; scatter only 2.65: the critical path hopped to another hardware queue at every fork).  With
-# deferred side launches (mh_plan_run) the side loss wins 0.9 % (2.048 -> 2.030 ms) and is on; the scatters still lose (2.056 on lane 1,
-# 2.27 on a lane of their own).
-SCATTER_LANE = int(os.environ.get("MH_SCATTER_LANE", "0"))
+# The reduction of the loss value + the validation metrics run on a side lane (SIDE_LOSS: 2.048 -> 2.030 ms since side launches are deferred,
+# profiles/r02_experiments.txt #10, #20); the warp-gradient scatters on a lane of their own lost in every variant (2.056 / 2.27 ms) and
+# stay in line.
 ONE_FILL = os.environ.get("MH_ONE_FILL", "1") != "0"       # one zero fill for all level feature gradients + the g fill on the filter-gradient lane
 FUSE_BACK = os.environ.get("MH_FUSE_BACK", "1") != "0"     # one launch for a level's correlation gradient + warp gradient (mh_corr_warp_bwd)
 PYR_BF16_FROM = int(os.environ.get("MH_PYR_BF16_FROM", "7"))     # 'mixed': pyramid layers from this one on run plain bf16 in the forward pass (13 = none)
-PACK_LANE = int(os.environ.get("MH_PACK_LANE", "0"))        # lane of the per-step mh_pack_weights launch (0 = in line)
 # the first N filter-gradient batches of a backward pass are launched at once instead of after the next lane-0 op (MH_OP_NODEFER)
 NODEFER_BATCHES = int(os.environ.get("MH_NODEFER_BATCHES", "0"))
 SIDE_LOSS = os.environ.get("MH_SIDE_LOSS", "1") != "0"     # on since side launches are deferred: 2.048 -> 2.030 ms (r02z)
@@ -89,14 +84,12 @@ def madnet_manifest(radius_d=2, stride=1):
     return out
 
 
-# pyramid layers after whose input gradient the pending filter gradients are issued in addition to every 4th layer (e.g. "3,2": the last
-# batch -- conv4..conv1 -- then does not wait for the LAST input gradient).  Measured: -0.4 % with two side lanes, +0.6 % with the one
-# lane that is the default since side launches are deferred (profiles/r02_experiments.txt #16) -> off by default
-# one launch for a head's output gradient + input gradient (mh_head_bwd) instead of resize gradient / copies + the K = 1 input-gradient kernel
+
+# one launch for a head's output gradient + input gradient (mh_head_bwd) instead of resize gradient / copies + the K = 1 input-gradient kernel,
+# and the level-2 head's forward pass storing its result in the context input and in `final` too (mh_conv2d_head)
 FUSE_HEAD = os.environ.get("MH_FUSE_HEAD", "1") != "0"
 # input gradients stage the bf16 shadow of dz when the previous input gradient's epilogue wrote one (mh_conv2d_sh2)
 SHADOW_DGRAD = os.environ.get("MH_SHADOW_DGRAD", "1") != "0"
-PYR_TAIL_FLUSH = tuple(int(x) for x in os.environ.get("MH_PYR_TAIL_FLUSH", "").split(",") if x)
 
 
 class Params(object):
@@ -112,9 +105,6 @@ class Params(object):
         self.total = off
         self.w = torch.zeros(off, device=device)
         self.m = torch.zeros(off, device=device)
-        # transposed filter banks [tap][Cout][Cin] (same offsets as w): the k-fastest operand of the LDS-free small-layer kernel's
-        # forward pass, rewritten at the start of every step by ONE mh_transpose_weights launch (engine.record_forward)
-        self.wt = torch.zeros(off, device=device)
         # + 4 floats behind the gradients: the step's loss result lives there, so the shared-model mode all-reduces the
         # gradients AND the loss that drives the reward / reset logic with ONE collective (adapter.py)
         self.g_loss = torch.zeros(off + 4, device=device)     # [gradients | loss result (4 floats)]
@@ -174,7 +164,7 @@ class MadNetEngine(object):
         self._plans = {}
         self._zeros_needed = []
         # filter gradients: atomic-free split reduction (ops.conv2d_wgrad_partial) unless switched off
-        self.partial_wgrad = os.environ.get("MH_WGRAD_ATOMIC", "0") != "1"   # False: splits accumulate with fp32 atomics straight into g
+        self.partial_wgrad = True            # False (tests): splits accumulate with fp32 atomics straight into g (measured slower: +10 %)
         # ... recorded on a side lane: the filter gradients are off the critical path (only the optimizer needs
         # them), so they overlap with the input-gradient chain as a parallel branch of the hipGraph
         # ONE lane since mh_plan_run defers side launches past the next lane-0 op (2.08 ms against 2.28 ms with two lanes, 2.20 ms with
@@ -182,16 +172,12 @@ class MadNetEngine(object):
         self.wgrad_lanes = int(os.environ.get("MH_WGRAD_LANES", "1"))
         # one launch per level for the inter-level upsample + warp + cost volume + concat (mh_level_front_fwd) instead of three
         self.fuse_front = os.environ.get("MH_FUSE_FRONT", "1") != "0"        # (environment switch: in-situ A/B runs)
-        # bf16 / mixed: hand every forward conv the transposed filter bank too, so that the small layers can take the LDS-free kernel
-        # (EXPERIMENT, off by default: the LDS-free kernel measured slower, csrc/conv_direct.hip -- MH_CONV_DIRECT=1 / 2 enables it)
-        self.use_direct = precision != "fp32" and os.environ.get("MH_CONV_DIRECT", "0") != "0"
         # split-bf16 3x3 layers of the 1/4- and 1/8-resolution estimators and the context network stream their weights from MFMA
         # fragment banks (mh_conv2d_wb), re-packed by ONE launch at the start of every step
         # ... and (bf16 / mixed) the layers of the 1/16-1/64 levels -- forward and input gradient -- take the small-layer bank kernel
         self.use_bank = precision in ("mixed", "bf16") and os.environ.get("MH_CONV_BANK", "1") != "0"
         self.bank_small_maxpix = int(os.environ.get("MH_CONV_BANK_SMALL_MAXPIX", "4096"))
-        self.bank_small_maxpix_dgrad = int(os.environ.get("MH_CONV_BANK_SMALL_MAXPIX_DGRAD", "0"))
-        self.bank_min_n = int(os.environ.get("MH_CONV_BANK_MIN_N", "32"))
+        self.bank_min_n = 32
         self.banks = {}
         self.banks_d = {}
         self.wsa = ops.WgradWorkspace(device)
@@ -356,59 +342,30 @@ class MadNetEngine(object):
                 plan.append((n, 1, 0))
             if n in stride2:
                 continue                                            # (forward only: the stride-2 input gradient runs parity classes on the tiled kernel)
-            if bcode == 1 and pix <= max(self.bank_small_maxpix, self.bank_small_maxpix_dgrad) and K >= 16 and N >= 16 and 9 * ((N + 31) // 32) <= 64:
+            if bcode == 1 and pix <= 2 * self.bank_small_maxpix and K >= 16 and N >= 16 and 9 * ((N + 31) // 32) <= 64:
                 plan.append((n, 1, 1))
         return plan
 
-    def Wt_(self, base):
-        """transposed view of the layer's filter bank (None in the fp32 mode: the exact-fp32 path has no LDS-free kernel)"""
-        if not self.use_direct:
-            return None
-        P = self.params
-        o = P.offset[base + "/weights"]
-        return P.wt[o:o + P.numel(base + "/weights")]
-
-    # =========================================================================================
-    # forward  (MadNet._preprocess_inputs + _build_network, Nets/MadNet.py:56-66,251-364)
-    # =========================================================================================
     def record_forward(self, r, make_disps=()):
         B, lib = self.B, r
         head2_fused = False
-        if self.use_direct:
-            names = [n for n, shp in self.params.manifest if n.endswith("/weights") and shp[3] >= 16 and shp[2] % 8 == 0]
-            ops.transpose_weights(lib, [(self.params.tensor(n), self.Wt_(n[:-len("/weights")])) for n in names], self.dev, r.keep)
         if self.use_bank:
             plan = self._bank_plan()
             for n, planes, trans in plan:
                 tgt = self.banks_d if trans else self.banks
                 if n not in tgt:
                     tgt[n] = torch.zeros(ops.pack_bytes(self.W_(n), planes, trans) // 4, device=self.dev)
-            # PACK_LANE = 1: the pack launch runs on the side lane next to the first pyramid layers (none of them reads a bank) and is
-            # joined in front of the first layer that does
-            side_pack = PACK_LANE > 0 and self.wgrad_lanes > 0 and hasattr(lib, "lane")
-            if side_pack:
-                lib.lane = PACK_LANE
-            try:
-                ops.pack_weights(lib, [(self.W_(n), (self.banks_d if trans else self.banks)[n], planes, trans) for n, planes, trans in plan],
-                                 self.dev, r.keep)
-            finally:
-                if side_pack:
-                    lib.lane = 0
-        else:
-            side_pack = False
+            # (in line: on a side lane beside the first pyramid layers, which read no bank, it measured no gain -- profiles/r03_experiments.txt)
+            ops.pack_weights(lib, [(self.W_(n), (self.banks_d if trans else self.banks)[n], planes, trans) for n, planes, trans in plan],
+                             self.dev, r.keep)
         ops.pad_reflect(lib, self.lr, self.X0, self.pt, self.pl)
         x = ops.View(self.X0, 2 * B, self.Hp, self.Wp, 3, 4)
         for i, (ci, co, s) in enumerate(PYR, 1):
             o = self._fv(self.F[i])
-            if side_pack and self.Wb_(pyr_name(i)) is not None:
-                r.join_lanes_next = 1 << PACK_LANE
-                side_pack = False
             sh = self._out_shadow(o, pyr_name(i + 1)) if i < 12 else None       # F_i is the input of layer i + 1 (stride 1 or 2: both streamed)
-            ops.conv2d_fwd(lib, x, self.W_(pyr_name(i)), self.b_(pyr_name(i)), o, stride=s, alpha=ALPHA, wt=self.Wt_(pyr_name(i)),
+            ops.conv2d_fwd(lib, x, self.W_(pyr_name(i)), self.b_(pyr_name(i)), o, stride=s, alpha=ALPHA,
                            wb=self.Wb_(pyr_name(i)), precision=self._pyr_code(i), shadow=sh)
             x = o
-        if side_pack:
-            r.join_lanes_next = 1 << PACK_LANE
         for k in LEVELS:
             f = FEAT[k]
             h, w, c = self.fshape[f]
@@ -445,7 +402,7 @@ class MadNetEngine(object):
                     x = o
                     continue
                 ops.conv2d_fwd(lib, x, self.W_(est_name(k, j + 1)), self.b_(est_name(k, j + 1)), o,
-                               alpha=(1.0 if last else ALPHA), precision=fprec, wt=self.Wt_(est_name(k, j + 1)),
+                               alpha=(1.0 if last else ALPHA), precision=fprec,
                                wb=self.Wb_(est_name(k, j + 1)), shadow=(None if last else self._out_shadow(o, est_name(k, j + 2))))
                 x = o
             if k != 2:
@@ -463,7 +420,7 @@ class MadNetEngine(object):
         x = cin
         for j, (co, rate) in enumerate(CTX[:-1]):
             o = self._fv(self.Cx[j])
-            ops.conv2d_fwd(lib, x, self.W_(ctx_name(j + 1)), self.b_(ctx_name(j + 1)), o, dil=rate, alpha=ALPHA, wt=self.Wt_(ctx_name(j + 1)),
+            ops.conv2d_fwd(lib, x, self.W_(ctx_name(j + 1)), self.b_(ctx_name(j + 1)), o, dil=rate, alpha=ALPHA,
                            wb=self.Wb_(ctx_name(j + 1)), shadow=self._out_shadow(o, ctx_name(j + 2)))
             x = o
         # final_disp = V2_init + context7  (accumulating epilogue)
@@ -604,7 +561,6 @@ class MadNetEngine(object):
         segs = []                           # partial filter-gradient segments of this backward pass
 
         pending = []                        # deferred filter-gradient launches (flushed as one side-lane batch)
-        scatter_pending = [False]           # warp-gradient scatters issued on SCATTER_LANE and not joined yet
 
         def wgrad(xv, dzv, base, stride=1, dil=1):
             dw, db = P.tensor(base + "/weights", "g"), P.tensor(base + "/biases", "g")
@@ -774,7 +730,7 @@ class MadNetEngine(object):
                     if not fuse_head(k + 1, du=self.du[k], Hr=self.Hp // s_up, Wr=self.Wp // s_up, mul=20.0 / s_up):
                         ops.resize_bwd(lib, self.du[k], self.V[k + 1], self.dV[k + 1], self.Hp // s_up, self.Wp // s_up,
                                        mul=20.0 / s_up, mode=0, accumulate=acc_flag(("V", k + 1)))
-            elif FUSE_BACK and SCATTER_LANE == 0 and ("F", f, 1) in written:
+            elif FUSE_BACK and ("F", f, 1) in written:
                 # the level's correlation + concat gradient and the warp gradient in ONE launch (mh_corr_warp_bwd): the gradient w.r.t. the warped
                 # features never goes to memory; the scatter target was zeroed by the pass's single fill (or holds earlier contributions)
                 du = self.du[k] if need_u else None
@@ -793,24 +749,10 @@ class MadNetEngine(object):
                 # warp gradient: scatter into the right tower's feature gradient (atomics -> zero first)
                 dFr = self._half(self.dF[f], True)
                 fresh = not acc_flag(("F", f, 1))
-                if SCATTER_LANE > 0 and self.wgrad_lanes > 0 and hasattr(lib, "lane"):
-                    # the coordinate gradient feeds the next level (critical path); the scatter only feeds the pyramid backward at
-                    # the very end: it runs (with its zero fill) on side lane 3, joined right before the pyramid section
-                    if du is not None:
-                        ops.warp_bwd(lib, self._fv(self.dRw[k]), self._half(self.F[f], True), self.u[k], None, du=du, acc_u=True)
-                    lib.lane = SCATTER_LANE
-                    try:
-                        if fresh:
-                            ops_fill(lib, self.dF[f][B:], 0, self.dF[f][B:].numel())
-                        ops.warp_bwd(lib, self._fv(self.dRw[k]), self._half(self.F[f], True), self.u[k], dFr, du=None)
-                    finally:
-                        lib.lane = 0
-                    scatter_pending[0] = True
-                else:
-                    if fresh:
-                        ops_fill(lib, self.dF[f][B:], 0, self.dF[f][B:].numel())
-                    ops.warp_bwd(lib, self._fv(self.dRw[k]), self._half(self.F[f], True), self.u[k], dFr,
-                                 du=du, acc_u=True)
+                if fresh:
+                    ops_fill(lib, self.dF[f][B:], 0, self.dF[f][B:].numel())
+                ops.warp_bwd(lib, self._fv(self.dRw[k]), self._half(self.F[f], True), self.u[k], dFr,
+                             du=du, acc_u=True)
                 if need_u:
                     # u_k = resize(V_{k+1}) * 20/2^k   (MadNet.py:274: u_{k} built at level k+1 with scales[k])
                     s_up = 2 ** k
@@ -823,8 +765,6 @@ class MadNetEngine(object):
         # the second is still being computed
         if hasattr(r, "cut"):
             r.cut()
-        if scatter_pending[0]:
-            r.join_lanes_next = 1 << SCATTER_LANE          # the right-tower scatters must have landed; the filter-gradient lanes keep going
         top = None
         for i in range(12, 0, -1):
             if ("F", i, 0) in written or ("F", i, 1) in written or ("Fd", i) in written:
@@ -859,7 +799,7 @@ class MadNetEngine(object):
                     ops.conv2d_dgrad(lib, self._fv(self.dF[i]), self.W_(pyr_name(i)), self._fv(self.dF[i - 1]),
                                      stride=PYR[i - 1][2], accumulate=accumulate, mask_ref=self._fv(self.F[i - 1]),
                                      mask_alpha=ALPHA, wb=self.Wd_(pyr_name(i)), shadow=sh)
-                if i % 4 == 1 or i in PYR_TAIL_FLUSH:
+                if i % 4 == 1:
                     flush()
         flush()
         ops.wgrad_reduce(lib, segs, self.dev, r.keep)          # (serial variant only: the side-lane batches reduce themselves)

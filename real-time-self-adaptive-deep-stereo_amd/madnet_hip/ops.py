@@ -110,7 +110,7 @@ def conv_geometry(H, W, kh, kw, stride, dil):
 
 
 def conv2d_fwd(lib, x, w, b, out, stride=1, dil=1, alpha=1.0, accumulate=False, mask_ref=None, mask_alpha=1.0,
-               mask_range=(0, 0), stream=None, precision=None, wt=None, wb=None, shadow=None):
+               mask_range=(0, 0), stream=None, precision=None, wb=None, shadow=None):
     """out (+)= leaky(conv2d_SAME(x, w) + b) [* leaky'(mask_ref)].  x,out: View; w: HWIO [kh,kw,Cin,Cout].
     wb: the layer's MFMA fragment bank (pack_weights) -- split-bf16 3x3 layers then stream their weights from it."""
     kh, kw, cin, cout = w.shape
@@ -124,26 +124,8 @@ def conv2d_fwd(lib, x, w, b, out, stride=1, dil=1, alpha=1.0, accumulate=False, 
         lib.conv2d_sh(C.byref(d), _p(x), _p(w), _p(wb), _p(b), _p(out), _p(mask_ref), C.c_void_p(shadow.ptr), _p(stream))
     elif wb is not None:
         lib.conv2d_wb(C.byref(d), _p(x), _p(w), _p(wb), _p(b), _p(out), _p(mask_ref), _p(stream))
-    elif wt is not None:       # wt: the transposed filter bank [tap][Cout][Cin] (transpose_weights): lets the small layers run LDS-free
-        lib.conv2d_wt(C.byref(d), _p(x), _p(w), _p(wt), _p(b), _p(out), _p(mask_ref), _p(stream))
     else:
         lib.conv2d(C.byref(d), _p(x), _p(w), _p(b), _p(out), _p(mask_ref), _p(stream))
-
-
-def transpose_weights(lib, pairs, device, keep, stream=None):
-    """pairs: [(src HWIO tensor, dst tensor of the same numel)] -> dst[tap][n][k] = src[tap][k][n] for every pair, ONE launch.
-    `keep`: list that keeps the device table alive as long as the plan."""
-    if not pairs:
-        return
-    arr = (_ffi.TransposeSeg * len(pairs))()
-    blk = 0
-    for i, (src, dst) in enumerate(pairs):
-        kh, kw, K, N = src.shape
-        arr[i].src, arr[i].dst, arr[i].taps, arr[i].K, arr[i].N, arr[i].blk0 = src.data_ptr(), dst.data_ptr(), kh * kw, K, N, blk
-        blk += (kh * kw * K * N + 255) // 256
-    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
-    keep.append(table)
-    lib.transpose_weights(C.c_void_p(table.data_ptr()), len(pairs), blk, _p(stream))
 
 
 def pack_bytes(w, planes=2, trans=0):

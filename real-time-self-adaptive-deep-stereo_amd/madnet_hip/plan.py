@@ -79,11 +79,6 @@ class Recorder(object):
             if splits > 1:
                 self.stats["wgrad_ws_bytes"] += 2 * 4.0 * splits * taps * d.K * d.N      # written by the splits, read by the reduction
 
-    def conv2d_wt(self, dref, inp, w, wt, bias, out, mask, stream):
-        d = dref._obj
-        self._tally(d, "conv")
-        self._op(_ffi.OP_CONV, self._desc_ints(d) + [0, d.precision], [d.alpha, d.mask_alpha], [inp, w, bias, out, mask, wt])
-
     def conv2d_wb(self, dref, inp, w, wb, bias, out, mask, stream):
         d = dref._obj
         self._tally(d, "conv")
@@ -101,9 +96,6 @@ class Recorder(object):
 
     def pack_weights(self, segs, nseg, nblocks, stream):
         self._op(_ffi.OP_PACK_W, [nseg, nblocks], [], [segs])
-
-    def transpose_weights(self, segs, nseg, nblocks, stream):
-        self._op(_ffi.OP_TRANSPOSE_W, [nseg, nblocks], [], [segs])
 
     def conv2d(self, dref, inp, w, bias, out, mask, stream):
         d = dref._obj

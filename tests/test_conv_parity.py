@@ -491,68 +491,6 @@ def test_precision_code_2_falls_back_to_exact_fp32(backend):
 
 # (B, H, W, Cin, Cout, stride, dilation): the coarse estimator layers (Cin = 200 / 136 / 104 incl. a 32-k tail), pyramid layers (stride 1 / 2),
 # ragged pixel counts, Cout = 1-wide tiles excluded (N >= 16)
-DIRECT_CASES = [(1, 6, 20, 200, 128, 1, 1), (1, 12, 40, 136, 128, 1, 1), (2, 5, 9, 104, 96, 1, 1), (1, 7, 11, 64, 32, 1, 1),
-                (1, 9, 13, 96, 96, 1, 1), (1, 12, 16, 96, 128, 2, 1), (1, 8, 9, 32, 64, 1, 2), (1, 24, 40, 40, 128, 1, 1)]
-
-
-@pytest.mark.parametrize("prec", [1, 2], ids=["bf16", "bf16x3"])
-@pytest.mark.parametrize("case", DIRECT_CASES)
-def test_conv_direct_kernel(backend, case, prec):
-    """LDS-free small-layer kernel (csrc/conv_direct.hip), forced onto the layer: forward through the transposed filter bank written by
-    mh_transpose_weights (bias + leaky), and -- stride 1 -- the input gradient straight off the HWIO bank (accumulate + leaky-gradient
-    mask).  bf16: against the oracle on bf16-rounded operands; split-bf16 (forward only): against the unrounded fp64 oracle."""
-    B, H, W, Ci, Co, s, dil = case
-    dev = backend.device
-    x = _rand((B, H, W, Ci), 131, dev)
-    w = _rand((3, 3, Ci, Co), 132, dev, 0.2)
-    b = _rand((Co,), 133, dev)
-    Ho, Wo, _, _ = ops.conv_geometry(H, W, 3, 3, s, dil)
-    gz = _rand((B, Ho, Wo, Co), 134, dev)
-    wt = torch.full((w.numel(),), float("nan"), device=dev)
-    keep = []
-    ops.transpose_weights(backend.lib, [(w, wt)], dev, keep)
-    backend.sync()
-    assert torch.equal(wt.view(9, Co, Ci).cpu(), w.view(9, Ci, Co).permute(0, 2, 1).contiguous().cpu())
-    if prec == 1:
-        y_ref = T.conv2d(_bf(x.cpu()), _bf(w.cpu()), b.cpu(), stride=s, dilation=dil, alpha=0.2)
-        tol = 1e-4
-    else:
-        y_ref = T.conv2d(x.cpu().double(), w.cpu().double(), b.cpu().double(), stride=s, dilation=dil, alpha=0.2).float()
-        tol = 4e-5
-    old = _rand((B, H, W, Ci), 135, dev); mref = _rand((B, H, W, Ci), 136, dev)
-    dx = old.clone()
-    backend.lib.tune_conv_direct(2)
-    try:
-        y = torch.full(y_ref.shape, float("nan"), device=dev)
-        ops.conv2d_fwd(backend.lib, ops.view(x), w, b, ops.view(y), stride=s, dil=dil, alpha=0.2, precision=prec, wt=wt)
-        k_fwd = backend.lib.last_kernel().decode()
-        if s == 1 and prec == 1:
-            ops.PRECISION = 1
-            try:
-                ops.conv2d_dgrad(backend.lib, ops.view(gz), w, ops.view(dx), stride=1, dil=dil, accumulate=True, mask_ref=ops.view(mref), mask_alpha=0.2)
-            finally:
-                ops.PRECISION = 0
-            k_bwd = backend.lib.last_kernel().decode()
-        backend.sync()
-    finally:
-        launches = backend.lib.tune_conv_direct(-1)
-    assert "conv_direct_kernel" in k_fwd and ("bf16x3" in k_fwd) == (prec == 2), k_fwd
-    assert (y.cpu() - y_ref).abs().max().item() <= tol * max(1.0, y_ref.abs().max().item())
-    if s == 1 and prec == 1:
-        assert "conv_direct_kernel" in k_bwd and "dgrad" in k_bwd and launches == 2, (k_bwd, launches)
-        _, gx_ref, _, _ = _oracle_grads(x.cpu(), _bf(w.cpu()), b.cpu(), 1, dil, 1.0, _bf(gz.cpu()))
-        exp = (old.cpu() + gx_ref) * torch.where(mref.cpu() > 0, 1.0, 0.2)
-        assert (dx.cpu() - exp).abs().max().item() <= 1e-4 * max(1.0, gx_ref.abs().max().item())
-    # without wt the forward call falls back to the tiled kernel (same numbers up to the summation order)
-    y2 = torch.empty_like(y)
-    backend.lib.tune_conv_direct(2)
-    try:
-        ops.conv2d_fwd(backend.lib, ops.view(x), w, b, ops.view(y2), stride=s, dil=dil, alpha=0.2, precision=1)
-        assert "conv_direct" not in backend.lib.last_kernel().decode()
-    finally:
-        backend.lib.tune_conv_direct(-1)
-
-
 GROUP_LAYERS = [   # (H, W, Cin, Cout, stride, dil, precision): one batch = the filter gradients a pyramid level issues together
     (12, 20, 128, 128, 1, 1, 1), (12, 20, 128, 96, 1, 1, 1), (12, 20, 96, 64, 1, 1, 1), (12, 20, 64, 32, 1, 1, 1), (12, 20, 32, 1, 1, 1, 1),
     (12, 20, 38, 128, 1, 2, 1), (12, 20, 16, 16, 2, 1, 1), (12, 20, 3, 16, 2, 1, 1), (12, 20, 16, 32, 1, 1, 0), (12, 20, 32, 64, 1, 1, 1),
