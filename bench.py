@@ -330,6 +330,8 @@ def main():
                     help="S > 1: S INDEPENDENT stereo streams per GPU, each with its PRIVATE model / momentum / captured graph, replayed on S HIP "
                          "streams at once (SURVEY 8(e): stream i -> GPU i mod G; a batch-1 step cannot fill 256 CUs, concurrent streams can); "
                          "value = pairs/s over all streams")
+    ap.add_argument("--concurrent-graphs", action="store_true",
+                    help="--concurrent-streams: one hipGraph per model on a stream of its own (default: the models' step chains as parallel branches of ONE graph)")
     ap.add_argument("--early-reduce", action="store_true", help="--shared-model: force the two-piece all-reduce on a 1-rank group too (default: only when world > 1)")
     ap.add_argument("--late-reduce", action="store_true",
                     help="--shared-model: ONE all-reduce behind the whole backward pass instead of [estimators + context + loss] early / [pyramid] late")
@@ -453,24 +455,46 @@ def main():
     CS = args.concurrent_streams
     if CS > 1:
         assert dev.kind == "cuda" and not shared and use_graph, "--concurrent-streams needs hipGraph replay on a GPU, private models"
-        streams = [dev.stream] + [torch.cuda.Stream() for _ in range(CS - 1)]
+        from madnet_hip.plan import MultiPlan
+        branches = not args.concurrent_graphs
+        # branches of one graph: every model's chain is serial (no side lane: a fork inside a forked branch crashes hipStreamEndCapture on this
+        # runtime, profiles/r03_experiments.txt #15) -- the OTHER models' chains are what fills the gaps
+        lanes = 0 if branches else None
+        if lanes is not None:
+            eng.wgrad_lanes = lanes
+            plan = eng.build_plan(args.mode, lr=1e-4)
         plans, more_engines = [plan], []           # (the engines own the buffers the captured graphs point into)
         for i in range(1, CS):
             e_i = mk(args.precision)
+            if lanes is not None:
+                e_i.wgrad_lanes = lanes
             li, ri, gi = S.make_pair(H, W, stream_id=1000 * (rank + 1) + i)
             e_i.set_inputs(li, ri, gi[..., 0])
-            p_i = e_i.build_plan(args.mode, lr=1e-4)
-            with torch.cuda.stream(streams[i]):
-                p_i.run(lib, streams[i].cuda_stream)
-                streams[i].synchronize()
-                p_i.capture(lib, streams[i].cuda_stream)
-            plans.append(p_i)
+            plans.append(e_i.build_plan(args.mode, lr=1e-4))
             more_engines.append(e_i)
+        if args.concurrent_graphs:
+            # one graph per model, each on a stream of its own (rounds 1-2: the launches do not overlap on this runtime, +3 %)
+            streams = [dev.stream] + [torch.cuda.Stream() for _ in range(CS - 1)]
+            for p_i, st in zip(plans[1:], streams[1:]):
+                with torch.cuda.stream(st):
+                    p_i.run(lib, st.cuda_stream)
+                    st.synchronize()
+                    p_i.capture(lib, st.cuda_stream)
 
-        def one_step():                      # noqa: F811  -- one "step" = every stream advances by one frame
-            for p_i, st in zip(plans, streams):
-                p_i.launch(lib, st.cuda_stream)
-        _log("%d concurrent private streams captured" % CS)
+            def one_step():                      # noqa: F811  -- one "step" = every stream advances by one frame
+                for p_i, st in zip(plans, streams):
+                    p_i.launch(lib, st.cuda_stream)
+        else:
+            # the S step chains as parallel branches of ONE graph (mh_plans_run)
+            mp = MultiPlan(plans)
+            with dev.ctx():
+                mp.run(lib, dev.sh)                  # eager once (validates every launch)
+                dev.sync_stream()
+                mp.capture(lib, dev.sh)
+
+            def one_step():                      # noqa: F811
+                mp.launch(lib, dev.sh)
+        _log("%d concurrent private streams captured (%s)" % (CS, "one graph each" if args.concurrent_graphs else "branches of one graph"))
     with dev.ctx():
         for _ in range(args.warmup):
             one_step()

@@ -413,6 +413,13 @@ typedef struct mh_op {
     int64_t n;
 } mh_op;
 int mh_plan_run(const mh_op* ops, int32_t nops, void* stream);
+/* Several INDEPENDENT plans -- the step chains of private-model streams that share one GPU -- as parallel branches: plan 0 on
+ * `stream`, plan i > 0 on a library-owned branch stream forked from `stream` and joined before the call returns, each with side lanes of its
+ * own; captured between mh_graph_begin / mh_graph_end the S chains are S concurrent branches of ONE graph.  Plans may use lanes
+ * 0 .. MH_MAX_LANES - 2.  mh_plans_prepare(nplans) creates the branch streams and must be called once per thread outside a capture. */
+typedef struct mh_plan_ref { const mh_op* ops; int32_t nops; int32_t reserved; } mh_plan_ref;
+int mh_plans_prepare(int32_t nplans);
+int mh_plans_run(const mh_plan_ref* plans, int32_t nplans, void* stream);
 /* Threading: every entry point is re-entrant; the side streams / events of mh_plan_run are per host thread and device, the
  * tuning hooks are process-wide atomics meant for benchmarks.
  * hipGraph wrappers: capture everything launched on `stream` between begin/end. */

@@ -289,9 +289,10 @@ static int run_wgrad_batch(const mh_op* ops, int m, void* s) {
     return mh_conv2d_wgrad_partial_group(items, m, s);
 }
 
-extern "C" int mh_plan_run(const mh_op* ops, int32_t nops, void* stream) {
+// `fixed` != null: the side lanes of this run come from that lane set instead of the calling thread's (mh_plans_run: one set per plan)
+static int plan_run_impl(const mh_op* ops, int32_t nops, void* stream, Lanes* fixed) {
     MH_REQUIRE(ops || nops == 0, MH_ERR_ARG, "mh_plan_run: null plan");
-    Lanes* L = nullptr;
+    Lanes* L = fixed;
     bool dirty[MH_MAX_LANES] = {};
     bool stale[MH_MAX_LANES];          // lane 0 has launched work since this lane's last fork edge
     for (bool& b : stale) b = true;
@@ -362,6 +363,74 @@ extern "C" int mh_plan_run(const mh_op* ops, int32_t nops, void* stream) {
     }
     if (ndef) { if (int e = flush_deferred()) { join(); return e; } }
     return join();
+}
+
+extern "C" int mh_plan_run(const mh_op* ops, int32_t nops, void* stream) { return plan_run_impl(ops, nops, stream, nullptr); }
+
+// Several INDEPENDENT plans (private-model streams of one GPU: SURVEY 8(e) "several streams per GPU") as parallel branches: plan 0 runs on the
+// caller's stream with the thread's own side lanes, plan i > 0 on a library-owned branch stream (forked from the caller's stream here, joined
+// before the call returns) with a lane set of its own -- under mh_graph_begin / end the S step chains become S concurrent branches of ONE
+// graph, which is what lets the latency-bound chains of small kernels share the chip (separate graph launches on separate streams do not
+// overlap on this runtime: profiles/r02_experiments.txt #2).  Plans must keep to lanes 0 .. MH_MAX_LANES - 2.
+namespace {
+struct ThreadBranches {
+    std::vector<Lanes*> sets[16];
+    ~ThreadBranches() {
+        LanePool& P = lane_pool();
+        std::lock_guard<std::mutex> g(P.m);
+        for (int d = 0; d < 16; ++d) { for (Lanes* L : sets[d]) P.free_[d].push_back(L); sets[d].clear(); }
+    }
+};
+thread_local ThreadBranches t_branches;
+int branch_get(int idx, Lanes** out) {
+    int dev = 0;
+    MH_HIP(hipGetDevice(&dev));
+    MH_REQUIRE(dev >= 0 && dev < 16, MH_ERR_UNSUPPORTED, "device index %d out of range", dev);
+    auto& v = t_branches.sets[dev];
+    while ((int)v.size() <= idx) {
+        LanePool& P = lane_pool();
+        Lanes* L = nullptr;
+        {
+            std::lock_guard<std::mutex> g(P.m);
+            if (!P.free_[dev].empty()) { L = P.free_[dev].back(); P.free_[dev].pop_back(); }
+        }
+        if (!L) {
+            L = new Lanes;
+            for (int k = 1; k < MH_MAX_LANES; ++k) MH_HIP(hipStreamCreateWithFlags(&L->aux[k], hipStreamNonBlocking));
+            for (auto& e : L->ev) MH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            L->ready = true;
+        }
+        v.push_back(L);
+    }
+    *out = v[idx];
+    return 0;
+}
+}  // namespace
+extern "C" int mh_plans_prepare(int32_t nplans) {       // creates the branch streams / events (never inside a capture)
+    MH_REQUIRE(nplans >= 1 && nplans <= 16, MH_ERR_ARG, "mh_plans_prepare: 1 .. 16 plans");
+    for (int i = 1; i < nplans; ++i) { Lanes* L = nullptr; if (int e = branch_get(i - 1, &L)) return e; }
+    return mh_lanes_init();
+}
+extern "C" int mh_plans_run(const mh_plan_ref* plans, int32_t nplans, void* stream) {
+    MH_REQUIRE(plans && nplans >= 1 && nplans <= 16, MH_ERR_ARG, "mh_plans_run: 1 .. 16 plans");
+    for (int i = 0; i < nplans; ++i) {
+        MH_REQUIRE(plans[i].ops || plans[i].nops == 0, MH_ERR_ARG, "mh_plans_run: null plan %d", i);
+        for (int k = 0; k < plans[i].nops; ++k)
+            MH_REQUIRE((plans[i].ops[k].i[26] & 0xff) < MH_MAX_LANES - 1, MH_ERR_UNSUPPORTED, "mh_plans_run: plan %d uses lane %d (the last lane is the branch stream)", i,
+                       plans[i].ops[k].i[26] & 0xff);
+    }
+    hipStream_t s0 = (hipStream_t)stream;
+    Lanes* sets[16] = {};
+    for (int i = 1; i < nplans; ++i) {
+        if (int e = branch_get(i - 1, &sets[i])) return e;
+        if (int e = lane_edge(*sets[i], s0, sets[i]->aux[MH_MAX_LANES - 1])) return e;          // fork
+    }
+    int rc = 0;
+    for (int i = 0; i < nplans && !rc; ++i)
+        rc = plan_run_impl(plans[i].ops, plans[i].nops, i == 0 ? (void*)s0 : (void*)sets[i]->aux[MH_MAX_LANES - 1], i == 0 ? nullptr : sets[i]);
+    for (int i = 1; i < nplans; ++i)                                                          // join (also after an error: never leave a capture forked)
+        if (int e = lane_edge(*sets[i], sets[i]->aux[MH_MAX_LANES - 1], s0)) { if (!rc) rc = e; }
+    return rc;
 }
 
 

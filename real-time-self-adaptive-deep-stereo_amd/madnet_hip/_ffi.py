@@ -57,6 +57,10 @@ class ShadowSeg(C.Structure):        # mh_shadow_seg
                 ("dst_ld", C.c_int32), ("blk0", C.c_int32)]
 
 
+class PlanRef(C.Structure):          # mh_plan_ref
+    _fields_ = [("ops", C.c_void_p), ("nops", C.c_int32), ("reserved", C.c_int32)]
+
+
 class HeadBwdDesc(C.Structure):      # mh_head_bwd_desc
     _fields_ = [(n, C.c_int32) for n in ("kind", "B", "H", "W", "N", "Hr", "Wr", "cy", "cx", "Ho", "Wo")] + [("mul", C.c_float)] + \
                [(n, C.c_int32) for n in ("src0_ld", "src1_ld", "dx_ld", "mask_ld", "accumulate_dx")] + [("mask_alpha", C.c_float)]
@@ -100,6 +104,8 @@ SIGNATURES = {
     "mh_conv2d_wgrad_partial_group": (_I, [C.POINTER(WgradItem), _I, _P]),
     "mh_wgrad_reduce": (_I, [_P, _I, _I, _P]),
     "mh_shadow_cast": (_I, [_P, _I, _I, _P]),
+    "mh_plans_prepare": (_I, [_I]),
+    "mh_plans_run": (_I, [C.POINTER(PlanRef), _I, _P]),
     "mh_conv2d_sh2": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mh_conv2d_head": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     "mh_head_bwd": (_I, [C.POINTER(HeadBwdDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -265,3 +265,37 @@ class Plan(object):
             lib.graph_launch(self.graph, C.c_void_p(stream))
         else:
             self.run(lib, stream)
+
+
+class MultiPlan(object):
+    """Several independent plans (one per private-model stream of a GPU) replayed as parallel branches of ONE hipGraph (mh_plans_run): the
+    latency-bound step chains of S models share the chip instead of queueing behind one another."""
+
+    def __init__(self, plans):
+        self.plans = list(plans)
+        self.refs = (_ffi.PlanRef * len(self.plans))()
+        for i, p in enumerate(self.plans):
+            self.refs[i].ops, self.refs[i].nops = C.addressof(p.arr), p.n
+        self.graph = None
+        self.n = sum(p.n for p in self.plans)
+
+    def run(self, lib, stream):
+        lib.plans_prepare(len(self.plans))
+        lib.plans_run(self.refs, len(self.plans), C.c_void_p(stream))
+
+    def capture(self, lib, stream):
+        lib.plans_prepare(len(self.plans))
+        s = C.c_void_p(stream)
+        lib.graph_begin(s)
+        try:
+            lib.plans_run(self.refs, len(self.plans), s)
+        finally:
+            g = C.c_void_p()
+            lib.graph_end(s, C.byref(g))
+        self.graph = g
+
+    def launch(self, lib, stream):
+        if self.graph is not None:
+            lib.graph_launch(self.graph, C.c_void_p(stream))
+        else:
+            self.run(lib, stream)

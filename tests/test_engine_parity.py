@@ -721,3 +721,52 @@ def test_step_with_fused_head_backward_emulated():
 def _ffi_mod():
     from madnet_hip import _ffi
     return _ffi
+
+
+@pytest.mark.parametrize("bname,size", [SIZES[0], pytest.param("hip", (128, 256), marks=pytest.mark.gpu, id="hip-128x256")])
+def test_private_models_as_branches_of_one_graph(bname, size):
+    """mh_plans_run / plan.MultiPlan (several private-model streams on one GPU): the FULL steps of S = 3 engines -- their own weights,
+    their own frames -- run as parallel branches (captured into ONE hipGraph on the GPU), two steps; every engine ends where it ends when its plan
+    runs alone.  Same kernels on the same data: equal up to the landing order of the fp32 atomics (bias / warp gradients)."""
+    from madnet_hip.plan import MultiPlan
+    backend = _backend(bname)
+    H, W = size
+    S_ = 3
+    shapes = OM.variable_shapes()
+
+    def make(i):
+        wn = S.calibrated_weights(shapes, 1 + i)
+        l, r, gt = S.make_pair(H, W, stream_id=7 * i)
+        eng = E.MadNetEngine(backend.lib, H, W, B=1, device=backend.device, weights=wn, precision="mixed")
+        eng.set_inputs(l, r, gt[..., 0])
+        return eng
+
+    alone = []
+    for i in range(S_):
+        eng = make(i)
+        plan = eng.build_plan("FULL", lr=1e-3)
+        for _ in range(2):
+            plan.run(backend.lib, 0)
+        backend.sync()
+        alone.append((eng.params.w.clone(), eng.pred.clone(), float(eng.res_loss[0].item())))
+    engines = [make(i) for i in range(S_)]
+    for e in engines:
+        e.wgrad_lanes = 0            # serial chains: a fork inside a forked branch crashes hipStreamEndCapture on ROCm 7.2 (profiles/r03_experiments.txt #15)
+    mp = MultiPlan([e.build_plan("FULL", lr=1e-3) for e in engines])
+    if bname == "hip":
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            mp.capture(backend.lib, st.cuda_stream)
+            for _ in range(2):
+                mp.launch(backend.lib, st.cuda_stream)
+        st.synchronize()
+    else:
+        for _ in range(2):
+            mp.run(backend.lib, 0)
+    backend.sync()
+    for i, eng in enumerate(engines):
+        w0, p0, l0 = alone[i]
+        assert (eng.params.w - w0).abs().max().item() <= 1e-7 * max(1.0, w0.abs().max().item()), i
+        assert (eng.pred - p0).abs().max().item() <= 1e-4 and abs(float(eng.res_loss[0].item()) - l0) <= 1e-6, i
+    # the streams really are different problems
+    assert (alone[0][1] - alone[1][1]).abs().mean().item() > 1e-2
