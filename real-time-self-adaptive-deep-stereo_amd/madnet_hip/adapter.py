@@ -130,11 +130,10 @@ class Adapter(object):
             return []
         return sum((self.blocks[i][1] for i in key), [])
 
-    def step(self, left, right, gt=None, proxy=None):
-        eng = self.eng
+    def _sample_key(self, proxy=None):
+        """sample the portion(s) of the network to train (Stereo_Online_Adaptation.py:181-189) -> the plan key of this step"""
         if self.loss == "proxy" and proxy is None:
             raise ValueError("loss='proxy' needs the proxy disparity map of every frame")
-        # ---- sample the portion(s) of the network to train (Stereo_Online_Adaptation.py:181-189)
         if self.mode == "MAD" and self.step_count % self.sample_frequency == 0:
             distribution = softmax(self.sample_distribution)
             self.blocks_to_train = [int(b) for b in np.asarray(self.sampler.sample(distribution)).reshape(-1)]
@@ -143,16 +142,31 @@ class Adapter(object):
         key = "FULL" if self.mode == "FULL" else ("NONE" if self.mode == "NONE" else tuple(self.blocks_to_train))
         if self.step_count % self.dilation != 0:        # Stereo_Continual_Adaptation.py:205: no update op on this frame
             key = "NONE"
+        return key
+
+    def _upload(self, left, right, gt=None, proxy=None):
+        """frame -> the engine's input buffers (on the CURRENT stream)"""
+        eng = self.eng
+        eng.left.copy_(_as(left, eng.left), non_blocking=True)
+        eng.right.copy_(_as(right, eng.right), non_blocking=True)
+        if gt is not None:
+            eng.gt.copy_(_as(gt, eng.gt), non_blocking=True)
+        if proxy is not None:
+            eng.proxy.copy_(_as(proxy, eng.proxy), non_blocking=True)
+
+    def _readback(self):
+        """results -> the pinned host buffer (on the CURRENT stream)"""
+        self._host[0:4].copy_(self.eng.res_loss, non_blocking=True)
+        self._host[4:8].copy_(self.eng.res_met, non_blocking=True)
+
+    def step(self, left, right, gt=None, proxy=None):
+        eng = self.eng
+        key = self._sample_key(proxy)
         plans = self._plan(key)
         sh = self.stream.cuda_stream if self.cuda else 0
         ctx = torch.cuda.stream(self.stream) if self.cuda else _null()
         with ctx:
-            eng.left.copy_(_as(left, eng.left), non_blocking=True)
-            eng.right.copy_(_as(right, eng.right), non_blocking=True)
-            if gt is not None:
-                eng.gt.copy_(_as(gt, eng.gt), non_blocking=True)
-            if proxy is not None:
-                eng.proxy.copy_(_as(proxy, eng.proxy), non_blocking=True)
+            self._upload(left, right, gt, proxy)
             plans[0].launch(self.lib, sh)
             if self.shared and len(plans) == 3:
                 # FULL, two pieces: plans = [forward + loss + estimator / context backward, pyramid backward, update].  The first
@@ -180,10 +194,14 @@ class Adapter(object):
                     self.dist.all_reduce(P.g_loss[o:o + c], group=self.pg)
                 self.collectives_last_step = len(rng)
                 plans[1].launch(self.lib, sh)
-            self._host[0:4].copy_(eng.res_loss, non_blocking=True)
-            self._host[4:8].copy_(eng.res_met, non_blocking=True)
+            self._readback()
         if self.cuda:
             self.stream.synchronize()
+        return self._finish()
+
+    def _finish(self):
+        """host side of a step whose results sit in the pinned buffer: reward update, reset check, bookkeeping"""
+        eng = self.eng
         new_loss = float(self._host[0]) / (self.world if self.shared else 1)
         epe = float(self._host[4]); bad3 = float(self._host[5])
         # ---- reward update of the sampling logits (Stereo_Online_Adaptation.py:211-224)
@@ -216,6 +234,51 @@ class Adapter(object):
         self.step_count += 1
         return {"epe": epe, "bad3": bad3, "loss": new_loss, "disparity": eng.pred,
                 "blocks": list(self.blocks_to_train) if self.mode == "MAD" else [], "reset": did_reset}
+
+
+class MultiAdapter(object):
+    """S stereo streams with PRIVATE models on ONE GPU ("several streams per GPU may be batched"): every stream keeps its own
+    Adapter -- weights, optimizer state, sampler, reward logic, reset -- and one step() advances all of them; the S step plans run as parallel
+    branches of ONE hipGraph (mh_plans_run), one graph per combination of plan keys (FULL / NONE: one; MAD: the sampled blocks of every stream).
+    The models' chains are serial inside their branch (engine.wgrad_lanes = 0, set here before any plan is built)."""
+
+    def __init__(self, adapters):
+        from .plan import MultiPlan
+        self._MultiPlan = MultiPlan
+        self.adapters = list(adapters)
+        assert self.adapters and all(not a.shared for a in self.adapters), "private models only"
+        a0 = self.adapters[0]
+        self.lib, self.cuda = a0.lib, a0.cuda
+        for a in self.adapters:
+            assert not a._plans, "build the MultiAdapter before the adapters' first step"
+            a.eng.wgrad_lanes = 0
+            a.use_graph = False            # the combination is captured here, not the single plans
+        self.stream = a0.stream
+        for a in self.adapters:
+            a.stream = self.stream         # ONE stream orders uploads, the graph, read-backs and resets of every model
+        self._graphs = {}
+
+    def step(self, frames):
+        """frames: one (left, right[, gt[, proxy]]) tuple per stream -> [Adapter.step()'s dict per stream]"""
+        assert len(frames) == len(self.adapters)
+        keys = tuple(a._sample_key(f[3] if len(f) > 3 else None) for a, f in zip(self.adapters, frames))
+        mp = self._graphs.get(keys)
+        sh = self.stream.cuda_stream if self.cuda else 0
+        ctx = torch.cuda.stream(self.stream) if self.cuda else _null()
+        with ctx:
+            for a, f in zip(self.adapters, frames):
+                a._upload(*f)
+            if mp is None:
+                mp = self._MultiPlan([a._plan(k)[0] for a, k in zip(self.adapters, keys)])
+                if self.cuda:
+                    mp.capture(self.lib, sh)
+                self._graphs[keys] = mp
+            mp.launch(self.lib, sh)
+            for a in self.adapters:
+                a._readback()
+        if self.cuda:
+            self.stream.synchronize()
+        return [a._finish() for a in self.adapters]
 
 
 class _null(object):

@@ -98,3 +98,39 @@ def test_adapter_reset_restores_weights_not_momentum(hip):
     assert out["reset"] and ad.reset_counter == 1
     assert torch.equal(net.engine.params.w, w0)                   # weights restored ...
     assert net.engine.params.m.abs().max().item() > 0             # ... momentum accumulators persist (App. D.8)
+
+
+def test_multi_adapter_private_streams_match_single_adapters(hip):
+    """MultiAdapter (several private-model streams on one GPU): a FULL stream and a MAD stream (SEQUENTIAL sampler) advance together --
+    their step plans replayed as parallel branches of one hipGraph (one graph per combination of plan keys) -- and every stream reports and ends
+    exactly where its own Adapter ends when it runs alone on the same frames (to the landing order of the fp32 atomics)."""
+    import Nets
+    from madnet_hip.adapter import Adapter, MultiAdapter
+    H, W, lr, steps = 128, 256, 1e-3, 4
+    blocks_cfg = json.load(open(os.path.join(PKG, "block_config", "MadNet_full.json")))
+    frames = [[S.make_pair(H, W, frame=t, stream_id=sid) for t in range(steps)] for sid in range(2)]
+
+    def make(sid):
+        wn = S.calibrated_weights(OM.variable_shapes(), 1 + sid)
+        left = torch.zeros(1, H, W, 3, device="cuda"); right = torch.zeros_like(left)
+        net = Nets.get_stereo_net("MADNet", {"left_img": left, "right_img": right, "split_layers": [None], "sequence": True,
+                                              "train_portion": "BEGIN", "bulkhead": sid == 1, "weights": wn, "precision": "mixed"})
+        if sid == 0:
+            return net, Adapter(net, mode="FULL", lr=lr, ssim_th=10.0)
+        return net, Adapter(net, mode="MAD", block_config=blocks_cfg, lr=lr, sample_mode="SEQUENTIAL", num_blocks=1, ssim_th=10.0)
+
+    alone = []
+    for sid in range(2):
+        net, ad = make(sid)
+        outs = [ad.step(fr[0], fr[1], fr[2][..., 0]) for fr in frames[sid]]
+        alone.append((outs, net.engine.params.w.clone()))
+    pairs = [make(sid) for sid in range(2)]
+    multi = MultiAdapter([ad for _, ad in pairs])
+    got = [multi.step([(frames[sid][t][0], frames[sid][t][1], frames[sid][t][2][..., 0]) for sid in range(2)]) for t in range(steps)]
+    assert len(multi._graphs) == 4              # FULL x the 4 blocks the sequential sampler walked through
+    for sid in range(2):
+        for t in range(steps):
+            a, b = alone[sid][0][t], got[t][sid]
+            assert a["blocks"] == b["blocks"] and abs(a["loss"] - b["loss"]) <= 1e-6 and abs(a["epe"] - b["epe"]) <= 1e-5, (sid, t, a["loss"], b["loss"])
+        w0, w1 = alone[sid][1], pairs[sid][0].engine.params.w
+        assert (w0 - w1).abs().max().item() <= 1e-7 * max(1.0, w0.abs().max().item()), sid

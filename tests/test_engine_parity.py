@@ -770,3 +770,38 @@ def test_private_models_as_branches_of_one_graph(bname, size):
         assert (eng.pred - p0).abs().max().item() <= 1e-4 and abs(float(eng.res_loss[0].item()) - l0) <= 1e-6, i
     # the streams really are different problems
     assert (alone[0][1] - alone[1][1]).abs().mean().item() > 1e-2
+
+
+def test_multi_adapter_private_streams_emulated():
+    """adapter.MultiAdapter on the CPU emulator (the GPU version with a captured graph: tests/test_api_gpu.py): a FULL stream and a MAD stream with
+    private models advance together through mh_plans_run; losses, EPEs, sampled blocks and final weights equal those of the two Adapters run alone."""
+    from conftest import _emul_backend
+    from madnet_hip.adapter import Adapter, MultiAdapter
+    import Nets
+    be = _emul_backend()
+    H, W, lr, steps = 48, 64, 1e-3, 2
+    blocks_cfg = json.load(open(os.path.join(PKG, "block_config", "MadNet_full.json")))
+    frames = [[S.make_pair(H, W, frame=t, stream_id=sid) for t in range(steps)] for sid in range(2)]
+
+    def make(sid):
+        wn = S.calibrated_weights(OM.variable_shapes(), 1 + sid)
+        left = torch.zeros(1, H, W, 3); right = torch.zeros_like(left)
+        net = Nets.get_stereo_net("MADNet", {"left_img": left, "right_img": right, "split_layers": [None], "sequence": True, "train_portion": "BEGIN",
+                                              "bulkhead": sid == 1, "weights": wn, "precision": "mixed", "_lib": be.lib, "_device": "cpu"})
+        if sid == 0:
+            return net, Adapter(net, mode="FULL", lr=lr, ssim_th=10.0, use_graph=False)
+        return net, Adapter(net, mode="MAD", block_config=blocks_cfg, lr=lr, sample_mode="SEQUENTIAL", num_blocks=1, ssim_th=10.0, use_graph=False)
+
+    alone = []
+    for sid in range(2):
+        net, ad = make(sid)
+        alone.append(([ad.step(fr[0], fr[1], fr[2][..., 0]) for fr in frames[sid]], net.engine.params.w.clone()))
+    pairs = [make(sid) for sid in range(2)]
+    multi = MultiAdapter([ad for _, ad in pairs])
+    got = [multi.step([(frames[sid][t][0], frames[sid][t][1], frames[sid][t][2][..., 0]) for sid in range(2)]) for t in range(steps)]
+    assert len(multi._graphs) == 2
+    for sid in range(2):
+        for t in range(steps):
+            a, b = alone[sid][0][t], got[t][sid]
+            assert a["blocks"] == b["blocks"] and abs(a["loss"] - b["loss"]) <= 1e-7 and abs(a["epe"] - b["epe"]) <= 1e-6
+        assert (alone[sid][1] - pairs[sid][0].engine.params.w).abs().max().item() <= 1e-10
