@@ -1117,6 +1117,13 @@ int bank_small_maxpix() {
     if (m == -2) { const char* e = getenv("MH_CONV_BANK_SMALL_MAXPIX"); m = e ? atoi(e) : 4096; g_bank_small_maxpix.store(m, std::memory_order_relaxed); }
     return m;
 }
+std::atomic<int> g_bank_small_tile_wgs{-1};       // -1: not resolved yet (MH_CONV_BANK_SMALL_TILE_WGS, default 200; 0 = never)
+int bank_small_tile_wgs() {
+    int m = g_bank_small_tile_wgs.load(std::memory_order_relaxed);
+    if (m < 0) { const char* e = getenv("MH_CONV_BANK_SMALL_TILE_WGS"); m = e ? atoi(e) : 200; g_bank_small_tile_wgs.store(m, std::memory_order_relaxed); }
+    return m;
+}
+extern "C" int mh_tune_conv_bank_tile(int max_wgs) { return g_bank_small_tile_wgs.exchange(max_wgs < 0 ? -1 : max_wgs); }
 extern "C" int mh_tune_conv_bank(int small_maxpix) {
     g_bank_small_maxpix = small_maxpix < 0 ? -2 : small_maxpix;
     return g_bank_launches.exchange(0);
@@ -1202,6 +1209,15 @@ int mh_conv_patch_launch(ConvArgs& a, hipStream_t s) {
         if (all || (wb && bn == 128 && big)) { rc = launch_bank<2, 4, 4, 2, true>(a, s); if (!all || rc) return rc; }
         const bool w4 = !all && (patch_mode() & 0x10000) != 0;                                 // mode bit 16: 64-pixel tile with 4 waves of 64x32 (half the fragment bytes per MFMA)
         if (all || (wb && bn == 128 && w4)) { rc = launch_bank<1, 4, 4, 2, true>(a, s); if (!all || rc) return rc; }
+        // under-filled grids (the 1/8-resolution level: 120 tiles of 64x128, 60 of 128x64 on 256 CUs): a 64-pixel x 64-column tile with 4 waves
+        // doubles / quadruples the workgroups (the patch is staged once per column tile more; profiles/r03_experiments.txt #16)
+        const int small_wg = bank_small_tile_wgs();
+        bool few = false;
+        if (wb && (bn == 128 || bn == 64)) {
+            const int d = a.dil, th = bn == 128 ? 4 : 8;
+            few = (int64_t)a.B * d * d * mh_cdiv(mh_cdiv(a.Ho, d), th) * mh_cdiv(mh_cdiv(a.Wo, d), 16) < small_wg;
+        }
+        if (all || (wb && few)) { rc = launch_bank<2, 2, 2, 2, true>(a, s); if (!all || rc) return rc; }
         if (all || (wb && bn == 128)) { rc = launch_bank<2, 4, 2, 2, true>(a, s); if (!all || rc) return rc; }
         if (all || (wb && bn == 64)) { rc = launch_bank<4, 2, 2, 2, true>(a, s); if (!all || rc) return rc; }
         if (all || (wb && bn == 32)) { rc = launch_bank<8, 1, 1, 2, true>(a, s); if (!all || rc) return rc; }

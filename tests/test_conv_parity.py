@@ -540,7 +540,8 @@ def test_wgrad_partial_group_matches_single_launches(backend):
 
 @pytest.mark.parametrize("case", X3_CASES + [(1, 12, 20, 64, 32, 1), (1, 9, 21, 40, 36, 2),
                                             (2, 9, 21, 32, 32, 1), (1, 10, 18, 64, 32, 2)])      # the 32-column tile
-def test_conv_split_bf16_fragment_bank_kernel(backend, case):
+@pytest.mark.parametrize("small_tile", [False, True], ids=["tile128", "tile64x64"])
+def test_conv_split_bf16_fragment_bank_kernel(backend, case, small_tile):
     """mh_conv2d_wb: the split-bf16 forward kernel that streams its weight operand from the MFMA fragment bank mh_pack_weights writes
     (no LDS staging of the weights, no barrier in the K walk).  Same arithmetic, same summation order as the LDS-staged split-bf16
     kernel -> compared bit for bit with it, and against the unrounded fp64 oracle at the 2^-16 level."""
@@ -560,17 +561,22 @@ def test_conv_split_bf16_fragment_bank_kernel(backend, case):
     ops.pack_weights(backend.lib, [(w, bank)], dev, keep)
     backend.lib.tune_conv_patch(128)          # forced: these shapes are far below the pixel-count heuristic
     backend.lib.tune_conv_bank(0)             # 0: the small-layer bank kernel stays out of the way (it has its own test)
+    # small_tile: the 64-pixel x 64-column instance with 4 waves that under-filled grids take (1 << 30: always; 0: never)
+    prev_tile = backend.lib.tune_conv_bank_tile((1 << 30) if small_tile else 0)
     try:
         y = torch.full(y_ref.shape, float("nan"), device=dev)
         y0 = torch.full(y_ref.shape, float("nan"), device=dev)
         with ops.precision_scope("mixed"):
             ops.conv2d_fwd(backend.lib, xv, w, b, ops.view(y), stride=1, dil=dil, alpha=0.2, wb=bank)
+            name = backend.lib.last_kernel().decode()
+            assert ("conv_bank_kernel<2,2,2,2" in name) == (small_tile and Co > 32), name        # (<= 32 columns: the 128x32 tile either way)
             nb = backend.lib.tune_conv_bank(0)
             ops.conv2d_fwd(backend.lib, xv, w, b, ops.view(y0), stride=1, dil=dil, alpha=0.2)
         backend.sync()
     finally:
         launches = backend.lib.tune_conv_patch(-1)
         nb2 = backend.lib.tune_conv_bank(-1)
+        backend.lib.tune_conv_bank_tile(prev_tile)
     err = (y.cpu() - y_ref).abs().max().item()
     assert err <= 4e-5 * max(1.0, y_ref.abs().max().item()), err
     if Co >= 48:
