@@ -421,7 +421,7 @@ class DispNetEngine(object):
     def build_plan(self, mode, lr=1e-4, grad_scale=1.0, update=True, part="all", loss_weights=None, max_disp=192.0,
                    optimizer="momentum", **_):
         r = Recorder()
-        r.wgrad_group_max_m = int(os.environ.get("MH_DISPNET_GROUP_MAXM", "0"))      # per-plan cap of the grouped filter gradients (0 = library default; 4096 and 16384 measure the same here)
+        r.wgrad_group_max_m = 0      # per-plan cap of the grouped filter gradients (0 = library default; 4096 and 16384 measure the same here)
         self.wsa.reset()
         # DispNet's filter gradients (few pixels, 256-1024 channels) keep the round-1 pixel-split targets: 3.99 vs 4.08 ms (the split counts are resolved
         # while the plan is recorded and stored in it)

@@ -35,7 +35,7 @@ ONE_FILL = os.environ.get("MH_ONE_FILL", "1") != "0"       # one zero fill for a
 FUSE_BACK = os.environ.get("MH_FUSE_BACK", "1") != "0"     # one launch for a level's correlation gradient + warp gradient (mh_corr_warp_bwd)
 PYR_BF16_FROM = int(os.environ.get("MH_PYR_BF16_FROM", "7"))     # 'mixed': pyramid layers from this one on run plain bf16 in the forward pass (13 = none)
 # the first N filter-gradient batches of a backward pass are launched at once instead of after the next lane-0 op (MH_OP_NODEFER)
-NODEFER_BATCHES = int(os.environ.get("MH_NODEFER_BATCHES", "0"))
+NODEFER_BATCHES = 0             # (module attribute: tests / experiments set it; early side launches measured slower, r03 #3)
 SIDE_LOSS = os.environ.get("MH_SIDE_LOSS", "1") != "0"     # on since side launches are deferred: 2.048 -> 2.030 ms (r02z)
 
 
@@ -184,7 +184,7 @@ class MadNetEngine(object):
         # bf16 backward: the filter gradients of the stride-1 3x3 layers run on the streaming kernel (mh_wgrad_stream: one launch per batch,
         # operands from bf16 shadows of the activations / gradient maps); MH_WGRAD_STREAM=0 keeps the tiled kernels
         self.use_stream = precision in ("mixed", "bf16") and os.environ.get("MH_WGRAD_STREAM", "1") != "0"
-        self.stream_min_pix = int(os.environ.get("MH_WGRAD_STREAM_MINPIX", "0"))
+        self.stream_min_pix = 0
         self.shadows = {}                   # (data pointer, B, H, W, C) -> ops.Shadow, allocated once per engine
         # ... written by the epilogue of the kernel that produces the tensor (mh_conv2d_sh) wherever a conv kernel is the producer; the rest
         # (cost-volume buffers, heads, the top pyramid gradient) go through one mh_shadow_cast per batch.  MH_FUSE_SHADOWS=0: cast everything

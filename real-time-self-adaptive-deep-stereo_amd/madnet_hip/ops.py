@@ -302,8 +302,8 @@ def shadow_cast(lib, pairs, device, keep, stream=None):
 import os as _os
 # waves per workgroup of the streaming filter-gradient kernel (0 = the caller's choice: the engines take 4 for a batch-1 step -- the
 # kernel then shares the chip with the input-gradient chain, 1.870 -> 1.818 ms per step -- and 8 for batched streams: 163 -> 138 us per batch)
-WGRAD_STREAM_WAVES = int(_os.environ.get("MH_WGRAD_STREAM_WAVES", "0"))
-WGRAD_STREAM_WGS = int(_os.environ.get("MH_WGRAD_STREAM_WGS", "256"))        # workgroups a batch is divided into (one per CU)
+WGRAD_STREAM_WAVES = 0            # 0 = the caller's choice (4 waves at batch 1, 8 for batched streams: r03 #4)
+WGRAD_STREAM_WGS = 256        # workgroups a batch is divided into (one per CU)
 
 
 def wgrad_stream_ok(x, dz, dw, stride, dil):
