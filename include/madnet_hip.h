@@ -284,6 +284,15 @@ int mh_u8_to_f32(const uint8_t* in, float* out, int64_t n, void* stream);
  * bytes, no conversion, bit-identical result; every other kernel ignores it and reads `in`.  in_shadow may be NULL. */
 int mh_conv2d_sh2(const mh_conv_desc* d, const float* in, const void* in_shadow, const float* w, const void* wb, const float* bias,
                   float* out, const float* mask_ref, void* out_shadow, void* stream);
+/* mh_conv2d_sh2 with two more options of the patch-staged input-gradient kernel (every other kernel ignores them and behaves like mh_conv2d_sh2):
+ * mask_shadow = the bf16 shadow of mask_ref (pixel stride = N rounded up to 32): the leaky mask tests only the sign, so 8 bytes of the shadow
+ * replace 16 of the fp32 activation; flags & MH_CONV_SHADOW_ONLY: the fp32 result is NOT stored, only out_shadow (legal when every consumer of
+ * the result takes its shadow -- ask mh_conv2d_takes_shadows for the consuming launch; needs out_shadow, no accumulation).
+ * mh_conv2d_takes_shadows(d, ...) = 1 if the launch described by d / these pointers would stage in_shadow (and honour the options), else 0. */
+#define MH_CONV_SHADOW_ONLY 1
+int mh_conv2d_sh3(const mh_conv_desc* d, const float* in, const void* in_shadow, const float* w, const void* wb, const float* bias,
+                  float* out, const float* mask_ref, const void* mask_shadow, void* out_shadow, int32_t flags, void* stream);
+int mh_conv2d_takes_shadows(const mh_conv_desc* d, const float* in, const float* w, const void* wb, float* out, const float* mask_ref);
 /* Forward pass of a disparity head (mh_conv2d with N = 1, mode 0) that also stores its result at up to two more places, each with its own
  * pixel stride (floats): a channel slot of a concatenated buffer (the context network's input, Nets/MadNet.py:155-157) and / or the buffer the
  * next stage accumulates into (final = V2 + context, MadNet.py:171).  out2 / out3 may be NULL.  Saves the copy launches behind the head. */

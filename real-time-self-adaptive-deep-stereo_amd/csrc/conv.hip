@@ -1076,7 +1076,7 @@ int mh_conv_init() {
     return rc ? rc : conv_dispatch(a, nullptr);
 }
 
-struct HeadOuts { float* out2; int out2_ld; float* out3; int out3_ld; const void* in_shadow; };
+struct HeadOuts { float* out2; int out2_ld; float* out3; int out3_ld; const void* in_shadow; const void* mask_shadow = nullptr; int flags = 0; int query = 0; };
 static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, const float* wt, const void* wb, const float* bias,
                       float* out, const float* mask_ref, void* stream, void* out_shadow = nullptr, const HeadOuts* head = nullptr);
 int mh_shadow_cast_one(const float* src, int src_ld, int C, void* dst, int dst_ld, int64_t npix, hipStream_t s);      // wgrad_stream.hip
@@ -1104,6 +1104,21 @@ extern "C" int mh_conv2d_sh2(const mh_conv_desc* d, const float* in, const void*
     const HeadOuts h{nullptr, 0, nullptr, 0, in_shadow};
     return conv_entry(d, in, w, nullptr, wb, bias, out, mask_ref, stream, out_shadow, &h);
 }
+extern "C" int mh_conv2d_sh3(const mh_conv_desc* d, const float* in, const void* in_shadow, const float* w, const void* wb, const float* bias,
+                             float* out, const float* mask_ref, const void* mask_shadow, void* out_shadow, int32_t flags, void* stream) {
+    MH_REQUIRE(!out_shadow || (((uintptr_t)out_shadow) & 15u) == 0, MH_ERR_ALIGN, "mh_conv2d_sh3: out_shadow must be 16-byte aligned");
+    MH_REQUIRE(!in_shadow || (((uintptr_t)in_shadow) & 15u) == 0, MH_ERR_ALIGN, "mh_conv2d_sh3: in_shadow must be 16-byte aligned");
+    MH_REQUIRE(!mask_shadow || (((uintptr_t)mask_shadow) & 15u) == 0, MH_ERR_ALIGN, "mh_conv2d_sh3: mask_shadow must be 16-byte aligned");
+    MH_REQUIRE(!(flags & 1) || (out_shadow && !d->accumulate), MH_ERR_ARG, "mh_conv2d_sh3: MH_CONV_SHADOW_ONLY needs out_shadow and no accumulation");
+    HeadOuts h{nullptr, 0, nullptr, 0, in_shadow};
+    h.mask_shadow = mask_shadow; h.flags = flags;
+    return conv_entry(d, in, w, nullptr, wb, bias, out, mask_ref, stream, out_shadow, &h);
+}
+extern "C" int mh_conv2d_takes_shadows(const mh_conv_desc* d, const float* in, const float* w, const void* wb, float* out, const float* mask_ref) {
+    HeadOuts h{nullptr, 0, nullptr, 0, nullptr};
+    h.query = 1;
+    return conv_entry(d, in, w, nullptr, wb, nullptr, out, mask_ref, nullptr, nullptr, &h);
+}
 extern "C" int mh_conv2d_head(const mh_conv_desc* d, const float* in, const float* w, const float* bias, float* out,
                               float* out2, int32_t out2_ld, float* out3, int32_t out3_ld, void* stream) {
     MH_REQUIRE(d && d->N == 1 && d->mode == 0, MH_ERR_ARG, "mh_conv2d_head: a forward conv with ONE output channel");
@@ -1124,6 +1139,7 @@ static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, co
     a.in = in; a.w = w; a.bias = bias; a.out = out; a.mask_ref = mask_ref;
     a.out2 = a.out3 = nullptr; a.out2_ld = a.out3_ld = 0;
     a.in_shadow = nullptr; a.in_shadow_bytes = 0;
+    a.mask_shadow = nullptr; a.mask_shadow_bytes = 0; a.mask_shadow_ld = 0; a.no_f32_out = 0;
 #ifdef MH_PHASE_TIMING
     a.dbg = g_conv_dbg;
 #endif
@@ -1188,6 +1204,12 @@ static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, co
     a.shadow = nullptr; a.shadow_ld = (d->N + 31) / 32 * 32; a.shadow_done = 0;
     hipStream_t hs = (hipStream_t)stream;
     int rc;
+    if (head && head->query) {
+        // mh_conv2d_takes_shadows: would this launch stage the bf16 shadow of its input (and honour the shadow-only options)?  Same dispatch order
+        // as below: only the patch-staged input-gradient kernel does.
+        if (conv_n1_ok(a) || conv_k1_dgrad_ok(a) || mh_conv_rows_ok(a) || conv_thin_ok(a) || mh_conv_bank_small_ok(a)) return 0;
+        return (mh_conv_patch_ok(a) && a.mode == 1 && a.bf16) ? 1 : 0;
+    }
     if (head && (head->out2 || head->out3)) {
         MH_REQUIRE(conv_n1_ok(a), MH_ERR_UNSUPPORTED, "mh_conv2d_head: the layer does not fit the single-output-channel kernel (Cin %% 4, aligned operands, <= 64 KB of weights)");
         a.out2 = head->out2; a.out2_ld = head->out2_ld; a.out3 = head->out3; a.out3_ld = head->out3_ld;
@@ -1202,6 +1224,14 @@ static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, co
         if (head && head->in_shadow && a.mode == 1 && a.bf16) {          // (only this family stages a shadow; the others read the fp32 tensor)
             const int64_t sb = (int64_t)d->B * d->Hi * d->Wi * ((d->K + 31) / 32 * 32) * 2;
             if (sb < (1ll << 31) - 64) { a.in_shadow = (const unsigned short*)head->in_shadow; a.in_shadow_bytes = (unsigned)sb; }
+        }
+        if (head && a.mode == 1 && a.bf16) {
+            const int sld = (d->N + 31) / 32 * 32;
+            const int64_t mb = (int64_t)d->B * d->Ho * d->Wo * sld * 2;
+            if (head->mask_shadow && mask_ref && mb < (1ll << 31) - 64 && d->mask_c0 == 0 && (d->mask_c1 == 0 || d->mask_c1 == d->N)) {
+                a.mask_shadow = (const unsigned short*)head->mask_shadow; a.mask_shadow_bytes = (unsigned)mb; a.mask_shadow_ld = sld;
+            }
+            if ((head->flags & 1) && out_shadow && !d->accumulate) a.no_f32_out = 1;
         }
         rc = mh_conv_patch_launch(a, hs);
     }

@@ -8,6 +8,8 @@ struct ConvArgs {
     unsigned short* shadow; int shadow_ld; // != null: the epilogue also writes bf16(out) to shadow[pixel][shadow_ld] (operand of mh_wgrad_stream)
     const unsigned short* in_shadow; unsigned in_shadow_bytes;   // != null: bf16 shadow of `in` (pixel stride = K rounded up to 32, zero padded): the patch-staged
                                                                  // input-gradient kernel stages it as it is instead of converting the fp32 tensor
+    const unsigned short* mask_shadow; unsigned mask_shadow_bytes; int mask_shadow_ld;   // != null: the leaky mask reads the bf16 shadow of mask_ref (sign test only)
+    int no_f32_out;                      // 1: only the bf16 shadow of the result is stored (the consumers take the shadow; needs shadow, no accumulate)
     float* out2; float* out3; int out2_ld, out3_ld;   // single-output-channel forward conv (mh_conv2d_head): copies of the result (a concat slot, the next stage's accumulator)
     int shadow_done;                       // set by the launcher of a kernel family whose epilogue wrote the shadow (else conv_entry casts afterwards)
 #ifdef MH_PHASE_TIMING

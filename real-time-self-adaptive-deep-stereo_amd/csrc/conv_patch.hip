@@ -528,6 +528,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1,
     constexpr int PASSES = (BM + RP - 1) / RP;
     const __amdgpu_buffer_rsrc_t rs_out = mh_make_rsrc(p.out, p.out_bytes);
     const __amdgpu_buffer_rsrc_t rs_mask = mh_make_rsrc(p.mask_ref ? p.mask_ref : p.out, p.mask_ref ? p.mask_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_msh = mh_make_rsrc(p.mask_shadow ? (const void*)p.mask_shadow : (const void*)p.out, p.mask_shadow ? p.mask_shadow_bytes : 0u);
     const int c4 = tid % C4;
     const int n = n0 + c4 * 4;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -543,6 +544,13 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1,
         const int ooff = ok ? (m * p.out_ld + n) * 4 : MH_OOB;
         float4 old = make_float4(0.f, 0.f, 0.f, 0.f), mk = make_float4(1.f, 1.f, 1.f, 1.f);
         if (p.accumulate) old = mh_buf_load4(rs_out, ooff);
+        if (DGRAD && p.mask_shadow) {
+            // the mask only asks for the sign: 8 bytes of the activation's bf16 shadow instead of 16 of the fp32 tensor (bf16 keeps sign and zero)
+            const u32x2 m2 = __builtin_amdgcn_raw_buffer_load_b64(rs_msh, ok ? (m * p.mask_shadow_ld + n) * 2 : MH_OOB, 0, 0);
+            const unsigned lo2 = m2[0], hi2 = m2[1];
+            mk.x = __builtin_bit_cast(float, lo2 << 16); mk.y = __builtin_bit_cast(float, lo2 & 0xffff0000u);
+            mk.z = __builtin_bit_cast(float, hi2 << 16); mk.w = __builtin_bit_cast(float, hi2 & 0xffff0000u);
+        } else
         if (p.mask_ref) mk = mh_buf_load4(rs_mask, ok ? (m * p.mask_ld + n) * 4 : MH_OOB);
         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
         if (p.alpha != 1.0f) {
@@ -556,7 +564,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1,
             v.z *= (mk.z > 0.f || n + 2 < p.mask_c0 || n + 2 >= p.mask_c1) ? 1.0f : p.mask_alpha;
             v.w *= (mk.w > 0.f || n + 3 < p.mask_c0 || n + 3 >= p.mask_c1) ? 1.0f : p.mask_alpha;
         }
-        if (ok) *reinterpret_cast<float4*>(p.out + (int64_t)m * p.out_ld + n) = v;
+        if (ok && !(DGRAD && p.no_f32_out)) *reinterpret_cast<float4*>(p.out + (int64_t)m * p.out_ld + n) = v;
         if (ok && p.shadow) *reinterpret_cast<uint2*>(p.shadow + (int64_t)m * p.shadow_ld + n) = make_uint2(mh_pack_bf16(v.x, v.y), mh_pack_bf16(v.z, v.w));
     }
 }

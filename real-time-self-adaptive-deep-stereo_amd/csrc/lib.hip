@@ -106,6 +106,8 @@ static int run_op(const mh_op& o, void* s) {
     switch (o.kind) {
         case MH_OP_CONV: {
             mh_conv_desc d; desc_from_op(o, d);
+            if (i[23] & 6) return mh_conv2d_sh3(&d, (const float*)p[0], (i[23] & 1) ? p[5] : nullptr, (const float*)p[1], p[6], nullptr, (float*)p[3], (const float*)p[4],
+                                              (i[23] & 2) ? p[2] : nullptr, p[7], (i[23] & 4) ? MH_CONV_SHADOW_ONLY : 0, s);      // (input gradients carry no bias: p[2] = mask shadow)
             if (i[23]) return mh_conv2d_sh2(&d, (const float*)p[0], p[5], (const float*)p[1], p[6], (const float*)p[2], (float*)p[3], (const float*)p[4], p[7], s);
             if (p[7]) return mh_conv2d_sh(&d, (const float*)p[0], (const float*)p[1], p[6], (const float*)p[2], (float*)p[3], (const float*)p[4], p[7], s);
             if (p[6]) return mh_conv2d_wb(&d, (const float*)p[0], (const float*)p[1], p[6], (const float*)p[2], (float*)p[3], (const float*)p[4], s);

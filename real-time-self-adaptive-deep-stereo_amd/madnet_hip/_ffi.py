@@ -108,6 +108,8 @@ SIGNATURES = {
     "mh_plans_prepare": (_I, [_I]),
     "mh_plans_run": (_I, [C.POINTER(PlanRef), _I, _P]),
     "mh_conv2d_sh2": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mh_conv2d_sh3": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "mh_conv2d_takes_shadows": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "mh_conv2d_head": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     "mh_head_bwd": (_I, [C.POINTER(HeadBwdDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mh_wgrad_stream_plan": (_I, [C.POINTER(WgsLayer), _I, _I, _I, C.POINTER(C.c_int32)]),
@@ -155,7 +157,7 @@ SIGNATURES = {
     "mh_event_destroy": (_I, [_P]),
     "mh_stream_sync": (_I, [_P]),
 }
-_NO_STATUS = {"mh_tune_wgrad_target_pct", "mh_tune_conv_bank_tile", "mh_tune_conv_rows", "mh_last_error", "mh_last_kernel", "mh_tune_conv_bank", "mh_pack_bytes", "mh_abi_version", "mh_tune_conv_patch", "mh_crc32c", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats", "mh_proxy_ws_floats"}
+_NO_STATUS = {"mh_tune_wgrad_target_pct", "mh_conv2d_takes_shadows", "mh_tune_conv_bank_tile", "mh_tune_conv_rows", "mh_last_error", "mh_last_kernel", "mh_tune_conv_bank", "mh_pack_bytes", "mh_abi_version", "mh_tune_conv_patch", "mh_crc32c", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats", "mh_proxy_ws_floats"}
 
 
 class MadnetHipError(RuntimeError):

@@ -90,6 +90,8 @@ def madnet_manifest(radius_d=2, stride=1):
 FUSE_HEAD = os.environ.get("MH_FUSE_HEAD", "1") != "0"
 # input gradients stage the bf16 shadow of dz when the previous input gradient's epilogue wrote one (mh_conv2d_sh2)
 SHADOW_DGRAD = os.environ.get("MH_SHADOW_DGRAD", "1") != "0"
+# ... and then do not store the fp32 gradient map at all when its only reader is such an input gradient (engine._elide_fp32_gradient_maps)
+SHADOW_ONLY = os.environ.get("MH_SHADOW_ONLY", "1") != "0"
 
 
 class Params(object):
@@ -465,6 +467,42 @@ class MadNetEngine(object):
         key = (v.ptr, v.B, v.H, v.W, v.C)
         return self.shadows.get(key) if key in self._fresh else None
 
+    def _elide_fp32_gradient_maps(self, r):
+        """Post-pass over the recorded plan (dead-store elimination): an input-gradient launch that writes the bf16 shadow of its result does not
+        store the fp32 map when the ONLY op that touches that buffer afterwards is the next input gradient and that launch stages the shadow
+        (mh_conv2d_takes_shadows answers for the recorded descriptor): inside the 1/4-resolution estimator and the context network the gradient
+        maps then exist in bf16 only (15.7 MB less written per 128-channel layer)."""
+        if not (SHADOW_DGRAD and SHADOW_ONLY):
+            return 0
+        import ctypes as C
+        from . import _ffi
+        ops_ = r.ops
+        n = 0
+        spans = []
+        for idx, o in enumerate(ops_):
+            if o.kind == _ffi.OP_CONV and o.i[13] == 1 and o.p[7] and not o.i[18] and o.i[22] == 1 and o.p[3]:
+                spans.append((idx, int(o.p[3]), int(o.p[3]) + 4 * o.i[0] * o.i[3] * o.i[4] * o.i[16]))
+        for idx, lo, hi in spans:
+            users = []
+            for j, q in enumerate(ops_):
+                if j == idx:
+                    continue
+                if any(q.p[k] and lo <= int(q.p[k]) < hi for k in range(8)):
+                    users.append(j)
+            if len(users) != 1 or users[0] < idx:
+                continue
+            c = ops_[users[0]]
+            if not (c.kind == _ffi.OP_CONV and c.i[13] == 1 and int(c.p[0]) == lo and (c.i[23] & 1) and c.i[22] == 1):
+                continue
+            if sum(1 for k in range(8) if c.p[k] and lo <= int(c.p[k]) < hi) != 1:
+                continue
+            d = _ffi.ConvDesc(*([c.i[k] for k in range(18)] + [c.i[18], c.f[0], c.f[1], c.i[19], c.i[20], c.i[22]]))
+            if self.lib.conv2d_takes_shadows(C.byref(d), C.c_void_p(c.p[0]), C.c_void_p(c.p[1]), C.c_void_p(c.p[6]), C.c_void_p(c.p[3]), C.c_void_p(c.p[4])) != 1:
+                continue
+            ops_[idx].i[23] |= 4
+            n += 1
+        return n
+
     def _front_fused(self):
         return self.fuse_front and self.warping and self.cstride == 1 and self.D <= 9
 
@@ -645,7 +683,8 @@ class MadNetEngine(object):
             if need_dx:
                 ops.conv2d_dgrad(lib, dzv, self.W_(base), dxv, stride=stride, dil=dil, accumulate=acc_flag(dx_key),
                                  mask_ref=x_act, mask_alpha=ALPHA, wb=self.Wd_(base),
-                                 shadow=(self._out_shadow(dxv, below) if below else None), dz_shadow=self._fresh_shadow(dzv))
+                                 shadow=(self._out_shadow(dxv, below) if below else None), dz_shadow=self._fresh_shadow(dzv),
+                                 mask_shadow=(self._fresh_shadow(x_act) if x_act is not None else None))
 
         if heads is None:
             heads = {head: (self.dpred if head == "final" else self.ddisp_k)}
@@ -890,6 +929,7 @@ class MadNetEngine(object):
             self.record_backward(r, None, tv, bulkhead=False, heads=heads)
         if update and part in ("all", "update"):
             self.record_update_adam(r, tv, lr, grad_scale=grad_scale)
+        self._elide_fp32_gradient_maps(r)
         return r.compile()
 
     def _build_plan(self, r, mode, lr, block_vars, block_level, grad_scale, update, blocks, part, optimizer="momentum"):
@@ -945,6 +985,7 @@ class MadNetEngine(object):
                     record_update(r, bv, lr, grad_scale=grad_scale)
         else:
             raise ValueError("unknown mode %r" % (mode,))
+        self._elide_fp32_gradient_maps(r)
         return r.compile_parts() if part == "grad_split" else r.compile()
 
     # convenience: eager single forward -------------------------------------------------------

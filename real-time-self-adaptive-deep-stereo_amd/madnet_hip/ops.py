@@ -160,7 +160,7 @@ def pack_weights(lib, pairs, device, keep, stream=None):
 
 
 def conv2d_dgrad(lib, dz, w, dx, stride=1, dil=1, accumulate=False, mask_ref=None, mask_alpha=1.0, mask_range=(0, 0),
-                 stream=None, wb=None, shadow=None, dz_shadow=None):
+                 stream=None, wb=None, shadow=None, dz_shadow=None, mask_shadow=None):
     """dx (+)= conv2d_backprop_input(dz, w); optionally fused dx *= leaky'(mask_ref).
     dz: View [B,Ho,Wo,Cout]; dx: View [B,H,W,Cin]; w: HWIO of the forward conv."""
     kh, kw, cin, cout = w.shape
@@ -169,11 +169,14 @@ def conv2d_dgrad(lib, dz, w, dx, stride=1, dil=1, accumulate=False, mask_ref=Non
     d = conv_desc(dx.B, Ho, Wo, dx.H, dx.W, cout, cin, kh, kw, stride, dil, pt, pl, 1, 1, dz.ld, dx.ld,
                   mask_ld=(mask_ref.ld if mask_ref is not None else 0), accumulate=int(accumulate),
                   alpha=1.0, mask_alpha=mask_alpha, mask_c0=mask_range[0], mask_c1=mask_range[1], precision=_bwd_precision())
-    if dz_shadow is not None:   # dz_shadow: ops.Shadow of dz a producer already wrote: the patch-staged kernel stages it instead of converting dz
-        assert (dz_shadow.B, dz_shadow.H, dz_shadow.W, dz_shadow.C) == (dz.B, dz.H, dz.W, dz.C)
+    if dz_shadow is not None or mask_shadow is not None:
+        # dz_shadow / mask_shadow: ops.Shadow of dz / of mask_ref that a producer already wrote: the patch-staged kernel stages the first instead of
+        # converting dz and tests the sign of the second instead of reading the fp32 activation (other kernels ignore both)
+        assert dz_shadow is None or (dz_shadow.B, dz_shadow.H, dz_shadow.W, dz_shadow.C) == (dz.B, dz.H, dz.W, dz.C)
+        assert mask_shadow is None or (mask_ref is not None and (mask_shadow.B, mask_shadow.H, mask_shadow.W, mask_shadow.C) == (dx.B, dx.H, dx.W, dx.C))
         assert shadow is None or (shadow.B, shadow.H, shadow.W, shadow.C) == (dx.B, dx.H, dx.W, dx.C)
-        lib.conv2d_sh2(C.byref(d), _p(dz), C.c_void_p(dz_shadow.ptr), _p(w), _p(wb), None, _p(dx), _p(mask_ref),
-                       (C.c_void_p(shadow.ptr) if shadow is not None else None), _p(stream))
+        sp = lambda sh: C.c_void_p(sh.ptr) if sh is not None else None
+        lib.conv2d_sh3(C.byref(d), _p(dz), sp(dz_shadow), _p(w), _p(wb), None, _p(dx), _p(mask_ref), sp(mask_shadow), sp(shadow), 0, _p(stream))
     elif shadow is not None:   # shadow: ops.Shadow of dx, written by the epilogue (dx is the next layer's dz operand of wgrad_stream)
         assert (shadow.B, shadow.H, shadow.W, shadow.C) == (dx.B, dx.H, dx.W, dx.C)
         lib.conv2d_sh(C.byref(d), _p(dz), _p(w), _p(wb), None, _p(dx), _p(mask_ref), C.c_void_p(shadow.ptr), _p(stream))

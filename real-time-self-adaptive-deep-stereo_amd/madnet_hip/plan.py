@@ -94,6 +94,13 @@ class Recorder(object):
         self._tally(d, "conv")
         self._op(_ffi.OP_CONV, self._desc_ints(d) + [0, d.precision, 1], [d.alpha, d.mask_alpha], [inp, w, bias, out, mask, in_shadow, wb, shadow])
 
+    def conv2d_sh3(self, dref, inp, in_shadow, w, wb, bias, out, mask, mask_shadow, shadow, flags, stream):
+        d = dref._obj
+        assert bias is None
+        self._tally(d, "conv")
+        bits = (1 if in_shadow is not None else 0) | (2 if mask_shadow is not None else 0) | (4 if flags & 1 else 0)
+        self._op(_ffi.OP_CONV, self._desc_ints(d) + [0, d.precision, bits], [d.alpha, d.mask_alpha], [inp, w, mask_shadow, out, mask, in_shadow, wb, shadow])
+
     def pack_weights(self, segs, nseg, nblocks, stream):
         self._op(_ffi.OP_PACK_W, [nseg, nblocks], [], [segs])
 

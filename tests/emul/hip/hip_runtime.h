@@ -274,6 +274,13 @@ static inline void __builtin_amdgcn_raw_buffer_store_b64(emul_u32x2 v, __amdgpu_
     for (int e = 0; e < 2; ++e)
         if ((unsigned long long)off + 4ull * e + 4ull <= r.bytes) { unsigned x = v[e]; memcpy((char*)r.base + off + 4 * e, &x, 4); }
 }
+static inline emul_u32x2 __builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
+    emul_u32x2 v = {0u, 0u};
+    const unsigned off = (unsigned)voff + (unsigned)soff;
+    for (int e = 0; e < 2; ++e)
+        if ((unsigned long long)off + 4ull * e + 4ull <= r.bytes) { unsigned x; memcpy(&x, r.base + off + 4 * e, 4); v[e] = x; }
+    return v;
+}
 static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
     const unsigned off = (unsigned)voff + (unsigned)soff;
     unsigned x = 0;

@@ -805,3 +805,41 @@ def test_multi_adapter_private_streams_emulated():
             a, b = alone[sid][0][t], got[t][sid]
             assert a["blocks"] == b["blocks"] and abs(a["loss"] - b["loss"]) <= 1e-7 and abs(a["epe"] - b["epe"]) <= 1e-6
         assert (alone[sid][1] - pairs[sid][0].engine.params.w).abs().max().item() <= 1e-10
+
+
+@pytest.mark.parametrize("bname,size", [SIZES[0], pytest.param("hip", (375, 1242), marks=pytest.mark.gpu, id="hip-375x1242")])
+def test_step_with_bf16_only_gradient_maps(bname, size):
+    """engine._elide_fp32_gradient_maps: an input gradient whose fp32 result only the next (shadow-staging) input gradient would read stores just the
+    bf16 shadow, and the leaky masks test the sign of the activations' shadows (mh_conv2d_sh3).  Same filter gradients as the step that writes every
+    fp32 map -- with the fp32 gradient maps poisoned beforehand, so a kernel that still read one would show."""
+    backend = _backend(bname)
+    H, W = size
+    wn = S.calibrated_weights(OM.variable_shapes(), 1)
+    l, r, gt = S.make_pair(H, W)
+    saved = E.SHADOW_ONLY
+    if bname == "emul":
+        backend.lib.tune_conv_patch(128)            # at 60x100 the heuristic would keep the patch kernel out
+    out = {}
+    try:
+        for only in (True, False):
+            E.SHADOW_ONLY = only
+            eng = E.MadNetEngine(backend.lib, H, W, B=1, device=backend.device, weights=wn, precision="mixed")
+            eng.set_inputs(l, r, gt[..., 0])
+            plan = eng.build_plan("FULL", lr=1e-4, update=False)
+            n_only = sum(1 for k in range(plan.n) if plan.arr[k].kind == 1 and plan.arr[k].i[23] & 4)
+            n_mask = sum(1 for k in range(plan.n) if plan.arr[k].kind == 1 and plan.arr[k].i[23] & 2)
+            for k in E.LEVELS:
+                for t in eng.dE[k]:
+                    t.fill_(float("nan"))
+            for t in eng.dCx:
+                t.fill_(float("nan"))
+            plan.run(backend.lib, 0)
+            backend.sync()
+            out[only] = (eng.params.g.clone(), n_only, n_mask)
+    finally:
+        E.SHADOW_ONLY = saved
+        if bname == "emul":
+            backend.lib.tune_conv_patch(-1)
+    (g1, n1, m1), (g0, n0, m0) = out[True], out[False]
+    assert n0 == 0 and n1 >= 7 and m1 >= 9, (n0, n1, m1)
+    assert torch.isfinite(g1).all() and ((g1 - g0).norm() / g0.norm()).item() <= 1e-6
