@@ -1164,6 +1164,15 @@ static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, co
         a.vecC = (d->N % 4 == 0) && (d->out_ld % 4 == 0) && mh_aligned16(out) && (!bias || mh_aligned16(bias)) &&
                  (!mask_ref || (d->mask_ld % 4 == 0 && mh_aligned16(mask_ref))) && ob < (1ll << 31) - 64 && mb < (1ll << 31) - 64;
         a.out_bytes = (unsigned)(a.vecC ? ob : 0); a.mask_bytes = (unsigned)(a.vecC ? mb : 0);
+        // (the estimators' first layers: 38 / 70 / ... input channels in rows of 40 / 72 / ...: see ConvArgs::vecCpad)
+        a.vecCpad = 0;
+        const int n4 = (d->N + 3) / 4 * 4;
+        if (!a.vecC && d->mode == 1 && d->N % 4 != 0 && !bias && d->out_ld % 4 == 0 && d->out_ld >= n4 && mh_aligned16(out) &&
+            (!mask_ref || (d->mask_ld % 4 == 0 && d->mask_ld >= n4 && mh_aligned16(mask_ref)))) {
+            const int64_t obp = (((int64_t)d->B * d->Ho * d->Wo - 1) * d->out_ld + n4) * 4;
+            const int64_t mbp = mask_ref ? (((int64_t)d->B * d->Ho * d->Wo - 1) * d->mask_ld + n4) * 4 : 0;
+            if (obp < (1ll << 31) - 64 && mbp < (1ll << 31) - 64) { a.vecCpad = 1; a.out_bytes = (unsigned)obp; a.mask_bytes = (unsigned)mbp; }
+        }
     }
     a.sshift = 0;
     while ((1 << a.sshift) < d->stride) ++a.sshift;

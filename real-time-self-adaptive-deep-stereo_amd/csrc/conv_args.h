@@ -24,6 +24,8 @@ struct ConvArgs {
     int bf16;        // throughput mode: bf16 MFMA inputs, fp32 accumulate
     int x3;          // split-bf16 request (precision 2): kernels with an x3 instance run hi/lo bf16 operands, 3 MFMAs per product; the others exact fp32
     int vecC;        // 16-byte epilogue legal (N, out_ld, mask_ld multiples of 4, aligned pointers)
+    int vecCpad;     // input gradient whose N is NOT a multiple of 4 but whose rows are padded to one (out_ld, mask_ld >= round_up(N, 4)): the patch-staged
+                     // kernel's 16-byte epilogue is legal -- the channels N .. round_up(N, 4) - 1 (row padding nobody reads) receive zeros
     int M;           // B*Ho*Wo
     int vecA, vecB;  // 16-byte vector loads legal for A / B
     int mtiles, ntiles;

@@ -1167,7 +1167,7 @@ int mh_conv_bank_small_launch(ConvArgs& a, hipStream_t s) {
 
 bool mh_conv_patch_ok(const ConvArgs& a) {
     if (patch_mode() == 0) return false;
-    if (!((a.bf16 || (a.x3 && a.mode == 0)) && a.vecA && a.vecB && a.vecC)) return false;
+    if (!((a.bf16 || (a.x3 && a.mode == 0)) && a.vecA && a.vecB && (a.vecC || (a.vecCpad && a.mode == 1 && a.bf16)))) return false;
     if (!(a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad_t == a.dil && a.pad_l == a.dil && a.Hi == a.Ho && a.Wi == a.Wo)) return false;
     // with a fragment bank the split-bf16 forward kernel also takes 32..47 output channels (half of its 64-column tile idles, still 18 -> 11 us
     // for the 64->32 layers at 1/4 resolution against the exact-fp32 gather kernel; step -0.9 %)

@@ -985,7 +985,8 @@ def test_conv_rows_kernel_stride2(backend, case, x3):
     assert torch.equal(sh.t[..., :Co].cpu(), y.cpu().to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("case", [(1, 12, 20, 128, 128, 1), (1, 9, 21, 64, 96, 2), (2, 10, 18, 128, 40, 1), (1, 14, 19, 96, 64, 4), (1, 9, 33, 64, 32, 1)])
+@pytest.mark.parametrize("case", [(1, 12, 20, 128, 128, 1), (1, 9, 21, 64, 96, 2), (2, 10, 18, 128, 40, 1), (1, 14, 19, 96, 64, 4), (1, 9, 33, 64, 32, 1),
+                                  (1, 12, 20, 38, 128, 1), (2, 9, 17, 70, 128, 1)])     # 38 / 70 gradient channels in rows of 40 / 72 (the estimators' first layers)
 def test_conv_patch_input_gradient_from_the_shadow(backend, case):
     """mh_conv2d_sh2: the patch-staged input-gradient kernel stages the bf16 shadow of dz (written by an earlier epilogue / mh_shadow_cast) instead of
     converting the fp32 tensor -- the same round-to-nearest-even done earlier, so dx is BIT-identical; the fp32 dz is not read at all (poisoned here)."""
@@ -995,8 +996,9 @@ def test_conv_patch_input_gradient_from_the_shadow(backend, case):
     gz = _rand((B, H, W, Co), 814, dev)
     old = _rand((B, H, W, Ci), 815, dev)
     mref = _rand((B, H, W, Ci), 816, dev)
+    ldx = (Ci + 3) // 4 * 4
     zb, zv = _padded(gz, Co)
-    mb, mv = _padded(mref, Ci)
+    mb, mv = _padded(mref, ldx)
     keep = []
     shz = ops.Shadow(B, H, W, Co, dev)
     ops.shadow_cast(backend.lib, [(zv, shz)], dev, keep)
@@ -1005,7 +1007,7 @@ def test_conv_patch_input_gradient_from_the_shadow(backend, case):
     outs = []
     try:
         for use_shadow in (False, True):
-            dxb, dxv = _padded(old, Ci)
+            dxb, dxv = _padded(old, ldx)
             if use_shadow:
                 zb.fill_(float("nan"))
             ops.PRECISION_BWD = 1
@@ -1020,3 +1022,8 @@ def test_conv_patch_input_gradient_from_the_shadow(backend, case):
     finally:
         backend.lib.tune_conv_patch(-1)
     assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
+    xr = torch.zeros(B, H, W, Ci, dtype=torch.float64, requires_grad=True)
+    yr = T.conv2d(xr, _bf(w.cpu()).double(), None, dilation=dil, alpha=1.0)
+    (gx,) = torch.autograd.grad(yr, [xr], _bf(gz.cpu()).double())
+    exp = ((old.cpu().double() + gx) * torch.where(mref.cpu() > 0, 1.0, 0.2)).float()
+    assert (outs[1] - exp).abs().max().item() <= 2e-5 * max(1.0, gx.abs().max().item())
