@@ -363,7 +363,7 @@ def test_conv_bf16_patch_kernel(backend, case):
     # dispatch rule (mh_conv_patch_ok): >= 32 output columns (a 32-column tile since round 3), >= 32 reduction channels, 16-byte rows;
     # mode 1: these shapes are too small for the tile heuristic -> gather kernel
     fwd_ok = Co >= 32 and Ci >= 32 and Co % 4 == 0
-    dgrad_ok = Ci >= 32 and Co >= 32 and Ci % 4 == 0
+    dgrad_ok = Ci >= 32 and Co >= 32            # (the gradient rows are padded to a multiple of 4 floats here: Cin = 38 qualifies since round 3, #18)
     assert launches == (0 if mode == 1 else int(fwd_ok) + int(dgrad_ok))
     assert (y.cpu() - y_ref).abs().max().item() <= 1e-4 * max(1.0, y_ref.abs().max().item())
     exp = (old.cpu() + gx_ref) * torch.where(mref.cpu() > 0, 1.0, 0.2)
