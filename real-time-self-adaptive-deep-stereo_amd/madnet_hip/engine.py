@@ -87,6 +87,11 @@ def madnet_manifest(radius_d=2, stride=1):
 
 # one launch for a head's output gradient + input gradient (mh_head_bwd) instead of resize gradient / copies + the K = 1 input-gradient kernel,
 # and the level-2 head's forward pass storing its result in the context input and in `final` too (mh_conv2d_head)
+# the first filter-gradient batches of a backward pass (context network, estimators 2 and 3: issued long before the step ends) run on 192
+# workgroups instead of 256: a quarter less split workspace and a quarter of the CUs left to the main chain (profiles/r03_experiments.txt #20:
+# 1.635 -> 1.629 ms; 128 / 96 workgroups: 1.649 / 1.652)
+EARLY_WGS = 192
+EARLY_BATCHES = 3
 FUSE_HEAD = os.environ.get("MH_FUSE_HEAD", "1") != "0"
 # input gradients stage the bf16 shadow of dz when the previous input gradient's epilogue wrote one (mh_conv2d_sh2)
 SHADOW_DGRAD = os.environ.get("MH_SHADOW_DGRAD", "1") != "0"
@@ -636,7 +641,8 @@ class MadNetEngine(object):
                         else:
                             todo.append((xv, dzv, dw, db, stride, dil))
                     ops.shadow_cast(lib, casts, self.dev, r.keep)
-                    ops.wgrad_stream(lib, self.lib, self.wsa, batch, items, self.dev, r.keep, nwaves=(4 if self.B == 1 else 8))
+                    ops.wgrad_stream(lib, self.lib, self.wsa, batch, items, self.dev, r.keep, nwaves=(4 if self.B == 1 else 8),
+                                     target_wgs=(EARLY_WGS if (EARLY_WGS and self.B == 1 and nflush[0] <= EARLY_BATCHES) else None))
                 for xv, dzv, dw, db, stride, dil in todo:
                     if self.partial_wgrad:
                         ops.conv2d_wgrad_partial(lib, self.lib, self.wsa, batch, xv, dzv, dw, db, stride=stride, dil=dil)
