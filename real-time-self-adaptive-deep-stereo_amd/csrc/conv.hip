@@ -1225,7 +1225,18 @@ static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, co
     }
     if (conv_n1_ok(a)) rc = launch_conv_n1(a, hs);
     else if (conv_k1_dgrad_ok(a)) { a.shadow = (unsigned short*)out_shadow; a.shadow_done = 1; rc = launch_conv_k1_dgrad(a, hs); }
-    else if (mh_conv_rows_ok(a)) { a.shadow = (unsigned short*)out_shadow; a.shadow_done = 1; rc = mh_conv_rows_launch(a, hs); }
+    else if (mh_conv_rows_ok(a)) {
+        a.shadow = (unsigned short*)out_shadow; a.shadow_done = 1;
+        if (head && head->in_shadow && head->mask_shadow && mask_ref && a.mode == 1 && a.bf16 && d->mask_c0 == 0 && (d->mask_c1 == 0 || d->mask_c1 == d->N)) {
+            // input AND mask from bf16 shadows (the row kernel takes both or neither)
+            const int64_t sb = (int64_t)d->B * d->Hi * d->Wi * ((d->K + 31) / 32 * 32) * 2, mb = (int64_t)d->B * d->Ho * d->Wo * ((d->N + 31) / 32 * 32) * 2;
+            if (sb < (1ll << 31) - 64 && mb < (1ll << 31) - 64) {
+                a.in_shadow = (const unsigned short*)head->in_shadow; a.in_shadow_bytes = (unsigned)sb;
+                a.mask_shadow = (const unsigned short*)head->mask_shadow; a.mask_shadow_bytes = (unsigned)mb; a.mask_shadow_ld = (d->N + 31) / 32 * 32;
+            }
+        }
+        rc = mh_conv_rows_launch(a, hs);
+    }
     else if (conv_thin_ok(a)) rc = launch_conv_thin(a, hs);
     else if (mh_conv_bank_small_ok(a)) { a.shadow = (unsigned short*)out_shadow; a.shadow_done = 1; rc = mh_conv_bank_small_launch(a, hs); }
     else if (mh_conv_patch_ok(a)) {

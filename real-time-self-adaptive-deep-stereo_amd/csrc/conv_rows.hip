@@ -44,7 +44,9 @@ __device__ __forceinline__ void rows_cvt(const float4& a, const float4& b, u32x4
 // EPI: the epilogue reads the old output (accumulate) and / or a leaky-gradient mask; those loads are issued BEFORE the next row's prefetch so that
 // waiting for them does not drain it.
 // NQ: channel quads per lane that exist (2: <= 16 output channels, 4: <= 32) -- compile time, so that no all-out-of-range store is issued.
-template <int S, bool X3, bool EPI, int NQ>
+// SH: the input AND the leaky mask come from bf16 shadows (input gradient whose predecessor wrote the shadow of dz, activation shadow from the
+// forward pass): one 16-byte load per fragment instead of two + a conversion, 8 mask bytes instead of 16.
+template <int S, bool X3, bool EPI, int NQ, bool SH = false>
 __global__ __launch_bounds__(256) void conv_rows_kernel(ConvArgs p, int R, int strips, int rblocks, unsigned mulK, unsigned mulN) {
     // filter bank -> LDS in A-fragment order, zero padded: sA[tap][output channel m < 32][input channel kk < 16].  forward: HWIO w[t][kk][m] ;
     // input gradient: taps flipped and the bank transposed, w[8 - t][m][kk] (m = input channel of the forward conv)
@@ -60,12 +62,14 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(ConvArgs p, int R, int s
     const int r1 = min(r0 + R, p.Ho);
     const int lp = lane & 31, lh = lane >> 5;
 
-    const __amdgpu_buffer_rsrc_t rs_in = mh_make_rsrc(p.in, p.in_bytes);
+    const __amdgpu_buffer_rsrc_t rs_in = SH ? mh_make_rsrc(p.in_shadow, p.in_shadow_bytes) : mh_make_rsrc(p.in, p.in_bytes);
+    const int sh_ld = (p.K + 31) & ~31;              // (SH) pixel stride of the input's shadow, halfs
     // byte offset of (row, pixel S * (x0 + lp) + dx - pad, channel 8 * lh) ; K <= 8: the upper half-wave has no channels
     const bool kok = 8 * lh < p.K;
     auto row_off = [&](int r, int dx) -> int {
         const int x = S * (x0 + lp) + dx - p.pad_l;
         const bool ok = active && kok && (unsigned)r < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
+        if (SH) return ok ? (((b * p.Hi + r) * p.Wi + x) * sh_ld + 8 * lh) * 2 : MH_OOB;
         return ok ? (((b * p.Hi + r) * p.Wi + x) * p.in_ld + 8 * lh) * 4 : MH_OOB;
     };
     // K % 4 != 0 (the image layer: 3 channels in a 4-float pixel): whatever sits in the padding lanes of the last group must not meet the MFMA
@@ -75,12 +79,13 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(ConvArgs p, int R, int s
         for (int dx = 0; dx < 3; ++dx) {
             const int o = row_off(r, dx);
             dst[dx][0] = mh_buf_load4(rs_in, o);
-            dst[dx][1] = mh_buf_load4(rs_in, (o == MH_OOB || 8 * lh + 4 >= p.K) ? MH_OOB : o + 16);
+            if (!SH) dst[dx][1] = mh_buf_load4(rs_in, (o == MH_OOB || 8 * lh + 4 >= p.K) ? MH_OOB : o + 16);
         }
     };
     auto cvt_row = [&](float4 (&src)[3][2], u32x4* Bh, u32x4* Bl) {
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
+            if (SH) { Bh[dx] = __builtin_bit_cast(u32x4, src[dx][0]); Bl[dx] = (u32x4){0u, 0u, 0u, 0u}; continue; }      // 8 bf16 as they lie in the shadow
             if (ktail) {            // (wave-uniform; K < 8 here: only the first group carries channels)
                 float4& v = src[dx][0];
                 if (ktail < 2) v.y = 0.f;
@@ -150,6 +155,8 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(ConvArgs p, int R, int s
     // so the compiler can count the outstanding stores and the next row's loads stay in flight across the epilogue.
     const __amdgpu_buffer_rsrc_t rs_out = mh_make_rsrc(p.out, p.out_bytes);
     const __amdgpu_buffer_rsrc_t rs_mask = mh_make_rsrc(p.mask_ref, p.mask_ref ? p.mask_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_msh = mh_make_rsrc(SH ? (const void*)p.mask_shadow : (const void*)p.out, SH ? p.mask_shadow_bytes : 0u);
+    const int msh_ld = (p.N + 31) & ~31;
     const __amdgpu_buffer_rsrc_t rs_sh = mh_make_rsrc(p.shadow, p.shadow ? (unsigned)p.M * (unsigned)p.shadow_ld * 2u : 0u);
     float4 oldv[NQ], mkv[NQ];
     auto epi_load = [&](int y) {
@@ -161,6 +168,11 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(ConvArgs p, int R, int s
             const int n = 8 * q + 4 * lh;
             const bool ok = y >= 0 && x < p.Wo && n < p.N;
             oldv[q] = mh_buf_load4(rs_out, (ok && p.accumulate) ? (m * p.out_ld + n) * 4 : MH_OOB);
+            if (SH) {        // sign of the activation's bf16 shadow (pixel stride = N rounded up to 32 halfs)
+                const u32x2 m2 = __builtin_amdgcn_raw_buffer_load_b64(rs_msh, ok ? (m * msh_ld + n) * 2 : MH_OOB, 0, 0);
+                mkv[q] = make_float4(__builtin_bit_cast(float, m2[0] << 16), __builtin_bit_cast(float, m2[0] & 0xffff0000u),
+                                     __builtin_bit_cast(float, m2[1] << 16), __builtin_bit_cast(float, m2[1] & 0xffff0000u));
+            } else
             mkv[q] = mh_buf_load4(rs_mask, ok ? (m * p.mask_ld + n) * 4 : MH_OOB);
         }
     };
@@ -287,6 +299,11 @@ int mh_conv_rows_launch(ConvArgs& a, hipStream_t s) {
 #define MH_ROWS(Sv, X3v, EPIv)                                                                                                          \
     { if (a.N <= 16) hipLaunchKernelGGL((conv_rows_kernel<Sv, X3v, EPIv, 2>), dim3(grid), dim3(256), 0, s, a, R, strips, rblocks, mulK, mulN);       \
       else hipLaunchKernelGGL((conv_rows_kernel<Sv, X3v, EPIv, 4>), dim3(grid), dim3(256), 0, s, a, R, strips, rblocks, mulK, mulN); }
+    const bool sh = a.stride == 1 && !a.x3 && epi && a.in_shadow && a.mask_shadow && a.mask_ref;
+    if (sh) {
+        if (a.N <= 16) hipLaunchKernelGGL((conv_rows_kernel<1, false, true, 2, true>), dim3(grid), dim3(256), 0, s, a, R, strips, rblocks, mulK, mulN);
+        else hipLaunchKernelGGL((conv_rows_kernel<1, false, true, 4, true>), dim3(grid), dim3(256), 0, s, a, R, strips, rblocks, mulK, mulN);
+    } else
     if (a.stride == 1) {
         if (a.x3) MH_ROWS(1, true, false)
         else if (epi) MH_ROWS(1, false, true)
@@ -297,7 +314,7 @@ int mh_conv_rows_launch(ConvArgs& a, hipStream_t s) {
         else MH_ROWS(2, false, false)
     }
 #undef MH_ROWS
-    mh_note_kernel("conv_rows_kernel<%s,%s,s%d> R=%d grid %d", a.mode == 1 ? "dgrad" : "fwd", a.x3 ? "bf16x3" : "bf16", a.stride, R, grid);
+    mh_note_kernel("conv_rows_kernel<%s,%s,s%d%s> R=%d grid %d", a.mode == 1 ? "dgrad" : "fwd", a.x3 ? "bf16x3" : "bf16", a.stride, sh ? ",shadows" : "", R, grid);
     return mh_check_launch("conv_rows");
 }
 

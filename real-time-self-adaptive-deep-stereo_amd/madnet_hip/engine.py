@@ -843,7 +843,8 @@ class MadNetEngine(object):
                     sh = self._out_shadow(self._fv(self.dF[i - 1]), pyr_name(i - 1)) if (i - 1 > 1) else None       # (conv1's 3-channel input keeps the tiled kernel)
                     ops.conv2d_dgrad(lib, self._fv(self.dF[i]), self.W_(pyr_name(i)), self._fv(self.dF[i - 1]),
                                      stride=PYR[i - 1][2], accumulate=accumulate, mask_ref=self._fv(self.F[i - 1]),
-                                     mask_alpha=ALPHA, wb=self.Wd_(pyr_name(i)), shadow=sh)
+                                     mask_alpha=ALPHA, wb=self.Wd_(pyr_name(i)), shadow=sh,
+                                     dz_shadow=self._fresh_shadow(self._fv(self.dF[i])), mask_shadow=self._fresh_shadow(self._fv(self.F[i - 1])))
                 if i % 4 == 1:
                     flush()
         flush()

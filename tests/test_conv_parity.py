@@ -929,6 +929,23 @@ def test_conv_rows_kernel(backend, case, what):
             assert (outs[0] - exp).abs().max().item() <= 2e-5 * sc
             assert (outs[0] - outs[1]).abs().max().item() <= 4e-5 * sc
             assert torch.equal(sh.t[..., :Ci].cpu(), outs[0].to(torch.bfloat16))
+            # the same launch with dz and the mask taken from their bf16 shadows (mh_conv2d_sh3): bit-identical, the fp32 dz is not read
+            keep = []
+            shz, shm = ops.Shadow(B, H, W, Co, dev), ops.Shadow(B, H, W, Ci, dev)
+            ops.shadow_cast(backend.lib, [(zv, shz), (mv, shm)], dev, keep)
+            backend.sync()
+            zb.fill_(float("nan"))
+            backend.lib.tune_conv_rows(1)
+            dxb, dxv = _padded(old, ldx)
+            ops.PRECISION_BWD = 1
+            try:
+                ops.conv2d_dgrad(backend.lib, zv, w, dxv, accumulate=True, mask_ref=mv, mask_alpha=0.2, dz_shadow=shz, mask_shadow=shm)
+            finally:
+                ops.PRECISION_BWD = None
+            name = backend.lib.last_kernel().decode()
+            backend.sync()
+            assert "conv_rows_kernel<dgrad,bf16,s1,shadows>" in name, name
+            assert torch.equal(dxb[..., :Ci].cpu(), outs[0])
     finally:
         backend.lib.tune_conv_rows(prev)
 
