@@ -133,4 +133,5 @@ def test_multi_adapter_private_streams_match_single_adapters(hip):
             a, b = alone[sid][0][t], got[t][sid]
             assert a["blocks"] == b["blocks"] and abs(a["loss"] - b["loss"]) <= 1e-6 and abs(a["epe"] - b["epe"]) <= 1e-5, (sid, t, a["loss"], b["loss"])
         w0, w1 = alone[sid][1], pairs[sid][0].engine.params.w
-        assert (w0 - w1).abs().max().item() <= 1e-7 * max(1.0, w0.abs().max().item()), sid
+        # (four steps at lr 1e-3: the landing order of the fp32 atomics -- bias / warp gradients -- differs between a replayed graph and eager launches: ~1e-7)
+        assert (w0 - w1).abs().max().item() <= 1e-6 * max(1.0, w0.abs().max().item()), sid

@@ -766,7 +766,7 @@ def test_private_models_as_branches_of_one_graph(bname, size):
     backend.sync()
     for i, eng in enumerate(engines):
         w0, p0, l0 = alone[i]
-        assert (eng.params.w - w0).abs().max().item() <= 1e-7 * max(1.0, w0.abs().max().item()), i
+        assert (eng.params.w - w0).abs().max().item() <= 1e-6 * max(1.0, w0.abs().max().item()), i
         assert (eng.pred - p0).abs().max().item() <= 1e-4 and abs(float(eng.res_loss[0].item()) - l0) <= 1e-6, i
     # the streams really are different problems
     assert (alone[0][1] - alone[1][1]).abs().mean().item() > 1e-2
