@@ -94,3 +94,55 @@ def test_corr_and_misc_argument_checks(backend):
     assert _raw(backend, "plan_run")(op, 1, None) == ERR_ARG and "plan op 0" in _msg(backend)
     op[0].kind = _ffi.OP_FILL; op[0].i[26] = 7
     assert _raw(backend, "plan_run")(op, 1, None) == ERR_ARG and "lane" in _msg(backend)
+
+
+def test_round3_entry_points_argument_checks(backend):
+    """mh_head_bwd, mh_conv2d_head, mh_conv2d_sh3, mh_conv2d_takes_shadows, mh_plans_run: argument errors return a negative code with a message
+    and launch nothing; the dispatch query answers 1 only for a launch that would stage its input's shadow."""
+    dev = backend.device
+    P = lambda t: C.c_void_p(t.data_ptr())
+    B, H, W, N = 1, 12, 20, 32
+    w = torch.zeros(3, 3, N, 1, device=dev)
+    dV = torch.full((B, H, W), float("nan"), device=dev)
+    dx = torch.full((B, H, W, N), float("nan"), device=dev)
+    du = torch.zeros(B, 2 * H, 2 * W, device=dev)
+    hb = _raw(backend, "head_bwd")
+    d = _ffi.HeadBwdDesc()
+    d.kind, d.B, d.H, d.W, d.N, d.Hr, d.Wr, d.Ho, d.Wo, d.mul, d.dx_ld = 0, B, H, W, N, 2 * H, 2 * W, 2 * H, 2 * W, 1.0, N
+    assert hb(C.byref(d), None, None, P(dV), None, P(w), P(dx), None, None, None) == ERR_ARG            # no source at all
+    d.kind = 2
+    assert hb(C.byref(d), P(du), None, P(dV), None, P(w), P(dx), None, None, None) == ERR_ARG and "kind" in _msg(backend)
+    d.kind, d.N = 0, 30
+    assert hb(C.byref(d), P(du), None, P(dV), None, P(w), P(dx), None, None, None) == ERR_ARG             # N must be a multiple of 4
+    d.N, d.dx_ld = N, N + 2
+    assert hb(C.byref(d), P(du), None, P(dV), None, P(w), P(dx), None, None, None) == ERR_ALIGN
+    backend.sync()
+    assert torch.isnan(dV).all() and torch.isnan(dx).all()
+    # mh_conv2d_head: only a forward conv with ONE output channel
+    x = torch.zeros(B, H, W, N, device=dev); o = torch.zeros(B, H, W, device=dev); o2 = torch.zeros(B, H, W, device=dev)
+    dc = ops.conv_desc(B, H, W, H, W, N, 8, 3, 3, 1, 1, 1, 1, 0, 0, N, 8)
+    head = _raw(backend, "conv2d_head")
+    assert head(C.byref(dc), P(x), P(w), None, P(o), P(o2), 1, None, 0, None) == ERR_ARG and "ONE output channel" in _msg(backend)
+    dc1 = ops.conv_desc(B, H, W, H, W, N, 1, 3, 3, 1, 1, 1, 1, 0, 0, N, 1)
+    assert head(C.byref(dc1), P(x), P(w), None, P(o), P(o2), 0, None, 0, None) == ERR_ARG                 # pixel stride of an extra output
+    # mh_conv2d_sh3: shadow-only needs the shadow and no accumulation
+    wd = torch.zeros(3, 3, 64, 64, device=dev); gz = torch.zeros(B, H, W, 64, device=dev); gx = torch.zeros(B, H, W, 64, device=dev)
+    dd = ops.conv_desc(B, H, W, H, W, 64, 64, 3, 3, 1, 1, 1, 1, 1, 1, 64, 64, precision=1)
+    sh3 = _raw(backend, "conv2d_sh3")
+    assert sh3(C.byref(dd), P(gz), None, P(wd), None, None, P(gx), None, None, None, 1, None) == ERR_ARG and "SHADOW_ONLY" in _msg(backend)
+    # the dispatch query: the patch-staged input gradient (forced on at this size) stages shadows, the same layer in fp32 does not
+    q = _raw(backend, "conv2d_takes_shadows")
+    backend.lib.tune_conv_patch(128)
+    try:
+        assert q(C.byref(dd), P(gz), P(wd), None, P(gx), None) == 1
+        d0 = ops.conv_desc(B, H, W, H, W, 64, 64, 3, 3, 1, 1, 1, 1, 1, 1, 64, 64, precision=0)
+        assert q(C.byref(d0), P(gz), P(wd), None, P(gx), None) == 0
+        df = ops.conv_desc(B, H, W, H, W, 64, 64, 3, 3, 1, 1, 1, 1, 0, 0, 64, 64, precision=1)
+        assert q(C.byref(df), P(gz), P(wd), None, P(gx), None) == 0                                       # a forward conv
+    finally:
+        backend.lib.tune_conv_patch(-1)
+    # mh_plans_run: a plan that uses the last lane (reserved for the branch streams) is refused
+    op = (_ffi.Op * 1)(); op[0].kind = _ffi.OP_FILL; op[0].i[26] = 4
+    refs = (_ffi.PlanRef * 1)(); refs[0].ops, refs[0].nops = C.addressof(op), 1
+    assert _raw(backend, "plans_run")(refs, 1, None) < 0 and "lane" in _msg(backend)
+    assert _raw(backend, "plans_run")(refs, 0, None) == ERR_ARG
