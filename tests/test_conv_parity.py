@@ -1044,3 +1044,25 @@ def test_conv_patch_input_gradient_from_the_shadow(backend, case):
     (gx,) = torch.autograd.grad(yr, [xr], _bf(gz.cpu()).double())
     exp = ((old.cpu().double() + gx) * torch.where(mref.cpu() > 0, 1.0, 0.2)).float()
     assert (outs[1] - exp).abs().max().item() <= 2e-5 * max(1.0, gx.abs().max().item())
+
+
+@pytest.mark.parametrize("case", [(1, 12, 20, 32), (2, 9, 13, 32), (1, 24, 80, 64)])
+def test_conv2d_head_extra_destinations(backend, case):
+    """mh_conv2d_head: the single-output-channel forward conv of a disparity head also stores its result in a channel slot of a wider buffer and in
+    a second map, bit-identical to mh_conv2d; neighbours of the slot stay untouched."""
+    B, H, W, Ci = case
+    dev = backend.device
+    x = _rand((B, H, W, Ci), 511, dev)
+    w = _rand((3, 3, Ci, 1), 512, dev, 0.3)
+    b = _rand((1,), 513, dev)
+    y0 = torch.full((B, H, W, 1), float("nan"), device=dev)
+    ops.conv2d_fwd(backend.lib, ops.view(x), w, b, ops.view(y0))
+    y = torch.full((B, H, W, 1), float("nan"), device=dev)
+    cat = torch.full((B, H, W, 36), 3.0, device=dev)            # e.g. [features (33) | disparity | padding]
+    acc = torch.full((B, H, W, 1), float("nan"), device=dev)
+    slot = ops.View(cat, B, H, W, 36, 36).slice(33, 34)
+    ops.conv2d_head(backend.lib, ops.view(x), w, b, ops.view(y), copies=(slot, ops.view(acc)))
+    assert "conv_n1_fwd_kernel" in backend.lib.last_kernel().decode()
+    backend.sync()
+    assert torch.equal(y.cpu(), y0.cpu()) and torch.equal(acc.cpu(), y0.cpu()) and torch.equal(cat[..., 33:34].cpu(), y0.cpu())
+    assert (cat[..., :33] == 3.0).all() and (cat[..., 34:] == 3.0).all()
