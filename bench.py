@@ -38,6 +38,9 @@ DTYPE_LABEL = {
 }
 
 
+_OVERRIDES = []
+
+
 def _emit(obj):
     """The ONE JSON line, as the LAST thing on stdout: RCCL prints a version banner through C stdio when the first
     communicator is created -- flush the C buffers first so it cannot trail the JSON line."""
@@ -46,6 +49,8 @@ def _emit(obj):
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
+    if _OVERRIDES:
+        obj["overrides"] = list(_OVERRIDES)          # a --set A/B run says so in its line
     sys.stdout.write(json.dumps(obj) + "\n")
     sys.stdout.flush()
 
@@ -305,6 +310,30 @@ def drift_report(args, lib, dev, wn, mk, frames=8):
     return out
 
 
+def apply_overrides(items, lib, E):
+    """--set KEY=VALUE: module flags and library hooks are applied at once; returns the per-engine attributes (applied to every engine built)."""
+    import ast
+    per_engine = {}
+    _OVERRIDES[:] = items
+    for it in items:
+        key, _, val = it.partition("=")
+        scope, _, name = key.partition(".")
+        try:
+            v = ast.literal_eval(val)
+        except (ValueError, SyntaxError):
+            v = val
+        if scope == "engine":
+            assert hasattr(E, name), "--set %s: no such flag in madnet_hip/engine.py" % key
+            setattr(E, name, v)
+        elif scope == "eng":
+            per_engine[name] = v
+        elif scope == "tune":
+            getattr(lib, "tune_" + name)(int(v))
+        else:
+            raise SystemExit("--set %s: scope must be engine. / eng. / tune." % key)
+    return per_engine
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -340,6 +369,10 @@ def main():
                          "the backward plan and the momentum plan, scaled by 1/world (BASELINE config 5); default: private models, no collective")
     ap.add_argument("--wgrad-lanes", type=int, default=-1, help="side lanes for the filter gradients (default: the engine's; 0 = serial, for clean per-kernel profiles)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE", dest="overrides",
+                    help="A/B override (repeatable; the JSON line lists them under 'overrides'): engine.NAME=v sets a module flag of madnet_hip/engine.py "
+                         "(FUSE_HEAD, SHADOW_ONLY, EARLY_WGS ...), eng.NAME=v an attribute of every engine built (fuse_front, use_bank ...), "
+                         "tune.NAME=int calls the library hook mh_tune_NAME (conv_rows, conv_bank_tile, wgrad_target_pct ...)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-step-surface", action="store_true")
@@ -370,6 +403,7 @@ def main():
 
     from madnet_hip import _ffi, engine as E, dispnet_engine as DE, synthetic as S, benchtools as BT
     lib = _ffi.lib()
+    eng_overrides = apply_overrides(args.overrides, lib, E)
     H, W = args.height, args.width
     if args.mode == "MAD":
         return bench_mad(args, lib, dev, rank, world, dist)
@@ -380,6 +414,15 @@ def main():
     SB = args.streams_per_gpu
     mk = (lambda prec: DE.DispNetEngine(lib, H, W, B=SB, device=dev.name, weights=wn, precision=prec)) if dispnet else \
          (lambda prec: E.MadNetEngine(lib, H, W, B=SB, device=dev.name, weights=wn, precision=prec))
+    if eng_overrides:
+        mk0 = mk
+
+        def mk(prec):
+            e = mk0(prec)
+            for k, v in eng_overrides.items():
+                assert hasattr(e, k), "--set eng.%s: no such engine attribute" % k
+                setattr(e, k, v)
+            return e
     eng = mk(args.precision)
 
     def feed(e):

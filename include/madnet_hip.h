@@ -129,7 +129,7 @@ typedef struct mh_wgrad_item {
     const float* in; const float* dout;
     float* ws; float* db;
     int32_t dout_ld, splits;
-    int32_t group_max_m;  /* > 0: group this layer only if it has at most this many reduction pixels (0 = library default 4096 / MH_WGRAD_GROUP_MAXM);
+    int32_t group_max_m;  /* > 0: group this layer only if it has at most this many reduction pixels (0 = library default 4096);
                              the largest value of a batch applies to the whole batch */
     int32_t reserved;
 } mh_wgrad_item;
@@ -381,13 +381,13 @@ int mh_bias_grad(const float* dz, int32_t dz_ld, int64_t npix, int32_t nch, floa
 int mh_tune_conv_tile(int bm, int bn);
 int mh_tune_conv_thin(int min_pixels);   /* weights-stationary thin-layer kernel from this many output pixels (0 = default, < 0 = never) */
 int mh_tune_conv_patch(int mode);        /* patch-staged bf16 kernel of the stride-1 3x3 layers: 0 = off, 1 = on (tile heuristic), 64 / 128 = forced pixel tile, +256 = 8-wave variant, +2048 = generic-K instances only, +4096 = forward layers only, +8192 = no generic-K input gradients, < 0 = built-in default; returns the number of launches of that kernel since the previous call */
-int mh_tune_conv_x3_igemm(int on);       /* split-bf16 (precision 2) on the tiled implicit-GEMM kernel for forward layers without a patch / bank instance: 0 = exact fp32 there (default: measured faster), 1 = on, < 0 = default / MH_CONV_X3_IGEMM */
-int mh_tune_conv_rows(int min_pixels);   /* row-streaming kernel of the thin 3x3 stride-1 layers (conv_rows.hip: <= 16 input, <= 32 output channels): takes layers of at least this many output pixels (0 = never, < 0 = default 65536 / MH_CONV_ROWS_MINPIX); returns the previous setting (-1 = default not resolved yet) */
-int mh_tune_conv_bank_tile(int max_wgs);     /* split-bf16 bank kernel: layers whose 64x128 / 128x64 grid would have fewer workgroups than this take the 64x64 tile with 4 waves (0 = never, < 0 = default 200 / MH_CONV_BANK_SMALL_TILE_WGS); returns the previous setting */
-int mh_tune_conv_bank(int small_maxpix); /* fragment-bank kernels (mh_conv2d_wb): the small-layer kernel takes layers of up to this many output pixels (0 = never, < 0 = default 4096 / MH_CONV_BANK_SMALL_MAXPIX); returns the number of bank-kernel launches since the previous call */
+int mh_tune_conv_x3_igemm(int on);       /* split-bf16 (precision 2) on the tiled implicit-GEMM kernel for forward layers without a patch / bank instance: 0 = exact fp32 there (default: measured faster), 1 = on, < 0 = default */
+int mh_tune_conv_rows(int min_pixels);   /* row-streaming kernel of the thin 3x3 stride-1 layers (conv_rows.hip: <= 16 input, <= 32 output channels): takes layers of at least this many output pixels (0 = never, < 0 = default 65536); returns the previous setting (-1 = default not resolved yet) */
+int mh_tune_conv_bank_tile(int max_wgs);     /* split-bf16 bank kernel: layers whose 64x128 / 128x64 grid would have fewer workgroups than this take the 64x64 tile with 4 waves (0 = never, < 0 = default 200); returns the previous setting */
+int mh_tune_conv_bank(int small_maxpix); /* fragment-bank kernels (mh_conv2d_wb): the small-layer kernel takes layers of up to this many output pixels (0 = never, < 0 = default 4096); returns the number of bank-kernel launches since the previous call */
 int mh_tune_wgrad_wgs(int target_workgroups);
 int mh_tune_wgrad_target_pct(int pct);   /* scale (percent) of the filter-gradient pixel-split workgroup targets for the split counts resolved from now on (a plan stores the counts it was recorded with); 0 = default.  Returns the PREVIOUS value (NOT a status code) so that a caller can scope the setting: DispNet's engine records with 150 under a process-wide lock and restores what it found */
-int mh_tune_wgrad_stream(int dist);     /* prefetch distance (row groups in flight) of the streaming filter-gradient kernel: 1 or 2, 0 = default / MH_WGRAD_STREAM_DIST */
+int mh_tune_wgrad_stream(int dist);     /* prefetch distance (row groups in flight) of the streaming filter-gradient kernel: 1 or 2, 0 = default */
 int mh_tune_corr(int direct);
 
 /* host utility: CRC-32C (Castagnoli) of a host buffer, chained through `crc` (0 to start) -- used by the TensorFlow

@@ -872,12 +872,11 @@ static int launch_conv_thin(ConvArgs& a, hipStream_t s) {
 
 // split-bf16 on the tiled kernel: OFF by default.  Measured (profiles/r02_experiments.txt #27): the forward layers that have no patch / bank instance
 // are latency bound on their small tiles, and the doubled LDS planes + split conversions cost more than the exact-fp32 MFMAs they replace
-// (MADNet FULL 2.02 -> 2.17 ms, DispNet 4.39 -> 4.35 ms).  MH_CONV_X3_IGEMM=1 / mh_tune_conv_x3_igemm(1) switch it on (parity-tested).
+// (MADNet FULL 2.02 -> 2.17 ms, DispNet 4.39 -> 4.35 ms).  mh_tune_conv_x3_igemm(1) switches it on (parity-tested).
 static std::atomic<int> g_x3_igemm{-1};
 static bool conv_x3_igemm_on() {
     int v = g_x3_igemm.load(std::memory_order_relaxed);
-    if (v < 0) { const char* e = getenv("MH_CONV_X3_IGEMM"); v = e ? (atoi(e) != 0) : 0; g_x3_igemm.store(v, std::memory_order_relaxed); }
-    return v != 0;
+    return v > 0;
 }
 extern "C" int mh_tune_conv_x3_igemm(int on) { g_x3_igemm = on < 0 ? -1 : (on != 0); return 0; }
 static bool g_no_uni = false;    // tuning hook: disable the uniform-tap fast path (A/B experiments)
@@ -974,11 +973,10 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
 // workgroups (about 2 per CU, i.e. 2 waves per SIMD to overlap one wave's load/LDS phase with
 // another's MFMAs); when no tile reaches that, take the one with the most workgroups.  Big tiles
 // use KT=32; the small, latency-bound ones KT=64/128 (fewer barriers, more bytes in flight).
-// mh_tune_conv_tile(bm, bn) / MH_CONV_BM force a tile for experiments.
+// mh_tune_conv_tile(bm, bn) forces a tile for experiments.
 static int g_force_bm = -1, g_force_bn = 0, g_force_kt = 0;
 static int forced_bm() {
-    if (g_force_bm < 0) { const char* e = getenv("MH_CONV_BM"); g_force_bm = e ? atoi(e) : 0; }
-    return g_force_bm;
+    return g_force_bm < 0 ? 0 : g_force_bm;
 }
 extern "C" int mh_tune_conv_thin(int min_pixels) { g_thin_min_m = min_pixels == 0 ? 16384 : min_pixels; return 0; }
 extern "C" int mh_tune_conv_tile(int bm, int bn) {

@@ -1088,10 +1088,9 @@ int launch_patch_n(ConvArgs& a, hipStream_t s, int bn) {
 // (round 3: a 32-column tile for the layers with <= 32 output columns -- 32 -> 32, 64 -> 32 and their input gradients: with the 64-column tile half of
 //  every MFMA and of the epilogue was padding: 15.0 -> 13.6 us forward, 16.5 -> 14.9 us input gradient for the pyramid's 32 -> 32 layer at 96x320 x 2.
 //  A 16-column tile for the 16 -> 16 layer at 192x640 was measured too and is SLOWER than the tiled kernel (32.3 vs 28.7 us forward, 41.4 vs 28.4 us input
-//  gradient): per-workgroup latency, not padding, bounds that layer -- removed.  MH_CONV_PATCH_THIN=0 restores the 64-column floor)
-static int patch_thin() { return 1; }
+//  gradient): per-workgroup latency, not padding, bounds that layer -- removed.)
 int patch_bn(const ConvArgs& a) {
-    if (patch_thin() && a.N <= 32) return 32;
+    if (a.N <= 32) return 32;
     return a.x3 ? (a.N > 64 ? 128 : 64) : (a.N > 96 ? 128 : (a.N > 64 ? 96 : 64));
 }
 
@@ -1119,17 +1118,15 @@ extern "C" int mh_pack_weights(const mh_pack_seg* segs_device, int32_t nseg, int
     hipLaunchKernelGGL(pack_weights_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, segs_device, nseg);
     return mh_check_launch("pack_weights");
 }
-std::atomic<int> g_bank_small_maxpix{-2};          // -2: not resolved yet (MH_CONV_BANK_SMALL_MAXPIX, default 4096)
+std::atomic<int> g_bank_small_maxpix{-2};          // -2: the default (4096; the engines' bank_small_maxpix must agree: they pack the banks for it)
 int bank_small_maxpix() {
-    int m = g_bank_small_maxpix.load(std::memory_order_relaxed);
-    if (m == -2) { const char* e = getenv("MH_CONV_BANK_SMALL_MAXPIX"); m = e ? atoi(e) : 4096; g_bank_small_maxpix.store(m, std::memory_order_relaxed); }
-    return m;
+    const int m = g_bank_small_maxpix.load(std::memory_order_relaxed);
+    return m == -2 ? 4096 : m;
 }
-std::atomic<int> g_bank_small_tile_wgs{-1};       // -1: not resolved yet (MH_CONV_BANK_SMALL_TILE_WGS, default 200; 0 = never)
+std::atomic<int> g_bank_small_tile_wgs{-1};       // -1: the default (200); 0 = never
 int bank_small_tile_wgs() {
-    int m = g_bank_small_tile_wgs.load(std::memory_order_relaxed);
-    if (m < 0) { const char* e = getenv("MH_CONV_BANK_SMALL_TILE_WGS"); m = e ? atoi(e) : 200; g_bank_small_tile_wgs.store(m, std::memory_order_relaxed); }
-    return m;
+    const int m = g_bank_small_tile_wgs.load(std::memory_order_relaxed);
+    return m < 0 ? 200 : m;
 }
 extern "C" int mh_tune_conv_bank_tile(int max_wgs) { return g_bank_small_tile_wgs.exchange(max_wgs < 0 ? -1 : max_wgs); }
 extern "C" int mh_tune_conv_bank(int small_maxpix) {
@@ -1138,7 +1135,7 @@ extern "C" int mh_tune_conv_bank(int small_maxpix) {
 }
 
 // small-layer bank kernel: stride-1 "SAME" 3x3, bank present, reduction <= 64 chunks (K <= 224), few enough pixels that the tiled kernels
-// are latency bound (default <= 4096 output pixels: the 1/16-1/64 levels; MH_CONV_BANK_SMALL_MAXPIX overrides, 0 = off)
+// are latency bound (default <= 4096 output pixels: the 1/16-1/64 levels; mh_tune_conv_bank overrides, 0 = off)
 bool mh_conv_bank_small_ok(const ConvArgs& a) {
     // input gradients: twice the forward limit (the 1/8-resolution level too: 1.804-1.809 -> 1.800-1.802 ms per step against the tiled kernel
     // there, profiles/r03_experiments.txt #11; in the forward pass that level runs split-bf16 on the big bank kernel)
@@ -1169,11 +1166,7 @@ bool mh_conv_patch_ok(const ConvArgs& a) {
     if (patch_mode() == 0) return false;
     if (!((a.bf16 || (a.x3 && a.mode == 0)) && a.vecA && a.vecB && (a.vecC || (a.vecCpad && a.mode == 1 && a.bf16)))) return false;
     if (!(a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad_t == a.dil && a.pad_l == a.dil && a.Hi == a.Ho && a.Wi == a.Wo)) return false;
-    // with a fragment bank the split-bf16 forward kernel also takes 32..47 output channels (half of its 64-column tile idles, still 18 -> 11 us
-    // for the 64->32 layers at 1/4 resolution against the exact-fp32 gather kernel; step -0.9 %)
-    constexpr int bank_min_n = 32;
-    const bool bank_fwd = a.x3 && a.wb && a.mode == 0;
-    const int min_n = patch_thin() ? 32 : (bank_fwd ? bank_min_n : 48);                           // the 32-column tile: from 32 output columns
+    constexpr int min_n = 32;                                                                   // the 32-column tile: from 32 output columns
     if (a.ncls != 0 || a.N < min_n || a.K < 32 || a.dil > 64) return false;
     if (a.x3 && a.mode == 0 && !a.wb && (a.N < 48 || a.K < 32)) return false;                      // the LDS-staged split-bf16 instances keep their floor
     if (a.mode == 1 && (patch_mode() & 0x1000)) return false;                                  // mode bit 12: forward layers only
@@ -1184,10 +1177,7 @@ bool mh_conv_patch_ok(const ConvArgs& a) {
     const int d = a.dil, TH = bm / 16;
     const int64_t cover = (int64_t)d * d * mh_cdiv(mh_cdiv(a.Ho, d), TH) * TH * mh_cdiv(mh_cdiv(a.Wo, d), 16) * 16;
     if ((patch_mode() & 0xff) == 1) {
-        // thresholds of the heuristic (environment overrides for the in-situ A/B runs of scripts/gpu_ab.sh)
-        static int min_pix = -1, max_cover = -1;
-        if (min_pix < 0) { const char* e = getenv("MH_CONV_PATCH_MINPIX"); min_pix = e ? atoi(e) : 24576; }
-        if (max_cover < 0) { const char* e = getenv("MH_CONV_PATCH_COVER"); max_cover = e ? atoi(e) : 220; }
+        constexpr int min_pix = 24576, max_cover = 220;          // thresholds of the heuristic
         // lattice tiles may cover up to 2.2x the image: round 1 set 125 % (bf16 kernel vs the bf16 gather kernel, stand-alone); in the round-2 step the
         // context layers of dilation 8 / 16 (213 % at 96x320) are faster on the patch / bank kernels than on the tiled ones, forward (where the
         // alternative is exact fp32: 40 us) and input gradient alike: 1.986 -> 1.956 ms, bf16 mode 1.887 -> 1.869, MAD 1.104 -> 1.087 (r03y3)
@@ -1197,7 +1187,7 @@ bool mh_conv_patch_ok(const ConvArgs& a) {
         // 24-29 us; at 1920 pixels fp32 wins, 14 vs 19.5 us -- profiles/r02_microbench_x3dbg.txt)
         // (measured in situ: 128-column layers 24-28 -> 19-20 us, the 64-column one 17.6 -> 20.8 us: wide layers only)
         // with a fragment bank the split-bf16 kernel also beats the exact-fp32 gather kernel on the <= 64-column layers at 1/8 resolution
-        static const int bank_min_pix = []() { const char* e = getenv("MH_CONV_BANK_MINPIX"); return e ? atoi(e) : 7680; }();      // A/B hook
+        constexpr int bank_min_pix = 7680;
         const int need = (a.x3 && a.wb && a.mode == 0) ? (bank_min_pix < min_pix ? bank_min_pix : min_pix) : ((a.x3 && a.N > 64) ? min_pix * 5 / 16 : min_pix);
         if ((int64_t)a.B * a.Ho * a.Wo < need) return false;
     }

@@ -260,9 +260,8 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(ConvArgs p, int R, int s
 // bank kernels keep the 32 -> 32 layers at 1/4 resolution)
 std::atomic<int> g_rows_minpix{-1};
 int rows_minpix() {
-    int v = g_rows_minpix.load(std::memory_order_relaxed);
-    if (v < 0) { const char* e = getenv("MH_CONV_ROWS_MINPIX"); v = e ? atoi(e) : 65536; g_rows_minpix.store(v, std::memory_order_relaxed); }
-    return v;
+    const int v = g_rows_minpix.load(std::memory_order_relaxed);
+    return v < 0 ? 65536 : v;
 }
 
 }  // namespace

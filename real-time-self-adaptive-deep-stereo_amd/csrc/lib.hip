@@ -308,7 +308,6 @@ static int plan_run_impl(const mh_op* ops, int32_t nops, void* stream, Lanes* fi
     // captured graph the first node created under a parent inherits the parent's hardware queue and later children move to another
     // queue behind a cross-queue dependency (~15-20 us, seen as idle time on the critical path after every batch of filter gradients:
     // profiles/r02_experiments.txt #16); this way the critical-path successor is the first child and the side batch pays the hop.
-    static const int defer_on = []() { const char* e = getenv("MH_DEFER_SIDE"); return e ? atoi(e) : 1; }();
     struct Deferred { int32_t k; int m, lane; };
     Deferred deferred[64];
     int ndef = 0;
@@ -342,7 +341,7 @@ static int plan_run_impl(const mh_op* ops, int32_t nops, void* stream, Lanes* fi
             if (!e && stale[lane]) { e = lane_edge(*L, main_s, L->aux[lane]); stale[lane] = false; }
             if (!e) {
                 dirty[lane] = true;
-                if (defer_on && !(sched & MH_OP_NODEFER)) { deferred[ndef].k = k; deferred[ndef].m = m; deferred[ndef].lane = lane; ++ndef; }
+                if (!(sched & MH_OP_NODEFER)) { deferred[ndef].k = k; deferred[ndef].m = m; deferred[ndef].lane = lane; ++ndef; }
                 else {
                     if (ndef) e = flush_deferred();          // keep the lane's order
                     if (!e) e = run((void*)L->aux[lane]);
@@ -447,7 +446,7 @@ extern "C" int mh_graph_end(void* stream, void** graph_exec_out) {
     MH_HIP(hipStreamEndCapture((hipStream_t)stream, &g));
     hipGraphExec_t ge = nullptr;
     hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-    hipGraphDestroy(g);
+    (void)hipGraphDestroy(g);
     if (e != hipSuccess) { mh_set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return (int)e; }
     *graph_exec_out = (void*)ge;
     return 0;

@@ -510,17 +510,16 @@ int launch_wgrad_bf16(WgradArgs& a, hipStream_t s) {
     constexpr int units = WM * WN * MT * NT;
     // workgroup targets of the pixel split: 256 / 512 / 1024 by tile size (round 1: 384 / 768 / 1536, tuned while the filter gradients overlapped the
     // input-gradient chain; in the deferred one-lane step they mostly run alone and fewer splits = less partial-sum traffic: 1.961 -> 1.912 ms at 2/3,
-    // 1.911 at 1/2, 1.964 at 0.4, 2.03 at 1/3; experiments #34).  MH_WGRAD_TARGET_PCT scales them (A/B hook).
-    static const int env_scale0 = []() { const char* e = getenv("MH_WGRAD_TARGET_PCT"); return e ? atoi(e) : 100; }();
+    // 1.911 at 1/2, 1.964 at 0.4, 2.03 at 1/3; experiments #34).  mh_tune_wgrad_target_pct scales them.
     const int tuned = g_wgrad_target_pct.load(std::memory_order_relaxed);
-    const int env_scale = tuned > 0 ? tuned : env_scale0;
+    const int env_scale = tuned > 0 ? tuned : 100;
     // (layers with more than 65536 reduction pixels -- several streams batched through one model, DispNet's / the pyramid's full-size layers -- are
     //  throughput bound and keep the round-1 targets: B = 4 batched 834 vs 796 pairs/s)
     const int base_t = a.M > 65536 ? (units >= 32 ? 384 : (units >= 8 ? 768 : 1536)) : (units >= 32 ? 256 : (units >= 8 ? 512 : 1024));
     const int target = g_wgrad_target_wgs > 0 ? g_wgrad_target_wgs : base_t * env_scale / 100;
     int splits = a.forced_splits > 0 ? a.forced_splits : mh_cdiv(target, base);
     int maxs = mh_cdiv(a.M, PT * 2);
-    static const int cap = []() { const char* e = getenv("MH_WGRAD_MAXSPLITS"); return e ? atoi(e) : 192; }();   // A/B hook
+    constexpr int cap = 192;
     if (maxs > cap) maxs = cap;          // the split reduction walks the splits of an element serially (1280 splits of the flat
                                          // 3->16 layer cost a 190 us single-block tail in wgrad_reduce_kernel)
     if (splits > maxs) splits = maxs;
@@ -718,8 +717,7 @@ static int wgrad_dispatch(WgradArgs& a, hipStream_t s) {
     // 128 x 128 tile with 8 waves of 32 x 64 for the layers that are launched on their own (> 4096 reduction pixels): 126 VGPRs instead of
     // 208 -> 4 waves per SIMD instead of 2 for the same two workgroups per CU; 32.4 -> 28.6 us at 96x320 (profiles/r02_microbench_wgrad_tiles.txt;
     // the 128x64 / 64x128 tiles gain nothing from 8 waves).  Smaller layers keep the 4-wave shape: it is the one the grouped launch runs.
-    static const int w8_on = []() { const char* e = getenv("MH_WGRAD_W8"); return e ? atoi(e) : 1; }();       // A/B hook
-    MH_WG(K > 64 && N > 64 && a.M > 4096 && a.bf16 && w8_on && g_wgrad_w8 != 3, 4, 2, 2, 4, 32)
+    MH_WG(K > 64 && N > 64 && a.M > 4096 && a.bf16 && g_wgrad_w8 != 3, 4, 2, 2, 4, 32)
     MH_WG(K > 64 && N > 64, 2, 2, 4, 4, 32)                 // 128 x 128
     MH_WG(K > 64 && N > 32 && N <= 64, 2, 2, 4, 2, 32)      // 128 x 64
     MH_WG(K > 64 && N <= 32, 4, 1, 2, 1, 32)                // 128 x 16
@@ -767,10 +765,9 @@ static int wgrad_entry(const mh_conv_desc* d, const float* in, const float* dout
     a.vecB = mh_aligned16(dout) && (dout_ld % 4 == 0) && (d->N % 4 == 0);
     a.dbg_plain_store = g_wgrad_plain;
     a.bf16 = (d->precision == 1);
-    static const int flat_on = []() { const char* e = getenv("MH_WGRAD_FLAT"); return e ? atoi(e) : 1; }();      // A/B hook
     // measured: the 7x7 image layer of DispNet 210 -> ~60 us per tower, but MADNet's 3x3 one is 1 % slower flat (9 taps only
-    // re-read dz 9x from L2, and the flat tables cost more than they save) -> many-tap layers only; MH_WGRAD_FLAT=2 forces it
-    a.flat = (flat_on && a.bf16 && a.vecA && a.vecB && d->K <= 4 && (a.taps >= 16 || (flat_on == 2 && a.taps > 1))) ? 1 : 0;
+    // re-read dz 9x from L2, and the flat tables cost more than they save) -> many-tap layers only
+    a.flat = (a.bf16 && a.vecA && a.vecB && d->K <= 4 && a.taps >= 16) ? 1 : 0;
     a.ws = ws; a.forced_splits = forced_splits; a.query = query;
     {
         const int64_t inb = (((int64_t)d->B * d->Hi * d->Wi - 1) * d->in_ld + (int64_t)((d->K + 3) / 4) * 4) * 4;
@@ -809,7 +806,6 @@ extern "C" int mh_conv2d_wgrad_partial(const mh_conv_desc* d, const float* in, c
 // is a handful of workgroups that costs its dispatch latency, not its work.  Exact-fp32 layers and leftovers go out one by one.
 extern "C" int mh_conv2d_wgrad_partial_group(const mh_wgrad_item* items, int32_t n, void* stream) {
     MH_REQUIRE(items && n > 0, MH_ERR_ARG, "mh_conv2d_wgrad_partial_group: empty item list");
-    static const int group_on = []() { const char* e = getenv("MH_WGRAD_GROUP"); return e ? atoi(e) : 1; }();      // A/B hook
     WgradGroup G;            // ~1.5 KB: built on the host, passed by value as the kernel argument
     G.n = 0; G.blk0[0] = 0;
     size_t lds = 0;
@@ -843,10 +839,9 @@ extern "C" int mh_conv2d_wgrad_partial_group(const mh_wgrad_item* items, int32_t
         // fill the chip alone, and as one long grid they only coarsen the interleaving with the input-gradient chain (measured: +1.5 %
         // step time with everything grouped); 1- and 2-wave tile shapes would idle most of a 256-thread workgroup.
         // (cap re-swept at the end of round 2, experiments #35: 16384: 1.918 ms | 8192: 1.903 | 4096: 1.899 | 2048: 1.905)
-        static const int env_max_m = []() { const char* e = getenv("MH_WGRAD_GROUP_MAXM"); return e ? atoi(e) : 0; }();
-        const int max_m = env_max_m > 0 ? env_max_m : (batch_max_m > 0 ? batch_max_m : 4096);
+        const int max_m = batch_max_m > 0 ? batch_max_m : 4096;
         const bool narrow = (c.cfg == 8 || c.cfg == 10 || c.cfg == 11);
-        if (!group_on || c.cfg < 0 || narrow || a.M > max_m || c.lds > (size_t)MH_WG_GROUP_LDS || c.nblocks <= 0) {
+        if (c.cfg < 0 || narrow || a.M > max_m || c.lds > (size_t)MH_WG_GROUP_LDS || c.nblocks <= 0) {
             if (int rc = single(it)) return rc;
             continue;
         }

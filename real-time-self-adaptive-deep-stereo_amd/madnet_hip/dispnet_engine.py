@@ -198,9 +198,10 @@ class DispNetEngine(object):
     # too -- conv_redir, conv3 .. conv6/1 and the three coarsest up-blocks (profiles/r02_precision_map_dispnet.txt: rounding ONE group's operands to
     # bf16, everything else fp32); conv1 (6.9e-3), conv2 (9.7e-4), up2 (1.0e-3), up1 (5.7e-3) and prediction (9.1e-3) keep split-bf16 / exact fp32
     MIXED_BF16_FWD = ("conv_redir", "conv3", "conv4", "conv5", "conv6", "up5", "up4", "up3")
+    WGRAD_TARGET_PCT = 150       # scale of the filter-gradient pixel-split targets while a plan is recorded (_build_plan)
 
     def _fwd_code(self, wn):
-        if self.precision != "mixed" or os.environ.get("MH_DISPNET_MIXED_BF16", "1") == "0":
+        if self.precision != "mixed":
             return None
         head = wn.split("/")[0]
         return 1 if head in self.MIXED_BF16_FWD else None
@@ -427,7 +428,7 @@ class DispNetEngine(object):
         # while the plan is recorded and stored in it)
         # (a process-wide hook: recorded under a lock, and what another caller had set is restored -- ADVICE r02)
         with _TUNE_LOCK:
-            prev = self.lib.tune_wgrad_target_pct(int(os.environ.get("MH_DISPNET_WGRAD_TARGET_PCT", "150")))
+            prev = self.lib.tune_wgrad_target_pct(self.WGRAD_TARGET_PCT)
             try:
                 return self._build_plan_scoped(r, mode, lr, grad_scale, update, part, loss_weights, max_disp, optimizer)
             finally:

@@ -31,12 +31,12 @@ ALPHA = 0.2   # MadNet._leaky_relu (Nets/MadNet.py:366-367)
 # The reduction of the loss value + the validation metrics run on a side lane (SIDE_LOSS: 2.048 -> 2.030 ms since side launches are deferred,
 # profiles/r02_experiments.txt #10, #20); the warp-gradient scatters on a lane of their own lost in every variant (2.056 / 2.27 ms) and
 # stay in line.
-ONE_FILL = os.environ.get("MH_ONE_FILL", "1") != "0"       # one zero fill for all level feature gradients + the g fill on the filter-gradient lane
-FUSE_BACK = os.environ.get("MH_FUSE_BACK", "1") != "0"     # one launch for a level's correlation gradient + warp gradient (mh_corr_warp_bwd)
+ONE_FILL = True       # one zero fill for all level feature gradients + the g fill on the filter-gradient lane
+FUSE_BACK = True     # one launch for a level's correlation gradient + warp gradient (mh_corr_warp_bwd)
 PYR_BF16_FROM = int(os.environ.get("MH_PYR_BF16_FROM", "7"))     # 'mixed': pyramid layers from this one on run plain bf16 in the forward pass (13 = none)
 # the first N filter-gradient batches of a backward pass are launched at once instead of after the next lane-0 op (MH_OP_NODEFER)
 NODEFER_BATCHES = 0             # (module attribute: tests / experiments set it; early side launches measured slower, r03 #3)
-SIDE_LOSS = os.environ.get("MH_SIDE_LOSS", "1") != "0"     # on since side launches are deferred: 2.048 -> 2.030 ms (r02z)
+SIDE_LOSS = True     # on since side launches are deferred: 2.048 -> 2.030 ms (r02z)
 
 
 def _r4(c):
@@ -92,11 +92,11 @@ def madnet_manifest(radius_d=2, stride=1):
 # 1.635 -> 1.629 ms; 128 / 96 workgroups: 1.649 / 1.652)
 EARLY_WGS = 192
 EARLY_BATCHES = 3
-FUSE_HEAD = os.environ.get("MH_FUSE_HEAD", "1") != "0"
+FUSE_HEAD = True
 # input gradients stage the bf16 shadow of dz when the previous input gradient's epilogue wrote one (mh_conv2d_sh2)
-SHADOW_DGRAD = os.environ.get("MH_SHADOW_DGRAD", "1") != "0"
+SHADOW_DGRAD = True
 # ... and then do not store the fp32 gradient map at all when its only reader is such an input gradient (engine._elide_fp32_gradient_maps)
-SHADOW_ONLY = os.environ.get("MH_SHADOW_ONLY", "1") != "0"
+SHADOW_ONLY = True
 
 
 class Params(object):
@@ -178,12 +178,12 @@ class MadNetEngine(object):
         # two lanes undeferred: profiles/r02_experiments.txt #16)
         self.wgrad_lanes = int(os.environ.get("MH_WGRAD_LANES", "1"))
         # one launch per level for the inter-level upsample + warp + cost volume + concat (mh_level_front_fwd) instead of three
-        self.fuse_front = os.environ.get("MH_FUSE_FRONT", "1") != "0"        # (environment switch: in-situ A/B runs)
+        self.fuse_front = True
         # split-bf16 3x3 layers of the 1/4- and 1/8-resolution estimators and the context network stream their weights from MFMA
         # fragment banks (mh_conv2d_wb), re-packed by ONE launch at the start of every step
         # ... and (bf16 / mixed) the layers of the 1/16-1/64 levels -- forward and input gradient -- take the small-layer bank kernel
         self.use_bank = precision in ("mixed", "bf16") and os.environ.get("MH_CONV_BANK", "1") != "0"
-        self.bank_small_maxpix = int(os.environ.get("MH_CONV_BANK_SMALL_MAXPIX", "4096"))
+        self.bank_small_maxpix = 4096           # = the library default (mh_tune_conv_bank): the banks are packed for the layers that kernel takes
         self.bank_min_n = 32
         self.banks = {}
         self.banks_d = {}
@@ -194,8 +194,8 @@ class MadNetEngine(object):
         self.stream_min_pix = 0
         self.shadows = {}                   # (data pointer, B, H, W, C) -> ops.Shadow, allocated once per engine
         # ... written by the epilogue of the kernel that produces the tensor (mh_conv2d_sh) wherever a conv kernel is the producer; the rest
-        # (cost-volume buffers, heads, the top pyramid gradient) go through one mh_shadow_cast per batch.  MH_FUSE_SHADOWS=0: cast everything
-        self.fuse_shadows = os.environ.get("MH_FUSE_SHADOWS", "1") != "0"
+        # (cost-volume buffers, heads, the top pyramid gradient) go through one mh_shadow_cast per batch.  fuse_shadows = False: cast everything
+        self.fuse_shadows = True
         self._fresh = set()                 # shadows a producer wrote in the plan being recorded
         self._stream_train = set()          # trainable variables of that plan
 
@@ -621,9 +621,6 @@ class MadNetEngine(object):
             buffers that nothing later in the step overwrites, so they may run concurrently with everything that
             follows on lane 0 until the reduction joins them."""
             if not pending:
-                return
-            if os.environ.get("MH_DEBUG_SKIP_WGRAD", "0") == "1":       # timing experiment only (WRONG results): the step without any filter gradient
-                del pending[:]
                 return
             side = self.wgrad_lanes > 0 and hasattr(lib, "lane")
             if side:

@@ -53,3 +53,26 @@ def test_bench_shared_model_two_ranks_two_pieces():
     sm = d["shared_model"]
     assert d["n_gpus"] == 2 and len(sm["pieces_bytes"]) == 2 and sm["collective_ms_alone"] > 0
     assert sm["pieces_bytes"][0] > 2 * sm["pieces_bytes"][1] and sum(sm["pieces_bytes"]) == 4 * (3826088 + 4)
+
+
+def test_bench_set_overrides_are_applied_and_reported(capsys):
+    """bench.py --set: module flags / library hooks applied at once, engine attributes returned for every engine built, and the JSON line
+    lists the overrides (an A/B run cannot pass for the default configuration)."""
+    import types
+    import pytest
+    sys.path.insert(0, ROOT)
+    import bench
+    calls = []
+    lib = types.SimpleNamespace(tune_conv_rows=lambda v: calls.append(("conv_rows", v)))
+    E = types.SimpleNamespace(FUSE_HEAD=True, EARLY_WGS=192)
+    try:
+        per = bench.apply_overrides(["engine.FUSE_HEAD=False", "engine.EARLY_WGS=128", "eng.fuse_front=False", "tune.conv_rows=0"], lib, E)
+        assert per == {"fuse_front": False} and E.FUSE_HEAD is False and E.EARLY_WGS == 128 and calls == [("conv_rows", 0)]
+        bench._emit({"value": 1})
+        assert json.loads(capsys.readouterr().out)["overrides"][0] == "engine.FUSE_HEAD=False"
+        with pytest.raises(AssertionError):
+            bench.apply_overrides(["engine.NO_SUCH_FLAG=1"], lib, E)
+        with pytest.raises(SystemExit):
+            bench.apply_overrides(["other.x=1"], lib, E)
+    finally:
+        bench._OVERRIDES[:] = []

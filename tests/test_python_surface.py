@@ -81,6 +81,33 @@ def test_bilinear_sampler_general(surface):
     assert (imd.grad.cpu() - ic.grad).abs().max().item() <= 1e-5
 
 
+def test_bilinear_sampler_non_finite_coordinates_stay_in_bounds(surface):
+    """NaN / Inf / huge coordinates (a diverged network feeding preprocessing.bilinear_sampler): the tap indices are clamped BEFORE the integer cast
+    (fmaxf / fminf return the non-NaN operand), so the gather and the gradient scatter stay inside the image; the pixels with finite coordinates
+    are what they are without the bad ones, and huge finite coordinates follow the oracle (weights 0 in fp32)."""
+    P, _, be = surface
+    B, Hs, Ws, C, Ht, Wt = 1, 6, 8, 2, 4, 5
+    img = _r((B, Hs, Ws, C), 21)
+    rng = np.random.default_rng(22)
+    good = torch.from_numpy(np.stack([rng.uniform(-1, Ws, (B, Ht, Wt)), rng.uniform(-1, Hs, (B, Ht, Wt))], -1).astype(np.float32))
+    bad = good.clone()
+    bad[0, 0, 0, 0] = float("nan"); bad[0, 0, 1, 1] = float("nan"); bad[0, 1, 0, 0] = float("inf"); bad[0, 1, 1, 1] = float("-inf")
+    bad[0, 2, 0] = torch.tensor([1e30, -1e30]); bad[0, 2, 1] = torch.tensor([-3e9, 3e9])
+    finite = torch.ones(B, Ht, Wt, dtype=torch.bool); finite[0, 0, :2] = False; finite[0, 1, :2] = False
+    outs = {}
+    for name, c in (("good", good), ("bad", bad)):
+        imd = _leaf(img, be.device); cd = _leaf(c, be.device)
+        out = P.bilinear_sampler(imd, cd)
+        out.backward(torch.ones_like(out))
+        be.sync()
+        outs[name] = (out.detach().cpu(), cd.grad.cpu(), imd.grad.cpu())
+    ref = T.bilinear_sampler(img, torch.where(finite[..., None], bad, good))       # (the oracle, like TF's gather, rejects NaN indices)
+    keep = finite.clone(); keep[0, 2, :2] = False                      # pixels whose coordinates are the same in both runs
+    assert torch.equal(outs["bad"][0][keep], outs["good"][0][keep]) and torch.equal(outs["bad"][1][keep], outs["good"][1][keep])
+    assert (outs["bad"][0][finite] - ref[finite]).abs().max().item() <= 1e-5          # incl. the 1e30 / 3e9 ones
+    assert torch.isfinite(outs["bad"][0][finite]).all()
+
+
 def test_warp_image_matches_oracle_and_fused_loss_kernel(surface):
     """preprocessing.warp_image = bilinear_sampler at (x - d, y): equals the oracle's warp_image, including disparities that
     leave the image; its gradient w.r.t. the disparity is what the fused loss kernel differentiates."""
