@@ -328,7 +328,7 @@ def apply_overrides(items, lib, E):
         elif scope == "eng":
             per_engine[name] = v
         elif scope == "tune":
-            getattr(lib, "tune_" + name)(int(v))
+            getattr(lib, "tune_" + name)(*[int(x) for x in (v if isinstance(v, tuple) else (v,))])        # tune.conv_tile=524288,0
         else:
             raise SystemExit("--set %s: scope must be engine. / eng. / tune." % key)
     return per_engine

@@ -56,9 +56,13 @@ __device__ __forceinline__ int swz_group(int row, int g) { return g ^ ((row >> 2
 // X3 (forward, BF16 layout): split-bf16 -- hi and lo planes of both tiles in LDS, three bf16 MFMAs per product (lo*hi + hi*lo + hi*hi): the
 // forward layers without a patch / bank instance (strided, thin, wide-K, 5x5 / 7x7: the MADNet pyramid, most of DispNet) stay inside the
 // 1e-3 px tolerance at a third of the bf16 MFMA rate instead of on the exact-fp32 MFMA (a sixteenth, and 8x the MFMA instruction count).
-template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool VEC, bool UNI, bool BF16, int KG = 1, bool X3 = false>
+// RAG (forward, UNI, bf16): K is NOT a multiple of KT (DispNet's iconv layers read 1024+1, 768+1, 384+1 concat channels): the uniform-tap walk runs over K
+// rounded up to whole K-tiles per tap -- weight rows >= K are dropped by one offset compare per load, activation groups >= K load nothing (partial
+// groups are zeroed by the store-time select) -- instead of falling back to the per-thread (tap, channel) cursor of the generic loader.
+template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool VEC, bool UNI, bool BF16, int KG = 1, bool X3 = false, bool RAG = false>
 __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
     static_assert(!X3 || (BF16 && !DGRAD && VEC), "split-bf16 instances: forward, vector path, bf16 tile layout");
+    static_assert(!RAG || (UNI && BF16 && !DGRAD && VEC && !X3), "ragged-K instances: bf16 forward on the uniform-tap loader");
 #ifdef MH_PHASE_TIMING
     const unsigned long long ts0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
@@ -217,8 +221,9 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
             b_off[j] = (live && n < p.N) ? o : MH_OOB;
         }
     }
-    int u_tap = 0, u_c0 = kg * KT;    // wave-uniform cursor of the NEXT tile to load (UNI); K % KT == 0
-    while (UNI && u_c0 >= p.K) { u_c0 -= p.K; ++u_tap; }
+    const int Kc = RAG ? (p.K + KT - 1) / KT * KT : p.K;       // channels one tap occupies in the K walk
+    int u_tap = 0, u_c0 = kg * KT;    // wave-uniform cursor of the NEXT tile to load (UNI); Kc % KT == 0
+    while (UNI && u_c0 >= Kc) { u_c0 -= Kc; ++u_tap; }
 
     // Register stages.  Small tiles (PF2) are latency bound -- one exposed load -> LDS -> MFMA round trip per
     // K-tile -- and run with prefetch distance 2: K-tiles t+1 and t+2 are in flight while tile t is multiplied.
@@ -241,22 +246,26 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
             const int dx = __builtin_amdgcn_readfirstlane(tap_dx[tapc]);
             const int sdy = DGRAD ? -dy : dy, sdx = DGRAD ? -dx : dx;
             const int toff = ((sdy * p.Wi + sdx) * p.in_ld + u_c0) * 4;
-            a_kb_st = 0;                                         // K % KT == 0: no channel padding inside a tile
+            a_kb_st = RAG ? u_c0 + ga * 4 : 0;                   // K % KT == 0: no channel padding inside a tile
+            const bool cok = !RAG || u_c0 + ga * 4 < p.K;        // ragged: this thread's channel group lies behind K in the tap's last tile
 #pragma unroll
             for (int j = 0; j < AROWS; ++j) {
                 const int iy = a_by[j] + sdy, ix = a_bx[j] + sdx;
-                const bool ok = tok && a_rowok[j] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+                const bool ok = tok && cok && a_rowok[j] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
                 ra_v[j] = mh_buf_load4(rs_in, ok ? a_off[j] + toff : MH_OOB);
             }
             const int wt = pcm ? __builtin_amdgcn_readfirstlane(tap_id[tapc]) : u_tap;
             const int woff = tok ? (!DGRAD ? (wt * p.K + u_c0) * p.N : wt * p.N * p.K + u_c0) * 4 : MH_OOB;
+            // ragged: row kk of the tile is real iff u_c0 + kk < K  <=>  b_off + u_c0 * N * 4 < K * N * 4   (b_off = (kk * N + n) * 4, n < N)
+            const unsigned rel = RAG ? (unsigned)(u_c0 * p.N * 4) : 0u, lim = (unsigned)(p.K * p.N * 4);
 #pragma unroll
             for (int j = 0; j < BITEMS; ++j) {
                 // MH_OOB + anything stays out of range (offsets are < 2^31 and num_records < 2^31)
-                rb_v[j] = mh_buf_load4(rs_w, (b_off[j] == MH_OOB || !tok) ? MH_OOB : b_off[j] + woff);
+                const bool dead = b_off[j] == MH_OOB || !tok || (RAG && (unsigned)b_off[j] + rel >= lim);
+                rb_v[j] = mh_buf_load4(rs_w, dead ? MH_OOB : b_off[j] + woff);
             }
             u_c0 += KT * KG;
-            while (u_c0 >= p.K) { u_c0 -= p.K; ++u_tap; }
+            while (u_c0 >= Kc) { u_c0 -= Kc; ++u_tap; }
             return;
         }
         {
@@ -408,8 +417,9 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int ntile = ((ntaps * p.G + GPT - 1) / GPT + KG - 1) / KG;     // K-tiles per group (the same count for every group:
-                                                                          // tiles past the end load zeros)
+    const int ntile = RAG ? (ntaps * (Kc / KT) + KG - 1) / KG
+                          : ((ntaps * p.G + GPT - 1) / GPT + KG - 1) / KG;     // K-tiles per group (the same count for every group:
+                                                                                // tiles past the end load zeros)
     const int li = lane & 15, lq = lane >> 4;
 
     auto compute_tile = [&](int buf) {
@@ -880,10 +890,11 @@ static bool conv_x3_igemm_on() {
 }
 extern "C" int mh_tune_conv_x3_igemm(int on) { g_x3_igemm = on < 0 ? -1 : (on != 0); return 0; }
 static bool g_no_uni = false;    // tuning hook: disable the uniform-tap fast path (A/B experiments)
+static bool g_ragged_uni = true; // tuning hook: ragged-K layers on the uniform-tap loader (bit 19 of mh_tune_conv_tile's bm clears it)
 static bool g_split_k = true;    // tuning hook: intra-workgroup split-K of the small tiles
 static bool g_parity_classes = true;   // tuning hook: stride-2 dgrad as 4 parity-class sub-problems
 
-template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool VEC, bool UNI, bool BF16, int KG = 1, bool X3 = false>
+template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool VEC, bool UNI, bool BF16, int KG = 1, bool X3 = false, bool RAG = false>
 int launch_one(ConvArgs& a, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
     constexpr size_t tiles = (BF16 ? (size_t)(2 * (BM + BN) * (KT + 16)) * 2 : (size_t)(2 * (BM + BN) * (KT + 4)) * sizeof(float)) * (X3 ? 2 : 1);
@@ -892,7 +903,7 @@ int launch_one(ConvArgs& a, hipStream_t s) {
     static bool attr_done = false;       // LDS > 64 KiB needs the opt-in once per instantiation
     if (!attr_done) {
         if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC, UNI, BF16, KG, X3>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC, UNI, BF16, KG, X3, RAG>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) { mh_set_error("conv: hipFuncSetAttribute(%d B LDS): %s", (int)lds, hipGetErrorString(e)); return (int)e; }
         }
@@ -908,13 +919,13 @@ int launch_one(ConvArgs& a, hipStream_t s) {
     }
     const int nwg = a.mtiles * a.ntiles;
     mh_note_kernel("conv_igemm_kernel<%d,%d,%d,%d,KT=%d,%s,%s,%s,%s,KG=%d> tile %dx%d grid %d", WM, WN, MT, NT, KT, DGRAD ? "dgrad" : "fwd",
-                   VEC ? "vec" : "scalar", UNI ? "uni" : "gen", X3 ? "bf16x3" : BF16 ? "bf16" : "f32", KG, BM, BN, nwg);
-    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC, UNI, BF16, KG, X3>), dim3(nwg), dim3(256 * KG), lds, s, a);
+                   VEC ? "vec" : "scalar", RAG ? "uni-ragged" : UNI ? "uni" : "gen", X3 ? "bf16x3" : BF16 ? "bf16" : "f32", KG, BM, BN, nwg);
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC, UNI, BF16, KG, X3, RAG>), dim3(nwg), dim3(256 * KG), lds, s, a);
     return mh_check_launch("conv_igemm");
 }
 
 // small latency-bound tile on a grid smaller than the chip with a long K walk: 4 K groups per workgroup
-template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool UNI, bool BF16, bool X3 = false>
+template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool UNI, bool BF16, bool X3 = false, bool RAG = false>
 int launch_vec(ConvArgs& a, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
     constexpr bool SMALL = (BM * BN <= 32 * 64) && (BM <= 64) && KT == 64;
@@ -925,11 +936,11 @@ int launch_vec(ConvArgs& a, hipStream_t s) {
         const int64_t nwg = all ? 0 : (int64_t)mh_cdiv(a.M, BM) * mh_cdiv(a.N, BN);
         const int ktiles = all ? 0 : mh_cdiv(a.taps * a.G * 4, KT);
         if (all || (g_split_k && a.vecC && nwg <= 256 && ktiles >= 8)) {
-            const int rc = launch_one<WM, WN, MT, NT, KT, DGRAD, true, UNI, BF16, KGV, X3>(a, s);
+            const int rc = launch_one<WM, WN, MT, NT, KT, DGRAD, true, UNI, BF16, KGV, X3, RAG>(a, s);
             if (!all || rc) return rc;
         }
     }
-    return launch_one<WM, WN, MT, NT, KT, DGRAD, true, UNI, BF16, 1, X3>(a, s);
+    return launch_one<WM, WN, MT, NT, KT, DGRAD, true, UNI, BF16, 1, X3, RAG>(a, s);
 }
 
 // F32 / B16: which arithmetic variants of this (tile, KT) are instantiated (bf16 runs KT = 64 only)
@@ -956,6 +967,9 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
         if (all || (dg && !vec)) { rc = launch_one<WM, WN, MT, NT, KT, true, false, false, false>(a, s); if (!all || rc) return rc; }
     }
     if constexpr (B16) {
+        // ragged K on the uniform-tap loader: from 4 K-tiles per tap on (the padding of the last tile is then < 25 % of the walk)
+        const bool rag = bf && !dg && !uni && !x3 && (a.K % KT != 0) && a.K > 4 * KT && !g_no_uni && g_ragged_uni;
+        if (all || rag) { rc = launch_vec<WM, WN, MT, NT, KT, false, true, true, false, true>(a, s); if (!all || rc) return rc; }
         if (all || (bf && !dg && uni)) { rc = launch_vec<WM, WN, MT, NT, KT, false, true, true>(a, s); if (!all || rc) return rc; }
         if (all || (bf && !dg && !uni)) { rc = launch_vec<WM, WN, MT, NT, KT, false, false, true>(a, s); if (!all || rc) return rc; }
         if (all || (bf && dg && uni)) { rc = launch_vec<WM, WN, MT, NT, KT, true, true, true>(a, s); if (!all || rc) return rc; }
@@ -984,6 +998,7 @@ extern "C" int mh_tune_conv_tile(int bm, int bn) {
     g_no_uni = ((bm >> 16) & 1) != 0;      // bit 16 of bm: disable the uniform-tap fast path
     g_split_k = ((bm >> 17) & 1) == 0;     // bit 17 of bm: disable the intra-workgroup split-K
     g_parity_classes = ((bm >> 18) & 1) == 0;   // bit 18 of bm: disable the stride-2 parity classes
+    g_ragged_uni = ((bm >> 19) & 1) == 0;       // bit 19 of bm: ragged-K layers back on the generic loader
     return 0;
 }
 

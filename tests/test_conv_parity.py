@@ -194,6 +194,56 @@ def _bf(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
 
+# bf16 forward layers whose K is NOT a multiple of the K-tile (DispNet's iconv layers: 1024+1 / 768+1 / 384+1 concat channels): uniform-tap walk over K
+# rounded up to whole tiles (conv_igemm_kernel<..., RAG>); (tile, (B, H, W, Ci, in_ld, Co, stride, dil))
+RAGGED_CASES = [
+    ((32, 64, 64), (1, 7, 10, 257, 260, 64, 1, 1)),        # one real channel in the last tile (split-K groups: 37 K-tiles on 4 workgroups)
+    ((32, 32, 64), (1, 6, 9, 321, 324, 40, 1, 1)),         # output columns not a multiple of the tile
+    ((64, 64, 64), (2, 5, 8, 300, 300, 64, 1, 2)),         # K % 4 == 0, row stride == K (the groups behind K do not exist), dilation 2
+    ((64, 32, 64), (1, 9, 11, 385, 388, 32, 2, 1)),        # stride 2
+    ((0, 0, 0), (1, 8, 12, 385, 388, 192, 1, 1)),          # tile picked by the heuristic
+]
+
+
+@pytest.mark.parametrize("tile,shape", RAGGED_CASES)
+def test_conv_bf16_ragged_k_uniform_tap(backend, tile, shape):
+    bm, bn, kt = tile
+    B, H, W, Ci, ld, Co, s, d = shape
+    dev = backend.device
+    x = _rand((B, H, W, Ci), 61, dev)
+    w = _rand((3, 3, Ci, Co), 62, dev, 0.1)
+    b = _rand((Co,), 63, dev)
+    y_ref = T.conv2d(_bf(x.cpu()), _bf(w.cpu()), b.cpu(), stride=s, dilation=d, alpha=0.2)
+    xb, xv = _padded(x, ld)
+    if ld > Ci:
+        xb[..., Ci:] = float("inf")       # the padding channels of a row must never reach an MFMA (Inf x a dropped weight row = NaN)
+    outs = {}
+    ops.PRECISION = 1
+    try:
+        for ragged in (1, 0):
+            backend.lib.tune_conv_tile(bm | ((1 - ragged) << 19), bn | (kt << 16))
+            y = torch.full(y_ref.shape, float("nan"), device=dev)
+            ops.conv2d_fwd(backend.lib, xv, w, b, ops.view(y), stride=s, dil=d, alpha=0.2)
+            name = backend.lib.last_kernel().decode()
+            assert ("uni-ragged" in name) == bool(ragged) and ",bf16," in name, name
+            backend.sync()
+            outs[ragged] = y.cpu()
+    finally:
+        ops.PRECISION = 0
+        backend.lib.tune_conv_tile(0, 0)
+    tol = 1e-4 * max(1.0, y_ref.abs().max().item())
+    assert (outs[1] - y_ref).abs().max().item() <= tol and (outs[0] - y_ref).abs().max().item() <= tol
+    # 256 input channels and fewer stay on the generic loader (the padded walk would waste > 20 %)
+    x2 = _rand((1, 6, 8, 130), 64, dev); x2b, x2v = _padded(x2, 132)
+    ops.PRECISION = 1
+    try:
+        ops.conv2d_fwd(backend.lib, x2v, _rand((3, 3, 130, 32), 65, dev), None, ops.view(torch.empty(1, 6, 8, 32, device=dev)))
+        assert "gen" in backend.lib.last_kernel().decode()
+    finally:
+        ops.PRECISION = 0
+
+
+
 BF16_CASES = [(1, 9, 14, 64, 32, 1, 2), (2, 8, 12, 128, 24, 1, 1), (1, 12, 20, 32, 32, 2, 1), (1, 7, 11, 38, 20, 1, 1),
               (1, 10, 16, 96, 64, 1, 1), (1, 9, 13, 3, 16, 2, 1), (1, 6, 10, 128, 128, 1, 4)]
 
