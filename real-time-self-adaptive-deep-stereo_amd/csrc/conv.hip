@@ -852,7 +852,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvArgs p) {
     }
 }
 
-static int g_thin_min_m = 16384;   // tuning hook (mh_tune_conv_thin): pixel count from which the weights-stationary kernel is used; < 0 = never
+static std::atomic<int> g_thin_min_m{16384};   // tuning hook (mh_tune_conv_thin): pixel count from which the weights-stationary kernel is used; < 0 = never
 
 static bool conv_thin_ok(const ConvArgs& a) {
     const bool g_pow2 = a.G == 1 || a.G == 2 || a.G == 4 || a.G == 8;
@@ -889,10 +889,10 @@ static bool conv_x3_igemm_on() {
     return v > 0;
 }
 extern "C" int mh_tune_conv_x3_igemm(int on) { g_x3_igemm = on < 0 ? -1 : (on != 0); return 0; }
-static bool g_no_uni = false;    // tuning hook: disable the uniform-tap fast path (A/B experiments)
-static bool g_ragged_uni = true; // tuning hook: ragged-K layers on the uniform-tap loader (bit 19 of mh_tune_conv_tile's bm clears it)
-static bool g_split_k = true;    // tuning hook: intra-workgroup split-K of the small tiles
-static bool g_parity_classes = true;   // tuning hook: stride-2 dgrad as 4 parity-class sub-problems
+static std::atomic<bool> g_no_uni{false};    // tuning hook: disable the uniform-tap fast path (A/B experiments)
+static std::atomic<bool> g_ragged_uni{true}; // tuning hook: ragged-K layers on the uniform-tap loader (bit 19 of mh_tune_conv_tile's bm clears it)
+static std::atomic<bool> g_split_k{true};   // tuning hook: intra-workgroup split-K of the small tiles
+static std::atomic<bool> g_parity_classes{true};   // tuning hook: stride-2 dgrad as 4 parity-class sub-problems
 
 template <int WM, int WN, int MT, int NT, int KT, bool DGRAD, bool VEC, bool UNI, bool BF16, int KG = 1, bool X3 = false, bool RAG = false>
 int launch_one(ConvArgs& a, hipStream_t s) {
@@ -988,9 +988,10 @@ int launch_cfg(ConvArgs& a, hipStream_t s) {
 // another's MFMAs); when no tile reaches that, take the one with the most workgroups.  Big tiles
 // use KT=32; the small, latency-bound ones KT=64/128 (fewer barriers, more bytes in flight).
 // mh_tune_conv_tile(bm, bn) forces a tile for experiments.
-static int g_force_bm = -1, g_force_bn = 0, g_force_kt = 0;
+static std::atomic<int> g_force_bm{-1}, g_force_bn{0}, g_force_kt{0};
 static int forced_bm() {
-    return g_force_bm < 0 ? 0 : g_force_bm;
+    const int v = g_force_bm.load(std::memory_order_relaxed);
+    return v < 0 ? 0 : v;
 }
 extern "C" int mh_tune_conv_thin(int min_pixels) { g_thin_min_m = min_pixels == 0 ? 16384 : min_pixels; return 0; }
 extern "C" int mh_tune_conv_tile(int bm, int bn) {

@@ -12,9 +12,11 @@
 //   corr_fwd_direct (D <= 9, the MADNet radius-2 volume; default): a group of LPP lanes owns a pixel and splits the
 //     channels, 1 + D independent 16-byte buffer loads per lane (the right-feature window is served from L1/L2), the D
 //     partial dot products meet in __shfl_xor butterflies -- 67-75 % of the HBM peak at the SURVEY 8(d) protocol shape;
-//   corr_fwd_small (D <= 9, LDS-staged right window; kept behind mh_tune_corr(0) -- measured slower than direct);
+//   corr_fwd_small (D <= 9, LDS-staged right window, plain pointers): the path of feature maps >= 2 GiB (no buffer descriptor) and the A/B partner of
+//     corr_fwd_direct behind mh_tune_corr(0) -- measured slower than direct;
 //   corr_fwd_mfma (D > 9, DispNet's 81-shift volume): the band of the row-wise product L * R^T on the fp32 MFMA;
 //   corr_fwd_large (generic fallback for the fused-concat forms of large D).
+#include <atomic>
 #include "mh_common.h"
 
 namespace {
@@ -767,7 +769,7 @@ int mh_corr_init() {
     return 0;
 }
 
-static int g_corr_direct = 1;
+static std::atomic<int> g_corr_direct{1};
 // tuning hook: 0 = LDS-staged window kernel, 1 = direct (no LDS) kernel for D <= 9
 extern "C" int mh_tune_corr(int direct) { g_corr_direct = direct; return 0; }
 

@@ -30,13 +30,13 @@ struct WgradArgs {
     int dbg_plain_store;   // timing experiment only: plain stores instead of atomics (WRONG results)
 };
 
-static int g_wgrad_target_wgs = 0;
+static std::atomic<int> g_wgrad_target_wgs{0};
 // tuning hook (microbenchmarks): number of workgroups the pixel split aims for (0 = heuristic)
 static std::atomic<int> g_wgrad_target_pct{0};     // mh_tune_wgrad_target_pct: scale of the pixel-split workgroup targets while a plan is recorded (0 = default)
 extern "C" int mh_tune_wgrad_target_pct(int pct) { return g_wgrad_target_pct.exchange(pct > 0 ? pct : 0); }      // returns the PREVIOUS value (not a status): callers that scope the setting restore it
-static int g_wgrad_plain = 0;
-static int g_wgrad_tile64 = 0;
-static int g_wgrad_w8 = 0;
+static std::atomic<int> g_wgrad_plain{0};
+static std::atomic<int> g_wgrad_tile64{0};
+static std::atomic<int> g_wgrad_w8{0};
 extern "C" int mh_tune_wgrad_wgs(int target) {
     g_wgrad_plain = target < 0;                    // negative: timing experiment with plain stores (wrong results)
     if (target < 0) target = -target;
@@ -516,7 +516,8 @@ int launch_wgrad_bf16(WgradArgs& a, hipStream_t s) {
     // (layers with more than 65536 reduction pixels -- several streams batched through one model, DispNet's / the pyramid's full-size layers -- are
     //  throughput bound and keep the round-1 targets: B = 4 batched 834 vs 796 pairs/s)
     const int base_t = a.M > 65536 ? (units >= 32 ? 384 : (units >= 8 ? 768 : 1536)) : (units >= 32 ? 256 : (units >= 8 ? 512 : 1024));
-    const int target = g_wgrad_target_wgs > 0 ? g_wgrad_target_wgs : base_t * env_scale / 100;
+    const int forced_wgs = g_wgrad_target_wgs.load(std::memory_order_relaxed);
+    const int target = forced_wgs > 0 ? forced_wgs : base_t * env_scale / 100;
     int splits = a.forced_splits > 0 ? a.forced_splits : mh_cdiv(target, base);
     int maxs = mh_cdiv(a.M, PT * 2);
     constexpr int cap = 192;
@@ -556,7 +557,8 @@ int launch_wgrad_one(WgradArgs& a, hipStream_t s) {
     // measured (profiles/r01_microbench.txt): big dW tiles want ~1.5 workgroups per CU, tiny ones (a
     // few MFMAs per reduction tile) need many more to hide their latency
     constexpr int units = WM * WN * MT * NT;
-    const int target = g_wgrad_target_wgs > 0 ? g_wgrad_target_wgs : (units >= 32 ? 384 : (units >= 8 ? 768 : 1536));
+    const int forced_wgs = g_wgrad_target_wgs.load(std::memory_order_relaxed);
+    const int target = forced_wgs > 0 ? forced_wgs : (units >= 32 ? 384 : (units >= 8 ? 768 : 1536));
     int splits = a.forced_splits > 0 ? a.forced_splits : mh_cdiv(target, base);
     const int maxs = mh_cdiv(a.M, PT * 4);
     if (splits > maxs) splits = maxs;
