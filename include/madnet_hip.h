@@ -378,7 +378,8 @@ int mh_fill(float* p, int64_t n, float v, void* stream);
 int mh_bias_grad(const float* dz, int32_t dz_ld, int64_t npix, int32_t nch, float* db, void* stream);
 
 /* ---- tuning hooks used by scripts/microbench.py (0 = built-in heuristic) ------------------ */
-int mh_tune_conv_tile(int bm, int bn);
+int mh_tune_conv_tile(int bm, int bn);   /* tiled implicit-GEMM kernel: force the bm x bn tile (bits 0-15; 0 = heuristic), K-tile = bn >> 16; bm bits 16-19 switch off the
+                                            uniform-tap loader / the intra-workgroup split-K / the stride-2 parity classes / the ragged-K uniform-tap instances (A/B) */
 int mh_tune_conv_thin(int min_pixels);   /* weights-stationary thin-layer kernel from this many output pixels (0 = default, < 0 = never) */
 int mh_tune_conv_patch(int mode);        /* patch-staged bf16 kernel of the stride-1 3x3 layers: 0 = off, 1 = on (tile heuristic), 64 / 128 = forced pixel tile, +256 = 8-wave variant, +2048 = generic-K instances only, +4096 = forward layers only, +8192 = no generic-K input gradients, < 0 = built-in default; returns the number of launches of that kernel since the previous call */
 int mh_tune_conv_x3_igemm(int on);       /* split-bf16 (precision 2) on the tiled implicit-GEMM kernel for forward layers without a patch / bank instance: 0 = exact fp32 there (default: measured faster), 1 = on, < 0 = default */
