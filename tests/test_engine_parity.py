@@ -726,12 +726,12 @@ def _ffi_mod():
 @pytest.mark.parametrize("bname,size", [SIZES[0], pytest.param("hip", (128, 256), marks=pytest.mark.gpu, id="hip-128x256")])
 def test_private_models_as_branches_of_one_graph(bname, size):
     """mh_plans_run / plan.MultiPlan (several private-model streams on one GPU): the FULL steps of S = 3 engines -- their own weights,
-    their own frames -- run as parallel branches (captured into ONE hipGraph on the GPU), two steps; every engine ends where it ends when its plan
+    their own frames (S = 2 on the emulator) -- run as parallel branches (captured into ONE hipGraph on the GPU), two steps; every engine ends where it ends when its plan
     runs alone.  Same kernels on the same data: equal up to the landing order of the fp32 atomics (bias / warp gradients)."""
     from madnet_hip.plan import MultiPlan
     backend = _backend(bname)
     H, W = size
-    S_ = 3
+    S_ = 3 if bname == "hip" else 2          # (the emulator runs a FULL step in ~4 s)
     shapes = OM.variable_shapes()
 
     def make(i):
