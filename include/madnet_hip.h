@@ -388,6 +388,7 @@ int mh_tune_conv_bank_tile(int max_wgs);     /* split-bf16 bank kernel: layers w
 int mh_tune_conv_bank(int small_maxpix); /* fragment-bank kernels (mh_conv2d_wb): the small-layer kernel takes layers of up to this many output pixels (0 = never, < 0 = default 4096); returns the number of bank-kernel launches since the previous call */
 int mh_tune_wgrad_wgs(int target_workgroups);
 int mh_tune_wgrad_target_pct(int pct);   /* scale (percent) of the filter-gradient pixel-split workgroup targets for the split counts resolved from now on (a plan stores the counts it was recorded with); 0 = default.  Returns the PREVIOUS value (NOT a status code) so that a caller can scope the setting: DispNet's engine records with 150 under a process-wide lock and restores what it found */
+int mh_tune_wgrad_image(int on);        /* image-layer filter-gradient kernel (3x3, Cin <= 3, Cout = 16, bf16; wgrad.hip): 0 = off (default: not yet timed on the GPU), 1 = on, > 1 = on with this many workgroups; returns the previous setting */
 int mh_tune_wgrad_stream(int dist);     /* prefetch distance (row groups in flight) of the streaming filter-gradient kernel: 1 or 2, 0 = default */
 int mh_tune_corr(int direct);
 

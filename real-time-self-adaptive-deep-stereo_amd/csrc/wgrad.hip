@@ -681,6 +681,121 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(WgradGroup g) {
     }
 }
 
+// ---- the image layer (3x3, Cin <= 3, Cout = 16: MADNet's conv1) ---------------------------------------------------------------------------
+// dW[(tap, c)][n] = sum over output pixels of x[pixel + tap][c] * dz[pixel][n] is a 16 x 32 x M product with M = 245 760 at 1242x375: 432 results, 0.2 GFLOP,
+// and 28 MB of operands.  The tiled kernel spends 20 us on it (167 pixel splits of a 16 x 16 tile, 1503 workgroups) and the reduction of its 167
+// partial gradients another 12 -- both at the very END of the step, behind the last input gradient, where nothing hides them.  Here a wave owns 32
+// output pixels per MFMA pair: lane (li, lq) gathers dz[8 lq .. + 7][n = li] (A operand) and the two columns li / li + 16 of the im2col row of the
+// same 8 pixels (B operands: 8 + 16 independent 4-byte buffer loads, out-of-image taps = out-of-range offsets = 0), rounds to bf16 like the tiled
+// kernel and issues two MFMAs; the 16 waves of a workgroup meet in LDS, so a launch leaves ONE partial gradient per workgroup (64 instead of 167) for
+// the step's reduction launch.  The bias gradient stays exact fp32: the lanes sum the dz values they load.  Default OFF (mh_tune_wgrad_image) until it
+// has been timed in the step on the MI355X: written after the round's GPU budget was spent (parity: emulator).
+constexpr int IMG_WAVES = 16;
+static std::atomic<int> g_wgrad_image{0};
+extern "C" int mh_tune_wgrad_image(int on) { return g_wgrad_image.exchange(on > 0 ? on : 0); }      // returns the previous setting; > 1 = workgroup count
+
+__global__ __launch_bounds__(64 * IMG_WAVES) void wgrad_image_kernel(WgradArgs p) {
+    __shared__ float part[IMG_WAVES][2][256];
+    __shared__ float bpart[IMG_WAVES][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rs_in = mh_make_rsrc(p.in, p.in_bytes);
+    const __amdgpu_buffer_rsrc_t rs_dz = mh_make_rsrc(p.dz, p.dz_bytes);
+    const int ncol = 9 * p.K;
+    int dy[2], dx[2], cc[2];
+    bool colok[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int col = li + 16 * t;
+        colok[t] = col < ncol;
+        const int tap = colok[t] ? col / p.K : 0;
+        cc[t] = colok[t] ? col - tap * p.K : 0;
+        dy[t] = tap / 3 - p.pad_t;
+        dx[t] = tap % 3 - p.pad_l;
+    }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    const int m_begin = blockIdx.x * p.chunk;
+    const int m_end = (m_begin + p.chunk < p.M) ? m_begin + p.chunk : p.M;
+    for (int m0 = m_begin + wave * 32; m0 < m_end; m0 += IMG_WAVES * 32) {
+        const int m = m0 + lq * 8;
+        int ox = m % p.Wo;
+        const int t2 = m / p.Wo;
+        int oy = t2 % p.Ho, b = t2 / p.Ho;
+        float av[8], b0[8], b1[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool live = m + i < m_end;
+            av[i] = mh_buf_load1(rs_dz, live ? ((m + i) * p.dz_ld + li) * 4 : MH_OOB);
+            const int iy0 = oy * p.stride, ix0 = ox * p.stride;
+            {
+                const int iy = iy0 + dy[0], ix = ix0 + dx[0];
+                const bool ok = live && colok[0] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+                b0[i] = mh_buf_load1(rs_in, ok ? (((b * p.Hi + iy) * p.Wi + ix) * p.in_ld + cc[0]) * 4 : MH_OOB);
+            }
+            {
+                const int iy = iy0 + dy[1], ix = ix0 + dx[1];
+                const bool ok = live && colok[1] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+                b1[i] = mh_buf_load1(rs_in, ok ? (((b * p.Hi + iy) * p.Wi + ix) * p.in_ld + cc[1]) * 4 : MH_OOB);
+            }
+            if (++ox == p.Wo) { ox = 0; if (++oy == p.Ho) { oy = 0; ++b; } }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bsum += av[i];
+        const u32x4 A = {mh_pack_bf16(av[0], av[1]), mh_pack_bf16(av[2], av[3]), mh_pack_bf16(av[4], av[5]), mh_pack_bf16(av[6], av[7])};
+        const u32x4 B0 = {mh_pack_bf16(b0[0], b0[1]), mh_pack_bf16(b0[2], b0[3]), mh_pack_bf16(b0[4], b0[5]), mh_pack_bf16(b0[6], b0[7])};
+        const u32x4 B1 = {mh_pack_bf16(b1[0], b1[1]), mh_pack_bf16(b1[2], b1[3]), mh_pack_bf16(b1[4], b1[5]), mh_pack_bf16(b1[6], b1[7])};
+        acc0 = mh_mfma_bf16(A, B0, acc0);            // D[n = 4 lq + r][column li]
+        acc1 = mh_mfma_bf16(A, B1, acc1);            // D[n][column li + 16]
+    }
+    // the workgroup's partial gradient: part[wave][t][column * 16 + n]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        part[wave][0][li * 16 + lq * 4 + r] = acc0[r];
+        part[wave][1][li * 16 + lq * 4 + r] = acc1[r];
+    }
+    bsum += __shfl_xor(bsum, 16);
+    bsum += __shfl_xor(bsum, 32);
+    if (lane < 16) bpart[wave][lane] = bsum;
+    __syncthreads();
+    const int e = threadIdx.x;
+    if (e < 512) {
+        const int t = e >> 8, idx = e & 255;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < IMG_WAVES; ++w) v += part[w][t][idx];
+        const int col = t * 16 + (idx >> 4), n = idx & 15;
+        if (col < ncol) p.ws[(int64_t)blockIdx.x * (ncol * 16) + col * 16 + n] = v;
+    } else if (e < 512 + 16 && p.db) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < IMG_WAVES; ++w) v += bpart[w][e - 512];
+        atomicAdd(p.db + (e - 512), v);
+    }
+}
+
+static bool wgrad_image_ok(const WgradArgs& a) {
+    return g_wgrad_image.load(std::memory_order_relaxed) > 0 && a.bf16 && a.kh == 3 && a.kw == 3 && a.dil == 1 && a.K * 9 <= 32 && a.N == 16 &&
+           (a.ws || a.query) && !a.dw && a.M >= 8192 && (a.stride == 1 || a.stride == 2);
+}
+
+static int launch_wgrad_image(WgradArgs& a, hipStream_t s) {
+    const int tuned = g_wgrad_image.load(std::memory_order_relaxed);
+    int splits = a.forced_splits > 0 ? a.forced_splits : (tuned > 1 ? tuned : 64);
+    const int maxs = mh_cdiv(a.M, 32 * IMG_WAVES);            // at least one 32-pixel step per wave
+    if (splits > maxs) splits = maxs;
+    if (splits < 1) splits = 1;
+    int chunk = mh_cdiv(a.M, splits);
+    chunk = (chunk + 31) / 32 * 32;
+    a.splits = mh_cdiv(a.M, chunk);                           // idempotent: forcing the returned count reproduces it
+    a.chunk = chunk;
+    if (a.query) return 0;
+    if (t_capture) { t_capture->cfg = -1; t_capture->nblocks = 0; t_capture->lds = 0; return 0; }      // never part of a grouped launch
+    mh_note_kernel("wgrad_image_kernel K=%d splits %d grid %d x %d waves", a.K, a.splits, a.splits, IMG_WAVES);
+    hipLaunchKernelGGL(wgrad_image_kernel, dim3(a.splits), dim3(64 * IMG_WAVES), 0, s, a);
+    return mh_check_launch("wgrad_image");
+}
+
 static bool wgrad_n1_ok(const WgradArgs& a) {
     return a.N == 1 && a.taps == 9 && a.vecA && (a.K % 4 == 0) && a.K <= 1024 && a.M > 0;
 }
@@ -778,7 +893,8 @@ static int wgrad_entry(const mh_conv_desc* d, const float* in, const float* dout
         a.in_bytes = (unsigned)inb; a.dz_bytes = (unsigned)dzb;
     }
     t_capture = cap;
-    const int rc = wgrad_n1_ok(a) ? launch_wgrad_n1(a, (hipStream_t)stream) : wgrad_dispatch(a, (hipStream_t)stream);
+    const int rc = wgrad_n1_ok(a) ? launch_wgrad_n1(a, (hipStream_t)stream)
+                   : wgrad_image_ok(a) ? launch_wgrad_image(a, (hipStream_t)stream) : wgrad_dispatch(a, (hipStream_t)stream);
     t_capture = nullptr;
     if (splits_out) *splits_out = a.splits;
     if (out_args) *out_args = a;

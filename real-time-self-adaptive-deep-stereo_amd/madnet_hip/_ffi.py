@@ -98,6 +98,7 @@ SIGNATURES = {
     "mh_pack_weights": (_I, [_P, _I, _I, _P]),
     "mh_pack_bytes": (_L, [_I, _I, _I, _I]),
     "mh_tune_conv_bank": (_I, [_I]),
+    "mh_tune_wgrad_image": (_I, [_I]),
     "mh_tune_conv_bank_tile": (_I, [_I]),
     "mh_tune_conv_rows": (_I, [_I]),
     "mh_tune_wgrad_target_pct": (_I, [_I]),
@@ -157,7 +158,7 @@ SIGNATURES = {
     "mh_event_destroy": (_I, [_P]),
     "mh_stream_sync": (_I, [_P]),
 }
-_NO_STATUS = {"mh_tune_wgrad_target_pct", "mh_conv2d_takes_shadows", "mh_tune_conv_bank_tile", "mh_tune_conv_rows", "mh_last_error", "mh_last_kernel", "mh_tune_conv_bank", "mh_pack_bytes", "mh_abi_version", "mh_tune_conv_patch", "mh_crc32c", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats", "mh_proxy_ws_floats"}
+_NO_STATUS = {"mh_tune_wgrad_target_pct", "mh_tune_wgrad_image", "mh_conv2d_takes_shadows", "mh_tune_conv_bank_tile", "mh_tune_conv_rows", "mh_last_error", "mh_last_kernel", "mh_tune_conv_bank", "mh_pack_bytes", "mh_abi_version", "mh_tune_conv_patch", "mh_crc32c", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats", "mh_proxy_ws_floats"}
 
 
 class MadnetHipError(RuntimeError):
