@@ -694,7 +694,7 @@ constexpr int IMG_WAVES = 16;
 static std::atomic<int> g_wgrad_image{0};
 extern "C" int mh_tune_wgrad_image(int on) { return g_wgrad_image.exchange(on > 0 ? on : 0); }      // returns the previous setting; > 1 = workgroup count
 
-__global__ __launch_bounds__(64 * IMG_WAVES) void wgrad_image_kernel(WgradArgs p) {
+__global__ __launch_bounds__(64 * IMG_WAVES) void wgrad_image_kernel(WgradArgs p, unsigned mulWo, unsigned mulHo) {
     __shared__ float part[IMG_WAVES][2][256];
     __shared__ float bpart[IMG_WAVES][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -702,43 +702,44 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void wgrad_image_kernel(WgradArgs p
     const __amdgpu_buffer_rsrc_t rs_in = mh_make_rsrc(p.in, p.in_bytes);
     const __amdgpu_buffer_rsrc_t rs_dz = mh_make_rsrc(p.dz, p.dz_bytes);
     const int ncol = 9 * p.K;
-    int dy[2], dx[2], cc[2];
+    // this lane's two im2col columns: (tap, channel) -> row / column shift and the element offset from the pixel's own position
+    int dy[2], dx[2], coff[2];
     bool colok[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int col = li + 16 * t;
         colok[t] = col < ncol;
         const int tap = colok[t] ? col / p.K : 0;
-        cc[t] = colok[t] ? col - tap * p.K : 0;
+        const int c = colok[t] ? col - tap * p.K : 0;
         dy[t] = tap / 3 - p.pad_t;
         dx[t] = tap % 3 - p.pad_l;
+        coff[t] = ((dy[t] * p.Wi + dx[t]) * p.in_ld + c) * 4;
     }
+    const unsigned step_x = (unsigned)(p.stride * p.in_ld * 4), step_z = (unsigned)(p.dz_ld * 4);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
     const int m_begin = blockIdx.x * p.chunk;
-    const int m_end = (m_begin + p.chunk < p.M) ? m_begin + p.chunk : p.M;
+    const int m_end = (m_begin + p.chunk < p.M) ? m_begin + p.chunk : p.M;          // multiples of 8 (chunk % 32 == 0, Wo % 8 == 0)
     for (int m0 = m_begin + wave * 32; m0 < m_end; m0 += IMG_WAVES * 32) {
+        // this lane's 8 pixels m .. m + 7 lie in ONE output row (Wo % 8 == 0) and are live or dead together
         const int m = m0 + lq * 8;
-        int ox = m % p.Wo;
-        const int t2 = m / p.Wo;
-        int oy = t2 % p.Ho, b = t2 / p.Ho;
+        const bool live = m < m_end;
+        const int t2 = (int)__umulhi((unsigned)m, mulWo), ox = m - t2 * p.Wo;
+        const int b = (int)__umulhi((unsigned)t2, mulHo), oy = t2 - b * p.Ho;
+        const int iy0 = oy * p.stride, ix0 = ox * p.stride;
+        const unsigned base = (unsigned)(((b * p.Hi + iy0) * p.Wi + ix0) * p.in_ld * 4);
+        const bool row0 = live && colok[0] && (unsigned)(iy0 + dy[0]) < (unsigned)p.Hi;
+        const bool row1 = live && colok[1] && (unsigned)(iy0 + dy[1]) < (unsigned)p.Hi;
+        unsigned zoff = live ? (unsigned)((m * p.dz_ld + li) * 4) : (unsigned)MH_OOB;      // MH_OOB + 7 steps stays out of range (unsigned)
+        unsigned xo0 = base + (unsigned)coff[0], xo1 = base + (unsigned)coff[1];
+        int ixa = ix0 + dx[0], ixb = ix0 + dx[1];
         float av[8], b0[8], b1[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const bool live = m + i < m_end;
-            av[i] = mh_buf_load1(rs_dz, live ? ((m + i) * p.dz_ld + li) * 4 : MH_OOB);
-            const int iy0 = oy * p.stride, ix0 = ox * p.stride;
-            {
-                const int iy = iy0 + dy[0], ix = ix0 + dx[0];
-                const bool ok = live && colok[0] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-                b0[i] = mh_buf_load1(rs_in, ok ? (((b * p.Hi + iy) * p.Wi + ix) * p.in_ld + cc[0]) * 4 : MH_OOB);
-            }
-            {
-                const int iy = iy0 + dy[1], ix = ix0 + dx[1];
-                const bool ok = live && colok[1] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-                b1[i] = mh_buf_load1(rs_in, ok ? (((b * p.Hi + iy) * p.Wi + ix) * p.in_ld + cc[1]) * 4 : MH_OOB);
-            }
-            if (++ox == p.Wo) { ox = 0; if (++oy == p.Ho) { oy = 0; ++b; } }
+            av[i] = mh_buf_load1(rs_dz, (int)zoff);
+            b0[i] = mh_buf_load1(rs_in, (row0 && (unsigned)ixa < (unsigned)p.Wi) ? (int)xo0 : MH_OOB);
+            b1[i] = mh_buf_load1(rs_in, (row1 && (unsigned)ixb < (unsigned)p.Wi) ? (int)xo1 : MH_OOB);
+            zoff += step_z; xo0 += step_x; xo1 += step_x; ixa += p.stride; ixb += p.stride;
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) bsum += av[i];
@@ -776,7 +777,8 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void wgrad_image_kernel(WgradArgs p
 
 static bool wgrad_image_ok(const WgradArgs& a) {
     return g_wgrad_image.load(std::memory_order_relaxed) > 0 && a.bf16 && a.kh == 3 && a.kw == 3 && a.dil == 1 && a.K * 9 <= 32 && a.N == 16 &&
-           (a.ws || a.query) && !a.dw && a.M >= 8192 && (a.stride == 1 || a.stride == 2);
+           (a.ws || a.query) && !a.dw && a.M >= 8192 && (a.stride == 1 || a.stride == 2) && a.Wo % 8 == 0 &&
+           (int64_t)a.M * (a.Wo > a.Ho ? a.Wo : a.Ho) < (1ll << 32);          // (the multiply-high divisions of the pixel index are exact below that)
 }
 
 static int launch_wgrad_image(WgradArgs& a, hipStream_t s) {
@@ -792,7 +794,8 @@ static int launch_wgrad_image(WgradArgs& a, hipStream_t s) {
     if (a.query) return 0;
     if (t_capture) { t_capture->cfg = -1; t_capture->nblocks = 0; t_capture->lds = 0; return 0; }      // never part of a grouped launch
     mh_note_kernel("wgrad_image_kernel K=%d splits %d grid %d x %d waves", a.K, a.splits, a.splits, IMG_WAVES);
-    hipLaunchKernelGGL(wgrad_image_kernel, dim3(a.splits), dim3(64 * IMG_WAVES), 0, s, a);
+    const unsigned mulWo = (unsigned)(((1ull << 32) + a.Wo - 1) / a.Wo), mulHo = (unsigned)(((1ull << 32) + a.Ho - 1) / a.Ho);
+    hipLaunchKernelGGL(wgrad_image_kernel, dim3(a.splits), dim3(64 * IMG_WAVES), 0, s, a, mulWo, mulHo);
     return mh_check_launch("wgrad_image");
 }
 

@@ -13,7 +13,7 @@ from test_engine_parity import _backend, _ffi_mod
 
 
 # (B, H, W, Cin, in_ld, stride): the image layer's filter gradient (3x3, Cout = 16) on its own kernel (mh_tune_wgrad_image, default off)
-IMAGE_WGRAD_CASES = [(2, 96, 180, 3, 3, 2), (1, 96, 96, 3, 4, 1), (2, 131, 135, 1, 1, 2), (1, 181, 203, 2, 4, 2)]       # >= 8192 output pixels
+IMAGE_WGRAD_CASES = [(2, 96, 192, 3, 3, 2), (1, 96, 96, 3, 4, 1), (2, 131, 143, 1, 1, 2), (1, 181, 207, 2, 4, 2)]       # >= 8192 output pixels, output rows of 8 k pixels
 
 
 @pytest.mark.parametrize("how", ["single", "plan"])
@@ -49,7 +49,7 @@ def test_wgrad_image_layer_kernel(backend, case, how):
             x2 = _rand((1, 12, 20, 32), 303, dev); gz2 = _rand((1, 12, 20, 32), 304, dev)
             dw2 = torch.full((3, 3, 32, 32), float("nan"), device=dev); db2 = torch.zeros(32, device=dev)
             ops.conv2d_wgrad_partial(tgt, backend.lib, wsa, segs, ops.view(x2), ops.view(gz2), dw2, db2)
-            assert segs[0][3] == (min(64, (B * Ho * Wo + 511) // 512) if on else segs[0][3])
+            assert Wo % 8 == 0 and segs[0][3] == (min(64, (B * Ho * Wo + 511) // 512) if on else segs[0][3])
             ops.wgrad_reduce(tgt, segs, dev, keep)
             if rec is not None:
                 rec.compile().run(backend.lib, None)
@@ -67,6 +67,30 @@ def test_wgrad_image_layer_kernel(backend, case, how):
     for on in (1, 0):
         assert (res[on][1] - gb_ref).abs().max().item() <= 1e-4 * max(1.0, gb_ref.abs().max().item()), on
     assert torch.equal(res[1][2], res[0][2])                      # the neighbour layer is untouched by the switch
+
+
+def test_wgrad_image_layer_kernel_declines_ragged_rows(backend):
+    """output rows that are not a multiple of 8 pixels (a lane's 8 pixels would straddle rows) and small layers stay on the tiled kernel"""
+    import ctypes as C
+    dev = backend.device
+    prev = backend.lib.tune_wgrad_image(1)
+    ops.PRECISION_BWD = 1
+    ops.PRECISION = 1
+    try:
+        for (H, W, s) in ((96, 180, 2), (40, 64, 1)):
+            x = _rand((2, H, W, 3), 311, dev)
+            Ho, Wo, _, _ = ops.conv_geometry(H, W, 3, 3, s, 1)
+            gz = _rand((2, Ho, Wo, 16), 312, dev)
+            xb, xv = _padded(x, 4)
+            wsa = ops.WgradWorkspace(dev); wsa.CHUNK = 1 << 20
+            segs = []
+            dw = torch.zeros(3, 3, 3, 16, device=dev); db = torch.zeros(16, device=dev)
+            ops.conv2d_wgrad_partial(backend.lib, backend.lib, wsa, segs, xv, ops.view(gz), dw, db, stride=s)
+            assert "wgrad_image" not in backend.lib.last_kernel().decode()
+    finally:
+        ops.PRECISION = 0
+        ops.PRECISION_BWD = None
+        backend.lib.tune_wgrad_image(prev)
 
 
 def _image_layer_kernel_ab(backend, H, W):
