@@ -55,6 +55,16 @@ def ctx_name(j):
     return "model/context-%d" % j
 
 
+def _merge_ranges(ranges):
+    out = []
+    for a, b in sorted(ranges):
+        if out and a <= out[-1][1]:
+            out[-1] = (out[-1][0], max(out[-1][1], b))
+        else:
+            out.append((a, b))
+    return out
+
+
 def madnet_manifest(radius_d=2, stride=1):
     """Ordered [(variable name, shape)] -- flat-buffer order.  Names are the TF variable names of
     the reference graph."""
@@ -93,6 +103,9 @@ def madnet_manifest(radius_d=2, stride=1):
 EARLY_WGS = 192
 EARLY_BATCHES = 3
 FUSE_HEAD = True
+# FULL momentum steps: every filter-gradient batch is followed by the momentum update of its layers on its own lane, the launch behind the join covers
+# only what is left.  OFF: prepared at the end of round 3 and never timed on the MI355X (profiles/r03_experiments.txt #26; bench.py --set engine.EARLY_UPDATE=True)
+EARLY_UPDATE = False
 # input gradients stage the bf16 shadow of dz when the previous input gradient's epilogue wrote one (mh_conv2d_sh2)
 SHADOW_DGRAD = True
 # ... and then do not store the fp32 gradient map at all when its only reader is such an input gradient (engine._elide_fp32_gradient_maps)
@@ -571,8 +584,11 @@ class MadNetEngine(object):
             prev = up_V[k]
         return pyr_tr, pyr_need, est_tr, ctx_tr, up_V
 
-    def record_backward(self, r, head, train_vars, bulkhead, heads=None):
-        """head: 'final' (loss on rescaled_prediction, FULL mode) or a level k in LEVELS
+    def record_backward(self, r, head, train_vars, bulkhead, heads=None, early_update=None):
+        """early_update = (lr, momentum, grad_scale) (EARLY_UPDATE, FULL momentum steps): the update of a batch's layers follows the batch's reduction on its
+        lane -- their input gradients were launched before the batch's fork edge and nothing later in the step reads those weights (the fragment banks
+        were packed at the start of the step) -- instead of ONE launch over every parameter behind the join; returns the ranges updated that way.
+        head: 'final' (loss on rescaled_prediction, FULL mode) or a level k in LEVELS
         (loss on the _make_disp of that level / of the context output for k=2, MAD mode).
         Assumes the matching d(loss)/d(disparity map) is already in self.dpred / self.ddisp_k.
         heads (offline training, Train.py:100): {'final' | level: gradient buffer} -- a loss on EVERY prediction at once;
@@ -604,11 +620,20 @@ class MadNetEngine(object):
         segs = []                           # partial filter-gradient segments of this backward pass
 
         pending = []                        # deferred filter-gradient launches (flushed as one side-lane batch)
+        batched = (self.wgrad_lanes > 0 and hasattr(lib, "lane")) or (self.use_stream and self.partial_wgrad)
+        if not batched:
+            early_update = None
+        fresh, early = [], []               # early_update: parameter ranges the batch being collected completes / ranges already updated
 
         def wgrad(xv, dzv, base, stride=1, dil=1):
             dw, db = P.tensor(base + "/weights", "g"), P.tensor(base + "/biases", "g")
-            if (self.wgrad_lanes > 0 and hasattr(lib, "lane")) or (self.use_stream and self.partial_wgrad):
+            if batched:
                 pending.append((xv, dzv, dw, db, stride, dil))      # issued per batch (flush): on a side lane, and / or as one streamed launch
+                if early_update is not None:
+                    for t in (dw, db):
+                        a = (t.data_ptr() - P.g.data_ptr()) // 4
+                        assert 0 <= a and a + t.numel() <= P.total
+                        fresh.append((a, min((a + t.numel() + 3) & ~3, P.total)))       # (+ the tensor's alignment padding: zero gradient, zero momentum)
             elif not self.partial_wgrad:
                 ops.conv2d_wgrad(lib, xv, dzv, dw, db, stride=stride, dil=dil)
             else:
@@ -648,11 +673,17 @@ class MadNetEngine(object):
                 # the batch's split reduction follows on the SAME lane: it too is off the critical path
                 if batch:
                     ops.wgrad_reduce(lib, batch, self.dev, r.keep)
+                if early_update is not None:
+                    lr_, mom_, gs_ = early_update
+                    for a, b in _merge_ranges(fresh):
+                        ops.momentum(lib, P.w[a:b], P.m[a:b], P.g[a:b], lr_, mom_, gs_)
+                        early.append((a, b))
             finally:
                 if side:
                     lib.lane = 0
                     lib.nodefer = False
                 del pending[:]
+                del fresh[:]
 
         def acc_flag(key):
             a = key in written
@@ -847,12 +878,27 @@ class MadNetEngine(object):
         flush()
         ops.wgrad_reduce(lib, segs, self.dev, r.keep)          # (serial variant only: the side-lane batches reduce themselves)
         r.join_next = True                                      # whatever comes next (the optimizer) waits for the side lanes
+        return _merge_ranges(early)
 
-    def record_update(self, r, train_vars, lr, momentum=0.9, grad_scale=1.0):
-        """MomentumOptimizer apply on the (coalesced) ranges of train_vars."""
+    def record_update(self, r, train_vars, lr, momentum=0.9, grad_scale=1.0, done=()):
+        """MomentumOptimizer apply on the (coalesced) ranges of train_vars; done: sorted disjoint [first, end) ranges that
+        record_backward(early_update=...) has updated already."""
         P = self.params
+
+        def emit(a, b):
+            ops.momentum(r, P.w[a:b], P.m[a:b], P.g[a:b], lr, momentum, grad_scale, n=b - a)
         for o, c in P.ranges(train_vars):
-            ops.momentum(r, P.w[o:o + c], P.m[o:o + c], P.g[o:o + c], lr, momentum, grad_scale, n=c)
+            a, end = o, o + c
+            for d0, d1 in done:
+                if d1 <= a:
+                    continue
+                if d0 >= end:
+                    break
+                if d0 > a:
+                    emit(a, d0)
+                a = max(a, d1)
+            if a < end:
+                emit(a, end)
 
     def record_update_adam(self, r, train_vars, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
         """tf.train.AdamOptimizer(lr, 0.9).apply_gradients (Train.py:95,102) on the coalesced ranges of train_vars; the
@@ -952,12 +998,17 @@ class MadNetEngine(object):
                 self.record_loss_metrics(r, with_grad=False)
         elif mode == "FULL":
             tv = self.all_vars()
+            done = ()
             if do_grad:
                 self.record_forward(r)
                 self.record_loss_metrics(r, with_grad=True)
-                self.record_backward(r, "final", tv, bulkhead=False)
+                eu = (lr, 0.9, grad_scale) if (EARLY_UPDATE and do_upd and part == "all" and optimizer == "momentum") else None
+                done = self.record_backward(r, "final", tv, bulkhead=False, early_update=eu)
             if do_upd:
-                record_update(r, tv, lr, grad_scale=grad_scale)
+                if done:
+                    self.record_update(r, tv, lr, grad_scale=grad_scale, done=done)
+                else:
+                    record_update(r, tv, lr, grad_scale=grad_scale)
         elif mode == "MAD":
             if do_grad:
                 self.record_forward(r, make_disps=tuple(lv for lv, _ in blocks))

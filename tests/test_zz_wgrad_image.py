@@ -1,8 +1,10 @@
-"""The image layer's filter gradient on its own kernel (wgrad_image_kernel, csrc/wgrad.hip; mh_tune_wgrad_image, default OFF).
+"""Two changes to the TAIL of the MADNet step that were written after round 3's GPU budget was spent (profiles/r03_experiments.txt #25, #26), both default OFF:
+the image layer's filter gradient on its own kernel (wgrad_image_kernel, csrc/wgrad.hip; mh_tune_wgrad_image) and the momentum update per filter-gradient
+batch on the batch's lane (engine.EARLY_UPDATE).
 
-The kernel was written after round 3's GPU budget was spent: it is parity-checked on the CPU emulator only, the product does not dispatch it, and its
-MI355X tests live in THIS file -- the last one pytest collects -- so that they run after every test of the validated path.  Next round's first GPU call
-times it in the step (python bench.py --set tune.wgrad_image=1) and either makes it the default or removes it."""
+They are parity-checked on the CPU emulator only, the product does not use them, and their MI355X tests live in THIS file -- the last one pytest
+collects -- so that they run after every test of the validated path.  Next round's first GPU call (scripts/gpu_next_first.sh) times them in the step
+and either makes them defaults or removes them."""
 import pytest
 import torch
 
@@ -129,3 +131,48 @@ def test_step_with_image_layer_filter_gradient_kernel_gpu():
     _image_layer_kernel_ab(_backend("hip"), 375, 1242)
 
 
+
+
+def _early_update_ab(backend, H, W, precision):
+    """FULL momentum step with the per-batch updates (engine.EARLY_UPDATE) against the single update behind the join: the same elementwise update of the
+    same gradients; every parameter updated exactly once; only the last batch's layers + whatever has no filter gradient are left for the final launch."""
+    F = _ffi_mod()
+    wn = S.calibrated_weights(OM.variable_shapes(), 1)
+    l, r, gt = S.make_pair(H, W)
+    res = {}
+    saved = E.EARLY_UPDATE
+    try:
+        for early in (True, False):
+            E.EARLY_UPDATE = early
+            eng = E.MadNetEngine(backend.lib, H, W, B=1, device=backend.device, weights=wn, precision=precision)
+            eng.set_inputs(l, r, gt[..., 0])
+            plan = eng.build_plan("FULL", lr=1e-3)
+            P = eng.params
+            mom = [o for o in plan.arr if o.kind == F.OP_MOMENTUM]
+            spans = sorted(((o.p[0] - P.w.data_ptr()) // 4, (o.p[0] - P.w.data_ptr()) // 4 + o.n) for o in mom)
+            assert spans[0][0] == 0 and spans[-1][1] == P.total and all(a[1] == b[0] for a, b in zip(spans, spans[1:])), spans       # a partition
+            on_side = sum(1 for o in mom if (o.i[26] & 0xff) > 0)
+            assert (len(mom) >= 6 and on_side >= len(mom) - 1) if early else (len(mom) == 1 and on_side == 0), (len(mom), on_side)
+            snaps = []
+            for _ in range(2):
+                plan.run(backend.lib, 0)
+                backend.sync()
+                snaps.append((P.w.clone().cpu(), P.m.clone().cpu(), eng.pred.clone().cpu()))
+            res[early] = snaps
+    finally:
+        E.EARLY_UPDATE = saved
+    # two runs of the SAME plan differ by ~1e-8 in a few gradient elements (fp32 atomics), amplified by the bf16 roundings of the second step
+    for step, tols in ((0, (1e-9, 1e-7, 1e-5)), (1, (1e-6, 4e-4, 1e-3))):
+        for a, b, tol in zip(res[True][step], res[False][step], tols):
+            assert (a - b).abs().max().item() <= tol, (step, tol, (a - b).abs().max().item())
+
+
+@pytest.mark.parametrize("precision", ["fp32", "mixed"])
+def test_early_update_equals_late_update_emulated(precision):
+    from conftest import _emul_backend
+    _early_update_ab(_emul_backend(), 60, 100, precision)
+
+
+@pytest.mark.gpu
+def test_early_update_equals_late_update_gpu():
+    _early_update_ab(_backend("hip"), 375, 1242, "mixed")
