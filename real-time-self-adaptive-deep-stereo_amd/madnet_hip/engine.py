@@ -623,7 +623,7 @@ class MadNetEngine(object):
         batched = (self.wgrad_lanes > 0 and hasattr(lib, "lane")) or (self.use_stream and self.partial_wgrad)
         if not batched:
             early_update = None
-        fresh, early = [], []               # early_update: parameter ranges the batch being collected completes / ranges already updated
+        upd_fresh, upd_done = [], []        # early_update: parameter ranges the batch being collected completes / ranges already updated
 
         def wgrad(xv, dzv, base, stride=1, dil=1):
             dw, db = P.tensor(base + "/weights", "g"), P.tensor(base + "/biases", "g")
@@ -633,7 +633,7 @@ class MadNetEngine(object):
                     for t in (dw, db):
                         a = (t.data_ptr() - P.g.data_ptr()) // 4
                         assert 0 <= a and a + t.numel() <= P.total
-                        fresh.append((a, min((a + t.numel() + 3) & ~3, P.total)))       # (+ the tensor's alignment padding: zero gradient, zero momentum)
+                        upd_fresh.append((a, min((a + t.numel() + 3) & ~3, P.total)))       # (+ the tensor's alignment padding: zero gradient, zero momentum)
             elif not self.partial_wgrad:
                 ops.conv2d_wgrad(lib, xv, dzv, dw, db, stride=stride, dil=dil)
             else:
@@ -675,15 +675,15 @@ class MadNetEngine(object):
                     ops.wgrad_reduce(lib, batch, self.dev, r.keep)
                 if early_update is not None:
                     lr_, mom_, gs_ = early_update
-                    for a, b in _merge_ranges(fresh):
+                    for a, b in _merge_ranges(upd_fresh):
                         ops.momentum(lib, P.w[a:b], P.m[a:b], P.g[a:b], lr_, mom_, gs_)
-                        early.append((a, b))
+                        upd_done.append((a, b))
             finally:
                 if side:
                     lib.lane = 0
                     lib.nodefer = False
                 del pending[:]
-                del fresh[:]
+                del upd_fresh[:]
 
         def acc_flag(key):
             a = key in written
@@ -878,7 +878,7 @@ class MadNetEngine(object):
         flush()
         ops.wgrad_reduce(lib, segs, self.dev, r.keep)          # (serial variant only: the side-lane batches reduce themselves)
         r.join_next = True                                      # whatever comes next (the optimizer) waits for the side lanes
-        return _merge_ranges(early)
+        return _merge_ranges(upd_done)
 
     def record_update(self, r, train_vars, lr, momentum=0.9, grad_scale=1.0, done=()):
         """MomentumOptimizer apply on the (coalesced) ranges of train_vars; done: sorted disjoint [first, end) ranges that
