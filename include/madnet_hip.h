@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 10
+#define MH_ABI_VERSION 11
 
 /* status codes of every int-returning entry point: 0 = launched; a NEGATIVE code means an argument check failed and
  * nothing was launched or written; a POSITIVE value is the hipError_t of a failed launch / runtime call.
@@ -100,11 +100,36 @@ typedef struct mh_pack_seg {
     int32_t planes;       /* 2: hi + lo (split-bf16); 1: hi only */
     int32_t blk0;         /* exclusive prefix sum of ceil(taps*ceil(K/32)*ceil(N/16)*64 / 256) over the table */
     int32_t trans;        /* 0: src[tap][K][N] (forward: K = Cin, N = Cout); 1: src[tap][N][K] (the same HWIO bank seen by the input
-                             gradient: K = Cout is the reduction, N = Cin the output column) */
+                             gradient: K = Cout is the reduction, N = Cin the output column); 2: forward bank in the 32x32x16 register image
+                             mh_conv2d_planes reads (planes = 2, mh_pack32_bytes bytes; blk0 then counts ceil(taps*ceil(K/16)*ceil(N/32)*64 / 256)) */
 } mh_pack_seg;
 int64_t mh_pack_bytes(int32_t taps, int32_t K, int32_t N, int32_t planes);
+int64_t mh_pack32_bytes(int32_t taps, int32_t K, int32_t N);
 /* segs_device: table in DEVICE memory; nblocks = the sum the blk0 fields prefix. */
 int mh_pack_weights(const mh_pack_seg* segs_device, int32_t nseg, int32_t nblocks, void* stream);
+
+/* ---- split-bf16 forward pass from PRE-SPLIT operands (round 4; csrc/conv_planes.hip): tf.nn.conv2d / atrous_conv2d + bias_add + leaky
+ *      (Nets/sharedLayers.py:54-77) of the stride-1 3x3 layers, activations carried as TWO bf16 NHWC planes hi = bf16(x), lo = bf16(x - hi)
+ *      (pixel stride `*_pld` halfs >= the channel count rounded up to 16, a multiple of 8; the padding channels must be ZERO) -- the hi plane is
+ *      the bf16 shadow mh_wgrad_stream and the input gradients read.  Same products as precision code 2 of mh_conv2d (lo*hi + hi*lo + hi*hi).
+ *   d         : the forward descriptor (mode 0, stride 1, 'SAME', kh = kw = 3, any dilation; in_ld / precision / accumulate are ignored / must be 0)
+ *   wb32      : mh_pack_weights(trans = 2) image of the HWIO bank, mh_pack32_bytes(9, K, N) bytes
+ *   out       : fp32 result [pixel][d->out_ld] or NULL (only where a consumer without a plane path exists)
+ *   out_hi/lo : result planes [pixel][out_pld] or NULL
+ * mh_conv2d_planes_ok(d) = 1 if the layer has an instance (N <= 128 and a multiple of 8; ceil(K/16) in {2,3,4,5,6,8}).
+ * mh_plane_split: fp32 NHWC -> hi (+ lo) planes for tensors no plane-writing kernel produces (one launch per table; lo may be NULL = mh_shadow_cast). */
+int mh_conv2d_planes_ok(const mh_conv_desc* d);
+int mh_conv2d_planes(const mh_conv_desc* d, const void* in_hi, const void* in_lo, int32_t in_pld, const void* wb32, const float* bias,
+                     float* out, void* out_hi, void* out_lo, int32_t out_pld, void* stream);
+typedef struct mh_plane_seg {
+    const float* src;     /* fp32 [npix][src_ld], C valid channels */
+    void* hi;             /* bf16 [npix][dst_ld]: bf16(src), channels >= C zero; 16-byte aligned */
+    void* lo;             /* bf16 [npix][dst_ld]: bf16(src - hi), or NULL */
+    int64_t npix;
+    int32_t C, src_ld, dst_ld;
+    int32_t blk0;         /* exclusive prefix sum of ceil(npix * dst_ld / 8 / 256) over the table */
+} mh_plane_seg;
+int mh_plane_split(const mh_plane_seg* segs_device, int32_t nseg, int32_t nblocks, void* stream);
 
 /* weight+bias gradient: dw[tap][K][N] += sum_pixels in(pixel,tap)[k] * dout[pixel][n] ;
  * db[n] += sum_pixels dout[pixel][n].  `d` describes the FORWARD conv (mode 0 geometry:
@@ -377,20 +402,7 @@ int mh_fill(float* p, int64_t n, float v, void* stream);
 /* db[c] += sum_p dz[p][c]  (BiasAddGrad of conv2d_transpose, whose filter gradient runs with swapped operands) */
 int mh_bias_grad(const float* dz, int32_t dz_ld, int64_t npix, int32_t nch, float* db, void* stream);
 
-/* ---- tuning hooks used by scripts/microbench.py (0 = built-in heuristic) ------------------ */
-int mh_tune_conv_tile(int bm, int bn);   /* tiled implicit-GEMM kernel: force the bm x bn tile (bits 0-15; 0 = heuristic), K-tile = bn >> 16; bm bits 16-19 switch off the
-                                            uniform-tap loader / the intra-workgroup split-K / the stride-2 parity classes / the ragged-K uniform-tap instances (A/B) */
-int mh_tune_conv_thin(int min_pixels);   /* weights-stationary thin-layer kernel from this many output pixels (0 = default, < 0 = never) */
-int mh_tune_conv_patch(int mode);        /* patch-staged bf16 kernel of the stride-1 3x3 layers: 0 = off, 1 = on (tile heuristic), 64 / 128 = forced pixel tile, +256 = 8-wave variant, +2048 = generic-K instances only, +4096 = forward layers only, +8192 = no generic-K input gradients, < 0 = built-in default; returns the number of launches of that kernel since the previous call */
-int mh_tune_conv_x3_igemm(int on);       /* split-bf16 (precision 2) on the tiled implicit-GEMM kernel for forward layers without a patch / bank instance: 0 = exact fp32 there (default: measured faster), 1 = on, < 0 = default */
-int mh_tune_conv_rows(int min_pixels);   /* row-streaming kernel of the thin 3x3 stride-1 layers (conv_rows.hip: <= 16 input, <= 32 output channels): takes layers of at least this many output pixels (0 = never, < 0 = default 65536); returns the previous setting (-1 = default not resolved yet) */
-int mh_tune_conv_bank_tile(int max_wgs);     /* split-bf16 bank kernel: layers whose 64x128 / 128x64 grid would have fewer workgroups than this take the 64x64 tile with 4 waves (0 = never, < 0 = default 200); returns the previous setting */
-int mh_tune_conv_bank(int small_maxpix); /* fragment-bank kernels (mh_conv2d_wb): the small-layer kernel takes layers of up to this many output pixels (0 = never, < 0 = default 4096); returns the number of bank-kernel launches since the previous call */
-int mh_tune_wgrad_wgs(int target_workgroups);
-int mh_tune_wgrad_target_pct(int pct);   /* scale (percent) of the filter-gradient pixel-split workgroup targets for the split counts resolved from now on (a plan stores the counts it was recorded with); 0 = default.  Returns the PREVIOUS value (NOT a status code) so that a caller can scope the setting: DispNet's engine records with 150 under a process-wide lock and restores what it found */
-int mh_tune_wgrad_image(int on);        /* image-layer filter-gradient kernel (3x3, Cin <= 3, Cout = 16, bf16; wgrad.hip): 0 = off (default: not yet timed on the GPU), 1 = on, > 1 = on with this many workgroups; returns the previous setting */
-int mh_tune_wgrad_stream(int dist);     /* prefetch distance (row groups in flight) of the streaming filter-gradient kernel: 1 or 2, 0 = default */
-int mh_tune_corr(int direct);
+/* (the process-wide tuning hooks of the benchmarks live in madnet_hip_tune.h: none of them is part of the reference interface) */
 
 /* host utility: CRC-32C (Castagnoli) of a host buffer, chained through `crc` (0 to start) -- used by the TensorFlow
  * checkpoint importer that replaces tf.train.NewCheckpointReader (Data_utils/weights_utils.py:29). */
@@ -402,7 +414,7 @@ enum { MH_OP_CONV = 1, MH_OP_WGRAD, MH_OP_CORR_FWD, MH_OP_CORR_BWD, MH_OP_WARP_F
        MH_OP_RESIZE_FWD, MH_OP_RESIZE_BWD, MH_OP_PAD_REFLECT, MH_OP_LOSS, MH_OP_METRICS,
        MH_OP_MOMENTUM, MH_OP_COPY_CH, MH_OP_LEAKY_BWD, MH_OP_FILL, MH_OP_BIAS_GRAD,
        MH_OP_WGRAD_PARTIAL, MH_OP_WGRAD_REDUCE, MH_OP_PROXY_LOSS, MH_OP_SUPERVISED_LOSS, MH_OP_ADAM, MH_OP_ADAM_ADVANCE,
-       MH_OP_RESIZE_IMAGE, MH_OP_LEVEL_FRONT, MH_OP_RESERVED_25 /* (was: transposed filter banks of the retired LDS-free kernel) */, MH_OP_PACK_W, MH_OP_CORR_WARP_BWD, MH_OP_SHADOW_CAST, MH_OP_WGRAD_STREAM, MH_OP_HEAD_BWD, MH_OP_HEAD_FWD };
+       MH_OP_RESIZE_IMAGE, MH_OP_LEVEL_FRONT, MH_OP_RESERVED_25 /* (was: transposed filter banks of the retired LDS-free kernel) */, MH_OP_PACK_W, MH_OP_CORR_WARP_BWD, MH_OP_SHADOW_CAST, MH_OP_WGRAD_STREAM, MH_OP_HEAD_BWD, MH_OP_HEAD_FWD, MH_OP_CONV_PLANES, MH_OP_PLANE_SPLIT };
 /* i[26] of every op is its scheduling word: low byte = lane (0 = the caller's stream; 1..MH_MAX_LANES-1 = side
  * streams owned by the library: the op is forked from lane 0 right before it, i.e. ordered after everything recorded so
  * far, and runs concurrently with the lane-0 ops that follow); MH_OP_JOIN = lane 0 first waits for all side lanes.

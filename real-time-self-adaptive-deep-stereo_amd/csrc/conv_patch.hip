@@ -913,9 +913,28 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const mh_pack_seg* __
         if (segs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const mh_pack_seg sg = segs[lo];
-    const int cpt = (sg.K + 31) >> 5, np16 = (sg.N + 15) >> 4;
     const int e = ((int)blockIdx.x - sg.blk0) * 256 + (int)threadIdx.x;
     const int lane = e & 63, qt = e >> 6;
+    if (sg.trans == 2) {
+        // the 32x32x16 register image of conv_planes_kernel (forward, hi + lo): bank[(tap * K16 + s)][32-column tile][plane][lane][8 bf16], lane l
+        // holding w[tap][16 s + 8 (l >> 5) .. + 7][32 tile + (l & 31)]
+        const int k16 = (sg.K + 15) >> 4, nt32 = (sg.N + 31) >> 5;
+        if (qt >= sg.taps * k16 * nt32) return;
+        const int nt = qt % nt32, q = qt / nt32;
+        const int st = q % k16, tap = q / k16;
+        const int k0 = st * 16 + (lane >> 5) * 8, n = nt * 32 + (lane & 31);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (k0 + j < sg.K && n < sg.N) ? sg.src[((int64_t)tap * sg.K + k0 + j) * sg.N + n] : 0.f;
+        unsigned hh[4], ll[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mh_split_bf16x2(v[2 * j], v[2 * j + 1], hh[j], ll[j]);
+        u32x4* dst = reinterpret_cast<u32x4*>(sg.dst) + (int64_t)qt * 128 + lane;
+        dst[0] = (u32x4){hh[0], hh[1], hh[2], hh[3]};
+        dst[64] = (u32x4){ll[0], ll[1], ll[2], ll[3]};
+        return;
+    }
+    const int cpt = (sg.K + 31) >> 5, np16 = (sg.N + 15) >> 4;
     if (qt >= sg.taps * cpt * np16) return;
     const int nt = qt % np16, q = qt / np16;
     const int c = q % cpt, tap = q / cpt;

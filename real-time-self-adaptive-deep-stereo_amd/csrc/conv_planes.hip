@@ -1,0 +1,362 @@
+// conv_planes.hip -- split-bf16 ("bf16x3") forward pass of the stride-1 "SAME" 3x3 (dilated) layers from PRE-SPLIT operands (round 4).
+// What is computed: tf.nn.conv2d / atrous_conv2d + bias_add + leaky (Nets/sharedLayers.py:54-77) for the estimator / context / pyramid layers
+// of Nets/MadNet.py:73-171,173-249 -- the same three-MFMA products (lo*hi + hi*lo + hi*hi, fp32 accumulate) as conv_bank_kernel<..., X3>.
+//
+// Why a new kernel (profiles/r03_pmc_roofline.json): conv_bank_kernel stages fp32 activations through VGPRs and splits them
+// into hi / lo bf16 in EVERY consumer workgroup (6.7 M VALU for 1.7 M MFMAs), feeds each 32x32 wave tile from 1 KB bank fragments that serve only
+// 4 MFMAs (the K walk runs at the L2 -> L1 rate of the fragment loads, ~45 B/clk/CU) and writes fp32 + a bf16 shadow.  Here
+//   * an activation lives in HBM as TWO bf16 NHWC planes, hi = bf16(x) and lo = bf16(x - hi) (pixel stride = channels rounded up to 32, padding
+//     zero): the hi plane IS the shadow the streamed filter gradient and the input gradients already read; the producer's epilogue splits each
+//     element once, the consumer never converts;
+//   * the patch (tile + one-lattice-pixel halo, both planes) goes global -> LDS by LDS DMA (buffer_load_dwordx4 ... lds): no VGPR round trip, no
+//     VALU, no ds_write; the LDS image is [patch row][patch column][2*K16 + 1 chunks of 16 B] -- the odd chunk count (one pad chunk per pixel, written
+//     as zeros by out-of-range lanes) makes every ds_read_b128 lane group of the v_mfma_f32_32x32x16_bf16 A operand hit 16 distinct bank quads;
+//   * a wave owns MBW stacked 32-pixel M-blocks x 32 output columns (v_mfma_f32_32x32x16_bf16, 16 accumulator registers per block): one 1 KB bank
+//     fragment per plane feeds 3 * MBW MFMAs of 32 cycles -- at MBW = 4 the fragment stream is ~21 B/clk/CU;
+//   * the weights come from a fragment bank in the 32x32x16 register image (mh_pack_weights, trans = 2) straight into registers, three steps ahead;
+//     the K walk (9 taps x K16 steps of 16 channels) is fully unrolled: no barrier, no address arithmetic (every LDS offset is an immediate);
+//   * the epilogue transposes the tile through LDS and stores 16 bytes per lane: hi plane, lo plane and (only where a non-plane consumer exists) fp32.
+#include "conv_args.h"
+#include <stdlib.h>
+#include <atomic>
+
+namespace {
+
+struct PlanesArgs {
+    const unsigned short* in_hi; const unsigned short* in_lo;     // bf16 planes [B][H][W][in_pld]
+    const void* wb;                                               // fragment bank, 32x32x16 image: [(tap * K16 + s)][32-column tile][plane][lane][8 bf16]
+    const float* bias;
+    float* out; unsigned short* out_hi; unsigned short* out_lo;   // any of them may be null
+    unsigned in_bytes, wb_bytes, out_bytes, outp_bytes;
+    int in_pld, out_ld, out_pld;
+    int B, H, W, K, N, dil;
+    float alpha;
+    int tiles_y, tiles_x, ntiles_n, nwg;
+    int dbg;                                                      // timing experiments: 1 = skip the K walk, 2 = skip the staging
+};
+
+// MC: columns of a 32-pixel M-block (32: one row of 32 lattice pixels; 16: two rows of 16).  WM x WN waves; a wave owns MBW M-blocks x 32 columns.
+// K16: 16-channel steps per tap (K rounded up to 16).
+template <int MC, int WM, int WN, int MBW, int K16>
+struct PlanesGeo {
+    static constexpr int MR = 32 / MC;                 // rows of an M-block
+    static constexpr int NW = WM * WN, NTH = NW * 64;
+    static constexpr int TR = WM * MBW * MR;           // tile rows (lattice)
+    static constexpr int BM = WM * MBW * 32, BN = WN * 32;
+    static constexpr int PR = TR + 2, PC = MC + 2;     // patch rows / columns
+    static constexpr int NCK = 2 * K16;                // data chunks (16 B = 8 channels) per patch pixel and plane
+    static constexpr int NCK1 = NCK + 1;               // + one pad chunk: odd => conflict-free ds_read_b128 groups
+    // two-row M-blocks: the second row must start a multiple of 16 chunks after the first (its 8 lanes of a 16-lane read group take the bank quads the
+    // first row's 8 lanes leave free)
+    static constexpr int ROWP = MR == 1 ? PC * NCK1 : ((PC * NCK1 + 15) / 16) * 16;
+    static constexpr int PLANE_BLKS = (PR * ROWP * 16 + 1023) / 1024;
+    static constexpr int PLANE_BYTES = PLANE_BLKS * 1024;
+    static constexpr int CS = BN + 4;
+    static constexpr int LDS_TILES = 2 * PLANE_BYTES, LDS_CS = BM * CS * 4;
+    static constexpr int LDS = LDS_TILES > LDS_CS ? LDS_TILES : LDS_CS;
+};
+
+template <int MC, int WM, int WN, int MBW, int K16>
+__global__ __launch_bounds__(WM * WN * 64) void conv_planes_kernel(PlanesArgs p) {
+    using G = PlanesGeo<MC, WM, WN, MBW, K16>;
+    constexpr int MR = G::MR, NW = G::NW, NTH = G::NTH, TR = G::TR, BM = G::BM, BN = G::BN, PR = G::PR, PC = G::PC;
+    constexpr int NCK = G::NCK, NCK1 = G::NCK1, ROWP = G::ROWP, PLANE_BLKS = G::PLANE_BLKS, PLANE_BYTES = G::PLANE_BYTES, CS = G::CS;
+    HIP_DYNAMIC_SHARED(float, smem_all)
+    unsigned char* const smem = reinterpret_cast<unsigned char*>(smem_all);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int d = p.dil;
+
+    int lin = mh_xcd_remap(blockIdx.x, p.nwg);
+    const int tile_n = lin % p.ntiles_n; lin /= p.ntiles_n;
+    const int ttx = lin % p.tiles_x; lin /= p.tiles_x;
+    const int tty = lin % p.tiles_y; lin /= p.tiles_y;
+    const int cx = lin % d; lin /= d;
+    const int cy = lin % d;
+    const int b = lin / d;
+    const int n0 = tile_n * BN;
+    const int y00 = cy + d * (tty * TR), x00 = cx + d * (ttx * MC);       // image position of tile pixel (0, 0)
+
+    // ---- weight fragments: ring of NSTB steps, PF steps ahead (ordinary loads: hipcc counts them) -----------------------------------
+    constexpr int T = 9 * K16, NSTB = 4, PF = 3;
+    const __amdgpu_buffer_rsrc_t rs_b = mh_make_rsrc(p.wb, p.wb_bytes);
+    const int nt32 = (p.N + 31) >> 5;
+    const int nt = tile_n * WN + wn;
+    const int voff_b = nt < nt32 ? nt * 2048 + lane * 16 : MH_OOB;
+    const int step_b = nt32 * 2048;
+    u32x4 fb[NSTB][2];
+    auto issue_b = [&](int t, int slot) {
+        if (t < T) {
+            fb[slot][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff_b, t * step_b, 0);
+            fb[slot][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff_b, t * step_b + 1024, 0);
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < PF; ++t) issue_b(t, t % NSTB);
+
+    // ---- stage the patch: LDS DMA, both planes; chunk g of a plane <- (patch row, patch column, channel chunk) ------------------------------
+    if (!(p.dbg & 2)) {
+        const mh_dma_src rs_h = mh_make_dma_src(p.in_hi, p.in_bytes), rs_l = mh_make_dma_src(p.in_lo, p.in_bytes);
+        const int pix_b = p.in_pld * 2;
+        for (int i = wave; i < PLANE_BLKS; i += NW) {
+            const int g = i * 64 + lane;
+            const int pr = g / ROWP, rem = g - pr * ROWP;
+            const int pc = rem / NCK1, c = rem - pc * NCK1;
+            const int iy = y00 + (pr - 1) * d, ix = x00 + (pc - 1) * d;
+            const bool ok = pr < PR && pc < PC && c < NCK && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const int off = ok ? ((b * p.H + iy) * p.W + ix) * pix_b + c * 16 : MH_OOB;
+            mh_glds16(rs_h, smem + i * 1024, off);
+            mh_glds16(rs_l, smem + PLANE_BYTES + i * 1024, off);
+        }
+    }
+    MH_WAIT_VMCNT(0);
+    __syncthreads();
+
+    f32x16 acc[MBW];
+#pragma unroll
+    for (int mb = 0; mb < MBW; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+
+    // ---- K walk: step t = (tap t / K16, channels 16 (t % K16) .. +15); A fragments one step ahead (two register sets) ---------------------
+    {
+        const int j = lane & 31, kg = lane >> 5;
+        const int lr = MR == 1 ? 0 : (j >> 4), lc = MR == 1 ? j : (j & 15);
+        const unsigned char* const a_h = smem + (((wm * MBW * MR + lr) * ROWP + lc * NCK1 + kg) * 16);
+        const unsigned char* const a_l = a_h + PLANE_BYTES;
+        u32x4 fa[2][MBW][2];
+        auto issue_a = [&](int t, int set) {
+            if (t < T) {
+                const int tap = t / K16, s = t - tap * K16;
+                const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+                for (int mb = 0; mb < MBW; ++mb) {
+                    const int imm = (((mb * MR + ky) * ROWP + kx * NCK1 + 2 * s) * 16);
+                    fa[set][mb][0] = *reinterpret_cast<const u32x4*>(a_h + imm);
+                    fa[set][mb][1] = *reinterpret_cast<const u32x4*>(a_l + imm);
+                }
+            }
+        };
+        issue_a(0, 0);
+        if (!(p.dbg & 1)) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int sa = t & 1, sb = t % NSTB;
+                // lo(A)*hi(B), hi(A)*lo(B), hi(A)*hi(B) -- term outermost: consecutive MFMAs hit different accumulators
+#pragma unroll
+                for (int term = 0; term < 3; ++term) {
+#pragma unroll
+                    for (int mb = 0; mb < MBW; ++mb) {
+                        acc[mb] = mh_mfma_bf16_32(fa[sa][mb][term == 0 ? 1 : 0], fb[sb][term == 1 ? 1 : 0], acc[mb]);
+                        if (term == 0 && mb == 0) issue_a(t + 1, sa ^ 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                issue_b(t + PF, (t + PF) % NSTB);          // slot of step t - 1: free
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    __syncthreads();                                 // every wave is done with the patch: the accumulator tile goes over it
+
+    // ---- epilogue: accumulators -> LDS [pixel][column], then 8 consecutive columns per lane: bias, leaky, split, 16-byte stores ----------------
+    float* const Cs = smem_all;
+    {
+        const int col = wn * 32 + (lane & 31);
+#pragma unroll
+        for (int mb = 0; mb < MBW; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Cs[((wm * MBW + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CS + col] = acc[mb][r];
+    }
+    __syncthreads();
+    constexpr int C8 = BN / 8;
+    static_assert(NTH % C8 == 0, "a thread keeps its 8-column group");
+    constexpr int RP = NTH / C8;
+    const int c8 = tid % C8;
+    const int n = n0 + c8 * 8;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = (p.bias && n + e < p.N) ? p.bias[n + e] : 0.f;
+    const __amdgpu_buffer_rsrc_t rs_o = mh_make_rsrc(p.out ? p.out : (float*)p.out_hi, p.out ? p.out_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_oh = mh_make_rsrc(p.out_hi ? p.out_hi : (unsigned short*)p.out, p.out_hi ? p.outp_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_ol = mh_make_rsrc(p.out_lo ? p.out_lo : (unsigned short*)p.out, p.out_lo ? p.outp_bytes : 0u);
+#pragma unroll 2
+    for (int m = tid / C8; m < BM; m += RP) {
+        const int blk = m >> 5, w = m & 31;
+        const int row = MR == 1 ? blk : blk * 2 + (w >> 4), colp = MR == 1 ? w : (w & 15);
+        const int y = y00 + row * d, x = x00 + colp * d;
+        const bool ok = y < p.H && x < p.W && n < p.N;
+        const int pix = (b * p.H + y) * p.W + x;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(&Cs[m * CS + c8 * 8]), v1 = *reinterpret_cast<const f32x4*>(&Cs[m * CS + c8 * 8 + 4]);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[e] += bv[e];
+            if (p.alpha != 1.0f) v[e] = v[e] > 0.f ? v[e] : p.alpha * v[e];
+        }
+        unsigned hh[4], ll[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mh_split_bf16x2(v[2 * e], v[2 * e + 1], hh[e], ll[e]);
+        const int op = ok ? (pix * p.out_pld + n) * 2 : MH_OOB;
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4){hh[0], hh[1], hh[2], hh[3]}, rs_oh, op, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4){ll[0], ll[1], ll[2], ll[3]}, rs_ol, op, 0, 0);
+        const int of = ok ? (pix * p.out_ld + n) * 4 : MH_OOB;
+        mh_buf_store4(rs_o, of, make_float4(v[0], v[1], v[2], v[3]));
+        mh_buf_store4(rs_o, of == MH_OOB ? MH_OOB : of + 16, make_float4(v[4], v[5], v[6], v[7]));
+    }
+}
+
+// fp32 NHWC -> the two bf16 planes (the operands of conv_planes_kernel): tensors no plane-writing kernel produces (cost-volume buffers, exact-fp32
+// layers' outputs).  lo may be null (then exactly mh_shadow_cast).
+__global__ __launch_bounds__(256) void plane_split_kernel(const mh_plane_seg* __restrict__ segs, int nseg) {
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (segs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const mh_plane_seg sg = segs[lo];
+    const int g8 = sg.dst_ld >> 3;
+    const int64_t item = (int64_t)((int)blockIdx.x - sg.blk0) * 256 + threadIdx.x;
+    if (item >= sg.npix * g8) return;
+    const int64_t pix = item / g8;
+    const int c0 = (int)(item - pix * g8) * 8;
+    const float* s = sg.src + pix * sg.src_ld + c0;
+    float v[8];
+    if (c0 + 8 <= sg.C && (sg.src_ld & 3) == 0 && ((uintptr_t)sg.src & 15) == 0) {
+        const float4 a = *reinterpret_cast<const float4*>(s), bq = *reinterpret_cast<const float4*>(s + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = bq.x; v[5] = bq.y; v[6] = bq.z; v[7] = bq.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (c0 + e < sg.C) ? s[e] : 0.f;
+    }
+    unsigned hh[4], ll[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mh_split_bf16x2(v[2 * e], v[2 * e + 1], hh[e], ll[e]);
+    *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(sg.hi) + pix * sg.dst_ld + c0) = (u32x4){hh[0], hh[1], hh[2], hh[3]};
+    if (sg.lo) *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(sg.lo) + pix * sg.dst_ld + c0) = (u32x4){ll[0], ll[1], ll[2], ll[3]};
+}
+
+std::atomic<int> g_planes_mode{0};       // mh_tune_conv_planes: bits 0-3 tile variant (0 = heuristic), bit 8 = skip the K walk, bit 9 = skip the staging (timing experiments)
+std::atomic<int> g_planes_launches{0};
+
+template <int MC, int WM, int WN, int MBW, int K16>
+int launch_planes(PlanesArgs& a, hipStream_t s, bool attr_only) {
+    using G = PlanesGeo<MC, WM, WN, MBW, K16>;
+    static_assert(G::LDS <= 160 * 1024, "patch planes exceed the LDS");
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_planes_kernel<MC, WM, WN, MBW, K16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { mh_set_error("conv_planes: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_done = true;
+    }
+    if (attr_only) return 0;
+    const int d = a.dil;
+    a.tiles_y = mh_cdiv(mh_cdiv(a.H, d), G::TR);
+    a.tiles_x = mh_cdiv(mh_cdiv(a.W, d), MC);
+    a.ntiles_n = mh_cdiv(a.N, G::BN);
+    a.nwg = a.B * d * d * a.tiles_y * a.tiles_x * a.ntiles_n;
+    a.dbg = (g_planes_mode.load(std::memory_order_relaxed) >> 8) & 3;
+    ++g_planes_launches;
+    mh_note_kernel("conv_planes_kernel<MC=%d,%dx%d waves,MBW=%d,K16=%d> tile %dx%d K=%d dil=%d grid %d lds %d", MC, WM, WN, MBW, K16, G::BM, G::BN, a.K, a.dil, a.nwg, G::LDS);
+    hipLaunchKernelGGL((conv_planes_kernel<MC, WM, WN, MBW, K16>), dim3(a.nwg), dim3(G::NTH), G::LDS, s, a);
+    return mh_check_launch("conv_planes");
+}
+
+// tile variants per (N, K16); v = the tuning hook's variant (0 = heuristic)
+template <int K16>
+int dispatch_planes_k(PlanesArgs& a, hipStream_t s, int v, bool all) {
+    int rc = 0;
+    const int n32 = all ? 0 : mh_cdiv(a.N, 32);
+    // 128 columns: 4 waves side by side; 128-pixel tile (one workgroup per CU) or 64-pixel tile (two)
+    if (all || (n32 == 4 && (v == 0 || v == 1))) { rc = launch_planes<32, 1, 4, 4, K16>(a, s, all); if (!all || rc) return rc; }
+    if (all || (n32 == 4 && v == 2)) { rc = launch_planes<32, 1, 4, 2, K16>(a, s, all); if (!all || rc) return rc; }
+    if (all || (n32 == 4 && v == 3)) { rc = launch_planes<16, 1, 4, 4, K16>(a, s, all); if (!all || rc) return rc; }
+    if (all || (n32 == 4 && v == 4)) { rc = launch_planes<16, 1, 4, 2, K16>(a, s, all); if (!all || rc) return rc; }
+    if (all || (n32 == 3 && (v == 0 || v == 1))) { rc = launch_planes<32, 2, 3, 2, K16>(a, s, all); if (!all || rc) return rc; }
+    if (all || (n32 == 3 && v >= 2)) { rc = launch_planes<16, 2, 3, 2, K16>(a, s, all); if (!all || rc) return rc; }
+    if (all || (n32 == 2 && (v == 0 || v == 1))) { rc = launch_planes<32, 2, 2, 2, K16>(a, s, all); if (!all || rc) return rc; }
+    if (all || (n32 == 2 && v >= 2)) { rc = launch_planes<16, 2, 2, 2, K16>(a, s, all); if (!all || rc) return rc; }
+    if (all || (n32 == 1 && (v == 0 || v == 1))) { rc = launch_planes<32, 4, 1, 1, K16>(a, s, all); if (!all || rc) return rc; }
+    if (all || (n32 == 1 && v >= 2)) { rc = launch_planes<16, 4, 1, 1, K16>(a, s, all); if (!all || rc) return rc; }
+    if (all) return 0;
+    mh_set_error("mh_conv2d_planes: no tile variant for N = %d", a.N);
+    return MH_ERR_UNSUPPORTED;
+}
+
+int dispatch_planes(PlanesArgs& a, hipStream_t s, bool all) {
+    const int v = g_planes_mode.load(std::memory_order_relaxed) & 15;
+    const int k16 = all ? 0 : mh_cdiv(a.K, 16);
+    int rc = 0;
+    if (all || k16 == 8) { rc = dispatch_planes_k<8>(a, s, v, all); if (!all || rc) return rc; }
+    if (all || k16 == 6) { rc = dispatch_planes_k<6>(a, s, v, all); if (!all || rc) return rc; }
+    if (all || k16 == 4) { rc = dispatch_planes_k<4>(a, s, v, all); if (!all || rc) return rc; }
+    if (all || k16 == 2) { rc = dispatch_planes_k<2>(a, s, v, all); if (!all || rc) return rc; }
+    if (all || k16 == 3) { rc = dispatch_planes_k<3>(a, s, v, all); if (!all || rc) return rc; }
+    if (all || k16 == 5) { rc = dispatch_planes_k<5>(a, s, v, all); if (!all || rc) return rc; }
+    if (all) return 0;
+    mh_set_error("mh_conv2d_planes: no instance for K = %d (16-channel steps per tap: 2, 3, 4, 5, 6, 8)", a.K);
+    return MH_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+int mh_conv_planes_init() {
+    PlanesArgs a = {};
+    return dispatch_planes(a, nullptr, true);
+}
+
+extern "C" int mh_tune_conv_planes(int mode) {
+    g_planes_mode = mode < 0 ? 0 : mode;
+    return g_planes_launches.exchange(0);
+}
+
+extern "C" int64_t mh_pack32_bytes(int32_t taps, int32_t K, int32_t N) {
+    return (int64_t)taps * ((K + 15) / 16) * ((N + 31) / 32) * 2048;
+}
+
+extern "C" int mh_plane_split(const mh_plane_seg* segs_device, int32_t nseg, int32_t nblocks, void* stream) {
+    MH_REQUIRE(segs_device && nseg > 0 && nblocks > 0, MH_ERR_ARG, "mh_plane_split: empty segment table");
+    hipLaunchKernelGGL(plane_split_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, segs_device, nseg);
+    return mh_check_launch("plane_split");
+}
+
+extern "C" int mh_conv2d_planes_ok(const mh_conv_desc* d) {
+    if (!d) return 0;
+    if (!(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->mode == 0 && d->pad_t == d->dil && d->pad_l == d->dil && d->Hi == d->Ho && d->Wi == d->Wo)) return 0;
+    if (d->accumulate || d->dil < 1 || d->dil > 64 || d->N < 1 || d->N > 128 || (d->N & 7)) return 0;
+    const int k16 = (d->K + 15) / 16;
+    return (k16 >= 2 && k16 <= 6) || k16 == 8;
+}
+
+extern "C" int mh_conv2d_planes(const mh_conv_desc* d, const void* in_hi, const void* in_lo, int32_t in_pld, const void* wb32, const float* bias,
+                                float* out, void* out_hi, void* out_lo, int32_t out_pld, void* stream) {
+    MH_REQUIRE(d && in_hi && in_lo && wb32, MH_ERR_ARG, "mh_conv2d_planes: null descriptor / input planes / fragment bank");
+    MH_REQUIRE(out || out_hi || out_lo, MH_ERR_ARG, "mh_conv2d_planes: no output");
+    MH_REQUIRE(mh_conv2d_planes_ok(d), MH_ERR_UNSUPPORTED,
+               "mh_conv2d_planes: forward stride-1 'SAME' 3x3 layers, N <= 128 (multiple of 8), K in 17..96 or 113..128, no accumulation");
+    MH_REQUIRE(d->B > 0 && d->Hi > 0 && d->Wi > 0, MH_ERR_ARG, "mh_conv2d_planes: non-positive size");
+    const int k16 = (d->K + 15) / 16;
+    MH_REQUIRE(in_pld >= k16 * 16 && (in_pld & 7) == 0, MH_ERR_ARG, "mh_conv2d_planes: in_pld must cover K rounded up to 16 (multiple of 8)");
+    MH_REQUIRE(mh_aligned16(in_hi) && mh_aligned16(in_lo) && mh_aligned16(wb32), MH_ERR_ALIGN, "mh_conv2d_planes: 16-byte aligned planes / bank");
+    if (out) MH_REQUIRE(d->out_ld >= d->N && (d->out_ld & 3) == 0 && mh_aligned16(out), MH_ERR_ALIGN, "mh_conv2d_planes: out rows must be 16-byte aligned");
+    if (out_hi || out_lo) {
+        MH_REQUIRE(out_pld >= d->N && (out_pld & 7) == 0, MH_ERR_ARG, "mh_conv2d_planes: out_pld must cover N (multiple of 8)");
+        MH_REQUIRE(mh_aligned16(out_hi) && mh_aligned16(out_lo), MH_ERR_ALIGN, "mh_conv2d_planes: 16-byte aligned output planes");
+    }
+    const int64_t npix = (int64_t)d->B * d->Hi * d->Wi;
+    MH_REQUIRE(npix * in_pld * 2 < (1ll << 31) && npix * d->out_ld * 4 < (1ll << 31) && npix * (int64_t)out_pld * 2 < (1ll << 31), MH_ERR_UNSUPPORTED,
+               "mh_conv2d_planes: tensors must be < 2 GiB");
+    PlanesArgs a = {};
+    a.in_hi = (const unsigned short*)in_hi; a.in_lo = (const unsigned short*)in_lo; a.wb = wb32; a.bias = bias;
+    a.out = out; a.out_hi = (unsigned short*)out_hi; a.out_lo = (unsigned short*)out_lo;
+    a.in_bytes = (unsigned)(npix * in_pld * 2);
+    a.wb_bytes = (unsigned)mh_pack32_bytes(9, d->K, d->N);
+    a.out_bytes = out ? (unsigned)(npix * d->out_ld * 4) : 0u;
+    a.outp_bytes = (unsigned)(npix * out_pld * 2);
+    a.in_pld = in_pld; a.out_ld = d->out_ld; a.out_pld = out_pld;
+    a.B = d->B; a.H = d->Hi; a.W = d->Wi; a.K = d->K; a.N = d->N; a.dil = d->dil;
+    a.alpha = d->alpha;
+    return dispatch_planes(a, (hipStream_t)stream, false);
+}

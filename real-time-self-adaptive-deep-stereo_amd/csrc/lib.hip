@@ -37,6 +37,7 @@ int mh_check_launch(const char* what) {
 int mh_conv_init();
 int mh_wgrad_init();
 int mh_wgrad_stream_init();
+int mh_conv_planes_init();
 int mh_corr_init();
 static int mh_lanes_init();
 
@@ -46,6 +47,7 @@ extern "C" int mh_init(void) {
     if (int e = mh_conv_init()) return e;
     if (int e = mh_wgrad_init()) return e;
     if (int e = mh_wgrad_stream_init()) return e;
+    if (int e = mh_conv_planes_init()) return e;
     if (int e = mh_corr_init()) return e;
     return mh_lanes_init();          // side streams / events of the plan executor (not creatable inside a capture)
 }
@@ -151,6 +153,12 @@ static int run_op(const mh_op& o, void* s) {
             d.mul = o.f[0]; d.mask_alpha = o.f[1];
             return mh_head_bwd(&d, (const float*)p[0], (const float*)p[1], (float*)p[2], p[3], (const float*)p[4], (float*)p[5], (const float*)p[6], p[7], s);
         }
+        case MH_OP_CONV_PLANES: {  // i = mh_conv_desc ints as CONV, i[23] = in_pld, i[24] = out_pld ; p: in_hi in_lo bank bias out out_hi out_lo
+            mh_conv_desc d; desc_from_op(o, d);
+            return mh_conv2d_planes(&d, p[0], p[1], i[23], p[2], (const float*)p[3], (float*)p[4], p[5], p[6], i[24], s);
+        }
+        case MH_OP_PLANE_SPLIT:
+            return mh_plane_split((const mh_plane_seg*)p[0], i[0], i[1], s);
         case MH_OP_PACK_W:
             return mh_pack_weights((const mh_pack_seg*)p[0], i[0], i[1], s);
         case MH_OP_WGRAD_REDUCE:

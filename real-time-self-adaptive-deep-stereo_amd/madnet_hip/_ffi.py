@@ -1,4 +1,4 @@
-"""ctypes binding of libmadnet_hip.so (C-ABI declared in include/madnet_hip.h).
+"""ctypes binding of libmadnet_hip.so (C-ABI declared in include/madnet_hip.h; tuning hooks in include/madnet_hip_tune.h).
 
 The reference binds its native op with tf.load_op_library (Nets/sharedLayers.py:11-17);
 cffi is not available here, stdlib ctypes is.  PyTorch tensors are storage only: every call
@@ -31,7 +31,7 @@ class Op(C.Structure):
 (OP_CONV, OP_WGRAD, OP_CORR_FWD, OP_CORR_BWD, OP_WARP_FWD, OP_WARP_BWD, OP_RESIZE_FWD, OP_RESIZE_BWD,
  OP_PAD_REFLECT, OP_LOSS, OP_METRICS, OP_MOMENTUM, OP_COPY_CH, OP_LEAKY_BWD, OP_FILL, OP_BIAS_GRAD,
  OP_WGRAD_PARTIAL, OP_WGRAD_REDUCE, OP_PROXY_LOSS, OP_SUPERVISED_LOSS, OP_ADAM, OP_ADAM_ADVANCE, OP_RESIZE_IMAGE, OP_LEVEL_FRONT, OP_RESERVED_25, OP_PACK_W, OP_CORR_WARP_BWD,
- OP_SHADOW_CAST, OP_WGRAD_STREAM, OP_HEAD_BWD, OP_HEAD_FWD) = range(1, 32)
+ OP_SHADOW_CAST, OP_WGRAD_STREAM, OP_HEAD_BWD, OP_HEAD_FWD, OP_CONV_PLANES, OP_PLANE_SPLIT) = range(1, 34)
 
 
 OP_JOIN = 0x100
@@ -54,6 +54,11 @@ class WgradItem(C.Structure):        # mh_wgrad_item
 
 class ShadowSeg(C.Structure):        # mh_shadow_seg
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("npix", C.c_int64), ("C", C.c_int32), ("src_ld", C.c_int32),
+                ("dst_ld", C.c_int32), ("blk0", C.c_int32)]
+
+
+class PlaneSeg(C.Structure):         # mh_plane_seg
+    _fields_ = [("src", C.c_void_p), ("hi", C.c_void_p), ("lo", C.c_void_p), ("npix", C.c_int64), ("C", C.c_int32), ("src_ld", C.c_int32),
                 ("dst_ld", C.c_int32), ("blk0", C.c_int32)]
 
 
@@ -97,6 +102,11 @@ SIGNATURES = {
     "mh_conv2d_sh": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "mh_pack_weights": (_I, [_P, _I, _I, _P]),
     "mh_pack_bytes": (_L, [_I, _I, _I, _I]),
+    "mh_pack32_bytes": (_L, [_I, _I, _I]),
+    "mh_conv2d_planes_ok": (_I, [C.POINTER(ConvDesc)]),
+    "mh_conv2d_planes": (_I, [C.POINTER(ConvDesc), _P, _P, _I, _P, _P, _P, _P, _P, _I, _P]),
+    "mh_plane_split": (_I, [_P, _I, _I, _P]),
+    "mh_tune_conv_planes": (_I, [_I]),
     "mh_tune_conv_bank": (_I, [_I]),
     "mh_tune_wgrad_image": (_I, [_I]),
     "mh_tune_conv_bank_tile": (_I, [_I]),
@@ -158,7 +168,7 @@ SIGNATURES = {
     "mh_event_destroy": (_I, [_P]),
     "mh_stream_sync": (_I, [_P]),
 }
-_NO_STATUS = {"mh_tune_wgrad_target_pct", "mh_tune_wgrad_image", "mh_conv2d_takes_shadows", "mh_tune_conv_bank_tile", "mh_tune_conv_rows", "mh_last_error", "mh_last_kernel", "mh_tune_conv_bank", "mh_pack_bytes", "mh_abi_version", "mh_tune_conv_patch", "mh_crc32c", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats", "mh_proxy_ws_floats"}
+_NO_STATUS = {"mh_pack32_bytes", "mh_conv2d_planes_ok", "mh_tune_conv_planes", "mh_tune_wgrad_target_pct", "mh_tune_wgrad_image", "mh_conv2d_takes_shadows", "mh_tune_conv_bank_tile", "mh_tune_conv_rows", "mh_last_error", "mh_last_kernel", "mh_tune_conv_bank", "mh_pack_bytes", "mh_abi_version", "mh_tune_conv_patch", "mh_crc32c", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats", "mh_proxy_ws_floats"}
 
 
 class MadnetHipError(RuntimeError):

@@ -130,6 +130,8 @@ def conv2d_fwd(lib, x, w, b, out, stride=1, dil=1, alpha=1.0, accumulate=False, 
 
 def pack_bytes(w, planes=2, trans=0):
     kh, kw, K, N = w.shape
+    if trans == 2:          # the 32x32x16 register image of conv2d_planes (hi + lo)
+        return kh * kw * ((K + 15) // 16) * ((N + 31) // 32) * 2048
     if trans:
         K, N = N, K
     return kh * kw * ((K + 31) // 32) * ((N + 15) // 16) * planes * 1024
@@ -148,12 +150,16 @@ def pack_weights(lib, pairs, device, keep, stream=None):
         planes = pr[2] if len(pr) > 2 else 2
         trans = pr[3] if len(pr) > 3 else 0
         kh, kw, K, N = src.shape
-        if trans:
+        if trans == 1:
             K, N = N, K
         assert dst.numel() * dst.element_size() >= pack_bytes(src, planes, trans) and dst.data_ptr() % 16 == 0
+        assert trans != 2 or planes == 2
         arr[i].src, arr[i].dst, arr[i].taps, arr[i].K, arr[i].N = src.data_ptr(), dst.data_ptr(), kh * kw, K, N
         arr[i].planes, arr[i].blk0, arr[i].trans = planes, blk, trans
-        blk += (kh * kw * ((K + 31) // 32) * ((N + 15) // 16) * 64 + 255) // 256
+        if trans == 2:
+            blk += (kh * kw * ((K + 15) // 16) * ((N + 31) // 32) * 64 + 255) // 256
+        else:
+            blk += (kh * kw * ((K + 31) // 32) * ((N + 15) // 16) * 64 + 255) // 256
     table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
     keep.append(table)
     lib.pack_weights(C.c_void_p(table.data_ptr()), len(pairs), blk, _p(stream))
@@ -284,6 +290,67 @@ class Shadow(object):
     @property
     def ptr(self):
         return self.t.data_ptr()
+
+
+class Planes(object):
+    """An activation as TWO bf16 NHWC planes, hi = bf16(x) and lo = bf16(x - hi) ([B,H,W,shadow_ld(C)], pad = 0): the operand format of
+    conv2d_planes (csrc/conv_planes.hip).  `hi` is an ordinary Shadow -- the one the streamed filter gradient and the input gradients read."""
+    __slots__ = ("hi", "lo")
+
+    def __init__(self, hi, device):
+        self.hi = hi
+        self.lo = Shadow(hi.B, hi.H, hi.W, hi.C, device)
+
+    B = property(lambda self: self.hi.B)
+    H = property(lambda self: self.hi.H)
+    W = property(lambda self: self.hi.W)
+    C = property(lambda self: self.hi.C)
+    ld = property(lambda self: self.hi.ld)
+
+
+def conv2d_planes_ok(qlib, x, w, dil=1):
+    """does conv2d_planes have an instance for this stride-1 'SAME' 3x3 layer?  (qlib = the real library)"""
+    kh, kw, cin, cout = w.shape
+    if (kh, kw) != (3, 3):
+        return False
+    d = conv_desc(x.B, x.H, x.W, x.H, x.W, cin, cout, 3, 3, 1, dil, dil, dil, 0, 0, 0, 0, precision=2)
+    return qlib.conv2d_planes_ok(C.byref(d)) == 1
+
+
+def conv2d_planes(lib, xp, w, wb32, b, out=None, out_planes=None, dil=1, alpha=1.0, stream=None):
+    """leaky(conv2d_SAME(x, w) + b) in split-bf16 from the input's planes `xp` (Planes); results: `out` (fp32 View or None) and / or
+    `out_planes` (Planes, or a bare Shadow = hi plane only).  wb32: pack_weights(trans = 2) bank of w."""
+    kh, kw, cin, cout = w.shape
+    assert (kh, kw) == (3, 3) and xp.C == cin
+    d = conv_desc(xp.B, xp.H, xp.W, xp.H, xp.W, cin, cout, 3, 3, 1, dil, dil, dil, 0, 0, 0, (out.ld if out is not None else 0), alpha=alpha, precision=2)
+    ohi = olo = None
+    opld = 0
+    if out_planes is not None:
+        hi = out_planes.hi if isinstance(out_planes, Planes) else out_planes
+        lo = out_planes.lo if isinstance(out_planes, Planes) else None
+        assert (hi.B, hi.H, hi.W, hi.C) == (xp.B, xp.H, xp.W, cout)
+        ohi, olo, opld = C.c_void_p(hi.ptr), (C.c_void_p(lo.ptr) if lo is not None else None), hi.ld
+    if out is not None:
+        assert (out.B, out.H, out.W, out.C) == (xp.B, xp.H, xp.W, cout)
+    lib.conv2d_planes(C.byref(d), C.c_void_p(xp.hi.ptr), C.c_void_p(xp.lo.ptr), xp.ld, _p(wb32), _p(b), _p(out), ohi, olo, opld, _p(stream))
+
+
+def plane_split(lib, pairs, device, keep, stream=None):
+    """pairs: [(View src, Planes or Shadow dst)] -> hi = bf16(src), lo = bf16(src - hi) (a bare Shadow: hi only), ONE launch (mh_plane_split)."""
+    if not pairs:
+        return
+    arr = (_ffi.PlaneSeg * len(pairs))()
+    blk = 0
+    for i, (src, dst) in enumerate(pairs):
+        hi = dst.hi if isinstance(dst, Planes) else dst
+        lo = dst.lo if isinstance(dst, Planes) else None
+        assert (src.B, src.H, src.W, src.C) == (hi.B, hi.H, hi.W, hi.C), "planes / source geometry mismatch"
+        arr[i].src, arr[i].hi, arr[i].lo, arr[i].npix, arr[i].C = src.ptr, hi.ptr, (lo.ptr if lo is not None else None), src.npix, src.C
+        arr[i].src_ld, arr[i].dst_ld, arr[i].blk0 = src.ld, hi.ld, blk
+        blk += (src.npix * (hi.ld // 8) + 255) // 256
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+    keep.append(table)
+    lib.plane_split(C.c_void_p(table.data_ptr()), len(pairs), blk, _p(stream))
 
 
 def shadow_cast(lib, pairs, device, keep, stream=None):

@@ -101,6 +101,15 @@ class Recorder(object):
         bits = (1 if in_shadow is not None else 0) | (2 if mask_shadow is not None else 0) | (4 if flags & 1 else 0)
         self._op(_ffi.OP_CONV, self._desc_ints(d) + [0, d.precision, bits], [d.alpha, d.mask_alpha], [inp, w, mask_shadow, out, mask, in_shadow, wb, shadow])
 
+    def conv2d_planes(self, dref, in_hi, in_lo, in_pld, wb32, bias, out, out_hi, out_lo, out_pld, stream):
+        d = dref._obj
+        self._tally(d, "conv")
+        ints = self._desc_ints(d) + [0, 2, in_pld, out_pld]
+        self._op(_ffi.OP_CONV_PLANES, ints, [d.alpha, d.mask_alpha], [in_hi, in_lo, wb32, bias, out, out_hi, out_lo])
+
+    def plane_split(self, segs, nseg, nblocks, stream):
+        self._op(_ffi.OP_PLANE_SPLIT, [nseg, nblocks], [], [segs])
+
     def pack_weights(self, segs, nseg, nblocks, stream):
         self._op(_ffi.OP_PACK_W, [nseg, nblocks], [], [segs])
 

@@ -267,6 +267,61 @@ def run_bank():
     print("mh_pack_weights, 13 layers (%.1f MB of banks): %.1f us" % (sum(b.numel() * 4 for b in banks) / 1e6, t))
 
 
+def run_planes():
+    """split-bf16 forward from pre-split planes (mh_conv2d_planes, csrc/conv_planes.hip) against the fragment-bank kernel on the same layer:
+    tile variants, phase breakdown (no K walk / no staging), planes-only vs fp32 + planes output, the split launch."""
+    PL = [("L2 128->128 d1", 1, 96, 320, 128, 128, 1), ("L2 128->128 d2", 1, 96, 320, 128, 128, 2), ("L2 128->128 d4", 1, 96, 320, 128, 128, 4),
+          ("L2 128->96 d8", 1, 96, 320, 128, 96, 8), ("L2 96->64 d16", 1, 96, 320, 96, 64, 16),
+          ("L2 128->96", 1, 96, 320, 128, 96, 1), ("L2 96->64", 1, 96, 320, 96, 64, 1), ("L2 64->32", 1, 96, 320, 64, 32, 1), ("L2 38->128", 1, 96, 320, 38, 128, 1),
+          ("L2 33->128", 1, 96, 320, 33, 128, 1), ("P 32->32 x2", 2, 96, 320, 32, 32, 1),
+          ("L3 128->128", 1, 48, 160, 128, 128, 1), ("L3 70->128", 1, 48, 160, 70, 128, 1), ("L3 96->64", 1, 48, 160, 96, 64, 1), ("P 64->64 x2", 2, 48, 160, 64, 64, 1)]
+    only = os.environ.get("MB_ONLY")
+    print("%-16s %8s | %8s %8s %8s %8s | %8s %8s %8s | %8s   %s" % ("layer (fwd)", "bank", "v1", "v2", "v3", "v4", "v1 noK", "v1 nostg", "v1 pl-only", "split", "max|diff| vs bank"))
+    for name, B, H, W, Ci, Co, d in PL:
+        if only and only not in name:
+            continue
+        ld = (Ci + 3) // 4 * 4
+        xb = torch.zeros(B, H, W, ld, device=dev); xb[..., :Ci] = torch.randn(B, H, W, Ci, device=dev); xv = ops.View(xb, B, H, W, Ci, ld)
+        w = torch.randn(3, 3, Ci, Co, device=dev) * 0.05; b = torch.randn(Co, device=dev)
+        y = torch.empty(B, H, W, Co, device=dev); y2 = torch.empty(B, H, W, Co, device=dev)
+        keep = []
+        bank = torch.zeros(ops.pack_bytes(w) // 4, device=dev)
+        bank32 = torch.zeros(ops.pack_bytes(w, 2, 2) // 4, device=dev)
+        ops.pack_weights(lib, [(w, bank), (w, bank32, 2, 2)], dev, keep)
+        xp = ops.Planes(ops.Shadow(B, H, W, Ci, dev), dev)
+        yp = ops.Planes(ops.Shadow(B, H, W, Co, dev), dev)
+        ops.plane_split(lib, [(xv, xp)], dev, keep)
+        sh = stream.cuda_stream
+        lib.tune_conv_bank(0); lib.tune_conv_patch(128)
+        ops.PRECISION = 2
+        with torch.cuda.stream(stream):
+            t_bank = _time_ms(lib, stream, lambda: ops.conv2d_fwd(lib, xv, w, b, ops.view(y), stride=1, dil=d, alpha=0.2, stream=sh, wb=bank), 20) * 1e3
+        ops.PRECISION = 0
+        lib.tune_conv_patch(-1); lib.tune_conv_bank(-1)
+        res = []
+        for mode, outv, outp in ((1, y2, yp), (2, y2, yp), (3, y2, yp), (4, y2, yp), (1 + 256, y2, yp), (1 + 512, y2, yp), (1, None, yp)):
+            lib.tune_conv_planes(mode)
+            try:
+                with torch.cuda.stream(stream):
+                    res.append(_time_ms(lib, stream, lambda: ops.conv2d_planes(lib, xp, w, bank32, b, out=(ops.view(outv) if outv is not None else None), out_planes=outp,
+                                                                               dil=d, alpha=0.2, stream=sh), 20) * 1e3)
+            except Exception as e:
+                res.append(float("nan"))
+        lib.tune_conv_planes(0)
+        with torch.cuda.stream(stream):
+            t_split = _time_ms(lib, stream, lambda: ops.plane_split(lib, [(xv, xp)], dev, keep, stream=sh), 20) * 1e3
+        ops.conv2d_planes(lib, xp, w, bank32, b, out=ops.view(y2), out_planes=yp, dil=d, alpha=0.2)
+        kn = lib.last_kernel().decode()
+        torch.cuda.synchronize()
+        flops = 2.0 * B * H * W * 9 * Ci * Co
+        best = min(r for r in res[:4] if r == r)
+        print("%-16s %8.1f | %8.1f %8.1f %8.1f %8.1f | %8.1f %8.1f %8.1f | %8.1f   %.3g  (best %.0f TF/s algorithmic = %.3f of 2.5 PF; %s)"
+              % (name, t_bank, res[0], res[1], res[2], res[3], res[4], res[5], res[6], t_split, (y - y2).abs().max().item(), flops / (best * 1e-6) / 1e12,
+                 flops / (best * 1e-6) / 2.5e15, kn[:70]))
+
+
+if what == "planes":
+    run_planes()
 if what == "wgradp":
     run_wgradp()
 if what == "bank":

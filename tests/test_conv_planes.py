@@ -1,0 +1,144 @@
+"""mh_conv2d_planes / mh_plane_split / mh_pack_weights(trans = 2) (csrc/conv_planes.hip): the split-bf16 forward pass of the stride-1 3x3 layers
+(Nets/sharedLayers.py:54-77 for the layers of Nets/MadNet.py:73-171) from PRE-SPLIT operands -- activations as hi / lo bf16 planes staged by LDS DMA,
+weights from a fragment bank in the 32x32x16 MFMA register image.  Checked against
+  * the fp64 oracle at the 2^-16 level (the arithmetic claim of the split-bf16 forward mode),
+  * the existing split-bf16 kernel on the same fp32 inputs (same three products per element, another summation order: fp32 round-off apart),
+  * itself: output planes == the split of the fp32 result, bit for bit; untouched padding channels stay zero."""
+import pytest
+import torch
+
+from madnet_hip import ops
+from oracle import tf_ops as T
+
+
+def _rand(shape, seed, dev, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev)
+
+
+def _split_ref(x):
+    """hi = bf16(x), lo = bf16(x - hi) as the kernels compute them (round to nearest even)"""
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return hi, lo
+
+
+def _planes_of(lib, x, dev, keep):
+    """Planes of an fp32 NHWC tensor through mh_plane_split (+ the check of that kernel against torch's bf16 rounding)"""
+    B, H, W, C = x.shape
+    pl = ops.Planes(ops.Shadow(B, H, W, C, dev), dev)
+    ops.plane_split(lib, [(ops.view(x), pl)], dev, keep)
+    hi, lo = _split_ref(x.cpu())
+    assert torch.equal(pl.hi.t.cpu()[..., :C], hi) and torch.equal(pl.lo.t.cpu()[..., :C], lo)
+    assert not pl.hi.t.cpu()[..., C:].float().abs().sum() and not pl.lo.t.cpu()[..., C:].float().abs().sum()
+    return pl
+
+
+# (B, H, W, Cin, Cout, dil, variant): variant = mh_tune_conv_planes tile variant (0 = heuristic; 1..4 see csrc/conv_planes.hip dispatch_planes_k)
+CASES = [
+    (1, 9, 37, 128, 128, 1, 1), (1, 9, 37, 128, 128, 1, 2), (1, 11, 21, 128, 128, 1, 3), (1, 11, 21, 128, 128, 1, 4),
+    (1, 12, 40, 128, 128, 2, 0), (2, 7, 33, 128, 96, 1, 1), (1, 20, 18, 128, 96, 1, 3), (1, 10, 35, 96, 64, 1, 1), (1, 18, 20, 96, 64, 4, 2),
+    (1, 9, 34, 64, 32, 1, 1), (1, 19, 17, 64, 32, 1, 2), (2, 8, 40, 32, 32, 1, 0),
+    (1, 8, 33, 38, 128, 1, 1),       # the estimators' first layer: 38 channels in rows of 64 halfs, three 16-channel steps per tap
+    (1, 8, 33, 33, 128, 1, 3), (1, 9, 20, 70, 128, 1, 1), (1, 6, 20, 64, 64, 16, 1), (1, 12, 40, 128, 96, 8, 0),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv2d_planes_vs_oracle_and_split_bf16_kernel(backend, case):
+    B, H, W, Ci, Co, dil, variant = case
+    lib, dev = backend.lib, backend.device
+    x = _rand((B, H, W, Ci), 211, dev)
+    w = _rand((3, 3, Ci, Co), 212, dev, 0.2)
+    b = _rand((Co,), 213, dev)
+    y_ref = T.conv2d(x.cpu().double(), w.cpu().double(), b.cpu().double(), stride=1, dilation=dil, alpha=0.2).float()
+    keep = []
+    assert ops.conv2d_planes_ok(lib, ops.view(x), w, dil)
+    xp = _planes_of(lib, x, dev, keep)
+    bank = torch.full((ops.pack_bytes(w, 2, 2) // 4,), float("nan"), device=dev)
+    assert ops.pack_bytes(w, 2, 2) == lib.pack32_bytes(9, Ci, Co)
+    ops.pack_weights(lib, [(w, bank, 2, 2)], dev, keep)
+    y = torch.full((B, H, W, Co), float("nan"), device=dev)
+    yp = ops.Planes(ops.Shadow(B, H, W, Co, dev), dev)
+    lib.tune_conv_planes(variant)
+    try:
+        ops.conv2d_planes(lib, xp, w, bank, b, out=ops.view(y), out_planes=yp, dil=dil, alpha=0.2)
+        name = lib.last_kernel().decode()
+        backend.sync()
+        # planes only (no fp32 result) and fp32 only: the same values
+        yp2 = ops.Planes(ops.Shadow(B, H, W, Co, dev), dev)
+        ops.conv2d_planes(lib, xp, w, bank, b, out=None, out_planes=yp2, dil=dil, alpha=0.2)
+        y3 = torch.full((B, H, W, Co), float("nan"), device=dev)
+        ops.conv2d_planes(lib, xp, w, bank, b, out=ops.view(y3), out_planes=None, dil=dil, alpha=0.2)
+        backend.sync()
+    finally:
+        assert lib.tune_conv_planes(0) == 3
+    assert "conv_planes_kernel" in name, name
+    yc = y.cpu()
+    assert torch.isfinite(yc).all()
+    scale = max(1.0, y_ref.abs().max().item())
+    err = (yc - y_ref).abs().max().item()
+    assert err <= 4e-5 * scale, (err, name)
+    hi, lo = _split_ref(yc)
+    assert torch.equal(yp.hi.t.cpu()[..., :Co], hi) and torch.equal(yp.lo.t.cpu()[..., :Co], lo)
+    assert torch.equal(yp2.hi.t.cpu(), yp.hi.t.cpu()) and torch.equal(yp2.lo.t.cpu(), yp.lo.t.cpu()) and torch.equal(y3.cpu(), yc)
+    # the existing split-bf16 forward kernel on the fp32 tensor: identical products, another summation order
+    if Ci % 4 == 0:
+        y0 = torch.full((B, H, W, Co), float("nan"), device=dev)
+        lib.tune_conv_patch(128)
+        try:
+            with ops.precision_scope("mixed"):
+                ops.conv2d_fwd(lib, ops.view(x), w, b, ops.view(y0), stride=1, dil=dil, alpha=0.2)
+            backend.sync()
+        finally:
+            lib.tune_conv_patch(-1)
+        d0 = (yc - y0.cpu()).abs().max().item()
+        assert d0 <= 4e-5 * scale, d0
+
+
+def test_conv2d_planes_chain_equals_fp32_reference_chain(backend):
+    """two layers back to back through planes only (no fp32 tensor in between): what the engines' forward chains do"""
+    lib, dev = backend.lib, backend.device
+    B, H, W = 1, 10, 36
+    x = _rand((B, H, W, 64), 311, dev)
+    w1, b1 = _rand((3, 3, 64, 96), 312, dev, 0.1), _rand((96,), 313, dev)
+    w2, b2 = _rand((3, 3, 96, 64), 314, dev, 0.1), _rand((64,), 315, dev)
+    keep = []
+    xp = _planes_of(lib, x, dev, keep)
+    banks = [torch.zeros(ops.pack_bytes(w, 2, 2) // 4, device=dev) for w in (w1, w2)]
+    ops.pack_weights(lib, [(w1, banks[0], 2, 2), (w2, banks[1], 2, 2)], dev, keep)
+    mid = ops.Planes(ops.Shadow(B, H, W, 96, dev), dev)
+    y = torch.zeros(B, H, W, 64, device=dev)
+    ops.conv2d_planes(lib, xp, w1, banks[0], b1, out=None, out_planes=mid, dil=1, alpha=0.2)
+    ops.conv2d_planes(lib, mid, w2, banks[1], b2, out=ops.view(y), out_planes=None, dil=2, alpha=0.2)
+    backend.sync()
+    r1 = T.conv2d(x.cpu().double(), w1.cpu().double(), b1.cpu().double(), stride=1, dilation=1, alpha=0.2)
+    r2 = T.conv2d(r1, w2.cpu().double(), b2.cpu().double(), stride=1, dilation=2, alpha=0.2).float()
+    err = (y.cpu() - r2).abs().max().item()
+    assert err <= 1e-4 * max(1.0, r2.abs().max().item()), err
+
+
+def test_conv2d_planes_argument_checks(backend):
+    from madnet_hip import _ffi
+    import ctypes as C
+    lib, dev = backend.lib, backend.device
+    x = torch.zeros(1, 4, 8, 64, device=dev)
+    w = torch.zeros(3, 3, 64, 32, device=dev)
+    keep = []
+    xp = _planes_of(lib, x, dev, keep)
+    bank = torch.zeros(ops.pack_bytes(w, 2, 2) // 4, device=dev)
+    y = torch.zeros(1, 4, 8, 32, device=dev)
+    with pytest.raises(_ffi.MadnetHipError):          # no output at all
+        ops.conv2d_planes(lib, xp, w, bank, None, out=None, out_planes=None)
+    d = ops.conv_desc(1, 4, 8, 4, 8, 64, 32, 3, 3, 2, 1, 1, 1, 0, 0, 0, 32, precision=2)     # stride 2: no instance
+    assert lib.conv2d_planes_ok(C.byref(d)) == 0
+    rc = lib._raw_mh_conv2d_planes(C.byref(d), xp.hi.ptr, xp.lo.ptr, xp.ld, bank.data_ptr(), None, y.data_ptr(), None, None, 0, None)
+    assert rc == -3 and b"mh_conv2d_planes" in lib.last_error()
+    d = ops.conv_desc(1, 4, 8, 4, 8, 64, 32, 3, 3, 1, 1, 1, 1, 0, 0, 0, 32, precision=2)
+    assert lib.conv2d_planes_ok(C.byref(d)) == 1
+    rc = lib._raw_mh_conv2d_planes(C.byref(d), xp.hi.ptr, xp.lo.ptr, 40, bank.data_ptr(), None, y.data_ptr(), None, None, 0, None)   # plane stride < K
+    assert rc == -1
+    rc = lib._raw_mh_conv2d_planes(C.byref(d), xp.hi.ptr + 2, xp.lo.ptr, xp.ld, bank.data_ptr(), None, y.data_ptr(), None, None, 0, None)
+    assert rc == -2
+    assert not ops.conv2d_planes_ok(lib, ops.view(torch.zeros(1, 4, 8, 200, device=dev)), torch.zeros(3, 3, 200, 32), 1)      # K > 128
+    assert not ops.conv2d_planes_ok(lib, ops.view(x), torch.zeros(3, 3, 64, 160), 1)                                            # N > 128
