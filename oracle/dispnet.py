@@ -1,7 +1,8 @@
 """CPU ORACLE (test infrastructure, NOT product code) -- DispNet-C graph + FULL adaptation step.
 
 Restates Nets/DispNet.py (whole file) on torch-CPU with the TF 1.12 op semantics of oracle/tf_ops.py.
-PARITY UNPINNED (no TF available, the reference has no tests).  Variable names follow the reference
+WIRING PINNED (round 4): tests/test_ref_graph.py holds forward / loss / gradients to the reference's own graph code executed under
+oracle/tf_shim (oracle/ref_graph.py); the TF library kernels' arithmetic stays "parity unpinned" (oracle/tf_ops.py header).  Variable names follow the reference
 scopes under the driver's 'model/' (SURVEY App. C): default bias name is 'bias' (sharedLayers.py:54,80).
 """
 import torch

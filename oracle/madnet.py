@@ -1,8 +1,9 @@
 """CPU ORACLE (test infrastructure, NOT product code) -- MADNet graph + online step.
 
 Restates Nets/MadNet.py (whole file) and the per-frame loop body of
-Stereo_Online_Adaptation.py:178-253 on torch-CPU with autograd.  PARITY UNPINNED
-(see oracle/tf_ops.py header): no TF available, no reference tests exist.
+Stereo_Online_Adaptation.py:178-253 on torch-CPU with autograd.  WIRING PINNED (round 4): tests/test_ref_graph.py holds this file's forward / loss / gradients to what the reference's own
+graph code computes when oracle/ref_graph.py executes it under oracle/tf_shim; the TF library kernels' arithmetic stays
+"parity unpinned" (oracle/tf_ops.py header).
 
 Weights are a dict {TF variable name -> torch tensor} using the names the reference
 graph creates under the driver's outer scope 'model/' (SURVEY App. C).

@@ -1,0 +1,111 @@
+"""TEST INFRASTRUCTURE (CPU oracle): runs the REFERENCE's own graph code -- /root/reference/Nets (Stereo_net.py, sharedLayers.py, MadNet.py,
+DispNet.py), Losses/loss_factory.py, Data_utils/preprocessing.py, imported read-only from where they lie -- eagerly under oracle/tf_shim's
+stand-in `tensorflow` module, and dumps what it computes.  This is how the hand-written wiring of oracle/madnet.py / oracle/dispnet.py is PINNED
+to the reference source (tests/test_ref_graph.py; fixtures tests/golden/ref_graph_*.npz are minted by tests/golden/make_ref_graph_golden.py).
+
+Runs as a SUBPROCESS with a path of its own: the reference's module names (Nets, Losses, Data_utils) are also the names of the product's API
+mirror, so the two must never share an interpreter.  Nothing under /root/reference is written (sys.dont_write_bytecode).
+
+    python oracle/ref_graph.py --net MADNet --inputs in.npz --out out.npz [--bulkhead 1] [--block-config block_config/MadNet_full.json]
+
+in.npz : left, right [B,H,W,3] float32 (0..255), every variable under its TF name ('model/...').
+out.npz: disp_<i> = net.get_disparities()[i]; loss = the full-resolution reprojection loss (Stereo_Online_Adaptation.py:68-70);
+         FULL (--bulkhead 0): grad/<var> = d loss / d var for every variable                     (Stereo_Online_Adaptation.py:126-128)
+         MAD  (--bulkhead 1): blockloss_<k>, bgrad_<k>/<var> for every block k of the config     (Stereo_Online_Adaptation.py:96-118)
+         layers = json {layer key: [variable names]} as StereoNet._add_to_layers recorded them, in creation order; varnames = creation order.
+"""
+import argparse
+import json
+import os
+import sys
+
+REF = os.environ.get("MADNET_REFERENCE_ROOT", "/root/reference")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--net", default="MADNet")
+    ap.add_argument("--inputs", required=True)
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--bulkhead", type=int, default=0)
+    ap.add_argument("--block-config", default=None)
+    ap.add_argument("--threads", type=int, default=0)
+    a = ap.parse_args()
+
+    sys.dont_write_bytecode = True
+    here = os.path.dirname(os.path.abspath(__file__))
+    # the reference tree + the stand-in tensorflow FIRST; none of the product's directories
+    sys.path[:] = [os.path.join(here, "tf_shim"), REF] + [p for p in sys.path if p and os.path.abspath(p) != os.path.dirname(here)
+                                                            and "real-time-self-adaptive-deep-stereo_amd" not in p] + [os.path.dirname(here)]
+    import numpy as np
+    import torch
+    if a.threads:
+        torch.set_num_threads(a.threads)
+    import tensorflow as tf
+    assert tf.__version__.endswith("shim") and tf.__file__.startswith(here), "the stand-in tensorflow must be the one imported"
+    import Nets                                     # /root/reference/Nets/__init__.py
+    from Losses import loss_factory                 # /root/reference/Losses/loss_factory.py
+    from Data_utils import preprocessing            # /root/reference/Data_utils/preprocessing.py
+    for m in (Nets, loss_factory, preprocessing):
+        assert os.path.abspath(m.__file__).startswith(os.path.abspath(REF)), m.__file__
+
+    z = np.load(a.inputs)
+    left = tf.constant(z["left"], tf.float32)
+    right = tf.constant(z["right"], tf.float32)
+    tf.reset_default_graph()
+    tf.set_initial_values({k: z[k] for k in z.files if k.startswith("model/")})
+
+    # Stereo_Online_Adaptation.py:53-66, verbatim argument set
+    with tf.variable_scope("model"):
+        net_args = {}
+        net_args["left_img"] = left
+        net_args["right_img"] = right
+        net_args["split_layers"] = [None]
+        net_args["sequence"] = True
+        net_args["train_portion"] = "BEGIN"
+        net_args["bulkhead"] = True if a.bulkhead else False
+        stereo_net = Nets.get_stereo_net(a.net, net_args)
+        predictions = stereo_net.get_disparities()
+    inputs = {"left": left, "right": right}
+    # Stereo_Online_Adaptation.py:68-70
+    with tf.variable_scope("full_res_loss"):
+        full_loss = loss_factory.get_reprojection_loss("mean_SSIM_l1", reduced=True)(predictions, inputs)
+
+    out = {"loss": np.float32(full_loss.t.detach().numpy())}
+    for i, p in enumerate(predictions):
+        out["disp_%d" % i] = p.t.detach().numpy()
+    variables = tf.trainable_variables()
+    out["varnames"] = json.dumps([v.var_name for v in variables])
+    out["layers"] = json.dumps({k: [v.var_name for v in stereo_net.get_variables(k)] for k in stereo_net.get_layers_names()})
+    out["trainable"] = json.dumps([v.var_name for v in stereo_net.get_trainable_variables()])
+
+    if not a.bulkhead:
+        # FULL: disparity_trainer.minimize(full_reconstruction_loss) over every trainable variable (:126-128)
+        gs = torch.autograd.grad(full_loss.t, [v.t for v in variables], allow_unused=True)
+        for v, g in zip(variables, gs):
+            if g is not None:
+                out["grad/" + v.var_name] = g.numpy()
+    elif a.block_config:
+        # MAD: one train op per prediction but the last, each on the variables of its block (:88-118), reprojectionScale = 1
+        train_config = json.load(open(a.block_config))
+        preds = predictions[:-1]
+        assert len(preds) == len(train_config)
+        for counter, p in enumerate(preds):
+            multiplier = tf.cast(tf.shape(left)[1] // tf.shape(p)[1], tf.float32)
+            p = preprocessing.resize_to_prediction(p, inputs["left"]) * multiplier
+            with tf.variable_scope("reprojection_" + str(counter)):
+                rl = loss_factory.get_reprojection_loss("mean_SSIM_l1", reduced=True)([p], inputs)
+            var_accumulator = []
+            for name in train_config[counter]:
+                var_accumulator += stereo_net.get_variables(name)
+            out["blockloss_%d" % counter] = np.float32(rl.t.detach().numpy())
+            out["blockvars_%d" % counter] = json.dumps([v.var_name for v in var_accumulator])
+            gs = torch.autograd.grad(rl.t, [v.t for v in var_accumulator], allow_unused=True, retain_graph=True)
+            for v, g in zip(var_accumulator, gs):
+                if g is not None:
+                    out["bgrad_%d/%s" % (counter, v.var_name)] = g.numpy()
+    np.savez(a.out, **out)
+
+
+if __name__ == "__main__":
+    main()

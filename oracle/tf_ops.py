@@ -2,11 +2,16 @@
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 
-PARITY UNPINNED: the reference ships no tests / golden vectors and TensorFlow 1.x
-cannot be imported in this environment, so every function here restates the
-*documented* TF 1.12 semantics.  The restatement is cross-checked
-against an independent loop-level numpy restatement (oracle/loops.py), a plain-C
-restatement (oracle/c/oracle_ops.c) and fp64 finite differences (tests/).
+PARITY: the reference ships no tests / golden vectors and TensorFlow 1.x cannot be imported in this
+environment, so the functions here restate the *documented* TF 1.12 kernel semantics
+-- "parity unpinned" for the arithmetic INSIDE TensorFlow's library kernels (conv2d, resize_images,
+avg_pool, ...).  They are cross-checked against an independent loop-level numpy restatement
+(oracle/loops.py), a plain-C restatement (oracle/c/oracle_ops.c) and fp64 finite differences (tests/).
+What IS pinned to the reference itself: the correlation (the reference's own kernel, oracle/_ref), the
+samplers (the reference module imported) and -- round 4 -- the whole graph WIRING around these kernels:
+oracle/tf_shim binds the reference's `tf.*` calls to the functions below and oracle/ref_graph.py EXECUTES
+/root/reference/Nets/*.py, Losses/loss_factory.py, Data_utils/preprocessing.py as written
+(tests/test_ref_graph.py, fixtures tests/golden/ref_graph_*.npz).
 
 All tensors at this API are NHWC like the reference; torch kernels are called NCHW
 internally.  Each function cites the reference call-site it restates.

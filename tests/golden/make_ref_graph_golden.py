@@ -1,0 +1,109 @@
+"""Mints tests/golden/ref_graph_*.npz by EXECUTING THE REFERENCE'S OWN GRAPH CODE (/root/reference/Nets/*.py, Losses/loss_factory.py,
+Data_utils/preprocessing.py) under oracle/tf_shim's eager stand-in for tensorflow (oracle/ref_graph.py, one subprocess per case), in the build
+container where /root/reference exists.  Committed so that the vectors travel to boxes without the reference tree: tests/test_ref_graph.py checks
+the CPU oracle against them everywhere and the HIP engines against them on the MI355X.
+
+    python tests/golden/make_ref_graph_golden.py            (about two minutes on 8 cores)
+
+Inputs are the seeded synthetic pair / weights of madnet_hip/synthetic.py (cases(): the ONE definition both this script and the test use).
+Stored per case: every disparity the network returns (full arrays for the small cases, an 8x8-strided sample at 375x1242), the full-resolution
+loss, and for every gradient [sum, l2 norm, max |.|, 16 strided samples] -- 3.8 M (MADNet) / 42 M (DispNet) gradient values do not belong in git."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in (ROOT, os.path.join(ROOT, "real-time-self-adaptive-deep-stereo_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+GOLD = os.path.join(ROOT, "tests", "golden")
+REF = os.environ.get("MADNET_REFERENCE_ROOT", "/root/reference")
+
+
+def dispnet_weights():
+    """Xavier-uniform filters (sharedLayers.py:4), small random biases (all-zero biases would leave the bias path untested), seed 0"""
+    from oracle import dispnet as OD
+    rs = np.random.RandomState(0)
+    w = {}
+    for n, shp in OD.variable_shapes().items():
+        if len(shp) == 4:
+            lim = np.sqrt(6.0 / (shp[0] * shp[1] * (shp[2] + shp[3])))
+            w[n] = rs.uniform(-lim, lim, size=shp).astype(np.float32)
+        else:
+            w[n] = (rs.randn(*shp) * 0.01).astype(np.float32)
+    return w
+
+
+def cases():
+    """name -> (net, H, W, bulkhead, block config or None, stride of the stored disparity sample)"""
+    return {
+        "madnet_full_60x100": ("MADNet", 60, 100, 0, None, 1),
+        "madnet_mad_60x100": ("MADNet", 60, 100, 1, "MadNet_full.json", 1),
+        "madnet_mad_pyramid_only_60x100": ("MADNet", 60, 100, 1, "MadNet_piramid_only.json", 1),
+        "dispnet_full_64x128": ("Dispnet", 64, 128, 0, None, 1),
+        "madnet_full_375x1242": ("MADNet", 375, 1242, 0, None, 8),
+    }
+
+
+def case_inputs(name):
+    from madnet_hip import synthetic as S
+    from oracle import madnet as OM
+    net, H, W, bulk, cfg, stride = cases()[name]
+    wn = S.calibrated_weights(OM.variable_shapes(), 1) if net == "MADNet" else dispnet_weights()
+    l, r, gt = S.make_pair(H, W)
+    return net, l, r, gt, wn, bulk, cfg, stride
+
+
+def grad_stats(g):
+    g = np.asarray(g, dtype=np.float32).reshape(-1)
+    idx = np.linspace(0, g.size - 1, 16).astype(np.int64)
+    return np.concatenate([[g.astype(np.float64).sum(), np.sqrt((g.astype(np.float64) ** 2).sum()), np.abs(g).max()], g[idx]]).astype(np.float64)
+
+
+def run_reference(name, threads=0):
+    """the reference graph's outputs for a case: dict of arrays (what oracle/ref_graph.py wrote)"""
+    net, l, r, gt, wn, bulk, cfg, stride = case_inputs(name)
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in.npz"), os.path.join(td, "out.npz")
+        np.savez(fin, left=l, right=r, **wn)
+        cmd = [sys.executable, os.path.join(ROOT, "oracle", "ref_graph.py"), "--net", net, "--inputs", fin, "--out", fout, "--bulkhead", str(bulk)]
+        if cfg:
+            cmd += ["--block-config", os.path.join(REF, "block_config", cfg)]
+        if threads:
+            cmd += ["--threads", str(threads)]
+        env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+        rc = subprocess.run(cmd, capture_output=True, text=True, env=env)
+        if rc.returncode != 0:
+            raise RuntimeError("oracle/ref_graph.py failed for %s:\n%s" % (name, rc.stderr[-3000:]))
+        z = np.load(fout)
+        return {k: z[k] for k in z.files}
+
+
+def compact(name, ref):
+    stride = cases()[name][5]
+    out = {}
+    for k, v in ref.items():
+        if k.startswith("disp_"):
+            out[k] = v[:, ::stride, ::stride, :].astype(np.float32)
+            out["mean_" + k] = np.float64(v.astype(np.float64).mean())
+        elif k.startswith("grad/") or k.startswith("bgrad_"):
+            out["stats:" + k] = grad_stats(v)
+        else:
+            out[k] = v
+    return out
+
+
+if __name__ == "__main__":
+    only = sys.argv[1:]
+    for name in cases():
+        if only and name not in only:
+            continue
+        ref = run_reference(name)
+        c = compact(name, ref)
+        path = os.path.join(GOLD, "ref_graph_%s.npz" % name)
+        np.savez_compressed(path, **c)
+        print("%-34s %4d arrays  %7.1f KB  loss %.8f" % (name, len(c), os.path.getsize(path) / 1024.0, float(ref["loss"])))
