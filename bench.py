@@ -373,6 +373,9 @@ def main():
                     help="A/B override (repeatable; the JSON line lists them under 'overrides'): engine.NAME=v sets a module flag of madnet_hip/engine.py "
                          "(FUSE_HEAD, SHADOW_ONLY, EARLY_WGS ...), eng.NAME=v an attribute of every engine built (fuse_front, use_bank ...), "
                          "tune.NAME=int calls the library hook mh_tune_NAME (conv_rows, conv_bank_tile, wgrad_target_pct ...)")
+    ap.add_argument("--stamps", type=int, default=0, metavar="N",
+                    help="also replay a STAMPED copy of the step N times (device time stamps as plan ops, engine.STAMPS) and report where the side lane starts "
+                         "and how long the tail behind the last input gradient is (tail_us, side_lane_start_us) -- measured inside the untraced graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-step-surface", action="store_true")
@@ -610,6 +613,8 @@ def main():
     }
     if shared_info is not None:
         out["shared_model"] = shared_info
+    if args.stamps > 0 and rank == 0 and not dispnet and not shared and CS == 1 and use_graph:
+        out["tail"] = BT.tail_stamps(lib, E, mk, feed, args, dev, ms)
     if rank == 0 and world == 1 and dispnet and SB == 1 and dev.kind == "cuda" and not args.no_cpu_baseline:
         # DispNet: disparity of the run's arithmetic mode against the fp32 CPU oracle on the bench pair (the same check MADNet's line carries)
         from oracle import dispnet as OD

@@ -128,6 +128,8 @@ typedef struct mh_plane_seg {
     int64_t npix;
     int32_t C, src_ld, dst_ld;
     int32_t blk0;         /* exclusive prefix sum of ceil(npix * dst_ld / 8 / 256) over the table */
+    const float* src2;    /* NULL, or a second source whose C2 channels follow src's C (a fused tf.concat: [features | disparity], MadNet.py:123) */
+    int32_t C2, src2_ld;
 } mh_plane_seg;
 int mh_plane_split(const mh_plane_seg* segs_device, int32_t nseg, int32_t nblocks, void* stream);
 
@@ -228,6 +230,12 @@ int mh_corr_fwd_prec(const float* L, int32_t l_ld, const float* R, int32_t r_ld,
 int mh_level_front_fwd(const float* Vc, int32_t Hc, int32_t Wc, float mul, const float* L, int32_t l_ld, const float* R, int32_t r_ld,
                        float* out, int32_t out_ld, int32_t coff, float* Rw, int32_t rw_ld, float* u,
                        int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t zero_tail, void* stream);
+/* mh_level_front_fwd that ALSO writes the estimator input as bf16 planes (out_hi: the shadow the filter gradient reads; out_lo, may be NULL: the lo
+ * plane mh_conv2d_planes needs), pixel stride out_pld halfs >= coff + D + 1, padding channels untouched (allocate zeroed). */
+int mh_level_front_fwd_planes(const float* Vc, int32_t Hc, int32_t Wc, float mul, const float* L, int32_t l_ld, const float* R, int32_t r_ld,
+                              float* out, int32_t out_ld, int32_t coff, float* Rw, int32_t rw_ld, float* u,
+                              int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t zero_tail,
+                              void* out_hi, void* out_lo, int32_t out_pld, void* stream);
 /* g: gradient w.r.t. the buffer written by mh_corr_fwd (same ld / coff).
  * dL[p][c] (+)= [copy_left] g[p][c] + (1/C) sum_j g[p][coff+j] R[p+i_j][c]
  * dR[p][c] (+)=                      (1/C) sum_j g[p-i_j][coff+j] L[p-i_j][c]
@@ -313,11 +321,22 @@ int mh_conv2d_sh2(const mh_conv_desc* d, const float* in, const void* in_shadow,
  * mask_shadow = the bf16 shadow of mask_ref (pixel stride = N rounded up to 32): the leaky mask tests only the sign, so 8 bytes of the shadow
  * replace 16 of the fp32 activation; flags & MH_CONV_SHADOW_ONLY: the fp32 result is NOT stored, only out_shadow (legal when every consumer of
  * the result takes its shadow -- ask mh_conv2d_takes_shadows for the consuming launch; needs out_shadow, no accumulation).
- * mh_conv2d_takes_shadows(d, ...) = 1 if the launch described by d / these pointers would stage in_shadow (and honour the options), else 0. */
+ * mh_conv2d_takes_shadows(d, ...) != 0 if the launch described by d / these pointers would stage in_shadow (and honour the options), else 0. */
 #define MH_CONV_SHADOW_ONLY 1
+/* flags & MH_CONV_IN_F32_STALE / MH_CONV_MASK_F32_STALE: the caller did not store the fp32 `in` / `mask_ref` (its producer ran with
+ * MH_CONV_SHADOW_ONLY, or wrote planes only): the call FAILS (MH_ERR_UNSUPPORTED, nothing launched) unless the dispatched kernel stages in_shadow /
+ * reads mask_shadow -- a plan recorded under one dispatch can never silently read a tensor nobody wrote when it is replayed under another.
+ * mh_conv2d_takes_shadows returns a bit mask: 1 = in_shadow would be staged, 2 = the mask would be read from mask_shadow. */
+#define MH_CONV_IN_F32_STALE 2
+#define MH_CONV_MASK_F32_STALE 4
 int mh_conv2d_sh3(const mh_conv_desc* d, const float* in, const void* in_shadow, const float* w, const void* wb, const float* bias,
                   float* out, const float* mask_ref, const void* mask_shadow, void* out_shadow, int32_t flags, void* stream);
 int mh_conv2d_takes_shadows(const mh_conv_desc* d, const float* in, const float* w, const void* wb, float* out, const float* mask_ref);
+/* mh_conv2d_sh that writes BOTH planes of its result, out_hi = bf16(out) and out_lo = bf16(out - out_hi) ([pixel][N rounded up to 32]): the producer side
+ * of mh_conv2d_planes for layers that run from fp32 operands (the exact-fp32 stride-2 pyramid layers in front of conv4 / conv6).  The tiled kernel's
+ * vector epilogue stores them itself; behind any other kernel family one split launch follows. */
+int mh_conv2d_sh4(const mh_conv_desc* d, const float* in, const float* w, const void* wb, const float* bias, float* out, const float* mask_ref,
+                  void* out_hi, void* out_lo, void* stream);
 /* Forward pass of a disparity head (mh_conv2d with N = 1, mode 0) that also stores its result at up to two more places, each with its own
  * pixel stride (floats): a channel slot of a concatenated buffer (the context network's input, Nets/MadNet.py:155-157) and / or the buffer the
  * next stage accumulates into (final = V2 + context, MadNet.py:171).  out2 / out3 may be NULL.  Saves the copy launches behind the head. */
@@ -399,6 +418,10 @@ int mh_copy_channels(const float* src, int32_t src_ld, float* dst, int32_t dst_l
 int mh_leaky_bwd(float* dy, int32_t dy_ld, const float* y, int32_t y_ld, int64_t npix, int32_t nch,
                  float alpha, void* stream);
 int mh_fill(float* p, int64_t n, float v, void* stream);
+/* diagnostics: stores the device's constant-rate wall clock (ticks of mh_stamp_rate_khz() kHz) into the 8-byte slot -- recorded as a plan op
+ * (MH_OP_STAMP) it times the REPLAYED graph from the inside: start of the side lane, end of the input-gradient chain, end of the step */
+int mh_stamp(void* slot, void* stream);
+int64_t mh_stamp_rate_khz(void);
 /* db[c] += sum_p dz[p][c]  (BiasAddGrad of conv2d_transpose, whose filter gradient runs with swapped operands) */
 int mh_bias_grad(const float* dz, int32_t dz_ld, int64_t npix, int32_t nch, float* db, void* stream);
 
@@ -414,7 +437,7 @@ enum { MH_OP_CONV = 1, MH_OP_WGRAD, MH_OP_CORR_FWD, MH_OP_CORR_BWD, MH_OP_WARP_F
        MH_OP_RESIZE_FWD, MH_OP_RESIZE_BWD, MH_OP_PAD_REFLECT, MH_OP_LOSS, MH_OP_METRICS,
        MH_OP_MOMENTUM, MH_OP_COPY_CH, MH_OP_LEAKY_BWD, MH_OP_FILL, MH_OP_BIAS_GRAD,
        MH_OP_WGRAD_PARTIAL, MH_OP_WGRAD_REDUCE, MH_OP_PROXY_LOSS, MH_OP_SUPERVISED_LOSS, MH_OP_ADAM, MH_OP_ADAM_ADVANCE,
-       MH_OP_RESIZE_IMAGE, MH_OP_LEVEL_FRONT, MH_OP_RESERVED_25 /* (was: transposed filter banks of the retired LDS-free kernel) */, MH_OP_PACK_W, MH_OP_CORR_WARP_BWD, MH_OP_SHADOW_CAST, MH_OP_WGRAD_STREAM, MH_OP_HEAD_BWD, MH_OP_HEAD_FWD, MH_OP_CONV_PLANES, MH_OP_PLANE_SPLIT };
+       MH_OP_RESIZE_IMAGE, MH_OP_LEVEL_FRONT, MH_OP_RESERVED_25 /* (was: transposed filter banks of the retired LDS-free kernel) */, MH_OP_PACK_W, MH_OP_CORR_WARP_BWD, MH_OP_SHADOW_CAST, MH_OP_WGRAD_STREAM, MH_OP_HEAD_BWD, MH_OP_HEAD_FWD, MH_OP_CONV_PLANES, MH_OP_PLANE_SPLIT, MH_OP_STAMP };
 /* i[26] of every op is its scheduling word: low byte = lane (0 = the caller's stream; 1..MH_MAX_LANES-1 = side
  * streams owned by the library: the op is forked from lane 0 right before it, i.e. ordered after everything recorded so
  * far, and runs concurrently with the lane-0 ops that follow); MH_OP_JOIN = lane 0 first waits for all side lanes.

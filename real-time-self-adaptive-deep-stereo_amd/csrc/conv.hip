@@ -598,7 +598,13 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(ConvArgs p) {
                 v.w *= (mk.w > 0.f || n + 3 < p.mask_c0 || n + 3 >= p.mask_c1) ? 1.0f : p.mask_alpha;
             }
             if (ok) *reinterpret_cast<float4*>(p.out + (int64_t)m * p.out_ld + n) = v;
-            if (ok && p.shadow) *reinterpret_cast<uint2*>(p.shadow + (int64_t)m * p.shadow_ld + n) = make_uint2(mh_pack_bf16(v.x, v.y), mh_pack_bf16(v.z, v.w));
+            if (ok && p.shadow) {
+                uint2 hi, lo;
+                mh_split_bf16x2(v.x, v.y, hi.x, lo.x);
+                mh_split_bf16x2(v.z, v.w, hi.y, lo.y);
+                *reinterpret_cast<uint2*>(p.shadow + (int64_t)m * p.shadow_ld + n) = hi;
+                if (p.shadow_lo) *reinterpret_cast<uint2*>(p.shadow_lo + (int64_t)m * p.shadow_ld + n) = lo;
+            }
         }
 #ifdef MH_PHASE_TIMING
         if (p.dbg && threadIdx.x == 0) {
@@ -1090,7 +1096,8 @@ int mh_conv_init() {
     return rc ? rc : conv_dispatch(a, nullptr);
 }
 
-struct HeadOuts { float* out2; int out2_ld; float* out3; int out3_ld; const void* in_shadow; const void* mask_shadow = nullptr; int flags = 0; int query = 0; };
+struct HeadOuts { float* out2; int out2_ld; float* out3; int out3_ld; const void* in_shadow; const void* mask_shadow = nullptr; int flags = 0; int query = 0; void* out_lo = nullptr; };
+int mh_plane_split_one(const float* src, int src_ld, int C, void* hi, void* lo, int dst_ld, int64_t npix, hipStream_t s);      // conv_planes.hip
 static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, const float* wt, const void* wb, const float* bias,
                       float* out, const float* mask_ref, void* stream, void* out_shadow = nullptr, const HeadOuts* head = nullptr);
 int mh_shadow_cast_one(const float* src, int src_ld, int C, void* dst, int dst_ld, int64_t npix, hipStream_t s);      // wgrad_stream.hip
@@ -1127,6 +1134,14 @@ extern "C" int mh_conv2d_sh3(const mh_conv_desc* d, const float* in, const void*
     HeadOuts h{nullptr, 0, nullptr, 0, in_shadow};
     h.mask_shadow = mask_shadow; h.flags = flags;
     return conv_entry(d, in, w, nullptr, wb, bias, out, mask_ref, stream, out_shadow, &h);
+}
+extern "C" int mh_conv2d_sh4(const mh_conv_desc* d, const float* in, const float* w, const void* wb, const float* bias, float* out, const float* mask_ref,
+                             void* out_hi, void* out_lo, void* stream) {
+    MH_REQUIRE(out_hi && out_lo, MH_ERR_ARG, "mh_conv2d_sh4: both output planes");
+    MH_REQUIRE(mh_aligned16(out_hi) && mh_aligned16(out_lo), MH_ERR_ALIGN, "mh_conv2d_sh4: output planes must be 16-byte aligned");
+    HeadOuts h{nullptr, 0, nullptr, 0, nullptr};
+    h.out_lo = out_lo;
+    return conv_entry(d, in, w, nullptr, wb, bias, out, mask_ref, stream, out_hi, &h);
 }
 extern "C" int mh_conv2d_takes_shadows(const mh_conv_desc* d, const float* in, const float* w, const void* wb, float* out, const float* mask_ref) {
     HeadOuts h{nullptr, 0, nullptr, 0, nullptr};
@@ -1225,19 +1240,37 @@ static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, co
     // bf16 shadow of the output (operand of mh_wgrad_stream): written by the epilogue of the kernel families that have the store, by a cast
     // launch behind the others
     a.shadow = nullptr; a.shadow_ld = (d->N + 31) / 32 * 32; a.shadow_done = 0;
+    a.shadow_lo = nullptr; a.shadow_lo_done = 0;
+    void* const out_lo = head ? head->out_lo : nullptr;
     hipStream_t hs = (hipStream_t)stream;
     int rc;
     if (head && head->query) {
         // mh_conv2d_takes_shadows: would this launch stage the bf16 shadow of its input (and honour the shadow-only options)?  Same dispatch order
         // as below: only the patch-staged input-gradient kernel does.
         if (conv_n1_ok(a) || conv_k1_dgrad_ok(a) || mh_conv_rows_ok(a) || conv_thin_ok(a) || mh_conv_bank_small_ok(a)) return 0;
-        return (mh_conv_patch_ok(a) && a.mode == 1 && a.bf16) ? 1 : 0;
+        if (!(mh_conv_patch_ok(a) && a.mode == 1 && a.bf16)) return 0;
+        // (the same byte bounds as the launch below: a shadow of 2 GiB or more is not staged)
+        const int64_t sbq = (int64_t)d->B * d->Hi * d->Wi * ((d->K + 31) / 32 * 32) * 2, mbq = (int64_t)d->B * d->Ho * d->Wo * ((d->N + 31) / 32 * 32) * 2;
+        if (sbq >= (1ll << 31) - 64) return 0;
+        const bool mask_sh = mask_ref && mbq < (1ll << 31) - 64 && d->mask_c0 == 0 && (d->mask_c1 == 0 || d->mask_c1 == d->N);
+        return 1 | (mask_sh ? 2 : 0);
     }
+    // MH_CONV_IN_F32_STALE / MH_CONV_MASK_F32_STALE: the caller elided the fp32 tensor (only its bf16 shadow is valid): a launch whose kernel would read the
+    // fp32 tensor is refused -- the dispatch is re-decided on every eager replay from process-wide tuning hooks, so a plan recorded under other
+    // settings must fail loudly instead of reading a tensor nobody stored
+    auto stale_ok = [&]() -> bool {
+        if (!head) return true;
+        if ((head->flags & MH_CONV_IN_F32_STALE) && !a.in_shadow) { mh_set_error("mh_conv2d_sh3: the fp32 input was elided (MH_CONV_IN_F32_STALE) but the dispatched kernel does not stage in_shadow"); return false; }
+        if ((head->flags & MH_CONV_MASK_F32_STALE) && mask_ref && !a.mask_shadow) { mh_set_error("mh_conv2d_sh3: the fp32 mask was elided (MH_CONV_MASK_F32_STALE) but the dispatched kernel does not read mask_shadow"); return false; }
+        return true;
+    };
     if (head && (head->out2 || head->out3)) {
         MH_REQUIRE(conv_n1_ok(a), MH_ERR_UNSUPPORTED, "mh_conv2d_head: the layer does not fit the single-output-channel kernel (Cin %% 4, aligned operands, <= 64 KB of weights)");
         a.out2 = head->out2; a.out2_ld = head->out2_ld; a.out3 = head->out3; a.out3_ld = head->out3_ld;
     }
-    if (conv_n1_ok(a)) rc = launch_conv_n1(a, hs);
+    const bool stale_any = head && (head->flags & (MH_CONV_IN_F32_STALE | MH_CONV_MASK_F32_STALE));
+    if (stale_any && (conv_n1_ok(a) || conv_k1_dgrad_ok(a) || (!mh_conv_rows_ok(a) && (conv_thin_ok(a) || mh_conv_bank_small_ok(a))))) { stale_ok(); rc = MH_ERR_UNSUPPORTED; }
+    else if (conv_n1_ok(a)) rc = launch_conv_n1(a, hs);
     else if (conv_k1_dgrad_ok(a)) { a.shadow = (unsigned short*)out_shadow; a.shadow_done = 1; rc = launch_conv_k1_dgrad(a, hs); }
     else if (mh_conv_rows_ok(a)) {
         a.shadow = (unsigned short*)out_shadow; a.shadow_done = 1;
@@ -1249,7 +1282,7 @@ static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, co
                 a.mask_shadow = (const unsigned short*)head->mask_shadow; a.mask_shadow_bytes = (unsigned)mb; a.mask_shadow_ld = (d->N + 31) / 32 * 32;
             }
         }
-        rc = mh_conv_rows_launch(a, hs);
+        rc = stale_ok() ? mh_conv_rows_launch(a, hs) : MH_ERR_UNSUPPORTED;
     }
     else if (conv_thin_ok(a)) rc = launch_conv_thin(a, hs);
     else if (mh_conv_bank_small_ok(a)) { a.shadow = (unsigned short*)out_shadow; a.shadow_done = 1; rc = mh_conv_bank_small_launch(a, hs); }
@@ -1267,13 +1300,19 @@ static int conv_entry(const mh_conv_desc* d, const float* in, const float* w, co
             }
             if ((head->flags & 1) && out_shadow && !d->accumulate) a.no_f32_out = 1;
         }
-        rc = mh_conv_patch_launch(a, hs);
+        rc = stale_ok() ? mh_conv_patch_launch(a, hs) : MH_ERR_UNSUPPORTED;
     }
+    else if (!stale_ok()) rc = MH_ERR_UNSUPPORTED;
     else {
-        if (a.vecC) { a.shadow = (unsigned short*)out_shadow; a.shadow_done = 1; }      // the tiled kernel's vector epilogue has the store
+        if (a.vecC) {      // the tiled kernel's vector epilogue has the stores (hi and, where asked for, lo)
+            a.shadow = (unsigned short*)out_shadow; a.shadow_done = 1;
+            if (out_shadow && out_lo) { a.shadow_lo = (unsigned short*)out_lo; a.shadow_lo_done = 1; }
+        }
         rc = conv_dispatch(a, hs);
     }
-    if (!rc && out_shadow && !a.shadow_done)
+    if (!rc && out_shadow && out_lo && !a.shadow_lo_done)       // a family without the lo store: one split launch behind it (hi rewritten with the same bits)
+        rc = mh_plane_split_one(out, d->out_ld, d->N, out_shadow, out_lo, a.shadow_ld, (int64_t)d->B * d->Ho * d->Wo, hs);
+    else if (!rc && out_shadow && !a.shadow_done)
         rc = mh_shadow_cast_one(out, d->out_ld, d->N, out_shadow, a.shadow_ld, (int64_t)d->B * d->Ho * d->Wo, hs);
     return rc;
 }

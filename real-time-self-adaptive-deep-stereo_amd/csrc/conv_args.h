@@ -6,6 +6,8 @@ struct ConvArgs {
     const float* in; const float* w; const float* bias; float* out; const float* mask_ref;
     const void* wb; unsigned wb_bytes;     // fragment bank of w (mh_pack_weights), or null
     unsigned short* shadow; int shadow_ld; // != null: the epilogue also writes bf16(out) to shadow[pixel][shadow_ld] (operand of mh_wgrad_stream)
+    unsigned short* shadow_lo;             // != null (with shadow): the epilogue also writes bf16(out - bf16(out)): shadow / shadow_lo = the hi / lo planes mh_conv2d_planes reads
+    int shadow_lo_done;                    // set where a kernel family's epilogue wrote it (else conv_entry splits afterwards)
     const unsigned short* in_shadow; unsigned in_shadow_bytes;   // != null: bf16 shadow of `in` (pixel stride = K rounded up to 32, zero padded): the patch-staged
                                                                  // input-gradient kernel stages it as it is instead of converting the fp32 tensor
     const unsigned short* mask_shadow; unsigned mask_shadow_bytes; int mask_shadow_ld;   // != null: the leaky mask reads the bf16 shadow of mask_ref (sign test only)

@@ -228,8 +228,13 @@ __global__ __launch_bounds__(256) void plane_split_kernel(const mh_plane_seg* __
         const float4 a = *reinterpret_cast<const float4*>(s), bq = *reinterpret_cast<const float4*>(s + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = bq.x; v[5] = bq.y; v[6] = bq.z; v[7] = bq.w;
     } else {
+        // channels [C, C + C2) come from the second source (a fused tf.concat: the context network's input = [features | disparity], MadNet.py:123)
+        const float* s2 = sg.src2 ? sg.src2 + pix * sg.src2_ld : nullptr;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (c0 + e < sg.C) ? s[e] : 0.f;
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e;
+            v[e] = c < sg.C ? s[e] : ((s2 && c < sg.C + sg.C2) ? s2[c - sg.C] : 0.f);
+        }
     }
     unsigned hh[4], ll[4];
 #pragma unroll
@@ -264,40 +269,73 @@ int launch_planes(PlanesArgs& a, hipStream_t s, bool attr_only) {
     return mh_check_launch("conv_planes");
 }
 
-// tile variants per (N, K16); v = the tuning hook's variant (0 = heuristic)
-template <int K16>
-int dispatch_planes_k(PlanesArgs& a, hipStream_t s, int v, bool all) {
-    int rc = 0;
-    const int n32 = all ? 0 : mh_cdiv(a.N, 32);
-    // 128 columns: 4 waves side by side; 128-pixel tile (one workgroup per CU) or 64-pixel tile (two)
-    if (all || (n32 == 4 && (v == 0 || v == 1))) { rc = launch_planes<32, 1, 4, 4, K16>(a, s, all); if (!all || rc) return rc; }
-    if (all || (n32 == 4 && v == 2)) { rc = launch_planes<32, 1, 4, 2, K16>(a, s, all); if (!all || rc) return rc; }
-    if (all || (n32 == 4 && v == 3)) { rc = launch_planes<16, 1, 4, 4, K16>(a, s, all); if (!all || rc) return rc; }
-    if (all || (n32 == 4 && v == 4)) { rc = launch_planes<16, 1, 4, 2, K16>(a, s, all); if (!all || rc) return rc; }
-    if (all || (n32 == 3 && (v == 0 || v == 1))) { rc = launch_planes<32, 2, 3, 2, K16>(a, s, all); if (!all || rc) return rc; }
-    if (all || (n32 == 3 && v >= 2)) { rc = launch_planes<16, 2, 3, 2, K16>(a, s, all); if (!all || rc) return rc; }
-    if (all || (n32 == 2 && (v == 0 || v == 1))) { rc = launch_planes<32, 2, 2, 2, K16>(a, s, all); if (!all || rc) return rc; }
-    if (all || (n32 == 2 && v >= 2)) { rc = launch_planes<16, 2, 2, 2, K16>(a, s, all); if (!all || rc) return rc; }
-    if (all || (n32 == 1 && (v == 0 || v == 1))) { rc = launch_planes<32, 4, 1, 1, K16>(a, s, all); if (!all || rc) return rc; }
-    if (all || (n32 == 1 && v >= 2)) { rc = launch_planes<16, 4, 1, 1, K16>(a, s, all); if (!all || rc) return rc; }
-    if (all) return 0;
-    mh_set_error("mh_conv2d_planes: no tile variant for N = %d", a.N);
-    return MH_ERR_UNSUPPORTED;
+// ---- instance table + tile choice ---------------------------------------------------------------------------------------------------------
+// Every (N rounded up to 32, K16) pair has the 128-pixel instances of both M-block shapes; the pairs MADNet's layers use also have 64- / 32-pixel
+// instances for grids that would not fill the chip (the 1/8-resolution level: 60 tiles of 128 pixels on 256 CUs).
+struct PlanesInst { int mc, wm, wn, mbw, k16, lds; int (*launch)(PlanesArgs&, hipStream_t, bool); };
+#define PL_INST(MC, WM, WN, MBW, K16) {MC, WM, WN, MBW, K16, PlanesGeo<MC, WM, WN, MBW, K16>::LDS, &launch_planes<MC, WM, WN, MBW, K16>}
+#define PL_BOTH(WM, WN, MBW, K16) PL_INST(32, WM, WN, MBW, K16), PL_INST(16, WM, WN, MBW, K16)
+#define PL_BASE(K16) PL_BOTH(1, 4, 4, K16), PL_BOTH(2, 3, 2, K16), PL_BOTH(2, 2, 2, K16), PL_BOTH(4, 1, 1, K16)
+const PlanesInst g_planes_inst[] = {
+    PL_BASE(2), PL_BASE(3), PL_BASE(4), PL_BASE(5), PL_BASE(6), PL_BASE(8),
+    // 128 columns: 64- and 32-pixel tiles (K = 33 / 38 / 70 / 128: the estimators' and the context network's first and second layers)
+    PL_BOTH(1, 4, 2, 3), PL_BOTH(1, 4, 2, 5), PL_BOTH(1, 4, 2, 8), PL_BOTH(1, 4, 1, 5), PL_BOTH(1, 4, 1, 8),
+    // 96 columns (128 -> 96): 64 pixels x 3 waves, 32 pixels x 3 waves
+    PL_BOTH(1, 3, 2, 8), PL_BOTH(1, 3, 1, 8),
+    // 64 columns (96 -> 64, 64 -> 64): 64 pixels x 4 waves, 32 pixels x 2 waves
+    PL_BOTH(2, 2, 1, 6), PL_BOTH(2, 2, 1, 4), PL_BOTH(1, 2, 1, 6), PL_BOTH(1, 2, 1, 4),
+    // 32 columns (64 -> 32, 32 -> 32): 64 pixels x 2 waves
+    PL_BOTH(2, 1, 1, 4), PL_BOTH(2, 1, 1, 2),
+};
+constexpr int N_PLANES_INST = sizeof(g_planes_inst) / sizeof(g_planes_inst[0]);
+
+// estimated duration of a launch on 256 CUs, in units of one M-block's K walk: workgroup rounds x (M-blocks per wave x SIMD oversubscription + a
+// fixed share for staging / epilogue / launch that grows as the walk gets shorter).  Measured anchors (profiles/r04_microbench_planes.txt):
+// 240 x 128-pixel tiles = 480 x 64-pixel tiles at 96x320; 60 x 128 pixels is 1.6x slower than 120 x 64 pixels at 48x160; sub-lattices of a dilation
+// whose 32-column tiles spill into a second round (dilation 4: 288 workgroups) lose 1.5x against the 16-column shape (240).
+float planes_cost(const PlanesInst& I, const PlanesArgs& a, int* nwg_out) {
+    const int mr = 32 / I.mc, tr = I.wm * I.mbw * mr, d = a.dil;
+    const int64_t nwg = (int64_t)a.B * d * d * mh_cdiv(mh_cdiv(a.H, d), tr) * mh_cdiv(mh_cdiv(a.W, d), I.mc) * mh_cdiv(a.N, I.wn * 32);
+    const int nw = I.wm * I.wn;
+    int wpc = (160 * 1024) / I.lds;                         // co-resident workgroups per CU: LDS, and at most 8 waves worth scheduling for
+    if (wpc * nw > 8) wpc = 8 / nw > 0 ? 8 / nw : 1;
+    if (wpc < 1) wpc = 1;
+    // round by round: a CU holds min(wpc, what is left / 256) workgroups, its busiest SIMD ceil(workgroups x waves / 4) waves
+    float t = 0.f;
+    for (int64_t left = nwg; left > 0; left -= 256 * wpc) {
+        const int64_t per_cu = (left + 255) / 256 < wpc ? (left + 255) / 256 : wpc;
+        const int64_t simd = (per_cu * nw + 3) / 4;
+        t += (float)I.mbw * (float)simd + 20.f / (float)I.k16;
+    }
+    if (nwg_out) *nwg_out = (int)nwg;
+    return t;
 }
 
 int dispatch_planes(PlanesArgs& a, hipStream_t s, bool all) {
+    if (all) {
+        for (int i = 0; i < N_PLANES_INST; ++i)
+            if (int rc = g_planes_inst[i].launch(a, s, true)) return rc;
+        return 0;
+    }
     const int v = g_planes_mode.load(std::memory_order_relaxed) & 15;
-    const int k16 = all ? 0 : mh_cdiv(a.K, 16);
-    int rc = 0;
-    if (all || k16 == 8) { rc = dispatch_planes_k<8>(a, s, v, all); if (!all || rc) return rc; }
-    if (all || k16 == 6) { rc = dispatch_planes_k<6>(a, s, v, all); if (!all || rc) return rc; }
-    if (all || k16 == 4) { rc = dispatch_planes_k<4>(a, s, v, all); if (!all || rc) return rc; }
-    if (all || k16 == 2) { rc = dispatch_planes_k<2>(a, s, v, all); if (!all || rc) return rc; }
-    if (all || k16 == 3) { rc = dispatch_planes_k<3>(a, s, v, all); if (!all || rc) return rc; }
-    if (all || k16 == 5) { rc = dispatch_planes_k<5>(a, s, v, all); if (!all || rc) return rc; }
-    if (all) return 0;
-    mh_set_error("mh_conv2d_planes: no instance for K = %d (16-channel steps per tap: 2, 3, 4, 5, 6, 8)", a.K);
-    return MH_ERR_UNSUPPORTED;
+    const int k16 = mh_cdiv(a.K, 16), n32 = mh_cdiv(a.N, 32);
+    // forced variants (mh_tune_conv_planes): 1 / 2 / 5 = 128- / 64- / 32-pixel tiles of 32-column M-blocks, 3 / 4 / 6 = the same of 16-column M-blocks
+    const int want_mc = (v == 3 || v == 4 || v == 6) ? 16 : 32, want_px = (v == 1 || v == 3) ? 128 : ((v == 2 || v == 4) ? 64 : 32);
+    const PlanesInst* best = nullptr;
+    float best_cost = 0.f;
+    for (int i = 0; i < N_PLANES_INST; ++i) {
+        const PlanesInst& I = g_planes_inst[i];
+        if (I.k16 != k16 || I.wn != n32) continue;
+        float c = planes_cost(I, a, nullptr);
+        if (v != 0) c = (I.mc == want_mc ? 0.f : 1000.f) + (float)abs(I.wm * I.mbw * 32 - want_px);        // forced: the closest available shape
+        else c -= 1e-3f * (float)(I.wm * I.mbw) + (I.mc == 32 ? 5e-4f : 0.f);                                // ties: the larger tile, then the one-row M-block
+        if (!best || c < best_cost) { best = &I; best_cost = c; }
+    }
+    if (!best) {
+        mh_set_error("mh_conv2d_planes: no instance for K = %d, N = %d (16-channel steps per tap: 2, 3, 4, 5, 6, 8; N <= 128)", a.K, a.N);
+        return MH_ERR_UNSUPPORTED;
+    }
+    return best->launch(a, s, false);
 }
 
 }  // namespace
@@ -314,6 +352,30 @@ extern "C" int mh_tune_conv_planes(int mode) {
 
 extern "C" int64_t mh_pack32_bytes(int32_t taps, int32_t K, int32_t N) {
     return (int64_t)taps * ((K + 15) / 16) * ((N + 31) / 32) * 2048;
+}
+
+static __global__ __launch_bounds__(256) void plane_split_one_kernel(mh_plane_seg sg) {
+    const int g8 = sg.dst_ld >> 3;
+    const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (item >= sg.npix * g8) return;
+    const int64_t pix = item / g8;
+    const int c0 = (int)(item - pix * g8) * 8;
+    const float* s = sg.src + pix * sg.src_ld + c0;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (c0 + e < sg.C) ? s[e] : 0.f;
+    unsigned hh[4], ll[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mh_split_bf16x2(v[2 * e], v[2 * e + 1], hh[e], ll[e]);
+    *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(sg.hi) + pix * sg.dst_ld + c0) = (u32x4){hh[0], hh[1], hh[2], hh[3]};
+    if (sg.lo) *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(sg.lo) + pix * sg.dst_ld + c0) = (u32x4){ll[0], ll[1], ll[2], ll[3]};
+}
+// one tensor, arguments by value (the fallback of mh_conv2d_sh4 for kernel families whose epilogue does not write the lo plane)
+int mh_plane_split_one(const float* src, int src_ld, int C, void* hi, void* lo, int dst_ld, int64_t npix, hipStream_t s) {
+    mh_plane_seg sg = {};
+    sg.src = src; sg.hi = hi; sg.lo = lo; sg.npix = npix; sg.C = C; sg.src_ld = src_ld; sg.dst_ld = dst_ld;
+    hipLaunchKernelGGL(plane_split_one_kernel, dim3((unsigned)((npix * (dst_ld / 8) + 255) / 256)), dim3(256), 0, s, sg);
+    return mh_check_launch("plane_split_one");
 }
 
 extern "C" int mh_plane_split(const mh_plane_seg* segs_device, int32_t nseg, int32_t nblocks, void* stream) {

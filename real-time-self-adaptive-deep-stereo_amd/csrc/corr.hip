@@ -170,6 +170,7 @@ struct FrontArgs {
     int l_ld, r_ld, out_ld, rw_ld, coff;
     int B, H, W, C, md, D, zero_tail;
     unsigned l_bytes, r_bytes;
+    unsigned short* out_hi; unsigned short* out_lo; int out_pld;      // != null: the estimator input also leaves as bf16 planes (hi [+ lo])
 };
 
 template <int LPP, int DT>
@@ -234,6 +235,13 @@ __global__ __launch_bounds__(256) void level_front_kernel(FrontArgs p) {
             bb[j] = mh_buf_load4(rsR, o1[j] == MH_OOB ? MH_OOB : o1[j] + c4 * 16);
         }
         if (live) *reinterpret_cast<float4*>(Op + c4 * 4) = l;
+        if (live && p.out_hi) {
+            uint2 hi, lo;
+            mh_split_bf16x2(l.x, l.y, hi.x, lo.x);
+            mh_split_bf16x2(l.z, l.w, hi.y, lo.y);
+            *reinterpret_cast<uint2*>(p.out_hi + (int64_t)pp * p.out_pld + c4 * 4) = hi;
+            if (p.out_lo) *reinterpret_cast<uint2*>(p.out_lo + (int64_t)pp * p.out_pld + c4 * 4) = lo;
+        }
 #pragma unroll
         for (int j = 0; j < DT; ++j) {
             float4 r;
@@ -256,6 +264,12 @@ __global__ __launch_bounds__(256) void level_front_kernel(FrontArgs p) {
             for (int j = 0; j < DT; ++j) v = (e == j) ? accd[j] * inv_c : v;
             if (e == p.D) v = uc;
             Op[p.coff + e] = v;
+            if (p.out_hi && e <= p.D) {
+                unsigned hi, lo;
+                mh_split_bf16x2(v, 0.f, hi, lo);
+                p.out_hi[(int64_t)pp * p.out_pld + p.coff + e] = (unsigned short)hi;
+                if (p.out_lo) p.out_lo[(int64_t)pp * p.out_pld + p.coff + e] = (unsigned short)lo;
+            }
         }
         if (sub == 0) p.u[pp] = uc;
     }
@@ -865,6 +879,15 @@ extern "C" int mh_corr_fwd_prec(const float* L, int32_t l_ld, const float* R, in
 extern "C" int mh_level_front_fwd(const float* Vc, int32_t Hc, int32_t Wc, float mul, const float* L, int32_t l_ld, const float* R,
                                   int32_t r_ld, float* out, int32_t out_ld, int32_t coff, float* Rw, int32_t rw_ld, float* u,
                                   int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t zero_tail, void* stream) {
+    return mh_level_front_fwd_planes(Vc, Hc, Wc, mul, L, l_ld, R, r_ld, out, out_ld, coff, Rw, rw_ld, u, B, H, W, C, max_disp, zero_tail, nullptr, nullptr, 0, stream);
+}
+extern "C" int mh_level_front_fwd_planes(const float* Vc, int32_t Hc, int32_t Wc, float mul, const float* L, int32_t l_ld, const float* R,
+                                         int32_t r_ld, float* out, int32_t out_ld, int32_t coff, float* Rw, int32_t rw_ld, float* u,
+                                         int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t zero_tail,
+                                         void* out_hi, void* out_lo, int32_t out_pld, void* stream) {
+    MH_REQUIRE(!out_lo || out_hi, MH_ERR_ARG, "mh_level_front_fwd_planes: the lo plane needs the hi plane");
+    MH_REQUIRE(!out_hi || (out_pld >= coff + 2 * max_disp + 2 && (out_pld & 3) == 0 && (((uintptr_t)out_hi) & 7u) == 0 && (((uintptr_t)out_lo) & 7u) == 0), MH_ERR_ARG,
+               "mh_level_front_fwd_planes: out_pld must cover coff + D + 1 (multiple of 4), planes 8-byte aligned");
     MH_REQUIRE(Vc && L && R && out && Rw && u, MH_ERR_ARG, "mh_level_front_fwd: null argument");
     MH_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && Hc > 0 && Wc > 0 && max_disp >= 0, MH_ERR_ARG, "mh_level_front_fwd: bad dimension");
     const int D = 2 * max_disp + 1;
@@ -881,6 +904,7 @@ extern "C" int mh_level_front_fwd(const float* Vc, int32_t Hc, int32_t Wc, float
     a.l_ld = l_ld; a.r_ld = r_ld; a.out_ld = out_ld; a.rw_ld = rw_ld; a.coff = coff;
     a.B = B; a.H = H; a.W = W; a.C = C; a.md = max_disp; a.D = D; a.zero_tail = zero_tail;
     a.l_bytes = (unsigned)lb; a.r_bytes = (unsigned)rb;
+    a.out_hi = (unsigned short*)out_hi; a.out_lo = (unsigned short*)out_lo; a.out_pld = out_pld;
     hipStream_t s = (hipStream_t)stream;
     const int C4 = C / 4;
     auto grid = [&](int lpp) { return dim3((unsigned)((npix * lpp + 255) / 256)); };

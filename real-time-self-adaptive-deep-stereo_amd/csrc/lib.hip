@@ -108,8 +108,10 @@ static int run_op(const mh_op& o, void* s) {
     switch (o.kind) {
         case MH_OP_CONV: {
             mh_conv_desc d; desc_from_op(o, d);
-            if (i[23] & 6) return mh_conv2d_sh3(&d, (const float*)p[0], (i[23] & 1) ? p[5] : nullptr, (const float*)p[1], p[6], nullptr, (float*)p[3], (const float*)p[4],
-                                              (i[23] & 2) ? p[2] : nullptr, p[7], (i[23] & 4) ? MH_CONV_SHADOW_ONLY : 0, s);      // (input gradients carry no bias: p[2] = mask shadow)
+            if (i[23] & 32) return mh_conv2d_sh4(&d, (const float*)p[0], (const float*)p[1], p[6], (const float*)p[2], (float*)p[3], (const float*)p[4], p[7], p[5], s);
+            if (i[23] & 30) return mh_conv2d_sh3(&d, (const float*)p[0], (i[23] & 1) ? p[5] : nullptr, (const float*)p[1], p[6], nullptr, (float*)p[3], (const float*)p[4],
+                                              (i[23] & 2) ? p[2] : nullptr, p[7],
+                                              ((i[23] & 4) ? MH_CONV_SHADOW_ONLY : 0) | ((i[23] & 8) ? MH_CONV_IN_F32_STALE : 0) | ((i[23] & 16) ? MH_CONV_MASK_F32_STALE : 0), s);      // (input gradients carry no bias: p[2] = mask shadow)
             if (i[23]) return mh_conv2d_sh2(&d, (const float*)p[0], p[5], (const float*)p[1], p[6], (const float*)p[2], (float*)p[3], (const float*)p[4], p[7], s);
             if (p[7]) return mh_conv2d_sh(&d, (const float*)p[0], (const float*)p[1], p[6], (const float*)p[2], (float*)p[3], (const float*)p[4], p[7], s);
             if (p[6]) return mh_conv2d_wb(&d, (const float*)p[0], (const float*)p[1], p[6], (const float*)p[2], (float*)p[3], (const float*)p[4], s);
@@ -157,6 +159,8 @@ static int run_op(const mh_op& o, void* s) {
             mh_conv_desc d; desc_from_op(o, d);
             return mh_conv2d_planes(&d, p[0], p[1], i[23], p[2], (const float*)p[3], (float*)p[4], p[5], p[6], i[24], s);
         }
+        case MH_OP_STAMP:
+            return mh_stamp(p[0], s);
         case MH_OP_PLANE_SPLIT:
             return mh_plane_split((const mh_plane_seg*)p[0], i[0], i[1], s);
         case MH_OP_PACK_W:
@@ -181,8 +185,8 @@ static int run_op(const mh_op& o, void* s) {
             return mh_resize_bwd((const float*)p[0], (const float*)p[1], (float*)p[2], i[10], i[0], i[1], i[2], i[3], i[4], i[5], i[6],
                                  i[7], i[8], o.f[0], i[9], s);
         case MH_OP_LEVEL_FRONT:
-            return mh_level_front_fwd((const float*)p[0], i[0], i[1], o.f[0], (const float*)p[1], i[2], (const float*)p[2], i[3], (float*)p[3],
-                                      i[4], i[5], (float*)p[4], i[6], (float*)p[5], i[7], i[8], i[9], i[10], i[11], i[12], s);
+            return mh_level_front_fwd_planes((const float*)p[0], i[0], i[1], o.f[0], (const float*)p[1], i[2], (const float*)p[2], i[3], (float*)p[3],
+                                             i[4], i[5], (float*)p[4], i[6], (float*)p[5], i[7], i[8], i[9], i[10], i[11], i[12], p[6], p[7], i[13], s);
         case MH_OP_RESIZE_IMAGE:
             return mh_resize_image_fwd((const float*)p[0], (float*)p[1], i[0], i[1], i[2], i[3], i[4], i[5], s);
         case MH_OP_PAD_REFLECT:

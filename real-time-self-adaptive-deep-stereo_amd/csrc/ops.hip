@@ -1084,6 +1084,22 @@ extern "C" int mh_bias_grad(const float* dz, int32_t dz_ld, int64_t npix, int32_
     return mh_check_launch("bias_grad");
 }
 
+// device time stamp (diagnostics of the replayed step: where the side lane starts, how long the tail behind the last input gradient is):
+// one lane stores the constant-rate wall clock (s_memrealtime, 100 MHz on gfx950) into a slot.  A plan op like any other, so the stamp sits at
+// its place in the captured graph and needs no tracer (rocprofv3 shifts the side queue by ~0.3 ms: profiles/r03_experiments.txt #3).
+__global__ void stamp_kernel(long long* slot) { *slot = wall_clock64(); }
+extern "C" int mh_stamp(void* slot, void* stream) {
+    MH_REQUIRE(slot && (((uintptr_t)slot) & 7u) == 0, MH_ERR_ARG, "mh_stamp: 8-byte aligned slot");
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long*)slot);
+    return mh_check_launch("stamp");
+}
+extern "C" int64_t mh_stamp_rate_khz(void) {
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return 0;
+    return khz;
+}
+
 extern "C" int mh_fill(float* p, int64_t n, float v, void* stream) {
     MH_REQUIRE(p && n > 0, MH_ERR_ARG, "mh_fill: bad argument");
     hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, n, v);

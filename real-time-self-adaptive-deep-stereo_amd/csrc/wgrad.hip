@@ -986,28 +986,43 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const mh_wgrad_seg* _
     }
     const mh_wgrad_seg sg = segs[lo];
     if (sg.size <= 1024 && sg.splits >= 32 && (sg.size & 3) == 0) {
-        // a small gradient with many splits (the 3-channel image layer: 432 values x 167 splits) is ONE block here: instead of ~100 threads walking
-        // every split (a chain of dependent loads: 22 us), the block's 256 threads share the splits of 64 elements at a time and meet in LDS
+        // a small gradient with many splits (the 3-channel image layer: 432 values x 167 splits) is ONE block here.  Round 3 walked the splits of 64
+        // elements at a time, 16 split groups deep: seven passes of ~11 DEPENDENT loads = 27 us at the very end of the step (device time stamps,
+        // round 4).  Now every float4 column of the gradient gets 256 / columns split groups at once and a thread keeps 8 loads in flight:
+        // 108 columns x 2 groups x 84 splits = 11 round trips.
         __shared__ float4 part[256];
-        for (int base = 0; base < sg.size; base += 64) {
-            const int e4 = threadIdx.x & 15, grp = threadIdx.x >> 4;      // 16 float4 columns x 16 split groups
-            const int e = base + e4 * 4;
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < sg.size)
-                for (int sp = grp; sp < sg.splits; sp += 16) {
-                    const float4 v = *reinterpret_cast<const float4*>(sg.ws + (int64_t)sp * sg.size + e);
-                    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
-                }
-            part[threadIdx.x] = t;
-            __syncthreads();
-            if (threadIdx.x < 16 && e < sg.size) {
-                float4 u = part[threadIdx.x];
-                for (int g2 = 1; g2 < 16; ++g2) { const float4 v = part[g2 * 16 + threadIdx.x]; u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w; }
-                float* d = sg.dst + e;
-                if (sg.accumulate) { d[0] += u.x; d[1] += u.y; d[2] += u.z; d[3] += u.w; }
-                else { d[0] = u.x; d[1] = u.y; d[2] = u.z; d[3] = u.w; }
+        const int ncol = sg.size >> 2;                                  // <= 256 float4 columns
+        const int G = 256 / ncol;                                       // split groups (>= 1)
+        const int col = threadIdx.x % ncol, grp = threadIdx.x / ncol;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (grp < G) {
+            const float* src = sg.ws + col * 4;
+            float4 acc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            int sp = grp;
+            for (; sp + 7 * G < sg.splits; sp += 8 * G) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (int64_t)(sp + u * G) * sg.size);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { acc[u].x += v[u].x; acc[u].y += v[u].y; acc[u].z += v[u].z; acc[u].w += v[u].w; }
             }
-            __syncthreads();
+            for (; sp < sg.splits; sp += G) {
+                const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)sp * sg.size);
+                acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { t.x += acc[u].x; t.y += acc[u].y; t.z += acc[u].z; t.w += acc[u].w; }
+        }
+        part[threadIdx.x] = t;
+        __syncthreads();
+        if (threadIdx.x < ncol) {
+            float4 u = part[threadIdx.x];
+            for (int g2 = 1; g2 < G; ++g2) { const float4 v = part[g2 * ncol + threadIdx.x]; u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w; }
+            float* d = sg.dst + threadIdx.x * 4;
+            if (sg.accumulate) { d[0] += u.x; d[1] += u.y; d[2] += u.z; d[3] += u.w; }
+            else { d[0] = u.x; d[1] = u.y; d[2] = u.z; d[3] = u.w; }
         }
         return;
     }

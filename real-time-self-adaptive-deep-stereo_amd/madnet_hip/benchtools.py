@@ -220,3 +220,47 @@ def op_work(op):
     B, Hi, Wi, Ho, Wo, K, N, kh, kw, mode = i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7], i[8], i[13]
     pix = Ho * Wo if (mode == 0 or op.kind != _ffi.OP_CONV) else Hi * Wi
     return 2.0 * B * pix * kh * kw * K * N, 4.0 * (B * Hi * Wi * K + B * Ho * Wo * N + kh * kw * K * N)
+
+
+def tail_stamps(lib, E, mk, feed, args, dev, plain_ms):
+    """Where the replayed step spends its end: a STAMPED copy of the plan (engine.STAMPS: mh_stamp ops at the start, the end of
+    the forward pass, the side lane's first op, the start / end of every filter-gradient batch, the end of the input-gradient chain, the join, the
+    end) is captured and replayed args.stamps times; all times in us from the step's first op, median over the replays.  No tracer involved: the
+    stamps are kernels of the graph itself (each costs the chain one ~2-5 us launch, `stamped_ms_per_step` tells by how much)."""
+    import numpy as np
+    E.STAMPS = True
+    try:
+        e = mk(args.precision); feed(e)
+        plan = e.build_plan(args.mode, lr=1e-4)
+    finally:
+        E.STAMPS = False
+    labels = list(e.stamp_labels)
+    rate_khz = float(lib.stamp_rate_khz()) or 1e5
+    rows = []
+    with dev.ctx():
+        plan.run(lib, dev.sh); dev.sync_stream()
+        plan.capture(lib, dev.sh)
+        for _ in range(5):
+            plan.launch(lib, dev.sh)
+        dev.sync_stream()
+        ms = _time_ms(lib, dev.stream, lambda: plan.launch(lib, dev.sh), 50)
+        for _ in range(args.stamps):
+            plan.launch(lib, dev.sh); dev.sync_stream()
+            rows.append(e.stamps[:len(labels)].cpu().numpy().astype(np.float64))
+    t = np.median(np.stack(rows), axis=0)
+    us = (t - t[0]) * 1e3 / rate_khz
+    at = {lab: float(u) for (lab, _), u in zip(labels, us)}
+    out = {"stamps_us": [{"label": lab, "lane": lane, "t_us": float(u)} for (lab, lane), u in zip(labels, us)],
+           "stamped_ms_per_step": ms, "plain_ms_per_step": plain_ms, "replays": args.stamps, "clock_khz": rate_khz}
+    if "chain_end" in at and "end" in at:
+        out["tail_us"] = at["end"] - at["chain_end"]                      # everything behind the last input gradient
+        out["join_wait_us"] = at.get("joined", at["chain_end"]) - at["chain_end"]      # of it: lane 0 idle, waiting for the side lane
+    if "side_lane_first_op" in at:
+        out["side_lane_start_us"] = at["side_lane_first_op"]
+    b = sorted((lab, u) for lab, u in at.items() if lab.startswith("wgrad_batch"))
+    if b:
+        out["first_wgrad_batch_start_us"] = min(u for lab, u in b if lab.endswith("_start"))
+        out["last_wgrad_batch_end_us"] = max(u for lab, u in b if lab.endswith("_end"))
+    if "forward_end" in at:
+        out["forward_us"] = at["forward_end"]
+    return out

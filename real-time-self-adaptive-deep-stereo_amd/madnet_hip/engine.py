@@ -106,6 +106,27 @@ FUSE_HEAD = True
 # FULL momentum steps: every filter-gradient batch is followed by the momentum update of its layers on its own lane, the launch behind the join covers
 # only what is left.  OFF: prepared at the end of round 3 and never timed on the MI355X (profiles/r03_experiments.txt #26; bench.py --set engine.EARLY_UPDATE=True)
 EARLY_UPDATE = False
+# The step's tail (device time stamps, bench.py --stamps, round 4): the last filter-gradient batch (conv4 .. conv1) could only start behind the LAST input
+# gradient -- conv1's filter gradient reads what conv2's input gradient writes -- so lane 0 sat idle for 91 us behind the chain (batch 76 us + join).
+# TAIL_SPLIT: the filter gradients of conv4 .. conv2 (their operands are final one layer earlier) leave as a batch of their own BEFORE conv2's input
+# gradient is launched and run beside it; only conv1's (the 3-channel image layer) is left for the tail.
+TAIL_SPLIT = True
+# ... and that last batch (conv1's filter gradient + its split reduction) runs on a side lane of its own, so it starts the moment conv2's input gradient
+# ends instead of queueing behind the conv4 .. conv2 batch on the filter-gradient lane (0 = same lane).  Its slice of the gradient buffer is zeroed on
+# that lane too (first op of the backward pass): everything that touches those floats stays in ONE lane's order.
+TAIL_LANE = 2
+# 'mixed': the split-bf16 forward layers (stride-1 3x3, > bank_small_maxpix pixels) run from PRE-SPLIT operands (mh_conv2d_planes, csrc/conv_planes.hip):
+# activations as hi / lo bf16 planes -- hi is the shadow the backward pass reads anyway -- written by the producer's epilogue, staged by LDS DMA
+USE_PLANES = os.environ.get("MH_CONV_PLANES", "1") != "0"
+# ... and the fp32 copy of such an activation is not stored when no op of the plan reads it (engine._elide_fp32_activations)
+PLANES_ONLY = True
+# ... and the planes of tensors no plane kernel produces are written by THEIR producers (the level front end, the exact-fp32 layers in front of conv4 /
+# conv6, one concat-split for the context network's input) instead of by a split launch in front of every consumer
+FUSE_SPLITS = True
+# diagnostics (bench.py --stamps): device time stamps (mh_stamp) recorded as plan ops at the start of the step, the end of the forward pass, the first
+# op of the side lane, the start / end of every filter-gradient batch, the end of the input-gradient chain, the join and the end of the step --
+# the REPLAYED graph timed from the inside, without a tracer.  Each stamp is a one-lane kernel: the stamped plan is a few us slower than the plain one.
+STAMPS = False
 # input gradients stage the bf16 shadow of dz when the previous input gradient's epilogue wrote one (mh_conv2d_sh2)
 SHADOW_DGRAD = True
 # ... and then do not store the fp32 gradient map at all when its only reader is such an input gradient (engine._elide_fp32_gradient_maps)
@@ -211,6 +232,10 @@ class MadNetEngine(object):
         self.fuse_shadows = True
         self._fresh = set()                 # shadows a producer wrote in the plan being recorded
         self._stream_train = set()          # trainable variables of that plan
+        self.use_planes = self.use_bank and precision == "mixed" and USE_PLANES
+        self.banks32 = {}                   # layer -> fragment bank in the 32x32x16 image (mh_pack_weights trans = 2)
+        self.planes = {}                    # (data pointer, B, H, W, C) -> ops.Planes (hi = the entry of self.shadows)
+        self._fresh_planes = set()          # planes (hi AND lo) a producer wrote in the plan being recorded
 
     # ---------------------------------------------------------------------------------------
     def _buf(self, *shape):
@@ -356,7 +381,9 @@ class MadNetEngine(object):
             if kh != 3:
                 continue
             small = pix <= self.bank_small_maxpix and 9 * ((K + 31) // 32) <= 64
-            if code == 2 and N >= 16 and K >= 16 and (small or (N >= self.bank_min_n and K >= self.bank_min_n)):
+            if code == 2 and not small and n not in stride2 and self._planes_layer(K, N):
+                plan.append((n, 2, 2))
+            elif code == 2 and N >= 16 and K >= 16 and (small or (N >= self.bank_min_n and K >= self.bank_min_n)):
                 plan.append((n, 2, 0))
             elif code == 1 and small and N >= 16 and K >= 16:
                 plan.append((n, 1, 0))
@@ -366,25 +393,83 @@ class MadNetEngine(object):
                 plan.append((n, 1, 1))
         return plan
 
+    def _stamp(self, lib, label):
+        if not STAMPS or not hasattr(lib, "stamp"):
+            return
+        if getattr(self, "stamps", None) is None:
+            self.stamps = torch.zeros(64, dtype=torch.int64, device=self.dev)
+        self.stamp_labels.append((label, getattr(lib, "lane", 0)))
+        ops.stamp(lib, self.stamps, len(self.stamp_labels) - 1)
+
+    def _planes_layer(self, K, N):
+        """does mh_conv2d_planes have an instance for a stride-1 3x3 layer with K input / N output channels?  (csrc/conv_planes.hip)"""
+        return self.use_planes and N % 8 == 0 and N <= 128 and ((K + 15) // 16) in (2, 3, 4, 5, 6, 8)
+
+    def _bank_of(self, trans):
+        return {0: self.banks, 1: self.banks_d, 2: self.banks32}[trans]
+
+    def _planes_of(self, v):
+        """the Planes object of View v (allocated on first use; its hi plane is v's Shadow)"""
+        key = (v.ptr, v.B, v.H, v.W, v.C)
+        pl = self.planes.get(key)
+        if pl is None:
+            sh = self.shadows.get(key)
+            if sh is None:
+                sh = self.shadows[key] = ops.Shadow(v.B, v.H, v.W, v.C, self.dev)
+            pl = self.planes[key] = ops.Planes(sh, self.dev)
+        return key, pl
+
+    def _in_planes(self, lib, v, r):
+        """planes of an input View: as a producer of this plan left them, else split here (one launch; tensors no plane-writing kernel produces)"""
+        key, pl = self._planes_of(v)
+        if key not in self._fresh_planes:
+            ops.plane_split(lib, [(v, pl)], self.dev, r.keep)
+            self._fresh_planes.add(key)
+            self._fresh.add(key)                # the hi plane is the tensor's bf16 shadow: no cast in the backward pass
+        return pl
+
+    def _conv_fwd(self, lib, r, x, base, o, stride=1, dil=1, alpha=ALPHA, precision=None, shadow_consumer=None):
+        """forward conv of layer `base`: from planes (mh_conv2d_planes) where the layer has a 32x32x16 bank, else the fp32-operand kernels"""
+        wb32 = self.banks32.get(base) if stride == 1 else None
+        if wb32 is not None:
+            xp = self._in_planes(lib, x, r)
+            key, op_ = self._planes_of(o)
+            ops.conv2d_planes(lib, xp, self.W_(base), wb32, self.b_(base), out=o, out_planes=op_, dil=dil, alpha=alpha)
+            self._fresh_planes.add(key)
+            self._fresh.add(key)
+            return
+        if shadow_consumer and shadow_consumer in self.banks32 and FUSE_SPLITS:
+            # the consumer runs from planes: this layer's epilogue writes them (mh_conv2d_sh4) instead of a split launch in front of the consumer
+            key, op_ = self._planes_of(o)
+            ops.conv2d_fwd(lib, x, self.W_(base), self.b_(base), o, stride=stride, dil=dil, alpha=alpha, wb=self.Wb_(base), precision=precision,
+                           out_planes=op_)
+            self._fresh_planes.add(key)
+            self._fresh.add(key)
+            return
+        sh = self._out_shadow(o, shadow_consumer) if shadow_consumer else None
+        ops.conv2d_fwd(lib, x, self.W_(base), self.b_(base), o, stride=stride, dil=dil, alpha=alpha,
+                       wb=self.Wb_(base), precision=precision, shadow=sh)
+
     def record_forward(self, r, make_disps=()):
         B, lib = self.B, r
         head2_fused = False
+        self._fresh_planes = set()
+        self._stamp(lib, "start")
         if self.use_bank:
             plan = self._bank_plan()
             for n, planes, trans in plan:
-                tgt = self.banks_d if trans else self.banks
+                tgt = self._bank_of(trans)
                 if n not in tgt:
                     tgt[n] = torch.zeros(ops.pack_bytes(self.W_(n), planes, trans) // 4, device=self.dev)
             # (in line: on a side lane beside the first pyramid layers, which read no bank, it measured no gain -- profiles/r03_experiments.txt)
-            ops.pack_weights(lib, [(self.W_(n), (self.banks_d if trans else self.banks)[n], planes, trans) for n, planes, trans in plan],
+            ops.pack_weights(lib, [(self.W_(n), self._bank_of(trans)[n], planes, trans) for n, planes, trans in plan],
                              self.dev, r.keep)
         ops.pad_reflect(lib, self.lr, self.X0, self.pt, self.pl)
         x = ops.View(self.X0, 2 * B, self.Hp, self.Wp, 3, 4)
         for i, (ci, co, s) in enumerate(PYR, 1):
             o = self._fv(self.F[i])
-            sh = self._out_shadow(o, pyr_name(i + 1)) if i < 12 else None       # F_i is the input of layer i + 1 (stride 1 or 2: both streamed)
-            ops.conv2d_fwd(lib, x, self.W_(pyr_name(i)), self.b_(pyr_name(i)), o, stride=s, alpha=ALPHA,
-                           wb=self.Wb_(pyr_name(i)), precision=self._pyr_code(i), shadow=sh)
+            # F_i is the input of layer i + 1 (stride 1 or 2: both streamed)
+            self._conv_fwd(lib, r, x, pyr_name(i), o, stride=s, precision=self._pyr_code(i), shadow_consumer=(pyr_name(i + 1) if i < 12 else None))
             x = o
         for k in LEVELS:
             f = FEAT[k]
@@ -396,7 +481,17 @@ class MadNetEngine(object):
             fused = k != 6 and self._front_fused()
             if fused:
                 # u_k = resize(V_{k+1}) * 20 / 2^k (MadNet.py:274), warp, cost volume + concat: one launch
-                ops.level_front_fwd(lib, self.V[k + 1], 20.0 / 2 ** k, Lk, Rk, dsi, self._fv(self.Rw[k]), self.u[k], self.md, coff=c)
+                xin = ops.View(self.dsi[k], B, h, w, c + self.D + 1, ld)
+                pl = None
+                if FUSE_SPLITS and self.use_planes and self.cstride == 1:
+                    key, pl_ = self._planes_of(xin)
+                    if est_name(k, 1) in self.banks32:
+                        pl = pl_                                  # hi + lo: the estimator's first layer runs from planes
+                        self._fresh_planes.add(key); self._fresh.add(key)
+                    elif (est_name(k, 1) + "/weights") in self._stream_train and self.use_stream and self.partial_wgrad and ops._bwd_precision() == 1:
+                        pl = pl_.hi                               # hi only: the shadow its streamed filter gradient reads (no cast in the backward pass)
+                        self._fresh.add(key)
+                ops.level_front_fwd(lib, self.V[k + 1], 20.0 / 2 ** k, Lk, Rk, dsi, self._fv(self.Rw[k]), self.u[k], self.md, coff=c, planes=pl)
             else:
                 if k != 6 and self.warping:
                     ops.warp_fwd(lib, Rk, self.u[k], self._fv(self.Rw[k]))
@@ -421,9 +516,8 @@ class MadNetEngine(object):
                     head2_fused = True
                     x = o
                     continue
-                ops.conv2d_fwd(lib, x, self.W_(est_name(k, j + 1)), self.b_(est_name(k, j + 1)), o,
-                               alpha=(1.0 if last else ALPHA), precision=fprec,
-                               wb=self.Wb_(est_name(k, j + 1)), shadow=(None if last else self._out_shadow(o, est_name(k, j + 2))))
+                self._conv_fwd(lib, r, x, est_name(k, j + 1), o, alpha=(1.0 if last else ALPHA), precision=fprec,
+                               shadow_consumer=(None if last else est_name(k, j + 2)))
                 x = o
             if k != 2:
                 sc = 2 ** (k - 1)
@@ -434,14 +528,21 @@ class MadNetEngine(object):
         # context network (MadNet._stereo_context_net, MadNet.py:122-171)
         h, w, c = self.fshape[4]
         cin = ops.View(self.ctx_in, B, h, w, c + 1, self.ctx_ld)
-        ops.copy_channels(lib, self._half(self.F[4], False), cin.slice(0, c))
-        if not head2_fused:
-            ops.copy_channels(lib, self._fv(self.V[2]), cin.slice(c, c + 1))
+        concat_split = FUSE_SPLITS and ctx_name(1) in self.banks32 and self.use_stream and self.partial_wgrad
+        if concat_split:
+            # the planes of tf.concat([left features, V2]) straight from the two sources: the first layer takes the planes, its streamed filter gradient
+            # the hi plane, its input gradient has no mask -- nothing reads an fp32 copy of the concatenation
+            key, pl = self._planes_of(cin)
+            ops.plane_split(lib, [((self._half(self.F[4], False), self._fv(self.V[2])), pl)], self.dev, r.keep)
+            self._fresh_planes.add(key); self._fresh.add(key)
+        else:
+            ops.copy_channels(lib, self._half(self.F[4], False), cin.slice(0, c))
+            if not head2_fused:
+                ops.copy_channels(lib, self._fv(self.V[2]), cin.slice(c, c + 1))
         x = cin
         for j, (co, rate) in enumerate(CTX[:-1]):
             o = self._fv(self.Cx[j])
-            ops.conv2d_fwd(lib, x, self.W_(ctx_name(j + 1)), self.b_(ctx_name(j + 1)), o, dil=rate, alpha=ALPHA,
-                           wb=self.Wb_(ctx_name(j + 1)), shadow=self._out_shadow(o, ctx_name(j + 2)))
+            self._conv_fwd(lib, r, x, ctx_name(j + 1), o, dil=rate, shadow_consumer=ctx_name(j + 2))
             x = o
         # final_disp = V2_init + context7  (accumulating epilogue)
         if not head2_fused:
@@ -451,6 +552,7 @@ class MadNetEngine(object):
             self._make_disp(lib, self.final, self.disp_k[2])
         # rescaled_prediction: relu AFTER resize (MadNet.py:362-364)
         ops.resize_fwd(lib, self.final, self.pred, self.Hp, self.Wp, self.pt, self.pl, mul=-20.0, mode=2)
+        self._stamp(lib, "forward_end")
 
     def _shadow(self, v, casts):
         """the bf16 shadow of View v (allocated on first use); queues its cast unless the producing kernel wrote it (self._fresh) or this
@@ -501,6 +603,8 @@ class MadNetEngine(object):
             if o.kind == _ffi.OP_CONV and o.i[13] == 1 and o.p[7] and not o.i[18] and o.i[22] == 1 and o.p[3]:
                 spans.append((idx, int(o.p[3]), int(o.p[3]) + 4 * o.i[0] * o.i[3] * o.i[4] * o.i[16]))
         for idx, lo, hi in spans:
+            if any(a < hi and lo < a + nb for _, a, nb in getattr(r, "refs", ())):
+                continue                # a device table (cast / split segment) reads the map
             users = []
             for j, q in enumerate(ops_):
                 if j == idx:
@@ -514,10 +618,72 @@ class MadNetEngine(object):
                 continue
             if sum(1 for k in range(8) if c.p[k] and lo <= int(c.p[k]) < hi) != 1:
                 continue
-            d = _ffi.ConvDesc(*([c.i[k] for k in range(18)] + [c.i[18], c.f[0], c.f[1], c.i[19], c.i[20], c.i[22]]))
-            if self.lib.conv2d_takes_shadows(C.byref(d), C.c_void_p(c.p[0]), C.c_void_p(c.p[1]), C.c_void_p(c.p[6]), C.c_void_p(c.p[3]), C.c_void_p(c.p[4])) != 1:
+            if not (self._takes_shadows(c) & 1):
                 continue
             ops_[idx].i[23] |= 4
+            c.i[23] |= 8            # MH_CONV_IN_F32_STALE: a replay whose dispatch no longer stages the shadow is refused, not wrong
+            n += 1
+        return n
+
+    def _takes_shadows(self, c):
+        """mh_conv2d_takes_shadows for a recorded OP_CONV: bit 1 = the launch stages in_shadow, bit 2 = it reads the mask from mask_shadow"""
+        import ctypes as C
+        from . import _ffi
+        d = _ffi.ConvDesc(*([c.i[k] for k in range(18)] + [c.i[18], c.f[0], c.f[1], c.i[19], c.i[20], c.i[22]]))
+        return self.lib.conv2d_takes_shadows(C.byref(d), C.c_void_p(c.p[0]), C.c_void_p(c.p[1]), C.c_void_p(c.p[6]), C.c_void_p(c.p[3]), C.c_void_p(c.p[4]))
+
+    def _standalone_activations(self):
+        """{data pointer: bytes} of the activation tensors that are allocations of their own (no view of them can start in front of them): the only
+        candidates for an elided fp32 store"""
+        out = {}
+        for k in LEVELS:
+            for t in self.E[k]:
+                out[t.data_ptr()] = t.numel() * 4
+        for t in self.Cx:
+            out[t.data_ptr()] = t.numel() * 4
+        return out
+
+    def _elide_fp32_activations(self, r):
+        """Post-pass (dead-store elimination, forward side): a plane-writing forward layer (OP_CONV_PLANES) does not store its fp32 result when no op
+        of the recorded plan reads that tensor -- the next forward layer takes the planes, the filter gradient the hi plane, the input gradient of the
+        next layer the sign of the hi plane for its leaky mask (it gets MH_CONV_MASK_F32_STALE, so a replay under another dispatch fails loudly).
+        Readers are found conservatively: any pointer field of any op, and any tensor a device table of an op references (Recorder.refs), that
+        OVERLAPS the buffer."""
+        if not (self.use_planes and PLANES_ONLY):
+            return 0
+        from . import _ffi
+        ops_ = r.ops
+        cand = self._standalone_activations()
+        n = 0
+        for idx, o in enumerate(ops_):
+            if o.kind != _ffi.OP_CONV_PLANES or not o.p[4] or not (o.p[5] and o.p[6]):
+                continue
+            lo = int(o.p[4])
+            if lo not in cand:
+                continue
+            hi = lo + cand[lo]
+            if any(a < hi and lo < a + nb for _, a, nb in getattr(r, "refs", ())):
+                continue
+            ok, mask_users = True, []
+            for j, q in enumerate(ops_):
+                if j == idx:
+                    continue
+                hits = [k for k in range(8) if q.p[k] and lo <= int(q.p[k]) < hi]
+                if not hits:
+                    continue
+                # the only tolerated reader: an input gradient that was given this tensor as its leaky mask TOGETHER with the mask's shadow and whose
+                # kernel tests the shadow
+                if (q.kind == _ffi.OP_CONV and q.i[13] == 1 and hits == [4] and int(q.p[4]) == lo and (q.i[23] & 2) and q.i[22] == 1
+                        and (self._takes_shadows(q) & 2)):
+                    mask_users.append(q)
+                    continue
+                ok = False
+                break
+            if not ok:
+                continue
+            o.p[4] = None
+            for q in mask_users:
+                q.i[23] |= 16           # MH_CONV_MASK_F32_STALE
             n += 1
         return n
 
@@ -554,6 +720,7 @@ class MadNetEngine(object):
         if side:
             r.lane = 1
             try:
+                self._stamp(r, "side_lane_first_op")
                 if self.loss_kind != "proxy":
                     ops.reprojection_loss(r, self.left, self.right, self.pred, self.loss_ws, self.res_loss, None, phase=2)
                 ops.metrics(r, self.pred, self.gt, self.met_ws, self.res_met, 3.0)
@@ -600,11 +767,17 @@ class MadNetEngine(object):
         # zero of the gradient ranges (bias gradients and single-split filter gradients accumulate): with ONE filter-gradient lane it goes
         # onto that lane -- everything that touches g runs there, behind it -- and off the critical path
         g_side = ONE_FILL and self.wgrad_lanes == 1 and hasattr(lib, "lane")
+        tail_vars = [pyr_name(1) + "/weights", pyr_name(1) + "/biases"]
+        tail_lane = TAIL_LANE if (TAIL_SPLIT and TAIL_LANE and g_side and pyr_tr[1] and pyr_tr[2] and all(v in train_vars for v in tail_vars)) else 0
         if g_side:
             lib.lane = 1
         try:
-            for o, c in P.ranges(train_vars):
+            for o, c in P.ranges([v for v in train_vars if not (tail_lane and v in tail_vars)]):
                 ops_fill(lib, P.g, o, c)
+            if tail_lane:
+                lib.lane = tail_lane
+                for o, c in P.ranges(tail_vars):
+                    ops_fill(lib, P.g, o, c)
         finally:
             if g_side:
                 lib.lane = 0
@@ -641,7 +814,7 @@ class MadNetEngine(object):
 
         nflush = [0]
 
-        def flush():
+        def flush(lane=None):
             """Issue the deferred filter gradients as ONE batch on a side lane (one fork edge): they read only
             buffers that nothing later in the step overwrites, so they may run concurrently with everything that
             follows on lane 0 until the reduction joins them."""
@@ -649,10 +822,11 @@ class MadNetEngine(object):
                 return
             side = self.wgrad_lanes > 0 and hasattr(lib, "lane")
             if side:
-                lib.lane = 1 + nflush[0] % self.wgrad_lanes
+                lib.lane = lane if lane else 1 + nflush[0] % self.wgrad_lanes
                 lib.nodefer = nflush[0] < NODEFER_BATCHES        # the first batches (context network, 1/4-resolution estimator) carry most of the work
             nflush[0] += 1
             try:
+                self._stamp(lib, "wgrad_batch%d_start" % nflush[0])
                 batch = []
                 todo = list(pending)
                 if self.use_stream and self.partial_wgrad and ops._bwd_precision() == 1:
@@ -678,6 +852,7 @@ class MadNetEngine(object):
                     for a, b in _merge_ranges(upd_fresh):
                         ops.momentum(lib, P.w[a:b], P.m[a:b], P.g[a:b], lr_, mom_, gs_)
                         upd_done.append((a, b))
+                self._stamp(lib, "wgrad_batch%d_end" % nflush[0])
             finally:
                 if side:
                     lib.lane = 0
@@ -866,6 +1041,8 @@ class MadNetEngine(object):
                         ops_fill(lib, self.dF[i - 1][B:], 0, self.dF[i - 1][B:].numel())
                 if pyr_tr[i]:
                     wgrad(xin, self._fv(self.dF[i]), pyr_name(i), stride=PYR[i - 1][2])
+                if TAIL_SPLIT and i == 2:
+                    flush()                 # conv4 .. conv2: beside conv2's input gradient, not behind it
                 if need_dx:
                     # dF[i-1] is complete after this launch (the cost-volume contributions were written earlier): it is the dz of layer i - 1
                     sh = self._out_shadow(self._fv(self.dF[i - 1]), pyr_name(i - 1)) if (i - 1 > 1) else None       # (conv1's 3-channel input keeps the tiled kernel)
@@ -874,10 +1051,13 @@ class MadNetEngine(object):
                                      mask_alpha=ALPHA, wb=self.Wd_(pyr_name(i)), shadow=sh,
                                      dz_shadow=self._fresh_shadow(self._fv(self.dF[i])), mask_shadow=self._fresh_shadow(self._fv(self.F[i - 1])))
                 if i % 4 == 1:
-                    flush()
+                    flush(lane=(tail_lane if i == 1 else None))
         flush()
+        self._stamp(lib, "chain_end")                           # lane 0: the last input gradient is behind us
         ops.wgrad_reduce(lib, segs, self.dev, r.keep)          # (serial variant only: the side-lane batches reduce themselves)
         r.join_next = True                                      # whatever comes next (the optimizer) waits for the side lanes
+        self._stamp(lib, "joined")                              # (takes the join edge: every side lane has finished)
+        r.join_next = True
         return _merge_ranges(upd_done)
 
     def record_update(self, r, train_vars, lr, momentum=0.9, grad_scale=1.0, done=()):
@@ -947,6 +1127,7 @@ class MadNetEngine(object):
         r = Recorder()
         self.wsa.reset()
         self._fresh = set()
+        self.stamp_labels = []
         if mode in ("FULL", "TRAIN"):
             self._stream_train = set(self.all_vars())
         elif mode == "MAD":
@@ -980,6 +1161,7 @@ class MadNetEngine(object):
         if update and part in ("all", "update"):
             self.record_update_adam(r, tv, lr, grad_scale=grad_scale)
         self._elide_fp32_gradient_maps(r)
+        self._elide_fp32_activations(r)
         return r.compile()
 
     def _build_plan(self, r, mode, lr, block_vars, block_level, grad_scale, update, blocks, part, optimizer="momentum"):
@@ -1040,7 +1222,9 @@ class MadNetEngine(object):
                     record_update(r, bv, lr, grad_scale=grad_scale)
         else:
             raise ValueError("unknown mode %r" % (mode,))
+        self._stamp(r, "end")
         self._elide_fp32_gradient_maps(r)
+        self._elide_fp32_activations(r)
         return r.compile_parts() if part == "grad_split" else r.compile()
 
     # convenience: eager single forward -------------------------------------------------------

@@ -110,16 +110,20 @@ def conv_geometry(H, W, kh, kw, stride, dil):
 
 
 def conv2d_fwd(lib, x, w, b, out, stride=1, dil=1, alpha=1.0, accumulate=False, mask_ref=None, mask_alpha=1.0,
-               mask_range=(0, 0), stream=None, precision=None, wb=None, shadow=None):
+               mask_range=(0, 0), stream=None, precision=None, wb=None, shadow=None, out_planes=None):
     """out (+)= leaky(conv2d_SAME(x, w) + b) [* leaky'(mask_ref)].  x,out: View; w: HWIO [kh,kw,Cin,Cout].
-    wb: the layer's MFMA fragment bank (pack_weights) -- split-bf16 3x3 layers then stream their weights from it."""
+    wb: the layer's MFMA fragment bank (pack_weights) -- split-bf16 3x3 layers then stream their weights from it.
+    out_planes: Planes of `out` (hi + lo) the launch writes too (mh_conv2d_sh4: the producer side of conv2d_planes)."""
     kh, kw, cin, cout = w.shape
     Ho, Wo, pt, pl = conv_geometry(x.H, x.W, kh, kw, stride, dil)
     assert (out.H, out.W, out.C) == (Ho, Wo, cout) and x.C == cin
     d = conv_desc(x.B, x.H, x.W, Ho, Wo, cin, cout, kh, kw, stride, dil, pt, pl, 0, 0, x.ld, out.ld, alpha=alpha,
                   mask_ld=(mask_ref.ld if mask_ref is not None else 0), accumulate=int(accumulate), mask_alpha=mask_alpha,
                   mask_c0=mask_range[0], mask_c1=mask_range[1], precision=precision)
-    if shadow is not None:     # shadow: ops.Shadow of `out` -- the epilogue also writes bf16(out) there (operand of wgrad_stream)
+    if out_planes is not None:
+        assert (out_planes.B, out_planes.H, out_planes.W, out_planes.C) == (out.B, out.H, out.W, out.C)
+        lib.conv2d_sh4(C.byref(d), _p(x), _p(w), _p(wb), _p(b), _p(out), _p(mask_ref), C.c_void_p(out_planes.hi.ptr), C.c_void_p(out_planes.lo.ptr), _p(stream))
+    elif shadow is not None:     # shadow: ops.Shadow of `out` -- the epilogue also writes bf16(out) there (operand of wgrad_stream)
         assert (shadow.B, shadow.H, shadow.W, shadow.C) == (out.B, out.H, out.W, out.C)
         lib.conv2d_sh(C.byref(d), _p(x), _p(w), _p(wb), _p(b), _p(out), _p(mask_ref), C.c_void_p(shadow.ptr), _p(stream))
     elif wb is not None:
@@ -344,12 +348,21 @@ def plane_split(lib, pairs, device, keep, stream=None):
     for i, (src, dst) in enumerate(pairs):
         hi = dst.hi if isinstance(dst, Planes) else dst
         lo = dst.lo if isinstance(dst, Planes) else None
-        assert (src.B, src.H, src.W, src.C) == (hi.B, hi.H, hi.W, hi.C), "planes / source geometry mismatch"
+        src2 = None
+        if isinstance(src, (tuple, list)):      # (View a, View b): the planes of tf.concat([a, b], -1)
+            src, src2 = src
+            assert (src2.B, src2.H, src2.W) == (src.B, src.H, src.W)
+        assert (src.B, src.H, src.W, src.C + (src2.C if src2 is not None else 0)) == (hi.B, hi.H, hi.W, hi.C), "planes / source geometry mismatch"
         arr[i].src, arr[i].hi, arr[i].lo, arr[i].npix, arr[i].C = src.ptr, hi.ptr, (lo.ptr if lo is not None else None), src.npix, src.C
         arr[i].src_ld, arr[i].dst_ld, arr[i].blk0 = src.ld, hi.ld, blk
+        if src2 is not None:
+            arr[i].src2, arr[i].C2, arr[i].src2_ld = src2.ptr, src2.C, src2.ld
         blk += (src.npix * (hi.ld // 8) + 255) // 256
     table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
     keep.append(table)
+    if hasattr(lib, "note_refs"):
+        flat = [v for src, _ in pairs for v in (src if isinstance(src, (tuple, list)) else (src,))]
+        lib.note_refs([(v.ptr, 4 * v.npix * v.ld) for v in flat])
     lib.plane_split(C.c_void_p(table.data_ptr()), len(pairs), blk, _p(stream))
 
 
@@ -366,6 +379,8 @@ def shadow_cast(lib, pairs, device, keep, stream=None):
         blk += (src.npix * (dst.ld // 8) + 255) // 256
     table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
     keep.append(table)
+    if hasattr(lib, "note_refs"):
+        lib.note_refs([(src.ptr, 4 * src.npix * src.ld) for src, _ in pairs])
     lib.shadow_cast(C.c_void_p(table.data_ptr()), len(pairs), blk, _p(stream))
 
 
@@ -456,11 +471,19 @@ def corr_fwd(lib, L, R, out, max_disp, stride=1, coff=0, u=None, copy_left=False
                           int(copy_left), int(zero_tail), prec, _p(stream))
 
 
-def level_front_fwd(lib, Vc, mul, L, R, out, Rw, u, max_disp, coff, zero_tail=True, stream=None):
+def level_front_fwd(lib, Vc, mul, L, R, out, Rw, u, max_disp, coff, zero_tail=True, stream=None, planes=None):
     """u = mul * resize(Vc) ; Rw = warp(R, u) ; out = [L | corr(L, Rw) | u | 0]  -- one launch (mh_level_front_fwd).
-    Vc: [B,Hc,Wc] tensor; L, R, Rw: Views [B,H,W,C]; out: View of the estimator input; u: [B,H,W] tensor."""
-    lib.level_front_fwd(_p(Vc), Vc.shape[1], Vc.shape[2], mul, _p(L), L.ld, _p(R), R.ld, _p(out), out.ld, coff, _p(Rw), Rw.ld, _p(u),
-                        L.B, L.H, L.W, L.C, max_disp, int(zero_tail), _p(stream))
+    Vc: [B,H,Wc] tensor; L, R, Rw: Views [B,H,W,C]; out: View of the estimator input; u: [B,H,W] tensor.
+    planes: Planes (hi + lo) or Shadow (hi only) of `out` that the launch writes too."""
+    if planes is None:
+        lib.level_front_fwd(_p(Vc), Vc.shape[1], Vc.shape[2], mul, _p(L), L.ld, _p(R), R.ld, _p(out), out.ld, coff, _p(Rw), Rw.ld, _p(u),
+                            L.B, L.H, L.W, L.C, max_disp, int(zero_tail), _p(stream))
+        return
+    hi = planes.hi if isinstance(planes, Planes) else planes
+    lo = planes.lo if isinstance(planes, Planes) else None
+    assert (hi.B, hi.H, hi.W) == (L.B, L.H, L.W) and hi.C == coff + 2 * max_disp + 2 and hi.ld >= hi.C
+    lib.level_front_fwd_planes(_p(Vc), Vc.shape[1], Vc.shape[2], mul, _p(L), L.ld, _p(R), R.ld, _p(out), out.ld, coff, _p(Rw), Rw.ld, _p(u),
+                               L.B, L.H, L.W, L.C, max_disp, int(zero_tail), C.c_void_p(hi.ptr), (C.c_void_p(lo.ptr) if lo is not None else None), hi.ld, _p(stream))
 
 
 def corr_bwd(lib, g, L, R, dL, dR, max_disp, stride=1, coff=0, du=None, acc_l=False, acc_r=False, acc_u=False,
@@ -601,3 +624,9 @@ def copy_channels(lib, src, dst, nch=None, scale=1.0, accumulate=False, stream=N
 
 def leaky_bwd(lib, dy, y, alpha, stream=None):
     lib.leaky_bwd(_p(dy), dy.ld, _p(y), y.ld, dy.npix, dy.C, alpha, _p(stream))
+
+
+def stamp(lib, slots, index, stream=None):
+    """slots[index] (int64 device tensor) = the device wall clock when this op runs (mh_stamp)"""
+    assert slots.dtype == torch.int64
+    lib.stamp(C.c_void_p(slots.data_ptr() + 8 * index), _p(stream))

@@ -35,6 +35,12 @@ class Recorder(object):
         self.work = {}              # op index -> (algorithmic flops, bytes) of the multi-layer ops (a streamed filter-gradient batch)
         self._pending_work = [0.0, 0.0]
         self.cuts = []              # op indices where compile_parts() splits the recording (a collective goes between the parts)
+        self.refs = []              # (op index, data pointer, bytes): tensors an op reaches through a DEVICE TABLE (segment tables of casts / splits /
+                                    # streamed filter gradients) -- invisible in the op's own pointer fields, seen by the dead-store post-passes
+
+    def note_refs(self, pairs):
+        """pairs: [(data pointer, bytes)] read or written through the device table of the op recorded NEXT"""
+        self.refs += [(len(self.ops), int(a), int(nb)) for a, nb in pairs if a]
 
     def cut(self):
         """Mark a split point: every op recorded so far forms one part (mh_plan_run joins the side lanes at the end of a plan, so
@@ -89,6 +95,11 @@ class Recorder(object):
         self._tally(d, "conv")
         self._op(_ffi.OP_CONV, self._desc_ints(d) + [0, d.precision], [d.alpha, d.mask_alpha], [inp, w, bias, out, mask, None, wb, shadow])
 
+    def conv2d_sh4(self, dref, inp, w, wb, bias, out, mask, out_hi, out_lo, stream):
+        d = dref._obj
+        self._tally(d, "conv")
+        self._op(_ffi.OP_CONV, self._desc_ints(d) + [0, d.precision, 32], [d.alpha, d.mask_alpha], [inp, w, bias, out, mask, out_lo, wb, out_hi])
+
     def conv2d_sh2(self, dref, inp, in_shadow, w, wb, bias, out, mask, shadow, stream):
         d = dref._obj
         self._tally(d, "conv")
@@ -106,6 +117,9 @@ class Recorder(object):
         self._tally(d, "conv")
         ints = self._desc_ints(d) + [0, 2, in_pld, out_pld]
         self._op(_ffi.OP_CONV_PLANES, ints, [d.alpha, d.mask_alpha], [in_hi, in_lo, wb32, bias, out, out_hi, out_lo])
+
+    def stamp(self, slot, stream):
+        self._op(_ffi.OP_STAMP, [], [], [slot])
 
     def plane_split(self, segs, nseg, nblocks, stream):
         self._op(_ffi.OP_PLANE_SPLIT, [nseg, nblocks], [], [segs])
@@ -169,7 +183,10 @@ class Recorder(object):
         self._op(_ffi.OP_CORR_FWD, [l_ld, r_ld, out_ld, coff, B, H, W, Cc, md, stride, copy_left, zero_tail, precision], [], [L, R, u, out])
 
     def level_front_fwd(self, Vc, Hc, Wc, mul, L, l_ld, R, r_ld, out, out_ld, coff, Rw, rw_ld, u, B, H, W, Cc, md, zero_tail, stream):
-        self._op(_ffi.OP_LEVEL_FRONT, [Hc, Wc, l_ld, r_ld, out_ld, coff, rw_ld, B, H, W, Cc, md, zero_tail], [mul], [Vc, L, R, out, Rw, u])
+        self._op(_ffi.OP_LEVEL_FRONT, [Hc, Wc, l_ld, r_ld, out_ld, coff, rw_ld, B, H, W, Cc, md, zero_tail, 0], [mul], [Vc, L, R, out, Rw, u])
+
+    def level_front_fwd_planes(self, Vc, Hc, Wc, mul, L, l_ld, R, r_ld, out, out_ld, coff, Rw, rw_ld, u, B, H, W, Cc, md, zero_tail, out_hi, out_lo, out_pld, stream):
+        self._op(_ffi.OP_LEVEL_FRONT, [Hc, Wc, l_ld, r_ld, out_ld, coff, rw_ld, B, H, W, Cc, md, zero_tail, out_pld], [mul], [Vc, L, R, out, Rw, u, out_hi, out_lo])
 
     def corr_bwd(self, g, g_ld, coff, L, l_ld, R, r_ld, dL, dl_ld, acc_l, dR, dr_ld, acc_r, du, acc_u,
                  B, H, W, Cc, md, stride, copy_left, stream):

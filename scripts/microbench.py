@@ -276,7 +276,7 @@ def run_planes():
           ("L2 33->128", 1, 96, 320, 33, 128, 1), ("P 32->32 x2", 2, 96, 320, 32, 32, 1),
           ("L3 128->128", 1, 48, 160, 128, 128, 1), ("L3 70->128", 1, 48, 160, 70, 128, 1), ("L3 96->64", 1, 48, 160, 96, 64, 1), ("P 64->64 x2", 2, 48, 160, 64, 64, 1)]
     only = os.environ.get("MB_ONLY")
-    print("%-16s %8s | %8s %8s %8s %8s | %8s %8s %8s | %8s   %s" % ("layer (fwd)", "bank", "v1", "v2", "v3", "v4", "v1 noK", "v1 nostg", "v1 pl-only", "split", "max|diff| vs bank"))
+    print("%-16s %8s | %8s | %8s %8s %8s %8s %8s %8s | %8s %8s   %s" % ("layer (fwd)", "bank", "auto", "32c 128p", "32c 64p", "16c 128p", "16c 64p", "32c 32p", "16c 32p", "auto noK", "auto pl-only", "max|diff| vs bank"))
     for name, B, H, W, Ci, Co, d in PL:
         if only and only not in name:
             continue
@@ -299,7 +299,7 @@ def run_planes():
         ops.PRECISION = 0
         lib.tune_conv_patch(-1); lib.tune_conv_bank(-1)
         res = []
-        for mode, outv, outp in ((1, y2, yp), (2, y2, yp), (3, y2, yp), (4, y2, yp), (1 + 256, y2, yp), (1 + 512, y2, yp), (1, None, yp)):
+        for mode, outv, outp in ((0, y2, yp), (1, y2, yp), (2, y2, yp), (3, y2, yp), (4, y2, yp), (5, y2, yp), (6, y2, yp), (256, y2, yp), (0, None, yp)):
             lib.tune_conv_planes(mode)
             try:
                 with torch.cuda.stream(stream):
@@ -308,16 +308,14 @@ def run_planes():
             except Exception as e:
                 res.append(float("nan"))
         lib.tune_conv_planes(0)
-        with torch.cuda.stream(stream):
-            t_split = _time_ms(lib, stream, lambda: ops.plane_split(lib, [(xv, xp)], dev, keep, stream=sh), 20) * 1e3
         ops.conv2d_planes(lib, xp, w, bank32, b, out=ops.view(y2), out_planes=yp, dil=d, alpha=0.2)
         kn = lib.last_kernel().decode()
         torch.cuda.synchronize()
         flops = 2.0 * B * H * W * 9 * Ci * Co
-        best = min(r for r in res[:4] if r == r)
-        print("%-16s %8.1f | %8.1f %8.1f %8.1f %8.1f | %8.1f %8.1f %8.1f | %8.1f   %.3g  (best %.0f TF/s algorithmic = %.3f of 2.5 PF; %s)"
-              % (name, t_bank, res[0], res[1], res[2], res[3], res[4], res[5], res[6], t_split, (y - y2).abs().max().item(), flops / (best * 1e-6) / 1e12,
-                 flops / (best * 1e-6) / 2.5e15, kn[:70]))
+        best = min(r for r in res[1:7] if r == r)
+        print("%-16s %8.1f | %8.1f | %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f | %8.1f %8.1f   %.3g  (auto %.0f TF/s algorithmic = %.3f of 2.5 PF, best forced %.1f; %s)"
+              % (name, t_bank, res[0], res[1], res[2], res[3], res[4], res[5], res[6], res[7], res[8], (y - y2).abs().max().item(), flops / (res[0] * 1e-6) / 1e12,
+                 flops / (res[0] * 1e-6) / 2.5e15, best, kn[:64]))
 
 
 if what == "planes":

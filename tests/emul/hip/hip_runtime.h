@@ -74,6 +74,10 @@ static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+enum { hipDeviceAttributeWallClockRate = 1 };
+static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 1000000; return hipSuccess; }      // the emulated wall clock: nanoseconds
+#include <time.h>
+static inline long long wall_clock64() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (long long)ts.tv_sec * 1000000000ll + ts.tv_nsec; }
 
 namespace emul {
 

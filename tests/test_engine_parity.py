@@ -843,3 +843,66 @@ def test_step_with_bf16_only_gradient_maps(bname, size):
     (g1, n1, m1), (g0, n0, m0) = out[True], out[False]
     assert n0 == 0 and n1 >= 7 and m1 >= 9, (n0, n1, m1)
     assert torch.isfinite(g1).all() and ((g1 - g0).norm() / g0.norm()).item() <= 1e-6
+
+
+@pytest.mark.parametrize("bname", [pytest.param("emul", id="emul"), pytest.param("hip", marks=pytest.mark.gpu, id="hip")])
+@pytest.mark.parametrize("mode", ["FULL", "MAD4", "NONE"])
+def test_mixed_forward_from_planes_matches_fp32_operand_path(bname, mode):
+    """'mixed' with the split-bf16 forward layers on mh_conv2d_planes (activations as hi / lo bf16 planes, fp32 copies elided where nothing reads
+    them) against the same step on the fp32-operand bank kernels: the same three products per element in another summation order -- disparity, loss
+    and post-step weights agree to fp32 round-off; the plan really took the planes kernel and really dropped fp32 stores.  (60x100: the small-layer
+    threshold is lowered so that the 1/4-resolution layers count as 'large'.)"""
+    backend = _backend(bname)
+    lib, dev = backend.lib, backend.device
+    wn = S.calibrated_weights(OM.variable_shapes(), 1)
+    l, r, gt = S.make_pair(60, 100)
+    res = {}
+    lib.tune_conv_bank(128); lib.tune_conv_patch(128)
+    try:
+        for planes in (True, False, "unfused"):
+            if planes == "unfused" and mode != "FULL":
+                continue
+            E.USE_PLANES = bool(planes)
+            E.FUSE_SPLITS = planes != "unfused"
+            eng = E.MadNetEngine(lib, 60, 100, B=1, device=dev, weights=wn, precision="mixed")
+            eng.bank_small_maxpix = 128
+            eng.set_inputs(l, r, gt[..., 0])
+            if mode == "FULL":
+                plan = eng.build_plan("FULL", lr=1e-3)
+            elif mode == "NONE":
+                plan = eng.build_plan("NONE")
+            else:
+                blocks = json.load(open(os.path.join(PKG, "block_config", "MadNet_full.json")))
+                lv = OM.layer_variables()
+                plan = eng.build_plan("MAD", lr=1e-3, block_vars=sum([lv[n] for n in blocks[4]], []), block_level=E.LEVELS[4])
+            lib.tune_conv_planes(0)
+            plan.run(lib, 0)
+            backend.sync()
+            from madnet_hip import _ffi
+            nplanes = lib.tune_conv_planes(0)
+            pops = [plan.arr[i] for i in range(plan.n)]
+            kinds = [o.kind for o in pops]
+            elided = sum(1 for o in pops if o.kind == _ffi.OP_CONV_PLANES and not o.p[4])
+            res[planes] = dict(pred=eng.pred.cpu().clone(), loss=eng.res_loss[0].item(), w={n: eng.params.tensor(n).cpu().clone() for n in wn},
+                               nplanes=nplanes, nrec=kinds.count(_ffi.OP_CONV_PLANES), elided=elided, splits=kinds.count(_ffi.OP_PLANE_SPLIT))
+    finally:
+        E.USE_PLANES = True
+        E.FUSE_SPLITS = True
+        lib.tune_conv_bank(-1); lib.tune_conv_patch(-1)
+    a, b = res[True], res[False]
+    if "unfused" in res:        # split launches in front of every consumer instead: the same planes, bit for bit the same step
+        u = res["unfused"]
+        assert u["splits"] == 4 and u["nplanes"] == 13
+        assert torch.equal(u["pred"], a["pred"])               # (the post-step weights carry the landing order of the fp32 atomics: compared below, against `b`)
+    assert a["nrec"] == 13 and a["nplanes"] == 13 and b["nrec"] == 0 and b["nplanes"] == 0, (a["nrec"], a["nplanes"], b["nrec"])     # conv4, conv6, 5 of estimator 2, 6 of the context network
+    # one split launch left: the concat-split of the context network's input; the inputs of conv4 / conv6 and the estimator's concat buffer get their
+    # planes from their producers' epilogues (engine.FUSE_SPLITS)
+    assert a["splits"] == 1
+    assert a["elided"] >= (9 if mode != "MAD4" else 4), a["elided"]
+    d = (a["pred"] - b["pred"]).abs()
+    # (fp32 summation order of 13 layers -- 32x32x16 against 16x16x32 MFMA steps -- amplified by the x20 disparity scales: measured 2.6e-4 / 4.2e-5)
+    assert d.max().item() <= 1e-3 and d.mean().item() <= 1.5e-4, (d.max().item(), d.mean().item())
+    assert abs(a["loss"] - b["loss"]) <= 2e-6
+    for n in wn:
+        step = (b["w"][n] - torch.from_numpy(wn[n])).abs().max().item()
+        assert (a["w"][n] - b["w"][n]).abs().max().item() <= 2e-2 * step + 2e-7 * max(1.0, b["w"][n].abs().max().item()), n      # (+ an ulp or two of the weight itself)
