@@ -101,7 +101,9 @@ typedef struct mh_pack_seg {
     int32_t blk0;         /* exclusive prefix sum of ceil(taps*ceil(K/32)*ceil(N/16)*64 / 256) over the table */
     int32_t trans;        /* 0: src[tap][K][N] (forward: K = Cin, N = Cout); 1: src[tap][N][K] (the same HWIO bank seen by the input
                              gradient: K = Cout is the reduction, N = Cin the output column); 2: forward bank in the 32x32x16 register image
-                             mh_conv2d_planes reads (planes = 2, mh_pack32_bytes bytes; blk0 then counts ceil(taps*ceil(K/16)*ceil(N/32)*64 / 256)) */
+                             mh_conv2d_planes reads (planes = 2, mh_pack32_bytes bytes; blk0 then counts ceil(taps*ceil(K/16)*ceil(N/32)*64 / 256));
+                             3: the input gradient's bank in that image (mh_conv2d_planes_bwd): planes = 1, K = Cout (reduction), N = Cin as for trans 1,
+                             taps mirrored, mh_pack32_bytes(taps, K, N) / 2 bytes */
 } mh_pack_seg;
 int64_t mh_pack_bytes(int32_t taps, int32_t K, int32_t N, int32_t planes);
 int64_t mh_pack32_bytes(int32_t taps, int32_t K, int32_t N);
@@ -121,6 +123,16 @@ int mh_pack_weights(const mh_pack_seg* segs_device, int32_t nseg, int32_t nblock
 int mh_conv2d_planes_ok(const mh_conv_desc* d);
 int mh_conv2d_planes(const mh_conv_desc* d, const void* in_hi, const void* in_lo, int32_t in_pld, const void* wb32, const float* bias,
                      float* out, void* out_hi, void* out_lo, int32_t out_pld, void* stream);
+/* Input gradient of such a layer from bf16 shadows, the same kernel with ONE plane (plain bf16, fp32 accumulate -- the arithmetic of precision code 1):
+ *   dx = conv2d_backprop_input(dz, w) [* (mask > 0 ? 1 : d->mask_alpha)]        (Conv2DBackpropInput + the gradient of tf.maximum(alpha x, x))
+ *   d      : the FORWARD descriptor of the layer (K = Cin, N = Cout, dil; in_ld = pixel stride of dx in floats)
+ *   dz_hi  : bf16 plane of d loss / d output [pixel][dz_pld], padding channels zero;  wb32t: mh_pack_weights(trans = 3) image of the HWIO bank
+ *   mask_hi: NULL, or the bf16 (hi) plane of the layer's INPUT activation [pixel][mask_pld] (only its sign is read)
+ *   dx     : fp32 result or NULL;  dx_hi: its bf16 plane [pixel][dx_pld] or NULL (the next input gradient's dz_hi, the filter gradient's operand)
+ * No accumulation, no channel-range mask: launches that need those stay on mh_conv2d (mode 1). */
+int mh_conv2d_planes_bwd_ok(const mh_conv_desc* d);
+int mh_conv2d_planes_bwd(const mh_conv_desc* d, const void* dz_hi, int32_t dz_pld, const void* wb32t, const void* mask_hi, int32_t mask_pld,
+                         float* dx, void* dx_hi, int32_t dx_pld, void* stream);
 typedef struct mh_plane_seg {
     const float* src;     /* fp32 [npix][src_ld], C valid channels */
     void* hi;             /* bf16 [npix][dst_ld]: bf16(src), channels >= C zero; 16-byte aligned */
@@ -437,7 +449,7 @@ enum { MH_OP_CONV = 1, MH_OP_WGRAD, MH_OP_CORR_FWD, MH_OP_CORR_BWD, MH_OP_WARP_F
        MH_OP_RESIZE_FWD, MH_OP_RESIZE_BWD, MH_OP_PAD_REFLECT, MH_OP_LOSS, MH_OP_METRICS,
        MH_OP_MOMENTUM, MH_OP_COPY_CH, MH_OP_LEAKY_BWD, MH_OP_FILL, MH_OP_BIAS_GRAD,
        MH_OP_WGRAD_PARTIAL, MH_OP_WGRAD_REDUCE, MH_OP_PROXY_LOSS, MH_OP_SUPERVISED_LOSS, MH_OP_ADAM, MH_OP_ADAM_ADVANCE,
-       MH_OP_RESIZE_IMAGE, MH_OP_LEVEL_FRONT, MH_OP_RESERVED_25 /* (was: transposed filter banks of the retired LDS-free kernel) */, MH_OP_PACK_W, MH_OP_CORR_WARP_BWD, MH_OP_SHADOW_CAST, MH_OP_WGRAD_STREAM, MH_OP_HEAD_BWD, MH_OP_HEAD_FWD, MH_OP_CONV_PLANES, MH_OP_PLANE_SPLIT, MH_OP_STAMP };
+       MH_OP_RESIZE_IMAGE, MH_OP_LEVEL_FRONT, MH_OP_RESERVED_25 /* (was: transposed filter banks of the retired LDS-free kernel) */, MH_OP_PACK_W, MH_OP_CORR_WARP_BWD, MH_OP_SHADOW_CAST, MH_OP_WGRAD_STREAM, MH_OP_HEAD_BWD, MH_OP_HEAD_FWD, MH_OP_CONV_PLANES, MH_OP_PLANE_SPLIT, MH_OP_STAMP, MH_OP_CONV_PLANES_BWD };
 /* i[26] of every op is its scheduling word: low byte = lane (0 = the caller's stream; 1..MH_MAX_LANES-1 = side
  * streams owned by the library: the op is forked from lane 0 right before it, i.e. ordered after everything recorded so
  * far, and runs concurrently with the lane-0 ops that follow); MH_OP_JOIN = lane 0 first waits for all side lanes.

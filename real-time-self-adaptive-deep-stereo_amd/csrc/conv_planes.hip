@@ -26,6 +26,8 @@ struct PlanesArgs {
     const unsigned short* in_hi; const unsigned short* in_lo;     // bf16 planes [B][H][W][in_pld]
     const void* wb;                                               // fragment bank, 32x32x16 image: [(tap * K16 + s)][32-column tile][plane][lane][8 bf16]
     const float* bias;
+    const unsigned short* mask_hi; int mask_pld; float mask_alpha;  // != null: out *= (mask > 0 ? 1 : mask_alpha), mask = a bf16 plane [pixel][mask_pld] (sign test: the
+                                                                   // fused gradient of tf.maximum(alpha x, x) in an input-gradient launch)
     float* out; unsigned short* out_hi; unsigned short* out_lo;   // any of them may be null
     unsigned in_bytes, wb_bytes, out_bytes, outp_bytes;
     int in_pld, out_ld, out_pld;
@@ -37,7 +39,7 @@ struct PlanesArgs {
 
 // MC: columns of a 32-pixel M-block (32: one row of 32 lattice pixels; 16: two rows of 16).  WM x WN waves; a wave owns MBW M-blocks x 32 columns.
 // K16: 16-channel steps per tap (K rounded up to 16).
-template <int MC, int WM, int WN, int MBW, int K16>
+template <int MC, int WM, int WN, int MBW, int K16, int PL = 2>
 struct PlanesGeo {
     static constexpr int MR = 32 / MC;                 // rows of an M-block
     static constexpr int NW = WM * WN, NTH = NW * 64;
@@ -52,13 +54,16 @@ struct PlanesGeo {
     static constexpr int PLANE_BLKS = (PR * ROWP * 16 + 1023) / 1024;
     static constexpr int PLANE_BYTES = PLANE_BLKS * 1024;
     static constexpr int CS = BN + 4;
-    static constexpr int LDS_TILES = 2 * PLANE_BYTES, LDS_CS = BM * CS * 4;
+    static constexpr int LDS_TILES = PL * PLANE_BYTES, LDS_CS = BM * CS * 4;
     static constexpr int LDS = LDS_TILES > LDS_CS ? LDS_TILES : LDS_CS;
 };
 
-template <int MC, int WM, int WN, int MBW, int K16>
+// PL = 2: split-bf16 (hi + lo planes of both operands, three MFMAs per product: the forward layers).  PL = 1: plain bf16 from the hi plane and a one-plane
+// bank (one MFMA per product): the INPUT GRADIENTS of the same layers -- a 'SAME' 3x3 input gradient is this forward walk over dz with the taps mirrored
+// and the bank transposed, which mh_pack_weights (trans = 3) bakes into the bank, so the kernel does not know the difference.
+template <int MC, int WM, int WN, int MBW, int K16, int PL>
 __global__ __launch_bounds__(WM * WN * 64) void conv_planes_kernel(PlanesArgs p) {
-    using G = PlanesGeo<MC, WM, WN, MBW, K16>;
+    using G = PlanesGeo<MC, WM, WN, MBW, K16, PL>;
     constexpr int MR = G::MR, NW = G::NW, NTH = G::NTH, TR = G::TR, BM = G::BM, BN = G::BN, PR = G::PR, PC = G::PC;
     constexpr int NCK = G::NCK, NCK1 = G::NCK1, ROWP = G::ROWP, PLANE_BLKS = G::PLANE_BLKS, PLANE_BYTES = G::PLANE_BYTES, CS = G::CS;
     HIP_DYNAMIC_SHARED(float, smem_all)
@@ -83,13 +88,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_planes_kernel(PlanesArgs p)
     const __amdgpu_buffer_rsrc_t rs_b = mh_make_rsrc(p.wb, p.wb_bytes);
     const int nt32 = (p.N + 31) >> 5;
     const int nt = tile_n * WN + wn;
-    const int voff_b = nt < nt32 ? nt * 2048 + lane * 16 : MH_OOB;
-    const int step_b = nt32 * 2048;
-    u32x4 fb[NSTB][2];
+    const int voff_b = nt < nt32 ? nt * (PL * 1024) + lane * 16 : MH_OOB;
+    const int step_b = nt32 * (PL * 1024);
+    u32x4 fb[NSTB][PL];
     auto issue_b = [&](int t, int slot) {
         if (t < T) {
             fb[slot][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff_b, t * step_b, 0);
-            fb[slot][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff_b, t * step_b + 1024, 0);
+            if constexpr (PL == 2) fb[slot][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff_b, t * step_b + 1024, 0);
         }
     };
 #pragma unroll
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_planes_kernel(PlanesArgs p)
             const bool ok = pr < PR && pc < PC && c < NCK && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             const int off = ok ? ((b * p.H + iy) * p.W + ix) * pix_b + c * 16 : MH_OOB;
             mh_glds16(rs_h, smem + i * 1024, off);
-            mh_glds16(rs_l, smem + PLANE_BYTES + i * 1024, off);
+            if constexpr (PL == 2) mh_glds16(rs_l, smem + PLANE_BYTES + i * 1024, off);
         }
     }
     MH_WAIT_VMCNT(0);
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_planes_kernel(PlanesArgs p)
         const int lr = MR == 1 ? 0 : (j >> 4), lc = MR == 1 ? j : (j & 15);
         const unsigned char* const a_h = smem + (((wm * MBW * MR + lr) * ROWP + lc * NCK1 + kg) * 16);
         const unsigned char* const a_l = a_h + PLANE_BYTES;
-        u32x4 fa[2][MBW][2];
+        u32x4 fa[2][MBW][PL];
         auto issue_a = [&](int t, int set) {
             if (t < T) {
                 const int tap = t / K16, s = t - tap * K16;
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_planes_kernel(PlanesArgs p)
                 for (int mb = 0; mb < MBW; ++mb) {
                     const int imm = (((mb * MR + ky) * ROWP + kx * NCK1 + 2 * s) * 16);
                     fa[set][mb][0] = *reinterpret_cast<const u32x4*>(a_h + imm);
-                    fa[set][mb][1] = *reinterpret_cast<const u32x4*>(a_l + imm);
+                    if constexpr (PL == 2) fa[set][mb][1] = *reinterpret_cast<const u32x4*>(a_l + imm);
                 }
             }
         };
@@ -145,11 +150,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_planes_kernel(PlanesArgs p)
                 const int sa = t & 1, sb = t % NSTB;
                 // lo(A)*hi(B), hi(A)*lo(B), hi(A)*hi(B) -- term outermost: consecutive MFMAs hit different accumulators
 #pragma unroll
-                for (int term = 0; term < 3; ++term) {
+                for (int term = (PL == 2 ? 0 : 2); term < 3; ++term) {
 #pragma unroll
                     for (int mb = 0; mb < MBW; ++mb) {
-                        acc[mb] = mh_mfma_bf16_32(fa[sa][mb][term == 0 ? 1 : 0], fb[sb][term == 1 ? 1 : 0], acc[mb]);
-                        if (term == 0 && mb == 0) issue_a(t + 1, sa ^ 1);
+                        acc[mb] = mh_mfma_bf16_32(fa[sa][mb][term == 0 ? PL - 1 : 0], fb[sb][term == 1 ? PL - 1 : 0], acc[mb]);
+                        if (term == (PL == 2 ? 0 : 2) && mb == 0) issue_a(t + 1, sa ^ 1);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -182,6 +187,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_planes_kernel(PlanesArgs p)
     const __amdgpu_buffer_rsrc_t rs_o = mh_make_rsrc(p.out ? p.out : (float*)p.out_hi, p.out ? p.out_bytes : 0u);
     const __amdgpu_buffer_rsrc_t rs_oh = mh_make_rsrc(p.out_hi ? p.out_hi : (unsigned short*)p.out, p.out_hi ? p.outp_bytes : 0u);
     const __amdgpu_buffer_rsrc_t rs_ol = mh_make_rsrc(p.out_lo ? p.out_lo : (unsigned short*)p.out, p.out_lo ? p.outp_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_mk = mh_make_rsrc(p.mask_hi ? (const void*)p.mask_hi : (const void*)p.in_hi, p.mask_hi ? (unsigned)((int64_t)p.B * p.H * p.W * p.mask_pld * 2) : 0u);
 #pragma unroll 2
     for (int m = tid / C8; m < BM; m += RP) {
         const int blk = m >> 5, w = m & 31;
@@ -195,6 +201,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_planes_kernel(PlanesArgs p)
         for (int e = 0; e < 8; ++e) {
             v[e] += bv[e];
             if (p.alpha != 1.0f) v[e] = v[e] > 0.f ? v[e] : p.alpha * v[e];
+        }
+        if (p.mask_hi) {        // 8 bf16 of the activation's hi plane: bf16 keeps sign and zero, the test is that of the fp32 tensor
+            const u32x4 mq = __builtin_amdgcn_raw_buffer_load_b128(rs_mk, ok ? (pix * p.mask_pld + n) * 2 : MH_OOB, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float mk = __builtin_bit_cast(float, (e & 1) ? (mq[e >> 1] & 0xffff0000u) : (mq[e >> 1] << 16));
+                v[e] *= mk > 0.f ? 1.0f : p.mask_alpha;
+            }
         }
         unsigned hh[4], ll[4];
 #pragma unroll
@@ -246,13 +260,13 @@ __global__ __launch_bounds__(256) void plane_split_kernel(const mh_plane_seg* __
 std::atomic<int> g_planes_mode{0};       // mh_tune_conv_planes: bits 0-3 tile variant (0 = heuristic), bit 8 = skip the K walk, bit 9 = skip the staging (timing experiments)
 std::atomic<int> g_planes_launches{0};
 
-template <int MC, int WM, int WN, int MBW, int K16>
+template <int MC, int WM, int WN, int MBW, int K16, int PL>
 int launch_planes(PlanesArgs& a, hipStream_t s, bool attr_only) {
-    using G = PlanesGeo<MC, WM, WN, MBW, K16>;
+    using G = PlanesGeo<MC, WM, WN, MBW, K16, PL>;
     static_assert(G::LDS <= 160 * 1024, "patch planes exceed the LDS");
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_planes_kernel<MC, WM, WN, MBW, K16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_planes_kernel<MC, WM, WN, MBW, K16, PL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { mh_set_error("conv_planes: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_done = true;
     }
@@ -264,16 +278,19 @@ int launch_planes(PlanesArgs& a, hipStream_t s, bool attr_only) {
     a.nwg = a.B * d * d * a.tiles_y * a.tiles_x * a.ntiles_n;
     a.dbg = (g_planes_mode.load(std::memory_order_relaxed) >> 8) & 3;
     ++g_planes_launches;
-    mh_note_kernel("conv_planes_kernel<MC=%d,%dx%d waves,MBW=%d,K16=%d> tile %dx%d K=%d dil=%d grid %d lds %d", MC, WM, WN, MBW, K16, G::BM, G::BN, a.K, a.dil, a.nwg, G::LDS);
-    hipLaunchKernelGGL((conv_planes_kernel<MC, WM, WN, MBW, K16>), dim3(a.nwg), dim3(G::NTH), G::LDS, s, a);
+    mh_note_kernel("conv_planes_kernel<MC=%d,%dx%d waves,MBW=%d,K16=%d,%s> tile %dx%d K=%d dil=%d grid %d lds %d", MC, WM, WN, MBW, K16, PL == 2 ? "bf16x3" : "bf16",
+                   G::BM, G::BN, a.K, a.dil, a.nwg, G::LDS);
+    hipLaunchKernelGGL((conv_planes_kernel<MC, WM, WN, MBW, K16, PL>), dim3(a.nwg), dim3(G::NTH), G::LDS, s, a);
     return mh_check_launch("conv_planes");
 }
 
 // ---- instance table + tile choice ---------------------------------------------------------------------------------------------------------
 // Every (N rounded up to 32, K16) pair has the 128-pixel instances of both M-block shapes; the pairs MADNet's layers use also have 64- / 32-pixel
 // instances for grids that would not fill the chip (the 1/8-resolution level: 60 tiles of 128 pixels on 256 CUs).
-struct PlanesInst { int mc, wm, wn, mbw, k16, lds; int (*launch)(PlanesArgs&, hipStream_t, bool); };
-#define PL_INST(MC, WM, WN, MBW, K16) {MC, WM, WN, MBW, K16, PlanesGeo<MC, WM, WN, MBW, K16>::LDS, &launch_planes<MC, WM, WN, MBW, K16>}
+struct PlanesInst { int mc, wm, wn, mbw, k16, lds; int (*launch)(PlanesArgs&, hipStream_t, bool); int pl; };
+#define PL_INST(MC, WM, WN, MBW, K16) {MC, WM, WN, MBW, K16, PlanesGeo<MC, WM, WN, MBW, K16, 2>::LDS, &launch_planes<MC, WM, WN, MBW, K16, 2>, 2}
+#define P1_INST(MC, WM, WN, MBW, K16) {MC, WM, WN, MBW, K16, PlanesGeo<MC, WM, WN, MBW, K16, 1>::LDS, &launch_planes<MC, WM, WN, MBW, K16, 1>, 1}
+#define P1_BOTH(WM, WN, MBW, K16) P1_INST(32, WM, WN, MBW, K16), P1_INST(16, WM, WN, MBW, K16)
 #define PL_BOTH(WM, WN, MBW, K16) PL_INST(32, WM, WN, MBW, K16), PL_INST(16, WM, WN, MBW, K16)
 #define PL_BASE(K16) PL_BOTH(1, 4, 4, K16), PL_BOTH(2, 3, 2, K16), PL_BOTH(2, 2, 2, K16), PL_BOTH(4, 1, 1, K16)
 const PlanesInst g_planes_inst[] = {
@@ -286,6 +303,12 @@ const PlanesInst g_planes_inst[] = {
     PL_BOTH(2, 2, 1, 6), PL_BOTH(2, 2, 1, 4), PL_BOTH(1, 2, 1, 6), PL_BOTH(1, 2, 1, 4),
     // 32 columns (64 -> 32, 32 -> 32): 64 pixels x 2 waves
     PL_BOTH(2, 1, 1, 4), PL_BOTH(2, 1, 1, 2),
+    // ---- one plane (plain bf16): the input gradients of those layers -- (reduction over Cout, output columns = Cin):
+    // 128 -> 128 (K16 8, 128 columns), 128 -> 96 (K16 6, 128), 96 -> 64 (K16 4, 96), 64 -> 32 (K16 2, 64), 64 -> 64 (K16 4, 64), 32 -> 32 (K16 2, 32)
+    P1_BOTH(1, 4, 4, 8), P1_BOTH(1, 4, 2, 8), P1_BOTH(1, 4, 1, 8), P1_BOTH(1, 4, 4, 6), P1_BOTH(1, 4, 2, 6), P1_BOTH(1, 4, 1, 6),
+    P1_BOTH(2, 3, 2, 4), P1_BOTH(1, 3, 2, 4), P1_BOTH(1, 3, 1, 4),
+    P1_BOTH(2, 2, 2, 2), P1_BOTH(2, 2, 1, 2), P1_BOTH(1, 2, 1, 2), P1_BOTH(2, 2, 2, 4), P1_BOTH(2, 2, 1, 4), P1_BOTH(1, 2, 1, 4),
+    P1_BOTH(4, 1, 1, 2), P1_BOTH(2, 1, 1, 2),
 };
 constexpr int N_PLANES_INST = sizeof(g_planes_inst) / sizeof(g_planes_inst[0]);
 
@@ -305,13 +328,13 @@ float planes_cost(const PlanesInst& I, const PlanesArgs& a, int* nwg_out) {
     for (int64_t left = nwg; left > 0; left -= 256 * wpc) {
         const int64_t per_cu = (left + 255) / 256 < wpc ? (left + 255) / 256 : wpc;
         const int64_t simd = (per_cu * nw + 3) / 4;
-        t += (float)I.mbw * (float)simd + 20.f / (float)I.k16;
+        t += (float)I.mbw * (float)simd + (I.pl == 2 ? 20.f : 60.f) / (float)I.k16;
     }
     if (nwg_out) *nwg_out = (int)nwg;
     return t;
 }
 
-int dispatch_planes(PlanesArgs& a, hipStream_t s, bool all) {
+int dispatch_planes(PlanesArgs& a, hipStream_t s, bool all, int pl = 2) {
     if (all) {
         for (int i = 0; i < N_PLANES_INST; ++i)
             if (int rc = g_planes_inst[i].launch(a, s, true)) return rc;
@@ -325,14 +348,14 @@ int dispatch_planes(PlanesArgs& a, hipStream_t s, bool all) {
     float best_cost = 0.f;
     for (int i = 0; i < N_PLANES_INST; ++i) {
         const PlanesInst& I = g_planes_inst[i];
-        if (I.k16 != k16 || I.wn != n32) continue;
+        if (I.k16 != k16 || I.wn != n32 || I.pl != pl) continue;
         float c = planes_cost(I, a, nullptr);
         if (v != 0) c = (I.mc == want_mc ? 0.f : 1000.f) + (float)abs(I.wm * I.mbw * 32 - want_px);        // forced: the closest available shape
         else c -= 1e-3f * (float)(I.wm * I.mbw) + (I.mc == 32 ? 5e-4f : 0.f);                                // ties: the larger tile, then the one-row M-block
         if (!best || c < best_cost) { best = &I; best_cost = c; }
     }
     if (!best) {
-        mh_set_error("mh_conv2d_planes: no instance for K = %d, N = %d (16-channel steps per tap: 2, 3, 4, 5, 6, 8; N <= 128)", a.K, a.N);
+        mh_set_error("mh_conv2d_planes%s: no instance for K = %d, N = %d", pl == 1 ? "_bwd" : "", a.K, a.N);
         return MH_ERR_UNSUPPORTED;
     }
     return best->launch(a, s, false);
@@ -352,6 +375,49 @@ extern "C" int mh_tune_conv_planes(int mode) {
 
 extern "C" int64_t mh_pack32_bytes(int32_t taps, int32_t K, int32_t N) {
     return (int64_t)taps * ((K + 15) / 16) * ((N + 31) / 32) * 2048;
+}
+
+static bool planes_has_instance(int k16, int n32, int pl) {
+    for (int i = 0; i < N_PLANES_INST; ++i)
+        if (g_planes_inst[i].k16 == k16 && g_planes_inst[i].wn == n32 && g_planes_inst[i].pl == pl) return true;
+    return false;
+}
+
+// ---- input gradient of a stride-1 'SAME' 3x3 layer from bf16 shadows: dx = conv2d_backprop_input(dz, w) [* leaky'(mask)] ----------------------------
+extern "C" int mh_conv2d_planes_bwd_ok(const mh_conv_desc* d) {
+    if (!d) return 0;
+    if (!(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_t == d->dil && d->pad_l == d->dil && d->Hi == d->Ho && d->Wi == d->Wo)) return 0;
+    if (d->dil < 1 || d->dil > 64 || d->K < 1 || d->K > 128 || (d->K & 7)) return 0;          // d = the FORWARD layer: K = Cin = the gradient's columns
+    return planes_has_instance((d->N + 15) / 16, (d->K + 31) / 32, 1) ? 1 : 0;
+}
+
+extern "C" int mh_conv2d_planes_bwd(const mh_conv_desc* d, const void* dz_hi, int32_t dz_pld, const void* wb32t, const void* mask_hi, int32_t mask_pld,
+                                    float* dx, void* dx_hi, int32_t dx_pld, void* stream) {
+    MH_REQUIRE(d && dz_hi && wb32t, MH_ERR_ARG, "mh_conv2d_planes_bwd: null descriptor / dz plane / fragment bank");
+    MH_REQUIRE(dx || dx_hi, MH_ERR_ARG, "mh_conv2d_planes_bwd: no output");
+    MH_REQUIRE(mh_conv2d_planes_bwd_ok(d), MH_ERR_UNSUPPORTED, "mh_conv2d_planes_bwd: stride-1 'SAME' 3x3 layers with an instance (Cin <= 128 and a multiple of 8)");
+    MH_REQUIRE(d->B > 0 && d->Hi > 0 && d->Wi > 0, MH_ERR_ARG, "mh_conv2d_planes_bwd: non-positive size");
+    const int k16 = (d->N + 15) / 16;
+    MH_REQUIRE(dz_pld >= k16 * 16 && (dz_pld & 7) == 0, MH_ERR_ARG, "mh_conv2d_planes_bwd: dz_pld must cover Cout rounded up to 16 (multiple of 8)");
+    MH_REQUIRE(mh_aligned16(dz_hi) && mh_aligned16(wb32t) && mh_aligned16(mask_hi) && mh_aligned16(dx_hi), MH_ERR_ALIGN, "mh_conv2d_planes_bwd: 16-byte aligned planes / bank");
+    MH_REQUIRE(!mask_hi || (mask_pld >= d->K && (mask_pld & 7) == 0), MH_ERR_ARG, "mh_conv2d_planes_bwd: mask_pld must cover Cin (multiple of 8)");
+    if (dx) MH_REQUIRE(d->in_ld >= d->K && (d->in_ld & 3) == 0 && mh_aligned16(dx), MH_ERR_ALIGN, "mh_conv2d_planes_bwd: dx rows (d->in_ld floats) must be 16-byte aligned");
+    if (dx_hi) MH_REQUIRE(dx_pld >= d->K && (dx_pld & 7) == 0, MH_ERR_ARG, "mh_conv2d_planes_bwd: dx_pld must cover Cin (multiple of 8)");
+    const int64_t npix = (int64_t)d->B * d->Hi * d->Wi;
+    MH_REQUIRE(npix * dz_pld * 2 < (1ll << 31) && npix * d->in_ld * 4 < (1ll << 31) && npix * (int64_t)dx_pld * 2 < (1ll << 31) && npix * (int64_t)mask_pld * 2 < (1ll << 31),
+               MH_ERR_UNSUPPORTED, "mh_conv2d_planes_bwd: tensors must be < 2 GiB");
+    PlanesArgs a = {};
+    a.in_hi = (const unsigned short*)dz_hi; a.in_lo = nullptr; a.wb = wb32t; a.bias = nullptr;
+    a.mask_hi = (const unsigned short*)mask_hi; a.mask_pld = mask_pld; a.mask_alpha = d->mask_alpha;
+    a.out = dx; a.out_hi = (unsigned short*)dx_hi; a.out_lo = nullptr;
+    a.in_bytes = (unsigned)(npix * dz_pld * 2);
+    a.wb_bytes = (unsigned)(mh_pack32_bytes(9, d->N, d->K) / 2);
+    a.out_bytes = dx ? (unsigned)(npix * d->in_ld * 4) : 0u;
+    a.outp_bytes = (unsigned)(npix * dx_pld * 2);
+    a.in_pld = dz_pld; a.out_ld = d->in_ld; a.out_pld = dx_pld;
+    a.B = d->B; a.H = d->Hi; a.W = d->Wi; a.K = d->N; a.N = d->K; a.dil = d->dil;      // the walk reduces over Cout and produces Cin columns
+    a.alpha = 1.0f;
+    return dispatch_planes(a, (hipStream_t)stream, false, 1);
 }
 
 static __global__ __launch_bounds__(256) void plane_split_one_kernel(mh_plane_seg sg) {
@@ -388,8 +454,7 @@ extern "C" int mh_conv2d_planes_ok(const mh_conv_desc* d) {
     if (!d) return 0;
     if (!(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->mode == 0 && d->pad_t == d->dil && d->pad_l == d->dil && d->Hi == d->Ho && d->Wi == d->Wo)) return 0;
     if (d->accumulate || d->dil < 1 || d->dil > 64 || d->N < 1 || d->N > 128 || (d->N & 7)) return 0;
-    const int k16 = (d->K + 15) / 16;
-    return (k16 >= 2 && k16 <= 6) || k16 == 8;
+    return planes_has_instance((d->K + 15) / 16, (d->N + 31) / 32, 2) ? 1 : 0;
 }
 
 extern "C" int mh_conv2d_planes(const mh_conv_desc* d, const void* in_hi, const void* in_lo, int32_t in_pld, const void* wb32, const float* bias,
@@ -412,6 +477,7 @@ extern "C" int mh_conv2d_planes(const mh_conv_desc* d, const void* in_hi, const 
                "mh_conv2d_planes: tensors must be < 2 GiB");
     PlanesArgs a = {};
     a.in_hi = (const unsigned short*)in_hi; a.in_lo = (const unsigned short*)in_lo; a.wb = wb32; a.bias = bias;
+    a.mask_hi = nullptr; a.mask_pld = 0; a.mask_alpha = 1.0f;
     a.out = out; a.out_hi = (unsigned short*)out_hi; a.out_lo = (unsigned short*)out_lo;
     a.in_bytes = (unsigned)(npix * in_pld * 2);
     a.wb_bytes = (unsigned)mh_pack32_bytes(9, d->K, d->N);

@@ -159,6 +159,10 @@ static int run_op(const mh_op& o, void* s) {
             mh_conv_desc d; desc_from_op(o, d);
             return mh_conv2d_planes(&d, p[0], p[1], i[23], p[2], (const float*)p[3], (float*)p[4], p[5], p[6], i[24], s);
         }
+        case MH_OP_CONV_PLANES_BWD: {   // i = the forward layer's mh_conv_desc ints, i[23] = dz_pld, i[24] = mask_pld, i[25] = dx_pld ; p: dz_hi bank mask_hi dx dx_hi
+            mh_conv_desc d; desc_from_op(o, d);
+            return mh_conv2d_planes_bwd(&d, p[0], i[23], p[1], p[2], i[24], (float*)p[3], p[4], i[25], s);
+        }
         case MH_OP_STAMP:
             return mh_stamp(p[0], s);
         case MH_OP_PLANE_SPLIT:

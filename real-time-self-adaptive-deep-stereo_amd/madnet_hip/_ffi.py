@@ -31,7 +31,7 @@ class Op(C.Structure):
 (OP_CONV, OP_WGRAD, OP_CORR_FWD, OP_CORR_BWD, OP_WARP_FWD, OP_WARP_BWD, OP_RESIZE_FWD, OP_RESIZE_BWD,
  OP_PAD_REFLECT, OP_LOSS, OP_METRICS, OP_MOMENTUM, OP_COPY_CH, OP_LEAKY_BWD, OP_FILL, OP_BIAS_GRAD,
  OP_WGRAD_PARTIAL, OP_WGRAD_REDUCE, OP_PROXY_LOSS, OP_SUPERVISED_LOSS, OP_ADAM, OP_ADAM_ADVANCE, OP_RESIZE_IMAGE, OP_LEVEL_FRONT, OP_RESERVED_25, OP_PACK_W, OP_CORR_WARP_BWD,
- OP_SHADOW_CAST, OP_WGRAD_STREAM, OP_HEAD_BWD, OP_HEAD_FWD, OP_CONV_PLANES, OP_PLANE_SPLIT, OP_STAMP) = range(1, 35)
+ OP_SHADOW_CAST, OP_WGRAD_STREAM, OP_HEAD_BWD, OP_HEAD_FWD, OP_CONV_PLANES, OP_PLANE_SPLIT, OP_STAMP, OP_CONV_PLANES_BWD) = range(1, 36)
 
 
 OP_JOIN = 0x100
@@ -106,6 +106,8 @@ SIGNATURES = {
     "mh_conv2d_planes_ok": (_I, [C.POINTER(ConvDesc)]),
     "mh_conv2d_planes": (_I, [C.POINTER(ConvDesc), _P, _P, _I, _P, _P, _P, _P, _P, _I, _P]),
     "mh_plane_split": (_I, [_P, _I, _I, _P]),
+    "mh_conv2d_planes_bwd_ok": (_I, [C.POINTER(ConvDesc)]),
+    "mh_conv2d_planes_bwd": (_I, [C.POINTER(ConvDesc), _P, _I, _P, _P, _I, _P, _P, _I, _P]),
     "mh_tune_conv_planes": (_I, [_I]),
     "mh_tune_conv_bank": (_I, [_I]),
     "mh_tune_wgrad_image": (_I, [_I]),
@@ -172,7 +174,7 @@ SIGNATURES = {
     "mh_event_destroy": (_I, [_P]),
     "mh_stream_sync": (_I, [_P]),
 }
-_NO_STATUS = {"mh_stamp_rate_khz", "mh_pack32_bytes", "mh_conv2d_planes_ok", "mh_tune_conv_planes", "mh_tune_wgrad_target_pct", "mh_tune_wgrad_image", "mh_conv2d_takes_shadows", "mh_tune_conv_bank_tile", "mh_tune_conv_rows", "mh_last_error", "mh_last_kernel", "mh_tune_conv_bank", "mh_pack_bytes", "mh_abi_version", "mh_tune_conv_patch", "mh_crc32c", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats", "mh_proxy_ws_floats"}
+_NO_STATUS = {"mh_conv2d_planes_bwd_ok", "mh_stamp_rate_khz", "mh_pack32_bytes", "mh_conv2d_planes_ok", "mh_tune_conv_planes", "mh_tune_wgrad_target_pct", "mh_tune_wgrad_image", "mh_conv2d_takes_shadows", "mh_tune_conv_bank_tile", "mh_tune_conv_rows", "mh_last_error", "mh_last_kernel", "mh_tune_conv_bank", "mh_pack_bytes", "mh_abi_version", "mh_tune_conv_patch", "mh_crc32c", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats", "mh_proxy_ws_floats"}
 
 
 class MadnetHipError(RuntimeError):

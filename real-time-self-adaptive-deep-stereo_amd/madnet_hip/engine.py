@@ -123,6 +123,9 @@ PLANES_ONLY = True
 # ... and the planes of tensors no plane kernel produces are written by THEIR producers (the level front end, the exact-fp32 layers in front of conv4 /
 # conv6, one concat-split for the context network's input) instead of by a split launch in front of every consumer
 FUSE_SPLITS = True
+# ... and the INPUT GRADIENTS of those layers (and of the 1/8-resolution estimator's) run the same kernel with one plane (mh_conv2d_planes_bwd): dz from the
+# bf16 shadow its producer wrote, the leaky mask from the activation's hi plane, the result as a shadow (+ fp32 only where something reads it)
+PLANES_DGRAD = True
 # diagnostics (bench.py --stamps): device time stamps (mh_stamp) recorded as plan ops at the start of the step, the end of the forward pass, the first
 # op of the side lane, the start / end of every filter-gradient batch, the end of the input-gradient chain, the join and the end of the step --
 # the REPLAYED graph timed from the inside, without a tracer.  Each stamp is a one-lane kernel: the stamped plan is a few us slower than the plain one.
@@ -234,6 +237,7 @@ class MadNetEngine(object):
         self._stream_train = set()          # trainable variables of that plan
         self.use_planes = self.use_bank and precision == "mixed" and USE_PLANES
         self.banks32 = {}                   # layer -> fragment bank in the 32x32x16 image (mh_pack_weights trans = 2)
+        self.banks32t = {}                  # layer -> the input gradient's one-plane bank in that image (trans = 3)
         self.planes = {}                    # (data pointer, B, H, W, C) -> ops.Planes (hi = the entry of self.shadows)
         self._fresh_planes = set()          # planes (hi AND lo) a producer wrote in the plan being recorded
 
@@ -389,6 +393,10 @@ class MadNetEngine(object):
                 plan.append((n, 1, 0))
             if n in stride2:
                 continue                                            # (forward only: the stride-2 input gradient runs parity classes on the tiled kernel)
+            if bcode == 1 and pix > self.bank_small_maxpix and PYR[int(n.rsplit("conv", 1)[1]) - 1][2] == 1 if "pyramid" in n else (bcode == 1 and pix > self.bank_small_maxpix):
+                if self._planes_bwd_layer(K, N):
+                    plan.append((n, 1, 3))
+                    continue
             if bcode == 1 and pix <= 2 * self.bank_small_maxpix and K >= 16 and N >= 16 and 9 * ((N + 31) // 32) <= 64:
                 plan.append((n, 1, 1))
         return plan
@@ -405,8 +413,16 @@ class MadNetEngine(object):
         """does mh_conv2d_planes have an instance for a stride-1 3x3 layer with K input / N output channels?  (csrc/conv_planes.hip)"""
         return self.use_planes and N % 8 == 0 and N <= 128 and ((K + 15) // 16) in (2, 3, 4, 5, 6, 8)
 
+    def _planes_bwd_layer(self, K, N):
+        """does mh_conv2d_planes_bwd have an instance for the input gradient of a stride-1 3x3 layer K -> N?"""
+        if not (self.use_planes and PLANES_DGRAD):
+            return False
+        import ctypes as C
+        d = ops.conv_desc(1, 8, 8, 8, 8, K, N, 3, 3, 1, 1, 1, 1, 0, 0, K, 0, precision=1)
+        return self.lib.conv2d_planes_bwd_ok(C.byref(d)) == 1
+
     def _bank_of(self, trans):
-        return {0: self.banks, 1: self.banks_d, 2: self.banks32}[trans]
+        return {0: self.banks, 1: self.banks_d, 2: self.banks32, 3: self.banks32t}[trans]
 
     def _planes_of(self, v):
         """the Planes object of View v (allocated on first use; its hi plane is v's Shadow)"""
@@ -641,6 +657,11 @@ class MadNetEngine(object):
                 out[t.data_ptr()] = t.numel() * 4
         for t in self.Cx:
             out[t.data_ptr()] = t.numel() * 4
+        for k in LEVELS:                    # ... and the gradient maps between the input gradients of an estimator / the context network
+            for t in self.dE[k]:
+                out[t.data_ptr()] = t.numel() * 4
+        for t in self.dCx:
+            out[t.data_ptr()] = t.numel() * 4
         return out
 
     def _elide_fp32_activations(self, r):
@@ -656,9 +677,13 @@ class MadNetEngine(object):
         cand = self._standalone_activations()
         n = 0
         for idx, o in enumerate(ops_):
-            if o.kind != _ffi.OP_CONV_PLANES or not o.p[4] or not (o.p[5] and o.p[6]):
+            if o.kind == _ffi.OP_CONV_PLANES and o.p[4] and o.p[5] and o.p[6]:
+                slot = 4                    # forward: fp32 result beside both planes
+            elif o.kind == _ffi.OP_CONV_PLANES_BWD and o.p[3] and o.p[4]:
+                slot = 3                    # input gradient: fp32 map beside its shadow
+            else:
                 continue
-            lo = int(o.p[4])
+            lo = int(o.p[slot])
             if lo not in cand:
                 continue
             hi = lo + cand[lo]
@@ -671,19 +696,23 @@ class MadNetEngine(object):
                 hits = [k for k in range(8) if q.p[k] and lo <= int(q.p[k]) < hi]
                 if not hits:
                     continue
-                # the only tolerated reader: an input gradient that was given this tensor as its leaky mask TOGETHER with the mask's shadow and whose
-                # kernel tests the shadow
+                # the only tolerated readers: an input gradient (tiled families) that was given this tensor as its leaky mask TOGETHER with the mask's
+                # shadow and whose kernel tests the shadow -- or as its dz together with dz's shadow and whose kernel stages the shadow
                 if (q.kind == _ffi.OP_CONV and q.i[13] == 1 and hits == [4] and int(q.p[4]) == lo and (q.i[23] & 2) and q.i[22] == 1
                         and (self._takes_shadows(q) & 2)):
-                    mask_users.append(q)
+                    mask_users.append((q, 16))          # MH_CONV_MASK_F32_STALE
+                    continue
+                if (q.kind == _ffi.OP_CONV and q.i[13] == 1 and hits == [0] and int(q.p[0]) == lo and (q.i[23] & 1) and q.i[22] == 1
+                        and (self._takes_shadows(q) & 1)):
+                    mask_users.append((q, 8))           # MH_CONV_IN_F32_STALE
                     continue
                 ok = False
                 break
             if not ok:
                 continue
-            o.p[4] = None
-            for q in mask_users:
-                q.i[23] |= 16           # MH_CONV_MASK_F32_STALE
+            o.p[slot] = None
+            for q, bit in mask_users:
+                q.i[23] |= bit
             n += 1
         return n
 
@@ -890,7 +919,21 @@ class MadNetEngine(object):
             if trainable:
                 wgrad(xv, dzv, base, stride=stride, dil=dil)
             if need_dx:
-                ops.conv2d_dgrad(lib, dzv, self.W_(base), dxv, stride=stride, dil=dil, accumulate=acc_flag(dx_key),
+                acc = acc_flag(dx_key)
+                wbt = self.banks32t.get(base) if (stride == 1 and not acc) else None
+                dzs = self._fresh_shadow(dzv) if wbt is not None else None
+                mks = self._fresh_shadow(x_act) if (wbt is not None and x_act is not None) else None
+                if wbt is not None and dzs is not None and (x_act is None or mks is not None):
+                    # one-plane walk of the planes kernel: dz from its shadow, the mask from the activation's hi plane; the result leaves as a shadow
+                    # (always: the next input gradient stages it) and, until the post-pass proves that nothing reads it, as fp32
+                    key = (dxv.ptr, dxv.B, dxv.H, dxv.W, dxv.C)
+                    sh = self.shadows.get(key)
+                    if sh is None:
+                        sh = self.shadows[key] = ops.Shadow(dxv.B, dxv.H, dxv.W, dxv.C, self.dev)
+                    ops.conv2d_planes_bwd(lib, dzs, self.W_(base), wbt, dx=dxv, dx_shadow=sh, mask_shadow=mks, mask_alpha=ALPHA, dil=dil)
+                    self._fresh.add(key)
+                    return
+                ops.conv2d_dgrad(lib, dzv, self.W_(base), dxv, stride=stride, dil=dil, accumulate=acc,
                                  mask_ref=x_act, mask_alpha=ALPHA, wb=self.Wd_(base),
                                  shadow=(self._out_shadow(dxv, below) if below else None), dz_shadow=self._fresh_shadow(dzv),
                                  mask_shadow=(self._fresh_shadow(x_act) if x_act is not None else None))
@@ -1046,6 +1089,14 @@ class MadNetEngine(object):
                 if need_dx:
                     # dF[i-1] is complete after this launch (the cost-volume contributions were written earlier): it is the dz of layer i - 1
                     sh = self._out_shadow(self._fv(self.dF[i - 1]), pyr_name(i - 1)) if (i - 1 > 1) else None       # (conv1's 3-channel input keeps the tiled kernel)
+                    wbt = self.banks32t.get(pyr_name(i)) if (PYR[i - 1][2] == 1 and not accumulate) else None
+                    dzs = self._fresh_shadow(self._fv(self.dF[i])) if wbt is not None else None
+                    mks = self._fresh_shadow(self._fv(self.F[i - 1])) if wbt is not None else None
+                    if wbt is not None and dzs is not None and mks is not None and sh is not None:
+                        ops.conv2d_planes_bwd(lib, dzs, self.W_(pyr_name(i)), wbt, dx=self._fv(self.dF[i - 1]), dx_shadow=sh, mask_shadow=mks, mask_alpha=ALPHA)
+                        if i % 4 == 1:
+                            flush(lane=(tail_lane if i == 1 else None))
+                        continue
                     ops.conv2d_dgrad(lib, self._fv(self.dF[i]), self.W_(pyr_name(i)), self._fv(self.dF[i - 1]),
                                      stride=PYR[i - 1][2], accumulate=accumulate, mask_ref=self._fv(self.F[i - 1]),
                                      mask_alpha=ALPHA, wb=self.Wd_(pyr_name(i)), shadow=sh,

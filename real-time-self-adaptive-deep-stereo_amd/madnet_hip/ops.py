@@ -136,6 +136,8 @@ def pack_bytes(w, planes=2, trans=0):
     kh, kw, K, N = w.shape
     if trans == 2:          # the 32x32x16 register image of conv2d_planes (hi + lo)
         return kh * kw * ((K + 15) // 16) * ((N + 31) // 32) * 2048
+    if trans == 3:          # ... of conv2d_planes_bwd: one plane, reduction over Cout, columns = Cin
+        return kh * kw * ((N + 15) // 16) * ((K + 31) // 32) * 1024
     if trans:
         K, N = N, K
     return kh * kw * ((K + 31) // 32) * ((N + 15) // 16) * planes * 1024
@@ -154,13 +156,13 @@ def pack_weights(lib, pairs, device, keep, stream=None):
         planes = pr[2] if len(pr) > 2 else 2
         trans = pr[3] if len(pr) > 3 else 0
         kh, kw, K, N = src.shape
-        if trans == 1:
+        if trans in (1, 3):
             K, N = N, K
         assert dst.numel() * dst.element_size() >= pack_bytes(src, planes, trans) and dst.data_ptr() % 16 == 0
-        assert trans != 2 or planes == 2
+        assert (trans != 2 or planes == 2) and (trans != 3 or planes == 1)
         arr[i].src, arr[i].dst, arr[i].taps, arr[i].K, arr[i].N = src.data_ptr(), dst.data_ptr(), kh * kw, K, N
         arr[i].planes, arr[i].blk0, arr[i].trans = planes, blk, trans
-        if trans == 2:
+        if trans in (2, 3):
             blk += (kh * kw * ((K + 15) // 16) * ((N + 31) // 32) * 64 + 255) // 256
         else:
             blk += (kh * kw * ((K + 31) // 32) * ((N + 15) // 16) * 64 + 255) // 256
@@ -337,6 +339,29 @@ def conv2d_planes(lib, xp, w, wb32, b, out=None, out_planes=None, dil=1, alpha=1
     if out is not None:
         assert (out.B, out.H, out.W, out.C) == (xp.B, xp.H, xp.W, cout)
     lib.conv2d_planes(C.byref(d), C.c_void_p(xp.hi.ptr), C.c_void_p(xp.lo.ptr), xp.ld, _p(wb32), _p(b), _p(out), ohi, olo, opld, _p(stream))
+
+
+def conv2d_planes_bwd_ok(qlib, dx, w, dil=1):
+    """does conv2d_planes_bwd have an instance for the input gradient of this stride-1 'SAME' 3x3 layer (w: HWIO of the forward layer)?"""
+    kh, kw, cin, cout = w.shape
+    if (kh, kw) != (3, 3):
+        return False
+    d = conv_desc(dx.B, dx.H, dx.W, dx.H, dx.W, cin, cout, 3, 3, 1, dil, dil, dil, 0, 0, dx.ld, 0, precision=1)
+    return qlib.conv2d_planes_bwd_ok(C.byref(d)) == 1
+
+
+def conv2d_planes_bwd(lib, dz_shadow, w, wb32t, dx=None, dx_shadow=None, mask_shadow=None, mask_alpha=1.0, dil=1, stream=None):
+    """dx = conv2d_backprop_input(dz, w) * leaky'(mask) from the bf16 shadow of dz (mh_conv2d_planes_bwd): w HWIO [3,3,Cin,Cout] of the forward layer,
+    wb32t = pack_weights(trans = 3) bank; results: dx (fp32 View or None) and / or dx_shadow (Shadow); mask_shadow: Shadow of the layer's input."""
+    kh, kw, cin, cout = w.shape
+    assert (kh, kw) == (3, 3) and dz_shadow.C == cout
+    B, H, W = dz_shadow.B, dz_shadow.H, dz_shadow.W
+    d = conv_desc(B, H, W, H, W, cin, cout, 3, 3, 1, dil, dil, dil, 0, 0, (dx.ld if dx is not None else 0), 0, mask_alpha=mask_alpha, precision=1)
+    for t in (dx, dx_shadow, mask_shadow):
+        assert t is None or (t.B, t.H, t.W, t.C) == (B, H, W, cin)
+    sp = lambda sh: C.c_void_p(sh.ptr) if sh is not None else None
+    lib.conv2d_planes_bwd(C.byref(d), C.c_void_p(dz_shadow.ptr), dz_shadow.ld, _p(wb32t), sp(mask_shadow), (mask_shadow.ld if mask_shadow is not None else 0),
+                          _p(dx), sp(dx_shadow), (dx_shadow.ld if dx_shadow is not None else 0), _p(stream))
 
 
 def plane_split(lib, pairs, device, keep, stream=None):

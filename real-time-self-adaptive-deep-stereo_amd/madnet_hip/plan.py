@@ -121,6 +121,14 @@ class Recorder(object):
     def stamp(self, slot, stream):
         self._op(_ffi.OP_STAMP, [], [], [slot])
 
+    def conv2d_planes_bwd(self, dref, dz_hi, dz_pld, wb32t, mask_hi, mask_pld, dx, dx_hi, dx_pld, stream):
+        d = dref._obj
+        # (tallied as the input-gradient launch it is: flops of the layer, dz in, dx out)
+        flops = 2.0 * d.B * d.Hi * d.Wi * 9 * d.K * d.N
+        self.stats["conv_flops"] += flops; self.stats["conv_bytes"] += 4.0 * (d.B * d.Hi * d.Wi * (d.K + d.N) + 9 * d.K * d.N); self.stats["conv_launches"] += 1
+        ints = self._desc_ints(d) + [0, 1, dz_pld, mask_pld, dx_pld]
+        self._op(_ffi.OP_CONV_PLANES_BWD, ints, [d.alpha, d.mask_alpha], [dz_hi, wb32t, mask_hi, dx, dx_hi])
+
     def plane_split(self, segs, nseg, nblocks, stream):
         self._op(_ffi.OP_PLANE_SPLIT, [nseg, nblocks], [], [segs])
 

@@ -56,4 +56,4 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_ffi.ConvDesc) == 24 * 4
     assert ctypes.sizeof(_ffi.Op) == 4 + 27 * 4 + 4 * 4 + 8 * 8 + 8
     assert ctypes.sizeof(_ffi.ShadowSeg) == 2 * 8 + 8 + 4 * 4 and ctypes.sizeof(_ffi.WgsLayer) == 4 * 8 + 14 * 4
-    assert ctypes.sizeof(_ffi.PlaneSeg) == 3 * 8 + 8 + 4 * 4
+    assert ctypes.sizeof(_ffi.PlaneSeg) == 3 * 8 + 8 + 4 * 4 + 8 + 2 * 4

@@ -142,3 +142,57 @@ def test_conv2d_planes_argument_checks(backend):
     assert rc == -2
     assert not ops.conv2d_planes_ok(lib, ops.view(torch.zeros(1, 4, 8, 200, device=dev)), torch.zeros(3, 3, 200, 32), 1)      # K > 128
     assert not ops.conv2d_planes_ok(lib, ops.view(x), torch.zeros(3, 3, 64, 160), 1)                                            # N > 128
+
+
+# (B, H, W, Cin, Cout, dil, variant): the input gradients of the layers above (reduction over Cout, columns = Cin)
+BWD_CASES = [
+    (1, 9, 37, 128, 128, 1, 0), (1, 11, 21, 128, 128, 2, 3), (1, 12, 40, 128, 96, 1, 2), (2, 7, 33, 96, 64, 1, 0), (1, 18, 20, 96, 64, 4, 4),
+    (1, 9, 34, 64, 32, 1, 0), (2, 8, 40, 32, 32, 1, 1), (1, 10, 35, 64, 64, 1, 5), (1, 6, 20, 64, 64, 16, 0),
+]
+
+
+@pytest.mark.parametrize("case", BWD_CASES)
+def test_conv2d_planes_bwd_vs_oracle_and_bf16_input_gradient(backend, case):
+    """mh_conv2d_planes_bwd: dx = conv2d_backprop_input(dz, w) * leaky'(x) from the bf16 shadow of dz and the one-plane mirrored / transposed bank
+    (mh_pack_weights trans = 3).  Against the oracle run on identically rounded operands (products of bf16 values are exact in fp32: only the fp32
+    summation order differs) and against the existing bf16 input-gradient kernel on the fp32 tensors; the shadow of dx is bf16(dx) bit for bit."""
+    B, H, W, Ci, Co, dil, variant = case
+    lib, dev = backend.lib, backend.device
+    dz = _rand((B, H, W, Co), 411, dev)
+    w = _rand((3, 3, Ci, Co), 412, dev, 0.2)
+    x = _rand((B, H, W, Ci), 413, dev)           # the forward layer's input: only its sign matters (leaky mask)
+    keep = []
+    # oracle: autograd of the forward conv on bf16-rounded dz / w (what precision code 1 computes)
+    wq = w.cpu().to(torch.bfloat16).double()
+    dzq = dz.cpu().to(torch.bfloat16).double()
+    xin = torch.zeros(B, H, W, Ci, dtype=torch.float64, requires_grad=True)
+    y = T.conv2d(xin, wq, None, stride=1, dilation=dil, alpha=1.0)
+    (g_ref,) = torch.autograd.grad(y, xin, dzq)
+    g_ref = (g_ref * torch.where(x.cpu().double() > 0, 1.0, 0.2)).float()
+    assert ops.conv2d_planes_bwd_ok(lib, ops.view(x), w, dil)
+    dzs = ops.Shadow(B, H, W, Co, dev); xs = ops.Shadow(B, H, W, Ci, dev)
+    ops.shadow_cast(lib, [(ops.view(dz), dzs), (ops.view(x), xs)], dev, keep)
+    bank = torch.full((ops.pack_bytes(w, 1, 3) // 4,), float("nan"), device=dev)
+    ops.pack_weights(lib, [(w, bank, 1, 3)], dev, keep)
+    dx = torch.full((B, H, W, Ci), float("nan"), device=dev)
+    dxs = ops.Shadow(B, H, W, Ci, dev)
+    lib.tune_conv_planes(variant)
+    try:
+        ops.conv2d_planes_bwd(lib, dzs, w, bank, dx=ops.view(dx), dx_shadow=dxs, mask_shadow=xs, mask_alpha=0.2, dil=dil)
+        name = lib.last_kernel().decode()
+        dxs2 = ops.Shadow(B, H, W, Ci, dev)
+        ops.conv2d_planes_bwd(lib, dzs, w, bank, dx=None, dx_shadow=dxs2, mask_shadow=xs, mask_alpha=0.2, dil=dil)       # shadow only
+        backend.sync()
+    finally:
+        assert lib.tune_conv_planes(0) == 2
+    assert "conv_planes_kernel" in name and ",bf16>" in name, name
+    dxc = dx.cpu()
+    scale = max(1.0, g_ref.abs().max().item())
+    assert torch.isfinite(dxc).all() and (dxc - g_ref).abs().max().item() <= 2e-5 * scale, ((dxc - g_ref).abs().max().item(), name)
+    assert torch.equal(dxs.t.cpu()[..., :Ci], dxc.to(torch.bfloat16)) and torch.equal(dxs2.t.cpu(), dxs.t.cpu())
+    # the existing bf16 input-gradient path on the fp32 tensors (same rounding of both operands)
+    dx0 = torch.zeros(B, H, W, Ci, device=dev)
+    with ops.precision_scope("bf16"):
+        ops.conv2d_dgrad(lib, ops.view(dz), w, ops.view(dx0), dil=dil, mask_ref=ops.view(x), mask_alpha=0.2)
+    backend.sync()
+    assert (dxc - dx0.cpu()).abs().max().item() <= 2e-5 * scale

@@ -884,7 +884,8 @@ def test_mixed_forward_from_planes_matches_fp32_operand_path(bname, mode):
             kinds = [o.kind for o in pops]
             elided = sum(1 for o in pops if o.kind == _ffi.OP_CONV_PLANES and not o.p[4])
             res[planes] = dict(pred=eng.pred.cpu().clone(), loss=eng.res_loss[0].item(), w={n: eng.params.tensor(n).cpu().clone() for n in wn},
-                               nplanes=nplanes, nrec=kinds.count(_ffi.OP_CONV_PLANES), elided=elided, splits=kinds.count(_ffi.OP_PLANE_SPLIT))
+                               nplanes=nplanes, nrec=kinds.count(_ffi.OP_CONV_PLANES), elided=elided, splits=kinds.count(_ffi.OP_PLANE_SPLIT),
+                               nbwd=kinds.count(_ffi.OP_CONV_PLANES_BWD), bwd_elided=sum(1 for o in pops if o.kind == _ffi.OP_CONV_PLANES_BWD and not o.p[3]))
     finally:
         E.USE_PLANES = True
         E.FUSE_SPLITS = True
@@ -892,9 +893,13 @@ def test_mixed_forward_from_planes_matches_fp32_operand_path(bname, mode):
     a, b = res[True], res[False]
     if "unfused" in res:        # split launches in front of every consumer instead: the same planes, bit for bit the same step
         u = res["unfused"]
-        assert u["splits"] == 4 and u["nplanes"] == 13
+        assert u["splits"] == 4 and u["nrec"] == 13 and u["nplanes"] == 13 + u["nbwd"]
         assert torch.equal(u["pred"], a["pred"])               # (the post-step weights carry the landing order of the fp32 atomics: compared below, against `b`)
-    assert a["nrec"] == 13 and a["nplanes"] == 13 and b["nrec"] == 0 and b["nplanes"] == 0, (a["nrec"], a["nplanes"], b["nrec"])     # conv4, conv6, 5 of estimator 2, 6 of the context network
+    assert a["nrec"] == 13 and a["nplanes"] == 13 + a["nbwd"] and b["nrec"] == 0 and b["nplanes"] == 0, (a["nrec"], a["nplanes"], b["nrec"])     # conv4, conv6, 5 of estimator 2, 6 of the context network
+    # the input gradients of those layers on the same kernel (one plane): 4 of estimator 2 + 5 of the context network + conv4 / conv6 in the FULL step,
+    # most of their fp32 gradient maps never stored
+    assert a["nbwd"] == {"FULL": 11, "MAD4": 9, "NONE": 0}[mode] and b["nbwd"] == 0, a["nbwd"]
+    assert mode == "NONE" or a["bwd_elided"] >= 5, a["bwd_elided"]
     # one split launch left: the concat-split of the context network's input; the inputs of conv4 / conv6 and the estimator's concat buffer get their
     # planes from their producers' epilogues (engine.FUSE_SPLITS)
     assert a["splits"] == 1
