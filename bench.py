@@ -645,7 +645,7 @@ def main():
                 name, f = next(iter(fam.items()))
                 i_top = f["top_index"]
                 kn = rows[i_top][2]
-                fam_rows = [rw for rw in rows if rw[2].startswith(name)]
+                fam_rows = [rw for rw in rows if BT.family_key(rw[2]) == name]
                 fl = sum(p_t.work.get(rw[0], BT.op_work(p_t.arr[rw[0]]))[0] for rw in fam_rows)
                 by = sum(p_t.work.get(rw[0], BT.op_work(p_t.arr[rw[0]]))[1] for rw in fam_rows)
                 fl_top = p_t.work.get(i_top, BT.op_work(p_t.arr[i_top]))[0]
@@ -655,8 +655,8 @@ def main():
                 tr = sum(trs) if all(t is not None for t in trs) else None
                 out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                    "mfma_issue_frac": (3.0 if "bf16x3" in kn else 1.0) * ach / peak,
-                                   "traffic": tr, "traffic_source": ("profiles/r03_pmc_roofline.json: sum over this family's launches, keyed by their kernel strings (rocprofv3 --pmc "
-                                                                     "FETCH_SIZE / WRITE_SIZE passes over the same plan: scripts/gpu_pmc_r03.sh)") if tr is not None else None,
+                                   "traffic": tr, "traffic_source": ("%s: sum over this family's launches, keyed by their kernel strings (rocprofv3 --pmc "
+                                                                     "FETCH_SIZE / WRITE_SIZE passes over the same plan: scripts/gpu_pmc_r04.sh)" % BT.PMC_SOURCE) if tr is not None else None,
                                    "launch_ms": f["us_per_step"] * 1e-3 / f["launches"], "launches_per_step": f["launches"], "us_per_step": f["us_per_step"],
                                    "algorithmic_flops_per_step": fl, "algorithmic_bytes_per_step": by,
                                    "share_of_kernel_time": f["us_per_step"] / tot if tot else None,
@@ -666,28 +666,41 @@ def main():
                                                       "traffic": BT._pmc_traffic(kn)},
                                    "selection": "the kernel family the recorded plan spends most time in, from the plan's own launch table (every op timed alone with HIP events, "
                                                 "10 launches each); achieved = the family's algorithmic flops per step / its summed launch time; frac against the DENSE bf16 MFMA peak"}
-                out["kernel_families"] = [{"kernel": k, "launches": v["launches"], "us_per_step": v["us_per_step"]} for k, v in list(fam.items())[:12]]
+                # every family of the table: time, algorithmic work and -- where the committed PMC passes cover all of its launches -- HBM traffic
+                kf = []
+                for k, v in list(fam.items())[:12]:
+                    rws = [rw for rw in rows if BT.family_key(rw[2]) == k]
+                    wk = [p_t.work.get(rw[0], BT.op_work(p_t.arr[rw[0]])) for rw in rws]
+                    f_fl, f_by = sum(x[0] for x in wk), sum(x[1] for x in wk)
+                    f_tr = [BT._pmc_traffic(rw[2]) for rw in rws]
+                    f_peak = BT.PEAK_F32_MFMA_TFLOPS if (",f32," in k.replace(" ", "") or "wgrad_kernel<" in k) else BT.PEAK_BF16_MFMA_TFLOPS
+                    ent = {"kernel": k, "launches": v["launches"], "us_per_step": v["us_per_step"]}
+                    if f_fl > 0 and v["us_per_step"] > 0:
+                        ent["achieved_tflops"] = f_fl / (v["us_per_step"] * 1e-6) / 1e12
+                        ent["frac"] = ent["achieved_tflops"] / f_peak
+                    if f_by > 0 and v["us_per_step"] > 0:
+                        ent["algorithmic_gbs"] = f_by / (v["us_per_step"] * 1e-6) / 1e9
+                        ent["hbm_frac"] = ent["algorithmic_gbs"] / BT.PEAK_HBM_GBS
+                        ent["algorithmic_bytes_per_step"] = f_by
+                    ent["traffic"] = sum(f_tr) if f_tr and all(t is not None for t in f_tr) else None
+                    kf.append(ent)
+                out["kernel_families"] = kf
                 out["kernel_time_sum_us"] = tot
                 del e_t, p_t
             except Exception as ex:      # never let the auxiliary measurement kill the bench line
                 out["roofline"] = {"error": repr(ex)}
             _log("roofline done")
-        d_or = None
-        if not args.no_cpu_baseline:
-            d_or = oracle_disparity(wn, l, r)
+        # every GPU measurement first, the CPU oracle (epe_vs_oracle, cpu_baseline: ~10 s of host time) last: a timeout can only cost the auxiliary keys
+        preds = {}
 
-        def epe_of(e):
+        def pred_of(prec):
+            e = mk(prec); feed(e)
             e.build_plan("NONE").run(lib, 0)
             torch.cuda.synchronize()
-            return float((e.pred.cpu() - d_or).abs().mean().item())
+            return e.pred.cpu().clone()
 
-        if d_or is not None:
-            e0 = mk(args.precision); feed(e0)
-            out["epe_vs_oracle"] = epe_of(e0)
-            out["epe_tolerance"] = 1e-3
-            out["within_tolerance"] = out["epe_vs_oracle"] <= 1e-3
-            del e0
-            _log("epe_vs_oracle %.3g" % out["epe_vs_oracle"])
+        if not args.no_cpu_baseline:
+            preds[args.precision] = pred_of(args.precision)
         if not args.no_paths:
             out["paths"] = {}
             for prec in ("fp32", "bf16", "mixed"):
@@ -702,11 +715,8 @@ def main():
                     reg = timed_regions(dev, None, step2, min(args.steps, 20), 3)
                 ms2 = statistics.median(1e3 * x / min(args.steps, 20) for x in reg)
                 out["paths"][prec] = {"dtype": DTYPE_LABEL[prec], "ms_per_step": ms2, "value": 1e3 / ms2, "unit": "pairs/s"}
-                if d_or is not None:
-                    e3 = mk(prec); feed(e3)
-                    out["paths"][prec]["epe_vs_oracle"] = epe_of(e3)
-                    out["paths"][prec]["within_tolerance"] = out["paths"][prec]["epe_vs_oracle"] <= 1e-3
-                    del e3
+                if not args.no_cpu_baseline:
+                    preds[prec] = pred_of(prec)
                 del e2
             _log("paths done")
         if args.drift_steps > 0 and args.precision != "fp32" and not args.no_paths:
@@ -722,6 +732,18 @@ def main():
                 out["step_surface"] = {"error": repr(ex)}
             _log("step surface done")
         if not args.no_cpu_baseline:
+            d_or = oracle_disparity(wn, l, r)
+            for prec, pr in preds.items():
+                epe = float((pr - d_or).abs().mean().item())
+                if prec == args.precision:
+                    out["epe_vs_oracle"] = epe
+                    out["epe_tolerance"] = 1e-3
+                    out["epe_note"] = "single-step: the disparity of ONE forward pass with the bench weights against the fp32 CPU oracle (drift over consecutive adaptation steps: `drift`)"
+                    out["within_tolerance"] = epe <= 1e-3
+                    _log("epe_vs_oracle %.3g" % epe)
+                elif "paths" in out and prec in out["paths"]:
+                    out["paths"][prec]["epe_vs_oracle"] = epe
+                    out["paths"][prec]["within_tolerance"] = epe <= 1e-3
             out["cpu_baseline"] = cpu_baseline(H, W, wn, l, r, gt, args.mode)
             _log("cpu baseline done")
     if dist is not None:

@@ -33,6 +33,8 @@ struct PatchGeo {
     float inv_kp4;          // 1 / (KP/4)
     unsigned mul_kp8;       // ceil(2^32 / (KP/8)): q / (KP/8) by multiplication (shadow staging)
     int dbg;                // timing experiments (scripts/microbench.py patchdbg): 1 = skip the K walk, 2 = skip the patch staging
+    mh_tile_decode dec;     // magic multipliers of the workgroup -> tile decode (mh_common.h)
+    mh_fastdiv f_kp4, f_pc; // ... and of the small-layer kernel's patch staging (item -> (pixel, 4-channel group), pixel -> (row, column))
 };
 
 constexpr int LSB = 80;     // weight tile row stride (halfs): 64 k + 16 pad = 40 dwords (conflict-free b128 reads)
@@ -59,13 +61,9 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1,
     const int li = lane & 15, lq = lane >> 4;
     const int d = p.dil;
 
-    int lin = mh_xcd_remap(blockIdx.x, g.nwg);
-    const int tile_n = lin % g.ntiles_n; lin /= g.ntiles_n;
-    const int ttx = lin % g.tiles_x; lin /= g.tiles_x;
-    const int tty = lin % g.tiles_y; lin /= g.tiles_y;
-    const int cx = lin % d; lin /= d;
-    const int cy = lin % d;
-    const int b = lin / d;
+    const int lin = mh_xcd_remap(blockIdx.x, g.nwg);
+    int tile_n, ttx, tty, cx, cy, b;
+    mh_decode_tile(lin, g.dec, tile_n, ttx, tty, cx, cy, b);
     const int n0 = tile_n * BN;
     const int y00 = cy + d * (tty * TH), x00 = cx + d * (ttx * 16);      // image position of tile pixel (0, 0)
 
@@ -590,13 +588,9 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1,
     const int li = lane & 15, lq = lane >> 4;
     const int d = p.dil;
 
-    int lin = mh_xcd_remap(blockIdx.x, g.nwg);
-    const int tile_n = lin % g.ntiles_n; lin /= g.ntiles_n;
-    const int ttx = lin % g.tiles_x; lin /= g.tiles_x;
-    const int tty = lin % g.tiles_y; lin /= g.tiles_y;
-    const int cx = lin % d; lin /= d;
-    const int cy = lin % d;
-    const int b = lin / d;
+    const int lin = mh_xcd_remap(blockIdx.x, g.nwg);
+    int tile_n, ttx, tty, cx, cy, b;
+    mh_decode_tile(lin, g.dec, tile_n, ttx, tty, cx, cy, b);
     const int n0 = tile_n * BN;
     const int y00 = cy + d * (tty * TH), x00 = cx + d * (ttx * 16);
 
@@ -788,19 +782,26 @@ __global__ __launch_bounds__(1024) void conv_bank_small_kernel(ConvArgs p, Patch
     const int st = DGRAD ? 1 : p.stride;             // forward: stride 1 (any dilation) or stride 2 (dilation 1): output pixel (i, j) reads patch (i*st + ky, j*st + kx)
     const int PC = st * 16 + 3 - st;                 // patch columns: 18 / 33 ; rows: st * TH + 3 - st = 4 / 5
 
-    int lin = mh_xcd_remap(blockIdx.x, g.nwg);
-    const int tile_n = lin % g.ntiles_n; lin /= g.ntiles_n;
-    const int ttx = lin % g.tiles_x; lin /= g.tiles_x;
-    const int tty = lin % g.tiles_y; lin /= g.tiles_y;
-    const int cx = lin % d; lin /= d;
-    const int cy = lin % d;
-    const int b = lin / d;
+    const int lin = mh_xcd_remap(blockIdx.x, g.nwg);
+    int tile_n, ttx, tty, cx, cy, b;
+    mh_decode_tile(lin, g.dec, tile_n, ttx, tty, cx, cy, b);
     const int n0 = tile_n * BN;
     const int y00 = cy + d * (tty * TH), x00 = cx + d * (ttx * 16);
 
     const __amdgpu_buffer_rsrc_t rs_in = mh_make_rsrc(p.in, p.in_bytes);
     const __amdgpu_buffer_rsrc_t rs_b = mh_make_rsrc(p.wb, p.wb_bytes);
 
+    // (the bias of this thread's output element: requested now, used in the epilogue -- a dependent global load there cost the launch a memory
+    //  round trip behind the reduction: round 4, scripts/exp/node_floor.py)
+    const int my_n = n0 + (tid & 31);
+    const float my_bias = (p.bias && my_n < p.N) ? p.bias[my_n] : 0.f;
+    // ... and the epilogue's other operands (the accumulation target, the leaky mask): their addresses are known now
+    const int my_row = tid >> 5;
+    const int my_y = y00 + (my_row >> 4) * d, my_x = x00 + (my_row & 15) * d;
+    const bool my_ok = my_y < p.Ho && my_x < p.Wo && my_n < p.N;
+    const int64_t my_m = ((int64_t)b * p.Ho + my_y) * p.Wo + my_x;
+    const float my_old = (my_ok && p.accumulate) ? p.out[my_m * p.out_ld + my_n] : 0.f;
+    const float my_mk = (my_ok && p.mask_ref) ? p.mask_ref[my_m * p.mask_ld + my_n] : 1.f;
     // ---- all weight fragments of this wave's chunks: requested first ------------------------------------------------------
     const int np16 = (p.N + 15) >> 4;
     const int stride_b = np16 * PL * 1024;
@@ -822,8 +823,8 @@ __global__ __launch_bounds__(1024) void conv_bank_small_kernel(ConvArgs p, Patch
         const int kp4 = g.KP >> 2;
         const int items = (st * TH + 3 - st) * PC * kp4;
         for (int q0 = tid; q0 < items; q0 += NTH) {
-            const int c4 = q0 % kp4, pp = q0 / kp4;
-            const int pi = pp / PC, pj = pp - pi * PC;
+            const int pp = mh_fdiv(q0, g.f_kp4), c4 = q0 - pp * kp4;
+            const int pi = mh_fdiv(pp, g.f_pc), pj = pp - pi * PC;
             const int iy = y00 * st - p.pad_t + pi * d, ix = x00 * st - p.pad_l + pj * d;      // (stride 1: pad = dilation)
             const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi && (c4 < p.G);
             float4 w = mh_buf_load4(rs_in, ok ? (((b * p.Hi + iy) * p.Wi + ix) * p.in_ld + c4 * 4) * 4 : MH_OOB);
@@ -888,17 +889,13 @@ __global__ __launch_bounds__(1024) void conv_bank_small_kernel(ConvArgs p, Patch
 #pragma unroll
         for (int w = 0; w < 16; ++w) v += Cs[(w * BM + row) * CS + col];
         const int n = n0 + col;
-        const int y = y00 + (row >> 4) * d, x = x00 + (row & 15) * d;
-        if (y < p.Ho && x < p.Wo && n < p.N) {
-            const int64_t m = ((int64_t)b * p.Ho + y) * p.Wo + x;
-            if (p.bias) v += p.bias[n];
+        if (my_ok) {
+            const int64_t m = my_m;
+            v += my_bias;
             if (p.alpha != 1.0f) v = v > 0.f ? v : p.alpha * v;
             float* dst = p.out + m * p.out_ld + n;
-            if (p.accumulate) v += *dst;
-            if (p.mask_ref) {
-                const float mk = p.mask_ref[m * p.mask_ld + n];
-                v *= (mk > 0.f || n < p.mask_c0 || n >= p.mask_c1) ? 1.0f : p.mask_alpha;
-            }
+            v += my_old;
+            if (p.mask_ref) v *= (my_mk > 0.f || n < p.mask_c0 || n >= p.mask_c1) ? 1.0f : p.mask_alpha;
             *dst = v;
             if (p.shadow) p.shadow[m * p.shadow_ld + n] = (unsigned short)mh_pack_bf16(v, 0.f);
         }
@@ -1014,6 +1011,7 @@ int launch_patch(ConvArgs& a, hipStream_t s) {
     g.tiles_x = mh_cdiv(mh_cdiv(a.Wo, d), 16);
     g.ntiles_n = mh_cdiv(a.N, BN);
     g.nwg = a.B * d * d * g.tiles_y * g.tiles_x * g.ntiles_n;
+    g.dec = mh_make_tile_decode(g.ntiles_n, g.tiles_x, g.tiles_y, d);
     g.KP = (a.K + 31) & ~31;
     g.CPT = g.KP / 32;
     g.PS = g.KP + 16;
@@ -1049,6 +1047,7 @@ int launch_bank(ConvArgs& a, hipStream_t s) {
     g.tiles_x = mh_cdiv(mh_cdiv(a.Wo, d), 16);
     g.ntiles_n = mh_cdiv(a.N, BN);
     g.nwg = a.B * d * d * g.tiles_y * g.tiles_x * g.ntiles_n;
+    g.dec = mh_make_tile_decode(g.ntiles_n, g.tiles_x, g.tiles_y, d);
     g.KP = (a.K + 31) & ~31;
     g.CPT = g.KP / 32;
     g.PS = g.KP + 16;
@@ -1083,12 +1082,14 @@ int launch_bank_small(ConvArgs& a, hipStream_t s) {
     g.tiles_x = mh_cdiv(mh_cdiv(a.Wo, d), 16);
     g.ntiles_n = mh_cdiv(a.N, 32);
     g.nwg = a.B * d * d * g.tiles_y * g.tiles_x * g.ntiles_n;
+    g.dec = mh_make_tile_decode(g.ntiles_n, g.tiles_x, g.tiles_y, d);
     g.KP = (a.K + 31) & ~31;
     g.CPT = g.KP / 32;
     g.PS = g.KP + 16;
     g.nchunk = 9 * g.CPT;
     const int st = DGRAD ? 1 : a.stride;
     g.patch_halfs = (st * 2 + 3 - st) * (st * 16 + 3 - st) * g.PS;
+    g.f_kp4 = mh_make_fastdiv(g.KP / 4); g.f_pc = mh_make_fastdiv(st * 16 + 3 - st);
     g.inv_kp4 = 1.0f / (float)(g.KP / 4);
     g.mul_kp8 = (unsigned)(((1ull << 32) + (g.KP / 8) - 1) / (g.KP / 8));
     g.dbg = 0;

@@ -34,6 +34,7 @@ struct PlanesArgs {
     int B, H, W, K, N, dil;
     float alpha;
     int tiles_y, tiles_x, ntiles_n, nwg;
+    mh_tile_decode dec;                                           // magic multipliers of the workgroup -> tile decode (mh_common.h)
     int dbg;                                                      // timing experiments: 1 = skip the K walk, 2 = skip the staging
 };
 
@@ -73,13 +74,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_planes_kernel(PlanesArgs p)
     const int wm = wave / WN, wn = wave % WN;
     const int d = p.dil;
 
-    int lin = mh_xcd_remap(blockIdx.x, p.nwg);
-    const int tile_n = lin % p.ntiles_n; lin /= p.ntiles_n;
-    const int ttx = lin % p.tiles_x; lin /= p.tiles_x;
-    const int tty = lin % p.tiles_y; lin /= p.tiles_y;
-    const int cx = lin % d; lin /= d;
-    const int cy = lin % d;
-    const int b = lin / d;
+    const int lin = mh_xcd_remap(blockIdx.x, p.nwg);
+    int tile_n, ttx, tty, cx, cy, b;
+    mh_decode_tile(lin, p.dec, tile_n, ttx, tty, cx, cy, b);
     const int n0 = tile_n * BN;
     const int y00 = cy + d * (tty * TR), x00 = cx + d * (ttx * MC);       // image position of tile pixel (0, 0)
 
@@ -214,11 +211,26 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_planes_kernel(PlanesArgs p)
 #pragma unroll
         for (int e = 0; e < 4; ++e) mh_split_bf16x2(v[2 * e], v[2 * e + 1], hh[e], ll[e]);
         const int op = ok ? (pix * p.out_pld + n) * 2 : MH_OOB;
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4){hh[0], hh[1], hh[2], hh[3]}, rs_oh, op, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4){ll[0], ll[1], ll[2], ll[3]}, rs_ol, op, 0, 0);
         const int of = ok ? (pix * p.out_ld + n) * 4 : MH_OOB;
-        mh_buf_store4(rs_o, of, make_float4(v[0], v[1], v[2], v[3]));
-        mh_buf_store4(rs_o, of == MH_OOB ? MH_OOB : of + 16, make_float4(v[4], v[5], v[6], v[7]));
+        const u32x4 qh = {hh[0], hh[1], hh[2], hh[3]}, ql = {ll[0], ll[1], ll[2], ll[3]};
+        const u32x4 f0 = __builtin_bit_cast(u32x4, make_float4(v[0], v[1], v[2], v[3])), f1 = __builtin_bit_cast(u32x4, make_float4(v[4], v[5], v[6], v[7]));
+        const int of1 = of == MH_OOB ? MH_OOB : of + 16;
+        if (p.dbg & 4) {            // experiment (mh_tune_conv_planes bit 10): write-through (sc1) stores -- nothing dirty left in L2 at the kernel boundary
+            __builtin_amdgcn_raw_buffer_store_b128(qh, rs_oh, op, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(ql, rs_ol, op, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(f0, rs_o, of, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(f1, rs_o, of1, 0, 16);
+        } else if (p.dbg & 8) {     // experiment (bit 11): non-temporal stores
+            __builtin_amdgcn_raw_buffer_store_b128(qh, rs_oh, op, 0, 2);
+            __builtin_amdgcn_raw_buffer_store_b128(ql, rs_ol, op, 0, 2);
+            __builtin_amdgcn_raw_buffer_store_b128(f0, rs_o, of, 0, 2);
+            __builtin_amdgcn_raw_buffer_store_b128(f1, rs_o, of1, 0, 2);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b128(qh, rs_oh, op, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(ql, rs_ol, op, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(f0, rs_o, of, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(f1, rs_o, of1, 0, 0);
+        }
     }
 }
 
@@ -276,7 +288,8 @@ int launch_planes(PlanesArgs& a, hipStream_t s, bool attr_only) {
     a.tiles_x = mh_cdiv(mh_cdiv(a.W, d), MC);
     a.ntiles_n = mh_cdiv(a.N, G::BN);
     a.nwg = a.B * d * d * a.tiles_y * a.tiles_x * a.ntiles_n;
-    a.dbg = (g_planes_mode.load(std::memory_order_relaxed) >> 8) & 3;
+    a.dec = mh_make_tile_decode(a.ntiles_n, a.tiles_x, a.tiles_y, d);
+    a.dbg = (g_planes_mode.load(std::memory_order_relaxed) >> 8) & 15;
     ++g_planes_launches;
     mh_note_kernel("conv_planes_kernel<MC=%d,%dx%d waves,MBW=%d,K16=%d,%s> tile %dx%d K=%d dil=%d grid %d lds %d", MC, WM, WN, MBW, K16, PL == 2 ? "bf16x3" : "bf16",
                    G::BM, G::BN, a.K, a.dil, a.nwg, G::LDS);

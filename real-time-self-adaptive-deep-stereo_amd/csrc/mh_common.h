@@ -65,6 +65,34 @@ __device__ __forceinline__ int mh_xcd_remap(int bid, int nwg) {
     return start + idx;
 }
 
+// Division of a small non-negative index by a LAUNCH-CONSTANT divisor.  gfx950 has no integer divider: for `lin / tiles_x` hipcc emits a ~30-instruction
+// dependent sequence (v_rcp_iflag_f32, Newton step, two corrections) -- five of them in a row decode a workgroup's tile before its first load address is
+// known: ~0.6 us at the head of EVERY conv launch (round 4: scripts/exp/node_floor.py, the ISA of conv_bank_small_kernel).  The host computes the
+// round-up magic multiplier instead: n / d = umulhi(n, 2^32 / d + 1), exact while n * d < 2^32 (tile counts: n < 2^20, d < 2^12).
+struct mh_fastdiv { unsigned d, m; };
+static inline mh_fastdiv mh_make_fastdiv(int d) {
+    mh_fastdiv f;
+    f.d = (unsigned)(d > 0 ? d : 1);
+    f.m = f.d > 1 ? (unsigned)((1ull << 32) / f.d + 1ull) : 0u;
+    return f;
+}
+__device__ __forceinline__ int mh_fdiv(int n, const mh_fastdiv& f) { return f.d > 1 ? (int)__umulhi((unsigned)n, f.m) : n; }
+// lin -> (column tile, x tile, y tile, lattice phase x, lattice phase y, batch) of the patch / bank / planes kernels
+struct mh_tile_decode { mh_fastdiv ntn, tx, ty, dd; };
+static inline mh_tile_decode mh_make_tile_decode(int ntiles_n, int tiles_x, int tiles_y, int d) {
+    mh_tile_decode t;
+    t.ntn = mh_make_fastdiv(ntiles_n); t.tx = mh_make_fastdiv(tiles_x); t.ty = mh_make_fastdiv(tiles_y); t.dd = mh_make_fastdiv(d);
+    return t;
+}
+__device__ __forceinline__ void mh_decode_tile(int lin, const mh_tile_decode& t, int& tile_n, int& ttx, int& tty, int& cx, int& cy, int& b) {
+    int q = mh_fdiv(lin, t.ntn); tile_n = lin - q * (int)t.ntn.d; lin = q;
+    q = mh_fdiv(lin, t.tx); ttx = lin - q * (int)t.tx.d; lin = q;
+    q = mh_fdiv(lin, t.ty); tty = lin - q * (int)t.ty.d; lin = q;
+    q = mh_fdiv(lin, t.dd); cx = lin - q * (int)t.dd.d; lin = q;
+    q = mh_fdiv(lin, t.dd); cy = lin - q * (int)t.dd.d;
+    b = q;
+}
+
 __device__ __forceinline__ float mh_wave_sum(float v) {
     v += __shfl_xor(v, 32);
     v += __shfl_xor(v, 16);

@@ -29,19 +29,52 @@ def _time_ms(lib, stream, fn, reps):
     return ms.value / reps
 
 
-def _pmc_traffic(key):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r03_pmc_roofline.json, produced by
-    scripts/gpu_pmc_r03.sh + scripts/pmc_summarize_r03.py); None if the file or the key is absent."""
+PMC_FILES = ("r04_pmc_roofline.json", "r03_pmc_roofline.json")
+PMC_SOURCE = None           # the file the last _pmc_traffic() hit came from
+
+
+def _pmc_json():
     import json
     import os
-    f = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles", "r03_pmc_roofline.json")
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles")
+    for f in PMC_FILES:
+        try:
+            return f, json.load(open(os.path.join(d, f)))
+        except Exception:
+            continue
+    return None, {}
+
+
+def _pmc_traffic(key):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r04_pmc_roofline.json, produced by scripts/gpu_pmc_r04.sh +
+    scripts/pmc_summarize_r04.py; the round-3 file as a fallback); `key` = a kernel string as mh_last_kernel reports it, or the name of a fixed
+    roofline entry (roofline_fwd, roofline_corr, ...: resolved through the file's fixed_kernels map).  None if absent."""
+    global PMC_SOURCE
+    f, j = _pmc_json()
     try:
-        j = json.load(open(f))
         if key not in j and key in j.get("fixed_kernels", {}):
             key = j["fixed_kernels"][key]              # roofline_* name -> the kernel string it ran
-        return j[key]["traffic_bytes"]
+        v = j[key]["traffic_bytes"]
+        PMC_SOURCE = "profiles/" + f
+        return v
     except Exception:
         return None
+
+
+def _pmc_entry(key):
+    f, j = _pmc_json()
+    if key not in j and key in j.get("fixed_kernels", {}):
+        key = j["fixed_kernels"][key]
+    return j.get(key)
+
+
+def family_key(kernel):
+    """kernel string -> family: the template name and its arguments, except for the planes kernel whose tile instances are ONE family per
+    arithmetic (the split-bf16 forward layers / their plain-bf16 input gradients)"""
+    import re
+    if kernel.startswith("conv_planes_kernel<"):
+        return "conv_planes_kernel<dgrad,bf16>" if "<dgrad," in kernel else "conv_planes_kernel<fwd,bf16x3>"
+    return re.split(r" tile | layers | grid | K=| \(", kernel)[0]
 
 
 def roofline(lib, eng, stream, reps=20):
@@ -66,18 +99,33 @@ def roofline(lib, eng, stream, reps=20):
         peak = PEAK_F32_MFMA_TFLOPS if (code == 0 or "f32" in kname.split("tile")[0]) else PEAK_BF16_MFMA_TFLOPS
         ach = flops / (ms * 1e-3) / 1e12
         tr = _pmc_traffic(kname)
+        if tr is None:
+            tr = _pmc_traffic(pmc_key)
         x3 = code == 2 and peak == PEAK_BF16_MFMA_TFLOPS
         # frac = ALGORITHMIC flops / time / the dense peak of the instruction family (2.5 PF for bf16 MFMA, whatever the number of
         # MFMAs a product costs); the share of the MFMA ISSUE rate the kernel sustains (3 instructions per product in split-bf16) is reported beside it
         return {"kernel": kname, "op": what, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                 "mfma_issue_frac": (3.0 if x3 else 1.0) * ach / peak,
                 "arithmetic": {0: "f32 MFMA", 1: "bf16 MFMA, f32 accumulate", 2: "split-bf16: 3 bf16 MFMAs per product (mfma_issue_frac = 3 x frac), f32 accumulate"}[code],
-                "traffic": tr, "traffic_source": ("profiles/r03_pmc_roofline.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_pmc_r03.sh on the same kernels and shapes, "
-                                                  "key %s; collected in the run that produced this round's committed bench line, not inside this process)" % pmc_key) if tr is not None else None,
+                "traffic": tr, "traffic_source": ("%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_pmc_r04.sh on the same kernels and shapes, "
+                                                  "key %s; collected in the run that produced this round's committed bench line, not inside this process)" % (PMC_SOURCE, pmc_key)) if tr is not None else None,
                 "launch_ms": ms, "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": algo_bytes}
+
+    planes = getattr(eng, "use_planes", False) and E.ctx_name(2) in getattr(eng, "banks32", {})
+    keep = []
+    if planes:
+        # what the plan runs: the layer from the hi / lo planes of its input (written by context-1's epilogue in the step; split here, outside the
+        # timed launches), results as planes only (the plan's post-pass elides the fp32 store of this layer)
+        _, xp = eng._planes_of(x)
+        _, op_ = eng._planes_of(o)
+        ops.plane_split(lib, [(x, xp)], eng.dev, keep, stream=sh)
+        algo_bytes = 2.0 * 2 * (2 * x.B * x.H * x.W * 128 + 9 * 128 * 128)
 
     def conv_fwd(code):
         def fn():
+            if planes and code == 2:
+                ops.conv2d_planes(lib, xp, w, eng.banks32[E.ctx_name(2)], b, out=None, out_planes=op_, dil=2, alpha=E.ALPHA, stream=sh)
+                return
             ops.PRECISION = code
             try:
                 ops.conv2d_fwd(lib, x, w, b, o, dil=2, alpha=E.ALPHA, stream=sh, wb=(wb if code == 2 else None))
@@ -85,22 +133,36 @@ def roofline(lib, eng, stream, reps=20):
                 ops.PRECISION = 0
         return fn
 
-    rl = entry(fwd_code, conv_fwd(fwd_code), "forward 3x3 128->128 @ %dx%d dil 2 (context-2)" % (x.H, x.W),
-               {0: "none", 1: "conv_fwd_bf16_patch_3x3_128_128_96x320",
-                2: "conv_fwd_x3_bank_3x3_128_128_96x320" if wb is not None else "conv_fwd_x3_patch_3x3_128_128_96x320"}[fwd_code])
+    rl = entry(fwd_code, conv_fwd(fwd_code), "forward 3x3 128->128 @ %dx%d dil 2 (context-2)%s" % (x.H, x.W, " from hi / lo planes, planes out: what the plan runs" if planes else ""),
+               "roofline_fwd")
     extra = {}
     # the same layer's input gradient and filter gradient in the BACKWARD arithmetic: by time the filter gradients are the
     # largest kernel family of the step (22 launches x 17 us)
     try:
         dz = ops.view(eng.dCx[1]); dx = ops.view(eng.dCx[0])
 
+        bwd_planes = planes and bwd_code == 1 and E.ctx_name(2) in getattr(eng, "banks32t", {})
+        if bwd_planes:
+            # what the plan runs: dz from its shadow, the mask from the activation's hi plane, the result as a shadow only
+            key = (dz.ptr, dz.B, dz.H, dz.W, dz.C)
+            dzs = eng.shadows.get(key) or ops.Shadow(dz.B, dz.H, dz.W, dz.C, eng.dev)
+            key = (dx.ptr, dx.B, dx.H, dx.W, dx.C)
+            dxs = eng.shadows.get(key) or ops.Shadow(dx.B, dx.H, dx.W, dx.C, eng.dev)
+            ops.shadow_cast(lib, [(dz, dzs)], eng.dev, keep, stream=sh)
+
         def dgrad():
+            if bwd_planes:
+                ops.conv2d_planes_bwd(lib, dzs, w, eng.banks32t[E.ctx_name(2)], dx=None, dx_shadow=dxs, mask_shadow=xp.hi, mask_alpha=E.ALPHA, dil=2, stream=sh)
+                return
             ops.PRECISION = bwd_code
             try:
                 ops.conv2d_dgrad(lib, dz, w, dx, dil=2, mask_ref=x, mask_alpha=E.ALPHA, stream=sh)
             finally:
                 ops.PRECISION = 0
-        extra["roofline_dgrad"] = entry(bwd_code, dgrad, "input gradient of the same layer", "conv_dgrad_bf16_patch_3x3_128_128_96x320" if bwd_code == 1 else "none")
+        extra["roofline_dgrad"] = entry(bwd_code, dgrad, "input gradient of the same layer" + (" (bf16 shadows in / out: what the plan runs)" if bwd_planes else ""),
+                                        "roofline_dgrad")
+        if bwd_planes:
+            extra["roofline_dgrad"]["algorithmic_bytes_per_launch"] = 2.0 * (2 * x.B * x.H * x.W * 128 + 9 * 128 * 128)
         dw = torch.empty_like(w); db = torch.zeros(128, device=eng.dev)
         wsa = ops.WgradWorkspace(eng.dev)
         keep = []
@@ -122,15 +184,17 @@ def roofline(lib, eng, stream, reps=20):
                 pl.run(lib, sh); kname = lib.last_kernel().decode()
                 ach = fl / (ms * 1e-3) / 1e12
                 tr = _pmc_traffic(kname)
+                if tr is None:
+                    tr = _pmc_traffic(pmc_key)
                 byts = sum(2.0 * xv.B * xv.H * xv.W * (ops.shadow_ld(xv.C) + ops.shadow_ld(zv.C)) + 4.0 * 9 * xv.C * zv.C for xv, zv, _, _, _ in layers)
                 return {"kernel": kname, "op": what, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / PEAK_BF16_MFMA_TFLOPS, "mfma_issue_frac": ach / PEAK_BF16_MFMA_TFLOPS, "arithmetic": "bf16 MFMA (32x32x16), f32 accumulate; operands = bf16 shadows",
-                        "traffic": tr, "traffic_source": ("profiles/r03_pmc_roofline.json key %s (rocprofv3 --pmc passes of scripts/gpu_pmc_r03.sh)" % pmc_key) if tr is not None else None,
+                        "traffic": tr, "traffic_source": ("%s key %s (rocprofv3 --pmc passes of scripts/gpu_pmc_r04.sh)" % (PMC_SOURCE, pmc_key)) if tr is not None else None,
                         "launch_ms": ms, "algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": byts,
                         "splits": [sg[3] for sg in segs], "workspace_bytes_per_launch": 4.0 * sum(sg[2] * sg[3] for sg in segs)}
             nw = 4 if x.B == 1 else 8
             extra["roofline_wgrad"] = stream_entry([(x, dz, dw, db, 2)], "filter gradient of the same layer, alone in its launch (streaming kernel; partial sums only)",
-                                                   "wgrad_stream_3x3_128_128_96x320", nw)
+                                                   "roofline_wgrad", nw)
             k = 2
             h, wd = eng.fshape[E.FEAT[k]][0], eng.fshape[E.FEAT[k]][1]
             cin = eng.fshape[E.FEAT[k]][2] + eng.D + 1
@@ -140,7 +204,7 @@ def roofline(lib, eng, stream, reps=20):
                 dzz = ops.view(eng.dV[k]) if j == 6 else ops.view(eng.dE[k][j - 1])
                 lay.append((xin, dzz, torch.empty_like(eng.W_(E.est_name(k, j))), torch.zeros(dzz.C, device=eng.dev), 1))
             extra["roofline_wgrad_batch"] = stream_entry(lay, "filter gradients of the six estimator-2 layers in ONE launch (what the step runs per backward batch)",
-                                                         "wgrad_stream_est2_batch_96x320", nw)
+                                                         "roofline_wgrad_batch", nw)
         else:
             segs = []
             ops.PRECISION = bwd_code
@@ -175,7 +239,7 @@ def roofline(lib, eng, stream, reps=20):
         g = byts / (ms_c * 1e-3) / 1e9
         extra["roofline_corr"] = {"kernel": lib.last_kernel().decode() + " (B=64 x %dx%dx%d, D=%d)" % (H, W, Cc, D), "bound": "hbm",
                                   "achieved": g, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": g / PEAK_HBM_GBS,
-                                  "traffic": _pmc_traffic("corr_fwd_B64_96x320x32_D5"), "traffic_source": "profiles/r03_pmc_roofline.json (rocprofv3 --pmc passes of scripts/gpu_pmc_r03.sh; collected beside this round's committed bench line, not inside this process)", "launch_ms": ms_c, "algorithmic_bytes_per_launch": byts}
+                                  "traffic": _pmc_traffic("roofline_corr"), "traffic_source": "profiles/r04_pmc_roofline.json (or the round-3 file), fixed_kernels.roofline_corr: rocprofv3 --pmc passes of scripts/gpu_pmc_r04.sh; collected beside this round's committed bench line, not inside this process", "launch_ms": ms_c, "algorithmic_bytes_per_launch": byts}
         L1, R1 = L[:1].contiguous(), R[:1].contiguous(); o1 = out[:1].contiguous()
         ms_1 = _time_ms(lib, stream, lambda: ops.corr_fwd(lib, ops.view(L1), ops.view(R1), ops.view(o1), md, stream=sh), 20)
         extra["roofline_corr"]["in_situ_B1_ms"] = ms_1
@@ -199,11 +263,14 @@ def plan_table(lib, plan, stream, reps=10):
         one[0].i[26] = 0                                    # on the caller's stream, no join
         us = 1e3 * _time_ms(lib, stream, lambda: lib.plan_run(one, 1, C.c_void_p(sh)), reps)
         k = lib.last_kernel().decode() if plan.arr[i].kind in (_ffi.OP_CONV, _ffi.OP_WGRAD, _ffi.OP_WGRAD_PARTIAL, _ffi.OP_WGRAD_STREAM, _ffi.OP_CORR_FWD,
-                                                              _ffi.OP_CORR_BWD, _ffi.OP_LEVEL_FRONT, _ffi.OP_CORR_WARP_BWD) else ("op kind %d" % plan.arr[i].kind)
+                                                              _ffi.OP_CORR_BWD, _ffi.OP_LEVEL_FRONT, _ffi.OP_CORR_WARP_BWD, _ffi.OP_CONV_PLANES,
+                                                              _ffi.OP_CONV_PLANES_BWD) else ("op kind %d" % plan.arr[i].kind)
+        if plan.arr[i].kind == _ffi.OP_CONV_PLANES_BWD:
+            k = k.replace("conv_planes_kernel<", "conv_planes_kernel<dgrad,")
         rows.append((i, int(plan.arr[i].kind), k, us))
     fam = {}
     for i, kind, k, us in rows:
-        key = re.split(r" tile | layers | grid | K=| \(", k)[0]
+        key = family_key(k)
         f = fam.setdefault(key, {"launches": 0, "us_per_step": 0.0, "top_us": 0.0, "top_index": -1})
         f["launches"] += 1; f["us_per_step"] += us
         if us > f["top_us"]:
@@ -214,6 +281,16 @@ def plan_table(lib, plan, stream, reps=10):
 def op_work(op):
     """(algorithmic flops, algorithmic bytes) of a conv / filter-gradient op record (SURVEY 8(d) definitions), else (0, 0)"""
     from . import _ffi
+    if op.kind in (_ffi.OP_CONV_PLANES, _ffi.OP_CONV_PLANES_BWD):
+        # planes layers: operands and results are bf16 planes: in 2 (hi, lo) x 2 B forward / 1 x 2 B backward per element, out likewise (+ 4 B where the
+        # fp32 copy is stored)
+        i = op.i
+        B, H, W, K, N = i[0], i[1], i[2], i[5], i[6]
+        fwd = op.kind == _ffi.OP_CONV_PLANES
+        cin, cout = (K, N) if fwd else (N, K)
+        pl = 2 if fwd else 1
+        f32 = 4.0 if op.p[4 if fwd else 3] else 0.0
+        return 2.0 * B * H * W * 9 * K * N, B * H * W * (cin * 2.0 * pl + cout * (2.0 * pl + f32)) + 9 * K * N * 2.0 * pl
     if op.kind not in (_ffi.OP_CONV, _ffi.OP_WGRAD, _ffi.OP_WGRAD_PARTIAL):
         return 0.0, 0.0
     i = op.i

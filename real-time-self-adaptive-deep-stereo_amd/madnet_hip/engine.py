@@ -110,7 +110,12 @@ EARLY_UPDATE = False
 # gradient -- conv1's filter gradient reads what conv2's input gradient writes -- so lane 0 sat idle for 91 us behind the chain (batch 76 us + join).
 # TAIL_SPLIT: the filter gradients of conv4 .. conv2 (their operands are final one layer earlier) leave as a batch of their own BEFORE conv2's input
 # gradient is launched and run beside it; only conv1's (the 3-channel image layer) is left for the tail.
-TAIL_SPLIT = True
+TAIL_SPLIT = False
+# generalisation: the pyramid's filter gradients leave for the side lane in batches; a batch is flushed AFTER the input gradient of layer i for i in
+# PYR_FLUSH_AFTER (the round-3 schedule: 9, 5, 1 = four layers per batch) and BEFORE the input gradient of layer i -- i.e. as soon as layer i's own
+# filter gradient has its operands -- for i in PYR_FLUSH_BEFORE
+PYR_FLUSH_AFTER = (9, 5, 1)
+PYR_FLUSH_BEFORE = ()
 # ... and that last batch (conv1's filter gradient + its split reduction) runs on a side lane of its own, so it starts the moment conv2's input gradient
 # ends instead of queueing behind the conv4 .. conv2 batch on the filter-gradient lane (0 = same lane).  Its slice of the gradient buffer is zeroed on
 # that lane too (first op of the backward pass): everything that touches those floats stays in ONE lane's order.
@@ -1084,8 +1089,8 @@ class MadNetEngine(object):
                         ops_fill(lib, self.dF[i - 1][B:], 0, self.dF[i - 1][B:].numel())
                 if pyr_tr[i]:
                     wgrad(xin, self._fv(self.dF[i]), pyr_name(i), stride=PYR[i - 1][2])
-                if TAIL_SPLIT and i == 2:
-                    flush()                 # conv4 .. conv2: beside conv2's input gradient, not behind it
+                if (TAIL_SPLIT and i == 2) or i in PYR_FLUSH_BEFORE:
+                    flush()                 # (TAIL_SPLIT: conv4 .. conv2 beside conv2's input gradient, not behind it)
                 if need_dx:
                     # dF[i-1] is complete after this launch (the cost-volume contributions were written earlier): it is the dz of layer i - 1
                     sh = self._out_shadow(self._fv(self.dF[i - 1]), pyr_name(i - 1)) if (i - 1 > 1) else None       # (conv1's 3-channel input keeps the tiled kernel)
@@ -1094,14 +1099,14 @@ class MadNetEngine(object):
                     mks = self._fresh_shadow(self._fv(self.F[i - 1])) if wbt is not None else None
                     if wbt is not None and dzs is not None and mks is not None and sh is not None:
                         ops.conv2d_planes_bwd(lib, dzs, self.W_(pyr_name(i)), wbt, dx=self._fv(self.dF[i - 1]), dx_shadow=sh, mask_shadow=mks, mask_alpha=ALPHA)
-                        if i % 4 == 1:
+                        if i in PYR_FLUSH_AFTER:
                             flush(lane=(tail_lane if i == 1 else None))
                         continue
                     ops.conv2d_dgrad(lib, self._fv(self.dF[i]), self.W_(pyr_name(i)), self._fv(self.dF[i - 1]),
                                      stride=PYR[i - 1][2], accumulate=accumulate, mask_ref=self._fv(self.F[i - 1]),
                                      mask_alpha=ALPHA, wb=self.Wd_(pyr_name(i)), shadow=sh,
                                      dz_shadow=self._fresh_shadow(self._fv(self.dF[i])), mask_shadow=self._fresh_shadow(self._fv(self.F[i - 1])))
-                if i % 4 == 1:
+                if i in PYR_FLUSH_AFTER:
                     flush(lane=(tail_lane if i == 1 else None))
         flush()
         self._stamp(lib, "chain_end")                           # lane 0: the last input gradient is behind us

@@ -285,6 +285,7 @@ def _mixed_vs_oracle(lib, device, H, W, force_patch, block=None):
     wn = S.calibrated_weights(OM.variable_shapes(), 1)
     l, r, gt = S.make_pair(H, W)
     lib.tune_conv_patch(force_patch)
+    lib.tune_conv_planes(0)
     try:
         eng = E.MadNetEngine(lib, H, W, B=1, device=device, weights=wn, precision="mixed")
         eng.set_inputs(l, r, gt[..., 0])
@@ -300,7 +301,7 @@ def _mixed_vs_oracle(lib, device, H, W, force_patch, block=None):
         if device != "cpu":
             torch.cuda.synchronize()
     finally:
-        launches = lib.tune_conv_patch(-1)
+        launches = lib.tune_conv_patch(-1) + lib.tune_conv_planes(0)       # patch-staged / fragment-bank / planes kernels that really ran
     wt = {k: torch.from_numpy(v.copy()) for k, v in wn.items()}
     acc = {k: torch.zeros_like(v) for k, v in wt.items()}
     if block is None:
