@@ -141,6 +141,25 @@ class _Null(object):
         return False
 
 
+def rccl_info(dev, dist, rank, world):
+    """who is in the job: world size, RCCL version, every rank's device / XCC count -- gathered once, printed by rank 0"""
+    torch = dev.torch
+    mine = {"rank": rank, "device": dev.name}
+    ver = None
+    if dev.kind == "cuda":
+        pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+        mine.update({"name": pr.name, "arch": getattr(pr, "gcnArchName", ""), "cus": int(pr.multi_processor_count), "xccs": int(pr.multi_processor_count) // 32,
+                     "hbm_gb": round(pr.total_memory / 2 ** 30, 1), "pci_bus_id": getattr(pr, "pci_bus_id", None),
+                     "hip_visible": os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES"))})
+        try:
+            ver = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            ver = None
+    ranks = [None] * world
+    dist.all_gather_object(ranks, mine)
+    return {"world": world, "backend": dist.get_backend(), "version": ver, "ranks": ranks}
+
+
 def timed_regions(dev, dist, one_step, steps, repeats, inner=1):
     """[seconds] of `repeats` consecutive regions of inner x K steps, each bracketed by barrier + synchronize, MAX over ranks."""
     torch = dev.torch
@@ -203,8 +222,10 @@ def bench_mad(args, lib, dev, rank, world, dist):
                                          "precision": args.precision, "warping": True, "context_net": True,
                                          "radius_d": 2, "stride": 1})
     cfg = json.load(open(os.path.join(PKG, "block_config", args.block_config)))
-    ad = Adapter(net, mode="MAD", block_config=cfg, lr=1e-4, sample_mode="PROBABILITY", num_blocks=1,
-                 use_graph=not args.no_graph)
+    # --shared-model: ONE model for all ranks -- the sampled block's gradient ranges + the loss travel as ONE all-reduce between the block's
+    # backward plan and its update plan (adapter.step); SEQUENTIAL sampling keeps the ranks on the same block without exchanging the draw
+    ad = Adapter(net, mode="MAD", block_config=cfg, lr=1e-4, sample_mode="SEQUENTIAL" if args.shared_model else "PROBABILITY", num_blocks=1,
+                 use_graph=not args.no_graph, shared_model=args.shared_model)
     for i in range(len(cfg)):
         ad._plan((i,))                       # compile + capture every block's plan outside the timed region
     last = {}
@@ -231,6 +252,8 @@ def bench_mad(args, lib, dev, rank, world, dist):
                                    "1 pair/GPU/step, %s" % (W, H, args.block_config),
                        "precision": args.precision,
                        "launch": "eager plan" if args.no_graph else "hipGraph replay per sampled block",
+                       "rccl": getattr(args, "rccl", None),
+                       "shared_model": bool(args.shared_model), "collectives_per_step": getattr(ad, "collectives_last_step", 0) if args.shared_model else 0,
                        "fetch_counter": ad.fetch_counter, "final_loss": last["o"]["loss"], "epe_vs_synthetic_gt": last["o"]["epe"]}})
 
 
@@ -403,6 +426,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl" if dev.kind == "cuda" else "gloo", rank=rank, world_size=world)
         assert dist.get_world_size() == args.gpus
+    rccl = rccl_info(dev, dist, rank, world) if dist is not None else None
+    args.rccl = rccl
 
     from madnet_hip import _ffi, engine as E, dispnet_engine as DE, synthetic as S, benchtools as BT
     lib = _ffi.lib()
@@ -493,6 +518,13 @@ def main():
                 else:
                     dist.all_reduce(G)
             one_step.collectives_only = collectives_only
+
+            def without_collectives():               # the same launches, no all-reduce: collective_ms_in_step = step with - step without
+                plan.launch(lib, dev.sh)
+                if pyr is not None:
+                    pyr.launch(lib, dev.sh)
+                upd.launch(lib, dev.sh)
+            one_step.without_collectives = without_collectives
             one_step.pieces = [int((G.numel() - lo) * 4), int(lo * 4)] if pyr is not None else [int(G.numel() * 4)]
         return one_step, plan
 
@@ -567,7 +599,11 @@ def main():
                 one_step.collectives_only()
             dev.sync_stream()
             coll_ms = (_t.perf_counter() - t0) * 1e3 / 20
-        shared_info = {"collective_ms_alone": coll_ms, "pieces_bytes": one_step.pieces,
+        # what the collectives cost INSIDE the step: the timed step minus the same launches without the all-reduce(s)
+        nocoll = timed_regions(dev, dist, one_step.without_collectives, args.steps, 1)
+        ms_without = 1e3 * nocoll[0] / args.steps
+        shared_info = {"collective_ms_alone": coll_ms, "collective_ms_in_step": ms - ms_without, "ms_per_step_without_collectives": ms_without,
+                       "pieces_bytes": one_step.pieces,
                        "order": ("[estimators + context + loss] async behind their backward pass, [pyramid] behind the pyramid's" if len(one_step.pieces) == 2
                                  else "one all-reduce behind the backward pass"),
                        "algbw_gbs": sum(one_step.pieces) / (coll_ms * 1e-3) / 1e9 if coll_ms > 0 else None}
@@ -613,6 +649,8 @@ def main():
     }
     if shared_info is not None:
         out["shared_model"] = shared_info
+    if rccl is not None:
+        out["rccl"] = rccl
     if args.stamps > 0 and rank == 0 and not dispnet and not shared and CS == 1 and use_graph:
         out["tail"] = BT.tail_stamps(lib, E, mk, feed, args, dev, ms)
     if rank == 0 and world == 1 and dispnet and SB == 1 and dev.kind == "cuda" and not args.no_cpu_baseline:

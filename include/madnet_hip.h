@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 11
+#define MH_ABI_VERSION 12
 
 /* status codes of every int-returning entry point: 0 = launched; a NEGATIVE code means an argument check failed and
  * nothing was launched or written; a POSITIVE value is the hipError_t of a failed launch / runtime call.
@@ -103,10 +103,17 @@ typedef struct mh_pack_seg {
                              gradient: K = Cout is the reduction, N = Cin the output column); 2: forward bank in the 32x32x16 register image
                              mh_conv2d_planes reads (planes = 2, mh_pack32_bytes bytes; blk0 then counts ceil(taps*ceil(K/16)*ceil(N/32)*64 / 256));
                              3: the input gradient's bank in that image (mh_conv2d_planes_bwd): planes = 1, K = Cout (reduction), N = Cin as for trans 1,
-                             taps mirrored, mh_pack32_bytes(taps, K, N) / 2 bytes */
+                             taps mirrored, mh_pack32_bytes(taps, K, N) / 2 bytes.  trans 2 with planes = 1: the one-plane (plain bf16) forward
+                             bank of mh_conv2d_planes(precision 1), mh_pack32_bytes / 2 bytes */
+    int32_t kc16;         /* trans 2 / 3: K-chunk of the image in 16-channel steps = mh_planes_kc16(K) (0: whole-K image; else the bank is
+                             [chunk][tap][step] and K is padded to whole chunks -- blk0 counts the padded steps) */
+    int32_t reserved;
 } mh_pack_seg;
 int64_t mh_pack_bytes(int32_t taps, int32_t K, int32_t N, int32_t planes);
-int64_t mh_pack32_bytes(int32_t taps, int32_t K, int32_t N);
+int64_t mh_pack32_bytes(int32_t taps, int32_t K, int32_t N);      /* two-plane image, K padded per mh_planes_kc16 */
+/* layout rule of the 32x32x16 images: 0 = whole-K (reductions up to 128 channels, and 97..112 / 193..208: DispNet's split-bf16 iconv layers),
+ * else the chunk in 16-channel steps (4: every longer reduction -- DispNet's 256 .. 1056-channel layers and their input gradients) */
+int mh_planes_kc16(int32_t K);
 /* segs_device: table in DEVICE memory; nblocks = the sum the blk0 fields prefix. */
 int mh_pack_weights(const mh_pack_seg* segs_device, int32_t nseg, int32_t nblocks, void* stream);
 
@@ -118,7 +125,11 @@ int mh_pack_weights(const mh_pack_seg* segs_device, int32_t nseg, int32_t nblock
  *   wb32      : mh_pack_weights(trans = 2) image of the HWIO bank, mh_pack32_bytes(9, K, N) bytes
  *   out       : fp32 result [pixel][d->out_ld] or NULL (only where a consumer without a plane path exists)
  *   out_hi/lo : result planes [pixel][out_pld] or NULL
- * mh_conv2d_planes_ok(d) = 1 if the layer has an instance (N <= 128 and a multiple of 8; ceil(K/16) in {2,3,4,5,6,8}).
+ *   d->precision 1: plain bf16 -- ONE MFMA per product from the hi plane and a one-plane bank (in_lo ignored, may be NULL): DispNet's 'mixed' forward
+ *   layers (Nets/DispNet.py:75-152).  Reductions over more than 128 channels run the K-chunked kernel (conv_planes_ck_kernel: a loader wave
+ *   streams 64-channel patch chunks through three LDS buffers by LDS DMA while four waves walk the previous chunk).
+ * mh_conv2d_planes_ok(d) = 1 if the layer has an instance (N a multiple of 8; MADNet: ceil(K/16) in {2,3,4,5,6,8}, N <= 128; DispNet: any K > 128,
+ *   and 97 -> 32 / 193 -> 64 split-bf16).
  * mh_plane_split: fp32 NHWC -> hi (+ lo) planes for tensors no plane-writing kernel produces (one launch per table; lo may be NULL = mh_shadow_cast). */
 int mh_conv2d_planes_ok(const mh_conv_desc* d);
 int mh_conv2d_planes(const mh_conv_desc* d, const void* in_hi, const void* in_lo, int32_t in_pld, const void* wb32, const float* bias,

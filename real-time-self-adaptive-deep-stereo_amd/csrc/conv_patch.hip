@@ -912,43 +912,32 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const mh_pack_seg* __
     const mh_pack_seg sg = segs[lo];
     const int e = ((int)blockIdx.x - sg.blk0) * 256 + (int)threadIdx.x;
     const int lane = e & 63, qt = e >> 6;
-    if (sg.trans == 3) {
-        // the ONE-plane bank of the input gradient in the 32x32x16 image (mh_conv2d_planes_bwd): reduction over Cout (sg.K), columns = Cin (sg.N), the
-        // same HWIO bank read transposed (src[tap][N][K]) with the taps MIRRORED (tap t of the walk = tap taps-1-t of the forward layer): the 'SAME'
-        // 3x3 input gradient then IS the forward walk of conv_planes_kernel over dz
+    if (sg.trans == 2 || sg.trans == 3) {
+        // the 32x32x16 register image of conv_planes_kernel: bank[chunk][tap][s][32-column tile][plane][lane][8 bf16], lane l holding the 8 reduction
+        // channels 16 (chunk * kc16 + s) + 8 (l >> 5) .. + 7 of column 32 tile + (l & 31).  kc16 = 0: one chunk = the whole reduction.
+        //   trans 2 (forward): K = Cin, N = Cout, src[tap][K][N]; planes = 2 (hi + lo, split-bf16) or 1 (plain bf16)
+        //   trans 3 (input gradient, mh_conv2d_planes_bwd): ONE plane, reduction over Cout (sg.K), columns = Cin (sg.N): the same HWIO bank read
+        //   transposed (src[tap][N][K]) with the taps MIRRORED (tap t of the walk = tap taps-1-t of the forward layer) -- the 'SAME' 3x3 input
+        //   gradient then IS the forward walk over dz
         const int k16 = (sg.K + 15) >> 4, nt32 = (sg.N + 31) >> 5;
-        if (qt >= sg.taps * k16 * nt32) return;
+        const int kc = sg.kc16 > 0 ? sg.kc16 : k16, nch = (k16 + kc - 1) / kc;
+        if (qt >= nch * sg.taps * kc * nt32) return;
         const int nt = qt % nt32, q = qt / nt32;
-        const int st = q % k16, tap = q / k16;
-        const int k0 = st * 16 + (lane >> 5) * 8, n = nt * 32 + (lane & 31);
-        const int ts = sg.taps - 1 - tap;
-        unsigned hh[4], ll[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float v0 = (k0 + 2 * j < sg.K && n < sg.N) ? sg.src[((int64_t)ts * sg.N + n) * sg.K + k0 + 2 * j] : 0.f;
-            const float v1 = (k0 + 2 * j + 1 < sg.K && n < sg.N) ? sg.src[((int64_t)ts * sg.N + n) * sg.K + k0 + 2 * j + 1] : 0.f;
-            mh_split_bf16x2(v0, v1, hh[j], ll[j]);
-        }
-        reinterpret_cast<u32x4*>(sg.dst)[(int64_t)qt * 64 + lane] = (u32x4){hh[0], hh[1], hh[2], hh[3]};
-        return;
-    }
-    if (sg.trans == 2) {
-        // the 32x32x16 register image of conv_planes_kernel (forward, hi + lo): bank[(tap * K16 + s)][32-column tile][plane][lane][8 bf16], lane l
-        // holding w[tap][16 s + 8 (l >> 5) .. + 7][32 tile + (l & 31)]
-        const int k16 = (sg.K + 15) >> 4, nt32 = (sg.N + 31) >> 5;
-        if (qt >= sg.taps * k16 * nt32) return;
-        const int nt = qt % nt32, q = qt / nt32;
-        const int st = q % k16, tap = q / k16;
-        const int k0 = st * 16 + (lane >> 5) * 8, n = nt * 32 + (lane & 31);
+        const int st = q % kc, q2 = q / kc;
+        const int tap = q2 % sg.taps, ch = q2 / sg.taps;
+        const int k0 = (ch * kc + st) * 16 + (lane >> 5) * 8, n = nt * 32 + (lane & 31);
+        const int ts = sg.trans == 3 ? sg.taps - 1 - tap : tap;
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (k0 + j < sg.K && n < sg.N) ? sg.src[((int64_t)tap * sg.K + k0 + j) * sg.N + n] : 0.f;
+        for (int j = 0; j < 8; ++j)
+            v[j] = (k0 + j < sg.K && n < sg.N) ? (sg.trans == 3 ? sg.src[((int64_t)ts * sg.N + n) * sg.K + k0 + j] : sg.src[((int64_t)ts * sg.K + k0 + j) * sg.N + n]) : 0.f;
         unsigned hh[4], ll[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) mh_split_bf16x2(v[2 * j], v[2 * j + 1], hh[j], ll[j]);
-        u32x4* dst = reinterpret_cast<u32x4*>(sg.dst) + (int64_t)qt * 128 + lane;
+        const int pln = (sg.trans == 3 || sg.planes < 2) ? 1 : 2;
+        u32x4* dst = reinterpret_cast<u32x4*>(sg.dst) + (int64_t)qt * (64 * pln) + lane;
         dst[0] = (u32x4){hh[0], hh[1], hh[2], hh[3]};
-        dst[64] = (u32x4){ll[0], ll[1], ll[2], ll[3]};
+        if (pln == 2) dst[64] = (u32x4){ll[0], ll[1], ll[2], ll[3]};
         return;
     }
     const int cpt = (sg.K + 31) >> 5, np16 = (sg.N + 15) >> 4;

@@ -20,6 +20,14 @@
 #include <stdlib.h>
 #include <atomic>
 
+// Bank layout rule (host and kernels agree by this function alone): reductions over more than 128 channels -- except 97..112 and 193..208, the
+// split-bf16 iconv layers of DispNet, which have whole-K instances -- are K-chunked in chunks of MH_PLANES_KC16 * 16 channels.
+#define MH_PLANES_KC16 4
+extern "C" int mh_planes_kc16(int32_t K) {
+    const int k16 = (K + 15) / 16;
+    return (k16 <= 8 || k16 == 13) ? 0 : MH_PLANES_KC16;
+}
+
 namespace {
 
 struct PlanesArgs {
@@ -28,6 +36,8 @@ struct PlanesArgs {
     const float* bias;
     const unsigned short* mask_hi; int mask_pld; float mask_alpha;  // != null: out *= (mask > 0 ? 1 : mask_alpha), mask = a bf16 plane [pixel][mask_pld] (sign test: the
                                                                    // fused gradient of tf.maximum(alpha x, x) in an input-gradient launch)
+    int mask_c0, mask_c1;                                          // ... for output columns in [mask_c0, mask_c1) only (a concat's member; whole row: 0, INT_MAX)
+    int nchunks;                                                   // K-chunked instances: chunks of K16 * 16 reduction channels (1 for the whole-K instances)
     float* out; unsigned short* out_hi; unsigned short* out_lo;   // any of them may be null
     unsigned in_bytes, wb_bytes, out_bytes, outp_bytes;
     int in_pld, out_ld, out_pld;
@@ -43,6 +53,7 @@ struct PlanesArgs {
 template <int MC, int WM, int WN, int MBW, int K16, int PL = 2>
 struct PlanesGeo {
     static constexpr int MR = 32 / MC;                 // rows of an M-block
+    static constexpr int MBW_ = MBW;
     static constexpr int NW = WM * WN, NTH = NW * 64;
     static constexpr int TR = WM * MBW * MR;           // tile rows (lattice)
     static constexpr int BM = WM * MBW * 32, BN = WN * 32;
@@ -58,6 +69,85 @@ struct PlanesGeo {
     static constexpr int LDS_TILES = PL * PLANE_BYTES, LDS_CS = BM * CS * 4;
     static constexpr int LDS = LDS_TILES > LDS_CS ? LDS_TILES : LDS_CS;
 };
+
+// the epilogue of both kernels: accumulators -> LDS [pixel][column], then 8 consecutive columns per lane: bias, leaky, mask, split, 16-byte stores.
+// `active`: the calling thread belongs to a compute wave (the K-chunked kernel's loader wave only keeps the barrier company); NTH = compute threads.
+template <class G>
+__device__ __forceinline__ void planes_epilogue(const PlanesArgs& p, float* smem_all, const f32x16 (&acc)[G::MBW_], int tid, bool active, int wm, int wn, int lane,
+                                                int n0, int y00, int x00, int b, int d) {
+    constexpr int MR = G::MR, NTH = G::NTH, BM = G::BM, BN = G::BN, CS = G::CS, MBW = G::MBW_;
+    // ---- epilogue: accumulators -> LDS [pixel][column], then 8 consecutive columns per lane: bias, leaky, split, 16-byte stores ----------------
+    float* const Cs = smem_all;
+    if (active) {
+        const int col = wn * 32 + (lane & 31);
+#pragma unroll
+        for (int mb = 0; mb < MBW; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Cs[((wm * MBW + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CS + col] = acc[mb][r];
+    }
+    __syncthreads();
+    if (!active) return;
+    constexpr int C8 = BN / 8;
+    static_assert(NTH % C8 == 0, "a thread keeps its 8-column group");
+    constexpr int RP = NTH / C8;
+    const int c8 = tid % C8;
+    const int n = n0 + c8 * 8;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = (p.bias && n + e < p.N) ? p.bias[n + e] : 0.f;
+    const __amdgpu_buffer_rsrc_t rs_o = mh_make_rsrc(p.out ? p.out : (float*)p.out_hi, p.out ? p.out_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_oh = mh_make_rsrc(p.out_hi ? p.out_hi : (unsigned short*)p.out, p.out_hi ? p.outp_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_ol = mh_make_rsrc(p.out_lo ? p.out_lo : (unsigned short*)p.out, p.out_lo ? p.outp_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_mk = mh_make_rsrc(p.mask_hi ? (const void*)p.mask_hi : (const void*)p.in_hi, p.mask_hi ? (unsigned)((int64_t)p.B * p.H * p.W * p.mask_pld * 2) : 0u);
+#pragma unroll 2
+    for (int m = tid / C8; m < BM; m += RP) {
+        const int blk = m >> 5, w = m & 31;
+        const int row = MR == 1 ? blk : blk * 2 + (w >> 4), colp = MR == 1 ? w : (w & 15);
+        const int y = y00 + row * d, x = x00 + colp * d;
+        const bool ok = y < p.H && x < p.W && n < p.N;
+        const int pix = (b * p.H + y) * p.W + x;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(&Cs[m * CS + c8 * 8]), v1 = *reinterpret_cast<const f32x4*>(&Cs[m * CS + c8 * 8 + 4]);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[e] += bv[e];
+            if (p.alpha != 1.0f) v[e] = v[e] > 0.f ? v[e] : p.alpha * v[e];
+        }
+        if (p.mask_hi) {        // 8 bf16 of the activation's hi plane: bf16 keeps sign and zero, the test is that of the fp32 tensor
+            const u32x4 mq = __builtin_amdgcn_raw_buffer_load_b128(rs_mk, ok ? (pix * p.mask_pld + n) * 2 : MH_OOB, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float mk = __builtin_bit_cast(float, (e & 1) ? (mq[e >> 1] & 0xffff0000u) : (mq[e >> 1] << 16));
+                v[e] *= (mk > 0.f || n + e < p.mask_c0 || n + e >= p.mask_c1) ? 1.0f : p.mask_alpha;
+            }
+        }
+        unsigned hh[4], ll[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mh_split_bf16x2(v[2 * e], v[2 * e + 1], hh[e], ll[e]);
+        const int op = ok ? (pix * p.out_pld + n) * 2 : MH_OOB;
+        const int of = ok ? (pix * p.out_ld + n) * 4 : MH_OOB;
+        const u32x4 qh = {hh[0], hh[1], hh[2], hh[3]}, ql = {ll[0], ll[1], ll[2], ll[3]};
+        const u32x4 f0 = __builtin_bit_cast(u32x4, make_float4(v[0], v[1], v[2], v[3])), f1 = __builtin_bit_cast(u32x4, make_float4(v[4], v[5], v[6], v[7]));
+        const int of1 = of == MH_OOB ? MH_OOB : of + 16;
+        if (p.dbg & 4) {            // experiment (mh_tune_conv_planes bit 10): write-through (sc1) stores -- nothing dirty left in L2 at the kernel boundary
+            __builtin_amdgcn_raw_buffer_store_b128(qh, rs_oh, op, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(ql, rs_ol, op, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(f0, rs_o, of, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(f1, rs_o, of1, 0, 16);
+        } else if (p.dbg & 8) {     // experiment (bit 11): non-temporal stores
+            __builtin_amdgcn_raw_buffer_store_b128(qh, rs_oh, op, 0, 2);
+            __builtin_amdgcn_raw_buffer_store_b128(ql, rs_ol, op, 0, 2);
+            __builtin_amdgcn_raw_buffer_store_b128(f0, rs_o, of, 0, 2);
+            __builtin_amdgcn_raw_buffer_store_b128(f1, rs_o, of1, 0, 2);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b128(qh, rs_oh, op, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(ql, rs_ol, op, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(f0, rs_o, of, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(f1, rs_o, of1, 0, 0);
+        }
+    }
+}
 
 // PL = 2: split-bf16 (hi + lo planes of both operands, three MFMAs per product: the forward layers).  PL = 1: plain bf16 from the hi plane and a one-plane
 // bank (one MFMA per product): the INPUT GRADIENTS of the same layers -- a 'SAME' 3x3 input gradient is this forward walk over dz with the taps mirrored
@@ -162,76 +252,152 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_planes_kernel(PlanesArgs p)
     }
     __syncthreads();                                 // every wave is done with the patch: the accumulator tile goes over it
 
-    // ---- epilogue: accumulators -> LDS [pixel][column], then 8 consecutive columns per lane: bias, leaky, split, 16-byte stores ----------------
-    float* const Cs = smem_all;
-    {
-        const int col = wn * 32 + (lane & 31);
+    planes_epilogue<G>(p, smem_all, acc, tid, true, wm, wn, lane, n0, y00, x00, b, d);
+}
+
+// ---- K-chunked variant (round 4, DispNet's 256 .. 1056-channel layers: Nets/DispNet.py:75-152) -------------------------------------------------
+// The reduction runs over `nchunks` chunks of K16 * 16 channels.  The patch of ONE chunk (both planes) is an LDS buffer; NBUF buffers rotate: a
+// dedicated LOADER wave (the last wave of the workgroup, no MFMA) issues the LDS DMA of chunk c + NBUF - 1 while the compute waves walk chunk c and
+// waits only for chunk c + 1 (s_waitcnt vmcnt(<loads of the newest chunk>)): its own vmcnt counter, so the compute waves' fragment loads never queue
+// behind the DMA.  One barrier per chunk.  The fragment bank is chunk-major ([chunk][tap][step]: mh_pack_weights kc16), so the weight ring runs
+// straight across the chunk boundaries (T = 9 K16 is a multiple of the ring length for K16 = 4 / 8).
+template <int MC, int WM, int WN, int MBW, int K16, int PL, int NBUF>
+struct PlanesCkGeo : PlanesGeo<MC, WM, WN, MBW, K16, PL> {
+    using B = PlanesGeo<MC, WM, WN, MBW, K16, PL>;
+    static constexpr int BUF_BYTES = PL * B::PLANE_BYTES;
+    static constexpr int NLOAD = PL * B::PLANE_BLKS;                 // DMA instructions of one chunk (all by the loader wave)
+    static constexpr int LDS_CK = NBUF * BUF_BYTES > B::LDS_CS ? NBUF * BUF_BYTES : B::LDS_CS;
+    static_assert(NLOAD <= 63, "the loader's vmcnt window");
+    static_assert((9 * K16) % 4 == 0, "the weight ring must close on a chunk boundary");
+};
+
+template <int MC, int WM, int WN, int MBW, int K16, int PL, int NBUF>
+__global__ __launch_bounds__((WM * WN + 1) * 64) void conv_planes_ck_kernel(PlanesArgs p) {
+    using G = PlanesCkGeo<MC, WM, WN, MBW, K16, PL, NBUF>;
+    constexpr int MR = G::MR, NW = G::NW, TR = G::TR, BN = G::BN, PR = G::PR, PC = G::PC;
+    constexpr int NCK = G::NCK, NCK1 = G::NCK1, ROWP = G::ROWP, PLANE_BLKS = G::PLANE_BLKS, PLANE_BYTES = G::PLANE_BYTES, BUF_BYTES = G::BUF_BYTES;
+    HIP_DYNAMIC_SHARED(float, smem_all)
+    unsigned char* const smem = reinterpret_cast<unsigned char*>(smem_all);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave == NW;
+    const int wm = loader ? 0 : wave / WN, wn = loader ? 0 : wave % WN;
+    const int d = p.dil;
+    const int nch = p.nchunks;
+
+    const int lin = mh_xcd_remap(blockIdx.x, p.nwg);
+    int tile_n, ttx, tty, cx, cy, b;
+    mh_decode_tile(lin, p.dec, tile_n, ttx, tty, cx, cy, b);
+    const int n0 = tile_n * BN;
+    const int y00 = cy + d * (tty * TR), x00 = cx + d * (ttx * MC);
+
+    // weight ring: the one-plane (plain bf16) walk spends 32 MBW cycles per step and DispNet's banks (up to 19 MB) come from HBM, not L2: eleven steps
+    // in flight (44 VGPRs) instead of three (microbenchmark r04: conv4_1 42 us with three)
+    constexpr int T = 9 * K16, NSTB = PL == 1 ? 12 : 4, PF = NSTB - 1;
+    static_assert(T % NSTB == 0, "the weight ring must close on a chunk boundary");
+    f32x16 acc[MBW];
 #pragma unroll
-        for (int mb = 0; mb < MBW; ++mb)
+    for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                Cs[((wm * MBW + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CS + col] = acc[mb][r];
-    }
-    __syncthreads();
-    constexpr int C8 = BN / 8;
-    static_assert(NTH % C8 == 0, "a thread keeps its 8-column group");
-    constexpr int RP = NTH / C8;
-    const int c8 = tid % C8;
-    const int n = n0 + c8 * 8;
-    float bv[8];
+        for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+
+    if (loader) {
+        // ---- the loader wave: chunk c -> buffer c % NBUF, NBUF - 1 chunks ahead of the walk ------------------------------------------------------
+        const mh_dma_src rs_h = mh_make_dma_src(p.in_hi, p.in_bytes), rs_l = mh_make_dma_src(PL == 2 ? p.in_lo : p.in_hi, p.in_bytes);
+        const int pix_b = p.in_pld * 2;
+        const int pld8 = p.in_pld >> 3;                       // 16-byte chunks of a plane pixel
+        // per 1 KB block of a plane buffer: the lane's patch pixel offset and channel chunk (chunk-independent), computed once
+        int base[PLANE_BLKS], cc[PLANE_BLKS];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = (p.bias && n + e < p.N) ? p.bias[n + e] : 0.f;
-    const __amdgpu_buffer_rsrc_t rs_o = mh_make_rsrc(p.out ? p.out : (float*)p.out_hi, p.out ? p.out_bytes : 0u);
-    const __amdgpu_buffer_rsrc_t rs_oh = mh_make_rsrc(p.out_hi ? p.out_hi : (unsigned short*)p.out, p.out_hi ? p.outp_bytes : 0u);
-    const __amdgpu_buffer_rsrc_t rs_ol = mh_make_rsrc(p.out_lo ? p.out_lo : (unsigned short*)p.out, p.out_lo ? p.outp_bytes : 0u);
-    const __amdgpu_buffer_rsrc_t rs_mk = mh_make_rsrc(p.mask_hi ? (const void*)p.mask_hi : (const void*)p.in_hi, p.mask_hi ? (unsigned)((int64_t)p.B * p.H * p.W * p.mask_pld * 2) : 0u);
-#pragma unroll 2
-    for (int m = tid / C8; m < BM; m += RP) {
-        const int blk = m >> 5, w = m & 31;
-        const int row = MR == 1 ? blk : blk * 2 + (w >> 4), colp = MR == 1 ? w : (w & 15);
-        const int y = y00 + row * d, x = x00 + colp * d;
-        const bool ok = y < p.H && x < p.W && n < p.N;
-        const int pix = (b * p.H + y) * p.W + x;
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(&Cs[m * CS + c8 * 8]), v1 = *reinterpret_cast<const f32x4*>(&Cs[m * CS + c8 * 8 + 4]);
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            v[e] += bv[e];
-            if (p.alpha != 1.0f) v[e] = v[e] > 0.f ? v[e] : p.alpha * v[e];
+        for (int i = 0; i < PLANE_BLKS; ++i) {
+            const int g = i * 64 + lane;
+            const int pr = g / ROWP, rem = g - pr * ROWP;
+            const int pc = rem / NCK1, c1 = rem - pc * NCK1;
+            const int iy = y00 + (pr - 1) * d, ix = x00 + (pc - 1) * d;
+            const bool ok = pr < PR && pc < PC && c1 < NCK && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            base[i] = ok ? ((b * p.H + iy) * p.W + ix) * pix_b + c1 * 16 : MH_OOB;
+            cc[i] = ok ? c1 : (1 << 28);
         }
-        if (p.mask_hi) {        // 8 bf16 of the activation's hi plane: bf16 keeps sign and zero, the test is that of the fp32 tensor
-            const u32x4 mq = __builtin_amdgcn_raw_buffer_load_b128(rs_mk, ok ? (pix * p.mask_pld + n) * 2 : MH_OOB, 0, 0);
+        auto stage = [&](int c) {
+            unsigned char* const dst = smem + (c % NBUF) * BUF_BYTES;
+            const int lim = c < nch ? pld8 - c * NCK : 0;       // channel chunks of this K chunk inside the plane row (chunks past the end: none)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float mk = __builtin_bit_cast(float, (e & 1) ? (mq[e >> 1] & 0xffff0000u) : (mq[e >> 1] << 16));
-                v[e] *= mk > 0.f ? 1.0f : p.mask_alpha;
+            for (int i = 0; i < PLANE_BLKS; ++i) {
+                const int off = cc[i] < lim ? base[i] + c * (NCK * 16) : MH_OOB;
+                mh_glds16(rs_h, dst + i * 1024, off);
+                if constexpr (PL == 2) mh_glds16(rs_l, dst + PLANE_BYTES + i * 1024, off);
+            }
+        };
+        // every chunk slot issues exactly NLOAD loads (chunks past the end: all lanes out of range -> zeros into a buffer nobody reads), so the
+        // vmcnt window is a constant
+        for (int c = 0; c < NBUF - 1; ++c) stage(c);
+        for (int c = 0; c < nch; ++c) {
+            // chunk c must have landed: all but the loads of the NBUF - 2 newer chunks in flight
+            if constexpr (NBUF >= 3) MH_WAIT_VMCNT((NBUF - 2) * G::NLOAD <= 63 ? (NBUF - 2) * G::NLOAD : 63);
+            else MH_WAIT_VMCNT(0);
+            __syncthreads();                                  // chunk c is visible; buffer (c - 1) % NBUF is free
+            stage(c + NBUF - 1);
+        }
+        MH_WAIT_VMCNT(0);
+        __syncthreads();                                      // the walk's last barrier
+    } else {
+        // ---- compute waves ------------------------------------------------------------------------------------------------------------------------
+        const __amdgpu_buffer_rsrc_t rs_b = mh_make_rsrc(p.wb, p.wb_bytes);
+        const int nt32 = (p.N + 31) >> 5;
+        const int nt = tile_n * WN + wn;
+        const int voff_b = nt < nt32 ? nt * (PL * 1024) + lane * 16 : MH_OOB;
+        const int step_b = nt32 * (PL * 1024);
+        const int t_all = nch * T;
+        u32x4 fb[NSTB][PL];
+        auto issue_b = [&](int gt, int slot) {
+            if (gt < t_all) {
+                fb[slot][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff_b, gt * step_b, 0);
+                if constexpr (PL == 2) fb[slot][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff_b, gt * step_b + 1024, 0);
+            }
+        };
+#pragma unroll
+        for (int t = 0; t < PF; ++t) issue_b(t, t % NSTB);
+        const int j = lane & 31, kg = lane >> 5;
+        const int lr = MR == 1 ? 0 : (j >> 4), lc = MR == 1 ? j : (j & 15);
+        const int a_off = (((wm * MBW * MR + lr) * ROWP + lc * NCK1 + kg) * 16);
+        for (int c = 0; c < nch; ++c) {
+            __syncthreads();                                  // chunk c has landed
+            const unsigned char* const a_h = smem + (c % NBUF) * BUF_BYTES + a_off;
+            const unsigned char* const a_l = a_h + PLANE_BYTES;
+            u32x4 fa[2][MBW][PL];
+            auto issue_a = [&](int t, int set) {
+                if (t < T) {
+                    const int tap = t / K16, s = t - tap * K16;
+                    const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+                    for (int mb = 0; mb < MBW; ++mb) {
+                        const int imm = (((mb * MR + ky) * ROWP + kx * NCK1 + 2 * s) * 16);
+                        fa[set][mb][0] = *reinterpret_cast<const u32x4*>(a_h + imm);
+                        if constexpr (PL == 2) fa[set][mb][1] = *reinterpret_cast<const u32x4*>(a_l + imm);
+                    }
+                }
+            };
+            issue_a(0, 0);
+            const int gt0 = c * T;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int sa = t & 1, sb = t % NSTB;
+#pragma unroll
+                for (int term = (PL == 2 ? 0 : 2); term < 3; ++term) {
+#pragma unroll
+                    for (int mb = 0; mb < MBW; ++mb) {
+                        acc[mb] = mh_mfma_bf16_32(fa[sa][mb][term == 0 ? PL - 1 : 0], fb[sb][term == 1 ? PL - 1 : 0], acc[mb]);
+                        if (term == (PL == 2 ? 0 : 2) && mb == 0) issue_a(t + 1, sa ^ 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                issue_b(gt0 + t + PF, (t + PF) % NSTB);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        unsigned hh[4], ll[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) mh_split_bf16x2(v[2 * e], v[2 * e + 1], hh[e], ll[e]);
-        const int op = ok ? (pix * p.out_pld + n) * 2 : MH_OOB;
-        const int of = ok ? (pix * p.out_ld + n) * 4 : MH_OOB;
-        const u32x4 qh = {hh[0], hh[1], hh[2], hh[3]}, ql = {ll[0], ll[1], ll[2], ll[3]};
-        const u32x4 f0 = __builtin_bit_cast(u32x4, make_float4(v[0], v[1], v[2], v[3])), f1 = __builtin_bit_cast(u32x4, make_float4(v[4], v[5], v[6], v[7]));
-        const int of1 = of == MH_OOB ? MH_OOB : of + 16;
-        if (p.dbg & 4) {            // experiment (mh_tune_conv_planes bit 10): write-through (sc1) stores -- nothing dirty left in L2 at the kernel boundary
-            __builtin_amdgcn_raw_buffer_store_b128(qh, rs_oh, op, 0, 16);
-            __builtin_amdgcn_raw_buffer_store_b128(ql, rs_ol, op, 0, 16);
-            __builtin_amdgcn_raw_buffer_store_b128(f0, rs_o, of, 0, 16);
-            __builtin_amdgcn_raw_buffer_store_b128(f1, rs_o, of1, 0, 16);
-        } else if (p.dbg & 8) {     // experiment (bit 11): non-temporal stores
-            __builtin_amdgcn_raw_buffer_store_b128(qh, rs_oh, op, 0, 2);
-            __builtin_amdgcn_raw_buffer_store_b128(ql, rs_ol, op, 0, 2);
-            __builtin_amdgcn_raw_buffer_store_b128(f0, rs_o, of, 0, 2);
-            __builtin_amdgcn_raw_buffer_store_b128(f1, rs_o, of1, 0, 2);
-        } else {
-            __builtin_amdgcn_raw_buffer_store_b128(qh, rs_oh, op, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(ql, rs_ol, op, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(f0, rs_o, of, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(f1, rs_o, of1, 0, 0);
-        }
+        __syncthreads();                                      // every wave is done with the patch buffers: the accumulator tile goes over them
     }
+    planes_epilogue<G>(p, smem_all, acc, tid, !loader, wm, wn, lane, n0, y00, x00, b, d);
 }
 
 // fp32 NHWC -> the two bf16 planes (the operands of conv_planes_kernel): tensors no plane-writing kernel produces (cost-volume buffers, exact-fp32
@@ -297,12 +463,39 @@ int launch_planes(PlanesArgs& a, hipStream_t s, bool attr_only) {
     return mh_check_launch("conv_planes");
 }
 
+template <int MC, int WM, int WN, int MBW, int K16, int PL, int NBUF>
+int launch_planes_ck(PlanesArgs& a, hipStream_t s, bool attr_only) {
+    using G = PlanesCkGeo<MC, WM, WN, MBW, K16, PL, NBUF>;
+    static_assert(G::LDS_CK <= 160 * 1024, "patch buffers exceed the LDS");
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_planes_ck_kernel<MC, WM, WN, MBW, K16, PL, NBUF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { mh_set_error("conv_planes_ck: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_done = true;
+    }
+    if (attr_only) return 0;
+    const int d = a.dil;
+    a.tiles_y = mh_cdiv(mh_cdiv(a.H, d), G::TR);
+    a.tiles_x = mh_cdiv(mh_cdiv(a.W, d), MC);
+    a.ntiles_n = mh_cdiv(a.N, G::BN);
+    a.nwg = a.B * d * d * a.tiles_y * a.tiles_x * a.ntiles_n;
+    a.dec = mh_make_tile_decode(a.ntiles_n, a.tiles_x, a.tiles_y, d);
+    a.nchunks = mh_cdiv(mh_cdiv(a.K, 16), K16);
+    a.dbg = 0;
+    ++g_planes_launches;
+    mh_note_kernel("conv_planes_ck_kernel<%dx%d waves + loader,MBW=%d,chunk K16=%d x %d,%s,%d buffers> tile %dx%d K=%d dil=%d grid %d lds %d", WM, WN, MBW, K16, a.nchunks,
+                   PL == 2 ? "bf16x3" : "bf16", NBUF, G::BM, G::BN, a.K, a.dil, a.nwg, G::LDS_CK);
+    hipLaunchKernelGGL((conv_planes_ck_kernel<MC, WM, WN, MBW, K16, PL, NBUF>), dim3(a.nwg), dim3((WM * WN + 1) * 64), G::LDS_CK, s, a);
+    return mh_check_launch("conv_planes_ck");
+}
+
 // ---- instance table + tile choice ---------------------------------------------------------------------------------------------------------
 // Every (N rounded up to 32, K16) pair has the 128-pixel instances of both M-block shapes; the pairs MADNet's layers use also have 64- / 32-pixel
 // instances for grids that would not fill the chip (the 1/8-resolution level: 60 tiles of 128 pixels on 256 CUs).
-struct PlanesInst { int mc, wm, wn, mbw, k16, lds; int (*launch)(PlanesArgs&, hipStream_t, bool); int pl; };
-#define PL_INST(MC, WM, WN, MBW, K16) {MC, WM, WN, MBW, K16, PlanesGeo<MC, WM, WN, MBW, K16, 2>::LDS, &launch_planes<MC, WM, WN, MBW, K16, 2>, 2}
-#define P1_INST(MC, WM, WN, MBW, K16) {MC, WM, WN, MBW, K16, PlanesGeo<MC, WM, WN, MBW, K16, 1>::LDS, &launch_planes<MC, WM, WN, MBW, K16, 1>, 1}
+struct PlanesInst { int mc, wm, wn, mbw, k16, lds; int (*launch)(PlanesArgs&, hipStream_t, bool); int pl; int nbuf; };    // nbuf > 0: K-chunked (k16 = the chunk)
+#define PL_INST(MC, WM, WN, MBW, K16) {MC, WM, WN, MBW, K16, PlanesGeo<MC, WM, WN, MBW, K16, 2>::LDS, &launch_planes<MC, WM, WN, MBW, K16, 2>, 2, 0}
+#define P1_INST(MC, WM, WN, MBW, K16) {MC, WM, WN, MBW, K16, PlanesGeo<MC, WM, WN, MBW, K16, 1>::LDS, &launch_planes<MC, WM, WN, MBW, K16, 1>, 1, 0}
+#define CK_INST(WN, MBW, PL, NBUF) {32, 1, WN, MBW, MH_PLANES_KC16, PlanesCkGeo<32, 1, WN, MBW, MH_PLANES_KC16, PL, NBUF>::LDS_CK, &launch_planes_ck<32, 1, WN, MBW, MH_PLANES_KC16, PL, NBUF>, PL, NBUF}
 #define P1_BOTH(WM, WN, MBW, K16) P1_INST(32, WM, WN, MBW, K16), P1_INST(16, WM, WN, MBW, K16)
 #define PL_BOTH(WM, WN, MBW, K16) PL_INST(32, WM, WN, MBW, K16), PL_INST(16, WM, WN, MBW, K16)
 #define PL_BASE(K16) PL_BOTH(1, 4, 4, K16), PL_BOTH(2, 3, 2, K16), PL_BOTH(2, 2, 2, K16), PL_BOTH(4, 1, 1, K16)
@@ -322,6 +515,14 @@ const PlanesInst g_planes_inst[] = {
     P1_BOTH(2, 3, 2, 4), P1_BOTH(1, 3, 2, 4), P1_BOTH(1, 3, 1, 4),
     P1_BOTH(2, 2, 2, 2), P1_BOTH(2, 2, 1, 2), P1_BOTH(1, 2, 1, 2), P1_BOTH(2, 2, 2, 4), P1_BOTH(2, 2, 1, 4), P1_BOTH(1, 2, 1, 4),
     P1_BOTH(4, 1, 1, 2), P1_BOTH(2, 1, 1, 2),
+    // ---- DispNet (Nets/DispNet.py:75-152) ------------------------------------------------------------------------------------------------
+    // split-bf16 forward of the two finest iconv layers: 193 -> 64 (K16 13: 64-pixel tiles, the patch planes fill the LDS) and 97 -> 32 (K16 7)
+    PL_INST(32, 1, 2, 2, 13), PL_INST(32, 1, 2, 1, 13), PL_INST(32, 4, 1, 1, 7), PL_INST(32, 2, 1, 1, 7),
+    // their input gradients (one plane): reduction over 64 / 32 output channels, 193 / 97 columns in 128-column tiles
+    P1_INST(32, 1, 4, 4, 4), P1_INST(32, 1, 4, 2, 4), P1_INST(32, 1, 4, 1, 4), P1_INST(32, 1, 4, 4, 2), P1_INST(32, 1, 4, 2, 2),
+    // K-chunked (chunks of 64 channels): every layer / input gradient with a reduction over more than 128 channels, 128- or 64-column tiles
+    CK_INST(4, 4, 1, 3), CK_INST(4, 2, 1, 3), CK_INST(4, 1, 1, 3), CK_INST(2, 2, 1, 3), CK_INST(2, 1, 1, 3),
+    CK_INST(4, 2, 2, 3), CK_INST(4, 1, 2, 3), CK_INST(2, 2, 2, 3), CK_INST(2, 1, 2, 3),
 };
 constexpr int N_PLANES_INST = sizeof(g_planes_inst) / sizeof(g_planes_inst[0]);
 
@@ -332,19 +533,39 @@ constexpr int N_PLANES_INST = sizeof(g_planes_inst) / sizeof(g_planes_inst[0]);
 float planes_cost(const PlanesInst& I, const PlanesArgs& a, int* nwg_out) {
     const int mr = 32 / I.mc, tr = I.wm * I.mbw * mr, d = a.dil;
     const int64_t nwg = (int64_t)a.B * d * d * mh_cdiv(mh_cdiv(a.H, d), tr) * mh_cdiv(mh_cdiv(a.W, d), I.mc) * mh_cdiv(a.N, I.wn * 32);
-    const int nw = I.wm * I.wn;
+    const int nw = I.wm * I.wn + (I.nbuf ? 1 : 0);
     int wpc = (160 * 1024) / I.lds;                         // co-resident workgroups per CU: LDS, and at most 8 waves worth scheduling for
     if (wpc * nw > 8) wpc = 8 / nw > 0 ? 8 / nw : 1;
     if (wpc < 1) wpc = 1;
+    // K-chunked instances: the walk is nchunks chunk walks long (in units of a K16 = 8 walk), and a wave with few M-blocks is bound by its weight
+    // fragments (1 KB per step per wave from L2, ~64 B/clk/CU: four waves need two M-blocks' worth of MFMA time per step to hide them)
+    float walk = (float)I.mbw;
+    if (I.nbuf) {
+        const int nch = mh_cdiv(mh_cdiv(a.K, 16), I.k16);
+        const float per_step = (float)I.mbw * (I.pl == 2 ? 3.f : 1.f);
+        walk = (per_step < 2.f ? 2.f : per_step) / (I.pl == 2 ? 3.f : 1.f) * (float)(nch * I.k16) / 8.f;
+    }
     // round by round: a CU holds min(wpc, what is left / 256) workgroups, its busiest SIMD ceil(workgroups x waves / 4) waves
     float t = 0.f;
     for (int64_t left = nwg; left > 0; left -= 256 * wpc) {
         const int64_t per_cu = (left + 255) / 256 < wpc ? (left + 255) / 256 : wpc;
-        const int64_t simd = (per_cu * nw + 3) / 4;
-        t += (float)I.mbw * (float)simd + (I.pl == 2 ? 20.f : 60.f) / (float)I.k16;
+        const int64_t simd = (per_cu * (I.wm * I.wn) + 3) / 4;
+        t += walk * (float)simd + (I.pl == 2 ? 20.f : 60.f) / (float)(I.nbuf ? 8 : I.k16);
     }
     if (nwg_out) *nwg_out = (int)nwg;
     return t;
+}
+
+// Which instances serve a layer: the bank's layout is fixed by the reduction length alone (mh_planes_kc16: whole-K image up to 128 channels and for
+// the two DispNet shapes with whole-K instances, chunk-major beyond), so a layer has either whole-K or chunked candidates, never both.
+// Columns: up to 128 -> the instance's width must be the layer's (rounded to 32); more -> 128-column tiles (chunked: 64-column tiles too).
+bool planes_inst_fits(const PlanesInst& I, int k16, int n32, int pl) {
+    if (I.pl != pl) return false;
+    const bool chunked = mh_planes_kc16(k16 * 16) != 0;
+    if (chunked != (I.nbuf != 0)) return false;
+    if (!chunked && I.k16 != k16) return false;
+    if (n32 <= 4) return chunked ? (I.wn == n32 || (n32 == 3 && I.wn == 4) || (n32 == 1 && I.wn == 2)) : I.wn == n32;
+    return I.wn == 4 || (chunked && I.wn == 2);
 }
 
 int dispatch_planes(PlanesArgs& a, hipStream_t s, bool all, int pl = 2) {
@@ -361,7 +582,7 @@ int dispatch_planes(PlanesArgs& a, hipStream_t s, bool all, int pl = 2) {
     float best_cost = 0.f;
     for (int i = 0; i < N_PLANES_INST; ++i) {
         const PlanesInst& I = g_planes_inst[i];
-        if (I.k16 != k16 || I.wn != n32 || I.pl != pl) continue;
+        if (!planes_inst_fits(I, k16, n32, pl)) continue;
         float c = planes_cost(I, a, nullptr);
         if (v != 0) c = (I.mc == want_mc ? 0.f : 1000.f) + (float)abs(I.wm * I.mbw * 32 - want_px);        // forced: the closest available shape
         else c -= 1e-3f * (float)(I.wm * I.mbw) + (I.mc == 32 ? 5e-4f : 0.f);                                // ties: the larger tile, then the one-row M-block
@@ -386,13 +607,17 @@ extern "C" int mh_tune_conv_planes(int mode) {
     return g_planes_launches.exchange(0);
 }
 
+// bytes of the two-plane image (one plane: half).  K-chunked layouts (mh_planes_kc16) pad the reduction to whole chunks.
 extern "C" int64_t mh_pack32_bytes(int32_t taps, int32_t K, int32_t N) {
-    return (int64_t)taps * ((K + 15) / 16) * ((N + 31) / 32) * 2048;
+    int k16 = (K + 15) / 16;
+    const int kc = mh_planes_kc16(K);
+    if (kc) k16 = (k16 + kc - 1) / kc * kc;
+    return (int64_t)taps * k16 * ((N + 31) / 32) * 2048;
 }
 
 static bool planes_has_instance(int k16, int n32, int pl) {
     for (int i = 0; i < N_PLANES_INST; ++i)
-        if (g_planes_inst[i].k16 == k16 && g_planes_inst[i].wn == n32 && g_planes_inst[i].pl == pl) return true;
+        if (planes_inst_fits(g_planes_inst[i], k16, n32, pl)) return true;
     return false;
 }
 
@@ -400,7 +625,7 @@ static bool planes_has_instance(int k16, int n32, int pl) {
 extern "C" int mh_conv2d_planes_bwd_ok(const mh_conv_desc* d) {
     if (!d) return 0;
     if (!(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_t == d->dil && d->pad_l == d->dil && d->Hi == d->Ho && d->Wi == d->Wo)) return 0;
-    if (d->dil < 1 || d->dil > 64 || d->K < 1 || d->K > 128 || (d->K & 7)) return 0;          // d = the FORWARD layer: K = Cin = the gradient's columns
+    if (d->dil < 1 || d->dil > 64 || d->K < 1 || d->K > 2048 || d->N < 1 || d->N > 2048) return 0;          // d = the FORWARD layer: K = Cin = the gradient's columns
     return planes_has_instance((d->N + 15) / 16, (d->K + 31) / 32, 1) ? 1 : 0;
 }
 
@@ -408,20 +633,25 @@ extern "C" int mh_conv2d_planes_bwd(const mh_conv_desc* d, const void* dz_hi, in
                                     float* dx, void* dx_hi, int32_t dx_pld, void* stream) {
     MH_REQUIRE(d && dz_hi && wb32t, MH_ERR_ARG, "mh_conv2d_planes_bwd: null descriptor / dz plane / fragment bank");
     MH_REQUIRE(dx || dx_hi, MH_ERR_ARG, "mh_conv2d_planes_bwd: no output");
-    MH_REQUIRE(mh_conv2d_planes_bwd_ok(d), MH_ERR_UNSUPPORTED, "mh_conv2d_planes_bwd: stride-1 'SAME' 3x3 layers with an instance (Cin <= 128 and a multiple of 8)");
+    MH_REQUIRE(mh_conv2d_planes_bwd_ok(d), MH_ERR_UNSUPPORTED, "mh_conv2d_planes_bwd: stride-1 'SAME' 3x3 layers with an instance");
     MH_REQUIRE(d->B > 0 && d->Hi > 0 && d->Wi > 0, MH_ERR_ARG, "mh_conv2d_planes_bwd: non-positive size");
     const int k16 = (d->N + 15) / 16;
+    const int k8 = (d->K + 7) & ~7;
     MH_REQUIRE(dz_pld >= k16 * 16 && (dz_pld & 7) == 0, MH_ERR_ARG, "mh_conv2d_planes_bwd: dz_pld must cover Cout rounded up to 16 (multiple of 8)");
     MH_REQUIRE(mh_aligned16(dz_hi) && mh_aligned16(wb32t) && mh_aligned16(mask_hi) && mh_aligned16(dx_hi), MH_ERR_ALIGN, "mh_conv2d_planes_bwd: 16-byte aligned planes / bank");
-    MH_REQUIRE(!mask_hi || (mask_pld >= d->K && (mask_pld & 7) == 0), MH_ERR_ARG, "mh_conv2d_planes_bwd: mask_pld must cover Cin (multiple of 8)");
-    if (dx) MH_REQUIRE(d->in_ld >= d->K && (d->in_ld & 3) == 0 && mh_aligned16(dx), MH_ERR_ALIGN, "mh_conv2d_planes_bwd: dx rows (d->in_ld floats) must be 16-byte aligned");
-    if (dx_hi) MH_REQUIRE(dx_pld >= d->K && (dx_pld & 7) == 0, MH_ERR_ARG, "mh_conv2d_planes_bwd: dx_pld must cover Cin (multiple of 8)");
+    MH_REQUIRE(!mask_hi || (mask_pld >= k8 && (mask_pld & 7) == 0), MH_ERR_ARG, "mh_conv2d_planes_bwd: mask_pld must cover Cin rounded up to 8 (multiple of 8)");
+    // the epilogue stores 8 columns per lane: rows must hold Cin rounded up to 8 (the concat buffers of DispNet are allocated that way)
+    if (dx) MH_REQUIRE(d->in_ld >= k8 && (d->in_ld & 3) == 0 && mh_aligned16(dx), MH_ERR_ALIGN, "mh_conv2d_planes_bwd: dx rows (d->in_ld floats >= Cin rounded up to 8) must be 16-byte aligned");
+    if (dx_hi) MH_REQUIRE(dx_pld >= k8 && (dx_pld & 7) == 0, MH_ERR_ARG, "mh_conv2d_planes_bwd: dx_pld must cover Cin rounded up to 8 (multiple of 8)");
+    MH_REQUIRE(!d->accumulate, MH_ERR_UNSUPPORTED, "mh_conv2d_planes_bwd: no accumulation");
     const int64_t npix = (int64_t)d->B * d->Hi * d->Wi;
     MH_REQUIRE(npix * dz_pld * 2 < (1ll << 31) && npix * d->in_ld * 4 < (1ll << 31) && npix * (int64_t)dx_pld * 2 < (1ll << 31) && npix * (int64_t)mask_pld * 2 < (1ll << 31),
                MH_ERR_UNSUPPORTED, "mh_conv2d_planes_bwd: tensors must be < 2 GiB");
     PlanesArgs a = {};
     a.in_hi = (const unsigned short*)dz_hi; a.in_lo = nullptr; a.wb = wb32t; a.bias = nullptr;
     a.mask_hi = (const unsigned short*)mask_hi; a.mask_pld = mask_pld; a.mask_alpha = d->mask_alpha;
+    a.mask_c0 = d->mask_c0; a.mask_c1 = (d->mask_c0 == 0 && d->mask_c1 == 0) ? 0x7fffffff : d->mask_c1;
+    a.nchunks = 1;
     a.out = dx; a.out_hi = (unsigned short*)dx_hi; a.out_lo = nullptr;
     a.in_bytes = (unsigned)(npix * dz_pld * 2);
     a.wb_bytes = (unsigned)(mh_pack32_bytes(9, d->N, d->K) / 2);
@@ -466,16 +696,17 @@ extern "C" int mh_plane_split(const mh_plane_seg* segs_device, int32_t nseg, int
 extern "C" int mh_conv2d_planes_ok(const mh_conv_desc* d) {
     if (!d) return 0;
     if (!(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->mode == 0 && d->pad_t == d->dil && d->pad_l == d->dil && d->Hi == d->Ho && d->Wi == d->Wo)) return 0;
-    if (d->accumulate || d->dil < 1 || d->dil > 64 || d->N < 1 || d->N > 128 || (d->N & 7)) return 0;
-    return planes_has_instance((d->K + 15) / 16, (d->N + 31) / 32, 2) ? 1 : 0;
+    if (d->accumulate || d->dil < 1 || d->dil > 64 || d->N < 1 || d->N > 2048 || (d->N & 7) || d->K < 1 || d->K > 2048) return 0;
+    return planes_has_instance((d->K + 15) / 16, (d->N + 31) / 32, d->precision == 1 ? 1 : 2) ? 1 : 0;
 }
 
 extern "C" int mh_conv2d_planes(const mh_conv_desc* d, const void* in_hi, const void* in_lo, int32_t in_pld, const void* wb32, const float* bias,
                                 float* out, void* out_hi, void* out_lo, int32_t out_pld, void* stream) {
-    MH_REQUIRE(d && in_hi && in_lo && wb32, MH_ERR_ARG, "mh_conv2d_planes: null descriptor / input planes / fragment bank");
+    MH_REQUIRE(d && in_hi && wb32, MH_ERR_ARG, "mh_conv2d_planes: null descriptor / input plane / fragment bank");
+    const int pl = d->precision == 1 ? 1 : 2;               // precision 1: plain bf16 from the hi plane and a ONE-plane bank; else split-bf16
+    MH_REQUIRE(pl == 1 || in_lo, MH_ERR_ARG, "mh_conv2d_planes: the split-bf16 form needs the lo plane");
     MH_REQUIRE(out || out_hi || out_lo, MH_ERR_ARG, "mh_conv2d_planes: no output");
-    MH_REQUIRE(mh_conv2d_planes_ok(d), MH_ERR_UNSUPPORTED,
-               "mh_conv2d_planes: forward stride-1 'SAME' 3x3 layers, N <= 128 (multiple of 8), K in 17..96 or 113..128, no accumulation");
+    MH_REQUIRE(mh_conv2d_planes_ok(d), MH_ERR_UNSUPPORTED, "mh_conv2d_planes: forward stride-1 'SAME' 3x3 layers with an instance, N a multiple of 8, no accumulation");
     MH_REQUIRE(d->B > 0 && d->Hi > 0 && d->Wi > 0, MH_ERR_ARG, "mh_conv2d_planes: non-positive size");
     const int k16 = (d->K + 15) / 16;
     MH_REQUIRE(in_pld >= k16 * 16 && (in_pld & 7) == 0, MH_ERR_ARG, "mh_conv2d_planes: in_pld must cover K rounded up to 16 (multiple of 8)");
@@ -489,15 +720,16 @@ extern "C" int mh_conv2d_planes(const mh_conv_desc* d, const void* in_hi, const 
     MH_REQUIRE(npix * in_pld * 2 < (1ll << 31) && npix * d->out_ld * 4 < (1ll << 31) && npix * (int64_t)out_pld * 2 < (1ll << 31), MH_ERR_UNSUPPORTED,
                "mh_conv2d_planes: tensors must be < 2 GiB");
     PlanesArgs a = {};
-    a.in_hi = (const unsigned short*)in_hi; a.in_lo = (const unsigned short*)in_lo; a.wb = wb32; a.bias = bias;
-    a.mask_hi = nullptr; a.mask_pld = 0; a.mask_alpha = 1.0f;
+    a.in_hi = (const unsigned short*)in_hi; a.in_lo = (const unsigned short*)(pl == 2 ? in_lo : nullptr); a.wb = wb32; a.bias = bias;
+    a.mask_hi = nullptr; a.mask_pld = 0; a.mask_alpha = 1.0f; a.mask_c0 = 0; a.mask_c1 = 0x7fffffff;
+    a.nchunks = 1;
     a.out = out; a.out_hi = (unsigned short*)out_hi; a.out_lo = (unsigned short*)out_lo;
     a.in_bytes = (unsigned)(npix * in_pld * 2);
-    a.wb_bytes = (unsigned)mh_pack32_bytes(9, d->K, d->N);
+    a.wb_bytes = (unsigned)(mh_pack32_bytes(9, d->K, d->N) / (pl == 1 ? 2 : 1));
     a.out_bytes = out ? (unsigned)(npix * d->out_ld * 4) : 0u;
     a.outp_bytes = (unsigned)(npix * out_pld * 2);
     a.in_pld = in_pld; a.out_ld = d->out_ld; a.out_pld = out_pld;
     a.B = d->B; a.H = d->Hi; a.W = d->Wi; a.K = d->K; a.N = d->N; a.dil = d->dil;
     a.alpha = d->alpha;
-    return dispatch_planes(a, (hipStream_t)stream, false);
+    return dispatch_planes(a, (hipStream_t)stream, false, pl);
 }

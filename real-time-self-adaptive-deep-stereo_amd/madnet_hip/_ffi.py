@@ -45,7 +45,7 @@ class WgradSeg(C.Structure):
 
 class PackSeg(C.Structure):          # mh_pack_seg
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("taps", C.c_int32), ("K", C.c_int32), ("N", C.c_int32),
-                ("planes", C.c_int32), ("blk0", C.c_int32), ("trans", C.c_int32)]
+                ("planes", C.c_int32), ("blk0", C.c_int32), ("trans", C.c_int32), ("kc16", C.c_int32), ("reserved", C.c_int32)]
 
 
 class WgradItem(C.Structure):        # mh_wgrad_item
@@ -86,6 +86,7 @@ SIGNATURES = {
     "mh_last_error": (C.c_char_p, []),
     "mh_last_kernel": (C.c_char_p, []),
     "mh_abi_version": (_I, []),
+    "mh_planes_kc16": (_I, [_I]),
     "mh_crc32c": (C.c_uint32, [C.c_char_p, _L, C.c_uint32]),
     "mh_device_count": (_I, []),
     "mh_init": (_I, []),
@@ -174,7 +175,7 @@ SIGNATURES = {
     "mh_event_destroy": (_I, [_P]),
     "mh_stream_sync": (_I, [_P]),
 }
-_NO_STATUS = {"mh_conv2d_planes_bwd_ok", "mh_stamp_rate_khz", "mh_pack32_bytes", "mh_conv2d_planes_ok", "mh_tune_conv_planes", "mh_tune_wgrad_target_pct", "mh_tune_wgrad_image", "mh_conv2d_takes_shadows", "mh_tune_conv_bank_tile", "mh_tune_conv_rows", "mh_last_error", "mh_last_kernel", "mh_tune_conv_bank", "mh_pack_bytes", "mh_abi_version", "mh_tune_conv_patch", "mh_crc32c", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats", "mh_proxy_ws_floats"}
+_NO_STATUS = {"mh_planes_kc16", "mh_conv2d_planes_bwd_ok", "mh_stamp_rate_khz", "mh_pack32_bytes", "mh_conv2d_planes_ok", "mh_tune_conv_planes", "mh_tune_wgrad_target_pct", "mh_tune_wgrad_image", "mh_conv2d_takes_shadows", "mh_tune_conv_bank_tile", "mh_tune_conv_rows", "mh_last_error", "mh_last_kernel", "mh_tune_conv_bank", "mh_pack_bytes", "mh_abi_version", "mh_tune_conv_patch", "mh_crc32c", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats", "mh_proxy_ws_floats"}
 
 
 class MadnetHipError(RuntimeError):

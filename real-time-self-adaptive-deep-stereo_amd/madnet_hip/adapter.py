@@ -11,6 +11,7 @@ FULL mode issues the collective in two pieces: [estimators + context network + l
 bytes, contiguous in the flat layout) as soon as the backward pass reaches the pyramid -- it runs on
 RCCL's stream while the pyramid's backward graph runs on ours -- and [pyramid] behind it.
 """
+import collections
 import numpy as np
 import torch
 
@@ -95,6 +96,7 @@ class Adapter(object):
         self.reset_counter = 0
         self.step_count = 0
         self._plans = {}
+        self._coll_buf = None          # staging buffer of the MAD shared-model collective (step)
         self.eng.params.w0 = self.eng.params.w.clone()              # restore target (initial weights)
         self._host = torch.zeros(8, pin_memory=self.cuda)
 
@@ -111,10 +113,10 @@ class Adapter(object):
                 if key == "NONE":
                     p = eng.build_plan("NONE", part=part)
                 elif key == "FULL":
-                    p = eng.build_plan("FULL", lr=self.lr, grad_scale=gs, part=part, optimizer=self.optimizer)
+                    p = eng.build_plan("FULL", lr=self.lr, grad_scale=gs, part=part, optimizer=self.optimizer, momentum=self.momentum)
                 else:
                     p = eng.build_plan("MAD", lr=self.lr, grad_scale=gs, part=part, blocks=[self.blocks[i] for i in key],
-                                       optimizer=self.optimizer)
+                                       optimizer=self.optimizer, momentum=self.momentum)
                 for q in (p if isinstance(p, list) else [p]):
                     if self.use_graph and q.n > 0:
                         with torch.cuda.stream(self.stream):
@@ -190,9 +192,23 @@ class Adapter(object):
                     rng[-1] = (rng[-1][0], rng[-1][1] + 4)
                 else:
                     rng.append(tail)
-                for o, c in rng:
+                if len(rng) == 1:
+                    o, c = rng[0]
                     self.dist.all_reduce(P.g_loss[o:o + c], group=self.pg)
-                self.collectives_last_step = len(rng)
+                else:
+                    # MAD: the flat layout keeps the pyramid first (the FULL step's early reduction wants it contiguous), so a block is two
+                    # ranges + the loss tail.  They travel as ONE collective through a staging buffer (a block is <= 1.5 M floats: the pack /
+                    # unpack copies cost less than one more latency-bound all-reduce)
+                    n = sum(c for _, c in rng)
+                    if self._coll_buf is None or self._coll_buf.numel() < n:
+                        self._coll_buf = torch.empty(n, dtype=P.g_loss.dtype, device=P.g_loss.device)
+                    buf = self._coll_buf[:n]
+                    torch.cat([P.g_loss[o:o + c] for o, c in rng], out=buf)
+                    self.dist.all_reduce(buf, group=self.pg)
+                    at = 0
+                    for o, c in rng:
+                        P.g_loss[o:o + c].copy_(buf[at:at + c]); at += c
+                self.collectives_last_step = 1
                 plans[1].launch(self.lib, sh)
             self._readback()
         if self.cuda:
@@ -256,13 +272,22 @@ class MultiAdapter(object):
         self.stream = a0.stream
         for a in self.adapters:
             a.stream = self.stream         # ONE stream orders uploads, the graph, read-backs and resets of every model
-        self._graphs = {}
+        self._graphs = collections.OrderedDict()       # plan-key tuple -> captured MultiPlan, least recently used first
+
+    # MAD with S streams can sample 5^S block combinations: the captured graphs are kept in an LRU of this many entries (evicted graph execs are
+    # destroyed; a combination that comes back is captured again, ~1 ms)
+    MAX_GRAPHS = 64
 
     def step(self, frames):
         """frames: one (left, right[, gt[, proxy]]) tuple per stream -> [Adapter.step()'s dict per stream]"""
         assert len(frames) == len(self.adapters)
+        for a, f in zip(self.adapters, frames):          # every frame is checked BEFORE any sampler advances
+            if a.loss == "proxy" and (len(f) <= 3 or f[3] is None):
+                raise ValueError("loss='proxy' needs the proxy disparity map of every frame")
         keys = tuple(a._sample_key(f[3] if len(f) > 3 else None) for a, f in zip(self.adapters, frames))
         mp = self._graphs.get(keys)
+        if mp is not None:
+            self._graphs.move_to_end(keys)
         sh = self.stream.cuda_stream if self.cuda else 0
         ctx = torch.cuda.stream(self.stream) if self.cuda else _null()
         with ctx:
@@ -273,6 +298,11 @@ class MultiAdapter(object):
                 if self.cuda:
                     mp.capture(self.lib, sh)
                 self._graphs[keys] = mp
+                while len(self._graphs) > self.MAX_GRAPHS:
+                    _, old = self._graphs.popitem(last=False)
+                    if old.graph is not None:
+                        self.stream.synchronize()            # its last replay may still be in flight
+                        self.lib.graph_destroy(old.graph); old.graph = None
             mp.launch(self.lib, sh)
             for a in self.adapters:
                 a._readback()

@@ -24,6 +24,17 @@ from .plan import Recorder
 MAX_DISP = 40
 ALPHA = 0.1     # default leaky slope of sharedLayers.conv2d / conv2d_transpose (sharedLayers.py:54,80)
 
+# 'mixed' / 'bf16': the stride-1 3x3 layers with at least PLANES_MIN_PIX pixels run mh_conv2d_planes / mh_conv2d_planes_bwd (csrc/conv_planes.hip; the
+# K-chunked kernel beyond 128 reduction channels) from bf16 planes -- the shadows the streamed filter gradient reads anyway, cast once in the forward
+# pass.  The coarser layers (conv5_1, conv6_1, iconv5: <= 480 pixels, 9 - 19 MB of weights for 16 - 60 workgroups) stay on the split-K igemm kernels
+# (scripts/microbench.py dispnet: 25 vs 41 us, 41 vs 73 us).  MH_CONV_PLANES=0 turns the path off.
+USE_PLANES = os.environ.get("MH_CONV_PLANES", "1") != "0"
+PLANES_MIN_PIX = 1920
+
+
+def _r8(c):
+    return (c + 7) // 8 * 8
+
 UP_BLOCKS = (("up5", 1024, 512, 512), ("up4", 512, 256, 512), ("up3", 256, 128, 256),
              ("up2", 128, 64, 128), ("up1", 64, 32, 64))       # name, Cin(bottom), Cout, Cskip
 
@@ -84,7 +95,7 @@ class Node(object):
 
 
 import threading
-_TUNE_LOCK = threading.Lock()      # serialises plan recording that scopes a process-wide tuning hook
+_TUNE_LOCK = ops.TUNE_LOCK          # serialises plan recording that scopes a process-wide tuning hook (shared with engine.MadNetEngine.build_plan)
 
 
 class DispNetEngine(object):
@@ -112,6 +123,10 @@ class DispNetEngine(object):
         # predictions) run on the streaming kernel (mh_wgrad_stream) from bf16 shadows cast per batch; MH_WGRAD_STREAM=0 keeps the tiled kernels
         self.use_stream = precision in ("mixed", "bf16") and os.environ.get("MH_WGRAD_STREAM", "1") != "0"
         self.shadows = {}
+        self.lo_planes = {}                 # shadow key -> lo plane (split-bf16 layers on mh_conv2d_planes)
+        self.banks_f, self.banks_b = {}, {}  # weight name -> fragment bank in the 32x32x16 image (forward: trans 2; input gradient: trans 3)
+        self._fresh = set()                 # shadow keys whose bf16 image is current in the plan being recorded
+        self.use_planes = USE_PLANES and precision in ("mixed", "bf16") and str(device).startswith(("cuda", "cpu"))
         self._build()
 
     # ---- graph construction -----------------------------------------------------------------------
@@ -146,7 +161,7 @@ class DispNetEngine(object):
         dims = {"up5": (h32, w32), "up4": (h16, w16), "up3": (h8, w8), "up2": (h4, w4), "up1": (h2, w2)}
         for name, cin, cout, skip in UP_BLOCKS:
             h, w = dims[name]
-            cat[name] = self._st(h, w, _r4(skip + cout + 1))
+            cat[name] = self._st(h, w, _r8(skip + cout + 1))            # rows of 8 k floats: mh_conv2d_planes_bwd stores 8 columns per lane
         N = self._node
         c1a = N("conv1a", cat["up1"], 0, 64, ALPHA); c1b = N("conv1b", self._st(h2, w2, 64), 0, 64, ALPHA)
         c2a = N("conv2a", cat["up2"], 0, 128, ALPHA); c2b = N("conv2b", self._st(h4, w4, 128), 0, 128, ALPHA)
@@ -207,8 +222,58 @@ class DispNetEngine(object):
         return 1 if head in self.MIXED_BF16_FWD else None
 
     # ---- forward --------------------------------------------------------------------------------------
-    def record_forward(self, r):
+    # ---- bf16-plane path of the stride-1 3x3 layers ---------------------------------------------------------------------------------------------
+    def _planes_fwd_kind(self, op):
+        """0: not on mh_conv2d_planes; 1: plain bf16 (one plane); 2: split-bf16 (hi + lo)"""
+        _, x, wn, out, stride, alpha, _ = op
+        w = self.W_(wn)
+        if not self.use_planes or stride != 1 or tuple(w.shape[:2]) != (3, 3) or x.st.H * x.st.W < PLANES_MIN_PIX or x.c0 != 0 or w.shape[3] % 8:
+            return 0
+        code = self._fwd_code(wn)
+        if code is None:
+            code = ops.PRECISION_CODES[self.precision][0]
+        if code not in (1, 2):
+            return 0
+        return code if ops.conv2d_planes_ok(self.lib, x.view(), w, 1, bf16=(code == 1)) else 0
+
+    def _planes_bwd_ok(self, op):
+        _, x, wn, out, stride, alpha, x_grad = op
+        w = self.W_(wn)
+        if not (self.use_planes and x_grad and stride == 1 and tuple(w.shape[:2]) == (3, 3) and x.st.H * x.st.W >= PLANES_MIN_PIX and x.c0 == 0):
+            return False
+        return ops._bwd_precision() == 1 and x.st.ld >= _r8(x.C) and ops.conv2d_planes_bwd_ok(self.lib, x.gview(), w, 1)
+
+    def _shadow_of(self, v):
+        key = (v.ptr, v.B, v.H, v.W, v.C)
+        sh = self.shadows.get(key)
+        if sh is None:
+            sh = self.shadows[key] = ops.Shadow(v.B, v.H, v.W, v.C, self.dev)
+        return key, sh
+
+    def _record_banks(self, r, backward):
+        """one mh_pack_weights launch at the head of the step: the banks of every layer on the plane kernels (re-packed every step: the weights move)"""
+        todo = []
+        for op in self.ops:
+            if op[0] != "conv":
+                continue
+            wn = op[2]
+            w = self.W_(wn)
+            kind = self._planes_fwd_kind(op)
+            if kind:
+                if wn not in self.banks_f or self.banks_f[wn][1] != kind:
+                    self.banks_f[wn] = (torch.zeros(ops.pack_bytes(w, kind, 2) // 4, device=self.dev), kind)
+                todo.append((w, self.banks_f[wn][0], kind, 2))
+            if backward and self._planes_bwd_ok(op):
+                if wn not in self.banks_b:
+                    self.banks_b[wn] = torch.zeros(ops.pack_bytes(w, 1, 3) // 4, device=self.dev)
+                todo.append((w, self.banks_b[wn], 1, 3))
+        ops.pack_weights(r, todo, self.dev, r.keep)
+
+    def record_forward(self, r, backward=True):
         B = self.B
+        self._fresh = set()
+        if self.use_planes:
+            self._record_banks(r, backward)
         # DispNet._preprocess_inputs (DispNet.py:59-73): x/255 - 100/255, reflect pad to a multiple of 64
         ops.pad_reflect(r, self.left, self.X0L.t, self.pt, self.pl, div=255.0, sub=100.0 / 255)
         ops.pad_reflect(r, self.right, self.X0R.t, self.pt, self.pl, div=255.0, sub=100.0 / 255)
@@ -216,6 +281,23 @@ class DispNetEngine(object):
             kind = op[0]
             if kind == "conv":
                 _, x, wn, out, stride, alpha, _ = op
+                kind = self._planes_fwd_kind(op)
+                if kind:
+                    # x -> bf16 plane(s) once (the hi plane is the shadow the streamed filter gradient reads: no cast in the backward pass)
+                    xv = x.view()
+                    key, sh = self._shadow_of(xv)
+                    if kind == 2:
+                        if key not in self.lo_planes:
+                            self.lo_planes[key] = ops.Shadow(xv.B, xv.H, xv.W, xv.C, self.dev)
+                        xp = ops.Planes.__new__(ops.Planes); xp.hi, xp.lo = sh, self.lo_planes[key]
+                        ops.plane_split(r, [(xv, xp)], self.dev, r.keep)
+                    else:
+                        xp = sh
+                        if key not in self._fresh:
+                            ops.shadow_cast(r, [(xv, sh)], self.dev, r.keep)
+                    self._fresh.add(key)
+                    ops.conv2d_planes(r, xp, self.W_(wn), self.banks_f[wn][0], self.b_(wn), out=out.view(), alpha=alpha, bf16=(kind == 1))
+                    continue
                 ops.conv2d_fwd(r, x.view(), self.W_(wn), self.b_(wn), out.view(), stride=stride, alpha=alpha, precision=self._fwd_code(wn))
             elif kind == "deconv":
                 _, x, wn, out, alpha = op
@@ -340,8 +422,25 @@ class DispNetEngine(object):
                 wgrad(x.view(), dz, self.W_(wn, "g"), self.b_(wn, "g"), stride)
                 if x_grad:
                     w = self.W_(wn)
-                    conv_like_dgrad(lambda dx, acc, ref, ma, rng: ops.conv2d_dgrad(lib, dz, w, dx, stride=stride, accumulate=acc,
-                                                                                    mask_ref=ref, mask_alpha=ma, mask_range=rng), x)
+
+                    def emit_dgrad(dx, acc, ref, ma, rng, op=op, dz=dz, w=w, wn=wn, stride=stride):
+                        if not acc and wn in self.banks_b and self._planes_bwd_ok(op):
+                            # dz (and the activation whose sign is the mask) as bf16 planes -- the casts the streamed filter gradient of this very
+                            # layer would queue on its side lane anyway -- then the one-plane walk over dz (mh_conv2d_planes_bwd)
+                            kz, dzs = self._shadow_of(dz)
+                            casts = [(dz, dzs)] if kz not in self._fresh else []
+                            ms = None
+                            if ref is not None:
+                                km, ms = self._shadow_of(ref)
+                                if km not in self._fresh:
+                                    casts.append((ref, ms))
+                                self._fresh.add(km)
+                            self._fresh.add(kz)
+                            ops.shadow_cast(lib, casts, self.dev, r.keep)
+                            ops.conv2d_planes_bwd(lib, dzs, w, self.banks_b[wn], dx=dx, mask_shadow=ms, mask_alpha=ma, mask_range=rng)
+                            return
+                        ops.conv2d_dgrad(lib, dz, w, dx, stride=stride, accumulate=acc, mask_ref=ref, mask_alpha=ma, mask_range=rng)
+                    conv_like_dgrad(emit_dgrad, x)
             elif kind == "deconv":
                 _, x, wn, out, alpha = op
                 assert out.written and out.remaining == 0, "gradient of %s incomplete" % out.name
@@ -374,7 +473,7 @@ class DispNetEngine(object):
         sh = self.shadows.get(key)
         if sh is None:
             sh = self.shadows[key] = ops.Shadow(v.B, v.H, v.W, v.C, self.dev)
-        if not any(c[1] is sh for c in casts):
+        if key not in self._fresh and not any(c[1] is sh for c in casts):
             casts.append((v, sh))
         return sh
 
@@ -420,7 +519,7 @@ class DispNetEngine(object):
         return r.compile()
 
     def build_plan(self, mode, lr=1e-4, grad_scale=1.0, update=True, part="all", loss_weights=None, max_disp=192.0,
-                   optimizer="momentum", **_):
+                   optimizer="momentum", momentum=0.9, **_):
         r = Recorder()
         r.wgrad_group_max_m = 0      # per-plan cap of the grouped filter gradients (0 = library default; 4096 and 16384 measure the same here)
         self.wsa.reset()
@@ -430,17 +529,17 @@ class DispNetEngine(object):
         with _TUNE_LOCK:
             prev = self.lib.tune_wgrad_target_pct(self.WGRAD_TARGET_PCT)
             try:
-                return self._build_plan_scoped(r, mode, lr, grad_scale, update, part, loss_weights, max_disp, optimizer)
+                return self._build_plan_scoped(r, mode, lr, grad_scale, update, part, loss_weights, max_disp, optimizer, momentum)
             finally:
                 self.lib.tune_wgrad_target_pct(prev)
 
-    def _build_plan_scoped(self, r, mode, lr, grad_scale, update, part, loss_weights, max_disp, optimizer="momentum"):
+    def _build_plan_scoped(self, r, mode, lr, grad_scale, update, part, loss_weights, max_disp, optimizer="momentum", momentum=0.9):
         with ops.precision_scope(self.precision):
             if mode == "TRAIN":
                 return self._build_train_plan(r, lr, grad_scale, update, part, loss_weights, max_disp)
-            return self._build_plan(r, mode, lr, grad_scale, update, part, optimizer)
+            return self._build_plan(r, mode, lr, grad_scale, update, part, optimizer, momentum)
 
-    def _build_plan(self, r, mode, lr, grad_scale, update, part, optimizer="momentum"):
+    def _build_plan(self, r, mode, lr, grad_scale, update, part, optimizer="momentum", momentum=0.9):
         if optimizer not in ("momentum", "adam"):
             raise ValueError("optimizer must be 'momentum' or 'adam'")
         do_grad = part in ("all", "grad")
@@ -448,7 +547,7 @@ class DispNetEngine(object):
         if mode not in ("NONE", "FULL"):
             raise ValueError("DispNet supports modes NONE and FULL (the reference's MAD assert fails for it)")
         if do_grad:
-            self.record_forward(r)
+            self.record_forward(r, backward=(mode == "FULL"))
             self.record_loss_metrics(r, with_grad=(mode == "FULL"))
             if mode == "FULL":
                 self.record_backward(r)
@@ -459,7 +558,7 @@ class DispNetEngine(object):
                 ops.adam(r, P.w, P.m, P.v, P.g, self.adam_state, lr, grad_scale=grad_scale, n=P.total)
                 ops.adam_advance(r, self.adam_state)
             else:
-                self.record_update(r, lr, grad_scale=grad_scale)
+                self.record_update(r, lr, momentum=momentum, grad_scale=grad_scale)
         return r.compile()
 
     def set_inputs(self, left, right, gt=None):

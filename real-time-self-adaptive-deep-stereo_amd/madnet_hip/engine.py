@@ -1171,12 +1171,12 @@ class MadNetEngine(object):
         return rng[0]
 
     def build_plan(self, mode, lr=1e-4, block_vars=None, block_level=None, grad_scale=1.0, update=True,
-                   blocks=None, part="all", loss_weights=None, max_disp=192.0, optimizer="momentum"):
+                   blocks=None, part="all", loss_weights=None, max_disp=192.0, optimizer="momentum", momentum=0.9):
         """mode: 'NONE' | 'FULL' | 'MAD' | 'TRAIN' (offline training step of Train.py: multi-scale supervised mean_l1 against
         self.gt with loss_weights from full to lowest resolution, every variable, Adam).
         For MAD: blocks = [(level, variable names), ...] (level in
         LEVELS, 2 = context output); block_level/block_vars is the single-block shorthand.
-        optimizer: 'momentum' (Stereo_Online_Adaptation.py:122) | 'adam' (the live demo, Demo/demo_model.py:164) for FULL / MAD.
+        optimizer: 'momentum' (Stereo_Online_Adaptation.py:122; `momentum` = its decay, 0.9 there) | 'adam' (the live demo, Demo/demo_model.py:164) for FULL / MAD.
         part: 'all' | 'grad' (everything up to the gradients) | 'update' (momentum apply only) -- the
         split lets a gradient all-reduce (shared-model multi-GPU mode) sit between two plans; 'grad_split' returns the 'grad' part as
         a LIST of two plans cut where the pyramid's backward pass starts (see madnet_manifest)."""
@@ -1193,10 +1193,12 @@ class MadNetEngine(object):
             self._stream_train = set()
         if part == "update":
             self._stream_train = set()
-        with ops.precision_scope(self.precision):
+        # the filter-gradient split counts are resolved while the plan is recorded, from a process-wide hook another engine's recording may be scoping
+        # (dispnet_engine.build_plan: 150 %): recordings are serialised
+        with ops.TUNE_LOCK, ops.precision_scope(self.precision):
             if mode == "TRAIN":
                 return self._build_train_plan(r, lr, grad_scale, update, part, loss_weights, max_disp)
-            return self._build_plan(r, mode, lr, block_vars, block_level, grad_scale, update, blocks, part, optimizer)
+            return self._build_plan(r, mode, lr, block_vars, block_level, grad_scale, update, blocks, part, optimizer, momentum)
 
     def _build_train_plan(self, r, lr, grad_scale, update, part, loss_weights, max_disp):
         """Train.py:56-62,94-102: bulkhead off, loss = sum_i w_i * mean_l1(disparities[-(i+1)], gt, valid), Adam(lr, 0.9)."""
@@ -1220,12 +1222,15 @@ class MadNetEngine(object):
         self._elide_fp32_activations(r)
         return r.compile()
 
-    def _build_plan(self, r, mode, lr, block_vars, block_level, grad_scale, update, blocks, part, optimizer="momentum"):
+    def _build_plan(self, r, mode, lr, block_vars, block_level, grad_scale, update, blocks, part, optimizer="momentum", momentum=0.9):
         if optimizer not in ("momentum", "adam"):
             raise ValueError("optimizer must be 'momentum' or 'adam'")
         # one AdamOptimizer serves every train op of the demo graph (Demo/demo_model.py:164): per-variable slots, ONE pair of beta
         # powers that advances with every executed train op -- which is what record_update_adam does per call
-        record_update = self.record_update if optimizer == "momentum" else self.record_update_adam
+        if optimizer == "momentum":
+            record_update = lambda rr, tv_, lr_, grad_scale=1.0: self.record_update(rr, tv_, lr_, momentum=momentum, grad_scale=grad_scale)
+        else:
+            record_update = self.record_update_adam
         if blocks is None and block_level is not None:
             blocks = [(block_level, block_vars)]
         do_grad = part in ("all", "grad", "grad_split")
@@ -1240,11 +1245,11 @@ class MadNetEngine(object):
             if do_grad:
                 self.record_forward(r)
                 self.record_loss_metrics(r, with_grad=True)
-                eu = (lr, 0.9, grad_scale) if (EARLY_UPDATE and do_upd and part == "all" and optimizer == "momentum") else None
+                eu = (lr, momentum, grad_scale) if (EARLY_UPDATE and do_upd and part == "all" and optimizer == "momentum") else None
                 done = self.record_backward(r, "final", tv, bulkhead=False, early_update=eu)
             if do_upd:
                 if done:
-                    self.record_update(r, tv, lr, grad_scale=grad_scale, done=done)
+                    self.record_update(r, tv, lr, momentum=momentum, grad_scale=grad_scale, done=done)
                 else:
                     record_update(r, tv, lr, grad_scale=grad_scale)
         elif mode == "MAD":

@@ -132,12 +132,23 @@ def conv2d_fwd(lib, x, w, b, out, stride=1, dil=1, alpha=1.0, accumulate=False, 
         lib.conv2d(C.byref(d), _p(x), _p(w), _p(b), _p(out), _p(mask_ref), _p(stream))
 
 
+def planes_kc16(K):
+    """layout rule of the 32x32x16 bank images (mh_planes_kc16): 0 = whole-K, else the K-chunk in 16-channel steps"""
+    k16 = (K + 15) // 16
+    return 0 if (k16 <= 8 or k16 == 13) else 4
+
+
+def _k16_padded(K):
+    k16, kc = (K + 15) // 16, planes_kc16(K)
+    return (k16 + kc - 1) // kc * kc if kc else k16
+
+
 def pack_bytes(w, planes=2, trans=0):
     kh, kw, K, N = w.shape
-    if trans == 2:          # the 32x32x16 register image of conv2d_planes (hi + lo)
-        return kh * kw * ((K + 15) // 16) * ((N + 31) // 32) * 2048
+    if trans == 2:          # the 32x32x16 register image of conv2d_planes (hi + lo, or hi only: plain bf16 forward)
+        return kh * kw * _k16_padded(K) * ((N + 31) // 32) * 1024 * planes
     if trans == 3:          # ... of conv2d_planes_bwd: one plane, reduction over Cout, columns = Cin
-        return kh * kw * ((N + 15) // 16) * ((K + 31) // 32) * 1024
+        return kh * kw * _k16_padded(N) * ((K + 31) // 32) * 1024
     if trans:
         K, N = N, K
     return kh * kw * ((K + 31) // 32) * ((N + 15) // 16) * planes * 1024
@@ -159,11 +170,12 @@ def pack_weights(lib, pairs, device, keep, stream=None):
         if trans in (1, 3):
             K, N = N, K
         assert dst.numel() * dst.element_size() >= pack_bytes(src, planes, trans) and dst.data_ptr() % 16 == 0
-        assert (trans != 2 or planes == 2) and (trans != 3 or planes == 1)
+        assert (trans != 3 or planes == 1)
         arr[i].src, arr[i].dst, arr[i].taps, arr[i].K, arr[i].N = src.data_ptr(), dst.data_ptr(), kh * kw, K, N
         arr[i].planes, arr[i].blk0, arr[i].trans = planes, blk, trans
+        arr[i].kc16 = planes_kc16(K) if trans in (2, 3) else 0
         if trans in (2, 3):
-            blk += (kh * kw * ((K + 15) // 16) * ((N + 31) // 32) * 64 + 255) // 256
+            blk += (kh * kw * _k16_padded(K) * ((N + 31) // 32) * 64 + 255) // 256
         else:
             blk += (kh * kw * ((K + 31) // 32) * ((N + 15) // 16) * 64 + 255) // 256
     table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
@@ -314,21 +326,26 @@ class Planes(object):
     ld = property(lambda self: self.hi.ld)
 
 
-def conv2d_planes_ok(qlib, x, w, dil=1):
-    """does conv2d_planes have an instance for this stride-1 'SAME' 3x3 layer?  (qlib = the real library)"""
+def conv2d_planes_ok(qlib, x, w, dil=1, bf16=False):
+    """does conv2d_planes have an instance for this stride-1 'SAME' 3x3 layer?  (qlib = the real library; bf16: the one-plane form)"""
     kh, kw, cin, cout = w.shape
     if (kh, kw) != (3, 3):
         return False
-    d = conv_desc(x.B, x.H, x.W, x.H, x.W, cin, cout, 3, 3, 1, dil, dil, dil, 0, 0, 0, 0, precision=2)
+    d = conv_desc(x.B, x.H, x.W, x.H, x.W, cin, cout, 3, 3, 1, dil, dil, dil, 0, 0, 0, 0, precision=1 if bf16 else 2)
     return qlib.conv2d_planes_ok(C.byref(d)) == 1
 
 
-def conv2d_planes(lib, xp, w, wb32, b, out=None, out_planes=None, dil=1, alpha=1.0, stream=None):
+def conv2d_planes(lib, xp, w, wb32, b, out=None, out_planes=None, dil=1, alpha=1.0, stream=None, bf16=False):
     """leaky(conv2d_SAME(x, w) + b) in split-bf16 from the input's planes `xp` (Planes); results: `out` (fp32 View or None) and / or
-    `out_planes` (Planes, or a bare Shadow = hi plane only).  wb32: pack_weights(trans = 2) bank of w."""
+    `out_planes` (Planes, or a bare Shadow = hi plane only).  wb32: pack_weights(trans = 2) bank of w.
+    bf16: plain bf16 (one MFMA per product) from the hi plane alone -- xp may be a bare Shadow, wb32 the ONE-plane bank (pack planes = 1)."""
     kh, kw, cin, cout = w.shape
     assert (kh, kw) == (3, 3) and xp.C == cin
-    d = conv_desc(xp.B, xp.H, xp.W, xp.H, xp.W, cin, cout, 3, 3, 1, dil, dil, dil, 0, 0, 0, (out.ld if out is not None else 0), alpha=alpha, precision=2)
+    if bf16:
+        xhi = xp.hi if isinstance(xp, Planes) else xp
+        xp = _HiOnly(xhi)
+    d = conv_desc(xp.B, xp.H, xp.W, xp.H, xp.W, cin, cout, 3, 3, 1, dil, dil, dil, 0, 0, 0, (out.ld if out is not None else 0), alpha=alpha,
+                  precision=1 if bf16 else 2)
     ohi = olo = None
     opld = 0
     if out_planes is not None:
@@ -338,7 +355,22 @@ def conv2d_planes(lib, xp, w, wb32, b, out=None, out_planes=None, dil=1, alpha=1
         ohi, olo, opld = C.c_void_p(hi.ptr), (C.c_void_p(lo.ptr) if lo is not None else None), hi.ld
     if out is not None:
         assert (out.B, out.H, out.W, out.C) == (xp.B, xp.H, xp.W, cout)
-    lib.conv2d_planes(C.byref(d), C.c_void_p(xp.hi.ptr), C.c_void_p(xp.lo.ptr), xp.ld, _p(wb32), _p(b), _p(out), ohi, olo, opld, _p(stream))
+    lib.conv2d_planes(C.byref(d), C.c_void_p(xp.hi.ptr), (C.c_void_p(xp.lo.ptr) if xp.lo is not None else None), xp.ld, _p(wb32), _p(b), _p(out), ohi, olo, opld,
+                      _p(stream))
+
+
+class _HiOnly(object):
+    """a Planes-shaped handle on a bare Shadow (the one-plane forms)"""
+    __slots__ = ("hi", "lo")
+
+    def __init__(self, hi):
+        self.hi, self.lo = hi, None
+
+    B = property(lambda self: self.hi.B)
+    H = property(lambda self: self.hi.H)
+    W = property(lambda self: self.hi.W)
+    C = property(lambda self: self.hi.C)
+    ld = property(lambda self: self.hi.ld)
 
 
 def conv2d_planes_bwd_ok(qlib, dx, w, dil=1):
@@ -350,13 +382,14 @@ def conv2d_planes_bwd_ok(qlib, dx, w, dil=1):
     return qlib.conv2d_planes_bwd_ok(C.byref(d)) == 1
 
 
-def conv2d_planes_bwd(lib, dz_shadow, w, wb32t, dx=None, dx_shadow=None, mask_shadow=None, mask_alpha=1.0, dil=1, stream=None):
+def conv2d_planes_bwd(lib, dz_shadow, w, wb32t, dx=None, dx_shadow=None, mask_shadow=None, mask_alpha=1.0, dil=1, stream=None, mask_range=(0, 0)):
     """dx = conv2d_backprop_input(dz, w) * leaky'(mask) from the bf16 shadow of dz (mh_conv2d_planes_bwd): w HWIO [3,3,Cin,Cout] of the forward layer,
     wb32t = pack_weights(trans = 3) bank; results: dx (fp32 View or None) and / or dx_shadow (Shadow); mask_shadow: Shadow of the layer's input."""
     kh, kw, cin, cout = w.shape
     assert (kh, kw) == (3, 3) and dz_shadow.C == cout
     B, H, W = dz_shadow.B, dz_shadow.H, dz_shadow.W
-    d = conv_desc(B, H, W, H, W, cin, cout, 3, 3, 1, dil, dil, dil, 0, 0, (dx.ld if dx is not None else 0), 0, mask_alpha=mask_alpha, precision=1)
+    d = conv_desc(B, H, W, H, W, cin, cout, 3, 3, 1, dil, dil, dil, 0, 0, (dx.ld if dx is not None else 0), 0, mask_alpha=mask_alpha, precision=1,
+                  mask_c0=mask_range[0], mask_c1=mask_range[1])
     for t in (dx, dx_shadow, mask_shadow):
         assert t is None or (t.B, t.H, t.W, t.C) == (B, H, W, cin)
     sp = lambda sh: C.c_void_p(sh.ptr) if sh is not None else None
@@ -410,6 +443,12 @@ def shadow_cast(lib, pairs, device, keep, stream=None):
 
 
 import os as _os
+import threading
+
+# serialises plan recording: recordings resolve process-wide tuning hooks (filter-gradient split targets) into the plan, and DispNet's recording
+# scopes one of them (RLock: a recording may nest)
+TUNE_LOCK = threading.RLock()
+
 # waves per workgroup of the streaming filter-gradient kernel (0 = the caller's choice: the engines take 4 for a batch-1 step -- the
 # kernel then shares the chip with the input-gradient chain, 1.870 -> 1.818 ms per step -- and 8 for batched streams: 163 -> 138 us per batch)
 WGRAD_STREAM_WAVES = 0            # 0 = the caller's choice (4 waves at batch 1, 8 for batched streams: r03 #4)

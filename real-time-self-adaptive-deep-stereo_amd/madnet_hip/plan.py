@@ -115,7 +115,7 @@ class Recorder(object):
     def conv2d_planes(self, dref, in_hi, in_lo, in_pld, wb32, bias, out, out_hi, out_lo, out_pld, stream):
         d = dref._obj
         self._tally(d, "conv")
-        ints = self._desc_ints(d) + [0, 2, in_pld, out_pld]
+        ints = self._desc_ints(d) + [0, (1 if d.precision == 1 else 2), in_pld, out_pld]
         self._op(_ffi.OP_CONV_PLANES, ints, [d.alpha, d.mask_alpha], [in_hi, in_lo, wb32, bias, out, out_hi, out_lo])
 
     def stamp(self, slot, stream):

@@ -318,6 +318,53 @@ def run_planes():
                  flops / (res[0] * 1e-6) / 2.5e15, best, kn[:64]))
 
 
+def run_dispnet():
+    """DispNet's stride-1 3x3 layers at 384x1280 (Nets/DispNet.py:75-152): the igemm kernels the engine ran in round 3 (bf16 / split-bf16 forward, bf16 input
+    gradient) against mh_conv2d_planes / mh_conv2d_planes_bwd (K-chunked beyond 128 channels)."""
+    DL = [("conv3_1 256->256", 48, 160, 256, 256, 1), ("conv4_1 512->512", 24, 80, 512, 512, 1), ("conv5_1 512->512", 12, 40, 512, 512, 1),
+          ("conv6_1 1024->1024", 6, 20, 1024, 1024, 1), ("iconv5 1025->512", 12, 40, 1025, 512, 1), ("iconv4 769->256", 24, 80, 769, 256, 1),
+          ("iconv3 385->128", 48, 160, 385, 128, 1), ("iconv2 193->64 x3", 96, 320, 193, 64, 2), ("iconv1 97->32 x3", 192, 640, 97, 32, 2)]
+    only = os.environ.get("MB_ONLY")
+    print("%-22s | %9s %9s %7s | %9s %9s %7s |  %s" % ("layer", "fwd igemm", "fwd planes", "TF/s", "dgrad ig.", "dg planes", "TF/s", "kernels"))
+    sh = stream.cuda_stream
+    for name, H, W, Ci, Co, code in DL:
+        if only and only not in name:
+            continue
+        B = 1
+        ld = (Ci + 7) // 8 * 8
+        xb = torch.zeros(B, H, W, ld, device=dev); xb[..., :Ci] = torch.randn(B, H, W, Ci, device=dev); xv = ops.View(xb, B, H, W, Ci, ld)
+        w = torch.randn(3, 3, Ci, Co, device=dev) * 0.03; b = torch.randn(Co, device=dev)
+        y = torch.empty(B, H, W, Co, device=dev); y2 = torch.empty(B, H, W, Co, device=dev)
+        dz = torch.randn(B, H, W, Co, device=dev); dx = torch.zeros(B, H, W, ld, device=dev); dx2 = torch.zeros(B, H, W, ld, device=dev)
+        dxv, dx2v = ops.View(dx, B, H, W, Ci, ld), ops.View(dx2, B, H, W, Ci, ld)
+        keep = []
+        pl = 2 if code == 2 else 1
+        bankf = torch.zeros(ops.pack_bytes(w, pl, 2) // 4, device=dev); bankb = torch.zeros(ops.pack_bytes(w, 1, 3) // 4, device=dev)
+        ops.pack_weights(lib, [(w, bankf, pl, 2), (w, bankb, 1, 3)], dev, keep)
+        xp = ops.Planes(ops.Shadow(B, H, W, Ci, dev), dev); yp = ops.Shadow(B, H, W, Co, dev)
+        ops.plane_split(lib, [(xv, xp)], dev, keep)
+        dzs = ops.Shadow(B, H, W, Co, dev); ops.shadow_cast(lib, [(ops.view(dz), dzs)], dev, keep)
+        flops = 2.0 * B * H * W * 9 * Ci * Co
+        with torch.cuda.stream(stream):
+            ops.PRECISION = code
+            t0 = _time_ms(lib, stream, lambda: ops.conv2d_fwd(lib, xv, w, b, ops.view(y), alpha=0.1, stream=sh), 10) * 1e3
+            k0 = lib.last_kernel().decode()
+            ops.PRECISION = 0
+            t1 = _time_ms(lib, stream, lambda: ops.conv2d_planes(lib, xp, w, bankf, b, out=ops.view(y2), out_planes=yp, alpha=0.1, stream=sh, bf16=(pl == 1)), 10) * 1e3
+            k1 = lib.last_kernel().decode()
+            ops.PRECISION_BWD = 1; ops.PRECISION = 1
+            t2 = _time_ms(lib, stream, lambda: ops.conv2d_dgrad(lib, ops.view(dz), w, dxv, mask_ref=xv, mask_alpha=0.1, stream=sh), 10) * 1e3
+            ops.PRECISION_BWD = None; ops.PRECISION = 0
+            t3 = _time_ms(lib, stream, lambda: ops.conv2d_planes_bwd(lib, dzs, w, bankb, dx=dx2v, mask_shadow=xp.hi, mask_alpha=0.1, stream=sh), 10) * 1e3
+            k3 = lib.last_kernel().decode()
+        torch.cuda.synchronize()
+        e_f = (y - y2).abs().max().item() / max(1.0, y.abs().max().item()); e_b = (dx - dx2).abs().max().item() / max(1.0, dx.abs().max().item())
+        print("%-22s | %9.1f %9.1f %7.0f | %9.1f %9.1f %7.0f |  fwd %s | bwd %s | rel diff fwd %.2g bwd %.2g | was %s"
+              % (name, t0, t1, flops / (t1 * 1e-6) / 1e12, t2, t3, flops / (t3 * 1e-6) / 1e12, k1[22:100], k3[22:100], e_f, e_b, k0[:60]))
+
+
+if what == "dispnet":
+    run_dispnet()
 if what == "planes":
     run_planes()
 if what == "wgradp":

@@ -140,8 +140,9 @@ def test_conv2d_planes_argument_checks(backend):
     assert rc == -1
     rc = lib._raw_mh_conv2d_planes(C.byref(d), xp.hi.ptr + 2, xp.lo.ptr, xp.ld, bank.data_ptr(), None, y.data_ptr(), None, None, 0, None)
     assert rc == -2
-    assert not ops.conv2d_planes_ok(lib, ops.view(torch.zeros(1, 4, 8, 200, device=dev)), torch.zeros(3, 3, 200, 32), 1)      # K > 128
-    assert not ops.conv2d_planes_ok(lib, ops.view(x), torch.zeros(3, 3, 64, 160), 1)                                            # N > 128
+    assert not ops.conv2d_planes_ok(lib, ops.view(torch.zeros(1, 4, 8, 200, device=dev)), torch.zeros(3, 3, 200, 32), 1)      # K16 = 13 has 64 columns only
+    assert not ops.conv2d_planes_ok(lib, ops.view(x), torch.zeros(3, 3, 64, 20), 1)                                             # N not a multiple of 8
+    assert ops.conv2d_planes_ok(lib, ops.view(x), torch.zeros(3, 3, 64, 160), 1)                                                # two 128-column tiles
 
 
 # (B, H, W, Cin, Cout, dil, variant): the input gradients of the layers above (reduction over Cout, columns = Cin)
@@ -196,3 +197,110 @@ def test_conv2d_planes_bwd_vs_oracle_and_bf16_input_gradient(backend, case):
         ops.conv2d_dgrad(lib, ops.view(dz), w, ops.view(dx0), dil=dil, mask_ref=ops.view(x), mask_alpha=0.2)
     backend.sync()
     assert (dxc - dx0.cpu()).abs().max().item() <= 2e-5 * scale
+
+
+# ---- DispNet's layers (Nets/DispNet.py:75-152): K-chunked reductions (> 128 channels), one-plane (plain bf16) forward, wide gradients ----------------
+# (B, H, W, Cin, Cout): forward, plain bf16 from the hi plane and the one-plane chunk-major bank
+CK_FWD_CASES = [(1, 6, 33, 256, 256), (1, 5, 20, 385, 128), (1, 3, 35, 512, 256), (2, 4, 9, 1025, 128), (1, 7, 40, 136, 64)]
+
+
+@pytest.mark.parametrize("case", CK_FWD_CASES)
+def test_conv2d_planes_chunked_bf16_forward(backend, case):
+    """mh_conv2d_planes(precision 1) on reductions over more than 128 channels: conv_planes_ck_kernel (a loader wave streams 64-channel patch chunks
+    through three LDS buffers).  Against the fp64 oracle on bf16-rounded operands (only the fp32 summation order differs); hi-plane output ==
+    bf16(out) bit for bit."""
+    B, H, W, Ci, Co = case
+    lib, dev = backend.lib, backend.device
+    x = _rand((B, H, W, Ci), 511, dev)
+    w = _rand((3, 3, Ci, Co), 512, dev, 0.05)
+    bias = _rand((Co,), 513, dev, 0.1)
+    keep = []
+    ref = T.conv2d(x.cpu().to(torch.bfloat16).double(), w.cpu().to(torch.bfloat16).double(), bias.cpu().double(), stride=1, dilation=1, alpha=0.1).float()
+    assert ops.planes_kc16(Ci) == 4 == lib.planes_kc16(Ci)
+    assert ops.conv2d_planes_ok(lib, ops.view(x), w, 1, bf16=True)
+    xs = ops.Shadow(B, H, W, Ci, dev)
+    ops.shadow_cast(lib, [(ops.view(x), xs)], dev, keep)
+    bank = torch.full((ops.pack_bytes(w, 1, 2) // 4,), float("nan"), device=dev)
+    ops.pack_weights(lib, [(w, bank, 1, 2)], dev, keep)
+    out = torch.full((B, H, W, Co), float("nan"), device=dev)
+    os_ = ops.Shadow(B, H, W, Co, dev)
+    lib.tune_conv_planes(0)
+    ops.conv2d_planes(lib, xs, w, bank, bias, out=ops.view(out), out_planes=os_, alpha=0.1, bf16=True)
+    name = lib.last_kernel().decode()
+    backend.sync()
+    assert lib.tune_conv_planes(0) == 1
+    assert "conv_planes_ck_kernel" in name and ",bf16," in name, name
+    oc = out.cpu()
+    scale = max(1.0, ref.abs().max().item())
+    assert torch.isfinite(oc).all() and (oc - ref).abs().max().item() <= 3e-5 * scale, ((oc - ref).abs().max().item(), name)
+    assert torch.equal(os_.t.cpu()[..., :Co], oc.to(torch.bfloat16))
+
+
+# (B, H, W, Cin, Cout, mask range or None): input gradients -- reduction over Cout (chunked beyond 128), Cin columns in 128-column tiles, rows of
+# Cin rounded up to 8 floats; the leaky mask of ONE member of a concat (DispNet's up-sampling blocks: [skip | deconv | up_predict])
+CK_BWD_CASES = [(1, 6, 33, 256, 256, None), (1, 5, 20, 385, 128, (256, 384)), (1, 3, 17, 1025, 512, (512, 1024)), (1, 7, 36, 193, 64, (0, 128)),
+                (1, 9, 40, 97, 32, (64, 96)), (2, 4, 9, 512, 512, None)]
+
+
+@pytest.mark.parametrize("case", CK_BWD_CASES)
+def test_conv2d_planes_bwd_wide_and_chunked(backend, case):
+    B, H, W, Ci, Co, mrange = case
+    lib, dev = backend.lib, backend.device
+    dz = _rand((B, H, W, Co), 611, dev)
+    w = _rand((3, 3, Ci, Co), 612, dev, 0.05)
+    x = _rand((B, H, W, Ci), 613, dev)
+    keep = []
+    wq = w.cpu().to(torch.bfloat16).double()
+    dzq = dz.cpu().to(torch.bfloat16).double()
+    xin = torch.zeros(B, H, W, Ci, dtype=torch.float64, requires_grad=True)
+    y = T.conv2d(xin, wq, None, stride=1, dilation=1, alpha=1.0)
+    (g_ref,) = torch.autograd.grad(y, xin, dzq)
+    mk = torch.where(x.cpu().double() > 0, 1.0, 0.1)
+    if mrange is not None:
+        keepc = torch.ones(Ci, dtype=torch.bool); keepc[mrange[0]:mrange[1]] = False
+        mk[..., keepc] = 1.0
+    g_ref = (g_ref * mk).float()
+    assert ops.conv2d_planes_bwd_ok(lib, ops.view(x), w, 1)
+    dzs = ops.Shadow(B, H, W, Co, dev); xs = ops.Shadow(B, H, W, Ci, dev)
+    ops.shadow_cast(lib, [(ops.view(dz), dzs), (ops.view(x), xs)], dev, keep)
+    bank = torch.full((ops.pack_bytes(w, 1, 3) // 4,), float("nan"), device=dev)
+    ops.pack_weights(lib, [(w, bank, 1, 3)], dev, keep)
+    ld = (Ci + 7) // 8 * 8
+    dxb = torch.full((B, H, W, ld), float("nan"), device=dev)
+    dx = ops.View(dxb, B, H, W, Ci, ld)
+    lib.tune_conv_planes(0)
+    ops.conv2d_planes_bwd(lib, dzs, w, bank, dx=dx, mask_shadow=xs, mask_alpha=0.1, mask_range=(mrange or (0, 0)))
+    name = lib.last_kernel().decode()
+    backend.sync()
+    assert lib.tune_conv_planes(0) == 1
+    assert ("conv_planes_ck_kernel" in name) == (Co > 128), name
+    dxc = dxb.cpu()[..., :Ci]
+    scale = max(1.0, g_ref.abs().max().item())
+    assert torch.isfinite(dxc).all() and (dxc - g_ref).abs().max().item() <= 3e-5 * scale, ((dxc - g_ref).abs().max().item(), name)
+    assert not dxb.cpu()[..., Ci:].abs().sum()                     # the row padding is written as zeros
+
+
+@pytest.mark.parametrize("case", [(1, 6, 40, 193, 64), (1, 9, 37, 97, 32)])
+def test_conv2d_planes_split_bf16_dispnet_iconv_shapes(backend, case):
+    """the whole-K split-bf16 instances of DispNet's two finest iconv layers (193 -> 64: K16 13, 97 -> 32: K16 7) at the 2^-16 level"""
+    B, H, W, Ci, Co = case
+    lib, dev = backend.lib, backend.device
+    x = _rand((B, H, W, Ci), 711, dev)
+    w = _rand((3, 3, Ci, Co), 712, dev, 0.05)
+    bias = _rand((Co,), 713, dev, 0.1)
+    keep = []
+    ref = T.conv2d(x.cpu().double(), w.cpu().double(), bias.cpu().double(), stride=1, dilation=1, alpha=1.0).float()
+    assert ops.planes_kc16(Ci) == 0 == lib.planes_kc16(Ci)
+    assert ops.conv2d_planes_ok(lib, ops.view(x), w, 1)
+    xp = _planes_of(lib, x, dev, keep)
+    bank = torch.full((ops.pack_bytes(w, 2, 2) // 4,), float("nan"), device=dev)
+    ops.pack_weights(lib, [(w, bank, 2, 2)], dev, keep)
+    out = torch.full((B, H, W, Co), float("nan"), device=dev)
+    ops.conv2d_planes(lib, xp, w, bank, bias, out=ops.view(out), alpha=1.0)
+    name = lib.last_kernel().decode()
+    backend.sync()
+    lib.tune_conv_planes(0)
+    oc = out.cpu()
+    scale = max(1.0, ref.abs().max().item())
+    assert "conv_planes_kernel" in name and "bf16x3" in name, name
+    assert torch.isfinite(oc).all() and (oc - ref).abs().max().item() <= 6e-5 * scale, ((oc - ref).abs().max().item(), name)

@@ -131,6 +131,47 @@ def test_dispnet_bf16_patch_kernel_vs_gather_kernel_emulated():
 
 
 @pytest.mark.slow
+@pytest.mark.parametrize("precision", ["mixed", "bf16"])
+def test_dispnet_plane_kernels_vs_igemm_path_emulated(precision):
+    """Round 4: DispNet's stride-1 3x3 layers on mh_conv2d_planes / mh_conv2d_planes_bwd (K-chunked beyond 128 channels; forward plain bf16 or
+    split-bf16 per the precision map, input gradients plain bf16 with the mask of ONE concat member) against the same engine with the path off: the same
+    products, another summation order -- disparity and gradients must agree at the fp32 round-off level of the layers involved."""
+    from conftest import _emul_backend
+    backend = _emul_backend()
+    H, W = 40, 64
+    wn = S.calibrated_weights(OD.variable_shapes(), 1)
+    l, r, gt = S.make_pair(H, W)
+    out = {}
+    old = DE.PLANES_MIN_PIX
+    try:
+        for on in (False, True):
+            DE.PLANES_MIN_PIX = 1 if on else 1 << 30
+            backend.lib.tune_conv_planes(0)
+            eng = DE.DispNetEngine(backend.lib, H, W, B=1, device="cpu", weights=wn, precision=precision)
+            eng.set_inputs(l, r, gt[..., 0])
+            plan = eng.build_plan("FULL", lr=1e-4)
+            plan.run(backend.lib, 0)
+            out[on] = (eng.pred.clone(), eng.params.g.clone(), backend.lib.tune_conv_planes(0), float(eng.res_loss[0]))
+    finally:
+        DE.PLANES_MIN_PIX = old
+    (p0, g0, n0, l0), (p1, g1, n1, l1) = out[False], out[True]
+    # conv3/1 .. conv6/1 and iconv5 .. iconv1: forward (9; 'bf16': 7 -- the whole-K instances of iconv2 / iconv1 are split-bf16 only) + input gradients (9)
+    assert n0 == 0 and n1 >= (18 if precision == "mixed" else 16), (n0, n1)
+    # yardstick = the fp32 engine (at this size the igemm path runs several of these layers in exact fp32 -- its small-layer kernels -- so the two
+    # paths differ by bf16 rounding of those layers, not only by summation order)
+    e32 = DE.DispNetEngine(backend.lib, H, W, B=1, device="cpu", weights=wn, precision="fp32")
+    e32.set_inputs(l, r, gt[..., 0])
+    e32.build_plan("FULL", lr=1e-4).run(backend.lib, 0)
+    p32, g32 = e32.pred, e32.params.g
+    dev0, dev1 = (p0 - p32).abs().mean().item(), (p1 - p32).abs().mean().item()
+    gd0, gd1 = (g0 - g32).norm().item() / g32.norm().item(), (g1 - g32).norm().item() / g32.norm().item()
+    print("DispNet %s plane kernels (emulated): disparity dev vs fp32 igemm path %.3g planes %.3g; gradient dev %.3g / %.3g; mutual %.3g / %.3g; launches %d"
+          % (precision, dev0, dev1, gd0, gd1, (p1 - p0).abs().mean().item(), (g1 - g0).norm().item() / g32.norm().item(), n1))
+    assert dev1 <= 1.5 * dev0 + (1e-4 if precision == "mixed" else 1e-3)
+    assert gd1 <= 1.5 * gd0 + 1e-3 and abs(l1 - l0) <= 1e-3 * max(1.0, abs(l0))
+
+
+@pytest.mark.slow
 def test_dispnet_full_step_emulated():
     from conftest import _emul_backend
     _run(_emul_backend(), 40, 64, "FULL")        # pads to 64x64

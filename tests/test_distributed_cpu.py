@@ -91,6 +91,71 @@ def test_shared_model_allreduce_world2(early):
     assert np.allclose(res[0][3], w_ref.numpy(), rtol=1e-5, atol=1e-7)
 
 
+def _mad_worker(rank, world, port, q):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["MH_EMUL_THREADS"] = "4"
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import json
+        from madnet_hip import _ffi, engine as E, synthetic as S
+        from madnet_hip.adapter import Adapter
+        import Nets
+        lib = _ffi.Lib(os.path.join(ROOT, "tests", "emul", "libmadnet_emul.so"))
+        lib.ensure_init()
+        wn = S.calibrated_weights(dict(E.madnet_manifest()), 1)
+        l, r, gt = S.make_pair(H, W, stream_id=rank)
+        net = Nets.get_stereo_net("MADNet", {"left_img": torch.from_numpy(l), "right_img": torch.from_numpy(r), "split_layers": [None],
+                                              "sequence": True, "train_portion": "BEGIN", "bulkhead": True, "weights": wn,
+                                              "_lib": lib, "_device": "cpu"})
+        cfg = json.load(open(os.path.join(PKG, "block_config", "MadNet_full.json")))
+        # SEQUENTIAL sampling: every rank trains the same block on the same step without exchanging the draw
+        ad = Adapter(net, mode="MAD", lr=1e-2, shared_model=True, use_graph=False, block_config=cfg, sample_mode="SEQUENTIAL", num_blocks=1)
+        seen = []
+        for _ in range(2):
+            out = ad.step(l, r, gt[..., 0])
+            seen.append((tuple(out["blocks"]), ad.collectives_last_step))
+        w_after = net.engine.params.w.clone()
+        ws = [torch.zeros_like(w_after) for _ in range(world)]
+        dist.all_gather(ws, w_after)
+        P = net.engine.params
+        rng = P.ranges(ad._train_vars(tuple(ad.blocks_to_train)))
+        q.put((rank, seen, bool(torch.equal(ws[0], ws[1])), out["loss"], rng, P.g.clone().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_shared_model_mad_block_is_one_collective_world2():
+    """a MAD block is two ranges of the flat layout + the loss tail -- they must travel as ONE all-reduce, and the ranks must hold
+    identical weights and the SUMMED block gradient afterwards."""
+    from conftest import _emul_backend
+    backend = _emul_backend()
+    import socket
+    import numpy as np
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1], "ranks trained different blocks"
+    assert all(c == 1 for _, c in res[0][1]), "a MAD shared step must be ONE collective: %r" % (res[0][1],)
+    assert len(res[0][4]) == 2, "a MAD block is two ranges of the flat layout"
+    assert res[0][2] and res[1][2], "ranks diverged after the shared MAD update"
+    assert abs(res[0][3] - res[1][3]) < 1e-9
+    for o, c in res[0][4]:          # the reduced block gradient is the same buffer content on both ranks
+        assert np.array_equal(res[0][5][o:o + c], res[1][5][o:o + c]) and np.abs(res[0][5][o:o + c]).max() > 0
+
+
 def test_stream_sharding_is_disjoint():
     """stream i -> rank i mod G: bench.py / Adapter use make_pair(stream_id=rank)."""
     from madnet_hip import synthetic as S
