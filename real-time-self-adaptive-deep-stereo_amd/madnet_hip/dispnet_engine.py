@@ -18,7 +18,7 @@ import os
 import torch
 
 from . import ops
-from .engine import Params, _r4
+from .engine import Params, _r4, _merge_ranges
 from .plan import Recorder
 
 MAX_DISP = 40
@@ -29,6 +29,13 @@ ALPHA = 0.1     # default leaky slope of sharedLayers.conv2d / conv2d_transpose 
 # pass.  The coarser layers (conv5_1, conv6_1, iconv5: <= 480 pixels, 9 - 19 MB of weights for 16 - 60 workgroups) stay on the split-K igemm kernels
 # (scripts/microbench.py dispnet: 25 vs 41 us, 41 vs 73 us).  MH_CONV_PLANES=0 turns the path off.
 USE_PLANES = os.environ.get("MH_CONV_PLANES", "1") != "0"
+# FULL momentum steps: every filter-gradient batch is followed, on its own side lane, by the momentum update of the layers it completes; the launch behind
+# the join covers what is left (the towers' shared conv1 / conv2).  DispNet has 42 M parameters: one update over all of them is 840 MB of traffic, 144 us
+# at the very end of the step (round-3 timeline) -- spread over the batches it runs beside the input-gradient chain.  MH_EARLY_UPDATE=0 turns it off.
+EARLY_UPDATE = os.environ.get("MH_EARLY_UPDATE", "1") != "0"
+# filter gradients leave for a side lane in batches of FLUSH_MIN layers, the batches alternating over SIDE_LANES lanes
+FLUSH_MIN = int(os.environ.get("MH_DN_FLUSH_MIN", "3"))
+SIDE_LANES = int(os.environ.get("MH_DN_LANES", "1"))      # (r04 sweep at 375x1242: 1 lane 3.21 ms, 2 lanes 3.39, 3 lanes 3.48 -- every extra stream of the captured graph costs)
 PLANES_MIN_PIX = 1920
 
 
@@ -338,10 +345,12 @@ class DispNetEngine(object):
                 last_masks.append(m)
         return acc, last_masks
 
-    def record_backward(self, r, heads=()):
+    def record_backward(self, r, heads=(), early_update=None):
         """heads (offline training): [(prediction node, d loss / d make_disp(node))] -- every _make_disp output carries its own
         loss term (Train.py:100); each is one more consumer of its node and is injected before the op list is walked."""
+        """early_update = (lr, momentum, grad_scale): see EARLY_UPDATE; returns the sorted disjoint [first, end) parameter ranges updated here"""
         lib, B, P = r, self.B, self.params
+        upd_fresh, upd_done = [], []
         ops_fill(lib, P.g, 0, P.total)
         for n in self.nodes.values():
             n.remaining, n.written = n.consumers, False
@@ -362,13 +371,20 @@ class DispNetEngine(object):
                 uses[op[2]] = uses.get(op[2], 0) + 1
         shared_dw = set(self.W_(wn, "g").data_ptr() for wn, c in uses.items() if c > 1)
 
-        def wgrad(xv, dzv, dw, db, stride):
+        def wgrad(xv, dzv, dw, db, stride, db_t=None):
             pending.append((xv, dzv, dw, db, stride))
+            if early_update is not None and dw.data_ptr() not in shared_dw:
+                for t in (dw, db if db is not None else db_t):
+                    if t is None:
+                        continue
+                    a = (t.data_ptr() - P.g.data_ptr()) // 4
+                    assert 0 <= a and a + t.numel() <= P.total
+                    upd_fresh.append((a, min((a + t.numel() + 3) & ~3, P.total)))      # (+ the tensor's alignment padding: zero gradient, zero momentum)
 
         def flush(force=False):
-            if not pending or (len(pending) < 3 and not force):
+            if not pending or (len(pending) < FLUSH_MIN and not force):
                 return
-            lib.lane = 1 + nflush[0] % 2
+            lib.lane = 1 + nflush[0] % SIDE_LANES
             nflush[0] += 1
             try:
                 batch = []
@@ -390,9 +406,15 @@ class DispNetEngine(object):
                     ops.conv2d_wgrad_partial(lib, self.lib, self.wsa, (segs2 if dup else segs) if shared else batch, xv, dzv, dw, db,
                                              stride=stride, direct_ok=not shared)
                 ops.wgrad_reduce(lib, batch, self.dev, r.keep)
+                if early_update is not None:
+                    lr_, mom_, gs_ = early_update
+                    for a, b in _merge_ranges(upd_fresh):
+                        ops.momentum(lib, P.w[a:b], P.m[a:b], P.g[a:b], lr_, mom_, gs_)
+                        upd_done.append((a, b))
             finally:
                 lib.lane = 0
                 del pending[:]
+                del upd_fresh[:]
 
         def conv_like_dgrad(emit, xnode):
             """emit(dx_view, accumulate, mask_ref, mask_alpha, mask_range); handles the leaky-mask fusion."""
@@ -447,8 +469,8 @@ class DispNetEngine(object):
                 dz = out.gview()
                 # y = conv2d_transpose(x, w[kh,kw,Cout,Cin]) is the input-gradient of the SAME conv F with HWIO = w:
                 # dw = filter-gradient of F with (input = dz, output-gradient = x); db = sum(dz); dx = F(dz)
-                wgrad(dz, x.view(), self.W_(wn, "g"), None, 2)
                 ops.bias_grad(lib, dz, self.b_(wn, "g"))
+                wgrad(dz, x.view(), self.W_(wn, "g"), None, 2, db_t=self.b_(wn, "g"))
                 w = self.W_(wn)
                 conv_like_dgrad(lambda dx, acc, ref, ma, rng: ops.conv2d_fwd(lib, dz, w, None, dx, stride=2, alpha=1.0, accumulate=acc,
                                                                               mask_ref=ref, mask_alpha=ma, mask_range=rng), x)
@@ -466,6 +488,7 @@ class DispNetEngine(object):
         r.join_next = True
         ops.wgrad_reduce(lib, segs, self.dev, r.keep)
         ops.wgrad_reduce(lib, segs2, self.dev, r.keep, accumulate=True)
+        return _merge_ranges(upd_done)
 
     def _shadow(self, v, casts):
         """the bf16 shadow of View v (allocated on first use) + its cast queued for this batch"""
@@ -477,9 +500,14 @@ class DispNetEngine(object):
             casts.append((v, sh))
         return sh
 
-    def record_update(self, r, lr, momentum=0.9, grad_scale=1.0):
+    def record_update(self, r, lr, momentum=0.9, grad_scale=1.0, done=()):
+        """MomentumOptimizer apply on every parameter; done: sorted disjoint [first, end) ranges record_backward(early_update=...) has updated already"""
         P = self.params
-        ops.momentum(r, P.w, P.m, P.g, lr, momentum, grad_scale, n=P.total)
+        a = 0
+        for d0, d1 in list(done) + [(P.total, P.total)]:
+            if d0 > a:
+                ops.momentum(r, P.w[a:d0], P.m[a:d0], P.g[a:d0], lr, momentum, grad_scale, n=d0 - a)
+            a = max(a, d1)
 
     def all_vars(self):
         return [n for n, _ in self.params.manifest]
@@ -549,8 +577,12 @@ class DispNetEngine(object):
         if do_grad:
             self.record_forward(r, backward=(mode == "FULL"))
             self.record_loss_metrics(r, with_grad=(mode == "FULL"))
+            done = ()
             if mode == "FULL":
-                self.record_backward(r)
+                eu = (lr, momentum, grad_scale) if (EARLY_UPDATE and do_upd and part == "all" and optimizer == "momentum") else None
+                done = self.record_backward(r, early_update=eu) or ()
+        else:
+            done = ()
         if mode == "FULL" and do_upd:
             if optimizer == "adam":                       # the live demo's FULL mode (Demo/demo_model.py:148-149,164)
                 self._ensure_train_buffers()
@@ -558,7 +590,7 @@ class DispNetEngine(object):
                 ops.adam(r, P.w, P.m, P.v, P.g, self.adam_state, lr, grad_scale=grad_scale, n=P.total)
                 ops.adam_advance(r, self.adam_state)
             else:
-                self.record_update(r, lr, momentum=momentum, grad_scale=grad_scale)
+                self.record_update(r, lr, momentum=momentum, grad_scale=grad_scale, done=done)
         return r.compile()
 
     def set_inputs(self, left, right, gt=None):

@@ -172,6 +172,39 @@ def test_dispnet_plane_kernels_vs_igemm_path_emulated(precision):
 
 
 @pytest.mark.slow
+def test_dispnet_early_update_equals_one_update_emulated():
+    """dispnet_engine.EARLY_UPDATE: the momentum update issued per filter-gradient batch (side lanes) + the rest behind the join == ONE update over all
+    parameters -- same gradients, same element-wise arithmetic: weights and momentum must agree to the atomics noise of the gradients."""
+    from conftest import _emul_backend
+    backend = _emul_backend()
+    H, W = 40, 64
+    wn = S.calibrated_weights(OD.variable_shapes(), 1)
+    l, r, gt = S.make_pair(H, W)
+    res = {}
+    old = DE.EARLY_UPDATE
+    try:
+        for on in (False, True):
+            DE.EARLY_UPDATE = on
+            eng = DE.DispNetEngine(backend.lib, H, W, B=1, device="cpu", weights=wn, precision="mixed")
+            eng.set_inputs(l, r, gt[..., 0])
+            plan = eng.build_plan("FULL", lr=1e-3, momentum=0.8)
+            n_mom = sum(1 for i in range(plan.n) if plan.arr[i].kind == _ffi_kind("OP_MOMENTUM"))
+            plan.run(backend.lib, 0)
+            res[on] = (eng.params.w.clone(), eng.params.m.clone(), n_mom)
+    finally:
+        DE.EARLY_UPDATE = old
+    assert res[False][2] == 1 and res[True][2] > 3, (res[False][2], res[True][2])
+    # (identical up to the atomics noise of the bias gradients, ~4e-9 between two runs of the SAME plan)
+    assert (res[False][0] - res[True][0]).abs().max().item() <= 1e-9 and (res[False][1] - res[True][1]).abs().max().item() <= 1e-7
+    assert (res[True][1] != 0).float().mean().item() > 0.5
+
+
+def _ffi_kind(name):
+    from madnet_hip import _ffi
+    return getattr(_ffi, name)
+
+
+@pytest.mark.slow
 def test_dispnet_full_step_emulated():
     from conftest import _emul_backend
     _run(_emul_backend(), 40, 64, "FULL")        # pads to 64x64
