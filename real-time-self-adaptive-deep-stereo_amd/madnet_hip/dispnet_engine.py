@@ -34,7 +34,7 @@ USE_PLANES = os.environ.get("MH_CONV_PLANES", "1") != "0"
 # at the very end of the step (round-3 timeline) -- spread over the batches it runs beside the input-gradient chain.  MH_EARLY_UPDATE=0 turns it off.
 EARLY_UPDATE = os.environ.get("MH_EARLY_UPDATE", "1") != "0"
 # filter gradients leave for a side lane in batches of FLUSH_MIN layers, the batches alternating over SIDE_LANES lanes
-FLUSH_MIN = int(os.environ.get("MH_DN_FLUSH_MIN", "3"))
+FLUSH_MIN = int(os.environ.get("MH_DN_FLUSH_MIN", "2"))       # (one lane: 2 -> 3.15 ms, 3 -> 3.23, 4 -> 3.16, 6 -> 3.20, 12 -> 3.33)
 SIDE_LANES = int(os.environ.get("MH_DN_LANES", "1"))      # (r04 sweep at 375x1242: 1 lane 3.21 ms, 2 lanes 3.39, 3 lanes 3.48 -- every extra stream of the captured graph costs)
 PLANES_MIN_PIX = 1920
 
