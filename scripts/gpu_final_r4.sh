@@ -4,7 +4,7 @@
 # the summaries (the merge back is limited to 64 MiB).   SKIP_TESTS=1 / SKIP_PMC=1 / SKIP_VARIANTS=1 shorten it.
 TAG=${1:-r4final}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; WORK=/tmp/r4work; mkdir -p $WORK
 R=$GRAFT_REPO_ROOT
-if [ "$SKIP_TESTS" != "1" ]; then timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 | tee $OUT/pytest_gpu.txt; fi
+if [ "$SKIP_TESTS" != "1" ]; then timeout 1800 python -m pytest tests -m gpu -q 2>&1 | tail -4 | tee $OUT/pytest_gpu.txt; fi
 timeout 900 python bench.py --stamps 20 2>$OUT/bench.err | tail -1 > $OUT/bench_default_stamps.json
 timeout 900 python bench.py 2>>$OUT/bench.err | tail -1 > $OUT/bench_default.json
 if [ "$SKIP_VARIANTS" != "1" ]; then

@@ -817,18 +817,21 @@ def test_step_with_bf16_only_gradient_maps(bname, size):
     H, W = size
     wn = S.calibrated_weights(OM.variable_shapes(), 1)
     l, r, gt = S.make_pair(H, W)
-    saved = E.SHADOW_ONLY
+    saved = E.SHADOW_ONLY, E.PLANES_ONLY
     if bname == "emul":
         backend.lib.tune_conv_patch(128)            # at 60x100 the heuristic would keep the patch kernel out
     out = {}
     try:
         for only in (True, False):
-            E.SHADOW_ONLY = only
+            E.SHADOW_ONLY = E.PLANES_ONLY = only          # (PLANES_ONLY: the same elision for the layers on the plane kernels)
             eng = E.MadNetEngine(backend.lib, H, W, B=1, device=backend.device, weights=wn, precision="mixed")
             eng.set_inputs(l, r, gt[..., 0])
             plan = eng.build_plan("FULL", lr=1e-4, update=False)
-            n_only = sum(1 for k in range(plan.n) if plan.arr[k].kind == 1 and plan.arr[k].i[23] & 4)
-            n_mask = sum(1 for k in range(plan.n) if plan.arr[k].kind == 1 and plan.arr[k].i[23] & 2)
+            # (input gradients on mh_conv2d_planes_bwd, round 4: p = dz_hi, bank, mask_hi, dx, dx_hi -- fp32 elided = no dx, mask = a shadow's sign)
+            from madnet_hip import _ffi
+            pb = [plan.arr[k] for k in range(plan.n) if plan.arr[k].kind == _ffi.OP_CONV_PLANES_BWD]
+            n_only = sum(1 for k in range(plan.n) if plan.arr[k].kind == 1 and plan.arr[k].i[23] & 4) + sum(1 for o in pb if not o.p[3])
+            n_mask = sum(1 for k in range(plan.n) if plan.arr[k].kind == 1 and plan.arr[k].i[23] & 2) + sum(1 for o in pb if o.p[2])
             for k in E.LEVELS:
                 for t in eng.dE[k]:
                     t.fill_(float("nan"))
@@ -838,7 +841,7 @@ def test_step_with_bf16_only_gradient_maps(bname, size):
             backend.sync()
             out[only] = (eng.params.g.clone(), n_only, n_mask)
     finally:
-        E.SHADOW_ONLY = saved
+        E.SHADOW_ONLY, E.PLANES_ONLY = saved
         if bname == "emul":
             backend.lib.tune_conv_patch(-1)
     (g1, n1, m1), (g0, n0, m0) = out[True], out[False]
