@@ -445,6 +445,17 @@ int mh_fill(float* p, int64_t n, float v, void* stream);
  * (MH_OP_STAMP) it times the REPLAYED graph from the inside: start of the side lane, end of the input-gradient chain, end of the step */
 int mh_stamp(void* slot, void* stream);
 int64_t mh_stamp_rate_khz(void);
+/* ---- deterministic test mode (MH_DETERMINISTIC=1 in the Python engines).  The step's only order-dependent arithmetic is its float
+ * atomics (bias gradients, the warp-gradient scatter, the sampler's image gradient, un-split filter gradients).  After
+ * mh_deterministic_add(base, n, twin) every such atomic whose destination lies in [base, base + n) accumulates value * 2^48 into the 64-bit
+ * integer twin[dst - base] instead (integer atomics are associative: any arrival order, any replay, the same bits); mh_det_flush adds the
+ * twin into the float buffer and clears it -- the engines record it (MH_OP_DET_FLUSH) behind the warp-gradient scatter of every level and
+ * in front of the optimizer.  twin: n int64, zero-initialised, owned by the caller.  At most 8 ranges per process; add / remove synchronise the
+ * device (not inside a capture).  |sums| must stay below 2^15; resolution 2^-48. */
+int mh_deterministic_add(float* base, int64_t n, void* twin);
+int mh_deterministic_remove(float* base);
+int mh_deterministic_ranges(void);
+int mh_det_flush(float* dst, void* twin, int64_t n, void* stream);
 /* db[c] += sum_p dz[p][c]  (BiasAddGrad of conv2d_transpose, whose filter gradient runs with swapped operands) */
 int mh_bias_grad(const float* dz, int32_t dz_ld, int64_t npix, int32_t nch, float* db, void* stream);
 
@@ -460,7 +471,7 @@ enum { MH_OP_CONV = 1, MH_OP_WGRAD, MH_OP_CORR_FWD, MH_OP_CORR_BWD, MH_OP_WARP_F
        MH_OP_RESIZE_FWD, MH_OP_RESIZE_BWD, MH_OP_PAD_REFLECT, MH_OP_LOSS, MH_OP_METRICS,
        MH_OP_MOMENTUM, MH_OP_COPY_CH, MH_OP_LEAKY_BWD, MH_OP_FILL, MH_OP_BIAS_GRAD,
        MH_OP_WGRAD_PARTIAL, MH_OP_WGRAD_REDUCE, MH_OP_PROXY_LOSS, MH_OP_SUPERVISED_LOSS, MH_OP_ADAM, MH_OP_ADAM_ADVANCE,
-       MH_OP_RESIZE_IMAGE, MH_OP_LEVEL_FRONT, MH_OP_RESERVED_25 /* (was: transposed filter banks of the retired LDS-free kernel) */, MH_OP_PACK_W, MH_OP_CORR_WARP_BWD, MH_OP_SHADOW_CAST, MH_OP_WGRAD_STREAM, MH_OP_HEAD_BWD, MH_OP_HEAD_FWD, MH_OP_CONV_PLANES, MH_OP_PLANE_SPLIT, MH_OP_STAMP, MH_OP_CONV_PLANES_BWD };
+       MH_OP_RESIZE_IMAGE, MH_OP_LEVEL_FRONT, MH_OP_RESERVED_25 /* (was: transposed filter banks of the retired LDS-free kernel) */, MH_OP_PACK_W, MH_OP_CORR_WARP_BWD, MH_OP_SHADOW_CAST, MH_OP_WGRAD_STREAM, MH_OP_HEAD_BWD, MH_OP_HEAD_FWD, MH_OP_CONV_PLANES, MH_OP_PLANE_SPLIT, MH_OP_STAMP, MH_OP_CONV_PLANES_BWD, MH_OP_DET_FLUSH };
 /* i[26] of every op is its scheduling word: low byte = lane (0 = the caller's stream; 1..MH_MAX_LANES-1 = side
  * streams owned by the library: the op is forked from lane 0 right before it, i.e. ordered after everything recorded so
  * far, and runs concurrently with the lane-0 ops that follow); MH_OP_JOIN = lane 0 first waits for all side lanes.

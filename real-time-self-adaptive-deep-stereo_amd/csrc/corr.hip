@@ -458,8 +458,8 @@ __global__ __launch_bounds__(256) void corr_warp_bwd_kernel(CorrWarpBwdArgs p) {
             if (p.dimg) {
                 float* d0 = p.dimg + (rowbase + i0) * p.dimg_ld + c4 * 4;
                 float* d1 = p.dimg + (rowbase + i1) * p.dimg_ld + c4 * 4;
-                if (w0 != 0.f) { atomicAdd(d0 + 0, w0 * r.x); atomicAdd(d0 + 1, w0 * r.y); atomicAdd(d0 + 2, w0 * r.z); atomicAdd(d0 + 3, w0 * r.w); }
-                if (w1 != 0.f) { atomicAdd(d1 + 0, w1 * r.x); atomicAdd(d1 + 1, w1 * r.y); atomicAdd(d1 + 2, w1 * r.z); atomicAdd(d1 + 3, w1 * r.w); }
+                if (w0 != 0.f) { mh_atomic_add(d0 + 0, w0 * r.x); mh_atomic_add(d0 + 1, w0 * r.y); mh_atomic_add(d0 + 2, w0 * r.z); mh_atomic_add(d0 + 3, w0 * r.w); }
+                if (w1 != 0.f) { mh_atomic_add(d1 + 0, w1 * r.x); mh_atomic_add(d1 + 1, w1 * r.y); mh_atomic_add(d1 + 2, w1 * r.z); mh_atomic_add(d1 + 3, w1 * r.w); }
             }
             // ... and contract it with the slope of the interpolation
             if (p.du) {
@@ -988,3 +988,6 @@ extern "C" int mh_corr_bwd(const float* g, int32_t g_ld, int32_t coff, const flo
     hipLaunchKernelGGL(corr_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return mh_check_launch("corr_bwd");
 }
+
+// this translation unit's copy of the deterministic-accumulation table (mh_common.h)
+extern "C" int mh_det_sync_corr(const void* t) { return mh_det_upload(*reinterpret_cast<const mh_det_table*>(t)); }

@@ -52,6 +52,41 @@ extern "C" int mh_init(void) {
     return mh_lanes_init();          // side streams / events of the plan executor (not creatable inside a capture)
 }
 extern "C" int mh_abi_version(void) { return MH_ABI_VERSION; }
+
+// ---- deterministic accumulation: the process-wide range table, mirrored into every translation unit that has atomics (mh_common.h) ----------------
+extern "C" int mh_det_sync_corr(const void*);
+extern "C" int mh_det_sync_ops(const void*);
+extern "C" int mh_det_sync_wgrad(const void*);
+extern "C" int mh_det_sync_wgrad_stream(const void*);
+namespace {
+std::mutex g_det_mutex;
+mh_det_table g_det_host = {};
+int det_sync() {
+    if (hipError_t e = hipDeviceSynchronize()) { mh_set_error("mh_deterministic: %s", hipGetErrorString(e)); return (int)e; }     // no launch in flight may see half a table
+    for (auto fn : {mh_det_sync_corr, mh_det_sync_ops, mh_det_sync_wgrad, mh_det_sync_wgrad_stream})
+        if (int e = fn(&g_det_host)) { mh_set_error("mh_deterministic: table upload failed (%d)", e); return e; }
+    return 0;
+}
+}  // namespace
+extern "C" int mh_deterministic_add(float* base, int64_t n, void* acc) {
+    MH_REQUIRE(base && acc && n > 0, MH_ERR_ARG, "mh_deterministic_add: null range");
+    MH_REQUIRE((((uintptr_t)acc) & 7u) == 0, MH_ERR_ALIGN, "mh_deterministic_add: the fixed-point twin must be 8-byte aligned");
+    std::lock_guard<std::mutex> g(g_det_mutex);
+    MH_REQUIRE(g_det_host.n < 8, MH_ERR_UNSUPPORTED, "mh_deterministic_add: at most 8 ranges");
+    const int i = g_det_host.n++;
+    g_det_host.lo[i] = base; g_det_host.hi[i] = base + n; g_det_host.acc[i] = (long long*)acc;
+    return det_sync();
+}
+extern "C" int mh_deterministic_remove(float* base) {
+    std::lock_guard<std::mutex> g(g_det_mutex);
+    int k = 0;
+    for (int i = 0; i < g_det_host.n; ++i)
+        if (g_det_host.lo[i] != base) { g_det_host.lo[k] = g_det_host.lo[i]; g_det_host.hi[k] = g_det_host.hi[i]; g_det_host.acc[k] = g_det_host.acc[i]; ++k; }
+    if (k == g_det_host.n) return 0;
+    g_det_host.n = k;
+    return det_sync();
+}
+extern "C" int mh_deterministic_ranges(void) { std::lock_guard<std::mutex> g(g_det_mutex); return g_det_host.n; }
 // host utility for the TensorFlow-checkpoint importer (Data_utils/tf_checkpoint.py): CRC-32C (Castagnoli), bytewise table
 extern "C" uint32_t mh_crc32c(const void* data, int64_t n, uint32_t crc) {
     static uint32_t table[256];
@@ -163,6 +198,8 @@ static int run_op(const mh_op& o, void* s) {
             mh_conv_desc d; desc_from_op(o, d);
             return mh_conv2d_planes_bwd(&d, p[0], i[23], p[1], p[2], i[24], (float*)p[3], p[4], i[25], s);
         }
+        case MH_OP_DET_FLUSH:        // p: dst, twin ; n
+            return mh_det_flush((float*)p[0], p[1], o.n, s);
         case MH_OP_STAMP:
             return mh_stamp(p[0], s);
         case MH_OP_PLANE_SPLIT:

@@ -65,6 +65,26 @@ __device__ __forceinline__ int mh_xcd_remap(int bid, int nwg) {
     return start + idx;
 }
 
+// ---- deterministic accumulation (mh_deterministic_add, MH_DETERMINISTIC=1 in the engines) ------------------------------------------------------------
+// The step's only order-dependent arithmetic is its float atomics: bias gradients (one atomicAdd per workgroup and channel), the warp-gradient
+// scatter of mh_corr_warp_bwd / mh_warp_bwd, the sampler's image gradient, un-split filter gradients.  In deterministic mode a destination inside a
+// registered range accumulates into a 64-bit FIXED-POINT twin instead (value * 2^48 -- the per-pixel gradients of a mean-reduced loss are ~1e-8 --, integer
+// atomics: associative, so any arrival order gives the same
+// bits); mh_det_flush adds the twin into the float buffer and clears it.  One table per translation unit (no relocatable device code): lib.hip keeps
+// them in step.  Off (n = 0): one scalar load and a uniform branch per atomic site.
+struct mh_det_table { int n; int pad; const float* lo[8]; const float* hi[8]; long long* acc[8]; };
+static __device__ mh_det_table g_mh_det;
+__device__ __forceinline__ void mh_atomic_add(float* dst, float v) {
+    const int n = g_mh_det.n;
+    for (int i = 0; i < n; ++i)
+        if (dst >= g_mh_det.lo[i] && dst < g_mh_det.hi[i]) {
+            atomicAdd(reinterpret_cast<unsigned long long*>(g_mh_det.acc[i] + (dst - g_mh_det.lo[i])), (unsigned long long)(long long)llrintf(v * 281474976710656.0f));
+            return;
+        }
+    atomicAdd(dst, v);
+}
+static inline int mh_det_upload(const mh_det_table& t) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_mh_det), &t, sizeof(t)); }
+
 // Division of a small non-negative index by a LAUNCH-CONSTANT divisor.  gfx950 has no integer divider: for `lin / tiles_x` hipcc emits a ~30-instruction
 // dependent sequence (v_rcp_iflag_f32, Newton step, two corrections) -- five of them in a row decode a workgroup's tile before its first load address is
 // known: ~0.6 us at the head of EVERY conv launch (round 4: scripts/exp/node_floor.py, the ISA of conv_bank_small_kernel).  The host computes the

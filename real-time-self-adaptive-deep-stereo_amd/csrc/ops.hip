@@ -70,8 +70,8 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpArgs p) {
             if (p.dimg) {
                 float* d0 = p.dimg + (rowbase + i0) * p.dimg_ld + c4 * 4;
                 float* d1 = p.dimg + (rowbase + i1) * p.dimg_ld + c4 * 4;
-                if (w0 != 0.f) { atomicAdd(d0 + 0, w0 * gv.x); atomicAdd(d0 + 1, w0 * gv.y); atomicAdd(d0 + 2, w0 * gv.z); atomicAdd(d0 + 3, w0 * gv.w); }
-                if (w1 != 0.f) { atomicAdd(d1 + 0, w1 * gv.x); atomicAdd(d1 + 1, w1 * gv.y); atomicAdd(d1 + 2, w1 * gv.z); atomicAdd(d1 + 3, w1 * gv.w); }
+                if (w0 != 0.f) { mh_atomic_add(d0 + 0, w0 * gv.x); mh_atomic_add(d0 + 1, w0 * gv.y); mh_atomic_add(d0 + 2, w0 * gv.z); mh_atomic_add(d0 + 3, w0 * gv.w); }
+                if (w1 != 0.f) { mh_atomic_add(d1 + 0, w1 * gv.x); mh_atomic_add(d1 + 1, w1 * gv.y); mh_atomic_add(d1 + 2, w1 * gv.z); mh_atomic_add(d1 + 3, w1 * gv.w); }
             }
             if (p.du) {
                 const float4 a = *reinterpret_cast<const float4*>(p.img + (rowbase + i0) * p.img_ld + c4 * 4);
@@ -421,8 +421,8 @@ __global__ __launch_bounds__(256) void sampler_bwd_kernel(SamplerArgs p) {
             gx += gv * (wy0 * (i10 - i00) + wy1 * (i11 - i01));
             gy += gv * (wx0 * (i01 - i00) + wx1 * (i11 - i10));
             if (p.dimg) {
-                atomicAdd(p.dimg + idx[0] * p.C + c, gv * w[0]); atomicAdd(p.dimg + idx[1] * p.C + c, gv * w[1]);
-                atomicAdd(p.dimg + idx[2] * p.C + c, gv * w[2]); atomicAdd(p.dimg + idx[3] * p.C + c, gv * w[3]);
+                mh_atomic_add(p.dimg + idx[0] * p.C + c, gv * w[0]); mh_atomic_add(p.dimg + idx[1] * p.C + c, gv * w[1]);
+                mh_atomic_add(p.dimg + idx[2] * p.C + c, gv * w[2]); mh_atomic_add(p.dimg + idx[3] * p.C + c, gv * w[3]);
             }
         }
         if (p.dcoords) { p.dcoords[q * 2] = gx; p.dcoords[q * 2 + 1] = gy; }
@@ -785,7 +785,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* dz, int dz_
     for (int o = nchp; o < 64; o <<= 1) v += __shfl_xor(v, o);
     red[w][lane] = v;
     __syncthreads();
-    if (w == 0 && pl == 0 && c < nch) atomicAdd(db + c, (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+    if (w == 0 && pl == 0 && c < nch) mh_atomic_add(db + c, (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
 }
 
 __global__ __launch_bounds__(256) void fill_kernel(float* p, int64_t n, float v) {
@@ -1087,6 +1087,21 @@ extern "C" int mh_bias_grad(const float* dz, int32_t dz_ld, int64_t npix, int32_
 // device time stamp (diagnostics of the replayed step: where the side lane starts, how long the tail behind the last input gradient is):
 // one lane stores the constant-rate wall clock (s_memrealtime, 100 MHz on gfx950) into a slot.  A plan op like any other, so the stamp sits at
 // its place in the captured graph and needs no tracer (rocprofv3 shifts the side queue by ~0.3 ms: profiles/r03_experiments.txt #3).
+// deterministic mode: float buffer += its fixed-point twin (value * 2^48), twin cleared (mh_common.h: mh_atomic_add)
+__global__ __launch_bounds__(256) void det_flush_kernel(float* dst, long long* acc, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const long long a = acc[i];
+        if (a) { dst[i] += (float)((double)a * (1.0 / 281474976710656.0)); acc[i] = 0; }
+    }
+}
+extern "C" int mh_det_flush(float* dst, void* acc, int64_t n, void* stream) {
+    MH_REQUIRE(dst && acc && n >= 0, MH_ERR_ARG, "mh_det_flush: null buffer");
+    if (n == 0) return 0;
+    const int64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(det_flush_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, dst, (long long*)acc, n);
+    return mh_check_launch("det_flush");
+}
+
 __global__ void stamp_kernel(long long* slot) { *slot = wall_clock64(); }
 extern "C" int mh_stamp(void* slot, void* stream) {
     MH_REQUIRE(slot && (((uintptr_t)slot) & 7u) == 0, MH_ERR_ARG, "mh_stamp: 8-byte aligned slot");
@@ -1105,3 +1120,6 @@ extern "C" int mh_fill(float* p, int64_t n, float v, void* stream) {
     hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, n, v);
     return mh_check_launch("fill");
 }
+
+// this translation unit's copy of the deterministic-accumulation table (mh_common.h)
+extern "C" int mh_det_sync_ops(const void* t) { return mh_det_upload(*reinterpret_cast<const mh_det_table*>(t)); }

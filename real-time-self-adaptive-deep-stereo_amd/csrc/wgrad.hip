@@ -260,11 +260,11 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
                 const int n = n0 + wn * NT * 16 + j * 16 + li;
                 if (n < p.N) {
                     float* d = dwb + ((int64_t)tap * p.K + k) * p.N + n;
-                    if (plain) *d = acc[i][j][r]; else atomicAdd(d, acc[i][j][r]);
+                    if (plain) *d = acc[i][j][r]; else mh_atomic_add(d, acc[i][j][r]);
                 }
             }
         }
-    if (do_bias && n0 + tid < p.N) atomicAdd(p.db + n0 + tid, bsum);
+    if (do_bias && n0 + tid < p.N) mh_atomic_add(p.db + n0 + tid, bsum);
 }
 
 
@@ -461,7 +461,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& p, const int bl
                 const int n = n0 + wn * NT * 16 + j * 16 + li;
                 if (n < p.N) {
                     float* d = dwb + ((int64_t)tp * p.K + k) * p.N + n;
-                    if (plain) *d = acc[i][j][r]; else atomicAdd(d, acc[i][j][r]);
+                    if (plain) *d = acc[i][j][r]; else mh_atomic_add(d, acc[i][j][r]);
                 }
             }
         }
@@ -477,7 +477,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& p, const int bl
             float t = 0.f;
 #pragma unroll
             for (int r = 0; r < NTH / (BN / 4); ++r) t += red[r * BN + tid];
-            atomicAdd(p.db + n0 + tid, t);
+            mh_atomic_add(p.db + n0 + tid, t);
         }
     }
 }
@@ -631,12 +631,12 @@ __device__ __forceinline__ void wgrad_n1_body(const WgradArgs& p, const int bloc
     for (int e = tid; e < TAPS * p.K; e += 256) {
         float v = 0.f;
         for (int sl = 0; sl < slots; ++sl) v += smem[sl * TAPS * p.K + e];
-        if (p.ws) dst[e] = v; else atomicAdd(dst + e, v);
+        if (p.ws) dst[e] = v; else mh_atomic_add(dst + e, v);
     }
     if (p.db && tid == 0) {
         float v = 0.f;
         for (int i = 0; i < 256; ++i) v += bred[i];
-        atomicAdd(p.db, v);
+        mh_atomic_add(p.db, v);
     }
 }
 template <int TAPS>
@@ -771,7 +771,7 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void wgrad_image_kernel(WgradArgs p
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < IMG_WAVES; ++w) v += bpart[w][e - 512];
-        atomicAdd(p.db + (e - 512), v);
+        mh_atomic_add(p.db + (e - 512), v);
     }
 }
 
@@ -1066,3 +1066,6 @@ extern "C" int mh_wgrad_reduce(const mh_wgrad_seg* segs_device, int32_t nseg, in
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, segs_device, nseg);
     return mh_check_launch("wgrad_reduce");
 }
+
+// this translation unit's copy of the deterministic-accumulation table (mh_common.h)
+extern "C" int mh_det_sync_wgrad(const void* t) { return mh_det_upload(*reinterpret_cast<const mh_det_table*>(t)); }

@@ -257,7 +257,7 @@ __device__ __forceinline__ void wgrad_stream_body(const mh_wgs_layer& L, const i
         if (t3 == 0 && do_bias && tid < 32 && n0 + tid < L.N) {
             float t = 0.f;
             for (int w = 0; w < NW; ++w) t += bred[w * 64 + tid] + bred[w * 64 + 32 + tid];
-            atomicAdd(L.db + n0 + tid, t);
+            mh_atomic_add(L.db + n0 + tid, t);
         }
         __syncthreads();
     }
@@ -413,3 +413,6 @@ extern "C" int mh_wgrad_stream(const mh_wgs_layer* layers_device, int32_t nlayer
     if (dist >= 2 && nwaves <= 6) return stream_launch<3, 2>(layers_device, nlayers, nblocks, nwaves, s, false);
     return stream_launch<3, 1>(layers_device, nlayers, nblocks, nwaves, s, false);
 }
+
+// this translation unit's copy of the deterministic-accumulation table (mh_common.h)
+extern "C" int mh_det_sync_wgrad_stream(const void* t) { return mh_det_upload(*reinterpret_cast<const mh_det_table*>(t)); }

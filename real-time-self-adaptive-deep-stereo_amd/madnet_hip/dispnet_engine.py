@@ -134,7 +134,28 @@ class DispNetEngine(object):
         self.banks_f, self.banks_b = {}, {}  # weight name -> fragment bank in the 32x32x16 image (forward: trans 2; input gradient: trans 3)
         self._fresh = set()                 # shadow keys whose bf16 image is current in the plan being recorded
         self.use_planes = USE_PLANES and precision in ("mixed", "bf16") and str(device).startswith(("cuda", "cpu"))
+        # deterministic test mode (engine.DETERMINISTIC): the bias-gradient atomics accumulate into a fixed-point twin of the flat gradient buffer
+        from . import engine as _E
+        self.deterministic = _E.DETERMINISTIC
+        self._det_bases = []
+        if self.deterministic:
+            import ctypes as _C
+            self.det_g = torch.zeros(self.params.total, dtype=torch.int64, device=device)
+            lib.deterministic_add(_C.c_void_p(self.params.g.data_ptr()), self.params.total, _C.c_void_p(self.det_g.data_ptr()))
+            self._det_bases.append(self.params.g.data_ptr())
         self._build()
+
+    def close(self):
+        import ctypes as _C
+        for b in self._det_bases:
+            self.lib.deterministic_remove(_C.c_void_p(b))
+        self._det_bases = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # ---- graph construction -----------------------------------------------------------------------
     def _st(self, H, W, ld, grad=True):
@@ -488,6 +509,10 @@ class DispNetEngine(object):
         r.join_next = True
         ops.wgrad_reduce(lib, segs, self.dev, r.keep)
         ops.wgrad_reduce(lib, segs2, self.dev, r.keep, accumulate=True)
+        if self.deterministic:
+            import ctypes as _C
+            assert not upd_done
+            lib.det_flush(_C.c_void_p(P.g.data_ptr()), _C.c_void_p(self.det_g.data_ptr()), P.total, None)
         return _merge_ranges(upd_done)
 
     def _shadow(self, v, casts):
@@ -579,7 +604,7 @@ class DispNetEngine(object):
             self.record_loss_metrics(r, with_grad=(mode == "FULL"))
             done = ()
             if mode == "FULL":
-                eu = (lr, momentum, grad_scale) if (EARLY_UPDATE and do_upd and part == "all" and optimizer == "momentum") else None
+                eu = (lr, momentum, grad_scale) if (EARLY_UPDATE and do_upd and part == "all" and optimizer == "momentum" and not self.deterministic) else None
                 done = self.record_backward(r, early_update=eu) or ()
         else:
             done = ()

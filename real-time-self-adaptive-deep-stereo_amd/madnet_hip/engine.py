@@ -122,6 +122,10 @@ PYR_FLUSH_BEFORE = ()
 TAIL_LANE = 2
 # 'mixed': the split-bf16 forward layers (stride-1 3x3, > bank_small_maxpix pixels) run from PRE-SPLIT operands (mh_conv2d_planes, csrc/conv_planes.hip):
 # activations as hi / lo bf16 planes -- hi is the shadow the backward pass reads anyway -- written by the producer's epilogue, staged by LDS DMA
+# Deterministic test mode: the float atomics of a step (bias gradients, warp-gradient scatter) accumulate into
+# 64-bit fixed-point twins (mh_deterministic_add) that the plan flushes behind every level's scatter and in front of the optimizer -- two replays
+# of the same step then give bit-identical weights.  At most four deterministic engines per process (two ranges each).
+DETERMINISTIC = os.environ.get("MH_DETERMINISTIC", "0") == "1"
 USE_PLANES = os.environ.get("MH_CONV_PLANES", "1") != "0"
 # ... and the fp32 copy of such an activation is not stored when no op of the plan reads it (engine._elide_fp32_activations)
 PLANES_ONLY = True
@@ -278,6 +282,15 @@ class MadNetEngine(object):
                 off += n
             else:
                 self.dF[i] = z(B2, hh, ww, co)
+        self.deterministic = DETERMINISTIC
+        self._det_bases = []
+        if self.deterministic:
+            self.det_g = torch.zeros(self.params.total, dtype=torch.int64, device=self.dev)
+            self.det_dF = torch.zeros(self.dF_levels.numel(), dtype=torch.int64, device=self.dev)
+            import ctypes as _C
+            for base, n, twin in ((self.params.g, self.params.total, self.det_g), (self.dF_levels, self.dF_levels.numel(), self.det_dF)):
+                self.lib.deterministic_add(_C.c_void_p(base.data_ptr()), n, _C.c_void_p(twin.data_ptr()))
+                self._det_bases.append(base.data_ptr())
         self.Rw, self.dRw, self.dsi, self.ddsi, self.E, self.dE, self.V, self.dV, self.u, self.du = ({} for _ in range(10))
         self.dsi_ld = {}
         for k in LEVELS:
@@ -1032,6 +1045,7 @@ class MadNetEngine(object):
                 du = self.du[k] if need_u else None
                 ops.corr_warp_bwd(lib, g, Lk, self._fv(self.Rw[k]), self._half(self.F[f], True), self.u[k], dL, self._half(self.dF[f], True), du,
                                   self.md, self.cstride, coff=c, acc_l=acc_flag(("F", f, 0)), copy_left=True)
+                self._det_flush(lib, self.dF[f][B:], self.det_dF if self.deterministic else None, self.dF_levels)
                 if need_u:
                     s_up = 2 ** k
                     if not fuse_head(k + 1, du=self.du[k], Hr=self.Hp // s_up, Wr=self.Wp // s_up, mul=20.0 / s_up):
@@ -1049,6 +1063,7 @@ class MadNetEngine(object):
                     ops_fill(lib, self.dF[f][B:], 0, self.dF[f][B:].numel())
                 ops.warp_bwd(lib, self._fv(self.dRw[k]), self._half(self.F[f], True), self.u[k], dFr,
                              du=du, acc_u=True)
+                self._det_flush(lib, self.dF[f][B:], self.det_dF if self.deterministic else None, self.dF_levels)
                 if need_u:
                     # u_k = resize(V_{k+1}) * 20/2^k   (MadNet.py:274: u_{k} built at level k+1 with scales[k])
                     s_up = 2 ** k
@@ -1114,7 +1129,33 @@ class MadNetEngine(object):
         r.join_next = True                                      # whatever comes next (the optimizer) waits for the side lanes
         self._stamp(lib, "joined")                              # (takes the join edge: every side lane has finished)
         r.join_next = True
+        if self.deterministic:
+            assert not upd_done, "deterministic mode: no early update (the bias gradients are still in their fixed-point twins)"
+            self._det_flush(lib, self.params.g, self.det_g, self.params.g)
+            r.join_next = True
         return _merge_ranges(upd_done)
+
+    def _det_flush(self, lib, t, twin_all, base_all):
+        """deterministic mode: t (a contiguous slice of base_all) += its fixed-point twin; recorded where the next reader of t follows"""
+        if not self.deterministic:
+            return
+        import ctypes as _C
+        off = (t.data_ptr() - base_all.data_ptr()) // 4
+        assert t.is_contiguous() and 0 <= off and off + t.numel() <= base_all.numel()
+        lib.det_flush(_C.c_void_p(t.data_ptr()), _C.c_void_p(twin_all.data_ptr() + 8 * off), t.numel(), None)
+
+    def close(self):
+        """deterministic mode: un-register this engine's ranges (the table holds 8 per process)"""
+        import ctypes as _C
+        for b in self._det_bases:
+            self.lib.deterministic_remove(_C.c_void_p(b))
+        self._det_bases = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def record_update(self, r, train_vars, lr, momentum=0.9, grad_scale=1.0, done=()):
         """MomentumOptimizer apply on the (coalesced) ranges of train_vars; done: sorted disjoint [first, end) ranges that

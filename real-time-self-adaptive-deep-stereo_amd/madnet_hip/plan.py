@@ -121,6 +121,9 @@ class Recorder(object):
     def stamp(self, slot, stream):
         self._op(_ffi.OP_STAMP, [], [], [slot])
 
+    def det_flush(self, dst, twin, n, stream):
+        self._op(_ffi.OP_DET_FLUSH, [], [], [dst, twin], n=n)
+
     def conv2d_planes_bwd(self, dref, dz_hi, dz_pld, wb32t, mask_hi, mask_pld, dx, dx_hi, dx_pld, stream):
         d = dref._obj
         # (tallied as the input-gradient launch it is: flops of the layer, dz in, dx out)

@@ -300,6 +300,9 @@ static inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsig
     return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (sh & 31));
 }
 
+static inline unsigned long long atomicAdd(unsigned long long* addr, unsigned long long v) { return __atomic_fetch_add(addr, v, __ATOMIC_RELAXED); }
+#define HIP_SYMBOL(x) (&(x))
+static inline hipError_t hipMemcpyToSymbol(void* sym, const void* src, size_t n) { memcpy(sym, src, n); return hipSuccess; }
 static inline float atomicAdd(float* addr, float v) {
     uint32_t* p = (uint32_t*)addr;
     uint32_t old = __atomic_load_n(p, __ATOMIC_RELAXED);

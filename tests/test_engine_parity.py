@@ -849,6 +849,43 @@ def test_step_with_bf16_only_gradient_maps(bname, size):
     assert torch.isfinite(g1).all() and ((g1 - g0).norm() / g0.norm()).item() <= 1e-6
 
 
+@pytest.mark.parametrize("bname,size", [SIZES[0], pytest.param("hip", (375, 1242), marks=pytest.mark.gpu, id="hip-375x1242")])
+def test_deterministic_mode_replays_bit_identical(bname, size):
+    """MH_DETERMINISTIC (engine.DETERMINISTIC): the float atomics of the step -- bias gradients, the warp-gradient scatter --
+    accumulate into 64-bit fixed-point twins (mh_deterministic_add) flushed behind every level's scatter and in front of the optimizer: two
+    independent runs of the same three FULL steps give torch.equal weights and momentum (the emulator runs its workgroups on four threads, the
+    MI355X on 256 CUs: the arrival order of the atomics differs from run to run), and agree with the default mode to its atomics noise."""
+    backend = _backend(bname)
+    H, W = size
+    wn = S.calibrated_weights(OM.variable_shapes(), 1)
+    l, r, gt = S.make_pair(H, W)
+    saved = E.DETERMINISTIC
+    res = []
+    try:
+        for det in (True, True, False):
+            E.DETERMINISTIC = det
+            eng = E.MadNetEngine(backend.lib, H, W, B=1, device=backend.device, weights=wn, precision="mixed")
+            assert backend.lib.deterministic_ranges() == (2 if det else 0)
+            eng.set_inputs(l, r, gt[..., 0])
+            plan = eng.build_plan("FULL", lr=1e-3)
+            plan.run(backend.lib, 0)
+            backend.sync()
+            first = (eng.params.w.clone(), eng.params.m.clone())
+            for _ in range(2):
+                plan.run(backend.lib, 0)
+            backend.sync()
+            res.append((eng.params.w.clone(), eng.params.m.clone(), eng.pred.clone(), first))
+            eng.close()
+            assert backend.lib.deterministic_ranges() == 0
+    finally:
+        E.DETERMINISTIC = saved
+    (w0, m0, p0, f0), (w1, m1, p1, f1), (w2, m2, p2, f2) = res
+    assert torch.equal(w0, w1) and torch.equal(m0, m1) and torch.equal(p0, p1)
+    # against the default mode after ONE step (later steps amplify the atomics noise of the default mode through the adapted weights)
+    scale = f2[1].abs().max().item()
+    assert (f0[1] - f2[1]).abs().max().item() <= 1e-4 * scale and (f0[0] - f2[0]).abs().max().item() <= 1e-6
+
+
 @pytest.mark.parametrize("bname", [pytest.param("emul", id="emul"), pytest.param("hip", marks=pytest.mark.gpu, id="hip")])
 @pytest.mark.parametrize("mode", ["FULL", "MAD4", "NONE"])
 def test_mixed_forward_from_planes_matches_fp32_operand_path(bname, mode):
