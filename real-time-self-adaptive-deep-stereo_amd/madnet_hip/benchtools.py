@@ -290,7 +290,8 @@ def op_work(op):
         cin, cout = (K, N) if fwd else (N, K)
         pl = 2 if fwd else 1
         f32 = 4.0 if op.p[4 if fwd else 3] else 0.0
-        return 2.0 * B * H * W * 9 * K * N, B * H * W * (cin * 2.0 * pl + cout * (2.0 * pl + f32)) + 9 * K * N * 2.0 * pl
+        mask = 2.0 * cout if (not fwd and op.p[2]) else 0.0      # the input gradient reads the activation's hi plane once for the sign test
+        return 2.0 * B * H * W * 9 * K * N, B * H * W * (cin * 2.0 * pl + cout * (2.0 * pl + f32) + mask) + 9 * K * N * 2.0 * pl
     if op.kind not in (_ffi.OP_CONV, _ffi.OP_WGRAD, _ffi.OP_WGRAD_PARTIAL):
         return 0.0, 0.0
     i = op.i
