@@ -23,9 +23,12 @@
 // Bank layout rule (host and kernels agree by this function alone): reductions over more than 128 channels -- except 97..112 and 193..208, the
 // split-bf16 iconv layers of DispNet, which have whole-K instances -- are K-chunked in chunks of MH_PLANES_KC16 * 16 channels.
 #define MH_PLANES_KC16 4
+#ifndef MH_PLANES_WHOLE_MAX
+#define MH_PLANES_WHOLE_MAX 8
+#endif
 extern "C" int mh_planes_kc16(int32_t K) {
     const int k16 = (K + 15) / 16;
-    return (k16 <= 8 || k16 == 13) ? 0 : MH_PLANES_KC16;
+    return (k16 <= MH_PLANES_WHOLE_MAX || k16 == 13) ? 0 : MH_PLANES_KC16;
 }
 
 namespace {
@@ -171,7 +174,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_planes_kernel(PlanesArgs p)
     const int y00 = cy + d * (tty * TR), x00 = cx + d * (ttx * MC);       // image position of tile pixel (0, 0)
 
     // ---- weight fragments: ring of NSTB steps, PF steps ahead (ordinary loads: hipcc counts them) -----------------------------------
-    constexpr int T = 9 * K16, NSTB = 4, PF = 3;
+    // weight-fragment ring: in the replayed step the banks come from MALL / HBM (everything else the step touches has passed through the L2 since the
+    // previous replay), so three steps in flight (1150 cycles at MBW = 4, PL = 2) do not cover the latency: eight (r04: step 1.525 -> 1.481 ms; twelve: the same)
+#ifndef MH_PLANES_RING2
+#define MH_PLANES_RING2 8
+#endif
+#ifndef MH_PLANES_RING1
+#define MH_PLANES_RING1 8
+#endif
+    constexpr int T = 9 * K16, NSTB = PL == 2 ? MH_PLANES_RING2 : MH_PLANES_RING1, PF = NSTB - 1;
     const __amdgpu_buffer_rsrc_t rs_b = mh_make_rsrc(p.wb, p.wb_bytes);
     const int nt32 = (p.N + 31) >> 5;
     const int nt = tile_n * WN + wn;
@@ -522,7 +533,7 @@ const PlanesInst g_planes_inst[] = {
     P1_INST(32, 1, 4, 4, 4), P1_INST(32, 1, 4, 2, 4), P1_INST(32, 1, 4, 1, 4), P1_INST(32, 1, 4, 4, 2), P1_INST(32, 1, 4, 2, 2),
     // K-chunked (chunks of 64 channels): every layer / input gradient with a reduction over more than 128 channels, 128- or 64-column tiles
     CK_INST(4, 4, 1, 3), CK_INST(4, 2, 1, 3), CK_INST(4, 1, 1, 3), CK_INST(2, 2, 1, 3), CK_INST(2, 1, 1, 3),
-    CK_INST(4, 2, 2, 3), CK_INST(4, 1, 2, 3), CK_INST(2, 2, 2, 3), CK_INST(2, 1, 2, 3),
+    CK_INST(4, 2, 2, 3), CK_INST(4, 1, 2, 3), CK_INST(2, 2, 2, 3), CK_INST(2, 1, 2, 3), CK_INST(4, 4, 2, 2), CK_INST(3, 4, 1, 3), CK_INST(3, 2, 1, 3), CK_INST(3, 2, 2, 3), CK_INST(3, 1, 2, 3),
 };
 constexpr int N_PLANES_INST = sizeof(g_planes_inst) / sizeof(g_planes_inst[0]);
 
@@ -626,6 +637,7 @@ extern "C" int mh_conv2d_planes_bwd_ok(const mh_conv_desc* d) {
     if (!d) return 0;
     if (!(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_t == d->dil && d->pad_l == d->dil && d->Hi == d->Ho && d->Wi == d->Wo)) return 0;
     if (d->dil < 1 || d->dil > 64 || d->K < 1 || d->K > 2048 || d->N < 1 || d->N > 2048) return 0;          // d = the FORWARD layer: K = Cin = the gradient's columns
+    if (d->in_ld > 0 && d->in_ld < ((d->K + 7) & ~7)) return 0;                                              // dx rows must hold Cin rounded up to 8 (8 columns per lane)
     return planes_has_instance((d->N + 15) / 16, (d->K + 31) / 32, 1) ? 1 : 0;
 }
 

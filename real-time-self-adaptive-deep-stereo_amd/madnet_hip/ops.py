@@ -132,10 +132,13 @@ def conv2d_fwd(lib, x, w, b, out, stride=1, dil=1, alpha=1.0, accumulate=False, 
         lib.conv2d(C.byref(d), _p(x), _p(w), _p(b), _p(out), _p(mask_ref), _p(stream))
 
 
+PLANES_WHOLE_MAX = int(__import__("os").environ.get("MH_PLANES_WHOLE_MAX", "8"))      # must equal the library's build (csrc/conv_planes.hip: MH_PLANES_WHOLE_MAX)
+
+
 def planes_kc16(K):
-    """layout rule of the 32x32x16 bank images (mh_planes_kc16): 0 = whole-K, else the K-chunk in 16-channel steps"""
+    """layout rule of the 32x32x16 bank images (mh_planes_kc16; tests assert that the two agree): 0 = whole-K, else the K-chunk in 16-channel steps"""
     k16 = (K + 15) // 16
-    return 0 if (k16 <= 8 or k16 == 13) else 4
+    return 0 if (k16 <= PLANES_WHOLE_MAX or k16 == 13) else 4
 
 
 def _k16_padded(K):
