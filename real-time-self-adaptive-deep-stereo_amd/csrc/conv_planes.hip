@@ -73,14 +73,47 @@ struct PlanesGeo {
     static constexpr int LDS = LDS_TILES > LDS_CS ? LDS_TILES : LDS_CS;
 };
 
+// What the epilogue needs from memory, requested BEFORE the K walk (round 4: the eight conditional bias loads behind the walk's last barrier and the
+// mask loads inside the store loop each exposed a MALL / HBM round trip per launch -- ~1 us of a 20 - 30 us layer, 33 launches per step): the thread's
+// 8 bias values (two 16-byte buffer loads, out-of-range columns read 0) and, in the one-plane form, the mask chunks of every pixel row it will store.
+template <class G, int PL>
+struct PlanesEpiPre {
+    static constexpr int ITER = (G::BM * (G::BN / 8) + G::NTH - 1) / G::NTH;
+    f32x4 b0, b1;
+    u32x4 mk[PL == 1 ? ITER : 1];
+};
+template <class G, int PL>
+__device__ __forceinline__ void planes_epilogue_prefetch(const PlanesArgs& p, int tid, int n0, int y00, int x00, int b, int d, PlanesEpiPre<G, PL>& pre) {
+    constexpr int MR = G::MR, NTH = G::NTH, BM = G::BM, C8 = G::BN / 8, RP = NTH / C8;
+    const int n = n0 + (tid % C8) * 8;
+    const __amdgpu_buffer_rsrc_t rs_b = mh_make_rsrc(p.bias ? (const void*)p.bias : (const void*)p.in_hi, p.bias ? (unsigned)(p.N * 4) : 0u);
+    pre.b0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, n * 4, 0, 0));
+    pre.b1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, n * 4 + 16, 0, 0));
+    if constexpr (PL == 1) {
+        if (p.mask_hi && tid < NTH) {
+            const __amdgpu_buffer_rsrc_t rs_mk = mh_make_rsrc((const void*)p.mask_hi, (unsigned)((int64_t)p.B * p.H * p.W * p.mask_pld * 2));
+#pragma unroll
+            for (int it = 0; it < PlanesEpiPre<G, PL>::ITER; ++it) {
+                const int m = tid / C8 + it * RP;
+                const int blk = m >> 5, w = m & 31;
+                const int row = MR == 1 ? blk : blk * 2 + (w >> 4), colp = MR == 1 ? w : (w & 15);
+                const int y = y00 + row * d, x = x00 + colp * d;
+                const bool ok = m < BM && y < p.H && x < p.W && n < p.N;
+                pre.mk[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_mk, ok ? (((b * p.H + y) * p.W + x) * p.mask_pld + n) * 2 : MH_OOB, 0, 0);
+            }
+        }
+    }
+}
+
 // the epilogue of both kernels: accumulators -> LDS [pixel][column], then 8 consecutive columns per lane: bias, leaky, mask, split, 16-byte stores.
 // `active`: the calling thread belongs to a compute wave (the K-chunked kernel's loader wave only keeps the barrier company); NTH = compute threads.
-template <class G>
+template <class G, int PL>
 __device__ __forceinline__ void planes_epilogue(const PlanesArgs& p, float* smem_all, const f32x16 (&acc)[G::MBW_], int tid, bool active, int wm, int wn, int lane,
-                                                int n0, int y00, int x00, int b, int d) {
+                                                int n0, int y00, int x00, int b, int d, const PlanesEpiPre<G, PL>& pre) {
     constexpr int MR = G::MR, NTH = G::NTH, BM = G::BM, BN = G::BN, CS = G::CS, MBW = G::MBW_;
     // ---- epilogue: accumulators -> LDS [pixel][column], then 8 consecutive columns per lane: bias, leaky, split, 16-byte stores ----------------
     float* const Cs = smem_all;
+    if (p.dbg & 16) return;                   // timing experiment (mh_tune_conv_planes bit 12): no epilogue at all
     if (active) {
         const int col = wn * 32 + (lane & 31);
 #pragma unroll
@@ -96,15 +129,15 @@ __device__ __forceinline__ void planes_epilogue(const PlanesArgs& p, float* smem
     constexpr int RP = NTH / C8;
     const int c8 = tid % C8;
     const int n = n0 + c8 * 8;
-    float bv[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = (p.bias && n + e < p.N) ? p.bias[n + e] : 0.f;
+    const float bv[8] = {pre.b0[0], pre.b0[1], pre.b0[2], pre.b0[3], pre.b1[0], pre.b1[1], pre.b1[2], pre.b1[3]};
     const __amdgpu_buffer_rsrc_t rs_o = mh_make_rsrc(p.out ? p.out : (float*)p.out_hi, p.out ? p.out_bytes : 0u);
     const __amdgpu_buffer_rsrc_t rs_oh = mh_make_rsrc(p.out_hi ? p.out_hi : (unsigned short*)p.out, p.out_hi ? p.outp_bytes : 0u);
     const __amdgpu_buffer_rsrc_t rs_ol = mh_make_rsrc(p.out_lo ? p.out_lo : (unsigned short*)p.out, p.out_lo ? p.outp_bytes : 0u);
     const __amdgpu_buffer_rsrc_t rs_mk = mh_make_rsrc(p.mask_hi ? (const void*)p.mask_hi : (const void*)p.in_hi, p.mask_hi ? (unsigned)((int64_t)p.B * p.H * p.W * p.mask_pld * 2) : 0u);
-#pragma unroll 2
-    for (int m = tid / C8; m < BM; m += RP) {
+#pragma unroll
+    for (int it = 0; it < PlanesEpiPre<G, PL>::ITER; ++it) {
+        const int m = tid / C8 + it * RP;
+        if (m >= BM) break;
         const int blk = m >> 5, w = m & 31;
         const int row = MR == 1 ? blk : blk * 2 + (w >> 4), colp = MR == 1 ? w : (w & 15);
         const int y = y00 + row * d, x = x00 + colp * d;
@@ -118,7 +151,9 @@ __device__ __forceinline__ void planes_epilogue(const PlanesArgs& p, float* smem
             if (p.alpha != 1.0f) v[e] = v[e] > 0.f ? v[e] : p.alpha * v[e];
         }
         if (p.mask_hi) {        // 8 bf16 of the activation's hi plane: bf16 keeps sign and zero, the test is that of the fp32 tensor
-            const u32x4 mq = __builtin_amdgcn_raw_buffer_load_b128(rs_mk, ok ? (pix * p.mask_pld + n) * 2 : MH_OOB, 0, 0);
+            u32x4 mq;
+            if constexpr (PL == 1) mq = pre.mk[it];
+            else mq = __builtin_amdgcn_raw_buffer_load_b128(rs_mk, ok ? (pix * p.mask_pld + n) * 2 : MH_OOB, 0, 0);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float mk = __builtin_bit_cast(float, (e & 1) ? (mq[e >> 1] & 0xffff0000u) : (mq[e >> 1] << 16));
@@ -128,8 +163,9 @@ __device__ __forceinline__ void planes_epilogue(const PlanesArgs& p, float* smem
         unsigned hh[4], ll[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) mh_split_bf16x2(v[2 * e], v[2 * e + 1], hh[e], ll[e]);
-        const int op = ok ? (pix * p.out_pld + n) * 2 : MH_OOB;
-        const int of = ok ? (pix * p.out_ld + n) * 4 : MH_OOB;
+        const bool st = ok && !(p.dbg & 32);      // timing experiment (bit 13): the whole epilogue but its stores
+        const int op = st ? (pix * p.out_pld + n) * 2 : MH_OOB;
+        const int of = st ? (pix * p.out_ld + n) * 4 : MH_OOB;
         const u32x4 qh = {hh[0], hh[1], hh[2], hh[3]}, ql = {ll[0], ll[1], ll[2], ll[3]};
         const u32x4 f0 = __builtin_bit_cast(u32x4, make_float4(v[0], v[1], v[2], v[3])), f1 = __builtin_bit_cast(u32x4, make_float4(v[4], v[5], v[6], v[7]));
         const int of1 = of == MH_OOB ? MH_OOB : of + 16;
@@ -172,6 +208,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_planes_kernel(PlanesArgs p)
     mh_decode_tile(lin, p.dec, tile_n, ttx, tty, cx, cy, b);
     const int n0 = tile_n * BN;
     const int y00 = cy + d * (tty * TR), x00 = cx + d * (ttx * MC);       // image position of tile pixel (0, 0)
+    PlanesEpiPre<G, PL> pre;
+    planes_epilogue_prefetch<G, PL>(p, tid, n0, y00, x00, b, d, pre);
 
     // ---- weight fragments: ring of NSTB steps, PF steps ahead (ordinary loads: hipcc counts them) -----------------------------------
     // weight-fragment ring: in the replayed step the banks come from MALL / HBM (everything else the step touches has passed through the L2 since the
@@ -263,7 +301,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_planes_kernel(PlanesArgs p)
     }
     __syncthreads();                                 // every wave is done with the patch: the accumulator tile goes over it
 
-    planes_epilogue<G>(p, smem_all, acc, tid, true, wm, wn, lane, n0, y00, x00, b, d);
+    planes_epilogue<G, PL>(p, smem_all, acc, tid, true, wm, wn, lane, n0, y00, x00, b, d, pre);
 }
 
 // ---- K-chunked variant (round 4, DispNet's 256 .. 1056-channel layers: Nets/DispNet.py:75-152) -------------------------------------------------
@@ -301,6 +339,8 @@ __global__ __launch_bounds__((WM * WN + 1) * 64) void conv_planes_ck_kernel(Plan
     mh_decode_tile(lin, p.dec, tile_n, ttx, tty, cx, cy, b);
     const int n0 = tile_n * BN;
     const int y00 = cy + d * (tty * TR), x00 = cx + d * (ttx * MC);
+    PlanesEpiPre<G, PL> pre;
+    planes_epilogue_prefetch<G, PL>(p, tid, n0, y00, x00, b, d, pre);
 
     // weight ring: the one-plane (plain bf16) walk spends 32 MBW cycles per step and DispNet's banks (up to 19 MB) come from HBM, not L2: eleven steps
     // in flight (44 VGPRs) instead of three (microbenchmark r04: conv4_1 42 us with three)
@@ -408,7 +448,7 @@ __global__ __launch_bounds__((WM * WN + 1) * 64) void conv_planes_ck_kernel(Plan
         }
         __syncthreads();                                      // every wave is done with the patch buffers: the accumulator tile goes over them
     }
-    planes_epilogue<G>(p, smem_all, acc, tid, !loader, wm, wn, lane, n0, y00, x00, b, d);
+    planes_epilogue<G, PL>(p, smem_all, acc, tid, !loader, wm, wn, lane, n0, y00, x00, b, d, pre);
 }
 
 // fp32 NHWC -> the two bf16 planes (the operands of conv_planes_kernel): tensors no plane-writing kernel produces (cost-volume buffers, exact-fp32
@@ -466,7 +506,7 @@ int launch_planes(PlanesArgs& a, hipStream_t s, bool attr_only) {
     a.ntiles_n = mh_cdiv(a.N, G::BN);
     a.nwg = a.B * d * d * a.tiles_y * a.tiles_x * a.ntiles_n;
     a.dec = mh_make_tile_decode(a.ntiles_n, a.tiles_x, a.tiles_y, d);
-    a.dbg = (g_planes_mode.load(std::memory_order_relaxed) >> 8) & 15;
+    a.dbg = (g_planes_mode.load(std::memory_order_relaxed) >> 8) & 255;
     ++g_planes_launches;
     mh_note_kernel("conv_planes_kernel<MC=%d,%dx%d waves,MBW=%d,K16=%d,%s> tile %dx%d K=%d dil=%d grid %d lds %d", MC, WM, WN, MBW, K16, PL == 2 ? "bf16x3" : "bf16",
                    G::BM, G::BN, a.K, a.dil, a.nwg, G::LDS);

@@ -363,6 +363,32 @@ def run_dispnet():
               % (name, t0, t1, flops / (t1 * 1e-6) / 1e12, t2, t3, flops / (t3 * 1e-6) / 1e12, k1[22:100], k3[22:100], e_f, e_b, k0[:60]))
 
 
+def run_planes_phases():
+    """where a plane-kernel launch spends its time: the biggest MADNet layer (128 -> 128 at 96x320) with phases removed (mh_tune_conv_planes bits
+    8 = no K walk, 9 = no staging, 12 = no epilogue, 13 = epilogue without its stores), fp32 + planes output and planes only"""
+    B, H, W, Ci, Co = 1, 96, 320, 128, 128
+    x = torch.randn(B, H, W, Ci, device=dev); w = torch.randn(3, 3, Ci, Co, device=dev) * 0.05; b = torch.randn(Co, device=dev)
+    keep = []
+    bank32 = torch.zeros(ops.pack_bytes(w, 2, 2) // 4, device=dev)
+    ops.pack_weights(lib, [(w, bank32, 2, 2)], dev, keep)
+    xp = ops.Planes(ops.Shadow(B, H, W, Ci, dev), dev); yp = ops.Planes(ops.Shadow(B, H, W, Co, dev), dev)
+    ops.plane_split(lib, [(ops.view(x), xp)], dev, keep)
+    y = torch.empty(B, H, W, Co, device=dev)
+    sh = stream.cuda_stream
+    for label, bits in (("full", 0), ("no K walk", 1), ("no staging", 2), ("no epilogue", 16), ("no stores", 32), ("no K walk, no epilogue", 17), ("no K walk, no stores", 33),
+                        ("no K walk, no staging, no epilogue (launch + weight ring)", 19), ("no K walk, no staging", 3)):
+        res = []
+        for outv in (y, None):
+            lib.tune_conv_planes(bits << 8)
+            with torch.cuda.stream(stream):
+                res.append(_time_ms(lib, stream, lambda: ops.conv2d_planes(lib, xp, w, bank32, b, out=(ops.view(outv) if outv is not None else None), out_planes=yp,
+                                                                           alpha=0.2, stream=sh), 20) * 1e3)
+        lib.tune_conv_planes(0)
+        print("%-62s fp32 + planes %6.1f us    planes only %6.1f us" % (label, res[0], res[1]))
+
+
+if what == "phases":
+    run_planes_phases()
 if what == "dispnet":
     run_dispnet()
 if what == "planes":
