@@ -654,13 +654,54 @@ __global__ __launch_bounds__(256) void conv_n1_fwd_kernel(ConvArgs p) {
     HIP_DYNAMIC_SHARED(float, wsm)                 // [taps][K]
     const int tid = threadIdx.x;
     const int nw4 = p.taps * p.K / 4;
-    for (int i = tid; i < nw4; i += 256) reinterpret_cast<float4*>(wsm)[i] = reinterpret_cast<const float4*>(p.w)[i];
-    __syncthreads();
     constexpr int PPB = 256 / LPP;
     const int sub = tid % LPP;
     const int G4 = p.K >> 2;
     const __amdgpu_buffer_rsrc_t rs_in = mh_make_rsrc(p.in, p.in_bytes);
     const float bias = p.bias ? p.bias[0] : 0.f;
+    // The disparity heads (3x3, one channel group per lane, one pixel per lane group: every launch of the MADNet step): all nine taps are requested
+    // before the filter bank goes to LDS -- the tap loop below waits for each load before it issues the next, nine dependent memory round trips for
+    // 2 KB of work per pixel (round 4: ~7 us per launch at every level)
+    if (p.taps == 9 && p.kw == 3 && G4 <= LPP && (int64_t)gridDim.x * PPB >= p.M) {
+        const int m = blockIdx.x * PPB + tid / LPP;
+        const bool live = m < p.M;
+        const int mm = live ? m : 0;
+        const int ox = mm % p.Wo;
+        const int t2 = mm / p.Wo;
+        const int oy = t2 % p.Ho, b = t2 / p.Ho;
+        float4 x[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t - ky * 3;
+            const int iy = oy * p.stride + ky * p.dil - p.pad_t, ix = ox * p.stride + kx * p.dil - p.pad_l;
+            const bool ok = live && sub < G4 && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            x[t] = mh_buf_load4(rs_in, ok ? (((b * p.Hi + iy) * p.Wi + ix) * p.in_ld + sub * 4) * 4 : MH_OOB);
+        }
+        const float old = (live && sub == 0 && p.accumulate) ? p.out[(int64_t)m * p.out_ld] : 0.f;
+        for (int i = tid; i < nw4; i += 256) reinterpret_cast<float4*>(wsm)[i] = reinterpret_cast<const float4*>(p.w)[i];
+        __syncthreads();
+        float acc = 0.f;
+        if (sub < G4) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float4 w = *reinterpret_cast<const float4*>(wsm + t * p.K + sub * 4);
+                acc += (x[t].x * w.x + x[t].y * w.y) + (x[t].z * w.z + x[t].w * w.w);
+            }
+        }
+#pragma unroll
+        for (int o = LPP >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (live && sub == 0) {
+            float v = acc + bias;
+            if (p.alpha != 1.0f) v = v > 0.f ? v : p.alpha * v;
+            v += old;
+            p.out[(int64_t)m * p.out_ld] = v;
+            if (p.out2) p.out2[(int64_t)m * p.out2_ld] = v;
+            if (p.out3) p.out3[(int64_t)m * p.out3_ld] = v;
+        }
+        return;
+    }
+    for (int i = tid; i < nw4; i += 256) reinterpret_cast<float4*>(wsm)[i] = reinterpret_cast<const float4*>(p.w)[i];
+    __syncthreads();
     for (int m = blockIdx.x * PPB + tid / LPP; m - tid / LPP < p.M; m += gridDim.x * PPB) {     // uniform trip count per wave
         const bool live = m < p.M;
         const int mm = live ? m : 0;

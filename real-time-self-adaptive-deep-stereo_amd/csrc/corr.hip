@@ -403,7 +403,11 @@ struct CorrWarpBwdArgs {
     int acc_l;
     int B, H, W, C, md, stride, D, copy_left;
 };
-template <int LPP>
+// DT > 0: at most DT shifts, tensors under 2 GiB -- every operand of a channel group (DT correlation gradients of both directions, DT right / left
+// feature vectors) is requested through range-checked buffer loads before the first product: the generic loop below loads inside `if (in range)`
+// blocks, which the compiler cannot hoist, i.e. 2 DT DEPENDENT memory round trips per channel group (round 4: 13 - 15 us per launch on the 12x40 and
+// 24x80 levels, which have microseconds of work).  Same products in the same order (out-of-range shifts add 0).
+template <int LPP, int DT = 0>
 __global__ __launch_bounds__(256) void corr_warp_bwd_kernel(CorrWarpBwdArgs p) {
     const int C4 = p.C >> 2;
     constexpr int PPB = 256 / LPP;
@@ -427,9 +431,40 @@ __global__ __launch_bounds__(256) void corr_warp_bwd_kernel(CorrWarpBwdArgs p) {
         const float w0 = (x1 - cx) * m0, w1 = (cx - x0) * m1;
         const int i0 = (int)x0s, i1 = (int)x1s;
         float dcx = 0.f;
+        float gvr[DT > 0 ? DT : 1], gvl[DT > 0 ? DT : 1];
+        int orw[DT > 0 ? DT : 1], ol[DT > 0 ? DT : 1];
+        __amdgpu_buffer_rsrc_t rs_g, rs_rw, rs_l;
+        if constexpr (DT > 0) {
+            rs_g = mh_make_rsrc(p.g, (unsigned)(npix * p.g_ld * 4));
+            rs_rw = mh_make_rsrc(p.Rw, (unsigned)(npix * p.rw_ld * 4));
+            rs_l = mh_make_rsrc(p.L, (unsigned)(npix * p.l_ld * 4));
+#pragma unroll
+            for (int j = 0; j < DT; ++j) {
+                const int i = j * p.stride - p.md;
+                const int xs = x + i, xl = x - i;
+                const bool okr = live && j < p.D && xs >= 0 && xs < p.W, okl = live && j < p.D && xl >= 0 && xl < p.W;
+                gvr[j] = mh_buf_load1(rs_g, okr ? (int)((pp * p.g_ld + p.coff + j) * 4) : MH_OOB);
+                gvl[j] = mh_buf_load1(rs_g, okl ? (int)(((rowbase + xl) * p.g_ld + p.coff + j) * 4) : MH_OOB);
+                orw[j] = okr ? (int)((rowbase + xs) * p.rw_ld * 4) : MH_OOB;
+                ol[j] = okl ? (int)((rowbase + xl) * p.l_ld * 4) : MH_OOB;
+            }
+        }
         for (int c4 = sub; c4 < C4; c4 += LPP) {
             if (!live) continue;
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f), r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (DT > 0) {
+                float4 rvv[DT], lvv[DT];
+#pragma unroll
+                for (int j = 0; j < DT; ++j) {
+                    rvv[j] = mh_buf_load4(rs_rw, orw[j] == MH_OOB ? MH_OOB : orw[j] + c4 * 16);
+                    lvv[j] = mh_buf_load4(rs_l, ol[j] == MH_OOB ? MH_OOB : ol[j] + c4 * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < DT; ++j) {
+                    if (orw[j] != MH_OOB) { a.x += gvr[j] * rvv[j].x; a.y += gvr[j] * rvv[j].y; a.z += gvr[j] * rvv[j].z; a.w += gvr[j] * rvv[j].w; }
+                    if (ol[j] != MH_OOB) { r.x += gvl[j] * lvv[j].x; r.y += gvl[j] * lvv[j].y; r.z += gvl[j] * lvv[j].z; r.w += gvl[j] * lvv[j].w; }
+                }
+            } else
             for (int j = 0; j < p.D; ++j) {
                 const int i = j * p.stride - p.md;
                 const int xs = x + i;
@@ -936,10 +971,16 @@ extern "C" int mh_corr_warp_bwd(const float* g, int32_t g_ld, int32_t coff, cons
     const int64_t npix = (int64_t)B * H * W;
     hipStream_t s = (hipStream_t)stream;
     auto grid = [&](int lpp) { int64_t b = (npix * lpp + 255) / 256; return (int)(b > (1 << 20) ? (1 << 20) : b); };
-    if (C4 <= 4) hipLaunchKernelGGL((corr_warp_bwd_kernel<4>), dim3(grid(4)), dim3(256), 0, s, a);
+    const int64_t ldmax = g_ld > rw_ld ? (g_ld > l_ld ? g_ld : l_ld) : (rw_ld > l_ld ? rw_ld : l_ld);
+    const bool fast = a.D <= 5 && npix * ldmax * 4 < (1ll << 31) - 64;        // MADNet's radius-2 volumes: the branch-free form
+    if (fast) {
+        if (C4 <= 4) hipLaunchKernelGGL((corr_warp_bwd_kernel<4, 5>), dim3(grid(4)), dim3(256), 0, s, a);
+        else if (C4 <= 8) hipLaunchKernelGGL((corr_warp_bwd_kernel<8, 5>), dim3(grid(8)), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((corr_warp_bwd_kernel<16, 5>), dim3(grid(16)), dim3(256), 0, s, a);
+    } else if (C4 <= 4) hipLaunchKernelGGL((corr_warp_bwd_kernel<4>), dim3(grid(4)), dim3(256), 0, s, a);
     else if (C4 <= 8) hipLaunchKernelGGL((corr_warp_bwd_kernel<8>), dim3(grid(8)), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((corr_warp_bwd_kernel<16>), dim3(grid(16)), dim3(256), 0, s, a);
-    mh_note_kernel("corr_warp_bwd_kernel<LPP=%d> C=%d D=%d", C4 <= 4 ? 4 : C4 <= 8 ? 8 : 16, C, a.D);
+    mh_note_kernel("corr_warp_bwd_kernel<LPP=%d%s> C=%d D=%d", C4 <= 4 ? 4 : C4 <= 8 ? 8 : 16, fast ? ",DT=5" : "", C, a.D);
     return mh_check_launch("corr_warp_bwd");
 }
 
