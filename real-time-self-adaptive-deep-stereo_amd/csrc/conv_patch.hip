@@ -904,11 +904,7 @@ __global__ __launch_bounds__(1024) void conv_bank_small_kernel(ConvArgs p, Patch
 
 // fragment bank writer: one thread per (chunk, 16-column tile, lane): 8 k-values of one output column -> 16 bytes per plane
 __global__ __launch_bounds__(256) void pack_weights_kernel(const mh_pack_seg* __restrict__ segs, int nseg) {
-    int lo = 0, hi = nseg - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (segs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
-    }
+    const int lo = mh_find_seg(segs, nseg, (int)blockIdx.x);
     const mh_pack_seg sg = segs[lo];
     const int e = ((int)blockIdx.x - sg.blk0) * 256 + (int)threadIdx.x;
     const int lane = e & 63, qt = e >> 6;

@@ -454,11 +454,7 @@ __global__ __launch_bounds__((WM * WN + 1) * 64) void conv_planes_ck_kernel(Plan
 // fp32 NHWC -> the two bf16 planes (the operands of conv_planes_kernel): tensors no plane-writing kernel produces (cost-volume buffers, exact-fp32
 // layers' outputs).  lo may be null (then exactly mh_shadow_cast).
 __global__ __launch_bounds__(256) void plane_split_kernel(const mh_plane_seg* __restrict__ segs, int nseg) {
-    int lo = 0, hi = nseg - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (segs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
-    }
+    const int lo = mh_find_seg(segs, nseg, (int)blockIdx.x);
     const mh_plane_seg sg = segs[lo];
     const int g8 = sg.dst_ld >> 3;
     const int64_t item = (int64_t)((int)blockIdx.x - sg.blk0) * 256 + threadIdx.x;

@@ -85,6 +85,30 @@ __device__ __forceinline__ void mh_atomic_add(float* dst, float v) {
 }
 static inline int mh_det_upload(const mh_det_table& t) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_mh_det), &t, sizeof(t)); }
 
+// Workgroup -> segment of a batched launch's device table (segs[].blk0 = exclusive prefix of the segments' block counts).  The table's blk0 column goes
+// to LDS first (one coalesced round trip) and the binary search runs there: searched in global memory it is log2(nseg) DEPENDENT loads in front of a
+// workgroup's first useful load (7 for the 73-layer bank table of mh_pack_weights: ~3 us per workgroup, round 4).  Called by every thread of a
+// 256-thread workgroup (it contains a barrier).
+template <class SEG>
+__device__ __forceinline__ int mh_find_seg(const SEG* __restrict__ segs, int nseg, int blk) {
+    __shared__ int s_blk0[256];
+    int lo = 0, hi = nseg - 1;
+    if (nseg <= 256) {
+        if ((int)threadIdx.x < nseg) s_blk0[threadIdx.x] = segs[threadIdx.x].blk0;
+        __syncthreads();
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_blk0[mid] <= blk) lo = mid; else hi = mid - 1;
+        }
+        return lo;
+    }
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (segs[mid].blk0 <= blk) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
 // Division of a small non-negative index by a LAUNCH-CONSTANT divisor.  gfx950 has no integer divider: for `lin / tiles_x` hipcc emits a ~30-instruction
 // dependent sequence (v_rcp_iflag_f32, Newton step, two corrections) -- five of them in a row decode a workgroup's tile before its first load address is
 // known: ~0.6 us at the head of EVERY conv launch (round 4: scripts/exp/node_floor.py, the ISA of conv_bank_small_kernel).  The host computes the

@@ -723,6 +723,19 @@ __global__ __launch_bounds__(256) void proxy_grad_kernel(ProxyArgs p) {
 // ------------------------------------------------------------------------------------------
 // momentum / glue
 // ------------------------------------------------------------------------------------------
+// 16-byte form (all three buffers 16-byte aligned: the engines' flat buffers are): two loads in flight per lane, the launch sits behind the join
+// at the very end of the step.  Same arithmetic per element.
+__global__ __launch_bounds__(256) void momentum4_kernel(float4* var, float4* acc, const float4* g, int64_t n4, float lr, float mom, float gs) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 m = acc[i], gg = g[i];
+        float4 v = var[i];
+        float4 a;
+        a.x = mom * m.x + gs * gg.x; a.y = mom * m.y + gs * gg.y; a.z = mom * m.z + gs * gg.z; a.w = mom * m.w + gs * gg.w;
+        acc[i] = a;
+        v.x -= lr * a.x; v.y -= lr * a.y; v.z -= lr * a.z; v.w -= lr * a.w;
+        var[i] = v;
+    }
+}
 __global__ __launch_bounds__(256) void momentum_kernel(float* var, float* acc, const float* g, int64_t n, float lr, float mom, float gs) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float a = mom * acc[i] + gs * g[i];
@@ -1053,7 +1066,13 @@ extern "C" int mh_adam_advance(float* state, float beta1, float beta2, void* str
 extern "C" int mh_momentum(float* var, float* accum, const float* grad, int64_t n, float lr, float momentum,
                            float grad_scale, void* stream) {
     MH_REQUIRE(var && accum && grad && n > 0, MH_ERR_ARG, "mh_momentum: bad argument");
-    hipLaunchKernelGGL(momentum_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, var, accum, grad, n, lr, momentum, grad_scale);
+    const int64_t n4 = n >> 2;
+    if (n4 > 0 && (((uintptr_t)var | (uintptr_t)accum | (uintptr_t)grad) & 15u) == 0)
+        hipLaunchKernelGGL(momentum4_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, (float4*)var, (float4*)accum, (const float4*)grad, n4, lr, momentum,
+                           grad_scale);
+    else if (n4 > 0) { hipLaunchKernelGGL(momentum_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, var, accum, grad, n, lr, momentum, grad_scale); return mh_check_launch("momentum"); }
+    if (n & 3)          // (the tail of a range that is not a multiple of 4)
+        hipLaunchKernelGGL(momentum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, var + 4 * n4, accum + 4 * n4, grad + 4 * n4, n & 3, lr, momentum, grad_scale);
     return mh_check_launch("momentum");
 }
 

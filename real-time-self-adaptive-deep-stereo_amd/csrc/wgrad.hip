@@ -688,10 +688,11 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(WgradGroup g) {
 // output pixels per MFMA pair: lane (li, lq) gathers dz[8 lq .. + 7][n = li] (A operand) and the two columns li / li + 16 of the im2col row of the
 // same 8 pixels (B operands: 8 + 16 independent 4-byte buffer loads, out-of-image taps = out-of-range offsets = 0), rounds to bf16 like the tiled
 // kernel and issues two MFMAs; the 16 waves of a workgroup meet in LDS, so a launch leaves ONE partial gradient per workgroup (64 instead of 167) for
-// the step's reduction launch.  The bias gradient stays exact fp32: the lanes sum the dz values they load.  Default OFF (mh_tune_wgrad_image) until it
-// has been timed in the step on the MI355X: written after the round's GPU budget was spent (parity: emulator).
+// the step's reduction launch.  The bias gradient stays exact fp32: the lanes sum the dz values they load.  History: the first A/B (start of round 4)
+// showed nothing -- the 27 us split reduction behind it dominated the tail; with the reduction at ~6 us this launch IS the tail: 256 workgroups (64 .. 192: level with the tiled kernel),
+// step 1.465 -> 1.453 ms (profiles/r04_experiments.txt #14).  mh_tune_wgrad_image(0) = the tiled kernel.
 constexpr int IMG_WAVES = 16;
-static std::atomic<int> g_wgrad_image{0};
+static std::atomic<int> g_wgrad_image{256};
 extern "C" int mh_tune_wgrad_image(int on) { return g_wgrad_image.exchange(on > 0 ? on : 0); }      // returns the previous setting; > 1 = workgroup count
 
 __global__ __launch_bounds__(64 * IMG_WAVES) void wgrad_image_kernel(WgradArgs p, unsigned mulWo, unsigned mulHo) {
@@ -979,11 +980,7 @@ extern "C" int mh_conv2d_wgrad_partial_group(const mh_wgrad_item* items, int32_t
 namespace {
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const mh_wgrad_seg* __restrict__ segs, int nseg) {
     // block -> segment: segs[].blk0 is the exclusive prefix of the segments' block counts
-    int lo = 0, hi = nseg - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (segs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
-    }
+    const int lo = mh_find_seg(segs, nseg, (int)blockIdx.x);
     const mh_wgrad_seg sg = segs[lo];
     if (sg.size <= 1024 && sg.splits >= 32 && (sg.size & 3) == 0) {
         // a small gradient with many splits (the 3-channel image layer: 432 values x 167 splits) is ONE block here.  Round 3 walked the splits of 64
@@ -1030,9 +1027,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const mh_wgrad_seg* _
     if (e0 >= sg.size) return;
     if ((sg.size & 3) == 0) {       // every split slice 16-byte aligned (ws is): vector path
         const float* src = sg.ws + e0;
-        // 4 independent accumulators = 4 loads in flight per lane (a single dependent chain ran at 2.6 TB/s)
+        // 4 independent accumulators = 4 loads in flight per lane (a single dependent chain ran at 2.6 TB/s); with many splits 16 at a time first:
+        // a 64 - 170-split layer of the step's LAST batch was 16 - 40 dependent rounds of four loads, all of it exposed behind the join (round 4)
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t, t2 = t, t3 = t;
         int s = 0;
+        for (; s + 16 <= sg.splits; s += 16) {
+            float4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const float4*>(src + (int64_t)(s + u) * sg.size);
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) {
+                t.x += v[u].x; t.y += v[u].y; t.z += v[u].z; t.w += v[u].w;
+                t1.x += v[u + 1].x; t1.y += v[u + 1].y; t1.z += v[u + 1].z; t1.w += v[u + 1].w;
+                t2.x += v[u + 2].x; t2.y += v[u + 2].y; t2.z += v[u + 2].z; t2.w += v[u + 2].w;
+                t3.x += v[u + 3].x; t3.y += v[u + 3].y; t3.z += v[u + 3].z; t3.w += v[u + 3].w;
+            }
+        }
         for (; s + 4 <= sg.splits; s += 4) {
             const float4 v0 = *reinterpret_cast<const float4*>(src + (int64_t)(s + 0) * sg.size);
             const float4 v1 = *reinterpret_cast<const float4*>(src + (int64_t)(s + 1) * sg.size);

@@ -34,11 +34,7 @@ struct WsGeo { int nw, wave_bytes; };
 
 // ---- shadow cast: fp32 NHWC (any channel stride) -> bf16 NHWC with the channel count padded to a multiple of 32 (pad = 0) -----------------
 __global__ __launch_bounds__(256) void shadow_cast_kernel(const mh_shadow_seg* __restrict__ segs, int nseg) {
-    int lo = 0, hi = nseg - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (segs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
-    }
+    const int lo = mh_find_seg(segs, nseg, (int)blockIdx.x);
     const mh_shadow_seg sg = segs[lo];
     const int g8 = sg.dst_ld >> 3;                                   // 8-channel groups per pixel
     const int64_t item = (int64_t)((int)blockIdx.x - sg.blk0) * 256 + threadIdx.x;
