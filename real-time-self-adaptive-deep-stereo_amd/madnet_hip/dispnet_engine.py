@@ -134,6 +134,7 @@ class DispNetEngine(object):
         self.banks_f, self.banks_b = {}, {}  # weight name -> fragment bank in the 32x32x16 image (forward: trans 2; input gradient: trans 3)
         self._fresh = set()                 # shadow keys whose bf16 image is current in the plan being recorded
         self.use_planes = USE_PLANES and precision in ("mixed", "bf16") and str(device).startswith(("cuda", "cpu"))
+        ops.check_planes_rule(self.lib)
         # deterministic test mode (engine.DETERMINISTIC): the bias-gradient atomics accumulate into a fixed-point twin of the flat gradient buffer
         from . import engine as _E
         self.deterministic = _E.DETERMINISTIC

@@ -283,6 +283,7 @@ class MadNetEngine(object):
             else:
                 self.dF[i] = z(B2, hh, ww, co)
         self.deterministic = DETERMINISTIC
+        ops.check_planes_rule(self.lib)
         self._det_bases = []
         if self.deterministic:
             self.det_g = torch.zeros(self.params.total, dtype=torch.int64, device=self.dev)

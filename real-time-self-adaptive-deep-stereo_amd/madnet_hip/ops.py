@@ -141,6 +141,13 @@ def planes_kc16(K):
     return 0 if (k16 <= PLANES_WHOLE_MAX or k16 == 13) else 4
 
 
+def check_planes_rule(qlib):
+    """the bank layout rule lives twice (here for sizing, in the library for the kernels): refuse to run on a library built with another rule"""
+    for K in (16, 97, 112, 128, 129, 193, 208, 256, 385, 1025):
+        if int(qlib.planes_kc16(K)) != planes_kc16(K):
+            raise RuntimeError("libmadnet_hip: mh_planes_kc16(%d) = %d, host rule %d (MH_PLANES_WHOLE_MAX mismatch)" % (K, qlib.planes_kc16(K), planes_kc16(K)))
+
+
 def _k16_padded(K):
     k16, kc = (K + 15) // 16, planes_kc16(K)
     return (k16 + kc - 1) // kc * kc if kc else k16
