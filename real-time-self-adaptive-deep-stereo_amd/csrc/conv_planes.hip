@@ -41,6 +41,7 @@ struct PlanesArgs {
                                                                    // fused gradient of tf.maximum(alpha x, x) in an input-gradient launch)
     int mask_c0, mask_c1;                                          // ... for output columns in [mask_c0, mask_c1) only (a concat's member; whole row: 0, INT_MAX)
     int nchunks;                                                   // K-chunked instances: chunks of K16 * 16 reduction channels (1 for the whole-K instances)
+    int Hin, Win;                                                  // stride-2 input gradient: size of dz (H, W = size of dx)
     float* out; unsigned short* out_hi; unsigned short* out_lo;   // any of them may be null
     unsigned in_bytes, wb_bytes, out_bytes, outp_bytes;
     int in_pld, out_ld, out_pld;
@@ -451,6 +452,89 @@ __global__ __launch_bounds__((WM * WN + 1) * 64) void conv_planes_ck_kernel(Plan
     planes_epilogue<G, PL>(p, smem_all, acc, tid, !loader, wm, wn, lane, n0, y00, x00, b, d, pre);
 }
 
+// ---- input gradient of the STRIDE-2 3x3 layers (MADNet pyramid conv3 / conv5 ...: Nets/MadNet.py:56-66, TF 'SAME' on even sizes: pad_before = 0) -------
+// dx[y][x] = sum over taps with y - ky, x - kx even of dz[(y - ky) / 2][(x - kx) / 2] * w[ky][kx]: the four parity classes of (y, x) are four small
+// convolutions over the SAME dz patch -- (even, even): taps {0,2} x {0,2} reading dz[i - {0,1}][j - {0,1}], (even, odd): {0,2} x {1}, (odd, even):
+// {1} x {0,2}, (odd, odd): {1} x {1} -- 9 tap products per dz pixel in all, against 36 tap slots (27 of them multiplied by structural zeros, each with its
+// gather) in the tiled kernel's zero-insertion form (r04 timeline: conv3's input gradient 27 - 34 us for 24 MB of traffic at 3.7x the algorithmic bytes).
+// A wave owns one row of 32 dz pixels and four class accumulators; the dz patch (tile + one row above, one column to the left) is staged by LDS DMA from
+// the bf16 shadow of dz, the bank is the one-plane mirrored / transposed image of mh_conv2d_planes_bwd (walk step t = forward tap 8 - t); each class
+// leaves through the common epilogue on the stride-2 lattice of dx (mask of the layer's input from its bf16 shadow, fp32 + shadow stores).
+template <int WM, int WN, int K16>
+__global__ __launch_bounds__(WM * WN * 64) void conv_planes_s2bwd_kernel(PlanesArgs p) {
+    using G = PlanesGeo<32, WM, WN, 1, K16, 1>;                      // epilogue geometry: one M-block per wave
+    constexpr int NW = G::NW, NTH = G::NTH, TR = WM, BN = G::BN, NCK = G::NCK, NCK1 = G::NCK1;
+    constexpr int PR = TR + 1, PC = 33, ROWP = PC * NCK1;
+    constexpr int PLANE_BLKS = (PR * ROWP * 16 + 1023) / 1024;
+    HIP_DYNAMIC_SHARED(float, smem_all)
+    unsigned char* const smem = reinterpret_cast<unsigned char*>(smem_all);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int lin = mh_xcd_remap(blockIdx.x, p.nwg);
+    int tile_n, ttx, tty, cx, cy, b;
+    mh_decode_tile(lin, p.dec, tile_n, ttx, tty, cx, cy, b);
+    const int n0 = tile_n * BN;
+    const int i00 = tty * TR, j00 = ttx * 32;                        // dz position of tile pixel (0, 0)
+
+    constexpr int T = 9 * K16, NSTB = 8, PF = NSTB - 1;
+    const __amdgpu_buffer_rsrc_t rs_b = mh_make_rsrc(p.wb, p.wb_bytes);
+    const int nt32 = (p.N + 31) >> 5;
+    const int nt = tile_n * WN + wn;
+    const int voff_b = nt < nt32 ? nt * 1024 + lane * 16 : MH_OOB;
+    const int step_b = nt32 * 1024;
+    u32x4 fb[NSTB];
+    auto issue_b = [&](int t, int slot) { if (t < T) fb[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff_b, t * step_b, 0); };
+#pragma unroll
+    for (int t = 0; t < PF; ++t) issue_b(t, t % NSTB);
+    {
+        const mh_dma_src rs_h = mh_make_dma_src(p.in_hi, p.in_bytes);
+        const int pix_b = p.in_pld * 2;
+        for (int i = wave; i < PLANE_BLKS; i += NW) {
+            const int g = i * 64 + lane;
+            const int pr = g / ROWP, rem = g - pr * ROWP;
+            const int pc = rem / NCK1, c = rem - pc * NCK1;
+            const int iy = i00 + pr - 1, ix = j00 + pc - 1;
+            const bool ok = pr < PR && c < NCK && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+            mh_glds16(rs_h, smem + i * 1024, ok ? ((b * p.Hin + iy) * p.Win + ix) * pix_b + c * 16 : MH_OOB);
+        }
+    }
+    MH_WAIT_VMCNT(0);
+    __syncthreads();
+    f32x16 acc[4][1];                                                // class 2 py + px
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][0][r] = 0.f;
+    {
+        const int j = lane & 31, kg = lane >> 5;
+        const unsigned char* const a0 = smem + ((wm * ROWP + j * NCK1 + kg) * 16);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int tap = t / K16, s = t - tap * K16;
+            const int f = 8 - tap;                                   // forward tap of this bank step
+            const int ky = f / 3, kx = f - ky * 3;
+            const int cls = (ky == 1 ? 2 : 0) + (kx == 1 ? 1 : 0);
+            const int imm = (((ky == 2 ? 0 : 1) * ROWP + (kx == 2 ? 0 : 1) * NCK1 + 2 * s) * 16);
+            const u32x4 fa = *reinterpret_cast<const u32x4*>(a0 + imm);
+            acc[cls][0] = mh_mfma_bf16_32(fa, fb[t % NSTB], acc[cls][0]);
+            issue_b(t + PF, (t + PF) % NSTB);
+        }
+    }
+    __syncthreads();
+    PlanesEpiPre<G, 2> pre;
+    {
+        const int n = n0 + (tid % (BN / 8)) * 8;
+        (void)n; (void)NTH;
+        pre.b0 = (f32x4){0.f, 0.f, 0.f, 0.f}; pre.b1 = pre.b0;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        planes_epilogue<G, 2>(p, smem_all, acc[c], tid, true, wm, wn, lane, n0, 2 * i00 + (c >> 1), 2 * j00 + (c & 1), b, 2, pre);
+        __syncthreads();
+    }
+}
+
 // fp32 NHWC -> the two bf16 planes (the operands of conv_planes_kernel): tensors no plane-writing kernel produces (cost-volume buffers, exact-fp32
 // layers' outputs).  lo may be null (then exactly mh_shadow_cast).
 __global__ __launch_bounds__(256) void plane_split_kernel(const mh_plane_seg* __restrict__ segs, int nseg) {
@@ -534,6 +618,30 @@ int launch_planes_ck(PlanesArgs& a, hipStream_t s, bool attr_only) {
                    PL == 2 ? "bf16x3" : "bf16", NBUF, G::BM, G::BN, a.K, a.dil, a.nwg, G::LDS_CK);
     hipLaunchKernelGGL((conv_planes_ck_kernel<MC, WM, WN, MBW, K16, PL, NBUF>), dim3(a.nwg), dim3((WM * WN + 1) * 64), G::LDS_CK, s, a);
     return mh_check_launch("conv_planes_ck");
+}
+
+template <int WM, int WN, int K16>
+int launch_planes_s2bwd(PlanesArgs& a, hipStream_t s) {
+    using G = PlanesGeo<32, WM, WN, 1, K16, 1>;
+    constexpr int PR = WM + 1, ROWP = 33 * G::NCK1;
+    constexpr int LDS_P = ((PR * ROWP * 16 + 1023) / 1024) * 1024;
+    constexpr int LDS = LDS_P > G::LDS_CS ? LDS_P : G::LDS_CS;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_planes_s2bwd_kernel<WM, WN, K16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { mh_set_error("conv_planes_s2bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_done = true;
+    }
+    a.tiles_y = mh_cdiv(a.Hin, WM);
+    a.tiles_x = mh_cdiv(a.Win, 32);
+    a.ntiles_n = mh_cdiv(a.N, G::BN);
+    a.nwg = a.B * a.tiles_y * a.tiles_x * a.ntiles_n;
+    a.dec = mh_make_tile_decode(a.ntiles_n, a.tiles_x, a.tiles_y, 1);
+    a.dbg = 0;
+    ++g_planes_launches;
+    mh_note_kernel("conv_planes_s2bwd_kernel<%dx%d waves,K16=%d,bf16> dz tile %dx32 -> dx %dx64, K=%d N=%d grid %d lds %d", WM, WN, K16, WM, 2 * WM, a.K, a.N, a.nwg, LDS);
+    hipLaunchKernelGGL((conv_planes_s2bwd_kernel<WM, WN, K16>), dim3(a.nwg), dim3(WM * WN * 64), LDS, s, a);
+    return mh_check_launch("conv_planes_s2bwd");
 }
 
 // ---- instance table + tile choice ---------------------------------------------------------------------------------------------------------
@@ -669,8 +777,15 @@ static bool planes_has_instance(int k16, int n32, int pl) {
 }
 
 // ---- input gradient of a stride-1 'SAME' 3x3 layer from bf16 shadows: dx = conv2d_backprop_input(dz, w) [* leaky'(mask)] ----------------------------
+// stride-2 layers (forward 3x3, 'SAME' on even sizes: no padding in front): Cout in {32, 64} (K16 2 / 4), Cin <= 32
+static bool planes_s2bwd_ok(const mh_conv_desc* d) {
+    return d->kh == 3 && d->kw == 3 && d->stride == 2 && d->dil == 1 && d->pad_t == 0 && d->pad_l == 0 && d->Hi == 2 * d->Ho && d->Wi == 2 * d->Wo &&
+           (d->N == 32 || d->N == 64) && d->K >= 1 && d->K <= 32 && !d->accumulate && (d->in_ld == 0 || d->in_ld >= ((d->K + 7) & ~7));
+}
+
 extern "C" int mh_conv2d_planes_bwd_ok(const mh_conv_desc* d) {
     if (!d) return 0;
+    if (d->stride == 2) return planes_s2bwd_ok(d) ? 1 : 0;
     if (!(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_t == d->dil && d->pad_l == d->dil && d->Hi == d->Ho && d->Wi == d->Wo)) return 0;
     if (d->dil < 1 || d->dil > 64 || d->K < 1 || d->K > 2048 || d->N < 1 || d->N > 2048) return 0;          // d = the FORWARD layer: K = Cin = the gradient's columns
     if (d->in_ld > 0 && d->in_ld < ((d->K + 7) & ~7)) return 0;                                              // dx rows must hold Cin rounded up to 8 (8 columns per lane)
@@ -681,7 +796,7 @@ extern "C" int mh_conv2d_planes_bwd(const mh_conv_desc* d, const void* dz_hi, in
                                     float* dx, void* dx_hi, int32_t dx_pld, void* stream) {
     MH_REQUIRE(d && dz_hi && wb32t, MH_ERR_ARG, "mh_conv2d_planes_bwd: null descriptor / dz plane / fragment bank");
     MH_REQUIRE(dx || dx_hi, MH_ERR_ARG, "mh_conv2d_planes_bwd: no output");
-    MH_REQUIRE(mh_conv2d_planes_bwd_ok(d), MH_ERR_UNSUPPORTED, "mh_conv2d_planes_bwd: stride-1 'SAME' 3x3 layers with an instance");
+    MH_REQUIRE(mh_conv2d_planes_bwd_ok(d), MH_ERR_UNSUPPORTED, "mh_conv2d_planes_bwd: 'SAME' 3x3 layers with an instance (stride 1; stride 2: Cout 32 or 64, Cin <= 32, even sizes)");
     MH_REQUIRE(d->B > 0 && d->Hi > 0 && d->Wi > 0, MH_ERR_ARG, "mh_conv2d_planes_bwd: non-positive size");
     const int k16 = (d->N + 15) / 16;
     const int k8 = (d->K + 7) & ~7;
@@ -708,6 +823,14 @@ extern "C" int mh_conv2d_planes_bwd(const mh_conv_desc* d, const void* dz_hi, in
     a.in_pld = dz_pld; a.out_ld = d->in_ld; a.out_pld = dx_pld;
     a.B = d->B; a.H = d->Hi; a.W = d->Wi; a.K = d->N; a.N = d->K; a.dil = d->dil;      // the walk reduces over Cout and produces Cin columns
     a.alpha = 1.0f;
+    a.Hin = d->Ho; a.Win = d->Wo;
+    if (d->stride == 2) {
+        a.in_bytes = (unsigned)((int64_t)d->B * d->Ho * d->Wo * dz_pld * 2);
+        a.dil = 1;
+        const bool few = (int64_t)d->B * mh_cdiv(d->Ho, 4) * mh_cdiv(d->Wo, 32) < 256;       // fewer than a workgroup per CU: two-row tiles
+        if (d->N == 32) return few ? launch_planes_s2bwd<2, 1, 2>(a, (hipStream_t)stream) : launch_planes_s2bwd<4, 1, 2>(a, (hipStream_t)stream);
+        return few ? launch_planes_s2bwd<2, 1, 4>(a, (hipStream_t)stream) : launch_planes_s2bwd<4, 1, 4>(a, (hipStream_t)stream);
+    }
     return dispatch_planes(a, (hipStream_t)stream, false, 1);
 }
 

@@ -418,6 +418,16 @@ class MadNetEngine(object):
                     continue
             if bcode == 1 and pix <= 2 * self.bank_small_maxpix and K >= 16 and N >= 16 and 9 * ((N + 31) // 32) <= 64:
                 plan.append((n, 1, 1))
+        # the LARGE stride-2 pyramid layers whose input gradient is the first contribution to its target (conv3: F2 feeds no cost volume): the parity-class
+        # plane kernel (mh_conv2d_planes_bwd on a stride-2 descriptor) from the one-plane mirrored / transposed bank
+        if bcode == 1 and self.use_planes and PLANES_DGRAD:
+            for i in range(3, 13):
+                h, w = self.fshape[i][0], self.fshape[i][1]
+                if PYR[i - 1][2] == 2 and 2 * B * h * w > self.bank_small_maxpix and (i - 1) not in FEAT.values():
+                    _, _, K, N = shapes[pyr_name(i) + "/weights"]
+                    dxv = self._fv(self.dF[i - 1])
+                    if ops.conv2d_planes_bwd_ok(self.lib, dxv, self.W_(pyr_name(i)), 1, stride=2):
+                        plan.append((pyr_name(i), 1, 3))
         return plan
 
     def _stamp(self, lib, label):
@@ -1110,11 +1120,12 @@ class MadNetEngine(object):
                 if need_dx:
                     # dF[i-1] is complete after this launch (the cost-volume contributions were written earlier): it is the dz of layer i - 1
                     sh = self._out_shadow(self._fv(self.dF[i - 1]), pyr_name(i - 1)) if (i - 1 > 1) else None       # (conv1's 3-channel input keeps the tiled kernel)
-                    wbt = self.banks32t.get(pyr_name(i)) if (PYR[i - 1][2] == 1 and not accumulate) else None
+                    wbt = self.banks32t.get(pyr_name(i)) if not accumulate else None       # (stride-2 layers: only those _bank_plan gave a bank)
                     dzs = self._fresh_shadow(self._fv(self.dF[i])) if wbt is not None else None
                     mks = self._fresh_shadow(self._fv(self.F[i - 1])) if wbt is not None else None
                     if wbt is not None and dzs is not None and mks is not None and sh is not None:
-                        ops.conv2d_planes_bwd(lib, dzs, self.W_(pyr_name(i)), wbt, dx=self._fv(self.dF[i - 1]), dx_shadow=sh, mask_shadow=mks, mask_alpha=ALPHA)
+                        ops.conv2d_planes_bwd(lib, dzs, self.W_(pyr_name(i)), wbt, dx=self._fv(self.dF[i - 1]), dx_shadow=sh, mask_shadow=mks, mask_alpha=ALPHA,
+                                              stride=PYR[i - 1][2])
                         if i in PYR_FLUSH_AFTER:
                             flush(lane=(tail_lane if i == 1 else None))
                         continue

@@ -306,3 +306,50 @@ def test_conv2d_planes_split_bf16_dispnet_iconv_shapes(backend, case):
     scale = max(1.0, ref.abs().max().item())
     assert "conv_planes_kernel" in name and "bf16x3" in name, name
     assert torch.isfinite(oc).all() and (oc - ref).abs().max().item() <= 6e-5 * scale, ((oc - ref).abs().max().item(), name)
+
+
+# (B, Hz, Wz, Cin, Cout): input gradient of the STRIDE-2 3x3 layers (MADNet pyramid conv3 16 -> 32, conv5 32 -> 64; dz is Hz x Wz, dx 2Hz x 2Wz)
+S2_BWD_CASES = [(1, 5, 33, 16, 32), (2, 8, 40, 32, 64), (1, 3, 70, 24, 32), (1, 24, 80, 16, 32)]
+
+
+@pytest.mark.parametrize("case", S2_BWD_CASES)
+def test_conv2d_planes_bwd_stride2(backend, case):
+    """mh_conv2d_planes_bwd on a stride-2 layer (conv_planes_s2bwd_kernel: the four parity classes of the output pixels as four small convolutions over one
+    dz patch): against the autograd of the oracle's stride-2 conv on bf16-rounded operands (fp32 summation order apart) and the tiled bf16 input-gradient
+    kernel; the shadow of dx is bf16(dx) bit for bit."""
+    B, Hz, Wz, Ci, Co = case
+    H, W = 2 * Hz, 2 * Wz
+    lib, dev = backend.lib, backend.device
+    dz = _rand((B, Hz, Wz, Co), 811, dev)
+    w = _rand((3, 3, Ci, Co), 812, dev, 0.2)
+    x = _rand((B, H, W, Ci), 813, dev)
+    keep = []
+    wq = w.cpu().to(torch.bfloat16).double()
+    dzq = dz.cpu().to(torch.bfloat16).double()
+    xin = torch.zeros(B, H, W, Ci, dtype=torch.float64, requires_grad=True)
+    y = T.conv2d(xin, wq, None, stride=2, dilation=1, alpha=1.0)
+    assert tuple(y.shape) == (B, Hz, Wz, Co)
+    (g_ref,) = torch.autograd.grad(y, xin, dzq)
+    g_ref = (g_ref * torch.where(x.cpu().double() > 0, 1.0, 0.2)).float()
+    ld = (Ci + 7) // 8 * 8
+    dxb = torch.full((B, H, W, ld), float("nan"), device=dev)
+    dx = ops.View(dxb, B, H, W, Ci, ld)
+    assert ops.conv2d_planes_bwd_ok(lib, dx, w, 1, stride=2)
+    dzs = ops.Shadow(B, Hz, Wz, Co, dev); xs = ops.Shadow(B, H, W, Ci, dev); dxs = ops.Shadow(B, H, W, Ci, dev)
+    ops.shadow_cast(lib, [(ops.view(dz), dzs), (ops.view(x), xs)], dev, keep)
+    bank = torch.full((ops.pack_bytes(w, 1, 3) // 4,), float("nan"), device=dev)
+    ops.pack_weights(lib, [(w, bank, 1, 3)], dev, keep)
+    lib.tune_conv_planes(0)
+    ops.conv2d_planes_bwd(lib, dzs, w, bank, dx=dx, dx_shadow=dxs, mask_shadow=xs, mask_alpha=0.2, stride=2)
+    name = lib.last_kernel().decode()
+    backend.sync()
+    assert lib.tune_conv_planes(0) == 1 and "conv_planes_s2bwd_kernel" in name, name
+    dxc = dxb.cpu()[..., :Ci]
+    scale = max(1.0, g_ref.abs().max().item())
+    assert torch.isfinite(dxc).all() and (dxc - g_ref).abs().max().item() <= 2e-5 * scale, ((dxc - g_ref).abs().max().item(), name)
+    assert torch.equal(dxs.t.cpu()[..., :Ci], dxc.to(torch.bfloat16))
+    dx0 = torch.zeros(B, H, W, Ci, device=dev)
+    with ops.precision_scope("bf16"):
+        ops.conv2d_dgrad(lib, ops.view(dz), w, ops.view(dx0), stride=2, mask_ref=ops.view(x), mask_alpha=0.2)
+    backend.sync()
+    assert (dxc - dx0.cpu()).abs().max().item() <= 2e-5 * scale
