@@ -793,8 +793,21 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* dz, int dz_
     const int c = blockIdx.y * 64 + (lane & (nchp - 1));
     const int pl = lane / nchp;
     float v = 0.f;
-    if (c < nch)
-        for (int64_t q = ((int64_t)blockIdx.x * 4 + w) * ppw + pl; q < npix; q += (int64_t)gridDim.x * 4 * ppw) v += dz[q * dz_ld + c];
+    if (c < nch) {
+        // eight loads in flight per lane (one per iteration left the launch latency bound: 15 - 30 dependent round trips on DispNet's 192x640 maps)
+        const int64_t st = (int64_t)gridDim.x * 4 * ppw;
+        int64_t q = ((int64_t)blockIdx.x * 4 + w) * ppw + pl;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (; q + 7 * st < npix; q += 8 * st) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = dz[(q + u * st) * dz_ld + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += t[u];
+        }
+        for (; q < npix; q += st) a[0] += dz[q * dz_ld + c];
+        v = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
     for (int o = nchp; o < 64; o <<= 1) v += __shfl_xor(v, o);
     red[w][lane] = v;
     __syncthreads();

@@ -34,6 +34,7 @@ USE_PLANES = os.environ.get("MH_CONV_PLANES", "1") != "0"
 # at the very end of the step (round-3 timeline) -- spread over the batches it runs beside the input-gradient chain.  MH_EARLY_UPDATE=0 turns it off.
 EARLY_UPDATE = os.environ.get("MH_EARLY_UPDATE", "1") != "0"
 # filter gradients leave for a side lane in batches of FLUSH_MIN layers, the batches alternating over SIDE_LANES lanes
+ZERO_GRADS_EARLY = os.environ.get("MH_DN_ZERO_EARLY", "0") != "0"      # the gradient buffer's zero fill on the side lane beside the forward pass (see record_forward)
 FLUSH_MIN = int(os.environ.get("MH_DN_FLUSH_MIN", "2"))       # (one lane: 2 -> 3.15 ms, 3 -> 3.23, 4 -> 3.16, 6 -> 3.20, 12 -> 3.33)
 SIDE_LANES = int(os.environ.get("MH_DN_LANES", "1"))      # (r04 sweep at 375x1242: 1 lane 3.21 ms, 2 lanes 3.39, 3 lanes 3.48 -- every extra stream of the captured graph costs)
 PLANES_MIN_PIX = 1920
@@ -303,6 +304,16 @@ class DispNetEngine(object):
         self._fresh = set()
         if self.use_planes:
             self._record_banks(r, backward)
+        self._grad_zeroed_early = False
+        if backward and ZERO_GRADS_EARLY and hasattr(r, "lane"):
+            # the 168 MB zero fill of the flat gradient buffer (21 us at the HBM rate) leaves the main lane: it runs on the filter gradients' side lane
+            # beside the forward pass (nothing touches the gradients before the backward pass, whose first op joins the lane)
+            r.lane = 1
+            try:
+                ops_fill(r, self.params.g, 0, self.params.total)
+            finally:
+                r.lane = 0
+            self._grad_zeroed_early = True
         # DispNet._preprocess_inputs (DispNet.py:59-73): x/255 - 100/255, reflect pad to a multiple of 64
         ops.pad_reflect(r, self.left, self.X0L.t, self.pt, self.pl, div=255.0, sub=100.0 / 255)
         ops.pad_reflect(r, self.right, self.X0R.t, self.pt, self.pl, div=255.0, sub=100.0 / 255)
@@ -373,7 +384,11 @@ class DispNetEngine(object):
         """early_update = (lr, momentum, grad_scale): see EARLY_UPDATE; returns the sorted disjoint [first, end) parameter ranges updated here"""
         lib, B, P = r, self.B, self.params
         upd_fresh, upd_done = [], []
-        ops_fill(lib, P.g, 0, P.total)
+        if getattr(self, "_grad_zeroed_early", False):
+            lib.join_lanes_next = 1 << 1            # (the fill issued on lane 1 at the head of the forward pass)
+            self._grad_zeroed_early = False
+        else:
+            ops_fill(lib, P.g, 0, P.total)
         for n in self.nodes.values():
             n.remaining, n.written = n.consumers, False
         for n, _ in heads:
