@@ -219,20 +219,30 @@ __device__ __forceinline__ float head_dv_from_du(const ResizeArgs& p, int b, int
     if (exact2) {
         // Hr = 2 Hi, no crop: fine row Y = 2 sy sits on the coarse row (weight 1), its neighbours half way (0.5; the last fine row clamps
         // onto the last coarse row: 1).  Same candidates, weights and order as the general walk below -- bit-identical, without its index search.
-        float acc = 0.f;
+        // (the nine candidates are loaded unconditionally from clamped addresses and the out-of-range ones dropped by a select: loads inside `continue`
+        //  branches were nine memory round trips one after the other -- round 4)
+        float v[9], wgt[9];
+        bool ok[9];
 #pragma unroll
         for (int dy = -1; dy <= 1; ++dy) {
             const int Y = 2 * sy + dy;
-            if ((unsigned)Y >= (unsigned)p.Ho) continue;
+            const bool oky = (unsigned)Y < (unsigned)p.Ho;
+            const int Yc = oky ? Y : 2 * sy;
             const float wy = dy == 0 ? 1.0f : ((dy == 1 && sy == p.Hi - 1) ? 1.0f : 0.5f);
 #pragma unroll
             for (int dx = -1; dx <= 1; ++dx) {
                 const int X = 2 * sx + dx;
-                if ((unsigned)X >= (unsigned)p.Wo) continue;
+                const bool okx = (unsigned)X < (unsigned)p.Wo;
+                const int Xc = okx ? X : 2 * sx;
                 const float wx = dx == 0 ? 1.0f : ((dx == 1 && sx == p.Wi - 1) ? 1.0f : 0.5f);
-                acc += gimg[(int64_t)Y * p.Wo + X] * wy * wx;
+                const int k = (dy + 1) * 3 + dx + 1;
+                v[k] = gimg[(int64_t)Yc * p.Wo + Xc] * wy;
+                wgt[k] = wx; ok[k] = oky && okx;
             }
         }
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc += ok[k] ? v[k] * wgt[k] : 0.f;
         return acc * p.mul;
     }
     const float isy = 1.0f / p.sy, isx = 1.0f / p.sx;
@@ -285,6 +295,52 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs p) {
     __syncthreads();
     // dx[y][x][n] = mask(sum_taps dV[y + 1 - ky][x + 1 - kx] * w[ky][kx][n]) (+ old)
     const int G4 = p.N >> 2;
+    if (G4 <= 16 && (p.acc_dx || p.mask_ref)) {
+        // up to 8 items per thread: the old map / the mask of every item requested before the first is consumed (a load per loop iteration behind a store
+        // to the same buffer cannot be hoisted by the compiler: four dependent round trips for a 32-channel head)
+        constexpr int MAXIT = HB_TH * HB_TW * 16 / 256;
+        float4 oldv[MAXIT], mkv[MAXIT];
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int i = tid + it * 256;
+            const int g = i % G4, px = i / G4;
+            const int iy = px / HB_TW, ix = px - iy * HB_TW;
+            const int y = y0 + iy, x = x0 + ix;
+            const bool live = i < HB_TH * HB_TW * G4 && y < H && x < W;
+            const int64_t m = ((int64_t)b * H + (live ? y : y0)) * W + (live ? x : x0);
+            oldv[it] = (live && p.acc_dx) ? *reinterpret_cast<const float4*>(p.dx + m * p.dx_ld + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            mkv[it] = (live && p.mask_ref) ? *reinterpret_cast<const float4*>(p.mask_ref + m * p.mask_ld + g * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+        }
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int i = tid + it * 256;
+            if (i >= HB_TH * HB_TW * G4) break;
+            const int g = i % G4, px = i / G4;
+            const int iy = px / HB_TW, ix = px - iy * HB_TW;
+            const int y = y0 + iy, x = x0 + ix;
+            if (y >= H || x >= W) continue;
+            const int n = g * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ky = t / 3, kx = t - ky * 3;
+                const float z = sV[(iy + 2 - ky) * (HB_TW + 2) + ix + 2 - kx];
+                const float4 w = *reinterpret_cast<const float4*>(sW + t * p.N + n);
+                v.x += z * w.x; v.y += z * w.y; v.z += z * w.z; v.w += z * w.w;
+            }
+            const int64_t m = ((int64_t)b * H + y) * W + x;
+            float* dst = p.dx + m * p.dx_ld + n;
+            if (p.acc_dx) { const float4 o = oldv[it]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            if (p.mask_ref) {
+                const float4 mk = mkv[it];
+                v.x *= mk.x > 0.f ? 1.0f : p.mask_alpha; v.y *= mk.y > 0.f ? 1.0f : p.mask_alpha;
+                v.z *= mk.z > 0.f ? 1.0f : p.mask_alpha; v.w *= mk.w > 0.f ? 1.0f : p.mask_alpha;
+            }
+            *reinterpret_cast<float4*>(dst) = v;
+            if (p.dx_sh) *reinterpret_cast<uint2*>(p.dx_sh + m * p.dx_sh_ld + n) = make_uint2(mh_pack_bf16(v.x, v.y), mh_pack_bf16(v.z, v.w));
+        }
+        return;
+    }
     for (int i = tid; i < HB_TH * HB_TW * G4; i += 256) {
         const int g = i % G4, px = i / G4;
         const int iy = px / HB_TW, ix = px - iy * HB_TW;

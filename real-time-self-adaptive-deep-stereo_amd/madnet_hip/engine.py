@@ -111,6 +111,10 @@ EARLY_UPDATE = False
 # TAIL_SPLIT: the filter gradients of conv4 .. conv2 (their operands are final one layer earlier) leave as a batch of their own BEFORE conv2's input
 # gradient is launched and run beside it; only conv1's (the 3-channel image layer) is left for the tail.
 TAIL_SPLIT = False
+# The flush behind the last input gradient: the streamed layers of the last batch (conv4 .. conv2) on lane 0 -- idle from there to the join -- while the
+# side lane does the image layer (round 4: the side lane's second-to-last batch ends with the input-gradient chain, so the whole last batch, 62 us, was
+# exposed: profiles/r04_experiments.txt #17)
+TAIL_MAIN = True
 # generalisation: the pyramid's filter gradients leave for the side lane in batches; a batch is flushed AFTER the input gradient of layer i for i in
 # PYR_FLUSH_AFTER (the round-3 schedule: 9, 5, 1 = four layers per batch) and BEFORE the input gradient of layer i -- i.e. as soon as layer i's own
 # filter gradient has its operands -- for i in PYR_FLUSH_BEFORE
@@ -872,13 +876,26 @@ class MadNetEngine(object):
 
         nflush = [0]
 
-        def flush(lane=None):
+        chain_stamped = [False]
+
+        def flush(lane=None, tail=False, on_main=False):
             """Issue the deferred filter gradients as ONE batch on a side lane (one fork edge): they read only
             buffers that nothing later in the step overwrites, so they may run concurrently with everything that
-            follows on lane 0 until the reduction joins them."""
+            follows on lane 0 until the reduction joins them.
+            tail (the flush behind the LAST input gradient, TAIL_MAIN): nothing follows on lane 0 any more, so the batch is split -- the layers of the
+            streamed kernel (conv4 .. conv2) run on lane 0 itself while the side lane does the image layer's gradient and its reduction."""
             if not pending:
                 return
-            side = self.wgrad_lanes > 0 and hasattr(lib, "lane")
+            if tail and TAIL_MAIN and self.wgrad_lanes > 0 and hasattr(lib, "lane") and self.use_stream and self.partial_wgrad and ops._bwd_precision() == 1:
+                streamed = [it for it in pending if ops.wgrad_stream_ok(it[0], it[1], it[2], it[4], it[5]) and it[0].npix >= self.stream_min_pix]
+                rest = [it for it in pending if not any(it is q for q in streamed)]
+                if streamed and rest:
+                    pending[:] = rest
+                    flush(lane=lane)
+                    pending[:] = streamed
+                    flush(on_main=True)
+                    return
+            side = self.wgrad_lanes > 0 and hasattr(lib, "lane") and not on_main
             if side:
                 lib.lane = lane if lane else 1 + nflush[0] % self.wgrad_lanes
                 lib.nodefer = nflush[0] < NODEFER_BATCHES        # the first batches (context network, 1/4-resolution estimator) carry most of the work
@@ -1134,9 +1151,13 @@ class MadNetEngine(object):
                                      mask_alpha=ALPHA, wb=self.Wd_(pyr_name(i)), shadow=sh,
                                      dz_shadow=self._fresh_shadow(self._fv(self.dF[i])), mask_shadow=self._fresh_shadow(self._fv(self.F[i - 1])))
                 if i in PYR_FLUSH_AFTER:
-                    flush(lane=(tail_lane if i == 1 else None))
+                    if i == 1:
+                        self._stamp(lib, "chain_end")           # lane 0: the last input gradient is behind us (the tail flush may put work on lane 0 again)
+                        chain_stamped[0] = True
+                    flush(lane=(tail_lane if i == 1 else None), tail=(i == 1))
         flush()
-        self._stamp(lib, "chain_end")                           # lane 0: the last input gradient is behind us
+        if not chain_stamped[0]:
+            self._stamp(lib, "chain_end")                       # lane 0: the last input gradient is behind us
         ops.wgrad_reduce(lib, segs, self.dev, r.keep)          # (serial variant only: the side-lane batches reduce themselves)
         r.join_next = True                                      # whatever comes next (the optimizer) waits for the side lanes
         self._stamp(lib, "joined")                              # (takes the join edge: every side lane has finished)
