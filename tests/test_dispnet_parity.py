@@ -131,7 +131,7 @@ def test_dispnet_bf16_patch_kernel_vs_gather_kernel_emulated():
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("precision", ["mixed", "bf16"])
+@pytest.mark.parametrize("precision", ["mixed"])          # ('bf16' differs only in which layers take the one-plane form: covered by the kernel tests)
 def test_dispnet_plane_kernels_vs_igemm_path_emulated(precision):
     """Round 4: DispNet's stride-1 3x3 layers on mh_conv2d_planes / mh_conv2d_planes_bwd (K-chunked beyond 128 channels; forward plain bf16 or
     split-bf16 per the precision map, input gradients plain bf16 with the mask of ONE concat member) against the same engine with the path off: the same

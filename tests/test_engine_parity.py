@@ -853,7 +853,7 @@ def test_step_with_bf16_only_gradient_maps(bname, size):
 def test_deterministic_mode_replays_bit_identical(bname, size):
     """MH_DETERMINISTIC (engine.DETERMINISTIC): the float atomics of the step -- bias gradients, the warp-gradient scatter --
     accumulate into 64-bit fixed-point twins (mh_deterministic_add) flushed behind every level's scatter and in front of the optimizer: two
-    independent runs of the same three FULL steps give torch.equal weights and momentum (the emulator runs its workgroups on four threads, the
+    independent runs of the same two (MI355X: three) FULL steps give torch.equal weights and momentum (the emulator runs its workgroups on four threads, the
     MI355X on 256 CUs: the arrival order of the atomics differs from run to run), and agree with the default mode to its atomics noise."""
     backend = _backend(bname)
     H, W = size
@@ -871,7 +871,7 @@ def test_deterministic_mode_replays_bit_identical(bname, size):
             plan.run(backend.lib, 0)
             backend.sync()
             first = (eng.params.w.clone(), eng.params.m.clone())
-            for _ in range(2):
+            for _ in range(2 if bname == "hip" else 1):
                 plan.run(backend.lib, 0)
             backend.sync()
             res.append((eng.params.w.clone(), eng.params.m.clone(), eng.pred.clone(), first))
