@@ -886,7 +886,9 @@ class MadNetEngine(object):
             streamed kernel (conv4 .. conv2) run on lane 0 itself while the side lane does the image layer's gradient and its reduction."""
             if not pending:
                 return
-            if tail and TAIL_MAIN and self.wgrad_lanes > 0 and hasattr(lib, "lane") and self.use_stream and self.partial_wgrad and ops._bwd_precision() == 1:
+            # (not with early_update: the ranges a batch completes are collected per flush, not per half)
+            if (tail and TAIL_MAIN and early_update is None and self.wgrad_lanes > 0 and hasattr(lib, "lane") and self.use_stream and self.partial_wgrad
+                    and ops._bwd_precision() == 1):
                 streamed = [it for it in pending if ops.wgrad_stream_ok(it[0], it[1], it[2], it[4], it[5]) and it[0].npix >= self.stream_min_pix]
                 rest = [it for it in pending if not any(it is q for q in streamed)]
                 if streamed and rest:
