@@ -36,7 +36,7 @@ for n in 1 2 4 8; do
   run private_n$n $n
   run shared_n$n $n --shared-model
 done
-for n in 1 $MAXG; do
+for n in $(printf '1\n%s\n' "$MAXG" | sort -un); do
   run private_s4_n$n $n --concurrent-streams 4
 done
 run mad_shared_n$MAXG $MAXG --mode MAD --shared-model
