@@ -22,7 +22,7 @@ int mh_tune_wgrad_image(int on);        /* image-layer filter-gradient kernel (3
 int mh_tune_wgrad_stream(int dist);     /* prefetch distance (row groups in flight) of the streaming filter-gradient kernel: 1 or 2, 0 = default */
 int mh_tune_corr(int direct);
 
-int mh_tune_conv_planes(int mode);       /* pre-split-operand forward kernel (mh_conv2d_planes): bits 0-3 = tile variant (0 = heuristic), bit 8 = skip the K walk, bit 9 = skip the patch staging (timing experiments); returns the number of launches of that kernel since the previous call */
+int mh_tune_conv_planes(int mode);       /* pre-split-operand forward kernel (mh_conv2d_planes): bits 0-3 = tile variant (0 = heuristic), bit 8 = skip the K walk, bit 9 = skip the patch staging, bit 12 = skip the epilogue, bit 13 = epilogue without its stores (timing experiments: scripts/microbench.py phases); returns the number of launches of the plane kernels since the previous call */
 
 #ifdef __cplusplus
 }

@@ -1,4 +1,11 @@
-// conv_planes.hip -- split-bf16 ("bf16x3") forward pass of the stride-1 "SAME" 3x3 (dilated) layers from PRE-SPLIT operands (round 4).
+// conv_planes.hip -- the plane kernels (round 4).  Three kernels over activations kept as bf16 NHWC planes:
+//   conv_planes_kernel        stride-1 'SAME' 3x3 (dilated) layers, whole reduction in one LDS patch: split-bf16 forward (PL = 2) and, with one plane and a
+//                             mirrored / transposed bank, their input gradients and plain-bf16 forward layers (PL = 1)
+//   conv_planes_ck_kernel     the same walk over reductions of more than 128 channels (DispNet): K-chunked, a loader wave streams 64-channel patch chunks
+//                             through three LDS buffers
+//   conv_planes_s2bwd_kernel  input gradient of the stride-2 3x3 layers: four parity classes = four small convolutions over one dz patch
+// What follows describes the first; the other two have their own headers further down.
+// -- split-bf16 ("bf16x3") forward pass of the stride-1 "SAME" 3x3 (dilated) layers from PRE-SPLIT operands.
 // What is computed: tf.nn.conv2d / atrous_conv2d + bias_add + leaky (Nets/sharedLayers.py:54-77) for the estimator / context / pyramid layers
 // of Nets/MadNet.py:73-171,173-249 -- the same three-MFMA products (lo*hi + hi*lo + hi*hi, fp32 accumulate) as conv_bank_kernel<..., X3>.
 //
@@ -49,7 +56,7 @@ struct PlanesArgs {
     float alpha;
     int tiles_y, tiles_x, ntiles_n, nwg;
     mh_tile_decode dec;                                           // magic multipliers of the workgroup -> tile decode (mh_common.h)
-    int dbg;                                                      // timing experiments: 1 = skip the K walk, 2 = skip the staging
+    int dbg;                                                      // timing experiments (scripts/microbench.py phases): 1 = skip the K walk, 2 = skip the staging, 16 = no epilogue, 32 = no stores
 };
 
 // MC: columns of a 32-pixel M-block (32: one row of 32 lattice pixels; 16: two rows of 16).  WM x WN waves; a wave owns MBW M-blocks x 32 columns.
@@ -170,22 +177,11 @@ __device__ __forceinline__ void planes_epilogue(const PlanesArgs& p, float* smem
         const u32x4 qh = {hh[0], hh[1], hh[2], hh[3]}, ql = {ll[0], ll[1], ll[2], ll[3]};
         const u32x4 f0 = __builtin_bit_cast(u32x4, make_float4(v[0], v[1], v[2], v[3])), f1 = __builtin_bit_cast(u32x4, make_float4(v[4], v[5], v[6], v[7]));
         const int of1 = of == MH_OOB ? MH_OOB : of + 16;
-        if (p.dbg & 4) {            // experiment (mh_tune_conv_planes bit 10): write-through (sc1) stores -- nothing dirty left in L2 at the kernel boundary
-            __builtin_amdgcn_raw_buffer_store_b128(qh, rs_oh, op, 0, 16);
-            __builtin_amdgcn_raw_buffer_store_b128(ql, rs_ol, op, 0, 16);
-            __builtin_amdgcn_raw_buffer_store_b128(f0, rs_o, of, 0, 16);
-            __builtin_amdgcn_raw_buffer_store_b128(f1, rs_o, of1, 0, 16);
-        } else if (p.dbg & 8) {     // experiment (bit 11): non-temporal stores
-            __builtin_amdgcn_raw_buffer_store_b128(qh, rs_oh, op, 0, 2);
-            __builtin_amdgcn_raw_buffer_store_b128(ql, rs_ol, op, 0, 2);
-            __builtin_amdgcn_raw_buffer_store_b128(f0, rs_o, of, 0, 2);
-            __builtin_amdgcn_raw_buffer_store_b128(f1, rs_o, of1, 0, 2);
-        } else {
-            __builtin_amdgcn_raw_buffer_store_b128(qh, rs_oh, op, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(ql, rs_ol, op, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(f0, rs_o, of, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(f1, rs_o, of1, 0, 0);
-        }
+        // (write-through and non-temporal stores were measured: +11 / +5 us per step, profiles/r04_experiments.txt #6)
+        __builtin_amdgcn_raw_buffer_store_b128(qh, rs_oh, op, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(ql, rs_ol, op, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(f0, rs_o, of, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(f1, rs_o, of1, 0, 0);
     }
 }
 
