@@ -54,3 +54,28 @@ x0 = torch.randn(1, 24, 80, 128, device=dev) * 0.1; x1 = torch.zeros(1, 24, 80, 
 per_node("conv_bank_small 24x80 128->128 (bf16, 240 WGs)", lambda r, i: ops.conv2d_fwd(r, ops.view(x0 if i % 2 == 0 else x1), w, bias, ops.view(x1 if i % 2 == 0 else x0), alpha=0.2, wb=bank))
 ops.PRECISION = 0
 
+
+# ---- the plane kernel inside a replayed graph, phases removed (mh_tune_conv_planes bits 8 = no K walk, 9 = no staging, 12 = no epilogue, 13 = no stores):
+# what a launch costs in the step, without the eager-launch floor of scripts/microbench.py phases
+def planes_chain(label, B, H, W, Ci, Co, bits_list):
+    x = torch.randn(B, H, W, Ci, device=dev) * 0.1
+    w = torch.randn(3, 3, Ci, Co, device=dev) * 0.02; b = torch.zeros(Co, device=dev)
+    keep = []
+    bank32 = torch.zeros(ops.pack_bytes(w, 2, 2) // 4, device=dev)
+    ops.pack_weights(lib, [(w, bank32, 2, 2)], dev, keep)
+    xp = ops.Planes(ops.Shadow(B, H, W, Ci, dev), dev)
+    yp = [ops.Planes(ops.Shadow(B, H, W, Co, dev), dev) for _ in range(2)]
+    ops.plane_split(lib, [(ops.view(x), xp)], dev, keep)
+    for bits, name in bits_list:
+        lib.tune_conv_planes(bits << 8)
+        try:
+            # (the chain alternates two output plane sets; the input stays: the phases, not the data flow, are measured)
+            per_node("planes %s: %s" % (label, name), lambda r, i: ops.conv2d_planes(r, xp, w, bank32, b, out=None, out_planes=yp[i % 2], alpha=0.2), n=32)
+        finally:
+            lib.tune_conv_planes(0)
+
+
+PH = [(0, "full"), (1, "no K walk"), (16, "no epilogue"), (17, "no K walk, no epilogue"), (19, "no K walk, no staging, no epilogue"), (33, "no K walk, no stores")]
+planes_chain("128->128 80x304", 1, 80, 304, 128, 128, PH)
+planes_chain("38->128 80x304", 1, 80, 304, 38, 128, PH)
+planes_chain("128->128 40x152", 1, 40, 152, 128, 128, PH)
