@@ -140,7 +140,12 @@ int mh_conv2d_planes(const mh_conv_desc* d, const void* in_hi, const void* in_lo
  *   dz_hi  : bf16 plane of d loss / d output [pixel][dz_pld], padding channels zero;  wb32t: mh_pack_weights(trans = 3) image of the HWIO bank
  *   mask_hi: NULL, or the bf16 (hi) plane of the layer's INPUT activation [pixel][mask_pld] (only its sign is read)
  *   dx     : fp32 result or NULL;  dx_hi: its bf16 plane [pixel][dx_pld] or NULL (the next input gradient's dz_hi, the filter gradient's operand)
- * No accumulation, no channel-range mask: launches that need those stay on mh_conv2d (mode 1). */
+ * d->mask_c0 / mask_c1: the mask applies to output channels [c0, c1) only (one member of a concat: DispNet's up-sampling blocks); 0, 0 = all.
+ * dx rows (d->in_ld) and dx_pld must hold Cin rounded up to 8 (the epilogue stores 8 channels per lane; the padding columns receive zeros).
+ * Reductions over more than 128 output channels run the K-chunked kernel (bank packed with kc16 = mh_planes_kc16(Cout)).
+ * STRIDE-2 layers (d->stride = 2, 3x3, 'SAME' on even sizes i.e. pad_t = pad_l = 0, Hi = 2 Ho, Wi = 2 Wo; Cout 32 or 64, Cin <= 32): the parity-class
+ * kernel -- the four parities of (y, x) are four small convolutions over one dz patch; same bank (trans = 3), same operands, dz_hi is [B][Ho][Wo].
+ * No accumulation: launches that need it stay on mh_conv2d (mode 1). */
 int mh_conv2d_planes_bwd_ok(const mh_conv_desc* d);
 int mh_conv2d_planes_bwd(const mh_conv_desc* d, const void* dz_hi, int32_t dz_pld, const void* wb32t, const void* mask_hi, int32_t mask_pld,
                          float* dx, void* dx_hi, int32_t dx_pld, void* stream);
