@@ -110,6 +110,7 @@ EARLY_UPDATE = False
 # gradient -- conv1's filter gradient reads what conv2's input gradient writes -- so lane 0 sat idle for 91 us behind the chain (batch 76 us + join).
 # TAIL_SPLIT: the filter gradients of conv4 .. conv2 (their operands are final one layer earlier) leave as a batch of their own BEFORE conv2's input
 # gradient is launched and run beside it; only conv1's (the 3-channel image layer) is left for the tail.
+PACK_SIDE = False     # mh_pack_weights on the side lane beside pad_reflect / conv1: FULL -3 us (noise), but NONE / MAD get a second stream: +55 / +35 us (r04_experiments.txt #19)
 TAIL_SPLIT = False
 # The flush behind the last input gradient: the streamed layers of the last batch (conv4 .. conv2) on lane 0 -- idle from there to the join -- while the
 # side lane does the image layer (round 4: the side lane's second-to-last batch ends with the input-gradient chain, so the whole last batch, 62 us, was
@@ -510,13 +511,23 @@ class MadNetEngine(object):
                 tgt = self._bank_of(trans)
                 if n not in tgt:
                     tgt[n] = torch.zeros(ops.pack_bytes(self.W_(n), planes, trans) // 4, device=self.dev)
-            # (in line: on a side lane beside the first pyramid layers, which read no bank, it measured no gain -- profiles/r03_experiments.txt)
-            ops.pack_weights(lib, [(self.W_(n), self._bank_of(trans)[n], planes, trans) for n, planes, trans in plan],
-                             self.dev, r.keep)
+            # (in line: on a side lane beside the first pyramid layers, which read no bank, it measured no gain -- profiles/r03_experiments.txt; PACK_SIDE
+            #  repeats that experiment: the launch on lane 1 beside pad_reflect + conv1 (28 us), joined in front of conv2)
+            side_pack = PACK_SIDE and hasattr(lib, "lane") and self.wgrad_lanes > 0
+            if side_pack:
+                lib.lane = 1
+            try:
+                ops.pack_weights(lib, [(self.W_(n), self._bank_of(trans)[n], planes, trans) for n, planes, trans in plan],
+                                 self.dev, r.keep)
+            finally:
+                if side_pack:
+                    lib.lane = 0
         ops.pad_reflect(lib, self.lr, self.X0, self.pt, self.pl)
         x = ops.View(self.X0, 2 * B, self.Hp, self.Wp, 3, 4)
         for i, (ci, co, s) in enumerate(PYR, 1):
             o = self._fv(self.F[i])
+            if i == 2 and self.use_bank and PACK_SIDE and hasattr(lib, "lane") and self.wgrad_lanes > 0:
+                lib.join_lanes_next = 1 << 1                  # conv1 (3 input channels) never has a bank: every later layer waits for the packing
             # F_i is the input of layer i + 1 (stride 1 or 2: both streamed)
             self._conv_fwd(lib, r, x, pyr_name(i), o, stride=s, precision=self._pyr_code(i), shadow_consumer=(pyr_name(i + 1) if i < 12 else None))
             x = o
