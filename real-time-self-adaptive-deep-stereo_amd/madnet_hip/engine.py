@@ -228,6 +228,9 @@ class MadNetEngine(object):
         # ONE lane since mh_plan_run defers side launches past the next lane-0 op (2.08 ms against 2.28 ms with two lanes, 2.20 ms with
         # two lanes undeferred: profiles/r02_experiments.txt #16)
         self.wgrad_lanes = int(os.environ.get("MH_WGRAD_LANES", "1"))
+        # MAD plans (one block's backward pass: six to thirteen filter gradients) run as ONE serial chain unless MH_WGRAD_LANES says otherwise: the side
+        # stream costs the captured graph more than the overlap of so few launches returns (round 4: 0.896 / 0.889 -> 0.877 / 0.880 ms per MAD step)
+        self.mad_serial = "MH_WGRAD_LANES" not in os.environ
         # one launch per level for the inter-level upsample + warp + cost volume + concat (mh_level_front_fwd) instead of three
         self.fuse_front = True
         # split-bf16 3x3 layers of the 1/4- and 1/8-resolution estimators and the context network stream their weights from MFMA
@@ -1282,10 +1285,16 @@ class MadNetEngine(object):
             self._stream_train = set()
         # the filter-gradient split counts are resolved while the plan is recorded, from a process-wide hook another engine's recording may be scoping
         # (dispnet_engine.build_plan: 150 %): recordings are serialised
-        with ops.TUNE_LOCK, ops.precision_scope(self.precision):
-            if mode == "TRAIN":
-                return self._build_train_plan(r, lr, grad_scale, update, part, loss_weights, max_disp)
-            return self._build_plan(r, mode, lr, block_vars, block_level, grad_scale, update, blocks, part, optimizer, momentum)
+        lanes = self.wgrad_lanes
+        if mode == "MAD" and self.mad_serial and lanes == 1:
+            self.wgrad_lanes = 0
+        try:
+            with ops.TUNE_LOCK, ops.precision_scope(self.precision):
+                if mode == "TRAIN":
+                    return self._build_train_plan(r, lr, grad_scale, update, part, loss_weights, max_disp)
+                return self._build_plan(r, mode, lr, block_vars, block_level, grad_scale, update, blocks, part, optimizer, momentum)
+        finally:
+            self.wgrad_lanes = lanes
 
     def _build_train_plan(self, r, lr, grad_scale, update, part, loss_weights, max_disp):
         """Train.py:56-62,94-102: bulkhead off, loss = sum_i w_i * mean_l1(disparities[-(i+1)], gt, valid), Adam(lr, 0.9)."""
