@@ -459,7 +459,7 @@ __global__ __launch_bounds__((WM * WN + 1) * 64) void conv_planes_ck_kernel(Plan
 template <int WM, int WN, int K16>
 __global__ __launch_bounds__(WM * WN * 64) void conv_planes_s2bwd_kernel(PlanesArgs p) {
     using G = PlanesGeo<32, WM, WN, 1, K16, 1>;                      // epilogue geometry: one M-block per wave
-    constexpr int NW = G::NW, NTH = G::NTH, TR = WM, BN = G::BN, NCK = G::NCK, NCK1 = G::NCK1;
+    constexpr int NW = G::NW, TR = WM, BN = G::BN, NCK = G::NCK, NCK1 = G::NCK1;
     constexpr int PR = TR + 1, PC = 33, ROWP = PC * NCK1;
     constexpr int PLANE_BLKS = (PR * ROWP * 16 + 1023) / 1024;
     HIP_DYNAMIC_SHARED(float, smem_all)
@@ -518,12 +518,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_planes_s2bwd_kernel(PlanesA
         }
     }
     __syncthreads();
-    PlanesEpiPre<G, 2> pre;
-    {
-        const int n = n0 + (tid % (BN / 8)) * 8;
-        (void)n; (void)NTH;
-        pre.b0 = (f32x4){0.f, 0.f, 0.f, 0.f}; pre.b1 = pre.b0;
-    }
+    PlanesEpiPre<G, 2> pre;                                          // no bias in an input gradient; the mask is read inside the epilogue's loop (PL = 2 form)
+    pre.b0 = (f32x4){0.f, 0.f, 0.f, 0.f}; pre.b1 = pre.b0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         planes_epilogue<G, 2>(p, smem_all, acc[c], tid, true, wm, wn, lane, n0, 2 * i00 + (c >> 1), 2 * j00 + (c & 1), b, 2, pre);
