@@ -724,6 +724,13 @@ def main():
                     kf.append(ent)
                 out["kernel_families"] = kf
                 out["kernel_time_sum_us"] = tot
+                # Is this box throttling?  The replayed step against the sum of its launches timed ALONE in short bursts (the plan table): ~1.0 on a healthy
+                # MI355X (the side lane hides about what the dependencies cost); one box of the builder's pool ran every chip-filling kernel ~1.8x slower
+                # INSIDE the sustained replay while the same launches were normal stand-alone: 2.06 ms against a 1.43 ms launch sum = 1.44
+                # (profiles/r04_bench_line_slow_box.json).  A reader comparing rounds or boxes should look at this number first.
+                out["box"] = {"replay_over_launch_sum": (ms * 1e3) / tot if tot else None,
+                              "note": "ms_per_step / sum of the plan's launches timed alone; ~1.0 = healthy, >= 1.3 = the GPU slows down under the sustained replay "
+                                      "(power / thermal state of the box), not a property of the build"}
                 del e_t, p_t
             except Exception as ex:      # never let the auxiliary measurement kill the bench line
                 out["roofline"] = {"error": repr(ex)}
