@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 12
+#define MH_ABI_VERSION 13
 
 /* status codes of every int-returning entry point: 0 = launched; a NEGATIVE code means an argument check failed and
  * nothing was launched or written; a POSITIVE value is the hipError_t of a failed launch / runtime call.
@@ -273,6 +273,15 @@ int mh_corr_bwd(const float* g, int32_t g_ld, int32_t coff, const float* L, int3
                 float* dR, int32_t dr_ld, int32_t acc_r, float* du, int32_t acc_u,
                 int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t stride,
                 int32_t copy_left, void* stream);
+/* The same gradient with a chosen arithmetic for the LARGE shift counts (D > 9, DispNet's 81-shift volume of Nets/DispNet.py:100-101; gradient of
+ * Nets/sharedLayers.py:41-51): precision 0 = exact fp32 (mh_corr_bwd), 1 = operands (features and g) rounded to bf16, fp32 accumulation on
+ * v_mfma_f32_16x16x32_bf16 -- the arithmetic of the other input gradients of the 'mixed' / 'bf16' engine modes -- 2 = runs as 0.  D <= 9 is pure
+ * bandwidth and always exact fp32. */
+int mh_corr_bwd_prec(const float* g, int32_t g_ld, int32_t coff, const float* L, int32_t l_ld,
+                     const float* R, int32_t r_ld, float* dL, int32_t dl_ld, int32_t acc_l,
+                     float* dR, int32_t dr_ld, int32_t acc_r, float* du, int32_t acc_u,
+                     int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t stride,
+                     int32_t copy_left, int32_t precision, void* stream);
 /* One pyramid level's backward front end in ONE launch: mh_corr_bwd with the WARPED right features Rw as the right operand (fused cost volume +
  * concat form), followed by mh_warp_bwd of the resulting gradient -- which is never stored: dimg (+)= the bilinear scatter of it to the unwarped
  * right features' gradient (fp32 atomics: dimg must hold zeros or earlier contributions), du = g[.., coff + D] + the coordinate gradient of the

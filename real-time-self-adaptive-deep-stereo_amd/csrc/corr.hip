@@ -16,7 +16,9 @@
 //     corr_fwd_direct behind mh_tune_corr(0) -- measured slower than direct;
 //   corr_fwd_mfma (D > 9, DispNet's 81-shift volume): the band of the row-wise product L * R^T on the fp32 MFMA;
 //   corr_fwd_large (generic fallback for the fused-concat forms of large D).
+#include <algorithm>
 #include <atomic>
+#include <type_traits>
 #include "mh_common.h"
 
 namespace {
@@ -29,6 +31,7 @@ struct CorrArgs {
     int B, H, W, C, md, stride, D;
     int copy_left, zero_tail, segs;
     unsigned l_bytes, r_bytes;
+    int remap;       // large-D bf16 kernel: XCD-aware workgroup order (the segments of an image row share one L2)
 };
 
 // LPP lanes per pixel (power of two <= 64), TW pixels per workgroup segment.
@@ -511,6 +514,143 @@ __global__ __launch_bounds__(256) void corr_warp_bwd_kernel(CorrWarpBwdArgs p) {
     }
 }
 
+// Row-owned form of the same launch (round 5): ONE workgroup owns ONE image row.  The warp of _linear_warping (MadNet.py:400-436) moves pixels along x
+// only, so every bilinear tap of a row's gradient lands in the SAME row of the right tower's feature gradient: the scatter runs on an LDS copy of that
+// row (ds_add, W x C accumulators) and leaves as plain 16-byte read-modify-write stores -- no global atomics (the atomic form sends 2 x C device-scope
+// fp32 atomics per pixel to the memory side: 2 M at 96x320x32, 34.6 MB of WRITE_SIZE for a 3.9 MB result, 89 % of the wave cycles waiting:
+// profiles/r04_pmc_roofline.json).  Round 3 rejected a first row kernel (r03_experiments.txt #12) because its walk loaded inside `if (in range)` blocks:
+// 2 D dependent memory round trips per channel group on 96 workgroups.  Here the u row is staged first (its taps address the slope loads), then
+// every operand of a channel group -- DT gradients of both directions, DT warped-right / left vectors, the two slope taps, the accumulate operand -- is
+// requested through range-checked buffer loads before the first product: two round trips per pass whatever D is.
+//   DET = false: fp32 LDS atomics (summation order varies from run to run at rounding level, like the global-atomic form);
+//   DET = true (a deterministic range is registered, mh_deterministic_add): 64-bit fixed-point LDS accumulators (value * 2^48, integer adds are
+//   associative): bit-identical from run to run WITHOUT the global fixed-point twin and its flush launch.
+template <int LPP, int DT, bool DET>
+__global__ __launch_bounds__(1024) void corr_warp_bwd_row_kernel(CorrWarpBwdArgs p) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    constexpr int NT = 1024, PPB = NT / LPP;
+    using acc_t = typename std::conditional<DET, unsigned long long, float>::type;
+    acc_t* const racc = reinterpret_cast<acc_t*>(smem);                        // [W][C]
+    float* const su = smem + (size_t)p.W * p.C * (DET ? 2 : 1);               // [W]
+    const int tid = threadIdx.x, sub = tid % LPP;
+    const int C4 = p.C >> 2;
+    const float inv_c = 1.0f / (float)p.C;
+    const int row = blockIdx.x;                                               // b*H + y
+    const int rowbase = row * p.W;
+    const int npix = p.B * p.H * p.W;
+    const __amdgpu_buffer_rsrc_t rs_g = mh_make_rsrc(p.g, (unsigned)((size_t)npix * p.g_ld * 4));
+    const __amdgpu_buffer_rsrc_t rs_rw = mh_make_rsrc(p.Rw, (unsigned)((size_t)npix * p.rw_ld * 4));
+    const __amdgpu_buffer_rsrc_t rs_l = mh_make_rsrc(p.L, (unsigned)((size_t)npix * p.l_ld * 4));
+    const __amdgpu_buffer_rsrc_t rs_img = mh_make_rsrc(p.img, (unsigned)((size_t)npix * p.img_ld * 4));
+    const __amdgpu_buffer_rsrc_t rs_dl = mh_make_rsrc(p.dL, (unsigned)((size_t)npix * p.dl_ld * 4));
+    // fp32 form: the LDS row starts from the row's previous content (requested with the u row: one round trip) and leaves as plain stores;
+    // fixed-point form: starts from zero, the previous content is added at the flush (its conversion would round what an earlier launch left)
+    const int nq = p.W * C4;
+    if constexpr (DET) {
+        for (int i = tid; i < p.W * p.C; i += NT) racc[i] = 0ull;
+    } else {
+        for (int q = tid; q < nq; q += NT) {
+            const int x = q / C4, c4 = q - x * C4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.dimg) v = *reinterpret_cast<const float4*>(p.dimg + (int64_t)(rowbase + x) * p.dimg_ld + c4 * 4);
+            *reinterpret_cast<float4*>(racc + x * p.C + c4 * 4) = v;
+        }
+    }
+    for (int x = tid; x < p.W; x += NT) su[x] = p.u[rowbase + x];
+    __syncthreads();
+    for (int xb = 0; xb < p.W; xb += PPB) {
+        const int x = xb + tid / LPP;
+        const bool live = x < p.W;
+        const int pp = rowbase + (live ? x : 0);
+        const float cx = (float)x + su[live ? x : 0];
+        const float x0 = floorf(cx), x1 = x0 + 1.0f;
+        const float xmax = (float)(p.W - 1);
+        const float x0s = fminf(fmaxf(x0, 0.f), xmax), x1s = fminf(fmaxf(x1, 0.f), xmax);
+        const float m0 = (x0 == x0s) ? 1.f : 0.f, m1 = (x1 == x1s) ? 1.f : 0.f;
+        const float w0 = (x1 - cx) * m0, w1 = (cx - x0) * m1;
+        const int i0 = (int)x0s, i1 = (int)x1s;
+        float gvr[DT], gvl[DT];
+        int orw[DT], ol[DT];
+#pragma unroll
+        for (int j = 0; j < DT; ++j) {
+            const int i = j * p.stride - p.md;
+            const int xs = x + i, xl = x - i;
+            const bool okr = live && j < p.D && xs >= 0 && xs < p.W, okl = live && j < p.D && xl >= 0 && xl < p.W;
+            gvr[j] = mh_buf_load1(rs_g, okr ? (pp * p.g_ld + p.coff + j) * 4 : MH_OOB);
+            gvl[j] = mh_buf_load1(rs_g, okl ? ((rowbase + xl) * p.g_ld + p.coff + j) * 4 : MH_OOB);
+            orw[j] = okr ? (rowbase + xs) * p.rw_ld * 4 : MH_OOB;
+            ol[j] = okl ? (rowbase + xl) * p.l_ld * 4 : MH_OOB;
+        }
+        const float gu = mh_buf_load1(rs_g, (live && p.du) ? (pp * p.g_ld + p.coff + p.D) * 4 : MH_OOB);
+        float dcx = 0.f;
+        for (int c4 = sub; c4 < C4; c4 += LPP) {
+            float4 rvv[DT], lvv[DT];
+#pragma unroll
+            for (int j = 0; j < DT; ++j) {
+                rvv[j] = mh_buf_load4(rs_rw, orw[j] == MH_OOB ? MH_OOB : orw[j] + c4 * 16);
+                lvv[j] = mh_buf_load4(rs_l, ol[j] == MH_OOB ? MH_OOB : ol[j] + c4 * 16);
+            }
+            const float4 gl = mh_buf_load4(rs_g, (live && p.copy_left) ? (pp * p.g_ld + c4 * 4) * 4 : MH_OOB);
+            const float4 dlo = mh_buf_load4(rs_dl, (live && p.acc_l) ? (pp * p.dl_ld + c4 * 4) * 4 : MH_OOB);
+            const float4 s0 = mh_buf_load4(rs_img, (live && p.du) ? ((rowbase + i0) * p.img_ld + c4 * 4) * 4 : MH_OOB);
+            const float4 s1 = mh_buf_load4(rs_img, (live && p.du) ? ((rowbase + i1) * p.img_ld + c4 * 4) * 4 : MH_OOB);
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < DT; ++j) {
+                if (orw[j] != MH_OOB) { a.x += gvr[j] * rvv[j].x; a.y += gvr[j] * rvv[j].y; a.z += gvr[j] * rvv[j].z; a.w += gvr[j] * rvv[j].w; }
+                if (ol[j] != MH_OOB) { r.x += gvl[j] * lvv[j].x; r.y += gvl[j] * lvv[j].y; r.z += gvl[j] * lvv[j].z; r.w += gvl[j] * lvv[j].w; }
+            }
+            a.x *= inv_c; a.y *= inv_c; a.z *= inv_c; a.w *= inv_c;
+            r.x *= inv_c; r.y *= inv_c; r.z *= inv_c; r.w *= inv_c;
+            a.x += gl.x; a.y += gl.y; a.z += gl.z; a.w += gl.w;            // (zeros unless copy_left / acc_l: out-of-range loads)
+            a.x += dlo.x; a.y += dlo.y; a.z += dlo.z; a.w += dlo.w;
+            if (live) {
+                *reinterpret_cast<float4*>(p.dL + (int64_t)pp * p.dl_ld + c4 * 4) = a;
+                if (p.dimg) {
+                    acc_t* d0 = racc + i0 * p.C + c4 * 4;
+                    acc_t* d1 = racc + i1 * p.C + c4 * 4;
+                    const float t0[4] = {w0 * r.x, w0 * r.y, w0 * r.z, w0 * r.w}, t1[4] = {w1 * r.x, w1 * r.y, w1 * r.z, w1 * r.w};
+                    if constexpr (DET) {
+#pragma unroll 1
+                        for (int e = 0; e < 4; ++e) {          // (rolled: the 64-bit conversions of an unrolled body spill at 128 VGPRs)
+                            if (w0 != 0.f) atomicAdd(d0 + e, (unsigned long long)(long long)llrintf(t0[e] * 281474976710656.0f));
+                            if (w1 != 0.f) atomicAdd(d1 + e, (unsigned long long)(long long)llrintf(t1[e] * 281474976710656.0f));
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (w0 != 0.f) atomicAdd(d0 + e, t0[e]);
+                            if (w1 != 0.f) atomicAdd(d1 + e, t1[e]);
+                        }
+                    }
+                }
+            }
+            dcx += r.x * (m1 * s1.x - m0 * s0.x) + r.y * (m1 * s1.y - m0 * s0.y) + r.z * (m1 * s1.z - m0 * s0.z) + r.w * (m1 * s1.w - m0 * s0.w);
+        }
+        if (p.du) {
+#pragma unroll
+            for (int o = LPP >> 1; o > 0; o >>= 1) dcx += __shfl_xor(dcx, o);
+            if (live && sub == 0) p.du[pp] = gu + dcx;
+        }
+    }
+    if (!p.dimg) return;
+    __syncthreads();
+    // the row of the right tower's feature gradient: += what the row's taps left in LDS (this workgroup is the row's only writer)
+    for (int q = tid; q < nq; q += NT) {
+        const int x = q / C4, c4 = q - x * C4;
+        float4* dst = reinterpret_cast<float4*>(p.dimg + (int64_t)(rowbase + x) * p.dimg_ld + c4 * 4);
+        const acc_t* s = racc + x * p.C + c4 * 4;
+        if constexpr (DET) {
+            float4 v = *dst;
+            v.x += (float)((double)(long long)s[0] * (1.0 / 281474976710656.0)); v.y += (float)((double)(long long)s[1] * (1.0 / 281474976710656.0));
+            v.z += (float)((double)(long long)s[2] * (1.0 / 281474976710656.0)); v.w += (float)((double)(long long)s[3] * (1.0 / 281474976710656.0));
+            *dst = v;
+        } else {
+            *dst = *reinterpret_cast<const float4*>(s);
+        }
+    }
+}
+
 // Large shift counts (DispNet, D = 81) on the matrix cores: out[x][d] = mean_c L[x][c] * R[x + d - md][c] is the band
 // |x' - x| <= md of the row-wise product L_row (W x C) * R_row^T (C x W).  One workgroup = one 64-pixel row segment,
 // one wave = 16 pixels; the right-feature window [x0 - md, x0 + 64 + md) is staged once in LDS (k-contiguous rows,
@@ -584,8 +724,9 @@ __global__ __launch_bounds__(256) void corr_fwd_mfma_bf16(CorrArgs p) {
     unsigned short* const Wh = reinterpret_cast<unsigned short*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
-    const int seg = blockIdx.x % p.segs;
-    const int row = blockIdx.x / p.segs;              // b*H + y
+    const int bid = p.remap ? mh_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int seg = bid % p.segs;
+    const int row = bid / p.segs;                     // b*H + y
     const int x0 = seg * 64;
     const int nb = (2 * p.md + 16 + 15) / 16;         // 16-column blocks per wave
     const int rows = 48 + 16 * nb;                    // window rows any wave touches
@@ -792,6 +933,156 @@ __global__ __launch_bounds__(CS16 >= 2 ? 512 : 256) void corr_bwd_mfma(CorrBwdAr
     }
 }
 
+// The same gradient on the bf16 matrix cores (precision code 1 of mh_corr_bwd_prec: the arithmetic of every other gradient of the 'mixed' / 'bf16' modes).
+// The exact-fp32 pair above issues 6 x 4 x C/16 = 192 v_mfma_f32_16x16x4_f32 per 16 pixels and direction: at 35 FLOP/B the fp32 MFMA rate is its ceiling
+// (27 % of the HBM peak at the protocol shape, profiles/r02_microbench_corr.txt).  Here the other feature's window sits in LDS as bf16 [pixel][C + 16]
+// -- NHWC rows as they come from memory, converted at the store -- and the MFMA B operand (8 consecutive WINDOW PIXELS of one channel per lane) is
+// fetched with the transposing LDS read (ds_read_b64_tr_b16: two reads per operand); the band of g is gathered from a bf16 LDS copy as the A operand and
+// reused by all C/16 channel blocks: 3 x C/16 = 24 v_mfma_f32_16x16x32_bf16 per wave and direction at C = 128.  Results leave through an LDS transpose
+// as whole 4 C-byte pixel rows (16-byte stores), not as 64-byte column fragments.  Workgroup ids are remapped so that the segments of an image row run on
+// ONE XCD: the 2.25x window overlap between neighbouring segments is served by that XCD's L2 instead of being fetched once per XCD.
+template <int CS16, bool RIGHT>
+__global__ __launch_bounds__(256) void corr_bwd_mfma_bf16(CorrBwdArgs p, int segs, int remap) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    constexpr int C = CS16 * 16, RS = C + 16;              // halfs per window row (8 dwords of padding: the 4 rows of a transposing read hit distinct banks)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int bid = remap ? mh_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int seg = bid % segs;
+    const int row = bid / segs;
+    const int x0 = seg * 64;
+    const int nks = (2 * p.md + 16 + 31) / 32;             // 32-pixel k-steps of a wave's band
+    const int rows = 48 + 32 * nks;                        // window pixels any wave touches (rows past the band read as zeros: 0 x garbage must not happen)
+    const int DP = (p.D + 7) & ~7;                         // halfs per g row
+    unsigned short* const Ws = reinterpret_cast<unsigned short*>(smem);            // [rows][RS]
+    const int grows = RIGHT ? rows : 64;
+    unsigned short* const Gs = Ws + rows * RS;                                     // [grows][DP]
+    const float* Wsrc = RIGHT ? p.L : p.R;
+    const int w_ld = RIGHT ? p.l_ld : p.r_ld;
+    const int npix = p.B * p.H * p.W;
+    const __amdgpu_buffer_rsrc_t rsW = mh_make_rsrc(Wsrc, (unsigned)(((size_t)npix - 1) * w_ld * 4 + (size_t)C * 4));
+    const __amdgpu_buffer_rsrc_t rsG = mh_make_rsrc(p.g, (unsigned)((size_t)npix * p.g_ld * 4));
+    constexpr int U = 8;
+    {   // the other operand's window, U independent 16-byte loads in flight per thread, rounded to bf16 at the LDS store
+        const int items = rows * (C / 4);
+        for (int q0 = tid; q0 < items; q0 += 256 * U) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = q0 + 256 * u;
+                const int xw = q / (C / 4), c4 = q - xw * (C / 4);
+                const int xs = x0 - p.md + xw;
+                const bool ok = q < items && xs >= 0 && xs < p.W;
+                v[u] = mh_buf_load4(rsW, ok ? ((row * p.W + xs) * w_ld + c4 * 4) * 4 : MH_OOB);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = q0 + 256 * u;
+                if (q < items) {
+                    const int xw = q / (C / 4), c4 = q - xw * (C / 4);
+                    *reinterpret_cast<uint2*>(Ws + xw * RS + c4 * 4) = make_uint2(mh_pack_bf16(v[u].x, v[u].y), mh_pack_bf16(v[u].z, v[u].w));
+                }
+            }
+        }
+    }
+    {   // g rows: the 64 outputs (left gradient) / the window (right gradient), rounded to bf16
+        const int gx0 = RIGHT ? x0 - p.md : x0;
+        const int D4 = (p.D + 3) >> 2;
+        if (((p.g_ld | p.coff) & 3) == 0 && p.coff + 4 * D4 <= p.g_ld) {
+            // 16-byte rows: the columns d >= D of the last group hold whatever follows the volume in the row; the band gather never reads them
+            const int items = grows * D4;
+            const float inv = 1.0f / (float)D4;
+            for (int q0 = tid; q0 < items; q0 += 256 * U) {
+                float4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int q = q0 + 256 * u;
+                    const int gr = (int)(((float)q + 0.5f) * inv), d4 = q - gr * D4;
+                    const int xs = gx0 + gr;
+                    const bool ok = q < items && xs >= 0 && xs < p.W;
+                    v[u] = mh_buf_load4(rsG, ok ? ((row * p.W + xs) * p.g_ld + p.coff + d4 * 4) * 4 : MH_OOB);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int q = q0 + 256 * u;
+                    if (q < items) {
+                        const int gr = (int)(((float)q + 0.5f) * inv), d4 = q - gr * D4;
+                        *reinterpret_cast<uint2*>(Gs + gr * DP + d4 * 4) = make_uint2(mh_pack_bf16(v[u].x, v[u].y), mh_pack_bf16(v[u].z, v[u].w));
+                    }
+                }
+            }
+        } else {
+            const int DP2 = DP >> 1, items = grows * DP2;
+            const float inv = 1.0f / (float)DP2;
+            for (int q0 = tid; q0 < items; q0 += 256 * U) {
+                float a[U], b[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int q = q0 + 256 * u;
+                    const int gr = (int)(((float)q + 0.5f) * inv), d = 2 * (q - gr * DP2);
+                    const int xs = gx0 + gr;
+                    const bool ok = q < items && xs >= 0 && xs < p.W;
+                    const int base = ((row * p.W + xs) * p.g_ld + p.coff + d) * 4;
+                    a[u] = mh_buf_load1(rsG, (ok && d < p.D) ? base : MH_OOB);
+                    b[u] = mh_buf_load1(rsG, (ok && d + 1 < p.D) ? base + 4 : MH_OOB);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int q = q0 + 256 * u;
+                    if (q < items) reinterpret_cast<unsigned*>(Gs)[q] = mh_pack_bf16(a[u], b[u]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    f32x4 acc[CS16];
+#pragma unroll
+    for (int cb = 0; cb < CS16; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < nks; ++ks) {
+        // A operand (band of g): row m = li, k = 8 lq + t  <->  window pixel 16 wave + 32 ks + 8 lq + t
+        unsigned short ah[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int kw = ks * 32 + lq * 8 + t;
+            // left: output pixel 16 wave + li, shift d = kw - li ; right: g pixel = window pixel 16 wave + kw, d = li - kw + 2 md
+            const int d = RIGHT ? li - kw + 2 * p.md : kw - li;
+            const int gr = RIGHT ? 16 * wave + kw : 16 * wave + li;
+            ah[t] = (d >= 0 && d < p.D) ? Gs[gr * DP + d] : (unsigned short)0;
+        }
+        const u32x4 a = (u32x4){(unsigned)ah[0] | ((unsigned)ah[1] << 16), (unsigned)ah[2] | ((unsigned)ah[3] << 16),
+                                (unsigned)ah[4] | ((unsigned)ah[5] << 16), (unsigned)ah[6] | ((unsigned)ah[7] << 16)};
+        // B operand: k = window pixel, n = channel: lane s of a 16-lane group addresses row (s >> 2), channels 4 (s & 3) .. + 3 of a [4][16] block
+        const unsigned short* Wb = Ws + (16 * wave + 32 * ks + 8 * lq + (li >> 2)) * RS + 4 * (li & 3);
+#pragma unroll
+        for (int cb = 0; cb < CS16; ++cb) {
+            const uint2 b0 = mh_lds_read_tr16(Wb + cb * 16), b1 = mh_lds_read_tr16(Wb + 4 * RS + cb * 16);
+            acc[cb] = mh_mfma_bf16(a, (u32x4){b0.x, b0.y, b1.x, b1.y}, acc[cb]);
+        }
+    }
+    __syncthreads();                                       // every wave is done with the window: its space takes the result tile
+    // acc[cb][r]: pixel 16 wave + 4 lq + r, channel 16 cb + li  ->  LDS [64 pixels][C + 4] fp32  ->  whole pixel rows
+    float* const Ts = smem;
+    constexpr int TS = C + 4;
+    const float inv_c = 1.0f / (float)C;
+#pragma unroll
+    for (int cb = 0; cb < CS16; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ts[(16 * wave + 4 * lq + r) * TS + cb * 16 + li] = acc[cb][r] * inv_c;
+    __syncthreads();
+    float* const out = RIGHT ? p.dR : p.dL;
+    const int o_ld = RIGHT ? p.dr_ld : p.dl_ld;
+    const int accf = RIGHT ? p.acc_r : p.acc_l;
+    for (int q = tid; q < 64 * (C / 4); q += 256) {
+        const int px = q / (C / 4), c4 = q - px * (C / 4);
+        const int x = x0 + px;
+        if (x >= p.W) continue;
+        float4 v = *reinterpret_cast<const float4*>(Ts + px * TS + c4 * 4);
+        float4* o = reinterpret_cast<float4*>(out + ((int64_t)row * p.W + x) * o_ld + c4 * 4);
+        if (accf) { const float4 t = *o; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        *o = v;
+    }
+}
+
 }  // namespace
 
 int mh_corr_init() {
@@ -815,12 +1106,29 @@ int mh_corr_init() {
     MH_CORRB_ATTR(1, false) MH_CORRB_ATTR(2, false) MH_CORRB_ATTR(4, false) MH_CORRB_ATTR(8, false) MH_CORRB_ATTR(16, false)
     MH_CORRB_ATTR(1, true) MH_CORRB_ATTR(2, true) MH_CORRB_ATTR(4, true) MH_CORRB_ATTR(8, true) MH_CORRB_ATTR(16, true)
 #undef MH_CORRB_ATTR
+#define MH_CORRBH_ATTR(CSv)                                                                                                    \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_bwd_mfma_bf16<CSv, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+    if (e != hipSuccess) { mh_set_error("corr: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }                 \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_bwd_mfma_bf16<CSv, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+    if (e != hipSuccess) { mh_set_error("corr: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    MH_CORRBH_ATTR(2) MH_CORRBH_ATTR(4) MH_CORRBH_ATTR(8) MH_CORRBH_ATTR(16)
+#undef MH_CORRBH_ATTR
+#define MH_CWBR_ATTR(LPPv, Dv)                                                                                                 \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_warp_bwd_row_kernel<LPPv, 5, Dv>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+    if (e != hipSuccess) { mh_set_error("corr: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    MH_CWBR_ATTR(4, false) MH_CWBR_ATTR(8, false) MH_CWBR_ATTR(16, false) MH_CWBR_ATTR(4, true) MH_CWBR_ATTR(8, true) MH_CWBR_ATTR(16, true)
+#undef MH_CWBR_ATTR
     return 0;
 }
 
 static std::atomic<int> g_corr_direct{1};
+// mh_tune_corr_row: 1 (default) = row-owned backward front end (LDS scatter), 0 = the global-atomic form
+static std::atomic<int> g_corr_row{1};
+static std::atomic<int> g_corr_remap{1};             // XCD-aware workgroup order of the large-D bf16 kernels (mh_tune_corr bit 1 clears it)
+static std::atomic<int> g_corr_det_ranges{0};        // how many deterministic ranges are registered (mh_det_sync_corr keeps it in step)
+extern "C" int mh_tune_corr_row(int on) { g_corr_row = on; return 0; }
 // tuning hook: 0 = LDS-staged window kernel, 1 = direct (no LDS) kernel for D <= 9
-extern "C" int mh_tune_corr(int direct) { g_corr_direct = direct; return 0; }
+extern "C" int mh_tune_corr(int direct) { g_corr_direct = direct & 1; g_corr_remap = (direct & 2) ? 0 : 1; return 0; }
 
 extern "C" int mh_corr_fwd(const float* L, int32_t l_ld, const float* R, int32_t r_ld, const float* u,
                            float* out, int32_t out_ld, int32_t coff,
@@ -845,7 +1153,7 @@ extern "C" int mh_corr_fwd_prec(const float* L, int32_t l_ld, const float* R, in
     CorrArgs a;
     a.L = L; a.R = R; a.u = u; a.out = out; a.l_ld = l_ld; a.r_ld = r_ld; a.out_ld = out_ld; a.coff = coff;
     a.B = B; a.H = H; a.W = W; a.C = C; a.md = max_disp; a.stride = stride; a.D = D;
-    a.copy_left = copy_left; a.zero_tail = zero_tail;
+    a.copy_left = copy_left; a.zero_tail = zero_tail; a.remap = g_corr_remap.load();
     hipStream_t s = (hipStream_t)stream;
     const int C4 = C / 4;
     const int64_t lb = (((int64_t)B * H * W - 1) * l_ld + C) * 4, rb = (((int64_t)B * H * W - 1) * r_ld + C) * 4;
@@ -973,6 +1281,19 @@ extern "C" int mh_corr_warp_bwd(const float* g, int32_t g_ld, int32_t coff, cons
     auto grid = [&](int lpp) { int64_t b = (npix * lpp + 255) / 256; return (int)(b > (1 << 20) ? (1 << 20) : b); };
     const int64_t ldmax = g_ld > rw_ld ? (g_ld > l_ld ? g_ld : l_ld) : (rw_ld > l_ld ? rw_ld : l_ld);
     const bool fast = a.D <= 5 && npix * ldmax * 4 < (1ll << 31) - 64;        // MADNet's radius-2 volumes: the branch-free form
+    // row-owned form: LDS copy of the row's right-tower gradient (W x C accumulators) + the u row; every operand under 2 GiB (buffer descriptors)
+    const bool det = g_corr_det_ranges.load() > 0;
+    const size_t row_lds = ((size_t)W * C * (det ? 8 : 4) + (size_t)W * 4 + 15) & ~(size_t)15;
+    const int64_t ldmax2 = std::max<int64_t>(std::max<int64_t>(ldmax, img_ld), std::max<int64_t>(dl_ld, dimg ? dimg_ld : 0));
+    if (g_corr_row.load() && fast && row_lds <= 150 * 1024 && npix * ldmax2 * 4 < (1ll << 31) - 64 && (int64_t)B * H < (1 << 30)) {
+        const dim3 grid((unsigned)(B * H));
+#define MH_CWB_ROW(LPPv) { if (det) hipLaunchKernelGGL((corr_warp_bwd_row_kernel<LPPv, 5, true>), grid, dim3(1024), row_lds, s, a);   \
+                           else hipLaunchKernelGGL((corr_warp_bwd_row_kernel<LPPv, 5, false>), grid, dim3(1024), row_lds, s, a); }
+        if (C4 <= 4) MH_CWB_ROW(4) else if (C4 <= 8) MH_CWB_ROW(8) else MH_CWB_ROW(16)
+#undef MH_CWB_ROW
+        mh_note_kernel("corr_warp_bwd_row_kernel<LPP=%d,DT=5%s> C=%d D=%d grid %d x 16 waves lds %d", C4 <= 4 ? 4 : C4 <= 8 ? 8 : 16, det ? ",det" : "", C, a.D, B * H, (int)row_lds);
+        return mh_check_launch("corr_warp_bwd_row");
+    }
     if (fast) {
         if (C4 <= 4) hipLaunchKernelGGL((corr_warp_bwd_kernel<4, 5>), dim3(grid(4)), dim3(256), 0, s, a);
         else if (C4 <= 8) hipLaunchKernelGGL((corr_warp_bwd_kernel<8, 5>), dim3(grid(8)), dim3(256), 0, s, a);
@@ -989,6 +1310,15 @@ extern "C" int mh_corr_bwd(const float* g, int32_t g_ld, int32_t coff, const flo
                            float* dR, int32_t dr_ld, int32_t acc_r, float* du, int32_t acc_u,
                            int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t stride,
                            int32_t copy_left, void* stream) {
+    return mh_corr_bwd_prec(g, g_ld, coff, L, l_ld, R, r_ld, dL, dl_ld, acc_l, dR, dr_ld, acc_r, du, acc_u, B, H, W, C, max_disp, stride, copy_left, 0, stream);
+}
+
+extern "C" int mh_corr_bwd_prec(const float* g, int32_t g_ld, int32_t coff, const float* L, int32_t l_ld,
+                                const float* R, int32_t r_ld, float* dL, int32_t dl_ld, int32_t acc_l,
+                                float* dR, int32_t dr_ld, int32_t acc_r, float* du, int32_t acc_u,
+                                int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t stride,
+                                int32_t copy_left, int32_t precision, void* stream) {
+    MH_REQUIRE(precision >= 0 && precision <= 2, MH_ERR_ARG, "mh_corr_bwd_prec: precision must be 0 (fp32), 1 (bf16) or 2 (split-bf16: runs as fp32)");
     MH_REQUIRE(g && L && R && dL && dR, MH_ERR_ARG, "mh_corr_bwd: null argument");
     MH_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && max_disp >= 0 && stride >= 1, MH_ERR_ARG, "mh_corr_bwd: bad dimension");
     MH_REQUIRE(C % 4 == 0 && l_ld % 4 == 0 && r_ld % 4 == 0 && dl_ld % 4 == 0 && dr_ld % 4 == 0 &&
@@ -1002,6 +1332,31 @@ extern "C" int mh_corr_bwd(const float* g, int32_t g_ld, int32_t coff, const flo
     a.B = B; a.H = H; a.W = W; a.C = C; a.md = max_disp; a.stride = stride; a.D = 2 * max_disp / stride + 1;
     a.copy_left = copy_left;
     a.total = (int64_t)B * H * W * (C / 4);
+    if (precision == 1 && g_corr_direct && a.D > MAXD_SMALL && stride == 1 && !copy_left && !du && C % 16 == 0 && C >= 32 && C <= 256 &&
+        (C == 32 || C == 64 || C == 128 || C == 256) && (int64_t)B * H * W * std::max(std::max(g_ld, l_ld), r_ld) * 4 < (1ll << 31) - 64) {
+        // bf16 operands on v_mfma_f32_16x16x32_bf16 (the arithmetic of the other gradients in the 'mixed' / 'bf16' modes)
+        const int nks = (2 * max_disp + 16 + 31) / 32, rows = 48 + 32 * nks, DPh = (((a.D + 3) & ~3) + 7) & ~7;
+        const size_t tile = (size_t)64 * (C + 4) * 4;
+        const size_t lds_l = std::max(tile, ((size_t)rows * (C + 16) + (size_t)64 * DPh) * 2), lds_r = std::max(tile, ((size_t)rows * (C + 16) + (size_t)rows * DPh) * 2);
+        if (lds_r <= 150 * 1024) {
+            const int segs = mh_cdiv(W, 64);
+            const dim3 grid(segs * B * H);
+            hipStream_t s = (hipStream_t)stream;
+            const int remap = g_corr_remap.load();
+#define MH_CORRBH(CSv)                                                                                          \
+            hipLaunchKernelGGL((corr_bwd_mfma_bf16<CSv, false>), grid, dim3(256), lds_l, s, a, segs, remap);    \
+            hipLaunchKernelGGL((corr_bwd_mfma_bf16<CSv, true>), grid, dim3(256), lds_r, s, a, segs, remap);
+            switch (C) {
+                case 32: MH_CORRBH(2) break;
+                case 64: MH_CORRBH(4) break;
+                case 128: MH_CORRBH(8) break;
+                default: MH_CORRBH(16) break;
+            }
+#undef MH_CORRBH
+            mh_note_kernel("corr_bwd_mfma_bf16<C/16=%d> left + right, grid %d x 4 waves lds %d / %d", C / 16, segs * B * H, (int)lds_l, (int)lds_r);
+            return mh_check_launch("corr_bwd_mfma_bf16");
+        }
+    }
     {   // large shift counts: banded GEMM on the MFMA (two launches: left and right gradient)
         const int nb = (2 * max_disp + 31) / 16, rows = 48 + 16 * nb, DP = (a.D + 3) & ~3;
         const size_t lds_l = ((size_t)rows * (C + 4) + 64 * DP) * sizeof(float), lds_r = ((size_t)rows * (C + 4) + (size_t)rows * DP) * sizeof(float);
@@ -1021,14 +1376,19 @@ extern "C" int mh_corr_bwd(const float* g, int32_t g_ld, int32_t coff, const flo
                 default: MH_CORRB(16) break;
             }
 #undef MH_CORRB
+            mh_note_kernel("corr_bwd_mfma<C/16=%d> left + right (exact fp32)", C / 16);
             return mh_check_launch("corr_bwd_mfma");
         }
     }
     int blocks = (int)((a.total + 255) / 256);
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(corr_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    mh_note_kernel("corr_bwd_kernel C=%d D=%d", C, a.D);
     return mh_check_launch("corr_bwd");
 }
 
 // this translation unit's copy of the deterministic-accumulation table (mh_common.h)
-extern "C" int mh_det_sync_corr(const void* t) { return mh_det_upload(*reinterpret_cast<const mh_det_table*>(t)); }
+extern "C" int mh_det_sync_corr(const void* t) {
+    g_corr_det_ranges = reinterpret_cast<const mh_det_table*>(t)->n;
+    return mh_det_upload(*reinterpret_cast<const mh_det_table*>(t));
+}

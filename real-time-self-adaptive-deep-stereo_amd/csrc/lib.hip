@@ -117,7 +117,7 @@ extern "C" int mh_device_count(void) {
 //            p[0]=in p[1]=w p[2]=bias p[3]=out p[4]=mask_ref
 //  WGRAD     same desc; i[21]=dout_ld ; p[0]=in p[1]=dout p[2]=dw p[3]=db
 //  CORR_FWD  i: l_ld r_ld out_ld coff B H W C md stride copy_left zero_tail ; p: L R u out
-//  CORR_BWD  i: g_ld coff l_ld r_ld dl_ld acc_l dr_ld acc_r acc_u B H W C md stride copy_left ; p: g L R dL dR du
+//  CORR_BWD  i: g_ld coff l_ld r_ld dl_ld acc_l dr_ld acc_r acc_u B H W C md stride copy_left precision ; p: g L R dL dR du
 //  WARP_FWD  i: img_ld out_ld B H W C ; p: img u out
 //  WARP_BWD  i: g_ld img_ld dimg_ld acc_u B H W C ; p: g img u dimg du
 //  RESIZE_*  i: B Hi Wi Hr Wr cy cx Ho Wo mode accumulate ; f[0]=mul ; FWD p: in out ; BWD p: g in din
@@ -212,9 +212,9 @@ static int run_op(const mh_op& o, void* s) {
             return mh_corr_fwd_prec((const float*)p[0], i[0], (const float*)p[1], i[1], (const float*)p[2], (float*)p[3], i[2], i[3],
                                     i[4], i[5], i[6], i[7], i[8], i[9], i[10], i[11], i[12], s);
         case MH_OP_CORR_BWD:
-            return mh_corr_bwd((const float*)p[0], i[0], i[1], (const float*)p[1], i[2], (const float*)p[2], i[3],
-                               (float*)p[3], i[4], i[5], (float*)p[4], i[6], i[7], (float*)p[5], i[8],
-                               i[9], i[10], i[11], i[12], i[13], i[14], i[15], s);
+            return mh_corr_bwd_prec((const float*)p[0], i[0], i[1], (const float*)p[1], i[2], (const float*)p[2], i[3],
+                                    (float*)p[3], i[4], i[5], (float*)p[4], i[6], i[7], (float*)p[5], i[8],
+                                    i[9], i[10], i[11], i[12], i[13], i[14], i[15], i[16], s);
         case MH_OP_WARP_FWD:
             return mh_warp_fwd((const float*)p[0], i[0], (const float*)p[1], (float*)p[2], i[1], i[2], i[3], i[4], i[5], s);
         case MH_OP_WARP_BWD:

@@ -95,6 +95,7 @@ SIGNATURES = {
     "mh_tune_conv_patch": (_I, [_I]),
     "mh_tune_wgrad_wgs": (_I, [_I]),
     "mh_tune_corr": (_I, [_I]),
+    "mh_tune_corr_row": (_I, [_I]),
     "mh_conv2d": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     "mh_conv2d_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _I, _P, _P, _P]),
     "mh_conv2d_wgrad_partial": (_I, [C.POINTER(ConvDesc), _P, _P, _I, _P, C.POINTER(C.c_int32), _P, _P]),
@@ -140,6 +141,7 @@ SIGNATURES = {
     "mh_corr_fwd_prec": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mh_level_front_fwd": (_I, [_P, _I, _I, _F, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "mh_corr_bwd": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mh_corr_bwd_prec": (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mh_shift_corr": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "mh_shift_corr_grad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "mh_warp_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),

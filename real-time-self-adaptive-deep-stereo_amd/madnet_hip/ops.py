@@ -569,9 +569,11 @@ def level_front_fwd(lib, Vc, mul, L, R, out, Rw, u, max_disp, coff, zero_tail=Tr
 
 
 def corr_bwd(lib, g, L, R, dL, dR, max_disp, stride=1, coff=0, du=None, acc_l=False, acc_r=False, acc_u=False,
-             copy_left=False, stream=None):
-    lib.corr_bwd(_p(g), g.ld, coff, _p(L), L.ld, _p(R), R.ld, _p(dL), dL.ld, int(acc_l), _p(dR), dR.ld, int(acc_r),
-                 _p(du), int(acc_u), L.B, L.H, L.W, L.C, max_disp, stride, int(copy_left), _p(stream))
+             copy_left=False, stream=None, precision=None):
+    """precision: None = the backward code of the plan being recorded; only the large-D MFMA kernels use it (1 = bf16 operands)."""
+    prec = _bwd_precision() if precision is None else precision
+    lib.corr_bwd_prec(_p(g), g.ld, coff, _p(L), L.ld, _p(R), R.ld, _p(dL), dL.ld, int(acc_l), _p(dR), dR.ld, int(acc_r),
+                      _p(du), int(acc_u), L.B, L.H, L.W, L.C, max_disp, stride, int(copy_left), int(prec), _p(stream))
 
 
 def corr_warp_bwd(lib, g, L, Rw, img, u, dL, dimg, du, max_disp, stride=1, coff=0, acc_l=False, copy_left=False, stream=None):

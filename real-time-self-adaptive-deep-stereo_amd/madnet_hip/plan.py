@@ -201,7 +201,11 @@ class Recorder(object):
 
     def corr_bwd(self, g, g_ld, coff, L, l_ld, R, r_ld, dL, dl_ld, acc_l, dR, dr_ld, acc_r, du, acc_u,
                  B, H, W, Cc, md, stride, copy_left, stream):
-        self._op(_ffi.OP_CORR_BWD, [g_ld, coff, l_ld, r_ld, dl_ld, acc_l, dr_ld, acc_r, acc_u, B, H, W, Cc, md, stride, copy_left],
+        self.corr_bwd_prec(g, g_ld, coff, L, l_ld, R, r_ld, dL, dl_ld, acc_l, dR, dr_ld, acc_r, du, acc_u, B, H, W, Cc, md, stride, copy_left, 0, stream)
+
+    def corr_bwd_prec(self, g, g_ld, coff, L, l_ld, R, r_ld, dL, dl_ld, acc_l, dR, dr_ld, acc_r, du, acc_u,
+                      B, H, W, Cc, md, stride, copy_left, precision, stream):
+        self._op(_ffi.OP_CORR_BWD, [g_ld, coff, l_ld, r_ld, dl_ld, acc_l, dr_ld, acc_r, acc_u, B, H, W, Cc, md, stride, copy_left, precision],
                  [], [g, L, R, dL, dR, du])
 
     def corr_warp_bwd(self, g, g_ld, coff, L, l_ld, Rw, rw_ld, img, img_ld, u, dL, dl_ld, acc_l, dimg, dimg_ld, du, B, H, W, Cc, md, stride, copy_left, stream):

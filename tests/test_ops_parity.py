@@ -416,10 +416,12 @@ def test_corr_fwd_large_d_bf16_and_split_bf16(backend, case):
     assert e2 <= 5e-6 and e2 * 30 <= e1, (e1, e2)          # |corr| ~ 0.3: 2^-16 relative per product, averaged over C channels
 
 
-@pytest.mark.parametrize("case", [(1, 12, 40, 32, 2, 1), (2, 9, 21, 96, 2, 1), (1, 7, 33, 64, 2, 1), (1, 6, 20, 192, 2, 1), (1, 10, 17, 16, 1, 1)])
-def test_corr_warp_bwd_fused_matches_corr_bwd_then_warp_bwd(backend, case):
+@pytest.mark.parametrize("form", ["row", "atomic"])
+@pytest.mark.parametrize("case", [(1, 12, 40, 32, 2, 1), (2, 9, 21, 96, 2, 1), (1, 7, 33, 64, 2, 1), (1, 6, 20, 192, 2, 1), (1, 10, 17, 16, 1, 1), (1, 3, 300, 32, 2, 1)])
+def test_corr_warp_bwd_fused_matches_corr_bwd_then_warp_bwd(backend, case, form):
     """mh_corr_warp_bwd = mh_corr_bwd (warped right features as the right operand, fused concat form) + mh_warp_bwd of its result in one launch: dL and the
-    coordinate gradient du are compared with the two-launch sequence at rounding level, the atomic scatter with the tolerance of its summation order."""
+    coordinate gradient du are compared with the two-launch sequence at rounding level, the scatter with the tolerance of its summation order.
+    form: 'row' = the row-owned kernel (LDS scatter, round 5: the default), 'atomic' = the global-atomic kernel (mh_tune_corr_row(0))."""
     B, H, W, Cc, md, stride = case
     dev = backend.device
     D = 2 * md // stride + 1
@@ -427,33 +429,110 @@ def test_corr_warp_bwd_fused_matches_corr_bwd_then_warp_bwd(backend, case):
     g = torch.randn(B, H, W, ld, device=dev)
     L = torch.randn(B, H, W, Cc, device=dev); R = torch.randn(B, H, W, Cc, device=dev)
     u = (torch.rand(B, H, W, device=dev) - 0.5) * 6.0
+    if W >= 100:
+        u = u * 20.0                      # taps far from their pixel, many of them clamped / masked at the row ends
     Rw = torch.zeros(B, H, W, Cc, device=dev)
     ops.warp_fwd(backend.lib, ops.view(R), u, ops.view(Rw))
     gv = ops.View(g, B, H, W, ld, ld)
     outs = []
-    for fused in (False, True):
-        dL = torch.full((B, H, W, Cc), 0.25, device=dev)                 # acc_l: accumulate onto an earlier contribution
-        dimg = torch.full((B, H, W, Cc), -0.5, device=dev)              # the scatter target holds an earlier contribution too
-        du = torch.full((B, H, W), float("nan"), device=dev)
-        if fused:
-            ops.corr_warp_bwd(backend.lib, gv, ops.view(L), ops.view(Rw), ops.view(R), u, ops.view(dL), ops.view(dimg), du, md, stride, coff=Cc, acc_l=True, copy_left=True)
-            assert "corr_warp_bwd_kernel" in backend.lib.last_kernel().decode()
-        else:
-            dRw = torch.zeros(B, H, W, Cc, device=dev)
-            ops.corr_bwd(backend.lib, gv, ops.view(L), ops.view(Rw), ops.view(dL), ops.view(dRw), md, stride, coff=Cc, du=du, acc_l=True, acc_r=False, acc_u=False, copy_left=True)
-            ops.warp_bwd(backend.lib, ops.view(dRw), ops.view(R), u, ops.view(dimg), du=du, acc_u=True)
+    backend.lib.tune_corr_row(1 if form == "row" else 0)
+    try:
+        for fused in (False, True):
+            dL = torch.full((B, H, W, Cc), 0.25, device=dev)                 # acc_l: accumulate onto an earlier contribution
+            dimg = torch.full((B, H, W, Cc), -0.5, device=dev)              # the scatter target holds an earlier contribution too
+            du = torch.full((B, H, W), float("nan"), device=dev)
+            if fused:
+                ops.corr_warp_bwd(backend.lib, gv, ops.view(L), ops.view(Rw), ops.view(R), u, ops.view(dL), ops.view(dimg), du, md, stride, coff=Cc, acc_l=True, copy_left=True)
+                assert ("corr_warp_bwd_row_kernel" if form == "row" else "corr_warp_bwd_kernel") in backend.lib.last_kernel().decode()
+            else:
+                dRw = torch.zeros(B, H, W, Cc, device=dev)
+                ops.corr_bwd(backend.lib, gv, ops.view(L), ops.view(Rw), ops.view(dL), ops.view(dRw), md, stride, coff=Cc, du=du, acc_l=True, acc_r=False, acc_u=False, copy_left=True)
+                ops.warp_bwd(backend.lib, ops.view(dRw), ops.view(R), u, ops.view(dimg), du=du, acc_u=True)
+            backend.sync()
+            outs.append((dL.cpu(), dimg.cpu(), du.cpu()))
+        (dL0, di0, du0), (dL1, di1, du1) = outs
+        assert torch.isfinite(du1).all()
+        assert (dL0 - dL1).abs().max().item() <= 1e-6 * max(1.0, dL0.abs().max().item())
+        assert (du0 - du1).abs().max().item() <= 2e-5 * max(1.0, du0.abs().max().item())
+        assert (di0 - di1).abs().max().item() <= 2e-5 * max(1.0, di0.abs().max().item())
+        # du only / scatter only
+        du2 = torch.full((B, H, W), float("nan"), device=dev); dL2 = torch.zeros(B, H, W, Cc, device=dev)
+        ops.corr_warp_bwd(backend.lib, gv, ops.view(L), ops.view(Rw), ops.view(R), u, ops.view(dL2), None, du2, md, stride, coff=Cc, copy_left=True)
+        dimg3 = torch.full((B, H, W, Cc), -0.5, device=dev); dL3 = torch.zeros(B, H, W, Cc, device=dev)
+        ops.corr_warp_bwd(backend.lib, gv, ops.view(L), ops.view(Rw), ops.view(R), u, ops.view(dL3), ops.view(dimg3), None, md, stride, coff=Cc, copy_left=True)
         backend.sync()
-        outs.append((dL.cpu(), dimg.cpu(), du.cpu()))
-    (dL0, di0, du0), (dL1, di1, du1) = outs
-    assert torch.isfinite(du1).all()
-    assert (dL0 - dL1).abs().max().item() <= 1e-6 * max(1.0, dL0.abs().max().item())
-    assert (du0 - du1).abs().max().item() <= 2e-5 * max(1.0, du0.abs().max().item())
-    assert (di0 - di1).abs().max().item() <= 2e-5 * max(1.0, di0.abs().max().item())
-    # du only / scatter only
-    du2 = torch.full((B, H, W), float("nan"), device=dev); dL2 = torch.zeros(B, H, W, Cc, device=dev)
-    ops.corr_warp_bwd(backend.lib, gv, ops.view(L), ops.view(Rw), ops.view(R), u, ops.view(dL2), None, du2, md, stride, coff=Cc, copy_left=True)
+        assert (du2.cpu() - du1).abs().max().item() <= 2e-5 * max(1.0, du1.abs().max().item())
+        assert (dimg3.cpu() - di1).abs().max().item() <= 2e-5 * max(1.0, di1.abs().max().item())
+        assert (dL3.cpu() - dL2.cpu()).abs().max().item() == 0.0
+    finally:
+        backend.lib.tune_corr_row(1)
+
+
+def test_corr_warp_bwd_row_form_is_deterministic_without_a_twin(backend):
+    """With a deterministic range registered (mh_deterministic_add) the row-owned kernel accumulates its LDS row in 64-bit fixed point: two launches on
+    the same operands give bit-identical scatters (the global-atomic form needs the range's fixed-point twin + mh_det_flush for that), equal to the
+    fp32 LDS form at rounding level."""
+    B, H, W, Cc, md = 1, 6, 70, 32, 2
+    dev = backend.device
+    D = 2 * md + 1
+    ld = (Cc + D + 1 + 3) // 4 * 4
+    g = torch.randn(B, H, W, ld, device=dev)
+    L = torch.randn(B, H, W, Cc, device=dev); R = torch.randn(B, H, W, Cc, device=dev)
+    u = (torch.rand(B, H, W, device=dev) - 0.5) * 9.0
+    Rw = torch.zeros(B, H, W, Cc, device=dev)
+    ops.warp_fwd(backend.lib, ops.view(R), u, ops.view(Rw))
+    gv = ops.View(g, B, H, W, ld, ld)
+
+    def run():
+        dL = torch.zeros(B, H, W, Cc, device=dev); dimg = torch.full((B, H, W, Cc), 0.125, device=dev); du = torch.zeros(B, H, W, device=dev)
+        ops.corr_warp_bwd(backend.lib, gv, ops.view(L), ops.view(Rw), ops.view(R), u, ops.view(dL), ops.view(dimg), du, md, 1, coff=Cc, copy_left=True)
+        backend.sync()
+        return dimg.cpu(), backend.lib.last_kernel().decode()
+
+    plain, k0 = run()
+    assert "corr_warp_bwd_row_kernel" in k0 and "det" not in k0
+    import ctypes as C
+    other = torch.zeros(64, device=dev); twin = torch.zeros(64, dtype=torch.int64, device=dev)          # an unrelated registered range switches the mode on
+    assert backend.lib.deterministic_add(C.c_void_p(other.data_ptr()), 64, C.c_void_p(twin.data_ptr())) == 0
+    try:
+        a, k1 = run()
+        b, _ = run()
+    finally:
+        backend.lib.deterministic_remove(C.c_void_p(other.data_ptr()))
+    assert ",det" in k1
+    assert torch.equal(a, b)
+    assert (a - plain).abs().max().item() <= 2e-5 * max(1.0, plain.abs().max().item())
+
+
+@pytest.mark.parametrize("case", [(1, 2, 70, 128, 40), (2, 1, 131, 64, 40), (1, 2, 40, 32, 10), (1, 1, 200, 256, 24)])
+def test_corr_bwd_large_d_bf16(backend, case):
+    """Gradient of DispNet's 81-shift volume on the bf16 matrix cores (mh_corr_bwd_prec, precision 1): judged against autograd of the TF formulation
+    (sharedLayers.py:41-51) on bf16-ROUNDED g, L, R (products of bf16 values are exact in fp32: only the summation order is left), and against the exact
+    fp32 kernel pair at bf16 level; ragged row ends, both borders, accumulate flags, a g buffer with channels behind the volume."""
+    B, H, W, C, md = case
+    dev = backend.device
+    D = 2 * md + 1
+    ld = (D + 5 + 3) // 4 * 4
+    L = _rand((B, H, W, C), 81, dev); R = _rand((B, H, W, C), 82, dev)
+    g = _rand((B, H, W, ld), 83, dev)
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    Lr = bf(L.cpu()).double().requires_grad_(True); Rr = bf(R.cpu()).double().requires_grad_(True)
+    out = T.correlation(Lr, Rr, md, 1)
+    (out * bf(g.cpu()[..., :D]).double()).sum().backward()
+    gv = ops.View(g, B, H, W, D, ld)
+    dL = torch.full((B, H, W, C), 0.5, device=dev); dR = torch.full((B, H, W, C), float("nan"), device=dev)
+    ops.corr_bwd(backend.lib, gv, ops.view(L), ops.view(R), ops.view(dL), ops.view(dR), md, 1, coff=0, acc_l=True, acc_r=False, precision=1)
+    k = backend.lib.last_kernel().decode()
     backend.sync()
-    assert (du2.cpu() - du1).abs().max().item() <= 2e-5 * max(1.0, du1.abs().max().item())
+    assert "corr_bwd_mfma_bf16" in k, k
+    sc = max(1.0, Lr.grad.abs().max().item())
+    assert (dL.cpu() - 0.5 - Lr.grad.float()).abs().max().item() <= 2e-6 * sc
+    assert (dR.cpu() - Rr.grad.float()).abs().max().item() <= 2e-6 * sc
+    dL0 = torch.zeros(B, H, W, C, device=dev); dR0 = torch.zeros(B, H, W, C, device=dev)
+    ops.corr_bwd(backend.lib, gv, ops.view(L), ops.view(R), ops.view(dL0), ops.view(dR0), md, 1, coff=0, precision=0)
+    backend.sync()
+    assert "bf16" not in backend.lib.last_kernel().decode()
+    assert (dL.cpu() - 0.5 - dL0.cpu()).abs().max().item() <= 2e-2 * sc and (dR.cpu() - dR0.cpu()).abs().max().item() <= 2e-2 * sc
 
 
 @pytest.mark.parametrize("case", [(1, 12, 40, 32), (2, 9, 21, 32), (1, 3, 5, 32), (1, 24, 80, 16), (1, 1, 2, 32)])
