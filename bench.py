@@ -119,7 +119,7 @@ class Dev(object):
             self.stream = torch.cuda.Stream()
             self.sh = self.stream.cuda_stream
         else:
-            self.ndev, self.index, self.name, self.stream, self.sh = 0, 0, "cpu", None, 0
+            self.ndev, self.index, self.name, self.stream, self.sh = 0, 0, "cpu", _NoStream(), 0
 
     def ctx(self):
         return self.torch.cuda.stream(self.stream) if self.kind == "cuda" else _Null()
@@ -131,6 +131,14 @@ class Dev(object):
     def sync(self):
         if self.kind == "cuda":
             self.torch.cuda.synchronize()
+
+
+class _NoStream(object):
+    """--device cpu (plumbing tests): what the roofline helpers ask of a torch stream"""
+    cuda_stream = 0
+
+    def synchronize(self):
+        pass
 
 
 class _Null(object):
@@ -357,6 +365,259 @@ def apply_overrides(items, lib, E):
     return per_engine
 
 
+class BoxSampler(object):
+    """GPU clock / power of the bench device sampled from sysfs (hwmon freq1_input / power1_average, pp_dpm_sclk) by a host thread every 50 ms while a
+    timed region runs (is a slow box a clock / power state?).  Files that do not exist are skipped; no tool is spawned."""
+
+    def __init__(self, index=0):
+        import glob
+        self.files = {}
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+        cards = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk")) or glob.glob(os.path.join(c, "hwmon/hwmon*/freq1_input"))]
+        if cards:
+            c = cards[min(index, len(cards) - 1)]
+            for key, pat in (("sclk_hz", "hwmon/hwmon*/freq1_input"), ("power_uw", "hwmon/hwmon*/power1_average"), ("power_uw", "hwmon/hwmon*/power1_input"),
+                             ("temp_mc", "hwmon/hwmon*/temp1_input")):
+                g = glob.glob(os.path.join(c, pat))
+                if g and key not in self.files:
+                    self.files[key] = g[0]
+            if os.path.exists(os.path.join(c, "pp_dpm_sclk")):
+                self.files["dpm_sclk"] = os.path.join(c, "pp_dpm_sclk")
+        self.samples = []
+        self._stop = None
+
+    def _read(self):
+        out = {}
+        for k, f in self.files.items():
+            try:
+                t = open(f).read()
+                if k == "dpm_sclk":
+                    cur = [ln for ln in t.splitlines() if ln.strip().endswith("*")]
+                    if cur:
+                        out["dpm_sclk_mhz"] = float(cur[0].split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+                else:
+                    out[k] = float(t.strip())
+            except Exception:
+                pass
+        return out
+
+    def __enter__(self):
+        import threading
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                r = self._read()
+                if r:
+                    self.samples.append(r)
+                self._stop.wait(0.05)
+        self.idle = self._read()
+        self._t = threading.Thread(target=loop, daemon=True)
+        if self.files:
+            self._t.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self.files:
+            self._t.join(timeout=1.0)
+        return False
+
+    def summary(self):
+        if not self.samples:
+            return None
+
+        def stat(key, scale):
+            v = [x[key] * scale for x in self.samples if key in x]
+            return {"min": min(v), "median": statistics.median(v), "max": max(v)} if v else None
+        out = {"samples": len(self.samples), "sclk_mhz_during_replay": stat("sclk_hz", 1e-6) or stat("dpm_sclk_mhz", 1.0),
+               "power_w_during_replay": stat("power_uw", 1e-6), "temp_c_during_replay": stat("temp_mc", 1e-3)}
+        if "sclk_hz" in self.idle:
+            out["sclk_mhz_before"] = self.idle["sclk_hz"] * 1e-6
+        if "power_uw" in self.idle:
+            out["power_w_before"] = self.idle["power_uw"] * 1e-6
+        return out
+
+
+def _short_regions(dev, one_step, steps, seconds=0.5, repeats=3):
+    """median ms/step of `repeats` timed regions of >= `seconds` (a config of the `configs` block: shorter than the headline's five 1-s regions)"""
+    inner = inner_reps(dev, None, one_step, steps, seconds)
+    reg = timed_regions(dev, None, one_step, steps, repeats, inner)
+    tb = timing_block(reg, steps, inner)
+    return tb["ms_per_step_median"], {"repeats": repeats, "timed_steps_per_repeat": steps * inner, "ms_per_step_all": tb["ms_per_step_all"]}
+
+
+def config_mad(args, lib, dev, wn, l, r, gt, BT):
+    """BASELINE config 3 inside the driver's one command: MADNet MAD modular adaptation (block_config/MadNet_piramid_only.json, --sampleMode PROBABILITY
+    --numBlocks 1, np.random.seed(0): SURVEY 8(d)) through Nets.get_stereo_net + Adapter.step, i.e. with the host sampling + loss read-back of the
+    reference's loop body (Stereo_Online_Adaptation.py:178-253).  Returns (entry, context for the CPU leg)."""
+    import numpy as np
+    import torch
+    import Nets
+    from madnet_hip.adapter import Adapter
+    tl, tr, tg = (torch.from_numpy(a).to(dev.name) for a in (l, r, gt[..., 0]))
+    net = Nets.get_stereo_net("MADNet", {"left_img": tl, "right_img": tr, "split_layers": [None], "sequence": True, "train_portion": "BEGIN", "bulkhead": True,
+                                         "weights": wn, "precision": args.precision, "warping": True, "context_net": True, "radius_d": 2, "stride": 1})
+    cfg_name = "MadNet_piramid_only.json"
+    cfg = json.load(open(os.path.join(PKG, "block_config", cfg_name)))
+    np.random.seed(0)
+    ad = Adapter(net, mode="MAD", block_config=cfg, lr=1e-4, sample_mode="PROBABILITY", num_blocks=1, use_graph=not args.no_graph)
+    for i in range(len(cfg)):
+        ad._plan((i,))
+    first = ad.step(tl, tr, tg)
+    dev.sync()
+    pred0 = first["disparity"].detach().float().cpu().clone()           # forward pass with the PRE-update weights = the bench weights
+    last = {}
+
+    def one_step():
+        last["o"] = ad.step(tl, tr, tg)
+
+    for _ in range(args.warmup):
+        one_step()
+    ms, tb = _short_regions(dev, one_step, args.steps)
+    tot = float(sum(ad.fetch_counter))
+    shares = [c / tot for c in ad.fetch_counter]
+    ent = {"metric": "adapted stereo pairs/sec, MADNet MAD modular online adaptation 1242x375", "value": 1e3 / ms, "unit": "pairs/s", "ms_per_step": ms, "timing": tb,
+           "config": {"workload": "MADNet MAD adaptation step via Nets.get_stereo_net + Adapter.step (host block sampling, forward + loss + EPE + one block's backward + update, "
+                                  "loss read-back every step), %dx%d, 1 pair/GPU/step, %s, sampleMode PROBABILITY, numBlocks 1, np.random.seed(0)" % (args.width, args.height, cfg_name),
+                      "precision": args.precision, "launch": "hipGraph replay per sampled block", "fetch_counter": list(ad.fetch_counter),
+                      "ops_per_step_by_block": [ad._plan((i,))[0].n for i in range(len(cfg))], "final_loss": last["o"]["loss"], "epe_vs_synthetic_gt": last["o"]["epe"]}}
+    if not args.no_roofline:
+        with dev.ctx():
+            rep = BT.family_report(lib, [ad._plan((i,))[0] for i in range(len(cfg))], dev.stream, weights=shares)
+        ent["roofline"] = rep["roofline"]
+        ent["roofline"]["weights"] = "launch table of every block's plan, weighted by the share of the timed steps that sampled the block"
+        ent["kernel_families"] = rep["kernel_families"]
+        ent["kernel_time_sum_us"] = rep["kernel_time_sum_us"]
+    top = max(range(len(cfg)), key=lambda i: ad.fetch_counter[i])
+    return ent, {"pred0": pred0, "block_index": top, "block_vars": list(ad.blocks[top][1]), "shares": shares}
+
+
+def config_dispnet(args, lib, dev, l, r, gt, BT):
+    """BASELINE config 4 inside the driver's one command: DispNet (Nets/DispNet.py:75-152, block_config/dispnet_full.json is only usable with FULL: SURVEY
+    App. C) full-backprop adaptation step, 81-shift correlation volume."""
+    import torch
+    from madnet_hip import dispnet_engine as DE, synthetic as S
+    wn = S.calibrated_weights(dict(DE.dispnet_manifest()), 1)
+    H, W = args.height, args.width
+    mk = lambda: DE.DispNetEngine(lib, H, W, B=1, device=dev.name, weights=wn, precision=args.precision)
+    e0 = mk(); e0.set_inputs(l, r, gt[..., 0])
+    e0.build_plan("NONE").run(lib, 0)
+    dev.sync()
+    pred0 = e0.pred.cpu().clone()
+    del e0
+    eng = mk(); eng.set_inputs(l, r, gt[..., 0])
+    plan = eng.build_plan("FULL", lr=1e-4)
+    with dev.ctx():
+        plan.run(lib, dev.sh)
+        dev.sync_stream()
+        if dev.kind == "cuda" and not args.no_graph:
+            plan.capture(lib, dev.sh)
+
+        def one_step():
+            plan.launch(lib, dev.sh)
+        for _ in range(args.warmup):
+            one_step()
+        dev.sync_stream()
+        ms, tb = _short_regions(dev, one_step, args.steps)
+    st = plan.stats
+    flops = st.get("conv_flops", 0.0) + st.get("wgrad_flops", 0.0)
+    ent = {"metric": "adapted stereo pairs/sec, DispNet full-backprop online adaptation 1242x375", "value": 1e3 / ms, "unit": "pairs/s", "ms_per_step": ms, "timing": tb,
+           "config": {"workload": "DispNet FULL adaptation step (fwd + SSIM/L1 loss + EPE + bwd + momentum), %dx%d, 1 pair/GPU/step, 81-shift correlation volume" % (W, H),
+                      "precision": args.precision, "launch": "hipGraph replay", "ops_per_step": plan.n, "final_loss": float(eng.res_loss[0].item()),
+                      "epe_vs_synthetic_gt": float(eng.res_met[0].item()), "pred_nonzero_frac": float((eng.pred != 0).float().mean().item())},
+           "step_aggregate": {"conv_gflop_per_step": flops / 1e9, "achieved_tflops": flops / (ms * 1e-3) / 1e12, "step_mfma_frac": flops / (ms * 1e-3) / 1e12 / BT.PEAK_BF16_MFMA_TFLOPS}}
+    if not args.no_roofline:
+        e_t = mk(); e_t.set_inputs(l, r, gt[..., 0])
+        p_t = e_t.build_plan("FULL", lr=1e-4)
+        with dev.ctx():
+            rep = BT.family_report(lib, [p_t], dev.stream)
+        ent["roofline"] = rep["roofline"]
+        ent["kernel_families"] = rep["kernel_families"]
+        ent["kernel_time_sum_us"] = rep["kernel_time_sum_us"]
+        ent["box"] = {"replay_over_launch_sum": ms * 1e3 / rep["kernel_time_sum_us"] if rep["kernel_time_sum_us"] else None}
+        del e_t, p_t
+    return ent, {"pred0": pred0, "wn": wn}
+
+
+def config_private(args, lib, dev, mk, S_, rank, BT, nstreams=4):
+    """SURVEY 8(e) "several streams per GPU": `nstreams` independent stereo streams with PRIVATE models on this GPU, their FULL step chains as parallel
+    branches of ONE hipGraph (mh_plans_run); value = pairs/s over all streams."""
+    from madnet_hip.plan import MultiPlan
+    H, W = args.height, args.width
+    engines, plans = [], []
+    for i in range(nstreams):
+        e = mk(args.precision)
+        e.wgrad_lanes = 0            # serial chain per branch (a fork inside a forked branch crashes hipStreamEndCapture on ROCm 7.2: profiles/r03_experiments.txt #15)
+        li, ri, gi = S_.make_pair(H, W, stream_id=1000 * (rank + 1) + i)
+        e.set_inputs(li, ri, gi[..., 0])
+        plans.append(e.build_plan("FULL", lr=1e-4))
+        engines.append(e)
+    mp = MultiPlan(plans)
+    with dev.ctx():
+        mp.run(lib, dev.sh)
+        dev.sync_stream()
+        if dev.kind == "cuda":
+            mp.capture(lib, dev.sh)
+
+        def one_step():
+            mp.launch(lib, dev.sh)
+        for _ in range(args.warmup):
+            one_step()
+        dev.sync_stream()
+        ms, tb = _short_regions(dev, one_step, args.steps)
+    ent = {"metric": "adapted stereo pairs/sec over %d private-model streams on ONE GPU, MADNet full-backprop 1242x375" % nstreams, "value": nstreams * 1e3 / ms, "unit": "pairs/s",
+           "ms_per_step": ms, "pairs_per_step": nstreams, "timing": tb,
+           "config": {"workload": "MADNet FULL adaptation step x %d independent streams with private models (weights, momentum, frames), branches of one hipGraph" % nstreams,
+                      "precision": args.precision, "launch": "hipGraph replay (mh_plans_run)", "ops_per_step": sum(p.n for p in plans),
+                      "final_loss_per_stream": [float(e.res_loss[0].item()) for e in engines]},
+           "grouped_launch_ceiling": "one grid per layer serving all streams (per-stream weight pointers, SURVEY 8(e)) computes what --streams-per-gpu %d (shared model, batched "
+                                     "through the same kernels) computes plus the weight indirection: that batched form is its upper bound -- see configs.batched4" % nstreams}
+    if not args.no_roofline:
+        with dev.ctx():
+            rep = BT.family_report(lib, [plans[0]], dev.stream)
+        ent["roofline"] = rep["roofline"]
+        ent["roofline"]["note"] = "launch table of ONE stream's serial chain (every launch timed alone); the %d chains share the chip in the replay" % nstreams
+        ent["kernel_time_sum_us_one_stream"] = rep["kernel_time_sum_us"]
+    return ent
+
+
+def config_batched(args, lib, dev, wn, S_, rank, nstreams=4):
+    """the same `nstreams` streams sharing ONE model, batched through the same kernels (B = nstreams): what a grouped launch with per-stream weight
+    pointers would compute, minus the pointer indirection -- the ceiling of that design"""
+    import numpy as np
+    from madnet_hip import engine as E
+    H, W = args.height, args.width
+    e = E.MadNetEngine(lib, H, W, B=nstreams, device=dev.name, weights=wn, precision=args.precision)
+    pairs = [S_.make_pair(H, W, stream_id=1000 * (rank + 1) + i) for i in range(nstreams)]
+    e.set_inputs(np.concatenate([q[0] for q in pairs]), np.concatenate([q[1] for q in pairs]), np.concatenate([q[2][..., 0] for q in pairs]))
+    plan = e.build_plan("FULL", lr=1e-4)
+    with dev.ctx():
+        plan.run(lib, dev.sh)
+        dev.sync_stream()
+        if dev.kind == "cuda":
+            plan.capture(lib, dev.sh)
+
+        def one_step():
+            plan.launch(lib, dev.sh)
+        for _ in range(args.warmup):
+            one_step()
+        dev.sync_stream()
+        ms, tb = _short_regions(dev, one_step, args.steps)
+    return {"metric": "adapted stereo pairs/sec over %d streams sharing one model on ONE GPU (batched), MADNet full-backprop 1242x375" % nstreams, "value": nstreams * 1e3 / ms,
+            "unit": "pairs/s", "ms_per_step": ms, "pairs_per_step": nstreams, "timing": tb, "config": {"workload": "MADNet FULL adaptation step, B = %d" % nstreams, "ops_per_step": plan.n}}
+
+
+def cpu_leg(fn, steps, what, cores):
+    """`steps` timed calls of fn() after one warm-up call -> cpu_baseline entry (kind 'port': the torch-CPU oracle; TensorFlow cannot run here)"""
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "pairs/s", "cores": cores, "kind": "port", "sample": what % steps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -402,6 +663,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-step-surface", action="store_true")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` block of the default line (BASELINE configs 3 / 4 = MAD / DispNet, 4 private-model streams, their batched ceiling) and the "
+                         "extra correlation rooflines")
+    ap.add_argument("--extras-on-cpu", action="store_true", help="--device cpu only (tests): also walk the roofline / paths / configs code of the default line on the emulator")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
                     help="cpu = plumbing test of the launcher path only (emulator library via MADNET_HIP_LIB, gloo); never a result")
     args = ap.parse_args()
@@ -578,7 +843,8 @@ def main():
             one_step()
         dev.sync_stream()
         inner = inner_reps(dev, dist, one_step, args.steps, args.min_region_seconds)
-        regions = timed_regions(dev, dist, one_step, args.steps, args.repeats, inner)
+        with BoxSampler(dev.index) as box_sampler:
+            regions = timed_regions(dev, dist, one_step, args.steps, args.repeats, inner)
     tb = timing_block(regions, args.steps, inner)
     ms = tb["ms_per_step_median"]
     _log("timed regions done: median %.3f ms/step (min %.3f, max %.3f)" % (ms, tb["ms_per_step_min"], tb["ms_per_step_max"]))
@@ -666,74 +932,44 @@ def main():
         out["epe_tolerance"] = 1e-3
         out["within_tolerance"] = out["epe_vs_oracle"] <= 1e-3
         del e0
-    extras = rank == 0 and world == 1 and not dispnet and SB == 1 and CS == 1 and not shared and dev.kind == "cuda" and args.mode == "FULL"
+    extras = rank == 0 and world == 1 and not dispnet and SB == 1 and CS == 1 and not shared and (dev.kind == "cuda" or args.extras_on_cpu) and args.mode == "FULL"
+    if args.extras_on_cpu:
+        BT.WARMUP_LAUNCHES, BT.TABLE_REPS = 0, 1
     if extras:
         if not args.no_roofline:
-            with dev.ctx():
-                out["roofline_fwd"], extra = BT.roofline(lib, eng, dev.stream)
-            out.update(extra)
+            if dev.kind == "cuda":         # (the emulator's events read 0 ms)
+                with dev.ctx():
+                    out["roofline_fwd"], extra = BT.roofline(lib, eng, dev.stream)
+                out.update(extra)
             # top-level `roofline` = the kernel family the recorded plan spends most of its time in (every op of the plan timed alone on a
-            # scratch engine), priced on its most expensive launch: algorithmic flops / time / the DENSE bf16 MFMA peak
+            # scratch engine): algorithmic flops / time / the DENSE bf16 MFMA peak; PMC traffic keyed by kernel string
             try:
                 e_t = mk(args.precision); feed(e_t)
                 p_t = e_t.build_plan(args.mode, lr=1e-4)
                 with dev.ctx():
-                    rows, fam = BT.plan_table(lib, p_t, dev.stream)
-                tot = sum(r[3] for r in rows)
-                name, f = next(iter(fam.items()))
-                i_top = f["top_index"]
-                kn = rows[i_top][2]
-                fam_rows = [rw for rw in rows if BT.family_key(rw[2]) == name]
-                fl = sum(p_t.work.get(rw[0], BT.op_work(p_t.arr[rw[0]]))[0] for rw in fam_rows)
-                by = sum(p_t.work.get(rw[0], BT.op_work(p_t.arr[rw[0]]))[1] for rw in fam_rows)
-                fl_top = p_t.work.get(i_top, BT.op_work(p_t.arr[i_top]))[0]
-                peak = BT.PEAK_F32_MFMA_TFLOPS if (",f32," in kn.replace(" ", "") or "wgrad_kernel<" in kn) else BT.PEAK_BF16_MFMA_TFLOPS
-                ach = fl / (f["us_per_step"] * 1e-6) / 1e12 if f["us_per_step"] > 0 else 0.0
-                trs = [BT._pmc_traffic(rw[2]) for rw in fam_rows]
-                tr = sum(trs) if all(t is not None for t in trs) else None
-                out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                                   "mfma_issue_frac": (3.0 if "bf16x3" in kn else 1.0) * ach / peak,
-                                   "traffic": tr, "traffic_source": ("%s: sum over this family's launches, keyed by their kernel strings (rocprofv3 --pmc "
-                                                                     "FETCH_SIZE / WRITE_SIZE passes over the same plan: scripts/gpu_pmc_r04.sh)" % BT.PMC_SOURCE) if tr is not None else None,
-                                   "launch_ms": f["us_per_step"] * 1e-3 / f["launches"], "launches_per_step": f["launches"], "us_per_step": f["us_per_step"],
-                                   "algorithmic_flops_per_step": fl, "algorithmic_bytes_per_step": by,
-                                   "share_of_kernel_time": f["us_per_step"] / tot if tot else None,
-                                   "longest_launch": {"kernel": kn, "plan_op_index": i_top, "launch_ms": f["top_us"] * 1e-3,
-                                                      "achieved": fl_top / (f["top_us"] * 1e-6) / 1e12 if f["top_us"] > 0 else None,
-                                                      "frac": fl_top / (f["top_us"] * 1e-6) / 1e12 / peak if f["top_us"] > 0 else None,
-                                                      "traffic": BT._pmc_traffic(kn)},
-                                   "selection": "the kernel family the recorded plan spends most time in, from the plan's own launch table (every op timed alone with HIP events, "
-                                                "10 launches each); achieved = the family's algorithmic flops per step / its summed launch time; frac against the DENSE bf16 MFMA peak"}
-                # every family of the table: time, algorithmic work and -- where the committed PMC passes cover all of its launches -- HBM traffic
-                kf = []
-                for k, v in list(fam.items())[:12]:
-                    rws = [rw for rw in rows if BT.family_key(rw[2]) == k]
-                    wk = [p_t.work.get(rw[0], BT.op_work(p_t.arr[rw[0]])) for rw in rws]
-                    f_fl, f_by = sum(x[0] for x in wk), sum(x[1] for x in wk)
-                    f_tr = [BT._pmc_traffic(rw[2]) for rw in rws]
-                    f_peak = BT.PEAK_F32_MFMA_TFLOPS if (",f32," in k.replace(" ", "") or "wgrad_kernel<" in k) else BT.PEAK_BF16_MFMA_TFLOPS
-                    ent = {"kernel": k, "launches": v["launches"], "us_per_step": v["us_per_step"]}
-                    if f_fl > 0 and v["us_per_step"] > 0:
-                        ent["achieved_tflops"] = f_fl / (v["us_per_step"] * 1e-6) / 1e12
-                        ent["frac"] = ent["achieved_tflops"] / f_peak
-                    if f_by > 0 and v["us_per_step"] > 0:
-                        ent["algorithmic_gbs"] = f_by / (v["us_per_step"] * 1e-6) / 1e9
-                        ent["hbm_frac"] = ent["algorithmic_gbs"] / BT.PEAK_HBM_GBS
-                        ent["algorithmic_bytes_per_step"] = f_by
-                    ent["traffic"] = sum(f_tr) if f_tr and all(t is not None for t in f_tr) else None
-                    kf.append(ent)
-                out["kernel_families"] = kf
-                out["kernel_time_sum_us"] = tot
+                    rep = BT.family_report(lib, [p_t], dev.stream)
+                out["roofline"] = rep["roofline"]
+                out["kernel_families"] = rep["kernel_families"]
+                tot = out["kernel_time_sum_us"] = rep["kernel_time_sum_us"]
                 # Is this box throttling?  The replayed step against the sum of its launches timed ALONE in short bursts (the plan table): ~1.0 on a healthy
                 # MI355X (the side lane hides about what the dependencies cost); one box of the builder's pool ran every chip-filling kernel ~1.8x slower
                 # INSIDE the sustained replay while the same launches were normal stand-alone: 2.06 ms against a 1.43 ms launch sum = 1.44
                 # (profiles/r04_bench_line_slow_box.json).  A reader comparing rounds or boxes should look at this number first.
                 out["box"] = {"replay_over_launch_sum": (ms * 1e3) / tot if tot else None,
                               "note": "ms_per_step / sum of the plan's launches timed alone; ~1.0 = healthy, >= 1.3 = the GPU slows down under the sustained replay "
-                                      "(power / thermal state of the box), not a property of the build"}
+                                      "(power / thermal state of the box), not a property of the build; sclk / power: sysfs samples every 50 ms during the timed regions"}
+                bs = box_sampler.summary()
+                if bs:
+                    out["box"].update(bs)
                 del e_t, p_t
             except Exception as ex:      # never let the auxiliary measurement kill the bench line
                 out["roofline"] = {"error": repr(ex)}
+            if not args.no_configs and dev.kind == "cuda":
+                try:
+                    with dev.ctx():
+                        out.update(BT.corr_rooflines(lib, dev.stream, md=eng.md))
+                except Exception as ex:
+                    out["roofline_corr_bwd"] = {"error": repr(ex)}
             _log("roofline done")
         # every GPU measurement first, the CPU oracle (epe_vs_oracle, cpu_baseline: ~10 s of host time) last: a timeout can only cost the auxiliary keys
         preds = {}
@@ -741,7 +977,7 @@ def main():
         def pred_of(prec):
             e = mk(prec); feed(e)
             e.build_plan("NONE").run(lib, 0)
-            torch.cuda.synchronize()
+            dev.sync()
             return e.pred.cpu().clone()
 
         if not args.no_cpu_baseline:
@@ -776,6 +1012,20 @@ def main():
             except Exception as ex:      # never let the auxiliary measurement kill the bench line
                 out["step_surface"] = {"error": repr(ex)}
             _log("step surface done")
+        cfg_ctx = {}
+        if not args.no_configs:
+            out["configs"] = {}
+            for key, fn in (("mad", lambda: config_mad(args, lib, dev, wn, l, r, gt, BT)), ("dispnet", lambda: config_dispnet(args, lib, dev, l, r, gt, BT)),
+                            ("private4", lambda: (config_private(args, lib, dev, mk, S, rank, BT), None)), ("batched4", lambda: (config_batched(args, lib, dev, wn, S, rank), None))):
+                try:
+                    out["configs"][key], cfg_ctx[key] = fn()
+                    _log("config %s: %.3f ms/step" % (key, out["configs"][key]["ms_per_step"]))
+                except Exception as ex:      # never let a side configuration kill the bench line
+                    if args.extras_on_cpu:
+                        raise
+                    out["configs"][key] = {"error": repr(ex)}
+                if dev.kind == "cuda":
+                    torch.cuda.empty_cache()
         if not args.no_cpu_baseline:
             d_or = oracle_disparity(wn, l, r)
             for prec, pr in preds.items():
@@ -791,6 +1041,39 @@ def main():
                     out["paths"][prec]["within_tolerance"] = epe <= 1e-3
             out["cpu_baseline"] = cpu_baseline(H, W, wn, l, r, gt, args.mode)
             _log("cpu baseline done")
+            # the CPU legs of the side configurations (bounded: 3 + 2 oracle steps)
+            cores = out["cpu_baseline"]["cores"]
+            c = cfg_ctx.get("mad")
+            if c:
+                from oracle import madnet as OM
+                e = out["configs"]["mad"]
+                epe = float((c["pred0"].reshape(d_or.shape) - d_or).abs().mean().item())
+                e.update({"epe_vs_oracle": epe, "epe_tolerance": 1e-3, "within_tolerance": epe <= 1e-3})
+                wt = {k: torch.from_numpy(v.copy()) for k, v in wn.items()}
+                acc = {k: torch.zeros_like(v) for k, v in wt.items()}
+                tl_, tr_, tg_ = (torch.from_numpy(a) for a in (l, r, gt))
+                e["cpu_baseline"] = cpu_leg(lambda: OM.step(wt, acc, tl_, tr_, tg_, mode="MAD", block_vars=c["block_vars"], block_index=c["block_index"], lr=1e-4), 3,
+                                            "%%d MAD steps of the torch-CPU oracle (oracle/madnet.py) on the same pair, block %d (the most sampled one), torch.set_num_threads(%d)"
+                                            % (c["block_index"], cores), cores)
+            c = cfg_ctx.get("dispnet")
+            if c:
+                from oracle import dispnet as OD
+                e = out["configs"]["dispnet"]
+                wt = {k: torch.from_numpy(v.copy()) for k, v in c["wn"].items()}
+                tl_, tr_, tg_ = (torch.from_numpy(a) for a in (l, r, gt))
+                with torch.no_grad():
+                    d_od = OD.forward(wt, tl_, tr_)[-1][..., 0]
+                epe = float((c["pred0"].reshape(d_od.shape) - d_od).abs().mean().item())
+                e.update({"epe_vs_oracle": epe, "epe_tolerance": 1e-3, "within_tolerance": epe <= 1e-3})
+                acc = {k: torch.zeros_like(v) for k, v in wt.items()}
+                e["cpu_baseline"] = cpu_leg(lambda: OD.step(wt, acc, tl_, tr_, tg_, mode="FULL", lr=1e-4), 2,
+                                            "%%d FULL steps of the torch-CPU oracle (oracle/dispnet.py) on the same pair, torch.set_num_threads(%d)" % cores, cores)
+            for key in ("private4", "batched4"):
+                if isinstance(out.get("configs", {}).get(key), dict) and "value" in out["configs"][key]:
+                    out["configs"][key]["cpu_baseline"] = dict(out["cpu_baseline"], note="per stream: the headline's FULL step (the streams are independent)")
+                    out["configs"][key]["epe_vs_oracle"] = out.get("epe_vs_oracle")
+                    out["configs"][key]["within_tolerance"] = out.get("within_tolerance")
+            _log("cpu legs of the side configurations done")
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:

@@ -393,6 +393,60 @@ __global__ __launch_bounds__(256) void corr_bwd_kernel(CorrBwdArgs p) {
     }
 }
 
+// Branch-free form of the gather kernel for small shift counts (D <= DT, tensors under 2 GiB): one lane = one (pixel, 4-channel group), every operand --
+// DT gradients of both directions, DT right / left feature vectors, the accumulate operands -- requested through range-checked buffer loads before the
+// first product (the loop above loads inside `if (in range)` blocks: 2 D dependent round trips per lane), one workgroup per 256 lanes, no persistent loop.
+template <int DT>
+__global__ __launch_bounds__(256) void corr_bwd_direct(CorrBwdArgs p) {
+    const int C4 = p.C >> 2;
+    const float inv_c = 1.0f / (float)p.C;
+    const int npix = p.B * p.H * p.W;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const bool live = q < npix * C4;
+    const int pix = live ? q / C4 : 0, c4 = live ? q - pix * C4 : 0;
+    const int x = pix % p.W;
+    const int rowbase = pix - x;
+    const __amdgpu_buffer_rsrc_t rs_g = mh_make_rsrc(p.g, (unsigned)((size_t)npix * p.g_ld * 4));
+    const __amdgpu_buffer_rsrc_t rs_r = mh_make_rsrc(p.R, (unsigned)(((size_t)npix - 1) * p.r_ld * 4 + (size_t)p.C * 4));
+    const __amdgpu_buffer_rsrc_t rs_l = mh_make_rsrc(p.L, (unsigned)(((size_t)npix - 1) * p.l_ld * 4 + (size_t)p.C * 4));
+    const __amdgpu_buffer_rsrc_t rs_dl = mh_make_rsrc(p.dL, (unsigned)(((size_t)npix - 1) * p.dl_ld * 4 + (size_t)p.C * 4));
+    const __amdgpu_buffer_rsrc_t rs_dr = mh_make_rsrc(p.dR, (unsigned)(((size_t)npix - 1) * p.dr_ld * 4 + (size_t)p.C * 4));
+    float gvr[DT], gvl[DT];
+    float4 rvv[DT], lvv[DT];
+    bool okr[DT], okl[DT];
+#pragma unroll
+    for (int j = 0; j < DT; ++j) {
+        const int i = j * p.stride - p.md;
+        const int xs = x + i, xl = x - i;
+        okr[j] = live && j < p.D && xs >= 0 && xs < p.W; okl[j] = live && j < p.D && xl >= 0 && xl < p.W;
+        gvr[j] = mh_buf_load1(rs_g, okr[j] ? (pix * p.g_ld + p.coff + j) * 4 : MH_OOB);
+        gvl[j] = mh_buf_load1(rs_g, okl[j] ? ((rowbase + xl) * p.g_ld + p.coff + j) * 4 : MH_OOB);
+        rvv[j] = mh_buf_load4(rs_r, okr[j] ? ((rowbase + xs) * p.r_ld + c4 * 4) * 4 : MH_OOB);
+        lvv[j] = mh_buf_load4(rs_l, okl[j] ? ((rowbase + xl) * p.l_ld + c4 * 4) * 4 : MH_OOB);
+    }
+    const float4 gl = mh_buf_load4(rs_g, (live && p.copy_left) ? (pix * p.g_ld + c4 * 4) * 4 : MH_OOB);
+    const float4 ol = mh_buf_load4(rs_dl, (live && p.acc_l) ? (pix * p.dl_ld + c4 * 4) * 4 : MH_OOB);
+    const float4 orr = mh_buf_load4(rs_dr, (live && p.acc_r) ? (pix * p.dr_ld + c4 * 4) * 4 : MH_OOB);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < DT; ++j) {
+        if (okr[j]) { a.x += gvr[j] * rvv[j].x; a.y += gvr[j] * rvv[j].y; a.z += gvr[j] * rvv[j].z; a.w += gvr[j] * rvv[j].w; }
+        if (okl[j]) { r.x += gvl[j] * lvv[j].x; r.y += gvl[j] * lvv[j].y; r.z += gvl[j] * lvv[j].z; r.w += gvl[j] * lvv[j].w; }
+    }
+    a.x *= inv_c; a.y *= inv_c; a.z *= inv_c; a.w *= inv_c;
+    r.x *= inv_c; r.y *= inv_c; r.z *= inv_c; r.w *= inv_c;
+    if (p.copy_left) { a.x += gl.x; a.y += gl.y; a.z += gl.z; a.w += gl.w; }
+    if (p.acc_l) { a.x += ol.x; a.y += ol.y; a.z += ol.z; a.w += ol.w; }
+    if (p.acc_r) { r.x += orr.x; r.y += orr.y; r.z += orr.z; r.w += orr.w; }
+    if (!live) return;
+    *reinterpret_cast<float4*>(p.dL + (int64_t)pix * p.dl_ld + c4 * 4) = a;
+    *reinterpret_cast<float4*>(p.dR + (int64_t)pix * p.dr_ld + c4 * 4) = r;
+    if (p.du && c4 == 0) {
+        const float gu = p.g[(int64_t)pix * p.g_ld + p.coff + p.D];
+        p.du[pix] = p.acc_u ? p.du[pix] + gu : gu;
+    }
+}
+
 // One level's backward front end in ONE launch: the gradient of the fused cost volume + concat (corr_bwd_kernel with the WARPED right features
 // as its right operand) and, straight from registers, the gradient of the warp that made them (ops.hip: warp_bwd_kernel): the gradient w.r.t. the
 // warped features is never stored -- it is scattered into the right tower's feature gradient (bilinear taps, fp32 atomics onto a zeroed buffer)
@@ -1378,6 +1432,15 @@ extern "C" int mh_corr_bwd_prec(const float* g, int32_t g_ld, int32_t coff, cons
 #undef MH_CORRB
             mh_note_kernel("corr_bwd_mfma<C/16=%d> left + right (exact fp32)", C / 16);
             return mh_check_launch("corr_bwd_mfma");
+        }
+    }
+    {
+        const int64_t npix = (int64_t)B * H * W;
+        const int64_t ldm = std::max(std::max(std::max(g_ld, l_ld), std::max(r_ld, dl_ld)), dr_ld);
+        if (g_corr_direct && a.D <= 5 && npix * ldm * 4 < (1ll << 31) - 64 && a.total < (1ll << 31) - 256) {
+            hipLaunchKernelGGL(corr_bwd_direct<5>, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+            mh_note_kernel("corr_bwd_direct<DT=5> C=%d D=%d", C, a.D);
+            return mh_check_launch("corr_bwd_direct");
         }
     }
     int blocks = (int)((a.total + 255) / 256);

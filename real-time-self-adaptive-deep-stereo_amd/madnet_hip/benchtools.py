@@ -12,11 +12,15 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0          # dense (the 5 PF headline includes 2:1 
 PEAK_HBM_GBS = 8000.0
 
 
+WARMUP_LAUNCHES = 3         # untimed launches in front of every timed burst
+TABLE_REPS = 10             # timed launches per op of a plan table
+
+
 def _time_ms(lib, stream, fn, reps):
     s = C.c_void_p(stream.cuda_stream)
     e0, e1 = C.c_void_p(), C.c_void_p()
     lib.event_create(C.byref(e0)); lib.event_create(C.byref(e1))
-    for _ in range(3):
+    for _ in range(WARMUP_LAUNCHES):
         fn()
     lib.stream_sync(s)
     lib.event_record(e0, s)
@@ -33,16 +37,23 @@ PMC_FILES = ("r05_pmc_roofline.json", "r04_pmc_roofline.json")        # the firs
 PMC_SOURCE = None           # the file the last _pmc_traffic() hit came from
 
 
+_PMC_CACHE = None
+
+
 def _pmc_json():
-    import json
-    import os
-    d = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles")
-    for f in PMC_FILES:
-        try:
-            return f, json.load(open(os.path.join(d, f)))
-        except Exception:
-            continue
-    return None, {}
+    """(file name, parsed JSON) of THE committed PMC summary: the first of PMC_FILES that exists (parsed once per process)"""
+    global _PMC_CACHE
+    if _PMC_CACHE is None:
+        import json
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles")
+        _PMC_CACHE = (None, {})
+        for f in PMC_FILES:
+            try:
+                _PMC_CACHE = (f, json.load(open(os.path.join(d, f))))
+                break
+            except Exception:
+                continue
+    return _PMC_CACHE
 
 
 def _pmc_traffic(key):
@@ -66,6 +77,13 @@ def _pmc_entry(key):
     if key not in j and key in j.get("fixed_kernels", {}):
         key = j["fixed_kernels"][key]
     return j.get(key)
+
+
+def _fixed_source(key):
+    """provenance string of a fixed roofline entry's `traffic` (ONE file: the first of PMC_FILES that exists), None when the file has no such entry"""
+    if _pmc_traffic(key) is None:
+        return None
+    return "%s, fixed_kernels.%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_pmc_r05.sh (L2 flushed before the measured launch); collected beside this round's committed bench line, not inside this process" % (PMC_SOURCE, key)
 
 
 def family_key(kernel):
@@ -239,7 +257,7 @@ def roofline(lib, eng, stream, reps=20):
         g = byts / (ms_c * 1e-3) / 1e9
         extra["roofline_corr"] = {"kernel": lib.last_kernel().decode() + " (B=64 x %dx%dx%d, D=%d)" % (H, W, Cc, D), "bound": "hbm",
                                   "achieved": g, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": g / PEAK_HBM_GBS,
-                                  "traffic": _pmc_traffic("roofline_corr"), "traffic_source": "profiles/r04_pmc_roofline.json (or the round-3 file), fixed_kernels.roofline_corr: rocprofv3 --pmc passes of scripts/gpu_pmc_r04.sh; collected beside this round's committed bench line, not inside this process", "launch_ms": ms_c, "algorithmic_bytes_per_launch": byts}
+                                  "traffic": _pmc_traffic("roofline_corr"), "traffic_source": _fixed_source("roofline_corr"), "launch_ms": ms_c, "algorithmic_bytes_per_launch": byts}
         L1, R1 = L[:1].contiguous(), R[:1].contiguous(); o1 = out[:1].contiguous()
         ms_1 = _time_ms(lib, stream, lambda: ops.corr_fwd(lib, ops.view(L1), ops.view(R1), ops.view(o1), md, stream=sh), 20)
         extra["roofline_corr"]["in_situ_B1_ms"] = ms_1
@@ -280,7 +298,7 @@ def op_kernel_name(lib, op):
     return "op kind %d" % op.kind
 
 
-def plan_table(lib, plan, stream, reps=10):
+def plan_table(lib, plan, stream, reps=None):
     """Every op of a recorded plan timed ALONE (HIP events on the launch stream, `reps` launches each) with the kernel the dispatcher chose
     (mh_last_kernel): which kernel family the step spends its time in, from the plan's own launch table.  The ops mutate the engine they were
     recorded on (optimizer, accumulating gradients): run it on a scratch engine.  Returns (rows, families): rows = [(index, kind, kernel, us)],
@@ -288,6 +306,7 @@ def plan_table(lib, plan, stream, reps=10):
     from . import _ffi
     rows = []
     sh = stream.cuda_stream
+    reps = reps or TABLE_REPS
     for i in range(plan.n):
         one = (_ffi.Op * 1)(plan.arr[i])
         one[0].i[26] = 0                                    # on the caller's stream, no join
@@ -430,4 +449,73 @@ def tail_stamps(lib, E, mk, feed, args, dev, plain_ms):
         out["last_wgrad_batch_end_us"] = max(u for lab, u in b if lab.endswith("_end"))
     if "forward_end" in at:
         out["forward_us"] = at["forward_end"]
+    return out
+
+
+def corr_rooflines(lib, stream, md=2, C2=32, H=96, W=320, reps=10):
+    """SURVEY 8(d) correlation protocol beyond the forward level-2 entry of roofline(): working sets larger than the 256 MiB Infinity Cache, HIP events on
+    the launch stream.  Returns
+      roofline_corr_bwd       mh_corr_bwd (TF-form gradient, sharedLayers.py:41-51) at the level-2 shape x 64 streams; bytes = B H W (4C + D) 4
+      roofline_corr_warp_bwd  mh_corr_warp_bwd -- what the step runs per level: correlation + concat gradient fused with the warp gradient -- same shape,
+                              bytes = every operand once: reads g (C + D + 1), L, Rw, the right features (slope taps), u, the accumulate operands dL and
+                              dimg; writes dL, dimg, du = B H W (8C + D + 3) 4
+      roofline_corr_d81_fwd / _bwd   DispNet's 81-shift volume (md 40, C 128) x 16 streams in the bf16 arithmetic of the 'mixed' mode
+                              (mh_corr_fwd_prec / mh_corr_bwd_prec precision 1); bytes = B H W (2C + D) 4 / B H W (4C + D) 4"""
+    sh = stream.cuda_stream
+    dev = "cuda"
+    out = {}
+
+    def ent(kernel, byts, ms, key, extra=None):
+        g = byts / (ms * 1e-3) / 1e9
+        e = {"kernel": kernel, "bound": "hbm", "achieved": g, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": g / PEAK_HBM_GBS, "traffic": _pmc_traffic(key),
+             "traffic_source": _fixed_source(key), "launch_ms": ms, "algorithmic_bytes_per_launch": byts}
+        if extra:
+            e.update(extra)
+        return e
+
+    try:
+        B, D = 64, 2 * md + 1
+        ld = (C2 + D + 1 + 3) // 4 * 4
+        L = torch.randn(B, H, W, C2, device=dev); R = torch.randn(B, H, W, C2, device=dev)
+        g = torch.randn(B, H, W, ld, device=dev)
+        dL = torch.zeros(B, H, W, C2, device=dev); dR = torch.zeros(B, H, W, C2, device=dev)
+        gv = ops.View(g, B, H, W, ld, ld)
+        ms = _time_ms(lib, stream, lambda: ops.corr_bwd(lib, gv, ops.view(L), ops.view(R), ops.view(dL), ops.view(dR), md, 1, coff=C2, stream=sh, precision=0), reps)
+        out["roofline_corr_bwd"] = ent(lib.last_kernel().decode() + " (B=%d x %dx%dx%d, D=%d)" % (B, H, W, C2, D), float(B) * H * W * (4 * C2 + D) * 4, ms, "roofline_corr_bwd")
+        u = (torch.rand(B, H, W, device=dev) - 0.5) * 8.0
+        Rw = torch.empty_like(R); du = torch.zeros(B, H, W, device=dev)
+        ops.warp_fwd(lib, ops.view(R), u, ops.view(Rw), stream=sh)
+        ms = _time_ms(lib, stream, lambda: ops.corr_warp_bwd(lib, gv, ops.view(L), ops.view(Rw), ops.view(R), u, ops.view(dL), ops.view(dR), du, md, 1, coff=C2, acc_l=True,
+                                                              copy_left=True, stream=sh), reps)
+        kname = lib.last_kernel().decode()
+        e = ent(kname + " (B=%d x %dx%dx%d)" % (B, H, W, C2), float(B) * H * W * (8 * C2 + D + 3) * 4, ms, "roofline_corr_warp_bwd")
+        # in situ: one stream, cache resident, launch bound -- what the step's level-2 node costs
+        L1, R1, Rw1, g1, u1 = (t[:1].contiguous() for t in (L, R, Rw, g, u))
+        dL1 = torch.zeros_like(L1); dR1 = torch.zeros_like(L1); du1 = torch.zeros(1, H, W, device=dev)
+        gv1 = ops.View(g1, 1, H, W, ld, ld)
+        e["in_situ_B1_ms"] = _time_ms(lib, stream, lambda: ops.corr_warp_bwd(lib, gv1, ops.view(L1), ops.view(Rw1), ops.view(R1), u1, ops.view(dL1), ops.view(dR1), du1, md, 1,
+                                                                          coff=C2, acc_l=True, copy_left=True, stream=sh), 2 * reps)
+        out["roofline_corr_warp_bwd"] = e
+        del L, R, g, dL, dR, Rw, u, du
+    except Exception as ex:
+        out["roofline_corr_bwd"] = {"error": repr(ex)}
+    try:
+        B, C, mdl = 16, 128, 40
+        D = 2 * mdl + 1
+        L = torch.randn(B, H, W, C, device=dev); R = torch.randn(B, H, W, C, device=dev)
+        vol = torch.empty(B, H, W, D, device=dev)
+        ms = _time_ms(lib, stream, lambda: ops.corr_fwd(lib, ops.view(L), ops.view(R), ops.view(vol), mdl, stream=sh, precision=1), reps)
+        out["roofline_corr_d81_fwd"] = ent(lib.last_kernel().decode() + " (B=%d x %dx%dx%d, D=%d)" % (B, H, W, C, D), float(B) * H * W * (2 * C + D) * 4, ms, "roofline_corr_d81_fwd")
+        ld = (D + 3) // 4 * 4
+        g = torch.randn(B, H, W, ld, device=dev)
+        dL = torch.empty_like(L); dR = torch.empty_like(R)
+        gv = ops.View(g, B, H, W, D, ld)
+        ms = _time_ms(lib, stream, lambda: ops.corr_bwd(lib, gv, ops.view(L), ops.view(R), ops.view(dL), ops.view(dR), mdl, 1, coff=0, stream=sh, precision=1), reps)
+        e = ent(lib.last_kernel().decode() + " (B=%d x %dx%dx%d, D=%d)" % (B, H, W, C, D), float(B) * H * W * (4 * C + D) * 4, ms, "roofline_corr_d81_bwd")
+        ms0 = _time_ms(lib, stream, lambda: ops.corr_bwd(lib, gv, ops.view(L), ops.view(R), ops.view(dL), ops.view(dR), mdl, 1, coff=0, stream=sh, precision=0), max(2, reps // 3))
+        e["exact_fp32_launch_ms"] = ms0
+        e["exact_fp32_frac"] = float(B) * H * W * (4 * C + D) * 4 / (ms0 * 1e-3) / 1e9 / PEAK_HBM_GBS
+        out["roofline_corr_d81_bwd"] = e
+    except Exception as ex:
+        out["roofline_corr_d81_bwd"] = {"error": repr(ex)}
     return out
