@@ -705,6 +705,153 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_row_kernel(CorrWarpBwdArgs
     }
 }
 
+// The row-owned form with the row's operands STAGED in LDS (the default fp32 path): the walk above still reads every left / warped-right vector at DT
+// shifted positions from L1 / L2 -- 14 global loads per (pixel, channel group) and one memory round trip per pass and channel-group iteration, on ONE
+// workgroup per row (measured, MI355X: 35 us at 96x320x32 with 96 workgroups, no better than the atomic form; 2x better only when many rows fill the chip).
+// Here ONE round trip brings the whole row in: the left and the warped-right feature rows, the D + 1 correlation / disparity channels of g, the u row and
+// the previous content of the row of the right tower's gradient go to LDS (each element read once, coalesced), the per-item operands that do not
+// depend on u (the concat-copy part of g, the accumulate operand of dL) to registers; a second round trip fetches the two slope taps of every item (their
+// address needs u).  The 2 DT shifted products then read LDS.  A thread owns at most NI = 3 (pixel, channel group) items: LPP >= C / 4 lanes per pixel.
+template <int LPP, int DT>
+__global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdArgs p) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    constexpr int NT = 1024, PPB = NT / LPP, NI = 3, GS = 8;
+    static_assert(DT + 1 <= GS, "g staging holds D + 1 channels");
+    const int C4 = p.C >> 2, WC = p.W * p.C;
+    float* const sL = smem;                     // [W][C]
+    float* const sR = smem + WC;                // [W][C]   warped right features
+    float* const racc = smem + 2 * WC;          // [W][C]   the row of the right tower's gradient
+    float* const sg = smem + 3 * WC;            // [W][GS]  g[coff .. coff + D]
+    float* const su = sg + p.W * GS;            // [W]
+    const int tid = threadIdx.x, sub = tid % LPP;
+    const float inv_c = 1.0f / (float)p.C;
+    const int row = blockIdx.x;
+    const int rowbase = row * p.W;
+    const int npix = p.B * p.H * p.W;
+    const __amdgpu_buffer_rsrc_t rs_g = mh_make_rsrc(p.g, (unsigned)((size_t)npix * p.g_ld * 4));
+    const __amdgpu_buffer_rsrc_t rs_rw = mh_make_rsrc(p.Rw, (unsigned)((size_t)npix * p.rw_ld * 4));
+    const __amdgpu_buffer_rsrc_t rs_l = mh_make_rsrc(p.L, (unsigned)((size_t)npix * p.l_ld * 4));
+    const __amdgpu_buffer_rsrc_t rs_img = mh_make_rsrc(p.img, (unsigned)((size_t)npix * p.img_ld * 4));
+    const __amdgpu_buffer_rsrc_t rs_dl = mh_make_rsrc(p.dL, (unsigned)((size_t)npix * p.dl_ld * 4));
+    const __amdgpu_buffer_rsrc_t rs_di = mh_make_rsrc(p.dimg ? p.dimg : p.dL, (unsigned)((size_t)npix * (p.dimg ? p.dimg_ld : p.dl_ld) * 4));
+    // ---- round trip 1: everything whose address does not depend on u ------------------------------------------------------------------------------
+    const int nq = p.W * C4;
+    float4 vl[NI], vr[NI], vd[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int q = tid + k * NT;
+        const int x = q / C4, c4 = q - x * C4;
+        const bool ok = q < nq;
+        vl[k] = mh_buf_load4(rs_l, ok ? ((rowbase + x) * p.l_ld + c4 * 4) * 4 : MH_OOB);
+        vr[k] = mh_buf_load4(rs_rw, ok ? ((rowbase + x) * p.rw_ld + c4 * 4) * 4 : MH_OOB);
+        vd[k] = mh_buf_load4(rs_di, (ok && p.dimg) ? ((rowbase + x) * p.dimg_ld + c4 * 4) * 4 : MH_OOB);
+    }
+    float vg[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {              // W * GS <= NI * NT (host check)
+        const int q = tid + k * NT;
+        const int x = q / GS, j = q - x * GS;
+        vg[k] = mh_buf_load1(rs_g, (x < p.W && j <= p.D) ? ((rowbase + x) * p.g_ld + p.coff + j) * 4 : MH_OOB);
+    }
+    const float vu = (tid < p.W) ? p.u[rowbase + tid] : 0.f;        // W <= NT (host check)
+    float4 gl[NI], dlo[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int x = k * PPB + tid / LPP;
+        const bool ok = x < p.W && sub < C4;
+        const int pp = rowbase + x;
+        gl[k] = mh_buf_load4(rs_g, (ok && p.copy_left) ? (pp * p.g_ld + sub * 4) * 4 : MH_OOB);
+        dlo[k] = mh_buf_load4(rs_dl, (ok && p.acc_l) ? (pp * p.dl_ld + sub * 4) * 4 : MH_OOB);
+    }
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int q = tid + k * NT;
+        if (q < nq) {
+            const int x = q / C4, c4 = q - x * C4;
+            *reinterpret_cast<float4*>(sL + x * p.C + c4 * 4) = vl[k];
+            *reinterpret_cast<float4*>(sR + x * p.C + c4 * 4) = vr[k];
+            *reinterpret_cast<float4*>(racc + x * p.C + c4 * 4) = vd[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int q = tid + k * NT;
+        if (q < p.W * GS) sg[q] = vg[k];
+    }
+    if (tid < p.W) su[tid] = vu;
+    __syncthreads();
+    // ---- round trip 2: the slope taps (right features at the two source columns of every pixel's warp) ------------------------------------------------
+    float4 s0[NI], s1[NI];
+    float w0[NI], w1[NI], m0[NI], m1[NI];
+    int i0[NI], i1[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int x = k * PPB + tid / LPP;
+        const bool live = x < p.W && sub < C4;
+        const float cx = (float)x + su[x < p.W ? x : 0];
+        const float x0 = floorf(cx), x1 = x0 + 1.0f;
+        const float xmax = (float)(p.W - 1);
+        const float x0s = fminf(fmaxf(x0, 0.f), xmax), x1s = fminf(fmaxf(x1, 0.f), xmax);
+        m0[k] = (x0 == x0s) ? 1.f : 0.f; m1[k] = (x1 == x1s) ? 1.f : 0.f;
+        w0[k] = (x1 - cx) * m0[k]; w1[k] = (cx - x0) * m1[k];
+        i0[k] = (int)x0s; i1[k] = (int)x1s;
+        s0[k] = mh_buf_load4(rs_img, (live && p.du) ? ((rowbase + i0[k]) * p.img_ld + sub * 4) * 4 : MH_OOB);
+        s1[k] = mh_buf_load4(rs_img, (live && p.du) ? ((rowbase + i1[k]) * p.img_ld + sub * 4) * 4 : MH_OOB);
+    }
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int x = k * PPB + tid / LPP;
+        const bool live = x < p.W && sub < C4;
+        const int xq = x < p.W ? x : 0;
+        const int pp = rowbase + xq;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), r = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int cc = (sub < C4 ? sub : 0) * 4;
+#pragma unroll
+        for (int j = 0; j < DT; ++j) {
+            const int i = j * p.stride - p.md;
+            const int xs = xq + i, xl = xq - i;
+            const bool okr = j < p.D && xs >= 0 && xs < p.W, okl = j < p.D && xl >= 0 && xl < p.W;
+            const int xsc = okr ? xs : xq, xlc = okl ? xl : xq;
+            const float gr = sg[xq * GS + j], gq = sg[xlc * GS + j];
+            const float4 rv = *reinterpret_cast<const float4*>(sR + xsc * p.C + cc);
+            const float4 lv = *reinterpret_cast<const float4*>(sL + xlc * p.C + cc);
+            if (okr) { a.x += gr * rv.x; a.y += gr * rv.y; a.z += gr * rv.z; a.w += gr * rv.w; }
+            if (okl) { r.x += gq * lv.x; r.y += gq * lv.y; r.z += gq * lv.z; r.w += gq * lv.w; }
+        }
+        a.x *= inv_c; a.y *= inv_c; a.z *= inv_c; a.w *= inv_c;
+        r.x *= inv_c; r.y *= inv_c; r.z *= inv_c; r.w *= inv_c;
+        if (p.copy_left) { a.x += gl[k].x; a.y += gl[k].y; a.z += gl[k].z; a.w += gl[k].w; }
+        if (p.acc_l) { a.x += dlo[k].x; a.y += dlo[k].y; a.z += dlo[k].z; a.w += dlo[k].w; }
+        float dcx = 0.f;
+        if (live) {
+            *reinterpret_cast<float4*>(p.dL + (int64_t)pp * p.dl_ld + cc) = a;
+            if (p.dimg) {
+                float* d0 = racc + i0[k] * p.C + cc;
+                float* d1 = racc + i1[k] * p.C + cc;
+                if (w0[k] != 0.f) { atomicAdd(d0 + 0, w0[k] * r.x); atomicAdd(d0 + 1, w0[k] * r.y); atomicAdd(d0 + 2, w0[k] * r.z); atomicAdd(d0 + 3, w0[k] * r.w); }
+                if (w1[k] != 0.f) { atomicAdd(d1 + 0, w1[k] * r.x); atomicAdd(d1 + 1, w1[k] * r.y); atomicAdd(d1 + 2, w1[k] * r.z); atomicAdd(d1 + 3, w1[k] * r.w); }
+            }
+            dcx = r.x * (m1[k] * s1[k].x - m0[k] * s0[k].x) + r.y * (m1[k] * s1[k].y - m0[k] * s0[k].y) + r.z * (m1[k] * s1[k].z - m0[k] * s0[k].z) +
+                  r.w * (m1[k] * s1[k].w - m0[k] * s0[k].w);
+        }
+        if (p.du) {
+#pragma unroll
+            for (int o = LPP >> 1; o > 0; o >>= 1) dcx += __shfl_xor(dcx, o);
+            if (x < p.W && sub == 0) p.du[pp] = sg[xq * GS + p.D] + dcx;
+        }
+    }
+    if (!p.dimg) return;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int q = tid + k * NT;
+        if (q < nq) {
+            const int x = q / C4, c4 = q - x * C4;
+            *reinterpret_cast<float4*>(p.dimg + (int64_t)(rowbase + x) * p.dimg_ld + c4 * 4) = *reinterpret_cast<const float4*>(racc + x * p.C + c4 * 4);
+        }
+    }
+}
+
 // Large shift counts (DispNet, D = 81) on the matrix cores: out[x][d] = mean_c L[x][c] * R[x + d - md][c] is the band
 // |x' - x| <= md of the row-wise product L_row (W x C) * R_row^T (C x W).  One workgroup = one 64-pixel row segment,
 // one wave = 16 pixels; the right-feature window [x0 - md, x0 + 64 + md) is staged once in LDS (k-contiguous rows,
@@ -1167,6 +1314,11 @@ int mh_corr_init() {
     if (e != hipSuccess) { mh_set_error("corr: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     MH_CORRBH_ATTR(2) MH_CORRBH_ATTR(4) MH_CORRBH_ATTR(8) MH_CORRBH_ATTR(16)
 #undef MH_CORRBH_ATTR
+#define MH_CWBL_ATTR(LPPv)                                                                                                    \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_warp_bwd_rowlds_kernel<LPPv, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024); \
+    if (e != hipSuccess) { mh_set_error("corr: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    MH_CWBL_ATTR(8) MH_CWBL_ATTR(16) MH_CWBL_ATTR(32)
+#undef MH_CWBL_ATTR
 #define MH_CWBR_ATTR(LPPv, Dv)                                                                                                 \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_warp_bwd_row_kernel<LPPv, 5, Dv>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
     if (e != hipSuccess) { mh_set_error("corr: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
@@ -1176,7 +1328,7 @@ int mh_corr_init() {
 }
 
 static std::atomic<int> g_corr_direct{1};
-// mh_tune_corr_row: 1 (default) = row-owned backward front end (LDS scatter), 0 = the global-atomic form
+// mh_tune_corr_row: 1 (default) = row-owned backward front end with the row's operands staged in LDS, 3 = row-owned, operands from L1 / L2, 0 = the global-atomic form
 static std::atomic<int> g_corr_row{1};
 static std::atomic<int> g_corr_remap{1};             // XCD-aware workgroup order of the large-D bf16 kernels (mh_tune_corr bit 1 clears it)
 static std::atomic<int> g_corr_det_ranges{0};        // how many deterministic ranges are registered (mh_det_sync_corr keeps it in step)
@@ -1341,6 +1493,16 @@ extern "C" int mh_corr_warp_bwd(const float* g, int32_t g_ld, int32_t coff, cons
     const int64_t ldmax2 = std::max<int64_t>(std::max<int64_t>(ldmax, img_ld), std::max<int64_t>(dl_ld, dimg ? dimg_ld : 0));
     if (g_corr_row.load() && fast && row_lds <= 150 * 1024 && npix * ldmax2 * 4 < (1ll << 31) - 64 && (int64_t)B * H < (1 << 30)) {
         const dim3 grid((unsigned)(B * H));
+        // operands staged in LDS (fp32 mode): 3 rows of W x C floats + the g / u rows; a thread owns <= 3 (pixel, channel group) items
+        const int lpp = C4 <= 8 ? 8 : C4 <= 16 ? 16 : 32;
+        const size_t lds_st = ((size_t)3 * W * C + (size_t)W * 9) * 4;
+        if (!det && (g_corr_row.load() & 2) == 0 && C4 <= 32 && W <= 3 * (1024 / lpp) && (int64_t)W * C4 <= 3 * 1024 && W * 8 <= 3 * 1024 && lds_st <= 155 * 1024) {
+            if (lpp == 8) hipLaunchKernelGGL((corr_warp_bwd_rowlds_kernel<8, 5>), grid, dim3(1024), lds_st, s, a);
+            else if (lpp == 16) hipLaunchKernelGGL((corr_warp_bwd_rowlds_kernel<16, 5>), grid, dim3(1024), lds_st, s, a);
+            else hipLaunchKernelGGL((corr_warp_bwd_rowlds_kernel<32, 5>), grid, dim3(1024), lds_st, s, a);
+            mh_note_kernel("corr_warp_bwd_rowlds_kernel<LPP=%d,DT=5> C=%d D=%d grid %d x 16 waves lds %d", lpp, C, a.D, B * H, (int)lds_st);
+            return mh_check_launch("corr_warp_bwd_rowlds");
+        }
 #define MH_CWB_ROW(LPPv) { if (det) hipLaunchKernelGGL((corr_warp_bwd_row_kernel<LPPv, 5, true>), grid, dim3(1024), row_lds, s, a);   \
                            else hipLaunchKernelGGL((corr_warp_bwd_row_kernel<LPPv, 5, false>), grid, dim3(1024), row_lds, s, a); }
         if (C4 <= 4) MH_CWB_ROW(4) else if (C4 <= 8) MH_CWB_ROW(8) else MH_CWB_ROW(16)

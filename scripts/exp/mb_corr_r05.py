@@ -30,11 +30,11 @@ for (B, H, W, C) in [(1, 96, 320, 32), (1, 48, 160, 64), (1, 24, 80, 96), (1, 12
     dL = torch.zeros_like(L); dimg = torch.zeros_like(L); du = torch.zeros(B, H, W, device=dev)
     gv = ops.View(g, B, H, W, ld, ld)
     byts = float(B) * H * W * (8 * C + D + 3) * 4
-    for row in (0, 1):
+    for row in (0, 3, 1):
         lib.tune_corr_row(row)
         us = t_us(lambda: ops.corr_warp_bwd(lib, gv, ops.view(L), ops.view(Rw), ops.view(R), u, ops.view(dL), ops.view(dimg), du, 2, 1, coff=C, acc_l=True, copy_left=True, stream=sh),
                   20 if B < 64 else 8)
-        print("B=%-2d %3dx%3dx%3d  %-6s %8.1f us  %7.0f GB/s algorithmic (%4.1f %% of 8 TB/s)   %s" % (B, H, W, C, "row" if row else "atomic", us, byts / us / 1e3, byts / us / 1e3 / 80, lib.last_kernel().decode()))
+        print("B=%-2d %3dx%3dx%3d  %-6s %8.1f us  %7.0f GB/s algorithmic (%4.1f %% of 8 TB/s)   %s" % (B, H, W, C, {0: "atomic", 3: "row", 1: "rowlds"}[row], us, byts / us / 1e3, byts / us / 1e3 / 80, lib.last_kernel().decode()))
     lib.tune_corr_row(1)
     if B == 64:
         dR = torch.zeros_like(L)

@@ -416,12 +416,13 @@ def test_corr_fwd_large_d_bf16_and_split_bf16(backend, case):
     assert e2 <= 5e-6 and e2 * 30 <= e1, (e1, e2)          # |corr| ~ 0.3: 2^-16 relative per product, averaged over C channels
 
 
-@pytest.mark.parametrize("form", ["row", "atomic"])
+@pytest.mark.parametrize("form", ["rowlds", "row", "atomic"])
 @pytest.mark.parametrize("case", [(1, 12, 40, 32, 2, 1), (2, 9, 21, 96, 2, 1), (1, 7, 33, 64, 2, 1), (1, 6, 20, 192, 2, 1), (1, 10, 17, 16, 1, 1), (1, 3, 300, 32, 2, 1)])
 def test_corr_warp_bwd_fused_matches_corr_bwd_then_warp_bwd(backend, case, form):
     """mh_corr_warp_bwd = mh_corr_bwd (warped right features as the right operand, fused concat form) + mh_warp_bwd of its result in one launch: dL and the
     coordinate gradient du are compared with the two-launch sequence at rounding level, the scatter with the tolerance of its summation order.
-    form: 'row' = the row-owned kernel (LDS scatter, round 5: the default), 'atomic' = the global-atomic kernel (mh_tune_corr_row(0))."""
+    form: 'rowlds' = the row-owned kernel with the row's operands staged in LDS (round 5: the default), 'row' = row-owned, operands from L1 / L2
+    (mh_tune_corr_row(3); also what 'rowlds' falls back to beyond 128 channels), 'atomic' = the global-atomic kernel (mh_tune_corr_row(0))."""
     B, H, W, Cc, md, stride = case
     dev = backend.device
     D = 2 * md // stride + 1
@@ -435,7 +436,8 @@ def test_corr_warp_bwd_fused_matches_corr_bwd_then_warp_bwd(backend, case, form)
     ops.warp_fwd(backend.lib, ops.view(R), u, ops.view(Rw))
     gv = ops.View(g, B, H, W, ld, ld)
     outs = []
-    backend.lib.tune_corr_row(1 if form == "row" else 0)
+    backend.lib.tune_corr_row({"rowlds": 1, "row": 3, "atomic": 0}[form])
+    expect = {"rowlds": "corr_warp_bwd_rowlds_kernel" if Cc <= 128 else "corr_warp_bwd_row_kernel", "row": "corr_warp_bwd_row_kernel", "atomic": "corr_warp_bwd_kernel"}[form]
     try:
         for fused in (False, True):
             dL = torch.full((B, H, W, Cc), 0.25, device=dev)                 # acc_l: accumulate onto an earlier contribution
@@ -443,7 +445,7 @@ def test_corr_warp_bwd_fused_matches_corr_bwd_then_warp_bwd(backend, case, form)
             du = torch.full((B, H, W), float("nan"), device=dev)
             if fused:
                 ops.corr_warp_bwd(backend.lib, gv, ops.view(L), ops.view(Rw), ops.view(R), u, ops.view(dL), ops.view(dimg), du, md, stride, coff=Cc, acc_l=True, copy_left=True)
-                assert ("corr_warp_bwd_row_kernel" if form == "row" else "corr_warp_bwd_kernel") in backend.lib.last_kernel().decode()
+                assert expect in backend.lib.last_kernel().decode()
             else:
                 dRw = torch.zeros(B, H, W, Cc, device=dev)
                 ops.corr_bwd(backend.lib, gv, ops.view(L), ops.view(Rw), ops.view(dL), ops.view(dRw), md, stride, coff=Cc, du=du, acc_l=True, acc_r=False, acc_u=False, copy_left=True)
@@ -490,7 +492,7 @@ def test_corr_warp_bwd_row_form_is_deterministic_without_a_twin(backend):
         return dimg.cpu(), backend.lib.last_kernel().decode()
 
     plain, k0 = run()
-    assert "corr_warp_bwd_row_kernel" in k0 and "det" not in k0
+    assert "corr_warp_bwd_rowlds_kernel" in k0
     import ctypes as C
     other = torch.zeros(64, device=dev); twin = torch.zeros(64, dtype=torch.int64, device=dev)          # an unrelated registered range switches the mode on
     assert backend.lib.deterministic_add(C.c_void_p(other.data_ptr()), 64, C.c_void_p(twin.data_ptr())) == 0
