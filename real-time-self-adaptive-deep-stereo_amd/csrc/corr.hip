@@ -705,13 +705,19 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_row_kernel(CorrWarpBwdArgs
     }
 }
 
-// The row-owned form with the row's operands STAGED in LDS (the default fp32 path): the walk above still reads every left / warped-right vector at DT
-// shifted positions from L1 / L2 -- 14 global loads per (pixel, channel group) and one memory round trip per pass and channel-group iteration, on ONE
-// workgroup per row (measured, MI355X: 35 us at 96x320x32 with 96 workgroups, no better than the atomic form; 2x better only when many rows fill the chip).
-// Here ONE round trip brings the whole row in: the left and the warped-right feature rows, the D + 1 correlation / disparity channels of g, the u row and
-// the previous content of the row of the right tower's gradient go to LDS (each element read once, coalesced), the per-item operands that do not
-// depend on u (the concat-copy part of g, the accumulate operand of dL) to registers; a second round trip fetches the two slope taps of every item (their
-// address needs u).  The 2 DT shifted products then read LDS.  A thread owns at most NI = 3 (pixel, channel group) items: LPP >= C / 4 lanes per pixel.
+// The row-owned form with the row's operands STAGED in LDS and the scatter turned into a GATHER (the default path, round 5).
+// Measured on the MI355X (profiles/r05_experiments.txt #2, #3): both scatter forms above take ~35 us per row whatever the level -- 96 workgroups at 96x320x32
+// in the replayed step are no faster than the 2 M global atomics (1.457 vs 1.426 ms per step), and 6144 rows on 256 CUs (B = 64) run at 35 us per row and CU:
+// the time is the row's 20 k ds_add_f32 lane operations (4-way bank conflicts between the pixel groups of a wave), not its memory traffic.  So:
+//   * ONE round trip brings the row in: the left and the warped-right feature rows, the D + 1 correlation / disparity channels of g and the u row go to LDS
+//     (each element read once, coalesced), the per-item operands that do not depend on u (the concat-copy part of g, the accumulate operand of dL) to
+//     registers; a second round trip fetches the two slope taps of every item (their address needs u).  The 2 DT shifted products read LDS;
+//   * the gradient w.r.t. the warped features r(x) of every pixel is stored to LDS (plain 16-byte stores, every item its own slot) with the pixel's tap
+//     columns and weights; after a barrier every (source column xs, channel group) item GATHERS: the pixels whose taps can land on xs lie within
+//     ceil(max |u|) + 1 columns of it (max |u| of the row: wave maxima through LDS), each candidate costs an LDS broadcast read and two compares, a match
+//     one 16-byte read and four FMAs.  Ascending x, fixed order: the sum is bit-identical from run to run -- no atomics, no fixed-point twin, and the
+//     same kernel serves the deterministic mode.
+// A thread owns at most NI = 3 (pixel, channel group) items: LPP >= C / 4 lanes per pixel.
 template <int LPP, int DT>
 __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdArgs p) {
     HIP_DYNAMIC_SHARED(float, smem)
@@ -720,9 +726,14 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
     const int C4 = p.C >> 2, WC = p.W * p.C;
     float* const sL = smem;                     // [W][C]
     float* const sR = smem + WC;                // [W][C]   warped right features
-    float* const racc = smem + 2 * WC;          // [W][C]   the row of the right tower's gradient
+    float* const rb = smem + 2 * WC;            // [W][C]   gradient w.r.t. the warped right features
     float* const sg = smem + 3 * WC;            // [W][GS]  g[coff .. coff + D]
     float* const su = sg + p.W * GS;            // [W]
+    float* const sw0 = su + p.W;                // [W] tap weights (0 where the tap is masked) and tap columns of every pixel
+    float* const sw1 = sw0 + p.W;
+    int* const si0 = reinterpret_cast<int*>(sw1 + p.W);
+    int* const si1 = si0 + p.W;
+    float* const smax = reinterpret_cast<float*>(si1 + p.W);     // [16] wave maxima of |u|
     const int tid = threadIdx.x, sub = tid % LPP;
     const float inv_c = 1.0f / (float)p.C;
     const int row = blockIdx.x;
@@ -736,7 +747,7 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
     const __amdgpu_buffer_rsrc_t rs_di = mh_make_rsrc(p.dimg ? p.dimg : p.dL, (unsigned)((size_t)npix * (p.dimg ? p.dimg_ld : p.dl_ld) * 4));
     // ---- round trip 1: everything whose address does not depend on u ------------------------------------------------------------------------------
     const int nq = p.W * C4;
-    float4 vl[NI], vr[NI], vd[NI];
+    float4 vl[NI], vr[NI];
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
         const int q = tid + k * NT;
@@ -744,7 +755,6 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
         const bool ok = q < nq;
         vl[k] = mh_buf_load4(rs_l, ok ? ((rowbase + x) * p.l_ld + c4 * 4) * 4 : MH_OOB);
         vr[k] = mh_buf_load4(rs_rw, ok ? ((rowbase + x) * p.rw_ld + c4 * 4) * 4 : MH_OOB);
-        vd[k] = mh_buf_load4(rs_di, (ok && p.dimg) ? ((rowbase + x) * p.dimg_ld + c4 * 4) * 4 : MH_OOB);
     }
     float vg[NI];
 #pragma unroll
@@ -770,7 +780,6 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
             const int x = q / C4, c4 = q - x * C4;
             *reinterpret_cast<float4*>(sL + x * p.C + c4 * 4) = vl[k];
             *reinterpret_cast<float4*>(sR + x * p.C + c4 * 4) = vr[k];
-            *reinterpret_cast<float4*>(racc + x * p.C + c4 * 4) = vd[k];
         }
     }
 #pragma unroll
@@ -778,12 +787,17 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
         const int q = tid + k * NT;
         if (q < p.W * GS) sg[q] = vg[k];
     }
-    if (tid < p.W) su[tid] = vu;
+    {
+        float m = fabsf(vu);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (tid < p.W) su[tid] = vu;
+        if ((tid & 63) == 0) smax[tid >> 6] = m;
+    }
     __syncthreads();
     // ---- round trip 2: the slope taps (right features at the two source columns of every pixel's warp) ------------------------------------------------
     float4 s0[NI], s1[NI];
-    float w0[NI], w1[NI], m0[NI], m1[NI];
-    int i0[NI], i1[NI];
+    float m0[NI], m1[NI];
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
         const int x = k * PPB + tid / LPP;
@@ -793,10 +807,10 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
         const float xmax = (float)(p.W - 1);
         const float x0s = fminf(fmaxf(x0, 0.f), xmax), x1s = fminf(fmaxf(x1, 0.f), xmax);
         m0[k] = (x0 == x0s) ? 1.f : 0.f; m1[k] = (x1 == x1s) ? 1.f : 0.f;
-        w0[k] = (x1 - cx) * m0[k]; w1[k] = (cx - x0) * m1[k];
-        i0[k] = (int)x0s; i1[k] = (int)x1s;
-        s0[k] = mh_buf_load4(rs_img, (live && p.du) ? ((rowbase + i0[k]) * p.img_ld + sub * 4) * 4 : MH_OOB);
-        s1[k] = mh_buf_load4(rs_img, (live && p.du) ? ((rowbase + i1[k]) * p.img_ld + sub * 4) * 4 : MH_OOB);
+        const int i0 = (int)x0s, i1 = (int)x1s;
+        s0[k] = mh_buf_load4(rs_img, (live && p.du) ? ((rowbase + i0) * p.img_ld + sub * 4) * 4 : MH_OOB);
+        s1[k] = mh_buf_load4(rs_img, (live && p.du) ? ((rowbase + i1) * p.img_ld + sub * 4) * 4 : MH_OOB);
+        if (x < p.W && sub == 0) { sw0[x] = (x1 - cx) * m0[k]; sw1[x] = (cx - x0) * m1[k]; si0[x] = i0; si1[x] = i1; }
     }
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
@@ -825,12 +839,7 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
         float dcx = 0.f;
         if (live) {
             *reinterpret_cast<float4*>(p.dL + (int64_t)pp * p.dl_ld + cc) = a;
-            if (p.dimg) {
-                float* d0 = racc + i0[k] * p.C + cc;
-                float* d1 = racc + i1[k] * p.C + cc;
-                if (w0[k] != 0.f) { atomicAdd(d0 + 0, w0[k] * r.x); atomicAdd(d0 + 1, w0[k] * r.y); atomicAdd(d0 + 2, w0[k] * r.z); atomicAdd(d0 + 3, w0[k] * r.w); }
-                if (w1[k] != 0.f) { atomicAdd(d1 + 0, w1[k] * r.x); atomicAdd(d1 + 1, w1[k] * r.y); atomicAdd(d1 + 2, w1[k] * r.z); atomicAdd(d1 + 3, w1[k] * r.w); }
-            }
+            *reinterpret_cast<float4*>(rb + xq * p.C + cc) = r;
             dcx = r.x * (m1[k] * s1[k].x - m0[k] * s0[k].x) + r.y * (m1[k] * s1[k].y - m0[k] * s0[k].y) + r.z * (m1[k] * s1[k].z - m0[k] * s0[k].z) +
                   r.w * (m1[k] * s1[k].w - m0[k] * s0[k].w);
         }
@@ -841,14 +850,35 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
         }
     }
     if (!p.dimg) return;
+    // ---- the row of the right tower's gradient: previous content (requested now, used behind the barrier) + the gathered taps -----------------------------
+    float4 vd[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int q = tid + k * NT;
+        const int x = q / C4, c4 = q - x * C4;
+        vd[k] = mh_buf_load4(rs_di, q < nq ? ((rowbase + x) * p.dimg_ld + c4 * 4) * 4 : MH_OOB);
+    }
+    float um = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) um = fmaxf(um, smax[w]);
+    const int reach = (um < (float)p.W ? (int)ceilf(um) : p.W) + 1;      // |x - xs| <= ceil(max |u|) + 1 for every tap that lands on xs (NaN / inf: the whole row)
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
         const int q = tid + k * NT;
-        if (q < nq) {
-            const int x = q / C4, c4 = q - x * C4;
-            *reinterpret_cast<float4*>(p.dimg + (int64_t)(rowbase + x) * p.dimg_ld + c4 * 4) = *reinterpret_cast<const float4*>(racc + x * p.C + c4 * 4);
+        if (q >= nq) continue;
+        const int xs = q / C4, c4 = q - xs * C4;
+        float4 acc = vd[k];
+        const int xa = xs - reach > 0 ? xs - reach : 0, xb = xs + reach < p.W - 1 ? xs + reach : p.W - 1;
+        for (int x = xa; x <= xb; ++x) {
+            const bool h0 = si0[x] == xs && sw0[x] != 0.f, h1 = si1[x] == xs && sw1[x] != 0.f;
+            if (h0 || h1) {
+                const float4 rv = *reinterpret_cast<const float4*>(rb + x * p.C + c4 * 4);
+                if (h0) { const float w = sw0[x]; acc.x += w * rv.x; acc.y += w * rv.y; acc.z += w * rv.z; acc.w += w * rv.w; }
+                if (h1) { const float w = sw1[x]; acc.x += w * rv.x; acc.y += w * rv.y; acc.z += w * rv.z; acc.w += w * rv.w; }
+            }
         }
+        *reinterpret_cast<float4*>(p.dimg + (int64_t)(rowbase + xs) * p.dimg_ld + c4 * 4) = acc;
     }
 }
 
@@ -1493,10 +1523,12 @@ extern "C" int mh_corr_warp_bwd(const float* g, int32_t g_ld, int32_t coff, cons
     const int64_t ldmax2 = std::max<int64_t>(std::max<int64_t>(ldmax, img_ld), std::max<int64_t>(dl_ld, dimg ? dimg_ld : 0));
     if (g_corr_row.load() && fast && row_lds <= 150 * 1024 && npix * ldmax2 * 4 < (1ll << 31) - 64 && (int64_t)B * H < (1 << 30)) {
         const dim3 grid((unsigned)(B * H));
-        // operands staged in LDS (fp32 mode): 3 rows of W x C floats + the g / u rows; a thread owns <= 3 (pixel, channel group) items
+        // operands staged in LDS: 3 rows of W x C floats + the g / u / tap rows; a thread owns <= 3 (pixel, channel group) items.  Gather, no atomics:
+        // deterministic as it is (mh_tune_corr_row bit 1 set = the scatter form below; bit 2 = this launch without its scatter / gather part: timing)
         const int lpp = C4 <= 8 ? 8 : C4 <= 16 ? 16 : 32;
-        const size_t lds_st = ((size_t)3 * W * C + (size_t)W * 9) * 4;
-        if (!det && (g_corr_row.load() & 2) == 0 && C4 <= 32 && W <= 3 * (1024 / lpp) && (int64_t)W * C4 <= 3 * 1024 && W * 8 <= 3 * 1024 && lds_st <= 155 * 1024) {
+        const size_t lds_st = ((size_t)3 * W * C + (size_t)W * 13 + 16) * 4;
+        if ((g_corr_row.load() & 2) == 0 && C4 <= 32 && W <= 3 * (1024 / lpp) && (int64_t)W * C4 <= 3 * 1024 && W * 8 <= 3 * 1024 && lds_st <= 155 * 1024) {
+            if (g_corr_row.load() & 4) a.dimg = nullptr;
             if (lpp == 8) hipLaunchKernelGGL((corr_warp_bwd_rowlds_kernel<8, 5>), grid, dim3(1024), lds_st, s, a);
             else if (lpp == 16) hipLaunchKernelGGL((corr_warp_bwd_rowlds_kernel<16, 5>), grid, dim3(1024), lds_st, s, a);
             else hipLaunchKernelGGL((corr_warp_bwd_rowlds_kernel<32, 5>), grid, dim3(1024), lds_st, s, a);

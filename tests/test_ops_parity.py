@@ -471,9 +471,9 @@ def test_corr_warp_bwd_fused_matches_corr_bwd_then_warp_bwd(backend, case, form)
 
 
 def test_corr_warp_bwd_row_form_is_deterministic_without_a_twin(backend):
-    """With a deterministic range registered (mh_deterministic_add) the row-owned kernel accumulates its LDS row in 64-bit fixed point: two launches on
-    the same operands give bit-identical scatters (the global-atomic form needs the range's fixed-point twin + mh_det_flush for that), equal to the
-    fp32 LDS form at rounding level."""
+    """The default row-owned kernel GATHERS the warp-gradient taps in a fixed order: two launches on the same operands give bit-identical results, with
+    or without a registered deterministic range (the global-atomic form needs the range's fixed-point twin + mh_det_flush for that).  The scatter form
+    of the row kernel (mh_tune_corr_row(3)) switches to 64-bit fixed-point LDS accumulators when a range is registered: also bit-identical."""
     B, H, W, Cc, md = 1, 6, 70, 32, 2
     dev = backend.device
     D = 2 * md + 1
@@ -492,18 +492,22 @@ def test_corr_warp_bwd_row_form_is_deterministic_without_a_twin(backend):
         return dimg.cpu(), backend.lib.last_kernel().decode()
 
     plain, k0 = run()
-    assert "corr_warp_bwd_rowlds_kernel" in k0
+    again, _ = run()
+    assert "corr_warp_bwd_rowlds_kernel" in k0 and torch.equal(plain, again)
     import ctypes as C
     other = torch.zeros(64, device=dev); twin = torch.zeros(64, dtype=torch.int64, device=dev)          # an unrelated registered range switches the mode on
     assert backend.lib.deterministic_add(C.c_void_p(other.data_ptr()), 64, C.c_void_p(twin.data_ptr())) == 0
     try:
         a, k1 = run()
-        b, _ = run()
+        backend.lib.tune_corr_row(3)
+        b, k2 = run()
+        c, _ = run()
     finally:
+        backend.lib.tune_corr_row(1)
         backend.lib.deterministic_remove(C.c_void_p(other.data_ptr()))
-    assert ",det" in k1
-    assert torch.equal(a, b)
-    assert (a - plain).abs().max().item() <= 2e-5 * max(1.0, plain.abs().max().item())
+    assert "corr_warp_bwd_rowlds_kernel" in k1 and torch.equal(a, plain)
+    assert "corr_warp_bwd_row_kernel" in k2 and ",det" in k2 and torch.equal(b, c)
+    assert (b - plain).abs().max().item() <= 2e-5 * max(1.0, plain.abs().max().item())
 
 
 @pytest.mark.parametrize("case", [(1, 2, 70, 128, 40), (2, 1, 131, 64, 40), (1, 2, 40, 32, 10), (1, 1, 200, 256, 24)])
