@@ -721,7 +721,7 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_row_kernel(CorrWarpBwdArgs
 template <int LPP, int DT>
 __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdArgs p) {
     HIP_DYNAMIC_SHARED(float, smem)
-    constexpr int NT = 1024, PPB = NT / LPP, NI = 3, GS = 8;
+    constexpr int NT = 1024, PPB = NT / LPP, NI = 3, GS = 8, KL = 8;
     static_assert(DT + 1 <= GS, "g staging holds D + 1 channels");
     const int C4 = p.C >> 2, WC = p.W * p.C;
     float* const sL = smem;                     // [W][C]
@@ -731,9 +731,8 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
     float* const su = sg + p.W * GS;            // [W]
     float* const sw0 = su + p.W;                // [W] tap weights (0 where the tap is masked) and tap columns of every pixel
     float* const sw1 = sw0 + p.W;
-    int* const si0 = reinterpret_cast<int*>(sw1 + p.W);
-    int* const si1 = si0 + p.W;
-    float* const smax = reinterpret_cast<float*>(si1 + p.W);     // [16] wave maxima of |u|
+    int* const cnt = reinterpret_cast<int*>(sw1 + p.W);          // [W]      taps that land on a source column ...
+    int* const lst = cnt + p.W;                                  // [W][KL]  ... and who they are: (pixel << 1) | tap
     const int tid = threadIdx.x, sub = tid % LPP;
     const float inv_c = 1.0f / (float)p.C;
     const int row = blockIdx.x;
@@ -787,13 +786,7 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
         const int q = tid + k * NT;
         if (q < p.W * GS) sg[q] = vg[k];
     }
-    {
-        float m = fabsf(vu);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        if (tid < p.W) su[tid] = vu;
-        if ((tid & 63) == 0) smax[tid >> 6] = m;
-    }
+    if (tid < p.W) { su[tid] = vu; cnt[tid] = 0; }
     __syncthreads();
     // ---- round trip 2: the slope taps (right features at the two source columns of every pixel's warp) ------------------------------------------------
     float4 s0[NI], s1[NI];
@@ -810,7 +803,13 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
         const int i0 = (int)x0s, i1 = (int)x1s;
         s0[k] = mh_buf_load4(rs_img, (live && p.du) ? ((rowbase + i0) * p.img_ld + sub * 4) * 4 : MH_OOB);
         s1[k] = mh_buf_load4(rs_img, (live && p.du) ? ((rowbase + i1) * p.img_ld + sub * 4) * 4 : MH_OOB);
-        if (x < p.W && sub == 0) { sw0[x] = (x1 - cx) * m0[k]; sw1[x] = (cx - x0) * m1[k]; si0[x] = i0; si1[x] = i1; }
+        if (x < p.W && sub == 0 && p.dimg) {
+            // the pixel's two taps register with their source columns: integer LDS atomics, two per PIXEL (the float scatter needed 2 C per pixel)
+            const float w0 = (x1 - cx) * m0[k], w1 = (cx - x0) * m1[k];
+            sw0[x] = w0; sw1[x] = w1;
+            if (w0 != 0.f) { const int sl = atomicAdd(cnt + i0, 1); if (sl < KL) lst[i0 * KL + sl] = x << 1; }
+            if (w1 != 0.f) { const int sl = atomicAdd(cnt + i1, 1); if (sl < KL) lst[i1 * KL + sl] = (x << 1) | 1; }
+        }
     }
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
@@ -858,10 +857,6 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
         const int x = q / C4, c4 = q - x * C4;
         vd[k] = mh_buf_load4(rs_di, q < nq ? ((rowbase + x) * p.dimg_ld + c4 * 4) * 4 : MH_OOB);
     }
-    float um = 0.f;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) um = fmaxf(um, smax[w]);
-    const int reach = (um < (float)p.W ? (int)ceilf(um) : p.W) + 1;      // |x - xs| <= ceil(max |u|) + 1 for every tap that lands on xs (NaN / inf: the whole row)
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
@@ -869,13 +864,41 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
         if (q >= nq) continue;
         const int xs = q / C4, c4 = q - xs * C4;
         float4 acc = vd[k];
-        const int xa = xs - reach > 0 ? xs - reach : 0, xb = xs + reach < p.W - 1 ? xs + reach : p.W - 1;
-        for (int x = xa; x <= xb; ++x) {
-            const bool h0 = si0[x] == xs && sw0[x] != 0.f, h1 = si1[x] == xs && sw1[x] != 0.f;
-            if (h0 || h1) {
-                const float4 rv = *reinterpret_cast<const float4*>(rb + x * p.C + c4 * 4);
-                if (h0) { const float w = sw0[x]; acc.x += w * rv.x; acc.y += w * rv.y; acc.z += w * rv.z; acc.w += w * rv.w; }
-                if (h1) { const float w = sw1[x]; acc.x += w * rv.x; acc.y += w * rv.y; acc.z += w * rv.z; acc.w += w * rv.w; }
+        const int n = cnt[xs];
+        if (n <= KL) {
+            // the column's taps in ascending (pixel, tap) order whatever order they registered in: the sum is bit-identical from run to run
+            const int4 ea = *reinterpret_cast<const int4*>(lst + xs * KL), eb = *reinterpret_cast<const int4*>(lst + xs * KL + 4);
+            int e[KL] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
+#pragma unroll
+            for (int i = 0; i < KL; ++i) e[i] = i < n ? e[i] : 0x7fffffff;
+            if (n > 2) {
+#define MH_CSWAP(i, j) { const int lo_ = min(e[i], e[j]), hi_ = max(e[i], e[j]); e[i] = lo_; e[j] = hi_; }
+                MH_CSWAP(0, 1) MH_CSWAP(2, 3) MH_CSWAP(4, 5) MH_CSWAP(6, 7) MH_CSWAP(0, 2) MH_CSWAP(1, 3) MH_CSWAP(4, 6) MH_CSWAP(5, 7) MH_CSWAP(1, 2) MH_CSWAP(5, 6)
+                MH_CSWAP(0, 4) MH_CSWAP(1, 5) MH_CSWAP(2, 6) MH_CSWAP(3, 7) MH_CSWAP(2, 4) MH_CSWAP(3, 5) MH_CSWAP(1, 2) MH_CSWAP(3, 4) MH_CSWAP(5, 6)
+#undef MH_CSWAP
+            } else if (n == 2 && e[1] < e[0]) { const int t = e[0]; e[0] = e[1]; e[1] = t; }
+#pragma unroll
+            for (int i = 0; i < KL; ++i) {
+                if (i < n) {
+                    const int x = e[i] >> 1;
+                    const float w = (e[i] & 1) ? sw1[x] : sw0[x];
+                    const float4 rv = *reinterpret_cast<const float4*>(rb + x * p.C + c4 * 4);
+                    acc.x += w * rv.x; acc.y += w * rv.y; acc.z += w * rv.z; acc.w += w * rv.w;
+                }
+            }
+        } else {
+            // more than KL taps land on this column (strong compression of the warp): scan the row, ascending
+            for (int x = 0; x < p.W; ++x) {
+                const float cx = (float)x + su[x];
+                const float x0 = floorf(cx);
+                const float xmax = (float)(p.W - 1);
+                const float x0s = fminf(fmaxf(x0, 0.f), xmax), x1s = fminf(fmaxf(x0 + 1.0f, 0.f), xmax);
+                const bool h0 = (int)x0s == xs && sw0[x] != 0.f, h1 = (int)x1s == xs && sw1[x] != 0.f;
+                if (h0 || h1) {
+                    const float4 rv = *reinterpret_cast<const float4*>(rb + x * p.C + c4 * 4);
+                    if (h0) { const float w = sw0[x]; acc.x += w * rv.x; acc.y += w * rv.y; acc.z += w * rv.z; acc.w += w * rv.w; }
+                    if (h1) { const float w = sw1[x]; acc.x += w * rv.x; acc.y += w * rv.y; acc.z += w * rv.z; acc.w += w * rv.w; }
+                }
             }
         }
         *reinterpret_cast<float4*>(p.dimg + (int64_t)(rowbase + xs) * p.dimg_ld + c4 * 4) = acc;
@@ -1526,7 +1549,7 @@ extern "C" int mh_corr_warp_bwd(const float* g, int32_t g_ld, int32_t coff, cons
         // operands staged in LDS: 3 rows of W x C floats + the g / u / tap rows; a thread owns <= 3 (pixel, channel group) items.  Gather, no atomics:
         // deterministic as it is (mh_tune_corr_row bit 1 set = the scatter form below; bit 2 = this launch without its scatter / gather part: timing)
         const int lpp = C4 <= 8 ? 8 : C4 <= 16 ? 16 : 32;
-        const size_t lds_st = ((size_t)3 * W * C + (size_t)W * 13 + 16) * 4;
+        const size_t lds_st = ((size_t)3 * W * C + (size_t)W * (8 + 1 + 2 + 1 + 8)) * 4;
         if ((g_corr_row.load() & 2) == 0 && C4 <= 32 && W <= 3 * (1024 / lpp) && (int64_t)W * C4 <= 3 * 1024 && W * 8 <= 3 * 1024 && lds_st <= 155 * 1024) {
             if (g_corr_row.load() & 4) a.dimg = nullptr;
             if (lpp == 8) hipLaunchKernelGGL((corr_warp_bwd_rowlds_kernel<8, 5>), grid, dim3(1024), lds_st, s, a);

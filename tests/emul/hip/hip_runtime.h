@@ -301,6 +301,7 @@ static inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsig
 }
 
 static inline unsigned long long atomicAdd(unsigned long long* addr, unsigned long long v) { return __atomic_fetch_add(addr, v, __ATOMIC_RELAXED); }
+static inline int atomicAdd(int* addr, int v) { return __atomic_fetch_add(addr, v, __ATOMIC_RELAXED); }
 #define HIP_SYMBOL(x) (&(x))
 static inline hipError_t hipMemcpyToSymbol(void* sym, const void* src, size_t n) { memcpy(sym, src, n); return hipSuccess; }
 static inline float atomicAdd(float* addr, float v) {

@@ -470,6 +470,36 @@ def test_corr_warp_bwd_fused_matches_corr_bwd_then_warp_bwd(backend, case, form)
         backend.lib.tune_corr_row(1)
 
 
+def test_corr_warp_bwd_many_taps_on_one_column(backend):
+    """A warp that sends MANY pixels to the same source column (u = const - x over a span: 12 / 40 taps per column, more than the 8 slots of a
+    column's tap list in the row kernel): the gather falls back to scanning the row for such columns; result = the two-launch sequence."""
+    B, H, W, Cc, md = 1, 3, 40, 32, 2
+    dev = backend.device
+    D = 2 * md + 1
+    ld = (Cc + D + 1 + 3) // 4 * 4
+    g = torch.randn(B, H, W, ld, device=dev)
+    L = torch.randn(B, H, W, Cc, device=dev); R = torch.randn(B, H, W, Cc, device=dev)
+    xs = torch.arange(W, dtype=torch.float32)
+    u = torch.zeros(B, H, W)
+    u[0, 0] = 17.3 - xs                                  # the whole row lands on columns 17 / 18
+    u[0, 1, 10:22] = 5.5 - xs[10:22]                     # twelve pixels on columns 5 / 6, the rest in place
+    u[0, 2] = (torch.rand(W) - 0.5) * 3.0
+    u = u.to(dev)
+    Rw = torch.zeros(B, H, W, Cc, device=dev)
+    ops.warp_fwd(backend.lib, ops.view(R), u, ops.view(Rw))
+    gv = ops.View(g, B, H, W, ld, ld)
+    dL0 = torch.zeros(B, H, W, Cc, device=dev); dRw = torch.zeros(B, H, W, Cc, device=dev); di0 = torch.zeros(B, H, W, Cc, device=dev); du0 = torch.zeros(B, H, W, device=dev)
+    ops.corr_bwd(backend.lib, gv, ops.view(L), ops.view(Rw), ops.view(dL0), ops.view(dRw), md, 1, coff=Cc, du=du0, copy_left=True)
+    ops.warp_bwd(backend.lib, ops.view(dRw), ops.view(R), u, ops.view(di0), du=du0, acc_u=True)
+    dL1 = torch.zeros(B, H, W, Cc, device=dev); di1 = torch.zeros(B, H, W, Cc, device=dev); du1 = torch.zeros(B, H, W, device=dev)
+    ops.corr_warp_bwd(backend.lib, gv, ops.view(L), ops.view(Rw), ops.view(R), u, ops.view(dL1), ops.view(di1), du1, md, 1, coff=Cc, copy_left=True)
+    backend.sync()
+    assert "corr_warp_bwd_rowlds_kernel" in backend.lib.last_kernel().decode()
+    assert (di0.cpu() - di1.cpu()).abs().max().item() <= 2e-5 * max(1.0, di0.abs().max().item())
+    assert (du0.cpu() - du1.cpu()).abs().max().item() <= 2e-5 * max(1.0, du0.abs().max().item())
+    assert di0[0, 0].abs().max().item() > 2.0 * di0[0, 2].abs().max().item()       # (the test means something: 40 taps summed on one column)
+
+
 def test_corr_warp_bwd_row_form_is_deterministic_without_a_twin(backend):
     """The default row-owned kernel GATHERS the warp-gradient taps in a fixed order: two launches on the same operands give bit-identical results, with
     or without a registered deterministic range (the global-atomic form needs the range's fixed-point twin + mh_det_flush for that).  The scatter form
