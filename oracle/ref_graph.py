@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--bulkhead", type=int, default=0)
     ap.add_argument("--block-config", default=None)
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--warping", type=int, default=1, help="MADNet kwarg `warping` (Nets/MadNet.py:13,282-285): 0 = correlate against the un-warped right features")
     a = ap.parse_args()
 
     sys.dont_write_bytecode = True
@@ -64,6 +65,8 @@ def main():
         net_args["sequence"] = True
         net_args["train_portion"] = "BEGIN"
         net_args["bulkhead"] = True if a.bulkhead else False
+        if not a.warping:
+            net_args["warping"] = False
         stereo_net = Nets.get_stereo_net(a.net, net_args)
         predictions = stereo_net.get_disparities()
     inputs = {"left": left, "right": right}

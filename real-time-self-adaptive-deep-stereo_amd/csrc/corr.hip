@@ -721,7 +721,7 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_row_kernel(CorrWarpBwdArgs
 template <int LPP, int DT>
 __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdArgs p) {
     HIP_DYNAMIC_SHARED(float, smem)
-    constexpr int NT = 1024, PPB = NT / LPP, NI = 3, GS = 8, KL = 8;
+    constexpr int NT = 1024, PPB = NT / LPP, NI = 3, GS = 8, KL = 8, NOVF = 63;
     static_assert(DT + 1 <= GS, "g staging holds D + 1 channels");
     const int C4 = p.C >> 2, WC = p.W * p.C;
     float* const sL = smem;                     // [W][C]
@@ -733,6 +733,8 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
     float* const sw1 = sw0 + p.W;
     int* const cnt = reinterpret_cast<int*>(sw1 + p.W);          // [W]      taps that land on a source column ...
     int* const lst = cnt + p.W;                                  // [W][KL]  ... and who they are: (pixel << 1) | tap
+    int* const ovf = lst + p.W * KL;                             // [NOVF]   taps beyond a column's KL slots: (column << 16) | (pixel << 1) | tap
+    int* const novf = ovf + NOVF;                                // how many of those
     const int tid = threadIdx.x, sub = tid % LPP;
     const float inv_c = 1.0f / (float)p.C;
     const int row = blockIdx.x;
@@ -787,6 +789,7 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
         if (q < p.W * GS) sg[q] = vg[k];
     }
     if (tid < p.W) { su[tid] = vu; cnt[tid] = 0; }
+    if (tid == 0) novf[0] = 0;
     __syncthreads();
     // ---- round trip 2: the slope taps (right features at the two source columns of every pixel's warp) ------------------------------------------------
     float4 s0[NI], s1[NI];
@@ -807,8 +810,16 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
             // the pixel's two taps register with their source columns: integer LDS atomics, two per PIXEL (the float scatter needed 2 C per pixel)
             const float w0 = (x1 - cx) * m0[k], w1 = (cx - x0) * m1[k];
             sw0[x] = w0; sw1[x] = w1;
-            if (w0 != 0.f) { const int sl = atomicAdd(cnt + i0, 1); if (sl < KL) lst[i0 * KL + sl] = x << 1; }
-            if (w1 != 0.f) { const int sl = atomicAdd(cnt + i1, 1); if (sl < KL) lst[i1 * KL + sl] = (x << 1) | 1; }
+            if (w0 != 0.f) {
+                const int sl = atomicAdd(cnt + i0, 1);
+                if (sl < KL) lst[i0 * KL + sl] = x << 1;
+                else { const int o = atomicAdd(novf, 1); if (o < NOVF) ovf[o] = (i0 << 16) | (x << 1); }
+            }
+            if (w1 != 0.f) {
+                const int sl = atomicAdd(cnt + i1, 1);
+                if (sl < KL) lst[i1 * KL + sl] = (x << 1) | 1;
+                else { const int o = atomicAdd(novf, 1); if (o < NOVF) ovf[o] = (i1 << 16) | (x << 1) | 1; }
+            }
         }
     }
 #pragma unroll
@@ -886,8 +897,24 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
                     acc.x += w * rv.x; acc.y += w * rv.y; acc.z += w * rv.z; acc.w += w * rv.w;
                 }
             }
+        } else if (novf[0] <= NOVF) {
+            // more than KL taps land on this column (strong compression of the warp), the surplus sits in the row's overflow pool: the column's taps from
+            // both places, smallest (pixel, tap) key first (selection: such columns are rare and hold a handful of taps)
+            const int no = novf[0];
+            int last = -1;
+            for (;;) {
+                int best = 0x7fffffff;
+                for (int i = 0; i < KL; ++i) { const int kq = lst[xs * KL + i]; if (kq > last && kq < best) best = kq; }
+                for (int j = 0; j < no; ++j) { const int eq = ovf[j]; const int kq = eq & 0xffff; if ((eq >> 16) == xs && kq > last && kq < best) best = kq; }
+                if (best == 0x7fffffff) break;
+                const int x = best >> 1;
+                const float w = (best & 1) ? sw1[x] : sw0[x];
+                const float4 rv = *reinterpret_cast<const float4*>(rb + x * p.C + c4 * 4);
+                acc.x += w * rv.x; acc.y += w * rv.y; acc.z += w * rv.z; acc.w += w * rv.w;
+                last = best;
+            }
         } else {
-            // more than KL taps land on this column (strong compression of the warp): scan the row, ascending
+            // the pool overflowed too (most of the row lands on a few columns): scan the row, ascending
             for (int x = 0; x < p.W; ++x) {
                 const float cx = (float)x + su[x];
                 const float x0 = floorf(cx);
@@ -1549,8 +1576,8 @@ extern "C" int mh_corr_warp_bwd(const float* g, int32_t g_ld, int32_t coff, cons
         // operands staged in LDS: 3 rows of W x C floats + the g / u / tap rows; a thread owns <= 3 (pixel, channel group) items.  Gather, no atomics:
         // deterministic as it is (mh_tune_corr_row bit 1 set = the scatter form below; bit 2 = this launch without its scatter / gather part: timing)
         const int lpp = C4 <= 8 ? 8 : C4 <= 16 ? 16 : 32;
-        const size_t lds_st = ((size_t)3 * W * C + (size_t)W * (8 + 1 + 2 + 1 + 8)) * 4;
-        if ((g_corr_row.load() & 2) == 0 && C4 <= 32 && W <= 3 * (1024 / lpp) && (int64_t)W * C4 <= 3 * 1024 && W * 8 <= 3 * 1024 && lds_st <= 155 * 1024) {
+        const size_t lds_st = ((size_t)3 * W * C + (size_t)W * (8 + 1 + 2 + 1 + 8) + 64) * 4;
+        if ((g_corr_row.load() & 2) == 0 && C4 <= 32 && W <= 3 * (1024 / lpp) && (int64_t)W * C4 <= 3 * 1024 && W * 8 <= 3 * 1024 && W < 32768 && lds_st <= 155 * 1024) {
             if (g_corr_row.load() & 4) a.dimg = nullptr;
             if (lpp == 8) hipLaunchKernelGGL((corr_warp_bwd_rowlds_kernel<8, 5>), grid, dim3(1024), lds_st, s, a);
             else if (lpp == 16) hipLaunchKernelGGL((corr_warp_bwd_rowlds_kernel<16, 5>), grid, dim3(1024), lds_st, s, a);

@@ -43,15 +43,19 @@ for (B, H, W, C) in [(1, 96, 320, 32), (1, 48, 160, 64), (1, 24, 80, 96), (1, 12
     dL = torch.zeros_like(L); dimg = torch.zeros_like(L); du = torch.zeros(B, H, W, device=dev)
     gv = ops.View(g, B, H, W, ld, ld)
     byts = float(B) * H * W * (8 * C + D + 3) * 4
-    for amp in ((8.0, 48.0) if B == 1 else (8.0,)):
-        u = (torch.rand(B, H, W, device=dev) - 0.5) * amp
+    for amp in ((8.0, 48.0, -48.0) if B == 1 else (8.0,)):
+        if amp > 0:
+            u = (torch.rand(B, H, W, device=dev) - 0.5) * amp                    # white noise: adversarial (taps pile up at random)
+        else:
+            xx = torch.arange(W, device=dev, dtype=torch.float32)
+            u = (0.5 * amp * torch.sin(xx / 25.0))[None, None, :].expand(B, H, W).contiguous() + (torch.rand(B, H, W, device=dev) - 0.5)      # smooth, like a disparity map
         Rw = torch.empty_like(R); ops.warp_fwd(lib, ops.view(R), u, ops.view(Rw)); torch.cuda.synchronize()
-        for mode in (0, 3, 1, 5):
+        for mode in (0, 1):
             lib.tune_corr_row(mode)
             us, k = graph_us(lambda r: ops.corr_warp_bwd(r, gv, ops.view(L), ops.view(Rw), ops.view(R), u, ops.view(dL), ops.view(dimg), du, 2, 1, coff=C, acc_l=True, copy_left=True),
                              n=(20 if B < 64 else 3), reps=(10 if B < 64 else 4))
-            print("B=%-2d %3dx%3dx%3d |u|<=%2d %-16s %8.1f us  %7.0f GB/s algorithmic (%4.1f %% of 8 TB/s)   %s"
-                  % (B, H, W, C, amp / 2, {0: "atomic", 3: "row scatter", 1: "row gather", 5: "row, no gather"}[mode], us, byts / us / 1e3, byts / us / 1e3 / 80, k))
+            print("B=%-2d %3dx%3dx%3d |u|<=%2d%s %-16s %8.1f us  %7.0f GB/s algorithmic (%4.1f %% of 8 TB/s)   %s"
+                  % (B, H, W, C, abs(amp) / 2, ("~" if amp < 0 else " "), {0: "atomic", 3: "row scatter", 1: "row gather", 5: "row, no gather"}[mode], us, byts / us / 1e3, byts / us / 1e3 / 80, k))
         lib.tune_corr_row(1)
     if B == 64:
         dR = torch.zeros_like(L)
