@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--block-config", default=None)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--warping", type=int, default=1, help="MADNet kwarg `warping` (Nets/MadNet.py:13,282-285): 0 = correlate against the un-warped right features")
+    ap.add_argument("--reprojection-scale", type=int, default=1, help="MAD: --reprojectionScale of Stereo_Online_Adaptation.py:91-95,309")
     a = ap.parse_args()
 
     sys.dont_write_bytecode = True
@@ -93,11 +94,16 @@ def main():
         train_config = json.load(open(a.block_config))
         preds = predictions[:-1]
         assert len(preds) == len(train_config)
+
+        def scale_tensor(tensor, scale):            # Stereo_Online_Adaptation.py:22-23 (a function of the driver script: restated, it calls the reference's rescale_image)
+            return preprocessing.rescale_image(tensor, [tf.shape(tensor)[1] // scale, tf.shape(tensor)[2] // scale])
+
+        inputs_modules = {"left": scale_tensor(left, a.reprojection_scale), "right": scale_tensor(right, a.reprojection_scale)}      # :91-95
         for counter, p in enumerate(preds):
             multiplier = tf.cast(tf.shape(left)[1] // tf.shape(p)[1], tf.float32)
-            p = preprocessing.resize_to_prediction(p, inputs["left"]) * multiplier
+            p = preprocessing.resize_to_prediction(p, inputs_modules["left"]) * multiplier
             with tf.variable_scope("reprojection_" + str(counter)):
-                rl = loss_factory.get_reprojection_loss("mean_SSIM_l1", reduced=True)([p], inputs)
+                rl = loss_factory.get_reprojection_loss("mean_SSIM_l1", reduced=True)([p], inputs_modules)
             var_accumulator = []
             for name in train_config[counter]:
                 var_accumulator += stereo_net.get_variables(name)

@@ -46,6 +46,7 @@ def cases():
         "madnet_mad_60x100": ("MADNet", 60, 100, 1, "MadNet_full.json", 1),
         "madnet_mad_pyramid_only_60x100": ("MADNet", 60, 100, 1, "MadNet_piramid_only.json", 1),
         "madnet_full_60x100_nowarp": ("MADNet", 60, 100, 0, None, 1, 0),         # warping=False (Nets/MadNet.py:282-285 ...)
+        "madnet_mad_60x100_rs2": ("MADNet", 60, 100, 1, "MadNet_full.json", 1, 1, 2),      # --reprojectionScale 2 (Stereo_Online_Adaptation.py:91-107)
         "dispnet_full_64x128": ("Dispnet", 64, 128, 0, None, 1),
         "madnet_full_375x1242": ("MADNet", 375, 1242, 0, None, 8),
         "dispnet_full_375x1242": ("Dispnet", 375, 1242, 0, None, 8),             # the reflect pad to 384x1280 and the final crop executed from the reference source
@@ -55,6 +56,11 @@ def cases():
 def warping_of(name):
     c = cases()[name]
     return bool(c[6]) if len(c) > 6 else True
+
+
+def reprojection_scale_of(name):
+    c = cases()[name]
+    return int(c[7]) if len(c) > 7 else 1
 
 
 def case_inputs(name):
@@ -98,6 +104,8 @@ def run_reference(name, threads=0):
             cmd += ["--threads", str(threads)]
         if not warping_of(name):
             cmd += ["--warping", "0"]
+        if reprojection_scale_of(name) != 1:
+            cmd += ["--reprojection-scale", str(reprojection_scale_of(name))]
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
         rc = subprocess.run(cmd, capture_output=True, text=True, env=env)
         if rc.returncode != 0:

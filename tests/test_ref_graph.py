@@ -61,7 +61,10 @@ def _oracle_case(name):
             bv = sum((lv[n] for n in names), [])
             p = disps[k]
             mult = float(lt.shape[1] // p.shape[1])                       # Stereo_Online_Adaptation.py:102-103
-            lk = T.reprojection_loss(T.resize_bilinear(p, lt.shape[1], lt.shape[2]) * mult, lt, rt)
+            rs = G.reprojection_scale_of(name)                            # :91-95: the blocks' losses see the frames scaled down, `mult` stays the ratio to the full frame
+            ls = T.resize_bilinear(lt, lt.shape[1] // rs, lt.shape[2] // rs) if rs != 1 else lt
+            rr = T.resize_bilinear(rt, rt.shape[1] // rs, rt.shape[2] // rs) if rs != 1 else rt
+            lk = T.reprojection_loss(T.resize_bilinear(p, ls.shape[1], ls.shape[2]) * mult, ls, rr)
             out["blockloss_%d" % k] = np.float32(lk.detach().numpy())
             out["blockvars_%d" % k] = json.dumps(bv)
             gs = torch.autograd.grad(lk, [wt[n] for n in bv], allow_unused=True, retain_graph=True)
@@ -206,13 +209,15 @@ def test_hip_madnet_engine_vs_reference_graph_fixture(hip, name):
 
 
 @pytest.mark.gpu
-def test_hip_mad_blocks_vs_reference_graph_fixture(hip):
-    """bulkhead on: block losses and block gradients of the exact-fp32 engine against the reference graph's MAD train ops"""
+@pytest.mark.parametrize("name", ["madnet_mad_60x100", "madnet_mad_60x100_rs2"])
+def test_hip_mad_blocks_vs_reference_graph_fixture(hip, name):
+    """bulkhead on: block losses and block gradients of the exact-fp32 engine against the reference graph's MAD train ops (also with --reprojectionScale 2)"""
     from madnet_hip import engine as E
-    name = "madnet_mad_60x100"
     net, l, r, gt, wn, bulk, cfg, stride = G.case_inputs(name)
     gold = _golden(name)
     eng = E.MadNetEngine(hip.lib, l.shape[1], l.shape[2], B=1, device="cuda", weights=wn)
+    if G.reprojection_scale_of(name) != 1:
+        eng.set_reprojection_scale(G.reprojection_scale_of(name))
     eng.set_inputs(l, r, gt[..., 0])
     for k, level in enumerate(E.LEVELS):
         bv = json.loads(str(gold["blockvars_%d" % k]))
