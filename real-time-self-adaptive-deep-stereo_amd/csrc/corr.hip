@@ -712,16 +712,17 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_row_kernel(CorrWarpBwdArgs
 //   * ONE round trip brings the row in: the left and the warped-right feature rows, the D + 1 correlation / disparity channels of g and the u row go to LDS
 //     (each element read once, coalesced), the per-item operands that do not depend on u (the concat-copy part of g, the accumulate operand of dL) to
 //     registers; a second round trip fetches the two slope taps of every item (their address needs u).  The 2 DT shifted products read LDS;
-//   * the gradient w.r.t. the warped features r(x) of every pixel is stored to LDS (plain 16-byte stores, every item its own slot) with the pixel's tap
-//     columns and weights; after a barrier every (source column xs, channel group) item GATHERS: the pixels whose taps can land on xs lie within
-//     ceil(max |u|) + 1 columns of it (max |u| of the row: wave maxima through LDS), each candidate costs an LDS broadcast read and two compares, a match
-//     one 16-byte read and four FMAs.  Ascending x, fixed order: the sum is bit-identical from run to run -- no atomics, no fixed-point twin, and the
-//     same kernel serves the deterministic mode.
+//   * the gradient w.r.t. the warped features r(x) of every pixel is stored to LDS (plain 16-byte stores, every item its own slot); the row's taps are
+//     bucketed by the source column they land on -- a counting sort in LDS: two INTEGER atomics per pixel count, one wave scans the W counters, two more
+//     atomics per pixel place (pixel, tap) keys into the column's segment (the float scatter needed 2 C atomics per pixel) -- and every (source column,
+//     channel group) item GATHERS its segment: typically two taps, one 16-byte read and four FMAs each.  Segments of up to 64 taps are summed in ascending
+//     key order whatever order they were placed in (sorting network up to 8, selection beyond): bit-identical from run to run -- no float atomics, no
+//     fixed-point twin, the same kernel serves the deterministic mode; only a fold of more than 64 taps onto one column is summed in arrival order.
 // A thread owns at most NI = 3 (pixel, channel group) items: LPP >= C / 4 lanes per pixel.
 template <int LPP, int DT>
 __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdArgs p) {
     HIP_DYNAMIC_SHARED(float, smem)
-    constexpr int NT = 1024, PPB = NT / LPP, NI = 3, GS = 8, KL = 8, NOVF = 63;
+    constexpr int NT = 1024, PPB = NT / LPP, NI = 3, GS = 8, KL = 8, KSEL = 64;
     static_assert(DT + 1 <= GS, "g staging holds D + 1 channels");
     const int C4 = p.C >> 2, WC = p.W * p.C;
     float* const sL = smem;                     // [W][C]
@@ -731,10 +732,9 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
     float* const su = sg + p.W * GS;            // [W]
     float* const sw0 = su + p.W;                // [W] tap weights (0 where the tap is masked) and tap columns of every pixel
     float* const sw1 = sw0 + p.W;
-    int* const cnt = reinterpret_cast<int*>(sw1 + p.W);          // [W]      taps that land on a source column ...
-    int* const lst = cnt + p.W;                                  // [W][KL]  ... and who they are: (pixel << 1) | tap
-    int* const ovf = lst + p.W * KL;                             // [NOVF]   taps beyond a column's KL slots: (column << 16) | (pixel << 1) | tap
-    int* const novf = ovf + NOVF;                                // how many of those
+    int* const cnt = reinterpret_cast<int*>(sw1 + p.W);          // [W]      taps that land on a source column (counted, then counted down by the placement)
+    int* const base = cnt + p.W;                                 // [W + 1]  exclusive prefix sum of cnt: the column's segment of ent
+    int* const ent = base + p.W + 1;                             // [2 W]    (pixel << 1) | tap, bucketed by source column
     const int tid = threadIdx.x, sub = tid % LPP;
     const float inv_c = 1.0f / (float)p.C;
     const int row = blockIdx.x;
@@ -789,7 +789,6 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
         if (q < p.W * GS) sg[q] = vg[k];
     }
     if (tid < p.W) { su[tid] = vu; cnt[tid] = 0; }
-    if (tid == 0) novf[0] = 0;
     __syncthreads();
     // ---- round trip 2: the slope taps (right features at the two source columns of every pixel's warp) ------------------------------------------------
     float4 s0[NI], s1[NI];
@@ -807,19 +806,11 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
         s0[k] = mh_buf_load4(rs_img, (live && p.du) ? ((rowbase + i0) * p.img_ld + sub * 4) * 4 : MH_OOB);
         s1[k] = mh_buf_load4(rs_img, (live && p.du) ? ((rowbase + i1) * p.img_ld + sub * 4) * 4 : MH_OOB);
         if (x < p.W && sub == 0 && p.dimg) {
-            // the pixel's two taps register with their source columns: integer LDS atomics, two per PIXEL (the float scatter needed 2 C per pixel)
+            // the pixel's two taps are counted at their source columns: integer LDS atomics, two per PIXEL
             const float w0 = (x1 - cx) * m0[k], w1 = (cx - x0) * m1[k];
             sw0[x] = w0; sw1[x] = w1;
-            if (w0 != 0.f) {
-                const int sl = atomicAdd(cnt + i0, 1);
-                if (sl < KL) lst[i0 * KL + sl] = x << 1;
-                else { const int o = atomicAdd(novf, 1); if (o < NOVF) ovf[o] = (i0 << 16) | (x << 1); }
-            }
-            if (w1 != 0.f) {
-                const int sl = atomicAdd(cnt + i1, 1);
-                if (sl < KL) lst[i1 * KL + sl] = (x << 1) | 1;
-                else { const int o = atomicAdd(novf, 1); if (o < NOVF) ovf[o] = (i1 << 16) | (x << 1) | 1; }
-            }
+            if (w0 != 0.f) atomicAdd(cnt + i0, 1);
+            if (w1 != 0.f) atomicAdd(cnt + i1, 1);
         }
     }
 #pragma unroll
@@ -860,7 +851,7 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
         }
     }
     if (!p.dimg) return;
-    // ---- the row of the right tower's gradient: previous content (requested now, used behind the barrier) + the gathered taps -----------------------------
+    // ---- the row of the right tower's gradient: previous content (requested now, used behind the barriers) + the gathered taps -----------------------------
     float4 vd[NI];
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
@@ -869,19 +860,51 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
         vd[k] = mh_buf_load4(rs_di, q < nq ? ((rowbase + x) * p.dimg_ld + c4 * 4) * 4 : MH_OOB);
     }
     __syncthreads();
+    if (tid < 64) {
+        // exclusive prefix sum of the W column counts by ONE wave: lane l owns columns [l * per, (l + 1) * per)
+        const int per = (p.W + 63) >> 6;
+        int sum = 0;
+        for (int i = 0; i < per; ++i) { const int x = tid * per + i; if (x < p.W) sum += cnt[x]; }
+        int inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (tid >= o) inc += t; }
+        int run = inc - sum;
+        for (int i = 0; i < per; ++i) { const int x = tid * per + i; if (x < p.W) { base[x] = run; run += cnt[x]; } }
+        if (tid == 63) base[p.W] = inc;
+    }
+    __syncthreads();
+    // placement: every tap takes a slot of its column's segment (counting the column's counter down: the segment fills from its end)
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int x = k * PPB + tid / LPP;
+        if (x < p.W && sub == 0) {
+            const float cx = (float)x + su[x];
+            const float x0 = floorf(cx);
+            const float xmax = (float)(p.W - 1);
+            const int i0 = (int)fminf(fmaxf(x0, 0.f), xmax), i1 = (int)fminf(fmaxf(x0 + 1.0f, 0.f), xmax);
+            if (sw0[x] != 0.f) ent[base[i0] + atomicAdd(cnt + i0, -1) - 1] = x << 1;
+            if (sw1[x] != 0.f) ent[base[i1] + atomicAdd(cnt + i1, -1) - 1] = (x << 1) | 1;
+        }
+    }
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
         const int q = tid + k * NT;
         if (q >= nq) continue;
         const int xs = q / C4, c4 = q - xs * C4;
         float4 acc = vd[k];
-        const int n = cnt[xs];
+        const int b0 = base[xs], n = base[xs + 1] - b0;
+        auto add = [&](int key) {
+            const int x = key >> 1;
+            const float w = (key & 1) ? sw1[x] : sw0[x];
+            const float4 rv = *reinterpret_cast<const float4*>(rb + x * p.C + c4 * 4);
+            acc.x += w * rv.x; acc.y += w * rv.y; acc.z += w * rv.z; acc.w += w * rv.w;
+        };
         if (n <= KL) {
-            // the column's taps in ascending (pixel, tap) order whatever order they registered in: the sum is bit-identical from run to run
-            const int4 ea = *reinterpret_cast<const int4*>(lst + xs * KL), eb = *reinterpret_cast<const int4*>(lst + xs * KL + 4);
-            int e[KL] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
+            // the column's taps in ascending (pixel, tap) order whatever order they were placed in: the sum is bit-identical from run to run
+            int e[KL];
 #pragma unroll
-            for (int i = 0; i < KL; ++i) e[i] = i < n ? e[i] : 0x7fffffff;
+            for (int i = 0; i < KL; ++i) e[i] = i < n ? ent[b0 + i] : 0x7fffffff;
             if (n > 2) {
 #define MH_CSWAP(i, j) { const int lo_ = min(e[i], e[j]), hi_ = max(e[i], e[j]); e[i] = lo_; e[j] = hi_; }
                 MH_CSWAP(0, 1) MH_CSWAP(2, 3) MH_CSWAP(4, 5) MH_CSWAP(6, 7) MH_CSWAP(0, 2) MH_CSWAP(1, 3) MH_CSWAP(4, 6) MH_CSWAP(5, 7) MH_CSWAP(1, 2) MH_CSWAP(5, 6)
@@ -889,44 +912,19 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
 #undef MH_CSWAP
             } else if (n == 2 && e[1] < e[0]) { const int t = e[0]; e[0] = e[1]; e[1] = t; }
 #pragma unroll
-            for (int i = 0; i < KL; ++i) {
-                if (i < n) {
-                    const int x = e[i] >> 1;
-                    const float w = (e[i] & 1) ? sw1[x] : sw0[x];
-                    const float4 rv = *reinterpret_cast<const float4*>(rb + x * p.C + c4 * 4);
-                    acc.x += w * rv.x; acc.y += w * rv.y; acc.z += w * rv.z; acc.w += w * rv.w;
-                }
-            }
-        } else if (novf[0] <= NOVF) {
-            // more than KL taps land on this column (strong compression of the warp), the surplus sits in the row's overflow pool: the column's taps from
-            // both places, smallest (pixel, tap) key first (selection: such columns are rare and hold a handful of taps)
-            const int no = novf[0];
+            for (int i = 0; i < KL; ++i)
+                if (i < n) add(e[i]);
+        } else if (n <= KSEL) {
+            // a compressed stretch of the warp: selection, smallest key first (n^2 LDS reads of a short segment)
             int last = -1;
-            for (;;) {
+            for (int t = 0; t < n; ++t) {
                 int best = 0x7fffffff;
-                for (int i = 0; i < KL; ++i) { const int kq = lst[xs * KL + i]; if (kq > last && kq < best) best = kq; }
-                for (int j = 0; j < no; ++j) { const int eq = ovf[j]; const int kq = eq & 0xffff; if ((eq >> 16) == xs && kq > last && kq < best) best = kq; }
-                if (best == 0x7fffffff) break;
-                const int x = best >> 1;
-                const float w = (best & 1) ? sw1[x] : sw0[x];
-                const float4 rv = *reinterpret_cast<const float4*>(rb + x * p.C + c4 * 4);
-                acc.x += w * rv.x; acc.y += w * rv.y; acc.z += w * rv.z; acc.w += w * rv.w;
+                for (int i = 0; i < n; ++i) { const int kq = ent[b0 + i]; if (kq > last && kq < best) best = kq; }
+                add(best);
                 last = best;
             }
         } else {
-            // the pool overflowed too (most of the row lands on a few columns): scan the row, ascending
-            for (int x = 0; x < p.W; ++x) {
-                const float cx = (float)x + su[x];
-                const float x0 = floorf(cx);
-                const float xmax = (float)(p.W - 1);
-                const float x0s = fminf(fmaxf(x0, 0.f), xmax), x1s = fminf(fmaxf(x0 + 1.0f, 0.f), xmax);
-                const bool h0 = (int)x0s == xs && sw0[x] != 0.f, h1 = (int)x1s == xs && sw1[x] != 0.f;
-                if (h0 || h1) {
-                    const float4 rv = *reinterpret_cast<const float4*>(rb + x * p.C + c4 * 4);
-                    if (h0) { const float w = sw0[x]; acc.x += w * rv.x; acc.y += w * rv.y; acc.z += w * rv.z; acc.w += w * rv.w; }
-                    if (h1) { const float w = sw1[x]; acc.x += w * rv.x; acc.y += w * rv.y; acc.z += w * rv.z; acc.w += w * rv.w; }
-                }
-            }
+            for (int i = 0; i < n; ++i) add(ent[b0 + i]);          // a fold of > KSEL taps onto one column: arrival order
         }
         *reinterpret_cast<float4*>(p.dimg + (int64_t)(rowbase + xs) * p.dimg_ld + c4 * 4) = acc;
     }
@@ -1576,7 +1574,7 @@ extern "C" int mh_corr_warp_bwd(const float* g, int32_t g_ld, int32_t coff, cons
         // operands staged in LDS: 3 rows of W x C floats + the g / u / tap rows; a thread owns <= 3 (pixel, channel group) items.  Gather, no atomics:
         // deterministic as it is (mh_tune_corr_row bit 1 set = the scatter form below; bit 2 = this launch without its scatter / gather part: timing)
         const int lpp = C4 <= 8 ? 8 : C4 <= 16 ? 16 : 32;
-        const size_t lds_st = ((size_t)3 * W * C + (size_t)W * (8 + 1 + 2 + 1 + 8) + 64) * 4;
+        const size_t lds_st = ((size_t)3 * W * C + (size_t)W * (8 + 1 + 2 + 1 + 1 + 2) + 8) * 4;
         if ((g_corr_row.load() & 2) == 0 && C4 <= 32 && W <= 3 * (1024 / lpp) && (int64_t)W * C4 <= 3 * 1024 && W * 8 <= 3 * 1024 && W < 32768 && lds_st <= 155 * 1024) {
             if (g_corr_row.load() & 4) a.dimg = nullptr;
             if (lpp == 8) hipLaunchKernelGGL((corr_warp_bwd_rowlds_kernel<8, 5>), grid, dim3(1024), lds_st, s, a);

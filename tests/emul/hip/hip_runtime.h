@@ -234,6 +234,19 @@ static inline float __shfl_xor(float v, int mask) {
     return w.fa[par][lane ^ mask];
 }
 
+// __shfl_up (wave64): lane l receives the value of lane l - delta, lanes below delta keep their own
+static inline int __shfl_up(int v, unsigned delta) {
+    emul::Wave& w = emul::my_wave();
+    const int lane = emul::tls().cur_index & 63;
+    const int par = w.gen & 1;
+    float f; memcpy(&f, &v, 4);
+    w.fa[par][lane] = f;
+    emul::wave_rendezvous(w);
+    const float g = w.fa[par][lane >= (int)delta ? lane - (int)delta : lane];
+    int r; memcpy(&r, &g, 4);
+    return r;
+}
+
 typedef float emul_f32x4 __attribute__((vector_size(16)));
 static inline emul_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emul_f32x4 c, int, int, int) {
     emul::Wave& w = emul::my_wave();

@@ -497,7 +497,7 @@ def test_corr_warp_bwd_many_taps_on_one_column(backend):
     assert "corr_warp_bwd_rowlds_kernel" in backend.lib.last_kernel().decode()
     assert (di0.cpu() - di1.cpu()).abs().max().item() <= 2e-5 * max(1.0, di0.abs().max().item())
     assert (du0.cpu() - du1.cpu()).abs().max().item() <= 2e-5 * max(1.0, du0.abs().max().item())
-    assert di0[0, 0].abs().max().item() > 2.0 * di0[0, 2].abs().max().item()       # (the test means something: 40 taps summed on one column)
+    assert int((di0[0, 0].abs().sum(-1) > 0).sum().item()) == 2 and int((di0[0, 2].abs().sum(-1) > 0).sum().item()) > 30       # (row 0: every tap on two columns)
 
 
 def test_corr_warp_bwd_row_form_is_deterministic_without_a_twin(backend):
