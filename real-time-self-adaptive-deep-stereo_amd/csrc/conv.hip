@@ -969,14 +969,15 @@ int launch_one(ConvArgs& a, hipStream_t s) {
     constexpr size_t tiles = (BF16 ? (size_t)(2 * (BM + BN) * (KT + 16)) * 2 : (size_t)(2 * (BM + BN) * (KT + 4)) * sizeof(float)) * (X3 ? 2 : 1);
     constexpr size_t lds = KG * tiles + 1536;          // + tap_dy / tap_dx / tap_id [64] and row_m [128]
     static_assert(lds <= 160 * 1024, "tiles do not fit the 160 KiB LDS");
-    static bool attr_done = false;       // LDS > 64 KiB needs the opt-in once per instantiation
-    if (!attr_done) {
+    static std::atomic<uint64_t> attr_done{0};       // LDS > 64 KiB needs the opt-in once per instantiation
+    const uint64_t attr_dev = mh_device_bit();
+    if (!(attr_done.load(std::memory_order_relaxed) & attr_dev)) {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC, UNI, BF16, KG, X3, RAG>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) { mh_set_error("conv: hipFuncSetAttribute(%d B LDS): %s", (int)lds, hipGetErrorString(e)); return (int)e; }
         }
-        attr_done = true;
+        attr_done.fetch_or(attr_dev);
     }
     if (a.M < 0) return 0;               // mh_init(): attribute set-up only
     a.mtiles = mh_cdiv(a.M, BM);

@@ -21,6 +21,7 @@
 // hipcc shuffles them through v_accvgpr_* moves at every loop back-edge.
 #include "conv_args.h"
 #include <stdlib.h>
+#include <algorithm>
 #include <atomic>
 
 namespace {
@@ -981,12 +982,13 @@ std::atomic<int> g_patch_launches{0};     // since the last mh_tune_conv_patch()
 template <int WM, int WN, int MT, int NT, bool DGRAD, int CPTC = 0, bool X3 = false>
 int launch_patch(ConvArgs& a, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16, TH = BM / 16;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::atomic<uint64_t> attr_done{0};
+    const uint64_t attr_dev = mh_device_bit();
+    if (!(attr_done.load(std::memory_order_relaxed) & attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<WM, WN, MT, NT, DGRAD, CPTC, X3>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)PATCH_LDS_MAX);
         if (e != hipSuccess) { mh_set_error("conv_patch: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_done = true;
+        attr_done.fetch_or(attr_dev);
     }
     if (a.M < 0) return 0;
     PatchGeo g;
@@ -996,6 +998,11 @@ int launch_patch(ConvArgs& a, hipStream_t s) {
     g.tiles_x = mh_cdiv(mh_cdiv(a.Wo, d), 16);
     g.ntiles_n = mh_cdiv(a.N, BN);
     g.nwg = a.B * d * d * g.tiles_y * g.tiles_x * g.ntiles_n;
+    {
+        const int64_t nwg64 = (int64_t)g.nwg;
+        const int dmax = std::max(std::max(g.ntiles_n, g.tiles_x), std::max(g.tiles_y, (int)d));
+        MH_REQUIRE(mh_fastdiv_ok(nwg64, dmax), MH_ERR_UNSUPPORTED, "tile decode: %lld workgroups x divisor %d exceeds the 2^32 range of the magic-multiplier division", (long long)nwg64, dmax);
+    }
     g.dec = mh_make_tile_decode(g.ntiles_n, g.tiles_x, g.tiles_y, d);
     g.KP = (a.K + 31) & ~31;
     g.CPT = g.KP / 32;
@@ -1017,12 +1024,13 @@ std::atomic<int> g_bank_launches{0};
 template <int WM, int WN, int MT, int NT, bool X3>
 int launch_bank(ConvArgs& a, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16, TH = BM / 16;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::atomic<uint64_t> attr_done{0};
+    const uint64_t attr_dev = mh_device_bit();
+    if (!(attr_done.load(std::memory_order_relaxed) & attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bank_kernel<WM, WN, MT, NT, X3>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)PATCH_LDS_MAX);
         if (e != hipSuccess) { mh_set_error("conv_bank: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_done = true;
+        attr_done.fetch_or(attr_dev);
     }
     if (a.M < 0) return 0;
     PatchGeo g;
@@ -1032,6 +1040,11 @@ int launch_bank(ConvArgs& a, hipStream_t s) {
     g.tiles_x = mh_cdiv(mh_cdiv(a.Wo, d), 16);
     g.ntiles_n = mh_cdiv(a.N, BN);
     g.nwg = a.B * d * d * g.tiles_y * g.tiles_x * g.ntiles_n;
+    {
+        const int64_t nwg64 = (int64_t)g.nwg;
+        const int dmax = std::max(std::max(g.ntiles_n, g.tiles_x), std::max(g.tiles_y, (int)d));
+        MH_REQUIRE(mh_fastdiv_ok(nwg64, dmax), MH_ERR_UNSUPPORTED, "tile decode: %lld workgroups x divisor %d exceeds the 2^32 range of the magic-multiplier division", (long long)nwg64, dmax);
+    }
     g.dec = mh_make_tile_decode(g.ntiles_n, g.tiles_x, g.tiles_y, d);
     g.KP = (a.K + 31) & ~31;
     g.CPT = g.KP / 32;
@@ -1052,12 +1065,13 @@ int launch_bank(ConvArgs& a, hipStream_t s) {
 
 template <bool DGRAD, int PL>
 int launch_bank_small(ConvArgs& a, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::atomic<uint64_t> attr_done{0};
+    const uint64_t attr_dev = mh_device_bit();
+    if (!(attr_done.load(std::memory_order_relaxed) & attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bank_small_kernel<DGRAD, PL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)PATCH_LDS_MAX);
         if (e != hipSuccess) { mh_set_error("conv_bank_small: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_done = true;
+        attr_done.fetch_or(attr_dev);
     }
     if (a.M < 0) return 0;
     PatchGeo g;
@@ -1067,6 +1081,11 @@ int launch_bank_small(ConvArgs& a, hipStream_t s) {
     g.tiles_x = mh_cdiv(mh_cdiv(a.Wo, d), 16);
     g.ntiles_n = mh_cdiv(a.N, 32);
     g.nwg = a.B * d * d * g.tiles_y * g.tiles_x * g.ntiles_n;
+    {
+        const int64_t nwg64 = (int64_t)g.nwg;
+        const int dmax = std::max(std::max(g.ntiles_n, g.tiles_x), std::max(g.tiles_y, (int)d));
+        MH_REQUIRE(mh_fastdiv_ok(nwg64, dmax), MH_ERR_UNSUPPORTED, "tile decode: %lld workgroups x divisor %d exceeds the 2^32 range of the magic-multiplier division", (long long)nwg64, dmax);
+    }
     g.dec = mh_make_tile_decode(g.ntiles_n, g.tiles_x, g.tiles_y, d);
     g.KP = (a.K + 31) & ~31;
     g.CPT = g.KP / 32;

@@ -25,6 +25,7 @@
 //   * the epilogue transposes the tile through LDS and stores 16 bytes per lane: hi plane, lo plane and (only where a non-plane consumer exists) fp32.
 #include "conv_args.h"
 #include <stdlib.h>
+#include <algorithm>
 #include <atomic>
 
 // Bank layout rule (host and kernels agree by this function alone): reductions over more than 128 channels -- except 97..112 and 193..208, the
@@ -565,11 +566,12 @@ template <int MC, int WM, int WN, int MBW, int K16, int PL>
 int launch_planes(PlanesArgs& a, hipStream_t s, bool attr_only) {
     using G = PlanesGeo<MC, WM, WN, MBW, K16, PL>;
     static_assert(G::LDS <= 160 * 1024, "patch planes exceed the LDS");
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::atomic<uint64_t> attr_done{0};
+    const uint64_t attr_dev = mh_device_bit();
+    if (!(attr_done.load(std::memory_order_relaxed) & attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_planes_kernel<MC, WM, WN, MBW, K16, PL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { mh_set_error("conv_planes: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_done = true;
+        attr_done.fetch_or(attr_dev);
     }
     if (attr_only) return 0;
     const int d = a.dil;
@@ -577,6 +579,11 @@ int launch_planes(PlanesArgs& a, hipStream_t s, bool attr_only) {
     a.tiles_x = mh_cdiv(mh_cdiv(a.W, d), MC);
     a.ntiles_n = mh_cdiv(a.N, G::BN);
     a.nwg = a.B * d * d * a.tiles_y * a.tiles_x * a.ntiles_n;
+    {
+        const int64_t nwg64 = (int64_t)a.nwg;
+        const int dmax = std::max(std::max(a.ntiles_n, a.tiles_x), std::max(a.tiles_y, (int)d));
+        MH_REQUIRE(mh_fastdiv_ok(nwg64, dmax), MH_ERR_UNSUPPORTED, "tile decode: %lld workgroups x divisor %d exceeds the 2^32 range of the magic-multiplier division", (long long)nwg64, dmax);
+    }
     a.dec = mh_make_tile_decode(a.ntiles_n, a.tiles_x, a.tiles_y, d);
     a.dbg = (g_planes_mode.load(std::memory_order_relaxed) >> 8) & 255;
     ++g_planes_launches;
@@ -590,11 +597,12 @@ template <int MC, int WM, int WN, int MBW, int K16, int PL, int NBUF>
 int launch_planes_ck(PlanesArgs& a, hipStream_t s, bool attr_only) {
     using G = PlanesCkGeo<MC, WM, WN, MBW, K16, PL, NBUF>;
     static_assert(G::LDS_CK <= 160 * 1024, "patch buffers exceed the LDS");
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::atomic<uint64_t> attr_done{0};
+    const uint64_t attr_dev = mh_device_bit();
+    if (!(attr_done.load(std::memory_order_relaxed) & attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_planes_ck_kernel<MC, WM, WN, MBW, K16, PL, NBUF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { mh_set_error("conv_planes_ck: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_done = true;
+        attr_done.fetch_or(attr_dev);
     }
     if (attr_only) return 0;
     const int d = a.dil;
@@ -602,6 +610,11 @@ int launch_planes_ck(PlanesArgs& a, hipStream_t s, bool attr_only) {
     a.tiles_x = mh_cdiv(mh_cdiv(a.W, d), MC);
     a.ntiles_n = mh_cdiv(a.N, G::BN);
     a.nwg = a.B * d * d * a.tiles_y * a.tiles_x * a.ntiles_n;
+    {
+        const int64_t nwg64 = (int64_t)a.nwg;
+        const int dmax = std::max(std::max(a.ntiles_n, a.tiles_x), std::max(a.tiles_y, (int)d));
+        MH_REQUIRE(mh_fastdiv_ok(nwg64, dmax), MH_ERR_UNSUPPORTED, "tile decode: %lld workgroups x divisor %d exceeds the 2^32 range of the magic-multiplier division", (long long)nwg64, dmax);
+    }
     a.dec = mh_make_tile_decode(a.ntiles_n, a.tiles_x, a.tiles_y, d);
     a.nchunks = mh_cdiv(mh_cdiv(a.K, 16), K16);
     a.dbg = 0;
@@ -618,16 +631,22 @@ int launch_planes_s2bwd(PlanesArgs& a, hipStream_t s) {
     constexpr int PR = WM + 1, ROWP = 33 * G::NCK1;
     constexpr int LDS_P = ((PR * ROWP * 16 + 1023) / 1024) * 1024;
     constexpr int LDS = LDS_P > G::LDS_CS ? LDS_P : G::LDS_CS;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::atomic<uint64_t> attr_done{0};
+    const uint64_t attr_dev = mh_device_bit();
+    if (!(attr_done.load(std::memory_order_relaxed) & attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_planes_s2bwd_kernel<WM, WN, K16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { mh_set_error("conv_planes_s2bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_done = true;
+        attr_done.fetch_or(attr_dev);
     }
     a.tiles_y = mh_cdiv(a.Hin, WM);
     a.tiles_x = mh_cdiv(a.Win, 32);
     a.ntiles_n = mh_cdiv(a.N, G::BN);
     a.nwg = a.B * a.tiles_y * a.tiles_x * a.ntiles_n;
+    {
+        const int64_t nwg64 = (int64_t)a.nwg;
+        const int dmax = std::max(std::max(a.ntiles_n, a.tiles_x), std::max(a.tiles_y, (int)1));
+        MH_REQUIRE(mh_fastdiv_ok(nwg64, dmax), MH_ERR_UNSUPPORTED, "tile decode: %lld workgroups x divisor %d exceeds the 2^32 range of the magic-multiplier division", (long long)nwg64, dmax);
+    }
     a.dec = mh_make_tile_decode(a.ntiles_n, a.tiles_x, a.tiles_y, 1);
     a.dbg = 0;
     ++g_planes_launches;

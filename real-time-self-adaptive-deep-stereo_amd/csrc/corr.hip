@@ -713,9 +713,10 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_row_kernel(CorrWarpBwdArgs
 //     (each element read once, coalesced), the per-item operands that do not depend on u (the concat-copy part of g, the accumulate operand of dL) to
 //     registers; a second round trip fetches the two slope taps of every item (their address needs u).  The 2 DT shifted products read LDS;
 //   * the gradient w.r.t. the warped features r(x) of every pixel is stored to LDS (plain 16-byte stores, every item its own slot); the row's taps are
-//     bucketed by the source column they land on -- a counting sort in LDS: two INTEGER atomics per pixel count, one wave scans the W counters, two more
-//     atomics per pixel place (pixel, tap) keys into the column's segment (the float scatter needed 2 C atomics per pixel) -- and every (source column,
-//     channel group) item GATHERS its segment: typically two taps, one 16-byte read and four FMAs each.  Segments of up to 64 taps are summed in ascending
+//     bucketed by the source column they land on: two INTEGER LDS atomics per pixel (the float scatter needed 2 C per pixel) count the column's taps and
+//     hand out a slot of its 8-entry list; only when some column overflows its list (a compressed stretch of the warp) the taps are bucketed again by a
+//     counting sort without capacity (one wave scans the W counters, two more atomics per pixel place the keys).  Every (source column, channel group)
+//     item then GATHERS its taps: typically two, one 16-byte read and four FMAs each.  Segments of up to 64 taps are summed in ascending
 //     key order whatever order they were placed in (sorting network up to 8, selection beyond): bit-identical from run to run -- no float atomics, no
 //     fixed-point twin, the same kernel serves the deterministic mode; only a fold of more than 64 taps onto one column is summed in arrival order.
 // A thread owns at most NI = 3 (pixel, channel group) items: LPP >= C / 4 lanes per pixel.
@@ -734,7 +735,9 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
     float* const sw1 = sw0 + p.W;
     int* const cnt = reinterpret_cast<int*>(sw1 + p.W);          // [W]      taps that land on a source column (counted, then counted down by the placement)
     int* const base = cnt + p.W;                                 // [W + 1]  exclusive prefix sum of cnt: the column's segment of ent
-    int* const ent = base + p.W + 1;                             // [2 W]    (pixel << 1) | tap, bucketed by source column
+    int* const ent_all = base + p.W + 1;                         // [2 W]    (pixel << 1) | tap, bucketed by source column (counting sort: only when a column overflows its list)
+    int* const lst = ent_all + 2 * p.W;                              // [W][KL]  the first KL taps of every column, placed while they are counted
+    int* const over = lst + p.W * KL;                            // [1]      some column received more than KL taps
     const int tid = threadIdx.x, sub = tid % LPP;
     const float inv_c = 1.0f / (float)p.C;
     const int row = blockIdx.x;
@@ -789,6 +792,7 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
         if (q < p.W * GS) sg[q] = vg[k];
     }
     if (tid < p.W) { su[tid] = vu; cnt[tid] = 0; }
+    if (tid == 0) over[0] = 0;
     __syncthreads();
     // ---- round trip 2: the slope taps (right features at the two source columns of every pixel's warp) ------------------------------------------------
     float4 s0[NI], s1[NI];
@@ -809,8 +813,8 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
             // the pixel's two taps are counted at their source columns: integer LDS atomics, two per PIXEL
             const float w0 = (x1 - cx) * m0[k], w1 = (cx - x0) * m1[k];
             sw0[x] = w0; sw1[x] = w1;
-            if (w0 != 0.f) atomicAdd(cnt + i0, 1);
-            if (w1 != 0.f) atomicAdd(cnt + i1, 1);
+            if (w0 != 0.f) { const int sl = atomicAdd(cnt + i0, 1); if (sl < KL) lst[i0 * KL + sl] = x << 1; else over[0] = 1; }
+            if (w1 != 0.f) { const int sl = atomicAdd(cnt + i1, 1); if (sl < KL) lst[i1 * KL + sl] = (x << 1) | 1; else over[0] = 1; }
         }
     }
 #pragma unroll
@@ -860,40 +864,46 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
         vd[k] = mh_buf_load4(rs_di, q < nq ? ((rowbase + x) * p.dimg_ld + c4 * 4) * 4 : MH_OOB);
     }
     __syncthreads();
-    if (tid < 64) {
-        // exclusive prefix sum of the W column counts by ONE wave: lane l owns columns [l * per, (l + 1) * per)
-        const int per = (p.W + 63) >> 6;
-        int sum = 0;
-        for (int i = 0; i < per; ++i) { const int x = tid * per + i; if (x < p.W) sum += cnt[x]; }
-        int inc = sum;
+    // The common case: no column received more than KL taps -- every tap already sits in its column's list.  Otherwise (a compressed stretch of the
+    // warp) the taps are bucketed again without a capacity: counting sort -- one wave scans the W counters, every tap takes a slot of its column's segment.
+    const bool spill = over[0] != 0;
+    if (spill) {
+        if (tid < 64) {
+            // exclusive prefix sum of the W column counts by ONE wave: lane l owns columns [l * per, (l + 1) * per)
+            const int per = (p.W + 63) >> 6;
+            int sum = 0;
+            for (int i = 0; i < per; ++i) { const int x = tid * per + i; if (x < p.W) sum += cnt[x]; }
+            int inc = sum;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (tid >= o) inc += t; }
-        int run = inc - sum;
-        for (int i = 0; i < per; ++i) { const int x = tid * per + i; if (x < p.W) { base[x] = run; run += cnt[x]; } }
-        if (tid == 63) base[p.W] = inc;
-    }
-    __syncthreads();
-    // placement: every tap takes a slot of its column's segment (counting the column's counter down: the segment fills from its end)
-#pragma unroll
-    for (int k = 0; k < NI; ++k) {
-        const int x = k * PPB + tid / LPP;
-        if (x < p.W && sub == 0) {
-            const float cx = (float)x + su[x];
-            const float x0 = floorf(cx);
-            const float xmax = (float)(p.W - 1);
-            const int i0 = (int)fminf(fmaxf(x0, 0.f), xmax), i1 = (int)fminf(fmaxf(x0 + 1.0f, 0.f), xmax);
-            if (sw0[x] != 0.f) ent[base[i0] + atomicAdd(cnt + i0, -1) - 1] = x << 1;
-            if (sw1[x] != 0.f) ent[base[i1] + atomicAdd(cnt + i1, -1) - 1] = (x << 1) | 1;
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (tid >= o) inc += t; }
+            int run = inc - sum;
+            for (int i = 0; i < per; ++i) { const int x = tid * per + i; if (x < p.W) { base[x] = run; run += cnt[x]; } }
+            if (tid == 63) base[p.W] = inc;
         }
+        __syncthreads();
+        // placement, counting the column's counter down: the segment fills from its end
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int x = k * PPB + tid / LPP;
+            if (x < p.W && sub == 0) {
+                const float cx = (float)x + su[x];
+                const float x0 = floorf(cx);
+                const float xmax = (float)(p.W - 1);
+                const int i0 = (int)fminf(fmaxf(x0, 0.f), xmax), i1 = (int)fminf(fmaxf(x0 + 1.0f, 0.f), xmax);
+                if (sw0[x] != 0.f) ent_all[base[i0] + atomicAdd(cnt + i0, -1) - 1] = x << 1;
+                if (sw1[x] != 0.f) ent_all[base[i1] + atomicAdd(cnt + i1, -1) - 1] = (x << 1) | 1;
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
         const int q = tid + k * NT;
         if (q >= nq) continue;
         const int xs = q / C4, c4 = q - xs * C4;
         float4 acc = vd[k];
-        const int b0 = base[xs], n = base[xs + 1] - b0;
+        const int* const ent = spill ? ent_all + base[xs] : lst + xs * KL;
+        const int b0 = 0, n = spill ? base[xs + 1] - base[xs] : cnt[xs];
         auto add = [&](int key) {
             const int x = key >> 1;
             const float w = (key & 1) ? sw1[x] : sw0[x];
@@ -1574,7 +1584,7 @@ extern "C" int mh_corr_warp_bwd(const float* g, int32_t g_ld, int32_t coff, cons
         // operands staged in LDS: 3 rows of W x C floats + the g / u / tap rows; a thread owns <= 3 (pixel, channel group) items.  Gather, no atomics:
         // deterministic as it is (mh_tune_corr_row bit 1 set = the scatter form below; bit 2 = this launch without its scatter / gather part: timing)
         const int lpp = C4 <= 8 ? 8 : C4 <= 16 ? 16 : 32;
-        const size_t lds_st = ((size_t)3 * W * C + (size_t)W * (8 + 1 + 2 + 1 + 1 + 2) + 8) * 4;
+        const size_t lds_st = ((size_t)3 * W * C + (size_t)W * (8 + 1 + 2 + 1 + 1 + 2 + 8) + 8) * 4;
         if ((g_corr_row.load() & 2) == 0 && C4 <= 32 && W <= 3 * (1024 / lpp) && (int64_t)W * C4 <= 3 * 1024 && W * 8 <= 3 * 1024 && W < 32768 && lds_st <= 155 * 1024) {
             if (g_corr_row.load() & 4) a.dimg = nullptr;
             if (lpp == 8) hipLaunchKernelGGL((corr_warp_bwd_rowlds_kernel<8, 5>), grid, dim3(1024), lds_st, s, a);

@@ -61,11 +61,21 @@ extern "C" int mh_det_sync_wgrad_stream(const void*);
 namespace {
 std::mutex g_det_mutex;
 mh_det_table g_det_host = {};
+int g_det_device = -1;             // the device whose copy of the table holds the ranges (ONE per process: the table is a __device__ symbol, one copy per device)
 int det_sync() {
-    if (hipError_t e = hipDeviceSynchronize()) { mh_set_error("mh_deterministic: %s", hipGetErrorString(e)); return (int)e; }     // no launch in flight may see half a table
-    for (auto fn : {mh_det_sync_corr, mh_det_sync_ops, mh_det_sync_wgrad, mh_det_sync_wgrad_stream})
-        if (int e = fn(&g_det_host)) { mh_set_error("mh_deterministic: table upload failed (%d)", e); return e; }
-    return 0;
+    // upload + synchronise on the OWNING device whatever is current (an engine garbage-collected while another device was current left
+    // the owner with a stale entry pointing at a freed twin)
+    int cur = 0;
+    if (hipError_t e = hipGetDevice(&cur)) { mh_set_error("mh_deterministic: %s", hipGetErrorString(e)); return (int)e; }
+    const bool sw = g_det_device >= 0 && g_det_device != cur;
+    if (sw) if (hipError_t e = hipSetDevice(g_det_device)) { mh_set_error("mh_deterministic: %s", hipGetErrorString(e)); return (int)e; }
+    int rc = 0;
+    if (hipError_t e = hipDeviceSynchronize()) { mh_set_error("mh_deterministic: %s (not callable while a stream capture is active)", hipGetErrorString(e)); rc = (int)e; }     // no launch in flight may see half a table
+    if (!rc)
+        for (auto fn : {mh_det_sync_corr, mh_det_sync_ops, mh_det_sync_wgrad, mh_det_sync_wgrad_stream})
+            if (int e = fn(&g_det_host)) { mh_set_error("mh_deterministic: table upload failed (%d)", e); rc = e; break; }
+    if (sw) hipSetDevice(cur);
+    return rc;
 }
 }  // namespace
 extern "C" int mh_deterministic_add(float* base, int64_t n, void* acc) {
@@ -73,6 +83,11 @@ extern "C" int mh_deterministic_add(float* base, int64_t n, void* acc) {
     MH_REQUIRE((((uintptr_t)acc) & 7u) == 0, MH_ERR_ALIGN, "mh_deterministic_add: the fixed-point twin must be 8-byte aligned");
     std::lock_guard<std::mutex> g(g_det_mutex);
     MH_REQUIRE(g_det_host.n < 8, MH_ERR_UNSUPPORTED, "mh_deterministic_add: at most 8 ranges");
+    int cur = 0;
+    if (hipError_t e = hipGetDevice(&cur)) { mh_set_error("mh_deterministic_add: %s", hipGetErrorString(e)); return (int)e; }
+    MH_REQUIRE(g_det_host.n == 0 || cur == g_det_device, MH_ERR_UNSUPPORTED,
+               "mh_deterministic_add: the ranges of a process live on ONE device (registered on device %d, current device %d)", g_det_device, cur);
+    g_det_device = cur;
     const int i = g_det_host.n++;
     g_det_host.lo[i] = base; g_det_host.hi[i] = base + n; g_det_host.acc[i] = (long long*)acc;
     return det_sync();

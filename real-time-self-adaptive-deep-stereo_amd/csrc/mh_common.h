@@ -21,6 +21,9 @@ void mh_note_kernel(const char* fmt, ...);
     } while (0)
 
 static inline int mh_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+// hipFuncSetAttribute (the > 64 KiB dynamic-LDS opt-in) applies to the CURRENT device only: the per-instantiation "done" flags are one bit per device
+// id (a function-static bool made the first launch on a second device of the same process fail)
+static inline uint64_t mh_device_bit() { int d = 0; if (hipGetDevice(&d) != hipSuccess) d = 0; return 1ull << (d & 63); }
 static inline bool mh_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
 // ---- buffer (SRD) loads with hardware bounds checking --------------------------------------
@@ -78,7 +81,9 @@ __device__ __forceinline__ void mh_atomic_add(float* dst, float v) {
     const int n = g_mh_det.n;
     for (int i = 0; i < n; ++i)
         if (dst >= g_mh_det.lo[i] && dst < g_mh_det.hi[i]) {
-            atomicAdd(reinterpret_cast<unsigned long long*>(g_mh_det.acc[i] + (dst - g_mh_det.lo[i])), (unsigned long long)(long long)llrintf(v * 281474976710656.0f));
+            // |v| is clamped below 2^15 (llrintf of a larger product is undefined; the running sum of a mean-reduced loss's gradients stays far inside)
+            atomicAdd(reinterpret_cast<unsigned long long*>(g_mh_det.acc[i] + (dst - g_mh_det.lo[i])),
+                      (unsigned long long)(long long)llrintf(fminf(fmaxf(v, -32767.0f), 32767.0f) * 281474976710656.0f));
             return;
         }
     atomicAdd(dst, v);
@@ -121,6 +126,8 @@ static inline mh_fastdiv mh_make_fastdiv(int d) {
     return f;
 }
 __device__ __forceinline__ int mh_fdiv(int n, const mh_fastdiv& f) { return f.d > 1 ? (int)__umulhi((unsigned)n, f.m) : n; }
+// the round-up multiplier is exact while n * d < 2^32: every launcher checks its largest dividend against its largest divisor
+static inline bool mh_fastdiv_ok(int64_t nmax, int64_t dmax) { return nmax >= 0 && dmax >= 1 && nmax * dmax < (1ll << 32); }
 // lin -> (column tile, x tile, y tile, lattice phase x, lattice phase y, batch) of the patch / bank / planes kernels
 struct mh_tile_decode { mh_fastdiv ntn, tx, ty, dd; };
 static inline mh_tile_decode mh_make_tile_decode(int ntiles_n, int tiles_x, int tiles_y, int d) {

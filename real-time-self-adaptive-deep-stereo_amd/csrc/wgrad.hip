@@ -494,14 +494,15 @@ int launch_wgrad_bf16(WgradArgs& a, hipStream_t s) {
     constexpr size_t tiles_b = (size_t)(2 * (BK + BN) * (PT + 8)) * 2;
     constexpr size_t lds_max = tiles_b + 2 * (BK / 4) * PT * 4;        // flat mode keeps BK/4 pixel tables per buffer
     const size_t lds = tiles_b + 2 * (a.flat ? BK / 4 : 1) * PT * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::atomic<uint64_t> attr_done{0};
+    const uint64_t attr_dev = mh_device_bit();
+    if (!(attr_done.load(std::memory_order_relaxed) & attr_dev)) {
         if (lds_max > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<WM, WN, MT, NT>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
             if (e != hipSuccess) { mh_set_error("wgrad_bf16: hipFuncSetAttribute(%d B LDS): %s", (int)lds_max, hipGetErrorString(e)); return (int)e; }
         }
-        attr_done = true;
+        attr_done.fetch_or(attr_dev);
     }
     if (a.M < 0) return 0;
     a.ktiles = a.flat ? 1 : mh_cdiv(a.K, BK);
@@ -540,14 +541,15 @@ template <int WM, int WN, int MT, int NT, int PT, bool VEC>
 int launch_wgrad_one(WgradArgs& a, hipStream_t s) {
     constexpr int BK = WM * MT * 16, BN = WN * NT * 16;
     constexpr size_t lds = (size_t)(2 * (BK + BN) * (PT + 4)) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::atomic<uint64_t> attr_done{0};
+    const uint64_t attr_dev = mh_device_bit();
+    if (!(attr_done.load(std::memory_order_relaxed) & attr_dev)) {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<WM, WN, MT, NT, PT, VEC>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) { mh_set_error("wgrad: hipFuncSetAttribute(%d B LDS): %s", (int)lds, hipGetErrorString(e)); return (int)e; }
         }
-        attr_done = true;
+        attr_done.fetch_or(attr_dev);
     }
     if (a.M < 0) return 0;               // mh_init(): attribute set-up only
     a.ktiles = mh_cdiv(a.K, BK);

@@ -288,11 +288,12 @@ struct StreamCfg { int nxg, dist; };
 template <int NXG, int D, int S = 1>
 static int stream_launch(const mh_wgs_layer* tab, int nlayers, int nblocks, int nw, hipStream_t s, bool attr_only) {
     constexpr int WAVE_BYTES = (S * D + 3) * NXG * 1024 + (D + 1) * WS_ZSLOT;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::atomic<uint64_t> attr_done{0};
+    const uint64_t attr_dev = mh_device_bit();
+    if (!(attr_done.load(std::memory_order_relaxed) & attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_stream_kernel<NXG, D, S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { mh_set_error("wgrad_stream: hipFuncSetAttribute(160 KB LDS): %s", hipGetErrorString(e)); return (int)e; }
-        attr_done = true;
+        attr_done.fetch_or(attr_dev);
     }
     if (attr_only) return 0;
     const size_t lds = (size_t)nw * WAVE_BYTES;
@@ -304,11 +305,12 @@ static int stream_launch(const mh_wgs_layer* tab, int nlayers, int nblocks, int 
 
 static int stream_launch_mixed(const mh_wgs_layer* tab, int nlayers, int nblocks, int nw, hipStream_t s, bool attr_only) {
     constexpr int WAVE_BYTES = 5 * 5 * 1024 + 2 * WS_ZSLOT;            // the stride-2 instance's rings (the stride-1 ones need 16 KB)
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::atomic<uint64_t> attr_done{0};
+    const uint64_t attr_dev = mh_device_bit();
+    if (!(attr_done.load(std::memory_order_relaxed) & attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_stream_mixed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { mh_set_error("wgrad_stream: hipFuncSetAttribute(160 KB LDS): %s", hipGetErrorString(e)); return (int)e; }
-        attr_done = true;
+        attr_done.fetch_or(attr_dev);
     }
     if (attr_only) return 0;
     const size_t lds = (size_t)nw * WAVE_BYTES;

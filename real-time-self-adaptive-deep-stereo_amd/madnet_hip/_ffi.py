@@ -207,12 +207,14 @@ class Lib(object):
                 setattr(self, name[3:], fn)
             else:
                 setattr(self, name[3:], self._checked(name, fn))
-        self._inited = False
+        self._inited = set()
 
-    def ensure_init(self):
-        if not self._inited:
+    def ensure_init(self, device_index=None):
+        """mh_init (the > 64 KiB dynamic-LDS opt-in of every kernel instantiation, the plan executor's side streams) applies to the CURRENT device:
+        once per device a process uses (engines call it with their device current)"""
+        if device_index not in self._inited:
             self.init()
-            self._inited = True
+            self._inited.add(device_index)
 
     def _checked(self, name, fn):
         def call(*a):

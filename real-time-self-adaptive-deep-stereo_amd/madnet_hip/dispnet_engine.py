@@ -112,6 +112,10 @@ class DispNetEngine(object):
             raise ValueError("precision must be one of %s" % sorted(ops.PRECISION_CODES))
         self.precision = precision
         self.lib, self.dev = lib, device
+        _td = torch.device(device)
+        if _td.type == "cuda" and hasattr(lib, "ensure_init"):
+            with torch.cuda.device(_td):                  # the per-device set-up of the library, with THIS engine's device current (a process may drive several)
+                lib.ensure_init(torch.cuda.current_device())
         self.B, self.H0, self.W0 = B, H, W
         self.Hp = H if H % 64 == 0 else (H // 64 + 1) * 64
         self.Wp = W if W % 64 == 0 else (W // 64 + 1) * 64
@@ -155,7 +159,9 @@ class DispNetEngine(object):
 
     def __del__(self):
         try:
-            self.close()
+            # (never from inside a stream capture: un-registering synchronises the device, which would invalidate the capture -- call close() explicitly)
+            if self._det_bases and not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+                self.close()
         except Exception:
             pass
 

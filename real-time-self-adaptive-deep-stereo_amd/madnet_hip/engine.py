@@ -134,6 +134,8 @@ DETERMINISTIC = os.environ.get("MH_DETERMINISTIC", "0") == "1"
 USE_PLANES = os.environ.get("MH_CONV_PLANES", "1") != "0"
 # ... and the fp32 copy of such an activation is not stored when no op of the plan reads it (engine._elide_fp32_activations)
 PLANES_ONLY = True
+# tests: fill every fp32 buffer whose store a plan elides with NaN when the plan is built (engine._note_elided)
+POISON_ELIDED = os.environ.get("MH_POISON_ELIDED", "0") == "1"
 # ... and the planes of tensors no plane kernel produces are written by THEIR producers (the level front end, the exact-fp32 layers in front of conv4 /
 # conv6, one concat-split for the context network's input) instead of by a split launch in front of every consumer
 FUSE_SPLITS = True
@@ -209,6 +211,10 @@ class MadNetEngine(object):
         # disparity still joins the estimator input
         self.warping = bool(warping)
         self.lib, self.dev = lib, device
+        _td = torch.device(device)
+        if _td.type == "cuda" and hasattr(lib, "ensure_init"):
+            with torch.cuda.device(_td):                  # the per-device set-up of the library, with THIS engine's device current (a process may drive several)
+                lib.ensure_init(torch.cuda.current_device())
         self.B, self.H0, self.W0 = B, H, W
         self.md, self.cstride = radius_d, stride
         self.D = 2 * radius_d // stride + 1
@@ -685,8 +691,30 @@ class MadNetEngine(object):
                 continue
             ops_[idx].i[23] |= 4
             c.i[23] |= 8            # MH_CONV_IN_F32_STALE: a replay whose dispatch no longer stages the shadow is refused, not wrong
+            self._note_elided(r, lo, hi - lo)
             n += 1
         return n
+
+    def _note_elided(self, r, ptr, nbytes):
+        """An fp32 buffer no op of this plan writes any more.  Kept on the recorder / plan (plan.elided) so that a reader OUTSIDE the plan can ask; with
+        MH_POISON_ELIDED=1 (tests) the buffer is filled with NaN at once: an op that still reads it -- a device-table op whose table building forgot
+        Recorder.note_refs, a debug read of engine.E / Cx -- then fails loudly instead of consuming a stale map."""
+        if not hasattr(r, "elided"):
+            r.elided = []
+        r.elided.append((int(ptr), int(nbytes)))
+        if POISON_ELIDED:
+            t = self._tensor_by_ptr().get(int(ptr))
+            if t is not None:
+                t.fill_(float("nan"))
+
+    def _tensor_by_ptr(self):
+        out = {}
+        for k in LEVELS:
+            for t in list(self.E[k]) + list(self.dE[k]):
+                out[t.data_ptr()] = t
+        for t in list(self.Cx) + list(self.dCx):
+            out[t.data_ptr()] = t
+        return out
 
     def _takes_shadows(self, c):
         """mh_conv2d_takes_shadows for a recorded OP_CONV: bit 1 = the launch stages in_shadow, bit 2 = it reads the mask from mask_shadow"""
@@ -760,6 +788,7 @@ class MadNetEngine(object):
             o.p[slot] = None
             for q, bit in mask_users:
                 q.i[23] |= bit
+            self._note_elided(r, lo, hi - lo)
             n += 1
         return n
 
@@ -1202,7 +1231,9 @@ class MadNetEngine(object):
 
     def __del__(self):
         try:
-            self.close()
+            # (never from inside a stream capture: un-registering synchronises the device, which would invalidate the capture -- call close() explicitly)
+            if self._det_bases and not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+                self.close()
         except Exception:
             pass
 

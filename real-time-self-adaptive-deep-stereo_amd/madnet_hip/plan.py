@@ -272,6 +272,7 @@ class Recorder(object):
         arr = (_ffi.Op * len(self.ops))(*self.ops)
         p = Plan(arr, len(self.ops), self.keep, dict(self.stats))
         p.work = dict(self.work)
+        p.elided = list(getattr(self, "elided", ()))       # [(pointer, bytes)] of fp32 buffers this plan no longer writes (engine._note_elided)
         return p
 
     def compile_parts(self):

@@ -74,6 +74,7 @@ static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 enum { hipDeviceAttributeWallClockRate = 1 };
 static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 1000000; return hipSuccess; }      // the emulated wall clock: nanoseconds
 #include <time.h>
