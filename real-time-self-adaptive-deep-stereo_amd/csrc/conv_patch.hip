@@ -794,15 +794,19 @@ __global__ __launch_bounds__(1024) void conv_bank_small_kernel(ConvArgs p, Patch
 
     // (the bias of this thread's output element: requested now, used in the epilogue -- a dependent global load there cost the launch a memory
     //  round trip behind the reduction: round 4, scripts/exp/node_floor.py)
+    // Round 5: these three were CONDITIONAL global loads -- behind each `if` hipcc joins with s_waitcnt vmcnt(0), so the launch spent a whole memory round
+    // trip on them before it had even requested its weight fragments (ISA of round 4's build; ~1 us of every 5 us small-layer node).  Range-checked buffer
+    // loads now: unconditional, an absent operand is a descriptor of zero bytes (reads 0).
     const int my_n = n0 + (tid & 31);
-    const float my_bias = (p.bias && my_n < p.N) ? p.bias[my_n] : 0.f;
-    // ... and the epilogue's other operands (the accumulation target, the leaky mask): their addresses are known now
     const int my_row = tid >> 5;
     const int my_y = y00 + (my_row >> 4) * d, my_x = x00 + (my_row & 15) * d;
     const bool my_ok = my_y < p.Ho && my_x < p.Wo && my_n < p.N;
     const int64_t my_m = ((int64_t)b * p.Ho + my_y) * p.Wo + my_x;
-    const float my_old = (my_ok && p.accumulate) ? p.out[my_m * p.out_ld + my_n] : 0.f;
-    const float my_mk = (my_ok && p.mask_ref) ? p.mask_ref[my_m * p.mask_ld + my_n] : 1.f;
+    const __amdgpu_buffer_rsrc_t rs_bias = mh_make_rsrc(p.bias ? (const void*)p.bias : (const void*)p.in, p.bias ? (unsigned)(p.N * 4) : 0u);
+    const __amdgpu_buffer_rsrc_t rs_old = mh_make_rsrc(p.out, p.accumulate ? p.out_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_mk = mh_make_rsrc(p.mask_ref ? (const void*)p.mask_ref : (const void*)p.in, p.mask_ref ? p.mask_bytes : 0u);
+    float my_bias, my_old, my_mk;          // (requested behind the first round of patch loads, below: issued first, an unlucky register reuse made hipcc wait for them
+                                           //  in the middle of the fragment loads)
     // ---- all weight fragments of this wave's chunks: requested first ------------------------------------------------------
     const int np16 = (p.N + 15) >> 4;
     const int stride_b = np16 * PL * 1024;
@@ -820,27 +824,57 @@ __global__ __launch_bounds__(1024) void conv_bank_small_kernel(ConvArgs p, Patch
     }
 
     // ---- stage the 4 x 18 input patch (bf16; hi + lo planes for PL = 2) ---------------------------------------------------
+    // Round 5: straight-line, every load of the thread in flight before the first conversion.  The loop this replaces issued ONE load per iteration
+    // behind an s_waitcnt vmcnt(0) (a 128-channel layer's 2304 patch vectors = three serial memory round trips, on top of the weight fragments'), and any
+    // loop / branch here makes hipcc's waitcnt pass drain the fragment loads at its header: no loop (the launcher guarantees items <= ROUNDS * U * 1024),
+    // no branch (offsets by select, the division by multiply-high with a select for the divisor 1).
     {
+        constexpr int U = 4, ROUNDS = 2;
         const int kp4 = g.KP >> 2;
         const int items = (st * TH + 3 - st) * PC * kp4;
-        for (int q0 = tid; q0 < items; q0 += NTH) {
-            const int pp = mh_fdiv(q0, g.f_kp4), c4 = q0 - pp * kp4;
-            const int pi = mh_fdiv(pp, g.f_pc), pj = pp - pi * PC;
-            const int iy = y00 * st - p.pad_t + pi * d, ix = x00 * st - p.pad_l + pj * d;      // (stride 1: pad = dilation)
-            const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi && (c4 < p.G);
-            float4 w = mh_buf_load4(rs_in, ok ? (((b * p.Hi + iy) * p.Wi + ix) * p.in_ld + c4 * 4) * 4 : MH_OOB);
-            w.y = (c4 * 4 + 1 < p.K) ? w.y : 0.f;           // the row padding between K and in_ld is not ours to trust
-            w.z = (c4 * 4 + 2 < p.K) ? w.z : 0.f;
-            w.w = (c4 * 4 + 3 < p.K) ? w.w : 0.f;
-            const int lds = pp * g.PS + c4 * 4;
-            if constexpr (PL == 2) {
-                uint2 hi, lo;
-                mh_split_bf16x2(w.x, w.y, hi.x, lo.x);
-                mh_split_bf16x2(w.z, w.w, hi.y, lo.y);
-                *reinterpret_cast<uint2*>(Ph + lds) = hi;
-                *reinterpret_cast<uint2*>(Ph + g.patch_halfs + lds) = lo;
-            } else
-            *reinterpret_cast<uint2*>(Ph + lds) = make_uint2(mh_pack_bf16(w.x, w.y), mh_pack_bf16(w.z, w.w));
+        auto fdiv = [](int n, const mh_fastdiv& f) { const int h = (int)__umulhi((unsigned)n, f.m); return f.d > 1 ? h : n; };
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+            if (rd > 0 && items <= rd * U * NTH) break;          // (uniform; nothing is in flight here)
+            float4 wv[U];
+            int ldsv[U], c4v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = tid + (rd * U + u) * NTH;
+                const int pp = fdiv(q, g.f_kp4), c4 = q - pp * kp4;
+                const int pi = fdiv(pp, g.f_pc), pj = pp - pi * PC;
+                const int iy = y00 * st - p.pad_t + pi * d, ix = x00 * st - p.pad_l + pj * d;      // (stride 1: pad = dilation)
+                const bool ok = q < items && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi && (c4 < p.G);
+                int off = (((b * p.Hi + iy) * p.Wi + ix) * p.in_ld + c4 * 4) * 4;
+                MH_KEEP_VGPR(off);                               // (materialised: the select below stays a v_cndmask, not a branch around the multiplies)
+                wv[u] = mh_buf_load4(rs_in, ok ? off : MH_OOB);
+                ldsv[u] = q < items ? pp * g.PS + c4 * 4 : -1;
+                c4v[u] = c4;
+            }
+            if (rd == 0) {
+                my_bias = mh_buf_load1(rs_bias, my_n < p.N ? my_n * 4 : MH_OOB);
+                my_old = mh_buf_load1(rs_old, my_ok ? (int)((my_m * p.out_ld + my_n) * 4) : MH_OOB);
+                my_mk = mh_buf_load1(rs_mk, my_ok ? (int)((my_m * p.mask_ld + my_n) * 4) : MH_OOB);      // (no mask: the value is not used)
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float4 w = wv[u];
+                const int c4 = c4v[u];
+                w.y = (c4 * 4 + 1 < p.K) ? w.y : 0.f;           // the row padding between K and in_ld is not ours to trust
+                w.z = (c4 * 4 + 2 < p.K) ? w.z : 0.f;
+                w.w = (c4 * 4 + 3 < p.K) ? w.w : 0.f;
+                const int lds = ldsv[u];
+                if (lds >= 0) {
+                    if constexpr (PL == 2) {
+                        uint2 hi, lo;
+                        mh_split_bf16x2(w.x, w.y, hi.x, lo.x);
+                        mh_split_bf16x2(w.z, w.w, hi.y, lo.y);
+                        *reinterpret_cast<uint2*>(Ph + lds) = hi;
+                        *reinterpret_cast<uint2*>(Ph + g.patch_halfs + lds) = lo;
+                    } else
+                    *reinterpret_cast<uint2*>(Ph + lds) = make_uint2(mh_pack_bf16(w.x, w.y), mh_pack_bf16(w.z, w.w));
+                }
+            }
         }
     }
     __syncthreads();
@@ -895,7 +929,7 @@ __global__ __launch_bounds__(1024) void conv_bank_small_kernel(ConvArgs p, Patch
             v += my_bias;
             if (p.alpha != 1.0f) v = v > 0.f ? v : p.alpha * v;
             float* dst = p.out + m * p.out_ld + n;
-            v += my_old;
+            v += my_old;                                  // (0 unless accumulate)
             if (p.mask_ref) v *= (my_mk > 0.f || n < p.mask_c0 || n >= p.mask_c1) ? 1.0f : p.mask_alpha;
             *dst = v;
             if (p.shadow) p.shadow[m * p.shadow_ld + n] = (unsigned short)mh_pack_bf16(v, 0.f);
@@ -1193,6 +1227,7 @@ bool mh_conv_bank_small_ok(const ConvArgs& a) {
     if (9 * ((a.K + 31) / 32) > 64) return false;
     if (s2 && (size_t)5 * 33 * (((a.K + 31) & ~31) + 16) * 2 * (a.x3 ? 2 : 1) > PATCH_LDS_MAX) return false;
     if ((int64_t)a.B * a.Ho * a.Wo > maxpix) return false;
+    if ((s2 ? 5 * 33 : 4 * 18) * (((a.K + 31) & ~31) / 4) > 2 * 4 * 1024) return false;      // the patch staging is two straight-line rounds of 4 loads per thread
     const int d = a.dil;
     const int64_t cover = (int64_t)d * d * mh_cdiv(mh_cdiv(a.Ho, d), 2) * 2 * mh_cdiv(mh_cdiv(a.Wo, d), 16) * 16;
     return cover * 100 <= (int64_t)a.Ho * a.Wo * 250 && (int64_t)a.B * cover / 32 * mh_cdiv(a.N, 32) < (1 << 20);

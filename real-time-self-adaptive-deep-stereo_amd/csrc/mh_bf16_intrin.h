@@ -63,5 +63,8 @@ __device__ __forceinline__ void mh_glds16(const mh_dma_src& r, void* lds_wave_ba
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(dst), "s"(r.w) : "memory");
 }
+// keeps an integer in a VGPR as computed (an optimisation barrier on one value): a select between it and a constant then stays a v_cndmask instead of a
+// branch around the arithmetic that produced it (a branch near outstanding loads makes hipcc's waitcnt pass drain them at the join)
+#define MH_KEEP_VGPR(x) asm volatile("" : "+v"(x))
 #define MH_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define MH_WAIT_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")

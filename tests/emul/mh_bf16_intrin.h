@@ -93,5 +93,6 @@ static inline void mh_glds16(const mh_dma_src& r, void* lds_wave_base, int voff)
     unsigned char* dst = (unsigned char*)lds_wave_base + 16 * lane;
     if ((unsigned long long)off + 16ull <= r.bytes) memcpy(dst, r.base + off, 16); else memset(dst, 0, 16);
 }
+#define MH_KEEP_VGPR(x) do { } while (0)
 #define MH_WAIT_VMCNT(n) do { } while (0)
 #define MH_WAIT_LGKMCNT0() do { } while (0)
