@@ -77,7 +77,7 @@ struct PlanesGeo {
     static constexpr int ROWP = MR == 1 ? PC * NCK1 : ((PC * NCK1 + 15) / 16) * 16;
     static constexpr int PLANE_BLKS = (PR * ROWP * 16 + 1023) / 1024;
     static constexpr int PLANE_BYTES = PLANE_BLKS * 1024;
-    static constexpr int CS = BN + 4;
+    static constexpr int CS = BN + 8;                  // (= 8 mod 16: the two half-waves of an accumulator write -- rows 4 apart -- hit disjoint bank halves)
     static constexpr int LDS_TILES = PL * PLANE_BYTES, LDS_CS = BM * CS * 4;
     static constexpr int LDS = LDS_TILES > LDS_CS ? LDS_TILES : LDS_CS;
 };
