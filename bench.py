@@ -342,10 +342,13 @@ def drift_report(args, lib, dev, wn, mk, frames=8):
 
 
 def apply_overrides(items, lib, E):
-    """--set KEY=VALUE: module flags and library hooks are applied at once; returns the per-engine attributes (applied to every engine built)."""
+    """--set KEY=VALUE: library hooks are applied at once; returns (per-engine attributes, Schedule fields) for every engine built: engine.NAME=v is a
+    field of the engine's immutable madnet_hip.schedule.Schedule (FUSE_HEAD, TAIL_MAIN, EARLY_WGS ...), eng.NAME=v an attribute set after construction."""
     import ast
-    per_engine = {}
+    import dataclasses
+    per_engine, sched = {}, {}
     _OVERRIDES[:] = items
+    fields = {f.name for f in dataclasses.fields(E.Schedule)}
     for it in items:
         key, _, val = it.partition("=")
         scope, _, name = key.partition(".")
@@ -354,15 +357,15 @@ def apply_overrides(items, lib, E):
         except (ValueError, SyntaxError):
             v = val
         if scope == "engine":
-            assert hasattr(E, name), "--set %s: no such flag in madnet_hip/engine.py" % key
-            setattr(E, name, v)
+            assert name in fields, "--set %s: no such field in madnet_hip/schedule.py: Schedule" % key
+            sched[name] = v
         elif scope == "eng":
             per_engine[name] = v
         elif scope == "tune":
             getattr(lib, "tune_" + name)(*[int(x) for x in (v if isinstance(v, tuple) else (v,))])        # tune.conv_tile=524288,0
         else:
             raise SystemExit("--set %s: scope must be engine. / eng. / tune." % key)
-    return per_engine
+    return per_engine, sched
 
 
 class BoxSampler(object):
@@ -655,7 +658,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE", dest="overrides",
                     help="A/B override (repeatable; the JSON line lists them under 'overrides'): engine.NAME=v sets a module flag of madnet_hip/engine.py "
-                         "(FUSE_HEAD, SHADOW_ONLY, EARLY_WGS ...), eng.NAME=v an attribute of every engine built (fuse_front, use_bank ...), "
+                         "-- a field of the engines' immutable Schedule (madnet_hip/schedule.py: FUSE_HEAD, SHADOW_ONLY, EARLY_WGS ...) --, eng.NAME=v an attribute of every engine built (fuse_front, use_bank ...), "
                          "tune.NAME=int calls the library hook mh_tune_NAME (conv_rows, conv_bank_tile, wgrad_target_pct ...)")
     ap.add_argument("--stamps", type=int, default=0, metavar="N",
                     help="also replay a STAMPED copy of the step N times (device time stamps as plan ops, engine.STAMPS) and report where the side lane starts "
@@ -696,7 +699,7 @@ def main():
 
     from madnet_hip import _ffi, engine as E, dispnet_engine as DE, synthetic as S, benchtools as BT
     lib = _ffi.lib()
-    eng_overrides = apply_overrides(args.overrides, lib, E)
+    eng_overrides, sched_overrides = apply_overrides(args.overrides, lib, E)
     H, W = args.height, args.width
     if args.mode == "MAD":
         return bench_mad(args, lib, dev, rank, world, dist)
@@ -705,17 +708,16 @@ def main():
     wn = S.calibrated_weights(shapes, 1)
     l, r, gt = S.make_pair(H, W, stream_id=rank)
     SB = args.streams_per_gpu
-    mk = (lambda prec: DE.DispNetEngine(lib, H, W, B=SB, device=dev.name, weights=wn, precision=prec)) if dispnet else \
-         (lambda prec: E.MadNetEngine(lib, H, W, B=SB, device=dev.name, weights=wn, precision=prec))
-    if eng_overrides:
-        mk0 = mk
-
-        def mk(prec):
-            e = mk0(prec)
-            for k, v in eng_overrides.items():
-                assert hasattr(e, k), "--set eng.%s: no such engine attribute" % k
-                setattr(e, k, v)
-            return e
+    def mk(prec, **sched_kw):
+        """an engine of the run's network; sched_kw: Schedule fields on top of the --set engine.* overrides (MADNet)"""
+        if dispnet:
+            e = DE.DispNetEngine(lib, H, W, B=SB, device=dev.name, weights=wn, precision=prec)
+        else:
+            e = E.MadNetEngine(lib, H, W, B=SB, device=dev.name, weights=wn, precision=prec, schedule=E.Schedule(**dict(sched_overrides, **sched_kw)))
+        for k, v in eng_overrides.items():
+            assert hasattr(e, k), "--set eng.%s: no such engine attribute" % k
+            setattr(e, k, v)
+        return e
     eng = mk(args.precision)
 
     def feed(e):

@@ -409,17 +409,13 @@ def op_work(op):
 
 
 def tail_stamps(lib, E, mk, feed, args, dev, plain_ms):
-    """Where the replayed step spends its end: a STAMPED copy of the plan (engine.STAMPS: mh_stamp ops at the start, the end of
+    """Where the replayed step spends its end: a STAMPED copy of the plan (Schedule.STAMPS: mh_stamp ops at the start, the end of
     the forward pass, the side lane's first op, the start / end of every filter-gradient batch, the end of the input-gradient chain, the join, the
     end) is captured and replayed args.stamps times; all times in us from the step's first op, median over the replays.  No tracer involved: the
     stamps are kernels of the graph itself (each costs the chain one ~2-5 us launch, `stamped_ms_per_step` tells by how much)."""
     import numpy as np
-    E.STAMPS = True
-    try:
-        e = mk(args.precision); feed(e)
-        plan = e.build_plan(args.mode, lr=1e-4)
-    finally:
-        E.STAMPS = False
+    e = mk(args.precision, STAMPS=True); feed(e)              # (a Schedule of its own: the stamped plan never leaks into another engine)
+    plan = e.build_plan(args.mode, lr=1e-4)
     labels = list(e.stamp_labels)
     rate_khz = float(lib.stamp_rate_khz()) or 1e5
     rows = []

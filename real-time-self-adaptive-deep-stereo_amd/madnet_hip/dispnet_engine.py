@@ -20,24 +20,12 @@ import torch
 from . import ops
 from .engine import Params, _r4, _merge_ranges
 from .plan import Recorder
+from .schedule import DispNetSchedule
 
 MAX_DISP = 40
 ALPHA = 0.1     # default leaky slope of sharedLayers.conv2d / conv2d_transpose (sharedLayers.py:54,80)
 
-# 'mixed' / 'bf16': the stride-1 3x3 layers with at least PLANES_MIN_PIX pixels run mh_conv2d_planes / mh_conv2d_planes_bwd (csrc/conv_planes.hip; the
-# K-chunked kernel beyond 128 reduction channels) from bf16 planes -- the shadows the streamed filter gradient reads anyway, cast once in the forward
-# pass.  The coarser layers (conv5_1, conv6_1, iconv5: <= 480 pixels, 9 - 19 MB of weights for 16 - 60 workgroups) stay on the split-K igemm kernels
-# (scripts/microbench.py dispnet: 25 vs 41 us, 41 vs 73 us).  MH_CONV_PLANES=0 turns the path off.
-USE_PLANES = os.environ.get("MH_CONV_PLANES", "1") != "0"
-# FULL momentum steps: every filter-gradient batch is followed, on its own side lane, by the momentum update of the layers it completes; the launch behind
-# the join covers what is left (the towers' shared conv1 / conv2).  DispNet has 42 M parameters: one update over all of them is 840 MB of traffic, 144 us
-# at the very end of the step (round-3 timeline) -- spread over the batches it runs beside the input-gradient chain.  MH_EARLY_UPDATE=0 turns it off.
-EARLY_UPDATE = os.environ.get("MH_EARLY_UPDATE", "1") != "0"
-# filter gradients leave for a side lane in batches of FLUSH_MIN layers, the batches alternating over SIDE_LANES lanes
-ZERO_GRADS_EARLY = os.environ.get("MH_DN_ZERO_EARLY", "0") != "0"      # the gradient buffer's zero fill on the side lane beside the forward pass (see record_forward)
-FLUSH_MIN = int(os.environ.get("MH_DN_FLUSH_MIN", "2"))       # (one lane: 2 -> 3.15 ms, 3 -> 3.23, 4 -> 3.16, 6 -> 3.20, 12 -> 3.33)
-SIDE_LANES = int(os.environ.get("MH_DN_LANES", "1"))      # (r04 sweep at 375x1242: 1 lane 3.21 ms, 2 lanes 3.39, 3 lanes 3.48 -- every extra stream of the captured graph costs)
-PLANES_MIN_PIX = 1920
+# (the scheduling switches live in madnet_hip/schedule.py: an immutable DispNetSchedule per engine, self.sched)
 
 
 def _r8(c):
@@ -107,7 +95,9 @@ _TUNE_LOCK = ops.TUNE_LOCK          # serialises plan recording that scopes a pr
 
 
 class DispNetEngine(object):
-    def __init__(self, lib, H, W, B=1, device="cuda", weights=None, precision="fp32"):
+    def __init__(self, lib, H, W, B=1, device="cuda", weights=None, precision="fp32", schedule=None):
+        """schedule: a madnet_hip.schedule.DispNetSchedule (immutable): how this engine's plans are recorded"""
+        self.sched = schedule if schedule is not None else DispNetSchedule()
         if precision not in ops.PRECISION_CODES:
             raise ValueError("precision must be one of %s" % sorted(ops.PRECISION_CODES))
         self.precision = precision
@@ -138,11 +128,10 @@ class DispNetEngine(object):
         self.lo_planes = {}                 # shadow key -> lo plane (split-bf16 layers on mh_conv2d_planes)
         self.banks_f, self.banks_b = {}, {}  # weight name -> fragment bank in the 32x32x16 image (forward: trans 2; input gradient: trans 3)
         self._fresh = set()                 # shadow keys whose bf16 image is current in the plan being recorded
-        self.use_planes = USE_PLANES and precision in ("mixed", "bf16") and str(device).startswith(("cuda", "cpu"))
+        self.use_planes = self.sched.USE_PLANES and precision in ("mixed", "bf16") and str(device).startswith(("cuda", "cpu"))
         ops.check_planes_rule(self.lib)
         # deterministic test mode (engine.DETERMINISTIC): the bias-gradient atomics accumulate into a fixed-point twin of the flat gradient buffer
-        from . import engine as _E
-        self.deterministic = _E.DETERMINISTIC
+        self.deterministic = self.sched.DETERMINISTIC
         self._det_bases = []
         if self.deterministic:
             import ctypes as _C
@@ -263,7 +252,7 @@ class DispNetEngine(object):
         """0: not on mh_conv2d_planes; 1: plain bf16 (one plane); 2: split-bf16 (hi + lo)"""
         _, x, wn, out, stride, alpha, _ = op
         w = self.W_(wn)
-        if not self.use_planes or stride != 1 or tuple(w.shape[:2]) != (3, 3) or x.st.H * x.st.W < PLANES_MIN_PIX or x.c0 != 0 or w.shape[3] % 8:
+        if not self.use_planes or stride != 1 or tuple(w.shape[:2]) != (3, 3) or x.st.H * x.st.W < self.sched.PLANES_MIN_PIX or x.c0 != 0 or w.shape[3] % 8:
             return 0
         code = self._fwd_code(wn)
         if code is None:
@@ -275,7 +264,7 @@ class DispNetEngine(object):
     def _planes_bwd_ok(self, op):
         _, x, wn, out, stride, alpha, x_grad = op
         w = self.W_(wn)
-        if not (self.use_planes and x_grad and stride == 1 and tuple(w.shape[:2]) == (3, 3) and x.st.H * x.st.W >= PLANES_MIN_PIX and x.c0 == 0):
+        if not (self.use_planes and x_grad and stride == 1 and tuple(w.shape[:2]) == (3, 3) and x.st.H * x.st.W >= self.sched.PLANES_MIN_PIX and x.c0 == 0):
             return False
         return ops._bwd_precision() == 1 and x.st.ld >= _r8(x.C) and ops.conv2d_planes_bwd_ok(self.lib, x.gview(), w, 1)
 
@@ -311,7 +300,7 @@ class DispNetEngine(object):
         if self.use_planes:
             self._record_banks(r, backward)
         self._grad_zeroed_early = False
-        if backward and ZERO_GRADS_EARLY and hasattr(r, "lane"):
+        if backward and self.sched.ZERO_GRADS_EARLY and hasattr(r, "lane"):
             # the 168 MB zero fill of the flat gradient buffer (21 us at the HBM rate) leaves the main lane: it runs on the filter gradients' side lane
             # beside the forward pass (nothing touches the gradients before the backward pass, whose first op joins the lane)
             r.lane = 1
@@ -387,7 +376,7 @@ class DispNetEngine(object):
     def record_backward(self, r, heads=(), early_update=None):
         """heads (offline training): [(prediction node, d loss / d make_disp(node))] -- every _make_disp output carries its own
         loss term (Train.py:100); each is one more consumer of its node and is injected before the op list is walked."""
-        """early_update = (lr, momentum, grad_scale): see EARLY_UPDATE; returns the sorted disjoint [first, end) parameter ranges updated here"""
+        """early_update = (lr, momentum, grad_scale): see self.sched.EARLY_UPDATE; returns the sorted disjoint [first, end) parameter ranges updated here"""
         lib, B, P = r, self.B, self.params
         upd_fresh, upd_done = [], []
         if getattr(self, "_grad_zeroed_early", False):
@@ -425,9 +414,9 @@ class DispNetEngine(object):
                     upd_fresh.append((a, min((a + t.numel() + 3) & ~3, P.total)))      # (+ the tensor's alignment padding: zero gradient, zero momentum)
 
         def flush(force=False):
-            if not pending or (len(pending) < FLUSH_MIN and not force):
+            if not pending or (len(pending) < self.sched.FLUSH_MIN and not force):
                 return
-            lib.lane = 1 + nflush[0] % SIDE_LANES
+            lib.lane = 1 + nflush[0] % self.sched.SIDE_LANES
             nflush[0] += 1
             try:
                 batch = []
@@ -626,7 +615,7 @@ class DispNetEngine(object):
             self.record_loss_metrics(r, with_grad=(mode == "FULL"))
             done = ()
             if mode == "FULL":
-                eu = (lr, momentum, grad_scale) if (EARLY_UPDATE and do_upd and part == "all" and optimizer == "momentum" and not self.deterministic) else None
+                eu = (lr, momentum, grad_scale) if (self.sched.EARLY_UPDATE and do_upd and part == "all" and optimizer == "momentum" and not self.deterministic) else None
                 done = self.record_backward(r, early_update=eu) or ()
         else:
             done = ()

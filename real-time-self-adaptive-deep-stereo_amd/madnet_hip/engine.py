@@ -20,136 +20,17 @@ import torch
 
 from . import ops
 from .plan import Recorder
+from .schedule import Schedule
+from .elision import ElisionPasses
+from .backward import BackwardRecorder, ops_fill      # noqa: F401
 
-PYR = [(3, 16, 2), (16, 16, 1), (16, 32, 2), (32, 32, 1), (32, 64, 2), (64, 64, 1),
-       (64, 96, 2), (96, 96, 1), (96, 128, 2), (128, 128, 1), (128, 192, 2), (192, 192, 1)]
-EST = [128, 128, 96, 64, 32, 1]
-CTX = [(128, 1), (128, 2), (128, 4), (96, 8), (64, 16), (32, 1), (1, 1)]
-LEVELS = (6, 5, 4, 3, 2)
-FEAT = {6: 12, 5: 10, 4: 8, 3: 6, 2: 4}
-ALPHA = 0.2   # MadNet._leaky_relu (Nets/MadNet.py:366-367)
-# The reduction of the loss value + the validation metrics run on a side lane (SIDE_LOSS: 2.048 -> 2.030 ms since side launches are deferred,
-# profiles/r02_experiments.txt #10, #20); the warp-gradient scatters on a lane of their own lost in every variant (2.056 / 2.27 ms) and
-# stay in line.
-ONE_FILL = True       # one zero fill for all level feature gradients + the g fill on the filter-gradient lane
-FUSE_BACK = True     # one launch for a level's correlation gradient + warp gradient (mh_corr_warp_bwd)
-PYR_BF16_FROM = int(os.environ.get("MH_PYR_BF16_FROM", "7"))     # 'mixed': pyramid layers from this one on run plain bf16 in the forward pass (13 = none)
-# the first N filter-gradient batches of a backward pass are launched at once instead of after the next lane-0 op (MH_OP_NODEFER)
-NODEFER_BATCHES = 0             # (module attribute: tests / experiments set it; early side launches measured slower, r03 #3)
-SIDE_LOSS = True     # on since side launches are deferred: 2.048 -> 2.030 ms (r02z)
-
-
-def _r4(c):
-    return (c + 3) // 4 * 4
-
-
-def pyr_name(i):
-    return "model/gc-read-pyramid/conv%d" % i
-
-
-def est_name(k, j):
-    return "model/G%d/fgc-volume-filtering-%d/disp-%d" % (k, k, j)
-
-
-def ctx_name(j):
-    return "model/context-%d" % j
-
-
-def _merge_ranges(ranges):
-    out = []
-    for a, b in sorted(ranges):
-        if out and a <= out[-1][1]:
-            out[-1] = (out[-1][0], max(out[-1][1], b))
-        else:
-            out.append((a, b))
-    return out
-
-
-def madnet_manifest(radius_d=2, stride=1):
-    """Ordered [(variable name, shape)] -- flat-buffer order.  Names are the TF variable names of
-    the reference graph."""
-    D = 2 * radius_d // stride + 1
-    out = []
-
-    def conv(base, k, ci, co):
-        out.append((base + "/weights", (k, k, ci, co)))
-        out.append((base + "/biases", (co,)))
-
-    # the twelve pyramid layers first, then estimator by estimator (the context network behind estimator 2): the backward pass
-    # finishes the estimator / context gradients BEFORE it starts on the pyramid, so [estimators | loss] is one contiguous range whose
-    # all-reduce overlaps the pyramid's backward pass in the shared-model mode, and the pyramid is the other (adapter.py).  A MAD
-    # block = its pyramid layers (contiguous) + its estimator (contiguous): two ranges.
-    for i in range(1, 13):
-        conv(pyr_name(i), 3, PYR[i - 1][0], PYR[i - 1][1])
-    for k in (2, 3, 4, 5, 6):
-        cin = PYR[FEAT[k] - 1][1] + D + (0 if k == 6 else 1)
-        for j, co in enumerate(EST):
-            conv(est_name(k, j + 1), 3, cin, co)
-            cin = co
-        if k == 2:
-            cin = PYR[3][1] + 1
-            for j, (co, _) in enumerate(CTX):
-                conv(ctx_name(j + 1), 3, cin, co)
-                cin = co
-    return out
+from .netdef import PYR, EST, CTX, LEVELS, FEAT, ALPHA, _r4, pyr_name, est_name, ctx_name, _merge_ranges, madnet_manifest      # noqa: E402,F401  (re-exported: E.LEVELS ...)
 
 
 
-# one launch for a head's output gradient + input gradient (mh_head_bwd) instead of resize gradient / copies + the K = 1 input-gradient kernel,
-# and the level-2 head's forward pass storing its result in the context input and in `final` too (mh_conv2d_head)
-# the first filter-gradient batches of a backward pass (context network, estimators 2 and 3: issued long before the step ends) run on 192
-# workgroups instead of 256: a quarter less split workspace and a quarter of the CUs left to the main chain (profiles/r03_experiments.txt #20:
-# 1.635 -> 1.629 ms; 128 / 96 workgroups: 1.649 / 1.652)
-EARLY_WGS = 192
-EARLY_BATCHES = 3
-FUSE_HEAD = True
-# FULL momentum steps: every filter-gradient batch is followed by the momentum update of its layers on its own lane, the launch behind the join covers
-# only what is left.  OFF: prepared at the end of round 3 and never timed on the MI355X (profiles/r03_experiments.txt #26; bench.py --set engine.EARLY_UPDATE=True)
-EARLY_UPDATE = False
-# The step's tail (device time stamps, bench.py --stamps, round 4): the last filter-gradient batch (conv4 .. conv1) could only start behind the LAST input
-# gradient -- conv1's filter gradient reads what conv2's input gradient writes -- so lane 0 sat idle for 91 us behind the chain (batch 76 us + join).
-# TAIL_SPLIT: the filter gradients of conv4 .. conv2 (their operands are final one layer earlier) leave as a batch of their own BEFORE conv2's input
-# gradient is launched and run beside it; only conv1's (the 3-channel image layer) is left for the tail.
-PACK_SIDE = False     # mh_pack_weights on the side lane beside pad_reflect / conv1: FULL -3 us (noise), but NONE / MAD get a second stream: +55 / +35 us (r04_experiments.txt #19)
-TAIL_SPLIT = False
-# The flush behind the last input gradient: the streamed layers of the last batch (conv4 .. conv2) on lane 0 -- idle from there to the join -- while the
-# side lane does the image layer (round 4: the side lane's second-to-last batch ends with the input-gradient chain, so the whole last batch, 62 us, was
-# exposed: profiles/r04_experiments.txt #17)
-TAIL_MAIN = True
-# generalisation: the pyramid's filter gradients leave for the side lane in batches; a batch is flushed AFTER the input gradient of layer i for i in
-# PYR_FLUSH_AFTER (the round-3 schedule: 9, 5, 1 = four layers per batch) and BEFORE the input gradient of layer i -- i.e. as soon as layer i's own
-# filter gradient has its operands -- for i in PYR_FLUSH_BEFORE
-PYR_FLUSH_AFTER = (9, 5, 1)
-PYR_FLUSH_BEFORE = ()
-# ... and that last batch (conv1's filter gradient + its split reduction) runs on a side lane of its own, so it starts the moment conv2's input gradient
-# ends instead of queueing behind the conv4 .. conv2 batch on the filter-gradient lane (0 = same lane).  Its slice of the gradient buffer is zeroed on
-# that lane too (first op of the backward pass): everything that touches those floats stays in ONE lane's order.
-TAIL_LANE = 2
-# 'mixed': the split-bf16 forward layers (stride-1 3x3, > bank_small_maxpix pixels) run from PRE-SPLIT operands (mh_conv2d_planes, csrc/conv_planes.hip):
-# activations as hi / lo bf16 planes -- hi is the shadow the backward pass reads anyway -- written by the producer's epilogue, staged by LDS DMA
-# Deterministic test mode (SURVEY 7, VERDICT r03 next 9): the float atomics of a step (bias gradients, warp-gradient scatter) accumulate into
-# 64-bit fixed-point twins (mh_deterministic_add) that the plan flushes behind every level's scatter and in front of the optimizer -- two replays
-# of the same step then give bit-identical weights.  At most four deterministic engines per process (two ranges each).
-DETERMINISTIC = os.environ.get("MH_DETERMINISTIC", "0") == "1"
-USE_PLANES = os.environ.get("MH_CONV_PLANES", "1") != "0"
-# ... and the fp32 copy of such an activation is not stored when no op of the plan reads it (engine._elide_fp32_activations)
-PLANES_ONLY = True
-# tests: fill every fp32 buffer whose store a plan elides with NaN when the plan is built (engine._note_elided)
-POISON_ELIDED = os.environ.get("MH_POISON_ELIDED", "0") == "1"
-# ... and the planes of tensors no plane kernel produces are written by THEIR producers (the level front end, the exact-fp32 layers in front of conv4 /
-# conv6, one concat-split for the context network's input) instead of by a split launch in front of every consumer
-FUSE_SPLITS = True
-# ... and the INPUT GRADIENTS of those layers (and of the 1/8-resolution estimator's) run the same kernel with one plane (mh_conv2d_planes_bwd): dz from the
-# bf16 shadow its producer wrote, the leaky mask from the activation's hi plane, the result as a shadow (+ fp32 only where something reads it)
-PLANES_DGRAD = True
-# diagnostics (bench.py --stamps): device time stamps (mh_stamp) recorded as plan ops at the start of the step, the end of the forward pass, the first
-# op of the side lane, the start / end of every filter-gradient batch, the end of the input-gradient chain, the join and the end of the step --
-# the REPLAYED graph timed from the inside, without a tracer.  Each stamp is a one-lane kernel: the stamped plan is a few us slower than the plain one.
-STAMPS = False
-# input gradients stage the bf16 shadow of dz when the previous input gradient's epilogue wrote one (mh_conv2d_sh2)
-SHADOW_DGRAD = True
-# ... and then do not store the fp32 gradient map at all when its only reader is such an input gradient (engine._elide_fp32_gradient_maps)
-SHADOW_ONLY = True
+
+
+
 
 
 class Params(object):
@@ -200,10 +81,12 @@ class Params(object):
         return [(o, c) for o, c in out]
 
 
-class MadNetEngine(object):
-    def __init__(self, lib, H, W, B=1, device="cuda", radius_d=2, stride=1, warping=True, weights=None, precision="fp32"):
+class MadNetEngine(ElisionPasses, BackwardRecorder):
+    def __init__(self, lib, H, W, B=1, device="cuda", radius_d=2, stride=1, warping=True, weights=None, precision="fp32", schedule=None):
         """precision: 'fp32' = exact fp32 MFMA (parity path, default) | 'bf16' = bf16 MFMA inputs with fp32
-        accumulation in the conv forward / input-gradient kernels (throughput mode; tensors stay fp32)."""
+        accumulation in the conv forward / input-gradient kernels (throughput mode; tensors stay fp32).
+        schedule: a madnet_hip.schedule.Schedule (immutable; default = the committed bench line's): how this engine's plans are recorded."""
+        self.sched = schedule if schedule is not None else Schedule()
         if precision not in ops.PRECISION_CODES:
             raise ValueError("precision must be one of %s" % sorted(ops.PRECISION_CODES))
         self.precision = precision
@@ -258,7 +141,7 @@ class MadNetEngine(object):
         self.fuse_shadows = True
         self._fresh = set()                 # shadows a producer wrote in the plan being recorded
         self._stream_train = set()          # trainable variables of that plan
-        self.use_planes = self.use_bank and precision == "mixed" and USE_PLANES
+        self.use_planes = self.use_bank and precision == "mixed" and self.sched.USE_PLANES
         self.banks32 = {}                   # layer -> fragment bank in the 32x32x16 image (mh_pack_weights trans = 2)
         self.banks32t = {}                  # layer -> the input gradient's one-plane bank in that image (trans = 3)
         self.planes = {}                    # (data pointer, B, H, W, C) -> ops.Planes (hi = the entry of self.shadows)
@@ -296,7 +179,7 @@ class MadNetEngine(object):
                 off += n
             else:
                 self.dF[i] = z(B2, hh, ww, co)
-        self.deterministic = DETERMINISTIC
+        self.deterministic = self.sched.DETERMINISTIC
         ops.check_planes_rule(self.lib)
         self._det_bases = []
         if self.deterministic:
@@ -384,7 +267,7 @@ class MadNetEngine(object):
         """forward precision code of pyramid layer i: in 'mixed' conv7 .. conv12 (1/16 resolution and below) run plain bf16 -- rounding ONE of them
         to bf16 moves the final disparity by 7e-5 (conv7), 6.8e-5 (conv8), 8e-6 (conv9 .. conv12) px, 1.7e-4 px together (per-layer map,
         profiles/r02_precision_map.txt); conv1 .. conv6 (9e-3 .. 9e-4 each) keep split-bf16 / exact fp32.  None = the mode's code."""
-        if self.precision == "mixed" and i >= PYR_BF16_FROM:
+        if self.precision == "mixed" and i >= self.sched.PYR_BF16_FROM:
             return 1
         return fcode
 
@@ -434,7 +317,7 @@ class MadNetEngine(object):
                 plan.append((n, 1, 1))
         # the LARGE stride-2 pyramid layers whose input gradient is the first contribution to its target (conv3: F2 feeds no cost volume): the parity-class
         # plane kernel (mh_conv2d_planes_bwd on a stride-2 descriptor) from the one-plane mirrored / transposed bank
-        if bcode == 1 and self.use_planes and PLANES_DGRAD:
+        if bcode == 1 and self.use_planes and self.sched.PLANES_DGRAD:
             for i in range(3, 13):
                 h, w = self.fshape[i][0], self.fshape[i][1]
                 if PYR[i - 1][2] == 2 and 2 * B * h * w > self.bank_small_maxpix and (i - 1) not in FEAT.values():
@@ -445,7 +328,7 @@ class MadNetEngine(object):
         return plan
 
     def _stamp(self, lib, label):
-        if not STAMPS or not hasattr(lib, "stamp"):
+        if not self.sched.STAMPS or not hasattr(lib, "stamp"):
             return
         if getattr(self, "stamps", None) is None:
             self.stamps = torch.zeros(64, dtype=torch.int64, device=self.dev)
@@ -458,7 +341,7 @@ class MadNetEngine(object):
 
     def _planes_bwd_layer(self, K, N):
         """does mh_conv2d_planes_bwd have an instance for the input gradient of a stride-1 3x3 layer K -> N?"""
-        if not (self.use_planes and PLANES_DGRAD):
+        if not (self.use_planes and self.sched.PLANES_DGRAD):
             return False
         import ctypes as C
         d = ops.conv_desc(1, 8, 8, 8, 8, K, N, 3, 3, 1, 1, 1, 1, 0, 0, K, 0, precision=1)
@@ -497,7 +380,7 @@ class MadNetEngine(object):
             self._fresh_planes.add(key)
             self._fresh.add(key)
             return
-        if shadow_consumer and shadow_consumer in self.banks32 and FUSE_SPLITS:
+        if shadow_consumer and shadow_consumer in self.banks32 and self.sched.FUSE_SPLITS:
             # the consumer runs from planes: this layer's epilogue writes them (mh_conv2d_sh4) instead of a split launch in front of the consumer
             key, op_ = self._planes_of(o)
             ops.conv2d_fwd(lib, x, self.W_(base), self.b_(base), o, stride=stride, dil=dil, alpha=alpha, wb=self.Wb_(base), precision=precision,
@@ -522,7 +405,7 @@ class MadNetEngine(object):
                     tgt[n] = torch.zeros(ops.pack_bytes(self.W_(n), planes, trans) // 4, device=self.dev)
             # (in line: on a side lane beside the first pyramid layers, which read no bank, it measured no gain -- profiles/r03_experiments.txt; PACK_SIDE
             #  repeats that experiment: the launch on lane 1 beside pad_reflect + conv1 (28 us), joined in front of conv2)
-            side_pack = PACK_SIDE and hasattr(lib, "lane") and self.wgrad_lanes > 0
+            side_pack = self.sched.PACK_SIDE and hasattr(lib, "lane") and self.wgrad_lanes > 0
             if side_pack:
                 lib.lane = 1
             try:
@@ -535,7 +418,7 @@ class MadNetEngine(object):
         x = ops.View(self.X0, 2 * B, self.Hp, self.Wp, 3, 4)
         for i, (ci, co, s) in enumerate(PYR, 1):
             o = self._fv(self.F[i])
-            if i == 2 and self.use_bank and PACK_SIDE and hasattr(lib, "lane") and self.wgrad_lanes > 0:
+            if i == 2 and self.use_bank and self.sched.PACK_SIDE and hasattr(lib, "lane") and self.wgrad_lanes > 0:
                 lib.join_lanes_next = 1 << 1                  # conv1 (3 input channels) never has a bank: every later layer waits for the packing
             # F_i is the input of layer i + 1 (stride 1 or 2: both streamed)
             self._conv_fwd(lib, r, x, pyr_name(i), o, stride=s, precision=self._pyr_code(i), shadow_consumer=(pyr_name(i + 1) if i < 12 else None))
@@ -552,7 +435,7 @@ class MadNetEngine(object):
                 # u_k = resize(V_{k+1}) * 20 / 2^k (MadNet.py:274), warp, cost volume + concat: one launch
                 xin = ops.View(self.dsi[k], B, h, w, c + self.D + 1, ld)
                 pl = None
-                if FUSE_SPLITS and self.use_planes and self.cstride == 1:
+                if self.sched.FUSE_SPLITS and self.use_planes and self.cstride == 1:
                     key, pl_ = self._planes_of(xin)
                     if est_name(k, 1) in self.banks32:
                         pl = pl_                                  # hi + lo: the estimator's first layer runs from planes
@@ -576,7 +459,7 @@ class MadNetEngine(object):
             for j, co in enumerate(EST):
                 last = j == len(EST) - 1
                 o = self._fv(self.V[k]) if last else self._fv(self.E[k][j])
-                if last and k == 2 and FUSE_HEAD and hasattr(lib, "conv2d_head"):
+                if last and k == 2 and self.sched.FUSE_HEAD and hasattr(lib, "conv2d_head"):
                     # the level-2 head also fills the disparity slot of the context network's input and seeds final = V2 + context7 (two copy
                     # launches on the critical chain before)
                     h4, w4, c4_ = self.fshape[4]
@@ -597,7 +480,7 @@ class MadNetEngine(object):
         # context network (MadNet._stereo_context_net, MadNet.py:122-171)
         h, w, c = self.fshape[4]
         cin = ops.View(self.ctx_in, B, h, w, c + 1, self.ctx_ld)
-        concat_split = FUSE_SPLITS and ctx_name(1) in self.banks32 and self.use_stream and self.partial_wgrad
+        concat_split = self.sched.FUSE_SPLITS and ctx_name(1) in self.banks32 and self.use_stream and self.partial_wgrad
         if concat_split:
             # the planes of tf.concat([left features, V2]) straight from the two sources: the first layer takes the planes, its streamed filter gradient
             # the hi plane, its input gradient has no mask -- nothing reads an fp32 copy of the concatenation
@@ -651,146 +534,11 @@ class MadNetEngine(object):
     def _fresh_shadow(self, v):
         """the bf16 shadow of View v if a producer recorded earlier in this plan wrote it (the patch-staged input-gradient kernel then stages
         it instead of converting v), else None"""
-        if not (SHADOW_DGRAD and ops._bwd_precision() == 1):
+        if not (self.sched.SHADOW_DGRAD and ops._bwd_precision() == 1):
             return None
         key = (v.ptr, v.B, v.H, v.W, v.C)
         return self.shadows.get(key) if key in self._fresh else None
 
-    def _elide_fp32_gradient_maps(self, r):
-        """Post-pass over the recorded plan (dead-store elimination): an input-gradient launch that writes the bf16 shadow of its result does not
-        store the fp32 map when the ONLY op that touches that buffer afterwards is the next input gradient and that launch stages the shadow
-        (mh_conv2d_takes_shadows answers for the recorded descriptor): inside the 1/4-resolution estimator and the context network the gradient
-        maps then exist in bf16 only (15.7 MB less written per 128-channel layer)."""
-        if not (SHADOW_DGRAD and SHADOW_ONLY):
-            return 0
-        import ctypes as C
-        from . import _ffi
-        ops_ = r.ops
-        n = 0
-        spans = []
-        for idx, o in enumerate(ops_):
-            if o.kind == _ffi.OP_CONV and o.i[13] == 1 and o.p[7] and not o.i[18] and o.i[22] == 1 and o.p[3]:
-                spans.append((idx, int(o.p[3]), int(o.p[3]) + 4 * o.i[0] * o.i[3] * o.i[4] * o.i[16]))
-        for idx, lo, hi in spans:
-            if any(a < hi and lo < a + nb for _, a, nb in getattr(r, "refs", ())):
-                continue                # a device table (cast / split segment) reads the map
-            users = []
-            for j, q in enumerate(ops_):
-                if j == idx:
-                    continue
-                if any(q.p[k] and lo <= int(q.p[k]) < hi for k in range(8)):
-                    users.append(j)
-            if len(users) != 1 or users[0] < idx:
-                continue
-            c = ops_[users[0]]
-            if not (c.kind == _ffi.OP_CONV and c.i[13] == 1 and int(c.p[0]) == lo and (c.i[23] & 1) and c.i[22] == 1):
-                continue
-            if sum(1 for k in range(8) if c.p[k] and lo <= int(c.p[k]) < hi) != 1:
-                continue
-            if not (self._takes_shadows(c) & 1):
-                continue
-            ops_[idx].i[23] |= 4
-            c.i[23] |= 8            # MH_CONV_IN_F32_STALE: a replay whose dispatch no longer stages the shadow is refused, not wrong (ADVICE r03)
-            self._note_elided(r, lo, hi - lo)
-            n += 1
-        return n
-
-    def _note_elided(self, r, ptr, nbytes):
-        """An fp32 buffer no op of this plan writes any more.  Kept on the recorder / plan (plan.elided) so that a reader OUTSIDE the plan can ask; with
-        MH_POISON_ELIDED=1 (tests) the buffer is filled with NaN at once: an op that still reads it -- a device-table op whose table building forgot
-        Recorder.note_refs, a debug read of engine.E / Cx -- then fails loudly instead of consuming a stale map."""
-        if not hasattr(r, "elided"):
-            r.elided = []
-        r.elided.append((int(ptr), int(nbytes)))
-        if POISON_ELIDED:
-            t = self._tensor_by_ptr().get(int(ptr))
-            if t is not None:
-                t.fill_(float("nan"))
-
-    def _tensor_by_ptr(self):
-        out = {}
-        for k in LEVELS:
-            for t in list(self.E[k]) + list(self.dE[k]):
-                out[t.data_ptr()] = t
-        for t in list(self.Cx) + list(self.dCx):
-            out[t.data_ptr()] = t
-        return out
-
-    def _takes_shadows(self, c):
-        """mh_conv2d_takes_shadows for a recorded OP_CONV: bit 1 = the launch stages in_shadow, bit 2 = it reads the mask from mask_shadow"""
-        import ctypes as C
-        from . import _ffi
-        d = _ffi.ConvDesc(*([c.i[k] for k in range(18)] + [c.i[18], c.f[0], c.f[1], c.i[19], c.i[20], c.i[22]]))
-        return self.lib.conv2d_takes_shadows(C.byref(d), C.c_void_p(c.p[0]), C.c_void_p(c.p[1]), C.c_void_p(c.p[6]), C.c_void_p(c.p[3]), C.c_void_p(c.p[4]))
-
-    def _standalone_activations(self):
-        """{data pointer: bytes} of the activation tensors that are allocations of their own (no view of them can start in front of them): the only
-        candidates for an elided fp32 store"""
-        out = {}
-        for k in LEVELS:
-            for t in self.E[k]:
-                out[t.data_ptr()] = t.numel() * 4
-        for t in self.Cx:
-            out[t.data_ptr()] = t.numel() * 4
-        for k in LEVELS:                    # ... and the gradient maps between the input gradients of an estimator / the context network
-            for t in self.dE[k]:
-                out[t.data_ptr()] = t.numel() * 4
-        for t in self.dCx:
-            out[t.data_ptr()] = t.numel() * 4
-        return out
-
-    def _elide_fp32_activations(self, r):
-        """Post-pass (dead-store elimination, forward side): a plane-writing forward layer (OP_CONV_PLANES) does not store its fp32 result when no op
-        of the recorded plan reads that tensor -- the next forward layer takes the planes, the filter gradient the hi plane, the input gradient of the
-        next layer the sign of the hi plane for its leaky mask (it gets MH_CONV_MASK_F32_STALE, so a replay under another dispatch fails loudly).
-        Readers are found conservatively: any pointer field of any op, and any tensor a device table of an op references (Recorder.refs), that
-        OVERLAPS the buffer."""
-        if not (self.use_planes and PLANES_ONLY):
-            return 0
-        from . import _ffi
-        ops_ = r.ops
-        cand = self._standalone_activations()
-        n = 0
-        for idx, o in enumerate(ops_):
-            if o.kind == _ffi.OP_CONV_PLANES and o.p[4] and o.p[5] and o.p[6]:
-                slot = 4                    # forward: fp32 result beside both planes
-            elif o.kind == _ffi.OP_CONV_PLANES_BWD and o.p[3] and o.p[4]:
-                slot = 3                    # input gradient: fp32 map beside its shadow
-            else:
-                continue
-            lo = int(o.p[slot])
-            if lo not in cand:
-                continue
-            hi = lo + cand[lo]
-            if any(a < hi and lo < a + nb for _, a, nb in getattr(r, "refs", ())):
-                continue
-            ok, mask_users = True, []
-            for j, q in enumerate(ops_):
-                if j == idx:
-                    continue
-                hits = [k for k in range(8) if q.p[k] and lo <= int(q.p[k]) < hi]
-                if not hits:
-                    continue
-                # the only tolerated readers: an input gradient (tiled families) that was given this tensor as its leaky mask TOGETHER with the mask's
-                # shadow and whose kernel tests the shadow -- or as its dz together with dz's shadow and whose kernel stages the shadow
-                if (q.kind == _ffi.OP_CONV and q.i[13] == 1 and hits == [4] and int(q.p[4]) == lo and (q.i[23] & 2) and q.i[22] == 1
-                        and (self._takes_shadows(q) & 2)):
-                    mask_users.append((q, 16))          # MH_CONV_MASK_F32_STALE
-                    continue
-                if (q.kind == _ffi.OP_CONV and q.i[13] == 1 and hits == [0] and int(q.p[0]) == lo and (q.i[23] & 1) and q.i[22] == 1
-                        and (self._takes_shadows(q) & 1)):
-                    mask_users.append((q, 8))           # MH_CONV_IN_F32_STALE
-                    continue
-                ok = False
-                break
-            if not ok:
-                continue
-            o.p[slot] = None
-            for q, bit in mask_users:
-                q.i[23] |= bit
-            self._note_elided(r, lo, hi - lo)
-            n += 1
-        return n
 
     def _front_fused(self):
         return self.fuse_front and self.warping and self.cstride == 1 and self.D <= 9
@@ -811,7 +559,7 @@ class MadNetEngine(object):
     def record_loss_metrics(self, r, with_grad):
         """full-resolution reprojection loss (Stereo_Online_Adaptation.py:70) -- or, loss_kind 'proxy', the proxy-label
         mean_l1 of the continual variant (Stereo_Continual_Adaptation.py:75, weight 0.01) -- + EPE/bad3 (:74-82)."""
-        side = SIDE_LOSS and self.wgrad_lanes > 0 and hasattr(r, "lane")
+        side = self.sched.SIDE_LOSS and self.wgrad_lanes > 0 and hasattr(r, "lane")
         if self.loss_kind == "proxy":
             ops.proxy_loss(r, self.pred, self.proxy, self.proxy_ws, self.res_loss, self.dpred if with_grad else None, weight=0.01)
         elif side:
@@ -837,381 +585,6 @@ class MadNetEngine(object):
     # =========================================================================================
     # backward
     # =========================================================================================
-    def _train_flags(self, train_vars, bulkhead):
-        tv = set(train_vars)
-        pyr_tr = {i: (pyr_name(i) + "/weights") in tv for i in range(1, 13)}
-        pyr_need = {}                       # gradient w.r.t. F_i needed?
-        acc = False
-        for i in range(1, 13):
-            acc = acc or pyr_tr[i]
-            pyr_need[i] = acc
-        est_tr = {k: [(est_name(k, j) + "/weights") in tv for j in range(1, 7)] for k in LEVELS}
-        ctx_tr = [(ctx_name(j) + "/weights") in tv for j in range(1, 8)]
-        # anything trainable upstream of V_k (deeper levels chain only through u when not bulkhead)
-        up_V = {}
-        prev = False
-        for k in LEVELS:
-            need_u = (not bulkhead) and prev and k != 6
-            up_V[k] = any(est_tr[k]) or pyr_need[FEAT[k]] or need_u
-            prev = up_V[k]
-        return pyr_tr, pyr_need, est_tr, ctx_tr, up_V
-
-    def record_backward(self, r, head, train_vars, bulkhead, heads=None, early_update=None):
-        """early_update = (lr, momentum, grad_scale) (EARLY_UPDATE, FULL momentum steps): the update of a batch's layers follows the batch's reduction on its
-        lane -- their input gradients were launched before the batch's fork edge and nothing later in the step reads those weights (the fragment banks
-        were packed at the start of the step) -- instead of ONE launch over every parameter behind the join; returns the ranges updated that way.
-        head: 'final' (loss on rescaled_prediction, FULL mode) or a level k in LEVELS
-        (loss on the _make_disp of that level / of the context output for k=2, MAD mode).
-        Assumes the matching d(loss)/d(disparity map) is already in self.dpred / self.ddisp_k.
-        heads (offline training, Train.py:100): {'final' | level: gradient buffer} -- a loss on EVERY prediction at once;
-        the per-head gradients accumulate where the heads meet (dfinal, dV[k]).
-        Emits: zero of the touched gradient ranges, all needed dgrad/wgrad kernels."""
-        lib, B = r, self.B
-        P = self.params
-        pyr_tr, pyr_need, est_tr, ctx_tr, up_V = self._train_flags(train_vars, bulkhead)
-        # zero of the gradient ranges (bias gradients and single-split filter gradients accumulate): with ONE filter-gradient lane it goes
-        # onto that lane -- everything that touches g runs there, behind it -- and off the critical path
-        g_side = ONE_FILL and self.wgrad_lanes == 1 and hasattr(lib, "lane")
-        tail_vars = [pyr_name(1) + "/weights", pyr_name(1) + "/biases"]
-        tail_lane = TAIL_LANE if (TAIL_SPLIT and TAIL_LANE and g_side and pyr_tr[1] and pyr_tr[2] and all(v in train_vars for v in tail_vars)) else 0
-        if g_side:
-            lib.lane = 1
-        try:
-            for o, c in P.ranges([v for v in train_vars if not (tail_lane and v in tail_vars)]):
-                ops_fill(lib, P.g, o, c)
-            if tail_lane:
-                lib.lane = tail_lane
-                for o, c in P.ranges(tail_vars):
-                    ops_fill(lib, P.g, o, c)
-        finally:
-            if g_side:
-                lib.lane = 0
-        # ONE fill for the feature gradients of all cost-volume levels (13.9 MB at 1242x375) instead of a fill in front of every level's
-        # warp-gradient scatter: both towers start from zero, every contribution accumulates
-        prezero = ONE_FILL and self.warping and not bulkhead
-        if prezero:
-            ops_fill(lib, self.dF_levels, 0, self.dF_levels.numel())
-        written = set()                     # gradient buffers that already hold a contribution
-        if prezero:
-            for i in FEAT.values():
-                written.add(("F", i, 0)); written.add(("F", i, 1))
-        segs = []                           # partial filter-gradient segments of this backward pass
-
-        pending = []                        # deferred filter-gradient launches (flushed as one side-lane batch)
-        batched = (self.wgrad_lanes > 0 and hasattr(lib, "lane")) or (self.use_stream and self.partial_wgrad)
-        if not batched:
-            early_update = None
-        upd_fresh, upd_done = [], []        # early_update: parameter ranges the batch being collected completes / ranges already updated
-
-        def wgrad(xv, dzv, base, stride=1, dil=1):
-            dw, db = P.tensor(base + "/weights", "g"), P.tensor(base + "/biases", "g")
-            if batched:
-                pending.append((xv, dzv, dw, db, stride, dil))      # issued per batch (flush): on a side lane, and / or as one streamed launch
-                if early_update is not None:
-                    for t in (dw, db):
-                        a = (t.data_ptr() - P.g.data_ptr()) // 4
-                        assert 0 <= a and a + t.numel() <= P.total
-                        upd_fresh.append((a, min((a + t.numel() + 3) & ~3, P.total)))       # (+ the tensor's alignment padding: zero gradient, zero momentum)
-            elif not self.partial_wgrad:
-                ops.conv2d_wgrad(lib, xv, dzv, dw, db, stride=stride, dil=dil)
-            else:
-                ops.conv2d_wgrad_partial(lib, self.lib, self.wsa, segs, xv, dzv, dw, db, stride=stride, dil=dil)
-
-        nflush = [0]
-
-        chain_stamped = [False]
-
-        def flush(lane=None, tail=False, on_main=False):
-            """Issue the deferred filter gradients as ONE batch on a side lane (one fork edge): they read only
-            buffers that nothing later in the step overwrites, so they may run concurrently with everything that
-            follows on lane 0 until the reduction joins them.
-            tail (the flush behind the LAST input gradient, TAIL_MAIN): nothing follows on lane 0 any more, so the batch is split -- the layers of the
-            streamed kernel (conv4 .. conv2) run on lane 0 itself while the side lane does the image layer's gradient and its reduction."""
-            if not pending:
-                return
-            # (not with early_update: the ranges a batch completes are collected per flush, not per half)
-            if (tail and TAIL_MAIN and early_update is None and self.wgrad_lanes > 0 and hasattr(lib, "lane") and self.use_stream and self.partial_wgrad
-                    and ops._bwd_precision() == 1):
-                streamed = [it for it in pending if ops.wgrad_stream_ok(it[0], it[1], it[2], it[4], it[5]) and it[0].npix >= self.stream_min_pix]
-                rest = [it for it in pending if not any(it is q for q in streamed)]
-                if streamed and rest:
-                    pending[:] = rest
-                    flush(lane=lane)
-                    pending[:] = streamed
-                    flush(on_main=True)
-                    return
-            side = self.wgrad_lanes > 0 and hasattr(lib, "lane") and not on_main
-            if side:
-                lib.lane = lane if lane else 1 + nflush[0] % self.wgrad_lanes
-                lib.nodefer = nflush[0] < NODEFER_BATCHES        # the first batches (context network, 1/4-resolution estimator) carry most of the work
-            nflush[0] += 1
-            try:
-                self._stamp(lib, "wgrad_batch%d_start" % nflush[0])
-                batch = []
-                todo = list(pending)
-                if self.use_stream and self.partial_wgrad and ops._bwd_precision() == 1:
-                    items, casts, todo = [], [], []
-                    for xv, dzv, dw, db, stride, dil in pending:
-                        if ops.wgrad_stream_ok(xv, dzv, dw, stride, dil) and xv.npix >= self.stream_min_pix:
-                            items.append((self._shadow(xv, casts), self._shadow(dzv, casts), dw, db, dil))
-                        else:
-                            todo.append((xv, dzv, dw, db, stride, dil))
-                    ops.shadow_cast(lib, casts, self.dev, r.keep)
-                    ops.wgrad_stream(lib, self.lib, self.wsa, batch, items, self.dev, r.keep, nwaves=(4 if self.B == 1 else 8),
-                                     target_wgs=(EARLY_WGS if (EARLY_WGS and self.B == 1 and nflush[0] <= EARLY_BATCHES) else None))
-                for xv, dzv, dw, db, stride, dil in todo:
-                    if self.partial_wgrad:
-                        ops.conv2d_wgrad_partial(lib, self.lib, self.wsa, batch, xv, dzv, dw, db, stride=stride, dil=dil)
-                    else:
-                        ops.conv2d_wgrad(lib, xv, dzv, dw, db, stride=stride, dil=dil)
-                # the batch's split reduction follows on the SAME lane: it too is off the critical path
-                if batch:
-                    ops.wgrad_reduce(lib, batch, self.dev, r.keep)
-                if early_update is not None:
-                    lr_, mom_, gs_ = early_update
-                    for a, b in _merge_ranges(upd_fresh):
-                        ops.momentum(lib, P.w[a:b], P.m[a:b], P.g[a:b], lr_, mom_, gs_)
-                        upd_done.append((a, b))
-                self._stamp(lib, "wgrad_batch%d_end" % nflush[0])
-            finally:
-                if side:
-                    lib.lane = 0
-                    lib.nodefer = False
-                del pending[:]
-                del upd_fresh[:]
-
-        def acc_flag(key):
-            a = key in written
-            written.add(key)
-            return a
-
-        head_done = set()                   # levels whose head's input gradient went out with mh_head_bwd
-
-        def fuse_head(k, **src):
-            """dV[k] from its only source (the finer level's coordinate gradient through the x2 resize, or -- level 2 -- dfinal + the disparity
-            channel of the context input's gradient) AND the input gradient of estimator k's head, in one launch; False = not applicable
-            (another contribution already sits in dV[k], nothing below the head needs a gradient, switched off)."""
-            if not (FUSE_HEAD and hasattr(lib, "head_bwd") and up_V[k] and ("V", k) not in written):
-                return False
-            need_u_k = (not bulkhead) and k != 6 and up_V[k + 1]
-            if not (any(est_tr[k][:5]) or pyr_need[FEAT[k]] or need_u_k):
-                return False
-            dxv, dVv = self._fv(self.dE[k][4]), self._fv(self.dV[k])
-            ops.head_bwd(lib, self.W_(est_name(k, 6)), self.dV[k], dxv, mask_ref=self._fv(self.E[k][4]), mask_alpha=ALPHA,
-                         accumulate_dx=acc_flag(("est", k, 5)), dV_shadow=self._out_shadow(dVv, est_name(k, 6)),
-                         dx_shadow=self._out_shadow(dxv, est_name(k, 5)), **src)
-            written.add(("V", k))
-            head_done.add(k)
-            return True
-
-        def conv_bwd(xv, base, dzv, dxv, dx_key, x_act, stride=1, dil=1, need_dx=True, trainable=True, below=None):
-            """below: the layer whose output gradient dxv is (its filter gradient reads it as dz): the input gradient's epilogue then also
-            writes the bf16 shadow"""
-            if trainable:
-                wgrad(xv, dzv, base, stride=stride, dil=dil)
-            if need_dx:
-                acc = acc_flag(dx_key)
-                wbt = self.banks32t.get(base) if (stride == 1 and not acc) else None
-                dzs = self._fresh_shadow(dzv) if wbt is not None else None
-                mks = self._fresh_shadow(x_act) if (wbt is not None and x_act is not None) else None
-                if wbt is not None and dzs is not None and (x_act is None or mks is not None):
-                    # one-plane walk of the planes kernel: dz from its shadow, the mask from the activation's hi plane; the result leaves as a shadow
-                    # (always: the next input gradient stages it) and, until the post-pass proves that nothing reads it, as fp32
-                    key = (dxv.ptr, dxv.B, dxv.H, dxv.W, dxv.C)
-                    sh = self.shadows.get(key)
-                    if sh is None:
-                        sh = self.shadows[key] = ops.Shadow(dxv.B, dxv.H, dxv.W, dxv.C, self.dev)
-                    ops.conv2d_planes_bwd(lib, dzs, self.W_(base), wbt, dx=dxv, dx_shadow=sh, mask_shadow=mks, mask_alpha=ALPHA, dil=dil)
-                    self._fresh.add(key)
-                    return
-                ops.conv2d_dgrad(lib, dzv, self.W_(base), dxv, stride=stride, dil=dil, accumulate=acc,
-                                 mask_ref=x_act, mask_alpha=ALPHA, wb=self.Wd_(base),
-                                 shadow=(self._out_shadow(dxv, below) if below else None), dz_shadow=self._fresh_shadow(dzv),
-                                 mask_shadow=(self._fresh_shadow(x_act) if x_act is not None else None))
-
-        if heads is None:
-            heads = {head: (self.dpred if head == "final" else self.ddisp_k)}
-        start_level = 2 if ("final" in heads or 2 in heads) else min(heads)
-        h2, w2, c2 = self.fshape[4]
-        # ---- heads ------------------------------------------------------------------------------
-        for hd in sorted(heads, key=lambda x: (0 if x == "final" else x)):
-            gbuf = heads[hd]
-            if hd == "final":
-                ops.resize_bwd(lib, gbuf, self.final, self.dfinal, self.Hp, self.Wp, self.pt, self.pl,
-                               mul=-20.0, mode=2, accumulate=acc_flag(("final",)))
-            elif hd == 2:
-                ops.resize_bwd(lib, gbuf, self.final, self.dfinal, self.Hp, self.Wp, self.pt, self.pl,
-                               mul=-20.0, mode=1, accumulate=acc_flag(("final",)))
-            else:
-                ops.resize_bwd(lib, gbuf, self.V[hd], self.dV[hd], self.Hp, self.Wp, self.pt, self.pl,
-                               mul=-20.0, mode=1, accumulate=acc_flag(("V", hd)))
-        # ---- context network ----------------------------------------------------------------------
-        if start_level == 2:
-            any_below = up_V[2]
-            if any(ctx_tr) or any_below:
-                # final = V2 + c7 : dc7 = dfinal ; dV2 (+)= dfinal
-                dz = self._fv(self.dfinal)
-                for j in range(7, 0, -1):
-                    xin = ops.View(self.ctx_in, B, h2, w2, c2 + 1, self.ctx_ld) if j == 1 else self._fv(self.Cx[j - 2])
-                    dx = ops.View(self.dctx_in, B, h2, w2, c2 + 1, self.ctx_ld) if j == 1 else self._fv(self.dCx[j - 2])
-                    need_dx = any(ctx_tr[:j - 1]) or any_below
-                    conv_bwd(xin, ctx_name(j), dz, dx, ("ctx", j - 1), (None if j == 1 else self._fv(self.Cx[j - 2])),
-                             dil=CTX[j - 1][1], need_dx=need_dx, trainable=ctx_tr[j - 1], below=(ctx_name(j - 1) if j > 1 else None))
-                    dz = dx
-                    if not need_dx:
-                        break
-            flush()
-            if up_V[2]:
-                dci = ops.View(self.dctx_in, B, h2, w2, c2 + 1, self.ctx_ld)
-                if not fuse_head(2, addends=(self._fv(self.dfinal), dci.slice(c2, c2 + 1))):
-                    ops.copy_channels(lib, self._fv(self.dfinal), self._fv(self.dV[2]), accumulate=acc_flag(("V", 2)))
-                    ops.copy_channels(lib, dci.slice(c2, c2 + 1), self._fv(self.dV[2]), accumulate=acc_flag(("V", 2)))
-                if pyr_need[4]:
-                    ops.copy_channels(lib, dci.slice(0, c2), self._half(self.dF[4], False), accumulate=acc_flag(("F", 4, 0)))
-        # ---- levels start_level .. 6 ---------------------------------------------------------------
-        for k in LEVELS[::-1]:
-            if k < start_level:
-                continue
-            if not up_V[k] or ("V", k) not in written:
-                break
-            f = FEAT[k]
-            h, w, c = self.fshape[f]
-            ld = self.dsi_ld[k]
-            cin = c + self.D + (0 if k == 6 else 1)
-            need_u = (not bulkhead) and k != 6 and up_V[k + 1]
-            need_dsi = pyr_need[f] or need_u
-            dz = self._fv(self.dV[k])
-            for j in range(6, 0, -1):
-                xin = ops.View(self.dsi[k], B, h, w, cin, ld) if j == 1 else self._fv(self.E[k][j - 2])
-                dx = ops.View(self.ddsi[k], B, h, w, cin, ld) if j == 1 else self._fv(self.dE[k][j - 2])
-                need_dx = any(est_tr[k][:j - 1]) or need_dsi
-                if j == 6 and k in head_done:           # its input gradient is already there: only the filter gradient is left
-                    if est_tr[k][5]:
-                        wgrad(xin, dz, est_name(k, 6))
-                    dz = dx
-                    continue
-                conv_bwd(xin, est_name(k, j), dz, dx, ("est", k, j - 1), (None if j == 1 else self._fv(self.E[k][j - 2])),
-                         need_dx=need_dx, trainable=est_tr[k][j - 1], below=(est_name(k, j - 1) if j > 1 else None))
-                dz = dx
-                if not need_dx:
-                    break
-            flush()
-            if not need_dsi:
-                break
-            # correlation (+ fused concat) gradient
-            Lk = self._half(self.F[f], False)
-            g = ops.View(self.ddsi[k], B, h, w, ld, ld)
-            dL = self._half(self.dF[f], False)
-            if k == 6 or not self.warping:
-                Rk = self._half(self.F[f], True)
-                du = self.du[k] if (k != 6 and need_u) else None      # un-warped levels: u only feeds the estimator input
-                ops.corr_bwd(lib, g, Lk, Rk, dL, self._half(self.dF[f], True), self.md, self.cstride, coff=c, du=du,
-                             acc_l=acc_flag(("F", f, 0)), acc_r=acc_flag(("F", f, 1)), acc_u=False, copy_left=True)
-                if du is not None:
-                    s_up = 2 ** k
-                    if not fuse_head(k + 1, du=self.du[k], Hr=self.Hp // s_up, Wr=self.Wp // s_up, mul=20.0 / s_up):
-                        ops.resize_bwd(lib, self.du[k], self.V[k + 1], self.dV[k + 1], self.Hp // s_up, self.Wp // s_up,
-                                       mul=20.0 / s_up, mode=0, accumulate=acc_flag(("V", k + 1)))
-            elif FUSE_BACK and ("F", f, 1) in written:
-                # the level's correlation + concat gradient and the warp gradient in ONE launch (mh_corr_warp_bwd): the gradient w.r.t. the warped
-                # features never goes to memory; the scatter target was zeroed by the pass's single fill (or holds earlier contributions)
-                du = self.du[k] if need_u else None
-                ops.corr_warp_bwd(lib, g, Lk, self._fv(self.Rw[k]), self._half(self.F[f], True), self.u[k], dL, self._half(self.dF[f], True), du,
-                                  self.md, self.cstride, coff=c, acc_l=acc_flag(("F", f, 0)), copy_left=True)
-                self._det_flush(lib, self.dF[f][B:], self.det_dF if self.deterministic else None, self.dF_levels)
-                if need_u:
-                    s_up = 2 ** k
-                    if not fuse_head(k + 1, du=self.du[k], Hr=self.Hp // s_up, Wr=self.Wp // s_up, mul=20.0 / s_up):
-                        ops.resize_bwd(lib, self.du[k], self.V[k + 1], self.dV[k + 1], self.Hp // s_up, self.Wp // s_up,
-                                       mul=20.0 / s_up, mode=0, accumulate=acc_flag(("V", k + 1)))
-            else:
-                Rk = self._fv(self.Rw[k])
-                du = self.du[k] if need_u else None
-                ops.corr_bwd(lib, g, Lk, Rk, dL, self._fv(self.dRw[k]), self.md, self.cstride, coff=c, du=du,
-                             acc_l=acc_flag(("F", f, 0)), acc_r=False, acc_u=False, copy_left=True)
-                # warp gradient: scatter into the right tower's feature gradient (atomics -> zero first)
-                dFr = self._half(self.dF[f], True)
-                fresh = not acc_flag(("F", f, 1))
-                if fresh:
-                    ops_fill(lib, self.dF[f][B:], 0, self.dF[f][B:].numel())
-                ops.warp_bwd(lib, self._fv(self.dRw[k]), self._half(self.F[f], True), self.u[k], dFr,
-                             du=du, acc_u=True)
-                self._det_flush(lib, self.dF[f][B:], self.det_dF if self.deterministic else None, self.dF_levels)
-                if need_u:
-                    # u_k = resize(V_{k+1}) * 20/2^k   (MadNet.py:274: u_{k} built at level k+1 with scales[k])
-                    s_up = 2 ** k
-                    if not fuse_head(k + 1, du=self.du[k], Hr=self.Hp // s_up, Wr=self.Wp // s_up, mul=20.0 / s_up):
-                        ops.resize_bwd(lib, self.du[k], self.V[k + 1], self.dV[k + 1], self.Hp // s_up, self.Wp // s_up,
-                                       mul=20.0 / s_up, mode=0, accumulate=acc_flag(("V", k + 1)))
-        # ---- pyramid towers (batch 2B, shared weights) ---------------------------------------------
-        # split point of build_plan(part='grad_split'): every gradient of the estimators / the context network is final here (their
-        # batches were flushed level by level), the pyramid's come after -- the shared-model step all-reduces the first range while
-        # the second is still being computed
-        if hasattr(r, "cut"):
-            r.cut()
-        top = None
-        for i in range(12, 0, -1):
-            if ("F", i, 0) in written or ("F", i, 1) in written or ("Fd", i) in written:
-                top = i
-                break
-        if top is not None and pyr_need[top]:
-            # features that feed only the cost volume still need their own leaky gradient
-            if ("Fd", top) not in written:
-                if ("F", top, 0) not in written:
-                    ops_fill(lib, self.dF[top][:B], 0, self.dF[top][:B].numel())
-                if ("F", top, 1) not in written:
-                    ops_fill(lib, self.dF[top][B:], 0, self.dF[top][B:].numel())
-                ops.leaky_bwd(lib, self._fv(self.dF[top]), self._fv(self.F[top]), ALPHA)
-            for i in range(top, 0, -1):
-                if not pyr_need[i]:
-                    break
-                xin = ops.View(self.X0, 2 * B, self.Hp, self.Wp, 3, 4) if i == 1 else self._fv(self.F[i - 1])
-                need_dx = i > 1 and pyr_need[i - 1]
-                accumulate = False
-                if need_dx:
-                    has_l, has_r = ("F", i - 1, 0) in written, ("F", i - 1, 1) in written
-                    accumulate = has_l or has_r
-                    if accumulate and not has_l:
-                        ops_fill(lib, self.dF[i - 1][:B], 0, self.dF[i - 1][:B].numel())
-                    if accumulate and not has_r:
-                        ops_fill(lib, self.dF[i - 1][B:], 0, self.dF[i - 1][B:].numel())
-                if pyr_tr[i]:
-                    wgrad(xin, self._fv(self.dF[i]), pyr_name(i), stride=PYR[i - 1][2])
-                if (TAIL_SPLIT and i == 2) or i in PYR_FLUSH_BEFORE:
-                    flush()                 # (TAIL_SPLIT: conv4 .. conv2 beside conv2's input gradient, not behind it)
-                if need_dx:
-                    # dF[i-1] is complete after this launch (the cost-volume contributions were written earlier): it is the dz of layer i - 1
-                    sh = self._out_shadow(self._fv(self.dF[i - 1]), pyr_name(i - 1)) if (i - 1 > 1) else None       # (conv1's 3-channel input keeps the tiled kernel)
-                    wbt = self.banks32t.get(pyr_name(i)) if not accumulate else None       # (stride-2 layers: only those _bank_plan gave a bank)
-                    dzs = self._fresh_shadow(self._fv(self.dF[i])) if wbt is not None else None
-                    mks = self._fresh_shadow(self._fv(self.F[i - 1])) if wbt is not None else None
-                    if wbt is not None and dzs is not None and mks is not None and sh is not None:
-                        ops.conv2d_planes_bwd(lib, dzs, self.W_(pyr_name(i)), wbt, dx=self._fv(self.dF[i - 1]), dx_shadow=sh, mask_shadow=mks, mask_alpha=ALPHA,
-                                              stride=PYR[i - 1][2])
-                        if i in PYR_FLUSH_AFTER:
-                            flush(lane=(tail_lane if i == 1 else None))
-                        continue
-                    ops.conv2d_dgrad(lib, self._fv(self.dF[i]), self.W_(pyr_name(i)), self._fv(self.dF[i - 1]),
-                                     stride=PYR[i - 1][2], accumulate=accumulate, mask_ref=self._fv(self.F[i - 1]),
-                                     mask_alpha=ALPHA, wb=self.Wd_(pyr_name(i)), shadow=sh,
-                                     dz_shadow=self._fresh_shadow(self._fv(self.dF[i])), mask_shadow=self._fresh_shadow(self._fv(self.F[i - 1])))
-                if i in PYR_FLUSH_AFTER:
-                    if i == 1:
-                        self._stamp(lib, "chain_end")           # lane 0: the last input gradient is behind us (the tail flush may put work on lane 0 again)
-                        chain_stamped[0] = True
-                    flush(lane=(tail_lane if i == 1 else None), tail=(i == 1))
-        flush()
-        if not chain_stamped[0]:
-            self._stamp(lib, "chain_end")                       # lane 0: the last input gradient is behind us
-        ops.wgrad_reduce(lib, segs, self.dev, r.keep)          # (serial variant only: the side-lane batches reduce themselves)
-        r.join_next = True                                      # whatever comes next (the optimizer) waits for the side lanes
-        self._stamp(lib, "joined")                              # (takes the join edge: every side lane has finished)
-        r.join_next = True
-        if self.deterministic:
-            assert not upd_done, "deterministic mode: no early update (the bias gradients are still in their fixed-point twins)"
-            self._det_flush(lib, self.params.g, self.det_g, self.params.g)
-            r.join_next = True
-        return _merge_ranges(upd_done)
 
     def _det_flush(self, lib, t, twin_all, base_all):
         """deterministic mode: t (a contiguous slice of base_all) += its fixed-point twin; recorded where the next reader of t follows"""
@@ -1372,7 +745,7 @@ class MadNetEngine(object):
             if do_grad:
                 self.record_forward(r)
                 self.record_loss_metrics(r, with_grad=True)
-                eu = (lr, momentum, grad_scale) if (EARLY_UPDATE and do_upd and part == "all" and optimizer == "momentum") else None
+                eu = (lr, momentum, grad_scale) if (self.sched.EARLY_UPDATE and do_upd and part == "all" and optimizer == "momentum") else None
                 done = self.record_backward(r, "final", tv, bulkhead=False, early_update=eu)
             if do_upd:
                 if done:
@@ -1423,10 +796,3 @@ class MadNetEngine(object):
             self.gt.copy_(torch.as_tensor(gt, dtype=torch.float32).reshape(self.gt.shape))
         if proxy is not None:
             self.proxy.copy_(torch.as_tensor(proxy, dtype=torch.float32).reshape(self.proxy.shape))
-
-
-def ops_fill(lib, t, off, count):
-    """record/launch a zero fill of t.flatten()[off:off+count]."""
-    import ctypes as C
-    flat = t.reshape(-1)
-    lib.fill(C.c_void_p(flat.data_ptr() + 4 * off), count, 0.0, None)

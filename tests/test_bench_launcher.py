@@ -64,10 +64,11 @@ def test_bench_set_overrides_are_applied_and_reported(capsys):
     import bench
     calls = []
     lib = types.SimpleNamespace(tune_conv_rows=lambda v: calls.append(("conv_rows", v)))
-    E = types.SimpleNamespace(FUSE_HEAD=True, EARLY_WGS=192)
+    from madnet_hip import engine as E
     try:
-        per = bench.apply_overrides(["engine.FUSE_HEAD=False", "engine.EARLY_WGS=128", "eng.fuse_front=False", "tune.conv_rows=0"], lib, E)
-        assert per == {"fuse_front": False} and E.FUSE_HEAD is False and E.EARLY_WGS == 128 and calls == [("conv_rows", 0)]
+        per, sched = bench.apply_overrides(["engine.FUSE_HEAD=False", "engine.EARLY_WGS=128", "eng.fuse_front=False", "tune.conv_rows=0"], lib, E)
+        assert per == {"fuse_front": False} and sched == {"FUSE_HEAD": False, "EARLY_WGS": 128} and calls == [("conv_rows", 0)]
+        assert E.Schedule().FUSE_HEAD is True and E.Schedule(**sched).EARLY_WGS == 128            # (the default is untouched: the override lives in the engines built with it)
         bench._emit({"value": 1})
         assert json.loads(capsys.readouterr().out)["overrides"][0] == "engine.FUSE_HEAD=False"
         with pytest.raises(AssertionError):

@@ -142,18 +142,16 @@ def test_dispnet_plane_kernels_vs_igemm_path_emulated(precision):
     wn = S.calibrated_weights(OD.variable_shapes(), 1)
     l, r, gt = S.make_pair(H, W)
     out = {}
-    old = DE.PLANES_MIN_PIX
     try:
         for on in (False, True):
-            DE.PLANES_MIN_PIX = 1 if on else 1 << 30
             backend.lib.tune_conv_planes(0)
-            eng = DE.DispNetEngine(backend.lib, H, W, B=1, device="cpu", weights=wn, precision=precision)
+            eng = DE.DispNetEngine(backend.lib, H, W, B=1, device="cpu", weights=wn, precision=precision, schedule=DE.DispNetSchedule(PLANES_MIN_PIX=(1 if on else 1 << 30)))
             eng.set_inputs(l, r, gt[..., 0])
             plan = eng.build_plan("FULL", lr=1e-4)
             plan.run(backend.lib, 0)
             out[on] = (eng.pred.clone(), eng.params.g.clone(), backend.lib.tune_conv_planes(0), float(eng.res_loss[0]))
     finally:
-        DE.PLANES_MIN_PIX = old
+        pass
     (p0, g0, n0, l0), (p1, g1, n1, l1) = out[False], out[True]
     # conv3/1 .. conv6/1 and iconv5 .. iconv1: forward (9; 'bf16': 7 -- the whole-K instances of iconv2 / iconv1 are split-bf16 only) + input gradients (9)
     assert n0 == 0 and n1 >= (18 if precision == "mixed" else 16), (n0, n1)
@@ -173,7 +171,7 @@ def test_dispnet_plane_kernels_vs_igemm_path_emulated(precision):
 
 @pytest.mark.slow
 def test_dispnet_early_update_equals_one_update_emulated():
-    """dispnet_engine.EARLY_UPDATE: the momentum update issued per filter-gradient batch (side lanes) + the rest behind the join == ONE update over all
+    """DispNetSchedule.EARLY_UPDATE: the momentum update issued per filter-gradient batch (side lanes) + the rest behind the join == ONE update over all
     parameters -- same gradients, same element-wise arithmetic: weights and momentum must agree to the atomics noise of the gradients."""
     from conftest import _emul_backend
     backend = _emul_backend()
@@ -181,18 +179,16 @@ def test_dispnet_early_update_equals_one_update_emulated():
     wn = S.calibrated_weights(OD.variable_shapes(), 1)
     l, r, gt = S.make_pair(H, W)
     res = {}
-    old = DE.EARLY_UPDATE
     try:
         for on in (False, True):
-            DE.EARLY_UPDATE = on
-            eng = DE.DispNetEngine(backend.lib, H, W, B=1, device="cpu", weights=wn, precision="mixed")
+            eng = DE.DispNetEngine(backend.lib, H, W, B=1, device="cpu", weights=wn, precision="mixed", schedule=DE.DispNetSchedule(EARLY_UPDATE=on))
             eng.set_inputs(l, r, gt[..., 0])
             plan = eng.build_plan("FULL", lr=1e-3, momentum=0.8)
             n_mom = sum(1 for i in range(plan.n) if plan.arr[i].kind == _ffi_kind("OP_MOMENTUM"))
             plan.run(backend.lib, 0)
             res[on] = (eng.params.w.clone(), eng.params.m.clone(), n_mom)
     finally:
-        DE.EARLY_UPDATE = old
+        pass
     assert res[False][2] == 1 and res[True][2] > 3, (res[False][2], res[True][2])
     # (identical up to the atomics noise of the bias gradients, ~4e-9 between two runs of the SAME plan)
     assert (res[False][0] - res[True][0]).abs().max().item() <= 1e-9 and (res[False][1] - res[True][1]).abs().max().item() <= 1e-7

@@ -556,15 +556,11 @@ def test_plan_scheduling_switches_do_not_change_results_emulated(monkeypatch):
     l, r, gt = S.make_pair(H, W)
 
     def run(**kw):
-        for k, v in kw.items():
-            if k != "lanes":
-                monkeypatch.setattr(E, k, v)
-        eng = E.MadNetEngine(backend.lib, H, W, B=1, device="cpu", weights=wn, precision="mixed")
+        eng = E.MadNetEngine(backend.lib, H, W, B=1, device="cpu", weights=wn, precision="mixed", schedule=E.Schedule(**{k: v for k, v in kw.items() if k != "lanes"}))
         if "lanes" in kw:
             eng.wgrad_lanes = kw["lanes"]
         eng.set_inputs(l, r, gt[..., 0])
         eng.build_plan("FULL", lr=1e-4).run(backend.lib, 0)
-        monkeypatch.undo()
         return eng.pred.clone(), float(eng.res_loss[0].item()), eng.params.w.clone()
 
     p0, l0, w0 = run()
@@ -700,18 +696,16 @@ def test_step_with_fused_head_backward_emulated():
     wn = S.calibrated_weights(OM.variable_shapes(), 1)
     l, r, gt = S.make_pair(H, W)
     out = {}
-    saved = E.FUSE_HEAD
     try:
         for fused in (True, False):
-            E.FUSE_HEAD = fused
-            eng = E.MadNetEngine(backend.lib, H, W, B=1, device="cpu", weights=wn, precision="fp32")
+            eng = E.MadNetEngine(backend.lib, H, W, B=1, device="cpu", weights=wn, precision="fp32", schedule=E.Schedule(FUSE_HEAD=fused))
             eng.set_inputs(l, r, gt[..., 0])
             plan = eng.build_plan("FULL", lr=1e-4, update=False)
             n_head = sum(1 for k in range(plan.n) if plan.arr[k].kind == _ffi_mod().OP_HEAD_BWD)
             plan.run(backend.lib, 0)
             out[fused] = (eng.params.g.clone(), n_head, plan.n)
     finally:
-        E.FUSE_HEAD = saved
+        pass
     (g1, n1, ops1), (g0, n0, ops0) = out[True], out[False]
     # backward: 2 copies + 4 resize gradients + 5 head input gradients -> 5 launches; forward: the level-2 head stores its result in the context
     # input and in `final` itself (mh_conv2d_head): 2 copies less
@@ -817,14 +811,13 @@ def test_step_with_bf16_only_gradient_maps(bname, size):
     H, W = size
     wn = S.calibrated_weights(OM.variable_shapes(), 1)
     l, r, gt = S.make_pair(H, W)
-    saved = E.SHADOW_ONLY, E.PLANES_ONLY
     if bname == "emul":
         backend.lib.tune_conv_patch(128)            # at 60x100 the heuristic would keep the patch kernel out
     out = {}
     try:
         for only in (True, False):
-            E.SHADOW_ONLY = E.PLANES_ONLY = only          # (PLANES_ONLY: the same elision for the layers on the plane kernels)
-            eng = E.MadNetEngine(backend.lib, H, W, B=1, device=backend.device, weights=wn, precision="mixed")
+            # (PLANES_ONLY: the same elision for the layers on the plane kernels)
+            eng = E.MadNetEngine(backend.lib, H, W, B=1, device=backend.device, weights=wn, precision="mixed", schedule=E.Schedule(SHADOW_ONLY=only, PLANES_ONLY=only))
             eng.set_inputs(l, r, gt[..., 0])
             plan = eng.build_plan("FULL", lr=1e-4, update=False)
             # (input gradients on mh_conv2d_planes_bwd, round 4: p = dz_hi, bank, mask_hi, dx, dx_hi -- fp32 elided = no dx, mask = a shadow's sign)
@@ -841,7 +834,6 @@ def test_step_with_bf16_only_gradient_maps(bname, size):
             backend.sync()
             out[only] = (eng.params.g.clone(), n_only, n_mask)
     finally:
-        E.SHADOW_ONLY, E.PLANES_ONLY = saved
         if bname == "emul":
             backend.lib.tune_conv_patch(-1)
     (g1, n1, m1), (g0, n0, m0) = out[True], out[False]
@@ -859,12 +851,10 @@ def test_deterministic_mode_replays_bit_identical(bname, size):
     H, W = size
     wn = S.calibrated_weights(OM.variable_shapes(), 1)
     l, r, gt = S.make_pair(H, W)
-    saved = E.DETERMINISTIC
     res = []
     try:
         for det in (True, True, False):
-            E.DETERMINISTIC = det
-            eng = E.MadNetEngine(backend.lib, H, W, B=1, device=backend.device, weights=wn, precision="mixed")
+            eng = E.MadNetEngine(backend.lib, H, W, B=1, device=backend.device, weights=wn, precision="mixed", schedule=E.Schedule(DETERMINISTIC=det))
             assert backend.lib.deterministic_ranges() == (2 if det else 0)
             eng.set_inputs(l, r, gt[..., 0])
             plan = eng.build_plan("FULL", lr=1e-3)
@@ -878,7 +868,7 @@ def test_deterministic_mode_replays_bit_identical(bname, size):
             eng.close()
             assert backend.lib.deterministic_ranges() == 0
     finally:
-        E.DETERMINISTIC = saved
+        pass
     (w0, m0, p0, f0), (w1, m1, p1, f1), (w2, m2, p2, f2) = res
     assert torch.equal(w0, w1) and torch.equal(m0, m1) and torch.equal(p0, p1)
     # against the default mode after ONE step (later steps amplify the atomics noise of the default mode through the adapted weights)
@@ -903,9 +893,7 @@ def test_mixed_forward_from_planes_matches_fp32_operand_path(bname, mode):
         for planes in (True, False, "unfused"):
             if planes == "unfused" and mode != "FULL":
                 continue
-            E.USE_PLANES = bool(planes)
-            E.FUSE_SPLITS = planes != "unfused"
-            eng = E.MadNetEngine(lib, 60, 100, B=1, device=dev, weights=wn, precision="mixed")
+            eng = E.MadNetEngine(lib, 60, 100, B=1, device=dev, weights=wn, precision="mixed", schedule=E.Schedule(USE_PLANES=bool(planes), FUSE_SPLITS=(planes != "unfused")))
             eng.bank_small_maxpix = 128
             eng.set_inputs(l, r, gt[..., 0])
             if mode == "FULL":
@@ -928,8 +916,6 @@ def test_mixed_forward_from_planes_matches_fp32_operand_path(bname, mode):
                                nplanes=nplanes, nrec=kinds.count(_ffi.OP_CONV_PLANES), elided=elided, splits=kinds.count(_ffi.OP_PLANE_SPLIT),
                                nbwd=kinds.count(_ffi.OP_CONV_PLANES_BWD), bwd_elided=sum(1 for o in pops if o.kind == _ffi.OP_CONV_PLANES_BWD and not o.p[3]))
     finally:
-        E.USE_PLANES = True
-        E.FUSE_SPLITS = True
         lib.tune_conv_bank(-1); lib.tune_conv_patch(-1)
     a, b = res[True], res[False]
     if "unfused" in res:        # split launches in front of every consumer instead: the same planes, bit for bit the same step

@@ -1,6 +1,6 @@
 """Two changes to the TAIL of the MADNet step that were written after round 3's GPU budget was spent (profiles/r03_experiments.txt #25, #26), both default OFF:
 the image layer's filter gradient on its own kernel (wgrad_image_kernel, csrc/wgrad.hip; mh_tune_wgrad_image) and the momentum update per filter-gradient
-batch on the batch's lane (engine.EARLY_UPDATE).
+batch on the batch's lane (Schedule.EARLY_UPDATE).
 
 They are parity-checked on the CPU emulator only, the product does not use them, and their MI355X tests live in THIS file -- the last one pytest
 collects -- so that they run after every test of the validated path.  Next round's first GPU call (scripts/gpu_next_first.sh) times them in the step
@@ -134,17 +134,15 @@ def test_step_with_image_layer_filter_gradient_kernel_gpu():
 
 
 def _early_update_ab(backend, H, W, precision):
-    """FULL momentum step with the per-batch updates (engine.EARLY_UPDATE) against the single update behind the join: the same elementwise update of the
+    """FULL momentum step with the per-batch updates (Schedule.EARLY_UPDATE) against the single update behind the join: the same elementwise update of the
     same gradients; every parameter updated exactly once; only the last batch's layers + whatever has no filter gradient are left for the final launch."""
     F = _ffi_mod()
     wn = S.calibrated_weights(OM.variable_shapes(), 1)
     l, r, gt = S.make_pair(H, W)
     res = {}
-    saved = E.EARLY_UPDATE
     try:
         for early in (True, False):
-            E.EARLY_UPDATE = early
-            eng = E.MadNetEngine(backend.lib, H, W, B=1, device=backend.device, weights=wn, precision=precision)
+            eng = E.MadNetEngine(backend.lib, H, W, B=1, device=backend.device, weights=wn, precision=precision, schedule=E.Schedule(EARLY_UPDATE=early))
             eng.set_inputs(l, r, gt[..., 0])
             plan = eng.build_plan("FULL", lr=1e-3)
             P = eng.params
@@ -160,7 +158,7 @@ def _early_update_ab(backend, H, W, precision):
                 snaps.append((P.w.clone().cpu(), P.m.clone().cpu(), eng.pred.clone().cpu()))
             res[early] = snaps
     finally:
-        E.EARLY_UPDATE = saved
+        pass
     # two runs of the SAME plan differ by ~1e-8 in a few gradient elements (fp32 atomics), amplified by the bf16 roundings of the second step
     for step, tols in ((0, (1e-9, 1e-7, 1e-5)), (1, (1e-6, 4e-4, 1e-3))):
         for a, b, tol in zip(res[True][step], res[False][step], tols):
