@@ -400,6 +400,23 @@ def op_work(op):
         f32 = 4.0 if op.p[4 if fwd else 3] else 0.0
         mask = 2.0 * cout if (not fwd and op.p[2]) else 0.0      # the input gradient reads the activation's hi plane once for the sign test
         return 2.0 * B * H * W * 9 * K * N, B * H * W * (cin * 2.0 * pl + cout * (2.0 * pl + f32) + mask) + 9 * K * N * 2.0 * pl
+    # correlation family: HBM-bound, bytes = every operand once (forward B H W (2C + D) 4, gradient B H W (4C + D) 4; the fused forms add what they fuse)
+    if op.kind == _ffi.OP_CORR_FWD:
+        B, H, W, Cc, md, st = op.i[4], op.i[5], op.i[6], op.i[7], op.i[8], op.i[9]
+        D = 2 * md // max(st, 1) + 1
+        return 2.0 * B * H * W * Cc * D, 4.0 * B * H * W * (2 * Cc + D + (Cc if op.i[10] else 0))
+    if op.kind == _ffi.OP_CORR_BWD:
+        B, H, W, Cc, md, st = op.i[9], op.i[10], op.i[11], op.i[12], op.i[13], op.i[14]
+        D = 2 * md // max(st, 1) + 1
+        return 4.0 * B * H * W * Cc * D, 4.0 * B * H * W * (4 * Cc + D + (Cc if op.i[15] else 0))
+    if op.kind == _ffi.OP_CORR_WARP_BWD:
+        B, H, W, Cc, md, st = op.i[8], op.i[9], op.i[10], op.i[11], op.i[12], op.i[13]
+        D = 2 * md // max(st, 1) + 1
+        return 4.0 * B * H * W * Cc * D, 4.0 * B * H * W * (8 * Cc + D + 3)        # reads g (C + D + 1), L, Rw, the right features, u, dL, dimg; writes dL, dimg, du
+    if op.kind == _ffi.OP_LEVEL_FRONT:
+        B, H, W, Cc, md = op.i[7], op.i[8], op.i[9], op.i[10], op.i[11]
+        D = 2 * md + 1
+        return 2.0 * B * H * W * Cc * D, 4.0 * B * H * W * (2 * Cc + (Cc + D + 1) + Cc + 1)        # reads L, R; writes [L | corr | u], the warped features, u
     if op.kind not in (_ffi.OP_CONV, _ffi.OP_WGRAD, _ffi.OP_WGRAD_PARTIAL):
         return 0.0, 0.0
     i = op.i

@@ -68,9 +68,11 @@ for d in ("FETCH_SIZE", "WRITE_SIZE", "SQ"):
     for g, op in zip(groups, G):
         if op.get("dup"):
             continue
-        e = per.setdefault(op["kernel"], {"plan": op["plan"], "plan_op_index": op["index"], "algorithmic_flops": op["flops"], "algorithmic_bytes": op["bytes"], "kernels_per_launch": len(g)})
+        key = op["kernel"] if not op.get("fixed") else "%s [%s]" % (op["kernel"], op["fixed"])       # (a fixed entry never shares its counters with a plan op of the same kernel string)
+        e = per.setdefault(key, {"plan": op["plan"], "plan_op_index": op["index"], "algorithmic_flops": op["flops"], "algorithmic_bytes": op["bytes"], "kernels_per_launch": len(g)})
         if op.get("fixed"):
             e["fixed_roofline_entry"] = op["fixed"]
+            meta["fixed"][op["fixed"]] = key
         for c in g[0]["c"]:
             e[c] = sum(x["c"].get(c, 0.0) for x in g)
         if g[0]["us"] is not None:
