@@ -716,14 +716,14 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_row_kernel(CorrWarpBwdArgs
 //     bucketed by the source column they land on: two INTEGER LDS atomics per pixel (the float scatter needed 2 C per pixel) count the column's taps and
 //     hand out a slot of its 8-entry list; only when some column overflows its list (a compressed stretch of the warp) the taps are bucketed again by a
 //     counting sort without capacity (one wave scans the W counters, two more atomics per pixel place the keys).  Every (source column, channel group)
-//     item then GATHERS its taps: typically two, one 16-byte read and four FMAs each.  Segments of up to 64 taps are summed in ascending
+//     item then GATHERS its taps: typically two, one 16-byte read and four FMAs each.  Segments of up to 16 taps are summed in ascending
 //     key order whatever order they were placed in (sorting network up to 8, selection beyond): bit-identical from run to run -- no float atomics, no
-//     fixed-point twin, the same kernel serves the deterministic mode; only a fold of more than 64 taps onto one column is summed in arrival order.
+//     fixed-point twin, the same kernel serves the deterministic mode; only a fold of more than 16 taps onto one column is summed in arrival order.
 // A thread owns at most NI = 3 (pixel, channel group) items: LPP >= C / 4 lanes per pixel.
 template <int LPP, int DT>
 __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdArgs p) {
     HIP_DYNAMIC_SHARED(float, smem)
-    constexpr int NT = 1024, PPB = NT / LPP, NI = 3, GS = 8, KL = 8, KSEL = 64;
+    constexpr int NT = 1024, PPB = NT / LPP, NI = 3, GS = 8, KL = 8, KSEL = 16;
     static_assert(DT + 1 <= GS, "g staging holds D + 1 channels");
     const int C4 = p.C >> 2, WC = p.W * p.C;
     float* const sL = smem;                     // [W][C]
