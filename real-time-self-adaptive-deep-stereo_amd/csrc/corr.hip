@@ -1231,12 +1231,10 @@ __global__ __launch_bounds__(CS16 >= 2 ? 512 : 256) void corr_bwd_mfma(CorrBwdAr
 // as whole 4 C-byte pixel rows (16-byte stores), not as 64-byte column fragments.  Workgroup ids are remapped so that the segments of an image row run on
 // ONE XCD: the 2.25x window overlap between neighbouring segments is served by that XCD's L2 instead of being fetched once per XCD.
 template <int CS16, bool RIGHT>
-__global__ __launch_bounds__(256) void corr_bwd_mfma_bf16(CorrBwdArgs p, int segs, int remap) {
-    HIP_DYNAMIC_SHARED(float, smem)
+__device__ __forceinline__ void corr_bwd_mfma_bf16_body(const CorrBwdArgs& p, int segs, int bid, float* smem) {
     constexpr int C = CS16 * 16, RS = C + 16;              // halfs per window row (8 dwords of padding: the 4 rows of a transposing read hit distinct banks)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
-    const int bid = remap ? mh_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     const int seg = bid % segs;
     const int row = bid / segs;
     const int x0 = seg * 64;
@@ -1372,6 +1370,24 @@ __global__ __launch_bounds__(256) void corr_bwd_mfma_bf16(CorrBwdArgs p, int seg
     }
 }
 
+// BOTH directions in ONE grid: workgroup 2 s computes the left gradient of segment s, workgroup 2 s + 1 the right gradient of the same segment.  With the
+// XCD-aware order the pair runs on one XCD at about the same time, so the g rows the two share (the left one's 64 are a subset of the right one's window)
+// come from HBM once and from that L2 the second time (two launches read g twice: 14 % of the gradient's traffic), and the step has one launch less.
+template <int CS16>
+__global__ __launch_bounds__(256) void corr_bwd_mfma_bf16_pair(CorrBwdArgs p, int segs, int remap) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    const int lin = remap ? mh_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    if (lin & 1) corr_bwd_mfma_bf16_body<CS16, true>(p, segs, lin >> 1, smem);
+    else corr_bwd_mfma_bf16_body<CS16, false>(p, segs, lin >> 1, smem);
+}
+
+// (one direction per launch: the A/B partner behind mh_tune_corr bit 2)
+template <int CS16, bool RIGHT>
+__global__ __launch_bounds__(256) void corr_bwd_mfma_bf16_one(CorrBwdArgs p, int segs, int remap) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    corr_bwd_mfma_bf16_body<CS16, RIGHT>(p, segs, remap ? mh_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x, smem);
+}
+
 }  // namespace
 
 int mh_corr_init() {
@@ -1396,9 +1412,11 @@ int mh_corr_init() {
     MH_CORRB_ATTR(1, true) MH_CORRB_ATTR(2, true) MH_CORRB_ATTR(4, true) MH_CORRB_ATTR(8, true) MH_CORRB_ATTR(16, true)
 #undef MH_CORRB_ATTR
 #define MH_CORRBH_ATTR(CSv)                                                                                                    \
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_bwd_mfma_bf16<CSv, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_bwd_mfma_bf16_pair<CSv>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
     if (e != hipSuccess) { mh_set_error("corr: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }                 \
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_bwd_mfma_bf16<CSv, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_bwd_mfma_bf16_one<CSv, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+    if (e != hipSuccess) { mh_set_error("corr: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }                 \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_bwd_mfma_bf16_one<CSv, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
     if (e != hipSuccess) { mh_set_error("corr: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     MH_CORRBH_ATTR(2) MH_CORRBH_ATTR(4) MH_CORRBH_ATTR(8) MH_CORRBH_ATTR(16)
 #undef MH_CORRBH_ATTR
@@ -1418,11 +1436,12 @@ int mh_corr_init() {
 static std::atomic<int> g_corr_direct{1};
 // mh_tune_corr_row: 1 (default) = row-owned backward front end with the row's operands staged in LDS, 3 = row-owned, operands from L1 / L2, 0 = the global-atomic form
 static std::atomic<int> g_corr_row{1};
+static std::atomic<int> g_corr_pair{1};              // large-D bf16 gradient: both directions in one grid (mh_tune_corr bit 2 clears it: two launches)
 static std::atomic<int> g_corr_remap{1};             // XCD-aware workgroup order of the large-D bf16 kernels (mh_tune_corr bit 1 clears it)
 static std::atomic<int> g_corr_det_ranges{0};        // how many deterministic ranges are registered (mh_det_sync_corr keeps it in step)
 extern "C" int mh_tune_corr_row(int on) { g_corr_row = on; return 0; }
 // tuning hook: 0 = LDS-staged window kernel, 1 = direct (no LDS) kernel for D <= 9
-extern "C" int mh_tune_corr(int direct) { g_corr_direct = direct & 1; g_corr_remap = (direct & 2) ? 0 : 1; return 0; }
+extern "C" int mh_tune_corr(int direct) { g_corr_direct = direct & 1; g_corr_remap = (direct & 2) ? 0 : 1; g_corr_pair = (direct & 4) ? 0 : 1; return 0; }
 
 extern "C" int mh_corr_fwd(const float* L, int32_t l_ld, const float* R, int32_t r_ld, const float* u,
                            float* out, int32_t out_ld, int32_t coff,
@@ -1643,15 +1662,15 @@ extern "C" int mh_corr_bwd_prec(const float* g, int32_t g_ld, int32_t coff, cons
         // bf16 operands on v_mfma_f32_16x16x32_bf16 (the arithmetic of the other gradients in the 'mixed' / 'bf16' modes)
         const int nks = (2 * max_disp + 16 + 31) / 32, rows = 48 + 32 * nks, DPh = (((a.D + 3) & ~3) + 7) & ~7;
         const size_t tile = (size_t)64 * (C + 4) * 4;
-        const size_t lds_l = std::max(tile, ((size_t)rows * (C + 16) + (size_t)64 * DPh) * 2), lds_r = std::max(tile, ((size_t)rows * (C + 16) + (size_t)rows * DPh) * 2);
+        const size_t lds_r = std::max(tile, ((size_t)rows * (C + 16) + (size_t)rows * DPh) * 2);       // (the right-gradient workgroups need more: g rows of the whole window)
         if (lds_r <= 150 * 1024) {
             const int segs = mh_cdiv(W, 64);
             const dim3 grid(segs * B * H);
             hipStream_t s = (hipStream_t)stream;
             const int remap = g_corr_remap.load();
-#define MH_CORRBH(CSv)                                                                                          \
-            hipLaunchKernelGGL((corr_bwd_mfma_bf16<CSv, false>), grid, dim3(256), lds_l, s, a, segs, remap);    \
-            hipLaunchKernelGGL((corr_bwd_mfma_bf16<CSv, true>), grid, dim3(256), lds_r, s, a, segs, remap);
+#define MH_CORRBH(CSv) { if (g_corr_pair.load()) hipLaunchKernelGGL((corr_bwd_mfma_bf16_pair<CSv>), dim3(2 * segs * B * H), dim3(256), lds_r, s, a, segs, remap);  \
+                         else { hipLaunchKernelGGL((corr_bwd_mfma_bf16_one<CSv, false>), dim3(segs * B * H), dim3(256), lds_r, s, a, segs, remap);                   \
+                                hipLaunchKernelGGL((corr_bwd_mfma_bf16_one<CSv, true>), dim3(segs * B * H), dim3(256), lds_r, s, a, segs, remap); } }
             switch (C) {
                 case 32: MH_CORRBH(2) break;
                 case 64: MH_CORRBH(4) break;
@@ -1659,7 +1678,7 @@ extern "C" int mh_corr_bwd_prec(const float* g, int32_t g_ld, int32_t coff, cons
                 default: MH_CORRBH(16) break;
             }
 #undef MH_CORRBH
-            mh_note_kernel("corr_bwd_mfma_bf16<C/16=%d> left + right, grid %d x 4 waves lds %d / %d", C / 16, segs * B * H, (int)lds_l, (int)lds_r);
+            mh_note_kernel("corr_bwd_mfma_bf16_pair<C/16=%d> left + right in %s of %d x 4 waves, lds %d", C / 16, g_corr_pair.load() ? "one grid" : "two grids", (g_corr_pair.load() ? 2 : 1) * segs * B * H, (int)lds_r);
             return mh_check_launch("corr_bwd_mfma_bf16");
         }
     }

@@ -79,12 +79,12 @@ if "--no-d81" not in sys.argv:
         dL = torch.empty_like(L); dR = torch.empty_like(R)
         bf, bb = float(B) * H * W * (2 * C + D) * 4, float(B) * H * W * (4 * C + D) * 4
         n = 3 if B == 16 else 20
-        for tune, tag in ((1, "xcd order"), (3, "plain order")):
+        for tune, tag in ((1, "xcd order"), (5, "xcd, 2 grids"), (3, "plain order")):
             lib.tune_corr(tune)
             us, k = graph_us(lambda r: ops.corr_fwd(r, ops.view(L), ops.view(R), ops.view(vol), md, precision=1), n=n, reps=5)
-            print("B=%-2d fwd bf16  %-11s %8.1f us  %7.0f GB/s (%4.1f %%)   %s" % (B, tag, us, bf / us / 1e3, bf / us / 1e3 / 80, k))
+            print("B=%-2d fwd bf16  %-12s %8.1f us  %7.0f GB/s (%4.1f %%)   %s" % (B, tag, us, bf / us / 1e3, bf / us / 1e3 / 80, k))
             us, k = graph_us(lambda r: ops.corr_bwd(r, gv, ops.view(L), ops.view(R), ops.view(dL), ops.view(dR), md, 1, coff=0, precision=1), n=n, reps=5)
-            print("B=%-2d bwd bf16  %-11s %8.1f us  %7.0f GB/s (%4.1f %%)   %s" % (B, tag, us, bb / us / 1e3, bb / us / 1e3 / 80, k))
+            print("B=%-2d bwd bf16  %-12s %8.1f us  %7.0f GB/s (%4.1f %%)   %s" % (B, tag, us, bb / us / 1e3, bb / us / 1e3 / 80, k))
         lib.tune_corr(1)
         us, k = graph_us(lambda r: ops.corr_bwd(r, gv, ops.view(L), ops.view(R), ops.view(dL), ops.view(dR), md, 1, coff=0, precision=0), n=n, reps=3)
         print("B=%-2d bwd fp32               %8.1f us  %7.0f GB/s (%4.1f %%)   %s" % (B, us, bb / us / 1e3, bb / us / 1e3 / 80, k))

@@ -560,7 +560,7 @@ def test_corr_bwd_large_d_bf16(backend, case):
     ops.corr_bwd(backend.lib, gv, ops.view(L), ops.view(R), ops.view(dL), ops.view(dR), md, 1, coff=0, acc_l=True, acc_r=False, precision=1)
     k = backend.lib.last_kernel().decode()
     backend.sync()
-    assert "corr_bwd_mfma_bf16" in k, k
+    assert "corr_bwd_mfma_bf16_pair" in k, k
     sc = max(1.0, Lr.grad.abs().max().item())
     assert (dL.cpu() - 0.5 - Lr.grad.float()).abs().max().item() <= 2e-6 * sc
     assert (dR.cpu() - Rr.grad.float()).abs().max().item() <= 2e-6 * sc
