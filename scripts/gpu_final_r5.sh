@@ -33,5 +33,6 @@ timeout 300 python scripts/plan_table.py --model dispnet > $OUT/plan_table_dispn
 timeout 300 python scripts/exp/mb_corr_r05.py > $OUT/microbench_corr.txt 2>&1
 timeout 200 python scripts/exp/planes_phases_step.py > $OUT/planes_phases_step.txt 2>&1
 python scripts/kernel_resources.py > $OUT/kernel_resources.txt 2>/dev/null
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; tail -3 $OUT/smoke.txt
 for f in $OUT/bench_*.json; do echo "$f: $(cut -c1-200 $f)"; done
 tail -3 $OUT/graph_timeline_default.txt; head -3 $OUT/plan_table_madnet.txt; tail -5 $OUT/pmc.log; du -sh $OUT
