@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 13
+#define MH_ABI_VERSION 14
 
 /* status codes of every int-returning entry point: 0 = launched; a NEGATIVE code means an argument check failed and
  * nothing was launched or written; a POSITIVE value is the hipError_t of a failed launch / runtime call.
@@ -264,6 +264,17 @@ int mh_level_front_fwd_planes(const float* Vc, int32_t Hc, int32_t Wc, float mul
                               float* out, int32_t out_ld, int32_t coff, float* Rw, int32_t rw_ld, float* u,
                               int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t zero_tail,
                               void* out_hi, void* out_lo, int32_t out_pld, void* stream);
+/* mh_level_front_fwd_planes that ALSO runs the disparity head of the COARSER level (MadNet.py:118, the last layer of _stereo_estimator: 3x3, K -> 1 channels,
+ * no activation) instead of reading its result: Vc[b][y][x] = sum_{tap,k} X[b][y + ky - 1][x + kx - 1][k] * hw[tap][k] + hb[0] (zero padding, fp32, the
+ * arithmetic of mh_conv2d_fwd's single-output-channel kernel) is an OUTPUT here -- every element of Vc[B,Hc,Wc] is stored -- and u is interpolated from the
+ * values as computed.  One launch less on the forward chain per level.  X: [B,Hc,Wc,x_ld] activations of the estimator's fifth layer; hw: the head's HWIO
+ * bank [3][3][K][1] (16-byte aligned); hb: its bias or NULL.  Served shapes: mh_level_front_head_ok (K % 4 == 0, K <= 32, D <= 9) -- MH_ERR_UNSUPPORTED otherwise. */
+int mh_level_front_head_fwd(const float* X, int32_t x_ld, int32_t K, const float* hw, const float* hb, float* Vc, int32_t Hc, int32_t Wc, float mul,
+                            const float* L, int32_t l_ld, const float* R, int32_t r_ld, float* out, int32_t out_ld, int32_t coff, float* Rw, int32_t rw_ld,
+                            float* u, int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t zero_tail,
+                            void* out_hi, void* out_lo, int32_t out_pld, void* stream);
+/* 1 when mh_level_front_head_fwd serves the shape, 0 when the head has to stay a launch of its own (no status, no error message) */
+int mh_level_front_head_ok(int32_t Hc, int32_t Wc, int32_t H, int32_t W, int32_t C, int32_t K, int32_t max_disp);
 /* g: gradient w.r.t. the buffer written by mh_corr_fwd (same ld / coff).
  * dL[p][c] (+)= [copy_left] g[p][c] + (1/C) sum_j g[p][coff+j] R[p+i_j][c]
  * dR[p][c] (+)=                      (1/C) sum_j g[p-i_j][coff+j] L[p-i_j][c]
@@ -504,7 +515,7 @@ typedef struct mh_op {
     int32_t kind;
     int32_t i[27];
     float f[4];
-    void* p[8];
+    void* p[12];
     int64_t n;
 } mh_op;
 int mh_plan_run(const mh_op* ops, int32_t nops, void* stream);

@@ -174,11 +174,20 @@ struct FrontArgs {
     int B, H, W, C, md, D, zero_tail;
     unsigned l_bytes, r_bytes;
     unsigned short* out_hi; unsigned short* out_lo; int out_pld;      // != null: the estimator input also leaves as bf16 planes (hi [+ lo])
+    // HEAD instances (mh_level_front_head_fwd): Vc is an OUTPUT -- the coarser level's disparity head (3x3, K -> 1, linear) runs in this launch
+    const float* X; const float* hw; const float* hb; float* Vw; int x_ld, K, segs, cwcap; unsigned x_bytes;
 };
 
-template <int LPP, int DT>
+// HEAD (round 5, mh_level_front_head_fwd): the disparity head of the COARSER level -- Vc = conv3x3(X, hw) + hb, 32 -> 1 channels, linear (MadNet.py:118) -- is
+// computed here instead of by a launch of its own in front of this one (a 4.5 - 5 us node of the forward chain per level for 0.1 - 2 MFLOP).  A workgroup
+// owns PPB pixels of ONE row: they read two coarse rows x <= cwcap columns of Vc; the workgroup stages the 4 x (cw + 2) x K patch of X those need, computes
+// the <= 2 * cwcap head values with conv_n1_fwd_kernel's arithmetic (8 lanes per value, same tap order, same butterfly), keeps them in LDS for its own
+// interpolation and stores them to Vc: every coarse pixel is read by some fine pixel, so the union of the stores is the whole map (neighbouring workgroups
+// write identical values to the columns they share).
+template <int LPP, int DT, bool HEAD>
 __global__ __launch_bounds__(256) void level_front_kernel(FrontArgs p) {
     constexpr int PPB = 256 / LPP;
+    HIP_DYNAMIC_SHARED(float, fsm)                // HEAD: Xs [4][cwcap + 2][K] | Ws [9][K] | Vs [2][cwcap]
     const int tid = threadIdx.x;
     const int sub = tid % LPP;
     const int C4 = p.C >> 2;
@@ -186,9 +195,18 @@ __global__ __launch_bounds__(256) void level_front_kernel(FrontArgs p) {
     const int npix = p.B * p.H * p.W;
     const __amdgpu_buffer_rsrc_t rsL = mh_make_rsrc(p.L, p.l_bytes);
     const __amdgpu_buffer_rsrc_t rsR = mh_make_rsrc(p.R, p.r_bytes);
-    const int pix = blockIdx.x * PPB + tid / LPP;
-    const bool live = pix < npix;
-    const int pp = live ? pix : 0;
+    int pix;
+    bool live;
+    if constexpr (HEAD) {
+        const int seg = blockIdx.x % p.segs, rowi = blockIdx.x / p.segs;
+        const int xx = seg * PPB + tid / LPP;
+        live = xx < p.W;
+        pix = rowi * p.W + (live ? xx : 0);
+    } else {
+        pix = blockIdx.x * PPB + tid / LPP;
+        live = pix < npix;
+    }
+    const int pp = (HEAD || live) ? pix : 0;      // (HEAD: a lane without a pixel still belongs to its workgroup's row -- it stages that row's patch)
     const int x = pp % p.W;
     const int t2 = pp / p.W;
     const int y = t2 % p.H, b = t2 / p.H;
@@ -199,6 +217,71 @@ __global__ __launch_bounds__(256) void level_front_kernel(FrontArgs p) {
     const float ty = srcy - (float)y0;
     const float* V0 = p.Vc + ((int64_t)b * p.Hc + y0) * p.Wc;
     const float* V1 = p.Vc + ((int64_t)b * p.Hc + y1) * p.Wc;
+    int c_lo = 0;
+    if constexpr (HEAD) {
+        // (y, b and hence y0 / y1 are workgroup-uniform: one row per workgroup)
+        const int G4 = p.K >> 2;
+        const int xs0 = (blockIdx.x % p.segs) * PPB;
+        const int flo = max(xs0 - p.md, 0), fhi = min(xs0 + PPB - 1 + p.md, p.W - 1);
+        c_lo = (int)((float)flo * p.sx);
+        const int c_hi = min((int)((float)fhi * p.sx) + 1, p.Wc - 1);
+        const int cw = c_hi - c_lo + 1;                     // <= cwcap (the launcher's bound)
+        const int pw = cw + 2;
+        float* const Xs = fsm;
+        float* const Ws = fsm + 4 * (p.cwcap + 2) * p.K;
+        float* const Vs = Ws + 9 * p.K;
+        const __amdgpu_buffer_rsrc_t rsX = mh_make_rsrc(p.X, p.x_bytes);
+        // patch rows y0 - 1 .. y0 + 2, columns c_lo - 1 .. c_hi + 1; all loads in flight before the first LDS store (the launcher guarantees items <= 6 * 256)
+        constexpr int U = 6;
+        const int items = 4 * pw * G4;
+        float4 xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = tid + u * 256;
+            const int g = q % G4, t3 = q / G4;
+            const int pc = t3 % pw, pr = t3 / pw;
+            const int yc = y0 - 1 + pr, xc = c_lo - 1 + pc;
+            const bool ok = q < items && (unsigned)yc < (unsigned)p.Hc && (unsigned)xc < (unsigned)p.Wc;
+            xv[u] = mh_buf_load4(rsX, ok ? (((b * p.Hc + yc) * p.Wc + xc) * p.x_ld + g * 4) * 4 : MH_OOB);
+        }
+        float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < 9 * G4) wv = reinterpret_cast<const float4*>(p.hw)[tid];
+        const float hbias = p.hb ? p.hb[0] : 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = tid + u * 256;
+            if (q < items) *reinterpret_cast<float4*>(Xs + q * 4) = xv[u];          // [pr][pc][g] with pw columns: q = (pr * pw + pc) * G4 + g
+        }
+        if (tid < 9 * G4) *reinterpret_cast<float4*>(Ws + tid * 4) = wv;
+        __syncthreads();
+        const int dy1 = y1 - y0;                            // 0 on the last coarse row
+        const int nv = 2 * cw;
+        const int hs = tid & 7;                              // 8 lanes per head value (conv_n1_fwd_kernel<8>: one channel group per lane)
+        for (int v0 = 0; v0 < nv; v0 += 32) {                // (uniform trip count: the butterfly below needs every lane)
+            const int v = v0 + (tid >> 3);
+            const bool vl = v < nv;
+            const int r = vl ? v / cw : 0, c = vl ? v - r * cw : 0;
+            const int dy = r ? dy1 : 0;
+            float acc = 0.f;
+            if (hs < G4) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int ky = t / 3, kx = t - ky * 3;
+                    const float4 xq = *reinterpret_cast<const float4*>(Xs + (((dy + ky) * pw + c + kx) * G4 + hs) * 4);
+                    const float4 w = *reinterpret_cast<const float4*>(Ws + t * p.K + hs * 4);      // (the bank in registers -- 9 loads per lane -- measured SLOWER: #11)
+                    acc += (xq.x * w.x + xq.y * w.y) + (xq.z * w.z + xq.w * w.w);
+                }
+            }
+#pragma unroll
+            for (int o = 4; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            if (vl && hs == 0) {
+                const float val = acc + hbias;
+                Vs[r * p.cwcap + c] = val;
+                p.Vw[((int64_t)b * p.Hc + y0 + dy) * p.Wc + c_lo + c] = val;
+            }
+        }
+        __syncthreads();
+    }
     float w0[DT], w1[DT], uc = 0.f;
     int o0[DT], o1[DT];
 #pragma unroll
@@ -212,7 +295,12 @@ __global__ __launch_bounds__(256) void level_front_kernel(FrontArgs p) {
         const float srcx = (float)xq * p.sx;
         const int x0 = (int)srcx, x1 = min(x0 + 1, p.Wc - 1);
         const float tx = srcx - (float)x0;
-        const float tl = V0[x0], tr = V0[x1], bl = V1[x0], br = V1[x1];
+        float tl, tr, bl, br;
+        if constexpr (HEAD) {
+            const float* const Vs = fsm + 4 * (p.cwcap + 2) * p.K + 9 * p.K;      // this workgroup's two coarse rows, columns from c_lo
+            const int i0 = in ? x0 - c_lo : 0, i1 = in ? x1 - c_lo : 0;          // (a lane without a pixel / a shift outside the row reads nothing of its own)
+            tl = Vs[i0]; tr = Vs[i1]; bl = Vs[p.cwcap + i0]; br = Vs[p.cwcap + i1];
+        } else { tl = V0[x0]; tr = V0[x1]; bl = V1[x0]; br = V1[x1]; }
         const float top = tl + (tr - tl) * tx, bot = bl + (br - bl) * tx;
         const float uj = (top + (bot - top) * ty) * p.mul;                 // resize_fwd mode 0
         if (j == p.md) uc = uj;
@@ -1537,10 +1625,26 @@ extern "C" int mh_level_front_fwd(const float* Vc, int32_t Hc, int32_t Wc, float
                                   int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t zero_tail, void* stream) {
     return mh_level_front_fwd_planes(Vc, Hc, Wc, mul, L, l_ld, R, r_ld, out, out_ld, coff, Rw, rw_ld, u, B, H, W, C, max_disp, zero_tail, nullptr, nullptr, 0, stream);
 }
-extern "C" int mh_level_front_fwd_planes(const float* Vc, int32_t Hc, int32_t Wc, float mul, const float* L, int32_t l_ld, const float* R,
-                                         int32_t r_ld, float* out, int32_t out_ld, int32_t coff, float* Rw, int32_t rw_ld, float* u,
-                                         int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t zero_tail,
-                                         void* out_hi, void* out_lo, int32_t out_pld, void* stream) {
+// columns of the coarse map a workgroup of `ppb` pixels (+ max_disp shifts either side) can touch: the HEAD instances' LDS row length
+static int front_head_cwcap(int Wc, int W, int ppb, int max_disp) {
+    const int span = ppb - 1 + 2 * max_disp;                          // fine columns between the first and the last tap's pixel
+    const int64_t c = ((int64_t)span * Wc + W - 1) / W + 3;            // floor(hi * sx) - floor(lo * sx) <= ceil(span * sx); + the x1 column, + rounding slack
+    return (int)(c < Wc ? c : Wc);
+}
+extern "C" int mh_level_front_head_ok(int32_t Hc, int32_t Wc, int32_t H, int32_t W, int32_t C, int32_t K, int32_t max_disp) {
+    if (Hc <= 0 || Wc <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || max_disp < 0) return 0;
+    if (K % 4 != 0 || K > 32 || 2 * max_disp + 1 > MAXD_SMALL) return 0;           // 8 lanes per head value, one channel group each
+    const int C4 = C / 4, lpp = C4 <= 4 ? 4 : (C4 <= 8 ? 8 : 16);
+    const int cw = front_head_cwcap(Wc, W, 256 / lpp, max_disp);
+    if (4 * (cw + 2) * (K / 4) > 6 * 256) return 0;                                 // the patch staging is six straight-line loads per thread
+    return ((size_t)4 * (cw + 2) * K + 9 * K + 2 * cw) * sizeof(float) <= 48 * 1024 ? 1 : 0;
+}
+
+static int level_front_launch(const float* X, int32_t x_ld, int32_t K, const float* hw, const float* hb,
+                              const float* Vc, int32_t Hc, int32_t Wc, float mul, const float* L, int32_t l_ld, const float* R,
+                              int32_t r_ld, float* out, int32_t out_ld, int32_t coff, float* Rw, int32_t rw_ld, float* u,
+                              int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t zero_tail,
+                              void* out_hi, void* out_lo, int32_t out_pld, void* stream) {
     MH_REQUIRE(!out_lo || out_hi, MH_ERR_ARG, "mh_level_front_fwd_planes: the lo plane needs the hi plane");
     MH_REQUIRE(!out_hi || (out_pld >= coff + 2 * max_disp + 2 && (out_pld & 3) == 0 && (((uintptr_t)out_hi) & 7u) == 0 && (((uintptr_t)out_lo) & 7u) == 0), MH_ERR_ARG,
                "mh_level_front_fwd_planes: out_pld must cover coff + D + 1 (multiple of 4), planes 8-byte aligned");
@@ -1561,16 +1665,55 @@ extern "C" int mh_level_front_fwd_planes(const float* Vc, int32_t Hc, int32_t Wc
     a.B = B; a.H = H; a.W = W; a.C = C; a.md = max_disp; a.D = D; a.zero_tail = zero_tail;
     a.l_bytes = (unsigned)lb; a.r_bytes = (unsigned)rb;
     a.out_hi = (unsigned short*)out_hi; a.out_lo = (unsigned short*)out_lo; a.out_pld = out_pld;
+    a.X = nullptr; a.hw = nullptr; a.hb = nullptr; a.Vw = nullptr; a.x_ld = 0; a.K = 0; a.segs = 0; a.cwcap = 0; a.x_bytes = 0;
     hipStream_t s = (hipStream_t)stream;
     const int C4 = C / 4;
-    auto grid = [&](int lpp) { return dim3((unsigned)((npix * lpp + 255) / 256)); };
+    const int lpp = C4 <= 4 ? 4 : (C4 <= 8 ? 8 : 16);
+    if (X) {
+        // the coarser level's disparity head inside this launch (mh_level_front_head_fwd)
+        MH_REQUIRE(mh_level_front_head_ok(Hc, Wc, H, W, C, K, max_disp) == 1, MH_ERR_UNSUPPORTED,
+                   "mh_level_front_head_fwd: K = %d channels / %dx%d -> %dx%d not served (ask mh_level_front_head_ok; run the head as a launch of its own)", K, Hc, Wc, H, W);
+        MH_REQUIRE(hw && x_ld >= K && x_ld % 4 == 0 && mh_aligned16(X) && mh_aligned16(hw), MH_ERR_ALIGN, "mh_level_front_head_fwd: X rows / head weights must be 16-byte aligned");
+        const int64_t xb = (((int64_t)B * Hc * Wc - 1) * x_ld + K) * 4;
+        MH_REQUIRE(xb < (1ll << 31) - 64, MH_ERR_UNSUPPORTED, "mh_level_front_head_fwd: X must be < 2 GiB");
+        a.X = X; a.hw = hw; a.hb = hb; a.Vw = const_cast<float*>(Vc); a.x_ld = x_ld; a.K = K; a.x_bytes = (unsigned)xb;
+        const int ppb = 256 / lpp;
+        a.segs = mh_cdiv(W, ppb);
+        a.cwcap = front_head_cwcap(Wc, W, ppb, max_disp);
+        const size_t lds = ((size_t)4 * (a.cwcap + 2) * K + 9 * K + 2 * a.cwcap) * sizeof(float);
+        const dim3 g((unsigned)((int64_t)a.segs * B * H));
+#define MH_FRONTH(LPPv)                                                                                                      \
+    { if (D <= 5) hipLaunchKernelGGL((level_front_kernel<LPPv, 5, true>), g, dim3(256), lds, s, a);                          \
+      else hipLaunchKernelGGL((level_front_kernel<LPPv, MAXD_SMALL, true>), g, dim3(256), lds, s, a); }
+        if (lpp == 4) MH_FRONTH(4) else if (lpp == 8) MH_FRONTH(8) else MH_FRONTH(16)
+#undef MH_FRONTH
+        mh_note_kernel("level_front_kernel<LPP=%d,DT=%d,HEAD=%d> grid %d lds %d", lpp, D <= 5 ? 5 : MAXD_SMALL, K, (int)g.x, (int)lds);
+        return mh_check_launch("level_front_head_fwd");
+    }
+    auto grid = [&](int l) { return dim3((unsigned)((npix * l + 255) / 256)); };
 #define MH_FRONT(LPPv)                                                                                              \
-    { if (D <= 5) hipLaunchKernelGGL((level_front_kernel<LPPv, 5>), grid(LPPv), dim3(256), 0, s, a);                \
-      else hipLaunchKernelGGL((level_front_kernel<LPPv, MAXD_SMALL>), grid(LPPv), dim3(256), 0, s, a); }
-    if (C4 <= 4) MH_FRONT(4) else if (C4 <= 8) MH_FRONT(8) else MH_FRONT(16)
+    { if (D <= 5) hipLaunchKernelGGL((level_front_kernel<LPPv, 5, false>), grid(LPPv), dim3(256), 0, s, a);                \
+      else hipLaunchKernelGGL((level_front_kernel<LPPv, MAXD_SMALL, false>), grid(LPPv), dim3(256), 0, s, a); }
+    if (lpp == 4) MH_FRONT(4) else if (lpp == 8) MH_FRONT(8) else MH_FRONT(16)
 #undef MH_FRONT
-    mh_note_kernel("level_front_kernel<LPP=%d,DT=%d>", C4 <= 4 ? 4 : (C4 <= 8 ? 8 : 16), D <= 5 ? 5 : MAXD_SMALL);
+    mh_note_kernel("level_front_kernel<LPP=%d,DT=%d>", lpp, D <= 5 ? 5 : MAXD_SMALL);
     return mh_check_launch("level_front_fwd");
+}
+
+extern "C" int mh_level_front_fwd_planes(const float* Vc, int32_t Hc, int32_t Wc, float mul, const float* L, int32_t l_ld, const float* R,
+                                         int32_t r_ld, float* out, int32_t out_ld, int32_t coff, float* Rw, int32_t rw_ld, float* u,
+                                         int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t zero_tail,
+                                         void* out_hi, void* out_lo, int32_t out_pld, void* stream) {
+    return level_front_launch(nullptr, 0, 0, nullptr, nullptr, Vc, Hc, Wc, mul, L, l_ld, R, r_ld, out, out_ld, coff, Rw, rw_ld, u, B, H, W, C, max_disp, zero_tail, out_hi, out_lo,
+                              out_pld, stream);
+}
+extern "C" int mh_level_front_head_fwd(const float* X, int32_t x_ld, int32_t K, const float* hw, const float* hb, float* Vc, int32_t Hc, int32_t Wc, float mul,
+                                       const float* L, int32_t l_ld, const float* R, int32_t r_ld, float* out, int32_t out_ld, int32_t coff, float* Rw, int32_t rw_ld,
+                                       float* u, int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t zero_tail,
+                                       void* out_hi, void* out_lo, int32_t out_pld, void* stream) {
+    MH_REQUIRE(X, MH_ERR_ARG, "mh_level_front_head_fwd: null argument");
+    return level_front_launch(X, x_ld, K, hw, hb, Vc, Hc, Wc, mul, L, l_ld, R, r_ld, out, out_ld, coff, Rw, rw_ld, u, B, H, W, C, max_disp, zero_tail, out_hi, out_lo, out_pld,
+                              stream);
 }
 
 extern "C" int mh_corr_warp_bwd(const float* g, int32_t g_ld, int32_t coff, const float* L, int32_t l_ld, const float* Rw, int32_t rw_ld,

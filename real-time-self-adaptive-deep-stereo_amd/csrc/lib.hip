@@ -241,6 +241,10 @@ static int run_op(const mh_op& o, void* s) {
             return mh_resize_bwd((const float*)p[0], (const float*)p[1], (float*)p[2], i[10], i[0], i[1], i[2], i[3], i[4], i[5], i[6],
                                  i[7], i[8], o.f[0], i[9], s);
         case MH_OP_LEVEL_FRONT:
+            if (p[8])           // the coarser level's disparity head in the same launch: X, head bank, head bias; i[14] = x_ld, i[15] = K
+                return mh_level_front_head_fwd((const float*)p[8], i[14], i[15], (const float*)p[9], (const float*)p[10], (float*)p[0], i[0], i[1], o.f[0],
+                                               (const float*)p[1], i[2], (const float*)p[2], i[3], (float*)p[3], i[4], i[5], (float*)p[4], i[6], (float*)p[5],
+                                               i[7], i[8], i[9], i[10], i[11], i[12], p[6], p[7], i[13], s);
             return mh_level_front_fwd_planes((const float*)p[0], i[0], i[1], o.f[0], (const float*)p[1], i[2], (const float*)p[2], i[3], (float*)p[3],
                                              i[4], i[5], (float*)p[4], i[6], (float*)p[5], i[7], i[8], i[9], i[10], i[11], i[12], p[6], p[7], i[13], s);
         case MH_OP_RESIZE_IMAGE:

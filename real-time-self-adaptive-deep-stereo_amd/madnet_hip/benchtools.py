@@ -416,7 +416,12 @@ def op_work(op):
     if op.kind == _ffi.OP_LEVEL_FRONT:
         B, H, W, Cc, md = op.i[7], op.i[8], op.i[9], op.i[10], op.i[11]
         D = 2 * md + 1
-        return 2.0 * B * H * W * Cc * D, 4.0 * B * H * W * (2 * Cc + (Cc + D + 1) + Cc + 1)        # reads L, R; writes [L | corr | u], the warped features, u
+        fl, by = 2.0 * B * H * W * Cc * D, 4.0 * B * H * W * (2 * Cc + (Cc + D + 1) + Cc + 1)        # reads L, R; writes [L | corr | u], the warped features, u
+        if op.p[8]:                 # + the coarser level's disparity head (3x3, K -> 1): reads its input once, writes the coarse disparity
+            Hc, Wc, K = op.i[0], op.i[1], op.i[15]
+            fl += 2.0 * B * Hc * Wc * 9 * K
+            by += 4.0 * B * Hc * Wc * (K + 1)
+        return fl, by
     if op.kind not in (_ffi.OP_CONV, _ffi.OP_WGRAD, _ffi.OP_WGRAD_PARTIAL):
         return 0.0, 0.0
     i = op.i

@@ -28,14 +28,14 @@ class ElisionPasses(object):
             for j, q in enumerate(ops_):
                 if j == idx:
                     continue
-                if any(q.p[k] and lo <= int(q.p[k]) < hi for k in range(8)):
+                if any(q.p[k] and lo <= int(q.p[k]) < hi for k in range(len(q.p))):
                     users.append(j)
             if len(users) != 1 or users[0] < idx:
                 continue
             c = ops_[users[0]]
             if not (c.kind == _ffi.OP_CONV and c.i[13] == 1 and int(c.p[0]) == lo and (c.i[23] & 1) and c.i[22] == 1):
                 continue
-            if sum(1 for k in range(8) if c.p[k] and lo <= int(c.p[k]) < hi) != 1:
+            if sum(1 for k in range(len(c.p)) if c.p[k] and lo <= int(c.p[k]) < hi) != 1:
                 continue
             if not (self._takes_shadows(c) & 1):
                 continue
@@ -118,7 +118,7 @@ class ElisionPasses(object):
             for j, q in enumerate(ops_):
                 if j == idx:
                     continue
-                hits = [k for k in range(8) if q.p[k] and lo <= int(q.p[k]) < hi]
+                hits = [k for k in range(len(q.p)) if q.p[k] and lo <= int(q.p[k]) < hi]
                 if not hits:
                     continue
                 # the only tolerated readers: an input gradient (tiled families) that was given this tensor as its leaky mask TOGETHER with the mask's

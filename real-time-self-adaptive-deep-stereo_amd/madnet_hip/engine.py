@@ -395,6 +395,7 @@ class MadNetEngine(ElisionPasses, BackwardRecorder):
     def record_forward(self, r, make_disps=()):
         B, lib = self.B, r
         head2_fused = False
+        pending_head = None
         self._fresh_planes = set()
         self._stamp(lib, "start")
         if self.use_bank:
@@ -431,6 +432,8 @@ class MadNetEngine(ElisionPasses, BackwardRecorder):
             ld = self.dsi_ld[k]
             dsi = ops.View(self.dsi[k], B, h, w, ld, ld)
             fused = k != 6 and self._front_fused()
+            head = pending_head
+            pending_head = None
             if fused:
                 # u_k = resize(V_{k+1}) * 20 / 2^k (MadNet.py:274), warp, cost volume + concat: one launch
                 xin = ops.View(self.dsi[k], B, h, w, c + self.D + 1, ld)
@@ -443,7 +446,15 @@ class MadNetEngine(ElisionPasses, BackwardRecorder):
                     elif (est_name(k, 1) + "/weights") in self._stream_train and self.use_stream and self.partial_wgrad and ops._bwd_precision() == 1:
                         pl = pl_.hi                               # hi only: the shadow its streamed filter gradient reads (no cast in the backward pass)
                         self._fresh.add(key)
-                ops.level_front_fwd(lib, self.V[k + 1], 20.0 / 2 ** k, Lk, Rk, dsi, self._fv(self.Rw[k]), self.u[k], self.md, coff=c, planes=pl)
+                if head is not None:
+                    # ... and the disparity head of level k + 1 (recorded nowhere else: see below)
+                    hx, hname = head
+                    ops.level_front_head_fwd(lib, hx, self.W_(hname), self.b_(hname), self.V[k + 1], 20.0 / 2 ** k, Lk, Rk, dsi, self._fv(self.Rw[k]), self.u[k], self.md,
+                                             coff=c, planes=pl)
+                    if (k + 1) in make_disps:
+                        self._make_disp(lib, self.V[k + 1], self.disp_k[k + 1])
+                else:
+                    ops.level_front_fwd(lib, self.V[k + 1], 20.0 / 2 ** k, Lk, Rk, dsi, self._fv(self.Rw[k]), self.u[k], self.md, coff=c, planes=pl)
             else:
                 if k != 6 and self.warping:
                     ops.warp_fwd(lib, Rk, self.u[k], self._fv(self.Rw[k]))
@@ -468,6 +479,11 @@ class MadNetEngine(ElisionPasses, BackwardRecorder):
                     head2_fused = True
                     x = o
                     continue
+                if last and k != 2 and self._head_in_front(k, x):
+                    # levels 6 .. 3: the head runs inside level k - 1's front-end launch, which needs its result first (Schedule.HEAD_IN_FRONT)
+                    pending_head = (x, est_name(k, j + 1))
+                    x = o
+                    continue
                 self._conv_fwd(lib, r, x, est_name(k, j + 1), o, alpha=(1.0 if last else ALPHA), precision=fprec,
                                shadow_consumer=(None if last else est_name(k, j + 2)))
                 x = o
@@ -475,8 +491,9 @@ class MadNetEngine(ElisionPasses, BackwardRecorder):
                 sc = 2 ** (k - 1)
                 if not self._front_fused():          # (fused: level k-1's front kernel computes u itself)
                     ops.resize_fwd(lib, self.V[k], self.u[k - 1], self.Hp // sc, self.Wp // sc, mul=20.0 / sc, mode=0)
-                if k in make_disps:
+                if k in make_disps and pending_head is None:
                     self._make_disp(lib, self.V[k], self.disp_k[k])
+        assert pending_head is None
         # context network (MadNet._stereo_context_net, MadNet.py:122-171)
         h, w, c = self.fshape[4]
         cin = ops.View(self.ctx_in, B, h, w, c + 1, self.ctx_ld)
@@ -542,6 +559,13 @@ class MadNetEngine(ElisionPasses, BackwardRecorder):
 
     def _front_fused(self):
         return self.fuse_front and self.warping and self.cstride == 1 and self.D <= 9
+
+    def _head_in_front(self, k, x):
+        """the disparity head of level k inside level k - 1's front-end launch (Schedule.HEAD_IN_FRONT), when the library serves the shape"""
+        if not (self.sched.HEAD_IN_FRONT and self._front_fused() and hasattr(self.lib, "level_front_head_ok")):
+            return False
+        h, w, c = self.fshape[FEAT[k - 1]]
+        return self.lib.level_front_head_ok(x.H, x.W, h, w, c, x.C, self.md) == 1
 
     def _conv_acc(self, lib, x, base, out, rate):
         import ctypes as C

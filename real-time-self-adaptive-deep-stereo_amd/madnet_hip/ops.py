@@ -568,6 +568,20 @@ def level_front_fwd(lib, Vc, mul, L, R, out, Rw, u, max_disp, coff, zero_tail=Tr
                                L.B, L.H, L.W, L.C, max_disp, int(zero_tail), C.c_void_p(hi.ptr), (C.c_void_p(lo.ptr) if lo is not None else None), hi.ld, _p(stream))
 
 
+def level_front_head_fwd(lib, X, hw, hb, Vc, mul, L, R, out, Rw, u, max_disp, coff, zero_tail=True, stream=None, planes=None):
+    """level_front_fwd whose coarse disparity Vc is COMPUTED in the launch: Vc = conv3x3(X, hw) + hb, the disparity head of the coarser level (mh_level_front_head_fwd).
+    X: View [B,Hc,Wc,K]; hw: the head's [3,3,K,1] weights; hb: its bias tensor or None; Vc: [B,Hc,Wc] tensor (output)."""
+    hi = lo = None
+    if planes is not None:
+        hi = planes.hi if isinstance(planes, Planes) else planes
+        lo = planes.lo if isinstance(planes, Planes) else None
+        assert (hi.B, hi.H, hi.W) == (L.B, L.H, L.W) and hi.C == coff + 2 * max_disp + 2 and hi.ld >= hi.C
+    assert (X.B, X.H, X.W) == (L.B, Vc.shape[1], Vc.shape[2]) and tuple(hw.shape) == (3, 3, X.C, 1)
+    lib.level_front_head_fwd(_p(X), X.ld, X.C, _p(hw), _p(hb), _p(Vc), Vc.shape[1], Vc.shape[2], mul, _p(L), L.ld, _p(R), R.ld, _p(out), out.ld, coff, _p(Rw), Rw.ld,
+                             _p(u), L.B, L.H, L.W, L.C, max_disp, int(zero_tail), (C.c_void_p(hi.ptr) if hi is not None else None),
+                             (C.c_void_p(lo.ptr) if lo is not None else None), (hi.ld if hi is not None else 0), _p(stream))
+
+
 def corr_bwd(lib, g, L, R, dL, dR, max_disp, stride=1, coff=0, du=None, acc_l=False, acc_r=False, acc_u=False,
              copy_left=False, stream=None, precision=None):
     """precision: None = the backward code of the plan being recorded; only the large-D MFMA kernels use it (1 = bf16 operands)."""

@@ -199,6 +199,11 @@ class Recorder(object):
     def level_front_fwd_planes(self, Vc, Hc, Wc, mul, L, l_ld, R, r_ld, out, out_ld, coff, Rw, rw_ld, u, B, H, W, Cc, md, zero_tail, out_hi, out_lo, out_pld, stream):
         self._op(_ffi.OP_LEVEL_FRONT, [Hc, Wc, l_ld, r_ld, out_ld, coff, rw_ld, B, H, W, Cc, md, zero_tail, out_pld], [mul], [Vc, L, R, out, Rw, u, out_hi, out_lo])
 
+    def level_front_head_fwd(self, X, x_ld, K, hw, hb, Vc, Hc, Wc, mul, L, l_ld, R, r_ld, out, out_ld, coff, Rw, rw_ld, u, B, H, W, Cc, md, zero_tail, out_hi, out_lo, out_pld,
+                             stream):
+        self._op(_ffi.OP_LEVEL_FRONT, [Hc, Wc, l_ld, r_ld, out_ld, coff, rw_ld, B, H, W, Cc, md, zero_tail, out_pld, x_ld, K], [mul],
+                 [Vc, L, R, out, Rw, u, out_hi, out_lo, X, hw, hb])
+
     def corr_bwd(self, g, g_ld, coff, L, l_ld, R, r_ld, dL, dl_ld, acc_l, dR, dr_ld, acc_r, du, acc_u,
                  B, H, W, Cc, md, stride, copy_left, stream):
         self.corr_bwd_prec(g, g_ld, coff, L, l_ld, R, r_ld, dL, dl_ld, acc_l, dR, dr_ld, acc_r, du, acc_u, B, H, W, Cc, md, stride, copy_left, 0, stream)

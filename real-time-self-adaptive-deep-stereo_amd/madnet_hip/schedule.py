@@ -38,6 +38,9 @@ class Schedule(object):
     # one launch for a head's output gradient + input gradient (mh_head_bwd) instead of resize gradient / copies + the K = 1 input-gradient kernel,
     # and the level-2 head's forward pass storing its result in the context input and in `final` too (mh_conv2d_head)
     FUSE_HEAD: bool = True
+    # the disparity heads of levels 6 .. 3 run INSIDE the next level's front-end launch (mh_level_front_head_fwd) instead of as launches of their own in front
+    # of it: four 4.5 - 5 us nodes off the forward chain (r05_experiments.txt #11)
+    HEAD_IN_FRONT: bool = True
     # FULL momentum steps: every filter-gradient batch is followed by the momentum update of its layers on its own lane, the launch behind the join
     # covers only what is left.  Measured worse together with the tail split (r04 #17)
     EARLY_UPDATE: bool = False

@@ -38,7 +38,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(dll, n), "symbol %s declared in include/madnet_hip.h but not exported" % n
     assert set(names) == set(_ffi.SIGNATURES.keys()), set(names) ^ set(_ffi.SIGNATURES.keys())
-    assert dll.mh_abi_version() == 13
+    assert dll.mh_abi_version() == 14
 
 
 def test_product_loader_fails_loudly_without_gpu():
@@ -54,6 +54,6 @@ def test_product_loader_fails_loudly_without_gpu():
 def test_struct_layout_matches_header():
     from madnet_hip import _ffi
     assert ctypes.sizeof(_ffi.ConvDesc) == 24 * 4
-    assert ctypes.sizeof(_ffi.Op) == 4 + 27 * 4 + 4 * 4 + 8 * 8 + 8
+    assert ctypes.sizeof(_ffi.Op) == 4 + 27 * 4 + 4 * 4 + 12 * 8 + 8
     assert ctypes.sizeof(_ffi.ShadowSeg) == 2 * 8 + 8 + 4 * 4 and ctypes.sizeof(_ffi.WgsLayer) == 4 * 8 + 14 * 4
     assert ctypes.sizeof(_ffi.PlaneSeg) == 3 * 8 + 8 + 4 * 4 + 8 + 2 * 4

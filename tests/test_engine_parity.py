@@ -565,8 +565,13 @@ def test_plan_scheduling_switches_do_not_change_results_emulated(monkeypatch):
 
     p0, l0, w0 = run()
     for kw, exact in (({"NODEFER_BATCHES": 3}, True), ({"lanes": 2}, True), ({"lanes": 0}, True), ({"SIDE_LOSS": False}, True),
-                      ({"ONE_FILL": False}, False), ({"FUSE_BACK": False}, False)):
+                      ({"ONE_FILL": False}, False), ({"FUSE_BACK": False}, False), ({"HEAD_IN_FRONT": False}, "head")):
         p1, l1, w1 = run(**kw)
+        if exact == "head":
+            # the disparity heads of levels 6 .. 3 as launches of their own: the same arithmetic in another kernel -- on the emulator (one compiler, no fma
+            # contraction differences) the coarse disparities, hence everything downstream, must come out bit for bit
+            assert torch.equal(p0, p1) and l0 == l1 and (w0 - w1).abs().max().item() <= 1e-10, (kw, (p0 - p1).abs().max().item(), (w0 - w1).abs().max().item())
+            continue
         assert torch.equal(p0, p1) and l0 == l1, kw
         # scheduling only: the same kernels on the same data (the fp32 atomics of the bias / warp gradients may land in another order: ~1e-13);
         # ONE_FILL / FUSE_BACK swap kernels (accumulate onto zero, fused correlation + warp gradient) = another fp32 summation order

@@ -392,6 +392,78 @@ def test_level_front_fused_matches_resize_warp_corr(backend, case):
     ok, err = _close(out1[..., C:C + D], ref); assert ok, err
 
 
+@pytest.mark.parametrize("case", [(1, 12, 40, 128, 2, 32), (2, 6, 10, 32, 2, 32), (1, 9, 17, 64, 3, 32), (1, 24, 80, 96, 2, 32), (1, 5, 7, 16, 1, 16), (1, 48, 160, 32, 2, 32),
+                                  (1, 2, 4, 128, 2, 32)])
+def test_level_front_with_the_coarser_head_inside(backend, case):
+    """mh_level_front_head_fwd (the disparity head of the coarser level computed IN the front-end launch, MadNet.py:118 then :274-295) == the head as a launch
+    of its own (mh_conv2d_fwd, 3x3 K -> 1, linear) followed by mh_level_front_fwd: the stored Vc bit for bit where the two kernels contract alike (asserted to
+    2 ulp-of-sum), u / warped features / cost volume to the interpolation's noise; every element of Vc is written (NaN canary); odd sizes, two images, a row
+    shorter than a workgroup; and the planes of the estimator input.  Against the oracle: conv2d + resize_images + _linear_warping + correlation."""
+    B, H, W, C, md, K = case
+    dev = backend.device
+    lib = backend.lib
+    Hc, Wc = (H + 1) // 2, (W + 1) // 2
+    assert lib.level_front_head_ok(Hc, Wc, H, W, C, K, md) == 1
+    X = _rand((B, Hc, Wc, K), 71, dev)
+    hw = _rand((3, 3, K, 1), 72, dev, 0.2)
+    hb = _rand((1,), 73, dev)
+    L = _rand((B, H, W, C), 62, dev); R = _rand((B, H, W, C), 63, dev)
+    mul = 20.0 / 8
+    D = 2 * md + 1
+    ld = (C + D + 1 + 3) // 4 * 4
+    # the two launches
+    V0 = torch.full((B, Hc, Wc), float("nan"), device=dev)
+    ops.conv2d_fwd(lib, ops.view(X), hw, hb, ops.View(V0, B, Hc, Wc, 1, 1), alpha=1.0)
+    assert "conv_n1_fwd_kernel" in lib.last_kernel().decode()
+    u0 = torch.full((B, H, W), float("nan"), device=dev); Rw0 = torch.full((B, H, W, C), float("nan"), device=dev)
+    out0 = torch.full((B, H, W, ld), float("nan"), device=dev)
+    ops.level_front_fwd(lib, V0, mul, ops.view(L), ops.view(R), ops.View(out0, B, H, W, ld, ld), ops.view(Rw0), u0, md, coff=C)
+    # one launch
+    V1 = torch.full((B, Hc, Wc), float("nan"), device=dev)
+    u1 = torch.full((B, H, W), float("nan"), device=dev); Rw1 = torch.full((B, H, W, C), float("nan"), device=dev)
+    out1 = torch.full((B, H, W, ld), float("nan"), device=dev)
+    pl = ops.Planes(ops.Shadow(B, H, W, C + D + 1, dev), dev)
+    ops.level_front_head_fwd(lib, ops.view(X), hw, hb, V1, mul, ops.view(L), ops.view(R), ops.View(out1, B, H, W, ld, ld), ops.view(Rw1), u1, md, coff=C, planes=pl)
+    assert "HEAD=%d" % K in lib.last_kernel().decode()
+    backend.sync()
+    v0, v1 = V0.cpu(), V1.cpu()
+    assert torch.isfinite(v1).all()                                       # every coarse pixel was stored by some workgroup
+    dv = (v1 - v0).abs().max().item()
+    assert dv <= 2e-6 * max(1.0, v0.abs().max().item()), dv
+    du = (u1.cpu() - u0.cpu()).abs().max().item()
+    assert du <= 1e-5 + 4.0 * mul * dv
+    assert (Rw1.cpu() - Rw0.cpu()).abs().max().item() <= 1e-5 + 32.0 * du       # |du| x the steepest |R[x+1] - R[x]| of the map
+    assert torch.equal(out1[..., :C].cpu(), L.cpu()) and torch.equal(out1[..., C + D].cpu(), u1.cpu())
+    assert torch.all(out1[..., C + D + 1:].cpu() == 0)
+    assert (out1[..., C:C + D].cpu() - out0[..., C:C + D].cpu()).abs().max().item() <= 1e-5 + 32.0 * du
+    # the planes: hi + lo of what the launch stored in fp32
+    hi = pl.hi.t.float().cpu()[..., :C + D + 1]
+    lo = pl.lo.t.float().cpu()[..., :C + D + 1]
+    assert ((hi + lo) - out1[..., :C + D + 1].cpu()).abs().max().item() <= 2e-5 * max(1.0, out1[..., :C + D + 1].abs().max().item())
+    # oracle
+    Vo = T.conv2d(X.cpu(), hw.cpu(), hb.cpu(), 1, 1, 1.0)
+    ok, err = _close(V1, Vo[..., 0]); assert ok, err
+    uo = T.resize_bilinear(Vo, H, W) * mul
+    ref = T.correlation(L.cpu(), T.linear_warp(R.cpu(), uo), md, 1)
+    ok, err = _close(out1[..., C:C + D], ref); assert ok, err
+
+
+def test_level_front_head_refuses_what_it_does_not_serve(backend):
+    """K > 32 head channels / D > 9: mh_level_front_head_ok says 0 and the entry point answers MH_ERR_UNSUPPORTED instead of running something else"""
+    lib = backend.lib
+    assert lib.level_front_head_ok(6, 10, 12, 20, 32, 64, 2) == 0 and lib.level_front_head_ok(6, 10, 12, 20, 32, 30, 2) == 0
+    assert lib.level_front_head_ok(6, 10, 12, 20, 32, 32, 5) == 0 and lib.level_front_head_ok(6, 10, 12, 20, 32, 32, 2) == 1
+    dev = backend.device
+    B, H, W, C, md, K = 1, 12, 20, 32, 2, 64
+    X = _rand((B, 6, 10, K), 1, dev); hw = _rand((3, 3, K, 1), 2, dev); V = torch.zeros(B, 6, 10, device=dev)
+    L = _rand((B, H, W, C), 3, dev); R = _rand((B, H, W, C), 4, dev)
+    ld = 40
+    out = torch.zeros(B, H, W, ld, device=dev); Rw = torch.zeros(B, H, W, C, device=dev); u = torch.zeros(B, H, W, device=dev)
+    with pytest.raises(Exception) as e:
+        ops.level_front_head_fwd(lib, ops.view(X), hw, None, V, 2.5, ops.view(L), ops.view(R), ops.View(out, B, H, W, ld, ld), ops.view(Rw), u, md, coff=C)
+    assert "mh_level_front_head_ok" in str(e.value)
+
+
 @pytest.mark.parametrize("case", [(1, 2, 70, 128, 40), (2, 1, 131, 64, 40), (1, 2, 40, 32, 10), (1, 1, 200, 256, 24)])
 def test_corr_fwd_large_d_bf16_and_split_bf16(backend, case):
     """DispNet's 81-shift volume on the bf16 matrix cores (mh_corr_fwd_prec): precision 1 = operands rounded to bf16 (judged
