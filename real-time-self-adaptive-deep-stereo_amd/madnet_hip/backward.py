@@ -272,7 +272,8 @@ class BackwardRecorder(object):
                 dz = dx
                 if not need_dx:
                     break
-            flush()
+            if k in self.sched.EST_FLUSH_AFTER or k == 6 or not need_dsi:
+                flush()
             if not need_dsi:
                 break
             # correlation (+ fused concat) gradient

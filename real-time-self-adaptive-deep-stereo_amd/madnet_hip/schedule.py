@@ -56,6 +56,10 @@ class Schedule(object):
     # the pyramid's filter gradients leave for the side lane in batches; a batch is flushed AFTER the input gradient of layer i for i in
     # PYR_FLUSH_AFTER (9, 5, 1 = four layers per batch) and BEFORE the input gradient of layer i for i in PYR_FLUSH_BEFORE
     PYR_FLUSH_AFTER: tuple = (9, 5, 1)
+    # the estimators' filter gradients leave as one batch per level in this tuple (level 6 always flushes); a level not named rides with the next batch.
+    # Every flush is a fork edge on lane 0 (a 4.5 us gap in front of the level's correlation gradient in the traced graph), yet fewer batches measured
+    # SLOWER: (2,3,6) +5 us, (2,6) +17 us, (6,) +190 us per step (r05_experiments.txt #12)
+    EST_FLUSH_AFTER: tuple = (2, 3, 4, 5, 6)
     PYR_FLUSH_BEFORE: tuple = ()
     # (TAIL_SPLIT) the last batch on a side lane of its own (0 = same lane); its slice of the gradient buffer is zeroed on that lane too
     TAIL_LANE: int = 2
