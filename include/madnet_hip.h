@@ -411,6 +411,16 @@ int mh_head_bwd(const mh_head_bwd_desc* d, const float* src0, const float* src1,
 int mh_pad_reflect(const float* in, float* out, int32_t B, int32_t H, int32_t W, int32_t C,
                    int32_t Hp, int32_t Wp, int32_t pad_t, int32_t pad_l, int32_t out_ld,
                    float div, float sub, void* stream);
+/* The image layer's forward pass straight from the frames: out = leaky(conv3x3(reflect_pad(frames / div - sub), w) + bias), i.e. mh_pad_reflect followed by
+ * mh_conv2d_fwd on the padded frames (Stereo_net._preprocess_inputs + the first conv2d of MadNet._pyramid_features, MadNet.py:56-60) WITHOUT reading or writing the
+ * padded copy: frames [NB,H0,W0,C] fp32, padded frame Hp x Wp with the image at (reflect_t, reflect_l), SAME padding offsets pad_t / pad_l of the strided conv on
+ * the padded frame (zeros outside it), w HWIO [3][3][C][N], out [NB,ceil(Hp/stride),ceil(Wp/stride),out_ld]; shadow (may be NULL): the bf16 copy of out the
+ * streamed filter gradient of the next layer reads, pixel stride shadow_ld halfs.  Exact fp32 arithmetic.  Served: C = 3, N = 16, stride 1 / 2
+ * (mh_conv_image_ok; MH_ERR_UNSUPPORTED otherwise). */
+int mh_conv_image_fwd(const float* frames, int32_t NB, int32_t H0, int32_t W0, int32_t C, int32_t Hp, int32_t Wp, int32_t reflect_t, int32_t reflect_l,
+                      float div, float sub, const float* w, const float* bias, int32_t N, int32_t stride, int32_t pad_t, int32_t pad_l, float alpha,
+                      float* out, int32_t out_ld, void* shadow, int32_t shadow_ld, void* stream);
+int mh_conv_image_ok(int32_t C, int32_t N, int32_t kh, int32_t kw, int32_t stride);       /* 1 / 0, no status */
 
 /* ---- loss_factory.get_reprojection_loss('mean_SSIM_l1') forward + gradient w.r.t. the
  *      disparity (Losses/loss_factory.py:128-164,353-395; preprocessing.py:121-230) ------
@@ -496,7 +506,7 @@ enum { MH_OP_CONV = 1, MH_OP_WGRAD, MH_OP_CORR_FWD, MH_OP_CORR_BWD, MH_OP_WARP_F
        MH_OP_RESIZE_FWD, MH_OP_RESIZE_BWD, MH_OP_PAD_REFLECT, MH_OP_LOSS, MH_OP_METRICS,
        MH_OP_MOMENTUM, MH_OP_COPY_CH, MH_OP_LEAKY_BWD, MH_OP_FILL, MH_OP_BIAS_GRAD,
        MH_OP_WGRAD_PARTIAL, MH_OP_WGRAD_REDUCE, MH_OP_PROXY_LOSS, MH_OP_SUPERVISED_LOSS, MH_OP_ADAM, MH_OP_ADAM_ADVANCE,
-       MH_OP_RESIZE_IMAGE, MH_OP_LEVEL_FRONT, MH_OP_RESERVED_25 /* (was: transposed filter banks of the retired LDS-free kernel) */, MH_OP_PACK_W, MH_OP_CORR_WARP_BWD, MH_OP_SHADOW_CAST, MH_OP_WGRAD_STREAM, MH_OP_HEAD_BWD, MH_OP_HEAD_FWD, MH_OP_CONV_PLANES, MH_OP_PLANE_SPLIT, MH_OP_STAMP, MH_OP_CONV_PLANES_BWD, MH_OP_DET_FLUSH };
+       MH_OP_RESIZE_IMAGE, MH_OP_LEVEL_FRONT, MH_OP_RESERVED_25 /* (was: transposed filter banks of the retired LDS-free kernel) */, MH_OP_PACK_W, MH_OP_CORR_WARP_BWD, MH_OP_SHADOW_CAST, MH_OP_WGRAD_STREAM, MH_OP_HEAD_BWD, MH_OP_HEAD_FWD, MH_OP_CONV_PLANES, MH_OP_PLANE_SPLIT, MH_OP_STAMP, MH_OP_CONV_PLANES_BWD, MH_OP_DET_FLUSH, MH_OP_CONV_IMAGE };
 /* i[26] of every op is its scheduling word: low byte = lane (0 = the caller's stream; 1..MH_MAX_LANES-1 = side
  * streams owned by the library: the op is forked from lane 0 right before it, i.e. ordered after everything recorded so
  * far, and runs concurrently with the lane-0 ops that follow); MH_OP_JOIN = lane 0 first waits for all side lanes.

@@ -318,3 +318,105 @@ int mh_conv_rows_launch(ConvArgs& a, hipStream_t s) {
 }
 
 extern "C" int mh_tune_conv_rows(int min_pixels) { return g_rows_minpix.exchange(min_pixels < 0 ? -1 : min_pixels); }
+
+// ---- the image layer, forward, straight from the frames (round 5: mh_conv_image_fwd) -----------------------------------------------------------
+// MADNet's conv1 (3 -> 16, 3x3, stride 2, Nets/MadNet.py:56-60) on the reflect-padded pair (Stereo_net._preprocess_inputs -> pad_image): 0.2 GFLOP over
+// 11 MB of pixels and 16 + 16 MB of results.  As two launches -- mh_pad_reflect writing the padded copy (11 us), then the row-streaming kernel above with 3 of
+// its 16 MFMA reduction lanes alive (18 us) -- it was 29 us at the head of the forward chain, where nothing overlaps it.  Here a THREAD owns an output pixel:
+// its 27 inputs are loaded from the ORIGINAL frames through the reflection (the padded copy is not read: it is only needed by this layer's filter gradient,
+// at the other end of the step, and is written on a side lane), the bank is read through the scalar cache (uniform addresses: s_load, operands of v_fmac),
+// 432 exact-fp32 FMAs, leaky, four 16-byte stores + the bf16 shadow.  HBM bound (8 - 10 us).  Exact fp32: no rounding of the frames at all.
+struct ImageConvArgs {
+    const float* raw; const float* w; const float* bias; float* out; unsigned short* shadow;
+    int NB, H0, W0, Hp, Wp, rpt, rpl, Ho, Wo, stride, pad_t, pad_l, out_ld, shadow_ld, M;
+    float div, sub, alpha;
+    unsigned raw_bytes;
+};
+
+namespace {
+__global__ __launch_bounds__(256) void conv_image_fwd_kernel(ImageConvArgs p) {
+    constexpr int C = 3, N = 16;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    const bool live = m < p.M;
+    const int mm = live ? m : 0;
+    const int ox = mm % p.Wo;
+    const int t2 = mm / p.Wo;
+    const int oy = t2 % p.Ho, b = t2 / p.Ho;
+    const __amdgpu_buffer_rsrc_t rs = mh_make_rsrc(p.raw, p.raw_bytes);
+    // all 27 loads are UNCONDITIONAL (a tap outside the padded frame = an out-of-range offset = 0): a load behind a branch costs hipcc its count of what is in
+    // flight, and the 27 requests become 27 round trips (the first build of this kernel: s_cbranch_execz + s_waitcnt vmcnt(0) around every one of them)
+    float xv[9][C];
+    unsigned inmask = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int ky = t / 3, kx = t - ky * 3;
+        const int py = oy * p.stride + ky - p.pad_t, px = ox * p.stride + kx - p.pad_l;          // in the padded frame: outside it the SAME padding's zeros
+        const bool in = live && (unsigned)py < (unsigned)p.Hp && (unsigned)px < (unsigned)p.Wp;
+        int sy = py - p.rpt, sx = px - p.rpl;                                                    // mh_pad_reflect's mapping
+        sy = sy < 0 ? -sy : (sy >= p.H0 ? 2 * (p.H0 - 1) - sy : sy);
+        sx = sx < 0 ? -sx : (sx >= p.W0 ? 2 * (p.W0 - 1) - sx : sx);
+        int off = (((b * p.H0 + sy) * p.W0 + sx) * C) * 4;
+        MH_KEEP_VGPR(off);
+        off = in ? off : MH_OOB;
+        inmask |= in ? (1u << t) : 0u;
+#pragma unroll
+        for (int c = 0; c < C; ++c) xv[t][c] = mh_buf_load1(rs, off == MH_OOB ? MH_OOB : off + 4 * c);
+    }
+    if (p.div != 1.0f || p.sub != 0.f) {             // (uniform; MADNet feeds the frames as they are, DispNet-style preprocessing divides and shifts)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < C; ++c) xv[t][c] = ((inmask >> t) & 1u) ? (xv[t][c] / p.div - p.sub) : 0.f;
+    }
+    float acc[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) acc[n] = p.bias ? MH_CONST_F32_PTR(p.bias)[n] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const MH_CONST_F32* wr = MH_CONST_F32_PTR(p.w) + (t * C + c) * N;           // (uniform address, constant address space: s_load, operands of v_fmac)
+#pragma unroll
+            for (int n = 0; n < N; ++n) acc[n] += xv[t][c] * wr[n];
+        }
+    if (!live) return;
+#pragma unroll
+    for (int n = 0; n < N; ++n) acc[n] = (p.alpha == 1.0f || acc[n] > 0.f) ? acc[n] : p.alpha * acc[n];
+    float* const o = p.out + (int64_t)m * p.out_ld;
+#pragma unroll
+    for (int q = 0; q < N / 4; ++q) *reinterpret_cast<float4*>(o + 4 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    if (p.shadow) {
+        unsigned short* const sh = p.shadow + (int64_t)m * p.shadow_ld;
+#pragma unroll
+        for (int q = 0; q < N / 8; ++q)
+            *reinterpret_cast<u32x4*>(sh + 8 * q) = (u32x4){mh_pack_bf16(acc[8 * q], acc[8 * q + 1]), mh_pack_bf16(acc[8 * q + 2], acc[8 * q + 3]),
+                                                            mh_pack_bf16(acc[8 * q + 4], acc[8 * q + 5]), mh_pack_bf16(acc[8 * q + 6], acc[8 * q + 7])};
+    }
+}
+}  // namespace
+
+extern "C" int mh_conv_image_ok(int32_t C, int32_t N, int32_t kh, int32_t kw, int32_t stride) {
+    return (C == 3 && N == 16 && kh == 3 && kw == 3 && (stride == 1 || stride == 2)) ? 1 : 0;
+}
+
+extern "C" int mh_conv_image_fwd(const float* frames, int32_t NB, int32_t H0, int32_t W0, int32_t C, int32_t Hp, int32_t Wp, int32_t reflect_t, int32_t reflect_l,
+                                 float div, float sub, const float* w, const float* bias, int32_t N, int32_t stride, int32_t pad_t, int32_t pad_l, float alpha,
+                                 float* out, int32_t out_ld, void* shadow, int32_t shadow_ld, void* stream) {
+    MH_REQUIRE(frames && w && out, MH_ERR_ARG, "mh_conv_image_fwd: null argument");
+    MH_REQUIRE(mh_conv_image_ok(C, N, 3, 3, stride) == 1, MH_ERR_UNSUPPORTED, "mh_conv_image_fwd: serves 3 -> 16 channels, 3x3, stride 1 / 2 (got %d -> %d, stride %d)", C, N, stride);
+    MH_REQUIRE(NB > 0 && H0 > 1 && W0 > 1 && Hp >= H0 && Wp >= W0 && reflect_t >= 0 && reflect_l >= 0 && reflect_t < H0 && reflect_l < W0 && Hp - H0 - reflect_t < H0 &&
+               Wp - W0 - reflect_l < W0 && Hp - H0 - reflect_t >= 0 && Wp - W0 - reflect_l >= 0, MH_ERR_ARG, "mh_conv_image_fwd: bad frame / padding geometry");
+    MH_REQUIRE(div != 0.f && pad_t >= 0 && pad_t <= 1 && pad_l >= 0 && pad_l <= 1, MH_ERR_ARG, "mh_conv_image_fwd: div must be non-zero, SAME padding offsets 0 / 1");
+    MH_REQUIRE(out_ld >= N && out_ld % 4 == 0 && mh_aligned16(out) && mh_aligned16(w) && (!shadow || (shadow_ld >= N && shadow_ld % 8 == 0 && mh_aligned16(shadow))), MH_ERR_ALIGN,
+               "mh_conv_image_fwd: 16-byte rows required");
+    const int Ho = (Hp + stride - 1) / stride, Wo = (Wp + stride - 1) / stride;
+    const int64_t M = (int64_t)NB * Ho * Wo, rb = (int64_t)NB * H0 * W0 * C * 4;
+    MH_REQUIRE(M < (1ll << 31) - 256 && rb < (1ll << 31) - 64, MH_ERR_UNSUPPORTED, "mh_conv_image_fwd: tensors must be < 2 GiB");
+    ImageConvArgs a;
+    a.raw = frames; a.w = w; a.bias = bias; a.out = out; a.shadow = (unsigned short*)shadow;
+    a.NB = NB; a.H0 = H0; a.W0 = W0; a.Hp = Hp; a.Wp = Wp; a.rpt = reflect_t; a.rpl = reflect_l; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.pad_t = pad_t; a.pad_l = pad_l;
+    a.out_ld = out_ld; a.shadow_ld = shadow_ld; a.M = (int)M; a.div = div; a.sub = sub; a.alpha = alpha; a.raw_bytes = (unsigned)rb;
+    hipLaunchKernelGGL(conv_image_fwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    mh_note_kernel("conv_image_fwd_kernel<3,16,s%d> grid %d", stride, (int)((M + 255) / 256));
+    return mh_check_launch("conv_image_fwd");
+}

@@ -213,6 +213,9 @@ static int run_op(const mh_op& o, void* s) {
             mh_conv_desc d; desc_from_op(o, d);
             return mh_conv2d_planes_bwd(&d, p[0], i[23], p[1], p[2], i[24], (float*)p[3], p[4], i[25], s);
         }
+        case MH_OP_CONV_IMAGE:       // i: NB H0 W0 C Hp Wp reflect_t reflect_l N stride pad_t pad_l out_ld shadow_ld ; f: div sub alpha ; p: frames w bias out shadow
+            return mh_conv_image_fwd((const float*)p[0], i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7], o.f[0], o.f[1], (const float*)p[1], (const float*)p[2], i[8], i[9], i[10],
+                                     i[11], o.f[2], (float*)p[3], i[12], p[4], i[13], s);
         case MH_OP_DET_FLUSH:        // p: dst, twin ; n
             return mh_det_flush((float*)p[0], p[1], o.n, s);
         case MH_OP_STAMP:

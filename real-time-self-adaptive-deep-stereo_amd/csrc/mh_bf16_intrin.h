@@ -66,5 +66,9 @@ __device__ __forceinline__ void mh_glds16(const mh_dma_src& r, void* lds_wave_ba
 // keeps an integer in a VGPR as computed (an optimisation barrier on one value): a select between it and a constant then stays a v_cndmask instead of a
 // branch around the arithmetic that produced it (a branch near outstanding loads makes hipcc's waitcnt pass drain them at the join)
 #define MH_KEEP_VGPR(x) asm volatile("" : "+v"(x))
+// a read-only global pointer as a CONSTANT-address-space pointer: loads at wave-uniform addresses through it are scalar loads (s_load_dword*) whose results
+// feed v_fmac as SGPR operands -- a filter bank read by every lane alike costs no vector-memory instruction at all
+typedef const __attribute__((address_space(4))) float MH_CONST_F32;
+#define MH_CONST_F32_PTR(p) ((MH_CONST_F32*)(p))
 #define MH_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define MH_WAIT_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")

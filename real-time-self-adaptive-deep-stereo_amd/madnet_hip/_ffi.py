@@ -31,7 +31,7 @@ class Op(C.Structure):
 (OP_CONV, OP_WGRAD, OP_CORR_FWD, OP_CORR_BWD, OP_WARP_FWD, OP_WARP_BWD, OP_RESIZE_FWD, OP_RESIZE_BWD,
  OP_PAD_REFLECT, OP_LOSS, OP_METRICS, OP_MOMENTUM, OP_COPY_CH, OP_LEAKY_BWD, OP_FILL, OP_BIAS_GRAD,
  OP_WGRAD_PARTIAL, OP_WGRAD_REDUCE, OP_PROXY_LOSS, OP_SUPERVISED_LOSS, OP_ADAM, OP_ADAM_ADVANCE, OP_RESIZE_IMAGE, OP_LEVEL_FRONT, OP_RESERVED_25, OP_PACK_W, OP_CORR_WARP_BWD,
- OP_SHADOW_CAST, OP_WGRAD_STREAM, OP_HEAD_BWD, OP_HEAD_FWD, OP_CONV_PLANES, OP_PLANE_SPLIT, OP_STAMP, OP_CONV_PLANES_BWD, OP_DET_FLUSH) = range(1, 37)
+ OP_SHADOW_CAST, OP_WGRAD_STREAM, OP_HEAD_BWD, OP_HEAD_FWD, OP_CONV_PLANES, OP_PLANE_SPLIT, OP_STAMP, OP_CONV_PLANES_BWD, OP_DET_FLUSH, OP_CONV_IMAGE) = range(1, 38)
 
 
 OP_JOIN = 0x100
@@ -129,6 +129,8 @@ SIGNATURES = {
     "mh_level_front_fwd_planes": (_I, [_P, _I, _I, _F, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "mh_level_front_head_fwd": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _F, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "mh_level_front_head_ok": (_I, [_I, _I, _I, _I, _I, _I, _I]),
+    "mh_conv_image_fwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P, _I, _I, _I, _I, _F, _P, _I, _P, _I, _P]),
+    "mh_conv_image_ok": (_I, [_I, _I, _I, _I, _I]),
     "mh_conv2d_head": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     "mh_head_bwd": (_I, [C.POINTER(HeadBwdDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mh_wgrad_stream_plan": (_I, [C.POINTER(WgsLayer), _I, _I, _I, C.POINTER(C.c_int32)]),
@@ -183,7 +185,7 @@ SIGNATURES = {
     "mh_event_destroy": (_I, [_P]),
     "mh_stream_sync": (_I, [_P]),
 }
-_NO_STATUS = {"mh_level_front_head_ok", "mh_deterministic_ranges", "mh_planes_kc16", "mh_conv2d_planes_bwd_ok", "mh_stamp_rate_khz", "mh_pack32_bytes", "mh_conv2d_planes_ok", "mh_tune_conv_planes", "mh_tune_wgrad_target_pct", "mh_tune_wgrad_image", "mh_conv2d_takes_shadows", "mh_tune_conv_bank_tile", "mh_tune_conv_rows", "mh_last_error", "mh_last_kernel", "mh_tune_conv_bank", "mh_pack_bytes", "mh_abi_version", "mh_tune_conv_patch", "mh_crc32c", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats", "mh_proxy_ws_floats"}
+_NO_STATUS = {"mh_conv_image_ok", "mh_level_front_head_ok", "mh_deterministic_ranges", "mh_planes_kc16", "mh_conv2d_planes_bwd_ok", "mh_stamp_rate_khz", "mh_pack32_bytes", "mh_conv2d_planes_ok", "mh_tune_conv_planes", "mh_tune_wgrad_target_pct", "mh_tune_wgrad_image", "mh_conv2d_takes_shadows", "mh_tune_conv_bank_tile", "mh_tune_conv_rows", "mh_last_error", "mh_last_kernel", "mh_tune_conv_bank", "mh_pack_bytes", "mh_abi_version", "mh_tune_conv_patch", "mh_crc32c", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats", "mh_proxy_ws_floats"}
 
 
 class MadnetHipError(RuntimeError):

@@ -279,7 +279,7 @@ OP_KERNEL_NAMES = {
     "OP_HEAD_BWD": "head_bwd_kernel (disparity head: output gradient + 3x3 Cin->1 input gradient)", "OP_HEAD_FWD": "conv_n1_fwd_kernel (disparity head with extra destinations)",
     "OP_PLANE_SPLIT": "plane_split_kernel (hi / lo bf16 planes + fused concat)", "OP_STAMP": "stamp_kernel", "OP_DET_FLUSH": "det_flush_kernel",
 }
-_REPORTING = ("OP_CONV", "OP_WGRAD", "OP_WGRAD_PARTIAL", "OP_WGRAD_STREAM", "OP_CORR_FWD", "OP_CORR_BWD", "OP_LEVEL_FRONT", "OP_CORR_WARP_BWD", "OP_CONV_PLANES",
+_REPORTING = ("OP_CONV", "OP_WGRAD", "OP_WGRAD_PARTIAL", "OP_WGRAD_STREAM", "OP_CORR_FWD", "OP_CORR_BWD", "OP_LEVEL_FRONT", "OP_CORR_WARP_BWD", "OP_CONV_PLANES", "OP_CONV_IMAGE",
               "OP_CONV_PLANES_BWD")
 
 
@@ -413,6 +413,10 @@ def op_work(op):
         B, H, W, Cc, md, st = op.i[8], op.i[9], op.i[10], op.i[11], op.i[12], op.i[13]
         D = 2 * md // max(st, 1) + 1
         return 4.0 * B * H * W * Cc * D, 4.0 * B * H * W * (8 * Cc + D + 3)        # reads g (C + D + 1), L, Rw, the right features, u, dL, dimg; writes dL, dimg, du
+    if op.kind == _ffi.OP_CONV_IMAGE:
+        NB, H0, W0, Cc, Hp, Wp, N, st = op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[8], op.i[9]
+        Ho, Wo = (Hp + st - 1) // st, (Wp + st - 1) // st
+        return 2.0 * NB * Ho * Wo * 9 * Cc * N, 4.0 * (NB * H0 * W0 * Cc + NB * Ho * Wo * N + 9 * Cc * N) + (2.0 * NB * Ho * Wo * N if op.p[4] else 0.0)
     if op.kind == _ffi.OP_LEVEL_FRONT:
         B, H, W, Cc, md = op.i[7], op.i[8], op.i[9], op.i[10], op.i[11]
         D = 2 * md + 1

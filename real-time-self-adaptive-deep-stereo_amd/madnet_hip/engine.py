@@ -392,8 +392,10 @@ class MadNetEngine(ElisionPasses, BackwardRecorder):
         ops.conv2d_fwd(lib, x, self.W_(base), self.b_(base), o, stride=stride, dil=dil, alpha=alpha,
                        wb=self.Wb_(base), precision=precision, shadow=sh)
 
-    def record_forward(self, r, make_disps=()):
+    def record_forward(self, r, make_disps=(), need_x0=True):
+        """need_x0 = False: nothing of the plan reads the padded frames X0 after the forward pass (no backward pass): with Schedule.IMAGE_CONV they are not written"""
         B, lib = self.B, r
+        self._x0_pending = False
         head2_fused = False
         pending_head = None
         self._fresh_planes = set()
@@ -415,10 +417,26 @@ class MadNetEngine(ElisionPasses, BackwardRecorder):
             finally:
                 if side_pack:
                     lib.lane = 0
-        ops.pad_reflect(lib, self.lr, self.X0, self.pt, self.pl)
+        image_conv = (self.sched.IMAGE_CONV and hasattr(self.lib, "conv_image_ok") and self.lib.conv_image_ok(PYR[0][0], PYR[0][1], 3, 3, PYR[0][2]) == 1)
+        if image_conv:
+            # the padded copy: only conv1's filter gradient reads it (need_x0: the plan has a backward pass) -- off the chain, on lane 1 when there is one
+            if need_x0:
+                # ONE filter-gradient lane + the side reductions of the loss: the padding launch rides on lane 1 in front of those (record_loss_metrics) -- no fork
+                # edge of its own (a fork at the head of the step cost lane 0 most of what the launch gave back: r05_experiments.txt #15), and conv1's filter
+                # gradient runs on that lane, behind it.  Any other lane layout: in line, as before.
+                self._x0_pending = bool(hasattr(lib, "lane") and self.wgrad_lanes == 1 and self.sched.SIDE_LOSS and self.loss_kind != "proxy" and not self.sched.TAIL_SPLIT)
+                if not self._x0_pending:
+                    ops.pad_reflect(lib, self.lr, self.X0, self.pt, self.pl)
+        else:
+            ops.pad_reflect(lib, self.lr, self.X0, self.pt, self.pl)
         x = ops.View(self.X0, 2 * B, self.Hp, self.Wp, 3, 4)
         for i, (ci, co, s) in enumerate(PYR, 1):
             o = self._fv(self.F[i])
+            if i == 1 and image_conv:
+                ops.conv_image_fwd(lib, self.lr, self.Hp, self.Wp, self.pt, self.pl, self.W_(pyr_name(1)), self.b_(pyr_name(1)), o, stride=s, alpha=ALPHA,
+                                   shadow=self._out_shadow(o, pyr_name(2)))
+                x = o
+                continue
             if i == 2 and self.use_bank and self.sched.PACK_SIDE and hasattr(lib, "lane") and self.wgrad_lanes > 0:
                 lib.join_lanes_next = 1 << 1                  # conv1 (3 input channels) never has a bank: every later layer waits for the packing
             # F_i is the input of layer i + 1 (stride 1 or 2: both streamed)
@@ -580,10 +598,18 @@ class MadNetEngine(ElisionPasses, BackwardRecorder):
         """MadNet._make_disp (MadNet.py:68-71): crop(resize(relu(-20 V)))."""
         ops.resize_fwd(lib, V, out, self.Hp, self.Wp, self.pt, self.pl, mul=-20.0, mode=1)
 
+    def _flush_x0(self, r):
+        """Schedule.IMAGE_CONV: the padding launch record_forward held back (it goes onto lane 1 with the loss reductions); called with the lane it should run on"""
+        if getattr(self, "_x0_pending", False):
+            ops.pad_reflect(r, self.lr, self.X0, self.pt, self.pl)
+            self._x0_pending = False
+
     def record_loss_metrics(self, r, with_grad):
         """full-resolution reprojection loss (Stereo_Online_Adaptation.py:70) -- or, loss_kind 'proxy', the proxy-label
         mean_l1 of the continual variant (Stereo_Continual_Adaptation.py:75, weight 0.01) -- + EPE/bad3 (:74-82)."""
         side = self.sched.SIDE_LOSS and self.wgrad_lanes > 0 and hasattr(r, "lane")
+        if not side:
+            self._flush_x0(r)
         if self.loss_kind == "proxy":
             ops.proxy_loss(r, self.pred, self.proxy, self.proxy_ws, self.res_loss, self.dpred if with_grad else None, weight=0.01)
         elif side:
@@ -598,6 +624,7 @@ class MadNetEngine(ElisionPasses, BackwardRecorder):
             r.lane = 1
             try:
                 self._stamp(r, "side_lane_first_op")
+                self._flush_x0(r)               # (the padded frames: read by conv1's filter gradient only, on this lane, at the far end of the step)
                 if self.loss_kind != "proxy":
                     ops.reprojection_loss(r, self.left, self.right, self.pred, self.loss_ws, self.res_loss, None, phase=2)
                 ops.metrics(r, self.pred, self.gt, self.met_ws, self.res_met, 3.0)
@@ -731,6 +758,7 @@ class MadNetEngine(ElisionPasses, BackwardRecorder):
         tv = self.all_vars()
         if part in ("all", "grad"):
             self.record_forward(r, make_disps=tuple(LEVELS))
+            self._flush_x0(r)
             order = ["final"] + sorted(LEVELS)                      # disparities[-1], [-2] (context), [-3] (level 3) ... [-6] (level 6)
             heads = {}
             for i, hd in enumerate(order):
@@ -761,7 +789,7 @@ class MadNetEngine(ElisionPasses, BackwardRecorder):
         do_upd = update and part in ("all", "update")
         if mode == "NONE":
             if do_grad:
-                self.record_forward(r)
+                self.record_forward(r, need_x0=False)
                 self.record_loss_metrics(r, with_grad=False)
         elif mode == "FULL":
             tv = self.all_vars()
@@ -808,6 +836,7 @@ class MadNetEngine(ElisionPasses, BackwardRecorder):
         else:
             raise ValueError("unknown mode %r" % (mode,))
         self._stamp(r, "end")
+        assert not getattr(self, "_x0_pending", False), "the padding launch record_forward held back was never recorded"
         self._elide_fp32_gradient_maps(r)
         self._elide_fp32_activations(r)
         return r.compile_parts() if part == "grad_split" else r.compile()

@@ -664,6 +664,18 @@ def resize_image(lib, x, out, stream=None):
     lib.resize_image_fwd(_p(x), _p(out), B, H, W, Cc, out.shape[1], out.shape[2], _p(stream))
 
 
+def conv_image_fwd(lib, frames, Hp, Wp, reflect_t, reflect_l, w, bias, out, stride=2, alpha=1.0, div=1.0, sub=0.0, shadow=None, stream=None):
+    """out = leaky(conv3x3(reflect_pad(frames / div - sub), w) + bias) from the frames themselves (mh_conv_image_fwd): frames [NB,H0,W0,3] tensor, out a View
+    [NB,ceil(Hp/stride),ceil(Wp/stride),16]; shadow: the Shadow of `out` the launch writes too."""
+    NB, H0, W0, Cc = frames.shape
+    kh, kw, cin, cout = w.shape
+    assert (kh, kw, cin) == (3, 3, Cc) and cout == out.C
+    Ho, Wo, pt, pl = conv_geometry(Hp, Wp, 3, 3, stride, 1)
+    assert (out.B, out.H, out.W) == (NB, Ho, Wo)
+    lib.conv_image_fwd(_p(frames), NB, H0, W0, Cc, Hp, Wp, reflect_t, reflect_l, div, sub, _p(w), _p(bias), cout, stride, pt, pl, alpha, _p(out), out.ld,
+                       (C.c_void_p(shadow.ptr) if shadow is not None else None), (shadow.ld if shadow is not None else 0), _p(stream))
+
+
 def pad_reflect(lib, x, out, pad_t, pad_l, div=1.0, sub=0.0, stream=None):
     """out = reflect_pad(x / div - sub).  x: [B,H,W,C] tensor; out: [B,Hp,Wp,out_ld] tensor."""
     B, H, W, Cc = x.shape

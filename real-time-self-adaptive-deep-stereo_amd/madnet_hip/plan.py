@@ -199,6 +199,9 @@ class Recorder(object):
     def level_front_fwd_planes(self, Vc, Hc, Wc, mul, L, l_ld, R, r_ld, out, out_ld, coff, Rw, rw_ld, u, B, H, W, Cc, md, zero_tail, out_hi, out_lo, out_pld, stream):
         self._op(_ffi.OP_LEVEL_FRONT, [Hc, Wc, l_ld, r_ld, out_ld, coff, rw_ld, B, H, W, Cc, md, zero_tail, out_pld], [mul], [Vc, L, R, out, Rw, u, out_hi, out_lo])
 
+    def conv_image_fwd(self, frames, NB, H0, W0, Cc, Hp, Wp, rpt, rpl, div, sub, w, bias, N, stride, pad_t, pad_l, alpha, out, out_ld, shadow, shadow_ld, stream):
+        self._op(_ffi.OP_CONV_IMAGE, [NB, H0, W0, Cc, Hp, Wp, rpt, rpl, N, stride, pad_t, pad_l, out_ld, shadow_ld], [div, sub, alpha], [frames, w, bias, out, shadow])
+
     def level_front_head_fwd(self, X, x_ld, K, hw, hb, Vc, Hc, Wc, mul, L, l_ld, R, r_ld, out, out_ld, coff, Rw, rw_ld, u, B, H, W, Cc, md, zero_tail, out_hi, out_lo, out_pld,
                              stream):
         self._op(_ffi.OP_LEVEL_FRONT, [Hc, Wc, l_ld, r_ld, out_ld, coff, rw_ld, B, H, W, Cc, md, zero_tail, out_pld, x_ld, K], [mul],

@@ -40,7 +40,11 @@ class Schedule(object):
     FUSE_HEAD: bool = True
     # the disparity heads of levels 6 .. 3 run INSIDE the next level's front-end launch (mh_level_front_head_fwd) instead of as launches of their own in front
     # of it: four 4.5 - 5 us nodes off the forward chain (r05_experiments.txt #11)
-    HEAD_IN_FRONT: bool = True
+    HEAD_IN_FRONT: bool = field(default_factory=_env_flag("MH_HEAD_IN_FRONT", "1"))
+    # conv1 (3 -> 16, stride 2) runs straight from the frames through the reflection (mh_conv_image_fwd: exact fp32, one thread per output pixel) instead of
+    # mh_pad_reflect + the row-streaming kernel: 29 us -> ~10 us at the head of the forward chain.  The padded copy X0 is then only read by conv1's filter
+    # gradient at the far end of the step: its padding launch leaves on lane 1 (or not at all when the plan has no backward pass)
+    IMAGE_CONV: bool = field(default_factory=_env_flag("MH_IMAGE_CONV", "1"))
     # FULL momentum steps: every filter-gradient batch is followed by the momentum update of its layers on its own lane, the launch behind the join
     # covers only what is left.  Measured worse together with the tail split (r04 #17)
     EARLY_UPDATE: bool = False

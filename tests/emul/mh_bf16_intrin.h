@@ -94,5 +94,7 @@ static inline void mh_glds16(const mh_dma_src& r, void* lds_wave_base, int voff)
     if ((unsigned long long)off + 16ull <= r.bytes) memcpy(dst, r.base + off, 16); else memset(dst, 0, 16);
 }
 #define MH_KEEP_VGPR(x) do { } while (0)
+typedef const float MH_CONST_F32;
+#define MH_CONST_F32_PTR(p) ((MH_CONST_F32*)(p))
 #define MH_WAIT_VMCNT(n) do { } while (0)
 #define MH_WAIT_LGKMCNT0() do { } while (0)

@@ -167,6 +167,41 @@ def test_pad_reflect(backend):
     assert torch.all(out.cpu()[..., 3] == 0)
 
 
+@pytest.mark.parametrize("case", [(2, 11, 14, 8, 2, 1.0, 0.0), (2, 41, 37, 64, 2, 1.0, 0.0), (1, 30, 23, 16, 1, 1.0, 0.0), (2, 13, 18, 8, 2, 255.0, 100.0 / 255), (4, 60, 100, 64, 2, 1.0, 0.0)])
+def test_conv_image_fwd_from_the_frames(backend, case):
+    """mh_conv_image_fwd (conv1 straight from the frames through the reflection, MadNet.py:56-60 after Stereo_net._preprocess_inputs -> pad_image) == the oracle's
+    pad_image + conv2d(stride) + leaky, and == mh_pad_reflect + mh_conv2d_fwd (exact fp32) -- padded sizes that are odd / even (the SAME padding of a stride-2
+    layer sits at the END of an even frame), reflection depths up to the frame size - 1, the x / div - sub preprocessing, the bf16 shadow, NaN canaries."""
+    NB, H0, W0, factor, stride, div, sub = case
+    dev, lib = backend.device, backend.lib
+    g = torch.Generator().manual_seed(11)
+    frames = torch.floor(torch.rand(NB, H0, W0, 3, generator=g) * 256).to(dev)
+    w = _rand((3, 3, 3, 16), 12, dev, 0.3); b = _rand((16,), 13, dev)
+    xp = T.pad_image((frames.cpu() / div - sub) if (div != 1.0 or sub != 0.0) else frames.cpu(), factor)
+    Hp, Wp = xp.shape[1], xp.shape[2]
+    pt, pl = (Hp - H0) // 2, (Wp - W0) // 2
+    ref = T.conv2d(xp, w.cpu(), b.cpu(), stride, 1, 0.2)
+    Ho, Wo = ref.shape[1], ref.shape[2]
+    out = torch.full((NB, Ho, Wo, 16), float("nan"), device=dev)
+    sh = ops.Shadow(NB, Ho, Wo, 16, dev)
+    assert lib.conv_image_ok(3, 16, 3, 3, stride) == 1 and lib.conv_image_ok(4, 16, 3, 3, 2) == 0 and lib.conv_image_ok(3, 32, 3, 3, 2) == 0
+    ops.conv_image_fwd(lib, frames, Hp, Wp, pt, pl, w, b, ops.view(out), stride=stride, alpha=0.2, div=div, sub=sub, shadow=sh)
+    assert "conv_image_fwd_kernel" in lib.last_kernel().decode()
+    # the two launches it replaces, exact fp32
+    x0 = torch.zeros(NB, Hp, Wp, 4, device=dev)
+    ops.pad_reflect(lib, frames, x0, pt, pl, div=div, sub=sub)
+    out2 = torch.full((NB, Ho, Wo, 16), float("nan"), device=dev)
+    ops.conv2d_fwd(lib, ops.View(x0, NB, Hp, Wp, 3, 4), w, b, ops.view(out2), stride=stride, alpha=0.2, precision=0)
+    backend.sync()
+    o = out.cpu()
+    assert torch.isfinite(o).all()
+    scale = max(1.0, ref.abs().max().item())
+    assert (o - ref).abs().max().item() <= 2e-6 * scale, (o - ref).abs().max().item()
+    assert (o - out2.cpu()).abs().max().item() <= 2e-6 * scale
+    shv = sh.t.float().cpu()
+    assert torch.equal(shv[..., :16], o.to(torch.bfloat16).float()) and torch.all(shv[..., 16:] == 0)
+
+
 @pytest.mark.parametrize("shape", [(1, 9, 14), (2, 12, 21)])
 def test_reprojection_loss_and_grad(backend, shape):
     B, H, W = shape
