@@ -379,18 +379,35 @@ __global__ __launch_bounds__(256) void conv_image_fwd_kernel(ImageConvArgs p) {
 #pragma unroll
             for (int n = 0; n < N; ++n) acc[n] += xv[t][c] * wr[n];
         }
-    if (!live) return;
 #pragma unroll
     for (int n = 0; n < N; ++n) acc[n] = (p.alpha == 1.0f || acc[n] > 0.f) ? acc[n] : p.alpha * acc[n];
-    float* const o = p.out + (int64_t)m * p.out_ld;
+    // The results leave through LDS: a thread holds the 64 bytes of ITS pixel, so a 16-byte store instruction would touch 64 lines with a quarter line each.
+    // Transposed, consecutive lanes write consecutive 16 bytes: four fully coalesced 1 KB stores per wave (and two for the shadow).
+    __shared__ __attribute__((aligned(16))) float so[256 * 20];           // [thread][16 + 4 pad]: 80-byte rows keep the float4 writes of 8 neighbours on distinct banks
+    const int tid = threadIdx.x;
 #pragma unroll
-    for (int q = 0; q < N / 4; ++q) *reinterpret_cast<float4*>(o + 4 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    for (int q = 0; q < N / 4; ++q) *reinterpret_cast<float4*>(so + tid * 20 + 4 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    __syncthreads();
+    const int m0 = blockIdx.x * 256;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = j * 256 + tid;                 // (pixel of the workgroup, channel quad): consecutive lanes = consecutive 16 bytes of out
+        const int pl = e >> 2, q = e & 3;
+        const float4 v = *reinterpret_cast<const float4*>(so + pl * 20 + 4 * q);
+        const int mo = m0 + pl;
+        if (mo < p.M) *reinterpret_cast<float4*>(p.out + (int64_t)mo * p.out_ld + 4 * q) = v;
+    }
     if (p.shadow) {
-        unsigned short* const sh = p.shadow + (int64_t)m * p.shadow_ld;
 #pragma unroll
-        for (int q = 0; q < N / 8; ++q)
-            *reinterpret_cast<u32x4*>(sh + 8 * q) = (u32x4){mh_pack_bf16(acc[8 * q], acc[8 * q + 1]), mh_pack_bf16(acc[8 * q + 2], acc[8 * q + 3]),
-                                                            mh_pack_bf16(acc[8 * q + 4], acc[8 * q + 5]), mh_pack_bf16(acc[8 * q + 6], acc[8 * q + 7])};
+        for (int j = 0; j < 2; ++j) {
+            const int e = j * 256 + tid;             // (pixel, channel octet)
+            const int pl = e >> 1, q = e & 1;
+            const float4 a = *reinterpret_cast<const float4*>(so + pl * 20 + 8 * q), b2 = *reinterpret_cast<const float4*>(so + pl * 20 + 8 * q + 4);
+            const int mo = m0 + pl;
+            if (mo < p.M)
+                *reinterpret_cast<u32x4*>(p.shadow + (int64_t)mo * p.shadow_ld + 8 * q) =
+                    (u32x4){mh_pack_bf16(a.x, a.y), mh_pack_bf16(a.z, a.w), mh_pack_bf16(b2.x, b2.y), mh_pack_bf16(b2.z, b2.w)};
+        }
     }
 }
 }  // namespace
