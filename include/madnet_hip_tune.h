@@ -20,7 +20,7 @@ int mh_tune_wgrad_wgs(int target_workgroups);
 int mh_tune_wgrad_target_pct(int pct);   /* scale (percent) of the filter-gradient pixel-split workgroup targets for the split counts resolved from now on (a plan stores the counts it was recorded with); 0 = default.  Returns the PREVIOUS value (NOT a status code) so that a caller can scope the setting: DispNet's engine records with 150 under a process-wide lock and restores what it found */
 int mh_tune_wgrad_image(int on);        /* image-layer filter-gradient kernel (3x3, Cin <= 3, Cout = 16, bf16; wgrad.hip): 0 = off (default: not yet timed on the GPU), 1 = on, > 1 = on with this many workgroups; returns the previous setting */
 int mh_tune_wgrad_stream(int dist);     /* prefetch distance (row groups in flight) of the streaming filter-gradient kernel: 1 or 2, 0 = default */
-int mh_tune_corr(int direct);
+int mh_tune_corr(int direct);            /* bit 0 (default SET): the direct small-D kernels; bit 1: plain instead of XCD-aware workgroup order of the large-D kernels; bit 2: the large-D bf16 gradient as two launches; bit 3: one fine row per workgroup in mh_level_front_head_fwd (default: two, when H = 2 Hc).  Default state = mh_tune_corr(1) */
 int mh_tune_corr_row(int on);            /* backward front end of a pyramid level (mh_corr_warp_bwd): 1 = row-owned form, the warp-gradient scatter on an LDS copy of the row, the row's operands staged in LDS (default), 3 = row-owned without the operand staging, 0 = the global-atomic form */
 
 int mh_tune_conv_planes(int mode);       /* pre-split-operand forward kernel (mh_conv2d_planes): bits 0-3 = tile variant (0 = heuristic), bit 8 = skip the K walk, bit 9 = skip the patch staging, bit 12 = skip the epilogue, bit 13 = epilogue without its stores (timing experiments: scripts/microbench.py phases); returns the number of launches of the plane kernels since the previous call */

@@ -175,7 +175,7 @@ struct FrontArgs {
     unsigned l_bytes, r_bytes;
     unsigned short* out_hi; unsigned short* out_lo; int out_pld;      // != null: the estimator input also leaves as bf16 planes (hi [+ lo])
     // HEAD instances (mh_level_front_head_fwd): Vc is an OUTPUT -- the coarser level's disparity head (3x3, K -> 1, linear) runs in this launch
-    const float* X; const float* hw; const float* hb; float* Vw; int x_ld, K, segs, cwcap; unsigned x_bytes;
+    const float* X; const float* hw; const float* hb; float* Vw; int x_ld, K, segs, cwcap, rows2, rowpairs; unsigned x_bytes;
 };
 
 // HEAD (round 5, mh_level_front_head_fwd): the disparity head of the COARSER level -- Vc = conv3x3(X, hw) + hb, 32 -> 1 channels, linear (MadNet.py:118) -- is
@@ -197,11 +197,23 @@ __global__ __launch_bounds__(256) void level_front_kernel(FrontArgs p) {
     const __amdgpu_buffer_rsrc_t rsR = mh_make_rsrc(p.R, p.r_bytes);
     int pix;
     bool live;
+    const int wg = (int)blockIdx.x;              // (an XCD-aware order -- bands of rows per XCD -- measured no better: r05_experiments.txt #17)
     if constexpr (HEAD) {
-        const int seg = blockIdx.x % p.segs, rowi = blockIdx.x / p.segs;
-        const int xx = seg * PPB + tid / LPP;
-        live = xx < p.W;
-        pix = rowi * p.W + (live ? xx : 0);
+        const int seg = wg % p.segs, rowi = wg / p.segs;
+        if (p.rows2) {
+            // H = 2 Hc: the fine rows 2r and 2r + 1 interpolate from the SAME two coarse rows -- a workgroup takes PPB / 2 columns of both, and the head values it
+            // has to compute (2 x its coarse columns) drop by a third (r05_experiments.txt #17)
+            constexpr int HALF = PPB / 2;
+            const int rp = rowi % p.rowpairs, bb = rowi / p.rowpairs;
+            const int j = tid / LPP, r = j >= HALF ? 1 : 0;
+            const int xx = seg * HALF + (j - r * HALF);
+            live = xx < p.W;
+            pix = (bb * p.H + 2 * rp + r) * p.W + (live ? xx : 0);
+        } else {
+            const int xx = seg * PPB + tid / LPP;
+            live = xx < p.W;
+            pix = rowi * p.W + (live ? xx : 0);
+        }
     } else {
         pix = blockIdx.x * PPB + tid / LPP;
         live = pix < npix;
@@ -221,8 +233,9 @@ __global__ __launch_bounds__(256) void level_front_kernel(FrontArgs p) {
     if constexpr (HEAD) {
         // (y, b and hence y0 / y1 are workgroup-uniform: one row per workgroup)
         const int G4 = p.K >> 2;
-        const int xs0 = (blockIdx.x % p.segs) * PPB;
-        const int flo = max(xs0 - p.md, 0), fhi = min(xs0 + PPB - 1 + p.md, p.W - 1);
+        const int wpx = p.rows2 ? PPB / 2 : PPB;             // columns of this workgroup
+        const int xs0 = (wg % p.segs) * wpx;
+        const int flo = max(xs0 - p.md, 0), fhi = min(xs0 + wpx - 1 + p.md, p.W - 1);
         c_lo = (int)((float)flo * p.sx);
         const int c_hi = min((int)((float)fhi * p.sx) + 1, p.Wc - 1);
         const int cw = c_hi - c_lo + 1;                     // <= cwcap (the launcher's bound)
@@ -1524,12 +1537,13 @@ int mh_corr_init() {
 static std::atomic<int> g_corr_direct{1};
 // mh_tune_corr_row: 1 (default) = row-owned backward front end with the row's operands staged in LDS, 3 = row-owned, operands from L1 / L2, 0 = the global-atomic form
 static std::atomic<int> g_corr_row{1};
+static std::atomic<int> g_front_rows2{1};            // level front end with the head inside: two fine rows per workgroup (mh_tune_corr bit 3 clears it: one row)
 static std::atomic<int> g_corr_pair{1};              // large-D bf16 gradient: both directions in one grid (mh_tune_corr bit 2 clears it: two launches)
 static std::atomic<int> g_corr_remap{1};             // XCD-aware workgroup order of the large-D bf16 kernels (mh_tune_corr bit 1 clears it)
 static std::atomic<int> g_corr_det_ranges{0};        // how many deterministic ranges are registered (mh_det_sync_corr keeps it in step)
 extern "C" int mh_tune_corr_row(int on) { g_corr_row = on; return 0; }
 // tuning hook: 0 = LDS-staged window kernel, 1 = direct (no LDS) kernel for D <= 9
-extern "C" int mh_tune_corr(int direct) { g_corr_direct = direct & 1; g_corr_remap = (direct & 2) ? 0 : 1; g_corr_pair = (direct & 4) ? 0 : 1; return 0; }
+extern "C" int mh_tune_corr(int direct) { g_corr_direct = direct & 1; g_corr_remap = (direct & 2) ? 0 : 1; g_corr_pair = (direct & 4) ? 0 : 1; g_front_rows2 = (direct & 8) ? 0 : 1; return 0; }
 
 extern "C" int mh_corr_fwd(const float* L, int32_t l_ld, const float* R, int32_t r_ld, const float* u,
                            float* out, int32_t out_ld, int32_t coff,
@@ -1665,7 +1679,7 @@ static int level_front_launch(const float* X, int32_t x_ld, int32_t K, const flo
     a.B = B; a.H = H; a.W = W; a.C = C; a.md = max_disp; a.D = D; a.zero_tail = zero_tail;
     a.l_bytes = (unsigned)lb; a.r_bytes = (unsigned)rb;
     a.out_hi = (unsigned short*)out_hi; a.out_lo = (unsigned short*)out_lo; a.out_pld = out_pld;
-    a.X = nullptr; a.hw = nullptr; a.hb = nullptr; a.Vw = nullptr; a.x_ld = 0; a.K = 0; a.segs = 0; a.cwcap = 0; a.x_bytes = 0;
+    a.X = nullptr; a.hw = nullptr; a.hb = nullptr; a.Vw = nullptr; a.x_ld = 0; a.K = 0; a.segs = 0; a.cwcap = 0; a.x_bytes = 0; a.rows2 = 0; a.rowpairs = 0;
     hipStream_t s = (hipStream_t)stream;
     const int C4 = C / 4;
     const int lpp = C4 <= 4 ? 4 : (C4 <= 8 ? 8 : 16);
@@ -1678,10 +1692,13 @@ static int level_front_launch(const float* X, int32_t x_ld, int32_t K, const flo
         MH_REQUIRE(xb < (1ll << 31) - 64, MH_ERR_UNSUPPORTED, "mh_level_front_head_fwd: X must be < 2 GiB");
         a.X = X; a.hw = hw; a.hb = hb; a.Vw = const_cast<float*>(Vc); a.x_ld = x_ld; a.K = K; a.x_bytes = (unsigned)xb;
         const int ppb = 256 / lpp;
-        a.segs = mh_cdiv(W, ppb);
-        a.cwcap = front_head_cwcap(Wc, W, ppb, max_disp);
+        a.rows2 = (H == 2 * Hc && g_front_rows2.load(std::memory_order_relaxed)) ? 1 : 0;
+        const int wpx = a.rows2 ? ppb / 2 : ppb;
+        a.rowpairs = H / 2;
+        a.segs = mh_cdiv(W, wpx);
+        a.cwcap = front_head_cwcap(Wc, W, wpx, max_disp);
         const size_t lds = ((size_t)4 * (a.cwcap + 2) * K + 9 * K + 2 * a.cwcap) * sizeof(float);
-        const dim3 g((unsigned)((int64_t)a.segs * B * H));
+        const dim3 g((unsigned)((int64_t)a.segs * B * (a.rows2 ? H / 2 : H)));
 #define MH_FRONTH(LPPv)                                                                                                      \
     { if (D <= 5) hipLaunchKernelGGL((level_front_kernel<LPPv, 5, true>), g, dim3(256), lds, s, a);                          \
       else hipLaunchKernelGGL((level_front_kernel<LPPv, MAXD_SMALL, true>), g, dim3(256), lds, s, a); }

@@ -471,6 +471,17 @@ def test_level_front_with_the_coarser_head_inside(backend, case):
     assert torch.equal(out1[..., :C].cpu(), L.cpu()) and torch.equal(out1[..., C + D].cpu(), u1.cpu())
     assert torch.all(out1[..., C + D + 1:].cpu() == 0)
     assert (out1[..., C:C + D].cpu() - out0[..., C:C + D].cpu()).abs().max().item() <= 1e-5 + 32.0 * du
+    if H == 2 * Hc:
+        # the default instance gave two fine rows to a workgroup; one row per workgroup (mh_tune_corr bit 3) must store the same bits
+        lib.tune_corr(1 | 8)
+        try:
+            V2 = torch.full((B, Hc, Wc), float("nan"), device=dev); u2 = torch.empty(B, H, W, device=dev); Rw2 = torch.empty(B, H, W, C, device=dev)
+            out2 = torch.full((B, H, W, ld), float("nan"), device=dev)
+            ops.level_front_head_fwd(lib, ops.view(X), hw, hb, V2, mul, ops.view(L), ops.view(R), ops.View(out2, B, H, W, ld, ld), ops.view(Rw2), u2, md, coff=C)
+            backend.sync()
+        finally:
+            lib.tune_corr(1)
+        assert torch.equal(V2.cpu(), v1) and torch.equal(u2.cpu(), u1.cpu()) and torch.equal(out2.cpu(), out1.cpu()) and torch.equal(Rw2.cpu(), Rw1.cpu())
     # the planes: hi + lo of what the launch stored in fp32
     hi = pl.hi.t.float().cpu()[..., :C + D + 1]
     lo = pl.lo.t.float().cpu()[..., :C + D + 1]
