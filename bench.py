@@ -972,6 +972,10 @@ def main():
                 bs = box_sampler.summary()
                 if bs:
                     out["box"].update(bs)
+                # (round 5, profiles/r05_bench_line_slow_box.json: the slow box drew 436 W before the run and 662 W during the replay -- healthy ones 250 - 300 W --
+                #  with the core clock reported at 2344 MHz: the number to look at beside the ratio is the power, not the clock)
+                r_ = out["box"]["replay_over_launch_sum"]
+                out["box"]["healthy"] = None if r_ is None else bool(r_ < 1.3)
                 del e_t, p_t
             except Exception as ex:      # never let the auxiliary measurement kill the bench line
                 out["roofline"] = {"error": repr(ex)}

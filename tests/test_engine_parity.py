@@ -565,8 +565,13 @@ def test_plan_scheduling_switches_do_not_change_results_emulated(monkeypatch):
 
     p0, l0, w0 = run()
     for kw, exact in (({"NODEFER_BATCHES": 3}, True), ({"lanes": 2}, True), ({"lanes": 0}, True), ({"SIDE_LOSS": False}, True),
-                      ({"ONE_FILL": False}, False), ({"FUSE_BACK": False}, False), ({"HEAD_IN_FRONT": False}, "head")):
+                      ({"ONE_FILL": False}, False), ({"FUSE_BACK": False}, False), ({"HEAD_IN_FRONT": False}, "head"), ({"IMAGE_CONV": False}, "image")):
         p1, l1, w1 = run(**kw)
+        if exact == "image":
+            # conv1 on the padded copy (pad_reflect + the row kernel, split-bf16) instead of straight from the frames (exact fp32): other arithmetic in ONE layer
+            # (2^-16 relative per product) -- the step must agree far inside the oracle tolerance
+            assert (p0 - p1).abs().mean().item() <= 2e-4 and abs(l0 - l1) <= 1e-5 * abs(l0) and (w0 - w1).abs().max().item() <= 1e-6, (kw, (p0 - p1).abs().mean().item(), l0, l1)
+            continue
         if exact == "head":
             # the disparity heads of levels 6 .. 3 as launches of their own: the same arithmetic in another kernel -- on the emulator (one compiler, no fma
             # contraction differences) the coarse disparities, hence everything downstream, must come out bit for bit
