@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5, call n: HEAD_IN_FRONT with the head's bank in registers: kernel trace of the NONE step (on / off) + FULL same-box A/B
-TAG=${1:-r5n}; bash scripts/gpu_r5_m.sh $TAG; OUT=gpurun_out/$TAG
+TAG=${1:-r5n}; bash scripts/history/r05/gpu_r5_m.sh $TAG; OUT=gpurun_out/$TAG
 timeout 300 python -m pytest tests/test_ops_parity.py -q -m gpu -k "level_front" 2>&1 | tail -2
 for i in 1 2 3; do
   for v in on off; do
