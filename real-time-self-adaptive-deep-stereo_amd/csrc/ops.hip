@@ -555,34 +555,70 @@ __global__ __launch_bounds__(256) void loss_tile_kernel(LossArgs p, int tiles_x,
     const float s = 1.0f / 256.0f;
     const float xmax = (float)(p.W - 1);
     // ---- A -------------------------------------------------------------------------------------
+    // Round 5: the three halo pixels of a thread go through the phase TOGETHER -- three disparity loads in flight, then all 27 image loads (range-checked buffer
+    // loads: a pixel outside the image = an out-of-range offset = zeros, no branch around a load).  The loop this replaces waited for disp, then for its nine
+    // image values, once per pixel: six dependent memory round trips at the head of a launch that sits on the forward chain of every mode.
     float l1 = 0.f;
-    for (int i = tid; i < LT_HH * LT_HW; i += 256) {
-        const int ly = i / LT_HW, lx = i - ly * LT_HW;
-        const int y = y0t - 2 + ly, x = x0t - 2 + lx;
-        float r0v = 0.f, r1v = 0.f, r2v = 0.f, y0v = 0.f, y1v = 0.f, y2v = 0.f;
-        if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
-            const int64_t rowbase = ((int64_t)b * p.H + y) * p.W;
-            const int64_t q = rowbase + x;
-            const float cx = (float)x - p.disp[q];
+    {
+        constexpr int NI = (LT_HH * LT_HW + 255) / 256;          // 3
+        const unsigned npx = (unsigned)p.B * (unsigned)p.H * (unsigned)p.W;
+        const __amdgpu_buffer_rsrc_t rs_d = mh_make_rsrc(p.disp, npx * 4u);
+        const __amdgpu_buffer_rsrc_t rs_l = mh_make_rsrc(p.left, npx * 12u);
+        const __amdgpu_buffer_rsrc_t rs_r = mh_make_rsrc(p.right, npx * 12u);
+        int qv[NI], rbv[NI];
+        bool inb[NI];
+        float dv[NI];
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int i = tid + u * 256;
+            const int ly = i / LT_HW, lx = i - ly * LT_HW;
+            const int y = y0t - 2 + ly, x = x0t - 2 + lx;
+            inb[u] = i < LT_HH * LT_HW && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            rbv[u] = (b * p.H + y) * p.W;
+            qv[u] = rbv[u] + x;
+            dv[u] = mh_buf_load1(rs_d, inb[u] ? qv[u] * 4 : MH_OOB);
+        }
+        float av[NI][3], bv[NI][3], lv[NI][3], w0v[NI], w1v[NI];
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int i = tid + u * 256;
+            const int ly = i / LT_HW, lx = i - ly * LT_HW;
+            const int x = x0t - 2 + lx;
+            const float cx = (float)x - dv[u];
             const float xf0 = floorf(cx), xf1 = xf0 + 1.0f;
-            const float w0 = xf1 - cx, w1 = cx - xf0;
+            w0v[u] = xf1 - cx; w1v[u] = cx - xf0;
             const int i0 = (int)clampf(xf0, 0.f, xmax), i1 = (int)clampf(xf1, 0.f, xmax);
-            const float* r0 = p.right + (rowbase + i0) * 3;
-            const float* r1 = p.right + (rowbase + i1) * 3;
-            const float* lp = p.left + q * 3;
-            const float a0 = r0[0] * s, a1 = r0[1] * s, a2 = r0[2] * s;
-            const float b0 = r1[0] * s, b1 = r1[1] * s, b2 = r1[2] * s;
-            r0v = w0 * a0 + w1 * b0; r1v = w0 * a1 + w1 * b1; r2v = w0 * a2 + w1 * b2;
-            y0v = lp[0] * s; y1v = lp[1] * s; y2v = lp[2] * s;
-            const int iy = ly - 2, ix = lx - 2;
-            if ((unsigned)iy < (unsigned)LT_H && (unsigned)ix < (unsigned)LT_W) {
-                float* d = s_drep + (iy * LT_W + ix) * 3;
-                d[0] = b0 - a0; d[1] = b1 - a1; d[2] = b2 - a2;
-                l1 += fabsf(r0v - y0v) + fabsf(r1v - y1v) + fabsf(r2v - y2v);
+            int o0 = (rbv[u] + i0) * 12, o1 = (rbv[u] + i1) * 12, ol = qv[u] * 12;
+            MH_KEEP_VGPR(o0); MH_KEEP_VGPR(o1); MH_KEEP_VGPR(ol);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                av[u][c] = mh_buf_load1(rs_r, inb[u] ? o0 + 4 * c : MH_OOB);
+                bv[u][c] = mh_buf_load1(rs_r, inb[u] ? o1 + 4 * c : MH_OOB);
+                lv[u][c] = mh_buf_load1(rs_l, inb[u] ? ol + 4 * c : MH_OOB);
             }
         }
-        s_rep[i * 3 + 0] = r0v; s_rep[i * 3 + 1] = r1v; s_rep[i * 3 + 2] = r2v;
-        s_y[i * 3 + 0] = y0v; s_y[i * 3 + 1] = y1v; s_y[i * 3 + 2] = y2v;
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int i = tid + u * 256;
+            if (i >= LT_HH * LT_HW) break;
+            const int ly = i / LT_HW, lx = i - ly * LT_HW;
+            float r0v = 0.f, r1v = 0.f, r2v = 0.f, y0v = 0.f, y1v = 0.f, y2v = 0.f;
+            if (inb[u]) {
+                const float a0 = av[u][0] * s, a1 = av[u][1] * s, a2 = av[u][2] * s;
+                const float b0 = bv[u][0] * s, b1 = bv[u][1] * s, b2 = bv[u][2] * s;
+                const float w0 = w0v[u], w1 = w1v[u];
+                r0v = w0 * a0 + w1 * b0; r1v = w0 * a1 + w1 * b1; r2v = w0 * a2 + w1 * b2;
+                y0v = lv[u][0] * s; y1v = lv[u][1] * s; y2v = lv[u][2] * s;
+                const int iy = ly - 2, ix = lx - 2;
+                if ((unsigned)iy < (unsigned)LT_H && (unsigned)ix < (unsigned)LT_W) {
+                    float* d = s_drep + (iy * LT_W + ix) * 3;
+                    d[0] = b0 - a0; d[1] = b1 - a1; d[2] = b2 - a2;
+                    l1 += fabsf(r0v - y0v) + fabsf(r1v - y1v) + fabsf(r2v - y2v);
+                }
+            }
+            s_rep[i * 3 + 0] = r0v; s_rep[i * 3 + 1] = r1v; s_rep[i * 3 + 2] = r2v;
+            s_y[i * 3 + 0] = y0v; s_y[i * 3 + 1] = y1v; s_y[i * 3 + 2] = y2v;
+        }
     }
     __syncthreads();
     // ---- B -------------------------------------------------------------------------------------
@@ -1064,7 +1100,7 @@ extern "C" int mh_reprojection_loss_phase(const float* left, const float* right,
     MH_REQUIRE(B > 0 && H >= 3 && W >= 3, MH_ERR_ARG, "mh_reprojection_loss: image must be at least 3x3");
     MH_REQUIRE(mh_aligned16(ws), MH_ERR_ALIGN, "mh_reprojection_loss: workspace must be 16-byte aligned");
     const int64_t n = (int64_t)B * H * W, nw = (int64_t)B * (H - 2) * (W - 2);
-    MH_REQUIRE(n < (1ll << 31), MH_ERR_ARG, "mh_reprojection_loss: too many pixels");
+    MH_REQUIRE(n * 12 < (1ll << 31) - 64, MH_ERR_ARG, "mh_reprojection_loss: too many pixels (32-bit byte offsets into the frames)");
     LossArgs a{};
     a.left = left; a.right = right; a.disp = disp; a.result = result; a.ddisp = ddisp; a.grad_scale = grad_scale;
     a.B = B; a.H = H; a.W = W;
