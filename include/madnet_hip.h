@@ -268,7 +268,8 @@ int mh_level_front_fwd_planes(const float* Vc, int32_t Hc, int32_t Wc, float mul
  * no activation) instead of reading its result: Vc[b][y][x] = sum_{tap,k} X[b][y + ky - 1][x + kx - 1][k] * hw[tap][k] + hb[0] (zero padding, fp32, the
  * arithmetic of mh_conv2d_fwd's single-output-channel kernel) is an OUTPUT here -- every element of Vc[B,Hc,Wc] is stored -- and u is interpolated from the
  * values as computed.  One launch less on the forward chain per level.  X: [B,Hc,Wc,x_ld] activations of the estimator's fifth layer; hw: the head's HWIO
- * bank [3][3][K][1] (16-byte aligned); hb: its bias or NULL.  Served shapes: mh_level_front_head_ok (K % 4 == 0, K <= 32, D <= 9) -- MH_ERR_UNSUPPORTED otherwise. */
+ * bank [3][3][K][1] (16-byte aligned); hb: its bias or NULL.  Served shapes: mh_level_front_head_ok (K % 4 == 0, K <= 32, D <= 9, and an UP-scaling geometry
+ * H >= Hc, W >= Wc: a coarse pixel is stored by the workgroup whose fine pixels interpolate from it) -- MH_ERR_UNSUPPORTED otherwise. */
 int mh_level_front_head_fwd(const float* X, int32_t x_ld, int32_t K, const float* hw, const float* hb, float* Vc, int32_t Hc, int32_t Wc, float mul,
                             const float* L, int32_t l_ld, const float* R, int32_t r_ld, float* out, int32_t out_ld, int32_t coff, float* Rw, int32_t rw_ld,
                             float* u, int32_t B, int32_t H, int32_t W, int32_t C, int32_t max_disp, int32_t zero_tail,

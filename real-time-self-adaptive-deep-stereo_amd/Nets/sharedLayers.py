@@ -140,9 +140,11 @@ class _CorrFn(torch.autograd.Function):
 
 def correlation(x, y, max_disp, name='corr', mode=MODE, stride=1):
     """corr[b,h,w,j] = mean_c x[b,h,w,c] * y[b,h,w+i_j,c], i_j = -max_disp + j*stride (zero outside)."""
-    if mode == 'TF':
-        raise Exception("mode='TF' (pure TensorFlow slices) does not exist here: the HIP op is the path; "
-                        "the TF formulation lives in oracle/tf_ops.py as the parity oracle")
+    if mode not in ('TF', 'HIP', 'CUDA'):
+        raise Exception("correlation mode must be 'TF', 'HIP' or 'CUDA' (reference sharedLayers.py:23-51), got %r" % (mode,))
+    # 'TF' (the reference's default: pad + slice + reduce_mean in TensorFlow, sharedLayers.py:41-51) and 'CUDA' (its native ShiftCorr op, :30-40) name two
+    # implementations of ONE formula; here both run the HIP op, which computes that formula (tests/test_ref_pin.py: three-way against the reference's own
+    # kernel and the TF restatement).  No TensorFlow-style slicing path exists in the product -- the restatement of it is the parity oracle (oracle/tf_ops.py).
     return _CorrFn.apply(x, y, int(max_disp), int(stride))
 
 

@@ -1648,6 +1648,7 @@ static int front_head_cwcap(int Wc, int W, int ppb, int max_disp) {
 extern "C" int mh_level_front_head_ok(int32_t Hc, int32_t Wc, int32_t H, int32_t W, int32_t C, int32_t K, int32_t max_disp) {
     if (Hc <= 0 || Wc <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || max_disp < 0) return 0;
     if (K % 4 != 0 || K > 32 || 2 * max_disp + 1 > MAXD_SMALL) return 0;           // 8 lanes per head value, one channel group each
+    if (H < Hc || W < Wc) return 0;            // every coarse pixel is stored by the workgroup whose fine pixels interpolate from it: needs an up-scaling geometry
     const int C4 = C / 4, lpp = C4 <= 4 ? 4 : (C4 <= 8 ? 8 : 16);
     const int cw = front_head_cwcap(Wc, W, 256 / lpp, max_disp);
     if (4 * (cw + 2) * (K / 4) > 6 * 256) return 0;                                 // the patch staging is six straight-line loads per thread

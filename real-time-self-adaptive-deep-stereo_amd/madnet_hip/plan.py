@@ -291,6 +291,7 @@ class Recorder(object):
             arr = (_ffi.Op * (b - a))(*self.ops[a:b])
             p = Plan(arr, b - a, self.keep, dict(self.stats) if not parts else {})
             p.work = {k - a: v for k, v in self.work.items() if a <= k < b}
+            p.elided = list(getattr(self, "elided", ()))   # the elision is a property of the recorded step, whichever part a reader holds
             parts.append(p)
         return parts
 
@@ -302,6 +303,7 @@ class Plan(object):
         self.arr, self.n, self.keep, self.stats = arr, n, keep, stats or {}
         self.graph = None
         self.work = {}
+        self.elided = []          # [(pointer, bytes)] of fp32 buffers the recorded step no longer writes (Recorder.compile / compile_parts fill it)
 
     def run(self, lib, stream):
         lib.plan_run(self.arr, self.n, C.c_void_p(stream))

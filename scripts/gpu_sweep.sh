@@ -19,7 +19,7 @@ for item in $SWEEP; do
 import json
 try:
     j = json.loads(open("$OUT/$name.json").read())
-    print("%-28s %.4f ms  %.1f pairs/s  all %s" % ("$name", j["ms_per_step"], j["value"], ["%.3f" % x for x in j["timing"]["ms_per_step_all"]]))
+    print("%-28s %.4f ms  %.1f pairs/s  min %.3f max %.3f" % ("$name", j["ms_per_step"], j["value"], j["timing"]["ms_per_step_min"], j["timing"]["ms_per_step_max"]))
 except Exception as e:
     print("$name", "failed", e); print(open("$OUT/$name.err").read()[-800:])
 PY

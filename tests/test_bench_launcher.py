@@ -77,3 +77,47 @@ def test_bench_set_overrides_are_applied_and_reported(capsys):
             bench.apply_overrides(["other.x=1"], lib, E)
     finally:
         bench._OVERRIDES[:] = []
+
+
+def test_bench_line_fits_the_drivers_tail_and_parses(capsys, tmp_path, monkeypatch):
+    """The LAST stdout line must stay under bench.LINE_BUDGET bytes whatever the detail record weighs (BENCH_r05.json: a 30.8 KB line was not parsed by the
+    driver), must json.loads, and must carry the contract's keys + roofline + cpu_baseline; the complete record goes to the detail file."""
+    sys.path.insert(0, ROOT)
+    import bench
+    fam = [{"kernel": "conv_planes_kernel<fwd,bf16x3> %d" % i, "launches": 18.0, "us_per_step": 281.36289 - i, "frac": 0.0902084338, "note": "x" * 300} for i in range(60)]
+    roof = {"kernel": "conv_planes_kernel<fwd,bf16x3>", "bound": "mfma", "achieved": 225.5210846667391, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.09020843386669565,
+            "traffic": 404845216.0, "algorithmic_bytes_per_step": 330852864.0, "us_per_step": 281.3628979027271, "selection": "y" * 400, "traffic_source": "z" * 300}
+    corr = {"kernel": "k" * 100, "bound": "hbm", "achieved": 5504.04, "peak": 8000.0, "unit": "GB/s", "frac": 0.688, "traffic": 570981376, "traffic_source": "t" * 260,
+            "launch_ms": 0.0985, "algorithmic_bytes_per_launch": 542638080.0}
+    side = {"metric": "m" * 90, "value": 1162.7772096048839, "ms_per_step": 0.86, "timing": {"ms_per_step_all": [0.86] * 40}, "roofline": dict(roof), "kernel_families": fam,
+            "cpu_baseline": {"value": 1.3, "cores": 64}, "epe_vs_oracle": 1.95e-4, "within_tolerance": True, "config": {"workload": "w" * 300}}
+    full = {"metric": "adapted stereo pairs/sec (whole node), MADNet full-backprop online adaptation 1242x375", "value": 741.1583452669294, "unit": "pairs/s", "n_gpus": 1,
+            "steps": 20, "warmup": 5, "ms_per_step": 1.349239344582767, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": bench.DTYPE_LABEL["mixed"],
+            "data": "synthetic", "timing": {"repeats": 5, "ms_per_step_min": 1.34, "ms_per_step_max": 1.35, "ms_per_step_all": [1.35] * 5, "timed_steps_per_repeat": 740, "note": "n" * 200},
+            "config": {"workload": "MADNet FULL adaptation step (fwd+SSIM/L1 loss+EPE+bwd+momentum), 1242x375, 1 pair/GPU/step, private model per stream", "precision": "mixed",
+                       "launch": "hipGraph replay", "timed_region": "r" * 200, "ops_per_step": 138, "final_loss": 0.0055, "epe_vs_synthetic_gt": 4.13},
+            "roofline": roof, "kernel_families": fam, "roofline_fwd": dict(roof), "roofline_corr": corr, "roofline_corr_bwd": dict(corr), "roofline_corr_warp_bwd": dict(corr),
+            "roofline_corr_d81_fwd": dict(corr), "roofline_corr_d81_bwd": dict(corr),
+            "cpu_baseline": {"value": 0.977295994283161, "unit": "pairs/s", "cores": 64, "kind": "port", "sample": "8 FULL steps of the torch-CPU oracle"},
+            "epe_vs_oracle": 0.000195, "epe_tolerance": 1e-3, "within_tolerance": True, "step_surface": {"value": 701.4, "unit": "pairs/s", "ms_per_step": 1.4256, "what": "s" * 300},
+            "paths": {"fp32": {"dtype": "d" * 100, "value": 265.9, "ms_per_step": 3.76, "epe_vs_oracle": 1.1e-5, "within_tolerance": True}},
+            "drift": {"what": "q" * 200, "step_10": {"epe_vs_fp32_engine": 0.0142, "loss": 0.02}, "step_100": {"epe_vs_fp32_engine": 0.085}},
+            "configs": {"mad": dict(side), "dispnet": dict(side), "private4": dict(side), "batched4": dict(side)},
+            "box": {"replay_over_launch_sum": 0.94, "healthy": True, "during_replay": {"power_w": {"min": 1.0}}, "note": "b" * 300}}
+    assert len(json.dumps(full)) > 5 * bench.LINE_BUDGET
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    bench._emit(full)
+    outp = capsys.readouterr().out
+    assert outp.endswith("\n") and outp.count("\n") == 1
+    line = outp.strip()
+    assert len(line.encode()) < 6144 and len(line.encode()) < bench.LINE_BUDGET
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert abs(d["value"] - full["value"]) <= 1e-5 * full["value"] and d["config"]["workload"] == full["config"]["workload"]
+    assert set(("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"]) and d["roofline"]["traffic"] == 404845216
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 64
+    assert abs(d["roofline_corr"]["warp_bwd_d5"]["frac"] - 0.688) < 1e-9 and d["configs"]["dispnet"]["roofline"]["frac"] > 0 and d["step_surface"]["value"] == 701.4
+    assert d["drift"] == {"step_10": 0.0142, "step_100": 0.085}
+    det = json.load(open(os.path.join(str(tmp_path), d["detail"])))
+    assert det["kernel_families"][59]["kernel"].endswith(" 59") and det["value"] == full["value"]        # the complete record, full doubles

@@ -499,6 +499,8 @@ def test_level_front_head_refuses_what_it_does_not_serve(backend):
     lib = backend.lib
     assert lib.level_front_head_ok(6, 10, 12, 20, 32, 64, 2) == 0 and lib.level_front_head_ok(6, 10, 12, 20, 32, 30, 2) == 0
     assert lib.level_front_head_ok(6, 10, 12, 20, 32, 32, 5) == 0 and lib.level_front_head_ok(6, 10, 12, 20, 32, 32, 2) == 1
+    # a down-scaling geometry would leave coarse pixels no fine pixel interpolates from un-stored: not served
+    assert lib.level_front_head_ok(12, 20, 6, 10, 32, 32, 2) == 0 and lib.level_front_head_ok(6, 20, 12, 10, 32, 32, 2) == 0
     dev = backend.device
     B, H, W, C, md, K = 1, 12, 20, 32, 2, 64
     X = _rand((B, 6, 10, K), 1, dev); hw = _rand((3, 3, K, 1), 2, dev); V = torch.zeros(B, 6, 10, device=dev)

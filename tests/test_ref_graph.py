@@ -334,3 +334,48 @@ def test_loss_kernels_vs_reference_loss_factory(backend):
     backend.sync()
     assert abs(res[0].item() - float(gold["proxy_loss"])) <= 2e-6 * abs(float(gold["proxy_loss"]))
     assert np.abs(dp.cpu().numpy() - gold["proxy_grad"][..., 0]).max() <= 2e-6 * np.abs(gold["proxy_grad"]).max()
+
+
+def test_loss_factory_builders_vs_reference_loss_factory(backend, monkeypatch):
+    """The drop-in module path: Losses.loss_factory.get_supervised_loss / get_proxy_loss (reference signatures, loss_factory.py:256,304) as torch.autograd.Functions
+    over mh_supervised_loss / mh_proxy_loss, against the reference-executed fixture: reduced value, per-scale parts, gradient w.r.t. every prediction."""
+    from Data_utils import preprocessing as P
+    from Losses import loss_factory as LF
+    monkeypatch.setattr(P, "_lib", lambda: backend.lib)
+    monkeypatch.setattr(LF, "_lib", lambda: backend.lib)
+    gold, z = _loss_golden(), GL.inputs()
+    dev, n = backend.device, GL.NPRED
+    inputs = {k: torch.from_numpy(z[k]).to(dev) for k in ("left", "right", "target", "proxy")}
+
+    def preds():
+        return [torch.from_numpy(z["pred_%d" % i]).to(dev).requires_grad_(True) for i in range(n)]
+
+    p = preds()
+    loss = LF.get_supervised_loss("mean_l1", multiScale=True, logs=False, weights=GL.SUP_WEIGHTS, max_disp=GL.MAX_DISP)(p, inputs)        # Train.py:100
+    loss.backward()
+    backend.sync()
+    assert abs(loss.item() - float(gold["sup_loss"])) <= 4e-6 * abs(float(gold["sup_loss"]))
+    for i in range(n):
+        gref = gold["sup_grad_%d" % i]
+        assert np.abs(p[i].grad.cpu().numpy() - gref).max() <= 2e-6 * np.abs(gref).max(), i
+    parts = LF.get_supervised_loss("mean_l1", multiScale=True, weights=GL.SUP_WEIGHTS, reduced=False, max_disp=GL.MAX_DISP)(preds(), inputs)
+    assert np.allclose([q.item() for q in parts], gold["sup_parts"], rtol=2e-6)
+    p = preds()
+    l1 = LF.get_supervised_loss("mean_l1", max_disp=GL.MAX_DISP)(p, inputs)                   # multiScale=False: the last prediction only, weight 1
+    l1.backward()
+    assert abs(l1.item() - float(gold["sup1_loss"])) <= 2e-6 * abs(float(gold["sup1_loss"])) and p[0].grad is None
+    assert np.abs(p[-1].grad.cpu().numpy() - gold["sup1_grad"]).max() <= 2e-6 * np.abs(gold["sup1_grad"]).max()
+    p = preds()
+    lp = LF.get_proxy_loss("mean_l1")(p, inputs)                                              # Stereo_Continual_Adaptation.py:75 (weights 0.01)
+    lp.backward()
+    assert abs(lp.item() - float(gold["proxy_loss"])) <= 2e-6 * abs(float(gold["proxy_loss"]))
+    assert np.abs(p[-1].grad.cpu().numpy() - gold["proxy_grad"]).max() <= 2e-6 * np.abs(gold["proxy_grad"]).max()
+    for i in range(n):
+        q = preds()[i]
+        lq = LF.get_proxy_loss("mean_l1", weights=[0.1] * 10, reduced=True)([q], inputs)      # :112, one block's prediction
+        lq.backward()
+        assert abs(lq.item() - float(gold["proxy01_loss_%d" % i])) <= 2e-6 * abs(float(gold["proxy01_loss_%d" % i])), i
+        assert np.abs(q.grad.cpu().numpy() - gold["proxy01_grad_%d" % i]).max() <= 2e-6 * np.abs(gold["proxy01_grad_%d" % i]).max(), i
+    for builder in (LF.get_supervised_loss, LF.get_proxy_loss):
+        with pytest.raises(Exception):
+            builder("sum_l2")                                                                 # a name of the reference's table that is not a kernel here: loud

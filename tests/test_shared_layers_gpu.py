@@ -19,8 +19,11 @@ def test_correlation_op_and_gradient(hip):
     out.backward(g)
     gx, gy = torch.autograd.grad(ref, [xc, yc], g.cpu())
     assert (x.grad.cpu() - gx).abs().max().item() < 1e-5 and (y.grad.cpu() - gy).abs().max().item() < 1e-5
+    # mode='TF' (the reference's default) and mode='CUDA' name the same formula: both run the HIP op here, bit-identical to the default call
+    for mode in ('TF', 'CUDA'):
+        assert torch.equal(SL.correlation(x, y, 2, mode=mode), out)
     with pytest.raises(Exception):
-        SL.correlation(x, y, 2, mode='TF')
+        SL.correlation(x, y, 2, mode='numpy')
 
 
 def test_conv_ops_and_gradients(hip):
