@@ -447,14 +447,17 @@ def drift_report(args, lib, dev, wn, mk, frames=8):
     return out
 
 
-def apply_overrides(items, lib, E):
+def apply_overrides(items, lib, E, sched_cls=None):
     """--set KEY=VALUE: library hooks are applied at once; returns (per-engine attributes, Schedule fields) for every engine built: engine.NAME=v is a
     field of the engine's immutable madnet_hip.schedule.Schedule (FUSE_HEAD, TAIL_MAIN, EARLY_WGS ...), eng.NAME=v an attribute set after construction."""
     import ast
     import dataclasses
     per_engine, sched = {}, {}
     _OVERRIDES[:] = items
-    fields = {f.name for f in dataclasses.fields(E.Schedule)}
+    # engine.NAME is checked against the schedule of the network the run builds (MADNet: Schedule, --model dispnet: DispNetSchedule): a field of the other
+    # network's schedule fails loudly instead of labelling an A/B run that changed nothing (ADVICE r05)
+    sched_cls = sched_cls if sched_cls is not None else E.Schedule
+    fields = {f.name for f in dataclasses.fields(sched_cls)}
     for it in items:
         key, _, val = it.partition("=")
         scope, _, name = key.partition(".")
@@ -463,7 +466,7 @@ def apply_overrides(items, lib, E):
         except (ValueError, SyntaxError):
             v = val
         if scope == "engine":
-            assert name in fields, "--set %s: no such field in madnet_hip/schedule.py: Schedule" % key
+            assert name in fields, "--set %s: no such field in madnet_hip/schedule.py: %s" % (key, sched_cls.__name__)
             sched[name] = v
         elif scope == "eng":
             per_engine[name] = v
@@ -823,7 +826,7 @@ def main():
 
     from madnet_hip import _ffi, engine as E, dispnet_engine as DE, synthetic as S, benchtools as BT
     lib = _ffi.lib()
-    eng_overrides, sched_overrides = apply_overrides(args.overrides, lib, E)
+    eng_overrides, sched_overrides = apply_overrides(args.overrides, lib, E, DE.DispNetSchedule if args.model == "dispnet" else E.Schedule)
     H, W = args.height, args.width
     if args.mode == "MAD":
         return bench_mad(args, lib, dev, rank, world, dist)
@@ -835,7 +838,7 @@ def main():
     def mk(prec, **sched_kw):
         """an engine of the run's network; sched_kw: Schedule fields on top of the --set engine.* overrides (MADNet)"""
         if dispnet:
-            e = DE.DispNetEngine(lib, H, W, B=SB, device=dev.name, weights=wn, precision=prec)
+            e = DE.DispNetEngine(lib, H, W, B=SB, device=dev.name, weights=wn, precision=prec, schedule=DE.DispNetSchedule(**dict(sched_overrides, **sched_kw)))
         else:
             e = E.MadNetEngine(lib, H, W, B=SB, device=dev.name, weights=wn, precision=prec, schedule=E.Schedule(**dict(sched_overrides, **sched_kw)))
         for k, v in eng_overrides.items():

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 14
+#define MH_ABI_VERSION 15
 
 /* status codes of every int-returning entry point: 0 = launched; a NEGATIVE code means an argument check failed and
  * nothing was launched or written; a POSITIVE value is the hipError_t of a failed launch / runtime call.
@@ -172,12 +172,16 @@ int mh_conv2d_wgrad(const mh_conv_desc* d, const float* in, const float* dout, i
  * Stereo_Online_Adaptation.py:114's minimize()): pixel split s writes its partial filter gradient to
  * ws[s][kh*kw*K*N] with plain stores; mh_wgrad_reduce then sums the splits of EVERY layer in one launch.
  *   query : ws == NULL -> *splits = number of pixel splits this geometry uses (nothing is launched);
- *   launch: ws != NULL, *splits = the queried value; ws must hold *splits * kh*kw*K*N floats, 16-byte
- *           aligned; it is fully overwritten (no zeroing needed).  db (may be NULL) is still accumulated. */
+ *   launch: ws != NULL, *splits = the queried value; ws must hold *splits * (kh*kw*K*N + (db ? N : 0)) floats, 16-byte
+ *           aligned; it is fully overwritten (no zeroing needed).  Bias gradient (ABI 15): with *splits > 1 the bias partial sums of
+ *           split s are STORED at ws[*splits * kh*kw*K*N + s * N + n] and db is not touched -- sum them with one more mh_wgrad_seg
+ *           {ws + *splits * kh*kw*K*N, db, N, *splits} in the same mh_wgrad_reduce launch (fixed summation order: two replays of a step
+ *           give bit-identical bias gradients; ABI <= 14 added one float atomic per workgroup and channel to db).  With *splits == 1 a
+ *           channel has a single addend, which is atomically added to db as before (zero db first). */
 int mh_conv2d_wgrad_partial(const mh_conv_desc* d, const float* in, const float* dout, int32_t dout_ld,
                             float* ws, int32_t* splits, float* db, void* stream);
 /* Several layers' partial filter gradients in one launch (same contract per item as mh_conv2d_wgrad_partial with ws != NULL: `splits` from a
- * query call).  bf16-mode layers share one grid; exact-fp32 layers are launched one by one.  Replaces the per-layer Conv2DBackpropFilter nodes
+ * query call, the bias partial sums behind the filter partials).  bf16-mode layers share one grid; exact-fp32 layers are launched one by one.  Replaces the per-layer Conv2DBackpropFilter nodes
  * TF schedules for one tf.gradients() call (Stereo_Online_Adaptation.py:126-128). */
 typedef struct mh_wgrad_item {
     mh_conv_desc d;
@@ -207,8 +211,10 @@ int mh_wgrad_reduce(const mh_wgrad_seg* segs_device, int32_t nseg, int32_t nbloc
  *   mh_wgrad_stream_plan  : HOST-side planner.  Fills ktiles / ntiles / splits / blk0 of every layer record so that about `target_wgs` workgroups
  *                           of `nwaves` waves share the batch in proportion to the rows they stream; *nblocks_out = the grid.  The caller then
  *                           points layer.ws at splits * 9*K*N floats (16-byte aligned; or at dw itself when splits == 1) and uploads the table.
- *   mh_wgrad_stream       : the launch.  ws[split][9][K][N] is fully overwritten (sum the splits with mh_wgrad_reduce); db (may be NULL) is
- *                           accumulated with atomics.  max_dil = the largest dilation in the table (1 .. 16), -2 for a table of stride-2 layers, -3 for a table that mixes
+ *   mh_wgrad_stream       : the launch.  ws[split][9][K][N] is fully overwritten (sum the splits with mh_wgrad_reduce).  Bias gradient (db != NULL; ABI 15):
+ *                           a layer with splits > 1 needs splits * N more floats behind its filter partials -- the bias partial sums are stored at
+ *                           ws[splits * 9*K*N + split * N + n], db is not touched, one more reduction segment {.., db, N, splits} sums them in split order;
+ *                           a layer with ONE split adds its single addend per channel to db atomically (zero db first).  max_dil = the largest dilation in the table (1 .. 16), -2 for a table of stride-2 layers, -3 for a table that mixes
  *                           stride-1 (dilation <= 8) and stride-2 layers. */
 typedef struct mh_shadow_seg {
     const float* src;     /* fp32 [npix][src_ld], C valid channels */
@@ -491,9 +497,16 @@ int64_t mh_stamp_rate_khz(void);
 int mh_deterministic_add(float* base, int64_t n, void* twin);
 int mh_deterministic_remove(float* base);
 int mh_deterministic_ranges(void);
+/* 1 if an addend outside the twin's range (|v| >= 2^15, or NaN: e.g. a huge grad_scale) was SATURATED since the previous call, 0 if not, < 0 = -hipError.
+ * Device-synchronising; not inside a stream capture. */
+int mh_deterministic_overflow(void);
 int mh_det_flush(float* dst, void* twin, int64_t n, void* stream);
 /* db[c] += sum_p dz[p][c]  (BiasAddGrad of conv2d_transpose, whose filter gradient runs with swapped operands) */
 int mh_bias_grad(const float* dz, int32_t dz_ld, int64_t npix, int32_t nch, float* db, void* stream);
+/* the same column sums without float atomics (ABI 15; bit-identical replays of a step): workgroup g stores its partial sums to ws[g][nch] (fully overwritten),
+ * nblocks = mh_bias_grad_blocks(npix, nch) (1 .. 1024); sum them with an mh_wgrad_seg {ws, db, nch, nblocks} in the batch's mh_wgrad_reduce launch. */
+int mh_bias_grad_blocks(int64_t npix, int32_t nch);
+int mh_bias_grad_partial(const float* dz, int32_t dz_ld, int64_t npix, int32_t nch, float* ws, int32_t nblocks, void* stream);
 
 /* (the process-wide tuning hooks of the benchmarks live in madnet_hip_tune.h: none of them is part of the reference interface) */
 

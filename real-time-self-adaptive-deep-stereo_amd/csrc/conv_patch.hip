@@ -36,6 +36,11 @@ struct PatchGeo {
     int dbg;                // timing experiments (scripts/microbench.py patchdbg): 1 = skip the K walk, 2 = skip the patch staging
     mh_tile_decode dec;     // magic multipliers of the workgroup -> tile decode (mh_common.h)
     mh_fastdiv f_kp4, f_pc; // ... and of the small-layer kernel's patch staging (item -> (pixel, 4-channel group), pixel -> (row, column))
+    // small-layer kernel: where a workgroup runs (8 XCDs with an L2 each; block b runs on XCD b % 8).  xuse < 8: the launch has 8 * per blocks and only the
+    // `per` blocks of XCDs 0 .. xuse - 1 work (the others exit at once) -- a layer of <= 64 workgroups reads its bank and its patch through ONE L2.
+    // n_major: the column tile is the SLOW index of the logical order, so an XCD's contiguous chunk shares bank slices instead of input patches.
+    int xuse, per, n_major;
+    mh_fastdiv f_pt;        // pixel tiles per column tile (n_major decode)
 };
 
 constexpr int LSB = 80;     // weight tile row stride (halfs): 64 k + 16 pad = 40 dwords (conflict-free b128 reads)
@@ -783,9 +788,18 @@ __global__ __launch_bounds__(1024) void conv_bank_small_kernel(ConvArgs p, Patch
     const int st = DGRAD ? 1 : p.stride;             // forward: stride 1 (any dilation) or stride 2 (dilation 1): output pixel (i, j) reads patch (i*st + ky, j*st + kx)
     const int PC = st * 16 + 3 - st;                 // patch columns: 18 / 33 ; rows: st * TH + 3 - st = 4 / 5
 
-    const int lin = mh_xcd_remap(blockIdx.x, g.nwg);
+    int lin;
+    if (g.xuse < 8) {                                 // (uniform per workgroup: a whole block leaves before any barrier)
+        const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+        lin = xcd * g.per + idx;
+        if (xcd >= g.xuse || lin >= g.nwg) return;
+    } else lin = mh_xcd_remap(blockIdx.x, g.nwg);
     int tile_n, ttx, tty, cx, cy, b;
-    mh_decode_tile(lin, g.dec, tile_n, ttx, tty, cx, cy, b);
+    if (g.n_major) {
+        const int tn = mh_fdiv(lin, g.f_pt);
+        mh_decode_tile(lin - tn * (int)g.f_pt.d, g.dec, tile_n, ttx, tty, cx, cy, b);        // (dec.ntn = 1 here: tile_n comes back 0)
+        tile_n = tn;
+    } else mh_decode_tile(lin, g.dec, tile_n, ttx, tty, cx, cy, b);
     const int n0 = tile_n * BN;
     const int y00 = cy + d * (tty * TH), x00 = cx + d * (ttx * 16);
 
@@ -1097,6 +1111,7 @@ int launch_bank(ConvArgs& a, hipStream_t s) {
     return mh_check_launch("conv_bank");
 }
 
+std::atomic<int> g_bank_small_place{-1};          // mh_tune_conv_bank_small: workgroup placement of the small-layer kernel (-1 = the model)
 template <bool DGRAD, int PL>
 int launch_bank_small(ConvArgs& a, hipStream_t s) {
     static std::atomic<uint64_t> attr_done{0};
@@ -1120,8 +1135,26 @@ int launch_bank_small(ConvArgs& a, hipStream_t s) {
         const int dmax = std::max(std::max(g.ntiles_n, g.tiles_x), std::max(g.tiles_y, (int)d));
         MH_REQUIRE(mh_fastdiv_ok(nwg64, dmax), MH_ERR_UNSUPPORTED, "tile decode: %lld workgroups x divisor %d exceeds the 2^32 range of the magic-multiplier division", (long long)nwg64, dmax);
     }
-    g.dec = mh_make_tile_decode(g.ntiles_n, g.tiles_x, g.tiles_y, d);
     g.KP = (a.K + 31) & ~31;
+    // ---- placement (round 6): which L2s see the layer.  Bytes an XCD's chunk pulls through its L2 under the two logical orders, for X = xuse XCDs:
+    //   pixel-major (column tile fastest): every XCD reads the whole bank, the input once over all XCDs  ->  X * bank + in
+    //   column-major (n_major)           : an XCD reads ntn / X (>= 1) column slices and every pixel of them -> max(X, ntn) / ntn * bank + min(X, ntn) * in
+    // and X itself: the fewest XCDs that still give every workgroup a CU of its own (32 CUs per XCD), so that a 24-workgroup layer is ONE L2's business.
+    {
+        const int mode = g_bank_small_place.load(std::memory_order_relaxed);      // -1 / 3 = model, 0 = round-5 order (all XCDs, pixel-major), 1 = model without confinement, 2 = confinement only
+        const int npt = g.nwg / g.ntiles_n;
+        int X = 8;
+        if (mode < 0 || mode >= 2) { X = 1; while (X < 8 && mh_cdiv(g.nwg, X) > 32) X *= 2; }
+        const double bank = 9.0 * g.KP * a.N * 2.0 * PL, in = (double)a.B * (DGRAD ? a.Ho : a.Hi) * (DGRAD ? a.Wo : a.Wi) * a.K * 4.0;
+        const double pix_major = X * bank + in;
+        const double col_major = (double)std::max(X, g.ntiles_n) / g.ntiles_n * bank + std::min(X, g.ntiles_n) * in;
+        g.n_major = (mode != 0 && mode != 2 && col_major < pix_major) ? 1 : 0;
+        g.xuse = X;
+        g.per = mh_cdiv(g.nwg, X);
+        g.f_pt = mh_make_fastdiv(npt);
+        MH_REQUIRE(mh_fastdiv_ok((int64_t)g.nwg, npt), MH_ERR_UNSUPPORTED, "tile decode: %d workgroups x %d pixel tiles exceeds the magic-multiplier range", g.nwg, npt);
+    }
+    g.dec = mh_make_tile_decode(g.n_major ? 1 : g.ntiles_n, g.tiles_x, g.tiles_y, d);
     g.CPT = g.KP / 32;
     g.PS = g.KP + 16;
     g.nchunk = 9 * g.CPT;
@@ -1134,9 +1167,10 @@ int launch_bank_small(ConvArgs& a, hipStream_t s) {
     const size_t patch = (size_t)g.patch_halfs * 2 * PL, cs = (size_t)16 * 32 * 33 * 4;
     const size_t lds = patch > cs ? patch : cs;
     ++g_bank_launches;
+    const int nblocks = g.xuse < 8 ? 8 * g.per : g.nwg;
     mh_note_kernel("conv_bank_small_kernel<%s,%s> tile 32x32 K=%d N=%d dil=%d grid %d lds %d", DGRAD ? "dgrad" : "fwd", PL == 2 ? "bf16x3" : "bf16", a.K, a.N, a.dil,
                    g.nwg, (int)lds);
-    hipLaunchKernelGGL((conv_bank_small_kernel<DGRAD, PL>), dim3(g.nwg), dim3(1024), lds, s, a, g);
+    hipLaunchKernelGGL((conv_bank_small_kernel<DGRAD, PL>), dim3(nblocks), dim3(1024), lds, s, a, g);
     return mh_check_launch("conv_bank_small");
 }
 
@@ -1206,6 +1240,7 @@ int bank_small_tile_wgs() {
     const int m = g_bank_small_tile_wgs.load(std::memory_order_relaxed);
     return m < 0 ? 200 : m;
 }
+extern "C" int mh_tune_conv_bank_small(int mode) { return g_bank_small_place.exchange(mode < 0 ? -1 : mode); }
 extern "C" int mh_tune_conv_bank_tile(int max_wgs) { return g_bank_small_tile_wgs.exchange(max_wgs < 0 ? -1 : max_wgs); }
 extern "C" int mh_tune_conv_bank(int small_maxpix) {
     g_bank_small_maxpix = small_maxpix < 0 ? -2 : small_maxpix;

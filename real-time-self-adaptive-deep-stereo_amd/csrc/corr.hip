@@ -824,7 +824,7 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_row_kernel(CorrWarpBwdArgs
 template <int LPP, int DT>
 __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdArgs p) {
     HIP_DYNAMIC_SHARED(float, smem)
-    constexpr int NT = 1024, PPB = NT / LPP, NI = 3, GS = 8, KL = 8, KSEL = 16;
+    constexpr int NT = 1024, PPB = NT / LPP, NI = 3, GS = 8, KL = 8;
     static_assert(DT + 1 <= GS, "g staging holds D + 1 channels");
     const int C4 = p.C >> 2, WC = p.W * p.C;
     float* const sL = smem;                     // [W][C]
@@ -1025,8 +1025,9 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
 #pragma unroll
             for (int i = 0; i < KL; ++i)
                 if (i < n) add(e[i]);
-        } else if (n <= KSEL) {
-            // a compressed stretch of the warp: selection, smallest key first (n^2 LDS reads of a short segment)
+        } else {
+            // a compressed stretch of the warp: selection, smallest key first (n^2 LDS reads of the segment).  No cap: a fold of many taps onto
+            // one column -- a diverged disparity map -- is slow here (n <= 2 W), never summed in arrival order: the launch has no order-dependent arithmetic.
             int last = -1;
             for (int t = 0; t < n; ++t) {
                 int best = 0x7fffffff;
@@ -1034,8 +1035,6 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
                 add(best);
                 last = best;
             }
-        } else {
-            for (int i = 0; i < n; ++i) add(ent[b0 + i]);          // a fold of > KSEL taps onto one column: arrival order
         }
         *reinterpret_cast<float4*>(p.dimg + (int64_t)(rowbase + xs) * p.dimg_ld + c4 * 4) = acc;
     }
@@ -1887,3 +1886,4 @@ extern "C" int mh_det_sync_corr(const void* t) {
     g_corr_det_ranges = reinterpret_cast<const mh_det_table*>(t)->n;
     return mh_det_upload(*reinterpret_cast<const mh_det_table*>(t));
 }
+extern "C" int mh_det_ovf_corr(void) { return mh_det_overflow_take(); }      // this translation unit's saturation flag of the deterministic twin (mh_common.h)

@@ -102,6 +102,27 @@ extern "C" int mh_deterministic_remove(float* base) {
     return det_sync();
 }
 extern "C" int mh_deterministic_ranges(void) { std::lock_guard<std::mutex> g(g_det_mutex); return g_det_host.n; }
+extern "C" int mh_det_ovf_corr(void);
+extern "C" int mh_det_ovf_ops(void);
+extern "C" int mh_det_ovf_wgrad(void);
+extern "C" int mh_det_ovf_wgrad_stream(void);
+// 1 if an addend outside the fixed-point twin's range (|v| >= 2^15, or NaN) was saturated since the previous call, 0 if not, < 0 = -hipError.  Synchronises the
+// device the ranges live on; not callable inside a stream capture.
+extern "C" int mh_deterministic_overflow(void) {
+    std::lock_guard<std::mutex> g(g_det_mutex);
+    int cur = 0;
+    if (hipError_t e = hipGetDevice(&cur)) return -(int)e;
+    const bool sw = g_det_device >= 0 && g_det_device != cur;
+    if (sw) if (hipError_t e = hipSetDevice(g_det_device)) return -(int)e;
+    int any = 0;
+    for (auto fn : {mh_det_ovf_corr, mh_det_ovf_ops, mh_det_ovf_wgrad, mh_det_ovf_wgrad_stream}) {
+        const int v = fn();
+        if (v < 0) { any = v; break; }
+        any |= v;
+    }
+    if (sw) (void)hipSetDevice(cur);
+    return any;
+}
 // host utility for the TensorFlow-checkpoint importer (Data_utils/tf_checkpoint.py): CRC-32C (Castagnoli), bytewise table
 extern "C" uint32_t mh_crc32c(const void* data, int64_t n, uint32_t crc) {
     static uint32_t table[256];
@@ -268,6 +289,7 @@ static int run_op(const mh_op& o, void* s) {
         case MH_OP_FILL:
             return mh_fill((float*)p[0], o.n, o.f[0], s);
         case MH_OP_BIAS_GRAD:
+            if (i[2] > 0) return mh_bias_grad_partial((const float*)p[0], i[0], o.n, i[1], (float*)p[1], i[2], s);      // p[1] = workspace [i[2]][nch]
             return mh_bias_grad((const float*)p[0], i[0], o.n, i[1], (float*)p[1], s);
         default:
             mh_set_error("mh_plan_run: unknown op kind %d", o.kind);

@@ -77,11 +77,15 @@ __device__ __forceinline__ int mh_xcd_remap(int bid, int nwg) {
 // them in step.  Off (n = 0): one scalar load and a uniform branch per atomic site.
 struct mh_det_table { int n; int pad; const float* lo[8]; const float* hi[8]; long long* acc[8]; };
 static __device__ mh_det_table g_mh_det;
+// Supported addend range of the fixed-point twin: |v| < 2^15 (value * 2^48 must fit 63 bits).  A larger addend -- a loss scale (grad_scale) far above the
+// mean-reduced losses' -- is SATURATED, and says so: a sticky per-translation-unit flag that mh_deterministic_overflow() collects.
+static __device__ int g_mh_det_ovf;
 __device__ __forceinline__ void mh_atomic_add(float* dst, float v) {
     const int n = g_mh_det.n;
     for (int i = 0; i < n; ++i)
         if (dst >= g_mh_det.lo[i] && dst < g_mh_det.hi[i]) {
             // |v| is clamped below 2^15 (llrintf of a larger product is undefined; the running sum of a mean-reduced loss's gradients stays far inside)
+            if (!(fabsf(v) < 32767.0f)) g_mh_det_ovf = 1;           // (also NaN) reported by mh_deterministic_overflow()
             atomicAdd(reinterpret_cast<unsigned long long*>(g_mh_det.acc[i] + (dst - g_mh_det.lo[i])),
                       (unsigned long long)(long long)llrintf(fminf(fmaxf(v, -32767.0f), 32767.0f) * 281474976710656.0f));
             return;
@@ -89,6 +93,14 @@ __device__ __forceinline__ void mh_atomic_add(float* dst, float v) {
     atomicAdd(dst, v);
 }
 static inline int mh_det_upload(const mh_det_table& t) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_mh_det), &t, sizeof(t)); }
+// this translation unit's saturation flag: read (device-synchronising copy) and cleared; < 0 = -hipError
+static inline int mh_det_overflow_take() {
+    int v = 0;
+    const int zero = 0;
+    if (hipError_t e = hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_mh_det_ovf), sizeof(v))) return -(int)e;
+    if (v) if (hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_mh_det_ovf), &zero, sizeof(zero))) return -(int)e;
+    return v ? 1 : 0;
+}
 
 // Workgroup -> segment of a batched launch's device table (segs[].blk0 = exclusive prefix of the segments' block counts).  The table's blk0 column goes
 // to LDS first (one coalesced round trip) and the binary search runs there: searched in global memory it is log2(nseg) DEPENDENT loads in front of a

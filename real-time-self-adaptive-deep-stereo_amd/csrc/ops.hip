@@ -878,7 +878,7 @@ __global__ __launch_bounds__(256) void leaky_bwd_kernel(float* dy, int dy_ld, co
 // column sums, coalesced along the channels: a wave row = 64/nchp pixels x nchp channels (nchp = power of two covering
 // min(nch, 64)), blockIdx.y = 64-channel chunk; pixels strided over waves and workgroups; shuffle reduction over the
 // pixels of a wave row, LDS over the 4 waves, one atomic per channel per workgroup.
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float* dz, int dz_ld, int64_t npix, int nch, float* db, int nchp) {
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* dz, int dz_ld, int64_t npix, int nch, float* db, int nchp, float* ws) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int ppw = 64 / nchp;
@@ -903,7 +903,11 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* dz, int dz_
     for (int o = nchp; o < 64; o <<= 1) v += __shfl_xor(v, o);
     red[w][lane] = v;
     __syncthreads();
-    if (w == 0 && pl == 0 && c < nch) mh_atomic_add(db + c, (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+    if (w == 0 && pl == 0 && c < nch) {
+        const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        // partial form (round 6): the workgroup's column sums go to ws[blockIdx.x][nch] with plain stores and mh_wgrad_reduce sums the workgroups in order
+        if (ws) ws[(int64_t)blockIdx.x * nch + c] = t; else mh_atomic_add(db + c, t);
+    }
 }
 
 __global__ __launch_bounds__(256) void fill_kernel(float* p, int64_t n, float v) {
@@ -1204,8 +1208,27 @@ extern "C" int mh_bias_grad(const float* dz, int32_t dz_ld, int64_t npix, int32_
     int gx = (int)((rows + 4 * 8 - 1) / (4 * 8));                          // ~8 rows per wave
     if (gx > 1024) gx = 1024;
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(gx, (nch + 63) / 64), dim3(256), 0, (hipStream_t)stream, dz, dz_ld, npix, nch, db, nchp);
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(gx, (nch + 63) / 64), dim3(256), 0, (hipStream_t)stream, dz, dz_ld, npix, nch, db, nchp, (float*)nullptr);
     return mh_check_launch("bias_grad");
+}
+
+extern "C" int mh_bias_grad_blocks(int64_t npix, int32_t nch) {
+    if (npix <= 0 || nch <= 0) return 0;
+    int nchp = 1;
+    while (nchp < nch && nchp < 64) nchp <<= 1;
+    const int64_t rows = (npix + (64 / nchp) - 1) / (64 / nchp);
+    int64_t gx = (rows + 4 * 8 - 1) / (4 * 8);
+    return (int)(gx > 1024 ? 1024 : (gx < 1 ? 1 : gx));
+}
+
+extern "C" int mh_bias_grad_partial(const float* dz, int32_t dz_ld, int64_t npix, int32_t nch, float* ws, int32_t nblocks, void* stream) {
+    MH_REQUIRE(dz && ws && npix > 0 && nch > 0 && dz_ld >= nch, MH_ERR_ARG, "mh_bias_grad_partial: bad argument");
+    MH_REQUIRE(nblocks == mh_bias_grad_blocks(npix, nch), MH_ERR_ARG, "mh_bias_grad_partial: nblocks %d must be mh_bias_grad_blocks(npix, nch) = %d (the workspace was sized for it)",
+               nblocks, mh_bias_grad_blocks(npix, nch));
+    int nchp = 1;
+    while (nchp < nch && nchp < 64) nchp <<= 1;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(nblocks, (nch + 63) / 64), dim3(256), 0, (hipStream_t)stream, dz, dz_ld, npix, nch, (float*)nullptr, nchp, ws);
+    return mh_check_launch("bias_grad_partial");
 }
 
 // device time stamp (diagnostics of the replayed step: where the side lane starts, how long the tail behind the last input gradient is):
@@ -1247,3 +1270,4 @@ extern "C" int mh_fill(float* p, int64_t n, float v, void* stream) {
 
 // this translation unit's copy of the deterministic-accumulation table (mh_common.h)
 extern "C" int mh_det_sync_ops(const void* t) { return mh_det_upload(*reinterpret_cast<const mh_det_table*>(t)); }
+extern "C" int mh_det_ovf_ops(void) { return mh_det_overflow_take(); }      // this translation unit's saturation flag of the deterministic twin (mh_common.h)

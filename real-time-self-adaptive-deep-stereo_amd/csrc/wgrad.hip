@@ -30,6 +30,14 @@ struct WgradArgs {
     int dbg_plain_store;   // timing experiment only: plain stores instead of atomics (WRONG results)
 };
 
+// Bias gradients in partial-sum mode (round 6: the product path replays bit-identically).  With a workspace and MORE THAN ONE pixel split the bias partial
+// sums of split s go to ws[splits * taps*K*N + s * N + n] -- behind the filter partials, plain stores, summed in split order by the same mh_wgrad_reduce launch
+// -- instead of one float atomic per workgroup and channel, whose arrival order changed the last bits from replay to replay.  One split (or no workspace): a
+// channel receives a single addend, the atomic onto the zeroed db is already order-free.
+__device__ __forceinline__ float* wgrad_bias_ws(const WgradArgs& p) {
+    return (p.ws && p.splits > 1) ? p.ws + (int64_t)p.splits * ((int64_t)p.taps * p.K * p.N) : nullptr;
+}
+
 static std::atomic<int> g_wgrad_target_wgs{0};
 // tuning hook (microbenchmarks): number of workgroups the pixel split aims for (0 = heuristic)
 static std::atomic<int> g_wgrad_target_pct{0};     // mh_tune_wgrad_target_pct: scale of the pixel-split workgroup targets while a plan is recorded (0 = default)
@@ -264,7 +272,10 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_kernel(WgradArgs p) {
                 }
             }
         }
-    if (do_bias && n0 + tid < p.N) mh_atomic_add(p.db + n0 + tid, bsum);
+    if (do_bias && n0 + tid < p.N) {
+        float* const wsb = wgrad_bias_ws(p);
+        if (wsb) wsb[(int64_t)split * p.N + n0 + tid] = bsum; else mh_atomic_add(p.db + n0 + tid, bsum);
+    }
 }
 
 
@@ -477,7 +488,8 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradArgs& p, const int bl
             float t = 0.f;
 #pragma unroll
             for (int r = 0; r < NTH / (BN / 4); ++r) t += red[r * BN + tid];
-            mh_atomic_add(p.db + n0 + tid, t);
+            float* const wsb = wgrad_bias_ws(p);
+            if (wsb) wsb[(int64_t)split * p.N + n0 + tid] = t; else mh_atomic_add(p.db + n0 + tid, t);
         }
     }
 }
@@ -638,7 +650,8 @@ __device__ __forceinline__ void wgrad_n1_body(const WgradArgs& p, const int bloc
     if (p.db && tid == 0) {
         float v = 0.f;
         for (int i = 0; i < 256; ++i) v += bred[i];
-        mh_atomic_add(p.db, v);
+        float* const wsb = wgrad_bias_ws(p);
+        if (wsb) wsb[split] = v; else mh_atomic_add(p.db, v);
     }
 }
 template <int TAPS>
@@ -774,7 +787,8 @@ __global__ __launch_bounds__(64 * IMG_WAVES) void wgrad_image_kernel(WgradArgs p
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < IMG_WAVES; ++w) v += bpart[w][e - 512];
-        mh_atomic_add(p.db + (e - 512), v);
+        float* const wsb = wgrad_bias_ws(p);
+        if (wsb) wsb[(int64_t)blockIdx.x * 16 + (e - 512)] = v; else mh_atomic_add(p.db + (e - 512), v);
     }
 }
 
@@ -1088,3 +1102,4 @@ extern "C" int mh_wgrad_reduce(const mh_wgrad_seg* segs_device, int32_t nseg, in
 
 // this translation unit's copy of the deterministic-accumulation table (mh_common.h)
 extern "C" int mh_det_sync_wgrad(const void* t) { return mh_det_upload(*reinterpret_cast<const mh_det_table*>(t)); }
+extern "C" int mh_det_ovf_wgrad(void) { return mh_det_overflow_take(); }      // this translation unit's saturation flag of the deterministic twin (mh_common.h)

@@ -20,7 +20,8 @@
 //     workgroup writes ONE partial tile: the split workspace shrinks ~8x against one partial per wave;
 //   * one grid serves every layer of a batch (table in device memory): the chip's workgroups are divided over (layer, tile, pixel split) in
 //     proportion to the work, each wave streams tens of rows instead of a handful, and the dispatch latency is paid once per batch.
-// Partial tiles go to ws[split][9][K][N] (the layout mh_wgrad_reduce sums), or straight to dw when a layer has a single split.
+// Partial tiles go to ws[split][9][K][N] (the layout mh_wgrad_reduce sums), or straight to dw when a layer has a single split; the bias partial sums of a
+// layer with several splits follow as ws[splits * 9*K*N + split * N + n] (fixed-order reduction instead of atomics: bit-identical replays).
 #include "mh_common.h"
 #include <stdlib.h>
 #include <atomic>
@@ -253,7 +254,11 @@ __device__ __forceinline__ void wgrad_stream_body(const mh_wgs_layer& L, const i
         if (t3 == 0 && do_bias && tid < 32 && n0 + tid < L.N) {
             float t = 0.f;
             for (int w = 0; w < NW; ++w) t += bred[w * 64 + tid] + bred[w * 64 + 32 + tid];
-            mh_atomic_add(L.db + n0 + tid, t);
+            // round 6: with more than one pixel split the bias partial sums go BEHIND the filter partials, ws[splits][9][K][N] | [splits][N], plain stores summed in
+            // split order by the batch's mh_wgrad_reduce (one more segment) -- a float atomic per workgroup and channel made the last bits of every bias gradient
+            // depend on the arrival order (scripts/exp/det_probe.py).  A single split is a single addend: the atomic onto the zeroed db is order-free.
+            if (L.splits > 1) L.ws[(int64_t)L.splits * ((int64_t)9 * L.K * L.N) + (int64_t)split * L.N + n0 + tid] = t;
+            else mh_atomic_add(L.db + n0 + tid, t);
         }
         __syncthreads();
     }
@@ -414,3 +419,4 @@ extern "C" int mh_wgrad_stream(const mh_wgs_layer* layers_device, int32_t nlayer
 
 // this translation unit's copy of the deterministic-accumulation table (mh_common.h)
 extern "C" int mh_det_sync_wgrad_stream(const void* t) { return mh_det_upload(*reinterpret_cast<const mh_det_table*>(t)); }
+extern "C" int mh_det_ovf_wgrad_stream(void) { return mh_det_overflow_take(); }      // this translation unit's saturation flag of the deterministic twin (mh_common.h)

@@ -114,6 +114,7 @@ SIGNATURES = {
     "mh_tune_conv_bank": (_I, [_I]),
     "mh_tune_wgrad_image": (_I, [_I]),
     "mh_tune_conv_bank_tile": (_I, [_I]),
+    "mh_tune_conv_bank_small": (_I, [_I]),
     "mh_tune_conv_rows": (_I, [_I]),
     "mh_tune_wgrad_target_pct": (_I, [_I]),
     "mh_tune_conv_x3_igemm": (_I, [_I]),
@@ -171,9 +172,12 @@ SIGNATURES = {
     "mh_deterministic_add": (_I, [_P, C.c_int64, _P]),
     "mh_deterministic_remove": (_I, [_P]),
     "mh_deterministic_ranges": (_I, []),
+    "mh_deterministic_overflow": (_I, []),
     "mh_det_flush": (_I, [_P, _P, C.c_int64, _P]),
     "mh_stamp_rate_khz": (_L, []),
     "mh_bias_grad": (_I, [_P, _I, _L, _I, _P, _P]),
+    "mh_bias_grad_blocks": (_I, [_L, _I]),
+    "mh_bias_grad_partial": (_I, [_P, _I, _L, _I, _P, _I, _P]),
     "mh_plan_run": (_I, [C.POINTER(Op), _I, _P]),
     "mh_graph_begin": (_I, [_P]),
     "mh_graph_end": (_I, [_P, C.POINTER(_P)]),
@@ -185,7 +189,7 @@ SIGNATURES = {
     "mh_event_destroy": (_I, [_P]),
     "mh_stream_sync": (_I, [_P]),
 }
-_NO_STATUS = {"mh_conv_image_ok", "mh_level_front_head_ok", "mh_deterministic_ranges", "mh_planes_kc16", "mh_conv2d_planes_bwd_ok", "mh_stamp_rate_khz", "mh_pack32_bytes", "mh_conv2d_planes_ok", "mh_tune_conv_planes", "mh_tune_wgrad_target_pct", "mh_tune_wgrad_image", "mh_conv2d_takes_shadows", "mh_tune_conv_bank_tile", "mh_tune_conv_rows", "mh_last_error", "mh_last_kernel", "mh_tune_conv_bank", "mh_pack_bytes", "mh_abi_version", "mh_tune_conv_patch", "mh_crc32c", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats", "mh_proxy_ws_floats"}
+_NO_STATUS = {"mh_deterministic_overflow", "mh_bias_grad_blocks", "mh_tune_conv_bank_small", "mh_conv_image_ok", "mh_level_front_head_ok", "mh_deterministic_ranges", "mh_planes_kc16", "mh_conv2d_planes_bwd_ok", "mh_stamp_rate_khz", "mh_pack32_bytes", "mh_conv2d_planes_ok", "mh_tune_conv_planes", "mh_tune_wgrad_target_pct", "mh_tune_wgrad_image", "mh_conv2d_takes_shadows", "mh_tune_conv_bank_tile", "mh_tune_conv_rows", "mh_last_error", "mh_last_kernel", "mh_tune_conv_bank", "mh_pack_bytes", "mh_abi_version", "mh_tune_conv_patch", "mh_crc32c", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats", "mh_proxy_ws_floats"}
 
 
 class MadnetHipError(RuntimeError):

@@ -209,7 +209,7 @@ def roofline(lib, eng, stream, reps=20):
                         "frac": ach / PEAK_BF16_MFMA_TFLOPS, "mfma_issue_frac": ach / PEAK_BF16_MFMA_TFLOPS, "arithmetic": "bf16 MFMA (32x32x16), f32 accumulate; operands = bf16 shadows",
                         "traffic": tr, "traffic_source": ("%s key %s (rocprofv3 --pmc passes of scripts/gpu_pmc_r04.sh)" % (PMC_SOURCE, pmc_key)) if tr is not None else None,
                         "launch_ms": ms, "algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": byts,
-                        "splits": [sg[3] for sg in segs], "workspace_bytes_per_launch": 4.0 * sum(sg[2] * sg[3] for sg in segs)}
+                        "splits": [sg[3] for sg in segs if len(sg) == 4], "workspace_bytes_per_launch": 4.0 * sum(sg[2] * sg[3] for sg in segs)}
             nw = 4 if x.B == 1 else 8
             extra["roofline_wgrad"] = stream_entry([(x, dz, dw, db, 2)], "filter gradient of the same layer, alone in its launch (streaming kernel; partial sums only)",
                                                    "roofline_wgrad", nw)

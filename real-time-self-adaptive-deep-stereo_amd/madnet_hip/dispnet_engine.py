@@ -396,6 +396,7 @@ class DispNetEngine(object):
         # (see engine.MadNetEngine.record_backward); a weight shared by two convs (conv1/conv2 of the two towers)
         # puts its second use into a second, accumulating reduction
         segs, segs2, pending, nflush = [], [], [], [0]
+        pending_bias = []                     # (dz view, bias gradient) of the transposed convs: column sums without atomics, issued with their layer's batch
         seen_dst = set()
         uses = {}
         for op in self.ops:                   # weights used by two convs (the towers' conv1 / conv2) must not be written directly
@@ -430,6 +431,9 @@ class DispNetEngine(object):
                             todo.append((xv, dzv, dw, db, stride))
                     ops.shadow_cast(lib, casts, self.dev, r.keep)
                     ops.wgrad_stream(lib, self.lib, self.wsa, batch, items, self.dev, r.keep, nwaves=(4 if self.B == 1 else 8))
+                for dzv, dbt in pending_bias:
+                    ops.bias_grad_partial(lib, self.lib, self.wsa, batch, dzv, dbt)
+                del pending_bias[:]
                 for xv, dzv, dw, db, stride in todo:
                     dup = dw.data_ptr() in seen_dst
                     seen_dst.add(dw.data_ptr())
@@ -501,7 +505,7 @@ class DispNetEngine(object):
                 dz = out.gview()
                 # y = conv2d_transpose(x, w[kh,kw,Cout,Cin]) is the input-gradient of the SAME conv F with HWIO = w:
                 # dw = filter-gradient of F with (input = dz, output-gradient = x); db = sum(dz); dx = F(dz)
-                ops.bias_grad(lib, dz, self.b_(wn, "g"))
+                pending_bias.append((dz, self.b_(wn, "g")))         # BiasAddGrad: per-workgroup partial sums + a segment of the batch's reduction (no float atomics)
                 wgrad(dz, x.view(), self.W_(wn, "g"), None, 2, db_t=self.b_(wn, "g"))
                 w = self.W_(wn)
                 conv_like_dgrad(lambda dx, acc, ref, ma, rng: ops.conv2d_fwd(lib, dz, w, None, dx, stride=2, alpha=1.0, accumulate=acc,

@@ -279,9 +279,14 @@ def conv2d_wgrad_partial(lib, qlib, wsa, segs, x, dz, dw, db, stride=1, dil=1, s
         # a single split IS the gradient: let it store straight into dw (same [tap][K][N] layout), nothing to reduce
         lib.conv2d_wgrad_partial(C.byref(d), _p(x), _p(dz), dz.ld, C.c_void_p(dw.data_ptr()), C.byref(splits), _p(db), _p(stream))
         return
-    ws = wsa.alloc(size * splits.value)
+    # with several splits the kernels store the bias partial sums behind the filter partials, ws[splits][size] | [splits][cout] (no float atomics:
+    # bit-identical replays); the same reduction launch sums them in split order
+    nb = cout * splits.value if (db is not None and splits.value > 1) else 0
+    ws = wsa.alloc(size * splits.value + nb)
     lib.conv2d_wgrad_partial(C.byref(d), _p(x), _p(dz), dz.ld, C.c_void_p(ws), C.byref(splits), _p(db), _p(stream))
     segs.append((ws, dw.data_ptr(), size, splits.value))
+    if nb:
+        segs.append((ws + 4 * size * splits.value, db.data_ptr(), cout, splits.value, 1))      # db += (the step zeroes its gradient ranges first)
 
 
 def wgrad_reduce(lib, segs, device, keep, stream=None, accumulate=False):
@@ -293,8 +298,11 @@ def wgrad_reduce(lib, segs, device, keep, stream=None, accumulate=False):
     assert len(set(s[1] for s in segs)) == len(segs), "a filter gradient may appear once per reduction"
     arr = (_ffi.WgradSeg * len(segs))()
     blk = 0
-    for k, (ws, dst, size, splits) in enumerate(segs):
-        arr[k].ws, arr[k].dst, arr[k].size, arr[k].splits, arr[k].blk0, arr[k].accumulate = ws, dst, size, splits, blk, int(accumulate)
+    for k, sg in enumerate(segs):
+        ws, dst, size, splits = sg[:4]
+        # a 5th field = the segment's own accumulate flag (bias partial sums: always dst += sum onto the zeroed gradient range, so that a single-split use
+        # of a shared weight -- an atomic addend -- is never overwritten)
+        arr[k].ws, arr[k].dst, arr[k].size, arr[k].splits, arr[k].blk0, arr[k].accumulate = ws, dst, size, splits, blk, int(sg[4] if len(sg) > 4 else accumulate)
         blk += (size + 1023) // 1024
     host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
     table = host.to(device)
@@ -522,8 +530,12 @@ def wgrad_stream(lib, qlib, wsa, segs, items, device, keep, stream=None, target_
         if L.splits == 1 and dw.data_ptr() % 16 == 0:
             L.ws = dw.data_ptr()
         else:
-            L.ws = wsa.alloc(size * L.splits)
+            # (splits > 1, or a dw that is not 16-byte aligned)  bias partial sums behind the filter partials, summed by the same reduction launch
+            nb = L.N * L.splits if (db is not None and L.splits > 1) else 0
+            L.ws = wsa.alloc(size * L.splits + nb)
             segs.append((L.ws, dw.data_ptr(), size, L.splits))
+            if nb:
+                segs.append((L.ws + 4 * size * L.splits, db.data_ptr(), L.N, L.splits, 1))
         if hasattr(lib, "tally_wgrad"):
             lib.tally_wgrad(zs.B, zs.H, zs.W, L.K, L.N, 9, L.splits)
     table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
@@ -680,6 +692,15 @@ def pad_reflect(lib, x, out, pad_t, pad_l, div=1.0, sub=0.0, stream=None):
     """out = reflect_pad(x / div - sub).  x: [B,H,W,C] tensor; out: [B,Hp,Wp,out_ld] tensor."""
     B, H, W, Cc = x.shape
     lib.pad_reflect(_p(x), _p(out), B, H, W, Cc, out.shape[1], out.shape[2], pad_t, pad_l, out.shape[3], div, sub, _p(stream))
+
+
+def bias_grad_partial(lib, qlib, wsa, segs, dz, db, stream=None):
+    """db += column sums of dz without float atomics: per-workgroup partial sums into the arena + one more segment for the batch's wgrad_reduce
+    (fixed summation order -- replays of a step are bit-identical).  `qlib` = the real library (grid query); `lib` may be a Recorder."""
+    nb = qlib.bias_grad_blocks(dz.npix, dz.C)
+    ws = wsa.alloc(nb * dz.C)
+    lib.bias_grad_partial(_p(dz), dz.ld, dz.npix, dz.C, C.c_void_p(ws), nb, _p(stream))
+    segs.append((ws, db.data_ptr(), dz.C, nb, 1))
 
 
 def bias_grad(lib, dz, db, stream=None):

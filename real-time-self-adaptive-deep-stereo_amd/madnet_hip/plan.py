@@ -272,6 +272,9 @@ class Recorder(object):
     def bias_grad(self, dz, dz_ld, npix, nch, db, stream):
         self._op(_ffi.OP_BIAS_GRAD, [dz_ld, nch], [], [dz, db], n=npix)
 
+    def bias_grad_partial(self, dz, dz_ld, npix, nch, ws, nblocks, stream):
+        self._op(_ffi.OP_BIAS_GRAD, [dz_ld, nch, nblocks], [], [dz, ws], n=npix)
+
     def fill(self, p, n, v, stream):
         self._op(_ffi.OP_FILL, [], [v], [p], n=n)
 

@@ -73,6 +73,12 @@ def test_bench_set_overrides_are_applied_and_reported(capsys):
         assert json.loads(capsys.readouterr().out)["overrides"][0] == "engine.FUSE_HEAD=False"
         with pytest.raises(AssertionError):
             bench.apply_overrides(["engine.NO_SUCH_FLAG=1"], lib, E)
+        # --model dispnet validates against DispNetSchedule: its own fields pass, MADNet-only fields fail loudly (they used to be silently ignored)
+        from madnet_hip import dispnet_engine as DE
+        _, ds = bench.apply_overrides(["engine.FLUSH_MIN=3", "engine.EARLY_UPDATE=False"], lib, E, DE.DispNetSchedule)
+        assert ds == {"FLUSH_MIN": 3, "EARLY_UPDATE": False} and DE.DispNetSchedule(**ds).FLUSH_MIN == 3
+        with pytest.raises(AssertionError):
+            bench.apply_overrides(["engine.FUSE_HEAD=False"], lib, E, DE.DispNetSchedule)
         with pytest.raises(SystemExit):
             bench.apply_overrides(["other.x=1"], lib, E)
     finally:

@@ -746,6 +746,52 @@ def test_conv_small_layer_bank_kernel(backend, case, what):
         assert (outs[0] - outs[1]).abs().max().item() <= 4e-5 * sc
 
 
+@pytest.mark.parametrize("case", [(1, 6, 20, 128, 128, 1), (1, 12, 40, 134, 128, 1), (2, 24, 80, 64, 96, 1), (1, 9, 33, 96, 192, 1), (1, 12, 20, 32, 48, 2), (1, 5, 17, 36, 20, 1)])
+def test_conv_small_layer_bank_kernel_placement_modes(backend, case):
+    """mh_tune_conv_bank_small (round 6): the workgroup -> (XCD, tile) map of the small-layer kernel -- every XCD with the pixel-major order (0), the
+    column-major order where the model prefers it (1), the layer confined to the fewest XCDs (2), both (3 = the default's model) -- is a permutation of
+    the same tiles (plus workgroups that exit at once): forward and input gradient are bit-identical in every mode, every output element is written."""
+    B, H, W, Ci, Co, dil = case
+    dev = backend.device
+    w = _rand((3, 3, Ci, Co), 812, dev, 0.2)
+    b = _rand((Co,), 813, dev)
+    x = _rand((B, H, W, Ci), 811, dev)
+    gz = _rand((B, H, W, Co), 814, dev)
+    mref = _rand((B, H, W, Ci), 816, dev)
+    keep = []
+    ldx = (Ci + 3) // 4 * 4
+    xb, xv = _padded(x, ldx)
+    zb, zv = _padded(gz, (Co + 3) // 4 * 4)
+    mb, mv = _padded(mref, ldx)
+    bank = torch.full((ops.pack_bytes(w, 1) // 4,), float("nan"), device=dev)
+    bank_t = torch.full((ops.pack_bytes(w, 1, 1) // 4,), float("nan"), device=dev)
+    ops.pack_weights(backend.lib, [(w, bank, 1, 0), (w, bank_t, 1, 1)], dev, keep)
+    backend.lib.tune_conv_bank(-1)
+    res = []
+    prev = backend.lib.tune_conv_bank_small(-1)
+    try:
+        for mode in (0, 1, 2, 3, -1):
+            backend.lib.tune_conv_bank_small(mode)
+            y = torch.full((B, H, W, Co), float("nan"), device=dev)
+            dxb = torch.full((B, H, W, ldx), float("nan"), device=dev)
+            with ops.precision_scope("bf16"):
+                ops.conv2d_fwd(backend.lib, xv, w, b, ops.view(y), dil=dil, alpha=0.2, wb=bank)
+                assert "conv_bank_small_kernel<fwd" in backend.lib.last_kernel().decode()
+            ops.PRECISION_BWD = 1
+            try:
+                ops.conv2d_dgrad(backend.lib, zv, w, ops.View(dxb, B, H, W, Ci, ldx), dil=dil, mask_ref=mv, mask_alpha=0.2, wb=bank_t)
+                assert "conv_bank_small_kernel<dgrad" in backend.lib.last_kernel().decode()
+            finally:
+                ops.PRECISION_BWD = None
+            backend.sync()
+            res.append((y.cpu().clone(), dxb[..., :Ci].cpu().clone()))
+    finally:
+        backend.lib.tune_conv_bank_small(prev)
+    assert torch.isfinite(res[0][0]).all() and torch.isfinite(res[0][1]).all()
+    for y, dx in res[1:]:
+        assert torch.equal(y, res[0][0]) and torch.equal(dx, res[0][1])
+
+
 def test_wgrad_bf16_eight_wave_tile(backend):
     """Filter gradient of a layer that is launched on its own (> 4096 reduction pixels) with > 64 input and output channels: the 128x128
     tile with 8 waves of 32x64 (wgrad_bf16_kernel<4,2,2,4>), partial sums + reduction, against the oracle on bf16-rounded operands."""
@@ -831,13 +877,17 @@ def test_wgrad_split_targets_follow_the_tuning_hook(backend):
     backend.lib.tune_wgrad_target_pct(0)
     assert counts[150] > counts[0] > counts[50] >= 1, counts
     # a count resolved under 150 % launches under the default setting
-    ws = torch.full((counts[150], 9 * Ci * Co), float("nan"), device=dev); db = torch.zeros(Co, device=dev)
-    sp = C.c_int32(counts[150])
+    # workspace (ABI 15): [splits][9*Ci*Co] filter partials, then [splits][Co] bias partials; db itself stays untouched when splits > 1
+    ns, size = counts[150], 9 * Ci * Co
+    ws = torch.full((ns * (size + Co),), float("nan"), device=dev); db = torch.zeros(Co, device=dev)
+    sp = C.c_int32(ns)
     backend.lib.conv2d_wgrad_partial(C.byref(d), ops._p(xv), ops._p(zv), zv.ld, C.c_void_p(ws.data_ptr()), C.byref(sp), C.c_void_p(db.data_ptr()), None)
     backend.sync()
     xr = _bf(x.cpu()).double(); w0 = torch.zeros(3, 3, Ci, Co, dtype=torch.float64, requires_grad=True)
     (gw,) = torch.autograd.grad(T.conv2d(xr, w0, None, alpha=1.0), [w0], _bf(gz.cpu()).double())
-    assert (ws.cpu().double().sum(0).view(3, 3, Ci, Co) - gw).abs().max().item() <= 2e-5 * max(1.0, gw.abs().max().item())
+    assert (ws[:ns * size].view(ns, size).cpu().double().sum(0).view(3, 3, Ci, Co) - gw).abs().max().item() <= 2e-5 * max(1.0, gw.abs().max().item())
+    gb = gz.cpu().double().sum((0, 1, 2))
+    assert ns > 1 and (db == 0).all() and (ws[ns * size:].view(ns, Co).cpu().double().sum(0) - gb).abs().max().item() <= 2e-5 * max(1.0, gb.abs().max().item())
 
 
 def test_wgrad_reduce_small_gradient_many_splits(backend):

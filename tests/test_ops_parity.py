@@ -296,6 +296,49 @@ def test_corr_fwd_both_kernels(backend, direct):
     ok, err = _close(out, ref); assert ok, err
 
 
+@pytest.mark.parametrize("case", [(1000, 1, 1), (777, 3, 4), (513, 12, 16), (300, 64, 64), (129, 200, 200), (70, 1024, 1024), (5, 96, 100), (40000, 32, 32)])
+def test_bias_grad_partial_column_sums(backend, case):
+    """mh_bias_grad_partial (ABI 15): the same column sums as per-workgroup partial rows ws[nblocks][nch] + one mh_wgrad_reduce segment that sums them in order
+    onto db (accumulating) -- no float atomics: two runs are bit-identical, the sum is the oracle's."""
+    npix, nch, ld = case
+    dev = backend.device
+    t = _rand((1, 1, npix, ld), 31, dev)
+    v = ops.View(t, 1, 1, npix, nch, ld)
+    db0 = _rand((nch,), 32, dev)
+    ref = db0.cpu().double() + t.cpu().double()[0, 0, :, :nch].sum(0)
+    outs = []
+    for _ in range(2):
+        db = db0.clone()
+        wsa = ops.WgradWorkspace(dev); segs, keep = [], []
+        ops.bias_grad_partial(backend.lib, backend.lib, wsa, segs, v, db)
+        assert len(segs) == 1 and segs[0][2] == nch and segs[0][3] == backend.lib.bias_grad_blocks(npix, nch) and segs[0][4] == 1
+        ops.wgrad_reduce(backend.lib, segs, dev, keep)
+        backend.sync()
+        outs.append(db.cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[0].double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_deterministic_twin_reports_saturated_addends(backend):
+    """mh_deterministic_overflow: an addend beyond the fixed-point twin's range (|v| >= 2^15) is saturated AND flagged; in-range sums are not."""
+    import ctypes as C
+    dev = backend.device
+    db = torch.zeros(4, device=dev); twin = torch.zeros(4, dtype=torch.int64, device=dev)
+    assert backend.lib.deterministic_overflow() == 0
+    assert backend.lib.deterministic_add(C.c_void_p(db.data_ptr()), 4, C.c_void_p(twin.data_ptr())) == 0
+    try:
+        small = torch.full((1, 1, 64, 4), 2.0, device=dev)
+        ops.bias_grad(backend.lib, ops.View(small, 1, 1, 64, 4, 4), db)
+        backend.sync()
+        assert backend.lib.deterministic_overflow() == 0
+        big = torch.full((1, 1, 64, 4), 1.0e5, device=dev)                 # a workgroup's column sum = 6.4e6 >> 32767
+        ops.bias_grad(backend.lib, ops.View(big, 1, 1, 64, 4, 4), db)
+        backend.sync()
+        assert backend.lib.deterministic_overflow() == 1 and backend.lib.deterministic_overflow() == 0        # sticky until read, then cleared
+    finally:
+        backend.lib.deterministic_remove(C.c_void_p(db.data_ptr()))
+
+
 @pytest.mark.parametrize("case", [(1000, 1, 1), (777, 3, 4), (513, 12, 16), (300, 64, 64), (129, 200, 200), (70, 1024, 1024), (5, 96, 100)])
 def test_bias_grad_column_sums(backend, case):
     """db += column sums of a [npix, nch] view with row stride ld (BiasAddGrad of the transposed convs)."""
@@ -618,6 +661,12 @@ def test_corr_warp_bwd_many_taps_on_one_column(backend):
     assert (di0.cpu() - di1.cpu()).abs().max().item() <= 2e-5 * max(1.0, di0.abs().max().item())
     assert (du0.cpu() - du1.cpu()).abs().max().item() <= 2e-5 * max(1.0, du0.abs().max().item())
     assert int((di0[0, 0].abs().sum(-1) > 0).sum().item()) == 2 and int((di0[0, 2].abs().sum(-1) > 0).sum().item()) > 30       # (row 0: every tap on two columns)
+    # a fold of 40 taps onto one column is summed in ascending (pixel, tap) order like any other (beyond 16 taps it used to be arrival order):
+    # a second launch gives the same bits
+    di2 = torch.zeros(B, H, W, Cc, device=dev); dL2 = torch.zeros(B, H, W, Cc, device=dev); du2 = torch.zeros(B, H, W, device=dev)
+    ops.corr_warp_bwd(backend.lib, gv, ops.view(L), ops.view(Rw), ops.view(R), u, ops.view(dL2), ops.view(di2), du2, md, 1, coff=Cc, copy_left=True)
+    backend.sync()
+    assert torch.equal(di1.cpu(), di2.cpu()) and torch.equal(du1.cpu(), du2.cpu())
 
 
 def test_corr_warp_bwd_row_form_is_deterministic_without_a_twin(backend):
