@@ -339,7 +339,9 @@ def bench_mad(args, lib, dev, rank, world, dist):
     # --shared-model: ONE model for all ranks -- the sampled block's gradient ranges + the loss travel as ONE all-reduce between the block's
     # backward plan and its update plan (adapter.step); SEQUENTIAL sampling keeps the ranks on the same block without exchanging the draw
     ad = Adapter(net, mode="MAD", block_config=cfg, lr=1e-4, sample_mode="SEQUENTIAL" if args.shared_model else "PROBABILITY", num_blocks=1,
-                 use_graph=not args.no_graph, shared_model=args.shared_model)
+                 use_graph=not args.no_graph, shared_model=args.shared_model, in_graph_collective=(False if args.host_collective else None))
+    if args.rccl is not None:
+        args.rccl["in_graph"] = ad.comm is not None
     for i in range(len(cfg)):
         ad._plan((i,))                       # compile + capture every block's plan outside the timed region
     last = {}
@@ -769,6 +771,9 @@ def main():
     ap.add_argument("--early-reduce", action="store_true", help="--shared-model: force the two-piece all-reduce on a 1-rank group too (default: only when world > 1)")
     ap.add_argument("--late-reduce", action="store_true",
                     help="--shared-model: ONE all-reduce behind the whole backward pass instead of [estimators + context + loss] early / [pyramid] late")
+    ap.add_argument("--host-collective", action="store_true",
+                    help="--shared-model: the round-5 form -- torch.distributed all-reduce between two captured graphs -- instead of the collective recorded inside the "
+                         "step's plan through the C-ABI (mh_allreduce_sum)")
     ap.add_argument("--shared-model", action="store_true",
                     help="the streams of ALL GPUs adapt ONE model: the flat gradient buffer is all-reduced (RCCL over xGMI) between "
                          "the backward plan and the momentum plan, scaled by 1/world (BASELINE config 5); default: private models, no collective")
@@ -861,8 +866,41 @@ def main():
     shared = args.shared_model and args.mode == "FULL"
     use_graph = (not args.no_graph) and dev.kind == "cuda"
 
+    comm = None
+    if shared and dev.kind == "cuda" and not args.host_collective and lib.comm_available() and not dispnet:
+        # the collective through the C-ABI, recorded INSIDE the step's plan: one hipGraph per shared-model step (madnet_hip/comm.py); torch.distributed has
+        # carried the unique id and is not touched again
+        from madnet_hip.comm import Comm
+        comm = Comm(lib, rank=rank, world=world, dist=dist, device=dev.name)
+        if rccl is not None:
+            rccl.update({"in_graph": True, "version": comm.version_string, "via": "libmadnet_hip.so: mh_comm_init / mh_allreduce_sum (MH_OP_ALLREDUCE plan op)"})
+    elif rccl is not None:
+        rccl["in_graph"] = False
+
     def make_step(e):
         """compile + validate eagerly + capture; returns (one_step, plan)"""
+        if shared and comm is not None:
+            plan = e.build_plan("FULL", lr=1e-4, grad_scale=1.0 / world, collective=comm)
+            bare = e.build_plan("FULL", lr=1e-4, grad_scale=1.0 / world)          # the same launches without the all-reduces: collective_ms_in_step = with - without
+            G, lo = e.params.g_loss, e.pyramid_range()[1]
+            with dev.ctx():
+                plan.run(lib, dev.sh)
+                dev.sync_stream()
+                if use_graph:
+                    plan.capture(lib, dev.sh)
+                    bare.capture(lib, dev.sh)
+
+            def one_step():
+                plan.launch(lib, dev.sh)
+            one_step.n_ops = plan.n
+
+            def collectives_only():
+                comm.allreduce(lib, [(G, lo, G.numel() - lo)], stream=dev.sh)
+                comm.allreduce(lib, [(G, 0, lo)], stream=dev.sh)
+            one_step.collectives_only = collectives_only
+            one_step.without_collectives = lambda: bare.launch(lib, dev.sh)
+            one_step.pieces = [int((G.numel() - lo) * 4), int(lo * 4)]
+            return one_step, plan
         if shared:
             # data-parallel SGD over all streams: grads (sum over ranks) * 1/world -> identical momentum update everywhere.  Two pieces
             # (madnet_hip/adapter.py): [estimators + context + loss] goes out asynchronously when the backward pass reaches the
@@ -999,6 +1037,7 @@ def main():
         ms_without = 1e3 * nocoll[0] / args.steps
         shared_info = {"collective_ms_alone": coll_ms, "collective_ms_in_step": ms - ms_without, "ms_per_step_without_collectives": ms_without,
                        "pieces_bytes": one_step.pieces,
+                       "in_graph": comm is not None,
                        "order": ("[estimators + context + loss] async behind their backward pass, [pyramid] behind the pyramid's" if len(one_step.pieces) == 2
                                  else "one all-reduce behind the backward pass"),
                        "algbw_gbs": sum(one_step.pieces) / (coll_ms * 1e-3) / 1e9 if coll_ms > 0 else None}

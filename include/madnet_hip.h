@@ -36,6 +36,7 @@ extern "C" {
 #define MH_OK 0
 #define MH_ERR_ARG (-1)          /* null pointer, non-positive size, ld smaller than the channel count, ... */
 #define MH_ERR_ALIGN (-2)        /* a 16-byte alignment / multiple-of-4 requirement of the entry point is violated */
+#define MH_ERR_COLLECTIVE (-4)   /* RCCL returned an error (mh_last_error carries its code and text) */
 #define MH_ERR_UNSUPPORTED (-3)  /* valid arguments outside what the kernels implement (sizes >= 2 GiB, odd mode combinations) */
 
 const char* mh_last_error(void);
@@ -508,6 +509,25 @@ int mh_bias_grad(const float* dz, int32_t dz_ld, int64_t npix, int32_t nch, floa
 int mh_bias_grad_blocks(int64_t npix, int32_t nch);
 int mh_bias_grad_partial(const float* dz, int32_t dz_ld, int64_t npix, int32_t nch, float* ws, int32_t nblocks, void* stream);
 
+/* ---- the collective of the shared-model mode (BASELINE config 5): RCCL all-reduce over xGMI behind the C-ABI ------------------------------------
+ * Streams with PRIVATE models need no collective.  Streams of several GPUs that adapt ONE model sum their flat fp32 gradient buffers (+ the 4 loss floats behind
+ * them) once per step, between the backward pass and the optimizer (the reference is single-GPU, Stereo_Online_Adaptation.py:39,114-128: every rank then applies
+ * the update the reference applies).  One process per GPU; rank 0 calls mh_comm_unique_id and hands the MH_COMM_ID_BYTES bytes to the others by any means
+ * (the host layer uses torch.distributed for exactly that), every rank calls mh_comm_init on its device (collective: returns when all `world` ranks have), then
+ * mh_allreduce_sum on its stream -- or records it as a plan op (MH_OP_ALLREDUCE) so that a captured step is ONE hipGraph with the collective inside.
+ * RCCL is resolved at run time (dlopen librccl.so; MADNET_HIP_RCCL = a full path): without it these entry points return MH_ERR_UNSUPPORTED and everything else
+ * works.  RCCL errors: MH_ERR_COLLECTIVE + mh_last_error(). */
+#define MH_COMM_ID_BYTES 128
+#define MH_ALLREDUCE_MAX_BUFS 8
+int mh_comm_available(void);                                    /* 1 when librccl.so was found and has the entry points (no status, no error message) */
+int mh_comm_unique_id(void* id);                                /* ncclGetUniqueId: MH_COMM_ID_BYTES bytes, rank 0 only */
+int mh_comm_init(const void* id, int32_t rank, int32_t world, void** comm);      /* ncclCommInitRank on the CURRENT device */
+int mh_comm_destroy(void* comm);
+int mh_comm_info(void* comm, int32_t* rank, int32_t* world, int32_t* rccl_version);       /* any out pointer may be NULL */
+/* in-place fp32 sum over the ranks of n <= MH_ALLREDUCE_MAX_BUFS device buffers as ONE RCCL group (a MAD block's two gradient ranges + the loss tail travel together).
+ * Every rank issues the same sequence of calls with the same counts.  Allowed inside a stream capture. */
+int mh_allreduce_sum(float* const* bufs, const int64_t* counts, int32_t n, void* comm, void* stream);
+
 /* (the process-wide tuning hooks of the benchmarks live in madnet_hip_tune.h: none of them is part of the reference interface) */
 
 /* host utility: CRC-32C (Castagnoli) of a host buffer, chained through `crc` (0 to start) -- used by the TensorFlow
@@ -520,7 +540,8 @@ enum { MH_OP_CONV = 1, MH_OP_WGRAD, MH_OP_CORR_FWD, MH_OP_CORR_BWD, MH_OP_WARP_F
        MH_OP_RESIZE_FWD, MH_OP_RESIZE_BWD, MH_OP_PAD_REFLECT, MH_OP_LOSS, MH_OP_METRICS,
        MH_OP_MOMENTUM, MH_OP_COPY_CH, MH_OP_LEAKY_BWD, MH_OP_FILL, MH_OP_BIAS_GRAD,
        MH_OP_WGRAD_PARTIAL, MH_OP_WGRAD_REDUCE, MH_OP_PROXY_LOSS, MH_OP_SUPERVISED_LOSS, MH_OP_ADAM, MH_OP_ADAM_ADVANCE,
-       MH_OP_RESIZE_IMAGE, MH_OP_LEVEL_FRONT, MH_OP_RESERVED_25 /* (was: transposed filter banks of the retired LDS-free kernel) */, MH_OP_PACK_W, MH_OP_CORR_WARP_BWD, MH_OP_SHADOW_CAST, MH_OP_WGRAD_STREAM, MH_OP_HEAD_BWD, MH_OP_HEAD_FWD, MH_OP_CONV_PLANES, MH_OP_PLANE_SPLIT, MH_OP_STAMP, MH_OP_CONV_PLANES_BWD, MH_OP_DET_FLUSH, MH_OP_CONV_IMAGE };
+       MH_OP_RESIZE_IMAGE, MH_OP_LEVEL_FRONT, MH_OP_RESERVED_25 /* (was: transposed filter banks of the retired LDS-free kernel) */, MH_OP_PACK_W, MH_OP_CORR_WARP_BWD, MH_OP_SHADOW_CAST, MH_OP_WGRAD_STREAM, MH_OP_HEAD_BWD, MH_OP_HEAD_FWD, MH_OP_CONV_PLANES, MH_OP_PLANE_SPLIT, MH_OP_STAMP, MH_OP_CONV_PLANES_BWD, MH_OP_DET_FLUSH, MH_OP_CONV_IMAGE,
+       MH_OP_ALLREDUCE /* mh_allreduce_sum: p[0] = comm, p[1 .. i[0]] = buffers, i[1 .. i[0]] = counts (floats, < 2^31 each) */ };
 /* i[26] of every op is its scheduling word: low byte = lane (0 = the caller's stream; 1..MH_MAX_LANES-1 = side
  * streams owned by the library: the op is forked from lane 0 right before it, i.e. ordered after everything recorded so
  * far, and runs concurrently with the lane-0 ops that follow); MH_OP_JOIN = lane 0 first waits for all side lanes.

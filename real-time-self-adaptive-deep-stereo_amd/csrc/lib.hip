@@ -239,6 +239,13 @@ static int run_op(const mh_op& o, void* s) {
                                      i[11], o.f[2], (float*)p[3], i[12], p[4], i[13], s);
         case MH_OP_DET_FLUSH:        // p: dst, twin ; n
             return mh_det_flush((float*)p[0], p[1], o.n, s);
+        case MH_OP_ALLREDUCE: {      // p[0] = comm, p[1 .. i[0]] = buffers ; i[1 .. i[0]] = counts
+            float* bufs[MH_ALLREDUCE_MAX_BUFS]; int64_t counts[MH_ALLREDUCE_MAX_BUFS];
+            const int nb = i[0];
+            if (nb < 1 || nb > MH_ALLREDUCE_MAX_BUFS) { mh_set_error("MH_OP_ALLREDUCE: %d buffers", nb); return MH_ERR_ARG; }
+            for (int k = 0; k < nb; ++k) { bufs[k] = (float*)p[1 + k]; counts[k] = i[1 + k]; }
+            return mh_allreduce_sum(bufs, counts, nb, p[0], s);
+        }
         case MH_OP_STAMP:
             return mh_stamp(p[0], s);
         case MH_OP_PLANE_SPLIT:

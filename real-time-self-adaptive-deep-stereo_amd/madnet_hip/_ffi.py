@@ -31,9 +31,11 @@ class Op(C.Structure):
 (OP_CONV, OP_WGRAD, OP_CORR_FWD, OP_CORR_BWD, OP_WARP_FWD, OP_WARP_BWD, OP_RESIZE_FWD, OP_RESIZE_BWD,
  OP_PAD_REFLECT, OP_LOSS, OP_METRICS, OP_MOMENTUM, OP_COPY_CH, OP_LEAKY_BWD, OP_FILL, OP_BIAS_GRAD,
  OP_WGRAD_PARTIAL, OP_WGRAD_REDUCE, OP_PROXY_LOSS, OP_SUPERVISED_LOSS, OP_ADAM, OP_ADAM_ADVANCE, OP_RESIZE_IMAGE, OP_LEVEL_FRONT, OP_RESERVED_25, OP_PACK_W, OP_CORR_WARP_BWD,
- OP_SHADOW_CAST, OP_WGRAD_STREAM, OP_HEAD_BWD, OP_HEAD_FWD, OP_CONV_PLANES, OP_PLANE_SPLIT, OP_STAMP, OP_CONV_PLANES_BWD, OP_DET_FLUSH, OP_CONV_IMAGE) = range(1, 38)
+ OP_SHADOW_CAST, OP_WGRAD_STREAM, OP_HEAD_BWD, OP_HEAD_FWD, OP_CONV_PLANES, OP_PLANE_SPLIT, OP_STAMP, OP_CONV_PLANES_BWD, OP_DET_FLUSH, OP_CONV_IMAGE, OP_ALLREDUCE) = range(1, 39)
 
 
+COMM_ID_BYTES = 128            # MH_COMM_ID_BYTES
+ALLREDUCE_MAX_BUFS = 8         # MH_ALLREDUCE_MAX_BUFS
 OP_JOIN = 0x100
 OP_NODEFER = 0x200
 MAX_LANES = 5
@@ -177,6 +179,12 @@ SIGNATURES = {
     "mh_stamp_rate_khz": (_L, []),
     "mh_bias_grad": (_I, [_P, _I, _L, _I, _P, _P]),
     "mh_bias_grad_blocks": (_I, [_L, _I]),
+    "mh_comm_available": (_I, []),
+    "mh_comm_unique_id": (_I, [_P]),
+    "mh_comm_init": (_I, [_P, _I, _I, C.POINTER(C.c_void_p)]),
+    "mh_comm_destroy": (_I, [_P]),
+    "mh_comm_info": (_I, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "mh_allreduce_sum": (_I, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), _I, _P, _P]),
     "mh_bias_grad_partial": (_I, [_P, _I, _L, _I, _P, _I, _P]),
     "mh_plan_run": (_I, [C.POINTER(Op), _I, _P]),
     "mh_graph_begin": (_I, [_P]),
@@ -189,7 +197,7 @@ SIGNATURES = {
     "mh_event_destroy": (_I, [_P]),
     "mh_stream_sync": (_I, [_P]),
 }
-_NO_STATUS = {"mh_deterministic_overflow", "mh_bias_grad_blocks", "mh_tune_conv_bank_small", "mh_conv_image_ok", "mh_level_front_head_ok", "mh_deterministic_ranges", "mh_planes_kc16", "mh_conv2d_planes_bwd_ok", "mh_stamp_rate_khz", "mh_pack32_bytes", "mh_conv2d_planes_ok", "mh_tune_conv_planes", "mh_tune_wgrad_target_pct", "mh_tune_wgrad_image", "mh_conv2d_takes_shadows", "mh_tune_conv_bank_tile", "mh_tune_conv_rows", "mh_last_error", "mh_last_kernel", "mh_tune_conv_bank", "mh_pack_bytes", "mh_abi_version", "mh_tune_conv_patch", "mh_crc32c", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats", "mh_proxy_ws_floats"}
+_NO_STATUS = {"mh_comm_available", "mh_deterministic_overflow", "mh_bias_grad_blocks", "mh_tune_conv_bank_small", "mh_conv_image_ok", "mh_level_front_head_ok", "mh_deterministic_ranges", "mh_planes_kc16", "mh_conv2d_planes_bwd_ok", "mh_stamp_rate_khz", "mh_pack32_bytes", "mh_conv2d_planes_ok", "mh_tune_conv_planes", "mh_tune_wgrad_target_pct", "mh_tune_wgrad_image", "mh_conv2d_takes_shadows", "mh_tune_conv_bank_tile", "mh_tune_conv_rows", "mh_last_error", "mh_last_kernel", "mh_tune_conv_bank", "mh_pack_bytes", "mh_abi_version", "mh_tune_conv_patch", "mh_crc32c", "mh_device_count", "mh_loss_ws_floats", "mh_metrics_ws_floats", "mh_proxy_ws_floats"}
 
 
 class MadnetHipError(RuntimeError):

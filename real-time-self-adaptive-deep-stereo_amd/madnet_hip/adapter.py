@@ -4,12 +4,15 @@ loss + EPE/bad3 -> selected backward(s) -> momentum update -> reward update -> r
 
 Every (mode, sampled blocks) combination is compiled once into a plan and replayed as a hipGraph.
 Multi-GPU: streams are independent by default (private weights, no collective).  With
-shared_model=True the flat GRADIENT buffer is all-reduced (RCCL over xGMI via torch.distributed)
-between the backward plan and the fused momentum plan, which is exactly data-parallel SGD; the loss
-used for the reward / reset decisions is averaged too so every rank samples the same block.
-FULL mode issues the collective in two pieces: [estimators + context network + loss] (73 % of the
-bytes, contiguous in the flat layout) as soon as the backward pass reaches the pyramid -- it runs on
-RCCL's stream while the pyramid's backward graph runs on ours -- and [pyramid] behind it.
+shared_model=True the flat GRADIENT buffer is all-reduced (RCCL over xGMI) between the backward pass
+and the fused momentum update, which is exactly data-parallel SGD; the loss used for the reward /
+reset decisions is averaged too so every rank samples the same block.
+On the GPU the collective goes through the C-ABI (madnet_hip/comm.py: mh_comm_init, mh_allreduce_sum) and
+is RECORDED in the step's plan (round 6): the shared-model step is ONE hipGraph replay.  FULL mode
+issues it in two pieces: [estimators + context network + loss] (73 % of the bytes, contiguous in the
+flat layout) on a side lane as soon as the backward pass reaches the pyramid, [pyramid] behind it;
+MAD: the block's ranges + the loss as one RCCL group.  torch.distributed only carries the unique id.
+(CPU emulator runs -- test plumbing, gloo -- keep the older form: the collective between two plans.)
 """
 import collections
 import numpy as np
@@ -28,7 +31,7 @@ class Adapter(object):
     def __init__(self, net, mode="MAD", block_config=None, lr=1e-4, momentum=0.9, sample_mode="PROBABILITY",
                  num_blocks=1, fixed_id=0, sample_frequency=1, ssim_th=0.5, reprojection_scale=1,
                  use_graph=True, shared_model=False, process_group=None, loss="reprojection", dilation=1, decay=0.99, uf=0.01,
-                 optimizer="momentum", reset_optimizer=False, reward_every_step_first=False, early_reduce=None):
+                 optimizer="momentum", reset_optimizer=False, reward_every_step_first=False, early_reduce=None, in_graph_collective=None):
         """loss='proxy', dilation, decay, uf: the continual-adaptation variant (Stereo_Continual_Adaptation.py:75-112,
         205-249, 302-304): proxy-label mean_l1 loss, weight update only every `dilation`-th frame, reward update
         sample_distribution = decay * sample_distribution (+ uf * gain on the last trained blocks).
@@ -58,10 +61,11 @@ class Adapter(object):
         self.sample_frequency, self.ssim_th = sample_frequency, ssim_th
         self.shared, self.pg = shared_model, process_group
         self.world = 1
+        self.comm = None               # madnet_hip.comm.Comm: the collective is recorded inside the step's plan (GPU); None: torch.distributed between two plans
         if shared_model:
             import torch.distributed as dist
             self.dist = dist
-            self.world = dist.get_world_size(process_group)
+            self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # shared FULL step: all-reduce the estimator / context gradients while the pyramid's backward pass still runs (False: ONE
         # collective behind the whole backward pass).  None = when there is a wire to hide (world > 1): on a 1-rank group the second graph
         # boundary + the extra stream hand-overs cost ~0.1 ms and hide nothing (profiles/r03_experiments.txt #11).
@@ -70,6 +74,13 @@ class Adapter(object):
         self.early_reduce = bool(early_reduce) and shared_model and mode == "FULL" and hasattr(self.eng, "pyramid_range")
         dev = self.eng.left.device
         self.cuda = dev.type == "cuda"
+        if shared_model and self.cuda and in_graph_collective is not False and hasattr(self.eng, "pyramid_range") and self.lib.comm_available():
+            from .comm import Comm
+            with torch.cuda.device(dev):
+                self.comm = Comm(self.lib, rank=(self.dist.get_rank(process_group) if self.dist.is_initialized() else 0), world=self.world,
+                                 dist=self.dist, group=process_group, device=dev)
+        elif in_graph_collective:
+            raise RuntimeError("in_graph_collective=True needs a GPU engine of MADNet and RCCL (mh_comm_available)")
         self.use_graph = use_graph and self.cuda
         self.stream = torch.cuda.Stream(device=dev) if self.cuda else None
         self.blocks = []
@@ -105,18 +116,19 @@ class Adapter(object):
         if key not in self._plans:
             eng = self.eng
             gs = 1.0 / self.world
-            parts = ("grad", "update") if self.shared else ("all",)
-            if self.shared and key == "FULL" and self.early_reduce:
+            parts = ("grad", "update") if (self.shared and self.comm is None) else ("all",)
+            if self.shared and self.comm is None and key == "FULL" and self.early_reduce:
                 parts = ("grad_split", "update")
+            coll = {"collective": self.comm} if (self.comm is not None and key != "NONE") else {}
             plans = []
             for part in parts:
                 if key == "NONE":
                     p = eng.build_plan("NONE", part=part)
                 elif key == "FULL":
-                    p = eng.build_plan("FULL", lr=self.lr, grad_scale=gs, part=part, optimizer=self.optimizer, momentum=self.momentum)
+                    p = eng.build_plan("FULL", lr=self.lr, grad_scale=gs, part=part, optimizer=self.optimizer, momentum=self.momentum, **coll)
                 else:
                     p = eng.build_plan("MAD", lr=self.lr, grad_scale=gs, part=part, blocks=[self.blocks[i] for i in key],
-                                       optimizer=self.optimizer, momentum=self.momentum)
+                                       optimizer=self.optimizer, momentum=self.momentum, **coll)
                 for q in (p if isinstance(p, list) else [p]):
                     if self.use_graph and q.n > 0:
                         with torch.cuda.stream(self.stream):
@@ -170,7 +182,10 @@ class Adapter(object):
         with ctx:
             self._upload(left, right, gt, proxy)
             plans[0].launch(self.lib, sh)
-            if self.shared and len(plans) == 3:
+            if self.shared and self.comm is not None:
+                # the collective(s) are ops of plans[0] (one hipGraph): nothing to do between plans
+                self.collectives_last_step = 0 if key == "NONE" else (2 if key == "FULL" else len(key))
+            elif self.shared and len(plans) == 3:
                 # FULL, two pieces: plans = [forward + loss + estimator / context backward, pyramid backward, update].  The first
                 # collective is asynchronous: RCCL's stream waits for plans[0], ours goes on with the pyramid.
                 P = eng.params

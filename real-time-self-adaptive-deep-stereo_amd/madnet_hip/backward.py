@@ -33,8 +33,10 @@ class BackwardRecorder(object):
             prev = up_V[k]
         return pyr_tr, pyr_need, est_tr, ctx_tr, up_V
 
-    def record_backward(self, r, head, train_vars, bulkhead, heads=None, early_update=None):
-        """early_update = (lr, momentum, grad_scale) (EARLY_UPDATE, FULL momentum steps): the update of a batch's layers follows the batch's reduction on its
+    def record_backward(self, r, head, train_vars, bulkhead, heads=None, early_update=None, at_cut=None):
+        """at_cut(r): called where the estimators' / context network's gradients (and the loss) are final and the pyramid's backward pass starts -- the point
+        build_plan(part='grad_split') cuts the recording at; the in-graph shared-model step records its first all-reduce there (engine._build_plan).
+        early_update = (lr, momentum, grad_scale) (EARLY_UPDATE, FULL momentum steps): the update of a batch's layers follows the batch's reduction on its
         lane -- their input gradients were launched before the batch's fork edge and nothing later in the step reads those weights (the fragment banks
         were packed at the start of the step) -- instead of ONE launch over every parameter behind the join; returns the ranges updated that way.
         head: 'final' (loss on rescaled_prediction, FULL mode) or a level k in LEVELS
@@ -327,6 +329,8 @@ class BackwardRecorder(object):
         # the second is still being computed
         if hasattr(r, "cut"):
             r.cut()
+        if at_cut is not None:
+            at_cut(r)
         top = None
         for i in range(12, 0, -1):
             if ("F", i, 0) in written or ("F", i, 1) in written or ("Fd", i) in written:

@@ -33,7 +33,7 @@ def _time_ms(lib, stream, fn, reps):
     return ms.value / reps
 
 
-PMC_FILES = ("r05_pmc_roofline.json", "r04_pmc_roofline.json")        # the first that exists is THE source (one file: VERDICT r04 weak 9b)
+PMC_FILES = ("r06_pmc_roofline.json", "r05_pmc_roofline.json")        # the first that exists is THE source (one file: VERDICT r04 weak 9b)
 PMC_SOURCE = None           # the file the last _pmc_traffic() hit came from
 
 
@@ -57,8 +57,8 @@ def _pmc_json():
 
 
 def _pmc_traffic(key):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r04_pmc_roofline.json, produced by scripts/gpu_pmc_r04.sh +
-    scripts/pmc_summarize_r04.py; the round-3 file as a fallback); `key` = a kernel string as mh_last_kernel reports it, or the name of a fixed
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r04_pmc_roofline.json, produced by scripts/gpu_pmc.sh +
+    scripts/pmc_summarize.py; the previous round's file as a fallback); `key` = a kernel string as mh_last_kernel reports it, or the name of a fixed
     roofline entry (roofline_fwd, roofline_corr, ...: resolved through the file's fixed_kernels map).  None if absent."""
     global PMC_SOURCE
     f, j = _pmc_json()
@@ -83,7 +83,7 @@ def _fixed_source(key):
     """provenance string of a fixed roofline entry's `traffic` (ONE file: the first of PMC_FILES that exists), None when the file has no such entry"""
     if _pmc_traffic(key) is None:
         return None
-    return "%s, fixed_kernels.%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_pmc_r05.sh (L2 flushed before the measured launch); collected beside this round's committed bench line, not inside this process" % (PMC_SOURCE, key)
+    return "%s, fixed_kernels.%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_pmc.sh (L2 flushed before the measured launch); collected beside this round's committed bench line, not inside this process" % (PMC_SOURCE, key)
 
 
 def family_key(kernel):
@@ -125,7 +125,7 @@ def roofline(lib, eng, stream, reps=20):
         return {"kernel": kname, "op": what, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                 "mfma_issue_frac": (3.0 if x3 else 1.0) * ach / peak,
                 "arithmetic": {0: "f32 MFMA", 1: "bf16 MFMA, f32 accumulate", 2: "split-bf16: 3 bf16 MFMAs per product (mfma_issue_frac = 3 x frac), f32 accumulate"}[code],
-                "traffic": tr, "traffic_source": ("%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_pmc_r04.sh on the same kernels and shapes, "
+                "traffic": tr, "traffic_source": ("%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_pmc.sh on the same kernels and shapes, "
                                                   "key %s; collected in the run that produced this round's committed bench line, not inside this process)" % (PMC_SOURCE, pmc_key)) if tr is not None else None,
                 "launch_ms": ms, "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": algo_bytes}
 
@@ -207,7 +207,7 @@ def roofline(lib, eng, stream, reps=20):
                 byts = sum(2.0 * xv.B * xv.H * xv.W * (ops.shadow_ld(xv.C) + ops.shadow_ld(zv.C)) + 4.0 * 9 * xv.C * zv.C for xv, zv, _, _, _ in layers)
                 return {"kernel": kname, "op": what, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / PEAK_BF16_MFMA_TFLOPS, "mfma_issue_frac": ach / PEAK_BF16_MFMA_TFLOPS, "arithmetic": "bf16 MFMA (32x32x16), f32 accumulate; operands = bf16 shadows",
-                        "traffic": tr, "traffic_source": ("%s key %s (rocprofv3 --pmc passes of scripts/gpu_pmc_r04.sh)" % (PMC_SOURCE, pmc_key)) if tr is not None else None,
+                        "traffic": tr, "traffic_source": ("%s key %s (rocprofv3 --pmc passes of scripts/gpu_pmc.sh)" % (PMC_SOURCE, pmc_key)) if tr is not None else None,
                         "launch_ms": ms, "algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": byts,
                         "splits": [sg[3] for sg in segs if len(sg) == 4], "workspace_bytes_per_launch": 4.0 * sum(sg[2] * sg[3] for sg in segs)}
             nw = 4 if x.B == 1 else 8

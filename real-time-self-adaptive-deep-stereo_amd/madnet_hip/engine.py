@@ -716,7 +716,7 @@ class MadNetEngine(ElisionPasses, BackwardRecorder):
         return rng[0]
 
     def build_plan(self, mode, lr=1e-4, block_vars=None, block_level=None, grad_scale=1.0, update=True,
-                   blocks=None, part="all", loss_weights=None, max_disp=192.0, optimizer="momentum", momentum=0.9):
+                   blocks=None, part="all", loss_weights=None, max_disp=192.0, optimizer="momentum", momentum=0.9, collective=None):
         """mode: 'NONE' | 'FULL' | 'MAD' | 'TRAIN' (offline training step of Train.py: multi-scale supervised mean_l1 against
         self.gt with loss_weights from full to lowest resolution, every variable, Adam).
         For MAD: blocks = [(level, variable names), ...] (level in
@@ -724,7 +724,10 @@ class MadNetEngine(ElisionPasses, BackwardRecorder):
         optimizer: 'momentum' (Stereo_Online_Adaptation.py:122; `momentum` = its decay, 0.9 there) | 'adam' (the live demo, Demo/demo_model.py:164) for FULL / MAD.
         part: 'all' | 'grad' (everything up to the gradients) | 'update' (momentum apply only) -- the
         split lets a gradient all-reduce (shared-model multi-GPU mode) sit between two plans; 'grad_split' returns the 'grad' part as
-        a LIST of two plans cut where the pyramid's backward pass starts (see madnet_manifest)."""
+        a LIST of two plans cut where the pyramid's backward pass starts (see madnet_manifest).
+        collective: a madnet_hip.comm.Comm (shared-model mode, part='all', FULL / MAD): the gradient all-reduce is RECORDED between the backward pass and the
+        optimizer (MH_OP_ALLREDUCE), so the step is one plan / one hipGraph.  FULL: [estimators + context + loss] leaves on a side lane where the pyramid's
+        backward pass starts, [pyramid] follows behind it on lane 0; MAD: the block's ranges + the loss tail as one RCCL group.  Pass grad_scale = 1 / world."""
         r = Recorder()
         self.wsa.reset()
         self._fresh = set()
@@ -747,7 +750,7 @@ class MadNetEngine(ElisionPasses, BackwardRecorder):
             with ops.TUNE_LOCK, ops.precision_scope(self.precision):
                 if mode == "TRAIN":
                     return self._build_train_plan(r, lr, grad_scale, update, part, loss_weights, max_disp)
-                return self._build_plan(r, mode, lr, block_vars, block_level, grad_scale, update, blocks, part, optimizer, momentum)
+                return self._build_plan(r, mode, lr, block_vars, block_level, grad_scale, update, blocks, part, optimizer, momentum, collective)
         finally:
             self.wgrad_lanes = lanes
 
@@ -774,9 +777,13 @@ class MadNetEngine(ElisionPasses, BackwardRecorder):
         self._elide_fp32_activations(r)
         return r.compile()
 
-    def _build_plan(self, r, mode, lr, block_vars, block_level, grad_scale, update, blocks, part, optimizer="momentum", momentum=0.9):
+    COLLECTIVE_LANE = 4            # the side lane of the shared-model step's first all-reduce (MH_MAX_LANES - 1: no filter-gradient batch uses it)
+
+    def _build_plan(self, r, mode, lr, block_vars, block_level, grad_scale, update, blocks, part, optimizer="momentum", momentum=0.9, collective=None):
         if optimizer not in ("momentum", "adam"):
             raise ValueError("optimizer must be 'momentum' or 'adam'")
+        if collective is not None and (part != "all" or mode not in ("FULL", "MAD") or not update):
+            raise ValueError("collective= records the all-reduce inside a complete FULL / MAD step (part='all', update=True)")
         # one AdamOptimizer serves every train op of the demo graph (Demo/demo_model.py:164): per-variable slots, ONE pair of beta
         # powers that advances with every executed train op -- which is what record_update_adam does per call
         if optimizer == "momentum":
@@ -797,8 +804,23 @@ class MadNetEngine(ElisionPasses, BackwardRecorder):
             if do_grad:
                 self.record_forward(r)
                 self.record_loss_metrics(r, with_grad=True)
-                eu = (lr, momentum, grad_scale) if (self.sched.EARLY_UPDATE and do_upd and part == "all" and optimizer == "momentum") else None
-                done = self.record_backward(r, "final", tv, bulkhead=False, early_update=eu)
+                eu = (lr, momentum, grad_scale) if (self.sched.EARLY_UPDATE and do_upd and part == "all" and optimizer == "momentum" and collective is None) else None
+                at_cut = None
+                if collective is not None:
+                    P, lo = self.params, self.pyramid_range()[1]
+
+                    def at_cut(rr):
+                        # every gradient behind the pyramid's range + the loss result is final once the side lanes have joined: that range (73 % of the bytes)
+                        # leaves on a lane of its own while the pyramid's backward pass runs on lane 0
+                        lane0, nd0 = rr.lane, rr.nodefer
+                        rr.join_next, rr.lane, rr.nodefer = True, self.COLLECTIVE_LANE, True
+                        collective.allreduce(rr, [(P.g_loss, lo, P.total + 4 - lo)])
+                        rr.lane, rr.nodefer = lane0, nd0
+                done = self.record_backward(r, "final", tv, bulkhead=False, early_update=eu, at_cut=at_cut)
+                if collective is not None:
+                    r.join_next = True                      # the pyramid's filter gradients (side lanes) and the first all-reduce (its lane) are behind us
+                    collective.allreduce(r, [(self.params.g_loss, 0, self.pyramid_range()[1])])
+                    r.join_next = True
             if do_upd:
                 if done:
                     self.record_update(r, tv, lr, momentum=momentum, grad_scale=grad_scale, done=done)
@@ -828,6 +850,18 @@ class MadNetEngine(ElisionPasses, BackwardRecorder):
                         ops.reprojection_loss(r, self.left, self.right, self.disp_k[lv], self.loss_ws_k, self.res_loss_k,
                                               self.ddisp_k)
                     self.record_backward(r, lv, bv, bulkhead=True)
+                if collective is not None:
+                    # the block's gradient ranges + the loss tail (behind the gradient buffer) as ONE RCCL group between the block's backward pass and its update
+                    P = self.params
+                    rng = [(P.g_loss, o, c) for o, c in P.ranges(bv)]
+                    if lv is blocks[0][0]:                          # (the loss result travels once per step: with the first block's gradients)
+                        if rng and rng[-1][1] + rng[-1][2] == P.total:
+                            rng[-1] = (P.g_loss, rng[-1][1], rng[-1][2] + 4)
+                        else:
+                            rng.append((P.g_loss, P.total, 4))
+                    r.join_next = True
+                    collective.allreduce(r, rng)
+                    r.join_next = True
                 if do_upd and part == "all":
                     record_update(r, bv, lr, grad_scale=grad_scale)
             if do_upd and part == "update":

@@ -272,6 +272,11 @@ class Recorder(object):
     def bias_grad(self, dz, dz_ld, npix, nch, db, stream):
         self._op(_ffi.OP_BIAS_GRAD, [dz_ld, nch], [], [dz, db], n=npix)
 
+    def allreduce_sum(self, bufs, counts, n, comm, stream):
+        """bufs / counts: ctypes arrays as for _ffi.Lib.allreduce_sum (the recorder copies the n pointers and counts into the op)"""
+        assert 1 <= n <= 8
+        self._op(_ffi.OP_ALLREDUCE, [n] + [int(counts[k]) for k in range(n)], [], [comm] + [bufs[k] for k in range(n)])
+
     def bias_grad_partial(self, dz, dz_ld, npix, nch, ws, nblocks, stream):
         self._op(_ffi.OP_BIAS_GRAD, [dz_ld, nch, nblocks], [], [dz, ws], n=npix)
 

@@ -1,7 +1,7 @@
 """How much would split-K over workgroups buy on DispNet's skinny-M / long-K layers?  Times the real layer and the same
 layer with K / 4 and K / 8 input channels (what one of 4 / 8 K-splits would run).  GPU box only."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "real-time-self-adaptive-deep-stereo_amd")):
     sys.path.insert(0, p)
 import torch

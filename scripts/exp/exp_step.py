@@ -1,8 +1,8 @@
 """Timing experiments on the full MADNet FULL step (hipGraph replay) under the library's tuning hooks.
-usage: python scripts/exp_step.py [--precision bf16] [--plain-wgrad] [--wgs N]   (GPU box only)"""
+usage: python scripts/exp/exp_step.py [--precision bf16] [--plain-wgrad] [--wgs N]   (GPU box only)"""
 import argparse, os, sys, time
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "real-time-self-adaptive-deep-stereo_amd"))
 from madnet_hip import _ffi, engine as E, synthetic as S
 

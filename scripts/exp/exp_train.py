@@ -4,7 +4,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "real-time-self-adaptive-deep-stereo_amd")):
     sys.path.insert(0, p)
 import numpy as np

@@ -2,7 +2,7 @@
 gather form with staged operands (1, the default) and that launch without its gather part (5: timing) -- at the four MADNet level shapes (B = 1: what the step
 runs) and at the SURVEY 8(d) protocol shape (B = 64); the 81-shift volume forward / backward (bf16 vs exact fp32, with and without the XCD-aware order).
 Every timing = N launches recorded into ONE hipGraph and replayed (HIP events around the replays): a Python launch loop costs more than these kernels.
-    python scripts/exp/mb_corr_r05.py"""
+    python scripts/exp/mb_corr.py"""
 import os
 import sys
 

@@ -3,7 +3,7 @@ context-network batches of MADNet at 96 x 320 (B = 1 and 4): shadow cast / strea
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "real-time-self-adaptive-deep-stereo_amd")):
     sys.path.insert(0, p)
 import torch

@@ -1,4 +1,4 @@
-"""Driver of scripts/gpu_pmc_r05.sh (run under rocprofv3 --pmc ...): launches, one by one behind a separator that is also an L2 flush (a 96 MB fill),
+"""Driver of scripts/gpu_pmc.sh (run under rocprofv3 --pmc ...): launches, one by one behind a separator that is also an L2 flush (a 96 MB fill),
   1. every conv / filter-gradient / correlation op of the recorded MADNet FULL plan ('mixed', 1242x375) -- the headline config;
   2. every such op of the MADNet MAD block plans (block_config/MadNet_piramid_only.json) whose kernel string the FULL plan did not launch -- config 3;
   3. every such op of the recorded DispNet FULL plan ('mixed') -- config 4;
@@ -19,6 +19,9 @@ import torch
 from madnet_hip import _ffi, engine as E, dispnet_engine as DE, synthetic as S, benchtools as BT, ops
 
 lib = _ffi.lib()
+for item in filter(None, os.environ.get("PMC_TUNE", "").split(",")):          # PMC_TUNE="conv_bank_small=0": library tuning hooks applied before anything is recorded
+    name, _, val = item.partition("=")
+    getattr(lib, "tune_" + name)(int(val))
 H, W = 375, 1242
 l, r, gt = S.make_pair(H, W)
 KINDS = (_ffi.OP_CONV, _ffi.OP_CONV_PLANES, _ffi.OP_CONV_PLANES_BWD, _ffi.OP_WGRAD_PARTIAL, _ffi.OP_WGRAD_STREAM, _ffi.OP_CORR_FWD, _ffi.OP_CORR_BWD, _ffi.OP_LEVEL_FRONT, _ffi.OP_CORR_WARP_BWD)

@@ -1,65 +1,109 @@
-"""Summarise the rocprofv3 --pmc passes of scripts/gpu_pmc.sh into profiles/r01_pmc_roofline.json.
-usage: python scripts/pmc_summarize.py gpurun_out/<tag>      (copies the raw CSVs to profiles/r01_pmc/ too)"""
-import csv, glob, json, os, shutil, sys
+"""Summarise the rocprofv3 --pmc passes of scripts/gpu_pmc.sh into profiles/<ROUND>_pmc_roofline.json (ROUND from the environment, default r06): one entry per kernel string of the recorded plans
+(MADNet FULL, the MAD block plans, DispNet FULL: what mh_last_kernel reports = what bench.py prints) plus the fixed roofline entries.
+usage: [ROUND=r06] python scripts/pmc_summarize.py gpurun_out/<tag>"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
 
 src = sys.argv[1]
+ROUND = os.environ.get("ROUND", "r06")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-dst = os.path.join(ROOT, "profiles", "r01_pmc")
-os.makedirs(dst, exist_ok=True)
+meta = json.load(open(os.path.join(src, "ops.json")))
+G = meta["groups"]
 
 
-def load(counter_dir):
-    fs = glob.glob(os.path.join(src, counter_dir, "**", "*counter_collection.csv"), recursive=True)
+def dispatches(d):
+    fs = glob.glob(os.path.join(src, d, "**", "*counter_collection.csv"), recursive=True)
     if not fs:
-        return None              # pass not collected in this run: the entries of the committed JSON are kept
-    f = fs[0]
-    shutil.copy(f, os.path.join(dst, counter_dir + "_counter_collection.csv"))
-    return list(csv.DictReader(open(f)))
+        return None
+    by = collections.OrderedDict()
+    for r in csv.DictReader(open(fs[0])):
+        k = int(r["Dispatch_Id"])
+        e = by.setdefault(k, {"kernel": r["Kernel_Name"], "grid": r.get("Grid_Size", ""), "c": {},
+                              "us": (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 if "End_Timestamp" in r else None})
+        e["c"][r["Counter_Name"]] = float(r["Counter_Value"])
+    return [by[k] for k in sorted(by)]
 
 
-def mean_of(rows, pred, counter):
-    v = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == counter and pred(r["Kernel_Name"])]
-    d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if r["Counter_Name"] == counter and pred(r["Kernel_Name"])]
-    v, d = v[1:] or v, d[1:] or d             # drop the first (cold) launch
-    return sum(v) / len(v), sum(d) / len(d) / 1e3
+def split(disp):
+    """dispatch groups between the 96 MB separators (fill_kernel with the separator's grid), and the tail behind the double separator"""
+    sizes = collections.Counter(e["grid"] for e in disp if "fill_kernel" in e["kernel"])
+    sep_grid = max(sizes, key=lambda k: (int(k) if str(k).isdigit() else 0))          # the separator is the largest fill of the run
+    groups, cur, tail = [], None, []
+    for k, e in enumerate(disp):
+        is_sep = "fill_kernel" in e["kernel"] and e["grid"] == sep_grid
+        if is_sep:
+            if cur is not None:
+                groups.append(cur)
+            cur = []
+            if k > 0 and "fill_kernel" in disp[k - 1]["kernel"] and disp[k - 1]["grid"] == sep_grid:
+                tail = disp[k + 1:]
+                cur = None
+                groups = groups[:-1] if groups and not groups[-1] else groups
+                break
+            continue
+        if cur is not None:
+            cur.append(e)
+    if cur:
+        groups.append(cur)
+    return [g for g in groups if g], tail
 
 
-def _targs(n):
-    return [a.strip() for a in n[n.index("<") + 1:n.index(">(")].split(",")]
-
-
-KERNELS = {
-    # conv_igemm_kernel<WM, WN, MT, NT, KT, DGRAD, VEC, UNI, BF16, KG>: template argument 9 is the arithmetic mode
-    "conv_3x3_128_128_96x320": (lambda n: "conv_igemm" in n and _targs(n)[8] == "false", 2 * 15728640 + 589824 + 512),
-    # the bf16 launch of that layer is taken by the patch-staged kernel (csrc/conv_patch.hip) unless MH_CONV_PATCH=0
-    "conv_3x3_128_128_96x320_bf16": (lambda n: "conv_patch_kernel" in n or ("conv_igemm" in n and _targs(n)[8] == "true"), 2 * 15728640 + 589824 + 512),
-    "corr_fwd_B64_96x320x32_D5": (lambda n: "corr_fwd" in n, 64 * 96 * 320 * (2 * 32 + 5) * 4),
-}
-fetch, write, sq = load("FETCH_SIZE"), load("WRITE_SIZE"), load("SQ")
-out = {"source": "scripts/gpu_pmc.sh (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ_* in separate passes, --kernel-trace only), raw CSVs in "
-                 "profiles/r01_pmc/; FETCH_SIZE and WRITE_SIZE are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies the 128-B "
-                 "requests of wide coalesced reads at 64 B); mean over launches 2..5 of scripts/pmc_kernels.py"}
-JSON = os.path.join(ROOT, "profiles", "r01_pmc_roofline.json")
-old = json.load(open(JSON)) if os.path.exists(JSON) else {}
-if "conv_3x3_128_128_96x320_bf16" in old and "conv_3x3_128_128_96x320_bf16_gather" not in old and old["conv_3x3_128_128_96x320_bf16"].get("launch_us_under_pmc", 0) > 30:
-    # the earlier pass measured the implicit-GEMM (gather) kernel on this layer: keep it beside the patch-staged one
-    out["conv_3x3_128_128_96x320_bf16_gather"] = old["conv_3x3_128_128_96x320_bf16"]
-elif "conv_3x3_128_128_96x320_bf16_gather" in old:
-    out["conv_3x3_128_128_96x320_bf16_gather"] = old["conv_3x3_128_128_96x320_bf16_gather"]
-for key, (pred, alg) in KERNELS.items():
-    f, us = mean_of(fetch, pred, "FETCH_SIZE")
-    w, _ = mean_of(write, pred, "WRITE_SIZE")
-    out[key] = {"fetch_kib_raw": round(f, 1), "write_kib": round(w, 1), "traffic_bytes": int(2 * f * 1024 + w * 1024),
-                "algorithmic_bytes": alg, "launch_us_under_pmc": round(us, 1)}
-for key, pred in (("conv_sq", KERNELS["conv_3x3_128_128_96x320"][0]), ("conv_bf16_sq", KERNELS["conv_3x3_128_128_96x320_bf16"][0]),
-                  ("corr_sq", KERNELS["corr_fwd_B64_96x320x32_D5"][0])):
-    if sq is None:
-        if key in old:
-            out[key if key != "conv_bf16_sq" else "conv_bf16_gather_sq"] = old[key]
+out = {"source": "scripts/gpu_pmc.sh: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_* in separate passes (--kernel-trace only) over scripts/pmc_plan.py: every conv / "
+                 "filter-gradient / correlation op of the recorded MADNet FULL plan, the MAD block plans and the DispNet FULL plan ('mixed', 1242x375) launched alone, keyed by the "
+                 "kernel string bench.py reports, plus the fixed roofline entries.  FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies the "
+                 "128-B requests of wide coalesced reads at 64 B); traffic_bytes = 2 * FETCH + WRITE of ONE launch behind a 96 MB fill (L2 flushed: what a layer sees in the step, where "
+                 "its input has just been written back by the previous kernel), summed over the kernels the op launches"}
+per = {}
+for d in ("FETCH_SIZE", "WRITE_SIZE", "SQ"):
+    disp = dispatches(d)
+    if disp is None:
         continue
-    d = {}
-    for c in sorted(set(r["Counter_Name"] for r in sq)):
-        d[c] = int(mean_of(sq, pred, c)[0])
-    out[key] = d
-json.dump(out, open(JSON, "w"), indent=1)
-print(json.dumps(out, indent=1))
+    groups, tail = split(disp)
+    groups = groups[-len(G):]
+    if len(groups) != len(G):
+        print("WARNING: pass %s has %d groups, the driver launched %d" % (d, len(groups), len(G)))
+    for g, op in zip(groups, G):
+        if op.get("dup"):
+            continue
+        key = op["kernel"] if not op.get("fixed") else "%s [%s]" % (op["kernel"], op["fixed"])       # (a fixed entry never shares its counters with a plan op of the same kernel string)
+        e = per.setdefault(key, {"plan": op["plan"], "plan_op_index": op["index"], "algorithmic_flops": op["flops"], "algorithmic_bytes": op["bytes"], "kernels_per_launch": len(g)})
+        if op.get("fixed"):
+            e["fixed_roofline_entry"] = op["fixed"]
+            meta["fixed"][op["fixed"]] = key
+        for c in g[0]["c"]:
+            e[c] = sum(x["c"].get(c, 0.0) for x in g)
+        if g[0]["us"] is not None:
+            e["launch_us_under_pmc"] = round(sum(x["us"] for x in g), 1)
+    runs = []
+    for e in tail:
+        if not any(t in e["kernel"] for t in ("conv_planes_kernel", "conv_bank_kernel", "conv_patch_kernel", "conv_igemm_kernel", "wgrad_stream_kernel", "wgrad_bf16_kernel", "corr_fwd")):
+            continue
+        sig = (e["kernel"], e["grid"])
+        if not runs or runs[-1][0] != sig:
+            runs.append((sig, []))
+        runs[-1][1].append(e)
+    order = ["roofline_fwd", "roofline_dgrad", "roofline_wgrad", "roofline_wgrad_batch", "roofline_corr", "roofline_corr_b1"]
+    for (sig, es), name in zip(runs, order):
+        kstr = meta.get("fixed", {}).get(name)
+        if not kstr or kstr in per and "plan_op_index" in per[kstr] and per[kstr].get("plan") != "tail":
+            continue                                        # (the same kernel string was measured as a plan op: that entry stands)
+        ee = per.setdefault(kstr, {"plan": "tail", "fixed_roofline_entry": name, "rocprof_kernel": sig[0][:100]})
+        for c in es[0]["c"]:
+            v = sorted(x["c"].get(c, 0.0) for x in es)
+            ee[c] = v[len(v) // 2]
+for k, e in per.items():
+    if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+        e["traffic_bytes"] = int(2 * e["FETCH_SIZE"] * 1024 + e["WRITE_SIZE"] * 1024)
+    out[k] = e
+out["fixed_kernels"] = meta.get("fixed", {})
+if os.environ.get("PMC_TUNE"):
+    out["tuning_hooks"] = os.environ["PMC_TUNE"]
+json.dump(out, open(os.path.join(ROOT, "profiles", "%s_pmc_roofline%s.json" % (ROUND, os.environ.get("PMC_SUFFIX", ""))), "w"), indent=1)
+print("%d keys" % len(out))
+for k, e in out.items():
+    if isinstance(e, dict) and "traffic_bytes" in e:
+        print("%-118s %-14s traffic %8.2f MB  alg %8.2f MB" % (k[:118], e.get("plan", ""), e["traffic_bytes"] / 1e6, e.get("algorithmic_bytes", 0) / 1e6))

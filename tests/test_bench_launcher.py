@@ -28,7 +28,7 @@ def test_bench_self_spawns_two_ranks():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "weak"
-    assert d["value"] > 0 and abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+    assert d["value"] > 0 and abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) <= 1e-4 * d["value"]          # (the line carries 6 significant digits)
     assert d["config"]["precision"] == "mixed" and d["timing"]["repeats"] == 1
 
 

@@ -1,10 +1,6 @@
-"""Two changes to the TAIL of the MADNet step that were written after round 3's GPU budget was spent (profiles/r03_experiments.txt #25, #26), both default OFF:
-the image layer's filter gradient on its own kernel (wgrad_image_kernel, csrc/wgrad.hip; mh_tune_wgrad_image) and the momentum update per filter-gradient
-batch on the batch's lane (Schedule.EARLY_UPDATE).
-
-They are parity-checked on the CPU emulator only, the product does not use them, and their MI355X tests live in THIS file -- the last one pytest
-collects -- so that they run after every test of the validated path.  Next round's first GPU call (scripts/gpu_next_first.sh) times them in the step
-and either makes them defaults or removes them."""
+"""The image layer's filter gradient on its own kernel (wgrad_image_kernel, csrc/wgrad.hip; mh_tune_wgrad_image: the default since round 4, 256 workgroups) and the
+momentum update per filter-gradient batch on the batch's lane (Schedule.EARLY_UPDATE: measured in round 5, left OFF for MADNet -- profiles/r05_experiments.txt #9 --,
+ON for DispNet).  Both were written after round 3's GPU budget was spent; this file (the last one pytest collects) keeps their emulator and MI355X parity tests."""
 import pytest
 import torch
 
