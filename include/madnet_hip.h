@@ -305,7 +305,10 @@ int mh_corr_bwd_prec(const float* g, int32_t g_ld, int32_t coff, const float* L,
  * concat form), followed by mh_warp_bwd of the resulting gradient -- which is never stored: dimg (+)= the bilinear scatter of it to the unwarped
  * right features' gradient (fp32 atomics: dimg must hold zeros or earlier contributions), du = g[.., coff + D] + the coordinate gradient of the
  * warp (img = the unwarped right features, u = the warp coordinates).  dimg or du may be NULL.  Replaces the gradients of
- * MadNet._linear_warping + correlation + concat of one level (MadNet.py:370-436, 77-80). */
+ * MadNet._linear_warping + correlation + concat of one level (MadNet.py:370-436, 77-80).
+ * acc_l: bit 0 = dL accumulates; bit 1 (MH_CORR_WARP_OVERWRITE_DIMG, ABI 15) = this launch is the FIRST writer of dimg: it is overwritten, nothing of it is read
+ * and it need not be zeroed (the row-owned gather kernel just stores; the scattering forms zero it themselves first). */
+#define MH_CORR_WARP_OVERWRITE_DIMG 2
 int mh_corr_warp_bwd(const float* g, int32_t g_ld, int32_t coff, const float* L, int32_t l_ld, const float* Rw, int32_t rw_ld,
                      const float* img, int32_t img_ld, const float* u, float* dL, int32_t dl_ld, int32_t acc_l,
                      float* dimg, int32_t dimg_ld, float* du,
@@ -554,7 +557,8 @@ enum { MH_OP_CONV = 1, MH_OP_WGRAD, MH_OP_CORR_FWD, MH_OP_CORR_BWD, MH_OP_WARP_F
  * price is that the runtime starts such a side chain late.  A batch with a lot of work is worth the queue hop of the critical path.) */
 #define MH_OP_NODEFER 0x200
 /* bits 16..23 of the scheduling word: lane 0 first waits for exactly the side lanes in this mask (bit l = lane l), leaving the others
- * running -- e.g. the scatter half of a warp gradient joined right before the pyramid backward while the filter gradients go on */
+ * running -- e.g. the scatter half of a warp gradient joined right before the pyramid backward while the filter gradients go on.  On an op of a
+ * SIDE lane the mask makes that lane (not lane 0) wait for the named lanes: lane-to-lane edges, lane 0 is not held up */
 #define MH_OP_JOIN_LANES(mask) (((mask) & 0xff) << 16)
 typedef struct mh_op {
     int32_t kind;

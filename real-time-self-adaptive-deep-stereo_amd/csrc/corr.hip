@@ -559,6 +559,7 @@ struct CorrWarpBwdArgs {
     float* dL; float* dimg; float* du;
     int g_ld, coff, l_ld, rw_ld, img_ld, dl_ld, dimg_ld;
     int acc_l;
+    int acc_img;         // 1: dimg += the gathered / scattered taps (it holds zeros or earlier contributions); 0: dimg is OVERWRITTEN (this launch is its first writer)
     int B, H, W, C, md, stride, D, copy_left;
 };
 // DT > 0: at most DT shifts, tensors under 2 GiB -- every operand of a channel group (DT correlation gradients of both directions, DT right / left
@@ -962,7 +963,7 @@ __global__ __launch_bounds__(1024) void corr_warp_bwd_rowlds_kernel(CorrWarpBwdA
     for (int k = 0; k < NI; ++k) {
         const int q = tid + k * NT;
         const int x = q / C4, c4 = q - x * C4;
-        vd[k] = mh_buf_load4(rs_di, q < nq ? ((rowbase + x) * p.dimg_ld + c4 * 4) * 4 : MH_OOB);
+        vd[k] = mh_buf_load4(rs_di, (q < nq && p.acc_img) ? ((rowbase + x) * p.dimg_ld + c4 * 4) * 4 : MH_OOB);      // (first writer: zeros, nothing read)
     }
     __syncthreads();
     // The common case: no column received more than KL taps -- every tap already sits in its column's list.  Otherwise (a compressed stretch of the
@@ -1746,11 +1747,20 @@ extern "C" int mh_corr_warp_bwd(const float* g, int32_t g_ld, int32_t coff, cons
     CorrWarpBwdArgs a;
     a.g = g; a.L = L; a.Rw = Rw; a.img = img; a.u = u; a.dL = dL; a.dimg = dimg; a.du = du;
     a.g_ld = g_ld; a.coff = coff; a.l_ld = l_ld; a.rw_ld = rw_ld; a.img_ld = img_ld; a.dl_ld = dl_ld; a.dimg_ld = dimg_ld;
-    a.acc_l = acc_l;
+    a.acc_l = acc_l & 1;
+    a.acc_img = (acc_l & MH_CORR_WARP_OVERWRITE_DIMG) ? 0 : 1;
     a.B = B; a.H = H; a.W = W; a.C = C; a.md = max_disp; a.stride = stride; a.D = 2 * max_disp / stride + 1; a.copy_left = copy_left;
     const int C4 = C / 4;
     const int64_t npix = (int64_t)B * H * W;
     hipStream_t s = (hipStream_t)stream;
+    // the forms that SCATTER into dimg (LDS copy of the row / global atomics) start from what dimg holds: an overwriting call zeroes it for them
+    auto zero_dimg = [&]() -> int {
+        if (a.acc_img || !dimg) return 0;
+        hipError_t e = (dimg_ld == C) ? hipMemsetAsync(dimg, 0, (size_t)npix * C * 4, s) : hipMemset2DAsync(dimg, (size_t)dimg_ld * 4, 0, (size_t)C * 4, (size_t)npix, s);
+        if (e != hipSuccess) { mh_set_error("mh_corr_warp_bwd: zeroing dimg: %s", hipGetErrorString(e)); return (int)e; }
+        a.acc_img = 1;
+        return 0;
+    };
     auto grid = [&](int lpp) { int64_t b = (npix * lpp + 255) / 256; return (int)(b > (1 << 20) ? (1 << 20) : b); };
     const int64_t ldmax = g_ld > rw_ld ? (g_ld > l_ld ? g_ld : l_ld) : (rw_ld > l_ld ? rw_ld : l_ld);
     const bool fast = a.D <= 5 && npix * ldmax * 4 < (1ll << 31) - 64;        // MADNet's radius-2 volumes: the branch-free form
@@ -1772,6 +1782,7 @@ extern "C" int mh_corr_warp_bwd(const float* g, int32_t g_ld, int32_t coff, cons
             mh_note_kernel("corr_warp_bwd_rowlds_kernel<LPP=%d,DT=5> C=%d D=%d grid %d x 16 waves lds %d", lpp, C, a.D, B * H, (int)lds_st);
             return mh_check_launch("corr_warp_bwd_rowlds");
         }
+        if (int rc = zero_dimg()) return rc;
 #define MH_CWB_ROW(LPPv) { if (det) hipLaunchKernelGGL((corr_warp_bwd_row_kernel<LPPv, 5, true>), grid, dim3(1024), row_lds, s, a);   \
                            else hipLaunchKernelGGL((corr_warp_bwd_row_kernel<LPPv, 5, false>), grid, dim3(1024), row_lds, s, a); }
         if (C4 <= 4) MH_CWB_ROW(4) else if (C4 <= 8) MH_CWB_ROW(8) else MH_CWB_ROW(16)
@@ -1779,6 +1790,7 @@ extern "C" int mh_corr_warp_bwd(const float* g, int32_t g_ld, int32_t coff, cons
         mh_note_kernel("corr_warp_bwd_row_kernel<LPP=%d,DT=5%s> C=%d D=%d grid %d x 16 waves lds %d", C4 <= 4 ? 4 : C4 <= 8 ? 8 : 16, det ? ",det" : "", C, a.D, B * H, (int)row_lds);
         return mh_check_launch("corr_warp_bwd_row");
     }
+    if (int rc = zero_dimg()) return rc;
     if (fast) {
         if (C4 <= 4) hipLaunchKernelGGL((corr_warp_bwd_kernel<4, 5>), dim3(grid(4)), dim3(256), 0, s, a);
         else if (C4 <= 8) hipLaunchKernelGGL((corr_warp_bwd_kernel<8, 5>), dim3(grid(8)), dim3(256), 0, s, a);

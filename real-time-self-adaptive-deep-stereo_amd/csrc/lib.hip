@@ -431,9 +431,16 @@ static int plan_run_impl(const mh_op* ops, int32_t nops, void* stream, Lanes* fi
         if (lane >= MH_MAX_LANES) { mh_set_error("lane %d out of range", lane); e = MH_ERR_ARG; }
         if (!e && ndef && ((sched & MH_OP_JOIN) || ((sched >> 16) & 0xff) || ndef >= 60)) e = flush_deferred();
         if (!e && (sched & MH_OP_JOIN)) e = join();
-        if (!e && ((sched >> 16) & 0xff)) {                   // join exactly these side lanes
+        if (!e && ((sched >> 16) & 0xff)) {
+            // join exactly these side lanes -- into lane 0 (an op of lane 0), or into the op's OWN side lane (round 6: the shared-model step's first all-reduce
+            // waits for the filter-gradient lanes on its lane while lane 0 walks on into the pyramid's backward pass; the waited-for lanes stay dirty for lane 0)
+            if (lane > 0 && !L) e = lanes_get(&L);
+            hipStream_t tgt = lane > 0 ? L->aux[lane] : main_s;
             for (int l = 1; l < MH_MAX_LANES && !e; ++l)
-                if (((sched >> 16) >> l) & 1) { if (dirty[l]) { e = lane_edge(*L, L->aux[l], main_s); dirty[l] = false; } }
+                if ((((sched >> 16) >> l) & 1) && l != lane && dirty[l]) {
+                    e = lane_edge(*L, L->aux[l], tgt);
+                    if (lane == 0) dirty[l] = false;
+                }
         }
         // batch = this op + the following partial-filter-gradient ops of the same lane (no join / lane change in between)
         int m = 1;

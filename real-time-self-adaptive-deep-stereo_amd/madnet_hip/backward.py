@@ -67,7 +67,10 @@ class BackwardRecorder(object):
                 lib.lane = 0
         # ONE fill for the feature gradients of all cost-volume levels (13.9 MB at 1242x375) instead of a fill in front of every level's
         # warp-gradient scatter: both towers start from zero, every contribution accumulates
-        prezero = self.sched.ONE_FILL and self.warping and not bulkhead
+        # (round 6) ... and NO fill where the fused back end is the FIRST writer of both halves: the row-owned gather kernel of mh_corr_warp_bwd stores
+        # every element of the left half (dL) and of the right half (the gathered warp taps) of its level's feature gradient
+        first_writer = self.sched.FIRST_WRITER and self.sched.FUSE_BACK and self.warping
+        prezero = self.sched.ONE_FILL and self.warping and not bulkhead and not first_writer
         if prezero:
             ops_fill(lib, self.dF_levels, 0, self.dF_levels.numel())
         written = set()                     # gradient buffers that already hold a contribution
@@ -292,12 +295,13 @@ class BackwardRecorder(object):
                     if not fuse_head(k + 1, du=self.du[k], Hr=self.Hp // s_up, Wr=self.Wp // s_up, mul=20.0 / s_up):
                         ops.resize_bwd(lib, self.du[k], self.V[k + 1], self.dV[k + 1], self.Hp // s_up, self.Wp // s_up,
                                        mul=20.0 / s_up, mode=0, accumulate=acc_flag(("V", k + 1)))
-            elif self.sched.FUSE_BACK and ("F", f, 1) in written:
+            elif self.sched.FUSE_BACK and (("F", f, 1) in written or first_writer):
                 # the level's correlation + concat gradient and the warp gradient in ONE launch (mh_corr_warp_bwd): the gradient w.r.t. the warped
-                # features never goes to memory; the scatter target was zeroed by the pass's single fill (or holds earlier contributions)
+                # features never goes to memory; the right half of the feature gradient was zeroed by the pass's single fill / holds earlier contributions,
+                # or (first_writer) is overwritten by this launch
                 du = self.du[k] if need_u else None
                 ops.corr_warp_bwd(lib, g, Lk, self._fv(self.Rw[k]), self._half(self.F[f], True), self.u[k], dL, self._half(self.dF[f], True), du,
-                                  self.md, self.cstride, coff=c, acc_l=acc_flag(("F", f, 0)), copy_left=True)
+                                  self.md, self.cstride, coff=c, acc_l=acc_flag(("F", f, 0)), copy_left=True, acc_img=acc_flag(("F", f, 1)))
                 self._det_flush(lib, self.dF[f][B:], self.det_dF if self.deterministic else None, self.dF_levels)
                 if need_u:
                     s_up = 2 ** k

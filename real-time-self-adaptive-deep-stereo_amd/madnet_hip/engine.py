@@ -813,7 +813,8 @@ class MadNetEngine(ElisionPasses, BackwardRecorder):
                         # every gradient behind the pyramid's range + the loss result is final once the side lanes have joined: that range (73 % of the bytes)
                         # leaves on a lane of its own while the pyramid's backward pass runs on lane 0
                         lane0, nd0 = rr.lane, rr.nodefer
-                        rr.join_next, rr.lane, rr.nodefer = True, self.COLLECTIVE_LANE, True
+                        # (lane-to-lane edges: the all-reduce's lane waits for the filter-gradient lanes 1 .. 3 and is forked from lane 0 here; lane 0 itself goes on)
+                        rr.join_lanes_next, rr.lane, rr.nodefer = 0b1110, self.COLLECTIVE_LANE, True
                         collective.allreduce(rr, [(P.g_loss, lo, P.total + 4 - lo)])
                         rr.lane, rr.nodefer = lane0, nd0
                 done = self.record_backward(r, "final", tv, bulkhead=False, early_update=eu, at_cut=at_cut)

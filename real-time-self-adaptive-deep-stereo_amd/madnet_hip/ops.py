@@ -602,10 +602,11 @@ def corr_bwd(lib, g, L, R, dL, dR, max_disp, stride=1, coff=0, du=None, acc_l=Fa
                       _p(du), int(acc_u), L.B, L.H, L.W, L.C, max_disp, stride, int(copy_left), int(prec), _p(stream))
 
 
-def corr_warp_bwd(lib, g, L, Rw, img, u, dL, dimg, du, max_disp, stride=1, coff=0, acc_l=False, copy_left=False, stream=None):
+def corr_warp_bwd(lib, g, L, Rw, img, u, dL, dimg, du, max_disp, stride=1, coff=0, acc_l=False, copy_left=False, stream=None, acc_img=True):
     """corr_bwd(g, L, Rw -> dL, dRw, du = g[disparity channel]) + warp_bwd(dRw, img, u -> dimg scatter, du += coordinate gradient) in one
-    launch; dRw is never stored.  dimg must be zero / hold earlier contributions (atomics).  dimg or du may be None."""
-    lib.corr_warp_bwd(_p(g), g.ld, coff, _p(L), L.ld, _p(Rw), Rw.ld, _p(img), img.ld, _p(u), _p(dL), dL.ld, int(acc_l),
+    launch; dRw is never stored.  acc_img=True: dimg holds zeros / earlier contributions and is added to; False: this launch is dimg's first writer
+    (overwritten, nothing read, no zero fill needed).  dimg or du may be None."""
+    lib.corr_warp_bwd(_p(g), g.ld, coff, _p(L), L.ld, _p(Rw), Rw.ld, _p(img), img.ld, _p(u), _p(dL), dL.ld, int(bool(acc_l)) | (0 if acc_img else 2),
                       _p(dimg), dimg.ld if dimg is not None else img.ld, _p(du), L.B, L.H, L.W, L.C, max_disp, stride, int(copy_left), _p(stream))
 
 

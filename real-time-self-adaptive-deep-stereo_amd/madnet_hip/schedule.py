@@ -23,6 +23,9 @@ class Schedule(object):
     # The reduction of the loss value + the validation metrics run on a side lane (2.048 -> 2.030 ms since side launches are deferred,
     # r02_experiments.txt #10, #20); the warp-gradient scatters on a lane of their own lost in every variant (2.056 / 2.27 ms) and stay in line.
     SIDE_LOSS: bool = True
+    # (round 6) the fused back end of a level (mh_corr_warp_bwd) is the FIRST writer of its level's feature gradient: no zero fill of the 13.9 MB of level
+    # feature gradients at the head of the backward pass, no read of the halves it writes (the row-owned kernel gathers -- it never needed zeros to add to)
+    FIRST_WRITER: bool = True
     ONE_FILL: bool = True            # one zero fill for all level feature gradients + the g fill on the filter-gradient lane
     FUSE_BACK: bool = True           # one launch for a level's correlation gradient + warp gradient (mh_corr_warp_bwd)
     # 'mixed': pyramid layers from this one on run plain bf16 in the forward pass (13 = none)

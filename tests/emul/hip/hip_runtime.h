@@ -318,6 +318,11 @@ static inline unsigned long long atomicAdd(unsigned long long* addr, unsigned lo
 static inline int atomicAdd(int* addr, int v) { return __atomic_fetch_add(addr, v, __ATOMIC_RELAXED); }
 #define HIP_SYMBOL(x) (&(x))
 static inline hipError_t hipMemcpyToSymbol(void* sym, const void* src, size_t n) { memcpy(sym, src, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemset2DAsync(void* p, size_t pitch, int v, size_t w, size_t h, hipStream_t) {
+    for (size_t r = 0; r < h; ++r) memset((char*)p + r * pitch, v, w);
+    return hipSuccess;
+}
 static inline hipError_t hipMemcpyFromSymbol(void* dst, const void* sym, size_t n) { memcpy(dst, sym, n); return hipSuccess; }
 static inline float atomicAdd(float* addr, float v) {
     uint32_t* p = (uint32_t*)addr;
