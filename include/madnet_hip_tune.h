@@ -15,7 +15,7 @@ int mh_tune_conv_patch(int mode);        /* patch-staged bf16 kernel of the stri
 int mh_tune_conv_x3_igemm(int on);       /* split-bf16 (precision 2) on the tiled implicit-GEMM kernel for forward layers without a patch / bank instance: 0 = exact fp32 there (default: measured faster), 1 = on, < 0 = default */
 int mh_tune_conv_rows(int min_pixels);   /* row-streaming kernel of the thin 3x3 stride-1 layers (conv_rows.hip: <= 16 input, <= 32 output channels): takes layers of at least this many output pixels (0 = never, < 0 = default 65536); returns the previous setting (-1 = default not resolved yet) */
 int mh_tune_conv_bank_tile(int max_wgs);     /* split-bf16 bank kernel: layers whose 64x128 / 128x64 grid would have fewer workgroups than this take the 64x64 tile with 4 waves (0 = never, < 0 = default 200); returns the previous setting */
-int mh_tune_conv_bank_small(int mode);   /* workgroup placement of the small-layer bank kernel: < 0 / 3 = model (fewest XCDs that give every workgroup its own CU + the logical order with the least L2 fill traffic), 0 = every XCD, pixel-major order (round 5), 1 = the order model on all XCDs, 2 = XCD confinement with the pixel-major order; returns the previous setting */
+int mh_tune_conv_bank_small(int mode);   /* workgroup placement of the small-layer bank kernel: 0 = every XCD, pixel-major order (round 5); 1 (default, also < 0) = the logical order with the least L2 fill traffic (column-major where the bank outweighs the input), all XCDs; 2 = the layer confined to the fewest XCDs that give every workgroup its own CU, pixel-major; 3 = both.  Measured time-neutral (profiles/r06_microbench_small_placement.txt).  Returns the previous setting */
 int mh_tune_conv_bank(int small_maxpix); /* fragment-bank kernels (mh_conv2d_wb): the small-layer kernel takes layers of up to this many output pixels (0 = never, < 0 = default 4096); returns the number of bank-kernel launches since the previous call */
 int mh_tune_wgrad_wgs(int target_workgroups);
 int mh_tune_wgrad_target_pct(int pct);   /* scale (percent) of the filter-gradient pixel-split workgroup targets for the split counts resolved from now on (a plan stores the counts it was recorded with); 0 = default.  Returns the PREVIOUS value (NOT a status code) so that a caller can scope the setting: DispNet's engine records with 150 under a process-wide lock and restores what it found */

@@ -1141,10 +1141,13 @@ int launch_bank_small(ConvArgs& a, hipStream_t s) {
     //   column-major (n_major)           : an XCD reads ntn / X (>= 1) column slices and every pixel of them -> max(X, ntn) / ntn * bank + min(X, ntn) * in
     // and X itself: the fewest XCDs that still give every workgroup a CU of its own (32 CUs per XCD), so that a 24-workgroup layer is ONE L2's business.
     {
-        const int mode = g_bank_small_place.load(std::memory_order_relaxed);      // -1 / 3 = model, 0 = round-5 order (all XCDs, pixel-major), 1 = model without confinement, 2 = confinement only
+        // 0 = round-5 order (all XCDs, pixel-major), 1 = the order model on all XCDs (DEFAULT: time-neutral, less L2 fill traffic), 2 = confinement only, 3 = both.
+        // Measured (profiles/r06_microbench_small_placement.txt): 5.1 - 5.8 us per node in EVERY mode; confinement costs the step +2 us (1.3330 vs 1.3309 ms).
+        const int mode_raw = g_bank_small_place.load(std::memory_order_relaxed);
+        const int mode = mode_raw < 0 ? 1 : mode_raw;
         const int npt = g.nwg / g.ntiles_n;
         int X = 8;
-        if (mode < 0 || mode >= 2) { X = 1; while (X < 8 && mh_cdiv(g.nwg, X) > 32) X *= 2; }
+        if (mode >= 2) { X = 1; while (X < 8 && mh_cdiv(g.nwg, X) > 32) X *= 2; }
         const double bank = 9.0 * g.KP * a.N * 2.0 * PL, in = (double)a.B * (DGRAD ? a.Ho : a.Hi) * (DGRAD ? a.Wo : a.Wi) * a.K * 4.0;
         const double pix_major = X * bank + in;
         const double col_major = (double)std::max(X, g.ntiles_n) / g.ntiles_n * bank + std::min(X, g.ntiles_n) * in;
