@@ -49,7 +49,8 @@ struct PlanesArgs {
                                                                    // fused gradient of tf.maximum(alpha x, x) in an input-gradient launch)
     int mask_c0, mask_c1;                                          // ... for output columns in [mask_c0, mask_c1) only (a concat's member; whole row: 0, INT_MAX)
     int nchunks;                                                   // K-chunked instances: chunks of K16 * 16 reduction channels (1 for the whole-K instances)
-    int Hin, Win;                                                  // stride-2 input gradient: size of dz (H, W = size of dx)
+    int Hin, Win;                                                  // stride-2 kernels: size of the INPUT of the walk (dz of the input gradient; x of the stride-2 forward); H, W = size of the result
+    int pad_t, pad_l;                                              // stride-2 forward: TF 'SAME' padding in front ((k - 2) / 2 on even sizes)
     float* out; unsigned short* out_hi; unsigned short* out_lo;   // any of them may be null
     unsigned in_bytes, wb_bytes, out_bytes, outp_bytes;
     int in_pld, out_ld, out_pld;
@@ -528,6 +529,123 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_planes_s2bwd_kernel(PlanesA
     }
 }
 
+// ---- STRIDE-2 forward layers, KH x KH (3 / 5), split-bf16 or plain bf16 from planes (round 6) ------------------------------------------------------------
+// What is computed: tf.nn.conv2d(x, w, strides 2, 'SAME') + bias + leaky (Nets/sharedLayers.py:54-66) of DispNet's conv2 (5x5, 64 -> 128 at 192x640 -> 96x320:
+// Nets/DispNet.py:80-84 -- 25 GFLOP for the two towers, until now 2 x 131 us on the exact-fp32 tiled kernel) and of the pyramids' 3x3 down-sampling layers.
+// out[y][x] = sum_{ky,kx,c} in[2y + ky - pt][2x + kx - pl][c] w[ky][kx][c]  (pt = pl = (KH - 2) / 2 on even sizes: TF pads mostly behind).
+// The walk is conv_planes_kernel's: a wave owns MBW output rows x 32 output columns x 32 output channels, weight fragments from the 32x32x16 bank
+// (KH * KH taps), no barrier, every LDS offset an immediate.  What changes is the patch: 2 MBW + KH - 2 input rows x 64 + KH - 2 input columns, staged by
+// LDS DMA with the columns SPLIT BY PARITY -- [row][parity][half-column][2 K16 + 1 chunks] -- so that the 32 lanes of an A-operand read (output columns
+// x .. x + 31 = input columns 2 x + kx: one parity, consecutive half-columns) stay the conflict-free stride of the stride-1 kernel.
+template <int KH, int WN, int MBW, int K16, int PL>
+struct PlanesS2Geo : PlanesGeo<32, 1, WN, MBW, K16, PL> {
+    using B = PlanesGeo<32, 1, WN, MBW, K16, PL>;
+    static constexpr int PR2 = 2 * MBW + KH - 2;                       // input rows of the patch
+    static constexpr int HC = 32 + (KH - 1) / 2;                       // half-columns per parity (even parity needs one more than odd for odd KH)
+    static constexpr int ROWP2 = 2 * HC * B::NCK1;                     // chunks per patch row
+    static constexpr int PLANE_BLKS2 = (PR2 * ROWP2 * 16 + 1023) / 1024;
+    static constexpr int PLANE_BYTES2 = PLANE_BLKS2 * 1024;
+    static constexpr int LDS2 = PL * PLANE_BYTES2 > B::LDS_CS ? PL * PLANE_BYTES2 : B::LDS_CS;
+};
+
+template <int KH, int WN, int MBW, int K16, int PL>
+__global__ __launch_bounds__(WN * 64) void conv_planes_s2fwd_kernel(PlanesArgs p) {
+    using G = PlanesS2Geo<KH, WN, MBW, K16, PL>;
+    using GB = typename G::B;
+    constexpr int NW = WN, BN = GB::BN, NCK = GB::NCK, NCK1 = GB::NCK1;
+    constexpr int PR = G::PR2, HC = G::HC, ROWP = G::ROWP2, PLANE_BLKS = G::PLANE_BLKS2, PLANE_BYTES = G::PLANE_BYTES2;
+    HIP_DYNAMIC_SHARED(float, smem_all)
+    unsigned char* const smem = reinterpret_cast<unsigned char*>(smem_all);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave;
+    const int lin = mh_xcd_remap(blockIdx.x, p.nwg);
+    int tile_n, ttx, tty, cx, cy, b;
+    mh_decode_tile(lin, p.dec, tile_n, ttx, tty, cx, cy, b);
+    const int n0 = tile_n * BN;
+    const int y00 = tty * MBW, x00 = ttx * 32;                        // OUTPUT position of tile pixel (0, 0)
+    PlanesEpiPre<GB, PL> pre;
+    planes_epilogue_prefetch<GB, PL>(p, tid, n0, y00, x00, b, 1, pre);
+
+    constexpr int T = KH * KH * K16, NSTB = 8, PF = NSTB - 1;
+    const __amdgpu_buffer_rsrc_t rs_b = mh_make_rsrc(p.wb, p.wb_bytes);
+    const int nt32 = (p.N + 31) >> 5;
+    const int nt = tile_n * WN + wn;
+    const int voff_b = nt < nt32 ? nt * (PL * 1024) + lane * 16 : MH_OOB;
+    const int step_b = nt32 * (PL * 1024);
+    u32x4 fb[NSTB][PL];
+    auto issue_b = [&](int t, int slot) {
+        if (t < T) {
+            fb[slot][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff_b, t * step_b, 0);
+            if constexpr (PL == 2) fb[slot][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff_b, t * step_b + 1024, 0);
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < PF; ++t) issue_b(t, t % NSTB);
+
+    // ---- stage the patch: chunk g of a plane <- (patch row, parity, half-column, channel chunk); input pixel = (2 y00 - pt + row, 2 x00 - pl + 2 half + parity)
+    {
+        const mh_dma_src rs_h = mh_make_dma_src(p.in_hi, p.in_bytes), rs_l = mh_make_dma_src(PL == 2 ? p.in_lo : p.in_hi, p.in_bytes);
+        const int pix_b = p.in_pld * 2;
+        const int iy0 = 2 * y00 - p.pad_t, ix0 = 2 * x00 - p.pad_l;
+        for (int i = wave; i < PLANE_BLKS; i += NW) {
+            const int g = i * 64 + lane;
+            const int pr = g / ROWP, rem = g - pr * ROWP;
+            const int ph = rem / NCK1, c = rem - ph * NCK1;              // ph = parity * HC + half-column
+            const int par = ph / HC, hc = ph - par * HC;
+            const int iy = iy0 + pr, ix = ix0 + 2 * hc + par;
+            const bool ok = pr < PR && c < NCK && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+            const int off = ok ? ((b * p.Hin + iy) * p.Win + ix) * pix_b + c * 16 : MH_OOB;
+            mh_glds16(rs_h, smem + i * 1024, off);
+            if constexpr (PL == 2) mh_glds16(rs_l, smem + PLANE_BYTES + i * 1024, off);
+        }
+    }
+    MH_WAIT_VMCNT(0);
+    __syncthreads();
+
+    f32x16 acc[MBW];
+#pragma unroll
+    for (int mb = 0; mb < MBW; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+    {
+        const int j = lane & 31, kg = lane >> 5;
+        const unsigned char* const a_h = smem + ((j * NCK1 + kg) * 16);
+        const unsigned char* const a_l = a_h + PLANE_BYTES;
+        u32x4 fa[2][MBW][PL];
+        auto issue_a = [&](int t, int set) {
+            if (t < T) {
+                const int tap = t / K16, s = t - tap * K16;
+                const int ky = tap / KH, kx = tap - ky * KH;
+#pragma unroll
+                for (int mb = 0; mb < MBW; ++mb) {
+                    const int imm = (((2 * mb + ky) * ROWP + ((kx & 1) * HC + (kx >> 1)) * NCK1 + 2 * s) * 16);
+                    fa[set][mb][0] = *reinterpret_cast<const u32x4*>(a_h + imm);
+                    if constexpr (PL == 2) fa[set][mb][1] = *reinterpret_cast<const u32x4*>(a_l + imm);
+                }
+            }
+        };
+        issue_a(0, 0);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int sa = t & 1, sb = t % NSTB;
+#pragma unroll
+            for (int term = (PL == 2 ? 0 : 2); term < 3; ++term) {
+#pragma unroll
+                for (int mb = 0; mb < MBW; ++mb) {
+                    acc[mb] = mh_mfma_bf16_32(fa[sa][mb][term == 0 ? PL - 1 : 0], fb[sb][term == 1 ? PL - 1 : 0], acc[mb]);
+                    if (term == (PL == 2 ? 0 : 2) && mb == 0) issue_a(t + 1, sa ^ 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            issue_b(t + PF, (t + PF) % NSTB);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();                                 // every wave is done with the patch: the accumulator tile goes over it
+    planes_epilogue<GB, PL>(p, smem_all, acc, tid, true, 0, wn, lane, n0, y00, x00, b, 1, pre);
+}
+
 // fp32 NHWC -> the two bf16 planes (the operands of conv_planes_kernel): tensors no plane-writing kernel produces (cost-volume buffers, exact-fp32
 // layers' outputs).  lo may be null (then exactly mh_shadow_cast).
 __global__ __launch_bounds__(256) void plane_split_kernel(const mh_plane_seg* __restrict__ segs, int nseg) {
@@ -655,6 +773,48 @@ int launch_planes_s2bwd(PlanesArgs& a, hipStream_t s) {
     return mh_check_launch("conv_planes_s2bwd");
 }
 
+template <int KH, int WN, int MBW, int K16, int PL>
+int launch_planes_s2fwd(PlanesArgs& a, hipStream_t s, bool attr_only) {
+    using G = PlanesS2Geo<KH, WN, MBW, K16, PL>;
+    static_assert(G::LDS2 <= 160 * 1024, "patch planes exceed the LDS");
+    static std::atomic<uint64_t> attr_done{0};
+    const uint64_t attr_dev = mh_device_bit();
+    if (!(attr_done.load(std::memory_order_relaxed) & attr_dev)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_planes_s2fwd_kernel<KH, WN, MBW, K16, PL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { mh_set_error("conv_planes_s2fwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_done.fetch_or(attr_dev);
+    }
+    if (attr_only) return 0;
+    a.tiles_y = mh_cdiv(a.H, MBW);
+    a.tiles_x = mh_cdiv(a.W, 32);
+    a.ntiles_n = mh_cdiv(a.N, WN * 32);
+    a.nwg = a.B * a.tiles_y * a.tiles_x * a.ntiles_n;
+    {
+        const int64_t nwg64 = (int64_t)a.nwg;
+        const int dmax = std::max(std::max(a.ntiles_n, a.tiles_x), std::max(a.tiles_y, 1));
+        MH_REQUIRE(mh_fastdiv_ok(nwg64, dmax), MH_ERR_UNSUPPORTED, "tile decode: %lld workgroups x divisor %d exceeds the 2^32 range of the magic-multiplier division", (long long)nwg64, dmax);
+    }
+    a.dec = mh_make_tile_decode(a.ntiles_n, a.tiles_x, a.tiles_y, 1);
+    a.dbg = 0;
+    ++g_planes_launches;
+    mh_note_kernel("conv_planes_s2fwd_kernel<%dx%d,1x%d waves,MBW=%d,K16=%d,%s> tile %dx%d K=%d grid %d lds %d", KH, KH, WN, MBW, K16, PL == 2 ? "bf16x3" : "bf16", MBW * 32, WN * 32,
+                   a.K, a.nwg, G::LDS2);
+    hipLaunchKernelGGL((conv_planes_s2fwd_kernel<KH, WN, MBW, K16, PL>), dim3(a.nwg), dim3(WN * 64), G::LDS2, s, a);
+    return mh_check_launch("conv_planes_s2fwd");
+}
+
+// the stride-2 forward instances: (kernel size, K16, 32-column waves) -> launcher.  DispNet conv2 (5x5, 64 -> 128); MADNet / DispNet 3x3 down-sampling layers as they get wired
+struct PlanesS2Inst { int kh, k16, wn, pl; int (*launch)(PlanesArgs&, hipStream_t, bool); };
+const PlanesS2Inst g_planes_s2_inst[] = {
+    {5, 4, 4, 2, &launch_planes_s2fwd<5, 4, 2, 4, 2>}, {5, 4, 4, 1, &launch_planes_s2fwd<5, 4, 2, 4, 1>},
+    {3, 1, 1, 2, &launch_planes_s2fwd<3, 1, 4, 1, 2>}, {3, 2, 2, 2, &launch_planes_s2fwd<3, 2, 4, 2, 2>}, {3, 4, 3, 2, &launch_planes_s2fwd<3, 3, 2, 4, 2>},
+};
+const PlanesS2Inst* planes_s2_find(int kh, int k16, int n32, int pl) {
+    for (const PlanesS2Inst& I : g_planes_s2_inst)
+        if (I.kh == kh && I.k16 == k16 && I.wn == n32 && I.pl == pl) return &I;
+    return nullptr;
+}
+
 // ---- instance table + tile choice ---------------------------------------------------------------------------------------------------------
 // Every (N rounded up to 32, K16) pair has the 128-pixel instances of both M-block shapes; the pairs MADNet's layers use also have 64- / 32-pixel
 // instances for grids that would not fill the chip (the 1/8-resolution level: 60 tiles of 128 pixels on 256 CUs).
@@ -765,6 +925,8 @@ int dispatch_planes(PlanesArgs& a, hipStream_t s, bool all, int pl = 2) {
 
 int mh_conv_planes_init() {
     PlanesArgs a = {};
+    for (const PlanesS2Inst& I : g_planes_s2_inst)
+        if (int rc = I.launch(a, nullptr, true)) return rc;
     return dispatch_planes(a, nullptr, true);
 }
 
@@ -875,8 +1037,17 @@ extern "C" int mh_plane_split(const mh_plane_seg* segs_device, int32_t nseg, int
     return mh_check_launch("plane_split");
 }
 
+// stride-2 forward: KH x KH 'SAME' on even sizes (pads (KH - 2) / 2 in front), an instance for (KH, K16, N / 32), N a multiple of 32
+static bool planes_s2fwd_ok(const mh_conv_desc* d) {
+    if (!(d->stride == 2 && d->mode == 0 && d->kh == d->kw && (d->kh == 3 || d->kh == 5) && d->dil == 1 && !d->accumulate)) return false;
+    if (d->Hi != 2 * d->Ho || d->Wi != 2 * d->Wo || d->pad_t != (d->kh - 2) / 2 || d->pad_l != (d->kh - 2) / 2) return false;
+    if (d->N % 32 != 0 || d->K < 1) return false;
+    return planes_s2_find(d->kh, (d->K + 15) / 16, d->N / 32, d->precision == 1 ? 1 : 2) != nullptr;
+}
+
 extern "C" int mh_conv2d_planes_ok(const mh_conv_desc* d) {
     if (!d) return 0;
+    if (d->stride == 2) return planes_s2fwd_ok(d) ? 1 : 0;
     if (!(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->mode == 0 && d->pad_t == d->dil && d->pad_l == d->dil && d->Hi == d->Ho && d->Wi == d->Wo)) return 0;
     if (d->accumulate || d->dil < 1 || d->dil > 64 || d->N < 1 || d->N > 2048 || (d->N & 7) || d->K < 1 || d->K > 2048) return 0;
     return planes_has_instance((d->K + 15) / 16, (d->N + 31) / 32, d->precision == 1 ? 1 : 2) ? 1 : 0;
@@ -888,7 +1059,7 @@ extern "C" int mh_conv2d_planes(const mh_conv_desc* d, const void* in_hi, const 
     const int pl = d->precision == 1 ? 1 : 2;               // precision 1: plain bf16 from the hi plane and a ONE-plane bank; else split-bf16
     MH_REQUIRE(pl == 1 || in_lo, MH_ERR_ARG, "mh_conv2d_planes: the split-bf16 form needs the lo plane");
     MH_REQUIRE(out || out_hi || out_lo, MH_ERR_ARG, "mh_conv2d_planes: no output");
-    MH_REQUIRE(mh_conv2d_planes_ok(d), MH_ERR_UNSUPPORTED, "mh_conv2d_planes: forward stride-1 'SAME' 3x3 layers with an instance, N a multiple of 8, no accumulation");
+    MH_REQUIRE(mh_conv2d_planes_ok(d), MH_ERR_UNSUPPORTED, "mh_conv2d_planes: forward stride-1 'SAME' 3x3 layers (or stride-2 3x3 / 5x5 on even sizes) with an instance, N a multiple of 8, no accumulation");
     MH_REQUIRE(d->B > 0 && d->Hi > 0 && d->Wi > 0, MH_ERR_ARG, "mh_conv2d_planes: non-positive size");
     const int k16 = (d->K + 15) / 16;
     MH_REQUIRE(in_pld >= k16 * 16 && (in_pld & 7) == 0, MH_ERR_ARG, "mh_conv2d_planes: in_pld must cover K rounded up to 16 (multiple of 8)");
@@ -898,20 +1069,25 @@ extern "C" int mh_conv2d_planes(const mh_conv_desc* d, const void* in_hi, const 
         MH_REQUIRE(out_pld >= d->N && (out_pld & 7) == 0, MH_ERR_ARG, "mh_conv2d_planes: out_pld must cover N (multiple of 8)");
         MH_REQUIRE(mh_aligned16(out_hi) && mh_aligned16(out_lo), MH_ERR_ALIGN, "mh_conv2d_planes: 16-byte aligned output planes");
     }
-    const int64_t npix = (int64_t)d->B * d->Hi * d->Wi;
-    MH_REQUIRE(npix * in_pld * 2 < (1ll << 31) && npix * d->out_ld * 4 < (1ll << 31) && npix * (int64_t)out_pld * 2 < (1ll << 31), MH_ERR_UNSUPPORTED,
+    const int64_t npix_in = (int64_t)d->B * d->Hi * d->Wi;
+    const int64_t npix = (int64_t)d->B * d->Ho * d->Wo;            // (= npix_in at stride 1)
+    MH_REQUIRE(npix_in * in_pld * 2 < (1ll << 31) && npix * d->out_ld * 4 < (1ll << 31) && npix * (int64_t)out_pld * 2 < (1ll << 31), MH_ERR_UNSUPPORTED,
                "mh_conv2d_planes: tensors must be < 2 GiB");
     PlanesArgs a = {};
     a.in_hi = (const unsigned short*)in_hi; a.in_lo = (const unsigned short*)(pl == 2 ? in_lo : nullptr); a.wb = wb32; a.bias = bias;
     a.mask_hi = nullptr; a.mask_pld = 0; a.mask_alpha = 1.0f; a.mask_c0 = 0; a.mask_c1 = 0x7fffffff;
     a.nchunks = 1;
     a.out = out; a.out_hi = (unsigned short*)out_hi; a.out_lo = (unsigned short*)out_lo;
-    a.in_bytes = (unsigned)(npix * in_pld * 2);
-    a.wb_bytes = (unsigned)(mh_pack32_bytes(9, d->K, d->N) / (pl == 1 ? 2 : 1));
+    a.in_bytes = (unsigned)(npix_in * in_pld * 2);
+    a.wb_bytes = (unsigned)(mh_pack32_bytes(d->kh * d->kw, d->K, d->N) / (pl == 1 ? 2 : 1));
     a.out_bytes = out ? (unsigned)(npix * d->out_ld * 4) : 0u;
     a.outp_bytes = (unsigned)(npix * out_pld * 2);
     a.in_pld = in_pld; a.out_ld = d->out_ld; a.out_pld = out_pld;
-    a.B = d->B; a.H = d->Hi; a.W = d->Wi; a.K = d->K; a.N = d->N; a.dil = d->dil;
+    a.B = d->B; a.H = d->Ho; a.W = d->Wo; a.K = d->K; a.N = d->N; a.dil = d->dil;
     a.alpha = d->alpha;
+    if (d->stride == 2) {
+        a.Hin = d->Hi; a.Win = d->Wi; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.dil = 1;
+        return planes_s2_find(d->kh, k16, d->N / 32, pl)->launch(a, (hipStream_t)stream, false);
+    }
     return dispatch_planes(a, (hipStream_t)stream, false, pl);
 }

@@ -252,14 +252,16 @@ class DispNetEngine(object):
         """0: not on mh_conv2d_planes; 1: plain bf16 (one plane); 2: split-bf16 (hi + lo)"""
         _, x, wn, out, stride, alpha, _ = op
         w = self.W_(wn)
-        if not self.use_planes or stride != 1 or tuple(w.shape[:2]) != (3, 3) or x.st.H * x.st.W < self.sched.PLANES_MIN_PIX or x.c0 != 0 or w.shape[3] % 8:
+        # stride 1: the 3x3 layers; stride 2 (round 6, Schedule.PLANES_S2): the 5x5 conv2 of both towers (Nets/DispNet.py:80-84 -- 25 GFLOP that ran in exact fp32)
+        shape_ok = (stride == 1 and tuple(w.shape[:2]) == (3, 3)) or (stride == 2 and self.sched.PLANES_S2 and w.shape[0] == w.shape[1])
+        if not self.use_planes or not shape_ok or x.st.H * x.st.W < self.sched.PLANES_MIN_PIX or x.c0 != 0 or w.shape[3] % 8:
             return 0
         code = self._fwd_code(wn)
         if code is None:
             code = ops.PRECISION_CODES[self.precision][0]
         if code not in (1, 2):
             return 0
-        return code if ops.conv2d_planes_ok(self.lib, x.view(), w, 1, bf16=(code == 1)) else 0
+        return code if ops.conv2d_planes_ok(self.lib, x.view(), w, 1, bf16=(code == 1), stride=stride) else 0
 
     def _planes_bwd_ok(self, op):
         _, x, wn, out, stride, alpha, x_grad = op
@@ -278,6 +280,7 @@ class DispNetEngine(object):
     def _record_banks(self, r, backward):
         """one mh_pack_weights launch at the head of the step: the banks of every layer on the plane kernels (re-packed every step: the weights move)"""
         todo = []
+        packed = set()                        # (the two towers' conv2 share one variable: one bank, packed once)
         for op in self.ops:
             if op[0] != "conv":
                 continue
@@ -287,7 +290,9 @@ class DispNetEngine(object):
             if kind:
                 if wn not in self.banks_f or self.banks_f[wn][1] != kind:
                     self.banks_f[wn] = (torch.zeros(ops.pack_bytes(w, kind, 2) // 4, device=self.dev), kind)
-                todo.append((w, self.banks_f[wn][0], kind, 2))
+                if (wn, "f") not in packed:
+                    todo.append((w, self.banks_f[wn][0], kind, 2))
+                    packed.add((wn, "f"))
             if backward and self._planes_bwd_ok(op):
                 if wn not in self.banks_b:
                     self.banks_b[wn] = torch.zeros(ops.pack_bytes(w, 1, 3) // 4, device=self.dev)
@@ -331,7 +336,7 @@ class DispNetEngine(object):
                         if key not in self._fresh:
                             ops.shadow_cast(r, [(xv, sh)], self.dev, r.keep)
                     self._fresh.add(key)
-                    ops.conv2d_planes(r, xp, self.W_(wn), self.banks_f[wn][0], self.b_(wn), out=out.view(), alpha=alpha, bf16=(kind == 1))
+                    ops.conv2d_planes(r, xp, self.W_(wn), self.banks_f[wn][0], self.b_(wn), out=out.view(), alpha=alpha, bf16=(kind == 1), stride=stride)
                     continue
                 ops.conv2d_fwd(r, x.view(), self.W_(wn), self.b_(wn), out.view(), stride=stride, alpha=alpha, precision=self._fwd_code(wn))
             elif kind == "deconv":

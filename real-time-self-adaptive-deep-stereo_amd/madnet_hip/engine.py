@@ -282,10 +282,16 @@ class MadNetEngine(ElisionPasses, BackwardRecorder):
         B = self.B
         layers = []          # (name, forward precision code, output pixels)
         stride2 = set()
+        s2_planes = []
         for i in range(2, 13):                                      # the stride-1 pyramid layers and the small stride-2 ones (conv7 / 9 / 11)
             h, w = (self.fshape[i][0], self.fshape[i][1])
             if PYR[i - 1][2] == 2:
                 if 2 * B * h * w > self.bank_small_maxpix:
+                    # (round 6) the LARGE stride-2 layers named by Schedule.PLANES_S2_FWD run the stride-2 plane kernel (split-bf16 from their producer's planes)
+                    # instead of the exact-fp32 tiled kernel: a 32x32x16 bank, forward only
+                    if (i in self.sched.PLANES_S2_FWD and self.use_planes and fcode == 2 and self._pyr_code(i, fcode) == 2
+                            and ops.conv2d_planes_ok(self.lib, self._fv(self.F[i - 1]), self.W_(pyr_name(i)), 1, stride=2)):
+                        s2_planes.append(pyr_name(i))
                     continue
                 stride2.add(pyr_name(i))
             layers.append((pyr_name(i), self._pyr_code(i, fcode), 2 * B * h * w))
@@ -295,7 +301,7 @@ class MadNetEngine(ElisionPasses, BackwardRecorder):
             layers += [(est_name(k, j), code, B * h * w) for j in range(1, 7)]
         h, w, _ = self.fshape[4]
         layers += [(ctx_name(j), fcode, B * h * w) for j in range(1, 8)]
-        plan = []
+        plan = [(n, 2, 2) for n in s2_planes]
         for n, code, pix in layers:
             kh, _, K, N = shapes[n + "/weights"]
             if kh != 3:
@@ -372,11 +378,11 @@ class MadNetEngine(ElisionPasses, BackwardRecorder):
 
     def _conv_fwd(self, lib, r, x, base, o, stride=1, dil=1, alpha=ALPHA, precision=None, shadow_consumer=None):
         """forward conv of layer `base`: from planes (mh_conv2d_planes) where the layer has a 32x32x16 bank, else the fp32-operand kernels"""
-        wb32 = self.banks32.get(base) if stride == 1 else None
+        wb32 = self.banks32.get(base)              # (stride 2: only the layers _bank_plan gave a 32x32x16 bank -- Schedule.PLANES_S2_FWD)
         if wb32 is not None:
             xp = self._in_planes(lib, x, r)
             key, op_ = self._planes_of(o)
-            ops.conv2d_planes(lib, xp, self.W_(base), wb32, self.b_(base), out=o, out_planes=op_, dil=dil, alpha=alpha)
+            ops.conv2d_planes(lib, xp, self.W_(base), wb32, self.b_(base), out=o, out_planes=op_, dil=dil, alpha=alpha, stride=stride)
             self._fresh_planes.add(key)
             self._fresh.add(key)
             return

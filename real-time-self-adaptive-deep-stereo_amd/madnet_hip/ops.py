@@ -344,35 +344,44 @@ class Planes(object):
     ld = property(lambda self: self.hi.ld)
 
 
-def conv2d_planes_ok(qlib, x, w, dil=1, bf16=False):
-    """does conv2d_planes have an instance for this stride-1 'SAME' 3x3 layer?  (qlib = the real library; bf16: the one-plane form)"""
+def conv2d_planes_ok(qlib, x, w, dil=1, bf16=False, stride=1):
+    """does conv2d_planes have an instance for this 'SAME' layer -- stride 1: 3x3 (dilated); stride 2 (round 6): 3x3 / 5x5 on even sizes?  (qlib = the real
+    library; bf16: the one-plane form)"""
     kh, kw, cin, cout = w.shape
-    if (kh, kw) != (3, 3):
+    if stride == 2:
+        if kh != kw or kh not in (3, 5) or dil != 1 or x.H % 2 or x.W % 2:
+            return False
+        pad = (kh - 2) // 2
+        d = conv_desc(x.B, x.H, x.W, x.H // 2, x.W // 2, cin, cout, kh, kw, 2, 1, pad, pad, 0, 0, 0, 0, precision=1 if bf16 else 2)
+        return qlib.conv2d_planes_ok(C.byref(d)) == 1
+    if (kh, kw) != (3, 3) or stride != 1:
         return False
     d = conv_desc(x.B, x.H, x.W, x.H, x.W, cin, cout, 3, 3, 1, dil, dil, dil, 0, 0, 0, 0, precision=1 if bf16 else 2)
     return qlib.conv2d_planes_ok(C.byref(d)) == 1
 
 
-def conv2d_planes(lib, xp, w, wb32, b, out=None, out_planes=None, dil=1, alpha=1.0, stream=None, bf16=False):
+def conv2d_planes(lib, xp, w, wb32, b, out=None, out_planes=None, dil=1, alpha=1.0, stream=None, bf16=False, stride=1):
     """leaky(conv2d_SAME(x, w) + b) in split-bf16 from the input's planes `xp` (Planes); results: `out` (fp32 View or None) and / or
     `out_planes` (Planes, or a bare Shadow = hi plane only).  wb32: pack_weights(trans = 2) bank of w.
     bf16: plain bf16 (one MFMA per product) from the hi plane alone -- xp may be a bare Shadow, wb32 the ONE-plane bank (pack planes = 1)."""
     kh, kw, cin, cout = w.shape
-    assert (kh, kw) == (3, 3) and xp.C == cin
+    assert xp.C == cin and ((kh, kw) == (3, 3) if stride == 1 else (stride == 2 and kh == kw and dil == 1 and xp.H % 2 == 0 and xp.W % 2 == 0))
     if bf16:
         xhi = xp.hi if isinstance(xp, Planes) else xp
         xp = _HiOnly(xhi)
-    d = conv_desc(xp.B, xp.H, xp.W, xp.H, xp.W, cin, cout, 3, 3, 1, dil, dil, dil, 0, 0, 0, (out.ld if out is not None else 0), alpha=alpha,
+    Ho, Wo = xp.H // stride, xp.W // stride
+    pad = dil if stride == 1 else (kh - 2) // 2                  # TF 'SAME': stride 2 on even sizes pads (k - 2) // 2 in front (SURVEY A.1)
+    d = conv_desc(xp.B, xp.H, xp.W, Ho, Wo, cin, cout, kh, kw, stride, dil, pad, pad, 0, 0, 0, (out.ld if out is not None else 0), alpha=alpha,
                   precision=1 if bf16 else 2)
     ohi = olo = None
     opld = 0
     if out_planes is not None:
         hi = out_planes.hi if isinstance(out_planes, Planes) else out_planes
         lo = out_planes.lo if isinstance(out_planes, Planes) else None
-        assert (hi.B, hi.H, hi.W, hi.C) == (xp.B, xp.H, xp.W, cout)
+        assert (hi.B, hi.H, hi.W, hi.C) == (xp.B, Ho, Wo, cout)
         ohi, olo, opld = C.c_void_p(hi.ptr), (C.c_void_p(lo.ptr) if lo is not None else None), hi.ld
     if out is not None:
-        assert (out.B, out.H, out.W, out.C) == (xp.B, xp.H, xp.W, cout)
+        assert (out.B, out.H, out.W, out.C) == (xp.B, Ho, Wo, cout)
     lib.conv2d_planes(C.byref(d), C.c_void_p(xp.hi.ptr), (C.c_void_p(xp.lo.ptr) if xp.lo is not None else None), xp.ld, _p(wb32), _p(b), _p(out), ohi, olo, opld,
                       _p(stream))
 

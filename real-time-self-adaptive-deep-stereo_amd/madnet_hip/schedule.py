@@ -23,6 +23,9 @@ class Schedule(object):
     # The reduction of the loss value + the validation metrics run on a side lane (2.048 -> 2.030 ms since side launches are deferred,
     # r02_experiments.txt #10, #20); the warp-gradient scatters on a lane of their own lost in every variant (2.056 / 2.27 ms) and stay in line.
     SIDE_LOSS: bool = True
+    # (round 6) pyramid layers (1-based) whose STRIDE-2 forward pass runs the stride-2 plane kernel (conv_planes_s2fwd_kernel: split-bf16 from the producer's
+    # planes) instead of the exact-fp32 tiled kernel.  conv5 reads conv4's planes (a plane kernel wrote them); conv3 would need conv2's lo plane (one more launch)
+    PLANES_S2_FWD: tuple = (5,)
     # (round 6) the fused back end of a level (mh_corr_warp_bwd) is the FIRST writer of its level's feature gradient: no zero fill of the 13.9 MB of level
     # feature gradients at the head of the backward pass, no read of the halves it writes (the row-owned kernel gathers -- it never needed zeros to add to)
     FIRST_WRITER: bool = True
@@ -102,6 +105,9 @@ class DispNetSchedule(object):
     # split-K igemm kernels (scripts/microbench.py dispnet: 25 vs 41 us, 41 vs 73 us).  MH_CONV_PLANES=0 turns the path off.
     USE_PLANES: bool = field(default_factory=_env_flag("MH_CONV_PLANES", "1"))
     PLANES_MIN_PIX: int = 1920
+    # (round 6) the stride-2 5x5 layer conv2 of both towers on the stride-2 plane kernel (conv_planes_s2fwd_kernel: split-bf16 from planes) instead of the exact-fp32
+    # tiled kernel
+    PLANES_S2: bool = True
     # FULL momentum steps: every filter-gradient batch is followed, on its own side lane, by the momentum update of the layers it completes; the launch
     # behind the join covers what is left.  DispNet has 42 M parameters: one update over all of them is 840 MB of traffic at the very end of the step.
     EARLY_UPDATE: bool = field(default_factory=_env_flag("MH_EARLY_UPDATE", "1"))

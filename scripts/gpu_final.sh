@@ -15,7 +15,10 @@ if [ "$SKIP_PMC" != "1" ]; then
   bash scripts/gpu_pmc.sh $TAG/pmc > $OUT/pmc.log 2>&1
   cp profiles/${ROUND}_pmc_roofline.json $OUT/ 2>/dev/null
 fi
-if [ "$SKIP_TESTS" != "1" ]; then timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -4 | tee $OUT/pytest_gpu.txt; fi
+if [ "$SKIP_TESTS" != "1" ]; then   # (RCCL prints a version banner through C stdio when the test processes exit: keep the log whole, quote the summary line)
+  timeout 2400 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" > $OUT/pytest_gpu.txt
+  grep -E "passed|failed|error" $OUT/pytest_gpu.log | tail -3 >> $OUT/pytest_gpu.txt; cat $OUT/pytest_gpu.txt
+fi
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; tail -3 $OUT/smoke.txt
 # the driver's own command, stdout kept whole (the ONE line, < 6 KB)
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2>>$OUT/bench.err; cp bench_detail.json $OUT/bench_default_detail.json

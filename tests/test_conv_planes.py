@@ -353,3 +353,47 @@ def test_conv2d_planes_bwd_stride2(backend, case):
         ops.conv2d_dgrad(lib, ops.view(dz), w, ops.view(dx0), stride=2, mask_ref=ops.view(x), mask_alpha=0.2)
     backend.sync()
     assert (dxc - dx0.cpu()).abs().max().item() <= 2e-5 * scale
+
+
+# (B, H, W, Cin, Cout, k): H, W even; the shapes with an instance -- DispNet conv2 (5x5, 64 -> 128) and the 3x3 down-sampling layers (16 -> 32, 32 -> 64, 64 -> 96)
+S2_CASES = [(1, 12, 72, 64, 128, 5), (2, 6, 68, 64, 128, 5), (1, 18, 40, 64, 128, 5), (1, 16, 66, 16, 32, 3), (1, 10, 132, 32, 64, 3), (2, 6, 68, 64, 96, 3)]
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["x3", "bf16"])
+@pytest.mark.parametrize("case", S2_CASES)
+def test_conv2d_planes_stride2_forward(backend, case, bf16):
+    """conv_planes_s2fwd_kernel (round 6): tf.nn.conv2d(strides 2, 'SAME') + bias + leaky (Nets/sharedLayers.py:54-66; DispNet conv2: Nets/DispNet.py:80-84) from
+    pre-split planes, patch columns split by parity.  TF 'SAME' on even sizes pads (k - 2) // 2 in front (SURVEY A.1: 5x5 -> 1, 3x3 -> 0).  Split-bf16 against the fp64
+    oracle at the 2^-16 level, plain bf16 against the oracle on bf16-rounded operands; ragged tiles (rows not a multiple of the tile, columns not a multiple of 32),
+    output planes == the split of the fp32 result."""
+    B, H, W, Ci, Co, k = case
+    lib, dev = backend.lib, backend.device
+    if bf16 and k != 5:
+        pytest.skip("the one-plane form is instantiated for the 5x5 layer only")
+    x = _rand((B, H, W, Ci), 311, dev)
+    w = _rand((k, k, Ci, Co), 312, dev, 0.1)
+    b = _rand((Co,), 313, dev)
+    keep = []
+    assert ops.conv2d_planes_ok(lib, ops.view(x), w, 1, bf16=bf16, stride=2)
+    assert not ops.conv2d_planes_ok(lib, ops.View(x, B, H - 1, W, Ci, Ci), w, 1, bf16=bf16, stride=2)          # odd sizes pad differently: not served
+    xp = _planes_of(lib, x, dev, keep)
+    planes = 1 if bf16 else 2
+    bank = torch.full((ops.pack_bytes(w, planes, 2) // 4,), float("nan"), device=dev)
+    assert ops.pack_bytes(w, 2, 2) == lib.pack32_bytes(k * k, Ci, Co)
+    ops.pack_weights(lib, [(w, bank, planes, 2)], dev, keep)
+    Ho, Wo = H // 2, W // 2
+    y = torch.full((B, Ho, Wo, Co), float("nan"), device=dev)
+    yp = ops.Planes(ops.Shadow(B, Ho, Wo, Co, dev), dev)
+    ops.conv2d_planes(lib, xp, w, bank, b, out=ops.view(y), out_planes=yp, alpha=0.1, bf16=bf16, stride=2)
+    assert "conv_planes_s2fwd_kernel<%dx%d" % (k, k) in lib.last_kernel().decode()
+    backend.sync()
+    if bf16:
+        bf = lambda t: t.to(torch.bfloat16).float()
+        ref = T.conv2d(bf(x.cpu()).double(), bf(w.cpu()).double(), b.cpu().double(), stride=2, alpha=0.1).float(); tol = 2e-5
+    else:
+        ref = T.conv2d(x.cpu().double(), w.cpu().double(), b.cpu().double(), stride=2, alpha=0.1).float(); tol = 4e-5
+    assert ref.shape == y.shape
+    err = (y.cpu() - ref).abs().max().item()
+    assert err <= tol * max(1.0, ref.abs().max().item()), err
+    hi, lo = _split_ref(y.cpu())
+    assert torch.equal(yp.hi.t.cpu()[..., :Co], hi) and torch.equal(yp.lo.t.cpu()[..., :Co], lo)
