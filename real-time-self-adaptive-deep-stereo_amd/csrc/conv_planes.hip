@@ -458,11 +458,15 @@ __global__ __launch_bounds__((WM * WN + 1) * 64) void conv_planes_ck_kernel(Plan
 // A wave owns one row of 32 dz pixels and four class accumulators; the dz patch (tile + one row above, one column to the left) is staged by LDS DMA from
 // the bf16 shadow of dz, the bank is the one-plane mirrored / transposed image of mh_conv2d_planes_bwd (walk step t = forward tap 8 - t); each class
 // leaves through the common epilogue on the stride-2 lattice of dx (mask of the layer's input from its bf16 shadow, fp32 + shadow stores).
-template <int WM, int WN, int K16>
+// KH = 5 (round 6: DispNet conv2, 'SAME' pads 1 in front): y + 1 - ky even -- even rows take ky in {1, 3} (dz rows i, i - 1), odd rows ky in {0, 2, 4} (dz rows i + 1, i, i - 1):
+// 2x2 + 2x3 + 3x2 + 3x3 = 25 tap products per dz pixel, the patch has a row / column on BOTH sides.  One formula for both sizes: class parity py = (ky + pt) & 1,
+// dz row offset di = (py + pt - ky) / 2.
+template <int WM, int WN, int K16, int KH = 3>
 __global__ __launch_bounds__(WM * WN * 64) void conv_planes_s2bwd_kernel(PlanesArgs p) {
     using G = PlanesGeo<32, WM, WN, 1, K16, 1>;                      // epilogue geometry: one M-block per wave
     constexpr int NW = G::NW, TR = WM, BN = G::BN, NCK = G::NCK, NCK1 = G::NCK1;
-    constexpr int PR = TR + 1, PC = 33, ROWP = PC * NCK1;
+    constexpr int PT = (KH - 2) / 2, BELOW = (KH == 5) ? 1 : 0;      // forward padding in front; dz rows / columns needed BEHIND the tile
+    constexpr int PR = TR + 1 + BELOW, PC = 33 + BELOW, ROWP = PC * NCK1;
     constexpr int PLANE_BLKS = (PR * ROWP * 16 + 1023) / 1024;
     HIP_DYNAMIC_SHARED(float, smem_all)
     unsigned char* const smem = reinterpret_cast<unsigned char*>(smem_all);
@@ -475,7 +479,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_planes_s2bwd_kernel(PlanesA
     const int n0 = tile_n * BN;
     const int i00 = tty * TR, j00 = ttx * 32;                        // dz position of tile pixel (0, 0)
 
-    constexpr int T = 9 * K16, NSTB = 8, PF = NSTB - 1;
+    constexpr int T = KH * KH * K16, NSTB = 8, PF = NSTB - 1;
     const __amdgpu_buffer_rsrc_t rs_b = mh_make_rsrc(p.wb, p.wb_bytes);
     const int nt32 = (p.N + 31) >> 5;
     const int nt = tile_n * WN + wn;
@@ -510,10 +514,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_planes_s2bwd_kernel(PlanesA
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int tap = t / K16, s = t - tap * K16;
-            const int f = 8 - tap;                                   // forward tap of this bank step
-            const int ky = f / 3, kx = f - ky * 3;
-            const int cls = (ky == 1 ? 2 : 0) + (kx == 1 ? 1 : 0);
-            const int imm = (((ky == 2 ? 0 : 1) * ROWP + (kx == 2 ? 0 : 1) * NCK1 + 2 * s) * 16);
+            const int f = KH * KH - 1 - tap;                         // forward tap of this bank step (the bank is the mirrored image)
+            const int ky = f / KH, kx = f - ky * KH;
+            const int py = (ky + PT) & 1, px = (kx + PT) & 1;        // the parity class of dx this tap feeds
+            const int di = (py + PT - ky) / 2, dj = (px + PT - kx) / 2;      // dz pixel = (i + di, j + dj), di / dj in {-1, 0, 1} (exact: the numerators are even)
+            const int cls = 2 * py + px;
+            const int imm = (((1 + di) * ROWP + (1 + dj) * NCK1 + 2 * s) * 16);      // patch (0, 0) = dz (i00 - 1, j00 - 1)
             const u32x4 fa = *reinterpret_cast<const u32x4*>(a0 + imm);
             acc[cls][0] = mh_mfma_bf16_32(fa, fb[t % NSTB], acc[cls][0]);
             issue_b(t + PF, (t + PF) % NSTB);
@@ -743,16 +749,17 @@ int launch_planes_ck(PlanesArgs& a, hipStream_t s, bool attr_only) {
     return mh_check_launch("conv_planes_ck");
 }
 
-template <int WM, int WN, int K16>
+template <int WM, int WN, int K16, int KH = 3>
 int launch_planes_s2bwd(PlanesArgs& a, hipStream_t s) {
     using G = PlanesGeo<32, WM, WN, 1, K16, 1>;
-    constexpr int PR = WM + 1, ROWP = 33 * G::NCK1;
+    constexpr int BELOW = (KH == 5) ? 1 : 0;
+    constexpr int PR = WM + 1 + BELOW, ROWP = (33 + BELOW) * G::NCK1;
     constexpr int LDS_P = ((PR * ROWP * 16 + 1023) / 1024) * 1024;
     constexpr int LDS = LDS_P > G::LDS_CS ? LDS_P : G::LDS_CS;
     static std::atomic<uint64_t> attr_done{0};
     const uint64_t attr_dev = mh_device_bit();
     if (!(attr_done.load(std::memory_order_relaxed) & attr_dev)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_planes_s2bwd_kernel<WM, WN, K16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_planes_s2bwd_kernel<WM, WN, K16, KH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { mh_set_error("conv_planes_s2bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_done.fetch_or(attr_dev);
     }
@@ -768,8 +775,8 @@ int launch_planes_s2bwd(PlanesArgs& a, hipStream_t s) {
     a.dec = mh_make_tile_decode(a.ntiles_n, a.tiles_x, a.tiles_y, 1);
     a.dbg = 0;
     ++g_planes_launches;
-    mh_note_kernel("conv_planes_s2bwd_kernel<%dx%d waves,K16=%d,bf16> dz tile %dx32 -> dx %dx64, K=%d N=%d grid %d lds %d", WM, WN, K16, WM, 2 * WM, a.K, a.N, a.nwg, LDS);
-    hipLaunchKernelGGL((conv_planes_s2bwd_kernel<WM, WN, K16>), dim3(a.nwg), dim3(WM * WN * 64), LDS, s, a);
+    mh_note_kernel("conv_planes_s2bwd_kernel<%dx%d waves,K16=%d,%dx%d,bf16> dz tile %dx32 -> dx %dx64, K=%d N=%d grid %d lds %d", WM, WN, K16, KH, KH, WM, 2 * WM, a.K, a.N, a.nwg, LDS);
+    hipLaunchKernelGGL((conv_planes_s2bwd_kernel<WM, WN, K16, KH>), dim3(a.nwg), dim3(WM * WN * 64), LDS, s, a);
     return mh_check_launch("conv_planes_s2bwd");
 }
 
@@ -804,15 +811,23 @@ int launch_planes_s2fwd(PlanesArgs& a, hipStream_t s, bool attr_only) {
 }
 
 // the stride-2 forward instances: (kernel size, K16, 32-column waves) -> launcher.  DispNet conv2 (5x5, 64 -> 128); MADNet / DispNet 3x3 down-sampling layers as they get wired
-struct PlanesS2Inst { int kh, k16, wn, pl; int (*launch)(PlanesArgs&, hipStream_t, bool); };
+struct PlanesS2Inst { int kh, k16, wn, pl, mbw; int (*launch)(PlanesArgs&, hipStream_t, bool); };
+#define S2_INST(KH, WN, MBW, K16, PL) {KH, K16, WN, PL, MBW, &launch_planes_s2fwd<KH, WN, MBW, K16, PL>}
 const PlanesS2Inst g_planes_s2_inst[] = {
-    {5, 4, 4, 2, &launch_planes_s2fwd<5, 4, 2, 4, 2>}, {5, 4, 4, 1, &launch_planes_s2fwd<5, 4, 2, 4, 1>},
-    {3, 1, 1, 2, &launch_planes_s2fwd<3, 1, 4, 1, 2>}, {3, 2, 2, 2, &launch_planes_s2fwd<3, 2, 4, 2, 2>}, {3, 4, 3, 2, &launch_planes_s2fwd<3, 3, 2, 4, 2>},
+    S2_INST(5, 4, 2, 4, 2), S2_INST(5, 4, 2, 4, 1),                                   // 5x5 64 -> 128: two output rows per tile is what the LDS holds (137 KB of patch planes)
+    S2_INST(3, 1, 4, 1, 2), S2_INST(3, 1, 2, 1, 2), S2_INST(3, 2, 4, 2, 2), S2_INST(3, 2, 2, 2, 2), S2_INST(3, 2, 1, 2, 2), S2_INST(3, 3, 2, 4, 2), S2_INST(3, 3, 1, 4, 2),
 };
-const PlanesS2Inst* planes_s2_find(int kh, int k16, int n32, int pl) {
-    for (const PlanesS2Inst& I : g_planes_s2_inst)
-        if (I.kh == kh && I.k16 == k16 && I.wn == n32 && I.pl == pl) return &I;
-    return nullptr;
+// the instance of a layer: the TALLEST tile (most output rows per wave = fewest weight-fragment loads per MFMA) that still gives every CU a workgroup, else the shortest
+const PlanesS2Inst* planes_s2_find(int kh, int k16, int n32, int pl, int64_t rows_x_coltiles = -1) {
+    const PlanesS2Inst* best = nullptr;
+    for (const PlanesS2Inst& I : g_planes_s2_inst) {
+        if (!(I.kh == kh && I.k16 == k16 && I.wn == n32 && I.pl == pl)) continue;
+        if (!best) { best = &I; continue; }
+        if (rows_x_coltiles < 0) continue;
+        const bool fills_b = rows_x_coltiles / best->mbw >= 192, fills_i = rows_x_coltiles / I.mbw >= 192;      // (three quarters of the CUs: 240 two-row tiles beat 480 one-row tiles)
+        if ((fills_i && (!fills_b || I.mbw > best->mbw)) || (!fills_i && !fills_b && I.mbw < best->mbw)) best = &I;
+    }
+    return best;
 }
 
 // ---- instance table + tile choice ---------------------------------------------------------------------------------------------------------
@@ -952,8 +967,11 @@ static bool planes_has_instance(int k16, int n32, int pl) {
 // ---- input gradient of a stride-1 'SAME' 3x3 layer from bf16 shadows: dx = conv2d_backprop_input(dz, w) [* leaky'(mask)] ----------------------------
 // stride-2 layers (forward 3x3, 'SAME' on even sizes: no padding in front): Cout in {32, 64} (K16 2 / 4), Cin <= 32
 static bool planes_s2bwd_ok(const mh_conv_desc* d) {
-    return d->kh == 3 && d->kw == 3 && d->stride == 2 && d->dil == 1 && d->pad_t == 0 && d->pad_l == 0 && d->Hi == 2 * d->Ho && d->Wi == 2 * d->Wo &&
-           (d->N == 32 || d->N == 64) && d->K >= 1 && d->K <= 32 && !d->accumulate && (d->in_ld == 0 || d->in_ld >= ((d->K + 7) & ~7));
+    if (!(d->stride == 2 && d->dil == 1 && d->Hi == 2 * d->Ho && d->Wi == 2 * d->Wo && !d->accumulate && (d->in_ld == 0 || d->in_ld >= ((d->K + 7) & ~7)))) return false;
+    if (d->kh == 3 && d->kw == 3 && d->pad_t == 0 && d->pad_l == 0) return (d->N == 32 || d->N == 64) && d->K >= 1 && d->K <= 32;
+    // 5x5 (DispNet conv2: 64 -> 128): reduction over 128 output channels (K16 8), 33 .. 64 gradient columns (two 32-column waves)
+    if (d->kh == 5 && d->kw == 5 && d->pad_t == 1 && d->pad_l == 1) return d->N == 128 && d->K > 32 && d->K <= 64;
+    return false;
 }
 
 extern "C" int mh_conv2d_planes_bwd_ok(const mh_conv_desc* d) {
@@ -969,7 +987,7 @@ extern "C" int mh_conv2d_planes_bwd(const mh_conv_desc* d, const void* dz_hi, in
                                     float* dx, void* dx_hi, int32_t dx_pld, void* stream) {
     MH_REQUIRE(d && dz_hi && wb32t, MH_ERR_ARG, "mh_conv2d_planes_bwd: null descriptor / dz plane / fragment bank");
     MH_REQUIRE(dx || dx_hi, MH_ERR_ARG, "mh_conv2d_planes_bwd: no output");
-    MH_REQUIRE(mh_conv2d_planes_bwd_ok(d), MH_ERR_UNSUPPORTED, "mh_conv2d_planes_bwd: 'SAME' 3x3 layers with an instance (stride 1; stride 2: Cout 32 or 64, Cin <= 32, even sizes)");
+    MH_REQUIRE(mh_conv2d_planes_bwd_ok(d), MH_ERR_UNSUPPORTED, "mh_conv2d_planes_bwd: 'SAME' 3x3 layers with an instance (stride 1; stride 2: Cout 32 or 64, Cin <= 32, even sizes) or the stride-2 5x5 layer 33..64 -> 128");
     MH_REQUIRE(d->B > 0 && d->Hi > 0 && d->Wi > 0, MH_ERR_ARG, "mh_conv2d_planes_bwd: non-positive size");
     const int k16 = (d->N + 15) / 16;
     const int k8 = (d->K + 7) & ~7;
@@ -990,7 +1008,7 @@ extern "C" int mh_conv2d_planes_bwd(const mh_conv_desc* d, const void* dz_hi, in
     a.nchunks = 1;
     a.out = dx; a.out_hi = (unsigned short*)dx_hi; a.out_lo = nullptr;
     a.in_bytes = (unsigned)(npix * dz_pld * 2);
-    a.wb_bytes = (unsigned)(mh_pack32_bytes(9, d->N, d->K) / 2);
+    a.wb_bytes = (unsigned)(mh_pack32_bytes(d->kh * d->kw, d->N, d->K) / 2);
     a.out_bytes = dx ? (unsigned)(npix * d->in_ld * 4) : 0u;
     a.outp_bytes = (unsigned)(npix * dx_pld * 2);
     a.in_pld = dz_pld; a.out_ld = d->in_ld; a.out_pld = dx_pld;
@@ -1001,6 +1019,7 @@ extern "C" int mh_conv2d_planes_bwd(const mh_conv_desc* d, const void* dz_hi, in
         a.in_bytes = (unsigned)((int64_t)d->B * d->Ho * d->Wo * dz_pld * 2);
         a.dil = 1;
         const bool few = (int64_t)d->B * mh_cdiv(d->Ho, 4) * mh_cdiv(d->Wo, 32) < 256;       // fewer than a workgroup per CU: two-row tiles
+        if (d->kh == 5) return few ? launch_planes_s2bwd<2, 2, 8, 5>(a, (hipStream_t)stream) : launch_planes_s2bwd<4, 2, 8, 5>(a, (hipStream_t)stream);
         if (d->N == 32) return few ? launch_planes_s2bwd<2, 1, 2>(a, (hipStream_t)stream) : launch_planes_s2bwd<4, 1, 2>(a, (hipStream_t)stream);
         return few ? launch_planes_s2bwd<2, 1, 4>(a, (hipStream_t)stream) : launch_planes_s2bwd<4, 1, 4>(a, (hipStream_t)stream);
     }
@@ -1087,7 +1106,7 @@ extern "C" int mh_conv2d_planes(const mh_conv_desc* d, const void* in_hi, const 
     a.alpha = d->alpha;
     if (d->stride == 2) {
         a.Hin = d->Hi; a.Win = d->Wi; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.dil = 1;
-        return planes_s2_find(d->kh, k16, d->N / 32, pl)->launch(a, (hipStream_t)stream, false);
+        return planes_s2_find(d->kh, k16, d->N / 32, pl, (int64_t)d->B * d->Ho * mh_cdiv(d->Wo, 32))->launch(a, (hipStream_t)stream, false);
     }
     return dispatch_planes(a, (hipStream_t)stream, false, pl);
 }

@@ -266,9 +266,10 @@ class DispNetEngine(object):
     def _planes_bwd_ok(self, op):
         _, x, wn, out, stride, alpha, x_grad = op
         w = self.W_(wn)
-        if not (self.use_planes and x_grad and stride == 1 and tuple(w.shape[:2]) == (3, 3) and x.st.H * x.st.W >= self.sched.PLANES_MIN_PIX and x.c0 == 0):
+        shape_ok = (stride == 1 and tuple(w.shape[:2]) == (3, 3)) or (stride == 2 and self.sched.PLANES_S2 and tuple(w.shape[:2]) == (5, 5))      # (round 6: conv2's parity-class form)
+        if not (self.use_planes and x_grad and shape_ok and x.st.H * x.st.W >= self.sched.PLANES_MIN_PIX and x.c0 == 0):
             return False
-        return ops._bwd_precision() == 1 and x.st.ld >= _r8(x.C) and ops.conv2d_planes_bwd_ok(self.lib, x.gview(), w, 1)
+        return ops._bwd_precision() == 1 and x.st.ld >= _r8(x.C) and ops.conv2d_planes_bwd_ok(self.lib, x.gview(), w, 1, stride=stride)
 
     def _shadow_of(self, v):
         key = (v.ptr, v.B, v.H, v.W, v.C)
@@ -296,12 +297,15 @@ class DispNetEngine(object):
             if backward and self._planes_bwd_ok(op):
                 if wn not in self.banks_b:
                     self.banks_b[wn] = torch.zeros(ops.pack_bytes(w, 1, 3) // 4, device=self.dev)
-                todo.append((w, self.banks_b[wn], 1, 3))
+                if (wn, "b") not in packed:
+                    todo.append((w, self.banks_b[wn], 1, 3))
+                    packed.add((wn, "b"))
         ops.pack_weights(r, todo, self.dev, r.keep)
 
     def record_forward(self, r, backward=True):
         B = self.B
         self._fresh = set()
+        self._fresh_lo = set()                # tensors whose hi AND lo planes a producer of this plan has written
         if self.use_planes:
             self._record_banks(r, backward)
         self._grad_zeroed_early = False
@@ -317,6 +321,14 @@ class DispNetEngine(object):
         # DispNet._preprocess_inputs (DispNet.py:59-73): x/255 - 100/255, reflect pad to a multiple of 64
         ops.pad_reflect(r, self.left, self.X0L.t, self.pt, self.pl, div=255.0, sub=100.0 / 255)
         ops.pad_reflect(r, self.right, self.X0R.t, self.pt, self.pl, div=255.0, sub=100.0 / 255)
+        # (round 6) a conv whose result is -- whole -- the input of a split-bf16 plane layer writes the hi / lo planes in its own epilogue (mh_conv2d_sh4) instead of a
+        # plane_split launch in front of the consumer: conv1 -> conv2 of both towers (2 x 12 us at 1242x375)
+        plane_consumers = {}
+        if self.sched.PLANES_S2:
+            for op2 in self.ops:
+                if op2[0] == "conv" and self._planes_fwd_kind(op2) == 2:
+                    xv2 = op2[1].view()
+                    plane_consumers[(xv2.ptr, xv2.B, xv2.H, xv2.W, xv2.C)] = True
         for op in self.ops:
             kind = op[0]
             if kind == "conv":
@@ -330,7 +342,8 @@ class DispNetEngine(object):
                         if key not in self.lo_planes:
                             self.lo_planes[key] = ops.Shadow(xv.B, xv.H, xv.W, xv.C, self.dev)
                         xp = ops.Planes.__new__(ops.Planes); xp.hi, xp.lo = sh, self.lo_planes[key]
-                        ops.plane_split(r, [(xv, xp)], self.dev, r.keep)
+                        if key not in self._fresh_lo:
+                            ops.plane_split(r, [(xv, xp)], self.dev, r.keep)
                     else:
                         xp = sh
                         if key not in self._fresh:
@@ -338,7 +351,17 @@ class DispNetEngine(object):
                     self._fresh.add(key)
                     ops.conv2d_planes(r, xp, self.W_(wn), self.banks_f[wn][0], self.b_(wn), out=out.view(), alpha=alpha, bf16=(kind == 1), stride=stride)
                     continue
-                ops.conv2d_fwd(r, x.view(), self.W_(wn), self.b_(wn), out.view(), stride=stride, alpha=alpha, precision=self._fwd_code(wn))
+                ov = out.view()
+                okey = (ov.ptr, ov.B, ov.H, ov.W, ov.C)
+                if okey in plane_consumers and ov.ld == ov.C and ov.C % 8 == 0:
+                    _, osh = self._shadow_of(ov)
+                    if okey not in self.lo_planes:
+                        self.lo_planes[okey] = ops.Shadow(ov.B, ov.H, ov.W, ov.C, self.dev)
+                    op_ = ops.Planes.__new__(ops.Planes); op_.hi, op_.lo = osh, self.lo_planes[okey]
+                    ops.conv2d_fwd(r, x.view(), self.W_(wn), self.b_(wn), ov, stride=stride, alpha=alpha, precision=self._fwd_code(wn), out_planes=op_)
+                    self._fresh_lo.add(okey); self._fresh.add(okey)
+                    continue
+                ops.conv2d_fwd(r, x.view(), self.W_(wn), self.b_(wn), ov, stride=stride, alpha=alpha, precision=self._fwd_code(wn))
             elif kind == "deconv":
                 _, x, wn, out, alpha = op
                 ops.conv2d_transpose_fwd(r, x.view(), self.W_(wn), self.b_(wn), out.view(), stride=2, alpha=alpha, precision=self._fwd_code(wn))
@@ -500,7 +523,7 @@ class DispNetEngine(object):
                                 self._fresh.add(km)
                             self._fresh.add(kz)
                             ops.shadow_cast(lib, casts, self.dev, r.keep)
-                            ops.conv2d_planes_bwd(lib, dzs, w, self.banks_b[wn], dx=dx, mask_shadow=ms, mask_alpha=ma, mask_range=rng)
+                            ops.conv2d_planes_bwd(lib, dzs, w, self.banks_b[wn], dx=dx, mask_shadow=ms, mask_alpha=ma, mask_range=rng, stride=stride)
                             return
                         ops.conv2d_dgrad(lib, dz, w, dx, stride=stride, accumulate=acc, mask_ref=ref, mask_alpha=ma, mask_range=rng)
                     conv_like_dgrad(emit_dgrad, x)

@@ -404,12 +404,13 @@ def conv2d_planes_bwd_ok(qlib, dx, w, dil=1, stride=1):
     """does conv2d_planes_bwd have an instance for the input gradient of this 'SAME' 3x3 layer (w: HWIO of the forward layer; stride 1, or stride 2 on
     even sizes)?"""
     kh, kw, cin, cout = w.shape
-    if (kh, kw) != (3, 3):
-        return False
     if stride == 2:
-        if dil != 1 or dx.H % 2 or dx.W % 2:
+        if kh != kw or kh not in (3, 5) or dil != 1 or dx.H % 2 or dx.W % 2:
             return False
-        d = conv_desc(dx.B, dx.H, dx.W, dx.H // 2, dx.W // 2, cin, cout, 3, 3, 2, 1, 0, 0, 0, 0, dx.ld, 0, precision=1)
+        pad = (kh - 2) // 2
+        d = conv_desc(dx.B, dx.H, dx.W, dx.H // 2, dx.W // 2, cin, cout, kh, kw, 2, 1, pad, pad, 0, 0, dx.ld, 0, precision=1)
+    elif (kh, kw) != (3, 3):
+        return False
     else:
         d = conv_desc(dx.B, dx.H, dx.W, dx.H, dx.W, cin, cout, 3, 3, 1, dil, dil, dil, 0, 0, dx.ld, 0, precision=1)
     return qlib.conv2d_planes_bwd_ok(C.byref(d)) == 1
@@ -419,11 +420,11 @@ def conv2d_planes_bwd(lib, dz_shadow, w, wb32t, dx=None, dx_shadow=None, mask_sh
     """dx = conv2d_backprop_input(dz, w) * leaky'(mask) from the bf16 shadow of dz (mh_conv2d_planes_bwd): w HWIO [3,3,Cin,Cout] of the forward layer,
     wb32t = pack_weights(trans = 3) bank; results: dx (fp32 View or None) and / or dx_shadow (Shadow); mask_shadow: Shadow of the layer's input."""
     kh, kw, cin, cout = w.shape
-    assert (kh, kw) == (3, 3) and dz_shadow.C == cout
-    B, H, W = dz_shadow.B, dz_shadow.H * stride, dz_shadow.W * stride              # size of dx (stride 2: even sizes, 'SAME' pads behind only)
+    assert dz_shadow.C == cout and ((kh, kw) == (3, 3) or (stride == 2 and kh == kw == 5))
+    B, H, W = dz_shadow.B, dz_shadow.H * stride, dz_shadow.W * stride              # size of dx (stride 2: even sizes, 'SAME' pads (k - 2) // 2 in front)
     assert stride in (1, 2) and (stride == 1 or dil == 1)
-    pad = dil if stride == 1 else 0
-    d = conv_desc(B, H, W, dz_shadow.H, dz_shadow.W, cin, cout, 3, 3, stride, dil, pad, pad, 0, 0, (dx.ld if dx is not None else 0), 0, mask_alpha=mask_alpha,
+    pad = dil if stride == 1 else (kh - 2) // 2
+    d = conv_desc(B, H, W, dz_shadow.H, dz_shadow.W, cin, cout, kh, kw, stride, dil, pad, pad, 0, 0, (dx.ld if dx is not None else 0), 0, mask_alpha=mask_alpha,
                   precision=1, mask_c0=mask_range[0], mask_c1=mask_range[1])
     for t in (dx, dx_shadow, mask_shadow):
         assert t is None or (t.B, t.H, t.W, t.C) == (B, H, W, cin)

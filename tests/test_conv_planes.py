@@ -309,7 +309,8 @@ def test_conv2d_planes_split_bf16_dispnet_iconv_shapes(backend, case):
 
 
 # (B, Hz, Wz, Cin, Cout): input gradient of the STRIDE-2 3x3 layers (MADNet pyramid conv3 16 -> 32, conv5 32 -> 64; dz is Hz x Wz, dx 2Hz x 2Wz)
-S2_BWD_CASES = [(1, 5, 33, 16, 32), (2, 8, 40, 32, 64), (1, 3, 70, 24, 32), (1, 24, 80, 16, 32)]
+# ... and (round 6, last field k = 5) of DispNet's 5x5 stride-2 conv2 (64 -> 128; 'SAME' pads 1 in front: the patch has a row / column on both sides)
+S2_BWD_CASES = [(1, 5, 33, 16, 32), (2, 8, 40, 32, 64), (1, 3, 70, 24, 32), (1, 24, 80, 16, 32), (1, 5, 33, 64, 128, 5), (2, 8, 40, 64, 128, 5), (1, 3, 70, 48, 128, 5)]
 
 
 @pytest.mark.parametrize("case", S2_BWD_CASES)
@@ -317,11 +318,12 @@ def test_conv2d_planes_bwd_stride2(backend, case):
     """mh_conv2d_planes_bwd on a stride-2 layer (conv_planes_s2bwd_kernel: the four parity classes of the output pixels as four small convolutions over one
     dz patch): against the autograd of the oracle's stride-2 conv on bf16-rounded operands (fp32 summation order apart) and the tiled bf16 input-gradient
     kernel; the shadow of dx is bf16(dx) bit for bit."""
-    B, Hz, Wz, Ci, Co = case
+    B, Hz, Wz, Ci, Co = case[:5]
+    k = case[5] if len(case) > 5 else 3
     H, W = 2 * Hz, 2 * Wz
     lib, dev = backend.lib, backend.device
     dz = _rand((B, Hz, Wz, Co), 811, dev)
-    w = _rand((3, 3, Ci, Co), 812, dev, 0.2)
+    w = _rand((k, k, Ci, Co), 812, dev, 0.2)
     x = _rand((B, H, W, Ci), 813, dev)
     keep = []
     wq = w.cpu().to(torch.bfloat16).double()
