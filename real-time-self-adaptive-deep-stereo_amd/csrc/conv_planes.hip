@@ -39,6 +39,16 @@ extern "C" int mh_planes_kc16(int32_t K) {
     return (k16 <= MH_PLANES_WHOLE_MAX || k16 == 13) ? 0 : MH_PLANES_KC16;
 }
 
+// walk step t = (tap t / K16, 16-channel step t % K16) -> its fragment's index in the bank: the bank is tap-major for whole-K layouts and chunk-major
+// ([chunk of MH_PLANES_KC16 steps][tap][step in chunk], the reduction padded to whole chunks) beyond 128 channels (mh_planes_kc16) -- the stride-2 kernels walk
+// tap-major either way (their patch holds the whole reduction) and pick the fragments where they lie.  Compile-time: the walks are fully unrolled.
+template <int K16, int TAPS>
+__host__ __device__ constexpr int planes_bank_step(int t) {
+    constexpr bool chunked = !(K16 <= MH_PLANES_WHOLE_MAX || K16 == 13);
+    const int tap = t / K16, s = t % K16;
+    return chunked ? ((s / MH_PLANES_KC16) * TAPS + tap) * MH_PLANES_KC16 + (s % MH_PLANES_KC16) : t;
+}
+
 namespace {
 
 struct PlanesArgs {
@@ -486,7 +496,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_planes_s2bwd_kernel(PlanesA
     const int voff_b = nt < nt32 ? nt * 1024 + lane * 16 : MH_OOB;
     const int step_b = nt32 * 1024;
     u32x4 fb[NSTB];
-    auto issue_b = [&](int t, int slot) { if (t < T) fb[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff_b, t * step_b, 0); };
+    auto issue_b = [&](int t, int slot) { if (t < T) fb[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff_b, planes_bank_step<K16, KH * KH>(t) * step_b, 0); };
 #pragma unroll
     for (int t = 0; t < PF; ++t) issue_b(t, t % NSTB);
     {
@@ -582,8 +592,9 @@ __global__ __launch_bounds__(WN * 64) void conv_planes_s2fwd_kernel(PlanesArgs p
     u32x4 fb[NSTB][PL];
     auto issue_b = [&](int t, int slot) {
         if (t < T) {
-            fb[slot][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff_b, t * step_b, 0);
-            if constexpr (PL == 2) fb[slot][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff_b, t * step_b + 1024, 0);
+            const int bt = planes_bank_step<K16, KH * KH>(t);
+            fb[slot][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff_b, bt * step_b, 0);
+            if constexpr (PL == 2) fb[slot][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff_b, bt * step_b + 1024, 0);
         }
     };
 #pragma unroll
@@ -815,13 +826,14 @@ struct PlanesS2Inst { int kh, k16, wn, pl, mbw; int (*launch)(PlanesArgs&, hipSt
 #define S2_INST(KH, WN, MBW, K16, PL) {KH, K16, WN, PL, MBW, &launch_planes_s2fwd<KH, WN, MBW, K16, PL>}
 const PlanesS2Inst g_planes_s2_inst[] = {
     S2_INST(5, 4, 2, 4, 2), S2_INST(5, 4, 2, 4, 1),                                   // 5x5 64 -> 128: two output rows per tile is what the LDS holds (137 KB of patch planes)
+    S2_INST(5, 4, 1, 10, 1),                                                           // 5x5 145 -> 256 (DispNet conv3, plain bf16): one output row per tile (115 KB of patch), 128-column tiles
     S2_INST(3, 1, 4, 1, 2), S2_INST(3, 1, 2, 1, 2), S2_INST(3, 2, 4, 2, 2), S2_INST(3, 2, 2, 2, 2), S2_INST(3, 2, 1, 2, 2), S2_INST(3, 3, 2, 4, 2), S2_INST(3, 3, 1, 4, 2),
 };
 // the instance of a layer: the TALLEST tile (most output rows per wave = fewest weight-fragment loads per MFMA) that still gives every CU a workgroup, else the shortest
 const PlanesS2Inst* planes_s2_find(int kh, int k16, int n32, int pl, int64_t rows_x_coltiles = -1) {
     const PlanesS2Inst* best = nullptr;
     for (const PlanesS2Inst& I : g_planes_s2_inst) {
-        if (!(I.kh == kh && I.k16 == k16 && I.wn == n32 && I.pl == pl)) continue;
+        if (!(I.kh == kh && I.k16 == k16 && (I.wn == n32 || (n32 > 4 && I.wn == 4)) && I.pl == pl)) continue;       // more than 128 columns: 128-column tiles
         if (!best) { best = &I; continue; }
         if (rows_x_coltiles < 0) continue;
         const bool fills_b = rows_x_coltiles / best->mbw >= 192, fills_i = rows_x_coltiles / I.mbw >= 192;      // (three quarters of the CUs: 240 two-row tiles beat 480 one-row tiles)
@@ -970,7 +982,7 @@ static bool planes_s2bwd_ok(const mh_conv_desc* d) {
     if (!(d->stride == 2 && d->dil == 1 && d->Hi == 2 * d->Ho && d->Wi == 2 * d->Wo && !d->accumulate && (d->in_ld == 0 || d->in_ld >= ((d->K + 7) & ~7)))) return false;
     if (d->kh == 3 && d->kw == 3 && d->pad_t == 0 && d->pad_l == 0) return (d->N == 32 || d->N == 64) && d->K >= 1 && d->K <= 32;
     // 5x5 (DispNet conv2: 64 -> 128): reduction over 128 output channels (K16 8), 33 .. 64 gradient columns (two 32-column waves)
-    if (d->kh == 5 && d->kw == 5 && d->pad_t == 1 && d->pad_l == 1) return d->N == 128 && d->K > 32 && d->K <= 64;
+    if (d->kh == 5 && d->kw == 5 && d->pad_t == 1 && d->pad_l == 1) return (d->N == 128 && d->K > 32 && d->K <= 64) || (d->N == 256 && d->K > 32 && d->K <= 2048);      // conv2 ; conv3 (145 columns in 64-column tiles)
     return false;
 }
 
@@ -1019,6 +1031,7 @@ extern "C" int mh_conv2d_planes_bwd(const mh_conv_desc* d, const void* dz_hi, in
         a.in_bytes = (unsigned)((int64_t)d->B * d->Ho * d->Wo * dz_pld * 2);
         a.dil = 1;
         const bool few = (int64_t)d->B * mh_cdiv(d->Ho, 4) * mh_cdiv(d->Wo, 32) < 256;       // fewer than a workgroup per CU: two-row tiles
+        if (d->kh == 5 && d->N == 256) return launch_planes_s2bwd<2, 2, 16, 5>(a, (hipStream_t)stream);        // DispNet conv3: reduction over 256 channels, two dz rows per tile (72 KB patch)
         if (d->kh == 5) return few ? launch_planes_s2bwd<2, 2, 8, 5>(a, (hipStream_t)stream) : launch_planes_s2bwd<4, 2, 8, 5>(a, (hipStream_t)stream);
         if (d->N == 32) return few ? launch_planes_s2bwd<2, 1, 2>(a, (hipStream_t)stream) : launch_planes_s2bwd<4, 1, 2>(a, (hipStream_t)stream);
         return few ? launch_planes_s2bwd<2, 1, 4>(a, (hipStream_t)stream) : launch_planes_s2bwd<4, 1, 4>(a, (hipStream_t)stream);

@@ -353,7 +353,7 @@ class DispNetEngine(object):
                     continue
                 ov = out.view()
                 okey = (ov.ptr, ov.B, ov.H, ov.W, ov.C)
-                if okey in plane_consumers and ov.ld == ov.C and ov.C % 8 == 0:
+                if okey in plane_consumers and ov.C % 8 == 0:        # (the fp32 result may be a slice of a concat buffer -- conv1a is a skip connection --: the planes are the view's own)
                     _, osh = self._shadow_of(ov)
                     if okey not in self.lo_planes:
                         self.lo_planes[okey] = ops.Shadow(ov.B, ov.H, ov.W, ov.C, self.dev)
