@@ -61,6 +61,7 @@ struct PlanesArgs {
     int nchunks;                                                   // K-chunked instances: chunks of K16 * 16 reduction channels (1 for the whole-K instances)
     int Hin, Win;                                                  // stride-2 kernels: size of the INPUT of the walk (dz of the input gradient; x of the stride-2 forward); H, W = size of the result
     int pad_t, pad_l;                                              // stride-2 forward: TF 'SAME' padding in front ((k - 2) / 2 on even sizes)
+    int acc_out;                                                   // 1: the fp32 result is ADDED to what `out` holds before the mask (an input gradient that is not the first contribution: (old + new) * mask)
     float* out; unsigned short* out_hi; unsigned short* out_lo;   // any of them may be null
     unsigned in_bytes, wb_bytes, out_bytes, outp_bytes;
     int in_pld, out_ld, out_pld;
@@ -169,6 +170,13 @@ __device__ __forceinline__ void planes_epilogue(const PlanesArgs& p, float* smem
         for (int e = 0; e < 8; ++e) {
             v[e] += bv[e];
             if (p.alpha != 1.0f) v[e] = v[e] > 0.f ? v[e] : p.alpha * v[e];
+        }
+        if (p.acc_out) {        // (uniform) earlier contributions to this gradient map: read where the result goes
+            const int ofa = ok ? (pix * p.out_ld + n) * 4 : MH_OOB;
+            const f32x4 o0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_o, ofa, 0, 0));
+            const f32x4 o1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_o, ofa == MH_OOB ? MH_OOB : ofa + 16, 0, 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += o0[e]; v[4 + e] += o1[e]; }
         }
         if (p.mask_hi) {        // 8 bf16 of the activation's hi plane: bf16 keeps sign and zero, the test is that of the fp32 tensor
             u32x4 mq;
@@ -826,7 +834,8 @@ struct PlanesS2Inst { int kh, k16, wn, pl, mbw; int (*launch)(PlanesArgs&, hipSt
 #define S2_INST(KH, WN, MBW, K16, PL) {KH, K16, WN, PL, MBW, &launch_planes_s2fwd<KH, WN, MBW, K16, PL>}
 const PlanesS2Inst g_planes_s2_inst[] = {
     S2_INST(5, 4, 2, 4, 2), S2_INST(5, 4, 2, 4, 1),                                   // 5x5 64 -> 128: two output rows per tile is what the LDS holds (137 KB of patch planes)
-    S2_INST(5, 4, 1, 10, 1),                                                           // 5x5 145 -> 256 (DispNet conv3, plain bf16): one output row per tile (115 KB of patch), 128-column tiles
+    // (measured and removed, round 6: a 5x5 145 -> 256 instance for DispNet conv3 -- the whole-K patch leaves room for ONE output row per tile, so every MFMA needs a
+    //  fresh 1 KB weight fragment: 299 us against 73 us on the tiled kernel.  That layer needs the K-chunked walk, not this one.)
     S2_INST(3, 1, 4, 1, 2), S2_INST(3, 1, 2, 1, 2), S2_INST(3, 2, 4, 2, 2), S2_INST(3, 2, 2, 2, 2), S2_INST(3, 2, 1, 2, 2), S2_INST(3, 3, 2, 4, 2), S2_INST(3, 3, 1, 4, 2),
 };
 // the instance of a layer: the TALLEST tile (most output rows per wave = fewest weight-fragment loads per MFMA) that still gives every CU a workgroup, else the shortest
@@ -979,7 +988,8 @@ static bool planes_has_instance(int k16, int n32, int pl) {
 // ---- input gradient of a stride-1 'SAME' 3x3 layer from bf16 shadows: dx = conv2d_backprop_input(dz, w) [* leaky'(mask)] ----------------------------
 // stride-2 layers (forward 3x3, 'SAME' on even sizes: no padding in front): Cout in {32, 64} (K16 2 / 4), Cin <= 32
 static bool planes_s2bwd_ok(const mh_conv_desc* d) {
-    if (!(d->stride == 2 && d->dil == 1 && d->Hi == 2 * d->Ho && d->Wi == 2 * d->Wo && !d->accumulate && (d->in_ld == 0 || d->in_ld >= ((d->K + 7) & ~7)))) return false;
+    if (!(d->stride == 2 && d->dil == 1 && d->Hi == 2 * d->Ho && d->Wi == 2 * d->Wo && (d->in_ld == 0 || d->in_ld >= ((d->K + 7) & ~7)))) return false;
+    if (d->accumulate && d->kh != 5) return false;                   // accumulation onto earlier contributions: the 5x5 instances (DispNet's skip connection conv1a)
     if (d->kh == 3 && d->kw == 3 && d->pad_t == 0 && d->pad_l == 0) return (d->N == 32 || d->N == 64) && d->K >= 1 && d->K <= 32;
     // 5x5 (DispNet conv2: 64 -> 128): reduction over 128 output channels (K16 8), 33 .. 64 gradient columns (two 32-column waves)
     if (d->kh == 5 && d->kw == 5 && d->pad_t == 1 && d->pad_l == 1) return (d->N == 128 && d->K > 32 && d->K <= 64) || (d->N == 256 && d->K > 32 && d->K <= 2048);      // conv2 ; conv3 (145 columns in 64-column tiles)
@@ -1009,7 +1019,8 @@ extern "C" int mh_conv2d_planes_bwd(const mh_conv_desc* d, const void* dz_hi, in
     // the epilogue stores 8 columns per lane: rows must hold Cin rounded up to 8 (the concat buffers of DispNet are allocated that way)
     if (dx) MH_REQUIRE(d->in_ld >= k8 && (d->in_ld & 3) == 0 && mh_aligned16(dx), MH_ERR_ALIGN, "mh_conv2d_planes_bwd: dx rows (d->in_ld floats >= Cin rounded up to 8) must be 16-byte aligned");
     if (dx_hi) MH_REQUIRE(dx_pld >= k8 && (dx_pld & 7) == 0, MH_ERR_ARG, "mh_conv2d_planes_bwd: dx_pld must cover Cin rounded up to 8 (multiple of 8)");
-    MH_REQUIRE(!d->accumulate, MH_ERR_UNSUPPORTED, "mh_conv2d_planes_bwd: no accumulation");
+    MH_REQUIRE(!d->accumulate || (d->stride == 2 && d->kh == 5 && dx), MH_ERR_UNSUPPORTED, "mh_conv2d_planes_bwd: accumulation only in the stride-2 5x5 form, onto the fp32 map");
+    MH_REQUIRE(!d->accumulate || !dx_hi, MH_ERR_UNSUPPORTED, "mh_conv2d_planes_bwd: an accumulating launch cannot leave the shadow of the TOTAL (it is not the last contribution's job here)");
     const int64_t npix = (int64_t)d->B * d->Hi * d->Wi;
     MH_REQUIRE(npix * dz_pld * 2 < (1ll << 31) && npix * d->in_ld * 4 < (1ll << 31) && npix * (int64_t)dx_pld * 2 < (1ll << 31) && npix * (int64_t)mask_pld * 2 < (1ll << 31),
                MH_ERR_UNSUPPORTED, "mh_conv2d_planes_bwd: tensors must be < 2 GiB");
@@ -1027,6 +1038,7 @@ extern "C" int mh_conv2d_planes_bwd(const mh_conv_desc* d, const void* dz_hi, in
     a.B = d->B; a.H = d->Hi; a.W = d->Wi; a.K = d->N; a.N = d->K; a.dil = d->dil;      // the walk reduces over Cout and produces Cin columns
     a.alpha = 1.0f;
     a.Hin = d->Ho; a.Win = d->Wo;
+    a.acc_out = d->accumulate ? 1 : 0;
     if (d->stride == 2) {
         a.in_bytes = (unsigned)((int64_t)d->B * d->Ho * d->Wo * dz_pld * 2);
         a.dil = 1;

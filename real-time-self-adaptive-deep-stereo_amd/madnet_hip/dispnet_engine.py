@@ -510,7 +510,7 @@ class DispNetEngine(object):
                     w = self.W_(wn)
 
                     def emit_dgrad(dx, acc, ref, ma, rng, op=op, dz=dz, w=w, wn=wn, stride=stride):
-                        if not acc and wn in self.banks_b and self._planes_bwd_ok(op):
+                        if (not acc or stride == 2) and wn in self.banks_b and self._planes_bwd_ok(op):          # (the stride-2 5x5 form accumulates: conv1a is a skip connection)
                             # dz (and the activation whose sign is the mask) as bf16 planes -- the casts the streamed filter gradient of this very
                             # layer would queue on its side lane anyway -- then the one-plane walk over dz (mh_conv2d_planes_bwd)
                             kz, dzs = self._shadow_of(dz)
@@ -523,7 +523,7 @@ class DispNetEngine(object):
                                 self._fresh.add(km)
                             self._fresh.add(kz)
                             ops.shadow_cast(lib, casts, self.dev, r.keep)
-                            ops.conv2d_planes_bwd(lib, dzs, w, self.banks_b[wn], dx=dx, mask_shadow=ms, mask_alpha=ma, mask_range=rng, stride=stride)
+                            ops.conv2d_planes_bwd(lib, dzs, w, self.banks_b[wn], dx=dx, mask_shadow=ms, mask_alpha=ma, mask_range=rng, stride=stride, accumulate=acc)
                             return
                         ops.conv2d_dgrad(lib, dz, w, dx, stride=stride, accumulate=acc, mask_ref=ref, mask_alpha=ma, mask_range=rng)
                     conv_like_dgrad(emit_dgrad, x)

@@ -416,7 +416,7 @@ def conv2d_planes_bwd_ok(qlib, dx, w, dil=1, stride=1):
     return qlib.conv2d_planes_bwd_ok(C.byref(d)) == 1
 
 
-def conv2d_planes_bwd(lib, dz_shadow, w, wb32t, dx=None, dx_shadow=None, mask_shadow=None, mask_alpha=1.0, dil=1, stream=None, mask_range=(0, 0), stride=1):
+def conv2d_planes_bwd(lib, dz_shadow, w, wb32t, dx=None, dx_shadow=None, mask_shadow=None, mask_alpha=1.0, dil=1, stream=None, mask_range=(0, 0), stride=1, accumulate=False):
     """dx = conv2d_backprop_input(dz, w) * leaky'(mask) from the bf16 shadow of dz (mh_conv2d_planes_bwd): w HWIO [3,3,Cin,Cout] of the forward layer,
     wb32t = pack_weights(trans = 3) bank; results: dx (fp32 View or None) and / or dx_shadow (Shadow); mask_shadow: Shadow of the layer's input."""
     kh, kw, cin, cout = w.shape
@@ -425,7 +425,7 @@ def conv2d_planes_bwd(lib, dz_shadow, w, wb32t, dx=None, dx_shadow=None, mask_sh
     assert stride in (1, 2) and (stride == 1 or dil == 1)
     pad = dil if stride == 1 else (kh - 2) // 2
     d = conv_desc(B, H, W, dz_shadow.H, dz_shadow.W, cin, cout, kh, kw, stride, dil, pad, pad, 0, 0, (dx.ld if dx is not None else 0), 0, mask_alpha=mask_alpha,
-                  precision=1, mask_c0=mask_range[0], mask_c1=mask_range[1])
+                  precision=1, mask_c0=mask_range[0], mask_c1=mask_range[1], accumulate=int(bool(accumulate)))     # accumulate: (old + new) * mask -- the stride-2 5x5 form only
     for t in (dx, dx_shadow, mask_shadow):
         assert t is None or (t.B, t.H, t.W, t.C) == (B, H, W, cin)
     sp = lambda sh: C.c_void_p(sh.ptr) if sh is not None else None
