@@ -989,7 +989,7 @@ static bool planes_has_instance(int k16, int n32, int pl) {
 // stride-2 layers (forward 3x3, 'SAME' on even sizes: no padding in front): Cout in {32, 64} (K16 2 / 4), Cin <= 32
 static bool planes_s2bwd_ok(const mh_conv_desc* d) {
     if (!(d->stride == 2 && d->dil == 1 && d->Hi == 2 * d->Ho && d->Wi == 2 * d->Wo && (d->in_ld == 0 || d->in_ld >= ((d->K + 7) & ~7)))) return false;
-    if (d->accumulate && d->kh != 5) return false;                   // accumulation onto earlier contributions: the 5x5 instances (DispNet's skip connection conv1a)
+    // (accumulation onto earlier contributions -- DispNet's skip connection conv1a, MADNet's conv5 whose input is a cost-volume level -- is served by every stride-2 instance)
     if (d->kh == 3 && d->kw == 3 && d->pad_t == 0 && d->pad_l == 0) return (d->N == 32 || d->N == 64) && d->K >= 1 && d->K <= 32;
     // 5x5 (DispNet conv2: 64 -> 128): reduction over 128 output channels (K16 8), 33 .. 64 gradient columns (two 32-column waves)
     if (d->kh == 5 && d->kw == 5 && d->pad_t == 1 && d->pad_l == 1) return (d->N == 128 && d->K > 32 && d->K <= 64) || (d->N == 256 && d->K > 32 && d->K <= 2048);      // conv2 ; conv3 (145 columns in 64-column tiles)
@@ -1019,8 +1019,8 @@ extern "C" int mh_conv2d_planes_bwd(const mh_conv_desc* d, const void* dz_hi, in
     // the epilogue stores 8 columns per lane: rows must hold Cin rounded up to 8 (the concat buffers of DispNet are allocated that way)
     if (dx) MH_REQUIRE(d->in_ld >= k8 && (d->in_ld & 3) == 0 && mh_aligned16(dx), MH_ERR_ALIGN, "mh_conv2d_planes_bwd: dx rows (d->in_ld floats >= Cin rounded up to 8) must be 16-byte aligned");
     if (dx_hi) MH_REQUIRE(dx_pld >= k8 && (dx_pld & 7) == 0, MH_ERR_ARG, "mh_conv2d_planes_bwd: dx_pld must cover Cin rounded up to 8 (multiple of 8)");
-    MH_REQUIRE(!d->accumulate || (d->stride == 2 && d->kh == 5 && dx), MH_ERR_UNSUPPORTED, "mh_conv2d_planes_bwd: accumulation only in the stride-2 5x5 form, onto the fp32 map");
-    MH_REQUIRE(!d->accumulate || !dx_hi, MH_ERR_UNSUPPORTED, "mh_conv2d_planes_bwd: an accumulating launch cannot leave the shadow of the TOTAL (it is not the last contribution's job here)");
+    // accumulate: dx = (what dx holds + this gradient) * mask -- the LAST contribution's form (the mask and the shadow are those of the total)
+    MH_REQUIRE(!d->accumulate || (d->stride == 2 && dx), MH_ERR_UNSUPPORTED, "mh_conv2d_planes_bwd: accumulation only in the stride-2 forms, onto the fp32 map");
     const int64_t npix = (int64_t)d->B * d->Hi * d->Wi;
     MH_REQUIRE(npix * dz_pld * 2 < (1ll << 31) && npix * d->in_ld * 4 < (1ll << 31) && npix * (int64_t)dx_pld * 2 < (1ll << 31) && npix * (int64_t)mask_pld * 2 < (1ll << 31),
                MH_ERR_UNSUPPORTED, "mh_conv2d_planes_bwd: tensors must be < 2 GiB");

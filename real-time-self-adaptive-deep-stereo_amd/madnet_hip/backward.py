@@ -368,12 +368,13 @@ class BackwardRecorder(object):
                 if need_dx:
                     # dF[i-1] is complete after this launch (the cost-volume contributions were written earlier): it is the dz of layer i - 1
                     sh = self._out_shadow(self._fv(self.dF[i - 1]), pyr_name(i - 1)) if (i - 1 > 1) else None       # (conv1's 3-channel input keeps the tiled kernel)
-                    wbt = self.banks32t.get(pyr_name(i)) if not accumulate else None       # (stride-2 layers: only those _bank_plan gave a bank)
+                    s2acc = accumulate and PYR[i - 1][2] == 2 and self.sched.PLANES_S2_ACC      # (the stride-2 parity-class kernel adds onto earlier contributions)
+                    wbt = self.banks32t.get(pyr_name(i)) if (not accumulate or s2acc) else None       # (stride-2 layers: only those _bank_plan gave a bank)
                     dzs = self._fresh_shadow(self._fv(self.dF[i])) if wbt is not None else None
                     mks = self._fresh_shadow(self._fv(self.F[i - 1])) if wbt is not None else None
                     if wbt is not None and dzs is not None and mks is not None and sh is not None:
                         ops.conv2d_planes_bwd(lib, dzs, self.W_(pyr_name(i)), wbt, dx=self._fv(self.dF[i - 1]), dx_shadow=sh, mask_shadow=mks, mask_alpha=ALPHA,
-                                              stride=PYR[i - 1][2])
+                                              stride=PYR[i - 1][2], accumulate=accumulate)
                         if i in self.sched.PYR_FLUSH_AFTER:
                             flush(lane=(tail_lane if i == 1 else None))
                         continue

@@ -190,7 +190,7 @@ class DispNetEngine(object):
         N = self._node
         c1a = N("conv1a", cat["up1"], 0, 64, ALPHA); c1b = N("conv1b", self._st(h2, w2, 64), 0, 64, ALPHA)
         c2a = N("conv2a", cat["up2"], 0, 128, ALPHA); c2b = N("conv2b", self._st(h4, w4, 128), 0, 128, ALPHA)
-        x3 = self._st(h4, w4, _r4(2 * MAX_DISP + 1 + 64))
+        x3 = self._st(h4, w4, _r8(2 * MAX_DISP + 1 + 64))            # (rows of 8 k floats: conv3's input gradient runs the parity-class plane kernel, 8 columns per lane -- round 6)
         corr = N("corr", x3, 0, 2 * MAX_DISP + 1); redir = N("conv_redir", x3, 2 * MAX_DISP + 1, 64, ALPHA)
         x3n = N("corr|redir", x3, 0, 2 * MAX_DISP + 1 + 64, members=[corr, redir])
         c3 = N("conv3", self._st(h8, w8, 256), 0, 256, ALPHA); c31 = N("conv3/1", cat["up3"], 0, 256, ALPHA)

@@ -326,7 +326,8 @@ class MadNetEngine(ElisionPasses, BackwardRecorder):
         if bcode == 1 and self.use_planes and self.sched.PLANES_DGRAD:
             for i in range(3, 13):
                 h, w = self.fshape[i][0], self.fshape[i][1]
-                if PYR[i - 1][2] == 2 and 2 * B * h * w > self.bank_small_maxpix and (i - 1) not in FEAT.values():
+                # (round 6: the parity-class kernel accumulates, so a layer whose input is a cost-volume level -- conv5: F4 already holds the correlation's gradient -- qualifies)
+                if PYR[i - 1][2] == 2 and 2 * B * h * w > self.bank_small_maxpix and ((i - 1) not in FEAT.values() or self.sched.PLANES_S2_ACC):
                     _, _, K, N = shapes[pyr_name(i) + "/weights"]
                     dxv = self._fv(self.dF[i - 1])
                     if ops.conv2d_planes_bwd_ok(self.lib, dxv, self.W_(pyr_name(i)), 1, stride=2):

@@ -26,6 +26,7 @@ class Schedule(object):
     # (round 6) pyramid layers (1-based) whose STRIDE-2 forward pass runs the stride-2 plane kernel (conv_planes_s2fwd_kernel: split-bf16 from the producer's
     # planes) instead of the exact-fp32 tiled kernel.  conv5 reads conv4's planes (a plane kernel wrote them); conv3 would need conv2's lo plane (one more launch)
     PLANES_S2_FWD: tuple = (5,)
+    PLANES_S2_ACC: bool = True      # stride-2 input gradients whose target already holds a contribution (conv5 -> the level-2 features) on the accumulating parity-class kernel
     # (round 6) the fused back end of a level (mh_corr_warp_bwd) is the FIRST writer of its level's feature gradient: no zero fill of the 13.9 MB of level
     # feature gradients at the head of the backward pass, no read of the halves it writes (the row-owned kernel gathers -- it never needed zeros to add to)
     FIRST_WRITER: bool = True

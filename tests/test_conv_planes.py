@@ -356,8 +356,8 @@ def test_conv2d_planes_bwd_stride2(backend, case):
         ops.conv2d_dgrad(lib, ops.view(dz), w, ops.view(dx0), stride=2, mask_ref=ops.view(x), mask_alpha=0.2)
     backend.sync()
     assert (dxc - dx0.cpu()).abs().max().item() <= 2e-5 * scale
-    if k == 5:
-        # accumulating form (round 6: DispNet's conv1a is a skip connection -- its gradient already holds the up-block's contribution): (old + new) * mask
+    if True:
+        # accumulating form (round 6: DispNet's conv1a is a skip connection, MADNet's conv5 reads a cost-volume level -- the gradient map already holds a contribution): (old + new) * mask
         old = _rand((B, H, W, Ci), 814, dev)
         dxb2 = torch.zeros(B, H, W, ld, device=dev); dxb2[..., :Ci] = old
         ops.conv2d_planes_bwd(lib, dzs, w, bank, dx=ops.View(dxb2, B, H, W, Ci, ld), mask_shadow=xs, mask_alpha=0.2, stride=2, accumulate=True)
