@@ -834,8 +834,9 @@ struct PlanesS2Inst { int kh, k16, wn, pl, mbw; int (*launch)(PlanesArgs&, hipSt
 #define S2_INST(KH, WN, MBW, K16, PL) {KH, K16, WN, PL, MBW, &launch_planes_s2fwd<KH, WN, MBW, K16, PL>}
 const PlanesS2Inst g_planes_s2_inst[] = {
     S2_INST(5, 4, 2, 4, 2), S2_INST(5, 4, 2, 4, 1),                                   // 5x5 64 -> 128: two output rows per tile is what the LDS holds (137 KB of patch planes)
-    // (measured and removed, round 6: a 5x5 145 -> 256 instance for DispNet conv3 -- the whole-K patch leaves room for ONE output row per tile, so every MFMA needs a
-    //  fresh 1 KB weight fragment: 299 us against 73 us on the tiled kernel.  That layer needs the K-chunked walk, not this one.)
+    S2_INST(5, 4, 2, 10, 1),                                                           // 5x5 145 -> 256 (DispNet conv3, plain bf16), TWO output rows per tile: 157 KB of patch (DispNetSchedule.PLANES_S2_CONV3)
+    // (round 6, r6j: a ONE-row instance of that layer measured 299 us against 73 us on the tiled kernel -- its 250-step walk was past hipcc's pragma-unroll budget and ran
+    //  from dynamically indexed registers, see the Makefile; the two-row instance below, built with the larger budget, replaced it)
     S2_INST(3, 1, 4, 1, 2), S2_INST(3, 1, 2, 1, 2), S2_INST(3, 2, 4, 2, 2), S2_INST(3, 2, 2, 2, 2), S2_INST(3, 2, 1, 2, 2), S2_INST(3, 3, 2, 4, 2), S2_INST(3, 3, 1, 4, 2),
 };
 // the instance of a layer: the TALLEST tile (most output rows per wave = fewest weight-fragment loads per MFMA) that still gives every CU a workgroup, else the shortest

@@ -253,7 +253,7 @@ class DispNetEngine(object):
         _, x, wn, out, stride, alpha, _ = op
         w = self.W_(wn)
         # stride 1: the 3x3 layers; stride 2 (round 6, Schedule.PLANES_S2): the 5x5 conv2 of both towers (Nets/DispNet.py:80-84 -- 25 GFLOP that ran in exact fp32)
-        shape_ok = (stride == 1 and tuple(w.shape[:2]) == (3, 3)) or (stride == 2 and self.sched.PLANES_S2 and w.shape[0] == w.shape[1])
+        shape_ok = (stride == 1 and tuple(w.shape[:2]) == (3, 3)) or (stride == 2 and self.sched.PLANES_S2 and w.shape[0] == w.shape[1] and (w.shape[2] <= 128 or self.sched.PLANES_S2_CONV3))
         if not self.use_planes or not shape_ok or x.st.H * x.st.W < self.sched.PLANES_MIN_PIX or x.c0 != 0 or w.shape[3] % 8:
             return 0
         code = self._fwd_code(wn)

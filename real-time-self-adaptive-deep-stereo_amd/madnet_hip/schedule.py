@@ -26,7 +26,9 @@ class Schedule(object):
     # (round 6) pyramid layers (1-based) whose STRIDE-2 forward pass runs the stride-2 plane kernel (conv_planes_s2fwd_kernel: split-bf16 from the producer's
     # planes) instead of the exact-fp32 tiled kernel.  conv5 reads conv4's planes (a plane kernel wrote them); conv3 would need conv2's lo plane (one more launch)
     PLANES_S2_FWD: tuple = (5,)
-    PLANES_S2_ACC: bool = True      # stride-2 input gradients whose target already holds a contribution (conv5 -> the level-2 features) on the accumulating parity-class kernel
+    # stride-2 input gradients whose target already holds a contribution (conv5 -> the level-2 features) on the accumulating parity-class kernel: measured +6 us per step
+    # (12.4 us against 12.9 us for the launch, 1.3296 / 1.3283 vs 1.3239 / 1.3225 ms for the step: r06_experiments.txt #9) -- off
+    PLANES_S2_ACC: bool = False
     # (round 6) the fused back end of a level (mh_corr_warp_bwd) is the FIRST writer of its level's feature gradient: no zero fill of the 13.9 MB of level
     # feature gradients at the head of the backward pass, no read of the halves it writes (the row-owned kernel gathers -- it never needed zeros to add to)
     FIRST_WRITER: bool = True
@@ -109,6 +111,8 @@ class DispNetSchedule(object):
     # (round 6) the stride-2 5x5 layer conv2 of both towers on the stride-2 plane kernel (conv_planes_s2fwd_kernel: split-bf16 from planes) instead of the exact-fp32
     # tiled kernel
     PLANES_S2: bool = True
+    # conv3's FORWARD pass (5x5, 145 -> 256, plain bf16) on the stride-2 plane kernel too: two-row tiles (157 KB of patch) -- 2.752 / 2.756 against 2.791 / 2.792 ms (r6m)
+    PLANES_S2_CONV3: bool = True
     # FULL momentum steps: every filter-gradient batch is followed, on its own side lane, by the momentum update of the layers it completes; the launch
     # behind the join covers what is left.  DispNet has 42 M parameters: one update over all of them is 840 MB of traffic at the very end of the step.
     EARLY_UPDATE: bool = field(default_factory=_env_flag("MH_EARLY_UPDATE", "1"))

@@ -1000,7 +1000,7 @@ def test_mixed_forward_from_planes_matches_fp32_operand_path(bname, mode):
     assert a["nrec"] == 14 and a["nplanes"] == 14 + a["nbwd"] and b["nrec"] == 0 and b["nplanes"] == 0, (a["nrec"], a["nplanes"], b["nrec"])
     # the input gradients of those layers on the same kernel (one plane): 4 of estimator 2 + 5 of the context network + conv4 / conv6 in the FULL step,
     # most of their fp32 gradient maps never stored
-    assert a["nbwd"] == {"FULL": 13, "MAD4": 10, "NONE": 0}[mode] and b["nbwd"] == 0, a["nbwd"]      # (+ the stride-2 input gradients of conv3 and, accumulating, conv5)
+    assert a["nbwd"] == {"FULL": 12, "MAD4": 10, "NONE": 0}[mode] and b["nbwd"] == 0, a["nbwd"]      # (+ the stride-2 input gradient of conv3; conv5 on the accumulating form is Schedule.PLANES_S2_ACC: measured slower, off)
     assert mode == "NONE" or a["bwd_elided"] >= 5, a["bwd_elided"]
     # one split launch left: the concat-split of the context network's input; the inputs of conv4 / conv6 and the estimator's concat buffer get their
     # planes from their producers' epilogues (engine.FUSE_SPLITS)
