@@ -376,7 +376,7 @@ def bench_mad(args, lib, dev, rank, world, dist):
 def step_surface(args, lib, dev, wn, frames=8):
     """The reference's own FPS definition (Stereo_Online_Adaptation.py:230-234,267-268): wall time of the loop INCLUDING the
     input side and the per-step host round trip.  FULL adaptation through Nets.get_stereo_net + Adapter.step, a fresh frame
-    every step delivered by Data_utils.data_reader.device_prefetcher (pinned ring + copy stream: 2 x 5.6 MB H2D per pair), loss /
+    every step delivered by Data_utils.data_reader.device_prefetcher (pinned ring + copy stream: 2 x 1.4 MB of 8-bit pixels + 1.9 MB of ground truth H2D per pair), loss /
     EPE read back every step (the reset check needs them)."""
     import torch
     import Nets
@@ -402,7 +402,7 @@ def step_surface(args, lib, dev, wn, frames=8):
                                          "warping": True, "context_net": True, "radius_d": 2, "stride": 1})
     ad = Adapter(net, mode="FULL", lr=1e-4, use_graph=not args.no_graph)
     ad._plan("FULL")
-    pf = device_prefetcher(Source(), device=dev.name, depth=3, consumer_stream=ad.stream)
+    pf = device_prefetcher(Source(), device=dev.name, depth=3, consumer_stream=ad.stream, cast=False)
     t0, k, out = None, 0, None
     for left, right, g in pf:
         if k == args.warmup:
@@ -414,7 +414,7 @@ def step_surface(args, lib, dev, wn, frames=8):
     dt = time.perf_counter() - t0
     return {"value": args.steps / dt, "unit": "pairs/s", "ms_per_step": 1e3 * dt / args.steps,
             "what": "Nets.get_stereo_net + Adapter.step(FULL), a NEW 8-bit frame pair every step through device_prefetcher (host->pinned->HBM "
-                    "on a copy stream, uint8->f32 cast on the GPU), loss/EPE read back every step -- the reference's FPS definition (Stereo_Online_Adaptation.py:230-234,267-268)",
+                    "on a copy stream, uint8->f32 cast by Adapter.step's copy into the engine's input buffers), loss/EPE read back every step -- the reference's FPS definition (Stereo_Online_Adaptation.py:230-234,267-268)",
             "frames": frames, "final_loss": out["loss"], "resets": ad.reset_counter}
 
 

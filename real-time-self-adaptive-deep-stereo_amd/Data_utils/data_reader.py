@@ -9,6 +9,7 @@ Every frame is centre-cropped / zero-padded to crop_shape like tf.image.resize_i
 import os
 import re
 
+import time
 import numpy as np
 
 
@@ -212,12 +213,21 @@ class device_prefetcher(object):
 
         for left, right, gt in device_prefetcher(dataset(...), 'cuda', consumer_stream=adapter.stream):
             adapter.step(left, right, gt)
+
+    The hand-over keeps the consumer's thread out of the reader's way (round 6, scripts/exp/prefetch_phases*.py: a reader woken by the consumer between two steps
+    cost the loop 30 us per step in GIL ping-pong, a cross-stream event wait in front of the step's graph 10 more): the consumer never wakes the reader -- it appends
+    the slot it is done with (+ an event on its stream) to a deque the reader POLLS when it runs out of slots -- never synchronises its stream, and waits on a
+    frame's upload event only if the upload is not complete yet.
     """
 
-    def __init__(self, data_set, device='cuda', depth=3, consumer_stream=None, lib=None):
-        """uint8 arrays from the data set are uploaded as uint8 and cast to float32 on the GPU (mh_u8_to_f32 on the copy stream;
-        `lib` = the loaded library, default the product's): the consumer always sees float32 tensors."""
+    POLL = 2e-4            # seconds between two looks of a reader that is out of slots
+
+    def __init__(self, data_set, device='cuda', depth=3, consumer_stream=None, lib=None, cast=True):
+        """uint8 arrays from the data set are uploaded as uint8; cast=True: cast to float32 on the GPU (mh_u8_to_f32 on the copy stream; `lib` = the loaded
+        library, default the product's) so that the consumer always sees float32 tensors; cast=False: yielded as uint8 device tensors (Adapter.step casts
+        while it copies them into the engine's input buffers: one kernel and 5.6 MB of traffic less per image)."""
         self._lib = lib
+        import collections
         import queue
         import threading
         import torch
@@ -225,8 +235,10 @@ class device_prefetcher(object):
         self._ds, self._depth = data_set, max(2, depth)
         self._dev = torch.device(device)
         self._cuda = self._dev.type == 'cuda'
-        self._q = queue.Queue(maxsize=self._depth)
-        self._free = queue.Queue()
+        self._cast = cast
+        self._q = queue.Queue()                  # unbounded: the ring bounds what is in flight, and a put that never blocks is never woken by the consumer
+        self._free = []                          # the reader's own list of free slots
+        self._returned = collections.deque()     # (slot, event on the consumer's stream): appended by the consumer, popped by the reader
         self._ring = None
         self._stop = threading.Event()
         self._thread = threading.Thread(target=self._reader, daemon=True)
@@ -238,17 +250,27 @@ class device_prefetcher(object):
         if self._ring is None:                   # allocate the ring on first use (shapes known now)
             self._ring = []
             u8 = [np.asarray(a).dtype == np.uint8 for a in arrays]
-            if any(u8) and self._lib is None:
+            if any(u8) and self._cast and self._lib is None:
                 from madnet_hip import _ffi
                 self._lib = _ffi.lib()
             for _ in range(self._depth + 1):
                 host = [t.empty(np.shape(a), dtype=(t.uint8 if q else t.float32), pin_memory=self._cuda) for a, q in zip(arrays, u8)]
                 stage = [t.empty(np.shape(a), dtype=t.uint8, device=self._dev) if q else None for a, q in zip(arrays, u8)]
-                devb = [t.empty(np.shape(a), dtype=t.float32, device=self._dev) for a in arrays]
-                self._ring.append((host, devb, t.cuda.Event() if self._cuda else None, stage))
-            for i in range(len(self._ring)):
-                self._free.put(i)
-        return self._free.get()
+                devb = [(s8 if (q and not self._cast) else t.empty(np.shape(a), dtype=t.float32, device=self._dev)) for a, q, s8 in zip(arrays, u8, stage)]
+                self._ring.append((host, devb, t.cuda.Event() if self._cuda else None, stage, t.cuda.Event() if self._cuda else None))
+            self._free = list(range(len(self._ring)))[::-1]
+        while not self._free:
+            try:
+                i, done = self._returned.popleft()
+            except IndexError:
+                if self._stop.is_set():
+                    return None
+                time.sleep(self.POLL)
+                continue
+            if done is not None:
+                done.synchronize()               # what the consumer enqueued on this slot's buffers has run (the GIL is released while waiting)
+            self._free.append(i)
+        return self._free.pop()
 
     def _reader(self):
         t = self._torch
@@ -257,7 +279,9 @@ class device_prefetcher(object):
                 if self._stop.is_set():
                     return
                 i = self._slot(arrays)
-                host, devb, ev, stage = self._ring[i]
+                if i is None:
+                    return
+                host, devb, ev, stage, _ = self._ring[i]
                 for h, a in zip(host, arrays):
                     np.copyto(h.numpy(), np.asarray(a).reshape(tuple(h.shape)), casting='unsafe')     # straight into the pinned slot
                 if self._cuda:
@@ -267,7 +291,8 @@ class device_prefetcher(object):
                                 d.copy_(h, non_blocking=True)
                             else:
                                 s8.copy_(h, non_blocking=True)
-                                self._lib.u8_to_f32(s8.data_ptr(), d.data_ptr(), s8.numel(), self._copy_stream.cuda_stream)
+                                if self._cast:
+                                    self._lib.u8_to_f32(s8.data_ptr(), d.data_ptr(), s8.numel(), self._copy_stream.cuda_stream)
                         ev.record(self._copy_stream)
                 else:
                     for h, d, s8 in zip(host, devb, stage):
@@ -275,7 +300,7 @@ class device_prefetcher(object):
                             d.copy_(h)
                         else:
                             s8.copy_(h)
-                            if self._lib is not None:
+                            if self._cast and self._lib is not None:
                                 self._lib.u8_to_f32(s8.data_ptr(), d.data_ptr(), s8.numel(), None)
                 self._q.put(i)
             self._q.put(None)
@@ -288,15 +313,18 @@ class device_prefetcher(object):
         while True:
             i = self._q.get()
             if prev is not None:
-                if self._cuda:                   # the consumer's work on the previous slot must be done before reuse
-                    (self._consumer or self._torch.cuda.current_stream(self._dev)).synchronize()
-                self._free.put(prev)
+                # the slot handed out last time: whatever the consumer enqueued on its buffers is in its stream by now -- an event behind it frees the slot for the reader
+                done = None
+                if self._cuda:
+                    done = self._ring[prev][4]
+                    done.record(self._consumer or self._torch.cuda.current_stream(self._dev))
+                self._returned.append((prev, done))
             if i is None:
                 return
             if isinstance(i, Exception):
                 raise i
-            host, devb, ev, _ = self._ring[i]
-            if self._cuda:
+            host, devb, ev, _, _ = self._ring[i]
+            if self._cuda and not ev.query():        # (uploads run a step ahead: usually complete -- no cross-stream edge in front of the step then)
                 (self._consumer or self._torch.cuda.current_stream(self._dev)).wait_event(ev)
             prev = i
             yield tuple(devb)

@@ -55,7 +55,7 @@ def main(args):
     with open(os.path.join(args.output, 'histogram.csv'), 'w') as f_out:
         f_out.write('Histogram\n')
     try:
-        frames = data_reader.device_prefetcher(data_set, dev, depth=3, consumer_stream=adapter.stream)
+        frames = data_reader.device_prefetcher(data_set, dev, depth=3, consumer_stream=adapter.stream, cast=False)
         for left, right, gt, proxy, real_width in frames:
             out = adapter.step(left, right, gt[..., 0], proxy=proxy[..., 0])
             d1, epe = d1_and_epe(out['disparity'][0], gt[0, ..., 0])

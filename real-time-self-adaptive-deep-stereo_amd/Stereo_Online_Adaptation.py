@@ -92,7 +92,7 @@ def main(args):
     t_begin = time.time()
     try:
         # decode + upload frame t+1 while frame t adapts (pinned ring + copy stream, Data_utils/data_reader.py)
-        frames = data_reader.device_prefetcher(data_set, dev, depth=3, consumer_stream=adapter.stream)
+        frames = data_reader.device_prefetcher(data_set, dev, depth=3, consumer_stream=adapter.stream, cast=False)
         for left, right, gt in frames:
             out = adapter.step(left, right, gt[..., 0])
             new_loss = out['loss']

@@ -220,6 +220,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_planes_kernel(PlanesArgs p)
     const int wm = wave / WN, wn = wave % WN;
     const int d = p.dil;
 
+    if (p.dbg & 128) mh_setprio<2>();        // experiment (mh_tune_conv_planes bit 15): the main lane's waves ahead of co-resident filter-gradient waves at the issue arbiters
     const int lin = mh_xcd_remap(blockIdx.x, p.nwg);
     int tile_n, ttx, tty, cx, cy, b;
     mh_decode_tile(lin, p.dec, tile_n, ttx, tty, cx, cy, b);
@@ -319,6 +320,226 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_planes_kernel(PlanesArgs p)
     __syncthreads();                                 // every wave is done with the patch: the accumulator tile goes over it
 
     planes_epilogue<G, PL>(p, smem_all, acc, tid, true, wm, wn, lane, n0, y00, x00, b, d, pre);
+}
+
+// ---- staggered variant (round 6): the 128 x 128 tile as TWO wave groups of 64 pixels each, out of phase ------------------------------------------------
+// One tile per CU means staging -> walk -> epilogue of a launch cannot overlap across tiles, and two co-resident 64-pixel workgroups run IN phase (r04 #5).  Here the
+// two halves are wave groups of ONE workgroup (2 x WN waves, two per SIMD) that share the staged patch and part company behind the staging barrier:
+//   * group 0 raises its issue priority (s_setprio) for the walk: it takes the MFMA pipe whenever it has an MFMA ready, group 1 fills the gaps -- group 0 ends its walk
+//     first, and its epilogue (VALU, LDS, stores) runs in the shadow of group 1's remaining MFMAs; what stays exposed is ONE half-tile epilogue;
+//   * no barrier behind the staging: the epilogue transposes per WAVE through a private 32 x 32 LDS block (wave-local: LDS operations of a wave execute in order), one
+//     M-block at a time, and stores the wave's own 32 columns (64-byte runs per pixel in the planes, 128 in the fp32 map); the patch is never overwritten.
+// Cost: each half walks the whole bank, so the weight-fragment stream per MFMA doubles (MBW = 2: ~43 B/clk/CU).
+template <int MC, int WN, int MBW, int K16, int PL>
+struct PlanesStgGeo : PlanesGeo<MC, 2, WN, MBW, K16, PL> {
+    using B = PlanesGeo<MC, 2, WN, MBW, K16, PL>;
+    static constexpr int TW = 40;                                   // floats per pixel row of a wave's transposition block (= 8 mod 16: the half-waves of an accumulator write hit disjoint bank halves)
+    static constexpr int WBUF = 32 * TW * 4;                        // bytes per wave
+    static constexpr int LDS_STG = B::LDS_TILES + B::NW * WBUF;
+};
+
+template <class G, int PL>
+struct PlanesStgPre {
+    f32x4 b0, b1;
+    u32x4 mk[PL == 1 ? 2 * G::MBW_ : 1];
+};
+
+// pixel p (0 .. 31) of M-block `blk` of the tile -> image position
+template <class G>
+__device__ __forceinline__ void planes_stg_pixel(int blk, int w, int y00, int x00, int d, int& y, int& x) {
+    constexpr int MR = G::MR;
+    const int row = MR == 1 ? blk : blk * 2 + (w >> 4), colp = MR == 1 ? w : (w & 15);
+    y = y00 + row * d; x = x00 + colp * d;
+}
+
+template <class G, int PL>
+__device__ __forceinline__ void planes_stg_prefetch(const PlanesArgs& p, int wm, int wn, int lane, int n0, int y00, int x00, int b, int d, PlanesStgPre<G, PL>& pre) {
+    constexpr int MBW = G::MBW_;
+    const int n = n0 + wn * 32 + (lane & 3) * 8;
+    const __amdgpu_buffer_rsrc_t rs_b = mh_make_rsrc(p.bias ? (const void*)p.bias : (const void*)p.in_hi, p.bias ? (unsigned)(p.N * 4) : 0u);
+    pre.b0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, n * 4, 0, 0));
+    pre.b1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, n * 4 + 16, 0, 0));
+    if constexpr (PL == 1) {
+        if (p.mask_hi) {
+            const __amdgpu_buffer_rsrc_t rs_mk = mh_make_rsrc((const void*)p.mask_hi, (unsigned)((int64_t)p.B * p.H * p.W * p.mask_pld * 2));
+#pragma unroll
+            for (int mb = 0; mb < MBW; ++mb)
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    int y, x;
+                    planes_stg_pixel<G>(wm * MBW + mb, ps * 16 + (lane >> 2), y00, x00, d, y, x);
+                    const bool ok = y < p.H && x < p.W && n < p.N;
+                    pre.mk[mb * 2 + ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_mk, ok ? (((b * p.H + y) * p.W + x) * p.mask_pld + n) * 2 : MH_OOB, 0, 0);
+                }
+        }
+    }
+}
+
+// a wave's own epilogue: per M-block, accumulators -> the wave's LDS block [pixel][column] -> 8 consecutive columns of 16 pixels per pass: bias, leaky, mask, split, 16-byte stores
+template <class G, int PL>
+__device__ __forceinline__ void planes_stg_epilogue(const PlanesArgs& p, float* wb, const f32x16 (&acc)[G::MBW_], int wm, int wn, int lane, int n0, int y00, int x00, int b, int d,
+                                                    const PlanesStgPre<G, PL>& pre) {
+    constexpr int MBW = G::MBW_, TW = G::TW;
+    if (p.dbg & 16) return;
+    const int c8 = lane & 3;
+    const int n = n0 + wn * 32 + c8 * 8;
+    const float bv[8] = {pre.b0[0], pre.b0[1], pre.b0[2], pre.b0[3], pre.b1[0], pre.b1[1], pre.b1[2], pre.b1[3]};
+    const __amdgpu_buffer_rsrc_t rs_o = mh_make_rsrc(p.out ? p.out : (float*)p.out_hi, p.out ? p.out_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_oh = mh_make_rsrc(p.out_hi ? p.out_hi : (unsigned short*)p.out, p.out_hi ? p.outp_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_ol = mh_make_rsrc(p.out_lo ? p.out_lo : (unsigned short*)p.out, p.out_lo ? p.outp_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_mk = mh_make_rsrc(p.mask_hi ? (const void*)p.mask_hi : (const void*)p.in_hi, p.mask_hi ? (unsigned)((int64_t)p.B * p.H * p.W * p.mask_pld * 2) : 0u);
+#pragma unroll
+    for (int mb = 0; mb < MBW; ++mb) {
+        mh_wave_sync();                            // the previous block's reads are behind us
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wb[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * TW + (lane & 31)] = acc[mb][r];
+        mh_wave_sync();
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int w = ps * 16 + (lane >> 2);
+            int y, x;
+            planes_stg_pixel<G>(wm * MBW + mb, w, y00, x00, d, y, x);
+            const bool ok = y < p.H && x < p.W && n < p.N;
+            const int pix = (b * p.H + y) * p.W + x;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(&wb[w * TW + c8 * 8]), v1 = *reinterpret_cast<const f32x4*>(&wb[w * TW + c8 * 8 + 4]);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] += bv[e];
+                if (p.alpha != 1.0f) v[e] = v[e] > 0.f ? v[e] : p.alpha * v[e];
+            }
+            if (p.acc_out) {
+                const int ofa = ok ? (pix * p.out_ld + n) * 4 : MH_OOB;
+                const f32x4 o0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_o, ofa, 0, 0));
+                const f32x4 o1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_o, ofa == MH_OOB ? MH_OOB : ofa + 16, 0, 0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += o0[e]; v[4 + e] += o1[e]; }
+            }
+            if (p.mask_hi) {
+                u32x4 mq;
+                if constexpr (PL == 1) mq = pre.mk[mb * 2 + ps];
+                else mq = __builtin_amdgcn_raw_buffer_load_b128(rs_mk, ok ? (pix * p.mask_pld + n) * 2 : MH_OOB, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float mk = __builtin_bit_cast(float, (e & 1) ? (mq[e >> 1] & 0xffff0000u) : (mq[e >> 1] << 16));
+                    v[e] *= (mk > 0.f || n + e < p.mask_c0 || n + e >= p.mask_c1) ? 1.0f : p.mask_alpha;
+                }
+            }
+            unsigned hh[4], ll[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mh_split_bf16x2(v[2 * e], v[2 * e + 1], hh[e], ll[e]);
+            const bool st = ok && !(p.dbg & 32);
+            const int op = st ? (pix * p.out_pld + n) * 2 : MH_OOB;
+            const int of = st ? (pix * p.out_ld + n) * 4 : MH_OOB;
+            const u32x4 qh = {hh[0], hh[1], hh[2], hh[3]}, ql = {ll[0], ll[1], ll[2], ll[3]};
+            const u32x4 f0 = __builtin_bit_cast(u32x4, make_float4(v[0], v[1], v[2], v[3])), f1 = __builtin_bit_cast(u32x4, make_float4(v[4], v[5], v[6], v[7]));
+            const int of1 = of == MH_OOB ? MH_OOB : of + 16;
+            __builtin_amdgcn_raw_buffer_store_b128(qh, rs_oh, op, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(ql, rs_ol, op, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(f0, rs_o, of, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(f1, rs_o, of1, 0, 0);
+        }
+    }
+}
+
+template <int MC, int WN, int MBW, int K16, int PL>
+__global__ __launch_bounds__(2 * WN * 64) void conv_planes_kernel_stg(PlanesArgs p) {
+    using G = PlanesStgGeo<MC, WN, MBW, K16, PL>;
+    constexpr int MR = G::MR, NW = G::NW, TR = G::TR, BN = G::BN, PR = G::PR, PC = G::PC;
+    constexpr int NCK = G::NCK, NCK1 = G::NCK1, ROWP = G::ROWP, PLANE_BLKS = G::PLANE_BLKS, PLANE_BYTES = G::PLANE_BYTES;
+    HIP_DYNAMIC_SHARED(float, smem_all)
+    unsigned char* const smem = reinterpret_cast<unsigned char*>(smem_all);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int d = p.dil;
+
+    const int lin = mh_xcd_remap(blockIdx.x, p.nwg);
+    int tile_n, ttx, tty, cx, cy, b;
+    mh_decode_tile(lin, p.dec, tile_n, ttx, tty, cx, cy, b);
+    const int n0 = tile_n * BN;
+    const int y00 = cy + d * (tty * TR), x00 = cx + d * (ttx * MC);
+    PlanesStgPre<G, PL> pre;
+    planes_stg_prefetch<G, PL>(p, wm, wn, lane, n0, y00, x00, b, d, pre);
+
+    constexpr int T = 9 * K16, NSTB = PL == 2 ? MH_PLANES_RING2 : MH_PLANES_RING1, PF = NSTB - 1;
+    const __amdgpu_buffer_rsrc_t rs_b = mh_make_rsrc(p.wb, p.wb_bytes);
+    const int nt32 = (p.N + 31) >> 5;
+    const int nt = tile_n * WN + wn;
+    const int voff_b = nt < nt32 ? nt * (PL * 1024) + lane * 16 : MH_OOB;
+    const int step_b = nt32 * (PL * 1024);
+    u32x4 fb[NSTB][PL];
+    auto issue_b = [&](int t, int slot) {
+        if (t < T) {
+            fb[slot][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff_b, t * step_b, 0);
+            if constexpr (PL == 2) fb[slot][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff_b, t * step_b + 1024, 0);
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < PF; ++t) issue_b(t, t % NSTB);
+
+    if (!(p.dbg & 2)) {
+        const mh_dma_src rs_h = mh_make_dma_src(p.in_hi, p.in_bytes), rs_l = mh_make_dma_src(p.in_lo, p.in_bytes);
+        const int pix_b = p.in_pld * 2;
+        for (int i = wave; i < PLANE_BLKS; i += NW) {
+            const int g = i * 64 + lane;
+            const int pr = g / ROWP, rem = g - pr * ROWP;
+            const int pc = rem / NCK1, c = rem - pc * NCK1;
+            const int iy = y00 + (pr - 1) * d, ix = x00 + (pc - 1) * d;
+            const bool ok = pr < PR && pc < PC && c < NCK && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const int off = ok ? ((b * p.H + iy) * p.W + ix) * pix_b + c * 16 : MH_OOB;
+            mh_glds16(rs_h, smem + i * 1024, off);
+            if constexpr (PL == 2) mh_glds16(rs_l, smem + PLANE_BYTES + i * 1024, off);
+        }
+    }
+    MH_WAIT_VMCNT(0);
+    __syncthreads();                                 // the only barrier of the kernel
+    if (wm == 0 && !(p.dbg & 64)) mh_setprio<3>();
+
+    f32x16 acc[MBW];
+#pragma unroll
+    for (int mb = 0; mb < MBW; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+    {
+        const int j = lane & 31, kg = lane >> 5;
+        const int lr = MR == 1 ? 0 : (j >> 4), lc = MR == 1 ? j : (j & 15);
+        const unsigned char* const a_h = smem + (((wm * MBW * MR + lr) * ROWP + lc * NCK1 + kg) * 16);
+        const unsigned char* const a_l = a_h + PLANE_BYTES;
+        u32x4 fa[2][MBW][PL];
+        auto issue_a = [&](int t, int set) {
+            if (t < T) {
+                const int tap = t / K16, s = t - tap * K16;
+                const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+                for (int mb = 0; mb < MBW; ++mb) {
+                    const int imm = (((mb * MR + ky) * ROWP + kx * NCK1 + 2 * s) * 16);
+                    fa[set][mb][0] = *reinterpret_cast<const u32x4*>(a_h + imm);
+                    if constexpr (PL == 2) fa[set][mb][1] = *reinterpret_cast<const u32x4*>(a_l + imm);
+                }
+            }
+        };
+        issue_a(0, 0);
+        if (!(p.dbg & 1)) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int sa = t & 1, sb = t % NSTB;
+#pragma unroll
+                for (int term = (PL == 2 ? 0 : 2); term < 3; ++term) {
+#pragma unroll
+                    for (int mb = 0; mb < MBW; ++mb) {
+                        acc[mb] = mh_mfma_bf16_32(fa[sa][mb][term == 0 ? PL - 1 : 0], fb[sb][term == 1 ? PL - 1 : 0], acc[mb]);
+                        if (term == (PL == 2 ? 0 : 2) && mb == 0) issue_a(t + 1, sa ^ 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                issue_b(t + PF, (t + PF) % NSTB);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    if (wm == 0) mh_setprio<0>();                   // its epilogue yields to the other group's walk
+    planes_stg_epilogue<G, PL>(p, reinterpret_cast<float*>(smem + G::LDS_TILES + wave * G::WBUF), acc, wm, wn, lane, n0, y00, x00, b, d, pre);
 }
 
 // ---- K-chunked variant (round 4, DispNet's 256 .. 1056-channel layers: Nets/DispNet.py:75-152) -------------------------------------------------
@@ -702,7 +923,7 @@ __global__ __launch_bounds__(256) void plane_split_kernel(const mh_plane_seg* __
     if (sg.lo) *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(sg.lo) + pix * sg.dst_ld + c0) = (u32x4){ll[0], ll[1], ll[2], ll[3]};
 }
 
-std::atomic<int> g_planes_mode{0};       // mh_tune_conv_planes: bits 0-3 tile variant (0 = heuristic), bit 8 = skip the K walk, bit 9 = skip the staging (timing experiments)
+std::atomic<int> g_planes_mode{0};       // mh_tune_conv_planes: bits 0-3 tile variant (0 = heuristic), bits 4 / 5 / 6 staggered tiles (dispatch_planes), bits 8 .. 15 timing experiments (PlanesArgs::dbg)
 std::atomic<int> g_planes_launches{0};
 
 template <int MC, int WM, int WN, int MBW, int K16, int PL>
@@ -734,6 +955,37 @@ int launch_planes(PlanesArgs& a, hipStream_t s, bool attr_only) {
                    G::BM, G::BN, a.K, a.dil, a.nwg, G::LDS);
     hipLaunchKernelGGL((conv_planes_kernel<MC, WM, WN, MBW, K16, PL>), dim3(a.nwg), dim3(G::NTH), G::LDS, s, a);
     return mh_check_launch("conv_planes");
+}
+
+template <int MC, int WN, int MBW, int K16, int PL>
+int launch_planes_stg(PlanesArgs& a, hipStream_t s, bool attr_only) {
+    using G = PlanesStgGeo<MC, WN, MBW, K16, PL>;
+    static_assert(G::LDS_STG <= 160 * 1024, "patch planes + the waves' transposition blocks exceed the LDS");
+    static std::atomic<uint64_t> attr_done{0};
+    const uint64_t attr_dev = mh_device_bit();
+    if (!(attr_done.load(std::memory_order_relaxed) & attr_dev)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_planes_kernel_stg<MC, WN, MBW, K16, PL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { mh_set_error("conv_planes (staggered): hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_done.fetch_or(attr_dev);
+    }
+    if (attr_only) return 0;
+    const int d = a.dil;
+    a.tiles_y = mh_cdiv(mh_cdiv(a.H, d), G::TR);
+    a.tiles_x = mh_cdiv(mh_cdiv(a.W, d), MC);
+    a.ntiles_n = mh_cdiv(a.N, G::BN);
+    a.nwg = a.B * d * d * a.tiles_y * a.tiles_x * a.ntiles_n;
+    {
+        const int64_t nwg64 = (int64_t)a.nwg;
+        const int dmax = std::max(std::max(a.ntiles_n, a.tiles_x), std::max(a.tiles_y, (int)d));
+        MH_REQUIRE(mh_fastdiv_ok(nwg64, dmax), MH_ERR_UNSUPPORTED, "tile decode: %lld workgroups x divisor %d exceeds the 2^32 range of the magic-multiplier division", (long long)nwg64, dmax);
+    }
+    a.dec = mh_make_tile_decode(a.ntiles_n, a.tiles_x, a.tiles_y, d);
+    a.dbg = (g_planes_mode.load(std::memory_order_relaxed) >> 8) & 255;
+    ++g_planes_launches;
+    mh_note_kernel("conv_planes_kernel<MC=%d,2x%d waves staggered,MBW=%d,K16=%d,%s> tile %dx%d K=%d dil=%d grid %d lds %d", MC, WN, MBW, K16, PL == 2 ? "bf16x3" : "bf16",
+                   G::BM, G::BN, a.K, a.dil, a.nwg, G::LDS_STG);
+    hipLaunchKernelGGL((conv_planes_kernel_stg<MC, WN, MBW, K16, PL>), dim3(a.nwg), dim3(G::NTH), G::LDS_STG, s, a);
+    return mh_check_launch("conv_planes (staggered)");
 }
 
 template <int MC, int WM, int WN, int MBW, int K16, int PL, int NBUF>
@@ -855,7 +1107,9 @@ const PlanesS2Inst* planes_s2_find(int kh, int k16, int n32, int pl, int64_t row
 // ---- instance table + tile choice ---------------------------------------------------------------------------------------------------------
 // Every (N rounded up to 32, K16) pair has the 128-pixel instances of both M-block shapes; the pairs MADNet's layers use also have 64- / 32-pixel
 // instances for grids that would not fill the chip (the 1/8-resolution level: 60 tiles of 128 pixels on 256 CUs).
-struct PlanesInst { int mc, wm, wn, mbw, k16, lds; int (*launch)(PlanesArgs&, hipStream_t, bool); int pl; int nbuf; };    // nbuf > 0: K-chunked (k16 = the chunk)
+struct PlanesInst { int mc, wm, wn, mbw, k16, lds; int (*launch)(PlanesArgs&, hipStream_t, bool); int pl; int nbuf; int stg; };    // nbuf > 0: K-chunked (k16 = the chunk); stg: staggered wave groups
+#define STG_INST(MC, WN, MBW, K16, PL) {MC, 2, WN, MBW, K16, PlanesStgGeo<MC, WN, MBW, K16, PL>::LDS_STG, &launch_planes_stg<MC, WN, MBW, K16, PL>, PL, 0, 1}
+#define STG_BOTH(WN, MBW, K16, PL) STG_INST(32, WN, MBW, K16, PL), STG_INST(16, WN, MBW, K16, PL)
 #define PL_INST(MC, WM, WN, MBW, K16) {MC, WM, WN, MBW, K16, PlanesGeo<MC, WM, WN, MBW, K16, 2>::LDS, &launch_planes<MC, WM, WN, MBW, K16, 2>, 2, 0}
 #define P1_INST(MC, WM, WN, MBW, K16) {MC, WM, WN, MBW, K16, PlanesGeo<MC, WM, WN, MBW, K16, 1>::LDS, &launch_planes<MC, WM, WN, MBW, K16, 1>, 1, 0}
 #define CK_INST(WN, MBW, PL, NBUF) {32, 1, WN, MBW, MH_PLANES_KC16, PlanesCkGeo<32, 1, WN, MBW, MH_PLANES_KC16, PL, NBUF>::LDS_CK, &launch_planes_ck<32, 1, WN, MBW, MH_PLANES_KC16, PL, NBUF>, PL, NBUF}
@@ -886,6 +1140,8 @@ const PlanesInst g_planes_inst[] = {
     // K-chunked (chunks of 64 channels): every layer / input gradient with a reduction over more than 128 channels, 128- or 64-column tiles
     CK_INST(4, 4, 1, 3), CK_INST(4, 2, 1, 3), CK_INST(4, 1, 1, 3), CK_INST(2, 2, 1, 3), CK_INST(2, 1, 1, 3),
     CK_INST(4, 2, 2, 3), CK_INST(4, 1, 2, 3), CK_INST(2, 2, 2, 3), CK_INST(2, 1, 2, 3), CK_INST(4, 4, 2, 2), CK_INST(3, 4, 1, 3), CK_INST(3, 2, 1, 3), CK_INST(3, 2, 2, 3), CK_INST(3, 1, 2, 3),
+    // ---- staggered wave groups (128 x 128 tiles as two out-of-phase halves): the 128-column layers of the estimators / the context network and their input gradients
+    STG_BOTH(4, 2, 3, 2), STG_BOTH(4, 2, 8, 2), STG_BOTH(4, 2, 6, 1), STG_BOTH(4, 2, 8, 1), STG_BOTH(3, 2, 8, 2), STG_BOTH(2, 2, 6, 2),
 };
 constexpr int N_PLANES_INST = sizeof(g_planes_inst) / sizeof(g_planes_inst[0]);
 
@@ -923,7 +1179,7 @@ float planes_cost(const PlanesInst& I, const PlanesArgs& a, int* nwg_out) {
 // the two DispNet shapes with whole-K instances, chunk-major beyond), so a layer has either whole-K or chunked candidates, never both.
 // Columns: up to 128 -> the instance's width must be the layer's (rounded to 32); more -> 128-column tiles (chunked: 64-column tiles too).
 bool planes_inst_fits(const PlanesInst& I, int k16, int n32, int pl) {
-    if (I.pl != pl) return false;
+    if (I.pl != pl || I.stg) return false;           // (staggered instances REPLACE the chosen 128-pixel instance: dispatch_planes)
     const bool chunked = mh_planes_kc16(k16 * 16) != 0;
     if (chunked != (I.nbuf != 0)) return false;
     if (!chunked && I.k16 != k16) return false;
@@ -955,6 +1211,19 @@ int dispatch_planes(PlanesArgs& a, hipStream_t s, bool all, int pl = 2) {
         mh_set_error("mh_conv2d_planes%s: no instance for K = %d, N = %d", pl == 1 ? "_bwd" : "", a.K, a.N);
         return MH_ERR_UNSUPPORTED;
     }
+    // a 128-pixel tile with one workgroup per CU: the staggered form of the same tile where it exists.  Forward layers: the default (mh_tune_conv_planes bit 6 = off, bit 4 = on
+    // beside a forced tile variant): -1 .. -2 us per launch alone and inside the step.  Input gradients: bit 5 only -- alone they gain 2 - 2.6 us per launch, but inside the FULL
+    // step they run beside the filter-gradient lanes, whose workgroups then find neither the LDS nor the wave slots they had: the step LOSES 11 - 15 us (r6n - r6p)
+    const int gm = g_planes_mode.load(std::memory_order_relaxed);
+    const bool stagger = pl == 2 ? ((gm & 16) || (v == 0 && !(gm & 64))) : (gm & 32) != 0;
+    int nwg_best = 0;
+    planes_cost(*best, a, &nwg_best);
+    // (one workgroup per CU is the premise: with two co-resident workgroups -- dilation 16, 512 tiles -- the staggered form measured 23.2 us against 20.4)
+    if (stagger && !best->nbuf && best->wm * best->mbw == 4 && nwg_best <= 256 && (!(gm & 128) || best->wn == 4))
+        for (int i = 0; i < N_PLANES_INST; ++i) {
+            const PlanesInst& J = g_planes_inst[i];
+            if (J.stg && J.mc == best->mc && J.k16 == best->k16 && J.pl == pl && J.wn == best->wn) return J.launch(a, s, false);
+        }
     return best->launch(a, s, false);
 }
 

@@ -72,3 +72,12 @@ typedef const __attribute__((address_space(4))) float MH_CONST_F32;
 #define MH_CONST_F32_PTR(p) ((MH_CONST_F32*)(p))
 #define MH_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define MH_WAIT_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// wave-local LDS exchange (a wave writes an LDS block and its lanes read each other's words back): the LDS executes one wave's operations in order, so all that is needed is
+// that the compiler keeps the order and the data has arrived -- a wavefront-scope fence, no s_barrier
+__device__ __forceinline__ void mh_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// s_setprio: the wave's issue priority (0 .. 3) among the waves of its SIMD
+template <int P> __device__ __forceinline__ void mh_setprio() { __builtin_amdgcn_s_setprio(P); }

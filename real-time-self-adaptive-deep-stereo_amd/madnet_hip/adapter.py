@@ -335,5 +335,7 @@ class _null(object):
 
 
 def _as(x, like):
+    if torch.is_tensor(x) and x.device == like.device:
+        return x.reshape(like.shape)            # (a uint8 frame from device_prefetcher(cast=False): copy_ casts while it copies)
     t = torch.as_tensor(x, dtype=torch.float32)
     return t.reshape(like.shape)

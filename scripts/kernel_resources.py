@@ -17,7 +17,11 @@ def main():
     show_all = "--all" in sys.argv
     tmp = tempfile.mkdtemp()
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    procs = [(s, subprocess.Popen(["/opt/rocm/bin/hipcc"] + FLAGS + [os.path.basename(s), "-o", os.path.join(tmp, os.path.basename(s) + ".s")],
+    # per-file flags of the Makefile ("conv_planes.o: CXXFLAGS += -mllvm -pragma-unroll-threshold=65536"): the table must describe the kernels that ship
+    extra = {}
+    for m in re.finditer(r"^(\w+)\.o:\s*CXXFLAGS\s*\+=\s*(.+)$", open(os.path.join(CSRC, "Makefile")).read(), re.M):
+        extra[m.group(1) + ".hip"] = m.group(2).split()
+    procs = [(s, subprocess.Popen(["/opt/rocm/bin/hipcc"] + FLAGS + extra.get(os.path.basename(s), []) + [os.path.basename(s), "-o", os.path.join(tmp, os.path.basename(s) + ".s")],
                                   cwd=CSRC, stderr=subprocess.DEVNULL)) for s in srcs]
     rows = []
     for s, p in procs:

@@ -10,8 +10,11 @@ from madnet_hip import _ffi, engine as E, dispnet_engine as DE, synthetic as S, 
 ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="madnet"); ap.add_argument("--precision", default="mixed"); ap.add_argument("--mode", default="FULL")
 ap.add_argument("--rows", type=int, default=400)
+ap.add_argument("--tune", action="append", default=[], help="NAME=int: calls mh_tune_NAME before the plan is recorded (conv_planes=16 ...)")
 a = ap.parse_args()
 lib = _ffi.lib()
+for t in a.tune:
+    getattr(lib, "tune_" + t.split("=")[0])(int(t.split("=")[1]))
 H, W = 375, 1242
 disp = a.model == "dispnet"
 wn = S.calibrated_weights(dict(DE.dispnet_manifest() if disp else E.madnet_manifest()), 1)

@@ -98,3 +98,6 @@ typedef const float MH_CONST_F32;
 #define MH_CONST_F32_PTR(p) ((MH_CONST_F32*)(p))
 #define MH_WAIT_VMCNT(n) do { } while (0)
 #define MH_WAIT_LGKMCNT0() do { } while (0)
+// wave-local LDS exchange: the lanes of a wave are fibers here, so the fence is a rendezvous of the wave
+static inline void mh_wave_sync() { emul::wave_rendezvous(emul::my_wave()); }
+template <int P> static inline void mh_setprio() {}

@@ -135,3 +135,29 @@ def test_multi_adapter_private_streams_match_single_adapters(hip):
         w0, w1 = alone[sid][1], pairs[sid][0].engine.params.w
         # (four steps at lr 1e-3: the landing order of the fp32 atomics -- bias / warp gradients -- differs between a replayed graph and eager launches: ~1e-7)
         assert (w0 - w1).abs().max().item() <= 1e-6 * max(1.0, w0.abs().max().item()), sid
+
+
+def test_adapter_behind_the_prefetcher_uint8_paths_agree(hip):
+    """The online loop's input side (Stereo_Online_Adaptation.py:95-97 here; tf.data prefetch in the reference, Data_utils/data_reader.py:171-175): 8-bit frames through
+    device_prefetcher into Adapter.step -- cast on the copy stream (cast=True, float32 frames) and cast by the step's own copy (cast=False, uint8 frames) -- give the
+    losses of the same frames handed over as float32 arrays, bit for bit, over more frames than the ring has slots (slot reuse behind the consumer's events)."""
+    import Nets
+    from madnet_hip.adapter import Adapter
+    from Data_utils.data_reader import device_prefetcher
+    H, W, steps = 64, 128, 9
+    wn = S.calibrated_weights(OM.variable_shapes(), 1)
+    frames = [S.make_pair(H, W, frame=t) for t in range(steps)]
+    frames8 = [(l.astype(np.uint8), r.astype(np.uint8), np.ascontiguousarray(g[..., 0])) for l, r, g in frames]
+    assert all(np.array_equal(a.astype(np.float32), f[0]) for a, f in zip([x[0] for x in frames8], frames))      # the synthetic pixels are integral
+
+    def run(feed):
+        left = torch.zeros(1, H, W, 3, device="cuda"); right = torch.zeros_like(left)
+        net = Nets.get_stereo_net("MADNet", {"left_img": left, "right_img": right, "weights": wn, "precision": "mixed"})
+        ad = Adapter(net, mode="FULL", lr=1e-4)
+        return [ad.step(*f)["loss"] for f in feed(ad)], net.engine.params.w.clone()
+
+    ref, w_ref = run(lambda ad: [(l, r, g[..., 0]) for l, r, g in frames])
+    for cast in (True, False):
+        got, w = run(lambda ad: device_prefetcher(frames8, "cuda", depth=2, consumer_stream=ad.stream, cast=cast))
+        assert got == ref, (cast, got, ref)
+        assert torch.equal(w, w_ref)

@@ -41,6 +41,8 @@ CASES = [
     (1, 9, 34, 64, 32, 1, 1), (1, 19, 17, 64, 32, 1, 2), (2, 8, 40, 32, 32, 1, 0),
     (1, 8, 33, 38, 128, 1, 1),       # the estimators' first layer: 38 channels in rows of 64 halfs, three 16-channel steps per tap
     (1, 8, 33, 33, 128, 1, 3), (1, 9, 20, 70, 128, 1, 1), (1, 6, 20, 64, 64, 16, 1), (1, 12, 40, 128, 96, 8, 0),
+    # + 16: the staggered form of the 128 x 128 tile (two out-of-phase wave groups, wave-local epilogue: conv_planes_kernel_stg)
+    (1, 9, 37, 128, 128, 1, 17), (1, 11, 21, 128, 128, 2, 19), (1, 8, 33, 38, 128, 1, 17), (2, 9, 40, 33, 128, 1, 19), (2, 7, 33, 128, 96, 1, 17), (1, 10, 35, 96, 64, 1, 19),
 ]
 
 
@@ -73,7 +75,7 @@ def test_conv2d_planes_vs_oracle_and_split_bf16_kernel(backend, case):
         backend.sync()
     finally:
         assert lib.tune_conv_planes(0) == 3
-    assert "conv_planes_kernel" in name, name
+    assert "conv_planes_kernel" in name and (variant == 0 or ("staggered" in name) == bool(variant & 16)), name       # (0: the heuristic staggers the 128-pixel tiles it picks)
     yc = y.cpu()
     assert torch.isfinite(yc).all()
     scale = max(1.0, y_ref.abs().max().item())
@@ -149,6 +151,7 @@ def test_conv2d_planes_argument_checks(backend):
 BWD_CASES = [
     (1, 9, 37, 128, 128, 1, 0), (1, 11, 21, 128, 128, 2, 3), (1, 12, 40, 128, 96, 1, 2), (2, 7, 33, 96, 64, 1, 0), (1, 18, 20, 96, 64, 4, 4),
     (1, 9, 34, 64, 32, 1, 0), (2, 8, 40, 32, 32, 1, 1), (1, 10, 35, 64, 64, 1, 5), (1, 6, 20, 64, 64, 16, 0),
+    (1, 9, 37, 128, 128, 1, 33), (1, 11, 21, 128, 128, 2, 35), (2, 6, 40, 128, 96, 1, 33),       # + 32: staggered wave groups
 ]
 
 
@@ -186,7 +189,7 @@ def test_conv2d_planes_bwd_vs_oracle_and_bf16_input_gradient(backend, case):
         backend.sync()
     finally:
         assert lib.tune_conv_planes(0) == 2
-    assert "conv_planes_kernel" in name and ",bf16>" in name, name
+    assert "conv_planes_kernel" in name and ",bf16>" in name and (("staggered" in name) == bool(variant & 32)), name
     dxc = dx.cpu()
     scale = max(1.0, g_ref.abs().max().item())
     assert torch.isfinite(dxc).all() and (dxc - g_ref).abs().max().item() <= 2e-5 * scale, ((dxc - g_ref).abs().max().item(), name)
