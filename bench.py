@@ -73,7 +73,7 @@ def compact_line(obj):
     if "dtype" in obj:
         out["dtype"] = obj["dtype"]
     cfg = obj.get("config", {})
-    out["config"] = _pick(cfg, ("workload", "precision", "launch", "timed_region", "ops_per_step", "shared_model", "collectives_per_step", "concurrent_private_streams_per_gpu",
+    out["config"] = _pick(cfg, ("workload", "precision", "launch", "timed_region", "step_sync", "ops_per_step", "shared_model", "collectives_per_step", "concurrent_private_streams_per_gpu",
                                 "final_loss", "epe_vs_synthetic_gt"))
     if isinstance(obj.get("timing"), dict):
         out["timing"] = _pick(obj["timing"], ("repeats", "ms_per_step_min", "ms_per_step_max", "timed_steps_per_repeat"))
@@ -747,6 +747,10 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--repeats", type=int, default=5, help="how many times the K-step region is timed (value = the median region)")
+    ap.add_argument("--graph-copies", type=int, default=1, help="executable graphs of the step, launched in turn (experiment)")
+    ap.add_argument("--step-sync", default="auto", choices=["auto", "none", "stream"],
+                    help="none: the K steps of a region are enqueued back to back; stream: the host synchronises the step's stream after every step (what a consumer of the "
+                         "disparity does); auto: stream for the single-stream private MADNet FULL step (measured faster), none elsewhere")
     ap.add_argument("--min-region-seconds", type=float, default=1.0,
                     help="every timed region is lengthened to at least this many seconds by repeating the K-step block inside it (0 = exactly K steps)")
     ap.add_argument("--drift-steps", type=int, default=100, help="N-step drift report: 'mixed' vs the fp32 engine after 10 and N adaptation steps on a frame-shifted synthetic video (0 = skip)")
@@ -934,7 +938,7 @@ def main():
             if use_graph:
                 for q in (plan, pyr, upd):
                     if q is not None:
-                        q.capture(lib, dev.sh)
+                        q.capture(lib, dev.sh, copies=args.graph_copies)
 
         def one_step():
             plan.launch(lib, dev.sh)
@@ -1005,6 +1009,21 @@ def main():
             def one_step():                      # noqa: F811
                 mp.launch(lib, dev.sh)
         _log("%d concurrent private streams captured (%s)" % (CS, "one graph each" if args.concurrent_graphs else "branches of one graph"))
+    if args.step_sync == "auto":
+        # measured per configuration (r6u, r6v; one box each, alternating): MADNet FULL private single stream -21 / -21 / -20 us and -16 / -10 us with the host wait;
+        # DispNet +21, forward only +14, four private streams +570, four batched streams +13 without it -- every configuration runs the loop that serves it better
+        args.step_sync = "stream" if (args.model == "madnet" and args.mode == "FULL" and CS == 1 and SB == 1 and not shared) else "none"
+    if args.step_sync == "stream":
+        # the host waits for every step before it launches the next (what a consumer of the disparity does; the reference's sess.run per frame).  Measured FASTER than
+        # enqueueing replays back to back: the next replay's first nodes no longer contend with the previous one's filter-gradient tail (r6t: 1286.5 against 1308.3 us)
+        launch_only = one_step
+
+        def one_step():                          # noqa: F811
+            launch_only()
+            dev.sync_stream()
+        for k in ("n_ops", "collectives_only", "without_collectives"):
+            if hasattr(launch_only, k):
+                setattr(one_step, k, getattr(launch_only, k))
     with dev.ctx():
         for _ in range(args.warmup):
             one_step()
@@ -1068,8 +1087,9 @@ def main():
                    "precision": args.precision,
                    "concurrent_private_streams_per_gpu": CS,
                    "launch": "hipGraph replay" if use_graph else "eager plan",
-                   "timed_region": "the step's launches on frames already resident in HBM (no upload, no read-back); the reference's FPS definition "
-                                   "(new frame + loss read-back every step) is `step_surface`",
+                   "timed_region": "the step's launches on frames already resident in HBM (no upload, no read-back)%s; the reference's FPS definition "
+                                   "(new frame + loss read-back every step) is `step_surface`" % (", the host waits for every step" if args.step_sync == "stream" else ", steps enqueued back to back"),
+                   "step_sync": args.step_sync,
                    "ops_per_step": getattr(one_step, "n_ops", plan.n), "final_loss": loss, "epe_vs_synthetic_gt": epe_gt,
                    "pred_nonzero_frac": nonzero,
                    "ranks_per_device": (world + dev.ndev - 1) // dev.ndev if dev.ndev else None},

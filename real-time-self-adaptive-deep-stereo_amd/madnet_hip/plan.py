@@ -316,20 +316,30 @@ class Plan(object):
     def run(self, lib, stream):
         lib.plan_run(self.arr, self.n, C.c_void_p(stream))
 
-    def capture(self, lib, stream):
-        """Capture the plan into a hipGraph on `stream` (must not be the legacy default stream)."""
+    def capture(self, lib, stream, copies=1):
+        """Capture the plan into a hipGraph on `stream` (must not be the legacy default stream).  copies > 1: that many executable graphs of the same plan, launched
+        in turn -- a replay enqueued while the previous one is in flight is then never the SAME executable (experiment r6v)."""
         s = C.c_void_p(stream)
-        lib.graph_begin(s)
-        try:
-            lib.plan_run(self.arr, self.n, s)
-        finally:
-            g = C.c_void_p()
-            lib.graph_end(s, C.byref(g))
-        self.graph = g
+        self.graphs = []
+        for _ in range(max(1, copies)):
+            lib.graph_begin(s)
+            try:
+                lib.plan_run(self.arr, self.n, s)
+            finally:
+                g = C.c_void_p()
+                lib.graph_end(s, C.byref(g))
+            self.graphs.append(g)
+        self.graph = self.graphs[0]
+        self._turn = 0
 
     def launch(self, lib, stream):
         if self.graph is not None:
-            lib.graph_launch(self.graph, C.c_void_p(stream))
+            gs = getattr(self, "graphs", None)
+            if gs and len(gs) > 1:
+                self._turn = (self._turn + 1) % len(gs)
+                lib.graph_launch(gs[self._turn], C.c_void_p(stream))
+            else:
+                lib.graph_launch(self.graph, C.c_void_p(stream))
         else:
             self.run(lib, stream)
 
