@@ -329,6 +329,20 @@ class DispNetEngine(object):
                 if op2[0] == "conv" and self._planes_fwd_kind(op2) == 2:
                     xv2 = op2[1].view()
                     plane_consumers[(xv2.ptr, xv2.B, xv2.H, xv2.W, xv2.C)] = True
+        vkey = lambda v: (v.ptr, v.B, v.H, v.W, v.C)
+        # activations whose bf16 shadow a later launch of this plan reads: input of a one-plane forward layer, of a streamed filter gradient (3x3, stride 1), leaky mask of
+        # a plane input gradient -- their producer writes the shadow
+        shadow_readers = set()
+        if self.use_planes and self.sched.PRODUCER_SHADOWS:
+            for op2 in self.ops:
+                if op2[0] != "conv":
+                    continue
+                _, x2, wn2, _, stride2, _, x_grad2 = op2
+                w2 = self.W_(wn2)
+                streamed = backward and self.use_stream and ops._bwd_precision() == 1 and tuple(w2.shape[:2]) == (3, 3) and stride2 == 1
+                masked = backward and x_grad2 and x2.alpha is not None and self._planes_bwd_ok(op2)
+                if self._planes_fwd_kind(op2) == 1 or streamed or masked:
+                    shadow_readers.add(vkey(x2.view()))
         for op in self.ops:
             kind = op[0]
             if kind == "conv":
@@ -349,10 +363,27 @@ class DispNetEngine(object):
                         if key not in self._fresh:
                             ops.shadow_cast(r, [(xv, sh)], self.dev, r.keep)
                     self._fresh.add(key)
-                    ops.conv2d_planes(r, xp, self.W_(wn), self.banks_f[wn][0], self.b_(wn), out=out.view(), alpha=alpha, bf16=(kind == 1), stride=stride)
+                    ov = out.view()
+                    okey = vkey(ov)
+                    outp = None
+                    if ov.C % 8 == 0 and okey in plane_consumers:
+                        _, osh = self._shadow_of(ov)
+                        if okey not in self.lo_planes:
+                            self.lo_planes[okey] = ops.Shadow(ov.B, ov.H, ov.W, ov.C, self.dev)
+                        outp = ops.Planes.__new__(ops.Planes); outp.hi, outp.lo = osh, self.lo_planes[okey]
+                        self._fresh_lo.add(okey); self._fresh.add(okey)
+                    elif ov.C % 8 == 0 and okey in shadow_readers:
+                        _, outp = self._shadow_of(ov)
+                        self._fresh.add(okey)
+                    ops.conv2d_planes(r, xp, self.W_(wn), self.banks_f[wn][0], self.b_(wn), out=ov, out_planes=outp, alpha=alpha, bf16=(kind == 1), stride=stride)
                     continue
                 ov = out.view()
                 okey = (ov.ptr, ov.B, ov.H, ov.W, ov.C)
+                if okey in shadow_readers and okey not in plane_consumers and ov.C % 8 == 0:
+                    _, osh = self._shadow_of(ov)
+                    ops.conv2d_fwd(r, x.view(), self.W_(wn), self.b_(wn), ov, stride=stride, alpha=alpha, precision=self._fwd_code(wn), shadow=osh)
+                    self._fresh.add(okey)
+                    continue
                 if okey in plane_consumers and ov.C % 8 == 0:        # (the fp32 result may be a slice of a concat buffer -- conv1a is a skip connection --: the planes are the view's own)
                     _, osh = self._shadow_of(ov)
                     if okey not in self.lo_planes:
@@ -480,16 +511,32 @@ class DispNetEngine(object):
                 del pending[:]
                 del upd_fresh[:]
 
+        # gradient maps whose bf16 shadow a later launch reads as its dz: the plane input gradient / the streamed filter gradient of the layer that produced the node
+        grad_readers = set()
+        if self.use_planes and self.sched.PRODUCER_SHADOWS and ops._bwd_precision() == 1:
+            for op2 in self.ops:
+                if op2[0] == "conv":
+                    _, x2, wn2, out2, stride2, _, x_grad2 = op2
+                    w2 = self.W_(wn2)
+                    if (self.use_stream and tuple(w2.shape[:2]) == (3, 3) and stride2 == 1) or self._planes_bwd_ok(op2):
+                        grad_readers.add(out2.name)
+
         def conv_like_dgrad(emit, xnode):
-            """emit(dx_view, accumulate, mask_ref, mask_alpha, mask_range); handles the leaky-mask fusion."""
+            """emit(dx_view, accumulate, mask_ref, mask_alpha, mask_range, shadow); handles the leaky-mask fusion.  shadow: the Shadow of dx when this contribution
+            COMPLETES the gradient map of a plain node whose shadow a later launch reads -- the emitting kernel writes it with its final values"""
             acc, masks = self._contribute(xnode)
             fused = masks[0] if masks else None
+            sh = None
+            if (not xnode.members and xnode.remaining == 0 and len(masks) <= 1 and xnode.name in grad_readers and xnode.C % 8 == 0
+                    and (fused is None or fused is xnode)):
+                gk, sh = self._shadow_of(xnode.gview())
+                self._fresh.add(gk)
             if fused is not None:
                 rng = (fused.c0 - xnode.c0, fused.c0 - xnode.c0 + fused.C)
                 ref = ops.View(xnode.st.t, B, xnode.st.H, xnode.st.W, xnode.C, xnode.st.ld, coff=xnode.c0)
-                emit(xnode.gview(), acc, ref, fused.alpha, rng)
+                emit(xnode.gview(), acc, ref, fused.alpha, rng, sh)
             else:
-                emit(xnode.gview(), acc, None, 1.0, (0, 0))
+                emit(xnode.gview(), acc, None, 1.0, (0, 0), sh)
             for m in masks[1:]:
                 ops.leaky_bwd(lib, m.gview(), m.view(), m.alpha)
 
@@ -509,7 +556,7 @@ class DispNetEngine(object):
                 if x_grad:
                     w = self.W_(wn)
 
-                    def emit_dgrad(dx, acc, ref, ma, rng, op=op, dz=dz, w=w, wn=wn, stride=stride):
+                    def emit_dgrad(dx, acc, ref, ma, rng, sh, op=op, dz=dz, w=w, wn=wn, stride=stride):
                         if (not acc or stride == 2) and wn in self.banks_b and self._planes_bwd_ok(op):          # (the stride-2 5x5 form accumulates: conv1a is a skip connection)
                             # dz (and the activation whose sign is the mask) as bf16 planes -- the casts the streamed filter gradient of this very
                             # layer would queue on its side lane anyway -- then the one-plane walk over dz (mh_conv2d_planes_bwd)
@@ -523,9 +570,9 @@ class DispNetEngine(object):
                                 self._fresh.add(km)
                             self._fresh.add(kz)
                             ops.shadow_cast(lib, casts, self.dev, r.keep)
-                            ops.conv2d_planes_bwd(lib, dzs, w, self.banks_b[wn], dx=dx, mask_shadow=ms, mask_alpha=ma, mask_range=rng, stride=stride, accumulate=acc)
+                            ops.conv2d_planes_bwd(lib, dzs, w, self.banks_b[wn], dx=dx, dx_shadow=sh, mask_shadow=ms, mask_alpha=ma, mask_range=rng, stride=stride, accumulate=acc)
                             return
-                        ops.conv2d_dgrad(lib, dz, w, dx, stride=stride, accumulate=acc, mask_ref=ref, mask_alpha=ma, mask_range=rng)
+                        ops.conv2d_dgrad(lib, dz, w, dx, stride=stride, accumulate=acc, mask_ref=ref, mask_alpha=ma, mask_range=rng, shadow=sh)
                     conv_like_dgrad(emit_dgrad, x)
             elif kind == "deconv":
                 _, x, wn, out, alpha = op
@@ -536,8 +583,8 @@ class DispNetEngine(object):
                 pending_bias.append((dz, self.b_(wn, "g")))         # BiasAddGrad: per-workgroup partial sums + a segment of the batch's reduction (no float atomics)
                 wgrad(dz, x.view(), self.W_(wn, "g"), None, 2, db_t=self.b_(wn, "g"))
                 w = self.W_(wn)
-                conv_like_dgrad(lambda dx, acc, ref, ma, rng: ops.conv2d_fwd(lib, dz, w, None, dx, stride=2, alpha=1.0, accumulate=acc,
-                                                                              mask_ref=ref, mask_alpha=ma, mask_range=rng), x)
+                conv_like_dgrad(lambda dx, acc, ref, ma, rng, sh: ops.conv2d_fwd(lib, dz, w, None, dx, stride=2, alpha=1.0, accumulate=acc,
+                                                                                  mask_ref=ref, mask_alpha=ma, mask_range=rng, shadow=sh), x)
             elif kind == "corr":
                 _, L, R, out, whole = op
                 assert out.written

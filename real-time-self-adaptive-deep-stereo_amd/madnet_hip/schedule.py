@@ -113,6 +113,10 @@ class DispNetSchedule(object):
     PLANES_S2: bool = True
     # conv3's FORWARD pass (5x5, 145 -> 256, plain bf16) on the stride-2 plane kernel too: two-row tiles (157 KB of patch) -- 2.752 / 2.756 against 2.791 / 2.792 ms (r6m)
     PLANES_S2_CONV3: bool = True
+    # (round 6) the bf16 shadow of an activation / a gradient map is written by the launch that PRODUCES it -- the plane kernels' epilogue (hi plane), mh_conv2d_sh of the
+    # tiled kernels; for a gradient map: its last contributor -- where a later launch reads it (plane forward layer, streamed filter gradient, plane input gradient, leaky
+    # mask), instead of a shadow_cast launch in front of the reader
+    PRODUCER_SHADOWS: bool = True
     # FULL momentum steps: every filter-gradient batch is followed, on its own side lane, by the momentum update of the layers it completes; the launch
     # behind the join covers what is left.  DispNet has 42 M parameters: one update over all of them is 840 MB of traffic at the very end of the step.
     EARLY_UPDATE: bool = field(default_factory=_env_flag("MH_EARLY_UPDATE", "1"))
