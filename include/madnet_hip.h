@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MH_ABI_VERSION 15
+#define MH_ABI_VERSION 16
 
 /* status codes of every int-returning entry point: 0 = launched; a NEGATIVE code means an argument check failed and
  * nothing was launched or written; a POSITIVE value is the hipError_t of a failed launch / runtime call.
@@ -368,6 +368,18 @@ int mh_bilinear_sampler_bwd(const float* g, const float* imgs, const float* coor
  *      (Data_utils/data_reader.py:98) executed after the host-to-device copy (1 byte per value over PCIe) */
 int mh_u8_to_f32(const uint8_t* in, float* out, int64_t n, void* stream);
 
+/* ---- the step's frames through a table the host rewrites between two replays of a captured step.  The reference feeds every sess.run through its input
+ *      pipeline (Stereo_Online_Adaptation.py:73-80: the iterator's tensors ARE the graph's inputs); a captured hipGraph reads fixed addresses, and a prefetcher
+ *      delivers frame t in slot t % depth -- so the step's first node looks the slot up: for k < count, src = table->src[k]: NULL or == dst[k]: nothing; else
+ *      dst[k][0 .. n[k]) = (float)src[...] (table->u8[k] != 0: 8-bit source values, the tf.cast of Data_utils/data_reader.py:98; else float32).  `table` must
+ *      be readable by the device when the kernel RUNS: device memory, or page-locked host memory through its device-side address (mh_host_device_pointer) --
+ *      the host then rewrites it without an API call, after the previous replay has completed.  Plan op: MH_OP_FETCH_INPUTS. */
+#define MH_FETCH_MAX 4
+typedef struct mh_input_table { const void* src[MH_FETCH_MAX]; int32_t u8[MH_FETCH_MAX]; } mh_input_table;
+int mh_fetch_inputs(const mh_input_table* table, float* const* dst, const int64_t* n, int32_t count, void* stream);
+/* device-side address of a page-locked (hipHostMalloc / torch pin_memory) host allocation */
+int mh_host_device_pointer(void* host, void** device);
+
 /* ---- preprocessing.pad_image (REFLECT, preprocessing.py:7-29) fused with the float cast
  *      and the channel padding 3 -> out_ld (extra channels zero) ------------------------ */
 /* out = in / div - sub  (MADNet: div=1, sub=0; DispNet._preprocess_inputs, DispNet.py:59-73: x/255 - 100/255) */
@@ -544,7 +556,8 @@ enum { MH_OP_CONV = 1, MH_OP_WGRAD, MH_OP_CORR_FWD, MH_OP_CORR_BWD, MH_OP_WARP_F
        MH_OP_MOMENTUM, MH_OP_COPY_CH, MH_OP_LEAKY_BWD, MH_OP_FILL, MH_OP_BIAS_GRAD,
        MH_OP_WGRAD_PARTIAL, MH_OP_WGRAD_REDUCE, MH_OP_PROXY_LOSS, MH_OP_SUPERVISED_LOSS, MH_OP_ADAM, MH_OP_ADAM_ADVANCE,
        MH_OP_RESIZE_IMAGE, MH_OP_LEVEL_FRONT, MH_OP_RESERVED_25 /* (was: transposed filter banks of the retired LDS-free kernel) */, MH_OP_PACK_W, MH_OP_CORR_WARP_BWD, MH_OP_SHADOW_CAST, MH_OP_WGRAD_STREAM, MH_OP_HEAD_BWD, MH_OP_HEAD_FWD, MH_OP_CONV_PLANES, MH_OP_PLANE_SPLIT, MH_OP_STAMP, MH_OP_CONV_PLANES_BWD, MH_OP_DET_FLUSH, MH_OP_CONV_IMAGE,
-       MH_OP_ALLREDUCE /* mh_allreduce_sum: p[0] = comm, p[1 .. i[0]] = buffers, i[1 .. i[0]] = counts (floats, < 2^31 each) */ };
+       MH_OP_ALLREDUCE /* mh_allreduce_sum: p[0] = comm, p[1 .. i[0]] = buffers, i[1 .. i[0]] = counts (floats, < 2^31 each) */,
+       MH_OP_FETCH_INPUTS /* mh_fetch_inputs: p[0] = table, p[1 .. i[0]] = destinations, i[1 .. i[0]] = counts (floats, < 2^31 each) */ };
 /* i[26] of every op is its scheduling word: low byte = lane (0 = the caller's stream; 1..MH_MAX_LANES-1 = side
  * streams owned by the library: the op is forked from lane 0 right before it, i.e. ordered after everything recorded so
  * far, and runs concurrently with the lane-0 ops that follow); MH_OP_JOIN = lane 0 first waits for all side lanes.

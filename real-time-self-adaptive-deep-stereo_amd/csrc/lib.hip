@@ -246,6 +246,13 @@ static int run_op(const mh_op& o, void* s) {
             for (int k = 0; k < nb; ++k) { bufs[k] = (float*)p[1 + k]; counts[k] = i[1 + k]; }
             return mh_allreduce_sum(bufs, counts, nb, p[0], s);
         }
+        case MH_OP_FETCH_INPUTS: {   // p[0] = table, p[1 .. i[0]] = destinations ; i[1 .. i[0]] = counts
+            float* dst[MH_FETCH_MAX]; int64_t cnt[MH_FETCH_MAX];
+            const int nb = i[0];
+            if (nb < 1 || nb > MH_FETCH_MAX) { mh_set_error("MH_OP_FETCH_INPUTS: %d entries", nb); return MH_ERR_ARG; }
+            for (int k = 0; k < nb; ++k) { dst[k] = (float*)p[1 + k]; cnt[k] = i[1 + k]; }
+            return mh_fetch_inputs((const mh_input_table*)p[0], dst, cnt, nb, s);
+        }
         case MH_OP_STAMP:
             return mh_stamp(p[0], s);
         case MH_OP_PLANE_SPLIT:

@@ -983,6 +983,64 @@ __global__ __launch_bounds__(256) void u8_to_f32_kernel(const unsigned char* __r
     }
 }
 
+// ---- the step's frames through a table the HOST rewrites between two replays of a captured step (mh_fetch_inputs) ---------------------------------------------------
+// A captured step reads its frames at fixed addresses; a prefetcher delivers frame t in slot t % depth.  Instead of three copy launches in front of every replay, the
+// step's first node reads the slot's addresses from a small table (device-visible host memory, or device memory the host updates) and moves / casts the frames into the
+// fixed input buffers itself.  Entry k: src[k] = NULL or == dst[k]: nothing to do; u8[k]: the source holds 8-bit values.
+struct FetchArgs { const mh_input_table* tab; float* dst[MH_FETCH_MAX]; int64_t n[MH_FETCH_MAX]; int64_t q0[MH_FETCH_MAX + 1]; };
+__global__ __launch_bounds__(256) void fetch_inputs_kernel(FetchArgs a) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one quad of floats
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < MH_FETCH_MAX; ++j) k += q >= a.q0[j] ? 1 : 0;
+    if (q >= a.q0[MH_FETCH_MAX]) return;
+    const void* src = a.tab->src[k];
+    float* dst = a.dst[k];
+    if (!src || src == (const void*)dst) return;
+    const int64_t e0 = (q - a.q0[k]) * 4, n = a.n[k];
+    if (a.tab->u8[k]) {
+        const unsigned char* in = (const unsigned char*)src;
+        if (e0 + 4 <= n && ((((uintptr_t)in) & 3u) | (((uintptr_t)dst) & 15u)) == 0) {
+            const unsigned v = *reinterpret_cast<const unsigned*>(in + e0);
+            *reinterpret_cast<float4*>(dst + e0) = make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24));
+        } else {
+            for (int64_t e = e0; e < e0 + 4 && e < n; ++e) dst[e] = (float)in[e];
+        }
+    } else {
+        const float* in = (const float*)src;
+        if (e0 + 4 <= n && ((((uintptr_t)in) | ((uintptr_t)dst)) & 15u) == 0) *reinterpret_cast<float4*>(dst + e0) = *reinterpret_cast<const float4*>(in + e0);
+        else for (int64_t e = e0; e < e0 + 4 && e < n; ++e) dst[e] = in[e];
+    }
+}
+
+extern "C" int mh_fetch_inputs(const mh_input_table* table, float* const* dst, const int64_t* n, int32_t count, void* stream) {
+    MH_REQUIRE(table && dst && n && count >= 1 && count <= MH_FETCH_MAX, MH_ERR_ARG, "mh_fetch_inputs: bad argument");
+    FetchArgs a{};
+    a.tab = table;
+    int64_t q = 0;
+    for (int k = 0; k < MH_FETCH_MAX; ++k) {
+        a.q0[k] = q;
+        if (k < count) {
+            MH_REQUIRE(dst[k] && n[k] >= 0, MH_ERR_ARG, "mh_fetch_inputs: null destination / negative count");
+            a.dst[k] = dst[k]; a.n[k] = n[k];
+            q += (n[k] + 3) / 4;
+        }
+    }
+    a.q0[MH_FETCH_MAX] = q;
+    if (q == 0) return 0;
+    MH_REQUIRE((q + 255) / 256 < (1ll << 31), MH_ERR_UNSUPPORTED, "mh_fetch_inputs: too many elements");
+    hipLaunchKernelGGL(fetch_inputs_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return mh_check_launch("fetch_inputs");
+}
+
+// the device-side address of a page-locked host allocation (what a kernel dereferences to read a table the host keeps writing)
+extern "C" int mh_host_device_pointer(void* host, void** device) {
+    MH_REQUIRE(host && device, MH_ERR_ARG, "mh_host_device_pointer: null argument");
+    hipError_t e = hipHostGetDevicePointer(device, host, 0);
+    if (e != hipSuccess) { mh_set_error("mh_host_device_pointer: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
 extern "C" int mh_u8_to_f32(const uint8_t* in, float* out, int64_t n, void* stream) {
     MH_REQUIRE(in && out && n > 0, MH_ERR_ARG, "mh_u8_to_f32: bad argument");
     MH_REQUIRE((n + 1023) / 1024 < (1ll << 31), MH_ERR_UNSUPPORTED, "mh_u8_to_f32: too many elements");

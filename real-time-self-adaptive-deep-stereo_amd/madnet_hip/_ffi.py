@@ -31,11 +31,16 @@ class Op(C.Structure):
 (OP_CONV, OP_WGRAD, OP_CORR_FWD, OP_CORR_BWD, OP_WARP_FWD, OP_WARP_BWD, OP_RESIZE_FWD, OP_RESIZE_BWD,
  OP_PAD_REFLECT, OP_LOSS, OP_METRICS, OP_MOMENTUM, OP_COPY_CH, OP_LEAKY_BWD, OP_FILL, OP_BIAS_GRAD,
  OP_WGRAD_PARTIAL, OP_WGRAD_REDUCE, OP_PROXY_LOSS, OP_SUPERVISED_LOSS, OP_ADAM, OP_ADAM_ADVANCE, OP_RESIZE_IMAGE, OP_LEVEL_FRONT, OP_RESERVED_25, OP_PACK_W, OP_CORR_WARP_BWD,
- OP_SHADOW_CAST, OP_WGRAD_STREAM, OP_HEAD_BWD, OP_HEAD_FWD, OP_CONV_PLANES, OP_PLANE_SPLIT, OP_STAMP, OP_CONV_PLANES_BWD, OP_DET_FLUSH, OP_CONV_IMAGE, OP_ALLREDUCE) = range(1, 39)
+ OP_SHADOW_CAST, OP_WGRAD_STREAM, OP_HEAD_BWD, OP_HEAD_FWD, OP_CONV_PLANES, OP_PLANE_SPLIT, OP_STAMP, OP_CONV_PLANES_BWD, OP_DET_FLUSH, OP_CONV_IMAGE, OP_ALLREDUCE, OP_FETCH_INPUTS) = range(1, 40)
 
 
 COMM_ID_BYTES = 128            # MH_COMM_ID_BYTES
 ALLREDUCE_MAX_BUFS = 8         # MH_ALLREDUCE_MAX_BUFS
+FETCH_MAX = 4                  # MH_FETCH_MAX
+
+
+class InputTable(C.Structure):     # mh_input_table
+    _fields_ = [("src", C.c_void_p * FETCH_MAX), ("u8", C.c_int32 * FETCH_MAX)]
 OP_JOIN = 0x100
 OP_NODEFER = 0x200
 MAX_LANES = 5
@@ -160,6 +165,8 @@ SIGNATURES = {
     "mh_bilinear_sampler_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "mh_bilinear_sampler_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "mh_u8_to_f32": (_I, [_P, _P, _L, _P]),
+    "mh_fetch_inputs": (_I, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), _I, _P]),
+    "mh_host_device_pointer": (_I, [_P, C.POINTER(C.c_void_p)]),
     "mh_pad_reflect": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
     "mh_loss_ws_floats": (_L, [_I, _I, _I]),
     "mh_reprojection_loss": (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _P]),

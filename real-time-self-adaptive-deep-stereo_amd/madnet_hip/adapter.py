@@ -15,11 +15,13 @@ MAD: the block's ranges + the loss as one RCCL group.  torch.distributed only ca
 (CPU emulator runs -- test plumbing, gloo -- keep the older form: the collective between two plans.)
 """
 import collections
+import os
 import numpy as np
 import torch
 
 from Sampler import sampler_factory
 from . import engine as E
+from . import ops
 
 
 def softmax(x):
@@ -31,7 +33,7 @@ class Adapter(object):
     def __init__(self, net, mode="MAD", block_config=None, lr=1e-4, momentum=0.9, sample_mode="PROBABILITY",
                  num_blocks=1, fixed_id=0, sample_frequency=1, ssim_th=0.5, reprojection_scale=1,
                  use_graph=True, shared_model=False, process_group=None, loss="reprojection", dilation=1, decay=0.99, uf=0.01,
-                 optimizer="momentum", reset_optimizer=False, reward_every_step_first=False, early_reduce=None, in_graph_collective=None):
+                 optimizer="momentum", reset_optimizer=False, reward_every_step_first=False, early_reduce=None, in_graph_collective=None, fetch_inputs=None):
         """loss='proxy', dilation, decay, uf: the continual-adaptation variant (Stereo_Continual_Adaptation.py:75-112,
         205-249, 302-304): proxy-label mean_l1 loss, weight update only every `dilation`-th frame, reward update
         sample_distribution = decay * sample_distribution (+ uf * gain on the last trained blocks).
@@ -83,6 +85,11 @@ class Adapter(object):
             raise RuntimeError("in_graph_collective=True needs a GPU engine of MADNet and RCCL (mh_comm_available)")
         self.use_graph = use_graph and self.cuda
         self.stream = torch.cuda.Stream(device=dev) if self.cuda else None
+        # frames that already sit in device memory (a prefetcher's slots) are read by the step's first node through a table the host rewrites per step
+        # (ops.InputTable / mh_fetch_inputs): no copy launches in front of the captured step; host frames take the copies of _upload
+        if fetch_inputs is None:
+            fetch_inputs = os.environ.get("MH_FETCH_INPUTS", "1") != "0"
+        self._tab = ops.InputTable(self.lib, dev) if fetch_inputs else None
         self.blocks = []
         if mode == "MAD" and not hasattr(self.eng, "record_backward") or (mode == "MAD" and net._netName != "MADNet"):
             raise NotImplementedError("MAD adaptation is only defined for MADNet (the reference's own assert "
@@ -122,8 +129,10 @@ class Adapter(object):
             coll = {"collective": self.comm} if (self.comm is not None and key != "NONE") else {}
             plans = []
             for part in parts:
+                if self._tab is not None:
+                    coll = dict(coll, inputs=self._tab)
                 if key == "NONE":
-                    p = eng.build_plan("NONE", part=part)
+                    p = eng.build_plan("NONE", part=part, inputs=self._tab)
                 elif key == "FULL":
                     p = eng.build_plan("FULL", lr=self.lr, grad_scale=gs, part=part, optimizer=self.optimizer, momentum=self.momentum, **coll)
                 else:
@@ -159,8 +168,16 @@ class Adapter(object):
         return key
 
     def _upload(self, left, right, gt=None, proxy=None):
-        """frame -> the engine's input buffers (on the CURRENT stream)"""
+        """frame -> the engine's input buffers: device tensors through the step's own first node (the table names them; nothing is launched here), host arrays by
+        copies on the CURRENT stream"""
         eng = self.eng
+        if self._tab is not None:
+            dsts = [eng.left, eng.right, eng.gt] + ([eng.proxy] if hasattr(eng, "proxy") else [])
+            srcs = [left, right, gt, proxy][:len(dsts)]
+            if all(x is None or _direct(x, d) for x, d in zip(srcs, dsts)) and (proxy is None or len(dsts) == 4):
+                self._tab.set(srcs)
+                return
+            self._tab.clear()
         eng.left.copy_(_as(left, eng.left), non_blocking=True)
         eng.right.copy_(_as(right, eng.right), non_blocking=True)
         if gt is not None:
@@ -332,6 +349,12 @@ class _null(object):
 
     def __exit__(self, *a):
         return False
+
+
+def _direct(x, like):
+    """can the step's first node read frame x itself?  a device tensor of the buffer's size, uint8 or float32, contiguous, 16-byte aligned"""
+    return (torch.is_tensor(x) and x.device == like.device and x.dtype in (torch.uint8, torch.float32) and x.is_contiguous() and x.numel() == like.numel()
+            and x.data_ptr() % 16 == 0)
 
 
 def _as(x, like):

@@ -662,8 +662,11 @@ class DispNetEngine(object):
         return r.compile()
 
     def build_plan(self, mode, lr=1e-4, grad_scale=1.0, update=True, part="all", loss_weights=None, max_disp=192.0,
-                   optimizer="momentum", momentum=0.9, **_):
+                   optimizer="momentum", momentum=0.9, inputs=None, **_):
+        """inputs: an ops.InputTable -- the plan's first op fills left / right / gt from the device tensors the table names (engine.MadNetEngine.build_plan)"""
         r = Recorder()
+        if inputs is not None and part != "update":
+            ops.fetch_inputs(r, inputs.ptr, [self.left, self.right, self.gt])
         r.wgrad_group_max_m = 0      # per-plan cap of the grouped filter gradients (0 = library default; 4096 and 16384 measure the same here)
         self.wsa.reset()
         # DispNet's filter gradients (few pixels, 256-1024 channels) keep the round-1 pixel-split targets: 3.99 vs 4.08 ms (the split counts are resolved

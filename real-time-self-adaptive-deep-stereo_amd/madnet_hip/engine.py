@@ -723,7 +723,7 @@ class MadNetEngine(ElisionPasses, BackwardRecorder):
         return rng[0]
 
     def build_plan(self, mode, lr=1e-4, block_vars=None, block_level=None, grad_scale=1.0, update=True,
-                   blocks=None, part="all", loss_weights=None, max_disp=192.0, optimizer="momentum", momentum=0.9, collective=None):
+                   blocks=None, part="all", loss_weights=None, max_disp=192.0, optimizer="momentum", momentum=0.9, collective=None, inputs=None):
         """mode: 'NONE' | 'FULL' | 'MAD' | 'TRAIN' (offline training step of Train.py: multi-scale supervised mean_l1 against
         self.gt with loss_weights from full to lowest resolution, every variable, Adam).
         For MAD: blocks = [(level, variable names), ...] (level in
@@ -734,8 +734,12 @@ class MadNetEngine(ElisionPasses, BackwardRecorder):
         a LIST of two plans cut where the pyramid's backward pass starts (see madnet_manifest).
         collective: a madnet_hip.comm.Comm (shared-model mode, part='all', FULL / MAD): the gradient all-reduce is RECORDED between the backward pass and the
         optimizer (MH_OP_ALLREDUCE), so the step is one plan / one hipGraph.  FULL: [estimators + context + loss] leaves on a side lane where the pyramid's
-        backward pass starts, [pyramid] follows behind it on lane 0; MAD: the block's ranges + the loss tail as one RCCL group.  Pass grad_scale = 1 / world."""
+        backward pass starts, [pyramid] follows behind it on lane 0; MAD: the block's ranges + the loss tail as one RCCL group.  Pass grad_scale = 1 / world.
+        inputs: an ops.InputTable -- the plan's FIRST op fills left / right / gt / proxy from the device tensors the table names when the plan runs (mh_fetch_inputs:
+        frames from a prefetcher's rotating slots without copy launches in front of a captured step); entries the host leaves empty keep the buffers as they are."""
         r = Recorder()
+        if inputs is not None and part != "update":
+            ops.fetch_inputs(r, inputs.ptr, [self.left, self.right, self.gt, self.proxy])
         self.wsa.reset()
         self._fresh = set()
         self.stamp_labels = []

@@ -460,6 +460,44 @@ def plane_split(lib, pairs, device, keep, stream=None):
     lib.plane_split(C.c_void_p(table.data_ptr()), len(pairs), blk, _p(stream))
 
 
+class InputTable(object):
+    """The frame table of mh_fetch_inputs: page-locked host memory the device reads through its device-side address, rewritten by the host between two replays of a
+    captured step (after the previous replay has completed) -- no API call, no copy launch in front of the step.  set([tensor | None, ...]): entry k = the device
+    tensor the step's k-th input buffer is filled from (uint8 or float32, contiguous), None = leave the buffer as it is."""
+
+    def __init__(self, lib, device):
+        cuda = torch.device(device).type == "cuda"
+        self.buf = torch.zeros(C.sizeof(_ffi.InputTable), dtype=torch.uint8, pin_memory=cuda)
+        self.tab = _ffi.InputTable.from_address(self.buf.data_ptr())
+        if cuda:
+            dp = C.c_void_p()
+            lib.host_device_pointer(C.c_void_p(self.buf.data_ptr()), C.byref(dp))
+            self.ptr = dp.value
+        else:
+            self.ptr = self.buf.data_ptr()
+        self.held = []                 # keeps the tensors of the current entries alive
+
+    def set(self, tensors):
+        assert len(tensors) <= _ffi.FETCH_MAX
+        for k in range(_ffi.FETCH_MAX):
+            t = tensors[k] if k < len(tensors) else None
+            self.tab.src[k] = t.data_ptr() if t is not None else None
+            self.tab.u8[k] = 1 if (t is not None and t.dtype == torch.uint8) else 0
+        self.held = [t for t in tensors if t is not None]
+
+    def clear(self):
+        self.set([])
+
+
+def fetch_inputs(lib, table_ptr, dsts, stream=None):
+    """the step's first node: every destination tensor (float32, contiguous) <- the tensor the table names for it (mh_fetch_inputs)"""
+    n = len(dsts)
+    dp = (C.c_void_p * n)(*[d.data_ptr() for d in dsts])
+    cnt = (C.c_int64 * n)(*[d.numel() for d in dsts])
+    assert all(d.dtype == torch.float32 and d.is_contiguous() for d in dsts)
+    lib.fetch_inputs(C.c_void_p(table_ptr), dp, cnt, n, _p(stream))
+
+
 def shadow_cast(lib, pairs, device, keep, stream=None):
     """pairs: [(View src, Shadow dst)] -> every dst = bf16(src), ONE launch (mh_shadow_cast).  `keep` keeps the device table alive."""
     if not pairs:

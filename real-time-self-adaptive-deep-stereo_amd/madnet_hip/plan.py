@@ -277,6 +277,11 @@ class Recorder(object):
         assert 1 <= n <= 8
         self._op(_ffi.OP_ALLREDUCE, [n] + [int(counts[k]) for k in range(n)], [], [comm] + [bufs[k] for k in range(n)])
 
+    def fetch_inputs(self, table, dst, counts, n, stream):
+        """table: device-visible address of an mh_input_table; dst / counts: ctypes arrays as for _ffi.Lib.fetch_inputs"""
+        assert 1 <= n <= _ffi.FETCH_MAX
+        self._op(_ffi.OP_FETCH_INPUTS, [n] + [int(counts[k]) for k in range(n)], [], [table] + [dst[k] for k in range(n)])
+
     def bias_grad_partial(self, dz, dz_ld, npix, nch, ws, nblocks, stream):
         self._op(_ffi.OP_BIAS_GRAD, [dz_ld, nch, nblocks], [], [dz, ws], n=npix)
 

@@ -38,7 +38,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(dll, n), "symbol %s declared in include/madnet_hip.h but not exported" % n
     assert set(names) == set(_ffi.SIGNATURES.keys()), set(names) ^ set(_ffi.SIGNATURES.keys())
-    assert dll.mh_abi_version() == 15
+    assert dll.mh_abi_version() == 16
 
 
 def test_product_loader_fails_loudly_without_gpu():

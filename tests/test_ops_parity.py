@@ -788,3 +788,44 @@ def test_head_bwd_matches_the_separate_launches(backend, case, kind):
     assert (dx0 - dx1).abs().max().item() <= 1e-6 * max(1.0, dx0.abs().max().item())
     assert torch.equal(shV1[..., 0], dV1.to(torch.bfloat16)) and (shV1[..., 1:] == 0).all()
     assert torch.equal(shx1[..., :N], dx1.to(torch.bfloat16))
+
+
+def test_fetch_inputs_table_direct_and_as_plan_op(backend):
+    """mh_fetch_inputs / MH_OP_FETCH_INPUTS: the step's first node fills its fixed input buffers from the tensors a host-rewritten table names -- uint8 sources are cast
+    (tf.cast of Data_utils/data_reader.py:98), float32 copied, an empty entry or the buffer itself left alone; sizes that are not multiples of four; the SAME recorded
+    plan follows the table from run to run (what a captured step does with a prefetcher's rotating slots)."""
+    from madnet_hip.plan import Recorder
+    lib, dev = backend.lib, backend.device
+    g = torch.Generator().manual_seed(5)
+    n_img, n_gt = 3 * 7 * 11 * 3 + 2, 7 * 11 + 1          # not multiples of 4
+    dst = [torch.full((n,), -7.0, device=dev) for n in (n_img, n_img, n_gt, n_gt)]
+    keep3 = dst[3].clone()
+    tab = ops.InputTable(lib, dev)
+
+    def frames(seed):
+        gg = torch.Generator().manual_seed(seed)
+        return (torch.randint(0, 256, (n_img,), generator=gg, dtype=torch.uint8).to(dev), torch.randint(0, 256, (n_img,), generator=gg).float().to(dev),
+                torch.randn(n_gt, generator=gg).to(dev))
+
+    a = frames(1)
+    tab.set([a[0], a[1], a[2], None])
+    ops.fetch_inputs(lib, tab.ptr, dst)
+    backend.sync()
+    assert torch.equal(dst[0].cpu(), a[0].cpu().float()) and torch.equal(dst[1].cpu(), a[1].cpu()) and torch.equal(dst[2].cpu(), a[2].cpu())
+    assert torch.equal(dst[3].cpu(), keep3.cpu())                         # empty entry: untouched
+    # the recorded op: one plan, the table rewritten between its runs; an entry naming the buffer itself is a no-op
+    r = Recorder()
+    ops.fetch_inputs(r, tab.ptr, dst)
+    plan = r.compile()
+    for seed in (2, 3):
+        b = frames(seed)
+        before1 = dst[1].clone()
+        tab.set([b[0], dst[1], None, b[2]])
+        plan.run(lib, backend.stream_handle() if hasattr(backend, "stream_handle") else 0)
+        backend.sync()
+        assert torch.equal(dst[0].cpu(), b[0].cpu().float()) and torch.equal(dst[1].cpu(), before1.cpu()) and torch.equal(dst[3].cpu(), b[2].cpu())
+        assert torch.equal(dst[2].cpu(), a[2].cpu())                    # not named since the first call
+    tab.clear()
+    plan.run(lib, 0)
+    backend.sync()
+    assert torch.equal(dst[0].cpu(), b[0].cpu().float())
