@@ -24,7 +24,7 @@ int mh_tune_wgrad_stream(int dist);     /* prefetch distance (row groups in flig
 int mh_tune_corr(int direct);            /* bit 0 (default SET): the direct small-D kernels; bit 1: plain instead of XCD-aware workgroup order of the large-D kernels; bit 2: the large-D bf16 gradient as two launches; bit 3: one fine row per workgroup in mh_level_front_head_fwd (default: two, when H = 2 Hc).  Default state = mh_tune_corr(1) */
 int mh_tune_corr_row(int on);            /* backward front end of a pyramid level (mh_corr_warp_bwd): 1 = row-owned form, the warp-gradient scatter on an LDS copy of the row, the row's operands staged in LDS (default), 3 = row-owned without the operand staging, 0 = the global-atomic form */
 
-int mh_tune_conv_planes(int mode);       /* pre-split-operand forward kernel (mh_conv2d_planes): bits 0-3 = tile variant (0 = heuristic), bit 4 / bit 5 = the staggered 128-pixel tile (two out-of-phase wave groups) for forward layers / input gradients beside a forced variant, bit 6 = no staggering under the heuristic (default: forward layers staggered), bit 8 = skip the K walk, bit 9 = skip the patch staging, bit 12 = skip the epilogue, bit 13 = epilogue without its stores, bit 14 = staggered groups without s_setprio, bit 15 = s_setprio 2 for the plain kernel (timing experiments: scripts/microbench.py phases); returns the number of launches of the plane kernels since the previous call */
+int mh_tune_conv_planes(int mode);       /* pre-split-operand forward kernel (mh_conv2d_planes): bits 0-3 = tile variant (0 = heuristic), bit 4 / bit 5 = the staggered 128-pixel tile (two out-of-phase wave groups of one workgroup) for forward layers / input gradients (default: off), bit 7 = ... only where the tile has 128 columns, bit 8 = skip the K walk, bit 9 = skip the patch staging, bit 12 = skip the epilogue, bit 13 = epilogue without its stores, bit 14 = staggered groups without s_setprio, bit 15 = s_setprio 2 for the plain kernel (timing experiments: scripts/microbench.py phases); returns the number of launches of the plane kernels since the previous call */
 
 #ifdef __cplusplus
 }

@@ -1211,11 +1211,11 @@ int dispatch_planes(PlanesArgs& a, hipStream_t s, bool all, int pl = 2) {
         mh_set_error("mh_conv2d_planes%s: no instance for K = %d, N = %d", pl == 1 ? "_bwd" : "", a.K, a.N);
         return MH_ERR_UNSUPPORTED;
     }
-    // a 128-pixel tile with one workgroup per CU: the staggered form of the same tile where it exists.  Forward layers: the default (mh_tune_conv_planes bit 6 = off, bit 4 = on
-    // beside a forced tile variant): -1 .. -2 us per launch alone and inside the step.  Input gradients: bit 5 only -- alone they gain 2 - 2.6 us per launch, but inside the FULL
-    // step they run beside the filter-gradient lanes, whose workgroups then find neither the LDS nor the wave slots they had: the step LOSES 11 - 15 us (r6n - r6p)
+    // a 128-pixel tile with one workgroup per CU: the staggered form of the same tile where it exists -- an OPTION (mh_tune_conv_planes bit 4: forward layers, bit 5: input
+    // gradients), off by default.  Alone a launch gains 1 - 2.6 us; inside the FULL step the input gradients run beside the filter-gradient lanes, whose workgroups then find
+    // neither the LDS nor the wave slots they had (the step LOSES 11 - 15 us), and the forward layers alone measured -6.6 .. +9.4 us over three boxes (r6n - r6r)
     const int gm = g_planes_mode.load(std::memory_order_relaxed);
-    const bool stagger = pl == 2 ? ((gm & 16) || (v == 0 && !(gm & 64))) : (gm & 32) != 0;
+    const bool stagger = (gm & (pl == 2 ? 16 : 32)) != 0;
     int nwg_best = 0;
     planes_cost(*best, a, &nwg_best);
     // (one workgroup per CU is the premise: with two co-resident workgroups -- dilation 16, 512 tiles -- the staggered form measured 23.2 us against 20.4)
