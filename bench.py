@@ -474,8 +474,12 @@ def apply_overrides(items, lib, E, sched_cls=None):
             per_engine[name] = v
         elif scope == "tune":
             getattr(lib, "tune_" + name)(*[int(x) for x in (v if isinstance(v, tuple) else (v,))])        # tune.conv_tile=524288,0
+        elif scope == "ops":                # a module-level knob of madnet_hip/ops.py (WGRAD_STREAM_WAVES, WGRAD_STREAM_WGS): experiments
+            from madnet_hip import ops as _ops
+            assert hasattr(_ops, name), "--set %s: no such name in madnet_hip/ops.py" % key
+            setattr(_ops, name, v)
         else:
-            raise SystemExit("--set %s: scope must be engine. / eng. / tune." % key)
+            raise SystemExit("--set %s: scope must be engine. / eng. / tune. / ops." % key)
     return per_engine, sched
 
 
