@@ -125,6 +125,9 @@ def test_live_loop_every_frame_is_one_oracle_adam_step_emulated(monkeypatch):
     from madnet_hip import synthetic as S
     backend = _emul_backend()
     H, W = 60, 100
+    # the sampler draws from numpy's global generator (Sampler/sampler_factory.py, as the reference does): seeded, so that the run trains the same blocks every time --
+    # Adam's first steps are sign-like (lr * g / |g|), and with an unlucky draw the third frame sat at 1.9e-3 px against this test's 1e-3 (1 run in ~10)
+    np.random.seed(11)
     dd, seen = _run_loop(backend.lib, "cpu", "MAD", 4, monkeypatch, H, W)
     assert len(seen) == 4 and len(dd.history) == 4
     # frame preparation: camera frame 2H x 2W -> (H+12, W+20) bilinear -> centre crop H x W
