@@ -812,6 +812,45 @@ def test_multi_adapter_private_streams_emulated():
         assert (alone[sid][1] - pairs[sid][0].engine.params.w).abs().max().item() <= 1e-10
 
 
+def test_adapter_frames_through_the_input_table_emulated():
+    """Adapter.step with frames that already are tensors on the engine's device -- float32 and uint8 -- reads them through the step's first node (mh_fetch_inputs, the host
+    rewrites the table every step); host arrays take the copies in front of the step; fetch_inputs=False never uses the table.  Same losses, same weights, bit for bit; a
+    frame handed over WITHOUT ground truth keeps the previous one (entry left empty)."""
+    from conftest import _emul_backend
+    from madnet_hip.adapter import Adapter
+    from madnet_hip import _ffi
+    import Nets
+    be = _emul_backend()
+    H, W, steps = 48, 64, 3
+    frames = [S.make_pair(H, W, frame=t) for t in range(steps)]
+
+    def run(kind, fetch):
+        wn = S.calibrated_weights(OM.variable_shapes(), 1)
+        left = torch.zeros(1, H, W, 3); right = torch.zeros_like(left)
+        net = Nets.get_stereo_net("MADNet", {"left_img": left, "right_img": right, "weights": wn, "precision": "mixed", "_lib": be.lib, "_device": "cpu"})
+        ad = Adapter(net, mode="FULL", lr=1e-3, ssim_th=10.0, use_graph=False, fetch_inputs=fetch)
+        out = []
+        for t, (l, r, g) in enumerate(frames):
+            if kind == "numpy":
+                f = (l, r, g[..., 0])
+            elif kind == "f32":
+                f = (torch.from_numpy(l).reshape(1, H, W, 3), torch.from_numpy(r).reshape(1, H, W, 3), torch.from_numpy(np.ascontiguousarray(g[..., 0])))
+            else:
+                f = (torch.from_numpy(l.astype(np.uint8)), torch.from_numpy(r.astype(np.uint8)), torch.from_numpy(np.ascontiguousarray(g[..., 0])))
+            if t == 2:
+                f = f[:2]                        # no ground truth this frame: the previous one stays
+            out.append(ad.step(*f))
+        plan = ad._plan("FULL")[0]
+        has_fetch = any(plan.arr[i].kind == _ffi.OP_FETCH_INPUTS for i in range(plan.n))
+        return [(o["loss"], o["epe"]) for o in out], net.engine.params.w.clone(), has_fetch
+
+    ref, w_ref, hf = run("numpy", False)
+    assert not hf
+    for kind in ("f32", "u8"):                   # (host arrays with the table present: every other Adapter test)
+        got, w, hf = run(kind, True)
+        assert hf and got == ref and torch.equal(w, w_ref), (kind, got, ref)
+
+
 @pytest.mark.parametrize("bname,size", [SIZES[0], pytest.param("hip", (375, 1242), marks=pytest.mark.gpu, id="hip-375x1242")])
 def test_step_with_bf16_only_gradient_maps(bname, size):
     """engine._elide_fp32_gradient_maps: an input gradient whose fp32 result only the next (shadow-staging) input gradient would read stores just the
