@@ -13,5 +13,5 @@ done
 [ "${PMC_PASSES:-all}" = "all" ] && timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/SQ -o pmc -- python $GRAFT_REPO_ROOT/scripts/pmc_plan.py > $GRAFT_REPO_ROOT/$OUT/SQ.log 2>&1
 cd $GRAFT_REPO_ROOT; tail -2 $OUT/FETCH_SIZE.log $OUT/SQ.log
 python scripts/pmc_summarize.py $OUT | tail -70
-cp profiles/${ROUND}_pmc_roofline.json $OUT/
+cp profiles/${ROUND}_pmc_roofline${PMC_SUFFIX}.json $OUT/
 find $OUT -type f -size +3M -delete
