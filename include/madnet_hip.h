@@ -568,7 +568,7 @@ enum { MH_OP_CONV = 1, MH_OP_WGRAD, MH_OP_CORR_FWD, MH_OP_CORR_BWD, MH_OP_WARP_F
 /* side-lane op: launch it at once.  (Default: mh_plan_run takes the fork edge where the op stands but launches side-lane ops only after the
  * next lane-0 op, so that in a captured graph the lane-0 successor is the first child of the fork node and keeps its hardware queue; the
  * price is that the runtime starts such a side chain late.  A batch with a lot of work is worth the queue hop of the critical path.) */
-#define MH_OP_NODEFER 0x200
+#define MH_OP_NODEFER 0x200      /* (ignored on an op that carries a lane mask for its OWN side lane: such an op is always deferred) */
 /* bits 16..23 of the scheduling word: lane 0 first waits for exactly the side lanes in this mask (bit l = lane l), leaving the others
  * running -- e.g. the scatter half of a warp gradient joined right before the pyramid backward while the filter gradients go on.  On an op of a
  * SIDE lane the mask makes that lane (not lane 0) wait for the named lanes: lane-to-lane edges, lane 0 is not held up */

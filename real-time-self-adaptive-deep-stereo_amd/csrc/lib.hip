@@ -459,7 +459,12 @@ static int plan_run_impl(const mh_op* ops, int32_t nops, void* stream, Lanes* fi
             if (!e && stale[lane]) { e = lane_edge(*L, main_s, L->aux[lane]); stale[lane] = false; }
             if (!e) {
                 dirty[lane] = true;
-                if (!(sched & MH_OP_NODEFER)) { deferred[ndef].k = k; deferred[ndef].m = m; deferred[ndef].lane = lane; ++ndef; }
+                // MH_OP_NODEFER is not honoured on an op that joins other side lanes into its own (round 6, scripts/exp/cut_update_probe.py): created at once, such a node is
+                // the FIRST child of the fork in a captured graph -- it inherits lane 0's hardware queue and the critical chain moves to another one (+0.4 ms per step
+                // measured) -- and a momentum update recorded that way gave weights 8e-6 off the plain step after four replays while the eager run and the deferred
+                // form were bit-identical.  Deferred, the op is created behind the next lane-0 op like every other side-lane launch.
+                const bool at_once = (sched & MH_OP_NODEFER) && !((sched >> 16) & 0xff);
+                if (!at_once) { deferred[ndef].k = k; deferred[ndef].m = m; deferred[ndef].lane = lane; ++ndef; }
                 else {
                     if (ndef) e = flush_deferred();          // keep the lane's order
                     if (!e) e = run((void*)L->aux[lane]);

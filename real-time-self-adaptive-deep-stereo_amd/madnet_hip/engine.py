@@ -828,7 +828,26 @@ class MadNetEngine(ElisionPasses, BackwardRecorder):
                         rr.join_lanes_next, rr.lane, rr.nodefer = 0b1110, self.COLLECTIVE_LANE, True
                         collective.allreduce(rr, [(P.g_loss, lo, P.total + 4 - lo)])
                         rr.lane, rr.nodefer = lane0, nd0
+                cut_done = []
+                if (collective is None and eu is None and self.sched.CUT_UPDATE and do_upd and part == "all" and optimizer == "momentum"
+                        and self.wgrad_lanes > 0 and hasattr(r, "lane") and not self.deterministic):      # (the deterministic twin is flushed in front of the optimizer: one update)
+                    P, lo = self.params, self.pyramid_range()[1]
+
+                    def at_cut(rr):                              # noqa: F811
+                        lane0, nd0 = rr.lane, rr.nodefer
+                        variant = os.environ.get("MH_CUT_VARIANT", "lane4")
+                        if variant == "lane0":                   # diagnostic: the update on lane 0 itself behind a join of the filter-gradient lanes
+                            rr.join_lanes_next = 0b1110
+                        elif variant == "lane4_defer":
+                            rr.join_lanes_next, rr.lane, rr.nodefer = 0b1110, self.COLLECTIVE_LANE, False
+                        else:
+                            rr.join_lanes_next, rr.lane, rr.nodefer = 0b1110, self.COLLECTIVE_LANE, True
+                        ops.momentum(rr, P.w[lo:P.total], P.m[lo:P.total], P.g[lo:P.total], lr, momentum, grad_scale, n=P.total - lo)
+                        rr.lane, rr.nodefer = lane0, nd0
+                        cut_done.append((lo, P.total))
                 done = self.record_backward(r, "final", tv, bulkhead=False, early_update=eu, at_cut=at_cut)
+                if cut_done:
+                    done = tuple(done or ()) + tuple(cut_done)
                 if collective is not None:
                     r.join_next = True                      # the pyramid's filter gradients (side lanes) and the first all-reduce (its lane) are behind us
                     collective.allreduce(r, [(self.params.g_loss, 0, self.pyramid_range()[1])])

@@ -57,6 +57,10 @@ class Schedule(object):
     # FULL momentum steps: every filter-gradient batch is followed by the momentum update of its layers on its own lane, the launch behind the join
     # covers only what is left.  Measured worse together with the tail split (r04 #17)
     EARLY_UPDATE: bool = False
+    # (round 6) FULL momentum steps of a private model: where the pyramid's backward pass starts, the estimators' and the context network's gradients are final -- 73 % of the
+    # parameters, one contiguous range behind the pyramid's -- and their update leaves on a lane of its own (it waits for the filter-gradient lanes, lane 0 walks on);
+    # the launch behind the final join covers the pyramid's range only.  ONE more launch (EARLY_UPDATE: seven), off the step's tail.  Measured +8 us (r6ag): off
+    CUT_UPDATE: bool = False
     # mh_pack_weights on the side lane beside pad_reflect / conv1: FULL -3 us (noise), but NONE / MAD get a second stream: +55 / +35 us (r04 #19)
     PACK_SIDE: bool = False
     # The step's tail (device time stamps, bench.py --stamps, round 4): the last filter-gradient batch (conv4 .. conv1) could only start behind the
