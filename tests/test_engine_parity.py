@@ -964,6 +964,46 @@ def test_product_path_replays_bit_identical(bname, size, net):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("net", ["madnet", "dispnet"])
+def test_captured_graph_replays_equal_the_eager_plan_bit_for_bit(hip, net):
+    """The captured hipGraph of the default FULL step (side lanes as parallel branches, deferred side-lane launches, lane joins) against the SAME plan run eagerly on
+    streams: four steps from the same weights end with torch.equal weights, momentum, gradients and disparity.  With no order-dependent arithmetic left in the step this is an
+    exact check of the graph's dependency structure -- round 6 met a form (a lane-to-lane join op created at once, r06_experiments.txt #20) whose captured replays drifted
+    8e-6 from the eager run while every tolerance-based test stayed green."""
+    H, W = 375, 1242
+    if net == "dispnet":
+        from madnet_hip import dispnet_engine as DE
+        from oracle import dispnet as OD
+        wn = S.calibrated_weights(OD.variable_shapes(), 1)
+        mk = lambda: DE.DispNetEngine(hip.lib, H, W, B=1, device=hip.device, weights=wn, precision="mixed")
+    else:
+        wn = S.calibrated_weights(OM.variable_shapes(), 1)
+        mk = lambda: E.MadNetEngine(hip.lib, H, W, B=1, device=hip.device, weights=wn, precision="mixed")
+    pairs = [S.make_pair(H, W, frame=t) for t in range(4)]
+    res = []
+    for graph in (False, True):
+        eng = mk()
+        plan = eng.build_plan("FULL", lr=1e-3)
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            if graph:
+                eng.set_inputs(*[pairs[0][0], pairs[0][1], pairs[0][2][..., 0]])
+                w_keep, m_keep = eng.params.w.clone(), eng.params.m.clone()
+                plan.capture(hip.lib, st.cuda_stream)          # (capturing launches nothing: the state is what it was)
+                assert torch.equal(eng.params.w, w_keep) and torch.equal(eng.params.m, m_keep)
+            for l, r, gt in pairs:
+                eng.set_inputs(l, r, gt[..., 0])
+                st.synchronize()
+                plan.launch(hip.lib, st.cuda_stream)
+                st.synchronize()
+        res.append((eng.params.w.clone(), eng.params.m.clone(), eng.params.g.clone(), eng.pred.clone()))
+        if hasattr(eng, "close"):
+            eng.close()
+    for a, b in zip(res[0], res[1]):
+        assert torch.isfinite(a).all() and torch.equal(a, b), (a - b).abs().max().item()
+
+
+@pytest.mark.gpu
 def test_mixed_drift_against_the_fp32_engine_is_bounded():
     """the bench's arithmetic ('mixed': bf16 gradients) and the exact-fp32 engine adapt side by side on the same frame-shifted synthetic video
     from the same weights (bench.py's drift protocol: stream 200, 8 frames, lr 1e-4); after 10 steps their disparities differ by <= 2e-2 px (measured 1.4e-2;
